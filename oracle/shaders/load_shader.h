@@ -1,0 +1,23 @@
+// ORACLE / TEST INFRASTRUCTURE. Stand-in for the file swgl/build.rs:25-37
+// generates: includes every (hand-written) shader header and maps the
+// "name FEATURE,FEATURE" key sent through ShaderSourceByName (gl.cc:1431) to
+// its program loader.
+#include "wr_common.h"
+#include "brush_base.h"
+#include "ps_quad_textured.h"
+#include "brush_solid.h"
+#include "composite.h"
+#include "ps_clear.h"
+
+ProgramLoader load_shader(const char* name) {
+#define WRSH_ENTRY(KEY, SYM) \
+  if (!strcmp(name, KEY)) return SYM##_program::loader;
+  WRSH_ENTRY("ps_quad_textured", ps_quad_textured)
+  WRSH_ENTRY("brush_solid", brush_solid)
+  WRSH_ENTRY("brush_solid ALPHA_PASS", brush_solid_ALPHA_PASS)
+  WRSH_ENTRY("composite TEXTURE_2D", composite_TEXTURE_2D)
+  WRSH_ENTRY("composite FAST_PATH,TEXTURE_2D", composite_FAST_PATH_TEXTURE_2D)
+  WRSH_ENTRY("ps_clear", ps_clear)
+#undef WRSH_ENTRY
+  return nullptr;
+}

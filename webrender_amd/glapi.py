@@ -1,0 +1,220 @@
+"""ctypes binding of the GL-shaped C ABI shared by libwrhip (the product) and the
+reference's swgl (the oracle, tests only).
+
+The symbol set and signatures are the `extern "C"` block of the reference's
+Rust shim, swgl/src/swgl_fns.rs:23-322 (99 functions); `include/wrhip.h`
+declares the same set for libwrhip.  Method names here are the C names, so a
+call sequence written against this class reads like the reference's
+`impl Gl for Context` forwarding code (swgl_fns.rs:500-2489).
+
+Every call can optionally be recorded into a `Trace` (see trace.py) so the same
+call stream can be replayed against another backend or by the native replayer.
+"""
+import ctypes as C
+import os
+
+c_void_p, c_char_p = C.c_void_p, C.c_char_p
+i32, u32, u8, f32, f64 = C.c_int32, C.c_uint32, C.c_uint8, C.c_float, C.c_double
+u64, isz, usz = C.c_uint64, C.c_ssize_t, C.c_size_t
+P = c_void_p
+
+# name -> (restype, argtypes).  Order follows swgl_fns.rs:23-322.
+SIGNATURES = {
+    "ActiveTexture": (None, [u32]),
+    "BindTexture": (None, [u32, u32]),
+    "BindBuffer": (None, [u32, u32]),
+    "BindVertexArray": (None, [u32]),
+    "BindFramebuffer": (None, [u32, u32]),
+    "BindRenderbuffer": (None, [u32, u32]),
+    "BlendFunc": (None, [u32, u32, u32, u32]),
+    "BlendColor": (None, [f32, f32, f32, f32]),
+    "BlendEquation": (None, [u32]),
+    "Enable": (None, [u32]),
+    "Disable": (None, [u32]),
+    "GenQueries": (None, [i32, P]),
+    "BeginQuery": (None, [u32, u32]),
+    "EndQuery": (None, [u32]),
+    "GetQueryObjectui64v": (None, [u32, u32, P]),
+    "GenBuffers": (None, [i32, P]),
+    "GenTextures": (None, [i32, P]),
+    "GenFramebuffers": (None, [i32, P]),
+    "GenRenderbuffers": (None, [i32, P]),
+    "BufferData": (None, [u32, usz, P, u32]),
+    "BufferSubData": (None, [u32, isz, usz, P]),
+    "MapBuffer": (P, [u32, u32]),
+    "MapBufferRange": (P, [u32, isz, usz, u32]),
+    "UnmapBuffer": (u8, [u32]),
+    "TexStorage2D": (None, [u32, i32, u32, i32, i32]),
+    "FramebufferTexture2D": (None, [u32, u32, u32, u32, i32]),
+    "CheckFramebufferStatus": (u32, [u32]),
+    "InvalidateFramebuffer": (None, [u32, i32, P]),
+    "TexImage2D": (None, [u32, i32, i32, i32, i32, i32, u32, u32, P]),
+    "TexSubImage2D": (None, [u32, i32, i32, i32, i32, i32, u32, u32, P]),
+    "GenerateMipmap": (None, [u32]),
+    "GetUniformLocation": (i32, [u32, c_char_p]),
+    "BindAttribLocation": (None, [u32, u32, c_char_p]),
+    "GetAttribLocation": (i32, [u32, c_char_p]),
+    "GenVertexArrays": (None, [i32, P]),
+    "VertexAttribPointer": (None, [u32, i32, u32, u8, i32, P]),
+    "VertexAttribIPointer": (None, [u32, i32, u32, i32, P]),
+    "CreateShader": (u32, [u32]),
+    "AttachShader": (None, [u32, u32]),
+    "CreateProgram": (u32, []),
+    "Uniform1i": (None, [i32, i32]),
+    "Uniform4fv": (None, [i32, i32, P]),
+    "UniformMatrix4fv": (None, [i32, i32, u8, P]),
+    "DrawElementsInstanced": (None, [u32, i32, u32, isz, i32]),
+    "EnableVertexAttribArray": (None, [u32]),
+    "VertexAttribDivisor": (None, [u32, u32]),
+    "LinkProgram": (None, [u32]),
+    "GetLinkStatus": (i32, [u32]),
+    "UseProgram": (None, [u32]),
+    "SetViewport": (None, [i32, i32, i32, i32]),
+    "FramebufferRenderbuffer": (None, [u32, u32, u32, u32]),
+    "RenderbufferStorage": (None, [u32, u32, i32, i32]),
+    "DepthMask": (None, [u8]),
+    "DepthFunc": (None, [u32]),
+    "SetScissor": (None, [i32, i32, i32, i32]),
+    "ClearColor": (None, [f32, f32, f32, f32]),
+    "ClearDepth": (None, [f64]),
+    "Clear": (None, [u32]),
+    "ClearTexSubImage": (None, [u32, i32, i32, i32, i32, i32, i32, i32, u32, u32, P]),
+    "ClearTexImage": (None, [u32, i32, u32, u32, P]),
+    "ClearColorRect": (None, [u32, i32, i32, i32, i32, f32, f32, f32, f32]),
+    "PixelStorei": (None, [u32, i32]),
+    "ReadPixels": (None, [i32, i32, i32, i32, u32, u32, P]),
+    "Finish": (None, []),
+    "ShaderSourceByName": (None, [u32, c_char_p]),
+    "TexParameteri": (None, [u32, u32, i32]),
+    "CopyImageSubData": (None, [u32, u32, i32, i32, i32, i32, u32, u32, i32, i32, i32, i32, i32, i32, i32]),
+    "CopyTexSubImage2D": (None, [u32, i32, i32, i32, i32, i32, i32, i32]),
+    "BlitFramebuffer": (None, [i32, i32, i32, i32, i32, i32, i32, i32, u32, u32]),
+    "GetIntegerv": (None, [u32, P]),
+    "GetBooleanv": (None, [u32, P]),
+    "GetString": (c_char_p, [u32]),
+    "GetStringi": (c_char_p, [u32, u32]),
+    "GetError": (u32, []),
+    "InitDefaultFramebuffer": (None, [i32, i32, i32, i32, i32, P]),
+    "GetColorBuffer": (P, [u32, u8, P, P, P]),
+    "ResolveFramebuffer": (None, [u32]),
+    "SetTextureBuffer": (None, [u32, u32, i32, i32, i32, P, i32, i32]),
+    "SetTextureParameter": (None, [u32, u32, i32]),
+    "DeleteTexture": (None, [u32]),
+    "DeleteRenderbuffer": (None, [u32]),
+    "DeleteFramebuffer": (None, [u32]),
+    "DeleteBuffer": (None, [u32]),
+    "DeleteVertexArray": (None, [u32]),
+    "DeleteQuery": (None, [u32]),
+    "DeleteShader": (None, [u32]),
+    "DeleteProgram": (None, [u32]),
+    "LockFramebuffer": (P, [u32]),
+    "LockTexture": (P, [u32]),
+    "LockResource": (None, [P]),
+    "UnlockResource": (None, [P]),
+    "GetResourceBuffer": (P, [P, P, P, P]),
+    "Composite": (None, [P, P, i32, i32, i32, i32, i32, i32, i32, i32, u8, u8, u8, u32, i32, i32, i32, i32]),
+    "CompositeYUV": (None, [P, P, P, P, i32, u32, i32, i32, i32, i32, i32, i32, i32, i32, u8, u8, i32, i32, i32, i32]),
+    "CreateContext": (P, []),
+    "ReferenceContext": (None, [P]),
+    "DestroyContext": (None, [P]),
+    "MakeCurrent": (None, [P]),
+    "ReportMemory": (usz, [P, P]),
+}
+assert len(SIGNATURES) == 99
+
+# libwrhip-only introspection hooks (include/wrhip.h, "libwrhip additions").
+EXTRA_SIGNATURES = {
+    "WrhipGetStats": (None, [P]),
+    "WrhipResetStats": (None, []),
+    "WrhipSetProfiling": (None, [i32]),
+    "WrhipSetShard": (None, [i32, i32]),
+    "WrhipGetTextureDevicePtr": (P, [u32, P, P, P]),
+    "WrhipGetFramebufferTexture": (u32, [u32]),
+    "WrhipDeviceName": (c_char_p, []),
+}
+
+
+class WrhipStats(C.Structure):
+    _fields_ = [(n, u64) for n in (
+        "flushes", "kernel_launches", "raster_launches", "raster_ns",
+        "raster_algo_bytes", "raster_pixels", "prims", "h2d_bytes", "d2h_bytes")]
+
+
+def _as_ptr(x):
+    """bytes / bytearray / numpy array / ctypes object / int / None -> void*."""
+    if x is None:
+        return None, None
+    if isinstance(x, int):
+        return x, None
+    if isinstance(x, (bytes, bytearray)):
+        buf = (C.c_char * len(x)).from_buffer_copy(x) if isinstance(x, bytes) \
+            else (C.c_char * len(x)).from_buffer(x)
+        return C.addressof(buf), buf
+    if hasattr(x, "ctypes"):  # numpy
+        return x.ctypes.data, x
+    return C.addressof(x), x
+
+
+class GL:
+    """One loaded backend library.  `lib.Name(args)` calls the C symbol."""
+
+    def __init__(self, path, trace=None):
+        self.path = os.path.abspath(path)
+        self._dll = C.CDLL(self.path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        self.trace = trace
+        self.is_wrhip = hasattr(self._dll, "WrhipGetStats")
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._dll, name)  # AttributeError if symbol missing
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, self._wrap(name, fn, args))
+        if self.is_wrhip:
+            for name, (res, args) in EXTRA_SIGNATURES.items():
+                fn = getattr(self._dll, name)
+                fn.restype, fn.argtypes = res, args
+                setattr(self, name, fn)
+
+    def _wrap(self, name, fn, argtypes):
+        ptr_idx = [i for i, t in enumerate(argtypes) if t is P]
+        gl = self
+
+        def call(*a):
+            if gl.trace is not None:
+                gl.trace.record(name, a)
+            if ptr_idx:
+                a = list(a)
+                keep = []
+                for i in ptr_idx:
+                    a[i], k = _as_ptr(a[i])
+                    keep.append(k)
+            return fn(*a)
+        call.__name__ = name
+        return call
+
+    # --- small conveniences (not part of the ABI) -------------------------
+    def gen(self, fn_name):
+        out = u32(0)
+        getattr(self, fn_name)(1, out)
+        return out.value
+
+    def stats(self):
+        s = WrhipStats()
+        self.WrhipGetStats(C.byref(s))
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+
+def repo_root():
+    return os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def wrhip_path():
+    return os.path.join(repo_root(), "webrender_amd", "csrc", "libwrhip.so")
+
+
+def load_wrhip(trace=None):
+    """Load the product backend.  Fails loudly if the HIP library is not built:
+    there is no CPU fallback in the product path."""
+    p = wrhip_path()
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not built -- run `python -c 'import __graft_entry__ as g; g.build()'`")
+    return GL(p, trace)

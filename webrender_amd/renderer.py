@@ -1,0 +1,231 @@
+"""Host-side mirror of the part of `webrender::Renderer` that turns a built
+`Frame` into the GL call stream (webrender/src/renderer/mod.rs):
+
+  bind_frame_data + gpu buffer textures    mod.rs:4418-4430, 4540-4558
+  draw_frame pass / target loop            mod.rs:4525-4841
+  draw_picture_cache_target                mod.rs:2669-2803
+  draw_alpha_batch_container               mod.rs:2804-2969
+  draw_instanced_batch                     mod.rs:2022-2065
+  composite_frame / composite_simple       mod.rs:4843-4905, 3340-3484
+  draw_tile_list                           mod.rs:3126-3334
+
+The call order is the contract the backend must honour; this module is the
+stand-in for the Rust caller (which cannot be built here) and is what both the
+oracle and libwrhip are driven by in tests and bench.
+"""
+import numpy as np
+from . import glconst as G
+from .device import Device, ortho, SAMPLER_SLOTS
+from .frame import TEX_W
+
+
+class Renderer:
+    def __init__(self, gl, width, height):
+        self.gl = gl
+        self.device = Device(gl)
+        self.width, self.height = width, height
+        self.device.init_default_framebuffer(width, height)
+        self.textures = {}       # TextureRef.name -> device.Texture
+        self.data_tex = {}       # sampler name -> (device.Texture, rows)
+        self.frame_count = 0
+        d = self.device
+        # dummy 1x1 white texture bound for TextureSource::Invalid/Dummy
+        # (renderer/mod.rs:1063-1090 dummy cache texture)
+        self.dummy = d.create_texture(1, 1, G.GL_RGBA8)
+        d.upload_texture(self.dummy, 0, 0, 1, 1, G.GL_BGRA, G.GL_UNSIGNED_BYTE,
+                         np.array([255, 255, 255, 255], dtype=np.uint8))
+
+    # ---- resources -------------------------------------------------------
+    def resolve(self, ref):
+        if ref is None:
+            return self.dummy
+        tex = self.textures.get(ref.name)
+        if tex is None or (tex.width, tex.height, tex.format) != (ref.w, ref.h, ref.fmt):
+            if tex is not None:
+                self.device.delete_texture(tex)
+            tex = self.device.create_texture(ref.w, ref.h, ref.fmt, ref.filter,
+                                             ref.render_target, ref.with_depth)
+            self.textures[ref.name] = tex
+            if ref.pixels is not None:
+                fmt = ref.upload_format or (G.GL_RED if ref.fmt == G.GL_R8 else G.GL_BGRA)
+                self.device.upload_texture(tex, 0, 0, ref.w, ref.h, fmt,
+                                           G.GL_UNSIGNED_BYTE, ref.pixels)
+        return tex
+
+    def _update_data_texture(self, sampler, store, fmt, upload_fmt, upload_ty, min_rows=1):
+        d = self.device
+        data = store.texture_data(min_rows)
+        rows = data.shape[0]
+        cur = self.data_tex.get(sampler)
+        if cur is None or cur[1] < rows:
+            if cur is not None:
+                d.delete_texture(cur[0])
+            tex = d.create_texture(TEX_W, rows, fmt, G.GL_NEAREST)
+            self.data_tex[sampler] = (tex, rows)
+        tex = self.data_tex[sampler][0]
+        d.upload_texture(tex, 0, 0, TEX_W, rows, upload_fmt, upload_ty, data)
+        d.bind_texture(SAMPLER_SLOTS[sampler], tex.id)
+
+    def bind_frame_data(self, frame):
+        F, I = (G.GL_RGBA32F, G.GL_RGBA, G.GL_FLOAT), (G.GL_RGBA32I, G.GL_RGBA_INTEGER, G.GL_INT)
+        self._update_data_texture("sPrimitiveHeadersF", frame.prim_headers_f, *F)
+        self._update_data_texture("sPrimitiveHeadersI", frame.prim_headers_i, *I)
+        self._update_data_texture("sTransformPalette", frame.transforms, *F)
+        self._update_data_texture("sRenderTasks", frame.render_tasks, *F)
+        # GPU cache: persistent 1024 x >=20 RGBAF32 texture (gpu_cache.rs:46)
+        self._update_data_texture("sGpuCache", frame.gpu_cache, *F, min_rows=20)
+
+    def _create_gpu_buffer_texture(self, sampler, store, fmt, upload_fmt, upload_ty):
+        d = self.device
+        data = store.texture_data()
+        tex = d.create_texture(TEX_W, data.shape[0], fmt, G.GL_NEAREST)
+        d.upload_texture(tex, 0, 0, TEX_W, data.shape[0], upload_fmt, upload_ty, data)
+        d.bind_texture(SAMPLER_SLOTS[sampler], tex.id)
+        return tex
+
+    # ---- drawing -----------------------------------------------------------
+    def _bind_step_textures(self, step):
+        d = self.device
+        for slot in (0, 1, 2, 9):  # Color0-2 + ClipMask, mod.rs:2066-2100
+            ref = step.textures.get(slot)
+            d.bind_texture(slot, self.resolve(ref).id if ref is not None else self.dummy.id)
+
+    def _draw_step(self, step, projection):
+        d = self.device
+        desc = step.desc
+        prog = d.create_program(step.shader, desc)
+        vao = d.create_vao(desc)
+        d.bind_program(prog, projection)
+        self._bind_step_textures(step)
+        d.draw_instanced_batch(vao, step.instances)
+
+    def draw_picture_cache_target(self, target):
+        d = self.device
+        tex = self.resolve(target.texture)
+        d.bind_draw_target(tex.fbo_with_depth or tex.fbo, tex.width, tex.height)
+        projection = ortho(0.0, tex.width, 0.0, tex.height)
+        d.enable_depth_write()
+        d.set_blend(False)
+        d.clear_target(target.clear_color, 1.0, target.clear_rect)
+        d.disable_depth_write()
+        # draw_alpha_batch_container
+        if target.opaque:
+            d.set_blend(False)
+            d.enable_depth(G.GL_LEQUAL)
+            d.enable_depth_write()
+            for step in target.opaque:
+                self._draw_step(step, projection)
+            d.disable_depth_write()
+        else:
+            d.disable_depth()
+        if target.alpha:
+            d.set_blend(True)
+            prev = None
+            for step in target.alpha:
+                if step.blend != prev:
+                    d.set_blend_mode(step.blend)
+                    prev = step.blend
+                self._draw_step(step, projection)
+            d.set_blend(False)
+        d.disable_depth()
+        d.invalidate_depth_target()
+
+    def draw_offscreen_target(self, target):
+        """Alpha / colour / texture-cache targets: generic ordered steps
+        (draw_alpha_target mod.rs:3754-3929, draw_texture_cache_target 3931-)."""
+        d = self.device
+        tex = self.resolve(target.texture)
+        d.bind_draw_target(tex.fbo, tex.width, tex.height)
+        projection = ortho(0.0, tex.width, 0.0, tex.height)
+        d.disable_depth()
+        d.disable_depth_write()
+        d.set_blend(False)
+        if target.clear_color is not None:
+            d.clear_target(target.clear_color, None, target.clear_rect)
+        blend_on, prev = False, None
+        for step in target.steps:
+            want = step.blend is not None
+            if want != blend_on:
+                d.set_blend(want)
+                blend_on = want
+            if want and step.blend != prev:
+                d.set_blend_mode(step.blend)
+                prev = step.blend
+            self._draw_step(step, projection)
+        if blend_on:
+            d.set_blend(False)
+
+    def composite_simple(self, frame):
+        d = self.device
+        d.bind_draw_target(0, frame.width, frame.height)
+        d.disable_depth_write()
+        d.disable_depth()
+        # wrench: surface_origin_is_top_left == false -> flipped ortho (mod.rs:4861-4866)
+        projection = ortho(0.0, frame.width, frame.height, 0.0)
+        d.clear_target(frame.clear_color, None, None)
+        opaque = [t for t in frame.composite_tiles if t.opaque]
+        alpha = [t for t in frame.composite_tiles if not t.opaque]
+
+        def draw_tile_list(tiles):
+            # one batch per texture change (mod.rs:3260-3334)
+            batch, cur = [], None
+            def flush():
+                if not batch:
+                    return
+                key = "composite FAST_PATH,TEXTURE_2D"
+                prog = d.create_program(key, "COMPOSITE")
+                vao = d.create_vao("COMPOSITE")
+                d.bind_program(prog, projection)
+                d.bind_texture(0, self.resolve(cur).id)
+                d.draw_instanced_batch(vao, np.stack(batch))
+            for t in tiles:
+                if cur is not None and t.texture is not cur:
+                    flush()
+                    batch.clear()
+                cur = t.texture
+                batch.append(frame.composite_instance(t.rect, t.clip_rect))
+            flush()
+
+        if opaque:
+            d.set_blend(False)
+            draw_tile_list(opaque)
+        if alpha:
+            d.set_blend(True)
+            d.set_blend_mode("PremultipliedAlpha")
+            draw_tile_list(list(reversed(alpha)))
+            d.set_blend(False)
+
+    def render(self, frame):
+        """Renderer::render_impl / draw_frame for one frame."""
+        d = self.device
+        for ref in frame.static_textures:
+            self.resolve(ref)
+        d.disable_depth_write()
+        d.set_blend(False)
+        self.bind_frame_data(frame)
+        gbf = self._create_gpu_buffer_texture("sGpuBufferF", frame.gpu_buffer_f,
+                                              G.GL_RGBA32F, G.GL_RGBA, G.GL_FLOAT)
+        gbi = self._create_gpu_buffer_texture("sGpuBufferI", frame.gpu_buffer_i,
+                                              G.GL_RGBA32I, G.GL_RGBA_INTEGER, G.GL_INT)
+        for targets in frame.passes:
+            for target in targets:
+                if target.kind == "picture_tile":
+                    self.draw_picture_cache_target(target)
+                else:
+                    self.draw_offscreen_target(target)
+        self.composite_simple(frame)
+        # end_frame (mod.rs:4826-4841)
+        d.delete_texture(gbf)
+        d.delete_texture(gbi)
+        self.frame_count += 1
+
+    def read_pixels(self):
+        """wrench reftest readback: glReadPixels(RGBA) of the whole window
+        (reftest.rs:306-319); rows are bottom-up in GL terms, returned as-is."""
+        return self.device.read_pixels_rgba8(0, 0, self.width, self.height)
+
+    def finish(self):
+        self.gl.Finish()
+
+    def destroy(self):
+        self.device.destroy()
