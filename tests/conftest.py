@@ -1,0 +1,58 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def oracle_lib(kind="gcc"):
+    p = os.path.join(ROOT, "oracle", "_ref", f"libswgl_ref_{kind}.so")
+    return p if os.path.exists(p) else None
+
+
+def hostsim_lib():
+    p = os.path.join(ROOT, "webrender_amd", "csrc", "libwrhip_hostsim.so")
+    return p if os.path.exists(p) else None
+
+
+def wrhip_lib():
+    return os.path.join(ROOT, "webrender_amd", "csrc", "libwrhip.so")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build native pieces once per session if they are missing (CPU-only: hipcc
+    cross-compiles gfx950 without a GPU)."""
+    need = [wrhip_lib(), os.path.join(ROOT, "webrender_amd", "csrc", "libwr_replay.so")]
+    if not all(os.path.exists(p) for p in need) or hostsim_lib() is None:
+        import __graft_entry__ as g
+        g.build()
+
+
+@pytest.fixture(scope="session")
+def oracle_gcc():
+    p = oracle_lib("gcc")
+    if p is None:
+        pytest.skip("oracle/_ref/libswgl_ref_gcc.so not built (needs /root/reference)")
+    return p
+
+
+@pytest.fixture(scope="session")
+def oracle_clang():
+    p = oracle_lib("clang")
+    if p is None:
+        pytest.skip("oracle/_ref/libswgl_ref_clang.so not built (needs /root/reference)")
+    return p
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    p = hostsim_lib()
+    if p is None:
+        pytest.skip("hostsim library not built")
+    return p

@@ -1,0 +1,1588 @@
+// wrhip.hip -- libwrhip: the MI355X draw backend behind WebRender's GL-shaped
+// C ABI (include/wrhip.h == the extern "C" block of swgl/src/swgl_fns.rs:23-322).
+//
+// Host side: a GL object store and state tracker (conceptually what
+// swgl/src/gl.cc:665-2661 does, written fresh) that *records* work instead of
+// executing it.  DrawElementsInstanced / Clear append draw packets to the
+// pending list of their render target; everything pending is flushed together
+// -- all targets in one vertex + bin + raster launch -- when a result is needed
+// (a pending target gets sampled, read back, overwritten from the host, or
+// Finish()).  See DESIGN.md §3-§4.
+#include <vector>
+#include <algorithm>
+#include <time.h>
+
+#include "../../include/wrhip.h"
+#include "wrhip_glenum.h"
+#include "wrhip_types.h"
+#include "wrhip_rt.h"
+#include "wrhip_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Object store with swgl's id policy (first free slot >= 1; gl.cc:674-745) so
+// object names match the reference's for identical call streams.
+template <typename O>
+struct ObjectStore {
+  std::vector<O*> objects;
+  size_t first_free = 1;
+  ~ObjectStore() { for (O* o : objects) delete o; }
+  size_t insert() {
+    size_t i = first_free;
+    while (i < objects.size() && objects[i]) i++;
+    first_free = i;
+    if (i >= objects.size()) objects.resize(i + 1, nullptr);
+    objects[i] = new O();
+    return i;
+  }
+  O& operator[](size_t i) {
+    if (i >= objects.size()) objects.resize(i + 1, nullptr);
+    if (!objects[i]) objects[i] = new O();
+    return *objects[i];
+  }
+  O* find(size_t i) const { return i < objects.size() ? objects[i] : nullptr; }
+  bool erase(size_t i) {
+    if (i < objects.size() && objects[i]) {
+      delete objects[i];
+      objects[i] = nullptr;
+      if (i < first_free) first_free = i;
+      return true;
+    }
+    return false;
+  }
+};
+
+struct Query { uint64_t value = 0; };
+
+struct Buffer {
+  uint8_t* buf = nullptr;
+  size_t size = 0, capacity = 0;
+  bool allocate(size_t n) {
+    if (n == size) return true;
+    if (n <= capacity) { size = n; return true; }
+    uint8_t* nb = (uint8_t*)realloc(buf, n);
+    if (!nb) { free(buf); buf = nullptr; size = capacity = 0; return false; }
+    buf = nb; size = capacity = n;
+    return true;
+  }
+  ~Buffer() { free(buf); }
+};
+
+struct Texture {
+  GLenum internal_format = 0;
+  int width = 0, height = 0;
+  int bpp = 0;
+  int stride = 0;            // bytes; 4-byte aligned like gl.cc:268
+  void* dptr = nullptr;      // HBM storage
+  size_t dsize = 0;
+  GLenum min_filter = GL_NEAREST, mag_filter = GL_LINEAR;
+  int offx = 0, offy = 0;
+  int locked = 0;
+  // host mirror handed out by GetColorBuffer / GetResourceBuffer
+  uint8_t* hmirror = nullptr;
+  size_t hmirror_size = 0;
+  // externally supplied backing store (SetTextureBuffer / InitDefaultFramebuffer(buf))
+  void* ext_buf = nullptr;
+  int ext_stride = 0;
+  // depth attachment state (gl.cc:394-420 CLEARED flag; rasterize.h:962)
+  bool depth_cleared = false;
+  bool depth_materialized = false;
+  uint32_t depth_value = 0xFFFFFF;
+  // hazards against the pending list
+  bool pending_read = false, pending_write = false;
+  int pending_target = -1;   // index into Context::work when pending_write
+  bool has_storage() const { return dptr != nullptr; }
+};
+
+struct VertexAttrib {
+  size_t size = 0; GLenum type = 0; bool normalized = false; GLsizei stride = 0; GLuint offset = 0;
+  bool enabled = false; GLuint divisor = 0; GLuint vertex_buffer = 0;
+};
+#define MAX_ATTRIBS 17
+#define NULL_ATTRIB 16
+struct VertexArray {
+  VertexAttrib attribs[MAX_ATTRIBS];
+  GLuint element_array_buffer_binding = 0;
+};
+struct Framebuffer { GLuint color_attachment = 0, depth_attachment = 0; };
+struct Renderbuffer { GLuint texture = 0; };
+struct Shader { GLenum type = 0; int kind = WR_SH_NONE; };
+
+// Static description of the programs the backend implements.
+struct ShaderInfo {
+  const char* key; int kind;
+  const char* attribs[10];   // [0] = per-vertex aPosition, then instance attributes in shader order
+  unsigned samplers;         // bit s set: program declares the sampler of slot s
+};
+#define S(x) (1u << (x))
+const unsigned PRIM_SAMPLERS = S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) |
+                               S(WR_S_PRIM_HEADERS_F) | S(WR_S_PRIM_HEADERS_I) | S(WR_S_CLIP_MASK);
+const ShaderInfo SHADERS[] = {
+    {"ps_quad_textured", WR_SH_PS_QUAD_TEXTURED, {"aPosition", "aData"},
+     S(WR_S_COLOR0) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
+    {"brush_solid", WR_SH_BRUSH_SOLID, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_solid ALPHA_PASS", WR_SH_BRUSH_SOLID_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"composite TEXTURE_2D", WR_SH_COMPOSITE,
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
+     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
+    {"composite FAST_PATH,TEXTURE_2D", WR_SH_COMPOSITE_FAST,
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
+     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
+    {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
+};
+#undef S
+const char* const SAMPLER_NAMES[WR_MAX_TEX] = {
+    "sColor0", "sColor1", "sColor2", "sGpuCache", "sTransformPalette", "sRenderTasks", "sDither",
+    "sPrimitiveHeadersF", "sPrimitiveHeadersI", "sClipMask", "sGpuBufferF", "sGpuBufferI"};
+const int UNIFORM_TRANSFORM = WR_MAX_TEX + 1;   // sampler s -> uniform index s+1
+
+struct Program {
+  const ShaderInfo* info = nullptr;
+  bool linked = false, deleted = false;
+  int attrib_loc[10];
+  int sampler_unit[WR_MAX_TEX];
+  float transform[16];
+  Program() {
+    for (int& a : attrib_loc) a = NULL_ATTRIB;
+    for (int& s : sampler_unit) s = 0;
+    memset(transform, 0, sizeof(transform));
+  }
+};
+
+// One render target with work pending in the current batch of deferred draws.
+struct TargetWork {
+  GLuint tex = 0;
+  GLuint depth_tex = 0;
+  std::vector<WrDrawDesc> draws;   // submission order; inst_offset relative to `inst`
+  std::vector<uint8_t> inst;       // instance bytes snapshotted at draw time
+  std::vector<GLuint> reads;       // textures sampled by these draws
+  int prims = 0;
+};
+
+const size_t MAX_TEXTURE_UNITS = 16;
+
+struct Context {
+  int32_t references = 1;
+  ObjectStore<Query> queries;
+  ObjectStore<Buffer> buffers;
+  ObjectStore<Texture> textures;
+  ObjectStore<VertexArray> vertex_arrays;
+  ObjectStore<Framebuffer> framebuffers;
+  ObjectStore<Renderbuffer> renderbuffers;
+  ObjectStore<Shader> shaders;
+  ObjectStore<Program> programs;
+
+  GLenum last_error = GL_NO_ERROR;
+  int viewport[4] = {0, 0, 0, 0};  // x0,y0,x1,y1
+  bool blend = false;
+  GLenum blendfunc_srgb = GL_ONE, blendfunc_drgb = GL_ZERO, blendfunc_sa = GL_ONE, blendfunc_da = GL_ZERO;
+  GLenum blend_equation = GL_FUNC_ADD;
+  uint32_t blendcolor[2] = {0, 0};
+  int blend_key = WR_BLEND_NONE;
+  bool depthtest = false, depthmask = true;
+  GLenum depthfunc = GL_LESS;
+  bool scissortest = false;
+  int scissor[4] = {0, 0, 0, 0};
+  float clearcolor[4] = {0, 0, 0, 0};
+  double cleardepth = 1;
+  int unpack_row_length = 0;
+
+  struct TextureUnit { GLuint texture_2d_binding = 0, texture_rectangle_binding = 0; };
+  TextureUnit texture_units[MAX_TEXTURE_UNITS];
+  int active_texture_unit = 0;
+  GLuint current_program = 0, current_vertex_array = 0;
+  GLuint pixel_pack_buffer_binding = 0, pixel_unpack_buffer_binding = 0, array_buffer_binding = 0;
+  GLuint time_elapsed_query = 0, samples_passed_query = 0;
+  GLuint renderbuffer_binding = 0, draw_framebuffer_binding = 0, read_framebuffer_binding = 0;
+  GLuint unknown_binding = 0;
+
+  // ---- device side ------------------------------------------------------
+  wr_stream_t stream;
+  // deferred work
+  std::vector<TargetWork> work;       // render targets with pending draws
+  std::vector<GLuint> referenced;     // textures with pending_read/pending_write set
+  // frame arenas (pinned host + HBM), ring of 3
+  static const int NARENA = 3;
+  uint8_t* harena[NARENA] = {nullptr, nullptr, nullptr};
+  size_t harena_size[NARENA] = {0, 0, 0};
+  wr_event_t arena_event[NARENA];
+  bool arena_used[NARENA] = {false, false, false};
+  int arena_index = 0;
+  uint8_t* darena = nullptr; size_t darena_size = 0;
+  WrPrim* dprims = nullptr; size_t dprims_cap = 0;
+  unsigned long long* dmasks = nullptr; size_t dmasks_cap = 0;
+  WrUnsupportedCounters* dcounters = nullptr;
+  // upload staging ring (pinned)
+  uint8_t* staging = nullptr; size_t staging_size = 0, staging_pos = 0;
+  // profiling
+  bool profiling = false;
+  wr_event_t ev_a, ev_b;
+  WrhipStats stats;
+  int shard_rank = 0, shard_world = 1;
+
+  Context() {
+    wrrt::stream_create(&stream);
+    for (int i = 0; i < NARENA; i++) wrrt::event_create(&arena_event[i]);
+    wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
+    memset(&stats, 0, sizeof(stats));
+    dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
+    wrrt::memset8(dcounters, 0, sizeof(WrUnsupportedCounters), stream);
+  }
+  ~Context();
+
+  GLuint& get_binding(GLenum name) {
+    switch (name) {
+      case GL_PIXEL_PACK_BUFFER: return pixel_pack_buffer_binding;
+      case GL_PIXEL_UNPACK_BUFFER: return pixel_unpack_buffer_binding;
+      case GL_ARRAY_BUFFER: return array_buffer_binding;
+      case GL_ELEMENT_ARRAY_BUFFER: return vertex_arrays[current_vertex_array].element_array_buffer_binding;
+      case GL_TEXTURE_2D: return texture_units[active_texture_unit].texture_2d_binding;
+      case GL_TEXTURE_RECTANGLE: return texture_units[active_texture_unit].texture_rectangle_binding;
+      case GL_TIME_ELAPSED: return time_elapsed_query;
+      case GL_SAMPLES_PASSED: return samples_passed_query;
+      case GL_RENDERBUFFER: return renderbuffer_binding;
+      case GL_DRAW_FRAMEBUFFER: return draw_framebuffer_binding;
+      case GL_READ_FRAMEBUFFER: return read_framebuffer_binding;
+      default: return unknown_binding;
+    }
+  }
+};
+
+Context* ctx = nullptr;
+bool g_rt_ok = false, g_rt_tried = false;
+char g_device_name[256] = "";
+
+void ensure_runtime() {
+  if (g_rt_tried) {
+    if (!g_rt_ok) { fprintf(stderr, "libwrhip: no HIP device available; this backend has no CPU path\n"); abort(); }
+    return;
+  }
+  g_rt_tried = true;
+  int dev = 0;
+  g_rt_ok = wrrt::init(&dev, g_device_name, sizeof(g_device_name));
+  if (!g_rt_ok) { fprintf(stderr, "libwrhip: no HIP device available; this backend has no CPU path\n"); abort(); }
+}
+
+// ---------------------------------------------------------------------------
+int bytes_for_internal_format(GLenum f) {
+  switch (f) {
+    case GL_RGBA32F: case GL_RGBA32I: return 16;
+    case GL_RGBA8: case GL_BGRA8: case GL_RGBA: return 4;
+    case GL_R8: case GL_RED: return 1;
+    case GL_RG8: case GL_RG: return 2;
+    case GL_DEPTH_COMPONENT: case GL_DEPTH_COMPONENT16: case GL_DEPTH_COMPONENT24: case GL_DEPTH_COMPONENT32: return 4;
+    case GL_RGB_RAW_422_APPLE: return 2;
+    case GL_R16: return 2;
+    case GL_RG16: return 4;
+    default: return 0;
+  }
+}
+int aligned_stride(int row_bytes) { return (row_bytes + 3) & ~3; }
+GLenum remap_internal_format(GLenum format) {
+  switch (format) {
+    case GL_DEPTH_COMPONENT: return GL_DEPTH_COMPONENT24;
+    case GL_RGBA: return GL_RGBA8;
+    case GL_RED: return GL_R8;
+    case GL_RG: return GL_RG8;
+    case GL_RGB_422_APPLE: return GL_RGB_RAW_422_APPLE;
+    default: return format;
+  }
+}
+int wr_format(GLenum f) {
+  switch (f) {
+    case GL_RGBA32F: return WR_FMT_RGBA32F;
+    case GL_RGBA32I: return WR_FMT_RGBA32I;
+    case GL_RGBA8: return WR_FMT_RGBA8;
+    case GL_R8: return WR_FMT_R8;
+    case GL_RG8: return WR_FMT_RG8;
+    case GL_R16: return WR_FMT_R16;
+    case GL_RG16: return WR_FMT_RG16;
+    case GL_DEPTH_COMPONENT24: return WR_FMT_DEPTH24;
+    default: return WR_FMT_NONE;
+  }
+}
+GLenum internal_format_for_data(GLenum format, GLenum ty) {
+  if (format == GL_RED && ty == GL_UNSIGNED_BYTE) return GL_R8;
+  if ((format == GL_RGBA || format == GL_BGRA) && (ty == GL_UNSIGNED_BYTE || ty == GL_UNSIGNED_INT_8_8_8_8_REV)) return GL_RGBA8;
+  if (format == GL_RGBA && ty == GL_FLOAT) return GL_RGBA32F;
+  if (format == GL_RGBA_INTEGER && ty == GL_INT) return GL_RGBA32I;
+  if (format == GL_RG && ty == GL_UNSIGNED_BYTE) return GL_RG8;
+  if (format == GL_RGB_422_APPLE && ty == GL_UNSIGNED_SHORT_8_8_REV_APPLE) return GL_RGB_RAW_422_APPLE;
+  if (format == GL_RED && ty == GL_UNSIGNED_SHORT) return GL_R16;
+  if (format == GL_RG && ty == GL_UNSIGNED_SHORT) return GL_RG16;
+  return 0;
+}
+bool format_requires_conversion(GLenum external_format, GLenum internal_format) {
+  return external_format == GL_RGBA && internal_format == GL_RGBA8;
+}
+void out_of_memory() { ctx->last_error = GL_OUT_OF_MEMORY; }
+
+uint64_t get_time_value() {
+  struct timespec tp;
+  clock_gettime(CLOCK_MONOTONIC, &tp);
+  return tp.tv_sec * 1000000000ULL + tp.tv_nsec;
+}
+
+// ---------------------------------------------------------------------------
+// Deferred work: flush
+void flush_all();
+
+uint8_t* staging_alloc(size_t n) {
+  Context* c = ctx;
+  n = (n + 255) & ~size_t(255);
+  if (n > c->staging_size) {
+    wrrt::stream_sync(c->stream);
+    wrrt::pinned_free(c->staging);
+    c->staging_size = std::max(n, size_t(64) << 20);
+    c->staging = (uint8_t*)wrrt::pinned_alloc(c->staging_size);
+    c->staging_pos = 0;
+  }
+  if (c->staging_pos + n > c->staging_size) {
+    wrrt::stream_sync(c->stream);   // everything staged so far has been consumed
+    c->staging_pos = 0;
+  }
+  uint8_t* p = c->staging + c->staging_pos;
+  c->staging_pos += n;
+  return p;
+}
+
+void mark_ref(GLuint id, Texture& t, bool write, int target_index = -1) {
+  if (!t.pending_read && !t.pending_write) ctx->referenced.push_back(id);
+  if (write) { t.pending_write = true; t.pending_target = target_index; }
+  else t.pending_read = true;
+}
+
+void flush_work(const std::vector<int>& sel);
+
+// Flush every pending target except the one rendering into texture `keep`
+// (whose register-resident depth state would otherwise be lost mid-target).
+// Flushing more than strictly needed keeps the launch count per frame low:
+// all independent targets go through one vertex/bin/raster launch.
+void flush_except(GLuint keep) {
+  std::vector<int> sel;
+  for (size_t i = 0; i < ctx->work.size(); i++) if (ctx->work[i].tex != keep) sel.push_back((int)i);
+  if (!sel.empty()) flush_work(sel);
+}
+
+// A host- or copy-side write to texture `t` (or its deletion / reallocation)
+// must not overtake pending draws that read or write it.
+void sync_texture_for_write(Texture& t) { if (t.pending_read || t.pending_write) flush_all(); }
+void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); }
+
+void free_texture_storage(Texture& t) {
+  sync_texture_for_write(t);
+  if (t.dptr) {
+    // storage may still be in use by already-enqueued kernels/copies
+    wrrt::stream_sync(ctx->stream);
+    wrrt::dev_free(t.dptr);
+    t.dptr = nullptr; t.dsize = 0;
+  }
+  free(t.hmirror); t.hmirror = nullptr; t.hmirror_size = 0;
+  t.depth_materialized = false;
+}
+
+bool allocate_texture(Texture& t) {
+  int bpp = bytes_for_internal_format(t.internal_format);
+  int stride = aligned_stride(bpp * t.width);
+  size_t size = (size_t)stride * t.height;
+  t.bpp = bpp; t.stride = stride;
+  if (t.internal_format == GL_DEPTH_COMPONENT24) {
+    // depth lives in registers during a flush; HBM storage is only
+    // materialised if a depth buffer must survive a flush (rare)
+    return true;
+  }
+  if (size == 0) return true;
+  if (!t.dptr || size > t.dsize) {
+    if (t.dptr) { wrrt::stream_sync(ctx->stream); wrrt::dev_free(t.dptr); }
+    t.dptr = wrrt::dev_alloc(size + 64);
+    t.dsize = size;
+    if (!t.dptr) return false;
+  }
+  return true;
+}
+
+void set_tex_storage(Texture& t, GLenum external_format, GLsizei width, GLsizei height, void* buf = nullptr,
+                     GLsizei stride = 0) {
+  GLenum internal_format = remap_internal_format(external_format);
+  sync_texture_for_write(t);
+  if (t.width != width || t.height != height || t.internal_format != internal_format) {
+    t.internal_format = internal_format; t.width = width; t.height = height;
+  }
+  t.depth_cleared = false; t.depth_materialized = false;
+  if (!allocate_texture(t)) out_of_memory();
+  t.ext_buf = nullptr; t.ext_stride = 0;
+  if (buf && t.dptr) {
+    bool conv = format_requires_conversion(external_format, internal_format);
+    if (!conv) { t.ext_buf = buf; t.ext_stride = stride; }
+    // upload current contents of the external buffer
+    size_t row = (size_t)t.bpp * width;
+    uint8_t* st = staging_alloc(row * height);
+    for (int y = 0; y < height; y++) {
+      const uint8_t* s = (const uint8_t*)buf + (size_t)y * stride;
+      uint8_t* d = st + (size_t)y * row;
+      if (conv) {
+        for (int x = 0; x < width; x++) {
+          uint32_t p = ((const uint32_t*)s)[x]; uint32_t rb = p & 0x00FF00FF;
+          ((uint32_t*)d)[x] = (p & 0xFF00FF00) | (rb << 16) | (rb >> 16);
+        }
+      } else memcpy(d, s, row);
+    }
+    wrrt::copy2d(t.dptr, t.stride, st, row, row, height, 0, ctx->stream);
+    ctx->stats.h2d_bytes += row * height;
+  }
+}
+
+int hash_blend_key(Context* c) {
+  GLenum srgb = c->blendfunc_srgb, drgb = c->blendfunc_drgb, sa = c->blendfunc_sa, da = c->blendfunc_da;
+  if (c->blend_equation != GL_FUNC_ADD) {
+    switch (c->blend_equation) {
+      case GL_MIN: return WR_BLEND_MIN;
+      case GL_MAX: return WR_BLEND_MAX;
+      default: return WR_BLEND_UNSUPPORTED;  // KHR advanced equations: mix-blend, out of scope
+    }
+  }
+  bool sep = (srgb != sa || drgb != da);
+#define K2(s, d) (!sep && srgb == (s) && drgb == (d))
+#define K4(s, d, a, b) (srgb == (s) && drgb == (d) && sa == (a) && da == (b))
+  if (K2(GL_ONE, GL_ZERO)) return WR_BLEND_NONE;
+  if (K4(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA, GL_ONE, GL_ONE_MINUS_SRC_ALPHA)) return WR_BLEND_ALPHA;
+  if (K2(GL_ONE, GL_ONE_MINUS_SRC_ALPHA)) return WR_BLEND_PREMULT;
+  if (K2(GL_ZERO, GL_ONE_MINUS_SRC_COLOR)) return WR_BLEND_ZERO_INV_SRC_COLOR;
+  if (K4(GL_ZERO, GL_ONE_MINUS_SRC_COLOR, GL_ZERO, GL_ONE)) return WR_BLEND_ZERO_INV_SRC_COLOR_A1;
+  if (K2(GL_ZERO, GL_ONE_MINUS_SRC_ALPHA)) return WR_BLEND_DEST_OUT;
+  if (K2(GL_ZERO, GL_SRC_COLOR)) return WR_BLEND_MULTIPLY;
+  if (K2(GL_ONE, GL_ONE)) return WR_BLEND_ADD;
+  if (K4(GL_ONE, GL_ONE, GL_ONE, GL_ONE_MINUS_SRC_ALPHA)) return WR_BLEND_ADD_A_OVER;
+  if (K4(GL_ONE_MINUS_DST_ALPHA, GL_ONE, GL_ZERO, GL_ONE)) return WR_BLEND_INV_DST_A;
+  if (K2(GL_CONSTANT_COLOR, GL_ONE_MINUS_SRC_COLOR)) return WR_BLEND_CONST_COLOR;
+  if (K2(GL_ONE, GL_ONE_MINUS_SRC1_COLOR)) return WR_BLEND_DUAL_SRC;
+#undef K2
+#undef K4
+  return WR_BLEND_UNSUPPORTED;
+}
+
+GLenum remap_blendfunc(GLenum rgb, GLenum a) {  // gl.cc:1240-1292
+  switch (a) {
+    case GL_SRC_ALPHA: if (rgb == GL_SRC_COLOR) a = GL_SRC_COLOR; break;
+    case GL_ONE_MINUS_SRC_ALPHA: if (rgb == GL_ONE_MINUS_SRC_COLOR) a = GL_ONE_MINUS_SRC_COLOR; break;
+    case GL_DST_ALPHA: if (rgb == GL_DST_COLOR) a = GL_DST_COLOR; break;
+    case GL_ONE_MINUS_DST_ALPHA: if (rgb == GL_ONE_MINUS_DST_COLOR) a = GL_ONE_MINUS_DST_COLOR; break;
+    case GL_CONSTANT_ALPHA: if (rgb == GL_CONSTANT_COLOR) a = GL_CONSTANT_COLOR; break;
+    case GL_ONE_MINUS_CONSTANT_ALPHA: if (rgb == GL_ONE_MINUS_CONSTANT_COLOR) a = GL_ONE_MINUS_CONSTANT_COLOR; break;
+    case GL_SRC_COLOR: if (rgb == GL_SRC_ALPHA) a = GL_SRC_ALPHA; break;
+    case GL_ONE_MINUS_SRC_COLOR: if (rgb == GL_ONE_MINUS_SRC_ALPHA) a = GL_ONE_MINUS_SRC_ALPHA; break;
+    case GL_DST_COLOR: if (rgb == GL_DST_ALPHA) a = GL_DST_ALPHA; break;
+    case GL_ONE_MINUS_DST_COLOR: if (rgb == GL_ONE_MINUS_DST_ALPHA) a = GL_ONE_MINUS_DST_ALPHA; break;
+    case GL_CONSTANT_COLOR: if (rgb == GL_CONSTANT_ALPHA) a = GL_CONSTANT_ALPHA; break;
+    case GL_ONE_MINUS_CONSTANT_COLOR: if (rgb == GL_ONE_MINUS_CONSTANT_ALPHA) a = GL_ONE_MINUS_CONSTANT_ALPHA; break;
+    case GL_SRC1_ALPHA: if (rgb == GL_SRC1_COLOR) a = GL_SRC1_COLOR; break;
+    case GL_ONE_MINUS_SRC1_ALPHA: if (rgb == GL_ONE_MINUS_SRC1_COLOR) a = GL_ONE_MINUS_SRC1_COLOR; break;
+    case GL_SRC1_COLOR: if (rgb == GL_SRC1_ALPHA) a = GL_SRC1_ALPHA; break;
+    case GL_ONE_MINUS_SRC1_COLOR: if (rgb == GL_ONE_MINUS_SRC1_ALPHA) a = GL_ONE_MINUS_SRC1_ALPHA; break;
+  }
+  return a;
+}
+
+Framebuffer* get_framebuffer(GLenum target, bool fallback = false) {
+  if (target == GL_FRAMEBUFFER) target = GL_DRAW_FRAMEBUFFER;
+  Framebuffer* fb = ctx->framebuffers.find(ctx->get_binding(target));
+  if (fallback && !fb) fb = &ctx->framebuffers[0];
+  return fb;
+}
+
+// apply_scissor(t), gl.cc:857-864, in texture pixels
+void apply_scissor(const Texture& t, int out[4]) {
+  int x0 = 0, y0 = 0, x1 = t.width, y1 = t.height;
+  if (ctx->scissortest) {
+    x0 = std::max(x0, ctx->scissor[0] - t.offx); y0 = std::max(y0, ctx->scissor[1] - t.offy);
+    x1 = std::min(x1, ctx->scissor[2] - t.offx); y1 = std::min(y1, ctx->scissor[3] - t.offy);
+  }
+  out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1;
+}
+
+int find_or_add_work(GLuint tex_id) {
+  {
+    Texture& t = ctx->textures[tex_id];
+    if (t.pending_write && t.pending_target >= 0) return t.pending_target;
+    // the target is about to be written: pending draws that sample it must run first
+    if (t.pending_read) flush_all();
+  }
+  TargetWork w;
+  w.tex = tex_id;
+  ctx->work.push_back(w);
+  int idx = (int)ctx->work.size() - 1;
+  mark_ref(tex_id, ctx->textures[tex_id], true, idx);
+  return idx;
+}
+
+void record_clear(GLuint tex_id, bool color, uint32_t color_value, bool depth, GLuint depth_tex, uint32_t depth_value,
+                  const int rect[4]) {
+  {
+    Texture& t = ctx->textures[tex_id];
+    if (!t.has_storage()) return;
+  }
+  int wi = find_or_add_work(tex_id);
+  Texture& t = ctx->textures[tex_id];
+  WrDrawDesc d;
+  memset(&d, 0, sizeof(d));
+  d.shader = WR_SH_CLEAR_OP;
+  d.target = wi;
+  d.count = 1;
+  d.flags = (color ? WR_DF_CLEAR_COLOR : 0) | (depth ? WR_DF_CLEAR_DEPTH : 0);
+  d.clip[0] = std::max(rect[0], 0); d.clip[1] = std::max(rect[1], 0);
+  d.clip[2] = std::min(rect[2], t.width); d.clip[3] = std::min(rect[3], t.height);
+  d.clear_color = color_value;
+  d.clear_depth = depth_value;
+  for (int k = 0; k < 8; k++) d.attr_off[k] = -1;
+  TargetWork& w = ctx->work[wi];
+  if (depth) w.depth_tex = depth_tex;
+  w.draws.push_back(d);
+  w.prims += 1;
+}
+
+void download_texture(Texture& t) {
+  // HBM -> host mirror (or external buffer) after a full flush
+  sync_texture_for_read(t);
+  if (!t.dptr) return;
+  size_t row = (size_t)t.bpp * t.width;
+  if (t.ext_buf) {
+    wrrt::copy2d(t.ext_buf, t.ext_stride, t.dptr, t.stride, row, t.height, 1, ctx->stream);
+  } else {
+    size_t need = (size_t)t.stride * t.height;
+    if (t.hmirror_size < need) { free(t.hmirror); t.hmirror = (uint8_t*)malloc(need + 64); t.hmirror_size = need; }
+    wrrt::copy2d(t.hmirror, t.stride, t.dptr, t.stride, row, t.height, 1, ctx->stream);
+  }
+  ctx->stats.d2h_bytes += row * t.height;
+  wrrt::stream_sync(ctx->stream);
+}
+
+Context::~Context() {
+  Context* saved = ctx;
+  ctx = this;
+  flush_all();
+  wrrt::stream_sync(stream);
+  for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
+  for (int i = 0; i < NARENA; i++) { wrrt::pinned_free(harena[i]); wrrt::event_destroy(arena_event[i]); }
+  wrrt::dev_free(darena); wrrt::dev_free(dprims); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
+  wrrt::pinned_free(staging);
+  wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
+  wrrt::stream_destroy(stream);
+  ctx = saved == this ? nullptr : saved;
+}
+
+// ---------------------------------------------------------------------------
+// Execute the selected pending targets: one H2D copy of the frame arena, then
+// vertex + bin + raster launches covering every selected target at once.
+void flush_work(const std::vector<int>& sel_in) {
+  Context* c = ctx;
+  if (!c || c->work.empty() || sel_in.empty()) return;
+  std::vector<int> sel(sel_in);
+  std::sort(sel.begin(), sel.end());
+  sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
+  // RGBA8 targets first so each raster kernel gets a contiguous bin range
+  std::stable_sort(sel.begin(), sel.end(), [&](int a, int b) {
+    return (c->textures[c->work[a].tex].internal_format == GL_R8) < (c->textures[c->work[b].tex].internal_format == GL_R8);
+  });
+  const int n_targets = (int)sel.size();
+  std::vector<WrDrawDesc> draws;
+  std::vector<WrTargetDesc> targets(n_targets);
+  std::vector<uint8_t> inst;
+  int prim_cursor = 0, bin_cursor = 0, word_cursor = 0, bins_rgba = 0;
+  uint64_t algo_bytes = 0, pixels = 0;
+  for (int oi = 0; oi < n_targets; oi++) {
+    TargetWork& w = c->work[sel[oi]];
+    Texture& t = c->textures[w.tex];
+    WrTargetDesc& T = targets[oi];
+    memset(&T, 0, sizeof(T));
+    T.color = t.dptr; T.width = t.width; T.height = t.height; T.stride = t.stride;
+    T.format = t.internal_format == GL_R8 ? WR_FMT_R8 : WR_FMT_RGBA8;
+    T.bins_x = (t.width + WR_BIN_W - 1) / WR_BIN_W; T.bins_y = (t.height + WR_BIN_H - 1) / WR_BIN_H;
+    T.first_bin = bin_cursor; T.first_prim = prim_cursor;
+    T.load_color = 1; T.init_color = 0; T.load_depth = 0; T.store_depth = 0;
+    Texture* dt = w.depth_tex ? c->textures.find(w.depth_tex) : nullptr;
+    T.init_depth = dt ? dt->depth_value : 0xFFFFFF;
+    T.row_begin = 0; T.row_end = T.bins_y;
+    if (c->shard_world > 1) {  // contiguous strips of bin rows per rank (DESIGN.md multi-GPU)
+      T.row_begin = (int)((int64_t)T.bins_y * c->shard_rank / c->shard_world);
+      T.row_end = (int)((int64_t)T.bins_y * (c->shard_rank + 1) / c->shard_world);
+    }
+    size_t inst_base = (inst.size() + 15) & ~size_t(15);
+    inst.resize(inst_base + w.inst.size());
+    if (!w.inst.empty()) memcpy(inst.data() + inst_base, w.inst.data(), w.inst.size());
+    bool any_kept = false;
+    for (const WrDrawDesc& d0 : w.draws) {
+      WrDrawDesc d = d0;
+      d.target = oi;
+      d.inst_offset += inst_base;
+      // Leading full-target clears initialise the bins instead of loading HBM.
+      if (!any_kept && d.shader == WR_SH_CLEAR_OP && d.clip[0] <= 0 && d.clip[1] <= 0 && d.clip[2] >= t.width &&
+          d.clip[3] >= t.height) {
+        if (d.flags & WR_DF_CLEAR_COLOR) { T.load_color = 0; T.init_color = d.clear_color; }
+        if (d.flags & WR_DF_CLEAR_DEPTH) { T.init_depth = d.clear_depth; }
+        continue;
+      }
+      any_kept = true;
+      d.first_prim = prim_cursor;
+      prim_cursor += d.count;
+      draws.push_back(d);
+    }
+    T.end_prim = prim_cursor;
+    int nrel = T.end_prim - T.first_prim;
+    T.words_per_bin = (nrel + 63) / 64;
+    T.word_base = word_cursor;
+    word_cursor += T.words_per_bin * T.bins_x * T.bins_y;
+    bin_cursor += T.bins_x * T.bins_y;
+    if (T.format == WR_FMT_RGBA8) bins_rgba = bin_cursor;
+    uint64_t owned = (uint64_t)t.width * std::max(0, std::min(t.height, T.row_end * WR_BIN_H) - T.row_begin * WR_BIN_H);
+    pixels += owned;
+    algo_bytes += owned * t.bpp * (T.load_color ? 2 : 1);
+    {  // unique source texels sampled: bounded by what a 1:1 mapping can touch
+      uint64_t src = 0;
+      for (GLuint id : w.reads)
+        if (Texture* rt = c->textures.find(id))
+          if (rt->internal_format == GL_RGBA8 || rt->internal_format == GL_R8) src += (uint64_t)rt->stride * rt->height;
+      algo_bytes += std::min<uint64_t>(src, owned * t.bpp);
+    }
+    if (dt && dt->depth_cleared && nrel > 0) {
+      // The depth buffer outlives this flush only as a uniform value; WebRender
+      // always clears before and invalidates after each target, so this only
+      // triggers for foreign call patterns.
+      bool wrote = false;
+      for (const WrDrawDesc& d0 : w.draws) if ((d0.flags & WR_DF_DEPTH_WRITE) && d0.shader != WR_SH_CLEAR_OP) wrote = true;
+      if (wrote) {
+        static bool warned = false;
+        if (!warned) { fprintf(stderr, "libwrhip: depth buffer contents dropped at flush (not invalidated by caller)\n"); warned = true; }
+      }
+    }
+  }
+  const int n_prims = prim_cursor, n_bins = bin_cursor, n_words = word_cursor;
+  const int nd = (int)draws.size();
+  if (n_bins > 0) {
+    // ---- frame arena: [draws | targets | instance bytes] -> one H2D copy ----
+    size_t off_draws = 0;
+    size_t off_targets = (off_draws + sizeof(WrDrawDesc) * nd + 255) & ~size_t(255);
+    size_t off_inst = (off_targets + sizeof(WrTargetDesc) * n_targets + 255) & ~size_t(255);
+    size_t total = off_inst + inst.size() + 256;
+    int ai = c->arena_index; c->arena_index = (ai + 1) % Context::NARENA;
+    if (c->arena_used[ai]) wrrt::event_sync(&c->arena_event[ai]);
+    if (c->harena_size[ai] < total) {
+      wrrt::pinned_free(c->harena[ai]);
+      c->harena_size[ai] = total * 2;
+      c->harena[ai] = (uint8_t*)wrrt::pinned_alloc(c->harena_size[ai]);
+    }
+    if (c->darena_size < total) {
+      wrrt::stream_sync(c->stream);
+      wrrt::dev_free(c->darena);
+      c->darena_size = total * 2;
+      c->darena = (uint8_t*)wrrt::dev_alloc(c->darena_size);
+    }
+    uint8_t* h = c->harena[ai];
+    if (nd) memcpy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
+    memcpy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
+    if (!inst.empty()) memcpy(h + off_inst, inst.data(), inst.size());
+    wrrt::h2d(c->darena, h, total, c->stream);
+    wrrt::event_record(&c->arena_event[ai], c->stream);
+    c->arena_used[ai] = true;
+    c->stats.h2d_bytes += total;
+    algo_bytes += inst.size() + sizeof(WrDrawDesc) * nd;
+    // ---- scratch ----
+    if (c->dprims_cap < (size_t)n_prims + 1) {
+      wrrt::stream_sync(c->stream);
+      wrrt::dev_free(c->dprims);
+      c->dprims_cap = (size_t)(n_prims + 1) * 2;
+      c->dprims = (WrPrim*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrPrim));
+    }
+    if (c->dmasks_cap < (size_t)n_words + 1) {
+      wrrt::stream_sync(c->stream);
+      wrrt::dev_free(c->dmasks);
+      c->dmasks_cap = (size_t)(n_words + 1) * 2;
+      c->dmasks = (unsigned long long*)wrrt::dev_alloc(c->dmasks_cap * 8);
+    }
+    wrrt::memset8(c->dmasks, 0, (size_t)n_words * 8, c->stream);
+    const WrDrawDesc* ddraws = (const WrDrawDesc*)(c->darena + off_draws);
+    const WrTargetDesc* dtargets = (const WrTargetDesc*)(c->darena + off_targets);
+    const uint8_t* dinst = c->darena + off_inst;
+    if (n_prims > 0) {
+      WR_LAUNCH(wr_vertex_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, n_prims, c->dcounters);
+      WR_LAUNCH(wr_bin_kernel, (n_prims + 255) / 256, 256, c->stream, (const WrPrim*)c->dprims, n_prims, ddraws, dtargets, c->dmasks);
+      c->stats.kernel_launches += 2;
+    }
+#ifdef WRHIP_HOSTSIM
+    if (getenv("WRHIP_DEBUG")) {
+      fprintf(stderr, "flush: targets %d draws %d prims %d bins %d words %d\n", n_targets, nd, n_prims, n_bins, n_words);
+      for (int i = 0; i < n_targets; i++)
+        fprintf(stderr, "  T%d %dx%d fmt %d load %d init %08x prims [%d,%d) wpb %d\n", i, targets[i].width, targets[i].height,
+                targets[i].format, targets[i].load_color, targets[i].init_color, targets[i].first_prim, targets[i].end_prim,
+                targets[i].words_per_bin);
+      for (int i = 0; i < nd && i < 6; i++)
+        fprintf(stderr, "  D%d sh %d tgt %d first %d n %d blend %d flags %x clip %d %d %d %d vp %g %g %g %g\n", i, draws[i].shader,
+                draws[i].target, draws[i].first_prim, draws[i].count, draws[i].blend, draws[i].flags, draws[i].clip[0],
+                draws[i].clip[1], draws[i].clip[2], draws[i].clip[3], draws[i].vp_origin[0], draws[i].vp_origin[1],
+                draws[i].vp_size[0], draws[i].vp_size[1]);
+      for (int i = 0; i < nd && i < 6; i++)
+        fprintf(stderr, "     inst off %llu stride %d attr_off %d %d %d %d %d %d bytes %d %d quad %g %g %g %g %g %g %g %g\n",
+                (unsigned long long)draws[i].inst_offset, draws[i].inst_stride, draws[i].attr_off[0], draws[i].attr_off[1],
+                draws[i].attr_off[2], draws[i].attr_off[3], draws[i].attr_off[4], draws[i].attr_off[5], draws[i].attr_bytes[0],
+                draws[i].attr_bytes[1], draws[i].quad[0], draws[i].quad[1], draws[i].quad[2], draws[i].quad[3], draws[i].quad[4],
+                draws[i].quad[5], draws[i].quad[6], draws[i].quad[7]);
+      for (int i = 0; i < nd && i < 6; i++) {
+        const float* f = (const float*)(dinst + draws[i].inst_offset);
+        fprintf(stderr, "     flush inst D%d: %g %g %g %g (inst.size %zu)\n", i, f[0], f[1], f[2], f[3], inst.size());
+      }
+      for (int i = 0; i < n_prims && i < 6; i++) {
+        const WrPrim& P = c->dprims[i];
+        fprintf(stderr, "  P%d kind %d rect %d %d %d %d z %u blend %d flags %x color %08x %08x\n", i, P.kind, P.x0, P.y0, P.x1, P.y1,
+                P.z, P.blend, P.flags, P.color[0], P.color[1]);
+      }
+    }
+#endif
+    if (c->profiling) wrrt::event_record(&c->ev_a, c->stream);
+    if (bins_rgba > 0) {
+      WR_LAUNCH(wr_raster_kernel<WR_FMT_RGBA8>, bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
+                (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, 0);
+      c->stats.kernel_launches++; c->stats.raster_launches++;
+    }
+    if (n_bins > bins_rgba) {
+      WR_LAUNCH(wr_raster_kernel<WR_FMT_R8>, n_bins - bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
+                (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, bins_rgba);
+      c->stats.kernel_launches++; c->stats.raster_launches++;
+    }
+    if (c->profiling) {
+      wrrt::event_record(&c->ev_b, c->stream);
+      wrrt::event_sync(&c->ev_b);
+      c->stats.raster_ns += (uint64_t)(wrrt::event_elapsed_ms(&c->ev_a, &c->ev_b) * 1.0e6);
+    }
+    c->stats.flushes++;
+    c->stats.prims += n_prims;
+    c->stats.raster_pixels += pixels;
+    c->stats.raster_algo_bytes += algo_bytes;
+  }
+  // ---- drop the flushed work, keep the rest, rebuild hazard flags ----------
+  std::vector<char> gone(c->work.size(), 0);
+  for (int i : sel) gone[i] = 1;
+  std::vector<TargetWork> rest;
+  for (size_t i = 0; i < c->work.size(); i++) if (!gone[i]) rest.push_back(std::move(c->work[i]));
+  c->work.swap(rest);
+  for (GLuint id : c->referenced)
+    if (Texture* t = c->textures.find(id)) { t->pending_read = t->pending_write = false; t->pending_target = -1; }
+  c->referenced.clear();
+  for (size_t i = 0; i < c->work.size(); i++) {
+    mark_ref(c->work[i].tex, c->textures[c->work[i].tex], true, (int)i);
+    for (GLuint id : c->work[i].reads) if (Texture* t = c->textures.find(id)) mark_ref(id, *t, false);
+  }
+}
+
+void flush_all() {
+  Context* c = ctx;
+  if (!c || c->work.empty()) return;
+  std::vector<int> sel(c->work.size());
+  for (size_t i = 0; i < sel.size(); i++) sel[i] = (int)i;
+  flush_work(sel);
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+extern "C" {
+
+void UseProgram(GLuint program) {
+  if (ctx->current_program && program != ctx->current_program) {
+    Program* p = ctx->programs.find(ctx->current_program);
+    if (p && p->deleted) ctx->programs.erase(ctx->current_program);
+  }
+  ctx->current_program = program;
+}
+void SetViewport(GLint x, GLint y, GLsizei width, GLsizei height) {
+  ctx->viewport[0] = x; ctx->viewport[1] = y; ctx->viewport[2] = x + width; ctx->viewport[3] = y + height;
+}
+void Enable(GLenum cap) {
+  switch (cap) { case GL_BLEND: ctx->blend = true; break; case GL_DEPTH_TEST: ctx->depthtest = true; break;
+    case GL_SCISSOR_TEST: ctx->scissortest = true; break; }
+}
+void Disable(GLenum cap) {
+  switch (cap) { case GL_BLEND: ctx->blend = false; break; case GL_DEPTH_TEST: ctx->depthtest = false; break;
+    case GL_SCISSOR_TEST: ctx->scissortest = false; break; }
+}
+GLenum GetError(void) { GLenum e = ctx->last_error; ctx->last_error = GL_NO_ERROR; return e; }
+
+static const char* const extensions[] = {
+    "GL_ARB_blend_func_extended", "GL_ARB_clear_texture", "GL_ARB_copy_image", "GL_ARB_draw_instanced",
+    "GL_ARB_explicit_attrib_location", "GL_ARB_instanced_arrays", "GL_ARB_invalidate_subdata",
+    "GL_ARB_texture_storage", "GL_EXT_timer_query", "GL_KHR_blend_equation_advanced",
+    "GL_KHR_blend_equation_advanced_coherent", "GL_APPLE_rgb_422"};
+
+void GetIntegerv(GLenum pname, GLint* params) {
+  switch (pname) {
+    case GL_MAX_TEXTURE_UNITS: case GL_MAX_TEXTURE_IMAGE_UNITS: params[0] = MAX_TEXTURE_UNITS; break;
+    case GL_MAX_TEXTURE_SIZE: params[0] = 1 << 15; break;
+    case GL_MAX_ARRAY_TEXTURE_LAYERS: params[0] = 0; break;
+    case GL_READ_FRAMEBUFFER_BINDING: params[0] = ctx->read_framebuffer_binding; break;
+    case GL_DRAW_FRAMEBUFFER_BINDING: params[0] = ctx->draw_framebuffer_binding; break;
+    case GL_PIXEL_PACK_BUFFER_BINDING: params[0] = ctx->pixel_pack_buffer_binding; break;
+    case GL_PIXEL_UNPACK_BUFFER_BINDING: params[0] = ctx->pixel_unpack_buffer_binding; break;
+    case GL_NUM_EXTENSIONS: params[0] = sizeof(extensions) / sizeof(extensions[0]); break;
+    case GL_MAJOR_VERSION: params[0] = 3; break;
+    case GL_MINOR_VERSION: params[0] = 2; break;
+    case GL_MIN_PROGRAM_TEXEL_OFFSET: params[0] = 0; break;
+    case GL_MAX_PROGRAM_TEXEL_OFFSET: params[0] = 8; break;
+    default: break;
+  }
+}
+void GetBooleanv(GLenum pname, GLboolean* params) { if (pname == GL_DEPTH_WRITEMASK) params[0] = ctx->depthmask; }
+const char* GetString(GLenum name) {
+  switch (name) {
+    case GL_VENDOR: return "Mozilla Gfx";
+    // Must start with "Software WebRender": webrender::Device keys its swgl
+    // code paths (native clip masks / AA, immediate uploads) on it
+    // (device/gl.rs:1645-1650, 1775-1779).
+    case GL_RENDERER: return "Software WebRender (wrhip, AMD gfx950 HIP)";
+    case GL_VERSION: return "3.2";
+    case GL_SHADING_LANGUAGE_VERSION: return "1.50";
+    default: return nullptr;
+  }
+}
+const char* GetStringi(GLenum name, GLuint index) {
+  if (name == GL_EXTENSIONS && index < sizeof(extensions) / sizeof(extensions[0])) return extensions[index];
+  return nullptr;
+}
+
+void BlendFunc(GLenum srgb, GLenum drgb, GLenum sa, GLenum da) {
+  ctx->blendfunc_srgb = srgb; ctx->blendfunc_drgb = drgb;
+  ctx->blendfunc_sa = remap_blendfunc(srgb, sa); ctx->blendfunc_da = remap_blendfunc(drgb, da);
+  ctx->blend_key = hash_blend_key(ctx);
+}
+void BlendColor(GLfloat r, GLfloat g, GLfloat b, GLfloat a) {
+  // round_pixel((Float){b, g, r, a}) -> U16 (gl.cc:1336-1339)
+  uint32_t bb = uint32_t(int(b * 255.0f + 0.5f)) & 0xFFFF, gg = uint32_t(int(g * 255.0f + 0.5f)) & 0xFFFF;
+  uint32_t rr = uint32_t(int(r * 255.0f + 0.5f)) & 0xFFFF, aa = uint32_t(int(a * 255.0f + 0.5f)) & 0xFFFF;
+  ctx->blendcolor[0] = bb | (gg << 16); ctx->blendcolor[1] = rr | (aa << 16);
+}
+void BlendEquation(GLenum mode) {
+  if (mode != ctx->blend_equation) { ctx->blend_equation = mode; ctx->blend_key = hash_blend_key(ctx); }
+}
+void DepthMask(GLboolean flag) { ctx->depthmask = flag; }
+void DepthFunc(GLenum func) { ctx->depthfunc = func; }
+void SetScissor(GLint x, GLint y, GLsizei width, GLsizei height) {
+  ctx->scissor[0] = x; ctx->scissor[1] = y; ctx->scissor[2] = x + width; ctx->scissor[3] = y + height;
+}
+void ClearColor(GLfloat r, GLfloat g, GLfloat b, GLfloat a) {
+  ctx->clearcolor[0] = r; ctx->clearcolor[1] = g; ctx->clearcolor[2] = b; ctx->clearcolor[3] = a;
+}
+void ClearDepth(GLdouble depth) { ctx->cleardepth = depth; }
+void ActiveTexture(GLenum texture) {
+  int u = int(texture - GL_TEXTURE0);
+  ctx->active_texture_unit = u < 0 ? 0 : (u > int(MAX_TEXTURE_UNITS - 1) ? int(MAX_TEXTURE_UNITS - 1) : u);
+}
+
+static inline void unlink(GLuint& binding, GLuint n) { if (binding == n) binding = 0; }
+
+void GenQueries(GLsizei n, GLuint* result) { for (int i = 0; i < n; i++) result[i] = (GLuint)ctx->queries.insert(); }
+void DeleteQuery(GLuint n) {
+  if (n && ctx->queries.erase(n)) { unlink(ctx->time_elapsed_query, n); unlink(ctx->samples_passed_query, n); }
+}
+void GenBuffers(int32_t n, GLuint* result) { for (int i = 0; i < n; i++) result[i] = (GLuint)ctx->buffers.insert(); }
+void DeleteBuffer(GLuint n) {
+  if (n && ctx->buffers.erase(n)) {
+    unlink(ctx->pixel_pack_buffer_binding, n); unlink(ctx->pixel_unpack_buffer_binding, n); unlink(ctx->array_buffer_binding, n);
+  }
+}
+void GenVertexArrays(int32_t n, GLuint* result) { for (int i = 0; i < n; i++) result[i] = (GLuint)ctx->vertex_arrays.insert(); }
+void DeleteVertexArray(GLuint n) { if (n && ctx->vertex_arrays.erase(n)) unlink(ctx->current_vertex_array, n); }
+
+GLuint CreateShader(GLenum type) { GLuint id = (GLuint)ctx->shaders.insert(); ctx->shaders[id].type = type; return id; }
+void ShaderSourceByName(GLuint shader, const GLchar* name) {
+  Shader& s = ctx->shaders[shader];
+  s.kind = WR_SH_NONE;
+  for (const ShaderInfo& info : SHADERS) if (!strcmp(info.key, name)) s.kind = info.kind;
+}
+void AttachShader(GLuint program, GLuint shader) {
+  Program& p = ctx->programs[program];
+  Shader& s = ctx->shaders[shader];
+  if (!p.info && s.kind != WR_SH_NONE)
+    for (const ShaderInfo& info : SHADERS) if (info.kind == s.kind) p.info = &info;
+}
+void DeleteShader(GLuint n) { if (n) ctx->shaders.erase(n); }
+GLuint CreateProgram(void) { return (GLuint)ctx->programs.insert(); }
+void DeleteProgram(GLuint n) {
+  if (!n) return;
+  if (ctx->current_program == n) { if (Program* p = ctx->programs.find(n)) p->deleted = true; }
+  else ctx->programs.erase(n);
+}
+void LinkProgram(GLuint program) { Program& p = ctx->programs[program]; if (p.info) p.linked = true; }
+GLint GetLinkStatus(GLuint program) { Program* p = ctx->programs.find(program); return p && p->info ? 1 : 0; }
+void BindAttribLocation(GLuint program, GLuint index, const GLchar* name) {
+  Program& p = ctx->programs[program];
+  if (!p.info) return;
+  for (int k = 0; k < 10 && p.info->attribs[k]; k++) if (!strcmp(p.info->attribs[k], name)) { p.attrib_loc[k] = index; return; }
+}
+GLint GetAttribLocation(GLuint program, const GLchar* name) {
+  Program& p = ctx->programs[program];
+  if (!p.info) return -1;
+  for (int k = 0; k < 10 && p.info->attribs[k]; k++)
+    if (!strcmp(p.info->attribs[k], name)) return p.attrib_loc[k] != NULL_ATTRIB ? p.attrib_loc[k] : -1;
+  return -1;
+}
+GLint GetUniformLocation(GLuint program, const GLchar* name) {
+  Program& p = ctx->programs[program];
+  if (!p.info) return -1;
+  if (!strcmp(name, "uTransform")) return UNIFORM_TRANSFORM;
+  for (int s = 0; s < WR_MAX_TEX; s++)
+    if (((p.info->samplers >> s) & 1) && !strcmp(SAMPLER_NAMES[s], name)) return s + 1;
+  return -1;
+}
+void Uniform1i(GLint location, GLint v0) {
+  Program* p = ctx->programs.find(ctx->current_program);
+  if (p && location >= 1 && location <= WR_MAX_TEX) p->sampler_unit[location - 1] = v0;
+}
+void Uniform4fv(GLint, GLsizei, const GLfloat*) {}
+void UniformMatrix4fv(GLint location, GLsizei, GLboolean, const GLfloat* value) {
+  Program* p = ctx->programs.find(ctx->current_program);
+  if (p && location == UNIFORM_TRANSFORM) memcpy(p->transform, value, sizeof(float) * 16);
+}
+
+void BeginQuery(GLenum target, GLuint id) {
+  ctx->get_binding(target) = id;
+  Query& q = ctx->queries[id];
+  if (target == GL_SAMPLES_PASSED) q.value = 0;
+  else if (target == GL_TIME_ELAPSED) {
+    // TIME_ELAPSED must cover the GPU work issued inside the query (renderer
+    // GpuProfiler, device/query_gl.rs:141-163): drain what came before.
+    flush_all(); wrrt::stream_sync(ctx->stream);
+    q.value = get_time_value();
+  }
+}
+void EndQuery(GLenum target) {
+  Query& q = ctx->queries[ctx->get_binding(target)];
+  if (target == GL_TIME_ELAPSED) {
+    flush_all(); wrrt::stream_sync(ctx->stream);
+    q.value = get_time_value() - q.value;
+  }
+  ctx->get_binding(target) = 0;
+}
+void GetQueryObjectui64v(GLuint id, GLenum pname, GLuint64* params) {
+  if (pname == GL_QUERY_RESULT) params[0] = ctx->queries[id].value;
+}
+
+void BindVertexArray(GLuint vao) { ctx->current_vertex_array = vao; }
+void BindTexture(GLenum target, GLuint texture) { ctx->get_binding(target) = texture; }
+void BindBuffer(GLenum target, GLuint buffer) { ctx->get_binding(target) = buffer; }
+void BindFramebuffer(GLenum target, GLuint fb) {
+  if (target == GL_FRAMEBUFFER) { ctx->read_framebuffer_binding = fb; ctx->draw_framebuffer_binding = fb; }
+  else ctx->get_binding(target) = fb;
+}
+void BindRenderbuffer(GLenum target, GLuint rb) { ctx->get_binding(target) = rb; }
+void PixelStorei(GLenum name, GLint param) { if (name == GL_UNPACK_ROW_LENGTH) ctx->unpack_row_length = param; }
+
+void TexStorage2D(GLenum target, GLint, GLenum internal_format, GLsizei width, GLsizei height) {
+  Texture& t = ctx->textures[ctx->get_binding(target)];
+  set_tex_storage(t, internal_format, width, height);
+}
+
+static void* pixel_unpack_data(const void* data) {
+  if (ctx->pixel_unpack_buffer_binding) {
+    Buffer& b = ctx->buffers[ctx->pixel_unpack_buffer_binding];
+    return b.buf ? b.buf + (size_t)data : nullptr;
+  }
+  return (void*)data;
+}
+static void* pixel_pack_data(void* data) {
+  if (ctx->pixel_pack_buffer_binding) {
+    Buffer& b = ctx->buffers[ctx->pixel_pack_buffer_binding];
+    return b.buf ? b.buf + (size_t)data : nullptr;
+  }
+  return data;
+}
+
+void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLsizei width, GLsizei height,
+                   GLenum format, GLenum ty, const void* data_) {
+  if (level != 0) return;
+  const uint8_t* data = (const uint8_t*)pixel_unpack_data(data_);
+  if (!data) return;
+  Texture& t = ctx->textures[ctx->get_binding(target)];
+  if (!t.dptr || width <= 0 || height <= 0) return;
+  if (xoffset < 0 || yoffset < 0 || xoffset + width > t.width || yoffset + height > t.height) return;
+  if (t.internal_format != internal_format_for_data(format, ty)) return;
+  sync_texture_for_write(t);
+  GLsizei row_length = ctx->unpack_row_length != 0 ? ctx->unpack_row_length : width;
+  bool conv = format_requires_conversion(format, t.internal_format);
+  size_t src_stride = (size_t)row_length * t.bpp;
+  size_t row = (size_t)width * t.bpp;
+  uint8_t* st = staging_alloc(row * height);
+  for (int y = 0; y < height; y++) {
+    const uint8_t* s = data + (size_t)y * src_stride;
+    uint8_t* d = st + (size_t)y * row;
+    if (conv) {  // GL_RGBA upload into BGRA storage: copy_bgra8_to_rgba8 (gl.cc:1649-1661)
+      for (int x = 0; x < width; x++) {
+        uint32_t p; memcpy(&p, s + 4 * x, 4);
+        uint32_t rb = p & 0x00FF00FF;
+        p = (p & 0xFF00FF00) | (rb << 16) | (rb >> 16);
+        memcpy(d + 4 * x, &p, 4);
+      }
+    } else memcpy(d, s, row);
+  }
+  wrrt::copy2d((uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, st, row, row, height, 0,
+               ctx->stream);
+  ctx->stats.h2d_bytes += row * height;
+}
+void TexImage2D(GLenum target, GLint level, GLint internal_format, GLsizei width, GLsizei height, GLint, GLenum format,
+                GLenum ty, const void* data) {
+  if (level != 0) return;
+  TexStorage2D(target, 1, internal_format, width, height);
+  TexSubImage2D(target, 0, 0, 0, width, height, format, ty, data);
+}
+void GenerateMipmap(GLenum) {}
+void SetTextureParameter(GLuint texid, GLenum pname, GLint param) {
+  Texture& t = ctx->textures[texid];
+  if (pname == GL_TEXTURE_MIN_FILTER) t.min_filter = param;
+  else if (pname == GL_TEXTURE_MAG_FILTER) t.mag_filter = param;
+}
+void TexParameteri(GLenum target, GLenum pname, GLint param) { SetTextureParameter(ctx->get_binding(target), pname, param); }
+void GenTextures(int32_t n, GLuint* result) { for (int i = 0; i < n; i++) result[i] = (GLuint)ctx->textures.insert(); }
+void DeleteTexture(GLuint n) {
+  if (!n) return;
+  if (Texture* t = ctx->textures.find(n)) {
+    free_texture_storage(*t);
+    ctx->textures.erase(n);
+    for (size_t i = 0; i < MAX_TEXTURE_UNITS; i++) {
+      unlink(ctx->texture_units[i].texture_2d_binding, n);
+      unlink(ctx->texture_units[i].texture_rectangle_binding, n);
+    }
+  }
+}
+void GenRenderbuffers(int32_t n, GLuint* result) { for (int i = 0; i < n; i++) result[i] = (GLuint)ctx->renderbuffers.insert(); }
+void DeleteRenderbuffer(GLuint n) {
+  if (!n) return;
+  if (Renderbuffer* rb = ctx->renderbuffers.find(n)) {
+    GLuint tex = rb->texture;
+    for (Framebuffer* fb : ctx->framebuffers.objects)
+      if (fb) { unlink(fb->color_attachment, tex); unlink(fb->depth_attachment, tex); }
+    DeleteTexture(tex);
+    ctx->renderbuffers.erase(n);
+    unlink(ctx->renderbuffer_binding, n);
+  }
+}
+void GenFramebuffers(int32_t n, GLuint* result) { for (int i = 0; i < n; i++) result[i] = (GLuint)ctx->framebuffers.insert(); }
+void DeleteFramebuffer(GLuint n) {
+  if (n && ctx->framebuffers.erase(n)) { unlink(ctx->read_framebuffer_binding, n); unlink(ctx->draw_framebuffer_binding, n); }
+}
+void RenderbufferStorage(GLenum target, GLenum internal_format, GLsizei width, GLsizei height) {
+  Renderbuffer& r = ctx->renderbuffers[ctx->get_binding(target)];
+  if (!r.texture) GenTextures(1, &r.texture);
+  switch (internal_format) {
+    case GL_DEPTH_COMPONENT: case GL_DEPTH_COMPONENT16: case GL_DEPTH_COMPONENT24: case GL_DEPTH_COMPONENT32:
+      internal_format = GL_DEPTH_COMPONENT24; break;
+  }
+  set_tex_storage(ctx->textures[r.texture], internal_format, width, height);
+}
+
+static int bytes_per_type(GLenum type) {
+  switch (type) { case GL_INT: case GL_FLOAT: return 4; case GL_UNSIGNED_SHORT: return 2; case GL_UNSIGNED_BYTE: return 1; default: return 0; }
+}
+void VertexAttribPointer(GLuint index, GLint size, GLenum type, GLboolean normalized, GLsizei stride, const GLvoid* offset) {
+  if (index >= NULL_ATTRIB) return;
+  VertexAttrib& va = ctx->vertex_arrays[ctx->current_vertex_array].attribs[index];
+  va.size = size * bytes_per_type(type); va.type = type; va.normalized = normalized; va.stride = stride;
+  va.offset = (GLuint)(uintptr_t)offset; va.vertex_buffer = ctx->array_buffer_binding;
+}
+void VertexAttribIPointer(GLuint index, GLint size, GLenum type, GLsizei stride, const GLvoid* offset) {
+  if (index >= NULL_ATTRIB) return;
+  VertexAttrib& va = ctx->vertex_arrays[ctx->current_vertex_array].attribs[index];
+  va.size = size * bytes_per_type(type); va.type = type; va.normalized = false; va.stride = stride;
+  va.offset = (GLuint)(uintptr_t)offset; va.vertex_buffer = ctx->array_buffer_binding;
+}
+void EnableVertexAttribArray(GLuint index) {
+  if (index >= NULL_ATTRIB) return;
+  ctx->vertex_arrays[ctx->current_vertex_array].attribs[index].enabled = true;
+}
+void VertexAttribDivisor(GLuint index, GLuint divisor) {
+  if (index >= NULL_ATTRIB || divisor > 1) return;
+  ctx->vertex_arrays[ctx->current_vertex_array].attribs[index].divisor = divisor;
+}
+void BufferData(GLenum target, GLsizeiptr size, const GLvoid* data, GLenum) {
+  Buffer& b = ctx->buffers[ctx->get_binding(target)];
+  if (size != b.size && !b.allocate(size)) out_of_memory();
+  if (data && b.buf && size <= b.size) memcpy(b.buf, data, size);
+}
+void BufferSubData(GLenum target, GLintptr offset, GLsizeiptr size, const GLvoid* data) {
+  Buffer& b = ctx->buffers[ctx->get_binding(target)];
+  if (data && b.buf && offset + size <= b.size) memcpy(&b.buf[offset], data, size);
+}
+void* MapBuffer(GLenum target, GLbitfield) { return ctx->buffers[ctx->get_binding(target)].buf; }
+void* MapBufferRange(GLenum target, GLintptr offset, GLsizeiptr length, GLbitfield) {
+  Buffer& b = ctx->buffers[ctx->get_binding(target)];
+  if (b.buf && offset >= 0 && length > 0 && offset + length <= b.size) return b.buf + offset;
+  return nullptr;
+}
+GLboolean UnmapBuffer(GLenum target) { return ctx->buffers[ctx->get_binding(target)].buf != nullptr; }
+
+void FramebufferTexture2D(GLenum target, GLenum attachment, GLenum, GLuint texture, GLint) {
+  Framebuffer& fb = ctx->framebuffers[ctx->get_binding(target)];
+  if (attachment == GL_COLOR_ATTACHMENT0) fb.color_attachment = texture;
+  else if (attachment == GL_DEPTH_ATTACHMENT) fb.depth_attachment = texture;
+}
+void FramebufferRenderbuffer(GLenum target, GLenum attachment, GLenum, GLuint renderbuffer) {
+  Framebuffer& fb = ctx->framebuffers[ctx->get_binding(target)];
+  Renderbuffer& rb = ctx->renderbuffers[renderbuffer];
+  if (attachment == GL_COLOR_ATTACHMENT0) fb.color_attachment = rb.texture;
+  else if (attachment == GL_DEPTH_ATTACHMENT) fb.depth_attachment = rb.texture;
+}
+GLenum CheckFramebufferStatus(GLenum target) {
+  Framebuffer* fb = get_framebuffer(target);
+  if (!fb || !fb->color_attachment) return GL_FRAMEBUFFER_UNSUPPORTED;
+  return GL_FRAMEBUFFER_COMPLETE;
+}
+
+void InitDefaultFramebuffer(int32_t x, int32_t y, int32_t width, int32_t height, int32_t stride, void* buf) {
+  Framebuffer& fb = ctx->framebuffers[0];
+  if (!fb.color_attachment) GenTextures(1, &fb.color_attachment);
+  Texture& colortex = ctx->textures[fb.color_attachment];
+  if (buf && stride == 0) stride = aligned_stride(4 * width);
+  set_tex_storage(colortex, GL_RGBA8, width, height, buf, stride);
+  colortex.offx = x; colortex.offy = y;
+  if (!fb.depth_attachment) GenTextures(1, &fb.depth_attachment);
+  Texture& depthtex = ctx->textures[fb.depth_attachment];
+  set_tex_storage(depthtex, GL_DEPTH_COMPONENT24, width, height);
+  depthtex.offx = x; depthtex.offy = y;
+}
+void* GetColorBuffer(GLuint fbo, GLboolean flush, int32_t* width, int32_t* height, int32_t* stride) {
+  Framebuffer* fb = ctx->framebuffers.find(fbo);
+  if (!fb || !fb->color_attachment) return nullptr;
+  Texture& t = ctx->textures[fb->color_attachment];
+  if (flush) flush_all();
+  if (width) *width = t.width;
+  if (height) *height = t.height;
+  if (!t.dptr) return nullptr;
+  download_texture(t);
+  if (stride) *stride = t.ext_buf ? t.ext_stride : t.stride;
+  return t.ext_buf ? t.ext_buf : t.hmirror;
+}
+void ResolveFramebuffer(GLuint fbo) {
+  Framebuffer* fb = ctx->framebuffers.find(fbo);
+  if (!fb || !fb->color_attachment) return;
+  Texture& t = ctx->textures[fb->color_attachment];
+  flush_all();
+  if (t.ext_buf) download_texture(t);
+}
+void SetTextureBuffer(GLuint texid, GLenum internal_format, GLsizei width, GLsizei height, GLsizei stride, void* buf,
+                      GLsizei, GLsizei) {
+  set_tex_storage(ctx->textures[texid], internal_format, width, height, buf, stride);
+}
+
+void ClearTexSubImage(GLenum texture, GLint level, GLint xoffset, GLint yoffset, GLint zoffset, GLsizei width,
+                      GLsizei height, GLsizei depth, GLenum format, GLenum type, const void* data) {
+  if (level != 0) return;
+  Texture& t = ctx->textures[texture];
+  if (width <= 0 || height <= 0 || depth <= 0) return;
+  (void)zoffset;
+  int rect[4] = {xoffset - t.offx, yoffset - t.offy, xoffset + width - t.offx, yoffset + height - t.offy};
+  if (t.internal_format == GL_DEPTH_COMPONENT24) {
+    uint32_t value = 0xFFFFFF;
+    if (format == GL_DEPTH_COMPONENT) {
+      if (type == GL_DOUBLE) value = uint32_t(*(const GLdouble*)data * 0xFFFFFF);
+      else if (type == GL_FLOAT) value = uint32_t(*(const GLfloat*)data * 0xFFFFFF);
+    }
+    // Depth is cleared through the colour target it is attached to (see Clear);
+    // a direct clear just records the uniform value (gl.cc:2405-2415).
+    bool full = rect[0] <= 0 && rect[1] <= 0 && rect[2] >= t.width && rect[3] >= t.height;
+    if (!t.depth_cleared || full) { t.depth_cleared = true; t.depth_value = value; t.depth_materialized = false; }
+    return;
+  }
+  uint32_t color = 0xFF000000;
+  if (type == GL_FLOAT) {
+    const GLfloat* f = (const GLfloat*)data;
+    float v[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    switch (format) {
+      case GL_RGBA: v[3] = f[3];
+      case GL_RGB: v[2] = f[2];
+      case GL_RG: v[1] = f[1];
+      case GL_RED: v[0] = f[0]; break;
+      default: break;
+    }
+    uint32_t c[4];
+    for (int i = 0; i < 4; i++) {  // round_pixel + CONVERT(.., U8): truncating byte conversion (gl.cc:2440)
+      c[i] = uint32_t(int(v[i] * 255.0f + 0.5f)) & 0xFF;
+    }
+    color = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+  } else if (type == GL_UNSIGNED_BYTE) {
+    const GLubyte* b = (const GLubyte*)data;
+    switch (format) {
+      case GL_RGBA: color = (color & ~0xFF000000) | (uint32_t(b[3]) << 24);
+      case GL_RGB: color = (color & ~0x00FF0000) | (uint32_t(b[2]) << 16);
+      case GL_RG: color = (color & ~0x0000FF00) | (uint32_t(b[1]) << 8);
+      case GL_RED: color = (color & ~0x000000FF) | uint32_t(b[0]); break;
+      default: break;
+    }
+  }
+  switch (t.internal_format) {
+    case GL_RGBA8:
+      record_clear(texture, true, (color & 0xFF00FF00) | ((color << 16) & 0xFF0000) | ((color >> 16) & 0xFF), false, 0, 0, rect);
+      break;
+    case GL_R8: record_clear(texture, true, color & 0xFF, false, 0, 0, rect); break;
+    default: break;  // RG8 targets are not drawn to by WebRender
+  }
+}
+void ClearTexImage(GLenum texture, GLint level, GLenum format, GLenum type, const void* data) {
+  Texture& t = ctx->textures[texture];
+  ClearTexSubImage(texture, level, t.offx, t.offy, 0, t.width, t.height, 1, format, type, data);
+}
+void Clear(GLbitfield mask) {
+  Framebuffer& fb = *get_framebuffer(GL_DRAW_FRAMEBUFFER, true);
+  bool do_depth = (mask & GL_DEPTH_BUFFER_BIT) && fb.depth_attachment;
+  uint32_t dvalue = 0;
+  if (do_depth) {
+    Texture& dt = ctx->textures[fb.depth_attachment];
+    dvalue = uint32_t(ctx->cleardepth * 0xFFFFFF);
+    // gl.cc:2405-2415: a scissored clear of an uninitialised depth buffer fills all of it
+    int r[4] = {0, 0, dt.width, dt.height};
+    if (ctx->scissortest) {
+      r[0] = std::max(0, ctx->scissor[0] - dt.offx); r[1] = std::max(0, ctx->scissor[1] - dt.offy);
+      r[2] = std::min(dt.width, ctx->scissor[2] - dt.offx); r[3] = std::min(dt.height, ctx->scissor[3] - dt.offy);
+    }
+    bool full = r[0] <= 0 && r[1] <= 0 && r[2] >= dt.width && r[3] >= dt.height;
+    if (fb.color_attachment && ctx->textures[fb.color_attachment].has_storage()) {
+      int rect[4] = {r[0], r[1], r[2], r[3]};
+      if (!dt.depth_cleared) { rect[0] = 0; rect[1] = 0; rect[2] = dt.width; rect[3] = dt.height; full = true; }
+      record_clear(fb.color_attachment, false, 0, true, fb.depth_attachment, dvalue, rect);
+    }
+    if (full) dt.depth_value = dvalue;
+    dt.depth_cleared = true;
+  }
+  if ((mask & GL_COLOR_BUFFER_BIT) && fb.color_attachment) {
+    Texture& t = ctx->textures[fb.color_attachment];
+    int x0 = t.offx, y0 = t.offy, x1 = t.offx + t.width, y1 = t.offy + t.height;
+    if (ctx->scissortest) {
+      x0 = std::max(x0, ctx->scissor[0]); y0 = std::max(y0, ctx->scissor[1]);
+      x1 = std::min(x1, ctx->scissor[2]); y1 = std::min(y1, ctx->scissor[3]);
+    }
+    ClearTexSubImage(fb.color_attachment, 0, x0, y0, 0, x1 - x0, y1 - y0, 1, GL_RGBA, GL_FLOAT, ctx->clearcolor);
+  }
+}
+void ClearColorRect(GLuint fbo, GLint xoffset, GLint yoffset, GLsizei width, GLsizei height, GLfloat r, GLfloat g,
+                    GLfloat b, GLfloat a) {
+  GLfloat color[] = {r, g, b, a};
+  Framebuffer& fb = ctx->framebuffers[fbo];
+  Texture& t = ctx->textures[fb.color_attachment];
+  int x0 = std::max(xoffset, t.offx), y0 = std::max(yoffset, t.offy);
+  int x1 = std::min(xoffset + width, t.offx + t.width), y1 = std::min(yoffset + height, t.offy + t.height);
+  ClearTexSubImage(fb.color_attachment, 0, x0, y0, 0, x1 - x0, y1 - y0, 1, GL_RGBA, GL_FLOAT, color);
+}
+void InvalidateFramebuffer(GLenum target, GLsizei num_attachments, const GLenum* attachments) {
+  Framebuffer* fb = get_framebuffer(target);
+  if (!fb || num_attachments <= 0 || !attachments) return;
+  for (GLsizei i = 0; i < num_attachments; i++) {
+    if (attachments[i] == GL_DEPTH_ATTACHMENT && fb->depth_attachment) {
+      Texture& t = ctx->textures[fb->depth_attachment];
+      t.depth_cleared = false; t.depth_materialized = false;
+    }
+  }
+}
+
+void ReadPixels(GLint x, GLint y, GLsizei width, GLsizei height, GLenum format, GLenum type, void* data_) {
+  uint8_t* data = (uint8_t*)pixel_pack_data(data_);
+  if (!data) return;
+  Framebuffer* fb = get_framebuffer(GL_READ_FRAMEBUFFER);
+  if (!fb) return;
+  Texture& t = ctx->textures[fb->color_attachment];
+  if (!t.dptr) return;
+  sync_texture_for_read(t);
+  x -= t.offx; y -= t.offy;
+  if (internal_format_for_data(format, type) != t.internal_format) return;
+  uint8_t* dest = data;
+  size_t destStride = (size_t)width * t.bpp;
+  if (y < 0) { dest += -y * destStride; height += y; y = 0; }
+  if (y + height > t.height) height = t.height - y;
+  if (x < 0) { dest += -x * t.bpp; width += x; x = 0; }
+  if (x + width > t.width) width = t.width - x;
+  if (width <= 0 || height <= 0) return;
+  size_t row = (size_t)width * t.bpp;
+  wrrt::copy2d(dest, destStride, (const uint8_t*)t.dptr + (size_t)y * t.stride + (size_t)x * t.bpp, t.stride, row, height, 1,
+               ctx->stream);
+  wrrt::stream_sync(ctx->stream);
+  ctx->stats.d2h_bytes += row * height;
+  if (format_requires_conversion(format, t.internal_format)) {
+    for (int yy = 0; yy < height; yy++) {
+      uint32_t* p = (uint32_t*)(dest + (size_t)yy * destStride);
+      for (int xx = 0; xx < width; xx++) {
+        uint32_t v; memcpy(&v, &p[xx], 4);
+        uint32_t rb = v & 0x00FF00FF;
+        v = (v & 0xFF00FF00) | (rb << 16) | (rb >> 16);
+        memcpy(&p[xx], &v, 4);
+      }
+    }
+  }
+}
+
+void CopyImageSubData(GLuint srcName, GLenum srcTarget, GLint, GLint srcX, GLint srcY, GLint, GLuint dstName,
+                      GLenum dstTarget, GLint, GLint dstX, GLint dstY, GLint, GLsizei srcWidth, GLsizei srcHeight,
+                      GLsizei) {
+  if (srcTarget == GL_RENDERBUFFER) srcName = ctx->renderbuffers[srcName].texture;
+  if (dstTarget == GL_RENDERBUFFER) dstName = ctx->renderbuffers[dstName].texture;
+  Texture& s = ctx->textures[srcName];
+  Texture& d = ctx->textures[dstName];
+  if (!s.dptr || !d.dptr || s.internal_format != d.internal_format) return;
+  if (srcX < 0 || srcY < 0 || dstX < 0 || dstY < 0 || srcX + srcWidth > s.width || srcY + srcHeight > s.height ||
+      dstX + srcWidth > d.width || dstY + srcHeight > d.height) return;
+  sync_texture_for_read(s);
+  sync_texture_for_write(d);
+  wrrt::copy2d((uint8_t*)d.dptr + (size_t)dstY * d.stride + (size_t)dstX * d.bpp, d.stride,
+               (const uint8_t*)s.dptr + (size_t)srcY * s.stride + (size_t)srcX * s.bpp, s.stride,
+               (size_t)srcWidth * s.bpp, srcHeight, 2, ctx->stream);
+}
+void CopyTexSubImage2D(GLenum target, GLint, GLint xoffset, GLint yoffset, GLint x, GLint y, GLsizei width, GLsizei height) {
+  Framebuffer* fb = get_framebuffer(GL_READ_FRAMEBUFFER);
+  if (!fb) return;
+  CopyImageSubData(fb->color_attachment, GL_TEXTURE_2D, 0, x, y, 0, ctx->get_binding(target), GL_TEXTURE_2D, 0, xoffset,
+                   yoffset, 0, width, height, 1);
+}
+void BlitFramebuffer(GLint srcX0, GLint srcY0, GLint srcX1, GLint srcY1, GLint dstX0, GLint dstY0, GLint dstX1, GLint dstY1,
+                     GLbitfield mask, GLenum) {
+  // composite.h:434-483.  Only the unscaled, unflipped copy WebRender's
+  // blit_render_target uses for same-size blits is implemented ("next": scaled).
+  if (!(mask & GL_COLOR_BUFFER_BIT)) return;
+  Framebuffer* srcfb = get_framebuffer(GL_READ_FRAMEBUFFER);
+  Framebuffer* dstfb = get_framebuffer(GL_DRAW_FRAMEBUFFER);
+  if (!srcfb || !dstfb) return;
+  if (srcX1 - srcX0 != dstX1 - dstX0 || srcY1 - srcY0 != dstY1 - dstY0 || srcX1 < srcX0 || srcY1 < srcY0) {
+    fprintf(stderr, "libwrhip: scaled/flipped BlitFramebuffer not implemented\n");
+    return;
+  }
+  Texture& s = ctx->textures[srcfb->color_attachment];
+  Texture& d = ctx->textures[dstfb->color_attachment];
+  int w = srcX1 - srcX0, h = srcY1 - srcY0;
+  int sx = srcX0 - s.offx, sy = srcY0 - s.offy, dx = dstX0 - d.offx, dy = dstY0 - d.offy;
+  // clip to both textures
+  int cx0 = std::max(std::max(0, -sx), -dx), cy0 = std::max(std::max(0, -sy), -dy);
+  int cx1 = std::min(std::min(w, s.width - sx), d.width - dx), cy1 = std::min(std::min(h, s.height - sy), d.height - dy);
+  if (ctx->scissortest) {
+    cx0 = std::max(cx0, ctx->scissor[0] - d.offx - dx); cy0 = std::max(cy0, ctx->scissor[1] - d.offy - dy);
+    cx1 = std::min(cx1, ctx->scissor[2] - d.offx - dx); cy1 = std::min(cy1, ctx->scissor[3] - d.offy - dy);
+  }
+  if (cx1 <= cx0 || cy1 <= cy0) return;
+  CopyImageSubData(srcfb->color_attachment, GL_TEXTURE_2D, 0, sx + cx0, sy + cy0, 0, dstfb->color_attachment, GL_TEXTURE_2D,
+                   0, dx + cx0, dy + cy0, 0, cx1 - cx0, cy1 - cy0, 1);
+}
+
+// ---- the hot path: record one instanced batch ------------------------------
+void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr offset, GLsizei instancecount) {
+  Context* c = ctx;
+  Program* prog = c->programs.find(c->current_program);
+  if (offset < 0 || count <= 0 || instancecount <= 0 || !prog || !prog->info) return;
+  Framebuffer& fb = *get_framebuffer(GL_DRAW_FRAMEBUFFER, true);
+  if (!fb.color_attachment) return;
+  GLuint color_id = fb.color_attachment;
+  {
+    Texture& colortex = c->textures[color_id];
+    if (!colortex.dptr) return;
+    if (colortex.internal_format != GL_RGBA8 && colortex.internal_format != GL_R8) return;
+  }
+  VertexArray& v = c->vertex_arrays[c->current_vertex_array];
+  // Only WebRender's instanced unit quad is supported: TRIANGLES, 6 x u16,
+  // indices i, i+1, i+2, i+2, i+1, i+3 (rasterize.h:1646-1659; vertex.rs:1079-1080).
+  if (mode != GL_TRIANGLES || type != GL_UNSIGNED_SHORT || count != 6) {
+    fprintf(stderr, "libwrhip: unsupported draw (mode %x type %x count %d)\n", mode, type, count);
+    return;
+  }
+  Buffer& ib = c->buffers[v.element_array_buffer_binding];
+  if (!ib.buf || (size_t)offset + 12 > ib.size) return;
+  const uint16_t* idx = (const uint16_t*)(ib.buf + offset);
+  if (!(idx[1] == idx[0] + 1 && idx[2] == idx[0] + 2 && idx[5] == idx[0] + 3)) {
+    fprintf(stderr, "libwrhip: unsupported index pattern\n");
+    return;
+  }
+  const ShaderInfo* info = prog->info;
+  WrDrawDesc d;
+  memset(&d, 0, sizeof(d));
+  d.shader = info->kind;
+  d.count = instancecount;
+  // per-vertex aPosition of the 4 quad lanes 0,1,3,2 (load_attrib, gl.cc:1031-1039)
+  {
+    int loc = prog->attrib_loc[0];
+    VertexAttrib& va = v.attribs[loc];
+    Buffer& vb = c->buffers[va.vertex_buffer];
+    static const int lane_vertex[4] = {0, 1, 3, 2};
+    for (int n = 0; n < 4; n++) {
+      float xy[2] = {0.f, 0.f};
+      if (loc != NULL_ATTRIB && va.enabled && vb.buf) {
+        const uint8_t* src = vb.buf + (size_t)va.stride * (idx[0] + lane_vertex[n]) + va.offset;
+        int comps = 2;
+        for (int k = 0; k < comps; k++) {
+          if (va.type == GL_UNSIGNED_BYTE) {
+            if ((size_t)k < va.size) xy[k] = va.normalized ? float(src[k]) * (1.0f / 255.0f) : float(src[k]);
+          } else if (va.type == GL_UNSIGNED_SHORT) {
+            if ((size_t)k * 2 < va.size) { uint16_t u; memcpy(&u, src + 2 * k, 2); xy[k] = va.normalized ? float(u) * (1.0f / 65535.0f) : float(u); }
+          } else if (va.type == GL_FLOAT) {
+            if ((size_t)k * 4 < va.size) memcpy(&xy[k], src + 4 * k, 4);
+          }
+        }
+      }
+      d.quad[2 * n] = xy[0]; d.quad[2 * n + 1] = xy[1];
+    }
+  }
+  // instance attributes: all must come from one interleaved instance buffer
+  GLuint inst_buf = 0; int inst_stride = 0;
+  for (int k = 0; k < 8; k++) { d.attr_off[k] = -1; d.attr_bytes[k] = 0; }
+  for (int k = 1; k < 10 && info->attribs[k]; k++) {
+    int loc = prog->attrib_loc[k];
+    if (loc == NULL_ATTRIB) continue;
+    VertexAttrib& va = v.attribs[loc];
+    if (!va.enabled || va.divisor != 1) continue;
+    if (va.type != GL_INT && va.type != GL_FLOAT) { fprintf(stderr, "libwrhip: unsupported instance attribute type %x\n", va.type); continue; }
+    if (!inst_buf) { inst_buf = va.vertex_buffer; inst_stride = va.stride; }
+    if (va.vertex_buffer != inst_buf || va.stride != inst_stride) { fprintf(stderr, "libwrhip: split instance buffers unsupported\n"); continue; }
+    d.attr_off[k - 1] = va.offset; d.attr_bytes[k - 1] = (int)va.size;
+  }
+  Buffer* instb = inst_buf ? c->buffers.find(inst_buf) : nullptr;
+  size_t need = (size_t)inst_stride * instancecount;
+  if (!instb || !instb->buf || need > instb->size) {
+    if (inst_buf) { fprintf(stderr, "libwrhip: instance buffer too small\n"); return; }
+  }
+  // textures sampled by this program: a pending target that gets sampled must be rendered first
+  for (int s = 0; s < WR_MAX_TEX; s++) {
+    if (!((info->samplers >> s) & 1)) continue;
+    GLuint tid = c->texture_units[prog->sampler_unit[s] & 15].texture_2d_binding;
+    Texture* t = tid ? c->textures.find(tid) : nullptr;
+    if (!t || !t->dptr || tid == color_id) continue;   // null sampler
+    if (t->pending_write) flush_except(color_id);
+  }
+  int wi = find_or_add_work(color_id);   // may flush (target sampled by pending draws)
+  Texture& colortex = c->textures[color_id];
+  for (int s = 0; s < WR_MAX_TEX; s++) {
+    if (!((info->samplers >> s) & 1)) continue;
+    GLuint tid = c->texture_units[prog->sampler_unit[s] & 15].texture_2d_binding;
+    Texture* t = tid ? c->textures.find(tid) : nullptr;
+    if (!t || !t->dptr || tid == color_id) continue;
+    WrTexDesc& td = d.tex[s];
+    td.ptr = t->dptr; td.width = t->width; td.height = t->height;
+    td.stride = t->bpp >= 4 ? t->stride / 4 : (t->bpp == 2 ? t->stride / 2 : t->stride);
+    td.format = (int16_t)wr_format(t->internal_format);
+    td.linear = (t->mag_filter == GL_LINEAR || t->mag_filter == GL_LINEAR_MIPMAP_LINEAR || t->mag_filter == GL_LINEAR_MIPMAP_NEAREST) && t->width >= 2;
+    mark_ref(tid, *t, false);
+    std::vector<GLuint>& reads = c->work[wi].reads;
+    if (std::find(reads.begin(), reads.end(), tid) == reads.end()) reads.push_back(tid);
+  }
+  d.target = wi;
+  d.blend = c->blend ? c->blend_key : WR_BLEND_NONE;
+  if (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC || d.blend == WR_BLEND_CONST_COLOR ||
+      d.blend == WR_BLEND_MIN || d.blend == WR_BLEND_MAX) {
+    fprintf(stderr, "libwrhip: blend mode not implemented yet (key %d)\n", d.blend);
+  }
+  d.flags = 0;
+  Texture* depthtex = (c->depthtest && fb.depth_attachment) ? c->textures.find(fb.depth_attachment) : nullptr;
+  if (depthtex && depthtex->internal_format == GL_DEPTH_COMPONENT24 && depthtex->depth_cleared) {
+    d.flags |= WR_DF_DEPTH_TEST;
+    if (c->depthmask) d.flags |= WR_DF_DEPTH_WRITE;
+    if (c->depthfunc == GL_LESS) d.flags |= WR_DF_DEPTH_LESS;
+    c->work[wi].depth_tex = fb.depth_attachment;
+  }
+  apply_scissor(colortex, d.clip);
+  d.vp_origin[0] = float(c->viewport[0] - colortex.offx); d.vp_origin[1] = float(c->viewport[1] - colortex.offy);
+  d.vp_size[0] = float(c->viewport[2] - c->viewport[0]); d.vp_size[1] = float(c->viewport[3] - c->viewport[1]);
+  memcpy(d.transform, prog->transform, sizeof(d.transform));
+  d.blend_color[0] = c->blendcolor[0]; d.blend_color[1] = c->blendcolor[1];
+  // snapshot the instance bytes (the caller may overwrite the VBO right after)
+  TargetWork& w = c->work[wi];
+  size_t pos = (w.inst.size() + 15) & ~size_t(15);
+  w.inst.resize(pos + need);
+  if (need) memcpy(w.inst.data() + pos, instb->buf, need);
+  d.inst_offset = pos; d.inst_stride = inst_stride;
+#ifdef WRHIP_HOSTSIM
+  if (getenv("WRHIP_DEBUG") && need >= 16) { const float* f = (const float*)(w.inst.data() + pos); fprintf(stderr, "record: sh %d buf %u need %zu first %g %g %g %g\n", d.shader, inst_buf, need, f[0], f[1], f[2], f[3]); }
+#endif
+  w.draws.push_back(d);
+  w.prims += instancecount;
+}
+
+void Finish(void) {
+  flush_all();
+  wrrt::stream_sync(ctx->stream);
+  // externally backed default framebuffer: make the result visible to the host
+  Framebuffer* fb = ctx->framebuffers.find(0);
+  if (fb && fb->color_attachment) {
+    Texture& t = ctx->textures[fb->color_attachment];
+    if (t.ext_buf) download_texture(t);
+  }
+}
+
+void MakeCurrent(WrhipContext* c) { ctx = (Context*)c; }
+WrhipContext* CreateContext(void) {
+  ensure_runtime();
+  return (WrhipContext*)new Context();
+}
+void ReferenceContext(WrhipContext* c) { if (c) ++((Context*)c)->references; }
+void DestroyContext(WrhipContext* c_) {
+  Context* c = (Context*)c_;
+  if (!c) return;
+  if (--c->references > 0) return;
+  if (ctx == c) { delete c; ctx = nullptr; }
+  else delete c;
+}
+size_t ReportMemory(WrhipContext* c_, size_t (*)(const void*)) {
+  Context* c = (Context*)c_;
+  size_t size = 0;
+  if (c) for (Texture* t : c->textures.objects) if (t && t->dptr && !t->ext_buf) size += t->dsize;
+  return size;
+}
+
+// ---- locking / compositor extras (composite.h:485-593) ----------------------
+// LockedTexture* is the Texture itself; locking pins a host mirror.
+LockedTexture* LockFramebuffer(GLuint fbo) {
+  Framebuffer* fb = ctx->framebuffers.find(fbo);
+  if (!fb || !fb->color_attachment) return nullptr;
+  Texture& t = ctx->textures[fb->color_attachment];
+  flush_all(); download_texture(t);
+  t.locked++;
+  return (LockedTexture*)&t;
+}
+LockedTexture* LockTexture(GLuint tex) {
+  Texture* t = ctx->textures.find(tex);
+  if (!t || !t->dptr) return nullptr;
+  flush_all(); download_texture(*t);
+  t->locked++;
+  return (LockedTexture*)t;
+}
+void LockResource(LockedTexture* r) { if (r) ((Texture*)r)->locked++; }
+void UnlockResource(LockedTexture* r) { if (r && ((Texture*)r)->locked > 0) ((Texture*)r)->locked--; }
+void* GetResourceBuffer(LockedTexture* r, int32_t* width, int32_t* height, int32_t* stride) {
+  Texture* t = (Texture*)r;
+  if (!t) return nullptr;
+  if (width) *width = t->width;
+  if (height) *height = t->height;
+  if (stride) *stride = t->ext_buf ? t->ext_stride : t->stride;
+  return t->ext_buf ? t->ext_buf : t->hmirror;
+}
+void Composite(LockedTexture*, LockedTexture*, GLint, GLint, GLsizei, GLsizei, GLint, GLint, GLsizei, GLsizei, GLboolean,
+               GLboolean, GLboolean, GLenum, GLint, GLint, GLsizei, GLsizei) {
+  // Gecko's software-compositor entry point; wrench composites through the
+  // `composite` shader instead.  Out of scope, fails loudly.
+  fprintf(stderr, "libwrhip: Composite() is not implemented (out of scope)\n");
+  abort();
+}
+void CompositeYUV(LockedTexture*, LockedTexture*, LockedTexture*, LockedTexture*, YuvRangedColorSpace, GLuint, GLint, GLint,
+                  GLsizei, GLsizei, GLint, GLint, GLsizei, GLsizei, GLboolean, GLboolean, GLint, GLint, GLsizei, GLsizei) {
+  fprintf(stderr, "libwrhip: CompositeYUV() is not implemented (out of scope)\n");
+  abort();
+}
+
+// ---- libwrhip additions ------------------------------------------------------
+void WrhipGetStats(WrhipStats* out) { if (ctx && out) *out = ctx->stats; }
+void WrhipResetStats(void) { if (ctx) memset(&ctx->stats, 0, sizeof(ctx->stats)); }
+void WrhipSetProfiling(int enabled) { if (ctx) ctx->profiling = enabled != 0; }
+void WrhipSetShard(int rank, int world) { if (ctx) { flush_all(); ctx->shard_rank = rank; ctx->shard_world = world < 1 ? 1 : world; } }
+void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height, int32_t* stride) {
+  Texture* t = ctx ? ctx->textures.find(tex) : nullptr;
+  if (!t) return nullptr;
+  sync_texture_for_read(*t);
+  if (width) *width = t->width;
+  if (height) *height = t->height;
+  if (stride) *stride = t->stride;
+  return t->dptr;
+}
+GLuint WrhipGetFramebufferTexture(GLuint fbo) {
+  Framebuffer* fb = ctx ? ctx->framebuffers.find(fbo) : nullptr;
+  return fb ? fb->color_attachment : 0;
+}
+const char* WrhipDeviceName(void) { return g_rt_ok ? g_device_name : nullptr; }
+
+}  // extern "C"

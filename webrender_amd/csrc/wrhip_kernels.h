@@ -1,0 +1,948 @@
+// wrhip_kernels.h -- gfx950 kernels of the WebRender draw backend.
+//
+// Three kernels per flush (see wrhip_types.h for the data flow):
+//   wr_vertex_kernel   one thread per instance; restates the vertex stage of
+//                      the bound WebRender shader + swgl's draw_quad setup
+//                      (swgl/src/rasterize.h:1549-1633) in strict fp32
+//                      (compiled with -ffp-contract=off: same op order and
+//                      rounding as the reference's gcc build)
+//   wr_bin_kernel      one thread per prim; ordered per-bin bitmasks
+//   wr_raster_kernel   one 256-thread workgroup per 64x64 bin; each lane owns
+//                      4x4 pixels in registers, prims are applied in
+//                      submission order with swgl's integer blend math
+//                      (swgl/src/blend.h:416-735), pixels are read at most
+//                      once and written once
+//
+// No MFMA: this is integer pixel work bound by HBM traffic / VALU issue.
+#pragma once
+#include "wrhip_types.h"
+
+#ifndef WR_DEVICE
+#define WR_DEVICE __device__ __forceinline__
+#endif
+
+// ---------------------------------------------------------------------------
+// small vector helpers
+struct wf2 { float x, y; };
+struct wf4 { float x, y, z, w; };
+struct wi4 { int x, y, z, w; };
+
+WR_DEVICE float wr_min(float a, float b) { return a < b ? a : b; }   // glsl.h:162
+WR_DEVICE float wr_max(float a, float b) { return a > b ? a : b; }   // glsl.h:163
+WR_DEVICE float wr_clamp(float a, float lo, float hi) { return wr_min(wr_max(a, lo), hi); }
+WR_DEVICE int wr_imin(int a, int b) { return a < b ? a : b; }
+WR_DEVICE int wr_imax(int a, int b) { return a > b ? a : b; }
+WR_DEVICE int wr_iclamp(int a, int lo, int hi) { return wr_imin(wr_imax(a, lo), hi); }
+
+// clampCoord, texture.h:70-72
+WR_DEVICE int wr_clamp_coord(int c, int limit, int base = 0) { return wr_imin(wr_imax(c, base), limit - 1); }
+
+// texelFetch(sampler2D RGBA32F, ivec2_scalar, 0), texture.h:283-292
+WR_DEVICE wf4 wr_fetch_f(const WrTexDesc& t, int x, int y) {
+  wf4 r = {0.f, 0.f, 0.f, 0.f};
+  if (!t.ptr) return r;  // null_sampler: 1x1 transparent black (gl.cc:901-912)
+  x = wr_clamp_coord(x, t.width);
+  y = wr_clamp_coord(y, t.height);
+  if (t.format == WR_FMT_RGBA32F) {
+    const float* p = (const float*)t.ptr + (size_t)x * 4 + (size_t)y * t.stride;
+    r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+  } else {  // RGBA8: pixel_to_vec4, texture.h:101-105
+    uint32_t p = ((const uint32_t*)t.ptr)[(size_t)x + (size_t)y * t.stride];
+    r.x = float((p >> 16) & 0xFF) * (1.0f / 255.0f);
+    r.y = float((p >> 8) & 0xFF) * (1.0f / 255.0f);
+    r.z = float(p & 0xFF) * (1.0f / 255.0f);
+    r.w = float(p >> 24) * (1.0f / 255.0f);
+  }
+  return r;
+}
+
+WR_DEVICE wi4 wr_fetch_i(const WrTexDesc& t, int x, int y) {  // texture.h:338-343
+  wi4 r = {0, 0, 0, 0};
+  if (!t.ptr) return r;
+  x = wr_clamp_coord(x, t.width);
+  y = wr_clamp_coord(y, t.height);
+  const int* p = (const int*)t.ptr + (size_t)x * 4 + (size_t)y * t.stride;
+  r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+  return r;
+}
+
+// get_fetch_uv, shared.glsl:77 ; get_gpu_cache_uv gpu_cache.glsl:16
+WR_DEVICE void wr_fetch_uv(int i, unsigned vpi, int& u, int& v) {
+  u = int(vpi * (unsigned(i) % (1024u / vpi)));
+  v = int(unsigned(i) / (1024u / vpi));
+}
+
+struct WrMat4 { wf4 c[4]; };
+
+// mat4_scalar * vec4, glsl.h:2582-2598 (left-to-right sums, no contraction)
+WR_DEVICE wf4 wr_mul(const WrMat4& m, wf4 v) {
+  wf4 u;
+  u.x = m.c[0].x * v.x + m.c[1].x * v.y + m.c[2].x * v.z + m.c[3].x * v.w;
+  u.y = m.c[0].y * v.x + m.c[1].y * v.y + m.c[2].y * v.z + m.c[3].y * v.w;
+  u.z = m.c[0].z * v.x + m.c[1].z * v.y + m.c[2].z * v.z + m.c[3].z * v.w;
+  u.w = m.c[0].w * v.x + m.c[1].w * v.y + m.c[2].w * v.z + m.c[3].w * v.w;
+  return u;
+}
+
+struct WrTransform { WrMat4 m, inv_m; bool axis_aligned; };
+
+// fetch_transform, transform.glsl:22-46
+WR_DEVICE WrTransform wr_fetch_transform(const WrDrawDesc& d, int id) {
+  WrTransform t;
+  t.axis_aligned = (id >> 23) == 0;
+  int index = id & 0x007fffff;
+  int u, v;
+  wr_fetch_uv(index, 8u, u, v);
+  for (int k = 0; k < 4; k++) {
+    t.m.c[k] = wr_fetch_f(d.tex[WR_S_TRANSFORMS], u + k, v);
+    t.inv_m.c[k] = wr_fetch_f(d.tex[WR_S_TRANSFORMS], u + 4 + k, v);
+  }
+  return t;
+}
+
+struct WrTask { wf2 p0, p1; float dps; wf2 origin; };
+
+// fetch_render_task_data / fetch_picture_task, render_task.glsl:17-79
+WR_DEVICE WrTask wr_fetch_task(const WrDrawDesc& d, int address) {
+  int u, v;
+  wr_fetch_uv(address, 2u, u, v);
+  wf4 t0 = wr_fetch_f(d.tex[WR_S_RENDER_TASKS], u, v);
+  wf4 t1 = wr_fetch_f(d.tex[WR_S_RENDER_TASKS], u + 1, v);
+  WrTask t;
+  t.p0 = {t0.x, t0.y}; t.p1 = {t0.z, t0.w};
+  t.dps = t1.x; t.origin = {t1.y, t1.z};
+  return t;
+}
+
+// instance attribute loads (load_flat_attrib, gl.cc:1044-1062): copies
+// min(sizeof(T), va.size) bytes, the rest is zero.
+template <typename T>
+WR_DEVICE T wr_load_attr(const WrDrawDesc& d, const uint8_t* arena, int instance, int k) {
+  const int n = int(sizeof(T) / 4);
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (d.attr_off[k] >= 0) {
+    const uint8_t* src = arena + d.inst_offset + (size_t)d.inst_stride * instance + d.attr_off[k];
+    int words = d.attr_bytes[k] / 4;
+    for (int i = 0; i < n; i++)
+      if (i < words) __builtin_memcpy(&w[i], src + 4 * i, 4);
+  }
+  T out;
+  __builtin_memcpy(&out, w, sizeof(T));
+  return out;
+}
+
+// round_pixel (portable path): cast(v * 255 + 0.5), glsl.h:732-744
+WR_DEVICE int wr_round_pixel(float v) { return int(v * 255.0f + 0.5f); }
+
+// pack_pixels_RGBA8(vec4_scalar) -> WideRGBA8 lanes (b,g,r,a) as u16, then the
+// value is what later gets `pack`ed; we keep the u16 quadruple (blend.h:41-45,
+// packRGBA8 portable: CONVERT i32 -> u16 wraps).
+WR_DEVICE void wr_pack_color(wf4 c, uint32_t out[2]) {
+  uint32_t b = uint32_t(wr_round_pixel(c.z)) & 0xFFFF;
+  uint32_t g = uint32_t(wr_round_pixel(c.y)) & 0xFFFF;
+  uint32_t r = uint32_t(wr_round_pixel(c.x)) & 0xFFFF;
+  uint32_t a = uint32_t(wr_round_pixel(c.w)) & 0xFFFF;
+  out[0] = b | (g << 16);
+  out[1] = r | (a << 16);
+}
+
+// ---------------------------------------------------------------------------
+// Vertex stage outputs before draw_quad
+struct WrVsOut {
+  float px[4], py[4], pz[4], pw[4];  // gl_Position per SIMD lane (lane order 0,1,3,2)
+  int kind;            // WrPrimKind
+  wf4 color;           // flat colour (solid) / modulation colour (textured)
+  int has_color;       // textured: colour != NoColor
+  float u[4], v[4];    // varying uv per lane
+  wf4 uv_bounds;
+  int tex_slot;
+  int aa_edges;        // swgl_antiAlias mask
+  int has_mask;        // swgl_clipMask set
+  int tail_clamp;      // fragment main(): clamps uv to uv_bounds
+  int tail_modulate;   // fragment main(): multiplies texel by colour
+};
+
+// ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
+WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+  wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
+  int prim_address_i = aData.x, prim_address_f = aData.y;
+  int quad_flags = (aData.z >> 24) & 0xff;
+  int edge_flags = (aData.z >> 16) & 0xff;
+  int part_index = (aData.z >> 8) & 0xff;
+  int segment_index = aData.z & 0xff;
+  int picture_task_address = aData.w;
+
+  int hu = int(unsigned(prim_address_i) % 1024u), hv = int(unsigned(prim_address_i) / 1024u);
+  wi4 header = wr_fetch_i(d.tex[WR_S_GPU_BUFFER_I], hu, hv);
+  int transform_id = header.x, z_id = header.y;
+  WrTransform transform = wr_fetch_transform(d, transform_id);
+  WrTask task = wr_fetch_task(d, picture_task_address);
+
+  int fu = int(unsigned(prim_address_f) % 1024u), fv = int(unsigned(prim_address_f) / 1024u);
+  const WrTexDesc& gbf = d.tex[WR_S_GPU_BUFFER_F];
+  wf4 t0 = wr_fetch_f(gbf, fu, fv), t1 = wr_fetch_f(gbf, fu + 1, fv), t2 = wr_fetch_f(gbf, fu + 2, fv);
+  wf4 pso = wr_fetch_f(gbf, fu + 3, fv), prim_color = wr_fetch_f(gbf, fu + 4, fv);
+  float z = float(z_id);
+
+  wf4 seg_rect, seg_uv;
+  if (segment_index == 0xff) { seg_rect = t0; seg_uv = t2; }
+  else {
+    int base = prim_address_f + 5 + segment_index * 2;
+    int su = int(unsigned(base) % 1024u), sv = int(unsigned(base) / 1024u);
+    seg_rect = wr_fetch_f(gbf, su, sv);
+    seg_uv = wr_fetch_f(gbf, su + 1, sv);
+  }
+  // local_coverage_rect
+  float l0x = wr_max(seg_rect.x, t1.x), l0y = wr_max(seg_rect.y, t1.y);
+  float l1x = wr_min(seg_rect.z, t1.z), l1y = wr_min(seg_rect.w, t1.w);
+  l1x = wr_max(l0x, l1x); l1y = wr_max(l0y, l1y);
+  int aa = 0;
+  switch (part_index) {
+    case 1: l1x = l0x + 2.0f; aa = 1; break;
+    case 2: l0x = l0x + 2.0f; l1x = l1x - 2.0f; l1y = l0y + 2.0f; aa = 2; break;
+    case 3: l0x = l1x - 2.0f; aa = 4; break;
+    case 4: l0x = l0x + 2.0f; l1x = l1x - 2.0f; l0y = l1y - 2.0f; aa = 8; break;
+    case 0:
+      l0x += (edge_flags & 1) ? 2.0f : 0.0f;
+      l1x -= (edge_flags & 4) ? 2.0f : 0.0f;
+      l0y += (edge_flags & 2) ? 2.0f : 0.0f;
+      l1y -= (edge_flags & 8) ? 2.0f : 0.0f;
+      break;
+    default: aa = edge_flags; break;
+  }
+  o.aa_edges = aa;
+  o.has_mask = 0;
+  float dps = task.dps;
+  if (quad_flags & 4) dps = 1.0f;
+  float fox = -task.origin.x + task.p0.x, foy = -task.origin.y + task.p0.y;
+
+  // pattern transform of the segment rect (scale_offset_map_rect)
+  float sr0x = seg_rect.x * pso.x + pso.z, sr0y = seg_rect.y * pso.y + pso.w;
+  float sr1x = seg_rect.z * pso.x + pso.z, sr1y = seg_rect.w * pso.y + pso.w;
+  bool textured = (seg_uv.x != seg_uv.z) || (seg_uv.y != seg_uv.w);
+  float tsx = 1.f, tsy = 1.f;
+  if (textured) {
+    tsx = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].width : 1);
+    tsy = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].height : 1);
+  }
+  for (int n = 0; n < 4; n++) {
+    float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    // mix(p0, p1, aPosition) = (p1 - p0) * a + p0
+    float lx = (l1x - l0x) * ax + l0x, ly = (l1y - l0y) * ay + l0y;
+    wf4 world = wr_mul(transform.m, wf4{lx, ly, 0.0f, 1.0f});
+    float dx = world.x * dps, dy = world.y * dps;
+    float vlx = lx, vly = ly;
+    if (quad_flags & 2) {  // QF_APPLY_DEVICE_CLIP
+      float c1x = task.origin.x + task.p1.x - task.p0.x, c1y = task.origin.y + task.p1.y - task.p0.y;
+      dx = wr_clamp(dx, task.origin.x, c1x);
+      dy = wr_clamp(dy, task.origin.y, c1y);
+      wf4 lp = wr_mul(transform.inv_m, wf4{dx / dps, dy / dps, 0.0f, 1.0f});
+      vlx = lp.x; vly = lp.y;
+    }
+    wf4 gp = wr_mul(*(const WrMat4*)d.transform,
+                    wf4{dx + fox * world.w, dy + foy * world.w, z * world.w, world.w});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+    if (textured) {
+      float ilx = vlx * pso.x + pso.z, ily = vly * pso.y + pso.w;
+      float fx = (ilx - sr0x) / (sr1x - sr0x), fy = (ily - sr0y) / (sr1y - sr0y);
+      float uvx = (seg_uv.z - seg_uv.x) * fx + seg_uv.x, uvy = (seg_uv.w - seg_uv.y) * fy + seg_uv.y;
+      o.u[n] = uvx / tsx; o.v[n] = uvy / tsy;
+    } else { o.u[n] = 0.f; o.v[n] = 0.f; }
+  }
+  if (textured) {
+    o.kind = (quad_flags & 16) ? WR_PK_UNSUPPORTED : WR_PK_TEX_RGBA8;
+    o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    o.has_color = 1;   // swgl_commitTextureLinearColorRGBA8(..., v_color)
+    o.tail_clamp = 1; o.tail_modulate = 1;
+    o.uv_bounds = wf4{(seg_uv.x + 0.5f) / tsx, (seg_uv.y + 0.5f) / tsy, (seg_uv.z - 0.5f) / tsx, (seg_uv.w - 0.5f) / tsy};
+    o.tex_slot = WR_S_COLOR0;
+  } else {
+    o.kind = WR_PK_SOLID;
+    o.color = prim_color;
+    o.has_color = 0;
+  }
+}
+
+// brush.glsl:95-222 + prim_shared.glsl:54-200 + brush_solid.glsl:22-40
+WR_DEVICE void wr_vs_brush_solid(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+  wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
+  int prim_header_address = aData.x, clip_address = aData.y;
+  int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
+  // fetch_prim_header
+  int u, v;
+  wr_fetch_uv(prim_header_address, 2u, u, v);
+  wf4 local_rect = wr_fetch_f(d.tex[WR_S_PRIM_HEADERS_F], u, v);
+  wf4 local_clip = wr_fetch_f(d.tex[WR_S_PRIM_HEADERS_F], u + 1, v);
+  wi4 data0 = wr_fetch_i(d.tex[WR_S_PRIM_HEADERS_I], u, v);
+  wi4 data1 = wr_fetch_i(d.tex[WR_S_PRIM_HEADERS_I], u + 1, v);
+  float z = float(data0.x);
+  int specific = data0.y, transform_id = data0.z, task_address = data0.w;
+  WrTransform transform = wr_fetch_transform(d, transform_id);
+  WrTask task = wr_fetch_task(d, task_address);
+  // fetch_clip_area
+  wf2 ca_p0 = {0.f, 0.f}, ca_p1 = {0.f, 0.f}, ca_origin = {0.f, 0.f};
+  if (clip_address < 0x7FFFFFFF) {
+    WrTask ct = wr_fetch_task(d, clip_address);
+    ca_p0 = ct.p0; ca_p1 = ct.p1; ca_origin = ct.origin;
+  }
+  int edge_flags = (flags >> 12) & 0xf, brush_flags = flags & 0xfff;
+  wf4 seg = local_rect;
+  if (segment_index != 0xffff) {
+    int sa = specific + 1 /*VECS_PER_SPECIFIC_BRUSH*/ + segment_index * 2;
+    wf4 i0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(sa) % 1024u), int(unsigned(sa) / 1024u));
+    seg = wf4{i0.x + local_rect.x, i0.y + local_rect.y, i0.z + local_rect.x, i0.w + local_rect.y};
+  }
+  wf4 adj = seg;
+  int aa = 0;
+  bool antialiased = !transform.axis_aligned || (brush_flags & 1024);
+  if (antialiased) {
+    aa = edge_flags | (local_clip.x > seg.x ? 1 : 0) | (local_clip.y > seg.y ? 2 : 0) |
+         (local_clip.z < seg.z ? 4 : 0) | (local_clip.w < seg.w ? 8 : 0);
+    adj.x = wr_clamp(seg.x, local_clip.x, local_clip.z); adj.y = wr_clamp(seg.y, local_clip.y, local_clip.w);
+    adj.z = wr_clamp(seg.z, local_clip.x, local_clip.z); adj.w = wr_clamp(seg.w, local_clip.y, local_clip.w);
+    local_clip = wf4{-1.0e16f, -1.0e16f, 1.0e16f, 1.0e16f};
+  }
+  o.aa_edges = aa;
+  // write_clip -> swgl_clipMask: enabled iff bb_size != 0 (swgl_ext.h:1867-1876)
+  o.has_mask = ((ca_p1.x - ca_p0.x) != 0.0f || (ca_p1.y - ca_p0.y) != 0.0f) ? 1 : 0;
+  float fox = -task.origin.x + task.p0.x, foy = -task.origin.y + task.p0.y;
+  for (int n = 0; n < 4; n++) {
+    float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    float lx = (adj.z - adj.x) * ax + adj.x, ly = (adj.w - adj.y) * ay + adj.y;
+    lx = wr_clamp(lx, local_clip.x, local_clip.z); ly = wr_clamp(ly, local_clip.y, local_clip.w);
+    wf4 world = wr_mul(transform.m, wf4{lx, ly, 0.0f, 1.0f});
+    float dx = world.x * task.dps, dy = world.y * task.dps;
+    wf4 gp = wr_mul(*(const WrMat4*)d.transform,
+                    wf4{dx + fox * world.w, dy + foy * world.w, z * world.w, world.w});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+    o.u[n] = 0.f; o.v[n] = 0.f;
+  }
+  // brush_vs (brush_solid.glsl:24-40)
+  wf4 color = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(specific) % 1024u), int(unsigned(specific) / 1024u));
+  float opacity = float(data1.x) / 65535.0f;
+  o.color = wf4{color.x * opacity, color.y * opacity, color.z * opacity, color.w * opacity};
+  o.kind = WR_PK_SOLID;
+  o.has_color = 0;
+}
+
+// composite.glsl:73-159
+WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int inst, bool fast, WrVsOut& o) {
+  wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
+  wf4 aClip = wr_load_attr<wf4>(d, arena, inst, 1);
+  wf4 aColor = wr_load_attr<wf4>(d, arena, inst, 2);
+  wf4 aParams = wr_load_attr<wf4>(d, arena, inst, 3);
+  wf4 aUv = wr_load_attr<wf4>(d, arena, inst, 4);
+  wf2 aFlip = wr_load_attr<wf2>(d, arena, inst, 5);
+  // mix(aDeviceRect.xyzw, aDeviceRect.zwxy, aFlip.xyxy)
+  wf4 dr;
+  dr.x = (aDeviceRect.z - aDeviceRect.x) * aFlip.x + aDeviceRect.x;
+  dr.y = (aDeviceRect.w - aDeviceRect.y) * aFlip.y + aDeviceRect.y;
+  dr.z = (aDeviceRect.x - aDeviceRect.z) * aFlip.x + aDeviceRect.z;
+  dr.w = (aDeviceRect.y - aDeviceRect.w) * aFlip.y + aDeviceRect.w;
+  wf4 bounds = {wr_min(aUv.x, aUv.z), wr_min(aUv.y, aUv.w), wr_max(aUv.x, aUv.z), wr_max(aUv.y, aUv.w)};
+  bool unnorm = int(aParams.y) == 1;
+#ifdef WRHIP_HOSTSIM
+  if (getenv("WRHIP_DEBUG_VS")) fprintf(stderr, "   comp: rect %g %g %g %g clip %g %g %g %g flip %g %g dr %g %g %g %g\n", aDeviceRect.x, aDeviceRect.y, aDeviceRect.z, aDeviceRect.w, aClip.x, aClip.y, aClip.z, aClip.w, aFlip.x, aFlip.y, dr.x, dr.y, dr.z, dr.w);
+#endif
+  float tsx = 1.f, tsy = 1.f;
+  if (unnorm) {
+    tsx = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].width : 1);
+    tsy = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].height : 1);
+    bounds = wf4{(bounds.x + 0.5f) / tsx, (bounds.y + 0.5f) / tsy, (bounds.z + -0.5f) / tsx, (bounds.w + -0.5f) / tsy};
+  }
+  for (int n = 0; n < 4; n++) {
+    float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    float wx = (dr.z - dr.x) * ax + dr.x, wy = (dr.w - dr.y) * ay + dr.y;
+    float cx = wr_clamp(wx, aClip.x, aClip.z), cy = wr_clamp(wy, aClip.y, aClip.w);
+    float ux = (cx - dr.x) / (dr.z - dr.x), uy = (cy - dr.y) / (dr.w - dr.y);
+    ux = (aUv.z - aUv.x) * ux + aUv.x; uy = (aUv.w - aUv.y) * uy + aUv.y;
+    if (unnorm) { ux = ux / tsx; uy = uy / tsy; }
+    o.u[n] = ux; o.v[n] = uy;
+    wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{cx, cy, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.kind = WR_PK_TEX_RGBA8;
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0;
+  if (fast) {
+    o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    o.has_color = 0;
+    o.tail_clamp = 0; o.tail_modulate = 0;
+    o.uv_bounds = wf4{0.f, 0.f, 1.f, 1.f};
+  } else {
+    o.color = aColor;
+    o.tail_clamp = 1; o.tail_modulate = 1;
+    // swgl_drawSpanRGBA8: colour modulation only if colour != vec4(1.0) (composite.glsl:224-228)
+    o.has_color = (aColor.x != 1.f || aColor.y != 1.f || aColor.z != 1.f || aColor.w != 1.f) ? 1 : 0;
+    o.uv_bounds = bounds;
+  }
+}
+
+// ps_clear.glsl:9-25
+WR_DEVICE void wr_vs_ps_clear(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+  wf4 aRect = wr_load_attr<wf4>(d, arena, inst, 0);
+  wf4 aColor = wr_load_attr<wf4>(d, arena, inst, 1);
+  for (int n = 0; n < 4; n++) {
+    float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    float x = (aRect.z - aRect.x) * ax + aRect.x, y = (aRect.w - aRect.y) * ay + aRect.y;
+    wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{x, y, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.w /* gl_Position.z = gl_Position.w */; o.pw[n] = gp.w;
+    o.u[n] = 0.f; o.v[n] = 0.f;
+  }
+  o.kind = WR_PK_SOLID;
+  o.color = aColor;
+  o.has_color = 0; o.aa_edges = 0; o.has_mask = 0;
+}
+
+WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
+
+// draw_quad (rasterize.h:1549-1633) + the axis-aligned closed form of
+// draw_quad_spans (rasterize.h:783-1055): for a rectangle both edge slopes are
+// exactly 0, so every row has the same span and rows are those whose centre
+// lies in [top, bottom] after clipping.
+WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut& o, WrPrim& P,
+                              WrUnsupportedCounters* cnt) {
+  P.kind = WR_PK_NONE;
+  P.draw = draw_index;
+  P.blend = (int16_t)d.blend;
+  P.flags = d.flags & (WR_PF_DEPTH_TEST | WR_PF_DEPTH_WRITE | WR_PF_DEPTH_LESS);
+  P.x0 = P.y0 = P.x1 = P.y1 = 0;
+  if (o.pw[1] != o.pw[0] || o.pw[2] != o.pw[0] || o.pw[3] != o.pw[0]) {  // perspective path: "next"
+    atomicAdd(&cnt->perspective_prims, 1u);
+    return;
+  }
+  float w = 1.0f / o.pw[0];
+  if (!wr_isfinite(w)) w = 0.0f;
+  float sx[4], sy[4];
+  for (int n = 0; n < 4; n++) {
+    sx[n] = (o.px[n] * w + 1.0f) * 0.5f * d.vp_size[0] + d.vp_origin[0];
+    sy[n] = (o.py[n] * w + 1.0f) * 0.5f * d.vp_size[1] + d.vp_origin[1];
+  }
+  float cx0 = float(d.clip[0]), cy0 = float(d.clip[1]), cx1 = float(d.clip[2]), cy1 = float(d.clip[3]);
+#ifdef WRHIP_HOSTSIM
+  if (getenv("WRHIP_DEBUG_VS"))
+    fprintf(stderr, "    vs: pos (%g %g %g %g) (%g %g) (%g %g) (%g %g) screen (%g %g) (%g %g) (%g %g) (%g %g)\n", o.px[0], o.py[0], o.pz[0],
+            o.pw[0], o.px[1], o.py[1], o.px[2], o.py[2], o.px[3], o.py[3], sx[0], sy[0], sx[1], sy[1], sx[2], sy[2], sx[3], sy[3]);
+#endif
+  // ClipRect::overlaps, rasterize.h:465-477
+  int sides = 0;
+  for (int n = 0; n < 4; n++) {
+    sides |= sx[n] < cx1 ? (sx[n] > cx0 ? 3 : 1) : 2;
+    sides |= sy[n] < cy1 ? (sy[n] > cy0 ? 12 : 4) : 8;
+  }
+  if (sides != 0xF) return;
+  float screenZ = (o.pz[0] * w + 1.0f) * 0.5f;
+  if (screenZ < 0.0f || screenZ > 1.0f) return;
+  P.z = uint32_t(16777215.0f * screenZ);
+
+  if (o.aa_edges != 0 && d.blend != WR_BLEND_NONE) {  // swgl_antiAlias needs blending; AA path is "next"
+    P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
+  }
+  if (o.has_mask && d.blend != WR_BLEND_NONE) {
+    P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
+  }
+  // lanes: 0=(0,0) 1=(1,0) 2=(1,1) 3=(0,1) of the unit quad
+  bool typeA = sy[0] == sy[1] && sy[2] == sy[3] && sx[0] == sx[3] && sx[1] == sx[2];
+  bool typeB = sx[0] == sx[1] && sx[2] == sx[3] && sy[0] == sy[3] && sy[1] == sy[2];
+  if (!typeA && !typeB) {  // general quads (rotations): "next"
+    P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
+  }
+  float xa = sx[0], xb = sx[2], ya = sy[0], yb = sy[2];
+  float xmin = wr_min(xa, xb), xmax = wr_max(xa, xb), ymin = wr_min(ya, yb), ymax = wr_max(ya, yb);
+  // clipSpan = clipRect.x_range().clip(edge x range); span = clipSpan.clip({left.x,right.x}).round()
+  float sx0 = wr_clamp(xmin, cx0, cx1), sx1 = wr_clamp(xmax, cx0, cx1);
+  int ix0 = int(floorf(sx0 + 0.5f)), ix1 = int(floorf(sx1 + 0.5f));
+  // first row centre: floor(max(min(l0.y, clip.y1), clip.y0) + 0.5) + 0.5 ; rows while y <= min(bottom, clip.y1)
+  float ystart = floorf(wr_max(wr_min(ymin, cy1), cy0) + 0.5f) + 0.5f;
+  float ylimit = wr_min(ymax, cy1);
+  int iy0 = int(ystart);
+  int iy1 = int(floorf(ylimit - 0.5f)) + 1;
+  while ((float(iy1) + 0.5f) <= ylimit) iy1++;
+  while (iy1 > iy0 && (float(iy1 - 1) + 0.5f) > ylimit) iy1--;
+  if (ix1 <= ix0 || iy1 <= iy0) return;
+  P.x0 = ix0; P.x1 = ix1; P.y0 = iy0; P.y1 = iy1;
+  P.kind = (int16_t)o.kind;
+  if (o.kind == WR_PK_SOLID) {
+    wr_pack_color(o.color, P.color);
+  } else if (o.kind == WR_PK_TEX_RGBA8) {
+    if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
+    if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
+    if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
+    P.tex_slot = o.tex_slot;
+    P.uv_bounds[0] = o.uv_bounds.x; P.uv_bounds[1] = o.uv_bounds.y;
+    P.uv_bounds[2] = o.uv_bounds.z; P.uv_bounds[3] = o.uv_bounds.w;
+    P.fcolor[0] = o.color.x; P.fcolor[1] = o.color.y; P.fcolor[2] = o.color.z; P.fcolor[3] = o.color.w;
+    // Edge interpolants (Edge ctor, rasterize.h:858-876). Find which lanes are
+    // top-left/top-right/bottom-left/bottom-right on screen.
+    int tl = 0, tr = 0, bl = 0, br = 0;
+    for (int n = 0; n < 4; n++) {
+      bool left = sx[n] == xmin, top = sy[n] == ymin;
+      if (left && top) tl = n; else if (!left && top) tr = n; else if (left) bl = n; else br = n;
+    }
+    float yScale = 1.0f / wr_max(ymax - ymin, 1.0f / 256.0f);
+    float dy0 = ystart - ymin;
+    // left edge
+    float lsu = (o.u[bl] - o.u[tl]) * yScale, lsv = (o.v[bl] - o.v[tl]) * yScale;
+    float rsu = (o.u[br] - o.u[tr]) * yScale, rsv = (o.v[br] - o.v[tr]) * yScale;
+    P.uvL0[0] = o.u[tl] + dy0 * lsu; P.uvL0[1] = o.v[tl] + dy0 * lsv;
+    P.uvR0[0] = o.u[tr] + dy0 * rsu; P.uvR0[1] = o.v[tr] + dy0 * rsv;
+    P.uvLs[0] = lsu; P.uvLs[1] = lsv; P.uvRs[0] = rsu; P.uvRs[1] = rsv;
+    P.xl = xmin; P.xr = xmax;
+  }
+}
+
+__global__ void wr_vertex_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
+                                 int n_prims, WrUnsupportedCounters* cnt) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_prims) return;
+  // binary search for the draw containing this instance
+  int lo = 0, hi = n_draws - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (draws[mid].first_prim <= gid) lo = mid; else hi = mid - 1;
+  }
+  const WrDrawDesc& d = draws[lo];
+  int inst = gid - d.first_prim;
+  WrPrim P;
+  if (d.shader == WR_SH_CLEAR_OP) {
+    P.kind = WR_PK_CLEAR; P.blend = WR_BLEND_NONE; P.draw = lo; P.z = d.clear_depth;
+    P.flags = d.flags & (WR_PF_CLEAR_COLOR | WR_PF_CLEAR_DEPTH);
+    P.x0 = d.clip[0]; P.y0 = d.clip[1]; P.x1 = d.clip[2]; P.y1 = d.clip[3];
+    P.color[0] = d.clear_color; P.color[1] = 0;
+    if (P.x1 <= P.x0 || P.y1 <= P.y0) P.kind = WR_PK_NONE;
+    prims[gid] = P;
+    return;
+  }
+  WrVsOut o;
+  o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
+  switch (d.shader) {
+    case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
+    case WR_SH_BRUSH_SOLID:
+    case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush_solid(d, arena, inst, o); break;
+    case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
+    case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
+    case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
+    default:
+      P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo;
+      prims[gid] = P;
+      return;
+  }
+  wr_finish_prim(d, lo, o, P, cnt);
+  prims[gid] = P;
+}
+
+// ---------------------------------------------------------------------------
+// Binning: bit (p - T.first_prim) of bin b's mask row <=> prim p touches bin b.
+__global__ void wr_bin_kernel(const WrPrim* __restrict__ prims, int n_prims,
+                              const WrDrawDesc* __restrict__ draws,
+                              const WrTargetDesc* __restrict__ targets,
+                              unsigned long long* __restrict__ masks) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_prims) return;
+  const WrPrim& P = prims[gid];
+  if (P.kind == WR_PK_NONE || P.kind == WR_PK_UNSUPPORTED) return;
+  const WrTargetDesc& T = targets[draws[P.draw].target];
+  int bx0 = wr_imax(P.x0, 0) / WR_BIN_W, bx1 = (wr_imin(P.x1, T.width) - 1) / WR_BIN_W;
+  int by0 = wr_imax(P.y0, 0) / WR_BIN_H, by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
+  by0 = wr_imax(by0, T.row_begin); by1 = wr_imin(by1, T.row_end - 1);
+  int rel = gid - T.first_prim;
+  unsigned long long bit = 1ull << (rel & 63);
+  int word = rel >> 6;
+  for (int by = by0; by <= by1; by++)
+    for (int bx = bx0; bx <= bx1; bx++)
+      atomicOr(&masks[(size_t)T.word_base + (size_t)(by * T.bins_x + bx) * T.words_per_bin + word], bit);
+}
+
+// ---------------------------------------------------------------------------
+// Blend stage (swgl/src/blend.h).  Pixels are BGRA8 in a u32; arithmetic is
+// done on 4 x u16 lanes exactly as WideRGBA8 (wrapping 16-bit), then `pack`ed
+// with the portable saturating pack (texture.h:14-21).
+
+struct WrWide { uint32_t bg, ra; };   // (b | g<<16), (r | a<<16): 4 x u16
+
+WR_DEVICE WrWide wr_unpack(uint32_t p) {
+  WrWide w;
+  w.bg = (p & 0xFF) | ((p & 0xFF00) << 8);
+  w.ra = ((p >> 16) & 0xFF) | ((p >> 24) << 16);
+  return w;
+}
+// genericPackWide: p = (p | (p > 255 ? 0xFFFF : 0)) + (p >> 15); low byte
+WR_DEVICE uint32_t wr_pack1(uint32_t v) {  // v: one u16 lane
+  uint32_t m = v > 255u ? 0xFFFFu : 0u;
+  return (((v | m) + (v >> 15))) & 0xFFu;
+}
+WR_DEVICE uint32_t wr_pack(WrWide w) {
+  return wr_pack1(w.bg & 0xFFFF) | (wr_pack1(w.bg >> 16) << 8) |
+         (wr_pack1(w.ra & 0xFFFF) << 16) | (wr_pack1(w.ra >> 16) << 24);
+}
+// lane-wise u16 ops on a pair packed in u32 (wrapping mod 2^16 per lane)
+WR_DEVICE uint32_t wr_add2(uint32_t a, uint32_t b) { return ((a & 0xFFFF) + (b & 0xFFFF) & 0xFFFF) | (((a >> 16) + (b >> 16)) << 16); }
+WR_DEVICE uint32_t wr_sub2(uint32_t a, uint32_t b) { return ((a & 0xFFFF) - (b & 0xFFFF) & 0xFFFF) | (((a >> 16) - (b >> 16)) << 16); }
+// muldiv255: (x*y + x) >> 8 in u16 lanes (blend.h:126-128)
+WR_DEVICE uint32_t wr_muldiv255_2(uint32_t x, uint32_t y) {
+  uint32_t lo = (((x & 0xFFFF) * (y & 0xFFFF) + (x & 0xFFFF)) & 0xFFFF) >> 8;
+  uint32_t hi = ((((x >> 16) * (y >> 16) + (x >> 16)) & 0xFFFF) >> 8);
+  return lo | (hi << 16);
+}
+WR_DEVICE uint32_t wr_splat_a(uint32_t ra) { uint32_t a = ra >> 16; return a | (a << 16); }
+
+// blend_pixels for RGBA8 (blend.h:416-701): the keys WebRender's in-scope
+// batches use.  `src` already has clip-mask/AA weights applied.
+WR_DEVICE uint32_t wr_blend_rgba8(int key, uint32_t dstp, WrWide src, const WrDrawDesc* d) {
+  WrWide dst = wr_unpack(dstp), r;
+  switch (key) {
+    default:
+    case WR_BLEND_NONE: r = src; break;
+    case WR_BLEND_PREMULT: {  // src + dst - muldiv255(dst, alphas(src))
+      uint32_t a = wr_splat_a(src.ra);
+      r.bg = wr_sub2(wr_add2(src.bg, dst.bg), wr_muldiv255_2(dst.bg, a));
+      r.ra = wr_sub2(wr_add2(src.ra, dst.ra), wr_muldiv255_2(dst.ra, a));
+    } break;
+    case WR_BLEND_ALPHA: {  // addlow(dst, muldiv255(alphas(src), (src | ALPHA_OPAQUE) - dst))
+      uint32_t a = wr_splat_a(src.ra);
+      uint32_t tbg = wr_muldiv255_2(a, wr_sub2(src.bg, dst.bg));
+      uint32_t tra = wr_muldiv255_2(a, wr_sub2(src.ra | (255u << 16), dst.ra));
+      // addlow: byte-wise add (blend.h:201-205)
+      r.bg = ((dst.bg & 0x00FF00FF) + (tbg & 0x00FF00FF)) & 0x00FF00FF;
+      r.bg |= (((dst.bg >> 8) & 0x00FF00FF) + ((tbg >> 8) & 0x00FF00FF) & 0x00FF00FF) << 8;
+      r.ra = ((dst.ra & 0x00FF00FF) + (tra & 0x00FF00FF)) & 0x00FF00FF;
+      r.ra |= (((dst.ra >> 8) & 0x00FF00FF) + ((tra >> 8) & 0x00FF00FF) & 0x00FF00FF) << 8;
+    } break;
+    case WR_BLEND_ZERO_INV_SRC_COLOR:  // dst - muldiv255(dst, src)
+      r.bg = wr_sub2(dst.bg, wr_muldiv255_2(dst.bg, src.bg));
+      r.ra = wr_sub2(dst.ra, wr_muldiv255_2(dst.ra, src.ra));
+      break;
+    case WR_BLEND_ZERO_INV_SRC_COLOR_A1:  // dst - (muldiv255(dst, src) & RGB_MASK)
+      r.bg = wr_sub2(dst.bg, wr_muldiv255_2(dst.bg, src.bg));
+      r.ra = wr_sub2(dst.ra, wr_muldiv255_2(dst.ra, src.ra) & 0x0000FFFF);
+      break;
+    case WR_BLEND_DEST_OUT: {  // dst - muldiv255(dst, alphas(src))
+      uint32_t a = wr_splat_a(src.ra);
+      r.bg = wr_sub2(dst.bg, wr_muldiv255_2(dst.bg, a));
+      r.ra = wr_sub2(dst.ra, wr_muldiv255_2(dst.ra, a));
+    } break;
+    case WR_BLEND_MULTIPLY:  // muldiv255(src, dst)
+      r.bg = wr_muldiv255_2(src.bg, dst.bg);
+      r.ra = wr_muldiv255_2(src.ra, dst.ra);
+      break;
+    case WR_BLEND_ADD:
+      r.bg = wr_add2(src.bg, dst.bg); r.ra = wr_add2(src.ra, dst.ra);
+      break;
+    case WR_BLEND_ADD_A_OVER:  // src + dst - (muldiv255(dst, src) & ALPHA_MASK)
+      r.bg = wr_add2(src.bg, dst.bg);
+      r.ra = wr_sub2(wr_add2(src.ra, dst.ra), wr_muldiv255_2(dst.ra, src.ra) & 0xFFFF0000);
+      break;
+    case WR_BLEND_INV_DST_A: {  // dst + ((src - muldiv255(src, alphas(dst))) & RGB_MASK)
+      uint32_t a = wr_splat_a(dst.ra);
+      r.bg = wr_add2(dst.bg, wr_sub2(src.bg, wr_muldiv255_2(src.bg, a)));
+      r.ra = wr_add2(dst.ra, wr_sub2(src.ra, wr_muldiv255_2(src.ra, a)) & 0x0000FFFF);
+    } break;
+    case WR_BLEND_SCREEN:  // ONE, ONE_MINUS_SRC_COLOR is not in swgl's key table: treated as unsupported upstream
+      r = src; break;
+  }
+  (void)d;
+  return wr_pack(r);
+}
+
+// R8 targets: blend_pixels(uint8_t*) (blend.h:703-735)
+WR_DEVICE uint32_t wr_blend_r8(int key, uint32_t dst, uint32_t src) {
+  uint32_t r;
+  switch (key) {
+    default:
+    case WR_BLEND_NONE: r = src; break;
+    case WR_BLEND_MULTIPLY: r = (((src * dst + src) & 0xFFFF) >> 8); break;
+    case WR_BLEND_ADD: r = (src + dst) & 0xFFFF; break;
+  }
+  return wr_pack1(r);
+}
+
+// applyColor(src, color) = muldiv255(color, src)  (blend.h:156-159)
+WR_DEVICE WrWide wr_apply_color(WrWide src, const uint32_t color[2]) {
+  WrWide r;
+  r.bg = wr_muldiv255_2(color[0], src.bg);
+  r.ra = wr_muldiv255_2(color[1], src.ra);
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// Texture sampling helpers used by textured prims.
+
+// textureLinearUnpackedRGBA8 for ONE pixel (texture.h:1028-1071): 7-bit
+// fixed-point bilinear on quantised coords i = uv*size*128 + (0.5 - 64).
+WR_DEVICE WrWide wr_sample_linear_rgba8(const WrTexDesc& t, int qx, int qy) {
+  int fx = qx, fy = qy;
+  int ix = qx >> 7, iy = qy >> 7;
+  // computeRow(sampler, i) with margin 1
+  int cx = wr_clamp_coord(ix, t.width - 1), cy = wr_clamp_coord(iy, t.height);
+  const uint32_t* buf = (const uint32_t*)t.ptr;
+  size_t row0 = (size_t)cx + (size_t)cy * t.stride;
+  size_t row1 = row0 + ((iy >= 0 && iy < t.height - 1) ? t.stride : 0);
+  // computeFracX: ((frac.x & (i.x >= 0)) | overread) & 0x7F) - overread, overread = i.x > width-2 as all-ones
+  int over = ix > t.width - 2 ? -1 : 0;
+  int fracx = ((((ix >= 0) ? fx : 0) | over) & 0x7F) - over;
+  int fracy = fy & 0x7F;
+  uint32_t a0 = buf[row0], a0n = buf[row0 + 1], a1 = buf[row1], a1n = buf[row1 + 1];
+  WrWide out;
+  int ch[4];
+  for (int c = 0; c < 4; c++) {
+    int p00 = (a0 >> (8 * c)) & 0xFF, p01 = (a0n >> (8 * c)) & 0xFF;
+    int p10 = (a1 >> (8 * c)) & 0xFF, p11 = (a1n >> (8 * c)) & 0xFF;
+    // int16 arithmetic: a0 += ((a1 - a0) * fracy) >> 7 ; then columns
+    int l = (int16_t)(p00 + (int16_t)(((int16_t)((p10 - p00) * fracy)) >> 7));
+    int r = (int16_t)(p01 + (int16_t)(((int16_t)((p11 - p01) * fracy)) >> 7));
+    ch[c] = (int16_t)(l + (int16_t)(((int16_t)((r - l) * fracx)) >> 7));
+  }
+  out.bg = (uint32_t(ch[0]) & 0xFFFF) | ((uint32_t(ch[1]) & 0xFFFF) << 16);
+  out.ra = (uint32_t(ch[2]) & 0xFFFF) | ((uint32_t(ch[3]) & 0xFFFF) << 16);
+  return out;
+}
+
+// ---------------------------------------------------------------------------
+// Raster stage.  Lane l of wave w in the workgroup of bin (bx,by) owns pixels
+//   x = 64*bx + 4*(l & 15) + i,   y = 64*by + 16*w + (l >> 4) + 4*j,  i,j in 0..3
+// i.e. for a fixed j the wave touches 4 consecutive rows x 256 contiguous bytes.
+
+struct WrTexRowSetup {   // per (prim,row) setup of swgl_commitTexture*RGBA8
+  int nearest;           // LINEAR_FILTER_NEAREST decision (needsTextureLinear)
+  int span_main;         // pixels [span_main, len) of the span go through main()
+  int ix, minX, maxX;    // nearest-fast
+  size_t row;            // row offset (elements)
+  float u0, v0, du, dv;  // uv at span start / per pixel step
+};
+
+// One pixel of a WR_PK_TEX_RGBA8 prim on row y (returns WideRGBA8 source).
+WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y, bool& ok) {
+  ok = true;
+  // interpolants at this row (Edge::interp) and span start (rasterize.h:1003-1017)
+  float k = float(y - P.y0);
+  float Lu = P.uvL0[0] + k * P.uvLs[0], Lv = P.uvL0[1] + k * P.uvLs[1];
+  float Ru = P.uvR0[0] + k * P.uvRs[0], Rv = P.uvR0[1] + k * P.uvRs[1];
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
+  float start = float(P.x0) + 0.5f - P.xl;
+  float ou = Lu + su * start, ov = Lv + sv * start;
+  int len = P.x1 - P.x0;
+  int n = x - P.x0;
+  int span = len & ~3;
+  float W = float(t.width), H = float(t.height);
+  const uint32_t* buf = (const uint32_t*)t.ptr;
+  if (n < span && len >= 4) {
+    // swgl_commitTextureLinear -> needsTextureLinear (swgl_ext.h:553-587)
+    // P lanes: x: ou, ou+su ; y: ov, ov+sv
+    int filter;  // 0 nearest, 1 fallback, 2 upscale, 3 fast, 4 downscale
+    float ou1 = ou + su, ov1 = ov + sv;
+    if (!t.linear) {
+      // swgl_commitTextureNearest: needsNearestFallback (swgl_ext.h:876-880)
+      float py0 = ov * H, py1 = ov1 * H, px0 = ou * W, px1 = ou1 * W;
+      int sp = (span & ~127) + 128;
+      int scaled = int(roundf((px1 - px0) * float(sp)));
+      bool fallback = (py1 - py0) * float(span) >= 0.5f || scaled != sp;
+      filter = fallback ? 1 : 0;
+      if (fallback) { ok = false; return WrWide{0, 0}; }  // blendTextureNearestRepeat<false>: "next"
+    } else if (t.width < 2) {
+      filter = 0;
+    } else if (ov != ov1) {
+      filter = 1;
+    } else {
+      float px0 = ou * W, px1 = ou1 * W, py0 = ov * H;
+      int sp = (span & ~127) + 128;
+      int scaled = int(roundf((px1 - px0) * float(sp)));
+      if (scaled != sp) {
+        filter = (px0 < px1 && px1 - px0 <= 1.0f) ? 2 : (scaled == sp * 2 ? 4 : 1);
+      } else if ((int(px0 * 4.0f + 0.5f) & 3) != 2 || (int(py0 * 4.0f + 0.5f) & 3) != 2) {
+        filter = 3;
+      } else {
+        filter = 0;
+      }
+    }
+    if (filter == 0) {
+      // blendTextureNearestFast (swgl_ext.h:475-537)
+      int ix = int(ou * W), iy = int(ov * H);
+      int minUx = int(P.uv_bounds[0] * W), minUy = int(P.uv_bounds[1] * H);
+      int maxUx = int(P.uv_bounds[2] * W), maxUy = int(P.uv_bounds[3] * H);
+      size_t row = (size_t)wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height) * t.stride;
+      int minX = wr_iclamp(minUx, 0, t.width - 1);
+      int maxX = wr_iclamp(maxUx, minX, t.width - 1);
+      int sx = wr_iclamp(ix + n, minX, maxX);
+      return wr_unpack(buf[row + sx]);
+    }
+    // Linear filters.  All variants evaluate the same 7-bit bilinear formula;
+    // quantised coordinate stepping follows blendTextureLinearFallback
+    // (swgl_ext.h:172-183): per 4-pixel chunk uv += uv_step, lanes offset by the
+    // quantised per-pixel delta.
+    float qs = 128.0f;
+    float q0x = ou * W * qs + (0.5f - 0.5f * qs), q1x = ou1 * W * qs + (0.5f - 0.5f * qs);
+    float q0y = ov * H * qs + (0.5f - 0.5f * qs), q1y = ov1 * H * qs + (0.5f - 0.5f * qs);
+    float stepx = 4.0f * (q1x - q0x), stepy = 4.0f * (q1y - q0y);
+    float minx = wr_max(P.uv_bounds[0] * W * qs + (0.5f - 0.5f * qs), 0.0f);
+    float miny = wr_max(P.uv_bounds[1] * H * qs + (0.5f - 0.5f * qs), 0.0f);
+    float maxx = wr_max(P.uv_bounds[2] * W * qs + (0.5f - 0.5f * qs), minx);
+    float maxy = wr_max(P.uv_bounds[3] * H * qs + (0.5f - 0.5f * qs), miny);
+    int chunk = n >> 2, lane = n & 3;
+    // lanes of the quantised uv Float: uv.x = {q0x, q(ou+su), q(ou+2su), q(ou+3su)} (init_interp)
+    float lu = ou, lv = ov;
+    for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
+    float qx = lu * W * qs + (0.5f - 0.5f * qs), qy = lv * H * qs + (0.5f - 0.5f * qs);
+    for (int c = 0; c < chunk; c++) { qx += stepx; qy += stepy; }
+    qx = wr_clamp(qx, minx, maxx); qy = wr_clamp(qy, miny, maxy);
+    return wr_sample_linear_rgba8(t, int(qx), int(qy));
+  }
+  // Tail pixels: fragment shader main() -> texture(sColor0, uv) -> round_pixel
+  // uv of this pixel: lanes of init_interp + whole-chunk steps (glsl.h:3084-3089)
+  // uv of this pixel: its init_interp lane (glsl.h:3084-3089), then
+  // step_interp_inputs(drawn): v_uv0 += interp_step * (drawn * 0.25), interp_step = step * 4
+  float lu = ou, lv = ov;
+  {
+    int lane = (n - span) & 3;
+    for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
+    float chunks = float(span) * 0.25f;
+    if (len >= 4) { lu = lu + (su * 4.0f) * chunks; lv = lv + (sv * 4.0f) * chunks; }
+  }
+  float cu = wr_clamp(lu, P.uv_bounds[0], P.uv_bounds[2]), cv = wr_clamp(lv, P.uv_bounds[1], P.uv_bounds[3]);
+  bool clamp_uv = (P.flags & WR_PF_TAIL_CLAMP) != 0;
+  if (!clamp_uv) { cu = lu; cv = lv; }
+  float tb, tg, tr, ta;
+  if (t.linear) {
+    int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
+    WrWide s = wr_sample_linear_rgba8(t, qx, qy);
+    tb = float(s.bg & 0xFFFF) * (1.0f / 255.0f); tg = float(s.bg >> 16) * (1.0f / 255.0f);
+    tr = float(s.ra & 0xFFFF) * (1.0f / 255.0f); ta = float(s.ra >> 16) * (1.0f / 255.0f);
+  } else {
+    int tx = wr_clamp_coord(int(cu * W), t.width), ty = wr_clamp_coord(int(cv * H), t.height);
+    uint32_t p = buf[(size_t)tx + (size_t)ty * t.stride];
+    tb = float(p & 0xFF) * (1.0f / 255.0f); tg = float((p >> 8) & 0xFF) * (1.0f / 255.0f);
+    tr = float((p >> 16) & 0xFF) * (1.0f / 255.0f); ta = float(p >> 24) * (1.0f / 255.0f);
+  }
+  if (P.flags & WR_PF_TAIL_MODULATE) { tr = P.fcolor[0] * tr; tg = P.fcolor[1] * tg; tb = P.fcolor[2] * tb; ta = P.fcolor[3] * ta; }
+  WrWide s;
+  wr_pack_color(wf4{tr, tg, tb, ta}, (uint32_t*)&s);
+  ok = true;
+  // signal to caller that applyColor must NOT be applied again for tail pixels
+  s.ra |= 0;  // (no-op; modulation handled above)
+  return s;
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(256)
+wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
+                 const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                 const unsigned long long* __restrict__ masks, int bin_offset) {
+  const int bin = blockIdx.x + bin_offset;
+  // locate the target owning this bin
+  int t = 0;
+  {
+    int lo = 0, hi = n_targets - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (targets[mid].first_bin <= bin) lo = mid; else hi = mid - 1;
+    }
+    t = lo;
+  }
+  const WrTargetDesc& T = targets[t];
+  if (T.format != FMT) return;
+  const int lb = bin - T.first_bin;
+  const int bx = lb % T.bins_x, by = lb / T.bins_x;
+  if (by < T.row_begin || by >= T.row_end) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wx0 = bx * WR_BIN_W, wy0 = by * WR_BIN_H + wave * 16;
+  const int px = wx0 + (lane & 15) * 4;
+  const int py = wy0 + (lane >> 4);
+  constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
+
+  uint32_t col[4][4];
+  uint32_t dep[4][4];
+  // ---- initial pixel state ---------------------------------------------
+  for (int j = 0; j < 4; j++) {
+    int y = py + 4 * j;
+    for (int i = 0; i < 4; i++) { col[j][i] = T.init_color; dep[j][i] = T.init_depth; }
+    if (y < T.height) {
+      if (T.load_color) {
+        const uint8_t* rowp = (const uint8_t*)T.color + (size_t)y * T.stride;
+        if (BPP == 4) {
+          if (px + 4 <= T.width && ((T.stride & 15) == 0)) {
+            uint4 v = *(const uint4*)(rowp + (size_t)px * 4);
+            col[j][0] = v.x; col[j][1] = v.y; col[j][2] = v.z; col[j][3] = v.w;
+          } else {
+            for (int i = 0; i < 4; i++) if (px + i < T.width) col[j][i] = ((const uint32_t*)rowp)[px + i];
+          }
+        } else {
+          for (int i = 0; i < 4; i++) if (px + i < T.width) col[j][i] = rowp[px + i];
+        }
+      }
+      if (T.load_depth && T.depth) {
+        for (int i = 0; i < 4; i++) if (px + i < T.width) dep[j][i] = T.depth[(size_t)y * T.width + px + i];
+      }
+    }
+  }
+  // ---- apply every prim of this bin, in submission order -----------------
+  const unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
+  for (int w = 0; w < T.words_per_bin; w++) {
+    unsigned long long m = mw[w];
+    while (m) {
+      int bit = __builtin_ctzll(m);
+      m &= m - 1;
+      const WrPrim& P = prims[T.first_prim + w * 64 + bit];
+      // wave-uniform reject against this wave's 64x16 strip
+      if (P.x1 <= wx0 || P.x0 >= wx0 + WR_BIN_W || P.y1 <= wy0 || P.y0 >= wy0 + 16) continue;
+      const int kind = P.kind, blend = P.blend, flags = P.flags;
+      const uint32_t z = P.z;
+      const WrDrawDesc* D = &draws[P.draw];
+      for (int j = 0; j < 4; j++) {
+        int y = py + 4 * j;
+        bool rowin = y >= P.y0 && y < P.y1;
+        for (int i = 0; i < 4; i++) {
+          int x = px + i;
+          bool in = rowin && x >= P.x0 && x < P.x1;
+          if (!in) continue;
+          if (kind == WR_PK_CLEAR) {
+            if (flags & WR_PF_CLEAR_COLOR) col[j][i] = P.color[0];
+            if (flags & WR_PF_CLEAR_DEPTH) dep[j][i] = z;
+            continue;
+          }
+          if (flags & WR_PF_DEPTH_TEST) {
+            bool pass = (flags & WR_PF_DEPTH_LESS) ? (z < dep[j][i]) : (z <= dep[j][i]);
+            if (!pass) continue;
+            if (flags & WR_PF_DEPTH_WRITE) dep[j][i] = z;
+          }
+          if (FMT == WR_FMT_RGBA8) {
+            WrWide src;
+            if (kind == WR_PK_SOLID) {
+              src.bg = P.color[0]; src.ra = P.color[1];
+            } else {
+              bool ok;
+              src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y, ok);
+              int n = x - P.x0, len = P.x1 - P.x0;
+              bool in_span = len >= 4 && n < (len & ~3);
+              if (in_span && (flags & WR_PF_HAS_COLOR)) src = wr_apply_color(src, P.color);
+            }
+            col[j][i] = wr_blend_rgba8(blend, col[j][i], src, D);
+          } else {
+            // R8 target: pack_pixels_R8(v_color.x) (blend.h:67-73)
+            uint32_t src = P.color[1] & 0xFFFF;  // r lane
+            col[j][i] = wr_blend_r8(blend, col[j][i], src);
+          }
+        }
+      }
+    }
+  }
+  // ---- write back ------------------------------------------------------------
+  for (int j = 0; j < 4; j++) {
+    int y = py + 4 * j;
+    if (y >= T.height) continue;
+    uint8_t* rowp = (uint8_t*)T.color + (size_t)y * T.stride;
+    if (BPP == 4) {
+      if (px + 4 <= T.width && ((T.stride & 15) == 0)) {
+        *(uint4*)(rowp + (size_t)px * 4) = make_uint4(col[j][0], col[j][1], col[j][2], col[j][3]);
+      } else {
+        for (int i = 0; i < 4; i++) if (px + i < T.width) ((uint32_t*)rowp)[px + i] = col[j][i];
+      }
+    } else {
+      for (int i = 0; i < 4; i++) if (px + i < T.width) rowp[px + i] = (uint8_t)col[j][i];
+    }
+    if (T.store_depth && T.depth) {
+      for (int i = 0; i < 4; i++) if (px + i < T.width) T.depth[(size_t)y * T.width + px + i] = dep[j][i];
+    }
+  }
+}

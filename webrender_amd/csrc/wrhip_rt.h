@@ -1,0 +1,125 @@
+// wrhip_rt.h -- thin runtime layer under the GL state tracker.
+//
+// Product build (hipcc, gfx950): HIP runtime, one stream per context, pinned
+// staging memory, hipEvents for GPU timing.
+//
+// WRHIP_HOSTSIM build (plain g++, *test infrastructure only*): the very same
+// kernel sources are compiled for the host and each launch is executed as a
+// serial loop over blocks/threads.  It exists so the deferred-rendering logic
+// and the integer pixel pipeline can be checked against the oracle in the
+// GPU-less authoring container (tests/, -m "not gpu").  It is built as a
+// separate library (libwrhip_hostsim.so) that no product entry point loads;
+// libwrhip.so itself has no CPU path and aborts when no HIP device is present.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef WRHIP_HOSTSIM
+// ---------------------------------------------------------------------------
+#include <math.h>
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+struct wr_dim3 { unsigned x, y, z; };
+static thread_local wr_dim3 blockIdx, threadIdx, blockDim, gridDim;
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
+static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p |= v; return o; }
+typedef int wr_stream_t;
+typedef struct { double t; } wr_event_t;
+#define WR_LAUNCH(kernel, grid, block, stream, ...)                     \
+  do {                                                                  \
+    gridDim = wr_dim3{(unsigned)(grid), 1, 1};                          \
+    blockDim = wr_dim3{(unsigned)(block), 1, 1};                        \
+    for (unsigned _b = 0; _b < (unsigned)(grid); _b++)                  \
+      for (unsigned _t = 0; _t < (unsigned)(block); _t++) {             \
+        blockIdx = wr_dim3{_b, 0, 0};                                   \
+        threadIdx = wr_dim3{_t, 0, 0};                                  \
+        kernel(__VA_ARGS__);                                            \
+      }                                                                 \
+  } while (0)
+namespace wrrt {
+static inline bool init(int*, char* name, size_t n) { snprintf(name, n, "hostsim (CPU, tests only)"); return true; }
+static inline void* dev_alloc(size_t n) { return calloc(1, n ? n : 1); }
+static inline void dev_free(void* p) { free(p); }
+static inline void* pinned_alloc(size_t n) { return malloc(n ? n : 1); }
+static inline void pinned_free(void* p) { free(p); }
+static inline void stream_create(wr_stream_t* s) { *s = 0; }
+static inline void stream_destroy(wr_stream_t) {}
+static inline void stream_sync(wr_stream_t) {}
+static inline void h2d(void* d, const void* s, size_t n, wr_stream_t) { memcpy(d, s, n); }
+static inline void d2h(void* d, const void* s, size_t n, wr_stream_t) { memcpy(d, s, n); }
+static inline void d2d(void* d, const void* s, size_t n, wr_stream_t) { memmove(d, s, n); }
+static inline void copy2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, int, wr_stream_t) {
+  for (size_t y = 0; y < h; y++) memmove((char*)d + y * dp, (const char*)s + y * sp, w);
+}
+static inline void memset8(void* d, int v, size_t n, wr_stream_t) { memset(d, v, n); }
+static inline void event_create(wr_event_t* e) { e->t = 0; }
+static inline void event_destroy(wr_event_t) {}
+static inline void event_record(wr_event_t*, wr_stream_t) {}
+static inline void event_sync(wr_event_t*) {}
+static inline float event_elapsed_ms(wr_event_t*, wr_event_t*) { return 0.f; }
+}  // namespace wrrt
+#else
+// ---------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+typedef hipStream_t wr_stream_t;
+typedef hipEvent_t wr_event_t;
+#define WR_HIP_CHECK(expr)                                                          \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      fprintf(stderr, "libwrhip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), \
+              __FILE__, __LINE__);                                                  \
+      abort();                                                                      \
+    }                                                                               \
+  } while (0)
+#define WR_LAUNCH(kernel, grid, block, stream, ...)                          \
+  do {                                                                       \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
+    WR_HIP_CHECK(hipGetLastError());                                         \
+  } while (0)
+namespace wrrt {
+static inline bool init(int* device, char* name, size_t n) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return false;
+  int dev = 0;
+  const char* lr = getenv("LOCAL_RANK");
+  if (lr) dev = atoi(lr) % count;
+  WR_HIP_CHECK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  WR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  snprintf(name, n, "%s (%s)", prop.name, prop.gcnArchName);
+  *device = dev;
+  return true;
+}
+static inline void* dev_alloc(size_t n) { void* p = nullptr; WR_HIP_CHECK(hipMalloc(&p, n ? n : 16)); return p; }
+static inline void dev_free(void* p) { if (p) WR_HIP_CHECK(hipFree(p)); }
+static inline void* pinned_alloc(size_t n) { void* p = nullptr; WR_HIP_CHECK(hipHostMalloc(&p, n ? n : 16, hipHostMallocDefault)); return p; }
+static inline void pinned_free(void* p) { if (p) WR_HIP_CHECK(hipHostFree(p)); }
+static inline void stream_create(wr_stream_t* s) { WR_HIP_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
+static inline void stream_destroy(wr_stream_t s) { WR_HIP_CHECK(hipStreamDestroy(s)); }
+static inline void stream_sync(wr_stream_t s) { WR_HIP_CHECK(hipStreamSynchronize(s)); }
+static inline void h2d(void* d, const void* s, size_t n, wr_stream_t st) { WR_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st)); }
+static inline void d2h(void* d, const void* s, size_t n, wr_stream_t st) { WR_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st)); }
+static inline void d2d(void* d, const void* s, size_t n, wr_stream_t st) { WR_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st)); }
+// kind: 0 h2d, 1 d2h, 2 d2d
+static inline void copy2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, int kind, wr_stream_t st) {
+  hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (w == 0 || h == 0) return;
+  WR_HIP_CHECK(hipMemcpy2DAsync(d, dp, s, sp, w, h, k, st));
+}
+static inline void memset8(void* d, int v, size_t n, wr_stream_t st) { if (n) WR_HIP_CHECK(hipMemsetAsync(d, v, n, st)); }
+static inline void event_create(wr_event_t* e) { WR_HIP_CHECK(hipEventCreate(e)); }
+static inline void event_destroy(wr_event_t e) { WR_HIP_CHECK(hipEventDestroy(e)); }
+static inline void event_record(wr_event_t* e, wr_stream_t s) { WR_HIP_CHECK(hipEventRecord(*e, s)); }
+static inline void event_sync(wr_event_t* e) { WR_HIP_CHECK(hipEventSynchronize(*e)); }
+static inline float event_elapsed_ms(wr_event_t* a, wr_event_t* b) { float ms = 0; WR_HIP_CHECK(hipEventElapsedTime(&ms, *a, *b)); return ms; }
+}  // namespace wrrt
+#endif

@@ -1,0 +1,172 @@
+// wrhip_types.h -- structures shared between the host-side GL state tracker
+// (wrhip_gl.cpp part of wrhip.hip) and the gfx950 kernels (wrhip_kernels.h).
+//
+// Data flow of one flush:
+//   host: DrawDesc[] (one per DrawElementsInstanced / clear), TargetDesc[],
+//         instance bytes  --(one H2D copy of the frame arena)-->  HBM
+//   wr_vertex_kernel : instance -> Prim (screen rect, depth, packed colour,
+//                      sampling setup); restates the shader's vertex stage
+//   wr_bin_kernel    : Prim -> per-bin ordered bitmasks (bit i of word w of bin
+//                      b = prim 64*w+i touches bin b); order = submission order
+//   wr_raster_kernel : one workgroup per 64x64 bin; pixels stay in registers
+//                      while every prim of the bin is applied in order; each
+//                      destination pixel is read at most once and written once
+#pragma once
+#include <stdint.h>
+
+#define WR_BIN_W 64
+#define WR_BIN_H 64
+#define WR_MAX_TEX 12  // sampler slots, renderer/mod.rs:371-385
+
+// Texture slots (TextureSampler order, renderer/mod.rs:371-385)
+enum WrSlot {
+  WR_S_COLOR0 = 0, WR_S_COLOR1, WR_S_COLOR2, WR_S_GPU_CACHE, WR_S_TRANSFORMS,
+  WR_S_RENDER_TASKS, WR_S_DITHER, WR_S_PRIM_HEADERS_F, WR_S_PRIM_HEADERS_I,
+  WR_S_CLIP_MASK, WR_S_GPU_BUFFER_F, WR_S_GPU_BUFFER_I
+};
+
+enum WrTexFormat {  // texture.h TextureFormat
+  WR_FMT_NONE = 0, WR_FMT_RGBA32F, WR_FMT_RGBA32I, WR_FMT_RGBA8, WR_FMT_R8,
+  WR_FMT_RG8, WR_FMT_R16, WR_FMT_RG16, WR_FMT_DEPTH24
+};
+
+// Shader programs known to the backend.  Keys are the "name FEATURES" strings
+// WebRender sends through ShaderSourceByName (webrender_build/src/
+// shader_features.rs:64-248).
+enum WrShader {
+  WR_SH_NONE = 0,
+  WR_SH_PS_QUAD_TEXTURED,
+  WR_SH_BRUSH_SOLID,
+  WR_SH_BRUSH_SOLID_ALPHA,
+  WR_SH_COMPOSITE,
+  WR_SH_COMPOSITE_FAST,
+  WR_SH_PS_CLEAR,
+  WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
+  WR_SH_COUNT
+};
+
+// Blend keys actually reachable from WebRender's BlendModes
+// (device/gl.rs:3901-4025 -> gl.cc:614-660 hash_blend_key).
+enum WrBlend {
+  WR_BLEND_NONE = 0,               // GL_ONE, GL_ZERO / blend disabled
+  WR_BLEND_ALPHA,                  // SRC_ALPHA, 1-SRC_ALPHA, ONE, 1-SRC_ALPHA
+  WR_BLEND_PREMULT,                // ONE, 1-SRC_ALPHA
+  WR_BLEND_ZERO_INV_SRC_COLOR,     // ZERO, 1-SRC_COLOR
+  WR_BLEND_ZERO_INV_SRC_COLOR_A1,  // ZERO, 1-SRC_COLOR, ZERO, ONE
+  WR_BLEND_DEST_OUT,               // ZERO, 1-SRC_ALPHA
+  WR_BLEND_MULTIPLY,               // ZERO, SRC_COLOR
+  WR_BLEND_ADD,                    // ONE, ONE
+  WR_BLEND_ADD_A_OVER,             // ONE, ONE, ONE, 1-SRC_ALPHA
+  WR_BLEND_INV_DST_A,              // 1-DST_ALPHA, ONE, ZERO, ONE
+  WR_BLEND_CONST_COLOR,            // CONSTANT_COLOR, 1-SRC_COLOR
+  WR_BLEND_DUAL_SRC,               // ONE, 1-SRC1_COLOR
+  WR_BLEND_MIN, WR_BLEND_MAX,
+  WR_BLEND_SCREEN,                 // ONE, 1-SRC_COLOR
+  WR_BLEND_DROP_SHADOW, WR_BLEND_SUBPIXEL_TEXT,
+  WR_BLEND_UNSUPPORTED
+};
+
+struct WrTexDesc {
+  const void* ptr;   // HBM address (nullptr -> swgl's 1x1 transparent null sampler)
+  int32_t width, height;
+  int32_t stride;    // in elements: bytes/4 for bpp>=4, bytes/2 for bpp 2, bytes for bpp 1 (gl.cc:883-899)
+  int16_t format;    // WrTexFormat
+  int16_t linear;    // TextureFilter::LINEAR (and width >= 2, gl.cc:874-880)
+};
+
+enum WrDrawFlags {
+  WR_DF_DEPTH_TEST = 1,    // depth test on AND depth attachment present AND cleared (rasterize.h:962)
+  WR_DF_DEPTH_WRITE = 2,
+  WR_DF_DEPTH_LESS = 4,    // GL_LESS instead of GL_LEQUAL
+  WR_DF_CLEAR_COLOR = 8,   // WR_SH_CLEAR_OP
+  WR_DF_CLEAR_DEPTH = 16,
+};
+
+struct WrDrawDesc {
+  int32_t shader;        // WrShader
+  int32_t target;        // index into WrTargetDesc[]
+  int32_t first_prim;    // global prim index of instance 0
+  int32_t count;         // instances
+  int32_t blend;         // WrBlend (WR_BLEND_NONE when GL_BLEND disabled)
+  int32_t flags;         // WrDrawFlags
+  int32_t clip[4];       // apply_scissor(colortex) in target pixels: x0,y0,x1,y1 (gl.cc:857-864)
+  float vp_origin[2];    // viewport.origin - colortex.offset   (rasterize.h:1571-1573)
+  float vp_size[2];
+  float transform[16];   // uTransform, column-major
+  float quad[8];         // aPosition of the 4 SIMD lanes in swgl lane order 0,1,3,2 (gl.cc:1031-1039)
+  uint32_t clear_color;  // WR_SH_CLEAR_OP: BGRA8 / R8 value
+  uint32_t clear_depth;  // WR_SH_CLEAR_OP: 24-bit depth
+  uint32_t blend_color[2];  // ctx->blendcolor as 4 x u16 (b,g,r,a)
+  uint64_t inst_offset;  // byte offset of this draw's instance data in the arena
+  int32_t inst_stride;
+  int32_t attr_off[8];   // byte offset of the shader's k-th instance attribute, -1 = unbound (zeros)
+  int32_t attr_bytes[8]; // bytes provided by the VAO for that attribute (VertexAttrib::size)
+  WrTexDesc tex[WR_MAX_TEX];
+};
+
+struct WrTargetDesc {
+  void* color;          // HBM
+  uint32_t* depth;      // HBM flat depth (u32 per pixel) or nullptr
+  int32_t width, height;
+  int32_t stride;       // bytes
+  int32_t format;       // WR_FMT_RGBA8 | WR_FMT_R8
+  int32_t load_color;   // 1: bins start from HBM content, 0: from init_color
+  uint32_t init_color;
+  int32_t load_depth;   // 1: depth bins start from `depth`, 0: from init_depth
+  uint32_t init_depth;
+  int32_t store_depth;  // 1: write depth back to `depth`
+  int32_t bins_x, bins_y;
+  int32_t first_bin;    // global bin index of bin (0,0)
+  int32_t first_prim, end_prim;  // global prim range of this target
+  int32_t word_base;    // first u64 word of this target's bin masks
+  int32_t words_per_bin;
+  int32_t row_begin, row_end;    // bin rows owned by this process (multi-GPU strip sharding)
+};
+
+enum WrPrimKind {
+  WR_PK_NONE = 0,       // culled / nothing to draw
+  WR_PK_CLEAR,
+  WR_PK_SOLID,          // swgl_commitSolid* / flat fragment colour
+  WR_PK_TEX_RGBA8,      // swgl_commitTexture*RGBA8 family (rect, axis-aligned uv)
+  WR_PK_UNSUPPORTED,
+};
+
+enum WrPrimFlags {
+  WR_PF_DEPTH_TEST = 1, WR_PF_DEPTH_WRITE = 2, WR_PF_DEPTH_LESS = 4,
+  WR_PF_CLEAR_COLOR = 8, WR_PF_CLEAR_DEPTH = 16,
+  WR_PF_HAS_COLOR = 32,   // textured: modulate by colour (applyColor)
+  WR_PF_TAIL_CLAMP = 64,     // main(): clamp uv to uv_bounds before sampling
+  WR_PF_TAIL_MODULATE = 128, // main(): multiply texel by fcolor
+};
+
+// Output of the vertex stage: everything the raster stage needs for one quad.
+struct WrPrim {
+  int32_t x0, y0, x1, y1;   // covered pixel rect [x0,x1) x [y0,y1) in target pixels (already clipped)
+  uint32_t z;               // uint32(0xFFFFFF * screenZ)  (rasterize.h:1593)
+  int16_t kind;             // WrPrimKind
+  int16_t blend;            // WrBlend
+  int32_t flags;            // WrPrimFlags
+  int32_t draw;             // index of the WrDrawDesc (textures, clip)
+  uint32_t color[2];        // packed WideRGBA8 (b,g | r,a as u16 pairs)
+  // textured prims: edge interpolants (Edge, rasterize.h:850-886) of the
+  // screen-left and screen-right edges at the first covered row, per-row
+  // slopes, and the unclipped edge x positions
+  float uvL0[2], uvLs[2], uvR0[2], uvRs[2];
+  float xl, xr;
+  float uv_bounds[4];       // uv_rect passed to swgl_commitTexture*
+  float fcolor[4];          // float colour for the fragment-shader (tail) path
+  int32_t tex_slot;         // sampler slot
+  int32_t pad;
+};
+
+struct WrFlushParams {
+  int32_t n_draws, n_targets, n_prims, n_bins;
+  int32_t n_words;          // total u64 mask words
+  int32_t pad[3];
+};
+
+// statistics mirrored into WrhipStats (include/wrhip.h)
+struct WrUnsupportedCounters {
+  uint32_t unsupported_prims;
+  uint32_t perspective_prims;
+};

@@ -1,0 +1,80 @@
+"""Frame harness: records the C-ABI call stream of rendering a scene and
+replays it natively -- the stand-in for `wrench png` / `wrench perf`
+(wrench/src/main.rs:517-814, perf.rs:198-270).
+
+  setup trace  CreateContext .. first frame .. Finish   (resource creation, untimed)
+  frame trace  one steady-state frame .. Finish         (what `perf` times: the
+               full tile-raster + composite stream is re-issued every iteration,
+               see BASELINE.md §1 on why wrench's own loop would only re-composite)
+  read trace   ReadPixels of the window (reftest.rs:306-319)
+"""
+import numpy as np
+from . import glconst as G
+from .glapi import GL
+from .renderer import Renderer
+from .trace import Trace, NativeReplayer, TAG_SCRATCH
+
+
+class RecordedScene:
+    def __init__(self, width, height, setup, frame, read, read_offset):
+        self.width, self.height = width, height
+        self.setup, self.frame, self.read, self.read_offset = setup, frame, read, read_offset
+
+
+def record_scene(recording_backend_path, frame):
+    """Run `frame` twice through the Python Renderer mirror against
+    `recording_backend_path`, capturing the call stream."""
+    tr = Trace()
+    gl = GL(recording_backend_path, tr)
+    r = Renderer(gl, frame.width, frame.height)
+    r.render(frame)
+    r.finish()
+    setup = tr.serialize()
+    tr2 = Trace()
+    tr2.scratch = 0
+    gl.trace = tr2
+    r.render(frame)
+    r.finish()
+    frame_bytes = tr2.serialize()
+    tr3 = Trace()
+    gl.trace = tr3
+    px = r.read_pixels()
+    read_bytes = tr3.serialize()
+    read_off = [v for (_, args) in tr3.calls for (tag, _, v) in args if tag == TAG_SCRATCH][-1]
+    gl.trace = None
+    r.destroy()
+    return RecordedScene(frame.width, frame.height, setup, frame_bytes, read_bytes, read_off), px
+
+
+class ScenePlayer:
+    """Replays a RecordedScene against a backend library natively."""
+
+    def __init__(self, backend_path, scene):
+        self.scene = scene
+        self.rp = NativeReplayer(backend_path)
+        self.rp.exec(scene.setup)
+
+    def frames(self, warmup, iters):
+        return self.rp.loop(self.scene.frame, warmup, iters)
+
+    def read_pixels(self):
+        self.rp.exec(self.scene.read)
+        n = self.scene.width * self.scene.height * 4
+        buf = self.rp.scratch(self.scene.read_offset, n)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.scene.height, self.scene.width, 4).copy()
+
+    def symbol(self, name):
+        return self.rp.symbol(name)
+
+
+def render_direct(backend_path, frame, frames=1):
+    """Render through the Python mirror without tracing; returns RGBA8 pixels."""
+    gl = GL(backend_path)
+    r = Renderer(gl, frame.width, frame.height)
+    for _ in range(frames):
+        r.render(frame)
+    r.finish()
+    px = r.read_pixels()
+    stats = gl.stats() if gl.is_wrhip else None
+    r.destroy()
+    return px, stats
