@@ -589,6 +589,7 @@ void flush_work(const std::vector<int>& sel_in) {
   std::vector<WrTargetDesc> targets(n_targets);
   std::vector<uint8_t> inst;
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0, bins_rgba = 0;
+  bool any_depth = false;
   uint64_t algo_bytes = 0, pixels = 0;
   for (int oi = 0; oi < n_targets; oi++) {
     TargetWork& w = c->work[sel[oi]];
@@ -623,6 +624,7 @@ void flush_work(const std::vector<int>& sel_in) {
         continue;
       }
       any_kept = true;
+      if (d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) any_depth = true;
       d.first_prim = prim_cursor;
       prim_cursor += d.count;
       draws.push_back(d);
@@ -739,12 +741,16 @@ void flush_work(const std::vector<int>& sel_in) {
 #endif
     if (c->profiling) wrrt::event_record(&c->ev_a, c->stream);
     if (bins_rgba > 0) {
-      WR_LAUNCH(wr_raster_kernel<WR_FMT_RGBA8>, bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
-                (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, 0);
+      if (any_depth)
+        WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, true>), bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
+                  (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, 0);
+      else
+        WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, false>), bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
+                  (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, 0);
       c->stats.kernel_launches++; c->stats.raster_launches++;
     }
     if (n_bins > bins_rgba) {
-      WR_LAUNCH(wr_raster_kernel<WR_FMT_R8>, n_bins - bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
+      WR_LAUNCH((wr_raster_kernel<WR_FMT_R8, false>), n_bins - bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
                 (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, bins_rgba);
       c->stats.kernel_launches++; c->stats.raster_launches++;
     }

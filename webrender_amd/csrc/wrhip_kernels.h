@@ -824,13 +824,56 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y,
   return s;
 }
 
-template <int FMT>
+// Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
+// Kept out of line so the fast paths below stay small and the 16 pixels of a
+// lane stay in registers.
+__device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const WrDrawDesc* D, int x, int y, uint32_t dstp) {
+  const WrPrim& P = *Pp;
+  WrWide src;
+  if (P.kind == WR_PK_SOLID) {
+    src.bg = P.color[0]; src.ra = P.color[1];
+  } else {
+    bool ok;
+    src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y, ok);
+    int n = x - P.x0, len = P.x1 - P.x0;
+    bool in_span = len >= 4 && n < (len & ~3);
+    if (in_span && (P.flags & WR_PF_HAS_COLOR)) src = wr_apply_color(src, P.color);
+  }
+  return wr_blend_rgba8(P.blend, dstp, src, D);
+}
+
+// min of two 16-bit fields packed in a u32 (v_pk_min_u16)
+WR_DEVICE uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
+#ifdef WRHIP_HOSTSIM
+  uint32_t lo = (a & 0xFFFF) < (b & 0xFFFF) ? (a & 0xFFFF) : (b & 0xFFFF);
+  uint32_t hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+  return lo | (hi << 16);
+#else
+  typedef unsigned short wr_us2 __attribute__((ext_vector_type(2)));
+  wr_us2 r = __builtin_elementwise_min(__builtin_bit_cast(wr_us2, a), __builtin_bit_cast(wr_us2, b));
+  return __builtin_bit_cast(uint32_t, r);
+#endif
+}
+WR_DEVICE uint32_t wr_mul24(uint32_t a, uint32_t b) {
+#ifdef WRHIP_HOSTSIM
+  return a * b;
+#else
+  return __umul24(a, b);
+#endif
+}
+
+// Pixels are held as two registers of 2 x 16-bit fields: lo = (B, R), hi = (G, A)
+// of the BGRA8 texel -- i.e. WideRGBA8 with the channels paired so that one
+// 32-bit multiply serves two channels (fields never carry into each other:
+// 255 * 256 < 2^16).
+#define WR_M8 0x00FF00FFu
+
+template <int FMT, bool DEPTH>
 __global__ void __launch_bounds__(256)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const unsigned long long* __restrict__ masks, int bin_offset) {
   const int bin = blockIdx.x + bin_offset;
-  // locate the target owning this bin
   int t = 0;
   {
     int lo = 0, hi = n_targets - 1;
@@ -850,30 +893,39 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
   const int px = wx0 + (lane & 15) * 4;
   const int py = wy0 + (lane >> 4);
   constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
+  const bool vec_ok = BPP == 4 && px + 4 <= T.width && ((T.stride & 15) == 0);
 
-  uint32_t col[4][4];
-  uint32_t dep[4][4];
+  // RGBA8: lo/hi channel pairs; R8: value in lo
+  uint32_t plo[16], phi[16], dep[16];
   // ---- initial pixel state ---------------------------------------------
+#pragma unroll
   for (int j = 0; j < 4; j++) {
-    int y = py + 4 * j;
-    for (int i = 0; i < 4; i++) { col[j][i] = T.init_color; dep[j][i] = T.init_depth; }
-    if (y < T.height) {
-      if (T.load_color) {
-        const uint8_t* rowp = (const uint8_t*)T.color + (size_t)y * T.stride;
-        if (BPP == 4) {
-          if (px + 4 <= T.width && ((T.stride & 15) == 0)) {
-            uint4 v = *(const uint4*)(rowp + (size_t)px * 4);
-            col[j][0] = v.x; col[j][1] = v.y; col[j][2] = v.z; col[j][3] = v.w;
-          } else {
-            for (int i = 0; i < 4; i++) if (px + i < T.width) col[j][i] = ((const uint32_t*)rowp)[px + i];
-          }
+    const int y = py + 4 * j;
+    uint32_t c[4] = {T.init_color, T.init_color, T.init_color, T.init_color};
+    if (T.load_color && y < T.height) {
+      const uint8_t* rowp = (const uint8_t*)T.color + (size_t)y * T.stride;
+      if (BPP == 4) {
+        if (vec_ok) {
+          uint4 v = *(const uint4*)(rowp + (size_t)px * 4);
+          c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
         } else {
-          for (int i = 0; i < 4; i++) if (px + i < T.width) col[j][i] = rowp[px + i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) if (px + i < T.width) c[i] = ((const uint32_t*)rowp)[px + i];
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (px + i < T.width) c[i] = rowp[px + i];
       }
-      if (T.load_depth && T.depth) {
-        for (int i = 0; i < 4; i++) if (px + i < T.width) dep[j][i] = T.depth[(size_t)y * T.width + px + i];
-      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (BPP == 4) { plo[4 * j + i] = c[i] & WR_M8; phi[4 * j + i] = (c[i] >> 8) & WR_M8; }
+      else { plo[4 * j + i] = c[i]; phi[4 * j + i] = 0; }
+      dep[4 * j + i] = T.init_depth;
+    }
+    if (DEPTH && T.load_depth && T.depth && y < T.height) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (px + i < T.width) dep[4 * j + i] = T.depth[(size_t)y * T.width + px + i];
     }
   }
   // ---- apply every prim of this bin, in submission order -----------------
@@ -881,68 +933,155 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
   for (int w = 0; w < T.words_per_bin; w++) {
     unsigned long long m = mw[w];
     while (m) {
-      int bit = __builtin_ctzll(m);
+      const int bit = __builtin_ctzll(m);
       m &= m - 1;
-      const WrPrim& P = prims[T.first_prim + w * 64 + bit];
+      const WrPrim* Pp = &prims[T.first_prim + w * 64 + bit];
+      const int x0 = Pp->x0, y0 = Pp->y0, x1 = Pp->x1, y1 = Pp->y1;
       // wave-uniform reject against this wave's 64x16 strip
-      if (P.x1 <= wx0 || P.x0 >= wx0 + WR_BIN_W || P.y1 <= wy0 || P.y0 >= wy0 + 16) continue;
-      const int kind = P.kind, blend = P.blend, flags = P.flags;
-      const uint32_t z = P.z;
-      const WrDrawDesc* D = &draws[P.draw];
-      for (int j = 0; j < 4; j++) {
-        int y = py + 4 * j;
-        bool rowin = y >= P.y0 && y < P.y1;
-        for (int i = 0; i < 4; i++) {
-          int x = px + i;
-          bool in = rowin && x >= P.x0 && x < P.x1;
-          if (!in) continue;
-          if (kind == WR_PK_CLEAR) {
-            if (flags & WR_PF_CLEAR_COLOR) col[j][i] = P.color[0];
-            if (flags & WR_PF_CLEAR_DEPTH) dep[j][i] = z;
-            continue;
-          }
-          if (flags & WR_PF_DEPTH_TEST) {
-            bool pass = (flags & WR_PF_DEPTH_LESS) ? (z < dep[j][i]) : (z <= dep[j][i]);
-            if (!pass) continue;
-            if (flags & WR_PF_DEPTH_WRITE) dep[j][i] = z;
-          }
-          if (FMT == WR_FMT_RGBA8) {
-            WrWide src;
-            if (kind == WR_PK_SOLID) {
-              src.bg = P.color[0]; src.ra = P.color[1];
-            } else {
-              bool ok;
-              src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y, ok);
-              int n = x - P.x0, len = P.x1 - P.x0;
-              bool in_span = len >= 4 && n < (len & ~3);
-              if (in_span && (flags & WR_PF_HAS_COLOR)) src = wr_apply_color(src, P.color);
+      if (x1 <= wx0 || x0 >= wx0 + WR_BIN_W || y1 <= wy0 || y0 >= wy0 + 16) continue;
+      const int kind = Pp->kind, blend = Pp->blend, flags = Pp->flags;
+      const uint32_t z = Pp->z;
+      // per-lane coverage
+      bool cx[4], cy[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) cy[j] = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
+
+      if (kind == WR_PK_CLEAR) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const bool in = cx[i] && cy[j];
+            if (flags & WR_PF_CLEAR_COLOR) {
+              uint32_t c = Pp->color[0];
+              uint32_t nlo = BPP == 4 ? (c & WR_M8) : c, nhi = BPP == 4 ? ((c >> 8) & WR_M8) : 0;
+              plo[4 * j + i] = in ? nlo : plo[4 * j + i];
+              phi[4 * j + i] = in ? nhi : phi[4 * j + i];
             }
-            col[j][i] = wr_blend_rgba8(blend, col[j][i], src, D);
+            if (DEPTH && (flags & WR_PF_CLEAR_DEPTH)) dep[4 * j + i] = in ? z : dep[4 * j + i];
+          }
+        continue;
+      }
+      const bool dtest = DEPTH && (flags & WR_PF_DEPTH_TEST);
+      const bool dwrite = (flags & WR_PF_DEPTH_WRITE) != 0, dless = (flags & WR_PF_DEPTH_LESS) != 0;
+
+      if (FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
+        // ---- fast paths: swgl_commitSolidRGBA8 with no blend / premultiplied alpha ----
+        const uint32_t c0 = Pp->color[0], c1 = Pp->color[1];   // (b,g) (r,a) u16 pairs
+        // pack() saturation of the constant source, then channel pairing
+        const uint32_t sb = wr_pack1(c0 & 0xFFFF), sg = wr_pack1(c0 >> 16), sr = wr_pack1(c1 & 0xFFFF), sa = wr_pack1(c1 >> 16);
+        if (blend == WR_BLEND_NONE) {
+          const uint32_t slo = sb | (sr << 16), shi = sg | (sa << 16);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              bool in = cx[i] && cy[j];
+              if (dtest) {
+                const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
+                in = in && pass;
+                if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
+              }
+              plo[4 * j + i] = in ? slo : plo[4 * j + i];
+              phi[4 * j + i] = in ? shi : phi[4 * j + i];
+            }
+        } else {
+          // src + dst - ((dst * (a + 1)) >> 8), u16 lanes, then pack() clamp to 255.
+          // The unsaturated source lanes take part in the sum exactly as in swgl.
+          const uint32_t ulo = (c0 & 0xFFFF) | ((c1 & 0xFFFF) << 16);   // (b, r) raw u16
+          const uint32_t uhi = (c0 >> 16) | (c1 & 0xFFFF0000u);          // (g, a) raw u16
+          const uint32_t araw = c1 >> 16;
+          const bool simple = ((c0 | c1) & 0xFF00FF00u) == 0;           // all source lanes <= 255
+          if (simple) {
+            const uint32_t k = araw + 1;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                bool in = cx[i] && cy[j];
+                if (dtest) {
+                  const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
+                  in = in && pass;
+                  if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
+                }
+                const uint32_t dl = plo[4 * j + i], dh = phi[4 * j + i];
+                uint32_t nl = dl + ulo - ((wr_mul24(dl, k) >> 8) & WR_M8);
+                uint32_t nh = dh + uhi - ((wr_mul24(dh, k) >> 8) & WR_M8);
+                nl = wr_pk_min_u16(nl, WR_M8);
+                nh = wr_pk_min_u16(nh, WR_M8);
+                plo[4 * j + i] = in ? nl : dl;
+                phi[4 * j + i] = in ? nh : dh;
+              }
           } else {
-            // R8 target: pack_pixels_R8(v_color.x) (blend.h:67-73)
-            uint32_t src = P.color[1] & 0xFFFF;  // r lane
-            col[j][i] = wr_blend_r8(blend, col[j][i], src);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                bool in = cx[i] && cy[j];
+                if (dtest) {
+                  const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
+                  in = in && pass;
+                  if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
+                }
+                if (in) {
+                  uint32_t r = wr_generic_pixel_rgba8(Pp, &draws[Pp->draw], px + i, py + 4 * j,
+                                                      plo[4 * j + i] | (phi[4 * j + i] << 8));
+                  plo[4 * j + i] = r & WR_M8; phi[4 * j + i] = (r >> 8) & WR_M8;
+                }
+              }
           }
         }
+        continue;
       }
+      // ---- generic path ----
+      const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          bool in = cx[i] && cy[j];
+          if (dtest) {
+            const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
+            in = in && pass;
+            if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
+          }
+          if (in) {
+            if (FMT == WR_FMT_RGBA8) {
+              uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + i, py + 4 * j, plo[4 * j + i] | (phi[4 * j + i] << 8));
+              plo[4 * j + i] = r & WR_M8; phi[4 * j + i] = (r >> 8) & WR_M8;
+            } else {
+              // R8 target: pack_pixels_R8(v_color.x) (blend.h:67-73)
+              plo[4 * j + i] = wr_blend_r8(blend, plo[4 * j + i], Pp->color[1] & 0xFFFF);
+            }
+          }
+        }
     }
   }
   // ---- write back ------------------------------------------------------------
+#pragma unroll
   for (int j = 0; j < 4; j++) {
-    int y = py + 4 * j;
+    const int y = py + 4 * j;
     if (y >= T.height) continue;
     uint8_t* rowp = (uint8_t*)T.color + (size_t)y * T.stride;
     if (BPP == 4) {
-      if (px + 4 <= T.width && ((T.stride & 15) == 0)) {
-        *(uint4*)(rowp + (size_t)px * 4) = make_uint4(col[j][0], col[j][1], col[j][2], col[j][3]);
+      uint32_t c[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) c[i] = plo[4 * j + i] | (phi[4 * j + i] << 8);
+      if (vec_ok) {
+        *(uint4*)(rowp + (size_t)px * 4) = make_uint4(c[0], c[1], c[2], c[3]);
       } else {
-        for (int i = 0; i < 4; i++) if (px + i < T.width) ((uint32_t*)rowp)[px + i] = col[j][i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (px + i < T.width) ((uint32_t*)rowp)[px + i] = c[i];
       }
     } else {
-      for (int i = 0; i < 4; i++) if (px + i < T.width) rowp[px + i] = (uint8_t)col[j][i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (px + i < T.width) rowp[px + i] = (uint8_t)plo[4 * j + i];
     }
-    if (T.store_depth && T.depth) {
-      for (int i = 0; i < 4; i++) if (px + i < T.width) T.depth[(size_t)y * T.width + px + i] = dep[j][i];
+    if (DEPTH && T.store_depth && T.depth) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (px + i < T.width) T.depth[(size_t)y * T.width + px + i] = dep[4 * j + i];
     }
   }
 }

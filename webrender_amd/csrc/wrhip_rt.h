@@ -23,6 +23,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 struct wr_dim3 { unsigned x, y, z; };
