@@ -9,6 +9,7 @@
 // (a pending target gets sampled, read back, overwritten from the host, or
 // Finish()).  See DESIGN.md §3-§4.
 #include <vector>
+#include <map>
 #include <algorithm>
 #include <time.h>
 
@@ -211,8 +212,14 @@ struct Context {
   int arena_index = 0;
   uint8_t* darena = nullptr; size_t darena_size = 0;
   WrPrim* dprims = nullptr; size_t dprims_cap = 0;
+  WrRec* drecs = nullptr;
   unsigned long long* dmasks = nullptr; size_t dmasks_cap = 0;
   WrUnsupportedCounters* dcounters = nullptr;
+  // HBM pool for texture storage: per-frame textures (GpuBufferF/I, render
+  // targets) are recycled without hipMalloc/hipFree or a device sync; reuse is
+  // safe because every consumer runs on this context's single stream.
+  std::multimap<size_t, void*> pool;
+  size_t pool_bytes = 0;
   // upload staging ring (pinned)
   uint8_t* staging = nullptr; size_t staging_size = 0, staging_pos = 0;
   // profiling
@@ -370,12 +377,40 @@ void flush_except(GLuint keep) {
 void sync_texture_for_write(Texture& t) { if (t.pending_read || t.pending_write) flush_all(); }
 void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); }
 
+size_t pool_round(size_t n) {
+  size_t g = n <= (1u << 20) ? 4096 : (size_t(1) << 16);
+  return (n + g - 1) / g * g;
+}
+void* pool_alloc(size_t n, size_t* actual) {
+  Context* c = ctx;
+  size_t r = pool_round(n);
+  auto it = c->pool.lower_bound(r);
+  if (it != c->pool.end() && it->first <= r + r / 4) {
+    void* p = it->second; *actual = it->first;
+    c->pool_bytes -= it->first;
+    c->pool.erase(it);
+    return p;
+  }
+  *actual = r;
+  return wrrt::dev_alloc(r + 64);
+}
+void pool_free(void* p, size_t n) {
+  Context* c = ctx;
+  c->pool.insert(std::make_pair(n, p));
+  c->pool_bytes += n;
+  while (c->pool_bytes > (size_t(2) << 30) && !c->pool.empty()) {   // trim: keep at most 2 GiB idle
+    auto it = --c->pool.end();
+    wrrt::stream_sync(c->stream);
+    wrrt::dev_free(it->second);
+    c->pool_bytes -= it->first;
+    c->pool.erase(it);
+  }
+}
+
 void free_texture_storage(Texture& t) {
   sync_texture_for_write(t);
   if (t.dptr) {
-    // storage may still be in use by already-enqueued kernels/copies
-    wrrt::stream_sync(ctx->stream);
-    wrrt::dev_free(t.dptr);
+    pool_free(t.dptr, t.dsize);
     t.dptr = nullptr; t.dsize = 0;
   }
   free(t.hmirror); t.hmirror = nullptr; t.hmirror_size = 0;
@@ -394,9 +429,10 @@ bool allocate_texture(Texture& t) {
   }
   if (size == 0) return true;
   if (!t.dptr || size > t.dsize) {
-    if (t.dptr) { wrrt::stream_sync(ctx->stream); wrrt::dev_free(t.dptr); }
-    t.dptr = wrrt::dev_alloc(size + 64);
-    t.dsize = size;
+    if (t.dptr) pool_free(t.dptr, t.dsize);
+    size_t actual = 0;
+    t.dptr = pool_alloc(size, &actual);
+    t.dsize = actual;
     if (!t.dptr) return false;
   }
   return true;
@@ -563,8 +599,10 @@ Context::~Context() {
   flush_all();
   wrrt::stream_sync(stream);
   for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
+  for (auto& kv : pool) wrrt::dev_free(kv.second);
+  pool.clear();
   for (int i = 0; i < NARENA; i++) { wrrt::pinned_free(harena[i]); wrrt::event_destroy(arena_event[i]); }
-  wrrt::dev_free(darena); wrrt::dev_free(dprims); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
+  wrrt::dev_free(darena); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::stream_destroy(stream);
@@ -588,6 +626,7 @@ void flush_work(const std::vector<int>& sel_in) {
   std::vector<WrDrawDesc> draws;
   std::vector<WrTargetDesc> targets(n_targets);
   std::vector<uint8_t> inst;
+  std::vector<int> cand;   // prims whose shader may sample a colour texture (copy classification)
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0, bins_rgba = 0;
   bool any_depth = false;
   uint64_t algo_bytes = 0, pixels = 0;
@@ -626,6 +665,9 @@ void flush_work(const std::vector<int>& sel_in) {
       any_kept = true;
       if (d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) any_depth = true;
       d.first_prim = prim_cursor;
+      if ((d.shader == WR_SH_COMPOSITE || d.shader == WR_SH_COMPOSITE_FAST || d.shader == WR_SH_PS_QUAD_TEXTURED) &&
+          d.tex[WR_S_COLOR0].ptr)
+        for (int k = 0; k < d.count; k++) cand.push_back(prim_cursor + k);
       prim_cursor += d.count;
       draws.push_back(d);
     }
@@ -665,7 +707,8 @@ void flush_work(const std::vector<int>& sel_in) {
     size_t off_draws = 0;
     size_t off_targets = (off_draws + sizeof(WrDrawDesc) * nd + 255) & ~size_t(255);
     size_t off_inst = (off_targets + sizeof(WrTargetDesc) * n_targets + 255) & ~size_t(255);
-    size_t total = off_inst + inst.size() + 256;
+    size_t off_cand = (off_inst + inst.size() + 255) & ~size_t(255);
+    size_t total = off_cand + cand.size() * sizeof(int) + 256;
     int ai = c->arena_index; c->arena_index = (ai + 1) % Context::NARENA;
     if (c->arena_used[ai]) wrrt::event_sync(&c->arena_event[ai]);
     if (c->harena_size[ai] < total) {
@@ -683,6 +726,7 @@ void flush_work(const std::vector<int>& sel_in) {
     if (nd) memcpy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     memcpy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
     if (!inst.empty()) memcpy(h + off_inst, inst.data(), inst.size());
+    if (!cand.empty()) memcpy(h + off_cand, cand.data(), cand.size() * sizeof(int));
     wrrt::h2d(c->darena, h, total, c->stream);
     wrrt::event_record(&c->arena_event[ai], c->stream);
     c->arena_used[ai] = true;
@@ -694,6 +738,8 @@ void flush_work(const std::vector<int>& sel_in) {
       wrrt::dev_free(c->dprims);
       c->dprims_cap = (size_t)(n_prims + 1) * 2;
       c->dprims = (WrPrim*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrPrim));
+      wrrt::dev_free(c->drecs);
+      c->drecs = (WrRec*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrRec));
     }
     if (c->dmasks_cap < (size_t)n_words + 1) {
       wrrt::stream_sync(c->stream);
@@ -706,7 +752,12 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(c->darena + off_targets);
     const uint8_t* dinst = c->darena + off_inst;
     if (n_prims > 0) {
-      WR_LAUNCH(wr_vertex_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, n_prims, c->dcounters);
+      WR_LAUNCH(wr_vertex_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, n_prims, c->dcounters);
+      if (!cand.empty()) {
+        WR_LAUNCH(wr_classify_kernel, (int)cand.size(), 64, c->stream, ddraws, c->dprims, c->drecs,
+                  (const int*)(c->darena + off_cand), (int)cand.size());
+        c->stats.kernel_launches++;
+      }
       WR_LAUNCH(wr_bin_kernel, (n_prims + 255) / 256, 256, c->stream, (const WrPrim*)c->dprims, n_prims, ddraws, dtargets, c->dmasks);
       c->stats.kernel_launches += 2;
     }
@@ -743,15 +794,15 @@ void flush_work(const std::vector<int>& sel_in) {
     if (bins_rgba > 0) {
       if (any_depth)
         WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, true>), bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
-                  (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, 0);
+                  (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const unsigned long long*)c->dmasks, 0);
       else
         WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, false>), bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
-                  (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, 0);
+                  (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const unsigned long long*)c->dmasks, 0);
       c->stats.kernel_launches++; c->stats.raster_launches++;
     }
     if (n_bins > bins_rgba) {
       WR_LAUNCH((wr_raster_kernel<WR_FMT_R8, false>), n_bins - bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
-                (const WrPrim*)c->dprims, (const unsigned long long*)c->dmasks, bins_rgba);
+                (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const unsigned long long*)c->dmasks, bins_rgba);
       c->stats.kernel_launches++; c->stats.raster_launches++;
     }
     if (c->profiling) {

@@ -404,6 +404,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
                               WrUnsupportedCounters* cnt) {
   P.kind = WR_PK_NONE;
   P.draw = draw_index;
+  P.color[0] = P.color[1] = 0; P.z = 0; P.tex_slot = 0;
   P.blend = (int16_t)d.blend;
   P.flags = d.flags & (WR_PF_DEPTH_TEST | WR_PF_DEPTH_WRITE | WR_PF_DEPTH_LESS);
   P.x0 = P.y0 = P.x1 = P.y1 = 0;
@@ -489,69 +490,6 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     P.uvLs[0] = lsu; P.uvLs[1] = lsv; P.uvRs[0] = rsu; P.uvRs[1] = rsv;
     P.xl = xmin; P.xr = xmax;
   }
-}
-
-__global__ void wr_vertex_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
-                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
-                                 int n_prims, WrUnsupportedCounters* cnt) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n_prims) return;
-  // binary search for the draw containing this instance
-  int lo = 0, hi = n_draws - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (draws[mid].first_prim <= gid) lo = mid; else hi = mid - 1;
-  }
-  const WrDrawDesc& d = draws[lo];
-  int inst = gid - d.first_prim;
-  WrPrim P;
-  if (d.shader == WR_SH_CLEAR_OP) {
-    P.kind = WR_PK_CLEAR; P.blend = WR_BLEND_NONE; P.draw = lo; P.z = d.clear_depth;
-    P.flags = d.flags & (WR_PF_CLEAR_COLOR | WR_PF_CLEAR_DEPTH);
-    P.x0 = d.clip[0]; P.y0 = d.clip[1]; P.x1 = d.clip[2]; P.y1 = d.clip[3];
-    P.color[0] = d.clear_color; P.color[1] = 0;
-    if (P.x1 <= P.x0 || P.y1 <= P.y0) P.kind = WR_PK_NONE;
-    prims[gid] = P;
-    return;
-  }
-  WrVsOut o;
-  o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
-  switch (d.shader) {
-    case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
-    case WR_SH_BRUSH_SOLID:
-    case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush_solid(d, arena, inst, o); break;
-    case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
-    case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
-    case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
-    default:
-      P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo;
-      prims[gid] = P;
-      return;
-  }
-  wr_finish_prim(d, lo, o, P, cnt);
-  prims[gid] = P;
-}
-
-// ---------------------------------------------------------------------------
-// Binning: bit (p - T.first_prim) of bin b's mask row <=> prim p touches bin b.
-__global__ void wr_bin_kernel(const WrPrim* __restrict__ prims, int n_prims,
-                              const WrDrawDesc* __restrict__ draws,
-                              const WrTargetDesc* __restrict__ targets,
-                              unsigned long long* __restrict__ masks) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n_prims) return;
-  const WrPrim& P = prims[gid];
-  if (P.kind == WR_PK_NONE || P.kind == WR_PK_UNSUPPORTED) return;
-  const WrTargetDesc& T = targets[draws[P.draw].target];
-  int bx0 = wr_imax(P.x0, 0) / WR_BIN_W, bx1 = (wr_imin(P.x1, T.width) - 1) / WR_BIN_W;
-  int by0 = wr_imax(P.y0, 0) / WR_BIN_H, by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
-  by0 = wr_imax(by0, T.row_begin); by1 = wr_imin(by1, T.row_end - 1);
-  int rel = gid - T.first_prim;
-  unsigned long long bit = 1ull << (rel & 63);
-  int word = rel >> 6;
-  for (int by = by0; by <= by1; by++)
-    for (int bx = bx0; bx <= bx1; bx++)
-      atomicOr(&masks[(size_t)T.word_base + (size_t)(by * T.bins_x + bx) * T.words_per_bin + word], bit);
 }
 
 // ---------------------------------------------------------------------------
@@ -703,106 +641,126 @@ WR_DEVICE WrWide wr_sample_linear_rgba8(const WrTexDesc& t, int qx, int qy) {
 //   x = 64*bx + 4*(l & 15) + i,   y = 64*by + 16*w + (l >> 4) + 4*j,  i,j in 0..3
 // i.e. for a fixed j the wave touches 4 consecutive rows x 256 contiguous bytes.
 
-struct WrTexRowSetup {   // per (prim,row) setup of swgl_commitTexture*RGBA8
-  int nearest;           // LINEAR_FILTER_NEAREST decision (needsTextureLinear)
-  int span_main;         // pixels [span_main, len) of the span go through main()
-  int ix, minX, maxX;    // nearest-fast
-  size_t row;            // row offset (elements)
-  float u0, v0, du, dv;  // uv at span start / per pixel step
+// Per-(prim,row) setup of swgl_commitTexture*RGBA8 as seen by draw_span:
+// interpolants at the span start, the filter decision of needsTextureLinear /
+// needsNearestFallback, and the nearest-fast row/column clamps.
+struct WrTexRow {
+  float ou, ov, su, sv;  // uv at span start, per-pixel step (rasterize.h:1003-1017)
+  int len, span;         // span length; pixels [0,span) go through draw_span, the rest through main()
+  int filter;            // 0 nearest-fast, 1 linear fallback, 2 upscale, 3 fast, 4 downscale, -1 unsupported
+  int ix, minX, maxX;    // nearest-fast: first texel column and clamps
+  int srow;              // nearest-fast: clamped source row
 };
 
-// One pixel of a WR_PK_TEX_RGBA8 prim on row y (returns WideRGBA8 source).
-WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y, bool& ok) {
-  ok = true;
-  // interpolants at this row (Edge::interp) and span start (rasterize.h:1003-1017)
+WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
+  WrTexRow r;
   float k = float(y - P.y0);
   float Lu = P.uvL0[0] + k * P.uvLs[0], Lv = P.uvL0[1] + k * P.uvLs[1];
   float Ru = P.uvR0[0] + k * P.uvRs[0], Rv = P.uvR0[1] + k * P.uvRs[1];
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
-  float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
+  r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
   float start = float(P.x0) + 0.5f - P.xl;
-  float ou = Lu + su * start, ov = Lv + sv * start;
-  int len = P.x1 - P.x0;
-  int n = x - P.x0;
-  int span = len & ~3;
+  r.ou = Lu + r.su * start; r.ov = Lv + r.sv * start;
+  r.len = P.x1 - P.x0;
+  r.span = r.len >= 4 ? (r.len & ~3) : 0;
+  r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
+  if (r.span == 0) return r;
   float W = float(t.width), H = float(t.height);
-  const uint32_t* buf = (const uint32_t*)t.ptr;
-  if (n < span && len >= 4) {
-    // swgl_commitTextureLinear -> needsTextureLinear (swgl_ext.h:553-587)
-    // P lanes: x: ou, ou+su ; y: ov, ov+sv
-    int filter;  // 0 nearest, 1 fallback, 2 upscale, 3 fast, 4 downscale
-    float ou1 = ou + su, ov1 = ov + sv;
-    if (!t.linear) {
-      // swgl_commitTextureNearest: needsNearestFallback (swgl_ext.h:876-880)
-      float py0 = ov * H, py1 = ov1 * H, px0 = ou * W, px1 = ou1 * W;
-      int sp = (span & ~127) + 128;
-      int scaled = int(roundf((px1 - px0) * float(sp)));
-      bool fallback = (py1 - py0) * float(span) >= 0.5f || scaled != sp;
-      filter = fallback ? 1 : 0;
-      if (fallback) { ok = false; return WrWide{0, 0}; }  // blendTextureNearestRepeat<false>: "next"
-    } else if (t.width < 2) {
-      filter = 0;
-    } else if (ov != ov1) {
-      filter = 1;
+  float ou1 = r.ou + r.su, ov1 = r.ov + r.sv;
+  if (!t.linear) {
+    // swgl_commitTextureNearest: needsNearestFallback (swgl_ext.h:876-880)
+    float py0 = r.ov * H, py1 = ov1 * H, px0 = r.ou * W, px1 = ou1 * W;
+    int sp = (r.span & ~127) + 128;
+    int scaled = int(roundf((px1 - px0) * float(sp)));
+    bool fallback = (py1 - py0) * float(r.span) >= 0.5f || scaled != sp;
+    r.filter = fallback ? -1 : 0;   // blendTextureNearestRepeat<false>: "next"
+  } else if (t.width < 2) {
+    r.filter = 0;
+  } else if (r.ov != ov1) {
+    r.filter = 1;
+  } else {
+    // needsTextureLinear (swgl_ext.h:553-587)
+    float px0 = r.ou * W, px1 = ou1 * W, py0 = r.ov * H;
+    int sp = (r.span & ~127) + 128;
+    int scaled = int(roundf((px1 - px0) * float(sp)));
+    if (scaled != sp) {
+      r.filter = (px0 < px1 && px1 - px0 <= 1.0f) ? 2 : (scaled == sp * 2 ? 4 : 1);
+    } else if ((int(px0 * 4.0f + 0.5f) & 3) != 2 || (int(py0 * 4.0f + 0.5f) & 3) != 2) {
+      r.filter = 3;
     } else {
-      float px0 = ou * W, px1 = ou1 * W, py0 = ov * H;
-      int sp = (span & ~127) + 128;
-      int scaled = int(roundf((px1 - px0) * float(sp)));
-      if (scaled != sp) {
-        filter = (px0 < px1 && px1 - px0 <= 1.0f) ? 2 : (scaled == sp * 2 ? 4 : 1);
-      } else if ((int(px0 * 4.0f + 0.5f) & 3) != 2 || (int(py0 * 4.0f + 0.5f) & 3) != 2) {
-        filter = 3;
-      } else {
-        filter = 0;
-      }
+      r.filter = 0;
     }
-    if (filter == 0) {
-      // blendTextureNearestFast (swgl_ext.h:475-537)
-      int ix = int(ou * W), iy = int(ov * H);
-      int minUx = int(P.uv_bounds[0] * W), minUy = int(P.uv_bounds[1] * H);
-      int maxUx = int(P.uv_bounds[2] * W), maxUy = int(P.uv_bounds[3] * H);
-      size_t row = (size_t)wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height) * t.stride;
-      int minX = wr_iclamp(minUx, 0, t.width - 1);
-      int maxX = wr_iclamp(maxUx, minX, t.width - 1);
-      int sx = wr_iclamp(ix + n, minX, maxX);
-      return wr_unpack(buf[row + sx]);
+  }
+  if (r.filter == 0) {
+    // blendTextureNearestFast (swgl_ext.h:475-537)
+    r.ix = int(r.ou * W);
+    int iy = int(r.ov * H);
+    int minUx = int(P.uv_bounds[0] * W), minUy = int(P.uv_bounds[1] * H);
+    int maxUx = int(P.uv_bounds[2] * W), maxUy = int(P.uv_bounds[3] * H);
+    r.srow = wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height);
+    r.minX = wr_iclamp(minUx, 0, t.width - 1);
+    r.maxX = wr_iclamp(maxUx, r.minX, t.width - 1);
+  }
+  return r;
+}
+
+// Quantised (1/128 texel) sample position of a fragment-shader (tail) pixel:
+// its init_interp lane (glsl.h:3084-3089), then step_interp_inputs(drawn).
+WR_DEVICE void wr_tex_tail_uv(const WrPrim& P, const WrTexRow& r, int n, float& cu, float& cv) {
+  float lu = r.ou, lv = r.ov;
+  int lane = (n - r.span) & 3;
+  for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
+  if (r.span > 0) {
+    float chunks = float(r.span) * 0.25f;
+    lu = lu + (r.su * 4.0f) * chunks; lv = lv + (r.sv * 4.0f) * chunks;
+  }
+  cu = lu; cv = lv;
+  if (P.flags & WR_PF_TAIL_CLAMP) {
+    cu = wr_clamp(lu, P.uv_bounds[0], P.uv_bounds[2]); cv = wr_clamp(lv, P.uv_bounds[1], P.uv_bounds[3]);
+  }
+}
+
+// One pixel of a WR_PK_TEX_RGBA8 prim on row y (returns the WideRGBA8 source,
+// colour modulation included).
+WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y) {
+  const WrTexRow r = wr_tex_row(P, t, y);
+  const int n = x - P.x0;
+  const float W = float(t.width), H = float(t.height);
+  const uint32_t* buf = (const uint32_t*)t.ptr;
+  if (n < r.span) {
+    WrWide s;
+    if (r.filter == 0) {
+      int sx = wr_iclamp(r.ix + n, r.minX, r.maxX);
+      s = wr_unpack(buf[(size_t)r.srow * t.stride + sx]);
+    } else {
+      // Linear filters.  All variants evaluate the same 7-bit bilinear formula;
+      // quantised coordinate stepping follows blendTextureLinearFallback
+      // (swgl_ext.h:172-183): per 4-pixel chunk uv += uv_step, lanes offset by
+      // their init_interp value.  (Upscale/Fast/Downscale index arithmetic: "next".)
+      const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+      float ou1 = r.ou + r.su, ov1 = r.ov + r.sv;
+      float q0x = r.ou * W * qs + qo, q1x = ou1 * W * qs + qo;
+      float q0y = r.ov * H * qs + qo, q1y = ov1 * H * qs + qo;
+      float stepx = 4.0f * (q1x - q0x), stepy = 4.0f * (q1y - q0y);
+      float minx = wr_max(P.uv_bounds[0] * W * qs + qo, 0.0f);
+      float miny = wr_max(P.uv_bounds[1] * H * qs + qo, 0.0f);
+      float maxx = wr_max(P.uv_bounds[2] * W * qs + qo, minx);
+      float maxy = wr_max(P.uv_bounds[3] * H * qs + qo, miny);
+      int chunk = n >> 2, lane = n & 3;
+      float lu = r.ou, lv = r.ov;
+      for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
+      float qx = lu * W * qs + qo, qy = lv * H * qs + qo;
+      for (int c = 0; c < chunk; c++) { qx += stepx; qy += stepy; }
+      qx = wr_clamp(qx, minx, maxx); qy = wr_clamp(qy, miny, maxy);
+      s = wr_sample_linear_rgba8(t, int(qx), int(qy));
     }
-    // Linear filters.  All variants evaluate the same 7-bit bilinear formula;
-    // quantised coordinate stepping follows blendTextureLinearFallback
-    // (swgl_ext.h:172-183): per 4-pixel chunk uv += uv_step, lanes offset by the
-    // quantised per-pixel delta.
-    float qs = 128.0f;
-    float q0x = ou * W * qs + (0.5f - 0.5f * qs), q1x = ou1 * W * qs + (0.5f - 0.5f * qs);
-    float q0y = ov * H * qs + (0.5f - 0.5f * qs), q1y = ov1 * H * qs + (0.5f - 0.5f * qs);
-    float stepx = 4.0f * (q1x - q0x), stepy = 4.0f * (q1y - q0y);
-    float minx = wr_max(P.uv_bounds[0] * W * qs + (0.5f - 0.5f * qs), 0.0f);
-    float miny = wr_max(P.uv_bounds[1] * H * qs + (0.5f - 0.5f * qs), 0.0f);
-    float maxx = wr_max(P.uv_bounds[2] * W * qs + (0.5f - 0.5f * qs), minx);
-    float maxy = wr_max(P.uv_bounds[3] * H * qs + (0.5f - 0.5f * qs), miny);
-    int chunk = n >> 2, lane = n & 3;
-    // lanes of the quantised uv Float: uv.x = {q0x, q(ou+su), q(ou+2su), q(ou+3su)} (init_interp)
-    float lu = ou, lv = ov;
-    for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
-    float qx = lu * W * qs + (0.5f - 0.5f * qs), qy = lv * H * qs + (0.5f - 0.5f * qs);
-    for (int c = 0; c < chunk; c++) { qx += stepx; qy += stepy; }
-    qx = wr_clamp(qx, minx, maxx); qy = wr_clamp(qy, miny, maxy);
-    return wr_sample_linear_rgba8(t, int(qx), int(qy));
+    if (P.flags & WR_PF_HAS_COLOR) s = wr_apply_color(s, P.color);
+    return s;
   }
   // Tail pixels: fragment shader main() -> texture(sColor0, uv) -> round_pixel
-  // uv of this pixel: lanes of init_interp + whole-chunk steps (glsl.h:3084-3089)
-  // uv of this pixel: its init_interp lane (glsl.h:3084-3089), then
-  // step_interp_inputs(drawn): v_uv0 += interp_step * (drawn * 0.25), interp_step = step * 4
-  float lu = ou, lv = ov;
-  {
-    int lane = (n - span) & 3;
-    for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
-    float chunks = float(span) * 0.25f;
-    if (len >= 4) { lu = lu + (su * 4.0f) * chunks; lv = lv + (sv * 4.0f) * chunks; }
-  }
-  float cu = wr_clamp(lu, P.uv_bounds[0], P.uv_bounds[2]), cv = wr_clamp(lv, P.uv_bounds[1], P.uv_bounds[3]);
-  bool clamp_uv = (P.flags & WR_PF_TAIL_CLAMP) != 0;
-  if (!clamp_uv) { cu = lu; cv = lv; }
+  float cu, cv;
+  wr_tex_tail_uv(P, r, n, cu, cv);
   float tb, tg, tr, ta;
   if (t.linear) {
     int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
@@ -817,11 +775,165 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y,
   }
   if (P.flags & WR_PF_TAIL_MODULATE) { tr = P.fcolor[0] * tr; tg = P.fcolor[1] * tg; tb = P.fcolor[2] * tb; ta = P.fcolor[3] * ta; }
   WrWide s;
-  wr_pack_color(wf4{tr, tg, tb, ta}, (uint32_t*)&s);
-  ok = true;
-  // signal to caller that applyColor must NOT be applied again for tail pixels
-  s.ra |= 0;  // (no-op; modulation handled above)
+  uint32_t pc[2];
+  wr_pack_color(wf4{tr, tg, tb, ta}, pc);
+  s.bg = pc[0]; s.ra = pc[1];
   return s;
+}
+
+// Copy classification.  A textured prim is a plain texel copy if every covered
+// pixel takes exactly one source texel at a fixed integer offset.  EVERY row is
+// checked with the same arithmetic the generic path uses, so choosing the fast
+// path can never change a pixel.  Typical for the composite pass (tile -> window).
+//
+// Row k of prim P: returns false if the row is not a pure copy, else the source
+// column of pixel x0 (ix) and the source row (srow).
+WR_DEVICE bool wr_tex_copy_row(const WrPrim& P, const WrTexDesc& t, int k, int& ix, int& srow) {
+  const float W = float(t.width), H = float(t.height);
+  WrTexRow r = wr_tex_row(P, t, P.y0 + k);
+  ix = 0; srow = 0;
+  if (r.span > 0) {
+    if (r.filter != 0) return false;
+    if (r.ix < r.minX || r.ix + r.span - 1 > r.maxX) return false;
+    ix = r.ix; srow = r.srow;
+  }
+  // tail pixels (fragment shader path) must land exactly on texel centres of
+  // the same row / consecutive columns, unmodulated
+  for (int n = r.span; n < r.len; n++) {
+    float cu, cv;
+    wr_tex_tail_uv(P, r, n, cu, cv);
+    int tx, ty;
+    if (t.linear) {
+      int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
+      if ((qx & 0x7F) != 0 || (qy & 0x7F) != 0) return false;
+      tx = qx >> 7; ty = qy >> 7;
+      if (tx < 0 || tx > t.width - 2 || ty < 0 || ty >= t.height) return false;
+    } else {
+      tx = int(cu * W); ty = int(cv * H);
+      if (tx < 0 || tx >= t.width || ty < 0 || ty >= t.height) return false;
+    }
+    if (P.flags & WR_PF_TAIL_MODULATE) {
+      if (P.fcolor[0] != 1.0f || P.fcolor[1] != 1.0f || P.fcolor[2] != 1.0f || P.fcolor[3] != 1.0f) return false;
+    }
+    if (r.span > 0 || n > 0) { if (ty != srow || tx != ix + n) return false; }
+    else { ix = tx; srow = ty; }
+  }
+  return true;
+}
+
+WR_DEVICE WrRec wr_make_rec(const WrPrim& P) {
+  WrRec r;
+  r.x0 = P.x0; r.y0 = P.y0; r.x1 = P.x1; r.y1 = P.y1; r.z = P.z;
+  r.kbf = (uint32_t(P.kind) & 0xFF) | ((uint32_t(P.blend) & 0xFF) << 8) | (uint32_t(P.flags) << 16);
+  r.c0 = P.color[0]; r.c1 = P.color[1];
+  return r;
+}
+
+__global__ void wr_vertex_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
+                                 WrRec* __restrict__ recs, int n_prims, WrUnsupportedCounters* cnt) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_prims) return;
+  // binary search for the draw containing this instance
+  int lo = 0, hi = n_draws - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (draws[mid].first_prim <= gid) lo = mid; else hi = mid - 1;
+  }
+  const WrDrawDesc& d = draws[lo];
+  int inst = gid - d.first_prim;
+  WrPrim P;
+  if (d.shader == WR_SH_CLEAR_OP) {
+    P.kind = WR_PK_CLEAR; P.blend = WR_BLEND_NONE; P.draw = lo; P.z = d.clear_depth;
+    P.flags = d.flags & (WR_PF_CLEAR_COLOR | WR_PF_CLEAR_DEPTH);
+    P.x0 = d.clip[0]; P.y0 = d.clip[1]; P.x1 = d.clip[2]; P.y1 = d.clip[3];
+    P.color[0] = d.clear_color; P.color[1] = 0;
+    if (P.x1 <= P.x0 || P.y1 <= P.y0) P.kind = WR_PK_NONE;
+    prims[gid] = P;
+    recs[gid] = wr_make_rec(P);
+    return;
+  }
+  WrVsOut o;
+  o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
+  switch (d.shader) {
+    case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
+    case WR_SH_BRUSH_SOLID:
+    case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush_solid(d, arena, inst, o); break;
+    case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
+    case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
+    case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
+    default:
+      P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
+      P.color[0] = P.color[1] = 0;
+      prims[gid] = P;
+      recs[gid] = wr_make_rec(P);
+      return;
+  }
+  wr_finish_prim(d, lo, o, P, cnt);
+  prims[gid] = P;
+  recs[gid] = wr_make_rec(P);
+}
+
+// One wave per candidate prim (prims of draws whose shader can sample a
+// colour texture); lanes split the rows.
+__global__ void wr_classify_kernel(const WrDrawDesc* __restrict__ draws, WrPrim* __restrict__ prims,
+                                   WrRec* __restrict__ recs, const int* __restrict__ cand, int n_cand) {
+  const int ci = blockIdx.x;
+  if (ci >= n_cand) return;
+  const int gid = cand[ci];
+  WrPrim& P = prims[gid];
+  if (P.kind != WR_PK_TEX_RGBA8) return;
+  const WrTexDesc& t = draws[P.draw].tex[P.tex_slot];
+  if (!t.ptr || t.format != WR_FMT_RGBA8 || (P.flags & WR_PF_HAS_COLOR)) return;
+  const int rows = P.y1 - P.y0;
+  int ix0, srow0, ix1 = 0, srow1 = 0;
+  bool ok = wr_tex_copy_row(P, t, 0, ix0, srow0);
+  int step = 1;
+  if (ok && rows > 1) {
+    ok = wr_tex_copy_row(P, t, 1, ix1, srow1);
+    step = srow1 - srow0;
+    ok = ok && ix1 == ix0 && (step == 1 || step == -1);
+  }
+#ifdef WRHIP_HOSTSIM
+  if (threadIdx.x != 0) return;
+  for (int k = 2; ok && k < rows; k++) {
+    int ix, srow;
+    ok = wr_tex_copy_row(P, t, k, ix, srow) && ix == ix0 && srow == srow0 + k * step;
+  }
+#else
+  for (int k = 2 + (int)threadIdx.x; k < rows; k += 64) {
+    int ix, srow;
+    ok = ok && wr_tex_copy_row(P, t, k, ix, srow) && ix == ix0 && srow == srow0 + k * step;
+  }
+  ok = __all(ok);
+  if (threadIdx.x != 0) return;
+#endif
+  if (ok) {
+    P.kind = WR_PK_TEX_COPY; P.copy_sx0 = ix0; P.copy_sy0 = srow0; P.copy_step = step;
+    recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_TEX_COPY;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Binning: bit (p - T.first_prim) of bin b's mask row <=> prim p touches bin b.
+__global__ void wr_bin_kernel(const WrPrim* __restrict__ prims, int n_prims,
+                              const WrDrawDesc* __restrict__ draws,
+                              const WrTargetDesc* __restrict__ targets,
+                              unsigned long long* __restrict__ masks) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_prims) return;
+  const WrPrim& P = prims[gid];
+  if (P.kind == WR_PK_NONE || P.kind == WR_PK_UNSUPPORTED) return;
+  const WrTargetDesc& T = targets[draws[P.draw].target];
+  int bx0 = wr_imax(P.x0, 0) / WR_BIN_W, bx1 = (wr_imin(P.x1, T.width) - 1) / WR_BIN_W;
+  int by0 = wr_imax(P.y0, 0) / WR_BIN_H, by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
+  by0 = wr_imax(by0, T.row_begin); by1 = wr_imin(by1, T.row_end - 1);
+  int rel = gid - T.first_prim;
+  unsigned long long bit = 1ull << (rel & 63);
+  int word = rel >> 6;
+  for (int by = by0; by <= by1; by++)
+    for (int bx = bx0; bx <= bx1; bx++)
+      atomicOr(&masks[(size_t)T.word_base + (size_t)(by * T.bins_x + bx) * T.words_per_bin + word], bit);
 }
 
 // Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
@@ -833,11 +945,7 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
   if (P.kind == WR_PK_SOLID) {
     src.bg = P.color[0]; src.ra = P.color[1];
   } else {
-    bool ok;
-    src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y, ok);
-    int n = x - P.x0, len = P.x1 - P.x0;
-    bool in_span = len >= 4 && n < (len & ~3);
-    if (in_span && (P.flags & WR_PF_HAS_COLOR)) src = wr_apply_color(src, P.color);
+    src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y);
   }
   return wr_blend_rgba8(P.blend, dstp, src, D);
 }
@@ -854,6 +962,14 @@ WR_DEVICE uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, r);
 #endif
 }
+// ((u >> 8) & 0x00FF00FF) in one v_perm_b32: bytes (u.b1, 0, u.b3, 0)
+WR_DEVICE uint32_t wr_hi_bytes(uint32_t u) {
+#ifdef WRHIP_HOSTSIM
+  return (u >> 8) & 0x00FF00FFu;
+#else
+  return __builtin_amdgcn_perm(0u, u, 0x0c030c01u);
+#endif
+}
 WR_DEVICE uint32_t wr_mul24(uint32_t a, uint32_t b) {
 #ifdef WRHIP_HOSTSIM
   return a * b;
@@ -868,10 +984,161 @@ WR_DEVICE uint32_t wr_mul24(uint32_t a, uint32_t b) {
 // 255 * 256 < 2^16).
 #define WR_M8 0x00FF00FFu
 
+// Apply one prim to the 16 pixels of this lane.  All prim parameters are
+// wave-uniform (SGPRs); (px,py) is the lane's first pixel, (wx0,wy0) the
+// wave's 64x16 strip origin.
+template <int FMT, bool DEPTH>
+WR_DEVICE void wr_apply_prim(uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t (&dep)[16],
+                             const int x0, const int y0, const int x1, const int y1, const uint32_t z,
+                             const uint32_t kbf, const uint32_t c0, const uint32_t c1,
+                             const WrPrim* Pp, const WrDrawDesc* draws,
+                             const int px, const int py, const int wx0, const int wy0) {
+  constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
+  const int kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = kbf >> 16;
+  // per-lane coverage
+  bool cx[4], cy[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
+#pragma unroll
+  for (int j = 0; j < 4; j++) cy[j] = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
+
+  if (kind == WR_PK_CLEAR) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const bool in = cx[q & 3] && cy[q >> 2];
+      if (flags & WR_PF_CLEAR_COLOR) {
+        uint32_t nlo = BPP == 4 ? (c0 & WR_M8) : c0, nhi = BPP == 4 ? ((c0 >> 8) & WR_M8) : 0;
+        plo[q] = in ? nlo : plo[q];
+        phi[q] = in ? nhi : phi[q];
+      }
+      if (DEPTH && (flags & WR_PF_CLEAR_DEPTH)) dep[q] = in ? z : dep[q];
+    }
+    return;
+  }
+  const bool dtest = DEPTH && (flags & WR_PF_DEPTH_TEST);
+  const bool dwrite = (flags & WR_PF_DEPTH_WRITE) != 0, dless = (flags & WR_PF_DEPTH_LESS) != 0;
+  // does the prim cover this wave's whole 64x16 strip?  (uniform)
+  const bool full = x0 <= wx0 && x1 >= wx0 + WR_BIN_W && y0 <= wy0 && y1 >= wy0 + 16;
+
+// Applies BODY (new channel pairs nl/nh computed from dl/dh) to the 16 pixels
+// of this lane, with coverage / depth predicates only where needed.
+#define WR_FOR_PIXELS(BODY)                                                          \
+  if (full && !dtest) {                                                               \
+    _Pragma("unroll") for (int q = 0; q < 16; q++) {                                  \
+      const uint32_t dl = plo[q], dh = phi[q]; uint32_t nl, nh; BODY;                 \
+      plo[q] = nl; phi[q] = nh;                                                       \
+    }                                                                                 \
+  } else {                                                                            \
+    _Pragma("unroll") for (int q = 0; q < 16; q++) {                                  \
+      bool in = cx[q & 3] && cy[q >> 2];                                              \
+      if (dtest) {                                                                    \
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);                       \
+        in = in && pass;                                                              \
+        if (dwrite) dep[q] = in ? z : dep[q];                                         \
+      }                                                                               \
+      const uint32_t dl = plo[q], dh = phi[q]; uint32_t nl, nh; BODY;                 \
+      plo[q] = in ? nl : dl; phi[q] = in ? nh : dh;                                   \
+    }                                                                                 \
+  }
+
+  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
+    // ---- fast path: swgl_commitSolidRGBA8 with no blend / premultiplied alpha ----
+    // premultiplied:  src + dst - ((dst * (a + 1)) >> 8) in u16 lanes, then pack() clamp.
+    //   With K = 255 - a:  dst - ((dst*(a+1)) >> 8) == (dst*K + 255) >> 8   (exact),
+    //   so per channel pair  new = ((dst*K + 0x00FF00FF) >> 8 & M) + src.
+    //   For a valid premultiplied colour (b,g,r <= a) the result never exceeds
+    //   255 and src folds into the rounding constant: new = hi_bytes(dst*K + C).
+    // no blend: the same formula with K = 0 and src = pack(colour).
+    const bool bytes = ((c0 | c1) & 0xFF00FF00u) == 0;             // all source lanes <= 255
+    uint32_t b = c0 & 0xFFFF, g = c0 >> 16, r = c1 & 0xFFFF, a = c1 >> 16;
+    uint32_t K = 255u - a;
+    bool folded = bytes && b <= a && g <= a && r <= a;
+    if (blend == WR_BLEND_NONE) {
+      b = wr_pack1(b); g = wr_pack1(g); r = wr_pack1(r); a = wr_pack1(a);
+      K = 0; folded = true;
+    }
+    const uint32_t ulo = b | (r << 16), uhi = g | (a << 16);
+    if (folded) {
+      const uint32_t Clo = WR_M8 + (ulo << 8), Chi = WR_M8 + (uhi << 8);
+      WR_FOR_PIXELS({ nl = wr_hi_bytes(wr_mul24(dl, K) + Clo); nh = wr_hi_bytes(wr_mul24(dh, K) + Chi); })
+      return;
+    }
+    if (bytes) {
+      WR_FOR_PIXELS({ nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(dl, K) + WR_M8) + ulo, WR_M8);
+                      nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(dh, K) + WR_M8) + uhi, WR_M8); })
+      return;
+    }
+    // colours outside [0,1]: fall through to the generic path
+  }
+  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_COPY && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
+    // ---- 1:1 texel copy (composite pass): 4 consecutive source texels per row ----
+    const WrTexDesc& tex = draws[Pp->draw].tex[Pp->tex_slot];
+    const uint32_t* sbuf = (const uint32_t*)tex.ptr;
+    const int sxl = Pp->copy_sx0 + (px - x0);
+    const int step = Pp->copy_step, sy0 = Pp->copy_sy0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int y = py + 4 * j;
+      if (!cy[j]) continue;
+      const uint32_t* srow = sbuf + (size_t)(sy0 + (y - y0) * step) * tex.stride;
+      uint32_t sp[4];
+      const bool allx = cx[0] && cx[3];
+      if (allx && ((sxl & 3) == 0) && ((tex.stride & 3) == 0)) {
+        uint4 v = *(const uint4*)(srow + sxl);
+        sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) sp[i] = cx[i] ? srow[sxl + i] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        bool in = cx[i];
+        if (dtest) {
+          const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+          in = in && pass;
+          if (dwrite) dep[q] = in ? z : dep[q];
+        }
+        const uint32_t sl = sp[i] & WR_M8, sh = (sp[i] >> 8) & WR_M8;
+        uint32_t nl = sl, nh = sh;
+        if (blend == WR_BLEND_PREMULT) {
+          const uint32_t K = 255u - (sh >> 16);
+          nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
+          nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
+        }
+        plo[q] = in ? nl : plo[q]; phi[q] = in ? nh : phi[q];
+      }
+    }
+    return;
+  }
+  // ---- generic path ----
+  const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    bool in = cx[q & 3] && cy[q >> 2];
+    if (dtest) {
+      const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+      in = in && pass;
+      if (dwrite) dep[q] = in ? z : dep[q];
+    }
+    if (in) {
+      if (FMT == WR_FMT_RGBA8) {
+        uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + (q & 3), py + 4 * (q >> 2), plo[q] | (phi[q] << 8));
+        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+      } else {
+        // R8 target: pack_pixels_R8(v_color.x) (blend.h:67-73)
+        plo[q] = wr_blend_r8(blend, plo[q], c1 & 0xFFFF);
+      }
+    }
+  }
+#undef WR_FOR_PIXELS
+}
+
 template <int FMT, bool DEPTH>
 __global__ void __launch_bounds__(256)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                 const WrRec* __restrict__ recs,
                  const unsigned long long* __restrict__ masks, int bin_offset) {
   const int bin = blockIdx.x + bin_offset;
   int t = 0;
@@ -931,133 +1198,43 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
   // ---- apply every prim of this bin, in submission order -----------------
   const unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
   for (int w = 0; w < T.words_per_bin; w++) {
-    unsigned long long m = mw[w];
-    while (m) {
-      const int bit = __builtin_ctzll(m);
-      m &= m - 1;
-      const WrPrim* Pp = &prims[T.first_prim + w * 64 + bit];
-      const int x0 = Pp->x0, y0 = Pp->y0, x1 = Pp->x1, y1 = Pp->y1;
-      // wave-uniform reject against this wave's 64x16 strip
-      if (x1 <= wx0 || x0 >= wx0 + WR_BIN_W || y1 <= wy0 || y0 >= wy0 + 16) continue;
-      const int kind = Pp->kind, blend = Pp->blend, flags = Pp->flags;
-      const uint32_t z = Pp->z;
-      // per-lane coverage
-      bool cx[4], cy[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
-#pragma unroll
-      for (int j = 0; j < 4; j++) cy[j] = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
-
-      if (kind == WR_PK_CLEAR) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const bool in = cx[i] && cy[j];
-            if (flags & WR_PF_CLEAR_COLOR) {
-              uint32_t c = Pp->color[0];
-              uint32_t nlo = BPP == 4 ? (c & WR_M8) : c, nhi = BPP == 4 ? ((c >> 8) & WR_M8) : 0;
-              plo[4 * j + i] = in ? nlo : plo[4 * j + i];
-              phi[4 * j + i] = in ? nhi : phi[4 * j + i];
-            }
-            if (DEPTH && (flags & WR_PF_CLEAR_DEPTH)) dep[4 * j + i] = in ? z : dep[4 * j + i];
-          }
-        continue;
-      }
-      const bool dtest = DEPTH && (flags & WR_PF_DEPTH_TEST);
-      const bool dwrite = (flags & WR_PF_DEPTH_WRITE) != 0, dless = (flags & WR_PF_DEPTH_LESS) != 0;
-
-      if (FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
-        // ---- fast paths: swgl_commitSolidRGBA8 with no blend / premultiplied alpha ----
-        const uint32_t c0 = Pp->color[0], c1 = Pp->color[1];   // (b,g) (r,a) u16 pairs
-        // pack() saturation of the constant source, then channel pairing
-        const uint32_t sb = wr_pack1(c0 & 0xFFFF), sg = wr_pack1(c0 >> 16), sr = wr_pack1(c1 & 0xFFFF), sa = wr_pack1(c1 >> 16);
-        if (blend == WR_BLEND_NONE) {
-          const uint32_t slo = sb | (sr << 16), shi = sg | (sa << 16);
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              bool in = cx[i] && cy[j];
-              if (dtest) {
-                const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
-                in = in && pass;
-                if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
-              }
-              plo[4 * j + i] = in ? slo : plo[4 * j + i];
-              phi[4 * j + i] = in ? shi : phi[4 * j + i];
-            }
-        } else {
-          // src + dst - ((dst * (a + 1)) >> 8), u16 lanes, then pack() clamp to 255.
-          // The unsaturated source lanes take part in the sum exactly as in swgl.
-          const uint32_t ulo = (c0 & 0xFFFF) | ((c1 & 0xFFFF) << 16);   // (b, r) raw u16
-          const uint32_t uhi = (c0 >> 16) | (c1 & 0xFFFF0000u);          // (g, a) raw u16
-          const uint32_t araw = c1 >> 16;
-          const bool simple = ((c0 | c1) & 0xFF00FF00u) == 0;           // all source lanes <= 255
-          if (simple) {
-            const uint32_t k = araw + 1;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-              for (int i = 0; i < 4; i++) {
-                bool in = cx[i] && cy[j];
-                if (dtest) {
-                  const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
-                  in = in && pass;
-                  if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
-                }
-                const uint32_t dl = plo[4 * j + i], dh = phi[4 * j + i];
-                uint32_t nl = dl + ulo - ((wr_mul24(dl, k) >> 8) & WR_M8);
-                uint32_t nh = dh + uhi - ((wr_mul24(dh, k) >> 8) & WR_M8);
-                nl = wr_pk_min_u16(nl, WR_M8);
-                nh = wr_pk_min_u16(nh, WR_M8);
-                plo[4 * j + i] = in ? nl : dl;
-                phi[4 * j + i] = in ? nh : dh;
-              }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-              for (int i = 0; i < 4; i++) {
-                bool in = cx[i] && cy[j];
-                if (dtest) {
-                  const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
-                  in = in && pass;
-                  if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
-                }
-                if (in) {
-                  uint32_t r = wr_generic_pixel_rgba8(Pp, &draws[Pp->draw], px + i, py + 4 * j,
-                                                      plo[4 * j + i] | (phi[4 * j + i] << 8));
-                  plo[4 * j + i] = r & WR_M8; phi[4 * j + i] = (r >> 8) & WR_M8;
-                }
-              }
-          }
-        }
-        continue;
-      }
-      // ---- generic path ----
-      const WrDrawDesc* D = &draws[Pp->draw];
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          bool in = cx[i] && cy[j];
-          if (dtest) {
-            const bool pass = dless ? (z < dep[4 * j + i]) : (z <= dep[4 * j + i]);
-            in = in && pass;
-            if (dwrite) dep[4 * j + i] = in ? z : dep[4 * j + i];
-          }
-          if (in) {
-            if (FMT == WR_FMT_RGBA8) {
-              uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + i, py + 4 * j, plo[4 * j + i] | (phi[4 * j + i] << 8));
-              plo[4 * j + i] = r & WR_M8; phi[4 * j + i] = (r >> 8) & WR_M8;
-            } else {
-              // R8 target: pack_pixels_R8(v_color.x) (blend.h:67-73)
-              plo[4 * j + i] = wr_blend_r8(blend, plo[4 * j + i], Pp->color[1] & 0xFFFF);
-            }
-          }
-        }
+    const unsigned long long m = mw[w];
+    if (!m) continue;
+    const int base = T.first_prim + w * 64;
+#ifdef WRHIP_HOSTSIM
+    // serial reference iteration (host simulation has no cross-lane ops)
+    unsigned long long live = m;
+    while (live) {
+      const int bit = __builtin_ctzll(live);
+      live &= live - 1;
+      const WrRec R = recs[base + bit];
+      if (R.x1 <= wx0 || R.x0 >= wx0 + WR_BIN_W || R.y1 <= wy0 || R.y0 >= wy0 + 16) continue;
+      wr_apply_prim<FMT, DEPTH>(plo, phi, dep, R.x0, R.y0, R.x1, R.y1, R.z, R.kbf, R.c0, R.c1, &prims[base + bit], draws,
+                                px, py, wx0, wy0);
     }
+#else
+    // Wave-cooperative fetch: lane l loads the record of the word's l-th prim
+    // (one memory latency for up to 64 prims), tests it against this wave's
+    // strip, and the survivors -- a ballot mask, still in submission order -- are
+    // broadcast one by one with v_readlane into SGPRs.
+    const bool has = (m >> lane) & 1ull;
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+    if (has) {
+      const uint4* rp = (const uint4*)&recs[base + lane];
+      ra = rp[0]; rb = rp[1];
+    }
+    const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + 16);
+    unsigned long long live = __ballot(hit);
+    while (live) {
+      const int bit = __builtin_ctzll(live);
+      live &= live - 1;
+      const int x0 = __builtin_amdgcn_readlane((int)ra.x, bit), y0 = __builtin_amdgcn_readlane((int)ra.y, bit);
+      const int x1 = __builtin_amdgcn_readlane((int)ra.z, bit), y1 = __builtin_amdgcn_readlane((int)ra.w, bit);
+      const uint32_t z = __builtin_amdgcn_readlane((int)rb.x, bit), kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
+      const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
+      wr_apply_prim<FMT, DEPTH>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], draws, px, py, wx0, wy0);
+    }
+#endif
   }
   // ---- write back ------------------------------------------------------------
 #pragma unroll
