@@ -227,12 +227,14 @@ struct Context {
   wr_event_t ev_a, ev_b;
   WrhipStats stats;
   int shard_rank = 0, shard_world = 1;
+  int rows_per_lane = 4;
 
   Context() {
     wrrt::stream_create(&stream);
     for (int i = 0; i < NARENA; i++) wrrt::event_create(&arena_event[i]);
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
+    if (const char* e = getenv("WRHIP_ROWS")) rows_per_lane = atoi(e) == 8 ? 8 : 4;
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
     wrrt::memset8(dcounters, 0, sizeof(WrUnsupportedCounters), stream);
   }
@@ -626,7 +628,6 @@ void flush_work(const std::vector<int>& sel_in) {
   std::vector<WrDrawDesc> draws;
   std::vector<WrTargetDesc> targets(n_targets);
   std::vector<uint8_t> inst;
-  std::vector<int> cand;   // prims whose shader may sample a colour texture (copy classification)
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0, bins_rgba = 0;
   bool any_depth = false;
   uint64_t algo_bytes = 0, pixels = 0;
@@ -665,9 +666,6 @@ void flush_work(const std::vector<int>& sel_in) {
       any_kept = true;
       if (d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) any_depth = true;
       d.first_prim = prim_cursor;
-      if ((d.shader == WR_SH_COMPOSITE || d.shader == WR_SH_COMPOSITE_FAST || d.shader == WR_SH_PS_QUAD_TEXTURED) &&
-          d.tex[WR_S_COLOR0].ptr)
-        for (int k = 0; k < d.count; k++) cand.push_back(prim_cursor + k);
       prim_cursor += d.count;
       draws.push_back(d);
     }
@@ -707,8 +705,7 @@ void flush_work(const std::vector<int>& sel_in) {
     size_t off_draws = 0;
     size_t off_targets = (off_draws + sizeof(WrDrawDesc) * nd + 255) & ~size_t(255);
     size_t off_inst = (off_targets + sizeof(WrTargetDesc) * n_targets + 255) & ~size_t(255);
-    size_t off_cand = (off_inst + inst.size() + 255) & ~size_t(255);
-    size_t total = off_cand + cand.size() * sizeof(int) + 256;
+    size_t total = off_inst + inst.size() + 256;
     int ai = c->arena_index; c->arena_index = (ai + 1) % Context::NARENA;
     if (c->arena_used[ai]) wrrt::event_sync(&c->arena_event[ai]);
     if (c->harena_size[ai] < total) {
@@ -726,7 +723,6 @@ void flush_work(const std::vector<int>& sel_in) {
     if (nd) memcpy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     memcpy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
     if (!inst.empty()) memcpy(h + off_inst, inst.data(), inst.size());
-    if (!cand.empty()) memcpy(h + off_cand, cand.data(), cand.size() * sizeof(int));
     wrrt::h2d(c->darena, h, total, c->stream);
     wrrt::event_record(&c->arena_event[ai], c->stream);
     c->arena_used[ai] = true;
@@ -746,20 +742,18 @@ void flush_work(const std::vector<int>& sel_in) {
       wrrt::dev_free(c->dmasks);
       c->dmasks_cap = (size_t)(n_words + 1) * 2;
       c->dmasks = (unsigned long long*)wrrt::dev_alloc(c->dmasks_cap * 8);
+      wrrt::memset8(c->dmasks, 0, c->dmasks_cap * 8, c->stream);   // raster workgroups re-zero what they consume
     }
+#ifdef WRHIP_HOSTSIM
     wrrt::memset8(c->dmasks, 0, (size_t)n_words * 8, c->stream);
+#endif
     const WrDrawDesc* ddraws = (const WrDrawDesc*)(c->darena + off_draws);
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(c->darena + off_targets);
     const uint8_t* dinst = c->darena + off_inst;
     if (n_prims > 0) {
-      WR_LAUNCH(wr_vertex_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, n_prims, c->dcounters);
-      if (!cand.empty()) {
-        WR_LAUNCH(wr_classify_kernel, (int)cand.size(), 64, c->stream, ddraws, c->dprims, c->drecs,
-                  (const int*)(c->darena + off_cand), (int)cand.size());
-        c->stats.kernel_launches++;
-      }
-      WR_LAUNCH(wr_bin_kernel, (n_prims + 255) / 256, 256, c->stream, (const WrPrim*)c->dprims, n_prims, ddraws, dtargets, c->dmasks);
-      c->stats.kernel_launches += 2;
+      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, n_prims,
+                dtargets, c->dmasks, c->dcounters);
+      c->stats.kernel_launches += 1;
     }
 #ifdef WRHIP_HOSTSIM
     if (getenv("WRHIP_DEBUG")) {
@@ -791,20 +785,25 @@ void flush_work(const std::vector<int>& sel_in) {
     }
 #endif
     if (c->profiling) wrrt::event_record(&c->ev_a, c->stream);
+    // R = rows per lane: 4 (four waves per 64x64 bin, 16 pixels per lane) measured
+    // faster than 8 on MI355X (profiles/); WRHIP_ROWS=8 selects two waves x 32 pixels.
+    const int R = c->rows_per_lane;
+#define WR_RASTER(FMT, DEPTH, NB, OFF)                                                                              \
+  do {                                                                                                              \
+    if (R == 8)                                                                                                     \
+      WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 8>), NB, 128, c->stream, dtargets, n_targets, ddraws,                 \
+                (const WrPrim*)c->dprims, (const WrRec*)c->drecs, c->dmasks, OFF);                                  \
+    else                                                                                                            \
+      WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4>), NB, 256, c->stream, dtargets, n_targets, ddraws,                 \
+                (const WrPrim*)c->dprims, (const WrRec*)c->drecs, c->dmasks, OFF);                                  \
+    c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
+  } while (0)
     if (bins_rgba > 0) {
-      if (any_depth)
-        WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, true>), bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
-                  (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const unsigned long long*)c->dmasks, 0);
-      else
-        WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, false>), bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
-                  (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const unsigned long long*)c->dmasks, 0);
-      c->stats.kernel_launches++; c->stats.raster_launches++;
+      if (any_depth) WR_RASTER(WR_FMT_RGBA8, true, bins_rgba, 0);
+      else WR_RASTER(WR_FMT_RGBA8, false, bins_rgba, 0);
     }
-    if (n_bins > bins_rgba) {
-      WR_LAUNCH((wr_raster_kernel<WR_FMT_R8, false>), n_bins - bins_rgba, 256, c->stream, dtargets, n_targets, ddraws,
-                (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const unsigned long long*)c->dmasks, bins_rgba);
-      c->stats.kernel_launches++; c->stats.raster_launches++;
-    }
+    if (n_bins > bins_rgba) WR_RASTER(WR_FMT_R8, false, n_bins - bins_rgba, bins_rgba);
+#undef WR_RASTER
     if (c->profiling) {
       wrrt::event_record(&c->ev_b, c->stream);
       wrrt::event_sync(&c->ev_b);

@@ -781,59 +781,41 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
   return s;
 }
 
-// Copy classification.  A textured prim is a plain texel copy if every covered
-// pixel takes exactly one source texel at a fixed integer offset.  EVERY row is
-// checked with the same arithmetic the generic path uses, so choosing the fast
-// path can never change a pixel.  Typical for the composite pass (tile -> window).
-//
-// Row k of prim P: returns false if the row is not a pure copy, else the source
-// column of pixel x0 (ix) and the source row (srow).
-WR_DEVICE bool wr_tex_copy_row(const WrPrim& P, const WrTexDesc& t, int k, int& ix, int& srow) {
-  const float W = float(t.width), H = float(t.height);
-  WrTexRow r = wr_tex_row(P, t, P.y0 + k);
-  ix = 0; srow = 0;
-  if (r.span > 0) {
-    if (r.filter != 0) return false;
-    if (r.ix < r.minX || r.ix + r.span - 1 > r.maxX) return false;
-    ix = r.ix; srow = r.srow;
-  }
-  // tail pixels (fragment shader path) must land exactly on texel centres of
-  // the same row / consecutive columns, unmodulated
-  for (int n = r.span; n < r.len; n++) {
-    float cu, cv;
-    wr_tex_tail_uv(P, r, n, cu, cv);
-    int tx, ty;
-    if (t.linear) {
-      int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
-      if ((qx & 0x7F) != 0 || (qy & 0x7F) != 0) return false;
-      tx = qx >> 7; ty = qy >> 7;
-      if (tx < 0 || tx > t.width - 2 || ty < 0 || ty >= t.height) return false;
-    } else {
-      tx = int(cu * W); ty = int(cv * H);
-      if (tx < 0 || tx >= t.width || ty < 0 || ty >= t.height) return false;
-    }
-    if (P.flags & WR_PF_TAIL_MODULATE) {
-      if (P.fcolor[0] != 1.0f || P.fcolor[1] != 1.0f || P.fcolor[2] != 1.0f || P.fcolor[3] != 1.0f) return false;
-    }
-    if (r.span > 0 || n > 0) { if (ty != srow || tx != ix + n) return false; }
-    else { ix = tx; srow = ty; }
-  }
-  return true;
-}
-
-WR_DEVICE WrRec wr_make_rec(const WrPrim& P) {
+// Compact raster record.  Solid prims on RGBA8 targets drawn without blending
+// or with premultiplied-alpha blending of a valid premultiplied colour are
+// pre-folded into (K, Clo, Chi) so the raster hot path is  new = hi_bytes(dst*K + C):
+//   premultiplied:  src + dst - ((dst*(a+1)) >> 8)  ==  src + ((dst*K + 255) >> 8),  K = 255 - a
+//   no blend:       K = 0, src = pack(colour)
+// (fields never overflow because the result is <= 255 when b,g,r <= a).
+WR_DEVICE WrRec wr_make_rec(const WrPrim& P, int target_format) {
   WrRec r;
   r.x0 = P.x0; r.y0 = P.y0; r.x1 = P.x1; r.y1 = P.y1; r.z = P.z;
-  r.kbf = (uint32_t(P.kind) & 0xFF) | ((uint32_t(P.blend) & 0xFF) << 8) | (uint32_t(P.flags) << 16);
+  uint32_t kind = uint32_t(P.kind) & 0xFF;
   r.c0 = P.color[0]; r.c1 = P.color[1];
+  uint32_t Kf = 0;
+  if (kind == WR_PK_SOLID && target_format == WR_FMT_RGBA8 && (P.blend == WR_BLEND_NONE || P.blend == WR_BLEND_PREMULT)) {
+    const uint32_t c0 = P.color[0], c1 = P.color[1];
+    const bool bytes = ((c0 | c1) & 0xFF00FF00u) == 0;
+    uint32_t b = c0 & 0xFFFF, g = c0 >> 16, rr = c1 & 0xFFFF, a = c1 >> 16;
+    uint32_t K = 255u - a;
+    bool folded = bytes && b <= a && g <= a && rr <= a;
+    if (P.blend == WR_BLEND_NONE) { b = wr_pack1(b); g = wr_pack1(g); rr = wr_pack1(rr); a = wr_pack1(a); K = 0; folded = true; }
+    if (folded) {
+      kind = WR_PK_SOLID_FOLDED;
+      r.c0 = 0x00FF00FFu + ((b | (rr << 16)) << 8);
+      r.c1 = 0x00FF00FFu + ((g | (a << 16)) << 8);
+      Kf = K & 0xFF;
+    }
+  }
+  r.kbf = kind | ((uint32_t(P.blend) & 0xFF) << 8) | ((uint32_t(P.flags) & 0xFF) << 16) | (Kf << 24);
   return r;
 }
 
-__global__ void wr_vertex_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
-                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
-                                 WrRec* __restrict__ recs, int n_prims, WrUnsupportedCounters* cnt) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n_prims) return;
+// Vertex stage of one instance: locate its draw, run the shader's vertex
+// function, then swgl's draw_quad setup.
+WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws, const uint8_t* __restrict__ arena,
+                              int gid, WrPrim& P, WrUnsupportedCounters* cnt) {
+  P.blend = 0; P.flags = 0; P.z = 0; P.color[0] = P.color[1] = 0; P.tex_slot = 0;
   // binary search for the draw containing this instance
   int lo = 0, hi = n_draws - 1;
   while (lo < hi) {
@@ -842,15 +824,12 @@ __global__ void wr_vertex_kernel(const WrDrawDesc* __restrict__ draws, int n_dra
   }
   const WrDrawDesc& d = draws[lo];
   int inst = gid - d.first_prim;
-  WrPrim P;
   if (d.shader == WR_SH_CLEAR_OP) {
     P.kind = WR_PK_CLEAR; P.blend = WR_BLEND_NONE; P.draw = lo; P.z = d.clear_depth;
     P.flags = d.flags & (WR_PF_CLEAR_COLOR | WR_PF_CLEAR_DEPTH);
     P.x0 = d.clip[0]; P.y0 = d.clip[1]; P.x1 = d.clip[2]; P.y1 = d.clip[3];
     P.color[0] = d.clear_color; P.color[1] = 0;
     if (P.x1 <= P.x0 || P.y1 <= P.y0) P.kind = WR_PK_NONE;
-    prims[gid] = P;
-    recs[gid] = wr_make_rec(P);
     return;
   }
   WrVsOut o;
@@ -865,75 +844,79 @@ __global__ void wr_vertex_kernel(const WrDrawDesc* __restrict__ draws, int n_dra
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
-      prims[gid] = P;
-      recs[gid] = wr_make_rec(P);
       return;
   }
   wr_finish_prim(d, lo, o, P, cnt);
-  prims[gid] = P;
-  recs[gid] = wr_make_rec(P);
 }
 
-// One wave per candidate prim (prims of draws whose shader can sample a
-// colour texture); lanes split the rows.
-__global__ void wr_classify_kernel(const WrDrawDesc* __restrict__ draws, WrPrim* __restrict__ prims,
-                                   WrRec* __restrict__ recs, const int* __restrict__ cand, int n_cand) {
-  const int ci = blockIdx.x;
-  if (ci >= n_cand) return;
-  const int gid = cand[ci];
-  WrPrim& P = prims[gid];
-  if (P.kind != WR_PK_TEX_RGBA8) return;
-  const WrTexDesc& t = draws[P.draw].tex[P.tex_slot];
-  if (!t.ptr || t.format != WR_FMT_RGBA8 || (P.flags & WR_PF_HAS_COLOR)) return;
-  const int rows = P.y1 - P.y0;
-  int ix0, srow0, ix1 = 0, srow1 = 0;
-  bool ok = wr_tex_copy_row(P, t, 0, ix0, srow0);
-  int step = 1;
-  if (ok && rows > 1) {
-    ok = wr_tex_copy_row(P, t, 1, ix1, srow1);
-    step = srow1 - srow0;
-    ok = ok && ix1 == ix0 && (step == 1 || step == -1);
+
+// Binning: bit (p - T.first_prim) of bin b's mask row <=> prim p touches bin b.
+// Small prims set their few bits themselves; prims spanning many bins are
+// handled by the whole wave (lanes stride over the bins), so a full-tile quad
+// costs 2-3 wave iterations instead of >100 serial atomics.
+WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDesc* draws, const WrTargetDesc* targets,
+                           unsigned long long* masks) {
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bins_x = 1, wpb = 0;
+  unsigned long long* base = masks;
+  unsigned long long bit = 0;
+  if (valid && P.kind != WR_PK_NONE && P.kind != WR_PK_UNSUPPORTED) {
+    const WrTargetDesc& T = targets[draws[P.draw].target];
+    bx0 = wr_imax(P.x0, 0) / WR_BIN_W; bx1 = (wr_imin(P.x1, T.width) - 1) / WR_BIN_W;
+    by0 = wr_imax(P.y0, 0) / WR_BIN_H; by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
+    by0 = wr_imax(by0, T.row_begin); by1 = wr_imin(by1, T.row_end - 1);
+    const int rel = gid - T.first_prim;
+    bit = 1ull << (rel & 63);
+    bins_x = T.bins_x; wpb = T.words_per_bin;
+    base = masks + (size_t)T.word_base + (rel >> 6);
   }
+  const int nbx = bx1 - bx0 + 1, nby = by1 - by0 + 1;
+  const int nb = (nbx > 0 && nby > 0) ? nbx * nby : 0;
 #ifdef WRHIP_HOSTSIM
-  if (threadIdx.x != 0) return;
-  for (int k = 2; ok && k < rows; k++) {
-    int ix, srow;
-    ok = wr_tex_copy_row(P, t, k, ix, srow) && ix == ix0 && srow == srow0 + k * step;
+  for (int k = 0; k < nb; k++) {
+    int bx = bx0 + k % nbx, by = by0 + k / nbx;
+    atomicOr(&base[(size_t)(by * bins_x + bx) * wpb], bit);
   }
 #else
-  for (int k = 2 + (int)threadIdx.x; k < rows; k += 64) {
-    int ix, srow;
-    ok = ok && wr_tex_copy_row(P, t, k, ix, srow) && ix == ix0 && srow == srow0 + k * step;
+  const int SMALL = 8;
+  if (nb > 0 && nb <= SMALL) {
+    for (int k = 0; k < nb; k++) {
+      int bx = bx0 + k % nbx, by = by0 + k / nbx;
+      atomicOr(&base[(size_t)(by * bins_x + bx) * wpb], bit);
+    }
   }
-  ok = __all(ok);
-  if (threadIdx.x != 0) return;
+  unsigned long long big = __ballot(nb > SMALL);
+  const int lane = threadIdx.x & 63;
+  while (big) {
+    const int b = __builtin_ctzll(big);
+    big &= big - 1;
+    const int sbx0 = __builtin_amdgcn_readlane(bx0, b), snbx = __builtin_amdgcn_readlane(nbx, b);
+    const int sby0 = __builtin_amdgcn_readlane(by0, b), snb = __builtin_amdgcn_readlane(nb, b);
+    const int sbins_x = __builtin_amdgcn_readlane(bins_x, b), swpb = __builtin_amdgcn_readlane(wpb, b);
+    const unsigned blo = __builtin_amdgcn_readlane((unsigned)(bit & 0xFFFFFFFFu), b), bhi = __builtin_amdgcn_readlane((unsigned)(bit >> 32), b);
+    const unsigned plo_ = __builtin_amdgcn_readlane((unsigned)((uintptr_t)base & 0xFFFFFFFFu), b);
+    const unsigned phi_ = __builtin_amdgcn_readlane((unsigned)((uintptr_t)base >> 32), b);
+    unsigned long long* sbase = (unsigned long long*)(((uintptr_t)phi_ << 32) | plo_);
+    const unsigned long long sbit = ((unsigned long long)bhi << 32) | blo;
+    for (int k = lane; k < snb; k += 64) {
+      int bx = sbx0 + k % snbx, by = sby0 + k / snbx;
+      atomicOr(&sbase[(size_t)(by * sbins_x + bx) * swpb], sbit);
+    }
+  }
 #endif
-  if (ok) {
-    P.kind = WR_PK_TEX_COPY; P.copy_sx0 = ix0; P.copy_sy0 = srow0; P.copy_step = step;
-    recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_TEX_COPY;
-  }
 }
 
-// ---------------------------------------------------------------------------
-// Binning: bit (p - T.first_prim) of bin b's mask row <=> prim p touches bin b.
-__global__ void wr_bin_kernel(const WrPrim* __restrict__ prims, int n_prims,
-                              const WrDrawDesc* __restrict__ draws,
-                              const WrTargetDesc* __restrict__ targets,
-                              unsigned long long* __restrict__ masks) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n_prims) return;
-  const WrPrim& P = prims[gid];
-  if (P.kind == WR_PK_NONE || P.kind == WR_PK_UNSUPPORTED) return;
-  const WrTargetDesc& T = targets[draws[P.draw].target];
-  int bx0 = wr_imax(P.x0, 0) / WR_BIN_W, bx1 = (wr_imin(P.x1, T.width) - 1) / WR_BIN_W;
-  int by0 = wr_imax(P.y0, 0) / WR_BIN_H, by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
-  by0 = wr_imax(by0, T.row_begin); by1 = wr_imin(by1, T.row_end - 1);
-  int rel = gid - T.first_prim;
-  unsigned long long bit = 1ull << (rel & 63);
-  int word = rel >> 6;
-  for (int by = by0; by <= by1; by++)
-    for (int bx = bx0; bx <= bx1; bx++)
-      atomicOr(&masks[(size_t)T.word_base + (size_t)(by * T.bins_x + bx) * T.words_per_bin + word], bit);
+// Vertex stage + binning, one thread per instance.
+__global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+                                const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
+                                WrRec* __restrict__ recs, int n_prims, const WrTargetDesc* __restrict__ targets,
+                                unsigned long long* __restrict__ masks, WrUnsupportedCounters* cnt) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = gid < n_prims;
+  WrPrim P;
+  P.kind = WR_PK_NONE; P.draw = 0; P.x0 = P.y0 = P.x1 = P.y1 = 0;
+  if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, cnt);
+  if (valid) { prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format); }
+  wr_bin_prim(P, valid, gid, draws, targets, masks);
 }
 
 // Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
@@ -984,27 +967,67 @@ WR_DEVICE uint32_t wr_mul24(uint32_t a, uint32_t b) {
 // 255 * 256 < 2^16).
 #define WR_M8 0x00FF00FFu
 
-// Apply one prim to the 16 pixels of this lane.  All prim parameters are
-// wave-uniform (SGPRs); (px,py) is the lane's first pixel, (wx0,wy0) the
-// wave's 64x16 strip origin.
-template <int FMT, bool DEPTH>
-WR_DEVICE void wr_apply_prim(uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t (&dep)[16],
+// Apply one prim to the 4*R pixels of this lane (4 wide x R rows, rows 4 apart).
+// All prim parameters are wave-uniform (SGPRs); (px,py) is the lane's first
+// pixel, (wx0,wy0) the wave's 64 x 4R strip origin.
+template <int FMT, bool DEPTH, int R>
+WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uint32_t (&dep)[4 * R],
                              const int x0, const int y0, const int x1, const int y1, const uint32_t z,
                              const uint32_t kbf, const uint32_t c0, const uint32_t c1,
                              const WrPrim* Pp, const WrDrawDesc* draws,
                              const int px, const int py, const int wx0, const int wy0) {
   constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
-  const int kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = kbf >> 16;
+  constexpr int NPX = 4 * R;
+  const int kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
+  const bool dtest = DEPTH && (flags & WR_PF_DEPTH_TEST);
+  const bool dwrite = (flags & WR_PF_DEPTH_WRITE) != 0, dless = (flags & WR_PF_DEPTH_LESS) != 0;
+  // does the prim cover this wave's whole strip?  (uniform)
+  const bool full = x0 <= wx0 && x1 >= wx0 + WR_BIN_W && y0 <= wy0 && y1 >= wy0 + 4 * R;
+
+  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID_FOLDED) {
+    // ---- hot path: swgl_commitSolidRGBA8, no blend or premultiplied alpha ----
+    //   new = hi_bytes(dst * K + C) per channel pair; K, C prepared by wr_make_rec.
+    const uint32_t K = kbf >> 24, Clo = c0, Chi = c1;
+    if (full && !dtest) {
+#pragma unroll
+      for (int q = 0; q < NPX; q++) {
+        plo[q] = wr_hi_bytes(wr_mul24(plo[q], K) + Clo);
+        phi[q] = wr_hi_bytes(wr_mul24(phi[q], K) + Chi);
+      }
+      return;
+    }
+    bool cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const bool cyj = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        bool in = cx[i] && cyj;
+        if (dtest) {
+          const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+          in = in && pass;
+          if (dwrite) dep[q] = in ? z : dep[q];
+        }
+        const uint32_t nl = wr_hi_bytes(wr_mul24(plo[q], K) + Clo), nh = wr_hi_bytes(wr_mul24(phi[q], K) + Chi);
+        plo[q] = in ? nl : plo[q]; phi[q] = in ? nh : phi[q];
+      }
+    }
+    return;
+  }
+
   // per-lane coverage
-  bool cx[4], cy[4];
+  bool cx[4], cy[R];
 #pragma unroll
   for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
 #pragma unroll
-  for (int j = 0; j < 4; j++) cy[j] = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
+  for (int j = 0; j < R; j++) cy[j] = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
 
   if (kind == WR_PK_CLEAR) {
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < NPX; q++) {
       const bool in = cx[q & 3] && cy[q >> 2];
       if (flags & WR_PF_CLEAR_COLOR) {
         uint32_t nlo = BPP == 4 ? (c0 & WR_M8) : c0, nhi = BPP == 4 ? ((c0 >> 8) & WR_M8) : 0;
@@ -1015,98 +1038,80 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t 
     }
     return;
   }
-  const bool dtest = DEPTH && (flags & WR_PF_DEPTH_TEST);
-  const bool dwrite = (flags & WR_PF_DEPTH_WRITE) != 0, dless = (flags & WR_PF_DEPTH_LESS) != 0;
-  // does the prim cover this wave's whole 64x16 strip?  (uniform)
-  const bool full = x0 <= wx0 && x1 >= wx0 + WR_BIN_W && y0 <= wy0 && y1 >= wy0 + 16;
 
-// Applies BODY (new channel pairs nl/nh computed from dl/dh) to the 16 pixels
-// of this lane, with coverage / depth predicates only where needed.
-#define WR_FOR_PIXELS(BODY)                                                          \
-  if (full && !dtest) {                                                               \
-    _Pragma("unroll") for (int q = 0; q < 16; q++) {                                  \
-      const uint32_t dl = plo[q], dh = phi[q]; uint32_t nl, nh; BODY;                 \
-      plo[q] = nl; phi[q] = nh;                                                       \
-    }                                                                                 \
-  } else {                                                                            \
-    _Pragma("unroll") for (int q = 0; q < 16; q++) {                                  \
-      bool in = cx[q & 3] && cy[q >> 2];                                              \
-      if (dtest) {                                                                    \
-        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);                       \
-        in = in && pass;                                                              \
-        if (dwrite) dep[q] = in ? z : dep[q];                                         \
-      }                                                                               \
-      const uint32_t dl = plo[q], dh = phi[q]; uint32_t nl, nh; BODY;                 \
-      plo[q] = in ? nl : dl; phi[q] = in ? nh : dh;                                   \
-    }                                                                                 \
+  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID && blend == WR_BLEND_PREMULT && ((c0 | c1) & 0xFF00FF00u) == 0) {
+    // premultiplied blend of a colour whose channels exceed its alpha: same
+    // formula, but the sum can pass 255 and needs pack()'s clamp
+    const uint32_t K = 255u - (c1 >> 16);
+    const uint32_t ulo = (c0 & 0xFFFF) | ((c1 & 0xFFFF) << 16), uhi = (c0 >> 16) | (c1 & 0xFFFF0000u);
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      bool in = cx[q & 3] && cy[q >> 2];
+      if (dtest) {
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+        in = in && pass;
+        if (dwrite) dep[q] = in ? z : dep[q];
+      }
+      const uint32_t nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + ulo, WR_M8);
+      const uint32_t nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + uhi, WR_M8);
+      plo[q] = in ? nl : plo[q]; phi[q] = in ? nh : phi[q];
+    }
+    return;
   }
-
-  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
-    // ---- fast path: swgl_commitSolidRGBA8 with no blend / premultiplied alpha ----
-    // premultiplied:  src + dst - ((dst * (a + 1)) >> 8) in u16 lanes, then pack() clamp.
-    //   With K = 255 - a:  dst - ((dst*(a+1)) >> 8) == (dst*K + 255) >> 8   (exact),
-    //   so per channel pair  new = ((dst*K + 0x00FF00FF) >> 8 & M) + src.
-    //   For a valid premultiplied colour (b,g,r <= a) the result never exceeds
-    //   255 and src folds into the rounding constant: new = hi_bytes(dst*K + C).
-    // no blend: the same formula with K = 0 and src = pack(colour).
-    const bool bytes = ((c0 | c1) & 0xFF00FF00u) == 0;             // all source lanes <= 255
-    uint32_t b = c0 & 0xFFFF, g = c0 >> 16, r = c1 & 0xFFFF, a = c1 >> 16;
-    uint32_t K = 255u - a;
-    bool folded = bytes && b <= a && g <= a && r <= a;
-    if (blend == WR_BLEND_NONE) {
-      b = wr_pack1(b); g = wr_pack1(g); r = wr_pack1(r); a = wr_pack1(a);
-      K = 0; folded = true;
-    }
-    const uint32_t ulo = b | (r << 16), uhi = g | (a << 16);
-    if (folded) {
-      const uint32_t Clo = WR_M8 + (ulo << 8), Chi = WR_M8 + (uhi << 8);
-      WR_FOR_PIXELS({ nl = wr_hi_bytes(wr_mul24(dl, K) + Clo); nh = wr_hi_bytes(wr_mul24(dh, K) + Chi); })
-      return;
-    }
-    if (bytes) {
-      WR_FOR_PIXELS({ nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(dl, K) + WR_M8) + ulo, WR_M8);
-                      nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(dh, K) + WR_M8) + uhi, WR_M8); })
-      return;
-    }
-    // colours outside [0,1]: fall through to the generic path
-  }
-  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_COPY && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
-    // ---- 1:1 texel copy (composite pass): 4 consecutive source texels per row ----
-    const WrTexDesc& tex = draws[Pp->draw].tex[Pp->tex_slot];
+  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_RGBA8 && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
+    // ---- swgl_commitTexture*RGBA8: per lane-row span setup, then 4 texels ----
+    // Rows whose 4 pixels all fall in the nearest-fast part of the span
+    // (blendTextureNearestFast, swgl_ext.h:475-537) fetch their texels directly;
+    // anything else (linear filters, fragment-shader tail) goes pixel by pixel
+    // through the out-of-line generic path.
+    const WrPrim& P = *Pp;
+    const WrDrawDesc* D = &draws[P.draw];
+    const WrTexDesc& tex = D->tex[P.tex_slot];
     const uint32_t* sbuf = (const uint32_t*)tex.ptr;
-    const int sxl = Pp->copy_sx0 + (px - x0);
-    const int step = Pp->copy_step, sy0 = Pp->copy_sy0;
+    const int n0 = px - x0;
+    const bool has_color = (flags & WR_PF_HAS_COLOR) != 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < R; j++) {
       const int y = py + 4 * j;
-      if (!cy[j]) continue;
-      const uint32_t* srow = sbuf + (size_t)(sy0 + (y - y0) * step) * tex.stride;
-      uint32_t sp[4];
-      const bool allx = cx[0] && cx[3];
-      if (allx && ((sxl & 3) == 0) && ((tex.stride & 3) == 0)) {
-        uint4 v = *(const uint4*)(srow + sxl);
-        sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
-      } else {
+      uint32_t sp[4] = {0, 0, 0, 0};
+      bool rowfast = false;
+      if (cy[j] && sbuf) {
+        const WrTexRow r = wr_tex_row(P, tex, y);
+        rowfast = r.filter == 0 && n0 >= 0 && n0 + 4 <= r.span;
+        if (rowfast) {
+          const uint32_t* srow = sbuf + (size_t)r.srow * tex.stride;
 #pragma unroll
-        for (int i = 0; i < 4; i++) sp[i] = cx[i] ? srow[sxl + i] : 0u;
+          for (int i = 0; i < 4; i++) sp[i] = srow[wr_iclamp(r.ix + n0 + i, r.minX, r.maxX)];
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
-        bool in = cx[i];
+        bool in = cx[i] && cy[j];
         if (dtest) {
           const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
           in = in && pass;
           if (dwrite) dep[q] = in ? z : dep[q];
         }
-        const uint32_t sl = sp[i] & WR_M8, sh = (sp[i] >> 8) & WR_M8;
-        uint32_t nl = sl, nh = sh;
-        if (blend == WR_BLEND_PREMULT) {
-          const uint32_t K = 255u - (sh >> 16);
-          nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
-          nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
+        if (rowfast) {
+          uint32_t sl = sp[i] & WR_M8, sh = (sp[i] >> 8) & WR_M8;
+          if (has_color) {  // applyColor: muldiv255(colour, src) per channel
+            const uint32_t cb = c0 & 0xFFFF, cg = c0 >> 16, cr = c1 & 0xFFFF, ca = c1 >> 16;
+            const uint32_t sb = sl & 0xFFFF, sr = sl >> 16, sg = sh & 0xFFFF, sa = sh >> 16;
+            sl = (((cb * sb + cb) & 0xFFFF) >> 8) | ((((cr * sr + cr) & 0xFFFF) >> 8) << 16);
+            sh = (((cg * sg + cg) & 0xFFFF) >> 8) | ((((ca * sa + ca) & 0xFFFF) >> 8) << 16);
+          }
+          uint32_t nl = sl, nh = sh;
+          if (blend == WR_BLEND_PREMULT) {
+            const uint32_t K = 255u - (sh >> 16);
+            nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
+            nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
+          }
+          plo[q] = in ? nl : plo[q]; phi[q] = in ? nh : phi[q];
+        } else if (in) {
+          uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + i, y, plo[q] | (phi[q] << 8));
+          plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
         }
-        plo[q] = in ? nl : plo[q]; phi[q] = in ? nh : phi[q];
       }
     }
     return;
@@ -1114,7 +1119,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t 
   // ---- generic path ----
   const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
-  for (int q = 0; q < 16; q++) {
+  for (int q = 0; q < NPX; q++) {
     bool in = cx[q & 3] && cy[q >> 2];
     if (dtest) {
       const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
@@ -1131,15 +1136,16 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t 
       }
     }
   }
-#undef WR_FOR_PIXELS
 }
 
-template <int FMT, bool DEPTH>
-__global__ void __launch_bounds__(256)
+// One workgroup per 64x64 bin; 64/(4R) waves of 64 lanes, each lane 4 x R pixels.
+template <int FMT, bool DEPTH, int R>
+__global__ void __launch_bounds__(1024 / R)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs,
-                 const unsigned long long* __restrict__ masks, int bin_offset) {
+                 unsigned long long* __restrict__ masks, int bin_offset) {
+  constexpr int NPX = 4 * R, STRIP = 4 * R;
   const int bin = blockIdx.x + bin_offset;
   int t = 0;
   {
@@ -1155,18 +1161,25 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
   const int lb = bin - T.first_bin;
   const int bx = lb % T.bins_x, by = lb / T.bins_x;
   if (by < T.row_begin || by >= T.row_end) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wx0 = bx * WR_BIN_W, wy0 = by * WR_BIN_H + wave * 16;
+  // the wave index is uniform across the wave: say so, or everything derived
+  // from it (strip origin, coverage class of a prim) is treated as divergent
+#ifdef WRHIP_HOSTSIM
+  const int wave = threadIdx.x >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+  const int lane = threadIdx.x & 63;
+  const int wx0 = bx * WR_BIN_W, wy0 = by * WR_BIN_H + wave * STRIP;
   const int px = wx0 + (lane & 15) * 4;
   const int py = wy0 + (lane >> 4);
   constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
   const bool vec_ok = BPP == 4 && px + 4 <= T.width && ((T.stride & 15) == 0);
 
   // RGBA8: lo/hi channel pairs; R8: value in lo
-  uint32_t plo[16], phi[16], dep[16];
+  uint32_t plo[NPX], phi[NPX], dep[NPX];
   // ---- initial pixel state ---------------------------------------------
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < R; j++) {
     const int y = py + 4 * j;
     uint32_t c[4] = {T.init_color, T.init_color, T.init_color, T.init_color};
     if (T.load_color && y < T.height) {
@@ -1196,34 +1209,48 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
     }
   }
   // ---- apply every prim of this bin, in submission order -----------------
-  const unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
-  for (int w = 0; w < T.words_per_bin; w++) {
-    const unsigned long long m = mw[w];
-    if (!m) continue;
-    const int base = T.first_prim + w * 64;
+  unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
 #ifdef WRHIP_HOSTSIM
+  for (int w = 0; w < T.words_per_bin; w++) {
     // serial reference iteration (host simulation has no cross-lane ops)
-    unsigned long long live = m;
+    unsigned long long live = mw[w];
+    const int base = T.first_prim + w * 64;
     while (live) {
       const int bit = __builtin_ctzll(live);
       live &= live - 1;
-      const WrRec R = recs[base + bit];
-      if (R.x1 <= wx0 || R.x0 >= wx0 + WR_BIN_W || R.y1 <= wy0 || R.y0 >= wy0 + 16) continue;
-      wr_apply_prim<FMT, DEPTH>(plo, phi, dep, R.x0, R.y0, R.x1, R.y1, R.z, R.kbf, R.c0, R.c1, &prims[base + bit], draws,
-                                px, py, wx0, wy0);
+      const WrRec Rc = recs[base + bit];
+      if (Rc.x1 <= wx0 || Rc.x0 >= wx0 + WR_BIN_W || Rc.y1 <= wy0 || Rc.y0 >= wy0 + STRIP) continue;
+      wr_apply_prim<FMT, DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, &prims[base + bit],
+                                   draws, px, py, wx0, wy0);
     }
+  }
 #else
-    // Wave-cooperative fetch: lane l loads the record of the word's l-th prim
-    // (one memory latency for up to 64 prims), tests it against this wave's
-    // strip, and the survivors -- a ballot mask, still in submission order -- are
-    // broadcast one by one with v_readlane into SGPRs.
-    const bool has = (m >> lane) & 1ull;
-    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-    if (has) {
-      const uint4* rp = (const uint4*)&recs[base + lane];
-      ra = rp[0]; rb = rp[1];
+  // Wave-cooperative fetch: lane l loads the record of the word's l-th prim
+  // (one memory latency for up to 64 prims, the next word's records are
+  // requested before the current word is processed), tests it against this
+  // wave's strip, and the survivors -- a ballot mask, still in submission
+  // order -- are broadcast one by one with v_readlane into SGPRs.
+  const int nw = T.words_per_bin;
+  unsigned long long m_next = nw > 0 ? mw[0] : 0ull;
+  uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
+  if ((m_next >> lane) & 1ull) {
+    const uint4* rp = (const uint4*)&recs[T.first_prim + lane];
+    na = rp[0]; nb = rp[1];
+  }
+  for (int w = 0; w < nw; w++) {
+    const unsigned long long m = m_next;
+    const uint4 ra = na, rb = nb;
+    const int base = T.first_prim + w * 64;
+    if (w + 1 < nw) {
+      m_next = mw[w + 1];
+      if ((m_next >> lane) & 1ull) {
+        const uint4* rp = (const uint4*)&recs[base + 64 + lane];
+        na = rp[0]; nb = rp[1];
+      }
     }
-    const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + 16);
+    if (!m) continue;
+    const bool has = (m >> lane) & 1ull;
+    const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);
     unsigned long long live = __ballot(hit);
     while (live) {
       const int bit = __builtin_ctzll(live);
@@ -1232,13 +1259,17 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       const int x1 = __builtin_amdgcn_readlane((int)ra.z, bit), y1 = __builtin_amdgcn_readlane((int)ra.w, bit);
       const uint32_t z = __builtin_amdgcn_readlane((int)rb.x, bit), kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
       const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
-      wr_apply_prim<FMT, DEPTH>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], draws, px, py, wx0, wy0);
+      wr_apply_prim<FMT, DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], draws, px, py, wx0, wy0);
     }
-#endif
   }
+  // Self-cleaning bin masks: once every wave of the workgroup has consumed the
+  // bin's words, zero them so the next flush needs no memset launch.
+  __syncthreads();
+  for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) mw[w] = 0ull;
+#endif
   // ---- write back ------------------------------------------------------------
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < R; j++) {
     const int y = py + 4 * j;
     if (y >= T.height) continue;
     uint8_t* rowp = (uint8_t*)T.color + (size_t)y * T.stride;

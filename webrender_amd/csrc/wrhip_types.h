@@ -128,8 +128,8 @@ enum WrPrimKind {
   WR_PK_CLEAR,
   WR_PK_SOLID,          // swgl_commitSolid* / flat fragment colour
   WR_PK_TEX_RGBA8,      // swgl_commitTexture*RGBA8 family (rect, axis-aligned uv)
-  WR_PK_TEX_COPY,       // textured prim proven to be a 1:1 texel copy (wr_tex_is_copy)
   WR_PK_UNSUPPORTED,
+  WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
 };
 
 enum WrPrimFlags {
@@ -157,7 +157,7 @@ struct WrPrim {
   float uv_bounds[4];       // uv_rect passed to swgl_commitTexture*
   float fcolor[4];          // float colour for the fragment-shader (tail) path
   int32_t tex_slot;         // sampler slot
-  int32_t copy_sx0, copy_sy0, copy_step;  // WR_PK_TEX_COPY: src texel of (x0,y0), row step (+1/-1)
+  int32_t pad[3];
 };
 
 // Compact per-prim record the raster stage streams (32 B, dense array): the
