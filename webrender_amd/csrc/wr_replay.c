@@ -78,6 +78,19 @@ static int run_once(wr_replay* R, const uint8_t* t, size_t len) {
 
 int wr_replay_exec(wr_replay* R, const uint8_t* trace, size_t len) { return run_once(R, trace, len); }
 
+/* Throughput loop: replays the frame trace `iters` times back to back, then calls
+ * the backend's Finish() once.  Returns total wall milliseconds in *total_ms. */
+int wr_replay_stream(wr_replay* R, const uint8_t* trace, size_t len, int iters, double* total_ms) {
+  void (*finish)(void) = (void (*)(void))dlsym(R->dl, "Finish");
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int i = 0; i < iters; i++) { int rc = run_once(R, trace, len); if (rc) return rc; }
+  if (finish) finish();
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  *total_ms = (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6;
+  return 0;
+}
+
 int wr_replay_loop(wr_replay* R, const uint8_t* trace, size_t len, int warmup, int iters, double* ms_out) {
   for (int i = 0; i < warmup; i++) { int rc = run_once(R, trace, len); if (rc) return rc; }
   for (int i = 0; i < iters; i++) {

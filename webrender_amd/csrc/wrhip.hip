@@ -203,14 +203,17 @@ struct Context {
   // deferred work
   std::vector<TargetWork> work;       // render targets with pending draws
   std::vector<GLuint> referenced;     // textures with pending_read/pending_write set
-  // frame arenas (pinned host + HBM), ring of 3
-  static const int NARENA = 3;
-  uint8_t* harena[NARENA] = {nullptr, nullptr, nullptr};
-  size_t harena_size[NARENA] = {0, 0, 0};
-  wr_event_t arena_event[NARENA];
-  bool arena_used[NARENA] = {false, false, false};
-  int arena_index = 0;
-  uint8_t* darena = nullptr; size_t darena_size = 0;
+  // Host->HBM traffic is batched: texture uploads (TexSubImage2D ...) and the
+  // per-flush frame arena are bump-allocated from one pinned staging ring and
+  // moved with ONE async DMA per flush into the device mirror `dupload` at the
+  // same offsets; a scatter kernel then writes texture rows to their
+  // destinations.  (Individual hipMemcpy*Async calls cost 6-40 us of host time
+  // and ~15 us of GPU-side latency each on this stack.)
+  struct UploadSeg { uint64_t src_off; void* dst; uint32_t dst_stride, row_bytes, rows, pad; };
+  std::vector<UploadSeg> useg;
+  size_t upload_begin = 0;        // staging offset where the pending batch starts
+  bool upload_open = false;
+  uint8_t* dupload = nullptr;     // HBM mirror of the staging ring
   WrPrim* dprims = nullptr; size_t dprims_cap = 0;
   WrRec* drecs = nullptr;
   unsigned long long* dmasks = nullptr; size_t dmasks_cap = 0;
@@ -231,7 +234,6 @@ struct Context {
 
   Context() {
     wrrt::stream_create(&stream);
-    for (int i = 0; i < NARENA; i++) wrrt::event_create(&arena_event[i]);
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
     if (const char* e = getenv("WRHIP_ROWS")) rows_per_lane = atoi(e) == 8 ? 8 : 4;
@@ -337,23 +339,75 @@ uint64_t get_time_value() {
 // Deferred work: flush
 void flush_all();
 
-uint8_t* staging_alloc(size_t n) {
+void flush_uploads(size_t extra_end = 0);
+
+const size_t STAGING_BYTES = size_t(96) << 20;
+
+// Bump allocation from the pinned staging ring.  Returns the byte offset.
+size_t staging_alloc(size_t n) {
   Context* c = ctx;
   n = (n + 255) & ~size_t(255);
-  if (n > c->staging_size) {
+  if (!c->staging || n > c->staging_size) {
+    flush_uploads();
     wrrt::stream_sync(c->stream);
     wrrt::pinned_free(c->staging);
-    c->staging_size = std::max(n, size_t(64) << 20);
+    wrrt::dev_free(c->dupload);
+    c->staging_size = std::max(n * 2, STAGING_BYTES);
     c->staging = (uint8_t*)wrrt::pinned_alloc(c->staging_size);
+    c->dupload = (uint8_t*)wrrt::dev_alloc(c->staging_size);
     c->staging_pos = 0;
   }
   if (c->staging_pos + n > c->staging_size) {
+    flush_uploads();                // the pending batch must stay contiguous
     wrrt::stream_sync(c->stream);   // everything staged so far has been consumed
     c->staging_pos = 0;
   }
-  uint8_t* p = c->staging + c->staging_pos;
+  if (!c->upload_open) { c->upload_open = true; c->upload_begin = c->staging_pos; }
+  size_t off = c->staging_pos;
   c->staging_pos += n;
-  return p;
+  return off;
+}
+
+// Queue rows already written at staging offset `src_off` for texture memory.
+void queue_upload(size_t src_off, void* dst, size_t dst_stride, size_t row_bytes, size_t rows) {
+  Context::UploadSeg sg;
+  sg.src_off = src_off; sg.dst = dst; sg.dst_stride = (uint32_t)dst_stride; sg.row_bytes = (uint32_t)row_bytes;
+  sg.rows = (uint32_t)rows; sg.pad = 0;
+  ctx->useg.push_back(sg);
+  ctx->stats.h2d_bytes += row_bytes * rows;
+}
+
+// One DMA for everything staged since the last flush, then the scatter kernel.
+void flush_uploads(size_t) {
+  Context* c = ctx;
+  if (!c->upload_open) return;
+  size_t nseg = c->useg.size();
+  size_t seg_off = 0;
+  if (nseg) {
+    // descriptors ride along in the same batch (cannot wrap: checked by caller paths via staging_alloc)
+    size_t need = (nseg * sizeof(WrUploadSeg) + 255) & ~size_t(255);
+    if (c->staging_pos + need > c->staging_size) {
+      // no room for descriptors at the tail: ship data first with per-segment copies
+      for (auto& sg : c->useg)
+        wrrt::copy2d(sg.dst, sg.dst_stride, c->staging + sg.src_off, sg.row_bytes, sg.row_bytes, sg.rows, 0, c->stream);
+      c->useg.clear(); nseg = 0;
+    } else {
+      seg_off = c->staging_pos; c->staging_pos += need;
+      WrUploadSeg* d = (WrUploadSeg*)(c->staging + seg_off);
+      for (size_t i = 0; i < nseg; i++) {
+        d[i].src = c->dupload + c->useg[i].src_off; d[i].dst = c->useg[i].dst;
+        d[i].dst_stride = c->useg[i].dst_stride; d[i].row_bytes = c->useg[i].row_bytes; d[i].rows = c->useg[i].rows; d[i].pad = 0;
+      }
+    }
+  }
+  size_t b = c->upload_begin, e = c->staging_pos;
+  if (e > b) wrrt::h2d(c->dupload + b, c->staging + b, e - b, c->stream);
+  if (nseg) {
+    WR_LAUNCH(wr_upload_kernel, (int)nseg * 8, 256, c->stream, (const WrUploadSeg*)(c->dupload + seg_off), (int)nseg);
+    c->stats.kernel_launches++;
+    c->useg.clear();
+  }
+  c->upload_open = false;
 }
 
 void mark_ref(GLuint id, Texture& t, bool write, int target_index = -1) {
@@ -377,7 +431,7 @@ void flush_except(GLuint keep) {
 // A host- or copy-side write to texture `t` (or its deletion / reallocation)
 // must not overtake pending draws that read or write it.
 void sync_texture_for_write(Texture& t) { if (t.pending_read || t.pending_write) flush_all(); }
-void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); }
+void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); flush_uploads(); }
 
 size_t pool_round(size_t n) {
   size_t g = n <= (1u << 20) ? 4096 : (size_t(1) << 16);
@@ -411,6 +465,7 @@ void pool_free(void* p, size_t n) {
 
 void free_texture_storage(Texture& t) {
   sync_texture_for_write(t);
+  flush_uploads();   // queued rows may target this storage
   if (t.dptr) {
     pool_free(t.dptr, t.dsize);
     t.dptr = nullptr; t.dsize = 0;
@@ -431,7 +486,7 @@ bool allocate_texture(Texture& t) {
   }
   if (size == 0) return true;
   if (!t.dptr || size > t.dsize) {
-    if (t.dptr) pool_free(t.dptr, t.dsize);
+    if (t.dptr) { flush_uploads(); pool_free(t.dptr, t.dsize); }
     size_t actual = 0;
     t.dptr = pool_alloc(size, &actual);
     t.dsize = actual;
@@ -455,7 +510,8 @@ void set_tex_storage(Texture& t, GLenum external_format, GLsizei width, GLsizei 
     if (!conv) { t.ext_buf = buf; t.ext_stride = stride; }
     // upload current contents of the external buffer
     size_t row = (size_t)t.bpp * width;
-    uint8_t* st = staging_alloc(row * height);
+    size_t st_off = staging_alloc(row * height);
+    uint8_t* st = ctx->staging + st_off;
     for (int y = 0; y < height; y++) {
       const uint8_t* s = (const uint8_t*)buf + (size_t)y * stride;
       uint8_t* d = st + (size_t)y * row;
@@ -466,8 +522,7 @@ void set_tex_storage(Texture& t, GLenum external_format, GLsizei width, GLsizei 
         }
       } else memcpy(d, s, row);
     }
-    wrrt::copy2d(t.dptr, t.stride, st, row, row, height, 0, ctx->stream);
-    ctx->stats.h2d_bytes += row * height;
+    queue_upload(st_off, t.dptr, t.stride, row, height);
   }
 }
 
@@ -599,12 +654,12 @@ Context::~Context() {
   Context* saved = ctx;
   ctx = this;
   flush_all();
+  flush_uploads();
   wrrt::stream_sync(stream);
   for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
-  for (int i = 0; i < NARENA; i++) { wrrt::pinned_free(harena[i]); wrrt::event_destroy(arena_event[i]); }
-  wrrt::dev_free(darena); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
+  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::stream_destroy(stream);
@@ -706,26 +761,13 @@ void flush_work(const std::vector<int>& sel_in) {
     size_t off_targets = (off_draws + sizeof(WrDrawDesc) * nd + 255) & ~size_t(255);
     size_t off_inst = (off_targets + sizeof(WrTargetDesc) * n_targets + 255) & ~size_t(255);
     size_t total = off_inst + inst.size() + 256;
-    int ai = c->arena_index; c->arena_index = (ai + 1) % Context::NARENA;
-    if (c->arena_used[ai]) wrrt::event_sync(&c->arena_event[ai]);
-    if (c->harena_size[ai] < total) {
-      wrrt::pinned_free(c->harena[ai]);
-      c->harena_size[ai] = total * 2;
-      c->harena[ai] = (uint8_t*)wrrt::pinned_alloc(c->harena_size[ai]);
-    }
-    if (c->darena_size < total) {
-      wrrt::stream_sync(c->stream);
-      wrrt::dev_free(c->darena);
-      c->darena_size = total * 2;
-      c->darena = (uint8_t*)wrrt::dev_alloc(c->darena_size);
-    }
-    uint8_t* h = c->harena[ai];
+    size_t aoff = staging_alloc(total);
+    uint8_t* h = c->staging + aoff;
     if (nd) memcpy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     memcpy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
     if (!inst.empty()) memcpy(h + off_inst, inst.data(), inst.size());
-    wrrt::h2d(c->darena, h, total, c->stream);
-    wrrt::event_record(&c->arena_event[ai], c->stream);
-    c->arena_used[ai] = true;
+    flush_uploads();     // one DMA: queued texture uploads + this arena; then the scatter kernel
+    uint8_t* darena = c->dupload + aoff;
     c->stats.h2d_bytes += total;
     algo_bytes += inst.size() + sizeof(WrDrawDesc) * nd;
     // ---- scratch ----
@@ -747,9 +789,9 @@ void flush_work(const std::vector<int>& sel_in) {
 #ifdef WRHIP_HOSTSIM
     wrrt::memset8(c->dmasks, 0, (size_t)n_words * 8, c->stream);
 #endif
-    const WrDrawDesc* ddraws = (const WrDrawDesc*)(c->darena + off_draws);
-    const WrTargetDesc* dtargets = (const WrTargetDesc*)(c->darena + off_targets);
-    const uint8_t* dinst = c->darena + off_inst;
+    const WrDrawDesc* ddraws = (const WrDrawDesc*)(darena + off_draws);
+    const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
+    const uint8_t* dinst = darena + off_inst;
     if (n_prims > 0) {
       WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, n_prims,
                 dtargets, c->dmasks, c->dcounters);
@@ -1065,7 +1107,8 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
   bool conv = format_requires_conversion(format, t.internal_format);
   size_t src_stride = (size_t)row_length * t.bpp;
   size_t row = (size_t)width * t.bpp;
-  uint8_t* st = staging_alloc(row * height);
+  size_t st_off = staging_alloc(row * height);
+  uint8_t* st = ctx->staging + st_off;
   for (int y = 0; y < height; y++) {
     const uint8_t* s = data + (size_t)y * src_stride;
     uint8_t* d = st + (size_t)y * row;
@@ -1078,9 +1121,7 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
       }
     } else memcpy(d, s, row);
   }
-  wrrt::copy2d((uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, st, row, row, height, 0,
-               ctx->stream);
-  ctx->stats.h2d_bytes += row * height;
+  queue_upload(st_off, (uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, row, height);
 }
 void TexImage2D(GLenum target, GLint level, GLint internal_format, GLsizei width, GLsizei height, GLint, GLenum format,
                 GLenum ty, const void* data) {
@@ -1382,6 +1423,7 @@ void CopyImageSubData(GLuint srcName, GLenum srcTarget, GLint, GLint srcX, GLint
       dstX + srcWidth > d.width || dstY + srcHeight > d.height) return;
   sync_texture_for_read(s);
   sync_texture_for_write(d);
+  flush_uploads();
   wrrt::copy2d((uint8_t*)d.dptr + (size_t)dstY * d.stride + (size_t)dstX * d.bpp, d.stride,
                (const uint8_t*)s.dptr + (size_t)srcY * s.stride + (size_t)srcX * s.bpp, s.stride,
                (size_t)srcWidth * s.bpp, srcHeight, 2, ctx->stream);
@@ -1552,6 +1594,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
 
 void Finish(void) {
   flush_all();
+  flush_uploads();
   wrrt::stream_sync(ctx->stream);
   // externally backed default framebuffer: make the result visible to the host
   Framebuffer* fb = ctx->framebuffers.find(0);

@@ -169,6 +169,10 @@ struct WrRec {
   uint32_t c0, c1;       // WrPrim::color
 };
 
+// One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM
+// mirror of the staging ring) -> `dst` with `dst_stride`.
+struct WrUploadSeg { const uint8_t* src; void* dst; uint32_t dst_stride, row_bytes, rows, pad; };
+
 struct WrFlushParams {
   int32_t n_draws, n_targets, n_prims, n_bins;
   int32_t n_words;          // total u64 mask words

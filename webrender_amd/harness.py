@@ -16,9 +16,10 @@ from .trace import Trace, NativeReplayer, TAG_SCRATCH
 
 
 class RecordedScene:
-    def __init__(self, width, height, setup, frame, read, read_offset):
+    def __init__(self, width, height, setup, frame, read, read_offset, stream=None):
         self.width, self.height = width, height
         self.setup, self.frame, self.read, self.read_offset = setup, frame, read, read_offset
+        self.stream = stream or frame
 
 
 def record_scene(recording_backend_path, frame):
@@ -34,6 +35,7 @@ def record_scene(recording_backend_path, frame):
     tr2.scratch = 0
     gl.trace = tr2
     r.render(frame)
+    stream_bytes = tr2.serialize()      # the frame without a trailing Finish (throughput loops)
     r.finish()
     frame_bytes = tr2.serialize()
     tr3 = Trace()
@@ -43,7 +45,7 @@ def record_scene(recording_backend_path, frame):
     read_off = [v for (_, args) in tr3.calls for (tag, _, v) in args if tag == TAG_SCRATCH][-1]
     gl.trace = None
     r.destroy()
-    return RecordedScene(frame.width, frame.height, setup, frame_bytes, read_bytes, read_off), px
+    return RecordedScene(frame.width, frame.height, setup, frame_bytes, read_bytes, read_off, stream_bytes), px
 
 
 class ScenePlayer:
@@ -56,6 +58,10 @@ class ScenePlayer:
 
     def frames(self, warmup, iters):
         return self.rp.loop(self.scene.frame, warmup, iters)
+
+    def stream(self, iters):
+        """`iters` frames back to back, one Finish at the end; total wall ms."""
+        return self.rp.stream(self.scene.stream, iters)
 
     def read_pixels(self):
         self.rp.exec(self.scene.read)

@@ -131,6 +131,8 @@ class NativeReplayer:
         self.lib.wr_replay_loop.restype = C.c_int
         self.lib.wr_replay_loop.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int,
                                             C.POINTER(C.c_double)]
+        self.lib.wr_replay_stream.restype = C.c_int
+        self.lib.wr_replay_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         self.lib.wr_replay_scratch.restype = C.c_void_p
         self.lib.wr_replay_scratch.argtypes = [C.c_void_p, C.c_size_t]
         self.lib.wr_replay_sym.restype = C.c_void_p
@@ -152,6 +154,15 @@ class NativeReplayer:
         if rc != 0:
             raise RuntimeError(f"trace replay failed at call {rc - 1}")
         return np.array(out[:], dtype=np.float64)
+
+    def stream(self, trace_bytes, iters):
+        """Replay `iters` frames back to back with one Finish() at the end
+        (throughput mode); returns total wall ms."""
+        out = C.c_double(0.0)
+        rc = self.lib.wr_replay_stream(self.h, trace_bytes, len(trace_bytes), iters, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"trace replay failed at call {rc - 1}")
+        return out.value
 
     def scratch(self, offset, nbytes):
         """Bytes the last replay wrote through an output pointer (e.g. ReadPixels)."""
