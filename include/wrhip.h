@@ -234,6 +234,10 @@ void WrhipSetProfiling(int enabled);
 /* Restrict rasterisation to tile-rows owned by `rank` of `world` (multi-GPU
  * sharding by render-target strips). world<=1 disables. */
 void WrhipSetShard(int rank, int world);
+/* Restrict rasterisation of render target `tex` to pixel rows [y0,y1) (rows
+ * outside are neither computed nor stored); y0==y1 removes the restriction.
+ * Used by the multi-GPU harness to give each rank a screen-space strip. */
+void WrhipSetTargetRows(GLuint tex, int32_t y0, int32_t y1);
 /* Device pointer + geometry of a texture's HBM storage (for RCCL gather). */
 void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height,
                                int32_t* stride);

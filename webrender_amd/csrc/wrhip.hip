@@ -91,6 +91,7 @@ struct Texture {
   bool depth_materialized = false;
   uint32_t depth_value = 0xFFFFFF;
   // hazards against the pending list
+  int own_y0 = 0, own_y1 = 0;   // multi-GPU: owned pixel rows (0,0 = all)
   bool pending_read = false, pending_write = false;
   int pending_target = -1;   // index into Context::work when pending_write
   bool has_storage() const { return dptr != nullptr; }
@@ -698,10 +699,12 @@ void flush_work(const std::vector<int>& sel_in) {
     T.load_color = 1; T.init_color = 0; T.load_depth = 0; T.store_depth = 0;
     Texture* dt = w.depth_tex ? c->textures.find(w.depth_tex) : nullptr;
     T.init_depth = dt ? dt->depth_value : 0xFFFFFF;
-    T.row_begin = 0; T.row_end = T.bins_y;
-    if (c->shard_world > 1) {  // contiguous strips of bin rows per rank (DESIGN.md multi-GPU)
-      T.row_begin = (int)((int64_t)T.bins_y * c->shard_rank / c->shard_world);
-      T.row_end = (int)((int64_t)T.bins_y * (c->shard_rank + 1) / c->shard_world);
+    T.y_begin = 0; T.y_end = t.height;
+    if (t.own_y1 > t.own_y0) {   // WrhipSetTargetRows: rows of this target owned by this process
+      T.y_begin = std::max(0, t.own_y0); T.y_end = std::min(t.height, t.own_y1);
+    } else if (c->shard_world > 1) {  // WrhipSetShard: contiguous strips of bin rows per rank
+      T.y_begin = (int)((int64_t)T.bins_y * c->shard_rank / c->shard_world) * WR_BIN_H;
+      T.y_end = std::min(t.height, (int)((int64_t)T.bins_y * (c->shard_rank + 1) / c->shard_world) * WR_BIN_H);
     }
     size_t inst_base = (inst.size() + 15) & ~size_t(15);
     inst.resize(inst_base + w.inst.size());
@@ -731,7 +734,7 @@ void flush_work(const std::vector<int>& sel_in) {
     word_cursor += T.words_per_bin * T.bins_x * T.bins_y;
     bin_cursor += T.bins_x * T.bins_y;
     if (T.format == WR_FMT_RGBA8) bins_rgba = bin_cursor;
-    uint64_t owned = (uint64_t)t.width * std::max(0, std::min(t.height, T.row_end * WR_BIN_H) - T.row_begin * WR_BIN_H);
+    uint64_t owned = (uint64_t)t.width * std::max(0, T.y_end - T.y_begin);
     pixels += owned;
     algo_bytes += owned * t.bpp * (T.load_color ? 2 : 1);
     {  // unique source texels sampled: bounded by what a 1:1 mapping can touch
@@ -1669,6 +1672,12 @@ void WrhipGetStats(WrhipStats* out) { if (ctx && out) *out = ctx->stats; }
 void WrhipResetStats(void) { if (ctx) memset(&ctx->stats, 0, sizeof(ctx->stats)); }
 void WrhipSetProfiling(int enabled) { if (ctx) ctx->profiling = enabled != 0; }
 void WrhipSetShard(int rank, int world) { if (ctx) { flush_all(); ctx->shard_rank = rank; ctx->shard_world = world < 1 ? 1 : world; } }
+void WrhipSetTargetRows(GLuint tex, int32_t y0, int32_t y1) {
+  if (!ctx) return;
+  flush_all();
+  Texture& t = ctx->textures[tex];
+  t.own_y0 = y0; t.own_y1 = y1;
+}
 void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height, int32_t* stride) {
   Texture* t = ctx ? ctx->textures.find(tex) : nullptr;
   if (!t) return nullptr;

@@ -863,7 +863,7 @@ WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDes
     const WrTargetDesc& T = targets[draws[P.draw].target];
     bx0 = wr_imax(P.x0, 0) / WR_BIN_W; bx1 = (wr_imin(P.x1, T.width) - 1) / WR_BIN_W;
     by0 = wr_imax(P.y0, 0) / WR_BIN_H; by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
-    by0 = wr_imax(by0, T.row_begin); by1 = wr_imin(by1, T.row_end - 1);
+    by0 = wr_imax(by0, T.y_begin / WR_BIN_H); by1 = wr_imin(by1, (T.y_end - 1) / WR_BIN_H);
     const int rel = gid - T.first_prim;
     bit = 1ull << (rel & 63);
     bins_x = T.bins_x; wpb = T.words_per_bin;
@@ -1182,7 +1182,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
   if (T.format != FMT) return;
   const int lb = bin - T.first_bin;
   const int bx = lb % T.bins_x, by = lb / T.bins_x;
-  if (by < T.row_begin || by >= T.row_end) return;
+  if ((by + 1) * WR_BIN_H <= T.y_begin || by * WR_BIN_H >= T.y_end) return;
   // the wave index is uniform across the wave: say so, or everything derived
   // from it (strip origin, coverage class of a prim) is treated as divergent
 #ifdef WRHIP_HOSTSIM
@@ -1293,7 +1293,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
 #pragma unroll
   for (int j = 0; j < R; j++) {
     const int y = py + 4 * j;
-    if (y >= T.height) continue;
+    if (y >= T.height || y < T.y_begin || y >= T.y_end) continue;
     uint8_t* rowp = (uint8_t*)T.color + (size_t)y * T.stride;
     if (BPP == 4) {
       uint32_t c[4];

@@ -120,7 +120,7 @@ struct WrTargetDesc {
   int32_t first_prim, end_prim;  // global prim range of this target
   int32_t word_base;    // first u64 word of this target's bin masks
   int32_t words_per_bin;
-  int32_t row_begin, row_end;    // bin rows owned by this process (multi-GPU strip sharding)
+  int32_t y_begin, y_end;        // pixel rows owned by this process (multi-GPU strip sharding)
 };
 
 enum WrPrimKind {

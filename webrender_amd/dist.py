@@ -1,0 +1,157 @@
+"""Multi-GPU: screen-space strip sharding of one frame + RCCL all-gather of the
+window framebuffer.
+
+One process per GPU.  Every rank replays the *same* call stream (the data
+textures and instance arrays are small and broadcast by construction), but
+tells its backend which pixel rows of each render target it owns
+(`WrhipSetTargetRows`): rank r owns the screen rows [Y0_r, Y1_r) -- multiples of
+64 so they coincide with raster bins -- of every picture-cache tile and of the
+window.  Rows outside are neither rasterised nor stored.  Off-screen mask / blur
+targets are left unrestricted (replicated on every rank: they are tiny compared
+with tiles and would otherwise have to be exchanged between passes).
+
+The only collective is the all-gather that reassembles the framebuffer: each
+rank contributes its strip (equal-sized, padded) and receives the others, over
+xGMI with RCCL ("nccl" backend of torch.distributed) or gloo on CPU tests.
+"""
+import ctypes as C
+import numpy as np
+
+
+def strip_rows(height, rank, world, align=64):
+    """Screen rows [y0, y1) owned by `rank`: equal counts of `align`-row groups."""
+    groups = (height + align - 1) // align
+    per = (groups + world - 1) // world
+    y0 = min(height, rank * per * align)
+    y1 = min(height, (rank + 1) * per * align)
+    return y0, y1, per * align
+
+
+def target_rows_for_rank(rec, rank, world):
+    """{texture name: (y0, y1)} in texture rows for this rank, plus the window
+    strip in framebuffer rows.  The window projection is y-flipped
+    (renderer/mod.rs:4861-4866): screen row y is framebuffer row H-1-y."""
+    H = rec.height
+    sy0, sy1, _ = strip_rows(H, rank, world)
+    rows = {}
+    for name, (x0, y0, x1, y1) in rec.tile_rects.items():
+        ty0 = int(max(sy0 - y0, 0))
+        ty1 = int(min(sy1 - y0, y1 - y0))
+        rows[name] = (ty0, ty1) if ty1 > ty0 else (0, -1)   # (0,-1): owns nothing
+    fb = (H - sy1, H - sy0)
+    return rows, fb
+
+
+class DeviceArray:
+    """Minimal __cuda_array_interface__ wrapper so torch can view HBM owned by libwrhip."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+class ShardedFramePlayer:
+    """Renders `workload` with rows sharded over `world` ranks and all-gathers
+    the window.  Interface mirrors harness.ScenePlayer (frames / stream)."""
+
+    def __init__(self, lib, workload, encoding, rank, world, device="cuda", frame=None):
+        import torch
+        import torch.distributed as dist
+        from .harness import record_scene, ScenePlayer
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = rank, world
+        if frame is None:
+            from bench import make_frame
+            frame = make_frame(workload, encoding=encoding)
+        self.width, self.height = frame.width, frame.height
+        rec, _ = record_scene(lib, frame)
+        self.rec = rec
+        self.player = ScenePlayer(lib, rec)
+        sym = self.player.symbol
+        set_rows = C.CFUNCTYPE(None, C.c_uint32, C.c_int32, C.c_int32)(sym("WrhipSetTargetRows"))
+        fb_tex = C.CFUNCTYPE(C.c_uint32, C.c_uint32)(sym("WrhipGetFramebufferTexture"))(0)
+        get_ptr = C.CFUNCTYPE(C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p)(sym("WrhipGetTextureDevicePtr"))
+        rows, fb_rows = target_rows_for_rank(rec, rank, world)
+        for name, (y0, y1) in rows.items():
+            tid = rec.texture_ids[name]
+            if y1 > y0:
+                set_rows(tid, y0, y1)
+            else:
+                set_rows(tid, 1 << 30, (1 << 30) + 1)       # owns no row of this tile
+        if fb_rows[1] > fb_rows[0]:
+            set_rows(fb_tex, fb_rows[0], fb_rows[1])
+        else:
+            set_rows(fb_tex, 1 << 30, (1 << 30) + 1)
+        self.fb_rows = fb_rows
+        _, _, self.strip = strip_rows(self.height, rank, world)
+        self.row_bytes = self.width * 4
+        self.device = device
+        if device == "cuda":
+            ptr = get_ptr(fb_tex, None, None, None)
+            self.fb = torch.as_tensor(DeviceArray(ptr, self.height * self.row_bytes), device="cuda")
+        else:
+            self.fb = None       # CPU/gloo test path reads the strip back through ReadPixels
+        chunk = self.strip * self.row_bytes
+        self.send = [torch.zeros(chunk, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.gathered = [torch.zeros(chunk * world, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.pending = None
+        self.k = 0
+
+    # -- one frame: render own strips, then contribute to the all-gather ------
+    def _frame(self):
+        self.player.rp.exec(self.rec.frame)          # includes Finish(): strip is in HBM
+        i = self.k & 1
+        self.k += 1
+        y0, y1 = self.fb_rows
+        n = max(0, y1 - y0) * self.row_bytes
+        if self.device == "cuda":
+            if n:
+                self.send[i][:n].copy_(self.fb[y0 * self.row_bytes:y0 * self.row_bytes + n])
+        else:
+            px = self.player.read_pixels()             # RGBA bytes; strips are byte-exact either way
+            if n:
+                self.send[i][:n] = self.torch.from_numpy(px[y0:y1].reshape(-1).copy())
+        if self.pending is not None:
+            self.pending.wait()
+        self.pending = self.dist.all_gather_into_tensor(self.gathered[i], self.send[i], async_op=True)
+
+    def frames(self, warmup, iters):
+        import time
+        out = []
+        for it in range(warmup + iters):
+            t0 = time.perf_counter()
+            self._frame()
+            if it >= warmup:
+                out.append((time.perf_counter() - t0) * 1e3)
+        self._drain()
+        return np.array(out)
+
+    def stream(self, iters):
+        for _ in range(iters):
+            self._frame()
+        self._drain()
+
+    def _drain(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+        if self.device == "cuda":
+            self.torch.cuda.synchronize()
+
+    def assembled(self):
+        """The reassembled window (uint8 [H, W, 4]) from the last gather, in
+        framebuffer row order (bottom-up, as ReadPixels returns it)."""
+        self._drain()
+        g = self.gathered[(self.k - 1) & 1].cpu().numpy()
+        chunk = self.strip * self.row_bytes
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        for r in range(self.world):
+            sy0, sy1, _ = strip_rows(self.height, r, self.world)
+            if sy1 <= sy0:
+                continue
+            f0, f1 = self.height - sy1, self.height - sy0
+            out[f0:f1] = g[r * chunk:r * chunk + (f1 - f0) * self.row_bytes].reshape(f1 - f0, self.width, 4)
+        return out
+
+    def symbol(self, name):
+        return self.player.symbol(name)

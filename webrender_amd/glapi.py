@@ -128,6 +128,7 @@ EXTRA_SIGNATURES = {
     "WrhipResetStats": (None, []),
     "WrhipSetProfiling": (None, [i32]),
     "WrhipSetShard": (None, [i32, i32]),
+    "WrhipSetTargetRows": (None, [u32, i32, i32]),
     "WrhipGetTextureDevicePtr": (P, [u32, P, P, P]),
     "WrhipGetFramebufferTexture": (u32, [u32]),
     "WrhipDeviceName": (c_char_p, []),

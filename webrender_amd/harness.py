@@ -20,6 +20,8 @@ class RecordedScene:
         self.width, self.height = width, height
         self.setup, self.frame, self.read, self.read_offset = setup, frame, read, read_offset
         self.stream = stream or frame
+        self.texture_ids = {}     # TextureRef.name -> backend texture id (deterministic across replays)
+        self.tile_rects = {}      # TextureRef.name -> composite rect (x0,y0,x1,y1) in device px
 
 
 def record_scene(recording_backend_path, frame):
@@ -44,8 +46,11 @@ def record_scene(recording_backend_path, frame):
     read_bytes = tr3.serialize()
     read_off = [v for (_, args) in tr3.calls for (tag, _, v) in args if tag == TAG_SCRATCH][-1]
     gl.trace = None
+    rec = RecordedScene(frame.width, frame.height, setup, frame_bytes, read_bytes, read_off, stream_bytes)
+    rec.texture_ids = {name: t.id for name, t in r.textures.items()}
+    rec.tile_rects = {t.texture.name: t.rect for t in frame.composite_tiles}
     r.destroy()
-    return RecordedScene(frame.width, frame.height, setup, frame_bytes, read_bytes, read_off, stream_bytes), px
+    return rec, px
 
 
 class ScenePlayer:
