@@ -8,6 +8,14 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch bundles its own HIP runtime; if it is going to be used in this process
+    # (RCCL test) it has to initialise the device before libwrhip does.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 def oracle_lib(kind="gcc"):

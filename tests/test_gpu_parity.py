@@ -106,3 +106,26 @@ def test_native_replay_and_launch_count():
     ms = p.frames(3, 10)
     assert np.array_equal(p.read_pixels(), px)
     assert (ms > 0).all()
+
+
+def test_sharded_player_single_rank_rccl():
+    """The N>1 harness with world_size=1 on the real device: torch views libwrhip's
+    framebuffer in HBM through __cuda_array_interface__ and RCCL all-gathers it."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from webrender_amd.dist import ShardedFramePlayer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        make = lambda: scenes.cfg2_overlapping_rects(width=2048, height=1080, n=150, seed=31)
+        p = ShardedFramePlayer(wrhip_lib(), "custom", "quad", 0, 1, device="cuda", frame=make())
+        p.frames(1, 3)
+        p.stream(3)
+        got = p.assembled()                       # raw BGRA bytes as stored in HBM
+        want, _ = render_direct(wrhip_lib(), make())   # ReadPixels(GL_RGBA)
+        assert np.array_equal(got[..., [2, 1, 0, 3]], want)
+    finally:
+        dist.destroy_process_group()
