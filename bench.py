@@ -39,6 +39,9 @@ def make_frame(workload, **kw):
         return scenes.cfg5_many_rects(**kw)
     if workload == "cfg1":
         return scenes.cfg1_solid_colors(**kw)
+    if workload == "cfg3":
+        kw.pop("encoding", None)
+        return scenes.cfg3_text(**kw)
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -170,6 +173,8 @@ def main():
                 "cfg2": "1000 overlapping translucent rects (ps_quad_textured + premultiplied-alpha blend), "
                         "3840x2160, 20 picture-cache tiles + composite, seed 2",
                 "cfg5": "100k rects (50% opaque), 7680x4320, 72 tiles + composite, seed 5",
+                "cfg3": "text: 200 lines x 250 glyphs (ps_text_run, R8 glyph atlas 2048^2, premultiplied-alpha "
+                        "blend), 3840x2160, 20 tiles + composite, seed 3",
                 "cfg1": "16x16 opaque rect grid 1024x1024"}[args.workload],
                 "encoding": args.encoding, "target": f"{frame_w}x{frame_h}",
                 "parallelism": "single GPU" if world == 1 else

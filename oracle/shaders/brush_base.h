@@ -21,8 +21,9 @@ struct PrimitiveHeader {
   ivec4_scalar user_data;
 };
 
+// Helpers shared by every shader that includes prim_shared.glsl (brush_*, ps_text_run).
 template <typename Derived>
-struct brush_vert_base : VertexShaderImpl, CommonState {
+struct prim_vert_base : VertexShaderImpl, CommonState {
   AttribTable attribs;
   int a_aPosition, a_aData;
   vec2 aPosition;
@@ -101,6 +102,31 @@ struct brush_vert_base : VertexShaderImpl, CommonState {
                   area.task_rect.p0, rect_size(area.task_rect));
   }
 
+  static void load_attribs(VertexShaderImpl* impl, VertexAttrib* attribs,
+                           uint32_t start, int instance, int count) {
+    Derived* self = (Derived*)impl;
+    load_attrib(self->aPosition, attribs[self->attribs.locs[self->a_aPosition]],
+                start, instance, count);
+    load_flat_attrib(self->aData, attribs[self->attribs.locs[self->a_aData]],
+                     start, instance, count);
+  }
+
+  prim_vert_base() {
+    used = (1u << U_sColor0) | (1u << U_sGpuCache) |
+           (1u << U_sTransformPalette) | (1u << U_sRenderTasks) |
+           (1u << U_sPrimitiveHeadersF) | (1u << U_sPrimitiveHeadersI) |
+           (1u << U_sClipMask) | (1u << U_uTransform);
+    a_aPosition = attribs.add("aPosition");
+    a_aData = attribs.add("aData");
+  }
+};
+
+// brush.glsl:95-222: main() + brush_shader_main_vs.
+template <typename Derived>
+struct brush_vert_base : prim_vert_base<Derived> {
+  using prim_vert_base<Derived>::aData;
+  using prim_vert_base<Derived>::aPosition;
+  using prim_vert_base<Derived>::BRUSH_FLAG_FORCE_AA;
   void main() {
     // decode_instance_attributes, prim_shared.glsl:60-72
     int prim_header_address = aData.x;
@@ -109,10 +135,10 @@ struct brush_vert_base : VertexShaderImpl, CommonState {
     int flags = aData.z >> 16;
     int resource_address = aData.w & 0xffffff;
 
-    PrimitiveHeader ph = fetch_prim_header(prim_header_address);
-    Transform transform = fetch_transform(ph.transform_id);
-    PictureTask task = fetch_picture_task(ph.picture_task_address);
-    ClipArea clip_area = fetch_clip_area(clip_address);
+    PrimitiveHeader ph = this->fetch_prim_header(prim_header_address);
+    Transform transform = this->fetch_transform(ph.transform_id);
+    PictureTask task = this->fetch_picture_task(ph.picture_task_address);
+    ClipArea clip_area = this->fetch_clip_area(clip_address);
 
     // brush_shader_main_vs, brush.glsl:95-195
     int edge_flags = (flags >> 12) & 0xf;
@@ -126,8 +152,8 @@ struct brush_vert_base : VertexShaderImpl, CommonState {
     } else {
       int segment_address = ph.specific_prim_address +
                             Derived::VECS_PER_SPECIFIC_BRUSH + segment_index * 2;
-      vec4_scalar i0 = fetch_from_gpu_cache(segment_address, 0);
-      vec4_scalar i1 = fetch_from_gpu_cache(segment_address, 1);
+      vec4_scalar i0 = this->fetch_from_gpu_cache(segment_address, 0);
+      vec4_scalar i1 = this->fetch_from_gpu_cache(segment_address, 1);
       segment_rect = RectWithEndpoint{vec2_scalar(i0.x, i0.y),
                                       vec2_scalar(i0.z, i0.w)};
       segment_rect.p0 += ph.local_rect.p0;
@@ -139,7 +165,7 @@ struct brush_vert_base : VertexShaderImpl, CommonState {
     bool antialiased = !transform.is_axis_aligned ||
                        ((brush_flags & BRUSH_FLAG_FORCE_AA) != 0);
     if (antialiased) {
-      adjusted_segment_rect = clip_and_init_antialiasing(
+      adjusted_segment_rect = this->clip_and_init_antialiasing(
           segment_rect, ph.local_clip_rect, edge_flags);
       ph.local_clip_rect.p0 = vec2_scalar(-1.0e16f);
       ph.local_clip_rect.p1 = vec2_scalar(1.0e16f);
@@ -149,32 +175,15 @@ struct brush_vert_base : VertexShaderImpl, CommonState {
         mix(adjusted_segment_rect.p0, adjusted_segment_rect.p1, aPosition);
 
     BrushVertexInfo vi =
-        write_vertex(local_pos, ph.local_clip_rect, ph.z, transform, task);
+        this->write_vertex(local_pos, ph.local_clip_rect, ph.z, transform, task);
 
-    write_clip(clip_area, task);
+    this->write_clip(clip_area, task);
 
     static_cast<Derived*>(this)->brush_vs(
         vi, ph.specific_prim_address, ph.local_rect, segment_rect, ph.user_data,
         resource_address, transform.m, task, brush_flags, segment_data);
   }
 
-  static void load_attribs(VertexShaderImpl* impl, VertexAttrib* attribs,
-                           uint32_t start, int instance, int count) {
-    Derived* self = (Derived*)impl;
-    load_attrib(self->aPosition, attribs[self->attribs.locs[self->a_aPosition]],
-                start, instance, count);
-    load_flat_attrib(self->aData, attribs[self->attribs.locs[self->a_aData]],
-                     start, instance, count);
-  }
-
-  brush_vert_base() {
-    used = (1u << U_sColor0) | (1u << U_sGpuCache) |
-           (1u << U_sTransformPalette) | (1u << U_sRenderTasks) |
-           (1u << U_sPrimitiveHeadersF) | (1u << U_sPrimitiveHeadersI) |
-           (1u << U_sClipMask) | (1u << U_uTransform);
-    a_aPosition = attribs.add("aPosition");
-    a_aData = attribs.add("aData");
-  }
 };
 
 }  // namespace wrsh

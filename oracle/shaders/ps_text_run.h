@@ -1,0 +1,187 @@
+// ORACLE / TEST INFRASTRUCTURE. Hand-written stand-ins for the generated headers
+// of shader keys "ps_text_run ALPHA_PASS,TEXTURE_2D" and
+// "ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D"
+// (webrender_build/src/shader_features.rs:210-226). Restates
+// webrender/res/ps_text_run.glsl:36-338 (non-GLYPH_TRANSFORM branch) on top of
+// the prim_shared helpers in brush_base.h, with SWGL defined (SWGL_BLEND,
+// SWGL_CLIP_DIST, SWGL_CLIP_MASK, SWGL_DRAW_SPAN: base.glsl:38-44).
+
+#define WRSH_PS_TEXT_RUN(NAME, KEYSTR, DUAL_SOURCE)                            \
+  struct NAME##_vert : wrsh::prim_vert_base<NAME##_vert> {                     \
+    typedef NAME##_vert Self;                                                  \
+    vec4_scalar v_color;                                                       \
+    vec3_scalar v_mask_swizzle;                                                \
+    vec4_scalar v_uv_bounds;                                                   \
+    vec2 v_uv;                                                                 \
+    struct InterpOutputs {                                                     \
+      vec2_scalar v_uv;                                                        \
+    };                                                                         \
+    static vec2_scalar get_snap_bias(int subpx_dir) {                          \
+      switch (subpx_dir) {                                                     \
+        case 0:                                                                \
+        default:                                                               \
+          return vec2_scalar(0.5f);                                            \
+        case 1:                                                                \
+          return vec2_scalar(0.125f, 0.5f);                                    \
+        case 2:                                                                \
+          return vec2_scalar(0.5f, 0.125f);                                    \
+        case 3:                                                                \
+          return vec2_scalar(0.125f);                                          \
+      }                                                                        \
+    }                                                                          \
+    void main() {                                                              \
+      using namespace wrsh;                                                    \
+      /* decode_instance_attributes, prim_shared.glsl:60-72 */                 \
+      int prim_header_address = aData.x;                                       \
+      int clip_address = aData.y;                                              \
+      int segment_index = aData.z & 0xffff;                                    \
+      int flags = aData.z >> 16;                                               \
+      int resource_address = aData.w & 0xffffff;                               \
+      PrimitiveHeader ph = fetch_prim_header(prim_header_address);             \
+      Transform transform = fetch_transform(ph.transform_id);                  \
+      ClipArea clip_area = fetch_clip_area(clip_address);                      \
+      PictureTask task = fetch_picture_task(ph.picture_task_address);          \
+      int glyph_index = segment_index;                                         \
+      int subpx_dir = (flags >> 8) & 0xff;                                     \
+      int color_mode = flags & 0xff;                                           \
+      vec4_scalar text_color = fetch_from_gpu_cache_1(ph.specific_prim_address); \
+      vec2_scalar text_offset = ph.local_rect.p1;                              \
+      /* fetch_glyph, ps_text_run.glsl:40-53 */                                \
+      int glyph_address =                                                      \
+          ph.specific_prim_address + 1 + int(unsigned(glyph_index) / 2u);      \
+      vec4_scalar gdata = fetch_from_gpu_cache_1(glyph_address);               \
+      vec2_scalar glyph_offset = (unsigned(glyph_index) % 2u == 1u)            \
+                                     ? vec2_scalar(gdata.z, gdata.w)           \
+                                     : vec2_scalar(gdata.x, gdata.y);          \
+      glyph_offset += ph.local_rect.p0;                                        \
+      /* fetch_glyph_resource, ps_text_run.glsl:61-64 */                       \
+      vec4_scalar res_uv_rect = fetch_from_gpu_cache(resource_address, 0);     \
+      vec4_scalar res1 = fetch_from_gpu_cache(resource_address, 1);            \
+      vec2_scalar res_offset = vec2_scalar(res1.x, res1.y);                    \
+      float res_scale = res1.z;                                                \
+      vec2_scalar snap_bias = get_snap_bias(subpx_dir);                        \
+      /* ps_text_run.glsl:155-190 */                                           \
+      float raster_scale = float(ph.user_data.x) / 65535.0f;                   \
+      float glyph_raster_scale = raster_scale * task.device_pixel_scale;       \
+      float glyph_scale_inv = res_scale / glyph_raster_scale;                  \
+      vec2_scalar raster_glyph_offset =                                        \
+          floor(glyph_offset * glyph_raster_scale + snap_bias) / res_scale;    \
+      vec2_scalar glyph_origin =                                               \
+          glyph_scale_inv * (res_offset + raster_glyph_offset) + text_offset;  \
+      RectWithEndpoint glyph_rect{                                             \
+          glyph_origin,                                                        \
+          glyph_origin + glyph_scale_inv * (vec2_scalar(res_uv_rect.z,         \
+                                                        res_uv_rect.w) -       \
+                                            vec2_scalar(res_uv_rect.x,         \
+                                                        res_uv_rect.y))};      \
+      vec2 local_pos = mix(glyph_rect.p0, glyph_rect.p1, aPosition);           \
+      BrushVertexInfo vi =                                                     \
+          write_vertex(local_pos, ph.local_clip_rect, ph.z, transform, task);  \
+      vec2 f = (vi.local_pos - glyph_rect.p0) / rect_size(glyph_rect);         \
+      write_clip(clip_area, task);                                             \
+      /* ps_text_run.glsl:219-255 with SWGL_BLEND */                           \
+      switch (color_mode) {                                                    \
+        case 0: /* COLOR_MODE_ALPHA */                                         \
+          v_mask_swizzle = vec3_scalar(0.0f, 1.0f, 1.0f);                      \
+          v_color = text_color;                                                \
+          break;                                                               \
+        case 2: /* COLOR_MODE_BITMAP_SHADOW */                                 \
+          swgl_blendDropShadow(text_color);                                    \
+          v_mask_swizzle = vec3_scalar(1.0f, 0.0f, 0.0f);                      \
+          v_color = vec4_scalar(1.0f);                                         \
+          break;                                                               \
+        case 3: /* COLOR_MODE_COLOR_BITMAP */                                  \
+          v_mask_swizzle = vec3_scalar(1.0f, 0.0f, 0.0f);                      \
+          v_color = vec4_scalar(text_color.w);                                 \
+          break;                                                               \
+        case 1: /* COLOR_MODE_SUBPX_DUAL_SOURCE */                             \
+          swgl_blendSubpixelText(text_color);                                  \
+          v_mask_swizzle = vec3_scalar(1.0f, 0.0f, 0.0f);                      \
+          v_color = vec4_scalar(1.0f);                                         \
+          break;                                                               \
+        default:                                                               \
+          v_mask_swizzle = vec3_scalar(0.0f, 0.0f, 0.0f);                      \
+          v_color = vec4_scalar(1.0f);                                         \
+      }                                                                        \
+      ivec2_scalar ts = textureSize(sColor0, 0);                               \
+      vec2_scalar texture_size = vec2_scalar(float(ts.x), float(ts.y));        \
+      vec2_scalar st0 = vec2_scalar(res_uv_rect.x, res_uv_rect.y) / texture_size; \
+      vec2_scalar st1 = vec2_scalar(res_uv_rect.z, res_uv_rect.w) / texture_size; \
+      v_uv = mix(st0, st1, f);                                                 \
+      v_uv_bounds = (res_uv_rect + vec4_scalar(0.5f, 0.5f, -0.5f, -0.5f)) /    \
+                    vec4_scalar(texture_size.x, texture_size.y,                \
+                                texture_size.x, texture_size.y);               \
+    }                                                                          \
+    ALWAYS_INLINE void store_interp_outputs(char* dest_ptr, size_t stride) {   \
+      for (int n = 0; n < 4; n++) {                                            \
+        auto* dest = reinterpret_cast<InterpOutputs*>(dest_ptr);               \
+        dest->v_uv = get_nth(v_uv, n);                                         \
+        dest_ptr += stride;                                                    \
+      }                                                                        \
+    }                                                                          \
+    WRSH_VERT_ABI(Self)                                                        \
+    NAME##_vert() { WRSH_VERT_WIRING(Self) }                                   \
+  };                                                                           \
+  struct NAME##_frag : FragmentShaderImpl, NAME##_vert {                       \
+    typedef NAME##_frag Self;                                                  \
+    typedef NAME##_vert::InterpOutputs InterpInputs;                           \
+    InterpInputs interp_step;                                                  \
+    static void read_interp_inputs(FragmentShaderImpl* impl,                   \
+                                   const void* init_, const void* step_) {     \
+      Self* self = (Self*)impl;                                                \
+      const InterpInputs* init = (const InterpInputs*)init_;                   \
+      const InterpInputs* step = (const InterpInputs*)step_;                   \
+      self->v_uv = init_interp(init->v_uv, step->v_uv);                        \
+      self->interp_step.v_uv = step->v_uv * 4.0f;                              \
+    }                                                                          \
+    ALWAYS_INLINE void step_interp_inputs(int steps = 4) {                     \
+      float chunks = steps * 0.25f;                                            \
+      v_uv += interp_step.v_uv * chunks;                                       \
+    }                                                                          \
+    /* text_fs + main, ps_text_run.glsl:271-318 */                             \
+    void main() {                                                              \
+      vec2 tc = clamp(v_uv, vec2_scalar(v_uv_bounds.x, v_uv_bounds.y),         \
+                      vec2_scalar(v_uv_bounds.z, v_uv_bounds.w));              \
+      vec4 mask = texture(sColor0, tc);                                        \
+      if (v_mask_swizzle.z != 0.0f) mask = mask.sel(X, X, X, X);               \
+      if (!(DUAL_SOURCE)) {                                                    \
+        vec3 rgb = mask.sel(X, Y, Z) * v_mask_swizzle.x +                      \
+                   mask.sel(W, W, W) * v_mask_swizzle.y;                       \
+        mask = vec4(rgb, mask.w);                                              \
+      }                                                                        \
+      vec4 color = vec4(v_color) * mask;                                       \
+      float clip_mask = 1.0f; /* do_clip() */                                  \
+      color *= clip_mask;                                                      \
+      gl_FragColor = color;                                                    \
+    }                                                                          \
+    /* ps_text_run.glsl:320-338 */                                             \
+    void swgl_drawSpanRGBA8() {                                                \
+      if (v_mask_swizzle.x != 0.0f && v_mask_swizzle.x != 1.0f) {              \
+        return;                                                                \
+      }                                                                        \
+      if (DUAL_SOURCE) {                                                       \
+        swgl_commitTextureLinearRGBA8(sColor0, v_uv, v_uv_bounds);             \
+      } else if (swgl_isTextureR8(sColor0)) {                                  \
+        swgl_commitTextureLinearColorR8ToRGBA8(sColor0, v_uv, v_uv_bounds,     \
+                                               v_color);                       \
+      } else {                                                                 \
+        swgl_commitTextureLinearColorRGBA8(sColor0, v_uv, v_uv_bounds,         \
+                                           v_color);                           \
+      }                                                                        \
+    }                                                                          \
+    WRSH_FRAG_ABI(Self)                                                        \
+    static int draw_span_RGBA8(FragmentShaderImpl* impl) {                     \
+      Self* self = (Self*)impl;                                                \
+      DISPATCH_DRAW_SPAN(self, RGBA8);                                         \
+    }                                                                          \
+    NAME##_frag() {                                                            \
+      WRSH_FRAG_WIRING()                                                       \
+      draw_span_RGBA8_func = &draw_span_RGBA8;                                 \
+    }                                                                          \
+  };                                                                           \
+  WRSH_PROGRAM(NAME, KEYSTR)
+
+WRSH_PS_TEXT_RUN(ps_text_run_ALPHA_PASS_TEXTURE_2D,
+                 "ps_text_run ALPHA_PASS,TEXTURE_2D", false)
+WRSH_PS_TEXT_RUN(ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D,
+                 "ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", true)

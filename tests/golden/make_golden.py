@@ -28,6 +28,12 @@ def main():
     out["cfg2_4k_quad"] = digest(render_direct(LIB, scenes.cfg2_overlapping_rects())[0])
     out["cfg2_4k_brush"] = digest(render_direct(LIB, scenes.cfg2_overlapping_rects(encoding="brush"))[0])
     out["cfg5_small"] = digest(render_direct(LIB, scenes.cfg5_many_rects(width=2048, height=1024, n=5000))[0])
+    # text: digests are only meaningful with the very same PIL/FreeType glyph
+    # bitmaps, so the atlas digest is recorded next to them
+    out["glyph_atlas"] = digest(scenes.build_glyph_atlas()[0])
+    out["cfg3_small"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12))[0])
+    out["cfg3_small_zoom"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, glyph_zoom=1.25))[0])
+    out["cfg3_4k"] = digest(render_direct(LIB, scenes.cfg3_text())[0])
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "digests.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1))
 

@@ -132,6 +132,7 @@ const ShaderInfo SHADERS[] = {
      {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
+    {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
 };
 #undef S
 const char* const SAMPLER_NAMES[WR_MAX_TEX] = {

@@ -325,6 +325,83 @@ WR_DEVICE void wr_vs_brush_solid(const WrDrawDesc& d, const uint8_t* arena, int 
   o.has_color = 0;
 }
 
+// ps_text_run.glsl:98-268, non-GLYPH_TRANSFORM branch (vertex stage), with the
+// prim_shared.glsl helpers.  Colour modes that need a blend override
+// (swgl_blendDropShadow / swgl_blendSubpixelText, :229-247) are "next".
+WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+  wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
+  int prim_header_address = aData.x, clip_address = aData.y;
+  int glyph_index = aData.z & 0xffff, flags = aData.z >> 16;
+  int resource_address = aData.w & 0xffffff;
+  int u, v;
+  wr_fetch_uv(prim_header_address, 2u, u, v);
+  wf4 local_rect = wr_fetch_f(d.tex[WR_S_PRIM_HEADERS_F], u, v);
+  wf4 local_clip = wr_fetch_f(d.tex[WR_S_PRIM_HEADERS_F], u + 1, v);
+  wi4 data0 = wr_fetch_i(d.tex[WR_S_PRIM_HEADERS_I], u, v);
+  wi4 data1 = wr_fetch_i(d.tex[WR_S_PRIM_HEADERS_I], u + 1, v);
+  float z = float(data0.x);
+  int specific = data0.y, transform_id = data0.z, task_address = data0.w;
+  WrTransform transform = wr_fetch_transform(d, transform_id);
+  wf2 ca_p0 = {0.f, 0.f}, ca_p1 = {0.f, 0.f};
+  if (clip_address < 0x7FFFFFFF) {
+    WrTask ct = wr_fetch_task(d, clip_address);
+    ca_p0 = ct.p0; ca_p1 = ct.p1;
+  }
+  WrTask task = wr_fetch_task(d, task_address);
+  int subpx_dir = (flags >> 8) & 0xff, color_mode = flags & 0xff;
+  const WrTexDesc& gc = d.tex[WR_S_GPU_CACHE];
+  wf4 text_color = wr_fetch_f(gc, int(unsigned(specific) % 1024u), int(unsigned(specific) / 1024u));
+  float tox = local_rect.z, toy = local_rect.w;   // text_offset = ph.local_rect.p1
+  // fetch_glyph: two glyph offsets per GPU-cache block
+  int ga = specific + 1 + int(unsigned(glyph_index) / 2u);
+  wf4 gdata = wr_fetch_f(gc, int(unsigned(ga) % 1024u), int(unsigned(ga) / 1024u));
+  float gox = (unsigned(glyph_index) % 2u == 1u) ? gdata.z : gdata.x;
+  float goy = (unsigned(glyph_index) % 2u == 1u) ? gdata.w : gdata.y;
+  gox += local_rect.x; goy += local_rect.y;
+  // fetch_glyph_resource
+  int rx = int(unsigned(resource_address) % 1024u), ry = int(unsigned(resource_address) / 1024u);
+  wf4 uvr = wr_fetch_f(gc, rx, ry);
+  wf4 res1 = wr_fetch_f(gc, rx + 1, ry);
+  float res_scale = res1.z;
+  float sbx = (subpx_dir == 1 || subpx_dir == 3) ? 0.125f : 0.5f;   // get_snap_bias
+  float sby = (subpx_dir == 2 || subpx_dir == 3) ? 0.125f : 0.5f;
+  float raster_scale = float(data1.x) / 65535.0f;
+  float grs = raster_scale * task.dps;
+  float gsi = res_scale / grs;
+  float rgx = floorf(gox * grs + sbx) / res_scale, rgy = floorf(goy * grs + sby) / res_scale;
+  float g0x = gsi * (res1.x + rgx) + tox, g0y = gsi * (res1.y + rgy) + toy;
+  float g1x = g0x + gsi * (uvr.z - uvr.x), g1y = g0y + gsi * (uvr.w - uvr.y);
+  o.aa_edges = 0;
+  o.has_mask = ((ca_p1.x - ca_p0.x) != 0.0f || (ca_p1.y - ca_p0.y) != 0.0f) ? 1 : 0;
+  const WrTexDesc& atlas = d.tex[WR_S_COLOR0];
+  float tsx = float(atlas.width), tsy = float(atlas.height);
+  float st0x = uvr.x / tsx, st0y = uvr.y / tsy, st1x = uvr.z / tsx, st1y = uvr.w / tsy;
+  float fox = -task.origin.x + task.p0.x, foy = -task.origin.y + task.p0.y;
+  for (int n = 0; n < 4; n++) {
+    float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    float lx = (g1x - g0x) * ax + g0x, ly = (g1y - g0y) * ay + g0y;
+    lx = wr_clamp(lx, local_clip.x, local_clip.z); ly = wr_clamp(ly, local_clip.y, local_clip.w);
+    wf4 world = wr_mul(transform.m, wf4{lx, ly, 0.0f, 1.0f});
+    float dx = world.x * task.dps, dy = world.y * task.dps;
+    wf4 gp = wr_mul(*(const WrMat4*)d.transform,
+                    wf4{dx + fox * world.w, dy + foy * world.w, z * world.w, world.w});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+    float fx = (lx - g0x) / (g1x - g0x), fy = (ly - g0y) / (g1y - g0y);
+    o.u[n] = (st1x - st0x) * fx + st0x; o.v[n] = (st1y - st0y) * fy + st0y;
+  }
+  o.uv_bounds = wf4{(uvr.x + 0.5f) / tsx, (uvr.y + 0.5f) / tsy, (uvr.z + -0.5f) / tsx, (uvr.w + -0.5f) / tsy};
+  o.tex_slot = WR_S_COLOR0;
+  o.has_color = 1; o.tail_clamp = 1; o.tail_modulate = 1;
+  const bool r8 = atlas.format == WR_FMT_R8;
+  if (color_mode == 0 && r8 && atlas.width >= 2 && atlas.linear) {          // COLOR_MODE_ALPHA on the R8 glyph atlas
+    o.kind = WR_PK_TEX_R8; o.color = text_color;
+  } else if (color_mode == 3 && atlas.format == WR_FMT_RGBA8) {              // COLOR_MODE_COLOR_BITMAP
+    o.kind = WR_PK_TEX_RGBA8; o.color = wf4{text_color.w, text_color.w, text_color.w, text_color.w};
+  } else {
+    o.kind = WR_PK_UNSUPPORTED; o.color = wf4{0, 0, 0, 0};
+  }
+}
+
 // composite.glsl:73-159
 WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int inst, bool fast, WrVsOut& o) {
   wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
@@ -463,9 +540,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (ix1 <= ix0 || iy1 <= iy0) return;
   P.x0 = ix0; P.x1 = ix1; P.y0 = iy0; P.y1 = iy1;
   P.kind = (int16_t)o.kind;
+  if (o.kind == WR_PK_UNSUPPORTED) { atomicAdd(&cnt->unsupported_prims, 1u); return; }
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
-  } else if (o.kind == WR_PK_TEX_RGBA8) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -636,6 +714,23 @@ WR_DEVICE WrWide wr_sample_linear_rgba8(const WrTexDesc& t, int qx, int qy) {
   return out;
 }
 
+// textureLinearUnpackedR8 for ONE pixel (texture.h:543-574): same 7-bit
+// bilinear on a 1-byte texel; rows first, then columns, int16 wrap-around.
+WR_DEVICE int wr_sample_linear_r8(const WrTexDesc& t, int qx, int qy) {
+  int ix = qx >> 7, iy = qy >> 7;
+  int cx = wr_clamp_coord(ix, t.width - 1), cy = wr_clamp_coord(iy, t.height);
+  const uint8_t* buf = (const uint8_t*)t.ptr;
+  size_t row0 = (size_t)cx + (size_t)cy * t.stride;
+  size_t row1 = row0 + ((iy >= 0 && iy < t.height - 1) ? t.stride : 0);
+  int over = ix > t.width - 2 ? -1 : 0;
+  int fracx = ((((ix >= 0) ? qx : 0) | over) & 0x7F) - over;
+  int fracy = qy & 0x7F;
+  int p00 = buf[row0], p01 = buf[row0 + 1], p10 = buf[row1], p11 = buf[row1 + 1];
+  int l = (int16_t)(p00 + (int16_t)(((int16_t)((p10 - p00) * fracy)) >> 7));
+  int r = (int16_t)(p01 + (int16_t)(((int16_t)((p11 - p01) * fracy)) >> 7));
+  return (int16_t)(l + (int16_t)(((int16_t)((r - l) * fracx)) >> 7));
+}
+
 // ---------------------------------------------------------------------------
 // Raster stage.  Lane l of wave w in the workgroup of bin (bx,by) owns pixels
 //   x = 64*bx + 4*(l & 15) + i,   y = 64*by + 16*w + (l >> 4) + 4*j,  i,j in 0..3
@@ -668,7 +763,9 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   if (r.span == 0) return r;
   float W = float(t.width), H = float(t.height);
   float ou1 = r.ou + r.su, ov1 = r.ov + r.sv;
-  if (!t.linear) {
+  if (P.kind == WR_PK_TEX_R8) {
+    r.filter = 1;   // blendTextureLinearR8 (swgl_ext.h:634-650): always the quantised fallback stepping
+  } else if (!t.linear) {
     // swgl_commitTextureNearest: needsNearestFallback (swgl_ext.h:876-880)
     float py0 = r.ov * H, py1 = ov1 * H, px0 = r.ou * W, px1 = ou1 * W;
     int sp = (r.span & ~127) + 128;
@@ -753,7 +850,12 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
       float qx = lu * W * qs + qo, qy = lv * H * qs + qo;
       for (int c = 0; c < chunk; c++) { qx += stepx; qy += stepy; }
       qx = wr_clamp(qx, minx, maxx); qy = wr_clamp(qy, miny, maxy);
-      s = wr_sample_linear_rgba8(t, int(qx), int(qy));
+      if (P.kind == WR_PK_TEX_R8) {   // expand_mask(buf, r): r in all four channels (blend.h)
+        uint32_t m = uint32_t(wr_sample_linear_r8(t, int(qx), int(qy))) & 0xFFFF;
+        s.bg = s.ra = m | (m << 16);
+      } else {
+        s = wr_sample_linear_rgba8(t, int(qx), int(qy));
+      }
     }
     if (P.flags & WR_PF_HAS_COLOR) s = wr_apply_color(s, P.color);
     return s;
@@ -762,7 +864,13 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
   float cu, cv;
   wr_tex_tail_uv(P, r, n, cu, cv);
   float tb, tg, tr, ta;
-  if (t.linear) {
+  if (P.kind == WR_PK_TEX_R8) {
+    // textureLinearR8 (texture.h:576-583) -> vec4(r,0,0,1); ps_text_run.glsl:278-283
+    // swizzles it to rrrr for COLOR_MODE_ALPHA.
+    int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
+    float m = float(wr_sample_linear_r8(t, qx, qy)) * (1.0f / 255.0f);
+    tb = tg = tr = ta = m;
+  } else if (t.linear) {
     int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
     WrWide s = wr_sample_linear_rgba8(t, qx, qy);
     tb = float(s.bg & 0xFFFF) * (1.0f / 255.0f); tg = float(s.bg >> 16) * (1.0f / 255.0f);
@@ -841,6 +949,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
+    case WR_SH_PS_TEXT_RUN: wr_vs_ps_text_run(d, arena, inst, o); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;

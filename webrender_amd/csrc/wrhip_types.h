@@ -41,6 +41,7 @@ enum WrShader {
   WR_SH_COMPOSITE,
   WR_SH_COMPOSITE_FAST,
   WR_SH_PS_CLEAR,
+  WR_SH_PS_TEXT_RUN,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -130,6 +131,7 @@ enum WrPrimKind {
   WR_PK_TEX_RGBA8,      // swgl_commitTexture*RGBA8 family (rect, axis-aligned uv)
   WR_PK_UNSUPPORTED,
   WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
+  WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
 };
 
 enum WrPrimFlags {

@@ -190,6 +190,35 @@ class Frame:
                 np.int32(np.uint32(w & 0xFFFFFFFF))]
 
     @staticmethod
+    def glyph_instance(prim_header, glyph_index, resource_address, clip_task=CLIP_TASK_EMPTY,
+                       subpx_dir=0, color_mode=0):
+        """gpu_types.rs:511-528 GlyphInstance::build."""
+        return [prim_header, clip_task,
+                (subpx_dir << 24) | (color_mode << 16) | glyph_index, resource_address]
+
+    def add_text_run(self, color_premul, glyph_points):
+        """prim_store/text_run.rs:107-132: [premultiplied colour] then the glyph
+        points, two per block (an odd tail block keeps the previous .zw)."""
+        pts = np.asarray(glyph_points, np.float32).reshape(-1, 2)
+        blocks = [list(color_premul)]
+        blk = [0.0, 0.0, 0.0, 0.0]
+        for i, (x, y) in enumerate(pts):
+            if (i & 1) == 0:
+                blk[0], blk[1] = x, y
+            else:
+                blk[2], blk[3] = x, y
+                blocks.append(list(blk))
+        if len(pts) & 1:
+            blocks.append(list(blk))
+        return self.gpu_cache.push(blocks)
+
+    def add_glyph_resource(self, uv_rect, offset, scale=1.0):
+        """texture_cache.rs:157-168 ImageSource blocks of a cached glyph:
+        [uv_rect texels], [glyph.left, -glyph.top, scale, 0] (resource_cache.rs
+        glyph user_data)."""
+        return self.gpu_cache.push([list(uv_rect), [offset[0], offset[1], scale, 0.0]])
+
+    @staticmethod
     def composite_instance(rect, clip_rect, color=(1, 1, 1, 1), uv_rect=(0, 0, 1, 1),
                            uv_type=0, flip=(0.0, 0.0)):
         """gpu_types.rs:289-311 CompositeInstance (120 bytes)."""

@@ -149,9 +149,135 @@ def cfg5_many_rects(width=7680, height=4320, n=100_000, encoding="quad", seed=5,
     return build_rect_frame(width, height, rects, premultiply(rgba), opaque, encoding, **kw)
 
 
+# ---------------------------------------------------------------------------
+# Text (BASELINE config 3).  The glyph *content* comes from PIL/FreeType
+# rasterising DejaVu Sans (the reference's wr_glyph_rasterizer cannot be built
+# here; SURVEY.md §8c: text content parity is unpinned, the blit is pinned).
+FONT_PATH = "/usr/share/fonts/truetype/dejavu/DejaVuSans.ttf"
+ATLAS_SIZE = 2048       # glyph atlas: R8 2048^2 (texture_cache.rs:533-540)
+_atlas_cache = {}
+
+
+def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127)):
+    """Shelf-pack one bitmap per (size, char) into an R8 atlas.  Returns
+    (pixels[2048,2048] u8, {(size, ch): (uv_rect texels, (left, -top), advance)})."""
+    key = (tuple(sizes), tuple(chars))
+    if key in _atlas_cache:
+        return _atlas_cache[key]
+    from PIL import ImageFont
+    atlas = np.zeros((ATLAS_SIZE, ATLAS_SIZE), np.uint8)
+    table = {}
+    x = y = 1
+    shelf = 0
+    for size in sizes:
+        font = ImageFont.truetype(FONT_PATH, size)
+        ascent, _ = font.getmetrics()
+        for ch in chars:
+            c = chr(ch)
+            l, t, r, b = font.getbbox(c)
+            w, h = r - l, b - t
+            if w <= 0 or h <= 0:
+                continue
+            bmp = np.frombuffer(bytes(font.getmask(c, mode="L")), np.uint8)
+            mw, mh = font.getmask(c, mode="L").size
+            bmp = bmp.reshape(mh, mw)
+            w, h = mw, mh
+            if x + w + 1 > ATLAS_SIZE:
+                x, y, shelf = 1, y + shelf + 1, 0
+            assert y + h + 1 <= ATLAS_SIZE
+            atlas[y:y + h, x:x + w] = bmp
+            table[(size, ch)] = ((float(x), float(y), float(x + w), float(y + h)),
+                                 (float(l), float(t - ascent)), float(font.getlength(c)))
+            x += w + 1
+            shelf = max(shelf, h)
+    _atlas_cache[key] = (atlas, table)
+    return atlas, table
+
+
+def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=25, seed=3,
+              glyph_zoom=1.0, device_pixel_scale=1.0, tile_filter=None, **kw):
+    """`lines` x `glyphs_per_line` glyphs in runs of `run_len`, black-ish text
+    on white, COLOR_MODE_ALPHA from an R8 atlas, PremultipliedAlpha blend
+    (batch.rs:1109-1290).  glyph_zoom != 1 draws the cached bitmaps magnified
+    (local raster space: raster_scale = 1/zoom) so that sampling is truly bilinear."""
+    rng = np.random.default_rng(seed)
+    atlas, table = build_glyph_atlas()
+    sizes = sorted({k[0] for k in table})
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    atlas_ref = TextureRef("glyph_atlas_r8", ATLAS_SIZE, ATLAS_SIZE, G.GL_R8, G.GL_LINEAR,
+                           pixels=atlas, upload_format=G.GL_RED)
+    frame.static_textures.append(atlas_ref)
+    res_addr = {k: frame.add_glyph_resource(v[0], v[1], 1.0) for k, v in table.items()}
+    raster_scale = 1.0 / glyph_zoom
+    dps = device_pixel_scale
+    k_dev = glyph_zoom            # device px per atlas texel
+
+    # lay the runs out in local (layout) space
+    runs = []     # (origin xy, ref offset (unsnapped, snapped), colour, [(size,ch)], points, device bbox)
+    pitch = height / dps / lines
+    z = 1
+    for li in range(lines):
+        size = int(rng.choice(sizes))
+        pen = float(rng.uniform(0.0, 40.0))
+        base_y = float(size + li * pitch + rng.uniform(0.0, 1.0))
+        chars = rng.integers(33, 127, size=glyphs_per_line)
+        chars = [int(c) if (size, int(c)) in table else 65 for c in chars]
+        for r0 in range(0, glyphs_per_line, run_len):
+            run_chars = chars[r0:r0 + run_len]
+            origin = (pen, base_y)
+            pts, x = [], 0.0
+            for c in run_chars:
+                pts.append((x, 0.0))
+                x += table[(size, c)][2] * glyph_zoom / dps
+            pen += x
+            rgba = np.array([[rng.integers(0, 96), rng.integers(0, 96), rng.integers(0, 96),
+                              rng.integers(160, 256)]], np.uint8)
+            color = premultiply(rgba)[0]
+            ref = ((2.25, 1.5), (2.0, 2.0)) if (len(runs) % 7) == 3 else ((0.0, 0.0), (0.0, 0.0))
+            # conservative device-space bounds of the run (for tile assignment)
+            asc = size * 1.3 * k_dev
+            bx0, bx1 = origin[0] * dps - 2 * size, (origin[0] + x) * dps + 2 * size
+            by0, by1 = origin[1] * dps - asc, origin[1] * dps + 0.5 * size * k_dev + 2
+            runs.append((origin, ref, color, size, run_chars, pts, (bx0, by0, bx1, by1), z))
+            z += 1
+
+    run_addr = [frame.add_text_run(r[2], r[5]) for r in runs]
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR,
+                         render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), dps,
+                                     (float(ox), float(oy)))
+        inst = []
+        for ri, (origin, ref, color, size, run_chars, pts, bb, zid) in enumerate(runs):
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
+                continue
+            local_rect = (origin[0] - ref[0][0], origin[1] - ref[0][1], ref[1][0], ref[1][1])
+            ph = frame.add_prim_header(local_rect, (-BIG, -BIG, BIG, BIG), zid, run_addr[ri], 0, task,
+                                       (int(round(raster_scale * 65535.0)), 0, 0, 0))
+            for gi, c in enumerate(run_chars):
+                inst.append(frame.glyph_instance(ph, gi, res_addr[(size, c)]))
+        if inst:
+            target.alpha.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES",
+                                     np.array(inst, dtype=np.int32), "PremultipliedAlpha", "alpha",
+                                     textures={0: atlas_ref}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    frame.n_glyphs = sum(len(s.instances) for t in targets for s in t.alpha)
+    return frame
+
+
 SCENES = {
     "cfg1": cfg1_solid_colors,
     "simple_batching": simple_batching,
     "cfg2": cfg2_overlapping_rects,
+    "cfg3": cfg3_text,
     "cfg5": cfg5_many_rects,
 }
