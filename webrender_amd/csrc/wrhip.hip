@@ -218,6 +218,7 @@ struct Context {
   uint8_t* dupload = nullptr;     // HBM mirror of the staging ring
   WrPrim* dprims = nullptr; size_t dprims_cap = 0;
   WrRec* drecs = nullptr;
+  WrTexRec* dtexrecs = nullptr;
   unsigned long long* dmasks = nullptr; size_t dmasks_cap = 0;
   WrUnsupportedCounters* dcounters = nullptr;
   // HBM pool for texture storage: per-frame textures (GpuBufferF/I, render
@@ -232,13 +233,11 @@ struct Context {
   wr_event_t ev_a, ev_b;
   WrhipStats stats;
   int shard_rank = 0, shard_world = 1;
-  int rows_per_lane = 4;
 
   Context() {
     wrrt::stream_create(&stream);
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
-    if (const char* e = getenv("WRHIP_ROWS")) rows_per_lane = atoi(e) == 8 ? 8 : 4;
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
     wrrt::memset8(dcounters, 0, sizeof(WrUnsupportedCounters), stream);
   }
@@ -661,7 +660,7 @@ Context::~Context() {
   for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
-  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
+  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(dtexrecs); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::stream_destroy(stream);
@@ -782,6 +781,8 @@ void flush_work(const std::vector<int>& sel_in) {
       c->dprims = (WrPrim*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrPrim));
       wrrt::dev_free(c->drecs);
       c->drecs = (WrRec*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrRec));
+      wrrt::dev_free(c->dtexrecs);
+      c->dtexrecs = (WrTexRec*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrTexRec));
     }
     if (c->dmasks_cap < (size_t)n_words + 1) {
       wrrt::stream_sync(c->stream);
@@ -797,7 +798,7 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
     const uint8_t* dinst = darena + off_inst;
     if (n_prims > 0) {
-      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, n_prims,
+      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, c->dtexrecs, n_prims,
                 dtargets, c->dmasks, c->dcounters);
       c->stats.kernel_launches += 1;
     }
@@ -831,24 +832,39 @@ void flush_work(const std::vector<int>& sel_in) {
     }
 #endif
     if (c->profiling) wrrt::event_record(&c->ev_a, c->stream);
-    // R = rows per lane: 4 (four waves per 64x64 bin, 16 pixels per lane) measured
-    // faster than 8 on MI355X (profiles/); WRHIP_ROWS=8 selects two waves x 32 pixels.
-    const int R = c->rows_per_lane;
+    // Four waves per 64x64 bin, each lane owning 4 x 4 pixels (R = 4; two waves x
+    // 32 pixels measured slower on MI355X, profiles/r01_*).  The kernel is
+    // specialised on the prim families present in the launch (FEAT) so that
+    // rect-only passes do not pay the registers of the texture paths.
+    int feat = 0;
+    for (int i = 0; i < nd; i++) {
+      switch (draws[i].shader) {
+        case WR_SH_PS_TEXT_RUN: feat |= 3; break;
+        case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA: case WR_SH_PS_CLEAR: case WR_SH_CLEAR_OP: break;
+        // quads drawn with the 1x1 dummy texture bound are solid (a textured one would still be
+        // drawn correctly by the generic path: FEAT only selects fast paths)
+        case WR_SH_PS_QUAD_TEXTURED: if (draws[i].tex[WR_S_COLOR0].width >= 2) feat |= 1; break;
+        default: feat |= 1; break;
+      }
+    }
+#define WR_RASTER_F(FMT, DEPTH, FEAT, NB, OFF)                                                                      \
+  do {                                                                                                              \
+    WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), NB, 256, c->stream, dtargets, n_targets, ddraws,             \
+              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrTexRec*)c->dtexrecs, c->dmasks, OFF);      \
+    c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
+  } while (0)
 #define WR_RASTER(FMT, DEPTH, NB, OFF)                                                                              \
   do {                                                                                                              \
-    if (R == 8)                                                                                                     \
-      WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 8>), NB, 128, c->stream, dtargets, n_targets, ddraws,                 \
-                (const WrPrim*)c->dprims, (const WrRec*)c->drecs, c->dmasks, OFF);                                  \
-    else                                                                                                            \
-      WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4>), NB, 256, c->stream, dtargets, n_targets, ddraws,                 \
-                (const WrPrim*)c->dprims, (const WrRec*)c->drecs, c->dmasks, OFF);                                  \
-    c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
+    if (FMT == WR_FMT_R8 || feat == 0) WR_RASTER_F(FMT, DEPTH, 0, NB, OFF);                                         \
+    else if (feat == 1) WR_RASTER_F(FMT, DEPTH, 1, NB, OFF);                                                        \
+    else WR_RASTER_F(FMT, DEPTH, 3, NB, OFF);                                                                       \
   } while (0)
     if (bins_rgba > 0) {
       if (any_depth) WR_RASTER(WR_FMT_RGBA8, true, bins_rgba, 0);
       else WR_RASTER(WR_FMT_RGBA8, false, bins_rgba, 0);
     }
-    if (n_bins > bins_rgba) WR_RASTER(WR_FMT_R8, false, n_bins - bins_rgba, bins_rgba);
+    if (n_bins > bins_rgba) WR_RASTER_F(WR_FMT_R8, false, 0, n_bins - bins_rgba, bins_rgba);
+#undef WR_RASTER_F
 #undef WR_RASTER
     if (c->profiling) {
       wrrt::event_record(&c->ev_b, c->stream);
@@ -1618,6 +1634,9 @@ void DestroyContext(WrhipContext* c_) {
   Context* c = (Context*)c_;
   if (!c) return;
   if (--c->references > 0) return;
+#ifdef WRHIP_HOSTSIM
+  if (getenv("WRHIP_DEBUG")) fprintf(stderr, "paths: r8fast %llu (unit %llu) generic %llu accum_loop %llu\n", wr_dbg_paths[0], wr_dbg_paths[3], wr_dbg_paths[1], wr_dbg_paths[2]);
+#endif
   if (ctx == c) { delete c; ctx = nullptr; }
   else delete c;
 }

@@ -684,6 +684,39 @@ WR_DEVICE WrWide wr_apply_color(WrWide src, const uint32_t color[2]) {
 // ---------------------------------------------------------------------------
 // Texture sampling helpers used by textured prims.
 
+// s0 + step + step + ... (c adds, each rounded to fp32), as swgl's span loops
+// accumulate quantised UVs (`uv += uv_step`, swgl_ext.h:176).  Closed form when
+// provably identical: if s0 and step are both multiples of 2^g and every partial
+// sum is below 2^(g+24) in magnitude, every add is exact, so the result is the
+// real number s0 + c*step (partial sums are monotone between the end points).
+// hostsim only: which raster paths ran (printed at DestroyContext under WRHIP_DEBUG)
+#ifdef WRHIP_HOSTSIM
+static unsigned long long wr_dbg_paths[8];
+#define WR_DBG_PATH(i) (wr_dbg_paths[i]++)
+#else
+#define WR_DBG_PATH(i) ((void)0)
+#endif
+WR_DEVICE int wr_low_bit_exp(float x) {
+  uint32_t b; __builtin_memcpy(&b, &x, 4);
+  uint32_t e = (b >> 23) & 0xFF, m = b & 0x7FFFFF;
+  if (e == 0) return m ? -1000 : 1000;         // denormal: force the loop; zero: no constraint
+  m |= 0x800000;
+  return int(e) - 150 + __builtin_ctz(m);
+}
+WR_DEVICE float wr_accum(float s0, float step, int c) {
+  if (c <= 0) return s0;
+  const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
+  const int g = g0 < g1 ? g0 : g1;
+  const double end = double(s0) + double(c) * double(step);
+  const double a0 = s0 < 0 ? -double(s0) : double(s0), a1 = end < 0 ? -end : end;
+  const double bound = a0 > a1 ? a0 : a1;
+  if (g > -900 && g < 100 && bound < __builtin_ldexp(1.0, g + 24)) return float(end);
+  WR_DBG_PATH(2);
+  float s = s0;
+  for (int i = 0; i < c; i++) s += step;
+  return s;
+}
+
 // textureLinearUnpackedRGBA8 for ONE pixel (texture.h:1028-1071): 7-bit
 // fixed-point bilinear on quantised coords i = uv*size*128 + (0.5 - 64).
 WR_DEVICE WrWide wr_sample_linear_rgba8(const WrTexDesc& t, int qx, int qy) {
@@ -848,7 +881,7 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
       float lu = r.ou, lv = r.ov;
       for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
       float qx = lu * W * qs + qo, qy = lv * H * qs + qo;
-      for (int c = 0; c < chunk; c++) { qx += stepx; qy += stepy; }
+      qx = wr_accum(qx, stepx, chunk); qy = wr_accum(qy, stepy, chunk);
       qx = wr_clamp(qx, minx, maxx); qy = wr_clamp(qy, miny, maxy);
       if (P.kind == WR_PK_TEX_R8) {   // expand_mask(buf, r): r in all four channels (blend.h)
         uint32_t m = uint32_t(wr_sample_linear_r8(t, int(qx), int(qy))) & 0xFFFF;
@@ -917,6 +950,69 @@ WR_DEVICE WrRec wr_make_rec(const WrPrim& P, int target_format) {
   }
   r.kbf = kind | ((uint32_t(P.blend) & 0xFF) << 8) | ((uint32_t(P.flags) & 0xFF) << 16) | (Kf << 24);
   return r;
+}
+
+// Sampling setup of a textured prim (see WrTexRec).
+WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
+  WrTexRec t;
+  t.ptr = tex.ptr; t.stride = tex.stride; t.wh = uint32_t(tex.width) | (uint32_t(tex.height) << 16);
+  const float W = float(tex.width), H = float(tex.height);
+  const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float Lu = P.uvL0[0] + 0.0f, Ru = P.uvR0[0] + 0.0f;
+  t.su = (Ru - Lu) * stepScale;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  t.ou = Lu + t.su * start;
+  const int len = P.x1 - P.x0;
+  t.span = len >= 4 ? (len & ~3) : 0;
+  const float q0x = t.ou * W * qs + qo, q1x = (t.ou + t.su) * W * qs + qo;
+  t.stepx = 4.0f * (q1x - q0x);
+  t.minx = wr_max(P.uv_bounds[0] * W * qs + qo, 0.0f);
+  t.maxx = wr_max(P.uv_bounds[2] * W * qs + qo, t.minx);
+  t.miny = wr_max(P.uv_bounds[1] * H * qs + qo, 0.0f);
+  t.maxy = wr_max(P.uv_bounds[3] * H * qs + qo, t.miny);
+  t.ub0 = P.uv_bounds[0]; t.ub1 = P.uv_bounds[1]; t.ub2 = P.uv_bounds[2]; t.ub3 = P.uv_bounds[3];
+  t.lv0 = P.uvL0[1]; t.lvs = P.uvLs[1]; t.y0 = P.y0;
+  const int need = WR_PF_TAIL_CLAMP | WR_PF_TAIL_MODULATE | WR_PF_HAS_COLOR;
+  t.simple = (tex.ptr && P.uvLs[0] == 0.0f && P.uvRs[0] == 0.0f && P.uvL0[1] == P.uvR0[1] && P.uvLs[1] == P.uvRs[1] &&
+              (P.flags & need) == need && ((P.color[0] | P.color[1]) & 0xFF00FF00u) == 0 && tex.width >= 2) ? 1 : 0;
+  t.fcolor[0] = P.fcolor[0]; t.fcolor[1] = P.fcolor[1]; t.fcolor[2] = P.fcolor[2]; t.fcolor[3] = P.fcolor[3];
+  // Exact evaluation of every column / row coordinate of small prims (glyphs):
+  // if they all land on texel centres the raster stage needs no float math.
+  t.unit = 0; t.ix0 = t.iy0 = 0; t.tix[0] = t.tix[1] = t.tix[2] = 0;
+  const int rows = P.y1 - P.y0;
+  if (t.simple && len <= 128 && rows <= 128) {
+    bool ok = true;
+    int q0 = 0;
+    for (int n = 0; n < len && ok; n++) {
+      const bool tail = n >= t.span;
+      const int lane = (tail ? n - t.span : n) & 3;
+      float lu = t.ou;
+      for (int i = 0; i < lane; i++) lu += t.su;
+      int qx;
+      if (!tail) {
+        qx = int(wr_clamp(wr_accum(lu * W * qs + qo, t.stepx, n >> 2), t.minx, t.maxx));
+        if (n == 0) q0 = qx;
+        ok = qx == q0 + 128 * n;
+      } else {
+        if (t.span > 0) lu = lu + (t.su * 4.0f) * (float(t.span) * 0.25f);
+        qx = int(wr_clamp(lu, t.ub0, t.ub2) * W * 128.0f + (0.5f - 64.0f));
+        t.tix[n - t.span] = qx >> 7;
+      }
+      ok = ok && (qx & 0x7F) == 0 && qx >= 0 && (qx >> 7) <= tex.width - 2;
+    }
+    int r0 = 0;
+    for (int r = 0; r < rows && ok; r++) {
+      const float ov = t.lv0 + float(r) * t.lvs;
+      const int qs_ = int(wr_clamp(ov * H * qs + qo, t.miny, t.maxy));
+      const int qt_ = int(wr_clamp(ov, t.ub1, t.ub3) * H * 128.0f + (0.5f - 64.0f));
+      if (r == 0) r0 = qs_;
+      ok = qs_ == r0 + 128 * r && qt_ == qs_ && (qs_ & 0x7F) == 0 && qs_ >= 0 && (qs_ >> 7) <= tex.height - 1;
+    }
+    if (ok && rows > 0) { t.unit = 1; t.ix0 = q0 >> 7; t.iy0 = r0 >> 7; }
+  }
+  return t;
 }
 
 // Vertex stage of one instance: locate its draw, run the shader's vertex
@@ -1017,14 +1113,18 @@ WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDes
 // Vertex stage + binning, one thread per instance.
 __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
-                                WrRec* __restrict__ recs, int n_prims, const WrTargetDesc* __restrict__ targets,
-                                unsigned long long* __restrict__ masks, WrUnsupportedCounters* cnt) {
+                                WrRec* __restrict__ recs, WrTexRec* __restrict__ texrecs, int n_prims,
+                                const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
+                                WrUnsupportedCounters* cnt) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = gid < n_prims;
   WrPrim P;
   P.kind = WR_PK_NONE; P.draw = 0; P.x0 = P.y0 = P.x1 = P.y1 = 0;
   if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, cnt);
-  if (valid) { prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format); }
+  if (valid) {
+    prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
+    if (P.kind == WR_PK_TEX_R8) texrecs[gid] = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
+  }
   wr_bin_prim(P, valid, gid, draws, targets, masks);
 }
 
@@ -1101,7 +1201,7 @@ WR_DEVICE uint32_t wr_mul24(uint32_t a, uint32_t b) {
 // Apply one prim to the 4*R pixels of this lane (4 wide x R rows, rows 4 apart).
 // All prim parameters are wave-uniform (SGPRs); (px,py) is the lane's first
 // pixel, (wx0,wy0) the wave's 64 x 4R strip origin.
-template <int FMT, bool DEPTH, int R>
+template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uint32_t (&dep)[4 * R],
                              const int x0, const int y0, const int x1, const int y1, const uint32_t z,
                              const uint32_t kbf, const uint32_t c0, const uint32_t c1,
@@ -1189,7 +1289,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if (FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_RGBA8 && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
+  if ((FEAT & 1) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_RGBA8 && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
     // ---- swgl_commitTexture*RGBA8: per lane-row span setup, then 4 texels ----
     // Rows whose 4 pixels all fall in the nearest-fast part of the span
     // (blendTextureNearestFast, swgl_ext.h:475-537) fetch their texels directly;
@@ -1248,6 +1348,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     return;
   }
   // ---- generic path ----
+  WR_DBG_PATH(1);
   const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
   for (int q = 0; q < NPX; q++) {
@@ -1269,12 +1370,161 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
   }
 }
 
+// swgl_commitTextureLinearColorR8ToRGBA8 (glyph blits) for prims whose WrTexRec
+// is `simple`: the quantised x coordinate of a column is the same on every row,
+// so it is set up once per prim, the y coordinate once per row, and a pixel
+// costs one atlas byte when both 7-bit fractions are zero.  `T` is wave-uniform.
+template <bool DEPTH, int R>
+WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uint32_t (&dep)[4 * R],
+                               const int x0, const int y0, const int x1, const int y1, const uint32_t z,
+                               const uint32_t kbf, const uint32_t c0, const uint32_t c1,
+                               const WrTexRec& T, const WrDrawDesc* draws, const WrPrim* Pp, const int px, const int py) {
+  WR_DBG_PATH(0);
+  const int blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
+  const bool dtest = DEPTH && (flags & WR_PF_DEPTH_TEST);
+  const bool dwrite = (flags & WR_PF_DEPTH_WRITE) != 0, dless = (flags & WR_PF_DEPTH_LESS) != 0;
+  const uint8_t* sbuf = (const uint8_t*)T.ptr;
+  const int tw = int(T.wh & 0xFFFF), th = int(T.wh >> 16);
+  const float W = float(tw), H = float(th);
+  const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+  const int span = T.span;
+  bool cx[4], cy[R];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
+#pragma unroll
+  for (int j = 0; j < R; j++) cy[j] = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
+  const uint32_t clo = (c0 & 0xFFFF) | (c1 << 16), chi = (c0 >> 16) | (c1 & 0xFFFF0000u);
+  if (T.unit) {
+    // every sample is exactly one texel: m = atlas[iy0 + row][ix0 + n] (tail columns from tix[])
+    WR_DBG_PATH(3);
+    int colu[4]; bool tl[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int n = px + i - x0, k = n - span;
+      tl[i] = k >= 0;
+      colu[i] = k < 0 ? T.ix0 + n : (k == 0 ? T.tix[0] : (k == 1 ? T.tix[1] : T.tix[2]));
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      if (!cy[j]) continue;
+      const uint8_t* srow = sbuf + (size_t)(T.iy0 + (py + 4 * j - T.y0)) * T.stride;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        bool in = cx[i];
+        if (dtest) {
+          const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+          in = in && pass;
+          if (dwrite) dep[q] = in ? z : dep[q];
+        }
+        if (!in) continue;
+        const uint32_t um = srow[colu[i]];
+        if (!tl[i]) {
+          const uint32_t sl = wr_hi_bytes(wr_mul24(clo, um) + clo), sh = wr_hi_bytes(wr_mul24(chi, um) + chi);
+          uint32_t nl = sl, nh = sh;
+          if (blend == WR_BLEND_PREMULT) {
+            const uint32_t K = 255u - (sh >> 16);
+            nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
+            nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
+          }
+          plo[q] = nl; phi[q] = nh;
+        } else {
+          const float mf = float(um) * (1.0f / 255.0f);
+          uint32_t pc[2];
+          wr_pack_color(wf4{T.fcolor[0] * mf, T.fcolor[1] * mf, T.fcolor[2] * mf, T.fcolor[3] * mf}, pc);
+          WrWide src; src.bg = pc[0]; src.ra = pc[1];
+          const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, &draws[Pp->draw]);
+          plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+        }
+      }
+    }
+    return;
+  }
+  int col[4], fracx[4]; bool tail[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int n = px + i - x0;
+    int qx = 0;
+    tail[i] = n >= span;
+    if (cx[i]) {
+      const int lane = (tail[i] ? n - span : n) & 3;
+      float lu = T.ou;
+      if (lane > 0) lu += T.su;
+      if (lane > 1) lu += T.su;
+      if (lane > 2) lu += T.su;
+      if (!tail[i]) {
+        const float q = wr_accum(lu * W * qs + qo, T.stepx, n >> 2);
+        qx = int(wr_clamp(q, T.minx, T.maxx));
+      } else {
+        if (span > 0) lu = lu + (T.su * 4.0f) * (float(span) * 0.25f);
+        const float cu = wr_clamp(lu, T.ub0, T.ub2);
+        qx = int(cu * W * 128.0f + (0.5f - 64.0f));
+      }
+    }
+    const int ix = qx >> 7;
+    const int over = ix > tw - 2 ? -1 : 0;
+    col[i] = wr_clamp_coord(ix, tw - 1);
+    fracx[i] = ((((ix >= 0) ? qx : 0) | over) & 0x7F) - over;
+  }
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    if (!cy[j]) continue;
+    const int y = py + 4 * j;
+    const float k = float(y - T.y0);
+    const float ov = T.lv0 + k * T.lvs;      // Lv == Rv on this kind of prim, so sv == 0 exactly
+    const int qy_span = int(wr_clamp(ov * H * qs + qo, T.miny, T.maxy));
+    const int qy_tail = int(wr_clamp(ov, T.ub1, T.ub3) * H * 128.0f + (0.5f - 64.0f));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int q = 4 * j + i;
+      bool in = cx[i];
+      if (dtest) {
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+        in = in && pass;
+        if (dwrite) dep[q] = in ? z : dep[q];
+      }
+      if (!in) continue;
+      const int qy = tail[i] ? qy_tail : qy_span;
+      const int iy = qy >> 7, fracy = qy & 0x7F;
+      const size_t row0 = (size_t)col[i] + (size_t)wr_clamp_coord(iy, th) * T.stride;
+      int m = sbuf[row0];
+      if ((fracx[i] | fracy) != 0) {
+        const size_t row1 = row0 + ((iy >= 0 && iy < th - 1) ? T.stride : 0);
+        const int p01 = sbuf[row0 + 1], p10 = sbuf[row1], p11 = sbuf[row1 + 1];
+        const int l = (int16_t)(m + (int16_t)(((int16_t)((p10 - m) * fracy)) >> 7));
+        const int r = (int16_t)(p01 + (int16_t)(((int16_t)((p11 - p01) * fracy)) >> 7));
+        m = (int16_t)(l + (int16_t)(((int16_t)((r - l) * fracx[i])) >> 7));
+      }
+      if (!tail[i]) {
+        // applyColor(expand_mask(m), colour) = muldiv255 per channel, then the blend
+        const uint32_t um = uint32_t(m);
+        const uint32_t sl = wr_hi_bytes(wr_mul24(clo, um) + clo), sh = wr_hi_bytes(wr_mul24(chi, um) + chi);
+        uint32_t nl = sl, nh = sh;
+        if (blend == WR_BLEND_PREMULT) {
+          const uint32_t K = 255u - (sh >> 16);
+          nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
+          nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
+        }
+        plo[q] = nl; phi[q] = nh;
+      } else {
+        // fragment-shader tail: texel -> float, modulate, round_pixel, generic blend
+        const float mf = float(m) * (1.0f / 255.0f);
+        uint32_t pc[2];
+        wr_pack_color(wf4{T.fcolor[0] * mf, T.fcolor[1] * mf, T.fcolor[2] * mf, T.fcolor[3] * mf}, pc);
+        WrWide src; src.bg = pc[0]; src.ra = pc[1];
+        const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, &draws[Pp->draw]);
+        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+      }
+    }
+  }
+}
+
 // One workgroup per 64x64 bin; 64/(4R) waves of 64 lanes, each lane 4 x R pixels.
-template <int FMT, bool DEPTH, int R>
+template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void __launch_bounds__(1024 / R)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
-                 const WrRec* __restrict__ recs,
+                 const WrRec* __restrict__ recs, const WrTexRec* __restrict__ texrecs,
                  unsigned long long* __restrict__ masks, int bin_offset) {
   constexpr int NPX = 4 * R, STRIP = 4 * R;
   const int bin = blockIdx.x + bin_offset;
@@ -1351,8 +1601,14 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       live &= live - 1;
       const WrRec Rc = recs[base + bit];
       if (Rc.x1 <= wx0 || Rc.x0 >= wx0 + WR_BIN_W || Rc.y1 <= wy0 || Rc.y0 >= wy0 + STRIP) continue;
-      wr_apply_prim<FMT, DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, &prims[base + bit],
-                                   draws, px, py, wx0, wy0);
+      const int rblend = (Rc.kbf >> 8) & 0xFF;
+      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && (Rc.kbf & 0xFF) == WR_PK_TEX_R8 && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+          texrecs[base + bit].simple)
+        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, texrecs[base + bit],
+                                  draws, &prims[base + bit], px, py);
+      else
+        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, &prims[base + bit],
+                                     draws, px, py, wx0, wy0);
     }
   }
 #else
@@ -1390,7 +1646,12 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       const int x1 = __builtin_amdgcn_readlane((int)ra.z, bit), y1 = __builtin_amdgcn_readlane((int)ra.w, bit);
       const uint32_t z = __builtin_amdgcn_readlane((int)rb.x, bit), kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
       const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
-      wr_apply_prim<FMT, DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], draws, px, py, wx0, wy0);
+      const int rblend = (kbf >> 8) & 0xFF;
+      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && (kbf & 0xFF) == WR_PK_TEX_R8 && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+          texrecs[base + bit].simple)
+        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, texrecs[base + bit], draws, &prims[base + bit], px, py);
+      else
+        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], draws, px, py, wx0, wy0);
     }
   }
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the

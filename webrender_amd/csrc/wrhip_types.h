@@ -171,6 +171,32 @@ struct WrRec {
   uint32_t c0, c1;       // WrPrim::color
 };
 
+// Per-prim sampling setup of an axis-aligned textured prim, prepared by the
+// setup kernel so the raster stage needs no dependent loads (prim -> draw ->
+// texture descriptor) before it can address texels.  Quantised-coordinate
+// arithmetic of LINEAR_QUANTIZE_UV / blendTextureLinearFallback
+// (swgl_ext.h:160-183) and of the fragment-shader tail.
+struct WrTexRec {
+  const void* ptr;          // atlas / source base address
+  int32_t stride;           // elements
+  uint32_t wh;              // width | height << 16
+  float ou, su;             // u at the span start, per-pixel step
+  float stepx;              // quantised step per 4-pixel chunk
+  float minx, maxx;         // quantised clamp (uv_rect)
+  float ub0, ub2;           // uv_bounds.x / .z (tail clamp)
+  int32_t span;             // pixels [0,span) of a row go through draw_span
+  float lv0, lvs;           // v at row y0, per-row slope
+  float miny, maxy;
+  float ub1, ub3;
+  int32_t y0;
+  int32_t simple;           // 1: u constant on vertical edges, v on horizontal ones, colour is bytes
+  float fcolor[4];
+  // `unit`: every sample of the prim is exactly one texel (both 7-bit fractions zero, no
+  // clamping), texel (ix0 + n, iy0 + row) for span pixel n; tix[] = columns of the <= 3 tail pixels
+  int32_t unit, ix0, iy0;
+  int32_t tix[3];
+};
+
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM
 // mirror of the staging ring) -> `dst` with `dst_stride`.
 struct WrUploadSeg { const uint8_t* src; void* dst; uint32_t dst_stride, row_bytes, rows, pad; };
