@@ -9,6 +9,7 @@
 #include "composite.h"
 #include "ps_clear.h"
 #include "ps_text_run.h"
+#include "cs_blur.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -22,6 +23,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("ps_text_run ALPHA_PASS,TEXTURE_2D", ps_text_run_ALPHA_PASS_TEXTURE_2D)
   WRSH_ENTRY("ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D",
              ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D)
+  WRSH_ENTRY("cs_blur ALPHA_TARGET", cs_blur_ALPHA_TARGET)
+  WRSH_ENTRY("cs_blur COLOR_TARGET", cs_blur_COLOR_TARGET)
 #undef WRSH_ENTRY
   return nullptr;
 }

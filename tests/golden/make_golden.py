@@ -34,6 +34,10 @@ def main():
     out["cfg3_small"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12))[0])
     out["cfg3_small_zoom"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, glyph_zoom=1.25))[0])
     out["cfg3_4k"] = digest(render_direct(LIB, scenes.cfg3_text())[0])
+    for name, kw in (("blur_r8", dict(fmt="r8")), ("blur_rgba8", dict(fmt="rgba8")),
+                     ("blur_r8_sigmas", dict(fmt="r8", content=(40, 30), sigma=[0.8, 1.7, 3.2, 4.0], n_tasks=12, origin=(0, 0))),
+                     ("blur_rgba8_tiny", dict(fmt="rgba8", content=(5, 3), sigma=1.2, n_tasks=9, origin=(1, 1), atlas=64))):
+        out[name] = digest(render_direct(LIB, scenes.blur_chain(**kw))[0]["blur_h"])
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "digests.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1))
 

@@ -44,6 +44,31 @@ CASES = [
 ]
 
 
+
+BLUR_CASES = [
+    ("blur_r8", dict(fmt="r8")),
+    ("blur_rgba8", dict(fmt="rgba8")),
+    ("blur_r8_sigmas", dict(fmt="r8", content=(40, 30), sigma=[0.8, 1.7, 3.2, 4.0], n_tasks=12, origin=(0, 0))),
+    ("blur_rgba8_big", dict(fmt="rgba8", content=(61, 47), sigma=4.0, n_tasks=6, origin=(3, 2), atlas=512)),
+    ("blur_r8_edges", dict(fmt="r8", content=(126, 62), sigma=[3.0, 0.0], n_tasks=4, origin=(0, 0), atlas=258, pattern="noise")),
+    ("blur_rgba8_tiny", dict(fmt="rgba8", content=(5, 3), sigma=1.2, n_tasks=9, origin=(1, 1), atlas=64)),
+]
+
+
+@pytest.mark.parametrize("name,kw", BLUR_CASES, ids=[c[0] for c in BLUR_CASES])
+def test_hostsim_blur_matches_oracle(hostsim, oracle_gcc, name, kw):
+    """cs_blur vertical + horizontal passes (R8 and RGBA8 targets): every
+    render target of the chain is compared, not only the window."""
+    want, _ = render_direct(oracle_gcc, scenes.blur_chain(**kw))
+    got, _ = render_direct(hostsim, scenes.blur_chain(**kw))
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    assert want["blur_h"].any()
+    if name in GOLDEN:
+        assert digest(got["blur_h"]) == GOLDEN[name]
+
+
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
 def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     want, _ = render_direct(oracle_gcc, make())

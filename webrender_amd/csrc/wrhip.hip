@@ -133,6 +133,10 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
     {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"cs_blur ALPHA_TARGET", WR_SH_CS_BLUR_ALPHA,
+     {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
+    {"cs_blur COLOR_TARGET", WR_SH_CS_BLUR_COLOR,
+     {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
 };
 #undef S
 const char* const SAMPLER_NAMES[WR_MAX_TEX] = {
@@ -218,7 +222,7 @@ struct Context {
   uint8_t* dupload = nullptr;     // HBM mirror of the staging ring
   WrPrim* dprims = nullptr; size_t dprims_cap = 0;
   WrRec* drecs = nullptr;
-  WrTexRec* dtexrecs = nullptr;
+  WrAux* daux = nullptr;
   unsigned long long* dmasks = nullptr; size_t dmasks_cap = 0;
   WrUnsupportedCounters* dcounters = nullptr;
   // HBM pool for texture storage: per-frame textures (GpuBufferF/I, render
@@ -660,7 +664,7 @@ Context::~Context() {
   for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
-  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(dtexrecs); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
+  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(daux); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::stream_destroy(stream);
@@ -781,8 +785,8 @@ void flush_work(const std::vector<int>& sel_in) {
       c->dprims = (WrPrim*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrPrim));
       wrrt::dev_free(c->drecs);
       c->drecs = (WrRec*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrRec));
-      wrrt::dev_free(c->dtexrecs);
-      c->dtexrecs = (WrTexRec*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrTexRec));
+      wrrt::dev_free(c->daux);
+      c->daux = (WrAux*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrAux));
     }
     if (c->dmasks_cap < (size_t)n_words + 1) {
       wrrt::stream_sync(c->stream);
@@ -798,7 +802,7 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
     const uint8_t* dinst = darena + off_inst;
     if (n_prims > 0) {
-      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, c->dtexrecs, n_prims,
+      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, c->daux, n_prims,
                 dtargets, c->dmasks, c->dcounters);
       c->stats.kernel_launches += 1;
     }
@@ -850,7 +854,7 @@ void flush_work(const std::vector<int>& sel_in) {
 #define WR_RASTER_F(FMT, DEPTH, FEAT, NB, OFF)                                                                      \
   do {                                                                                                              \
     WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), NB, 256, c->stream, dtargets, n_targets, ddraws,             \
-              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrTexRec*)c->dtexrecs, c->dmasks, OFF);      \
+              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrAux*)c->daux, c->dmasks, OFF);      \
     c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
   } while (0)
 #define WR_RASTER(FMT, DEPTH, NB, OFF)                                                                              \

@@ -402,6 +402,83 @@ WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int 
   }
 }
 
+// exp() of the vertex stage.  The reference calls libm expf (glsl.h:803), which
+// is correctly rounded in practice; the device evaluates in fp64 and rounds once.
+WR_DEVICE float wr_expf(float x) {
+#ifdef WRHIP_HOSTSIM
+  return expf(x);
+#else
+  return (float)exp((double)x);
+#endif
+}
+
+// cs_blur.glsl:47-121 (vertex stage) + the per-instance part of blendGaussianBlur
+// (swgl_ext.h:951-960: bounds) and of gaussianBlurHorizontal/Vertical
+// (texture.h:1176-1214: the 8.8 fixed-point tap weights, identical for every pixel).
+WR_DEVICE void wr_vs_cs_blur(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrBlurRec& B) {
+  const int task_address = wr_load_attr<int>(d, arena, inst, 0);
+  const int src_address = wr_load_attr<int>(d, arena, inst, 1);
+  const int direction = wr_load_attr<int>(d, arena, inst, 2);
+  const wf4 params = wr_load_attr<wf4>(d, arena, inst, 3);   // (std deviation, region.x, region.y)
+  int u, v;
+  wr_fetch_uv(task_address, 2u, u, v);
+  const wf4 target = wr_fetch_f(d.tex[WR_S_RENDER_TASKS], u, v);
+  wr_fetch_uv(src_address, 2u, u, v);
+  const wf4 src = wr_fetch_f(d.tex[WR_S_RENDER_TASKS], u, v);
+  const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+  const float tsx = float(tex.width), tsy = float(tex.height);
+  const float sigma = params.x;
+  const int support = int(ceilf(1.5f * sigma)) * 2;
+  float g0 = 1.0f, g1 = 1.0f;
+  if (support > 0) {
+    g0 = 1.0f / (sqrtf(2.0f * 3.14159265f) * sigma);
+    g1 = wr_expf(-0.5f / (sigma * sigma));
+    float cx = g0, cy = g1, cz = g1 * g1;
+    float total = cx;
+    for (int i = 1; i <= support; i += 2) {
+      cx *= cy; cy *= cz;
+      float sub = cx;
+      cx *= cy; cy *= cz;
+      sub += cx;
+      total += 2.0f * sub;
+    }
+    g0 /= total;
+  }
+  B.ptr = tex.ptr; B.stride = tex.stride; B.wh = uint32_t(tex.width) | (uint32_t(tex.height) << 16);
+  B.format = tex.format; B.linear = tex.linear;
+  B.coeffs[0] = g0; B.coeffs[1] = g1;
+  B.offset_scale[0] = direction == 0 ? 1.0f / tsx : 0.0f;
+  B.offset_scale[1] = direction == 1 ? 1.0f / tsy : 0.0f;
+  B.hori = B.offset_scale[0] != 0.0f ? 1 : 0;
+  B.radius = support;
+  B.uv_rect[0] = (src.x + 0.5f) / tsx; B.uv_rect[1] = (src.y + 0.5f) / tsy;
+  B.uv_rect[2] = (src.x + params.y - 0.5f) / tsx; B.uv_rect[3] = (src.y + params.z - 0.5f) / tsy;
+  B.bounds[0] = int(B.uv_rect[0] * tsx); B.bounds[1] = int(B.uv_rect[1] * tsy);
+  B.bounds[2] = int(B.uv_rect[2] * tsx); B.bounds[3] = int(B.uv_rect[3] * tsy);
+  {
+    float coeff = g0 * 256.0f, step = g1;
+    const float step2 = g1 * g1;
+    B.weights[0] = uint16_t(coeff + 0.5f);
+    for (int k = 1; k <= support && k <= WR_BLUR_MAX_RADIUS; k++) {
+      coeff *= step; step *= step2;
+      B.weights[k] = uint16_t(coeff + 0.5f);
+    }
+  }
+  const float u0 = src.x / tsx, v0 = src.y / tsy, u1 = src.z / tsx, v1 = src.w / tsy;
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    const float x = (target.z - target.x) * ax + target.x, y = (target.w - target.y) * ay + target.y;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{x, y, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+    o.u[n] = (u1 - u0) * ax + u0; o.v[n] = (v1 - v0) * ay + v0;
+  }
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{0, 0, 0, 0};
+  o.uv_bounds = wf4{B.uv_rect[0], B.uv_rect[1], B.uv_rect[2], B.uv_rect[3]};
+  o.tex_slot = WR_S_COLOR0;
+  o.kind = support <= WR_BLUR_MAX_RADIUS ? WR_PK_BLUR : WR_PK_UNSUPPORTED;
+}
+
 // composite.glsl:73-159
 WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int inst, bool fast, WrVsOut& o) {
   wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
@@ -543,7 +620,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_UNSUPPORTED) { atomicAdd(&cnt->unsupported_prims, 1u); return; }
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1018,7 +1095,7 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
 // Vertex stage of one instance: locate its draw, run the shader's vertex
 // function, then swgl's draw_quad setup.
 WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws, const uint8_t* __restrict__ arena,
-                              int gid, WrPrim& P, WrUnsupportedCounters* cnt) {
+                              int gid, WrPrim& P, WrAux* aux, WrUnsupportedCounters* cnt) {
   P.blend = 0; P.flags = 0; P.z = 0; P.color[0] = P.color[1] = 0; P.tex_slot = 0;
   // binary search for the draw containing this instance
   int lo = 0, hi = n_draws - 1;
@@ -1046,6 +1123,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
     case WR_SH_PS_TEXT_RUN: wr_vs_ps_text_run(d, arena, inst, o); break;
+    case WR_SH_CS_BLUR_ALPHA: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
+    case WR_SH_CS_BLUR_COLOR: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -1113,17 +1192,17 @@ WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDes
 // Vertex stage + binning, one thread per instance.
 __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
-                                WrRec* __restrict__ recs, WrTexRec* __restrict__ texrecs, int n_prims,
+                                WrRec* __restrict__ recs, WrAux* __restrict__ aux, int n_prims,
                                 const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
                                 WrUnsupportedCounters* cnt) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = gid < n_prims;
   WrPrim P;
   P.kind = WR_PK_NONE; P.draw = 0; P.x0 = P.y0 = P.x1 = P.y1 = 0;
-  if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, cnt);
+  if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, aux, cnt);
   if (valid) {
     prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
-    if (P.kind == WR_PK_TEX_R8) texrecs[gid] = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
+    if (P.kind == WR_PK_TEX_R8) aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
   }
   wr_bin_prim(P, valid, gid, draws, targets, masks);
 }
@@ -1162,6 +1241,170 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
     src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y);
   }
   return wr_blend_rgba8(P.blend, dstp, src, D);
+}
+
+// ---------------------------------------------------------------------------
+// cs_blur, one destination pixel.  Returns the unpacked source value(s) that go
+// to the blend stage: 4 x u16 (RGBA8 targets) or the value in .bg's low half (R8).
+//   span part   blendGaussianBlur (swgl_ext.h:951-978): 4-pixel chunks from the
+//               integer texel position of the span start, while they fit in
+//               min(bounds.z, start + span, width); 8.8 fixed-point taps with
+//               saturating adds (texture.h:1165-1308)
+//   the rest    the float fragment shader (cs_blur.glsl:137-181)
+template <int FMT>
+__device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* Bp, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrBlurRec& B = *Bp;
+  const int tw = int(B.wh & 0xFFFF), th = int(B.wh >> 16);
+  const float W = float(tw), H = float(th);
+  // interpolants at the span start (as wr_tex_row)
+  const float k = float(y - P.y0);
+  const float Lu = P.uvL0[0] + k * P.uvLs[0], Lv = P.uvL0[1] + k * P.uvLs[1];
+  const float Ru = P.uvR0[0] + k * P.uvRs[0], Rv = P.uvR0[1] + k * P.uvRs[1];
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  const float ou = Lu + su * start, ov = Lv + sv * start;
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  const int n = x - P.x0;
+  constexpr int NCH = FMT == WR_FMT_RGBA8 ? 4 : 1;
+  const bool fmt_ok = B.format == FMT && B.ptr != nullptr;
+  const int startX = int(ou * W), curY = int(ov * H);
+  int drawn = 0;
+  if (fmt_ok && span > 0) {
+    const int endX = wr_imin(wr_imin(B.bounds[2], startX + span), tw);
+    if (endX - startX >= 4) drawn = (endX - startX) & ~3;
+  }
+  WrWide out; out.bg = out.ra = 0;
+  if (n < drawn) {
+    const int kk = n & 3, ix = startX + (n & ~3);
+    const int radius = B.radius;
+    uint32_t sum[NCH];
+    const uint32_t w0 = B.weights[0];
+    if (B.hori) {
+      const size_t row = (size_t)wr_clamp_coord(ix, tw - 1) + (size_t)wr_clamp_coord(curY, th) * B.stride;
+      const int lb = ix - wr_imax(B.bounds[0], 0), rb = wr_imin(B.bounds[2], tw - 1) - ix;
+      if (FMT == WR_FMT_RGBA8) {
+        const uint32_t* buf = (const uint32_t*)B.ptr;
+        const uint32_t c = buf[row + kk];
+        for (int ch = 0; ch < NCH; ch++) sum[ch] = (((c >> (8 * ch)) & 0xFF) * w0) & 0xFFFF;
+        for (int o = 1; o <= radius; o++) {
+          const uint32_t r = buf[(ptrdiff_t)row + ((kk + o <= 3) ? kk + o : wr_imin(kk + o, rb))];
+          const uint32_t l = buf[(ptrdiff_t)row + ((o <= kk) ? kk - o : -wr_imin(o - kk, lb))];
+          const uint32_t w = B.weights[o];
+          for (int ch = 0; ch < NCH; ch++) {
+            const uint32_t t = ((((r >> (8 * ch)) & 0xFF) + ((l >> (8 * ch)) & 0xFF)) * w) & 0xFFFF;
+            const uint32_t a = sum[ch] + t;
+            sum[ch] = a > 0xFFFF ? 0xFFFF : a;
+          }
+        }
+      } else {
+        const uint8_t* buf = (const uint8_t*)B.ptr;
+        sum[0] = (uint32_t(buf[row + kk]) * w0) & 0xFFFF;
+        for (int o = 1; o <= radius; o++) {
+          const uint32_t r = buf[(ptrdiff_t)row + ((kk + o <= 3) ? kk + o : wr_imin(kk + o, rb))];
+          const uint32_t l = buf[(ptrdiff_t)row + ((o <= kk) ? kk - o : -wr_imin(o - kk, lb))];
+          const uint32_t t = ((r + l) * B.weights[o]) & 0xFFFF;
+          const uint32_t a = sum[0] + t;
+          sum[0] = a > 0xFFFF ? 0xFFFF : a;
+        }
+      }
+    } else {
+      const size_t row = (size_t)wr_clamp_coord(ix, tw - 1) + (size_t)wr_clamp_coord(curY, th) * B.stride;
+      const int below = curY - wr_imax(B.bounds[1], 0), above = wr_imin(B.bounds[3], th - 1) - curY;
+      const int amax = wr_imax(above, 0), bmax = wr_imax(below, 0);
+      if (FMT == WR_FMT_RGBA8) {
+        const uint32_t* buf = (const uint32_t*)B.ptr;
+        const uint32_t c = buf[row + kk];
+        for (int ch = 0; ch < NCH; ch++) sum[ch] = (((c >> (8 * ch)) & 0xFF) * w0) & 0xFFFF;
+        for (int o = 1; o <= radius; o++) {
+          const uint32_t r = buf[(ptrdiff_t)row + kk + (ptrdiff_t)wr_imin(o, amax) * B.stride];
+          const uint32_t l = buf[(ptrdiff_t)row + kk - (ptrdiff_t)wr_imin(o, bmax) * B.stride];
+          const uint32_t w = B.weights[o];
+          for (int ch = 0; ch < NCH; ch++) {
+            const uint32_t t = ((((r >> (8 * ch)) & 0xFF) + ((l >> (8 * ch)) & 0xFF)) * w) & 0xFFFF;
+            const uint32_t a = sum[ch] + t;
+            sum[ch] = a > 0xFFFF ? 0xFFFF : a;
+          }
+        }
+      } else {
+        const uint8_t* buf = (const uint8_t*)B.ptr;
+        sum[0] = (uint32_t(buf[row + kk]) * w0) & 0xFFFF;
+        for (int o = 1; o <= radius; o++) {
+          const uint32_t r = buf[(ptrdiff_t)row + kk + (ptrdiff_t)wr_imin(o, amax) * B.stride];
+          const uint32_t l = buf[(ptrdiff_t)row + kk - (ptrdiff_t)wr_imin(o, bmax) * B.stride];
+          const uint32_t t = ((r + l) * B.weights[o]) & 0xFFFF;
+          const uint32_t a = sum[0] + t;
+          sum[0] = a > 0xFFFF ? 0xFFFF : a;
+        }
+      }
+    }
+    if (FMT == WR_FMT_RGBA8) {
+      out.bg = (sum[0] >> 8) | ((sum[1] >> 8) << 16);
+      out.ra = (sum[2] >> 8) | ((sum[3] >> 8) << 16);
+    } else {
+      out.bg = sum[0] >> 8;
+    }
+    return out;
+  }
+  // ---- fragment shader: uv of this pixel = its init_interp lane, stepped by
+  // `drawn` at once (DISPATCH_DRAW_SPAN) and then chunk by chunk
+  const int lane = (n - drawn) & 3, m = (n - drawn) >> 2;
+  float lu = ou, lv = ov;
+  for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
+  if (drawn > 0) { const float chunks = float(drawn) * 0.25f; lu = lu + (su * 4.0f) * chunks; lv = lv + (sv * 4.0f) * chunks; }
+  lu = wr_accum(lu, (su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (sv * 4.0f) * 1.0f, m);
+  const WrTexDesc t{B.ptr, tw, th, B.stride, (int16_t)B.format, (int16_t)B.linear};
+  auto sample = [&](float uu, float vv, float (&c)[4]) {
+    // texture(sColor0, uv): linear (texture.h:1028-1071 / 576-583) or nearest
+    if (B.format == WR_FMT_R8) {
+      float r;
+      if (t.linear) r = float(wr_sample_linear_r8(t, int(uu * W * 128.0f + (0.5f - 64.0f)), int(vv * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
+      else r = float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(uu * W), tw) + (size_t)wr_clamp_coord(int(vv * H), th) * t.stride]) * (1.0f / 255.0f);
+      c[0] = r; c[1] = 0.0f; c[2] = 0.0f; c[3] = 1.0f;
+    } else {
+      uint32_t b, g, r, a;
+      if (t.linear) {
+        const WrWide s = wr_sample_linear_rgba8(t, int(uu * W * 128.0f + (0.5f - 64.0f)), int(vv * H * 128.0f + (0.5f - 64.0f)));
+        b = s.bg & 0xFFFF; g = s.bg >> 16; r = s.ra & 0xFFFF; a = s.ra >> 16;
+      } else {
+        const uint32_t p = ((const uint32_t*)t.ptr)[(size_t)wr_clamp_coord(int(uu * W), tw) + (size_t)wr_clamp_coord(int(vv * H), th) * t.stride];
+        b = p & 0xFF; g = (p >> 8) & 0xFF; r = (p >> 16) & 0xFF; a = p >> 24;
+      }
+      c[0] = float(r) * (1.0f / 255.0f); c[1] = float(g) * (1.0f / 255.0f);
+      c[2] = float(b) * (1.0f / 255.0f); c[3] = float(a) * (1.0f / 255.0f);
+    }
+  };
+  float gx = B.coeffs[0], gy = B.coeffs[1];
+  const float gz = gy * gy;
+  float c0[4], avg[4];
+  if (!t.ptr) { c0[0] = c0[1] = c0[2] = c0[3] = 0.0f; } else sample(lu, lv, c0);
+  for (int ch = 0; ch < 4; ch++) avg[ch] = c0[ch] * gx;
+  const int support = wr_imin(B.radius, 300);
+  for (int i = 1; i <= support; i += 2) {
+    gx *= gy; gy *= gz;
+    float sub = gx;
+    gx *= gy; gy *= gz;
+    sub += gx;
+    const float ratio = gx / sub;
+    const float offx = B.offset_scale[0] * (float(i) + ratio), offy = B.offset_scale[1] * (float(i) + ratio);
+    float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (t.ptr) {
+      sample(wr_max(lu - offx, B.uv_rect[0]), wr_max(lv - offy, B.uv_rect[1]), a);
+      sample(wr_min(lu + offx, B.uv_rect[2]), wr_min(lv + offy, B.uv_rect[3]), b);
+    }
+    for (int ch = 0; ch < 4; ch++) avg[ch] += (a[ch] + b[ch]) * sub;
+  }
+  if (FMT == WR_FMT_RGBA8) {
+    if (B.format == WR_FMT_R8) { avg[1] = avg[2] = avg[3] = avg[0]; }   // ALPHA_TARGET shader on a colour target: vec4(r)
+    uint32_t pc[2];
+    wr_pack_color(wf4{avg[0], avg[1], avg[2], avg[3]}, pc);
+    out.bg = pc[0]; out.ra = pc[1];
+  } else {
+    out.bg = uint32_t(wr_round_pixel(avg[0])) & 0xFFFF;
+  }
+  return out;
 }
 
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
@@ -1205,7 +1448,7 @@ template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uint32_t (&dep)[4 * R],
                              const int x0, const int y0, const int x1, const int y1, const uint32_t z,
                              const uint32_t kbf, const uint32_t c0, const uint32_t c1,
-                             const WrPrim* Pp, const WrDrawDesc* draws,
+                             const WrPrim* Pp, const WrAux* Ap, const WrDrawDesc* draws,
                              const int px, const int py, const int wx0, const int wy0) {
   constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
   constexpr int NPX = 4 * R;
@@ -1343,6 +1586,21 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
           uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + i, y, plo[q] | (phi[q] << 8));
           plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
         }
+      }
+    }
+    return;
+  }
+  if (kind == WR_PK_BLUR) {
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      if (!(cx[q & 3] && cy[q >> 2])) continue;
+      const WrWide src = wr_blur_pixel<FMT>(Pp, &Ap->blur, px + (q & 3), py + 4 * (q >> 2));
+      if (FMT == WR_FMT_RGBA8) {
+        const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+      } else {
+        plo[q] = wr_blend_r8(blend, plo[q], src.bg & 0xFFFF);
       }
     }
     return;
@@ -1524,7 +1782,7 @@ template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void __launch_bounds__(1024 / R)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
-                 const WrRec* __restrict__ recs, const WrTexRec* __restrict__ texrecs,
+                 const WrRec* __restrict__ recs, const WrAux* __restrict__ aux,
                  unsigned long long* __restrict__ masks, int bin_offset) {
   constexpr int NPX = 4 * R, STRIP = 4 * R;
   const int bin = blockIdx.x + bin_offset;
@@ -1603,12 +1861,12 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       if (Rc.x1 <= wx0 || Rc.x0 >= wx0 + WR_BIN_W || Rc.y1 <= wy0 || Rc.y0 >= wy0 + STRIP) continue;
       const int rblend = (Rc.kbf >> 8) & 0xFF;
       if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && (Rc.kbf & 0xFF) == WR_PK_TEX_R8 && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
-          texrecs[base + bit].simple)
-        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, texrecs[base + bit],
+          aux[base + bit].tex.simple)
+        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, aux[base + bit].tex,
                                   draws, &prims[base + bit], px, py);
       else
         wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, &prims[base + bit],
-                                     draws, px, py, wx0, wy0);
+                                     &aux[base + bit], draws, px, py, wx0, wy0);
     }
   }
 #else
@@ -1648,10 +1906,10 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
       const int rblend = (kbf >> 8) & 0xFF;
       if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && (kbf & 0xFF) == WR_PK_TEX_R8 && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
-          texrecs[base + bit].simple)
-        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, texrecs[base + bit], draws, &prims[base + bit], px, py);
+          aux[base + bit].tex.simple)
+        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[base + bit].tex, draws, &prims[base + bit], px, py);
       else
-        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], draws, px, py, wx0, wy0);
+        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], &aux[base + bit], draws, px, py, wx0, wy0);
     }
   }
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the

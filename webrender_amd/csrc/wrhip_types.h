@@ -42,6 +42,8 @@ enum WrShader {
   WR_SH_COMPOSITE_FAST,
   WR_SH_PS_CLEAR,
   WR_SH_PS_TEXT_RUN,
+  WR_SH_CS_BLUR_ALPHA,
+  WR_SH_CS_BLUR_COLOR,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -131,6 +133,7 @@ enum WrPrimKind {
   WR_PK_TEX_RGBA8,      // swgl_commitTexture*RGBA8 family (rect, axis-aligned uv)
   WR_PK_UNSUPPORTED,
   WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
+  WR_PK_BLUR,           // swgl_commitGaussianBlur{R8,RGBA8}: one separable pass (WrBlurRec)
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
 };
 
@@ -195,6 +198,27 @@ struct WrTexRec {
   // clamping), texel (ix0 + n, iy0 + row) for span pixel n; tix[] = columns of the <= 3 tail pixels
   int32_t unit, ix0, iy0;
   int32_t tix[3];
+};
+
+// One separable Gaussian pass (cs_blur.glsl + swgl_ext.h:947-996, texture.h:1165-1308).
+#define WR_BLUR_MAX_RADIUS 32
+struct WrBlurRec {
+  const void* ptr;          // source render target
+  int32_t stride;           // elements
+  uint32_t wh;              // width | height << 16
+  int32_t format, linear;   // source WrTexFormat, filter
+  int32_t hori, radius;     // vOffsetScale.x != 0, vSupport.x
+  int32_t bounds[4];        // make_ivec4(vUvRect * size)
+  float coeffs[2];          // vGaussCoefficients
+  float uv_rect[4];         // vUvRect
+  float offset_scale[2];    // vOffsetScale
+  uint16_t weights[WR_BLUR_MAX_RADIUS + 2];   // uint16_t(coeff_o + 0.5), 8.8 fixed point, o = 0..radius
+};
+
+// per-prim side record, written by the setup kernel for the kinds that need one
+union WrAux {
+  WrTexRec tex;
+  WrBlurRec blur;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

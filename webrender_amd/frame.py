@@ -138,6 +138,7 @@ class Frame:
         self.passes = []            # list of lists of Target
         self.composite_tiles = []
         self.static_textures = []   # atlases to upload once
+        self.readback = []          # TextureRefs the tests read back besides the window
         self.add_transform(identity_transform(), identity_transform())  # id 0 = IDENTITY
         self._n_headers = 0
 

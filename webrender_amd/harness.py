@@ -79,13 +79,19 @@ class ScenePlayer:
 
 
 def render_direct(backend_path, frame, frames=1):
-    """Render through the Python mirror without tracing; returns RGBA8 pixels."""
+    """Render through the Python mirror without tracing; returns RGBA8 window
+    pixels, or {texture name: pixels, "window": ...} when the frame asks for
+    render-target readbacks (Frame.readback)."""
     gl = GL(backend_path)
     r = Renderer(gl, frame.width, frame.height)
     for _ in range(frames):
         r.render(frame)
     r.finish()
     px = r.read_pixels()
+    extra = {ref.name: r.device.read_texture(r.resolve(ref)) for ref in getattr(frame, "readback", [])}
     stats = gl.stats() if gl.is_wrhip else None
     r.destroy()
+    if extra:
+        extra["window"] = px
+        return extra, stats
     return px, stats

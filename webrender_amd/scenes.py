@@ -274,6 +274,74 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
     return frame
 
 
+# ---------------------------------------------------------------------------
+# Separable Gaussian blur chain (the off-screen half of BASELINE config 4).
+BLUR_DTYPE = np.dtype([("a", "<i4", (3,)), ("p", "<f4", (3,))])   # BlurInstance, gpu_types.rs:109-118
+
+
+def blur_instance(task_address, src_task_address, direction, std_dev, region):
+    inst = np.zeros(1, BLUR_DTYPE)
+    inst["a"][0] = (task_address, src_task_address, direction)
+    inst["p"][0] = (std_dev, region[0], region[1])
+    return inst
+
+
+def blur_chain(fmt="r8", content=(83, 83), sigma=2.5, atlas=256, n_tasks=1, seed=4, origin=(17, 9),
+               window=(256, 256), pattern="shapes"):
+    """`n_tasks` independent [vertical -> horizontal] cs_blur task pairs
+    (render_task.rs:1120-1215 new_blur): source content in `blur_src`
+    (standing in for the mask / picture the blur reads), vertical pass into
+    `blur_v`, horizontal pass into `blur_h`.  Rects packed on a grid in
+    `atlas`-sized targets like the render-task allocator would
+    (render_target.rs alloc).  Returns a Frame whose `readback` lists the
+    target textures to compare."""
+    rng = np.random.default_rng(seed)
+    cw, ch = content
+    color = fmt == "rgba8"
+    glfmt = G.GL_RGBA8 if color else G.GL_R8
+    if color:
+        src = rng.integers(0, 256, size=(atlas, atlas, 4), dtype=np.uint8)
+    else:
+        src = rng.integers(0, 256, size=(atlas, atlas), dtype=np.uint8)
+    if pattern == "shapes":       # rounded blobs: what a mask really looks like, plus some noise
+        yy, xx = np.mgrid[0:atlas, 0:atlas]
+        m = (((xx // 23 + yy // 31) % 2) * 255).astype(np.uint8)
+        if color:
+            src = np.where(rng.uniform(size=(atlas, atlas, 1)) < 0.7, m[..., None], src).astype(np.uint8)
+            src[..., :3] = (src[..., :3].astype(np.uint16) * src[..., 3:4] // 255).astype(np.uint8)
+        else:
+            src = np.where(rng.uniform(size=(atlas, atlas)) < 0.7, m, src).astype(np.uint8)
+    frame = Frame(window[0], window[1], (1.0, 1.0, 1.0, 1.0))
+    t_src = TextureRef("blur_src", atlas, atlas, glfmt, G.GL_LINEAR, pixels=src,
+                       upload_format=G.GL_BGRA if color else G.GL_RED)
+    t_v = TextureRef("blur_v", atlas, atlas, glfmt, G.GL_LINEAR, render_target=True)
+    t_h = TextureRef("blur_h", atlas, atlas, glfmt, G.GL_LINEAR, render_target=True)
+    frame.static_textures.append(t_src)
+    key = "cs_blur COLOR_TARGET" if color else "cs_blur ALPHA_TARGET"
+    zero = (0.0, 0.0, 0.0, 0.0)
+    tgt_v = Target(t_v, "color" if color else "alpha", clear_color=zero)
+    tgt_h = Target(t_h, "color" if color else "alpha", clear_color=zero)
+    per_row = max(1, (atlas - origin[0]) // (cw + 3))
+    vi, hi = [], []
+    for k in range(n_tasks):
+        gx, gy = k % per_row, k // per_row
+        x0, y0 = origin[0] + gx * (cw + 3), origin[1] + gy * (ch + 3)
+        assert y0 + ch <= atlas
+        rect = (float(x0), float(y0), float(x0 + cw), float(y0 + ch))
+        a_src = frame.add_render_task(rect)
+        a_v = frame.add_render_task(rect)
+        a_h = frame.add_render_task(rect)
+        sg = sigma if np.isscalar(sigma) else sigma[k % len(sigma)]
+        vi.append(blur_instance(a_v, a_src, 1, sg, (cw, ch)))
+        hi.append(blur_instance(a_h, a_v, 0, sg, (cw, ch)))
+    tgt_v.steps.append(Step(key, "BLUR", np.concatenate(vi), None, "none", textures={0: t_src}))
+    tgt_h.steps.append(Step(key, "BLUR", np.concatenate(hi), None, "none", textures={0: t_v}))
+    frame.passes.append([tgt_v])
+    frame.passes.append([tgt_h])
+    frame.readback = [t_v, t_h]
+    return frame
+
+
 SCENES = {
     "cfg1": cfg1_solid_colors,
     "simple_batching": simple_batching,
