@@ -34,6 +34,8 @@ def main():
     out["cfg3_small"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12))[0])
     out["cfg3_small_zoom"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, glyph_zoom=1.25))[0])
     out["cfg3_4k"] = digest(render_direct(LIB, scenes.cfg3_text())[0])
+    out["masked_rects"] = digest(render_direct(LIB, scenes.masked_rects())[0])
+    out["masked_rects_frac"] = digest(render_direct(LIB, scenes.masked_rects(fractional=True))[0])
     for name, kw in (("blur_r8", dict(fmt="r8")), ("blur_rgba8", dict(fmt="rgba8")),
                      ("blur_r8_sigmas", dict(fmt="r8", content=(40, 30), sigma=[0.8, 1.7, 3.2, 4.0], n_tasks=12, origin=(0, 0))),
                      ("blur_rgba8_tiny", dict(fmt="rgba8", content=(5, 3), sigma=1.2, n_tasks=9, origin=(1, 1), atlas=64))):

@@ -844,7 +844,10 @@ void flush_work(const std::vector<int>& sel_in) {
     for (int i = 0; i < nd; i++) {
       switch (draws[i].shader) {
         case WR_SH_PS_TEXT_RUN: feat |= 3; break;
-        case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA: case WR_SH_PS_CLEAR: case WR_SH_CLEAR_OP: break;
+        case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA:
+          if (draws[i].blend != WR_BLEND_NONE && draws[i].tex[WR_S_CLIP_MASK].width >= 2) feat |= 2;   // masked solids
+          break;
+        case WR_SH_PS_CLEAR: case WR_SH_CLEAR_OP: break;
         // quads drawn with the 1x1 dummy texture bound are solid (a textured one would still be
         // drawn correctly by the generic path: FEAT only selects fast paths)
         case WR_SH_PS_QUAD_TEXTURED: if (draws[i].tex[WR_S_COLOR0].width >= 2) feat |= 1; break;

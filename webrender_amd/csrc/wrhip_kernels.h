@@ -158,6 +158,7 @@ struct WrVsOut {
   int tex_slot;
   int aa_edges;        // swgl_antiAlias mask
   int has_mask;        // swgl_clipMask set
+  float mask_offset[2], mask_bb[4];   // swgl_clipMask(offset, bb_origin, bb_size) arguments
   int tail_clamp;      // fragment main(): clamps uv to uv_bounds
   int tail_modulate;   // fragment main(): multiplies texel by colour
 };
@@ -305,6 +306,10 @@ WR_DEVICE void wr_vs_brush_solid(const WrDrawDesc& d, const uint8_t* arena, int 
   o.aa_edges = aa;
   // write_clip -> swgl_clipMask: enabled iff bb_size != 0 (swgl_ext.h:1867-1876)
   o.has_mask = ((ca_p1.x - ca_p0.x) != 0.0f || (ca_p1.y - ca_p0.y) != 0.0f) ? 1 : 0;
+  // write_clip (prim_shared.glsl:183-200): (task_rect.p0 - content_origin) - (area.task_rect.p0 - area.screen_origin)
+  o.mask_offset[0] = (task.p0.x - task.origin.x) - (ca_p0.x - ca_origin.x);
+  o.mask_offset[1] = (task.p0.y - task.origin.y) - (ca_p0.y - ca_origin.y);
+  o.mask_bb[0] = ca_p0.x; o.mask_bb[1] = ca_p0.y; o.mask_bb[2] = ca_p1.x - ca_p0.x; o.mask_bb[3] = ca_p1.y - ca_p0.y;
   float fox = -task.origin.x + task.p0.x, foy = -task.origin.y + task.p0.y;
   for (int n = 0; n < 4; n++) {
     float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
@@ -574,6 +579,22 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     sy[n] = (o.py[n] * w + 1.0f) * 0.5f * d.vp_size[1] + d.vp_origin[1];
   }
   float cx0 = float(d.clip[0]), cy0 = float(d.clip[1]), cx1 = float(d.clip[2]), cy1 = float(d.clip[3]);
+  bool masked = false;
+  if (o.has_mask && d.blend != WR_BLEND_NONE) {
+    // ClipRect ctor (rasterize.h:408-444): clip-mask bounds constrain the draw rect
+    const WrTexDesc& mt = d.tex[WR_S_CLIP_MASK];
+    if (o.kind != WR_PK_SOLID || mt.format != WR_FMT_R8 || !mt.ptr) {   // masked textured prims: "next"
+      P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
+    }
+    int bx0 = int(o.mask_bb[0]), by0 = int(o.mask_bb[1]);
+    int bx1 = bx0 + int(o.mask_bb[2]), by1 = by0 + int(o.mask_bb[3]);
+    bx0 = wr_imax(bx0, 0); by0 = wr_imax(by0, 0); bx1 = wr_imin(bx1, mt.width); by1 = wr_imin(by1, mt.height);
+    const int offx = int(o.mask_offset[0]) + int(d.vp_origin[0]), offy = int(o.mask_offset[1]) + int(d.vp_origin[1]);
+    cx0 = wr_max(cx0, float(bx0 + offx)); cy0 = wr_max(cy0, float(by0 + offy));
+    cx1 = wr_min(cx1, float(bx1 + offx)); cy1 = wr_min(cy1, float(by1 + offy));
+    P.mask_off[0] = offx; P.mask_off[1] = offy;
+    masked = true;
+  }
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG_VS"))
     fprintf(stderr, "    vs: pos (%g %g %g %g) (%g %g) (%g %g) (%g %g) screen (%g %g) (%g %g) (%g %g) (%g %g)\n", o.px[0], o.py[0], o.pz[0],
@@ -591,9 +612,6 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   P.z = uint32_t(16777215.0f * screenZ);
 
   if (o.aa_edges != 0 && d.blend != WR_BLEND_NONE) {  // swgl_antiAlias needs blending; AA path is "next"
-    P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
-  }
-  if (o.has_mask && d.blend != WR_BLEND_NONE) {
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
   // lanes: 0=(0,0) 1=(1,0) 2=(1,1) 3=(0,1) of the unit quad
@@ -616,10 +634,11 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   while (iy1 > iy0 && (float(iy1 - 1) + 0.5f) > ylimit) iy1--;
   if (ix1 <= ix0 || iy1 <= iy0) return;
   P.x0 = ix0; P.x1 = ix1; P.y0 = iy0; P.y1 = iy1;
-  P.kind = (int16_t)o.kind;
+  P.kind = masked ? (int16_t)WR_PK_SOLID_MASKED : (int16_t)o.kind;
   if (o.kind == WR_PK_UNSUPPORTED) { atomicAdd(&cnt->unsupported_prims, 1u); return; }
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
+    if (masked) P.tex_slot = WR_S_CLIP_MASK;
   } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
@@ -1203,6 +1222,17 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
   if (valid) {
     prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
     if (P.kind == WR_PK_TEX_R8) aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
+    if (P.kind == WR_PK_SOLID_MASKED) {
+      // a masked solid is a unit-texel read of the mask: reuse the glyph path's record
+      const WrTexDesc& mt = draws[P.draw].tex[WR_S_CLIP_MASK];
+      WrTexRec t;
+      __builtin_memset(&t, 0, sizeof(t));
+      t.ptr = mt.ptr; t.stride = mt.stride; t.wh = uint32_t(mt.width) | (uint32_t(mt.height) << 16);
+      t.span = 0x40000000; t.y0 = P.y0;
+      t.simple = ((P.color[0] | P.color[1]) & 0xFF00FF00u) == 0 ? 1 : 0;
+      t.unit = 1; t.ix0 = P.x0 - P.mask_off[0]; t.iy0 = P.y0 - P.mask_off[1];
+      aux[gid].tex = t;
+    }
   }
   wr_bin_prim(P, valid, gid, draws, targets, masks);
 }
@@ -1237,6 +1267,12 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
   WrWide src;
   if (P.kind == WR_PK_SOLID) {
     src.bg = P.color[0]; src.ra = P.color[1];
+  } else if (P.kind == WR_PK_SOLID_MASKED) {
+    // applyColor(expand_mask(mask), colour) (swgl_ext.h:11-23); mask texel 1:1 at (x,y) - offset
+    const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
+    const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
+    WrWide mm; mm.bg = mm.ra = m | (m << 16);
+    src = wr_apply_color(mm, P.color);
   } else {
     src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y);
   }
@@ -1860,7 +1896,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       const WrRec Rc = recs[base + bit];
       if (Rc.x1 <= wx0 || Rc.x0 >= wx0 + WR_BIN_W || Rc.y1 <= wy0 || Rc.y0 >= wy0 + STRIP) continue;
       const int rblend = (Rc.kbf >> 8) & 0xFF;
-      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && (Rc.kbf & 0xFF) == WR_PK_TEX_R8 && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 || (Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
         wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, aux[base + bit].tex,
                                   draws, &prims[base + bit], px, py);
@@ -1905,7 +1941,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       const uint32_t z = __builtin_amdgcn_readlane((int)rb.x, bit), kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
       const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
       const int rblend = (kbf >> 8) & 0xFF;
-      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && (kbf & 0xFF) == WR_PK_TEX_R8 && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_TEX_R8 || (kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
         wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[base + bit].tex, draws, &prims[base + bit], px, py);
       else

@@ -133,6 +133,7 @@ enum WrPrimKind {
   WR_PK_TEX_RGBA8,      // swgl_commitTexture*RGBA8 family (rect, axis-aligned uv)
   WR_PK_UNSUPPORTED,
   WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
+  WR_PK_SOLID_MASKED,   // commit_masked_solid_span: flat colour x R8 clip mask sampled 1:1 (swgl_clipMask)
   WR_PK_BLUR,           // swgl_commitGaussianBlur{R8,RGBA8}: one separable pass (WrBlurRec)
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
 };
@@ -162,7 +163,8 @@ struct WrPrim {
   float uv_bounds[4];       // uv_rect passed to swgl_commitTexture*
   float fcolor[4];          // float colour for the fragment-shader (tail) path
   int32_t tex_slot;         // sampler slot
-  int32_t pad[3];
+  int32_t mask_off[2];      // WR_PK_SOLID_MASKED: target pixel - mask texel (swgl_ClipMaskOffset)
+  int32_t pad[1];
 };
 
 // Compact per-prim record the raster stage streams (32 B, dense array): the

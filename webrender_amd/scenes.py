@@ -275,6 +275,73 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
 
 
 # ---------------------------------------------------------------------------
+# Clip-masked rectangles: brush_solid ALPHA_PASS instances whose clip task
+# address points at an R8 mask region (prim_shared.glsl:183-200 write_clip ->
+# swgl_clipMask).  The masks themselves are uploaded here; in a full frame they
+# are what cs_clip_rectangle / cs_clip_box_shadow render in an earlier pass.
+def mask_atlas(size=1024, seed=11):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    m = 0.5 + 0.5 * np.sin(xx / 9.0) * np.cos(yy / 13.0)
+    m = np.clip(m * 1.4 - 0.2, 0.0, 1.0)
+    m = (m * 255.0 + 0.5).astype(np.uint8)
+    noise = rng.integers(0, 256, size=(size, size), dtype=np.uint8)
+    return np.where(rng.uniform(size=(size, size)) < 0.1, noise, m).astype(np.uint8)
+
+
+def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional=False, tile_filter=None):
+    rng, rects = random_rects(n, width, height, 16, 200, seed, fractional)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    alpha = np.round(rng.uniform(0.3, 1.0, size=n) * 255).astype(np.uint8)
+    colors = premultiply(np.concatenate([rgb, alpha[:, None]], axis=1))
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    t_mask = TextureRef("clip_mask_atlas", atlas, atlas, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(atlas),
+                        upload_format=G.GL_RED)
+    frame.static_textures.append(t_mask)
+    # one clip task per prim (every third prim is unmasked)
+    clip_tasks = []
+    for i in range(n):
+        if i % 3 == 2:
+            clip_tasks.append(None)
+            continue
+        w, h = int(rects[i, 2] - rects[i, 0]), int(rects[i, 3] - rects[i, 1])
+        mw, mh = w + int(rng.integers(-12, 5)), h + int(rng.integers(-12, 5))
+        mx, my = int(rng.integers(0, atlas - mw - 1)), int(rng.integers(0, atlas - mh - 1))
+        if i % 10 == 0:       # a task hanging over the atlas edge: bounds are clamped to the mask
+            mx = atlas - mw // 2
+        sx = float(np.floor(rects[i, 0])) + float(rng.integers(-6, 7))
+        sy = float(np.floor(rects[i, 1])) + float(rng.integers(-6, 7))
+        if fractional and i % 4 == 1:
+            sx += 0.5
+        clip_tasks.append(((float(mx), float(my), float(mx + mw), float(my + mh)), (sx, sy)))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        hit = np.nonzero((rects[:, 0] < x1) & (rects[:, 2] > x0) & (rects[:, 1] < y1) & (rects[:, 3] > y0))[0]
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        inst = []
+        for i in hit:
+            addr = frame.gpu_cache.push([list(colors[i])])
+            ph = frame.add_prim_header(rects[i], (-BIG, -BIG, BIG, BIG), int(i + 1), addr, 0, task, (65535, 0, 0, 0))
+            ct = clip_tasks[i]
+            clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
+            inst.append(frame.brush_instance(ph, clip_addr))
+        if inst:
+            target.alpha.append(Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={9: t_mask}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
+
+
+# ---------------------------------------------------------------------------
 # Separable Gaussian blur chain (the off-screen half of BASELINE config 4).
 BLUR_DTYPE = np.dtype([("a", "<i4", (3,)), ("p", "<f4", (3,))])   # BlurInstance, gpu_types.rs:109-118
 
