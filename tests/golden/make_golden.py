@@ -34,6 +34,7 @@ def main():
     out["cfg3_small"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12))[0])
     out["cfg3_small_zoom"] = digest(render_direct(LIB, scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, glyph_zoom=1.25))[0])
     out["cfg3_4k"] = digest(render_direct(LIB, scenes.cfg3_text())[0])
+    out["scaled_composites"] = digest(render_direct(LIB, scenes.scaled_composites())[0])
     out["masked_rects"] = digest(render_direct(LIB, scenes.masked_rects())[0])
     out["masked_rects_frac"] = digest(render_direct(LIB, scenes.masked_rects(fractional=True))[0])
     for name, kw in (("blur_r8", dict(fmt="r8")), ("blur_rgba8", dict(fmt="rgba8")),

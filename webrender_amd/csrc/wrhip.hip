@@ -1642,7 +1642,7 @@ void DestroyContext(WrhipContext* c_) {
   if (!c) return;
   if (--c->references > 0) return;
 #ifdef WRHIP_HOSTSIM
-  if (getenv("WRHIP_DEBUG")) fprintf(stderr, "paths: r8fast %llu (unit %llu) generic %llu accum_loop %llu\n", wr_dbg_paths[0], wr_dbg_paths[3], wr_dbg_paths[1], wr_dbg_paths[2]);
+  if (getenv("WRHIP_DEBUG")) fprintf(stderr, "paths: r8fast %llu (unit %llu) generic %llu accum_loop %llu linear: fallback %llu upscale %llu fast %llu downscale %llu\n", wr_dbg_paths[0], wr_dbg_paths[3], wr_dbg_paths[1], wr_dbg_paths[2], wr_dbg_paths[4], wr_dbg_paths[5], wr_dbg_paths[6], wr_dbg_paths[7]);
 #endif
   if (ctx == c) { delete c; ctx = nullptr; }
   else delete c;

@@ -23,6 +23,13 @@
 
 // ---------------------------------------------------------------------------
 // small vector helpers
+// hostsim only: which raster paths ran (printed at DestroyContext under WRHIP_DEBUG)
+#ifdef WRHIP_HOSTSIM
+static unsigned long long wr_dbg_paths[8];
+#define WR_DBG_PATH(i) (wr_dbg_paths[i]++)
+#else
+#define WR_DBG_PATH(i) ((void)0)
+#endif
 struct wf2 { float x, y; };
 struct wf4 { float x, y, z, w; };
 struct wi4 { int x, y, z, w; };
@@ -785,13 +792,6 @@ WR_DEVICE WrWide wr_apply_color(WrWide src, const uint32_t color[2]) {
 // provably identical: if s0 and step are both multiples of 2^g and every partial
 // sum is below 2^(g+24) in magnitude, every add is exact, so the result is the
 // real number s0 + c*step (partial sums are monotone between the end points).
-// hostsim only: which raster paths ran (printed at DestroyContext under WRHIP_DEBUG)
-#ifdef WRHIP_HOSTSIM
-static unsigned long long wr_dbg_paths[8];
-#define WR_DBG_PATH(i) (wr_dbg_paths[i]++)
-#else
-#define WR_DBG_PATH(i) ((void)0)
-#endif
 WR_DEVICE int wr_low_bit_exp(float x) {
   uint32_t b; __builtin_memcpy(&b, &x, 4);
   uint32_t e = (b >> 23) & 0xFF, m = b & 0x7FFFFF;
@@ -861,6 +861,130 @@ WR_DEVICE int wr_sample_linear_r8(const WrTexDesc& t, int qx, int qy) {
 }
 
 // ---------------------------------------------------------------------------
+// blendTextureLinear (swgl_ext.h:172-455): the exact per-pixel value of a span
+// committed with linear filtering, for every filter variant swgl dispatches to.
+//   q[k], qy[k]   quantised (1/128 texel) coordinates of the span's first four
+//                 pixels (LINEAR_QUANTIZE_UV applied to the 4 SIMD lanes)
+//   filter        needsTextureLinear's choice: 1 fallback, 2 upscale, 3 fast, 4 downscale
+// NCH = 4 (RGBA8 texels) or 1 (R8); out[] gets the int16 lane values.
+template <int NCH>
+WR_DEVICE void wr_fetch_texel(const WrTexDesc& t, size_t idx, int (&c)[4]) {
+  if (NCH == 4) {
+    const uint32_t p = ((const uint32_t*)t.ptr)[idx];
+    c[0] = p & 0xFF; c[1] = (p >> 8) & 0xFF; c[2] = (p >> 16) & 0xFF; c[3] = p >> 24;
+  } else {
+    c[0] = ((const uint8_t*)t.ptr)[idx]; c[1] = c[2] = c[3] = 0;
+  }
+}
+// src0 + (((src1 - src0) * fracy) >> 7) for the texel column `x` of a row pair
+template <int NCH>
+WR_DEVICE void wr_row_lerp(const WrTexDesc& t, size_t row0, size_t row1, ptrdiff_t x, int fracy, int (&v)[4]) {
+  int a[4], b[4];
+  wr_fetch_texel<NCH>(t, row0 + x, a);
+  wr_fetch_texel<NCH>(t, row1 + x, b);
+  for (int c = 0; c < NCH; c++) v[c] = (int16_t)(a[c] + (int16_t)(((int16_t)((b[c] - a[c]) * fracy)) >> 7));
+}
+WR_DEVICE int wr_frac_x(const WrTexDesc& t, int ix, int q) {   // computeFracX, texture.h:466-469
+  const int over = ix > t.width - 2 ? -1 : 0;
+  return ((((ix >= 0) ? q : 0) | over) & 0x7F) - over;
+}
+template <int NCH>
+WR_DEVICE void wr_bilinear(const WrTexDesc& t, int qx, int qy, int (&v)[4]) {   // textureLinearUnpacked{RGBA8,R8}
+  const int ix = qx >> 7, iy = qy >> 7;
+  const size_t row0 = (size_t)wr_clamp_coord(ix, t.width - 1) + (size_t)wr_clamp_coord(iy, t.height) * t.stride;
+  const size_t row1 = row0 + ((iy >= 0 && iy < t.height - 1) ? t.stride : 0);
+  const int fracx = wr_frac_x(t, ix, qx), fracy = qy & 0x7F;
+  int l[4], r[4];
+  wr_row_lerp<NCH>(t, row0, row1, 0, fracy, l);
+  wr_row_lerp<NCH>(t, row0, row1, 1, fracy, r);
+  for (int c = 0; c < NCH; c++) v[c] = (int16_t)(l[c] + (int16_t)(((int16_t)((r[c] - l[c]) * fracx)) >> 7));
+}
+
+template <int NCH>
+WR_DEVICE void wr_linear_span_pixel(const WrTexDesc& t, const float (&q)[4], const float (&qy)[4], float stepx, float stepy,
+                                    float minx, float maxx, float miny, float maxy, int filter, int span, int n,
+                                    int (&out)[4]) {
+  const int k = n & 3;
+  int before = 0, inside = 0;
+  float U[4] = {q[0], q[1], q[2], q[3]};        // uv.x of the four lanes as the dispatcher advances it
+  if (filter != 1) {
+    // blendTextureLinearDispatch (swgl_ext.h:378-440)
+    const float beforeDist = wr_max(0.0f, minx) - U[0];
+    if (beforeDist > 0.0f) {
+      before = wr_iclamp(int(ceilf(beforeDist / stepx)) * 4, 0, span);
+      const float adv = float(before / 4) * stepx;
+      for (int i = 0; i < 4; i++) U[i] += adv;
+    }
+    const float insideDist = wr_min(maxx, float((t.width - 4) * 128)) - U[0];
+    if (stepx > 0.0f && insideDist >= stepx) {
+      inside = span - before;
+      if (filter == 4) inside = wr_imin(int(insideDist * (0.5f / 128.0f)) & ~3, inside);
+      else if (filter == 2) inside = wr_imin(int(insideDist / stepx) * 4, inside);
+      else inside = wr_imin(int(insideDist * (1.0f / 128.0f)) & ~3, inside);
+      if (inside < 0) inside = 0;
+    }
+  }
+  if (filter == 1 || n < before || n >= before + inside) {
+    // blendTextureLinearFallback: uv += uv_step per chunk, clamp, full bilinear
+    float ux, uy;
+    int c;
+    if (filter == 1 || n < before) {
+      c = n >> 2; ux = q[k]; uy = qy[k];
+    } else {
+      const float adv = float(inside / 4) * stepx;
+      c = (n - before - inside) >> 2; ux = U[k] + adv; uy = qy[k];
+    }
+    WR_DBG_PATH(4);
+    ux = wr_accum(ux, stepx, c); uy = wr_accum(uy, stepy, c);
+    wr_bilinear<NCH>(t, int(wr_clamp(ux, minx, maxx)), int(wr_clamp(uy, miny, maxy)), out);
+    return;
+  }
+  const int j = n - before;             // pixel index inside the fast run
+  const int iq0y = int(wr_clamp(qy[0], miny, maxy));
+  const int iy = iq0y >> 7, fracy = iq0y & 0x7F;
+  const size_t rowy = (size_t)wr_clamp_coord(iy, t.height) * t.stride;
+  const size_t nexty = (iy >= 0 && iy < t.height - 1) ? t.stride : 0;
+  if (filter == 3 || filter == 4) {
+    // blendTextureLinearFast / Downscale: constant fractions from lane 0 of the run start
+    const int iq0 = int(wr_clamp(U[0], minx, maxx));
+    const int ix = iq0 >> 7;
+    const int fracx = wr_frac_x(t, ix, iq0);
+    const size_t row0 = rowy + wr_clamp_coord(ix, t.width - 1), row1 = row0 + nexty;
+    WR_DBG_PATH(filter == 3 ? 6 : 7);
+    const ptrdiff_t x = filter == 3 ? j : 2 * j;
+    int a[4], b[4];
+    wr_row_lerp<NCH>(t, row0, row1, x, fracy, a);
+    wr_row_lerp<NCH>(t, row0, row1, x + 1, fracy, b);
+    for (int c = 0; c < NCH; c++) out[c] = (int16_t)(a[c] + (int16_t)(((int16_t)((b[c] - a[c]) * fracx)) >> 7));
+    return;
+  }
+  // blendTextureLinearUpscale (swgl_ext.h:203-284): chunk m of the run
+  WR_DBG_PATH(5);
+  const int m = j >> 2;
+  int ich[4], fch[4], ixn0;
+  for (int i = 0; i < 4; i++) {
+    if (m == 0) {
+      const int iq = int(wr_clamp(U[i], minx, maxx));
+      ich[i] = iq >> 7; fch[i] = wr_frac_x(t, ich[i], iq);
+    } else {
+      const int iq = int(wr_accum(U[i], stepx, m));
+      ich[i] = iq >> 7; fch[i] = iq & 0x7F;
+    }
+  }
+  ixn0 = int(wr_accum(U[0], stepx, m + 1)) >> 7;
+  int S[4] = {0, 1, 2, 3}, N[4] = {1, 2, 3, 4};      // indices into src[]; 4 = the sample shifted in from srcn
+  if (ich[1] == ich[0]) { S[3] = S[2]; S[2] = S[1]; S[1] = S[0]; N[3] = N[2]; N[2] = N[1]; N[1] = N[0]; }
+  if (ich[2] == ich[1]) { S[3] = S[2]; S[2] = S[1]; N[3] = N[2]; N[2] = N[1]; }
+  if (ich[3] == ich[2]) { S[3] = S[2]; N[3] = N[2]; }
+  const size_t row0 = rowy, row1 = rowy + nexty;      // computeRow(sampler, (0, i.y.x)): absolute x indexing
+  int a[4], b[4];
+  wr_row_lerp<NCH>(t, row0, row1, (ptrdiff_t)ich[0] + S[k], fracy, a);
+  if (N[k] < 4) wr_row_lerp<NCH>(t, row0, row1, (ptrdiff_t)ich[0] + N[k], fracy, b);
+  else wr_row_lerp<NCH>(t, row0, row1, (ptrdiff_t)ixn0 + (ixn0 == ich[3] ? 1 : 0), fracy, b);
+  for (int c = 0; c < NCH; c++) out[c] = (int16_t)(a[c] + (int16_t)(((int16_t)((b[c] - a[c]) * fch[k])) >> 7));
+}
+
+// ---------------------------------------------------------------------------
 // Raster stage.  Lane l of wave w in the workgroup of bin (bx,by) owns pixels
 //   x = 64*bx + 4*(l & 15) + i,   y = 64*by + 16*w + (l >> 4) + 4*j,  i,j in 0..3
 // i.e. for a fixed j the wave touches 4 consecutive rows x 256 contiguous bytes.
@@ -878,9 +1002,10 @@ struct WrTexRow {
 
 WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   WrTexRow r;
-  float k = float(y - P.y0);
-  float Lu = P.uvL0[0] + k * P.uvLs[0], Lv = P.uvL0[1] + k * P.uvLs[1];
-  float Ru = P.uvR0[0] + k * P.uvRs[0], Rv = P.uvR0[1] + k * P.uvRs[1];
+  // Edge::nextRow (rasterize.h:878-882) steps the interpolants by repeated addition
+  const int k = y - P.y0;
+  float Lu = wr_accum(P.uvL0[0], P.uvLs[0], k), Lv = wr_accum(P.uvL0[1], P.uvLs[1], k);
+  float Ru = wr_accum(P.uvR0[0], P.uvRs[0], k), Rv = wr_accum(P.uvR0[1], P.uvRs[1], k);
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
@@ -960,30 +1085,30 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
       int sx = wr_iclamp(r.ix + n, r.minX, r.maxX);
       s = wr_unpack(buf[(size_t)r.srow * t.stride + sx]);
     } else {
-      // Linear filters.  All variants evaluate the same 7-bit bilinear formula;
-      // quantised coordinate stepping follows blendTextureLinearFallback
-      // (swgl_ext.h:172-183): per 4-pixel chunk uv += uv_step, lanes offset by
-      // their init_interp value.  (Upscale/Fast/Downscale index arithmetic: "next".)
+      // Linear filters: exact per-variant evaluation (wr_linear_span_pixel)
       const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
-      float ou1 = r.ou + r.su, ov1 = r.ov + r.sv;
-      float q0x = r.ou * W * qs + qo, q1x = ou1 * W * qs + qo;
-      float q0y = r.ov * H * qs + qo, q1y = ov1 * H * qs + qo;
-      float stepx = 4.0f * (q1x - q0x), stepy = 4.0f * (q1y - q0y);
-      float minx = wr_max(P.uv_bounds[0] * W * qs + qo, 0.0f);
-      float miny = wr_max(P.uv_bounds[1] * H * qs + qo, 0.0f);
-      float maxx = wr_max(P.uv_bounds[2] * W * qs + qo, minx);
-      float maxy = wr_max(P.uv_bounds[3] * H * qs + qo, miny);
-      int chunk = n >> 2, lane = n & 3;
-      float lu = r.ou, lv = r.ov;
-      for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
-      float qx = lu * W * qs + qo, qy = lv * H * qs + qo;
-      qx = wr_accum(qx, stepx, chunk); qy = wr_accum(qy, stepy, chunk);
-      qx = wr_clamp(qx, minx, maxx); qy = wr_clamp(qy, miny, maxy);
+      float q[4], qy[4];
+      {
+        float lu = r.ou, lv = r.ov;
+        for (int i = 0; i < 4; i++) {
+          q[i] = lu * W * qs + qo; qy[i] = lv * H * qs + qo;
+          lu += r.su; lv += r.sv;
+        }
+      }
+      const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
+      const float minx = wr_max(P.uv_bounds[0] * W * qs + qo, 0.0f);
+      const float miny = wr_max(P.uv_bounds[1] * H * qs + qo, 0.0f);
+      const float maxx = wr_max(P.uv_bounds[2] * W * qs + qo, minx);
+      const float maxy = wr_max(P.uv_bounds[3] * H * qs + qo, miny);
+      int v[4];
       if (P.kind == WR_PK_TEX_R8) {   // expand_mask(buf, r): r in all four channels (blend.h)
-        uint32_t m = uint32_t(wr_sample_linear_r8(t, int(qx), int(qy))) & 0xFFFF;
+        wr_linear_span_pixel<1>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, 1, r.span, n, v);
+        const uint32_t m = uint32_t(v[0]) & 0xFFFF;
         s.bg = s.ra = m | (m << 16);
       } else {
-        s = wr_sample_linear_rgba8(t, int(qx), int(qy));
+        wr_linear_span_pixel<4>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, r.filter, r.span, n, v);
+        s.bg = (uint32_t(v[0]) & 0xFFFF) | ((uint32_t(v[1]) & 0xFFFF) << 16);
+        s.ra = (uint32_t(v[2]) & 0xFFFF) | ((uint32_t(v[3]) & 0xFFFF) << 16);
       }
     }
     if (P.flags & WR_PF_HAS_COLOR) s = wr_apply_color(s, P.color);
@@ -1099,8 +1224,8 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
       ok = ok && (qx & 0x7F) == 0 && qx >= 0 && (qx >> 7) <= tex.width - 2;
     }
     int r0 = 0;
-    for (int r = 0; r < rows && ok; r++) {
-      const float ov = t.lv0 + float(r) * t.lvs;
+    float ov = t.lv0;
+    for (int r = 0; r < rows && ok; r++, ov += t.lvs) {
       const int qs_ = int(wr_clamp(ov * H * qs + qo, t.miny, t.maxy));
       const int qt_ = int(wr_clamp(ov, t.ub1, t.ub3) * H * 128.0f + (0.5f - 64.0f));
       if (r == 0) r0 = qs_;
@@ -1294,9 +1419,9 @@ __device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* 
   const int tw = int(B.wh & 0xFFFF), th = int(B.wh >> 16);
   const float W = float(tw), H = float(th);
   // interpolants at the span start (as wr_tex_row)
-  const float k = float(y - P.y0);
-  const float Lu = P.uvL0[0] + k * P.uvLs[0], Lv = P.uvL0[1] + k * P.uvLs[1];
-  const float Ru = P.uvR0[0] + k * P.uvRs[0], Rv = P.uvR0[1] + k * P.uvRs[1];
+  const int k = y - P.y0;
+  const float Lu = wr_accum(P.uvL0[0], P.uvLs[0], k), Lv = wr_accum(P.uvL0[1], P.uvLs[1], k);
+  const float Ru = wr_accum(P.uvR0[0], P.uvRs[0], k), Rv = wr_accum(P.uvR0[1], P.uvRs[1], k);
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
@@ -1764,8 +1889,7 @@ WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], u
   for (int j = 0; j < R; j++) {
     if (!cy[j]) continue;
     const int y = py + 4 * j;
-    const float k = float(y - T.y0);
-    const float ov = T.lv0 + k * T.lvs;      // Lv == Rv on this kind of prim, so sv == 0 exactly
+    const float ov = wr_accum(T.lv0, T.lvs, y - T.y0);      // Lv == Rv on this kind of prim, so sv == 0 exactly
     const int qy_span = int(wr_clamp(ov * H * qs + qo, T.miny, T.maxy));
     const int qy_tail = int(wr_clamp(ov, T.ub1, T.ub3) * H * 128.0f + (0.5f - 64.0f));
 #pragma unroll

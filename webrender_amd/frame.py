@@ -119,10 +119,21 @@ class Target:
 
 
 class CompositeTile:
-    def __init__(self, texture, rect, clip_rect=None, opaque=True, color=None):
+    """One CompositeInstance.  Plain picture-cache tiles (no colour, whole
+    texture) go through the FAST_PATH program; tiles / external surfaces with a
+    colour, a uv sub-rect (texels) or a flip through "composite TEXTURE_2D"
+    (composite.rs:1090-1160, renderer/mod.rs:3260-3334)."""
+
+    def __init__(self, texture, rect, clip_rect=None, opaque=True, color=None, uv_rect=None,
+                 flip=(0.0, 0.0)):
         self.texture, self.rect = texture, rect
         self.clip_rect = clip_rect or rect
         self.opaque, self.color = opaque, color
+        self.uv_rect, self.flip = uv_rect, flip
+
+    @property
+    def fast(self):
+        return self.color is None and self.uv_rect is None and self.flip == (0.0, 0.0)
 
 
 class Frame:

@@ -167,23 +167,29 @@ class Renderer:
         alpha = [t for t in frame.composite_tiles if not t.opaque]
 
         def draw_tile_list(tiles):
-            # one batch per texture change (mod.rs:3260-3334)
+            # one batch per texture / program change (mod.rs:3260-3334)
             batch, cur = [], None
             def flush():
                 if not batch:
                     return
-                key = "composite FAST_PATH,TEXTURE_2D"
+                key = "composite FAST_PATH,TEXTURE_2D" if cur[1] else "composite TEXTURE_2D"
                 prog = d.create_program(key, "COMPOSITE")
                 vao = d.create_vao("COMPOSITE")
                 d.bind_program(prog, projection)
-                d.bind_texture(0, self.resolve(cur).id)
+                d.bind_texture(0, self.resolve(cur[0]).id)
                 d.draw_instanced_batch(vao, np.stack(batch))
             for t in tiles:
-                if cur is not None and t.texture is not cur:
+                k = (t.texture, t.fast)
+                if cur is not None and (k[0] is not cur[0] or k[1] != cur[1]):
                     flush()
                     batch.clear()
-                cur = t.texture
-                batch.append(frame.composite_instance(t.rect, t.clip_rect))
+                cur = k
+                if t.fast:
+                    batch.append(frame.composite_instance(t.rect, t.clip_rect))
+                else:
+                    uv = t.uv_rect or (0.0, 0.0, float(t.texture.w), float(t.texture.h))
+                    batch.append(frame.composite_instance(t.rect, t.clip_rect, t.color or (1, 1, 1, 1), uv,
+                                                          uv_type=1, flip=t.flip))
             flush()
 
         if opaque:

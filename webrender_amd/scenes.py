@@ -275,6 +275,45 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
 
 
 # ---------------------------------------------------------------------------
+# Scaled / offset textured composites: exercises every linear-filter variant
+# swgl dispatches to (nearest-fast, fast, upscale, downscale, fallback and the
+# clamped lead-in / lead-out of blendTextureLinearDispatch, swgl_ext.h:378-440).
+def scaled_composites(width=1024, height=768, seed=21, src=192):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (0.2, 0.3, 0.4, 1.0))
+    texs = []
+    for i in range(3):
+        px = rng.integers(0, 256, size=(src, src, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:src, 0:src]
+        px[..., 3] = np.where(((xx // 16 + yy // 16) % 2) == 0, 255, rng.integers(64, 256, size=(src, src))).astype(np.uint8)
+        px[..., :3] = (px[..., :3].astype(np.uint16) * px[..., 3:4] // 255).astype(np.uint8)
+        texs.append(TextureRef(f"surface_{i}", src, src, G.GL_RGBA8, G.GL_LINEAR, pixels=px, upload_format=G.GL_BGRA))
+    frame.static_textures += texs
+    S = float(src)
+    cases = [
+        # (tex, x, y, w, h, uv_rect, color)
+        (0, 10.0, 10.0, S, S, None, None),                          # 1:1 aligned
+        (1, 220.3, 12.6, S, S, None, None),                         # 1:1, subpixel offset  -> FAST
+        (2, 430.0, 8.0, S * 1.5, S * 1.5, None, None),              # upscale
+        (0, 740.5, 20.25, S * 0.5, S * 0.5, None, None),            # exact 2x downscale
+        (1, 860.0, 30.0, S * 0.37, S * 0.61, None, None),           # arbitrary downscale -> FALLBACK
+        (2, 12.0, 320.0, 300.0, 180.0, (20.0, 30.0, 120.0, 90.0), None),      # sub-rect upscale x3
+        (0, 330.7, 330.2, 150.0, 150.0, (0.0, 0.0, 150.0, 150.0), (0.5, 0.25, 0.75, 1.0)),   # colour modulated
+        (1, 500.0, 340.0, S * 3.7, S * 1.0, None, None),            # strong x upscale, partly off-screen
+        (2, -50.5, 560.0, S, S, None, None),                        # hangs over the left edge
+        (0, 200.0, 560.5, S * 2.0, S * 0.5, (0.0, 0.0, S, S), None),
+        (1, 640.0, 560.0, S, S, (10.5, 10.5, 100.5, 100.5), None),  # fractional uv rect
+    ]
+    for (ti, x, y, w, h, uv, color) in cases:
+        rect = (x, y, x + w, y + h)
+        clip = (max(x, 0.0), max(y, 0.0), min(x + w, float(width)), min(y + h, float(height)))
+        uvr = uv or (0.0, 0.0, S, S)
+        frame.composite_tiles.append(CompositeTile(texs[ti], rect, clip, opaque=False, color=color, uv_rect=uvr))
+    frame.passes.append([])
+    return frame
+
+
+# ---------------------------------------------------------------------------
 # Clip-masked rectangles: brush_solid ALPHA_PASS instances whose clip task
 # address points at an R8 mask region (prim_shared.glsl:183-200 write_clip ->
 # swgl_clipMask).  The masks themselves are uploaded here; in a full frame they
