@@ -10,6 +10,7 @@
 #include "ps_clear.h"
 #include "ps_text_run.h"
 #include "cs_blur.h"
+#include "cs_scale.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -25,6 +26,7 @@ ProgramLoader load_shader(const char* name) {
              ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D)
   WRSH_ENTRY("cs_blur ALPHA_TARGET", cs_blur_ALPHA_TARGET)
   WRSH_ENTRY("cs_blur COLOR_TARGET", cs_blur_COLOR_TARGET)
+  WRSH_ENTRY("cs_scale TEXTURE_2D", cs_scale_TEXTURE_2D)
 #undef WRSH_ENTRY
   return nullptr;
 }

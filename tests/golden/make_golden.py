@@ -39,7 +39,9 @@ def main():
     out["masked_rects_frac"] = digest(render_direct(LIB, scenes.masked_rects(fractional=True))[0])
     for name, kw in (("blur_r8", dict(fmt="r8")), ("blur_rgba8", dict(fmt="rgba8")),
                      ("blur_r8_sigmas", dict(fmt="r8", content=(40, 30), sigma=[0.8, 1.7, 3.2, 4.0], n_tasks=12, origin=(0, 0))),
-                     ("blur_rgba8_tiny", dict(fmt="rgba8", content=(5, 3), sigma=1.2, n_tasks=9, origin=(1, 1), atlas=64))):
+                     ("blur_rgba8_tiny", dict(fmt="rgba8", content=(5, 3), sigma=1.2, n_tasks=9, origin=(1, 1), atlas=64)),
+                     ("blur_r8_scaled", dict(fmt="r8", scale_steps=2, content=(166, 140), sigma=2.5)),
+                     ("blur_rgba8_scaled", dict(fmt="rgba8", scale_steps=2, content=(150, 97), sigma=3.0))):
         out[name] = digest(render_direct(LIB, scenes.blur_chain(**kw))[0]["blur_h"])
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "digests.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1))

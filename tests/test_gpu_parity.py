@@ -64,6 +64,10 @@ BLUR_CASES = [
     ("blur_rgba8_big", dict(fmt="rgba8", content=(61, 47), sigma=4.0, n_tasks=6, origin=(3, 2), atlas=512)),
     ("blur_r8_edges", dict(fmt="r8", content=(126, 62), sigma=[3.0, 0.0], n_tasks=4, origin=(0, 0), atlas=258, pattern="noise")),
     ("blur_rgba8_tiny", dict(fmt="rgba8", content=(5, 3), sigma=1.2, n_tasks=9, origin=(1, 1), atlas=64)),
+    # cs_scale halvings in front of the blur (std deviation > 4 in the frame builder)
+    ("blur_r8_scaled", dict(fmt="r8", scale_steps=2, content=(166, 140), sigma=2.5)),
+    ("blur_rgba8_scaled", dict(fmt="rgba8", scale_steps=2, content=(150, 97), sigma=3.0)),
+    ("blur_rgba8_scaled4", dict(fmt="rgba8", scale_steps=1, content=(64, 64), sigma=1.0, n_tasks=4, origin=(0, 0))),
 ]
 
 

@@ -491,6 +491,38 @@ WR_DEVICE void wr_vs_cs_blur(const WrDrawDesc& d, const uint8_t* arena, int inst
   o.kind = support <= WR_BLUR_MAX_RADIUS ? WR_PK_BLUR : WR_PK_UNSUPPORTED;
 }
 
+// cs_scale.glsl:24-52 (vertex stage).  swgl_drawSpanRGBA8 = swgl_commitTextureLinearRGBA8
+// (:61-65); there is no R8 span function, and a format mismatch makes the
+// commit draw nothing (matchTextureFormat): both cases run main() per pixel.
+WR_DEVICE void wr_vs_cs_scale(const WrDrawDesc& d, const uint8_t* arena, int inst, int target_format, WrVsOut& o) {
+  const wf4 tr = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf4 sr = wr_load_attr<wf4>(d, arena, inst, 1);
+  const float type = wr_load_attr<float>(d, arena, inst, 2);
+  const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+  wf4 uvr = {wr_min(sr.x, sr.z), wr_min(sr.y, sr.w), wr_max(sr.x, sr.z), wr_max(sr.y, sr.w)};
+  const bool unnorm = int(type) == 1;
+  const float tsx = float(tex.width), tsy = float(tex.height);
+  if (unnorm) {
+    uvr = wf4{uvr.x + 0.5f, uvr.y + 0.5f, uvr.z - 0.5f, uvr.w - 0.5f};
+    uvr = wf4{uvr.x / tsx, uvr.y / tsy, uvr.z / tsx, uvr.w / tsy};
+  }
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    float u = sr.x + (sr.z - sr.x) * ax, v = sr.y + (sr.w - sr.y) * ay;
+    if (unnorm) { u /= tsx; v /= tsy; }
+    o.u[n] = u; o.v[n] = v;
+    const float x = (tr.z - tr.x) * ax + tr.x, y = (tr.w - tr.y) * ay + tr.y;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{x, y, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = uvr;
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.tail_clamp = 1; o.tail_modulate = 0;
+  o.kind = (target_format == WR_FMT_RGBA8 && tex.format == WR_FMT_RGBA8) ? WR_PK_TEX_RGBA8 : WR_PK_TEX_FS;
+}
+
 // composite.glsl:73-159
 WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int inst, bool fast, WrVsOut& o) {
   wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
@@ -646,7 +678,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1014,6 +1046,7 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   r.len = P.x1 - P.x0;
   r.span = r.len >= 4 ? (r.len & ~3) : 0;
   r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
+  if (P.kind == WR_PK_TEX_FS) r.span = 0;     // no draw_span for this program/target: all main()
   if (r.span == 0) return r;
   float W = float(t.width), H = float(t.height);
   float ou1 = r.ou + r.su, ov1 = r.ov + r.sv;
@@ -1059,13 +1092,16 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
 // Quantised (1/128 texel) sample position of a fragment-shader (tail) pixel:
 // its init_interp lane (glsl.h:3084-3089), then step_interp_inputs(drawn).
 WR_DEVICE void wr_tex_tail_uv(const WrPrim& P, const WrTexRow& r, int n, float& cu, float& cv) {
+  // init_interp lane (glsl.h:3084-3089), step_interp_inputs(drawn) once
+  // (DISPATCH_DRAW_SPAN), then one step_interp_inputs() per 4-pixel chunk run by main()
   float lu = r.ou, lv = r.ov;
-  int lane = (n - r.span) & 3;
+  const int lane = (n - r.span) & 3, m = (n - r.span) >> 2;
   for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
   if (r.span > 0) {
     float chunks = float(r.span) * 0.25f;
     lu = lu + (r.su * 4.0f) * chunks; lv = lv + (r.sv * 4.0f) * chunks;
   }
+  lu = wr_accum(lu, (r.su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (r.sv * 4.0f) * 1.0f, m);
   cu = lu; cv = lv;
   if (P.flags & WR_PF_TAIL_CLAMP) {
     cu = wr_clamp(lu, P.uv_bounds[0], P.uv_bounds[2]); cv = wr_clamp(lv, P.uv_bounds[1], P.uv_bounds[3]);
@@ -1124,6 +1160,12 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
     int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
     float m = float(wr_sample_linear_r8(t, qx, qy)) * (1.0f / 255.0f);
     tb = tg = tr = ta = m;
+  } else if (t.format == WR_FMT_R8) {
+    // texture() of an R8 sampler: vec4(r, 0, 0, 1)
+    float m;
+    if (t.linear) m = float(wr_sample_linear_r8(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
+    else m = float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride]) * (1.0f / 255.0f);
+    tr = m; tg = 0.0f; tb = 0.0f; ta = 1.0f;
   } else if (t.linear) {
     int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
     WrWide s = wr_sample_linear_rgba8(t, qx, qy);
@@ -1239,7 +1281,7 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
 // Vertex stage of one instance: locate its draw, run the shader's vertex
 // function, then swgl's draw_quad setup.
 WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws, const uint8_t* __restrict__ arena,
-                              int gid, WrPrim& P, WrAux* aux, WrUnsupportedCounters* cnt) {
+                              int gid, WrPrim& P, WrAux* aux, const WrTargetDesc* targets, WrUnsupportedCounters* cnt) {
   P.blend = 0; P.flags = 0; P.z = 0; P.color[0] = P.color[1] = 0; P.tex_slot = 0;
   // binary search for the draw containing this instance
   int lo = 0, hi = n_draws - 1;
@@ -1269,6 +1311,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_PS_TEXT_RUN: wr_vs_ps_text_run(d, arena, inst, o); break;
     case WR_SH_CS_BLUR_ALPHA: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     case WR_SH_CS_BLUR_COLOR: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
+    case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -1343,7 +1386,7 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
   const bool valid = gid < n_prims;
   WrPrim P;
   P.kind = WR_PK_NONE; P.draw = 0; P.x0 = P.y0 = P.x1 = P.y1 = 0;
-  if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, aux, cnt);
+  if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, aux, targets, cnt);
   if (valid) {
     prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
     if (P.kind == WR_PK_TEX_R8) aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
@@ -1782,8 +1825,11 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + (q & 3), py + 4 * (q >> 2), plo[q] | (phi[q] << 8));
         plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
       } else {
-        // R8 target: pack_pixels_R8(v_color.x) (blend.h:67-73)
-        plo[q] = wr_blend_r8(blend, plo[q], c1 & 0xFFFF);
+        // R8 target: pack_pixels_R8(gl_FragColor.x) (blend.h:67-73)
+        uint32_t srcr = c1 & 0xFFFF;
+        if (kind == WR_PK_TEX_FS || kind == WR_PK_TEX_RGBA8)
+          srcr = wr_tex_pixel(*Pp, D->tex[Pp->tex_slot], px + (q & 3), py + 4 * (q >> 2)).ra & 0xFFFF;
+        plo[q] = wr_blend_r8(blend, plo[q], srcr);
       }
     }
   }

@@ -44,6 +44,7 @@ enum WrShader {
   WR_SH_PS_TEXT_RUN,
   WR_SH_CS_BLUR_ALPHA,
   WR_SH_CS_BLUR_COLOR,
+  WR_SH_CS_SCALE,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -134,6 +135,7 @@ enum WrPrimKind {
   WR_PK_UNSUPPORTED,
   WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
   WR_PK_SOLID_MASKED,   // commit_masked_solid_span: flat colour x R8 clip mask sampled 1:1 (swgl_clipMask)
+  WR_PK_TEX_FS,         // textured quad with no usable span shader: every pixel runs the fragment shader's main()
   WR_PK_BLUR,           // swgl_commitGaussianBlur{R8,RGBA8}: one separable pass (WrBlurRec)
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
 };

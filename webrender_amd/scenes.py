@@ -392,14 +392,18 @@ def blur_instance(task_address, src_task_address, direction, std_dev, region):
     return inst
 
 
+SCALE_DTYPE = np.dtype([("t", "<f4", (4,)), ("s", "<f4", (4,)), ("k", "<f4")])   # ScalingInstance, gpu_types.rs:121-143
+
+
 def blur_chain(fmt="r8", content=(83, 83), sigma=2.5, atlas=256, n_tasks=1, seed=4, origin=(17, 9),
-               window=(256, 256), pattern="shapes"):
-    """`n_tasks` independent [vertical -> horizontal] cs_blur task pairs
-    (render_task.rs:1120-1215 new_blur): source content in `blur_src`
-    (standing in for the mask / picture the blur reads), vertical pass into
-    `blur_v`, horizontal pass into `blur_h`.  Rects packed on a grid in
-    `atlas`-sized targets like the render-task allocator would
-    (render_target.rs alloc).  Returns a Frame whose `readback` lists the
+               window=(256, 256), pattern="shapes", scale_steps=0):
+    """`n_tasks` independent [downscale x scale_steps -> vertical -> horizontal]
+    task chains (render_task.rs:1120-1215 new_blur): source content in
+    `blur_src` (standing in for the mask / picture the blur reads), `cs_scale`
+    halvings into `scale_k` (used when the std deviation exceeds
+    MAX_BLUR_STD_DEV = 4), vertical cs_blur into `blur_v`, horizontal into
+    `blur_h`.  Rects packed on a grid in `atlas`-sized targets like the
+    render-task allocator would.  Returns a Frame whose `readback` lists the
     target textures to compare."""
     rng = np.random.default_rng(seed)
     cw, ch = content
@@ -420,31 +424,50 @@ def blur_chain(fmt="r8", content=(83, 83), sigma=2.5, atlas=256, n_tasks=1, seed
     frame = Frame(window[0], window[1], (1.0, 1.0, 1.0, 1.0))
     t_src = TextureRef("blur_src", atlas, atlas, glfmt, G.GL_LINEAR, pixels=src,
                        upload_format=G.GL_BGRA if color else G.GL_RED)
-    t_v = TextureRef("blur_v", atlas, atlas, glfmt, G.GL_LINEAR, render_target=True)
-    t_h = TextureRef("blur_h", atlas, atlas, glfmt, G.GL_LINEAR, render_target=True)
     frame.static_textures.append(t_src)
-    key = "cs_blur COLOR_TARGET" if color else "cs_blur ALPHA_TARGET"
+    kind = "color" if color else "alpha"
     zero = (0.0, 0.0, 0.0, 0.0)
-    tgt_v = Target(t_v, "color" if color else "alpha", clear_color=zero)
-    tgt_h = Target(t_h, "color" if color else "alpha", clear_color=zero)
     per_row = max(1, (atlas - origin[0]) // (cw + 3))
-    vi, hi = [], []
+    rects = []
     for k in range(n_tasks):
         gx, gy = k % per_row, k // per_row
         x0, y0 = origin[0] + gx * (cw + 3), origin[1] + gy * (ch + 3)
         assert y0 + ch <= atlas
-        rect = (float(x0), float(y0), float(x0 + cw), float(y0 + ch))
+        rects.append((float(x0), float(y0), float(x0 + cw), float(y0 + ch)))
+    # downscale passes: each task's rect keeps its origin, its size halves (rounded up)
+    cur_tex, cur_rects, size = t_src, rects, (cw, ch)
+    frame.readback = []
+    for step in range(scale_steps):
+        size = ((size[0] + 1) // 2, (size[1] + 1) // 2)
+        t_s = TextureRef(f"scale_{step}", atlas, atlas, glfmt, G.GL_LINEAR, render_target=True)
+        tgt = Target(t_s, kind, clear_color=zero)
+        nxt, inst = [], np.zeros(n_tasks, SCALE_DTYPE)
+        for k, r in enumerate(cur_rects):
+            nr = (r[0], r[1], r[0] + size[0], r[1] + size[1])
+            nxt.append(nr)
+            inst["t"][k], inst["s"][k], inst["k"][k] = nr, r, 1.0
+        tgt.steps.append(Step("cs_scale TEXTURE_2D", "SCALE", inst, None, "none", textures={0: cur_tex}))
+        frame.passes.append([tgt])
+        frame.readback.append(t_s)
+        cur_tex, cur_rects = t_s, nxt
+    t_v = TextureRef("blur_v", atlas, atlas, glfmt, G.GL_LINEAR, render_target=True)
+    t_h = TextureRef("blur_h", atlas, atlas, glfmt, G.GL_LINEAR, render_target=True)
+    key = "cs_blur COLOR_TARGET" if color else "cs_blur ALPHA_TARGET"
+    tgt_v = Target(t_v, kind, clear_color=zero)
+    tgt_h = Target(t_h, kind, clear_color=zero)
+    vi, hi = [], []
+    for k, rect in enumerate(cur_rects):
         a_src = frame.add_render_task(rect)
         a_v = frame.add_render_task(rect)
         a_h = frame.add_render_task(rect)
         sg = sigma if np.isscalar(sigma) else sigma[k % len(sigma)]
-        vi.append(blur_instance(a_v, a_src, 1, sg, (cw, ch)))
-        hi.append(blur_instance(a_h, a_v, 0, sg, (cw, ch)))
-    tgt_v.steps.append(Step(key, "BLUR", np.concatenate(vi), None, "none", textures={0: t_src}))
+        vi.append(blur_instance(a_v, a_src, 1, sg, size))
+        hi.append(blur_instance(a_h, a_v, 0, sg, size))
+    tgt_v.steps.append(Step(key, "BLUR", np.concatenate(vi), None, "none", textures={0: cur_tex}))
     tgt_h.steps.append(Step(key, "BLUR", np.concatenate(hi), None, "none", textures={0: t_v}))
     frame.passes.append([tgt_v])
     frame.passes.append([tgt_h])
-    frame.readback = [t_v, t_h]
+    frame.readback += [t_v, t_h]
     return frame
 
 
