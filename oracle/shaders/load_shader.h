@@ -11,6 +11,7 @@
 #include "ps_text_run.h"
 #include "cs_blur.h"
 #include "cs_scale.h"
+#include "cs_clip_rectangle.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -27,6 +28,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_blur ALPHA_TARGET", cs_blur_ALPHA_TARGET)
   WRSH_ENTRY("cs_blur COLOR_TARGET", cs_blur_COLOR_TARGET)
   WRSH_ENTRY("cs_scale TEXTURE_2D", cs_scale_TEXTURE_2D)
+  WRSH_ENTRY("cs_clip_rectangle", cs_clip_rectangle)
+  WRSH_ENTRY("cs_clip_rectangle FAST_PATH", cs_clip_rectangle_FAST_PATH)
 #undef WRSH_ENTRY
   return nullptr;
 }

@@ -213,9 +213,9 @@ struct CommonState {
   }
 };
 
-// Generic attribute-location table (lib.rs:437-465), up to 12 named attribs.
+// Generic attribute-location table (lib.rs:437-465), up to 20 named attribs.
 struct AttribTable {
-  static constexpr int MAX = 12;
+  static constexpr int MAX = 20;
   const char* names[MAX] = {nullptr};
   int locs[MAX];
   int count = 0;

@@ -89,6 +89,24 @@ def test_hip_blur_matches_oracle(name, kw):
     assert ref or name in GOLDEN
 
 
+CLIP_CASES = [("clip_masks", dict()), ("clip_masks_dps", dict(dps=1.5, seed=32)), ("clip_masks_many", dict(n=60, seed=33))]
+
+
+@pytest.mark.parametrize("name,kw", CLIP_CASES, ids=[c[0] for c in CLIP_CASES])
+def test_hip_clip_rectangle_matches_oracle(name, kw):
+    """cs_clip_rectangle masks on the GPU: float coverage -> +-1 LSB allowed by
+    north_star, the committed digest pins the exact result."""
+    got, _ = render_direct(wrhip_lib(), scenes.clip_masks(**kw))
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, scenes.clip_masks(**kw))
+        d = np.abs(got["clip_masks"].astype(int) - want["clip_masks"].astype(int))
+        assert d.max() <= 1
+    if name in GOLDEN:
+        assert digest(got["clip_masks"]) == GOLDEN[name] or ref
+    assert ref or name in GOLDEN
+
+
 @pytest.mark.parametrize("name,make", SMALL, ids=[c[0] for c in SMALL])
 def test_hip_matches_oracle_small(name, make):
     got, stats = render_direct(wrhip_lib(), make())

@@ -77,6 +77,22 @@ def test_hostsim_blur_matches_oracle(hostsim, oracle_gcc, name, kw):
         assert digest(got["blur_h"]) == GOLDEN[name]
 
 
+CLIP_CASES = [("clip_masks", dict()), ("clip_masks_dps", dict(dps=1.5, seed=32)), ("clip_masks_many", dict(n=60, seed=33))]
+
+
+@pytest.mark.parametrize("name,kw", CLIP_CASES, ids=[c[0] for c in CLIP_CASES])
+def test_hostsim_clip_rectangle_matches_oracle(hostsim, oracle_gcc, name, kw):
+    """cs_clip_rectangle (uniform-radius fast path and general path, clip and
+    clip-out, second clip multiplied in) into an R8 alpha target."""
+    want, _ = render_direct(oracle_gcc, scenes.clip_masks(**kw))
+    got, _ = render_direct(hostsim, scenes.clip_masks(**kw))
+    assert np.array_equal(got["clip_masks"], want["clip_masks"])
+    v = want["clip_masks"]
+    assert (v == 0).any() and (v == 255).any() and ((v > 0) & (v < 255)).any()
+    if name in GOLDEN:
+        assert digest(got["clip_masks"]) == GOLDEN[name]
+
+
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
 def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     want, _ = render_direct(oracle_gcc, make())

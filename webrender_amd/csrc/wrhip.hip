@@ -114,7 +114,7 @@ struct Shader { GLenum type = 0; int kind = WR_SH_NONE; };
 // Static description of the programs the backend implements.
 struct ShaderInfo {
   const char* key; int kind;
-  const char* attribs[10];   // [0] = per-vertex aPosition, then instance attributes in shader order
+  const char* attribs[WR_MAX_ATTRIBS + 2];   // [0] = per-vertex aPosition, then instance attributes in shader order
   unsigned samplers;         // bit s set: program declares the sampler of slot s
 };
 #define S(x) (1u << (x))
@@ -133,8 +133,16 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
     {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
+#define CLIP_RECT_ATTRIBS                                                                                             \
+  {"aPosition", "aClipDeviceArea", "aClipOrigins", "aDevicePixelScale", "aTransformIds", "aClipLocalPos",           \
+   "aClipLocalRect", "aClipMode", "aClipRect_TL", "aClipRadii_TL", "aClipRect_TR", "aClipRadii_TR", "aClipRect_BL", \
+   "aClipRadii_BL", "aClipRect_BR", "aClipRadii_BR"}
+    {"cs_clip_rectangle", WR_SH_CS_CLIP_RECT, CLIP_RECT_ATTRIBS,
+     S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
+    {"cs_clip_rectangle FAST_PATH", WR_SH_CS_CLIP_RECT_FAST, CLIP_RECT_ATTRIBS,
+     S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
     {"cs_scale TEXTURE_2D", WR_SH_CS_SCALE, {"aPosition", "aScaleTargetRect", "aScaleSourceRect", "aSourceRectType"},
-     1u << WR_S_COLOR0},
+     S(WR_S_COLOR0)},
     {"cs_blur ALPHA_TARGET", WR_SH_CS_BLUR_ALPHA,
      {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
     {"cs_blur COLOR_TARGET", WR_SH_CS_BLUR_COLOR,
@@ -149,7 +157,7 @@ const int UNIFORM_TRANSFORM = WR_MAX_TEX + 1;   // sampler s -> uniform index s+
 struct Program {
   const ShaderInfo* info = nullptr;
   bool linked = false, deleted = false;
-  int attrib_loc[10];
+  int attrib_loc[WR_MAX_ATTRIBS + 2];
   int sampler_unit[WR_MAX_TEX];
   float transform[16];
   Program() {
@@ -634,7 +642,7 @@ void record_clear(GLuint tex_id, bool color, uint32_t color_value, bool depth, G
   d.clip[2] = std::min(rect[2], t.width); d.clip[3] = std::min(rect[3], t.height);
   d.clear_color = color_value;
   d.clear_depth = depth_value;
-  for (int k = 0; k < 8; k++) d.attr_off[k] = -1;
+  for (int k = 0; k < WR_MAX_ATTRIBS; k++) d.attr_off[k] = -1;
   TargetWork& w = ctx->work[wi];
   if (depth) w.depth_tex = depth_tex;
   w.draws.push_back(d);
@@ -1042,12 +1050,12 @@ GLint GetLinkStatus(GLuint program) { Program* p = ctx->programs.find(program); 
 void BindAttribLocation(GLuint program, GLuint index, const GLchar* name) {
   Program& p = ctx->programs[program];
   if (!p.info) return;
-  for (int k = 0; k < 10 && p.info->attribs[k]; k++) if (!strcmp(p.info->attribs[k], name)) { p.attrib_loc[k] = index; return; }
+  for (int k = 0; k < WR_MAX_ATTRIBS + 1 && p.info->attribs[k]; k++) if (!strcmp(p.info->attribs[k], name)) { p.attrib_loc[k] = index; return; }
 }
 GLint GetAttribLocation(GLuint program, const GLchar* name) {
   Program& p = ctx->programs[program];
   if (!p.info) return -1;
-  for (int k = 0; k < 10 && p.info->attribs[k]; k++)
+  for (int k = 0; k < WR_MAX_ATTRIBS + 1 && p.info->attribs[k]; k++)
     if (!strcmp(p.info->attribs[k], name)) return p.attrib_loc[k] != NULL_ATTRIB ? p.attrib_loc[k] : -1;
   return -1;
 }
@@ -1549,8 +1557,8 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   }
   // instance attributes: all must come from one interleaved instance buffer
   GLuint inst_buf = 0; int inst_stride = 0;
-  for (int k = 0; k < 8; k++) { d.attr_off[k] = -1; d.attr_bytes[k] = 0; }
-  for (int k = 1; k < 10 && info->attribs[k]; k++) {
+  for (int k = 0; k < WR_MAX_ATTRIBS; k++) { d.attr_off[k] = -1; d.attr_bytes[k] = 0; }
+  for (int k = 1; k < WR_MAX_ATTRIBS + 1 && info->attribs[k]; k++) {
     int loc = prog->attrib_loc[k];
     if (loc == NULL_ATTRIB) continue;
     VertexAttrib& va = v.attribs[loc];

@@ -523,6 +523,87 @@ WR_DEVICE void wr_vs_cs_scale(const WrDrawDesc& d, const uint8_t* arena, int ins
   o.kind = (target_format == WR_FMT_RGBA8 && tex.format == WR_FMT_RGBA8) ? WR_PK_TEX_RGBA8 : WR_PK_TEX_FS;
 }
 
+// clip_shared.glsl:43-78 write_clip_tile_vertex + transform.glsl:48-90
+// (get_node_pos / untransform / ray_plane), one corner of the quad.
+WR_DEVICE wf4 wr_get_node_pos(float px, float py, const WrTransform& t) {
+  const wf4 ah = t.m.c[3];   // m * (0,0,0,1)
+  const float ax = ah.x / ah.w, ay = ah.y / ah.w, az = ah.z / ah.w;
+  const float nx = t.inv_m.c[0].z, ny = t.inv_m.c[1].z, nz = t.inv_m.c[2].z;
+  const float pz = -10000.0f;
+  float tt = 0.0f;
+  const float denom = nx * 0.0f + ny * 0.0f + nz * 1.0f;
+  if (fabsf(denom) > 1e-6f) {
+    const float dx = ax - px, dy = ay - py, dz = az - pz;
+    tt = (dx * nx + dy * ny + dz * nz) / denom;
+  }
+  const float z = pz + 1.0f * tt;
+  return wr_mul(t.inv_m, wf4{px, py, z, 1.0f});
+}
+
+// cs_clip_rectangle.glsl:81-153 (vertex stage)
+WR_DEVICE void wr_vs_cs_clip_rect(const WrDrawDesc& d, const uint8_t* arena, int inst, bool fast, WrVsOut& o, WrClipRec& C) {
+  const wf4 area = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf4 origins = wr_load_attr<wf4>(d, arena, inst, 1);
+  const float dps = wr_load_attr<float>(d, arena, inst, 2);
+  const wi4 tids = wr_load_attr<wi4>(d, arena, inst, 3);
+  const wf2 lpos = wr_load_attr<wf2>(d, arena, inst, 4);
+  const wf4 lrect = wr_load_attr<wf4>(d, arena, inst, 5);
+  const float mode = wr_load_attr<float>(d, arena, inst, 6);
+  const wf4 rad_tl = wr_load_attr<wf4>(d, arena, inst, 8), rad_tr = wr_load_attr<wf4>(d, arena, inst, 10);
+  const wf4 rad_bl = wr_load_attr<wf4>(d, arena, inst, 12), rad_br = wr_load_attr<wf4>(d, arena, inst, 14);
+  const WrTransform clip_t = wr_fetch_transform(d, tids.x), prim_t = wr_fetch_transform(d, tids.y);
+  // local_rect.p0 = local_pos; local_rect.p1 += local_pos - p0
+  const float diffx = lpos.x - lrect.x, diffy = lpos.y - lrect.y;
+  const float r0x = lpos.x, r0y = lpos.y, r1x = lrect.z + diffx, r1y = lrect.w + diffy;
+  float lw[4];
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    const float sx = (area.z - area.x) * ax + area.x, sy = (area.w - area.y) * ay + area.y;
+    const float devx = origins.z + sx, devy = origins.w + sy;
+    const float wx = devx / dps, wy = devy / dps;
+    wf4 pos = wr_mul(prim_t.m, wf4{wx, wy, 0.0f, 1.0f});
+    pos.x /= pos.w; pos.y /= pos.w; pos.z /= pos.w;
+    const wf4 p = wr_get_node_pos(pos.x, pos.y, clip_t);
+    float lx = p.x * pos.w, ly = p.y * pos.w;
+    lw[n] = p.w * pos.w;
+    if (fast) {
+      const float hx = 0.5f * (r1x - r0x), hy = 0.5f * (r1y - r0y);
+      lx -= (hx + lpos.x) * lw[n]; ly -= (hy + lpos.y) * lw[n];
+    }
+    o.u[n] = lx; o.v[n] = ly;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{origins.x + sx, origins.y + sy, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  C.fast = fast ? 1 : 0; C.mode = mode; C.w = lw[0];
+  C.bounds[0] = r0x; C.bounds[1] = r0y; C.bounds[2] = r1x; C.bounds[3] = r1y;
+  if (fast) {
+    const float hx = 0.5f * (r1x - r0x), hy = 0.5f * (r1y - r0y), radius = rad_tl.x;
+    C.params[0] = hx - radius; C.params[1] = hy - radius; C.params[2] = radius;
+  } else {
+    C.params[0] = C.params[1] = C.params[2] = 0.0f;
+    const float rr[4][2] = {{rad_tl.x, rad_tl.y}, {rad_tr.x, rad_tr.y}, {rad_br.x, rad_br.y}, {rad_bl.x, rad_bl.y}};
+    const float cx[4] = {r0x + rr[0][0], r1x - rr[1][0], r1x - rr[2][0], r0x + rr[3][0]};
+    const float cy[4] = {r0y + rr[0][1], r0y + rr[1][1], r1y - rr[2][1], r1y - rr[3][1]};
+    for (int k = 0; k < 4; k++) {
+      C.center_radius[k][0] = cx[k]; C.center_radius[k][1] = cy[k];
+      C.center_radius[k][2] = 1.0f / wr_max(rr[k][0] * rr[k][0], 1.0e-6f);
+      C.center_radius[k][3] = 1.0f / wr_max(rr[k][1] * rr[k][1], 1.0e-6f);
+    }
+    // half-space normals and a point on each diagonal (:132-152)
+    const float nx[4] = {-rr[0][1], rr[1][1], rr[2][1], -rr[3][1]};
+    const float ny[4] = {-rr[0][0], -rr[1][0], rr[2][0], rr[3][0]};
+    const float qx[4] = {r0x, r1x - rr[1][0], r1x, r0x + rr[3][0]};
+    const float qy[4] = {r0y + rr[0][1], r0y, r1y - rr[2][1], r1y};
+    for (int k = 0; k < 4; k++) { C.plane[k][0] = nx[k]; C.plane[k][1] = ny[k]; C.plane[k][2] = nx[k] * qx[k] + ny[k] * qy[k]; }
+  }
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{0, 0, 0, 0};
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_COLOR0;
+  // perspective-varying w is not handled by the span rasteriser either (:226-228 falls back to main()): "next"
+  o.kind = (lw[1] == lw[0] && lw[2] == lw[0] && lw[3] == lw[0]) ? WR_PK_CLIP_RECT : WR_PK_UNSUPPORTED;
+}
+
 // composite.glsl:73-159
 WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int inst, bool fast, WrVsOut& o) {
   wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
@@ -678,7 +759,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1311,6 +1392,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_PS_TEXT_RUN: wr_vs_ps_text_run(d, arena, inst, o); break;
     case WR_SH_CS_BLUR_ALPHA: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     case WR_SH_CS_BLUR_COLOR: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
+    case WR_SH_CS_CLIP_RECT: wr_vs_cs_clip_rect(d, arena, inst, false, o, aux[gid].clip); break;
+    case WR_SH_CS_CLIP_RECT_FAST: wr_vs_cs_clip_rect(d, arena, inst, true, o, aux[gid].clip); break;
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
@@ -1611,6 +1694,168 @@ __device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* 
   return out;
 }
 
+// ---------------------------------------------------------------------------
+// cs_clip_rectangle, one destination pixel of an R8 mask (returns the u16 value
+// handed to the blend stage).  Span part: the rounded-rectangle span rasteriser
+// of cs_clip_rectangle.glsl:223-495, replayed per pixel -- the run lengths are
+// closed-form in chunk units, the local position of an AA chunk follows the
+// same jump-then-accumulate sequence as the reference.  Tail (< 4 pixels) and
+// spans shorter than 4: the fragment shader (:170-199).
+WR_DEVICE float wr_clip_dist(const WrClipRec& C, float px, float py) {
+  if (C.fast) {   // sd_rounded_box
+    const float dx = fabsf(px) - C.params[0], dy = fabsf(py) - C.params[1];
+    const float mx = wr_max(dx, 0.0f), my = wr_max(dy, 0.0f);
+    return (sqrtf(mx * mx + my * my) + wr_min(wr_max(dx, dy), 0.0f)) - C.params[2];
+  }
+  // distance_to_rounded_rect, ellipse.glsl:50-92
+  float cx = 1.0e-6f, cy = 1.0e-6f, cz = 1.0f, cw = 1.0f;
+  if (px * C.plane[0][0] + py * C.plane[0][1] > C.plane[0][2]) { cx = C.center_radius[0][0] - px; cy = C.center_radius[0][1] - py; cz = C.center_radius[0][2]; cw = C.center_radius[0][3]; }
+  if (px * C.plane[1][0] + py * C.plane[1][1] > C.plane[1][2]) { cx = (C.center_radius[1][0] - px) * -1.0f; cy = (C.center_radius[1][1] - py) * 1.0f; cz = C.center_radius[1][2]; cw = C.center_radius[1][3]; }
+  if (px * C.plane[2][0] + py * C.plane[2][1] > C.plane[2][2]) { cx = px - C.center_radius[2][0]; cy = py - C.center_radius[2][1]; cz = C.center_radius[2][2]; cw = C.center_radius[2][3]; }
+  if (px * C.plane[3][0] + py * C.plane[3][1] > C.plane[3][2]) { cx = (C.center_radius[3][0] - px) * 1.0f; cy = (C.center_radius[3][1] - py) * -1.0f; cz = C.center_radius[3][2]; cw = C.center_radius[3][3]; }
+  const float prx = cx * cz, pry = cy * cw;
+  const float g = (cx * prx + cy * pry) - 1.0f;
+  const float dgx = (1.0f + 1.0f) * prx, dgy = (1.0f + 1.0f) * pry;
+  const float e = g * (1.0f / sqrtf(dgx * dgx + dgy * dgy));
+  const float r = wr_max(wr_max(C.bounds[0] - px, px - C.bounds[2]), wr_max(C.bounds[1] - py, py - C.bounds[3]));
+  return wr_max(e, r);
+}
+WR_DEVICE float wr_step01(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
+
+__device__ __noinline__ uint32_t wr_clip_rect_pixel(const WrPrim* Pp, const WrClipRec* Cp, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrClipRec& C = *Cp;
+  const int k = y - P.y0;
+  const float Lu = wr_accum(P.uvL0[0], P.uvLs[0], k), Lv = wr_accum(P.uvL0[1], P.uvLs[1], k);
+  const float Ru = wr_accum(P.uvR0[0], P.uvRs[0], k), Rv = wr_accum(P.uvR0[1], P.uvRs[1], k);
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  const float ou = Lu + su * start, ov = Lv + sv * start;
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  const int n = x - P.x0;
+  const float mode = C.mode;
+  // the four SIMD lanes of vLocalPos.xy at the span start (init_interp)
+  float lx[4], ly[4];
+  lx[0] = ou; ly[0] = ov;
+  for (int i = 1; i < 4; i++) { lx[i] = lx[i - 1] + su; ly[i] = ly[i - 1] + sv; }
+  if (n < span) {
+    float w = C.w;
+    if (w <= 0.0f) return 0u;                       // swgl_commitSolidR8(0.0)
+    w = 1.0f / w;
+    float px4[4], py4[4];
+    for (int i = 0; i < 4; i++) { px4[i] = lx[i] * w; py4[i] = ly[i] * w; }
+    const float p0x = px4[0], p0y = py4[0];
+    const float stx = (su * 4.0f) * w, sty = (sv * 4.0f) * w;
+    const float step_scale = wr_max(stx * stx + sty * sty, 1.0e-6f);
+    const float aa_range = 1.0f / (fabsf(px4[1] - px4[0]) + fabsf(py4[1] - py4[0]));
+    float aa_margin = 1.0f / sqrtf(aa_range * aa_range * step_scale);
+    float cr[4];
+    if (C.fast) { cr[0] = -C.params[0] - C.params[2]; cr[1] = -C.params[1] - C.params[2]; cr[2] = C.params[0] + C.params[2]; cr[3] = C.params[1] + C.params[2]; }
+    else { cr[0] = C.bounds[0]; cr[1] = C.bounds[1]; cr[2] = C.bounds[2]; cr[3] = C.bounds[3]; }
+    const bool negx = stx < 0.0f, negy = sty < 0.0f;
+    float cd[4] = {(negx ? cr[2] : cr[0]) - p0x, (negy ? cr[3] : cr[1]) - p0y, (negx ? cr[0] : cr[2]) - p0x, (negy ? cr[1] : cr[3]) - p0y};
+    const float rsx = 1.0f / stx, rsy = 1.0f / sty;
+    cd[0] = stx != 0.0f ? cd[0] * rsx : 1.0e6f * wr_step01(0.0f, cd[0]);
+    cd[1] = sty != 0.0f ? cd[1] * rsy : 1.0e6f * wr_step01(0.0f, cd[1]);
+    cd[2] = stx != 0.0f ? cd[2] * rsx : 1.0e6f * wr_step01(0.0f, cd[2]);
+    cd[3] = sty != 0.0f ? cd[3] * rsy : 1.0e6f * wr_step01(0.0f, cd[3]);
+    float opaque_start = wr_max(cd[0], cd[1]), opaque_end = wr_min(cd[2], cd[3]);
+    float aa_start = opaque_start, aa_end = opaque_end;
+    int start_corner = -1, end_corner = -1;          // which plane/corner was hit (general path)
+    float pl[4][3];
+    if (C.fast) {
+      const float offset = (C.params[0] + C.params[1] + C.params[2]) * C.params[2];
+      const float z = C.params[2];
+      pl[0][0] = -z; pl[0][1] = -z; pl[1][0] = z; pl[1][1] = -z; pl[2][0] = z; pl[2][1] = z; pl[3][0] = -z; pl[3][1] = z;
+      for (int c = 0; c < 4; c++) pl[c][2] = offset;
+    } else {
+      for (int c = 0; c < 4; c++) { pl[c][0] = C.plane[c][0]; pl[c][1] = C.plane[c][1]; pl[c][2] = C.plane[c][2]; }
+    }
+    for (int c = 0; c < 4; c++) {                    // CLIP_CORNER in TL, TR, BR, BL order
+      const float dist = (p0x * pl[c][0] + p0y * pl[c][1]) - pl[c][2];
+      const float scale = -(stx * pl[c][0] + sty * pl[c][1]);
+      if (scale >= 0.0f) {
+        if (dist > opaque_start * scale) {
+          start_corner = c;
+          const float inv_scale = 1.0f / wr_max(scale, 1.0e-6f);
+          opaque_start = dist * inv_scale;
+          const float apex = (0.7071f - 0.5f) * 2.0f * fabsf(pl[c][0] * pl[c][1]);
+          aa_start = opaque_start - apex * inv_scale;
+        }
+      } else if (dist > opaque_end * scale) {
+        end_corner = c;
+        const float inv_scale = 1.0f / wr_min(scale, -1.0e-6f);
+        opaque_end = dist * inv_scale;
+        const float apex = (0.7071f - 0.5f) * 2.0f * fabsf(pl[c][0] * pl[c][1]);
+        aa_end = opaque_end - apex * inv_scale;
+      }
+    }
+    aa_margin = wr_max(aa_margin - wr_max(aa_start - aa_end, 0.0f), 0.0f);
+    aa_start -= aa_margin; aa_end += aa_margin;
+    const float sl = float(span), ss = 4.0f;
+    const int A = int(wr_clamp(sl - ss * floorf(aa_start), 0.0f, sl)) >> 2, B = int(wr_clamp(sl - ss * ceilf(opaque_start), 0.0f, sl)) >> 2;
+    const int Cc = int(wr_clamp(sl - ss * floorf(opaque_end), 0.0f, sl)) >> 2, D = int(wr_clamp(sl - ss * ceilf(aa_end), 0.0f, sl)) >> 2;
+    // remaining-length bookkeeping of the five phases, in chunks
+    const int S = span >> 2;
+    const int R1 = S > A ? A : S, n1 = S - R1;
+    const int n2 = R1 > B ? R1 - B : 0, R2 = R1 - n2;
+    const int n3 = R2 > Cc ? R2 - Cc : 0, R3 = R2 - n3;
+    const int n4 = R3 > D ? R3 - D : 0;
+    const int c = n >> 2, lane = n & 3;
+    if (c < n1) return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
+    // start of the first AA run
+    float qx = px4[lane], qy = py4[lane];
+    if (n1 > 0) { qx = qx + float(n1) * stx; qy = qy + float(n1) * sty; }
+    int corner = -1;
+    if (c < n1 + n2) {
+      qx = wr_accum(qx, stx, c - n1); qy = wr_accum(qy, sty, c - n1);
+      corner = start_corner;
+    } else if (c < n1 + n2 + n3) {
+      return uint32_t(wr_round_pixel(1.0f - mode)) & 0xFFFF;
+    } else if (c < n1 + n2 + n3 + n4) {
+      qx = wr_accum(qx, stx, n2); qy = wr_accum(qy, sty, n2);
+      if (n3 > 0) { qx = qx + float(n3) * stx; qy = qy + float(n3) * sty; }
+      qx = wr_accum(qx, stx, c - n1 - n2 - n3); qy = wr_accum(qy, sty, c - n1 - n2 - n3);
+      corner = end_corner;
+    } else {
+      return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
+    }
+    float dist;
+    if (C.fast) {
+      dist = wr_clip_dist(C, qx, qy);
+    } else {
+      const float rect = wr_max(wr_max(C.bounds[0] - qx, qx - C.bounds[2]), wr_max(C.bounds[1] - qy, qy - C.bounds[3]));
+      dist = rect;
+      if (corner >= 0 && qx * C.plane[corner][0] + qy * C.plane[corner][1] > C.plane[corner][2]) {
+        const float ex = qx - C.center_radius[corner][0], ey = qy - C.center_radius[corner][1];
+        const float prx = ex * C.center_radius[corner][2], pry = ey * C.center_radius[corner][3];
+        const float g = (ex * prx + ey * pry) - 1.0f;
+        const float dgx = (1.0f + 1.0f) * prx, dgy = (1.0f + 1.0f) * pry;
+        dist = g * (1.0f / sqrtf(dgx * dgx + dgy * dgy));
+      }
+    }
+    const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
+    return uint32_t(wr_round_pixel(((1.0f - alpha) - alpha) * mode + alpha)) & 0xFFFF;
+  }
+  // ---- fragment shader (tail chunk): lanes stepped by `span` at once
+  float tx[4], ty[4];
+  for (int i = 0; i < 4; i++) {
+    tx[i] = lx[i]; ty[i] = ly[i];
+    if (span > 0) { const float chunks = float(span) * 0.25f; tx[i] = tx[i] + (su * 4.0f) * chunks; ty[i] = ty[i] + (sv * 4.0f) * chunks; }
+  }
+  const int lane = (n - span) & 3, m = (n - span) >> 2;
+  float fx[2], fy[2], qx = 0.0f, qy = 0.0f;
+  for (int i = 0; i < 2; i++) { fx[i] = wr_accum(tx[i], (su * 4.0f) * 1.0f, m) / C.w; fy[i] = wr_accum(ty[i], (sv * 4.0f) * 1.0f, m) / C.w; }
+  qx = wr_accum(tx[lane], (su * 4.0f) * 1.0f, m) / C.w; qy = wr_accum(ty[lane], (sv * 4.0f) * 1.0f, m) / C.w;
+  const float aa_range = 1.0f / (fabsf(fx[1] - fx[0]) + fabsf(fy[1] - fy[0]));
+  const float dist = wr_clip_dist(C, qx, qy);
+  const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
+  const float fin = ((1.0f - alpha) - alpha) * mode + alpha;
+  return uint32_t(wr_round_pixel(C.w > 0.0f ? fin : 0.0f)) & 0xFFFF;
+}
+
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
 WR_DEVICE uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
 #ifdef WRHIP_HOSTSIM
@@ -1791,6 +2036,14 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
           plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
         }
       }
+    }
+    return;
+  }
+  if (FMT == WR_FMT_R8 && kind == WR_PK_CLIP_RECT) {
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      if (!(cx[q & 3] && cy[q >> 2])) continue;
+      plo[q] = wr_blend_r8(blend, plo[q], wr_clip_rect_pixel(Pp, &Ap->clip, px + (q & 3), py + 4 * (q >> 2)));
     }
     return;
   }

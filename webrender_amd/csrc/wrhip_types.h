@@ -16,7 +16,8 @@
 
 #define WR_BIN_W 64
 #define WR_BIN_H 64
-#define WR_MAX_TEX 12  // sampler slots, renderer/mod.rs:371-385
+#define WR_MAX_TEX 12
+#define WR_MAX_ATTRIBS 16  // instance attributes of one program (CLIP_RECT has 15: vertex.rs:359-445)  // sampler slots, renderer/mod.rs:371-385
 
 // Texture slots (TextureSampler order, renderer/mod.rs:371-385)
 enum WrSlot {
@@ -45,6 +46,8 @@ enum WrShader {
   WR_SH_CS_BLUR_ALPHA,
   WR_SH_CS_BLUR_COLOR,
   WR_SH_CS_SCALE,
+  WR_SH_CS_CLIP_RECT,
+  WR_SH_CS_CLIP_RECT_FAST,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -103,8 +106,8 @@ struct WrDrawDesc {
   uint32_t blend_color[2];  // ctx->blendcolor as 4 x u16 (b,g,r,a)
   uint64_t inst_offset;  // byte offset of this draw's instance data in the arena
   int32_t inst_stride;
-  int32_t attr_off[8];   // byte offset of the shader's k-th instance attribute, -1 = unbound (zeros)
-  int32_t attr_bytes[8]; // bytes provided by the VAO for that attribute (VertexAttrib::size)
+  int32_t attr_off[WR_MAX_ATTRIBS];   // byte offset of the shader's k-th instance attribute, -1 = unbound (zeros)
+  int32_t attr_bytes[WR_MAX_ATTRIBS]; // bytes provided by the VAO for that attribute (VertexAttrib::size)
   WrTexDesc tex[WR_MAX_TEX];
 };
 
@@ -136,6 +139,7 @@ enum WrPrimKind {
   WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
   WR_PK_SOLID_MASKED,   // commit_masked_solid_span: flat colour x R8 clip mask sampled 1:1 (swgl_clipMask)
   WR_PK_TEX_FS,         // textured quad with no usable span shader: every pixel runs the fragment shader's main()
+  WR_PK_CLIP_RECT,      // cs_clip_rectangle's rounded-rect span rasteriser (WrClipRec)
   WR_PK_BLUR,           // swgl_commitGaussianBlur{R8,RGBA8}: one separable pass (WrBlurRec)
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
 };
@@ -219,10 +223,22 @@ struct WrBlurRec {
   uint16_t weights[WR_BLUR_MAX_RADIUS + 2];   // uint16_t(coeff_o + 0.5), 8.8 fixed point, o = 0..radius
 };
 
+// cs_clip_rectangle flat varyings (cs_clip_rectangle.glsl:7-21)
+struct WrClipRec {
+  int32_t fast;             // FAST_PATH program
+  float mode;               // vClipMode.x
+  float w;                  // vLocalPos.w (constant: affine transforms only)
+  float params[3];          // vClipParams (fast path)
+  float center_radius[4][4];  // vClipCenter_Radius_{TL,TR,BR,BL}
+  float plane[4][3];        // vClipPlane_{TL,TR,BR,BL}
+  float bounds[4];          // vTransformBounds
+};
+
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
   WrTexRec tex;
   WrBlurRec blur;
+  WrClipRec clip;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

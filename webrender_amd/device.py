@@ -57,6 +57,13 @@ DESC = {
     "SCALE": VertexDescriptor(_POS, [
         ("aScaleTargetRect", 4, F32), ("aScaleSourceRect", 4, F32),
         ("aSourceRectType", 1, F32)]),
+    # vertex.rs:359-445
+    "CLIP_RECT": VertexDescriptor(_POS, [
+        ("aClipDeviceArea", 4, F32), ("aClipOrigins", 4, F32), ("aDevicePixelScale", 1, F32),
+        ("aTransformIds", 2, I32), ("aClipLocalPos", 2, F32), ("aClipLocalRect", 4, F32),
+        ("aClipMode", 1, F32), ("aClipRect_TL", 4, F32), ("aClipRadii_TL", 4, F32),
+        ("aClipRect_TR", 4, F32), ("aClipRadii_TR", 4, F32), ("aClipRect_BL", 4, F32),
+        ("aClipRadii_BL", 4, F32), ("aClipRect_BR", 4, F32), ("aClipRadii_BR", 4, F32)]),
     # vertex.rs:732-780
     "COMPOSITE": VertexDescriptor(_POS, [
         ("aDeviceRect", 4, F32), ("aDeviceClipRect", 4, F32), ("aColor", 4, F32),

@@ -381,6 +381,88 @@ def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional
 
 
 # ---------------------------------------------------------------------------
+# Rounded-rectangle clip masks (cs_clip_rectangle, fast and general path).
+CLIP_RECT_DTYPE = np.dtype([
+    ("area", "<f4", (4,)), ("origins", "<f4", (4,)), ("dps", "<f4"), ("tids", "<i4", (2,)),
+    ("lpos", "<f4", (2,)), ("lrect", "<f4", (4,)), ("mode", "<f4"),
+    ("corners", "<f4", (8, 4))])      # [rect, radii] x TL, TR, BL, BR  (ClipMaskInstanceRect, gpu_types.rs:207-228)
+
+
+def clip_rect_instance(task_rect, screen_origin, dps, local_pos, size, radii, mode, sub_rect=None):
+    """ClipData::rounded_rect (prim_store/mod.rs:816-878): rect at the origin of
+    the clip's local space, corner rects + (outer radius, inner radius 0).
+    radii = ((tlw,tlh),(trw,trh),(blw,blh),(brw,brh))."""
+    w, h = size
+    inst = np.zeros(1, CLIP_RECT_DTYPE)
+    tw, th = task_rect[2] - task_rect[0], task_rect[3] - task_rect[1]
+    inst["area"][0] = sub_rect or (0.0, 0.0, tw, th)
+    inst["origins"][0] = (task_rect[0], task_rect[1], screen_origin[0], screen_origin[1])
+    inst["dps"][0] = dps
+    inst["tids"][0] = (0, 0)
+    inst["lpos"][0] = local_pos
+    inst["lrect"][0] = (0.0, 0.0, w, h)
+    inst["mode"][0] = float(mode)
+    (tl, tr, bl, br) = radii
+    c = inst["corners"][0]
+    c[0] = (0.0, 0.0, tl[0], tl[1]); c[1] = (tl[0], tl[1], 0.0, 0.0)
+    c[2] = (w - tr[0], 0.0, w, tr[1]); c[3] = (tr[0], tr[1], 0.0, 0.0)
+    c[4] = (0.0, h - bl[1], bl[0], h); c[5] = (bl[0], bl[1], 0.0, 0.0)
+    c[6] = (w - br[0], h - br[1], w, h); c[7] = (br[0], br[1], 0.0, 0.0)
+    return inst
+
+
+def clip_masks(n=24, atlas=1024, seed=31, dps=1.0, window=(256, 256)):
+    """`n` rounded-rect mask tasks in one R8 alpha target: even tasks have a
+    uniform radius (FAST_PATH program), odd ones four different elliptical
+    corners (general program); a third of them clip-out; some are followed by a
+    second clip multiplied on top (draw_clip_batch_list, renderer/mod.rs:3564-3640)."""
+    rng = np.random.default_rng(seed)
+    frame = Frame(window[0], window[1], (1.0, 1.0, 1.0, 1.0))
+    t_mask = TextureRef("clip_masks", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
+    tgt = Target(t_mask, "alpha", clear_color=(1.0, 1.0, 1.0, 1.0))
+    fast0, slow0, fast1, slow1 = [], [], [], []
+    x = y = 4
+    shelf = 0
+    for k in range(n):
+        w, h = float(rng.integers(30, 220)), float(rng.integers(30, 160))
+        if k % 5 == 0:
+            w += 0.5
+        lpos = (float(rng.uniform(0, 500)), float(rng.uniform(0, 500)))
+        tw = int(np.ceil(w * dps)) + int(rng.integers(-12, 13))
+        th = int(np.ceil(h * dps)) + int(rng.integers(-12, 13))
+        if x + tw + 4 > atlas:
+            x, y, shelf = 4, y + shelf + 4, 0
+        task = (float(x), float(y), float(x + tw), float(y + th))
+        x += tw + 4
+        shelf = max(shelf, th)
+        so = (float(np.floor(lpos[0] * dps)) + float(rng.integers(-8, 9)),
+              float(np.floor(lpos[1] * dps)) + float(rng.integers(-8, 9)))
+        mode = 1 if k % 3 == 2 else 0
+        if k % 2 == 0:
+            r = float(rng.integers(0, int(min(w, h) / 2)))
+            radii = ((r, r),) * 4
+            (fast0 if True else fast1).append(clip_rect_instance(task, so, dps, lpos, (w, h), radii, mode))
+        else:
+            mx, my = w / 2, h / 2
+            radii = tuple((float(rng.uniform(0, mx)), float(rng.uniform(0, my))) for _ in range(4))
+            if k % 7 == 1:
+                radii = ((0.0, 0.0),) + radii[1:]
+            slow0.append(clip_rect_instance(task, so, dps, lpos, (w, h), radii, mode))
+        if k % 4 == 1:       # a second, smaller clip on the same task, multiplied in
+            r2 = float(rng.integers(2, 20))
+            inst2 = clip_rect_instance(task, so, dps, (lpos[0] + 7.25, lpos[1] + 5.5), (w * 0.8, h * 0.7),
+                                       ((r2, r2),) * 4, 0)
+            fast1.append(inst2)
+    tgt.steps.append(Step("cs_clip_rectangle FAST_PATH", "CLIP_RECT", np.concatenate(fast0), None, "none"))
+    tgt.steps.append(Step("cs_clip_rectangle", "CLIP_RECT", np.concatenate(slow0), None, "none"))
+    if fast1:
+        tgt.steps.append(Step("cs_clip_rectangle FAST_PATH", "CLIP_RECT", np.concatenate(fast1), "Multiply", "none"))
+    frame.passes.append([tgt])
+    frame.readback = [t_mask]
+    return frame
+
+
+# ---------------------------------------------------------------------------
 # Separable Gaussian blur chain (the off-screen half of BASELINE config 4).
 BLUR_DTYPE = np.dtype([("a", "<i4", (3,)), ("p", "<f4", (3,))])   # BlurInstance, gpu_types.rs:109-118
 
