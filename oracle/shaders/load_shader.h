@@ -12,6 +12,7 @@
 #include "cs_blur.h"
 #include "cs_scale.h"
 #include "cs_clip_rectangle.h"
+#include "cs_clip_box_shadow.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -30,6 +31,7 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_scale TEXTURE_2D", cs_scale_TEXTURE_2D)
   WRSH_ENTRY("cs_clip_rectangle", cs_clip_rectangle)
   WRSH_ENTRY("cs_clip_rectangle FAST_PATH", cs_clip_rectangle_FAST_PATH)
+  WRSH_ENTRY("cs_clip_box_shadow TEXTURE_2D", cs_clip_box_shadow)
 #undef WRSH_ENTRY
   return nullptr;
 }

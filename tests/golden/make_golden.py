@@ -36,6 +36,8 @@ def main():
     out["cfg3_4k"] = digest(render_direct(LIB, scenes.cfg3_text())[0])
     out["clip_masks"] = digest(render_direct(LIB, scenes.clip_masks())[0]["clip_masks"])
     out["clip_masks_dps"] = digest(render_direct(LIB, scenes.clip_masks(dps=1.5, seed=32))[0]["clip_masks"])
+    out["box_shadow_masks"] = digest(render_direct(LIB, scenes.box_shadow_masks())[0]["box_shadow_masks"])
+    out["box_shadow_masks_dps"] = digest(render_direct(LIB, scenes.box_shadow_masks(dps=1.5, seed=42))[0]["box_shadow_masks"])
     out["scaled_composites"] = digest(render_direct(LIB, scenes.scaled_composites())[0])
     out["masked_rects"] = digest(render_direct(LIB, scenes.masked_rects())[0])
     out["masked_rects_frac"] = digest(render_direct(LIB, scenes.masked_rects(fractional=True))[0])

@@ -107,6 +107,22 @@ def test_hip_clip_rectangle_matches_oracle(name, kw):
     assert ref or name in GOLDEN
 
 
+BOX_CASES = [("box_shadow_masks", dict()), ("box_shadow_masks_dps", dict(dps=1.5, seed=42)), ("box_shadow_masks_many", dict(n=40, seed=43))]
+
+
+@pytest.mark.parametrize("name,kw", BOX_CASES, ids=[c[0] for c in BOX_CASES])
+def test_hip_box_shadow_matches_oracle(name, kw):
+    got, _ = render_direct(wrhip_lib(), scenes.box_shadow_masks(**kw))
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, scenes.box_shadow_masks(**kw))
+        d = np.abs(got["box_shadow_masks"].astype(int) - want["box_shadow_masks"].astype(int))
+        assert d.max() <= 1
+    if name in GOLDEN:
+        assert digest(got["box_shadow_masks"]) == GOLDEN[name] or ref
+    assert ref or name in GOLDEN
+
+
 @pytest.mark.parametrize("name,make", SMALL, ids=[c[0] for c in SMALL])
 def test_hip_matches_oracle_small(name, make):
     got, stats = render_direct(wrhip_lib(), make())

@@ -93,6 +93,22 @@ def test_hostsim_clip_rectangle_matches_oracle(hostsim, oracle_gcc, name, kw):
         assert digest(got["clip_masks"]) == GOLDEN[name]
 
 
+BOX_CASES = [("box_shadow_masks", dict()), ("box_shadow_masks_dps", dict(dps=1.5, seed=42)), ("box_shadow_masks_many", dict(n=40, seed=43))]
+
+
+@pytest.mark.parametrize("name,kw", BOX_CASES, ids=[c[0] for c in BOX_CASES])
+def test_hostsim_box_shadow_matches_oracle(hostsim, oracle_gcc, name, kw):
+    """cs_clip_box_shadow: nine-patch stretch of a cached blurred shadow into
+    R8 mask tasks (stretch / simple modes per axis, clip and clip-out)."""
+    want, _ = render_direct(oracle_gcc, scenes.box_shadow_masks(**kw))
+    got, _ = render_direct(hostsim, scenes.box_shadow_masks(**kw))
+    assert np.array_equal(got["box_shadow_masks"], want["box_shadow_masks"])
+    v = want["box_shadow_masks"]
+    assert (v == 0).any() and (v == 255).any() and ((v > 0) & (v < 255)).any()
+    if name in GOLDEN:
+        assert digest(got["box_shadow_masks"]) == GOLDEN[name]
+
+
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
 def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     want, _ = render_direct(oracle_gcc, make())

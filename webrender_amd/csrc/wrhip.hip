@@ -141,6 +141,10 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
     {"cs_clip_rectangle FAST_PATH", WR_SH_CS_CLIP_RECT_FAST, CLIP_RECT_ATTRIBS,
      S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
+    {"cs_clip_box_shadow TEXTURE_2D", WR_SH_CS_CLIP_BOX_SHADOW,
+     {"aPosition", "aClipDeviceArea", "aClipOrigins", "aDevicePixelScale", "aTransformIds", "aClipDataResourceAddress",
+      "aClipSrcRectSize", "aClipMode", "aStretchMode", "aClipDestRect"},
+     S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
     {"cs_scale TEXTURE_2D", WR_SH_CS_SCALE, {"aPosition", "aScaleTargetRect", "aScaleSourceRect", "aSourceRectType"},
      S(WR_S_COLOR0)},
     {"cs_blur ALPHA_TARGET", WR_SH_CS_BLUR_ALPHA,
@@ -1558,12 +1562,14 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   // instance attributes: all must come from one interleaved instance buffer
   GLuint inst_buf = 0; int inst_stride = 0;
   for (int k = 0; k < WR_MAX_ATTRIBS; k++) { d.attr_off[k] = -1; d.attr_bytes[k] = 0; }
+  d.attr_u16 = 0;
   for (int k = 1; k < WR_MAX_ATTRIBS + 1 && info->attribs[k]; k++) {
     int loc = prog->attrib_loc[k];
     if (loc == NULL_ATTRIB) continue;
     VertexAttrib& va = v.attribs[loc];
     if (!va.enabled || va.divisor != 1) continue;
-    if (va.type != GL_INT && va.type != GL_FLOAT) { fprintf(stderr, "libwrhip: unsupported instance attribute type %x\n", va.type); continue; }
+    if (va.type != GL_INT && va.type != GL_FLOAT && va.type != GL_UNSIGNED_SHORT) { fprintf(stderr, "libwrhip: unsupported instance attribute type %x\n", va.type); continue; }
+    if (va.type == GL_UNSIGNED_SHORT) d.attr_u16 |= 1u << (k - 1);
     if (!inst_buf) { inst_buf = va.vertex_buffer; inst_stride = va.stride; }
     if (va.vertex_buffer != inst_buf || va.stride != inst_stride) { fprintf(stderr, "libwrhip: split instance buffers unsupported\n"); continue; }
     d.attr_off[k - 1] = va.offset; d.attr_bytes[k - 1] = (int)va.size;

@@ -129,9 +129,15 @@ WR_DEVICE T wr_load_attr(const WrDrawDesc& d, const uint8_t* arena, int instance
   uint32_t w[4] = {0, 0, 0, 0};
   if (d.attr_off[k] >= 0) {
     const uint8_t* src = arena + d.inst_offset + (size_t)d.inst_stride * instance + d.attr_off[k];
-    int words = d.attr_bytes[k] / 4;
-    for (int i = 0; i < n; i++)
-      if (i < words) __builtin_memcpy(&w[i], src + 4 * i, 4);
+    if ((d.attr_u16 >> k) & 1u) {            // integer attribute stored as u16 components (load_flat_attrib converts)
+      const int comps = d.attr_bytes[k] / 2;
+      for (int i = 0; i < n; i++)
+        if (i < comps) { uint16_t h; __builtin_memcpy(&h, src + 2 * i, 2); w[i] = h; }
+    } else {
+      int words = d.attr_bytes[k] / 4;
+      for (int i = 0; i < n; i++)
+        if (i < words) __builtin_memcpy(&w[i], src + 4 * i, 4);
+    }
   }
   T out;
   __builtin_memcpy(&out, w, sizeof(T));
@@ -166,6 +172,7 @@ struct WrVsOut {
   int aa_edges;        // swgl_antiAlias mask
   int has_mask;        // swgl_clipMask set
   float mask_offset[2], mask_bb[4];   // swgl_clipMask(offset, bb_origin, bb_size) arguments
+  float u2[4], v2[4];  // a second interpolated vec2 varying (WR_PK_BOX_SHADOW: vLocalPos.xy)
   int tail_clamp;      // fragment main(): clamps uv to uv_bounds
   int tail_modulate;   // fragment main(): multiplies texel by colour
 };
@@ -604,6 +611,57 @@ WR_DEVICE void wr_vs_cs_clip_rect(const WrDrawDesc& d, const uint8_t* arena, int
   o.kind = (lw[1] == lw[0] && lw[2] == lw[0] && lw[3] == lw[0]) ? WR_PK_CLIP_RECT : WR_PK_UNSUPPORTED;
 }
 
+// cs_clip_box_shadow.glsl:59-119 (vertex stage)
+WR_DEVICE void wr_vs_cs_clip_box_shadow(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrBoxRec& B) {
+  const wf4 area = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf4 origins = wr_load_attr<wf4>(d, arena, inst, 1);
+  const float dps = wr_load_attr<float>(d, arena, inst, 2);
+  const wi4 tids = wr_load_attr<wi4>(d, arena, inst, 3);
+  const wi4 res = wr_load_attr<wi4>(d, arena, inst, 4);
+  const wf2 src_size = wr_load_attr<wf2>(d, arena, inst, 5);
+  const int mode = wr_load_attr<int>(d, arena, inst, 6);
+  const wi4 stretch = wr_load_attr<wi4>(d, arena, inst, 7);
+  const wf4 dest = wr_load_attr<wf4>(d, arena, inst, 8);
+  const WrTransform clip_t = wr_fetch_transform(d, tids.x), prim_t = wr_fetch_transform(d, tids.y);
+  const wf4 res0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], res.x, res.y);      // fetch_image_source_direct
+  const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+  const float tsx = float(tex.width), tsy = float(tex.height);
+  const float dsx = dest.z - dest.x, dsy = dest.w - dest.y;
+  float lw[4];
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    const float sx = (area.z - area.x) * ax + area.x, sy = (area.w - area.y) * ay + area.y;
+    const float devx = origins.z + sx, devy = origins.w + sy;
+    wf4 pos = wr_mul(prim_t.m, wf4{devx / dps, devy / dps, 0.0f, 1.0f});
+    pos.x /= pos.w; pos.y /= pos.w; pos.z /= pos.w;
+    const wf4 p = wr_get_node_pos(pos.x, pos.y, clip_t);
+    const float lx = p.x * pos.w, ly = p.y * pos.w;
+    lw[n] = p.w * pos.w;
+    const float px = lx / lw[n], py = ly / lw[n];
+    float ux = stretch.x == 0 ? (px - dest.x) / src_size.x : (px - dest.x) / dsx;
+    float uy = stretch.y == 0 ? (py - dest.y) / src_size.y : (py - dest.y) / dsy;
+    o.u[n] = ux * lw[n]; o.v[n] = uy * lw[n];
+    o.u2[n] = lx; o.v2[n] = ly;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{origins.x + sx, origins.y + sy, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  B.ptr = tex.ptr; B.stride = tex.stride; B.wh = uint32_t(tex.width) | (uint32_t(tex.height) << 16);
+  B.format = tex.format; B.linear = tex.linear;
+  B.mode = float(mode); B.w = lw[0];
+  B.edge[0] = stretch.x == 0 ? 0.5f : 1.0f; B.edge[2] = stretch.x == 0 ? (dsx / src_size.x) - 0.5f : 1.0f;
+  B.edge[1] = stretch.y == 0 ? 0.5f : 1.0f; B.edge[3] = stretch.y == 0 ? (dsy / src_size.y) - 0.5f : 1.0f;
+  B.uv_bounds[0] = (res0.x + 0.5f) / tsx; B.uv_bounds[1] = (res0.y + 0.5f) / tsy;
+  B.uv_bounds[2] = (res0.z - 0.5f) / tsx; B.uv_bounds[3] = (res0.w - 0.5f) / tsy;
+  B.uv_noclamp[0] = res0.x / tsx; B.uv_noclamp[1] = res0.y / tsy; B.uv_noclamp[2] = res0.z / tsx; B.uv_noclamp[3] = res0.w / tsy;
+  B.bounds[0] = dest.x; B.bounds[1] = dest.y; B.bounds[2] = dest.z; B.bounds[3] = dest.w;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{0, 0, 0, 0};
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_COLOR0;
+  const bool affine = lw[1] == lw[0] && lw[2] == lw[0] && lw[3] == lw[0];
+  o.kind = (affine && tex.format == WR_FMT_R8 && tex.ptr) ? WR_PK_BOX_SHADOW : WR_PK_UNSUPPORTED;
+}
+
 // composite.glsl:73-159
 WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int inst, bool fast, WrVsOut& o) {
   wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
@@ -679,7 +737,7 @@ WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
 // draw_quad_spans (rasterize.h:783-1055): for a rectangle both edge slopes are
 // exactly 0, so every row has the same span and rows are those whose centre
 // lies in [top, bottom] after clipping.
-WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut& o, WrPrim& P,
+WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut& o, WrPrim& P, WrAux* auxp,
                               WrUnsupportedCounters* cnt) {
   P.kind = WR_PK_NONE;
   P.draw = draw_index;
@@ -759,7 +817,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -783,6 +841,14 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     P.uvR0[0] = o.u[tr] + dy0 * rsu; P.uvR0[1] = o.v[tr] + dy0 * rsv;
     P.uvLs[0] = lsu; P.uvLs[1] = lsv; P.uvRs[0] = rsu; P.uvRs[1] = rsv;
     P.xl = xmin; P.xr = xmax;
+    if (o.kind == WR_PK_BOX_SHADOW) {
+      WrBoxRec& B = auxp->box;
+      const float l2u = (o.u2[bl] - o.u2[tl]) * yScale, l2v = (o.v2[bl] - o.v2[tl]) * yScale;
+      const float r2u = (o.u2[br] - o.u2[tr]) * yScale, r2v = (o.v2[br] - o.v2[tr]) * yScale;
+      B.lpL0[0] = o.u2[tl] + dy0 * l2u; B.lpL0[1] = o.v2[tl] + dy0 * l2v;
+      B.lpR0[0] = o.u2[tr] + dy0 * r2u; B.lpR0[1] = o.v2[tr] + dy0 * r2v;
+      B.lpLs[0] = l2u; B.lpLs[1] = l2v; B.lpRs[0] = r2u; B.lpRs[1] = r2v;
+    }
   }
 }
 
@@ -1394,13 +1460,14 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_BLUR_COLOR: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     case WR_SH_CS_CLIP_RECT: wr_vs_cs_clip_rect(d, arena, inst, false, o, aux[gid].clip); break;
     case WR_SH_CS_CLIP_RECT_FAST: wr_vs_cs_clip_rect(d, arena, inst, true, o, aux[gid].clip); break;
+    case WR_SH_CS_CLIP_BOX_SHADOW: wr_vs_cs_clip_box_shadow(d, arena, inst, o, aux[gid].box); break;
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
       return;
   }
-  wr_finish_prim(d, lo, o, P, cnt);
+  wr_finish_prim(d, lo, o, P, &aux[gid], cnt);
 }
 
 
@@ -1856,6 +1923,185 @@ __device__ __noinline__ uint32_t wr_clip_rect_pixel(const WrPrim* Pp, const WrCl
   return uint32_t(wr_round_pixel(C.w > 0.0f ? fin : 0.0f)) & 0xFFFF;
 }
 
+// ---------------------------------------------------------------------------
+// cs_clip_box_shadow, one destination pixel of an R8 mask: the nine-patch span
+// shader (cs_clip_box_shadow.glsl:150-324) replayed up to the pixel's chunk --
+// solid lead-in, then [transitional chunk, sector run] pairs whose runs are
+// swgl_commitPartialTextureLinear(Invert)R8 / solid centre fills -- or the
+// fragment shader (:123-138) for the tail.
+WR_DEVICE float wr_r8_texture(const WrTexDesc& t, float u, float v) {   // texture(sColor0, uv).r of an R8 sampler
+  const float W = float(t.width), H = float(t.height);
+  if (t.linear) return float(wr_sample_linear_r8(t, int(u * W * 128.0f + (0.5f - 64.0f)), int(v * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
+  return float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(u * W), t.width) + (size_t)wr_clamp_coord(int(v * H), t.height) * t.stride]) * (1.0f / 255.0f);
+}
+WR_DEVICE void wr_box_map_uv(const WrBoxRec& B, float ul, float vl, float& u, float& v) {   // :124-127
+  u = wr_clamp(ul, 0.0f, B.edge[0]); v = wr_clamp(vl, 0.0f, B.edge[1]);
+  u += wr_max(0.0f, ul - B.edge[2]); v += wr_max(0.0f, vl - B.edge[3]);
+  u = (B.uv_noclamp[2] - B.uv_noclamp[0]) * u + B.uv_noclamp[0];
+  v = (B.uv_noclamp[3] - B.uv_noclamp[1]) * v + B.uv_noclamp[1];
+}
+WR_DEVICE float wr_box_shade(const WrBoxRec& B, const WrTexDesc& t, float ul, float vl, float lx, float ly) {
+  float u, v;
+  wr_box_map_uv(B, ul, vl, u, v);
+  u = wr_clamp(u, B.uv_bounds[0], B.uv_bounds[2]); v = wr_clamp(v, B.uv_bounds[1], B.uv_bounds[3]);
+  const float in = (wr_step01(B.bounds[0], lx) - wr_step01(B.bounds[2], lx)) * (wr_step01(B.bounds[1], ly) - wr_step01(B.bounds[3], ly));
+  const float texel = wr_r8_texture(t, u, v);
+  const float alpha = ((1.0f - texel) - texel) * B.mode + texel;
+  return (alpha - B.mode) * in + B.mode;
+}
+
+__device__ __noinline__ uint32_t wr_box_shadow_pixel(const WrPrim* Pp, const WrBoxRec* Bp, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrBoxRec& B = *Bp;
+  const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear};
+  const int k = y - P.y0;
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  // row interpolants of vUv and vLocalPos.xy
+  float o4[4], s4[4];
+  {
+    const float L[4] = {wr_accum(P.uvL0[0], P.uvLs[0], k), wr_accum(P.uvL0[1], P.uvLs[1], k), wr_accum(B.lpL0[0], B.lpLs[0], k), wr_accum(B.lpL0[1], B.lpLs[1], k)};
+    const float R[4] = {wr_accum(P.uvR0[0], P.uvRs[0], k), wr_accum(P.uvR0[1], P.uvRs[1], k), wr_accum(B.lpR0[0], B.lpRs[0], k), wr_accum(B.lpR0[1], B.lpRs[1], k)};
+    for (int i = 0; i < 4; i++) { s4[i] = (R[i] - L[i]) * stepScale; o4[i] = L[i] + s4[i] * start; }
+  }
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  const int n = x - P.x0;
+  const float mode = B.mode;
+  // SIMD lanes at the span start: [component][lane]
+  float ln[4][4];
+  for (int c = 0; c < 4; c++) { ln[c][0] = o4[c]; for (int i = 1; i < 4; i++) ln[c][i] = ln[c][i - 1] + s4[c]; }
+  if (n >= span) {
+    // fragment shader
+    const int lane = (n - span) & 3, m = (n - span) >> 2;
+    float v4[4];
+    for (int c = 0; c < 4; c++) {
+      float a = ln[c][lane];
+      if (span > 0) a = a + (s4[c] * 4.0f) * (float(span) * 0.25f);
+      v4[c] = wr_accum(a, (s4[c] * 4.0f) * 1.0f, m);
+    }
+    const float r = wr_box_shade(B, t, v4[0] / B.w, v4[1] / B.w, v4[2] / B.w, v4[3] / B.w);
+    return uint32_t(wr_round_pixel(B.w > 0.0f ? r : 0.0f)) & 0xFFFF;
+  }
+  float w = B.w;
+  if (w <= 0.0f) return 0u;
+  w = 1.0f / w;
+  float cur[4][4], st[4];        // uv_linear.x, uv_linear.y, local_pos.x, local_pos.y lanes; per-chunk steps
+  for (int c = 0; c < 4; c++) { for (int i = 0; i < 4; i++) cur[c][i] = ln[c][i] * w; st[c] = (s4[c] * 4.0f) * w; }
+  const float sl = float(span), ss = 4.0f;
+  int shadow_start_len, shadow_end_len, osteps[4];
+  {
+    const float p0x = cur[2][0], p0y = cur[3][0];
+    const bool negx = st[2] < 0.0f, negy = st[3] < 0.0f;
+    float cd[4] = {(negx ? B.bounds[2] : B.bounds[0]) - p0x, (negy ? B.bounds[3] : B.bounds[1]) - p0y,
+                   (negx ? B.bounds[0] : B.bounds[2]) - p0x, (negy ? B.bounds[1] : B.bounds[3]) - p0y};
+    const float rsx = 1.0f / st[2], rsy = 1.0f / st[3];
+    cd[0] = st[2] != 0.0f ? cd[0] * rsx : 1.0e6f * wr_step01(0.0f, cd[0]);
+    cd[1] = st[3] != 0.0f ? cd[1] * rsy : 1.0e6f * wr_step01(0.0f, cd[1]);
+    cd[2] = st[2] != 0.0f ? cd[2] * rsx : 1.0e6f * wr_step01(0.0f, cd[2]);
+    cd[3] = st[3] != 0.0f ? cd[3] * rsy : 1.0e6f * wr_step01(0.0f, cd[3]);
+    const float shadow_start = wr_max(cd[0], cd[1]), shadow_end = wr_min(cd[2], cd[3]);
+    shadow_start_len = int(wr_clamp(sl - ss * floorf(shadow_start), 0.0f, sl));
+    shadow_end_len = int(wr_clamp(sl - ss * ceilf(shadow_end), 0.0f, sl));
+    const float u0 = cur[0][0], v0 = cur[1][0];
+    const bool ngx = st[0] < 0.0f, ngy = st[1] < 0.0f;
+    float od[4] = {(ngx ? B.edge[2] : B.edge[0]) - u0, (ngy ? B.edge[3] : B.edge[1]) - v0,
+                   (ngx ? B.edge[0] : B.edge[2]) - u0, (ngy ? B.edge[1] : B.edge[3]) - v0};
+    const float rux = 1.0f / st[0], ruy = 1.0f / st[1];
+    od[0] = st[0] != 0.0f ? od[0] * rux : 1.0e6f * wr_step01(0.0f, od[0]);
+    od[1] = st[1] != 0.0f ? od[1] * ruy : 1.0e6f * wr_step01(0.0f, od[1]);
+    od[2] = st[0] != 0.0f ? od[2] * rux : 1.0e6f * wr_step01(0.0f, od[2]);
+    od[3] = st[1] != 0.0f ? od[3] * ruy : 1.0e6f * wr_step01(0.0f, od[3]);
+    const float sel = float(shadow_end_len);
+    for (int i = 0; i < 4; i++) osteps[i] = int(wr_clamp(sl - ss * floorf(od[i]), sel, sl));
+  }
+  int R = span, pos = 0;
+  if (R > shadow_start_len) {
+    const int nb = R - shadow_start_len;
+    if (n < nb) return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
+    const float f = float(nb / 4);
+    for (int c = 0; c < 4; c++) for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+    R -= nb; pos += nb;
+  }
+  const int lane = n & 3;
+  while (R > 0) {
+    if (n < pos + 4) {            // transitional chunk: per-fragment mapping
+      return uint32_t(wr_round_pixel(wr_box_shade(B, t, cur[0][lane], cur[1][lane], cur[2][lane], cur[3][lane]))) & 0xFFFF;
+    }
+    for (int c = 0; c < 4; c++) for (int i = 0; i < 4; i++) cur[c][i] += st[c];
+    R -= 4; pos += 4;
+    if (R <= shadow_end_len) break;
+    int num_inside = R - 4 - shadow_end_len;
+    float ub[4] = {B.uv_bounds[0], B.uv_bounds[1], B.uv_bounds[2], B.uv_bounds[3]};
+    if (R >= osteps[1]) {
+      num_inside = wr_imin(num_inside, R - osteps[1]);
+    } else if (R >= osteps[3]) {
+      num_inside = wr_imin(num_inside, R - osteps[3]);
+      const float cc = wr_clamp((B.uv_noclamp[3] - B.uv_noclamp[1]) * B.edge[1] + B.uv_noclamp[1], B.uv_bounds[1], B.uv_bounds[3]);
+      ub[1] = cc; ub[3] = cc;
+    }
+    if (R >= osteps[0]) {
+      num_inside = wr_imin(num_inside, R - osteps[0]);
+    } else if (R >= osteps[2]) {
+      num_inside = wr_imin(num_inside, R - osteps[2]);
+      const float cc = wr_clamp((B.uv_noclamp[2] - B.uv_noclamp[0]) * B.edge[0] + B.uv_noclamp[0], B.uv_bounds[0], B.uv_bounds[2]);
+      ub[0] = cc; ub[2] = cc;
+    }
+    if (num_inside > 0) {
+      if (n < pos + num_inside) {
+        float pu[4], pv[4];
+        for (int i = 0; i < 4; i++) wr_box_map_uv(B, cur[0][i], cur[1][i], pu[i], pv[i]);
+        if (ub[0] == ub[2] && ub[1] == ub[3]) {
+          // centre sector: one texel for the whole run (pattern of the 4 lanes repeated)
+          const float texel = wr_r8_texture(t, wr_clamp(pu[lane], ub[0], ub[2]), wr_clamp(pv[lane], ub[1], ub[3]));
+          return uint32_t(wr_round_pixel(((1.0f - texel) - texel) * mode + texel)) & 0xFFFF;
+        }
+        // swgl_commitTextureLinear(R8, sColor0, uv, uv_bounds, NoColor/InvertColor, num_inside)
+        const float W = float(t.width), H = float(t.height);
+        const int j = n - pos;
+        int v = 0;
+        int filter;
+        {   // needsTextureLinear (swgl_ext.h:553-587)
+          if (t.width < 2) filter = 0;
+          else if (pv[0] != pv[1]) filter = 1;
+          else {
+            const float px0 = pu[0] * W, px1 = pu[1] * W, py0 = pv[0] * H;
+            const int sp = (num_inside & ~127) + 128;
+            const int scaled = int(roundf((px1 - px0) * float(sp)));
+            if (scaled != sp) filter = (px0 < px1 && px1 - px0 <= 1.0f) ? 2 : (scaled == sp * 2 ? 4 : 1);
+            else if ((int(px0 * 4.0f + 0.5f) & 3) != 2 || (int(py0 * 4.0f + 0.5f) & 3) != 2) filter = 3;
+            else filter = 0;
+          }
+        }
+        if (filter == 0) {
+          // blendTextureNearestFast (swgl_ext.h:475-537)
+          const int ix = int(pu[0] * W), iy = int(pv[0] * H);
+          const int minUx = int(ub[0] * W), minUy = int(ub[1] * H), maxUx = int(ub[2] * W), maxUy = int(ub[3] * H);
+          const int srow = wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height);
+          const int minX = wr_iclamp(minUx, 0, t.width - 1), maxX = wr_iclamp(maxUx, minX, t.width - 1);
+          v = ((const uint8_t*)t.ptr)[(size_t)srow * t.stride + wr_iclamp(ix + j, minX, maxX)];
+        } else {
+          const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+          float q[4], qy[4];
+          for (int i = 0; i < 4; i++) { q[i] = pu[i] * W * qs + qo; qy[i] = pv[i] * H * qs + qo; }
+          const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
+          const float minx = wr_max(ub[0] * W * qs + qo, 0.0f), miny = wr_max(ub[1] * H * qs + qo, 0.0f);
+          const float maxx = wr_max(ub[2] * W * qs + qo, minx), maxy = wr_max(ub[3] * H * qs + qo, miny);
+          int o[4];
+          wr_linear_span_pixel<1>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, filter, num_inside, j, o);
+          v = o[0];
+        }
+        if (mode != 0.0f) v = 255 - v;               // applyColor(src, InvertColor)
+        return uint32_t(v) & 0xFFFF;
+      }
+      const float f = float(num_inside / 4);
+      for (int c = 0; c < 4; c++) for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+      R -= num_inside; pos += num_inside;
+    }
+  }
+  return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
+}
+
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
 WR_DEVICE uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
 #ifdef WRHIP_HOSTSIM
@@ -2036,6 +2282,14 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
           plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
         }
       }
+    }
+    return;
+  }
+  if (FMT == WR_FMT_R8 && kind == WR_PK_BOX_SHADOW) {
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      if (!(cx[q & 3] && cy[q >> 2])) continue;
+      plo[q] = wr_blend_r8(blend, plo[q], wr_box_shadow_pixel(Pp, &Ap->box, px + (q & 3), py + 4 * (q >> 2)));
     }
     return;
   }

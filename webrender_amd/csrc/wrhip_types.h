@@ -48,6 +48,7 @@ enum WrShader {
   WR_SH_CS_SCALE,
   WR_SH_CS_CLIP_RECT,
   WR_SH_CS_CLIP_RECT_FAST,
+  WR_SH_CS_CLIP_BOX_SHADOW,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -107,7 +108,8 @@ struct WrDrawDesc {
   uint64_t inst_offset;  // byte offset of this draw's instance data in the arena
   int32_t inst_stride;
   int32_t attr_off[WR_MAX_ATTRIBS];   // byte offset of the shader's k-th instance attribute, -1 = unbound (zeros)
-  int32_t attr_bytes[WR_MAX_ATTRIBS]; // bytes provided by the VAO for that attribute (VertexAttrib::size)
+  int32_t attr_bytes[WR_MAX_ATTRIBS];
+  uint32_t attr_u16;     // bit k: attribute k is made of 16-bit unsigned integers (VertexAttributeKind::U16) // bytes provided by the VAO for that attribute (VertexAttrib::size)
   WrTexDesc tex[WR_MAX_TEX];
 };
 
@@ -139,6 +141,7 @@ enum WrPrimKind {
   WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
   WR_PK_SOLID_MASKED,   // commit_masked_solid_span: flat colour x R8 clip mask sampled 1:1 (swgl_clipMask)
   WR_PK_TEX_FS,         // textured quad with no usable span shader: every pixel runs the fragment shader's main()
+  WR_PK_BOX_SHADOW,     // cs_clip_box_shadow's nine-patch span shader (WrBoxRec)
   WR_PK_CLIP_RECT,      // cs_clip_rectangle's rounded-rect span rasteriser (WrClipRec)
   WR_PK_BLUR,           // swgl_commitGaussianBlur{R8,RGBA8}: one separable pass (WrBlurRec)
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
@@ -234,11 +237,27 @@ struct WrClipRec {
   float bounds[4];          // vTransformBounds
 };
 
+// cs_clip_box_shadow flat varyings (cs_clip_box_shadow.glsl:7-14) + the second
+// interpolated varying (vLocalPos.xy; vUv lives in WrPrim's uv interpolants)
+struct WrBoxRec {
+  const void* ptr;          // cached blurred shadow (R8)
+  int32_t stride;
+  uint32_t wh;
+  int32_t format, linear;
+  float mode, w;            // vClipMode.x, vLocalPos.w
+  float edge[4];            // vEdge
+  float uv_bounds[4];       // vUvBounds
+  float uv_noclamp[4];      // vUvBounds_NoClamp
+  float bounds[4];          // vTransformBounds
+  float lpL0[2], lpLs[2], lpR0[2], lpRs[2];   // edge interpolants of vLocalPos.xy (as WrPrim::uv*)
+};
+
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
   WrTexRec tex;
   WrBlurRec blur;
   WrClipRec clip;
+  WrBoxRec box;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

@@ -64,6 +64,11 @@ DESC = {
         ("aClipMode", 1, F32), ("aClipRect_TL", 4, F32), ("aClipRadii_TL", 4, F32),
         ("aClipRect_TR", 4, F32), ("aClipRadii_TR", 4, F32), ("aClipRect_BL", 4, F32),
         ("aClipRadii_BL", 4, F32), ("aClipRect_BR", 4, F32), ("aClipRadii_BR", 4, F32)]),
+    # vertex.rs:447-498
+    "CLIP_BOX_SHADOW": VertexDescriptor(_POS, [
+        ("aClipDeviceArea", 4, F32), ("aClipOrigins", 4, F32), ("aDevicePixelScale", 1, F32),
+        ("aTransformIds", 2, I32), ("aClipDataResourceAddress", 2, U16), ("aClipSrcRectSize", 2, F32),
+        ("aClipMode", 1, I32), ("aStretchMode", 2, I32), ("aClipDestRect", 4, F32)]),
     # vertex.rs:732-780
     "COMPOSITE": VertexDescriptor(_POS, [
         ("aDeviceRect", 4, F32), ("aDeviceClipRect", 4, F32), ("aColor", 4, F32),

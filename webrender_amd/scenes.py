@@ -463,6 +463,84 @@ def clip_masks(n=24, atlas=1024, seed=31, dps=1.0, window=(256, 256)):
 
 
 # ---------------------------------------------------------------------------
+# Box-shadow clip masks: nine-patch stretch of a cached blurred corner texture
+# (cs_clip_box_shadow; ClipMaskInstanceBoxShadow, gpu_types.rs:230-247).
+BOX_SHADOW_DTYPE = np.dtype([
+    ("area", "<f4", (4,)), ("origins", "<f4", (4,)), ("dps", "<f4"), ("tids", "<i4", (2,)),
+    ("res", "<u2", (2,)), ("src_size", "<f4", (2,)), ("mode", "<i4"), ("stretch", "<i4", (2,)),
+    ("dest", "<f4", (4,))])
+
+
+def blurred_shadow_tile(size, radius, sigma, rng):
+    """What the blur chain leaves in the texture cache for a box shadow: a
+    rounded rect blurred with std deviation `sigma` (numpy; the content only has
+    to be plausible -- both backends sample the same bytes)."""
+    from scipy.ndimage import gaussian_filter
+    n = size
+    yy, xx = np.mgrid[0:n, 0:n].astype(np.float32)
+    pad = 3.0 * sigma
+    x0, y0, x1, y1 = pad, pad, n - pad, n - pad
+    dx = np.maximum(np.maximum(x0 + radius - xx, xx - (x1 - radius)), 0.0)
+    dy = np.maximum(np.maximum(y0 + radius - yy, yy - (y1 - radius)), 0.0)
+    inside = (xx >= x0) & (xx < x1) & (yy >= y0) & (yy < y1) & (np.hypot(dx, dy) <= radius)
+    img = gaussian_filter(inside.astype(np.float32), sigma)
+    return np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8)
+
+
+def box_shadow_masks(n=16, atlas=1024, seed=41, dps=1.0, window=(256, 256)):
+    rng = np.random.default_rng(seed)
+    frame = Frame(window[0], window[1], (1.0, 1.0, 1.0, 1.0))
+    cache = np.zeros((512, 512), np.uint8)
+    tiles = []
+    for i, (sz, rad, sg) in enumerate([(96, 12.0, 5.0), (64, 20.0, 3.0), (128, 30.0, 8.0), (48, 4.0, 2.0)]):
+        x, y = 8 + (i % 2) * 200, 8 + (i // 2) * 200
+        cache[y:y + sz, x:x + sz] = blurred_shadow_tile(sz, rad, sg, rng)
+        addr = frame.gpu_cache.push([[x, y, x + sz, y + sz], [0.0, 0.0, 0.0, 0.0]])
+        tiles.append((sz, addr))
+    t_cache = TextureRef("shadow_cache", 512, 512, G.GL_R8, G.GL_LINEAR, pixels=cache, upload_format=G.GL_RED)
+    frame.static_textures.append(t_cache)
+    t_mask = TextureRef("box_shadow_masks", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
+    tgt = Target(t_mask, "alpha", clear_color=(1.0, 1.0, 1.0, 1.0))
+    inst = np.zeros(n, BOX_SHADOW_DTYPE)
+    x = y = 4
+    shelf = 0
+    for k in range(n):
+        sz, addr = tiles[k % len(tiles)]
+        src_local = sz / dps                       # the cached shadow is rasterised at device scale
+        stretch = (int(k % 3 == 1), int(k % 4 == 2))       # 0 = MODE_STRETCH, 1 = MODE_SIMPLE
+        w = src_local if stretch[0] else src_local + float(rng.integers(10, 260))
+        h = src_local if stretch[1] else src_local + float(rng.integers(10, 200))
+        if k % 5 == 3:
+            w += 0.5
+        lpos = (float(rng.uniform(0, 400)), float(rng.uniform(0, 400)))
+        if k % 2 == 0:
+            lpos = (float(np.floor(lpos[0])), float(np.floor(lpos[1])))
+        tw = int(np.ceil(w * dps)) + int(rng.integers(-10, 11))
+        th = int(np.ceil(h * dps)) + int(rng.integers(-10, 11))
+        if x + tw + 4 > atlas:
+            x, y, shelf = 4, y + shelf + 4, 0
+        task = (float(x), float(y), float(x + tw), float(y + th))
+        x += tw + 4
+        shelf = max(shelf, th)
+        so = (float(np.floor(lpos[0] * dps)) + float(rng.integers(-6, 7)),
+              float(np.floor(lpos[1] * dps)) + float(rng.integers(-6, 7)))
+        inst["area"][k] = (0.0, 0.0, tw, th)
+        inst["origins"][k] = (task[0], task[1], so[0], so[1])
+        inst["dps"][k] = dps
+        inst["tids"][k] = (0, 0)
+        inst["res"][k] = (addr % 1024, addr // 1024)
+        inst["src_size"][k] = (src_local, src_local)
+        inst["mode"][k] = 1 if k % 3 == 2 else 0
+        inst["stretch"][k] = stretch
+        inst["dest"][k] = (lpos[0], lpos[1], lpos[0] + w, lpos[1] + h)
+    tgt.steps.append(Step("cs_clip_box_shadow TEXTURE_2D", "CLIP_BOX_SHADOW", inst, None, "none",
+                          textures={0: t_cache}))
+    frame.passes.append([tgt])
+    frame.readback = [t_mask]
+    return frame
+
+
+# ---------------------------------------------------------------------------
 # Separable Gaussian blur chain (the off-screen half of BASELINE config 4).
 BLUR_DTYPE = np.dtype([("a", "<i4", (3,)), ("p", "<f4", (3,))])   # BlurInstance, gpu_types.rs:109-118
 
