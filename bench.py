@@ -39,6 +39,9 @@ def make_frame(workload, **kw):
         return scenes.cfg5_many_rects(**kw)
     if workload == "cfg1":
         return scenes.cfg1_solid_colors(**kw)
+    if workload == "cfg4":
+        kw.pop("encoding", None)
+        return scenes.cfg4_box_shadow(dps=2.0, **kw)
     if workload == "cfg3":
         kw.pop("encoding", None)
         return scenes.cfg3_text(**kw)
@@ -194,6 +197,9 @@ def main():
                 "cfg2": "1000 overlapping translucent rects (ps_quad_textured + premultiplied-alpha blend), "
                         "3840x2160, 20 picture-cache tiles + composite, seed 2",
                 "cfg5": "100k rects (50% opaque), 7680x4320, 72 tiles + composite, seed 5",
+                "cfg4": "box-shadow-large.yaml at device_pixel_scale 2 (shadow 1840^2 px): cs_clip_rectangle mask -> "
+                        "2 cs_scale halvings -> cs_blur V/H -> cs_clip_box_shadow x clip-out mask -> masked "
+                        "brush_solid -> composite, 3840x2160",
                 "cfg3": "text: 200 lines x 250 glyphs (ps_text_run, R8 glyph atlas 2048^2, premultiplied-alpha "
                         "blend), 3840x2160, 20 tiles + composite, seed 3",
                 "cfg1": "16x16 opaque rect grid 1024x1024"}[args.workload],

@@ -123,6 +123,21 @@ def test_hip_box_shadow_matches_oracle(name, kw):
     assert ref or name in GOLDEN
 
 
+@pytest.mark.parametrize("name,kw", [("cfg4_small", dict(width=1024, height=1024)), ("cfg4_4k_dps2", dict(dps=2.0))],
+                         ids=["small", "4k_dps2"])
+def test_hip_cfg4_box_shadow_chain(name, kw):
+    """BASELINE config 4 (box-shadow-large.yaml): the whole mask / scale / blur /
+    box-shadow / masked-brush chain on the GPU."""
+    got, _ = render_direct(wrhip_lib(), scenes.cfg4_box_shadow(**kw))
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, scenes.cfg4_box_shadow(**kw))
+        for k in want:
+            d = np.abs(got[k].astype(int) - want[k].astype(int))
+            assert d.max() <= 1, (k, int(d.max()))
+    assert digest(got["window"]) == GOLDEN[name] or ref
+
+
 @pytest.mark.parametrize("name,make", SMALL, ids=[c[0] for c in SMALL])
 def test_hip_matches_oracle_small(name, make):
     got, stats = render_direct(wrhip_lib(), make())

@@ -109,6 +109,19 @@ def test_hostsim_box_shadow_matches_oracle(hostsim, oracle_gcc, name, kw):
         assert digest(got["box_shadow_masks"]) == GOLDEN[name]
 
 
+def test_hostsim_cfg4_box_shadow_chain(hostsim, oracle_gcc):
+    """BASELINE config 4 end to end (1024^2 window): rounded-rect mask -> two
+    cs_scale halvings -> cs_blur V/H -> cs_clip_box_shadow x cs_clip_rectangle
+    clip-out -> masked brush_solid segments -> composite.  Every intermediate
+    that is read back must match, not only the window."""
+    mk = lambda: scenes.cfg4_box_shadow(width=1024, height=1024)
+    want, _ = render_direct(oracle_gcc, mk())
+    got, _ = render_direct(hostsim, mk())
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    assert digest(got["window"]) == GOLDEN["cfg4_small"]
+
+
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
 def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     want, _ = render_direct(oracle_gcc, make())

@@ -631,10 +631,143 @@ def blur_chain(fmt="r8", content=(83, 83), sigma=2.5, atlas=256, n_tasks=1, seed
     return frame
 
 
+# ---------------------------------------------------------------------------
+# BASELINE config 4: wrench/benchmarks/box-shadow-large.yaml -- the complete
+# box-shadow chain of SURVEY.md §3.3:
+#   cs_clip_rectangle (minimal rounded rect, R8)  ->  cs_scale halvings while the
+#   std deviation exceeds 4  ->  cs_blur V  ->  cs_blur H (the cached corner
+#   texture)  ->  per-prim mask task: cs_clip_box_shadow + cs_clip_rectangle
+#   clip-out of the box (multiplied)  ->  picture tiles: brush_solid ALPHA_PASS,
+#   4 segments, sampling the mask through swgl_clipMask  ->  composite.
+# Geometry from the yaml: bounds [100,100,800,800], blur-radius 20, radii
+# TL 20 / TR 10 / BL 25 / BR 100, blue, outset.  `dps` scales the whole page
+# (device_pixel_scale); sizes follow compute_box_shadow_parameters (clip.rs:1765-1856).
+def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=None, **kw):
+    BLUR_SAMPLE_SCALE, MAX_BLUR_STD_DEV = 3.0, 4.0      # box_shadow.rs:48, render_task.rs:37
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    radii = ((20.0, 20.0), (10.0, 10.0), (25.0, 25.0), (100.0, 100.0))     # TL, TR, BL, BR
+    blur_radius = 20.0
+    blur_region = float(np.ceil(BLUR_SAMPLE_SCALE * blur_radius))          # 60
+    corner = max(max(r[0] for r in radii), blur_region)
+    min_size = 2.0 * corner + blur_region                                  # 260
+    alloc = 2.0 * blur_region + np.ceil(min_size)                          # 380 (shadow_rect_alloc_size)
+    cache_px = int(np.ceil(alloc * dps))
+    sigma = blur_radius * 0.5 * dps
+    steps = 0
+    while sigma > MAX_BLUR_STD_DEV:
+        sigma *= 0.5
+        steps += 1
+    atlas = 1 << int(np.ceil(np.log2(max(cache_px + 8, 256))))
+    zero = (0.0, 0.0, 0.0, 0.0)
+    # -- pass 0: the minimal rounded rect, at cache resolution
+    t_m0 = TextureRef("bs_corner_mask", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
+    tgt = Target(t_m0, "alpha", clear_color=zero)
+    task0 = (4.0, 4.0, 4.0 + cache_px, 4.0 + cache_px)
+    tgt.steps.append(Step("cs_clip_rectangle", "CLIP_RECT",
+                          clip_rect_instance(task0, (0.0, 0.0), dps, (blur_region, blur_region), (min_size, min_size),
+                                             radii, 0), None, "none"))
+    frame.passes.append([tgt])
+    # -- downscale passes
+    cur_tex, cur_rect, size = t_m0, task0, cache_px
+    for st in range(steps):
+        size = (size + 1) // 2
+        t_s = TextureRef(f"bs_scale_{st}", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
+        tg = Target(t_s, "alpha", clear_color=zero)
+        nr = (4.0, 4.0, 4.0 + size, 4.0 + size)
+        inst = np.zeros(1, SCALE_DTYPE)
+        inst["t"][0], inst["s"][0], inst["k"][0] = nr, cur_rect, 1.0
+        tg.steps.append(Step("cs_scale TEXTURE_2D", "SCALE", inst, None, "none", textures={0: cur_tex}))
+        frame.passes.append([tg])
+        cur_tex, cur_rect = t_s, nr
+    # -- blur passes (the horizontal one lands in the texture cache)
+    t_v = TextureRef("bs_blur_v", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
+    t_cache = TextureRef("bs_texture_cache", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
+    a_src, a_v, a_h = (frame.add_render_task(cur_rect) for _ in range(3))
+    tg_v, tg_h = Target(t_v, "alpha", clear_color=zero), Target(t_cache, "alpha", clear_color=zero)
+    tg_v.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", blur_instance(a_v, a_src, 1, sigma, (size, size)), None,
+                           "none", textures={0: cur_tex}))
+    tg_h.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", blur_instance(a_h, a_v, 0, sigma, (size, size)), None,
+                           "none", textures={0: t_v}))
+    frame.passes.append([tg_v])
+    frame.passes.append([tg_h])
+    res = frame.gpu_cache.push([list(cur_rect), [0.0, 0.0, 0.0, 0.0]])     # ImageSource of the cached shadow
+    # -- per-prim mask tasks + masked brushes (n_shadows copies stacked down the page)
+    masks_w = int(np.ceil(920.0 * dps)) + 8
+    m_atlas_w = 1 << int(np.ceil(np.log2(masks_w)))
+    m_atlas_h = 1 << int(np.ceil(np.log2(masks_w * n_shadows)))
+    t_masks = TextureRef("bs_prim_masks", m_atlas_w, m_atlas_h, G.GL_R8, G.GL_LINEAR, render_target=True)
+    tg_m = Target(t_masks, "alpha", clear_color=(1.0, 1.0, 1.0, 1.0))
+    bs_inst = np.zeros(n_shadows, BOX_SHADOW_DTYPE)
+    co_inst = []
+    prims = []
+    for i in range(n_shadows):
+        oy = i * 1000.0
+        box = (100.0, 100.0 + oy, 900.0, 900.0 + oy)
+        dest = (box[0] - blur_region, box[1] - blur_region, box[2] + blur_region, box[3] + blur_region)
+        dev = tuple(v * dps for v in dest)
+        so = (float(np.floor(dev[0])), float(np.floor(dev[1])))
+        tw, th = int(np.ceil(dev[2]) - so[0]), int(np.ceil(dev[3]) - so[1])
+        task = (4.0, 4.0 + i * masks_w, 4.0 + tw, 4.0 + i * masks_w + th)
+        bs_inst["area"][i] = (0.0, 0.0, tw, th)
+        bs_inst["origins"][i] = (task[0], task[1], so[0], so[1])
+        bs_inst["dps"][i] = dps
+        bs_inst["res"][i] = (res % 1024, res // 1024)
+        bs_inst["src_size"][i] = (alloc, alloc)
+        bs_inst["mode"][i] = 0
+        bs_inst["stretch"][i] = (0, 0)
+        bs_inst["dest"][i] = dest
+        co_inst.append(clip_rect_instance(task, so, dps, (box[0], box[1]), (box[2] - box[0], box[3] - box[1]), radii, 1))
+        clip_task = frame.add_render_task(task, dps, so)
+        prims.append((dest, box, clip_task))
+    tg_m.steps.append(Step("cs_clip_box_shadow TEXTURE_2D", "CLIP_BOX_SHADOW", bs_inst, None, "none",
+                           textures={0: t_cache}))
+    tg_m.steps.append(Step("cs_clip_rectangle", "CLIP_RECT", np.concatenate(co_inst), "Multiply", "none"))
+    frame.passes.append([tg_m])
+    # -- picture tiles
+    color = premultiply(np.array([[0, 0, 255, 255]], np.uint8))[0]
+    addr_color = frame.gpu_cache.push([list(color)])
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), dps, (float(ox), float(oy)))
+        inst = []
+        for pi, (dest, box, clip_task) in enumerate(prims):
+            dv = [v * dps for v in dest]
+            if not (dv[0] < x1 and dv[2] > x0 and dv[1] < y1 and dv[3] > y0):
+                continue
+            # brush segments (prim_store BrushSegment): the ring around the box interior
+            ix0, iy0 = box[0] + 25.0, box[1] + 25.0          # inset by the largest left / top radii
+            ix1, iy1 = box[2] - 100.0, box[3] - 100.0        # ... right / bottom radii
+            segs = [(dest[0], dest[1], dest[2], iy0), (dest[0], iy1, dest[2], dest[3]),
+                    (dest[0], iy0, ix0, iy1), (ix1, iy0, dest[2], iy1)]
+            blocks = [list(color)]
+            for sg in segs:
+                blocks += [[sg[0] - dest[0], sg[1] - dest[1], sg[2] - dest[0], sg[3] - dest[1]], [0.0, 0.0, 0.0, 0.0]]
+            addr = frame.gpu_cache.push(blocks)
+            ph = frame.add_prim_header(dest, (-BIG, -BIG, BIG, BIG), pi + 1, addr, 0, task, (65535, 0, 0, 0))
+            for si in range(4):
+                inst.append(frame.brush_instance(ph, clip_task, segment=si))
+        if inst:
+            target.alpha.append(Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={9: t_masks}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    frame.readback = [t_cache, t_masks]
+    return frame
+
+
 SCENES = {
     "cfg1": cfg1_solid_colors,
     "simple_batching": simple_batching,
     "cfg2": cfg2_overlapping_rects,
     "cfg3": cfg3_text,
+    "cfg4": cfg4_box_shadow,
     "cfg5": cfg5_many_rects,
 }
