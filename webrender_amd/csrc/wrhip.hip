@@ -854,37 +854,48 @@ void flush_work(const std::vector<int>& sel_in) {
     // 32 pixels measured slower on MI355X, profiles/r01_*).  The kernel is
     // specialised on the prim families present in the launch (FEAT) so that
     // rect-only passes do not pay the registers of the texture paths.
-    int feat = 0;
+    int feat_rgba = 0, feat_r8 = 0;
     for (int i = 0; i < nd; i++) {
-      switch (draws[i].shader) {
-        case WR_SH_PS_TEXT_RUN: feat |= 3; break;
-        case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA:
-          if (draws[i].blend != WR_BLEND_NONE && draws[i].tex[WR_S_CLIP_MASK].width >= 2) feat |= 2;   // masked solids
-          break;
-        case WR_SH_PS_CLEAR: case WR_SH_CLEAR_OP: break;
-        // quads drawn with the 1x1 dummy texture bound are solid (a textured one would still be
-        // drawn correctly by the generic path: FEAT only selects fast paths)
-        case WR_SH_PS_QUAD_TEXTURED: if (draws[i].tex[WR_S_COLOR0].width >= 2) feat |= 1; break;
-        default: feat |= 1; break;
+      const bool to_r8 = targets[draws[i].target].format == WR_FMT_R8;
+      int f = 0;
+      if (!(draws[i].flags & WR_DF_SIMPLE)) {
+        switch (draws[i].shader) {
+          case WR_SH_PS_CLEAR: case WR_SH_CLEAR_OP: break;
+          case WR_SH_PS_TEXT_RUN: f = WR_FEAT_R8TEX | WR_FEAT_TEX | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA: f = WR_FEAT_R8TEX | WR_FEAT_GENERIC; break;   // masked / odd blend
+          case WR_SH_CS_BLUR_ALPHA: case WR_SH_CS_BLUR_COLOR: f = WR_FEAT_BLUR; break;
+          case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW: f = WR_FEAT_CLIP; break;
+          default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
+        }
       }
+      (to_r8 ? feat_r8 : feat_rgba) |= f;
     }
 #define WR_RASTER_F(FMT, DEPTH, FEAT, NB, OFF)                                                                      \
   do {                                                                                                              \
     WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), NB, 256, c->stream, dtargets, n_targets, ddraws,             \
-              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrAux*)c->daux, c->dmasks, OFF);      \
+              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrAux*)c->daux, c->dmasks, OFF);             \
     c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
   } while (0)
-#define WR_RASTER(FMT, DEPTH, NB, OFF)                                                                              \
+    // smallest instantiated superset of the launch's feature set
+#define WR_RASTER(DEPTH, NB, OFF)                                                                                   \
   do {                                                                                                              \
-    if (FMT == WR_FMT_R8 || feat == 0) WR_RASTER_F(FMT, DEPTH, 0, NB, OFF);                                         \
-    else if (feat == 1) WR_RASTER_F(FMT, DEPTH, 1, NB, OFF);                                                        \
-    else WR_RASTER_F(FMT, DEPTH, 3, NB, OFF);                                                                       \
+    if (feat_rgba == 0) WR_RASTER_F(WR_FMT_RGBA8, DEPTH, 0, NB, OFF);                                               \
+    else if (!(feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC)))                                                       \
+      WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC, NB, OFF);                                     \
+    else if (!(feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX)))                                       \
+      WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX, NB, OFF);                     \
+    else WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR, NB, OFF);   \
   } while (0)
     if (bins_rgba > 0) {
-      if (any_depth) WR_RASTER(WR_FMT_RGBA8, true, bins_rgba, 0);
-      else WR_RASTER(WR_FMT_RGBA8, false, bins_rgba, 0);
+      if (any_depth) WR_RASTER(true, bins_rgba, 0);
+      else WR_RASTER(false, bins_rgba, 0);
     }
-    if (n_bins > bins_rgba) WR_RASTER_F(WR_FMT_R8, false, 0, n_bins - bins_rgba, bins_rgba);
+    if (n_bins > bins_rgba) {
+      const int nb8 = n_bins - bins_rgba;
+      if (feat_r8 == 0) WR_RASTER_F(WR_FMT_R8, false, 0, nb8, bins_rgba);
+      else if (!(feat_r8 & WR_FEAT_CLIP)) WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR, nb8, bins_rgba);
+      else WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP, nb8, bins_rgba);
+    }
 #undef WR_RASTER_F
 #undef WR_RASTER
     if (c->profiling) {
@@ -1616,6 +1627,15 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     if (c->depthmask) d.flags |= WR_DF_DEPTH_WRITE;
     if (c->depthfunc == GL_LESS) d.flags |= WR_DF_DEPTH_LESS;
     c->work[wi].depth_tex = fb.depth_attachment;
+  }
+  {
+    // draws that can only produce solid prims with a blend the inline raster paths know (WrFeat)
+    const bool plain_blend = d.blend == WR_BLEND_NONE || d.blend == WR_BLEND_PREMULT;
+    const bool maskable = d.blend != WR_BLEND_NONE && d.tex[WR_S_CLIP_MASK].ptr && d.tex[WR_S_CLIP_MASK].width >= 2;
+    bool simple = false;
+    if (info->kind == WR_SH_BRUSH_SOLID || info->kind == WR_SH_BRUSH_SOLID_ALPHA) simple = plain_blend && !maskable;
+    else if (info->kind == WR_SH_PS_QUAD_TEXTURED) simple = plain_blend && d.tex[WR_S_COLOR0].width < 2;
+    if (simple) d.flags |= WR_DF_SIMPLE;
   }
   apply_scissor(colortex, d.clip);
   d.vp_origin[0] = float(c->viewport[0] - colortex.offx); d.vp_origin[1] = float(c->viewport[1] - colortex.offy);

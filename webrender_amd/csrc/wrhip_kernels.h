@@ -144,6 +144,47 @@ WR_DEVICE T wr_load_attr(const WrDrawDesc& d, const uint8_t* arena, int instance
   return out;
 }
 
+// s0 + step + step + ... (c adds, each rounded to fp32), as swgl's span loops
+// accumulate quantised UVs (`uv += uv_step`, swgl_ext.h:176).  Closed form when
+// provably identical: if s0 and step are both multiples of 2^g and every partial
+// sum is below 2^(g+24) in magnitude, every add is exact, so the result is the
+// real number s0 + c*step (partial sums are monotone between the end points).
+WR_DEVICE int wr_low_bit_exp(float x) {
+  uint32_t b; __builtin_memcpy(&b, &x, 4);
+  uint32_t e = (b >> 23) & 0xFF, m = b & 0x7FFFFF;
+  if (e == 0) return m ? -1000 : 1000;         // denormal: force the loop; zero: no constraint
+  m |= 0x800000;
+  return int(e) - 150 + __builtin_ctz(m);
+}
+WR_DEVICE bool wr_accum_is_linear(float s0, float step, int c) {
+  if (c <= 0 || step == 0.0f) return true;
+  const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
+  const int g = g0 < g1 ? g0 : g1;
+  const double end = double(s0) + double(c) * double(step);
+  const double a0 = s0 < 0 ? -double(s0) : double(s0), a1 = end < 0 ? -end : end;
+  const double bound = a0 > a1 ? a0 : a1;
+  return g > -900 && g < 100 && bound < __builtin_ldexp(1.0, g + 24);
+}
+WR_DEVICE float wr_accum(float s0, float step, int c) {
+  if (c <= 0 || step == 0.0f) return s0;
+  const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
+  const int g = g0 < g1 ? g0 : g1;
+  const double end = double(s0) + double(c) * double(step);
+  const double a0 = s0 < 0 ? -double(s0) : double(s0), a1 = end < 0 ? -end : end;
+  const double bound = a0 > a1 ? a0 : a1;
+  if (g > -900 && g < 100 && bound < __builtin_ldexp(1.0, g + 24)) return float(end);
+  WR_DBG_PATH(2);
+  float s = s0;
+  for (int i = 0; i < c; i++) s += step;
+  return s;
+}
+
+// row-k edge interpolant: closed form when the prim was verified linear over all its rows
+WR_DEVICE float wr_row_interp(float s0, float step, int k, bool linear) {
+  if (linear) return float(double(s0) + double(k) * double(step));
+  return wr_accum(s0, step, k);
+}
+
 // round_pixel (portable path): cast(v * 255 + 0.5), glsl.h:732-744
 WR_DEVICE int wr_round_pixel(float v) { return int(v * 255.0f + 0.5f); }
 
@@ -813,6 +854,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (ix1 <= ix0 || iy1 <= iy0) return;
   P.x0 = ix0; P.x1 = ix1; P.y0 = iy0; P.y1 = iy1;
   P.kind = masked ? (int16_t)WR_PK_SOLID_MASKED : (int16_t)o.kind;
+  P.rows_linear = 0;
+  if ((d.flags & WR_DF_SIMPLE) && P.kind != WR_PK_SOLID) {   // the launch's kernel has no path for it: say so
+    P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
+  }
   if (o.kind == WR_PK_UNSUPPORTED) { atomicAdd(&cnt->unsupported_prims, 1u); return; }
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
@@ -841,6 +886,11 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     P.uvR0[0] = o.u[tr] + dy0 * rsu; P.uvR0[1] = o.v[tr] + dy0 * rsv;
     P.uvLs[0] = lsu; P.uvLs[1] = lsv; P.uvRs[0] = rsu; P.uvRs[1] = rsv;
     P.xl = xmin; P.xr = xmax;
+    {
+      const int rows = iy1 - iy0 - 1;
+      P.rows_linear = (wr_accum_is_linear(P.uvL0[0], lsu, rows) && wr_accum_is_linear(P.uvL0[1], lsv, rows) &&
+                       wr_accum_is_linear(P.uvR0[0], rsu, rows) && wr_accum_is_linear(P.uvR0[1], rsv, rows)) ? 1 : 0;
+    }
     if (o.kind == WR_PK_BOX_SHADOW) {
       WrBoxRec& B = auxp->box;
       const float l2u = (o.u2[bl] - o.u2[tl]) * yScale, l2v = (o.v2[bl] - o.v2[tl]) * yScale;
@@ -965,32 +1015,6 @@ WR_DEVICE WrWide wr_apply_color(WrWide src, const uint32_t color[2]) {
 
 // ---------------------------------------------------------------------------
 // Texture sampling helpers used by textured prims.
-
-// s0 + step + step + ... (c adds, each rounded to fp32), as swgl's span loops
-// accumulate quantised UVs (`uv += uv_step`, swgl_ext.h:176).  Closed form when
-// provably identical: if s0 and step are both multiples of 2^g and every partial
-// sum is below 2^(g+24) in magnitude, every add is exact, so the result is the
-// real number s0 + c*step (partial sums are monotone between the end points).
-WR_DEVICE int wr_low_bit_exp(float x) {
-  uint32_t b; __builtin_memcpy(&b, &x, 4);
-  uint32_t e = (b >> 23) & 0xFF, m = b & 0x7FFFFF;
-  if (e == 0) return m ? -1000 : 1000;         // denormal: force the loop; zero: no constraint
-  m |= 0x800000;
-  return int(e) - 150 + __builtin_ctz(m);
-}
-WR_DEVICE float wr_accum(float s0, float step, int c) {
-  if (c <= 0) return s0;
-  const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
-  const int g = g0 < g1 ? g0 : g1;
-  const double end = double(s0) + double(c) * double(step);
-  const double a0 = s0 < 0 ? -double(s0) : double(s0), a1 = end < 0 ? -end : end;
-  const double bound = a0 > a1 ? a0 : a1;
-  if (g > -900 && g < 100 && bound < __builtin_ldexp(1.0, g + 24)) return float(end);
-  WR_DBG_PATH(2);
-  float s = s0;
-  for (int i = 0; i < c; i++) s += step;
-  return s;
-}
 
 // textureLinearUnpackedRGBA8 for ONE pixel (texture.h:1028-1071): 7-bit
 // fixed-point bilinear on quantised coords i = uv*size*128 + (0.5 - 64).
@@ -1183,8 +1207,9 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   WrTexRow r;
   // Edge::nextRow (rasterize.h:878-882) steps the interpolants by repeated addition
   const int k = y - P.y0;
-  float Lu = wr_accum(P.uvL0[0], P.uvLs[0], k), Lv = wr_accum(P.uvL0[1], P.uvLs[1], k);
-  float Ru = wr_accum(P.uvR0[0], P.uvRs[0], k), Rv = wr_accum(P.uvR0[1], P.uvRs[1], k);
+  const bool lin = P.rows_linear != 0;
+  float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+  float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
@@ -1526,6 +1551,71 @@ WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDes
 #endif
 }
 
+// Nearest-fast setup of an axis-aligned WR_PK_TEX_RGBA8 prim: the row-independent
+// part of what blendTextureNearestFast / needsTextureLinear (swgl_ext.h:475-587)
+// decide, evaluated once per prim here instead of per pixel in the raster stage.  Returns false when the x part of the decision already rules
+// the nearest-fast path out (scaled or subpixel-offset sampling).
+WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& T) {
+  if (!t.ptr || P.uvLs[0] != 0.0f || P.uvRs[0] != 0.0f || P.uvL0[1] != P.uvR0[1] || P.uvLs[1] != P.uvRs[1]) return false;
+  const WrTexRow r = wr_tex_row(P, t, P.y0);       // u, su, span and the x clamps do not depend on the row here
+  if (r.span == 0) return false;
+  const float W = float(t.width);
+  bool x_ok;
+  const float px0 = r.ou * W, px1 = (r.ou + r.su) * W;
+  const int sp = (r.span & ~127) + 128;
+  const int scaled = int(roundf((px1 - px0) * float(sp)));
+  if (!t.linear) x_ok = scaled == sp;
+  else if (t.width < 2) x_ok = true;
+  else x_ok = scaled == sp && (int(px0 * 4.0f + 0.5f) & 3) == 2;
+  if (!x_ok) return false;
+  __builtin_memset(&T, 0, sizeof(T));
+  T.ptr = t.ptr; T.stride = t.stride; T.wh = uint32_t(t.width) | (uint32_t(t.height) << 16);
+  T.span = r.span; T.y0 = P.y0;
+  T.ix0 = int(r.ou * W);
+  const int minUx = int(P.uv_bounds[0] * W), maxUx = int(P.uv_bounds[2] * W);
+  T.tix[0] = wr_iclamp(minUx, 0, t.width - 1);
+  T.tix[1] = wr_iclamp(maxUx, T.tix[0], t.width - 1);
+  T.lv0 = P.uvL0[1]; T.lvs = P.uvLs[1];
+  T.ub1 = P.uv_bounds[1]; T.ub3 = P.uv_bounds[3];
+  T.unit = (t.linear && t.width >= 2) ? 1 : 0;      // rows must also pass the texel-centre test
+  T.simple = 2;
+  // Rows that step exactly one texel per target row (tile composites): with a
+  // power-of-two height, v(k) = v0 + k/H holds exactly (rows_linear), so
+  // int(v(k)*H) = int(v0*H) + k and the texel-centre test gives the same answer on every row.
+  const int th = t.height;
+  const float H = float(th);
+  const float vstep = P.uvLs[1] * H;             // exact when H is a power of two
+#ifdef WRHIP_HOSTSIM
+  if (getenv("WRHIP_DEBUG_ROWS")) fprintf(stderr, "texrow: lin %d th %d vstep %.9g L0*H %.9g rows %d\n", P.rows_linear, th, vstep, P.uvL0[1] * H, P.y1 - P.y0);
+#endif
+  if (P.rows_linear && (th & (th - 1)) == 0 && th < 65536 && (vstep == 1.0f || vstep == -1.0f) && P.y1 - P.y0 < 65536) {
+    const float py0 = P.uvL0[1] * H;           // exact: scaling by a power of two
+    const float pyl = fabsf(py0) + float(P.y1 - P.y0);
+    const float pye = py0 + vstep * float(P.y1 - P.y0 - 1);                        // last row; every row keeps v*H >= 0
+    const bool exact = pyl < 4194304.0f && (py0 * 4.0f) == floorf(py0 * 4.0f) && py0 >= 0.0f && pye >= 0.0f;   // quarter-texel grid survives the adds
+    if (exact && (!T.unit || (int(py0 * 4.0f + 0.5f) & 3) == 2)) {
+      const int minUy = int(P.uv_bounds[1] * H), maxUy = int(P.uv_bounds[3] * H);
+      if (minUy <= maxUy) {
+        const int lo = wr_iclamp(minUy, 0, th - 1), hi = wr_iclamp(maxUy, 0, th - 1);
+        T.iy0 = int(py0);
+        T.tix[2] = vstep > 0.0f ? 1 : -1;
+        T.unit = lo | (hi << 16);
+        T.simple = 3;
+      }
+    }
+  }
+  return true;
+}
+WR_DEVICE int wr_texrow_entry(const WrTexRec& T, int rows_linear, int k) {
+  const int th = int(T.wh >> 16);
+  const float H = float(th);
+  const float ov = wr_row_interp(T.lv0, T.lvs, k, rows_linear != 0);
+  const float py0 = ov * H;
+  if (T.unit && (int(py0 * 4.0f + 0.5f) & 3) != 2) return -1;
+  const int iy = int(ov * H), minUy = int(T.ub1 * H), maxUy = int(T.ub3 * H);
+  return wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), th);
+}
+
 // Vertex stage + binning, one thread per instance.
 __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
@@ -1550,6 +1640,16 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
       t.simple = ((P.color[0] | P.color[1]) & 0xFF00FF00u) == 0 ? 1 : 0;
       t.unit = 1; t.ix0 = P.x0 - P.mask_off[0]; t.iy0 = P.y0 - P.mask_off[1];
       aux[gid].tex = t;
+    }
+    if (P.kind == WR_PK_TEX_RGBA8) {
+      const WrDrawDesc& d = draws[P.draw];
+      WrTexRec T;
+      if (wr_texrow_x_setup(P, d.tex[P.tex_slot], T)) {
+        if (T.simple == 2) T.tix[2] = P.rows_linear;      // rows resolved per lane-row in the raster stage (wr_texrow_entry)
+        aux[gid].tex = T;
+      } else {
+        aux[gid].tex.simple = 0;
+      }
     }
   }
   wr_bin_prim(P, valid, gid, draws, targets, masks);
@@ -1595,6 +1695,11 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
     src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y);
   }
   return wr_blend_rgba8(P.blend, dstp, src, D);
+}
+
+// red channel of a textured prim's fragment value (R8 targets)
+__device__ __noinline__ uint32_t wr_tex_pixel_r(const WrPrim* Pp, const WrDrawDesc* D, int x, int y) {
+  return wr_tex_pixel(*Pp, D->tex[Pp->tex_slot], x, y).ra & 0xFFFF;
 }
 
 // ---------------------------------------------------------------------------
@@ -2227,30 +2332,31 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & 1) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_RGBA8 && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT)) {
-    // ---- swgl_commitTexture*RGBA8: per lane-row span setup, then 4 texels ----
-    // Rows whose 4 pixels all fall in the nearest-fast part of the span
-    // (blendTextureNearestFast, swgl_ext.h:475-537) fetch their texels directly;
-    // anything else (linear filters, fragment-shader tail) goes pixel by pixel
-    // through the out-of-line generic path.
-    const WrPrim& P = *Pp;
-    const WrDrawDesc* D = &draws[P.draw];
-    const WrTexDesc& tex = D->tex[P.tex_slot];
-    const uint32_t* sbuf = (const uint32_t*)tex.ptr;
+  if ((FEAT & WR_FEAT_TEX) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_RGBA8 && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT) &&
+      Ap->tex.simple >= 2) {
+    // ---- swgl_commitTexture*RGBA8, nearest-fast rows (blendTextureNearestFast,
+    // swgl_ext.h:475-537): the source row of every target row was resolved by
+    // the setup kernel (unit rows) or is evaluated per lane-row; a lane fetches its 4 texels of each row.
+    // Rows / pixels outside that case go through the out-of-line generic path.
+    const WrTexRec& T = Ap->tex;
+    const uint32_t* sbuf = (const uint32_t*)T.ptr;
     const int n0 = px - x0;
     const bool has_color = (flags & WR_PF_HAS_COLOR) != 0;
+    const bool inspan = n0 >= 0 && n0 + 4 <= T.span;
+    const int xa = T.ix0 + n0;
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int y = py + 4 * j;
       uint32_t sp[4] = {0, 0, 0, 0};
       bool rowfast = false;
-      if (cy[j] && sbuf) {
-        const WrTexRow r = wr_tex_row(P, tex, y);
-        rowfast = r.filter == 0 && n0 >= 0 && n0 + 4 <= r.span;
+      if (cy[j] && inspan) {
+        const int srow = T.simple == 3 ? wr_iclamp(T.iy0 + T.tix[2] * (y - T.y0), T.unit & 0xFFFF, T.unit >> 16)
+                                        : wr_texrow_entry(T, T.tix[2], y - T.y0);
+        rowfast = srow >= 0;
         if (rowfast) {
-          const uint32_t* srow = sbuf + (size_t)r.srow * tex.stride;
+          const uint32_t* rp = sbuf + (size_t)srow * T.stride;
 #pragma unroll
-          for (int i = 0; i < 4; i++) sp[i] = srow[wr_iclamp(r.ix + n0 + i, r.minX, r.maxX)];
+          for (int i = 0; i < 4; i++) sp[i] = rp[wr_iclamp(xa + i, T.tix[0], T.tix[1])];
         }
       }
 #pragma unroll
@@ -2278,14 +2384,16 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
           }
           plo[q] = in ? nl : plo[q]; phi[q] = in ? nh : phi[q];
         } else if (in) {
-          uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + i, y, plo[q] | (phi[q] << 8));
-          plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+          if (FEAT & WR_FEAT_GENERIC) {
+            uint32_t r = wr_generic_pixel_rgba8(Pp, &draws[Pp->draw], px + i, y, plo[q] | (phi[q] << 8));
+            plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+          }
         }
       }
     }
     return;
   }
-  if (FMT == WR_FMT_R8 && kind == WR_PK_BOX_SHADOW) {
+  if ((FEAT & WR_FEAT_CLIP) && FMT == WR_FMT_R8 && kind == WR_PK_BOX_SHADOW) {
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
       if (!(cx[q & 3] && cy[q >> 2])) continue;
@@ -2293,7 +2401,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if (FMT == WR_FMT_R8 && kind == WR_PK_CLIP_RECT) {
+  if ((FEAT & WR_FEAT_CLIP) && FMT == WR_FMT_R8 && kind == WR_PK_CLIP_RECT) {
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
       if (!(cx[q & 3] && cy[q >> 2])) continue;
@@ -2301,7 +2409,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if (kind == WR_PK_BLUR) {
+  if ((FEAT & WR_FEAT_BLUR) && kind == WR_PK_BLUR) {
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -2329,13 +2437,15 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     if (in) {
       if (FMT == WR_FMT_RGBA8) {
-        uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + (q & 3), py + 4 * (q >> 2), plo[q] | (phi[q] << 8));
-        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+        if (FEAT & WR_FEAT_GENERIC) {
+          uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + (q & 3), py + 4 * (q >> 2), plo[q] | (phi[q] << 8));
+          plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+        }
       } else {
         // R8 target: pack_pixels_R8(gl_FragColor.x) (blend.h:67-73)
         uint32_t srcr = c1 & 0xFFFF;
-        if (kind == WR_PK_TEX_FS || kind == WR_PK_TEX_RGBA8)
-          srcr = wr_tex_pixel(*Pp, D->tex[Pp->tex_slot], px + (q & 3), py + 4 * (q >> 2)).ra & 0xFFFF;
+        if ((FEAT & WR_FEAT_GENERIC) && (kind == WR_PK_TEX_FS || kind == WR_PK_TEX_RGBA8))
+          srcr = wr_tex_pixel_r(Pp, D, px + (q & 3), py + 4 * (q >> 2));
         plo[q] = wr_blend_r8(blend, plo[q], srcr);
       }
     }
@@ -2573,7 +2683,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       const WrRec Rc = recs[base + bit];
       if (Rc.x1 <= wx0 || Rc.x0 >= wx0 + WR_BIN_W || Rc.y1 <= wy0 || Rc.y0 >= wy0 + STRIP) continue;
       const int rblend = (Rc.kbf >> 8) & 0xFF;
-      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 || (Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 || (Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
         wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, aux[base + bit].tex,
                                   draws, &prims[base + bit], px, py);
@@ -2618,7 +2728,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       const uint32_t z = __builtin_amdgcn_readlane((int)rb.x, bit), kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
       const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
       const int rblend = (kbf >> 8) & 0xFF;
-      if ((FEAT & 2) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_TEX_R8 || (kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_TEX_R8 || (kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
         wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[base + bit].tex, draws, &prims[base + bit], px, py);
       else

@@ -74,6 +74,20 @@ enum WrBlend {
   WR_BLEND_UNSUPPORTED
 };
 
+// Prim families a raster launch has to handle; the kernel is specialised on the
+// set so that rect-only passes carry neither the registers nor the code of the
+// texture / blur / clip paths.  The host derives it from the shaders and blend
+// states of the launch's draws (conservatively: a draw not marked WR_DF_SIMPLE
+// gets WR_FEAT_GENERIC, and a SIMPLE draw that yields anything but a solid is
+// counted as unsupported instead of being drawn wrongly).
+enum WrFeat {
+  WR_FEAT_TEX = 1,       // WR_PK_TEX_RGBA8 row fast path (composite, images)
+  WR_FEAT_R8TEX = 2,     // glyph blits / masked solids (WrTexRec)
+  WR_FEAT_GENERIC = 4,   // out-of-line per-pixel path: any blend key, linear filters, fragment-shader tails
+  WR_FEAT_BLUR = 8,      // cs_blur
+  WR_FEAT_CLIP = 16,     // cs_clip_rectangle / cs_clip_box_shadow (R8 targets)
+};
+
 struct WrTexDesc {
   const void* ptr;   // HBM address (nullptr -> swgl's 1x1 transparent null sampler)
   int32_t width, height;
@@ -88,6 +102,7 @@ enum WrDrawFlags {
   WR_DF_DEPTH_LESS = 4,    // GL_LESS instead of GL_LEQUAL
   WR_DF_CLEAR_COLOR = 8,   // WR_SH_CLEAR_OP
   WR_DF_CLEAR_DEPTH = 16,
+  WR_DF_SIMPLE = 32,       // host promise: every prim of this draw is a solid with blend NONE/PREMULT (see WrFeat)
 };
 
 struct WrDrawDesc {
@@ -173,7 +188,7 @@ struct WrPrim {
   float fcolor[4];          // float colour for the fragment-shader (tail) path
   int32_t tex_slot;         // sampler slot
   int32_t mask_off[2];      // WR_PK_SOLID_MASKED: target pixel - mask texel (swgl_ClipMaskOffset)
-  int32_t pad[1];
+  int32_t rows_linear;      // 1: edge interpolants at row k equal L0 + k*slope exactly (closed form of Edge::nextRow)
 };
 
 // Compact per-prim record the raster stage streams (32 B, dense array): the
@@ -209,6 +224,10 @@ struct WrTexRec {
   // clamping), texel (ix0 + n, iy0 + row) for span pixel n; tix[] = columns of the <= 3 tail pixels
   int32_t unit, ix0, iy0;
   int32_t tix[3];
+  // WR_PK_TEX_RGBA8 on the nearest-fast path (blendTextureNearestFast): texel column =
+  // clamp(ix0 + n, tix[0], tix[1]).  `simple` = 3: rows step one texel per target row, source row =
+  // clamp(iy0 + tix[2] * (y - y0), unit & 0xFFFF, unit >> 16).  `simple` = 2: the source row is
+  // evaluated per lane-row from (lv0, lvs) (wr_texrow_entry; tix[2] = rows_linear; -1 = general path).
 };
 
 // One separable Gaussian pass (cs_blur.glsl + swgl_ext.h:947-996, texture.h:1165-1308).
