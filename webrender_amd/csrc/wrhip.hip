@@ -237,8 +237,11 @@ struct Context {
   WrPrim* dprims = nullptr; size_t dprims_cap = 0;
   WrRec* drecs = nullptr;
   WrAux* daux = nullptr;
+  float* dvtab = nullptr;        // per-row v tables of nearest-fast textured prims (WrDrawDesc::vtab_base)
+  size_t dvtab_cap = 0;
   unsigned long long* dmasks = nullptr; size_t dmasks_cap = 0;
   WrUnsupportedCounters* dcounters = nullptr;
+  WrUnsupportedCounters seen = {};
   // HBM pool for texture storage: per-frame textures (GpuBufferF/I, render
   // targets) are recycled without hipMalloc/hipFree or a device sync; reuse is
   // safe because every consumer runs on this context's single stream.
@@ -678,7 +681,7 @@ Context::~Context() {
   for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
-  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(daux); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
+  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(daux); wrrt::dev_free(dvtab); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::stream_destroy(stream);
@@ -704,6 +707,7 @@ void flush_work(const std::vector<int>& sel_in) {
   std::vector<uint8_t> inst;
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0, bins_rgba = 0;
   bool any_depth = false;
+  size_t vtab_cursor = 0;
   uint64_t algo_bytes = 0, pixels = 0;
   for (int oi = 0; oi < n_targets; oi++) {
     TargetWork& w = c->work[sel[oi]];
@@ -743,6 +747,18 @@ void flush_work(const std::vector<int>& sel_in) {
       if (d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) any_depth = true;
       d.first_prim = prim_cursor;
       prim_cursor += d.count;
+      // per-row v table budget for draws whose prims can take the nearest-fast texture path
+      d.vtab_base = -1; d.vtab_rows = 0;
+      if (T.format == WR_FMT_RGBA8 && !(d.flags & WR_DF_SIMPLE) &&
+          (d.shader == WR_SH_COMPOSITE || d.shader == WR_SH_COMPOSITE_FAST || d.shader == WR_SH_CS_SCALE ||
+           d.shader == WR_SH_PS_QUAD_TEXTURED)) {
+        const int rows = std::max(0, std::min(d.clip[3], t.height) - std::max(d.clip[1], 0));
+        const size_t need = (size_t)rows * d.count;
+        if (rows > 0 && vtab_cursor + need <= ((size_t)64 << 20)) {
+          d.vtab_base = (int)vtab_cursor; d.vtab_rows = rows;
+          vtab_cursor += need;
+        }
+      }
       draws.push_back(d);
     }
     T.end_prim = prim_cursor;
@@ -802,6 +818,12 @@ void flush_work(const std::vector<int>& sel_in) {
       wrrt::dev_free(c->daux);
       c->daux = (WrAux*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrAux));
     }
+    if (c->dvtab_cap < vtab_cursor + 1) {
+      wrrt::stream_sync(c->stream);
+      wrrt::dev_free(c->dvtab);
+      c->dvtab_cap = (vtab_cursor + 1) * 2;
+      c->dvtab = (float*)wrrt::dev_alloc(c->dvtab_cap * sizeof(float));
+    }
     if (c->dmasks_cap < (size_t)n_words + 1) {
       wrrt::stream_sync(c->stream);
       wrrt::dev_free(c->dmasks);
@@ -817,7 +839,7 @@ void flush_work(const std::vector<int>& sel_in) {
     const uint8_t* dinst = darena + off_inst;
     if (n_prims > 0) {
       WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, c->daux, n_prims,
-                dtargets, c->dmasks, c->dcounters);
+                dtargets, c->dmasks, c->dvtab, c->dcounters);
       c->stats.kernel_launches += 1;
     }
 #ifdef WRHIP_HOSTSIM
@@ -873,7 +895,7 @@ void flush_work(const std::vector<int>& sel_in) {
 #define WR_RASTER_F(FMT, DEPTH, FEAT, NB, OFF)                                                                      \
   do {                                                                                                              \
     WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), NB, 256, c->stream, dtargets, n_targets, ddraws,             \
-              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrAux*)c->daux, c->dmasks, OFF);             \
+              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrAux*)c->daux, (const float*)c->dvtab, c->dmasks, OFF);             \
     c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
   } while (0)
     // smallest instantiated superset of the launch's feature set
@@ -1659,6 +1681,19 @@ void Finish(void) {
   flush_all();
   flush_uploads();
   wrrt::stream_sync(ctx->stream);
+  {
+    // prims the device could not draw faithfully are reported, never dropped silently
+    WrUnsupportedCounters h;
+    wrrt::d2h(&h, ctx->dcounters, sizeof(h), ctx->stream);
+    wrrt::stream_sync(ctx->stream);
+    if (h.unsupported_prims != ctx->seen.unsupported_prims || h.perspective_prims != ctx->seen.perspective_prims) {
+      fprintf(stderr, "libwrhip: %u prim(s) on not-yet-implemented paths (AA / rotated / masked-textured / blend override), %u perspective\n",
+              h.unsupported_prims - ctx->seen.unsupported_prims, h.perspective_prims - ctx->seen.perspective_prims);
+    }
+    static const bool dbgc = getenv("WRHIP_DEBUG_COUNTERS") != nullptr;
+    if (dbgc) fprintf(stderr, "libwrhip dbg counters: %u %u %u %u %u %u\n", h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5]);
+    ctx->seen = h;
+  }
   // externally backed default framebuffer: make the result visible to the host
   Framebuffer* fb = ctx->framebuffers.find(0);
   if (fb && fb->color_attachment) {

@@ -1555,7 +1555,7 @@ WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDes
 // part of what blendTextureNearestFast / needsTextureLinear (swgl_ext.h:475-587)
 // decide, evaluated once per prim here instead of per pixel in the raster stage.  Returns false when the x part of the decision already rules
 // the nearest-fast path out (scaled or subpixel-offset sampling).
-WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& T) {
+WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& T, WrUnsupportedCounters* cnt) {
   if (!t.ptr || P.uvLs[0] != 0.0f || P.uvRs[0] != 0.0f || P.uvL0[1] != P.uvR0[1] || P.uvLs[1] != P.uvRs[1]) return false;
   const WrTexRow r = wr_tex_row(P, t, P.y0);       // u, su, span and the x clamps do not depend on the row here
   if (r.span == 0) return false;
@@ -1585,6 +1585,9 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   const int th = t.height;
   const float H = float(th);
   const float vstep = P.uvLs[1] * H;             // exact when H is a power of two
+  atomicAdd(&cnt->dbg[0], 1u);
+  if (P.rows_linear) atomicAdd(&cnt->dbg[1], 1u);
+  if (vstep == 1.0f || vstep == -1.0f) atomicAdd(&cnt->dbg[2], 1u);
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG_ROWS")) fprintf(stderr, "texrow: lin %d th %d vstep %.9g L0*H %.9g rows %d\n", P.rows_linear, th, vstep, P.uvL0[1] * H, P.y1 - P.y0);
 #endif
@@ -1597,6 +1600,7 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
       const int minUy = int(P.uv_bounds[1] * H), maxUy = int(P.uv_bounds[3] * H);
       if (minUy <= maxUy) {
         const int lo = wr_iclamp(minUy, 0, th - 1), hi = wr_iclamp(maxUy, 0, th - 1);
+        atomicAdd(&cnt->dbg[3], 1u);
         T.iy0 = int(py0);
         T.tix[2] = vstep > 0.0f ? 1 : -1;
         T.unit = lo | (hi << 16);
@@ -1606,10 +1610,9 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   }
   return true;
 }
-WR_DEVICE int wr_texrow_entry(const WrTexRec& T, int rows_linear, int k) {
+WR_DEVICE int wr_texrow_entry(const WrTexRec& T, float ov) {
   const int th = int(T.wh >> 16);
   const float H = float(th);
-  const float ov = wr_row_interp(T.lv0, T.lvs, k, rows_linear != 0);
   const float py0 = ov * H;
   if (T.unit && (int(py0 * 4.0f + 0.5f) & 3) != 2) return -1;
   const int iy = int(ov * H), minUy = int(T.ub1 * H), maxUy = int(T.ub3 * H);
@@ -1621,7 +1624,7 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
                                 WrRec* __restrict__ recs, WrAux* __restrict__ aux, int n_prims,
                                 const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
-                                WrUnsupportedCounters* cnt) {
+                                float* __restrict__ vtab, WrUnsupportedCounters* cnt) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = gid < n_prims;
   WrPrim P;
@@ -1644,8 +1647,22 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
     if (P.kind == WR_PK_TEX_RGBA8) {
       const WrDrawDesc& d = draws[P.draw];
       WrTexRec T;
-      if (wr_texrow_x_setup(P, d.tex[P.tex_slot], T)) {
-        if (T.simple == 2) T.tix[2] = P.rows_linear;      // rows resolved per lane-row in the raster stage (wr_texrow_entry)
+      const int rows = P.y1 - P.y0;
+      if (wr_texrow_x_setup(P, d.tex[P.tex_slot], T, cnt) && (T.simple == 3 || (d.vtab_base >= 0 && rows <= d.vtab_rows))) {
+        if (T.simple == 2) {
+          // v of every target row, accumulated exactly like Edge::nextRow (a few hundred dependent adds)
+          T.iy0 = d.vtab_base + (gid - d.first_prim) * d.vtab_rows;
+          float* vp = vtab + T.iy0;
+          const float st = T.lvs;
+          float v = T.lv0;
+          int k = 0;
+          for (; k + 4 <= rows; k += 4) {
+            const float a = v, b = a + st, c = b + st, e = c + st;
+            v = e + st;
+            vp[k] = a; vp[k + 1] = b; vp[k + 2] = c; vp[k + 3] = e;
+          }
+          for (; k < rows; k++, v += st) vp[k] = v;
+        }
         aux[gid].tex = T;
       } else {
         aux[gid].tex.simple = 0;
@@ -2248,7 +2265,7 @@ template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uint32_t (&dep)[4 * R],
                              const int x0, const int y0, const int x1, const int y1, const uint32_t z,
                              const uint32_t kbf, const uint32_t c0, const uint32_t c1,
-                             const WrPrim* Pp, const WrAux* Ap, const WrDrawDesc* draws,
+                             const WrPrim* Pp, const WrAux* Ap, const WrDrawDesc* draws, const float* __restrict__ vtab,
                              const int px, const int py, const int wx0, const int wy0) {
   constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
   constexpr int NPX = 4 * R;
@@ -2351,7 +2368,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       bool rowfast = false;
       if (cy[j] && inspan) {
         const int srow = T.simple == 3 ? wr_iclamp(T.iy0 + T.tix[2] * (y - T.y0), T.unit & 0xFFFF, T.unit >> 16)
-                                        : wr_texrow_entry(T, T.tix[2], y - T.y0);
+                                        : wr_texrow_entry(T, vtab[T.iy0 + (y - T.y0)]);
         rowfast = srow >= 0;
         if (rowfast) {
           const uint32_t* rp = sbuf + (size_t)srow * T.stride;
@@ -2605,7 +2622,7 @@ template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void __launch_bounds__(1024 / R)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
-                 const WrRec* __restrict__ recs, const WrAux* __restrict__ aux,
+                 const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                  unsigned long long* __restrict__ masks, int bin_offset) {
   constexpr int NPX = 4 * R, STRIP = 4 * R;
   const int bin = blockIdx.x + bin_offset;
@@ -2689,7 +2706,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                                   draws, &prims[base + bit], px, py);
       else
         wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, &prims[base + bit],
-                                     &aux[base + bit], draws, px, py, wx0, wy0);
+                                     &aux[base + bit], draws, vtab, px, py, wx0, wy0);
     }
   }
 #else
@@ -2732,7 +2749,7 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
           aux[base + bit].tex.simple)
         wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[base + bit].tex, draws, &prims[base + bit], px, py);
       else
-        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], &aux[base + bit], draws, px, py, wx0, wy0);
+        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], &aux[base + bit], draws, vtab, px, py, wx0, wy0);
     }
   }
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the

@@ -124,6 +124,8 @@ struct WrDrawDesc {
   int32_t inst_stride;
   int32_t attr_off[WR_MAX_ATTRIBS];   // byte offset of the shader's k-th instance attribute, -1 = unbound (zeros)
   int32_t attr_bytes[WR_MAX_ATTRIBS];
+  int32_t vtab_base;     // first entry of this draw's per-row v table (-1: none), vtab_rows entries per instance
+  int32_t vtab_rows;
   uint32_t attr_u16;     // bit k: attribute k is made of 16-bit unsigned integers (VertexAttributeKind::U16) // bytes provided by the VAO for that attribute (VertexAttrib::size)
   WrTexDesc tex[WR_MAX_TEX];
 };
@@ -226,8 +228,9 @@ struct WrTexRec {
   int32_t tix[3];
   // WR_PK_TEX_RGBA8 on the nearest-fast path (blendTextureNearestFast): texel column =
   // clamp(ix0 + n, tix[0], tix[1]).  `simple` = 3: rows step one texel per target row, source row =
-  // clamp(iy0 + tix[2] * (y - y0), unit & 0xFFFF, unit >> 16).  `simple` = 2: the source row is
-  // evaluated per lane-row from (lv0, lvs) (wr_texrow_entry; tix[2] = rows_linear; -1 = general path).
+  // clamp(iy0 + tix[2] * (y - y0), unit & 0xFFFF, unit >> 16).  `simple` = 2: v of target row y is
+  // vtab[iy0 + y - y0] (the edge interpolant accumulated row by row by the setup kernel, as
+  // Edge::nextRow does); the raster stage derives the source row / texel-centre test from it.
 };
 
 // One separable Gaussian pass (cs_blur.glsl + swgl_ext.h:947-996, texture.h:1165-1308).
@@ -293,4 +296,5 @@ struct WrFlushParams {
 struct WrUnsupportedCounters {
   uint32_t unsupported_prims;
   uint32_t perspective_prims;
+  uint32_t dbg[6];          // diagnostics (WRHIP_DEBUG_COUNTERS)
 };
