@@ -1911,73 +1911,72 @@ WR_DEVICE float wr_clip_dist(const WrClipRec& C, float px, float py) {
 }
 WR_DEVICE float wr_step01(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
 
-__device__ __noinline__ uint32_t wr_clip_rect_pixel(const WrPrim* Pp, const WrClipRec* Cp, int x, int y) {
+struct WrRow4 { uint32_t v[4]; };
+
+// Four horizontally adjacent pixels (x .. x+3) of row y: the span-level setup is
+// evaluated once, each pixel then only classifies its chunk.
+__device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipRec* Cp, int x, int y) {
   const WrPrim& P = *Pp;
   const WrClipRec& C = *Cp;
+  WrRow4 out;
+  out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
   const int k = y - P.y0;
-  const float Lu = wr_accum(P.uvL0[0], P.uvLs[0], k), Lv = wr_accum(P.uvL0[1], P.uvLs[1], k);
-  const float Ru = wr_accum(P.uvR0[0], P.uvRs[0], k), Rv = wr_accum(P.uvR0[1], P.uvRs[1], k);
+  const bool lin = P.rows_linear != 0;
+  const float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+  const float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
   const float start = float(P.x0) + 0.5f - P.xl;
   const float ou = Lu + su * start, ov = Lv + sv * start;
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
-  const int n = x - P.x0;
   const float mode = C.mode;
   // the four SIMD lanes of vLocalPos.xy at the span start (init_interp)
-  float lx[4], ly[4];
-  lx[0] = ou; ly[0] = ov;
-  for (int i = 1; i < 4; i++) { lx[i] = lx[i - 1] + su; ly[i] = ly[i - 1] + sv; }
-  if (n < span) {
-    float w = C.w;
-    if (w <= 0.0f) return 0u;                       // swgl_commitSolidR8(0.0)
-    w = 1.0f / w;
-    float px4[4], py4[4];
-    for (int i = 0; i < 4; i++) { px4[i] = lx[i] * w; py4[i] = ly[i] * w; }
-    const float p0x = px4[0], p0y = py4[0];
-    const float stx = (su * 4.0f) * w, sty = (sv * 4.0f) * w;
+  const float lx0 = ou, lx1 = lx0 + su, lx2 = lx1 + su, lx3 = lx2 + su;
+  const float ly0 = ov, ly1 = ly0 + sv, ly2 = ly1 + sv, ly3 = ly2 + sv;
+  // ---- span-level setup (cs_clip_rectangle.glsl:223-420), once per row
+  const float wv = C.w;
+  const float w = 1.0f / wv;
+  const float p0x = lx0 * w, p0y = ly0 * w, p1x = lx1 * w, p1y = ly1 * w;
+  const float stx = (su * 4.0f) * w, sty = (sv * 4.0f) * w;
+  const float aa_range = 1.0f / (fabsf(p1x - p0x) + fabsf(p1y - p0y));
+  int n1 = 0, n2 = 0, n3 = 0, n4 = 0, start_corner = -1, end_corner = -1;
+  if (span > 0 && wv > 0.0f) {
     const float step_scale = wr_max(stx * stx + sty * sty, 1.0e-6f);
-    const float aa_range = 1.0f / (fabsf(px4[1] - px4[0]) + fabsf(py4[1] - py4[0]));
     float aa_margin = 1.0f / sqrtf(aa_range * aa_range * step_scale);
-    float cr[4];
-    if (C.fast) { cr[0] = -C.params[0] - C.params[2]; cr[1] = -C.params[1] - C.params[2]; cr[2] = C.params[0] + C.params[2]; cr[3] = C.params[1] + C.params[2]; }
-    else { cr[0] = C.bounds[0]; cr[1] = C.bounds[1]; cr[2] = C.bounds[2]; cr[3] = C.bounds[3]; }
+    float cr0, cr1, cr2, cr3;
+    if (C.fast) { cr0 = -C.params[0] - C.params[2]; cr1 = -C.params[1] - C.params[2]; cr2 = C.params[0] + C.params[2]; cr3 = C.params[1] + C.params[2]; }
+    else { cr0 = C.bounds[0]; cr1 = C.bounds[1]; cr2 = C.bounds[2]; cr3 = C.bounds[3]; }
     const bool negx = stx < 0.0f, negy = sty < 0.0f;
-    float cd[4] = {(negx ? cr[2] : cr[0]) - p0x, (negy ? cr[3] : cr[1]) - p0y, (negx ? cr[0] : cr[2]) - p0x, (negy ? cr[1] : cr[3]) - p0y};
+    float cd0 = (negx ? cr2 : cr0) - p0x, cd1 = (negy ? cr3 : cr1) - p0y, cd2 = (negx ? cr0 : cr2) - p0x, cd3 = (negy ? cr1 : cr3) - p0y;
     const float rsx = 1.0f / stx, rsy = 1.0f / sty;
-    cd[0] = stx != 0.0f ? cd[0] * rsx : 1.0e6f * wr_step01(0.0f, cd[0]);
-    cd[1] = sty != 0.0f ? cd[1] * rsy : 1.0e6f * wr_step01(0.0f, cd[1]);
-    cd[2] = stx != 0.0f ? cd[2] * rsx : 1.0e6f * wr_step01(0.0f, cd[2]);
-    cd[3] = sty != 0.0f ? cd[3] * rsy : 1.0e6f * wr_step01(0.0f, cd[3]);
-    float opaque_start = wr_max(cd[0], cd[1]), opaque_end = wr_min(cd[2], cd[3]);
+    cd0 = stx != 0.0f ? cd0 * rsx : 1.0e6f * wr_step01(0.0f, cd0);
+    cd1 = sty != 0.0f ? cd1 * rsy : 1.0e6f * wr_step01(0.0f, cd1);
+    cd2 = stx != 0.0f ? cd2 * rsx : 1.0e6f * wr_step01(0.0f, cd2);
+    cd3 = sty != 0.0f ? cd3 * rsy : 1.0e6f * wr_step01(0.0f, cd3);
+    float opaque_start = wr_max(cd0, cd1), opaque_end = wr_min(cd2, cd3);
     float aa_start = opaque_start, aa_end = opaque_end;
-    int start_corner = -1, end_corner = -1;          // which plane/corner was hit (general path)
-    float pl[4][3];
-    if (C.fast) {
-      const float offset = (C.params[0] + C.params[1] + C.params[2]) * C.params[2];
-      const float z = C.params[2];
-      pl[0][0] = -z; pl[0][1] = -z; pl[1][0] = z; pl[1][1] = -z; pl[2][0] = z; pl[2][1] = z; pl[3][0] = -z; pl[3][1] = z;
-      for (int c = 0; c < 4; c++) pl[c][2] = offset;
-    } else {
-      for (int c = 0; c < 4; c++) { pl[c][0] = C.plane[c][0]; pl[c][1] = C.plane[c][1]; pl[c][2] = C.plane[c][2]; }
-    }
+    const float offset = (C.params[0] + C.params[1] + C.params[2]) * C.params[2], z = C.params[2];
+#pragma unroll
     for (int c = 0; c < 4; c++) {                    // CLIP_CORNER in TL, TR, BR, BL order
-      const float dist = (p0x * pl[c][0] + p0y * pl[c][1]) - pl[c][2];
-      const float scale = -(stx * pl[c][0] + sty * pl[c][1]);
+      float pa, pb, pc;
+      if (C.fast) { pa = (c == 0 || c == 3) ? -z : z; pb = (c < 2) ? -z : z; pc = offset; }
+      else { pa = C.plane[c][0]; pb = C.plane[c][1]; pc = C.plane[c][2]; }
+      const float dist = (p0x * pa + p0y * pb) - pc;
+      const float scale = -(stx * pa + sty * pb);
       if (scale >= 0.0f) {
         if (dist > opaque_start * scale) {
           start_corner = c;
           const float inv_scale = 1.0f / wr_max(scale, 1.0e-6f);
           opaque_start = dist * inv_scale;
-          const float apex = (0.7071f - 0.5f) * 2.0f * fabsf(pl[c][0] * pl[c][1]);
+          const float apex = (0.7071f - 0.5f) * 2.0f * fabsf(pa * pb);
           aa_start = opaque_start - apex * inv_scale;
         }
       } else if (dist > opaque_end * scale) {
         end_corner = c;
         const float inv_scale = 1.0f / wr_min(scale, -1.0e-6f);
         opaque_end = dist * inv_scale;
-        const float apex = (0.7071f - 0.5f) * 2.0f * fabsf(pl[c][0] * pl[c][1]);
+        const float apex = (0.7071f - 0.5f) * 2.0f * fabsf(pa * pb);
         aa_end = opaque_end - apex * inv_scale;
       }
     }
@@ -1988,61 +1987,77 @@ __device__ __noinline__ uint32_t wr_clip_rect_pixel(const WrPrim* Pp, const WrCl
     const int Cc = int(wr_clamp(sl - ss * floorf(opaque_end), 0.0f, sl)) >> 2, D = int(wr_clamp(sl - ss * ceilf(aa_end), 0.0f, sl)) >> 2;
     // remaining-length bookkeeping of the five phases, in chunks
     const int S = span >> 2;
-    const int R1 = S > A ? A : S, n1 = S - R1;
-    const int n2 = R1 > B ? R1 - B : 0, R2 = R1 - n2;
-    const int n3 = R2 > Cc ? R2 - Cc : 0, R3 = R2 - n3;
-    const int n4 = R3 > D ? R3 - D : 0;
-    const int c = n >> 2, lane = n & 3;
-    if (c < n1) return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
-    // start of the first AA run
-    float qx = px4[lane], qy = py4[lane];
-    if (n1 > 0) { qx = qx + float(n1) * stx; qy = qy + float(n1) * sty; }
-    int corner = -1;
-    if (c < n1 + n2) {
-      qx = wr_accum(qx, stx, c - n1); qy = wr_accum(qy, sty, c - n1);
-      corner = start_corner;
-    } else if (c < n1 + n2 + n3) {
-      return uint32_t(wr_round_pixel(1.0f - mode)) & 0xFFFF;
-    } else if (c < n1 + n2 + n3 + n4) {
-      qx = wr_accum(qx, stx, n2); qy = wr_accum(qy, sty, n2);
-      if (n3 > 0) { qx = qx + float(n3) * stx; qy = qy + float(n3) * sty; }
-      qx = wr_accum(qx, stx, c - n1 - n2 - n3); qy = wr_accum(qy, sty, c - n1 - n2 - n3);
-      corner = end_corner;
-    } else {
-      return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
-    }
-    float dist;
-    if (C.fast) {
-      dist = wr_clip_dist(C, qx, qy);
-    } else {
-      const float rect = wr_max(wr_max(C.bounds[0] - qx, qx - C.bounds[2]), wr_max(C.bounds[1] - qy, qy - C.bounds[3]));
-      dist = rect;
-      if (corner >= 0 && qx * C.plane[corner][0] + qy * C.plane[corner][1] > C.plane[corner][2]) {
-        const float ex = qx - C.center_radius[corner][0], ey = qy - C.center_radius[corner][1];
-        const float prx = ex * C.center_radius[corner][2], pry = ey * C.center_radius[corner][3];
-        const float g = (ex * prx + ey * pry) - 1.0f;
-        const float dgx = (1.0f + 1.0f) * prx, dgy = (1.0f + 1.0f) * pry;
-        dist = g * (1.0f / sqrtf(dgx * dgx + dgy * dgy));
-      }
-    }
-    const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
-    return uint32_t(wr_round_pixel(((1.0f - alpha) - alpha) * mode + alpha)) & 0xFFFF;
+    const int R1 = S > A ? A : S;
+    n1 = S - R1;
+    n2 = R1 > B ? R1 - B : 0;
+    const int R2 = R1 - n2;
+    n3 = R2 > Cc ? R2 - Cc : 0;
+    const int R3 = R2 - n3;
+    n4 = R3 > D ? R3 - D : 0;
   }
-  // ---- fragment shader (tail chunk): lanes stepped by `span` at once
-  float tx[4], ty[4];
+  const uint32_t v_clear = uint32_t(wr_round_pixel(mode)) & 0xFFFF, v_opaque = uint32_t(wr_round_pixel(1.0f - mode)) & 0xFFFF;
+  // tail chunk (fragment shader): lanes stepped by `span` at once
+  const float chunks = float(span) * 0.25f;
+  const float tjx = (su * 4.0f) * chunks, tjy = (sv * 4.0f) * chunks;
+#pragma unroll
   for (int i = 0; i < 4; i++) {
-    tx[i] = lx[i]; ty[i] = ly[i];
-    if (span > 0) { const float chunks = float(span) * 0.25f; tx[i] = tx[i] + (su * 4.0f) * chunks; ty[i] = ty[i] + (sv * 4.0f) * chunks; }
+    const int n = x + i - P.x0;
+    if (n < 0 || n >= len) continue;
+    const int lane = n & 3;
+    const float lxl = lane == 0 ? lx0 : (lane == 1 ? lx1 : (lane == 2 ? lx2 : lx3));
+    const float lyl = lane == 0 ? ly0 : (lane == 1 ? ly1 : (lane == 2 ? ly2 : ly3));
+    if (n < span) {
+      if (wv <= 0.0f) { out.v[i] = 0; continue; }     // swgl_commitSolidR8(0.0)
+      const int c = n >> 2;
+      if (c < n1) { out.v[i] = v_clear; continue; }
+      float qx = lxl * w, qy = lyl * w;
+      if (n1 > 0) { qx = qx + float(n1) * stx; qy = qy + float(n1) * sty; }
+      int corner;
+      if (c < n1 + n2) {
+        qx = wr_accum(qx, stx, c - n1); qy = wr_accum(qy, sty, c - n1);
+        corner = start_corner;
+      } else if (c < n1 + n2 + n3) {
+        out.v[i] = v_opaque; continue;
+      } else if (c < n1 + n2 + n3 + n4) {
+        qx = wr_accum(qx, stx, n2); qy = wr_accum(qy, sty, n2);
+        if (n3 > 0) { qx = qx + float(n3) * stx; qy = qy + float(n3) * sty; }
+        qx = wr_accum(qx, stx, c - n1 - n2 - n3); qy = wr_accum(qy, sty, c - n1 - n2 - n3);
+        corner = end_corner;
+      } else {
+        out.v[i] = v_clear; continue;
+      }
+      float dist;
+      if (C.fast) {
+        dist = wr_clip_dist(C, qx, qy);
+      } else {
+        dist = wr_max(wr_max(C.bounds[0] - qx, qx - C.bounds[2]), wr_max(C.bounds[1] - qy, qy - C.bounds[3]));
+        if (corner >= 0 && qx * C.plane[corner][0] + qy * C.plane[corner][1] > C.plane[corner][2]) {
+          const float ex = qx - C.center_radius[corner][0], ey = qy - C.center_radius[corner][1];
+          const float prx = ex * C.center_radius[corner][2], pry = ey * C.center_radius[corner][3];
+          const float g = (ex * prx + ey * pry) - 1.0f;
+          const float dgx = (1.0f + 1.0f) * prx, dgy = (1.0f + 1.0f) * pry;
+          dist = g * (1.0f / sqrtf(dgx * dgx + dgy * dgy));
+        }
+      }
+      const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
+      out.v[i] = uint32_t(wr_round_pixel(((1.0f - alpha) - alpha) * mode + alpha)) & 0xFFFF;
+    } else {
+      // fragment shader: this pixel's lane and lanes 0/1 (fwidth) of its chunk
+      const int m = (n - span) >> 2;
+      float t0x = lx0, t0y = ly0, t1x = lx1, t1y = ly1, tlx = lxl, tly = lyl;
+      if (span > 0) { t0x = t0x + tjx; t0y = t0y + tjy; t1x = t1x + tjx; t1y = t1y + tjy; tlx = tlx + tjx; tly = tly + tjy; }
+      const float sx4 = (su * 4.0f) * 1.0f, sy4 = (sv * 4.0f) * 1.0f;
+      const float f0x = wr_accum(t0x, sx4, m) / wv, f0y = wr_accum(t0y, sy4, m) / wv;
+      const float f1x = wr_accum(t1x, sx4, m) / wv, f1y = wr_accum(t1y, sy4, m) / wv;
+      const float qx = wr_accum(tlx, sx4, m) / wv, qy = wr_accum(tly, sy4, m) / wv;
+      const float far = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));
+      const float dist = wr_clip_dist(C, qx, qy);
+      const float alpha = wr_clamp(0.5f - dist * far, 0.0f, 1.0f);
+      const float fin = ((1.0f - alpha) - alpha) * mode + alpha;
+      out.v[i] = uint32_t(wr_round_pixel(wv > 0.0f ? fin : 0.0f)) & 0xFFFF;
+    }
   }
-  const int lane = (n - span) & 3, m = (n - span) >> 2;
-  float fx[2], fy[2], qx = 0.0f, qy = 0.0f;
-  for (int i = 0; i < 2; i++) { fx[i] = wr_accum(tx[i], (su * 4.0f) * 1.0f, m) / C.w; fy[i] = wr_accum(ty[i], (sv * 4.0f) * 1.0f, m) / C.w; }
-  qx = wr_accum(tx[lane], (su * 4.0f) * 1.0f, m) / C.w; qy = wr_accum(ty[lane], (sv * 4.0f) * 1.0f, m) / C.w;
-  const float aa_range = 1.0f / (fabsf(fx[1] - fx[0]) + fabsf(fy[1] - fy[0]));
-  const float dist = wr_clip_dist(C, qx, qy);
-  const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
-  const float fin = ((1.0f - alpha) - alpha) * mode + alpha;
-  return uint32_t(wr_round_pixel(C.w > 0.0f ? fin : 0.0f)) & 0xFFFF;
+  return out;
 }
 
 // ---------------------------------------------------------------------------
@@ -2072,118 +2087,157 @@ WR_DEVICE float wr_box_shade(const WrBoxRec& B, const WrTexDesc& t, float ul, fl
   return (alpha - B.mode) * in + B.mode;
 }
 
-__device__ __noinline__ uint32_t wr_box_shadow_pixel(const WrPrim* Pp, const WrBoxRec* Bp, int x, int y) {
+WR_DEVICE float wr_sel4(float a0, float a1, float a2, float a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
+
+// Four horizontally adjacent pixels (x .. x+3) of row y: one span-level setup and
+// one walk of the nine-patch state machine serve all four.
+__device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxRec* Bp, int x, int y) {
   const WrPrim& P = *Pp;
   const WrBoxRec& B = *Bp;
+  WrRow4 out;
+  out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
   const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear};
   const int k = y - P.y0;
+  const bool lin = P.rows_linear != 0;     // (the vLocalPos interpolants share the uv ones' linearity in practice; checked below)
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float start = float(P.x0) + 0.5f - P.xl;
-  // row interpolants of vUv and vLocalPos.xy
+  // row interpolants: c = 0,1 vUv; 2,3 vLocalPos.xy
   float o4[4], s4[4];
   {
-    const float L[4] = {wr_accum(P.uvL0[0], P.uvLs[0], k), wr_accum(P.uvL0[1], P.uvLs[1], k), wr_accum(B.lpL0[0], B.lpLs[0], k), wr_accum(B.lpL0[1], B.lpLs[1], k)};
-    const float R[4] = {wr_accum(P.uvR0[0], P.uvRs[0], k), wr_accum(P.uvR0[1], P.uvRs[1], k), wr_accum(B.lpR0[0], B.lpRs[0], k), wr_accum(B.lpR0[1], B.lpRs[1], k)};
-    for (int i = 0; i < 4; i++) { s4[i] = (R[i] - L[i]) * stepScale; o4[i] = L[i] + s4[i] * start; }
+    const float L0 = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+    const float R0 = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+    const float L2 = wr_accum(B.lpL0[0], B.lpLs[0], k), L3 = wr_accum(B.lpL0[1], B.lpLs[1], k);
+    const float R2 = wr_accum(B.lpR0[0], B.lpRs[0], k), R3 = wr_accum(B.lpR0[1], B.lpRs[1], k);
+    s4[0] = (R0 - L0) * stepScale; o4[0] = L0 + s4[0] * start;
+    s4[1] = (R1 - L1) * stepScale; o4[1] = L1 + s4[1] * start;
+    s4[2] = (R2 - L2) * stepScale; o4[2] = L2 + s4[2] * start;
+    s4[3] = (R3 - L3) * stepScale; o4[3] = L3 + s4[3] * start;
   }
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
-  const int n = x - P.x0;
+  const int n0 = x - P.x0;
   const float mode = B.mode;
+  const uint32_t v_clear = uint32_t(wr_round_pixel(mode)) & 0xFFFF;
   // SIMD lanes at the span start: [component][lane]
   float ln[4][4];
-  for (int c = 0; c < 4; c++) { ln[c][0] = o4[c]; for (int i = 1; i < 4; i++) ln[c][i] = ln[c][i - 1] + s4[c]; }
-  if (n >= span) {
-    // fragment shader
+#pragma unroll
+  for (int c = 0; c < 4; c++) { ln[c][0] = o4[c]; ln[c][1] = ln[c][0] + s4[c]; ln[c][2] = ln[c][1] + s4[c]; ln[c][3] = ln[c][2] + s4[c]; }
+  // ---- tail pixels: fragment shader
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int n = n0 + i;
+    if (n < span || n >= len || n < 0) continue;
     const int lane = (n - span) & 3, m = (n - span) >> 2;
     float v4[4];
+#pragma unroll
     for (int c = 0; c < 4; c++) {
-      float a = ln[c][lane];
+      float a = wr_sel4(ln[c][0], ln[c][1], ln[c][2], ln[c][3], lane);
       if (span > 0) a = a + (s4[c] * 4.0f) * (float(span) * 0.25f);
       v4[c] = wr_accum(a, (s4[c] * 4.0f) * 1.0f, m);
     }
     const float r = wr_box_shade(B, t, v4[0] / B.w, v4[1] / B.w, v4[2] / B.w, v4[3] / B.w);
-    return uint32_t(wr_round_pixel(B.w > 0.0f ? r : 0.0f)) & 0xFFFF;
+    out.v[i] = uint32_t(wr_round_pixel(B.w > 0.0f ? r : 0.0f)) & 0xFFFF;
   }
+  // ---- span pixels
+  const int first = n0 < 0 ? 0 : n0, last = (n0 + 3 < span - 1) ? n0 + 3 : span - 1;    // my pixels inside [0, span)
+  if (first > last) return out;
   float w = B.w;
-  if (w <= 0.0f) return 0u;
+  if (w <= 0.0f) return out;                 // swgl_commitSolidR8(0.0): zeros
   w = 1.0f / w;
   float cur[4][4], st[4];        // uv_linear.x, uv_linear.y, local_pos.x, local_pos.y lanes; per-chunk steps
-  for (int c = 0; c < 4; c++) { for (int i = 0; i < 4; i++) cur[c][i] = ln[c][i] * w; st[c] = (s4[c] * 4.0f) * w; }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) cur[c][i] = ln[c][i] * w;
+    st[c] = (s4[c] * 4.0f) * w;
+  }
   const float sl = float(span), ss = 4.0f;
-  int shadow_start_len, shadow_end_len, osteps[4];
+  int shadow_start_len, shadow_end_len, os0, os1, os2, os3;
   {
     const float p0x = cur[2][0], p0y = cur[3][0];
     const bool negx = st[2] < 0.0f, negy = st[3] < 0.0f;
-    float cd[4] = {(negx ? B.bounds[2] : B.bounds[0]) - p0x, (negy ? B.bounds[3] : B.bounds[1]) - p0y,
-                   (negx ? B.bounds[0] : B.bounds[2]) - p0x, (negy ? B.bounds[1] : B.bounds[3]) - p0y};
+    float cd0 = (negx ? B.bounds[2] : B.bounds[0]) - p0x, cd1 = (negy ? B.bounds[3] : B.bounds[1]) - p0y;
+    float cd2 = (negx ? B.bounds[0] : B.bounds[2]) - p0x, cd3 = (negy ? B.bounds[1] : B.bounds[3]) - p0y;
     const float rsx = 1.0f / st[2], rsy = 1.0f / st[3];
-    cd[0] = st[2] != 0.0f ? cd[0] * rsx : 1.0e6f * wr_step01(0.0f, cd[0]);
-    cd[1] = st[3] != 0.0f ? cd[1] * rsy : 1.0e6f * wr_step01(0.0f, cd[1]);
-    cd[2] = st[2] != 0.0f ? cd[2] * rsx : 1.0e6f * wr_step01(0.0f, cd[2]);
-    cd[3] = st[3] != 0.0f ? cd[3] * rsy : 1.0e6f * wr_step01(0.0f, cd[3]);
-    const float shadow_start = wr_max(cd[0], cd[1]), shadow_end = wr_min(cd[2], cd[3]);
+    cd0 = st[2] != 0.0f ? cd0 * rsx : 1.0e6f * wr_step01(0.0f, cd0);
+    cd1 = st[3] != 0.0f ? cd1 * rsy : 1.0e6f * wr_step01(0.0f, cd1);
+    cd2 = st[2] != 0.0f ? cd2 * rsx : 1.0e6f * wr_step01(0.0f, cd2);
+    cd3 = st[3] != 0.0f ? cd3 * rsy : 1.0e6f * wr_step01(0.0f, cd3);
+    const float shadow_start = wr_max(cd0, cd1), shadow_end = wr_min(cd2, cd3);
     shadow_start_len = int(wr_clamp(sl - ss * floorf(shadow_start), 0.0f, sl));
     shadow_end_len = int(wr_clamp(sl - ss * ceilf(shadow_end), 0.0f, sl));
     const float u0 = cur[0][0], v0 = cur[1][0];
     const bool ngx = st[0] < 0.0f, ngy = st[1] < 0.0f;
-    float od[4] = {(ngx ? B.edge[2] : B.edge[0]) - u0, (ngy ? B.edge[3] : B.edge[1]) - v0,
-                   (ngx ? B.edge[0] : B.edge[2]) - u0, (ngy ? B.edge[1] : B.edge[3]) - v0};
+    float od0 = (ngx ? B.edge[2] : B.edge[0]) - u0, od1 = (ngy ? B.edge[3] : B.edge[1]) - v0;
+    float od2 = (ngx ? B.edge[0] : B.edge[2]) - u0, od3 = (ngy ? B.edge[1] : B.edge[3]) - v0;
     const float rux = 1.0f / st[0], ruy = 1.0f / st[1];
-    od[0] = st[0] != 0.0f ? od[0] * rux : 1.0e6f * wr_step01(0.0f, od[0]);
-    od[1] = st[1] != 0.0f ? od[1] * ruy : 1.0e6f * wr_step01(0.0f, od[1]);
-    od[2] = st[0] != 0.0f ? od[2] * rux : 1.0e6f * wr_step01(0.0f, od[2]);
-    od[3] = st[1] != 0.0f ? od[3] * ruy : 1.0e6f * wr_step01(0.0f, od[3]);
+    od0 = st[0] != 0.0f ? od0 * rux : 1.0e6f * wr_step01(0.0f, od0);
+    od1 = st[1] != 0.0f ? od1 * ruy : 1.0e6f * wr_step01(0.0f, od1);
+    od2 = st[0] != 0.0f ? od2 * rux : 1.0e6f * wr_step01(0.0f, od2);
+    od3 = st[1] != 0.0f ? od3 * ruy : 1.0e6f * wr_step01(0.0f, od3);
     const float sel = float(shadow_end_len);
-    for (int i = 0; i < 4; i++) osteps[i] = int(wr_clamp(sl - ss * floorf(od[i]), sel, sl));
+    os0 = int(wr_clamp(sl - ss * floorf(od0), sel, sl)); os1 = int(wr_clamp(sl - ss * floorf(od1), sel, sl));
+    os2 = int(wr_clamp(sl - ss * floorf(od2), sel, sl)); os3 = int(wr_clamp(sl - ss * floorf(od3), sel, sl));
   }
+  // everything not claimed by the walk below is the solid lead-in / lead-out
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (n0 + i >= 0 && n0 + i < span) out.v[i] = v_clear;
   int R = span, pos = 0;
   if (R > shadow_start_len) {
     const int nb = R - shadow_start_len;
-    if (n < nb) return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
     const float f = float(nb / 4);
-    for (int c = 0; c < 4; c++) for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+    }
     R -= nb; pos += nb;
   }
-  const int lane = n & 3;
-  while (R > 0) {
-    if (n < pos + 4) {            // transitional chunk: per-fragment mapping
-      return uint32_t(wr_round_pixel(wr_box_shade(B, t, cur[0][lane], cur[1][lane], cur[2][lane], cur[3][lane]))) & 0xFFFF;
+  while (R > 0 && pos <= last) {
+    if (pos + 4 > first) {            // transitional chunk holds some of my pixels: per-fragment mapping
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int n = n0 + i;
+        if (n < pos || n >= pos + 4 || n >= span) continue;
+        const int lane = n & 3;
+        out.v[i] = uint32_t(wr_round_pixel(wr_box_shade(B, t, wr_sel4(cur[0][0], cur[0][1], cur[0][2], cur[0][3], lane),
+                                                         wr_sel4(cur[1][0], cur[1][1], cur[1][2], cur[1][3], lane),
+                                                         wr_sel4(cur[2][0], cur[2][1], cur[2][2], cur[2][3], lane),
+                                                         wr_sel4(cur[3][0], cur[3][1], cur[3][2], cur[3][3], lane)))) & 0xFFFF;
+      }
     }
-    for (int c = 0; c < 4; c++) for (int i = 0; i < 4; i++) cur[c][i] += st[c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) cur[c][i] += st[c];
+    }
     R -= 4; pos += 4;
     if (R <= shadow_end_len) break;
     int num_inside = R - 4 - shadow_end_len;
-    float ub[4] = {B.uv_bounds[0], B.uv_bounds[1], B.uv_bounds[2], B.uv_bounds[3]};
-    if (R >= osteps[1]) {
-      num_inside = wr_imin(num_inside, R - osteps[1]);
-    } else if (R >= osteps[3]) {
-      num_inside = wr_imin(num_inside, R - osteps[3]);
+    float ub0 = B.uv_bounds[0], ub1 = B.uv_bounds[1], ub2 = B.uv_bounds[2], ub3 = B.uv_bounds[3];
+    if (R >= os1) {
+      num_inside = wr_imin(num_inside, R - os1);
+    } else if (R >= os3) {
+      num_inside = wr_imin(num_inside, R - os3);
       const float cc = wr_clamp((B.uv_noclamp[3] - B.uv_noclamp[1]) * B.edge[1] + B.uv_noclamp[1], B.uv_bounds[1], B.uv_bounds[3]);
-      ub[1] = cc; ub[3] = cc;
+      ub1 = cc; ub3 = cc;
     }
-    if (R >= osteps[0]) {
-      num_inside = wr_imin(num_inside, R - osteps[0]);
-    } else if (R >= osteps[2]) {
-      num_inside = wr_imin(num_inside, R - osteps[2]);
+    if (R >= os0) {
+      num_inside = wr_imin(num_inside, R - os0);
+    } else if (R >= os2) {
+      num_inside = wr_imin(num_inside, R - os2);
       const float cc = wr_clamp((B.uv_noclamp[2] - B.uv_noclamp[0]) * B.edge[0] + B.uv_noclamp[0], B.uv_bounds[0], B.uv_bounds[2]);
-      ub[0] = cc; ub[2] = cc;
+      ub0 = cc; ub2 = cc;
     }
     if (num_inside > 0) {
-      if (n < pos + num_inside) {
+      if (pos + num_inside > first && pos <= last) {
         float pu[4], pv[4];
+#pragma unroll
         for (int i = 0; i < 4; i++) wr_box_map_uv(B, cur[0][i], cur[1][i], pu[i], pv[i]);
-        if (ub[0] == ub[2] && ub[1] == ub[3]) {
-          // centre sector: one texel for the whole run (pattern of the 4 lanes repeated)
-          const float texel = wr_r8_texture(t, wr_clamp(pu[lane], ub[0], ub[2]), wr_clamp(pv[lane], ub[1], ub[3]));
-          return uint32_t(wr_round_pixel(((1.0f - texel) - texel) * mode + texel)) & 0xFFFF;
-        }
-        // swgl_commitTextureLinear(R8, sColor0, uv, uv_bounds, NoColor/InvertColor, num_inside)
+        const bool centre = ub0 == ub2 && ub1 == ub3;
         const float W = float(t.width), H = float(t.height);
-        const int j = n - pos;
-        int v = 0;
-        int filter;
-        {   // needsTextureLinear (swgl_ext.h:553-587)
+        int filter = 0;
+        if (!centre) {   // needsTextureLinear (swgl_ext.h:553-587)
           if (t.width < 2) filter = 0;
           else if (pv[0] != pv[1]) filter = 1;
           else {
@@ -2195,33 +2249,54 @@ __device__ __noinline__ uint32_t wr_box_shadow_pixel(const WrPrim* Pp, const WrB
             else filter = 0;
           }
         }
-        if (filter == 0) {
-          // blendTextureNearestFast (swgl_ext.h:475-537)
-          const int ix = int(pu[0] * W), iy = int(pv[0] * H);
-          const int minUx = int(ub[0] * W), minUy = int(ub[1] * H), maxUx = int(ub[2] * W), maxUy = int(ub[3] * H);
-          const int srow = wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height);
-          const int minX = wr_iclamp(minUx, 0, t.width - 1), maxX = wr_iclamp(maxUx, minX, t.width - 1);
-          v = ((const uint8_t*)t.ptr)[(size_t)srow * t.stride + wr_iclamp(ix + j, minX, maxX)];
-        } else {
-          const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
-          float q[4], qy[4];
-          for (int i = 0; i < 4; i++) { q[i] = pu[i] * W * qs + qo; qy[i] = pv[i] * H * qs + qo; }
-          const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
-          const float minx = wr_max(ub[0] * W * qs + qo, 0.0f), miny = wr_max(ub[1] * H * qs + qo, 0.0f);
-          const float maxx = wr_max(ub[2] * W * qs + qo, minx), maxy = wr_max(ub[3] * H * qs + qo, miny);
-          int o[4];
-          wr_linear_span_pixel<1>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, filter, num_inside, j, o);
-          v = o[0];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int n = n0 + i;
+          if (n < pos || n >= pos + num_inside || n >= span) continue;
+          const int lane = n & 3;
+          if (centre) {
+            // centre sector: one texel for the whole run (pattern of the 4 lanes repeated)
+            const float texel = wr_r8_texture(t, wr_clamp(wr_sel4(pu[0], pu[1], pu[2], pu[3], lane), ub0, ub2),
+                                              wr_clamp(wr_sel4(pv[0], pv[1], pv[2], pv[3], lane), ub1, ub3));
+            out.v[i] = uint32_t(wr_round_pixel(((1.0f - texel) - texel) * mode + texel)) & 0xFFFF;
+            continue;
+          }
+          // swgl_commitTextureLinear(R8, sColor0, uv, uv_bounds, NoColor/InvertColor, num_inside)
+          const int j = n - pos;
+          int v;
+          if (filter == 0) {
+            // blendTextureNearestFast (swgl_ext.h:475-537)
+            const int ix = int(pu[0] * W), iy = int(pv[0] * H);
+            const int minUx = int(ub0 * W), minUy = int(ub1 * H), maxUx = int(ub2 * W), maxUy = int(ub3 * H);
+            const int srow = wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height);
+            const int minX = wr_iclamp(minUx, 0, t.width - 1), maxX = wr_iclamp(maxUx, minX, t.width - 1);
+            v = ((const uint8_t*)t.ptr)[(size_t)srow * t.stride + wr_iclamp(ix + j, minX, maxX)];
+          } else {
+            const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+            float q[4], qy[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) { q[a] = pu[a] * W * qs + qo; qy[a] = pv[a] * H * qs + qo; }
+            const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
+            const float minx = wr_max(ub0 * W * qs + qo, 0.0f), miny = wr_max(ub1 * H * qs + qo, 0.0f);
+            const float maxx = wr_max(ub2 * W * qs + qo, minx), maxy = wr_max(ub3 * H * qs + qo, miny);
+            int o[4];
+            wr_linear_span_pixel<1>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, filter, num_inside, j, o);
+            v = o[0];
+          }
+          if (mode != 0.0f) v = 255 - v;               // applyColor(src, InvertColor)
+          out.v[i] = uint32_t(v) & 0xFFFF;
         }
-        if (mode != 0.0f) v = 255 - v;               // applyColor(src, InvertColor)
-        return uint32_t(v) & 0xFFFF;
       }
       const float f = float(num_inside / 4);
-      for (int c = 0; c < 4; c++) for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+      }
       R -= num_inside; pos += num_inside;
     }
   }
-  return uint32_t(wr_round_pixel(mode)) & 0xFFFF;
+  return out;
 }
 
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
@@ -2411,18 +2486,30 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     return;
   }
   if ((FEAT & WR_FEAT_CLIP) && FMT == WR_FMT_R8 && kind == WR_PK_BOX_SHADOW) {
+    if (!(cx[0] || cx[1] || cx[2] || cx[3])) return;
 #pragma unroll
-    for (int q = 0; q < NPX; q++) {
-      if (!(cx[q & 3] && cy[q >> 2])) continue;
-      plo[q] = wr_blend_r8(blend, plo[q], wr_box_shadow_pixel(Pp, &Ap->box, px + (q & 3), py + 4 * (q >> 2)));
+    for (int j = 0; j < R; j++) {
+      if (!cy[j]) continue;
+      const WrRow4 r4 = wr_box_shadow_row4(Pp, &Ap->box, px, py + 4 * j);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        if (cx[i]) plo[q] = wr_blend_r8(blend, plo[q], r4.v[i]);
+      }
     }
     return;
   }
   if ((FEAT & WR_FEAT_CLIP) && FMT == WR_FMT_R8 && kind == WR_PK_CLIP_RECT) {
+    if (!(cx[0] || cx[1] || cx[2] || cx[3])) return;
 #pragma unroll
-    for (int q = 0; q < NPX; q++) {
-      if (!(cx[q & 3] && cy[q >> 2])) continue;
-      plo[q] = wr_blend_r8(blend, plo[q], wr_clip_rect_pixel(Pp, &Ap->clip, px + (q & 3), py + 4 * (q >> 2)));
+    for (int j = 0; j < R; j++) {
+      if (!cy[j]) continue;
+      const WrRow4 r4 = wr_clip_rect_row4(Pp, &Ap->clip, px, py + 4 * j);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        if (cx[i]) plo[q] = wr_blend_r8(blend, plo[q], r4.v[i]);
+      }
     }
     return;
   }
