@@ -13,6 +13,7 @@
 #include "cs_scale.h"
 #include "cs_clip_rectangle.h"
 #include "cs_clip_box_shadow.h"
+#include "brush_image.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -32,6 +33,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_clip_rectangle", cs_clip_rectangle)
   WRSH_ENTRY("cs_clip_rectangle FAST_PATH", cs_clip_rectangle_FAST_PATH)
   WRSH_ENTRY("cs_clip_box_shadow TEXTURE_2D", cs_clip_box_shadow)
+  WRSH_ENTRY("brush_image TEXTURE_2D", brush_image_TEXTURE_2D)
+  WRSH_ENTRY("brush_image ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
 #undef WRSH_ENTRY
   return nullptr;
 }

@@ -40,6 +40,7 @@ def main():
     out["box_shadow_masks_dps"] = digest(render_direct(LIB, scenes.box_shadow_masks(dps=1.5, seed=42))[0]["box_shadow_masks"])
     out["cfg4_small"] = digest(render_direct(LIB, scenes.cfg4_box_shadow(width=1024, height=1024))[0]["window"])
     out["cfg4_4k_dps2"] = digest(render_direct(LIB, scenes.cfg4_box_shadow(dps=2.0))[0]["window"])
+    out["image_grid"] = digest(render_direct(LIB, scenes.image_grid())[0])
     out["scaled_composites"] = digest(render_direct(LIB, scenes.scaled_composites())[0])
     out["masked_rects"] = digest(render_direct(LIB, scenes.masked_rects())[0])
     out["masked_rects_frac"] = digest(render_direct(LIB, scenes.masked_rects(fractional=True))[0])

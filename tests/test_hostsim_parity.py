@@ -43,6 +43,8 @@ CASES = [
     ("masked_rects_frac", lambda: scenes.masked_rects(fractional=True)),
     ("masked_rects_wide", lambda: scenes.masked_rects(width=2048, height=1024, n=600, seed=5)),
     ("scaled_composites", lambda: scenes.scaled_composites()),
+    ("image_grid", lambda: scenes.image_grid()),
+    ("image_grid_wide", lambda: scenes.image_grid(width=2048, height=1024, n=300, seed=52)),
     ("empty", lambda: scenes.build_rect_frame(512, 512, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32),
                                                np.zeros(0, bool))),
 ]

@@ -125,6 +125,8 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
     {"brush_solid", WR_SH_BRUSH_SOLID, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_solid ALPHA_PASS", WR_SH_BRUSH_SOLID_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_image TEXTURE_2D", WR_SH_BRUSH_IMAGE, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_image ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"composite TEXTURE_2D", WR_SH_COMPOSITE,
      {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
@@ -751,7 +753,7 @@ void flush_work(const std::vector<int>& sel_in) {
       d.vtab_base = -1; d.vtab_rows = 0;
       if (T.format == WR_FMT_RGBA8 && !(d.flags & WR_DF_SIMPLE) &&
           (d.shader == WR_SH_COMPOSITE || d.shader == WR_SH_COMPOSITE_FAST || d.shader == WR_SH_CS_SCALE ||
-           d.shader == WR_SH_PS_QUAD_TEXTURED)) {
+           d.shader == WR_SH_PS_QUAD_TEXTURED || d.shader == WR_SH_BRUSH_IMAGE || d.shader == WR_SH_BRUSH_IMAGE_ALPHA)) {
         const int rows = std::max(0, std::min(d.clip[3], t.height) - std::max(d.clip[1], 0));
         const size_t need = (size_t)rows * d.count;
         if (rows > 0 && vtab_cursor + need <= ((size_t)64 << 20)) {

@@ -213,6 +213,7 @@ struct WrVsOut {
   int aa_edges;        // swgl_antiAlias mask
   int has_mask;        // swgl_clipMask set
   float mask_offset[2], mask_bb[4];   // swgl_clipMask(offset, bb_origin, bb_size) arguments
+  float uv_add[2];     // shader adds this to the interpolated uv before sampling (0 unless set)
   float u2[4], v2[4];  // a second interpolated vec2 varying (WR_PK_BOX_SHADOW: vLocalPos.xy)
   int tail_clamp;      // fragment main(): clamps uv to uv_bounds
   int tail_modulate;   // fragment main(): multiplies texel by colour
@@ -320,10 +321,14 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 }
 
 // brush.glsl:95-222 + prim_shared.glsl:54-200 + brush_solid.glsl:22-40
-WR_DEVICE void wr_vs_brush_solid(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+// `image`: 0 = brush_solid, 1 = brush_image (opaque pass), 2 = brush_image ALPHA_PASS (brush_image.glsl:54-314,
+// fast variant: no REPETITION / ANTIALIASING feature)
+WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o) {
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
+  const int resource_address = aData.w & 0xffffff;
+  const int vecs_per_brush = image ? 3 : 1;
   // fetch_prim_header
   int u, v;
   wr_fetch_uv(prim_header_address, 2u, u, v);
@@ -343,10 +348,12 @@ WR_DEVICE void wr_vs_brush_solid(const WrDrawDesc& d, const uint8_t* arena, int 
   }
   int edge_flags = (flags >> 12) & 0xf, brush_flags = flags & 0xfff;
   wf4 seg = local_rect;
+  wf4 seg_data = {0.f, 0.f, 0.f, 0.f};
   if (segment_index != 0xffff) {
-    int sa = specific + 1 /*VECS_PER_SPECIFIC_BRUSH*/ + segment_index * 2;
+    int sa = specific + vecs_per_brush + segment_index * 2;
     wf4 i0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(sa) % 1024u), int(unsigned(sa) / 1024u));
     seg = wf4{i0.x + local_rect.x, i0.y + local_rect.y, i0.z + local_rect.x, i0.w + local_rect.y};
+    seg_data = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(sa) % 1024u) + 1, int(unsigned(sa) / 1024u));
   }
   wf4 adj = seg;
   int aa = 0;
@@ -366,6 +373,7 @@ WR_DEVICE void wr_vs_brush_solid(const WrDrawDesc& d, const uint8_t* arena, int 
   o.mask_offset[1] = (task.p0.y - task.origin.y) - (ca_p0.y - ca_origin.y);
   o.mask_bb[0] = ca_p0.x; o.mask_bb[1] = ca_p0.y; o.mask_bb[2] = ca_p1.x - ca_p0.x; o.mask_bb[3] = ca_p1.y - ca_p0.y;
   float fox = -task.origin.x + task.p0.x, foy = -task.origin.y + task.p0.y;
+  float vlx[4], vly[4], vww[4];
   for (int n = 0; n < 4; n++) {
     float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
     float lx = (adj.z - adj.x) * ax + adj.x, ly = (adj.w - adj.y) * ay + adj.y;
@@ -376,13 +384,69 @@ WR_DEVICE void wr_vs_brush_solid(const WrDrawDesc& d, const uint8_t* arena, int 
                     wf4{dx + fox * world.w, dy + foy * world.w, z * world.w, world.w});
     o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
     o.u[n] = 0.f; o.v[n] = 0.f;
+    vlx[n] = lx; vly[n] = ly; vww[n] = world.w;
   }
-  // brush_vs (brush_solid.glsl:24-40)
   wf4 color = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(specific) % 1024u), int(unsigned(specific) / 1024u));
-  float opacity = float(data1.x) / 65535.0f;
-  o.color = wf4{color.x * opacity, color.y * opacity, color.z * opacity, color.w * opacity};
-  o.kind = WR_PK_SOLID;
-  o.has_color = 0;
+  if (!image) {
+    // brush_vs (brush_solid.glsl:24-40)
+    float opacity = float(data1.x) / 65535.0f;
+    o.color = wf4{color.x * opacity, color.y * opacity, color.z * opacity, color.w * opacity};
+    o.kind = WR_PK_SOLID;
+    o.has_color = 0;
+    return;
+  }
+  // brush_vs (brush_image.glsl:54-314)
+  const wf4 raw2 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(specific) % 1024u) + 2, int(unsigned(specific) / 1024u));
+  float stx = raw2.x, sty = raw2.y;
+  const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+  const float tsx = float(tex.width), tsy = float(tex.height);
+  const wf4 res0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(resource_address) % 1024u), int(unsigned(resource_address) / 1024u));
+  float uv0x = res0.x, uv0y = res0.y, uv1x = res0.z, uv1y = res0.w;
+  wf4 lr = local_rect;
+  if (stx < 0.0f) { stx = lr.z - lr.x; sty = lr.w - lr.y; }
+  if (brush_flags & 2) {                     // BRUSH_FLAG_SEGMENT_RELATIVE
+    lr = seg;
+    stx = lr.z - lr.x; sty = lr.w - lr.y;
+    if (brush_flags & 512) {                 // BRUSH_FLAG_TEXEL_RECT
+      const float usx = res0.z - res0.x, usy = res0.w - res0.y;
+      uv0x = res0.x + seg_data.x * usx; uv0y = res0.y + seg_data.y * usy;
+      uv1x = res0.x + seg_data.z * usx; uv1y = res0.y + seg_data.w * usy;
+    }
+  }
+  const bool persp = (brush_flags & 1) != 0;
+  if (brush_flags & 2048) { uv0x *= tsx; uv0y *= tsy; uv1x *= tsx; uv1y *= tsy; }   // NORMALIZED_UVS
+  const float mnx = wr_min(uv0x, uv1x), mny = wr_min(uv0y, uv1y), mxx = wr_max(uv0x, uv1x), mxy = wr_max(uv0y, uv1y);
+  o.uv_bounds = wf4{(mnx + 0.5f) / tsx, (mny + 0.5f) / tsy, (mxx - 0.5f) / tsx, (mxy - 0.5f) / tsy};   // v_uv_sample_bounds
+  const float rpx = (lr.z - lr.x) / stx, rpy = (lr.w - lr.y) / sty;
+  for (int n = 0; n < 4; n++) {
+    const float fx = (vlx[n] - lr.x) / (lr.z - lr.x), fy = (vly[n] - lr.y) / (lr.w - lr.y);
+    float uu = ((uv1x - uv0x) * fx + uv0x) - mnx, vv = ((uv1y - uv0y) * fy + uv0y) - mny;
+    uu *= rpx; vv *= rpy;
+    uu /= tsx; vv /= tsy;
+    if (!persp) { uu *= vww[n]; vv *= vww[n]; }
+    o.u[n] = uu; o.v[n] = vv;
+  }
+  o.uv_add[0] = mnx / tsx; o.uv_add[1] = mny / tsy;       // compute_repeated_uvs: v_uv * 1 + v_uv_bounds.xy
+  o.tex_slot = WR_S_COLOR0;
+  o.tail_clamp = 1;
+  o.kind = tex.format == WR_FMT_RGBA8 ? WR_PK_TEX_RGBA8 : WR_PK_TEX_FS;      // swgl_isTextureRGBA8, :381
+  if (data1.y != 0 || persp) { o.kind = WR_PK_UNSUPPORTED; return; }          // RASTER_SCREEN quads / perspective: next
+  if (image == 1) {
+    o.has_color = 0; o.tail_modulate = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    return;
+  }
+  const int color_mode = data1.x & 0xffff, blend_mode = data1.x >> 16;
+  const float opacity = float(data1.z) / 65535.0f;
+  if (blend_mode == 0) color.w *= opacity;
+  else { color.x *= opacity; color.y *= opacity; color.z *= opacity; color.w *= opacity; }
+  wf4 vcol;
+  if (color_mode == 4) vcol = color;                                          // COLOR_MODE_IMAGE
+  else if (color_mode == 3) vcol = wf4{color.w, color.w, color.w, color.w};   // COLOR_MODE_COLOR_BITMAP
+  else { o.kind = WR_PK_UNSUPPORTED; return; }                                // blend overrides / dual source: next
+  o.color = vcol;
+  o.tail_modulate = 1;
+  // swgl_commitTextureColorRGBA8 unless v_color == vec4(1.0) (:404-414)
+  o.has_color = (vcol.x != 1.0f || vcol.y != 1.0f || vcol.z != 1.0f || vcol.w != 1.0f) ? 1 : 0;
 }
 
 // ps_text_run.glsl:98-268, non-GLYPH_TRANSFORM branch (vertex stage), with the
@@ -783,6 +847,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   P.kind = WR_PK_NONE;
   P.draw = draw_index;
   P.color[0] = P.color[1] = 0; P.z = 0; P.tex_slot = 0;
+  P.uv_add[0] = o.uv_add[0]; P.uv_add[1] = o.uv_add[1];
   P.blend = (int16_t)d.blend;
   P.flags = d.flags & (WR_PF_DEPTH_TEST | WR_PF_DEPTH_WRITE | WR_PF_DEPTH_LESS);
   P.x0 = P.y0 = P.x1 = P.y1 = 0;
@@ -1221,23 +1286,25 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   if (P.kind == WR_PK_TEX_FS) r.span = 0;     // no draw_span for this program/target: all main()
   if (r.span == 0) return r;
   float W = float(t.width), H = float(t.height);
-  float ou1 = r.ou + r.su, ov1 = r.ov + r.sv;
+  // lanes 0 and 1 of the uv vector handed to swgl_commitTexture* (shader-side offset included)
+  const float p0u = r.ou + P.uv_add[0], p0v = r.ov + P.uv_add[1];
+  const float ou1 = (r.ou + r.su) + P.uv_add[0], ov1 = (r.ov + r.sv) + P.uv_add[1];
   if (P.kind == WR_PK_TEX_R8) {
     r.filter = 1;   // blendTextureLinearR8 (swgl_ext.h:634-650): always the quantised fallback stepping
   } else if (!t.linear) {
     // swgl_commitTextureNearest: needsNearestFallback (swgl_ext.h:876-880)
-    float py0 = r.ov * H, py1 = ov1 * H, px0 = r.ou * W, px1 = ou1 * W;
+    float py0 = p0v * H, py1 = ov1 * H, px0 = p0u * W, px1 = ou1 * W;
     int sp = (r.span & ~127) + 128;
     int scaled = int(roundf((px1 - px0) * float(sp)));
     bool fallback = (py1 - py0) * float(r.span) >= 0.5f || scaled != sp;
     r.filter = fallback ? -1 : 0;   // blendTextureNearestRepeat<false>: "next"
   } else if (t.width < 2) {
     r.filter = 0;
-  } else if (r.ov != ov1) {
+  } else if (p0v != ov1) {
     r.filter = 1;
   } else {
     // needsTextureLinear (swgl_ext.h:553-587)
-    float px0 = r.ou * W, px1 = ou1 * W, py0 = r.ov * H;
+    float px0 = p0u * W, px1 = ou1 * W, py0 = p0v * H;
     int sp = (r.span & ~127) + 128;
     int scaled = int(roundf((px1 - px0) * float(sp)));
     if (scaled != sp) {
@@ -1250,8 +1317,8 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   }
   if (r.filter == 0) {
     // blendTextureNearestFast (swgl_ext.h:475-537)
-    r.ix = int(r.ou * W);
-    int iy = int(r.ov * H);
+    r.ix = int(p0u * W);
+    int iy = int(p0v * H);
     int minUx = int(P.uv_bounds[0] * W), minUy = int(P.uv_bounds[1] * H);
     int maxUx = int(P.uv_bounds[2] * W), maxUy = int(P.uv_bounds[3] * H);
     r.srow = wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height);
@@ -1274,6 +1341,7 @@ WR_DEVICE void wr_tex_tail_uv(const WrPrim& P, const WrTexRow& r, int n, float& 
     lu = lu + (r.su * 4.0f) * chunks; lv = lv + (r.sv * 4.0f) * chunks;
   }
   lu = wr_accum(lu, (r.su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (r.sv * 4.0f) * 1.0f, m);
+  lu = lu + P.uv_add[0]; lv = lv + P.uv_add[1];
   cu = lu; cv = lv;
   if (P.flags & WR_PF_TAIL_CLAMP) {
     cu = wr_clamp(lu, P.uv_bounds[0], P.uv_bounds[2]); cv = wr_clamp(lv, P.uv_bounds[1], P.uv_bounds[3]);
@@ -1299,7 +1367,7 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
       {
         float lu = r.ou, lv = r.ov;
         for (int i = 0; i < 4; i++) {
-          q[i] = lu * W * qs + qo; qy[i] = lv * H * qs + qo;
+          q[i] = (lu + P.uv_add[0]) * W * qs + qo; qy[i] = (lv + P.uv_add[1]) * H * qs + qo;
           lu += r.su; lv += r.sv;
         }
       }
@@ -1455,6 +1523,8 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
 WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws, const uint8_t* __restrict__ arena,
                               int gid, WrPrim& P, WrAux* aux, const WrTargetDesc* targets, WrUnsupportedCounters* cnt) {
   P.blend = 0; P.flags = 0; P.z = 0; P.color[0] = P.color[1] = 0; P.tex_slot = 0;
+  P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0;
+  P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0;
   // binary search for the draw containing this instance
   int lo = 0, hi = n_draws - 1;
   while (lo < hi) {
@@ -1473,10 +1543,13 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
   }
   WrVsOut o;
   o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
+  o.uv_add[0] = o.uv_add[1] = 0.0f;
   switch (d.shader) {
     case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
     case WR_SH_BRUSH_SOLID:
-    case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush_solid(d, arena, inst, o); break;
+    case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush(d, arena, inst, 0, o); break;
+    case WR_SH_BRUSH_IMAGE: wr_vs_brush(d, arena, inst, 1, o); break;
+    case WR_SH_BRUSH_IMAGE_ALPHA: wr_vs_brush(d, arena, inst, 2, o); break;
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
@@ -1561,7 +1634,7 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   if (r.span == 0) return false;
   const float W = float(t.width);
   bool x_ok;
-  const float px0 = r.ou * W, px1 = (r.ou + r.su) * W;
+  const float px0 = (r.ou + P.uv_add[0]) * W, px1 = ((r.ou + r.su) + P.uv_add[0]) * W;
   const int sp = (r.span & ~127) + 128;
   const int scaled = int(roundf((px1 - px0) * float(sp)));
   if (!t.linear) x_ok = scaled == sp;
@@ -1571,11 +1644,12 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   __builtin_memset(&T, 0, sizeof(T));
   T.ptr = t.ptr; T.stride = t.stride; T.wh = uint32_t(t.width) | (uint32_t(t.height) << 16);
   T.span = r.span; T.y0 = P.y0;
-  T.ix0 = int(r.ou * W);
+  T.ix0 = int((r.ou + P.uv_add[0]) * W);
   const int minUx = int(P.uv_bounds[0] * W), maxUx = int(P.uv_bounds[2] * W);
   T.tix[0] = wr_iclamp(minUx, 0, t.width - 1);
   T.tix[1] = wr_iclamp(maxUx, T.tix[0], t.width - 1);
   T.lv0 = P.uvL0[1]; T.lvs = P.uvLs[1];
+  T.su = P.uv_add[1];                            // v offset applied to every row before sampling
   T.ub1 = P.uv_bounds[1]; T.ub3 = P.uv_bounds[3];
   T.unit = (t.linear && t.width >= 2) ? 1 : 0;      // rows must also pass the texel-centre test
   T.simple = 2;
@@ -1591,7 +1665,7 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG_ROWS")) fprintf(stderr, "texrow: lin %d th %d vstep %.9g L0*H %.9g rows %d\n", P.rows_linear, th, vstep, P.uvL0[1] * H, P.y1 - P.y0);
 #endif
-  if (P.rows_linear && (th & (th - 1)) == 0 && th < 65536 && (vstep == 1.0f || vstep == -1.0f) && P.y1 - P.y0 < 65536) {
+  if (P.rows_linear && P.uv_add[1] == 0.0f && (th & (th - 1)) == 0 && th < 65536 && (vstep == 1.0f || vstep == -1.0f) && P.y1 - P.y0 < 65536) {
     const float py0 = P.uvL0[1] * H;           // exact: scaling by a power of two
     const float pyl = fabsf(py0) + float(P.y1 - P.y0);
     const float pye = py0 + vstep * float(P.y1 - P.y0 - 1);                        // last row; every row keeps v*H >= 0
@@ -1610,9 +1684,10 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   }
   return true;
 }
-WR_DEVICE int wr_texrow_entry(const WrTexRec& T, float ov) {
+WR_DEVICE int wr_texrow_entry(const WrTexRec& T, float ov_raw) {
   const int th = int(T.wh >> 16);
   const float H = float(th);
+  const float ov = ov_raw + T.su;
   const float py0 = ov * H;
   if (T.unit && (int(py0 * 4.0f + 0.5f) & 3) != 2) return -1;
   const int iy = int(ov * H), minUy = int(T.ub1 * H), maxUy = int(T.ub3 * H);

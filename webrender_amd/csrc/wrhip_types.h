@@ -49,6 +49,8 @@ enum WrShader {
   WR_SH_CS_CLIP_RECT,
   WR_SH_CS_CLIP_RECT_FAST,
   WR_SH_CS_CLIP_BOX_SHADOW,
+  WR_SH_BRUSH_IMAGE,
+  WR_SH_BRUSH_IMAGE_ALPHA,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -191,6 +193,8 @@ struct WrPrim {
   int32_t tex_slot;         // sampler slot
   int32_t mask_off[2];      // WR_PK_SOLID_MASKED: target pixel - mask texel (swgl_ClipMaskOffset)
   int32_t rows_linear;      // 1: edge interpolants at row k equal L0 + k*slope exactly (closed form of Edge::nextRow)
+  float uv_add[2];          // added to the interpolated uv of every pixel before sampling (brush_image: + v_uv_bounds.xy)
+  int32_t pad2[2];
 };
 
 // Compact per-prim record the raster stage streams (32 B, dense array): the

@@ -314,6 +314,107 @@ def scaled_composites(width=1024, height=768, seed=21, src=192):
 
 
 # ---------------------------------------------------------------------------
+# Images: brush_image (fast variant) from a texture-cache atlas -- opaque images
+# in the opaque pass (front to back, depth), translucent / tinted ones in the
+# alpha pass (batch.rs:2060-2150; ImageBrushData gpu_types.rs:707-724; GPU blocks
+# prim_store/image.rs: [color, background_color, stretch_size]).
+def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=None, modes=(0, 1, 2, 3, 4), translucent=True, only=None):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    pix = np.zeros((atlas, atlas, 4), np.uint8)
+    srcs = []
+    x = y = 0
+    shelf = 0
+    for i in range(24):
+        w, h = int(rng.integers(24, 200)), int(rng.integers(24, 160))
+        if x + w > atlas:
+            x, y, shelf = 0, y + shelf, 0
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 0] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+        if i % 2 == 0:
+            img[..., 3] = 255                        # opaque image
+        img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)
+        pix[y:y + h, x:x + w] = img
+        addr = frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]])
+        srcs.append((w, h, addr, i % 2 == 0))
+        x += w
+        shelf = max(shelf, h)
+    t_atlas = TextureRef("image_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pix, upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+    prims = []
+    # Opaque-pass images sit on a non-overlapping grid in the top band: swgl restarts a span (chunk
+    # phase, span-vs-fragment-shader split) at every depth run, so a textured prim partly hidden
+    # behind an earlier opaque one is not bit-reproducible by a per-pixel evaluator;
+    # everything below the band is drawn in the alpha pass, where nothing fails the depth test.
+    band = 230
+    gx = 4.0
+    opaque_srcs = [s_ for s_ in srcs if s_[3]]
+    for k in range(max(1, n // 8)):
+        sw, sh, addr, _ = opaque_srcs[k % len(opaque_srcs)]
+        sc = (1.0, 1.0, 1.3, 0.5, 0.77)[modes[k % len(modes)]]
+        w, h = sw * sc, min(sh * sc, band - 8.0)
+        if gx + w + 4 > width:
+            break
+        off = 0.0 if modes[k % len(modes)] != 1 else 0.37
+        prims.append(((gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), addr, True, 1.0))
+        gx += float(np.ceil(w)) + 6.0
+    for k in range(n):
+        sw, sh, addr, opaque_img = srcs[int(rng.integers(0, len(srcs)))]
+        opaque_img = False
+        mode = modes[k % len(modes)]
+        if mode == 0:      # 1:1 at an integer position
+            w, h = float(sw), float(sh)
+            px, py = float(rng.integers(-20, width - 20)), float(rng.integers(band, height - 20))
+        elif mode == 1:    # 1:1 with a subpixel offset
+            w, h = float(sw), float(sh)
+            px, py = float(rng.uniform(0, width - sw)), float(rng.uniform(band, height - sh))
+        elif mode == 2:    # upscaled
+            sc = float(rng.uniform(1.1, 3.0))
+            w, h = sw * sc, sh * sc
+            px, py = float(rng.integers(0, width)) - w / 2, float(rng.integers(band + 300, height + 100)) - h / 2
+            py = max(py, float(band))
+        elif mode == 3:    # exact 2x downscale
+            w, h = sw * 0.5, sh * 0.5
+            px, py = float(rng.integers(0, width - sw)), float(rng.integers(band, height - sh))
+        else:              # arbitrary scale
+            w, h = sw * float(rng.uniform(0.3, 1.7)), sh * float(rng.uniform(0.3, 1.7))
+            px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - h))
+        opacity = 1.0 if (k % 3 or not translucent) else float(rng.uniform(0.3, 0.9))
+        prims.append(((px, py, px + w, py + h), addr, False, opacity))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        op, al = [], []
+        for zi, (rect, addr, opaque, opacity) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
+            ud = (4 | (1 << 16), 0, int(round(opacity * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, ud)
+            (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=addr))
+        if op:
+            target.opaque.append(Step("brush_image TEXTURE_2D", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
+                                      None, "opaque", textures={0: t_atlas}))
+        if al:
+            target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
+
+
+# ---------------------------------------------------------------------------
 # Clip-masked rectangles: brush_solid ALPHA_PASS instances whose clip task
 # address points at an R8 mask region (prim_shared.glsl:183-200 write_clip ->
 # swgl_clipMask).  The masks themselves are uploaded here; in a full frame they
