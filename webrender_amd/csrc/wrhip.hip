@@ -1659,6 +1659,19 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     bool simple = false;
     if (info->kind == WR_SH_BRUSH_SOLID || info->kind == WR_SH_BRUSH_SOLID_ALPHA) simple = plain_blend && !maskable;
     else if (info->kind == WR_SH_PS_QUAD_TEXTURED) simple = plain_blend && d.tex[WR_S_COLOR0].width < 2;
+    if (simple && d.blend != WR_BLEND_NONE && d.attr_off[0] >= 0 && d.attr_bytes[0] >= 12 && inst_stride >= 12) {
+      // swgl_antiAlias only matters with blending on; the request travels in aData.z of every
+      // instance (brush: flags = z >> 16, BRUSH_FLAG_FORCE_AA = 1024, gpu_types.rs:690-703; quad:
+      // part = (z >> 8) & 0xff, edge flags = (z >> 16) & 0xff, gpu_types.rs:564-589)
+      const uint8_t* ib = (const uint8_t*)instb->buf + d.attr_off[0];
+      for (int i = 0; i < instancecount && simple; i++) {
+        int32_t zw; memcpy(&zw, ib + (size_t)i * inst_stride + 8, 4);
+        if (info->kind == WR_SH_PS_QUAD_TEXTURED) {
+          const int part = (zw >> 8) & 0xff, edges = (zw >> 16) & 0xff;
+          if ((part >= 1 && part <= 4) || (part == 5 && edges != 0)) simple = false;
+        } else if ((zw >> 16) & 1024) simple = false;
+      }
+    }
     if (simple) d.flags |= WR_DF_SIMPLE;
   }
   apply_scissor(colortex, d.clip);

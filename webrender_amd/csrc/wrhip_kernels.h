@@ -895,7 +895,9 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (screenZ < 0.0f || screenZ > 1.0f) return;
   P.z = uint32_t(16777215.0f * screenZ);
 
-  if (o.aa_edges != 0 && d.blend != WR_BLEND_NONE) {  // swgl_antiAlias needs blending; AA path is "next"
+  // swgl_antiAlias only takes effect when blending is on (ClipRect ctor, rasterize.h:414-441)
+  const bool aa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
+  if (aa && (o.kind != WR_PK_SOLID || masked)) {      // AA on textured / masked prims: "next"
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
   // lanes: 0=(0,0) 1=(1,0) 2=(1,1) 3=(0,1) of the unit quad
@@ -909,8 +911,29 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   // clipSpan = clipRect.x_range().clip(edge x range); span = clipSpan.clip({left.x,right.x}).round()
   float sx0 = wr_clamp(xmin, cx0, cx1), sx1 = wr_clamp(xmax, cx0, cx1);
   int ix0 = int(floorf(sx0 + 0.5f)), ix1 = int(floorf(sx1 + 0.5f));
-  // first row centre: floor(max(min(l0.y, clip.y1), clip.y0) + 0.5) + 0.5 ; rows while y <= min(bottom, clip.y1)
-  float ystart = floorf(wr_max(wr_min(ymin, cy1), cy0) + 0.5f) + 0.5f;
+  float aaRound = 0.5f;
+  if (aa) {
+    // aa_span (rasterize.h:520-561) for vertical edges (x slope 0): an edge with its mask bit set is
+    // rounded out and gets a coverage ramp, the others round to nearest.  The mask bit of an edge is
+    // indexed by the vertex it ends at (Edge ctor: left edges pass l1i, right edges r0i).
+    int li, ri;                       // vertex index whose bit masks the screen-left / screen-right edge
+    if (typeA) { const bool flipx = sx[0] > sx[1]; li = flipx ? 2 : 0; ri = flipx ? 0 : 2; }
+    else { const bool flipx = sx[0] > sx[3]; li = flipx ? 3 : 1; ri = flipx ? 1 : 3; }
+    const bool ml = (o.aa_edges >> li) & 1, mr = (o.aa_edges >> ri) & 1;
+    const int l_start = ml ? int(floorf(sx0)) : int(floorf(sx0 + 0.5f));
+    const int l_end = ml ? int(ceilf(sx0)) : int(floorf(sx0 + 0.5f));
+    const int r_end = mr ? int(ceilf(sx1)) : int(floorf(sx1 + 0.5f));
+    ix0 = l_start; ix1 = r_end;
+    WrAARec& A = auxp->aa;
+    // aa_dist (rasterize.h:508-517): dx = dir * 256 * inversesqrt(1 + slope^2), slope == 0
+    const float dxl = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + 0.0f * 0.0f)), dxr = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + 0.0f * 0.0f));
+    A.lstart = ml ? 128.0f + dxl * (xmin - 0.5f) : 256.0f; A.lend = ml ? -dxl : 0.0f;
+    A.rstart = mr ? 128.0f + dxr * (xmax - 0.5f) : 256.0f; A.rend = mr ? -dxr : 0.0f;
+    A.laa_end = l_end;
+    aaRound = 0.0f;                   // conservative vertical round-out (rasterize.h:889-890)
+  }
+  // first row centre: floor(max(min(l0.y, clip.y1), clip.y0) + aaRound) + 0.5 ; rows while y <= min(bottom, clip.y1)
+  float ystart = floorf(wr_max(wr_min(ymin, cy1), cy0) + aaRound) + 0.5f;
   float ylimit = wr_min(ymax, cy1);
   int iy0 = int(ystart);
   int iy1 = int(floorf(ylimit - 0.5f)) + 1;
@@ -918,7 +941,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   while (iy1 > iy0 && (float(iy1 - 1) + 0.5f) > ylimit) iy1--;
   if (ix1 <= ix0 || iy1 <= iy0) return;
   P.x0 = ix0; P.x1 = ix1; P.y0 = iy0; P.y1 = iy1;
-  P.kind = masked ? (int16_t)WR_PK_SOLID_MASKED : (int16_t)o.kind;
+  P.kind = masked ? (int16_t)WR_PK_SOLID_MASKED : (aa ? (int16_t)WR_PK_SOLID_AA : (int16_t)o.kind);
   P.rows_linear = 0;
   if ((d.flags & WR_DF_SIMPLE) && P.kind != WR_PK_SOLID) {   // the launch's kernel has no path for it: say so
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
@@ -2600,6 +2623,32 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       } else {
         plo[q] = wr_blend_r8(blend, plo[q], src.bg & 0xFFFF);
       }
+    }
+    return;
+  }
+  if ((FEAT & WR_FEAT_GENERIC) && FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID_AA) {
+    // DO_AA (blend.h:433-446): src = muldiv256(src, coverage) ahead of the blend
+    const WrAARec& A = Ap->aa;
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      bool in = cx[q & 3] && cy[q >> 2];
+      if (dtest) {
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+        in = in && pass;
+        if (dwrite) dep[q] = in ? z : dep[q];
+      }
+      if (!in) continue;
+      const int n = px + (q & 3) - x0, lane = n & 3, base = x0 + (n & ~3);
+      const float off = float(4 * (base - A.laa_end));
+      const float dl = (A.lstart + float(A.laa_end + lane) * A.lend) + (A.lend / 4.0f) * off;
+      const float dr = (A.rstart + float(A.laa_end + lane) * A.rend) + (A.rend / 4.0f) * off;
+      const uint32_t cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
+      WrWide src;
+      src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+      src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+      const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+      plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;
   }

@@ -158,6 +158,7 @@ enum WrPrimKind {
   WR_PK_TEX_RGBA8,      // swgl_commitTexture*RGBA8 family (rect, axis-aligned uv)
   WR_PK_UNSUPPORTED,
   WR_PK_SOLID_FOLDED,   // WrRec only: solid prim pre-folded for the raster hot path (wr_make_rec)
+  WR_PK_SOLID_AA,       // flat colour with swgl_antiAlias edge coverage (axis-aligned quads; WrAARec)
   WR_PK_SOLID_MASKED,   // commit_masked_solid_span: flat colour x R8 clip mask sampled 1:1 (swgl_clipMask)
   WR_PK_TEX_FS,         // textured quad with no usable span shader: every pixel runs the fragment shader's main()
   WR_PK_BOX_SHADOW,     // cs_clip_box_shadow's nine-patch span shader (WrBoxRec)
@@ -278,12 +279,22 @@ struct WrBoxRec {
   float lpL0[2], lpLs[2], lpR0[2], lpRs[2];   // edge interpolants of vLocalPos.xy (as WrPrim::uv*)
 };
 
+// Anti-aliased axis-aligned quad (aa_span / aa_dist, rasterize.h:480-562; DO_AA, blend.h:433-446):
+// coverage of pixel X = clamp(min(L, R), 0, 256) with
+//   L = (lstart + float(laa_end + lane) * lend) + (lend / bpp) * float(bpp * (chunk_base - laa_end)), R likewise,
+// lane / chunk_base relative to the span start x0.
+struct WrAARec {
+  float lstart, lend, rstart, rend;
+  int32_t laa_end;
+};
+
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
   WrTexRec tex;
   WrBlurRec blur;
   WrClipRec clip;
   WrBoxRec box;
+  WrAARec aa;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

@@ -38,7 +38,7 @@ def premultiply(rgba_u8):
 
 
 def build_rect_frame(width, height, rects, colors, opaque, encoding="quad",
-                     clear_color=(1.0, 1.0, 1.0, 1.0), tile_filter=None):
+                     clear_color=(1.0, 1.0, 1.0, 1.0), tile_filter=None, aa_edges=0):
     """rects: float32 [N,4] (x0,y0,x1,y1) device px; colors: float32 [N,4]
     premultiplied; opaque: bool [N].  encoding: "quad" (ps_quad_textured, what
     Rectangle prims use today: prepare.rs:218-256) or "brush" (brush_solid,
@@ -70,12 +70,15 @@ def build_rect_frame(width, height, rects, colors, opaque, encoding="quad",
             if encoding == "quad":
                 qf = QF_APPLY_DEVICE_CLIP | (QF_IS_OPAQUE if opaque[i] else 0)
                 inst = frame.quad_instance(r, (-BIG, -BIG, BIG, BIG), c, int(z_ids[i]), task,
-                                           quad_flags=qf)
+                                           quad_flags=qf, edge_flags=0 if opaque[i] else aa_edges)
             else:
                 addr = frame.gpu_cache.push([list(c)])
                 ph = frame.add_prim_header(r, (-BIG, -BIG, BIG, BIG), int(z_ids[i]), addr, 0,
                                            task, (65535, 0, 0, 0))
-                inst = frame.brush_instance(ph, CLIP_TASK_EMPTY)
+                if aa_edges and not opaque[i]:      # BRUSH_FLAG_FORCE_AA + the edges to anti-alias
+                    inst = frame.brush_instance(ph, CLIP_TASK_EMPTY, brush_flags=1024, edge_flags=aa_edges)
+                else:
+                    inst = frame.brush_instance(ph, CLIP_TASK_EMPTY)
             (op_inst if opaque[i] else al_inst).append(inst)
         if encoding == "quad":
             sh_op = sh_al = "ps_quad_textured"
@@ -131,6 +134,7 @@ def random_rects(n, width, height, wmin, wmax, seed, fractional=False):
 
 def cfg2_overlapping_rects(width=3840, height=2160, n=1000, encoding="quad",
                            fractional=False, seed=2, **kw):
+    """kw: aa_edges=0..15 turns on swgl_antiAlias for the (translucent) rects."""
     rng, rects = random_rects(n, width, height, 64, 1024, seed, fractional)
     rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
     alpha = np.round(rng.uniform(0.25, 0.75, size=n) * 255).astype(np.uint8)
