@@ -14,6 +14,7 @@
 #include "cs_clip_rectangle.h"
 #include "cs_clip_box_shadow.h"
 #include "brush_image.h"
+#include "brush_linear_gradient.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -35,6 +36,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_clip_box_shadow TEXTURE_2D", cs_clip_box_shadow)
   WRSH_ENTRY("brush_image TEXTURE_2D", brush_image_TEXTURE_2D)
   WRSH_ENTRY("brush_image ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
+  WRSH_ENTRY("brush_linear_gradient", brush_linear_gradient)
+  WRSH_ENTRY("brush_linear_gradient ALPHA_PASS", brush_linear_gradient_ALPHA_PASS)
 #undef WRSH_ENTRY
   return nullptr;
 }

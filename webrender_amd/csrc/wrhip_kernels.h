@@ -323,12 +323,13 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 // brush.glsl:95-222 + prim_shared.glsl:54-200 + brush_solid.glsl:22-40
 // `image`: 0 = brush_solid, 1 = brush_image (opaque pass), 2 = brush_image ALPHA_PASS (brush_image.glsl:54-314,
 // fast variant: no REPETITION / ANTIALIASING feature)
-WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o) {
+// image: 0 brush_solid, 1 brush_image, 2 brush_image ALPHA_PASS, 3 brush_linear_gradient (G = its side record)
+WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr) {
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
   const int resource_address = aData.w & 0xffffff;
-  const int vecs_per_brush = image ? 3 : 1;
+  const int vecs_per_brush = image == 3 ? 2 : (image ? 3 : 1);
   // fetch_prim_header
   int u, v;
   wr_fetch_uv(prim_header_address, 2u, u, v);
@@ -393,6 +394,41 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.color = wf4{color.x * opacity, color.y * opacity, color.z * opacity, color.w * opacity};
     o.kind = WR_PK_SOLID;
     o.has_color = 0;
+    return;
+  }
+  if (image == 3) {
+    // brush_vs (brush_linear_gradient.glsl:31-64) + write_gradient_vertex (gradient_shared.glsl:19-52)
+    const wf4 d1 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(specific) % 1024u) + 1, int(unsigned(specific) / 1024u));
+    const int extend_mode = int(d1.x);
+    const float stx = d1.y, sty = d1.z;
+    for (int n = 0; n < 4; n++) {
+      float vx, vy;
+      if (brush_flags & 2) {                   // BRUSH_FLAG_SEGMENT_RELATIVE
+        vx = (vlx[n] - seg.x) / (seg.z - seg.x); vy = (vly[n] - seg.y) / (seg.w - seg.y);
+        vx = vx * (seg_data.z - seg_data.x) + seg_data.x; vy = vy * (seg_data.w - seg_data.y) + seg_data.y;
+        vx = vx * (local_rect.z - local_rect.x); vy = vy * (local_rect.w - local_rect.y);
+      } else {
+        vx = vlx[n] - local_rect.x; vy = vly[n] - local_rect.y;
+      }
+      o.u[n] = vx / stx; o.v[n] = vy / sty;
+    }
+    const float dirx = color.z - color.x, diry = color.w - color.y;   // end_point - start_point
+    const float dd = dirx * dirx + diry * diry;
+    float sdx = dirx / dd, sdy = diry / dd;
+    G->start_offset = color.x * sdx + color.y * sdy;
+    G->scale_dir[0] = sdx * stx; G->scale_dir[1] = sdy * sty;
+    G->address = data1.x;
+    G->repeat = extend_mode == 1 ? 1.0f : 0.0f;
+    // swgl_validateGradient(sGpuBufferF, get_gpu_buffer_uv(address), 130) (swgl_ext.h:1336-1347)
+    const WrTexDesc& gb = d.tex[WR_S_GPU_BUFFER_F];
+    const int ax = int(unsigned(data1.x) % 1024u), ay = int(unsigned(data1.x) / 1024u);
+    const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width &&
+                    ax + 2 * 130 <= gb.width;
+    G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
+    o.tex_slot = WR_S_GPU_BUFFER_F;
+    o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    o.kind = WR_PK_GRADIENT;
+    if (brush_flags & 1) o.kind = WR_PK_UNSUPPORTED;      // perspective interpolation: next
     return;
   }
   // brush_vs (brush_image.glsl:54-314)
@@ -950,7 +986,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1573,6 +1609,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush(d, arena, inst, 0, o); break;
     case WR_SH_BRUSH_IMAGE: wr_vs_brush(d, arena, inst, 1, o); break;
     case WR_SH_BRUSH_IMAGE_ALPHA: wr_vs_brush(d, arena, inst, 2, o); break;
+    case WR_SH_BRUSH_LINEAR_GRADIENT:
+    case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: wr_vs_brush(d, arena, inst, 3, o, &aux[gid].grad); break;
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
@@ -1815,6 +1853,190 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
 // red channel of a textured prim's fragment value (R8 targets)
 __device__ __noinline__ uint32_t wr_tex_pixel_r(const WrPrim* Pp, const WrDrawDesc* D, int x, int y) {
   return wr_tex_pixel(*Pp, D->tex[Pp->tex_slot], x, y).ra & 0xFFFF;
+}
+
+// ---------------------------------------------------------------------------
+// brush_linear_gradient: the 4 pixels x .. x+3 of row y (WideRGBA8 sources, b,g | r,a as u16 pairs).
+//   span part   commitLinearGradient (swgl_ext.h:1390-1578) walks the row from the span start:
+//               [run of whole chunks inside one merged table range, colour stepped in 0..0xFF00
+//               fixed point] [one per-sample table lookup chunk] ...  A pixel's value depends on
+//               the run it falls in, so the walk is replayed up to the chunk(s) holding x .. x+3.
+//   the rest    fragment shader: sample_gradient(dot(fract(v_pos), v_scale_dir) - v_start_offset)
+//               (brush_linear_gradient.glsl:66-83, gradient.glsl:42-61), also for every pixel when
+//               the table fails swgl_validateGradient or the per-chunk delta is not finite.
+struct WrGrad4 { WrWide v[4]; };
+
+WR_DEVICE bool wr_stops_merge(const float* stops, int a, int b) {   // GradientStops::can_merge
+  const float* sa = stops + 8 * a + 4; const float* sb = stops + 8 * b + 4;
+  return sa[0] == sb[0] && sa[1] == sb[1] && sa[2] == sb[2] && sa[3] == sb[3];
+}
+WR_DEVICE float wr_fract(float v) { return v - floorf(v); }
+WR_DEVICE uint32_t wr_u16_round1(float v) { return uint32_t(int(v * 1.0f + 0.5f)) & 0xFFFF; }   // CONVERT(round_pixel(v, 1), U16)
+
+// sampleGradient, one lane (swgl_ext.h:1349-1373): zyxw swizzle, round_pixel, packRGBA8 (wrapping)
+WR_DEVICE WrWide wr_sample_gradient(const float* stops, float entry) {
+  const int index = int(entry);
+  const float offset = entry - float(index);
+  const float* st = stops + 8 * index;
+  wf4 c = {st[0] + st[4] * offset, st[1] + st[5] * offset, st[2] + st[6] * offset, st[3] + st[7] * offset};
+  uint32_t pc[2];
+  wr_pack_color(c, pc);
+  WrWide w; w.bg = pc[0]; w.ra = pc[1];
+  return w;
+}
+
+__device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradRec* Gp, const WrDrawDesc* D, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrGradRec& G = *Gp;
+  WrGrad4 out;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { out.v[i].bg = 0; out.v[i].ra = 0; }
+  // interpolants of v_pos at the span start (rasterize.h:1003-1017), as wr_tex_row
+  const int k = y - P.y0;
+  const bool lin = P.rows_linear != 0;
+  const float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+  const float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  const float ou = Lu + su * start, ov = Lv + sv * start;
+  const int len = P.x1 - P.x0;
+  int span = len >= 4 ? (len & ~3) : 0;
+  // init_interp (glsl.h:3084-3089)
+  float px[4], py[4];
+  px[0] = ou; py[0] = ov;
+#pragma unroll
+  for (int i = 1; i < 4; i++) { px[i] = px[i - 1] + su; py[i] = py[i - 1] + sv; }
+  const float psx = (px[1] - px[0]) * 4.0f, psy = (py[1] - py[0]) * 4.0f;   // dFdx(pos) * 4
+  const float sdx = G.scale_dir[0], sdy = G.scale_dir[1];
+  const float delta = psx * sdx + psy * sdy;
+  if (!G.stops || !wr_isfinite(delta)) span = 0;
+  const int n_lo = wr_imax(x - P.x0, 0), n_hi = wr_imin(x + 3 - P.x0, len - 1);
+  if (n_hi < n_lo) return out;
+  const float size = 128.0f;
+  if (n_lo < span) {
+    const float* stops = G.stops;
+    const int c_lo = n_lo >> 2, c_hi = wr_imin(n_hi, span - 1) >> 2;     // chunks wanted
+    float dcxx = 0.25f * float(span), dcxy = 0.0f, dcyx = dcxx, dcyy = 0.0f;
+    if (psx != 0.0f) { const float r = 1.0f / psx; dcxx = (psx >= 0.0f ? 1.0f : 0.0f) * r; dcxy = 1.0f * r; }
+    if (psy != 0.0f) { const float r = 1.0f / psy; dcyx = (psy >= 0.0f ? 1.0f : 0.0f) * r; dcyy = 1.0f * r; }
+    int left = span, chunk = 0;          // chunk: index of the next chunk to be produced
+    while (left > 0 && chunk <= c_hi) {
+      float chunks = 0.25f * float(left);
+      float rx[4], ry[4], off[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { rx[i] = wr_fract(px[i]); ry[i] = wr_fract(py[i]); }
+      chunks = wr_min(chunks, dcxx - rx[0] * dcxy);
+      chunks = wr_min(chunks, dcyx - ry[0] * dcyy);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        off[i] = rx[i] * sdx + ry[i] * sdy - G.start_offset;
+        if (G.repeat != 0.0f) off[i] = wr_fract(off[i]);
+      }
+      float startEntry;
+      int minIndex, maxIndex;
+      if (off[0] < 0.0f) {
+        startEntry = 0.0f; minIndex = maxIndex = 0;
+        if (delta > 0.0f) chunks = wr_min(chunks, -off[0] / delta);
+      } else if (off[0] < 1.0f) {
+        startEntry = 1.0f + off[0] * size;
+        if (delta < 0.0f) chunks = wr_min(chunks, -off[0] / delta);
+        else if (delta > 0.0f) chunks = wr_min(chunks, (1.0f - off[0]) / delta);
+        const float endEntry = wr_clamp(1.0f + (off[0] + delta * float(int(chunks))) * size, 0.0f, 1.0f + size);
+        minIndex = maxIndex = int(startEntry);
+        if (delta > 0.0f) {
+          while (float(maxIndex + 1) < endEntry && wr_stops_merge(stops, maxIndex, maxIndex + 1)) maxIndex++;
+          chunks = wr_min(chunks, (float(maxIndex + 1) - startEntry) / (delta * size));
+        } else if (delta < 0.0f) {
+          while (float(minIndex - 1) > endEntry && wr_stops_merge(stops, minIndex - 1, minIndex)) minIndex--;
+          chunks = wr_min(chunks, (float(minIndex) - startEntry) / (delta * size));
+        }
+      } else {
+        startEntry = 1.0f + size; minIndex = maxIndex = int(startEntry);
+        if (delta < 0.0f) chunks = wr_min(chunks, (1.0f - off[0]) / delta);
+      }
+      if (chunks >= 1.0f) {
+        const int inside = int(chunks);
+        if (chunk + inside > c_lo) {
+          // colours of the merged range in 0..0xFF00, BGRA order
+          const float* s0 = stops + 8 * minIndex; const float* s1 = stops + 8 * maxIndex;
+          const float mn[4] = {s0[2] * 65280.0f, s0[1] * 65280.0f, s0[0] * 65280.0f, s0[3] * 65280.0f};
+          const float mx[4] = {(s1[2] + s1[6]) * 65280.0f, (s1[1] + s1[5]) * 65280.0f, (s1[0] + s1[4]) * 65280.0f,
+                               (s1[3] + s1[7]) * 65280.0f};
+          const float inv = 1.0f / float(maxIndex + 1 - minIndex);
+          const float se = startEntry - float(minIndex), ds = delta * size;
+          for (int c = wr_imax(c_lo, chunk); c <= c_hi && c < chunk + inside; c++) {
+            const int kk = c - chunk, seg = kk >> 6, r = kk & 63;
+            uint32_t ch[4][4];           // [pixel][channel]
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const float range = (mx[q] - mn[q]) * inv;
+              float cf = mn[q] + range * se + 128.0f;
+              const float dcf = range * ds;
+              const uint32_t dc = wr_u16_round1(dcf);
+              for (int t = 0; t < seg; t++) cf += dcf * 64.0f;
+              ch[0][q] = ((wr_u16_round1(cf) + uint32_t(r) * dc) & 0xFFFF) >> 8;
+              ch[1][q] = ((wr_u16_round1(cf + dcf * 0.25f) + uint32_t(r) * dc) & 0xFFFF) >> 8;
+              ch[2][q] = ((wr_u16_round1(cf + dcf * 0.5f) + uint32_t(r) * dc) & 0xFFFF) >> 8;
+              ch[3][q] = ((wr_u16_round1(cf + dcf * 0.75f) + uint32_t(r) * dc) & 0xFFFF) >> 8;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int o = P.x0 + 4 * c + i - x;
+              if (o >= 0 && o < 4) { out.v[o].bg = ch[i][0] | (ch[i][1] << 16); out.v[o].ra = ch[i][2] | (ch[i][3] << 16); }
+            }
+          }
+        }
+        chunk += inside;
+        left -= inside * 4;
+        if (left <= 0) break;
+        const float fi = float(inside);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          px[i] += psx * fi; py[i] += psy * fi;
+          off[i] = wr_fract(px[i]) * sdx + wr_fract(py[i]) * sdy - G.start_offset;
+          if (G.repeat != 0.0f) off[i] = wr_fract(off[i]);
+        }
+      }
+      if (chunk >= c_lo && chunk <= c_hi) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int o = P.x0 + 4 * chunk + i - x;
+          if (o >= 0 && o < 4) out.v[o] = wr_sample_gradient(stops, wr_clamp(off[i] * size + 1.0f, 0.0f, 1.0f + size));
+        }
+      }
+      chunk++;
+      left -= 4;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { px[i] += psx; py[i] += psy; }
+    }
+  }
+  if (n_hi >= span) {
+    // main() pixels: init_interp lane, step_interp_inputs(drawn) once, then one step per chunk run
+    const WrTexDesc& gb = D->tex[WR_S_GPU_BUFFER_F];
+    for (int n = wr_imax(n_lo, span); n <= n_hi; n++) {
+      const int lane = (n - span) & 3, m = (n - span) >> 2;
+      float lu = ou, lv = ov;
+      for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
+      if (span > 0) {
+        const float chunks = float(span) * 0.25f;
+        lu = lu + (su * 4.0f) * chunks; lv = lv + (sv * 4.0f) * chunks;
+      }
+      lu = wr_accum(lu, (su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (sv * 4.0f) * 1.0f, m);
+      float offset = wr_fract(lu) * sdx + wr_fract(lv) * sdy - G.start_offset;
+      offset -= floorf(offset) * G.repeat;
+      const float xe = wr_clamp(1.0f + offset * 128.0f, 0.0f, 1.0f + 128.0f);
+      const float ei = floorf(xe), ef = xe - ei;
+      const int addr = G.address + 2 * int(ei);
+      const wf4 t0 = wr_fetch_f(gb, int(unsigned(addr) % 1024u), int(unsigned(addr) / 1024u));
+      const wf4 t1 = wr_fetch_f(gb, int(unsigned(addr) % 1024u) + 1, int(unsigned(addr) / 1024u));
+      uint32_t pc[2];
+      wr_pack_color(wf4{t0.x + t1.x * ef, t0.y + t1.y * ef, t0.z + t1.z * ef, t0.w + t1.w * ef}, pc);
+      out.v[P.x0 + n - x].bg = pc[0]; out.v[P.x0 + n - x].ra = pc[1];
+    }
+  }
+  return out;
 }
 
 // ---------------------------------------------------------------------------
@@ -2622,6 +2844,29 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
       } else {
         plo[q] = wr_blend_r8(blend, plo[q], src.bg & 0xFFFF);
+      }
+    }
+    return;
+  }
+  if ((FEAT & WR_FEAT_GENERIC) && FMT == WR_FMT_RGBA8 && kind == WR_PK_GRADIENT) {
+    if (!(cx[0] || cx[1] || cx[2] || cx[3])) return;
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      if (!cy[j]) continue;
+      const WrGrad4 g4 = wr_gradient_row4(Pp, &Ap->grad, D, px, py + 4 * j);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        bool in = cx[i];
+        if (dtest) {
+          const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+          in = in && pass;
+          if (dwrite) dep[q] = in ? z : dep[q];
+        }
+        if (!in) continue;
+        const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), g4.v[i], D);
+        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
       }
     }
     return;

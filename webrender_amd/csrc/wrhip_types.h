@@ -51,6 +51,8 @@ enum WrShader {
   WR_SH_CS_CLIP_BOX_SHADOW,
   WR_SH_BRUSH_IMAGE,
   WR_SH_BRUSH_IMAGE_ALPHA,
+  WR_SH_BRUSH_LINEAR_GRADIENT,
+  WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -165,6 +167,7 @@ enum WrPrimKind {
   WR_PK_CLIP_RECT,      // cs_clip_rectangle's rounded-rect span rasteriser (WrClipRec)
   WR_PK_BLUR,           // swgl_commitGaussianBlur{R8,RGBA8}: one separable pass (WrBlurRec)
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
+  WR_PK_GRADIENT,       // swgl_commitLinearGradientRGBA8 (WrGradRec); v_pos travels in WrPrim's uv interpolants
 };
 
 enum WrPrimFlags {
@@ -288,6 +291,16 @@ struct WrAARec {
   int32_t laa_end;
 };
 
+// brush_linear_gradient flat varyings (brush_linear_gradient.glsl:7-10, gradient.glsl:5-11)
+struct WrGradRec {
+  const float* stops;       // swgl_validateGradient: first float of the 130 x (start, step) table in sGpuBufferF,
+                            // or nullptr (no span shader: every pixel runs main())
+  int32_t address;          // v_gradient_address.x
+  float repeat;             // v_gradient_repeat.x
+  float scale_dir[2];       // v_scale_dir
+  float start_offset;       // v_start_offset.x
+};
+
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
   WrTexRec tex;
@@ -295,6 +308,7 @@ union WrAux {
   WrClipRec clip;
   WrBoxRec box;
   WrAARec aa;
+  WrGradRec grad;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

@@ -876,3 +876,158 @@ SCENES = {
     "cfg4": cfg4_box_shadow,
     "cfg5": cfg5_many_rects,
 }
+
+
+# ---------------------------------------------------------------------------
+# Linear gradients: brush_linear_gradient instances (batch.rs:2679-2780).  The
+# colour table is the 130-entry (start, step) LUT GradientGpuBlockBuilder::build
+# writes into GpuBufferF (prim_store/gradient/mod.rs:108-320); the brush block in
+# the GPU cache is [start_point, end_point], [extend_mode, stretch_size, 0]
+# (prim_store/gradient/linear.rs:466-482).
+
+GRADIENT_TABLE_SIZE = 128
+
+
+def build_gradient_lut(stops, reverse=False):
+    """stops: [(offset, (r, g, b, a) straight-alpha floats)], first offset 0, last 1.
+    Returns a (260, 4) float32 array: entry i = [start_color, end_step]."""
+    f32 = np.float32
+
+    def premul(c):
+        c = np.asarray(c, f32)
+        return np.array([c[0] * c[3], c[1] * c[3], c[2] * c[3], c[3]], f32)
+
+    entries = np.ones((GRADIENT_TABLE_SIZE + 2, 2, 4), f32)
+    entries[:, 1, :] = 0.0
+    first, begin, end, last = 0, 1, GRADIENT_TABLE_SIZE + 1, GRADIENT_TABLE_SIZE + 1
+
+    def fill(start_idx, end_idx, c0, c1, prev_step):
+        inv_steps = f32(1.0) / f32(end_idx - start_idx)
+        step = ((c1 - c0) * inv_steps).astype(f32)
+        if np.array_equal(step, prev_step):
+            bits = step[3:4].view(np.uint32)
+            bits[0] = 1 if step[3] == 0.0 else bits[0] + 1
+        cur = c0.copy()
+        for i in range(start_idx, end_idx):
+            entries[i, 0] = cur
+            cur = (cur + step).astype(f32)
+            entries[i, 1] = step
+        return step
+
+    def get_index(offset):
+        v = f32(min(max(f32(offset), f32(0.0)), f32(1.0))) * f32(GRADIENT_TABLE_SIZE) + f32(begin)
+        return int(np.floor(v + f32(0.5)))        # f32::round (half away from zero, v > 0)
+
+    it = iter(stops)
+    cur_color = premul(next(it)[1])
+    prev_step = cur_color.copy()
+    if reverse:
+        prev_step = fill(last, last + 1, cur_color, cur_color, prev_step)
+        cur_idx = end
+        for off, col in it:
+            nxt, idx = premul(col), get_index(1.0 - off)
+            if idx < cur_idx:
+                prev_step = fill(idx, cur_idx, nxt, cur_color, prev_step)
+                cur_idx = idx
+            cur_color = nxt
+        fill(first, first + 1, cur_color, cur_color, prev_step)
+    else:
+        prev_step = fill(first, first + 1, cur_color, cur_color, prev_step)
+        cur_idx = begin
+        for off, col in it:
+            nxt, idx = premul(col), get_index(off)
+            if idx > cur_idx:
+                prev_step = fill(cur_idx, idx, cur_color, nxt, prev_step)
+                cur_idx = idx
+            cur_color = nxt
+        fill(last, last + 1, cur_color, cur_color, prev_step)
+    return entries.reshape(-1, 4)
+
+
+def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only=None, fractional=True):
+    """Opaque-pass gradients on a disjoint grid in the top band (see image_grid on why),
+    translucent / overlapping ones below it in the alpha pass."""
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+
+    def rand_stops(opaque, k):
+        offs = [0.0] + sorted(float(o) for o in rng.uniform(0.05, 0.95, size=k - 2)) + [1.0]
+        if k > 3 and rng.integers(0, 2):
+            offs[2] = offs[1]                       # hard stop
+        cols = []
+        for _ in range(k):
+            c = [float(v) / 255.0 for v in rng.integers(0, 256, size=3)]
+            cols.append(tuple(c) + ((1.0,) if opaque else (float(rng.integers(40, 256)) / 255.0,)))
+        return list(zip(offs, cols))
+
+    luts = []
+    for i in range(10):
+        opaque = i < 4
+        stops = rand_stops(opaque, int(rng.integers(2, 6)))
+        addr = frame.gpu_buffer_f.push(build_gradient_lut(stops, reverse=bool(i & 1)))
+        luts.append((addr, opaque))
+    prims = []
+    band = 200
+
+    def make(rect, opaque_pass, k):
+        x0, y0, x1, y1 = rect
+        w, h = x1 - x0, y1 - y0
+        lut, _ = luts[(k % 4) if opaque_pass else int(rng.integers(0, len(luts)))]
+        mode = k % 8
+        if mode == 0:   sp, ep = (0.0, 0.0), (w, 0.0)                    # horizontal, whole rect
+        elif mode == 1: sp, ep = (0.0, 0.0), (0.0, h)                    # vertical
+        elif mode == 2: sp, ep = (0.0, 0.0), (w, h)                      # diagonal
+        elif mode == 3: sp, ep = (w * 0.75, h * 0.5), (w * 0.25, h * 0.4)  # reversed direction, short line
+        elif mode == 4: sp, ep = (w * 0.3, 0.0), (w * 0.6, 0.0)          # clamps on both sides
+        elif mode == 5: sp, ep = (float(rng.uniform(0, w)), float(rng.uniform(0, h))), (float(rng.uniform(0, w)), float(rng.uniform(0, h)))
+        elif mode == 6: sp, ep = (0.0, 0.0), (w * 0.2, h * 0.1)
+        else:           sp, ep = (w * 0.5, h * 0.5), (w * 0.5, h * 0.5)                  # degenerate line: delta is not finite, every pixel runs main()
+        extend = 1 if (k % 3 == 1) else 0
+        stretch = (w, h) if k % 5 else (max(w / 2.5, 8.0), max(h / 1.5, 8.0))      # tiled pattern
+        spec = frame.gpu_cache.push([[sp[0], sp[1], ep[0], ep[1]], [float(extend), stretch[0], stretch[1], 0.0]])
+        prims.append((rect, spec, lut, opaque_pass))
+
+    gx = 4.0
+    k = 0
+    while True:
+        w, h = float(rng.integers(3, 180)), float(rng.integers(20, band - 10))
+        if gx + w + 4 > width:
+            break
+        off = 0.41 if (fractional and k % 2) else 0.0
+        make((gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), True, k)
+        gx += float(np.ceil(w)) + 5.0
+        k += 1
+    for k in range(n):
+        w, h = float(rng.uniform(2, 500)), float(rng.uniform(2, 400))
+        px, py = float(rng.uniform(-40, width - 20)), float(rng.uniform(band, height - 10))
+        if not fractional or k % 4 == 0:
+            px, py, w, h = float(int(px)), float(int(py)), float(int(w) + 1), float(int(h) + 1)
+        make((px, py, px + w, py + h), False, k)
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        op, al = [], []
+        for zi, (rect, spec, lut, opaque) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, (lut, 0, 0, 0))
+            (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY))
+        if op:
+            target.opaque.append(Step("brush_linear_gradient", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
+                                      None, "opaque"))
+        if al:
+            target.alpha.append(Step("brush_linear_gradient ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha"))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
