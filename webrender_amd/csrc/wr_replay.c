@@ -85,8 +85,13 @@ int wr_replay_stream(wr_replay* R, const uint8_t* trace, size_t len, int iters, 
   struct timespec a, b;
   clock_gettime(CLOCK_MONOTONIC, &a);
   for (int i = 0; i < iters; i++) { int rc = run_once(R, trace, len); if (rc) return rc; }
+  struct timespec c;
+  clock_gettime(CLOCK_MONOTONIC, &c);
   if (finish) finish();
   clock_gettime(CLOCK_MONOTONIC, &b);
+  if (getenv("WR_REPLAY_TIMING"))   /* host issue time vs. total: is the stream CPU- or GPU-bound? */
+    fprintf(stderr, "wr_replay: %d frames issued in %.3f ms, finished after %.3f ms\n", iters,
+            (c.tv_sec - a.tv_sec) * 1e3 + (c.tv_nsec - a.tv_nsec) * 1e-6, (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6);
   *total_ms = (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6;
   return 0;
 }

@@ -183,6 +183,7 @@ struct TargetWork {
   std::vector<uint8_t> inst;       // instance bytes snapshotted at draw time
   std::vector<GLuint> reads;       // textures sampled by these draws
   int prims = 0;
+  int level = 0;                   // dependency depth inside the pending batch: samples targets of lower levels only
 };
 
 const size_t MAX_TEXTURE_UNITS = 16;
@@ -623,9 +624,9 @@ void apply_scissor(const Texture& t, int out[4]) {
 int find_or_add_work(GLuint tex_id) {
   {
     Texture& t = ctx->textures[tex_id];
-    if (t.pending_write && t.pending_target >= 0) return t.pending_target;
-    // the target is about to be written: pending draws that sample it must run first
+    // the target is about to be written (again): pending draws that sample it must run first
     if (t.pending_read) flush_all();
+    if (t.pending_write && t.pending_target >= 0) return t.pending_target;
   }
   TargetWork w;
   w.tex = tex_id;
@@ -701,16 +702,20 @@ void flush_work(const std::vector<int>& sel_in) {
   std::vector<int> sel(sel_in);
   std::sort(sel.begin(), sel.end());
   sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
-  // RGBA8 targets first so each raster kernel gets a contiguous bin range
+  // by dependency level, RGBA8 targets first inside a level, so each raster launch gets a contiguous bin range
   std::stable_sort(sel.begin(), sel.end(), [&](int a, int b) {
+    const int la = c->work[a].level, lb = c->work[b].level;
+    if (la != lb) return la < lb;
     return (c->textures[c->work[a].tex].internal_format == GL_R8) < (c->textures[c->work[b].tex].internal_format == GL_R8);
   });
+  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false; };
+  std::vector<Level> levels;
+  std::vector<int> target_level;
   const int n_targets = (int)sel.size();
   std::vector<WrDrawDesc> draws;
   std::vector<WrTargetDesc> targets(n_targets);
   std::vector<uint8_t> inst;
-  int prim_cursor = 0, bin_cursor = 0, word_cursor = 0, bins_rgba = 0;
-  bool any_depth = false;
+  int prim_cursor = 0, bin_cursor = 0, word_cursor = 0;
   size_t vtab_cursor = 0;
   uint64_t algo_bytes = 0, pixels = 0;
   for (int oi = 0; oi < n_targets; oi++) {
@@ -718,6 +723,9 @@ void flush_work(const std::vector<int>& sel_in) {
     Texture& t = c->textures[w.tex];
     WrTargetDesc& T = targets[oi];
     memset(&T, 0, sizeof(T));
+    if (levels.empty() || w.level != c->work[sel[oi - 1]].level) { levels.emplace_back(); levels.back().bin0 = bin_cursor; }
+    Level& L = levels.back();
+    target_level.push_back((int)levels.size() - 1);
     T.color = t.dptr; T.width = t.width; T.height = t.height; T.stride = t.stride;
     T.format = t.internal_format == GL_R8 ? WR_FMT_R8 : WR_FMT_RGBA8;
     T.bins_x = (t.width + WR_BIN_W - 1) / WR_BIN_W; T.bins_y = (t.height + WR_BIN_H - 1) / WR_BIN_H;
@@ -748,7 +756,7 @@ void flush_work(const std::vector<int>& sel_in) {
         continue;
       }
       any_kept = true;
-      if (d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) any_depth = true;
+      if ((d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) && T.format == WR_FMT_RGBA8) L.any_depth = true;
       d.first_prim = prim_cursor;
       prim_cursor += d.count;
       // per-row v table budget for draws whose prims can take the nearest-fast texture path
@@ -771,7 +779,7 @@ void flush_work(const std::vector<int>& sel_in) {
     T.word_base = word_cursor;
     word_cursor += T.words_per_bin * T.bins_x * T.bins_y;
     bin_cursor += T.bins_x * T.bins_y;
-    if (T.format == WR_FMT_RGBA8) bins_rgba = bin_cursor;
+    (T.format == WR_FMT_RGBA8 ? L.bins_rgba : L.bins_r8) += T.bins_x * T.bins_y;
     uint64_t owned = (uint64_t)t.width * std::max(0, T.y_end - T.y_begin);
     pixels += owned;
     algo_bytes += owned * t.bpp * (T.load_color ? 2 : 1);
@@ -880,9 +888,9 @@ void flush_work(const std::vector<int>& sel_in) {
     // 32 pixels measured slower on MI355X, profiles/r01_*).  The kernel is
     // specialised on the prim families present in the launch (FEAT) so that
     // rect-only passes do not pay the registers of the texture paths.
-    int feat_rgba = 0, feat_r8 = 0;
     for (int i = 0; i < nd; i++) {
       const bool to_r8 = targets[draws[i].target].format == WR_FMT_R8;
+      Level& L = levels[target_level[draws[i].target]];
       int f = 0;
       if (!(draws[i].flags & WR_DF_SIMPLE)) {
         switch (draws[i].shader) {
@@ -891,10 +899,11 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA: f = WR_FEAT_R8TEX | WR_FEAT_GENERIC; break;   // masked / odd blend
           case WR_SH_CS_BLUR_ALPHA: case WR_SH_CS_BLUR_COLOR: f = WR_FEAT_BLUR; break;
           case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW: f = WR_FEAT_CLIP; break;
+          case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }
       }
-      (to_r8 ? feat_r8 : feat_rgba) |= f;
+      (to_r8 ? L.feat_r8 : L.feat_rgba) |= f;
     }
 #define WR_RASTER_F(FMT, DEPTH, FEAT, NB, OFF)                                                                      \
   do {                                                                                                              \
@@ -902,25 +911,28 @@ void flush_work(const std::vector<int>& sel_in) {
               (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrAux*)c->daux, (const float*)c->dvtab, c->dmasks, OFF);             \
     c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
   } while (0)
-    // smallest instantiated superset of the launch's feature set
+    // smallest instantiated superset of the level's feature set
 #define WR_RASTER(DEPTH, NB, OFF)                                                                                   \
   do {                                                                                                              \
-    if (feat_rgba == 0) WR_RASTER_F(WR_FMT_RGBA8, DEPTH, 0, NB, OFF);                                               \
-    else if (!(feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC)))                                                       \
+    if (L.feat_rgba == 0) WR_RASTER_F(WR_FMT_RGBA8, DEPTH, 0, NB, OFF);                                             \
+    else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC)))                                                     \
       WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC, NB, OFF);                                     \
-    else if (!(feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX)))                                       \
+    else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX)))                                     \
       WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX, NB, OFF);                     \
-    else WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR, NB, OFF);   \
+    else WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE, NB, OFF);   \
   } while (0)
-    if (bins_rgba > 0) {
-      if (any_depth) WR_RASTER(true, bins_rgba, 0);
-      else WR_RASTER(false, bins_rgba, 0);
-    }
-    if (n_bins > bins_rgba) {
-      const int nb8 = n_bins - bins_rgba;
-      if (feat_r8 == 0) WR_RASTER_F(WR_FMT_R8, false, 0, nb8, bins_rgba);
-      else if (!(feat_r8 & WR_FEAT_CLIP)) WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR, nb8, bins_rgba);
-      else WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP, nb8, bins_rgba);
+    // one raster launch per dependency level and target format, in level order on the one stream
+    for (const Level& L : levels) {
+      if (L.bins_rgba > 0) {
+        if (L.any_depth) WR_RASTER(true, L.bins_rgba, L.bin0);
+        else WR_RASTER(false, L.bins_rgba, L.bin0);
+      }
+      if (L.bins_r8 > 0) {
+        const int off8 = L.bin0 + L.bins_rgba;
+        if (L.feat_r8 == 0) WR_RASTER_F(WR_FMT_R8, false, 0, L.bins_r8, off8);
+        else if (!(L.feat_r8 & WR_FEAT_CLIP)) WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR, L.bins_r8, off8);
+        else WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP, L.bins_r8, off8);
+      }
     }
 #undef WR_RASTER_F
 #undef WR_RASTER
@@ -1616,15 +1628,19 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   if (!instb || !instb->buf || need > instb->size) {
     if (inst_buf) { fprintf(stderr, "libwrhip: instance buffer too small\n"); return; }
   }
-  // textures sampled by this program: a pending target that gets sampled must be rendered first
+  int wi = find_or_add_work(color_id);   // may flush (target sampled by pending draws)
+  // A pending target that gets sampled is not flushed on the spot: the sampling target moves one
+  // dependency level above it and the whole chain (masks -> blurs -> tiles -> composite) goes
+  // through ONE flush -- one arena copy, one upload scatter, one setup launch, one raster launch
+  // per level -- instead of a full launch sequence per pass.
   for (int s = 0; s < WR_MAX_TEX; s++) {
     if (!((info->samplers >> s) & 1)) continue;
     GLuint tid = c->texture_units[prog->sampler_unit[s] & 15].texture_2d_binding;
     Texture* t = tid ? c->textures.find(tid) : nullptr;
-    if (!t || !t->dptr || tid == color_id) continue;   // null sampler
-    if (t->pending_write) flush_except(color_id);
+    if (!t || !t->dptr || tid == color_id) continue;
+    if (t->pending_write && t->pending_target >= 0)
+      c->work[wi].level = std::max(c->work[wi].level, c->work[t->pending_target].level + 1);
   }
-  int wi = find_or_add_work(color_id);   // may flush (target sampled by pending draws)
   Texture& colortex = c->textures[color_id];
   for (int s = 0; s < WR_MAX_TEX; s++) {
     if (!((info->samplers >> s) & 1)) continue;

@@ -1720,9 +1720,6 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   const int th = t.height;
   const float H = float(th);
   const float vstep = P.uvLs[1] * H;             // exact when H is a power of two
-  atomicAdd(&cnt->dbg[0], 1u);
-  if (P.rows_linear) atomicAdd(&cnt->dbg[1], 1u);
-  if (vstep == 1.0f || vstep == -1.0f) atomicAdd(&cnt->dbg[2], 1u);
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG_ROWS")) fprintf(stderr, "texrow: lin %d th %d vstep %.9g L0*H %.9g rows %d\n", P.rows_linear, th, vstep, P.uvL0[1] * H, P.y1 - P.y0);
 #endif
@@ -1735,7 +1732,6 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
       const int minUy = int(P.uv_bounds[1] * H), maxUy = int(P.uv_bounds[3] * H);
       if (minUy <= maxUy) {
         const int lo = wr_iclamp(minUy, 0, th - 1), hi = wr_iclamp(maxUy, 0, th - 1);
-        atomicAdd(&cnt->dbg[3], 1u);
         T.iy0 = int(py0);
         T.tix[2] = vstep > 0.0f ? 1 : -1;
         T.unit = lo | (hi << 16);
@@ -1765,7 +1761,13 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
   const bool valid = gid < n_prims;
   WrPrim P;
   P.kind = WR_PK_NONE; P.draw = 0; P.x0 = P.y0 = P.x1 = P.y1 = 0;
+#ifdef WRHIP_TIMING
+  const unsigned long long tm0 = wall_clock64();
+#endif
   if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, aux, targets, cnt);
+#ifdef WRHIP_TIMING
+  const unsigned long long tm1 = wall_clock64();
+#endif
   if (valid) {
     prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
     if (P.kind == WR_PK_TEX_R8) aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
@@ -1805,7 +1807,15 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
       }
     }
   }
+#ifdef WRHIP_TIMING
+  const unsigned long long tm2 = wall_clock64();
+#endif
   wr_bin_prim(P, valid, gid, draws, targets, masks);
+#ifdef WRHIP_TIMING
+  const unsigned long long tm3 = wall_clock64();
+  if (n_prims < 64) { atomicMax(&cnt->dbg[0], (unsigned)(tm1 - tm0)); atomicMax(&cnt->dbg[1], (unsigned)(tm2 - tm1)); atomicMax(&cnt->dbg[2], (unsigned)(tm3 - tm2)); }
+  else { atomicMax(&cnt->dbg[3], (unsigned)(tm1 - tm0)); atomicMax(&cnt->dbg[4], (unsigned)(tm2 - tm1)); atomicMax(&cnt->dbg[5], (unsigned)(tm3 - tm2)); }
+#endif
 }
 
 // Scatter queued texture uploads from the staging mirror to their textures.
@@ -2848,7 +2858,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & WR_FEAT_GENERIC) && FMT == WR_FMT_RGBA8 && kind == WR_PK_GRADIENT) {
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_GRADIENT) {
     if (!(cx[0] || cx[1] || cx[2] || cx[3])) return;
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll

@@ -90,6 +90,7 @@ enum WrFeat {
   WR_FEAT_GENERIC = 4,   // out-of-line per-pixel path: any blend key, linear filters, fragment-shader tails
   WR_FEAT_BLUR = 8,      // cs_blur
   WR_FEAT_CLIP = 16,     // cs_clip_rectangle / cs_clip_box_shadow (R8 targets)
+  WR_FEAT_SHADE = 32,    // per-row shader replays on RGBA8 targets: gradients
 };
 
 struct WrTexDesc {
