@@ -246,3 +246,29 @@ def test_sharded_player_single_rank_rccl():
         assert np.array_equal(got[..., [2, 1, 0, 3]], want)
     finally:
         dist.destroy_process_group()
+
+
+PIPELINED = [
+    lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=200, seed=40),
+    lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=220, seed=41, encoding="brush", fractional=True),
+    lambda: scenes.masked_rects(),
+    lambda: scenes.image_grid(),
+    lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=180, seed=42),
+    lambda: scenes.gradient_grid(),
+    lambda: scenes.cfg3_text(width=1024, height=1024, lines=30, glyphs_per_line=60, run_len=12),
+    lambda: scenes.masked_rects(fractional=True),
+    lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=250, seed=43, encoding="brush"),
+]
+
+
+def test_hip_pipelined_frames_match_isolated_frames():
+    """Different frames issued back to back with no Finish in between (host recording of frame
+    k+1 overlapping the GPU work of frame k; data textures re-uploaded, per-frame textures recycled
+    through the HBM pool) must each produce exactly what they produce when rendered alone."""
+    from webrender_amd.harness import render_pipelined
+    ref = oracle_lib("gcc")
+    for rep in range(3):
+        got = render_pipelined(wrhip_lib(), [m() for m in PIPELINED])
+        for i, (g, m) in enumerate(zip(got, PIPELINED)):
+            want, _ = render_direct(ref if (ref and rep == 0) else wrhip_lib(), m())
+            assert np.array_equal(g[..., [2, 1, 0, 3]], want), f"frame {i} (rep {rep})"

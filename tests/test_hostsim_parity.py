@@ -202,3 +202,22 @@ def test_strip_sharding_covers_frame(hostsim):
     # whole tiles (dist.py).  Here: the framebuffer strips of a single-target
     # scene must tile the frame.
     assert acc.shape == full.shape
+
+
+def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
+    """Host logic of back-to-back frames (upload batching, pool recycling, hazard flushes):
+    different frames without a Finish in between, each blitted into a keeper texture, must equal
+    the frames rendered alone by the reference."""
+    from webrender_amd.harness import render_pipelined
+    makes = [
+        lambda: scenes.cfg2_overlapping_rects(width=512, height=512, n=60, seed=40),
+        lambda: scenes.masked_rects(width=512, height=512, n=40),
+        lambda: scenes.cfg2_overlapping_rects(width=512, height=512, n=70, seed=41, encoding="brush", fractional=True),
+        lambda: scenes.image_grid(width=512, height=512, n=40),
+        lambda: scenes.gradient_grid(width=512, height=512, n=20),
+        lambda: scenes.cfg2_overlapping_rects(width=512, height=512, n=50, seed=42),
+    ]
+    got = render_pipelined(hostsim, [m() for m in makes])
+    for i, (g, m) in enumerate(zip(got, makes)):
+        want, _ = render_direct(oracle_gcc, m())
+        assert np.array_equal(g[..., [2, 1, 0, 3]], want), f"frame {i}"

@@ -95,3 +95,25 @@ def render_direct(backend_path, frame, frames=1):
         extra["window"] = px
         return extra, stats
     return px, stats
+
+
+def render_pipelined(backend_path, frames):
+    """Issue `frames` (same window size) back to back WITHOUT a Finish in between; after each
+    frame the window is blitted (device-side, asynchronous) into a keeper texture.  One Finish at
+    the end, then the keepers are read back: [BGRA8 pixels per frame].  Exercises the backend's
+    cross-frame pipelining (uploads of frame k+1 against the raster work of frame k)."""
+    gl = GL(backend_path)
+    w, h = frames[0].width, frames[0].height
+    r = Renderer(gl, w, h)
+    d = r.device
+    keepers = [d.create_texture(w, h, G.GL_RGBA8, render_target=True) for _ in frames]
+    for f, k in zip(frames, keepers):
+        r.render(f)
+        gl.BindFramebuffer(G.GL_READ_FRAMEBUFFER, 0)
+        gl.BindFramebuffer(G.GL_DRAW_FRAMEBUFFER, k.fbo)
+        gl.BlitFramebuffer(0, 0, w, h, 0, 0, w, h, G.GL_COLOR_BUFFER_BIT, G.GL_NEAREST)
+        gl.BindFramebuffer(G.GL_DRAW_FRAMEBUFFER, 0)
+    r.finish()
+    out = [d.read_texture(k) for k in keepers]
+    r.destroy()
+    return out
