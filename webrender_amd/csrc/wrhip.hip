@@ -729,6 +729,9 @@ void flush_work(const std::vector<int>& sel_in) {
     T.color = t.dptr; T.width = t.width; T.height = t.height; T.stride = t.stride;
     T.format = t.internal_format == GL_R8 ? WR_FMT_R8 : WR_FMT_RGBA8;
     T.bins_x = (t.width + WR_BIN_W - 1) / WR_BIN_W; T.bins_y = (t.height + WR_BIN_H - 1) / WR_BIN_H;
+    // every target starts on a 64-prim boundary: a wave of the setup kernel then holds prims of one
+    // target and one mask word only (the slots in between are skipped as instance >= count)
+    prim_cursor = (prim_cursor + 63) & ~63;
     T.first_bin = bin_cursor; T.first_prim = prim_cursor;
     T.load_color = 1; T.init_color = 0; T.load_depth = 0; T.store_depth = 0;
     Texture* dt = w.depth_tex ? c->textures.find(w.depth_tex) : nullptr;
@@ -809,12 +812,23 @@ void flush_work(const std::vector<int>& sel_in) {
     size_t off_draws = 0;
     size_t off_targets = (off_draws + sizeof(WrDrawDesc) * nd + 255) & ~size_t(255);
     size_t off_inst = (off_targets + sizeof(WrTargetDesc) * n_targets + 255) & ~size_t(255);
-    size_t total = off_inst + inst.size() + 256;
+    // first draw of every 64-prim block (wr_vertex_prim starts its draw lookup there)
+    const int n_blocks = (n_prims + 63) / 64;
+    size_t off_blk = (off_inst + inst.size() + 255) & ~size_t(255);
+    size_t total = off_blk + sizeof(int) * n_blocks + 256;
     size_t aoff = staging_alloc(total);
     uint8_t* h = c->staging + aoff;
     if (nd) memcpy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     memcpy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
     if (!inst.empty()) memcpy(h + off_inst, inst.data(), inst.size());
+    {
+      int* blk = (int*)(h + off_blk);
+      int j = 0;
+      for (int b = 0; b < n_blocks; b++) {
+        while (j + 1 < nd && draws[j + 1].first_prim <= 64 * b) j++;
+        blk[b] = j;
+      }
+    }
     flush_uploads();     // one DMA: queued texture uploads + this arena; then the scatter kernel
     uint8_t* darena = c->dupload + aoff;
     c->stats.h2d_bytes += total;
@@ -849,9 +863,16 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrDrawDesc* ddraws = (const WrDrawDesc*)(darena + off_draws);
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
     const uint8_t* dinst = darena + off_inst;
+    const int* dblk = (const int*)(darena + off_blk);
     if (n_prims > 0) {
-      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd, dinst, c->dprims, c->drecs, c->daux, n_prims,
-                dtargets, c->dmasks, c->dvtab, c->dcounters);
+#ifdef WRHIP_TIMING
+      static const int setup_mode = getenv("WRHIP_SETUP_MODE") ? atoi(getenv("WRHIP_SETUP_MODE")) : 0;
+      const int nd_arg = nd | (setup_mode << 24);
+#else
+      const int nd_arg = nd;
+#endif
+      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd_arg, dinst, c->dprims, c->drecs, c->daux, n_prims,
+                dtargets, c->dmasks, c->dvtab, c->dcounters, dblk);
       c->stats.kernel_launches += 1;
     }
 #ifdef WRHIP_HOSTSIM
@@ -1724,7 +1745,8 @@ void Finish(void) {
               h.unsupported_prims - ctx->seen.unsupported_prims, h.perspective_prims - ctx->seen.perspective_prims);
     }
     static const bool dbgc = getenv("WRHIP_DEBUG_COUNTERS") != nullptr;
-    if (dbgc) fprintf(stderr, "libwrhip dbg counters: %u %u %u %u %u %u\n", h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5]);
+    if (dbgc) fprintf(stderr, "libwrhip dbg counters (delta): %u %u %u %u %u (max %u)\n", h.dbg[0] - ctx->seen.dbg[0], h.dbg[1] - ctx->seen.dbg[1],
+                      h.dbg[2] - ctx->seen.dbg[2], h.dbg[3] - ctx->seen.dbg[3], h.dbg[4] - ctx->seen.dbg[4], h.dbg[5]);
     ctx->seen = h;
   }
   // externally backed default framebuffer: make the result visible to the host

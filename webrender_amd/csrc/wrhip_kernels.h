@@ -44,32 +44,57 @@ WR_DEVICE int wr_iclamp(int a, int lo, int hi) { return wr_imin(wr_imax(a, lo), 
 // clampCoord, texture.h:70-72
 WR_DEVICE int wr_clamp_coord(int c, int limit, int base = 0) { return wr_imin(wr_imax(c, base), limit - 1); }
 
+// Data-texture fetches are written for the memory system, not as the reference's scalar code reads:
+// the vertex stage is a chain of dependent reads (instance -> headers -> transform / task / GPU
+// buffer rows) run by a handful of waves, so what it costs is round trips.  One 16-byte load per
+// texel, no control flow around it (a null sampler reads a zero texel instead of branching), so
+// the independent fetches of a stage are all in flight together.
+#ifdef WRHIP_HOSTSIM
+static const uint32_t wr_zero_texel[4] = {0, 0, 0, 0};
+#else
+__device__ const uint32_t wr_zero_texel[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+#endif
+struct wr_u4 { uint32_t x, y, z, w; };
+WR_DEVICE wr_u4 wr_load16(const void* p) {
+  wr_u4 r;
+#ifdef WRHIP_HOSTSIM
+  __builtin_memcpy(&r, p, 16);
+#else
+  const uint4 v = *(const uint4*)p;       // texel rows are 16-byte aligned (pool storage, 1024-texel rows)
+  r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+#endif
+  return r;
+}
+WR_DEVICE float wr_bits_f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+
 // texelFetch(sampler2D RGBA32F, ivec2_scalar, 0), texture.h:283-292
 WR_DEVICE wf4 wr_fetch_f(const WrTexDesc& t, int x, int y) {
-  wf4 r = {0.f, 0.f, 0.f, 0.f};
-  if (!t.ptr) return r;  // null_sampler: 1x1 transparent black (gl.cc:901-912)
-  x = wr_clamp_coord(x, t.width);
-  y = wr_clamp_coord(y, t.height);
-  if (t.format == WR_FMT_RGBA32F) {
-    const float* p = (const float*)t.ptr + (size_t)x * 4 + (size_t)y * t.stride;
-    r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
-  } else {  // RGBA8: pixel_to_vec4, texture.h:101-105
-    uint32_t p = ((const uint32_t*)t.ptr)[(size_t)x + (size_t)y * t.stride];
-    r.x = float((p >> 16) & 0xFF) * (1.0f / 255.0f);
-    r.y = float((p >> 8) & 0xFF) * (1.0f / 255.0f);
-    r.z = float(p & 0xFF) * (1.0f / 255.0f);
-    r.w = float(p >> 24) * (1.0f / 255.0f);
+  const void* base = t.ptr;
+  const int w = t.width, h = t.height, stride = t.stride, fmt = t.format;
+  x = wr_clamp_coord(x, w);
+  y = wr_clamp_coord(y, h);
+  const bool f32 = base && fmt == WR_FMT_RGBA32F;   // null_sampler: 1x1 transparent black (gl.cc:901-912)
+  const void* p = f32 ? (const void*)((const float*)base + (size_t)x * 4 + (size_t)y * stride) : (const void*)wr_zero_texel;
+  const wr_u4 v = wr_load16(p);
+  wf4 r = {wr_bits_f(v.x), wr_bits_f(v.y), wr_bits_f(v.z), wr_bits_f(v.w)};
+  if (base && fmt != WR_FMT_RGBA32F) {  // RGBA8: pixel_to_vec4, texture.h:101-105
+    uint32_t q = ((const uint32_t*)base)[(size_t)x + (size_t)y * stride];
+    r.x = float((q >> 16) & 0xFF) * (1.0f / 255.0f);
+    r.y = float((q >> 8) & 0xFF) * (1.0f / 255.0f);
+    r.z = float(q & 0xFF) * (1.0f / 255.0f);
+    r.w = float(q >> 24) * (1.0f / 255.0f);
   }
   return r;
 }
 
 WR_DEVICE wi4 wr_fetch_i(const WrTexDesc& t, int x, int y) {  // texture.h:338-343
-  wi4 r = {0, 0, 0, 0};
-  if (!t.ptr) return r;
-  x = wr_clamp_coord(x, t.width);
-  y = wr_clamp_coord(y, t.height);
-  const int* p = (const int*)t.ptr + (size_t)x * 4 + (size_t)y * t.stride;
-  r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+  const void* base = t.ptr;
+  const int w = t.width, h = t.height, stride = t.stride;
+  x = wr_clamp_coord(x, w);
+  y = wr_clamp_coord(y, h);
+  const void* p = base ? (const void*)((const int*)base + (size_t)x * 4 + (size_t)y * stride) : (const void*)wr_zero_texel;
+  const wr_u4 v = wr_load16(p);
+  wi4 r = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
   return r;
 }
 
@@ -872,6 +897,9 @@ WR_DEVICE void wr_vs_ps_clear(const WrDrawDesc& d, const uint8_t* arena, int ins
   o.has_color = 0; o.aa_edges = 0; o.has_mask = 0;
 }
 
+// a[i] for a runtime i without making `a` addressable (a dynamically indexed local array, and
+// the struct around it, would live in scratch memory)
+WR_DEVICE float wr_pick4(const float (&a)[4], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
 WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
 
 // draw_quad (rasterize.h:1549-1633) + the axis-aligned closed form of
@@ -1004,10 +1032,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     float yScale = 1.0f / wr_max(ymax - ymin, 1.0f / 256.0f);
     float dy0 = ystart - ymin;
     // left edge
-    float lsu = (o.u[bl] - o.u[tl]) * yScale, lsv = (o.v[bl] - o.v[tl]) * yScale;
-    float rsu = (o.u[br] - o.u[tr]) * yScale, rsv = (o.v[br] - o.v[tr]) * yScale;
-    P.uvL0[0] = o.u[tl] + dy0 * lsu; P.uvL0[1] = o.v[tl] + dy0 * lsv;
-    P.uvR0[0] = o.u[tr] + dy0 * rsu; P.uvR0[1] = o.v[tr] + dy0 * rsv;
+    float lsu = (wr_pick4(o.u, bl) - wr_pick4(o.u, tl)) * yScale, lsv = (wr_pick4(o.v, bl) - wr_pick4(o.v, tl)) * yScale;
+    float rsu = (wr_pick4(o.u, br) - wr_pick4(o.u, tr)) * yScale, rsv = (wr_pick4(o.v, br) - wr_pick4(o.v, tr)) * yScale;
+    P.uvL0[0] = wr_pick4(o.u, tl) + dy0 * lsu; P.uvL0[1] = wr_pick4(o.v, tl) + dy0 * lsv;
+    P.uvR0[0] = wr_pick4(o.u, tr) + dy0 * rsu; P.uvR0[1] = wr_pick4(o.v, tr) + dy0 * rsv;
     P.uvLs[0] = lsu; P.uvLs[1] = lsv; P.uvRs[0] = rsu; P.uvRs[1] = rsv;
     P.xl = xmin; P.xr = xmax;
     {
@@ -1017,10 +1045,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     }
     if (o.kind == WR_PK_BOX_SHADOW) {
       WrBoxRec& B = auxp->box;
-      const float l2u = (o.u2[bl] - o.u2[tl]) * yScale, l2v = (o.v2[bl] - o.v2[tl]) * yScale;
-      const float r2u = (o.u2[br] - o.u2[tr]) * yScale, r2v = (o.v2[br] - o.v2[tr]) * yScale;
-      B.lpL0[0] = o.u2[tl] + dy0 * l2u; B.lpL0[1] = o.v2[tl] + dy0 * l2v;
-      B.lpR0[0] = o.u2[tr] + dy0 * r2u; B.lpR0[1] = o.v2[tr] + dy0 * r2v;
+      const float l2u = (wr_pick4(o.u2, bl) - wr_pick4(o.u2, tl)) * yScale, l2v = (wr_pick4(o.v2, bl) - wr_pick4(o.v2, tl)) * yScale;
+      const float r2u = (wr_pick4(o.u2, br) - wr_pick4(o.u2, tr)) * yScale, r2v = (wr_pick4(o.v2, br) - wr_pick4(o.v2, tr)) * yScale;
+      B.lpL0[0] = wr_pick4(o.u2, tl) + dy0 * l2u; B.lpL0[1] = wr_pick4(o.v2, tl) + dy0 * l2v;
+      B.lpR0[0] = wr_pick4(o.u2, tr) + dy0 * r2u; B.lpR0[1] = wr_pick4(o.v2, tr) + dy0 * r2v;
       B.lpLs[0] = l2u; B.lpLs[1] = l2v; B.lpRs[0] = r2u; B.lpRs[1] = r2v;
     }
   }
@@ -1560,7 +1588,8 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
       } else {
         if (t.span > 0) lu = lu + (t.su * 4.0f) * (float(t.span) * 0.25f);
         qx = int(wr_clamp(lu, t.ub0, t.ub2) * W * 128.0f + (0.5f - 64.0f));
-        t.tix[n - t.span] = qx >> 7;
+        const int k = n - t.span;       // no dynamic index: the record must stay in registers
+        if (k == 0) t.tix[0] = qx >> 7; else if (k == 1) t.tix[1] = qx >> 7; else t.tix[2] = qx >> 7;
       }
       ok = ok && (qx & 0x7F) == 0 && qx >= 0 && (qx >> 7) <= tex.width - 2;
     }
@@ -1580,18 +1609,22 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
 // Vertex stage of one instance: locate its draw, run the shader's vertex
 // function, then swgl's draw_quad setup.
 WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws, const uint8_t* __restrict__ arena,
-                              int gid, WrPrim& P, WrAux* aux, const WrTargetDesc* targets, WrUnsupportedCounters* cnt) {
+                              int gid, WrPrim& P, WrAux* aux, const WrTargetDesc* targets, WrUnsupportedCounters* cnt,
+                              const int* __restrict__ blk) {
   P.blend = 0; P.flags = 0; P.z = 0; P.color[0] = P.color[1] = 0; P.tex_slot = 0;
   P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0;
   P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0;
-  // binary search for the draw containing this instance
-  int lo = 0, hi = n_draws - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (draws[mid].first_prim <= gid) lo = mid; else hi = mid - 1;
-  }
+  // the draw containing this instance: the host's per-block table gives the draw at the start of
+  // the 64-prim block, the rest is a short forward scan (a binary search over the draws was
+  // log2(n) dependent round trips before the first useful load)
+  int lo = blk[gid >> 6];
+  while (lo + 1 < n_draws && draws[lo + 1].first_prim <= gid) lo++;
   const WrDrawDesc& d = draws[lo];
   int inst = gid - d.first_prim;
+  if (inst >= d.count) {   // padding slot between two targets (targets start on 64-prim boundaries)
+    P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo;
+    return;
+  }
   if (d.shader == WR_SH_CLEAR_OP) {
     P.kind = WR_PK_CLEAR; P.blend = WR_BLEND_NONE; P.draw = lo; P.z = d.clear_depth;
     P.flags = d.flags & (WR_PF_CLEAR_COLOR | WR_PF_CLEAR_DEPTH);
@@ -1631,55 +1664,88 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
 
 
 // Binning: bit (p - T.first_prim) of bin b's mask row <=> prim p touches bin b.
-// Small prims set their few bits themselves; prims spanning many bins are
-// handled by the whole wave (lanes stride over the bins), so a full-tile quad
-// costs 2-3 wave iterations instead of >100 serial atomics.
+//
+// A wave holds 64 consecutive prims, i.e. (part of) one 64-bit mask word per bin, and "prim
+// touches bin (bx, by)" is separable: [bx0 <= bx <= bx1] AND [by0 <= by <= by1].  So the word of
+// every bin is built 64 prims at a time from ballots:  X[bx] = ballot(bx0 <= bx <= bx1) for the
+// columns and Y[by] for the rows of the group's union bin box, parked one per lane,
+// and the write phase lets lane l own bin l of the box: word = X[col] & Y[row]
+// via two ds_bpermute pairs, one atomicOr per non-empty bin.  A tile-sized batch (16 x 8 bins)
+// costs ~200 wave instructions however many bins its prims span -- the per-prim loops this
+// replaces spent ~100 per prim (integer divisions, one wave pass per large prim).
+// Lanes of a wave are grouped by (target, word): groups are processed one after the other.
 WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDesc* draws, const WrTargetDesc* targets,
                            unsigned long long* masks) {
-  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bins_x = 1, wpb = 0;
-  unsigned long long* base = masks;
-  unsigned long long bit = 0;
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, tgt = -1, rel = 0;
   if (valid && P.kind != WR_PK_NONE && P.kind != WR_PK_UNSUPPORTED) {
-    const WrTargetDesc& T = targets[draws[P.draw].target];
+    tgt = draws[P.draw].target;
+    const WrTargetDesc& T = targets[tgt];
     bx0 = wr_imax(P.x0, 0) / WR_BIN_W; bx1 = (wr_imin(P.x1, T.width) - 1) / WR_BIN_W;
     by0 = wr_imax(P.y0, 0) / WR_BIN_H; by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
     by0 = wr_imax(by0, T.y_begin / WR_BIN_H); by1 = wr_imin(by1, (T.y_end - 1) / WR_BIN_H);
-    const int rel = gid - T.first_prim;
-    bit = 1ull << (rel & 63);
-    bins_x = T.bins_x; wpb = T.words_per_bin;
-    base = masks + (size_t)T.word_base + (rel >> 6);
+    rel = gid - T.first_prim;
   }
-  const int nbx = bx1 - bx0 + 1, nby = by1 - by0 + 1;
-  const int nb = (nbx > 0 && nby > 0) ? nbx * nby : 0;
+  const bool has = tgt >= 0 && bx1 >= bx0 && by1 >= by0;
 #ifdef WRHIP_HOSTSIM
-  for (int k = 0; k < nb; k++) {
-    int bx = bx0 + k % nbx, by = by0 + k / nbx;
-    atomicOr(&base[(size_t)(by * bins_x + bx) * wpb], bit);
+  if (has) {
+    const WrTargetDesc& T = targets[tgt];
+    unsigned long long* base = masks + (size_t)T.word_base + (rel >> 6);
+    for (int by = by0; by <= by1; by++)
+      for (int bx = bx0; bx <= bx1; bx++) atomicOr(&base[(size_t)(by * T.bins_x + bx) * T.words_per_bin], 1ull << (rel & 63));
   }
 #else
-  const int SMALL = 8;
-  if (nb > 0 && nb <= SMALL) {
-    for (int k = 0; k < nb; k++) {
-      int bx = bx0 + k % nbx, by = by0 + k / nbx;
-      atomicOr(&base[(size_t)(by * bins_x + bx) * wpb], bit);
-    }
-  }
-  unsigned long long big = __ballot(nb > SMALL);
+  typedef short wr_s2 __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
-  while (big) {
-    const int b = __builtin_ctzll(big);
-    big &= big - 1;
-    const int sbx0 = __builtin_amdgcn_readlane(bx0, b), snbx = __builtin_amdgcn_readlane(nbx, b);
-    const int sby0 = __builtin_amdgcn_readlane(by0, b), snb = __builtin_amdgcn_readlane(nb, b);
-    const int sbins_x = __builtin_amdgcn_readlane(bins_x, b), swpb = __builtin_amdgcn_readlane(wpb, b);
-    const unsigned blo = __builtin_amdgcn_readlane((unsigned)(bit & 0xFFFFFFFFu), b), bhi = __builtin_amdgcn_readlane((unsigned)(bit >> 32), b);
-    const unsigned plo_ = __builtin_amdgcn_readlane((unsigned)((uintptr_t)base & 0xFFFFFFFFu), b);
-    const unsigned phi_ = __builtin_amdgcn_readlane((unsigned)((uintptr_t)base >> 32), b);
-    unsigned long long* sbase = (unsigned long long*)(((uintptr_t)phi_ << 32) | plo_);
-    const unsigned long long sbit = ((unsigned long long)bhi << 32) | blo;
-    for (int k = lane; k < snb; k += 64) {
-      int bx = sbx0 + k % snbx, by = sby0 + k / snbx;
-      atomicOr(&sbase[(size_t)(by * sbins_x + bx) * swpb], sbit);
+  unsigned long long todo = __ballot(has);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const int s_tgt = __builtin_amdgcn_readlane(tgt, leader), s_word = __builtin_amdgcn_readlane(rel >> 6, leader);
+    const bool mine = has && tgt == s_tgt && (rel >> 6) == s_word;
+    todo &= ~__ballot(mine);
+    // bit of lane L is (rel & 63) = L + shift, the same shift for the whole group (consecutive prims)
+    const int s_shift = __builtin_amdgcn_readlane((rel & 63) - lane, leader);
+    const WrTargetDesc& T = targets[s_tgt];
+    const int bins_x = T.bins_x, wpb = T.words_per_bin;
+    unsigned long long* base = masks + (size_t)T.word_base + s_word;
+    // union bin box of the group: packed 16-bit min / max butterflies
+    wr_s2 lo2 = {(short)(mine ? bx0 : 32767), (short)(mine ? by0 : 32767)};
+    wr_s2 hi2 = {(short)(mine ? bx1 : -1), (short)(mine ? by1 : -1)};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const wr_s2 ol = __builtin_bit_cast(wr_s2, __shfl_xor(__builtin_bit_cast(int, lo2), d));
+      const wr_s2 oh = __builtin_bit_cast(wr_s2, __shfl_xor(__builtin_bit_cast(int, hi2), d));
+      lo2 = __builtin_elementwise_min(lo2, ol); hi2 = __builtin_elementwise_max(hi2, oh);
+    }
+    const int ux0 = __builtin_amdgcn_readfirstlane((int)lo2.x), uy0 = __builtin_amdgcn_readfirstlane((int)lo2.y);
+    const int ux1 = __builtin_amdgcn_readfirstlane((int)hi2.x), uy1 = __builtin_amdgcn_readfirstlane((int)hi2.y);
+    for (int cx0 = ux0; cx0 <= ux1; cx0 += 64) {
+      const int W = wr_imin(64, ux1 - cx0 + 1);
+      unsigned xlo = 0, xhi = 0;                 // lane i: X[cx0 + i]
+      for (int i = 0; i < W; i++) {
+        const unsigned long long m = __ballot(mine && bx0 <= cx0 + i && bx1 >= cx0 + i);
+        xlo = lane == i ? (unsigned)m : xlo;
+        xhi = lane == i ? (unsigned)(m >> 32) : xhi;
+      }
+      const float rW = 1.0f / float(W);
+      for (int ry0 = uy0; ry0 <= uy1; ry0 += 64) {
+        const int H = wr_imin(64, uy1 - ry0 + 1);
+        unsigned ylo = 0, yhi = 0;               // lane j: Y[ry0 + j]
+        for (int j = 0; j < H; j++) {
+          const unsigned long long m = __ballot(mine && by0 <= ry0 + j && by1 >= ry0 + j);
+          ylo = lane == j ? (unsigned)m : ylo;
+          yhi = lane == j ? (unsigned)(m >> 32) : yhi;
+        }
+        for (int idx = lane; idx < W * H + lane; idx += 64) {   // trip count is wave-uniform (shuffles inside)
+          const bool live = idx < W * H;
+          const int row = live ? int((float(idx) + 0.5f) * rW) : 0;   // exact: idx < 4096, W <= 64
+          const int col = live ? idx - row * W : 0;
+          const unsigned wlo = (unsigned)__shfl((int)xlo, col) & (unsigned)__shfl((int)ylo, row);
+          const unsigned whi = (unsigned)__shfl((int)xhi, col) & (unsigned)__shfl((int)yhi, row);
+          unsigned long long w = ((unsigned long long)whi << 32) | wlo;
+          w = s_shift >= 0 ? (w << s_shift) : (w >> -s_shift);
+          if (live && w) atomicOr(&base[(size_t)((ry0 + row) * bins_x + cx0 + col) * wpb], w);
+        }
+      }
     }
   }
 #endif
@@ -1752,21 +1818,25 @@ WR_DEVICE int wr_texrow_entry(const WrTexRec& T, float ov_raw) {
 }
 
 // Vertex stage + binning, one thread per instance.
-__global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+__global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
                                 WrRec* __restrict__ recs, WrAux* __restrict__ aux, int n_prims,
                                 const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
-                                float* __restrict__ vtab, WrUnsupportedCounters* cnt) {
+                                float* __restrict__ vtab, WrUnsupportedCounters* cnt, const int* __restrict__ blk) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = gid < n_prims;
   WrPrim P;
   P.kind = WR_PK_NONE; P.draw = 0; P.x0 = P.y0 = P.x1 = P.y1 = 0;
 #ifdef WRHIP_TIMING
+  const int dbg_mode = n_draws >> 24;          // experiment switch: 1 empty kernel, 2 vertex stage only, 3 no binning
+  n_draws &= 0xFFFFFF;
+  if (dbg_mode == 1) return;
   const unsigned long long tm0 = wall_clock64();
 #endif
-  if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, aux, targets, cnt);
+  if (valid) wr_vertex_prim(draws, n_draws, arena, gid, P, aux, targets, cnt, blk);
 #ifdef WRHIP_TIMING
   const unsigned long long tm1 = wall_clock64();
+  if (dbg_mode == 2) { if (valid && P.x0 == 12345678) prims[gid] = P; return; }
 #endif
   if (valid) {
     prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
@@ -1810,11 +1880,18 @@ __global__ void wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draw
 #ifdef WRHIP_TIMING
   const unsigned long long tm2 = wall_clock64();
 #endif
+#ifdef WRHIP_TIMING
+  if (dbg_mode == 3) return;
+#endif
   wr_bin_prim(P, valid, gid, draws, targets, masks);
 #ifdef WRHIP_TIMING
   const unsigned long long tm3 = wall_clock64();
-  if (n_prims < 64) { atomicMax(&cnt->dbg[0], (unsigned)(tm1 - tm0)); atomicMax(&cnt->dbg[1], (unsigned)(tm2 - tm1)); atomicMax(&cnt->dbg[2], (unsigned)(tm3 - tm2)); }
-  else { atomicMax(&cnt->dbg[3], (unsigned)(tm1 - tm0)); atomicMax(&cnt->dbg[4], (unsigned)(tm2 - tm1)); atomicMax(&cnt->dbg[5], (unsigned)(tm3 - tm2)); }
+  if ((threadIdx.x & 63) == 0) {   // per-wave phase times, summed (host prints per-Finish deltas)
+    atomicAdd(&cnt->dbg[0], (unsigned)(tm1 - tm0)); atomicAdd(&cnt->dbg[1], (unsigned)(tm2 - tm1)); atomicAdd(&cnt->dbg[2], (unsigned)(tm3 - tm2));
+    atomicAdd(&cnt->dbg[3], 1u);
+    if (blockIdx.x == gridDim.x - 1) atomicAdd(&cnt->dbg[4], (unsigned)(tm3 - tm0));   // waves of the last workgroup (composite prims)
+    atomicMax(&cnt->dbg[5], (unsigned)(tm3 - tm0));
+  }
 #endif
 }
 
@@ -2657,6 +2734,54 @@ WR_DEVICE uint32_t wr_mul24(uint32_t a, uint32_t b) {
 #endif
 }
 
+// p = hi_bytes(p * K + C), in place.  Written as tied-operand asm on the device: v_mad_u32_u24 /
+// v_perm_b32 are three-address, and left to itself the compiler computes the 32 pixel registers
+// of a prim into a second register set and copies them back at the loop back-edge (16 v_mov_b64
+// per prim on top of the 64 useful VALU instructions -- seen in the round-1 ISA).
+WR_DEVICE void wr_fold_inplace(uint32_t& p, uint32_t K, uint32_t C) {
+#ifdef WRHIP_HOSTSIM
+  p = ((p * K + C) >> 8) & 0x00FF00FFu;
+#else
+  asm("v_mad_u32_u24 %0, %0, %1, %2\n\tv_perm_b32 %0, 0, %0, %3" : "+v"(p) : "s"(K), "v"(C), "v"(0x0c030c01u));
+#endif
+}
+// Lane masks: on the device a coverage predicate is kept as the 64-bit ballot of its compare
+// (an SGPR pair straight out of v_cmp), so combining the column and row predicates of a pixel is
+// one scalar AND instead of VALU selects; the host simulation keeps plain bools.
+#ifdef WRHIP_HOSTSIM
+typedef bool wr_lanemask;
+#define WR_LANEMASK(cond) (cond)
+#else
+typedef unsigned long long wr_lanemask;
+#define WR_LANEMASK(cond) __builtin_amdgcn_ballot_w64(cond)
+#endif
+// wr_fold_inplace for the lanes of `m` only (both channel pairs of one pixel): EXEC is narrowed
+// to the covered lanes around the four instructions, so a partially covered strip costs the same
+// four VALU instructions per pixel as a fully covered one plus two scalar instructions.
+WR_DEVICE void wr_fold_masked(uint32_t& lo, uint32_t& hi, uint32_t K, uint32_t Clo, uint32_t Chi, wr_lanemask m) {
+#ifdef WRHIP_HOSTSIM
+  if (m) { lo = ((lo * K + Clo) >> 8) & 0x00FF00FFu; hi = ((hi * K + Chi) >> 8) & 0x00FF00FFu; }
+#else
+  unsigned long long saved;
+  asm("s_and_saveexec_b64 %2, %3\n\t"
+      "v_mad_u32_u24 %0, %0, %4, %5\n\tv_perm_b32 %0, 0, %0, %7\n\t"
+      "v_mad_u32_u24 %1, %1, %4, %6\n\tv_perm_b32 %1, 0, %1, %7\n\t"
+      "s_mov_b64 exec, %2"
+      : "+v"(lo), "+v"(hi), "=&s"(saved)
+      : "s"(m), "s"(K), "v"(Clo), "v"(Chi), "v"(0x0c030c01u)
+      : "scc");
+#endif
+}
+
+// d = v in the lanes of m
+WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
+#ifdef WRHIP_HOSTSIM
+  if (m) d = v;
+#else
+  asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(d) : "v"(v), "s"(m));
+#endif
+}
+
 // Pixels are held as two registers of 2 x 16-bit fields: lo = (B, R), hi = (G, A)
 // of the BGRA8 texel -- i.e. WideRGBA8 with the channels paired so that one
 // 32-bit multiply serves two channels (fields never carry into each other:
@@ -2687,28 +2812,26 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     if (full && !dtest) {
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
-        plo[q] = wr_hi_bytes(wr_mul24(plo[q], K) + Clo);
-        phi[q] = wr_hi_bytes(wr_mul24(phi[q], K) + Chi);
+        wr_fold_inplace(plo[q], K, Clo);
+        wr_fold_inplace(phi[q], K, Chi);
       }
       return;
     }
-    bool cx[4];
+    wr_lanemask mx[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
+    for (int i = 0; i < 4; i++) mx[i] = WR_LANEMASK((unsigned)(px + i - x0) < (unsigned)(x1 - x0));
 #pragma unroll
     for (int j = 0; j < R; j++) {
-      const bool cyj = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
+      const wr_lanemask myj = WR_LANEMASK((unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0));
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
-        bool in = cx[i] && cyj;
+        wr_lanemask in = mx[i] & myj;
         if (dtest) {
-          const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
-          in = in && pass;
-          if (dwrite) dep[q] = in ? z : dep[q];
+          in = in & WR_LANEMASK(dless ? (z < dep[q]) : (z <= dep[q]));
+          if (dwrite) wr_select_masked(dep[q], z, in);
         }
-        const uint32_t nl = wr_hi_bytes(wr_mul24(plo[q], K) + Clo), nh = wr_hi_bytes(wr_mul24(phi[q], K) + Chi);
-        plo[q] = in ? nl : plo[q]; phi[q] = in ? nh : phi[q];
+        wr_fold_masked(plo[q], phi[q], K, Clo, Chi, in);
       }
     }
     return;
