@@ -15,6 +15,7 @@
 #include "cs_clip_box_shadow.h"
 #include "brush_image.h"
 #include "brush_linear_gradient.h"
+#include "brush_blend.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -38,6 +39,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("brush_image ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
   WRSH_ENTRY("brush_linear_gradient", brush_linear_gradient)
   WRSH_ENTRY("brush_linear_gradient ALPHA_PASS", brush_linear_gradient_ALPHA_PASS)
+  WRSH_ENTRY("brush_blend", brush_blend)
+  WRSH_ENTRY("brush_blend ALPHA_PASS", brush_blend_ALPHA_PASS)
 #undef WRSH_ENTRY
   return nullptr;
 }

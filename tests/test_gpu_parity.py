@@ -35,6 +35,8 @@ def test_device_is_gfx950():
     gl.DestroyContext(ctx)
 
 
+FILTER_OPS_EXACT = [0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]
+
 SMALL = [
     ("cfg1", lambda: scenes.cfg1_solid_colors()),
     ("cfg1_brush", lambda: scenes.cfg1_solid_colors(encoding="brush")),
@@ -56,6 +58,11 @@ SMALL = [
     ("gradient_grid", lambda: scenes.gradient_grid()),
     ("gradient_grid_wide", lambda: scenes.gradient_grid(width=2048, height=1024, n=300, seed=63)),
     ("gradient_grid_int", lambda: scenes.gradient_grid(width=1000, height=700, n=150, seed=65, fractional=False)),
+    # brush_blend: every filter op except hue-rotate is bit-exact (swgl's pow() is its own float approximation,
+    # restated); hue-rotate builds its matrix from libm's cosf / sinf in the vertex stage -> test below
+    ("filter_grid_exact", lambda: scenes.filter_grid(ops=FILTER_OPS_EXACT)),
+    ("filter_grid_exact_wide", lambda: scenes.filter_grid(width=2048, height=1024, n=160, seed=72, ops=FILTER_OPS_EXACT)),
+    ("filter_grid_exact_int", lambda: scenes.filter_grid(width=1000, height=700, n=60, seed=73, fractional=False, ops=FILTER_OPS_EXACT)),
     ("aa_rects_brush", lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True, encoding="brush", aa_edges=15)),
     ("aa_rects_quad", lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True, encoding="quad", aa_edges=15)),
     ("aa_rects_brush_lr", lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True, encoding="brush", aa_edges=5)),
@@ -272,3 +279,16 @@ def test_hip_pipelined_frames_match_isolated_frames():
         for i, (g, m) in enumerate(zip(got, PIPELINED)):
             want, _ = render_direct(ref if (ref and rep == 0) else wrhip_lib(), m())
             assert np.array_equal(g[..., [2, 1, 0, 3]], want), f"frame {i} (rep {rep})"
+
+
+def test_hip_filter_hue_rotate_within_one_lsb():
+    """FILTER_HUE_ROTATE: the colour matrix comes from cos / sin of the angle (blend.glsl:49-58), libm
+    on the reference's side and the device math library here -- the one brush_blend case that is
+    held to the north-star tolerance (+-1 LSB) instead of 0."""
+    ref = oracle_lib("gcc")
+    if not ref:
+        pytest.skip("oracle not built")
+    make = lambda: scenes.filter_grid(ops=[2], n=48, seed=74)
+    got, _ = render_direct(wrhip_lib(), make())
+    want, _ = render_direct(ref, make())
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1

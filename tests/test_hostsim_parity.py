@@ -48,6 +48,9 @@ CASES = [
     ("gradient_grid", lambda: scenes.gradient_grid()),
     ("gradient_grid_wide", lambda: scenes.gradient_grid(width=2048, height=1024, n=300, seed=63)),
     ("gradient_grid_int", lambda: scenes.gradient_grid(width=1000, height=700, n=150, seed=65, fractional=False)),
+    ("filter_grid", lambda: scenes.filter_grid()),
+    ("filter_grid_wide", lambda: scenes.filter_grid(width=2048, height=1024, n=160, seed=72)),
+    ("filter_grid_int", lambda: scenes.filter_grid(width=1000, height=700, n=60, seed=73, fractional=False)),
     ("aa_rects_brush", lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True, encoding="brush", aa_edges=15)),
     ("aa_rects_quad", lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True, encoding="quad", aa_edges=15)),
     ("aa_rects_brush_lr", lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True, encoding="brush", aa_edges=5)),

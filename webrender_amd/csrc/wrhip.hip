@@ -129,6 +129,8 @@ const ShaderInfo SHADERS[] = {
     {"brush_image ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_linear_gradient", WR_SH_BRUSH_LINEAR_GRADIENT, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
     {"brush_linear_gradient ALPHA_PASS", WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
+    {"brush_blend", WR_SH_BRUSH_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_blend ALPHA_PASS", WR_SH_BRUSH_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"composite TEXTURE_2D", WR_SH_COMPOSITE,
      {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
@@ -921,6 +923,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_CS_BLUR_ALPHA: case WR_SH_CS_BLUR_COLOR: f = WR_FEAT_BLUR; break;
           case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW: f = WR_FEAT_CLIP; break;
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }
       }

@@ -348,13 +348,15 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 // brush.glsl:95-222 + prim_shared.glsl:54-200 + brush_solid.glsl:22-40
 // `image`: 0 = brush_solid, 1 = brush_image (opaque pass), 2 = brush_image ALPHA_PASS (brush_image.glsl:54-314,
 // fast variant: no REPETITION / ANTIALIASING feature)
-// image: 0 brush_solid, 1 brush_image, 2 brush_image ALPHA_PASS, 3 brush_linear_gradient (G = its side record)
-WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr) {
+// image: 0 brush_solid, 1 brush_image, 2 brush_image ALPHA_PASS, 3 brush_linear_gradient (G = its side record),
+//        4 brush_blend (F = its side record)
+WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr,
+                            WrFilterRec* F = nullptr) {
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
   const int resource_address = aData.w & 0xffffff;
-  const int vecs_per_brush = image == 3 ? 2 : (image ? 3 : 1);
+  const int vecs_per_brush = image == 3 ? 2 : (image ? 3 : 1);   // VECS_PER_SPECIFIC_BRUSH
   // fetch_prim_header
   int u, v;
   wr_fetch_uv(prim_header_address, 2u, u, v);
@@ -454,6 +456,85 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
     o.kind = WR_PK_GRADIENT;
     if (brush_flags & 1) o.kind = WR_PK_UNSUPPORTED;      // perspective interpolation: next
+    return;
+  }
+  if (image == 4) {
+    // brush_vs (brush_blend.glsl:43-87)
+    const int src_address = data1.x;
+    const int sau = int(unsigned(src_address) % 1024u), sav = int(unsigned(src_address) / 1024u);
+    const wf4 res0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], sau, sav);                   // fetch_image_source (gpu_cache.glsl:104-109)
+    const int qa = src_address + 2;                                                  // fetch_image_source_extra (:127-135)
+    const int qu = int(unsigned(qa) % 1024u), qv = int(unsigned(qa) / 1024u);
+    const wf4 st_tl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu, qv), st_tr = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 1, qv);
+    const wf4 st_bl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 2, qv), st_br = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 3, qv);
+    const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+    const float itx = 1.0f / float(tex.ptr ? tex.width : 1), ity = 1.0f / float(tex.ptr ? tex.height : 1);
+    const float persp = (brush_flags & 1) ? 1.0f : 0.0f;
+    for (int n = 0; n < 4; n++) {
+      float fx = (vlx[n] - local_rect.x) / (local_rect.z - local_rect.x), fy = (vly[n] - local_rect.y) / (local_rect.w - local_rect.y);
+      // get_image_quad_uv (prim_shared.glsl:204-210): mix(a, b, t) = (b - a) * t + a
+      const float xx = (st_tr.x - st_tl.x) * fx + st_tl.x, xy = (st_tr.y - st_tl.y) * fx + st_tl.y, xw = (st_tr.w - st_tl.w) * fx + st_tl.w;
+      const float yx = (st_br.x - st_bl.x) * fx + st_bl.x, yy = (st_br.y - st_bl.y) * fx + st_bl.y, yw = (st_br.w - st_bl.w) * fx + st_bl.w;
+      const float zx = (yx - xx) * fy + xx, zy = (yy - xy) * fy + xy, zw = (yw - xw) * fy + xw;
+      fx = zx / zw; fy = zy / zw;
+      const float uu = (res0.z - res0.x) * fx + res0.x, vv = (res0.w - res0.y) * fy + res0.y;
+      const float pm = (1.0f - vww[n]) * persp + vww[n];          // mix(world_pos.w, 1.0, perspective_interpolate)
+      o.u[n] = uu * itx * pm; o.v[n] = vv * ity * pm;
+    }
+    o.uv_bounds = wf4{(res0.x + 0.5f) * itx, (res0.y + 0.5f) * ity, (res0.z - 0.5f) * itx, (res0.w - 0.5f) * ity};
+    o.tex_slot = WR_S_COLOR0;
+    o.tail_clamp = 1; o.tail_modulate = 0;
+    o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    o.kind = WR_PK_FILTER;
+    if (brush_flags & 1) { o.kind = WR_PK_UNSUPPORTED; return; }   // perspective interpolation: next
+    const float amount = float(data1.z) / 65536.0f;
+    const int op = data1.y & 0xffff;
+    F->op = op; F->amount = amount; F->table_address = 0;
+    F->funcs[0] = float((data1.y >> 28) & 0xf); F->funcs[1] = float((data1.y >> 24) & 0xf);
+    F->funcs[2] = float((data1.y >> 20) & 0xf); F->funcs[3] = float((data1.y >> 16) & 0xf);
+    // SetupFilterParams (blend.glsl:27-87); color_mat is column-major: m[4 * column + row]
+    float* m = F->color_mat;
+    for (int i = 0; i < 16; i++) m[i] = 0.0f;
+    for (int i = 0; i < 4; i++) F->color_offset[i] = 0.0f;
+    const float lumR = 0.2126f, lumG = 0.7152f, lumB = 0.0722f;
+    const float oneMinusLumR = 1.0f - lumR, oneMinusLumG = 1.0f - lumG, oneMinusLumB = 1.0f - lumB;
+    const float invAmount = 1.0f - amount;
+    if (op == 1) {          // FILTER_GRAYSCALE
+      m[0] = lumR + oneMinusLumR * invAmount; m[1] = lumR - lumR * invAmount; m[2] = lumR - lumR * invAmount;
+      m[4] = lumG - lumG * invAmount; m[5] = lumG + oneMinusLumG * invAmount; m[6] = lumG - lumG * invAmount;
+      m[8] = lumB - lumB * invAmount; m[9] = lumB - lumB * invAmount; m[10] = lumB + oneMinusLumB * invAmount;
+      m[15] = 1.0f;
+    } else if (op == 2) {   // FILTER_HUE_ROTATE
+      const float c = cosf(amount), sn = sinf(amount);
+      m[0] = lumR + oneMinusLumR * c - lumR * sn; m[1] = lumR - lumR * c + 0.143f * sn; m[2] = lumR - lumR * c - oneMinusLumR * sn;
+      m[4] = lumG - lumG * c - lumG * sn; m[5] = lumG + oneMinusLumG * c + 0.140f * sn; m[6] = lumG - lumG * c + lumG * sn;
+      m[8] = lumB - lumB * c + oneMinusLumB * sn; m[9] = lumB - lumB * c - 0.283f * sn; m[10] = lumB + oneMinusLumB * c + lumB * sn;
+      m[15] = 1.0f;
+    } else if (op == 4) {   // FILTER_SATURATE
+      m[0] = invAmount * lumR + amount; m[1] = invAmount * lumR; m[2] = invAmount * lumR;
+      m[4] = invAmount * lumG; m[5] = invAmount * lumG + amount; m[6] = invAmount * lumG;
+      m[8] = invAmount * lumB; m[9] = invAmount * lumB; m[10] = invAmount * lumB + amount;
+      m[15] = 1.0f;
+    } else if (op == 5) {   // FILTER_SEPIA
+      m[0] = 0.393f + 0.607f * invAmount; m[1] = 0.349f - 0.349f * invAmount; m[2] = 0.272f - 0.272f * invAmount;
+      m[4] = 0.769f - 0.769f * invAmount; m[5] = 0.686f + 0.314f * invAmount; m[6] = 0.534f - 0.534f * invAmount;
+      m[8] = 0.189f - 0.189f * invAmount; m[9] = 0.168f - 0.168f * invAmount; m[10] = 0.131f + 0.869f * invAmount;
+      m[15] = 1.0f;
+    } else if (op == 7) {   // FILTER_COLOR_MATRIX: 4 columns + offset from the GPU cache
+      const int gu = int(unsigned(data1.z) % 1024u), gv = int(unsigned(data1.z) / 1024u);
+      for (int k = 0; k < 4; k++) {
+        const wf4 col = wr_fetch_f(d.tex[WR_S_GPU_CACHE], gu + k, gv);
+        m[4 * k] = col.x; m[4 * k + 1] = col.y; m[4 * k + 2] = col.z; m[4 * k + 3] = col.w;
+      }
+      const int ou = int(unsigned(data1.z + 4) % 1024u), ov = int(unsigned(data1.z + 4) / 1024u);
+      const wf4 off = wr_fetch_f(d.tex[WR_S_GPU_CACHE], ou, ov);
+      F->color_offset[0] = off.x; F->color_offset[1] = off.y; F->color_offset[2] = off.z; F->color_offset[3] = off.w;
+    } else if (op == 11) {  // FILTER_COMPONENT_TRANSFER
+      F->table_address = data1.z;
+    } else if (op == 10) {  // FILTER_FLOOD
+      const wf4 off = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(data1.z) % 1024u), int(unsigned(data1.z) / 1024u));
+      F->color_offset[0] = off.x; F->color_offset[1] = off.y; F->color_offset[2] = off.z; F->color_offset[3] = off.w;
+    }
     return;
   }
   // brush_vs (brush_image.glsl:54-314)
@@ -1014,7 +1095,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1370,7 +1451,7 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   r.len = P.x1 - P.x0;
   r.span = r.len >= 4 ? (r.len & ~3) : 0;
   r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
-  if (P.kind == WR_PK_TEX_FS) r.span = 0;     // no draw_span for this program/target: all main()
+  if (P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER) r.span = 0;     // no draw_span for this program/target: all main()
   if (r.span == 0) return r;
   float W = float(t.width), H = float(t.height);
   // lanes 0 and 1 of the uv vector handed to swgl_commitTexture* (shader-side offset included)
@@ -1644,6 +1725,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_IMAGE_ALPHA: wr_vs_brush(d, arena, inst, 2, o); break;
     case WR_SH_BRUSH_LINEAR_GRADIENT:
     case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: wr_vs_brush(d, arena, inst, 3, o, &aux[gid].grad); break;
+    case WR_SH_BRUSH_BLEND:
+    case WR_SH_BRUSH_BLEND_ALPHA: wr_vs_brush(d, arena, inst, 4, o, nullptr, &aux[gid].filt); break;
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
@@ -2134,6 +2217,133 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
 //               min(bounds.z, start + span, width); 8.8 fixed-point taps with
 //               saturating adds (texture.h:1165-1308)
 //   the rest    the float fragment shader (cs_blur.glsl:137-181)
+// ---------------------------------------------------------------------------
+// brush_blend fragment shader (brush_blend.glsl:91-120, blend.glsl:90-237), one pixel.
+// swgl has no span shader for it: main() runs on every 4-pixel chunk with glsl.h's float
+// vectors, so the restatement is per pixel in strict fp32, same operation order.
+// pow() is glsl.h's approximation (glsl.h:776-799), not libm -- restated bit for bit.
+WR_DEVICE float wr_glsl_floor(float v) {            // glsl.h:687-690
+  const float roundtrip = float(int(v));
+  return roundtrip - (roundtrip > v ? 1.0f : 0.0f);
+}
+WR_DEVICE float wr_approx_log2(float x) {           // glsl.h:776-784
+  uint32_t b; __builtin_memcpy(&b, &x, 4);
+  const float e = float(b) * (1.0f / (1 << 23));
+  const uint32_t mb = (b & 0x007fffffu) | 0x3f000000u;
+  float m; __builtin_memcpy(&m, &mb, 4);
+  return e - 124.225514990f - 1.498030302f * m - 1.725879990f / (0.3520887068f + m);
+}
+WR_DEVICE float wr_approx_pow2(float x) {           // glsl.h:786-791; roundfast = cast(v * scale + 0.5f) (portable path)
+  const float f = x - wr_glsl_floor(x);
+  const float t = x + 121.274057500f - 1.490129070f * f + 27.728023300f / (4.84252568f - f);
+  const int32_t r = int32_t((1.0f * (1 << 23)) * t + 0.5f);
+  float o; __builtin_memcpy(&o, &r, 4);
+  return o;
+}
+WR_DEVICE float wr_glsl_pow(float x, float y) {     // glsl.h:797-799
+  return (x == 0.0f || x == 1.0f) ? x : wr_approx_pow2(wr_approx_log2(x) * y);
+}
+
+__device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrFilterRec& F = *Fp;
+  const WrTexDesc& t = D->tex[P.tex_slot];
+  // v_uv of this pixel as the 4-wide fragment loop steps it, clamped to v_uv_sample_bounds
+  const WrTexRow r = wr_tex_row(P, t, y);
+  float cu, cv;
+  wr_tex_tail_uv(P, r, x - P.x0, cu, cv);
+  // texture(sColor0, uv): texture.h:1028-1071 (linear RGBA8, 7-bit fractions) / nearest
+  const float W = float(t.width), H = float(t.height);
+  float cr, cg, cb, ca;
+  if (!t.ptr) { cr = cg = cb = ca = 0.0f; }
+  else if (t.format == WR_FMT_R8) {
+    float m;
+    if (t.linear) m = float(wr_sample_linear_r8(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
+    else m = float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride]) * (1.0f / 255.0f);
+    cr = m; cg = 0.0f; cb = 0.0f; ca = 1.0f;
+  } else if (t.linear) {
+    const WrWide s = wr_sample_linear_rgba8(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)));
+    cb = float(s.bg & 0xFFFF) * (1.0f / 255.0f); cg = float(s.bg >> 16) * (1.0f / 255.0f);
+    cr = float(s.ra & 0xFFFF) * (1.0f / 255.0f); ca = float(s.ra >> 16) * (1.0f / 255.0f);
+  } else {
+    const uint32_t p = ((const uint32_t*)t.ptr)[(size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride];
+    cb = float(p & 0xFF) * (1.0f / 255.0f); cg = float((p >> 8) & 0xFF) * (1.0f / 255.0f);
+    cr = float((p >> 16) & 0xFF) * (1.0f / 255.0f); ca = float(p >> 24) * (1.0f / 255.0f);
+  }
+  // CalculateFilter (blend.glsl:190-237): un-premultiply, filter
+  float alpha = ca;
+  float c[3] = {alpha != 0.0f ? cr / alpha : cr, alpha != 0.0f ? cg / alpha : cg, alpha != 0.0f ? cb / alpha : cb};
+  const float amount = F.amount;
+  switch (F.op) {
+    case 0:   // FILTER_CONTRAST
+      for (int i = 0; i < 3; i++) c[i] = wr_clamp(c[i] * amount - 0.5f * amount + 0.5f, 0.0f, 1.0f);
+      break;
+    case 3:   // FILTER_INVERT: mix(Cs, 1 - Cs, amount)
+      for (int i = 0; i < 3; i++) c[i] = ((1.0f - c[i]) - c[i]) * amount + c[i];
+      break;
+    case 6:   // FILTER_BRIGHTNESS
+      for (int i = 0; i < 3; i++) c[i] = wr_clamp(c[i] * amount, 0.0f, 1.0f);
+      break;
+    case 8:   // FILTER_SRGB_TO_LINEAR
+      for (int i = 0; i < 3; i++) {
+        const float c1 = c[i] / 12.92f, c2 = wr_glsl_pow(c[i] / 1.055f + (0.055f / 1.055f), 2.4f);
+        c[i] = c[i] <= 0.04045f ? c1 : c2;
+      }
+      break;
+    case 9:   // FILTER_LINEAR_TO_SRGB
+      for (int i = 0; i < 3; i++) {
+        const float c1 = c[i] * 12.92f, c2 = 1.055f * wr_glsl_pow(c[i], 1.0f / 2.4f) - 0.055f;
+        c[i] = c[i] <= 0.0031308f ? c1 : c2;
+      }
+      break;
+    case 11: {  // FILTER_COMPONENT_TRANSFER (blend.glsl:126-188)
+      float ch[4] = {c[0], c[1], c[2], alpha};
+      const WrTexDesc& gc = D->tex[WR_S_GPU_CACHE];
+      int offset = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int fn = int(F.funcs[i]);
+        if (fn == 1 || fn == 2) {           // TABLE / DISCRETE: 256-entry lookup, 4 values per block
+          const int k = int(wr_glsl_floor(ch[i] * 255.0f + 0.5f));
+          const unsigned a = unsigned(F.table_address + offset + k / 4);
+          const wf4 tx = wr_fetch_f(gc, int(a % 1024u), int(a / 1024u));
+          const int sel = k % 4;
+          const float v = sel == 0 ? tx.x : (sel == 1 ? tx.y : (sel == 2 ? tx.z : (sel == 3 ? tx.w : 0.0f)));
+          ch[i] = wr_clamp(v, 0.0f, 1.0f);
+          offset += 64;
+        } else if (fn == 3) {               // LINEAR
+          const unsigned a = unsigned(F.table_address + offset);
+          const wf4 tx = wr_fetch_f(gc, int(a % 1024u), int(a / 1024u));
+          ch[i] = wr_clamp(tx.x * ch[i] + tx.y, 0.0f, 1.0f);
+          offset += 1;
+        } else if (fn == 4) {               // GAMMA
+          const unsigned a = unsigned(F.table_address + offset);
+          const wf4 tx = wr_fetch_f(gc, int(a % 1024u), int(a / 1024u));
+          ch[i] = wr_clamp(tx.x * wr_glsl_pow(ch[i], tx.y) + tx.z, 0.0f, 1.0f);
+          offset += 1;
+        }
+      }
+      c[0] = ch[0]; c[1] = ch[1]; c[2] = ch[2]; alpha = ch[3];
+      break;
+    }
+    case 10:  // FILTER_FLOOD
+      c[0] = F.color_offset[0]; c[1] = F.color_offset[1]; c[2] = F.color_offset[2]; alpha = F.color_offset[3];
+      break;
+    default: {  // colour-matrix filters: color_mat * vec4(color, alpha) + color_offset (glsl.h:2582-2598 order)
+      const float* m = F.color_mat;
+      float o4[4];
+      for (int i = 0; i < 4; i++)
+        o4[i] = wr_clamp((m[i] * c[0] + m[4 + i] * c[1] + m[8 + i] * c[2] + m[12 + i] * alpha) + F.color_offset[i], 0.0f, 1.0f);
+      c[0] = o4[0]; c[1] = o4[1]; c[2] = o4[2]; alpha = o4[3];
+    }
+  }
+  // Fragment(alpha * vec4(color, 1.0)) -> pack_pixels_RGBA8
+  uint32_t pc[2];
+  wr_pack_color(wf4{alpha * c[0], alpha * c[1], alpha * c[2], alpha * 1.0f}, pc);
+  WrWide s; s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
 template <int FMT>
 __device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* Bp, int x, int y) {
   const WrPrim& P = *Pp;
@@ -3001,6 +3211,23 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), g4.v[i], D);
         plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
       }
+    }
+    return;
+  }
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_FILTER) {
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      bool in = cx[q & 3] && cy[q >> 2];
+      if (dtest) {
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+        in = in && pass;
+        if (dwrite) dep[q] = in ? z : dep[q];
+      }
+      if (!in) continue;
+      const WrWide src = wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2));
+      const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+      plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;
   }

@@ -53,6 +53,8 @@ enum WrShader {
   WR_SH_BRUSH_IMAGE_ALPHA,
   WR_SH_BRUSH_LINEAR_GRADIENT,
   WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA,
+  WR_SH_BRUSH_BLEND,
+  WR_SH_BRUSH_BLEND_ALPHA,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -90,7 +92,7 @@ enum WrFeat {
   WR_FEAT_GENERIC = 4,   // out-of-line per-pixel path: any blend key, linear filters, fragment-shader tails
   WR_FEAT_BLUR = 8,      // cs_blur
   WR_FEAT_CLIP = 16,     // cs_clip_rectangle / cs_clip_box_shadow (R8 targets)
-  WR_FEAT_SHADE = 32,    // per-row shader replays on RGBA8 targets: gradients
+  WR_FEAT_SHADE = 32,    // shader replays on RGBA8 targets: gradients (per row), brush_blend filters (per pixel)
 };
 
 struct WrTexDesc {
@@ -169,6 +171,7 @@ enum WrPrimKind {
   WR_PK_BLUR,           // swgl_commitGaussianBlur{R8,RGBA8}: one separable pass (WrBlurRec)
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
   WR_PK_GRADIENT,       // swgl_commitLinearGradientRGBA8 (WrGradRec); v_pos travels in WrPrim's uv interpolants
+  WR_PK_FILTER,         // brush_blend: fragment shader only (texture() + CalculateFilter, WrFilterRec); uv as WR_PK_TEX_FS
 };
 
 enum WrPrimFlags {
@@ -302,6 +305,16 @@ struct WrGradRec {
   float start_offset;       // v_start_offset.x
 };
 
+// brush_blend flat varyings (brush_blend.glsl:17-41)
+struct WrFilterRec {
+  int32_t op;               // v_op
+  int32_t table_address;    // v_table_address (component transfer data in sGpuCache)
+  float amount;             // v_amount
+  float funcs[4];           // v_funcs
+  float color_mat[16];      // v_color_mat, column-major
+  float color_offset[4];    // v_color_offset
+};
+
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
   WrTexRec tex;
@@ -310,6 +323,7 @@ union WrAux {
   WrBoxRec box;
   WrAARec aa;
   WrGradRec grad;
+  WrFilterRec filt;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

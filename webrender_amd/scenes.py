@@ -1031,3 +1031,144 @@ def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only
         frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
     frame.passes.append(targets)
     return frame
+
+
+# ---------------------------------------------------------------------------
+# brush_blend: CSS filters on picture surfaces (batch.rs:1726-1860).  The "picture" each
+# prim filters is a premultiplied RGBA8 image in a linear-filtered atlas (standing in for the
+# picture's render task); its ImageSource carries the UvRectKind::Quad corners that
+# get_image_quad_uv reads (gpu_types.rs:949-970).
+FILTER_CONTRAST, FILTER_GRAYSCALE, FILTER_HUE_ROTATE, FILTER_INVERT, FILTER_SATURATE, FILTER_SEPIA = 0, 1, 2, 3, 4, 5
+FILTER_BRIGHTNESS, FILTER_COLOR_MATRIX, FILTER_SRGB_TO_LINEAR, FILTER_LINEAR_TO_SRGB, FILTER_FLOOD = 6, 7, 8, 9, 10
+FILTER_COMPONENT_TRANSFER = 11
+CT_IDENTITY, CT_TABLE, CT_DISCRETE, CT_LINEAR, CT_GAMMA = 0, 1, 2, 3, 4
+
+
+def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=None, ops=None, only=None,
+                fractional=True):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    pix = np.zeros((atlas, atlas, 4), np.uint8)
+    srcs = []
+    x = y = shelf = 0
+    for i in range(20):
+        w, h = int(rng.integers(32, 180)), int(rng.integers(32, 150))
+        if x + w > atlas:
+            x, y, shelf = 0, y + shelf, 0
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 0] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+        img[..., 1] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+        if i % 3 == 0:
+            img[..., 3] = 255
+        elif i % 3 == 1:
+            img[..., 3] = np.where((xx // 8 + yy // 8) % 4 == 0, 0, img[..., 3])    # holes: alpha == 0 lanes
+        img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)   # premultiplied
+        pix[y:y + h, x:x + w] = img
+        if i % 4 == 3:     # a sub-quad in homogeneous coordinates (w != 1)
+            quad = [[0.125, 0.0625, 0.0, 1.0], [1.75, 0.125, 0.0, 2.0], [0.0625, 0.9375, 0.0, 1.0], [0.96875, 1.0, 0.0, 1.0]]
+        else:
+            quad = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
+        addr = frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]] + quad)
+        srcs.append((w, h, addr, i % 3 == 0))
+        x += w
+        shelf = max(shelf, h)
+    t_atlas = TextureRef("picture_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pix, upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+
+    def filter_params(k):
+        """-> (filter_mode, user_data.z) as batch.rs:1727-1756 / :1817-1823 encode them"""
+        op = (ops or list(range(12)))[k % len(ops or range(12))]
+        if op in (FILTER_CONTRAST, FILTER_GRAYSCALE, FILTER_INVERT, FILTER_SATURATE, FILTER_SEPIA, FILTER_BRIGHTNESS):
+            amount = float(rng.choice([0.0, 0.25, 0.5, 1.0, 1.5, 2.25])) if k % 2 else float(rng.uniform(0.0, 2.0))
+            return op, int(np.float32(amount) * np.float32(65536.0))
+        if op == FILTER_HUE_ROTATE:
+            angle = float(rng.uniform(0.0, 360.0))
+            return op, int(np.float32(0.01745329251) * np.float32(angle) * np.float32(65536.0))
+        if op in (FILTER_SRGB_TO_LINEAR, FILTER_LINEAR_TO_SRGB):
+            return op, 0
+        if op == FILTER_COLOR_MATRIX:
+            m = rng.uniform(-0.5, 1.2, size=(4, 4)).astype(np.float32)
+            off = rng.uniform(-0.2, 0.3, size=4).astype(np.float32)
+            return op, frame.gpu_cache.push([list(r) for r in m] + [list(off)])
+        if op == FILTER_FLOOD:
+            a = float(rng.uniform(0.2, 1.0))
+            return op, frame.gpu_cache.push([[float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), a]])
+        # component transfer: per channel r, g, b, a
+        funcs = [int(rng.integers(0, 5)) for _ in range(4)]
+        blocks = []
+        for f in funcs:
+            if f in (CT_TABLE, CT_DISCRETE):
+                nv = int(rng.integers(2, 7))
+                vals = rng.uniform(-0.1, 1.1, size=nv).astype(np.float32)
+                lut = np.empty(256, np.float32)
+                for i in range(256):      # filterdata.rs: the 256-entry expansion of the table / discrete function
+                    c = np.float32(i) / np.float32(255.0)
+                    if f == CT_TABLE:
+                        kk = min(int(c * (nv - 1)), nv - 2)
+                        lut[i] = vals[kk] + (c * (nv - 1) - kk) * (vals[kk + 1] - vals[kk])
+                    else:
+                        lut[i] = vals[min(int(c * nv), nv - 1)]
+                blocks += [list(lut[4 * j:4 * j + 4]) for j in range(64)]
+            elif f == CT_LINEAR:
+                blocks.append([float(rng.uniform(-1.5, 2.0)), float(rng.uniform(-0.3, 0.5)), 0.0, 0.0])
+            elif f == CT_GAMMA:
+                blocks.append([float(rng.uniform(0.5, 1.5)), float(rng.choice([0.4, 1.0, 2.2, 3.0])), float(rng.uniform(-0.1, 0.2)), 0.0])
+        addr = frame.gpu_cache.push(blocks) if blocks else 0
+        mode = FILTER_COMPONENT_TRANSFER | (funcs[0] << 28) | (funcs[1] << 24) | (funcs[2] << 20) | (funcs[3] << 16)
+        return int(np.int32(np.uint32(mode))), addr
+
+    prims = []
+    band = 200
+    gx = 4.0
+    opaque_srcs = [s_ for s_ in srcs if s_[3]]
+    for k in range(max(1, n // 6)):      # opaque pass: non-overlapping grid in the top band (see image_grid)
+        sw, sh, addr, _ = opaque_srcs[k % len(opaque_srcs)]
+        w, h = float(sw), float(min(sh, band - 8))
+        if gx + w + 4 > width:
+            break
+        mode, ud = filter_params(k)
+        if (mode & 0xffff) in (FILTER_COLOR_MATRIX, FILTER_FLOOD, FILTER_COMPONENT_TRANSFER):
+            mode, ud = FILTER_SEPIA, 65536      # these may introduce transparency: never batched opaque (batch.rs:1760)
+        off = 0.0 if (k % 2 == 0 or not fractional) else 0.37
+        prims.append(((gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), addr, True, mode, ud))
+        gx += float(np.ceil(w)) + 6.0
+    for k in range(n):
+        sw, sh, addr, _ = srcs[int(rng.integers(0, len(srcs)))]
+        sc = (1.0, 1.0, float(rng.uniform(1.1, 2.5)), 0.5, float(rng.uniform(0.4, 1.6)))[k % 5]
+        w, h = sw * sc, sh * sc
+        if k % 5 == 0 or not fractional:
+            px, py = float(rng.integers(-20, width - 20)), float(rng.integers(band, height - 20))
+            w, h = float(round(w)), float(round(h))
+        else:
+            px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - 40))
+        mode, ud = filter_params(k + 1000)
+        prims.append(((px, py, px + w, py + h), addr, False, mode, ud))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        op, al = [], []
+        for zi, (rect, addr, opaque, mode, ud) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (addr, mode, ud, 0))
+            (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15))
+        if op:
+            target.opaque.append(Step("brush_blend", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
+                                      None, "opaque", textures={0: t_atlas}))
+        if al:
+            target.alpha.append(Step("brush_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
