@@ -3099,6 +3099,31 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     const bool has_color = (flags & WR_PF_HAS_COLOR) != 0;
     const bool inspan = n0 >= 0 && n0 + 4 <= T.span;
     const int xa = T.ix0 + n0;
+    // Plain copy of a strip the prim covers completely (tile composites: unit rows, no blend, no
+    // colour, no column clamp in reach, 16-byte aligned columns): one 16-byte load per lane and
+    // row, two VALU instructions per pixel.  Every condition is wave-uniform.
+    {
+      const int xw = T.ix0 + (wx0 - x0);        // source column of the strip's first pixel
+      if (full && !dtest && blend == WR_BLEND_NONE && !has_color && T.simple == 3 && wx0 - x0 >= 0 &&
+          wx0 - x0 + WR_BIN_W <= T.span && xw >= T.tix[0] && xw + WR_BIN_W - 1 <= T.tix[1] && (xw & 3) == 0 &&
+          (T.stride & 3) == 0 && (((uintptr_t)T.ptr) & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          const int y = py + 4 * j;
+          const int srow = wr_iclamp(T.iy0 + T.tix[2] * (y - T.y0), T.unit & 0xFFFF, T.unit >> 16);
+#ifdef WRHIP_HOSTSIM
+          uint32_t v[4];
+          __builtin_memcpy(v, sbuf + (size_t)srow * T.stride + xa, 16);
+#else
+          const uint4 vv = *(const uint4*)(sbuf + (size_t)srow * T.stride + xa);
+          const uint32_t v[4] = {vv.x, vv.y, vv.z, vv.w};
+#endif
+#pragma unroll
+          for (int i = 0; i < 4; i++) { plo[4 * j + i] = v[i] & WR_M8; phi[4 * j + i] = (v[i] >> 8) & WR_M8; }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int y = py + 4 * j;
