@@ -2000,6 +2000,22 @@ __global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_seg
   }
 }
 
+// One pixel of an anti-aliased solid quad (DO_AA, blend.h:433-446): src = muldiv256(src, coverage)
+// ahead of the blend.  Out of line: its float math must not cost the textured kernels registers.
+__device__ __noinline__ uint32_t wr_aa_pixel_rgba8(const WrAARec* Ap, const WrDrawDesc* D, int blend, uint32_t c0, uint32_t c1,
+                                                    int n, int x0, uint32_t dstp) {
+  const WrAARec& A = *Ap;
+  const int lane = n & 3, base = x0 + (n & ~3);
+  const float off = float(4 * (base - A.laa_end));
+  const float dl = (A.lstart + float(A.laa_end + lane) * A.lend) + (A.lend / 4.0f) * off;
+  const float dr = (A.rstart + float(A.laa_end + lane) * A.rend) + (A.rend / 4.0f) * off;
+  const uint32_t cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
+  WrWide src;
+  src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+  src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+  return wr_blend_rgba8(blend, dstp, src, D);
+}
+
 // Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
 // Kept out of line so the fast paths below stay small and the 16 pixels of a
 // lane stay in registers.
@@ -3269,15 +3285,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (dwrite) dep[q] = in ? z : dep[q];
       }
       if (!in) continue;
-      const int n = px + (q & 3) - x0, lane = n & 3, base = x0 + (n & ~3);
-      const float off = float(4 * (base - A.laa_end));
-      const float dl = (A.lstart + float(A.laa_end + lane) * A.lend) + (A.lend / 4.0f) * off;
-      const float dr = (A.rstart + float(A.laa_end + lane) * A.rend) + (A.rend / 4.0f) * off;
-      const uint32_t cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
-      WrWide src;
-      src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
-      src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
-      const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+      const uint32_t r = wr_aa_pixel_rgba8(&A, D, blend, c0, c1, px + (q & 3) - x0, x0, plo[q] | (phi[q] << 8));
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;
