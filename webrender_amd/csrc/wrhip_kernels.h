@@ -190,6 +190,47 @@ WR_DEVICE bool wr_accum_is_linear(float s0, float step, int c) {
   const double bound = a0 > a1 ? a0 : a1;
   return g > -900 && g < 100 && bound < __builtin_ldexp(1.0, g + 24);
 }
+// The general case, binade by binade.  While the running sum stays inside one binade
+// [2^e, 2^(e+1)) its ulp u is fixed, the sum is a multiple of u, and fl(s + step) = s + q*u with
+// q = round(step / u) -- the same q every time unless step / u sits exactly on a rounding tie.  So
+// all the adds that stay inside the binade are one exact fp64 multiply-add; only the adds that
+// cross a binade boundary (and ties, zero / denormal sums) are executed one by one.  Verified
+// against the plain loop on random, dyadic, tie-prone and binade-floor inputs (tests/test_accum.py);
+// a 1840-row box-shadow mask spent ~900 dependent adds per interpolant and row in that loop.
+WR_DEVICE float wr_accum_binades(float s0, float step, int c) {
+  float s = s0;
+  int k = c;
+  while (k > 0) {
+    uint32_t b; __builtin_memcpy(&b, &s, 4);
+    const int ex = int((b >> 23) & 0xFF);
+    if (ex == 0 || ex == 0xFF) { s = s + step; k--; continue; }              // zero / denormal / inf / nan: plain step
+    const double u = ldexp(1.0, ex - 127 - 23);                              // ulp of the binade
+    const double r = double(step) / u;                                       // exact (power-of-two scaling)
+    if (!(r > -16777216.0 && r < 16777216.0)) { s = s + step; k--; continue; }   // step dwarfs the sum
+    const double q = rint(r);                                                // nearest, ties to even
+    const double fr = r - q;
+    if (fr == 0.5 || fr == -0.5) { s = s + step; k--; continue; }            // tie: the parity of s decides
+    const double as = s < 0.0f ? -double(s) : double(s);
+    const double lo = ldexp(1.0, ex - 127), hi = lo * 2.0;
+    const double dq = (s < 0.0f ? -q : q) * u;                               // signed change of |s| per add
+    if (dq == 0.0) {
+      // |step| < u/2: s + step rounds back to s -- unless s sits on the binade floor and moves down (finer grid below)
+      if (as == lo && ((step < 0.0f) != (s < 0.0f))) { s = s + step; k--; continue; }
+      return s;
+    }
+    const double n = dq > 0.0 ? floor((hi - as) / dq) - 2.0      // every exact sum s_i + step must stay <= hi
+                              : floor((as - lo) / -dq) - 2.0;    // ... and >= lo
+    if (n >= 1.0) {
+      const int steps = n > double(k) ? k : int(n);
+      s = float(double(s) + double(steps) * (q * u));                        // exact: multiples of u inside the binade
+      k -= steps;
+    }
+    // the few adds left up to (and across) the binade boundary: plain steps, no new analysis
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (k > 0) { s = s + step; k--; }
+  }
+  return s;
+}
 WR_DEVICE float wr_accum(float s0, float step, int c) {
   if (c <= 0 || step == 0.0f) return s0;
   const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
@@ -199,9 +240,7 @@ WR_DEVICE float wr_accum(float s0, float step, int c) {
   const double bound = a0 > a1 ? a0 : a1;
   if (g > -900 && g < 100 && bound < __builtin_ldexp(1.0, g + 24)) return float(end);
   WR_DBG_PATH(2);
-  float s = s0;
-  for (int i = 0; i < c; i++) s += step;
-  return s;
+  return wr_accum_binades(s0, step, c);
 }
 
 // row-k edge interpolant: closed form when the prim was verified linear over all its rows
@@ -2548,20 +2587,33 @@ struct WrRow4 { uint32_t v[4]; };
 
 // Four horizontally adjacent pixels (x .. x+3) of row y: the span-level setup is
 // evaluated once, each pixel then only classifies its chunk.
-__device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipRec* Cp, int x, int y) {
-  const WrPrim& P = *Pp;
-  const WrClipRec& C = *Cp;
-  WrRow4 out;
-  out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+// Interpolants of one target row at the span start (origin o[], per-pixel step s[]): what
+// Edge::nextRow has accumulated after (y - y0) rows.  They are the same for every pixel of the
+// row, and a wave's strip has 16 rows, so the raster stage evaluates them once per wave with 16
+// row-owning lanes and hands them round with ds_bpermute (wr_apply_prim) instead of once per lane-row.
+struct WrRowVals { float o[4], s[4]; };
+WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y) {
+  WrRowVals rv;
   const int k = y - P.y0;
   const bool lin = P.rows_linear != 0;
   const float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
   const float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
-  const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
   const float start = float(P.x0) + 0.5f - P.xl;
-  const float ou = Lu + su * start, ov = Lv + sv * start;
+  rv.s[0] = (Ru - Lu) * stepScale; rv.s[1] = (Rv - Lv) * stepScale;
+  rv.o[0] = Lu + rv.s[0] * start; rv.o[1] = Lv + rv.s[1] * start;
+  rv.s[2] = rv.s[3] = rv.o[2] = rv.o[3] = 0.0f;
+  return rv;
+}
+
+__device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipRec* Cp, WrRowVals rv, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrClipRec& C = *Cp;
+  WrRow4 out;
+  out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+  const float su = rv.s[0], sv = rv.s[1];
+  const float ou = rv.o[0], ov = rv.o[1];
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
   const float mode = C.mode;
   // the four SIMD lanes of vLocalPos.xy at the span start (init_interp)
@@ -2724,29 +2776,34 @@ WR_DEVICE float wr_sel4(float a0, float a1, float a2, float a3, int i) { return 
 
 // Four horizontally adjacent pixels (x .. x+3) of row y: one span-level setup and
 // one walk of the nine-patch state machine serve all four.
-__device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxRec* Bp, int x, int y) {
+// row interpolants of a cs_clip_box_shadow prim: c = 0,1 vUv; 2,3 vLocalPos.xy
+WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
+  WrRowVals rv;
+  const int k = y - P.y0;
+  const bool lin = P.rows_linear != 0;     // (the vLocalPos interpolants share the uv ones' linearity in practice; wr_accum checks)
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  const float L0 = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+  const float R0 = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+  const float L2 = wr_accum(B.lpL0[0], B.lpLs[0], k), L3 = wr_accum(B.lpL0[1], B.lpLs[1], k);
+  const float R2 = wr_accum(B.lpR0[0], B.lpRs[0], k), R3 = wr_accum(B.lpR0[1], B.lpRs[1], k);
+  rv.s[0] = (R0 - L0) * stepScale; rv.o[0] = L0 + rv.s[0] * start;
+  rv.s[1] = (R1 - L1) * stepScale; rv.o[1] = L1 + rv.s[1] * start;
+  rv.s[2] = (R2 - L2) * stepScale; rv.o[2] = L2 + rv.s[2] * start;
+  rv.s[3] = (R3 - L3) * stepScale; rv.o[3] = L3 + rv.s[3] * start;
+  return rv;
+}
+
+__device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxRec* Bp, WrRowVals rv, int x, int y) {
   const WrPrim& P = *Pp;
   const WrBoxRec& B = *Bp;
   WrRow4 out;
   out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
   const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear};
-  const int k = y - P.y0;
-  const bool lin = P.rows_linear != 0;     // (the vLocalPos interpolants share the uv ones' linearity in practice; checked below)
-  float stepScale = 1.0f / (P.xr - P.xl);
-  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
-  const float start = float(P.x0) + 0.5f - P.xl;
-  // row interpolants: c = 0,1 vUv; 2,3 vLocalPos.xy
   float o4[4], s4[4];
-  {
-    const float L0 = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
-    const float R0 = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
-    const float L2 = wr_accum(B.lpL0[0], B.lpLs[0], k), L3 = wr_accum(B.lpL0[1], B.lpLs[1], k);
-    const float R2 = wr_accum(B.lpR0[0], B.lpRs[0], k), R3 = wr_accum(B.lpR0[1], B.lpRs[1], k);
-    s4[0] = (R0 - L0) * stepScale; o4[0] = L0 + s4[0] * start;
-    s4[1] = (R1 - L1) * stepScale; o4[1] = L1 + s4[1] * start;
-    s4[2] = (R2 - L2) * stepScale; o4[2] = L2 + s4[2] * start;
-    s4[3] = (R3 - L3) * stepScale; o4[3] = L3 + s4[3] * start;
-  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) { o4[c] = rv.o[c]; s4[c] = rv.s[c]; }
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
   const int n0 = x - P.x0;
   const float mode = B.mode;
@@ -3190,11 +3247,22 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     return;
   }
   if ((FEAT & WR_FEAT_CLIP) && FMT == WR_FMT_R8 && kind == WR_PK_BOX_SHADOW) {
-    if (!(cx[0] || cx[1] || cx[2] || cx[3])) return;
+    const bool anyx = cx[0] || cx[1] || cx[2] || cx[3];
+#ifndef WRHIP_HOSTSIM
+    const WrRowVals mine = wr_box_row_vals(*Pp, Ap->box, wy0 + ((px - wx0) >> 2));   // lane (l & 15) owns strip row (l & 15)
+#endif
 #pragma unroll
     for (int j = 0; j < R; j++) {
-      if (!cy[j]) continue;
-      const WrRow4 r4 = wr_box_shadow_row4(Pp, &Ap->box, px, py + 4 * j);
+#ifdef WRHIP_HOSTSIM
+      const WrRowVals rv = wr_box_row_vals(*Pp, Ap->box, py + 4 * j);
+#else
+      WrRowVals rv;
+      const int src = (py - wy0) + 4 * j;      // the lane that evaluated this lane's row
+#pragma unroll
+      for (int c = 0; c < 4; c++) { rv.o[c] = __shfl(mine.o[c], src); rv.s[c] = __shfl(mine.s[c], src); }
+#endif
+      if (!cy[j] || !anyx) continue;
+      const WrRow4 r4 = wr_box_shadow_row4(Pp, &Ap->box, rv, px, py + 4 * j);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
@@ -3204,11 +3272,23 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     return;
   }
   if ((FEAT & WR_FEAT_CLIP) && FMT == WR_FMT_R8 && kind == WR_PK_CLIP_RECT) {
-    if (!(cx[0] || cx[1] || cx[2] || cx[3])) return;
+    const bool anyx = cx[0] || cx[1] || cx[2] || cx[3];
+#ifndef WRHIP_HOSTSIM
+    const WrRowVals mine = wr_clip_row_vals(*Pp, wy0 + ((px - wx0) >> 2));
+#endif
 #pragma unroll
     for (int j = 0; j < R; j++) {
-      if (!cy[j]) continue;
-      const WrRow4 r4 = wr_clip_rect_row4(Pp, &Ap->clip, px, py + 4 * j);
+#ifdef WRHIP_HOSTSIM
+      const WrRowVals rv = wr_clip_row_vals(*Pp, py + 4 * j);
+#else
+      WrRowVals rv;
+      const int src = (py - wy0) + 4 * j;
+#pragma unroll
+      for (int c = 0; c < 2; c++) { rv.o[c] = __shfl(mine.o[c], src); rv.s[c] = __shfl(mine.s[c], src); }
+      rv.o[2] = rv.o[3] = rv.s[2] = rv.s[3] = 0.0f;
+#endif
+      if (!cy[j] || !anyx) continue;
+      const WrRow4 r4 = wr_clip_rect_row4(Pp, &Ap->clip, rv, px, py + 4 * j);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
