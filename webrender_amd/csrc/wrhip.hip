@@ -94,6 +94,7 @@ struct Texture {
   int own_y0 = 0, own_y1 = 0;   // multi-GPU: owned pixel rows (0,0 = all)
   bool pending_read = false, pending_write = false;
   int pending_target = -1;   // index into Context::work when pending_write
+  bool tail_ref = false;     // read or written by the deferred last raster level (Context::Tail)
   bool has_storage() const { return dptr != nullptr; }
 };
 
@@ -241,12 +242,30 @@ struct Context {
   size_t upload_begin = 0;        // staging offset where the pending batch starts
   bool upload_open = false;
   uint8_t* dupload = nullptr;     // HBM mirror of the staging ring
-  WrPrim* dprims = nullptr; size_t dprims_cap = 0;
-  WrRec* drecs = nullptr;
-  WrAux* daux = nullptr;
-  float* dvtab = nullptr;        // per-row v tables of nearest-fast textured prims (WrDrawDesc::vtab_base)
-  size_t dvtab_cap = 0;
-  unsigned long long* dmasks = nullptr; size_t dmasks_cap = 0;
+  // Per-flush scratch, two sets used alternately (flush_seq & 1): the deferred tail of flush k
+  // still reads set k & 1 while the setup stage of flush k+1 fills the other one.
+  struct Scratch {
+    WrPrim* prims = nullptr; size_t prims_cap = 0;
+    WrRec* recs = nullptr;
+    WrAux* aux = nullptr;
+    float* vtab = nullptr; size_t vtab_cap = 0;   // per-row v tables of nearest-fast textured prims (WrDrawDesc::vtab_base)
+    unsigned long long* masks = nullptr; size_t masks_cap = 0;
+  } scratch[2];
+  int64_t flush_seq = 0;
+  // The last raster level of a flush (the composite pass of a frame) is not launched with its
+  // flush: it is held back and goes out fused with the setup stage of the NEXT flush
+  // (wr_setup_raster_kernel), which it does not depend on and which would otherwise sit between two
+  // frames as a dozen latency-bound workgroups plus a kernel boundary.  Anything that needs the
+  // tail's results, or touches a texture it reads or writes from outside the draw stream (host
+  // uploads, copies, readbacks, deletes, Finish), drains it first (drain_tail).
+  struct Tail {
+    bool pending = false;
+    int nb = 0, off = 0, n_targets = 0;
+    const WrTargetDesc* targets = nullptr; const WrDrawDesc* draws = nullptr;
+    int set = 0;
+    std::vector<GLuint> refs;
+  } tail;
+  bool defer_tail = true;
   WrUnsupportedCounters* dcounters = nullptr;
   WrUnsupportedCounters seen = {};
   // HBM pool for texture storage: per-frame textures (GpuBufferF/I, render
@@ -367,6 +386,9 @@ uint64_t get_time_value() {
 // ---------------------------------------------------------------------------
 // Deferred work: flush
 void flush_all();
+void drain_tail();
+// every host-side wait for the stream: the held-back raster level goes out first
+void sync_stream();
 
 void flush_uploads(size_t extra_end = 0);
 
@@ -378,7 +400,7 @@ size_t staging_alloc(size_t n) {
   n = (n + 255) & ~size_t(255);
   if (!c->staging || n > c->staging_size) {
     flush_uploads();
-    wrrt::stream_sync(c->stream);
+    sync_stream();
     wrrt::pinned_free(c->staging);
     wrrt::dev_free(c->dupload);
     c->staging_size = std::max(n * 2, STAGING_BYTES);
@@ -388,7 +410,7 @@ size_t staging_alloc(size_t n) {
   }
   if (c->staging_pos + n > c->staging_size) {
     flush_uploads();                // the pending batch must stay contiguous
-    wrrt::stream_sync(c->stream);   // everything staged so far has been consumed
+    sync_stream();   // everything staged so far has been consumed
     c->staging_pos = 0;
   }
   if (!c->upload_open) { c->upload_open = true; c->upload_begin = c->staging_pos; }
@@ -459,8 +481,8 @@ void flush_except(GLuint keep) {
 
 // A host- or copy-side write to texture `t` (or its deletion / reallocation)
 // must not overtake pending draws that read or write it.
-void sync_texture_for_write(Texture& t) { if (t.pending_read || t.pending_write) flush_all(); }
-void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); flush_uploads(); }
+void sync_texture_for_write(Texture& t) { if (t.pending_read || t.pending_write) flush_all(); if (t.tail_ref) drain_tail(); }
+void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); if (t.tail_ref) drain_tail(); flush_uploads(); }
 
 size_t pool_round(size_t n) {
   size_t g = n <= (1u << 20) ? 4096 : (size_t(1) << 16);
@@ -485,7 +507,7 @@ void pool_free(void* p, size_t n) {
   c->pool_bytes += n;
   while (c->pool_bytes > (size_t(2) << 30) && !c->pool.empty()) {   // trim: keep at most 2 GiB idle
     auto it = --c->pool.end();
-    wrrt::stream_sync(c->stream);
+    sync_stream();
     wrrt::dev_free(it->second);
     c->pool_bytes -= it->first;
     c->pool.erase(it);
@@ -676,7 +698,7 @@ void download_texture(Texture& t) {
     wrrt::copy2d(t.hmirror, t.stride, t.dptr, t.stride, row, t.height, 1, ctx->stream);
   }
   ctx->stats.d2h_bytes += row * t.height;
-  wrrt::stream_sync(ctx->stream);
+  sync_stream();
 }
 
 Context::~Context() {
@@ -684,11 +706,12 @@ Context::~Context() {
   ctx = this;
   flush_all();
   flush_uploads();
-  wrrt::stream_sync(stream);
+  sync_stream();
   for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
-  wrrt::dev_free(dupload); wrrt::dev_free(dprims); wrrt::dev_free(drecs); wrrt::dev_free(daux); wrrt::dev_free(dvtab); wrrt::dev_free(dmasks); wrrt::dev_free(dcounters);
+  wrrt::dev_free(dupload); wrrt::dev_free(dcounters);
+  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); }
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::stream_destroy(stream);
@@ -698,6 +721,28 @@ Context::~Context() {
 // ---------------------------------------------------------------------------
 // Execute the selected pending targets: one H2D copy of the frame arena, then
 // vertex + bin + raster launches covering every selected target at once.
+void tail_launched() {
+  Context::Tail& T = ctx->tail;
+  for (GLuint id : T.refs) if (Texture* t = ctx->textures.find(id)) t->tail_ref = false;
+  T.refs.clear();
+  T.pending = false;
+}
+// Launch the held-back raster level on its own (nothing to fuse it with, or its results are needed now).
+void drain_tail() {
+  Context* c = ctx;
+  if (!c || !c->tail.pending) return;
+  Context::Tail& T = c->tail;
+  Context::Scratch& TS = c->scratch[T.set];
+  WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, false, 4, WR_FEAT_TEX | WR_FEAT_GENERIC>), T.nb, 256, c->stream, T.targets, T.n_targets, T.draws,
+            (const WrPrim*)TS.prims, (const WrRec*)TS.recs, (const WrAux*)TS.aux, (const float*)TS.vtab, TS.masks, T.off);
+  c->stats.kernel_launches++; c->stats.raster_launches++;
+  tail_launched();
+}
+void sync_stream() {
+  drain_tail();
+  wrrt::stream_sync(ctx->stream);
+}
+
 void flush_work(const std::vector<int>& sel_in) {
   Context* c = ctx;
   if (!c || c->work.empty() || sel_in.empty()) return;
@@ -835,32 +880,31 @@ void flush_work(const std::vector<int>& sel_in) {
     uint8_t* darena = c->dupload + aoff;
     c->stats.h2d_bytes += total;
     algo_bytes += inst.size() + sizeof(WrDrawDesc) * nd;
-    // ---- scratch ----
-    if (c->dprims_cap < (size_t)n_prims + 1) {
-      wrrt::stream_sync(c->stream);
-      wrrt::dev_free(c->dprims);
-      c->dprims_cap = (size_t)(n_prims + 1) * 2;
-      c->dprims = (WrPrim*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrPrim));
-      wrrt::dev_free(c->drecs);
-      c->drecs = (WrRec*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrRec));
-      wrrt::dev_free(c->daux);
-      c->daux = (WrAux*)wrrt::dev_alloc(c->dprims_cap * sizeof(WrAux));
-    }
-    if (c->dvtab_cap < vtab_cursor + 1) {
-      wrrt::stream_sync(c->stream);
-      wrrt::dev_free(c->dvtab);
-      c->dvtab_cap = (vtab_cursor + 1) * 2;
-      c->dvtab = (float*)wrrt::dev_alloc(c->dvtab_cap * sizeof(float));
-    }
-    if (c->dmasks_cap < (size_t)n_words + 1) {
-      wrrt::stream_sync(c->stream);
-      wrrt::dev_free(c->dmasks);
-      c->dmasks_cap = (size_t)(n_words + 1) * 2;
-      c->dmasks = (unsigned long long*)wrrt::dev_alloc(c->dmasks_cap * 8);
-      wrrt::memset8(c->dmasks, 0, c->dmasks_cap * 8, c->stream);   // raster workgroups re-zero what they consume
+    // ---- scratch (two sets: the deferred tail of the previous flush still reads the other one) ----
+    Context::Scratch& S = c->scratch[c->flush_seq & 1];
+    if (S.prims_cap < (size_t)n_prims + 1 || S.vtab_cap < vtab_cursor + 1 || S.masks_cap < (size_t)n_words + 1) {
+      sync_stream();       // (drains the tail: nothing in flight references the buffers being replaced)
+      if (S.prims_cap < (size_t)n_prims + 1) {
+        wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux);
+        S.prims_cap = (size_t)(n_prims + 1) * 2;
+        S.prims = (WrPrim*)wrrt::dev_alloc(S.prims_cap * sizeof(WrPrim));
+        S.recs = (WrRec*)wrrt::dev_alloc(S.prims_cap * sizeof(WrRec));
+        S.aux = (WrAux*)wrrt::dev_alloc(S.prims_cap * sizeof(WrAux));
+      }
+      if (S.vtab_cap < vtab_cursor + 1) {
+        wrrt::dev_free(S.vtab);
+        S.vtab_cap = (vtab_cursor + 1) * 2;
+        S.vtab = (float*)wrrt::dev_alloc(S.vtab_cap * sizeof(float));
+      }
+      if (S.masks_cap < (size_t)n_words + 1) {
+        wrrt::dev_free(S.masks);
+        S.masks_cap = (size_t)(n_words + 1) * 2;
+        S.masks = (unsigned long long*)wrrt::dev_alloc(S.masks_cap * 8);
+        wrrt::memset8(S.masks, 0, S.masks_cap * 8, c->stream);   // raster workgroups re-zero what they consume
+      }
     }
 #ifdef WRHIP_HOSTSIM
-    wrrt::memset8(c->dmasks, 0, (size_t)n_words * 8, c->stream);
+    wrrt::memset8(S.masks, 0, (size_t)n_words * 8, c->stream);
 #endif
     const WrDrawDesc* ddraws = (const WrDrawDesc*)(darena + off_draws);
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
@@ -873,9 +917,24 @@ void flush_work(const std::vector<int>& sel_in) {
 #else
       const int nd_arg = nd;
 #endif
-      WR_LAUNCH(wr_setup_kernel, (n_prims + 255) / 256, 256, c->stream, ddraws, nd_arg, dinst, c->dprims, c->drecs, c->daux, n_prims,
-                dtargets, c->dmasks, c->dvtab, c->dcounters, dblk);
-      c->stats.kernel_launches += 1;
+      const int n_setup_blocks = (n_prims + 255) / 256;
+      if (c->tail.pending) {
+        // previous flush's held-back raster level + this flush's setup stage, one launch
+        Context::Tail& T = c->tail;
+        Context::Scratch& TS = c->scratch[T.set];
+        WrSetupArgs SA{ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims, dtargets, S.masks, S.vtab, c->dcounters, dblk};
+        WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, false, 4, WR_FEAT_TEX | WR_FEAT_GENERIC>), n_setup_blocks + T.nb, 256, c->stream,
+                  SA, n_setup_blocks, T.targets, T.n_targets, T.draws, (const WrPrim*)TS.prims, (const WrRec*)TS.recs,
+                  (const WrAux*)TS.aux, (const float*)TS.vtab, TS.masks, T.off);
+        c->stats.kernel_launches += 1; c->stats.raster_launches++;
+        tail_launched();
+      } else {
+        WR_LAUNCH(wr_setup_kernel, n_setup_blocks, 256, c->stream, ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims,
+                  dtargets, S.masks, S.vtab, c->dcounters, dblk);
+        c->stats.kernel_launches += 1;
+      }
+    } else {
+      drain_tail();
     }
 #ifdef WRHIP_HOSTSIM
     if (getenv("WRHIP_DEBUG")) {
@@ -900,7 +959,7 @@ void flush_work(const std::vector<int>& sel_in) {
         fprintf(stderr, "     flush inst D%d: %g %g %g %g (inst.size %zu)\n", i, f[0], f[1], f[2], f[3], inst.size());
       }
       for (int i = 0; i < n_prims && i < 6; i++) {
-        const WrPrim& P = c->dprims[i];
+        const WrPrim& P = S.prims[i];
         fprintf(stderr, "  P%d kind %d rect %d %d %d %d z %u blend %d flags %x color %08x %08x\n", i, P.kind, P.x0, P.y0, P.x1, P.y1,
                 P.z, P.blend, P.flags, P.color[0], P.color[1]);
       }
@@ -932,7 +991,7 @@ void flush_work(const std::vector<int>& sel_in) {
 #define WR_RASTER_F(FMT, DEPTH, FEAT, NB, OFF)                                                                      \
   do {                                                                                                              \
     WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), NB, 256, c->stream, dtargets, n_targets, ddraws,             \
-              (const WrPrim*)c->dprims, (const WrRec*)c->drecs, (const WrAux*)c->daux, (const float*)c->dvtab, c->dmasks, OFF);             \
+              (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, OFF);             \
     c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
   } while (0)
     // smallest instantiated superset of the level's feature set
@@ -945,10 +1004,26 @@ void flush_work(const std::vector<int>& sel_in) {
       WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX, NB, OFF);                     \
     else WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE, NB, OFF);   \
   } while (0)
-    // one raster launch per dependency level and target format, in level order on the one stream
-    for (const Level& L : levels) {
+    // one raster launch per dependency level and target format, in level order on the one stream;
+    // the last level is held back (Context::Tail) when the fused setup + raster kernel can take it
+    for (size_t li = 0; li < levels.size(); li++) {
+      const Level& L = levels[li];
       if (L.bins_rgba > 0) {
-        if (L.any_depth) WR_RASTER(true, L.bins_rgba, L.bin0);
+        const bool hold = li + 1 == levels.size() && c->defer_tail && !c->profiling && L.bins_r8 == 0 && !L.any_depth &&
+                          L.feat_rgba != 0 && !(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC));
+        if (hold) {
+          Context::Tail& T = c->tail;      // (the previous tail went out with this flush's setup launch)
+          T.pending = true; T.nb = L.bins_rgba; T.off = L.bin0; T.n_targets = n_targets;
+          T.targets = dtargets; T.draws = ddraws; T.set = (int)(c->flush_seq & 1);
+          for (int oi = 0; oi < n_targets; oi++) {
+            if (target_level[oi] != (int)li) continue;
+            const TargetWork& w = c->work[sel[oi]];
+            T.refs.push_back(w.tex);
+            for (GLuint id : w.reads) T.refs.push_back(id);
+          }
+          for (GLuint id : T.refs) if (Texture* t = c->textures.find(id)) t->tail_ref = true;
+        }
+        else if (L.any_depth) WR_RASTER(true, L.bins_rgba, L.bin0);
         else WR_RASTER(false, L.bins_rgba, L.bin0);
       }
       if (L.bins_r8 > 0) {
@@ -965,6 +1040,7 @@ void flush_work(const std::vector<int>& sel_in) {
       wrrt::event_sync(&c->ev_b);
       c->stats.raster_ns += (uint64_t)(wrrt::event_elapsed_ms(&c->ev_a, &c->ev_b) * 1.0e6);
     }
+    c->flush_seq++;
     c->stats.flushes++;
     c->stats.prims += n_prims;
     c->stats.raster_pixels += pixels;
@@ -1161,14 +1237,14 @@ void BeginQuery(GLenum target, GLuint id) {
   else if (target == GL_TIME_ELAPSED) {
     // TIME_ELAPSED must cover the GPU work issued inside the query (renderer
     // GpuProfiler, device/query_gl.rs:141-163): drain what came before.
-    flush_all(); wrrt::stream_sync(ctx->stream);
+    flush_all(); sync_stream();
     q.value = get_time_value();
   }
 }
 void EndQuery(GLenum target) {
   Query& q = ctx->queries[ctx->get_binding(target)];
   if (target == GL_TIME_ELAPSED) {
-    flush_all(); wrrt::stream_sync(ctx->stream);
+    flush_all(); sync_stream();
     q.value = get_time_value() - q.value;
   }
   ctx->get_binding(target) = 0;
@@ -1510,7 +1586,7 @@ void ReadPixels(GLint x, GLint y, GLsizei width, GLsizei height, GLenum format, 
   size_t row = (size_t)width * t.bpp;
   wrrt::copy2d(dest, destStride, (const uint8_t*)t.dptr + (size_t)y * t.stride + (size_t)x * t.bpp, t.stride, row, height, 1,
                ctx->stream);
-  wrrt::stream_sync(ctx->stream);
+  sync_stream();
   ctx->stats.d2h_bytes += row * height;
   if (format_requires_conversion(format, t.internal_format)) {
     for (int yy = 0; yy < height; yy++) {
@@ -1737,12 +1813,12 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
 void Finish(void) {
   flush_all();
   flush_uploads();
-  wrrt::stream_sync(ctx->stream);
+  sync_stream();
   {
     // prims the device could not draw faithfully are reported, never dropped silently
     WrUnsupportedCounters h;
     wrrt::d2h(&h, ctx->dcounters, sizeof(h), ctx->stream);
-    wrrt::stream_sync(ctx->stream);
+    sync_stream();
     if (h.unsupported_prims != ctx->seen.unsupported_prims || h.perspective_prims != ctx->seen.perspective_prims) {
       fprintf(stderr, "libwrhip: %u prim(s) on not-yet-implemented paths (AA / rotated / masked-textured / blend override), %u perspective\n",
               h.unsupported_prims - ctx->seen.unsupported_prims, h.perspective_prims - ctx->seen.perspective_prims);

@@ -1940,12 +1940,12 @@ WR_DEVICE int wr_texrow_entry(const WrTexRec& T, float ov_raw) {
 }
 
 // Vertex stage + binning, one thread per instance.
-__global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
                                 WrRec* __restrict__ recs, WrAux* __restrict__ aux, int n_prims,
                                 const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
-                                float* __restrict__ vtab, WrUnsupportedCounters* cnt, const int* __restrict__ blk) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+                                float* __restrict__ vtab, WrUnsupportedCounters* cnt, const int* __restrict__ blk, const int bid) {
+  const int gid = bid * (int)blockDim.x + (int)threadIdx.x;
   const bool valid = gid < n_prims;
   WrPrim P;
   P.kind = WR_PK_NONE; P.draw = 0; P.x0 = P.y0 = P.x1 = P.y1 = 0;
@@ -2011,10 +2011,18 @@ __global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restr
   if ((threadIdx.x & 63) == 0) {   // per-wave phase times, summed (host prints per-Finish deltas)
     atomicAdd(&cnt->dbg[0], (unsigned)(tm1 - tm0)); atomicAdd(&cnt->dbg[1], (unsigned)(tm2 - tm1)); atomicAdd(&cnt->dbg[2], (unsigned)(tm3 - tm2));
     atomicAdd(&cnt->dbg[3], 1u);
-    if (blockIdx.x == gridDim.x - 1) atomicAdd(&cnt->dbg[4], (unsigned)(tm3 - tm0));   // waves of the last workgroup (composite prims)
+    if (bid == (n_prims - 1) / (int)blockDim.x) atomicAdd(&cnt->dbg[4], (unsigned)(tm3 - tm0));   // waves of the last workgroup (composite prims)
     atomicMax(&cnt->dbg[5], (unsigned)(tm3 - tm0));
   }
 #endif
+}
+
+__global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+                                const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
+                                WrRec* __restrict__ recs, WrAux* __restrict__ aux, int n_prims,
+                                const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
+                                float* __restrict__ vtab, WrUnsupportedCounters* cnt, const int* __restrict__ blk) {
+  wr_setup_body(draws, n_draws, arena, prims, recs, aux, n_prims, targets, masks, vtab, cnt, blk, (int)blockIdx.x);
 }
 
 // Scatter queued texture uploads from the staging mirror to their textures.
@@ -3548,13 +3556,11 @@ WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], u
 
 // One workgroup per 64x64 bin; 64/(4R) waves of 64 lanes, each lane 4 x R pixels.
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void __launch_bounds__(1024 / R)
-wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
+WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
-                 unsigned long long* __restrict__ masks, int bin_offset) {
+                 unsigned long long* __restrict__ masks, const int bin) {
   constexpr int NPX = 4 * R, STRIP = 4 * R;
-  const int bin = blockIdx.x + bin_offset;
   int t = 0;
   {
     int lo = 0, hi = n_targets - 1;
@@ -3711,4 +3717,38 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
       for (int i = 0; i < 4; i++) if (px + i < T.width) T.depth[(size_t)y * T.width + px + i] = dep[4 * j + i];
     }
   }
+}
+
+template <int FMT, bool DEPTH, int R, int FEAT>
+__global__ void __launch_bounds__(1024 / R)
+wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
+                 const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                 const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
+                 unsigned long long* __restrict__ masks, int bin_offset) {
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)blockIdx.x + bin_offset);
+}
+
+// The setup stage of flush k+1 and the last raster level of flush k in ONE launch: the first
+// `n_setup_blocks` workgroups run wr_setup_body, the rest rasterise.  The two are independent
+// (different scratch sets, see Context::Tail in wrhip.hip), the setup stage is a dozen
+// latency-bound workgroups, and a kernel boundary costs ~5 us on top: fused, the setup stage
+// disappears behind the composite pass of the previous frame instead of standing between two
+// frames.  Setup workgroups come first so they are dispatched first.
+struct WrSetupArgs {
+  const WrDrawDesc* draws; int n_draws; const uint8_t* arena; WrPrim* prims; WrRec* recs; WrAux* aux; int n_prims;
+  const WrTargetDesc* targets; unsigned long long* masks; float* vtab; WrUnsupportedCounters* cnt; const int* blk;
+};
+template <int FMT, bool DEPTH, int R, int FEAT>
+__global__ void __launch_bounds__(1024 / R)
+wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
+                       const WrTargetDesc* __restrict__ targets, int n_targets,
+                       const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                       const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
+                       unsigned long long* __restrict__ masks, int bin_offset) {
+  if ((int)blockIdx.x < n_setup_blocks) {
+    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
+    return;
+  }
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks,
+                                      (int)blockIdx.x - n_setup_blocks + bin_offset);
 }
