@@ -39,6 +39,9 @@ CASES = [
     ("cfg3_small", lambda: scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12)),
     ("cfg3_small_zoom", lambda: scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, glyph_zoom=1.25)),
     ("cfg3_small_dps", lambda: scenes.cfg3_text(width=1000, height=500, lines=20, glyphs_per_line=60, run_len=12, device_pixel_scale=1.5)),
+    ("cfg3_small_modes", lambda: scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, color_modes=(0, 1, 2, 3))),
+    ("cfg3_small_dual", lambda: scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, color_modes=(1, 2), dual_source=True)),
+    ("cfg3_small_modes_zoom", lambda: scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, color_modes=(1, 2, 3), glyph_zoom=1.25)),
     ("masked_rects", lambda: scenes.masked_rects()),
     ("masked_rects_frac", lambda: scenes.masked_rects(fractional=True)),
     ("masked_rects_wide", lambda: scenes.masked_rects(width=2048, height=1024, n=600, seed=5)),

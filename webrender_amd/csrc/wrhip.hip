@@ -140,6 +140,7 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
     {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", WR_SH_PS_TEXT_RUN_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS},
 #define CLIP_RECT_ATTRIBS                                                                                             \
   {"aPosition", "aClipDeviceArea", "aClipOrigins", "aDevicePixelScale", "aTransformIds", "aClipLocalPos",           \
    "aClipLocalRect", "aClipMode", "aClipRect_TL", "aClipRadii_TL", "aClipRect_TR", "aClipRadii_TR", "aClipRect_BL", \
@@ -977,7 +978,7 @@ void flush_work(const std::vector<int>& sel_in) {
       if (!(draws[i].flags & WR_DF_SIMPLE)) {
         switch (draws[i].shader) {
           case WR_SH_PS_CLEAR: case WR_SH_CLEAR_OP: break;
-          case WR_SH_PS_TEXT_RUN: f = WR_FEAT_R8TEX | WR_FEAT_TEX | WR_FEAT_GENERIC; break;
+          case WR_SH_PS_TEXT_RUN: case WR_SH_PS_TEXT_RUN_DUAL: f = WR_FEAT_R8TEX | WR_FEAT_TEX | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA: f = WR_FEAT_R8TEX | WR_FEAT_GENERIC; break;   // masked / odd blend
           case WR_SH_CS_BLUR_ALPHA: case WR_SH_CS_BLUR_COLOR: f = WR_FEAT_BLUR; break;
           case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW: f = WR_FEAT_CLIP; break;
@@ -1758,8 +1759,11 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   }
   d.target = wi;
   d.blend = c->blend ? c->blend_key : WR_BLEND_NONE;
-  if (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC || d.blend == WR_BLEND_CONST_COLOR ||
-      d.blend == WR_BLEND_MIN || d.blend == WR_BLEND_MAX) {
+  // (GL_ONE, GL_ONE_MINUS_SRC1_COLOR under the dual-source text program is fine: every prim of that
+  // program replaces the key with swgl_blendSubpixelText / swgl_blendDropShadow in its vertex stage)
+  const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && info->kind == WR_SH_PS_TEXT_RUN_DUAL;
+  if (!dual_text && (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC || d.blend == WR_BLEND_CONST_COLOR ||
+      d.blend == WR_BLEND_MIN || d.blend == WR_BLEND_MAX)) {
     fprintf(stderr, "libwrhip: blend mode not implemented yet (key %d)\n", d.blend);
   }
   d.flags = 0;

@@ -281,6 +281,8 @@ struct WrVsOut {
   float u2[4], v2[4];  // a second interpolated vec2 varying (WR_PK_BOX_SHADOW: vLocalPos.xy)
   int tail_clamp;      // fragment main(): clamps uv to uv_bounds
   int tail_modulate;   // fragment main(): multiplies texel by colour
+  int blend_override;  // swgl_blendDropShadow / swgl_blendSubpixelText: WrBlend key replacing the draw's (0 = none)
+  wf4 blend_color;     // ... and its constant colour (swgl_BlendColorRGBA8)
 };
 
 // ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
@@ -633,7 +635,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
 // ps_text_run.glsl:98-268, non-GLYPH_TRANSFORM branch (vertex stage), with the
 // prim_shared.glsl helpers.  Colour modes that need a blend override
 // (swgl_blendDropShadow / swgl_blendSubpixelText, :229-247) are "next".
-WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int inst, bool dual_source, WrVsOut& o) {
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int glyph_index = aData.z & 0xffff, flags = aData.z >> 16;
@@ -698,12 +700,29 @@ WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int 
   o.tex_slot = WR_S_COLOR0;
   o.has_color = 1; o.tail_clamp = 1; o.tail_modulate = 1;
   const bool r8 = atlas.format == WR_FMT_R8;
-  if (color_mode == 0 && r8 && atlas.width >= 2 && atlas.linear) {          // COLOR_MODE_ALPHA on the R8 glyph atlas
+  const bool rgba = atlas.format == WR_FMT_RGBA8, r8lin = r8 && atlas.width >= 2 && atlas.linear;
+  // ps_text_run.glsl:219-255 with SWGL_BLEND; span shader :320-338
+  //   (1, 0, 0) swizzle + v_color: swgl_commitTextureLinearColor{RGBA8, R8ToRGBA8}(v_color);
+  //   DUAL_SOURCE program: swgl_commitTextureLinearRGBA8, no colour (and no swizzle in the fragment shader)
+  if (color_mode == 0 && r8lin && !dual_source) {                            // COLOR_MODE_ALPHA on the R8 glyph atlas
     o.kind = WR_PK_TEX_R8; o.color = text_color;
-  } else if (color_mode == 3 && atlas.format == WR_FMT_RGBA8) {              // COLOR_MODE_COLOR_BITMAP
+  } else if (color_mode == 3 && rgba) {                                      // COLOR_MODE_COLOR_BITMAP
     o.kind = WR_PK_TEX_RGBA8; o.color = wf4{text_color.w, text_color.w, text_color.w, text_color.w};
+  } else if ((color_mode == 1 || color_mode == 2) && rgba) {      // (subpixel masks and colour-bitmap shadows live in the BGRA8 atlas)
+    // COLOR_MODE_SUBPX_DUAL_SOURCE -> swgl_blendSubpixelText(text.color), COLOR_MODE_BITMAP_SHADOW ->
+    // swgl_blendDropShadow(text.color): the glyph is committed with v_color = 1 and the text colour
+    // travels in the blend stage (blend.h:680-691), per primitive
+    o.kind = WR_PK_TEX_RGBA8;
+    o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    o.has_color = 0;
+    o.blend_override = color_mode == 1 ? WR_BLEND_SUBPIXEL_TEXT : WR_BLEND_DROP_SHADOW;
+    o.blend_color = text_color;
   } else {
     o.kind = WR_PK_UNSUPPORTED; o.color = wf4{0, 0, 0, 0};
+  }
+  if (dual_source && o.kind == WR_PK_TEX_RGBA8) {
+    if (color_mode == 3) { o.kind = WR_PK_UNSUPPORTED; return; }   // colour bitmaps are never batched with the dual-source program
+    o.has_color = 0; o.tail_modulate = 1;       // main(): v_color (1) * mask, unswizzled
   }
 }
 
@@ -1131,6 +1150,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
   if (o.kind == WR_PK_UNSUPPORTED) { atomicAdd(&cnt->unsupported_prims, 1u); return; }
+  const bool blend_override = o.blend_override != 0 && d.blend != WR_BLEND_NONE;   // only while blending is on (ClipRect ctor, rasterize.h:412-417)
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
@@ -1172,6 +1192,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       B.lpLs[0] = l2u; B.lpLs[1] = l2v; B.lpRs[0] = r2u; B.lpRs[1] = r2v;
     }
   }
+  if (blend_override) {     // the prim's colour slot carries swgl_BlendColorRGBA8 (its own colour is 1: no modulation)
+    P.blend = (int16_t)o.blend_override;
+    wr_pack_color(o.blend_color, P.color);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1209,7 +1233,8 @@ WR_DEVICE uint32_t wr_splat_a(uint32_t ra) { uint32_t a = ra >> 16; return a | (
 
 // blend_pixels for RGBA8 (blend.h:416-701): the keys WebRender's in-scope
 // batches use.  `src` already has clip-mask/AA weights applied.
-WR_DEVICE uint32_t wr_blend_rgba8(int key, uint32_t dstp, WrWide src, const WrDrawDesc* d) {
+WR_DEVICE WrWide wr_apply_color(WrWide src, const uint32_t color[2]);
+WR_DEVICE uint32_t wr_blend_rgba8(int key, uint32_t dstp, WrWide src, const WrDrawDesc* d, const uint32_t* bc = nullptr) {
   WrWide dst = wr_unpack(dstp), r;
   switch (key) {
     default:
@@ -1257,6 +1282,22 @@ WR_DEVICE uint32_t wr_blend_rgba8(int key, uint32_t dstp, WrWide src, const WrDr
       uint32_t a = wr_splat_a(dst.ra);
       r.bg = wr_add2(dst.bg, wr_sub2(src.bg, wr_muldiv255_2(src.bg, a)));
       r.ra = wr_add2(dst.ra, wr_sub2(src.ra, wr_muldiv255_2(src.ra, a)) & 0x0000FFFF);
+    } break;
+    case WR_BLEND_DROP_SHADOW: {   // blend.h:680-685; bc = swgl_BlendColorRGBA8
+      if (!bc) { r = src; break; }
+      const uint32_t sa = wr_splat_a(src.ra);
+      WrWide al; al.bg = sa; al.ra = sa;
+      const WrWide col = wr_apply_color(al, bc);
+      const uint32_t ca = wr_splat_a(col.ra);
+      r.bg = wr_sub2(wr_add2(col.bg, dst.bg), wr_muldiv255_2(dst.bg, ca));
+      r.ra = wr_sub2(wr_add2(col.ra, dst.ra), wr_muldiv255_2(dst.ra, ca));
+    } break;
+    case WR_BLEND_SUBPIXEL_TEXT: { // blend.h:687-691; swgl_BlendAlphaRGBA8 = alphas(swgl_BlendColorRGBA8)
+      if (!bc) { r = src; break; }
+      const uint32_t ba[2] = {wr_splat_a(bc[1]), wr_splat_a(bc[1])};
+      const WrWide c1 = wr_apply_color(src, bc), c2 = wr_apply_color(src, ba);
+      r.bg = wr_sub2(wr_add2(c1.bg, dst.bg), wr_muldiv255_2(dst.bg, c2.bg));
+      r.ra = wr_sub2(wr_add2(c1.ra, dst.ra), wr_muldiv255_2(dst.ra, c2.ra));
     } break;
     case WR_BLEND_SCREEN:  // ONE, ONE_MINUS_SRC_COLOR is not in swgl's key table: treated as unsupported upstream
       r = src; break;
@@ -1756,6 +1797,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
   WrVsOut o;
   o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
   o.uv_add[0] = o.uv_add[1] = 0.0f;
+  o.blend_override = 0; o.blend_color = wf4{0, 0, 0, 0};
   switch (d.shader) {
     case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
     case WR_SH_BRUSH_SOLID:
@@ -1769,7 +1811,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
-    case WR_SH_PS_TEXT_RUN: wr_vs_ps_text_run(d, arena, inst, o); break;
+    case WR_SH_PS_TEXT_RUN: wr_vs_ps_text_run(d, arena, inst, false, o); break;
+    case WR_SH_PS_TEXT_RUN_DUAL: wr_vs_ps_text_run(d, arena, inst, true, o); break;
     case WR_SH_CS_BLUR_ALPHA: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     case WR_SH_CS_BLUR_COLOR: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     case WR_SH_CS_CLIP_RECT: wr_vs_cs_clip_rect(d, arena, inst, false, o, aux[gid].clip); break;
@@ -2080,7 +2123,7 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
   } else {
     src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y);
   }
-  return wr_blend_rgba8(P.blend, dstp, src, D);
+  return wr_blend_rgba8(P.blend, dstp, src, D, P.color);
 }
 
 // red channel of a textured prim's fragment value (R8 targets)

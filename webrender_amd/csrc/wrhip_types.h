@@ -43,6 +43,7 @@ enum WrShader {
   WR_SH_COMPOSITE_FAST,
   WR_SH_PS_CLEAR,
   WR_SH_PS_TEXT_RUN,
+  WR_SH_PS_TEXT_RUN_DUAL,   // ALPHA_PASS,DUAL_SOURCE_BLENDING
   WR_SH_CS_BLUR_ALPHA,
   WR_SH_CS_BLUR_COLOR,
   WR_SH_CS_SCALE,

@@ -199,11 +199,15 @@ def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127)):
 
 
 def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=25, seed=3,
-              glyph_zoom=1.0, device_pixel_scale=1.0, tile_filter=None, **kw):
+              glyph_zoom=1.0, device_pixel_scale=1.0, tile_filter=None, color_modes=(0,), dual_source=False, **kw):
     """`lines` x `glyphs_per_line` glyphs in runs of `run_len`, black-ish text
     on white, COLOR_MODE_ALPHA from an R8 atlas, PremultipliedAlpha blend
     (batch.rs:1109-1290).  glyph_zoom != 1 draws the cached bitmaps magnified
-    (local raster space: raster_scale = 1/zoom) so that sampling is truly bilinear."""
+    (local raster space: raster_scale = 1/zoom) so that sampling is truly bilinear.
+    color_modes other than 0 (cycled per run: 1 = COLOR_MODE_SUBPX_DUAL_SOURCE, 2 = COLOR_MODE_BITMAP_SHADOW,
+    3 = COLOR_MODE_COLOR_BITMAP) sample a BGRA8 atlas: per-channel coverage shifted by one texel per
+    channel, as a subpixel rasteriser produces; dual_source selects the DUAL_SOURCE_BLENDING program
+    (batch.rs:1150-1180: BlendMode::SubpixelDualSource)."""
     rng = np.random.default_rng(seed)
     atlas, table = build_glyph_atlas()
     sizes = sorted({k[0] for k in table})
@@ -211,6 +215,16 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
     atlas_ref = TextureRef("glyph_atlas_r8", ATLAS_SIZE, ATLAS_SIZE, G.GL_R8, G.GL_LINEAR,
                            pixels=atlas, upload_format=G.GL_RED)
     frame.static_textures.append(atlas_ref)
+    atlas_bgra_ref = None
+    if any(m != 0 for m in color_modes):
+        sub = np.zeros((ATLAS_SIZE, ATLAS_SIZE, 4), np.uint8)
+        sub[:, 1:, 0] = atlas[:, :-1]           # b: coverage one texel to the left
+        sub[..., 1] = atlas                      # g
+        sub[:, :-1, 2] = atlas[:, 1:]           # r: one texel to the right
+        sub[..., 3] = sub[..., :3].max(axis=2)   # a >= every channel (valid premultiplied colour bitmap)
+        atlas_bgra_ref = TextureRef("glyph_atlas_bgra8", ATLAS_SIZE, ATLAS_SIZE, G.GL_RGBA8, G.GL_LINEAR,
+                                    pixels=sub, upload_format=G.GL_BGRA)
+        frame.static_textures.append(atlas_bgra_ref)
     res_addr = {k: frame.add_glyph_resource(v[0], v[1], 1.0) for k, v in table.items()}
     raster_scale = 1.0 / glyph_zoom
     dps = device_pixel_scale
@@ -256,19 +270,26 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
         target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
         task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), dps,
                                      (float(ox), float(oy)))
-        inst = []
+        inst, inst_bgra = [], []
         for ri, (origin, ref, color, size, run_chars, pts, bb, zid) in enumerate(runs):
             if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
             local_rect = (origin[0] - ref[0][0], origin[1] - ref[0][1], ref[1][0], ref[1][1])
             ph = frame.add_prim_header(local_rect, (-BIG, -BIG, BIG, BIG), zid, run_addr[ri], 0, task,
                                        (int(round(raster_scale * 65535.0)), 0, 0, 0))
+            mode = color_modes[ri % len(color_modes)]
             for gi, c in enumerate(run_chars):
-                inst.append(frame.glyph_instance(ph, gi, res_addr[(size, c)]))
+                (inst if mode == 0 else inst_bgra).append(
+                    frame.glyph_instance(ph, gi, res_addr[(size, c)], color_mode=mode))
         if inst:
             target.alpha.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES",
                                      np.array(inst, dtype=np.int32), "PremultipliedAlpha", "alpha",
                                      textures={0: atlas_ref}))
+        if inst_bgra:
+            key = "ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D" if dual_source else "ps_text_run ALPHA_PASS,TEXTURE_2D"
+            target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(inst_bgra, dtype=np.int32),
+                                     "SubpixelDualSource" if dual_source else "PremultipliedAlpha", "alpha",
+                                     textures={0: atlas_bgra_ref}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
         clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
