@@ -58,6 +58,8 @@ SMALL = [
     ("scaled_composites", lambda: scenes.scaled_composites()),
     ("image_grid", lambda: scenes.image_grid()),
     ("image_grid_wide", lambda: scenes.image_grid(width=2048, height=1024, n=300, seed=52)),
+    ("image_grid_masked", lambda: scenes.image_grid(masked=True)),
+    ("filter_grid_masked", lambda: scenes.filter_grid(masked=True, seed=75, ops=FILTER_OPS_EXACT)),
     ("gradient_grid", lambda: scenes.gradient_grid()),
     ("gradient_grid_wide", lambda: scenes.gradient_grid(width=2048, height=1024, n=300, seed=63)),
     ("gradient_grid_int", lambda: scenes.gradient_grid(width=1000, height=700, n=150, seed=65, fractional=False)),

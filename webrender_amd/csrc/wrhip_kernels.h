@@ -1070,7 +1070,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.has_mask && d.blend != WR_BLEND_NONE) {
     // ClipRect ctor (rasterize.h:408-444): clip-mask bounds constrain the draw rect
     const WrTexDesc& mt = d.tex[WR_S_CLIP_MASK];
-    if (o.kind != WR_PK_SOLID || mt.format != WR_FMT_R8 || !mt.ptr) {   // masked textured prims: "next"
+    if (mt.format != WR_FMT_R8 || !mt.ptr || o.kind == WR_PK_BLUR || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
     }
     int bx0 = int(o.mask_bb[0]), by0 = int(o.mask_bb[1]);
@@ -1144,7 +1144,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   while (iy1 > iy0 && (float(iy1 - 1) + 0.5f) > ylimit) iy1--;
   if (ix1 <= ix0 || iy1 <= iy0) return;
   P.x0 = ix0; P.x1 = ix1; P.y0 = iy0; P.y1 = iy1;
-  P.kind = masked ? (int16_t)WR_PK_SOLID_MASKED : (aa ? (int16_t)WR_PK_SOLID_AA : (int16_t)o.kind);
+  P.kind = (masked && o.kind == WR_PK_SOLID) ? (int16_t)WR_PK_SOLID_MASKED : (aa ? (int16_t)WR_PK_SOLID_AA : (int16_t)o.kind);
+  if (masked && o.kind != WR_PK_SOLID) P.flags |= WR_PF_MASKED;
   P.rows_linear = 0;
   if ((d.flags & WR_DF_SIMPLE) && P.kind != WR_PK_SOLID) {   // the launch's kernel has no path for it: say so
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
@@ -1727,7 +1728,7 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
   t.lv0 = P.uvL0[1]; t.lvs = P.uvLs[1]; t.y0 = P.y0;
   const int need = WR_PF_TAIL_CLAMP | WR_PF_TAIL_MODULATE | WR_PF_HAS_COLOR;
   t.simple = (tex.ptr && P.uvLs[0] == 0.0f && P.uvRs[0] == 0.0f && P.uvL0[1] == P.uvR0[1] && P.uvLs[1] == P.uvRs[1] &&
-              (P.flags & need) == need && ((P.color[0] | P.color[1]) & 0xFF00FF00u) == 0 && tex.width >= 2) ? 1 : 0;
+              (P.flags & need) == need && !(P.flags & WR_PF_MASKED) && ((P.color[0] | P.color[1]) & 0xFF00FF00u) == 0 && tex.width >= 2) ? 1 : 0;
   t.fcolor[0] = P.fcolor[0]; t.fcolor[1] = P.fcolor[1]; t.fcolor[2] = P.fcolor[2]; t.fcolor[3] = P.fcolor[3];
   // Exact evaluation of every column / row coordinate of small prims (glyphs):
   // if they all land on texel centres the raster stage needs no float math.
@@ -2106,6 +2107,18 @@ __device__ __noinline__ uint32_t wr_aa_pixel_rgba8(const WrAARec* Ap, const WrDr
   return wr_blend_rgba8(blend, dstp, src, D);
 }
 
+// MASK_ blend keys (blend.h:458-460): src = muldiv255(src, expand_mask(clip mask texel)); the mask is
+// sampled 1:1 at (x, y) - swgl_ClipMaskOffset (get_clip_mask, blend.h:357-360)
+WR_DEVICE WrWide wr_mask_src(const WrPrim& P, const WrDrawDesc* D, int x, int y, WrWide src) {
+  if (!(P.flags & WR_PF_MASKED)) return src;
+  const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
+  const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
+  const uint32_t mm = m | (m << 16);
+  WrWide r;
+  r.bg = wr_muldiv255_2(src.bg, mm); r.ra = wr_muldiv255_2(src.ra, mm);
+  return r;
+}
+
 // Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
 // Kept out of line so the fast paths below stay small and the 16 pixels of a
 // lane stay in registers.
@@ -2121,7 +2134,7 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
     WrWide mm; mm.bg = mm.ra = m | (m << 16);
     src = wr_apply_color(mm, P.color);
   } else {
-    src = wr_tex_pixel(P, D->tex[P.tex_slot], x, y);
+    src = wr_mask_src(P, D, x, y, wr_tex_pixel(P, D->tex[P.tex_slot], x, y));
   }
   return wr_blend_rgba8(P.blend, dstp, src, D, P.color);
 }
@@ -3212,7 +3225,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     return;
   }
   if ((FEAT & WR_FEAT_TEX) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_RGBA8 && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT) &&
-      Ap->tex.simple >= 2) {
+      !(flags & WR_PF_MASKED) && Ap->tex.simple >= 2) {
     // ---- swgl_commitTexture*RGBA8, nearest-fast rows (blendTextureNearestFast,
     // swgl_ext.h:475-537): the source row of every target row was resolved by
     // the setup kernel (unit rows) or is evaluated per lane-row; a lane fetches its 4 texels of each row.
@@ -3380,7 +3393,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
           if (dwrite) dep[q] = in ? z : dep[q];
         }
         if (!in) continue;
-        const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), g4.v[i], D);
+        const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), wr_mask_src(*Pp, D, px + i, py + 4 * j, g4.v[i]), D);
         plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
       }
     }
@@ -3397,7 +3410,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (dwrite) dep[q] = in ? z : dep[q];
       }
       if (!in) continue;
-      const WrWide src = wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2));
+      const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2)));
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }

@@ -181,6 +181,8 @@ enum WrPrimFlags {
   WR_PF_HAS_COLOR = 32,   // textured: modulate by colour (applyColor)
   WR_PF_TAIL_CLAMP = 64,     // main(): clamp uv to uv_bounds before sampling
   WR_PF_TAIL_MODULATE = 128, // main(): multiply texel by fcolor
+  WR_PF_MASKED = 8,          // non-solid prim under swgl_clipMask: src = muldiv255(src, mask) ahead of the blend
+                             // (blend.h:458-460; shares its bit with WR_PF_CLEAR_COLOR -- clears are never masked)
 };
 
 // Output of the vertex stage: everything the raster stage needs for one quad.
@@ -200,7 +202,7 @@ struct WrPrim {
   float uv_bounds[4];       // uv_rect passed to swgl_commitTexture*
   float fcolor[4];          // float colour for the fragment-shader (tail) path
   int32_t tex_slot;         // sampler slot
-  int32_t mask_off[2];      // WR_PK_SOLID_MASKED: target pixel - mask texel (swgl_ClipMaskOffset)
+  int32_t mask_off[2];      // WR_PK_SOLID_MASKED / WR_PF_MASKED: target pixel - mask texel (swgl_ClipMaskOffset)
   int32_t rows_linear;      // 1: edge interpolants at row k equal L0 + k*slope exactly (closed form of Edge::nextRow)
   float uv_add[2];          // added to the interpolated uv of every pixel before sampling (brush_image: + v_uv_bounds.xy)
   int32_t pad2[2];

@@ -343,7 +343,8 @@ def scaled_composites(width=1024, height=768, seed=21, src=192):
 # in the opaque pass (front to back, depth), translucent / tinted ones in the
 # alpha pass (batch.rs:2060-2150; ImageBrushData gpu_types.rs:707-724; GPU blocks
 # prim_store/image.rs: [color, background_color, stretch_size]).
-def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=None, modes=(0, 1, 2, 3, 4), translucent=True, only=None):
+def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=None, modes=(0, 1, 2, 3, 4), translucent=True, only=None,
+               masked=False):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -407,6 +408,11 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
             px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - h))
         opacity = 1.0 if (k % 3 or not translucent) else float(rng.uniform(0.3, 0.9))
         prims.append(((px, py, px + w, py + h), addr, False, opacity))
+    t_mask, clip_tasks = None, [None] * len(prims)
+    if masked:      # alpha-pass images under swgl_clipMask (rounded-corner clips on images)
+        t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
+        frame.static_textures.append(t_mask)
+        clip_tasks = prim_clip_tasks(rng, [p[0] for p in prims], 1024, True)
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
@@ -424,13 +430,15 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
             spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
             ud = (4 | (1 << 16), 0, int(round(opacity * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
             ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, ud)
-            (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=addr))
+            ct = None if opaque else clip_tasks[zi]
+            clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
+            (op if opaque else al).append(frame.brush_instance(ph, clip_addr, resource_address=addr))
         if op:
             target.opaque.append(Step("brush_image TEXTURE_2D", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
                                       None, "opaque", textures={0: t_atlas}))
         if al:
             target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
-                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
         clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
@@ -452,6 +460,28 @@ def mask_atlas(size=1024, seed=11):
     m = (m * 255.0 + 0.5).astype(np.uint8)
     noise = rng.integers(0, 256, size=(size, size), dtype=np.uint8)
     return np.where(rng.uniform(size=(size, size)) < 0.1, noise, m).astype(np.uint8)
+
+
+def prim_clip_tasks(rng, rects, atlas=1024, fractional=False):
+    """One R8 clip-task region of the mask atlas per prim rect (every third prim unmasked): (task rect in
+    the atlas, screen origin) as masked_rects builds them -- mask smaller / larger than the prim, offset
+    by a few pixels, now and then hanging over the atlas edge."""
+    out = []
+    for i, r in enumerate(rects):
+        if i % 3 == 2:
+            out.append(None)
+            continue
+        w, h = max(8, int(r[2] - r[0])), max(8, int(r[3] - r[1]))
+        mw, mh = min(atlas - 2, max(4, w + int(rng.integers(-12, 5)))), min(atlas - 2, max(4, h + int(rng.integers(-12, 5))))
+        mx, my = int(rng.integers(0, atlas - mw - 1)), int(rng.integers(0, atlas - mh - 1))
+        if i % 10 == 0:
+            mx = atlas - mw // 2
+        sx = float(np.floor(r[0])) + float(rng.integers(-6, 7))
+        sy = float(np.floor(r[1])) + float(rng.integers(-6, 7))
+        if fractional and i % 4 == 1:
+            sx += 0.5
+        out.append(((float(mx), float(my), float(mx + mw), float(my + mh)), (sx, sy)))
+    return out
 
 
 def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional=False, tile_filter=None):
@@ -1066,7 +1096,7 @@ CT_IDENTITY, CT_TABLE, CT_DISCRETE, CT_LINEAR, CT_GAMMA = 0, 1, 2, 3, 4
 
 
 def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=None, ops=None, only=None,
-                fractional=True):
+                fractional=True, masked=False):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -1165,6 +1195,11 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
             px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - 40))
         mode, ud = filter_params(k + 1000)
         prims.append(((px, py, px + w, py + h), addr, False, mode, ud))
+    t_mask, clip_tasks = None, [None] * len(prims)
+    if masked:
+        t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
+        frame.static_textures.append(t_mask)
+        clip_tasks = prim_clip_tasks(rng, [p[0] for p in prims], 1024, True)
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
@@ -1180,13 +1215,15 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
             if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
                 continue
             ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (addr, mode, ud, 0))
-            (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15))
+            ct = None if opaque else clip_tasks[zi]
+            clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
+            (op if opaque else al).append(frame.brush_instance(ph, clip_addr, edge_flags=15))
         if op:
             target.opaque.append(Step("brush_blend", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
                                       None, "opaque", textures={0: t_atlas}))
         if al:
             target.alpha.append(Step("brush_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
-                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
         clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
