@@ -197,41 +197,80 @@ WR_DEVICE bool wr_accum_is_linear(float s0, float step, int c) {
 // cross a binade boundary (and ties, zero / denormal sums) are executed one by one.  Verified
 // against the plain loop on random, dyadic, tie-prone and binade-floor inputs (tests/test_accum.py);
 // a 1840-row box-shadow mask spent ~900 dependent adds per interpolant and row in that loop.
+// All in 32-bit integers, in units of u: S = the sum's 24-bit significand, q = round-half-even of the
+// step's significand shifted to the sum's exponent.  (An fp64 version of the same walk cost every
+// kernel that can reach the general pixel path ~20 VGPRs: with interprocedural register allocation a
+// caller keeps its live values above whatever its callees clobber -- and the glyph kernel sits
+// exactly at the 168-VGPR / 3-waves-per-SIMD step.)
 WR_DEVICE float wr_accum_binades(float s0, float step, int c) {
   float s = s0;
   int k = c;
+  uint32_t db; __builtin_memcpy(&db, &step, 4);
+  const int ed = int((db >> 23) & 0xFF);
+  const uint32_t md = (db & 0x7FFFFFu) | 0x800000u;
   while (k > 0) {
     uint32_t b; __builtin_memcpy(&b, &s, 4);
     const int ex = int((b >> 23) & 0xFF);
-    if (ex == 0 || ex == 0xFF) { s = s + step; k--; continue; }              // zero / denormal / inf / nan: plain step
-    const double u = ldexp(1.0, ex - 127 - 23);                              // ulp of the binade
-    const double r = double(step) / u;                                       // exact (power-of-two scaling)
-    if (!(r > -16777216.0 && r < 16777216.0)) { s = s + step; k--; continue; }   // step dwarfs the sum
-    const double q = rint(r);                                                // nearest, ties to even
-    const double fr = r - q;
-    if (fr == 0.5 || fr == -0.5) { s = s + step; k--; continue; }            // tie: the parity of s decides
-    const double as = s < 0.0f ? -double(s) : double(s);
-    const double lo = ldexp(1.0, ex - 127), hi = lo * 2.0;
-    const double dq = (s < 0.0f ? -q : q) * u;                               // signed change of |s| per add
-    if (dq == 0.0) {
+    const int sh = ex - ed;                      // step / u = md / 2^sh
+    // zero / denormal / inf / nan operands, or a step that dwarfs the sum (binades fly by): plain step
+    if (ex == 0 || ex == 0xFF || ed == 0 || ed == 0xFF || sh < 0) { s = s + step; k--; continue; }
+    uint32_t q;
+    bool tie = false;
+    if (sh == 0) q = md;
+    else if (sh > 25) q = 0;                     // step < u/4
+    else {
+      const uint32_t half = 1u << (sh - 1), rem = md & ((1u << sh) - 1u);
+      q = md >> sh;
+      if (rem > half) q++;
+      else if (rem == half) tie = true;          // the parity of s decides: step singly
+    }
+    if (tie) { s = s + step; k--; continue; }
+    const bool up = ((b ^ db) >> 31) == 0;       // same sign: |s| grows
+    const uint32_t S = (b & 0x7FFFFFu) | 0x800000u;
+    if (q == 0) {
       // |step| < u/2: s + step rounds back to s -- unless s sits on the binade floor and moves down (finer grid below)
-      if (as == lo && ((step < 0.0f) != (s < 0.0f))) { s = s + step; k--; continue; }
+      if (S == 0x800000u && !up) { s = s + step; k--; continue; }
       return s;
     }
-    const double n = dq > 0.0 ? floor((hi - as) / dq) - 2.0      // every exact sum s_i + step must stay <= hi
-                              : floor((as - lo) / -dq) - 2.0;    // ... and >= lo
-    if (n >= 1.0) {
-      const int steps = n > double(k) ? k : int(n);
-      s = float(double(s) + double(steps) * (q * u));                        // exact: multiples of u inside the binade
+    // adds that keep every exact sum inside the binade (conservative by >= 2 q: the true step is within q/2.. of q*u)
+    const uint32_t dist = up ? (0x1000000u - S) : (S - 0x800000u);
+    const int n = int(float(dist) / float(q)) - 3;
+    if (n >= 1) {
+      const int steps = n > k ? k : n;
+      const uint32_t S2 = up ? S + uint32_t(steps) * q : S - uint32_t(steps) * q;
+      const uint32_t nb = (b & 0x80000000u) | (uint32_t(ex) << 23) | (S2 & 0x7FFFFFu);
+      __builtin_memcpy(&s, &nb, 4);
       k -= steps;
     }
     // the few adds left up to (and across) the binade boundary: plain steps, no new analysis
 #pragma unroll
-    for (int i = 0; i < 4; i++) if (k > 0) { s = s + step; k--; }
+    for (int i = 0; i < 5; i++) if (k > 0) { s = s + step; k--; }
   }
   return s;
 }
 WR_DEVICE float wr_accum(float s0, float step, int c) {
+  if (c <= 0 || step == 0.0f) return s0;
+  // closed form when provably identical: s0 and step are multiples of 2^g and every partial sum stays
+  // below 2^(g+24), so every add is exact and the result is the real number s0 + c*step -- which one
+  // fused multiply-add delivers (single rounding of an exactly representable value).  fp32 / integer only.
+  if (c < (1 << 24)) {
+    const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
+    const int g = g0 < g1 ? g0 : g1;
+    const float end = fmaf(float(c), step, s0);
+    const float a0 = fabsf(s0), a1 = fabsf(end);
+    const float bound = a0 > a1 ? a0 : a1;
+    uint32_t bb; __builtin_memcpy(&bb, &bound, 4);
+    const int be = int((bb >> 23) & 0xFF) - 127;          // bound < 2^(be+1)
+    if (g > -900 && g < 100 && be + 1 <= g + 24 && be < 127) return end;
+  }
+  WR_DBG_PATH(2);
+  return wr_accum_binades(s0, step, c);
+}
+
+// The same sum for short spans (glyph-sized prims): closed form when provable, else the plain loop.
+// Used on the glyph blit path, whose kernel sits at an occupancy step and cannot afford the fp64
+// temporaries of wr_accum_binades in its inline code (168 -> 188 VGPRs = 3 -> 2 waves per SIMD).
+WR_DEVICE float wr_accum_short(float s0, float step, int c) {
   if (c <= 0 || step == 0.0f) return s0;
   const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
   const int g = g0 < g1 ? g0 : g1;
@@ -239,8 +278,9 @@ WR_DEVICE float wr_accum(float s0, float step, int c) {
   const double a0 = s0 < 0 ? -double(s0) : double(s0), a1 = end < 0 ? -end : end;
   const double bound = a0 > a1 ? a0 : a1;
   if (g > -900 && g < 100 && bound < __builtin_ldexp(1.0, g + 24)) return float(end);
-  WR_DBG_PATH(2);
-  return wr_accum_binades(s0, step, c);
+  float s = s0;
+  for (int i = 0; i < c; i++) s += step;
+  return s;
 }
 
 // row-k edge interpolant: closed form when the prim was verified linear over all its rows
@@ -3545,7 +3585,7 @@ WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], u
       if (lane > 1) lu += T.su;
       if (lane > 2) lu += T.su;
       if (!tail[i]) {
-        const float q = wr_accum(lu * W * qs + qo, T.stepx, n >> 2);
+        const float q = wr_accum_short(lu * W * qs + qo, T.stepx, n >> 2);
         qx = int(wr_clamp(q, T.minx, T.maxx));
       } else {
         if (span > 0) lu = lu + (T.su * 4.0f) * (float(span) * 0.25f);
@@ -3562,7 +3602,7 @@ WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], u
   for (int j = 0; j < R; j++) {
     if (!cy[j]) continue;
     const int y = py + 4 * j;
-    const float ov = wr_accum(T.lv0, T.lvs, y - T.y0);      // Lv == Rv on this kind of prim, so sv == 0 exactly
+    const float ov = wr_accum_short(T.lv0, T.lvs, y - T.y0);      // Lv == Rv on this kind of prim, so sv == 0 exactly
     const int qy_span = int(wr_clamp(ov * H * qs + qo, T.miny, T.maxy));
     const int qy_tail = int(wr_clamp(ov, T.ub1, T.ub3) * H * 128.0f + (0.5f - 64.0f));
 #pragma unroll
@@ -3775,8 +3815,20 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   }
 }
 
+// Register budget: the textured RGBA8 variants need ~155-175 VGPRs, right at the 168 that still lets 3
+// waves share a SIMD, and they are latency-bound (cfg3: 240 us at 3 waves, 340 us at 2).  The compiler
+// is asked to hold 3 waves per SIMD for them; that is only a win while it has to spill a handful of
+// cold values (forcing a 192-VGPR build of the glyph variant down cost 2x), so what their inline paths
+// and their callees need is kept small: with interprocedural register allocation a caller keeps its
+// live values above whatever its callees clobber (hence the integer wr_accum_binades, wr_accum_short on
+// the glyph path, wr_aa_pixel_rgba8 out of line).
+#ifdef WRHIP_HOSTSIM
+#define WR_RASTER_BOUNDS(R, FMT, FEAT) __launch_bounds__(1024 / R)
+#else
+#define WR_RASTER_BOUNDS(R, FMT, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) != 0 && (FEAT) < 16) ? 3 : 1)
+#endif
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void __launch_bounds__(1024 / R)
+__global__ void WR_RASTER_BOUNDS(R, FMT, FEAT)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
@@ -3795,7 +3847,7 @@ struct WrSetupArgs {
   const WrTargetDesc* targets; unsigned long long* masks; float* vtab; WrUnsupportedCounters* cnt; const int* blk;
 };
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void __launch_bounds__(1024 / R)
+__global__ void WR_RASTER_BOUNDS(R, FMT, FEAT)
 wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
                        const WrTargetDesc* __restrict__ targets, int n_targets,
                        const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
