@@ -1,0 +1,47 @@
+"""Register budgets of the raster kernels (gfx950 cross-compile, no GPU needed).
+
+The kernels are latency- or VALU-bound and their speed tracks occupancy in steps: the rect-only
+variant must stay at 64 VGPRs (8 waves per SIMD), the textured RGBA8 variants at 168 (3 waves; at 170
+they drop to 2 and the cfg3 glyph pass goes from 240 us to 340 us -- that happened twice during round
+1 when an innocent-looking code path grew).  This test compiles each variant on its own and checks
+the allocation the compiler reports."""
+import os
+import re
+import shutil
+import subprocess
+import pytest
+from conftest import ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+CSRC = os.path.join(ROOT, "webrender_amd", "csrc")
+SRC = '''
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "wrhip_types.h"
+#include "wrhip_kernels.h"
+template __global__ void wr_raster_kernel<WR_FMT_RGBA8, false, 4, KFEAT>(const WrTargetDesc*, int, const WrDrawDesc*, const WrPrim*,
+    const WrRec*, const WrAux*, const float*, unsigned long long*, int);
+'''
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result",
+         "-w", "--cuda-device-only", "-S", "-mllvm", "-structurizecfg-skip-uniform-regions"]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("feat,max_vgpr", [(0, 64), (5, 168), (7, 168)])
+def test_raster_kernel_vgpr_budget(tmp_path, feat, max_vgpr):
+    src = tmp_path / "one.hip"
+    src.write_text(SRC)
+    out = tmp_path / "one.s"
+    subprocess.check_call([HIPCC] + FLAGS + [f"-DKFEAT={feat}", "-I", CSRC, str(src), "-o", str(out)])
+    asm = out.read_text()
+    m = re.search(r"\.amdhsa_kernel _Z16wr_raster_kernelILi3ELb0ELi4ELi%dE.*?\.end_amdhsa_kernel" % feat, asm, re.S)
+    assert m, "kernel not found in the assembly"
+    vgpr = int(re.search(r"next_free_vgpr (\d+)", m.group(0)).group(1))
+    assert vgpr <= max_vgpr, f"FEAT={feat}: {vgpr} VGPRs > {max_vgpr}: the kernel lost a wave per SIMD"
+    if feat == 0:
+        assert int(re.search(r"private_segment_fixed_size (\d+)", m.group(0)).group(1)) == 0
+        body = asm[asm.index("\n_Z16wr_raster_kernelILi3ELb0ELi4ELi0E"):]
+        body = body[:body.index(".Lfunc_end")]
+        # the in-place loop: no register-file copies of the pixel state at the loop back-edge
+        assert body.count("v_mov_b64") < 80
