@@ -20,7 +20,10 @@ SRC = '''
 #include <string.h>
 #include "wrhip_types.h"
 #include "wrhip_kernels.h"
-template __global__ void wr_raster_kernel<WR_FMT_RGBA8, false, 4, KFEAT>(const WrTargetDesc*, int, const WrDrawDesc*, const WrPrim*,
+#ifndef KDEPTH
+#define KDEPTH false
+#endif
+template __global__ void wr_raster_kernel<WR_FMT_RGBA8, KDEPTH, 4, KFEAT>(const WrTargetDesc*, int, const WrDrawDesc*, const WrPrim*,
     const WrRec*, const WrAux*, const float*, unsigned long long*, int);
 '''
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result",
@@ -28,19 +31,20 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("feat,max_vgpr", [(0, 64), (5, 168), (7, 168)])
-def test_raster_kernel_vgpr_budget(tmp_path, feat, max_vgpr):
+@pytest.mark.parametrize("feat,depth,max_vgpr", [(0, 0, 64), (0, 1, 128), (5, 0, 168), (7, 0, 168)])
+def test_raster_kernel_vgpr_budget(tmp_path, feat, depth, max_vgpr):
     src = tmp_path / "one.hip"
     src.write_text(SRC)
     out = tmp_path / "one.s"
-    subprocess.check_call([HIPCC] + FLAGS + [f"-DKFEAT={feat}", "-I", CSRC, str(src), "-o", str(out)])
+    subprocess.check_call([HIPCC] + FLAGS + [f"-DKFEAT={feat}", f"-DKDEPTH={'true' if depth else 'false'}", "-I", CSRC, str(src), "-o", str(out)])
     asm = out.read_text()
-    m = re.search(r"\.amdhsa_kernel _Z16wr_raster_kernelILi3ELb0ELi4ELi%dE.*?\.end_amdhsa_kernel" % feat, asm, re.S)
+    m = re.search(r"\.amdhsa_kernel _Z16wr_raster_kernelILi3ELb%dELi4ELi%dE.*?\.end_amdhsa_kernel" % (depth, feat), asm, re.S)
     assert m, "kernel not found in the assembly"
     vgpr = int(re.search(r"next_free_vgpr (\d+)", m.group(0)).group(1))
     assert vgpr <= max_vgpr, f"FEAT={feat}: {vgpr} VGPRs > {max_vgpr}: the kernel lost a wave per SIMD"
     if feat == 0:
-        assert int(re.search(r"private_segment_fixed_size (\d+)", m.group(0)).group(1)) == 0
+        assert int(re.search(r"private_segment_fixed_size (\d+)", m.group(0)).group(1)) == 0      # no spills
+    if feat == 0 and not depth:
         body = asm[asm.index("\n_Z16wr_raster_kernelILi3ELb0ELi4ELi0E"):]
         body = body[:body.index(".Lfunc_end")]
         # the in-place loop: no register-file copies of the pixel state at the loop back-edge

@@ -3821,14 +3821,15 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 // cold values (forcing a 192-VGPR build of the glyph variant down cost 2x), so what their inline paths
 // and their callees need is kept small: with interprocedural register allocation a caller keeps its
 // live values above whatever its callees clobber (hence the integer wr_accum_binades, wr_accum_short on
-// the glyph path, wr_aa_pixel_rgba8 out of line).
+// the glyph path, wr_aa_pixel_rgba8 out of line).  The rect-only variants ask for 8 waves (64 VGPRs) and, depth-tested,
+// 4 (without a request that one drifted to 129 VGPRs = 3 waves and cfg5 lost 15 %).
 #ifdef WRHIP_HOSTSIM
-#define WR_RASTER_BOUNDS(R, FMT, FEAT) __launch_bounds__(1024 / R)
+#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R)
 #else
-#define WR_RASTER_BOUNDS(R, FMT, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) != 0 && (FEAT) < 16) ? 3 : 1)
+#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? 3 : ((DEPTH) ? 4 : 8)) : 0)
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void WR_RASTER_BOUNDS(R, FMT, FEAT)
+__global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
@@ -3847,7 +3848,7 @@ struct WrSetupArgs {
   const WrTargetDesc* targets; unsigned long long* masks; float* vtab; WrUnsupportedCounters* cnt; const int* blk;
 };
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void WR_RASTER_BOUNDS(R, FMT, FEAT)
+__global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
 wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
                        const WrTargetDesc* __restrict__ targets, int n_targets,
                        const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
