@@ -65,6 +65,8 @@ static inline void event_create(wr_event_t* e) { e->t = 0; }
 static inline void event_destroy(wr_event_t) {}
 static inline void event_record(wr_event_t*, wr_stream_t) {}
 static inline void event_sync(wr_event_t*) {}
+static inline void stream_wait_event(wr_stream_t, wr_event_t*) {}
+static inline void event_create_sync(wr_event_t* e) { e->t = 0; }
 static inline float event_elapsed_ms(wr_event_t*, wr_event_t*) { return 0.f; }
 }  // namespace wrrt
 #else
@@ -128,6 +130,9 @@ static inline void event_create(wr_event_t* e) { WR_HIP_CHECK(hipEventCreate(e))
 static inline void event_destroy(wr_event_t e) { WR_HIP_CHECK(hipEventDestroy(e)); }
 static inline void event_record(wr_event_t* e, wr_stream_t s) { WR_HIP_CHECK(hipEventRecord(*e, s)); }
 static inline void event_sync(wr_event_t* e) { WR_HIP_CHECK(hipEventSynchronize(*e)); }
+// ordering-only events (no timestamps) and cross-stream waits
+static inline void event_create_sync(wr_event_t* e) { WR_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming)); }
+static inline void stream_wait_event(wr_stream_t s, wr_event_t* e) { WR_HIP_CHECK(hipStreamWaitEvent(s, *e, 0)); }
 static inline float event_elapsed_ms(wr_event_t* a, wr_event_t* b) { float ms = 0; WR_HIP_CHECK(hipEventElapsedTime(&ms, *a, *b)); return ms; }
 }  // namespace wrrt
 #endif
