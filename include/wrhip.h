@@ -245,6 +245,13 @@ void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height,
 GLuint WrhipGetFramebufferTexture(GLuint fbo);
 /* Name of the HIP device the context runs on, or NULL if none. */
 const char* WrhipDeviceName(void);
+/* Submit everything recorded so far to the context's HIP stream (pending draws, queued uploads, the
+ * held-back composite level) WITHOUT waiting for it: after the call the stream holds all the work
+ * whose results a consumer enqueued behind it on the same stream will see.  The multi-GPU harness
+ * orders its framebuffer-strip copy and the RCCL all-gather this way instead of a Finish per frame. */
+void WrhipFlush(void);
+/* The context's hipStream_t (NULL in the host simulation), e.g. for torch.cuda.ExternalStream. */
+void* WrhipGetStream(void);
 
 #ifdef __cplusplus
 }

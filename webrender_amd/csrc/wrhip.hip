@@ -1948,5 +1948,18 @@ GLuint WrhipGetFramebufferTexture(GLuint fbo) {
   return fb ? fb->color_attachment : 0;
 }
 const char* WrhipDeviceName(void) { return g_rt_ok ? g_device_name : nullptr; }
+void WrhipFlush(void) {
+  if (!ctx) return;
+  flush_all();
+  flush_uploads();
+  drain_tail();
+}
+void* WrhipGetStream(void) {
+#ifdef WRHIP_HOSTSIM
+  return nullptr;
+#else
+  return ctx ? (void*)ctx->stream : nullptr;
+#endif
+}
 
 }  // extern "C"

@@ -83,14 +83,21 @@ class ShardedFramePlayer:
         else:
             set_rows(fb_tex, 1 << 30, (1 << 30) + 1)
         self.fb_rows = fb_rows
+        self._flush = C.CFUNCTYPE(None)(sym("WrhipFlush"))
+        self._get_stream = C.CFUNCTYPE(C.c_void_p)(sym("WrhipGetStream"))
         _, _, self.strip = strip_rows(self.height, rank, world)
         self.row_bytes = self.width * 4
         self.device = device
         if device == "cuda":
             ptr = get_ptr(fb_tex, None, None, None)
             self.fb = torch.as_tensor(DeviceArray(ptr, self.height * self.row_bytes), device="cuda")
+            # torch enqueues the strip copy and the all-gather behind the backend's own work on the
+            # backend's HIP stream: no host sync per frame, frames stay pipelined
+            sp = self._get_stream()
+            self.ext_stream = torch.cuda.ExternalStream(int(sp)) if sp else None
         else:
             self.fb = None       # CPU/gloo test path reads the strip back through ReadPixels
+            self.ext_stream = None
         chunk = self.strip * self.row_bytes
         self.send = [torch.zeros(chunk, dtype=torch.uint8, device=device) for _ in range(2)]
         self.gathered = [torch.zeros(chunk * world, dtype=torch.uint8, device=device) for _ in range(2)]
@@ -99,11 +106,21 @@ class ShardedFramePlayer:
 
     # -- one frame: render own strips, then contribute to the all-gather ------
     def _frame(self):
-        self.player.rp.exec(self.rec.frame)          # includes Finish(): strip is in HBM
         i = self.k & 1
         self.k += 1
         y0, y1 = self.fb_rows
         n = max(0, y1 - y0) * self.row_bytes
+        if self.device == "cuda" and self.ext_stream is not None:
+            self.player.rp.exec(self.rec.stream)     # the frame without a Finish
+            self._flush()                            # ... submitted (composite included), not waited for
+            with self.torch.cuda.stream(self.ext_stream):
+                if n:
+                    self.send[i][:n].copy_(self.fb[y0 * self.row_bytes:y0 * self.row_bytes + n])
+                if self.pending is not None:
+                    self.pending.wait()              # stream-side wait: the send buffer of two frames ago is free again
+                self.pending = self.dist.all_gather_into_tensor(self.gathered[i], self.send[i], async_op=True)
+            return
+        self.player.rp.exec(self.rec.frame)          # includes Finish(): strip is in HBM
         if self.device == "cuda":
             if n:
                 self.send[i][:n].copy_(self.fb[y0 * self.row_bytes:y0 * self.row_bytes + n])
@@ -133,7 +150,11 @@ class ShardedFramePlayer:
 
     def _drain(self):
         if self.pending is not None:
-            self.pending.wait()
+            if self.ext_stream is not None:
+                with self.torch.cuda.stream(self.ext_stream):
+                    self.pending.wait()
+            else:
+                self.pending.wait()
             self.pending = None
         if self.device == "cuda":
             self.torch.cuda.synchronize()

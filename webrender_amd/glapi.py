@@ -132,6 +132,8 @@ EXTRA_SIGNATURES = {
     "WrhipGetTextureDevicePtr": (P, [u32, P, P, P]),
     "WrhipGetFramebufferTexture": (u32, [u32]),
     "WrhipDeviceName": (c_char_p, []),
+    "WrhipFlush": (None, []),
+    "WrhipGetStream": (P, []),
 }
 
 
