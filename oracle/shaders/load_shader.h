@@ -16,6 +16,7 @@
 #include "brush_image.h"
 #include "brush_linear_gradient.h"
 #include "brush_blend.h"
+#include "ps_quad_mask.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -41,6 +42,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("brush_linear_gradient ALPHA_PASS", brush_linear_gradient_ALPHA_PASS)
   WRSH_ENTRY("brush_blend", brush_blend)
   WRSH_ENTRY("brush_blend ALPHA_PASS", brush_blend_ALPHA_PASS)
+  WRSH_ENTRY("ps_quad_mask", ps_quad_mask)
+  WRSH_ENTRY("ps_quad_mask FAST_PATH", ps_quad_mask_FAST_PATH)
 #undef WRSH_ENTRY
   return nullptr;
 }

@@ -60,6 +60,9 @@ SMALL = [
     ("image_grid_wide", lambda: scenes.image_grid(width=2048, height=1024, n=300, seed=52)),
     ("image_grid_masked", lambda: scenes.image_grid(masked=True)),
     ("filter_grid_masked", lambda: scenes.filter_grid(masked=True, seed=75, ops=FILTER_OPS_EXACT)),
+    ("quad_masks", lambda: scenes.quad_masks()),
+    ("quad_masks_wide", lambda: scenes.quad_masks(width=2048, height=1024, n=160, seed=82)),
+    ("quad_masks_int", lambda: scenes.quad_masks(width=1000, height=700, n=70, seed=83, fractional=False)),
     ("gradient_grid", lambda: scenes.gradient_grid()),
     ("gradient_grid_wide", lambda: scenes.gradient_grid(width=2048, height=1024, n=300, seed=63)),
     ("gradient_grid_int", lambda: scenes.gradient_grid(width=1000, height=700, n=150, seed=65, fractional=False)),

@@ -130,6 +130,10 @@ const ShaderInfo SHADERS[] = {
     {"brush_image ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_linear_gradient", WR_SH_BRUSH_LINEAR_GRADIENT, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
     {"brush_linear_gradient ALPHA_PASS", WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
+    {"ps_quad_mask", WR_SH_PS_QUAD_MASK, {"aPosition", "aData", "aClipData"},
+     S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
+    {"ps_quad_mask FAST_PATH", WR_SH_PS_QUAD_MASK_FAST, {"aPosition", "aData", "aClipData"},
+     S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
     {"brush_blend", WR_SH_BRUSH_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_blend ALPHA_PASS", WR_SH_BRUSH_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"composite TEXTURE_2D", WR_SH_COMPOSITE,
@@ -1004,6 +1008,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW: f = WR_FEAT_CLIP; break;
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }
       }

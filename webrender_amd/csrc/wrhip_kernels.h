@@ -326,7 +326,8 @@ struct WrVsOut {
 };
 
 // ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
-WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+// mask: 0 ps_quad_textured, 1 ps_quad_mask, 2 ps_quad_mask FAST_PATH (C = its side record)
+WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, int mask = 0, WrClipRec* C = nullptr) {
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_address_i = aData.x, prim_address_f = aData.y;
   int quad_flags = (aData.z >> 24) & 0xff;
@@ -388,6 +389,7 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
     tsx = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].width : 1);
     tsy = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].height : 1);
   }
+  float mlx[4], mly[4];
   for (int n = 0; n < 4; n++) {
     float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
     // mix(p0, p1, aPosition) = (p1 - p0) * a + p0
@@ -405,12 +407,60 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
     wf4 gp = wr_mul(*(const WrMat4*)d.transform,
                     wf4{dx + fox * world.w, dy + foy * world.w, z * world.w, world.w});
     o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+    mlx[n] = vlx * pso.x + pso.z; mly[n] = vly * pso.y + pso.w;      // prim_info.local_pos (scale_offset_map_point)
     if (textured) {
       float ilx = vlx * pso.x + pso.z, ily = vly * pso.y + pso.w;
       float fx = (ilx - sr0x) / (sr1x - sr0x), fy = (ily - sr0y) / (sr1y - sr0y);
       float uvx = (seg_uv.z - seg_uv.x) * fx + seg_uv.x, uvy = (seg_uv.w - seg_uv.y) * fy + seg_uv.y;
       o.u[n] = uvx / tsx; o.v[n] = uvy / tsy;
     } else { o.u[n] = 0.f; o.v[n] = 0.f; }
+  }
+  if (mask) {
+    // pattern_vertex (ps_quad_mask.glsl:65-152)
+    const wi4 cd = wr_load_attr<wi4>(d, arena, inst, 1);          // aClipData: [clip transform id, clip address, clip space, -]
+    const int cu_ = int(unsigned(cd.y) % 1024u), cv_ = int(unsigned(cd.y) / 1024u);
+    const wf4 c0 = wr_fetch_f(gbf, cu_, cv_), c1 = wr_fetch_f(gbf, cu_ + 1, cv_), c2 = wr_fetch_f(gbf, cu_ + 2, cv_), c3 = wr_fetch_f(gbf, cu_ + 3, cv_);
+    const WrTransform ct = wr_fetch_transform(d, cd.x);
+    const bool fast = mask == 2;
+    const float mode = fast ? c2.x : c3.x;
+    float cw[4];
+    for (int n = 0; n < 4; n++) {
+      const wf4 lp = wr_mul(ct.m, wf4{mlx[n], mly[n], 0.0f, 1.0f});
+      o.u[n] = lp.x; o.v[n] = lp.y; cw[n] = lp.w;
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) C->center_radius[i][j] = 0.0f;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) C->plane[i][j] = 0.0f;
+    for (int i = 0; i < 4; i++) C->bounds[i] = 0.0f;
+    C->params[0] = C->params[1] = C->params[2] = 0.0f;
+    C->fast = fast ? 1 : 0; C->mode = mode; C->w = cw[0];
+    if (fast) {
+      const float hx = 0.5f * (c0.z - c0.x), hy = 0.5f * (c0.w - c0.y), radius = c1.x;
+      for (int n = 0; n < 4; n++) { o.u[n] = o.u[n] - (hx + c0.x) * cw[n]; o.v[n] = o.v[n] - (hy + c0.y) * cw[n]; }
+      C->params[0] = hx - radius; C->params[1] = hy - radius; C->params[2] = radius;
+    } else {
+      if (cd.z == 0) { C->bounds[0] = c0.x; C->bounds[1] = c0.y; C->bounds[2] = c0.z; C->bounds[3] = c0.w; }   // CLIP_SPACE_RASTER
+      else {       // clip rect ∩ prim_info.local_clip_rect (the prim's clip through the pattern scale-offset)
+        const float pc0x = t1.x * pso.x + pso.z, pc0y = t1.y * pso.y + pso.w, pc1x = t1.z * pso.x + pso.z, pc1y = t1.w * pso.y + pso.w;
+        C->bounds[0] = wr_max(c0.x, pc0x); C->bounds[1] = wr_max(c0.y, pc0y); C->bounds[2] = wr_min(c0.z, pc1x); C->bounds[3] = wr_min(c0.w, pc1y);
+      }
+      // corners in WrClipRec order TL, TR, BR, BL; radii_top = (tl, tr), radii_bottom = (bl, br)
+      const float rx[4] = {c1.x, c1.z, c2.z, c2.x}, ry[4] = {c1.y, c1.w, c2.w, c2.y};
+      const float ccx[4] = {c0.x + rx[0], c0.z - rx[1], c0.z - rx[2], c0.x + rx[3]};
+      const float ccy[4] = {c0.y + ry[0], c0.y + ry[1], c0.w - ry[2], c0.w - ry[3]};
+      // half-space normals and the diagonal point they pass through (:118-136)
+      const float nx[4] = {-ry[0], ry[1], ry[2], -ry[3]}, ny[4] = {-rx[0], -rx[1], rx[2], rx[3]};
+      const float dx[4] = {c0.x, c0.z - rx[1], c0.z, c0.x + rx[3]}, dy[4] = {c0.y + ry[0], c0.y, c0.w - ry[2], c0.w};
+      for (int k = 0; k < 4; k++) {
+        C->center_radius[k][0] = ccx[k]; C->center_radius[k][1] = ccy[k];
+        C->center_radius[k][2] = 1.0f / wr_max(rx[k] * rx[k], 1.0e-6f);     // inverse_radii_squared, ellipse.glsl:33-35
+        C->center_radius[k][3] = 1.0f / wr_max(ry[k] * ry[k], 1.0e-6f);
+        C->plane[k][0] = nx[k]; C->plane[k][1] = ny[k]; C->plane[k][2] = nx[k] * dx[k] + ny[k] * dy[k];
+      }
+    }
+    o.kind = (cw[1] != cw[0] || cw[2] != cw[0] || cw[3] != cw[0] || !(quad_flags & 16)) ? WR_PK_UNSUPPORTED : WR_PK_QUAD_MASK;   // affine clip transforms, QF_IS_MASK
+    o.color = prim_color; o.has_color = 0;
+    o.tex_slot = WR_S_GPU_BUFFER_F;
+    return;
   }
   if (textured) {
     o.kind = (quad_flags & 16) ? WR_PK_UNSUPPORTED : WR_PK_TEX_RGBA8;
@@ -1195,7 +1245,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1572,7 +1622,7 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   r.len = P.x1 - P.x0;
   r.span = r.len >= 4 ? (r.len & ~3) : 0;
   r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
-  if (P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER) r.span = 0;     // no draw_span for this program/target: all main()
+  if (P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK) r.span = 0;     // no draw_span for this program/target: all main()
   if (r.span == 0) return r;
   float W = float(t.width), H = float(t.height);
   // lanes 0 and 1 of the uv vector handed to swgl_commitTexture* (shader-side offset included)
@@ -1841,6 +1891,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
   o.blend_override = 0; o.blend_color = wf4{0, 0, 0, 0};
   switch (d.shader) {
     case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
+    case WR_SH_PS_QUAD_MASK: wr_vs_ps_quad_textured(d, arena, inst, o, 1, &aux[gid].clip); break;
+    case WR_SH_PS_QUAD_MASK_FAST: wr_vs_ps_quad_textured(d, arena, inst, o, 2, &aux[gid].clip); break;
     case WR_SH_BRUSH_SOLID:
     case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush(d, arena, inst, 0, o); break;
     case WR_SH_BRUSH_IMAGE: wr_vs_brush(d, arena, inst, 1, o); break;
@@ -2687,6 +2739,29 @@ WR_DEVICE float wr_clip_dist(const WrClipRec& C, float px, float py) {
 }
 WR_DEVICE float wr_step01(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
 
+// ps_quad_mask fragment (ps_quad.glsl:399-415, ps_quad_mask.glsl:167-200): one pixel of main(), which
+// runs four pixels at a time -- fwidth() of the chunk is |lane1 - lane0| in x plus in y (glsl.h:765-768).
+__device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrClipRec& C = *Cp;
+  const WrTexRow r = wr_tex_row(P, D->tex[0], y);            // span == 0 for this kind: interpolants only
+  const int n = x - P.x0, n0 = n & ~3;
+  float f0x, f0y, f1x, f1y, qx, qy;
+  wr_tex_tail_uv(P, r, n0, f0x, f0y);
+  wr_tex_tail_uv(P, r, n0 + 1, f1x, f1y);
+  wr_tex_tail_uv(P, r, n, qx, qy);
+  const float wv = C.w;
+  f0x = f0x / wv; f0y = f0y / wv; f1x = f1x / wv; f1y = f1y / wv; qx = qx / wv; qy = qy / wv;   // vClipLocalPos.xy / vClipLocalPos.w
+  const float aa_range = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));   // recip(fwidth(pos).x), shared.glsl:145-148
+  const float dist = wr_clip_dist(C, qx, qy);
+  const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
+  const float fin = ((1.0f - alpha) - alpha) * C.mode + alpha;
+  uint32_t pc[2];
+  wr_pack_color(wf4{fin, fin, fin, fin}, pc);
+  WrWide s; s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
 struct WrRow4 { uint32_t v[4]; };
 
 // Four horizontally adjacent pixels (x .. x+3) of row y: the span-level setup is
@@ -3436,6 +3511,23 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), wr_mask_src(*Pp, D, px + i, py + 4 * j, g4.v[i]), D);
         plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
       }
+    }
+    return;
+  }
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_QUAD_MASK) {
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      bool in = cx[q & 3] && cy[q >> 2];
+      if (dtest) {
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+        in = in && pass;
+        if (dwrite) dep[q] = in ? z : dep[q];
+      }
+      if (!in) continue;
+      const WrWide src = wr_quad_mask_pixel(Pp, &Ap->clip, D, px + (q & 3), py + 4 * (q >> 2));
+      const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+      plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;
   }

@@ -56,6 +56,8 @@ enum WrShader {
   WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA,
   WR_SH_BRUSH_BLEND,
   WR_SH_BRUSH_BLEND_ALPHA,
+  WR_SH_PS_QUAD_MASK,
+  WR_SH_PS_QUAD_MASK_FAST,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -173,6 +175,7 @@ enum WrPrimKind {
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
   WR_PK_GRADIENT,       // swgl_commitLinearGradientRGBA8 (WrGradRec); v_pos travels in WrPrim's uv interpolants
   WR_PK_FILTER,         // brush_blend: fragment shader only (texture() + CalculateFilter, WrFilterRec); uv as WR_PK_TEX_FS
+  WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
 };
 
 enum WrPrimFlags {

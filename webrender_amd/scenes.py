@@ -1230,3 +1230,63 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
         frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
     frame.passes.append(targets)
     return frame
+
+
+# ---------------------------------------------------------------------------
+# ps_quad_mask: rounded-rectangle clips applied to quads.  The quad pattern is drawn first
+# (ps_quad_textured, solid colour), then one MaskInstance per clip multiplies the same pixels by the
+# clip's coverage (renderer: set_blend_mode_multiply; quad.rs / gpu_types.rs:618-624).
+def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractional=True, only=None):
+    from .frame import QF_APPLY_DEVICE_CLIP
+    QF_IS_MASK = 16
+    rng, rects = random_rects(n, width, height, 48, 360, seed, fractional)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    alpha = np.round(rng.uniform(0.4, 1.0, size=n) * 255).astype(np.uint8)
+    colors = premultiply(np.concatenate([rgb, alpha[:, None]], axis=1)).astype(np.float32) / np.float32(255.0)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    clips = []
+    for i in range(n):
+        x0, y0, x1, y1 = [float(v) for v in rects[i]]
+        w, h = x1 - x0, y1 - y0
+        inset = float(rng.uniform(0.0, 6.0)) if i % 3 else 0.0
+        cr = (x0 + inset, y0 + inset, x1 - inset * 0.5, y1 - inset)
+        mode = 1.0 if i % 7 == 3 else 0.0            # clip-out now and then
+        if i % 2 == 0:       # uniform radius: FAST_PATH
+            r = float(rng.uniform(2.0, min(w, h) * 0.45))
+            addr = frame.gpu_buffer_f.push([list(cr), [r, r, r, r], [mode, 0.0, 0.0, 0.0]])
+            clips.append((addr, True))
+        else:
+            rad = [float(rng.uniform(0.0, min(w, h) * 0.45)) for _ in range(8)]
+            if i % 5 == 0:
+                rad[0] = rad[1] = 0.0                 # a square corner
+            # radii_top = (tl.w, tl.h, tr.w, tr.h), radii_bottom = (bl.w, bl.h, br.w, br.h)
+            addr = frame.gpu_buffer_f.push([list(cr), rad[0:4], rad[4:8], [mode, 0.0, 0.0, 0.0]])
+            clips.append((addr, False))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        hit = np.nonzero((rects[:, 0] < x1) & (rects[:, 2] > x0) & (rects[:, 1] < y1) & (rects[:, 3] > y0))[0]
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        for i in hit:
+            if only is not None and i not in only:
+                continue
+            big = (-BIG, -BIG, BIG, BIG)
+            q = frame.quad_instance(rects[i], big, colors[i], int(i + 1), task)
+            target.alpha.append(Step("ps_quad_textured", "PRIM_INSTANCES", np.array([q], dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={}))
+            m = frame.quad_instance(rects[i], big, (1.0, 1.0, 1.0, 1.0), int(i + 1), task,
+                                    quad_flags=QF_APPLY_DEVICE_CLIP | QF_IS_MASK)
+            addr, fast = clips[i]
+            inst = np.array([m + [0, addr, int(i % 4 == 1), 0]], dtype=np.int32)     # clip transform 0 (identity), address, space
+            target.alpha.append(Step("ps_quad_mask FAST_PATH" if fast else "ps_quad_mask", "MASK", inst,
+                                     "Multiply", "alpha", textures={}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
