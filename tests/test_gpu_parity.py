@@ -300,3 +300,15 @@ def test_hip_filter_hue_rotate_within_one_lsb():
     got, _ = render_direct(wrhip_lib(), make())
     want, _ = render_direct(ref, make())
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_hip_filter_swatches_match_numpy_model():
+    """brush_blend on the device against the independent numpy model of the filter math (no oracle in
+    the loop): exact, except hue-rotate whose matrix depends on the device's cosf / sinf (<= 1 LSB)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle import check_filter_swatches
+    fr = scenes.filter_swatches()
+    px, _ = render_direct(wrhip_lib(), fr)
+    check_filter_swatches(px, fr, tol_hue=1)

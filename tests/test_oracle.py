@@ -70,3 +70,23 @@ def test_gcc_and_clang_oracles_agree(oracle_gcc, oracle_clang):
 def test_golden_digests(oracle_gcc, name, kw):
     got, _ = render_direct(oracle_gcc, scenes.cfg2_overlapping_rects(**kw))
     assert digest(got) == GOLDEN[name]
+
+
+def check_filter_swatches(px, fr, tol_hue=0):
+    H = px.shape[0]
+    for (x, y, img, op, params) in fr.swatches:
+        h, w = img.shape[:2]
+        want = np_model.filter_swatch(img[..., [2, 1, 0, 3]], op, params)     # atlas bytes are BGRA
+        got = px[H - y - h:H - y][::-1, x:x + w]                             # the window is bottom-up
+        d = np.abs(want.astype(int) - got.astype(int)).max()
+        assert d <= (tol_hue if op == scenes.FILTER_HUE_ROTATE else 0), f"filter op {op}: max diff {d}"
+
+
+def test_brush_blend_oracle_matches_numpy_model(oracle_gcc):
+    """The hand-written brush_blend shader header (oracle/shaders/brush_blend.h) against an independent
+    numpy float32 restatement of blend.glsl's filter math (oracle/np_model.py filter_swatch), on 36 swatches
+    covering the 12 filter ops: contrast, grayscale, hue-rotate, invert, saturate, sepia, brightness,
+    colour matrix, sRGB<->linear (swgl's approximate pow), flood, component transfer."""
+    fr = scenes.filter_swatches()
+    px, _ = render_direct(oracle_gcc, fr)
+    check_filter_swatches(px, fr)

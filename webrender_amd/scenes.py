@@ -1290,3 +1290,86 @@ def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractio
         frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
     frame.passes.append(targets)
     return frame
+
+
+def filter_swatches(seed=91):
+    """One 1024x512 tile of non-overlapping 64x48 brush_blend swatches, each a 1:1, integer-aligned copy
+    of its own premultiplied atlas image through one filter -- simple enough for an independent numpy
+    model of the filter math (oracle/np_model.py filter_swatch).  frame.swatches lists
+    (x, y, image RGBA u8 premultiplied, op, parameters)."""
+    rng = np.random.default_rng(seed)
+    W, H = 1024, 512
+    frame = Frame(W, H, (1.0, 1.0, 1.0, 1.0))
+    atlas = 512
+    pix = np.zeros((atlas, atlas, 4), np.uint8)
+    t_atlas = TextureRef("swatch_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pix, upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+    quad = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
+    sw, sh = 64, 48
+    specs = []
+    for op in range(12):
+        for rep in range(3):
+            specs.append(op)
+    frame.swatches = []
+    tex = TextureRef("tile_0_0", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+    target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+    task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (0.0, 0.0))
+    inst = []
+    for k, op in enumerate(specs):
+        ax, ay = (k % 7) * (sw + 4) + 2, (k // 7) * (sh + 4) + 2
+        img = rng.integers(0, 256, size=(sh, sw, 4), dtype=np.uint8)
+        if k % 3 == 0:
+            img[..., 3] = 255
+        if k % 3 == 2:
+            img[::5, :, 3] = 0                                        # alpha == 0 rows
+        img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)
+        pix[ay:ay + sh, ax:ax + sw] = img
+        addr = frame.gpu_cache.push([[ax, ay, ax + sw, ay + sh], [0.0, 0.0, 0.0, 0.0]] + quad)
+        params = {}
+        ud = 0
+        mode = op
+        if op in (FILTER_CONTRAST, FILTER_GRAYSCALE, FILTER_INVERT, FILTER_SATURATE, FILTER_SEPIA, FILTER_BRIGHTNESS):
+            amount = float(rng.choice([0.25, 0.5, 1.0, 1.75])) if k % 2 else float(rng.uniform(0.0, 2.0))
+            ud = int(np.float32(amount) * np.float32(65536.0))
+        elif op == FILTER_HUE_ROTATE:
+            ud = int(np.float32(0.01745329251) * np.float32(rng.uniform(0.0, 360.0)) * np.float32(65536.0))
+        elif op == FILTER_COLOR_MATRIX:
+            m = rng.uniform(-0.5, 1.2, size=(4, 4)).astype(np.float32)
+            off = rng.uniform(-0.2, 0.3, size=4).astype(np.float32)
+            ud = frame.gpu_cache.push([list(r) for r in m] + [list(off)])
+            params = {"matrix": m, "offset": off}
+        elif op == FILTER_FLOOD:
+            c = np.array([rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0.2, 1.0)], np.float32)
+            ud = frame.gpu_cache.push([list(c)])
+            params = {"flood": c}
+        elif op == FILTER_COMPONENT_TRANSFER:
+            funcs = [int(rng.integers(0, 5)) for _ in range(4)]
+            blocks, tabs = [], []
+            for f in funcs:
+                if f in (CT_TABLE, CT_DISCRETE):
+                    lut = rng.uniform(-0.1, 1.1, size=256).astype(np.float32)
+                    blocks += [list(lut[4 * j:4 * j + 4]) for j in range(64)]
+                    tabs.append(lut)
+                elif f == CT_LINEAR:
+                    v = np.array([rng.uniform(-1.5, 2.0), rng.uniform(-0.3, 0.5), 0.0, 0.0], np.float32)
+                    blocks.append(list(v)); tabs.append(v)
+                elif f == CT_GAMMA:
+                    v = np.array([rng.uniform(0.5, 1.5), rng.choice([0.4, 1.0, 2.2, 3.0]), rng.uniform(-0.1, 0.2), 0.0], np.float32)
+                    blocks.append(list(v)); tabs.append(v)
+                else:
+                    tabs.append(None)
+            ud = frame.gpu_cache.push(blocks) if blocks else 0
+            mode = int(np.int32(np.uint32(FILTER_COMPONENT_TRANSFER | (funcs[0] << 28) | (funcs[1] << 24) | (funcs[2] << 20) | (funcs[3] << 16))))
+            params = {"funcs": funcs, "tables": tabs}
+        params["user_data"] = ud
+        px, py = 8 + (k % 12) * (sw + 12), 8 + (k // 12) * (sh + 12)
+        rect = (float(px), float(py), float(px + sw), float(py + sh))
+        ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), k + 1, 0, 0, task, (addr, mode, ud, 0))
+        inst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15))
+        frame.swatches.append((px, py, img, op, params))
+    t_atlas.pixels = pix
+    target.alpha.append(Step("brush_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
+                             "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+    frame.passes.append([target])
+    frame.composite_tiles.append(CompositeTile(tex, (0.0, 0.0, float(TILE_W), float(TILE_H)), (0.0, 0.0, float(W), float(H)), opaque=True))
+    return frame
