@@ -50,6 +50,9 @@ CASES = [
     ("image_grid_wide", lambda: scenes.image_grid(width=2048, height=1024, n=300, seed=52)),
     ("image_grid_masked", lambda: scenes.image_grid(masked=True)),
     ("filter_grid_masked", lambda: scenes.filter_grid(masked=True, seed=75)),
+    ("rotated_rects", lambda: scenes.rotated_rects()),
+    ("rotated_rects_quad", lambda: scenes.rotated_rects(encoding="quad")),
+    ("rotated_rects_wide", lambda: scenes.rotated_rects(width=2048, height=1024, n=140, seed=97)),
     ("quad_masks", lambda: scenes.quad_masks()),
     ("quad_masks_wide", lambda: scenes.quad_masks(width=2048, height=1024, n=160, seed=82)),
     ("quad_masks_int", lambda: scenes.quad_masks(width=1000, height=700, n=70, seed=83, fractional=False)),

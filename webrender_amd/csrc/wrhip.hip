@@ -95,6 +95,11 @@ struct Texture {
   bool pending_read = false, pending_write = false;
   int pending_target = -1;   // index into Context::work when pending_write
   bool tail_ref = false;     // read or written by the deferred last raster level (Context::Tail)
+  // RGBA32I data textures: does any transform id in them carry TRANSFORM_NON_AXIS_ALIGNED (bit 23,
+  // transform.glsl:22-29)?  Read as sPrimitiveHeadersI (2 texels per prim, id in .z of the first) and as
+  // sGpuBufferI (ps_quad header, id in .x); maintained on upload.  A draw is only declared
+  // rectangle-only (WR_DF_SIMPLE) when the header texture it binds is clean.
+  bool complex_ids_headers = false, complex_ids_gpubuf = false;
   bool has_storage() const { return dptr != nullptr; }
 };
 
@@ -1337,6 +1342,17 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
       }
     } else memcpy(d, s, row);
   }
+  if (t.internal_format == GL_RGBA32I) {
+    if (xoffset == 0 && yoffset == 0) t.complex_ids_headers = t.complex_ids_gpubuf = false;   // (uploads start at the origin: a fresh frame)
+    const int32_t* iv = (const int32_t*)st;
+    const size_t ni = row * (size_t)height / 4;
+    bool h = false, g = false;
+    for (size_t i = 0; i + 3 < ni; i += 4) {
+      g |= ((uint32_t)iv[i] >> 23) != 0u;                            // ps_quad header: [transform_id, z, pattern input]
+      if ((i & 4) == 0) h |= ((uint32_t)iv[i + 2] >> 23) != 0u;      // prim header texel 0: [z, specific, transform_id, task]
+    }
+    t.complex_ids_headers |= h; t.complex_ids_gpubuf |= g;
+  }
   queue_upload(st_off, (uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, row, height);
 }
 void TexImage2D(GLenum target, GLint level, GLint internal_format, GLsizei width, GLsizei height, GLint, GLenum format,
@@ -1804,8 +1820,15 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     const bool plain_blend = d.blend == WR_BLEND_NONE || d.blend == WR_BLEND_PREMULT;
     const bool maskable = d.blend != WR_BLEND_NONE && d.tex[WR_S_CLIP_MASK].ptr && d.tex[WR_S_CLIP_MASK].width >= 2;
     bool simple = false;
-    if (info->kind == WR_SH_BRUSH_SOLID || info->kind == WR_SH_BRUSH_SOLID_ALPHA) simple = plain_blend && !maskable;
-    else if (info->kind == WR_SH_PS_QUAD_TEXTURED) simple = plain_blend && d.tex[WR_S_COLOR0].width < 2;
+    auto ids_clean = [&](int slot, bool headers) {
+      GLuint tid = c->texture_units[prog->sampler_unit[slot] & 15].texture_2d_binding;
+      Texture* ht = tid ? c->textures.find(tid) : nullptr;
+      return !ht || !(headers ? ht->complex_ids_headers : ht->complex_ids_gpubuf);
+    };
+    if (info->kind == WR_SH_BRUSH_SOLID || info->kind == WR_SH_BRUSH_SOLID_ALPHA)
+      simple = plain_blend && !maskable && ids_clean(WR_S_PRIM_HEADERS_I, true);
+    else if (info->kind == WR_SH_PS_QUAD_TEXTURED)
+      simple = plain_blend && d.tex[WR_S_COLOR0].width < 2 && ids_clean(WR_S_GPU_BUFFER_I, false);
     if (simple && d.blend != WR_BLEND_NONE && d.attr_off[0] >= 0 && d.attr_bytes[0] >= 12 && inst_stride >= 12) {
       // swgl_antiAlias only matters with blending on; the request travels in aData.z of every
       // instance (brush: flags = z >> 16, BRUSH_FLAG_FORCE_AA = 1024, gpu_types.rs:690-703; quad:

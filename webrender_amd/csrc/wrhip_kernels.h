@@ -1131,6 +1131,91 @@ WR_DEVICE void wr_vs_ps_clear(const WrDrawDesc& d, const uint8_t* arena, int ins
 WR_DEVICE float wr_pick4(const float (&a)[4], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
 WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
 
+// draw_quad_spans (rasterize.h:783-1055) for a general convex quad, walked at setup time: which vertex
+// starts, which edges are the span's left and right ones, when each edge ends and is replaced
+// (STEP_EDGE), the clip span of every edge pair.  Returns false for degenerate walks (nothing to draw)
+// or more runs than WrQuadRec holds.  p[] in vertex-lane order (0,0) (1,0) (1,1) (0,1).
+struct WrEdgeInst { float x, slope; int row, mask; };
+WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, float p1y, int mask) {   // Edge ctor, :850-876
+  WrEdgeInst e;
+  const float yScale = 1.0f / wr_max(p1y - p0y, 1.0f / 256.0f);
+  e.slope = (p1x - p0x) * yScale;
+  e.x = p0x + (y - p0y) * e.slope;
+  e.row = int(y); e.mask = mask;
+  return e;
+}
+WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], float cx0, float cy0, float cx1, float cy1, bool aa, int aa_mask,
+                            WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1) {
+  Q.nseg = 0; Q.aa = aa ? 1 : 0;
+  // top-most point (:794-799)
+  const int top = py[3] < py[2] ? (py[0] < py[1] ? (py[0] < py[3] ? 0 : 3) : (py[1] < py[3] ? 1 : 3))
+                                : (py[0] < py[1] ? (py[0] < py[2] ? 0 : 2) : (py[1] < py[2] ? 1 : 2));
+  const int next = (top + 1) & 3, prev = (top + 3) & 3;
+  int l0i, l1i, r0i, r1i;
+  if (wr_pick4(py, top) == wr_pick4(py, next)) { l0i = next; l1i = (next + 1) & 3; r0i = top; r1i = prev; }
+  else if (wr_pick4(py, top) == wr_pick4(py, prev)) { l0i = top; l1i = next; r0i = prev; r1i = (prev + 3) & 3; }
+  else { l0i = r0i = top; l1i = next; r1i = prev; }
+#define WR_PX(i) wr_pick4(px, i)
+#define WR_PY(i) wr_pick4(py, i)
+  const float aaRound = aa ? 0.0f : 0.5f;
+  float y = floorf(wr_max(wr_min(WR_PY(l0i), cy1), cy0) + aaRound) + 0.5f;
+  // the l-chain walks forward through the points, the r-chain backward; `flipped` says which one is the span's left edge
+  WrEdgeInst EL = wr_edge_init(y, WR_PX(l0i), WR_PY(l0i), WR_PX(l1i), WR_PY(l1i), (aa_mask >> l1i) & 1);
+  WrEdgeInst ER = wr_edge_init(y, WR_PX(r0i), WR_PY(r0i), WR_PX(r1i), WR_PY(r1i), (aa_mask >> r0i) & 1);
+  bool flipped;
+  {   // checkIfEdgesFlipped (:766-774)
+    const float l0x = WR_PX(l0i), r0x = WR_PX(r0i);
+    const float ax = WR_PX(l1i) - l0x, ay = WR_PY(l1i) - WR_PY(l0i), bx = WR_PX(r1i) - r0x, by = WR_PY(r1i) - WR_PY(r0i);
+    flipped = l0x > r0x || (l0x == r0x && (ax * by - ay * bx) > 0.0f);
+  }
+  float checkY = wr_min(wr_min(WR_PY(l1i), WR_PY(r1i)), cy1);
+  float b0, b1;
+#define WR_CLIPSPAN()                                                                                          \
+  do {                                                                                                         \
+    const float lo = wr_min(wr_min(WR_PX(l0i), WR_PX(l1i)), wr_min(WR_PX(r0i), WR_PX(r1i)));                   \
+    const float hi = wr_max(wr_max(WR_PX(l0i), WR_PX(l1i)), wr_max(WR_PX(r0i), WR_PX(r1i)));                   \
+    b0 = wr_clamp(lo, cx0, cx1); b1 = wr_clamp(hi, cx0, cx1);                                                  \
+  } while (0)
+  WR_CLIPSPAN();
+  bx0 = 0x7FFFFFFF; bx1 = -0x7FFFFFFF; by0 = int(y); by1 = int(y);
+  for (int guard = 0; guard < 16; guard++) {
+    if (y > checkY) {
+      if (y > cy1) break;
+      bool done = false;
+      if (y > WR_PY(l1i)) {          // STEP_EDGE(y, l0i, l0, l1i, l1, NEXT_POINT, r1i)
+        do { l0i = l1i; l1i = (l1i + 1) & 3; if (l0i == r1i) { done = true; break; } } while (y > WR_PY(l1i));
+        if (done) break;
+        EL = wr_edge_init(y, WR_PX(l0i), WR_PY(l0i), WR_PX(l1i), WR_PY(l1i), (aa_mask >> l1i) & 1);
+      }
+      if (y > WR_PY(r1i)) {          // STEP_EDGE(y, r0i, r0, r1i, r1, PREV_POINT, l1i)
+        do { r0i = r1i; r1i = (r1i + 3) & 3; if (r0i == l1i) { done = true; break; } } while (y > WR_PY(r1i));
+        if (done) break;
+        ER = wr_edge_init(y, WR_PX(r0i), WR_PY(r0i), WR_PX(r1i), WR_PY(r1i), (aa_mask >> r0i) & 1);
+      }
+      WR_CLIPSPAN();
+      checkY = wr_min(ceilf(wr_min(WR_PY(l1i), WR_PY(r1i)) - aaRound), cy1);
+    }
+    // rows y, y + 1, ... up to the last one that does not exceed checkY (at least this one)
+    int n = 1;
+    if (checkY >= y) n = int(floor(double(checkY) - double(y))) + 1;
+    if (Q.nseg >= 4) return false;
+    WrQuadSeg& S = Q.seg[Q.nseg++];
+    const WrEdgeInst& A = flipped ? ER : EL;
+    const WrEdgeInst& B = flipped ? EL : ER;
+    S.row_a = int(y); S.row_b = int(y) + n;
+    S.lx = A.x; S.ls = A.slope; S.lrow = A.row; S.lmask = A.mask;
+    S.rx = B.x; S.rs = B.slope; S.rrow = B.row; S.rmask = B.mask;
+    S.b0 = b0; S.b1 = b1;
+    bx0 = wr_imin(bx0, int(floorf(b0)) - 1); bx1 = wr_imax(bx1, int(ceilf(b1)) + 1);
+    by1 = S.row_b;
+    y = y + float(n);
+  }
+#undef WR_CLIPSPAN
+#undef WR_PX
+#undef WR_PY
+  return Q.nseg > 0;
+}
+
 // draw_quad (rasterize.h:1549-1633) + the axis-aligned closed form of
 // draw_quad_spans (rasterize.h:783-1055): for a rectangle both edge slopes are
 // exactly 0, so every row has the same span and rows are those whose centre
@@ -1196,8 +1281,20 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   // lanes: 0=(0,0) 1=(1,0) 2=(1,1) 3=(0,1) of the unit quad
   bool typeA = sy[0] == sy[1] && sy[2] == sy[3] && sx[0] == sx[3] && sx[1] == sx[2];
   bool typeB = sx[0] == sx[1] && sx[2] == sx[3] && sy[0] == sy[3] && sy[1] == sy[2];
-  if (!typeA && !typeB) {  // general quads (rotations): "next"
-    P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
+  if (!typeA && !typeB) {
+    // general convex quad (rotation / skew): solid colour only so far, textured / masked ones are "next"
+    if (o.kind != WR_PK_SOLID || masked || ((d.flags & WR_DF_SIMPLE) != 0)) {
+      P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
+    }
+    const bool qaa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
+    int bx0, by0, bx1, by1;
+    if (!wr_quad_walk(sx, sy, cx0, cy0, cx1, cy1, qaa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1)) return;
+    P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
+    if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
+    P.kind = WR_PK_SOLID_QUAD;
+    P.rows_linear = 0;
+    wr_pack_color(o.color, P.color);
+    return;
   }
   float xa = sx[0], xb = sx[2], ya = sy[0], yb = sy[2];
   float xmin = wr_min(xa, xb), xmax = wr_max(xa, xb), ymin = wr_min(ya, yb), ymax = wr_max(ya, yb);
@@ -2181,6 +2278,46 @@ __global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_seg
       ((uint8_t*)sg.dst)[r * sg.dst_stride + c] = sg.src[i];
     }
   }
+}
+
+// One pixel of a solid colour on a general quad: this row's span from the edge instances of its run
+// (aa_span / aa_edge / aa_dist, rasterize.h:480-562), the pixel's coverage (DO_AA, blend.h:433-446), the blend.
+// Returns the new pixel in the low word and 1 << 32 when the pixel is inside the row's span.
+__device__ __noinline__ unsigned long long wr_quad_pixel_rgba8(const WrQuadRec* Qp, const WrDrawDesc* D, int blend, uint32_t c0, uint32_t c1,
+                                                                int x, int y, uint32_t dstp_) {
+  const WrQuadRec& Q = *Qp;
+  const unsigned long long dstp = dstp_;
+  const unsigned long long HIT = 1ull << 32;
+  int si = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  if (si < 0) return dstp;
+  const WrQuadSeg& S = Q.seg[si];
+  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);   // Edge::nextRow, one add per row
+  WrWide src; src.bg = c0; src.ra = c1;
+  if (!Q.aa) {
+    const int s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)), s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+    if (x < s0 || x >= s1) return dstp;
+    return HIT | wr_blend_rgba8(blend, dstp_, src, D);
+  }
+  // aa_edge: masked edges use the row's x intercepts rounded out, the others the rounded x
+  const float radl = 0.5f * fabsf(S.ls), radr = 0.5f * fabsf(S.rs);
+  const int la0 = S.lmask ? int(floorf(wr_clamp(xl - radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+  const int la1 = S.lmask ? int(ceilf(wr_clamp(xl + radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+  const int ra1 = S.rmask ? int(ceilf(wr_clamp(xr + radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+  if (x < la0 || x >= ra1) return dstp;
+  // aa_dist
+  float lstart = 256.0f, lend = 0.0f, rstart = 256.0f, rend = 0.0f;
+  if (S.lmask) { const float dx = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.ls * S.ls)); lstart = 128.0f + dx * (xl - 0.5f); lend = -dx; }
+  if (S.rmask) { const float dx = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.rs * S.rs)); rstart = 128.0f + dx * (xr - 0.5f); rend = -dx; }
+  const int n = x - la0, lane = n & 3, base = la0 + (n & ~3);
+  const float off = float(4 * (base - la1));
+  const float dl = (lstart + float(la1 + lane) * lend) + (lend / 4.0f) * off;
+  const float dr = (rstart + float(la1 + lane) * rend) + (rend / 4.0f) * off;
+  const uint32_t cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
+  src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+  src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+  return HIT | wr_blend_rgba8(blend, dstp_, src, D);
 }
 
 // One pixel of an anti-aliased solid quad (DO_AA, blend.h:433-446): src = muldiv256(src, coverage)
@@ -3544,6 +3681,24 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       if (!in) continue;
       const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2)));
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+      plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+    }
+    return;
+  }
+  if ((FEAT & WR_FEAT_GENERIC) && FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID_QUAD) {
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      const bool in = cx[q & 3] && cy[q >> 2];
+      if (!in) continue;
+      const uint32_t before = plo[q] | (phi[q] << 8);
+      bool pass = true;
+      if (dtest) pass = dless ? (z < dep[q]) : (z <= dep[q]);
+      if (!pass) continue;
+      const unsigned long long rr = wr_quad_pixel_rgba8(&Ap->quad, D, blend, c0, c1, px + (q & 3), py + 4 * (q >> 2), before);
+      if (!(rr >> 32)) continue;
+      const uint32_t r = (uint32_t)rr;
+      if (dtest && dwrite) dep[q] = z;
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;

@@ -175,6 +175,7 @@ enum WrPrimKind {
   WR_PK_TEX_R8,         // swgl_commitTextureLinearColorR8ToRGBA8: R8 mask expanded to RGBA8, colour-modulated
   WR_PK_GRADIENT,       // swgl_commitLinearGradientRGBA8 (WrGradRec); v_pos travels in WrPrim's uv interpolants
   WR_PK_FILTER,         // brush_blend: fragment shader only (texture() + CalculateFilter, WrFilterRec); uv as WR_PK_TEX_FS
+  WR_PK_SOLID_QUAD,     // solid colour on a general (rotated / skewed) convex quad: per-row spans from WrQuadRec, optional AA
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
 };
 
@@ -321,6 +322,23 @@ struct WrFilterRec {
   float color_offset[4];    // v_color_offset
 };
 
+// General convex quad (draw_quad_spans, rasterize.h:783-1055): the scanline walk cut into the runs of
+// rows that share one pair of edge instances.  An Edge is (re)initialised at row `row` with x = `x`
+// and then steps x += slope once per row (Edge::nextRow), so its x on row y is the (y - row)-fold
+// sequential sum -- wr_accum.  `b0`,`b1`: clipSpan of the run; masks: swgl_AAEdgeMask bits of the edges.
+struct WrQuadSeg {
+  int32_t row_a, row_b;             // target rows [row_a, row_b)
+  float lx, ls; int32_t lrow;       // span-left edge
+  float rx, rs; int32_t rrow;       // span-right edge
+  float b0, b1;
+  int32_t lmask, rmask;
+};
+struct WrQuadRec {
+  int32_t nseg;
+  int32_t aa;                       // SWGL_CLIP_FLAG_AA set for this prim
+  WrQuadSeg seg[4];
+};
+
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
   WrTexRec tex;
@@ -330,6 +348,7 @@ union WrAux {
   WrAARec aa;
   WrGradRec grad;
   WrFilterRec filt;
+  WrQuadRec quad;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

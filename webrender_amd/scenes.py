@@ -1242,7 +1242,7 @@ def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractio
     rng, rects = random_rects(n, width, height, 48, 360, seed, fractional)
     rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
     alpha = np.round(rng.uniform(0.4, 1.0, size=n) * 255).astype(np.uint8)
-    colors = premultiply(np.concatenate([rgb, alpha[:, None]], axis=1)).astype(np.float32) / np.float32(255.0)
+    colors = premultiply(np.concatenate([rgb, alpha[:, None]], axis=1))
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     clips = []
     for i in range(n):
@@ -1294,8 +1294,8 @@ def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractio
 
 def filter_swatches(seed=91):
     """One 1024x512 tile of non-overlapping 64x48 brush_blend swatches, each a 1:1, integer-aligned copy
-    of its own premultiplied atlas image through one filter -- simple enough for an independent numpy
-    model of the filter math (oracle/np_model.py filter_swatch).  frame.swatches lists
+    of its own premultiplied atlas image through one filter -- simple enough for an independent
+    restatement of the filter math in the tests.  frame.swatches lists
     (x, y, image RGBA u8 premultiplied, op, parameters)."""
     rng = np.random.default_rng(seed)
     W, H = 1024, 512
@@ -1372,4 +1372,65 @@ def filter_swatches(seed=91):
                              "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
     frame.passes.append([target])
     frame.composite_tiles.append(CompositeTile(tex, (0.0, 0.0, float(TILE_W), float(TILE_H)), (0.0, 0.0, float(W), float(H)), opaque=True))
+    return frame
+
+
+# ---------------------------------------------------------------------------
+# Rotated / skewed solid rectangles: the general convex-quad path of draw_quad_spans (rasterize.h:783-1055)
+# with swgl_antiAlias on all four edges (brush.glsl: non-axis-aligned transforms take the antialiased branch).
+def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile_filter=None, only=None, opaque_frac=0.0):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    prims = []
+    for i in range(n):
+        w, h = float(rng.uniform(20, 320)), float(rng.uniform(20, 260))
+        cx, cy = float(rng.uniform(0, width)), float(rng.uniform(0, height))
+        th = float(rng.uniform(0, 2 * np.pi)) if i % 6 else float(rng.choice([np.pi / 4, np.pi / 6, 0.01]))
+        sk = float(rng.uniform(-0.4, 0.4)) if i % 4 == 1 else 0.0
+        c, s = np.cos(th), np.sin(th)
+        a = np.array([[c, -s + sk * c], [s, c + sk * s]], np.float64)          # rotation (x skew) about (cx, cy)
+        m = np.eye(4)
+        m[:2, :2] = a
+        m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+        inv = np.linalg.inv(m)
+        tid = frame.add_transform(m.T.astype(np.float32), inv.T.astype(np.float32), axis_aligned=False)   # blocks = columns
+        rgba = np.array([[rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256), rng.integers(90, 256)]], np.uint8)
+        opaque = rng.uniform() < opaque_frac
+        if opaque:
+            rgba[0, 3] = 255
+        col = premultiply(rgba)[0]
+        rect = (cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)
+        r = float(np.hypot(w, h)) * 0.75 + 4
+        prims.append((rect, tid, col, (cx - r, cy - r, cx + r, cy + r), opaque))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        op, al = [], []
+        for zi, (rect, tid, col, bb, opaque) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
+                continue
+            if encoding == "brush":
+                addr = frame.gpu_cache.push([list(col)])
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, addr, tid, task, (65535, 0, 0, 0))
+                (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15))
+            else:
+                (op if opaque else al).append(frame.quad_instance(rect, (-BIG, -BIG, BIG, BIG), col, zi + 1, task, transform_id=tid,
+                                                                  quad_flags=0, edge_flags=15))
+        key = ("brush_solid", "brush_solid ALPHA_PASS") if encoding == "brush" else ("ps_quad_textured", "ps_quad_textured")
+        if op:
+            target.opaque.append(Step(key[0], "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32), None, "opaque", textures={}))
+        if al:
+            target.alpha.append(Step(key[1], "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha", textures={}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
     return frame
