@@ -66,7 +66,7 @@ def pmc_traffic(workload, encoding):
     return int(sum(v) / len(v)), "profiles/" + os.path.basename(files[-1])
 
 
-def cpu_baseline(rec, budget_s=20.0):
+def cpu_baseline(rec, budget_s=12.0):
     """Reference swgl on one host core, bounded sample of the same frame trace."""
     from webrender_amd.harness import ScenePlayer
     lib = os.path.join(ROOT, "oracle", "_ref", "libswgl_ref_clang.so")
@@ -79,7 +79,7 @@ def cpu_baseline(rec, budget_s=20.0):
     t0 = time.perf_counter()
     ms = list(p.frames(0, 1))
     per = ms[0] / 1e3
-    n = int(max(2, min(12, budget_s / max(per, 1e-3))))
+    n = int(max(2, min(60, budget_s / max(per, 1e-3))))
     ms += list(p.frames(0, n - 1))
     ms = np.array(ms)
     return {"value": round(1e3 / ms.mean(), 4), "unit": "frames/s", "cores": 1, "kind": kind,
