@@ -195,6 +195,8 @@ struct TargetWork {
   std::vector<WrDrawDesc> draws;   // submission order; inst_offset relative to `inst`
   std::vector<uint8_t> inst;       // instance bytes snapshotted at draw time
   std::vector<GLuint> reads;       // textures sampled by these draws
+  std::vector<GLuint> rreads;      // ... the subset the RASTER stage can read (colour / mask samplers, filter tables, gradient
+                                   // stops); the data textures of the vertex stage are consumed by the setup kernel of the same flush
   int prims = 0;
   int level = 0;                   // dependency depth inside the pending batch: samples targets of lower levels only
 };
@@ -262,15 +264,17 @@ struct Context {
     unsigned long long* masks = nullptr; size_t masks_cap = 0;
   } scratch[2];
   int64_t flush_seq = 0;
-  // The last raster level of a flush (the composite pass of a frame) is not launched with its
-  // flush: it is held back and goes out fused with the setup stage of the NEXT flush
-  // (wr_setup_raster_kernel), which it does not depend on and which would otherwise sit between two
-  // frames as a dozen latency-bound workgroups plus a kernel boundary.  Anything that needs the
-  // tail's results, or touches a texture it reads or writes from outside the draw stream (host
-  // uploads, copies, readbacks, deletes, Finish), drains it first (drain_tail).
+  // The raster launches of a flush are not issued with it: they are held back, and the first of them
+  // goes out fused with the setup stage of the NEXT flush (wr_setup_raster_kernel), which it does not
+  // depend on and which would otherwise sit between two frames as a dozen latency-bound workgroups
+  // plus a kernel boundary; the rest follow in order.  Anything that needs their results, or touches a
+  // texture they read or write from outside the draw stream (host uploads, copies, readbacks,
+  // deletes, Finish), drains them first (drain_tail).
+  struct Held { int fmt, depth, feat, nb, off; };    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
   struct Tail {
     bool pending = false;
-    int nb = 0, off = 0, n_targets = 0;
+    std::vector<Held> held;          // the raster launches of the held-back flush, in order
+    int n_targets = 0;
     const WrTargetDesc* targets = nullptr; const WrDrawDesc* draws = nullptr;
     int set = 0;
     std::vector<GLuint> refs;
@@ -755,17 +759,56 @@ void tail_launched() {
   Context::Tail& T = ctx->tail;
   for (GLuint id : T.refs) if (Texture* t = ctx->textures.find(id)) t->tail_ref = false;
   T.refs.clear();
+  T.held.clear();
   T.pending = false;
 }
-// Launch the held-back raster level on its own (nothing to fuse it with, or its results are needed now).
+// The instantiated raster kernels: RGBA8 (+depth) x {0, TEX|GENERIC, +R8TEX, everything}, R8 x {0, GENERIC|BLUR, +CLIP}.
+// `SA` non-null: launch the fused setup + raster variant (only for the variants can_fuse() names).
+bool can_fuse(const Context::Held& H) {
+  return H.fmt == WR_FMT_RGBA8 && !H.depth && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC));
+}
+void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
+                   const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0) {
+  Context* c = ctx;
+#define WR_K(FMT, DEPTH, FEAT)                                                                                          \
+  do {                                                                                                                  \
+    WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), H.nb, 256, c->stream, targets, n_targets, draws,                 \
+              (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off); \
+  } while (0)
+#define WR_KF(FEAT)                                                                                                     \
+  do {                                                                                                                  \
+    WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, false, 4, FEAT>), n_setup_blocks + H.nb, 256, c->stream, *SA,        \
+              n_setup_blocks, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs,                  \
+              (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);                                               \
+  } while (0)
+  const int F5 = WR_FEAT_TEX | WR_FEAT_GENERIC, F7 = F5 | WR_FEAT_R8TEX, FA = F7 | WR_FEAT_BLUR | WR_FEAT_SHADE;
+  if (SA) { if (H.feat == 0) WR_KF(0); else WR_KF(WR_FEAT_TEX | WR_FEAT_GENERIC); }
+  else if (H.fmt == WR_FMT_RGBA8) {
+    if (H.depth) {
+      if (H.feat == 0) WR_K(WR_FMT_RGBA8, true, 0); else if (H.feat == F5) WR_K(WR_FMT_RGBA8, true, WR_FEAT_TEX | WR_FEAT_GENERIC);
+      else if (H.feat == F7) WR_K(WR_FMT_RGBA8, true, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX);
+      else WR_K(WR_FMT_RGBA8, true, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE);
+    } else {
+      if (H.feat == 0) WR_K(WR_FMT_RGBA8, false, 0); else if (H.feat == F5) WR_K(WR_FMT_RGBA8, false, WR_FEAT_TEX | WR_FEAT_GENERIC);
+      else if (H.feat == F7) WR_K(WR_FMT_RGBA8, false, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX);
+      else WR_K(WR_FMT_RGBA8, false, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE);
+    }
+    (void)FA;
+  } else {
+    if (H.feat == 0) WR_K(WR_FMT_R8, false, 0);
+    else if (H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR)) WR_K(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR);
+    else WR_K(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP);
+  }
+#undef WR_K
+#undef WR_KF
+  c->stats.kernel_launches++; c->stats.raster_launches++;
+}
+// Launch the held-back raster launches on their own (nothing to fuse them with, or their results are needed now).
 void drain_tail() {
   Context* c = ctx;
   if (!c || !c->tail.pending) return;
   Context::Tail& T = c->tail;
-  Context::Scratch& TS = c->scratch[T.set];
-  WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, false, 4, WR_FEAT_TEX | WR_FEAT_GENERIC>), T.nb, 256, c->stream, T.targets, T.n_targets, T.draws,
-            (const WrPrim*)TS.prims, (const WrRec*)TS.recs, (const WrAux*)TS.aux, (const float*)TS.vtab, TS.masks, T.off);
-  c->stats.kernel_launches++; c->stats.raster_launches++;
+  for (const Context::Held& H : T.held) launch_raster(H, T.targets, T.n_targets, T.draws, c->scratch[T.set]);
   tail_launched();
 }
 void sync_stream() {
@@ -948,20 +991,19 @@ void flush_work(const std::vector<int>& sel_in) {
       const int nd_arg = nd;
 #endif
       const int n_setup_blocks = (n_prims + 255) / 256;
-      if (c->tail.pending) {
-        // previous flush's held-back raster level + this flush's setup stage, one launch
+      if (c->tail.pending && can_fuse(c->tail.held[0])) {
+        // the first held-back raster launch of the previous flush + this flush's setup stage in one launch,
+        // then the rest of the previous flush's raster launches
         Context::Tail& T = c->tail;
-        Context::Scratch& TS = c->scratch[T.set];
         WrSetupArgs SA{ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims, dtargets, S.masks, S.vtab, c->dcounters, dblk};
-        WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, false, 4, WR_FEAT_TEX | WR_FEAT_GENERIC>), n_setup_blocks + T.nb, 256, c->stream,
-                  SA, n_setup_blocks, T.targets, T.n_targets, T.draws, (const WrPrim*)TS.prims, (const WrRec*)TS.recs,
-                  (const WrAux*)TS.aux, (const float*)TS.vtab, TS.masks, T.off);
-        c->stats.kernel_launches += 1; c->stats.raster_launches++;
+        launch_raster(T.held[0], T.targets, T.n_targets, T.draws, c->scratch[T.set], &SA, n_setup_blocks);
+        for (size_t hi = 1; hi < T.held.size(); hi++) launch_raster(T.held[hi], T.targets, T.n_targets, T.draws, c->scratch[T.set]);
         tail_launched();
       } else {
         WR_LAUNCH(wr_setup_kernel, n_setup_blocks, 256, c->stream, ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims,
                   dtargets, S.masks, S.vtab, c->dcounters, dblk);
         c->stats.kernel_launches += 1;
+        drain_tail();        // (held-back launches the fused kernel has no variant for)
       }
     } else {
       drain_tail();
@@ -1019,53 +1061,37 @@ void flush_work(const std::vector<int>& sel_in) {
       }
       (to_r8 ? L.feat_r8 : L.feat_rgba) |= f;
     }
-#define WR_RASTER_F(FMT, DEPTH, FEAT, NB, OFF)                                                                      \
-  do {                                                                                                              \
-    WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), NB, 256, c->stream, dtargets, n_targets, ddraws,             \
-              (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, OFF);             \
-    c->stats.kernel_launches++; c->stats.raster_launches++;                                                         \
-  } while (0)
-    // smallest instantiated superset of the level's feature set
-#define WR_RASTER(DEPTH, NB, OFF)                                                                                   \
-  do {                                                                                                              \
-    if (L.feat_rgba == 0) WR_RASTER_F(WR_FMT_RGBA8, DEPTH, 0, NB, OFF);                                             \
-    else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC)))                                                     \
-      WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC, NB, OFF);                                     \
-    else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX)))                                     \
-      WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX, NB, OFF);                     \
-    else WR_RASTER_F(WR_FMT_RGBA8, DEPTH, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE, NB, OFF);   \
-  } while (0)
-    // one raster launch per dependency level and target format, in level order on the one stream;
-    // the last level is held back (Context::Tail) when the fused setup + raster kernel can take it
-    for (size_t li = 0; li < levels.size(); li++) {
-      const Level& L = levels[li];
+    // one raster launch per dependency level and target format, in level order on the one stream: the
+    // smallest instantiated superset of each level's feature set.  They are held back (Context::Tail)
+    // unless the flush is being profiled or deferral is off.
+    std::vector<Context::Held> launches;
+    for (const Level& L : levels) {
       if (L.bins_rgba > 0) {
-        const bool hold = li + 1 == levels.size() && c->defer_tail && !c->profiling && L.bins_r8 == 0 && !L.any_depth &&
-                          L.feat_rgba != 0 && !(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC));
-        if (hold) {
-          Context::Tail& T = c->tail;      // (the previous tail went out with this flush's setup launch)
-          T.pending = true; T.nb = L.bins_rgba; T.off = L.bin0; T.n_targets = n_targets;
-          T.targets = dtargets; T.draws = ddraws; T.set = (int)(c->flush_seq & 1);
-          for (int oi = 0; oi < n_targets; oi++) {
-            if (target_level[oi] != (int)li) continue;
-            const TargetWork& w = c->work[sel[oi]];
-            T.refs.push_back(w.tex);
-            for (GLuint id : w.reads) T.refs.push_back(id);
-          }
-          for (GLuint id : T.refs) if (Texture* t = c->textures.find(id)) t->tail_ref = true;
-        }
-        else if (L.any_depth) WR_RASTER(true, L.bins_rgba, L.bin0);
-        else WR_RASTER(false, L.bins_rgba, L.bin0);
+        int f;
+        if (L.feat_rgba == 0) f = 0;
+        else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC))) f = WR_FEAT_TEX | WR_FEAT_GENERIC;
+        else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX))) f = WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX;
+        else f = WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE;
+        launches.push_back(Context::Held{WR_FMT_RGBA8, L.any_depth ? 1 : 0, f, L.bins_rgba, L.bin0});
       }
       if (L.bins_r8 > 0) {
-        const int off8 = L.bin0 + L.bins_rgba;
-        if (L.feat_r8 == 0) WR_RASTER_F(WR_FMT_R8, false, 0, L.bins_r8, off8);
-        else if (!(L.feat_r8 & WR_FEAT_CLIP)) WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR, L.bins_r8, off8);
-        else WR_RASTER_F(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP, L.bins_r8, off8);
+        const int f = L.feat_r8 == 0 ? 0 : (!(L.feat_r8 & WR_FEAT_CLIP) ? (WR_FEAT_GENERIC | WR_FEAT_BLUR) : (WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP));
+        launches.push_back(Context::Held{WR_FMT_R8, 0, f, L.bins_r8, L.bin0 + L.bins_rgba});
       }
     }
-#undef WR_RASTER_F
-#undef WR_RASTER
+    if (c->defer_tail && !c->profiling && !launches.empty()) {
+      Context::Tail& T = c->tail;      // (the previous tail went out with this flush's setup launch)
+      T.pending = true; T.held = launches; T.n_targets = n_targets;
+      T.targets = dtargets; T.draws = ddraws; T.set = (int)(c->flush_seq & 1);
+      for (int oi = 0; oi < n_targets; oi++) {
+        const TargetWork& w = c->work[sel[oi]];
+        T.refs.push_back(w.tex);
+        for (GLuint id : w.rreads) T.refs.push_back(id);
+      }
+      for (GLuint id : T.refs) if (Texture* t = c->textures.find(id)) t->tail_ref = true;
+    } else {
+      for (const Context::Held& H : launches) launch_raster(H, dtargets, n_targets, ddraws, S);
+    }
     if (c->profiling) {
       wrrt::event_record(&c->ev_b, c->stream);
       wrrt::event_sync(&c->ev_b);
@@ -1797,6 +1823,13 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     mark_ref(tid, *t, false);
     std::vector<GLuint>& reads = c->work[wi].reads;
     if (std::find(reads.begin(), reads.end(), tid) == reads.end()) reads.push_back(tid);
+    unsigned rmask = (1u << WR_S_COLOR0) | (1u << WR_S_COLOR1) | (1u << WR_S_COLOR2) | (1u << WR_S_CLIP_MASK);
+    if (info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA) rmask |= 1u << WR_S_GPU_CACHE;
+    if (info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA) rmask |= 1u << WR_S_GPU_BUFFER_F;
+    if ((rmask >> s) & 1) {
+      std::vector<GLuint>& rr = c->work[wi].rreads;
+      if (std::find(rr.begin(), rr.end(), tid) == rr.end()) rr.push_back(tid);
+    }
   }
   d.target = wi;
   d.blend = c->blend ? c->blend_key : WR_BLEND_NONE;

@@ -4094,8 +4094,14 @@ struct WrSetupArgs {
   const WrDrawDesc* draws; int n_draws; const uint8_t* arena; WrPrim* prims; WrRec* recs; WrAux* aux; int n_prims;
   const WrTargetDesc* targets; unsigned long long* masks; float* vtab; WrUnsupportedCounters* cnt; const int* blk;
 };
+// (the setup stage needs ~114 VGPRs: the fused rect variant asks for 4 waves per SIMD, not the 8 of the plain one)
+#ifdef WRHIP_HOSTSIM
+#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R)
+#else
+#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R, (FEAT) == 0 ? 4 : 3)
+#endif
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
+__global__ void WR_FUSED_BOUNDS(R, FEAT)
 wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
                        const WrTargetDesc* __restrict__ targets, int n_targets,
                        const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
