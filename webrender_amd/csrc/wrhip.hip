@@ -765,7 +765,8 @@ void tail_launched() {
 // The instantiated raster kernels: RGBA8 (+depth) x {0, TEX|GENERIC, +R8TEX, everything}, R8 x {0, GENERIC|BLUR, +CLIP}.
 // `SA` non-null: launch the fused setup + raster variant (only for the variants can_fuse() names).
 bool can_fuse(const Context::Held& H) {
-  return H.fmt == WR_FMT_RGBA8 && !H.depth && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC));
+  return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
+                                   H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
 }
 void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
                    const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0) {
@@ -775,14 +776,22 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), H.nb, 256, c->stream, targets, n_targets, draws,                 \
               (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off); \
   } while (0)
-#define WR_KF(FEAT)                                                                                                     \
+#define WR_KF(DEPTH, FEAT)                                                                                              \
   do {                                                                                                                  \
-    WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, false, 4, FEAT>), n_setup_blocks + H.nb, 256, c->stream, *SA,        \
+    WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, DEPTH, 4, FEAT>), n_setup_blocks + H.nb, 256, c->stream, *SA,        \
               n_setup_blocks, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs,                  \
               (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);                                               \
   } while (0)
   const int F5 = WR_FEAT_TEX | WR_FEAT_GENERIC, F7 = F5 | WR_FEAT_R8TEX, FA = F7 | WR_FEAT_BLUR | WR_FEAT_SHADE;
-  if (SA) { if (H.feat == 0) WR_KF(0); else WR_KF(WR_FEAT_TEX | WR_FEAT_GENERIC); }
+  if (SA) {
+    if (H.depth) {
+      if (H.feat == 0) WR_KF(true, 0); else if (H.feat == F5) WR_KF(true, WR_FEAT_TEX | WR_FEAT_GENERIC);
+      else WR_KF(true, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX);
+    } else {
+      if (H.feat == 0) WR_KF(false, 0); else if (H.feat == F5) WR_KF(false, WR_FEAT_TEX | WR_FEAT_GENERIC);
+      else WR_KF(false, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX);
+    }
+  }
   else if (H.fmt == WR_FMT_RGBA8) {
     if (H.depth) {
       if (H.feat == 0) WR_K(WR_FMT_RGBA8, true, 0); else if (H.feat == F5) WR_K(WR_FMT_RGBA8, true, WR_FEAT_TEX | WR_FEAT_GENERIC);
@@ -991,13 +1000,18 @@ void flush_work(const std::vector<int>& sel_in) {
       const int nd_arg = nd;
 #endif
       const int n_setup_blocks = (n_prims + 255) / 256;
-      if (c->tail.pending && can_fuse(c->tail.held[0])) {
-        // the first held-back raster launch of the previous flush + this flush's setup stage in one launch,
-        // then the rest of the previous flush's raster launches
+      int fuse_at = -1;
+      if (c->tail.pending)
+        for (size_t hi = 0; hi < c->tail.held.size() && fuse_at < 0; hi++) if (can_fuse(c->tail.held[hi])) fuse_at = (int)hi;
+      if (fuse_at >= 0) {
+        // the previous flush's held-back raster launches, in order; the first one the fused kernel has a
+        // variant for (normally the tile pass, the longest) carries this flush's setup stage along
         Context::Tail& T = c->tail;
         WrSetupArgs SA{ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims, dtargets, S.masks, S.vtab, c->dcounters, dblk};
-        launch_raster(T.held[0], T.targets, T.n_targets, T.draws, c->scratch[T.set], &SA, n_setup_blocks);
-        for (size_t hi = 1; hi < T.held.size(); hi++) launch_raster(T.held[hi], T.targets, T.n_targets, T.draws, c->scratch[T.set]);
+        for (size_t hi = 0; hi < T.held.size(); hi++) {
+          if ((int)hi == fuse_at) launch_raster(T.held[hi], T.targets, T.n_targets, T.draws, c->scratch[T.set], &SA, n_setup_blocks);
+          else launch_raster(T.held[hi], T.targets, T.n_targets, T.draws, c->scratch[T.set]);
+        }
         tail_launched();
       } else {
         WR_LAUNCH(wr_setup_kernel, n_setup_blocks, 256, c->stream, ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims,

@@ -4098,7 +4098,7 @@ struct WrSetupArgs {
 #ifdef WRHIP_HOSTSIM
 #define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R)
 #else
-#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R, (FEAT) == 0 ? 4 : 3)
+#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R, (FEAT) == 0 ? 4 : 3)   /* (depth-tested rect variant: 128 VGPRs as well) */
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_FUSED_BOUNDS(R, FEAT)
