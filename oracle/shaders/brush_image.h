@@ -1,11 +1,15 @@
 // ORACLE / TEST INFRASTRUCTURE. Hand-written stand-ins for the generated headers
 // of shader keys "brush_image TEXTURE_2D" and "brush_image ALPHA_PASS,TEXTURE_2D"
 // (the "fast" image brush: webrender_build/src/shader_features.rs:146-152,
-// renderer/shade.rs:981). Restates webrender/res/brush_image.glsl:54-314 (VS
-// without WR_FEATURE_REPETITION), 343-377 (FS), 380-428 (span) on brush_base.h.
+// renderer/shade.rs:981) and of the full image brush "brush_image
+// [ALPHA_PASS,]ANTIALIASING,REPETITION,TEXTURE_2D" (shader_features.rs:153-157,
+// shade.rs:995). Restates webrender/res/brush_image.glsl:54-314 (VS), 318-377
+// (FS), 380-428 (span) on brush_base.h. ANTIALIASING changes nothing under swgl
+// (antialias_brush() is 1.0 with SWGL_ANTIALIAS; the edge mask goes through
+// swgl_antiAlias in brush_base.h).
 // RASTER_SCREEN quads (get_image_quad_uv) are not restated: scenes use local raster space.
 
-#define WRSH_BRUSH_IMAGE(NAME, KEYSTR, ALPHA_PASS)                             \
+#define WRSH_BRUSH_IMAGE(NAME, KEYSTR, ALPHA_PASS, REPETITION)                 \
   struct NAME##_vert : wrsh::brush_vert_base<NAME##_vert> {                    \
     typedef NAME##_vert Self;                                                  \
     static constexpr int VECS_PER_SPECIFIC_BRUSH = 3;                          \
@@ -45,6 +49,54 @@
           uv0 = vec2_scalar(res0.x, res0.y) + vec2_scalar(segment_data.x, segment_data.y) * uv_size; \
           uv1 = vec2_scalar(res0.x, res0.y) + vec2_scalar(segment_data.z, segment_data.w) * uv_size; \
         }                                                                      \
+        if (REPETITION) {                                                      \
+          if ((brush_flags & BRUSH_FLAG_TEXEL_RECT) != 0) {                    \
+            vec2_scalar repeated_stretch_size = stretch_size;                  \
+            vec2_scalar horizontal_uv_size = uv1 - uv0;                        \
+            vec2_scalar vertical_uv_size = uv1 - uv0;                          \
+            if ((brush_flags & BRUSH_FLAG_SEGMENT_NINEPATCH_MIDDLE) != 0) {    \
+              repeated_stretch_size = segment_rect.p0 - prim_rect.p0;          \
+              float epsilon = 0.001f;                                          \
+              vertical_uv_size.x = uv0.x - res0.x;                             \
+              if (vertical_uv_size.x < epsilon ||                              \
+                  repeated_stretch_size.x < epsilon) {                         \
+                vertical_uv_size.x = res0.z - uv1.x;                           \
+                repeated_stretch_size.x = prim_rect.p1.x - segment_rect.p1.x;  \
+              }                                                                \
+              horizontal_uv_size.y = uv0.y - res0.y;                           \
+              if (horizontal_uv_size.y < epsilon ||                            \
+                  repeated_stretch_size.y < epsilon) {                         \
+                horizontal_uv_size.y = res0.w - uv1.y;                         \
+                repeated_stretch_size.y = prim_rect.p1.y - segment_rect.p1.y;  \
+              }                                                                \
+            }                                                                  \
+            if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_X) != 0) {            \
+              float uv_ratio = horizontal_uv_size.x / horizontal_uv_size.y;    \
+              stretch_size.x = repeated_stretch_size.y * uv_ratio;             \
+            }                                                                  \
+            if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_Y) != 0) {            \
+              float uv_ratio = vertical_uv_size.y / vertical_uv_size.x;        \
+              stretch_size.y = repeated_stretch_size.x * uv_ratio;             \
+            }                                                                  \
+          } else {                                                             \
+            if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_X) != 0) {            \
+              stretch_size.x = segment_data.z - segment_data.x;                \
+            }                                                                  \
+            if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_Y) != 0) {            \
+              stretch_size.y = segment_data.w - segment_data.y;                \
+            }                                                                  \
+          }                                                                    \
+          if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_X_ROUND) != 0) {        \
+            float segment_rect_width = segment_rect.p1.x - segment_rect.p0.x;  \
+            float nx = max(1.0f, round(segment_rect_width / stretch_size.x));  \
+            stretch_size.x = segment_rect_width / nx;                          \
+          }                                                                    \
+          if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_Y_ROUND) != 0) {        \
+            float segment_rect_height = segment_rect.p1.y - segment_rect.p0.y; \
+            float ny = max(1.0f, round(segment_rect_height / stretch_size.y)); \
+            stretch_size.y = segment_rect_height / ny;                         \
+          }                                                                    \
+        }                                                                      \
       }                                                                        \
       float perspective_interpolate =                                          \
           (brush_flags & BRUSH_FLAG_PERSPECTIVE_INTERPOLATION) != 0 ? 1.0f : 0.0f; \
@@ -67,6 +119,15 @@
       v_uv = mix(uv0, uv1, f) - min_uv;                                        \
       v_uv *= repeat;                                                          \
       vec2_scalar normalized_offset = vec2_scalar(0.0f);                       \
+      if (REPETITION) {                                                        \
+        if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_X_CENTERED) != 0) {       \
+          normalized_offset.x = 1.0f - fract(repeat.x * 0.5f + 0.5f);          \
+        }                                                                      \
+        if ((brush_flags & BRUSH_FLAG_SEGMENT_REPEAT_Y_CENTERED) != 0) {       \
+          normalized_offset.y = 1.0f - fract(repeat.y * 0.5f + 0.5f);          \
+        }                                                                      \
+        v_uv += normalized_offset * (max_uv - min_uv);                         \
+      }                                                                        \
       v_uv /= texture_size;                                                    \
       if (perspective_interpolate == 0.0f) {                                   \
         v_uv *= vi.world_pos.w;                                                \
@@ -74,6 +135,10 @@
       v_uv_bounds = vec4_scalar(min_uv.x, min_uv.y, max_uv.x, max_uv.y) /      \
                     vec4_scalar(texture_size.x, texture_size.y, texture_size.x, \
                                 texture_size.y);                               \
+      if (REPETITION) {                                                        \
+        v_uv /= vec2_scalar(v_uv_bounds.z - v_uv_bounds.x,                     \
+                            v_uv_bounds.w - v_uv_bounds.y);                    \
+      }                                                                        \
       if (ALPHA_PASS) {                                                        \
         v_tile_repeat_bounds = repeat + normalized_offset;                     \
         float opacity = float(prim_user_data.z) / 65535.0f;                    \
@@ -141,8 +206,25 @@
       float chunks = steps * 0.25f;                                            \
       v_uv += interp_step.v_uv * chunks;                                       \
     }                                                                          \
-    /* compute_repeated_uvs without REPETITION: :339 */                        \
+    /* compute_repeated_uvs: :318-341 */                                       \
     vec2 repeated_uvs(float perspective_divisor) const {                       \
+      if (REPETITION) {                                                        \
+        vec2_scalar uv_size = vec2_scalar(v_uv_bounds.z - v_uv_bounds.x,       \
+                                          v_uv_bounds.w - v_uv_bounds.y);      \
+        if (ALPHA_PASS) {                                                      \
+          vec2 local_uv = v_uv * perspective_divisor;                          \
+          local_uv = max(local_uv, vec2(Float(0.0f)));                              \
+          vec2 repeated_uv = fract(local_uv) * uv_size +                       \
+                             vec2_scalar(v_uv_bounds.x, v_uv_bounds.y);        \
+          repeated_uv.x = if_then_else(local_uv.x >= v_tile_repeat_bounds.x,   \
+                                       Float(v_uv_bounds.z), repeated_uv.x);   \
+          repeated_uv.y = if_then_else(local_uv.y >= v_tile_repeat_bounds.y,   \
+                                       Float(v_uv_bounds.w), repeated_uv.y);   \
+          return repeated_uv;                                                  \
+        }                                                                      \
+        return fract(v_uv * perspective_divisor) * uv_size +                   \
+               vec2_scalar(v_uv_bounds.x, v_uv_bounds.y);                      \
+      }                                                                        \
       return v_uv * perspective_divisor +                                      \
              vec2_scalar(v_uv_bounds.x, v_uv_bounds.y);                        \
     }                                                                          \
@@ -178,15 +260,33 @@
         }                                                                      \
       }                                                                        \
       float perspective_divisor = mix(1.0f, 1.0f, v_perspective.x);            \
-      vec2 uv = repeated_uvs(perspective_divisor);                             \
+      vec2 uv = REPETITION ? v_uv * perspective_divisor                        \
+                           : repeated_uvs(perspective_divisor);                \
       if (ALPHA_PASS) {                                                        \
         if (v_color != vec4_scalar(1.0f)) {                                    \
-          swgl_commitTextureColorRGBA8(sColor0, uv, v_uv_sample_bounds,        \
-                                       v_color);                               \
+          if (REPETITION) {                                                    \
+            swgl_commitTextureRepeatColorRGBA8(sColor0, uv,                    \
+                                               v_tile_repeat_bounds,           \
+                                               v_uv_bounds,                    \
+                                               v_uv_sample_bounds, v_color);   \
+          } else {                                                             \
+            swgl_commitTextureColorRGBA8(sColor0, uv, v_uv_sample_bounds,      \
+                                         v_color);                             \
+          }                                                                    \
           return;                                                              \
         }                                                                      \
       }                                                                        \
-      swgl_commitTextureRGBA8(sColor0, uv, v_uv_sample_bounds);                \
+      if (REPETITION) {                                                        \
+        if (ALPHA_PASS) {                                                      \
+          swgl_commitTextureRepeatRGBA8(sColor0, uv, v_tile_repeat_bounds,     \
+                                        v_uv_bounds, v_uv_sample_bounds);      \
+        } else {                                                               \
+          swgl_commitTextureRepeatRGBA8(sColor0, uv, vec2_scalar(0.0f),        \
+                                        v_uv_bounds, v_uv_sample_bounds);      \
+        }                                                                      \
+      } else {                                                                 \
+        swgl_commitTextureRGBA8(sColor0, uv, v_uv_sample_bounds);              \
+      }                                                                        \
     }                                                                          \
     WRSH_FRAG_ABI(Self)                                                        \
     static int draw_span_RGBA8(FragmentShaderImpl* impl) {                     \
@@ -200,5 +300,9 @@
   };                                                                           \
   WRSH_PROGRAM(NAME, KEYSTR)
 
-WRSH_BRUSH_IMAGE(brush_image_TEXTURE_2D, "brush_image TEXTURE_2D", false)
-WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_TEXTURE_2D, "brush_image ALPHA_PASS,TEXTURE_2D", true)
+WRSH_BRUSH_IMAGE(brush_image_TEXTURE_2D, "brush_image TEXTURE_2D", false, false)
+WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_TEXTURE_2D, "brush_image ALPHA_PASS,TEXTURE_2D", true, false)
+WRSH_BRUSH_IMAGE(brush_image_ANTIALIASING_REPETITION_TEXTURE_2D,
+                 "brush_image ANTIALIASING,REPETITION,TEXTURE_2D", false, true)
+WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_ANTIALIASING_REPETITION_TEXTURE_2D,
+                 "brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", true, true)

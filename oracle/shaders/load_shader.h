@@ -38,6 +38,9 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_clip_box_shadow TEXTURE_2D", cs_clip_box_shadow)
   WRSH_ENTRY("brush_image TEXTURE_2D", brush_image_TEXTURE_2D)
   WRSH_ENTRY("brush_image ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
+  WRSH_ENTRY("brush_image ANTIALIASING,REPETITION,TEXTURE_2D", brush_image_ANTIALIASING_REPETITION_TEXTURE_2D)
+  WRSH_ENTRY("brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D",
+             brush_image_ALPHA_PASS_ANTIALIASING_REPETITION_TEXTURE_2D)
   WRSH_ENTRY("brush_linear_gradient", brush_linear_gradient)
   WRSH_ENTRY("brush_linear_gradient ALPHA_PASS", brush_linear_gradient_ALPHA_PASS)
   WRSH_ENTRY("brush_blend", brush_blend)

@@ -51,6 +51,11 @@ CASES = [
     ("image_grid_masked", lambda: scenes.image_grid(masked=True)),
     ("filter_grid_masked", lambda: scenes.filter_grid(masked=True, seed=75)),
     ("rotated_rects", lambda: scenes.rotated_rects()),
+    ("image_repeat", lambda: scenes.image_repeat()),
+    ("image_repeat_nearest", lambda: scenes.image_repeat(nearest=True)),
+    ("image_repeat_wide", lambda: scenes.image_repeat(width=2048, height=1024, n=200, seed=58)),
+    ("image_repeat_nearest_wide", lambda: scenes.image_repeat(width=2048, height=1024, n=200, seed=59, nearest=True)),
+    ("image_repeat_opaque_int", lambda: scenes.image_repeat(width=1000, height=700, n=120, seed=60, translucent=False)),
     ("rotated_rects_quad", lambda: scenes.rotated_rects(encoding="quad")),
     ("rotated_rects_wide", lambda: scenes.rotated_rects(width=2048, height=1024, n=140, seed=97)),
     ("quad_masks", lambda: scenes.quad_masks()),

@@ -133,6 +133,8 @@ const ShaderInfo SHADERS[] = {
     {"brush_solid ALPHA_PASS", WR_SH_BRUSH_SOLID_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image TEXTURE_2D", WR_SH_BRUSH_IMAGE, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_image ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_linear_gradient", WR_SH_BRUSH_LINEAR_GRADIENT, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
     {"brush_linear_gradient ALPHA_PASS", WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
     {"ps_quad_mask", WR_SH_PS_QUAD_MASK, {"aPosition", "aData", "aClipData"},
@@ -1070,6 +1072,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_IMAGE_REPEAT: case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }
       }

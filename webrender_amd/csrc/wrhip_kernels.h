@@ -481,8 +481,11 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 // fast variant: no REPETITION / ANTIALIASING feature)
 // image: 0 brush_solid, 1 brush_image, 2 brush_image ALPHA_PASS, 3 brush_linear_gradient (G = its side record),
 //        4 brush_blend (F = its side record)
+// image: 0 brush_solid, 1 / 2 brush_image (opaque / ALPHA_PASS), 3 linear gradient, 4 brush_blend,
+//        5 / 6 brush_image with REPETITION (opaque / ALPHA_PASS; Rp = its side record)
 WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr,
-                            WrFilterRec* F = nullptr) {
+                            WrFilterRec* F = nullptr, WrRepeatRec* Rp = nullptr) {
+  const bool repetition = image == 5 || image == 6;
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
@@ -685,26 +688,72 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
       uv0x = res0.x + seg_data.x * usx; uv0y = res0.y + seg_data.y * usy;
       uv1x = res0.x + seg_data.z * usx; uv1y = res0.y + seg_data.w * usy;
     }
+    if (repetition) {                        // WR_FEATURE_REPETITION, brush_image.glsl:100-167
+      if (brush_flags & 512) {
+        float rsx = stx, rsy = sty;                                   // repeated_stretch_size
+        float hux = uv1x - uv0x, huy = uv1y - uv0y;                   // horizontal_uv_size
+        float vux = uv1x - uv0x, vuy = uv1y - uv0y;                   // vertical_uv_size
+        if (brush_flags & 256) {             // SEGMENT_NINEPATCH_MIDDLE
+          rsx = seg.x - local_rect.x; rsy = seg.y - local_rect.y;
+          const float epsilon = 0.001f;
+          vux = uv0x - res0.x;
+          if (vux < epsilon || rsx < epsilon) { vux = res0.z - uv1x; rsx = local_rect.z - seg.z; }
+          huy = uv0y - res0.y;
+          if (huy < epsilon || rsy < epsilon) { huy = res0.w - uv1y; rsy = local_rect.w - seg.w; }
+        }
+        if (brush_flags & 4) { const float uv_ratio = hux / huy; stx = rsy * uv_ratio; }
+        if (brush_flags & 8) { const float uv_ratio = vuy / vux; sty = rsx * uv_ratio; }
+      } else {
+        if (brush_flags & 4) stx = seg_data.z - seg_data.x;
+        if (brush_flags & 8) sty = seg_data.w - seg_data.y;
+      }
+      if (brush_flags & 16) {                // SEGMENT_REPEAT_X_ROUND
+        const float sw = seg.z - seg.x;
+        const float nx = wr_max(1.0f, roundf(sw / stx));
+        stx = sw / nx;
+      }
+      if (brush_flags & 32) {
+        const float sh = seg.w - seg.y;
+        const float ny = wr_max(1.0f, roundf(sh / sty));
+        sty = sh / ny;
+      }
+    }
   }
   const bool persp = (brush_flags & 1) != 0;
   if (brush_flags & 2048) { uv0x *= tsx; uv0y *= tsy; uv1x *= tsx; uv1y *= tsy; }   // NORMALIZED_UVS
   const float mnx = wr_min(uv0x, uv1x), mny = wr_min(uv0y, uv1y), mxx = wr_max(uv0x, uv1x), mxy = wr_max(uv0y, uv1y);
   o.uv_bounds = wf4{(mnx + 0.5f) / tsx, (mny + 0.5f) / tsy, (mxx - 0.5f) / tsx, (mxy - 0.5f) / tsy};   // v_uv_sample_bounds
   const float rpx = (lr.z - lr.x) / stx, rpy = (lr.w - lr.y) / sty;
+  float nox = 0.0f, noy = 0.0f;                            // normalized_offset
+  if (repetition) {
+    if (brush_flags & 64) { const float t = rpx * 0.5f + 0.5f; nox = 1.0f - (t - floorf(t)); }     // SEGMENT_REPEAT_X_CENTERED
+    if (brush_flags & 128) { const float t = rpy * 0.5f + 0.5f; noy = 1.0f - (t - floorf(t)); }
+  }
+  const float ubx = mnx / tsx, uby = mny / tsy, ubz = mxx / tsx, ubw = mxy / tsy;                   // v_uv_bounds
   for (int n = 0; n < 4; n++) {
     const float fx = (vlx[n] - lr.x) / (lr.z - lr.x), fy = (vly[n] - lr.y) / (lr.w - lr.y);
     float uu = ((uv1x - uv0x) * fx + uv0x) - mnx, vv = ((uv1y - uv0y) * fy + uv0y) - mny;
     uu *= rpx; vv *= rpy;
+    if (repetition) { uu += nox * (mxx - mnx); vv += noy * (mxy - mny); }
     uu /= tsx; vv /= tsy;
     if (!persp) { uu *= vww[n]; vv *= vww[n]; }
+    if (repetition) { uu /= (ubz - ubx); vv /= (ubw - uby); }
     o.u[n] = uu; o.v[n] = vv;
   }
-  o.uv_add[0] = mnx / tsx; o.uv_add[1] = mny / tsy;       // compute_repeated_uvs: v_uv * 1 + v_uv_bounds.xy
+  o.uv_add[0] = ubx; o.uv_add[1] = uby;                   // compute_repeated_uvs: v_uv * 1 + v_uv_bounds.xy
   o.tex_slot = WR_S_COLOR0;
   o.tail_clamp = 1;
   o.kind = tex.format == WR_FMT_RGBA8 ? WR_PK_TEX_RGBA8 : WR_PK_TEX_FS;      // swgl_isTextureRGBA8, :381
+  if (repetition) {
+    o.kind = WR_PK_TEX_REPEAT;
+    o.uv_add[0] = o.uv_add[1] = 0.0f; o.tail_clamp = 0;
+    Rp->uv_repeat[0] = ubx; Rp->uv_repeat[1] = uby; Rp->uv_repeat[2] = ubz; Rp->uv_repeat[3] = ubw;
+    Rp->tile_repeat[0] = image == 6 ? rpx + nox : 0.0f; Rp->tile_repeat[1] = image == 6 ? rpy + noy : 0.0f;
+    Rp->alpha_pass = image == 6; Rp->no_span = tex.format != WR_FMT_RGBA8;
+    if (tex.format != WR_FMT_RGBA8 && tex.format != WR_FMT_R8) { o.kind = WR_PK_UNSUPPORTED; return; }
+  }
   if (data1.y != 0 || persp) { o.kind = WR_PK_UNSUPPORTED; return; }          // RASTER_SCREEN quads / perspective: next
-  if (image == 1) {
+  if (image == 1 || image == 5) {
     o.has_color = 0; o.tail_modulate = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
     return;
   }
@@ -1342,7 +1391,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1720,7 +1769,7 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
   r.span = r.len >= 4 ? (r.len & ~3) : 0;
   r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
   if (P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK) r.span = 0;     // no draw_span for this program/target: all main()
-  if (r.span == 0) return r;
+  if (r.span == 0 || P.kind == WR_PK_TEX_REPEAT) return r;
   float W = float(t.width), H = float(t.height);
   // lanes 0 and 1 of the uv vector handed to swgl_commitTexture* (shader-side offset included)
   const float p0u = r.ou + P.uv_add[0], p0v = r.ov + P.uv_add[1];
@@ -1784,6 +1833,43 @@ WR_DEVICE void wr_tex_tail_uv(const WrPrim& P, const WrTexRow& r, int n, float& 
   }
 }
 
+// A fragment-shader (main()) pixel of a textured prim: texture(sColor0, (cu, cv)) -> optional colour
+// modulation -> round_pixel.
+WR_DEVICE WrWide wr_tex_tail_texel(const WrPrim& P, const WrTexDesc& t, float cu, float cv) {
+  const float W = float(t.width), H = float(t.height);
+  const uint32_t* buf = (const uint32_t*)t.ptr;
+  float tb, tg, tr, ta;
+  if (P.kind == WR_PK_TEX_R8) {
+    // textureLinearR8 (texture.h:576-583) -> vec4(r,0,0,1); ps_text_run.glsl:278-283
+    // swizzles it to rrrr for COLOR_MODE_ALPHA.
+    int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
+    float m = float(wr_sample_linear_r8(t, qx, qy)) * (1.0f / 255.0f);
+    tb = tg = tr = ta = m;
+  } else if (t.format == WR_FMT_R8) {
+    // texture() of an R8 sampler: vec4(r, 0, 0, 1)
+    float m;
+    if (t.linear) m = float(wr_sample_linear_r8(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
+    else m = float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride]) * (1.0f / 255.0f);
+    tr = m; tg = 0.0f; tb = 0.0f; ta = 1.0f;
+  } else if (t.linear) {
+    int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
+    WrWide s = wr_sample_linear_rgba8(t, qx, qy);
+    tb = float(s.bg & 0xFFFF) * (1.0f / 255.0f); tg = float(s.bg >> 16) * (1.0f / 255.0f);
+    tr = float(s.ra & 0xFFFF) * (1.0f / 255.0f); ta = float(s.ra >> 16) * (1.0f / 255.0f);
+  } else {
+    int tx = wr_clamp_coord(int(cu * W), t.width), ty = wr_clamp_coord(int(cv * H), t.height);
+    uint32_t p = buf[(size_t)tx + (size_t)ty * t.stride];
+    tb = float(p & 0xFF) * (1.0f / 255.0f); tg = float((p >> 8) & 0xFF) * (1.0f / 255.0f);
+    tr = float((p >> 16) & 0xFF) * (1.0f / 255.0f); ta = float(p >> 24) * (1.0f / 255.0f);
+  }
+  if (P.flags & WR_PF_TAIL_MODULATE) { tr = P.fcolor[0] * tr; tg = P.fcolor[1] * tg; tb = P.fcolor[2] * tb; ta = P.fcolor[3] * ta; }
+  WrWide s;
+  uint32_t pc[2];
+  wr_pack_color(wf4{tr, tg, tb, ta}, pc);
+  s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
 // One pixel of a WR_PK_TEX_RGBA8 prim on row y (returns the WideRGBA8 source,
 // colour modulation included).
 WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y) {
@@ -1829,35 +1915,160 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
   // Tail pixels: fragment shader main() -> texture(sColor0, uv) -> round_pixel
   float cu, cv;
   wr_tex_tail_uv(P, r, n, cu, cv);
-  float tb, tg, tr, ta;
-  if (P.kind == WR_PK_TEX_R8) {
-    // textureLinearR8 (texture.h:576-583) -> vec4(r,0,0,1); ps_text_run.glsl:278-283
-    // swizzles it to rrrr for COLOR_MODE_ALPHA.
-    int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
-    float m = float(wr_sample_linear_r8(t, qx, qy)) * (1.0f / 255.0f);
-    tb = tg = tr = ta = m;
-  } else if (t.format == WR_FMT_R8) {
-    // texture() of an R8 sampler: vec4(r, 0, 0, 1)
-    float m;
-    if (t.linear) m = float(wr_sample_linear_r8(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
-    else m = float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride]) * (1.0f / 255.0f);
-    tr = m; tg = 0.0f; tb = 0.0f; ta = 1.0f;
-  } else if (t.linear) {
-    int qx = int(cu * W * 128.0f + (0.5f - 64.0f)), qy = int(cv * H * 128.0f + (0.5f - 64.0f));
-    WrWide s = wr_sample_linear_rgba8(t, qx, qy);
-    tb = float(s.bg & 0xFFFF) * (1.0f / 255.0f); tg = float(s.bg >> 16) * (1.0f / 255.0f);
-    tr = float(s.ra & 0xFFFF) * (1.0f / 255.0f); ta = float(s.ra >> 16) * (1.0f / 255.0f);
-  } else {
-    int tx = wr_clamp_coord(int(cu * W), t.width), ty = wr_clamp_coord(int(cv * H), t.height);
-    uint32_t p = buf[(size_t)tx + (size_t)ty * t.stride];
-    tb = float(p & 0xFF) * (1.0f / 255.0f); tg = float((p >> 8) & 0xFF) * (1.0f / 255.0f);
-    tr = float((p >> 16) & 0xFF) * (1.0f / 255.0f); ta = float(p >> 24) * (1.0f / 255.0f);
+  return wr_tex_tail_texel(P, t, cu, cv);
+}
+
+// ---------------------------------------------------------------------------
+// brush_image with WR_FEATURE_REPETITION: swgl_commitTextureRepeat[Color]RGBA8 (swgl_ext.h:664-872).
+// The span walk is sequential -- runs of chunks that stay inside one tile go through the ordinary
+// linear dispatcher / a nearest run, the chunk that straddles a tile edge is sampled with explicit
+// repeat math, and the unquantised uv is advanced by float additions in between -- so the owner of
+// pixel n replays the walk of its row up to the chunk holding n.
+WR_DEVICE int wr_needs_linear(const WrTexDesc& t, float p0u, float p0v, float p1u, float p1v, int span) {   // swgl_ext.h:553-587
+  if (t.width < 2) return 0;
+  if (p0v != p1v) return 1;
+  const float px0 = p0u * float(t.width), px1 = p1u * float(t.width), py0 = p0v * float(t.height);
+  const int sp = (span & ~127) + 128;
+  const int scaled = int(roundf((px1 - px0) * float(sp)));
+  if (scaled != sp) return (px0 < px1 && px1 - px0 <= 1.0f) ? 2 : (scaled == sp * 2 ? 4 : 1);
+  if ((int(px0 * 4.0f + 0.5f) & 3) != 2 || (int(py0 * 4.0f + 0.5f) & 3) != 2) return 3;
+  return 0;
+}
+WR_DEVICE int wr_no_repeat_steps(const float (&uv)[4], float uv_step, float tile_repeat, int steps) {   // swgl_ext.h:679-700
+  float lo = uv[0], hi = uv[3];
+  if (hi < lo) { lo = uv[3]; hi = uv[0]; }
+  float limit = floorf(lo) + 1.0f;
+  if (tile_repeat > 0.0f) limit = wr_min(limit, tile_repeat);
+  if (!(lo >= 0.0f && hi < limit)) return 0;
+  return uv_step != 0.0f ? int(wr_clamp((limit - lo) / uv_step, 0.0f, float(steps))) : steps;
+}
+WR_DEVICE void wr_tile_repeat_uv(float u, float v, const float (&tile_repeat)[2], float& fu, float& fv) {   // tileRepeatUV, :664-673
+  if (tile_repeat[0] > 0.0f) {
+    u = wr_clamp(u, 0.0f, tile_repeat[0] - 1.0e-6f); v = wr_clamp(v, 0.0f, tile_repeat[1] - 1.0e-6f);
   }
-  if (P.flags & WR_PF_TAIL_MODULATE) { tr = P.fcolor[0] * tr; tg = P.fcolor[1] * tg; tb = P.fcolor[2] * tb; ta = P.fcolor[3] * ta; }
+  fu = u - floorf(u); fv = v - floorf(v);
+}
+__device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatRec* Rp, const WrDrawDesc* D, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrRepeatRec& R = *Rp;
+  const WrTexDesc& t = D->tex[P.tex_slot];
+  const WrTexRow r = wr_tex_row(P, t, y);
+  const int n = x - P.x0;
+  const int span = R.no_span ? 0 : r.span;
+  const float W = float(t.width), H = float(t.height);
+  if (n >= span) {
+    // main(): compute_repeated_uvs (brush_image.glsl:318-341), clamp to v_uv_sample_bounds, texture()
+    float lu = r.ou, lv = r.ov;
+    const int lane = (n - span) & 3, m = (n - span) >> 2;
+    for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
+    if (span > 0) {
+      const float chunks = float(span) * 0.25f;
+      lu = lu + (r.su * 4.0f) * chunks; lv = lv + (r.sv * 4.0f) * chunks;
+    }
+    lu = wr_accum(lu, (r.su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (r.sv * 4.0f) * 1.0f, m);
+    const float usx = R.uv_repeat[2] - R.uv_repeat[0], usy = R.uv_repeat[3] - R.uv_repeat[1];
+    float ru, rv;
+    if (R.alpha_pass) {
+      const float cu = wr_max(lu, 0.0f), cv = wr_max(lv, 0.0f);
+      ru = (cu - floorf(cu)) * usx + R.uv_repeat[0]; rv = (cv - floorf(cv)) * usy + R.uv_repeat[1];
+      if (cu >= R.tile_repeat[0]) ru = R.uv_repeat[2];
+      if (cv >= R.tile_repeat[1]) rv = R.uv_repeat[3];
+    } else {
+      ru = (lu - floorf(lu)) * usx + R.uv_repeat[0]; rv = (lv - floorf(lv)) * usy + R.uv_repeat[1];
+    }
+    ru = wr_clamp(ru, P.uv_bounds[0], P.uv_bounds[2]); rv = wr_clamp(rv, P.uv_bounds[1], P.uv_bounds[3]);
+    return wr_tex_tail_texel(P, t, ru, rv);
+  }
+  const int k = n & 3, c = n >> 2, total = span >> 2;
+  float ux[4], uy[4];
+  {
+    float lu = r.ou, lv = r.ov;
+    for (int i = 0; i < 4; i++) { ux[i] = lu; uy[i] = lv; lu += r.su; lv += r.sv; }
+  }
+  const float step_x = 4.0f * (ux[1] - ux[0]), step_y = 4.0f * (uy[1] - uy[0]);
+  const uint32_t* buf = (const uint32_t*)t.ptr;
   WrWide s;
-  uint32_t pc[2];
-  wr_pack_color(wf4{tr, tg, tb, ta}, pc);
-  s.bg = pc[0]; s.ra = pc[1];
+  if (t.linear) {
+    // blendTextureLinearRepeat (swgl_ext.h:702-753)
+    const float sc_x = R.uv_repeat[2] - R.uv_repeat[0], sc_y = R.uv_repeat[3] - R.uv_repeat[1];
+    int filter = wr_needs_linear(t, ux[0] * sc_x + R.uv_repeat[0], uy[0] * sc_y + R.uv_repeat[1], ux[1] * sc_x + R.uv_repeat[0],
+                                 uy[1] * sc_y + R.uv_repeat[1], span);
+    if (filter == 0) filter = 3;          // the dispatcher treats LINEAR_FILTER_NEAREST like FAST (swgl_ext.h:423-432)
+    const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+    const float qsx = sc_x * W * qs, qsy = sc_y * H * qs;
+    const float qox = R.uv_repeat[0] * W * qs + qo, qoy = R.uv_repeat[1] * H * qs + qo;
+    const float minx = wr_max(P.uv_bounds[0] * W * qs + qo, 0.0f), miny = wr_max(P.uv_bounds[1] * H * qs + qo, 0.0f);
+    const float maxx = wr_max(P.uv_bounds[2] * W * qs + qo, minx), maxy = wr_max(P.uv_bounds[3] * H * qs + qo, miny);
+    int v[4] = {0, 0, 0, 0};
+    int pos = 0;
+    while (pos < total) {
+      int steps = total - pos;
+      steps = wr_no_repeat_steps(ux, step_x, R.tile_repeat[0], steps);
+      if (steps > 0) steps = wr_no_repeat_steps(uy, step_y, R.tile_repeat[1], steps);
+      if (steps > 0) {
+        if (c < pos + steps) {
+          float q[4], qy[4];
+          for (int i = 0; i < 4; i++) { q[i] = (ux[i] - floorf(ux[i])) * qsx + qox; qy[i] = (uy[i] - floorf(uy[i])) * qsy + qoy; }
+          wr_linear_span_pixel<4>(t, q, qy, step_x * qsx, step_y * qsy, minx, maxx, miny, maxy, filter, steps * 4, n - pos * 4, v);
+          break;
+        }
+        pos += steps;
+        if (pos >= total) break;
+        const float ax = float(steps) * step_x, ay = float(steps) * step_y;
+        for (int i = 0; i < 4; i++) { ux[i] += ax; uy[i] += ay; }
+      }
+      if (c == pos) {
+        float fu, fv;
+        wr_tile_repeat_uv(ux[k], uy[k], R.tile_repeat, fu, fv);
+        wr_bilinear<4>(t, int(wr_clamp(fu * qsx + qox, minx, maxx)), int(wr_clamp(fv * qsy + qoy, miny, maxy)), v);
+        break;
+      }
+      pos += 1;
+      for (int i = 0; i < 4; i++) { ux[i] += step_x; uy[i] += step_y; }
+    }
+    s.bg = (uint32_t(v[0]) & 0xFFFF) | ((uint32_t(v[1]) & 0xFFFF) << 16);
+    s.ra = (uint32_t(v[2]) & 0xFFFF) | ((uint32_t(v[3]) & 0xFFFF) << 16);
+  } else {
+    // blendTextureNearestRepeat<BLEND, true> (swgl_ext.h:774-858); its uv_rect argument is v_uv_bounds
+    const float minx = R.uv_repeat[0] * W, miny = R.uv_repeat[1] * H, maxx = R.uv_repeat[2] * W, maxy = R.uv_repeat[3] * H;
+    const float sc_x = maxx - minx, sc_y = maxy - miny;
+    float su = 0.0f, sv = 0.0f;
+    const bool solid = (int(minx) + 1 >= int(maxx) || fabsf(step_x) * float(span) * sc_x < 0.5f) &&
+                       (int(miny) + 1 >= int(maxy) || fabsf(step_y) * float(span) * sc_y < 0.5f);
+    if (solid) {
+      float fu, fv;
+      wr_tile_repeat_uv(ux[k], uy[k], R.tile_repeat, fu, fv);
+      su = fu * sc_x + minx; sv = fv * sc_y + miny;
+    } else {
+      int pos = 0;
+      while (pos < total) {
+        int steps = total - pos;
+        steps = wr_no_repeat_steps(ux, step_x, R.tile_repeat[0], steps);
+        if (steps > 0) steps = wr_no_repeat_steps(uy, step_y, R.tile_repeat[1], steps);
+        if (steps > 0) {
+          if (c < pos + steps) {
+            const float iu = (ux[k] - floorf(ux[k])) * sc_x + minx, iv = (uy[k] - floorf(uy[k])) * sc_y + miny;
+            su = wr_accum(iu, step_x * sc_x, c - pos); sv = wr_accum(iv, step_y * sc_y, c - pos);
+            break;
+          }
+          pos += steps;
+          if (pos >= total) break;
+          const float ax = float(steps) * step_x, ay = float(steps) * step_y;
+          for (int i = 0; i < 4; i++) { ux[i] += ax; uy[i] += ay; }
+        }
+        if (c == pos) {
+          float fu, fv;
+          wr_tile_repeat_uv(ux[k], uy[k], R.tile_repeat, fu, fv);
+          su = fu * sc_x + minx; sv = fv * sc_y + miny;
+          break;
+        }
+        pos += 1;
+        for (int i = 0; i < 4; i++) { ux[i] += step_x; uy[i] += step_y; }
+      }
+    }
+    s = wr_unpack(buf[(size_t)wr_clamp_coord(int(su), t.width) + (size_t)wr_clamp_coord(int(sv), t.height) * t.stride]);
+  }
+  if (P.flags & WR_PF_HAS_COLOR) s = wr_apply_color(s, P.color);
   return s;
 }
 
@@ -1994,6 +2205,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush(d, arena, inst, 0, o); break;
     case WR_SH_BRUSH_IMAGE: wr_vs_brush(d, arena, inst, 1, o); break;
     case WR_SH_BRUSH_IMAGE_ALPHA: wr_vs_brush(d, arena, inst, 2, o); break;
+    case WR_SH_BRUSH_IMAGE_REPEAT: wr_vs_brush(d, arena, inst, 5, o, nullptr, nullptr, &aux[gid].rep); break;
+    case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: wr_vs_brush(d, arena, inst, 6, o, nullptr, nullptr, &aux[gid].rep); break;
     case WR_SH_BRUSH_LINEAR_GRADIENT:
     case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: wr_vs_brush(d, arena, inst, 3, o, &aux[gid].grad); break;
     case WR_SH_BRUSH_BLEND:
@@ -3668,7 +3881,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_FILTER) {
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_FILTER || kind == WR_PK_TEX_REPEAT)) {
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -3679,7 +3892,9 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (dwrite) dep[q] = in ? z : dep[q];
       }
       if (!in) continue;
-      const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2)));
+      const WrWide raw = kind == WR_PK_FILTER ? wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2))
+                                              : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2));
+      const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), raw);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }

@@ -52,6 +52,8 @@ enum WrShader {
   WR_SH_CS_CLIP_BOX_SHADOW,
   WR_SH_BRUSH_IMAGE,
   WR_SH_BRUSH_IMAGE_ALPHA,
+  WR_SH_BRUSH_IMAGE_REPEAT,        // brush_image ANTIALIASING,REPETITION,TEXTURE_2D
+  WR_SH_BRUSH_IMAGE_REPEAT_ALPHA,  // brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D
   WR_SH_BRUSH_LINEAR_GRADIENT,
   WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA,
   WR_SH_BRUSH_BLEND,
@@ -176,6 +178,7 @@ enum WrPrimKind {
   WR_PK_GRADIENT,       // swgl_commitLinearGradientRGBA8 (WrGradRec); v_pos travels in WrPrim's uv interpolants
   WR_PK_FILTER,         // brush_blend: fragment shader only (texture() + CalculateFilter, WrFilterRec); uv as WR_PK_TEX_FS
   WR_PK_SOLID_QUAD,     // solid colour on a general (rotated / skewed) convex quad: per-row spans from WrQuadRec, optional AA
+  WR_PK_TEX_REPEAT,     // swgl_commitTextureRepeat[Color]RGBA8 (brush_image REPETITION): per-row replay of the repeat walk (WrRepeatRec)
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
 };
 
@@ -339,8 +342,17 @@ struct WrQuadRec {
   WrQuadSeg seg[4];
 };
 
+// brush_image with WR_FEATURE_REPETITION (brush_image.glsl:318-341, 380-428; swgl_ext.h:664-872)
+struct WrRepeatRec {
+  float tile_repeat[2];             // v_tile_repeat_bounds (0,0 in the opaque pass)
+  float uv_repeat[4];               // v_uv_bounds
+  int32_t alpha_pass;               // compute_repeated_uvs' ALPHA_PASS branch in main()
+  int32_t no_span;                  // the span shader bails out (texture not RGBA8): every pixel runs main()
+};
+
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
+  WrRepeatRec rep;
   WrTexRec tex;
   WrBlurRec blur;
   WrClipRec clip;

@@ -448,6 +448,136 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
 
 
 # ---------------------------------------------------------------------------
+# Repeated images: the full image brush ("brush_image [ALPHA_PASS,]ANTIALIASING,REPETITION,TEXTURE_2D",
+# renderer/shade.rs:995) -- background tiling through ImageBrushData.stretch_size smaller (or larger)
+# than the primitive, and border-image style segments (BRUSH_FLAG_SEGMENT_RELATIVE with the REPEAT_X/Y,
+# *_ROUND and *_CENTERED flags, with and without a texel rect).  `nearest` switches the atlas sampler to
+# GL_NEAREST (blendTextureNearestRepeat instead of blendTextureLinearRepeat).
+def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=False, tile_filter=None, only=None, translucent=True):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    pix = np.zeros((atlas, atlas, 4), np.uint8)
+    srcs = []
+    x = y = shelf = 0
+    for i in range(20):
+        w, h = int(rng.integers(6, 70)), int(rng.integers(6, 60))
+        if i == 3:
+            w = 1                                      # one-texel-wide source: the solid-span shortcut
+        if i == 7:
+            w, h = 1, 1
+        if x + w > atlas:
+            x, y, shelf = 0, y + shelf, 0
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 1] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+        if i % 2 == 0:
+            img[..., 3] = 255
+        img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)
+        pix[y:y + h, x:x + w] = img
+        addr = frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]])
+        srcs.append((w, h, addr, i % 2 == 0))
+        x += w + 2
+        shelf = max(shelf, h + 2)
+    t_atlas = TextureRef("image_atlas", atlas, atlas, G.GL_RGBA8, G.GL_NEAREST if nearest else G.GL_LINEAR, pixels=pix,
+                         upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+    prims = []
+    band = 200
+    gx = 4.0
+    opaque_srcs = [s_ for s_ in srcs if s_[3]]
+    # opaque pass: non-overlapping (depth-run restarts, see image_grid)
+    for k in range(8):
+        sw, sh, addr, _ = opaque_srcs[k % len(opaque_srcs)]
+        w, h = float(rng.integers(60, 180)), float(rng.integers(60, band - 10))
+        if gx + w + 4 > width:
+            break
+        st = (float(sw), float(sh)) if k % 2 == 0 else (sw * float(rng.uniform(0.6, 2.2)), sh * float(rng.uniform(0.6, 2.2)))
+        off = 0.0 if k % 3 else 0.41
+        prims.append(dict(rect=(gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), addr=addr, opaque=True, opacity=1.0, stretch=st,
+                          segs=None))
+        gx += float(np.ceil(w)) + 7.0
+    for k in range(n):
+        sw, sh, addr, _ = srcs[int(rng.integers(0, len(srcs)))]
+        mode = k % 6
+        w, h = float(rng.integers(40, 400)), float(rng.integers(30, 300))
+        px, py = float(rng.integers(-30, width - 40)), float(rng.integers(band, height - 30))
+        if mode in (1, 3):
+            px += float(rng.uniform(0, 1)); py += float(rng.uniform(0, 1)); w += float(rng.uniform(0, 1))
+        segs = None
+        if mode == 0:        # 1:1 tiles
+            st = (float(sw), float(sh))
+        elif mode == 1:      # scaled tiles
+            st = (sw * float(rng.uniform(0.4, 3.0)), sh * float(rng.uniform(0.4, 3.0)))
+        elif mode == 2:      # tile larger than the primitive (repeat < 1)
+            st = (w * float(rng.uniform(1.1, 2.0)), h * float(rng.uniform(1.1, 2.0)))
+        elif mode == 3:      # no repetition through the repeat shader
+            st = (-1.0, -1.0)
+        else:                # border-image style segments
+            st = (-1.0, -1.0)
+            cw, ch = min(w / 3, 24.0), min(h / 3, 20.0)
+            xs, ys = (0.0, cw, w - cw, w), (0.0, ch, h - ch, h)
+            us, vs = (0.0, 0.3, 0.7, 1.0), (0.0, 0.25, 0.75, 1.0)
+            segs = []
+            for j in range(3):
+                for i in range(3):
+                    flags = 2                                   # SEGMENT_RELATIVE
+                    texel = mode == 4
+                    if texel:
+                        flags |= 512                            # TEXEL_RECT
+                        data = (us[i], vs[j], us[i + 1], vs[j + 1])
+                    else:
+                        data = (0.0, 0.0, float(sw) * 1.5, float(sh) * 0.75)
+                    if i == 1:
+                        flags |= 4 | (16 if (k // 6) % 2 else 0) | (64 if (k // 12) % 2 else 0)
+                    if j == 1:
+                        flags |= 8 | (32 if (k // 6) % 2 else 0) | (128 if (k // 12) % 2 else 0)
+                    if i == 1 and j == 1:
+                        flags |= 256                            # NINEPATCH_MIDDLE
+                    segs.append(((xs[i], ys[j], xs[i + 1], ys[j + 1]), data, flags))
+        opacity = 1.0 if (k % 3 or not translucent) else float(rng.uniform(0.3, 0.9))
+        prims.append(dict(rect=(px, py, px + w, py + h), addr=addr, opaque=False, opacity=opacity, stretch=st, segs=segs))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        op, al = [], []
+        for zi, pr in enumerate(prims):
+            rect = pr["rect"]
+            if only is not None and zi not in only:
+                continue
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            blocks = [[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [pr["stretch"][0], pr["stretch"][1], 0.0, 0.0]]
+            for (srect, sdata, _) in (pr["segs"] or []):
+                blocks += [list(srect), list(sdata)]
+            spec = frame.gpu_cache.push(blocks)
+            ud = (4 | (1 << 16), 0, int(round(pr["opacity"] * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, ud)
+            dst = op if pr["opaque"] else al
+            if pr["segs"] is None:
+                dst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=pr["addr"]))
+            else:
+                for si, (_, _, flags) in enumerate(pr["segs"]):
+                    dst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, segment=si, brush_flags=flags, resource_address=pr["addr"]))
+        if op:
+            target.opaque.append(Step("brush_image ANTIALIASING,REPETITION,TEXTURE_2D", "PRIM_INSTANCES",
+                                      np.array(op[::-1], dtype=np.int32), None, "opaque", textures={0: t_atlas}))
+        if al:
+            target.alpha.append(Step("brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", "PRIM_INSTANCES",
+                                     np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
+
+
+# ---------------------------------------------------------------------------
 # Clip-masked rectangles: brush_solid ALPHA_PASS instances whose clip task
 # address points at an R8 mask region (prim_shared.glsl:183-200 write_clip ->
 # swgl_clipMask).  The masks themselves are uploaded here; in a full frame they
