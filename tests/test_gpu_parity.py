@@ -61,6 +61,15 @@ SMALL = [
     ("image_grid_masked", lambda: scenes.image_grid(masked=True)),
     ("filter_grid_masked", lambda: scenes.filter_grid(masked=True, seed=75, ops=FILTER_OPS_EXACT)),
     ("rotated_rects", lambda: scenes.rotated_rects()),
+    ("rotated_images", lambda: scenes.rotated_images()),
+    ("rotated_images_repeat", lambda: scenes.rotated_images(repeat=True)),
+    ("rotated_images_masked", lambda: scenes.rotated_images(masked=True)),
+    ("rotated_images_nearest_wide", lambda: scenes.rotated_images(nearest=True, seed=103, width=2048, n=120)),
+    ("rotated_images_repeat_nearest", lambda: scenes.rotated_images(repeat=True, nearest=True, seed=102)),
+    ("rotated_images_repeat_masked", lambda: scenes.rotated_images(repeat=True, masked=True, seed=104)),
+    ("rotated_images_quad", lambda: scenes.rotated_images(encoding="quad")),
+    ("image_grid_nearest", lambda: scenes.image_grid(nearest=True)),
+    ("image_grid_nearest_masked_wide", lambda: scenes.image_grid(nearest=True, masked=True, seed=52, width=2048, n=200)),
     ("image_repeat", lambda: scenes.image_repeat()),
     ("image_repeat_nearest", lambda: scenes.image_repeat(nearest=True)),
     ("image_repeat_wide", lambda: scenes.image_repeat(width=2048, height=1024, n=200, seed=58)),

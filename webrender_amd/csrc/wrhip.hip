@@ -1076,6 +1076,7 @@ void flush_work(const std::vector<int>& sel_in) {
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }
       }
+      if (draws[i].flags & WR_DF_QUADS) f |= WR_FEAT_SHADE | WR_FEAT_GENERIC;
       (to_r8 ? L.feat_r8 : L.feat_rgba) |= f;
     }
     // one raster launch per dependency level and target format, in level order on the one stream: the
@@ -1893,6 +1894,25 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
       }
     }
     if (simple) d.flags |= WR_DF_SIMPLE;
+    // textured prims on rotated quads or with swgl_antiAlias need the WR_PK_TEX_QUAD path (WR_FEAT_SHADE launches): the
+    // transform ids in the bound header texture and the AA requests in the instances say whether this draw can hold any
+    const bool img = info->kind == WR_SH_BRUSH_IMAGE || info->kind == WR_SH_BRUSH_IMAGE_ALPHA ||
+                     info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA;
+    const bool texquad = info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2;
+    if (colortex.internal_format == GL_RGBA8 && (img || texquad)) {
+      bool quads = !ids_clean(img ? WR_S_PRIM_HEADERS_I : WR_S_GPU_BUFFER_I, img);
+      if (!quads && d.blend != WR_BLEND_NONE && d.attr_off[0] >= 0 && d.attr_bytes[0] >= 12 && inst_stride >= 12) {
+        const uint8_t* ib = (const uint8_t*)instb->buf + d.attr_off[0];
+        for (int i = 0; i < instancecount && !quads; i++) {
+          int32_t zw; memcpy(&zw, ib + (size_t)i * inst_stride + 8, 4);
+          if (texquad) {
+            const int part = (zw >> 8) & 0xff, edges = (zw >> 16) & 0xff;
+            if ((part >= 1 && part <= 4) || (part == 5 && edges != 0)) quads = true;
+          } else if ((zw >> 16) & 1024) quads = true;
+        }
+      }
+      if (quads) d.flags |= WR_DF_QUADS;
+    }
   }
   apply_scissor(colortex, d.clip);
   d.vp_origin[0] = float(c->viewport[0] - colortex.offx); d.vp_origin[1] = float(c->viewport[1] - colortex.offy);

@@ -1184,17 +1184,21 @@ WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
 // starts, which edges are the span's left and right ones, when each edge ends and is replaced
 // (STEP_EDGE), the clip span of every edge pair.  Returns false for degenerate walks (nothing to draw)
 // or more runs than WrQuadRec holds.  p[] in vertex-lane order (0,0) (1,0) (1,1) (0,1).
-struct WrEdgeInst { float x, slope; int row, mask; };
-WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, float p1y, int mask) {   // Edge ctor, :850-876
+struct WrEdgeInst { float x, slope; int row, mask; float u, v, us, vs; };
+WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, float p1y, int mask, float u0, float v0, float u1,
+                                  float v1) {   // Edge ctor, :850-876
   WrEdgeInst e;
   const float yScale = 1.0f / wr_max(p1y - p0y, 1.0f / 256.0f);
   e.slope = (p1x - p0x) * yScale;
   e.x = p0x + (y - p0y) * e.slope;
+  e.us = (u1 - u0) * yScale; e.vs = (v1 - v0) * yScale;
+  e.u = u0 + (y - p0y) * e.us; e.v = v0 + (y - p0y) * e.vs;
   e.row = int(y); e.mask = mask;
   return e;
 }
-WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], float cx0, float cy0, float cx1, float cy1, bool aa, int aa_mask,
-                            WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1) {
+// iu / iv: the shader's interpolated vec2 per vertex (zeros for solid prims)
+WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const float (&iu)[4], const float (&iv)[4], float cx0, float cy0,
+                            float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1) {
   Q.nseg = 0; Q.aa = aa ? 1 : 0;
   // top-most point (:794-799)
   const int top = py[3] < py[2] ? (py[0] < py[1] ? (py[0] < py[3] ? 0 : 3) : (py[1] < py[3] ? 1 : 3))
@@ -1209,8 +1213,10 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], float cx
   const float aaRound = aa ? 0.0f : 0.5f;
   float y = floorf(wr_max(wr_min(WR_PY(l0i), cy1), cy0) + aaRound) + 0.5f;
   // the l-chain walks forward through the points, the r-chain backward; `flipped` says which one is the span's left edge
-  WrEdgeInst EL = wr_edge_init(y, WR_PX(l0i), WR_PY(l0i), WR_PX(l1i), WR_PY(l1i), (aa_mask >> l1i) & 1);
-  WrEdgeInst ER = wr_edge_init(y, WR_PX(r0i), WR_PY(r0i), WR_PX(r1i), WR_PY(r1i), (aa_mask >> r0i) & 1);
+#define WR_EDGE(a, b, m) wr_edge_init(y, WR_PX(a), WR_PY(a), WR_PX(b), WR_PY(b), (aa_mask >> (m)) & 1, wr_pick4(iu, a), wr_pick4(iv, a), \
+                                     wr_pick4(iu, b), wr_pick4(iv, b))
+  WrEdgeInst EL = WR_EDGE(l0i, l1i, l1i);
+  WrEdgeInst ER = WR_EDGE(r0i, r1i, r0i);
   bool flipped;
   {   // checkIfEdgesFlipped (:766-774)
     const float l0x = WR_PX(l0i), r0x = WR_PX(r0i);
@@ -1234,12 +1240,12 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], float cx
       if (y > WR_PY(l1i)) {          // STEP_EDGE(y, l0i, l0, l1i, l1, NEXT_POINT, r1i)
         do { l0i = l1i; l1i = (l1i + 1) & 3; if (l0i == r1i) { done = true; break; } } while (y > WR_PY(l1i));
         if (done) break;
-        EL = wr_edge_init(y, WR_PX(l0i), WR_PY(l0i), WR_PX(l1i), WR_PY(l1i), (aa_mask >> l1i) & 1);
+        EL = WR_EDGE(l0i, l1i, l1i);
       }
       if (y > WR_PY(r1i)) {          // STEP_EDGE(y, r0i, r0, r1i, r1, PREV_POINT, l1i)
         do { r0i = r1i; r1i = (r1i + 3) & 3; if (r0i == l1i) { done = true; break; } } while (y > WR_PY(r1i));
         if (done) break;
-        ER = wr_edge_init(y, WR_PX(r0i), WR_PY(r0i), WR_PX(r1i), WR_PY(r1i), (aa_mask >> r0i) & 1);
+        ER = WR_EDGE(r0i, r1i, r0i);
       }
       WR_CLIPSPAN();
       checkY = wr_min(ceilf(wr_min(WR_PY(l1i), WR_PY(r1i)) - aaRound), cy1);
@@ -1254,12 +1260,15 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], float cx
     S.row_a = int(y); S.row_b = int(y) + n;
     S.lx = A.x; S.ls = A.slope; S.lrow = A.row; S.lmask = A.mask;
     S.rx = B.x; S.rs = B.slope; S.rrow = B.row; S.rmask = B.mask;
+    S.luv[0] = A.u; S.luv[1] = A.v; S.luvs[0] = A.us; S.luvs[1] = A.vs;
+    S.ruv[0] = B.u; S.ruv[1] = B.v; S.ruvs[0] = B.us; S.ruvs[1] = B.vs;
     S.b0 = b0; S.b1 = b1;
     bx0 = wr_imin(bx0, int(floorf(b0)) - 1); bx1 = wr_imax(bx1, int(ceilf(b1)) + 1);
     by1 = S.row_b;
     y = y + float(n);
   }
 #undef WR_CLIPSPAN
+#undef WR_EDGE
 #undef WR_PX
 #undef WR_PY
   return Q.nseg > 0;
@@ -1324,25 +1333,44 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
 
   // swgl_antiAlias only takes effect when blending is on (ClipRect ctor, rasterize.h:414-441)
   const bool aa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
-  if (aa && (o.kind != WR_PK_SOLID || masked)) {      // AA on textured / masked prims: "next"
+  // textured kinds that can ride on WrQuadRec (general quads, swgl_antiAlias) when the host gave the launch the path for it
+  const bool texq = (d.flags & WR_DF_QUADS) &&
+                    (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT);
+  if (aa && (o.kind != WR_PK_SOLID || masked) && !texq) {      // AA on masked solids / other shader families: "next"
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
   // lanes: 0=(0,0) 1=(1,0) 2=(1,1) 3=(0,1) of the unit quad
   bool typeA = sy[0] == sy[1] && sy[2] == sy[3] && sx[0] == sx[3] && sx[1] == sx[2];
   bool typeB = sx[0] == sx[1] && sx[2] == sx[3] && sy[0] == sy[3] && sy[1] == sy[2];
-  if (!typeA && !typeB) {
-    // general convex quad (rotation / skew): solid colour only so far, textured / masked ones are "next"
-    if (o.kind != WR_PK_SOLID || masked || ((d.flags & WR_DF_SIMPLE) != 0)) {
+  if ((!typeA && !typeB) || (aa && texq)) {
+    // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
+    const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
+    if (!solidq && !texq) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
     }
-    const bool qaa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
+    WrRepeatRec rep;
+    if (o.kind == WR_PK_TEX_REPEAT) rep = auxp->rep;          // the vertex stage left it in the (shared) side record
     int bx0, by0, bx1, by1;
-    if (!wr_quad_walk(sx, sy, cx0, cy0, cx1, cy1, qaa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1)) return;
+    if (!wr_quad_walk(sx, sy, o.u, o.v, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1)) return;
     P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
     if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-    P.kind = WR_PK_SOLID_QUAD;
     P.rows_linear = 0;
-    wr_pack_color(o.color, P.color);
+    if (solidq) {
+      P.kind = WR_PK_SOLID_QUAD;
+      wr_pack_color(o.color, P.color);
+      return;
+    }
+    P.kind = WR_PK_TEX_QUAD;
+    auxp->quad.base_kind = o.kind;
+    if (o.kind == WR_PK_TEX_REPEAT) auxp->quad.rep = rep;
+    if (masked) P.flags |= WR_PF_MASKED;
+    if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
+    if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
+    if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
+    P.tex_slot = o.tex_slot;
+    P.uv_bounds[0] = o.uv_bounds.x; P.uv_bounds[1] = o.uv_bounds.y; P.uv_bounds[2] = o.uv_bounds.z; P.uv_bounds[3] = o.uv_bounds.w;
+    P.fcolor[0] = o.color.x; P.fcolor[1] = o.color.y; P.fcolor[2] = o.color.z; P.fcolor[3] = o.color.w;
+    if (o.blend_override != 0 && d.blend != WR_BLEND_NONE) { P.blend = (int16_t)o.blend_override; wr_pack_color(o.blend_color, P.color); }
     return;
   }
   float xa = sx[0], xb = sx[2], ya = sy[0], yb = sy[2];
@@ -1753,19 +1781,16 @@ struct WrTexRow {
   int srow;              // nearest-fast: clamped source row
 };
 
-WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
+// (Lu, Lv) / (Ru, Rv): the edge interpolants on this row, xl / xr the edges' x, [x0, x0 + len) the row's span
+WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu, float Lv, float Ru, float Rv, float xl, float xr,
+                                   int x0, int len) {
   WrTexRow r;
-  // Edge::nextRow (rasterize.h:878-882) steps the interpolants by repeated addition
-  const int k = y - P.y0;
-  const bool lin = P.rows_linear != 0;
-  float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
-  float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
-  float stepScale = 1.0f / (P.xr - P.xl);
+  float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
-  float start = float(P.x0) + 0.5f - P.xl;
+  float start = float(x0) + 0.5f - xl;
   r.ou = Lu + r.su * start; r.ov = Lv + r.sv * start;
-  r.len = P.x1 - P.x0;
+  r.len = len;
   r.span = r.len >= 4 ? (r.len & ~3) : 0;
   r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
   if (P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK) r.span = 0;     // no draw_span for this program/target: all main()
@@ -1782,7 +1807,7 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
     int sp = (r.span & ~127) + 128;
     int scaled = int(roundf((px1 - px0) * float(sp)));
     bool fallback = (py1 - py0) * float(r.span) >= 0.5f || scaled != sp;
-    r.filter = fallback ? -1 : 0;   // blendTextureNearestRepeat<false>: "next"
+    r.filter = fallback ? -1 : 0;   // -1: blendTextureNearestRepeat<BLEND, false>
   } else if (t.width < 2) {
     r.filter = 0;
   } else if (p0v != ov1) {
@@ -1811,6 +1836,14 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
     r.maxX = wr_iclamp(maxUx, r.minX, t.width - 1);
   }
   return r;
+}
+WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
+  // Edge::nextRow (rasterize.h:878-882) steps the interpolants by repeated addition
+  const int k = y - P.y0;
+  const bool lin = P.rows_linear != 0;
+  const float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+  const float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+  return wr_tex_row_span(P, t, Lu, Lv, Ru, Rv, P.xl, P.xr, P.x0, P.x1 - P.x0);
 }
 
 // Quantised (1/128 texel) sample position of a fragment-shader (tail) pixel:
@@ -1872,9 +1905,7 @@ WR_DEVICE WrWide wr_tex_tail_texel(const WrPrim& P, const WrTexDesc& t, float cu
 
 // One pixel of a WR_PK_TEX_RGBA8 prim on row y (returns the WideRGBA8 source,
 // colour modulation included).
-WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y) {
-  const WrTexRow r = wr_tex_row(P, t, y);
-  const int n = x - P.x0;
+WR_DEVICE WrWide wr_tex_pixel_row(const WrPrim& P, const WrTexDesc& t, const WrTexRow& r, int n) {
   const float W = float(t.width), H = float(t.height);
   const uint32_t* buf = (const uint32_t*)t.ptr;
   if (n < r.span) {
@@ -1882,6 +1913,20 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
     if (r.filter == 0) {
       int sx = wr_iclamp(r.ix + n, r.minX, r.maxX);
       s = wr_unpack(buf[(size_t)r.srow * t.stride + sx]);
+    } else if (r.filter == -1) {
+      // blendTextureNearestRepeat<BLEND, false> (swgl_ext.h:774-858): nearest sampler, clamped, any scale
+      float pu[4], pv[4];
+      {
+        float lu = r.ou, lv = r.ov;
+        for (int i = 0; i < 4; i++) { pu[i] = (lu + P.uv_add[0]) * W; pv[i] = (lv + P.uv_add[1]) * H; lu += r.su; lv += r.sv; }
+      }
+      const float stepx = 4.0f * (pu[1] - pu[0]), stepy = 4.0f * (pv[1] - pv[0]);
+      const float minx = P.uv_bounds[0] * W, miny = P.uv_bounds[1] * H, maxx = P.uv_bounds[2] * W, maxy = P.uv_bounds[3] * H;
+      const bool solid = (int(minx) >= int(maxx) || fabsf(stepx) * float(r.span) * 1.0f < 0.5f) &&
+                         (int(miny) >= int(maxy) || fabsf(stepy) * float(r.span) * 1.0f < 0.5f);
+      const int k = n & 3, c = solid ? 0 : (n >> 2);
+      const float cu = wr_clamp(wr_accum(pu[k], stepx, c), minx, maxx), cv = wr_clamp(wr_accum(pv[k], stepy, c), miny, maxy);
+      s = wr_unpack(buf[(size_t)wr_clamp_coord(int(cu), t.width) + (size_t)wr_clamp_coord(int(cv), t.height) * t.stride]);
     } else {
       // Linear filters: exact per-variant evaluation (wr_linear_span_pixel)
       const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
@@ -1917,6 +1962,9 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y)
   wr_tex_tail_uv(P, r, n, cu, cv);
   return wr_tex_tail_texel(P, t, cu, cv);
 }
+WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y) {
+  return wr_tex_pixel_row(P, t, wr_tex_row(P, t, y), x - P.x0);
+}
 
 // ---------------------------------------------------------------------------
 // brush_image with WR_FEATURE_REPETITION: swgl_commitTextureRepeat[Color]RGBA8 (swgl_ext.h:664-872).
@@ -1948,12 +1996,7 @@ WR_DEVICE void wr_tile_repeat_uv(float u, float v, const float (&tile_repeat)[2]
   }
   fu = u - floorf(u); fv = v - floorf(v);
 }
-__device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatRec* Rp, const WrDrawDesc* D, int x, int y) {
-  const WrPrim& P = *Pp;
-  const WrRepeatRec& R = *Rp;
-  const WrTexDesc& t = D->tex[P.tex_slot];
-  const WrTexRow r = wr_tex_row(P, t, y);
-  const int n = x - P.x0;
+WR_DEVICE WrWide wr_repeat_pixel_row(const WrPrim& P, const WrRepeatRec& R, const WrTexDesc& t, const WrTexRow& r, int n) {
   const int span = R.no_span ? 0 : r.span;
   const float W = float(t.width), H = float(t.height);
   if (n >= span) {
@@ -2070,6 +2113,10 @@ __device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatR
   }
   if (P.flags & WR_PF_HAS_COLOR) s = wr_apply_color(s, P.color);
   return s;
+}
+__device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatRec* Rp, const WrDrawDesc* D, int x, int y) {
+  const WrTexDesc& t = D->tex[Pp->tex_slot];
+  return wr_repeat_pixel_row(*Pp, *Rp, t, wr_tex_row(*Pp, t, y), x - Pp->x0);
 }
 
 // Compact raster record.  Solid prims on RGBA8 targets drawn without blending
@@ -2579,6 +2626,57 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
     src = wr_mask_src(P, D, x, y, wr_tex_pixel(P, D->tex[P.tex_slot], x, y));
   }
   return wr_blend_rgba8(P.blend, dstp, src, D, P.color);
+}
+
+// One pixel of a textured prim on a general quad and / or with swgl_antiAlias (WR_PK_TEX_QUAD): this row's span and the
+// pixel's coverage as in wr_quad_pixel_rgba8, the edge interpolants stepped row by row (Edge::nextRow), then the base
+// kind's span shader / main() evaluation of pixel x - span.start, DO_AA ahead of the clip mask (blend.h:452-460).
+__device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim* Pp, const WrQuadRec* Qp, const WrDrawDesc* D, int x, int y,
+                                                                    uint32_t dstp_) {
+  const WrQuadRec& Q = *Qp;
+  const unsigned long long dstp = dstp_;
+  const unsigned long long HIT = 1ull << 32;
+  int si = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  if (si < 0) return dstp;
+  const WrQuadSeg& S = Q.seg[si];
+  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
+  int s0, s1;
+  uint32_t cov = 256;
+  if (!Q.aa) {
+    s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+    if (x < s0 || x >= s1) return dstp;
+  } else {
+    const float radl = 0.5f * fabsf(S.ls), radr = 0.5f * fabsf(S.rs);
+    const int la0 = S.lmask ? int(floorf(wr_clamp(xl - radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+    const int la1 = S.lmask ? int(ceilf(wr_clamp(xl + radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+    const int ra1 = S.rmask ? int(ceilf(wr_clamp(xr + radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+    if (x < la0 || x >= ra1) return dstp;
+    float lstart = 256.0f, lend = 0.0f, rstart = 256.0f, rend = 0.0f;
+    if (S.lmask) { const float dx = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.ls * S.ls)); lstart = 128.0f + dx * (xl - 0.5f); lend = -dx; }
+    if (S.rmask) { const float dx = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.rs * S.rs)); rstart = 128.0f + dx * (xr - 0.5f); rend = -dx; }
+    const int n = x - la0, lane = n & 3, base = la0 + (n & ~3);
+    const float off = float(4 * (base - la1));
+    const float dl = (lstart + float(la1 + lane) * lend) + (lend / 4.0f) * off;
+    const float dr = (rstart + float(la1 + lane) * rend) + (rend / 4.0f) * off;
+    cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
+    s0 = la0; s1 = ra1;
+  }
+  WrPrim Pl = *Pp;
+  Pl.kind = (int16_t)Q.base_kind;
+  const WrTexDesc& t = D->tex[Pl.tex_slot];
+  const float Lu = wr_accum(S.luv[0], S.luvs[0], y - S.lrow), Lv = wr_accum(S.luv[1], S.luvs[1], y - S.lrow);
+  const float Ru = wr_accum(S.ruv[0], S.ruvs[0], y - S.rrow), Rv = wr_accum(S.ruv[1], S.ruvs[1], y - S.rrow);
+  const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0);
+  WrWide src = Q.base_kind == WR_PK_TEX_REPEAT ? wr_repeat_pixel_row(Pl, Q.rep, t, r, x - s0) : wr_tex_pixel_row(Pl, t, r, x - s0);
+  if (Q.aa) {
+    const uint32_t c0 = src.bg, c1 = src.ra;
+    src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+    src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+  }
+  src = wr_mask_src(Pl, D, x, y, src);
+  return HIT | wr_blend_rgba8(Pl.blend, dstp_, src, D, Pl.color);
 }
 
 // red channel of a textured prim's fragment value (R8 targets)
@@ -3896,6 +3994,24 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
                                               : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2));
       const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), raw);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+      plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+    }
+    return;
+  }
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_QUAD) {
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      const bool in = cx[q & 3] && cy[q >> 2];
+      if (!in) continue;
+      const uint32_t before = plo[q] | (phi[q] << 8);
+      bool pass = true;
+      if (dtest) pass = dless ? (z < dep[q]) : (z <= dep[q]);
+      if (!pass) continue;
+      const unsigned long long rr = wr_quad_tex_pixel_rgba8(Pp, &Ap->quad, D, px + (q & 3), py + 4 * (q >> 2), before);
+      if (!(rr >> 32)) continue;
+      const uint32_t r = (uint32_t)rr;
+      if (dtest && dwrite) dep[q] = z;
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;

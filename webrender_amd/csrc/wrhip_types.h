@@ -114,6 +114,8 @@ enum WrDrawFlags {
   WR_DF_DEPTH_LESS = 4,    // GL_LESS instead of GL_LEQUAL
   WR_DF_CLEAR_COLOR = 8,   // WR_SH_CLEAR_OP
   WR_DF_CLEAR_DEPTH = 16,
+  WR_DF_QUADS = 64,        // host: this draw may hold textured prims on general (rotated) quads or with swgl_antiAlias;
+                           // its launch carries WR_FEAT_SHADE, where WR_PK_TEX_QUAD lives
   WR_DF_SIMPLE = 32,       // host promise: every prim of this draw is a solid with blend NONE/PREMULT (see WrFeat)
 };
 
@@ -179,6 +181,8 @@ enum WrPrimKind {
   WR_PK_FILTER,         // brush_blend: fragment shader only (texture() + CalculateFilter, WrFilterRec); uv as WR_PK_TEX_FS
   WR_PK_SOLID_QUAD,     // solid colour on a general (rotated / skewed) convex quad: per-row spans from WrQuadRec, optional AA
   WR_PK_TEX_REPEAT,     // swgl_commitTextureRepeat[Color]RGBA8 (brush_image REPETITION): per-row replay of the repeat walk (WrRepeatRec)
+  WR_PK_TEX_QUAD,       // a textured prim (WrQuadRec::base_kind) on a general convex quad and / or with swgl_antiAlias: per-row spans and
+                        // edge interpolants from WrQuadRec, then the base kind's span / main() evaluation
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
 };
 
@@ -335,11 +339,8 @@ struct WrQuadSeg {
   float rx, rs; int32_t rrow;       // span-right edge
   float b0, b1;
   int32_t lmask, rmask;
-};
-struct WrQuadRec {
-  int32_t nseg;
-  int32_t aa;                       // SWGL_CLIP_FLAG_AA set for this prim
-  WrQuadSeg seg[4];
+  // WR_PK_TEX_QUAD: the edges' interpolants (uv) at row lrow / rrow and their per-row slopes (Edge ctor, rasterize.h:870-874)
+  float luv[2], luvs[2], ruv[2], ruvs[2];
 };
 
 // brush_image with WR_FEATURE_REPETITION (brush_image.glsl:318-341, 380-428; swgl_ext.h:664-872)
@@ -348,6 +349,15 @@ struct WrRepeatRec {
   float uv_repeat[4];               // v_uv_bounds
   int32_t alpha_pass;               // compute_repeated_uvs' ALPHA_PASS branch in main()
   int32_t no_span;                  // the span shader bails out (texture not RGBA8): every pixel runs main()
+};
+
+struct WrQuadRec {
+  int32_t nseg;
+  int32_t aa;                       // SWGL_CLIP_FLAG_AA set for this prim
+  int32_t base_kind;                // WR_PK_TEX_QUAD: WR_PK_TEX_RGBA8 / TEX_FS / TEX_R8 / TEX_REPEAT
+  int32_t pad;
+  WrQuadSeg seg[4];
+  WrRepeatRec rep;                  // base_kind == WR_PK_TEX_REPEAT
 };
 
 // per-prim side record, written by the setup kernel for the kinds that need one

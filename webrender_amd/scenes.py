@@ -344,7 +344,7 @@ def scaled_composites(width=1024, height=768, seed=21, src=192):
 # alpha pass (batch.rs:2060-2150; ImageBrushData gpu_types.rs:707-724; GPU blocks
 # prim_store/image.rs: [color, background_color, stretch_size]).
 def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=None, modes=(0, 1, 2, 3, 4), translucent=True, only=None,
-               masked=False):
+               masked=False, nearest=False):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -366,7 +366,8 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
         srcs.append((w, h, addr, i % 2 == 0))
         x += w
         shelf = max(shelf, h)
-    t_atlas = TextureRef("image_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pix, upload_format=G.GL_BGRA)
+    t_atlas = TextureRef("image_atlas", atlas, atlas, G.GL_RGBA8, G.GL_NEAREST if nearest else G.GL_LINEAR, pixels=pix,
+                         upload_format=G.GL_BGRA)
     frame.static_textures.append(t_atlas)
     prims = []
     # Opaque-pass images sit on a non-overlapping grid in the top band: swgl restarts a span (chunk
@@ -1558,6 +1559,107 @@ def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile
             target.opaque.append(Step(key[0], "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32), None, "opaque", textures={}))
         if al:
             target.alpha.append(Step(key[1], "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha", textures={}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
+
+
+# ---------------------------------------------------------------------------
+# Images under rotations / skews, and axis-aligned ones with BRUSH_FLAG_FORCE_AA: textured prims on the
+# general-quad scanline walk with swgl_antiAlias edges (brush.glsl:150-170 -> swgl_antiAlias; blend.h DO_AA).
+# `repeat`: through the ANTIALIASING,REPETITION image brush with tiling stretch sizes; `masked`: under
+# swgl_clipMask as well.  Alpha pass only (AA needs blending, rasterize.h:414-441).
+def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=False, nearest=False, masked=False, tile_filter=None,
+                   only=None, encoding="brush"):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    pix = np.zeros((atlas, atlas, 4), np.uint8)
+    srcs = []
+    x = y = shelf = 0
+    for i in range(16):
+        w, h = int(rng.integers(12, 120)), int(rng.integers(12, 100))
+        if x + w > atlas:
+            x, y, shelf = 0, y + shelf, 0
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 0] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+        img[..., 1] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+        if i % 2 == 0:
+            img[..., 3] = 255
+        img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)
+        pix[y:y + h, x:x + w] = img
+        srcs.append((w, h, frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]]), (x, y, x + w, y + h)))
+        x += w + 2
+        shelf = max(shelf, h + 2)
+    t_atlas = TextureRef("image_atlas", atlas, atlas, G.GL_RGBA8, G.GL_NEAREST if nearest else G.GL_LINEAR, pixels=pix,
+                         upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+    prims = []
+    for i in range(n):
+        sw, sh, addr, texels = srcs[int(rng.integers(0, len(srcs)))]
+        sc = float(rng.uniform(0.6, 3.0))
+        w, h = sw * sc, sh * sc * float(rng.uniform(0.7, 1.4))
+        cx, cy = float(rng.uniform(0, width)), float(rng.uniform(0, height))
+        flags = 0
+        if i % 6 == 5:        # axis-aligned, anti-aliased on request
+            tid = 0
+            flags = 1024
+            cx, cy = cx + float(rng.uniform(0, 1)), cy + float(rng.uniform(0, 1))
+        else:
+            th = float(rng.uniform(0, 2 * np.pi)) if i % 6 else float(rng.choice([np.pi / 4, np.pi / 2, 0.01]))
+            sk = float(rng.uniform(-0.4, 0.4)) if i % 4 == 1 else 0.0
+            c, sn = np.cos(th), np.sin(th)
+            a = np.array([[c, -sn + sk * c], [sn, c + sk * sn]], np.float64)
+            m = np.eye(4)
+            m[:2, :2] = a
+            m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+            tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
+        rect = (cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)
+        rad = float(np.hypot(w, h)) * 0.75 + 4
+        st = (-1.0, -1.0)
+        if repeat and i % 3 != 2:
+            st = (sw * float(rng.uniform(0.5, 1.5)), sh * float(rng.uniform(0.5, 1.5))) if i % 3 else (float(sw), float(sh))
+        opacity = 1.0 if i % 3 else float(rng.uniform(0.3, 0.9))
+        prims.append((rect, tid, addr, (cx - rad, cy - rad, cx + rad, cy + rad), flags, st, opacity, texels))
+    t_mask, clip_tasks = None, [None] * len(prims)
+    if masked:
+        t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
+        frame.static_textures.append(t_mask)
+        clip_tasks = prim_clip_tasks(rng, [p[3] for p in prims], 1024, True)
+    key = "brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D" if repeat else "brush_image ALPHA_PASS,TEXTURE_2D"
+    if encoding == "quad":
+        key = "ps_quad_textured"
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        al = []
+        for zi, (rect, tid, addr, bb, flags, st, opacity, texels) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
+                continue
+            if encoding == "quad":      # ps_quad_textured sampling the atlas (pattern colour x texture)
+                al.append(frame.quad_instance(rect, (-BIG, -BIG, BIG, BIG), (opacity, opacity, opacity, opacity), zi + 1, task,
+                                              transform_id=tid, quad_flags=0, edge_flags=15 if (tid or flags) else 0,
+                                              uv_rect=tuple(float(v) for v in texels)))
+                continue
+            spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [st[0], st[1], 0.0, 0.0]])
+            ud = (4 | (1 << 16), 0, int(round(opacity * 65535.0)), 0)
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, tid, task, ud)
+            ct = clip_tasks[zi]
+            clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
+            al.append(frame.brush_instance(ph, clip_addr, brush_flags=flags, edge_flags=15, resource_address=addr))
+        if al:
+            target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha",
+                                     textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
         clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
