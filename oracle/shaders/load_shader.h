@@ -17,6 +17,7 @@
 #include "brush_linear_gradient.h"
 #include "brush_blend.h"
 #include "ps_quad_mask.h"
+#include "brush_opacity.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -45,6 +46,10 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("brush_linear_gradient ALPHA_PASS", brush_linear_gradient_ALPHA_PASS)
   WRSH_ENTRY("brush_blend", brush_blend)
   WRSH_ENTRY("brush_blend ALPHA_PASS", brush_blend_ALPHA_PASS)
+  WRSH_ENTRY("brush_opacity", brush_opacity)
+  WRSH_ENTRY("brush_opacity ALPHA_PASS", brush_opacity_ALPHA_PASS)
+  WRSH_ENTRY("brush_opacity ANTIALIASING", brush_opacity_ANTIALIASING)
+  WRSH_ENTRY("brush_opacity ALPHA_PASS,ANTIALIASING", brush_opacity_ALPHA_PASS_ANTIALIASING)
   WRSH_ENTRY("ps_quad_mask", ps_quad_mask)
   WRSH_ENTRY("ps_quad_mask FAST_PATH", ps_quad_mask_FAST_PATH)
 #undef WRSH_ENTRY

@@ -48,6 +48,7 @@ def main():
     out["rotated_images"] = digest(render_direct(LIB, scenes.rotated_images())[0])
     out["rotated_images_repeat"] = digest(render_direct(LIB, scenes.rotated_images(repeat=True))[0])
     out["rotated_images_quad"] = digest(render_direct(LIB, scenes.rotated_images(encoding="quad"))[0])
+    out["opacity_grid"] = digest(render_direct(LIB, scenes.filter_grid(shader="opacity"))[0])
     out["image_repeat"] = digest(render_direct(LIB, scenes.image_repeat())[0])
     out["image_repeat_nearest"] = digest(render_direct(LIB, scenes.image_repeat(nearest=True))[0])
     out["filter_grid_exact"] = digest(render_direct(LIB, scenes.filter_grid(ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]))[0])

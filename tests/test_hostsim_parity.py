@@ -60,6 +60,10 @@ CASES = [
     ("rotated_images_quad", lambda: scenes.rotated_images(encoding="quad")),
     ("image_grid_nearest", lambda: scenes.image_grid(nearest=True)),
     ("image_grid_nearest_masked_wide", lambda: scenes.image_grid(nearest=True, masked=True, seed=52, width=2048, n=200)),
+    ("opacity_grid", lambda: scenes.filter_grid(shader="opacity")),
+    ("opacity_grid_masked", lambda: scenes.filter_grid(shader="opacity", masked=True, seed=74)),
+    ("opacity_grid_wide", lambda: scenes.filter_grid(shader="opacity", width=2048, height=1024, n=160, seed=72)),
+    ("opacity_grid_int", lambda: scenes.filter_grid(shader="opacity", width=1000, height=700, n=60, seed=73, fractional=False)),
     ("image_repeat", lambda: scenes.image_repeat()),
     ("image_repeat_nearest", lambda: scenes.image_repeat(nearest=True)),
     ("image_repeat_wide", lambda: scenes.image_repeat(width=2048, height=1024, n=200, seed=58)),

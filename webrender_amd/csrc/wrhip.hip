@@ -141,6 +141,10 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
     {"ps_quad_mask FAST_PATH", WR_SH_PS_QUAD_MASK_FAST, {"aPosition", "aData", "aClipData"},
      S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
+    {"brush_opacity", WR_SH_BRUSH_OPACITY, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_opacity ANTIALIASING", WR_SH_BRUSH_OPACITY, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_opacity ALPHA_PASS", WR_SH_BRUSH_OPACITY_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_opacity ALPHA_PASS,ANTIALIASING", WR_SH_BRUSH_OPACITY_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_blend", WR_SH_BRUSH_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_blend ALPHA_PASS", WR_SH_BRUSH_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"composite TEXTURE_2D", WR_SH_COMPOSITE,
@@ -1897,6 +1901,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     // textured prims on rotated quads or with swgl_antiAlias need the WR_PK_TEX_QUAD path (WR_FEAT_SHADE launches): the
     // transform ids in the bound header texture and the AA requests in the instances say whether this draw can hold any
     const bool img = info->kind == WR_SH_BRUSH_IMAGE || info->kind == WR_SH_BRUSH_IMAGE_ALPHA ||
+                     info->kind == WR_SH_BRUSH_OPACITY || info->kind == WR_SH_BRUSH_OPACITY_ALPHA ||
                      info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA;
     const bool texquad = info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2;
     if (colortex.internal_format == GL_RGBA8 && (img || texquad)) {

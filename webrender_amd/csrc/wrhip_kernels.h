@@ -592,6 +592,37 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     if (brush_flags & 1) o.kind = WR_PK_UNSUPPORTED;      // perspective interpolation: next
     return;
   }
+  if (image == 7) {
+    // brush_vs (brush_opacity.glsl:25-63); span: swgl_commitTextureLinearColorRGBA8(sColor0, uv, v_uv_sample_bounds, v_opacity)
+    const int src_address = data1.x;
+    const int sau = int(unsigned(src_address) % 1024u), sav = int(unsigned(src_address) / 1024u);
+    const wf4 res0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], sau, sav);
+    const int qa = src_address + 2;
+    const int qu = int(unsigned(qa) % 1024u), qv = int(unsigned(qa) / 1024u);
+    const wf4 st_tl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu, qv), st_tr = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 1, qv);
+    const wf4 st_bl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 2, qv), st_br = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 3, qv);
+    const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+    const float tsx = float(tex.ptr ? tex.width : 1), tsy = float(tex.ptr ? tex.height : 1);
+    const float persp = (brush_flags & 1) ? 1.0f : 0.0f;
+    for (int n = 0; n < 4; n++) {
+      float fx = (vlx[n] - local_rect.x) / (local_rect.z - local_rect.x), fy = (vly[n] - local_rect.y) / (local_rect.w - local_rect.y);
+      const float xx = (st_tr.x - st_tl.x) * fx + st_tl.x, xy = (st_tr.y - st_tl.y) * fx + st_tl.y, xw = (st_tr.w - st_tl.w) * fx + st_tl.w;
+      const float yx = (st_br.x - st_bl.x) * fx + st_bl.x, yy = (st_br.y - st_bl.y) * fx + st_bl.y, yw = (st_br.w - st_bl.w) * fx + st_bl.w;
+      const float zx = (yx - xx) * fy + xx, zy = (yy - xy) * fy + xy, zw = (yw - xw) * fy + xw;
+      fx = zx / zw; fy = zy / zw;
+      const float uu = (res0.z - res0.x) * fx + res0.x, vv = (res0.w - res0.y) * fy + res0.y;
+      const float pm = (1.0f - vww[n]) * persp + vww[n];
+      o.u[n] = uu / tsx * pm; o.v[n] = vv / tsy * pm;
+    }
+    o.uv_bounds = wf4{(res0.x + 0.5f) / tsx, (res0.y + 0.5f) / tsy, (res0.z - 0.5f) / tsx, (res0.w - 0.5f) / tsy};
+    o.tex_slot = WR_S_COLOR0;
+    const float opacity = wr_clamp(float(data1.y) / 65536.0f, 0.0f, 1.0f);
+    o.color = wf4{opacity, opacity, opacity, opacity};
+    o.has_color = 1; o.tail_clamp = 1; o.tail_modulate = 1;
+    o.kind = tex.format == WR_FMT_RGBA8 ? WR_PK_TEX_RGBA8 : WR_PK_UNSUPPORTED;
+    if (brush_flags & 1) o.kind = WR_PK_UNSUPPORTED;      // perspective interpolation: next
+    return;
+  }
   if (image == 4) {
     // brush_vs (brush_blend.glsl:43-87)
     const int src_address = data1.x;
@@ -2252,6 +2283,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush(d, arena, inst, 0, o); break;
     case WR_SH_BRUSH_IMAGE: wr_vs_brush(d, arena, inst, 1, o); break;
     case WR_SH_BRUSH_IMAGE_ALPHA: wr_vs_brush(d, arena, inst, 2, o); break;
+    case WR_SH_BRUSH_OPACITY:
+    case WR_SH_BRUSH_OPACITY_ALPHA: wr_vs_brush(d, arena, inst, 7, o); break;
     case WR_SH_BRUSH_IMAGE_REPEAT: wr_vs_brush(d, arena, inst, 5, o, nullptr, nullptr, &aux[gid].rep); break;
     case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: wr_vs_brush(d, arena, inst, 6, o, nullptr, nullptr, &aux[gid].rep); break;
     case WR_SH_BRUSH_LINEAR_GRADIENT:

@@ -52,6 +52,8 @@ enum WrShader {
   WR_SH_CS_CLIP_BOX_SHADOW,
   WR_SH_BRUSH_IMAGE,
   WR_SH_BRUSH_IMAGE_ALPHA,
+  WR_SH_BRUSH_OPACITY,             // brush_opacity [ANTIALIASING]
+  WR_SH_BRUSH_OPACITY_ALPHA,       // brush_opacity ALPHA_PASS[,ANTIALIASING]
   WR_SH_BRUSH_IMAGE_REPEAT,        // brush_image ANTIALIASING,REPETITION,TEXTURE_2D
   WR_SH_BRUSH_IMAGE_REPEAT_ALPHA,  // brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D
   WR_SH_BRUSH_LINEAR_GRADIENT,

@@ -1227,7 +1227,7 @@ CT_IDENTITY, CT_TABLE, CT_DISCRETE, CT_LINEAR, CT_GAMMA = 0, 1, 2, 3, 4
 
 
 def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=None, ops=None, only=None,
-                fractional=True, masked=False):
+                fractional=True, masked=False, shader="blend"):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -1345,15 +1345,20 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
                 continue
             if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
                 continue
-            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (addr, mode, ud, 0))
+            if shader == "opacity":     # brush_opacity: user data = (image source address, opacity * 65536)
+                opv = (65536, 49152, 20000, 70000, 1, 0, 32768)[zi % 7] if opaque is False else 65536
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (addr, opv, 0, 0))
+            else:
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (addr, mode, ud, 0))
             ct = None if opaque else clip_tasks[zi]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
             (op if opaque else al).append(frame.brush_instance(ph, clip_addr, edge_flags=15))
+        keys = ("brush_opacity", "brush_opacity ALPHA_PASS,ANTIALIASING") if shader == "opacity" else ("brush_blend", "brush_blend ALPHA_PASS")
         if op:
-            target.opaque.append(Step("brush_blend", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
+            target.opaque.append(Step(keys[0], "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
                                       None, "opaque", textures={0: t_atlas}))
         if al:
-            target.alpha.append(Step("brush_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
+            target.alpha.append(Step(keys[1], "PRIM_INSTANCES", np.array(al, dtype=np.int32),
                                      "PremultipliedAlpha", "alpha", textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
