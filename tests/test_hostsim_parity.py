@@ -64,6 +64,9 @@ CASES = [
     ("opacity_grid_masked", lambda: scenes.filter_grid(shader="opacity", masked=True, seed=74)),
     ("opacity_grid_wide", lambda: scenes.filter_grid(shader="opacity", width=2048, height=1024, n=160, seed=72)),
     ("opacity_grid_int", lambda: scenes.filter_grid(shader="opacity", width=1000, height=700, n=60, seed=73, fractional=False)),
+    ("masked_rects_aa", lambda: scenes.masked_rects(force_aa=True, fractional=True)),
+    ("masked_rects_rotated", lambda: scenes.masked_rects(rotate=True, seed=13)),
+    ("masked_rects_rotated_aa_wide", lambda: scenes.masked_rects(rotate=True, force_aa=True, fractional=True, seed=14, width=2048, n=300)),
     ("image_repeat", lambda: scenes.image_repeat()),
     ("image_repeat_nearest", lambda: scenes.image_repeat(nearest=True)),
     ("image_repeat_wide", lambda: scenes.image_repeat(width=2048, height=1024, n=200, seed=58)),

@@ -1904,8 +1904,9 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
                      info->kind == WR_SH_BRUSH_OPACITY || info->kind == WR_SH_BRUSH_OPACITY_ALPHA ||
                      info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA;
     const bool texquad = info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2;
-    if (colortex.internal_format == GL_RGBA8 && (img || texquad)) {
-      bool quads = !ids_clean(img ? WR_S_PRIM_HEADERS_I : WR_S_GPU_BUFFER_I, img);
+    const bool solid_masked = (info->kind == WR_SH_BRUSH_SOLID || info->kind == WR_SH_BRUSH_SOLID_ALPHA) && maskable;
+    if (colortex.internal_format == GL_RGBA8 && (img || texquad || solid_masked)) {
+      bool quads = !ids_clean(texquad ? WR_S_GPU_BUFFER_I : WR_S_PRIM_HEADERS_I, !texquad);
       if (!quads && d.blend != WR_BLEND_NONE && d.attr_off[0] >= 0 && d.attr_bytes[0] >= 12 && inst_stride >= 12) {
         const uint8_t* ib = (const uint8_t*)instb->buf + d.attr_off[0];
         for (int i = 0; i < instancecount && !quads; i++) {

@@ -1366,7 +1366,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   const bool aa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
   // textured kinds that can ride on WrQuadRec (general quads, swgl_antiAlias) when the host gave the launch the path for it
   const bool texq = (d.flags & WR_DF_QUADS) &&
-                    (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT);
+                    (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT ||
+                     (o.kind == WR_PK_SOLID && masked));
   if (aa && (o.kind != WR_PK_SOLID || masked) && !texq) {      // AA on masked solids / other shader families: "next"
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
@@ -1392,7 +1393,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       return;
     }
     P.kind = WR_PK_TEX_QUAD;
-    auxp->quad.base_kind = o.kind;
+    auxp->quad.base_kind = o.kind == WR_PK_SOLID ? (int)WR_PK_SOLID_MASKED : o.kind;
+    if (o.kind == WR_PK_SOLID) wr_pack_color(o.color, P.color);
     if (o.kind == WR_PK_TEX_REPEAT) auxp->quad.rep = rep;
     if (masked) P.flags |= WR_PF_MASKED;
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
@@ -2701,6 +2703,27 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
   const WrTexDesc& t = D->tex[Pl.tex_slot];
   const float Lu = wr_accum(S.luv[0], S.luvs[0], y - S.lrow), Lv = wr_accum(S.luv[1], S.luvs[1], y - S.lrow);
   const float Ru = wr_accum(S.ruv[0], S.ruvs[0], y - S.rrow), Rv = wr_accum(S.ruv[1], S.ruvs[1], y - S.rrow);
+  if (Q.base_kind == WR_PK_SOLID_MASKED) {
+    // flat colour under swgl_clipMask: the whole chunks of the span go through commit_masked_solid_span (colour x mask, then DO_AA
+    // inside blend_span with the mask key overridden, swgl_ext.h:11-23), the < 4 leftover pixels through main() + blend_pixels
+    // (DO_AA, then the mask: blend.h:452-460)
+    const int len = s1 - s0, spanlen = len >= 4 ? (len & ~3) : 0;
+    WrWide src; src.bg = Pl.color[0]; src.ra = Pl.color[1];
+    const bool in_span = x - s0 < spanlen;
+    if (in_span) {
+      const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
+      const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - Pl.mask_off[1]) * mt.stride + (x - Pl.mask_off[0])];
+      WrWide mm; mm.bg = mm.ra = m | (m << 16);
+      src = wr_apply_color(mm, Pl.color);
+    }
+    if (Q.aa) {
+      const uint32_t c0 = src.bg, c1 = src.ra;
+      src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+      src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
+    }
+    if (!in_span) src = wr_mask_src(Pl, D, x, y, src);
+    return HIT | wr_blend_rgba8(Pl.blend, dstp_, src, D);
+  }
   const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0);
   WrWide src = Q.base_kind == WR_PK_TEX_REPEAT ? wr_repeat_pixel_row(Pl, Q.rep, t, r, x - s0) : wr_tex_pixel_row(Pl, t, r, x - s0);
   if (Q.aa) {

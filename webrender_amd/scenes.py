@@ -615,7 +615,9 @@ def prim_clip_tasks(rng, rects, atlas=1024, fractional=False):
     return out
 
 
-def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional=False, tile_filter=None):
+def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional=False, tile_filter=None, force_aa=False, rotate=False):
+    """`force_aa`: BRUSH_FLAG_FORCE_AA + all edge flags on every prim; `rotate`: every other prim under a rotation about its
+    centre (anti-aliased by brush.glsl:150-170) -- masked solids on the general-quad walk."""
     rng, rects = random_rects(n, width, height, 16, 200, seed, fractional)
     rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
     alpha = np.round(rng.uniform(0.3, 1.0, size=n) * 255).astype(np.uint8)
@@ -640,22 +642,34 @@ def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional
         if fractional and i % 4 == 1:
             sx += 0.5
         clip_tasks.append(((float(mx), float(my), float(mx + mw), float(my + mh)), (sx, sy)))
+    tids = [0] * n
+    grow = np.zeros(n)
+    if rotate:
+        for i in range(0, n, 2):
+            cx, cy = (rects[i, 0] + rects[i, 2]) / 2, (rects[i, 1] + rects[i, 3]) / 2
+            th = float(rng.uniform(0, 2 * np.pi))
+            a = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            m = np.eye(4)
+            m[:2, :2] = a
+            m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+            tids[i] = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
+            grow[i] = 0.25 * float(np.hypot(rects[i, 2] - rects[i, 0], rects[i, 3] - rects[i, 1])) + 2
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
             continue
         x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
-        hit = np.nonzero((rects[:, 0] < x1) & (rects[:, 2] > x0) & (rects[:, 1] < y1) & (rects[:, 3] > y0))[0]
+        hit = np.nonzero((rects[:, 0] - grow < x1) & (rects[:, 2] + grow > x0) & (rects[:, 1] - grow < y1) & (rects[:, 3] + grow > y0))[0]
         tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
         target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
         task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
         inst = []
         for i in hit:
             addr = frame.gpu_cache.push([list(colors[i])])
-            ph = frame.add_prim_header(rects[i], (-BIG, -BIG, BIG, BIG), int(i + 1), addr, 0, task, (65535, 0, 0, 0))
+            ph = frame.add_prim_header(rects[i], (-BIG, -BIG, BIG, BIG), int(i + 1), addr, tids[i], task, (65535, 0, 0, 0))
             ct = clip_tasks[i]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
-            inst.append(frame.brush_instance(ph, clip_addr))
+            inst.append(frame.brush_instance(ph, clip_addr, brush_flags=1024 if force_aa else 0, edge_flags=15 if (force_aa or tids[i]) else 0))
         if inst:
             target.alpha.append(Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
                                      "PremultipliedAlpha", "alpha", textures={9: t_mask}))
