@@ -1,0 +1,40 @@
+"""Parity cases shared by the host-simulation (-m "not gpu") and the MI355X (-m gpu) suites."""
+from webrender_amd import scenes
+
+_TEXT = dict(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12)
+
+# Depth runs (draw_depth_span, rasterize.h:612-664): every shader family behind opaque occluders -- opaque-pass
+# content drawn after a nearer occluder, and the depth-tested alpha pass.  swgl restarts the span shader at every run
+# of passing pixels; all of these are held to 0 differing bytes.
+OCCLUDED = [
+    ("occluded_images", lambda: scenes.add_occluders(scenes.image_grid(), zmax=135)),
+    ("occluded_images_nearest", lambda: scenes.add_occluders(scenes.image_grid(nearest=True), zmax=135, seed=8)),
+    ("occluded_images_wide", lambda: scenes.add_occluders(scenes.image_grid(width=2048, height=1024, n=300, seed=52), n=120, zmax=330, seed=21)),
+    ("occluded_images_masked", lambda: scenes.add_occluders(scenes.image_grid(masked=True), zmax=135, seed=22)),
+    ("occluded_gradients", lambda: scenes.add_occluders(scenes.gradient_grid(), zmax=80, seed=9)),
+    ("occluded_filters", lambda: scenes.add_occluders(scenes.filter_grid(ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]), zmax=72, seed=10)),
+    ("occluded_opacity", lambda: scenes.add_occluders(scenes.filter_grid(shader="opacity"), zmax=72, seed=19)),
+    ("occluded_image_repeat", lambda: scenes.add_occluders(scenes.image_repeat(), zmax=80, seed=11)),
+    ("occluded_image_repeat_nearest", lambda: scenes.add_occluders(scenes.image_repeat(nearest=True), zmax=80, seed=23)),
+    ("occluded_rotated_rects", lambda: scenes.add_occluders(scenes.rotated_rects(), zmax=70, seed=12)),
+    ("occluded_rotated_rects_quad", lambda: scenes.add_occluders(scenes.rotated_rects(encoding="quad"), zmax=70, seed=24)),
+    ("rotated_rects_opaque_pass", lambda: scenes.rotated_rects(opaque_frac=0.5, seed=96)),       # rotated depth writers
+    ("occluded_rotated_images", lambda: scenes.add_occluders(scenes.rotated_images(), zmax=60, seed=13)),
+    ("occluded_rotated_images_repeat", lambda: scenes.add_occluders(scenes.rotated_images(repeat=True), zmax=60, seed=14)),
+    ("occluded_rotated_images_masked", lambda: scenes.add_occluders(scenes.rotated_images(masked=True), zmax=60, seed=25)),
+    ("occluded_rotated_images_quad", lambda: scenes.add_occluders(scenes.rotated_images(encoding="quad"), zmax=60, seed=20)),
+    ("occluded_text", lambda: scenes.add_occluders(scenes.cfg3_text(**_TEXT), zmax=100, seed=15)),
+    ("occluded_text_zoom", lambda: scenes.add_occluders(scenes.cfg3_text(glyph_zoom=1.25, **_TEXT), zmax=100, seed=16)),
+    ("occluded_text_modes", lambda: scenes.add_occluders(scenes.cfg3_text(color_modes=(0, 1, 2, 3), **_TEXT), zmax=100, seed=26)),
+    ("occluded_aa_rects", lambda: scenes.add_occluders(scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True,
+                                                                                    encoding="brush", aa_edges=15), zmax=120, seed=17)),
+    ("occluded_aa_rects_quad", lambda: scenes.add_occluders(scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True,
+                                                                                         encoding="quad", aa_edges=15), zmax=120, seed=27)),
+    ("occluded_masked_rects", lambda: scenes.add_occluders(scenes.masked_rects(), zmax=150, seed=18)),
+    ("occluded_masked_rects_rotated_aa", lambda: scenes.add_occluders(scenes.masked_rects(rotate=True, force_aa=True, fractional=True, seed=14), zmax=150, seed=28)),
+    # many thin occluders: rows with more depth runs, narrow runs (< 4 px: every pixel through main())
+    ("occluded_images_slivers", lambda: scenes.add_occluders(scenes.image_grid(seed=53), n=160, zmax=135, seed=29, wmin=2, wmax=40)),
+    ("occluded_gradients_slivers", lambda: scenes.add_occluders(scenes.gradient_grid(seed=66), n=160, zmax=80, seed=30, wmin=2, wmax=40)),
+]
+OCCLUDED_GOLDEN = ("occluded_images", "occluded_gradients", "occluded_rotated_images", "occluded_rotated_rects", "occluded_image_repeat",
+                   "occluded_aa_rects", "occluded_images_slivers")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_gpu_check.sh [bench args]  -- GPU parity suite, then the bench line (on the GPU box via gpurun)
+# usage: tools/gpu_check.sh [bench args]  -- GPU parity suite, then the bench line (on the GPU box via gpurun)
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | tail -8 > gpurun_out/gpu_tests.log
 cat gpurun_out/gpu_tests.log

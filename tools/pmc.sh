@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> "<counters>" [bench args]  -- PMC pass (kernel-trace only, no other trace domains)
+# usage: tools/pmc.sh <tag> "<counters>" [bench args]  -- PMC pass (kernel-trace only, no other trace domains)
 tag=$1; ctr=$2; shift; shift
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/$tag
 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/$tag -o r -- python bench.py --no-cpu-baseline "$@" > gpurun_out/$tag/bench.log 2>&1

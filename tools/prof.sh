@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> [bench args...]   -- runs on the GPU box via gpurun
+# usage: tools/prof.sh <tag> [bench args...]   -- runs on the GPU box via gpurun
 tag=$1; shift
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o r -- python bench.py --no-cpu-baseline "$@" > gpurun_out/$tag/bench.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_round.sh <tag>  -- on the GPU box: bench lines of every BASELINE config + rocprof kernel stats of cfg2/3/4
+# usage: tools/round.sh <tag>  -- on the GPU box: bench lines of every BASELINE config + rocprof kernel stats of cfg2/3/4
 tag=$1
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/$tag
 python bench.py > gpurun_out/$tag/bench_cfg2.json 2> gpurun_out/$tag/bench_cfg2.err

@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage: tools_trace.sh <tag> [bench args] -- per-launch kernel durations of one steady-state frame (on the GPU box)
+# usage: tools/trace.sh <tag> [bench args] -- per-launch kernel durations of one steady-state frame (on the GPU box)
 tag=$1
-bash tools_prof.sh "$@" > /dev/null
+bash tools/prof.sh "$@" > /dev/null
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open('gpurun_out/$tag/r_kernel_trace.csv')))

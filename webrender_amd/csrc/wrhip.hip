@@ -882,6 +882,7 @@ void flush_work(const std::vector<int>& sel_in) {
     inst.resize(inst_base + w.inst.size());
     if (!w.inst.empty()) memcpy(inst.data() + inst_base, w.inst.data(), w.inst.size());
     bool any_kept = false;
+    T.dw_first = 0; T.dw_end = 0;
     for (const WrDrawDesc& d0 : w.draws) {
       WrDrawDesc d = d0;
       d.target = oi;
@@ -896,6 +897,10 @@ void flush_work(const std::vector<int>& sel_in) {
       any_kept = true;
       if ((d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) && T.format == WR_FMT_RGBA8) L.any_depth = true;
       d.first_prim = prim_cursor;
+      if ((d.flags & WR_DF_DEPTH_WRITE) && d.shader != WR_SH_CLEAR_OP) {
+        if (T.dw_end <= T.dw_first) T.dw_first = prim_cursor;
+        T.dw_end = prim_cursor + d.count;
+      }
       prim_cursor += d.count;
       // per-row v table budget for draws whose prims can take the nearest-fast texture path
       d.vtab_base = -1; d.vtab_rows = 0;

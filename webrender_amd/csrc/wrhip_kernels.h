@@ -1807,31 +1807,84 @@ WR_DEVICE void wr_linear_span_pixel(const WrTexDesc& t, const float (&q)[4], con
 // interpolants at the span start, the filter decision of needsTextureLinear /
 // needsNearestFallback, and the nearest-fast row/column clamps.
 struct WrTexRow {
-  float ou, ov, su, sv;  // uv at span start, per-pixel step (rasterize.h:1003-1017)
-  int len, span;         // span length; pixels [0,span) go through draw_span, the rest through main()
+  float su, sv;          // per-pixel step of the interpolants (rasterize.h:1003-1017)
+  float lu[4], lv[4];    // the interpolant vector (init_interp, glsl.h:3084-3089) at the start of the span shader's sub-span:
+                         // lane i belongs to pixel x0 + i.  Without depth runs that is the row's span start; inside depth
+                         // run k > 0 the lanes carry the chain of step_interp_inputs() calls of the runs before it
+  int x0;                // first pixel of the sub-span (the row's span start, or the start of the depth run)
+  int len, span;         // sub-span length; pixels [0,span) go through draw_span, the rest through main()
   int filter;            // 0 nearest-fast, 1 linear fallback, 2 upscale, 3 fast, 4 downscale, -1 unsupported
   int ix, minX, maxX;    // nearest-fast: first texel column and clamps
   int srow;              // nearest-fast: clamped source row
 };
 
-// (Lu, Lv) / (Ru, Rv): the edge interpolants on this row, xl / xr the edges' x, [x0, x0 + len) the row's span
+WR_DEVICE int wr_find_run(const WrRuns* R, int x) {
+  for (int i = 0; i < R->n; i++) if (x >= R->s[i] && x < R->e[i]) return i;
+  return -1;
+}
+// The interpolant lanes at the start of depth run k of a row (draw_depth_span, rasterize.h:612-664).  Run 0 is
+// initialised like any span (rasterize.h:1003-1017 with span.start moved past the failed pixels); every later run is
+// reached through the calls the runs before it made: step_interp_inputs(drawn) after a span shader that consumed the
+// whole chunks (DISPATCH_DRAW_SPAN) or one step_interp_inputs() per chunk run by main(), one more for a partial chunk,
+// then skip(skip - (4 - partial)).  All of them are `lane += interp_step * (steps * 0.25f)` with interp_step = step * 4.
+WR_DEVICE void wr_run_lanes(const WrRuns* R, int k, float L, float step, float xl, bool span_shader, float (&lane)[4]) {
+  const float start = float(R->s[0]) + 0.5f - xl;
+  lane[0] = L + step * start;
+#pragma unroll
+  for (int i = 1; i < 4; i++) lane[i] = lane[i - 1] + step;
+  const float step4 = step * 4.0f;
+  for (int j = 0; j < k; j++) {
+    const int n = R->e[j] - R->s[j], rem = n & 3, full = n >> 2;
+    if (full) {
+      if (span_shader) {
+        const float ch = float(n & ~3) * 0.25f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lane[i] = lane[i] + step4 * ch;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) lane[i] = wr_accum(lane[i], step4 * 1.0f, full);
+      }
+    }
+    if (rem) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) lane[i] = lane[i] + step4 * 1.0f;
+    }
+    const int skip = R->s[j + 1] - R->e[j];
+    const float ch = float(skip - (rem ? 4 - rem : 0)) * 0.25f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) lane[i] = lane[i] + step4 * ch;
+  }
+}
+
+// (Lu, Lv) / (Ru, Rv): the edge interpolants on this row, xl / xr the edges' x, [x0, x0 + len) the row's span.
+// `runs` (with the pixel x that is being evaluated): the row's depth runs -- the setup is then that of the run holding x.
 WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu, float Lv, float Ru, float Rv, float xl, float xr,
-                                   int x0, int len) {
+                                   int x0, int len, const WrRuns* runs = nullptr, int x = 0, bool no_span = false) {
   WrTexRow r;
   float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
-  float start = float(x0) + 0.5f - xl;
-  r.ou = Lu + r.su * start; r.ov = Lv + r.sv * start;
-  r.len = len;
+  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || no_span;   // no draw_span for this program/target: all main()
+  const int k = runs ? wr_find_run(runs, x) : -1;
+  if (k >= 0) {
+    r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
+    wr_run_lanes(runs, k, Lu, r.su, xl, !shaded, r.lu);
+    wr_run_lanes(runs, k, Lv, r.sv, xl, !shaded, r.lv);
+  } else {
+    const float start = float(x0) + 0.5f - xl;
+    r.x0 = x0; r.len = len;
+    r.lu[0] = Lu + r.su * start; r.lv[0] = Lv + r.sv * start;
+#pragma unroll
+    for (int i = 1; i < 4; i++) { r.lu[i] = r.lu[i - 1] + r.su; r.lv[i] = r.lv[i - 1] + r.sv; }
+  }
   r.span = r.len >= 4 ? (r.len & ~3) : 0;
   r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
-  if (P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK) r.span = 0;     // no draw_span for this program/target: all main()
+  if (shaded) r.span = 0;
   if (r.span == 0 || P.kind == WR_PK_TEX_REPEAT) return r;
   float W = float(t.width), H = float(t.height);
   // lanes 0 and 1 of the uv vector handed to swgl_commitTexture* (shader-side offset included)
-  const float p0u = r.ou + P.uv_add[0], p0v = r.ov + P.uv_add[1];
-  const float ou1 = (r.ou + r.su) + P.uv_add[0], ov1 = (r.ov + r.sv) + P.uv_add[1];
+  const float p0u = r.lu[0] + P.uv_add[0], p0v = r.lv[0] + P.uv_add[1];
+  const float ou1 = r.lu[1] + P.uv_add[0], ov1 = r.lv[1] + P.uv_add[1];
   if (P.kind == WR_PK_TEX_R8) {
     r.filter = 1;   // blendTextureLinearR8 (swgl_ext.h:634-650): always the quantised fallback stepping
   } else if (!t.linear) {
@@ -1870,13 +1923,13 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   }
   return r;
 }
-WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
+WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y, const WrRuns* runs = nullptr, int x = 0, bool no_span = false) {
   // Edge::nextRow (rasterize.h:878-882) steps the interpolants by repeated addition
   const int k = y - P.y0;
   const bool lin = P.rows_linear != 0;
   const float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
   const float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
-  return wr_tex_row_span(P, t, Lu, Lv, Ru, Rv, P.xl, P.xr, P.x0, P.x1 - P.x0);
+  return wr_tex_row_span(P, t, Lu, Lv, Ru, Rv, P.xl, P.xr, P.x0, P.x1 - P.x0, runs, x, no_span);
 }
 
 // Quantised (1/128 texel) sample position of a fragment-shader (tail) pixel:
@@ -1884,9 +1937,8 @@ WR_DEVICE WrTexRow wr_tex_row(const WrPrim& P, const WrTexDesc& t, int y) {
 WR_DEVICE void wr_tex_tail_uv(const WrPrim& P, const WrTexRow& r, int n, float& cu, float& cv) {
   // init_interp lane (glsl.h:3084-3089), step_interp_inputs(drawn) once
   // (DISPATCH_DRAW_SPAN), then one step_interp_inputs() per 4-pixel chunk run by main()
-  float lu = r.ou, lv = r.ov;
   const int lane = (n - r.span) & 3, m = (n - r.span) >> 2;
-  for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
+  float lu = wr_pick4(r.lu, lane), lv = wr_pick4(r.lv, lane);
   if (r.span > 0) {
     float chunks = float(r.span) * 0.25f;
     lu = lu + (r.su * 4.0f) * chunks; lv = lv + (r.sv * 4.0f) * chunks;
@@ -1949,10 +2001,7 @@ WR_DEVICE WrWide wr_tex_pixel_row(const WrPrim& P, const WrTexDesc& t, const WrT
     } else if (r.filter == -1) {
       // blendTextureNearestRepeat<BLEND, false> (swgl_ext.h:774-858): nearest sampler, clamped, any scale
       float pu[4], pv[4];
-      {
-        float lu = r.ou, lv = r.ov;
-        for (int i = 0; i < 4; i++) { pu[i] = (lu + P.uv_add[0]) * W; pv[i] = (lv + P.uv_add[1]) * H; lu += r.su; lv += r.sv; }
-      }
+      for (int i = 0; i < 4; i++) { pu[i] = (r.lu[i] + P.uv_add[0]) * W; pv[i] = (r.lv[i] + P.uv_add[1]) * H; }
       const float stepx = 4.0f * (pu[1] - pu[0]), stepy = 4.0f * (pv[1] - pv[0]);
       const float minx = P.uv_bounds[0] * W, miny = P.uv_bounds[1] * H, maxx = P.uv_bounds[2] * W, maxy = P.uv_bounds[3] * H;
       const bool solid = (int(minx) >= int(maxx) || fabsf(stepx) * float(r.span) * 1.0f < 0.5f) &&
@@ -1964,13 +2013,7 @@ WR_DEVICE WrWide wr_tex_pixel_row(const WrPrim& P, const WrTexDesc& t, const WrT
       // Linear filters: exact per-variant evaluation (wr_linear_span_pixel)
       const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
       float q[4], qy[4];
-      {
-        float lu = r.ou, lv = r.ov;
-        for (int i = 0; i < 4; i++) {
-          q[i] = (lu + P.uv_add[0]) * W * qs + qo; qy[i] = (lv + P.uv_add[1]) * H * qs + qo;
-          lu += r.su; lv += r.sv;
-        }
-      }
+      for (int i = 0; i < 4; i++) { q[i] = (r.lu[i] + P.uv_add[0]) * W * qs + qo; qy[i] = (r.lv[i] + P.uv_add[1]) * H * qs + qo; }
       const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
       const float minx = wr_max(P.uv_bounds[0] * W * qs + qo, 0.0f);
       const float miny = wr_max(P.uv_bounds[1] * H * qs + qo, 0.0f);
@@ -1995,8 +2038,9 @@ WR_DEVICE WrWide wr_tex_pixel_row(const WrPrim& P, const WrTexDesc& t, const WrT
   wr_tex_tail_uv(P, r, n, cu, cv);
   return wr_tex_tail_texel(P, t, cu, cv);
 }
-WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y) {
-  return wr_tex_pixel_row(P, t, wr_tex_row(P, t, y), x - P.x0);
+WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y, const WrRuns* runs = nullptr) {
+  const WrTexRow r = wr_tex_row(P, t, y, runs, x);
+  return wr_tex_pixel_row(P, t, r, x - r.x0);
 }
 
 // ---------------------------------------------------------------------------
@@ -2034,9 +2078,8 @@ WR_DEVICE WrWide wr_repeat_pixel_row(const WrPrim& P, const WrRepeatRec& R, cons
   const float W = float(t.width), H = float(t.height);
   if (n >= span) {
     // main(): compute_repeated_uvs (brush_image.glsl:318-341), clamp to v_uv_sample_bounds, texture()
-    float lu = r.ou, lv = r.ov;
     const int lane = (n - span) & 3, m = (n - span) >> 2;
-    for (int i = 0; i < lane; i++) { lu += r.su; lv += r.sv; }
+    float lu = wr_pick4(r.lu, lane), lv = wr_pick4(r.lv, lane);
     if (span > 0) {
       const float chunks = float(span) * 0.25f;
       lu = lu + (r.su * 4.0f) * chunks; lv = lv + (r.sv * 4.0f) * chunks;
@@ -2057,10 +2100,7 @@ WR_DEVICE WrWide wr_repeat_pixel_row(const WrPrim& P, const WrRepeatRec& R, cons
   }
   const int k = n & 3, c = n >> 2, total = span >> 2;
   float ux[4], uy[4];
-  {
-    float lu = r.ou, lv = r.ov;
-    for (int i = 0; i < 4; i++) { ux[i] = lu; uy[i] = lv; lu += r.su; lv += r.sv; }
-  }
+  for (int i = 0; i < 4; i++) { ux[i] = r.lu[i]; uy[i] = r.lv[i]; }
   const float step_x = 4.0f * (ux[1] - ux[0]), step_y = 4.0f * (uy[1] - uy[0]);
   const uint32_t* buf = (const uint32_t*)t.ptr;
   WrWide s;
@@ -2147,9 +2187,10 @@ WR_DEVICE WrWide wr_repeat_pixel_row(const WrPrim& P, const WrRepeatRec& R, cons
   if (P.flags & WR_PF_HAS_COLOR) s = wr_apply_color(s, P.color);
   return s;
 }
-__device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatRec* Rp, const WrDrawDesc* D, int x, int y) {
+__device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatRec* Rp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
   const WrTexDesc& t = D->tex[Pp->tex_slot];
-  return wr_repeat_pixel_row(*Pp, *Rp, t, wr_tex_row(*Pp, t, y), x - Pp->x0);
+  const WrTexRow r = wr_tex_row(*Pp, t, y, runs, x, Rp->no_span != 0);
+  return wr_repeat_pixel_row(*Pp, *Rp, t, r, x - r.x0);
 }
 
 // Compact raster record.  Solid prims on RGBA8 targets drawn without blending
@@ -2411,7 +2452,7 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   if (r.span == 0) return false;
   const float W = float(t.width);
   bool x_ok;
-  const float px0 = (r.ou + P.uv_add[0]) * W, px1 = ((r.ou + r.su) + P.uv_add[0]) * W;
+  const float px0 = (r.lu[0] + P.uv_add[0]) * W, px1 = (r.lu[1] + P.uv_add[0]) * W;
   const int sp = (r.span & ~127) + 128;
   const int scaled = int(roundf((px1 - px0) * float(sp)));
   if (!t.linear) x_ok = scaled == sp;
@@ -2421,7 +2462,7 @@ WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& 
   __builtin_memset(&T, 0, sizeof(T));
   T.ptr = t.ptr; T.stride = t.stride; T.wh = uint32_t(t.width) | (uint32_t(t.height) << 16);
   T.span = r.span; T.y0 = P.y0;
-  T.ix0 = int((r.ou + P.uv_add[0]) * W);
+  T.ix0 = int((r.lu[0] + P.uv_add[0]) * W);
   const int minUx = int(P.uv_bounds[0] * W), maxUx = int(P.uv_bounds[2] * W);
   T.tix[0] = wr_iclamp(minUx, 0, t.width - 1);
   T.tix[1] = wr_iclamp(maxUx, T.tix[0], t.width - 1);
@@ -2575,11 +2616,30 @@ __global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_seg
   }
 }
 
+// The span of row y of a general quad (aa_span, rasterize.h:520-561): [s0, s1) -- with swgl_antiAlias the rounded-out one,
+// [la0, ra1).  False: the row is outside the walk.
+WR_DEVICE bool wr_quad_row_span(const WrQuadRec& Q, int y, int& s0, int& s1) {
+  int si = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  if (si < 0) return false;
+  const WrQuadSeg& S = Q.seg[si];
+  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
+  if (!Q.aa) {
+    s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+  } else {
+    const float radl = 0.5f * fabsf(S.ls), radr = 0.5f * fabsf(S.rs);
+    s0 = S.lmask ? int(floorf(wr_clamp(xl - radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+    s1 = S.rmask ? int(ceilf(wr_clamp(xr + radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+  }
+  return true;
+}
+
 // One pixel of a solid colour on a general quad: this row's span from the edge instances of its run
 // (aa_span / aa_edge / aa_dist, rasterize.h:480-562), the pixel's coverage (DO_AA, blend.h:433-446), the blend.
 // Returns the new pixel in the low word and 1 << 32 when the pixel is inside the row's span.
 __device__ __noinline__ unsigned long long wr_quad_pixel_rgba8(const WrQuadRec* Qp, const WrDrawDesc* D, int blend, uint32_t c0, uint32_t c1,
-                                                                int x, int y, uint32_t dstp_) {
+                                                                int x, int y, uint32_t dstp_, const WrRuns* runs = nullptr) {
   const WrQuadRec& Q = *Qp;
   const unsigned long long dstp = dstp_;
   const unsigned long long HIT = 1ull << 32;
@@ -2605,7 +2665,10 @@ __device__ __noinline__ unsigned long long wr_quad_pixel_rgba8(const WrQuadRec* 
   float lstart = 256.0f, lend = 0.0f, rstart = 256.0f, rend = 0.0f;
   if (S.lmask) { const float dx = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.ls * S.ls)); lstart = 128.0f + dx * (xl - 0.5f); lend = -dx; }
   if (S.rmask) { const float dx = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.rs * S.rs)); rstart = 128.0f + dx * (xr - 0.5f); rend = -dx; }
-  const int n = x - la0, lane = n & 3, base = la0 + (n & ~3);
+  // the 4-pixel chunks DO_AA sees start at the span start -- with depth runs, at the start of the run holding x
+  int cs = la0;
+  if (runs) { const int k = wr_find_run(runs, x); if (k >= 0) cs = runs->s[k]; }
+  const int n = x - cs, lane = n & 3, base = cs + (n & ~3);
   const float off = float(4 * (base - la1));
   const float dl = (lstart + float(la1 + lane) * lend) + (lend / 4.0f) * off;
   const float dr = (rstart + float(la1 + lane) * rend) + (rend / 4.0f) * off;
@@ -2646,7 +2709,7 @@ WR_DEVICE WrWide wr_mask_src(const WrPrim& P, const WrDrawDesc* D, int x, int y,
 // Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
 // Kept out of line so the fast paths below stay small and the 16 pixels of a
 // lane stay in registers.
-__device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const WrDrawDesc* D, int x, int y, uint32_t dstp) {
+__device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const WrDrawDesc* D, int x, int y, uint32_t dstp, const WrRuns* runs = nullptr) {
   const WrPrim& P = *Pp;
   WrWide src;
   if (P.kind == WR_PK_SOLID) {
@@ -2658,7 +2721,7 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
     WrWide mm; mm.bg = mm.ra = m | (m << 16);
     src = wr_apply_color(mm, P.color);
   } else {
-    src = wr_mask_src(P, D, x, y, wr_tex_pixel(P, D->tex[P.tex_slot], x, y));
+    src = wr_mask_src(P, D, x, y, wr_tex_pixel(P, D->tex[P.tex_slot], x, y, runs));
   }
   return wr_blend_rgba8(P.blend, dstp, src, D, P.color);
 }
@@ -2667,7 +2730,7 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
 // pixel's coverage as in wr_quad_pixel_rgba8, the edge interpolants stepped row by row (Edge::nextRow), then the base
 // kind's span shader / main() evaluation of pixel x - span.start, DO_AA ahead of the clip mask (blend.h:452-460).
 __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim* Pp, const WrQuadRec* Qp, const WrDrawDesc* D, int x, int y,
-                                                                    uint32_t dstp_) {
+                                                                    uint32_t dstp_, const WrRuns* runs = nullptr) {
   const WrQuadRec& Q = *Qp;
   const unsigned long long dstp = dstp_;
   const unsigned long long HIT = 1ull << 32;
@@ -2691,12 +2754,18 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     float lstart = 256.0f, lend = 0.0f, rstart = 256.0f, rend = 0.0f;
     if (S.lmask) { const float dx = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.ls * S.ls)); lstart = 128.0f + dx * (xl - 0.5f); lend = -dx; }
     if (S.rmask) { const float dx = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.rs * S.rs)); rstart = 128.0f + dx * (xr - 0.5f); rend = -dx; }
-    const int n = x - la0, lane = n & 3, base = la0 + (n & ~3);
+    int cs = la0;
+    if (runs) { const int k = wr_find_run(runs, x); if (k >= 0) cs = runs->s[k]; }
+    const int n = x - cs, lane = n & 3, base = cs + (n & ~3);
     const float off = float(4 * (base - la1));
     const float dl = (lstart + float(la1 + lane) * lend) + (lend / 4.0f) * off;
     const float dr = (rstart + float(la1 + lane) * rend) + (rend / 4.0f) * off;
     cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
     s0 = la0; s1 = ra1;
+  }
+  if (runs) {        // the span the shader sees is the depth run holding x
+    const int k = wr_find_run(runs, x);
+    if (k >= 0) { s0 = runs->s[k]; s1 = runs->e[k]; } else runs = nullptr;
   }
   WrPrim Pl = *Pp;
   Pl.kind = (int16_t)Q.base_kind;
@@ -2724,8 +2793,8 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     if (!in_span) src = wr_mask_src(Pl, D, x, y, src);
     return HIT | wr_blend_rgba8(Pl.blend, dstp_, src, D);
   }
-  const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0);
-  WrWide src = Q.base_kind == WR_PK_TEX_REPEAT ? wr_repeat_pixel_row(Pl, Q.rep, t, r, x - s0) : wr_tex_pixel_row(Pl, t, r, x - s0);
+  const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0, runs, x, Q.base_kind == WR_PK_TEX_REPEAT && Q.rep.no_span != 0);
+  WrWide src = Q.base_kind == WR_PK_TEX_REPEAT ? wr_repeat_pixel_row(Pl, Q.rep, t, r, x - r.x0) : wr_tex_pixel_row(Pl, t, r, x - r.x0);
   if (Q.aa) {
     const uint32_t c0 = src.bg, c1 = src.ra;
     src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
@@ -2770,7 +2839,8 @@ WR_DEVICE WrWide wr_sample_gradient(const float* stops, float entry) {
   return w;
 }
 
-__device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradRec* Gp, const WrDrawDesc* D, int x, int y) {
+// `runs`: the row's depth runs; only pixel x is evaluated then (out.v[0]), inside the run that holds it.
+__device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradRec* Gp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
   const WrPrim& P = *Pp;
   const WrGradRec& G = *Gp;
   WrGrad4 out;
@@ -2784,20 +2854,28 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
-  const float start = float(P.x0) + 0.5f - P.xl;
-  const float ou = Lu + su * start, ov = Lv + sv * start;
-  const int len = P.x1 - P.x0;
+  const int kr = runs ? wr_find_run(runs, x) : -1;
+  const int X0 = kr >= 0 ? runs->s[kr] : P.x0;                    // start of the sub-span the span shader sees
+  const int len = kr >= 0 ? runs->e[kr] - X0 : P.x1 - P.x0;
+  const float start = float(kr >= 0 ? runs->s[0] : P.x0) + 0.5f - P.xl;
+  const float sdx = G.scale_dir[0], sdy = G.scale_dir[1];
   int span = len >= 4 ? (len & ~3) : 0;
   // init_interp (glsl.h:3084-3089)
   float px[4], py[4];
-  px[0] = ou; py[0] = ov;
+  px[0] = Lu + su * start; py[0] = Lv + sv * start;
 #pragma unroll
   for (int i = 1; i < 4; i++) { px[i] = px[i - 1] + su; py[i] = py[i - 1] + sv; }
+  if (kr > 0) {
+    const bool spans = G.stops && wr_isfinite(((px[1] - px[0]) * 4.0f) * sdx + ((py[1] - py[0]) * 4.0f) * sdy);
+    wr_run_lanes(runs, kr, Lu, su, P.xl, spans, px);
+    wr_run_lanes(runs, kr, Lv, sv, P.xl, spans, py);
+  }
+  const float ou = px[0], ov = py[0];
+  const float lu1 = px[1], lu2 = px[2], lu3 = px[3], lv1 = py[1], lv2 = py[2], lv3 = py[3];   // the lanes at the sub-span start
   const float psx = (px[1] - px[0]) * 4.0f, psy = (py[1] - py[0]) * 4.0f;   // dFdx(pos) * 4
-  const float sdx = G.scale_dir[0], sdy = G.scale_dir[1];
   const float delta = psx * sdx + psy * sdy;
   if (!G.stops || !wr_isfinite(delta)) span = 0;
-  const int n_lo = wr_imax(x - P.x0, 0), n_hi = wr_imin(x + 3 - P.x0, len - 1);
+  const int n_lo = wr_imax(x - X0, 0), n_hi = wr_imin(x + (kr >= 0 ? 0 : 3) - X0, len - 1);
   if (n_hi < n_lo) return out;
   const float size = 128.0f;
   if (n_lo < span) {
@@ -2868,7 +2946,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-              const int o = P.x0 + 4 * c + i - x;
+              const int o = X0 + 4 * c + i - x;
               if (o >= 0 && o < 4) { out.v[o].bg = ch[i][0] | (ch[i][1] << 16); out.v[o].ra = ch[i][2] | (ch[i][3] << 16); }
             }
           }
@@ -2887,7 +2965,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
       if (chunk >= c_lo && chunk <= c_hi) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int o = P.x0 + 4 * chunk + i - x;
+          const int o = X0 + 4 * chunk + i - x;
           if (o >= 0 && o < 4) out.v[o] = wr_sample_gradient(stops, wr_clamp(off[i] * size + 1.0f, 0.0f, 1.0f + size));
         }
       }
@@ -2902,8 +2980,8 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
     const WrTexDesc& gb = D->tex[WR_S_GPU_BUFFER_F];
     for (int n = wr_imax(n_lo, span); n <= n_hi; n++) {
       const int lane = (n - span) & 3, m = (n - span) >> 2;
-      float lu = ou, lv = ov;
-      for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
+      float lu = lane == 0 ? ou : (lane == 1 ? lu1 : (lane == 2 ? lu2 : lu3));
+      float lv = lane == 0 ? ov : (lane == 1 ? lv1 : (lane == 2 ? lv2 : lv3));
       if (span > 0) {
         const float chunks = float(span) * 0.25f;
         lu = lu + (su * 4.0f) * chunks; lv = lv + (sv * 4.0f) * chunks;
@@ -2918,7 +2996,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
       const wf4 t1 = wr_fetch_f(gb, int(unsigned(addr) % 1024u) + 1, int(unsigned(addr) / 1024u));
       uint32_t pc[2];
       wr_pack_color(wf4{t0.x + t1.x * ef, t0.y + t1.y * ef, t0.z + t1.z * ef, t0.w + t1.w * ef}, pc);
-      out.v[P.x0 + n - x].bg = pc[0]; out.v[P.x0 + n - x].ra = pc[1];
+      out.v[X0 + n - x].bg = pc[0]; out.v[X0 + n - x].ra = pc[1];
     }
   }
   return out;
@@ -2959,14 +3037,14 @@ WR_DEVICE float wr_glsl_pow(float x, float y) {     // glsl.h:797-799
   return (x == 0.0f || x == 1.0f) ? x : wr_approx_pow2(wr_approx_log2(x) * y);
 }
 
-__device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, int x, int y) {
+__device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
   const WrPrim& P = *Pp;
   const WrFilterRec& F = *Fp;
   const WrTexDesc& t = D->tex[P.tex_slot];
   // v_uv of this pixel as the 4-wide fragment loop steps it, clamped to v_uv_sample_bounds
-  const WrTexRow r = wr_tex_row(P, t, y);
+  const WrTexRow r = wr_tex_row(P, t, y, runs, x);
   float cu, cv;
-  wr_tex_tail_uv(P, r, x - P.x0, cu, cv);
+  wr_tex_tail_uv(P, r, x - r.x0, cu, cv);
   // texture(sColor0, uv): texture.h:1028-1071 (linear RGBA8, 7-bit fractions) / nearest
   const float W = float(t.width), H = float(t.height);
   float cr, cg, cb, ca;
@@ -3748,6 +3826,138 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Depth runs (draw_depth_span, rasterize.h:612-664).  A depth-tested prim whose pixels depend on where the span
+// shader's sub-span starts -- interpolated varyings, 4-pixel chunk phase of an AA ramp -- is drawn by swgl one run of
+// passing pixels at a time.  The depth a pixel holds when prim P arrives is min(clear value, z of every earlier
+// depth-writing prim covering it) (LEQUAL / LESS only ever lower it), so the runs of a row follow from geometry: P's
+// row span minus the row spans of the earlier depth writers with z below P's.  They extend across bins, whose depth
+// lives in other workgroups' registers, hence geometry and not the register file.
+//   phase 1   the wave scans the target's depth-writing prims that precede P (WrTargetDesc::dw_first / dw_end), 64
+//             records per step; the ones that can hide part of P on this strip's rows go to an LDS list (ballot-compacted)
+//   phase 2   (candidate, strip row) pairs spread over the lanes: the candidate's interval on that row -> LDS
+//   phase 3   16 row-owning lanes sweep their row: the runs [s, e) of pixels no candidate covers -> LDS (WrRuns)
+// The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
+// nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
+WR_DEVICE bool wr_kind_needs_runs(int kind) {
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER ||
+         kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
+}
+// interval of prim `ci` (a depth writer) on row y
+WR_DEVICE void wr_occ_interval(const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, int ci, int y, int& lo, int& hi) {
+  const WrRec Rc = recs[ci];
+  lo = hi = 0;
+  if (y < Rc.y0 || y >= Rc.y1) return;
+  const int kind = Rc.kbf & 0xFF;
+  if (kind == WR_PK_SOLID_QUAD || kind == WR_PK_TEX_QUAD) {
+    int s0, s1;
+    if (wr_quad_row_span(aux[ci].quad, y, s0, s1) && s1 > s0) { lo = wr_imax(s0, Rc.x0); hi = wr_imin(s1, Rc.x1); if (hi < lo) hi = lo; }
+    return;
+  }
+  lo = Rc.x0; hi = Rc.x1;
+}
+// phase 3 for one row: [a, b) minus the candidate intervals iv[c] = (lo, hi), c < nc
+template <typename IV>
+WR_DEVICE void wr_sweep_runs(WrRuns& R, int a, int b, int nc, IV iv) {
+  int n = 0, pos = a;
+  bool overflow = false;
+  while (pos < b) {
+    int s = pos;
+    for (bool moved = true; moved;) {
+      moved = false;
+      for (int c = 0; c < nc; c++) { int lo, hi; iv(c, lo, hi); if (lo <= s && s < hi) { s = hi; moved = true; } }
+    }
+    if (s >= b) break;
+    int e = b;
+    for (int c = 0; c < nc; c++) { int lo, hi; iv(c, lo, hi); if (hi > lo && lo > s && lo < e) e = lo; }
+    if (n == WR_MAX_RUNS) { overflow = true; break; }
+    R.s[n] = s; R.e[n] = e; n++;
+    pos = e;
+  }
+  R.n = overflow ? 0 : n;
+}
+template <int R4>
+WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, int pidx,
+                                      int x0, int y0, int x1, int y1, uint32_t z, uint32_t kbf, int wy0, int lane, int wave,
+                                      WrUnsupportedCounters* dbg_unused = nullptr) {
+  const int kind = kbf & 0xFF, flags = (kbf >> 16) & 0xFF;
+  const bool less = (flags & WR_PF_DEPTH_LESS) != 0;
+  const int end = wr_imin(T.dw_end, pidx);
+  const int ry0 = wr_imax(y0, wy0), ry1 = wr_imin(y1, wy0 + 4 * R4);
+  const bool quad = kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD;
+#ifdef WRHIP_HOSTSIM
+  // serial restatement: this thread does the whole wave's work for its own rows
+  static int cidx[WR_MAX_OCC];
+  static WrRuns runs[4 * R4];
+  int nc = 0;
+  for (int i = T.dw_first; i < end; i++) {
+    const WrRec Rc = recs[i];
+    const int ok = Rc.kbf & 0xFF, of = (Rc.kbf >> 16) & 0xFF;
+    if (!(of & WR_PF_DEPTH_WRITE) || ok == WR_PK_NONE || ok == WR_PK_UNSUPPORTED || ok == WR_PK_CLEAR) continue;
+    if (!(less ? Rc.z <= z : Rc.z < z)) continue;
+    if (Rc.x0 >= x1 || Rc.x1 <= x0 || Rc.y0 >= ry1 || Rc.y1 <= ry0) continue;
+    if (nc < WR_MAX_OCC) cidx[nc] = i;
+    nc++;
+  }
+  if (nc == 0) return nullptr;
+  if (nc > WR_MAX_OCC) return nullptr;          // (more occluders than the list holds: evaluated from the span start, as if unoccluded)
+  for (int j = 0; j < R4; j++) {
+    const int r = (lane >> 4) + 4 * j, y = wy0 + r;
+    WrRuns& RR = runs[r];
+    RR.n = 0;
+    if (y < ry0 || y >= ry1) continue;
+    int a = x0, b = x1;
+    if (quad) { int s0, s1; if (!wr_quad_row_span(aux[pidx].quad, y, s0, s1)) continue; a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
+    wr_sweep_runs(RR, a, b, nc, [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, cidx[c], y, lo, hi); });
+  }
+  return runs;
+#else
+  __shared__ int cidx[4][WR_MAX_OCC];
+  __shared__ short ivs[4][WR_MAX_OCC][4 * R4][2];
+  __shared__ WrRuns runs[4][4 * R4];
+  int nc = 0;
+  for (int b = T.dw_first; b < end; b += 64) {
+    const int i = b + lane;
+    bool hit = false;
+    if (i < end) {
+      const uint4* rp = (const uint4*)&recs[i];
+      const uint4 ra = rp[0], rb = rp[1];
+      const int ok = rb.y & 0xFF, of = (rb.y >> 16) & 0xFF;
+      hit = (of & WR_PF_DEPTH_WRITE) && ok != WR_PK_NONE && ok != WR_PK_UNSUPPORTED && ok != WR_PK_CLEAR && (less ? rb.x <= z : rb.x < z) &&
+            (int)ra.x < x1 && (int)ra.z > x0 && (int)ra.y < ry1 && (int)ra.w > ry0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int slot = nc + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < WR_MAX_OCC) cidx[wave][slot] = i;
+    }
+    nc += __popcll(m);
+  }
+  if (nc == 0 || nc > WR_MAX_OCC) return nullptr;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int idx = lane; idx < nc * 4 * R4; idx += 64) {
+    const int c = idx / (4 * R4), r = idx - c * (4 * R4);
+    int lo, hi;
+    wr_occ_interval(recs, aux, cidx[wave][c], wy0 + r, lo, hi);
+    ivs[wave][c][r][0] = (short)lo; ivs[wave][c][r][1] = (short)hi;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 4 * R4) {
+    const int r = lane, y = wy0 + r;
+    WrRuns& RR = runs[wave][r];
+    RR.n = 0;
+    if (y >= ry0 && y < ry1) {
+      int a = x0, b = x1;
+      bool ok = true;
+      if (quad) { int s0, s1; ok = wr_quad_row_span(aux[pidx].quad, y, s0, s1); a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
+      if (ok) wr_sweep_runs(RR, a, b, nc, [&](int c, int& lo, int& hi) { lo = ivs[wave][c][r][0]; hi = ivs[wave][c][r][1]; });
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return runs[wave];
+#endif
+}
+
 // Pixels are held as two registers of 2 x 16-bit fields: lo = (B, R), hi = (G, A)
 // of the BGRA8 texel -- i.e. WideRGBA8 with the channels paired so that one
 // 32-bit multiply serves two channels (fields never carry into each other:
@@ -3762,7 +3972,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
                              const int x0, const int y0, const int x1, const int y1, const uint32_t z,
                              const uint32_t kbf, const uint32_t c0, const uint32_t c1,
                              const WrPrim* Pp, const WrAux* Ap, const WrDrawDesc* draws, const float* __restrict__ vtab,
-                             const int px, const int py, const int wx0, const int wy0) {
+                             const int px, const int py, const int wx0, const int wy0, const WrRuns* rr = nullptr) {
   constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
   constexpr int NPX = 4 * R;
   const int kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
@@ -3844,7 +4054,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     return;
   }
   if ((FEAT & WR_FEAT_TEX) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_RGBA8 && (blend == WR_BLEND_NONE || blend == WR_BLEND_PREMULT) &&
-      !(flags & WR_PF_MASKED) && Ap->tex.simple >= 2) {
+      !(flags & WR_PF_MASKED) && Ap->tex.simple >= 2 && !rr) {
     // ---- swgl_commitTexture*RGBA8, nearest-fast rows (blendTextureNearestFast,
     // swgl_ext.h:475-537): the source row of every target row was resolved by
     // the setup kernel (unit rows) or is evaluated per lane-row; a lane fetches its 4 texels of each row.
@@ -4001,7 +4211,8 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
 #pragma unroll
     for (int j = 0; j < R; j++) {
       if (!cy[j]) continue;
-      const WrGrad4 g4 = wr_gradient_row4(Pp, &Ap->grad, D, px, py + 4 * j);
+      WrGrad4 g4;
+      if (!rr) g4 = wr_gradient_row4(Pp, &Ap->grad, D, px, py + 4 * j);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
@@ -4012,6 +4223,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
           if (dwrite) dep[q] = in ? z : dep[q];
         }
         if (!in) continue;
+        if (rr) g4.v[i] = wr_gradient_row4(Pp, &Ap->grad, D, px + i, py + 4 * j, &rr[py + 4 * j - wy0]).v[0];   // depth runs: pixel by pixel
         const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), wr_mask_src(*Pp, D, px + i, py + 4 * j, g4.v[i]), D);
         plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
       }
@@ -4046,8 +4258,9 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (dwrite) dep[q] = in ? z : dep[q];
       }
       if (!in) continue;
-      const WrWide raw = kind == WR_PK_FILTER ? wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2))
-                                              : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2));
+      const WrRuns* rq = rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr;
+      const WrWide raw = kind == WR_PK_FILTER ? wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2), rq)
+                                              : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2), rq);
       const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), raw);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
@@ -4064,9 +4277,10 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       bool pass = true;
       if (dtest) pass = dless ? (z < dep[q]) : (z <= dep[q]);
       if (!pass) continue;
-      const unsigned long long rr = wr_quad_tex_pixel_rgba8(Pp, &Ap->quad, D, px + (q & 3), py + 4 * (q >> 2), before);
-      if (!(rr >> 32)) continue;
-      const uint32_t r = (uint32_t)rr;
+      const unsigned long long hr = wr_quad_tex_pixel_rgba8(Pp, &Ap->quad, D, px + (q & 3), py + 4 * (q >> 2), before,
+                                                            rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
+      if (!(hr >> 32)) continue;
+      const uint32_t r = (uint32_t)hr;
       if (dtest && dwrite) dep[q] = z;
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
@@ -4082,9 +4296,10 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       bool pass = true;
       if (dtest) pass = dless ? (z < dep[q]) : (z <= dep[q]);
       if (!pass) continue;
-      const unsigned long long rr = wr_quad_pixel_rgba8(&Ap->quad, D, blend, c0, c1, px + (q & 3), py + 4 * (q >> 2), before);
-      if (!(rr >> 32)) continue;
-      const uint32_t r = (uint32_t)rr;
+      const unsigned long long hr = wr_quad_pixel_rgba8(&Ap->quad, D, blend, c0, c1, px + (q & 3), py + 4 * (q >> 2), before,
+                                                        rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
+      if (!(hr >> 32)) continue;
+      const uint32_t r = (uint32_t)hr;
       if (dtest && dwrite) dep[q] = z;
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
@@ -4103,7 +4318,9 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (dwrite) dep[q] = in ? z : dep[q];
       }
       if (!in) continue;
-      const uint32_t r = wr_aa_pixel_rgba8(&A, D, blend, c0, c1, px + (q & 3) - x0, x0, plo[q] | (phi[q] << 8));
+      int cs = x0;             // start of the 4-pixel chunks: the span start, or the start of the depth run holding the pixel
+      if (rr) { const WrRuns* rq = &rr[py + 4 * (q >> 2) - wy0]; const int k = wr_find_run(rq, px + (q & 3)); if (k >= 0) cs = rq->s[k]; }
+      const uint32_t r = wr_aa_pixel_rgba8(&A, D, blend, c0, c1, px + (q & 3) - cs, cs, plo[q] | (phi[q] << 8));
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;
@@ -4122,7 +4339,8 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     if (in) {
       if (FMT == WR_FMT_RGBA8) {
         if (FEAT & WR_FEAT_GENERIC) {
-          uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + (q & 3), py + 4 * (q >> 2), plo[q] | (phi[q] << 8));
+          uint32_t r = wr_generic_pixel_rgba8(Pp, D, px + (q & 3), py + 4 * (q >> 2), plo[q] | (phi[q] << 8),
+                                              rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
           plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
         }
       } else {
@@ -4365,13 +4583,18 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const WrRec Rc = recs[base + bit];
       if (Rc.x1 <= wx0 || Rc.x0 >= wx0 + WR_BIN_W || Rc.y1 <= wy0 || Rc.y0 >= wy0 + STRIP) continue;
       const int rblend = (Rc.kbf >> 8) & 0xFF;
-      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 || (Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+      const WrRuns* rr = nullptr;
+      if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
+        if (((Rc.kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(Rc.kbf & 0xFF) && T.dw_end > T.dw_first && base + bit > T.dw_first)
+          rr = wr_build_runs<R>(T, recs, aux, base + bit, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, wy0, lane, wave);
+      }
+      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED || ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
         wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, aux[base + bit].tex,
                                   draws, &prims[base + bit], px, py);
       else
         wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, Rc.c0, Rc.c1, &prims[base + bit],
-                                     &aux[base + bit], draws, vtab, px, py, wx0, wy0);
+                                     &aux[base + bit], draws, vtab, px, py, wx0, wy0, rr);
     }
   }
 #else
@@ -4410,11 +4633,16 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const uint32_t z = __builtin_amdgcn_readlane((int)rb.x, bit), kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
       const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
       const int rblend = (kbf >> 8) & 0xFF;
-      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_TEX_R8 || (kbf & 0xFF) == WR_PK_SOLID_MASKED) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
+      const WrRuns* rr = nullptr;
+      if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
+        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && T.dw_end > T.dw_first && base + bit > T.dw_first)
+          rr = wr_build_runs<R>(T, recs, aux, base + bit, x0, y0, x1, y1, z, kbf, wy0, lane, wave);
+      }
+      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_SOLID_MASKED || ((kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
         wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[base + bit].tex, draws, &prims[base + bit], px, py);
       else
-        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], &aux[base + bit], draws, vtab, px, py, wx0, wy0);
+        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], &aux[base + bit], draws, vtab, px, py, wx0, wy0, rr);
     }
   }
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the

@@ -163,6 +163,9 @@ struct WrTargetDesc {
   int32_t word_base;    // first u64 word of this target's bin masks
   int32_t words_per_bin;
   int32_t y_begin, y_end;        // pixel rows owned by this process (multi-GPU strip sharding)
+  int32_t dw_first, dw_end;      // global prim range spanned by this target's depth-writing draws (dw_end <= dw_first: none).
+                                 // A depth-tested prim that consumes interpolants looks there for what hides parts of its rows
+                                 // (draw_depth_span's sub-spans, rasterize.h:612-664)
 };
 
 enum WrPrimKind {
@@ -361,6 +364,15 @@ struct WrQuadRec {
   WrQuadSeg seg[4];
   WrRepeatRec rep;                  // base_kind == WR_PK_TEX_REPEAT
 };
+
+// Depth runs of one target row of one prim (draw_depth_span, rasterize.h:612-664): with depth testing on, swgl hands the
+// span shader one sub-span per maximal run of pixels that pass the test -- the 4-pixel chunk phase, the span / main()
+// split and the filter decisions restart at every run start, and the interpolants reach run k through the chain of
+// step_interp_inputs() calls of runs 0 .. k-1.  Built per (wave, prim) by the raster stage from the rects of the earlier
+// depth-writing prims that can hide part of the row (wr_build_runs); n == 0: nothing to restart (or more runs than fit).
+#define WR_MAX_RUNS 8
+#define WR_MAX_OCC 32
+struct WrRuns { int32_t n; int32_t s[WR_MAX_RUNS], e[WR_MAX_RUNS]; };
 
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {

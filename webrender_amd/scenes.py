@@ -1685,3 +1685,46 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
         frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
     frame.passes.append(targets)
     return frame
+
+
+# ---------------------------------------------------------------------------
+# Opaque occluders on top of any tile scene: axis-aligned opaque brush_solid rects in the opaque (depth-writing) pass of
+# every picture-cache tile, at z ids scattered through the scene's own.  Whatever they partly hide -- opaque-pass images
+# and gradients drawn after them, everything in the depth-tested alpha pass -- is drawn by swgl one depth run at a time
+# (draw_depth_span, rasterize.h:612-664): the 4-pixel chunk phase, the span-shader / main() split, the filter decisions
+# and the accumulated interpolants restart wherever a run of passing pixels starts.  `first`: tiles for which the
+# occluder batch is drawn ahead of the scene's own opaque batches (the others draw it last, so opaque content that is
+# nearer than an occluder is hidden by depth and content farther away is overwritten instead).
+def add_occluders(frame, n=40, seed=7, zmax=100, wmin=12, wmax=260, first=lambda tx, ty: (tx + ty) % 2 == 0):
+    rng = np.random.default_rng(seed)
+    occ = []
+    for i in range(n):
+        w, h = float(rng.integers(wmin, wmax)), float(rng.integers(wmin, wmax))
+        x, y = float(rng.integers(-20, frame.width)), float(rng.integers(-20, frame.height))
+        if i % 3 == 0:
+            x, y, w, h = x + float(rng.uniform(0, 1)), y + float(rng.uniform(0, 1)), w + float(rng.uniform(0, 1)), h + float(rng.uniform(0, 1))
+        rgb = rng.integers(0, 256, size=3)
+        col = [float(rgb[0]) / 255.0, float(rgb[1]) / 255.0, float(rgb[2]) / 255.0, 1.0]
+        occ.append(((x, y, x + w, y + h), int(rng.integers(1, zmax + 1)), frame.gpu_cache.push([col])))
+    for targets in frame.passes:
+        for target in targets:
+            name = target.texture.name
+            if target.kind != "picture_tile" or not name.startswith("tile_"):
+                continue
+            tx, ty = (int(v) for v in name.split("_")[1:3])
+            ox, oy = tx * TILE_W, ty * TILE_H
+            task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+            inst = []
+            for rect, z, addr in sorted(occ, key=lambda o: -o[1]):          # front to back
+                if not (rect[0] < ox + TILE_W and rect[2] > ox and rect[1] < oy + TILE_H and rect[3] > oy):
+                    continue
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), z, addr, 0, task, (65535, 0, 0, 0))
+                inst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY))
+            if not inst:
+                continue
+            step = Step("brush_solid", "PRIM_INSTANCES", np.array(inst, dtype=np.int32), None, "opaque", textures={})
+            if first(tx, ty):
+                target.opaque.insert(0, step)
+            else:
+                target.opaque.append(step)
+    return frame
