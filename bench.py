@@ -10,12 +10,24 @@ picture-cache tile rasterised, the composite pass, Finish), replayed natively
 (csrc/wr_replay.c) against libwrhip.  Workload at N=1 is BASELINE.json
 configs[1]: 1000 overlapping translucent rects at 3840x2160 ("cfg2").
 
+The timed region (K frames issued back to back + one Finish, between barrier +
+synchronize) is repeated REPEATS times and the median region is reported, so a
+short driver run (--steps 20 = 2 ms of cfg2) is a steady-state number and not
+one pipeline fill.
+
 One JSON line on rank 0 with metric/value plus
-  roofline      dominant kernel (wr_raster_kernel): algorithmic bytes per launch /
-                average launch duration measured with hipEvents on the
-                context's stream, against the 8 TB/s HBM peak
-  cpu_baseline  the reference's own swgl (oracle/_ref, clang build = what ships)
-                replaying the same call stream on one host core
+  roofline      the DOMINANT kernel -- the raster-kernel variant with the largest
+                summed GPU time per frame: its own algorithmic bytes per launch /
+                its own average launch duration (hipEvents on the context's
+                stream around every launch, WrhipSetProfiling), against the
+                8 TB/s HBM peak; `per_kernel` lists every kernel of the frame
+                the same way (upload scatter, setup stage, each raster variant)
+  cpu_baseline  the reference's own swgl rasteriser (oracle/_ref: gl.cc compiled
+                from /root/reference with this repo's hand-written shader
+                headers, clang build = the shipping flags) replaying the same
+                call stream on one host core, plus an N-process run (one
+                process per core, frames replayed independently) with the core
+                count stated
 """
 import argparse
 import json
@@ -29,6 +41,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+REPEATS = 7            # timed regions per run; the median is reported
 
 
 def make_frame(workload, **kw):
@@ -48,26 +61,47 @@ def make_frame(workload, **kw):
     raise SystemExit(f"unknown workload {workload}")
 
 
-def pmc_traffic(workload, encoding):
-    """HBM bytes per raster launch from the rocprofv3 PMC passes committed under
-    profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate runs of this
-    same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    16 B/lane streaming reads on gfx950).  None when no such profile exists for
-    the workload: counters cannot be collected from inside the timed process."""
+def kernel_label(k):
+    if k.kind == 0:
+        return "wr_upload_kernel"
+    if k.kind == 1:
+        return "wr_setup_kernel"
+    return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
+
+
+def pmc_traffic(workload, encoding, label):
+    """HBM bytes per launch of kernel `label` from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on
+    gfx950).  None when no such profile exists for the workload: counters cannot be collected
+    from inside the timed process.  In throughput mode the tile pass runs fused with the next
+    frame's setup stage (wr_setup_raster_kernel<...>): both spellings are matched."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                          f"*pmc_hbm_{workload}.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_hbm_{workload}.json")))
     if not files or encoding != "quad":
         return None
     d = json.load(open(files[-1]))
-    v = [k["hbm_bytes_per_launch"] for n, k in d["kernels"].items() if "wr_raster_kernel" in n]
-    if not v:
+    tag = label[label.index("<"):] if "<" in label else label
+    tot = n = 0
+    for name, k in d["kernels"].items():
+        if ("raster_kernel" + tag in name) if "<" in label else (label in name):
+            tot += k["hbm_bytes_per_launch"] * k["launches"]
+            n += k["launches"]
+    if not n:
         return None
-    return int(sum(v) / len(v)), "profiles/" + os.path.basename(files[-1])
+    return int(tot / n), "profiles/" + os.path.basename(files[-1])
+
+
+def _cpu_worker(args):
+    lib, rec, n = args
+    from webrender_amd.harness import ScenePlayer
+    p = ScenePlayer(lib, rec)
+    return list(p.frames(0, n))
 
 
 def cpu_baseline(rec, budget_s=12.0):
-    """Reference swgl on one host core, bounded sample of the same frame trace."""
+    """Reference swgl rasteriser on the host cores, bounded sample of the same frame trace: one core
+    (swgl is single-threaded by design, swgl/README.md:6), then one replaying process per core."""
     from webrender_amd.harness import ScenePlayer
     lib = os.path.join(ROOT, "oracle", "_ref", "libswgl_ref_clang.so")
     kind = "reference"
@@ -82,10 +116,27 @@ def cpu_baseline(rec, budget_s=12.0):
     n = int(max(2, min(60, budget_s / max(per, 1e-3))))
     ms += list(p.frames(0, n - 1))
     ms = np.array(ms)
-    return {"value": round(1e3 / ms.mean(), 4), "unit": "frames/s", "cores": 1, "kind": kind,
-            "ms_per_frame": round(float(ms.mean()), 3),
-            "sample": f"{len(ms)} frames of the same trace replayed by swgl ({os.path.basename(lib)}), "
-                      f"{time.perf_counter() - t0:.1f} s"}
+    out = {"value": round(1e3 / ms.mean(), 4), "unit": "frames/s", "cores": 1, "kind": kind,
+           "ms_per_frame": round(float(ms.mean()), 3),
+           "oracle": "swgl's gl.cc compiled unmodified from /root/reference; the 22 shader headers it includes are this "
+                     "repo's hand-written restatements of webrender/res/*.glsl (glsl-to-cxx needs cargo)",
+           "sample": f"{len(ms)} frames of the same trace replayed by swgl ({os.path.basename(lib)}), "
+                     f"{time.perf_counter() - t0:.1f} s"}
+    # N processes, one per core, each replaying whole frames (how a tile-parallel swgl would use the box)
+    try:
+        import multiprocessing as mp
+        cores = len(os.sched_getaffinity(0))
+        procs = max(1, min(cores, 64))
+        per_proc = int(max(2, min(30, 8.0 / max(ms.mean() / 1e3, 1e-3))))
+        t1 = time.perf_counter()
+        with mp.get_context("spawn").Pool(procs) as pool:
+            res = pool.map(_cpu_worker, [(lib, rec, per_proc)] * procs)
+        wall = max(sum(r) for r in res) / 1e3
+        out["multi_process"] = {"value": round(procs * per_proc / wall, 3), "unit": "frames/s", "cores": procs,
+                                "host_cores": cores, "sample": f"{procs} processes x {per_proc} frames, {time.perf_counter() - t1:.1f} s wall"}
+    except Exception as e:          # noqa: BLE001 -- the single-core figure is the contract; this one is extra
+        out["multi_process"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -137,24 +188,28 @@ def main():
     # a glFinish per frame; the backend pipelines host recording with GPU
     # execution), one Finish at the end, bracketed by barrier + synchronize.
     player.frames(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    player.stream(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # per-frame latency with a Finish after every frame (what `wrench perf` samples)
-    lat = player.frames(0, min(args.steps, 50))
+    regions = []
+    for _ in range(REPEATS):
+        barrier()
+        t0 = time.perf_counter()
+        player.stream(args.steps)
+        barrier()
+        regions.append(time.perf_counter() - t0)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor(regions, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)        # every region: the slowest rank
+        regions = [float(v) for v in t.tolist()]
+    elapsed = float(np.median(regions))
+    # per-frame latency with a Finish after every frame (what `wrench perf` samples)
+    lat = player.frames(0, min(args.steps, 50))
 
-    # ---- roofline of the dominant kernel (separate, event-timed pass) -------
+    # ---- per-kernel rooflines (separate, event-timed pass: one event pair + wait per launch) -------
     import ctypes as C
     roof = None
     if world == 1:
         get_stats = C.CFUNCTYPE(None, C.c_void_p)(player.symbol("WrhipGetStats"))
+        get_kstats = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)(player.symbol("WrhipGetKernelStats"))
         reset = C.CFUNCTYPE(None)(player.symbol("WrhipResetStats"))
         prof = C.CFUNCTYPE(None, C.c_int)(player.symbol("WrhipSetProfiling"))
         prof(1)
@@ -164,20 +219,35 @@ def main():
         player.frames(0, nprof)
         st = glapi.WrhipStats()
         get_stats(C.byref(st))
+        ks = (glapi.WrhipKernelStat * 32)()
+        nk = get_kstats(ks, 32)
         prof(0)
-        if st.raster_launches and st.raster_ns:
-            avg_ns = st.raster_ns / st.raster_launches
-            bytes_per_launch = st.raster_algo_bytes / st.raster_launches
-            achieved = bytes_per_launch / avg_ns  # GB/s
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "wr_raster_kernel<RGBA8>", "avg_launch_us": round(avg_ns / 1e3, 2),
-                    "algo_bytes_per_launch": int(bytes_per_launch),
-                    "launches_per_frame": st.raster_launches / nprof,
-                    "raster_us_per_frame": round(st.raster_ns / nprof / 1e3, 2)}
-            tr = pmc_traffic(args.workload, args.encoding)
+        per_kernel = []
+        for k in list(ks)[:nk]:
+            if not k.launches or not k.ns:
+                continue
+            us = k.ns / k.launches / 1e3
+            ab = k.algo_bytes / k.launches
+            e = {"name": kernel_label(k), "launches_per_frame": round(k.launches / nprof, 2), "us": round(us, 2),
+                 "us_per_frame": round(k.ns / nprof / 1e3, 2), "workgroups": int(k.workgroups / k.launches),
+                 "algo_bytes": int(ab), "GBps": round(ab / (k.ns / k.launches), 1),
+                 "frac": round(ab / (k.ns / k.launches) / HBM_PEAK_GBS, 4), "traffic": None}
+            tr = pmc_traffic(args.workload, args.encoding, e["name"])
             if tr:
-                roof["traffic"], roof["traffic_source"] = tr
+                e["traffic"], e["traffic_source"] = tr
+            per_kernel.append(e)
+        rasters = [e for e in per_kernel if e["name"].startswith("wr_raster_kernel")]
+        if rasters:
+            dom = max(rasters, key=lambda e: e["us_per_frame"])
+            roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                    "traffic": dom["traffic"], "kernel": dom["name"], "avg_launch_us": dom["us"],
+                    "algo_bytes_per_launch": dom["algo_bytes"],
+                    "raster_us_per_frame": round(sum(e["us_per_frame"] for e in rasters), 2),
+                    "kernel_us_per_frame": round(sum(e["us_per_frame"] for e in per_kernel), 2),
+                    "frame_algo_bytes": int(sum(e["algo_bytes"] * e["launches_per_frame"] for e in per_kernel)),
+                    "per_kernel": per_kernel}
+            if dom.get("traffic_source"):
+                roof["traffic_source"] = dom["traffic_source"]
 
     if rank == 0:
         fps = args.steps / elapsed
@@ -193,6 +263,7 @@ def main():
             "data": "synthetic",
             "mpixels_per_s": round(fps * frame_w * frame_h / 1e6, 1),
             "frame_latency_ms": round(float(np.mean(lat)), 4),
+            "timed_regions_ms": [round(1e3 * r, 3) for r in regions],
             "config": {"workload": f"{args.workload}: " + {
                 "cfg2": "1000 overlapping translucent rects (ps_quad_textured + premultiplied-alpha blend), "
                         "3840x2160, 20 picture-cache tiles + composite, seed 2",

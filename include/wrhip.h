@@ -229,8 +229,18 @@ typedef struct WrhipStats {
 } WrhipStats;
 void WrhipGetStats(WrhipStats* out);
 void WrhipResetStats(void);
-/* Enable hipEvent timing of raster launches (adds a sync per flush). */
+/* Enable hipEvent timing of every kernel launch (one event pair and a sync per launch: for measurement runs only). */
 void WrhipSetProfiling(int enabled);
+/* Per-kernel-variant totals collected while profiling is on: kind 0 = upload scatter, 1 = setup stage, 2 = raster
+ * kernel wr_raster_kernel<fmt, depth, 4, feat>.  algo_bytes: the launch's algorithmic bytes:
+ * raster launches count every destination pixel they own once (twice when the target's old content is loaded) plus
+ * the source texels their draws can sample; the setup stage counts instance + descriptor + record bytes.  Returns the
+ * number of entries written (<= max). */
+typedef struct WrhipKernelStat {
+  int32_t kind, fmt, depth, feat;
+  uint64_t launches, ns, algo_bytes, workgroups;
+} WrhipKernelStat;
+int32_t WrhipGetKernelStats(WrhipKernelStat* out, int32_t max);
 /* Restrict rasterisation to tile-rows owned by `rank` of `world` (multi-GPU
  * sharding by render-target strips). world<=1 disables. */
 void WrhipSetShard(int rank, int world);

@@ -38,3 +38,14 @@ OCCLUDED = [
 ]
 OCCLUDED_GOLDEN = ("occluded_images", "occluded_gradients", "occluded_rotated_images", "occluded_rotated_rects", "occluded_image_repeat",
                    "occluded_aa_rects", "occluded_images_slivers")
+
+
+# One batch of overlapping solids + images per blend key of swgl's table (gl.cc:614-645): the WebRender BlendModes
+# (device/gl.rs:3901-4025), MIN / MAX, the constant-colour key and the 15 KHR_blend_equation_advanced equations.
+BLEND = [
+    ("blend_modes", lambda: scenes.blend_modes()),
+    ("blend_modes_wide", lambda: scenes.blend_modes(width=2048, height=1024, per_state=20, seed=112, clear=(0.0, 0.0, 0.0, 0.0))),
+    ("blend_modes_opaque_dst", lambda: scenes.blend_modes(seed=113, clear=(0.3, 0.6, 0.1, 1.0))),
+    ("blend_modes_occluded", lambda: scenes.add_occluders(scenes.blend_modes(seed=114), zmax=300, seed=31)),
+]
+BLEND_GOLDEN = ("blend_modes", "blend_modes_wide")

@@ -276,7 +276,7 @@ struct Context {
   // plus a kernel boundary; the rest follow in order.  Anything that needs their results, or touches a
   // texture they read or write from outside the draw stream (host uploads, copies, readbacks,
   // deletes, Finish), drains them first (drain_tail).
-  struct Held { int fmt, depth, feat, nb, off; };    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
+  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; };    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
   struct Tail {
     bool pending = false;
     std::vector<Held> held;          // the raster launches of the held-back flush, in order
@@ -306,6 +306,7 @@ struct Context {
   bool profiling = false;
   wr_event_t ev_a, ev_b;
   WrhipStats stats;
+  std::vector<WrhipKernelStat> kstats;   // per kernel variant, while profiling
   int shard_rank = 0, shard_world = 1;
 
   Context() {
@@ -421,6 +422,8 @@ void drain_tail();
 void sync_stream();
 
 void flush_uploads(size_t extra_end = 0);
+void prof_begin();
+void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups);
 
 const size_t STAGING_BYTES = size_t(96) << 20;
 
@@ -492,7 +495,11 @@ void flush_uploads(size_t) {
     }
   }
   if (nseg) {
+    uint64_t up_bytes = 0;
+    for (auto& sg : c->useg) up_bytes += 2ull * sg.row_bytes * sg.rows;
+    prof_begin();
     WR_LAUNCH(wr_upload_kernel, (int)nseg * 8, 256, c->stream, (const WrUploadSeg*)(c->dupload + seg_off), (int)nseg);
+    prof_end(0, 0, 0, 0, up_bytes, nseg * 8);
     c->stats.kernel_launches++;
     c->useg.clear();
   }
@@ -621,7 +628,22 @@ int hash_blend_key(Context* c) {
     switch (c->blend_equation) {
       case GL_MIN: return WR_BLEND_MIN;
       case GL_MAX: return WR_BLEND_MAX;
-      default: return WR_BLEND_UNSUPPORTED;  // KHR advanced equations: mix-blend, out of scope
+      case GL_MULTIPLY_KHR: return WR_BLEND_MULTIPLY_KHR;
+      case GL_SCREEN_KHR: return WR_BLEND_SCREEN_KHR;
+      case GL_OVERLAY_KHR: return WR_BLEND_OVERLAY_KHR;
+      case GL_DARKEN_KHR: return WR_BLEND_DARKEN_KHR;
+      case GL_LIGHTEN_KHR: return WR_BLEND_LIGHTEN_KHR;
+      case GL_COLORDODGE_KHR: return WR_BLEND_COLORDODGE_KHR;
+      case GL_COLORBURN_KHR: return WR_BLEND_COLORBURN_KHR;
+      case GL_HARDLIGHT_KHR: return WR_BLEND_HARDLIGHT_KHR;
+      case GL_SOFTLIGHT_KHR: return WR_BLEND_SOFTLIGHT_KHR;
+      case GL_DIFFERENCE_KHR: return WR_BLEND_DIFFERENCE_KHR;
+      case GL_EXCLUSION_KHR: return WR_BLEND_EXCLUSION_KHR;
+      case GL_HSL_HUE_KHR: return WR_BLEND_HSL_HUE_KHR;
+      case GL_HSL_SATURATION_KHR: return WR_BLEND_HSL_SATURATION_KHR;
+      case GL_HSL_COLOR_KHR: return WR_BLEND_HSL_COLOR_KHR;
+      case GL_HSL_LUMINOSITY_KHR: return WR_BLEND_HSL_LUMINOSITY_KHR;
+      default: return WR_BLEND_UNSUPPORTED;
     }
   }
   bool sep = (srgb != sa || drgb != da);
@@ -761,6 +783,21 @@ Context::~Context() {
 // ---------------------------------------------------------------------------
 // Execute the selected pending targets: one H2D copy of the frame arena, then
 // vertex + bin + raster launches covering every selected target at once.
+// While profiling, every launch is bracketed by its own event pair and waited for (measurement runs only).
+void prof_begin() { if (ctx->profiling) wrrt::event_record(&ctx->ev_a, ctx->stream); }
+void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups) {
+  Context* c = ctx;
+  if (!c->profiling) return;
+  wrrt::event_record(&c->ev_b, c->stream);
+  wrrt::event_sync(&c->ev_b);
+  const uint64_t ns = (uint64_t)(wrrt::event_elapsed_ms(&c->ev_a, &c->ev_b) * 1.0e6);
+  WrhipKernelStat* k = nullptr;
+  for (WrhipKernelStat& e : c->kstats) if (e.kind == kind && e.fmt == fmt && e.depth == depth && e.feat == feat) k = &e;
+  if (!k) { c->kstats.push_back(WrhipKernelStat{kind, fmt, depth, feat, 0, 0, 0, 0}); k = &c->kstats.back(); }
+  k->launches++; k->ns += ns; k->algo_bytes += algo_bytes; k->workgroups += workgroups;
+  if (kind == 2) c->stats.raster_ns += ns;
+}
+
 void tail_launched() {
   Context::Tail& T = ctx->tail;
   for (GLuint id : T.refs) if (Texture* t = ctx->textures.find(id)) t->tail_ref = false;
@@ -789,6 +826,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
               (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);                                               \
   } while (0)
   const int F5 = WR_FEAT_TEX | WR_FEAT_GENERIC, F7 = F5 | WR_FEAT_R8TEX, FA = F7 | WR_FEAT_BLUR | WR_FEAT_SHADE;
+  prof_begin();
   if (SA) {
     if (H.depth) {
       if (H.feat == 0) WR_KF(true, 0); else if (H.feat == F5) WR_KF(true, WR_FEAT_TEX | WR_FEAT_GENERIC);
@@ -816,6 +854,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   }
 #undef WR_K
 #undef WR_KF
+  prof_end(2, H.fmt, H.depth, H.feat, H.algo_bytes, (uint64_t)H.nb);
   c->stats.kernel_launches++; c->stats.raster_launches++;
 }
 // Launch the held-back raster launches on their own (nothing to fuse them with, or their results are needed now).
@@ -843,7 +882,7 @@ void flush_work(const std::vector<int>& sel_in) {
     if (la != lb) return la < lb;
     return (c->textures[c->work[a].tex].internal_format == GL_R8) < (c->textures[c->work[b].tex].internal_format == GL_R8);
   });
-  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false; };
+  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false; uint64_t bytes_rgba = 0, bytes_r8 = 0; };
   std::vector<Level> levels;
   std::vector<int> target_level;
   const int n_targets = (int)sel.size();
@@ -925,13 +964,16 @@ void flush_work(const std::vector<int>& sel_in) {
     (T.format == WR_FMT_RGBA8 ? L.bins_rgba : L.bins_r8) += T.bins_x * T.bins_y;
     uint64_t owned = (uint64_t)t.width * std::max(0, T.y_end - T.y_begin);
     pixels += owned;
-    algo_bytes += owned * t.bpp * (T.load_color ? 2 : 1);
-    {  // unique source texels sampled: bounded by what a 1:1 mapping can touch
+    {
+      uint64_t tb = owned * t.bpp * (T.load_color ? 2 : 1);
+      // unique source texels sampled: bounded by what a 1:1 mapping can touch
       uint64_t src = 0;
       for (GLuint id : w.reads)
         if (Texture* rt = c->textures.find(id))
           if (rt->internal_format == GL_RGBA8 || rt->internal_format == GL_R8) src += (uint64_t)rt->stride * rt->height;
-      algo_bytes += std::min<uint64_t>(src, owned * t.bpp);
+      tb += std::min<uint64_t>(src, owned * t.bpp);
+      algo_bytes += tb;
+      (T.format == WR_FMT_RGBA8 ? L.bytes_rgba : L.bytes_r8) += tb;
     }
     if (dt && dt->depth_cleared && nrel > 0) {
       // The depth buffer outlives this flush only as a uniform value; WebRender
@@ -1025,8 +1067,10 @@ void flush_work(const std::vector<int>& sel_in) {
         }
         tail_launched();
       } else {
+        prof_begin();
         WR_LAUNCH(wr_setup_kernel, n_setup_blocks, 256, c->stream, ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims,
                   dtargets, S.masks, S.vtab, c->dcounters, dblk);
+        prof_end(1, 0, 0, 0, inst.size() + sizeof(WrDrawDesc) * nd + (uint64_t)n_prims * (sizeof(WrPrim) + sizeof(WrRec)), (uint64_t)n_setup_blocks);
         c->stats.kernel_launches += 1;
         drain_tail();        // (held-back launches the fused kernel has no variant for)
       }
@@ -1062,7 +1106,6 @@ void flush_work(const std::vector<int>& sel_in) {
       }
     }
 #endif
-    if (c->profiling) wrrt::event_record(&c->ev_a, c->stream);
     // Four waves per 64x64 bin, each lane owning 4 x 4 pixels (R = 4; two waves x
     // 32 pixels measured slower on MI355X, profiles/r01_*).  The kernel is
     // specialised on the prim families present in the launch (FEAT) so that
@@ -1099,11 +1142,11 @@ void flush_work(const std::vector<int>& sel_in) {
         else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC))) f = WR_FEAT_TEX | WR_FEAT_GENERIC;
         else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX))) f = WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX;
         else f = WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE;
-        launches.push_back(Context::Held{WR_FMT_RGBA8, L.any_depth ? 1 : 0, f, L.bins_rgba, L.bin0});
+        launches.push_back(Context::Held{WR_FMT_RGBA8, L.any_depth ? 1 : 0, f, L.bins_rgba, L.bin0, L.bytes_rgba});
       }
       if (L.bins_r8 > 0) {
         const int f = L.feat_r8 == 0 ? 0 : (!(L.feat_r8 & WR_FEAT_CLIP) ? (WR_FEAT_GENERIC | WR_FEAT_BLUR) : (WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP));
-        launches.push_back(Context::Held{WR_FMT_R8, 0, f, L.bins_r8, L.bin0 + L.bins_rgba});
+        launches.push_back(Context::Held{WR_FMT_R8, 0, f, L.bins_r8, L.bin0 + L.bins_rgba, L.bytes_r8});
       }
     }
     if (c->defer_tail && !c->profiling && !launches.empty()) {
@@ -1118,11 +1161,6 @@ void flush_work(const std::vector<int>& sel_in) {
       for (GLuint id : T.refs) if (Texture* t = c->textures.find(id)) t->tail_ref = true;
     } else {
       for (const Context::Held& H : launches) launch_raster(H, dtargets, n_targets, ddraws, S);
-    }
-    if (c->profiling) {
-      wrrt::event_record(&c->ev_b, c->stream);
-      wrrt::event_sync(&c->ev_b);
-      c->stats.raster_ns += (uint64_t)(wrrt::event_elapsed_ms(&c->ev_a, &c->ev_b) * 1.0e6);
     }
     c->flush_seq++;
     c->stats.flushes++;
@@ -1863,9 +1901,12 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   // (GL_ONE, GL_ONE_MINUS_SRC1_COLOR under the dual-source text program is fine: every prim of that
   // program replaces the key with swgl_blendSubpixelText / swgl_blendDropShadow in its vertex stage)
   const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && info->kind == WR_SH_PS_TEXT_RUN_DUAL;
-  if (!dual_text && (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC || d.blend == WR_BLEND_CONST_COLOR ||
-      d.blend == WR_BLEND_MIN || d.blend == WR_BLEND_MAX)) {
-    fprintf(stderr, "libwrhip: blend mode not implemented yet (key %d)\n", d.blend);
+  if (!dual_text && (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC)) {
+    // not in swgl's key table either (gl.cc:614-645: the reference asserts) -- or GL_ONE, GL_ONE_MINUS_SRC1_COLOR outside the
+    // dual-source text program, which needs gl_SecondaryFragColor from a shader that is not implemented
+    fprintf(stderr, "libwrhip: blend state without an implementation (funcs %x %x %x %x equation %x)\n", c->blendfunc_srgb, c->blendfunc_drgb,
+            c->blendfunc_sa, c->blendfunc_da, c->blend_equation);
+    c->last_error = GL_INVALID_OPERATION;
   }
   d.flags = 0;
   Texture* depthtex = (c->depthtest && fb.depth_attachment) ? c->textures.find(fb.depth_attachment) : nullptr;
@@ -2034,8 +2075,18 @@ void CompositeYUV(LockedTexture*, LockedTexture*, LockedTexture*, LockedTexture*
 
 // ---- libwrhip additions ------------------------------------------------------
 void WrhipGetStats(WrhipStats* out) { if (ctx && out) *out = ctx->stats; }
-void WrhipResetStats(void) { if (ctx) memset(&ctx->stats, 0, sizeof(ctx->stats)); }
-void WrhipSetProfiling(int enabled) { if (ctx) ctx->profiling = enabled != 0; }
+void WrhipResetStats(void) { if (ctx) { memset(&ctx->stats, 0, sizeof(ctx->stats)); ctx->kstats.clear(); } }
+void WrhipSetProfiling(int enabled) {
+  if (!ctx) return;
+  if (enabled && !ctx->profiling) { flush_all(); flush_uploads(); sync_stream(); }   // nothing held back may go out unprofiled
+  ctx->profiling = enabled != 0;
+}
+int32_t WrhipGetKernelStats(WrhipKernelStat* out, int32_t max) {
+  if (!ctx || !out) return 0;
+  int32_t n = 0;
+  for (const WrhipKernelStat& k : ctx->kstats) if (n < max) out[n++] = k;
+  return n;
+}
 void WrhipSetShard(int rank, int world) { if (ctx) { flush_all(); ctx->shard_rank = rank; ctx->shard_world = world < 1 ? 1 : world; } }
 void WrhipSetTargetRows(GLuint tex, int32_t y0, int32_t y1) {
   if (!ctx) return;

@@ -1532,7 +1532,159 @@ WR_DEVICE uint32_t wr_splat_a(uint32_t ra) { uint32_t a = ra >> 16; return a | (
 // blend_pixels for RGBA8 (blend.h:416-701): the keys WebRender's in-scope
 // batches use.  `src` already has clip-mask/AA weights applied.
 WR_DEVICE WrWide wr_apply_color(WrWide src, const uint32_t color[2]);
+
+// ---- the rest of swgl's blend-key table (blend.h:490-677): constant colour, MIN / MAX, and the
+// KHR_blend_equation_advanced equations on premultiplied values.  Out of line: none of it is hot.
+// Lane helpers on two u16 lanes in a u32 (WideRGBA8 arithmetic wraps mod 2^16 per lane).
+WR_DEVICE uint32_t wr_min2(uint32_t a, uint32_t b) {      // portable min(HalfRGBA8): unsigned lanes
+  const uint32_t lo = (a & 0xFFFF) < (b & 0xFFFF) ? (a & 0xFFFF) : (b & 0xFFFF), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+  return lo | (hi << 16);
+}
+WR_DEVICE uint32_t wr_max2(uint32_t a, uint32_t b) {
+  const uint32_t lo = (a & 0xFFFF) > (b & 0xFFFF) ? (a & 0xFFFF) : (b & 0xFFFF), hi = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+  return lo | (hi << 16);
+}
+WR_DEVICE uint32_t wr_neg2(uint32_t a) { return wr_sub2(0u, a); }
+// if_then_else(x * 2 <= y, t, e) per lane
+WR_DEVICE uint32_t wr_sel_le2(uint32_t x, uint32_t y, uint32_t t, uint32_t e) {
+  const bool lo = (((x & 0xFFFF) * 2u) & 0xFFFF) <= (y & 0xFFFF), hi = (((x >> 16) * 2u) & 0xFFFF) <= (y >> 16);
+  return ((lo ? t : e) & 0xFFFF) | ((hi ? t : e) & 0xFFFF0000u);
+}
+WR_DEVICE uint32_t wr_addlow2(uint32_t a, uint32_t b) {   // addlow: byte-wise add (blend.h:201-205)
+  return (((a & 0x00FF00FFu) + (b & 0x00FF00FFu)) & 0x00FF00FFu) | (((((a >> 8) & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu)) & 0x00FF00FFu) << 8);
+}
+WR_DEVICE float wr_recip_or(float v, float f) { return v != 0.0f ? 1.0f / v : f; }
+WR_DEVICE uint32_t wr_round_scaled(float v, float scale) { return uint32_t(int(v * scale + 0.5f)) & 0xFFFF; }   // round_pixel(v, scale) -> u16 lane
+// clip_color / set_lum / set_lum_sat (blend.h:296-327) on one pixel
+WR_DEVICE void wr_clip_color(float (&v)[3], float lum, float alpha) {
+  const float mincol = wr_max(-wr_min(wr_min(v[0], v[1]), v[2]), lum);
+  const float maxcol = wr_max(wr_max(wr_max(v[0], v[1]), v[2]), alpha - lum);
+  const float k = lum * (alpha - lum) * wr_recip_or(mincol * maxcol, 0.0f);
+  for (int i = 0; i < 3; i++) v[i] = lum + v[i] * k;
+}
+WR_DEVICE float wr_lumv3(const float (&v)[3]) { return v[0] * 0.30f + v[1] * 0.59f + v[2] * 0.11f; }
+WR_DEVICE void wr_set_lum(float (&base)[3], const float (&ref)[3], float alpha) {
+  const float lb = wr_lumv3(base);
+  for (int i = 0; i < 3; i++) base[i] = base[i] - lb;
+  wr_clip_color(base, wr_lumv3(ref), alpha);
+}
+WR_DEVICE void wr_set_lum_sat(float (&base)[3], const float (&sref)[3], const float (&lref)[3], float alpha) {
+  const float mn = wr_min(wr_min(base[0], base[1]), base[2]);
+  float diff[3] = {base[0] - mn, base[1] - mn, base[2] - mn};
+  const float sbase = wr_max(wr_max(diff[0], diff[1]), diff[2]);
+  const float ssat = wr_max(wr_max(sref[0], sref[1]), sref[2]) - wr_min(wr_min(sref[0], sref[1]), sref[2]);
+  const float rs = wr_recip_or(sbase, 0.0f);
+  for (int i = 0; i < 3; i++) base[i] = diff[i] * ssat * rs;
+  wr_set_lum(base, lref, alpha);
+}
+__device__ __noinline__ uint32_t wr_blend_advanced(int key, uint32_t dstp, uint32_t sbg, uint32_t sra, uint32_t bc0, uint32_t bc1) {
+  WrWide src; src.bg = sbg; src.ra = sra;
+  WrWide dst = wr_unpack(dstp), r;
+  const uint32_t sa = wr_splat_a(src.ra), da = wr_splat_a(dst.ra);
+  const uint32_t RGB_RA = 0x0000FFFFu, A_RA = 0xFFFF0000u;      // RGB_MASK / ALPHA_MASK on the (r, a) pair; the (b, g) pair is all colour
+  switch (key) {
+    case WR_BLEND_CONST_COLOR:      // addlow(dst, muldiv255(src, repeat2(ctx->blendcolor) - dst))
+      r.bg = wr_addlow2(dst.bg, wr_muldiv255_2(src.bg, wr_sub2(bc0, dst.bg)));
+      r.ra = wr_addlow2(dst.ra, wr_muldiv255_2(src.ra, wr_sub2(bc1, dst.ra)));
+      break;
+    case WR_BLEND_MIN: r.bg = wr_min2(src.bg, dst.bg); r.ra = wr_min2(src.ra, dst.ra); break;
+    case WR_BLEND_MAX: r.bg = wr_max2(src.bg, dst.bg); r.ra = wr_max2(src.ra, dst.ra); break;
+    case WR_BLEND_MULTIPLY_KHR: {   // diff = muldiv255(alphas(src) - (src & RGB), alphas(dst) - (dst & RGB)); src + dst + (diff & RGB) - alphas(diff)
+      const uint32_t dbg = wr_muldiv255_2(wr_sub2(sa, src.bg), wr_sub2(da, dst.bg));
+      const uint32_t dra = wr_muldiv255_2(wr_sub2(sa, src.ra & RGB_RA), wr_sub2(da, dst.ra & RGB_RA));
+      const uint32_t dal = wr_splat_a(dra);
+      r.bg = wr_sub2(wr_add2(wr_add2(src.bg, dst.bg), dbg), dal);
+      r.ra = wr_sub2(wr_add2(wr_add2(src.ra, dst.ra), dra & RGB_RA), dal);
+    } break;
+    case WR_BLEND_SCREEN_KHR:
+      r.bg = wr_sub2(wr_add2(src.bg, dst.bg), wr_muldiv255_2(src.bg, dst.bg));
+      r.ra = wr_sub2(wr_add2(src.ra, dst.ra), wr_muldiv255_2(src.ra, dst.ra));
+      break;
+    case WR_BLEND_OVERLAY_KHR:
+    case WR_BLEND_HARDLIGHT_KHR: {  // diff = muldiv255(src, dst) + muldiv255(srcA - src, dstA - dst); src + dst + (c * 2 <= cA ? (diff & RGB) - alphas(diff) : -diff)
+      const uint32_t dbg = wr_add2(wr_muldiv255_2(src.bg, dst.bg), wr_muldiv255_2(wr_sub2(sa, src.bg), wr_sub2(da, dst.bg)));
+      const uint32_t dra = wr_add2(wr_muldiv255_2(src.ra, dst.ra), wr_muldiv255_2(wr_sub2(sa, src.ra), wr_sub2(da, dst.ra)));
+      const uint32_t dal = wr_splat_a(dra);
+      const bool ov = key == WR_BLEND_OVERLAY_KHR;
+      const uint32_t tbg = wr_sel_le2(ov ? dst.bg : src.bg, ov ? da : sa, wr_sub2(dbg, dal), wr_neg2(dbg));
+      const uint32_t tra = wr_sel_le2(ov ? dst.ra : src.ra, ov ? da : sa, wr_sub2(dra & RGB_RA, dal), wr_neg2(dra));
+      r.bg = wr_add2(wr_add2(src.bg, dst.bg), tbg);
+      r.ra = wr_add2(wr_add2(src.ra, dst.ra), tra);
+    } break;
+    case WR_BLEND_DARKEN_KHR:       // src + dst - max(muldiv255(src, alphas(dst)), muldiv255(dst, alphas(src)))
+      r.bg = wr_sub2(wr_add2(src.bg, dst.bg), wr_max2(wr_muldiv255_2(src.bg, da), wr_muldiv255_2(dst.bg, sa)));
+      r.ra = wr_sub2(wr_add2(src.ra, dst.ra), wr_max2(wr_muldiv255_2(src.ra, da), wr_muldiv255_2(dst.ra, sa)));
+      break;
+    case WR_BLEND_LIGHTEN_KHR:
+      r.bg = wr_sub2(wr_add2(src.bg, dst.bg), wr_min2(wr_muldiv255_2(src.bg, da), wr_muldiv255_2(dst.bg, sa)));
+      r.ra = wr_sub2(wr_add2(src.ra, dst.ra), wr_min2(wr_muldiv255_2(src.ra, da), wr_muldiv255_2(dst.ra, sa)));
+      break;
+    case WR_BLEND_DIFFERENCE_KHR: { // diff = min(muldiv255(dst, alphas(src)), muldiv255(src, alphas(dst))); src + dst - diff - (diff & RGB)
+      const uint32_t dbg = wr_min2(wr_muldiv255_2(dst.bg, sa), wr_muldiv255_2(src.bg, da));
+      const uint32_t dra = wr_min2(wr_muldiv255_2(dst.ra, sa), wr_muldiv255_2(src.ra, da));
+      r.bg = wr_sub2(wr_sub2(wr_add2(src.bg, dst.bg), dbg), dbg);
+      r.ra = wr_sub2(wr_sub2(wr_add2(src.ra, dst.ra), dra), dra & RGB_RA);
+    } break;
+    case WR_BLEND_EXCLUSION_KHR: {
+      const uint32_t dbg = wr_muldiv255_2(src.bg, dst.bg), dra = wr_muldiv255_2(src.ra, dst.ra);
+      r.bg = wr_sub2(wr_sub2(wr_add2(src.bg, dst.bg), dbg), dbg);
+      r.ra = wr_sub2(wr_sub2(wr_add2(src.ra, dst.ra), dra), dra & RGB_RA);
+    } break;
+    default: {
+      // the float equations: lanes b, g, r, a as floats 0..255 (CONVERT(src, WideRGBA32F))
+      const float sf[4] = {float(src.bg & 0xFFFF), float(src.bg >> 16), float(src.ra & 0xFFFF), float(src.ra >> 16)};
+      const float df[4] = {float(dst.bg & 0xFFFF), float(dst.bg >> 16), float(dst.ra & 0xFFFF), float(dst.ra >> 16)};
+      const float sA = sf[3], dA = df[3];
+      float o[4];
+      const float k = 1.0f / 255.0f;
+      if (key == WR_BLEND_COLORDODGE_KHR || key == WR_BLEND_COLORBURN_KHR) {
+        for (int i = 0; i < 4; i++) {
+          float t;     // set_alphas(<colour term>, dstF)
+          if (i == 3) t = df[3];
+          else if (key == WR_BLEND_COLORDODGE_KHR) t = wr_min(dA, df[i] * sA * wr_recip_or(sA - sf[i], 255.0f));
+          else t = dA - wr_min(dA, (dA - df[i]) * sA * wr_recip_or(sf[i], 255.0f));
+          o[i] = sA * t + sf[i] * (255.0f - dA) + df[i] * (255.0f - sA);
+        }
+        r.bg = wr_round_scaled(o[0], k) | (wr_round_scaled(o[1], k) << 16);
+        r.ra = wr_round_scaled(o[2], k) | (wr_round_scaled(o[3], k) << 16);
+      } else if (key == WR_BLEND_SOFTLIGHT_KHR) {
+        const float ra_ = wr_recip_or(dA, 0.0f);
+        for (int i = 0; i < 4; i++) {
+          const float dstU = df[i] * ra_;
+          const float scale = sf[i] + sf[i] - sA;
+          float t = 0.0f;   // set_alphas(..., 0)
+          if (i < 3) t = scale * (scale < 0.0f ? 1.0f - dstU : wr_min((16.0f * dstU - 12.0f) * dstU + 3.0f, (1.0f / sqrtf(dstU)) - 1.0f));
+          o[i] = df[i] * (255.0f + t) + sf[i] * (255.0f - dA);
+        }
+        r.bg = wr_round_scaled(o[0], k) | (wr_round_scaled(o[1], k) << 16);
+        r.ra = wr_round_scaled(o[2], k) | (wr_round_scaled(o[3], k) << 16);
+      } else {
+        // DO_HSL (blend.h:651-677): vec4 in r, g, b, a order
+        const float sv[3] = {sf[2], sf[1], sf[0]}, dv[3] = {df[2], df[1], df[0]};
+        const float srcA = sA * k, dstA = dA * k, srcDstA = sA * dstA;
+        float sc[3], dc[3];
+        for (int i = 0; i < 3; i++) { sc[i] = sv[i] * dstA; dc[i] = dv[i] * srcA; }
+        float rgb[3];
+        if (key == WR_BLEND_HSL_HUE_KHR) { for (int i = 0; i < 3; i++) rgb[i] = sc[i]; wr_set_lum_sat(rgb, dc, dc, srcDstA); }
+        else if (key == WR_BLEND_HSL_SATURATION_KHR) { for (int i = 0; i < 3; i++) rgb[i] = dc[i]; wr_set_lum_sat(rgb, sc, dc, srcDstA); }
+        else if (key == WR_BLEND_HSL_COLOR_KHR) { for (int i = 0; i < 3; i++) rgb[i] = sc[i]; wr_set_lum(rgb, dc, srcDstA); }
+        else { for (int i = 0; i < 3; i++) rgb[i] = dc[i]; wr_set_lum(rgb, sc, srcDstA); }
+        float res[4];
+        for (int i = 0; i < 3; i++) res[i] = (((rgb[i] + sv[i]) - sc[i]) + dv[i]) - dc[i];
+        res[3] = (sA + dA) - srcDstA;
+        // pack_pixels_RGBA8(vec4, 1.0f): b, g, r, a lanes
+        r.bg = wr_round_scaled(res[2], 1.0f) | (wr_round_scaled(res[1], 1.0f) << 16);
+        r.ra = wr_round_scaled(res[0], 1.0f) | (wr_round_scaled(res[3], 1.0f) << 16);
+      }
+    } break;
+  }
+  (void)A_RA;
+  return wr_pack(r);
+}
+
 WR_DEVICE uint32_t wr_blend_rgba8(int key, uint32_t dstp, WrWide src, const WrDrawDesc* d, const uint32_t* bc = nullptr) {
+  if (key == WR_BLEND_CONST_COLOR || key == WR_BLEND_MIN || key == WR_BLEND_MAX || key > WR_BLEND_UNSUPPORTED)
+    return wr_blend_advanced(key, dstp, src.bg, src.ra, d ? d->blend_color[0] : 0u, d ? d->blend_color[1] : 0u);
   WrWide dst = wr_unpack(dstp), r;
   switch (key) {
     default:

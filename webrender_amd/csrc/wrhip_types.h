@@ -84,7 +84,13 @@ enum WrBlend {
   WR_BLEND_MIN, WR_BLEND_MAX,
   WR_BLEND_SCREEN,                 // ONE, 1-SRC_COLOR
   WR_BLEND_DROP_SHADOW, WR_BLEND_SUBPIXEL_TEXT,
-  WR_BLEND_UNSUPPORTED
+  WR_BLEND_UNSUPPORTED,
+  // KHR_blend_equation_advanced (BlendMode::Advanced: mix-blend-mode pictures drawn through brush_image on a backend
+  // that advertises the extension, device/gl.rs:3980-4025; blend.h:565-677), in GL enum order
+  WR_BLEND_MULTIPLY_KHR, WR_BLEND_SCREEN_KHR, WR_BLEND_OVERLAY_KHR, WR_BLEND_DARKEN_KHR, WR_BLEND_LIGHTEN_KHR,
+  WR_BLEND_COLORDODGE_KHR, WR_BLEND_COLORBURN_KHR, WR_BLEND_HARDLIGHT_KHR, WR_BLEND_SOFTLIGHT_KHR,
+  WR_BLEND_DIFFERENCE_KHR, WR_BLEND_EXCLUSION_KHR,
+  WR_BLEND_HSL_HUE_KHR, WR_BLEND_HSL_SATURATION_KHR, WR_BLEND_HSL_COLOR_KHR, WR_BLEND_HSL_LUMINOSITY_KHR,
 };
 
 // Prim families a raster launch has to handle; the kernel is specialised on the

@@ -321,8 +321,26 @@ class Device:
         "Screen": ((G.GL_ONE, G.GL_ONE_MINUS_SRC_COLOR), (G.GL_ONE, G.GL_ONE_MINUS_SRC_ALPHA)),
     }
 
+    ADVANCED = {"Multiply": G.GL_MULTIPLY_KHR, "Screen": G.GL_SCREEN_KHR, "Overlay": G.GL_OVERLAY_KHR, "Darken": G.GL_DARKEN_KHR,
+                "Lighten": G.GL_LIGHTEN_KHR, "ColorDodge": G.GL_COLORDODGE_KHR, "ColorBurn": G.GL_COLORBURN_KHR,
+                "HardLight": G.GL_HARDLIGHT_KHR, "SoftLight": G.GL_SOFTLIGHT_KHR, "Difference": G.GL_DIFFERENCE_KHR,
+                "Exclusion": G.GL_EXCLUSION_KHR, "Hue": G.GL_HSL_HUE_KHR, "Saturation": G.GL_HSL_SATURATION_KHR,
+                "Color": G.GL_HSL_COLOR_KHR, "Luminosity": G.GL_HSL_LUMINOSITY_KHR}
+
     def set_blend_mode(self, name):
-        self.set_blend_factors(*self.BLEND_MODES[name])
+        """device/gl.rs:3901-4025.  "Advanced:<MixBlendMode>" = set_blend_mode_advanced (KHR_blend_equation_advanced, what the
+        renderer uses for mix-blend-mode pictures when the backend advertises the extension); "SubpixelConstantTextColor:r,g,b,a"
+        = set_blend_mode_subpixel_constant_text_color; "Min" / "Max": the plain GL equations (in swgl's key table, gl.cc:627-628)."""
+        if name.startswith("Advanced:"):
+            self.gl.BlendEquation(self.ADVANCED[name.split(":", 1)[1]])
+        elif name in ("Min", "Max"):
+            self.gl.BlendEquation(G.GL_MIN if name == "Min" else G.GL_MAX)
+        elif name.startswith("SubpixelConstantTextColor:"):
+            r, g, b, a = (float(v) for v in name.split(":", 1)[1].split(","))
+            self.gl.BlendColor(r, g, b, a)
+            self.set_blend_factors((G.GL_CONSTANT_COLOR, G.GL_ONE_MINUS_SRC_COLOR), (G.GL_CONSTANT_ALPHA, G.GL_ONE_MINUS_SRC_ALPHA))
+        else:
+            self.set_blend_factors(*self.BLEND_MODES[name])
 
     def enable_depth(self, func=G.GL_LEQUAL):
         self.gl.Enable(G.GL_DEPTH_TEST)

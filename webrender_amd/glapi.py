@@ -127,6 +127,7 @@ EXTRA_SIGNATURES = {
     "WrhipGetStats": (None, [P]),
     "WrhipResetStats": (None, []),
     "WrhipSetProfiling": (None, [i32]),
+    "WrhipGetKernelStats": (i32, [P, i32]),
     "WrhipSetShard": (None, [i32, i32]),
     "WrhipSetTargetRows": (None, [u32, i32, i32]),
     "WrhipGetTextureDevicePtr": (P, [u32, P, P, P]),
@@ -141,6 +142,10 @@ class WrhipStats(C.Structure):
     _fields_ = [(n, u64) for n in (
         "flushes", "kernel_launches", "raster_launches", "raster_ns",
         "raster_algo_bytes", "raster_pixels", "prims", "h2d_bytes", "d2h_bytes")]
+
+
+class WrhipKernelStat(C.Structure):
+    _fields_ = [(n, i32) for n in ("kind", "fmt", "depth", "feat")] + [(n, u64) for n in ("launches", "ns", "algo_bytes", "workgroups")]
 
 
 def _as_ptr(x):

@@ -1728,3 +1728,88 @@ def add_occluders(frame, n=40, seed=7, zmax=100, wmin=12, wmax=260, first=lambda
             else:
                 target.opaque.append(step)
     return frame
+
+
+# ---------------------------------------------------------------------------
+# Every blend key of swgl's table (gl.cc:614-645, blend.h:466-701) over varied destination content: one batch of
+# overlapping translucent prims per blend state -- solids (brush_solid ALPHA_PASS) and images (brush_image ALPHA_PASS,
+# 1:1 and scaled) alternate, so both the solid-colour path and the textured paths go through the blend stage with each
+# key.  BlendMode names as in Device.set_blend_mode; "Advanced:*" are the KHR_blend_equation_advanced equations the
+# renderer uses for mix-blend-mode pictures on a backend that advertises the extension (device/gl.rs:3980-4025).
+BLEND_STATES = ("PremultipliedAlpha", "Alpha", "PremultipliedDestOut", "Multiply", "PlusLighter", "Min", "Max",
+                "SubpixelConstantTextColor:0.8,0.3,0.55,0.7",
+                "Advanced:Multiply", "Advanced:Screen", "Advanced:Overlay", "Advanced:Darken", "Advanced:Lighten",
+                "Advanced:ColorDodge", "Advanced:ColorBurn", "Advanced:HardLight", "Advanced:SoftLight", "Advanced:Difference",
+                "Advanced:Exclusion", "Advanced:Hue", "Advanced:Saturation", "Advanced:Color", "Advanced:Luminosity")
+
+
+def blend_modes(width=1024, height=1024, per_state=14, seed=111, states=BLEND_STATES, atlas=256, clear=(0.2, 0.35, 0.5, 0.75), only=None):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    pix = rng.integers(0, 256, size=(atlas, atlas, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:atlas, 0:atlas]
+    pix[..., 3] = ((xx + yy) * 255 // (2 * atlas - 2)).astype(np.uint8)          # alpha ramp 0 .. 255
+    pix[..., :3] = (pix[..., :3].astype(np.uint16) * pix[..., 3:4] // 255).astype(np.uint8)
+    t_atlas = TextureRef("blend_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pix, upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+    img_addr = frame.gpu_cache.push([[0, 0, atlas, atlas], [0.0, 0.0, 0.0, 0.0]])
+    groups = []          # (state, [(rect, kind, colour / opacity)])
+    # background content first, so the destination is not uniform: premultiplied translucent rects
+    bg = []
+    for i in range(30):
+        w, h = float(rng.integers(80, 400)), float(rng.integers(80, 400))
+        x, y = float(rng.integers(-40, width - 40)), float(rng.integers(-40, height - 40))
+        rgba = np.array([[rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256), rng.integers(30, 256)]], np.uint8)
+        bg.append(((x, y, x + w, y + h), "solid", premultiply(rgba)[0]))
+    groups.append(("PremultipliedAlpha", bg))
+    for st in states:
+        prims = []
+        for i in range(per_state):
+            w, h = float(rng.integers(40, 300)), float(rng.integers(40, 300))
+            x, y = float(rng.integers(-20, width - 20)), float(rng.integers(-20, height - 20))
+            if i % 3 == 2:
+                x, y = x + float(rng.uniform(0, 1)), y + float(rng.uniform(0, 1))
+            if i % 2 == 0:
+                rgba = np.array([[rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256)]], np.uint8)
+                col = premultiply(rgba)[0] if st != "Alpha" else rgba[0].astype(np.float32) / np.float32(255.0)
+                prims.append(((x, y, x + w, y + h), "solid", col))
+            else:
+                if i % 4 == 1:
+                    w, h = float(atlas), float(atlas)                               # 1:1
+                    x, y = float(int(x)), float(int(y))
+                prims.append(((x, y, x + w, y + h), "image", 1.0 if i % 3 else float(rng.uniform(0.3, 0.9))))
+        groups.append((st, prims))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=clear, clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        z = 1
+        for gi, (st, prims) in enumerate(groups):
+            if only is not None and gi != 0 and st not in only:
+                continue
+            sol, img = [], []
+            for rect, kind, val in prims:
+                z += 1
+                if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                    continue
+                if kind == "solid":
+                    addr = frame.gpu_cache.push([[float(v) for v in val]])
+                    ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), z, addr, 0, task, (65535, 0, 0, 0))
+                    sol.append(frame.brush_instance(ph, CLIP_TASK_EMPTY))
+                else:
+                    spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
+                    ud = (4 | (1 << 16), 0, int(round(val * 65535.0)), 0)
+                    ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), z, spec, 0, task, ud)
+                    img.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=img_addr))
+            if sol:
+                target.alpha.append(Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(sol, dtype=np.int32), st, "alpha", textures={}))
+            if img:
+                target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(img, dtype=np.int32), st, "alpha",
+                                         textures={0: t_atlas}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        frame.composite_tiles.append(CompositeTile(tex, rect, (float(x0), float(y0), float(min(x1, width)), float(min(y1, height))), opaque=True))
+    frame.passes.append(targets)
+    return frame
