@@ -29,6 +29,7 @@ def main():
     out["cfg2_small_frac"] = digest(render_direct(LIB, scenes.cfg2_overlapping_rects(width=1024, height=1024, n=200, seed=7, fractional=True))[0])
     out["cfg2_4k_quad"] = digest(render_direct(LIB, scenes.cfg2_overlapping_rects())[0])
     out["cfg2_4k_brush"] = digest(render_direct(LIB, scenes.cfg2_overlapping_rects(encoding="brush"))[0])
+    out["cfg5_8k"] = digest(render_direct(LIB, scenes.cfg5_many_rects())[0])
     out["cfg5_small"] = digest(render_direct(LIB, scenes.cfg5_many_rects(width=2048, height=1024, n=5000))[0])
     # text: digests are only meaningful with the very same PIL/FreeType glyph
     # bitmaps, so the atlas digest is recorded next to them
@@ -74,3 +75,16 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def abi_surface_golden():
+    """tests/golden/abi_surface.json: digests of everything tests/abi_surface.py observes on the oracle."""
+    import abi_surface
+    d = abi_surface.digest_of(abi_surface.run(LIB))
+    for k in abi_surface.BACKEND_SPECIFIC:
+        d.pop(k, None)
+    json.dump(d, open(os.path.join(ROOT, "tests", "golden", "abi_surface.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    abi_surface_golden()

@@ -54,7 +54,7 @@ struct ObjectStore {
   }
 };
 
-struct Query { uint64_t value = 0; };
+struct Query { uint64_t value = 0; int slot = -1; };   // slot: WrUnsupportedCounters::samples entry a GL_SAMPLES_PASSED query counts into
 
 struct Buffer {
   uint8_t* buf = nullptr;
@@ -88,8 +88,9 @@ struct Texture {
   int ext_stride = 0;
   // depth attachment state (gl.cc:394-420 CLEARED flag; rasterize.h:962)
   bool depth_cleared = false;
-  bool depth_materialized = false;
+  bool depth_materialized = false;   // dptr holds per-pixel depth (u32, width x height) that a pending / later target must load
   uint32_t depth_value = 0xFFFFFF;
+  GLuint depth_owner = 0;            // colour target whose pending work last used this depth attachment
   // hazards against the pending list
   int own_y0 = 0, own_y1 = 0;   // multi-GPU: owned pixel rows (0,0 = all)
   bool pending_read = false, pending_write = false;
@@ -205,6 +206,11 @@ struct TargetWork {
                                    // stops); the data textures of the vertex stage are consumed by the setup kernel of the same flush
   int prims = 0;
   int level = 0;                   // dependency depth inside the pending batch: samples targets of lower levels only
+  // depth: the value the attachment held when this target's first depth-using op was recorded (the renderbuffer is shared by
+  // same-size targets and direct clears change it without recording anything), and whether the caller still expects the
+  // depth these draws leave behind (no InvalidateFramebuffer / full clear by another user since)
+  uint32_t init_depth = 0xFFFFFF;
+  bool init_depth_set = false, depth_live = false;
 };
 
 const size_t MAX_TEXTURE_UNITS = 16;
@@ -308,6 +314,7 @@ struct Context {
   WrhipStats stats;
   std::vector<WrhipKernelStat> kstats;   // per kernel variant, while profiling
   int shard_rank = 0, shard_world = 1;
+  int next_query_slot = 0;
 
   Context() {
     wrrt::stream_create(&stream);
@@ -452,6 +459,17 @@ size_t staging_alloc(size_t n) {
   return off;
 }
 
+// The scatter kernel runs the segments of a batch concurrently: a write that overlaps one already queued must land after
+// it (GL: last write wins), so the batch queued so far goes out first.  Called before the new rows are staged.
+void order_upload(const void* dst, size_t dst_stride, size_t row_bytes, size_t rows) {
+  if (!rows || !row_bytes) return;
+  const uint8_t* b0 = (const uint8_t*)dst; const uint8_t* b1 = b0 + (rows - 1) * dst_stride + row_bytes;
+  for (const Context::UploadSeg& q : ctx->useg) {
+    const uint8_t* a0 = (const uint8_t*)q.dst; const uint8_t* a1 = a0 + (size_t)(q.rows - 1) * q.dst_stride + q.row_bytes;
+    if (a0 < b1 && b0 < a1) { flush_uploads(); return; }
+  }
+}
+
 // Queue rows already written at staging offset `src_off` for texture memory.
 void queue_upload(size_t src_off, void* dst, size_t dst_stride, size_t row_bytes, size_t rows) {
   Context::UploadSeg sg;
@@ -513,16 +531,6 @@ void mark_ref(GLuint id, Texture& t, bool write, int target_index = -1) {
 }
 
 void flush_work(const std::vector<int>& sel);
-
-// Flush every pending target except the one rendering into texture `keep`
-// (whose register-resident depth state would otherwise be lost mid-target).
-// Flushing more than strictly needed keeps the launch count per frame low:
-// all independent targets go through one vertex/bin/raster launch.
-void flush_except(GLuint keep) {
-  std::vector<int> sel;
-  for (size_t i = 0; i < ctx->work.size(); i++) if (ctx->work[i].tex != keep) sel.push_back((int)i);
-  if (!sel.empty()) flush_work(sel);
-}
 
 // A host- or copy-side write to texture `t` (or its deletion / reallocation)
 // must not overtake pending draws that read or write it.
@@ -606,6 +614,7 @@ void set_tex_storage(Texture& t, GLenum external_format, GLsizei width, GLsizei 
     if (!conv) { t.ext_buf = buf; t.ext_stride = stride; }
     // upload current contents of the external buffer
     size_t row = (size_t)t.bpp * width;
+    order_upload(t.dptr, t.stride, row, height);
     size_t st_off = staging_alloc(row * height);
     uint8_t* st = ctx->staging + st_off;
     for (int y = 0; y < height; y++) {
@@ -720,16 +729,39 @@ int find_or_add_work(GLuint tex_id) {
   return idx;
 }
 
+// A colour target is about to use depth attachment `depth_tex` (a test, a write, a partial clear).  If another target's
+// pending draws left depth there that the caller has neither invalidated nor cleared, that target must run first -- its
+// depth is materialised by the flush and loaded here (GL lets a depth buffer be carried from one colour target to the
+// next; WebRender clears it per target and never does).
+void claim_depth(GLuint tex_id, GLuint depth_tex, bool full_clear) {
+  Texture* dt = ctx->textures.find(depth_tex);
+  if (!dt) return;
+  if (dt->depth_owner && dt->depth_owner != tex_id) {
+    Texture* ot = ctx->textures.find(dt->depth_owner);
+    TargetWork* ow = (ot && ot->pending_write && ot->pending_target >= 0) ? &ctx->work[ot->pending_target] : nullptr;
+    if (ow && ow->depth_live && ow->depth_tex == depth_tex) {
+      if (full_clear || !dt->depth_cleared) ow->depth_live = false;      // overwritten / invalidated: nobody will read it
+      else flush_all();
+    }
+  }
+  dt->depth_owner = tex_id;
+}
+
 void record_clear(GLuint tex_id, bool color, uint32_t color_value, bool depth, GLuint depth_tex, uint32_t depth_value,
                   const int rect[4]) {
   {
     Texture& t = ctx->textures[tex_id];
     if (!t.has_storage()) return;
   }
+  if (depth) {
+    const Texture& ct = ctx->textures[tex_id];
+    claim_depth(tex_id, depth_tex, rect[0] <= 0 && rect[1] <= 0 && rect[2] >= ct.width && rect[3] >= ct.height);
+  }
   int wi = find_or_add_work(tex_id);
   Texture& t = ctx->textures[tex_id];
   WrDrawDesc d;
   memset(&d, 0, sizeof(d));
+  d.query_slot = -1;
   d.shader = WR_SH_CLEAR_OP;
   d.target = wi;
   d.count = 1;
@@ -740,7 +772,13 @@ void record_clear(GLuint tex_id, bool color, uint32_t color_value, bool depth, G
   d.clear_depth = depth_value;
   for (int k = 0; k < WR_MAX_ATTRIBS; k++) d.attr_off[k] = -1;
   TargetWork& w = ctx->work[wi];
-  if (depth) w.depth_tex = depth_tex;
+  if (depth) {
+    w.depth_tex = depth_tex;
+    Texture& dt = ctx->textures[depth_tex];
+    if (!w.init_depth_set) { w.init_depth = dt.depth_value; w.init_depth_set = true; }
+    w.depth_live = true;
+    dt.depth_owner = tex_id;
+  }
   w.draws.push_back(d);
   w.prims += 1;
 }
@@ -909,7 +947,8 @@ void flush_work(const std::vector<int>& sel_in) {
     T.first_bin = bin_cursor; T.first_prim = prim_cursor;
     T.load_color = 1; T.init_color = 0; T.load_depth = 0; T.store_depth = 0;
     Texture* dt = w.depth_tex ? c->textures.find(w.depth_tex) : nullptr;
-    T.init_depth = dt ? dt->depth_value : 0xFFFFFF;
+    T.init_depth = w.init_depth_set ? w.init_depth : (dt ? dt->depth_value : 0xFFFFFF);
+    if (dt && dt->depth_materialized && dt->dptr) { T.load_depth = 1; T.depth = (uint32_t*)dt->dptr; }
     T.y_begin = 0; T.y_end = t.height;
     if (t.own_y1 > t.own_y0) {   // WrhipSetTargetRows: rows of this target owned by this process
       T.y_begin = std::max(0, t.own_y0); T.y_end = std::min(t.height, t.own_y1);
@@ -930,7 +969,7 @@ void flush_work(const std::vector<int>& sel_in) {
       if (!any_kept && d.shader == WR_SH_CLEAR_OP && d.clip[0] <= 0 && d.clip[1] <= 0 && d.clip[2] >= t.width &&
           d.clip[3] >= t.height) {
         if (d.flags & WR_DF_CLEAR_COLOR) { T.load_color = 0; T.init_color = d.clear_color; }
-        if (d.flags & WR_DF_CLEAR_DEPTH) { T.init_depth = d.clear_depth; }
+        if (d.flags & WR_DF_CLEAR_DEPTH) { T.init_depth = d.clear_depth; T.load_depth = 0; }
         continue;
       }
       any_kept = true;
@@ -975,17 +1014,31 @@ void flush_work(const std::vector<int>& sel_in) {
       algo_bytes += tb;
       (T.format == WR_FMT_RGBA8 ? L.bytes_rgba : L.bytes_r8) += tb;
     }
-    if (dt && dt->depth_cleared && nrel > 0) {
-      // The depth buffer outlives this flush only as a uniform value; WebRender
-      // always clears before and invalidates after each target, so this only
-      // triggers for foreign call patterns.
-      bool wrote = false;
-      for (const WrDrawDesc& d0 : w.draws) if ((d0.flags & WR_DF_DEPTH_WRITE) && d0.shader != WR_SH_CLEAR_OP) wrote = true;
-      if (wrote) {
-        static bool warned = false;
-        if (!warned) { fprintf(stderr, "libwrhip: depth buffer contents dropped at flush (not invalidated by caller)\n"); warned = true; }
+    if (dt && nrel > 0 && w.depth_live && dt->depth_cleared && dt->depth_owner == w.tex) {
+      // The caller has not invalidated (or fully cleared) the depth these draws leave behind: it outlives the flush -- a
+      // flush in the middle of a target (host upload to a sampled texture, readback of the target being drawn, a
+      // TIME_ELAPSED query) -- so it is materialised: stored per pixel now, loaded by the continuation.  WebRender's own
+      // pattern (clear, draw, InvalidateFramebuffer, flush later) never gets here.
+      bool uses = T.load_depth != 0;
+      for (const WrDrawDesc& d0 : w.draws) if (d0.flags & (WR_DF_DEPTH_WRITE | WR_DF_CLEAR_DEPTH)) uses = true;
+      if (uses) {
+        const size_t need = (size_t)t.width * t.height * 4;
+        if (!dt->dptr || dt->dsize < need || dt->width != t.width || dt->height != t.height) {
+          // (depth attachments have the size of their colour target in every caller; anything else keeps the uniform value)
+          if (dt->width == t.width && dt->height == t.height) {
+            if (dt->dptr) pool_free(dt->dptr, dt->dsize);
+            size_t actual = 0;
+            dt->dptr = pool_alloc(need, &actual); dt->dsize = actual;
+          }
+        }
+        if (dt->dptr && dt->dsize >= need && dt->width == t.width && dt->height == t.height) {
+          T.depth = (uint32_t*)dt->dptr; T.store_depth = 1;
+          dt->depth_materialized = true;
+          L.any_depth = true;
+        }
       }
     }
+    if (T.load_depth) L.any_depth = true;
   }
   const int n_prims = prim_cursor, n_bins = bin_cursor, n_words = word_cursor;
   const int nd = (int)draws.size();
@@ -1325,6 +1378,7 @@ GLint GetLinkStatus(GLuint program) { Program* p = ctx->programs.find(program); 
 void BindAttribLocation(GLuint program, GLuint index, const GLchar* name) {
   Program& p = ctx->programs[program];
   if (!p.info) return;
+  if (index >= NULL_ATTRIB) return;      // 16 attribute slots + the null attribute (gl.cc:577-580)
   for (int k = 0; k < WR_MAX_ATTRIBS + 1 && p.info->attribs[k]; k++) if (!strcmp(p.info->attribs[k], name)) { p.attrib_loc[k] = index; return; }
 }
 GLint GetAttribLocation(GLuint program, const GLchar* name) {
@@ -1355,8 +1409,12 @@ void UniformMatrix4fv(GLint location, GLsizei, GLboolean, const GLfloat* value) 
 void BeginQuery(GLenum target, GLuint id) {
   ctx->get_binding(target) = id;
   Query& q = ctx->queries[id];
-  if (target == GL_SAMPLES_PASSED) q.value = 0;
-  else if (target == GL_TIME_ELAPSED) {
+  if (target == GL_SAMPLES_PASSED) {
+    // shaded pixels of the draws issued inside the query (gl.cc:2784-2787), counted by the setup stage into a device slot
+    q.value = 0;
+    q.slot = ctx->next_query_slot; ctx->next_query_slot = (ctx->next_query_slot + 1) % WR_QUERY_SLOTS;
+    wrrt::memset8(&ctx->dcounters->samples[q.slot], 0, sizeof(unsigned long long), ctx->stream);
+  } else if (target == GL_TIME_ELAPSED) {
     // TIME_ELAPSED must cover the GPU work issued inside the query (renderer
     // GpuProfiler, device/query_gl.rs:141-163): drain what came before.
     flush_all(); sync_stream();
@@ -1372,7 +1430,17 @@ void EndQuery(GLenum target) {
   ctx->get_binding(target) = 0;
 }
 void GetQueryObjectui64v(GLuint id, GLenum pname, GLuint64* params) {
-  if (pname == GL_QUERY_RESULT) params[0] = ctx->queries[id].value;
+  if (pname != GL_QUERY_RESULT) return;
+  Query& q = ctx->queries[id];
+  if (q.slot >= 0) {
+    flush_all();
+    unsigned long long v = 0;
+    wrrt::d2h(&v, &ctx->dcounters->samples[q.slot], sizeof(v), ctx->stream);
+    sync_stream();
+    q.value = v;
+    if (ctx->samples_passed_query != id) q.slot = -1;      // ended: the slot may be reused
+  }
+  params[0] = q.value;
 }
 
 void BindVertexArray(GLuint vao) { ctx->current_vertex_array = vao; }
@@ -1419,6 +1487,12 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
   bool conv = format_requires_conversion(format, t.internal_format);
   size_t src_stride = (size_t)row_length * t.bpp;
   size_t row = (size_t)width * t.bpp;
+  if (ctx->pixel_unpack_buffer_binding) {      // the rows must lie inside the bound pixel-unpack buffer
+    const Buffer& pb = ctx->buffers[ctx->pixel_unpack_buffer_binding];
+    const size_t off = (size_t)data_, need = (size_t)(height - 1) * src_stride + row;
+    if (off > pb.size || need > pb.size - off) return;
+  }
+  order_upload((uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, row, height);
   size_t st_off = staging_alloc(row * height);
   uint8_t* st = ctx->staging + st_off;
   for (int y = 0; y < height; y++) {
@@ -1606,7 +1680,12 @@ void ClearTexSubImage(GLenum texture, GLint level, GLint xoffset, GLint yoffset,
     // Depth is cleared through the colour target it is attached to (see Clear);
     // a direct clear just records the uniform value (gl.cc:2405-2415).
     bool full = rect[0] <= 0 && rect[1] <= 0 && rect[2] >= t.width && rect[3] >= t.height;
-    if (!t.depth_cleared || full) { t.depth_cleared = true; t.depth_value = value; t.depth_materialized = false; }
+    if (!t.depth_cleared || full) {
+      if (Texture* ot = t.depth_owner ? ctx->textures.find(t.depth_owner) : nullptr)
+        if (ot->pending_write && ot->pending_target >= 0 && ctx->work[ot->pending_target].depth_tex == texture)
+          ctx->work[ot->pending_target].depth_live = false;
+      t.depth_cleared = true; t.depth_value = value; t.depth_materialized = false;
+    }
     return;
   }
   uint32_t color = 0xFF000000;
@@ -1666,7 +1745,7 @@ void Clear(GLbitfield mask) {
       if (!dt.depth_cleared) { rect[0] = 0; rect[1] = 0; rect[2] = dt.width; rect[3] = dt.height; full = true; }
       record_clear(fb.color_attachment, false, 0, true, fb.depth_attachment, dvalue, rect);
     }
-    if (full) dt.depth_value = dvalue;
+    if (full) { dt.depth_value = dvalue; dt.depth_materialized = false; }
     dt.depth_cleared = true;
   }
   if ((mask & GL_COLOR_BUFFER_BIT) && fb.color_attachment) {
@@ -1695,6 +1774,10 @@ void InvalidateFramebuffer(GLenum target, GLsizei num_attachments, const GLenum*
     if (attachments[i] == GL_DEPTH_ATTACHMENT && fb->depth_attachment) {
       Texture& t = ctx->textures[fb->depth_attachment];
       t.depth_cleared = false; t.depth_materialized = false;
+      // the pending draws of the target it was attached to need not leave their depth behind
+      if (Texture* ot = t.depth_owner ? ctx->textures.find(t.depth_owner) : nullptr)
+        if (ot->pending_write && ot->pending_target >= 0 && ctx->work[ot->pending_target].depth_tex == fb->depth_attachment)
+          ctx->work[ot->pending_target].depth_live = false;
     }
   }
 }
@@ -1758,31 +1841,60 @@ void CopyTexSubImage2D(GLenum target, GLint, GLint xoffset, GLint yoffset, GLint
                    yoffset, 0, width, height, 1);
 }
 void BlitFramebuffer(GLint srcX0, GLint srcY0, GLint srcX1, GLint srcY1, GLint dstX0, GLint dstY0, GLint dstX1, GLint dstY1,
-                     GLbitfield mask, GLenum) {
-  // composite.h:434-483.  Only the unscaled, unflipped copy WebRender's
-  // blit_render_target uses for same-size blits is implemented ("next": scaled).
+                     GLbitfield mask, GLenum filter) {
+  // composite.h:432-483: no scissor, Y flips forced onto the dest side, nearest stepping (scale_blit) unless a scaled
+  // GL_LINEAR blit between equal renderable formats (linear_blit)
   if (!(mask & GL_COLOR_BUFFER_BIT)) return;
   Framebuffer* srcfb = get_framebuffer(GL_READ_FRAMEBUFFER);
   Framebuffer* dstfb = get_framebuffer(GL_DRAW_FRAMEBUFFER);
   if (!srcfb || !dstfb) return;
-  if (srcX1 - srcX0 != dstX1 - dstX0 || srcY1 - srcY0 != dstY1 - dstY0 || srcX1 < srcX0 || srcY1 < srcY0) {
-    fprintf(stderr, "libwrhip: scaled/flipped BlitFramebuffer not implemented\n");
-    return;
-  }
   Texture& s = ctx->textures[srcfb->color_attachment];
   Texture& d = ctx->textures[dstfb->color_attachment];
-  int w = srcX1 - srcX0, h = srcY1 - srcY0;
-  int sx = srcX0 - s.offx, sy = srcY0 - s.offy, dx = dstX0 - d.offx, dy = dstY0 - d.offy;
-  // clip to both textures
-  int cx0 = std::max(std::max(0, -sx), -dx), cy0 = std::max(std::max(0, -sy), -dy);
-  int cx1 = std::min(std::min(w, s.width - sx), d.width - dx), cy1 = std::min(std::min(h, s.height - sy), d.height - dy);
-  if (ctx->scissortest) {
-    cx0 = std::max(cx0, ctx->scissor[0] - d.offx - dx); cy0 = std::max(cy0, ctx->scissor[1] - d.offy - dy);
-    cx1 = std::min(cx1, ctx->scissor[2] - d.offx - dx); cy1 = std::min(cy1, ctx->scissor[3] - d.offy - dy);
+  if (!s.dptr || !d.dptr) return;
+  auto renderable = [](GLenum f) { return f == GL_R8 || f == GL_RG8 || f == GL_RGBA8; };
+  if (s.internal_format != d.internal_format && (!renderable(s.internal_format) || !renderable(d.internal_format))) return;
+  if (srcY1 < srcY0) { std::swap(srcY0, srcY1); std::swap(dstY0, dstY1); }
+  const bool invertY = dstY1 < dstY0;
+  if (invertY) std::swap(dstY0, dstY1);
+  const int sr[4] = {srcX0 - s.offx, srcY0 - s.offy, srcX1 - s.offx, srcY1 - s.offy};
+  const int dr[4] = {dstX0 - d.offx, dstY0 - d.offy, dstX1 - d.offx, dstY1 - d.offy};
+  const int srcW = sr[2] - sr[0], srcH = sr[3] - sr[1], dstW = dr[2] - dr[0], dstH = dr[3] - dr[1];
+  if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return;
+  const bool linear = !(srcW == dstW && srcH == dstH) && s.width >= 2 && filter == GL_LINEAR && s.internal_format == d.internal_format &&
+                      (s.internal_format == GL_RGBA8 || s.internal_format == GL_R8);
+  // dest bounds: dsttex.sample_bounds(dstReq) ∩ clipRect (= the whole request)
+  int b[4] = {std::max(0, dr[0]) - dr[0], std::max(0, dr[1]) - dr[1], std::min(d.width, dr[2]) - dr[0], std::min(d.height, dr[3]) - dr[1]};
+  b[0] = std::max(b[0], 0); b[1] = std::max(b[1], 0); b[2] = std::min(b[2], dstW); b[3] = std::min(b[3], dstH);
+  if (linear) {
+    // BlitFramebuffer hands linear_blit the dest request itself as clip rect (composite.h:478), and linear_blit intersects it
+    // with bounds that are RELATIVE to the request (composite.h:352-353): the reference's result, reproduced
+    b[0] = std::max(b[0], dr[0]); b[1] = std::max(b[1], dr[1]); b[2] = std::min(b[2], dr[2]); b[3] = std::min(b[3], dr[3]);
   }
-  if (cx1 <= cx0 || cy1 <= cy0) return;
-  CopyImageSubData(srcfb->color_attachment, GL_TEXTURE_2D, 0, sx + cx0, sy + cy0, 0, dstfb->color_attachment, GL_TEXTURE_2D,
-                   0, dx + cx0, dy + cy0, 0, cx1 - cx0, cy1 - cy0, 1);
+  if (!linear) {
+    // source texture bounds relative to the request, flipped if need be, scaled to dest space rounding inward
+    int c[4] = {0 - sr[0], 0 - sr[1], s.width - sr[0], s.height - sr[1]};
+    if (invertY) { const int y0 = srcH - c[1], y1 = srcH - c[3]; c[1] = y1; c[3] = y0; }
+    c[0] = (c[0] * dstW + (srcW - 1)) / srcW; c[1] = (c[1] * dstH + (srcH - 1)) / srcH;
+    c[2] = (c[2] * dstW) / srcW; c[3] = (c[3] * dstH) / srcH;
+    b[0] = std::max(b[0], c[0]); b[1] = std::max(b[1], c[1]); b[2] = std::min(b[2], c[2]); b[3] = std::min(b[3], c[3]);
+  }
+  if (b[2] <= b[0] || b[3] <= b[1]) return;
+  if (!linear && !invertY && srcW == dstW && srcH == dstH && s.internal_format == d.internal_format) {
+    CopyImageSubData(srcfb->color_attachment, GL_TEXTURE_2D, 0, sr[0] + b[0], sr[1] + b[1], 0, dstfb->color_attachment, GL_TEXTURE_2D,
+                     0, dr[0] + b[0], dr[1] + b[1], 0, b[2] - b[0], b[3] - b[1], 1);
+    return;
+  }
+  sync_texture_for_read(s);
+  sync_texture_for_write(d);
+  flush_uploads();
+  WrBlitArgs a;
+  a.src = s.dptr; a.dst = d.dptr; a.src_stride = s.stride; a.dst_stride = d.stride; a.sbpp = s.bpp; a.dbpp = d.bpp;
+  a.sw = s.width; a.sh = s.height;
+  a.srx0 = sr[0]; a.sry0 = sr[1]; a.srw = srcW; a.srh = srcH; a.drx0 = dr[0]; a.dry0 = dr[1]; a.drw = dstW; a.drh = dstH;
+  a.bx0 = b[0]; a.by0 = b[1]; a.bx1 = b[2]; a.by1 = b[3]; a.invert_y = invertY ? 1 : 0; a.linear = linear ? 1 : 0;
+  const long long n = (long long)(b[2] - b[0]) * (b[3] - b[1]);
+  WR_LAUNCH(wr_blit_kernel, (int)((n + 255) / 256), 256, ctx->stream, a);
+  ctx->stats.kernel_launches++;
 }
 
 // ---- the hot path: record one instanced batch ------------------------------
@@ -1825,8 +1937,9 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     static const int lane_vertex[4] = {0, 1, 3, 2};
     for (int n = 0; n < 4; n++) {
       float xy[2] = {0.f, 0.f};
-      if (loc != NULL_ATTRIB && va.enabled && vb.buf) {
-        const uint8_t* src = vb.buf + (size_t)va.stride * (idx[0] + lane_vertex[n]) + va.offset;
+      const size_t voff = (size_t)va.stride * (idx[0] + lane_vertex[n]) + va.offset;
+      if (loc != NULL_ATTRIB && va.enabled && vb.buf && voff + va.size <= vb.size) {
+        const uint8_t* src = vb.buf + voff;
         int comps = 2;
         for (int k = 0; k < comps; k++) {
           if (va.type == GL_UNSIGNED_BYTE) {
@@ -1860,6 +1973,10 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   size_t need = (size_t)inst_stride * instancecount;
   if (!instb || !instb->buf || need > instb->size) {
     if (inst_buf) { fprintf(stderr, "libwrhip: instance buffer too small\n"); return; }
+  }
+  if (c->depthtest && fb.depth_attachment) {
+    Texture* dtx = c->textures.find(fb.depth_attachment);
+    if (dtx && dtx->internal_format == GL_DEPTH_COMPONENT24 && dtx->depth_cleared) claim_depth(color_id, fb.depth_attachment, false);
   }
   int wi = find_or_add_work(color_id);   // may flush (target sampled by pending draws)
   // A pending target that gets sampled is not flushed on the spot: the sampling target moves one
@@ -1914,8 +2031,12 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     d.flags |= WR_DF_DEPTH_TEST;
     if (c->depthmask) d.flags |= WR_DF_DEPTH_WRITE;
     if (c->depthfunc == GL_LESS) d.flags |= WR_DF_DEPTH_LESS;
-    c->work[wi].depth_tex = fb.depth_attachment;
+    TargetWork& dw = c->work[wi];
+    dw.depth_tex = fb.depth_attachment;
+    if (!dw.init_depth_set) { dw.init_depth = depthtex->depth_value; dw.init_depth_set = true; }
+    dw.depth_live = true;
   }
+  d.query_slot = c->samples_passed_query ? c->queries[c->samples_passed_query].slot : -1;
   {
     // draws that can only produce solid prims with a blend the inline raster paths know (WrFeat)
     const bool plain_blend = d.blend == WR_BLEND_NONE || d.blend == WR_BLEND_PREMULT;
@@ -2064,13 +2185,13 @@ void Composite(LockedTexture*, LockedTexture*, GLint, GLint, GLsizei, GLsizei, G
                GLboolean, GLboolean, GLenum, GLint, GLint, GLsizei, GLsizei) {
   // Gecko's software-compositor entry point; wrench composites through the
   // `composite` shader instead.  Out of scope, fails loudly.
-  fprintf(stderr, "libwrhip: Composite() is not implemented (out of scope)\n");
-  abort();
+  fprintf(stderr, "libwrhip: Composite() is not implemented (Gecko's software compositor entry point, out of scope)\n");
+  if (ctx) ctx->last_error = GL_INVALID_OPERATION;
 }
 void CompositeYUV(LockedTexture*, LockedTexture*, LockedTexture*, LockedTexture*, YuvRangedColorSpace, GLuint, GLint, GLint,
                   GLsizei, GLsizei, GLint, GLint, GLsizei, GLsizei, GLboolean, GLboolean, GLint, GLint, GLsizei, GLsizei) {
-  fprintf(stderr, "libwrhip: CompositeYUV() is not implemented (out of scope)\n");
-  abort();
+  fprintf(stderr, "libwrhip: CompositeYUV() is not implemented (Gecko's software compositor entry point, out of scope)\n");
+  if (ctx) ctx->last_error = GL_INVALID_OPERATION;
 }
 
 // ---- libwrhip additions ------------------------------------------------------

@@ -1305,6 +1305,25 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
   return Q.nseg > 0;
 }
 
+// The span of row y of a general quad (aa_span, rasterize.h:520-561): [s0, s1) -- with swgl_antiAlias the rounded-out one,
+// [la0, ra1).  False: the row is outside the walk.
+WR_DEVICE bool wr_quad_row_span(const WrQuadRec& Q, int y, int& s0, int& s1) {
+  int si = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  if (si < 0) return false;
+  const WrQuadSeg& S = Q.seg[si];
+  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
+  if (!Q.aa) {
+    s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+  } else {
+    const float radl = 0.5f * fabsf(S.ls), radr = 0.5f * fabsf(S.rs);
+    s0 = S.lmask ? int(floorf(wr_clamp(xl - radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+    s1 = S.rmask ? int(ceilf(wr_clamp(xr + radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+  }
+  return true;
+}
+
 // draw_quad (rasterize.h:1549-1633) + the axis-aligned closed form of
 // draw_quad_spans (rasterize.h:783-1055): for a rectangle both edge slopes are
 // exactly 0, so every row has the same span and rows are those whose centre
@@ -2503,6 +2522,16 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
       return;
   }
   wr_finish_prim(d, lo, o, P, &aux[gid], cnt);
+  if (d.query_slot >= 0 && P.kind != WR_PK_NONE && P.kind != WR_PK_UNSUPPORTED) {
+    // GL_SAMPLES_PASSED: ctx->shaded_pixels += span.len() for every row with a non-empty span, before any depth test
+    unsigned long long n = 0;
+    if (P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) {
+      for (int y = P.y0; y < P.y1; y++) { int s0, s1; if (wr_quad_row_span(aux[gid].quad, y, s0, s1) && s1 > s0) n += (unsigned long long)(s1 - s0); }
+    } else {
+      n = (unsigned long long)(P.x1 - P.x0) * (unsigned long long)(P.y1 - P.y0);
+    }
+    if (n) atomicAdd(&cnt->samples[d.query_slot & (WR_QUERY_SLOTS - 1)], n);
+  }
 }
 
 
@@ -2768,23 +2797,57 @@ __global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_seg
   }
 }
 
-// The span of row y of a general quad (aa_span, rasterize.h:520-561): [s0, s1) -- with swgl_antiAlias the rounded-out one,
-// [la0, ra1).  False: the row is outside the walk.
-WR_DEVICE bool wr_quad_row_span(const WrQuadRec& Q, int y, int& s0, int& s1) {
-  int si = -1;
-#pragma unroll
-  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
-  if (si < 0) return false;
-  const WrQuadSeg& S = Q.seg[si];
-  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
-  if (!Q.aa) {
-    s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
-  } else {
-    const float radl = 0.5f * fabsf(S.ls), radr = 0.5f * fabsf(S.rs);
-    s0 = S.lmask ? int(floorf(wr_clamp(xl - radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
-    s1 = S.rmask ? int(ceilf(wr_clamp(xr + radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+// BlitFramebuffer with scaling / flipping / format conversion (composite.h:62-283, 285-418); one thread per dest pixel.
+__global__ void wr_blit_kernel(WrBlitArgs a) {
+  const int bw = a.bx1 - a.bx0, bh = a.by1 - a.by0;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)bw * bh) return;
+  const int i = int(idx % bw), j = int(idx / bw);
+  const int X = a.bx0 + i, Y = a.by0 + j;
+  uint8_t* dp = (uint8_t*)a.dst + (size_t)(a.dry0 + Y) * a.dst_stride + (size_t)(a.drx0 + X) * a.dbpp;
+  if (!a.linear) {
+    // scale_row's stepping: the source column of dest column X is floor(srcWidth * X / dstWidth), rows likewise
+    const int sx = a.srx0 + int((long long)a.srw * X / a.drw);
+    const int syr = int((long long)a.srh * Y / a.drh);
+    const int sy = a.invert_y ? a.sry0 + a.srh - 1 - syr : a.sry0 + syr;
+    const uint8_t* sp = (const uint8_t*)a.src + (size_t)sy * a.src_stride + (size_t)sx * a.sbpp;
+    if (a.sbpp == a.dbpp) { for (int k = 0; k < a.dbpp; k++) dp[k] = sp[k]; return; }
+    // convert_pixel (composite.h:5-70)
+    uint32_t v = 0;
+    if (a.sbpp == 4) __builtin_memcpy(&v, sp, 4); else if (a.sbpp == 2) { uint16_t h; __builtin_memcpy(&h, sp, 2); v = h; } else v = sp[0];
+    if (a.dbpp == 4) {
+      const uint32_t o = a.sbpp == 1 ? ((v << 16) | 0xFF000000u) : (((v & 0x00FFu) << 16) | (v & 0xFF00u) | 0xFF000000u);
+      __builtin_memcpy(dp, &o, 4);
+    } else if (a.dbpp == 1) {
+      dp[0] = a.sbpp == 4 ? uint8_t((v >> 16) & 0xFF) : uint8_t(v & 0xFF);
+    } else {
+      const uint16_t o = a.sbpp == 4 ? uint16_t(((v >> 16) & 0x00FF) | (v & 0xFF00)) : uint16_t(v);
+      __builtin_memcpy(dp, &o, 2);
+    }
+    return;
   }
-  return true;
+  // linear_blit: srcUV = quantize(srcReq.origin (+ size when flipped) + srcDUV * (dstBounds.origin + 0.5)), stepped by
+  // srcDUV * 128 per pixel (init_interp lanes, then one add of 4 * srcDU per 4-pixel chunk) and per row
+  float u0 = float(a.srx0), v0 = float(a.sry0);
+  float du = float(a.srw) / float(a.drw), dv = float(a.srh) / float(a.drh);
+  if (a.invert_y) { v0 += float(a.srh); dv = -dv; }
+  u0 += du * (float(a.bx0) + 0.5f); v0 += dv * (float(a.by0) + 0.5f);
+  u0 = u0 * 128.0f + (0.5f - 0.5f * 128.0f); v0 = v0 * 128.0f + (0.5f - 0.5f * 128.0f);
+  du *= 128.0f; dv *= 128.0f;
+  float lu = u0;
+  for (int k = 0; k < (i & 3); k++) lu = lu + du;
+  lu = wr_accum(lu, 4.0f * du, i >> 2);
+  const float lv = wr_accum(v0, dv, j);
+  WrTexDesc t;
+  t.ptr = a.src; t.width = a.sw; t.height = a.sh; t.stride = a.sbpp == 4 ? a.src_stride / 4 : (a.sbpp == 2 ? a.src_stride / 2 : a.src_stride);
+  t.format = a.sbpp == 4 ? WR_FMT_RGBA8 : WR_FMT_R8; t.linear = 1;
+  if (a.sbpp == 4) {
+    const WrWide w = wr_sample_linear_rgba8(t, int(lu), int(lv));
+    const uint32_t o = wr_pack(w);
+    __builtin_memcpy(dp, &o, 4);
+  } else {
+    dp[0] = (uint8_t)wr_pack1(uint32_t(wr_sample_linear_r8(t, int(lu), int(lv))) & 0xFFFF);
+  }
 }
 
 // One pixel of a solid colour on a general quad: this row's span from the edge instances of its run
@@ -4028,6 +4091,28 @@ WR_DEVICE void wr_sweep_runs(WrRuns& R, int a, int b, int nc, IV iv) {
   }
   R.n = overflow ? 0 : n;
 }
+// The same for a target that continues from a materialised depth buffer (a flush in the middle of the target: the prims
+// that wrote it are gone): pixel by pixel, a pixel passes when it passes against the loaded depth AND no candidate of this
+// flush covers it.  A foreign call pattern (WebRender never flushes mid-target with depth live); kept simple, not fast.
+template <typename IV>
+WR_DEVICE void wr_scan_runs(WrRuns& R, int a, int b, int nc, IV iv, const uint32_t* __restrict__ drow, uint32_t z, bool less) {
+  int n = 0, x = a;
+  bool overflow = false;
+  auto pass = [&](int px) {
+    if (!(less ? z < drow[px] : z <= drow[px])) return false;
+    for (int c = 0; c < nc; c++) { int lo, hi; iv(c, lo, hi); if (lo <= px && px < hi) return false; }
+    return true;
+  };
+  while (x < b) {
+    while (x < b && !pass(x)) x++;
+    if (x >= b) break;
+    const int s0 = x;
+    while (x < b && pass(x)) x++;
+    if (n == WR_MAX_RUNS) { overflow = true; break; }
+    R.s[n] = s0; R.e[n] = x; n++;
+  }
+  R.n = overflow ? 0 : n;
+}
 template <int R4>
 WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, int pidx,
                                       int x0, int y0, int x1, int y1, uint32_t z, uint32_t kbf, int wy0, int lane, int wave,
@@ -4037,6 +4122,7 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
   const int end = wr_imin(T.dw_end, pidx);
   const int ry0 = wr_imax(y0, wy0), ry1 = wr_imin(y1, wy0 + 4 * R4);
   const bool quad = kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD;
+  const bool loaded = T.load_depth && T.depth;       // continuation of a target whose depth was materialised
 #ifdef WRHIP_HOSTSIM
   // serial restatement: this thread does the whole wave's work for its own rows
   static int cidx[WR_MAX_OCC];
@@ -4051,7 +4137,7 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
     if (nc < WR_MAX_OCC) cidx[nc] = i;
     nc++;
   }
-  if (nc == 0) return nullptr;
+  if (nc == 0 && !loaded) return nullptr;
   if (nc > WR_MAX_OCC) return nullptr;          // (more occluders than the list holds: evaluated from the span start, as if unoccluded)
   for (int j = 0; j < R4; j++) {
     const int r = (lane >> 4) + 4 * j, y = wy0 + r;
@@ -4060,7 +4146,9 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
     if (y < ry0 || y >= ry1) continue;
     int a = x0, b = x1;
     if (quad) { int s0, s1; if (!wr_quad_row_span(aux[pidx].quad, y, s0, s1)) continue; a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
-    wr_sweep_runs(RR, a, b, nc, [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, cidx[c], y, lo, hi); });
+    auto iv = [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, cidx[c], y, lo, hi); };
+    if (loaded) wr_scan_runs(RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
+    else wr_sweep_runs(RR, a, b, nc, iv);
   }
   return runs;
 #else
@@ -4085,7 +4173,7 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
     }
     nc += __popcll(m);
   }
-  if (nc == 0 || nc > WR_MAX_OCC) return nullptr;
+  if ((nc == 0 && !loaded) || nc > WR_MAX_OCC) return nullptr;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int idx = lane; idx < nc * 4 * R4; idx += 64) {
     const int c = idx / (4 * R4), r = idx - c * (4 * R4);
@@ -4102,7 +4190,9 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
       int a = x0, b = x1;
       bool ok = true;
       if (quad) { int s0, s1; ok = wr_quad_row_span(aux[pidx].quad, y, s0, s1); a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
-      if (ok) wr_sweep_runs(RR, a, b, nc, [&](int c, int& lo, int& hi) { lo = ivs[wave][c][r][0]; hi = ivs[wave][c][r][1]; });
+      auto iv = [&](int c, int& lo, int& hi) { lo = ivs[wave][c][r][0]; hi = ivs[wave][c][r][1]; };
+      if (ok && loaded) wr_scan_runs(RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
+      else if (ok) wr_sweep_runs(RR, a, b, nc, iv);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -4737,7 +4827,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const int rblend = (Rc.kbf >> 8) & 0xFF;
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
-        if (((Rc.kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(Rc.kbf & 0xFF) && T.dw_end > T.dw_first && base + bit > T.dw_first)
+        if (((Rc.kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(Rc.kbf & 0xFF) && ((T.dw_end > T.dw_first && base + bit > T.dw_first) || T.load_depth))
           rr = wr_build_runs<R>(T, recs, aux, base + bit, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, wy0, lane, wave);
       }
       if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED || ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
@@ -4787,7 +4877,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const int rblend = (kbf >> 8) & 0xFF;
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
-        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && T.dw_end > T.dw_first && base + bit > T.dw_first)
+        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && base + bit > T.dw_first) || T.load_depth))
           rr = wr_build_runs<R>(T, recs, aux, base + bit, x0, y0, x1, y1, z, kbf, wy0, lane, wave);
       }
       if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_SOLID_MASKED || ((kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&

@@ -148,6 +148,8 @@ struct WrDrawDesc {
   int32_t attr_bytes[WR_MAX_ATTRIBS];
   int32_t vtab_base;     // first entry of this draw's per-row v table (-1: none), vtab_rows entries per instance
   int32_t vtab_rows;
+  int32_t query_slot;    // GL_SAMPLES_PASSED query active around this draw: slot of WrUnsupportedCounters::samples (-1: none)
+  int32_t pad_q;
   uint32_t attr_u16;     // bit k: attribute k is made of 16-bit unsigned integers (VertexAttributeKind::U16) // bytes provided by the VAO for that attribute (VertexAttrib::size)
   WrTexDesc tex[WR_MAX_TEX];
 };
@@ -404,8 +406,24 @@ struct WrFlushParams {
 };
 
 // statistics mirrored into WrhipStats (include/wrhip.h)
+#define WR_QUERY_SLOTS 64
 struct WrUnsupportedCounters {
   uint32_t unsupported_prims;
   uint32_t perspective_prims;
   uint32_t dbg[6];          // diagnostics (WRHIP_DEBUG_COUNTERS)
+  unsigned long long samples[WR_QUERY_SLOTS];   // GL_SAMPLES_PASSED: shaded pixels = sum of span lengths (rasterize.h:957-958, gl.cc:2784-2787)
+};
+
+// BlitFramebuffer (composite.h:167-283 scale_blit, 342-418 linear_blit): dst pixel (bx0 + i, by0 + j) of the requested
+// rect, sampled from the requested source rect with the reference's integer stepping (nearest) or its 1/128-texel
+// quantised uv walk (linear).
+struct WrBlitArgs {
+  const void* src; void* dst;
+  int32_t src_stride, dst_stride;      // bytes
+  int32_t sbpp, dbpp;
+  int32_t sw, sh;                      // source texture size
+  int32_t srx0, sry0, srw, srh;        // source request (texture pixels)
+  int32_t drx0, dry0, drw, drh;        // dest request
+  int32_t bx0, by0, bx1, by1;          // valid dest bounds, relative to the dest request
+  int32_t invert_y, linear;
 };
