@@ -187,7 +187,8 @@ def test_hostsim_matches_golden_without_oracle(hostsim):
 
 def test_repeated_frames_and_launch_count(hostsim):
     """Steady state: a whole frame (tile pass + composite that samples the tiles) is ONE flush
-    -- one upload scatter, one setup launch -- with one raster launch per dependency level."""
+    -- one upload scatter, one setup launch -- and, the composite being an opaque 1:1 copy of tiles that were
+    all redrawn, ONE raster launch: the tile pass writes the window as well (forwarded composites)."""
     frame = scenes.cfg2_overlapping_rects(width=2048, height=1024, n=100, seed=9)
     from webrender_amd.glapi import GL
     from webrender_amd.renderer import Renderer
@@ -198,7 +199,7 @@ def test_repeated_frames_and_launch_count(hostsim):
     gl.WrhipResetStats()
     r.render(frame); r.finish()
     st = gl.stats()
-    assert st["flushes"] == 1 and st["raster_launches"] == 2 and st["kernel_launches"] <= 4, st
+    assert st["flushes"] == 1 and st["raster_launches"] == 1 and st["kernel_launches"] <= 3, st
     assert np.array_equal(r.read_pixels(), first)
     r.destroy()
 

@@ -211,6 +211,9 @@ struct TargetWork {
   // depth these draws leave behind (no InvalidateFramebuffer / full clear by another user since)
   uint32_t init_depth = 0xFFFFFF;
   bool init_depth_set = false, depth_live = false;
+  // forwarded composite (set per flush by plan_forwarding): this target's finished pixels are also stored into `fwd_tex`
+  GLuint fwd_tex = 0; int fwd_dx = 0, fwd_y0 = 0, fwd_ys = 1, fwd_clip[4] = {0, 0, 0, 0};
+  bool forwarded_away = false;     // every draw of this target was turned into write-throughs of its sources: nothing left to rasterise
 };
 
 const size_t MAX_TEXTURE_UNITS = 16;
@@ -315,12 +318,15 @@ struct Context {
   std::vector<WrhipKernelStat> kstats;   // per kernel variant, while profiling
   int shard_rank = 0, shard_world = 1;
   int next_query_slot = 0;
+  bool forward_composites = true;      // WRHIP_NO_FORWARD=1 turns the write-through of opaque 1:1 composites off
+  bool profiling_no_forward = false;
 
   Context() {
     wrrt::stream_create(&stream);
     wrrt::stream_create(&copy_stream);
     wrrt::event_create_sync(&ev_copy);
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
+    forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
@@ -908,12 +914,116 @@ void sync_stream() {
   wrrt::stream_sync(ctx->stream);
 }
 
+// Forwarded composites.  A target whose pending work is [full clear,] N draws of `composite FAST_PATH` that each copy a whole
+// RGBA8 target of the same flush, unblended, texel for pixel (integer placement, optional y flip through the projection),
+// disjoint and together covering it completely -- the window of a frame whose picture-cache tiles were all redrawn -- does
+// not need a raster pass of its own: the tile pass stores each tile's pixels there as well (WrTargetDesc::fwd_*), which saves
+// the composite's read of every tile (4 B per window pixel) and a launch.  Anything else falls back to the ordinary path.
+static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
+  Context* c = ctx;
+  Texture& ft = c->textures[fb.tex];
+  if (ft.internal_format != GL_RGBA8 || ft.own_y1 > ft.own_y0 || c->shard_world > 1 || c->profiling_no_forward) return false;
+  struct Plan { int src; int dx, y0, ys, clip[4]; };
+  std::vector<Plan> plans;
+  bool seen_draw = false;
+  for (const WrDrawDesc& d : fb.draws) {
+    if (d.shader == WR_SH_CLEAR_OP) {
+      const bool full = d.clip[0] <= 0 && d.clip[1] <= 0 && d.clip[2] >= ft.width && d.clip[3] >= ft.height;
+      if (seen_draw || !full || (d.flags & WR_DF_CLEAR_DEPTH)) return false;
+      continue;
+    }
+    seen_draw = true;
+    if (d.shader != WR_SH_COMPOSITE_FAST || d.blend != WR_BLEND_NONE || (d.flags & (WR_DF_DEPTH_TEST | WR_DF_DEPTH_WRITE)) || d.query_slot >= 0) return false;
+    if (d.attr_off[0] < 0 || d.attr_off[1] < 0 || d.attr_off[4] < 0 || d.attr_bytes[0] < 16 || d.attr_bytes[1] < 16 || d.attr_bytes[4] < 16) return false;
+    if (d.quad[0] != 0.f || d.quad[1] != 0.f || d.quad[2] != 1.f || d.quad[3] != 0.f || d.quad[4] != 1.f || d.quad[5] != 1.f || d.quad[6] != 0.f || d.quad[7] != 1.f) return false;
+    const WrTexDesc& st = d.tex[WR_S_COLOR0];
+    if (!st.ptr || st.format != WR_FMT_RGBA8) return false;
+    int src = -1;
+    for (int wi : sel) if (&c->work[wi] != &fb && c->textures[c->work[wi].tex].dptr == st.ptr && c->work[wi].level < fb.level) src = wi;
+    if (src < 0) return false;
+    const Texture& stex = c->textures[c->work[src].tex];
+    if (stex.own_y1 > stex.own_y0) return false;
+    for (int i = 0; i < d.count; i++) {
+      const uint8_t* ip = fb.inst.data() + d.inst_offset + (size_t)i * d.inst_stride;
+      float rect[4], clip[4], prm[4] = {0, 0, 0, 0}, uv[4], flip[2] = {0, 0};
+      memcpy(rect, ip + d.attr_off[0], 16); memcpy(clip, ip + d.attr_off[1], 16); memcpy(uv, ip + d.attr_off[4], 16);
+      if (d.attr_off[3] >= 0 && d.attr_bytes[3] >= 16) memcpy(prm, ip + d.attr_off[3], 16);
+      if (d.attr_off[5] >= 0 && d.attr_bytes[5] >= 8) memcpy(flip, ip + d.attr_off[5], 8);
+      if (flip[0] != 0.f || flip[1] != 0.f || int(prm[1]) == 1 || uv[0] != 0.f || uv[1] != 0.f || uv[2] != 1.f || uv[3] != 1.f) return false;
+      // device space -> target pixels through the draw's projection and viewport, as the vertex stage + draw_quad do it
+      auto to_px = [&](float x, float y, float& sx, float& sy) {
+        const float* m = d.transform;
+        const float gx = m[0] * x + m[4] * y + m[12], gy = m[1] * x + m[5] * y + m[13], gw = m[3] * x + m[7] * y + m[15];
+        sx = (gx / gw + 1.0f) * 0.5f * d.vp_size[0] + d.vp_origin[0];
+        sy = (gy / gw + 1.0f) * 0.5f * d.vp_size[1] + d.vp_origin[1];
+      };
+      if (d.transform[1] != 0.f || d.transform[4] != 0.f || d.transform[3] != 0.f || d.transform[7] != 0.f) return false;   // axis-aligned, affine
+      float x0, y0, x1, y1, cx0, cy0, cx1, cy1;
+      to_px(rect[0], rect[1], x0, y0); to_px(rect[2], rect[3], x1, y1);
+      to_px(clip[0], clip[1], cx0, cy0); to_px(clip[2], clip[3], cx1, cy1);
+      auto near_int = [](float v, int& o) { o = (int)lrintf(v); return fabsf(v - (float)o) < 1.0f / 64.0f; };
+      int ix0, iy0, ix1, iy1, icx0, icy0, icx1, icy1;
+      if (!near_int(x0, ix0) || !near_int(y0, iy0) || !near_int(x1, ix1) || !near_int(y1, iy1) || !near_int(cx0, icx0) || !near_int(cy0, icy0) ||
+          !near_int(cx1, icx1) || !near_int(cy1, icy1)) return false;
+      if (ix1 - ix0 != stex.width || abs(iy1 - iy0) != stex.height) return false;          // texel for pixel
+      for (const Plan& q : plans) if (q.src == src) return false;                            // one destination per source
+      Plan P;
+      P.src = src; P.dx = ix0;
+      if (iy1 > iy0) { P.y0 = iy0; P.ys = 1; } else { P.y0 = iy0 - 1; P.ys = -1; }
+      P.clip[0] = std::max(std::max(std::min(icx0, icx1), d.clip[0]), std::max(0, std::min(ix0, ix1)));
+      P.clip[1] = std::max(std::max(std::min(icy0, icy1), d.clip[1]), std::max(0, std::min(iy0, iy1)));
+      P.clip[2] = std::min(std::min(std::max(icx0, icx1), d.clip[2]), std::min(ft.width, std::max(ix0, ix1)));
+      P.clip[3] = std::min(std::min(std::max(icy0, icy1), d.clip[3]), std::min(ft.height, std::max(iy0, iy1)));
+      if (P.clip[2] <= P.clip[0] || P.clip[3] <= P.clip[1]) { P.clip[0] = P.clip[1] = P.clip[2] = P.clip[3] = 0; }
+      plans.push_back(P);
+    }
+  }
+  if (plans.empty()) return false;
+  // disjoint and complete
+  long long area = 0;
+  for (size_t a = 0; a < plans.size(); a++) {
+    const int* A = plans[a].clip;
+    area += (long long)(A[2] - A[0]) * (A[3] - A[1]);
+    for (size_t b = a + 1; b < plans.size(); b++) {
+      const int* B = plans[b].clip;
+      if (A[0] < B[2] && B[0] < A[2] && A[1] < B[3] && B[1] < A[3]) return false;
+    }
+  }
+  if (area != (long long)ft.width * ft.height) return false;
+  for (const Plan& P : plans) {
+    TargetWork& sw = c->work[P.src];
+    sw.fwd_tex = fb.tex; sw.fwd_dx = P.dx; sw.fwd_y0 = P.y0; sw.fwd_ys = P.ys;
+    for (int k = 0; k < 4; k++) sw.fwd_clip[k] = P.clip[k];
+  }
+  fb.forwarded_away = true;
+  return true;
+}
+
 void flush_work(const std::vector<int>& sel_in) {
   Context* c = ctx;
   if (!c || c->work.empty() || sel_in.empty()) return;
   std::vector<int> sel(sel_in);
   std::sort(sel.begin(), sel.end());
   sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
+  // forwarded composites: targets that turn into write-throughs of their sources leave the launch sequence
+  std::vector<GLuint> forwarded_dst;
+  if (c->forward_composites) {
+    for (int wi : sel) { TargetWork& w = c->work[wi]; w.fwd_tex = 0; w.forwarded_away = false; }
+    for (int wi : sel) {
+      TargetWork& w = c->work[wi];
+      bool all_comp = !w.draws.empty();
+      for (const WrDrawDesc& d : w.draws) if (d.shader != WR_SH_CLEAR_OP && d.shader != WR_SH_COMPOSITE_FAST) { all_comp = false; break; }
+      if (all_comp && plan_forwarding(w, sel)) forwarded_dst.push_back(w.tex);
+    }
+    if (!forwarded_dst.empty()) {
+      std::vector<int> keep;
+      for (int wi : sel) if (!c->work[wi].forwarded_away) keep.push_back(wi);
+      // (the forwarded targets stay in sel_in's hazard bookkeeping below through `forwarded_sel`)
+      sel.swap(keep);
+    }
+  }
+  std::vector<int> forwarded_sel;
+  for (int wi : sel_in) if (c->work[wi].forwarded_away) forwarded_sel.push_back(wi);
   // by dependency level, RGBA8 targets first inside a level, so each raster launch gets a contiguous bin range
   std::stable_sort(sel.begin(), sel.end(), [&](int a, int b) {
     const int la = c->work[a].level, lb = c->work[b].level;
@@ -949,6 +1059,12 @@ void flush_work(const std::vector<int>& sel_in) {
     Texture* dt = w.depth_tex ? c->textures.find(w.depth_tex) : nullptr;
     T.init_depth = w.init_depth_set ? w.init_depth : (dt ? dt->depth_value : 0xFFFFFF);
     if (dt && dt->depth_materialized && dt->dptr) { T.load_depth = 1; T.depth = (uint32_t*)dt->dptr; }
+    T.fwd_color = nullptr;
+    if (w.fwd_tex) {
+      Texture& ft = c->textures[w.fwd_tex];
+      T.fwd_color = ft.dptr; T.fwd_stride = ft.stride; T.fwd_dx = w.fwd_dx; T.fwd_y0 = w.fwd_y0; T.fwd_ys = w.fwd_ys;
+      for (int k = 0; k < 4; k++) T.fwd_clip[k] = w.fwd_clip[k];
+    }
     T.y_begin = 0; T.y_end = t.height;
     if (t.own_y1 > t.own_y0) {   // WrhipSetTargetRows: rows of this target owned by this process
       T.y_begin = std::max(0, t.own_y0); T.y_end = std::min(t.height, t.own_y1);
@@ -1011,6 +1127,7 @@ void flush_work(const std::vector<int>& sel_in) {
         if (Texture* rt = c->textures.find(id))
           if (rt->internal_format == GL_RGBA8 || rt->internal_format == GL_R8) src += (uint64_t)rt->stride * rt->height;
       tb += std::min<uint64_t>(src, owned * t.bpp);
+      if (w.fwd_tex) tb += (uint64_t)std::max(0, w.fwd_clip[2] - w.fwd_clip[0]) * std::max(0, w.fwd_clip[3] - w.fwd_clip[1]) * 4;   // the write-through
       algo_bytes += tb;
       (T.format == WR_FMT_RGBA8 ? L.bytes_rgba : L.bytes_r8) += tb;
     }
@@ -1209,6 +1326,7 @@ void flush_work(const std::vector<int>& sel_in) {
       for (int oi = 0; oi < n_targets; oi++) {
         const TargetWork& w = c->work[sel[oi]];
         T.refs.push_back(w.tex);
+        if (w.fwd_tex) T.refs.push_back(w.fwd_tex);
         for (GLuint id : w.rreads) T.refs.push_back(id);
       }
       for (GLuint id : T.refs) if (Texture* t = c->textures.find(id)) t->tail_ref = true;
@@ -1224,6 +1342,7 @@ void flush_work(const std::vector<int>& sel_in) {
   // ---- drop the flushed work, keep the rest, rebuild hazard flags ----------
   std::vector<char> gone(c->work.size(), 0);
   for (int i : sel) gone[i] = 1;
+  for (int i : forwarded_sel) gone[i] = 1;
   std::vector<TargetWork> rest;
   for (size_t i = 0; i < c->work.size(); i++) if (!gone[i]) rest.push_back(std::move(c->work[i]));
   c->work.swap(rest);

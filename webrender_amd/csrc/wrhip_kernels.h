@@ -4893,6 +4893,13 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) mw[w] = 0ull;
 #endif
   // ---- write back ------------------------------------------------------------
+  // (forwarded composite, WrTargetDesc::fwd_*: every row is stored a second time at its place in the target that would have
+  // copied this one; everything about it but the row is uniform or per-lane constant)
+  uint8_t* const fwd = BPP == 4 ? (uint8_t*)T.fwd_color : nullptr;
+  const int fwd_stride = T.fwd_stride, fwd_y0 = T.fwd_y0, fwd_ys = T.fwd_ys;
+  const int fwd_cx0 = T.fwd_clip[0], fwd_cy0 = T.fwd_clip[1], fwd_cx1 = T.fwd_clip[2], fwd_cy1 = T.fwd_clip[3];
+  const int fX = px + T.fwd_dx;
+  const bool fwd_vec = fX >= fwd_cx0 && fX + 4 <= fwd_cx1 && px + 4 <= T.width && ((fX & 3) == 0) && ((fwd_stride & 15) == 0);
 #pragma unroll
   for (int j = 0; j < R; j++) {
     const int y = py + 4 * j;
@@ -4907,6 +4914,19 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       } else {
 #pragma unroll
         for (int i = 0; i < 4; i++) if (px + i < T.width) ((uint32_t*)rowp)[px + i] = c[i];
+      }
+      if (fwd) {
+        // forwarded composite: the same pixels, a second time, at their place in the target that would have copied them
+        const int Y = fwd_y0 + fwd_ys * y;
+        if (Y >= fwd_cy0 && Y < fwd_cy1) {
+          uint8_t* frow = fwd + (size_t)Y * fwd_stride;
+          if (fwd_vec) {
+            *(uint4*)(frow + (size_t)fX * 4) = make_uint4(c[0], c[1], c[2], c[3]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (fX + i >= fwd_cx0 && fX + i < fwd_cx1 && px + i < T.width) ((uint32_t*)frow)[fX + i] = c[i];
+          }
+        }
       }
     } else {
 #pragma unroll

@@ -171,6 +171,14 @@ struct WrTargetDesc {
   int32_t word_base;    // first u64 word of this target's bin masks
   int32_t words_per_bin;
   int32_t y_begin, y_end;        // pixel rows owned by this process (multi-GPU strip sharding)
+  // Write-through of an opaque 1:1 composite ("forwarded composites"): when the only thing a later target
+  // of the same flush does with this target is copy it unblended, texel for pixel, the raster stage stores every finished pixel
+  // row a second time at its place in that target -- pixel (x, y) goes to (x + fwd_dx, fwd_y0 + fwd_ys * y) if that lies inside
+  // fwd_clip -- and the composite draw (its 4 B/pixel read and its launch) is dropped.
+  void* fwd_color;               // nullptr: none
+  int32_t fwd_stride;            // bytes
+  int32_t fwd_dx, fwd_y0, fwd_ys;
+  int32_t fwd_clip[4];           // x0, y0, x1, y1 in the destination target
   int32_t dw_first, dw_end;      // global prim range spanned by this target's depth-writing draws (dw_end <= dw_first: none).
                                  // A depth-tested prim that consumes interpolants looks there for what hides parts of its rows
                                  // (draw_depth_span's sub-spans, rasterize.h:612-664)

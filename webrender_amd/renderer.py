@@ -99,7 +99,11 @@ class Renderer:
         self._bind_step_textures(step)
         d.draw_instanced_batch(vao, step.instances)
 
-    def draw_picture_cache_target(self, target):
+    def draw_picture_cache_target(self, target, valid_rect=None):
+        """Renderer::draw_picture_cache_target + draw_alpha_batch_container (renderer/mod.rs:2669-2968).  `valid_rect`: the
+        tile's valid rect in tile pixels (what the compositor shows of it: a tile at the edge of the window is only valid
+        inside the window) -- the picture task's scissor rect is dirty rect & valid rect (picture.rs:5213-5217), so the
+        batches are drawn scissored to it (mod.rs:2813-2820); the clear stays unscissored while dirty == valid (mod.rs:2701-2707)."""
         d = self.device
         tex = self.resolve(target.texture)
         d.bind_draw_target(tex.fbo_with_depth or tex.fbo, tex.width, tex.height)
@@ -109,6 +113,10 @@ class Renderer:
         d.clear_target(target.clear_color, 1.0, target.clear_rect)
         d.disable_depth_write()
         # draw_alpha_batch_container
+        uses_scissor = valid_rect is not None and tuple(valid_rect) != (0, 0, tex.width, tex.height)
+        if uses_scissor:
+            self.gl.Enable(G.GL_SCISSOR_TEST)
+            self.gl.SetScissor(valid_rect[0], valid_rect[1], valid_rect[2] - valid_rect[0], valid_rect[3] - valid_rect[1])
         if target.opaque:
             d.set_blend(False)
             d.enable_depth(G.GL_LEQUAL)
@@ -128,6 +136,8 @@ class Renderer:
                 self._draw_step(step, projection)
             d.set_blend(False)
         d.disable_depth()
+        if uses_scissor:
+            self.gl.Disable(G.GL_SCISSOR_TEST)
         d.invalidate_depth_target()
 
     def draw_offscreen_target(self, target):
@@ -213,10 +223,17 @@ class Renderer:
                                               G.GL_RGBA32F, G.GL_RGBA, G.GL_FLOAT)
         gbi = self._create_gpu_buffer_texture("sGpuBufferI", frame.gpu_buffer_i,
                                               G.GL_RGBA32I, G.GL_RGBA_INTEGER, G.GL_INT)
+        # valid rect of every composited tile, in tile pixels: clip rect & tile rect, relative to the tile origin
+        valid = {}
+        for t in frame.composite_tiles:
+            r_, c_ = t.rect, t.clip_rect
+            if t.uv_rect is None and all(float(v).is_integer() for v in tuple(r_) + tuple(c_)):
+                valid[t.texture.name] = (int(max(c_[0], r_[0]) - r_[0]), int(max(c_[1], r_[1]) - r_[1]),
+                                         int(min(c_[2], r_[2]) - r_[0]), int(min(c_[3], r_[3]) - r_[1]))
         for targets in frame.passes:
             for target in targets:
                 if target.kind == "picture_tile":
-                    self.draw_picture_cache_target(target)
+                    self.draw_picture_cache_target(target, valid.get(target.texture.name))
                 else:
                     self.draw_offscreen_target(target)
         self.composite_simple(frame)
