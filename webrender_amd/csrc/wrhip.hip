@@ -277,7 +277,6 @@ struct Context {
     WrAux* aux = nullptr;
     float* vtab = nullptr; size_t vtab_cap = 0;   // per-row v tables of nearest-fast textured prims (WrDrawDesc::vtab_base)
     unsigned long long* masks = nullptr; size_t masks_cap = 0;
-    unsigned* done = nullptr; size_t done_cap = 0;      // per-bin count of finished strips (self-resetting, wr_raster_body)
   } scratch[2];
   int64_t flush_seq = 0;
   // The raster launches of a flush are not issued with it: they are held back, and the first of them
@@ -303,7 +302,6 @@ struct Context {
   wr_stream_t copy_stream;
   wr_event_t ev_copy;
   bool copy_overlap = true;
-  unsigned* dqueue = nullptr;        // {next strip, waves that left}: the raster launches' work queue (self-resetting, wr_raster_units)
   WrUnsupportedCounters* dcounters = nullptr;
   WrUnsupportedCounters seen = {};
   // HBM pool for texture storage: per-frame textures (GpuBufferF/I, render
@@ -331,8 +329,6 @@ struct Context {
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
-    dqueue = (unsigned*)wrrt::dev_alloc(64);
-    wrrt::memset8(dqueue, 0, 64, stream);
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
     wrrt::memset8(dcounters, 0, sizeof(WrUnsupportedCounters), stream);
   }
@@ -819,8 +815,7 @@ Context::~Context() {
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
   wrrt::dev_free(dupload); wrrt::dev_free(dcounters);
-  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.done); }
-  wrrt::dev_free(dqueue);
+  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); }
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::event_destroy(ev_copy);
@@ -865,28 +860,16 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   Context* c = ctx;
 #define WR_K(FMT, DEPTH, FEAT)                                                                                          \
   do {                                                                                                                  \
-    WR_LAUNCH_LDS((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), grid, 256, lds, c->stream, targets, n_targets, draws,        \
-              (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off, Q); \
+    WR_LAUNCH((wr_raster_kernel<FMT, DEPTH, 4, FEAT>), H.nb, 256, c->stream, targets, n_targets, draws,                 \
+              (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off); \
   } while (0)
 #define WR_KF(DEPTH, FEAT)                                                                                              \
   do {                                                                                                                  \
-    WR_LAUNCH_LDS((wr_setup_raster_kernel<WR_FMT_RGBA8, DEPTH, 4, FEAT>), n_setup_blocks + grid, 256, lds, c->stream, *SA, \
+    WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, DEPTH, 4, FEAT>), n_setup_blocks + H.nb, 256, c->stream, *SA,        \
               n_setup_blocks, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs,                  \
-              (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off, Q);                                            \
+              (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);                                               \
   } while (0)
   const int F5 = WR_FEAT_TEX | WR_FEAT_GENERIC, F7 = F5 | WR_FEAT_R8TEX, FA = F7 | WR_FEAT_BLUR | WR_FEAT_SHADE;
-  // Residency of the rect-only launches (experiment knob): dynamic LDS per workgroup
-  static const int rect_lds = getenv("WRHIP_RECT_LDS") ? atoi(getenv("WRHIP_RECT_LDS")) : 0;
-  const size_t lds = (H.fmt == WR_FMT_RGBA8 && H.feat == 0) ? (size_t)rect_lds : 0;
-  // the strips of the launch's bins are handed out from a queue to `grid` workgroups of 4 waves (wr_raster_units): as many as
-  // the chip can hold (8 per CU at most), never more than there are bins
-#ifdef WRHIP_HOSTSIM
-  const int grid = H.nb;
-#else
-  static const int max_grid = getenv("WRHIP_RASTER_GRID") ? atoi(getenv("WRHIP_RASTER_GRID")) : 2048;
-  const int grid = std::min(H.nb, max_grid);
-#endif
-  WrQueue Q{c->dqueue, S.done, H.nb, grid * 4};
   prof_begin();
   if (SA) {
     if (H.depth) {
@@ -1204,7 +1187,7 @@ void flush_work(const std::vector<int>& sel_in) {
     algo_bytes += inst.size() + sizeof(WrDrawDesc) * nd;
     // ---- scratch (two sets: the deferred tail of the previous flush still reads the other one) ----
     Context::Scratch& S = c->scratch[c->flush_seq & 1];
-    if (S.prims_cap < (size_t)n_prims + 1 || S.vtab_cap < vtab_cursor + 1 || S.masks_cap < (size_t)n_words + 1 || S.done_cap < (size_t)n_bins + 1) {
+    if (S.prims_cap < (size_t)n_prims + 1 || S.vtab_cap < vtab_cursor + 1 || S.masks_cap < (size_t)n_words + 1) {
       sync_stream();       // (drains the tail: nothing in flight references the buffers being replaced)
       if (S.prims_cap < (size_t)n_prims + 1) {
         wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux);
@@ -1217,12 +1200,6 @@ void flush_work(const std::vector<int>& sel_in) {
         wrrt::dev_free(S.vtab);
         S.vtab_cap = (vtab_cursor + 1) * 2;
         S.vtab = (float*)wrrt::dev_alloc(S.vtab_cap * sizeof(float));
-      }
-      if (S.done_cap < (size_t)n_bins + 1) {
-        wrrt::dev_free(S.done);
-        S.done_cap = (size_t)(n_bins + 1) * 2;
-        S.done = (unsigned*)wrrt::dev_alloc(S.done_cap * 4);
-        wrrt::memset8(S.done, 0, S.done_cap * 4, c->stream);
       }
       if (S.masks_cap < (size_t)n_words + 1) {
         wrrt::dev_free(S.masks);

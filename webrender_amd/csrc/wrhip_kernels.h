@@ -4744,14 +4744,12 @@ WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], u
   }
 }
 
-// One 64 x 4R strip of a 64x64 bin per wave: 64 lanes, each lane 4 x R pixels.  `wave` says which strip of the bin
-// (the device build hands strips out from a queue, wr_raster_units; the host simulation runs one workgroup per bin);
-// `done`: per-bin count of finished strips -- the wave that finishes a bin's last strip zeroes its mask words.
+// One workgroup per 64x64 bin; 64/(4R) waves of 64 lanes, each lane 4 x R pixels.
 template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
-                 unsigned long long* __restrict__ masks, const int bin, const int wave_in, unsigned* __restrict__ done) {
+                 unsigned long long* __restrict__ masks, const int bin) {
   constexpr int NPX = 4 * R, STRIP = 4 * R;
   int t = 0;
   {
@@ -4768,16 +4766,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   const int bx = lb % T.bins_x, by = lb / T.bins_x;
   if ((by + 1) * WR_BIN_H <= T.y_begin || by * WR_BIN_H >= T.y_end) {
     // rows of another rank (multi-GPU strips): nothing to draw, but the setup stage has binned every prim here too, and
-    // the words must not survive into the next flush
+    // the mask words must not survive into the next flush
 #ifndef WRHIP_HOSTSIM
-    unsigned old = 0;
-    if ((threadIdx.x & 63) == 0) old = atomicAdd(&done[bin], 1u);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old == (unsigned)(64 / STRIP) - 1u) {
-      unsigned long long* mz = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
-      for (int w = threadIdx.x & 63; w < T.words_per_bin; w += 64) mz[w] = 0ull;
-      if ((threadIdx.x & 63) == 0) done[bin] = 0u;
-    }
+    unsigned long long* mz = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
+    for (int w = threadIdx.x; w < T.words_per_bin; w += (int)blockDim.x) mz[w] = 0ull;
 #endif
     return;
   }
@@ -4785,12 +4777,9 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // from it (strip origin, coverage class of a prim) is treated as divergent
 #ifdef WRHIP_HOSTSIM
   const int wave = threadIdx.x >> 6;
-  const int lw = wave;
 #else
-  const int wave = wave_in;
-  const int lw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // this wave's slot in the workgroup's LDS
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
-  (void)lw; (void)done;
   const int lane = threadIdx.x & 63;
   const int wx0 = bx * WR_BIN_W, wy0 = by * WR_BIN_H + wave * STRIP;
   const int px = wx0 + (lane & 15) * 4;
@@ -4847,7 +4836,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
         if (((Rc.kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(Rc.kbf & 0xFF) && ((T.dw_end > T.dw_first && base + bit > T.dw_first) || T.load_depth))
-          rr = wr_build_runs<R>(T, recs, aux, base + bit, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, wy0, lane, lw);
+          rr = wr_build_runs<R>(T, recs, aux, base + bit, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, wy0, lane, wave);
       }
       if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED || ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
@@ -4897,7 +4886,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
         if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && base + bit > T.dw_first) || T.load_depth))
-          rr = wr_build_runs<R>(T, recs, aux, base + bit, x0, y0, x1, y1, z, kbf, wy0, lane, lw);
+          rr = wr_build_runs<R>(T, recs, aux, base + bit, x0, y0, x1, y1, z, kbf, wy0, lane, wave);
       }
       if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_SOLID_MASKED || ((kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
           aux[base + bit].tex.simple)
@@ -4906,18 +4895,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
         wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], &aux[base + bit], draws, vtab, px, py, wx0, wy0, rr);
     }
   }
-  // Self-cleaning bin masks: the wave that finishes the last of a bin's strips zeroes the bin's words (and its strip
-  // counter), so the next flush needs no memset launch.  Every strip's reads of the words are complete by then: they were
-  // consumed before that strip's own increment.
-  {
-    unsigned old = 0;
-    if (lane == 0) old = atomicAdd(&done[bin], 1u);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old == (unsigned)(64 / STRIP) - 1u) {
-      for (int w = lane; w < nw; w += 64) mw[w] = 0ull;
-      if (lane == 0) done[bin] = 0u;
-    }
-  }
+  // Self-cleaning bin masks: once every wave of the workgroup has consumed the
+  // bin's words, zero them so the next flush needs no memset launch.
+  __syncthreads();
+  for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) mw[w] = 0ull;
 #endif
   // ---- write back ------------------------------------------------------------
   // (forwarded composite, WrTargetDesc::fwd_*: every row is stored a second time at its place in the target that would have
@@ -4974,40 +4955,6 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 // live values above whatever its callees clobber (hence the integer wr_accum_binades, wr_accum_short on
 // the glyph path, wr_aa_pixel_rgba8 out of line).  The rect-only variants ask for 8 waves (64 VGPRs) and, depth-tested,
 // 4 (without a request that one drifted to 129 VGPRs = 3 waves and cfg5 lost 15 %).
-// Strips are handed out from a queue.  The work of a strip is the number of prims that touch it, which varies by an order of
-// magnitude across a frame; with one workgroup per bin and the whole grid resident at once (a 4K frame is 2560 bins, the chip
-// holds 2048 workgroups of the rect kernel) the assignment of work to SIMDs is fixed at dispatch and the launch lasts as long
-// as the unluckiest SIMD (measured: VALU busy 62 % of the tile pass).  Here every wave of the launch takes the next strip
-// from an atomic counter until none is left (WrQueue::ctr[0]); the last wave to leave resets the counters for the next
-// launch (ctr[1] counts leavers).  Unit u = strip (u & 3) of bin (u >> 2): the four strips of a bin run side by side and
-// share its mask words and records in cache.
-struct WrQueue { unsigned* ctr; unsigned* done; int n_bins; int n_waves; };
-template <int FMT, bool DEPTH, int R, int FEAT>
-WR_DEVICE void wr_raster_units(const WrTargetDesc* __restrict__ targets, int n_targets,
-                 const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
-                 const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
-                 unsigned long long* __restrict__ masks, int bin_offset, WrQueue Q, int block) {
-#ifdef WRHIP_HOSTSIM
-  (void)Q;
-  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, block + bin_offset, 0, nullptr);
-#else
-  const unsigned n_units = (unsigned)Q.n_bins * (unsigned)(16 / R);
-  const int lane = threadIdx.x & 63;
-  for (;;) {
-    unsigned u = 0;
-    if (lane == 0) u = atomicAdd(&Q.ctr[0], 1u);
-    u = __builtin_amdgcn_readfirstlane(u);
-    if (u >= n_units) break;
-    wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)(u / (16 / R)) + bin_offset,
-                                        (int)(u % (16 / R)), Q.done);
-  }
-  if (lane == 0) {
-    const unsigned left = atomicAdd(&Q.ctr[1], 1u);
-    if (left == (unsigned)Q.n_waves - 1u) { Q.ctr[1] = 0u; __threadfence(); Q.ctr[0] = 0u; }
-  }
-#endif
-}
-
 #ifdef WRHIP_HOSTSIM
 #define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R)
 #else
@@ -5018,8 +4965,8 @@ __global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
 wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
-                 unsigned long long* __restrict__ masks, int bin_offset, WrQueue Q) {
-  wr_raster_units<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, bin_offset, Q, (int)blockIdx.x);
+                 unsigned long long* __restrict__ masks, int bin_offset) {
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)blockIdx.x + bin_offset);
 }
 
 // The setup stage of flush k+1 and the last raster level of flush k in ONE launch: the first
@@ -5044,10 +4991,11 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
                        const WrTargetDesc* __restrict__ targets, int n_targets,
                        const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                        const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
-                       unsigned long long* __restrict__ masks, int bin_offset, WrQueue Q) {
+                       unsigned long long* __restrict__ masks, int bin_offset) {
   if ((int)blockIdx.x < n_setup_blocks) {
     wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
     return;
   }
-  wr_raster_units<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, bin_offset, Q, (int)blockIdx.x - n_setup_blocks);
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks,
+                                      (int)blockIdx.x - n_setup_blocks + bin_offset);
 }

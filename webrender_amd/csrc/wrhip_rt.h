@@ -46,7 +46,6 @@ typedef struct { double t; } wr_event_t;
         kernel(__VA_ARGS__);                                            \
       }                                                                 \
   } while (0)
-#define WR_LAUNCH_LDS(kernel, grid, block, lds, stream, ...) WR_LAUNCH(kernel, grid, block, stream, __VA_ARGS__)
 namespace wrrt {
 static inline bool init(int*, char* name, size_t n) { snprintf(name, n, "hostsim (CPU, tests only)"); return true; }
 static inline void* dev_alloc(size_t n) { return calloc(1, n ? n : 1); }
@@ -88,13 +87,6 @@ typedef hipEvent_t wr_event_t;
 #define WR_LAUNCH(kernel, grid, block, stream, ...)                          \
   do {                                                                       \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
-    WR_HIP_CHECK(hipGetLastError());                                         \
-  } while (0)
-// with `lds` bytes of dynamic LDS per workgroup: bounds how many workgroups share a CU (160 KB of LDS), i.e. how much
-// of the grid is left for the dispatcher to hand out as workgroups retire ("residency")
-#define WR_LAUNCH_LDS(kernel, grid, block, lds, stream, ...)                 \
-  do {                                                                       \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__); \
     WR_HIP_CHECK(hipGetLastError());                                         \
   } while (0)
 namespace wrrt {
