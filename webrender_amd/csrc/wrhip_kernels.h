@@ -4764,15 +4764,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   if (T.format != FMT) return;
   const int lb = bin - T.first_bin;
   const int bx = lb % T.bins_x, by = lb / T.bins_x;
-  if ((by + 1) * WR_BIN_H <= T.y_begin || by * WR_BIN_H >= T.y_end) {
-    // rows of another rank (multi-GPU strips): nothing to draw, but the setup stage has binned every prim here too, and
-    // the mask words must not survive into the next flush
-#ifndef WRHIP_HOSTSIM
-    unsigned long long* mz = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
-    for (int w = threadIdx.x; w < T.words_per_bin; w += (int)blockDim.x) mz[w] = 0ull;
-#endif
-    return;
-  }
+  if ((by + 1) * WR_BIN_H <= T.y_begin || by * WR_BIN_H >= T.y_end) return;      // rows of another rank (the setup stage bins nothing there)
   // the wave index is uniform across the wave: say so, or everything derived
   // from it (strip origin, coverage class of a prim) is treated as divergent
 #ifdef WRHIP_HOSTSIM
