@@ -3583,19 +3583,18 @@ WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y) {
   return rv;
 }
 
-__device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipRec* Cp, WrRowVals rv, int x, int y) {
-  const WrPrim& P = *Pp;
-  const WrClipRec& C = *Cp;
-  WrRow4 out;
-  out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+// Span-level setup of a cs_clip_rectangle row (cs_clip_rectangle.glsl:223-420): the lengths, in 4-pixel chunks, of the
+// five phases [clear n1][AA n2][opaque n3][AA n4][clear ...] and the corners the two AA phases belong to.  It depends on
+// the prim and the row only, so the raster stage evaluates it once per wave with the 16 row-owning lanes (next to the row
+// interpolants) and hands it round; a 4-pixel group in a solid phase then costs a compare and a constant.
+struct WrClipRow { float w, aa_range, stx, sty; int n12, n34, corners; };     // n12 = n1 | n2 << 16, n34 likewise, corners = (start + 1) | (end + 1) << 8
+WR_DEVICE WrClipRow wr_clip_row_setup(const WrPrim& P, const WrClipRec& C, const WrRowVals& rv) {
+  WrClipRow cr;
   const float su = rv.s[0], sv = rv.s[1];
   const float ou = rv.o[0], ov = rv.o[1];
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
-  const float mode = C.mode;
-  // the four SIMD lanes of vLocalPos.xy at the span start (init_interp)
-  const float lx0 = ou, lx1 = lx0 + su, lx2 = lx1 + su, lx3 = lx2 + su;
-  const float ly0 = ov, ly1 = ly0 + sv, ly2 = ly1 + sv, ly3 = ly2 + sv;
-  // ---- span-level setup (cs_clip_rectangle.glsl:223-420), once per row
+  const float lx0 = ou, lx1 = lx0 + su;
+  const float ly0 = ov, ly1 = ly0 + sv;
   const float wv = C.w;
   const float w = 1.0f / wv;
   const float p0x = lx0 * w, p0y = ly0 * w, p1x = lx1 * w, p1y = ly1 * w;
@@ -3656,6 +3655,27 @@ __device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipR
     const int R3 = R2 - n3;
     n4 = R3 > D ? R3 - D : 0;
   }
+  cr.w = w; cr.aa_range = aa_range; cr.stx = stx; cr.sty = sty;
+  cr.n12 = n1 | (n2 << 16); cr.n34 = n3 | (n4 << 16); cr.corners = (start_corner + 1) | ((end_corner + 1) << 8);
+  return cr;
+}
+
+__device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipRec* Cp, WrRowVals rv, WrClipRow cr, int x, int y) {
+  const WrPrim& P = *Pp;
+  const WrClipRec& C = *Cp;
+  WrRow4 out;
+  out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+  const float su = rv.s[0], sv = rv.s[1];
+  const float ou = rv.o[0], ov = rv.o[1];
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  const float mode = C.mode;
+  // the four SIMD lanes of vLocalPos.xy at the span start (init_interp)
+  const float lx0 = ou, lx1 = lx0 + su, lx2 = lx1 + su, lx3 = lx2 + su;
+  const float ly0 = ov, ly1 = ly0 + sv, ly2 = ly1 + sv, ly3 = ly2 + sv;
+  const float wv = C.w;
+  const float w = cr.w, aa_range = cr.aa_range, stx = cr.stx, sty = cr.sty;
+  const int n1 = cr.n12 & 0xFFFF, n2 = cr.n12 >> 16, n3 = cr.n34 & 0xFFFF, n4 = cr.n34 >> 16;
+  const int start_corner = (cr.corners & 0xFF) - 1, end_corner = (cr.corners >> 8) - 1;
   const uint32_t v_clear = uint32_t(wr_round_pixel(mode)) & 0xFFFF, v_opaque = uint32_t(wr_round_pixel(1.0f - mode)) & 0xFFFF;
   // tail chunk (fragment shader): lanes stepped by `span` at once
   const float chunks = float(span) * 0.25f;
@@ -3771,7 +3791,52 @@ WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
   return rv;
 }
 
-__device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxRec* Bp, WrRowVals rv, int x, int y) {
+// Span-level setup of a cs_clip_box_shadow row (cs_clip_box_shadow.glsl:150-250): where the shadow rect and the four
+// nine-patch sector boundaries fall along the row, as remaining span lengths.  Prim and row only: evaluated by the
+// row-owning lanes of a wave and handed round (see WrClipRow).
+struct WrBoxRow { int ss_se, os01, os23; };       // shadow_start_len | shadow_end_len << 16, os0 | os1 << 16, os2 | os3 << 16
+WR_DEVICE WrBoxRow wr_box_row_setup(const WrPrim& P, const WrBoxRec& B, const WrRowVals& rv) {
+  WrBoxRow br;
+  br.ss_se = br.os01 = br.os23 = 0;
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  if (span <= 0 || !(B.w > 0.0f)) return br;
+  const float w = 1.0f / B.w;
+  float cur[4][1], st[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { cur[c][0] = rv.o[c] * w; st[c] = (rv.s[c] * 4.0f) * w; }
+  const float sl = float(span), ss = 4.0f;
+  int shadow_start_len, shadow_end_len, os0, os1, os2, os3;
+  {
+    const float p0x = cur[2][0], p0y = cur[3][0];
+    const bool negx = st[2] < 0.0f, negy = st[3] < 0.0f;
+    float cd0 = (negx ? B.bounds[2] : B.bounds[0]) - p0x, cd1 = (negy ? B.bounds[3] : B.bounds[1]) - p0y;
+    float cd2 = (negx ? B.bounds[0] : B.bounds[2]) - p0x, cd3 = (negy ? B.bounds[1] : B.bounds[3]) - p0y;
+    const float rsx = 1.0f / st[2], rsy = 1.0f / st[3];
+    cd0 = st[2] != 0.0f ? cd0 * rsx : 1.0e6f * wr_step01(0.0f, cd0);
+    cd1 = st[3] != 0.0f ? cd1 * rsy : 1.0e6f * wr_step01(0.0f, cd1);
+    cd2 = st[2] != 0.0f ? cd2 * rsx : 1.0e6f * wr_step01(0.0f, cd2);
+    cd3 = st[3] != 0.0f ? cd3 * rsy : 1.0e6f * wr_step01(0.0f, cd3);
+    const float shadow_start = wr_max(cd0, cd1), shadow_end = wr_min(cd2, cd3);
+    shadow_start_len = int(wr_clamp(sl - ss * floorf(shadow_start), 0.0f, sl));
+    shadow_end_len = int(wr_clamp(sl - ss * ceilf(shadow_end), 0.0f, sl));
+    const float u0 = cur[0][0], v0 = cur[1][0];
+    const bool ngx = st[0] < 0.0f, ngy = st[1] < 0.0f;
+    float od0 = (ngx ? B.edge[2] : B.edge[0]) - u0, od1 = (ngy ? B.edge[3] : B.edge[1]) - v0;
+    float od2 = (ngx ? B.edge[0] : B.edge[2]) - u0, od3 = (ngy ? B.edge[1] : B.edge[3]) - v0;
+    const float rux = 1.0f / st[0], ruy = 1.0f / st[1];
+    od0 = st[0] != 0.0f ? od0 * rux : 1.0e6f * wr_step01(0.0f, od0);
+    od1 = st[1] != 0.0f ? od1 * ruy : 1.0e6f * wr_step01(0.0f, od1);
+    od2 = st[0] != 0.0f ? od2 * rux : 1.0e6f * wr_step01(0.0f, od2);
+    od3 = st[1] != 0.0f ? od3 * ruy : 1.0e6f * wr_step01(0.0f, od3);
+    const float sel = float(shadow_end_len);
+    os0 = int(wr_clamp(sl - ss * floorf(od0), sel, sl)); os1 = int(wr_clamp(sl - ss * floorf(od1), sel, sl));
+    os2 = int(wr_clamp(sl - ss * floorf(od2), sel, sl)); os3 = int(wr_clamp(sl - ss * floorf(od3), sel, sl));
+  }
+  br.ss_se = shadow_start_len | (shadow_end_len << 16); br.os01 = os0 | (os1 << 16); br.os23 = os2 | (os3 << 16);
+  return br;
+}
+
+__device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxRec* Bp, WrRowVals rv, WrBoxRow br, int x, int y) {
   const WrPrim& P = *Pp;
   const WrBoxRec& B = *Bp;
   WrRow4 out;
@@ -3818,33 +3883,8 @@ __device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxR
     st[c] = (s4[c] * 4.0f) * w;
   }
   const float sl = float(span), ss = 4.0f;
-  int shadow_start_len, shadow_end_len, os0, os1, os2, os3;
-  {
-    const float p0x = cur[2][0], p0y = cur[3][0];
-    const bool negx = st[2] < 0.0f, negy = st[3] < 0.0f;
-    float cd0 = (negx ? B.bounds[2] : B.bounds[0]) - p0x, cd1 = (negy ? B.bounds[3] : B.bounds[1]) - p0y;
-    float cd2 = (negx ? B.bounds[0] : B.bounds[2]) - p0x, cd3 = (negy ? B.bounds[1] : B.bounds[3]) - p0y;
-    const float rsx = 1.0f / st[2], rsy = 1.0f / st[3];
-    cd0 = st[2] != 0.0f ? cd0 * rsx : 1.0e6f * wr_step01(0.0f, cd0);
-    cd1 = st[3] != 0.0f ? cd1 * rsy : 1.0e6f * wr_step01(0.0f, cd1);
-    cd2 = st[2] != 0.0f ? cd2 * rsx : 1.0e6f * wr_step01(0.0f, cd2);
-    cd3 = st[3] != 0.0f ? cd3 * rsy : 1.0e6f * wr_step01(0.0f, cd3);
-    const float shadow_start = wr_max(cd0, cd1), shadow_end = wr_min(cd2, cd3);
-    shadow_start_len = int(wr_clamp(sl - ss * floorf(shadow_start), 0.0f, sl));
-    shadow_end_len = int(wr_clamp(sl - ss * ceilf(shadow_end), 0.0f, sl));
-    const float u0 = cur[0][0], v0 = cur[1][0];
-    const bool ngx = st[0] < 0.0f, ngy = st[1] < 0.0f;
-    float od0 = (ngx ? B.edge[2] : B.edge[0]) - u0, od1 = (ngy ? B.edge[3] : B.edge[1]) - v0;
-    float od2 = (ngx ? B.edge[0] : B.edge[2]) - u0, od3 = (ngy ? B.edge[1] : B.edge[3]) - v0;
-    const float rux = 1.0f / st[0], ruy = 1.0f / st[1];
-    od0 = st[0] != 0.0f ? od0 * rux : 1.0e6f * wr_step01(0.0f, od0);
-    od1 = st[1] != 0.0f ? od1 * ruy : 1.0e6f * wr_step01(0.0f, od1);
-    od2 = st[0] != 0.0f ? od2 * rux : 1.0e6f * wr_step01(0.0f, od2);
-    od3 = st[1] != 0.0f ? od3 * ruy : 1.0e6f * wr_step01(0.0f, od3);
-    const float sel = float(shadow_end_len);
-    os0 = int(wr_clamp(sl - ss * floorf(od0), sel, sl)); os1 = int(wr_clamp(sl - ss * floorf(od1), sel, sl));
-    os2 = int(wr_clamp(sl - ss * floorf(od2), sel, sl)); os3 = int(wr_clamp(sl - ss * floorf(od3), sel, sl));
-  }
+  const int shadow_start_len = br.ss_se & 0xFFFF, shadow_end_len = br.ss_se >> 16;
+  const int os0 = br.os01 & 0xFFFF, os1 = br.os01 >> 16, os2 = br.os23 & 0xFFFF, os3 = br.os23 >> 16;
   // everything not claimed by the walk below is the solid lead-in / lead-out
 #pragma unroll
   for (int i = 0; i < 4; i++) if (n0 + i >= 0 && n0 + i < span) out.v[i] = v_clear;
@@ -4385,19 +4425,34 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     const bool anyx = cx[0] || cx[1] || cx[2] || cx[3];
 #ifndef WRHIP_HOSTSIM
     const WrRowVals mine = wr_box_row_vals(*Pp, Ap->box, wy0 + ((px - wx0) >> 2));   // lane (l & 15) owns strip row (l & 15)
+    const WrBoxRow mine_br = wr_box_row_setup(*Pp, Ap->box, mine);
 #endif
 #pragma unroll
     for (int j = 0; j < R; j++) {
 #ifdef WRHIP_HOSTSIM
       const WrRowVals rv = wr_box_row_vals(*Pp, Ap->box, py + 4 * j);
+      const WrBoxRow br = wr_box_row_setup(*Pp, Ap->box, rv);
 #else
       WrRowVals rv;
+      WrBoxRow br;
       const int src = (py - wy0) + 4 * j;      // the lane that evaluated this lane's row
 #pragma unroll
       for (int c = 0; c < 4; c++) { rv.o[c] = __shfl(mine.o[c], src); rv.s[c] = __shfl(mine.s[c], src); }
+      br.ss_se = __shfl(mine_br.ss_se, src); br.os01 = __shfl(mine_br.os01, src); br.os23 = __shfl(mine_br.os23, src);
 #endif
       if (!cy[j] || !anyx) continue;
-      const WrRow4 r4 = wr_box_shadow_row4(Pp, &Ap->box, rv, px, py + 4 * j);
+      WrRow4 r4;
+      {
+        // the solid lead-in (before the shadow rect starts) and lead-out (after it ends) of the row need no evaluation
+        const int n = px - x0, len = x1 - x0, span = len >= 4 ? (len & ~3) : 0;
+        const int lead_in = span - (br.ss_se & 0xFFFF), lead_out = span - (br.ss_se >> 16);
+        if (n >= 0 && n + 3 < span && Ap->box.w > 0.0f && (n + 3 < lead_in || n >= wr_imax(lead_out, lead_in) + 4)) {      // (the chunk at lead_in is always evaluated)
+          const uint32_t v = uint32_t(wr_round_pixel(Ap->box.mode)) & 0xFFFF;
+          r4.v[0] = r4.v[1] = r4.v[2] = r4.v[3] = v;
+        } else {
+          r4 = wr_box_shadow_row4(Pp, &Ap->box, rv, br, px, py + 4 * j);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
@@ -4410,20 +4465,40 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     const bool anyx = cx[0] || cx[1] || cx[2] || cx[3];
 #ifndef WRHIP_HOSTSIM
     const WrRowVals mine = wr_clip_row_vals(*Pp, wy0 + ((px - wx0) >> 2));
+    const WrClipRow mine_cr = wr_clip_row_setup(*Pp, Ap->clip, mine);
 #endif
 #pragma unroll
     for (int j = 0; j < R; j++) {
 #ifdef WRHIP_HOSTSIM
       const WrRowVals rv = wr_clip_row_vals(*Pp, py + 4 * j);
+      const WrClipRow cr = wr_clip_row_setup(*Pp, Ap->clip, rv);
 #else
       WrRowVals rv;
+      WrClipRow cr;
       const int src = (py - wy0) + 4 * j;
 #pragma unroll
       for (int c = 0; c < 2; c++) { rv.o[c] = __shfl(mine.o[c], src); rv.s[c] = __shfl(mine.s[c], src); }
       rv.o[2] = rv.o[3] = rv.s[2] = rv.s[3] = 0.0f;
+      cr.w = __shfl(mine_cr.w, src); cr.aa_range = __shfl(mine_cr.aa_range, src); cr.stx = __shfl(mine_cr.stx, src); cr.sty = __shfl(mine_cr.sty, src);
+      cr.n12 = __shfl(mine_cr.n12, src); cr.n34 = __shfl(mine_cr.n34, src); cr.corners = __shfl(mine_cr.corners, src);
 #endif
       if (!cy[j] || !anyx) continue;
-      const WrRow4 r4 = wr_clip_rect_row4(Pp, &Ap->clip, rv, px, py + 4 * j);
+      WrRow4 r4;
+      {
+        // a group whose pixels all sit in one solid phase of the row (clear / opaque) needs no evaluation at all
+        const int n = px - x0, len = x1 - x0, span = len >= 4 ? (len & ~3) : 0;
+        const int b1 = cr.n12 & 0xFFFF, b2 = b1 + (cr.n12 >> 16), b3 = b2 + (cr.n34 & 0xFFFF), b4 = b3 + (cr.n34 >> 16);
+        const int c0 = n >> 2, c3 = (n + 3) >> 2;
+        const int k0 = c0 < b1 ? 0 : (c0 < b2 ? 1 : (c0 < b3 ? 2 : (c0 < b4 ? 3 : 0)));
+        const int k3 = c3 < b1 ? 0 : (c3 < b2 ? 1 : (c3 < b3 ? 2 : (c3 < b4 ? 3 : 0)));
+        if (n >= 0 && n + 3 < span && k0 == k3 && (k0 == 0 || k0 == 2) && Ap->clip.w > 0.0f) {
+          const float mode = Ap->clip.mode;
+          const uint32_t v = uint32_t(wr_round_pixel(k0 == 0 ? mode : 1.0f - mode)) & 0xFFFF;
+          r4.v[0] = r4.v[1] = r4.v[2] = r4.v[3] = v;
+        } else {
+          r4 = wr_clip_rect_row4(Pp, &Ap->clip, rv, cr, px, py + 4 * j);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
