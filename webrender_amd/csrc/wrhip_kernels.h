@@ -3794,10 +3794,15 @@ WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
 // Span-level setup of a cs_clip_box_shadow row (cs_clip_box_shadow.glsl:150-250): where the shadow rect and the four
 // nine-patch sector boundaries fall along the row, as remaining span lengths.  Prim and row only: evaluated by the
 // row-owning lanes of a wave and handed round (see WrClipRow).
-struct WrBoxRow { int ss_se, os01, os23; };       // shadow_start_len | shadow_end_len << 16, os0 | os1 << 16, os2 | os3 << 16
+struct WrBoxRow {
+  int ss_se, os01, os23;       // shadow_start_len | shadow_end_len << 16, os0 | os1 << 16, os2 | os3 << 16
+  int xc;                      // [pa, pb) = xc & 0xFFFF, xc >> 16: the run of the row in which u is clamped to the nine-patch's stretched
+                               // middle column -- every pixel of it samples the same texel, so it has ONE value,
+  uint32_t vrow;               // ... this one (wr_box_row_finish evaluates a single pixel of the run)
+};
 WR_DEVICE WrBoxRow wr_box_row_setup(const WrPrim& P, const WrBoxRec& B, const WrRowVals& rv) {
   WrBoxRow br;
-  br.ss_se = br.os01 = br.os23 = 0;
+  br.ss_se = br.os01 = br.os23 = 0; br.xc = 0; br.vrow = 0;
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
   if (span <= 0 || !(B.w > 0.0f)) return br;
   const float w = 1.0f / B.w;
@@ -3833,6 +3838,25 @@ WR_DEVICE WrBoxRow wr_box_row_setup(const WrPrim& P, const WrBoxRec& B, const Wr
     os2 = int(wr_clamp(sl - ss * floorf(od2), sel, sl)); os3 = int(wr_clamp(sl - ss * floorf(od3), sel, sl));
   }
   br.ss_se = shadow_start_len | (shadow_end_len << 16); br.os01 = os0 | (os1 << 16); br.os23 = os2 | (os3 << 16);
+  // the walk of wr_box_shadow_row4, control flow only (it is all integer): find the run with u clamped
+  {
+    int R = span, pos = 0;
+    if (R > shadow_start_len) { const int nb = R - shadow_start_len; R -= nb; pos += nb; }
+    for (int guard = 0; guard < 16 && R > 0; guard++) {
+      R -= 4; pos += 4;
+      if (R <= shadow_end_len) break;
+      int num_inside = R - 4 - shadow_end_len;
+      bool xcl = false;
+      if (R >= os1) num_inside = wr_imin(num_inside, R - os1);
+      else if (R >= os3) num_inside = wr_imin(num_inside, R - os3);
+      if (R >= os0) num_inside = wr_imin(num_inside, R - os0);
+      else if (R >= os2) { num_inside = wr_imin(num_inside, R - os2); xcl = true; }
+      if (num_inside > 0) {
+        if (xcl && num_inside >= 8 && br.xc == 0) br.xc = pos | ((pos + num_inside) << 16);
+        R -= num_inside; pos += num_inside;
+      }
+    }
+  }
   return br;
 }
 
@@ -4003,6 +4027,13 @@ __device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxR
     }
   }
   return out;
+}
+
+// the one value of the row's u-clamped run (WrBoxRow::xc): stepx is exactly 0 there, so whichever filter the run takes,
+// every pixel of it gets what its first pixel gets
+WR_DEVICE void wr_box_row_finish(const WrPrim* Pp, const WrBoxRec* Bp, const WrRowVals& rv, WrBoxRow& br, int y) {
+  if (br.xc == 0 || rv.s[1] != 0.0f) { br.xc = 0; return; }      // (v must not move along the row either: axis-aligned prims)
+  br.vrow = wr_box_shadow_row4(Pp, Bp, rv, br, Pp->x0 + (br.xc & 0xFFFF), y).v[0];
 }
 
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
@@ -4425,13 +4456,15 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     const bool anyx = cx[0] || cx[1] || cx[2] || cx[3];
 #ifndef WRHIP_HOSTSIM
     const WrRowVals mine = wr_box_row_vals(*Pp, Ap->box, wy0 + ((px - wx0) >> 2));   // lane (l & 15) owns strip row (l & 15)
-    const WrBoxRow mine_br = wr_box_row_setup(*Pp, Ap->box, mine);
+    WrBoxRow mine_br = wr_box_row_setup(*Pp, Ap->box, mine);
+    wr_box_row_finish(Pp, &Ap->box, mine, mine_br, wy0 + ((px - wx0) >> 2));
 #endif
 #pragma unroll
     for (int j = 0; j < R; j++) {
 #ifdef WRHIP_HOSTSIM
       const WrRowVals rv = wr_box_row_vals(*Pp, Ap->box, py + 4 * j);
-      const WrBoxRow br = wr_box_row_setup(*Pp, Ap->box, rv);
+      WrBoxRow br = wr_box_row_setup(*Pp, Ap->box, rv);
+      wr_box_row_finish(Pp, &Ap->box, rv, br, py + 4 * j);
 #else
       WrRowVals rv;
       WrBoxRow br;
@@ -4439,6 +4472,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
 #pragma unroll
       for (int c = 0; c < 4; c++) { rv.o[c] = __shfl(mine.o[c], src); rv.s[c] = __shfl(mine.s[c], src); }
       br.ss_se = __shfl(mine_br.ss_se, src); br.os01 = __shfl(mine_br.os01, src); br.os23 = __shfl(mine_br.os23, src);
+      br.xc = __shfl(mine_br.xc, src); br.vrow = __shfl(mine_br.vrow, src);
 #endif
       if (!cy[j] || !anyx) continue;
       WrRow4 r4;
@@ -4449,6 +4483,8 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (n >= 0 && n + 3 < span && Ap->box.w > 0.0f && (n + 3 < lead_in || n >= wr_imax(lead_out, lead_in) + 4)) {      // (the chunk at lead_in is always evaluated)
           const uint32_t v = uint32_t(wr_round_pixel(Ap->box.mode)) & 0xFFFF;
           r4.v[0] = r4.v[1] = r4.v[2] = r4.v[3] = v;
+        } else if (br.xc != 0 && n >= (br.xc & 0xFFFF) && n + 4 <= (br.xc >> 16) && n + 3 < span) {
+          r4.v[0] = r4.v[1] = r4.v[2] = r4.v[3] = br.vrow;          // inside the u-clamped run: the row's one value
         } else {
           r4 = wr_box_shadow_row4(Pp, &Ap->box, rv, br, px, py + 4 * j);
         }
