@@ -5058,10 +5058,16 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 // live values above whatever its callees clobber (hence the integer wr_accum_binades, wr_accum_short on
 // the glyph path, wr_aa_pixel_rgba8 out of line).  The rect-only variants ask for 8 waves (64 VGPRs) and, depth-tested,
 // 4 (without a request that one drifted to 129 VGPRs = 3 waves and cfg5 lost 15 %).
+// The R8 clip-mask variant: the nine-patch row function alone wants 228 VGPRs (one wave per SIMD, every latency of a
+// launch of a few hundred workgroups exposed); now that solid groups never reach the row functions (wr_apply_prim), they
+// may spill: 2 waves per SIMD are asked for (measured: 1 wave 243 us, 2 waves 145 us, 3 waves 155 us per mask launch of cfg4).
+#ifndef WR_R8_CLIP_WAVES
+#define WR_R8_CLIP_WAVES 2
+#endif
 #ifdef WRHIP_HOSTSIM
 #define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R)
 #else
-#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? 3 : ((DEPTH) ? 4 : 8)) : 0)
+#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? 3 : ((DEPTH) ? 4 : 8)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
