@@ -1,0 +1,90 @@
+"""The GL-trace capture interposer (csrc/wr_capture.c): a frame driven through it over the reference's swgl is recorded
+call by call; replaying the recording natively on libwrhip (host simulation here, the HIP library under -m gpu) gives the
+pixels the reference produced while it was being captured."""
+import os
+import struct
+import subprocess
+import sys
+import numpy as np
+import pytest
+from conftest import ROOT, wrhip_lib, oracle_lib
+
+CAPTURE = os.path.join(ROOT, "webrender_amd", "csrc", "libwr_capture.so")
+
+DRIVER = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from webrender_amd import scenes, glconst as G
+from webrender_amd.glapi import GL
+from webrender_amd.renderer import Renderer
+import ctypes as C
+gl = GL(sys.argv[2])
+r = Renderer(gl, 512, 512)
+d = r.device
+for make in (lambda: scenes.cfg2_overlapping_rects(width=512, height=512, n=60, seed=40, encoding="brush", fractional=True),
+             lambda: scenes.add_occluders(scenes.image_grid(width=512, height=512, n=40), n=12, zmax=44, seed=5),
+             lambda: scenes.cfg3_text(width=512, height=512, lines=8, glyphs_per_line=24, run_len=12)):
+    r.render(make())
+# uploads through a mapped pixel-unpack buffer, which no call carries
+t = d.create_texture(32, 16, G.GL_RGBA8, render_target=True)
+pbo = gl.gen("GenBuffers")
+gl.BindBuffer(G.GL_PIXEL_UNPACK_BUFFER, pbo)
+gl.BufferData(G.GL_PIXEL_UNPACK_BUFFER, 32 * 16 * 4, None, G.GL_STREAM_DRAW)
+p = gl.MapBufferRange(G.GL_PIXEL_UNPACK_BUFFER, 0, 32 * 16 * 4, 2)
+img = np.random.default_rng(3).integers(0, 256, size=(16, 32, 4), dtype=np.uint8)
+C.memmove(p, img.ctypes.data, img.nbytes)
+gl.UnmapBuffer(G.GL_PIXEL_UNPACK_BUFFER)
+gl.ActiveTexture(G.GL_TEXTURE0); gl.BindTexture(G.GL_TEXTURE_2D, t.id)
+gl.TexSubImage2D(G.GL_TEXTURE_2D, 0, 0, 0, 32, 16, G.GL_BGRA, G.GL_UNSIGNED_BYTE, 0)
+gl.BindBuffer(G.GL_PIXEL_UNPACK_BUFFER, 0)
+gl.BindFramebuffer(G.GL_READ_FRAMEBUFFER, t.fbo); gl.BindFramebuffer(G.GL_DRAW_FRAMEBUFFER, 0)
+gl.BlitFramebuffer(0, 0, 32, 16, 8, 8, 8 + 64, 8 + 32, G.GL_COLOR_BUFFER_BIT, G.GL_NEAREST)
+gl.BindFramebuffer(G.GL_READ_FRAMEBUFFER, 0)
+r.finish()
+px = r.read_pixels()
+np.save(sys.argv[3], px)
+r.destroy()
+'''
+
+
+def capture(tmp_path, backend):
+    trace = tmp_path / "frame.wrtr"
+    px = tmp_path / "px.npy"
+    env = dict(os.environ, WR_CAPTURE_BACKEND=backend, WR_CAPTURE_FILE=str(trace))
+    subprocess.check_call([sys.executable, "-c", DRIVER, ROOT, CAPTURE, str(px)], env=env)
+    return trace.read_bytes(), np.load(px)
+
+
+def replay(backend, trace, shape):
+    """Native replay of the recording; the pixels its last ReadPixels wrote (into the replayer's scratch)."""
+    from webrender_amd.trace import NativeReplayer, FN_ID
+    rp = NativeReplayer(backend)
+    rp.exec(trace)
+    n_calls = struct.unpack_from("<I", trace, 4)[0]
+    pos, last = 16, None
+    for _ in range(n_calls):
+        fid, nargs = struct.unpack_from("<HH", trace, pos)
+        if fid == FN_ID["ReadPixels"]:
+            tag, aux, val = struct.unpack_from("<IIQ", trace, pos + 4 + 6 * 16)
+            last = (val, aux)
+        pos += 4 + nargs * 16
+    assert last is not None
+    return np.frombuffer(rp.scratch(last[0], last[1]), np.uint8).reshape(shape).copy()
+
+
+def test_capture_over_swgl_replays_on_hostsim(tmp_path, hostsim, oracle_gcc):
+    assert os.path.exists(CAPTURE)
+    trace, want = capture(tmp_path, oracle_gcc)
+    assert trace[:4] == b"WRTR" and len(trace) > 100_000
+    assert want.any()
+    assert np.array_equal(replay(hostsim, trace, want.shape), want)
+    assert np.array_equal(replay(oracle_gcc, trace, want.shape), want)      # and on the reference itself
+
+
+@pytest.mark.gpu
+def test_capture_replays_on_hip(tmp_path):
+    ref = oracle_lib("gcc")
+    if not ref:
+        pytest.skip("oracle not built")
+    trace, want = capture(tmp_path, ref)
+    assert np.array_equal(replay(wrhip_lib(), trace, want.shape), want)

@@ -2234,8 +2234,11 @@ void Finish(void) {
     wrrt::d2h(&h, ctx->dcounters, sizeof(h), ctx->stream);
     sync_stream();
     if (h.unsupported_prims != ctx->seen.unsupported_prims || h.perspective_prims != ctx->seen.perspective_prims) {
-      fprintf(stderr, "libwrhip: %u prim(s) on not-yet-implemented paths (AA / rotated / masked-textured / blend override), %u perspective\n",
+      fprintf(stderr, "libwrhip: %u prim(s) on not-yet-implemented paths (shader replays on rotated quads), %u perspective: not drawn\n",
               h.unsupported_prims - ctx->seen.unsupported_prims, h.perspective_prims - ctx->seen.perspective_prims);
+      // visible at the ABI, not only on stderr: the frame has holes, and the caller's GetError() says so (the reference
+      // itself only ever raises GL_OUT_OF_MEMORY, gl.cc:1125-1134, so any other code is unambiguous)
+      ctx->last_error = GL_INVALID_OPERATION;
     }
     static const bool dbgc = getenv("WRHIP_DEBUG_COUNTERS") != nullptr;
     if (dbgc) fprintf(stderr, "libwrhip dbg counters (delta): %u %u %u %u %u (max %u)\n", h.dbg[0] - ctx->seen.dbg[0], h.dbg[1] - ctx->seen.dbg[1],
