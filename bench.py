@@ -46,19 +46,7 @@ REPEATS = 7            # timed regions per run; the median is reported
 
 def make_frame(workload, **kw):
     from webrender_amd import scenes
-    if workload == "cfg2":
-        return scenes.cfg2_overlapping_rects(**kw)
-    if workload == "cfg5":
-        return scenes.cfg5_many_rects(**kw)
-    if workload == "cfg1":
-        return scenes.cfg1_solid_colors(**kw)
-    if workload == "cfg4":
-        kw.pop("encoding", None)
-        return scenes.cfg4_box_shadow(dps=2.0, **kw)
-    if workload == "cfg3":
-        kw.pop("encoding", None)
-        return scenes.cfg3_text(**kw)
-    raise SystemExit(f"unknown workload {workload}")
+    return scenes.make_workload(workload, **kw)
 
 
 def kernel_label(k):

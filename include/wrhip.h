@@ -245,8 +245,11 @@ int32_t WrhipGetKernelStats(WrhipKernelStat* out, int32_t max);
  * sharding by render-target strips). world<=1 disables. */
 void WrhipSetShard(int rank, int world);
 /* Restrict rasterisation of render target `tex` to pixel rows [y0,y1) (rows
- * outside are neither computed nor stored); y0==y1 removes the restriction.
- * Used by the multi-GPU harness to give each rank a screen-space strip. */
+ * outside are neither computed nor stored); y0==y1 removes the restriction;
+ * y1<y0, or a range outside the texture, means the target is not this
+ * process's at all: draws and clears into it are dropped when recorded (no
+ * instance snapshot, staging, upload or setup work).  Used by the multi-GPU
+ * harness to give each rank a screen-space strip. */
 void WrhipSetTargetRows(GLuint tex, int32_t y0, int32_t y1);
 /* Device pointer + geometry of a texture's HBM storage (for RCCL gather). */
 void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height,

@@ -23,6 +23,24 @@ make = lambda: scenes.cfg2_overlapping_rects(width=1024, height=1000, n=120, see
 p = ShardedFramePlayer(lib, "custom", "quad", rank, world, device="cpu", frame=make())
 p.frames(1, 2)
 got = p.assembled()
+# per-rank host / setup work: what this rank recorded, staged and set up for two frames ...
+import ctypes as C
+from webrender_amd.glapi import WrhipStats
+st = WrhipStats()
+reset = C.CFUNCTYPE(None)(p.symbol("WrhipResetStats")); get = C.CFUNCTYPE(None, C.c_void_p)(p.symbol("WrhipGetStats"))
+reset(); p.frames(0, 2); get(C.byref(st))
+mine = (st.prims, st.h2d_bytes)
+# ... against an unsharded player of the same frame
+from webrender_amd.harness import record_scene, ScenePlayer
+rec, _ = record_scene(lib, make())
+full = ScenePlayer(lib, rec)
+full.frames(1, 0)
+C.CFUNCTYPE(None)(full.symbol("WrhipResetStats"))(); full.frames(0, 2)
+sf = WrhipStats(); C.CFUNCTYPE(None, C.c_void_p)(full.symbol("WrhipGetStats"))(C.byref(sf))
+print(f"RANK{rank} prims {mine[0]} of {sf.prims}, h2d {mine[1]} of {sf.h2d_bytes}")
+if world == 2:      # the strips are whole tile rows: each rank records, stages and sets up about half of the frame's prims
+    # (the data textures -- prim headers, GPU buffers -- are uploaded by every rank: SURVEY section 8e, "broadcast H2D")
+    assert mine[0] < 0.65 * sf.prims and mine[1] < sf.h2d_bytes, (mine, sf.prims, sf.h2d_bytes)
 want, _ = render_direct(lib, make())
 ok = np.array_equal(got, want)
 # each rank only rasterised its own strip: pixels it does not own stay at the clear colour in its window

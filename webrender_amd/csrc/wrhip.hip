@@ -93,6 +93,7 @@ struct Texture {
   GLuint depth_owner = 0;            // colour target whose pending work last used this depth attachment
   // hazards against the pending list
   int own_y0 = 0, own_y1 = 0;   // multi-GPU: owned pixel rows (0,0 = all)
+  bool own_none = false;        // ... or none at all: draws and clears into this target are dropped when they are recorded
   bool pending_read = false, pending_write = false;
   int pending_target = -1;   // index into Context::work when pending_write
   bool tail_ref = false;     // read or written by the deferred last raster level (Context::Tail)
@@ -757,7 +758,7 @@ void record_clear(GLuint tex_id, bool color, uint32_t color_value, bool depth, G
                   const int rect[4]) {
   {
     Texture& t = ctx->textures[tex_id];
-    if (!t.has_storage()) return;
+    if (!t.has_storage() || t.own_none) return;
   }
   if (depth) {
     const Texture& ct = ctx->textures[tex_id];
@@ -2026,7 +2027,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   GLuint color_id = fb.color_attachment;
   {
     Texture& colortex = c->textures[color_id];
-    if (!colortex.dptr) return;
+    if (!colortex.dptr || colortex.own_none) return;      // (own_none: another rank's target, WrhipSetTargetRows)
     if (colortex.internal_format != GL_RGBA8 && colortex.internal_format != GL_R8) return;
   }
   VertexArray& v = c->vertex_arrays[c->current_vertex_array];
@@ -2336,6 +2337,8 @@ void WrhipSetTargetRows(GLuint tex, int32_t y0, int32_t y1) {
   flush_all();
   Texture& t = ctx->textures[tex];
   t.own_y0 = y0; t.own_y1 = y1;
+  t.own_none = y1 < y0 || y0 >= t.height || (y1 > y0 && y1 <= 0);
+  if (t.own_none) { t.own_y0 = t.height; t.own_y1 = t.height + 1; }
 }
 void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height, int32_t* stride) {
   Texture* t = ctx ? ctx->textures.find(tex) : nullptr;

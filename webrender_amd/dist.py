@@ -1,14 +1,18 @@
 """Multi-GPU: screen-space strip sharding of one frame + RCCL all-gather of the
 window framebuffer.
 
-One process per GPU.  Every rank replays the *same* call stream (the data
-textures and instance arrays are small and broadcast by construction), but
-tells its backend which pixel rows of each render target it owns
-(`WrhipSetTargetRows`): rank r owns the screen rows [Y0_r, Y1_r) -- multiples of
-64 so they coincide with raster bins -- of every picture-cache tile and of the
-window.  Rows outside are neither rasterised nor stored.  Off-screen mask / blur
-targets are left unrestricted (replicated on every rank: they are tiny compared
-with tiles and would otherwise have to be exchanged between passes).
+One process per GPU.  Every rank replays the *same* call stream, but tells its
+backend which pixel rows of each render target it owns (`WrhipSetTargetRows`):
+rank r owns the screen rows [Y0_r, Y1_r) -- multiples of 64 so they coincide
+with raster bins -- of every picture-cache tile and of the window.  Rows outside
+are neither rasterised nor stored, and a tile with NO row in the rank's strip is
+dropped when its draws are recorded: its instance bytes are not snapshotted,
+staged or uploaded and its prims never reach the setup stage, so the per-rank
+host and setup work shrinks with the number of ranks, not only the raster work
+(libwrhip: an empty row range makes DrawElementsInstanced / Clear on that target
+no-ops).  Off-screen mask / blur targets are left unrestricted (replicated on
+every rank: they are tiny compared with tiles and would otherwise have to be
+exchanged between passes).
 
 The only collective is the all-gather that reassembles the framebuffer: each
 rank contributes its strip (equal-sized, padded) and receives the others, over
@@ -19,11 +23,13 @@ import numpy as np
 
 
 def strip_rows(height, rank, world, align=64):
-    """Screen rows [y0, y1) owned by `rank`: equal counts of `align`-row groups."""
+    """Screen rows [y0, y1) owned by `rank`, and the (padded) strip height every rank contributes to the all-gather.
+    The `align`-row groups (raster bin rows) are dealt out as evenly as they go: rank r gets groups
+    [r * G // world, (r + 1) * G // world), so no rank is left without work while another holds two extra groups."""
     groups = (height + align - 1) // align
-    per = (groups + world - 1) // world
-    y0 = min(height, rank * per * align)
-    y1 = min(height, (rank + 1) * per * align)
+    g0, g1 = rank * groups // world, (rank + 1) * groups // world
+    y0, y1 = min(height, g0 * align), min(height, g1 * align)
+    per = max((r + 1) * groups // world - r * groups // world for r in range(world))
     return y0, y1, per * align
 
 
@@ -61,8 +67,8 @@ class ShardedFramePlayer:
         self.torch, self.dist = torch, dist
         self.rank, self.world = rank, world
         if frame is None:
-            from bench import make_frame
-            frame = make_frame(workload, encoding=encoding)
+            from .scenes import make_workload
+            frame = make_workload(workload, encoding=encoding)
         self.width, self.height = frame.width, frame.height
         rec, _ = record_scene(lib, frame)
         self.rec = rec
@@ -77,11 +83,11 @@ class ShardedFramePlayer:
             if y1 > y0:
                 set_rows(tid, y0, y1)
             else:
-                set_rows(tid, 1 << 30, (1 << 30) + 1)       # owns no row of this tile
+                set_rows(tid, 1, 0)                         # owns no row of this tile: its draws are dropped at record time
         if fb_rows[1] > fb_rows[0]:
             set_rows(fb_tex, fb_rows[0], fb_rows[1])
         else:
-            set_rows(fb_tex, 1 << 30, (1 << 30) + 1)
+            set_rows(fb_tex, 1, 0)
         self.fb_rows = fb_rows
         self._flush = C.CFUNCTYPE(None)(sym("WrhipFlush"))
         self._get_stream = C.CFUNCTYPE(C.c_void_p)(sym("WrhipGetStream"))

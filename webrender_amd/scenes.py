@@ -1813,3 +1813,20 @@ def blend_modes(width=1024, height=1024, per_state=14, seed=111, states=BLEND_ST
         frame.composite_tiles.append(CompositeTile(tex, rect, (float(x0), float(y0), float(min(x1, width)), float(min(y1, height))), opaque=True))
     frame.passes.append(targets)
     return frame
+
+
+def make_workload(workload, **kw):
+    """The BASELINE.json configs by name ("cfg1" .. "cfg5"), as bench.py and the multi-GPU harness build them."""
+    if workload == "cfg2":
+        return cfg2_overlapping_rects(**kw)
+    if workload == "cfg5":
+        return cfg5_many_rects(**kw)
+    if workload == "cfg1":
+        return cfg1_solid_colors(**kw)
+    if workload == "cfg4":
+        kw.pop("encoding", None)
+        return cfg4_box_shadow(dps=2.0, **kw)
+    if workload == "cfg3":
+        kw.pop("encoding", None)
+        return cfg3_text(**kw)
+    raise SystemExit(f"unknown workload {workload}")
