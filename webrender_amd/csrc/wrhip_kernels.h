@@ -4978,13 +4978,30 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     const bool has = (m >> lane) & 1ull;
     const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);
     unsigned long long live = __ballot(hit);
+    // Rect-only launches (FEAT == 0): the survivors' records come back through the scalar cache, one s_load_dwordx8 per prim
+    // issued a prim ahead, instead of eight v_readlane broadcasts out of the lanes that tested them -- the blend loop is
+    // VALU-bound and v_readlane is VALU (cfg2 tile pass 68.6 -> 61.1 us).  The index is wave-uniform and recs[] read-only.
+    // The textured variants keep the broadcasts (measured: the extra scalar round trip costs them 3 %).
+    constexpr bool SCALAR_RECS = FEAT == 0;
+    int nbit = live ? __builtin_ctzll(live) : 0;
+    WrRec nrec;
+    if (SCALAR_RECS) nrec = recs[base + nbit];
     while (live) {
-      const int bit = __builtin_ctzll(live);
+      const int bit = SCALAR_RECS ? nbit : __builtin_ctzll(live);
       live &= live - 1;
-      const int x0 = __builtin_amdgcn_readlane((int)ra.x, bit), y0 = __builtin_amdgcn_readlane((int)ra.y, bit);
-      const int x1 = __builtin_amdgcn_readlane((int)ra.z, bit), y1 = __builtin_amdgcn_readlane((int)ra.w, bit);
-      const uint32_t z = __builtin_amdgcn_readlane((int)rb.x, bit), kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
-      const uint32_t c0 = __builtin_amdgcn_readlane((int)rb.z, bit), c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
+      int x0, y0, x1, y1;
+      uint32_t z, kbf, c0, c1;
+      if (SCALAR_RECS) {
+        const WrRec Rc = nrec;
+        nbit = live ? __builtin_ctzll(live) : bit;
+        nrec = recs[base + nbit];
+        x0 = Rc.x0; y0 = Rc.y0; x1 = Rc.x1; y1 = Rc.y1; z = Rc.z; kbf = Rc.kbf; c0 = Rc.c0; c1 = Rc.c1;
+      } else {
+        x0 = __builtin_amdgcn_readlane((int)ra.x, bit); y0 = __builtin_amdgcn_readlane((int)ra.y, bit);
+        x1 = __builtin_amdgcn_readlane((int)ra.z, bit); y1 = __builtin_amdgcn_readlane((int)ra.w, bit);
+        z = __builtin_amdgcn_readlane((int)rb.x, bit); kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
+        c0 = __builtin_amdgcn_readlane((int)rb.z, bit); c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
+      }
       const int rblend = (kbf >> 8) & 0xFF;
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
