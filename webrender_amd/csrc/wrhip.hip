@@ -321,6 +321,7 @@ struct Context {
   int next_query_slot = 0;
   bool forward_composites = true;      // WRHIP_NO_FORWARD=1 turns the write-through of opaque 1:1 composites off
   bool profiling_no_forward = false;
+  bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
 
   Context() {
     wrrt::stream_create(&stream);
@@ -328,6 +329,7 @@ struct Context {
     wrrt::event_create_sync(&ev_copy);
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
+    thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
@@ -856,6 +858,9 @@ bool can_fuse(const Context::Held& H) {
   return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
                                    H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
 }
+#ifndef WR_THIN_MAX_BINS
+#define WR_THIN_MAX_BINS 256
+#endif
 void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
                    const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0) {
   Context* c = ctx;
@@ -893,9 +898,18 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     }
     (void)FA;
   } else {
-    if (H.feat == 0) WR_K(WR_FMT_R8, false, 0);
-    else if (H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR)) WR_K(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR);
+    // Small mask launches (blur / down-scale passes of a few dozen bins) leave most of the chip idle and are bound by one
+    // wave's critical path: there a bin is given 16 waves of 64 x 4 pixels (4 px per lane) instead of 4 waves of 64 x 16.
+    const bool thin = c->thin_r8 && H.nb <= WR_THIN_MAX_BINS;
+#define WR_K1(FEAT)                                                                                                     \
+  do {                                                                                                                  \
+    WR_LAUNCH((wr_raster_kernel<WR_FMT_R8, false, 1, FEAT>), H.nb, 1024, c->stream, targets, n_targets, draws,          \
+              (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off); \
+  } while (0)
+    if (H.feat == 0) { if (thin) WR_K1(0); else WR_K(WR_FMT_R8, false, 0); }
+    else if (H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR)) { if (thin) WR_K1(WR_FEAT_GENERIC | WR_FEAT_BLUR); else WR_K(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR); }
     else WR_K(WR_FMT_R8, false, WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP);
+#undef WR_K1
   }
 #undef WR_K
 #undef WR_KF
