@@ -54,6 +54,8 @@ def kernel_label(k):
         return "wr_upload_kernel"
     if k.kind == 1:
         return "wr_setup_kernel"
+    if k.kind == 3:
+        return "wr_mask_rows_kernel"
     return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
 
 

@@ -231,7 +231,7 @@ void WrhipGetStats(WrhipStats* out);
 void WrhipResetStats(void);
 /* Enable hipEvent timing of every kernel launch (one event pair and a sync per launch: for measurement runs only). */
 void WrhipSetProfiling(int enabled);
-/* Per-kernel-variant totals collected while profiling is on: kind 0 = upload scatter, 1 = setup stage, 2 = raster
+/* Per-kernel-variant totals collected while profiling is on: kind 0 = upload scatter, 1 = setup stage, 3 = mask rows (wr_mask_rows_kernel), 2 = raster
  * kernel wr_raster_kernel<fmt, depth, 4, feat>.  algo_bytes: the launch's algorithmic bytes:
  * raster launches count every destination pixel they own once (twice when the target's old content is loaded) plus
  * the source texels their draws can sample; the setup stage counts instance + descriptor + record bytes.  Returns the

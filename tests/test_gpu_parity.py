@@ -141,10 +141,13 @@ def test_hip_blur_matches_oracle(name, kw):
 CLIP_CASES = [("clip_masks", dict()), ("clip_masks_dps", dict(dps=1.5, seed=32)), ("clip_masks_many", dict(n=60, seed=33))]
 
 
+@pytest.mark.parametrize("evaluation", ["mask_rows", "in_raster"])
 @pytest.mark.parametrize("name,kw", CLIP_CASES, ids=[c[0] for c in CLIP_CASES])
-def test_hip_clip_rectangle_matches_oracle(name, kw):
+def test_hip_clip_rectangle_matches_oracle(name, kw, evaluation, monkeypatch):
     """cs_clip_rectangle masks on the GPU: float coverage -> +-1 LSB allowed by
     north_star, the committed digest pins the exact result."""
+    if evaluation == "in_raster":      # the prims evaluated inside the bin raster instead of by wr_mask_rows_kernel (the fallback
+        monkeypatch.setenv("WRHIP_NO_MASK_ROWS", "1")     # of a flush whose masks exceed the mask-row store)
     got, _ = render_direct(wrhip_lib(), scenes.clip_masks(**kw))
     ref = oracle_lib("gcc")
     if ref:
@@ -159,8 +162,11 @@ def test_hip_clip_rectangle_matches_oracle(name, kw):
 BOX_CASES = [("box_shadow_masks", dict()), ("box_shadow_masks_dps", dict(dps=1.5, seed=42)), ("box_shadow_masks_many", dict(n=40, seed=43))]
 
 
+@pytest.mark.parametrize("evaluation", ["mask_rows", "in_raster"])
 @pytest.mark.parametrize("name,kw", BOX_CASES, ids=[c[0] for c in BOX_CASES])
-def test_hip_box_shadow_matches_oracle(name, kw):
+def test_hip_box_shadow_matches_oracle(name, kw, evaluation, monkeypatch):
+    if evaluation == "in_raster":      # the prims evaluated inside the bin raster instead of by wr_mask_rows_kernel (the fallback
+        monkeypatch.setenv("WRHIP_NO_MASK_ROWS", "1")     # of a flush whose masks exceed the mask-row store)
     got, _ = render_direct(wrhip_lib(), scenes.box_shadow_masks(**kw))
     ref = oracle_lib("gcc")
     if ref:

@@ -125,10 +125,13 @@ def test_hostsim_blur_matches_oracle(hostsim, oracle_gcc, name, kw):
 CLIP_CASES = [("clip_masks", dict()), ("clip_masks_dps", dict(dps=1.5, seed=32)), ("clip_masks_many", dict(n=60, seed=33))]
 
 
+@pytest.mark.parametrize("evaluation", ["mask_rows", "in_raster"])
 @pytest.mark.parametrize("name,kw", CLIP_CASES, ids=[c[0] for c in CLIP_CASES])
-def test_hostsim_clip_rectangle_matches_oracle(hostsim, oracle_gcc, name, kw):
+def test_hostsim_clip_rectangle_matches_oracle(hostsim, oracle_gcc, name, kw, evaluation, monkeypatch):
     """cs_clip_rectangle (uniform-radius fast path and general path, clip and
     clip-out, second clip multiplied in) into an R8 alpha target."""
+    if evaluation == "in_raster":      # the prims evaluated inside the bin raster instead of by wr_mask_rows_kernel (the fallback
+        monkeypatch.setenv("WRHIP_NO_MASK_ROWS", "1")     # of a flush whose masks exceed the mask-row store)
     want, _ = render_direct(oracle_gcc, scenes.clip_masks(**kw))
     got, _ = render_direct(hostsim, scenes.clip_masks(**kw))
     assert np.array_equal(got["clip_masks"], want["clip_masks"])
@@ -141,10 +144,13 @@ def test_hostsim_clip_rectangle_matches_oracle(hostsim, oracle_gcc, name, kw):
 BOX_CASES = [("box_shadow_masks", dict()), ("box_shadow_masks_dps", dict(dps=1.5, seed=42)), ("box_shadow_masks_many", dict(n=40, seed=43))]
 
 
+@pytest.mark.parametrize("evaluation", ["mask_rows", "in_raster"])
 @pytest.mark.parametrize("name,kw", BOX_CASES, ids=[c[0] for c in BOX_CASES])
-def test_hostsim_box_shadow_matches_oracle(hostsim, oracle_gcc, name, kw):
+def test_hostsim_box_shadow_matches_oracle(hostsim, oracle_gcc, name, kw, evaluation, monkeypatch):
     """cs_clip_box_shadow: nine-patch stretch of a cached blurred shadow into
     R8 mask tasks (stretch / simple modes per axis, clip and clip-out)."""
+    if evaluation == "in_raster":      # the prims evaluated inside the bin raster instead of by wr_mask_rows_kernel (the fallback
+        monkeypatch.setenv("WRHIP_NO_MASK_ROWS", "1")     # of a flush whose masks exceed the mask-row store)
     want, _ = render_direct(oracle_gcc, scenes.box_shadow_masks(**kw))
     got, _ = render_direct(hostsim, scenes.box_shadow_masks(**kw))
     assert np.array_equal(got["box_shadow_masks"], want["box_shadow_masks"])

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/thin
 (timeout 900 python -m pytest tests -m gpu -q -k "cfg4 or blur or shadow or clip or mask" 2>&1 | tail -5) > gpurun_out/thin/tests.log 2>&1
 cat gpurun_out/thin/tests.log
-for v in "" "WRHIP_NO_THIN=1"; do
+for v in "" "WRHIP_NO_MASK_ROWS=1"; do
   echo "== $v"
   env $v python bench.py --workload cfg4 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | grep metric | python3 -c "
 import sys, json

@@ -278,6 +278,9 @@ struct Context {
     WrAux* aux = nullptr;
     float* vtab = nullptr; size_t vtab_cap = 0;   // per-row v tables of nearest-fast textured prims (WrDrawDesc::vtab_base)
     unsigned long long* masks = nullptr; size_t masks_cap = 0;
+    // mask-row store (WrMaskSlot): allocation word, slot list, row bytes
+    unsigned long long* mr_ctl = nullptr; WrMaskSlot* mr_slots = nullptr; size_t mr_slots_cap = 0;
+    uint8_t* mr_store = nullptr; size_t mr_store_cap = 0;
   } scratch[2];
   int64_t flush_seq = 0;
   // The raster launches of a flush are not issued with it: they are held back, and the first of them
@@ -286,7 +289,7 @@ struct Context {
   // plus a kernel boundary; the rest follow in order.  Anything that needs their results, or touches a
   // texture they read or write from outside the draw stream (host uploads, copies, readbacks,
   // deletes, Finish), drains them first (drain_tail).
-  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; };    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
+  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; int mr_rows = 0; };   // mr_rows > 0: wr_mask_rows_kernel goes first (bound on its rows)    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
   struct Tail {
     bool pending = false;
     std::vector<Held> held;          // the raster launches of the held-back flush, in order
@@ -321,6 +324,7 @@ struct Context {
   int next_query_slot = 0;
   bool forward_composites = true;      // WRHIP_NO_FORWARD=1 turns the write-through of opaque 1:1 composites off
   bool profiling_no_forward = false;
+  bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
 
   Context() {
@@ -330,6 +334,7 @@ struct Context {
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
+    mask_rows = getenv("WRHIP_NO_MASK_ROWS") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
@@ -818,7 +823,7 @@ Context::~Context() {
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
   wrrt::dev_free(dupload); wrrt::dev_free(dcounters);
-  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); }
+  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); }
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::event_destroy(ev_copy);
@@ -876,6 +881,15 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
               (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);                                               \
   } while (0)
   const int F5 = WR_FEAT_TEX | WR_FEAT_GENERIC, F7 = F5 | WR_FEAT_R8TEX, FA = F7 | WR_FEAT_BLUR | WR_FEAT_SHADE;
+  if (H.mr_rows > 0 && S.mr_ctl) {
+    // the cs_clip_* prims of this launch's targets, row by row (one wave per row), ahead of the bins that blend them
+    const int wgs = std::max(1, std::min((H.mr_rows + 3) / 4, 4096));
+    prof_begin();
+    WR_LAUNCH(wr_mask_rows_kernel, wgs, 256, c->stream, targets, H.off, H.off + H.nb, (const WrPrim*)S.prims, (const WrAux*)S.aux,
+              (const unsigned long long*)S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
+    prof_end(3, H.fmt, 0, 0, 0, (uint64_t)wgs);
+    c->stats.kernel_launches++;
+  }
   prof_begin();
   if (SA) {
     if (H.depth) {
@@ -1045,7 +1059,8 @@ void flush_work(const std::vector<int>& sel_in) {
     if (la != lb) return la < lb;
     return (c->textures[c->work[a].tex].internal_format == GL_R8) < (c->textures[c->work[b].tex].internal_format == GL_R8);
   });
-  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false; uint64_t bytes_rgba = 0, bytes_r8 = 0; };
+  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false; uint64_t bytes_rgba = 0, bytes_r8 = 0, mr_rows = 0; };
+  uint64_t mr_slots = 0, mr_rows = 0, mr_bytes = 0;      // bounds on what the cs_clip_* prims of this flush can reserve in the mask-row store
   std::vector<Level> levels;
   std::vector<int> target_level;
   const int n_targets = (int)sel.size();
@@ -1104,6 +1119,17 @@ void flush_work(const std::vector<int>& sel_in) {
         continue;
       }
       any_kept = true;
+      if (c->mask_rows && T.format == WR_FMT_R8 && !(d.flags & WR_DF_SIMPLE) &&
+          (d.shader == WR_SH_CS_CLIP_RECT || d.shader == WR_SH_CS_CLIP_RECT_FAST || d.shader == WR_SH_CS_CLIP_BOX_SHADOW)) {
+        const int cw = std::max(0, std::min(d.clip[2], t.width) - std::max(d.clip[0], 0));
+        const int ch = std::max(0, std::min(d.clip[3], t.height) - std::max(d.clip[1], 0));
+        if (cw > 0 && ch > 0 && d.count > 0) {
+          d.flags |= WR_DF_MASK_ROWS;
+          mr_slots += (uint64_t)d.count; mr_rows += (uint64_t)d.count * ch;
+          mr_bytes += (uint64_t)d.count * ((uint64_t)((cw + 7) & ~3) * ch + 16);
+          L.mr_rows += (uint64_t)d.count * ch;
+        }
+      }
       if ((d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) && T.format == WR_FMT_RGBA8) L.any_depth = true;
       d.first_prim = prim_cursor;
       if ((d.flags & WR_DF_DEPTH_WRITE) && d.shader != WR_SH_CLEAR_OP) {
@@ -1174,6 +1200,37 @@ void flush_work(const std::vector<int>& sel_in) {
   }
   const int n_prims = prim_cursor, n_bins = bin_cursor, n_words = word_cursor;
   const int nd = (int)draws.size();
+  // Mask-row store.  When the bounds fit, no reservation of the setup stage can fail and the R8 launches take the light
+  // variant (the rows kernel evaluates, the bins blend bytes); otherwise the store is capped, prims that do not fit keep their
+  // in-raster evaluation and the launches the variant that has it.
+  bool mr_on = mr_slots > 0, mr_safe = false;
+  if (mr_on) {
+    Context::Scratch& S = c->scratch[c->flush_seq & 1];
+    const uint64_t kCap = (uint64_t)1 << 30;
+    mr_safe = mr_slots <= WR_MR_MAX_SLOTS && mr_rows <= WR_MR_MAX_ROWS && mr_bytes <= kCap;
+    const size_t want_slots = (size_t)std::min<uint64_t>(mr_slots, WR_MR_MAX_SLOTS);
+    const size_t want_bytes = (size_t)std::min<uint64_t>(mr_bytes, mr_safe ? kCap : ((uint64_t)256 << 20));
+    if (!S.mr_ctl || S.mr_slots_cap < want_slots || S.mr_store_cap < want_bytes) {
+      sync_stream();
+      if (!S.mr_ctl) S.mr_ctl = (unsigned long long*)wrrt::dev_alloc(256);
+      if (S.mr_slots_cap < want_slots) {
+        wrrt::dev_free(S.mr_slots);
+        S.mr_slots_cap = std::min<size_t>(want_slots * 2, WR_MR_MAX_SLOTS);
+        S.mr_slots = (WrMaskSlot*)wrrt::dev_alloc(S.mr_slots_cap * sizeof(WrMaskSlot));
+      }
+      if (S.mr_store_cap < want_bytes) {
+        wrrt::dev_free(S.mr_store);
+        S.mr_store_cap = (want_bytes + 4095) & ~size_t(4095);
+        S.mr_store = (uint8_t*)wrrt::dev_alloc(S.mr_store_cap);
+      }
+    }
+    for (WrTargetDesc& T : targets) {
+      if (T.format != WR_FMT_R8) continue;
+      T.mr_ctl = S.mr_ctl; T.mr_slots = S.mr_slots; T.mr_store = S.mr_store;
+      T.mr_cap16 = (uint32_t)std::min<uint64_t>(S.mr_store_cap >> 4, WR_MR_MAX_CAP16);
+      T.mr_max_slots = (uint32_t)S.mr_slots_cap;
+    }
+  }
   if (n_bins > 0) {
     // ---- frame arena: [draws | targets | instance bytes] -> one H2D copy ----
     size_t off_draws = 0;
@@ -1230,6 +1287,7 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
     const uint8_t* dinst = darena + off_inst;
     const int* dblk = (const int*)(darena + off_blk);
+    if (mr_on) wrrt::memset8(S.mr_ctl, 0, 8, c->stream);     // (this set's previous user, two flushes back, has been launched)
     if (n_prims > 0) {
 #ifdef WRHIP_TIMING
       static const int setup_mode = getenv("WRHIP_SETUP_MODE") ? atoi(getenv("WRHIP_SETUP_MODE")) : 0;
@@ -1305,7 +1363,8 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_PS_TEXT_RUN: case WR_SH_PS_TEXT_RUN_DUAL: f = WR_FEAT_R8TEX | WR_FEAT_TEX | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA: f = WR_FEAT_R8TEX | WR_FEAT_GENERIC; break;   // masked / odd blend
           case WR_SH_CS_BLUR_ALPHA: case WR_SH_CS_BLUR_COLOR: f = WR_FEAT_BLUR; break;
-          case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW: f = WR_FEAT_CLIP; break;
+          case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW:
+            f = ((draws[i].flags & WR_DF_MASK_ROWS) && mr_safe) ? WR_FEAT_BLUR : WR_FEAT_CLIP; break;
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
@@ -1331,7 +1390,7 @@ void flush_work(const std::vector<int>& sel_in) {
       }
       if (L.bins_r8 > 0) {
         const int f = L.feat_r8 == 0 ? 0 : (!(L.feat_r8 & WR_FEAT_CLIP) ? (WR_FEAT_GENERIC | WR_FEAT_BLUR) : (WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP));
-        launches.push_back(Context::Held{WR_FMT_R8, 0, f, L.bins_r8, L.bin0 + L.bins_rgba, L.bytes_r8});
+        launches.push_back(Context::Held{WR_FMT_R8, 0, f, L.bins_r8, L.bin0 + L.bins_rgba, L.bytes_r8, (int)std::min<uint64_t>(L.mr_rows, WR_MR_MAX_ROWS)});
       }
     }
     if (c->defer_tail && !c->profiling && !launches.empty()) {

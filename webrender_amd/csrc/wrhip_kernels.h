@@ -202,7 +202,9 @@ WR_DEVICE bool wr_accum_is_linear(float s0, float step, int c) {
 // kernel that can reach the general pixel path ~20 VGPRs: with interprocedural register allocation a
 // caller keeps its live values above whatever its callees clobber -- and the glyph kernel sits
 // exactly at the 168-VGPR / 3-waves-per-SIMD step.)
-WR_DEVICE float wr_accum_binades(float s0, float step, int c) {
+// (out of line: 32 call sites reach it through wr_accum and it is the rare case -- inlined, its ~0.5 KB copies sat between the
+// instructions that do run, and a latency-bound launch walks its code with a cold instruction cache)
+__device__ __noinline__ float wr_accum_binades(float s0, float step, int c) {
   float s = s0;
   int k = c;
   uint32_t db; __builtin_memcpy(&db, &step, 4);
@@ -2712,6 +2714,32 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
 #endif
   if (valid) {
     prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
+    if ((P.kind == WR_PK_BOX_SHADOW || P.kind == WR_PK_CLIP_RECT) && (draws[P.draw].flags & WR_DF_MASK_ROWS) && P.x1 > P.x0 && P.y1 > P.y0) {
+      // reserve this prim's rows in the flush's mask-row store (WrMaskSlot); a prim that does not fit keeps its in-raster evaluation
+      const WrTargetDesc& T = targets[draws[P.draw].target];
+      if (T.mr_ctl) {
+        const uint32_t rows = uint32_t(P.y1 - P.y0), pitch = uint32_t(((P.x1 + 3) & ~3) - (P.x0 & ~3));
+        const unsigned long long n16 = ((unsigned long long)rows * pitch + 15) >> 4;
+        unsigned long long old = *(volatile unsigned long long*)T.mr_ctl;
+        for (;;) {
+          const unsigned long long ns = old >> 48, nr = (old >> 28) & 0xFFFFFull, nb = old & 0xFFFFFFFull;
+          if (ns + 1 > T.mr_max_slots || nr + rows > WR_MR_MAX_ROWS || nb + n16 > T.mr_cap16) break;
+          const unsigned long long want = ((ns + 1) << 48) | ((nr + rows) << 28) | (nb + n16);
+          const unsigned long long seen = atomicCAS(T.mr_ctl, old, want);
+          if (seen == old) {
+            WrMaskSlot sl;
+            sl.prim = gid; sl.target = draws[P.draw].target; sl.row0 = uint32_t(nr); sl.pitch = pitch; sl.off16 = uint32_t(nb);
+            sl.pad[0] = sl.pad[1] = sl.pad[2] = 0;
+            T.mr_slots[ns] = sl;
+            const unsigned long long addr = (unsigned long long)(T.mr_store + nb * 16);
+            recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_MASK_ROWS;
+            recs[gid].c0 = uint32_t(addr); recs[gid].c1 = uint32_t(addr >> 32); recs[gid].z = pitch;
+            break;
+          }
+          old = seen;
+        }
+      }
+    }
     if (P.kind == WR_PK_TEX_R8) aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
     if (P.kind == WR_PK_SOLID_MASKED) {
       // a masked solid is a unit-texel read of the mask: reuse the glyph path's record
@@ -4036,6 +4064,244 @@ WR_DEVICE void wr_box_row_finish(const WrPrim* Pp, const WrBoxRec* Bp, const WrR
   br.vrow = wr_box_shadow_row4(Pp, Bp, rv, br, Pp->x0 + (br.xc & 0xFFFF), y).v[0];
 }
 
+// ---------------------------------------------------------------------------
+// Mask rows (WrMaskSlot): one wave evaluates one target row of one cs_clip_* prim into the flush's mask-row store.
+// dst[n] is the byte of pixel x0 + n.  Every lane walks the row's state machine (the walk is the same for all of them: no
+// divergence) and the pixels of each run are dealt out to the lanes; no two lanes ever store to the same byte.
+WR_DEVICE void wr_fill_lanes(uint8_t* dst, int a, int b, uint32_t v, int lane) {
+  for (int n = a + lane; n < b; n += 64) dst[n] = (uint8_t)v;
+}
+// cs_clip_box_shadow (cs_clip_box_shadow.glsl:150-324): the walk of wr_box_shadow_row4 over the whole row
+WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, int y, int lane, uint8_t* dst) {
+  const WrRowVals rv = wr_box_row_vals(P, B, y);
+  const WrBoxRow br = wr_box_row_setup(P, B, rv);
+  const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear};
+  float o4[4], s4[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { o4[c] = rv.o[c]; s4[c] = rv.s[c]; }
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  const float mode = B.mode;
+  const uint32_t v_clear = uint32_t(wr_round_pixel(mode)) & 0xFFFF;
+  float ln[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { ln[c][0] = o4[c]; ln[c][1] = ln[c][0] + s4[c]; ln[c][2] = ln[c][1] + s4[c]; ln[c][3] = ln[c][2] + s4[c]; }
+  // ---- tail pixels [span, len): fragment shader
+  if (lane < len - span) {
+    const int n = span + lane;
+    const int sl4 = (n - span) & 3, m = (n - span) >> 2;
+    float v4[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float a = wr_sel4(ln[c][0], ln[c][1], ln[c][2], ln[c][3], sl4);
+      if (span > 0) a = a + (s4[c] * 4.0f) * (float(span) * 0.25f);
+      v4[c] = wr_accum(a, (s4[c] * 4.0f) * 1.0f, m);
+    }
+    const float r = wr_box_shade(B, t, v4[0] / B.w, v4[1] / B.w, v4[2] / B.w, v4[3] / B.w);
+    dst[n] = (uint8_t)(uint32_t(wr_round_pixel(B.w > 0.0f ? r : 0.0f)) & 0xFFFF);
+  }
+  if (span <= 0) return;
+  float w = B.w;
+  if (w <= 0.0f) { wr_fill_lanes(dst, 0, span, 0, lane); return; }      // swgl_commitSolidR8(0.0)
+  w = 1.0f / w;
+  float cur[4][4], st[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) cur[c][i] = ln[c][i] * w;
+    st[c] = (s4[c] * 4.0f) * w;
+  }
+  const int shadow_start_len = br.ss_se & 0xFFFF, shadow_end_len = br.ss_se >> 16;
+  const int os0 = br.os01 & 0xFFFF, os1 = br.os01 >> 16, os2 = br.os23 & 0xFFFF, os3 = br.os23 >> 16;
+  int R = span, pos = 0;
+  if (R > shadow_start_len) {                       // solid lead-in
+    const int nb = R - shadow_start_len;
+    const float f = float(nb / 4);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+    }
+    wr_fill_lanes(dst, 0, nb, v_clear, lane);
+    R -= nb; pos += nb;
+  }
+  while (R > 0) {
+    if (lane < 4) {                                  // transitional chunk: per-fragment mapping
+      const int n = pos + lane;
+      if (n < span) {
+        const int l4 = n & 3;
+        dst[n] = (uint8_t)(uint32_t(wr_round_pixel(wr_box_shade(B, t, wr_sel4(cur[0][0], cur[0][1], cur[0][2], cur[0][3], l4),
+                                                                 wr_sel4(cur[1][0], cur[1][1], cur[1][2], cur[1][3], l4),
+                                                                 wr_sel4(cur[2][0], cur[2][1], cur[2][2], cur[2][3], l4),
+                                                                 wr_sel4(cur[3][0], cur[3][1], cur[3][2], cur[3][3], l4)))) & 0xFFFF);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) cur[c][i] += st[c];
+    }
+    R -= 4; pos += 4;
+    if (R <= shadow_end_len) break;
+    int num_inside = R - 4 - shadow_end_len;
+    float ub0 = B.uv_bounds[0], ub1 = B.uv_bounds[1], ub2 = B.uv_bounds[2], ub3 = B.uv_bounds[3];
+    bool xcl = false;
+    if (R >= os1) {
+      num_inside = wr_imin(num_inside, R - os1);
+    } else if (R >= os3) {
+      num_inside = wr_imin(num_inside, R - os3);
+      const float cc = wr_clamp((B.uv_noclamp[3] - B.uv_noclamp[1]) * B.edge[1] + B.uv_noclamp[1], B.uv_bounds[1], B.uv_bounds[3]);
+      ub1 = cc; ub3 = cc;
+    }
+    if (R >= os0) {
+      num_inside = wr_imin(num_inside, R - os0);
+    } else if (R >= os2) {
+      num_inside = wr_imin(num_inside, R - os2);
+      const float cc = wr_clamp((B.uv_noclamp[2] - B.uv_noclamp[0]) * B.edge[0] + B.uv_noclamp[0], B.uv_bounds[0], B.uv_bounds[2]);
+      ub0 = cc; ub2 = cc;
+      xcl = true;
+    }
+    if (num_inside > 0) {
+      float pu[4], pv[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) wr_box_map_uv(B, cur[0][i], cur[1][i], pu[i], pv[i]);
+      const bool centre = ub0 == ub2 && ub1 == ub3;
+      const float W = float(t.width), H = float(t.height);
+      int filter = 0;
+      if (!centre) {   // needsTextureLinear (swgl_ext.h:553-587)
+        if (t.width < 2) filter = 0;
+        else if (pv[0] != pv[1]) filter = 1;
+        else {
+          const float px0 = pu[0] * W, px1 = pu[1] * W, py0 = pv[0] * H;
+          const int sp = (num_inside & ~127) + 128;
+          const int scaled = int(roundf((px1 - px0) * float(sp)));
+          if (scaled != sp) filter = (px0 < px1 && px1 - px0 <= 1.0f) ? 2 : (scaled == sp * 2 ? 4 : 1);
+          else if ((int(px0 * 4.0f + 0.5f) & 3) != 2 || (int(py0 * 4.0f + 0.5f) & 3) != 2) filter = 3;
+          else filter = 0;
+        }
+      }
+      // a run with u clamped to the nine-patch's stretched middle column and v not moving along the row samples one texel
+      // position: every pixel of it gets what its first pixel gets (WrBoxRow::xc)
+      const bool one_value = !centre && xcl && num_inside >= 8 && rv.s[1] == 0.0f;
+      const int end = wr_imin(pos + num_inside, span);
+      // pixel j of the run, sampled like swgl_commitTextureLinear(R8, sColor0, uv, uv_bounds, NoColor/InvertColor, num_inside)
+      auto run_pixel = [&](int j) -> uint32_t {
+        int v;
+        if (filter == 0) {
+          // blendTextureNearestFast (swgl_ext.h:475-537)
+          const int ix = int(pu[0] * W), iy = int(pv[0] * H);
+          const int minUx = int(ub0 * W), minUy = int(ub1 * H), maxUx = int(ub2 * W), maxUy = int(ub3 * H);
+          const int srow = wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), t.height);
+          const int minX = wr_iclamp(minUx, 0, t.width - 1), maxX = wr_iclamp(maxUx, minX, t.width - 1);
+          v = ((const uint8_t*)t.ptr)[(size_t)srow * t.stride + wr_iclamp(ix + j, minX, maxX)];
+        } else {
+          const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+          float q[4], qy[4];
+#pragma unroll
+          for (int a = 0; a < 4; a++) { q[a] = pu[a] * W * qs + qo; qy[a] = pv[a] * H * qs + qo; }
+          const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
+          const float minx = wr_max(ub0 * W * qs + qo, 0.0f), miny = wr_max(ub1 * H * qs + qo, 0.0f);
+          const float maxx = wr_max(ub2 * W * qs + qo, minx), maxy = wr_max(ub3 * H * qs + qo, miny);
+          int o[4];
+          wr_linear_span_pixel<1>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, filter, num_inside, j, o);
+          v = o[0];
+        }
+        if (mode != 0.0f) v = 255 - v;               // applyColor(src, InvertColor)
+        return uint32_t(v) & 0xFFFF;
+      };
+      if (centre) {
+        // centre sector: one texel for the whole run (pattern of the 4 lanes repeated; a lane's pixels are 64 apart)
+        const int l4 = (pos + lane) & 3;
+        const float texel = wr_r8_texture(t, wr_clamp(wr_sel4(pu[0], pu[1], pu[2], pu[3], l4), ub0, ub2),
+                                          wr_clamp(wr_sel4(pv[0], pv[1], pv[2], pv[3], l4), ub1, ub3));
+        wr_fill_lanes(dst, pos, end, uint32_t(wr_round_pixel(((1.0f - texel) - texel) * mode + texel)) & 0xFFFF, lane);
+      } else if (one_value) {
+        wr_fill_lanes(dst, pos, end, run_pixel(0), lane);
+      } else {
+        for (int n = pos + lane; n < end; n += 64) dst[n] = (uint8_t)run_pixel(n - pos);
+      }
+      const float f = float(num_inside / 4);
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
+      }
+      R -= num_inside; pos += num_inside;
+    }
+  }
+  wr_fill_lanes(dst, pos, span, v_clear, lane);      // solid lead-out
+}
+// cs_clip_rectangle (cs_clip_rectangle.glsl:223-420): the row's five phases are closed forms of the chunk index, so the lanes
+// take a chunk each; a chunk in a solid phase is a constant
+WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int y, int lane, uint8_t* dst) {
+  const WrPrim& P = *Pp;
+  const WrRowVals rv = wr_clip_row_vals(P, y);
+  const WrClipRow cr = wr_clip_row_setup(P, *Cp, rv);
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  const int b1 = cr.n12 & 0xFFFF, b2 = b1 + (cr.n12 >> 16), b3 = b2 + (cr.n34 & 0xFFFF), b4 = b3 + (cr.n34 >> 16);
+  const float mode = Cp->mode;
+  for (int c = lane; 4 * c < len; c += 64) {
+    const int n = 4 * c;
+    const int k = c < b1 ? 0 : (c < b2 ? 1 : (c < b3 ? 2 : (c < b4 ? 3 : 0)));
+    WrRow4 r4;
+    if (n + 3 < span && (k == 0 || k == 2) && Cp->w > 0.0f) {
+      const uint32_t v = uint32_t(wr_round_pixel(k == 0 ? mode : 1.0f - mode)) & 0xFFFF;
+      r4.v[0] = r4.v[1] = r4.v[2] = r4.v[3] = v;
+    } else {
+      r4 = wr_clip_rect_row4(Pp, Cp, rv, cr, P.x0 + n, y);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (n + i < len) dst[n + i] = (uint8_t)r4.v[i];
+  }
+}
+__global__ void __launch_bounds__(256) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
+                                                           const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
+                                                           const unsigned long long* __restrict__ ctl,
+                                                           const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
+  const unsigned long long a = *ctl;
+  const int ns = int(a >> 48), rows_total = int((a >> 28) & 0xFFFFFull);
+  const int lane = threadIdx.x & 63;
+  const int nwaves = int((gridDim.x * blockDim.x) >> 6);
+#ifdef WRHIP_HOSTSIM
+  const int gw = int((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+#else
+  // the wave index is wave-uniform: say so, and everything below (slot, prim, row) is read through the scalar cache
+  const int gw = __builtin_amdgcn_readfirstlane(int((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  // the first 64 slots, one per lane, requested together with the allocation word: a launch of a few hundred rows is one
+  // dependent-load chain per wave, every level of it a cold miss
+  WrMaskSlot mine;
+  mine.prim = mine.target = 0; mine.row0 = 0xFFFFFFFFu; mine.pitch = mine.off16 = 0;
+  if (lane < ns) mine = slots[lane];
+#endif
+  for (int item = gw; item < rows_total; item += nwaves) {
+    WrMaskSlot sl;
+#ifndef WRHIP_HOSTSIM
+    const unsigned long long le = __ballot(lane < ns && (int)mine.row0 <= item);
+    if (ns <= 64 || !(le >> 63)) {
+      const int idx = 63 - __builtin_clzll(le | 1ull);
+      sl.prim = __builtin_amdgcn_readlane(mine.prim, idx); sl.target = __builtin_amdgcn_readlane(mine.target, idx);
+      sl.row0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.row0, idx); sl.pitch = (uint32_t)__builtin_amdgcn_readlane((int)mine.pitch, idx);
+      sl.off16 = (uint32_t)__builtin_amdgcn_readlane((int)mine.off16, idx);
+    } else
+#endif
+    {
+      int lo = 0, hi = ns - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)slots[mid].row0 <= item) lo = mid; else hi = mid - 1;
+      }
+      sl = slots[lo];
+    }
+    const WrTargetDesc& T = targets[sl.target];
+    if (T.first_bin < bin_lo || T.first_bin >= bin_hi) continue;
+    const WrPrim* Pp = &prims[sl.prim];
+    const int y = Pp->y0 + (item - (int)sl.row0);
+    if (y < T.y_begin || y >= T.y_end) continue;      // rows of another rank
+    uint8_t* dst = store + (size_t)sl.off16 * 16 + (size_t)(y - Pp->y0) * sl.pitch + (Pp->x0 & 3);
+    if (Pp->kind == WR_PK_BOX_SHADOW) wr_box_shadow_row_lanes(*Pp, aux[sl.prim].box, y, lane, dst);
+    else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst);
+  }
+}
+
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
 WR_DEVICE uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
 #ifdef WRHIP_HOSTSIM
@@ -4333,6 +4599,24 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
 #pragma unroll
   for (int j = 0; j < R; j++) cy[j] = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
 
+  if ((FEAT & WR_FEAT_BLUR) && FMT == WR_FMT_R8 && kind == WR_PK_MASK_ROWS) {
+    // a cs_clip_* prim whose rows wr_mask_rows_kernel has evaluated: blend the stored bytes (c0/c1: address of the prim's
+    // first row at column x0 & ~3, z: pitch)
+    const uint8_t* base = (const uint8_t*)(((unsigned long long)c1 << 32) | c0);
+    const bool anyx = cx[0] || cx[1] || cx[2] || cx[3];
+    const int col = px - (x0 & ~3);
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      if (!cy[j] || !anyx) continue;
+      const uint32_t v = *(const uint32_t*)(base + (size_t)(py + 4 * j - y0) * z + col);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        if (cx[i]) plo[q] = wr_blend_r8(blend, plo[q], (v >> (8 * i)) & 0xFF);
+      }
+    }
+    return;
+  }
   if (kind == WR_PK_CLEAR) {
 #pragma unroll
     for (int q = 0; q < NPX; q++) {

@@ -124,6 +124,8 @@ enum WrDrawFlags {
   WR_DF_CLEAR_DEPTH = 16,
   WR_DF_QUADS = 64,        // host: this draw may hold textured prims on general (rotated) quads or with swgl_antiAlias;
                            // its launch carries WR_FEAT_SHADE, where WR_PK_TEX_QUAD lives
+  WR_DF_MASK_ROWS = 128,   // host: the cs_clip_* prims of this draw may be pre-evaluated row by row (wr_mask_rows_kernel) into the
+                           // flush's mask-row store; the raster stage then only blends the stored bytes (WR_PK_MASK_ROWS)
   WR_DF_SIMPLE = 32,       // host promise: every prim of this draw is a solid with blend NONE/PREMULT (see WrFeat)
 };
 
@@ -182,7 +184,32 @@ struct WrTargetDesc {
   int32_t dw_first, dw_end;      // global prim range spanned by this target's depth-writing draws (dw_end <= dw_first: none).
                                  // A depth-tested prim that consumes interpolants looks there for what hides parts of its rows
                                  // (draw_depth_span's sub-spans, rasterize.h:612-664)
+  // Mask-row store of the flush (R8 targets holding cs_clip_* draws, see WrMaskSlot); nullptr: none
+  unsigned long long* mr_ctl;    // allocation word: slots << 48 | rows << 28 | bytes / 16
+  struct WrMaskSlot* mr_slots;
+  uint8_t* mr_store;
+  uint32_t mr_cap16;             // capacity of mr_store in 16-byte units (< 2^28)
+  uint32_t mr_max_slots;         // capacity of mr_slots (< 2^16)
 };
+
+// Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
+// short evaluated ones; the span shaders' state machines are per row, not per pixel.  Inside the bin raster every wave of
+// every bin the prim touches would replay a row's state machine up to its own 64 pixels.  Instead the setup stage reserves
+// (y1 - y0) rows of pitch bytes in the flush's mask-row store for such a prim, wr_mask_rows_kernel evaluates each (prim, row)
+// ONCE with one wave -- the walk along the row is wave-uniform, the lanes share out the pixels of every run -- and the raster
+// stage blends the stored bytes like a 1:1 texture (WR_PK_MASK_ROWS: WrRec::c0/c1 = address of the prim's first stored row at
+// column x0 & ~3, WrRec::z = pitch).
+struct WrMaskSlot {
+  int32_t prim;                  // global prim index
+  int32_t target;                // its target (the rows kernel of a raster launch only evaluates that launch's targets)
+  uint32_t row0;                 // first work row of this prim in the flush-wide row numbering
+  uint32_t pitch;                // bytes per stored row (multiple of 4)
+  uint32_t off16;                // first stored row, in 16-byte units into mr_store
+  uint32_t pad[3];
+};
+#define WR_MR_MAX_SLOTS 65535u
+#define WR_MR_MAX_ROWS 1048575u
+#define WR_MR_MAX_CAP16 268435455u
 
 enum WrPrimKind {
   WR_PK_NONE = 0,       // culled / nothing to draw
@@ -205,6 +232,7 @@ enum WrPrimKind {
   WR_PK_TEX_QUAD,       // a textured prim (WrQuadRec::base_kind) on a general convex quad and / or with swgl_antiAlias: per-row spans and
                         // edge interpolants from WrQuadRec, then the base kind's span / main() evaluation
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
+  WR_PK_MASK_ROWS,      // WrRec only: a WR_PK_BOX_SHADOW / WR_PK_CLIP_RECT prim whose rows wr_mask_rows_kernel has evaluated (WrMaskSlot)
 };
 
 enum WrPrimFlags {
