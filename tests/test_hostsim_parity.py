@@ -264,3 +264,35 @@ def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
     for i, (g, m) in enumerate(zip(got, makes)):
         want, _ = render_direct(oracle_gcc, m())
         assert np.array_equal(g[..., [2, 1, 0, 3]], want), f"frame {i}"
+
+
+def test_texture_allocation_failure_is_sticky_out_of_memory(hostsim, monkeypatch):
+    """HBM exhaustion while allocating texture storage raises the sticky GL_OUT_OF_MEMORY swgl raises (gl.cc:1125-1134;
+    Renderer counts consecutive ones, renderer/mod.rs:1296-1303) instead of aborting; the texture stays unusable, draws to
+    it are dropped, and the context keeps working."""
+    from webrender_amd import glapi, glconst as G
+    monkeypatch.setenv("WRHIP_HOSTSIM_ALLOC_LIMIT", str(64 << 20))     # the test library refuses larger single allocations
+    gl = glapi.GL(hostsim)
+    ctx = gl.CreateContext()
+    gl.MakeCurrent(ctx)
+    big, small = gl.gen("GenTextures"), gl.gen("GenTextures")
+    gl.BindTexture(G.GL_TEXTURE_2D, big)
+    gl.TexStorage2D(G.GL_TEXTURE_2D, 1, G.GL_RGBA8, 8192, 8192)          # 256 MiB: refused
+    assert gl.GetError() == G.GL_OUT_OF_MEMORY
+    assert gl.GetError() == 0                                            # reading it clears it
+    fbo = gl.gen("GenFramebuffers")
+    gl.BindFramebuffer(G.GL_DRAW_FRAMEBUFFER, fbo)
+    gl.FramebufferTexture2D(G.GL_DRAW_FRAMEBUFFER, G.GL_COLOR_ATTACHMENT0, G.GL_TEXTURE_2D, big, 0)
+    gl.ClearColor(1.0, 0.0, 0.0, 1.0)
+    gl.Clear(G.GL_COLOR_BUFFER_BIT)                                      # nothing to clear: must not fault
+    gl.Finish()
+    gl.BindTexture(G.GL_TEXTURE_2D, small)
+    gl.TexStorage2D(G.GL_TEXTURE_2D, 1, G.GL_RGBA8, 64, 64)
+    assert gl.GetError() == 0
+    gl.FramebufferTexture2D(G.GL_DRAW_FRAMEBUFFER, G.GL_COLOR_ATTACHMENT0, G.GL_TEXTURE_2D, small, 0)
+    gl.BindFramebuffer(G.GL_READ_FRAMEBUFFER, fbo)
+    gl.Clear(G.GL_COLOR_BUFFER_BIT)
+    px = np.zeros((64, 64, 4), np.uint8)
+    gl.ReadPixels(0, 0, 64, 64, G.GL_RGBA, G.GL_UNSIGNED_BYTE, px)
+    assert (px[..., 0] == 255).all() and (px[..., 3] == 255).all()
+    gl.DestroyContext(ctx)

@@ -49,3 +49,26 @@ def test_raster_kernel_vgpr_budget(tmp_path, feat, depth, max_vgpr):
         body = body[:body.index(".Lfunc_end")]
         # the in-place loop: no register-file copies of the pixel state at the loop back-edge
         assert body.count("v_mov_b64") < 80
+
+
+FUSED_SRC = SRC.split("template __global__")[0] + '''
+template __global__ void wr_setup_raster_kernel<WR_FMT_RGBA8, KDEPTH, 4, KFEAT>(WrSetupArgs, int, const WrTargetDesc*, int, const WrDrawDesc*,
+    const WrPrim*, const WrRec*, const WrAux*, const float*, unsigned long long*, int);
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("feat,depth,max_vgpr", [(0, 0, 128), (0, 1, 128), (5, 0, 168), (7, 0, 168)])
+def test_fused_setup_raster_kernel_vgpr_budget(tmp_path, feat, depth, max_vgpr):
+    """The fused setup + raster variants (the tile pass of a frame carries the next frame's setup stage) run the raster
+    body at the occupancy the setup stage's registers leave: 4 waves per SIMD for the rect-only ones (the setup stage
+    needs ~110 VGPRs), 3 for the textured ones -- the same steps as the plain variants."""
+    src = tmp_path / "fused.hip"
+    src.write_text(FUSED_SRC)
+    out = tmp_path / "fused.s"
+    subprocess.check_call([HIPCC] + FLAGS + [f"-DKFEAT={feat}", f"-DKDEPTH={'true' if depth else 'false'}", "-I", CSRC, str(src), "-o", str(out)])
+    asm = out.read_text()
+    m = re.search(r"\.amdhsa_kernel _Z22wr_setup_raster_kernelILi3ELb%dELi4ELi%dE.*?\.end_amdhsa_kernel" % (depth, feat), asm, re.S)
+    assert m, "kernel not found in the assembly"
+    vgpr = int(re.search(r"next_free_vgpr (\d+)", m.group(0)).group(1))
+    assert vgpr <= max_vgpr, f"fused FEAT={feat}: {vgpr} VGPRs > {max_vgpr}: the kernel lost a wave per SIMD"

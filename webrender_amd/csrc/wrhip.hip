@@ -566,7 +566,16 @@ void* pool_alloc(size_t n, size_t* actual) {
     return p;
   }
   *actual = r;
-  return wrrt::dev_alloc(r + 64);
+  void* p = wrrt::try_dev_alloc(r + 64);
+  if (!p && !c->pool.empty()) {
+    // HBM exhausted: give the idle pool back and try once more before reporting GL_OUT_OF_MEMORY
+    sync_stream();
+    for (auto& kv : c->pool) wrrt::dev_free(kv.second);
+    c->pool.clear(); c->pool_bytes = 0;
+    p = wrrt::try_dev_alloc(r + 64);
+  }
+  if (!p) *actual = 0;
+  return p;
 }
 void pool_free(void* p, size_t n) {
   Context* c = ctx;

@@ -50,6 +50,7 @@ typedef struct { double t; } wr_event_t;
 namespace wrrt {
 static inline bool init(int*, char* name, size_t n) { snprintf(name, n, "hostsim (CPU, tests only)"); return true; }
 static inline void* dev_alloc(size_t n) { return calloc(1, n ? n : 1); }
+static inline void* try_dev_alloc(size_t n) { const char* lim = getenv("WRHIP_HOSTSIM_ALLOC_LIMIT"); if (lim && n > (size_t)atoll(lim)) return nullptr; return calloc(1, n ? n : 1); }
 static inline void dev_free(void* p) { free(p); }
 static inline void* pinned_alloc(size_t n) { return malloc(n ? n : 1); }
 static inline void pinned_free(void* p) { free(p); }
@@ -105,6 +106,16 @@ static inline bool init(int* device, char* name, size_t n) {
   return true;
 }
 static inline void* dev_alloc(size_t n) { void* p = nullptr; WR_HIP_CHECK(hipMalloc(&p, n ? n : 16)); return p; }
+// storage a caller can be refused (textures, buffers): nullptr when HBM is exhausted -- the state tracker turns that into the
+// sticky GL_OUT_OF_MEMORY swgl raises (gl.cc:1125-1134) instead of taking the process down
+static inline void* try_dev_alloc(size_t n) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, n ? n : 16);
+  if (e == hipSuccess) return p;
+  (void)hipGetLastError();
+  if (e != hipErrorOutOfMemory) { fprintf(stderr, "libwrhip: hipMalloc(%zu) failed: %s\n", n, hipGetErrorString(e)); abort(); }
+  return nullptr;
+}
 static inline void dev_free(void* p) { if (p) WR_HIP_CHECK(hipFree(p)); }
 static inline void* pinned_alloc(size_t n) { void* p = nullptr; WR_HIP_CHECK(hipHostMalloc(&p, n ? n : 16, hipHostMallocDefault)); return p; }
 static inline void pinned_free(void* p) { if (p) WR_HIP_CHECK(hipHostFree(p)); }
