@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from parity_cases import OCCLUDED, OCCLUDED_GOLDEN, BLEND, BLEND_GOLDEN
+from parity_cases import OCCLUDED, OCCLUDED_GOLDEN, BLEND, BLEND_GOLDEN, ROTATED, ROTATED_GOLDEN
 
 LIB = os.path.join(ROOT, "oracle", "_ref", "libswgl_ref_gcc.so")
 
@@ -60,8 +60,8 @@ def main():
     out["scaled_composites"] = digest(render_direct(LIB, scenes.scaled_composites())[0])
     out["masked_rects"] = digest(render_direct(LIB, scenes.masked_rects())[0])
     out["masked_rects_frac"] = digest(render_direct(LIB, scenes.masked_rects(fractional=True))[0])
-    for name, make in OCCLUDED + BLEND:
-        if name in OCCLUDED_GOLDEN + BLEND_GOLDEN:
+    for name, make in OCCLUDED + BLEND + ROTATED:
+        if name in OCCLUDED_GOLDEN + BLEND_GOLDEN + ROTATED_GOLDEN:
             out[name] = digest(render_direct(LIB, make())[0])
     for name, kw in (("blur_r8", dict(fmt="r8")), ("blur_rgba8", dict(fmt="rgba8")),
                      ("blur_r8_sigmas", dict(fmt="r8", content=(40, 30), sigma=[0.8, 1.7, 3.2, 4.0], n_tasks=12, origin=(0, 0))),

@@ -49,3 +49,20 @@ BLEND = [
     ("blend_modes_occluded", lambda: scenes.add_occluders(scenes.blend_modes(seed=114), zmax=300, seed=31)),
 ]
 BLEND_GOLDEN = ("blend_modes", "blend_modes_wide")
+
+
+# Shader replays on general quads: gradients, brush_blend / brush_opacity filters and ps_quad_mask clips
+# under rotations and skews -- per-row spans and edge interpolants from the quad walk, swgl_antiAlias edges, the base
+# shader's span / main() evaluation on each row -- with and without occluders (depth runs) and clip masks.  0 differing bytes.
+ROTATED = [
+    ("rotated_gradients", lambda: scenes.gradient_grid(rotate=True, seed=66)),
+    ("rotated_filters", lambda: scenes.filter_grid(rotate=True, seed=76, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11])),
+    ("rotated_filters_masked", lambda: scenes.filter_grid(rotate=True, masked=True, seed=77, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11])),
+    ("rotated_opacity", lambda: scenes.filter_grid(rotate=True, shader="opacity", seed=78)),
+    ("rotated_quad_masks", lambda: scenes.quad_masks(rotate=True, seed=86)),
+    ("occluded_rotated_gradients", lambda: scenes.add_occluders(scenes.gradient_grid(rotate=True, seed=67), zmax=80, seed=32)),
+    ("occluded_rotated_filters", lambda: scenes.add_occluders(scenes.filter_grid(rotate=True, seed=79, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]), zmax=72, seed=33)),
+    ("occluded_quad_masks", lambda: scenes.add_occluders(scenes.quad_masks(seed=88), zmax=80, seed=35)),
+    ("occluded_rotated_quad_masks", lambda: scenes.add_occluders(scenes.quad_masks(rotate=True, seed=87), zmax=80, seed=34)),
+]
+ROTATED_GOLDEN = ("rotated_gradients", "rotated_filters", "rotated_quad_masks")

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND
+from parity_cases import OCCLUDED, BLEND, ROTATED
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -193,7 +193,7 @@ def test_hip_cfg4_box_shadow_chain(name, kw):
     assert digest(got["window"]) == GOLDEN[name] or ref
 
 
-@pytest.mark.parametrize("name,make", SMALL + OCCLUDED + BLEND, ids=[c[0] for c in SMALL + OCCLUDED + BLEND])
+@pytest.mark.parametrize("name,make", SMALL + OCCLUDED + BLEND + ROTATED, ids=[c[0] for c in SMALL + OCCLUDED + BLEND + ROTATED])
 def test_hip_matches_oracle_small(name, make):
     got, stats = render_direct(wrhip_lib(), make())
     assert stats["raster_launches"] >= 1

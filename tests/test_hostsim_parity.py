@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND
+from parity_cases import OCCLUDED, BLEND, ROTATED
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -173,7 +173,7 @@ def test_hostsim_cfg4_box_shadow_chain(hostsim, oracle_gcc):
     assert digest(got["window"]) == GOLDEN["cfg4_small"]
 
 
-@pytest.mark.parametrize("name,make", CASES + OCCLUDED + BLEND, ids=[c[0] for c in CASES + OCCLUDED + BLEND])
+@pytest.mark.parametrize("name,make", CASES + OCCLUDED + BLEND + ROTATED, ids=[c[0] for c in CASES + OCCLUDED + BLEND + ROTATED])
 def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     want, _ = render_direct(oracle_gcc, make())
     got, stats = render_direct(hostsim, make())

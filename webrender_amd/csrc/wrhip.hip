@@ -2271,8 +2271,11 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     // transform ids in the bound header texture and the AA requests in the instances say whether this draw can hold any
     const bool img = info->kind == WR_SH_BRUSH_IMAGE || info->kind == WR_SH_BRUSH_IMAGE_ALPHA ||
                      info->kind == WR_SH_BRUSH_OPACITY || info->kind == WR_SH_BRUSH_OPACITY_ALPHA ||
-                     info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA;
-    const bool texquad = info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2;
+                     info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA ||
+                     info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
+                     info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA;
+    const bool texquad = (info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2) ||
+                         info->kind == WR_SH_PS_QUAD_MASK || info->kind == WR_SH_PS_QUAD_MASK_FAST;
     const bool solid_masked = (info->kind == WR_SH_BRUSH_SOLID || info->kind == WR_SH_BRUSH_SOLID_ALPHA) && maskable;
     if (colortex.internal_format == GL_RGBA8 && (img || texquad || solid_masked)) {
       bool quads = !ids_clean(texquad ? WR_S_GPU_BUFFER_I : WR_S_PRIM_HEADERS_I, !texquad);

@@ -1388,7 +1388,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   // textured kinds that can ride on WrQuadRec (general quads, swgl_antiAlias) when the host gave the launch the path for it
   const bool texq = (d.flags & WR_DF_QUADS) &&
                     (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT ||
-                     (o.kind == WR_PK_SOLID && masked));
+                     o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked));
   if (aa && (o.kind != WR_PK_SOLID || masked) && !texq) {      // AA on masked solids / other shader families: "next"
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
@@ -1401,8 +1401,12 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     if (!solidq && !texq) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
     }
-    WrRepeatRec rep;
-    if (o.kind == WR_PK_TEX_REPEAT) rep = auxp->rep;          // the vertex stage left it in the (shared) side record
+    // the base kind's side record: the vertex stage left it in the (shared) WrAux slot the quad record is about to take
+    union { WrRepeatRec rep; WrGradRec grad; WrFilterRec filt; WrClipRec clip; } base;
+    if (o.kind == WR_PK_TEX_REPEAT) base.rep = auxp->rep;
+    else if (o.kind == WR_PK_GRADIENT) base.grad = auxp->grad;
+    else if (o.kind == WR_PK_FILTER) base.filt = auxp->filt;
+    else if (o.kind == WR_PK_QUAD_MASK) base.clip = auxp->clip;
     int bx0, by0, bx1, by1;
     if (!wr_quad_walk(sx, sy, o.u, o.v, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1)) return;
     P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
@@ -1416,7 +1420,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     P.kind = WR_PK_TEX_QUAD;
     auxp->quad.base_kind = o.kind == WR_PK_SOLID ? (int)WR_PK_SOLID_MASKED : o.kind;
     if (o.kind == WR_PK_SOLID) wr_pack_color(o.color, P.color);
-    if (o.kind == WR_PK_TEX_REPEAT) auxp->quad.rep = rep;
+    if (o.kind == WR_PK_TEX_REPEAT) auxp->quad.rep = base.rep;
+    else if (o.kind == WR_PK_GRADIENT) auxp->quad.grad = base.grad;
+    else if (o.kind == WR_PK_FILTER) auxp->quad.filt = base.filt;
+    else if (o.kind == WR_PK_QUAD_MASK) auxp->quad.clip = base.clip;
     if (masked) P.flags |= WR_PF_MASKED;
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
@@ -2969,6 +2976,10 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
   return wr_blend_rgba8(P.blend, dstp, src, D, P.color);
 }
 
+struct WrGrad4 { WrWide v[4]; };
+__device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradRec* Gp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+__device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+__device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 // One pixel of a textured prim on a general quad and / or with swgl_antiAlias (WR_PK_TEX_QUAD): this row's span and the
 // pixel's coverage as in wr_quad_pixel_rgba8, the edge interpolants stepped row by row (Edge::nextRow), then the base
 // kind's span shader / main() evaluation of pixel x - span.start, DO_AA ahead of the clip mask (blend.h:452-460).
@@ -2985,6 +2996,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
   const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
   int s0, s1;
   uint32_t cov = 256;
+  bool aa_skip = false;
   if (!Q.aa) {
     s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
     if (x < s0 || x >= s1) return dstp;
@@ -3004,6 +3016,10 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     const float dl = (lstart + float(la1 + lane) * lend) + (lend / 4.0f) * off;
     const float dr = (rstart + float(la1 + lane) * rend) + (rend / 4.0f) * off;
     cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
+    // chunks inside the opaque interior skip DO_AA altogether (aa_span's swgl_OpaqueStart / swgl_OpaqueSize, rasterize.h:545-546;
+    // blend.h:433-436) -- not the same as multiplying by 256 when a main() output lane exceeds 255 (brush_blend, amount > 1)
+    const int ra0 = S.rmask ? int(floorf(wr_clamp(xr - radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+    aa_skip = (unsigned)(base - la1) < (unsigned)wr_imax(ra0 - la1 - 3, 0);
     s0 = la0; s1 = ra1;
   }
   if (runs) {        // the span the shader sees is the depth run holding x
@@ -3028,7 +3044,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
       WrWide mm; mm.bg = mm.ra = m | (m << 16);
       src = wr_apply_color(mm, Pl.color);
     }
-    if (Q.aa) {
+    if (Q.aa && !aa_skip) {
       const uint32_t c0 = src.bg, c1 = src.ra;
       src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
       src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
@@ -3036,9 +3052,21 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     if (!in_span) src = wr_mask_src(Pl, D, x, y, src);
     return HIT | wr_blend_rgba8(Pl.blend, dstp_, src, D);
   }
-  const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0, runs, x, Q.base_kind == WR_PK_TEX_REPEAT && Q.rep.no_span != 0);
-  WrWide src = Q.base_kind == WR_PK_TEX_REPEAT ? wr_repeat_pixel_row(Pl, Q.rep, t, r, x - r.x0) : wr_tex_pixel_row(Pl, t, r, x - r.x0);
-  if (Q.aa) {
+  WrWide src;
+  if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {
+    // shader replays that take their interpolants from the prim: hand them this row as a one-row axis-aligned prim (the span
+    // [s0, s1), the edges' x and interpolants on this row, no row stepping left to do)
+    Pl.uvL0[0] = Lu; Pl.uvL0[1] = Lv; Pl.uvR0[0] = Ru; Pl.uvR0[1] = Rv;
+    Pl.uvLs[0] = Pl.uvLs[1] = Pl.uvRs[0] = Pl.uvRs[1] = 0.0f;
+    Pl.xl = xl; Pl.xr = xr; Pl.x0 = s0; Pl.x1 = s1; Pl.y0 = y; Pl.y1 = y + 1; Pl.rows_linear = 1;
+    if (Q.base_kind == WR_PK_GRADIENT) src = wr_gradient_row4(&Pl, &Q.grad, D, x, y, runs).v[0];
+    else if (Q.base_kind == WR_PK_FILTER) src = wr_filter_pixel(&Pl, &Q.filt, D, x, y, runs);
+    else src = wr_quad_mask_pixel(&Pl, &Q.clip, D, x, y, runs);
+  } else {
+    const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0, runs, x, Q.base_kind == WR_PK_TEX_REPEAT && Q.rep.no_span != 0);
+    src = Q.base_kind == WR_PK_TEX_REPEAT ? wr_repeat_pixel_row(Pl, Q.rep, t, r, x - r.x0) : wr_tex_pixel_row(Pl, t, r, x - r.x0);
+  }
+  if (Q.aa && !aa_skip) {
     const uint32_t c0 = src.bg, c1 = src.ra;
     src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
     src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
@@ -3061,8 +3089,6 @@ __device__ __noinline__ uint32_t wr_tex_pixel_r(const WrPrim* Pp, const WrDrawDe
 //   the rest    fragment shader: sample_gradient(dot(fract(v_pos), v_scale_dir) - v_start_offset)
 //               (brush_linear_gradient.glsl:66-83, gradient.glsl:42-61), also for every pixel when
 //               the table fails swgl_validateGradient or the per-chunk delta is not finite.
-struct WrGrad4 { WrWide v[4]; };
-
 WR_DEVICE bool wr_stops_merge(const float* stops, int a, int b) {   // GradientStops::can_merge
   const float* sa = stops + 8 * a + 4; const float* sb = stops + 8 * b + 4;
   return sa[0] == sb[0] && sa[1] == sb[1] && sa[2] == sb[2] && sa[3] == sb[3];
@@ -3566,11 +3592,11 @@ WR_DEVICE float wr_step01(float edge, float x) { return x >= edge ? 1.0f : 0.0f;
 
 // ps_quad_mask fragment (ps_quad.glsl:399-415, ps_quad_mask.glsl:167-200): one pixel of main(), which
 // runs four pixels at a time -- fwidth() of the chunk is |lane1 - lane0| in x plus in y (glsl.h:765-768).
-__device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y) {
+__device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
   const WrPrim& P = *Pp;
   const WrClipRec& C = *Cp;
-  const WrTexRow r = wr_tex_row(P, D->tex[0], y);            // span == 0 for this kind: interpolants only
-  const int n = x - P.x0, n0 = n & ~3;
+  const WrTexRow r = wr_tex_row(P, D->tex[0], y, runs, x);   // span == 0 for this kind: interpolants only (of the depth run holding x)
+  const int n = x - r.x0, n0 = n & ~3;
   float f0x, f0y, f1x, f1y, qx, qy;
   wr_tex_tail_uv(P, r, n0, f0x, f0y);
   wr_tex_tail_uv(P, r, n0 + 1, f1x, f1y);
@@ -4392,7 +4418,7 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 // The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
 // nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
 WR_DEVICE bool wr_kind_needs_runs(int kind) {
-  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER ||
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK ||
          kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
 }
 // interval of prim `ci` (a depth writer) on row y
@@ -4878,7 +4904,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (dwrite) dep[q] = in ? z : dep[q];
       }
       if (!in) continue;
-      const WrWide src = wr_quad_mask_pixel(Pp, &Ap->clip, D, px + (q & 3), py + 4 * (q >> 2));
+      const WrWide src = wr_quad_mask_pixel(Pp, &Ap->clip, D, px + (q & 3), py + 4 * (q >> 2), rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }

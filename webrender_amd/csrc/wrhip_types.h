@@ -403,10 +403,15 @@ struct WrRepeatRec {
 struct WrQuadRec {
   int32_t nseg;
   int32_t aa;                       // SWGL_CLIP_FLAG_AA set for this prim
-  int32_t base_kind;                // WR_PK_TEX_QUAD: WR_PK_TEX_RGBA8 / TEX_FS / TEX_R8 / TEX_REPEAT
+  int32_t base_kind;                // WR_PK_TEX_QUAD: WR_PK_TEX_RGBA8 / TEX_FS / TEX_R8 / TEX_REPEAT / GRADIENT / FILTER / QUAD_MASK
   int32_t pad;
   WrQuadSeg seg[4];
-  WrRepeatRec rep;                  // base_kind == WR_PK_TEX_REPEAT
+  union {                           // the base kind's own side record (the quad record took its place in WrAux)
+    WrRepeatRec rep;                // WR_PK_TEX_REPEAT
+    WrGradRec grad;                 // WR_PK_GRADIENT
+    WrFilterRec filt;               // WR_PK_FILTER
+    WrClipRec clip;                 // WR_PK_QUAD_MASK
+  };
 };
 
 // Depth runs of one target row of one prim (draw_depth_span, rasterize.h:612-664): with depth testing on, swgl hands the

@@ -1140,7 +1140,25 @@ def build_gradient_lut(stops, reverse=False):
     return entries.reshape(-1, 4)
 
 
-def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only=None, fractional=True):
+def rotation_about(frame, rng, cx, cy, i):
+    """A non-axis-aligned transform (rotation, every fourth one skewed as well) about (cx, cy) -> transform id."""
+    th = float(rng.uniform(0, 2 * np.pi)) if i % 6 else float(rng.choice([np.pi / 4, np.pi / 2, 0.01]))
+    sk = float(rng.uniform(-0.4, 0.4)) if i % 4 == 1 else 0.0
+    c, sn = np.cos(th), np.sin(th)
+    a = np.array([[c, -sn + sk * c], [sn, c + sk * sn]], np.float64)
+    m = np.eye(4)
+    m[:2, :2] = a
+    m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+    return frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
+
+
+def rotated_bounds(rect):
+    x0, y0, x1, y1 = rect
+    cx, cy, rad = (x0 + x1) / 2, (y0 + y1) / 2, float(np.hypot(x1 - x0, y1 - y0)) * 0.75 + 4
+    return (cx - rad, cy - rad, cx + rad, cy + rad)
+
+
+def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only=None, fractional=True, rotate=False):
     """Opaque-pass gradients on a disjoint grid in the top band (see image_grid on why),
     translucent / overlapping ones below it in the alpha pass."""
     rng = np.random.default_rng(seed)
@@ -1181,7 +1199,10 @@ def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only
         extend = 1 if (k % 3 == 1) else 0
         stretch = (w, h) if k % 5 else (max(w / 2.5, 8.0), max(h / 1.5, 8.0))      # tiled pattern
         spec = frame.gpu_cache.push([[sp[0], sp[1], ep[0], ep[1]], [float(extend), stretch[0], stretch[1], 0.0]])
-        prims.append((rect, spec, lut, opaque_pass))
+        tid, bb = 0, rect
+        if rotate and not opaque_pass and k % 3 != 2:       # alpha-pass gradients under a rotation / skew: spans on general quads, AA edges
+            tid, bb = rotation_about(frame, rng, (x0 + x1) / 2, (y0 + y1) / 2, k), rotated_bounds(rect)
+        prims.append((rect, spec, lut, opaque_pass, tid, bb))
 
     gx = 4.0
     k = 0
@@ -1208,13 +1229,13 @@ def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only
         target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
         task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
         op, al = [], []
-        for zi, (rect, spec, lut, opaque) in enumerate(prims):
+        for zi, (rect, spec, lut, opaque, tid, bb) in enumerate(prims):
             if only is not None and zi not in only:
                 continue
-            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
-            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, (lut, 0, 0, 0))
-            (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY))
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, tid, task, (lut, 0, 0, 0))
+            (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15) if tid else frame.brush_instance(ph, CLIP_TASK_EMPTY))
         if op:
             target.opaque.append(Step("brush_linear_gradient", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
                                       None, "opaque"))
@@ -1241,7 +1262,7 @@ CT_IDENTITY, CT_TABLE, CT_DISCRETE, CT_LINEAR, CT_GAMMA = 0, 1, 2, 3, 4
 
 
 def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=None, ops=None, only=None,
-                fractional=True, masked=False, shader="blend"):
+                fractional=True, masked=False, shader="blend", rotate=False):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -1340,11 +1361,16 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
             px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - 40))
         mode, ud = filter_params(k + 1000)
         prims.append(((px, py, px + w, py + h), addr, False, mode, ud))
+    tids = [0] * len(prims)
+    if rotate:       # alpha-pass filters under a rotation / skew
+        for k, pr in enumerate(prims):
+            if not pr[2] and k % 3 != 2:
+                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k)
     t_mask, clip_tasks = None, [None] * len(prims)
     if masked:
         t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
         frame.static_textures.append(t_mask)
-        clip_tasks = prim_clip_tasks(rng, [p[0] for p in prims], 1024, True)
+        clip_tasks = prim_clip_tasks(rng, [rotated_bounds(p[0]) if tids[k] else p[0] for k, p in enumerate(prims)], 1024, True)
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
@@ -1357,13 +1383,14 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
         for zi, (rect, addr, opaque, mode, ud) in enumerate(prims):
             if only is not None and zi not in only:
                 continue
-            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+            bb = rotated_bounds(rect) if tids[zi] else rect
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
             if shader == "opacity":     # brush_opacity: user data = (image source address, opacity * 65536)
                 opv = (65536, 49152, 20000, 70000, 1, 0, 32768)[zi % 7] if opaque is False else 65536
-                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (addr, opv, 0, 0))
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, tids[zi], task, (addr, opv, 0, 0))
             else:
-                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (addr, mode, ud, 0))
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, tids[zi], task, (addr, mode, ud, 0))
             ct = None if opaque else clip_tasks[zi]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
             (op if opaque else al).append(frame.brush_instance(ph, clip_addr, edge_flags=15))
@@ -1386,7 +1413,7 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
 # ps_quad_mask: rounded-rectangle clips applied to quads.  The quad pattern is drawn first
 # (ps_quad_textured, solid colour), then one MaskInstance per clip multiplies the same pixels by the
 # clip's coverage (renderer: set_blend_mode_multiply; quad.rs / gpu_types.rs:618-624).
-def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractional=True, only=None):
+def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractional=True, only=None, rotate=False):
     from .frame import QF_APPLY_DEVICE_CLIP
     QF_IS_MASK = 16
     rng, rects = random_rects(n, width, height, 48, 360, seed, fractional)
@@ -1412,12 +1439,19 @@ def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractio
             # radii_top = (tl.w, tl.h, tr.w, tr.h), radii_bottom = (bl.w, bl.h, br.w, br.h)
             addr = frame.gpu_buffer_f.push([list(cr), rad[0:4], rad[4:8], [mode, 0.0, 0.0, 0.0]])
             clips.append((addr, False))
+    tids = [0] * n
+    bounds = np.array(rects, np.float64)
+    if rotate:       # quads (and the clips that live in their space) under a rotation / skew
+        for i in range(n):
+            if i % 3 != 2:
+                tids[i] = rotation_about(frame, rng, (rects[i][0] + rects[i][2]) / 2, (rects[i][1] + rects[i][3]) / 2, i)
+                bounds[i] = rotated_bounds(tuple(float(v) for v in rects[i]))
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
             continue
         x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
-        hit = np.nonzero((rects[:, 0] < x1) & (rects[:, 2] > x0) & (rects[:, 1] < y1) & (rects[:, 3] > y0))[0]
+        hit = np.nonzero((bounds[:, 0] < x1) & (bounds[:, 2] > x0) & (bounds[:, 1] < y1) & (bounds[:, 3] > y0))[0]
         tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
         target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
         task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
@@ -1425,10 +1459,17 @@ def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractio
             if only is not None and i not in only:
                 continue
             big = (-BIG, -BIG, BIG, BIG)
-            q = frame.quad_instance(rects[i], big, colors[i], int(i + 1), task)
+            if tids[i]:
+                q = frame.quad_instance(rects[i], big, colors[i], int(i + 1), task, transform_id=tids[i], quad_flags=0, edge_flags=15)
+                m = frame.quad_instance(rects[i], big, (1.0, 1.0, 1.0, 1.0), int(i + 1), task, transform_id=tids[i],
+                                        quad_flags=QF_IS_MASK, edge_flags=15)
+            else:
+                q = frame.quad_instance(rects[i], big, colors[i], int(i + 1), task)
+                m = None
             target.alpha.append(Step("ps_quad_textured", "PRIM_INSTANCES", np.array([q], dtype=np.int32),
                                      "PremultipliedAlpha", "alpha", textures={}))
-            m = frame.quad_instance(rects[i], big, (1.0, 1.0, 1.0, 1.0), int(i + 1), task,
+            if m is None:
+                m = frame.quad_instance(rects[i], big, (1.0, 1.0, 1.0, 1.0), int(i + 1), task,
                                     quad_flags=QF_APPLY_DEVICE_CLIP | QF_IS_MASK)
             addr, fast = clips[i]
             inst = np.array([m + [0, addr, int(i % 4 == 1), 0]], dtype=np.int32)     # clip transform 0 (identity), address, space
