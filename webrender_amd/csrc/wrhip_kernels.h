@@ -5165,6 +5165,72 @@ WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], u
   }
 }
 
+// Unit glyph blits, lane by lane (device loop of wr_raster_body).  A glyph of a text run is ~10 x 15 pixels: of the 64 lanes of
+// a 64 x 16 strip it lights 12-16, and a strip of a text line holds a dozen glyphs side by side -- applied one prim at a time,
+// every one of them costs the whole wave its 16 pixels per lane.  Within a run of consecutive unit-glyph prims (every sample
+// exactly one atlas texel: WrTexRec::unit, blend NONE / PREMULT, no depth test) the order only matters per pixel, so each lane
+// walks its OWN list -- the prims of the run whose rect reaches its 4 x 4R footprint, in submission order -- and the wave is
+// done after max-over-lanes(list length) rounds instead of one round per prim.  Same arithmetic as wr_apply_tex_r8's unit path;
+// the prim's record and sampling setup are per-lane values here (vector loads from recs[] / aux[]).
+struct WrGlyphLoad { uint4 ra, rb, ta, tb; };      // WrRec (32 B) and the first 32 bytes of its WrTexRec
+WR_DEVICE WrGlyphLoad wr_unit_glyph_fetch(const WrRec* __restrict__ rec, const WrTexRec* __restrict__ Tp) {
+  WrGlyphLoad g;
+  g.ra = ((const uint4*)rec)[0]; g.rb = ((const uint4*)rec)[1];
+  g.ta = ((const uint4*)Tp)[0]; g.tb = ((const uint4*)Tp)[1];
+  return g;
+}
+template <int R>
+WR_DEVICE void wr_unit_glyph_lane(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], const WrGlyphLoad& g, const WrTexRec* __restrict__ Tp,
+                                  const int px, const int py) {
+  const int x0 = (int)g.ra.x, y0 = (int)g.ra.y, x1 = (int)g.ra.z, y1 = (int)g.ra.w;
+  const uint32_t kbf = g.rb.y, c0 = g.rb.z, c1 = g.rb.w;
+  const int blend = (kbf >> 8) & 0xFF;
+  const uint8_t* sbuf = (const uint8_t*)(((unsigned long long)g.ta.y << 32) | g.ta.x);
+  const int stride = (int)g.ta.z, span = (int)g.ta.w, ix0 = (int)g.tb.y, iy0 = (int)g.tb.z, ty0 = (int)g.tb.w;
+  const uint32_t clo = (c0 & 0xFFFF) | (c1 << 16), chi = (c0 >> 16) | (c1 & 0xFFFF0000u);
+  bool cx[4];
+  int colu[4]; bool tl[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
+    const int n = px + i - x0, k = n - span;
+    tl[i] = k >= 0;
+    colu[i] = ix0 + n;
+  }
+  if (px + 3 - x0 >= span) {             // (the <= 3 tail pixels of the row: their columns come from tix[])
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int k = px + i - x0 - span; if (k >= 0) colu[i] = k == 0 ? Tp->tix[0] : (k == 1 ? Tp->tix[1] : Tp->tix[2]); }
+  }
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    if (!((unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0))) continue;
+    const uint8_t* srow = sbuf + (size_t)(iy0 + (py + 4 * j - ty0)) * stride;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int q = 4 * j + i;
+      if (!cx[i]) continue;
+      const uint32_t um = srow[colu[i]];
+      if (!tl[i]) {
+        const uint32_t sl = wr_hi_bytes(wr_mul24(clo, um) + clo), sh = wr_hi_bytes(wr_mul24(chi, um) + chi);
+        uint32_t nl = sl, nh = sh;
+        if (blend == WR_BLEND_PREMULT) {
+          const uint32_t K = 255u - (sh >> 16);
+          nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
+          nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
+        }
+        plo[q] = nl; phi[q] = nh;
+      } else {
+        const float mf = float(um) * (1.0f / 255.0f);
+        uint32_t pc[2];
+        wr_pack_color(wf4{Tp->fcolor[0] * mf, Tp->fcolor[1] * mf, Tp->fcolor[2] * mf, Tp->fcolor[3] * mf}, pc);
+        WrWide src; src.bg = pc[0]; src.ra = pc[1];
+        const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, nullptr);
+        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+      }
+    }
+  }
+}
+
 // One workgroup per 64x64 bin; 64/(4R) waves of 64 lanes, each lane 4 x R pixels.
 template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_targets,
@@ -5288,6 +5354,15 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     const bool has = (m >> lane) & 1ull;
     const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);
     unsigned long long live = __ballot(hit);
+    // prims of this word that are unit glyph blits (lane i looks at prim i): runs of them are applied lane by lane
+    unsigned long long glyphs = 0ull;
+    if constexpr ((FEAT & WR_FEAT_R8TEX) != 0 && FMT == WR_FMT_RGBA8) {
+      const uint32_t k8 = rb.y & 0xFF, b8 = (rb.y >> 8) & 0xFF;
+      bool g = hit && (k8 == WR_PK_TEX_R8 || k8 == WR_PK_SOLID_MASKED) && (b8 == WR_BLEND_NONE || b8 == WR_BLEND_PREMULT) &&
+               !(DEPTH && ((rb.y >> 16) & WR_PF_DEPTH_TEST));
+      if (g) { const WrTexRec* tp = &aux[base + lane].tex; g = tp->simple != 0 && tp->unit != 0; }
+      glyphs = __ballot(g);
+    }
     // Rect-only launches (FEAT == 0): the survivors' records come back through the scalar cache, one s_load_dwordx8 per prim
     // issued a prim ahead, instead of eight v_readlane broadcasts out of the lanes that tested them -- the blend loop is
     // VALU-bound and v_readlane is VALU (cfg2 tile pass 68.6 -> 61.1 us).  The index is wave-uniform and recs[] read-only.
@@ -5297,6 +5372,36 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     WrRec nrec;
     if (SCALAR_RECS) nrec = recs[base + nbit];
     while (live) {
+      if constexpr ((FEAT & WR_FEAT_R8TEX) != 0 && FMT == WR_FMT_RGBA8) {
+        if ((glyphs >> __builtin_ctzll(live)) & 1ull) {
+          // the run of surviving prims from here up to the next one that is not a unit glyph
+          const unsigned long long others = live & ~glyphs;
+          const unsigned long long run = others ? (live & ((others & (0ull - others)) - 1ull)) : live;
+          if (run & (run - 1ull)) {             // two or more: worth the per-lane lists
+            live &= ~run;
+            // which prims of the run reach this lane's footprint (columns px .. px+3, rows py, py+4, ..)
+            unsigned mlo = 0, mhi = 0;
+            for (unsigned long long rr_ = run; rr_; rr_ &= rr_ - 1ull) {
+              const int b = __builtin_ctzll(rr_);
+              const int gx0 = __builtin_amdgcn_readlane((int)ra.x, b), gy0 = __builtin_amdgcn_readlane((int)ra.y, b);
+              const int gx1 = __builtin_amdgcn_readlane((int)ra.z, b), gy1 = __builtin_amdgcn_readlane((int)ra.w, b);
+              const bool reach = px + 3 >= gx0 && px < gx1 && py + 4 * (R - 1) >= gy0 && py < gy1;
+              if (b < 32) mlo |= reach ? (1u << b) : 0u; else mhi |= reach ? (1u << (b - 32)) : 0u;
+            }
+            while (__ballot((mlo | mhi) != 0)) {
+              if (mlo | mhi) {
+                const int b = mlo ? __builtin_ctz(mlo) : 32 + __builtin_ctz(mhi);
+                if (mlo) mlo &= mlo - 1; else mhi &= mhi - 1;
+                // (requesting a lane's next records ahead of applying its current ones was tried: the 16 extra live VGPRs
+                // spill in this loop, 170 -> 420 us)
+                const WrGlyphLoad g = wr_unit_glyph_fetch(&recs[base + b], &aux[base + b].tex);
+                wr_unit_glyph_lane<R>(plo, phi, g, &aux[base + b].tex, px, py);
+              }
+            }
+            continue;
+          }
+        }
+      }
       const int bit = SCALAR_RECS ? nbit : __builtin_ctzll(live);
       live &= live - 1;
       int x0, y0, x1, y1;

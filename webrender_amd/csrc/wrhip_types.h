@@ -283,29 +283,31 @@ struct WrRec {
 // arithmetic of LINEAR_QUANTIZE_UV / blendTextureLinearFallback
 // (swgl_ext.h:160-183) and of the fragment-shader tail.
 struct WrTexRec {
+  // (what a unit glyph blit reads comes first, in 48 contiguous bytes: the lane-by-lane glyph path of the raster stage
+  // fetches it with per-lane addresses, wr_unit_glyph_lane)
   const void* ptr;          // atlas / source base address
   int32_t stride;           // elements
-  uint32_t wh;              // width | height << 16
-  float ou, su;             // u at the span start, per-pixel step
-  float stepx;              // quantised step per 4-pixel chunk
-  float minx, maxx;         // quantised clamp (uv_rect)
-  float ub0, ub2;           // uv_bounds.x / .z (tail clamp)
   int32_t span;             // pixels [0,span) of a row go through draw_span
-  float lv0, lvs;           // v at row y0, per-row slope
-  float miny, maxy;
-  float ub1, ub3;
-  int32_t y0;
-  int32_t simple;           // 1: u constant on vertical edges, v on horizontal ones, colour is bytes
-  float fcolor[4];
   // `unit`: every sample of the prim is exactly one texel (both 7-bit fractions zero, no
   // clamping), texel (ix0 + n, iy0 + row) for span pixel n; tix[] = columns of the <= 3 tail pixels
   int32_t unit, ix0, iy0;
+  int32_t y0;
+  int32_t simple;           // 1: u constant on vertical edges, v on horizontal ones, colour is bytes
   int32_t tix[3];
   // WR_PK_TEX_RGBA8 on the nearest-fast path (blendTextureNearestFast): texel column =
   // clamp(ix0 + n, tix[0], tix[1]).  `simple` = 3: rows step one texel per target row, source row =
   // clamp(iy0 + tix[2] * (y - y0), unit & 0xFFFF, unit >> 16).  `simple` = 2: v of target row y is
   // vtab[iy0 + y - y0] (the edge interpolant accumulated row by row by the setup kernel, as
   // Edge::nextRow does); the raster stage derives the source row / texel-centre test from it.
+  float fcolor[4];
+  uint32_t wh;              // width | height << 16
+  float ou, su;             // u at the span start, per-pixel step
+  float stepx;              // quantised step per 4-pixel chunk
+  float minx, maxx;         // quantised clamp (uv_rect)
+  float ub0, ub2;           // uv_bounds.x / .z (tail clamp)
+  float lv0, lvs;           // v at row y0, per-row slope
+  float miny, maxy;
+  float ub1, ub3;
 };
 
 // One separable Gaussian pass (cs_blur.glsl + swgl_ext.h:947-996, texture.h:1165-1308).
