@@ -18,6 +18,7 @@
 #include "brush_blend.h"
 #include "ps_quad_mask.h"
 #include "brush_opacity.h"
+#include "cs_border_solid.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -52,6 +53,7 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("brush_opacity ALPHA_PASS,ANTIALIASING", brush_opacity_ALPHA_PASS_ANTIALIASING)
   WRSH_ENTRY("ps_quad_mask", ps_quad_mask)
   WRSH_ENTRY("ps_quad_mask FAST_PATH", ps_quad_mask_FAST_PATH)
+  WRSH_ENTRY("cs_border_solid", cs_border_solid)
 #undef WRSH_ENTRY
   return nullptr;
 }

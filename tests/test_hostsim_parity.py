@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -181,6 +181,17 @@ def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     assert stats["raster_launches"] >= 1
     if name in GOLDEN and golden_applies(name):
         assert digest(got) == GOLDEN[name]
+
+
+@pytest.mark.parametrize("name,kw", BORDERS, ids=[c[0] for c in BORDERS])
+def test_hostsim_border_solid_matches_oracle(hostsim, oracle_gcc, name, kw):
+    want, _ = render_direct(oracle_gcc, scenes.border_solid(**kw))
+    got, _ = render_direct(hostsim, scenes.border_solid(**kw))
+    assert np.array_equal(got["border_cache"], want["border_cache"])
+    v = want["border_cache"][..., 3]
+    assert (v == 0).any() and (v == 255).any() and ((v > 0) & (v < 255)).any()
+    if name in GOLDEN:
+        assert digest(got["border_cache"]) == GOLDEN[name]
 
 
 def test_hostsim_matches_golden_without_oracle(hostsim):

@@ -1007,6 +1007,47 @@ WR_DEVICE void wr_vs_cs_scale(const WrDrawDesc& d, const uint8_t* arena, int ins
   o.kind = (target_format == WR_FMT_RGBA8 && tex.format == WR_FMT_RGBA8) ? WR_PK_TEX_RGBA8 : WR_PK_TEX_FS;
 }
 
+// cs_border_solid.glsl:84-128 (vertex stage).  No span function: every pixel runs main() (wr_border_solid_pixel).
+WR_DEVICE void wr_vs_cs_border_solid(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrBorderRec& B) {
+  const wf2 origin = wr_load_attr<wf2>(d, arena, inst, 0);
+  const wf4 rect = wr_load_attr<wf4>(d, arena, inst, 1);
+  const wf4 color0 = wr_load_attr<wf4>(d, arena, inst, 2), color1 = wr_load_attr<wf4>(d, arena, inst, 3);
+  const int flags = wr_load_attr<int>(d, arena, inst, 4);
+  const wf2 widths = wr_load_attr<wf2>(d, arena, inst, 5), radii = wr_load_attr<wf2>(d, arena, inst, 6);
+  const wf4 cp1 = wr_load_attr<wf4>(d, arena, inst, 7), cp2 = wr_load_attr<wf4>(d, arena, inst, 8);
+  const int segment = flags & 0xff;
+  const bool do_aa = ((flags >> 24) & 0xf0) != 0;
+  float osx = 0.0f, osy = 0.0f;        // get_outer_corner_scale
+  if (segment == 1) { osx = 1.0f; } else if (segment == 2) { osx = 1.0f; osy = 1.0f; } else if (segment == 3) { osy = 1.0f; }
+  const float sx = rect.z - rect.x, sy = rect.w - rect.y;
+  const float ox = osx * sx, oy = osy * sy;
+  const float csx = 1.0f - 2.0f * osx, csy = 1.0f - 2.0f * osy;
+  B.mix = segment < 4 ? (do_aa ? 1 : 2) : 0;
+  B.color0[0] = color0.x; B.color0[1] = color0.y; B.color0[2] = color0.z; B.color0[3] = color0.w;
+  B.color1[0] = color1.x; B.color1[1] = color1.y; B.color1[2] = color1.z; B.color1[3] = color1.w;
+  B.clip_center_sign[0] = ox + csx * radii.x; B.clip_center_sign[1] = oy + csy * radii.y; B.clip_center_sign[2] = csx; B.clip_center_sign[3] = csy;
+  B.clip_radii[0] = radii.x; B.clip_radii[1] = radii.y; B.clip_radii[2] = wr_max(radii.x - widths.x, 0.0f); B.clip_radii[3] = wr_max(radii.y - widths.y, 0.0f);
+  B.color_line[0] = ox; B.color_line[1] = oy; B.color_line[2] = widths.y * -csy; B.color_line[3] = widths.x * csx;
+  const float hsx = -csx, hsy = csy;
+  B.h_center_sign[0] = cp1.x + hsx * cp1.z; B.h_center_sign[1] = cp1.y + hsy * cp1.w; B.h_center_sign[2] = hsx; B.h_center_sign[3] = hsy;
+  B.h_radii[0] = cp1.z; B.h_radii[1] = cp1.w;
+  const float vsx = csx, vsy = -csy;
+  B.v_center_sign[0] = cp2.x + vsx * cp2.z; B.v_center_sign[1] = cp2.y + vsy * cp2.w; B.v_center_sign[2] = vsx; B.v_center_sign[3] = vsy;
+  B.v_radii[0] = cp2.z; B.v_radii[1] = cp2.w;
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    const float vx = sx * ax, vy = sy * ay;          // vPos
+    o.u[n] = vx; o.v[n] = vy;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{(origin.x + rect.x) + vx, (origin.y + rect.y) + vy, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{0, 0, 0, 0};
+  o.kind = WR_PK_BORDER_SOLID;
+}
+
 // clip_shared.glsl:43-78 write_clip_tile_vertex + transform.glsl:48-90
 // (get_node_pos / untransform / ray_plane), one corner of the quad.
 WR_DEVICE wf4 wr_get_node_pos(float px, float py, const WrTransform& t) {
@@ -1480,7 +1521,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -2044,7 +2085,7 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
-  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || no_span;   // no draw_span for this program/target: all main()
+  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || no_span;   // no draw_span for this program/target: all main()
   const int k = runs ? wr_find_run(runs, x) : -1;
   if (k >= 0) {
     r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
@@ -2525,6 +2566,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_CLIP_RECT_FAST: wr_vs_cs_clip_rect(d, arena, inst, true, o, aux[gid].clip); break;
     case WR_SH_CS_CLIP_BOX_SHADOW: wr_vs_cs_clip_box_shadow(d, arena, inst, o, aux[gid].box); break;
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
+    case WR_SH_CS_BORDER_SOLID: wr_vs_cs_border_solid(d, arena, inst, o, aux[gid].border); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -3613,6 +3655,62 @@ __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClip
   return s;
 }
 
+// cs_border_solid main() (cs_border_solid.glsl:132-177; ellipse.glsl:31-45, shared.glsl:110-189), one pixel: vPos of the pixel
+// and of lanes 0 / 1 of its 4-pixel chunk (fwidth).  normalize() of the flat colour-line direction is a / hypotf(a.x, a.y)
+// (glsl.h:630-640): glibc evaluates hypotf in double.
+WR_DEVICE float wr_ellipse_dist(float px, float py, float rx, float ry) {      // distance_to_ellipse
+  const float ix = 1.0f / wr_max(rx * rx, 1.0e-6f), iy = 1.0f / wr_max(ry * ry, 1.0e-6f);
+  const float scale = (rx > 0.0f && ry > 0.0f) ? 1.0f : 0.0f;
+  const float prx = px * ix, pry = py * iy;
+  const float g = (px * prx + py * pry) - scale;
+  const float dgx = (1.0f + scale) * prx, dgy = (1.0f + scale) * pry;
+  return g * (1.0f / sqrtf(dgx * dgx + dgy * dgy));
+}
+__device__ __noinline__ WrWide wr_border_solid_pixel(const WrPrim* Pp, const WrBorderRec* Bp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
+  const WrPrim& P = *Pp;
+  const WrBorderRec& B = *Bp;
+  const WrTexRow r = wr_tex_row(P, D->tex[0], y, runs, x);   // span == 0 for this kind: interpolants only
+  const int n = x - r.x0, n0 = n & ~3;
+  float f0x, f0y, f1x, f1y, qx, qy;
+  wr_tex_tail_uv(P, r, n0, f0x, f0y);
+  wr_tex_tail_uv(P, r, n0 + 1, f1x, f1y);
+  wr_tex_tail_uv(P, r, n, qx, qy);
+  const float aa_range = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));
+  const bool do_aa = B.mix != 2;
+  float mix_factor = 0.0f;
+  if (B.mix != 0) {
+    const float len = float(sqrt(double(B.color_line[2]) * double(B.color_line[2]) + double(B.color_line[3]) * double(B.color_line[3])));
+    const float nx = B.color_line[2] / len, ny = B.color_line[3] / len;
+    const float d_line = nx * (B.color_line[0] - qx) + ny * (B.color_line[1] - qy);
+    if (do_aa) mix_factor = wr_clamp(0.5f - (-d_line) * aa_range, 0.0f, 1.0f);
+    else mix_factor = (d_line + 0.0001f >= 0.0f) ? 1.0f : 0.0f;
+  }
+  float d = -1.0f;
+  {
+    const float rx = qx - B.clip_center_sign[0], ry = qy - B.clip_center_sign[1];
+    if (B.clip_center_sign[2] * rx < 0.0f && B.clip_center_sign[3] * ry < 0.0f) {
+      const float da = wr_ellipse_dist(rx, ry, B.clip_radii[0], B.clip_radii[1]), db = wr_ellipse_dist(rx, ry, B.clip_radii[2], B.clip_radii[3]);
+      d = wr_max(da, -db);
+    }
+  }
+  {
+    const float rx = qx - B.h_center_sign[0], ry = qy - B.h_center_sign[1];
+    if (B.h_center_sign[2] * rx < 0.0f && B.h_center_sign[3] * ry < 0.0f) d = wr_max(wr_ellipse_dist(rx, ry, B.h_radii[0], B.h_radii[1]), d);
+  }
+  {
+    const float rx = qx - B.v_center_sign[0], ry = qy - B.v_center_sign[1];
+    if (B.v_center_sign[2] * rx < 0.0f && B.v_center_sign[3] * ry < 0.0f) d = wr_max(wr_ellipse_dist(rx, ry, B.v_radii[0], B.v_radii[1]), d);
+  }
+  const float alpha = do_aa ? wr_clamp(0.5f - d * aa_range, 0.0f, 1.0f) : 1.0f;
+  float c[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) c[i] = ((B.color1[i] - B.color0[i]) * mix_factor + B.color0[i]) * alpha;
+  uint32_t pc[2];
+  wr_pack_color(wf4{c[0], c[1], c[2], c[3]}, pc);
+  WrWide s; s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
 struct WrRow4 { uint32_t v[4]; };
 
 // Four horizontally adjacent pixels (x .. x+3) of row y: the span-level setup is
@@ -4418,7 +4516,7 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 // The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
 // nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
 WR_DEVICE bool wr_kind_needs_runs(int kind) {
-  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK ||
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID ||
          kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
 }
 // interval of prim `ci` (a depth writer) on row y
@@ -4905,6 +5003,23 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       }
       if (!in) continue;
       const WrWide src = wr_quad_mask_pixel(Pp, &Ap->clip, D, px + (q & 3), py + 4 * (q >> 2), rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
+      const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
+      plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+    }
+    return;
+  }
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_BORDER_SOLID) {
+    const WrDrawDesc* D = &draws[Pp->draw];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      bool in = cx[q & 3] && cy[q >> 2];
+      if (dtest) {
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+        in = in && pass;
+        if (dwrite) dep[q] = in ? z : dep[q];
+      }
+      if (!in) continue;
+      const WrWide src = wr_border_solid_pixel(Pp, &Ap->border, D, px + (q & 3), py + 4 * (q >> 2), rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }

@@ -62,6 +62,7 @@ enum WrShader {
   WR_SH_BRUSH_BLEND_ALPHA,
   WR_SH_PS_QUAD_MASK,
   WR_SH_PS_QUAD_MASK_FAST,
+  WR_SH_CS_BORDER_SOLID,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -232,6 +233,7 @@ enum WrPrimKind {
   WR_PK_TEX_QUAD,       // a textured prim (WrQuadRec::base_kind) on a general convex quad and / or with swgl_antiAlias: per-row spans and
                         // edge interpolants from WrQuadRec, then the base kind's span / main() evaluation
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
+  WR_PK_BORDER_SOLID,   // cs_border_solid: fragment shader only (corner clips, edge-colour mix; WrBorderRec); vPos travels in the uv interpolants
   WR_PK_MASK_ROWS,      // WrRec only: a WR_PK_BOX_SHADOW / WR_PK_CLIP_RECT prim whose rows wr_mask_rows_kernel has evaluated (WrMaskSlot)
 };
 
@@ -380,6 +382,17 @@ struct WrFilterRec {
   float color_offset[4];    // v_color_offset
 };
 
+// cs_border_solid flat varyings (cs_border_solid.glsl:11-38)
+struct WrBorderRec {
+  float color0[4], color1[4];       // vColor0, vColor1
+  float color_line[4];              // vColorLine
+  int32_t mix;                      // vMixColors.x: 0 DONT_MIX, 1 MIX_AA, 2 MIX_NO_AA
+  float clip_center_sign[4];        // vClipCenter_Sign
+  float clip_radii[4];              // vClipRadii
+  float h_center_sign[4], v_center_sign[4];   // v{Horizontal,Vertical}ClipCenter_Sign
+  float h_radii[2], v_radii[2];     // v{Horizontal,Vertical}ClipRadii
+};
+
 // General convex quad (draw_quad_spans, rasterize.h:783-1055): the scanline walk cut into the runs of
 // rows that share one pair of edge instances.  An Edge is (re)initialised at row `row` with x = `x`
 // and then steps x += slope once per row (Edge::nextRow), so its x on row y is the (y - row)-fold
@@ -436,6 +449,7 @@ union WrAux {
   WrGradRec grad;
   WrFilterRec filt;
   WrQuadRec quad;
+  WrBorderRec border;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

@@ -53,6 +53,10 @@ DESC = {
     "BLUR": VertexDescriptor(_POS, [
         ("aBlurRenderTaskAddress", 1, I32), ("aBlurSourceTaskAddress", 1, I32),
         ("aBlurDirection", 1, I32), ("aBlurParams", 3, F32)]),
+    # vertex.rs:279-332 (BorderInstance, gpu_types.rs:193-202)
+    "BORDER": VertexDescriptor(_POS, [
+        ("aTaskOrigin", 2, F32), ("aRect", 4, F32), ("aColor0", 4, F32), ("aColor1", 4, F32), ("aFlags", 1, I32),
+        ("aWidths", 2, F32), ("aRadii", 2, F32), ("aClipParams1", 4, F32), ("aClipParams2", 4, F32)]),
     # vertex.rs:334-358
     "SCALE": VertexDescriptor(_POS, [
         ("aScaleTargetRect", 4, F32), ("aScaleSourceRect", 4, F32),

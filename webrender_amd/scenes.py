@@ -1871,3 +1871,124 @@ def make_workload(workload, **kw):
         kw.pop("encoding", None)
         return cfg3_text(**kw)
     raise SystemExit(f"unknown workload {workload}")
+
+
+# ---------------------------------------------------------------------------
+# cs_border_solid: the segments of solid borders (four corners, four edges) rendered into the texture cache, one render task
+# each (border.rs:654-1043 create_border_segments / add_corner_segment / add_edge_segment -> BorderSegmentCacheKey ->
+# build_border_instances :1380-1480 -> render_target.rs add_border_segment_task_to_target: task_origin = the task's origin in
+# the cache texture).  brush_image then stretches the cached segments over the border's layout rects; that half is the
+# image path and is exercised elsewhere.
+BORDER_DTYPE = np.dtype([("origin", "<f4", (2,)), ("rect", "<f4", (4,)), ("c0", "<f4", (4,)), ("c1", "<f4", (4,)), ("flags", "<i4"),
+                         ("widths", "<f4", (2,)), ("radii", "<f4", (2,)), ("cp", "<f4", (8,))])      # BorderInstance, gpu_types.rs:193-202
+SEG_TL, SEG_TR, SEG_BR, SEG_BL, SEG_LEFT, SEG_TOP, SEG_RIGHT, SEG_BOTTOM = range(8)     # BorderSegment, border.rs:123-132
+BORDER_STYLE_SOLID = 1
+
+
+def border_solid(n=40, seed=131, atlas=1024):
+    rng = np.random.default_rng(seed)
+    frame = Frame(atlas, atlas, (1.0, 1.0, 1.0, 1.0))
+    t_cache = TextureRef("border_cache", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+    tgt = Target(t_cache, "texture_cache", clear_color=(0.0, 0.0, 0.0, 0.0))
+    inst = []
+    x = y = shelf = 2
+
+    def place(w, h):
+        nonlocal x, y, shelf
+        w, h = int(np.ceil(w)), int(np.ceil(h))
+        if x + w + 2 > atlas:
+            x, y, shelf = 2, y + shelf + 2, 0
+        if y + h + 2 > atlas:
+            return None
+        o = (float(x), float(y))
+        x += w + 2
+        shelf = max(shelf, h)
+        return o
+
+    def premul(c):
+        return [c[0] * c[3], c[1] * c[3], c[2] * c[3], c[3]]
+
+    for k in range(n):
+        scale = float(rng.choice([1.0, 1.0, 1.5, 2.0]))
+        W, H = float(rng.uniform(60, 260)), float(rng.uniform(50, 200))
+        widths = [float(rng.choice([1.0, 2.0, 3.0, 6.5, 12.0, 20.0])) for _ in range(4)]        # left, top, right, bottom
+        if k % 7 == 3:
+            widths[int(rng.integers(0, 4))] = 0.0
+        rad = []                                                                                # tl, tr, br, bl: (w, h)
+        for c in range(4):
+            if (k + c) % 5 == 0:
+                rad.append((0.0, 0.0))
+            elif (k + c) % 5 == 1:
+                r_ = float(rng.uniform(2, min(W, H) * 0.45)); rad.append((r_, r_))
+            else:
+                rad.append((float(rng.uniform(1, W * 0.45)), float(rng.uniform(1, H * 0.45))))
+        cols = [[float(v) for v in rng.uniform(0, 1, size=3)] + [float(rng.choice([1.0, 1.0, 0.6]))] for _ in range(4)]   # left, top, right, bottom
+        if k % 3 == 0:
+            cols = [cols[0]] * 4
+        do_aa = k % 6 != 5
+        l, t, r, b = widths
+        # corner segment rects in the border's local space (border.rs:700-760): max(width, radius) on each axis
+        tl = (0.0, 0.0, max(l, rad[0][0]), max(t, rad[0][1]))
+        tr = (W - max(r, rad[1][0]), 0.0, W, max(t, rad[1][1]))
+        br = (W - max(r, rad[2][0]), H - max(b, rad[2][1]), W, H)
+        bl = (0.0, H - max(b, rad[3][1]), max(l, rad[3][0]), H)
+        outer = {SEG_TL: (0.0, 0.0), SEG_TR: (W, 0.0), SEG_BR: (W, H), SEG_BL: (0.0, H)}
+
+        def corner(seg, rect, side0, side1, wid, radius, h_seg, v_seg, h_rad, v_rad):
+            # add_corner_segment: adjacent corners that do not reach this segment collapse to a point on it (border.rs:1095-1160)
+            if wid[0] <= 0.0 and wid[1] <= 0.0:
+                return
+            ho, hr = outer[h_seg], h_rad
+            vo, vr = outer[v_seg], v_rad
+            if seg in (SEG_TL, SEG_BL):
+                if not (ho[0] - hr[0] < rect[2]):
+                    ho, hr = (rect[2], rect[1] if seg == SEG_TL else rect[3]), (0.0, 0.0)
+            else:
+                if not (ho[0] + hr[0] > rect[0]):
+                    ho, hr = (rect[0], rect[1] if seg == SEG_TR else rect[3]), (0.0, 0.0)
+            if seg in (SEG_TL, SEG_TR):
+                if not (vo[1] - vr[1] < rect[3]):
+                    vo, vr = (rect[0] if seg == SEG_TL else rect[2], rect[3]), (0.0, 0.0)
+            else:
+                if not (vo[1] + vr[1] > rect[1]):
+                    vo, vr = (rect[2] if seg == SEG_BR else rect[0], rect[1]), (0.0, 0.0)
+            tw, th = (rect[2] - rect[0]) * scale, (rect[3] - rect[1]) * scale
+            o = place(tw, th)
+            if o is None:
+                return
+            e = np.zeros(1, BORDER_DTYPE)
+            e["origin"][0] = o
+            e["rect"][0] = (0.0, 0.0, float(np.ceil(tw)), float(np.ceil(th)))
+            e["c0"][0], e["c1"][0] = premul(side0), premul(side1)
+            e["flags"][0] = seg | (BORDER_STYLE_SOLID << 8) | (BORDER_STYLE_SOLID << 16) | (int(do_aa) << 28)
+            e["widths"][0] = (float(np.ceil(wid[0] * scale)), float(np.ceil(wid[1] * scale)))
+            e["radii"][0] = (radius[0] * scale, radius[1] * scale)
+            e["cp"][0] = ((ho[0] - rect[0]) * scale, (ho[1] - rect[1]) * scale, hr[0] * scale, hr[1] * scale,
+                          (vo[0] - rect[0]) * scale, (vo[1] - rect[1]) * scale, vr[0] * scale, vr[1] * scale)
+            inst.append(e)
+
+        corner(SEG_TL, tl, cols[0], cols[1], (l, t), rad[0], SEG_TR, SEG_BL, rad[1], rad[3])
+        corner(SEG_TR, tr, cols[1], cols[2], (r, t), rad[1], SEG_TL, SEG_BR, rad[0], rad[2])
+        corner(SEG_BR, br, cols[2], cols[3], (r, b), rad[2], SEG_BL, SEG_TR, rad[3], rad[1])
+        corner(SEG_BL, bl, cols[3], cols[0], (l, b), rad[3], SEG_BR, SEG_TL, rad[2], rad[0])
+        # edges (add_edge_segment, border.rs:1181-1260): a solid edge is a 1-texel-long strip of the edge's width, stretched later
+        for seg, wid, col, size in ((SEG_LEFT, l, cols[0], (l, 1.0)), (SEG_TOP, t, cols[1], (1.0, t)),
+                                    (SEG_RIGHT, r, cols[2], (r, 1.0)), (SEG_BOTTOM, b, cols[3], (1.0, b))):
+            if wid <= 0.0:
+                continue
+            tw, th = size[0] * scale, size[1] * scale
+            o = place(tw, th)
+            if o is None:
+                continue
+            e = np.zeros(1, BORDER_DTYPE)
+            e["origin"][0] = o
+            e["rect"][0] = (0.0, 0.0, float(np.ceil(tw)), float(np.ceil(th)))
+            e["c0"][0] = e["c1"][0] = premul(col)
+            e["flags"][0] = seg | (BORDER_STYLE_SOLID << 8) | (BORDER_STYLE_SOLID << 16) | (int(do_aa) << 28)
+            e["widths"][0] = (float(np.ceil(size[0] * scale)), float(np.ceil(size[1] * scale)))
+            inst.append(e)
+    tgt.steps.append(Step("cs_border_solid", "BORDER", np.concatenate(inst), "PremultipliedAlpha", "none"))
+    frame.passes.append([tgt])
+    frame.readback = [t_cache]
+    frame.n_border_segments = len(inst)
+    return frame
