@@ -19,6 +19,7 @@
 #include "ps_quad_mask.h"
 #include "brush_opacity.h"
 #include "cs_border_solid.h"
+#include "cs_border_segment.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -54,6 +55,7 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("ps_quad_mask", ps_quad_mask)
   WRSH_ENTRY("ps_quad_mask FAST_PATH", ps_quad_mask_FAST_PATH)
   WRSH_ENTRY("cs_border_solid", cs_border_solid)
+  WRSH_ENTRY("cs_border_segment", cs_border_segment)
 #undef WRSH_ENTRY
   return nullptr;
 }

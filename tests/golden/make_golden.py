@@ -63,9 +63,11 @@ def main():
     for name, make in OCCLUDED + BLEND + ROTATED:
         if name in OCCLUDED_GOLDEN + BLEND_GOLDEN + ROTATED_GOLDEN:
             out[name] = digest(render_direct(LIB, make())[0])
-    from parity_cases import BORDERS
+    from parity_cases import BORDERS, BORDER_SEGMENTS
     for name, kw in BORDERS:
         out[name] = digest(render_direct(LIB, scenes.border_solid(**kw))[0]["border_cache"])
+    for name, kw in BORDER_SEGMENTS:
+        out[name] = digest(render_direct(LIB, scenes.border_segments(**kw))[0]["border_cache"])
     for name, kw in (("blur_r8", dict(fmt="r8")), ("blur_rgba8", dict(fmt="rgba8")),
                      ("blur_r8_sigmas", dict(fmt="r8", content=(40, 30), sigma=[0.8, 1.7, 3.2, 4.0], n_tasks=12, origin=(0, 0))),
                      ("blur_rgba8_tiny", dict(fmt="rgba8", content=(5, 3), sigma=1.2, n_tasks=9, origin=(1, 1), atlas=64)),

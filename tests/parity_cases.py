@@ -76,3 +76,10 @@ BORDERS = [
     ("border_solid_many", dict(n=90, seed=132)),
     ("border_solid_small_atlas", dict(n=12, seed=133, atlas=512)),
 ]
+
+# cs_border_segment: styled corners and edges (double, groove, ridge, inset / outset, black sides), dashed and dotted edges,
+# corner dashes and corner dots.
+BORDER_SEGMENTS = [
+    ("border_segments", dict()),
+    ("border_segments_many", dict(n=200, seed=142)),
+]

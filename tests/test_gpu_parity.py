@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -206,14 +206,17 @@ def test_hip_matches_oracle_small(name, make):
     assert ref or (name in GOLDEN and golden_applies(name))
 
 
-@pytest.mark.parametrize("name,kw", BORDERS, ids=[c[0] for c in BORDERS])
-def test_hip_border_solid_matches_oracle(name, kw):
+_BORDER_CASES = [(n, "border_solid", kw) for n, kw in BORDERS] + [(n, "border_segments", kw) for n, kw in BORDER_SEGMENTS]
+
+
+@pytest.mark.parametrize("name,scene,kw", _BORDER_CASES, ids=[c[0] for c in _BORDER_CASES])
+def test_hip_border_solid_matches_oracle(name, scene, kw):
     """cs_border_solid segments in the texture cache: float coverage (ellipse distances, colour-line mix) -> +-1 LSB allowed
     by north_star, the committed digest pins the exact result."""
-    got, _ = render_direct(wrhip_lib(), scenes.border_solid(**kw))
+    got, _ = render_direct(wrhip_lib(), getattr(scenes, scene)(**kw))
     ref = oracle_lib("gcc")
     if ref:
-        want, _ = render_direct(ref, scenes.border_solid(**kw))
+        want, _ = render_direct(ref, getattr(scenes, scene)(**kw))
         d = np.abs(got["border_cache"].astype(int) - want["border_cache"].astype(int))
         assert d.max() <= 1
     if name in GOLDEN:

@@ -174,6 +174,8 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0)},
     {"cs_border_solid", WR_SH_CS_BORDER_SOLID,
      {"aPosition", "aTaskOrigin", "aRect", "aColor0", "aColor1", "aFlags", "aWidths", "aRadii", "aClipParams1", "aClipParams2"}, 0},
+    {"cs_border_segment", WR_SH_CS_BORDER_SEGMENT,
+     {"aPosition", "aTaskOrigin", "aRect", "aColor0", "aColor1", "aFlags", "aWidths", "aRadii", "aClipParams1", "aClipParams2"}, 0},
     {"cs_blur ALPHA_TARGET", WR_SH_CS_BLUR_ALPHA,
      {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
     {"cs_blur COLOR_TARGET", WR_SH_CS_BLUR_COLOR,
@@ -1379,7 +1381,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
-          case WR_SH_CS_BORDER_SOLID: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_IMAGE_REPEAT: case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }

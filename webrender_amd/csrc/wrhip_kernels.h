@@ -1048,6 +1048,82 @@ WR_DEVICE void wr_vs_cs_border_solid(const WrDrawDesc& d, const uint8_t* arena, 
   o.kind = WR_PK_BORDER_SOLID;
 }
 
+// cs_border_segment.glsl:118-267 (vertex stage).  No span function: every pixel runs main() (wr_border_segment_pixel).
+WR_DEVICE float wr_hypotf(float x, float y) { return float(sqrt(double(x) * double(x) + double(y) * double(y))); }   // glibc hypotf
+WR_DEVICE void wr_border_side_colors(wf4 color, int style, float* r0, float* r1) {      // get_colors_for_side / mod_color
+  const bool is_black = color.x == 0.0f && color.y == 0.0f && color.z == 0.0f;
+  const float light_black = 0.7f, dark_black = 0.3f, dark_scale = 0.66666666f, light_scale = 1.0f;
+  float lighter[4], darker[4];
+  if (is_black) {
+    lighter[0] = lighter[1] = lighter[2] = light_black; darker[0] = darker[1] = darker[2] = dark_black;
+  } else {
+    lighter[0] = color.x * light_scale; lighter[1] = color.y * light_scale; lighter[2] = color.z * light_scale;
+    darker[0] = color.x * dark_scale; darker[1] = color.y * dark_scale; darker[2] = color.z * dark_scale;
+  }
+  lighter[3] = darker[3] = color.w;
+  const float plain[4] = {color.x, color.y, color.z, color.w};
+  for (int i = 0; i < 4; i++) {
+    r0[i] = style == 6 ? lighter[i] : (style == 7 ? darker[i] : plain[i]);
+    r1[i] = style == 6 ? darker[i] : (style == 7 ? lighter[i] : plain[i]);
+  }
+}
+WR_DEVICE void wr_vs_cs_border_segment(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrBorderSegRec& B) {
+  const wf2 origin = wr_load_attr<wf2>(d, arena, inst, 0);
+  const wf4 rect = wr_load_attr<wf4>(d, arena, inst, 1);
+  const wf4 color0 = wr_load_attr<wf4>(d, arena, inst, 2), color1 = wr_load_attr<wf4>(d, arena, inst, 3);
+  const int flags = wr_load_attr<int>(d, arena, inst, 4);
+  const wf2 widths = wr_load_attr<wf2>(d, arena, inst, 5), radii = wr_load_attr<wf2>(d, arena, inst, 6);
+  const wf4 cp1 = wr_load_attr<wf4>(d, arena, inst, 7), cp2 = wr_load_attr<wf4>(d, arena, inst, 8);
+  const int segment = flags & 0xff, style0 = (flags >> 8) & 0xff, style1 = (flags >> 16) & 0xff, clip_mode = (flags >> 24) & 0x0f;
+  float osx = 0.0f, osy = 0.0f;
+  if (segment == 1) { osx = 1.0f; } else if (segment == 2) { osx = 1.0f; osy = 1.0f; } else if (segment == 3) { osy = 1.0f; }
+  const float sx = rect.z - rect.x, sy = rect.w - rect.y;
+  const float ox = osx * sx, oy = osy * sy;
+  const float csx = 1.0f - 2.0f * osx, csy = 1.0f - 2.0f * osy;
+  int eax = 0, eay = 0;
+  float erx = 0.0f, ery = 0.0f;
+  switch (segment) {
+    case 0: eax = 0; eay = 1; erx = ox; ery = oy; break;
+    case 1: eax = 1; eay = 0; erx = ox - widths.x; ery = oy; break;
+    case 2: eax = 0; eay = 1; erx = ox - widths.x; ery = oy - widths.y; break;
+    case 3: eax = 1; eay = 0; erx = ox; ery = oy - widths.y; break;
+    case 5: case 7: eax = 1; eay = 1; break;
+    default: break;
+  }
+  B.segment = segment; B.clip_mode = clip_mode; B.style0 = style0; B.style1 = style1; B.edge_axis[0] = eax; B.edge_axis[1] = eay;
+  B.partial_widths[0] = widths.x / 3.0f; B.partial_widths[1] = widths.y / 3.0f; B.partial_widths[2] = widths.x / 2.0f; B.partial_widths[3] = widths.y / 2.0f;
+  wr_border_side_colors(color0, style0, B.color00, B.color01);
+  wr_border_side_colors(color1, style1, B.color10, B.color11);
+  B.clip_center_sign[0] = ox + csx * radii.x; B.clip_center_sign[1] = oy + csy * radii.y; B.clip_center_sign[2] = csx; B.clip_center_sign[3] = csy;
+  B.clip_radii[0] = radii.x; B.clip_radii[1] = radii.y; B.clip_radii[2] = wr_max(radii.x - widths.x, 0.0f); B.clip_radii[3] = wr_max(radii.y - widths.y, 0.0f);
+  B.color_line[0] = ox; B.color_line[1] = oy; B.color_line[2] = widths.y * -csy; B.color_line[3] = widths.x * csx;
+  B.edge_reference[0] = erx; B.edge_reference[1] = ery; B.edge_reference[2] = erx + widths.x; B.edge_reference[3] = ery + widths.y;
+  B.cp1[0] = cp1.x; B.cp1[1] = cp1.y; B.cp1[2] = cp1.z; B.cp1[3] = cp1.w;
+  B.cp2[0] = cp2.x; B.cp2[1] = cp2.y; B.cp2[2] = cp2.z; B.cp2[3] = cp2.w;
+  float dot_radius = cp1.z;
+  if (dot_radius > 0.5f) dot_radius += 2.0f;
+  const float cenx = (cp1.x + cp2.x) * 0.5f, ceny = (cp1.y + cp2.y) * 0.5f;
+  const float dash_r = wr_max(wr_hypotf(cp1.x - cp2.x, cp1.y - cp2.y), wr_max(widths.x, widths.y)) + 2.0f;
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    float vx = sx * ax, vy = sy * ay;          // vPos
+    if (clip_mode == 3) {                       // CLIP_DOT: the quad shrinks to the dot's box
+      vx = cp1.x + dot_radius * (2.0f * ax - 1.0f); vy = cp1.y + dot_radius * (2.0f * ay - 1.0f);
+      vx = wr_clamp(vx, 0.0f, sx); vy = wr_clamp(vy, 0.0f, sy);
+    } else if (clip_mode == 1) {                // CLIP_DASH_CORNER: ... to the dash's box
+      vx = wr_clamp(vx, cenx - dash_r, cenx + dash_r); vy = wr_clamp(vy, ceny - dash_r, ceny + dash_r);
+    }
+    o.u[n] = vx; o.v[n] = vy;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{(origin.x + rect.x) + vx, (origin.y + rect.y) + vy, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{0, 0, 0, 0};
+  o.kind = WR_PK_BORDER_SEGMENT;
+}
+
 // clip_shared.glsl:43-78 write_clip_tile_vertex + transform.glsl:48-90
 // (get_node_pos / untransform / ray_plane), one corner of the quad.
 WR_DEVICE wf4 wr_get_node_pos(float px, float py, const WrTransform& t) {
@@ -1521,7 +1597,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -2085,7 +2161,7 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
-  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || no_span;   // no draw_span for this program/target: all main()
+  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || no_span;   // no draw_span for this program/target: all main()
   const int k = runs ? wr_find_run(runs, x) : -1;
   if (k >= 0) {
     r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
@@ -2567,6 +2643,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_CLIP_BOX_SHADOW: wr_vs_cs_clip_box_shadow(d, arena, inst, o, aux[gid].box); break;
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
     case WR_SH_CS_BORDER_SOLID: wr_vs_cs_border_solid(d, arena, inst, o, aux[gid].border); break;
+    case WR_SH_CS_BORDER_SEGMENT: wr_vs_cs_border_segment(d, arena, inst, o, aux[gid].bseg); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -3711,6 +3788,102 @@ __device__ __noinline__ WrWide wr_border_solid_pixel(const WrPrim* Pp, const WrB
   return s;
 }
 
+// cs_border_segment main() (cs_border_segment.glsl:271-449), one pixel
+WR_DEVICE float wr_dist_aa(float aa_range, float sd) { return wr_clamp(0.5f - sd * aa_range, 0.0f, 1.0f); }
+WR_DEVICE float wr_dist_line(float p0x, float p0y, float dx, float dy, float px, float py) {     // distance_to_line, shared.glsl:110-113
+  const float len = wr_hypotf(dx, dy);
+  const float nx = dx / len, ny = dy / len;
+  return nx * (p0x - px) + ny * (p0y - py);
+}
+WR_DEVICE void wr_border_corner_color(const WrBorderSegRec& B, float rx, float ry, int style, const float* c0in, const float* c1in,
+                                      float mix_factor, float aa_range, float* out) {
+  float c0[4] = {c0in[0], c0in[1], c0in[2], c0in[3]};
+  if (style == 2) {
+    const float da = wr_ellipse_dist(rx, ry, B.clip_radii[0] - B.partial_widths[0], B.clip_radii[1] - B.partial_widths[1]);
+    const float db = wr_ellipse_dist(rx, ry, B.clip_radii[0] - 2.0f * B.partial_widths[0], B.clip_radii[1] - 2.0f * B.partial_widths[1]);
+    const float a = wr_dist_aa(aa_range, wr_min(-da, db));
+    for (int i = 0; i < 4; i++) c0[i] *= a;
+  } else if (style == 6 || style == 7) {
+    const float d = wr_ellipse_dist(rx, ry, B.clip_radii[0] - B.partial_widths[2], B.clip_radii[1] - B.partial_widths[3]);
+    const float alpha = wr_dist_aa(aa_range, d);
+    float sf = 0.0f;
+    if (B.segment == 1) sf = mix_factor; else if (B.segment == 2) sf = 1.0f; else if (B.segment == 3) sf = 1.0f - mix_factor;
+    for (int i = 0; i < 4; i++) {
+      const float a0 = (c0in[i] - c1in[i]) * sf + c1in[i];       // mix(color1, color0, sf)
+      const float a1 = (c1in[i] - c0in[i]) * sf + c0in[i];       // mix(color0, color1, sf)
+      c0[i] = (a1 - a0) * alpha + a0;
+    }
+  }
+  for (int i = 0; i < 4; i++) out[i] = c0[i];
+}
+WR_DEVICE void wr_border_edge_color(const WrBorderSegRec& B, float px, float py, int style, const float* c0in, const float* c1in,
+                                    float aa_range, int axis_id, float* out) {
+  const float ax = axis_id != 0 ? 0.0f : 1.0f, ay = axis_id != 0 ? 1.0f : 0.0f;
+  const float pos = px * ax + py * ay;
+  float c0[4] = {c0in[0], c0in[1], c0in[2], c0in[3]};
+  if (style == 2) {
+    float d = -1.0f;
+    const float pw = B.partial_widths[0] * ax + B.partial_widths[1] * ay;
+    if (pw >= 1.0f) {
+      const float r0 = (B.edge_reference[0] * ax + B.edge_reference[1] * ay) + pw, r1 = (B.edge_reference[2] * ax + B.edge_reference[3] * ay) - pw;
+      d = wr_min(pos - r0, r1 - pos);
+    }
+    const float a = wr_dist_aa(aa_range, d);
+    for (int i = 0; i < 4; i++) c0[i] *= a;
+  } else if (style == 6 || style == 7) {
+    const float ref = (B.edge_reference[0] + B.partial_widths[2]) * ax + (B.edge_reference[1] + B.partial_widths[3]) * ay;
+    const float alpha = wr_dist_aa(aa_range, pos - ref);
+    for (int i = 0; i < 4; i++) c0[i] = (c1in[i] - c0in[i]) * alpha + c0in[i];
+  }
+  for (int i = 0; i < 4; i++) out[i] = c0[i];
+}
+__device__ __noinline__ WrWide wr_border_segment_pixel(const WrPrim* Pp, const WrBorderSegRec* Bp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
+  const WrPrim& P = *Pp;
+  const WrBorderSegRec& B = *Bp;
+  const WrTexRow r = wr_tex_row(P, D->tex[0], y, runs, x);
+  const int n = x - r.x0, n0 = n & ~3;
+  float f0x, f0y, f1x, f1y, qx, qy;
+  wr_tex_tail_uv(P, r, n0, f0x, f0y);
+  wr_tex_tail_uv(P, r, n0 + 1, f1x, f1y);
+  wr_tex_tail_uv(P, r, n, qx, qy);
+  const float aa_range = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));
+  float mix_factor = 0.0f;
+  if (B.edge_axis[0] != B.edge_axis[1]) mix_factor = wr_dist_aa(aa_range, -wr_dist_line(B.color_line[0], B.color_line[1], B.color_line[2], B.color_line[3], qx, qy));
+  const float rx = qx - B.clip_center_sign[0], ry = qy - B.clip_center_sign[1];
+  const bool in_clip = B.clip_center_sign[2] * rx < 0.0f && B.clip_center_sign[3] * ry < 0.0f;
+  float d = -1.0f;
+  if (B.clip_mode == 3) {
+    const float dx = B.cp1[0] - qx, dy = B.cp1[1] - qy;
+    d = sqrtf(dx * dx + dy * dy) - B.cp1[2];
+  } else if (B.clip_mode == 2) {
+    const bool is_vertical = B.cp1[0] == 0.0f;
+    const float half_dash = is_vertical ? B.cp1[1] : B.cp1[0];
+    const float pos = is_vertical ? qy : qx;
+    if (!(pos < half_dash || pos > 3.0f * half_dash)) d = 1.0f;
+  } else if (B.clip_mode == 1) {
+    const float d0 = wr_dist_line(B.cp1[0], B.cp1[1], B.cp1[2], B.cp1[3], qx, qy), d1 = wr_dist_line(B.cp2[0], B.cp2[1], B.cp2[2], B.cp2[3], qx, qy);
+    d = wr_max(d0, -d1);
+  }
+  float c0[4], c1[4];
+  if (in_clip) {
+    const float da = wr_ellipse_dist(rx, ry, B.clip_radii[0], B.clip_radii[1]), db = wr_ellipse_dist(rx, ry, B.clip_radii[2], B.clip_radii[3]);
+    d = wr_max(d, wr_max(da, -db));
+    wr_border_corner_color(B, rx, ry, B.style0, B.color00, B.color01, mix_factor, aa_range, c0);
+    wr_border_corner_color(B, rx, ry, B.style1, B.color10, B.color11, mix_factor, aa_range, c1);
+  } else {
+    wr_border_edge_color(B, qx, qy, B.style0, B.color00, B.color01, aa_range, B.edge_axis[0], c0);
+    wr_border_edge_color(B, qx, qy, B.style1, B.color10, B.color11, aa_range, B.edge_axis[1], c1);
+  }
+  const float alpha = wr_dist_aa(aa_range, d);
+  float c[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) c[i] = ((c1[i] - c0[i]) * mix_factor + c0[i]) * alpha;
+  uint32_t pc[2];
+  wr_pack_color(wf4{c[0], c[1], c[2], c[3]}, pc);
+  WrWide s; s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
 struct WrRow4 { uint32_t v[4]; };
 
 // Four horizontally adjacent pixels (x .. x+3) of row y: the span-level setup is
@@ -4516,7 +4689,7 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 // The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
 // nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
 WR_DEVICE bool wr_kind_needs_runs(int kind) {
-  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID ||
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT ||
          kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
 }
 // interval of prim `ci` (a depth writer) on row y
@@ -5008,7 +5181,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_BORDER_SOLID) {
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT)) {
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -5019,7 +5192,9 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
         if (dwrite) dep[q] = in ? z : dep[q];
       }
       if (!in) continue;
-      const WrWide src = wr_border_solid_pixel(Pp, &Ap->border, D, px + (q & 3), py + 4 * (q >> 2), rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
+      const WrRuns* rq = rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr;
+      const WrWide src = kind == WR_PK_BORDER_SOLID ? wr_border_solid_pixel(Pp, &Ap->border, D, px + (q & 3), py + 4 * (q >> 2), rq)
+                                                    : wr_border_segment_pixel(Pp, &Ap->bseg, D, px + (q & 3), py + 4 * (q >> 2), rq);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }

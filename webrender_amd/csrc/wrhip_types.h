@@ -63,6 +63,7 @@ enum WrShader {
   WR_SH_PS_QUAD_MASK,
   WR_SH_PS_QUAD_MASK_FAST,
   WR_SH_CS_BORDER_SOLID,
+  WR_SH_CS_BORDER_SEGMENT,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -234,6 +235,7 @@ enum WrPrimKind {
                         // edge interpolants from WrQuadRec, then the base kind's span / main() evaluation
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
   WR_PK_BORDER_SOLID,   // cs_border_solid: fragment shader only (corner clips, edge-colour mix; WrBorderRec); vPos travels in the uv interpolants
+  WR_PK_BORDER_SEGMENT, // cs_border_segment: fragment shader only (styles double / groove / ridge, dot / dash clips; WrBorderSegRec)
   WR_PK_MASK_ROWS,      // WrRec only: a WR_PK_BOX_SHADOW / WR_PK_CLIP_RECT prim whose rows wr_mask_rows_kernel has evaluated (WrMaskSlot)
 };
 
@@ -393,6 +395,14 @@ struct WrBorderRec {
   float h_radii[2], v_radii[2];     // v{Horizontal,Vertical}ClipRadii
 };
 
+// cs_border_segment flat varyings (cs_border_segment.glsl:9-45)
+struct WrBorderSegRec {
+  float color00[4], color01[4], color10[4], color11[4];
+  float color_line[4];
+  int32_t segment, clip_mode, style0, style1, edge_axis[2];
+  float clip_center_sign[4], clip_radii[4], edge_reference[4], partial_widths[4], cp1[4], cp2[4];
+};
+
 // General convex quad (draw_quad_spans, rasterize.h:783-1055): the scanline walk cut into the runs of
 // rows that share one pair of edge instances.  An Edge is (re)initialised at row `row` with x = `x`
 // and then steps x += slope once per row (Edge::nextRow), so its x on row y is the (y - row)-fold
@@ -450,6 +460,7 @@ union WrAux {
   WrFilterRec filt;
   WrQuadRec quad;
   WrBorderRec border;
+  WrBorderSegRec bseg;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

@@ -1992,3 +1992,126 @@ def border_solid(n=40, seed=131, atlas=1024):
     frame.readback = [t_cache]
     frame.n_border_segments = len(inst)
     return frame
+
+
+# cs_border_segment: the styled segments -- double / groove / ridge / inset / outset corners and edges, dashed edges
+# (CLIP_DASH_EDGE), dotted edges and corner dots (CLIP_DOT), corner dashes (CLIP_DASH_CORNER) -- with the instance encodings of
+# border.rs:904-1043 (add_segment) and :330-560 (write_dashed / write_dotted_corner_instances).
+BS_NONE, BS_SOLID, BS_DOUBLE, BS_DOTTED, BS_DASHED, BS_HIDDEN, BS_GROOVE, BS_RIDGE, BS_INSET, BS_OUTSET = range(10)
+CLIP_NONE, CLIP_DASH_CORNER, CLIP_DASH_EDGE, CLIP_DOT = range(4)
+
+
+def border_segments(n=60, seed=141, atlas=1024):
+    rng = np.random.default_rng(seed)
+    frame = Frame(atlas, atlas, (1.0, 1.0, 1.0, 1.0))
+    t_cache = TextureRef("border_cache", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+    tgt = Target(t_cache, "texture_cache", clear_color=(0.0, 0.0, 0.0, 0.0))
+    inst = []
+    x = y = shelf = 2
+
+    def place(w, h):
+        nonlocal x, y, shelf
+        w, h = int(np.ceil(w)), int(np.ceil(h))
+        if x + w + 2 > atlas:
+            x, y, shelf = 2, y + shelf + 2, 0
+        if y + h + 2 > atlas:
+            return None
+        o = (float(x), float(y))
+        x += w + 2
+        shelf = max(shelf, h)
+        return o
+
+    def color():
+        c = [float(v) for v in rng.uniform(0, 1, size=3)] + [float(rng.choice([1.0, 1.0, 0.5]))]
+        if rng.integers(0, 6) == 0:
+            c[:3] = [0.0, 0.0, 0.0]                                   # black: mod_color's special case
+        return [c[0] * c[3], c[1] * c[3], c[2] * c[3], c[3]]
+
+    def push(o, size, c0, c1, seg, s0, s1, clip, widths, radii, cp):
+        e = np.zeros(1, BORDER_DTYPE)
+        e["origin"][0] = o
+        e["rect"][0] = (0.0, 0.0, size[0], size[1])
+        e["c0"][0], e["c1"][0] = c0, c1
+        e["flags"][0] = seg | (s0 << 8) | (s1 << 16) | (clip << 24) | (1 << 28)
+        e["widths"][0], e["radii"][0], e["cp"][0] = widths, radii, cp
+        inst.append(e)
+
+    corner_styles = [BS_SOLID, BS_DOUBLE, BS_GROOVE, BS_RIDGE, BS_INSET, BS_OUTSET]
+    for k in range(n):
+        kind = k % 6
+        if kind in (0, 1, 2):                                        # corner, no clip
+            seg = int(rng.integers(0, 4))
+            wx, wy = float(rng.choice([3.0, 6.0, 9.0, 14.0, 21.0])), float(rng.choice([3.0, 6.0, 9.0, 14.0, 21.0]))
+            rx, ry = (0.0, 0.0) if k % 5 == 0 else (float(rng.uniform(wx * 0.5, 70)), float(rng.uniform(wy * 0.5, 70)))
+            size = (float(np.ceil(max(wx, rx))), float(np.ceil(max(wy, ry))))
+            s0 = corner_styles[int(rng.integers(0, len(corner_styles)))]
+            s1 = s0 if k % 2 else corner_styles[int(rng.integers(0, len(corner_styles)))]
+            o = place(*size)
+            if o is None:
+                break
+            push(o, size, color(), color(), seg, s0, s1, CLIP_NONE, (wx, wy), (rx, ry), (0.0,) * 8)
+        elif kind == 3:                                              # corner dash: the band between two lines (point + tangent each)
+            seg = int(rng.integers(0, 4))
+            w_ = float(rng.choice([6.0, 10.0, 16.0]))
+            rad = float(rng.uniform(30, 80))
+            size = (float(np.ceil(rad)), float(np.ceil(rad)))
+            a0, a1 = sorted(float(v) for v in rng.uniform(0.1, 1.4, size=2))
+            ocx, ocy = (1.0 if seg in (1, 2) else 0.0), (1.0 if seg in (2, 3) else 0.0)
+            cx, cy = (size[0] if ocx == 0.0 else 0.0), (size[1] if ocy == 0.0 else 0.0)     # ellipse centre: the inner corner
+            sgx, sgy = (-1.0 if ocx == 0.0 else 1.0), (-1.0 if ocy == 0.0 else 1.0)
+            p0 = (cx + sgx * (rad - w_ / 2) * np.cos(a0), cy + sgy * (rad - w_ / 2) * np.sin(a0))
+            p1 = (cx + sgx * (rad - w_ / 2) * np.cos(a1), cy + sgy * (rad - w_ / 2) * np.sin(a1))
+            t0 = (-sgx * np.sin(a0), sgy * np.cos(a0))
+            t1 = (-sgx * np.sin(a1), sgy * np.cos(a1))
+            o = place(*size)
+            if o is None:
+                break
+            push(o, size, color(), color(), seg, BS_DASHED, BS_DASHED, CLIP_DASH_CORNER, (w_, w_), (rad, rad),
+                 (float(p0[0]), float(p0[1]), float(t0[0]), float(t0[1]), float(p1[0]), float(p1[1]), float(t1[0]), float(t1[1])))
+        elif kind == 4:                                              # dashed / dotted edges
+            seg = int(rng.integers(4, 8))
+            vertical = seg in (SEG_LEFT, SEG_RIGHT)
+            wid = float(rng.choice([2.0, 4.0, 7.0, 12.0]))
+            if k % 2:
+                ln = float(rng.integers(8, 90))
+                size = (wid, ln) if vertical else (ln, wid)
+                cp = (0.0, ln * 0.25) if vertical else (ln * 0.25, 0.0)
+                clip, st, cps = CLIP_DASH_EDGE, BS_DASHED, cp + (0.0,) * 6
+            else:
+                size = (wid, 2.0 * wid) if vertical else (2.0 * wid, wid)
+                cp = (wid * 0.5, wid, wid * 0.5) if vertical else (wid, wid * 0.5, wid * 0.5)
+                clip, st, cps = CLIP_DOT, BS_DOTTED, cp + (0.0,) * 5
+            o = place(*size)
+            if o is None:
+                break
+            c = color()
+            push(o, size, c, c, seg, st, st, clip, (wid, wid), (0.0, 0.0), cps)
+        else:                                                        # styled edges / corner dots
+            if k % 2:
+                seg = int(rng.integers(4, 8))
+                vertical = seg in (SEG_LEFT, SEG_RIGHT)
+                wid = float(rng.choice([3.0, 6.0, 9.0, 15.0]))
+                size = (wid, float(rng.integers(1, 12))) if vertical else (float(rng.integers(1, 12)), wid)
+                st = [BS_DOUBLE, BS_GROOVE, BS_RIDGE, BS_INSET][int(rng.integers(0, 4))]
+                o = place(*size)
+                if o is None:
+                    break
+                c = color()
+                push(o, size, c, c, seg, st, st, CLIP_NONE, (wid, wid), (0.0, 0.0), (0.0,) * 8)
+            else:
+                seg = int(rng.integers(0, 4))
+                w_ = float(rng.choice([4.0, 8.0, 13.0]))
+                rad = float(rng.uniform(24, 70))
+                size = (float(np.ceil(rad)), float(np.ceil(rad)))
+                dot_r = w_ * 0.5
+                dc = (float(rng.uniform(dot_r, size[0] - dot_r)), float(rng.uniform(dot_r, size[1] - dot_r)))
+                o = place(*size)
+                if o is None:
+                    break
+                push(o, size, color(), color(), seg, BS_DOTTED, BS_DOTTED, CLIP_DOT, (w_, w_), (rad, rad),
+                     (dc[0], dc[1], dot_r if k % 4 else 0.4, 0.0) + (0.0,) * 4)
+    tgt.steps.append(Step("cs_border_segment", "BORDER", np.concatenate(inst), "PremultipliedAlpha", "none"))
+    frame.passes.append([tgt])
+    frame.readback = [t_cache]
+    frame.n_border_segments = len(inst)
+    return frame
