@@ -20,6 +20,8 @@
 #include "brush_opacity.h"
 #include "cs_border_solid.h"
 #include "cs_border_segment.h"
+#include "cs_fast_linear_gradient.h"
+#include "cs_line_decoration.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -56,6 +58,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("ps_quad_mask FAST_PATH", ps_quad_mask_FAST_PATH)
   WRSH_ENTRY("cs_border_solid", cs_border_solid)
   WRSH_ENTRY("cs_border_segment", cs_border_segment)
+  WRSH_ENTRY("cs_fast_linear_gradient", cs_fast_linear_gradient)
+  WRSH_ENTRY("cs_line_decoration", cs_line_decoration)
 #undef WRSH_ENTRY
   return nullptr;
 }

@@ -66,6 +66,9 @@ def main():
     from parity_cases import BORDERS, BORDER_SEGMENTS
     for name, kw in BORDERS:
         out[name] = digest(render_direct(LIB, scenes.border_solid(**kw))[0]["border_cache"])
+    from parity_cases import DECORATIONS
+    for name, kw in DECORATIONS:
+        out[name] = digest(render_direct(LIB, scenes.cache_decorations(**kw))[0]["decoration_cache"])
     for name, kw in BORDER_SEGMENTS:
         out[name] = digest(render_direct(LIB, scenes.border_segments(**kw))[0]["border_cache"])
     for name, kw in (("blur_r8", dict(fmt="r8")), ("blur_rgba8", dict(fmt="rgba8")),

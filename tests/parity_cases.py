@@ -83,3 +83,10 @@ BORDER_SEGMENTS = [
     ("border_segments", dict()),
     ("border_segments_many", dict(n=200, seed=142)),
 ]
+
+# cs_fast_linear_gradient and cs_line_decoration (solid / dotted / dashed / wavy, both axes, thin wavy lines through the AA snap)
+# tasks in a texture-cache target.
+DECORATIONS = [
+    ("cache_decorations", dict()),
+    ("cache_decorations_many", dict(n_lines=200, n_grads=60, seed=152)),
+]

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -206,7 +206,12 @@ def test_hip_matches_oracle_small(name, make):
     assert ref or (name in GOLDEN and golden_applies(name))
 
 
-_BORDER_CASES = [(n, "border_solid", kw) for n, kw in BORDERS] + [(n, "border_segments", kw) for n, kw in BORDER_SEGMENTS]
+def _cache_key(scene):
+    return "decoration_cache" if scene == "cache_decorations" else "border_cache"
+
+
+_BORDER_CASES = ([(n, "border_solid", kw) for n, kw in BORDERS] + [(n, "border_segments", kw) for n, kw in BORDER_SEGMENTS] +
+                 [(n, "cache_decorations", kw) for n, kw in DECORATIONS])
 
 
 @pytest.mark.parametrize("name,scene,kw", _BORDER_CASES, ids=[c[0] for c in _BORDER_CASES])
@@ -217,10 +222,10 @@ def test_hip_border_solid_matches_oracle(name, scene, kw):
     ref = oracle_lib("gcc")
     if ref:
         want, _ = render_direct(ref, getattr(scenes, scene)(**kw))
-        d = np.abs(got["border_cache"].astype(int) - want["border_cache"].astype(int))
+        d = np.abs(got[_cache_key(scene)].astype(int) - want[_cache_key(scene)].astype(int))
         assert d.max() <= 1
     if name in GOLDEN:
-        assert digest(got["border_cache"]) == GOLDEN[name] or ref
+        assert digest(got[_cache_key(scene)]) == GOLDEN[name] or ref
     assert ref or name in GOLDEN
 
 

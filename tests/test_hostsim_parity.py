@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -183,18 +183,23 @@ def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
         assert digest(got) == GOLDEN[name]
 
 
-_BORDER_CASES = [(n, "border_solid", kw) for n, kw in BORDERS] + [(n, "border_segments", kw) for n, kw in BORDER_SEGMENTS]
+def _cache_key(scene):
+    return "decoration_cache" if scene == "cache_decorations" else "border_cache"
+
+
+_BORDER_CASES = ([(n, "border_solid", kw) for n, kw in BORDERS] + [(n, "border_segments", kw) for n, kw in BORDER_SEGMENTS] +
+                 [(n, "cache_decorations", kw) for n, kw in DECORATIONS])
 
 
 @pytest.mark.parametrize("name,scene,kw", _BORDER_CASES, ids=[c[0] for c in _BORDER_CASES])
 def test_hostsim_border_solid_matches_oracle(hostsim, oracle_gcc, name, scene, kw):
     want, _ = render_direct(oracle_gcc, getattr(scenes, scene)(**kw))
     got, _ = render_direct(hostsim, getattr(scenes, scene)(**kw))
-    assert np.array_equal(got["border_cache"], want["border_cache"])
-    v = want["border_cache"][..., 3]
+    assert np.array_equal(got[_cache_key(scene)], want[_cache_key(scene)])
+    v = want[_cache_key(scene)][..., 3]
     assert (v == 0).any() and (v == 255).any() and ((v > 0) & (v < 255)).any()
     if name in GOLDEN:
-        assert digest(got["border_cache"]) == GOLDEN[name]
+        assert digest(got[_cache_key(scene)]) == GOLDEN[name]
 
 
 def test_hostsim_matches_golden_without_oracle(hostsim):

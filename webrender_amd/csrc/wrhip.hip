@@ -176,6 +176,9 @@ const ShaderInfo SHADERS[] = {
      {"aPosition", "aTaskOrigin", "aRect", "aColor0", "aColor1", "aFlags", "aWidths", "aRadii", "aClipParams1", "aClipParams2"}, 0},
     {"cs_border_segment", WR_SH_CS_BORDER_SEGMENT,
      {"aPosition", "aTaskOrigin", "aRect", "aColor0", "aColor1", "aFlags", "aWidths", "aRadii", "aClipParams1", "aClipParams2"}, 0},
+    {"cs_fast_linear_gradient", WR_SH_CS_FAST_LINEAR_GRADIENT, {"aPosition", "aTaskRect", "aColor0", "aColor1", "aAxisSelect"}, 0},
+    {"cs_line_decoration", WR_SH_CS_LINE_DECORATION,
+     {"aPosition", "aTaskRect", "aLocalSize", "aWavyLineThickness", "aStyle", "aAxisSelect"}, 0},
     {"cs_blur ALPHA_TARGET", WR_SH_CS_BLUR_ALPHA,
      {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
     {"cs_blur COLOR_TARGET", WR_SH_CS_BLUR_COLOR,
@@ -1381,7 +1384,8 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
-          case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: case WR_SH_CS_FAST_LINEAR_GRADIENT: case WR_SH_CS_LINE_DECORATION:
+            f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_IMAGE_REPEAT: case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }

@@ -1124,6 +1124,54 @@ WR_DEVICE void wr_vs_cs_border_segment(const WrDrawDesc& d, const uint8_t* arena
   o.kind = WR_PK_BORDER_SEGMENT;
 }
 
+// cs_fast_linear_gradient.glsl:17-24 and cs_line_decoration.glsl:43-98 (vertex stages).  Neither program has a span function.
+WR_DEVICE float wr_mixf(float x, float y, float a) { return (y - x) * a + x; }      // glsl.h:2691-2700
+WR_DEVICE void wr_vs_cs_fast_linear_gradient(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrFastGradRec& G) {
+  const wf4 task = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf4 c0 = wr_load_attr<wf4>(d, arena, inst, 1), c1 = wr_load_attr<wf4>(d, arena, inst, 2);
+  const float axis = wr_load_attr<float>(d, arena, inst, 3);
+  G.color0[0] = c0.x; G.color0[1] = c0.y; G.color0[2] = c0.z; G.color0[3] = c0.w;
+  G.color1[0] = c1.x; G.color1[1] = c1.y; G.color1[2] = c1.z; G.color1[3] = c1.w;
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    o.u[n] = wr_mixf(0.0f, 1.0f, wr_mixf(ax, ay, axis)); o.v[n] = 0.0f;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{wr_mixf(task.x, task.z, ax), wr_mixf(task.y, task.w, ay), 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{0, 0, 0, 0};
+  o.kind = WR_PK_FAST_GRADIENT;
+}
+WR_DEVICE void wr_vs_cs_line_decoration(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrLineRec& L) {
+  const wf4 task = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf2 local = wr_load_attr<wf2>(d, arena, inst, 1);
+  const float wavy = wr_load_attr<float>(d, arena, inst, 2);
+  const int style = wr_load_attr<int>(d, arena, inst, 3);
+  const float axis = wr_load_attr<float>(d, arena, inst, 4);
+  const float sx = wr_mixf(local.x, local.y, axis), sy = wr_mixf(local.y, local.x, axis);
+  L.style = style;
+  L.params[0] = L.params[1] = L.params[2] = L.params[3] = 0.0f;
+  if (style == 2) { L.params[0] = sx; L.params[1] = 0.5f * sx; }
+  else if (style == 1) { const float diameter = sy; L.params[0] = diameter * 2.0f; L.params[1] = diameter / 2.0f; L.params[2] = 0.5f * sy; }
+  else if (style == 3) {
+    const float lt = wr_max(wavy, 1.0f);
+    L.params[0] = lt / 2.0f; L.params[1] = sy - lt; L.params[2] = wr_max((lt - 1.0f) * 2.0f, 1.0f); L.params[3] = sy;
+  }
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    o.u[n] = wr_mixf(ax, ay, axis) * sx; o.v[n] = wr_mixf(ay, ax, axis) * sy;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{wr_mixf(task.x, task.z, ax), wr_mixf(task.y, task.w, ay), 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{0, 0, 0, 0};
+  o.kind = WR_PK_LINE_DECORATION;
+}
+
 // clip_shared.glsl:43-78 write_clip_tile_vertex + transform.glsl:48-90
 // (get_node_pos / untransform / ray_plane), one corner of the quad.
 WR_DEVICE wf4 wr_get_node_pos(float px, float py, const WrTransform& t) {
@@ -1597,7 +1645,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT || o.kind == WR_PK_FAST_GRADIENT || o.kind == WR_PK_LINE_DECORATION) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -2161,7 +2209,7 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
-  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || no_span;   // no draw_span for this program/target: all main()
+  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span;   // no draw_span for this program/target: all main()
   const int k = runs ? wr_find_run(runs, x) : -1;
   if (k >= 0) {
     r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
@@ -2644,6 +2692,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
     case WR_SH_CS_BORDER_SOLID: wr_vs_cs_border_solid(d, arena, inst, o, aux[gid].border); break;
     case WR_SH_CS_BORDER_SEGMENT: wr_vs_cs_border_segment(d, arena, inst, o, aux[gid].bseg); break;
+    case WR_SH_CS_FAST_LINEAR_GRADIENT: wr_vs_cs_fast_linear_gradient(d, arena, inst, o, aux[gid].fgrad); break;
+    case WR_SH_CS_LINE_DECORATION: wr_vs_cs_line_decoration(d, arena, inst, o, aux[gid].line); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -3884,6 +3934,61 @@ __device__ __noinline__ WrWide wr_border_segment_pixel(const WrPrim* Pp, const W
   return s;
 }
 
+// cs_fast_linear_gradient main() (:28-30) and cs_line_decoration main() (:104-163), one pixel
+WR_DEVICE float wr_dist_line_v(float p0x, float p0y, float dx, float dy, float px, float py) {   // distance_to_line with a per-pixel direction:
+  const float len = sqrtf(dx * dx + dy * dy);                                                    // normalize() = a / sqrt(dot) (glsl.h:628, 637-640)
+  const float nx = dx / len, ny = dy / len;
+  return nx * (p0x - px) + ny * (p0y - py);
+}
+__device__ __noinline__ WrWide wr_cache_shader_pixel(const WrPrim* Pp, const WrAux* Ap, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
+  const WrPrim& P = *Pp;
+  const WrTexRow r = wr_tex_row(P, D->tex[0], y, runs, x);
+  const int n = x - r.x0, n0 = n & ~3;
+  float qx, qy;
+  wr_tex_tail_uv(P, r, n, qx, qy);
+  float c[4];
+  if (P.kind == WR_PK_FAST_GRADIENT) {
+    const WrFastGradRec& G = Ap->fgrad;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = (G.color1[i] - G.color0[i]) * qx + G.color0[i];
+  } else {
+    const WrLineRec& L = Ap->line;
+    float f0x, f0y, f1x, f1y;
+    wr_tex_tail_uv(P, r, n0, f0x, f0y);
+    wr_tex_tail_uv(P, r, n0 + 1, f1x, f1y);
+    const float aa_range = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));
+    float alpha = 1.0f;
+    if (L.style == 2) {
+      alpha = (L.params[1] >= floorf(qx + 0.5f)) ? 1.0f : 0.0f;                   // step(floor(pos.x + 0.5), vParams.y)
+    } else if (L.style == 1) {
+      const float dx = qx - L.params[1], dy = qy - L.params[2];
+      alpha = wr_dist_aa(aa_range, sqrtf(dx * dx + dy * dy) - L.params[1]);
+    } else if (L.style == 3) {
+      const float half_line_thickness = L.params[0], slope_length = L.params[1], flat_length = L.params[2], vertical_bounds = L.params[3];
+      const float half_period = slope_length + flat_length;
+      const float mid_height = vertical_bounds / 2.0f;
+      float peak_offset = mid_height - half_line_thickness;
+      const float two_hp = 2.0f * half_period;
+      const float m2 = qx - two_hp * floorf(qx / two_hp);                           // mod(pos.x, 2 * half_period)
+      const float flip = -2.0f * (((half_period >= m2) ? 1.0f : 0.0f) - 0.5f);      // step(m2, half_period)
+      peak_offset *= flip;
+      const float peak_height = mid_height + peak_offset;
+      const float px_ = qx - half_period * floorf(qx / half_period);                // mod(pos.x, half_period)
+      const float dist1 = wr_dist_line_v(0.0f, peak_height, 1.0f, -flip, px_, qy);
+      const float dist2 = wr_dist_line_v(0.0f, peak_height, 0.0f, -flip, px_, qy);
+      const float dist3 = wr_dist_line_v(flat_length, peak_height, -1.0f, -flip, px_, qy);
+      const float dist = fabsf(wr_max(wr_max(dist1, dist2), dist3));
+      alpha = wr_dist_aa(aa_range, dist - half_line_thickness);
+      if (half_line_thickness <= 1.0f) alpha = 1.0f - ((0.5f >= alpha) ? 1.0f : 0.0f);   // 1 - step(alpha, 0.5)
+    }
+    c[0] = c[1] = c[2] = c[3] = alpha;
+  }
+  uint32_t pc[2];
+  wr_pack_color(wf4{c[0], c[1], c[2], c[3]}, pc);
+  WrWide s; s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
 struct WrRow4 { uint32_t v[4]; };
 
 // Four horizontally adjacent pixels (x .. x+3) of row y: the span-level setup is
@@ -4689,7 +4794,7 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 // The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
 // nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
 WR_DEVICE bool wr_kind_needs_runs(int kind) {
-  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT ||
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION ||
          kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
 }
 // interval of prim `ci` (a depth writer) on row y
@@ -5181,7 +5286,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT)) {
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION)) {
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -5194,7 +5299,8 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       if (!in) continue;
       const WrRuns* rq = rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr;
       const WrWide src = kind == WR_PK_BORDER_SOLID ? wr_border_solid_pixel(Pp, &Ap->border, D, px + (q & 3), py + 4 * (q >> 2), rq)
-                                                    : wr_border_segment_pixel(Pp, &Ap->bseg, D, px + (q & 3), py + 4 * (q >> 2), rq);
+                         : kind == WR_PK_BORDER_SEGMENT ? wr_border_segment_pixel(Pp, &Ap->bseg, D, px + (q & 3), py + 4 * (q >> 2), rq)
+                                                        : wr_cache_shader_pixel(Pp, Ap, D, px + (q & 3), py + 4 * (q >> 2), rq);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }

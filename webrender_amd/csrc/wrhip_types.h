@@ -64,6 +64,8 @@ enum WrShader {
   WR_SH_PS_QUAD_MASK_FAST,
   WR_SH_CS_BORDER_SOLID,
   WR_SH_CS_BORDER_SEGMENT,
+  WR_SH_CS_FAST_LINEAR_GRADIENT,
+  WR_SH_CS_LINE_DECORATION,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -236,6 +238,8 @@ enum WrPrimKind {
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
   WR_PK_BORDER_SOLID,   // cs_border_solid: fragment shader only (corner clips, edge-colour mix; WrBorderRec); vPos travels in the uv interpolants
   WR_PK_BORDER_SEGMENT, // cs_border_segment: fragment shader only (styles double / groove / ridge, dot / dash clips; WrBorderSegRec)
+  WR_PK_FAST_GRADIENT,  // cs_fast_linear_gradient: main() only, mix(vColor0, vColor1, vPos) (WrFastGradRec); vPos travels in the u interpolant
+  WR_PK_LINE_DECORATION,// cs_line_decoration: main() only (solid / dashed / dotted / wavy; WrLineRec); vLocalPos in the uv interpolants
   WR_PK_MASK_ROWS,      // WrRec only: a WR_PK_BOX_SHADOW / WR_PK_CLIP_RECT prim whose rows wr_mask_rows_kernel has evaluated (WrMaskSlot)
 };
 
@@ -403,6 +407,10 @@ struct WrBorderSegRec {
   float clip_center_sign[4], clip_radii[4], edge_reference[4], partial_widths[4], cp1[4], cp2[4];
 };
 
+// cs_fast_linear_gradient / cs_line_decoration flat varyings
+struct WrFastGradRec { float color0[4], color1[4]; };
+struct WrLineRec { int32_t style; float params[4]; };
+
 // General convex quad (draw_quad_spans, rasterize.h:783-1055): the scanline walk cut into the runs of
 // rows that share one pair of edge instances.  An Edge is (re)initialised at row `row` with x = `x`
 // and then steps x += slope once per row (Edge::nextRow), so its x on row y is the (y - row)-fold
@@ -461,6 +469,8 @@ union WrAux {
   WrQuadRec quad;
   WrBorderRec border;
   WrBorderSegRec bseg;
+  WrFastGradRec fgrad;
+  WrLineRec line;
 };
 
 // One queued texture upload: `rows` rows of `row_bytes` packed at `src` (HBM

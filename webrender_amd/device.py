@@ -57,6 +57,12 @@ DESC = {
     "BORDER": VertexDescriptor(_POS, [
         ("aTaskOrigin", 2, F32), ("aRect", 4, F32), ("aColor0", 4, F32), ("aColor1", 4, F32), ("aFlags", 1, I32),
         ("aWidths", 2, F32), ("aRadii", 2, F32), ("aClipParams1", 4, F32), ("aClipParams2", 4, F32)]),
+    # vertex.rs:74-108 (LineDecorationJob, render_target.rs:1184-1190)
+    "LINE": VertexDescriptor(_POS, [
+        ("aTaskRect", 4, F32), ("aLocalSize", 2, F32), ("aWavyLineThickness", 1, F32), ("aStyle", 1, I32), ("aAxisSelect", 1, F32)]),
+    # vertex.rs:109-138 (FastLinearGradientInstance, prim_store/gradient/linear.rs:689-694)
+    "FAST_LINEAR_GRADIENT": VertexDescriptor(_POS, [
+        ("aTaskRect", 4, F32), ("aColor0", 4, F32), ("aColor1", 4, F32), ("aAxisSelect", 1, F32)]),
     # vertex.rs:334-358
     "SCALE": VertexDescriptor(_POS, [
         ("aScaleTargetRect", 4, F32), ("aScaleSourceRect", 4, F32),

@@ -2115,3 +2115,84 @@ def border_segments(n=60, seed=141, atlas=1024):
     frame.readback = [t_cache]
     frame.n_border_segments = len(inst)
     return frame
+
+
+# ---------------------------------------------------------------------------
+# cs_line_decoration and cs_fast_linear_gradient: texture-cache tasks (render_target.rs:1184-1190 LineDecorationJob, one
+# period of the pattern per task, drawn with premultiplied-alpha blending; prim_store/gradient/linear.rs:689-694
+# FastLinearGradientInstance, two-stop axis-aligned gradients drawn unblended).
+LINE_DTYPE = np.dtype([("task", "<f4", (4,)), ("local", "<f4", (2,)), ("wavy", "<f4"), ("style", "<i4"), ("axis", "<f4")])
+FASTGRAD_DTYPE = np.dtype([("task", "<f4", (4,)), ("c0", "<f4", (4,)), ("c1", "<f4", (4,)), ("axis", "<f4")])
+LINE_SOLID, LINE_DOTTED, LINE_DASHED, LINE_WAVY = range(4)
+
+
+def cache_decorations(n_lines=60, n_grads=40, seed=151, atlas=1024):
+    rng = np.random.default_rng(seed)
+    frame = Frame(atlas, atlas, (1.0, 1.0, 1.0, 1.0))
+    t_cache = TextureRef("decoration_cache", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+    tgt = Target(t_cache, "texture_cache", clear_color=(0.0, 0.0, 0.0, 0.0))
+    x = y = shelf = 2
+
+    def place(w, h):
+        nonlocal x, y, shelf
+        w, h = int(np.ceil(w)), int(np.ceil(h))
+        if x + w + 2 > atlas:
+            x, y, shelf = 2, y + shelf + 2, 0
+        if y + h + 2 > atlas:
+            return None
+        o = (float(x), float(y))
+        x += w + 2
+        shelf = max(shelf, h)
+        return o
+
+    grads = []
+    for k in range(n_grads):
+        w, h = float(rng.integers(8, 200)), float(rng.integers(8, 120))
+        if k % 5 == 0:
+            w, h = w + 0.5, h + 0.25                                   # fractional task rects
+        o = place(w, h)
+        if o is None:
+            break
+        e = np.zeros(1, FASTGRAD_DTYPE)
+        e["task"][0] = (o[0], o[1], o[0] + w, o[1] + h)
+        c0 = [float(v) for v in rng.uniform(0, 1, size=4)]
+        c1 = [float(v) for v in rng.uniform(0, 1, size=4)]
+        e["c0"][0] = [c0[0] * c0[3], c0[1] * c0[3], c0[2] * c0[3], c0[3]]
+        e["c1"][0] = [c1[0] * c1[3], c1[1] * c1[3], c1[2] * c1[3], c1[3]]
+        e["axis"][0] = float(k % 2)
+        grads.append(e)
+    lines = []
+    for k in range(n_lines):
+        style = (LINE_SOLID, LINE_DOTTED, LINE_DASHED, LINE_WAVY, LINE_WAVY, LINE_DOTTED)[k % 6]
+        vertical = k % 4 == 3
+        thick = float(rng.choice([1.0, 2.0, 3.0, 5.0, 8.0, 12.5]))
+        scale = float(rng.choice([1.0, 1.0, 2.0, 1.5]))
+        wavy = 0.0
+        # line_dec.rs get_line_decoration_size: one period of the pattern along the line, the line's thickness across
+        if style == LINE_DASHED:
+            local = (thick * 3.0 * 2.0 if k % 2 else thick * 4.0, thick)
+        elif style == LINE_DOTTED:
+            local = (thick * 2.0, thick)
+        elif style == LINE_WAVY:
+            wavy = max(1.0, float(np.floor(thick / 4.0 + 0.5))) if k % 2 else thick / 3.0
+            slope = thick - wavy
+            flat = max((wavy - 1.0) * 2.0, 1.0)
+            local = ((slope + flat) * 2.0, thick)
+        else:
+            local = (float(rng.integers(8, 64)), thick)
+        dev = (local[0] * scale, local[1] * scale)
+        tw, th = (dev[1], dev[0]) if vertical else dev
+        o = place(tw, th)
+        if o is None:
+            break
+        e = np.zeros(1, LINE_DTYPE)
+        e["task"][0] = (o[0], o[1], o[0] + float(np.ceil(tw)), o[1] + float(np.ceil(th)))
+        e["local"][0] = (local[1], local[0]) if vertical else local
+        e["wavy"][0], e["style"][0], e["axis"][0] = wavy, style, 1.0 if vertical else 0.0
+        lines.append(e)
+    tgt.steps.append(Step("cs_fast_linear_gradient", "FAST_LINEAR_GRADIENT", np.concatenate(grads), None, "none"))
+    tgt.steps.append(Step("cs_line_decoration", "LINE", np.concatenate(lines), "PremultipliedAlpha", "none"))
+    frame.passes.append([tgt])
+    frame.readback = [t_cache]
+    frame.n_tasks = (len(grads), len(lines))
+    return frame
