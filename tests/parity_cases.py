@@ -84,9 +84,10 @@ BORDER_SEGMENTS = [
     ("border_segments_many", dict(n=200, seed=142)),
 ]
 
-# cs_fast_linear_gradient and cs_line_decoration (solid / dotted / dashed / wavy, both axes, thin wavy lines through the AA snap)
+# cs_fast_linear_gradient, cs_linear_gradient and cs_line_decoration (solid / dotted / dashed / wavy, both axes, thin wavy lines through the AA snap)
 # tasks in a texture-cache target.
 DECORATIONS = [
     ("cache_decorations", dict()),
-    ("cache_decorations_many", dict(n_lines=200, n_grads=60, seed=152)),
+    ("cache_decorations_many", dict(n_lines=200, n_grads=60, n_lgrads=20, seed=152)),
+    ("cache_linear_gradients", dict(n_lines=1, n_grads=1, n_lgrads=200, seed=153)),      # cs_linear_gradient: the span shader with tileRepeat off
 ]

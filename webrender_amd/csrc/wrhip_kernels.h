@@ -582,6 +582,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     G->scale_dir[0] = sdx * stx; G->scale_dir[1] = sdy * sty;
     G->address = data1.x;
     G->repeat = extend_mode == 1 ? 1.0f : 0.0f;
+    G->no_tile = 0;
     // swgl_validateGradient(sGpuBufferF, get_gpu_buffer_uv(address), 130) (swgl_ext.h:1336-1347)
     const WrTexDesc& gb = d.tex[WR_S_GPU_BUFFER_F];
     const int ax = int(unsigned(data1.x) % 1024u), ay = int(unsigned(data1.x) / 1024u);
@@ -1122,6 +1123,36 @@ WR_DEVICE void wr_vs_cs_border_segment(const WrDrawDesc& d, const uint8_t* arena
   o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
   o.color = wf4{0, 0, 0, 0};
   o.kind = WR_PK_BORDER_SEGMENT;
+}
+
+// cs_linear_gradient.glsl:26-46 (vertex stage); the fragment side is brush_linear_gradient's replay with tileRepeat off
+WR_DEVICE void wr_vs_cs_linear_gradient(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrGradRec* G) {
+  const wf4 task = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf2 sp = wr_load_attr<wf2>(d, arena, inst, 1), ep = wr_load_attr<wf2>(d, arena, inst, 2), scale = wr_load_attr<wf2>(d, arena, inst, 3);
+  const int extend_mode = wr_load_attr<int>(d, arena, inst, 4), address = wr_load_attr<int>(d, arena, inst, 5);
+  const float dirx = ep.x - sp.x, diry = ep.y - sp.y;
+  const float dd = dirx * dirx + diry * diry;
+  const float sdx = dirx / dd, sdy = diry / dd;
+  G->start_offset = sp.x * sdx + sp.y * sdy;
+  G->scale_dir[0] = sdx * (task.z - task.x); G->scale_dir[1] = sdy * (task.w - task.y);
+  G->address = address;
+  G->repeat = extend_mode == 1 ? 1.0f : 0.0f;
+  G->no_tile = 1;
+  const WrTexDesc& gb = d.tex[WR_S_GPU_BUFFER_F];
+  const int ax = int(unsigned(address) % 1024u), ay = int(unsigned(address) / 1024u);
+  const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width && ax + 2 * 130 <= gb.width;
+  G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
+  for (int n = 0; n < 4; n++) {
+    const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
+    o.u[n] = ax_ * scale.x; o.v[n] = ay_ * scale.y;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{(task.z - task.x) * ax_ + task.x, (task.w - task.y) * ay_ + task.y, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_GPU_BUFFER_F;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.kind = WR_PK_GRADIENT;
 }
 
 // cs_fast_linear_gradient.glsl:17-24 and cs_line_decoration.glsl:43-98 (vertex stages).  Neither program has a span function.
@@ -2694,6 +2725,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_BORDER_SEGMENT: wr_vs_cs_border_segment(d, arena, inst, o, aux[gid].bseg); break;
     case WR_SH_CS_FAST_LINEAR_GRADIENT: wr_vs_cs_fast_linear_gradient(d, arena, inst, o, aux[gid].fgrad); break;
     case WR_SH_CS_LINE_DECORATION: wr_vs_cs_line_decoration(d, arena, inst, o, aux[gid].line); break;
+    case WR_SH_CS_LINEAR_GRADIENT: wr_vs_cs_linear_gradient(d, arena, inst, o, &aux[gid].grad); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -3320,16 +3352,19 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
     const float* stops = G.stops;
     const int c_lo = n_lo >> 2, c_hi = wr_imin(n_hi, span - 1) >> 2;     // chunks wanted
     float dcxx = 0.25f * float(span), dcxy = 0.0f, dcyx = dcxx, dcyy = 0.0f;
-    if (psx != 0.0f) { const float r = 1.0f / psx; dcxx = (psx >= 0.0f ? 1.0f : 0.0f) * r; dcxy = 1.0f * r; }
-    if (psy != 0.0f) { const float r = 1.0f / psy; dcyx = (psy >= 0.0f ? 1.0f : 0.0f) * r; dcyy = 1.0f * r; }
+    const bool tile = G.no_tile == 0;      // tileRepeat (swgl_ext.h:1411-1432)
+    if (tile && psx != 0.0f) { const float r = 1.0f / psx; dcxx = (psx >= 0.0f ? 1.0f : 0.0f) * r; dcxy = 1.0f * r; }
+    if (tile && psy != 0.0f) { const float r = 1.0f / psy; dcyx = (psy >= 0.0f ? 1.0f : 0.0f) * r; dcyy = 1.0f * r; }
     int left = span, chunk = 0;          // chunk: index of the next chunk to be produced
     while (left > 0 && chunk <= c_hi) {
       float chunks = 0.25f * float(left);
       float rx[4], ry[4], off[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) { rx[i] = wr_fract(px[i]); ry[i] = wr_fract(py[i]); }
-      chunks = wr_min(chunks, dcxx - rx[0] * dcxy);
-      chunks = wr_min(chunks, dcyx - ry[0] * dcyy);
+      for (int i = 0; i < 4; i++) { rx[i] = tile ? wr_fract(px[i]) : px[i]; ry[i] = tile ? wr_fract(py[i]) : py[i]; }
+      if (tile) {
+        chunks = wr_min(chunks, dcxx - rx[0] * dcxy);
+        chunks = wr_min(chunks, dcyx - ry[0] * dcyy);
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         off[i] = rx[i] * sdx + ry[i] * sdy - G.start_offset;
@@ -3396,7 +3431,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           px[i] += psx * fi; py[i] += psy * fi;
-          off[i] = wr_fract(px[i]) * sdx + wr_fract(py[i]) * sdy - G.start_offset;
+          off[i] = (tile ? wr_fract(px[i]) : px[i]) * sdx + (tile ? wr_fract(py[i]) : py[i]) * sdy - G.start_offset;
           if (G.repeat != 0.0f) off[i] = wr_fract(off[i]);
         }
       }
@@ -3425,7 +3460,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
         lu = lu + (su * 4.0f) * chunks; lv = lv + (sv * 4.0f) * chunks;
       }
       lu = wr_accum(lu, (su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (sv * 4.0f) * 1.0f, m);
-      float offset = wr_fract(lu) * sdx + wr_fract(lv) * sdy - G.start_offset;
+      float offset = (G.no_tile ? lu : wr_fract(lu)) * sdx + (G.no_tile ? lv : wr_fract(lv)) * sdy - G.start_offset;
       offset -= floorf(offset) * G.repeat;
       const float xe = wr_clamp(1.0f + offset * 128.0f, 0.0f, 1.0f + 128.0f);
       const float ei = floorf(xe), ef = xe - ei;

@@ -63,6 +63,10 @@ DESC = {
     # vertex.rs:109-138 (FastLinearGradientInstance, prim_store/gradient/linear.rs:689-694)
     "FAST_LINEAR_GRADIENT": VertexDescriptor(_POS, [
         ("aTaskRect", 4, F32), ("aColor0", 4, F32), ("aColor1", 4, F32), ("aAxisSelect", 1, F32)]),
+    # vertex.rs:139-180 (LinearGradientInstance, prim_store/gradient/linear.rs:727-734)
+    "LINEAR_GRADIENT": VertexDescriptor(_POS, [
+        ("aTaskRect", 4, F32), ("aStartPoint", 2, F32), ("aEndPoint", 2, F32), ("aScale", 2, F32),
+        ("aExtendMode", 1, I32), ("aGradientStopsAddress", 1, I32)]),
     # vertex.rs:334-358
     "SCALE": VertexDescriptor(_POS, [
         ("aScaleTargetRect", 4, F32), ("aScaleSourceRect", 4, F32),

@@ -2126,7 +2126,10 @@ FASTGRAD_DTYPE = np.dtype([("task", "<f4", (4,)), ("c0", "<f4", (4,)), ("c1", "<
 LINE_SOLID, LINE_DOTTED, LINE_DASHED, LINE_WAVY = range(4)
 
 
-def cache_decorations(n_lines=60, n_grads=40, seed=151, atlas=1024):
+LGRAD_DTYPE = np.dtype([("task", "<f4", (4,)), ("start", "<f4", (2,)), ("end", "<f4", (2,)), ("scale", "<f4", (2,)), ("extend", "<i4"), ("addr", "<i4")])
+
+
+def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, seed=151, atlas=1024):
     rng = np.random.default_rng(seed)
     frame = Frame(atlas, atlas, (1.0, 1.0, 1.0, 1.0))
     t_cache = TextureRef("decoration_cache", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, render_target=True)
@@ -2190,9 +2193,40 @@ def cache_decorations(n_lines=60, n_grads=40, seed=151, atlas=1024):
         e["local"][0] = (local[1], local[0]) if vertical else local
         e["wavy"][0], e["style"][0], e["axis"][0] = wavy, style, 1.0 if vertical else 0.0
         lines.append(e)
+    # cs_linear_gradient (LinearGradientInstance, prim_store/gradient/linear.rs:727-734): multi-stop gradients through the
+    # 128-entry table in sGpuBufferF; start / end points in the task's (scaled) pixel space
+    lgrads = []
+    for k in range(n_lgrads):
+        w, h = float(rng.integers(12, 220)), float(rng.integers(8, 120))
+        o = place(w, h)
+        if o is None:
+            break
+        nst = int(rng.integers(2, 6))
+        offs = [0.0] + sorted(float(v) for v in rng.uniform(0.05, 0.95, size=nst - 2)) + [1.0]
+        if nst > 3 and k % 2:
+            offs[2] = offs[1]                                        # hard stop
+        cols = [tuple(float(v) for v in rng.uniform(0, 1, size=3)) + (float(rng.choice([1.0, 0.7])),) for _ in range(nst)]
+        addr = frame.gpu_buffer_f.push(build_gradient_lut(list(zip(offs, cols)), reverse=bool(k & 1)))
+        sc = (1.0, 1.0) if k % 3 else (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+        mode = k % 7
+        W, H = w * sc[0], h * sc[1]
+        if mode == 0:   sp, ep = (0.0, 0.0), (W, 0.0)
+        elif mode == 1: sp, ep = (0.0, 0.0), (0.0, H)
+        elif mode == 2: sp, ep = (0.0, 0.0), (W, H)
+        elif mode == 3: sp, ep = (W * 0.75, H * 0.5), (W * 0.25, H * 0.4)
+        elif mode == 4: sp, ep = (W * 0.3, 0.0), (W * 0.6, 0.0)
+        elif mode == 5: sp, ep = (float(rng.uniform(0, W)), float(rng.uniform(0, H))), (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
+        else:           sp, ep = (W * 0.5, H * 0.5), (W * 0.5, H * 0.5)      # degenerate line: delta is not finite
+        e = np.zeros(1, LGRAD_DTYPE)
+        e["task"][0] = (o[0], o[1], o[0] + w, o[1] + h)
+        e["start"][0], e["end"][0], e["scale"][0] = sp, ep, sc
+        e["extend"][0], e["addr"][0] = (1 if k % 4 == 1 else 0), addr
+        lgrads.append(e)
     tgt.steps.append(Step("cs_fast_linear_gradient", "FAST_LINEAR_GRADIENT", np.concatenate(grads), None, "none"))
+    if lgrads:
+        tgt.steps.append(Step("cs_linear_gradient", "LINEAR_GRADIENT", np.concatenate(lgrads), None, "none"))
     tgt.steps.append(Step("cs_line_decoration", "LINE", np.concatenate(lines), "PremultipliedAlpha", "none"))
     frame.passes.append([tgt])
     frame.readback = [t_cache]
-    frame.n_tasks = (len(grads), len(lines))
+    frame.n_tasks = (len(grads), len(lines), len(lgrads))
     return frame
