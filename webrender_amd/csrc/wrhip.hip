@@ -290,6 +290,7 @@ struct Context {
     // mask-row store (WrMaskSlot): allocation word, slot list, row bytes
     unsigned long long* mr_ctl = nullptr; WrMaskSlot* mr_slots = nullptr; size_t mr_slots_cap = 0;
     uint8_t* mr_store = nullptr; size_t mr_store_cap = 0;
+    unsigned long long mr_seen = 0;      // profiling: wr_mask_rows_kernel's byte count at the previous read-back
   } scratch[2];
   int64_t flush_seq = 0;
   // The raster launches of a flush are not issued with it: they are held back, and the first of them
@@ -904,8 +905,15 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     const int wgs = std::max(1, std::min((H.mr_rows + 3) / 4, 4096));
     prof_begin();
     WR_LAUNCH(wr_mask_rows_kernel, wgs, 256, c->stream, targets, H.off, H.off + H.nb, (const WrPrim*)S.prims, (const WrAux*)S.aux,
-              (const unsigned long long*)S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
+              S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
     prof_end(3, H.fmt, 0, 0, 0, (uint64_t)wgs);
+    if (c->profiling) {          // bytes this launch evaluated: the kernel's running count, read back (profiling syncs per launch anyway)
+      unsigned long long seen = 0;
+      wrrt::d2h(&seen, S.mr_ctl + 1, 8, c->stream);
+      wrrt::stream_sync(c->stream);
+      for (WrhipKernelStat& e : c->kstats) if (e.kind == 3 && e.fmt == H.fmt) e.algo_bytes += seen - S.mr_seen;
+      S.mr_seen = seen;
+    }
     c->stats.kernel_launches++;
   }
   prof_begin();
@@ -1305,7 +1313,7 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
     const uint8_t* dinst = darena + off_inst;
     const int* dblk = (const int*)(darena + off_blk);
-    if (mr_on) wrrt::memset8(S.mr_ctl, 0, 8, c->stream);     // (this set's previous user, two flushes back, has been launched)
+    if (mr_on) { wrrt::memset8(S.mr_ctl, 0, 16, c->stream); S.mr_seen = 0; }     // (this set's previous user, two flushes back, has been launched)
     if (n_prims > 0) {
 #ifdef WRHIP_TIMING
       static const int setup_mode = getenv("WRHIP_SETUP_MODE") ? atoi(getenv("WRHIP_SETUP_MODE")) : 0;

@@ -4692,7 +4692,7 @@ WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int
 }
 __global__ void __launch_bounds__(256) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                                                            const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
-                                                           const unsigned long long* __restrict__ ctl,
+                                                           unsigned long long* __restrict__ ctl,
                                                            const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
   const unsigned long long a = *ctl;
   const int ns = int(a >> 48), rows_total = int((a >> 28) & 0xFFFFFull);
@@ -4734,6 +4734,7 @@ __global__ void __launch_bounds__(256) wr_mask_rows_kernel(const WrTargetDesc* _
     const int y = Pp->y0 + (item - (int)sl.row0);
     if (y < T.y_begin || y >= T.y_end) continue;      // rows of another rank
     uint8_t* dst = store + (size_t)sl.off16 * 16 + (size_t)(y - Pp->y0) * sl.pitch + (Pp->x0 & 3);
+    if (lane == 0) atomicAdd(&ctl[1], (unsigned long long)(Pp->x1 - Pp->x0));     // bytes evaluated (profiling: the launch's algorithmic bytes)
     if (Pp->kind == WR_PK_BOX_SHADOW) wr_box_shadow_row_lanes(*Pp, aux[sl.prim].box, y, lane, dst);
     else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst);
   }
