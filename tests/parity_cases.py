@@ -90,4 +90,6 @@ DECORATIONS = [
     ("cache_decorations", dict()),
     ("cache_decorations_many", dict(n_lines=200, n_grads=60, n_lgrads=20, seed=152)),
     ("cache_linear_gradients", dict(n_lines=1, n_grads=1, n_lgrads=200, seed=153)),      # cs_linear_gradient: the span shader with tileRepeat off
+    ("cache_radial_gradients", dict(n_lines=1, n_grads=1, n_lgrads=1, n_rgrads=200, seed=162)),   # cs_radial_gradient: swgl_commitRadialGradientRGBA8
+    ("cache_all", dict(n_lines=40, n_grads=20, n_lgrads=20, n_rgrads=30, seed=163)),
 ]

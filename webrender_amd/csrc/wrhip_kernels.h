@@ -582,7 +582,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     G->scale_dir[0] = sdx * stx; G->scale_dir[1] = sdy * sty;
     G->address = data1.x;
     G->repeat = extend_mode == 1 ? 1.0f : 0.0f;
-    G->no_tile = 0;
+    G->no_tile = 0; G->radial = 0;
     // swgl_validateGradient(sGpuBufferF, get_gpu_buffer_uv(address), 130) (swgl_ext.h:1336-1347)
     const WrTexDesc& gb = d.tex[WR_S_GPU_BUFFER_F];
     const int ax = int(unsigned(data1.x) % 1024u), ay = int(unsigned(data1.x) / 1024u);
@@ -1137,7 +1137,7 @@ WR_DEVICE void wr_vs_cs_linear_gradient(const WrDrawDesc& d, const uint8_t* aren
   G->scale_dir[0] = sdx * (task.z - task.x); G->scale_dir[1] = sdy * (task.w - task.y);
   G->address = address;
   G->repeat = extend_mode == 1 ? 1.0f : 0.0f;
-  G->no_tile = 1;
+  G->no_tile = 1; G->radial = 0;
   const WrTexDesc& gb = d.tex[WR_S_GPU_BUFFER_F];
   const int ax = int(unsigned(address) % 1024u), ay = int(unsigned(address) / 1024u);
   const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width && ax + 2 * 130 <= gb.width;
@@ -1145,6 +1145,37 @@ WR_DEVICE void wr_vs_cs_linear_gradient(const WrDrawDesc& d, const uint8_t* aren
   for (int n = 0; n < 4; n++) {
     const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
     o.u[n] = ax_ * scale.x; o.v[n] = ay_ * scale.y;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{(task.z - task.x) * ax_ + task.x, (task.w - task.y) * ay_ + task.y, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_GPU_BUFFER_F;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.kind = WR_PK_GRADIENT;
+}
+
+// cs_radial_gradient.glsl:26-47 (vertex stage)
+WR_DEVICE void wr_vs_cs_radial_gradient(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrGradRec* G) {
+  const wf4 task = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf2 center = wr_load_attr<wf2>(d, arena, inst, 1), scale = wr_load_attr<wf2>(d, arena, inst, 2);
+  const float r0 = wr_load_attr<float>(d, arena, inst, 3), r1 = wr_load_attr<float>(d, arena, inst, 4), ratio = wr_load_attr<float>(d, arena, inst, 5);
+  const int extend_mode = wr_load_attr<int>(d, arena, inst, 6), address = wr_load_attr<int>(d, arena, inst, 7);
+  const float rd = r1 - r0;
+  const float radius_scale = rd != 0.0f ? 1.0f / rd : 0.0f;
+  G->start_offset = r0 * radius_scale;
+  G->scale_dir[0] = G->scale_dir[1] = 0.0f;
+  G->address = address;
+  G->repeat = extend_mode == 1 ? 1.0f : 0.0f;
+  G->no_tile = 1; G->radial = 1;
+  const WrTexDesc& gb = d.tex[WR_S_GPU_BUFFER_F];
+  const int ax = int(unsigned(address) % 1024u), ay = int(unsigned(address) / 1024u);
+  const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width && ax + 2 * 130 <= gb.width;
+  G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
+  for (int n = 0; n < 4; n++) {
+    const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
+    o.u[n] = (((task.z - task.x) * ax_) * scale.x - center.x) * radius_scale;
+    o.v[n] = ((((task.w - task.y) * ay_) * scale.y - center.y) * radius_scale) * ratio;
     const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{(task.z - task.x) * ax_ + task.x, (task.w - task.y) * ay_ + task.y, 0.0f, 1.0f});
     o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
   }
@@ -2726,6 +2757,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_FAST_LINEAR_GRADIENT: wr_vs_cs_fast_linear_gradient(d, arena, inst, o, aux[gid].fgrad); break;
     case WR_SH_CS_LINE_DECORATION: wr_vs_cs_line_decoration(d, arena, inst, o, aux[gid].line); break;
     case WR_SH_CS_LINEAR_GRADIENT: wr_vs_cs_linear_gradient(d, arena, inst, o, &aux[gid].grad); break;
+    case WR_SH_CS_RADIAL_GRADIENT: wr_vs_cs_radial_gradient(d, arena, inst, o, &aux[gid].grad); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -3344,11 +3376,124 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
   const float lu1 = px[1], lu2 = px[2], lu3 = px[3], lv1 = py[1], lv2 = py[2], lv3 = py[3];   // the lanes at the sub-span start
   const float psx = (px[1] - px[0]) * 4.0f, psy = (py[1] - py[0]) * 4.0f;   // dFdx(pos) * 4
   const float delta = psx * sdx + psy * sdy;
-  if (!G.stops || !wr_isfinite(delta)) span = 0;
+  if (!G.stops || (!G.radial && !wr_isfinite(delta))) span = 0;
   const int n_lo = wr_imax(x - X0, 0), n_hi = wr_imin(x + (kr >= 0 ? 0 : 3) - X0, len - 1);
   if (n_hi < n_lo) return out;
   const float size = 128.0f;
-  if (n_lo < span) {
+  if (G.radial) {
+    // commitRadialGradient (swgl_ext.h:1629-1835): the row is walked from the span start -- runs of whole chunks inside one
+    // merged table range (colour = colorF + deltaColorF * length(pos) per pixel), per-sample table chunks in between -- with
+    // dot(pos, pos) accumulated chunk by chunk; replayed up to the chunk(s) holding x .. x+3
+    const float radius = G.start_offset;
+    float ddx = px[1] - px[0], ddy = py[1] - py[0];
+    float dd = ddx * ddx + ddy * ddy;
+    if (!wr_isfinite(dd) || !wr_isfinite(radius)) span = 0;
+    if (n_lo < span) {
+      const float* stops = G.stops;
+      const int c_hi = wr_imin(n_hi, span - 1) >> 2, c_lo = n_lo >> 2;
+      const float fspan = float(span);
+      float invDelta, middleT, middleB;
+      if (dd > 0.0f) {
+        invDelta = 1.0f / dd;
+        middleT = -(ddx * px[0] + ddy * py[0]) * invDelta;
+        middleB = middleT * middleT - (px[0] * px[0] + py[0] * py[0]) * invDelta;
+      } else { invDelta = 0.0f; middleT = fspan; middleB = 0.0f; }
+      const float mx_ = px[0] + ddx * middleT, my_ = py[0] + ddy * middleT, ex_ = px[0] + ddx * fspan, ey_ = py[0] + ddy * fspan;
+      const float mer_x = sqrtf(wr_max(mx_ * mx_ + my_ * my_, 1.0e-12f)), mer_y = sqrtf(wr_max(ex_ * ex_ + ey_ * ey_, 1.0e-12f));
+      const float middleRadius = fspan < middleT ? mer_y : mer_x, endRadius = mer_y;
+      ddx *= 4.0f; ddy *= 4.0f; dd *= 16.0f;
+      float dotPos[4], dotPosDelta[4], off[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { dotPos[i] = px[i] * px[i] + py[i] * py[i]; dotPosDelta[i] = 2.0f * (px[i] * ddx + py[i] * ddy) + dd; }
+      const float dd2 = 2.0f * dd;
+      for (int t = 0; t < span && (t >> 2) <= c_hi;) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) off[i] = sqrtf(wr_max(dotPos[i], 1.0e-12f)) - radius;
+        float startRadius = radius;
+        if (G.repeat != 0.0f) {
+          startRadius += off[0];
+#pragma unroll
+          for (int i = 0; i < 4; i++) off[i] = wr_fract(off[i]);
+          startRadius -= off[0];
+        }
+        float intercept = -1.0f;
+        int minIndex = 0, maxIndex = int(1.0f + size);
+        const bool past = float(t) >= middleT;
+        if (off[0] < 0.0f) {
+          maxIndex = minIndex;
+          if (past) intercept = radius;
+        } else if (off[0] < 1.0f) {
+          minIndex = int(1.0f + off[0] * size);
+          maxIndex = minIndex;
+          const float searchOffset = (past ? endRadius : middleRadius) - startRadius;
+          const int searchIndex = int(wr_clamp(1.0f + size * searchOffset, 1.0f, size));
+          if (past) {
+            while (maxIndex + 1 <= searchIndex && wr_stops_merge(stops, maxIndex, maxIndex + 1)) maxIndex++;
+            intercept = float(maxIndex + 1);
+          } else {
+            while (minIndex - 1 >= searchIndex && wr_stops_merge(stops, minIndex - 1, minIndex)) minIndex--;
+            intercept = float(minIndex);
+          }
+          intercept = wr_clamp((intercept - 1.0f) / size, 0.0f, 1.0f) + startRadius;
+        } else {
+          minIndex = maxIndex;
+          if (!past) intercept = radius + 1.0f;
+        }
+        float endT = past ? fspan : float(wr_imin(span, int(middleT)));
+        if (intercept >= 0.0f) {
+          float b = middleB + intercept * intercept * invDelta;
+          if (b > 0.0f) { b = sqrtf(b); endT = wr_min(endT, past ? middleT + b : middleT - b); }
+          else endT = wr_min(endT, middleT);
+        }
+        if (float(t) + 4.0f <= endT) {
+          const int inside = int(endT - float(t)) & ~3;
+          const float* s0 = stops + 8 * minIndex; const float* s1 = stops + 8 * maxIndex;
+          const float mn[4] = {s0[2] * 255.0f, s0[1] * 255.0f, s0[0] * 255.0f, s0[3] * 255.0f};
+          const float mxc[4] = {(s1[2] + s1[6]) * 255.0f, (s1[1] + s1[5]) * 255.0f, (s1[0] + s1[4]) * 255.0f, (s1[3] + s1[7]) * 255.0f};
+          const float k = size / float(maxIndex + 1 - minIndex);
+          const float base = startRadius + float(minIndex - 1) / size;
+          float dcol[4], col[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) { dcol[q] = (mxc[q] - mn[q]) * k; col[q] = mn[q] - dcol[q] * base; }
+          for (int c = 0; c < inside; c += 4) {
+            const int chunk = (t + c) >> 2;
+            if (chunk >= c_lo && chunk <= c_hi) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                const int o = X0 + t + c + i - x;
+                if (o >= 0 && o < 4) {
+                  const float og = sqrtf(dotPos[i]);
+                  const uint32_t cb = wr_u16_round1(col[0] + dcol[0] * og), cg = wr_u16_round1(col[1] + dcol[1] * og);
+                  const uint32_t cr = wr_u16_round1(col[2] + dcol[2] * og), ca = wr_u16_round1(col[3] + dcol[3] * og);
+                  out.v[o].bg = cb | (cg << 16); out.v[o].ra = cr | (ca << 16);
+                }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { dotPos[i] += dotPosDelta[i]; dotPosDelta[i] += dd2; }
+          }
+          t += inside;
+          if (t >= span) break;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            off[i] = sqrtf(wr_max(dotPos[i], 1.0e-12f)) - radius;
+            if (G.repeat != 0.0f) off[i] = wr_fract(off[i]);
+          }
+        }
+        const int chunk = t >> 2;
+        if (chunk >= c_lo && chunk <= c_hi) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int o = X0 + t + i - x;
+            if (o >= 0 && o < 4) out.v[o] = wr_sample_gradient(stops, wr_clamp(off[i] * size + 1.0f, 0.0f, 1.0f + size));
+          }
+        }
+        t += 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { dotPos[i] += dotPosDelta[i]; dotPosDelta[i] += dd2; }
+      }
+    }
+  } else if (n_lo < span) {
     const float* stops = G.stops;
     const int c_lo = n_lo >> 2, c_hi = wr_imin(n_hi, span - 1) >> 2;     // chunks wanted
     float dcxx = 0.25f * float(span), dcxy = 0.0f, dcyx = dcxx, dcyy = 0.0f;
@@ -3461,6 +3606,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
       }
       lu = wr_accum(lu, (su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (sv * 4.0f) * 1.0f, m);
       float offset = (G.no_tile ? lu : wr_fract(lu)) * sdx + (G.no_tile ? lv : wr_fract(lv)) * sdy - G.start_offset;
+      if (G.radial) offset = sqrtf(lu * lu + lv * lv) - G.start_offset;                   // length(v_pos) - v_start_radius.x
       offset -= floorf(offset) * G.repeat;
       const float xe = wr_clamp(1.0f + offset * 128.0f, 0.0f, 1.0f + 128.0f);
       const float ei = floorf(xe), ef = xe - ei;

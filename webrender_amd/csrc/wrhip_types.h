@@ -67,6 +67,7 @@ enum WrShader {
   WR_SH_CS_FAST_LINEAR_GRADIENT,
   WR_SH_CS_LINE_DECORATION,
   WR_SH_CS_LINEAR_GRADIENT,
+  WR_SH_CS_RADIAL_GRADIENT,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -378,6 +379,7 @@ struct WrGradRec {
   float scale_dir[2];       // v_scale_dir
   float start_offset;       // v_start_offset.x
   int32_t no_tile;          // cs_linear_gradient: v_pos is not wrapped to [0,1) (commitLinearGradient's tileRepeat == false)
+  int32_t radial;           // cs_radial_gradient: offset = length(v_pos) - start_offset (= v_start_radius.x), swgl_commitRadialGradientRGBA8
 };
 
 // brush_blend flat varyings (brush_blend.glsl:17-41)

@@ -67,6 +67,10 @@ DESC = {
     "LINEAR_GRADIENT": VertexDescriptor(_POS, [
         ("aTaskRect", 4, F32), ("aStartPoint", 2, F32), ("aEndPoint", 2, F32), ("aScale", 2, F32),
         ("aExtendMode", 1, I32), ("aGradientStopsAddress", 1, I32)]),
+    # vertex.rs:181-229 (RadialGradientInstance, prim_store/gradient/radial.rs)
+    "RADIAL_GRADIENT": VertexDescriptor(_POS, [
+        ("aTaskRect", 4, F32), ("aCenter", 2, F32), ("aScale", 2, F32), ("aStartRadius", 1, F32), ("aEndRadius", 1, F32),
+        ("aXYRatio", 1, F32), ("aExtendMode", 1, I32), ("aGradientStopsAddress", 1, I32)]),
     # vertex.rs:334-358
     "SCALE": VertexDescriptor(_POS, [
         ("aScaleTargetRect", 4, F32), ("aScaleSourceRect", 4, F32),

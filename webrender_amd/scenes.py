@@ -2129,7 +2129,11 @@ LINE_SOLID, LINE_DOTTED, LINE_DASHED, LINE_WAVY = range(4)
 LGRAD_DTYPE = np.dtype([("task", "<f4", (4,)), ("start", "<f4", (2,)), ("end", "<f4", (2,)), ("scale", "<f4", (2,)), ("extend", "<i4"), ("addr", "<i4")])
 
 
-def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, seed=151, atlas=1024):
+RGRAD_DTYPE = np.dtype([("task", "<f4", (4,)), ("center", "<f4", (2,)), ("scale", "<f4", (2,)), ("r0", "<f4"), ("r1", "<f4"), ("ratio", "<f4"),
+                        ("extend", "<i4"), ("addr", "<i4")])
+
+
+def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, seed=151, atlas=1024):
     rng = np.random.default_rng(seed)
     frame = Frame(atlas, atlas, (1.0, 1.0, 1.0, 1.0))
     t_cache = TextureRef("decoration_cache", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, render_target=True)
@@ -2222,11 +2226,41 @@ def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, seed=151, atlas=1024)
         e["start"][0], e["end"][0], e["scale"][0] = sp, ep, sc
         e["extend"][0], e["addr"][0] = (1 if k % 4 == 1 else 0), addr
         lgrads.append(e)
+    # cs_radial_gradient (RadialGradientInstance): centre / radii in the task's (scaled) pixel space, elliptical through xy_ratio
+    rgrads = []
+    for k in range(n_rgrads):
+        w, h = float(rng.integers(12, 220)), float(rng.integers(8, 120))
+        o = place(w, h)
+        if o is None:
+            break
+        nst = int(rng.integers(2, 6))
+        offs = [0.0] + sorted(float(v) for v in rng.uniform(0.05, 0.95, size=nst - 2)) + [1.0]
+        if nst > 3 and k % 2:
+            offs[2] = offs[1]
+        cols = [tuple(float(v) for v in rng.uniform(0, 1, size=3)) + (float(rng.choice([1.0, 0.7])),) for _ in range(nst)]
+        addr = frame.gpu_buffer_f.push(build_gradient_lut(list(zip(offs, cols)), reverse=bool(k & 1)))
+        sc = (1.0, 1.0) if k % 3 else (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+        W, H = w * sc[0], h * sc[1]
+        mode = k % 6
+        if mode == 0:   c, r0, r1 = (W * 0.5, H * 0.5), 0.0, min(W, H) * 0.5
+        elif mode == 1: c, r0, r1 = (0.0, 0.0), 0.0, float(np.hypot(W, H))
+        elif mode == 2: c, r0, r1 = (W * 0.3, H * 0.7), min(W, H) * 0.1, min(W, H) * 0.4
+        elif mode == 3: c, r0, r1 = (float(rng.uniform(-W, 2 * W)), float(rng.uniform(-H, 2 * H))), float(rng.uniform(0, 30)), float(rng.uniform(40, 200))
+        elif mode == 4: c, r0, r1 = (W * 0.5, H * 0.5), 10.0, 10.0                       # zero-length radius range: radius_scale = 0
+        else:           c, r0, r1 = (W * 0.5, -H), H * 0.9, H * 2.5                      # every row's span misses the centre row
+        e = np.zeros(1, RGRAD_DTYPE)
+        e["task"][0] = (o[0], o[1], o[0] + w, o[1] + h)
+        e["center"][0], e["scale"][0] = c, sc
+        e["r0"][0], e["r1"][0], e["ratio"][0] = r0, r1, (1.0 if k % 4 else float(rng.uniform(0.4, 2.5)))
+        e["extend"][0], e["addr"][0] = (1 if k % 4 == 1 else 0), addr
+        rgrads.append(e)
     tgt.steps.append(Step("cs_fast_linear_gradient", "FAST_LINEAR_GRADIENT", np.concatenate(grads), None, "none"))
+    if rgrads:
+        tgt.steps.append(Step("cs_radial_gradient", "RADIAL_GRADIENT", np.concatenate(rgrads), None, "none"))
     if lgrads:
         tgt.steps.append(Step("cs_linear_gradient", "LINEAR_GRADIENT", np.concatenate(lgrads), None, "none"))
     tgt.steps.append(Step("cs_line_decoration", "LINE", np.concatenate(lines), "PremultipliedAlpha", "none"))
     frame.passes.append([tgt])
     frame.readback = [t_cache]
-    frame.n_tasks = (len(grads), len(lines), len(lgrads))
+    frame.n_tasks = (len(grads), len(lines), len(lgrads), len(rgrads))
     return frame
