@@ -24,6 +24,7 @@
 #include "cs_line_decoration.h"
 #include "cs_linear_gradient.h"
 #include "cs_radial_gradient.h"
+#include "cs_conic_gradient.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -64,6 +65,7 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_line_decoration", cs_line_decoration)
   WRSH_ENTRY("cs_linear_gradient", cs_linear_gradient)
   WRSH_ENTRY("cs_radial_gradient", cs_radial_gradient)
+  WRSH_ENTRY("cs_conic_gradient", cs_conic_gradient)
 #undef WRSH_ENTRY
   return nullptr;
 }

@@ -92,4 +92,6 @@ DECORATIONS = [
     ("cache_linear_gradients", dict(n_lines=1, n_grads=1, n_lgrads=200, seed=153)),      # cs_linear_gradient: the span shader with tileRepeat off
     ("cache_radial_gradients", dict(n_lines=1, n_grads=1, n_lgrads=1, n_rgrads=200, seed=162)),   # cs_radial_gradient: swgl_commitRadialGradientRGBA8
     ("cache_all", dict(n_lines=40, n_grads=20, n_lgrads=20, n_rgrads=30, seed=163)),
+    # cs_conic_gradient: main() with libm atan2f -- bit-exact on the host build (same libm as the oracle), within 1 LSB on the GPU
+    ("cache_conic_gradients", dict(n_lines=1, n_grads=1, n_lgrads=1, n_rgrads=0, n_cgrads=150, seed=171)),
 ]

@@ -184,6 +184,9 @@ const ShaderInfo SHADERS[] = {
     {"cs_radial_gradient", WR_SH_CS_RADIAL_GRADIENT,
      {"aPosition", "aTaskRect", "aCenter", "aScale", "aStartRadius", "aEndRadius", "aXYRatio", "aExtendMode", "aGradientStopsAddress"},
      1u << WR_S_GPU_BUFFER_F},
+    {"cs_conic_gradient", WR_SH_CS_CONIC_GRADIENT,
+     {"aPosition", "aTaskRect", "aCenter", "aScale", "aStartOffset", "aEndOffset", "aAngle", "aExtendMode", "aGradientStopsAddress"},
+     1u << WR_S_GPU_BUFFER_F},
     {"cs_blur ALPHA_TARGET", WR_SH_CS_BLUR_ALPHA,
      {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
     {"cs_blur COLOR_TARGET", WR_SH_CS_BLUR_COLOR,
@@ -1394,7 +1397,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_CS_BLUR_ALPHA: case WR_SH_CS_BLUR_COLOR: f = WR_FEAT_BLUR; break;
           case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW:
             f = ((draws[i].flags & WR_DF_MASK_ROWS) && mr_safe) ? WR_FEAT_BLUR : WR_FEAT_CLIP; break;
-          case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: case WR_SH_CS_LINEAR_GRADIENT: case WR_SH_CS_RADIAL_GRADIENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: case WR_SH_CS_LINEAR_GRADIENT: case WR_SH_CS_RADIAL_GRADIENT: case WR_SH_CS_CONIC_GRADIENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: case WR_SH_CS_FAST_LINEAR_GRADIENT: case WR_SH_CS_LINE_DECORATION:

@@ -1186,6 +1186,36 @@ WR_DEVICE void wr_vs_cs_radial_gradient(const WrDrawDesc& d, const uint8_t* aren
   o.kind = WR_PK_GRADIENT;
 }
 
+// cs_conic_gradient.glsl:30-48 (vertex stage); no span function: main() per pixel with libm atan2f
+WR_DEVICE void wr_vs_cs_conic_gradient(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrGradRec* G) {
+  const wf4 task = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf2 center = wr_load_attr<wf2>(d, arena, inst, 1), scale = wr_load_attr<wf2>(d, arena, inst, 2);
+  const float o0 = wr_load_attr<float>(d, arena, inst, 3), o1 = wr_load_attr<float>(d, arena, inst, 4), angle = wr_load_attr<float>(d, arena, inst, 5);
+  const int extend_mode = wr_load_attr<int>(d, arena, inst, 6), address = wr_load_attr<int>(d, arena, inst, 7);
+  const float dd = o1 - o0;
+  const float offset_scale = dd != 0.0f ? 1.0f / dd : 0.0f;
+  G->conic_scale = offset_scale;
+  G->conic_angle = 3.141592653589793f / 2.0f - angle;
+  G->start_offset = o0 * offset_scale;
+  G->scale_dir[0] = center.x * offset_scale; G->scale_dir[1] = center.y * offset_scale;
+  G->address = address;
+  G->repeat = extend_mode == 1 ? 1.0f : 0.0f;
+  G->no_tile = 1; G->radial = 2;
+  G->stops = nullptr;                          // no span shader
+  for (int n = 0; n < 4; n++) {
+    const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
+    o.u[n] = (((task.z - task.x) * ax_) * offset_scale) * scale.x;
+    o.v[n] = (((task.w - task.y) * ay_) * offset_scale) * scale.y;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{(task.z - task.x) * ax_ + task.x, (task.w - task.y) * ay_ + task.y, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{0, 0, 0, 0};
+  o.tex_slot = WR_S_GPU_BUFFER_F;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.kind = WR_PK_GRADIENT;
+}
+
 // cs_fast_linear_gradient.glsl:17-24 and cs_line_decoration.glsl:43-98 (vertex stages).  Neither program has a span function.
 WR_DEVICE float wr_mixf(float x, float y, float a) { return (y - x) * a + x; }      // glsl.h:2691-2700
 WR_DEVICE void wr_vs_cs_fast_linear_gradient(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrFastGradRec& G) {
@@ -2758,6 +2788,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_LINE_DECORATION: wr_vs_cs_line_decoration(d, arena, inst, o, aux[gid].line); break;
     case WR_SH_CS_LINEAR_GRADIENT: wr_vs_cs_linear_gradient(d, arena, inst, o, &aux[gid].grad); break;
     case WR_SH_CS_RADIAL_GRADIENT: wr_vs_cs_radial_gradient(d, arena, inst, o, &aux[gid].grad); break;
+    case WR_SH_CS_CONIC_GRADIENT: wr_vs_cs_conic_gradient(d, arena, inst, o, &aux[gid].grad); break;
     default:
       P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; P.draw = lo; P.blend = 0; P.flags = 0; P.z = 0;
       P.color[0] = P.color[1] = 0;
@@ -3376,11 +3407,11 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
   const float lu1 = px[1], lu2 = px[2], lu3 = px[3], lv1 = py[1], lv2 = py[2], lv3 = py[3];   // the lanes at the sub-span start
   const float psx = (px[1] - px[0]) * 4.0f, psy = (py[1] - py[0]) * 4.0f;   // dFdx(pos) * 4
   const float delta = psx * sdx + psy * sdy;
-  if (!G.stops || (!G.radial && !wr_isfinite(delta))) span = 0;
+  if (!G.stops || G.radial == 2 || (!G.radial && !wr_isfinite(delta))) span = 0;
   const int n_lo = wr_imax(x - X0, 0), n_hi = wr_imin(x + (kr >= 0 ? 0 : 3) - X0, len - 1);
   if (n_hi < n_lo) return out;
   const float size = 128.0f;
-  if (G.radial) {
+  if (G.radial == 1) {
     // commitRadialGradient (swgl_ext.h:1629-1835): the row is walked from the span start -- runs of whole chunks inside one
     // merged table range (colour = colorF + deltaColorF * length(pos) per pixel), per-sample table chunks in between -- with
     // dot(pos, pos) accumulated chunk by chunk; replayed up to the chunk(s) holding x .. x+3
@@ -3606,7 +3637,11 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
       }
       lu = wr_accum(lu, (su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (sv * 4.0f) * 1.0f, m);
       float offset = (G.no_tile ? lu : wr_fract(lu)) * sdx + (G.no_tile ? lv : wr_fract(lv)) * sdy - G.start_offset;
-      if (G.radial) offset = sqrtf(lu * lu + lv * lv) - G.start_offset;                   // length(v_pos) - v_start_radius.x
+      if (G.radial == 1) offset = sqrtf(lu * lu + lv * lv) - G.start_offset;              // length(v_pos) - v_start_radius.x
+      if (G.radial == 2) {                                                                // cs_conic_gradient.glsl:52-65
+        const float cur = atan2f(lv - G.scale_dir[1], lu - G.scale_dir[0]) + G.conic_angle;
+        offset = wr_fract(cur / (2.0f * 3.141592653589793f)) * G.conic_scale - G.start_offset;
+      }
       offset -= floorf(offset) * G.repeat;
       const float xe = wr_clamp(1.0f + offset * 128.0f, 0.0f, 1.0f + 128.0f);
       const float ei = floorf(xe), ef = xe - ei;

@@ -71,6 +71,10 @@ DESC = {
     "RADIAL_GRADIENT": VertexDescriptor(_POS, [
         ("aTaskRect", 4, F32), ("aCenter", 2, F32), ("aScale", 2, F32), ("aStartRadius", 1, F32), ("aEndRadius", 1, F32),
         ("aXYRatio", 1, F32), ("aExtendMode", 1, I32), ("aGradientStopsAddress", 1, I32)]),
+    # vertex.rs:231-279 (ConicGradientInstance, prim_store/gradient/conic.rs)
+    "CONIC_GRADIENT": VertexDescriptor(_POS, [
+        ("aTaskRect", 4, F32), ("aCenter", 2, F32), ("aScale", 2, F32), ("aStartOffset", 1, F32), ("aEndOffset", 1, F32),
+        ("aAngle", 1, F32), ("aExtendMode", 1, I32), ("aGradientStopsAddress", 1, I32)]),
     # vertex.rs:334-358
     "SCALE": VertexDescriptor(_POS, [
         ("aScaleTargetRect", 4, F32), ("aScaleSourceRect", 4, F32),

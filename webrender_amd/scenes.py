@@ -2133,7 +2133,7 @@ RGRAD_DTYPE = np.dtype([("task", "<f4", (4,)), ("center", "<f4", (2,)), ("scale"
                         ("extend", "<i4"), ("addr", "<i4")])
 
 
-def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, seed=151, atlas=1024):
+def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, n_cgrads=0, seed=151, atlas=1024):
     rng = np.random.default_rng(seed)
     frame = Frame(atlas, atlas, (1.0, 1.0, 1.0, 1.0))
     t_cache = TextureRef("decoration_cache", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, render_target=True)
@@ -2254,7 +2254,30 @@ def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, seed=151,
         e["r0"][0], e["r1"][0], e["ratio"][0] = r0, r1, (1.0 if k % 4 else float(rng.uniform(0.4, 2.5)))
         e["extend"][0], e["addr"][0] = (1 if k % 4 == 1 else 0), addr
         rgrads.append(e)
+    # cs_conic_gradient (ConicGradientInstance): same instance layout as the radial one with (start offset, end offset, angle)
+    cgrads = []
+    for k in range(n_cgrads):
+        w, h = float(rng.integers(12, 220)), float(rng.integers(8, 120))
+        o = place(w, h)
+        if o is None:
+            break
+        nst = int(rng.integers(2, 6))
+        offs = [0.0] + sorted(float(v) for v in rng.uniform(0.05, 0.95, size=nst - 2)) + [1.0]
+        cols = [tuple(float(v) for v in rng.uniform(0, 1, size=3)) + (float(rng.choice([1.0, 0.7])),) for _ in range(nst)]
+        addr = frame.gpu_buffer_f.push(build_gradient_lut(list(zip(offs, cols)), reverse=bool(k & 1)))
+        sc = (1.0, 1.0) if k % 3 else (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+        W, H = w * sc[0], h * sc[1]
+        e = np.zeros(1, RGRAD_DTYPE)
+        e["task"][0] = (o[0], o[1], o[0] + w, o[1] + h)
+        e["center"][0] = (W * 0.5, H * 0.5) if k % 2 else (float(rng.uniform(-W * 0.2, W * 1.2)), float(rng.uniform(-H * 0.2, H * 1.2)))
+        e["scale"][0] = sc
+        e["r0"][0], e["r1"][0] = (0.0, 1.0) if k % 3 else (float(rng.uniform(0.0, 0.3)), float(rng.uniform(0.5, 1.0)))
+        e["ratio"][0] = float(rng.uniform(0.0, 2.0 * np.pi)) if k % 4 else 0.0          # the angle
+        e["extend"][0], e["addr"][0] = (1 if k % 4 == 1 else 0), addr
+        cgrads.append(e)
     tgt.steps.append(Step("cs_fast_linear_gradient", "FAST_LINEAR_GRADIENT", np.concatenate(grads), None, "none"))
+    if cgrads:
+        tgt.steps.append(Step("cs_conic_gradient", "CONIC_GRADIENT", np.concatenate(cgrads), None, "none"))
     if rgrads:
         tgt.steps.append(Step("cs_radial_gradient", "RADIAL_GRADIENT", np.concatenate(rgrads), None, "none"))
     if lgrads:
@@ -2262,5 +2285,5 @@ def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, seed=151,
     tgt.steps.append(Step("cs_line_decoration", "LINE", np.concatenate(lines), "PremultipliedAlpha", "none"))
     frame.passes.append([tgt])
     frame.readback = [t_cache]
-    frame.n_tasks = (len(grads), len(lines), len(lgrads), len(rgrads))
+    frame.n_tasks = (len(grads), len(lines), len(lgrads), len(rgrads), len(cgrads))
     return frame
