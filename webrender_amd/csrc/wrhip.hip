@@ -1157,9 +1157,9 @@ void flush_work(const std::vector<int>& sel_in) {
         const int ch = std::max(0, std::min(d.clip[3], t.height) - std::max(d.clip[1], 0));
         if (cw > 0 && ch > 0 && d.count > 0) {
           d.flags |= WR_DF_MASK_ROWS;
-          mr_slots += (uint64_t)d.count; mr_rows += (uint64_t)d.count * ch;
-          mr_bytes += (uint64_t)d.count * ((uint64_t)((cw + 7) & ~3) * ch + 16);
-          L.mr_rows += (uint64_t)d.count * ch;
+          mr_slots += (uint64_t)d.count; mr_rows += (uint64_t)d.count * ch * 1;      // work items: rows x parts
+          mr_bytes += (uint64_t)d.count * ((uint64_t)((cw + 7) & ~3) * ch + (uint64_t)ch * 4 + 32);      // rows + row map
+          L.mr_rows += (uint64_t)d.count * ch * 1;
         }
       }
       if ((d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) && T.format == WR_FMT_RGBA8) L.any_depth = true;

@@ -2962,6 +2962,125 @@ WR_DEVICE int wr_texrow_entry(const WrTexRec& T, float ov_raw) {
   return wr_clamp_coord(wr_iclamp(iy, minUy, maxUy), th);
 }
 
+WR_DEVICE float wr_step01(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
+// ---- cs_clip_box_shadow row setup (used by the setup stage for the mask-row key of a prim's middle row, by the rows kernel and
+// by the in-raster evaluation) ----
+// row interpolants of a cs_clip_box_shadow prim: c = 0,1 vUv; 2,3 vLocalPos.xy
+struct WrRowVals { float o[4], s[4]; };
+WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
+  WrRowVals rv;
+  const int k = y - P.y0;
+  const bool lin = P.rows_linear != 0;     // (the vLocalPos interpolants share the uv ones' linearity in practice; wr_accum checks)
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  const float L0 = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+  const float R0 = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+  const float L2 = wr_accum(B.lpL0[0], B.lpLs[0], k), L3 = wr_accum(B.lpL0[1], B.lpLs[1], k);
+  const float R2 = wr_accum(B.lpR0[0], B.lpRs[0], k), R3 = wr_accum(B.lpR0[1], B.lpRs[1], k);
+  rv.s[0] = (R0 - L0) * stepScale; rv.o[0] = L0 + rv.s[0] * start;
+  rv.s[1] = (R1 - L1) * stepScale; rv.o[1] = L1 + rv.s[1] * start;
+  rv.s[2] = (R2 - L2) * stepScale; rv.o[2] = L2 + rv.s[2] * start;
+  rv.s[3] = (R3 - L3) * stepScale; rv.o[3] = L3 + rv.s[3] * start;
+  return rv;
+}
+
+// Span-level setup of a cs_clip_box_shadow row (cs_clip_box_shadow.glsl:150-250): where the shadow rect and the four
+// nine-patch sector boundaries fall along the row, as remaining span lengths.  Prim and row only: evaluated by the
+// row-owning lanes of a wave and handed round (see WrClipRow).
+struct WrBoxRow {
+  int ss_se, os01, os23;       // shadow_start_len | shadow_end_len << 16, os0 | os1 << 16, os2 | os3 << 16
+  int xc;                      // [pa, pb) = xc & 0xFFFF, xc >> 16: the run of the row in which u is clamped to the nine-patch's stretched
+                               // middle column -- every pixel of it samples the same texel, so it has ONE value,
+  uint32_t vrow;               // ... this one (wr_box_row_finish evaluates a single pixel of the run)
+};
+WR_DEVICE WrBoxRow wr_box_row_setup(const WrPrim& P, const WrBoxRec& B, const WrRowVals& rv) {
+  WrBoxRow br;
+  br.ss_se = br.os01 = br.os23 = 0; br.xc = 0; br.vrow = 0;
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
+  if (span <= 0 || !(B.w > 0.0f)) return br;
+  const float w = 1.0f / B.w;
+  float cur[4][1], st[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { cur[c][0] = rv.o[c] * w; st[c] = (rv.s[c] * 4.0f) * w; }
+  const float sl = float(span), ss = 4.0f;
+  int shadow_start_len, shadow_end_len, os0, os1, os2, os3;
+  {
+    const float p0x = cur[2][0], p0y = cur[3][0];
+    const bool negx = st[2] < 0.0f, negy = st[3] < 0.0f;
+    float cd0 = (negx ? B.bounds[2] : B.bounds[0]) - p0x, cd1 = (negy ? B.bounds[3] : B.bounds[1]) - p0y;
+    float cd2 = (negx ? B.bounds[0] : B.bounds[2]) - p0x, cd3 = (negy ? B.bounds[1] : B.bounds[3]) - p0y;
+    const float rsx = 1.0f / st[2], rsy = 1.0f / st[3];
+    cd0 = st[2] != 0.0f ? cd0 * rsx : 1.0e6f * wr_step01(0.0f, cd0);
+    cd1 = st[3] != 0.0f ? cd1 * rsy : 1.0e6f * wr_step01(0.0f, cd1);
+    cd2 = st[2] != 0.0f ? cd2 * rsx : 1.0e6f * wr_step01(0.0f, cd2);
+    cd3 = st[3] != 0.0f ? cd3 * rsy : 1.0e6f * wr_step01(0.0f, cd3);
+    const float shadow_start = wr_max(cd0, cd1), shadow_end = wr_min(cd2, cd3);
+    shadow_start_len = int(wr_clamp(sl - ss * floorf(shadow_start), 0.0f, sl));
+    shadow_end_len = int(wr_clamp(sl - ss * ceilf(shadow_end), 0.0f, sl));
+    const float u0 = cur[0][0], v0 = cur[1][0];
+    const bool ngx = st[0] < 0.0f, ngy = st[1] < 0.0f;
+    float od0 = (ngx ? B.edge[2] : B.edge[0]) - u0, od1 = (ngy ? B.edge[3] : B.edge[1]) - v0;
+    float od2 = (ngx ? B.edge[0] : B.edge[2]) - u0, od3 = (ngy ? B.edge[1] : B.edge[3]) - v0;
+    const float rux = 1.0f / st[0], ruy = 1.0f / st[1];
+    od0 = st[0] != 0.0f ? od0 * rux : 1.0e6f * wr_step01(0.0f, od0);
+    od1 = st[1] != 0.0f ? od1 * ruy : 1.0e6f * wr_step01(0.0f, od1);
+    od2 = st[0] != 0.0f ? od2 * rux : 1.0e6f * wr_step01(0.0f, od2);
+    od3 = st[1] != 0.0f ? od3 * ruy : 1.0e6f * wr_step01(0.0f, od3);
+    const float sel = float(shadow_end_len);
+    os0 = int(wr_clamp(sl - ss * floorf(od0), sel, sl)); os1 = int(wr_clamp(sl - ss * floorf(od1), sel, sl));
+    os2 = int(wr_clamp(sl - ss * floorf(od2), sel, sl)); os3 = int(wr_clamp(sl - ss * floorf(od3), sel, sl));
+  }
+  br.ss_se = shadow_start_len | (shadow_end_len << 16); br.os01 = os0 | (os1 << 16); br.os23 = os2 | (os3 << 16);
+  // the walk of wr_box_shadow_row4, control flow only (it is all integer): find the run with u clamped
+  {
+    int R = span, pos = 0;
+    if (R > shadow_start_len) { const int nb = R - shadow_start_len; R -= nb; pos += nb; }
+    for (int guard = 0; guard < 16 && R > 0; guard++) {
+      R -= 4; pos += 4;
+      if (R <= shadow_end_len) break;
+      int num_inside = R - 4 - shadow_end_len;
+      bool xcl = false;
+      if (R >= os1) num_inside = wr_imin(num_inside, R - os1);
+      else if (R >= os3) num_inside = wr_imin(num_inside, R - os3);
+      if (R >= os0) num_inside = wr_imin(num_inside, R - os0);
+      else if (R >= os2) { num_inside = wr_imin(num_inside, R - os2); xcl = true; }
+      if (num_inside > 0) {
+        if (xcl && num_inside >= 8 && br.xc == 0) br.xc = pos | ((pos + num_inside) << 16);
+        R -= num_inside; pos += num_inside;
+      }
+    }
+  }
+  return br;
+}
+
+// Row key of a cs_clip_box_shadow prim on an axis-aligned transform (v and local y constant along the row: s[1] == s[3] == 0).
+// Everything wr_box_shadow_row_lanes computes from the row's v / local y goes through (a) the span lengths of
+// wr_box_row_setup, (b) wr_box_map_uv's v -- constant between the nine-patch's edges -- of o[1] * (1 / w) (span chunks) and of
+// o[1] / w (tail pixels), (c) the in-bounds factor of wr_box_shade for o[3] * (1 / w) and o[3] / w.  Two rows with equal keys
+// and equal x interpolants produce the same bytes.
+WR_DEVICE float wr_box_map_v(const WrBoxRec& B, float vl) {
+  float v = wr_clamp(vl, 0.0f, B.edge[1]);
+  v += wr_max(0.0f, vl - B.edge[3]);
+  return (B.uv_noclamp[3] - B.uv_noclamp[1]) * v + B.uv_noclamp[1];
+}
+WR_DEVICE WrBoxKey wr_box_row_key(const WrPrim& P, const WrBoxRec& B, const WrRowVals& r, const WrBoxRow& b) {
+  WrBoxKey k;
+  k.valid = (r.s[1] == 0.0f && r.s[3] == 0.0f && B.w > 0.0f) ? 1 : 0;
+  k.o0 = r.o[0]; k.s0 = r.s[0]; k.o2 = r.o[2]; k.s2 = r.s[2];
+  k.ss_se = b.ss_se; k.os01 = b.os01; k.os23 = b.os23;
+  const float w = 1.0f / B.w;
+  k.mv_mul = wr_box_map_v(B, r.o[1] * w); k.mv_div = wr_box_map_v(B, r.o[1] / B.w);
+  const float l = r.o[3] * w, ld = r.o[3] / B.w;
+  k.in_mul = wr_step01(B.bounds[1], l) - wr_step01(B.bounds[3], l);
+  k.in_div = wr_step01(B.bounds[1], ld) - wr_step01(B.bounds[3], ld);
+  return k;
+}
+WR_DEVICE bool wr_box_keys_equal(const WrBoxKey& a, const WrBoxKey& b) {
+  return a.valid && b.valid && a.o0 == b.o0 && a.s0 == b.s0 && a.o2 == b.o2 && a.s2 == b.s2 && a.ss_se == b.ss_se && a.os01 == b.os01 &&
+         a.os23 == b.os23 && a.mv_mul == b.mv_mul && a.mv_div == b.mv_div && a.in_mul == b.in_mul && a.in_div == b.in_div;
+}
+
 // Vertex stage + binning, one thread per instance.
 WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
@@ -2990,17 +3109,28 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
       const WrTargetDesc& T = targets[draws[P.draw].target];
       if (T.mr_ctl) {
         const uint32_t rows = uint32_t(P.y1 - P.y0), pitch = uint32_t(((P.x1 + 3) & ~3) - (P.x0 & ~3));
-        const unsigned long long n16 = ((unsigned long long)rows * pitch + 15) >> 4;
+        // [row map: rows x u32, padded to 16 B][rows x pitch bytes]
+        const unsigned long long map16 = ((unsigned long long)rows * 4 + 15) >> 4;
+        const unsigned long long n16 = map16 + (((unsigned long long)rows * pitch + 15) >> 4);
         unsigned long long old = *(volatile unsigned long long*)T.mr_ctl;
         for (;;) {
           const unsigned long long ns = old >> 48, nr = (old >> 28) & 0xFFFFFull, nb = old & 0xFFFFFFFull;
-          if (ns + 1 > T.mr_max_slots || nr + rows > WR_MR_MAX_ROWS || nb + n16 > T.mr_cap16) break;
-          const unsigned long long want = ((ns + 1) << 48) | ((nr + rows) << 28) | (nb + n16);
+          // wide rows are shared by several waves (a row is one dependent chain of texel fetches otherwise): work items = rows x parts
+          // (measured on cfg4's 1840-pixel rows: 2 or 4 waves per row lose -- every item pays the row setup again, 99 -> 138 us)
+          const uint32_t parts = 1u;
+          if (ns + 1 > T.mr_max_slots || nr + rows * parts > WR_MR_MAX_ROWS || nb + n16 > T.mr_cap16) break;
+          const unsigned long long want = ((ns + 1) << 48) | ((nr + rows * parts) << 28) | (nb + n16);
           const unsigned long long seen = atomicCAS(T.mr_ctl, old, want);
           if (seen == old) {
             WrMaskSlot sl;
             sl.prim = gid; sl.target = draws[P.draw].target; sl.row0 = uint32_t(nr); sl.pitch = pitch; sl.off16 = uint32_t(nb);
-            sl.pad[0] = sl.pad[1] = sl.pad[2] = 0;
+            sl.pad[0] = parts; sl.pad[1] = sl.pad[2] = 0;
+            sl.key.valid = 0;
+            if (P.kind == WR_PK_BOX_SHADOW) {
+              const int yc = P.y0 + (int(rows) >> 1);
+              const WrRowVals rvc = wr_box_row_vals(P, aux[gid].box, yc);
+              sl.key = wr_box_row_key(P, aux[gid].box, rvc, wr_box_row_setup(P, aux[gid].box, rvc));
+            }
             T.mr_slots[ns] = sl;
             const unsigned long long addr = (unsigned long long)(T.mr_store + nb * 16);
             recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_MASK_ROWS;
@@ -3973,7 +4103,6 @@ WR_DEVICE float wr_clip_dist(const WrClipRec& C, float px, float py) {
   const float r = wr_max(wr_max(C.bounds[0] - px, px - C.bounds[2]), wr_max(C.bounds[1] - py, py - C.bounds[3]));
   return wr_max(e, r);
 }
-WR_DEVICE float wr_step01(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
 
 // ps_quad_mask fragment (ps_quad.glsl:399-415, ps_quad_mask.glsl:167-200): one pixel of main(), which
 // runs four pixels at a time -- fwidth() of the chunk is |lane1 - lane0| in x plus in y (glsl.h:765-768).
@@ -4213,7 +4342,6 @@ struct WrRow4 { uint32_t v[4]; };
 // Edge::nextRow has accumulated after (y - y0) rows.  They are the same for every pixel of the
 // row, and a wave's strip has 16 rows, so the raster stage evaluates them once per wave with 16
 // row-owning lanes and hands them round with ds_bpermute (wr_apply_prim) instead of once per lane-row.
-struct WrRowVals { float o[4], s[4]; };
 WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y) {
   WrRowVals rv;
   const int k = y - P.y0;
@@ -4306,11 +4434,8 @@ WR_DEVICE WrClipRow wr_clip_row_setup(const WrPrim& P, const WrClipRec& C, const
   return cr;
 }
 
-__device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipRec* Cp, WrRowVals rv, WrClipRow cr, int x, int y) {
-  const WrPrim& P = *Pp;
-  const WrClipRec& C = *Cp;
-  WrRow4 out;
-  out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+// one pixel (n = x - P.x0) of a cs_clip_rectangle row
+WR_DEVICE uint32_t wr_clip_rect_px(const WrPrim& P, const WrClipRec& C, const WrRowVals& rv, const WrClipRow& cr, int n) {
   const float su = rv.s[0], sv = rv.s[1];
   const float ou = rv.o[0], ov = rv.o[1];
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
@@ -4323,67 +4448,66 @@ __device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipR
   const int n1 = cr.n12 & 0xFFFF, n2 = cr.n12 >> 16, n3 = cr.n34 & 0xFFFF, n4 = cr.n34 >> 16;
   const int start_corner = (cr.corners & 0xFF) - 1, end_corner = (cr.corners >> 8) - 1;
   const uint32_t v_clear = uint32_t(wr_round_pixel(mode)) & 0xFFFF, v_opaque = uint32_t(wr_round_pixel(1.0f - mode)) & 0xFFFF;
-  // tail chunk (fragment shader): lanes stepped by `span` at once
+  if (n < 0 || n >= len) return 0;
+  const int lane = n & 3;
+  const float lxl = lane == 0 ? lx0 : (lane == 1 ? lx1 : (lane == 2 ? lx2 : lx3));
+  const float lyl = lane == 0 ? ly0 : (lane == 1 ? ly1 : (lane == 2 ? ly2 : ly3));
+  if (n < span) {
+    if (wv <= 0.0f) return 0;     // swgl_commitSolidR8(0.0)
+    const int c = n >> 2;
+    if (c < n1) return v_clear;
+    float qx = lxl * w, qy = lyl * w;
+    if (n1 > 0) { qx = qx + float(n1) * stx; qy = qy + float(n1) * sty; }
+    int corner;
+    if (c < n1 + n2) {
+      qx = wr_accum(qx, stx, c - n1); qy = wr_accum(qy, sty, c - n1);
+      corner = start_corner;
+    } else if (c < n1 + n2 + n3) {
+      return v_opaque;
+    } else if (c < n1 + n2 + n3 + n4) {
+      qx = wr_accum(qx, stx, n2); qy = wr_accum(qy, sty, n2);
+      if (n3 > 0) { qx = qx + float(n3) * stx; qy = qy + float(n3) * sty; }
+      qx = wr_accum(qx, stx, c - n1 - n2 - n3); qy = wr_accum(qy, sty, c - n1 - n2 - n3);
+      corner = end_corner;
+    } else {
+      return v_clear;
+    }
+    float dist;
+    if (C.fast) {
+      dist = wr_clip_dist(C, qx, qy);
+    } else {
+      dist = wr_max(wr_max(C.bounds[0] - qx, qx - C.bounds[2]), wr_max(C.bounds[1] - qy, qy - C.bounds[3]));
+      if (corner >= 0 && qx * C.plane[corner][0] + qy * C.plane[corner][1] > C.plane[corner][2]) {
+        const float ex = qx - C.center_radius[corner][0], ey = qy - C.center_radius[corner][1];
+        const float prx = ex * C.center_radius[corner][2], pry = ey * C.center_radius[corner][3];
+        const float g = (ex * prx + ey * pry) - 1.0f;
+        const float dgx = (1.0f + 1.0f) * prx, dgy = (1.0f + 1.0f) * pry;
+        dist = g * (1.0f / sqrtf(dgx * dgx + dgy * dgy));
+      }
+    }
+    const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
+    return uint32_t(wr_round_pixel(((1.0f - alpha) - alpha) * mode + alpha)) & 0xFFFF;
+  }
+  // tail chunk (fragment shader): this pixel's lane and lanes 0/1 (fwidth) of its chunk, lanes stepped by `span` at once
   const float chunks = float(span) * 0.25f;
   const float tjx = (su * 4.0f) * chunks, tjy = (sv * 4.0f) * chunks;
+  const int m = (n - span) >> 2;
+  float t0x = lx0, t0y = ly0, t1x = lx1, t1y = ly1, tlx = lxl, tly = lyl;
+  if (span > 0) { t0x = t0x + tjx; t0y = t0y + tjy; t1x = t1x + tjx; t1y = t1y + tjy; tlx = tlx + tjx; tly = tly + tjy; }
+  const float sx4 = (su * 4.0f) * 1.0f, sy4 = (sv * 4.0f) * 1.0f;
+  const float f0x = wr_accum(t0x, sx4, m) / wv, f0y = wr_accum(t0y, sy4, m) / wv;
+  const float f1x = wr_accum(t1x, sx4, m) / wv, f1y = wr_accum(t1y, sy4, m) / wv;
+  const float qx = wr_accum(tlx, sx4, m) / wv, qy = wr_accum(tly, sy4, m) / wv;
+  const float far = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));
+  const float dist = wr_clip_dist(C, qx, qy);
+  const float alpha = wr_clamp(0.5f - dist * far, 0.0f, 1.0f);
+  const float fin = ((1.0f - alpha) - alpha) * mode + alpha;
+  return uint32_t(wr_round_pixel(wv > 0.0f ? fin : 0.0f)) & 0xFFFF;
+}
+__device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipRec* Cp, WrRowVals rv, WrClipRow cr, int x, int y) {
+  WrRow4 out;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int n = x + i - P.x0;
-    if (n < 0 || n >= len) continue;
-    const int lane = n & 3;
-    const float lxl = lane == 0 ? lx0 : (lane == 1 ? lx1 : (lane == 2 ? lx2 : lx3));
-    const float lyl = lane == 0 ? ly0 : (lane == 1 ? ly1 : (lane == 2 ? ly2 : ly3));
-    if (n < span) {
-      if (wv <= 0.0f) { out.v[i] = 0; continue; }     // swgl_commitSolidR8(0.0)
-      const int c = n >> 2;
-      if (c < n1) { out.v[i] = v_clear; continue; }
-      float qx = lxl * w, qy = lyl * w;
-      if (n1 > 0) { qx = qx + float(n1) * stx; qy = qy + float(n1) * sty; }
-      int corner;
-      if (c < n1 + n2) {
-        qx = wr_accum(qx, stx, c - n1); qy = wr_accum(qy, sty, c - n1);
-        corner = start_corner;
-      } else if (c < n1 + n2 + n3) {
-        out.v[i] = v_opaque; continue;
-      } else if (c < n1 + n2 + n3 + n4) {
-        qx = wr_accum(qx, stx, n2); qy = wr_accum(qy, sty, n2);
-        if (n3 > 0) { qx = qx + float(n3) * stx; qy = qy + float(n3) * sty; }
-        qx = wr_accum(qx, stx, c - n1 - n2 - n3); qy = wr_accum(qy, sty, c - n1 - n2 - n3);
-        corner = end_corner;
-      } else {
-        out.v[i] = v_clear; continue;
-      }
-      float dist;
-      if (C.fast) {
-        dist = wr_clip_dist(C, qx, qy);
-      } else {
-        dist = wr_max(wr_max(C.bounds[0] - qx, qx - C.bounds[2]), wr_max(C.bounds[1] - qy, qy - C.bounds[3]));
-        if (corner >= 0 && qx * C.plane[corner][0] + qy * C.plane[corner][1] > C.plane[corner][2]) {
-          const float ex = qx - C.center_radius[corner][0], ey = qy - C.center_radius[corner][1];
-          const float prx = ex * C.center_radius[corner][2], pry = ey * C.center_radius[corner][3];
-          const float g = (ex * prx + ey * pry) - 1.0f;
-          const float dgx = (1.0f + 1.0f) * prx, dgy = (1.0f + 1.0f) * pry;
-          dist = g * (1.0f / sqrtf(dgx * dgx + dgy * dgy));
-        }
-      }
-      const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
-      out.v[i] = uint32_t(wr_round_pixel(((1.0f - alpha) - alpha) * mode + alpha)) & 0xFFFF;
-    } else {
-      // fragment shader: this pixel's lane and lanes 0/1 (fwidth) of its chunk
-      const int m = (n - span) >> 2;
-      float t0x = lx0, t0y = ly0, t1x = lx1, t1y = ly1, tlx = lxl, tly = lyl;
-      if (span > 0) { t0x = t0x + tjx; t0y = t0y + tjy; t1x = t1x + tjx; t1y = t1y + tjy; tlx = tlx + tjx; tly = tly + tjy; }
-      const float sx4 = (su * 4.0f) * 1.0f, sy4 = (sv * 4.0f) * 1.0f;
-      const float f0x = wr_accum(t0x, sx4, m) / wv, f0y = wr_accum(t0y, sy4, m) / wv;
-      const float f1x = wr_accum(t1x, sx4, m) / wv, f1y = wr_accum(t1y, sy4, m) / wv;
-      const float qx = wr_accum(tlx, sx4, m) / wv, qy = wr_accum(tly, sy4, m) / wv;
-      const float far = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));
-      const float dist = wr_clip_dist(C, qx, qy);
-      const float alpha = wr_clamp(0.5f - dist * far, 0.0f, 1.0f);
-      const float fin = ((1.0f - alpha) - alpha) * mode + alpha;
-      out.v[i] = uint32_t(wr_round_pixel(wv > 0.0f ? fin : 0.0f)) & 0xFFFF;
-    }
-  }
+  for (int i = 0; i < 4; i++) out.v[i] = wr_clip_rect_px(*Pp, *Cp, rv, cr, x + i - Pp->x0);
   return out;
 }
 
@@ -4419,93 +4543,6 @@ WR_DEVICE float wr_sel4(float a0, float a1, float a2, float a3, int i) { return 
 // Four horizontally adjacent pixels (x .. x+3) of row y: one span-level setup and
 // one walk of the nine-patch state machine serve all four.
 // row interpolants of a cs_clip_box_shadow prim: c = 0,1 vUv; 2,3 vLocalPos.xy
-WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
-  WrRowVals rv;
-  const int k = y - P.y0;
-  const bool lin = P.rows_linear != 0;     // (the vLocalPos interpolants share the uv ones' linearity in practice; wr_accum checks)
-  float stepScale = 1.0f / (P.xr - P.xl);
-  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
-  const float start = float(P.x0) + 0.5f - P.xl;
-  const float L0 = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
-  const float R0 = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
-  const float L2 = wr_accum(B.lpL0[0], B.lpLs[0], k), L3 = wr_accum(B.lpL0[1], B.lpLs[1], k);
-  const float R2 = wr_accum(B.lpR0[0], B.lpRs[0], k), R3 = wr_accum(B.lpR0[1], B.lpRs[1], k);
-  rv.s[0] = (R0 - L0) * stepScale; rv.o[0] = L0 + rv.s[0] * start;
-  rv.s[1] = (R1 - L1) * stepScale; rv.o[1] = L1 + rv.s[1] * start;
-  rv.s[2] = (R2 - L2) * stepScale; rv.o[2] = L2 + rv.s[2] * start;
-  rv.s[3] = (R3 - L3) * stepScale; rv.o[3] = L3 + rv.s[3] * start;
-  return rv;
-}
-
-// Span-level setup of a cs_clip_box_shadow row (cs_clip_box_shadow.glsl:150-250): where the shadow rect and the four
-// nine-patch sector boundaries fall along the row, as remaining span lengths.  Prim and row only: evaluated by the
-// row-owning lanes of a wave and handed round (see WrClipRow).
-struct WrBoxRow {
-  int ss_se, os01, os23;       // shadow_start_len | shadow_end_len << 16, os0 | os1 << 16, os2 | os3 << 16
-  int xc;                      // [pa, pb) = xc & 0xFFFF, xc >> 16: the run of the row in which u is clamped to the nine-patch's stretched
-                               // middle column -- every pixel of it samples the same texel, so it has ONE value,
-  uint32_t vrow;               // ... this one (wr_box_row_finish evaluates a single pixel of the run)
-};
-WR_DEVICE WrBoxRow wr_box_row_setup(const WrPrim& P, const WrBoxRec& B, const WrRowVals& rv) {
-  WrBoxRow br;
-  br.ss_se = br.os01 = br.os23 = 0; br.xc = 0; br.vrow = 0;
-  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
-  if (span <= 0 || !(B.w > 0.0f)) return br;
-  const float w = 1.0f / B.w;
-  float cur[4][1], st[4];
-#pragma unroll
-  for (int c = 0; c < 4; c++) { cur[c][0] = rv.o[c] * w; st[c] = (rv.s[c] * 4.0f) * w; }
-  const float sl = float(span), ss = 4.0f;
-  int shadow_start_len, shadow_end_len, os0, os1, os2, os3;
-  {
-    const float p0x = cur[2][0], p0y = cur[3][0];
-    const bool negx = st[2] < 0.0f, negy = st[3] < 0.0f;
-    float cd0 = (negx ? B.bounds[2] : B.bounds[0]) - p0x, cd1 = (negy ? B.bounds[3] : B.bounds[1]) - p0y;
-    float cd2 = (negx ? B.bounds[0] : B.bounds[2]) - p0x, cd3 = (negy ? B.bounds[1] : B.bounds[3]) - p0y;
-    const float rsx = 1.0f / st[2], rsy = 1.0f / st[3];
-    cd0 = st[2] != 0.0f ? cd0 * rsx : 1.0e6f * wr_step01(0.0f, cd0);
-    cd1 = st[3] != 0.0f ? cd1 * rsy : 1.0e6f * wr_step01(0.0f, cd1);
-    cd2 = st[2] != 0.0f ? cd2 * rsx : 1.0e6f * wr_step01(0.0f, cd2);
-    cd3 = st[3] != 0.0f ? cd3 * rsy : 1.0e6f * wr_step01(0.0f, cd3);
-    const float shadow_start = wr_max(cd0, cd1), shadow_end = wr_min(cd2, cd3);
-    shadow_start_len = int(wr_clamp(sl - ss * floorf(shadow_start), 0.0f, sl));
-    shadow_end_len = int(wr_clamp(sl - ss * ceilf(shadow_end), 0.0f, sl));
-    const float u0 = cur[0][0], v0 = cur[1][0];
-    const bool ngx = st[0] < 0.0f, ngy = st[1] < 0.0f;
-    float od0 = (ngx ? B.edge[2] : B.edge[0]) - u0, od1 = (ngy ? B.edge[3] : B.edge[1]) - v0;
-    float od2 = (ngx ? B.edge[0] : B.edge[2]) - u0, od3 = (ngy ? B.edge[1] : B.edge[3]) - v0;
-    const float rux = 1.0f / st[0], ruy = 1.0f / st[1];
-    od0 = st[0] != 0.0f ? od0 * rux : 1.0e6f * wr_step01(0.0f, od0);
-    od1 = st[1] != 0.0f ? od1 * ruy : 1.0e6f * wr_step01(0.0f, od1);
-    od2 = st[0] != 0.0f ? od2 * rux : 1.0e6f * wr_step01(0.0f, od2);
-    od3 = st[1] != 0.0f ? od3 * ruy : 1.0e6f * wr_step01(0.0f, od3);
-    const float sel = float(shadow_end_len);
-    os0 = int(wr_clamp(sl - ss * floorf(od0), sel, sl)); os1 = int(wr_clamp(sl - ss * floorf(od1), sel, sl));
-    os2 = int(wr_clamp(sl - ss * floorf(od2), sel, sl)); os3 = int(wr_clamp(sl - ss * floorf(od3), sel, sl));
-  }
-  br.ss_se = shadow_start_len | (shadow_end_len << 16); br.os01 = os0 | (os1 << 16); br.os23 = os2 | (os3 << 16);
-  // the walk of wr_box_shadow_row4, control flow only (it is all integer): find the run with u clamped
-  {
-    int R = span, pos = 0;
-    if (R > shadow_start_len) { const int nb = R - shadow_start_len; R -= nb; pos += nb; }
-    for (int guard = 0; guard < 16 && R > 0; guard++) {
-      R -= 4; pos += 4;
-      if (R <= shadow_end_len) break;
-      int num_inside = R - 4 - shadow_end_len;
-      bool xcl = false;
-      if (R >= os1) num_inside = wr_imin(num_inside, R - os1);
-      else if (R >= os3) num_inside = wr_imin(num_inside, R - os3);
-      if (R >= os0) num_inside = wr_imin(num_inside, R - os0);
-      else if (R >= os2) { num_inside = wr_imin(num_inside, R - os2); xcl = true; }
-      if (num_inside > 0) {
-        if (xcl && num_inside >= 8 && br.xc == 0) br.xc = pos | ((pos + num_inside) << 16);
-        R -= num_inside; pos += num_inside;
-      }
-    }
-  }
-  return br;
-}
-
 __device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxRec* Bp, WrRowVals rv, WrBoxRow br, int x, int y) {
   const WrPrim& P = *Pp;
   const WrBoxRec& B = *Bp;
@@ -4686,13 +4723,14 @@ WR_DEVICE void wr_box_row_finish(const WrPrim* Pp, const WrBoxRec* Bp, const WrR
 // Mask rows (WrMaskSlot): one wave evaluates one target row of one cs_clip_* prim into the flush's mask-row store.
 // dst[n] is the byte of pixel x0 + n.  Every lane walks the row's state machine (the walk is the same for all of them: no
 // divergence) and the pixels of each run are dealt out to the lanes; no two lanes ever store to the same byte.
-WR_DEVICE void wr_fill_lanes(uint8_t* dst, int a, int b, uint32_t v, int lane) {
-  for (int n = a + lane; n < b; n += 64) dst[n] = (uint8_t)v;
+WR_DEVICE void wr_fill_lanes(uint8_t* dst, int a, int b, uint32_t v, int lane, int stride = 64) {      // lane: + 64 * part
+  for (int n = a + lane; n < b; n += stride) dst[n] = (uint8_t)v;
 }
 // cs_clip_box_shadow (cs_clip_box_shadow.glsl:150-324): the walk of wr_box_shadow_row4 over the whole row
-WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, int y, int lane, uint8_t* dst) {
-  const WrRowVals rv = wr_box_row_vals(P, B, y);
-  const WrBoxRow br = wr_box_row_setup(P, B, rv);
+WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const WrRowVals& rv, const WrBoxRow& br, int lane, uint8_t* dst,
+                                       int part = 0, int parts = 1) {
+  const int wl = lane + 64 * part, ws = 64 * parts;      // this wave's share of a run: pixels wl, wl + ws, ..
+  int tchunk = 0;                                         // transitional chunks go round the parts
   const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear};
   float o4[4], s4[4];
 #pragma unroll
@@ -4704,7 +4742,7 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, int y
 #pragma unroll
   for (int c = 0; c < 4; c++) { ln[c][0] = o4[c]; ln[c][1] = ln[c][0] + s4[c]; ln[c][2] = ln[c][1] + s4[c]; ln[c][3] = ln[c][2] + s4[c]; }
   // ---- tail pixels [span, len): fragment shader
-  if (lane < len - span) {
+  if (part == 0 && lane < len - span) {
     const int n = span + lane;
     const int sl4 = (n - span) & 3, m = (n - span) >> 2;
     float v4[4];
@@ -4719,7 +4757,7 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, int y
   }
   if (span <= 0) return;
   float w = B.w;
-  if (w <= 0.0f) { wr_fill_lanes(dst, 0, span, 0, lane); return; }      // swgl_commitSolidR8(0.0)
+  if (w <= 0.0f) { wr_fill_lanes(dst, 0, span, 0, wl, ws); return; }      // swgl_commitSolidR8(0.0)
   w = 1.0f / w;
   float cur[4][4], st[4];
 #pragma unroll
@@ -4739,11 +4777,13 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, int y
 #pragma unroll
       for (int i = 0; i < 4; i++) cur[c][i] += f * st[c];
     }
-    wr_fill_lanes(dst, 0, nb, v_clear, lane);
+    wr_fill_lanes(dst, 0, nb, v_clear, wl, ws);
     R -= nb; pos += nb;
   }
   while (R > 0) {
-    if (lane < 4) {                                  // transitional chunk: per-fragment mapping
+    const bool my_chunk = (tchunk % parts) == part;
+    tchunk++;
+    if (lane < 4 && my_chunk) {                      // transitional chunk: per-fragment mapping
       const int n = pos + lane;
       if (n < span) {
         const int l4 = n & 3;
@@ -4831,11 +4871,11 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, int y
         const int l4 = (pos + lane) & 3;
         const float texel = wr_r8_texture(t, wr_clamp(wr_sel4(pu[0], pu[1], pu[2], pu[3], l4), ub0, ub2),
                                           wr_clamp(wr_sel4(pv[0], pv[1], pv[2], pv[3], l4), ub1, ub3));
-        wr_fill_lanes(dst, pos, end, uint32_t(wr_round_pixel(((1.0f - texel) - texel) * mode + texel)) & 0xFFFF, lane);
+        wr_fill_lanes(dst, pos, end, uint32_t(wr_round_pixel(((1.0f - texel) - texel) * mode + texel)) & 0xFFFF, lane + 64 * part, ws);
       } else if (one_value) {
-        wr_fill_lanes(dst, pos, end, run_pixel(0), lane);
+        wr_fill_lanes(dst, pos, end, run_pixel(0), wl, ws);
       } else {
-        for (int n = pos + lane; n < end; n += 64) dst[n] = (uint8_t)run_pixel(n - pos);
+        for (int n = pos + wl; n < end; n += ws) dst[n] = (uint8_t)run_pixel(n - pos);
       }
       const float f = float(num_inside / 4);
 #pragma unroll
@@ -4846,32 +4886,40 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, int y
       R -= num_inside; pos += num_inside;
     }
   }
-  wr_fill_lanes(dst, pos, span, v_clear, lane);      // solid lead-out
+  wr_fill_lanes(dst, pos, span, v_clear, wl, ws);    // solid lead-out
 }
 // cs_clip_rectangle (cs_clip_rectangle.glsl:223-420): the row's five phases are closed forms of the chunk index, so the lanes
 // take a chunk each; a chunk in a solid phase is a constant
-WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int y, int lane, uint8_t* dst) {
+WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int y, int lane, uint8_t* dst, int part = 0, int parts = 1) {
+  const int wl = lane + 64 * part, ws = 64 * parts;
   const WrPrim& P = *Pp;
   const WrRowVals rv = wr_clip_row_vals(P, y);
   const WrClipRow cr = wr_clip_row_setup(P, *Cp, rv);
-  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
-  const int b1 = cr.n12 & 0xFFFF, b2 = b1 + (cr.n12 >> 16), b3 = b2 + (cr.n34 & 0xFFFF), b4 = b3 + (cr.n34 >> 16);
+  const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0, S = span >> 2;
+  const int n2 = cr.n12 >> 16, n4 = cr.n34 >> 16;
+  const int b1 = cr.n12 & 0xFFFF, b2 = b1 + n2, b3 = b2 + (cr.n34 & 0xFFFF), b4 = b3 + n4;
   const float mode = Cp->mode;
-  for (int c = lane; 4 * c < len; c += 64) {
-    const int n = 4 * c;
+  if (!(Cp->w > 0.0f)) {                        // (degenerate w: every pixel through the general function)
+    for (int n = wl; n < len; n += ws) dst[n] = (uint8_t)wr_clip_rect_px(P, *Cp, rv, cr, n);
+    return;
+  }
+  // the solid phases [0, b1) clear, [b2, b3) opaque, [b4, S) clear: constants, a chunk per lane
+  const uint32_t v_clear = uint32_t(wr_round_pixel(mode)) & 0xFF, v_opaque = uint32_t(wr_round_pixel(1.0f - mode)) & 0xFF;
+  for (int c = wl; c < S; c += ws) {
     const int k = c < b1 ? 0 : (c < b2 ? 1 : (c < b3 ? 2 : (c < b4 ? 3 : 0)));
-    WrRow4 r4;
-    if (n + 3 < span && (k == 0 || k == 2) && Cp->w > 0.0f) {
-      const uint32_t v = uint32_t(wr_round_pixel(k == 0 ? mode : 1.0f - mode)) & 0xFFFF;
-      r4.v[0] = r4.v[1] = r4.v[2] = r4.v[3] = v;
-    } else {
-      r4 = wr_clip_rect_row4(Pp, Cp, rv, cr, P.x0 + n, y);
-    }
+    if (k == 1 || k == 3) continue;
+    const uint32_t v = k == 0 ? v_clear : v_opaque;
 #pragma unroll
-    for (int i = 0; i < 4; i++) if (n + i < len) dst[n + i] = (uint8_t)r4.v[i];
+    for (int i = 0; i < 4; i++) dst[4 * c + i] = (uint8_t)v;
+  }
+  // the two AA phases and the tail, a PIXEL per lane
+  const int na = 4 * n2, nb = 4 * n4, nt = len - span;
+  for (int p = wl; p < na + nb + nt; p += ws) {
+    const int n = p < na ? 4 * b1 + p : (p < na + nb ? 4 * b3 + (p - na) : span + (p - na - nb));
+    dst[n] = (uint8_t)wr_clip_rect_px(P, *Cp, rv, cr, n);
   }
 }
-__global__ void __launch_bounds__(256) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
+__global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                                                            const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
                                                            unsigned long long* __restrict__ ctl,
                                                            const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
@@ -4887,18 +4935,21 @@ __global__ void __launch_bounds__(256) wr_mask_rows_kernel(const WrTargetDesc* _
   // the first 64 slots, one per lane, requested together with the allocation word: a launch of a few hundred rows is one
   // dependent-load chain per wave, every level of it a cold miss
   WrMaskSlot mine;
-  mine.prim = mine.target = 0; mine.row0 = 0xFFFFFFFFu; mine.pitch = mine.off16 = 0;
+  mine.prim = mine.target = 0; mine.row0 = 0xFFFFFFFFu; mine.pitch = mine.off16 = 0; mine.pad[0] = 1;
   if (lane < ns) mine = slots[lane];
 #endif
   for (int item = gw; item < rows_total; item += nwaves) {
     WrMaskSlot sl;
+    int si;
 #ifndef WRHIP_HOSTSIM
     const unsigned long long le = __ballot(lane < ns && (int)mine.row0 <= item);
     if (ns <= 64 || !(le >> 63)) {
       const int idx = 63 - __builtin_clzll(le | 1ull);
+      si = idx;
       sl.prim = __builtin_amdgcn_readlane(mine.prim, idx); sl.target = __builtin_amdgcn_readlane(mine.target, idx);
       sl.row0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.row0, idx); sl.pitch = (uint32_t)__builtin_amdgcn_readlane((int)mine.pitch, idx);
       sl.off16 = (uint32_t)__builtin_amdgcn_readlane((int)mine.off16, idx);
+      sl.pad[0] = (uint32_t)__builtin_amdgcn_readlane((int)mine.pad[0], idx);
     } else
 #endif
     {
@@ -4908,16 +4959,38 @@ __global__ void __launch_bounds__(256) wr_mask_rows_kernel(const WrTargetDesc* _
         if ((int)slots[mid].row0 <= item) lo = mid; else hi = mid - 1;
       }
       sl = slots[lo];
+      si = lo;
     }
     const WrTargetDesc& T = targets[sl.target];
     if (T.first_bin < bin_lo || T.first_bin >= bin_hi) continue;
     const WrPrim* Pp = &prims[sl.prim];
-    const int y = Pp->y0 + (item - (int)sl.row0);
+    const int parts = (int)sl.pad[0], idx = item - (int)sl.row0;
+    const int y = Pp->y0 + idx / parts, part = idx % parts;
     if (y < T.y_begin || y >= T.y_end) continue;      // rows of another rank
-    uint8_t* dst = store + (size_t)sl.off16 * 16 + (size_t)(y - Pp->y0) * sl.pitch + (Pp->x0 & 3);
-    if (lane == 0) atomicAdd(&ctl[1], (unsigned long long)(Pp->x1 - Pp->x0));     // bytes evaluated (profiling: the launch's algorithmic bytes)
-    if (Pp->kind == WR_PK_BOX_SHADOW) wr_box_shadow_row_lanes(*Pp, aux[sl.prim].box, y, lane, dst);
-    else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst);
+    const int nrows = Pp->y1 - Pp->y0;
+    const uint32_t rows_at = uint32_t((nrows * 4 + 15) & ~15);                     // the pixel rows follow the row map
+    uint8_t* pbase = store + (size_t)sl.off16 * 16;
+    uint32_t my_off = rows_at + uint32_t(y - Pp->y0) * sl.pitch;
+    WrRowVals brv;
+    WrBoxRow bbr;
+    if (Pp->kind == WR_PK_BOX_SHADOW) {
+      // the rows of a nine-patch's middle band are identical: a row whose key equals the key of the prim's middle row (left
+      // in the slot by the setup stage) points at that row's bytes instead of being evaluated (wr_box_row_key)
+      const int yc = Pp->y0 + (nrows >> 1);
+      brv = wr_box_row_vals(*Pp, aux[sl.prim].box, y);
+      bbr = wr_box_row_setup(*Pp, aux[sl.prim].box, brv);
+      if (y != yc && wr_box_keys_equal(wr_box_row_key(*Pp, aux[sl.prim].box, brv, bbr), slots[si].key)) {
+        if (lane == 0 && part == 0) ((uint32_t*)pbase)[y - Pp->y0] = rows_at + uint32_t(yc - Pp->y0) * sl.pitch;
+        continue;
+      }
+    }
+    if (lane == 0 && part == 0) {
+      ((uint32_t*)pbase)[y - Pp->y0] = my_off;
+      atomicAdd(&ctl[1], (unsigned long long)(Pp->x1 - Pp->x0));     // bytes evaluated (profiling: the launch's algorithmic bytes)
+    }
+    uint8_t* dst = pbase + my_off + (Pp->x0 & 3);
+    if (Pp->kind == WR_PK_BOX_SHADOW) wr_box_shadow_row_lanes(*Pp, aux[sl.prim].box, brv, bbr, lane, dst, part, parts);
+    else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst, part, parts);
   }
 }
 
@@ -5227,7 +5300,9 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
 #pragma unroll
     for (int j = 0; j < R; j++) {
       if (!cy[j] || !anyx) continue;
-      const uint32_t v = *(const uint32_t*)(base + (size_t)(py + 4 * j - y0) * z + col);
+      // (the row map: rows that came out identical to another row of the prim point at that row's bytes)
+      const uint32_t ro = ((const uint32_t*)base)[py + 4 * j - y0];
+      const uint32_t v = *(const uint32_t*)(base + ro + col);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;

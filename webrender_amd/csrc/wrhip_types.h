@@ -204,15 +204,23 @@ struct WrTargetDesc {
 // every bin the prim touches would replay a row's state machine up to its own 64 pixels.  Instead the setup stage reserves
 // (y1 - y0) rows of pitch bytes in the flush's mask-row store for such a prim, wr_mask_rows_kernel evaluates each (prim, row)
 // ONCE with one wave -- the walk along the row is wave-uniform, the lanes share out the pixels of every run -- and the raster
-// stage blends the stored bytes like a 1:1 texture (WR_PK_MASK_ROWS: WrRec::c0/c1 = address of the prim's first stored row at
-// column x0 & ~3, WrRec::z = pitch).
+// stage blends the stored bytes like a 1:1 texture (WR_PK_MASK_ROWS: WrRec::c0/c1 = address of the prim's reservation, WrRec::z =
+// pitch).  A reservation is [row map: one u32 byte offset per row][rows x pitch bytes, first column x0 & ~3]: rows that come
+// out identical to another row of the prim (the middle band of a nine-patch) point at that row's bytes and are not evaluated.
+struct WrBoxKey {                // what decides the bytes of a cs_clip_box_shadow row besides its x interpolants (wr_box_row_key)
+  float o0, s0, o2, s2;
+  int32_t ss_se, os01, os23;
+  float mv_mul, mv_div, in_mul, in_div;
+  int32_t valid;
+};
 struct WrMaskSlot {
   int32_t prim;                  // global prim index
   int32_t target;                // its target (the rows kernel of a raster launch only evaluates that launch's targets)
   uint32_t row0;                 // first work row of this prim in the flush-wide row numbering
   uint32_t pitch;                // bytes per stored row (multiple of 4)
   uint32_t off16;                // first stored row, in 16-byte units into mr_store
-  uint32_t pad[3];
+  uint32_t pad[3];               // pad[0]: waves sharing a row (1: see the setup stage)
+  WrBoxKey key;                  // cs_clip_box_shadow: key of the prim's middle row (rows equal to it are not evaluated)
 };
 #define WR_MR_MAX_SLOTS 65535u
 #define WR_MR_MAX_ROWS 1048575u

@@ -215,7 +215,8 @@ def repo_root():
 
 
 def wrhip_path():
-    return os.path.join(repo_root(), "webrender_amd", "csrc", "libwrhip.so")
+    # WRHIP_LIB_PATH: another build of the same library (A/B measurements of kernel variants on one GPU box)
+    return os.environ.get("WRHIP_LIB_PATH") or os.path.join(repo_root(), "webrender_amd", "csrc", "libwrhip.so")
 
 
 def load_wrhip(trace=None):
