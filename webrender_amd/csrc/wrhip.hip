@@ -885,6 +885,7 @@ void tail_launched() {
 // The instantiated raster kernels: RGBA8 (+depth) x {0, TEX|GENERIC, +R8TEX, everything}, R8 x {0, GENERIC|BLUR, +CLIP}.
 // `SA` non-null: launch the fused setup + raster variant (only for the variants can_fuse() names).
 bool can_fuse(const Context::Held& H) {
+  if (H.mr_rows > 0) return true;          // (the mask-rows launch ahead of an R8 raster launch: wr_setup_rows_kernel)
   return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
                                    H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
 }
@@ -910,6 +911,11 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     // the cs_clip_* prims of this launch's targets, row by row (one wave per row), ahead of the bins that blend them
     const int wgs = std::max(1, std::min((H.mr_rows + 3) / 4, 4096));
     prof_begin();
+    if (SA) {
+      WR_LAUNCH(wr_setup_rows_kernel, n_setup_blocks + wgs, 256, c->stream, *SA, n_setup_blocks, targets, H.off, H.off + H.nb,
+                (const WrPrim*)S.prims, (const WrAux*)S.aux, S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
+      SA = nullptr;                          // (the raster launch that follows is the plain one)
+    } else
     WR_LAUNCH(wr_mask_rows_kernel, wgs, 256, c->stream, targets, H.off, H.off + H.nb, (const WrPrim*)S.prims, (const WrAux*)S.aux,
               S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
     prof_end(3, H.fmt, 0, 0, 0, (uint64_t)wgs);
@@ -1330,7 +1336,14 @@ void flush_work(const std::vector<int>& sel_in) {
       const int n_setup_blocks = (n_prims + 255) / 256;
       int fuse_at = -1;
       if (c->tail.pending)
-        for (size_t hi = 0; hi < c->tail.held.size() && fuse_at < 0; hi++) if (can_fuse(c->tail.held[hi])) fuse_at = (int)hi;
+        {
+          // the launch that hides the setup stage best: the largest mask-rows launch if there is one, else the first raster
+          // launch the fused kernel has a variant for
+          int best_rows = 0;
+          for (size_t hi = 0; hi < c->tail.held.size(); hi++)
+            if (c->tail.held[hi].mr_rows > best_rows) { best_rows = c->tail.held[hi].mr_rows; fuse_at = (int)hi; }
+          for (size_t hi = 0; hi < c->tail.held.size() && fuse_at < 0; hi++) if (can_fuse(c->tail.held[hi])) fuse_at = (int)hi;
+        }
       if (fuse_at >= 0) {
         // the previous flush's held-back raster launches, in order; the first one the fused kernel has a
         // variant for (normally the tile pass, the longest) carries this flush's setup stage along

@@ -4919,19 +4919,19 @@ WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int
     dst[n] = (uint8_t)wr_clip_rect_px(P, *Cp, rv, cr, n);
   }
 }
-__global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
-                                                           const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
-                                                           unsigned long long* __restrict__ ctl,
-                                                           const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
+WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
+                                 const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
+                                 unsigned long long* __restrict__ ctl,
+                                 const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store, const int block, const int nblocks) {
   const unsigned long long a = *ctl;
   const int ns = int(a >> 48), rows_total = int((a >> 28) & 0xFFFFFull);
   const int lane = threadIdx.x & 63;
-  const int nwaves = int((gridDim.x * blockDim.x) >> 6);
+  const int nwaves = int((nblocks * blockDim.x) >> 6);
 #ifdef WRHIP_HOSTSIM
-  const int gw = int((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int gw = int((block * blockDim.x + threadIdx.x) >> 6);
 #else
   // the wave index is wave-uniform: say so, and everything below (slot, prim, row) is read through the scalar cache
-  const int gw = __builtin_amdgcn_readfirstlane(int((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int gw = __builtin_amdgcn_readfirstlane(int((block * blockDim.x + threadIdx.x) >> 6));
   // the first 64 slots, one per lane, requested together with the allocation word: a launch of a few hundred rows is one
   // dependent-load chain per wave, every level of it a cold miss
   WrMaskSlot mine;
@@ -4992,6 +4992,12 @@ __global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc
     if (Pp->kind == WR_PK_BOX_SHADOW) wr_box_shadow_row_lanes(*Pp, aux[sl.prim].box, brv, bbr, lane, dst, part, parts);
     else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst, part, parts);
   }
+}
+__global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
+                                                           const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
+                                                           unsigned long long* __restrict__ ctl,
+                                                           const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
+  wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
@@ -6227,4 +6233,16 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
   }
   wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks,
                                       (int)blockIdx.x - n_setup_blocks + bin_offset);
+}
+// The same fusion for a flush whose longest held-back launch is a mask-rows launch (cfg4: the tile passes are 11-17 us, the
+// setup stage of the next frame 30-50 us of dependent latency, the rows launch 50-100 us).
+__global__ void __launch_bounds__(256, 4)
+wr_setup_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
+                     const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, unsigned long long* __restrict__ ctl,
+                     const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
+  if ((int)blockIdx.x < n_setup_blocks) {
+    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
+    return;
+  }
+  wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, (int)blockIdx.x - n_setup_blocks, (int)gridDim.x - n_setup_blocks);
 }
