@@ -194,8 +194,28 @@ def main():
     # per-frame latency with a Finish after every frame (what `wrench perf` samples)
     lat = player.frames(0, min(args.steps, 50))
 
-    # ---- per-kernel rooflines (separate, event-timed pass: one event pair + wait per launch) -------
+    # ---- where the host side of a frame goes: the library's own phase timers over one more streamed region -------
     import ctypes as C
+    host = None
+    if world == 1:
+        _get = C.CFUNCTYPE(None, C.c_void_p)(player.symbol("WrhipGetStats"))
+        _reset = C.CFUNCTYPE(None)(player.symbol("WrhipResetStats"))
+        barrier()
+        _reset()
+        t0 = time.perf_counter()
+        player.stream(args.steps)
+        issued = time.perf_counter() - t0           # (stream() ends with the one Finish of the region)
+        barrier()
+        hs = glapi.WrhipStats()
+        _get(C.byref(hs))
+        n = float(args.steps)
+        host = {"unit": "us per frame", "wall": round(1e6 * issued / n, 2),
+                "record_draws": round(hs.host_record_ns / n / 1e3, 2), "stage_uploads": round(hs.host_upload_ns / n / 1e3, 2),
+                "flush_and_launch": round(hs.host_flush_ns / n / 1e3, 2), "blocked_on_stream": round(hs.host_wait_ns / n / 1e3, 2)}
+        host["other_calls_and_replayer"] = round(host["wall"] - host["record_draws"] - host["stage_uploads"] - host["flush_and_launch"]
+                                                 - host["blocked_on_stream"], 2)
+
+    # ---- per-kernel rooflines (separate, event-timed pass: one event pair + wait per launch) -------
     roof = None
     if world == 1:
         get_stats = C.CFUNCTYPE(None, C.c_void_p)(player.symbol("WrhipGetStats"))
@@ -268,6 +288,8 @@ def main():
                 "parallelism": "single GPU" if world == 1 else
                 f"tile rows sharded over {world} GPUs + RCCL all-gather of framebuffer strips"},
         }
+        if host:
+            out["host"] = host
         if roof:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:

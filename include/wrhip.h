@@ -226,6 +226,11 @@ typedef struct WrhipStats {
   uint64_t prims;              /* instances rasterised                      */
   uint64_t h2d_bytes;          /* bytes uploaded host->HBM                  */
   uint64_t d2h_bytes;          /* bytes read back HBM->host                 */
+  /* host time spent inside the library (std::chrono, nanoseconds): where the CPU side of a frame goes */
+  uint64_t host_record_ns;     /* DrawElementsInstanced: state snapshot + instance bytes             */
+  uint64_t host_upload_ns;     /* TexSubImage2D / TexImage2D / BufferData / BufferSubData: staging of uploaded bytes */
+  uint64_t host_flush_ns;      /* flush: descriptor arena, staging copy, kernel launches (no waiting) */
+  uint64_t host_wait_ns;       /* Finish / ReadPixels / queries: blocked on the stream               */
 } WrhipStats;
 void WrhipGetStats(WrhipStats* out);
 void WrhipResetStats(void);

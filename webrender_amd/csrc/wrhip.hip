@@ -12,6 +12,7 @@
 #include <map>
 #include <algorithm>
 #include <time.h>
+#include <chrono>
 
 #include "../../include/wrhip.h"
 #include "wrhip_glenum.h"
@@ -20,6 +21,26 @@
 #include "wrhip_kernels.h"
 
 namespace {
+// host-side phase timers (WrhipStats::host_*_ns).  Exclusive: a timer started inside another one (an upload that has to
+// flush, a flush that has to wait) pauses the outer one, so the phases add up to the time spent in the library.
+struct HostTimer {
+  uint64_t* acc;
+  HostTimer* outer;
+  std::chrono::steady_clock::time_point t0;
+  static HostTimer*& current() { static thread_local HostTimer* cur = nullptr; return cur; }
+  static uint64_t since(std::chrono::steady_clock::time_point t) {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count();
+  }
+  explicit HostTimer(uint64_t* a) : acc(a), outer(current()), t0(std::chrono::steady_clock::now()) {
+    if (outer && outer->acc) *outer->acc += since(outer->t0);
+    current() = this;
+  }
+  ~HostTimer() {
+    if (acc) *acc += since(t0);
+    current() = outer;
+    if (outer) outer->t0 = std::chrono::steady_clock::now();
+  }
+};
 
 // ---------------------------------------------------------------------------
 // Object store with swgl's id policy (first free slot >= 1; gl.cc:674-745) so
@@ -978,6 +999,7 @@ void drain_tail() {
 }
 void sync_stream() {
   drain_tail();
+  HostTimer ht(&ctx->stats.host_wait_ns);
   wrrt::stream_sync(ctx->stream);
 }
 
@@ -1069,6 +1091,7 @@ static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
 void flush_work(const std::vector<int>& sel_in) {
   Context* c = ctx;
   if (!c || c->work.empty() || sel_in.empty()) return;
+  HostTimer ht(&c->stats.host_flush_ns);
   std::vector<int> sel(sel_in);
   std::sort(sel.begin(), sel.end());
   sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
@@ -1716,6 +1739,7 @@ static void* pixel_pack_data(void* data) {
 void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLsizei width, GLsizei height,
                    GLenum format, GLenum ty, const void* data_) {
   if (level != 0) return;
+  HostTimer ht(&ctx->stats.host_upload_ns);
   const uint8_t* data = (const uint8_t*)pixel_unpack_data(data_);
   if (!data) return;
   Texture& t = ctx->textures[ctx->get_binding(target)];
@@ -1835,11 +1859,13 @@ void VertexAttribDivisor(GLuint index, GLuint divisor) {
   ctx->vertex_arrays[ctx->current_vertex_array].attribs[index].divisor = divisor;
 }
 void BufferData(GLenum target, GLsizeiptr size, const GLvoid* data, GLenum) {
+  HostTimer ht(&ctx->stats.host_upload_ns);
   Buffer& b = ctx->buffers[ctx->get_binding(target)];
   if (size != b.size && !b.allocate(size)) out_of_memory();
   if (data && b.buf && size <= b.size) memcpy(b.buf, data, size);
 }
 void BufferSubData(GLenum target, GLintptr offset, GLsizeiptr size, const GLvoid* data) {
+  HostTimer ht(&ctx->stats.host_upload_ns);
   Buffer& b = ctx->buffers[ctx->get_binding(target)];
   if (data && b.buf && offset + size <= b.size) memcpy(&b.buf[offset], data, size);
 }
@@ -2140,6 +2166,7 @@ void BlitFramebuffer(GLint srcX0, GLint srcY0, GLint srcX1, GLint srcY1, GLint d
 // ---- the hot path: record one instanced batch ------------------------------
 void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr offset, GLsizei instancecount) {
   Context* c = ctx;
+  HostTimer ht(c ? &c->stats.host_record_ns : nullptr);
   Program* prog = c->programs.find(c->current_program);
   if (offset < 0 || count <= 0 || instancecount <= 0 || !prog || !prog->info) return;
   Framebuffer& fb = *get_framebuffer(GL_DRAW_FRAMEBUFFER, true);

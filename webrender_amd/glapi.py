@@ -141,7 +141,8 @@ EXTRA_SIGNATURES = {
 class WrhipStats(C.Structure):
     _fields_ = [(n, u64) for n in (
         "flushes", "kernel_launches", "raster_launches", "raster_ns",
-        "raster_algo_bytes", "raster_pixels", "prims", "h2d_bytes", "d2h_bytes")]
+        "raster_algo_bytes", "raster_pixels", "prims", "h2d_bytes", "d2h_bytes",
+        "host_record_ns", "host_upload_ns", "host_flush_ns", "host_wait_ns")]
 
 
 class WrhipKernelStat(C.Structure):
