@@ -183,3 +183,137 @@ def filter_swatch(img, op, params):
     r = (src + dst - md) & 0xFFFF
     r = np.where(r > 255, np.where(r >> 15, 0, 255), r)        # saturating pack (texture.h:14-21)
     return r.astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# Texture-cache shaders (cs_border_solid, cs_fast_linear_gradient, cs_line_decoration), restated from the GLSL as whole-task
+# numpy expressions over the pixel grid -- a different formulation from both the oracle's 4-lane shader headers and the
+# HIP replays (no chunks, no interpolant stepping: a task rect sits on integer pixels, so the varying at pixel (i, j) is
+# exactly size * ((i + 0.5) / size) up to rounding and fwidth() is 1).  Pins the oracle's hand-written headers for these
+# programs within 1 LSB (tests/test_oracle.py).
+def _f(v):
+    return np.asarray(v, dtype=np.float32)
+
+
+def _distance_aa(aa_range, d):                        # shared.glsl:184-189
+    return np.clip(_f(0.5) - d * _f(aa_range), 0.0, 1.0).astype(np.float32)
+
+
+def _ellipse_dist(px, py, rx, ry):                    # ellipse.glsl:31-45 distance_to_ellipse
+    ix = _f(1.0) / max(_f(rx) * _f(rx), _f(1.0e-6))
+    iy = _f(1.0) / max(_f(ry) * _f(ry), _f(1.0e-6))
+    scale = _f(1.0 if (rx > 0.0 and ry > 0.0) else 0.0)
+    prx, pry = px * ix, py * iy
+    g = (px * prx + py * pry) - scale
+    dgx, dgy = (_f(1.0) + scale) * prx, (_f(1.0) + scale) * pry
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (g / np.sqrt(dgx * dgx + dgy * dgy)).astype(np.float32)
+
+
+def _pixel_grid(w, h):
+    x = (np.arange(w, dtype=np.float32) + _f(0.5))[None, :].repeat(h, axis=0)
+    y = (np.arange(h, dtype=np.float32) + _f(0.5))[:, None].repeat(w, axis=1)
+    return x, y
+
+
+def _to_u8(rgba):
+    """premultiplied float RGBA over a transparent target with (ONE, ONE_MINUS_SRC_ALPHA): the source itself; round_pixel"""
+    return np.clip(np.floor(rgba * _f(255.0) + _f(0.5)), 0, 255).astype(np.uint8)
+
+
+def border_solid_task(inst):
+    """cs_border_solid.glsl:84-177 for one BorderInstance (webrender_amd.scenes.BORDER_DTYPE record) -> uint8 [h, w, 4] RGBA"""
+    x0, y0, x1, y1 = [float(v) for v in inst["rect"]]
+    w, h = int(x1 - x0), int(y1 - y0)
+    flags = int(inst["flags"])
+    segment, do_aa = flags & 0xff, ((flags >> 24) & 0xf0) != 0
+    wx, wy = [_f(v) for v in inst["widths"]]
+    rx, ry = [_f(v) for v in inst["radii"]]
+    cp = [_f(v) for v in inst["cp"]]
+    osx, osy = {0: (0.0, 0.0), 1: (1.0, 0.0), 2: (1.0, 1.0), 3: (0.0, 1.0)}.get(segment, (0.0, 0.0))
+    ox, oy = _f(osx) * _f(w), _f(osy) * _f(h)
+    csx, csy = _f(1.0 - 2.0 * osx), _f(1.0 - 2.0 * osy)
+    mixc = (1 if do_aa else 2) if segment < 4 else 0
+    px, py = _pixel_grid(w, h)
+    aa_range = _f(1.0)
+    mix = np.zeros((h, w), np.float32)
+    if mixc != 0:
+        dx, dy = wy * -csy, wx * csx                      # vColorLine.zw
+        ln = _f(np.hypot(np.float64(dx), np.float64(dy)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nx, ny = dx / ln, dy / ln
+        d_line = nx * (ox - px) + ny * (oy - py)
+        mix = _distance_aa(aa_range, -d_line) if mixc == 1 else (d_line + _f(0.0001) >= 0).astype(np.float32)
+    d = np.full((h, w), -1.0, np.float32)
+    ccx, ccy = ox + csx * rx, oy + csy * ry
+    relx, rely = px - ccx, py - ccy
+    inr = (csx * relx < 0) & (csy * rely < 0)
+    da = _ellipse_dist(relx, rely, rx, ry)
+    db = _ellipse_dist(relx, rely, max(rx - wx, _f(0.0)), max(ry - wy, _f(0.0)))
+    d = np.where(inr, np.maximum(da, -db), d)
+    for (cx_, cy_, crx, cry, sx, sy) in ((cp[0], cp[1], cp[2], cp[3], -csx, csy), (cp[4], cp[5], cp[6], cp[7], csx, -csy)):
+        hx, hy = cx_ + sx * crx, cy_ + sy * cry
+        rx_, ry_ = px - hx, py - hy
+        inr = (sx * rx_ < 0) & (sy * ry_ < 0)
+        d = np.where(inr, np.maximum(_ellipse_dist(rx_, ry_, crx, cry), d), d)
+    alpha = _distance_aa(aa_range, d) if mixc != 2 else np.ones((h, w), np.float32)
+    c0, c1 = _f(inst["c0"]), _f(inst["c1"])
+    color = (c1[None, None, :] - c0[None, None, :]) * mix[..., None] + c0[None, None, :]
+    return _to_u8(color * alpha[..., None])
+
+
+def fast_linear_gradient_task(inst):
+    """cs_fast_linear_gradient.glsl:17-30 (FASTGRAD_DTYPE record; integer task rects only) -> uint8 [h, w, 4]"""
+    x0, y0, x1, y1 = [float(v) for v in inst["task"]]
+    w, h = int(round(x1 - x0)), int(round(y1 - y0))
+    px, py = _pixel_grid(w, h)
+    t = (py / _f(h)) if float(inst["axis"]) != 0.0 else (px / _f(w))
+    c0, c1 = _f(inst["c0"]), _f(inst["c1"])
+    return _to_u8((c1[None, None, :] - c0[None, None, :]) * t[..., None] + c0[None, None, :])
+
+
+def line_decoration_task(inst):
+    """cs_line_decoration.glsl:43-163 (LINE_DTYPE record) -> uint8 [h, w, 4] (vec4(alpha))"""
+    x0, y0, x1, y1 = [float(v) for v in inst["task"]]
+    w, h = int(round(x1 - x0)), int(round(y1 - y0))
+    axis = float(inst["axis"])
+    lsx, lsy = [_f(v) for v in inst["local"]]
+    sx, sy = (lsy, lsx) if axis != 0.0 else (lsx, lsy)               # size = mix(aLocalSize, aLocalSize.yx, aAxisSelect)
+    gx, gy = _pixel_grid(w, h)
+    ux, uy = gx / _f(w), gy / _f(h)                                   # aPosition
+    if axis != 0.0:
+        ux, uy = uy, ux
+    px, py = ux * sx, uy * sy                                        # vLocalPos
+    # fwidth: one device pixel along x in local units
+    step = (sx / _f(w)) if axis == 0.0 else (sy / _f(w))
+    aa_range = _f(1.0) / step
+    style = int(inst["style"])
+    alpha = np.ones((h, w), np.float32)
+    if style == 2:
+        alpha = (_f(0.5) * sx >= np.floor(px + _f(0.5))).astype(np.float32)
+    elif style == 1:
+        radius, center = sy / _f(2.0), _f(0.5) * sy
+        dx, dy = px - radius, py - center
+        alpha = _distance_aa(aa_range, np.sqrt(dx * dx + dy * dy) - radius)
+    elif style == 3:
+        lt = max(_f(inst["wavy"]), _f(1.0))
+        half, slope, flat, vb = lt / _f(2.0), sy - lt, max((lt - _f(1.0)) * _f(2.0), _f(1.0)), sy
+        hp = slope + flat
+        mid = vb / _f(2.0)
+        m2 = px - (_f(2.0) * hp) * np.floor(px / (_f(2.0) * hp))
+        flip = _f(-2.0) * ((hp >= m2).astype(np.float32) - _f(0.5))
+        peak = mid + (mid - half) * flip
+        qx = px - hp * np.floor(px / hp)
+
+        def dist_line(p0x, p0y, dx, dy):
+            ln = np.sqrt(dx * dx + dy * dy)
+            return (dx / ln) * (p0x - qx) + (dy / ln) * (p0y - py)
+        one = np.ones_like(px)
+        d1 = dist_line(_f(0.0), peak, one, -flip)
+        d2 = dist_line(_f(0.0), peak, one * _f(0.0), -flip)
+        d3 = dist_line(flat, peak, -one, -flip)
+        dist = np.abs(np.maximum(np.maximum(d1, d2), d3))
+        alpha = _distance_aa(aa_range, dist - half)
+        if half <= 1.0:
+            alpha = _f(1.0) - (_f(0.5) >= alpha).astype(np.float32)
+    return _to_u8(np.repeat(alpha[..., None], 4, axis=2))

@@ -90,3 +90,40 @@ def test_brush_blend_oracle_matches_numpy_model(oracle_gcc):
     fr = scenes.filter_swatches()
     px, _ = render_direct(oracle_gcc, fr)
     check_filter_swatches(px, fr)
+
+
+def _pin_tasks(cache, insts, origin_of, model, lsb_budget=0.002):
+    """compare every task's region of the read-back cache texture (RGBA, row 0 = target row 0) with the numpy model: within 1
+    LSB everywhere, and equal on all but a small fraction of the bytes"""
+    total = off = 0
+    for inst in insts:
+        want = model(inst)
+        if want.size == 0:
+            continue                      # (an empty task rect: nothing drawn)
+        ox, oy = origin_of(inst)
+        h, w = want.shape[:2]
+        got = cache[oy:oy + h, ox:ox + w]
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1, (inst, int(d.max()))
+        total += d.size
+        off += int((d > 0).sum())
+    assert total > 0 and off <= lsb_budget * total, (off, total)
+    return off, total
+
+
+def test_oracle_cache_shaders_match_numpy_models(oracle_gcc):
+    """The hand-written oracle headers of cs_border_solid, cs_fast_linear_gradient and cs_line_decoration against independent
+    whole-task numpy restatements of the GLSL (oracle/np_model.py)."""
+    fr = scenes.border_solid(n=30, seed=134)
+    got, _ = render_direct(oracle_gcc, fr)
+    cache = got["border_cache"][..., [2, 1, 0, 3]]          # the read-back bytes are the texture's BGRA storage
+    insts = np.concatenate([s.instances for s in fr.passes[0][0].steps])
+    _pin_tasks(cache, insts, lambda e: (int(e["origin"][0]), int(e["origin"][1])), np_model.border_solid_task)
+    fr = scenes.cache_decorations(n_lines=60, n_grads=30, n_lgrads=0, seed=154)
+    got, _ = render_direct(oracle_gcc, fr)
+    cache = got["decoration_cache"][..., [2, 1, 0, 3]]
+    steps = {s.shader: s.instances for s in fr.passes[0][0].steps}
+    grads = [e for e in steps["cs_fast_linear_gradient"] if all(float(v) == int(v) for v in e["task"])]
+    _pin_tasks(cache, grads, lambda e: (int(e["task"][0]), int(e["task"][1])), np_model.fast_linear_gradient_task)
+    _pin_tasks(cache, steps["cs_line_decoration"], lambda e: (int(e["task"][0]), int(e["task"][1])), np_model.line_decoration_task,
+               lsb_budget=0.01)
