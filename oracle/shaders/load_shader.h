@@ -25,6 +25,8 @@
 #include "cs_linear_gradient.h"
 #include "cs_radial_gradient.h"
 #include "cs_conic_gradient.h"
+#include "ps_quad_radial_gradient.h"
+#include "ps_quad_conic_gradient.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -66,6 +68,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_linear_gradient", cs_linear_gradient)
   WRSH_ENTRY("cs_radial_gradient", cs_radial_gradient)
   WRSH_ENTRY("cs_conic_gradient", cs_conic_gradient)
+  WRSH_ENTRY("ps_quad_radial_gradient", ps_quad_radial_gradient)
+  WRSH_ENTRY("ps_quad_conic_gradient", ps_quad_conic_gradient)
 #undef WRSH_ENTRY
   return nullptr;
 }

@@ -65,7 +65,14 @@ ROTATED = [
     ("occluded_quad_masks", lambda: scenes.add_occluders(scenes.quad_masks(seed=88), zmax=80, seed=35)),
     ("occluded_rotated_quad_masks", lambda: scenes.add_occluders(scenes.quad_masks(rotate=True, seed=87), zmax=80, seed=34)),
 ]
-ROTATED_GOLDEN = ("rotated_gradients", "rotated_filters", "rotated_quad_masks")
+# ps_quad_radial_gradient / ps_quad_conic_gradient (gradient patterns on the quad path): axis-aligned, rotated, occluded
+ROTATED += [
+    ("quad_gradients", lambda: scenes.quad_gradients()),
+    ("rotated_quad_gradients", lambda: scenes.quad_gradients(rotate=True, seed=182)),
+    ("occluded_quad_gradients", lambda: scenes.add_occluders(scenes.quad_gradients(seed=183), zmax=60, seed=36)),
+    ("occluded_rotated_quad_gradients", lambda: scenes.add_occluders(scenes.quad_gradients(rotate=True, seed=184), zmax=60, seed=37)),
+]
+ROTATED_GOLDEN = ("rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

@@ -329,7 +329,10 @@ struct WrVsOut {
 
 // ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
 // mask: 0 ps_quad_textured, 1 ps_quad_mask, 2 ps_quad_mask FAST_PATH (C = its side record)
-WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, int mask = 0, WrClipRec* C = nullptr) {
+// mask: 0 ps_quad_textured, 1 / 2 ps_quad_mask (general / FAST_PATH; C = its side record), 3 / 4 ps_quad_radial_gradient /
+// ps_quad_conic_gradient (G = the gradient side record)
+WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, int mask = 0, WrClipRec* C = nullptr,
+                                      WrGradRec* G = nullptr) {
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_address_i = aData.x, prim_address_f = aData.y;
   int quad_flags = (aData.z >> 24) & 0xff;
@@ -416,6 +419,42 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
       float uvx = (seg_uv.z - seg_uv.x) * fx + seg_uv.x, uvy = (seg_uv.w - seg_uv.y) * fy + seg_uv.y;
       o.u[n] = uvx / tsx; o.v[n] = uvy / tsy;
     } else { o.u[n] = 0.f; o.v[n] = 0.f; }
+  }
+  if (mask == 3 || mask == 4) {
+    // pattern_vertex of ps_quad_radial_gradient.glsl:37-53 / ps_quad_conic_gradient.glsl:40-56: info.pattern_input = header.zw
+    const int gu = int(unsigned(header.z) % 1024u), gv = int(unsigned(header.z) / 1024u);
+    const wf4 g0 = wr_fetch_f(gbf, gu, gv), g1 = wr_fetch_f(gbf, gu + 1, gv);
+    const float p0x = t0.x * pso.x + pso.z, p0y = t0.y * pso.y + pso.w;      // info.local_prim_rect.p0
+    G->address = header.w;
+    G->repeat = g1.w;
+    G->no_tile = 1;
+    G->scale_dir[0] = G->scale_dir[1] = 0.0f;
+    G->conic_scale = G->conic_angle = 0.0f;
+    const float dd_ = g1.y - g1.x;
+    const float inv = dd_ != 0.0f ? 1.0f / dd_ : 0.0f;
+    G->start_offset = g1.x * inv;
+    if (mask == 3) {
+      G->radial = 1;
+      for (int n = 0; n < 4; n++) {
+        o.u[n] = ((mlx[n] - p0x) * g0.z - g0.x) * inv;
+        o.v[n] = (((mly[n] - p0y) * g0.w - g0.y) * inv) * g1.z;
+      }
+      const int ax = int(unsigned(header.w) % 1024u), ay = int(unsigned(header.w) / 1024u);
+      const bool ok = gbf.format == WR_FMT_RGBA32F && gbf.ptr && ay >= 0 && ay < gbf.height && ax >= 0 && ax < gbf.width && ax + 2 * 130 <= gbf.width;
+      G->stops = ok ? (const float*)gbf.ptr + (size_t)ay * gbf.stride + (size_t)ax * 4 : nullptr;
+    } else {
+      G->radial = 3;
+      G->conic_scale = inv;
+      G->conic_angle = 3.141592653589793f / 2.0f - g1.z;
+      G->stops = nullptr;
+      for (int n = 0; n < 4; n++) { o.u[n] = (mlx[n] - p0x) * g0.z - g0.x; o.v[n] = (mly[n] - p0y) * g0.w - g0.y; }
+    }
+    // (main() multiplies the gradient by v_color and swizzles masks; the span shader does neither: only white, non-mask quads)
+    const bool plain = prim_color.x == 1.0f && prim_color.y == 1.0f && prim_color.z == 1.0f && prim_color.w == 1.0f && !(quad_flags & 16);
+    o.kind = plain ? WR_PK_GRADIENT : WR_PK_UNSUPPORTED;
+    o.color = wf4{1.f, 1.f, 1.f, 1.f}; o.has_color = 0;
+    o.tex_slot = WR_S_GPU_BUFFER_F;
+    return;
   }
   if (mask) {
     // pattern_vertex (ps_quad_mask.glsl:65-152)
@@ -2759,6 +2798,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
     case WR_SH_PS_QUAD_MASK: wr_vs_ps_quad_textured(d, arena, inst, o, 1, &aux[gid].clip); break;
     case WR_SH_PS_QUAD_MASK_FAST: wr_vs_ps_quad_textured(d, arena, inst, o, 2, &aux[gid].clip); break;
+    case WR_SH_PS_QUAD_RADIAL_GRADIENT: wr_vs_ps_quad_textured(d, arena, inst, o, 3, nullptr, &aux[gid].grad); break;
+    case WR_SH_PS_QUAD_CONIC_GRADIENT: wr_vs_ps_quad_textured(d, arena, inst, o, 4, nullptr, &aux[gid].grad); break;
     case WR_SH_BRUSH_SOLID:
     case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush(d, arena, inst, 0, o); break;
     case WR_SH_BRUSH_IMAGE: wr_vs_brush(d, arena, inst, 1, o); break;
@@ -3537,7 +3578,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
   const float lu1 = px[1], lu2 = px[2], lu3 = px[3], lv1 = py[1], lv2 = py[2], lv3 = py[3];   // the lanes at the sub-span start
   const float psx = (px[1] - px[0]) * 4.0f, psy = (py[1] - py[0]) * 4.0f;   // dFdx(pos) * 4
   const float delta = psx * sdx + psy * sdy;
-  if (!G.stops || G.radial == 2 || (!G.radial && !wr_isfinite(delta))) span = 0;
+  if (!G.stops || G.radial >= 2 || (!G.radial && !wr_isfinite(delta))) span = 0;
   const int n_lo = wr_imax(x - X0, 0), n_hi = wr_imin(x + (kr >= 0 ? 0 : 3) - X0, len - 1);
   if (n_hi < n_lo) return out;
   const float size = 128.0f;
@@ -3768,6 +3809,16 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
       lu = wr_accum(lu, (su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (sv * 4.0f) * 1.0f, m);
       float offset = (G.no_tile ? lu : wr_fract(lu)) * sdx + (G.no_tile ? lv : wr_fract(lv)) * sdy - G.start_offset;
       if (G.radial == 1) offset = sqrtf(lu * lu + lv * lv) - G.start_offset;              // length(v_pos) - v_start_radius.x
+      if (G.radial == 3) {                                                                // ps_quad_conic_gradient.glsl:60-81 (approx_atan2)
+        const float ax_ = fabsf(lu), ay_ = fabsf(lv);
+        const float slope = wr_min(ax_, ay_) / wr_max(ax_, ay_);
+        const float s2 = slope * slope;
+        float r = ((-0.0464964749f * s2 + 0.15931422f) * s2 - 0.327622764f) * s2 * slope + slope;
+        r = ay_ > ax_ ? 1.57079637f - r : r;
+        r = lu < 0.0f ? 3.14159274f - r : r;
+        r = r * copysignf(1.0f, lv);
+        offset = wr_fract((r + G.conic_angle) / (2.0f * 3.141592653589793f)) * G.conic_scale - G.start_offset;
+      }
       if (G.radial == 2) {                                                                // cs_conic_gradient.glsl:52-65
         const float cur = atan2f(lv - G.scale_dir[1], lu - G.scale_dir[0]) + G.conic_angle;
         offset = wr_fract(cur / (2.0f * 3.141592653589793f)) * G.conic_scale - G.start_offset;

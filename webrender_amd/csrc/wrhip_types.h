@@ -69,6 +69,8 @@ enum WrShader {
   WR_SH_CS_LINEAR_GRADIENT,
   WR_SH_CS_RADIAL_GRADIENT,
   WR_SH_CS_CONIC_GRADIENT,
+  WR_SH_PS_QUAD_RADIAL_GRADIENT,
+  WR_SH_PS_QUAD_CONIC_GRADIENT,
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -389,6 +391,7 @@ struct WrGradRec {
   float start_offset;       // v_start_offset.x
   int32_t no_tile;          // cs_linear_gradient: v_pos is not wrapped to [0,1) (commitLinearGradient's tileRepeat == false)
   int32_t radial;           // 1: cs_radial_gradient: offset = length(v_pos) - start_offset (= v_start_radius.x), swgl_commitRadialGradientRGBA8
+                            // 3: ps_quad_conic_gradient (main() only, approx_atan2 of v_dir: scale_dir = 0)
                             // 2: cs_conic_gradient (main() only): scale_dir = v_center, start_offset = v_start_offset,
   float conic_scale, conic_angle;   //    v_offset_scale, v_angle
 };

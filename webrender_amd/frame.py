@@ -180,13 +180,13 @@ class Frame:
     def quad_instance(self, bounds, clip, color, z_id, task_address, transform_id=0,
                       quad_flags=QF_APPLY_DEVICE_CLIP, edge_flags=0, part=PART_ALL,
                       segment=INVALID_QUAD_SEGMENT, uv_rect=(0, 0, 0, 0),
-                      scale_offset=(1.0, 1.0, 0.0, 0.0), segments=()):
+                      scale_offset=(1.0, 1.0, 0.0, 0.0), segments=(), pattern_input=(0, 0)):
         """quad.rs:941-1000 + gpu_types.rs:564-589.  `color` is premultiplied."""
         blocks = [list(bounds), list(clip), list(uv_rect), list(scale_offset), list(color)]
         for rect, uv in segments:
             blocks += [list(rect), list(uv)]
         addr_f = self.gpu_buffer_f.push(blocks)
-        addr_i = self.gpu_buffer_i.push([[transform_id, z_id, 0, 0]])
+        addr_i = self.gpu_buffer_i.push([[transform_id, z_id, int(pattern_input[0]), int(pattern_input[1])]])
         return [addr_i, addr_f,
                 (quad_flags << 24) | (edge_flags << 16) | (part << 8) | segment,
                 task_address]

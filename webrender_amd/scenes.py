@@ -2287,3 +2287,66 @@ def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, n_cgrads=
     frame.readback = [t_cache]
     frame.n_tasks = (len(grads), len(lines), len(lgrads), len(rgrads), len(cgrads))
     return frame
+
+
+# ---------------------------------------------------------------------------
+# ps_quad_radial_gradient / ps_quad_conic_gradient: gradient patterns on the quad path (quad.rs pattern kinds; the
+# QuadHeader's pattern_input = (address of the two gradient blocks in sGpuBufferF, address of the 128-entry stop table)).
+def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, only=None, rotate=False):
+    rng, rects = random_rects(n, width, height, 24, 380, seed, True)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    prims = []
+    for i in range(n):
+        x0, y0, x1, y1 = [float(v) for v in rects[i]]
+        w, h = x1 - x0, y1 - y0
+        nst = int(rng.integers(2, 6))
+        offs = [0.0] + sorted(float(v) for v in rng.uniform(0.05, 0.95, size=nst - 2)) + [1.0]
+        if nst > 3 and i % 2:
+            offs[2] = offs[1]
+        cols = [tuple(float(v) for v in rng.uniform(0, 1, size=3)) + (float(rng.choice([1.0, 1.0, 0.6])),) for _ in range(nst)]
+        table = frame.gpu_buffer_f.push(build_gradient_lut(list(zip(offs, cols)), reverse=bool(i & 1)))
+        repeat = 1.0 if i % 4 == 1 else 0.0
+        conic = i % 3 == 2
+        if conic:
+            c = (w * 0.5, h * 0.5) if i % 2 else (float(rng.uniform(0, w)), float(rng.uniform(0, h)))
+            s0, s1 = (0.0, 1.0) if i % 5 else (float(rng.uniform(0.0, 0.3)), float(rng.uniform(0.5, 1.0)))
+            blocks = [[c[0], c[1], 1.0, 1.0], [s0, s1, float(rng.uniform(0, 2 * np.pi)) if i % 4 else 0.0, repeat]]
+        else:
+            mode = i % 5
+            if mode == 0:   c, r0, r1 = (w * 0.5, h * 0.5), 0.0, min(w, h) * 0.5
+            elif mode == 1: c, r0, r1 = (0.0, 0.0), 0.0, float(np.hypot(w, h))
+            elif mode == 2: c, r0, r1 = (w * 0.3, h * 0.7), min(w, h) * 0.1, min(w, h) * 0.4
+            elif mode == 3: c, r0, r1 = (float(rng.uniform(-w, 2 * w)), float(rng.uniform(-h, 2 * h))), float(rng.uniform(0, 30)), float(rng.uniform(40, 200))
+            else:           c, r0, r1 = (w * 0.5, h * 0.5), 10.0, 10.0
+            ratio = 1.0 if i % 4 else float(rng.uniform(0.4, 2.5))
+            blocks = [[c[0], c[1], 1.0, 1.0], [r0, r1, ratio, repeat]]
+        params = frame.gpu_buffer_f.push(blocks)
+        tid = rotation_about(frame, rng, (x0 + x1) / 2, (y0 + y1) / 2, i) if (rotate and i % 3 != 1) else 0
+        prims.append((rects[i], conic, params, table, tid, rotated_bounds(tuple(float(v) for v in rects[i])) if tid else tuple(rects[i])))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        for zi, (rect, conic, params, table, tid, bb) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
+                continue
+            big = (-BIG, -BIG, BIG, BIG)
+            if tid:
+                q = frame.quad_instance(rect, big, (1.0, 1.0, 1.0, 1.0), zi + 1, task, transform_id=tid, quad_flags=0, edge_flags=15,
+                                        pattern_input=(params, table))
+            else:
+                q = frame.quad_instance(rect, big, (1.0, 1.0, 1.0, 1.0), zi + 1, task, pattern_input=(params, table))
+            target.alpha.append(Step("ps_quad_conic_gradient" if conic else "ps_quad_radial_gradient", "PRIM_INSTANCES",
+                                     np.array([q], dtype=np.int32), "PremultipliedAlpha", "alpha", textures={}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
