@@ -108,7 +108,7 @@ def cpu_baseline(rec, budget_s=12.0):
     ms = np.array(ms)
     out = {"value": round(1e3 / ms.mean(), 4), "unit": "frames/s", "cores": 1, "kind": kind,
            "ms_per_frame": round(float(ms.mean()), 3),
-           "oracle": "swgl's gl.cc compiled unmodified from /root/reference; the 24 shader headers (38 program keys) it includes are this "
+           "oracle": "swgl's gl.cc compiled unmodified from /root/reference; the shader headers (38 program keys) it includes are this "
                      "repo's hand-written restatements of webrender/res/*.glsl (glsl-to-cxx needs cargo)",
            "sample": f"{len(ms)} frames of the same trace replayed by swgl ({os.path.basename(lib)}), "
                      f"{time.perf_counter() - t0:.1f} s"}
