@@ -215,6 +215,28 @@ def run(backend_path):
     out["locked_default_framebuffer"] = np.stack([_ptr_bytes(pf + y * s_.value, w_.value * 4) for y in range(h_.value)])
     gl.UnlockResource(lf)
 
+    # ---- Composite(): locked RGBA8 -> locked RGBA8, copied or blended, scaled / flipped / clipped (composite.h:542-589)
+    ld = gl.LockTexture(big.id)
+    ls = gl.LockTexture(t1.id)
+    def composite(src, dd, opaque, flip_x=0, flip_y=0, filt=G.GL_NEAREST, clip=None):
+        clip = clip or dd
+        gl.Composite(ld, ls, src[0], src[1], src[2], src[3], dd[0], dd[1], dd[2], dd[3], opaque, flip_x, flip_y, filt,
+                     clip[0], clip[1], clip[2], clip[3])
+        pd = gl.GetResourceBuffer(ld, w_, h_, s_)
+        return np.stack([_ptr_bytes(pd + y * s_.value, w_.value * 4) for y in range(h_.value)])
+    out["composite_opaque_1to1"] = composite((0, 0, tw, th), (20, 30, tw, th), 1)
+    out["composite_blend_1to1"] = composite((0, 0, tw, th), (70, 40, tw, th), 0)
+    out["composite_blend_clipped"] = composite((0, 0, tw, th), (-10, -8, tw, th), 0, clip=(0, 0, 30, 25))
+    out["composite_opaque_scaled"] = composite((3, 2, 50, 40), (5, 60, 90, 45), 1)
+    out["composite_blend_scaled_flip_y"] = composite((0, 0, tw, th), (40, 10, 100, 90), 0, flip_y=1)
+    out["composite_opaque_linear"] = composite((0, 0, tw, th), (2, 2, 140, 100), 1, filt=G.GL_LINEAR)
+    out["composite_blend_linear_clip"] = composite((4, 4, 40, 30), (10, 10, 120, 95), 0, filt=G.GL_LINEAR, clip=(30, 25, 70, 50))
+    out["composite_flip_x"] = composite((0, 0, tw, th), (60, 50, tw, th), 1, flip_x=1)
+    out["composite_blend_flip_xy_scaled"] = composite((0, 0, tw, th), (0, 0, 150, 110), 0, flip_x=1, flip_y=1, filt=G.GL_LINEAR)
+    out["composite_src_outside"] = composite((-6, -4, tw + 12, th + 8), (30, 20, 100, 80), 1)
+    gl.UnlockResource(ls); gl.UnlockResource(ld)
+    out["composite_texture_after"] = _read_tex(d, big)
+
     # ---- externally backed texture: the caller's memory holds the result after ResolveFramebuffer -------------
     ext = np.zeros((40, 64, 4), np.uint8)
     ext[..., 1] = 200

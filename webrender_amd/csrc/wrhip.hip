@@ -2111,6 +2111,48 @@ void CopyTexSubImage2D(GLenum target, GLint, GLint xoffset, GLint yoffset, GLint
   CopyImageSubData(fb->color_attachment, GL_TEXTURE_2D, 0, x, y, 0, ctx->get_binding(target), GL_TEXTURE_2D, 0, xoffset,
                    yoffset, 0, width, height, 1);
 }
+// scale_blit / linear_blit (composite.h:166-432) between two textures.  sr / dr: source / dest request in texture pixels;
+// clip: valid dest rect RELATIVE to the dest request (nullptr: the request itself); quirk: BlitFramebuffer hands linear_blit the
+// absolute dest request as its clip rect (composite.h:478) -- reproduced.
+static void blit_textures(GLuint src_id, Texture& s, GLuint dst_id, Texture& d, const int sr[4], const int dr[4], bool invertX, bool invertY,
+                          bool linear, bool composite, const int* clip, bool blit_quirk) {
+  const int srcW = sr[2] - sr[0], srcH = sr[3] - sr[1], dstW = dr[2] - dr[0], dstH = dr[3] - dr[1];
+  if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return;
+  // dest bounds: dsttex.sample_bounds(dstReq) (relative to the request) ∩ clipRect
+  int b[4] = {std::max(0, dr[0]) - dr[0], std::max(0, dr[1]) - dr[1], std::min(d.width, dr[2]) - dr[0], std::min(d.height, dr[3]) - dr[1]};
+  b[0] = std::max(b[0], 0); b[1] = std::max(b[1], 0); b[2] = std::min(b[2], dstW); b[3] = std::min(b[3], dstH);
+  if (clip) { b[0] = std::max(b[0], clip[0]); b[1] = std::max(b[1], clip[1]); b[2] = std::min(b[2], clip[2]); b[3] = std::min(b[3], clip[3]); }
+  if (linear && blit_quirk) {
+    b[0] = std::max(b[0], dr[0]); b[1] = std::max(b[1], dr[1]); b[2] = std::min(b[2], dr[2]); b[3] = std::min(b[3], dr[3]);
+  }
+  if (!linear) {
+    // source texture bounds relative to the request, flipped if need be, scaled to dest space rounding inward
+    int c[4] = {0 - sr[0], 0 - sr[1], s.width - sr[0], s.height - sr[1]};
+    if (invertY) { const int y0 = srcH - c[1], y1 = srcH - c[3]; c[1] = y1; c[3] = y0; }
+    c[0] = (c[0] * dstW + (srcW - 1)) / srcW; c[1] = (c[1] * dstH + (srcH - 1)) / srcH;
+    c[2] = (c[2] * dstW) / srcW; c[3] = (c[3] * dstH) / srcH;
+    b[0] = std::max(b[0], c[0]); b[1] = std::max(b[1], c[1]); b[2] = std::min(b[2], c[2]); b[3] = std::min(b[3], c[3]);
+  }
+  if (b[2] <= b[0] || b[3] <= b[1]) return;
+  if (!composite && !linear && !invertY && srcW == dstW && srcH == dstH && s.internal_format == d.internal_format) {
+    CopyImageSubData(src_id, GL_TEXTURE_2D, 0, sr[0] + b[0], sr[1] + b[1], 0, dst_id, GL_TEXTURE_2D,
+                     0, dr[0] + b[0], dr[1] + b[1], 0, b[2] - b[0], b[3] - b[1], 1);
+    return;
+  }
+  sync_texture_for_read(s);
+  sync_texture_for_write(d);
+  flush_uploads();
+  WrBlitArgs a;
+  a.src = s.dptr; a.dst = d.dptr; a.src_stride = s.stride; a.dst_stride = d.stride; a.sbpp = s.bpp; a.dbpp = d.bpp;
+  a.sw = s.width; a.sh = s.height;
+  a.srx0 = sr[0]; a.sry0 = sr[1]; a.srw = srcW; a.srh = srcH; a.drx0 = dr[0]; a.dry0 = dr[1]; a.drw = dstW; a.drh = dstH;
+  a.bx0 = b[0]; a.by0 = b[1]; a.bx1 = b[2]; a.by1 = b[3]; a.invert_y = invertY ? 1 : 0; a.linear = linear ? 1 : 0;
+  a.invert_x = invertX ? 1 : 0; a.composite = composite ? 1 : 0;
+  const long long n = (long long)(b[2] - b[0]) * (b[3] - b[1]);
+  WR_LAUNCH(wr_blit_kernel, (int)((n + 255) / 256), 256, ctx->stream, a);
+  ctx->stats.kernel_launches++;
+}
+
 void BlitFramebuffer(GLint srcX0, GLint srcY0, GLint srcX1, GLint srcY1, GLint dstX0, GLint dstY0, GLint dstX1, GLint dstY1,
                      GLbitfield mask, GLenum filter) {
   // composite.h:432-483: no scissor, Y flips forced onto the dest side, nearest stepping (scale_blit) unless a scaled
@@ -2133,39 +2175,7 @@ void BlitFramebuffer(GLint srcX0, GLint srcY0, GLint srcX1, GLint srcY1, GLint d
   if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return;
   const bool linear = !(srcW == dstW && srcH == dstH) && s.width >= 2 && filter == GL_LINEAR && s.internal_format == d.internal_format &&
                       (s.internal_format == GL_RGBA8 || s.internal_format == GL_R8);
-  // dest bounds: dsttex.sample_bounds(dstReq) ∩ clipRect (= the whole request)
-  int b[4] = {std::max(0, dr[0]) - dr[0], std::max(0, dr[1]) - dr[1], std::min(d.width, dr[2]) - dr[0], std::min(d.height, dr[3]) - dr[1]};
-  b[0] = std::max(b[0], 0); b[1] = std::max(b[1], 0); b[2] = std::min(b[2], dstW); b[3] = std::min(b[3], dstH);
-  if (linear) {
-    // BlitFramebuffer hands linear_blit the dest request itself as clip rect (composite.h:478), and linear_blit intersects it
-    // with bounds that are RELATIVE to the request (composite.h:352-353): the reference's result, reproduced
-    b[0] = std::max(b[0], dr[0]); b[1] = std::max(b[1], dr[1]); b[2] = std::min(b[2], dr[2]); b[3] = std::min(b[3], dr[3]);
-  }
-  if (!linear) {
-    // source texture bounds relative to the request, flipped if need be, scaled to dest space rounding inward
-    int c[4] = {0 - sr[0], 0 - sr[1], s.width - sr[0], s.height - sr[1]};
-    if (invertY) { const int y0 = srcH - c[1], y1 = srcH - c[3]; c[1] = y1; c[3] = y0; }
-    c[0] = (c[0] * dstW + (srcW - 1)) / srcW; c[1] = (c[1] * dstH + (srcH - 1)) / srcH;
-    c[2] = (c[2] * dstW) / srcW; c[3] = (c[3] * dstH) / srcH;
-    b[0] = std::max(b[0], c[0]); b[1] = std::max(b[1], c[1]); b[2] = std::min(b[2], c[2]); b[3] = std::min(b[3], c[3]);
-  }
-  if (b[2] <= b[0] || b[3] <= b[1]) return;
-  if (!linear && !invertY && srcW == dstW && srcH == dstH && s.internal_format == d.internal_format) {
-    CopyImageSubData(srcfb->color_attachment, GL_TEXTURE_2D, 0, sr[0] + b[0], sr[1] + b[1], 0, dstfb->color_attachment, GL_TEXTURE_2D,
-                     0, dr[0] + b[0], dr[1] + b[1], 0, b[2] - b[0], b[3] - b[1], 1);
-    return;
-  }
-  sync_texture_for_read(s);
-  sync_texture_for_write(d);
-  flush_uploads();
-  WrBlitArgs a;
-  a.src = s.dptr; a.dst = d.dptr; a.src_stride = s.stride; a.dst_stride = d.stride; a.sbpp = s.bpp; a.dbpp = d.bpp;
-  a.sw = s.width; a.sh = s.height;
-  a.srx0 = sr[0]; a.sry0 = sr[1]; a.srw = srcW; a.srh = srcH; a.drx0 = dr[0]; a.dry0 = dr[1]; a.drw = dstW; a.drh = dstH;
-  a.bx0 = b[0]; a.by0 = b[1]; a.bx1 = b[2]; a.by1 = b[3]; a.invert_y = invertY ? 1 : 0; a.linear = linear ? 1 : 0;
-  const long long n = (long long)(b[2] - b[0]) * (b[3] - b[1]);
-  WR_LAUNCH(wr_blit_kernel, (int)((n + 255) / 256), 256, ctx->stream, a);
-  ctx->stats.kernel_launches++;
+  blit_textures(srcfb->color_attachment, s, dstfb->color_attachment, d, sr, dr, false, invertY, linear, false, nullptr, true);
 }
 
 // ---- the hot path: record one instanced batch ------------------------------
@@ -2460,12 +2470,30 @@ void* GetResourceBuffer(LockedTexture* r, int32_t* width, int32_t* height, int32
   if (stride) *stride = t->ext_buf ? t->ext_stride : t->stride;
   return t->ext_buf ? t->ext_buf : t->hmirror;
 }
-void Composite(LockedTexture*, LockedTexture*, GLint, GLint, GLsizei, GLsizei, GLint, GLint, GLsizei, GLsizei, GLboolean,
-               GLboolean, GLboolean, GLenum, GLint, GLint, GLsizei, GLsizei) {
-  // Gecko's software-compositor entry point; wrench composites through the
-  // `composite` shader instead.  Out of scope, fails loudly.
-  fprintf(stderr, "libwrhip: Composite() is not implemented (Gecko's software compositor entry point, out of scope)\n");
-  if (ctx) ctx->last_error = GL_INVALID_OPERATION;
+void Composite(LockedTexture* lockedDst, LockedTexture* lockedSrc, GLint srcX, GLint srcY, GLsizei srcWidth, GLsizei srcHeight, GLint dstX,
+               GLint dstY, GLsizei dstWidth, GLsizei dstHeight, GLboolean opaque, GLboolean flipX, GLboolean flipY, GLenum filter,
+               GLint clipX, GLint clipY, GLsizei clipWidth, GLsizei clipHeight) {
+  // composite.h:542-589: a (scaled, flipped, clipped) copy -- or, when !opaque, a premultiplied-over blend -- of a locked RGBA8
+  // texture into another one: scale_blit, or linear_blit for X flips and scaled GL_LINEAR copies.  The locked resources' host
+  // views are refreshed afterwards (the caller reads the destination through GetResourceBuffer).
+  if (!lockedDst || !lockedSrc || !ctx) return;
+  Texture& s = *(Texture*)lockedSrc;
+  Texture& d = *(Texture*)lockedDst;
+  if (s.bpp != 4 || d.bpp != 4 || !s.dptr || !d.dptr) return;
+  GLuint sid = 0, did = 0;
+  for (size_t i = 1; i < ctx->textures.objects.size(); i++) {
+    if (ctx->textures.objects[i] == &s) sid = (GLuint)i;
+    if (ctx->textures.objects[i] == &d) did = (GLuint)i;
+  }
+  const int sr[4] = {srcX - s.offx, srcY - s.offy, srcX + srcWidth - s.offx, srcY + srcHeight - s.offy};
+  const int dr[4] = {dstX - d.offx, dstY - d.offy, dstX + dstWidth - d.offx, dstY + dstHeight - d.offy};
+  if (sr[2] <= sr[0] || sr[3] <= sr[1] || dr[2] <= dr[0] || dr[3] <= dr[1]) return;
+  const int clip[4] = {clipX - dstX, clipY - dstY, clipX - dstX + clipWidth, clipY - dstY + clipHeight};
+  const bool same = (sr[2] - sr[0]) == (dr[2] - dr[0]) && (sr[3] - sr[1]) == (dr[3] - dr[1]);
+  const bool useLinear = s.width >= 2 && (flipX || (!same && filter == GL_LINEAR));
+  flush_all();
+  blit_textures(sid, s, did, d, sr, dr, flipX != 0, flipY != 0, useLinear, !opaque, clip, false);
+  download_texture(d);
 }
 void CompositeYUV(LockedTexture*, LockedTexture*, LockedTexture*, LockedTexture*, YuvRangedColorSpace, GLuint, GLint, GLint,
                   GLsizei, GLsizei, GLint, GLint, GLsizei, GLsizei, GLboolean, GLboolean, GLint, GLint, GLsizei, GLsizei) {

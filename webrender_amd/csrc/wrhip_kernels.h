@@ -3281,6 +3281,13 @@ __global__ void wr_blit_kernel(WrBlitArgs a) {
     const int syr = int((long long)a.srh * Y / a.drh);
     const int sy = a.invert_y ? a.sry0 + a.srh - 1 - syr : a.sry0 + syr;
     const uint8_t* sp = (const uint8_t*)a.src + (size_t)sy * a.src_stride + (size_t)sx * a.sbpp;
+    if (a.composite && a.sbpp == 4 && a.dbpp == 4) {       // copy_row / scale_row<true>: src + dst - muldiv255(dst, alphas(src))
+      uint32_t sv, dv;
+      __builtin_memcpy(&sv, sp, 4); __builtin_memcpy(&dv, dp, 4);
+      const uint32_t o = wr_blend_rgba8(WR_BLEND_PREMULT, dv, wr_unpack(sv), nullptr);
+      __builtin_memcpy(dp, &o, 4);
+      return;
+    }
     if (a.sbpp == a.dbpp) { for (int k = 0; k < a.dbpp; k++) dp[k] = sp[k]; return; }
     // convert_pixel (composite.h:5-70)
     uint32_t v = 0;
@@ -3300,6 +3307,7 @@ __global__ void wr_blit_kernel(WrBlitArgs a) {
   // srcDUV * 128 per pixel (init_interp lanes, then one add of 4 * srcDU per 4-pixel chunk) and per row
   float u0 = float(a.srx0), v0 = float(a.sry0);
   float du = float(a.srw) / float(a.drw), dv = float(a.srh) / float(a.drh);
+  if (a.invert_x) { u0 += float(a.srw); du = -du; }
   if (a.invert_y) { v0 += float(a.srh); dv = -dv; }
   u0 += du * (float(a.bx0) + 0.5f); v0 += dv * (float(a.by0) + 0.5f);
   u0 = u0 * 128.0f + (0.5f - 0.5f * 128.0f); v0 = v0 * 128.0f + (0.5f - 0.5f * 128.0f);
@@ -3313,7 +3321,12 @@ __global__ void wr_blit_kernel(WrBlitArgs a) {
   t.format = a.sbpp == 4 ? WR_FMT_RGBA8 : WR_FMT_R8; t.linear = 1;
   if (a.sbpp == 4) {
     const WrWide w = wr_sample_linear_rgba8(t, int(lu), int(lv));
-    const uint32_t o = wr_pack(w);
+    uint32_t o = wr_pack(w);
+    if (a.composite) {                                       // linear_row_blit<true>
+      uint32_t dv_;
+      __builtin_memcpy(&dv_, dp, 4);
+      o = wr_blend_rgba8(WR_BLEND_PREMULT, dv_, w, nullptr);
+    }
     __builtin_memcpy(dp, &o, 4);
   } else {
     dp[0] = (uint8_t)wr_pack1(uint32_t(wr_sample_linear_r8(t, int(lu), int(lv))) & 0xFFFF);

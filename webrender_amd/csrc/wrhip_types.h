@@ -522,4 +522,5 @@ struct WrBlitArgs {
   int32_t drx0, dry0, drw, drh;        // dest request
   int32_t bx0, by0, bx1, by1;          // valid dest bounds, relative to the dest request
   int32_t invert_y, linear;
+  int32_t invert_x, composite;         // Composite(): X flips (linear only), premultiplied-over blend instead of a copy (RGBA8 <- RGBA8)
 };
