@@ -2,7 +2,7 @@
 # usage: tools/round2_sq.sh <tag> -- SQ counters (waves, cycles, instruction mix, wait) of cfg2 / cfg3 / cfg4, one json per workload
 tag=$1
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
-for w in cfg2 cfg3 cfg4; do
+for w in ${WORKLOADS:-cfg2 cfg3 cfg4}; do
   mkdir -p gpurun_out/${tag}_sq_$w
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/${tag}_sq_$w -o r -- python bench.py --no-cpu-baseline --workload $w --steps 10 --warmup 3 > gpurun_out/${tag}_sq_$w/bench.log 2>&1
   python3 - <<PY

@@ -5990,6 +5990,24 @@ WR_DEVICE void wr_unit_glyph_lane(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R]
 }
 
 // One workgroup per 64x64 bin; 64/(4R) waves of 64 lanes, each lane 4 x R pixels.
+// Strip-level depth cap (all wave-uniform, scalar): an upper bound on every depth sample of the wave's strip.  Depth only
+// ever moves towards the viewer except through a clear, so once a depth-writing rect has covered the whole strip at z, a
+// later depth-tested prim at or behind z fails at every pixel of the strip and is skipped before any vector work -- what
+// swgl's depth runs do for whole spans (rasterize.h:573-660), at strip granularity.  WebRender submits its opaque pass front
+// to back for exactly this reason (batch.rs: opaque batches are drawn in reverse), so in a scene with real overdraw most
+// prims of a strip never reach the blend code.
+WR_DEVICE bool wr_zcap_rejects(uint32_t kbf, uint32_t z, uint32_t zcap) {
+  const uint32_t fl = (kbf >> 16) & 0xFF;
+  if (!(fl & WR_PF_DEPTH_TEST) || (kbf & 0xFF) == WR_PK_CLEAR) return false;
+  return (fl & WR_PF_DEPTH_LESS) ? z >= zcap : z > zcap;
+}
+WR_DEVICE uint32_t wr_zcap_after(uint32_t kbf, uint32_t z, uint32_t zcap, bool full) {
+  const uint32_t fl = (kbf >> 16) & 0xFF, k = kbf & 0xFF;
+  if (k == WR_PK_CLEAR) return (fl & WR_PF_CLEAR_DEPTH) ? (full ? z : (z > zcap ? z : zcap)) : zcap;
+  if (full && (k == WR_PK_SOLID_FOLDED || k == WR_PK_SOLID) && (fl & WR_PF_DEPTH_TEST) && (fl & WR_PF_DEPTH_WRITE)) return z < zcap ? z : zcap;
+  return zcap;
+}
+
 template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
@@ -6058,6 +6076,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     }
   }
   // ---- apply every prim of this bin, in submission order -----------------
+  uint32_t zcap = (DEPTH && !(T.load_depth && T.depth)) ? T.init_depth : 0xFFFFFFFFu;
   unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
 #ifdef WRHIP_HOSTSIM
   for (int w = 0; w < T.words_per_bin; w++) {
@@ -6069,6 +6088,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       live &= live - 1;
       const WrRec Rc = recs[base + bit];
       if (Rc.x1 <= wx0 || Rc.x0 >= wx0 + WR_BIN_W || Rc.y1 <= wy0 || Rc.y0 >= wy0 + STRIP) continue;
+      if constexpr (DEPTH) {
+        if (wr_zcap_rejects(Rc.kbf, Rc.z, zcap)) continue;
+        zcap = wr_zcap_after(Rc.kbf, Rc.z, zcap, Rc.x0 <= wx0 && Rc.x1 >= wx0 + WR_BIN_W && Rc.y0 <= wy0 && Rc.y1 >= wy0 + STRIP);
+      }
       const int rblend = (Rc.kbf >> 8) & 0xFF;
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
@@ -6090,26 +6113,84 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // requested before the current word is processed), tests it against this
   // wave's strip, and the survivors -- a ballot mask, still in submission
   // order -- are broadcast one by one with v_readlane into SGPRs.
+  // The bin's mask words are themselves fetched 64 at a time (lane l loads word l of the block, the next block is requested
+  // before this one is walked) and only the non-zero ones are visited.  A block whose set bits are thinly spread -- a target
+  // with 100 k prims has ~1500 words per bin of which a few dozen hold one bit each (cfg5) -- is compacted first: a wave
+  // prefix sum over the words' popcounts gives every set bit a slot, the lanes scatter their prim indices into a 64-entry
+  // LDS row of the wave, and one record fetch + ballot serves up to 64 prims of up to 4096 consecutive ones instead of one
+  // fetch per word.  Slots are in (word, bit) order, so submission order is kept.  Dense blocks keep the word-per-round walk.
+  __shared__ int pid_row[16][64];
   const int nw = T.words_per_bin;
-  unsigned long long m_next = nw > 0 ? mw[0] : 0ull;
+  int wb = 0, wb_next = 0;                       // block being walked / block whose words are in mv_next
+  unsigned long long mv = 0ull, mv_next = lane < nw ? mw[lane] : 0ull;
+  unsigned long long nz = 0ull;                  // dense walk: non-zero words of the block still to visit
+  int blk_rounds = 0, blk_round = 0, total = 0, prefix = 0;
+  bool sparse = false;
+  // next round: this lane's prim index (or -1), in dbase_ the index lane 0 would have in a dense round
+  auto next_round = [&](int& pid_, int& dbase_, bool& sp_) -> bool {
+    for (;;) {
+      if (blk_rounds == 0) {
+        if (wb_next >= nw) return false;
+        mv = mv_next; wb = wb_next; wb_next += 64;
+        mv_next = wb_next + lane < nw ? mw[wb_next + lane] : 0ull;
+        nz = __ballot(mv != 0ull);
+        if (!nz) continue;
+        const int cnt = __popcll(mv);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        prefix = inc - cnt;
+        total = __builtin_amdgcn_readlane(inc, 63);
+        const int nzw = __popcll(nz), rounds = (total + 63) >> 6;
+        sparse = rounds * 2 <= nzw;
+        blk_rounds = sparse ? rounds : nzw;
+        blk_round = 0;
+      }
+      blk_rounds--;
+      sp_ = sparse;
+      if (sparse) {
+        const int s0 = prefix - blk_round * 64;            // slot of this lane's first bit, relative to the round
+        if (s0 < 64 && s0 + __popcll(mv) > 0) {
+          int sl = s0;
+          for (unsigned long long bts = mv; bts; bts &= bts - 1ull, sl++)
+            if ((unsigned)sl < 64u) pid_row[wave][sl] = T.first_prim + (wb + lane) * 64 + __builtin_ctzll(bts);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pid_ = lane < total - blk_round * 64 ? pid_row[wave][lane] : -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        dbase_ = 0;
+      } else {
+        const int cw = __builtin_ctzll(nz);
+        nz &= nz - 1ull;
+        const unsigned long long m_ = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
+                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
+        dbase_ = T.first_prim + (wb + cw) * 64;
+        pid_ = ((m_ >> lane) & 1ull) ? dbase_ + lane : -1;
+      }
+      blk_round++;
+      return true;
+    }
+  };
+  int pid_n = -1, dbase_n = 0;
+  bool sp_n = false;
+  bool more = next_round(pid_n, dbase_n, sp_n);
   uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
-  if ((m_next >> lane) & 1ull) {
-    const uint4* rp = (const uint4*)&recs[T.first_prim + lane];
+  if (more && pid_n >= 0) {
+    const uint4* rp = (const uint4*)&recs[pid_n];
     na = rp[0]; nb = rp[1];
   }
-  for (int w = 0; w < nw; w++) {
-    const unsigned long long m = m_next;
+  while (more) {
+    const int pid = pid_n, dbase = dbase_n;
+    const bool sp = sp_n;
     const uint4 ra = na, rb = nb;
-    const int base = T.first_prim + w * 64;
-    if (w + 1 < nw) {
-      m_next = mw[w + 1];
-      if ((m_next >> lane) & 1ull) {
-        const uint4* rp = (const uint4*)&recs[base + 64 + lane];
-        na = rp[0]; nb = rp[1];
-      }
+    more = next_round(pid_n, dbase_n, sp_n);
+    if (more && pid_n >= 0) {
+      const uint4* rp = (const uint4*)&recs[pid_n];
+      na = rp[0]; nb = rp[1];
     }
-    if (!m) continue;
-    const bool has = (m >> lane) & 1ull;
+    // prim index of the round's lane `b_` (uniform b_)
+#define WR_PID(b_) (sp ? __builtin_amdgcn_readlane(pid, (b_)) : dbase + (b_))
+    const bool has = pid >= 0;
     const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);
     unsigned long long live = __ballot(hit);
     // prims of this word that are unit glyph blits (lane i looks at prim i): runs of them are applied lane by lane
@@ -6118,7 +6199,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const uint32_t k8 = rb.y & 0xFF, b8 = (rb.y >> 8) & 0xFF;
       bool g = hit && (k8 == WR_PK_TEX_R8 || k8 == WR_PK_SOLID_MASKED) && (b8 == WR_BLEND_NONE || b8 == WR_BLEND_PREMULT) &&
                !(DEPTH && ((rb.y >> 16) & WR_PF_DEPTH_TEST));
-      if (g) { const WrTexRec* tp = &aux[base + lane].tex; g = tp->simple != 0 && tp->unit != 0; }
+      if (g) { const WrTexRec* tp = &aux[pid].tex; g = tp->simple != 0 && tp->unit != 0; }
       glyphs = __ballot(g);
     }
     // Rect-only launches (FEAT == 0): the survivors' records come back through the scalar cache, one s_load_dwordx8 per prim
@@ -6128,7 +6209,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     constexpr bool SCALAR_RECS = FEAT == 0;
     int nbit = live ? __builtin_ctzll(live) : 0;
     WrRec nrec;
-    if (SCALAR_RECS) nrec = recs[base + nbit];
+    if (SCALAR_RECS) nrec = recs[WR_PID(nbit)];
     while (live) {
       if constexpr ((FEAT & WR_FEAT_R8TEX) != 0 && FMT == WR_FMT_RGBA8) {
         if ((glyphs >> __builtin_ctzll(live)) & 1ull) {
@@ -6147,13 +6228,19 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
               if (b < 32) mlo |= reach ? (1u << b) : 0u; else mhi |= reach ? (1u << (b - 32)) : 0u;
             }
             while (__ballot((mlo | mhi) != 0)) {
-              if (mlo | mhi) {
-                const int b = mlo ? __builtin_ctz(mlo) : 32 + __builtin_ctz(mhi);
+              const bool act = (mlo | mhi) != 0;
+              int b = lane;
+              if (act) {
+                b = mlo ? __builtin_ctz(mlo) : 32 + __builtin_ctz(mhi);
                 if (mlo) mlo &= mlo - 1; else mhi &= mhi - 1;
+              }
+              // (the shuffle runs with every lane active: a lane that has no glyph left may hold the index another one asks for)
+              const int gp = sp ? __shfl(pid, b) : dbase + b;
+              if (act) {
                 // (requesting a lane's next records ahead of applying its current ones was tried: the 16 extra live VGPRs
                 // spill in this loop, 170 -> 420 us)
-                const WrGlyphLoad g = wr_unit_glyph_fetch(&recs[base + b], &aux[base + b].tex);
-                wr_unit_glyph_lane<R>(plo, phi, g, &aux[base + b].tex, px, py);
+                const WrGlyphLoad g = wr_unit_glyph_fetch(&recs[gp], &aux[gp].tex);
+                wr_unit_glyph_lane<R>(plo, phi, g, &aux[gp].tex, px, py);
               }
             }
             continue;
@@ -6167,7 +6254,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       if (SCALAR_RECS) {
         const WrRec Rc = nrec;
         nbit = live ? __builtin_ctzll(live) : bit;
-        nrec = recs[base + nbit];
+        nrec = recs[WR_PID(nbit)];
         x0 = Rc.x0; y0 = Rc.y0; x1 = Rc.x1; y1 = Rc.y1; z = Rc.z; kbf = Rc.kbf; c0 = Rc.c0; c1 = Rc.c1;
       } else {
         x0 = __builtin_amdgcn_readlane((int)ra.x, bit); y0 = __builtin_amdgcn_readlane((int)ra.y, bit);
@@ -6175,23 +6262,29 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
         z = __builtin_amdgcn_readlane((int)rb.x, bit); kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
         c0 = __builtin_amdgcn_readlane((int)rb.z, bit); c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
       }
+      if constexpr (DEPTH) {
+        if (wr_zcap_rejects(kbf, z, zcap)) continue;
+        zcap = wr_zcap_after(kbf, z, zcap, x0 <= wx0 && x1 >= wx0 + WR_BIN_W && y0 <= wy0 && y1 >= wy0 + STRIP);
+      }
       const int rblend = (kbf >> 8) & 0xFF;
+      const int pi = WR_PID(bit);
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
-        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && base + bit > T.dw_first) || T.load_depth))
-          rr = wr_build_runs<R>(T, recs, aux, base + bit, x0, y0, x1, y1, z, kbf, wy0, lane, wave);
+        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && pi > T.dw_first) || T.load_depth))
+          rr = wr_build_runs<R>(T, recs, aux, pi, x0, y0, x1, y1, z, kbf, wy0, lane, wave);
       }
       if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_SOLID_MASKED || ((kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
-          aux[base + bit].tex.simple)
-        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[base + bit].tex, draws, &prims[base + bit], px, py);
+          aux[pi].tex.simple)
+        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[pi].tex, draws, &prims[pi], px, py);
       else
-        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[base + bit], &aux[base + bit], draws, vtab, px, py, wx0, wy0, rr);
+        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[pi], &aux[pi], draws, vtab, px, py, wx0, wy0, rr);
     }
   }
+#undef WR_PID
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the
   // bin's words, zero them so the next flush needs no memset launch.
   __syncthreads();
-  for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) mw[w] = 0ull;
+  for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) if (mw[w]) mw[w] = 0ull;      // (most words of a large target are empty already)
 #endif
   // ---- write back ------------------------------------------------------------
   // (forwarded composite, WrTargetDesc::fwd_*: every row is stored a second time at its place in the target that would have

@@ -85,8 +85,10 @@ def build_rect_frame(width, height, rects, colors, opaque, encoding="quad",
         else:
             sh_op, sh_al = "brush_solid", "brush_solid ALPHA_PASS"
         if op_inst:
+            # the opaque pass is submitted front to back: OpaqueBatchList::finalize reverses the instance arrays
+            # (batch.rs:487-499) and the renderer walks the opaque batches in reverse (renderer/mod.rs:2831-2836)
             target.opaque.append(Step(sh_op, "PRIM_INSTANCES",
-                                      np.array(op_inst, dtype=np.int32), None, "opaque"))
+                                      np.array(op_inst[::-1], dtype=np.int32), None, "opaque"))
         if al_inst:
             target.alpha.append(Step(sh_al, "PRIM_INSTANCES",
                                      np.array(al_inst, dtype=np.int32),
