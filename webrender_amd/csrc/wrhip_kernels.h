@@ -6004,7 +6004,10 @@ WR_DEVICE bool wr_zcap_rejects(uint32_t kbf, uint32_t z, uint32_t zcap) {
 WR_DEVICE uint32_t wr_zcap_after(uint32_t kbf, uint32_t z, uint32_t zcap, bool full) {
   const uint32_t fl = (kbf >> 16) & 0xFF, k = kbf & 0xFF;
   if (k == WR_PK_CLEAR) return (fl & WR_PF_CLEAR_DEPTH) ? (full ? z : (z > zcap ? z : zcap)) : zcap;
-  if (full && (k == WR_PK_SOLID_FOLDED || k == WR_PK_SOLID) && (fl & WR_PF_DEPTH_TEST) && (fl & WR_PF_DEPTH_WRITE)) return z < zcap ? z : zcap;
+  // (rect kinds whose every pixel of [x0, x1) x [y0, y1) writes depth when it passes: solids, unmasked axis-aligned images)
+  if (full && (k == WR_PK_SOLID_FOLDED || k == WR_PK_SOLID || (k == WR_PK_TEX_RGBA8 && !(fl & WR_PF_MASKED))) && (fl & WR_PF_DEPTH_TEST) &&
+      (fl & WR_PF_DEPTH_WRITE))
+    return z < zcap ? z : zcap;
   return zcap;
 }
 
