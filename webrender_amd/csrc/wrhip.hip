@@ -13,6 +13,11 @@
 #include <algorithm>
 #include <time.h>
 #include <chrono>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include <functional>
 
 #include "../../include/wrhip.h"
 #include "wrhip_glenum.h"
@@ -21,6 +26,59 @@
 #include "wrhip_kernels.h"
 
 namespace {
+// Helper threads for the large host copies (a frame of 100 k prims stages ~24 MB of data-texture rows and instance arrays; one
+// core copies that at ~45 GB/s, which had become the longest phase of such a frame).  run(f) calls f(part, parts) once per
+// part, part 0 on the calling thread, and returns when all parts are done.  The helpers only ever touch the row ranges they
+// are handed.  WRHIP_COPY_THREADS=0 turns them off.
+struct CopyPool {
+  int n = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  const std::function<void(int, int)>* job = nullptr;
+  uint64_t gen = 0;
+  std::atomic<int> left{0};
+  CopyPool() {
+    const char* e = getenv("WRHIP_COPY_THREADS");
+    int want = e ? atoi(e) : 3;
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (hc && (int)hc - 1 < want) want = (int)hc - 1;
+    n = want > 0 ? want : 0;
+    for (int i = 0; i < n; i++) std::thread([this, i] { worker(i + 1); }).detach();
+  }
+  void worker(int part) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int, int)>* j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return gen != seen; });
+        seen = gen; j = job;
+      }
+      (*j)(part, n + 1);
+      left.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void run(const std::function<void(int, int)>& f) {
+    if (!n) { f(0, 1); return; }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = &f; left.store(n, std::memory_order_relaxed); gen++;
+    }
+    cv.notify_all();
+    f(0, n + 1);
+    while (left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  }
+};
+CopyPool& copy_pool() { static CopyPool* p = new CopyPool(); return *p; }     // (never destroyed: the helpers outlive static destruction)
+constexpr size_t PARALLEL_COPY_MIN = 1u << 20;
+void big_memcpy(void* dst, const void* src, size_t n) {
+  if (n < PARALLEL_COPY_MIN) { memcpy(dst, src, n); return; }
+  copy_pool().run([&](int part, int parts) {
+    const size_t a = (n / 64 * part / parts) * 64, b = part + 1 == parts ? n : (n / 64 * (part + 1) / parts) * 64;
+    memcpy((uint8_t*)dst + a, (const uint8_t*)src + a, b - a);
+  });
+}
+
 // host-side phase timers (WrhipStats::host_*_ns).  Exclusive: a timer started inside another one (an upload that has to
 // flush, a flush that has to wait) pauses the outer one, so the phases add up to the time spent in the library.
 struct HostTimer {
@@ -1169,7 +1227,7 @@ void flush_work(const std::vector<int>& sel_in) {
     }
     size_t inst_base = (inst.size() + 15) & ~size_t(15);
     inst.resize(inst_base + w.inst.size());
-    if (!w.inst.empty()) memcpy(inst.data() + inst_base, w.inst.data(), w.inst.size());
+    if (!w.inst.empty()) big_memcpy(inst.data() + inst_base, w.inst.data(), w.inst.size());
     bool any_kept = false;
     T.dw_first = 0; T.dw_end = 0;
     for (const WrDrawDesc& d0 : w.draws) {
@@ -1309,7 +1367,7 @@ void flush_work(const std::vector<int>& sel_in) {
     uint8_t* h = c->staging + aoff;
     if (nd) memcpy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     memcpy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
-    if (!inst.empty()) memcpy(h + off_inst, inst.data(), inst.size());
+    if (!inst.empty()) big_memcpy(h + off_inst, inst.data(), inst.size());
     {
       int* blk = (int*)(h + off_blk);
       int j = 0;
@@ -1764,28 +1822,41 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
   order_upload((uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, row, height);
   size_t st_off = staging_alloc(row * height);
   uint8_t* st = ctx->staging + st_off;
-  for (int y = 0; y < height; y++) {
-    const uint8_t* s = data + (size_t)y * src_stride;
-    uint8_t* d = st + (size_t)y * row;
-    if (conv) {  // GL_RGBA upload into BGRA storage: copy_bgra8_to_rgba8 (gl.cc:1649-1661)
-      for (int x = 0; x < width; x++) {
-        uint32_t p; memcpy(&p, s + 4 * x, 4);
-        uint32_t rb = p & 0x00FF00FF;
-        p = (p & 0xFF00FF00) | (rb << 16) | (rb >> 16);
-        memcpy(d + 4 * x, &p, 4);
-      }
-    } else memcpy(d, s, row);
-  }
-  if (t.internal_format == GL_RGBA32I) {
-    if (xoffset == 0 && yoffset == 0) t.complex_ids_headers = t.complex_ids_gpubuf = false;   // (uploads start at the origin: a fresh frame)
-    const int32_t* iv = (const int32_t*)st;
-    const size_t ni = row * (size_t)height / 4;
+  const bool ids = t.internal_format == GL_RGBA32I;
+  std::atomic<int> id_flags{0};
+  auto copy_rows = [&](int part, int parts) {
+    const int ya = (int)((long long)height * part / parts), yb = (int)((long long)height * (part + 1) / parts);
     bool h = false, g = false;
-    for (size_t i = 0; i + 3 < ni; i += 4) {
-      g |= ((uint32_t)iv[i] >> 23) != 0u;                            // ps_quad header: [transform_id, z, pattern input]
-      if ((i & 4) == 0) h |= ((uint32_t)iv[i + 2] >> 23) != 0u;      // prim header texel 0: [z, specific, transform_id, task]
+    for (int y = ya; y < yb; y++) {
+      const uint8_t* s = data + (size_t)y * src_stride;
+      uint8_t* d = st + (size_t)y * row;
+      if (conv) {  // GL_RGBA upload into BGRA storage: copy_bgra8_to_rgba8 (gl.cc:1649-1661)
+        for (int x = 0; x < width; x++) {
+          uint32_t p; memcpy(&p, s + 4 * x, 4);
+          uint32_t rb = p & 0x00FF00FF;
+          p = (p & 0xFF00FF00) | (rb << 16) | (rb >> 16);
+          memcpy(d + 4 * x, &p, 4);
+        }
+      } else memcpy(d, s, row);
+      if (ids) {
+        // (rows are whole texels of four ints, and an upload that starts mid-row keeps the two-texel phase: the staged
+        // bytes are scanned as one array, as before)
+        const int32_t* iv = (const int32_t*)d;
+        const size_t i0 = (size_t)y * row / 4, ni = row / 4;
+        for (size_t i = 0; i + 3 < ni; i += 4) {
+          g |= ((uint32_t)iv[i] >> 23) != 0u;                                 // ps_quad header: [transform_id, z, pattern input]
+          if (((i0 + i) & 4) == 0) h |= ((uint32_t)iv[i + 2] >> 23) != 0u;    // prim header texel 0: [z, specific, transform_id, task]
+        }
+      }
     }
-    t.complex_ids_headers |= h; t.complex_ids_gpubuf |= g;
+    if (h || g) id_flags.fetch_or((h ? 1 : 0) | (g ? 2 : 0), std::memory_order_relaxed);
+  };
+  if (row * (size_t)height >= PARALLEL_COPY_MIN && height >= 8) copy_pool().run(copy_rows);
+  else copy_rows(0, 1);
+  if (ids) {
+    if (xoffset == 0 && yoffset == 0) t.complex_ids_headers = t.complex_ids_gpubuf = false;   // (uploads start at the origin: a fresh frame)
+    const int f = id_flags.load(std::memory_order_relaxed);
+    t.complex_ids_headers |= (f & 1) != 0; t.complex_ids_gpubuf |= (f & 2) != 0;
   }
   queue_upload(st_off, (uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, row, height);
 }
@@ -1867,12 +1938,12 @@ void BufferData(GLenum target, GLsizeiptr size, const GLvoid* data, GLenum) {
   HostTimer ht(&ctx->stats.host_upload_ns);
   Buffer& b = ctx->buffers[ctx->get_binding(target)];
   if (size != b.size && !b.allocate(size)) out_of_memory();
-  if (data && b.buf && size <= b.size) memcpy(b.buf, data, size);
+  if (data && b.buf && size <= b.size) big_memcpy(b.buf, data, size);
 }
 void BufferSubData(GLenum target, GLintptr offset, GLsizeiptr size, const GLvoid* data) {
   HostTimer ht(&ctx->stats.host_upload_ns);
   Buffer& b = ctx->buffers[ctx->get_binding(target)];
-  if (data && b.buf && offset + size <= b.size) memcpy(&b.buf[offset], data, size);
+  if (data && b.buf && offset + size <= b.size) big_memcpy(&b.buf[offset], data, size);
 }
 void* MapBuffer(GLenum target, GLbitfield) { return ctx->buffers[ctx->get_binding(target)].buf; }
 void* MapBufferRange(GLenum target, GLintptr offset, GLsizeiptr length, GLbitfield) {
@@ -2382,7 +2453,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   TargetWork& w = c->work[wi];
   size_t pos = (w.inst.size() + 15) & ~size_t(15);
   w.inst.resize(pos + need);
-  if (need) memcpy(w.inst.data() + pos, instb->buf, need);
+  if (need) big_memcpy(w.inst.data() + pos, instb->buf, need);
   d.inst_offset = pos; d.inst_stride = inst_stride;
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG") && need >= 16) { const float* f = (const float*)(w.inst.data() + pos); fprintf(stderr, "record: sh %d buf %u need %zu first %g %g %g %g\n", d.shader, inst_buf, need, f[0], f[1], f[2], f[3]); }

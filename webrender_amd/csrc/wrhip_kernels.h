@@ -6116,83 +6116,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // requested before the current word is processed), tests it against this
   // wave's strip, and the survivors -- a ballot mask, still in submission
   // order -- are broadcast one by one with v_readlane into SGPRs.
-  // The bin's mask words are themselves fetched 64 at a time (lane l loads word l of the block, the next block is requested
-  // before this one is walked) and only the non-zero ones are visited.  A block whose set bits are thinly spread -- a target
-  // with 100 k prims has ~1500 words per bin of which a few dozen hold one bit each (cfg5) -- is compacted first: a wave
-  // prefix sum over the words' popcounts gives every set bit a slot, the lanes scatter their prim indices into a 64-entry
-  // LDS row of the wave, and one record fetch + ballot serves up to 64 prims of up to 4096 consecutive ones instead of one
-  // fetch per word.  Slots are in (word, bit) order, so submission order is kept.  Dense blocks keep the word-per-round walk.
-  __shared__ int pid_row[16][64];
-  const int nw = T.words_per_bin;
-  int wb = 0, wb_next = 0;                       // block being walked / block whose words are in mv_next
-  unsigned long long mv = 0ull, mv_next = lane < nw ? mw[lane] : 0ull;
-  unsigned long long nz = 0ull;                  // dense walk: non-zero words of the block still to visit
-  int blk_rounds = 0, blk_round = 0, total = 0, prefix = 0;
-  bool sparse = false;
-  // next round: this lane's prim index (or -1), in dbase_ the index lane 0 would have in a dense round
-  auto next_round = [&](int& pid_, int& dbase_, bool& sp_) -> bool {
-    for (;;) {
-      if (blk_rounds == 0) {
-        if (wb_next >= nw) return false;
-        mv = mv_next; wb = wb_next; wb_next += 64;
-        mv_next = wb_next + lane < nw ? mw[wb_next + lane] : 0ull;
-        nz = __ballot(mv != 0ull);
-        if (!nz) continue;
-        const int cnt = __popcll(mv);
-        int inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-        prefix = inc - cnt;
-        total = __builtin_amdgcn_readlane(inc, 63);
-        const int nzw = __popcll(nz), rounds = (total + 63) >> 6;
-        sparse = rounds * 2 <= nzw;
-        blk_rounds = sparse ? rounds : nzw;
-        blk_round = 0;
-      }
-      blk_rounds--;
-      sp_ = sparse;
-      if (sparse) {
-        const int s0 = prefix - blk_round * 64;            // slot of this lane's first bit, relative to the round
-        if (s0 < 64 && s0 + __popcll(mv) > 0) {
-          int sl = s0;
-          for (unsigned long long bts = mv; bts; bts &= bts - 1ull, sl++)
-            if ((unsigned)sl < 64u) pid_row[wave][sl] = T.first_prim + (wb + lane) * 64 + __builtin_ctzll(bts);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        pid_ = lane < total - blk_round * 64 ? pid_row[wave][lane] : -1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        dbase_ = 0;
-      } else {
-        const int cw = __builtin_ctzll(nz);
-        nz &= nz - 1ull;
-        const unsigned long long m_ = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
-                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
-        dbase_ = T.first_prim + (wb + cw) * 64;
-        pid_ = ((m_ >> lane) & 1ull) ? dbase_ + lane : -1;
-      }
-      blk_round++;
-      return true;
-    }
-  };
-  int pid_n = -1, dbase_n = 0;
-  bool sp_n = false;
-  bool more = next_round(pid_n, dbase_n, sp_n);
-  uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
-  if (more && pid_n >= 0) {
-    const uint4* rp = (const uint4*)&recs[pid_n];
-    na = rp[0]; nb = rp[1];
-  }
-  while (more) {
-    const int pid = pid_n, dbase = dbase_n;
-    const bool sp = sp_n;
-    const uint4 ra = na, rb = nb;
-    more = next_round(pid_n, dbase_n, sp_n);
-    if (more && pid_n >= 0) {
-      const uint4* rp = (const uint4*)&recs[pid_n];
-      na = rp[0]; nb = rp[1];
-    }
-    // prim index of the round's lane `b_` (uniform b_)
+  // One round: up to 64 prims, lane i holding the record of prim `pid` (-1: none); in a dense round (sp false) lane i's prim is
+  // dbase + i.  Prim index of the round's lane `b_` (uniform b_):
 #define WR_PID(b_) (sp ? __builtin_amdgcn_readlane(pid, (b_)) : dbase + (b_))
+  auto do_round = [&](const int pid, const int dbase, const bool sp, const uint4 ra, const uint4 rb) __attribute__((always_inline)) {
     const bool has = pid >= 0;
     const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);
     unsigned long long live = __ballot(hit);
@@ -6282,8 +6209,124 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       else
         wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[pi], &aux[pi], draws, vtab, px, py, wx0, wy0, rr);
     }
-  }
+  };
 #undef WR_PID
+  const int nw = T.words_per_bin;
+  if constexpr (FMT == WR_FMT_RGBA8 && FEAT == 0 && !DEPTH) {
+    // The rect-only, depth-less variant runs at 8 waves per SIMD on 64 VGPRs with nothing to spare: it keeps the plain walk --
+    // the bin's mask words fetched 64 at a time (lane l loads word l of the block), the non-zero ones visited one per round,
+    // the next word's records requested before the current word is processed (the block walk below costs it 8 %, cfg2).
+    for (int wb = 0; wb < nw; wb += 64) {
+      const unsigned long long mv = wb + lane < nw ? mw[wb + lane] : 0ull;
+      unsigned long long nz = __ballot(mv != 0ull);
+      if (!nz) continue;
+      unsigned long long m_next;
+      uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
+      {
+        const int cw = __builtin_ctzll(nz);
+        m_next = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
+                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
+        if ((m_next >> lane) & 1ull) {
+          const uint4* rp = (const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
+          na = rp[0]; nb = rp[1];
+        }
+      }
+      while (nz) {
+        const int w = wb + __builtin_ctzll(nz);
+        nz &= nz - 1ull;
+        const unsigned long long m = m_next;
+        const uint4 ra = na, rb = nb;
+        const int base = T.first_prim + w * 64;
+        if (nz) {
+          const int cw = __builtin_ctzll(nz);
+          m_next = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
+          if ((m_next >> lane) & 1ull) {
+            const uint4* rp = (const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
+            na = rp[0]; nb = rp[1];
+          }
+        }
+        do_round(((m >> lane) & 1ull) ? base + lane : -1, base, false, ra, rb);
+      }
+    }
+  } else {
+  // The bin's mask words are themselves fetched 64 at a time (lane l loads word l of the block, the next block is requested
+  // before this one is walked) and only the non-zero ones are visited.  A block whose set bits are thinly spread -- a target
+  // with 100 k prims has ~1500 words per bin of which a few dozen hold one bit each (cfg5) -- is compacted first: a wave
+  // prefix sum over the words' popcounts gives every set bit a slot, the lanes scatter their prim indices into a 64-entry
+  // LDS row of the wave, and one record fetch + ballot serves up to 64 prims of up to 4096 consecutive ones instead of one
+  // fetch per word.  Slots are in (word, bit) order, so submission order is kept.  Dense blocks keep the word-per-round walk.
+  __shared__ int pid_row[16][64];
+  int wb = 0, wb_next = 0;                       // block being walked / block whose words are in mv_next
+  unsigned long long mv = 0ull, mv_next = lane < nw ? mw[lane] : 0ull;
+  unsigned long long nz = 0ull;                  // dense walk: non-zero words of the block still to visit
+  int blk_rounds = 0, blk_round = 0, total = 0, prefix = 0;
+  bool sparse = false;
+  // next round: this lane's prim index (or -1), in dbase_ the index lane 0 would have in a dense round
+  auto next_round = [&](int& pid_, int& dbase_, bool& sp_) -> bool {
+    for (;;) {
+      if (blk_rounds == 0) {
+        if (wb_next >= nw) return false;
+        mv = mv_next; wb = wb_next; wb_next += 64;
+        mv_next = wb_next + lane < nw ? mw[wb_next + lane] : 0ull;
+        nz = __ballot(mv != 0ull);
+        if (!nz) continue;
+        const int cnt = __popcll(mv);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        prefix = inc - cnt;
+        total = __builtin_amdgcn_readlane(inc, 63);
+        const int nzw = __popcll(nz), rounds = (total + 63) >> 6;
+        sparse = rounds * 2 <= nzw;
+        blk_rounds = sparse ? rounds : nzw;
+        blk_round = 0;
+      }
+      blk_rounds--;
+      sp_ = sparse;
+      if (sparse) {
+        const int s0 = prefix - blk_round * 64;            // slot of this lane's first bit, relative to the round
+        if (s0 < 64 && s0 + __popcll(mv) > 0) {
+          int sl = s0;
+          for (unsigned long long bts = mv; bts; bts &= bts - 1ull, sl++)
+            if ((unsigned)sl < 64u) pid_row[wave][sl] = T.first_prim + (wb + lane) * 64 + __builtin_ctzll(bts);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pid_ = lane < total - blk_round * 64 ? pid_row[wave][lane] : -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        dbase_ = 0;
+      } else {
+        const int cw = __builtin_ctzll(nz);
+        nz &= nz - 1ull;
+        const unsigned long long m_ = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
+                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
+        dbase_ = T.first_prim + (wb + cw) * 64;
+        pid_ = ((m_ >> lane) & 1ull) ? dbase_ + lane : -1;
+      }
+      blk_round++;
+      return true;
+    }
+  };
+  int pid_n = -1, dbase_n = 0;
+  bool sp_n = false;
+  bool more = next_round(pid_n, dbase_n, sp_n);
+  uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
+  if (more && pid_n >= 0) {
+    const uint4* rp = (const uint4*)&recs[pid_n];
+    na = rp[0]; nb = rp[1];
+  }
+  while (more) {
+    const int pid = pid_n, dbase = dbase_n;
+    const bool sp = sp_n;
+    const uint4 ra = na, rb = nb;
+    more = next_round(pid_n, dbase_n, sp_n);
+    if (more && pid_n >= 0) {
+      const uint4* rp = (const uint4*)&recs[pid_n];
+      na = rp[0]; nb = rp[1];
+    }
+    do_round(pid, dbase, sp, ra, rb);
+  }
+  }
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the
   // bin's words, zero them so the next flush needs no memset launch.
   __syncthreads();
