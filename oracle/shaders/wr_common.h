@@ -313,8 +313,12 @@ static void set_uniform_matrix4fv(VertexShaderImpl* impl, int index,
     self->bind_textures();                                                   \
   }
 
-// Fragment-side wiring for programs without perspective-specific paths: the
-// 2-D raster path (rasterize.h:783-1055) only ever uses the non-W variants.
+// Fragment-side wiring.  The 2-D raster path (rasterize.h:783-1055) only ever uses the non-W
+// variants.  The W variants (draw_perspective_spans, rasterize.h:1064-1280) are what the generated
+// run_perspective / skip_perspective do for a program WITHOUT interpolated varyings -- main(), then
+// step_perspective() (program.h:145-148: gl_FragCoord.z / .w advance by swgl_StepZW) -- so they are
+// exact for brush_solid and for the solid pattern of ps_quad_textured; the perspective-correct
+// varyings of the other programs (read_perspective_inputs: interpolant * 1/w) are not restated.
 #define WRSH_FRAG_ABI(Self)                                   \
   static void run(FragmentShaderImpl* impl) {                 \
     Self* self = (Self*)impl;                                 \
@@ -324,6 +328,17 @@ static void set_uniform_matrix4fv(VertexShaderImpl* impl, int index,
   static void skip(FragmentShaderImpl* impl, int steps) {     \
     Self* self = (Self*)impl;                                 \
     self->step_interp_inputs(steps);                          \
+  }                                                           \
+  static void run_w(FragmentShaderImpl* impl) {               \
+    Self* self = (Self*)impl;                                 \
+    self->main();                                             \
+    self->step_perspective();                                 \
+    self->step_interp_inputs();                               \
+  }                                                           \
+  static void skip_w(FragmentShaderImpl* impl, int steps) {   \
+    Self* self = (Self*)impl;                                 \
+    self->step_perspective(steps);                            \
+    self->step_interp_inputs(steps);                          \
   }
 
 #define WRSH_FRAG_WIRING()                    \
@@ -331,7 +346,7 @@ static void set_uniform_matrix4fv(VertexShaderImpl* impl, int index,
   run_func = &run;                            \
   skip_func = &skip;                          \
   init_span_w_func = &read_interp_inputs;     \
-  run_w_func = &run;                          \
-  skip_w_func = &skip;
+  run_w_func = &run_w;                        \
+  skip_w_func = &skip_w;
 
 }  // namespace wrsh

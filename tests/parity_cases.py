@@ -72,7 +72,16 @@ ROTATED += [
     ("occluded_quad_gradients", lambda: scenes.add_occluders(scenes.quad_gradients(seed=183), zmax=60, seed=36)),
     ("occluded_rotated_quad_gradients", lambda: scenes.add_occluders(scenes.quad_gradients(rotate=True, seed=184), zmax=60, seed=37)),
 ]
-ROTATED_GOLDEN = ("rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
+# draw_perspective (rasterize.h:1064-1280, 1449-1547): solid rects under projective transforms -- vertex w differs, screen
+# points from pos.xyz / w, depth interpolated per pixel along every span (the occluders' depth test is per sample) -- alone
+# and behind / in front of opaque occluders, both encodings.  0 differing bytes.
+ROTATED += [
+    ("perspective_rects", lambda: scenes.rotated_rects(perspective=True, seed=97)),
+    ("perspective_rects_quad", lambda: scenes.rotated_rects(perspective=True, encoding="quad", seed=98)),
+    ("occluded_perspective_rects", lambda: scenes.add_occluders(scenes.rotated_rects(perspective=True, seed=99), zmax=70, seed=38)),
+    ("occluded_perspective_rects_quad", lambda: scenes.add_occluders(scenes.rotated_rects(perspective=True, encoding="quad", seed=100), zmax=70, seed=39)),
+]
+ROTATED_GOLDEN = ("perspective_rects", "occluded_perspective_rects", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

@@ -285,6 +285,24 @@ def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
         assert np.array_equal(g[..., [2, 1, 0, 3]], want), f"frame {i}"
 
 
+def test_unimplemented_perspective_prims_are_reported(hostsim, capfd):
+    """Perspective prims outside the implemented set (here: depth-writing ones in the opaque pass) are counted by the setup
+    stage, reported on stderr at Finish and raise GL_INVALID_OPERATION -- not drawn wrongly, not dropped silently; the
+    alpha-pass ones of the same frame are drawn."""
+    from webrender_amd import glapi, glconst as G
+    from webrender_amd.renderer import Renderer
+    gl = glapi.GL(hostsim)
+    r = Renderer(gl, 512, 512)
+    r.render(scenes.rotated_rects(width=512, height=512, n=30, perspective=True, opaque_frac=0.5, seed=5))
+    r.finish()
+    assert gl.GetError() == G.GL_INVALID_OPERATION
+    assert gl.GetError() == 0
+    assert "perspective" in capfd.readouterr().err
+    px = r.read_pixels()
+    assert (px != 255).any()
+    r.destroy()
+
+
 def test_texture_allocation_failure_is_sticky_out_of_memory(hostsim, monkeypatch):
     """HBM exhaustion while allocating texture storage raises the sticky GL_OUT_OF_MEMORY swgl raises (gl.cc:1125-1134;
     Renderer counts consecutive ones, renderer/mod.rs:1296-1303) instead of aborting; the texture stays unusable, draws to

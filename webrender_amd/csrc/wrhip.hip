@@ -2472,7 +2472,7 @@ void Finish(void) {
     wrrt::d2h(&h, ctx->dcounters, sizeof(h), ctx->stream);
     sync_stream();
     if (h.unsupported_prims != ctx->seen.unsupported_prims || h.perspective_prims != ctx->seen.perspective_prims) {
-      fprintf(stderr, "libwrhip: %u prim(s) on not-yet-implemented paths (shader replays on rotated quads), %u perspective: not drawn\n",
+      fprintf(stderr, "libwrhip: %u prim(s) on not-yet-implemented paths, %u perspective ones (textured, clipped by the near / far planes or depth-writing): not drawn\n",
               h.unsupported_prims - ctx->seen.unsupported_prims, h.perspective_prims - ctx->seen.perspective_prims);
       // visible at the ABI, not only on stderr: the frame has holes, and the caller's GetError() says so (the reference
       // itself only ever raises GL_OUT_OF_MEMORY, gl.cc:1125-1134, so any other code is unambiguous)

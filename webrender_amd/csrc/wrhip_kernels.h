@@ -1635,16 +1635,33 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   P.blend = (int16_t)d.blend;
   P.flags = d.flags & (WR_PF_DEPTH_TEST | WR_PF_DEPTH_WRITE | WR_PF_DEPTH_LESS);
   P.x0 = P.y0 = P.x1 = P.y1 = 0;
-  if (o.pw[1] != o.pw[0] || o.pw[2] != o.pw[0] || o.pw[3] != o.pw[0]) {  // perspective path: "next"
-    atomicAdd(&cnt->perspective_prims, 1u);
-    return;
-  }
+  // draw_perspective (rasterize.h:1449-1547): any vertex w different from the others.  Implemented for solid colours
+  // (no varyings to divide by w) whose vertices lie between the near and far planes; clipping against the view volume
+  // (clip_side, :1286-1430), perspective-correct varyings and depth-WRITING perspective prims are counted and skipped.
+  const bool persp = o.pw[1] != o.pw[0] || o.pw[2] != o.pw[0] || o.pw[3] != o.pw[0];
   float w = 1.0f / o.pw[0];
   if (!wr_isfinite(w)) w = 0.0f;
-  float sx[4], sy[4];
-  for (int n = 0; n < 4; n++) {
-    sx[n] = (o.px[n] * w + 1.0f) * 0.5f * d.vp_size[0] + d.vp_origin[0];
-    sy[n] = (o.py[n] * w + 1.0f) * 0.5f * d.vp_size[1] + d.vp_origin[1];
+  float sx[4], sy[4], pz3[4], pw3[4];
+  if (persp) {
+    bool inside = true;
+    for (int n = 0; n < 4; n++) inside = inside && (o.pz[n] > -o.pw[n]) && (o.pz[n] < o.pw[n]);
+    if (!inside || o.kind != WR_PK_SOLID || (d.flags & WR_DF_DEPTH_WRITE)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
+    // screen = pos.xyz * (1 / pos.w) * scale + offset, scale = (viewport size, 1) / 2, offset = (viewport origin, 0) + scale
+    const float scx = d.vp_size[0] * 0.5f, scy = d.vp_size[1] * 0.5f;
+    const float ofx = d.vp_origin[0] + scx, ofy = d.vp_origin[1] + scy;
+    for (int n = 0; n < 4; n++) {
+      const float wn = 1.0f / o.pw[n];
+      sx[n] = o.px[n] * wn * scx + ofx;
+      sy[n] = o.py[n] * wn * scy + ofy;
+      pz3[n] = o.pz[n] * wn * 0.5f + 0.5f;
+      pw3[n] = wn;
+    }
+  } else {
+    for (int n = 0; n < 4; n++) {
+      sx[n] = (o.px[n] * w + 1.0f) * 0.5f * d.vp_size[0] + d.vp_origin[0];
+      sy[n] = (o.py[n] * w + 1.0f) * 0.5f * d.vp_size[1] + d.vp_origin[1];
+      pz3[n] = 0.f; pw3[n] = 0.f;
+    }
   }
   float cx0 = float(d.clip[0]), cy0 = float(d.clip[1]), cx1 = float(d.clip[2]), cy1 = float(d.clip[3]);
   bool masked = false;
@@ -1675,9 +1692,11 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     sides |= sy[n] < cy1 ? (sy[n] > cy0 ? 12 : 4) : 8;
   }
   if (sides != 0xF) return;
-  float screenZ = (o.pz[0] * w + 1.0f) * 0.5f;
-  if (screenZ < 0.0f || screenZ > 1.0f) return;
-  P.z = uint32_t(16777215.0f * screenZ);
+  if (!persp) {
+    float screenZ = (o.pz[0] * w + 1.0f) * 0.5f;
+    if (screenZ < 0.0f || screenZ > 1.0f) return;
+    P.z = uint32_t(16777215.0f * screenZ);
+  }     // (perspective: depth is per pixel, P.z = 0 keeps the strip depth cap from ever rejecting the prim)
 
   // swgl_antiAlias only takes effect when blending is on (ClipRect ctor, rasterize.h:414-441)
   const bool aa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
@@ -1691,9 +1710,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   // lanes: 0=(0,0) 1=(1,0) 2=(1,1) 3=(0,1) of the unit quad
   bool typeA = sy[0] == sy[1] && sy[2] == sy[3] && sx[0] == sx[3] && sx[1] == sx[2];
   bool typeB = sx[0] == sx[1] && sx[2] == sx[3] && sy[0] == sy[3] && sy[1] == sy[2];
-  if ((!typeA && !typeB) || (aa && texq)) {
+  if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
+    if (persp && !solidq) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     if (!solidq && !texq) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
     }
@@ -1704,7 +1724,11 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     else if (o.kind == WR_PK_FILTER) base.filt = auxp->filt;
     else if (o.kind == WR_PK_QUAD_MASK) base.clip = auxp->clip;
     int bx0, by0, bx1, by1;
-    if (!wr_quad_walk(sx, sy, o.u, o.v, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1)) return;
+    // (perspective: the edges carry screen z and 1/w where the textured kinds carry their uv -- Point3D edges step exactly like
+    // interpolants, rasterize.h:1127-1152 -- and draw_perspective_spans picks the same start vertex and edges as
+    // draw_quad_spans for any quad without three vertices on one row)
+    if (!wr_quad_walk(sx, sy, persp ? pz3 : o.u, persp ? pw3 : o.v, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1)) return;
+    auxp->quad.pad = persp ? 1 : 0;
     P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
     if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
     P.rows_linear = 0;
@@ -3374,6 +3398,34 @@ __device__ __noinline__ unsigned long long wr_quad_pixel_rgba8(const WrQuadRec* 
   src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
   src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
   return HIT | wr_blend_rgba8(blend, dstp_, src, D);
+}
+
+// The packed depth of one pixel of a perspective quad (draw_perspective_spans, rasterize.h:1236-1258 + packDepth :345): the
+// row's edges give z at the span's ends (Point3D edges, stepped once per row), stepZW = (right.zw - left.zw) / (right.x -
+// left.x), gl_FragCoord.z = init_interp(z at the span start's pixel centre, step) -- three sequential adds -- and every
+// 4-pixel chunk, drawn or skipped, adds 4 * step (step_perspective, program.h:145-148).
+__device__ __noinline__ uint32_t wr_persp_depth(const WrQuadRec* Qp, int x, int y) {
+  const WrQuadRec& Q = *Qp;
+  int si = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  if (si < 0) return 0xFFFFFFFFu;
+  const WrQuadSeg& S = Q.seg[si];
+  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
+  int s0;
+  if (!Q.aa) s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+  else s0 = S.lmask ? int(floorf(wr_clamp(xl - 0.5f * fabsf(S.ls), S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+  const float zl = wr_accum(S.luv[0], S.luvs[0], y - S.lrow), zr = wr_accum(S.ruv[0], S.ruvs[0], y - S.rrow);
+  float stepScale = 1.0f / (xr - xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float stepZ = (zr - zl) * stepScale;
+  const float z0 = zl + stepZ * ((float(s0) + 0.5f) - xl);
+  const int k = x - s0;
+  if (k < 0) return 0xFFFFFFFFu;
+  float zi = z0;
+  for (int i = 0; i < (k & 3); i++) zi = zi + stepZ;
+  const float zc = wr_accum(zi, stepZ * 4.0f, k >> 2);
+  return uint32_t(int(zc * 16777215.0f));
 }
 
 // One pixel of an anti-aliased solid quad (DO_AA, blend.h:433-446): src = muldiv256(src, coverage)
@@ -5709,19 +5761,24 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
   }
   if ((FEAT & WR_FEAT_GENERIC) && FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID_QUAD) {
     const WrDrawDesc* D = &draws[Pp->draw];
+    // perspective quads: depth varies per pixel, and the row is drawn chunk by chunk from the span start against the
+    // flattened depth row (draw_span<.., true>, rasterize.h:667-690) -- no restarts at depth runs
+    const bool persp = Ap->quad.pad != 0;
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
       const bool in = cx[q & 3] && cy[q >> 2];
       if (!in) continue;
       const uint32_t before = plo[q] | (phi[q] << 8);
       bool pass = true;
-      if (dtest) pass = dless ? (z < dep[q]) : (z <= dep[q]);
+      uint32_t zq = z;
+      if (dtest && persp) zq = wr_persp_depth(&Ap->quad, px + (q & 3), py + 4 * (q >> 2));
+      if (dtest) pass = dless ? (zq < dep[q]) : (zq <= dep[q]);
       if (!pass) continue;
       const unsigned long long hr = wr_quad_pixel_rgba8(&Ap->quad, D, blend, c0, c1, px + (q & 3), py + 4 * (q >> 2), before,
-                                                        rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
+                                                        (rr && !persp) ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
       if (!(hr >> 32)) continue;
       const uint32_t r = (uint32_t)hr;
-      if (dtest && dwrite) dep[q] = z;
+      if (dtest && dwrite) dep[q] = zq;
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;

@@ -1571,7 +1571,11 @@ def filter_swatches(seed=91):
 # ---------------------------------------------------------------------------
 # Rotated / skewed solid rectangles: the general convex-quad path of draw_quad_spans (rasterize.h:783-1055)
 # with swgl_antiAlias on all four edges (brush.glsl: non-axis-aligned transforms take the antialiased branch).
-def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile_filter=None, only=None, opaque_frac=0.0):
+def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile_filter=None, only=None, opaque_frac=0.0,
+                  perspective=False):
+    """perspective: every transform gets a projective row as well (w = 1 + k . (p - centre), w > 0 over the rect), so the
+    vertices' w differ and swgl takes draw_perspective (rasterize.h:1449-1547; wrench/benchmarks/transforms-simple.yaml is
+    the reference's own scene of this kind)."""
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     prims = []
@@ -1585,6 +1589,16 @@ def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile
         m = np.eye(4)
         m[:2, :2] = a
         m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+        if perspective:
+            # T(c) . P . R . T(-c): the projective row acts on the rotated offset from the centre, |k . offset| <= 0.6
+            rr_ = float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk))
+            k = rng.uniform(-1.0, 1.0, size=2)
+            k = k / max(float(np.hypot(*k)), 1e-3) * float(rng.uniform(0.15, 0.6)) / rr_
+            tneg, tpos, rot, pm = np.eye(4), np.eye(4), np.eye(4), np.eye(4)
+            tneg[:2, 3] = (-cx, -cy); tpos[:2, 3] = (cx, cy)
+            rot[:2, :2] = a
+            pm[3, 0], pm[3, 1] = k
+            m = tpos @ pm @ rot @ tneg
         inv = np.linalg.inv(m)
         tid = frame.add_transform(m.T.astype(np.float32), inv.T.astype(np.float32), axis_aligned=False)   # blocks = columns
         rgba = np.array([[rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256), rng.integers(90, 256)]], np.uint8)
