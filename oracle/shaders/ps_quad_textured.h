@@ -240,6 +240,30 @@ struct ps_quad_textured_frag : FragmentShaderImpl, ps_quad_textured_vert {
     v_uv0 += interp_step.v_uv0 * chunks;
   }
 
+  // the perspective entry points glsl-to-cxx emits for a program with a varying (lib.rs:660-690, 716-741): the edges
+  // interpolate v_uv0 / w, each chunk multiplies by 1 / gl_FragCoord.w, which step_perspective advances with z
+  struct InterpPerspective {
+    vec2 v_uv0;
+  };
+  InterpPerspective interp_perspective;
+  static void read_perspective_inputs(FragmentShaderImpl* impl, const void* init_,
+                                      const void* step_) {
+    Self* self = (Self*)impl;
+    const InterpInputs* init = (const InterpInputs*)init_;
+    const InterpInputs* step = (const InterpInputs*)step_;
+    Float w = 1.0f / self->gl_FragCoord.w;
+    self->interp_perspective.v_uv0 = init_interp(init->v_uv0, step->v_uv0);
+    self->v_uv0 = self->interp_perspective.v_uv0 * w;
+    self->interp_step.v_uv0 = step->v_uv0 * 4.0f;
+  }
+  ALWAYS_INLINE void step_perspective_inputs(int steps = 4) {
+    step_perspective(steps);
+    float chunks = steps * 0.25f;
+    Float w = 1.0f / gl_FragCoord.w;
+    interp_perspective.v_uv0 += interp_step.v_uv0 * chunks;
+    v_uv0 = w * interp_perspective.v_uv0;
+  }
+
   // ps_quad.glsl:399-415 + ps_quad_textured.glsl:41-48
   void main() {
     vec4 base_color = vec4(v_color);
@@ -273,6 +297,7 @@ struct ps_quad_textured_frag : FragmentShaderImpl, ps_quad_textured_vert {
   }
 
   WRSH_FRAG_ABI(Self)
+  WRSH_FRAG_ABI_PERSPECTIVE(Self)
   static int draw_span_RGBA8(FragmentShaderImpl* impl) {
     Self* self = (Self*)impl;
     DISPATCH_DRAW_SPAN(self, RGBA8);
@@ -280,8 +305,8 @@ struct ps_quad_textured_frag : FragmentShaderImpl, ps_quad_textured_vert {
 
   ps_quad_textured_frag() {
     WRSH_FRAG_WIRING()
+    WRSH_FRAG_WIRING_PERSPECTIVE()
     draw_span_RGBA8_func = &draw_span_RGBA8;
-    enable_perspective();
   }
 };
 

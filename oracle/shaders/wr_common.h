@@ -313,12 +313,16 @@ static void set_uniform_matrix4fv(VertexShaderImpl* impl, int index,
     self->bind_textures();                                                   \
   }
 
-// Fragment-side wiring.  The 2-D raster path (rasterize.h:783-1055) only ever uses the non-W
-// variants.  The W variants (draw_perspective_spans, rasterize.h:1064-1280) are what the generated
-// run_perspective / skip_perspective do for a program WITHOUT interpolated varyings -- main(), then
-// step_perspective() (program.h:145-148: gl_FragCoord.z / .w advance by swgl_StepZW) -- so they are
-// exact for brush_solid and for the solid pattern of ps_quad_textured; the perspective-correct
-// varyings of the other programs (read_perspective_inputs: interpolant * 1/w) are not restated.
+// Fragment-side wiring for programs WITHOUT interpolated varyings and without a read of
+// gl_FragCoord.z / .w (glsl-to-cxx: use_perspective false, lib.rs:656-659): the generated
+// constructor wires the W entry points of draw_perspective_spans (rasterize.h:1064-1280) to the
+// plain ones (lib.rs:3632-3636) -- so gl_FragCoord.z is NOT stepped from chunk to chunk and every
+// chunk of a perspective span is depth-tested with the z of the span's first four pixels.  That
+// is what brush_solid does.  Programs with varyings restate read_perspective_inputs /
+// step_perspective_inputs / run_perspective / skip_perspective themselves and use
+// WRSH_FRAG_WIRING_PERSPECTIVE (ps_quad_textured.h); the ones that have not been restated yet keep
+// this wiring, which is wrong for them under perspective -- libwrhip reports such prims as
+// unsupported, so they are never compared.
 #define WRSH_FRAG_ABI(Self)                                   \
   static void run(FragmentShaderImpl* impl) {                 \
     Self* self = (Self*)impl;                                 \
@@ -328,17 +332,6 @@ static void set_uniform_matrix4fv(VertexShaderImpl* impl, int index,
   static void skip(FragmentShaderImpl* impl, int steps) {     \
     Self* self = (Self*)impl;                                 \
     self->step_interp_inputs(steps);                          \
-  }                                                           \
-  static void run_w(FragmentShaderImpl* impl) {               \
-    Self* self = (Self*)impl;                                 \
-    self->main();                                             \
-    self->step_perspective();                                 \
-    self->step_interp_inputs();                               \
-  }                                                           \
-  static void skip_w(FragmentShaderImpl* impl, int steps) {   \
-    Self* self = (Self*)impl;                                 \
-    self->step_perspective(steps);                            \
-    self->step_interp_inputs(steps);                          \
   }
 
 #define WRSH_FRAG_WIRING()                    \
@@ -346,7 +339,25 @@ static void set_uniform_matrix4fv(VertexShaderImpl* impl, int index,
   run_func = &run;                            \
   skip_func = &skip;                          \
   init_span_w_func = &read_interp_inputs;     \
-  run_w_func = &run_w;                        \
-  skip_w_func = &skip_w;
+  run_w_func = &run;                          \
+  skip_w_func = &skip;
+
+// lib.rs:3576-3590, 3627-3631
+#define WRSH_FRAG_ABI_PERSPECTIVE(Self)                                   \
+  static void run_perspective(FragmentShaderImpl* impl) {                 \
+    Self* self = (Self*)impl;                                             \
+    self->main();                                                         \
+    self->step_perspective_inputs();                                      \
+  }                                                                       \
+  static void skip_perspective(FragmentShaderImpl* impl, int steps) {     \
+    Self* self = (Self*)impl;                                             \
+    self->step_perspective_inputs(steps);                                 \
+  }
+
+#define WRSH_FRAG_WIRING_PERSPECTIVE()             \
+  enable_perspective();                            \
+  init_span_w_func = &read_perspective_inputs;     \
+  run_w_func = &run_perspective;                   \
+  skip_w_func = &skip_perspective;
 
 }  // namespace wrsh

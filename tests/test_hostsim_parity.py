@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, PERSPECTIVE_MIXED
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -181,6 +181,17 @@ def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     assert stats["raster_launches"] >= 1
     if name in GOLDEN and golden_applies(name):
         assert digest(got) == GOLDEN[name]
+
+
+@pytest.mark.parametrize("name,make", PERSPECTIVE_MIXED, ids=[c[0] for c in PERSPECTIVE_MIXED])
+def test_hostsim_flattened_depth_rows_are_a_bounded_deviation(hostsim, oracle_gcc, name, make):
+    """2-D textured prims after a perspective prim on the same rows of a depth-tested target (parity_cases.PERSPECTIVE_MIXED):
+    at most 2 LSB per channel on well under 0.1 % of the pixels -- a known deviation until flattened rows are modelled."""
+    want, _ = render_direct(oracle_gcc, make())
+    got, _ = render_direct(hostsim, make())
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 2
+    assert (d.max(axis=-1) > 0).mean() < 0.001 and (d.max(axis=-1) > 1).mean() < 0.0001
 
 
 def _cache_key(scene):

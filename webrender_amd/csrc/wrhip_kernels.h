@@ -1513,21 +1513,25 @@ WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
 // starts, which edges are the span's left and right ones, when each edge ends and is replaced
 // (STEP_EDGE), the clip span of every edge pair.  Returns false for degenerate walks (nothing to draw)
 // or more runs than WrQuadRec holds.  p[] in vertex-lane order (0,0) (1,0) (1,1) (0,1).
-struct WrEdgeInst { float x, slope; int row, mask; float u, v, us, vs; };
+struct WrEdgeInst { float x, slope; int row, mask; float u, v, us, vs; float z, w, zs, ws; };
 WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, float p1y, int mask, float u0, float v0, float u1,
-                                  float v1) {   // Edge ctor, :850-876
+                                  float v1, float z0, float w0, float z1, float w1) {   // Edge ctor, :850-876 (:1127-1152 for z, w)
   WrEdgeInst e;
   const float yScale = 1.0f / wr_max(p1y - p0y, 1.0f / 256.0f);
   e.slope = (p1x - p0x) * yScale;
   e.x = p0x + (y - p0y) * e.slope;
   e.us = (u1 - u0) * yScale; e.vs = (v1 - v0) * yScale;
   e.u = u0 + (y - p0y) * e.us; e.v = v0 + (y - p0y) * e.vs;
+  e.zs = (z1 - z0) * yScale; e.ws = (w1 - w0) * yScale;
+  e.z = z0 + (y - p0y) * e.zs; e.w = w0 + (y - p0y) * e.ws;
   e.row = int(y); e.mask = mask;
   return e;
 }
 // iu / iv: the shader's interpolated vec2 per vertex (zeros for solid prims)
+// iz / iw: screen z and 1/w per vertex of a perspective quad (stored in Q.persp when `persp`)
 WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const float (&iu)[4], const float (&iv)[4], float cx0, float cy0,
-                            float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1) {
+                            float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1,
+                            const float (&iz)[4], const float (&iw)[4], bool persp) {
   Q.nseg = 0; Q.aa = aa ? 1 : 0;
   // top-most point (:794-799)
   const int top = py[3] < py[2] ? (py[0] < py[1] ? (py[0] < py[3] ? 0 : 3) : (py[1] < py[3] ? 1 : 3))
@@ -1543,7 +1547,7 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
   float y = floorf(wr_max(wr_min(WR_PY(l0i), cy1), cy0) + aaRound) + 0.5f;
   // the l-chain walks forward through the points, the r-chain backward; `flipped` says which one is the span's left edge
 #define WR_EDGE(a, b, m) wr_edge_init(y, WR_PX(a), WR_PY(a), WR_PX(b), WR_PY(b), (aa_mask >> (m)) & 1, wr_pick4(iu, a), wr_pick4(iv, a), \
-                                     wr_pick4(iu, b), wr_pick4(iv, b))
+                                     wr_pick4(iu, b), wr_pick4(iv, b), wr_pick4(iz, a), wr_pick4(iw, a), wr_pick4(iz, b), wr_pick4(iw, b))
   WrEdgeInst EL = WR_EDGE(l0i, l1i, l1i);
   WrEdgeInst ER = WR_EDGE(r0i, r1i, r0i);
   bool flipped;
@@ -1591,6 +1595,12 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
     S.rx = B.x; S.rs = B.slope; S.rrow = B.row; S.rmask = B.mask;
     S.luv[0] = A.u; S.luv[1] = A.v; S.luvs[0] = A.us; S.luvs[1] = A.vs;
     S.ruv[0] = B.u; S.ruv[1] = B.v; S.ruvs[0] = B.us; S.ruvs[1] = B.vs;
+    if (persp) {
+      WrPerspRec& R = Q.persp;
+      const int k = Q.nseg - 1;
+      R.lz[k] = A.z; R.lzs[k] = A.zs; R.lw[k] = A.w; R.lws[k] = A.ws;
+      R.rz[k] = B.z; R.rzs[k] = B.zs; R.rw[k] = B.w; R.rws[k] = B.ws;
+    }
     S.b0 = b0; S.b1 = b1;
     bx0 = wr_imin(bx0, int(floorf(b0)) - 1); bx1 = wr_imax(bx1, int(ceilf(b1)) + 1);
     by1 = S.row_b;
@@ -1645,7 +1655,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (persp) {
     bool inside = true;
     for (int n = 0; n < 4; n++) inside = inside && (o.pz[n] > -o.pw[n]) && (o.pz[n] < o.pw[n]);
-    if (!inside || o.kind != WR_PK_SOLID || (d.flags & WR_DF_DEPTH_WRITE)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
+    const bool ptex = d.shader == WR_SH_PS_QUAD_TEXTURED && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS);
+    if (!inside || !(o.kind == WR_PK_SOLID || ptex) || (d.flags & WR_DF_DEPTH_WRITE)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     // screen = pos.xyz * (1 / pos.w) * scale + offset, scale = (viewport size, 1) / 2, offset = (viewport origin, 0) + scale
     const float scx = d.vp_size[0] * 0.5f, scy = d.vp_size[1] * 0.5f;
     const float ofx = d.vp_origin[0] + scx, ofy = d.vp_origin[1] + scy;
@@ -1713,7 +1724,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq) { atomicAdd(&cnt->perspective_prims, 1u); return; }
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS))) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     if (!solidq && !texq) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
     }
@@ -1724,11 +1735,16 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     else if (o.kind == WR_PK_FILTER) base.filt = auxp->filt;
     else if (o.kind == WR_PK_QUAD_MASK) base.clip = auxp->clip;
     int bx0, by0, bx1, by1;
-    // (perspective: the edges carry screen z and 1/w where the textured kinds carry their uv -- Point3D edges step exactly like
-    // interpolants, rasterize.h:1127-1152 -- and draw_perspective_spans picks the same start vertex and edges as
-    // draw_quad_spans for any quad without three vertices on one row)
-    if (!wr_quad_walk(sx, sy, persp ? pz3 : o.u, persp ? pw3 : o.v, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1)) return;
-    auxp->quad.pad = persp ? 1 : 0;
+    // (perspective: the edges also carry screen z and 1/w -- Point3D edges step exactly like interpolants, rasterize.h:1127-1152 --
+    // the interpolants are pre-multiplied by the vertex's 1/w (:1138-1143), and draw_perspective_spans picks the same start
+    // vertex and edges as draw_quad_spans for any quad without three vertices on one row)
+    float qu[4], qv[4];
+    for (int n = 0; n < 4; n++) { qu[n] = persp ? o.u[n] * pw3[n] : o.u[n]; qv[n] = persp ? o.v[n] * pw3[n] : o.v[n]; }
+    if (!wr_quad_walk(sx, sy, qu, qv, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1, pz3, pw3, persp)) return;
+    // 1: a program without varyings (brush_solid): glsl-to-cxx wires its perspective entry points to the plain ones, which never
+    // step gl_FragCoord.z -- every chunk of a span is depth-tested with the z of the span's first four pixels; 2: a program with
+    // varyings (ps_quad_textured): run_perspective / skip_perspective advance z and w chunk by chunk (lib.rs:656-659, 3627-3636)
+    auxp->quad.pad = persp ? (d.shader == WR_SH_PS_QUAD_TEXTURED ? 2 : 1) : 0;
     P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
     if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
     P.rows_linear = 0;
@@ -3403,7 +3419,8 @@ __device__ __noinline__ unsigned long long wr_quad_pixel_rgba8(const WrQuadRec* 
 // The packed depth of one pixel of a perspective quad (draw_perspective_spans, rasterize.h:1236-1258 + packDepth :345): the
 // row's edges give z at the span's ends (Point3D edges, stepped once per row), stepZW = (right.zw - left.zw) / (right.x -
 // left.x), gl_FragCoord.z = init_interp(z at the span start's pixel centre, step) -- three sequential adds -- and every
-// 4-pixel chunk, drawn or skipped, adds 4 * step (step_perspective, program.h:145-148).
+// 4-pixel chunk, drawn or skipped, adds 4 * step (step_perspective, program.h:145-148) -- in a program that has varyings;
+// one without (WrQuadRec::pad == 1) runs its chunks through the plain run / skip, which leave gl_FragCoord.z alone.
 __device__ __noinline__ uint32_t wr_persp_depth(const WrQuadRec* Qp, int x, int y) {
   const WrQuadRec& Q = *Qp;
   int si = -1;
@@ -3415,7 +3432,7 @@ __device__ __noinline__ uint32_t wr_persp_depth(const WrQuadRec* Qp, int x, int 
   int s0;
   if (!Q.aa) s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
   else s0 = S.lmask ? int(floorf(wr_clamp(xl - 0.5f * fabsf(S.ls), S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
-  const float zl = wr_accum(S.luv[0], S.luvs[0], y - S.lrow), zr = wr_accum(S.ruv[0], S.ruvs[0], y - S.rrow);
+  const float zl = wr_accum(Q.persp.lz[si], Q.persp.lzs[si], y - S.lrow), zr = wr_accum(Q.persp.rz[si], Q.persp.rzs[si], y - S.rrow);
   float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float stepZ = (zr - zl) * stepScale;
@@ -3424,7 +3441,7 @@ __device__ __noinline__ uint32_t wr_persp_depth(const WrQuadRec* Qp, int x, int 
   if (k < 0) return 0xFFFFFFFFu;
   float zi = z0;
   for (int i = 0; i < (k & 3); i++) zi = zi + stepZ;
-  const float zc = wr_accum(zi, stepZ * 4.0f, k >> 2);
+  const float zc = Q.pad == 2 ? wr_accum(zi, stepZ * 4.0f, k >> 2) : zi;
   return uint32_t(int(zc * 16777215.0f));
 }
 
@@ -3553,7 +3570,25 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     return HIT | wr_blend_rgba8(Pl.blend, dstp_, src, D);
   }
   WrWide src;
-  if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {
+  if (Q.pad) {
+    // draw_perspective_spans (rasterize.h:1236-1258) + read_perspective_inputs / step_perspective_inputs (glsl-to-cxx
+    // lib.rs:660-741): no span shader, every chunk runs main() with v_uv0 = (uv / w interpolated along the span) * (1 /
+    // gl_FragCoord.w); both are init_interp lanes at the span start that every chunk, drawn or skipped, advances by 4 steps
+    const float wl = wr_accum(Q.persp.lw[si], Q.persp.lws[si], y - S.lrow), wr = wr_accum(Q.persp.rw[si], Q.persp.rws[si], y - S.rrow);
+    float stepScale = 1.0f / (xr - xl);
+    if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+    const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale, sw = (wr - wl) * stepScale;
+    const float start = (float(s0) + 0.5f) - xl;
+    float pu = Lu + su * start, pv = Lv + sv * start, fw = wl + sw * start;
+    const int k = x - s0;
+    for (int i = 0; i < (k & 3); i++) { pu = pu + su; pv = pv + sv; fw = fw + sw; }
+    pu = wr_accum(pu, (su * 4.0f) * 1.0f, k >> 2); pv = wr_accum(pv, (sv * 4.0f) * 1.0f, k >> 2);
+    fw = wr_accum(fw, sw * 4.0f, k >> 2);
+    const float wq = 1.0f / fw;
+    float cu = pu * wq + Pl.uv_add[0], cv = pv * wq + Pl.uv_add[1];
+    if (Pl.flags & WR_PF_TAIL_CLAMP) { cu = wr_clamp(cu, Pl.uv_bounds[0], Pl.uv_bounds[2]); cv = wr_clamp(cv, Pl.uv_bounds[1], Pl.uv_bounds[3]); }
+    src = wr_tex_tail_texel(Pl, t, cu, cv);
+  } else if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {
     // shader replays that take their interpolants from the prim: hand them this row as a one-row axis-aligned prim (the span
     // [s0, s1), the edges' x and interpolants on this row, no row stepping left to do)
     Pl.uvL0[0] = Lu; Pl.uvL0[1] = Lv; Pl.uvR0[0] = Ru; Pl.uvR0[1] = Rv;
@@ -5742,19 +5777,22 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
   }
   if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_QUAD) {
     const WrDrawDesc* D = &draws[Pp->draw];
+    const bool persp = Ap->quad.pad != 0;       // (see WR_PK_SOLID_QUAD below)
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
       const bool in = cx[q & 3] && cy[q >> 2];
       if (!in) continue;
       const uint32_t before = plo[q] | (phi[q] << 8);
       bool pass = true;
-      if (dtest) pass = dless ? (z < dep[q]) : (z <= dep[q]);
+      uint32_t zq = z;
+      if (dtest && persp) zq = wr_persp_depth(&Ap->quad, px + (q & 3), py + 4 * (q >> 2));
+      if (dtest) pass = dless ? (zq < dep[q]) : (zq <= dep[q]);
       if (!pass) continue;
       const unsigned long long hr = wr_quad_tex_pixel_rgba8(Pp, &Ap->quad, D, px + (q & 3), py + 4 * (q >> 2), before,
-                                                            rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
+                                                            (rr && !persp) ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
       if (!(hr >> 32)) continue;
       const uint32_t r = (uint32_t)hr;
-      if (dtest && dwrite) dep[q] = z;
+      if (dtest && dwrite) dep[q] = zq;
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }
     return;

@@ -1154,6 +1154,18 @@ def rotation_about(frame, rng, cx, cy, i):
     return frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
 
 
+def projective_about(a, cx, cy, rr, rng):
+    """T(c) . P . A . T(-c): the 2x2 map `a` about (cx, cy) followed by a projective row w = 1 + k . (rotated offset from the
+    centre) with |k . offset| <= 0.6 inside radius rr, so that w stays positive over the prim."""
+    k = rng.uniform(-1.0, 1.0, size=2)
+    k = k / max(float(np.hypot(*k)), 1e-3) * float(rng.uniform(0.15, 0.6)) / rr
+    tneg, tpos, rot, pm = np.eye(4), np.eye(4), np.eye(4), np.eye(4)
+    tneg[:2, 3] = (-cx, -cy); tpos[:2, 3] = (cx, cy)
+    rot[:2, :2] = a
+    pm[3, 0], pm[3, 1] = k
+    return tpos @ pm @ rot @ tneg
+
+
 def rotated_bounds(rect):
     x0, y0, x1, y1 = rect
     cx, cy, rad = (x0 + x1) / 2, (y0 + y1) / 2, float(np.hypot(x1 - x0, y1 - y0)) * 0.75 + 4
@@ -1590,15 +1602,7 @@ def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile
         m[:2, :2] = a
         m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
         if perspective:
-            # T(c) . P . R . T(-c): the projective row acts on the rotated offset from the centre, |k . offset| <= 0.6
-            rr_ = float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk))
-            k = rng.uniform(-1.0, 1.0, size=2)
-            k = k / max(float(np.hypot(*k)), 1e-3) * float(rng.uniform(0.15, 0.6)) / rr_
-            tneg, tpos, rot, pm = np.eye(4), np.eye(4), np.eye(4), np.eye(4)
-            tneg[:2, 3] = (-cx, -cy); tpos[:2, 3] = (cx, cy)
-            rot[:2, :2] = a
-            pm[3, 0], pm[3, 1] = k
-            m = tpos @ pm @ rot @ tneg
+            m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng)
         inv = np.linalg.inv(m)
         tid = frame.add_transform(m.T.astype(np.float32), inv.T.astype(np.float32), axis_aligned=False)   # blocks = columns
         rgba = np.array([[rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256), rng.integers(90, 256)]], np.uint8)
@@ -1607,7 +1611,7 @@ def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile
             rgba[0, 3] = 255
         col = premultiply(rgba)[0]
         rect = (cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)
-        r = float(np.hypot(w, h)) * 0.75 + 4
+        r = float(np.hypot(w, h)) * (1.4 if perspective else 0.75) + 4
         prims.append((rect, tid, col, (cx - r, cy - r, cx + r, cy + r), opaque))
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
@@ -1649,7 +1653,7 @@ def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile
 # `repeat`: through the ANTIALIASING,REPETITION image brush with tiling stretch sizes; `masked`: under
 # swgl_clipMask as well.  Alpha pass only (AA needs blending, rasterize.h:414-441).
 def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=False, nearest=False, masked=False, tile_filter=None,
-                   only=None, encoding="brush"):
+                   only=None, encoding="brush", perspective=False):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -1680,7 +1684,7 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
         w, h = sw * sc, sh * sc * float(rng.uniform(0.7, 1.4))
         cx, cy = float(rng.uniform(0, width)), float(rng.uniform(0, height))
         flags = 0
-        if i % 6 == 5:        # axis-aligned, anti-aliased on request
+        if i % 6 == 5 and perspective != "all":        # axis-aligned, anti-aliased on request
             tid = 0
             flags = 1024
             cx, cy = cx + float(rng.uniform(0, 1)), cy + float(rng.uniform(0, 1))
@@ -1692,9 +1696,11 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
             m = np.eye(4)
             m[:2, :2] = a
             m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+            if perspective:      # (see rotated_rects)
+                m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng)
             tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
         rect = (cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)
-        rad = float(np.hypot(w, h)) * 0.75 + 4
+        rad = float(np.hypot(w, h)) * (1.4 if perspective else 0.75) + 4
         st = (-1.0, -1.0)
         if repeat and i % 3 != 2:
             st = (sw * float(rng.uniform(0.5, 1.5)), sh * float(rng.uniform(0.5, 1.5))) if i % 3 else (float(sw), float(sh))
