@@ -206,6 +206,64 @@
       float chunks = steps * 0.25f;                                            \
       v_uv += interp_step.v_uv * chunks;                                       \
     }                                                                          \
+    /* the perspective entry points glsl-to-cxx emits for a program with a */  \
+    /* varying (lib.rs:660-690, 716-741, 3576-3590) */                         \
+    struct InterpPerspective {                                                 \
+      vec2 v_uv;                                                               \
+    };                                                                         \
+    InterpPerspective interp_perspective;                                      \
+    static void read_perspective_inputs(FragmentShaderImpl* impl,              \
+                                        const void* init_, const void* step_) { \
+      Self* self = (Self*)impl;                                                \
+      const InterpInputs* init = (const InterpInputs*)init_;                   \
+      const InterpInputs* step = (const InterpInputs*)step_;                   \
+      Float w = 1.0f / self->gl_FragCoord.w;                                   \
+      self->interp_perspective.v_uv = init_interp(init->v_uv, step->v_uv);     \
+      self->v_uv = self->interp_perspective.v_uv * w;                          \
+      self->interp_step.v_uv = step->v_uv * 4.0f;                              \
+    }                                                                          \
+    ALWAYS_INLINE void step_perspective_inputs(int steps = 4) {                \
+      step_perspective(steps);                                                 \
+      float chunks = steps * 0.25f;                                            \
+      Float w = 1.0f / gl_FragCoord.w;                                         \
+      interp_perspective.v_uv += interp_step.v_uv * chunks;                    \
+      v_uv = w * interp_perspective.v_uv;                                      \
+    }                                                                          \
+    static void run_perspective(FragmentShaderImpl* impl) {                    \
+      Self* self = (Self*)impl;                                                \
+      self->main_w();                                                          \
+      self->step_perspective_inputs();                                         \
+    }                                                                          \
+    static void skip_perspective(FragmentShaderImpl* impl, int steps) {        \
+      Self* self = (Self*)impl;                                                \
+      self->step_perspective_inputs(steps);                                    \
+    }                                                                          \
+    /* main() as generated, with gl_FragCoord.w read per lane (:343-377); */   \
+    /* the 2-D main() below is the same function with w == 1 folded in. */     \
+    /* REPETITION keys under perspective are not restated. */                  \
+    void main_w() {                                                            \
+      Float perspective_divisor =                                              \
+          mix(gl_FragCoord.w, Float(1.0f), Float(v_perspective.x));            \
+      vec2 repeated_uv = v_uv * perspective_divisor +                          \
+                         vec2_scalar(v_uv_bounds.x, v_uv_bounds.y);            \
+      vec2 uv = clamp(repeated_uv,                                             \
+                      vec2_scalar(v_uv_sample_bounds.x, v_uv_sample_bounds.y), \
+                      vec2_scalar(v_uv_sample_bounds.z, v_uv_sample_bounds.w)); \
+      vec4 texel = texture(sColor0, uv);                                       \
+      vec4 color;                                                              \
+      if (ALPHA_PASS) {                                                        \
+        float alpha = 1.0f;                                                    \
+        vec3 rgb = texel.sel(X, Y, Z) * v_mask_swizzle.x +                     \
+                   texel.sel(W, W, W) * v_mask_swizzle.y;                      \
+        texel = vec4(rgb, texel.w);                                            \
+        vec4 alpha_mask = texel * alpha;                                       \
+        color = vec4(v_color) * alpha_mask;                                    \
+        color *= 1.0f; /* do_clip() */                                         \
+      } else {                                                                 \
+        color = texel;                                                         \
+      }                                                                        \
+      gl_FragColor = color;                                                    \
+    }                                                                          \
     /* compute_repeated_uvs: :318-341 */                                       \
     vec2 repeated_uvs(float perspective_divisor) const {                       \
       if (REPETITION) {                                                        \
@@ -295,6 +353,9 @@
     }                                                                          \
     NAME##_frag() {                                                            \
       WRSH_FRAG_WIRING()                                                       \
+      if (!REPETITION) {                                                       \
+        WRSH_FRAG_WIRING_PERSPECTIVE()                                         \
+      }                                                                        \
       draw_span_RGBA8_func = &draw_span_RGBA8;                                 \
     }                                                                          \
   };                                                                           \

@@ -83,6 +83,11 @@ ROTATED += [
     # ps_quad_textured sampling an atlas under projective transforms: every pixel through main() with v_uv0 = (uv / w) * (1 / gl_FragCoord.w)
     ("perspective_images_quad", lambda: scenes.rotated_images(perspective="all", encoding="quad", seed=102)),
     ("occluded_perspective_images_quad", lambda: scenes.add_occluders(scenes.rotated_images(perspective="all", encoding="quad", seed=103), zmax=60, seed=40)),
+    # brush_image (picture composites under 3-D transforms): screen-space-linear uv (v_uv * world w at the vertices, * gl_FragCoord.w per
+    # pixel) and, with BRUSH_FLAG_PERSPECTIVE_INTERPOLATION, perspective-correct uv
+    ("perspective_images", lambda: scenes.rotated_images(perspective="all", seed=104)),
+    ("occluded_perspective_images", lambda: scenes.add_occluders(scenes.rotated_images(perspective="all", seed=105), zmax=60, seed=41)),
+    ("perspective_images_masked", lambda: scenes.rotated_images(perspective="all", masked=True, seed=106)),
 ]
 # A perspective span flattens the depth row it touches (rasterize.h:1226-1232), and swgl then draws every LATER depth-tested prim
 # on that row chunk by chunk through main() instead of handing the span shader one depth run at a time (:1021-1031).  That
@@ -92,7 +97,7 @@ ROTATED += [
 PERSPECTIVE_MIXED = [
     ("occluded_perspective_images_mixed", lambda: scenes.add_occluders(scenes.rotated_images(perspective=True, encoding="quad", seed=103), zmax=60, seed=40)),
 ]
-ROTATED_GOLDEN = ("perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
+ROTATED_GOLDEN = ("perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

@@ -325,6 +325,7 @@ struct WrVsOut {
   int tail_modulate;   // fragment main(): multiplies texel by colour
   int blend_override;  // swgl_blendDropShadow / swgl_blendSubpixelText: WrBlend key replacing the draw's (0 = none)
   wf4 blend_color;     // ... and its constant colour (swgl_BlendColorRGBA8)
+  float persp_div;     // brush_image: perspective_interpolate of `uv = v_uv * mix(gl_FragCoord.w, 1.0, .)` in main(); < 0: no such factor
 };
 
 // ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
@@ -825,7 +826,10 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     Rp->alpha_pass = image == 6; Rp->no_span = tex.format != WR_FMT_RGBA8;
     if (tex.format != WR_FMT_RGBA8 && tex.format != WR_FMT_R8) { o.kind = WR_PK_UNSUPPORTED; return; }
   }
-  if (data1.y != 0 || persp) { o.kind = WR_PK_UNSUPPORTED; return; }          // RASTER_SCREEN quads / perspective: next
+  if (data1.y != 0) { o.kind = WR_PK_UNSUPPORTED; return; }          // RASTER_SCREEN: next
+  // BRUSH_FLAG_PERSPECTIVE_INTERPOLATION: v_uv was (not) multiplied by world_pos.w above; main() multiplies by
+  // mix(gl_FragCoord.w, 1.0, perspective_interpolate) -- 1 on the 2-D path, evaluated per pixel on the perspective one
+  o.persp_div = persp ? 1.0f : 0.0f;
   if (image == 1 || image == 5) {
     o.has_color = 0; o.tail_modulate = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
     return;
@@ -1655,7 +1659,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (persp) {
     bool inside = true;
     for (int n = 0; n < 4; n++) inside = inside && (o.pz[n] > -o.pw[n]) && (o.pz[n] < o.pw[n]);
-    const bool ptex = d.shader == WR_SH_PS_QUAD_TEXTURED && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS);
+    // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
+    const bool ptex = (d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS);
     if (!inside || !(o.kind == WR_PK_SOLID || ptex) || (d.flags & WR_DF_DEPTH_WRITE)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     // screen = pos.xyz * (1 / pos.w) * scale + offset, scale = (viewport size, 1) / 2, offset = (viewport origin, 0) + scale
     const float scx = d.vp_size[0] * 0.5f, scy = d.vp_size[1] * 0.5f;
@@ -1744,7 +1749,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // 1: a program without varyings (brush_solid): glsl-to-cxx wires its perspective entry points to the plain ones, which never
     // step gl_FragCoord.z -- every chunk of a span is depth-tested with the z of the span's first four pixels; 2: a program with
     // varyings (ps_quad_textured): run_perspective / skip_perspective advance z and w chunk by chunk (lib.rs:656-659, 3627-3636)
-    auxp->quad.pad = persp ? (d.shader == WR_SH_PS_QUAD_TEXTURED ? 2 : 1) : 0;
+    auxp->quad.pad = persp ? ((o.kind == WR_PK_SOLID && d.shader != WR_SH_PS_QUAD_TEXTURED) ? 1 : 2) : 0;
+    if (persp) auxp->quad.persp.div = o.persp_div;
     P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
     if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
     P.rows_linear = 0;
@@ -2833,7 +2839,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
   WrVsOut o;
   o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
   o.uv_add[0] = o.uv_add[1] = 0.0f;
-  o.blend_override = 0; o.blend_color = wf4{0, 0, 0, 0};
+  o.blend_override = 0; o.blend_color = wf4{0, 0, 0, 0}; o.persp_div = -1.0f;
   switch (d.shader) {
     case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
     case WR_SH_PS_QUAD_MASK: wr_vs_ps_quad_textured(d, arena, inst, o, 1, &aux[gid].clip); break;
@@ -3585,7 +3591,12 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     pu = wr_accum(pu, (su * 4.0f) * 1.0f, k >> 2); pv = wr_accum(pv, (sv * 4.0f) * 1.0f, k >> 2);
     fw = wr_accum(fw, sw * 4.0f, k >> 2);
     const float wq = 1.0f / fw;
-    float cu = pu * wq + Pl.uv_add[0], cv = pv * wq + Pl.uv_add[1];
+    float cu = pu * wq, cv = pv * wq;
+    if (Q.persp.div >= 0.0f) {       // brush_image: v_uv * mix(gl_FragCoord.w, 1.0, perspective_interpolate)
+      const float pd = (1.0f - fw) * Q.persp.div + fw;
+      cu = cu * pd; cv = cv * pd;
+    }
+    cu = cu + Pl.uv_add[0]; cv = cv + Pl.uv_add[1];
     if (Pl.flags & WR_PF_TAIL_CLAMP) { cu = wr_clamp(cu, Pl.uv_bounds[0], Pl.uv_bounds[2]); cv = wr_clamp(cv, Pl.uv_bounds[1], Pl.uv_bounds[3]); }
     src = wr_tex_tail_texel(Pl, t, cu, cv);
   } else if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {

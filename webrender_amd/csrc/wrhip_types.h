@@ -453,7 +453,7 @@ struct WrRepeatRec {
 
 // draw_perspective_spans (rasterize.h:1064-1280): the edges of a run also carry screen z and 1/w (Point3D edges; values at row
 // lrow / rrow of the run and per-row slopes), and the uv of WrQuadSeg are uv / w
-struct WrPerspRec { float lz[4], lzs[4], lw[4], lws[4], rz[4], rzs[4], rw[4], rws[4]; };
+struct WrPerspRec { float lz[4], lzs[4], lw[4], lws[4], rz[4], rzs[4], rw[4], rws[4]; float div; };   // div: WrVsOut::persp_div
 
 struct WrQuadRec {
   int32_t nseg;

@@ -1698,6 +1698,8 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
             m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
             if perspective:      # (see rotated_rects)
                 m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng)
+                if i % 2 == 0:
+                    flags = 1         # BRUSH_FLAG_PERSPECTIVE_INTERPOLATION (brush encoding): perspective-correct uv
             tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
         rect = (cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)
         rad = float(np.hypot(w, h)) * (1.4 if perspective else 0.75) + 4
