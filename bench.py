@@ -283,6 +283,7 @@ def main():
                         "brush_solid -> composite, 3840x2160",
                 "cfg3": "text: 200 lines x 250 glyphs (ps_text_run, R8 glyph atlas 2048^2, premultiplied-alpha "
                         "blend), 3840x2160, 20 tiles + composite, seed 3",
+                "transforms": "wrench benchmarks/transforms-simple.yaml: 11 full-size translucent rects under rotate(45), 1024x1024",
                 "cfg1": "16x16 opaque rect grid 1024x1024"}[args.workload],
                 "encoding": args.encoding, "target": f"{frame_w}x{frame_h}",
                 "parallelism": "single GPU" if world == 1 else

@@ -88,6 +88,9 @@ ROTATED += [
     ("perspective_images", lambda: scenes.rotated_images(perspective="all", seed=104)),
     ("occluded_perspective_images", lambda: scenes.add_occluders(scenes.rotated_images(perspective="all", seed=105), zmax=60, seed=41)),
     ("perspective_images_masked", lambda: scenes.rotated_images(perspective="all", masked=True, seed=106)),
+    # brush_solid under swgl_clipMask and a projective transform (rounded-corner clips on 3-D transformed content)
+    ("perspective_masked_rects", lambda: scenes.masked_rects(perspective=True, force_aa=True, seed=15)),
+    ("occluded_perspective_masked_rects", lambda: scenes.add_occluders(scenes.masked_rects(perspective=True, force_aa=True, fractional=True, seed=16), zmax=150, seed=42)),
 ]
 # A perspective span flattens the depth row it touches (rasterize.h:1226-1232), and swgl then draws every LATER depth-tested prim
 # on that row chunk by chunk through main() instead of handing the span shader one depth run at a time (:1021-1031).  That
@@ -97,7 +100,12 @@ ROTATED += [
 PERSPECTIVE_MIXED = [
     ("occluded_perspective_images_mixed", lambda: scenes.add_occluders(scenes.rotated_images(perspective=True, encoding="quad", seed=103), zmax=60, seed=40)),
 ]
-ROTATED_GOLDEN = ("perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
+# wrench/benchmarks/transforms-simple.yaml (the reference's own transform benchmark): both encodings
+ROTATED += [
+    ("transforms_simple", lambda: scenes.transforms_simple()),
+    ("transforms_simple_quad", lambda: scenes.transforms_simple(encoding="quad")),
+]
+ROTATED_GOLDEN = ("transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

@@ -1729,7 +1729,9 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS))) { atomicAdd(&cnt->perspective_prims, 1u); return; }
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || (o.kind == WR_PK_SOLID && masked)))) {
+      atomicAdd(&cnt->perspective_prims, 1u); return;
+    }
     if (!solidq && !texq) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
     }
@@ -3379,43 +3381,51 @@ __global__ void wr_blit_kernel(WrBlitArgs a) {
   }
 }
 
-// One pixel of a solid colour on a general quad: this row's span from the edge instances of its run
-// (aa_span / aa_edge / aa_dist, rasterize.h:480-562), the pixel's coverage (DO_AA, blend.h:433-446), the blend.
-// Returns the new pixel in the low word and 1 << 32 when the pixel is inside the row's span.
-__device__ __noinline__ unsigned long long wr_quad_pixel_rgba8(const WrQuadRec* Qp, const WrDrawDesc* D, int blend, uint32_t c0, uint32_t c1,
-                                                                int x, int y, uint32_t dstp_, const WrRuns* runs = nullptr) {
+// A solid colour on a general quad, one row at a time: the row's span from the edge instances of its run (aa_span / aa_edge /
+// aa_dist, rasterize.h:480-562) -- the two edge sums are what costs (Edge::nextRow, one add per row: wr_accum), so they are
+// evaluated once per lane-row and shared by the row's pixels.
+struct WrQuadRowS { int ok, s0, s1, la1; float lstart, lend, rstart, rend; };
+__device__ __noinline__ WrQuadRowS wr_quad_row_setup(const WrQuadRec* Qp, int y) {
   const WrQuadRec& Q = *Qp;
-  const unsigned long long dstp = dstp_;
-  const unsigned long long HIT = 1ull << 32;
+  WrQuadRowS R;
+  R.ok = 0; R.s0 = R.s1 = R.la1 = 0; R.lstart = R.rstart = 256.0f; R.lend = R.rend = 0.0f;
   int si = -1;
 #pragma unroll
   for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
-  if (si < 0) return dstp;
+  if (si < 0) return R;
   const WrQuadSeg& S = Q.seg[si];
   const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);   // Edge::nextRow, one add per row
-  WrWide src; src.bg = c0; src.ra = c1;
+  R.ok = 1;
   if (!Q.aa) {
-    const int s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)), s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
-    if (x < s0 || x >= s1) return dstp;
-    return HIT | wr_blend_rgba8(blend, dstp_, src, D);
+    R.s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); R.s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+    return R;
   }
   // aa_edge: masked edges use the row's x intercepts rounded out, the others the rounded x
   const float radl = 0.5f * fabsf(S.ls), radr = 0.5f * fabsf(S.rs);
-  const int la0 = S.lmask ? int(floorf(wr_clamp(xl - radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
-  const int la1 = S.lmask ? int(ceilf(wr_clamp(xl + radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
-  const int ra1 = S.rmask ? int(ceilf(wr_clamp(xr + radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
-  if (x < la0 || x >= ra1) return dstp;
+  R.s0 = S.lmask ? int(floorf(wr_clamp(xl - radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+  R.la1 = S.lmask ? int(ceilf(wr_clamp(xl + radl, S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
+  R.s1 = S.rmask ? int(ceilf(wr_clamp(xr + radr, S.b0, S.b1))) : int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
   // aa_dist
-  float lstart = 256.0f, lend = 0.0f, rstart = 256.0f, rend = 0.0f;
-  if (S.lmask) { const float dx = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.ls * S.ls)); lstart = 128.0f + dx * (xl - 0.5f); lend = -dx; }
-  if (S.rmask) { const float dx = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.rs * S.rs)); rstart = 128.0f + dx * (xr - 0.5f); rend = -dx; }
+  if (S.lmask) { const float dx = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.ls * S.ls)); R.lstart = 128.0f + dx * (xl - 0.5f); R.lend = -dx; }
+  if (S.rmask) { const float dx = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.rs * S.rs)); R.rstart = 128.0f + dx * (xr - 0.5f); R.rend = -dx; }
+  return R;
+}
+// One pixel of that row: its coverage (DO_AA, blend.h:433-446), the blend.  Returns the new pixel in the low word and
+// 1 << 32 when the pixel is inside the row's span.
+__device__ __noinline__ unsigned long long wr_quad_row_pixel_rgba8(WrQuadRowS R, int aa, const WrDrawDesc* D, int blend, uint32_t c0, uint32_t c1,
+                                                                    int x, uint32_t dstp_, const WrRuns* runs = nullptr) {
+  const unsigned long long dstp = dstp_;
+  const unsigned long long HIT = 1ull << 32;
+  if (!R.ok || x < R.s0 || x >= R.s1) return dstp;
+  WrWide src; src.bg = c0; src.ra = c1;
+  if (!aa) return HIT | wr_blend_rgba8(blend, dstp_, src, D);
   // the 4-pixel chunks DO_AA sees start at the span start -- with depth runs, at the start of the run holding x
-  int cs = la0;
+  int cs = R.s0;
   if (runs) { const int k = wr_find_run(runs, x); if (k >= 0) cs = runs->s[k]; }
   const int n = x - cs, lane = n & 3, base = cs + (n & ~3);
-  const float off = float(4 * (base - la1));
-  const float dl = (lstart + float(la1 + lane) * lend) + (lend / 4.0f) * off;
-  const float dr = (rstart + float(la1 + lane) * rend) + (rend / 4.0f) * off;
+  const float off = float(4 * (base - R.la1));
+  const float dl = (R.lstart + float(R.la1 + lane) * R.lend) + (R.lend / 4.0f) * off;
+  const float dr = (R.rstart + float(R.la1 + lane) * R.rend) + (R.rend / 4.0f) * off;
   const uint32_t cov = uint32_t(int(wr_clamp(wr_min(dl, dr), 0.0f, 256.0f) * 1.0f + 0.5f)) & 0xFFFF;
   src.bg = ((((c0 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c0 >> 16) * cov) & 0xFFFF) >> 8) << 16);
   src.ra = ((((c1 & 0xFFFF) * cov) & 0xFFFF) >> 8) | (((((c1 >> 16) * cov) & 0xFFFF) >> 8) << 16);
@@ -3558,7 +3568,8 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     // flat colour under swgl_clipMask: the whole chunks of the span go through commit_masked_solid_span (colour x mask, then DO_AA
     // inside blend_span with the mask key overridden, swgl_ext.h:11-23), the < 4 leftover pixels through main() + blend_pixels
     // (DO_AA, then the mask: blend.h:452-460)
-    const int len = s1 - s0, spanlen = len >= 4 ? (len & ~3) : 0;
+    // (perspective: no span shader, every chunk through main())
+    const int len = s1 - s0, spanlen = (len >= 4 && !Q.pad) ? (len & ~3) : 0;
     WrWide src; src.bg = Pl.color[0]; src.ra = Pl.color[1];
     const bool in_span = x - s0 < spanlen;
     if (in_span) {
@@ -5406,6 +5417,26 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
 // Apply one prim to the 4*R pixels of this lane (4 wide x R rows, rows 4 apart).
 // All prim parameters are wave-uniform (SGPRs); (px,py) is the lane's first
 // pixel, (wx0,wy0) the wave's 64 x 4R strip origin.
+// Is the strip [wx0, wx0 + 64) x [wy0, wy0 + rows) inside the part of a (2-D) general quad where every pixel is covered
+// completely?  The rows must belong to one run of the walk (one left and one right edge, straight lines), the run's clip
+// span must contain the strip's columns, and both edges must stay clear of the columns by their anti-aliasing reach
+// (aa_edge rounds out by |slope| / 2, aa_dist reaches full coverage within sqrt(1 + slope^2) / 2 <= (|slope| + 1) / 2 of
+// the edge) plus two pixels for the difference between this straight-line estimate and the row-by-row sums.  Such a strip
+// takes the flat-colour path: coverage 256 leaves the colour as it is (DO_AA, blend.h:433-446).
+WR_DEVICE bool wr_strip_inside_quad(const WrQuadRec& Q, int wx0, int wy0, int rows) {
+  int si = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < Q.nseg && wy0 >= Q.seg[i].row_a && wy0 + rows <= Q.seg[i].row_b) si = i;
+  if (si < 0) return false;
+  const WrQuadSeg& S = Q.seg[si];
+  const float ya = float(wy0 - S.lrow), yb = float(wy0 + rows - 1 - S.lrow);
+  const float la = S.lx + S.ls * ya, lb = S.lx + S.ls * yb;
+  const float yc = float(wy0 - S.rrow), yd = float(wy0 + rows - 1 - S.rrow);
+  const float ra = S.rx + S.rs * yc, rb = S.rx + S.rs * yd;
+  const float lmax = wr_max(la, lb) + 0.5f * fabsf(S.ls) + 2.5f, rmin = wr_min(ra, rb) - 0.5f * fabsf(S.rs) - 2.5f;
+  return lmax <= float(wx0) && rmin >= float(wx0 + WR_BIN_W) && S.b0 <= float(wx0) && S.b1 >= float(wx0 + WR_BIN_W);
+}
+
 template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uint32_t (&dep)[4 * R],
                              const int x0, const int y0, const int x1, const int y1, const uint32_t z,
@@ -5414,7 +5445,17 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
                              const int px, const int py, const int wx0, const int wy0, const WrRuns* rr = nullptr) {
   constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
   constexpr int NPX = 4 * R;
-  const int kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
+  int kind = kbf & 0xFF;
+  const int blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
+  // a strip in the fully covered interior of a rotated / skewed solid quad is a flat-colour strip
+  // (premultiplied blend of an ordinary colour: the branch below; no blend: the colour itself; other keys keep the per-pixel path)
+  bool flat_copy = false;
+  if ((FEAT & WR_FEAT_GENERIC) && FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID_QUAD && Ap->quad.pad == 0 &&
+      ((blend == WR_BLEND_PREMULT && ((c0 | c1) & 0xFF00FF00u) == 0) || blend == WR_BLEND_NONE) &&
+      wr_strip_inside_quad(Ap->quad, wx0, wy0, 4 * R)) {
+    kind = WR_PK_SOLID;
+    flat_copy = blend == WR_BLEND_NONE;
+  }
   const bool dtest = DEPTH && (flags & WR_PF_DEPTH_TEST);
   const bool dwrite = (flags & WR_PF_DEPTH_WRITE) != 0, dless = (flags & WR_PF_DEPTH_LESS) != 0;
   // does the prim cover this wave's whole strip?  (uniform)
@@ -5493,6 +5534,20 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     return;
   }
 
+  if ((FEAT & WR_FEAT_GENERIC) && FMT == WR_FMT_RGBA8 && flat_copy) {
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+      bool in = cx[q & 3] && cy[q >> 2];
+      if (dtest) {
+        const bool pass = dless ? (z < dep[q]) : (z <= dep[q]);
+        in = in && pass;
+        if (dwrite) dep[q] = in ? z : dep[q];
+      }
+      plo[q] = in ? (c0 & 0xFFFF) | ((c1 & 0xFFFF) << 16) : plo[q];
+      phi[q] = in ? (c0 >> 16) | (c1 & 0xFFFF0000u) : phi[q];
+    }
+    return;
+  }
   if (FMT == WR_FMT_RGBA8 && kind == WR_PK_SOLID && blend == WR_BLEND_PREMULT && ((c0 | c1) & 0xFF00FF00u) == 0) {
     // premultiplied blend of a colour whose channels exceed its alpha: same
     // formula, but the sum can pass 255 and needs pack()'s clamp
@@ -5814,21 +5869,26 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     // flattened depth row (draw_span<.., true>, rasterize.h:667-690) -- no restarts at depth runs
     const bool persp = Ap->quad.pad != 0;
 #pragma unroll
-    for (int q = 0; q < NPX; q++) {
-      const bool in = cx[q & 3] && cy[q >> 2];
-      if (!in) continue;
-      const uint32_t before = plo[q] | (phi[q] << 8);
-      bool pass = true;
-      uint32_t zq = z;
-      if (dtest && persp) zq = wr_persp_depth(&Ap->quad, px + (q & 3), py + 4 * (q >> 2));
-      if (dtest) pass = dless ? (zq < dep[q]) : (zq <= dep[q]);
-      if (!pass) continue;
-      const unsigned long long hr = wr_quad_pixel_rgba8(&Ap->quad, D, blend, c0, c1, px + (q & 3), py + 4 * (q >> 2), before,
-                                                        (rr && !persp) ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
-      if (!(hr >> 32)) continue;
-      const uint32_t r = (uint32_t)hr;
-      if (dtest && dwrite) dep[q] = zq;
-      plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+    for (int j = 0; j < R; j++) {
+      if (!(cy[j] && (cx[0] || cx[1] || cx[2] || cx[3]))) continue;
+      const WrQuadRowS row = wr_quad_row_setup(&Ap->quad, py + 4 * j);       // the lane's row: shared by its four pixels
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        if (!cx[i]) continue;
+        const uint32_t before = plo[q] | (phi[q] << 8);
+        bool pass = true;
+        uint32_t zq = z;
+        if (dtest && persp) zq = wr_persp_depth(&Ap->quad, px + i, py + 4 * j);
+        if (dtest) pass = dless ? (zq < dep[q]) : (zq <= dep[q]);
+        if (!pass) continue;
+        const unsigned long long hr = wr_quad_row_pixel_rgba8(row, Ap->quad.aa, D, blend, c0, c1, px + i, before,
+                                                              (rr && !persp) ? &rr[py + 4 * j - wy0] : nullptr);
+        if (!(hr >> 32)) continue;
+        const uint32_t r = (uint32_t)hr;
+        if (dtest && dwrite) dep[q] = zq;
+        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+      }
     }
     return;
   }

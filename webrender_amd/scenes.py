@@ -617,7 +617,8 @@ def prim_clip_tasks(rng, rects, atlas=1024, fractional=False):
     return out
 
 
-def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional=False, tile_filter=None, force_aa=False, rotate=False):
+def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional=False, tile_filter=None, force_aa=False, rotate=False,
+                 perspective=False):
     """`force_aa`: BRUSH_FLAG_FORCE_AA + all edge flags on every prim; `rotate`: every other prim under a rotation about its
     centre (anti-aliased by brush.glsl:150-170) -- masked solids on the general-quad walk."""
     rng, rects = random_rects(n, width, height, 16, 200, seed, fractional)
@@ -646,16 +647,19 @@ def masked_rects(width=1024, height=1024, n=150, seed=12, atlas=1024, fractional
         clip_tasks.append(((float(mx), float(my), float(mx + mw), float(my + mh)), (sx, sy)))
     tids = [0] * n
     grow = np.zeros(n)
-    if rotate:
-        for i in range(0, n, 2):
+    if rotate or perspective:      # (perspective: every prim under a projective transform, see rotated_rects)
+        for i in range(0, n, 1 if perspective else 2):
             cx, cy = (rects[i, 0] + rects[i, 2]) / 2, (rects[i, 1] + rects[i, 3]) / 2
             th = float(rng.uniform(0, 2 * np.pi))
             a = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
             m = np.eye(4)
             m[:2, :2] = a
             m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+            hyp = float(np.hypot(rects[i, 2] - rects[i, 0], rects[i, 3] - rects[i, 1]))
+            if perspective:
+                m = projective_about(a, cx, cy, hyp * 0.5, rng)
             tids[i] = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
-            grow[i] = 0.25 * float(np.hypot(rects[i, 2] - rects[i, 0], rects[i, 3] - rects[i, 1])) + 2
+            grow[i] = (0.9 if perspective else 0.25) * hyp + 2
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
@@ -1647,6 +1651,42 @@ def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile
     return frame
 
 
+def transforms_simple(width=1024, height=1024, n=11, encoding="brush", tile_filter=None):
+    """wrench/benchmarks/transforms-simple.yaml: a stacking context under rotate(45) (about the origin of its 1024 x 1024
+    bounds) holding eleven full-size rects [255, 0, 0, 0.5] -- translucent solids on one shared non-axis-aligned transform,
+    anti-aliased edges, alpha pass."""
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    c = sn = float(np.sqrt(0.5))
+    m = np.eye(4)
+    m[:2, :2] = [[c, -sn], [sn, c]]
+    tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
+    col = premultiply(np.array([[255, 0, 0, 128]], np.uint8))[0]
+    rect = (0.0, 0.0, 1024.0, 1024.0)
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        al = []
+        for zi in range(n):
+            if encoding == "brush":
+                addr = frame.gpu_cache.push([list(col)])
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, addr, tid, task, (65535, 0, 0, 0))
+                al.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15))
+            else:
+                al.append(frame.quad_instance(rect, (-BIG, -BIG, BIG, BIG), col, zi + 1, task, transform_id=tid, quad_flags=0, edge_flags=15))
+        key = "brush_solid ALPHA_PASS" if encoding == "brush" else "ps_quad_textured"
+        target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha", textures={}))
+        targets.append(target)
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        frame.composite_tiles.append(CompositeTile(tex, (float(x0), float(y0), float(x1), float(y1)),
+                                                   (float(x0), float(y0), float(min(x1, width)), float(min(y1, height))), opaque=True))
+    frame.passes.append(targets)
+    return frame
+
+
 # ---------------------------------------------------------------------------
 # Images under rotations / skews, and axis-aligned ones with BRUSH_FLAG_FORCE_AA: textured prims on the
 # general-quad scanline walk with swgl_antiAlias edges (brush.glsl:150-170 -> swgl_antiAlias; blend.h DO_AA).
@@ -1894,6 +1934,8 @@ def make_workload(workload, **kw):
     if workload == "cfg3":
         kw.pop("encoding", None)
         return cfg3_text(**kw)
+    if workload == "transforms":          # wrench/benchmarks/transforms-simple.yaml (not a BASELINE config)
+        return transforms_simple(**kw)
     raise SystemExit(f"unknown workload {workload}")
 
 
