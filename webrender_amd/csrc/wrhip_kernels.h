@@ -3384,17 +3384,27 @@ __global__ void wr_blit_kernel(WrBlitArgs a) {
 // A solid colour on a general quad, one row at a time: the row's span from the edge instances of its run (aa_span / aa_edge /
 // aa_dist, rasterize.h:480-562) -- the two edge sums are what costs (Edge::nextRow, one add per row: wr_accum), so they are
 // evaluated once per lane-row and shared by the row's pixels.
-struct WrQuadRowS { int ok, s0, s1, la1; float lstart, lend, rstart, rend; };
-__device__ __noinline__ WrQuadRowS wr_quad_row_setup(const WrQuadRec* Qp, int y) {
+// (a lane's rows are 4 apart: the next row's sums are the previous row's plus four more adds when both rows lie in the same
+// run of the walk -- `prev`, with prev.ok -- instead of the whole sum from the run's first row again)
+struct WrQuadRowS { int ok, s0, s1, la1; float lstart, lend, rstart, rend; float xl, xr; int si, y; };
+__device__ __noinline__ WrQuadRowS wr_quad_row_setup(const WrQuadRec* Qp, int y, float pxl, float pxr, int psi, int py_) {
   const WrQuadRec& Q = *Qp;
   WrQuadRowS R;
   R.ok = 0; R.s0 = R.s1 = R.la1 = 0; R.lstart = R.rstart = 256.0f; R.lend = R.rend = 0.0f;
+  R.xl = R.xr = 0.0f; R.si = -1; R.y = y;
   int si = -1;
 #pragma unroll
   for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return R;
   const WrQuadSeg& S = Q.seg[si];
-  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);   // Edge::nextRow, one add per row
+  float xl, xr;
+  if (si == psi && y > py_ && y - py_ <= 8) {
+    xl = pxl; xr = pxr;
+    for (int i = py_; i < y; i++) { xl = xl + S.ls; xr = xr + S.rs; }
+  } else {
+    xl = wr_accum(S.lx, S.ls, y - S.lrow); xr = wr_accum(S.rx, S.rs, y - S.rrow);   // Edge::nextRow, one add per row
+  }
+  R.xl = xl; R.xr = xr; R.si = si;
   R.ok = 1;
   if (!Q.aa) {
     R.s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); R.s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
@@ -5868,10 +5878,13 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     // perspective quads: depth varies per pixel, and the row is drawn chunk by chunk from the span start against the
     // flattened depth row (draw_span<.., true>, rasterize.h:667-690) -- no restarts at depth runs
     const bool persp = Ap->quad.pad != 0;
+    float pxl = 0.0f, pxr = 0.0f;
+    int psi = -1, pyy = 0;
 #pragma unroll
     for (int j = 0; j < R; j++) {
       if (!(cy[j] && (cx[0] || cx[1] || cx[2] || cx[3]))) continue;
-      const WrQuadRowS row = wr_quad_row_setup(&Ap->quad, py + 4 * j);       // the lane's row: shared by its four pixels
+      const WrQuadRowS row = wr_quad_row_setup(&Ap->quad, py + 4 * j, pxl, pxr, psi, pyy);       // the lane's row: shared by its four pixels
+      pxl = row.xl; pxr = row.xr; psi = row.si; pyy = row.y;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = 4 * j + i;
