@@ -626,11 +626,16 @@ void flush_uploads(size_t) {
     }
   }
   if (nseg) {
-    uint64_t up_bytes = 0;
-    for (auto& sg : c->useg) up_bytes += 2ull * sg.row_bytes * sg.rows;
+    uint64_t up_bytes = 0, largest = 0;
+    for (auto& sg : c->useg) {
+      up_bytes += 2ull * sg.row_bytes * sg.rows;
+      largest = std::max<uint64_t>(largest, (uint64_t)sg.row_bytes * sg.rows);
+    }
+    // (a 100 k-prim frame uploads ~24 MB in half a dozen segments: at 8 workgroups per segment the scatter was a 160 us launch)
+    const int parts = (int)std::min<uint64_t>(256, std::max<uint64_t>(8, (largest + 65535) >> 16));
     prof_begin();
-    WR_LAUNCH(wr_upload_kernel, (int)nseg * 8, 256, c->stream, (const WrUploadSeg*)(c->dupload + seg_off), (int)nseg);
-    prof_end(0, 0, 0, 0, up_bytes, nseg * 8);
+    WR_LAUNCH(wr_upload_kernel, (int)nseg * parts, 256, c->stream, (const WrUploadSeg*)(c->dupload + seg_off), (int)nseg, parts);
+    prof_end(0, 0, 0, 0, up_bytes, nseg * parts);
     c->stats.kernel_launches++;
     c->useg.clear();
   }

@@ -3295,20 +3295,21 @@ __global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restr
 
 // Scatter queued texture uploads from the staging mirror to their textures.
 // 8 workgroups per segment; 16-byte lanes where the rows allow it.
-__global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs) {
-  const int si = blockIdx.x >> 3, part = blockIdx.x & 7;
+// `parts` workgroups per segment (the host sizes it for the largest segment of the batch: one per 64 KB, 8 .. 256)
+__global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs, int parts) {
+  const int si = (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
   if (si >= n_segs) return;
   const WrUploadSeg sg = segs[si];
   const size_t total = (size_t)sg.row_bytes * sg.rows;
   const bool vec = ((sg.row_bytes & 15) == 0) && ((sg.dst_stride & 15) == 0) && (((uintptr_t)sg.src & 15) == 0) && (((uintptr_t)sg.dst & 15) == 0);
   if (vec) {
     const size_t n16 = total >> 4, per_row = sg.row_bytes >> 4;
-    for (size_t i = (size_t)part * blockDim.x + threadIdx.x; i < n16; i += (size_t)8 * blockDim.x) {
+    for (size_t i = (size_t)part * blockDim.x + threadIdx.x; i < n16; i += (size_t)parts * blockDim.x) {
       size_t r = i / per_row, c = i - r * per_row;
       ((uint4*)((uint8_t*)sg.dst + r * sg.dst_stride))[c] = ((const uint4*)sg.src)[i];
     }
   } else {
-    for (size_t i = (size_t)part * blockDim.x + threadIdx.x; i < total; i += (size_t)8 * blockDim.x) {
+    for (size_t i = (size_t)part * blockDim.x + threadIdx.x; i < total; i += (size_t)parts * blockDim.x) {
       size_t r = i / sg.row_bytes, c = i - r * sg.row_bytes;
       ((uint8_t*)sg.dst)[r * sg.dst_stride + c] = sg.src[i];
     }
