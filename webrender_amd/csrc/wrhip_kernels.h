@@ -3443,23 +3443,58 @@ __device__ __noinline__ unsigned long long wr_quad_row_pixel_rgba8(WrQuadRowS R,
   return HIT | wr_blend_rgba8(blend, dstp_, src, D);
 }
 
+// The edge values of one row of a general quad -- x, the two interpolants and, under perspective, z and 1/w of the run's left
+// and right edge: Edge::nextRow, one add per row, i.e. a row-by-row sum (wr_accum) per value.  They are what a pixel of such
+// a prim costs, and they only depend on the row: a lane keeps the last row it evaluated (its four pixels of a row share it),
+// and its next row, four rows down in the same run, continues the sums with four adds each.
+struct WrQuadRowCache { int y, si; float xl, xr, lu, lv, ru, rv, wl, wr, zl, zr; };
+WR_DEVICE void wr_quad_row_edges(const WrQuadRec& Q, int si, int y, WrQuadRowCache* C, WrQuadRowCache& L) {
+  if (C && C->si == si && C->y == y) { L = *C; return; }
+  const WrQuadSeg& S = Q.seg[si];
+  const int dy = C ? y - C->y : 0;
+  if (C && C->si == si && dy > 0 && dy <= 8) {
+    L = *C;
+    for (int i = 0; i < dy; i++) {
+      L.xl = L.xl + S.ls; L.xr = L.xr + S.rs;
+      L.lu = L.lu + S.luvs[0]; L.lv = L.lv + S.luvs[1]; L.ru = L.ru + S.ruvs[0]; L.rv = L.rv + S.ruvs[1];
+      if (Q.pad) {
+        L.wl = L.wl + Q.persp.lws[si]; L.wr = L.wr + Q.persp.rws[si];
+        L.zl = L.zl + Q.persp.lzs[si]; L.zr = L.zr + Q.persp.rzs[si];
+      }
+    }
+  } else {
+    L.xl = wr_accum(S.lx, S.ls, y - S.lrow); L.xr = wr_accum(S.rx, S.rs, y - S.rrow);
+    L.lu = wr_accum(S.luv[0], S.luvs[0], y - S.lrow); L.lv = wr_accum(S.luv[1], S.luvs[1], y - S.lrow);
+    L.ru = wr_accum(S.ruv[0], S.ruvs[0], y - S.rrow); L.rv = wr_accum(S.ruv[1], S.ruvs[1], y - S.rrow);
+    L.wl = L.wr = L.zl = L.zr = 0.0f;
+    if (Q.pad) {
+      L.wl = wr_accum(Q.persp.lw[si], Q.persp.lws[si], y - S.lrow); L.wr = wr_accum(Q.persp.rw[si], Q.persp.rws[si], y - S.rrow);
+      L.zl = wr_accum(Q.persp.lz[si], Q.persp.lzs[si], y - S.lrow); L.zr = wr_accum(Q.persp.rz[si], Q.persp.rzs[si], y - S.rrow);
+    }
+  }
+  L.y = y; L.si = si;
+  if (C) *C = L;
+}
+
 // The packed depth of one pixel of a perspective quad (draw_perspective_spans, rasterize.h:1236-1258 + packDepth :345): the
 // row's edges give z at the span's ends (Point3D edges, stepped once per row), stepZW = (right.zw - left.zw) / (right.x -
 // left.x), gl_FragCoord.z = init_interp(z at the span start's pixel centre, step) -- three sequential adds -- and every
 // 4-pixel chunk, drawn or skipped, adds 4 * step (step_perspective, program.h:145-148) -- in a program that has varyings;
 // one without (WrQuadRec::pad == 1) runs its chunks through the plain run / skip, which leave gl_FragCoord.z alone.
-__device__ __noinline__ uint32_t wr_persp_depth(const WrQuadRec* Qp, int x, int y) {
+__device__ __noinline__ uint32_t wr_persp_depth(const WrQuadRec* Qp, int x, int y, WrQuadRowCache* cache = nullptr) {
   const WrQuadRec& Q = *Qp;
   int si = -1;
 #pragma unroll
   for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return 0xFFFFFFFFu;
   const WrQuadSeg& S = Q.seg[si];
-  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
+  WrQuadRowCache E;
+  wr_quad_row_edges(Q, si, y, cache, E);
+  const float xl = E.xl, xr = E.xr;
   int s0;
   if (!Q.aa) s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
   else s0 = S.lmask ? int(floorf(wr_clamp(xl - 0.5f * fabsf(S.ls), S.b0, S.b1))) : int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f));
-  const float zl = wr_accum(Q.persp.lz[si], Q.persp.lzs[si], y - S.lrow), zr = wr_accum(Q.persp.rz[si], Q.persp.rzs[si], y - S.rrow);
+  const float zl = E.zl, zr = E.zr;
   float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float stepZ = (zr - zl) * stepScale;
@@ -3528,7 +3563,7 @@ __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClip
 // pixel's coverage as in wr_quad_pixel_rgba8, the edge interpolants stepped row by row (Edge::nextRow), then the base
 // kind's span shader / main() evaluation of pixel x - span.start, DO_AA ahead of the clip mask (blend.h:452-460).
 __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim* Pp, const WrQuadRec* Qp, const WrDrawDesc* D, int x, int y,
-                                                                    uint32_t dstp_, const WrRuns* runs = nullptr) {
+                                                                    uint32_t dstp_, const WrRuns* runs = nullptr, WrQuadRowCache* cache = nullptr) {
   const WrQuadRec& Q = *Qp;
   const unsigned long long dstp = dstp_;
   const unsigned long long HIT = 1ull << 32;
@@ -3537,7 +3572,9 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
   for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return dstp;
   const WrQuadSeg& S = Q.seg[si];
-  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
+  WrQuadRowCache E;
+  wr_quad_row_edges(Q, si, y, cache, E);
+  const float xl = E.xl, xr = E.xr;
   int s0, s1;
   uint32_t cov = 256;
   bool aa_skip = false;
@@ -3573,8 +3610,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
   WrPrim Pl = *Pp;
   Pl.kind = (int16_t)Q.base_kind;
   const WrTexDesc& t = D->tex[Pl.tex_slot];
-  const float Lu = wr_accum(S.luv[0], S.luvs[0], y - S.lrow), Lv = wr_accum(S.luv[1], S.luvs[1], y - S.lrow);
-  const float Ru = wr_accum(S.ruv[0], S.ruvs[0], y - S.rrow), Rv = wr_accum(S.ruv[1], S.ruvs[1], y - S.rrow);
+  const float Lu = E.lu, Lv = E.lv, Ru = E.ru, Rv = E.rv;
   if (Q.base_kind == WR_PK_SOLID_MASKED) {
     // flat colour under swgl_clipMask: the whole chunks of the span go through commit_masked_solid_span (colour x mask, then DO_AA
     // inside blend_span with the mask key overridden, swgl_ext.h:11-23), the < 4 leftover pixels through main() + blend_pixels
@@ -3602,7 +3638,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     // draw_perspective_spans (rasterize.h:1236-1258) + read_perspective_inputs / step_perspective_inputs (glsl-to-cxx
     // lib.rs:660-741): no span shader, every chunk runs main() with v_uv0 = (uv / w interpolated along the span) * (1 /
     // gl_FragCoord.w); both are init_interp lanes at the span start that every chunk, drawn or skipped, advances by 4 steps
-    const float wl = wr_accum(Q.persp.lw[si], Q.persp.lws[si], y - S.lrow), wr = wr_accum(Q.persp.rw[si], Q.persp.rws[si], y - S.rrow);
+    const float wl = E.wl, wr = E.wr;
     float stepScale = 1.0f / (xr - xl);
     if (!wr_isfinite(stepScale)) stepScale = 0.0f;
     const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale, sw = (wr - wl) * stepScale;
@@ -5855,6 +5891,8 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
   if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && kind == WR_PK_TEX_QUAD) {
     const WrDrawDesc* D = &draws[Pp->draw];
     const bool persp = Ap->quad.pad != 0;       // (see WR_PK_SOLID_QUAD below)
+    WrQuadRowCache rowc;                        // the lane's current row (wr_quad_row_edges)
+    rowc.y = -0x40000000; rowc.si = -1;
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
       const bool in = cx[q & 3] && cy[q >> 2];
@@ -5862,11 +5900,11 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       const uint32_t before = plo[q] | (phi[q] << 8);
       bool pass = true;
       uint32_t zq = z;
-      if (dtest && persp) zq = wr_persp_depth(&Ap->quad, px + (q & 3), py + 4 * (q >> 2));
+      if (dtest && persp) zq = wr_persp_depth(&Ap->quad, px + (q & 3), py + 4 * (q >> 2), &rowc);
       if (dtest) pass = dless ? (zq < dep[q]) : (zq <= dep[q]);
       if (!pass) continue;
       const unsigned long long hr = wr_quad_tex_pixel_rgba8(Pp, &Ap->quad, D, px + (q & 3), py + 4 * (q >> 2), before,
-                                                            (rr && !persp) ? &rr[py + 4 * (q >> 2) - wy0] : nullptr);
+                                                            (rr && !persp) ? &rr[py + 4 * (q >> 2) - wy0] : nullptr, &rowc);
       if (!(hr >> 32)) continue;
       const uint32_t r = (uint32_t)hr;
       if (dtest && dwrite) dep[q] = zq;
