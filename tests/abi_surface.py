@@ -111,6 +111,21 @@ def run(backend_path):
     gl.TexSubImage2D(G.GL_TEXTURE_2D, 0, 14, 12, 12, 12, G.GL_BGRA, G.GL_UNSIGNED_BYTE, b2)        # overlaps the previous write: last wins
     gl.TexSubImage2D(G.GL_TEXTURE_2D, 0, 10, 10, 4, 4, G.GL_BGRA, G.GL_UNSIGNED_BYTE, b2)
     out["overlapping_uploads"] = _read_tex(d, t1)
+    # uploads of a megabyte and more (libwrhip splits the staging copy over helper threads and sizes the scatter launch by the
+    # segment), BGRA rows, RGBA rows that are swizzled on the way in, and a row-length upload into the middle
+    tbig = d.create_texture(1024, 600, G.GL_RGBA8, render_target=True)
+    gl.ActiveTexture(G.GL_TEXTURE0); gl.BindTexture(G.GL_TEXTURE_2D, tbig.id)
+    bigpx = rng.integers(0, 256, size=(600, 1024, 4), dtype=np.uint8)
+    gl.TexSubImage2D(G.GL_TEXTURE_2D, 0, 0, 0, 1024, 600, G.GL_BGRA, G.GL_UNSIGNED_BYTE, bigpx)
+    out["big_upload_bgra"] = _read_tex(d, tbig)
+    bigpx2 = rng.integers(0, 256, size=(520, 1024, 4), dtype=np.uint8)
+    gl.TexSubImage2D(G.GL_TEXTURE_2D, 0, 0, 40, 1024, 520, G.GL_RGBA, G.GL_UNSIGNED_BYTE, bigpx2)
+    out["big_upload_rgba"] = _read_tex(d, tbig)
+    gl.PixelStorei(G.GL_UNPACK_ROW_LENGTH, 1024)
+    gl.TexSubImage2D(G.GL_TEXTURE_2D, 0, 100, 10, 800, 500, G.GL_BGRA, G.GL_UNSIGNED_BYTE, bigpx)
+    gl.PixelStorei(G.GL_UNPACK_ROW_LENGTH, 0)
+    out["big_upload_row_length"] = _read_tex(d, tbig)
+    gl.BindTexture(G.GL_TEXTURE_2D, t1.id)
     t_r8 = d.create_texture(40, 24, G.GL_R8, render_target=True)
     r8 = rng.integers(0, 256, size=(24, 40), dtype=np.uint8)
     gl.BindTexture(G.GL_TEXTURE_2D, t_r8.id)
