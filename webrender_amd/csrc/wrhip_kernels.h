@@ -6337,98 +6337,102 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // One round: up to 64 prims, lane i holding the record of prim `pid` (-1: none); in a dense round (sp false) lane i's prim is
   // dbase + i.  Prim index of the round's lane `b_` (uniform b_):
 #define WR_PID(b_) (sp ? __builtin_amdgcn_readlane(pid, (b_)) : dbase + (b_))
+  // (a macro: the rect-only variant expands it in place -- wrapped in a lambda its tile pass was 4 % slower, cfg2 --, the other
+  // variants call it through an inlined lambda -- expanded in place the glyph variant's was 4 % slower, cfg3)
+#define WR_ROUND_BODY                                                                                                                                                                                   \
+    const bool has = pid >= 0;                                                                                                                                                                          \
+    const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);                                                                         \
+    unsigned long long live = __ballot(hit);                                                                                                                                                            \
+    /* prims of this word that are unit glyph blits (lane i looks at prim i): runs of them are applied lane by lane */                                                                                  \
+    unsigned long long glyphs = 0ull;                                                                                                                                                                   \
+    if constexpr ((FEAT & WR_FEAT_R8TEX) != 0 && FMT == WR_FMT_RGBA8) {                                                                                                                                 \
+      const uint32_t k8 = rb.y & 0xFF, b8 = (rb.y >> 8) & 0xFF;                                                                                                                                         \
+      bool g = hit && (k8 == WR_PK_TEX_R8 || k8 == WR_PK_SOLID_MASKED) && (b8 == WR_BLEND_NONE || b8 == WR_BLEND_PREMULT) &&                                                                            \
+               !(DEPTH && ((rb.y >> 16) & WR_PF_DEPTH_TEST));                                                                                                                                           \
+      if (g) { const WrTexRec* tp = &aux[pid].tex; g = tp->simple != 0 && tp->unit != 0; }                                                                                                              \
+      glyphs = __ballot(g);                                                                                                                                                                             \
+    }                                                                                                                                                                                                   \
+    /* Rect-only launches (FEAT == 0): the survivors' records come back through the scalar cache, one s_load_dwordx8 per prim */                                                                        \
+    /* issued a prim ahead, instead of eight v_readlane broadcasts out of the lanes that tested them -- the blend loop is */                                                                            \
+    /* VALU-bound and v_readlane is VALU (cfg2 tile pass 68.6 -> 61.1 us).  The index is wave-uniform and recs[] read-only. */                                                                          \
+    /* The textured variants keep the broadcasts (measured: the extra scalar round trip costs them 3 %). */                                                                                             \
+    constexpr bool SCALAR_RECS = FEAT == 0;                                                                                                                                                             \
+    int nbit = live ? __builtin_ctzll(live) : 0;                                                                                                                                                        \
+    WrRec nrec;                                                                                                                                                                                         \
+    if (SCALAR_RECS) nrec = recs[WR_PID(nbit)];                                                                                                                                                         \
+    while (live) {                                                                                                                                                                                      \
+      if constexpr ((FEAT & WR_FEAT_R8TEX) != 0 && FMT == WR_FMT_RGBA8) {                                                                                                                               \
+        if ((glyphs >> __builtin_ctzll(live)) & 1ull) {                                                                                                                                                 \
+    /* the run of surviving prims from here up to the next one that is not a unit glyph */                                                                                                              \
+          const unsigned long long others = live & ~glyphs;                                                                                                                                             \
+          const unsigned long long run = others ? (live & ((others & (0ull - others)) - 1ull)) : live;                                                                                                  \
+          if (run & (run - 1ull)) { /* two or more: worth the per-lane lists */                                                                                                                         \
+            live &= ~run;                                                                                                                                                                               \
+    /* which prims of the run reach this lane's footprint (columns px .. px+3, rows py, py+4, ..) */                                                                                                    \
+            unsigned mlo = 0, mhi = 0;                                                                                                                                                                  \
+            for (unsigned long long rr_ = run; rr_; rr_ &= rr_ - 1ull) {                                                                                                                                \
+              const int b = __builtin_ctzll(rr_);                                                                                                                                                       \
+              const int gx0 = __builtin_amdgcn_readlane((int)ra.x, b), gy0 = __builtin_amdgcn_readlane((int)ra.y, b);                                                                                   \
+              const int gx1 = __builtin_amdgcn_readlane((int)ra.z, b), gy1 = __builtin_amdgcn_readlane((int)ra.w, b);                                                                                   \
+              const bool reach = px + 3 >= gx0 && px < gx1 && py + 4 * (R - 1) >= gy0 && py < gy1;                                                                                                      \
+              if (b < 32) mlo |= reach ? (1u << b) : 0u; else mhi |= reach ? (1u << (b - 32)) : 0u;                                                                                                     \
+            }                                                                                                                                                                                           \
+            while (__ballot((mlo | mhi) != 0)) {                                                                                                                                                        \
+              const bool act = (mlo | mhi) != 0;                                                                                                                                                        \
+              int b = lane;                                                                                                                                                                             \
+              if (act) {                                                                                                                                                                                \
+                b = mlo ? __builtin_ctz(mlo) : 32 + __builtin_ctz(mhi);                                                                                                                                 \
+                if (mlo) mlo &= mlo - 1; else mhi &= mhi - 1;                                                                                                                                           \
+              }                                                                                                                                                                                         \
+    /* (the shuffle runs with every lane active: a lane that has no glyph left may hold the index another one asks for) */                                                                              \
+              const int gp = sp ? __shfl(pid, b) : dbase + b;                                                                                                                                           \
+              if (act) {                                                                                                                                                                                \
+    /* (requesting a lane's next records ahead of applying its current ones was tried: the 16 extra live VGPRs */                                                                                       \
+    /* spill in this loop, 170 -> 420 us) */                                                                                                                                                            \
+                const WrGlyphLoad g = wr_unit_glyph_fetch(&recs[gp], &aux[gp].tex);                                                                                                                     \
+                wr_unit_glyph_lane<R>(plo, phi, g, &aux[gp].tex, px, py);                                                                                                                               \
+              }                                                                                                                                                                                         \
+            }                                                                                                                                                                                           \
+            continue;                                                                                                                                                                                   \
+          }                                                                                                                                                                                             \
+        }                                                                                                                                                                                               \
+      }                                                                                                                                                                                                 \
+      const int bit = SCALAR_RECS ? nbit : __builtin_ctzll(live);                                                                                                                                       \
+      live &= live - 1;                                                                                                                                                                                 \
+      int x0, y0, x1, y1;                                                                                                                                                                               \
+      uint32_t z, kbf, c0, c1;                                                                                                                                                                          \
+      if (SCALAR_RECS) {                                                                                                                                                                                \
+        const WrRec Rc = nrec;                                                                                                                                                                          \
+        nbit = live ? __builtin_ctzll(live) : bit;                                                                                                                                                      \
+        nrec = recs[WR_PID(nbit)];                                                                                                                                                                      \
+        x0 = Rc.x0; y0 = Rc.y0; x1 = Rc.x1; y1 = Rc.y1; z = Rc.z; kbf = Rc.kbf; c0 = Rc.c0; c1 = Rc.c1;                                                                                                 \
+      } else {                                                                                                                                                                                          \
+        x0 = __builtin_amdgcn_readlane((int)ra.x, bit); y0 = __builtin_amdgcn_readlane((int)ra.y, bit);                                                                                                 \
+        x1 = __builtin_amdgcn_readlane((int)ra.z, bit); y1 = __builtin_amdgcn_readlane((int)ra.w, bit);                                                                                                 \
+        z = __builtin_amdgcn_readlane((int)rb.x, bit); kbf = __builtin_amdgcn_readlane((int)rb.y, bit);                                                                                                 \
+        c0 = __builtin_amdgcn_readlane((int)rb.z, bit); c1 = __builtin_amdgcn_readlane((int)rb.w, bit);                                                                                                 \
+      }                                                                                                                                                                                                 \
+      if constexpr (DEPTH) {                                                                                                                                                                            \
+        if (wr_zcap_rejects(kbf, z, zcap)) continue;                                                                                                                                                    \
+        zcap = wr_zcap_after(kbf, z, zcap, x0 <= wx0 && x1 >= wx0 + WR_BIN_W && y0 <= wy0 && y1 >= wy0 + STRIP);                                                                                        \
+      }                                                                                                                                                                                                 \
+      const int rblend = (kbf >> 8) & 0xFF;                                                                                                                                                             \
+      const int pi = WR_PID(bit);                                                                                                                                                                       \
+      const WrRuns* rr = nullptr;                                                                                                                                                                       \
+      if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {                                                                                                                                        \
+        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && pi > T.dw_first) || T.load_depth))                                                         \
+          rr = wr_build_runs<R>(T, recs, aux, pi, x0, y0, x1, y1, z, kbf, wy0, lane, wave);                                                                                                             \
+      }                                                                                                                                                                                                 \
+      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_SOLID_MASKED || ((kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&  \
+          aux[pi].tex.simple)                                                                                                                                                                           \
+        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[pi].tex, draws, &prims[pi], px, py);                                                                               \
+      else                                                                                                                                                                                              \
+        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[pi], &aux[pi], draws, vtab, px, py, wx0, wy0, rr);                                                     \
+    }                                                                                                                                                                                                   \
+  (void)0
   auto do_round = [&](const int pid, const int dbase, const bool sp, const uint4 ra, const uint4 rb) __attribute__((always_inline)) {
-    const bool has = pid >= 0;
-    const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);
-    unsigned long long live = __ballot(hit);
-    // prims of this word that are unit glyph blits (lane i looks at prim i): runs of them are applied lane by lane
-    unsigned long long glyphs = 0ull;
-    if constexpr ((FEAT & WR_FEAT_R8TEX) != 0 && FMT == WR_FMT_RGBA8) {
-      const uint32_t k8 = rb.y & 0xFF, b8 = (rb.y >> 8) & 0xFF;
-      bool g = hit && (k8 == WR_PK_TEX_R8 || k8 == WR_PK_SOLID_MASKED) && (b8 == WR_BLEND_NONE || b8 == WR_BLEND_PREMULT) &&
-               !(DEPTH && ((rb.y >> 16) & WR_PF_DEPTH_TEST));
-      if (g) { const WrTexRec* tp = &aux[pid].tex; g = tp->simple != 0 && tp->unit != 0; }
-      glyphs = __ballot(g);
-    }
-    // Rect-only launches (FEAT == 0): the survivors' records come back through the scalar cache, one s_load_dwordx8 per prim
-    // issued a prim ahead, instead of eight v_readlane broadcasts out of the lanes that tested them -- the blend loop is
-    // VALU-bound and v_readlane is VALU (cfg2 tile pass 68.6 -> 61.1 us).  The index is wave-uniform and recs[] read-only.
-    // The textured variants keep the broadcasts (measured: the extra scalar round trip costs them 3 %).
-    constexpr bool SCALAR_RECS = FEAT == 0;
-    int nbit = live ? __builtin_ctzll(live) : 0;
-    WrRec nrec;
-    if (SCALAR_RECS) nrec = recs[WR_PID(nbit)];
-    while (live) {
-      if constexpr ((FEAT & WR_FEAT_R8TEX) != 0 && FMT == WR_FMT_RGBA8) {
-        if ((glyphs >> __builtin_ctzll(live)) & 1ull) {
-          // the run of surviving prims from here up to the next one that is not a unit glyph
-          const unsigned long long others = live & ~glyphs;
-          const unsigned long long run = others ? (live & ((others & (0ull - others)) - 1ull)) : live;
-          if (run & (run - 1ull)) {             // two or more: worth the per-lane lists
-            live &= ~run;
-            // which prims of the run reach this lane's footprint (columns px .. px+3, rows py, py+4, ..)
-            unsigned mlo = 0, mhi = 0;
-            for (unsigned long long rr_ = run; rr_; rr_ &= rr_ - 1ull) {
-              const int b = __builtin_ctzll(rr_);
-              const int gx0 = __builtin_amdgcn_readlane((int)ra.x, b), gy0 = __builtin_amdgcn_readlane((int)ra.y, b);
-              const int gx1 = __builtin_amdgcn_readlane((int)ra.z, b), gy1 = __builtin_amdgcn_readlane((int)ra.w, b);
-              const bool reach = px + 3 >= gx0 && px < gx1 && py + 4 * (R - 1) >= gy0 && py < gy1;
-              if (b < 32) mlo |= reach ? (1u << b) : 0u; else mhi |= reach ? (1u << (b - 32)) : 0u;
-            }
-            while (__ballot((mlo | mhi) != 0)) {
-              const bool act = (mlo | mhi) != 0;
-              int b = lane;
-              if (act) {
-                b = mlo ? __builtin_ctz(mlo) : 32 + __builtin_ctz(mhi);
-                if (mlo) mlo &= mlo - 1; else mhi &= mhi - 1;
-              }
-              // (the shuffle runs with every lane active: a lane that has no glyph left may hold the index another one asks for)
-              const int gp = sp ? __shfl(pid, b) : dbase + b;
-              if (act) {
-                // (requesting a lane's next records ahead of applying its current ones was tried: the 16 extra live VGPRs
-                // spill in this loop, 170 -> 420 us)
-                const WrGlyphLoad g = wr_unit_glyph_fetch(&recs[gp], &aux[gp].tex);
-                wr_unit_glyph_lane<R>(plo, phi, g, &aux[gp].tex, px, py);
-              }
-            }
-            continue;
-          }
-        }
-      }
-      const int bit = SCALAR_RECS ? nbit : __builtin_ctzll(live);
-      live &= live - 1;
-      int x0, y0, x1, y1;
-      uint32_t z, kbf, c0, c1;
-      if (SCALAR_RECS) {
-        const WrRec Rc = nrec;
-        nbit = live ? __builtin_ctzll(live) : bit;
-        nrec = recs[WR_PID(nbit)];
-        x0 = Rc.x0; y0 = Rc.y0; x1 = Rc.x1; y1 = Rc.y1; z = Rc.z; kbf = Rc.kbf; c0 = Rc.c0; c1 = Rc.c1;
-      } else {
-        x0 = __builtin_amdgcn_readlane((int)ra.x, bit); y0 = __builtin_amdgcn_readlane((int)ra.y, bit);
-        x1 = __builtin_amdgcn_readlane((int)ra.z, bit); y1 = __builtin_amdgcn_readlane((int)ra.w, bit);
-        z = __builtin_amdgcn_readlane((int)rb.x, bit); kbf = __builtin_amdgcn_readlane((int)rb.y, bit);
-        c0 = __builtin_amdgcn_readlane((int)rb.z, bit); c1 = __builtin_amdgcn_readlane((int)rb.w, bit);
-      }
-      if constexpr (DEPTH) {
-        if (wr_zcap_rejects(kbf, z, zcap)) continue;
-        zcap = wr_zcap_after(kbf, z, zcap, x0 <= wx0 && x1 >= wx0 + WR_BIN_W && y0 <= wy0 && y1 >= wy0 + STRIP);
-      }
-      const int rblend = (kbf >> 8) & 0xFF;
-      const int pi = WR_PID(bit);
-      const WrRuns* rr = nullptr;
-      if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
-        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && pi > T.dw_first) || T.load_depth))
-          rr = wr_build_runs<R>(T, recs, aux, pi, x0, y0, x1, y1, z, kbf, wy0, lane, wave);
-      }
-      if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_SOLID_MASKED || ((kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
-          aux[pi].tex.simple)
-        wr_apply_tex_r8<DEPTH, R>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, aux[pi].tex, draws, &prims[pi], px, py);
-      else
-        wr_apply_prim<FMT, DEPTH, R, FEAT>(plo, phi, dep, x0, y0, x1, y1, z, kbf, c0, c1, &prims[pi], &aux[pi], draws, vtab, px, py, wx0, wy0, rr);
-    }
+    WR_ROUND_BODY;
   };
-#undef WR_PID
   const int nw = T.words_per_bin;
   if constexpr (FMT == WR_FMT_RGBA8 && FEAT == 0 && !DEPTH) {
     // The rect-only, depth-less variant runs at 8 waves per SIMD on 64 VGPRs with nothing to spare: it keeps the plain walk --
@@ -6464,7 +6468,11 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
             na = rp[0]; nb = rp[1];
           }
         }
-        do_round(((m >> lane) & 1ull) ? base + lane : -1, base, false, ra, rb);
+        {
+          const int pid = ((m >> lane) & 1ull) ? base + lane : -1, dbase = base;
+          const bool sp = false;
+          WR_ROUND_BODY;
+        }
       }
     }
   } else {
@@ -6545,6 +6553,8 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     do_round(pid, dbase, sp, ra, rb);
   }
   }
+#undef WR_ROUND_BODY
+#undef WR_PID
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the
   // bin's words, zero them so the next flush needs no memset launch.
   __syncthreads();
