@@ -14,6 +14,7 @@
 #include <time.h>
 #include <chrono>
 #include <thread>
+#include <pthread.h>
 #include <mutex>
 #include <condition_variable>
 #include <atomic>
@@ -37,7 +38,10 @@ struct CopyPool {
   const std::function<void(int, int)>* job = nullptr;
   uint64_t gen = 0;
   std::atomic<int> left{0};
+  static std::atomic<bool>& forked() { static std::atomic<bool> f{false}; return f; }
   CopyPool() {
+    // a fork()ed child inherits this object but not the helper threads: it copies on its own
+    pthread_atfork(nullptr, nullptr, +[] { forked().store(true); });
     const char* e = getenv("WRHIP_COPY_THREADS");
     int want = e ? atoi(e) : 3;
     const unsigned hc = std::thread::hardware_concurrency();
@@ -59,7 +63,7 @@ struct CopyPool {
     }
   }
   void run(const std::function<void(int, int)>& f) {
-    if (!n) { f(0, 1); return; }
+    if (!n || forked().load(std::memory_order_relaxed)) { f(0, 1); return; }
     {
       std::lock_guard<std::mutex> lk(m);
       job = &f; left.store(n, std::memory_order_relaxed); gen++;
