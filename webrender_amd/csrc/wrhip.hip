@@ -428,6 +428,7 @@ struct Context {
   bool forward_composites = true;      // WRHIP_NO_FORWARD=1 turns the write-through of opaque 1:1 composites off
   bool profiling_no_forward = false;
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
+  bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
 
   Context() {
@@ -437,6 +438,7 @@ struct Context {
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
+    cell_raster = getenv("WRHIP_NO_CELLS") == nullptr;
     mask_rows = getenv("WRHIP_NO_MASK_ROWS") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
@@ -1227,6 +1229,7 @@ void flush_work(const std::vector<int>& sel_in) {
       T.fwd_color = ft.dptr; T.fwd_stride = ft.stride; T.fwd_dx = w.fwd_dx; T.fwd_y0 = w.fwd_y0; T.fwd_ys = w.fwd_ys;
       for (int k = 0; k < 4; k++) T.fwd_clip[k] = w.fwd_clip[k];
     }
+    T.cells = c->cell_raster ? 1 : 0;
     T.y_begin = 0; T.y_end = t.height;
     if (t.own_y1 > t.own_y0) {   // WrhipSetTargetRows: rows of this target owned by this process
       T.y_begin = std::max(0, t.own_y0); T.y_end = std::min(t.height, t.own_y1);

@@ -6229,6 +6229,160 @@ WR_DEVICE uint32_t wr_zcap_after(uint32_t kbf, uint32_t z, uint32_t zcap, bool f
   return zcap;
 }
 
+
+#ifndef WRHIP_HOSTSIM
+// ---------------------------------------------------------------------------
+// Cell raster (rect-only launches, device only).  A bin that starts from a clear and receives nothing but axis-aligned flat
+// colours -- solid rects, clears -- has few DISTINCT pixels: the x edges and y edges of the prims that reach it cut it into
+// nx x ny cells, and every pixel of a cell sees the same prims in the same order on the same start value, so it ends up with
+// the same bytes (swgl's blend is a per-pixel function of (dst, src), blend.h:416-735, and the span is all-or-nothing per pixel
+// without swgl_antiAlias).  Instead of blending 4096 pixels through every prim, the workgroup
+//   A  collects the edges: the lanes fetch the records of the bin's prim list (the four waves share the words out), each
+//      sets the bits of its prim's column / row boundaries inside the bin, OR-combined through LDS;
+//   B  gives every lane ONE cell (its first pixel) and walks the prim list in submission order: per prim one coverage test
+//      and one blend per lane instead of sixteen -- only the waves that hold cells walk;
+//   C  expands: a pixel's cell is (rank of its row among the row boundaries, rank of its column), two popcounts, and its
+//      colour (and depth) one LDS read.
+// cfg2 (1000 translucent rects over a 4K frame, ~45 prims per bin cutting it into ~100 cells): the tile pass becomes a store
+// stream.  More than 256 cells (a bin crossed by dozens of small rects, cfg5) or a bin that loads its pixels: the pixel walk.
+struct WrCellShared {
+  unsigned long long edges[2];          // column / row boundaries: bit c = a class starts at column (row) c of the bin
+  uint32_t lo[256], hi[256], dep[256];
+  uint8_t colstart[64], rowstart[64];
+};
+template <bool DEPTH>
+WR_DEVICE bool wr_raster_cells(WrCellShared& sh, const WrTargetDesc& T, const WrRec* __restrict__ recs,
+                               const unsigned long long* __restrict__ mw, const int nw, const int bx0, const int by0,
+                               const int wave, const int lane, uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t (&dep)[16]) {
+  if (threadIdx.x == 0) { sh.edges[0] = 0ull; sh.edges[1] = 0ull; }
+  __syncthreads();
+  // ---- A: edges --------------------------------------------------------------
+  {
+    unsigned long long colb = 0ull, rowb = 0ull;
+    for (int wb = 0; wb < nw; wb += 64) {
+      const unsigned long long mv = wb + lane < nw ? mw[wb + lane] : 0ull;
+      const unsigned long long nz = __ballot(mv != 0ull);
+      // this wave's share: the non-zero words whose rank among them is wave, wave + 4, ..
+      int rank = 0;
+      for (unsigned long long rest = nz; rest; rest &= rest - 1ull, rank++) {
+        if ((rank & 3) != wave) continue;
+        const int cw = __builtin_ctzll(rest);
+        const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
+                                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
+        if ((m >> lane) & 1ull) {
+          const uint4 ra = *(const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
+          const int a0 = (int)ra.x - bx0, b0 = (int)ra.y - by0, a1 = (int)ra.z - bx0, b1 = (int)ra.w - by0;
+          if (a1 > 0 && a0 < WR_BIN_W && b1 > 0 && b0 < WR_BIN_H && a1 > a0 && b1 > b0) {
+            if (a0 > 0) colb |= 1ull << a0;
+            if (a1 < WR_BIN_W) colb |= 1ull << a1;
+            if (b0 > 0) rowb |= 1ull << b0;
+            if (b1 < WR_BIN_H) rowb |= 1ull << b1;
+          }
+        }
+      }
+    }
+    if (colb) atomicOr(&sh.edges[0], colb);
+    if (rowb) atomicOr(&sh.edges[1], rowb);
+  }
+  __syncthreads();
+  const unsigned long long colm = sh.edges[0], rowm = sh.edges[1];
+  const int nx = __builtin_amdgcn_readfirstlane(__popcll(colm) + 1), ny = __builtin_amdgcn_readfirstlane(__popcll(rowm) + 1);
+  const int ncell = nx * ny;
+  if (ncell > 256) return false;
+  // first column / row of every class
+  if (wave == 0) { if (((colm | 1ull) >> lane) & 1ull) sh.colstart[lane ? __popcll(colm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane; }
+  if (wave == 1) { if (((rowm | 1ull) >> lane) & 1ull) sh.rowstart[lane ? __popcll(rowm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane; }
+  __syncthreads();
+  // ---- B: one cell per lane, the prim list in order ----------------------------
+  if (wave * 64 < ncell) {
+    const int id = wave * 64 + lane;
+    const bool active = id < ncell;
+    const int iy = active ? id / nx : 0, ix = active ? id - iy * nx : 0;
+    const int cx = bx0 + sh.colstart[ix], cy = by0 + sh.rowstart[iy];
+    uint32_t lo = T.init_color & WR_M8, hi = (T.init_color >> 8) & WR_M8, dp = T.init_depth;
+    for (int wb = 0; wb < nw; wb += 64) {
+      const unsigned long long mv = wb + lane < nw ? mw[wb + lane] : 0ull;
+      unsigned long long nz = __ballot(mv != 0ull);
+      if (!nz) continue;
+      unsigned long long m_next;
+      uint4 na = make_uint4(0, 0, 0, 0);
+      {
+        const int cw = __builtin_ctzll(nz);
+        m_next = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
+                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
+        if ((m_next >> lane) & 1ull) na = *(const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
+      }
+      while (nz) {
+        const int w = wb + __builtin_ctzll(nz);
+        nz &= nz - 1ull;
+        const unsigned long long m = m_next;
+        const uint4 ra = na;
+        const int base = T.first_prim + w * 64;
+        if (nz) {
+          const int cw = __builtin_ctzll(nz);
+          m_next = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
+          if ((m_next >> lane) & 1ull) na = *(const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
+        }
+        const bool hit = ((m >> lane) & 1ull) && (int)ra.z > bx0 && (int)ra.x < bx0 + WR_BIN_W && (int)ra.w > by0 && (int)ra.y < by0 + WR_BIN_H;
+        unsigned long long live = __ballot(hit);
+        // the survivors' records through the scalar cache, one prim ahead (as the pixel walk does)
+        int nbit = live ? __builtin_ctzll(live) : 0;
+        WrRec nrec = recs[base + nbit];
+        while (live) {
+          const int bit = nbit;
+          live &= live - 1ull;
+          const WrRec Rc = nrec;
+          nbit = live ? __builtin_ctzll(live) : bit;
+          nrec = recs[base + nbit];
+          const uint32_t kbf = Rc.kbf, kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
+          bool in = active && (unsigned)(cx - Rc.x0) < (unsigned)(Rc.x1 - Rc.x0) && (unsigned)(cy - Rc.y0) < (unsigned)(Rc.y1 - Rc.y0);
+          if (kind == WR_PK_CLEAR) {
+            if (flags & WR_PF_CLEAR_COLOR) { lo = in ? (Rc.c0 & WR_M8) : lo; hi = in ? ((Rc.c0 >> 8) & WR_M8) : hi; }
+            if (DEPTH && (flags & WR_PF_CLEAR_DEPTH)) dp = in ? Rc.z : dp;
+            continue;
+          }
+          if (DEPTH && (flags & WR_PF_DEPTH_TEST)) {
+            in = in && ((flags & WR_PF_DEPTH_LESS) ? (Rc.z < dp) : (Rc.z <= dp));
+            if (flags & WR_PF_DEPTH_WRITE) dp = in ? Rc.z : dp;
+          }
+          if (kind == WR_PK_SOLID_FOLDED) {
+            wr_fold_masked(lo, hi, kbf >> 24, Rc.c0, Rc.c1, WR_LANEMASK(in));
+          } else if (kind == WR_PK_SOLID && blend == WR_BLEND_PREMULT && ((Rc.c0 | Rc.c1) & 0xFF00FF00u) == 0) {
+            const uint32_t K = 255u - (Rc.c1 >> 16);
+            const uint32_t ulo = (Rc.c0 & 0xFFFF) | ((Rc.c1 & 0xFFFF) << 16), uhi = (Rc.c0 >> 16) | (Rc.c1 & 0xFFFF0000u);
+            const uint32_t nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(lo, K) + WR_M8) + ulo, WR_M8);
+            const uint32_t nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(hi, K) + WR_M8) + uhi, WR_M8);
+            lo = in ? nl : lo; hi = in ? nh : hi;
+          }
+          // (any other kind draws nothing in a rect-only launch: it was reported by the setup stage, as on the pixel walk)
+        }
+      }
+    }
+    if (active) { sh.lo[id] = lo; sh.hi[id] = hi; if (DEPTH) sh.dep[id] = dp; }
+  }
+  __syncthreads();
+  // ---- C: expand ---------------------------------------------------------------
+  {
+    const int lx = (lane & 15) * 4, ly = wave * 16 + (lane >> 4);
+    int cxi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cxi[i] = __popcll(colm & ((2ull << (lx + i)) - 1ull));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int rc = __popcll(rowm & ((2ull << (ly + 4 * j)) - 1ull)) * nx;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int id = rc + cxi[i];
+        plo[4 * j + i] = sh.lo[id]; phi[4 * j + i] = sh.hi[id];
+        if (DEPTH) dep[4 * j + i] = sh.dep[id];
+      }
+    }
+  }
+  return true;
+}
+#endif
+
 template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
@@ -6265,7 +6419,18 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 
   // RGBA8: lo/hi channel pairs; R8: value in lo
   uint32_t plo[NPX], phi[NPX], dep[NPX];
+  unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
+  // (rect-only bins that start from a clear: the cell raster, when the bin's prims cut it into few enough cells)
+  bool cells_done = false;
+#ifndef WRHIP_HOSTSIM
+  if constexpr (FMT == WR_FMT_RGBA8 && FEAT == 0 && R == 4) {
+    __shared__ WrCellShared cell_sh;
+    if (T.cells && !T.load_color && !(DEPTH && T.load_depth && T.depth))
+      cells_done = wr_raster_cells<DEPTH>(cell_sh, T, recs, mw, T.words_per_bin, wx0, by * WR_BIN_H, wave, lane, plo, phi, dep);
+  }
+#endif
   // ---- initial pixel state ---------------------------------------------
+  if (!cells_done) {
 #pragma unroll
   for (int j = 0; j < R; j++) {
     const int y = py + 4 * j;
@@ -6296,9 +6461,9 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       for (int i = 0; i < 4; i++) if (px + i < T.width) dep[4 * j + i] = T.depth[(size_t)y * T.width + px + i];
     }
   }
+  }
   // ---- apply every prim of this bin, in submission order -----------------
   uint32_t zcap = (DEPTH && !(T.load_depth && T.depth)) ? T.init_depth : 0xFFFFFFFFu;
-  unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
 #ifdef WRHIP_HOSTSIM
   for (int w = 0; w < T.words_per_bin; w++) {
     // serial reference iteration (host simulation has no cross-lane ops)
@@ -6329,6 +6494,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     }
   }
 #else
+  if (!cells_done) {
   // Wave-cooperative fetch: lane l loads the record of the word's l-th prim
   // (one memory latency for up to 64 prims, the next word's records are
   // requested before the current word is processed), tests it against this
@@ -6555,6 +6721,8 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   }
 #undef WR_ROUND_BODY
 #undef WR_PID
+  }
+  const int nw = T.words_per_bin;
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the
   // bin's words, zero them so the next flush needs no memset launch.
   __syncthreads();

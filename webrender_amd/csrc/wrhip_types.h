@@ -199,6 +199,8 @@ struct WrTargetDesc {
   uint8_t* mr_store;
   uint32_t mr_cap16;             // capacity of mr_store in 16-byte units (< 2^28)
   uint32_t mr_max_slots;         // capacity of mr_slots (< 2^16)
+  int32_t cells;                 // 1: rect-only bins that start from a clear may take the cell raster (wr_raster_cells)
+  int32_t pad_;
 };
 
 // Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
