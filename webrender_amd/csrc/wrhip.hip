@@ -2504,7 +2504,21 @@ void Finish(void) {
 }
 
 void MakeCurrent(WrhipContext* c) { ctx = (Context*)c; }
+#ifdef WR_CELL_TIMING
+static void wr_dump_cell_times() {
+  const char* path = getenv("WRHIP_CELL_TIMES");
+  if (!path) return;
+  std::vector<unsigned long long> h(8192 * 16);
+  wrq::drain();
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(wr_cell_times), h.size() * 8) != hipSuccess) return;
+  if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+}
+#endif
 WrhipContext* CreateContext(void) {
+#ifdef WR_CELL_TIMING
+  static bool reg = false;
+  if (!reg) { reg = true; atexit(wr_dump_cell_times); }
+#endif
   ensure_runtime();
   return (WrhipContext*)new Context();
 }
@@ -2513,6 +2527,9 @@ void DestroyContext(WrhipContext* c_) {
   Context* c = (Context*)c_;
   if (!c) return;
   if (--c->references > 0) return;
+#ifdef WR_CELL_TIMING
+  wr_dump_cell_times();
+#endif
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG")) fprintf(stderr, "paths: r8fast %llu (unit %llu) generic %llu accum_loop %llu linear: fallback %llu upscale %llu fast %llu downscale %llu\n", wr_dbg_paths[0], wr_dbg_paths[3], wr_dbg_paths[1], wr_dbg_paths[2], wr_dbg_paths[4], wr_dbg_paths[5], wr_dbg_paths[6], wr_dbg_paths[7]);
 #endif
@@ -2626,6 +2643,9 @@ void WrhipFlush(void) {
   flush_all();
   flush_uploads();
   drain_tail();
+#ifndef WRHIP_HOSTSIM
+  wrq::drain();          // (the caller enqueues on the stream itself next: everything recorded so far must be on it)
+#endif
 }
 void* WrhipGetStream(void) {
 #ifdef WRHIP_HOSTSIM

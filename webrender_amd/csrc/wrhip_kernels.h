@@ -6230,6 +6230,9 @@ WR_DEVICE uint32_t wr_zcap_after(uint32_t kbf, uint32_t z, uint32_t zcap, bool f
 }
 
 
+#ifdef WRHIP_HOSTSIM
+#define WR_CT(i) ((void)0)
+#endif
 #ifndef WRHIP_HOSTSIM
 // ---------------------------------------------------------------------------
 // Cell raster (rect-only launches, device only).  A bin that starts from a clear and receives nothing but axis-aligned flat
@@ -6245,123 +6248,213 @@ WR_DEVICE uint32_t wr_zcap_after(uint32_t kbf, uint32_t z, uint32_t zcap, bool f
 //      colour (and depth) one LDS read.
 // cfg2 (1000 translucent rects over a 4K frame, ~45 prims per bin cutting it into ~100 cells): the tile pass becomes a store
 // stream.  More than 256 cells (a bin crossed by dozens of small rects, cfg5) or a bin that loads its pixels: the pixel walk.
+#define WR_CELL_MAX_PRIMS 128
 struct WrCellShared {
-  unsigned long long edges[2];          // column / row boundaries: bit c = a class starts at column (row) c of the bin
-  uint32_t lo[256], hi[256], dep[256];
-  uint8_t colstart[64], rowstart[64];
+  uint32_t color[256], dep[256];        // finished cells: packed BGRA8, depth
+  uint8_t colflag[64], rowflag[64];     // column / row boundaries: [c] != 0 = a class starts at column (row) c of the bin
+  uint8_t colstart[4][64], rowstart[4][64];   // per wave: first column / row of every class
+  int pid[WR_CELL_MAX_PRIMS];           // the bin's prim list in submission order: global prim indices ..
+  uint4 rec[2][WR_CELL_MAX_PRIMS + 4];  // .. and their records (+ padding the walk's last request may touch).  Depth-tested launches: (x0, y0, x1, y1), (z, kbf, c0, c1) as in WrRec;
+                                        // depth-less ones: (x0, x1 - x0, y0, y1 - y0), (K, Clo, Chi, -) -- every kind that draws is a fold
+  int bail;                             // a prim the cell walk has no form for (a solid whose blend needs pack()'s clamp)
 };
+static_assert(WR_CELL_MAX_PRIMS <= 256 && WR_CELL_MAX_PRIMS % 4 == 0, "A2 runs one thread per slot");
+#ifdef WR_CELL_TIMING
+__device__ unsigned long long wr_cell_times[8192 * 16];
+#define WR_CT(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) wr_cell_times[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WR_CT(i) ((void)0)
+#endif
+// wr_fold_inplace on both channel pairs of one pixel, K and C in VGPRs (a wave-uniform value read from LDS stays a vector)
+WR_DEVICE void wr_fold_masked_v(uint32_t& lo, uint32_t& hi, uint32_t K, uint32_t Clo, uint32_t Chi, wr_lanemask m) {
+  unsigned long long saved;
+  asm("s_and_saveexec_b64 %2, %3\n\t"
+      "v_mad_u32_u24 %0, %0, %4, %5\n\tv_perm_b32 %0, 0, %0, %7\n\t"
+      "v_mad_u32_u24 %1, %1, %4, %6\n\tv_perm_b32 %1, 0, %1, %7\n\t"
+      "s_mov_b64 exec, %2"
+      : "+v"(lo), "+v"(hi), "=&s"(saved)
+      : "s"(m), "v"(K), "v"(Clo), "v"(Chi), "v"(0x0c030c01u)
+      : "scc");
+}
+// Inclusive prefix sum over the 64 lanes of a wave in seven DPP adds (row shifts inside the rows of 16, then the row totals
+// broadcast down): no LDS round trips, unlike a __shfl_up ladder.
+WR_DEVICE int wr_wave_scan_incl(int x) {
+  int t = x;
+  t += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+  t += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+  t += __builtin_amdgcn_update_dpp(0, x, 0x113, 0xf, 0xf, true);      // row_shr:3
+  t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xe, true);      // row_shr:4  bank_mask:0xe
+  t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xc, true);      // row_shr:8  bank_mask:0xc
+  t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, true);      // row_bcast:15 row_mask:0xa
+  t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, true);      // row_bcast:31 row_mask:0xc
+  return t;
+}
+WR_DEVICE void wr_fold_inplace_v(uint32_t& p, uint32_t K, uint32_t C) {
+  asm("v_mad_u32_u24 %0, %0, %1, %2\n\tv_perm_b32 %0, 0, %0, %3" : "+v"(p) : "v"(K), "v"(C), "v"(0x0c030c01u));
+}
 template <bool DEPTH>
-WR_DEVICE bool wr_raster_cells(WrCellShared& sh, const WrTargetDesc& T, const WrRec* __restrict__ recs,
-                               const unsigned long long* __restrict__ mw, const int nw, const int bx0, const int by0,
+WR_DEVICE int wr_raster_cells(WrCellShared& sh, const WrTargetDesc& T, const WrRec* __restrict__ recs,
+                               unsigned long long* __restrict__ mw, const int nw, const int bx0, const int by0,
                                const int wave, const int lane, uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t (&dep)[16]) {
-  if (threadIdx.x == 0) { sh.edges[0] = 0ull; sh.edges[1] = 0ull; }
-  __syncthreads();
-  // ---- A: edges --------------------------------------------------------------
-  {
-    unsigned long long colb = 0ull, rowb = 0ull;
-    for (int wb = 0; wb < nw; wb += 64) {
-      const unsigned long long mv = wb + lane < nw ? mw[wb + lane] : 0ull;
-      const unsigned long long nz = __ballot(mv != 0ull);
-      // this wave's share: the non-zero words whose rank among them is wave, wave + 4, ..
-      int rank = 0;
-      for (unsigned long long rest = nz; rest; rest &= rest - 1ull, rank++) {
-        if ((rank & 3) != wave) continue;
-        const int cw = __builtin_ctzll(rest);
-        const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
-                                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
-        if ((m >> lane) & 1ull) {
-          const uint4 ra = *(const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
-          const int a0 = (int)ra.x - bx0, b0 = (int)ra.y - by0, a1 = (int)ra.z - bx0, b1 = (int)ra.w - by0;
-          if (a1 > 0 && a0 < WR_BIN_W && b1 > 0 && b0 < WR_BIN_H && a1 > a0 && b1 > b0) {
-            if (a0 > 0) colb |= 1ull << a0;
-            if (a1 < WR_BIN_W) colb |= 1ull << a1;
-            if (b0 > 0) rowb |= 1ull << b0;
-            if (b1 < WR_BIN_H) rowb |= 1ull << b1;
-          }
-        }
-      }
+  WR_CT(0);
+  // The waves of a workgroup sit on the four SIMDs of a CU in order, and the cell walk keeps the low wave indices busy (a bin
+  // has ~70 cells: one wave walks, sometimes two): the jobs rotate with the bin so that they spread over the SIMDs.
+  const int role = (wave + (int)(blockIdx.x >> 3)) & 3;
+  // ---- A1: the bin's prim list, compacted in submission order ---------------------------------------------------------------
+  // A prim's slot is the number of set bits ahead of its own in the bin's mask words: a wave prefix sum over the words'
+  // popcounts (every wave computes it, so all four agree on the total without a barrier); the lanes of a block are dealt out
+  // to the four waves to write the prim indices of their words.
+  if (threadIdx.x < 32) ((uint32_t*)sh.colflag)[threadIdx.x] = 0u;       // (colflag + rowflag: 128 bytes)
+  if (threadIdx.x == 32) sh.bail = 0;
+  int total = 0;
+  for (int wb = 0; wb < nw; wb += 64) {
+    const unsigned long long mv = wb + lane < nw ? mw[wb + lane] : 0ull;
+    const int cnt = __popcll(mv);
+    const int inc = wr_wave_scan_incl(cnt);
+    const int blk_total = __builtin_amdgcn_readlane(inc, 63);
+    if (total + blk_total > WR_CELL_MAX_PRIMS) return 0;      // (the same decision in every wave; nothing was modified)
+    if ((lane & 3) == role) {
+      int sl = total + inc - cnt;
+      for (unsigned long long bts = mv; bts; bts &= bts - 1ull, sl++) sh.pid[sl] = T.first_prim + (wb + lane) * 64 + __builtin_ctzll(bts);
     }
-    if (colb) atomicOr(&sh.edges[0], colb);
-    if (rowb) atomicOr(&sh.edges[1], rowb);
+    total += blk_total;
+  }
+  total = __builtin_amdgcn_readfirstlane(total);
+  if (total == 0) return 2;       // an empty bin (outside every draw's clip): nothing to walk, nothing to zero; no barrier met yet
+  __syncthreads();
+  WR_CT(1);
+  // ---- A2: one thread per prim: its record into LDS, its edges inside the bin into the flag bytes ----------------------------
+  {
+    const int sl = role * 64 + lane;
+    bool full = false;
+    if (sl < total) {
+      const uint4* rp = (const uint4*)&recs[sh.pid[sl]];
+      uint4 ra = rp[0], rb = rp[1];
+      const int a0 = (int)ra.x - bx0, b0 = (int)ra.y - by0, a1 = (int)ra.z - bx0, b1 = (int)ra.w - by0;
+      if (a1 > 0 && a0 < WR_BIN_W && b1 > 0 && b0 < WR_BIN_H && a1 > a0 && b1 > b0) {
+        if (a0 > 0) sh.colflag[a0] = 1;
+        if (a1 < WR_BIN_W) sh.colflag[a1] = 1;
+        if (b0 > 0) sh.rowflag[b0] = 1;
+        if (b1 < WR_BIN_H) sh.rowflag[b1] = 1;
+        full = a0 <= 0 && a1 >= WR_BIN_W && b0 <= 0 && b1 >= WR_BIN_H;
+      }
+      if (!DEPTH) {
+        // every kind that draws in a rect-only launch as new = hi_bytes(dst * K + C) on the rect (x0, w, y0, h)
+        const uint32_t kbf = rb.y, kind = kbf & 0xFF, flags = (kbf >> 16) & 0xFF;
+        uint4 qa = make_uint4(ra.x, ra.z - ra.x, ra.y, ra.w - ra.y), qb = make_uint4(kbf >> 24, rb.z, rb.w, 0);
+        if (kind == WR_PK_CLEAR && (flags & WR_PF_CLEAR_COLOR)) { qb.x = 0; qb.y = (rb.z & WR_M8) << 8; qb.z = rb.z & 0xFF00FF00u; }
+        else if (kind == WR_PK_SOLID && ((kbf >> 8) & 0xFF) == WR_BLEND_PREMULT && ((rb.z | rb.w) & 0xFF00FF00u) == 0) sh.bail = 1;
+        else if (kind != WR_PK_SOLID_FOLDED) { qa.y = 0; full = false; }      // (draws nothing here: reported by the setup stage, as on the pixel walk)
+        ra = qa; rb = qb;
+      }
+      sh.rec[0][sl] = ra; sh.rec[1][sl] = rb;
+    } else if (!DEPTH && sl < ((total + 3) & ~3)) {
+      sh.rec[0][sl] = make_uint4(0, 0, 0, 0); sh.rec[1][sl] = make_uint4(0, 0, 0, 0);      // (the walk takes four prims per trip: empty rects)
+    }
+    (void)full;
   }
   __syncthreads();
-  const unsigned long long colm = sh.edges[0], rowm = sh.edges[1];
-  const int nx = __builtin_amdgcn_readfirstlane(__popcll(colm) + 1), ny = __builtin_amdgcn_readfirstlane(__popcll(rowm) + 1);
+  WR_CT(2);
+  const unsigned long long colm = __ballot(sh.colflag[lane] != 0), rowm = __ballot(sh.rowflag[lane] != 0);
+  const int nx = __popcll(colm) + 1, ny = __popcll(rowm) + 1;
   const int ncell = nx * ny;
-  if (ncell > 256) return false;
-  // first column / row of every class
-  if (wave == 0) { if (((colm | 1ull) >> lane) & 1ull) sh.colstart[lane ? __popcll(colm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane; }
-  if (wave == 1) { if (((rowm | 1ull) >> lane) & 1ull) sh.rowstart[lane ? __popcll(rowm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane; }
-  __syncthreads();
+  if (ncell > 256 || sh.bail) return 0;
+  // (self-cleaning bin masks: every wave read the bin's words before the first barrier)
+  for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) if (mw[w]) mw[w] = 0ull;
+  // first column / row of every class (a table per wave: no workgroup barrier)
+  if (((colm | 1ull) >> lane) & 1ull) sh.colstart[role][lane ? __popcll(colm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane;
+  if (((rowm | 1ull) >> lane) & 1ull) sh.rowstart[role][lane ? __popcll(rowm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // ---- B: one cell per lane, the prim list in order ----------------------------
-  if (wave * 64 < ncell) {
-    const int id = wave * 64 + lane;
+  if (role * 64 < ncell) {
+    const int id = role * 64 + lane;
     const bool active = id < ncell;
     const int iy = active ? id / nx : 0, ix = active ? id - iy * nx : 0;
-    const int cx = bx0 + sh.colstart[ix], cy = by0 + sh.rowstart[iy];
+    const int cx = bx0 + sh.colstart[role][ix], cy = by0 + sh.rowstart[role][iy];
+    // rows of the bin this wave's cells lie in: [yb0, yb1)
+    const int iy_lo = (role * 64) / nx, iy_hi = (wr_imin(role * 64 + 64, ncell) - 1) / nx;
+    const int yb0 = DEPTH ? by0 + sh.rowstart[role][iy_lo] : 0, yb1 = DEPTH ? (iy_hi + 1 < ny ? by0 + sh.rowstart[role][iy_hi + 1] : by0 + WR_BIN_H) : 0;
     uint32_t lo = T.init_color & WR_M8, hi = (T.init_color >> 8) & WR_M8, dp = T.init_depth;
-    for (int wb = 0; wb < nw; wb += 64) {
-      const unsigned long long mv = wb + lane < nw ? mw[wb + lane] : 0ull;
-      unsigned long long nz = __ballot(mv != 0ull);
-      if (!nz) continue;
-      unsigned long long m_next;
-      uint4 na = make_uint4(0, 0, 0, 0);
-      {
-        const int cw = __builtin_ctzll(nz);
-        m_next = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
-                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
-        if ((m_next >> lane) & 1ull) na = *(const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
+    if constexpr (!DEPTH) {
+      // The walk: every prim of the bin, in order, four per trip, branch-free: a prim's fold constants and rect come out of
+      // LDS at a wave-uniform address (the next four requested before these are applied), every lane folds, and the lanes
+      // whose cell lies outside the rect keep their value.  One wave's dependent chain through ~40 prims is what a bin
+      // waits for, so the trip is straight-line code: no EXEC juggling, no scalar branches but the loop's own.
+      // (An idle lane's cell sits at x = INT_MAX: inside no rect.)
+      const int cxi = active ? cx : 0x7fffffff;
+      // (The reads are spelled out: with a provably uniform address the compiler splits each 16-byte read into one ds_read_b32
+      // per used dword, each with its own address register, and sinks them to their first use.)
+      typedef uint32_t wr_u32x4 __attribute__((ext_vector_type(4)));
+      uint32_t va = (uint32_t)(uintptr_t)&sh.rec[0][0];          // (a flat LDS address: the low half is the LDS offset)
+      constexpr int QOFF = (int)sizeof(uint4) * (WR_CELL_MAX_PRIMS + 4);       // rec[1] - rec[0]
+      const int ntrip = (total + 1) >> 1;          // two prims per trip
+#define WR_CELL_LOAD(S_)                                                                                        \
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:%5\n\tds_read_b128 %3, %4 offset:%6" \
+                   : "=&v"(r0##S_), "=&v"(r1##S_), "=&v"(q0##S_), "=&v"(q1##S_) : "v"(va), "n"(QOFF), "n"(QOFF + 16));   \
+      va += 32;
+#define WR_CELL_WAIT(S_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0##S_), "+v"(r1##S_), "+v"(q0##S_), "+v"(q1##S_));
+#define WR_CELL_APPLY(q_, r_)                                                                                  \
+      { const bool in = (unsigned)(cxi - (int)r_.x) < r_.y && (unsigned)(cy - (int)r_.z) < r_.w;                 \
+        const uint32_t nl = wr_hi_bytes(wr_mul24(lo, q_.x) + q_.y), nh = wr_hi_bytes(wr_mul24(hi, q_.x) + q_.z); \
+        lo = in ? nl : lo; hi = in ? nh : hi; }
+#define WR_CELL_APPLY2(S_) WR_CELL_APPLY(q0##S_, r0##S_) WR_CELL_APPLY(q1##S_, r1##S_)
+      wr_u32x4 q0A, q1A, r0A, r1A, q0B, q1B, r0B, r1B;
+      WR_CELL_LOAD(A)
+      for (int tr = 0; tr < ntrip; tr += 2) {
+        WR_CELL_WAIT(A)
+        WR_CELL_LOAD(B)              // (past the end of the list: the padding behind it)
+        WR_CELL_APPLY2(A)
+        if (tr + 1 >= ntrip) break;
+        WR_CELL_WAIT(B)
+        WR_CELL_LOAD(A)
+        WR_CELL_APPLY2(B)
       }
-      while (nz) {
-        const int w = wb + __builtin_ctzll(nz);
-        nz &= nz - 1ull;
-        const unsigned long long m = m_next;
-        const uint4 ra = na;
-        const int base = T.first_prim + w * 64;
-        if (nz) {
-          const int cw = __builtin_ctzll(nz);
-          m_next = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, cw) |
-                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), cw) << 32);
-          if ((m_next >> lane) & 1ull) na = *(const uint4*)&recs[T.first_prim + (wb + cw) * 64 + lane];
+      asm volatile("s_waitcnt lgkmcnt(0)");        // (the request in flight past the end)
+#undef WR_CELL_LOAD
+#undef WR_CELL_WAIT
+#undef WR_CELL_APPLY2
+#undef WR_CELL_APPLY
+    } else
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+      if (c0 + lane < total) { ra = sh.rec[0][c0 + lane]; rb = sh.rec[1][c0 + lane]; }
+      // (lane b holds prim c0 + b: the ones that reach this wave's rows)
+      unsigned long long live = __ballot(c0 + lane < total && (int)ra.w > yb0 && (int)ra.y < yb1);
+      while (live) {
+        const int b = __builtin_ctzll(live);
+        live &= live - 1ull;
+        const int x0 = __builtin_amdgcn_readlane((int)ra.x, b), y0 = __builtin_amdgcn_readlane((int)ra.y, b);
+        const int x1 = __builtin_amdgcn_readlane((int)ra.z, b), y1 = __builtin_amdgcn_readlane((int)ra.w, b);
+        const uint32_t z = (uint32_t)__builtin_amdgcn_readlane((int)rb.x, b), kbf = (uint32_t)__builtin_amdgcn_readlane((int)rb.y, b);
+        const uint32_t c0_ = (uint32_t)__builtin_amdgcn_readlane((int)rb.z, b), c1_ = (uint32_t)__builtin_amdgcn_readlane((int)rb.w, b);
+        const uint32_t kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
+        bool in = active && (unsigned)(cx - x0) < (unsigned)(x1 - x0) && (unsigned)(cy - y0) < (unsigned)(y1 - y0);
+        if (kind == WR_PK_CLEAR) {
+          if (flags & WR_PF_CLEAR_COLOR) { lo = in ? (c0_ & WR_M8) : lo; hi = in ? ((c0_ >> 8) & WR_M8) : hi; }
+          if (DEPTH && (flags & WR_PF_CLEAR_DEPTH)) dp = in ? z : dp;
+          continue;
         }
-        const bool hit = ((m >> lane) & 1ull) && (int)ra.z > bx0 && (int)ra.x < bx0 + WR_BIN_W && (int)ra.w > by0 && (int)ra.y < by0 + WR_BIN_H;
-        unsigned long long live = __ballot(hit);
-        // the survivors' records through the scalar cache, one prim ahead (as the pixel walk does)
-        int nbit = live ? __builtin_ctzll(live) : 0;
-        WrRec nrec = recs[base + nbit];
-        while (live) {
-          const int bit = nbit;
-          live &= live - 1ull;
-          const WrRec Rc = nrec;
-          nbit = live ? __builtin_ctzll(live) : bit;
-          nrec = recs[base + nbit];
-          const uint32_t kbf = Rc.kbf, kind = kbf & 0xFF, blend = (kbf >> 8) & 0xFF, flags = (kbf >> 16) & 0xFF;
-          bool in = active && (unsigned)(cx - Rc.x0) < (unsigned)(Rc.x1 - Rc.x0) && (unsigned)(cy - Rc.y0) < (unsigned)(Rc.y1 - Rc.y0);
-          if (kind == WR_PK_CLEAR) {
-            if (flags & WR_PF_CLEAR_COLOR) { lo = in ? (Rc.c0 & WR_M8) : lo; hi = in ? ((Rc.c0 >> 8) & WR_M8) : hi; }
-            if (DEPTH && (flags & WR_PF_CLEAR_DEPTH)) dp = in ? Rc.z : dp;
-            continue;
-          }
-          if (DEPTH && (flags & WR_PF_DEPTH_TEST)) {
-            in = in && ((flags & WR_PF_DEPTH_LESS) ? (Rc.z < dp) : (Rc.z <= dp));
-            if (flags & WR_PF_DEPTH_WRITE) dp = in ? Rc.z : dp;
-          }
-          if (kind == WR_PK_SOLID_FOLDED) {
-            wr_fold_masked(lo, hi, kbf >> 24, Rc.c0, Rc.c1, WR_LANEMASK(in));
-          } else if (kind == WR_PK_SOLID && blend == WR_BLEND_PREMULT && ((Rc.c0 | Rc.c1) & 0xFF00FF00u) == 0) {
-            const uint32_t K = 255u - (Rc.c1 >> 16);
-            const uint32_t ulo = (Rc.c0 & 0xFFFF) | ((Rc.c1 & 0xFFFF) << 16), uhi = (Rc.c0 >> 16) | (Rc.c1 & 0xFFFF0000u);
-            const uint32_t nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(lo, K) + WR_M8) + ulo, WR_M8);
-            const uint32_t nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(hi, K) + WR_M8) + uhi, WR_M8);
-            lo = in ? nl : lo; hi = in ? nh : hi;
-          }
-          // (any other kind draws nothing in a rect-only launch: it was reported by the setup stage, as on the pixel walk)
+        if (DEPTH && (flags & WR_PF_DEPTH_TEST)) {
+          in = in && ((flags & WR_PF_DEPTH_LESS) ? (z < dp) : (z <= dp));
+          if (flags & WR_PF_DEPTH_WRITE) dp = in ? z : dp;
         }
+        if (kind == WR_PK_SOLID_FOLDED) {
+          wr_fold_masked(lo, hi, kbf >> 24, c0_, c1_, WR_LANEMASK(in));
+        } else if (kind == WR_PK_SOLID && blend == WR_BLEND_PREMULT && ((c0_ | c1_) & 0xFF00FF00u) == 0) {
+          const uint32_t K = 255u - (c1_ >> 16);
+          const uint32_t ulo = (c0_ & 0xFFFF) | ((c1_ & 0xFFFF) << 16), uhi = (c0_ >> 16) | (c1_ & 0xFFFF0000u);
+          const uint32_t nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(lo, K) + WR_M8) + ulo, WR_M8);
+          const uint32_t nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(hi, K) + WR_M8) + uhi, WR_M8);
+          lo = in ? nl : lo; hi = in ? nh : hi;
+        }
+        // (any other kind draws nothing in a rect-only launch: it was reported by the setup stage, as on the pixel walk)
       }
     }
-    if (active) { sh.lo[id] = lo; sh.hi[id] = hi; if (DEPTH) sh.dep[id] = dp; }
+    if (active) { sh.color[id] = lo | (hi << 8); if (DEPTH) sh.dep[id] = dp; }
   }
+  WR_CT(3);
   __syncthreads();
+  WR_CT(4);
   // ---- C: expand ---------------------------------------------------------------
   {
     const int lx = (lane & 15) * 4, ly = wave * 16 + (lane >> 4);
@@ -6374,12 +6467,13 @@ WR_DEVICE bool wr_raster_cells(WrCellShared& sh, const WrTargetDesc& T, const Wr
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int id = rc + cxi[i];
-        plo[4 * j + i] = sh.lo[id]; phi[4 * j + i] = sh.hi[id];
+        const uint32_t v = sh.color[id];
+        plo[4 * j + i] = v & WR_M8; phi[4 * j + i] = (v >> 8) & WR_M8;
         if (DEPTH) dep[4 * j + i] = sh.dep[id];
       }
     }
   }
-  return true;
+  return 1;
 }
 #endif
 
@@ -6389,7 +6483,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                  unsigned long long* __restrict__ masks, const int bin) {
   constexpr int NPX = 4 * R, STRIP = 4 * R;
+  WR_CT(7);
+  // the target this bin belongs to: the last one whose first bin is not beyond it
   int t = 0;
+#ifdef WRHIP_HOSTSIM
   {
     int lo = 0, hi = n_targets - 1;
     while (lo < hi) {
@@ -6398,6 +6495,18 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     }
     t = lo;
   }
+#else
+  // (the lanes look at 64 targets at a time: one round trip for a frame's tiles instead of a binary search's five dependent ones)
+  for (int tb = 0; tb < n_targets; tb += 64) {
+    const int tl = tb + (int)(threadIdx.x & 63);
+    const bool le = tl < n_targets && targets[tl].first_bin <= bin;
+    const int c = __popcll(__ballot(le));
+    t += c;
+    if (c < 64) break;
+  }
+  t = t > 0 ? t - 1 : 0;
+#endif
+  WR_CT(8);
   const WrTargetDesc& T = targets[t];
   if (T.format != FMT) return;
   const int lb = bin - T.first_bin;
@@ -6421,14 +6530,22 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   uint32_t plo[NPX], phi[NPX], dep[NPX];
   unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
   // (rect-only bins that start from a clear: the cell raster, when the bin's prims cut it into few enough cells)
-  bool cells_done = false;
+  bool cells_done = false, empty_bin = false;      // (empty_bin: the cell raster found no prim in the bin's words)
 #ifndef WRHIP_HOSTSIM
-  if constexpr (FMT == WR_FMT_RGBA8 && FEAT == 0 && R == 4) {
-    __shared__ WrCellShared cell_sh;
+  constexpr bool CELLS = FMT == WR_FMT_RGBA8 && FEAT == 0 && R == 4;
+  constexpr size_t LDS_BYTES = CELLS && sizeof(WrCellShared) > sizeof(int) * 16 * 64 ? sizeof(WrCellShared) : sizeof(int) * 16 * 64;
+  __shared__ uint4 lds_raw[LDS_BYTES / 16];           // the cell raster's tables, or the pixel walk's compaction rows
+  if constexpr (CELLS) {
+    WrCellShared& cell_sh = *(WrCellShared*)lds_raw;
     if (T.cells && !T.load_color && !(DEPTH && T.load_depth && T.depth))
-      cells_done = wr_raster_cells<DEPTH>(cell_sh, T, recs, mw, T.words_per_bin, wx0, by * WR_BIN_H, wave, lane, plo, phi, dep);
+    {
+      // (the same in every lane -- decided on LDS contents behind barriers -- but only provably so once it is said)
+      const int cr = __builtin_amdgcn_readfirstlane(wr_raster_cells<DEPTH>(cell_sh, T, recs, mw, T.words_per_bin, wx0, by * WR_BIN_H, wave, lane, plo, phi, dep));
+      cells_done = cr == 1; empty_bin = cr == 2;
+    }
   }
 #endif
+  WR_CT(5);
   // ---- initial pixel state ---------------------------------------------
   if (!cells_done) {
 #pragma unroll
@@ -6599,7 +6716,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   auto do_round = [&](const int pid, const int dbase, const bool sp, const uint4 ra, const uint4 rb) __attribute__((always_inline)) {
     WR_ROUND_BODY;
   };
-  const int nw = T.words_per_bin;
+  const int nw = empty_bin ? 0 : T.words_per_bin;      // (an empty bin: nothing to walk, nothing to zero)
   if constexpr (FMT == WR_FMT_RGBA8 && FEAT == 0 && !DEPTH) {
     // The rect-only, depth-less variant runs at 8 waves per SIMD on 64 VGPRs with nothing to spare: it keeps the plain walk --
     // the bin's mask words fetched 64 at a time (lane l loads word l of the block), the non-zero ones visited one per round,
@@ -6648,7 +6765,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // prefix sum over the words' popcounts gives every set bit a slot, the lanes scatter their prim indices into a 64-entry
   // LDS row of the wave, and one record fetch + ballot serves up to 64 prims of up to 4096 consecutive ones instead of one
   // fetch per word.  Slots are in (word, bit) order, so submission order is kept.  Dense blocks keep the word-per-round walk.
-  __shared__ int pid_row[16][64];
+  int (*pid_row)[64] = (int (*)[64])lds_raw;
   int wb = 0, wb_next = 0;                       // block being walked / block whose words are in mv_next
   unsigned long long mv = 0ull, mv_next = lane < nw ? mw[lane] : 0ull;
   unsigned long long nz = 0ull;                  // dense walk: non-zero words of the block still to visit
@@ -6721,12 +6838,11 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   }
 #undef WR_ROUND_BODY
 #undef WR_PID
-  }
-  const int nw = T.words_per_bin;
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the
   // bin's words, zero them so the next flush needs no memset launch.
   __syncthreads();
   for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) if (mw[w]) mw[w] = 0ull;      // (most words of a large target are empty already)
+  }
 #endif
   // ---- write back ------------------------------------------------------------
   // (forwarded composite, WrTargetDesc::fwd_*: every row is stored a second time at its place in the target that would have
@@ -6773,6 +6889,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       for (int i = 0; i < 4; i++) if (px + i < T.width) T.depth[(size_t)y * T.width + px + i] = dep[4 * j + i];
     }
   }
+  WR_CT(6);
 }
 
 // Register budget: the textured RGBA8 variants need ~155-175 VGPRs, right at the 168 that still lets 3
