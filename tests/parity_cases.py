@@ -92,13 +92,45 @@ ROTATED += [
     ("perspective_masked_rects", lambda: scenes.masked_rects(perspective=True, force_aa=True, seed=15)),
     ("occluded_perspective_masked_rects", lambda: scenes.add_occluders(scenes.masked_rects(perspective=True, force_aa=True, fractional=True, seed=16), zmax=150, seed=42)),
 ]
-# A perspective span flattens the depth row it touches (rasterize.h:1226-1232), and swgl then draws every LATER depth-tested prim
-# on that row chunk by chunk through main() instead of handing the span shader one depth run at a time (:1021-1031).  That
-# switch is not modelled yet (it is a property of the whole target row, across bins): 2-D textured prims that follow a
-# perspective prim on the same rows keep the span shader's quantised uv stepping where swgl uses main()'s float uv.  A known,
-# bounded deviation: a few hundred pixels of a megapixel frame differ, by at most 2 LSB.
-PERSPECTIVE_MIXED = [
+# Flattened depth rows.  A perspective span flattens the depth row it touches (rasterize.h:1222-1232), and swgl then draws every
+# LATER depth-tested prim on that row chunk by chunk through main(), from the span start, instead of handing the span shader one
+# depth run at a time (:1021-1031).  The setup stage records, per target row, the first depth-tested perspective prim whose span
+# touches it (WrTargetDesc::flat_rows); later prims on such a row skip the span shader and the depth runs.  Also what makes
+# depth-WRITING perspective prims drawable: nobody needs runs against them.  All 0 differing bytes.
+_U = scenes.add_perspective_underlay
+FLAT = [
     ("occluded_perspective_images_mixed", lambda: scenes.add_occluders(scenes.rotated_images(perspective=True, encoding="quad", seed=103), zmax=60, seed=40)),
+    ("occluded_perspective_images_mixed_brush", lambda: scenes.add_occluders(scenes.rotated_images(perspective=True, seed=203), zmax=60, seed=44)),
+    ("perspective_depth_writers", lambda: scenes.rotated_rects(perspective=True, opaque_frac=0.5, seed=196)),
+    ("perspective_depth_writers_quad", lambda: scenes.rotated_rects(perspective=True, opaque_frac=0.5, encoding="quad", seed=197)),
+    ("perspective_depth_writers_occluded", lambda: scenes.add_occluders(scenes.rotated_rects(perspective=True, opaque_frac=0.5, seed=198), zmax=70, seed=43)),
+    ("flat_images", lambda: _U(scenes.image_grid())),
+    ("flat_images_nearest", lambda: _U(scenes.image_grid(nearest=True), seed=78)),
+    ("flat_images_masked", lambda: _U(scenes.image_grid(masked=True), seed=79)),
+    ("flat_images_occluded", lambda: _U(scenes.add_occluders(scenes.image_grid(), zmax=135), seed=80)),
+    ("flat_gradients", lambda: _U(scenes.gradient_grid(), seed=81)),
+    ("flat_filters", lambda: _U(scenes.filter_grid(ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]), seed=82)),
+    ("flat_opacity", lambda: _U(scenes.filter_grid(shader="opacity"), seed=83)),
+    ("flat_image_repeat", lambda: _U(scenes.image_repeat(), seed=84)),
+    ("flat_text", lambda: _U(scenes.cfg3_text(**_TEXT), seed=85)),
+    ("flat_text_modes", lambda: _U(scenes.cfg3_text(color_modes=(0, 1, 2, 3), **_TEXT), seed=86)),
+    ("flat_aa_rects", lambda: _U(scenes.cfg2_overlapping_rects(width=1024, height=1024, n=120, seed=7, fractional=True, encoding="brush", aa_edges=15), seed=87)),
+    ("flat_masked_rects", lambda: _U(scenes.masked_rects(), seed=88)),
+    ("flat_rotated_images", lambda: _U(scenes.rotated_images(), seed=89)),
+    ("flat_rotated_gradients", lambda: _U(scenes.gradient_grid(rotate=True, seed=66), seed=90)),
+    ("flat_quad_masks", lambda: _U(scenes.quad_masks(seed=88), seed=91)),
+    ("flat_quad_gradients", lambda: _U(scenes.quad_gradients(), seed=92)),
+    ("flat_rotated_rects", lambda: _U(scenes.rotated_rects(opaque_frac=0.3), seed=93)),
+]
+# Many depth runs per row: thin opaque slivers at a fixed pitch in front of the image grid's opaque-pass images.
+# Up to WR_MAX_RUNS runs per row / WR_MAX_OCC occluders per strip are reproduced exactly; beyond that the prim is reported.
+OCCLUDED += [
+    ("occluded_images_sliver_fence", lambda: scenes.add_slivers(scenes.image_grid(), pitch=40)),
+    ("occluded_images_sliver_fence_dense", lambda: scenes.add_slivers(scenes.image_grid(seed=54), pitch=17)),
+]
+RUN_OVERFLOW = [
+    ("sliver_fence_overflow", lambda: scenes.add_slivers(scenes.image_grid(), pitch=9)),
+    ("sliver_fence_overflow_4", lambda: scenes.add_slivers(scenes.image_grid(), pitch=4)),
 ]
 # wrench/benchmarks/transforms-simple.yaml (the reference's own transform benchmark): both encodings
 ROTATED += [

@@ -384,6 +384,7 @@ struct Context {
     unsigned long long* mr_ctl = nullptr; WrMaskSlot* mr_slots = nullptr; size_t mr_slots_cap = 0;
     uint8_t* mr_store = nullptr; size_t mr_store_cap = 0;
     unsigned long long mr_seen = 0;      // profiling: wr_mask_rows_kernel's byte count at the previous read-back
+    uint32_t* flat = nullptr; size_t flat_cap = 0;   // flattened-depth-row tables (WrTargetDesc::flat_rows), height + 1 words per target that needs one
   } scratch[2];
   int64_t flush_seq = 0;
   // The raster launches of a flush are not issued with it: they are held back, and the first of them
@@ -942,7 +943,7 @@ Context::~Context() {
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
   wrrt::dev_free(dupload); wrrt::dev_free(dcounters);
-  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); }
+  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); wrrt::dev_free(S.flat); }
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::event_destroy(ev_copy);
@@ -1197,6 +1198,8 @@ void flush_work(const std::vector<int>& sel_in) {
   uint64_t mr_slots = 0, mr_rows = 0, mr_bytes = 0;      // bounds on what the cs_clip_* prims of this flush can reserve in the mask-row store
   std::vector<Level> levels;
   std::vector<int> target_level;
+  std::vector<size_t> flat_off;          // per target: offset of its flattened-depth-row table (words), or SIZE_MAX
+  size_t flat_words = 0;
   const int n_targets = (int)sel.size();
   std::vector<WrDrawDesc> draws;
   std::vector<WrTargetDesc> targets(n_targets);
@@ -1287,6 +1290,14 @@ void flush_work(const std::vector<int>& sel_in) {
       draws.push_back(d);
     }
     T.end_prim = prim_cursor;
+    {
+      // a general-quad draw with the depth test on may hold perspective prims: they flatten the depth rows they touch
+      bool persp_possible = false;
+      if (T.format == WR_FMT_RGBA8)
+        for (const WrDrawDesc& d0 : w.draws) if ((d0.flags & WR_DF_XFORM) && (d0.flags & WR_DF_DEPTH_TEST) && !(d0.flags & WR_DF_SIMPLE)) { persp_possible = true; break; }
+      flat_off.push_back(persp_possible ? flat_words : SIZE_MAX);
+      if (persp_possible) flat_words += (size_t)t.height + 1;
+    }
     int nrel = T.end_prim - T.first_prim;
     T.words_per_bin = (nrel + 63) / 64;
     T.word_base = word_cursor;
@@ -1365,6 +1376,19 @@ void flush_work(const std::vector<int>& sel_in) {
       T.mr_cap16 = (uint32_t)std::min<uint64_t>(S.mr_store_cap >> 4, WR_MR_MAX_CAP16);
       T.mr_max_slots = (uint32_t)S.mr_slots_cap;
     }
+  }
+  for (WrTargetDesc& T : targets) { T.flat_rows = nullptr; T.counters = c->dcounters; }
+  static const bool no_flat = getenv("WRHIP_NO_FLAT") != nullptr;      // (debugging: leave flattened depth rows unmodelled)
+  if (flat_words && n_bins > 0 && !no_flat) {
+    Context::Scratch& S = c->scratch[c->flush_seq & 1];
+    if (S.flat_cap < flat_words) {
+      sync_stream();
+      wrrt::dev_free(S.flat);
+      S.flat_cap = flat_words * 2;
+      S.flat = (uint32_t*)wrrt::dev_alloc(S.flat_cap * 4);
+    }
+    wrrt::memset8(S.flat, 0xFF, flat_words * 4, c->stream);          // (this set's previous user, two flushes back, has been launched)
+    for (int oi = 0; oi < n_targets; oi++) if (flat_off[oi] != SIZE_MAX) targets[oi].flat_rows = S.flat + flat_off[oi];
   }
   if (n_bins > 0) {
     // ---- frame arena: [draws | targets | instance bytes] -> one H2D copy ----
@@ -2430,6 +2454,13 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
       }
     }
     if (simple) d.flags |= WR_DF_SIMPLE;
+    {
+      // can a prim of this draw sit under a rotation or a projective transform?  (brushes / text: transform ids in the prim
+      // headers; quads: in the GPU buffer)
+      const bool quad_prog = info->kind == WR_SH_PS_QUAD_TEXTURED || info->kind == WR_SH_PS_QUAD_MASK || info->kind == WR_SH_PS_QUAD_MASK_FAST ||
+                             info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT || info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT;
+      if (!ids_clean(quad_prog ? WR_S_GPU_BUFFER_I : WR_S_PRIM_HEADERS_I, !quad_prog)) d.flags |= WR_DF_XFORM;
+    }
     // textured prims on rotated quads or with swgl_antiAlias need the WR_PK_TEX_QUAD path (WR_FEAT_SHADE launches): the
     // transform ids in the bound header texture and the AA requests in the instances say whether this draw can hold any
     const bool img = info->kind == WR_SH_BRUSH_IMAGE || info->kind == WR_SH_BRUSH_IMAGE_ALPHA ||
@@ -2484,7 +2515,7 @@ void Finish(void) {
     wrrt::d2h(&h, ctx->dcounters, sizeof(h), ctx->stream);
     sync_stream();
     if (h.unsupported_prims != ctx->seen.unsupported_prims || h.perspective_prims != ctx->seen.perspective_prims) {
-      fprintf(stderr, "libwrhip: %u prim(s) on not-yet-implemented paths, %u perspective ones (textured, clipped by the near / far planes or depth-writing): not drawn\n",
+      fprintf(stderr, "libwrhip: %u prim(s) not reproduced exactly (no implementation: not drawn; more depth runs on a row than the tables hold: drawn from the span start), %u perspective ones (clipped by the near / far planes, or a program whose perspective inputs are not restated): not drawn\n",
               h.unsupported_prims - ctx->seen.unsupported_prims, h.perspective_prims - ctx->seen.perspective_prims);
       // visible at the ABI, not only on stderr: the frame has holes, and the caller's GetError() says so (the reference
       // itself only ever raises GL_OUT_OF_MEMORY, gl.cc:1125-1134, so any other code is unambiguous)

@@ -1661,7 +1661,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     for (int n = 0; n < 4; n++) inside = inside && (o.pz[n] > -o.pw[n]) && (o.pz[n] < o.pw[n]);
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
     const bool ptex = (d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS);
-    if (!inside || !(o.kind == WR_PK_SOLID || ptex) || (d.flags & WR_DF_DEPTH_WRITE)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
+    if (!inside || !(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     // screen = pos.xyz * (1 / pos.w) * scale + offset, scale = (viewport size, 1) / 2, offset = (viewport origin, 0) + scale
     const float scx = d.vp_size[0] * 0.5f, scy = d.vp_size[1] * 0.5f;
     const float ofx = d.vp_origin[0] + scx, ofy = d.vp_origin[1] + scy;
@@ -2388,7 +2388,8 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   float stepScale = 1.0f / (xr - xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
-  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span;   // no draw_span for this program/target: all main()
+  const bool flat = runs && runs->n < 0;      // a flattened depth row: chunk by chunk through main(), from the span start
+  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span || flat;   // no draw_span for this program/target: all main()
   const int k = runs ? wr_find_run(runs, x) : -1;
   if (k >= 0) {
     r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
@@ -2884,6 +2885,18 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
       return;
   }
   wr_finish_prim(d, lo, o, P, &aux[gid], cnt);
+  if ((P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) && aux[gid].quad.pad != 0 && (P.flags & WR_PF_DEPTH_TEST)) {
+    // a depth-tested perspective prim: the rows its spans touch are flattened from here on (WrTargetDesc::flat_rows)
+    uint32_t* fr = targets[d.target].flat_rows;
+    if (fr) {
+      bool any = false;
+      for (int y = P.y0; y < P.y1; y++) {
+        int s0, s1;
+        if (wr_quad_row_span(aux[gid].quad, y, s0, s1) && wr_imin(s1, P.x1) > wr_imax(s0, P.x0)) { atomicMin(&fr[y], (uint32_t)gid); any = true; }
+      }
+      if (any) atomicMin(&fr[targets[d.target].height], (uint32_t)gid);
+    }
+  }
   if (d.query_slot >= 0 && P.kind != WR_PK_NONE && P.kind != WR_PK_UNSUPPORTED) {
     // GL_SAMPLES_PASSED: ctx->shaded_pixels += span.len() for every row with a non-empty span, before any depth test
     unsigned long long n = 0;
@@ -3603,7 +3616,8 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     aa_skip = (unsigned)(base - la1) < (unsigned)wr_imax(ra0 - la1 - 3, 0);
     s0 = la0; s1 = ra1;
   }
-  if (runs) {        // the span the shader sees is the depth run holding x
+  const bool flat = runs && runs->n < 0;      // a flattened depth row (WrTargetDesc::flat_rows): the whole span, chunk by chunk through main()
+  if (runs && !flat) {        // the span the shader sees is the depth run holding x
     const int k = wr_find_run(runs, x);
     if (k >= 0) { s0 = runs->s[k]; s1 = runs->e[k]; } else runs = nullptr;
   }
@@ -3616,7 +3630,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     // inside blend_span with the mask key overridden, swgl_ext.h:11-23), the < 4 leftover pixels through main() + blend_pixels
     // (DO_AA, then the mask: blend.h:452-460)
     // (perspective: no span shader, every chunk through main())
-    const int len = s1 - s0, spanlen = (len >= 4 && !Q.pad) ? (len & ~3) : 0;
+    const int len = s1 - s0, spanlen = (len >= 4 && !Q.pad && !flat) ? (len & ~3) : 0;
     WrWide src; src.bg = Pl.color[0]; src.ra = Pl.color[1];
     const bool in_span = x - s0 < spanlen;
     if (in_span) {
@@ -3748,6 +3762,7 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
   const float psx = (px[1] - px[0]) * 4.0f, psy = (py[1] - py[0]) * 4.0f;   // dFdx(pos) * 4
   const float delta = psx * sdx + psy * sdy;
   if (!G.stops || G.radial >= 2 || (!G.radial && !wr_isfinite(delta))) span = 0;
+  if (runs && runs->n < 0) span = 0;        // a flattened depth row: every chunk through main()
   const int n_lo = wr_imax(x - X0, 0), n_hi = wr_imin(x + (kr >= 0 ? 0 : 3) - X0, len - 1);
   if (n_hi < n_lo) return out;
   const float size = 128.0f;
@@ -5344,7 +5359,7 @@ WR_DEVICE void wr_sweep_runs(WrRuns& R, int a, int b, int nc, IV iv) {
     R.s[n] = s; R.e[n] = e; n++;
     pos = e;
   }
-  R.n = overflow ? 0 : n;
+  R.n = overflow ? -2 : n;          // (-2: more runs than WrRuns holds; the caller reports it and falls back to the span start)
 }
 // The same for a target that continues from a materialised depth buffer (a flush in the middle of the target: the prims
 // that wrote it are gone): pixel by pixel, a pixel passes when it passes against the loaded depth AND no candidate of this
@@ -5366,7 +5381,7 @@ WR_DEVICE void wr_scan_runs(WrRuns& R, int a, int b, int nc, IV iv, const uint32
     if (n == WR_MAX_RUNS) { overflow = true; break; }
     R.s[n] = s0; R.e[n] = x; n++;
   }
-  R.n = overflow ? 0 : n;
+  R.n = overflow ? -2 : n;          // (-2: more runs than WrRuns holds; the caller reports it and falls back to the span start)
 }
 template <int R4>
 WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, int pidx,
@@ -5392,18 +5407,26 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
     if (nc < WR_MAX_OCC) cidx[nc] = i;
     nc++;
   }
-  if (nc == 0 && !loaded) return nullptr;
-  if (nc > WR_MAX_OCC) return nullptr;          // (more occluders than the list holds: evaluated from the span start, as if unoccluded)
+  bool anyflat = false;
+  if (T.flat_rows) for (int y = ry0; y < ry1; y++) if (T.flat_rows[y] < (uint32_t)pidx) anyflat = true;
+  if (nc == 0 && !loaded && !anyflat) return nullptr;
+  if (nc > WR_MAX_OCC) {          // more occluders than the list holds: evaluated from the span start, as if unoccluded -- and reported
+    if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u);
+    if (!anyflat) return nullptr;
+    nc = 0;
+  }
   for (int j = 0; j < R4; j++) {
     const int r = (lane >> 4) + 4 * j, y = wy0 + r;
     WrRuns& RR = runs[r];
     RR.n = 0;
     if (y < ry0 || y >= ry1) continue;
+    if (T.flat_rows && T.flat_rows[y] < (uint32_t)pidx) { RR.n = -1; continue; }
     int a = x0, b = x1;
     if (quad) { int s0, s1; if (!wr_quad_row_span(aux[pidx].quad, y, s0, s1)) continue; a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
     auto iv = [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, cidx[c], y, lo, hi); };
     if (loaded) wr_scan_runs(RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
     else wr_sweep_runs(RR, a, b, nc, iv);
+    if (RR.n == -2) { RR.n = 0; if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u); }
   }
   return runs;
 #else
@@ -5428,7 +5451,16 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
     }
     nc += __popcll(m);
   }
-  if ((nc == 0 && !loaded) || nc > WR_MAX_OCC) return nullptr;
+  // rows of the strip that an earlier perspective prim has flattened (lane r looks at strip row r)
+  bool myflat = false;
+  if (T.flat_rows && lane < 4 * R4 && wy0 + lane >= ry0 && wy0 + lane < ry1) myflat = T.flat_rows[wy0 + lane] < (uint32_t)pidx;
+  const bool anyflat = __ballot(myflat) != 0ull;
+  if (nc == 0 && !loaded && !anyflat) return nullptr;
+  if (nc > WR_MAX_OCC) {          // more occluders than the list holds: evaluated from the span start, as if unoccluded -- and reported
+    if (lane == 0 && T.counters) atomicAdd(&T.counters->unsupported_prims, 1u);
+    if (!anyflat) return nullptr;
+    nc = 0;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int idx = lane; idx < nc * 4 * R4; idx += 64) {
     const int c = idx / (4 * R4), r = idx - c * (4 * R4);
@@ -5441,13 +5473,15 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
     const int r = lane, y = wy0 + r;
     WrRuns& RR = runs[wave][r];
     RR.n = 0;
-    if (y >= ry0 && y < ry1) {
+    if (myflat) RR.n = -1;
+    else if (y >= ry0 && y < ry1) {
       int a = x0, b = x1;
       bool ok = true;
       if (quad) { int s0, s1; ok = wr_quad_row_span(aux[pidx].quad, y, s0, s1); a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
       auto iv = [&](int c, int& lo, int& hi) { lo = ivs[wave][c][r][0]; hi = ivs[wave][c][r][1]; };
       if (ok && loaded) wr_scan_runs(RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
       else if (ok) wr_sweep_runs(RR, a, b, nc, iv);
+      if (RR.n == -2) { RR.n = 0; if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u); }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -6580,6 +6614,8 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   }
   }
   // ---- apply every prim of this bin, in submission order -----------------
+  // (first depth-tested perspective prim of the target: later depth-tested prims look their rows up in T.flat_rows)
+  const uint32_t flat_first = (DEPTH && FEAT != 0 && T.flat_rows) ? T.flat_rows[T.height] : 0xFFFFFFFFu;
   uint32_t zcap = (DEPTH && !(T.load_depth && T.depth)) ? T.init_depth : 0xFFFFFFFFu;
 #ifdef WRHIP_HOSTSIM
   for (int w = 0; w < T.words_per_bin; w++) {
@@ -6598,7 +6634,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const int rblend = (Rc.kbf >> 8) & 0xFF;
       const WrRuns* rr = nullptr;
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {
-        if (((Rc.kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(Rc.kbf & 0xFF) && ((T.dw_end > T.dw_first && base + bit > T.dw_first) || T.load_depth))
+        if (((Rc.kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(Rc.kbf & 0xFF) && ((T.dw_end > T.dw_first && base + bit > T.dw_first) || T.load_depth || (uint32_t)(base + bit) > flat_first))
           rr = wr_build_runs<R>(T, recs, aux, base + bit, Rc.x0, Rc.y0, Rc.x1, Rc.y1, Rc.z, Rc.kbf, wy0, lane, wave);
       }
       if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((Rc.kbf & 0xFF) == WR_PK_SOLID_MASKED || ((Rc.kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&
@@ -6703,7 +6739,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const int pi = WR_PID(bit);                                                                                                                                                                       \
       const WrRuns* rr = nullptr;                                                                                                                                                                       \
       if constexpr (DEPTH && FMT == WR_FMT_RGBA8 && FEAT != 0) {                                                                                                                                        \
-        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && pi > T.dw_first) || T.load_depth))                                                         \
+        if (((kbf >> 16) & WR_PF_DEPTH_TEST) && wr_kind_needs_runs(kbf & 0xFF) && ((T.dw_end > T.dw_first && pi > T.dw_first) || T.load_depth || (uint32_t)pi > flat_first))                                                         \
           rr = wr_build_runs<R>(T, recs, aux, pi, x0, y0, x1, y1, z, kbf, wy0, lane, wave);                                                                                                             \
       }                                                                                                                                                                                                 \
       if ((FEAT & WR_FEAT_R8TEX) && FMT == WR_FMT_RGBA8 && ((kbf & 0xFF) == WR_PK_SOLID_MASKED || ((kbf & 0xFF) == WR_PK_TEX_R8 && !rr)) && (rblend == WR_BLEND_NONE || rblend == WR_BLEND_PREMULT) &&  \

@@ -33,6 +33,7 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p |= v; return o; }
+static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
 static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp, unsigned long long v) { unsigned long long o = *p; if (o == cmp) *p = v; return o; }
 typedef int wr_stream_t;
 typedef struct { double t; } wr_event_t;
@@ -114,10 +115,13 @@ struct Queue {
   std::condition_variable cv;
   bool enabled = false;
   int device = 0;
+  int spin_limit = 500;          // pause iterations (a few microseconds) before the helper blocks: a spinning helper on the
+                                 // recording thread's SMT sibling slows the staging copies down (measured: 18 -> 29 us per cfg2 frame)
   static std::atomic<bool>& forked() { static std::atomic<bool> f{false}; return f; }
   void start(int dev) {
     device = dev;
     enabled = getenv("WRHIP_NO_SUBMIT_THREAD") == nullptr;
+    if (const char* e = getenv("WRHIP_SUBMIT_SPIN")) spin_limit = atoi(e);
     if (!enabled) return;
     pthread_atfork(nullptr, nullptr, +[] { forked().store(true); });      // (a fork()ed child has no helper: it runs inline)
     std::thread([this] { run(); }).detach();
@@ -128,7 +132,7 @@ struct Queue {
       const uint64_t h = head.load(std::memory_order_relaxed);
       int spins = 0;
       while (tail.load(std::memory_order_acquire) == h) {
-        if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+        if (++spins < spin_limit) { __builtin_ia32_pause(); continue; }
         std::unique_lock<std::mutex> lk(m);
         sleeping.store(true, std::memory_order_seq_cst);
         cv.wait(lk, [&] { return tail.load(std::memory_order_acquire) != h; });

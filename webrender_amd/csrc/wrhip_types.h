@@ -136,6 +136,7 @@ enum WrDrawFlags {
   WR_DF_MASK_ROWS = 128,   // host: the cs_clip_* prims of this draw may be pre-evaluated row by row (wr_mask_rows_kernel) into the
                            // flush's mask-row store; the raster stage then only blends the stored bytes (WR_PK_MASK_ROWS)
   WR_DF_SIMPLE = 32,       // host promise: every prim of this draw is a solid with blend NONE/PREMULT (see WrFeat)
+  WR_DF_XFORM = 256,       // host: the transform ids this draw's prims can reference include non-axis-aligned ones (rotations, perspective)
 };
 
 struct WrDrawDesc {
@@ -201,6 +202,13 @@ struct WrTargetDesc {
   uint32_t mr_max_slots;         // capacity of mr_slots (< 2^16)
   int32_t cells;                 // 1: rect-only bins that start from a clear may take the cell raster (wr_raster_cells)
   int32_t pad_;
+  // Flattened depth rows.  A perspective span flattens the depth row it touches (rasterize.h:1222-1232), and swgl draws every
+  // LATER depth-tested prim on that row chunk by chunk from the span start through main() (:1021-1031) instead of handing the
+  // span shader one depth run at a time.  flat_rows[y] = index of the first depth-tested perspective prim with a non-empty
+  // span on target row y (0xFFFFFFFF: none), written by the setup stage; flat_rows[height] = the smallest of them (the raster
+  // stage's early-out).  nullptr: the target cannot hold such a prim (the host saw no general-quad draw with the depth test on).
+  uint32_t* flat_rows;
+  struct WrUnsupportedCounters* counters;      // where the raster stage reports what it could not draw exactly
 };
 
 // Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
@@ -477,8 +485,8 @@ struct WrQuadRec {
 // split and the filter decisions restart at every run start, and the interpolants reach run k through the chain of
 // step_interp_inputs() calls of runs 0 .. k-1.  Built per (wave, prim) by the raster stage from the rects of the earlier
 // depth-writing prims that can hide part of the row (wr_build_runs); n == 0: nothing to restart (or more runs than fit).
-#define WR_MAX_RUNS 8
-#define WR_MAX_OCC 32
+#define WR_MAX_RUNS 16
+#define WR_MAX_OCC 64
 struct WrRuns { int32_t n; int32_t s[WR_MAX_RUNS], e[WR_MAX_RUNS]; };
 
 // per-prim side record, written by the setup kernel for the kinds that need one

@@ -87,9 +87,12 @@ def render_direct(backend_path, frame, frames=1):
     for _ in range(frames):
         r.render(frame)
     r.finish()
+    err = gl.GetError()            # (libwrhip: GL_INVALID_OPERATION when a prim was on a path it cannot draw exactly)
     px = r.read_pixels()
     extra = {ref.name: r.device.read_texture(r.resolve(ref)) for ref in getattr(frame, "readback", [])}
     stats = gl.stats() if gl.is_wrhip else None
+    if stats is not None:
+        stats["gl_error"] = int(err)
     r.destroy()
     if extra:
         extra["window"] = px

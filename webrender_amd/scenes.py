@@ -1835,6 +1835,74 @@ def add_occluders(frame, n=40, seed=7, zmax=100, wmin=12, wmax=260, first=lambda
     return frame
 
 
+# Thin opaque slivers at a fixed pitch across a band of every picture tile, nearer than the scene's own content and drawn
+# ahead of it: a wide image behind them is cut into one depth run per gap (draw_depth_span restarts the span shader in each).
+# With a small pitch a row has more runs / a strip more occluders than the backend's depth-run tables hold: such a prim must be
+# REPORTED (GL_INVALID_OPERATION at Finish), never drawn from the span start as if nothing hid it.
+def add_slivers(frame, pitch=40, width=2, y0=0, y1=240, z=1 << 20):
+    addr = frame.gpu_cache.push([[0.1, 0.2, 0.3, 1.0]])
+    for targets in frame.passes:
+        for target in targets:
+            name = target.texture.name
+            if target.kind != "picture_tile" or not name.startswith("tile_"):
+                continue
+            tx, ty = (int(v) for v in name.split("_")[1:3])
+            ox, oy = tx * TILE_W, ty * TILE_H
+            if not (y0 < oy + TILE_H and y1 > oy):
+                continue
+            task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+            inst = []
+            for x in range(ox + 3, ox + TILE_W, pitch):
+                ph = frame.add_prim_header((float(x), float(y0), float(x + width), float(y1)), (-BIG, -BIG, BIG, BIG), z, addr, 0, task, (65535, 0, 0, 0))
+                inst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY))
+            target.opaque.insert(0, Step("brush_solid", "PRIM_INSTANCES", np.array(inst, dtype=np.int32), None, "opaque", textures={}))
+    return frame
+
+
+# ---------------------------------------------------------------------------
+# Flattened depth rows (rasterize.h:1222-1232, 1021-1031): a few solid rects under projective transforms drawn AHEAD of a
+# scene's own content in every picture tile -- some in the opaque pass (first batch: depth-writing perspective prims),
+# some at the head of the alpha pass (depth-tested only).  Every row their spans touch has its depth run array flattened,
+# and swgl then draws every later depth-tested prim on those rows chunk by chunk through main(), from the span start,
+# instead of handing the span shader one depth run at a time: the scene's families are exercised in that mode on the rows
+# under the rects and in the ordinary one everywhere else.
+def add_perspective_underlay(frame, n=10, seed=77, opaque_every=2):
+    rng = np.random.default_rng(seed)
+    under = []
+    for i in range(n):
+        w, h = float(rng.uniform(60, 360)), float(rng.uniform(30, 200))
+        cx, cy = float(rng.uniform(0, frame.width)), float(rng.uniform(0, frame.height))
+        th = float(rng.uniform(0, 2 * np.pi))
+        c, s = np.cos(th), np.sin(th)
+        a = np.array([[c, -s], [s, c]], np.float64)
+        m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5, rng)
+        tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
+        opaque = i % opaque_every == 0
+        rgba = np.array([[rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256), 255 if opaque else rng.integers(90, 230)]], np.uint8)
+        col = premultiply(rgba)[0]
+        r = float(np.hypot(w, h)) * 1.4 + 4
+        under.append(((cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2), tid, frame.gpu_cache.push([list(col)]), (cx - r, cy - r, cx + r, cy + r), opaque))
+    for targets in frame.passes:
+        for target in targets:
+            name = target.texture.name
+            if target.kind != "picture_tile" or not name.startswith("tile_"):
+                continue
+            tx, ty = (int(v) for v in name.split("_")[1:3])
+            ox, oy = tx * TILE_W, ty * TILE_H
+            task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+            op, al = [], []
+            for zi, (rect, tid, addr, bb, opaque) in enumerate(under):
+                if not (bb[0] < ox + TILE_W and bb[2] > ox and bb[1] < oy + TILE_H and bb[3] > oy):
+                    continue
+                ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, addr, tid, task, (65535, 0, 0, 0))
+                (op if opaque else al).append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15))
+            if op:
+                target.opaque.insert(0, Step("brush_solid", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32), None, "opaque", textures={}))
+            if al:
+                target.alpha.insert(0, Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha", textures={}))
+    return frame
+
+
 # ---------------------------------------------------------------------------
 # Every blend key of swgl's table (gl.cc:614-645, blend.h:466-701) over varied destination content: one batch of
 # overlapping translucent prims per blend state -- solids (brush_solid ALPHA_PASS) and images (brush_image ALPHA_PASS,
