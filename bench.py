@@ -8,7 +8,12 @@ A "step" is one frame: the complete C-ABI call stream WebRender's render thread
 issues for the workload (per-frame data-texture + instance uploads, every
 picture-cache tile rasterised, the composite pass, Finish), replayed natively
 (csrc/wr_replay.c) against libwrhip.  Workload at N=1 is BASELINE.json
-configs[1]: 1000 overlapping translucent rects at 3840x2160 ("cfg2").
+configs[1]: 1000 overlapping translucent rects at 3840x2160 ("cfg2").  At N>1
+it is configs[4] -- 100 k rects at 7680x4320 ("cfg5"), the configuration the
+tile sharding is for: one frame split N ways ("strong" scaling), the window
+reassembled by an RCCL all-gather; the line also carries the same workload on
+one GPU measured in the same run (`single_gpu_same_workload`), the
+gather-to-rank-0 variant and every rank's prims / upload bytes per frame.
 
 The timed region (K frames issued back to back + one Finish, between barrier +
 synchronize) is repeated REPEATS times and the median region is reported, so a
@@ -134,9 +139,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--workload", default=None,
+                    help="default: cfg2 (BASELINE configs[1], the headline) on one GPU, cfg5 (configs[4]: 100 k rects at 8K, "
+                         "the configuration the tile sharding is for) on several")
     ap.add_argument("--encoding", default="quad", choices=["quad", "brush"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="take the N > 1 code path (sharded player, collectives) even with one rank: a self-test")
     args = ap.parse_args()
 
     import torch
@@ -144,11 +152,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    sharded = world > 1 or args.sharded
+    if args.workload is None:
+        args.workload = "cfg5" if sharded else "cfg2"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libwrhip has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from webrender_amd import glapi
@@ -157,8 +171,23 @@ def main():
     if not os.path.exists(lib):
         raise SystemExit("libwrhip.so missing; run __graft_entry__.build()")
 
-    if world > 1:
+    single = None            # N > 1: the same workload unsharded on one GPU (rank 0), measured in this run: the 1-GPU point of the curve
+    if sharded:
         from webrender_amd.dist import ShardedFramePlayer
+        if rank == 0:
+            rec1, _ = record_scene(lib, make_frame(args.workload, encoding=args.encoding))
+            p1 = ScenePlayer(lib, rec1)
+            p1.frames(args.warmup, 0)
+            reg = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                p1.stream(args.steps)
+                torch.cuda.synchronize()
+                reg.append(time.perf_counter() - t0)
+            single = {"value": round(args.steps / float(np.median(reg)), 2), "unit": "frames/s", "n_gpus": 1,
+                      "note": "same workload, unsharded, rank 0's GPU, this run"}
+            del p1
         player = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world)
         frame_w, frame_h = player.width, player.height
         rec = None
@@ -169,7 +198,7 @@ def main():
         player = ScenePlayer(lib, rec)
 
     def barrier():
-        if world > 1:
+        if sharded:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -185,7 +214,7 @@ def main():
         player.stream(args.steps)
         barrier()
         regions.append(time.perf_counter() - t0)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         t = torch.tensor(regions, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)        # every region: the slowest rank
@@ -194,10 +223,40 @@ def main():
     # per-frame latency with a Finish after every frame (what `wrench perf` samples)
     lat = player.frames(0, min(args.steps, 50))
 
+    # ---- N > 1: per-rank work, and the same frames with the window gathered on rank 0 only ------------------------------------
+    multi = None
+    if sharded:
+        import ctypes as C
+        import torch.distributed as dist
+        st = glapi.WrhipStats()
+        C.CFUNCTYPE(None)(player.symbol("WrhipResetStats"))()
+        player.stream(args.steps)
+        C.CFUNCTYPE(None, C.c_void_p)(player.symbol("WrhipGetStats"))(C.byref(st))
+        mine = {"rank": rank, "prims_per_frame": int(st.prims // args.steps), "h2d_bytes_per_frame": int(st.h2d_bytes // args.steps),
+                "strip_rows": int(max(0, player.fb_rows[1] - player.fb_rows[0]))}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        del player
+        root = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="root")
+        root.frames(args.warmup, 0)
+        rr = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            root.stream(args.steps)
+            barrier()
+            rr.append(time.perf_counter() - t0)
+        t = torch.tensor(rr, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        multi = {"rccl_ranks": world, "collective": "all_gather of window strips (value); gather to rank 0 alongside",
+                 "gather_to_rank0": {"value": round(args.steps / float(np.median(t.tolist())), 2), "unit": "frames/s"},
+                 "allgather_bytes_per_frame": int(root.strip * root.row_bytes * world), "per_rank": per_rank}
+        player = root
+
     # ---- where the host side of a frame goes: the library's own phase timers over one more streamed region -------
     import ctypes as C
     host = None
-    if world == 1:
+    if not sharded:
         _get = C.CFUNCTYPE(None, C.c_void_p)(player.symbol("WrhipGetStats"))
         _reset = C.CFUNCTYPE(None)(player.symbol("WrhipResetStats"))
         barrier()
@@ -217,7 +276,7 @@ def main():
 
     # ---- per-kernel rooflines (separate, event-timed pass: one event pair + wait per launch) -------
     roof = None
-    if world == 1:
+    if not sharded:
         get_stats = C.CFUNCTYPE(None, C.c_void_p)(player.symbol("WrhipGetStats"))
         get_kstats = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)(player.symbol("WrhipGetKernelStats"))
         reset = C.CFUNCTYPE(None)(player.symbol("WrhipResetStats"))
@@ -267,7 +326,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
@@ -277,7 +336,7 @@ def main():
             "config": {"workload": f"{args.workload}: " + {
                 "cfg2": "1000 overlapping translucent rects (ps_quad_textured + premultiplied-alpha blend), "
                         "3840x2160, 20 picture-cache tiles + composite, seed 2",
-                "cfg5": "100k rects (50% opaque), 7680x4320, 72 tiles + composite, seed 5",
+                "cfg5": "100k rects (50% opaque), 7680x4320, 72 tiles + composite, seed 5 (BASELINE configs[4])",
                 "cfg4": "box-shadow-large.yaml at device_pixel_scale 2 (shadow 1840^2 px): cs_clip_rectangle mask -> "
                         "2 cs_scale halvings -> cs_blur V/H -> cs_clip_box_shadow x clip-out mask -> masked "
                         "brush_solid -> composite, 3840x2160",
@@ -286,19 +345,24 @@ def main():
                 "transforms": "wrench benchmarks/transforms-simple.yaml: 11 full-size translucent rects under rotate(45), 1024x1024",
                 "cfg1": "16x16 opaque rect grid 1024x1024"}[args.workload],
                 "encoding": args.encoding, "target": f"{frame_w}x{frame_h}",
-                "parallelism": "single GPU" if world == 1 else
+                "parallelism": "single GPU" if not sharded else
                 f"tile rows sharded over {world} GPUs + RCCL all-gather of framebuffer strips"},
         }
+        if multi:
+            out["multi_gpu"] = multi
+        if single:
+            out["single_gpu_same_workload"] = single
+            out["speedup_vs_single_gpu"] = round(fps / single["value"], 3)
         if host:
             out["host"] = host
         if roof:
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             cb = cpu_baseline(rec)
             if cb:
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -43,6 +43,13 @@ if world == 2:      # the strips are whole tile rows: each rank records, stages 
     assert mine[0] < 0.65 * sf.prims and mine[1] < sf.h2d_bytes, (mine, sf.prims, sf.h2d_bytes)
 want, _ = render_direct(lib, make())
 ok = np.array_equal(got, want)
+# the same frames with the window gathered on the presenting rank only (SURVEY section 8e: "or gather to the presenting GPU")
+p2 = ShardedFramePlayer(lib, "custom", "quad", rank, world, device="cpu", frame=make(), gather="root")
+p2.frames(1, 2)
+if rank == 0:
+    ok = ok and np.array_equal(p2.assembled(), want)
+else:
+    p2._drain()
 # each rank only rasterised its own strip: pixels it does not own stay at the clear colour in its window
 y0, y1 = p.fb_rows
 flags = torch.tensor([1 if ok else 0])

@@ -75,6 +75,30 @@ struct CopyPool {
 };
 CopyPool& copy_pool() { static CopyPool* p = new CopyPool(); return *p; }     // (never destroyed: the helpers outlive static destruction)
 constexpr size_t PARALLEL_COPY_MIN = 1u << 20;
+// Copy into the pinned staging ring with non-temporal stores: the ring is 96 MiB of memory the CPU never reads back (the
+// DMA engine does), so ordinary stores first fetch every destination line (read-for-ownership) and then evict useful
+// lines to keep it.  Streaming stores do neither; small copies keep memcpy.
+#if !defined(WRHIP_HOSTSIM) && (defined(__x86_64__) || defined(__SSE2__))
+#include <emmintrin.h>
+static inline void stage_copy(void* dst_, const void* src_, size_t n) {
+  uint8_t* d = (uint8_t*)dst_; const uint8_t* s = (const uint8_t*)src_;
+  static const bool plain = getenv("WRHIP_NO_STREAM_COPY") != nullptr;       // (A/B measurements)
+  if (n < 2048 || plain) { memcpy(d, s, n); return; }
+  const size_t head = (64 - ((uintptr_t)d & 63)) & 63;
+  if (head) { memcpy(d, s, head); d += head; s += head; n -= head; }
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m128i a = _mm_loadu_si128((const __m128i*)(s + i)), b = _mm_loadu_si128((const __m128i*)(s + i + 16));
+    const __m128i c = _mm_loadu_si128((const __m128i*)(s + i + 32)), e = _mm_loadu_si128((const __m128i*)(s + i + 48));
+    _mm_stream_si128((__m128i*)(d + i), a); _mm_stream_si128((__m128i*)(d + i + 16), b);
+    _mm_stream_si128((__m128i*)(d + i + 32), c); _mm_stream_si128((__m128i*)(d + i + 48), e);
+  }
+  if (i < n) memcpy(d + i, s + i, n - i);
+  _mm_sfence();
+}
+#else
+static inline void stage_copy(void* dst, const void* src, size_t n) { memcpy(dst, src, n); }
+#endif
 void big_memcpy(void* dst, const void* src, size_t n) {
   if (n < PARALLEL_COPY_MIN) { memcpy(dst, src, n); return; }
   copy_pool().run([&](int part, int parts) {
@@ -1401,9 +1425,10 @@ void flush_work(const std::vector<int>& sel_in) {
     size_t total = off_blk + sizeof(int) * n_blocks + 256;
     size_t aoff = staging_alloc(total);
     uint8_t* h = c->staging + aoff;
-    if (nd) memcpy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
-    memcpy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
-    if (!inst.empty()) big_memcpy(h + off_inst, inst.data(), inst.size());
+    if (nd) stage_copy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
+    stage_copy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
+    if (inst.size() >= PARALLEL_COPY_MIN) big_memcpy(h + off_inst, inst.data(), inst.size());
+    else if (!inst.empty()) stage_copy(h + off_inst, inst.data(), inst.size());
     {
       int* blk = (int*)(h + off_blk);
       int j = 0;
@@ -1873,11 +1898,11 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
           p = (p & 0xFF00FF00) | (rb << 16) | (rb >> 16);
           memcpy(d + 4 * x, &p, 4);
         }
-      } else memcpy(d, s, row);
+      } else stage_copy(d, s, row);
       if (ids) {
-        // (rows are whole texels of four ints, and an upload that starts mid-row keeps the two-texel phase: the staged
-        // bytes are scanned as one array, as before)
-        const int32_t* iv = (const int32_t*)d;
+        // (rows are whole texels of four ints, and an upload that starts mid-row keeps the two-texel phase: the uploaded
+        // bytes are scanned as one array, as before -- the caller's copy: the staged one went past the cache)
+        const int32_t* iv = (const int32_t*)s;
         const size_t i0 = (size_t)y * row / 4, ni = row / 4;
         for (size_t i = 0; i + 3 < ni; i += 4) {
           g |= ((uint32_t)iv[i] >> 23) != 0u;                                 // ps_quad header: [transform_id, z, pattern input]

@@ -60,12 +60,15 @@ class ShardedFramePlayer:
     """Renders `workload` with rows sharded over `world` ranks and all-gathers
     the window.  Interface mirrors harness.ScenePlayer (frames / stream)."""
 
-    def __init__(self, lib, workload, encoding, rank, world, device="cuda", frame=None):
+    def __init__(self, lib, workload, encoding, rank, world, device="cuda", frame=None, gather="all"):
+        """gather: "all" -- every rank receives the whole window (all-gather; north_star's reassembly step) -- or "root" --
+        only rank 0, the presenting GPU, does ("or gather to the presenting GPU if only one consumer")."""
         import torch
         import torch.distributed as dist
         from .harness import record_scene, ScenePlayer
         self.torch, self.dist = torch, dist
         self.rank, self.world = rank, world
+        self.gather = gather
         if frame is None:
             from .scenes import make_workload
             frame = make_workload(workload, encoding=encoding)
@@ -106,9 +109,18 @@ class ShardedFramePlayer:
             self.ext_stream = None
         chunk = self.strip * self.row_bytes
         self.send = [torch.zeros(chunk, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.gathered = [torch.zeros(chunk * world, dtype=torch.uint8, device=device) for _ in range(2)]
+        # (gather to rank 0: only the presenting rank holds the assembled window)
+        self.gathered = [torch.zeros(chunk * world if (gather == "all" or rank == 0) else 0, dtype=torch.uint8, device=device) for _ in range(2)]
         self.pending = None
         self.k = 0
+
+    def _collect(self, i):
+        """Start the collective that reassembles the window from every rank's strip (asynchronous)."""
+        if self.gather == "all":
+            return self.dist.all_gather_into_tensor(self.gathered[i], self.send[i], async_op=True)
+        chunk = self.send[i].numel()
+        outs = [self.gathered[i][r * chunk:(r + 1) * chunk] for r in range(self.world)] if self.rank == 0 else None
+        return self.dist.gather(self.send[i], outs, dst=0, async_op=True)
 
     # -- one frame: render own strips, then contribute to the all-gather ------
     def _frame(self):
@@ -124,7 +136,7 @@ class ShardedFramePlayer:
                     self.send[i][:n].copy_(self.fb[y0 * self.row_bytes:y0 * self.row_bytes + n])
                 if self.pending is not None:
                     self.pending.wait()              # stream-side wait: the send buffer of two frames ago is free again
-                self.pending = self.dist.all_gather_into_tensor(self.gathered[i], self.send[i], async_op=True)
+                self.pending = self._collect(i)
             return
         self.player.rp.exec(self.rec.frame)          # includes Finish(): strip is in HBM
         if self.device == "cuda":
@@ -136,7 +148,7 @@ class ShardedFramePlayer:
                 self.send[i][:n] = self.torch.from_numpy(px[y0:y1].reshape(-1).copy())
         if self.pending is not None:
             self.pending.wait()
-        self.pending = self.dist.all_gather_into_tensor(self.gathered[i], self.send[i], async_op=True)
+        self.pending = self._collect(i)
 
     def frames(self, warmup, iters):
         import time
