@@ -6282,7 +6282,7 @@ WR_DEVICE uint32_t wr_zcap_after(uint32_t kbf, uint32_t z, uint32_t zcap, bool f
 //      colour (and depth) one LDS read.
 // cfg2 (1000 translucent rects over a 4K frame, ~45 prims per bin cutting it into ~100 cells): the tile pass becomes a store
 // stream.  More than 256 cells (a bin crossed by dozens of small rects, cfg5) or a bin that loads its pixels: the pixel walk.
-#define WR_CELL_MAX_PRIMS 128
+#define WR_CELL_MAX_PRIMS 160
 struct WrCellShared {
   uint32_t color[256], dep[256];        // finished cells: packed BGRA8, depth
   uint8_t colflag[64], rowflag[64];     // column / row boundaries: [c] != 0 = a class starts at column (row) c of the bin
@@ -6329,7 +6329,8 @@ WR_DEVICE void wr_fold_inplace_v(uint32_t& p, uint32_t K, uint32_t C) {
 template <bool DEPTH>
 WR_DEVICE int wr_raster_cells(WrCellShared& sh, const WrTargetDesc& T, const WrRec* __restrict__ recs,
                                unsigned long long* __restrict__ mw, const int nw, const int bx0, const int by0,
-                               const int wave, const int lane, uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t (&dep)[16]) {
+                               const int wave, const int lane, uint32_t (&plo)[16], uint32_t (&phi)[16], uint32_t (&dep)[16],
+                               const bool try_cells, int& list_total) {
   WR_CT(0);
   // The waves of a workgroup sit on the four SIMDs of a CU in order, and the cell walk keeps the low wave indices busy (a bin
   // has ~70 cells: one wave walks, sometimes two): the jobs rotate with the bin so that they spread over the SIMDs.
@@ -6392,9 +6393,15 @@ WR_DEVICE int wr_raster_cells(WrCellShared& sh, const WrTargetDesc& T, const WrR
   const unsigned long long colm = __ballot(sh.colflag[lane] != 0), rowm = __ballot(sh.rowflag[lane] != 0);
   const int nx = __popcll(colm) + 1, ny = __popcll(rowm) + 1;
   const int ncell = nx * ny;
-  if (ncell > 256 || sh.bail) return 0;
-  // (self-cleaning bin masks: every wave read the bin's words before the first barrier)
-  for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) if (mw[w]) mw[w] = 0ull;
+  const bool cells_ok = try_cells && ncell <= 256 && !sh.bail;
+  // More cells than lanes (a bin crossed by dozens of small rects), or pixels / depth to load: the pixel walk -- over the
+  // list that is in LDS now (return 3), which spares each of the four waves the scan of the bin's mask words (a target of
+  // 100 k prims has 1563 of them per bin, a few dozen set bits in all) and the per-word record fetches.  Depth-tested launches
+  // only: the depth-less ones hold the records in their folded form.
+  if (!cells_ok && !DEPTH) return 0;
+  // (self-cleaning bin masks: every wave read the bin's words before the first barrier; only the words the list names are set)
+  for (int sl = threadIdx.x; sl < total; sl += (int)blockDim.x) mw[(sh.pid[sl] - T.first_prim) >> 6] = 0ull;
+  if (!cells_ok) { list_total = total; return 3; }
   // first column / row of every class (a table per wave: no workgroup barrier)
   if (((colm | 1ull) >> lane) & 1ull) sh.colstart[role][lane ? __popcll(colm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane;
   if (((rowm | 1ull) >> lane) & 1ull) sh.rowstart[role][lane ? __popcll(rowm & ((1ull << lane) - 1ull)) + 1 : 0] = (uint8_t)lane;
@@ -6565,17 +6572,21 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   unsigned long long* mw = masks + (size_t)T.word_base + (size_t)lb * T.words_per_bin;
   // (rect-only bins that start from a clear: the cell raster, when the bin's prims cut it into few enough cells)
   bool cells_done = false, empty_bin = false;      // (empty_bin: the cell raster found no prim in the bin's words)
+  int list_total = 0;                              // > 0: the bin's prim list sits in LDS (WrCellShared::pid / rec), its mask words are zeroed
 #ifndef WRHIP_HOSTSIM
   constexpr bool CELLS = FMT == WR_FMT_RGBA8 && FEAT == 0 && R == 4;
   constexpr size_t LDS_BYTES = CELLS && sizeof(WrCellShared) > sizeof(int) * 16 * 64 ? sizeof(WrCellShared) : sizeof(int) * 16 * 64;
   __shared__ uint4 lds_raw[LDS_BYTES / 16];           // the cell raster's tables, or the pixel walk's compaction rows
   if constexpr (CELLS) {
     WrCellShared& cell_sh = *(WrCellShared*)lds_raw;
-    if (T.cells && !T.load_color && !(DEPTH && T.load_depth && T.depth))
+    const bool try_cells = !T.load_color && !(DEPTH && T.load_depth && T.depth);
+    if (T.cells && (try_cells || DEPTH))
     {
       // (the same in every lane -- decided on LDS contents behind barriers -- but only provably so once it is said)
-      const int cr = __builtin_amdgcn_readfirstlane(wr_raster_cells<DEPTH>(cell_sh, T, recs, mw, T.words_per_bin, wx0, by * WR_BIN_H, wave, lane, plo, phi, dep));
+      int lt = 0;
+      const int cr = __builtin_amdgcn_readfirstlane(wr_raster_cells<DEPTH>(cell_sh, T, recs, mw, T.words_per_bin, wx0, by * WR_BIN_H, wave, lane, plo, phi, dep, try_cells, lt));
       cells_done = cr == 1; empty_bin = cr == 2;
+      if (cr == 3) list_total = __builtin_amdgcn_readfirstlane(lt);
     }
   }
 #endif
@@ -6660,7 +6671,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // variants call it through an inlined lambda -- expanded in place the glyph variant's was 4 % slower, cfg3)
 #define WR_ROUND_BODY                                                                                                                                                                                   \
     const bool has = pid >= 0;                                                                                                                                                                          \
-    const bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);                                                                         \
+    bool hit = has && !((int)ra.z <= wx0 || (int)ra.x >= wx0 + WR_BIN_W || (int)ra.w <= wy0 || (int)ra.y >= wy0 + STRIP);                                                                               \
+    /* (prims the strip's depth cap already rejects never reach the scalar walk: 64 of them per compare; the walk re-tests */                                                                           \
+    /* the survivors, since the cap may move while the round is applied) */                                                                                                                             \
+    if constexpr (DEPTH) hit = hit && !wr_zcap_rejects(rb.y, rb.x, zcap);                                                                                                                               \
     unsigned long long live = __ballot(hit);                                                                                                                                                            \
     /* prims of this word that are unit glyph blits (lane i looks at prim i): runs of them are applied lane by lane */                                                                                  \
     unsigned long long glyphs = 0ull;                                                                                                                                                                   \
@@ -6752,7 +6766,19 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   auto do_round = [&](const int pid, const int dbase, const bool sp, const uint4 ra, const uint4 rb) __attribute__((always_inline)) {
     WR_ROUND_BODY;
   };
-  const int nw = empty_bin ? 0 : T.words_per_bin;      // (an empty bin: nothing to walk, nothing to zero)
+  const int nw = (empty_bin || list_total > 0) ? 0 : T.words_per_bin;      // (an empty bin / a bin whose list is in LDS: no words to walk or zero)
+  if constexpr (CELLS && DEPTH) {
+    if (list_total > 0) {
+      // the bin's prims out of LDS, 64 per round (lane i: the list's entry c0 + i), in submission order
+      const WrCellShared& L = *(const WrCellShared*)lds_raw;
+      for (int c0 = 0; c0 < list_total; c0 += 64) {
+        int pid = -1;
+        uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+        if (c0 + lane < list_total) { pid = L.pid[c0 + lane]; ra = L.rec[0][c0 + lane]; rb = L.rec[1][c0 + lane]; }
+        do_round(pid, 0, true, ra, rb);
+      }
+    }
+  }
   if constexpr (FMT == WR_FMT_RGBA8 && FEAT == 0 && !DEPTH) {
     // The rect-only, depth-less variant runs at 8 waves per SIMD on 64 VGPRs with nothing to spare: it keeps the plain walk --
     // the bin's mask words fetched 64 at a time (lane l loads word l of the block), the non-zero ones visited one per round,
