@@ -2560,6 +2560,16 @@ void Finish(void) {
 }
 
 void MakeCurrent(WrhipContext* c) { ctx = (Context*)c; }
+#ifdef WRHIP_TIMING
+static void wr_dump_prim_times() {
+  const char* path = getenv("WRHIP_PRIM_TIMES");
+  if (!path) return;
+  std::vector<unsigned> h(16384 * 4);
+  wrq::drain();
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(wr_dbg_prim), h.size() * 4) != hipSuccess) return;
+  if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+}
+#endif
 #ifdef WR_CELL_TIMING
 static void wr_dump_cell_times() {
   const char* path = getenv("WRHIP_CELL_TIMES");
@@ -2575,6 +2585,10 @@ WrhipContext* CreateContext(void) {
   static bool reg = false;
   if (!reg) { reg = true; atexit(wr_dump_cell_times); }
 #endif
+#ifdef WRHIP_TIMING
+  static bool reg2 = false;
+  if (!reg2) { reg2 = true; atexit(wr_dump_prim_times); }
+#endif
   ensure_runtime();
   return (WrhipContext*)new Context();
 }
@@ -2585,6 +2599,9 @@ void DestroyContext(WrhipContext* c_) {
   if (--c->references > 0) return;
 #ifdef WR_CELL_TIMING
   wr_dump_cell_times();
+#endif
+#ifdef WRHIP_TIMING
+  wr_dump_prim_times();
 #endif
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG")) fprintf(stderr, "paths: r8fast %llu (unit %llu) generic %llu accum_loop %llu linear: fallback %llu upscale %llu fast %llu downscale %llu\n", wr_dbg_paths[0], wr_dbg_paths[3], wr_dbg_paths[1], wr_dbg_paths[2], wr_dbg_paths[4], wr_dbg_paths[5], wr_dbg_paths[6], wr_dbg_paths[7]);

@@ -2814,6 +2814,10 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
 
 // Vertex stage of one instance: locate its draw, run the shader's vertex
 // function, then swgl's draw_quad setup.
+#ifdef WRHIP_TIMING
+__device__ unsigned long long wr_dbg_mid[16384];
+__device__ unsigned wr_dbg_prim[16384 * 4];
+#endif
 WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws, const uint8_t* __restrict__ arena,
                               int gid, WrPrim& P, WrAux* aux, const WrTargetDesc* targets, WrUnsupportedCounters* cnt,
                               const int* __restrict__ blk) {
@@ -2884,6 +2888,9 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
       P.color[0] = P.color[1] = 0;
       return;
   }
+#ifdef WRHIP_TIMING
+  if (gid < 16384) wr_dbg_mid[gid] = wall_clock64();
+#endif
   wr_finish_prim(d, lo, o, P, &aux[gid], cnt);
   if ((P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) && aux[gid].quad.pad != 0 && (P.flags & WR_PF_DEPTH_TEST)) {
     // a depth-tested perspective prim: the rows its spans touch are flattened from here on (WrTargetDesc::flat_rows)
@@ -3282,6 +3289,7 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
   }
 #ifdef WRHIP_TIMING
   const unsigned long long tm2 = wall_clock64();
+  if (valid && gid < 16384) { wr_dbg_prim[gid * 4] = (unsigned)(tm1 - tm0); wr_dbg_prim[gid * 4 + 1] = (unsigned)(tm2 - tm1); wr_dbg_prim[gid * 4 + 2] = (unsigned)(wr_dbg_mid[gid] - tm0); wr_dbg_prim[gid * 4 + 3] = (unsigned)draws[P.draw].shader; }
 #endif
 #ifdef WRHIP_TIMING
   if (dbg_mode == 3) return;
