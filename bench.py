@@ -76,6 +76,12 @@ def pmc_traffic(workload, encoding, label):
     if not files or encoding != "quad":
         return None
     d = json.load(open(files[-1]))
+    # the counters describe the kernels they were collected with: a profile of other kernel sources says nothing about these
+    import hashlib
+    cur = hashlib.sha256(b"".join(open(os.path.join(ROOT, "webrender_amd", "csrc", f), "rb").read()
+                                  for f in ("wrhip_kernels.h", "wrhip_types.h"))).hexdigest()[:16]
+    if d.get("kernel_sources_sha256_16") != cur:
+        return None
     tag = label[label.index("<"):] if "<" in label else label
     tot = n = 0
     for name, k in d["kernels"].items():

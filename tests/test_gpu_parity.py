@@ -232,6 +232,43 @@ def test_hip_depth_run_overflow_is_reported(name, make):
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 4
 
 
+def _sweep_cases():
+    """Randomised scenes that stress the prim-list walks (dense and thinly spread mask words, several 64-word blocks, the cell
+    raster's and the LDS list walk's limits, the depth cap with opaque / translucent mixes) and the general-quad paths: the
+    fixed-seed part of tools/sweep.py, sized for the driver's run (about 20 s on the MI355X)."""
+    out = []
+    for seed in range(2):
+        for n, (w, h) in ((300, (512, 512)), (3000, (1024, 512)), (9000, (2048, 1024)), (30000, (2048, 2048))):
+            for enc in ("quad", "brush"):
+                out.append((f"rects_n{n}_{enc}_s{seed}", lambda n=n, w=w, h=h, enc=enc, seed=seed:
+                            scenes.cfg5_many_rects(width=w, height=h, n=n, seed=100 + seed, encoding=enc)))
+        # translucent-only and opaque-heavy mixes over a clear: cells where the bins are sparse, pixel / list walk where they are not
+        out.append((f"overlap_small_s{seed}", lambda seed=seed: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=2500, seed=300 + seed)))
+        out.append((f"overlap_frac_s{seed}", lambda seed=seed: scenes.cfg2_overlapping_rects(width=1536, height=1024, n=600, seed=310 + seed, fractional=True)))
+        out.append((f"rotated_s{seed}", lambda seed=seed: scenes.add_occluders(scenes.rotated_rects(n=120, seed=500 + seed, opaque_frac=0.3), zmax=120, seed=seed)))
+        out.append((f"persp_s{seed}", lambda seed=seed: scenes.add_occluders(scenes.rotated_rects(n=120, seed=600 + seed, perspective=True, opaque_frac=0.3), zmax=120, seed=seed)))
+        out.append((f"persp_images_s{seed}", lambda seed=seed: scenes.add_occluders(scenes.rotated_images(n=80, seed=700 + seed, perspective="all"), zmax=80, seed=seed)))
+        out.append((f"rot_images_s{seed}", lambda seed=seed: scenes.add_occluders(scenes.rotated_images(n=80, seed=800 + seed), zmax=80, seed=seed)))
+        out.append((f"images_s{seed}", lambda seed=seed: scenes.add_occluders(scenes.image_grid(width=2048, height=1024, n=400, seed=900 + seed), n=150, zmax=430, seed=seed)))
+        out.append((f"text_s{seed}", lambda seed=seed: scenes.add_occluders(scenes.cfg3_text(width=2048, height=1024, lines=50, glyphs_per_line=120, run_len=24, seed=seed), zmax=100, seed=seed)))
+    return out
+
+
+_SWEEP = _sweep_cases()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", _SWEEP, ids=[c[0] for c in _SWEEP])
+def test_hip_randomised_sweep_matches_oracle(name, make):
+    ref = oracle_lib("gcc")
+    if not ref:
+        pytest.skip("oracle not built")
+    want, _ = render_direct(ref, make())
+    got, stats = render_direct(wrhip_lib(), make())
+    assert np.array_equal(got, want)
+    assert stats["gl_error"] == 0
+
+
 def _cache_key(scene):
     return "decoration_cache" if scene == "cache_decorations" else "border_cache"
 

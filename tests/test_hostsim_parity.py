@@ -323,6 +323,47 @@ def test_unimplemented_perspective_prims_are_reported(hostsim, capfd):
     r.destroy()
 
 
+def test_undrawable_draws_are_refused_when_recorded(hostsim, capfd):
+    """A draw the backend has no path for -- a shader key without an implementation (cs_svg_filter), an index pattern that is
+    not the unit quad's -- raises GL_INVALID_OPERATION in the DrawElementsInstanced call itself (visible to the very next
+    GetError, before any Finish), and nothing is recorded for it."""
+    from webrender_amd import glapi, glconst as G
+    from webrender_amd.device import Device
+    gl = glapi.GL(hostsim)
+    d = Device(gl)
+    d.init_default_framebuffer(64, 64)
+    tex = d.create_texture(64, 64, G.GL_RGBA8, render_target=True)
+    d.bind_draw_target(tex.fbo, 64, 64)
+    d.clear_target((0.0, 0.0, 0.0, 1.0), None)
+    # (the link status already says so -- GetLinkStatus is what Device.create_program checks --; a caller that ignores it and
+    # draws anyway is told at the draw)
+    vs, fs = gl.CreateShader(G.GL_VERTEX_SHADER), gl.CreateShader(G.GL_FRAGMENT_SHADER)
+    gl.ShaderSourceByName(vs, b"cs_svg_filter"); gl.ShaderSourceByName(fs, b"cs_svg_filter")
+    pid = gl.CreateProgram()
+    gl.AttachShader(pid, vs); gl.AttachShader(pid, fs)
+    gl.LinkProgram(pid)
+    assert not gl.GetLinkStatus(pid)
+    vao = d.create_vao("PRIM_INSTANCES")
+    gl.UseProgram(pid)
+    assert gl.GetError() == 0
+    d.draw_instanced_batch(vao, np.zeros((3, 4), np.int32))
+    assert gl.GetError() == G.GL_INVALID_OPERATION and gl.GetError() == 0
+    assert "cs_svg_filter" in capfd.readouterr().err
+    # a known program, but not the unit quad
+    prog2 = d.create_program("brush_solid", "PRIM_INSTANCES")
+    d.bind_program(prog2, np.eye(4, dtype=np.float32))
+    gl.BindVertexArray(vao.id)
+    gl.BindBuffer(G.GL_ARRAY_BUFFER, vao.instance_vbo)
+    gl.BufferData(G.GL_ARRAY_BUFFER, 48, np.zeros((3, 4), np.int32), G.GL_STREAM_DRAW)
+    gl.DrawElementsInstanced(G.GL_TRIANGLES, 3, G.GL_UNSIGNED_SHORT, 0, 3)
+    assert gl.GetError() == G.GL_INVALID_OPERATION
+    gl.Finish()
+    assert gl.GetError() == 0
+    px = d.read_texture(tex)
+    assert (px[..., :3] == 0).all()          # nothing was drawn
+    d.destroy()
+
+
 def test_texture_allocation_failure_is_sticky_out_of_memory(hostsim, monkeypatch):
     """HBM exhaustion while allocating texture storage raises the sticky GL_OUT_OF_MEMORY swgl raises (gl.cc:1125-1134;
     Renderer counts consecutive ones, renderer/mod.rs:1296-1303) instead of aborting; the texture stays unusable, draws to

@@ -8,7 +8,8 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/${tag}_$ctr -o r -- python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_$ctr/bench.log 2>&1
 done
 python3 - <<PY
-import csv, collections, json, glob
+import csv, collections, json, glob, hashlib
+src_hash = hashlib.sha256(b"".join(open("webrender_amd/csrc/" + f, "rb").read() for f in ("wrhip_kernels.h", "wrhip_types.h"))).hexdigest()[:16]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/${tag}_%s/*counter_collection.csv" % ctr)
@@ -16,7 +17,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         name = row["Kernel_Name"].split("(")[0]
         agg[f"{name} grid={row['Grid_Size']}"][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"workload": "$wl quad (bench.py --workload $wl --steps 20 --warmup 5), separate --pmc passes for FETCH_SIZE and WRITE_SIZE; "
-                   "hbm_bytes_per_launch = 1024 * (2 * FETCH_SIZE_KB + WRITE_SIZE_KB)", "kernels": {}}
+                   "hbm_bytes_per_launch = 1024 * (2 * FETCH_SIZE_KB + WRITE_SIZE_KB)", "kernel_sources_sha256_16": src_hash, "kernels": {}}
 for k, v in agg.items():
     fk = sum(v.get("FETCH_SIZE", [0])) / max(1, len(v.get("FETCH_SIZE", [0])))
     wk = sum(v.get("WRITE_SIZE", [0])) / max(1, len(v.get("WRITE_SIZE", [0])))

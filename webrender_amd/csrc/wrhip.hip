@@ -224,7 +224,7 @@ struct VertexArray {
 };
 struct Framebuffer { GLuint color_attachment = 0, depth_attachment = 0; };
 struct Renderbuffer { GLuint texture = 0; };
-struct Shader { GLenum type = 0; int kind = WR_SH_NONE; };
+struct Shader { GLenum type = 0; int kind = WR_SH_NONE; char name[96] = ""; };
 
 // Static description of the programs the backend implements.
 struct ShaderInfo {
@@ -311,6 +311,8 @@ const int UNIFORM_TRANSFORM = WR_MAX_TEX + 1;   // sampler s -> uniform index s+
 
 struct Program {
   const ShaderInfo* info = nullptr;
+  char name[96] = "";            // the key ShaderSourceByName sent (kept for programs without an implementation)
+  bool refused_once = false;     // the draw-time refusal of an unimplemented program is printed once
   bool linked = false, deleted = false;
   int attrib_loc[WR_MAX_ATTRIBS + 2];
   int sampler_unit[WR_MAX_TEX];
@@ -1745,6 +1747,7 @@ GLuint CreateShader(GLenum type) { GLuint id = (GLuint)ctx->shaders.insert(); ct
 void ShaderSourceByName(GLuint shader, const GLchar* name) {
   Shader& s = ctx->shaders[shader];
   s.kind = WR_SH_NONE;
+  snprintf(s.name, sizeof(s.name), "%s", name ? name : "");
   for (const ShaderInfo& info : SHADERS) if (!strcmp(info.key, name)) s.kind = info.kind;
 }
 void AttachShader(GLuint program, GLuint shader) {
@@ -1752,6 +1755,7 @@ void AttachShader(GLuint program, GLuint shader) {
   Shader& s = ctx->shaders[shader];
   if (!p.info && s.kind != WR_SH_NONE)
     for (const ShaderInfo& info : SHADERS) if (info.kind == s.kind) p.info = &info;
+  if (!p.name[0]) memcpy(p.name, s.name, sizeof(p.name));
 }
 void DeleteShader(GLuint n) { if (n) ctx->shaders.erase(n); }
 GLuint CreateProgram(void) { return (GLuint)ctx->programs.insert(); }
@@ -2315,27 +2319,35 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   Context* c = ctx;
   HostTimer ht(c ? &c->stats.host_record_ns : nullptr);
   Program* prog = c->programs.find(c->current_program);
-  if (offset < 0 || count <= 0 || instancecount <= 0 || !prog || !prog->info) return;
+  if (offset < 0 || count <= 0 || instancecount <= 0 || !prog) return;
+  // What cannot be drawn is refused HERE, when the draw is recorded (GL_INVALID_OPERATION is visible to the caller's very
+  // next GetError()), not discovered by the device after the frame was presented without it.
+  auto refuse = [&](const char* why) {
+    c->last_error = GL_INVALID_OPERATION;
+    if (!prog->refused_once) fprintf(stderr, "libwrhip: draw refused (program '%s'): %s\n", prog->name, why);
+    prog->refused_once = true;
+  };
+  if (!prog->info) { refuse("this shader key has no implementation"); return; }
   Framebuffer& fb = *get_framebuffer(GL_DRAW_FRAMEBUFFER, true);
   if (!fb.color_attachment) return;
   GLuint color_id = fb.color_attachment;
   {
     Texture& colortex = c->textures[color_id];
     if (!colortex.dptr || colortex.own_none) return;      // (own_none: another rank's target, WrhipSetTargetRows)
-    if (colortex.internal_format != GL_RGBA8 && colortex.internal_format != GL_R8) return;
+    if (colortex.internal_format != GL_RGBA8 && colortex.internal_format != GL_R8) { refuse("colour target is neither RGBA8 nor R8"); return; }
   }
   VertexArray& v = c->vertex_arrays[c->current_vertex_array];
   // Only WebRender's instanced unit quad is supported: TRIANGLES, 6 x u16,
   // indices i, i+1, i+2, i+2, i+1, i+3 (rasterize.h:1646-1659; vertex.rs:1079-1080).
   if (mode != GL_TRIANGLES || type != GL_UNSIGNED_SHORT || count != 6) {
-    fprintf(stderr, "libwrhip: unsupported draw (mode %x type %x count %d)\n", mode, type, count);
+    refuse("only WebRender's instanced unit quad (TRIANGLES, 6 x UNSIGNED_SHORT) is drawn");
     return;
   }
   Buffer& ib = c->buffers[v.element_array_buffer_binding];
   if (!ib.buf || (size_t)offset + 12 > ib.size) return;
   const uint16_t* idx = (const uint16_t*)(ib.buf + offset);
   if (!(idx[1] == idx[0] + 1 && idx[2] == idx[0] + 2 && idx[5] == idx[0] + 3)) {
-    fprintf(stderr, "libwrhip: unsupported index pattern\n");
+    refuse("index pattern is not the unit quad's");
     return;
   }
   const ShaderInfo* info = prog->info;
@@ -2377,16 +2389,16 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     if (loc == NULL_ATTRIB) continue;
     VertexAttrib& va = v.attribs[loc];
     if (!va.enabled || va.divisor != 1) continue;
-    if (va.type != GL_INT && va.type != GL_FLOAT && va.type != GL_UNSIGNED_SHORT) { fprintf(stderr, "libwrhip: unsupported instance attribute type %x\n", va.type); continue; }
+    if (va.type != GL_INT && va.type != GL_FLOAT && va.type != GL_UNSIGNED_SHORT) { refuse("instance attribute type is neither INT, FLOAT nor UNSIGNED_SHORT"); return; }
     if (va.type == GL_UNSIGNED_SHORT) d.attr_u16 |= 1u << (k - 1);
     if (!inst_buf) { inst_buf = va.vertex_buffer; inst_stride = va.stride; }
-    if (va.vertex_buffer != inst_buf || va.stride != inst_stride) { fprintf(stderr, "libwrhip: split instance buffers unsupported\n"); continue; }
+    if (va.vertex_buffer != inst_buf || va.stride != inst_stride) { refuse("instance attributes come from more than one buffer / stride"); return; }
     d.attr_off[k - 1] = va.offset; d.attr_bytes[k - 1] = (int)va.size;
   }
   Buffer* instb = inst_buf ? c->buffers.find(inst_buf) : nullptr;
   size_t need = (size_t)inst_stride * instancecount;
   if (!instb || !instb->buf || need > instb->size) {
-    if (inst_buf) { fprintf(stderr, "libwrhip: instance buffer too small\n"); return; }
+    if (inst_buf) { refuse("instance buffer holds fewer bytes than instancecount x stride"); return; }
   }
   if (c->depthtest && fb.depth_attachment) {
     Texture* dtx = c->textures.find(fb.depth_attachment);
