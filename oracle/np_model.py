@@ -317,3 +317,237 @@ def line_decoration_task(inst):
         if half <= 1.0:
             alpha = _f(1.0) - (_f(0.5) >= alpha).astype(np.float32)
     return _to_u8(np.repeat(alpha[..., None], 4, axis=2))
+
+
+# ---------------------------------------------------------------------------
+# cs_clip_rectangle / cs_clip_box_shadow / cs_blur / cs_scale (BASELINE config 4's off-screen chain): whole-task restatements of
+# the GLSL main()s over the task's pixel grid -- no spans, no chunks, no interpolant stepping, none of swgl's span rasterisers
+# (cs_clip_rectangle.glsl:223-495, cs_clip_box_shadow.glsl:150-324, swgl_ext.h:951-978).  Identity clip / prim transforms, as the
+# scenes use them: local_pos = (screen_origin + sub_rect.p0 + pixel centre) / device_pixel_scale, w = 1.
+def _clip_local_pos(inst):
+    ax0, ay0, ax1, ay1 = [float(v) for v in inst["area"]]
+    w, h = int(round(ax1 - ax0)), int(round(ay1 - ay0))
+    gx, gy = _pixel_grid(w, h)
+    sox, soy = _f(inst["origins"][2]), _f(inst["origins"][3])
+    dps = _f(inst["dps"])
+    lx = (sox + (_f(ax0) + gx)) / dps
+    ly = (soy + (_f(ay0) + gy)) / dps
+    return lx, ly, dps, w, h
+
+
+def _round_r8(v):
+    return np.clip(np.floor(v * _f(255.0) + _f(0.5)), 0, 255).astype(np.uint8)
+
+
+def clip_rect_task(inst, fast):
+    """cs_clip_rectangle.glsl:81-199 for one ClipMaskInstanceRect (scenes.CLIP_RECT_DTYPE) -> uint8 [h, w] (the R8 mask, unblended)"""
+    lx, ly, dps, w, h = _clip_local_pos(inst)
+    aa_range = dps                                                   # recip(fwidth(local_pos).x), fwidth = 1 / dps per device pixel
+    lp = _f(inst["lpos"])
+    r0 = _f(inst["lrect"])
+    p0 = lp.copy()
+    p1 = r0[2:4] + (lp - r0[0:2])
+    mode = _f(inst["mode"])
+    corners = _f(inst["corners"])                                     # [rect TL, radii TL, rect TR, radii TR, rect BL, radii BL, rect BR, radii BR]
+    if fast:
+        half = _f(0.5) * (p1 - p0)
+        radius = corners[1][0]
+        px, py = lx - (half[0] + lp[0]), ly - (half[1] + lp[1])
+        bx, by = half[0] - radius, half[1] - radius
+        dx, dy = np.abs(px) - bx, np.abs(py) - by
+        ox, oy = np.maximum(dx, _f(0.0)), np.maximum(dy, _f(0.0))
+        dist = np.sqrt(ox * ox + oy * oy) + np.minimum(np.maximum(dx, dy), _f(0.0)) - radius
+    else:
+        r_tl, r_tr, r_bl, r_br = corners[1][0:2], corners[3][0:2], corners[5][0:2], corners[7][0:2]
+
+        def inv_r2(r):
+            return _f(1.0) / np.maximum(r * r, _f(1.0e-6))
+        c_tl, c_tr = p0 + r_tl, _f([p1[0] - r_tr[0], p0[1] + r_tr[1]])
+        c_br, c_bl = p1 - r_br, _f([p0[0] + r_bl[0], p1[1] - r_bl[1]])
+        n_tl, n_tr = _f([-r_tl[1], -r_tl[0]]), _f([r_tr[1], -r_tr[0]])
+        n_br, n_bl = _f([r_br[1], r_br[0]]), _f([-r_bl[1], r_bl[0]])
+        k_tl = n_tl[0] * p0[0] + n_tl[1] * (p0[1] + r_tl[1])
+        k_tr = n_tr[0] * (p1[0] - r_tr[0]) + n_tr[1] * p0[1]
+        k_br = n_br[0] * p1[0] + n_br[1] * (p1[1] - r_br[1])
+        k_bl = n_bl[0] * (p0[0] + r_bl[0]) + n_bl[1] * p1[1]
+        # corner selection in the shader's order (a later test overrides an earlier one)
+        cx = np.full((h, w), 1.0e-6, np.float32); cy = cx.copy()
+        ix = np.ones((h, w), np.float32); iy = ix.copy()
+        for (n, k, c, sx, sy, r) in ((n_tl, k_tl, c_tl, 1.0, 1.0, r_tl), (n_tr, k_tr, c_tr, -1.0, 1.0, r_tr),
+                                     (n_br, k_br, c_br, None, None, r_br), (n_bl, k_bl, c_bl, 1.0, -1.0, r_bl)):
+            sel = (lx * n[0] + ly * n[1]) > k
+            if sx is None:
+                vx, vy = lx - c[0], ly - c[1]
+            else:
+                vx, vy = (c[0] - lx) * _f(sx), (c[1] - ly) * _f(sy)
+            i2 = inv_r2(r)
+            cx, cy = np.where(sel, vx, cx), np.where(sel, vy, cy)
+            ix, iy = np.where(sel, i2[0], ix), np.where(sel, i2[1], iy)
+        prx, pry = cx * ix, cy * iy
+        g = (cx * prx + cy * pry) - _f(1.0)
+        dgx, dgy = _f(2.0) * prx, _f(2.0) * pry
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d_ell = g * (_f(1.0) / np.sqrt(dgx * dgx + dgy * dgy))
+        d_rect = np.maximum(np.maximum(p0[0] - lx, lx - p1[0]), np.maximum(p0[1] - ly, ly - p1[1]))
+        dist = np.maximum(d_ell, d_rect)
+    alpha = _distance_aa(aa_range, dist)
+    final = (_f(1.0) - alpha - alpha) * mode + alpha                  # mix(alpha, 1 - alpha, mode)
+    return _round_r8(final)
+
+
+def clip_rect_span_exempt(inst):
+    """Pixels of a cs_clip_rectangle task where swgl's span rasteriser (what actually runs, cs_clip_rectangle.glsl:223-495) is NOT
+    main(): the pixels within a pixel of the rect's straight edges.  A horizontal span has no y step to intersect the box with
+    (:271-284), so a row just outside is one solid run of the outside value; and the opaque run (:452-457) starts at the first
+    pixel whose CENTRE is inside the box (ceil(opaque_start), :418-421), so the inside half of an edge's coverage ramp is
+    committed as fully inside -- main() anti-aliases both sides (up to half a pixel's worth, 128 LSB).  bool [h, w]."""
+    lx, ly, dps, w, h = _clip_local_pos(inst)
+    lp = _f(inst["lpos"]); r0 = _f(inst["lrect"])
+    x0, y0 = lp[0], lp[1]
+    x1, y1 = r0[2] + (lp[0] - r0[0]), r0[3] + (lp[1] - r0[1])
+    one = _f(1.0) / dps
+    return (np.abs(ly - y0) < one) | (np.abs(ly - y1) < one) | (np.abs(lx - x0) < one) | (np.abs(lx - x1) < one)
+
+
+def _linear_r8(tex, u, v):
+    """texture(sampler2D of an R8 texture, LINEAR, uv) as swgl samples it (texture.h:424-473, 543-583): the position quantised to
+    1/128 texel, rows lerped then columns in 16-bit integers; returns float r in [0, 1]"""
+    H, W = tex.shape
+    qx = (u * _f(W) * _f(128.0) + _f(0.5 - 64.0)).astype(np.int64)     # truncation toward zero, as the cast does
+    qy = (v * _f(H) * _f(128.0) + _f(0.5 - 64.0)).astype(np.int64)
+    ix, iy = qx >> 7, qy >> 7
+    fx, fy = qx & 127, qy & 127
+    # clamp the 2x2 footprint into the texture (the shader's uv clamp keeps it half a texel inside already)
+    x0, x1 = np.clip(ix, 0, W - 1), np.clip(ix + 1, 0, W - 1)
+    y0, y1 = np.clip(iy, 0, H - 1), np.clip(iy + 1, 0, H - 1)
+    t = tex.astype(np.int64)
+    a, b, c, d = t[y0, x0], t[y0, x1], t[y1, x0], t[y1, x1]
+    l = a + (((c - a) * fy) >> 7)
+    r = b + (((d - b) * fy) >> 7)
+    return ((l + (((r - l) * fx) >> 7)).astype(np.float32)) * _f(1.0 / 255.0)
+
+
+def box_shadow_task(inst, cache, uv_rect):
+    """cs_clip_box_shadow.glsl:59-138 for one ClipMaskInstanceBoxShadow (scenes.BOX_SHADOW_DTYPE) sampling `cache` (the R8 shadow
+    texture, uv_rect = the resource's texel rect) -> uint8 [h, w]"""
+    lx, ly, dps, w, h = _clip_local_pos(inst)
+    d0, d1 = _f(inst["dest"][0:2]), _f(inst["dest"][2:4])
+    size = d1 - d0
+    src = _f(inst["src_size"])
+    mode = _f(int(inst["mode"]))
+    H, W = cache.shape
+    uvs, edges = [], []
+    for axis, pos in ((0, lx), (1, ly)):
+        if int(inst["stretch"][axis]) == 0:                            # MODE_STRETCH
+            e0, e1 = _f(0.5), (size[axis] / src[axis]) - _f(0.5)
+            uv = (pos - d0[axis]) / src[axis]
+        else:
+            e0 = e1 = _f(1.0)
+            uv = (pos - d0[axis]) / size[axis]
+        q = np.clip(uv, _f(0.0), e0) + np.maximum(_f(0.0), uv - e1)
+        uvs.append(q)
+    u0, v0, u1, v1 = [_f(t) for t in uv_rect]
+    nb = (u0 / _f(W), v0 / _f(H), u1 / _f(W), v1 / _f(H))
+    bb = ((u0 + _f(0.5)) / _f(W), (v0 + _f(0.5)) / _f(H), (u1 - _f(0.5)) / _f(W), (v1 - _f(0.5)) / _f(H))
+    uu = np.clip((nb[2] - nb[0]) * uvs[0] + nb[0], bb[0], bb[2])
+    vv = np.clip((nb[3] - nb[1]) * uvs[1] + nb[1], bb[1], bb[3])
+    texel = _linear_r8(cache, uu, vv)
+    inside = ((lx >= d0[0]) & (lx < d1[0]) & (ly >= d0[1]) & (ly < d1[1])).astype(np.float32)      # point_inside_rect (rect.glsl:15-18): step(p0, p) - step(p1, p)
+    alpha = (_f(1.0) - texel - texel) * mode + texel
+    result = (alpha - mode) * inside + mode
+    return _round_r8(result)
+
+
+def _lerp_axis(tex, pos, other, axis):
+    """texture(sColor0, uv) with LINEAR filtering where only one coordinate is off the texel centres: `pos` = the float texel
+    coordinate along `axis` (0 = x), `other` = the integer texel index along the other axis; exact float lerp (no 1/128 grid)."""
+    n = tex.shape[1 - axis] if axis == 0 else tex.shape[0]
+    t = pos - _f(0.5)
+    i0 = np.floor(t).astype(np.int64)
+    f = (t - i0).astype(np.float32)
+    a, b = np.clip(i0, 0, n - 1), np.clip(i0 + 1, 0, n - 1)
+    if axis == 0:
+        c0, c1 = tex[other, a], tex[other, b]
+    else:
+        c0, c1 = tex[a, other], tex[b, other]
+    if tex.ndim == 3:
+        f = f[..., None]
+    return c0 * (_f(1.0) - f) + c1 * f
+
+
+def blur_task(inst, src, src_rect, target_rect, horizontal):
+    """cs_blur.glsl:47-178 (one separable pass, main() only: float weights, two texels per lookup) for one BlurInstance
+    (scenes.BLUR_DTYPE) reading `src` (uint8 [H, W] or [H, W, 4], texture rows top-down) -> uint8 [h, w(, 4)] of the target rect.
+    swgl runs swgl_commitGaussianBlur* instead (swgl_ext.h:951-978: the same weights rounded to 8.8 fixed point, one tap per
+    texel): the two agree within 1 LSB."""
+    sigma = _f(inst["p"][0])
+    region = _f(inst["p"][1:3])
+    x0, y0, x1, y1 = [int(v) for v in target_rect]
+    sx0, sy0 = _f(src_rect[0]), _f(src_rect[1])
+    w, h = x1 - x0, y1 - y0
+    texf = src.astype(np.float32) * _f(1.0 / 255.0)
+    support = int(np.ceil(_f(1.5) * sigma)) * 2
+    if support > 0:
+        g0 = _f(1.0) / (_f(np.sqrt(_f(2.0 * 3.14159265))) * sigma)
+        g1 = _f(np.exp(_f(-0.5) / (sigma * sigma)))
+        cx, cy, cz = g0, g1, g1 * g1
+        total = cx
+        for i in range(1, support + 1, 2):
+            cx, cy = cx * cy, cy * cz
+            sub = cx
+            cx, cy = cx * cy, cy * cz
+            sub = sub + cx
+            total = total + _f(2.0) * sub
+        g0 = g0 / total
+    else:
+        g0, g1 = _f(1.0), _f(1.0)
+    gx, gy = _pixel_grid(w, h)
+    u, v = sx0 + gx, sy0 + gy                                          # vUv in texels: the source rect maps 1:1 onto the target rect
+    lo = (sx0 + _f(0.5), sy0 + _f(0.5))
+    hi = (sx0 + region[0] - _f(0.5), sy0 + region[1] - _f(0.5))
+    ix, iy = np.floor(u).astype(np.int64), np.floor(v).astype(np.int64)
+    H, W = src.shape[:2]
+    orig = texf[np.clip(iy, 0, H - 1), np.clip(ix, 0, W - 1)]
+    cx, cy, cz = g0, g1, g1 * g1
+    avg = orig * cx
+    for i in range(1, support + 1, 2):
+        cx, cy = cx * cy, cy * cz
+        sub = cx
+        cx, cy = cx * cy, cy * cz
+        sub = sub + cx
+        ratio = cx / sub
+        off = _f(i) + ratio
+        if horizontal:
+            s0 = _lerp_axis(texf, np.maximum(u - off, lo[0]), np.clip(iy, 0, H - 1), 0)
+            s1 = _lerp_axis(texf, np.minimum(u + off, hi[0]), np.clip(iy, 0, H - 1), 0)
+        else:
+            s0 = _lerp_axis(texf, np.maximum(v - off, lo[1]), np.clip(ix, 0, W - 1), 1)
+            s1 = _lerp_axis(texf, np.minimum(v + off, hi[1]), np.clip(ix, 0, W - 1), 1)
+        avg = avg + (s0 + s1) * sub
+    return np.clip(np.floor(avg * _f(255.0) + _f(0.5)), 0, 255).astype(np.uint8)
+
+
+def scale_task(inst, src):
+    """cs_scale.glsl:24-60 (main(): texture(sColor0, clamp(vUv, vUvRect)), unnormalised source rect) for one ScalingInstance
+    (scenes.SCALE_DTYPE) -> uint8 [h, w(, 4)]; exact float bilinear.  swgl runs swgl_commitTextureLinearRGBA8's 2:1 down-scale
+    filter on RGBA8 targets and main() with its 1/128-texel sampler on R8 ones: within 1 LSB of this."""
+    tx0, ty0, tx1, ty1 = [float(v) for v in inst["t"]]
+    sx0, sy0, sx1, sy1 = [_f(v) for v in inst["s"]]
+    w, h = int(round(tx1 - tx0)), int(round(ty1 - ty0))
+    gx, gy = _pixel_grid(w, h)
+    u = sx0 + (sx1 - sx0) * (gx / _f(w))
+    v = sy0 + (sy1 - sy0) * (gy / _f(h))
+    u = np.clip(u, min(sx0, sx1) + _f(0.5), max(sx0, sx1) - _f(0.5))
+    v = np.clip(v, min(sy0, sy1) + _f(0.5), max(sy0, sy1) - _f(0.5))
+    H, W = src.shape[:2]
+    texf = src.astype(np.float32) * _f(1.0 / 255.0)
+    tu, tv = u - _f(0.5), v - _f(0.5)
+    i0, j0 = np.floor(tu).astype(np.int64), np.floor(tv).astype(np.int64)
+    fu, fv = (tu - i0).astype(np.float32), (tv - j0).astype(np.float32)
+    if src.ndim == 3:
+        fu, fv = fu[..., None], fv[..., None]
+    a = texf[np.clip(j0, 0, H - 1), np.clip(i0, 0, W - 1)]; b = texf[np.clip(j0, 0, H - 1), np.clip(i0 + 1, 0, W - 1)]
+    c = texf[np.clip(j0 + 1, 0, H - 1), np.clip(i0, 0, W - 1)]; d = texf[np.clip(j0 + 1, 0, H - 1), np.clip(i0 + 1, 0, W - 1)]
+    top, bot = a * (_f(1.0) - fu) + b * fu, c * (_f(1.0) - fu) + d * fu
+    out = top * (_f(1.0) - fv) + bot * fv
+    return np.clip(np.floor(out * _f(255.0) + _f(0.5)), 0, 255).astype(np.uint8)

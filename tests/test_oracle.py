@@ -127,3 +127,98 @@ def test_oracle_cache_shaders_match_numpy_models(oracle_gcc):
     _pin_tasks(cache, grads, lambda e: (int(e["task"][0]), int(e["task"][1])), np_model.fast_linear_gradient_task)
     _pin_tasks(cache, steps["cs_line_decoration"], lambda e: (int(e["task"][0]), int(e["task"][1])), np_model.line_decoration_task,
                lsb_budget=0.01)
+
+
+def _pin_r8_tasks(mask, insts, model, lsb_budget, exempt=None, exempt_budget=0.06, outlier_budget=0.0, outlier_max=1):
+    """every task's sub-rect of the read-back R8 target against the numpy model: within 1 LSB everywhere, equal on all but
+    `lsb_budget` of the bytes.  `exempt(inst)`: pixels where the reference itself departs from main() (stated per model): left
+    out of the 1-LSB check, bounded in number (`exempt_budget`) and in size (half a pixel of coverage).  `outlier_budget`: the
+    fraction of the other pixels that may be off by more than 1 (never more than `outlier_max`)."""
+    total = off = ex = out = 0
+    for inst in insts:
+        want = model(inst)
+        ox, oy = int(inst["origins"][0] + inst["area"][0]), int(inst["origins"][1] + inst["area"][1])
+        h, w = want.shape
+        got = mask[oy:oy + h, ox:ox + w]
+        d = np.abs(got.astype(int) - want.astype(int))
+        if exempt is not None:
+            e = exempt(inst)
+            assert d[e].max(initial=0) <= 129
+            ex += int(e.sum())
+            d = np.where(e, 0, d)
+        assert d.max() <= max(1, outlier_max), (inst, int(d.max()), np.argwhere(d > 1)[:4])
+        total += d.size
+        off += int((d > 0).sum())
+        out += int((d > 1).sum())
+    assert total > 0 and off <= lsb_budget * total and ex <= exempt_budget * total and out <= outlier_budget * total, (off, ex, out, total)
+    return off, total
+
+
+def test_oracle_clip_masks_match_numpy_models(oracle_gcc):
+    """cs_clip_rectangle (FAST_PATH and general) and cs_clip_box_shadow: the oracle's hand-written headers -- main() AND the span
+    rasterisers swgl runs instead of it -- against whole-task numpy restatements of the GLSL main() alone (oracle/np_model.py:
+    clip_rect_task, box_shadow_task).  Within 1 LSB everywhere; the bytes that differ at all are the anti-aliased ones where
+    the span shader's float order differs from main()'s."""
+    fr = scenes.clip_masks(n=40, seed=33)
+    got, _ = render_direct(oracle_gcc, fr)
+    mask = got["clip_masks"]
+    mask = mask[..., 0] if mask.ndim == 3 else mask
+    steps = fr.passes[0][0].steps
+    second = {(float(e["origins"][0]), float(e["origins"][1])) for e in steps[2].instances} if len(steps) > 2 else set()
+    first = lambda insts: [e for e in insts if (float(e["origins"][0]), float(e["origins"][1])) not in second]
+    _pin_r8_tasks(mask, first(steps[0].instances), lambda e: np_model.clip_rect_task(e, True), lsb_budget=0.01, exempt=np_model.clip_rect_span_exempt)
+    # (general path: the span rasteriser's outer octagon -- the "apex" estimate of where a corner's coverage ramp ends,
+    # cs_clip_rectangle.glsl:332-343 -- cuts a handful of pixels whose main() coverage is a few percent, and inside a corner
+    # segment it evaluates EITHER the ellipse OR the rect distance (:436-441) where main() takes the larger of the two)
+    _pin_r8_tasks(mask, first(steps[1].instances), lambda e: np_model.clip_rect_task(e, False), lsb_budget=0.01, exempt=np_model.clip_rect_span_exempt,
+                  outlier_budget=0.0005, outlier_max=64)
+    for dps in (1.0, 2.0):
+        fr = scenes.box_shadow_masks(n=16, seed=43, dps=dps, atlas=1024 if dps == 1.0 else 2048)
+        got, _ = render_direct(oracle_gcc, fr)
+        mask = got["box_shadow_masks"]
+        mask = mask[..., 0] if mask.ndim == 3 else mask
+        cache_tex = fr.static_textures[0]
+        cache = np.asarray(cache_tex.pixels)
+        insts = fr.passes[0][0].steps[0].instances
+
+        def model(e):
+            addr = int(e["res"][0]) + 1024 * int(e["res"][1])
+            uv = fr.gpu_cache.data[addr]
+            return np_model.box_shadow_task(e, cache, [float(v) for v in uv])
+        _pin_r8_tasks(mask, insts, model, lsb_budget=0.02)
+
+
+@pytest.mark.parametrize("fmt", ["r8", "rgba8"])
+def test_oracle_blur_chain_matches_numpy_models(oracle_gcc, fmt):
+    """cs_scale and cs_blur (ALPHA_TARGET / COLOR_TARGET): every pass of a down-scale x 2 -> blur V -> blur H chain against the
+    float restatement of the GLSL main() (oracle/np_model.py: scale_task, blur_task), each pass fed with the ORACLE's own
+    previous target so errors do not accumulate.  swgl's span paths are integer (8.8 fixed-point taps, the 2:1 down-scale
+    filter, the 1/128-texel sampler): within 1 LSB for the blur, within 2 for the down-scale (a 2 x 2 average lands on
+    quarters; fewer than 2 % of the bytes are off by 2)."""
+    fr = scenes.blur_chain(fmt=fmt, scale_steps=2, content=(166, 140), sigma=[2.5, 1.3, 4.0], n_tasks=3, atlas=512)
+    got, _ = render_direct(oracle_gcc, fr)
+    cur = np.asarray(fr.static_textures[0].pixels)
+
+    def pin(name, insts, model, origin, max_lsb, over1_budget):
+        out = got[name]
+        out = out[..., 0] if (fmt == "r8" and out.ndim == 3) else out
+        tot = over = 0
+        for e in insts:
+            want = model(e)
+            x0, y0 = origin(e)
+            h, w = want.shape[:2]
+            d = np.abs(out[y0:y0 + h, x0:x0 + w].astype(int) - want.astype(int))
+            assert d.max() <= max_lsb, (name, int(d.max()))
+            tot += d.size
+            over += int((d > 1).sum())
+        assert tot > 0 and over <= over1_budget * tot, (name, over, tot)
+        return out
+
+    for pi, name in enumerate(("scale_0", "scale_1")):
+        insts = fr.passes[pi][0].steps[0].instances
+        cur = pin(name, insts, lambda e, cur=cur: np_model.scale_task(e, cur), lambda e: (int(e["t"][0]), int(e["t"][1])), 2, 0.02)
+    for pi, (name, hz) in enumerate((("blur_v", False), ("blur_h", True))):
+        insts = fr.passes[2 + pi][0].steps[0].instances
+        rect = lambda a: fr.render_tasks.data[2 * int(a)][:4]
+        cur = pin(name, insts, lambda e, cur=cur, hz=hz: np_model.blur_task(e, cur, rect(e["a"][1]), rect(e["a"][0]), hz),
+                  lambda e: (int(rect(e["a"][0])[0]), int(rect(e["a"][0])[1])), 1, 0.0)
