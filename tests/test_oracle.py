@@ -223,3 +223,28 @@ def test_oracle_blur_chain_matches_numpy_models(oracle_gcc, fmt):
         rect = lambda a: fr.render_tasks.data[2 * int(a)][:4]
         cur = pin(name, insts, lambda e, cur=cur, hz=hz: np_model.blur_task(e, cur, rect(e["a"][1]), rect(e["a"][0]), hz),
                   lambda e: (int(rect(e["a"][0])[0]), int(rect(e["a"][0])[1])), 2, 0.06)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(glyph_zoom=1.25), dict(device_pixel_scale=1.5, width=1000, height=500)], ids=["unit", "zoom", "dps"])
+def test_oracle_text_runs_match_numpy_model(oracle_gcc, kw):
+    """ps_text_run (BASELINE config 3's program): the glyph snapping of the vertex stage (ps_text_run.glsl:98-272: raster glyph
+    offset, glyph scale, text offset) and main()'s colour x mask, restated per glyph in numpy (oracle/np_model.py: text_tile),
+    against the oracle's hand-written header -- whose span shader multiplies colour and mask as 8-bit integers
+    (swgl_commitTextureLinearColorR8ToRGBA8) where main() rounds a float product, and overlapping glyphs carry that through
+    the blend: a glyph placed one pixel off would differ by tens of LSB on thousands of pixels; the allowance is 4 LSB on
+    under 1 % of the bytes."""
+    base = dict(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12)
+    base.update(kw)
+    fr = scenes.cfg3_text(**base)
+    got, _ = render_direct(oracle_gcc, fr)
+    atlas = np.asarray(fr.static_textures[0].pixels)
+    tot = off = over = 0
+    for tgt, ct in zip(fr.passes[0], fr.composite_tiles):
+        tile = np_model.text_tile(fr, tgt, atlas)
+        x0, y0, x1, y1 = [int(v) for v in ct.clip_rect]
+        d = np.abs(got[::-1][y0:y1, x0:x1].astype(int) - tile[:y1 - y0, :x1 - x0].astype(int))
+        assert d.max() <= 4
+        tot += d.size
+        off += int((d > 0).sum())
+        over += int((d > 1).sum())
+    assert (got != 255).any() and over <= 0.01 * tot and off <= 0.15 * tot, (off, over, tot)
