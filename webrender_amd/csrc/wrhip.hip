@@ -1295,6 +1295,11 @@ void flush_work(const std::vector<int>& sel_in) {
         }
       }
       if ((d.flags & (WR_DF_DEPTH_TEST | WR_DF_CLEAR_DEPTH)) && T.format == WR_FMT_RGBA8) L.any_depth = true;
+      // A wave of the setup stage runs every vertex shader its 64 prims need one after the other (divergence), and the setup
+      // stage of a small flush is one long dependent chain per wave: while the flush is small, a draw with another program
+      // starts a wave of its own (cfg4: the box-shadow and the clip-out rect of a mask target, 2 x 12 us in one wave).
+      if (prim_cursor < 4096 && (prim_cursor & 63) && !draws.empty() && draws.back().target == oi && draws.back().shader != d.shader)
+        prim_cursor = (prim_cursor + 63) & ~63;
       d.first_prim = prim_cursor;
       if ((d.flags & WR_DF_DEPTH_WRITE) && d.shader != WR_SH_CLEAR_OP) {
         if (T.dw_end <= T.dw_first) T.dw_first = prim_cursor;
