@@ -612,3 +612,177 @@ def text_tile(frame, target, atlas):
             a = src[..., 3:4]
             img[y0:y1, x0:x1] = src + dst - ((dst * a + dst) >> 8)
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# ps_quad_mask (+FAST_PATH) on top of a solid ps_quad_textured quad (scenes.quad_masks, identity transforms): the quad's pixel
+# coverage from ps_quad.glsl:187-330 (local rect ∩ clip, device position clamped to the task's content rect, pixel centres),
+# pattern_fragment of ps_quad_mask.glsl:171-207 (sd_rounded_box / distance_to_rounded_rect of ellipse.glsl:48-92, distance_aa
+# with swgl's aa range recip(fwidth) = 1) as whole-rect array expressions, blended with swgl's premultiplied-alpha key and
+# its multiply key (blend.h:473-482).  swgl has no span shader for this program: main() is what runs.
+def _rounded_rect_dist(lx, ly, p0, p1, r_tl, r_tr, r_br, r_bl, bounds):
+    def inv_r2(r):
+        return _f(1.0) / np.maximum(r * r, _f(1.0e-6))
+    c_tl, c_tr = p0 + r_tl, _f([p1[0] - r_tr[0], p0[1] + r_tr[1]])
+    c_br, c_bl = p1 - r_br, _f([p0[0] + r_bl[0], p1[1] - r_bl[1]])
+    n_tl, n_tr = _f([-r_tl[1], -r_tl[0]]), _f([r_tr[1], -r_tr[0]])
+    n_br, n_bl = _f([r_br[1], r_br[0]]), _f([-r_bl[1], r_bl[0]])
+    k_tl = n_tl[0] * p0[0] + n_tl[1] * (p0[1] + r_tl[1])
+    k_tr = n_tr[0] * (p1[0] - r_tr[0]) + n_tr[1] * p0[1]
+    k_br = n_br[0] * p1[0] + n_br[1] * (p1[1] - r_br[1])
+    k_bl = n_bl[0] * (p0[0] + r_bl[0]) + n_bl[1] * p1[1]
+    cx = np.full(lx.shape, 1.0e-6, np.float32); cy = cx.copy()
+    ix = np.ones(lx.shape, np.float32); iy = ix.copy()
+    for (n, k, c, sx, sy, r) in ((n_tl, k_tl, c_tl, 1.0, 1.0, r_tl), (n_tr, k_tr, c_tr, -1.0, 1.0, r_tr),
+                                 (n_br, k_br, c_br, None, None, r_br), (n_bl, k_bl, c_bl, 1.0, -1.0, r_bl)):
+        sel = (lx * n[0] + ly * n[1]) > k
+        if sx is None:
+            vx, vy = lx - c[0], ly - c[1]
+        else:
+            vx, vy = (c[0] - lx) * _f(sx), (c[1] - ly) * _f(sy)
+        i2 = inv_r2(r)
+        cx, cy = np.where(sel, vx, cx), np.where(sel, vy, cy)
+        ix, iy = np.where(sel, i2[0], ix), np.where(sel, i2[1], iy)
+    prx, pry = cx * ix, cy * iy
+    g = (cx * prx + cy * pry) - _f(1.0)
+    dgx, dgy = _f(2.0) * prx, _f(2.0) * pry
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d_ell = g * (_f(1.0) / np.sqrt(dgx * dgx + dgy * dgy))
+    d_rect = np.maximum(np.maximum(bounds[0] - lx, lx - bounds[2]), np.maximum(bounds[1] - ly, ly - bounds[3]))
+    return np.maximum(d_ell, d_rect)
+
+
+def _quad_pixels(bf, addr_f, trect, tdata):
+    """pixel range [x0, x1) x [y0, y1) of an untransformed QF_APPLY_DEVICE_CLIP quad in its target, and the local position of
+    the target's pixel (0, 0) corner (local = pixel + that, device pixel scale 1)"""
+    bounds, clip = _f(bf[addr_f]), _f(bf[addr_f + 1])
+    p0 = np.maximum(bounds[0:2], clip[0:2])
+    p1 = np.maximum(p0, np.minimum(bounds[2:4], clip[2:4]))
+    dps, corigin = tdata[0], tdata[1:3]
+    assert dps == 1.0
+    size = trect[2:4] - trect[0:2]
+    d0 = np.clip(p0 * dps, corigin, corigin + size) - corigin + trect[0:2]
+    d1 = np.clip(p1 * dps, corigin, corigin + size) - corigin + trect[0:2]
+    x0, y0 = [int(v) for v in np.floor(d0 + _f(0.5))]
+    x1, y1 = [int(v) for v in np.floor(d1 + _f(0.5))]
+    return x0, y0, x1, y1, corigin - trect[0:2]
+
+
+def quad_mask_tile(frame, target):
+    """One picture-cache tile of a scenes.quad_masks frame (rotate=False) -> uint8 [TILE_H, TILE_W, 4] RGBA"""
+    from webrender_amd.scenes import TILE_W, TILE_H
+    bf, tasks = frame.gpu_buffer_f.data, frame.render_tasks.data
+    img = np.empty((TILE_H, TILE_W, 4), np.int64)
+    img[:] = np.floor(_f(target.clear_color) * _f(255.0) + _f(0.5)).astype(np.int64)
+    for step in target.alpha:
+        inst = np.asarray(step.instances)[0]
+        addr_f, task_addr = int(inst[1]), int(inst[3])
+        trect, tdata = _f(tasks[2 * task_addr]), _f(tasks[2 * task_addr + 1])
+        x0, y0, x1, y1, off = _quad_pixels(bf, addr_f, trect, tdata)
+        if x1 <= x0 or y1 <= y0:
+            continue
+        dst = img[y0:y1, x0:x1]
+        if step.shader == "ps_quad_textured":
+            src = np.floor(_f(bf[addr_f + 4]) * _f(255.0) + _f(0.5)).astype(np.int64)
+            img[y0:y1, x0:x1] = src + dst - ((dst * src[3] + dst) >> 8)
+            continue
+        assert step.shader.startswith("ps_quad_mask")
+        lx = ((np.arange(x0, x1, dtype=np.float32) + _f(0.5)) + off[0])[None, :].repeat(y1 - y0, axis=0)
+        ly = ((np.arange(y0, y1, dtype=np.float32) + _f(0.5)) + off[1])[:, None].repeat(x1 - x0, axis=1)
+        ca = int(inst[5])
+        rect = _f(bf[ca])
+        if step.shader.endswith("FAST_PATH"):
+            radius, mode = _f(bf[ca + 1])[0], _f(bf[ca + 2])[0]
+            half = _f(0.5) * (rect[2:4] - rect[0:2])
+            px, py = lx - (half[0] + rect[0]), ly - (half[1] + rect[1])
+            dx, dy = np.abs(px) - (half[0] - radius), np.abs(py) - (half[1] - radius)
+            ox, oy = np.maximum(dx, _f(0.0)), np.maximum(dy, _f(0.0))
+            dist = np.sqrt(ox * ox + oy * oy) + np.minimum(np.maximum(dx, dy), _f(0.0)) - radius
+        else:
+            top, bot, mode = _f(bf[ca + 1]), _f(bf[ca + 2]), _f(bf[ca + 3])[0]
+            dist = _rounded_rect_dist(lx, ly, rect[0:2], rect[2:4], top[0:2], top[2:4], bot[2:4], bot[0:2], rect)
+        alpha = _distance_aa(_f(1.0), dist)
+        final = (_f(1.0) - alpha - alpha) * mode + alpha
+        src = np.floor(final * _f(255.0) + _f(0.5)).astype(np.int64)[..., None]
+        img[y0:y1, x0:x1] = (src * dst + src) >> 8
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# brush_linear_gradient (+ALPHA_PASS), identity transforms (scenes.gradient_grid, rotate=False): the brush vertex stage for an
+# untransformed prim (prim_shared.glsl:98-130: local rect ∩ local clip, device = local * dps - content origin + task origin,
+# pixel centres), write_gradient_vertex / brush_vs / brush_fs of gradient_shared.glsl:19-78 and brush_linear_gradient.glsl:33-79
+# and sample_gradient of gradient.glsl:32-63 (128-entry table of [start colour, step] pairs in the float GPU buffer) per
+# pixel.  swgl runs swgl_commitLinearGradientRGBA8 (swgl_ext.h:1390+) instead of main() wherever the gradient's step is
+# finite: that evaluates the table in 8-bit fixed point per chunk, hence an allowance in the test.
+def linear_gradient_tile(frame, target, skip=lambda spec: False):
+    from webrender_amd.scenes import TILE_W, TILE_H
+    cache, bf = frame.gpu_cache.data, frame.gpu_buffer_f.data
+    hf, hi, tasks = frame.prim_headers_f.data, frame.prim_headers_i.data, frame.render_tasks.data
+    img = np.empty((TILE_H, TILE_W, 4), np.int64)
+    img[:] = np.floor(_f(target.clear_color) * _f(255.0) + _f(0.5)).astype(np.int64)
+    dirty = np.zeros((TILE_H, TILE_W), bool)                 # pixels a skipped prim touched (and whatever is blended on top)
+    for steps, blend in ((target.opaque, False), (target.alpha, True)):
+        for step in steps:
+            assert step.shader.startswith("brush_linear_gradient")
+            for inst in np.asarray(step.instances):
+                ph = int(inst[0])
+                lr, lc = _f(hf[2 * ph]), _f(hf[2 * ph + 1])
+                h0, h1 = hi[2 * ph], hi[2 * ph + 1]
+                spec, tid, task_addr, lut = int(h0[1]), int(h0[2]), int(h0[3]), int(h1[0])
+                assert tid == 0
+                trect, tdata = _f(tasks[2 * task_addr]), _f(tasks[2 * task_addr + 1])
+                dps, corigin = tdata[0], tdata[1:3]
+                p0 = np.maximum(lr[0:2], lc[0:2])
+                p1 = np.minimum(lr[2:4], lc[2:4])
+                d0 = p0 * dps - corigin + trect[0:2]
+                d1 = p1 * dps - corigin + trect[0:2]
+                x0, x1 = int(np.floor(np.clip(d0[0], 0, TILE_W) + _f(0.5))), int(np.floor(np.clip(d1[0], 0, TILE_W) + _f(0.5)))
+                y0, y1 = int(np.floor(np.clip(d0[1], 0, TILE_H) + _f(0.5))), int(np.floor(np.clip(d1[1], 0, TILE_H) + _f(0.5)))
+                if x1 <= x0 or y1 <= y0:
+                    continue
+                g0, g1 = _f(cache[spec]), _f(cache[spec + 1])
+                if skip(g0):
+                    dirty[y0:y1, x0:x1] = True
+                    continue
+                sp, ep, extend, stretch = g0[0:2], g0[2:4], int(g1[0]), g1[1:3]
+                d = ep - sp
+                sd = d / (d[0] * d[0] + d[1] * d[1])
+                start = sp[0] * sd[0] + sp[1] * sd[1]
+                sd = sd * stretch
+                lx = ((np.arange(x0, x1, dtype=np.float32) + _f(0.5)) - trect[0] + corigin[0]) / dps
+                ly = ((np.arange(y0, y1, dtype=np.float32) + _f(0.5)) - trect[1] + corigin[1]) / dps
+                vx = ((lx - lr[0]) / stretch[0])[None, :]
+                vy = ((ly - lr[1]) / stretch[1])[:, None]
+                fx, fy = vx - np.floor(vx), vy - np.floor(vy)
+                off = (fx * sd[0] + fy * sd[1]) - start
+                if extend == 1:                              # EXTEND_MODE_REPEAT
+                    off = off - np.floor(off)
+                x = np.clip(_f(1.0) + off * _f(128.0), _f(0.0), _f(129.0)).astype(np.float32)
+                idx = np.floor(x)
+                fr = (x - idx).astype(np.float32)
+                ii = idx.astype(np.int64)
+                c = _f(bf[lut + 2 * ii]) + _f(bf[lut + 2 * ii + 1]) * fr[..., None]
+                src = np.floor(np.clip(c, 0.0, 1.0) * _f(255.0) + _f(0.5)).astype(np.int64)
+                if blend:
+                    dst = img[y0:y1, x0:x1]
+                    img[y0:y1, x0:x1] = src + dst - ((dst * src[..., 3:4] + dst) >> 8)
+                else:
+                    img[y0:y1, x0:x1] = src
+    return np.clip(img, 0, 255).astype(np.uint8), dirty
+
+
+# ---------------------------------------------------------------------------
+# composite (FAST_PATH, 1:1 tiles; composite.glsl: the tile's device rect clipped to its clip rect, uv = the tile's texels
+# one to one): the window is every tile's pixels inside its clip rect, in framebuffer row order (the projection is y-flipped,
+# renderer/mod.rs:4861-4866).
+def composite_window(frame, tiles, clear=(0, 0, 0, 0)):
+    """tiles: {texture name: uint8 [h, w, 4]} -> uint8 [H, W, 4] as ReadPixels returns it (bottom-up)"""
+    img = np.empty((frame.height, frame.width, 4), np.uint8)
+    img[:] = np.asarray(clear, np.uint8)
+    for ct in frame.composite_tiles:
+        rx0, ry0 = int(ct.rect[0]), int(ct.rect[1])
+        x0, y0, x1, y1 = [int(v) for v in ct.clip_rect]
+        x1, y1 = min(x1, frame.width), min(y1, frame.height)
+        img[y0:y1, x0:x1] = tiles[ct.texture.name][y0 - ry0:y1 - ry0, x0 - rx0:x1 - rx0]
+    return img[::-1].copy()
