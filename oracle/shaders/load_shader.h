@@ -27,6 +27,7 @@
 #include "cs_conic_gradient.h"
 #include "ps_quad_radial_gradient.h"
 #include "ps_quad_conic_gradient.h"
+#include "ps_copy.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -37,6 +38,7 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("composite TEXTURE_2D", composite_TEXTURE_2D)
   WRSH_ENTRY("composite FAST_PATH,TEXTURE_2D", composite_FAST_PATH_TEXTURE_2D)
   WRSH_ENTRY("ps_clear", ps_clear)
+  WRSH_ENTRY("ps_copy", ps_copy)
   WRSH_ENTRY("ps_text_run ALPHA_PASS,TEXTURE_2D", ps_text_run_ALPHA_PASS_TEXTURE_2D)
   WRSH_ENTRY("ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D",
              ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D)

@@ -167,3 +167,29 @@ DECORATIONS = [
     # cs_conic_gradient: main() with libm atan2f -- bit-exact on the host build (same libm as the oracle), within 1 LSB on the GPU
     ("cache_conic_gradients", dict(n_lines=1, n_grads=1, n_lgrads=1, n_rgrads=0, n_cgrads=150, seed=171)),
 ]
+
+
+# ps_copy: texture-cache copies / batched uploads.  The expected bytes follow from the scene alone -- a
+# copy is a copy -- so these cases need no oracle: `copies_expected` applies the CopyInstances in submission order in numpy.
+COPIES = [
+    ("copies", dict()),
+    ("copies_many_small", dict(n=200, seed=192, src_size=256, dst_size=300)),
+    ("copies_unchained", dict(n=40, seed=193, chained=False)),
+]
+
+
+def copies_expected(frame):
+    """{texture name: uint8 array as read_texture returns it} for a scenes.texture_cache_copies frame"""
+    import numpy as np
+    tex = {t.name: np.asarray(t.pixels) for t in frame.static_textures}
+    for targets in frame.passes:
+        for tg in targets:
+            ref = tg.texture
+            src = tex[tg.steps[0].textures[0].name]
+            dst = np.zeros((ref.h, ref.w) + src.shape[2:], np.uint8)
+            for e in tg.steps[0].instances:
+                sx0, sy0, sx1, sy1 = [int(v) for v in e["src"]]
+                dx0, dy0, dx1, dy1 = [int(v) for v in e["dst"]]
+                dst[dy0:dy1, dx0:dx1] = src[sy0:sy1, sx0:sx1]
+            tex[ref.name] = dst
+    return {t.name: tex[t.name] for t in frame.readback}

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -432,3 +432,20 @@ def test_hip_filter_swatches_match_numpy_model():
     fr = scenes.filter_swatches()
     px, _ = render_direct(wrhip_lib(), fr)
     check_filter_swatches(px, fr, tol_hue=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", COPIES, ids=[c[0] for c in COPIES])
+def test_hip_texture_cache_copies(name, kw):
+    """ps_copy: RGBA8 and R8 texture-cache copies (one pass feeding the next) equal the copies done in numpy, and swgl's."""
+    fr = scenes.texture_cache_copies(**kw)
+    want = copies_expected(fr)
+    got, st = render_direct(wrhip_lib(), scenes.texture_cache_copies(**kw))
+    assert st["gl_error"] == 0
+    ref = oracle_lib("gcc")
+    for k, v in want.items():
+        assert v.any() and np.array_equal(got[k], v), k
+    if ref:
+        sw, _ = render_direct(ref, scenes.texture_cache_copies(**kw))
+        for k, v in want.items():
+            assert np.array_equal(sw[k], v), k

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -394,3 +394,16 @@ def test_texture_allocation_failure_is_sticky_out_of_memory(hostsim, monkeypatch
     gl.ReadPixels(0, 0, 64, 64, G.GL_RGBA, G.GL_UNSIGNED_BYTE, px)
     assert (px[..., 0] == 255).all() and (px[..., 3] == 255).all()
     gl.DestroyContext(ctx)
+
+
+@pytest.mark.parametrize("name,kw", COPIES, ids=[c[0] for c in COPIES])
+def test_hostsim_texture_cache_copies(hostsim, oracle_gcc, name, kw):
+    """ps_copy: RGBA8 and R8 texture-cache copies (one pass feeding the next) equal the copies done in numpy -- and the oracle's
+    hand-written ps_copy header says the same."""
+    fr = scenes.texture_cache_copies(**kw)
+    want = copies_expected(fr)
+    got, st = render_direct(hostsim, scenes.texture_cache_copies(**kw))
+    ref, _ = render_direct(oracle_gcc, scenes.texture_cache_copies(**kw))
+    assert st["gl_error"] == 0
+    for k, v in want.items():
+        assert v.any() and np.array_equal(got[k], v) and np.array_equal(ref[k], v), k

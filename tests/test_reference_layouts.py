@@ -69,6 +69,7 @@ _STRUCT_DESC_DTYPE = [
     ("CompositeInstance", "COMPOSITE", None),
     ("ClearInstance", "CLEAR", None),
     ("MaskInstance", "MASK", None),
+    ("CopyInstance", "COPY", "COPY_DTYPE"),
 ]
 
 

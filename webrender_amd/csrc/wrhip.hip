@@ -283,6 +283,7 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
     {"cs_scale TEXTURE_2D", WR_SH_CS_SCALE, {"aPosition", "aScaleTargetRect", "aScaleSourceRect", "aSourceRectType"},
      S(WR_S_COLOR0)},
+    {"ps_copy", WR_SH_PS_COPY, {"aPosition", "a_src_rect", "a_dst_rect", "a_dst_texture_size"}, S(WR_S_COLOR0)},
     {"cs_border_solid", WR_SH_CS_BORDER_SOLID,
      {"aPosition", "aTaskOrigin", "aRect", "aColor0", "aColor1", "aFlags", "aWidths", "aRadii", "aClipParams1", "aClipParams2"}, 0},
     {"cs_border_segment", WR_SH_CS_BORDER_SEGMENT,
@@ -1041,9 +1042,10 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
               S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
     prof_end(3, H.fmt, 0, 0, 0, (uint64_t)wgs);
     if (c->profiling) {          // bytes this launch evaluated: the kernel's running count, read back (profiling syncs per launch anyway)
-      unsigned long long seen = 0;
-      wrrt::d2h(&seen, S.mr_ctl + 1, 8, c->stream);
+      unsigned long long parts[32], seen = 0;
+      wrrt::d2h(parts, S.mr_ctl + 32, sizeof(parts), c->stream);
       wrrt::stream_sync(c->stream);
+      for (unsigned long long v : parts) seen += v;
       for (WrhipKernelStat& e : c->kstats) if (e.kind == 3 && e.fmt == H.fmt) e.algo_bytes += seen - S.mr_seen;
       S.mr_seen = seen;
     }
@@ -1389,7 +1391,7 @@ void flush_work(const std::vector<int>& sel_in) {
     const size_t want_bytes = (size_t)std::min<uint64_t>(mr_bytes, mr_safe ? kCap : ((uint64_t)256 << 20));
     if (!S.mr_ctl || S.mr_slots_cap < want_slots || S.mr_store_cap < want_bytes) {
       sync_stream();
-      if (!S.mr_ctl) S.mr_ctl = (unsigned long long*)wrrt::dev_alloc(256);
+      if (!S.mr_ctl) S.mr_ctl = (unsigned long long*)wrrt::dev_alloc(512);       // [0] allocation word, [32..63] byte counters
       if (S.mr_slots_cap < want_slots) {
         wrrt::dev_free(S.mr_slots);
         S.mr_slots_cap = std::min<size_t>(want_slots * 2, WR_MR_MAX_SLOTS);
@@ -1478,7 +1480,7 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
     const uint8_t* dinst = darena + off_inst;
     const int* dblk = (const int*)(darena + off_blk);
-    if (mr_on) { wrrt::memset8(S.mr_ctl, 0, 16, c->stream); S.mr_seen = 0; }     // (this set's previous user, two flushes back, has been launched)
+    if (mr_on) { wrrt::memset8(S.mr_ctl, 0, 512, c->stream); S.mr_seen = 0; }     // (this set's previous user, two flushes back, has been launched)
     if (n_prims > 0) {
 #ifdef WRHIP_TIMING
       static const int setup_mode = getenv("WRHIP_SETUP_MODE") ? atoi(getenv("WRHIP_SETUP_MODE")) : 0;
@@ -2433,6 +2435,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     td.stride = t->bpp >= 4 ? t->stride / 4 : (t->bpp == 2 ? t->stride / 2 : t->stride);
     td.format = (int16_t)wr_format(t->internal_format);
     td.linear = (t->mag_filter == GL_LINEAR || t->mag_filter == GL_LINEAR_MIPMAP_LINEAR || t->mag_filter == GL_LINEAR_MIPMAP_NEAREST) && t->width >= 2;
+    if (info->kind == WR_SH_PS_COPY) td.linear = 0;      // texelFetch: the sampler's filter does not enter (ps_copy.glsl:36-38)
     mark_ref(tid, *t, false);
     std::vector<GLuint>& reads = c->work[wi].reads;
     if (std::find(reads.begin(), reads.end(), tid) == reads.end()) reads.push_back(tid);
@@ -2587,6 +2590,16 @@ static void wr_dump_prim_times() {
   if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
 }
 #endif
+#ifdef WR_ROWS_TIMING
+static void wr_dump_rows_times() {
+  const char* path = getenv("WRHIP_ROWS_TIMES");
+  if (!path) return;
+  std::vector<unsigned long long> h(4096 * 8);
+  wrq::drain();
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(wr_rows_times), h.size() * 8) != hipSuccess) return;
+  if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+}
+#endif
 #ifdef WR_CELL_TIMING
 static void wr_dump_cell_times() {
   const char* path = getenv("WRHIP_CELL_TIMES");
@@ -2616,6 +2629,9 @@ void DestroyContext(WrhipContext* c_) {
   if (--c->references > 0) return;
 #ifdef WR_CELL_TIMING
   wr_dump_cell_times();
+#endif
+#ifdef WR_ROWS_TIMING
+  wr_dump_rows_times();
 #endif
 #ifdef WRHIP_TIMING
   wr_dump_prim_times();

@@ -1051,6 +1051,33 @@ WR_DEVICE void wr_vs_cs_scale(const WrDrawDesc& d, const uint8_t* arena, int ins
   o.kind = (target_format == WR_FMT_RGBA8 && tex.format == WR_FMT_RGBA8) ? WR_PK_TEX_RGBA8 : WR_PK_TEX_FS;
 }
 
+// ps_copy.glsl:18-26 (vertex stage).  No uTransform: the destination rect maps straight to the target's pixels
+// (pos / (size / 2) - 1 and back through the viewport); no span function: every pixel runs main(), a texelFetch at the
+// truncated texel-space uv.  Carried as WR_PK_TEX_FS on the nearest sampler with uv / texture size: for the 1:1 copies the
+// renderer issues (source and destination rect of one size) a pixel centre sits half a texel from any truncation boundary, so
+// floor(u / W * W) is the texel int(u) is; any other rect pair is reported, not drawn.
+WR_DEVICE void wr_vs_ps_copy(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+  const wf4 sr = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf4 dr = wr_load_attr<wf4>(d, arena, inst, 1);
+  const wf2 ds = wr_load_attr<wf2>(d, arena, inst, 2);
+  const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+  const float tsx = float(tex.width), tsy = float(tex.height);
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    o.u[n] = ((sr.z - sr.x) * ax + sr.x) / tsx; o.v[n] = ((sr.w - sr.y) * ay + sr.y) / tsy;
+    const float x = (dr.z - dr.x) * ax + dr.x, y = (dr.w - dr.y) * ay + dr.y;
+    o.px[n] = x / (ds.x * 0.5f) - 1.0f; o.py[n] = y / (ds.y * 0.5f) - 1.0f; o.pz[n] = 0.0f; o.pw[n] = 1.0f;
+  }
+  o.uv_bounds = wf4{0.f, 0.f, 1.f, 1.f};
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.tail_clamp = 0; o.tail_modulate = 0;
+  const bool one_to_one = (sr.z - sr.x) == (dr.z - dr.x) && (sr.w - sr.y) == (dr.w - dr.y) && sr.x == floorf(sr.x) && sr.y == floorf(sr.y) &&
+                          dr.x == floorf(dr.x) && dr.y == floorf(dr.y) && (sr.z - sr.x) == floorf(sr.z - sr.x) && (sr.w - sr.y) == floorf(sr.w - sr.y);
+  o.kind = (one_to_one && tex.ptr) ? WR_PK_TEX_FS : WR_PK_UNSUPPORTED;
+}
+
 // cs_border_solid.glsl:84-128 (vertex stage).  No span function: every pixel runs main() (wr_border_solid_pixel).
 WR_DEVICE void wr_vs_cs_border_solid(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrBorderRec& B) {
   const wf2 origin = wr_load_attr<wf2>(d, arena, inst, 0);
@@ -2876,6 +2903,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_CLIP_RECT_FAST: wr_vs_cs_clip_rect(d, arena, inst, true, o, aux[gid].clip); break;
     case WR_SH_CS_CLIP_BOX_SHADOW: wr_vs_cs_clip_box_shadow(d, arena, inst, o, aux[gid].box); break;
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
+    case WR_SH_PS_COPY: wr_vs_ps_copy(d, arena, inst, o); break;
     case WR_SH_CS_BORDER_SOLID: wr_vs_cs_border_solid(d, arena, inst, o, aux[gid].border); break;
     case WR_SH_CS_BORDER_SEGMENT: wr_vs_cs_border_segment(d, arena, inst, o, aux[gid].bseg); break;
     case WR_SH_CS_FAST_LINEAR_GRADIENT: wr_vs_cs_fast_linear_gradient(d, arena, inst, o, aux[gid].fgrad); break;
@@ -3093,6 +3121,33 @@ WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
   rv.s[3] = (R3 - L3) * stepScale; rv.o[3] = L3 + rv.s[3] * start;
   return rv;
 }
+
+#ifndef WRHIP_HOSTSIM
+// The same for a row the whole wave works on (wr_mask_rows_body: y is wave-uniform): the eight sums -- each a walk over the
+// binades its running sum passes through when the closed form does not apply, ~5 k cycles -- are taken by eight lanes at once
+// instead of one after the other on values every lane holds (measured: 38 k of a box-shadow row's 118 k cycles, cfg4).
+WR_DEVICE WrRowVals wr_box_row_vals_wave(const WrPrim& P, const WrBoxRec& B, int y, int lane) {
+  WrRowVals rv;
+  const int k = y - P.y0;
+  const bool lin = P.rows_linear != 0;
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  const int i = lane & 7;
+  const float s0 = i == 0 ? P.uvL0[0] : i == 1 ? P.uvL0[1] : i == 2 ? P.uvR0[0] : i == 3 ? P.uvR0[1] : i == 4 ? B.lpL0[0] : i == 5 ? B.lpL0[1] : i == 6 ? B.lpR0[0] : B.lpR0[1];
+  const float st = i == 0 ? P.uvLs[0] : i == 1 ? P.uvLs[1] : i == 2 ? P.uvRs[0] : i == 3 ? P.uvRs[1] : i == 4 ? B.lpLs[0] : i == 5 ? B.lpLs[1] : i == 6 ? B.lpRs[0] : B.lpRs[1];
+  const float r = wr_row_interp(s0, st, k, lin && i < 4);
+  const float L0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)), L1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 1));
+  const float R0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 2)), R1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 3));
+  const float L2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 4)), L3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 5));
+  const float R2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 6)), R3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 7));
+  rv.s[0] = (R0 - L0) * stepScale; rv.o[0] = L0 + rv.s[0] * start;
+  rv.s[1] = (R1 - L1) * stepScale; rv.o[1] = L1 + rv.s[1] * start;
+  rv.s[2] = (R2 - L2) * stepScale; rv.o[2] = L2 + rv.s[2] * start;
+  rv.s[3] = (R3 - L3) * stepScale; rv.o[3] = L3 + rv.s[3] * start;
+  return rv;
+}
+#endif
 
 // Span-level setup of a cs_clip_box_shadow row (cs_clip_box_shadow.glsl:150-250): where the shadow rect and the four
 // nine-patch sector boundaries fall along the row, as remaining span lengths.  Prim and row only: evaluated by the
@@ -4599,6 +4654,27 @@ WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y) {
   rv.s[2] = rv.s[3] = rv.o[2] = rv.o[3] = 0.0f;
   return rv;
 }
+#ifndef WRHIP_HOSTSIM
+// (a row the whole wave works on: the four sums on four lanes at once, see wr_box_row_vals_wave)
+WR_DEVICE WrRowVals wr_clip_row_vals_wave(const WrPrim& P, int y, int lane) {
+  WrRowVals rv;
+  const int k = y - P.y0;
+  const bool lin = P.rows_linear != 0;
+  const int i = lane & 3;
+  const float s0 = i == 0 ? P.uvL0[0] : i == 1 ? P.uvL0[1] : i == 2 ? P.uvR0[0] : P.uvR0[1];
+  const float st = i == 0 ? P.uvLs[0] : i == 1 ? P.uvLs[1] : i == 2 ? P.uvRs[0] : P.uvRs[1];
+  const float r = wr_row_interp(s0, st, k, lin);
+  const float Lu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)), Lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 1));
+  const float Ru = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 2)), Rv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 3));
+  float stepScale = 1.0f / (P.xr - P.xl);
+  if (!wr_isfinite(stepScale)) stepScale = 0.0f;
+  const float start = float(P.x0) + 0.5f - P.xl;
+  rv.s[0] = (Ru - Lu) * stepScale; rv.s[1] = (Rv - Lv) * stepScale;
+  rv.o[0] = Lu + rv.s[0] * start; rv.o[1] = Lv + rv.s[1] * start;
+  rv.s[2] = rv.s[3] = rv.o[2] = rv.o[3] = 0.0f;
+  return rv;
+}
+#endif
 
 // Span-level setup of a cs_clip_rectangle row (cs_clip_rectangle.glsl:223-420): the lengths, in 4-pixel chunks, of the
 // five phases [clear n1][AA n2][opaque n3][AA n4][clear ...] and the corners the two AA phases belong to.  It depends on
@@ -5136,7 +5212,11 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const
 WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int y, int lane, uint8_t* dst, int part = 0, int parts = 1) {
   const int wl = lane + 64 * part, ws = 64 * parts;
   const WrPrim& P = *Pp;
+#ifdef WRHIP_HOSTSIM
   const WrRowVals rv = wr_clip_row_vals(P, y);
+#else
+  const WrRowVals rv = wr_clip_row_vals_wave(P, y, lane);      // (y is wave-uniform here)
+#endif
   const WrClipRow cr = wr_clip_row_setup(P, *Cp, rv);
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0, S = span >> 2;
   const int n2 = cr.n12 >> 16, n4 = cr.n34 >> 16;
@@ -5162,6 +5242,12 @@ WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int
     dst[n] = (uint8_t)wr_clip_rect_px(P, *Cp, rv, cr, n);
   }
 }
+#if defined(WR_ROWS_TIMING) && !defined(WRHIP_HOSTSIM)
+__device__ unsigned long long wr_rows_times[4096 * 8];      // debug build: phase timestamps of the first item of the launch's first 4096 waves
+#define WR_RT(i) do { if (lane == 0 && gw < 4096 && item == gw) wr_rows_times[gw * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WR_RT(i) ((void)0)
+#endif
 WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                                  const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
                                  unsigned long long* __restrict__ ctl,
@@ -5184,6 +5270,7 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
   for (int item = gw; item < rows_total; item += nwaves) {
     WrMaskSlot sl;
     int si;
+    WR_RT(0);
 #ifndef WRHIP_HOSTSIM
     const unsigned long long le = __ballot(lane < ns && (int)mine.row0 <= item);
     if (ns <= 64 || !(le >> 63)) {
@@ -5204,12 +5291,14 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
       sl = slots[lo];
       si = lo;
     }
+    WR_RT(1);
     const WrTargetDesc& T = targets[sl.target];
     if (T.first_bin < bin_lo || T.first_bin >= bin_hi) continue;
     const WrPrim* Pp = &prims[sl.prim];
     const int parts = (int)sl.pad[0], idx = item - (int)sl.row0;
     const int y = Pp->y0 + idx / parts, part = idx % parts;
     if (y < T.y_begin || y >= T.y_end) continue;      // rows of another rank
+    WR_RT(2);
     const int nrows = Pp->y1 - Pp->y0;
     const uint32_t rows_at = uint32_t((nrows * 4 + 15) & ~15);                     // the pixel rows follow the row map
     uint8_t* pbase = store + (size_t)sl.off16 * 16;
@@ -5220,8 +5309,14 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
       // the rows of a nine-patch's middle band are identical: a row whose key equals the key of the prim's middle row (left
       // in the slot by the setup stage) points at that row's bytes instead of being evaluated (wr_box_row_key)
       const int yc = Pp->y0 + (nrows >> 1);
+#ifdef WRHIP_HOSTSIM
       brv = wr_box_row_vals(*Pp, aux[sl.prim].box, y);
+#else
+      brv = wr_box_row_vals_wave(*Pp, aux[sl.prim].box, y, lane);
+#endif
+      WR_RT(3);
       bbr = wr_box_row_setup(*Pp, aux[sl.prim].box, brv);
+      WR_RT(4);
       if (y != yc && wr_box_keys_equal(wr_box_row_key(*Pp, aux[sl.prim].box, brv, bbr), slots[si].key)) {
         if (lane == 0 && part == 0) ((uint32_t*)pbase)[y - Pp->y0] = rows_at + uint32_t(yc - Pp->y0) * sl.pitch;
         continue;
@@ -5229,11 +5324,19 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
     }
     if (lane == 0 && part == 0) {
       ((uint32_t*)pbase)[y - Pp->y0] = my_off;
-      atomicAdd(&ctl[1], (unsigned long long)(Pp->x1 - Pp->x0));     // bytes evaluated (profiling: the launch's algorithmic bytes)
+      // bytes evaluated (profiling: the launch's algorithmic bytes), over 32 counters: one word took an atomic from every
+      // evaluated row, and a few thousand read-modify-writes of one address are tens of microseconds the launch ends on
+      atomicAdd(&ctl[32 + (gw & 31)], (unsigned long long)(Pp->x1 - Pp->x0));
     }
     uint8_t* dst = pbase + my_off + (Pp->x0 & 3);
+    WR_RT(5);
     if (Pp->kind == WR_PK_BOX_SHADOW) wr_box_shadow_row_lanes(*Pp, aux[sl.prim].box, brv, bbr, lane, dst, part, parts);
     else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst, part, parts);
+    WR_RT(6);
+#if defined(WR_ROWS_TIMING) && !defined(WRHIP_HOSTSIM)
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0 && gw < 4096 && item == gw) wr_rows_times[gw * 8 + 7] = ((unsigned long long)(Pp->kind == WR_PK_BOX_SHADOW ? 1 : 0) << 56) | ((unsigned long long)(uint32_t)y << 32) | (uint32_t)(__builtin_readcyclecounter() & 0xFFFFFFFFu);
+#endif
   }
 }
 __global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,

@@ -71,6 +71,7 @@ enum WrShader {
   WR_SH_CS_CONIC_GRADIENT,
   WR_SH_PS_QUAD_RADIAL_GRADIENT,
   WR_SH_PS_QUAD_CONIC_GRADIENT,
+  WR_SH_PS_COPY,                   // texture-cache copies, batched uploads (renderer/mod.rs:1808-1846, upload.rs:540-620)
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };

@@ -98,6 +98,8 @@ DESC = {
         ("aUvRect2", 4, F32), ("aFlip", 2, F32)]),
     # vertex.rs:782-802
     "CLEAR": VertexDescriptor(_POS, [("aRect", 4, F32), ("aColor", 4, F32)]),
+    # vertex.rs:802-826 (CopyInstance, gpu_types.rs:169-175)
+    "COPY": VertexDescriptor(_POS, [("a_src_rect", 4, F32), ("a_dst_rect", 4, F32), ("a_dst_texture_size", 2, F32)]),
     # vertex.rs:633-650 (MaskInstance, gpu_types.rs:618-624)
     "MASK": VertexDescriptor(_POS, [("aData", 4, I32), ("aClipData", 4, I32)]),
 }

@@ -1070,6 +1070,57 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
     return frame
 
 
+# ps_copy: texture-cache copies (the cache grows or is defragmented: renderer/mod.rs:1808-1846) and batched uploads (small
+# uploads are packed into a staging texture and blitted into place: renderer/upload.rs:540-620).  One CopyInstance per rect
+# (gpu_types.rs:169-175): source rect in source texels, destination rect in destination texels, both of one size.
+COPY_DTYPE = np.dtype([("src", "<f4", (4,)), ("dst", "<f4", (4,)), ("size", "<f4", (2,))])
+
+
+def texture_cache_copies(n=60, seed=191, src_size=512, dst_size=768, chained=True):
+    """`n` copies out of an RGBA8 and an R8 source atlas into cache textures of another size (later copies overwrite earlier
+    ones where they overlap); `chained`: a second pass copies out of the first pass' destination (a cache texture that is
+    defragmented right after it was filled)."""
+    rng = np.random.default_rng(seed)
+    frame = Frame(64, 64, (1.0, 1.0, 1.0, 1.0))
+    rgba = rng.integers(0, 256, size=(src_size, src_size, 4), dtype=np.uint8)
+    r8 = rng.integers(0, 256, size=(src_size, src_size), dtype=np.uint8)
+    t_src = TextureRef("copy_src_rgba", src_size, src_size, G.GL_RGBA8, G.GL_LINEAR, pixels=rgba)
+    t_src8 = TextureRef("copy_src_r8", src_size, src_size, G.GL_R8, G.GL_LINEAR, pixels=r8)
+    frame.static_textures += [t_src, t_src8]
+
+    def copies(src_w, dst_w, k, seed_):
+        r = np.random.default_rng(seed_)
+        inst = np.zeros(k, COPY_DTYPE)
+        for i in range(k):
+            w, h = int(r.integers(1, 200)), int(r.integers(1, 120))
+            if i % 7 == 0:
+                w, h = int(r.integers(1, 4)), int(r.integers(1, 4))            # glyph-sized
+            sx, sy = int(r.integers(0, src_w - w + 1)), int(r.integers(0, src_w - h + 1))
+            dx, dy = int(r.integers(0, dst_w - w + 1)), int(r.integers(0, dst_w - h + 1))
+            inst["src"][i] = (sx, sy, sx + w, sy + h)
+            inst["dst"][i] = (dx, dy, dx + w, dy + h)
+            inst["size"][i] = (dst_w, dst_w)
+        return inst
+    passes, out = [], []
+    for name, src, fmt in (("rgba", t_src, G.GL_RGBA8), ("r8", t_src8, G.GL_R8)):
+        t_dst = TextureRef(f"copy_dst_{name}", dst_size, dst_size, fmt, G.GL_LINEAR, render_target=True)
+        tg = Target(t_dst, "texture_cache", clear_color=(0.0, 0.0, 0.0, 0.0))
+        tg.steps.append(Step("ps_copy", "COPY", copies(src_size, dst_size, n, seed + len(out)), None, "none", textures={0: src}))
+        passes.append(tg)
+        out.append(t_dst)
+        if chained:
+            t_dst2 = TextureRef(f"copy_dst2_{name}", src_size, src_size, fmt, G.GL_LINEAR, render_target=True)
+            tg2 = Target(t_dst2, "texture_cache", clear_color=(0.0, 0.0, 0.0, 0.0))
+            tg2.steps.append(Step("ps_copy", "COPY", copies(dst_size, src_size, n // 2, seed + 7 + len(out)), None, "none", textures={0: t_dst}))
+            passes.append(tg2)
+            out.append(t_dst2)
+    frame.passes.append([t for t in passes if "dst2" not in t.texture.name])
+    if chained:
+        frame.passes.append([t for t in passes if "dst2" in t.texture.name])
+    frame.readback = out
+    return frame
+
+
 SCENES = {
     "cfg1": cfg1_solid_colors,
     "simple_batching": simple_batching,
