@@ -786,3 +786,108 @@ def composite_window(frame, tiles, clear=(0, 0, 0, 0)):
         x1, y1 = min(x1, frame.width), min(y1, frame.height)
         img[y0:y1, x0:x1] = tiles[ct.texture.name][y0 - ry0:y1 - ry0, x0 - rx0:x1 - rx0]
     return img[::-1].copy()
+
+
+# ---------------------------------------------------------------------------
+# brush_mix_blend (brush_mix_blend.glsl:88-330): an independent float32 restatement of the blend functions for 1:1 sampled
+# swatches (scenes.mix_blend_swatches), and the premultiplied-alpha blend over the opaque white clear.  Written from the GLSL
+# with np.where for its scalar branches; pins the hand-written shader header.
+def _lum(c):
+    return (c[..., 0] * F(0.3) + c[..., 1] * F(0.59)) + c[..., 2] * F(0.11)
+
+
+def _clip_color(C):
+    L = _lum(C)[..., None]
+    n = np.min(C, axis=-1, keepdims=True)
+    x = np.max(C, axis=-1, keepdims=True)
+    with np.errstate(all="ignore"):
+        C = np.where(n < 0, L + (((C - L) * L) / (L - n)), C).astype(np.float32)
+        C = np.where(x > 1, L + (((C - L) * (F(1.0) - L)) / (x - L)), C).astype(np.float32)
+    return C
+
+
+def _set_lum(C, l):
+    d = l - _lum(C)
+    return _clip_color((C + d[..., None]).astype(np.float32))
+
+
+def _sat(c):
+    return np.max(c, axis=-1) - np.min(c, axis=-1)
+
+
+def _set_sat(C, s):
+    """SetSat: the channel order decides which channel is min / mid / max (ties as the GLSL's <= chain resolves them)"""
+    r, g, b = C[..., 0], C[..., 1], C[..., 2]
+    out = np.zeros_like(C)
+    rg, gb, rb = r <= g, g <= b, r <= b
+    cases = [(rg & gb, (0, 1, 2)), (rg & ~gb & rb, (0, 2, 1)), (rg & ~gb & ~rb, (2, 0, 1)),
+             (~rg & rb, (1, 0, 2)), (~rg & ~rb & gb, (1, 2, 0)), (~rg & ~rb & ~gb, (2, 1, 0))]
+    for m, (imin, imid, imax) in cases:
+        cmin, cmid, cmax = C[..., imin], C[..., imid], C[..., imax]
+        gt = cmax > cmin
+        with np.errstate(all="ignore"):
+            mid = np.where(gt, ((cmid - cmin) * s) / (cmax - cmin), F(0.0)).astype(np.float32)
+        mx = np.where(gt, s, F(0.0)).astype(np.float32)
+        for idx, val in ((imin, np.zeros_like(mid)), (imid, mid), (imax, mx)):
+            out[..., idx] = np.where(m, val, out[..., idx])
+    return out
+
+
+def mix_blend_swatch(backdrop, source, mode):
+    """backdrop, source: premultiplied RGBA u8 [h, w, 4] -> RGBA u8 of the mix-blended swatch over opaque white"""
+    Cb4 = backdrop.astype(np.float32) * F(1.0 / 255.0)
+    Cs4 = source.astype(np.float32) * F(1.0 / 255.0)
+    ab, as_ = Cb4[..., 3:4], Cs4[..., 3:4]
+    with np.errstate(all="ignore"):
+        Cb = np.where(ab != 0, Cb4[..., :3] / ab, Cb4[..., :3]).astype(np.float32)
+        Cs = np.where(as_ != 0, Cs4[..., :3] / as_, Cs4[..., :3]).astype(np.float32)
+
+    def hard_light(cb, cs):
+        m = cb * (F(2.0) * cs)
+        t = F(2.0) * cs - F(1.0)
+        sc = cb + t - (cb * t)
+        st = (cs >= F(0.5)).astype(np.float32)
+        return ((sc - m) * st + m).astype(np.float32)
+    res = np.empty_like(Cb)
+    res[..., 0] = 1.0; res[..., 1] = 1.0; res[..., 2] = 0.0
+    with np.errstate(all="ignore"):
+        if mode == 1:
+            res = Cb * Cs
+        elif mode == 3:
+            res = hard_light(Cs, Cb)
+        elif mode == 4:
+            res = np.minimum(Cs, Cb)
+        elif mode == 5:
+            res = np.maximum(Cs, Cb)
+        elif mode == 6:
+            res = np.where(Cb == 0, F(0.0), np.where(Cs == 1, F(1.0), np.minimum(F(1.0), Cb / (F(1.0) - Cs))))
+        elif mode == 7:
+            res = np.where(Cb == 1, F(1.0), np.where(Cs == 0, F(0.0), F(1.0) - np.minimum(F(1.0), (F(1.0) - Cb) / Cs)))
+        elif mode == 8:
+            res = hard_light(Cb, Cs)
+        elif mode == 9:
+            lo = Cb - (F(1.0) - F(2.0) * Cs) * Cb * (F(1.0) - Cb)
+            D = np.where(Cb <= F(0.25), ((F(16.0) * Cb - F(12.0)) * Cb + F(4.0)) * Cb, np.sqrt(Cb)).astype(np.float32)
+            hi = Cb + (F(2.0) * Cs - F(1.0)) * (D - Cb)
+            res = np.where(Cs <= F(0.5), lo, hi)
+        elif mode == 10:
+            res = np.abs(Cb - Cs)
+        elif mode == 12:
+            res = _set_lum(_set_sat(Cs, _sat(Cb)), _lum(Cb))
+        elif mode == 13:
+            res = _set_lum(_set_sat(Cb, _sat(Cs)), _lum(Cb))
+        elif mode == 14:
+            res = _set_lum(Cs, _lum(Cb))
+        elif mode == 15:
+            res = _set_lum(Cb, _lum(Cs))
+    res = res.astype(np.float32)
+    rgb = ((F(1.0) - ab) * Cs + ab * res).astype(np.float32)
+    rgb = (rgb * as_).astype(np.float32)
+    frag = np.concatenate([rgb, as_], axis=-1)
+    with np.errstate(all="ignore"):
+        src = (frag * F(255.0) + F(0.5)).astype(np.int64)            # round_pixel (portable): cast(v * 255 + 0.5), wrapping to u16
+    src &= 0xFFFF
+    dst = np.full_like(src, 255)
+    a = src[..., 3:4]
+    out = (src + dst - ((dst * a + dst) >> 8)) & 0xFFFF               # blend.h:473-474 on u16 lanes, then pack (saturating)
+    return np.clip(out, 0, 255).astype(np.uint8)

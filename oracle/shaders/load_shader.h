@@ -28,6 +28,7 @@
 #include "ps_quad_radial_gradient.h"
 #include "ps_quad_conic_gradient.h"
 #include "ps_copy.h"
+#include "brush_mix_blend.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -57,6 +58,8 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("brush_linear_gradient ALPHA_PASS", brush_linear_gradient_ALPHA_PASS)
   WRSH_ENTRY("brush_blend", brush_blend)
   WRSH_ENTRY("brush_blend ALPHA_PASS", brush_blend_ALPHA_PASS)
+  WRSH_ENTRY("brush_mix_blend", brush_mix_blend)
+  WRSH_ENTRY("brush_mix_blend ALPHA_PASS", brush_mix_blend_ALPHA_PASS)
   WRSH_ENTRY("brush_opacity", brush_opacity)
   WRSH_ENTRY("brush_opacity ALPHA_PASS", brush_opacity_ALPHA_PASS)
   WRSH_ENTRY("brush_opacity ANTIALIASING", brush_opacity_ANTIALIASING)

@@ -193,3 +193,14 @@ def copies_expected(frame):
                 dst[dy0:dy1, dx0:dx1] = src[sy0:sy1, sx0:sx1]
             tex[ref.name] = dst
     return {t.name: tex[t.name] for t in frame.readback}
+
+
+# brush_mix_blend: the sixteen MixBlendMode values on backdrop / source picture pairs -- 1:1 swatches,
+# scaled and fractionally placed prims with linear and nearest sources, sub-quads in homogeneous coordinates, clip masks
+MIX_BLEND = [
+    ("mix_swatches", "mix_blend_swatches", dict()),
+    ("mix_grid", "mix_blend_grid", dict()),
+    ("mix_grid_nearest_src", "mix_blend_grid", dict(seed=204, n=60)),
+    ("mix_grid_masked", "mix_blend_grid", dict(seed=205, masked=True)),
+    ("mix_grid_integer", "mix_blend_grid", dict(seed=207, fractional=False, n=50)),
+]

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -449,3 +449,28 @@ def test_hip_texture_cache_copies(name, kw):
         sw, _ = render_direct(ref, scenes.texture_cache_copies(**kw))
         for k, v in want.items():
             assert np.array_equal(sw[k], v), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scene,kw", MIX_BLEND, ids=[c[0] for c in MIX_BLEND])
+def test_hip_mix_blend_matches_oracle(name, scene, kw):
+    """brush_mix_blend on the MI355X: +-1 LSB allowed where the device's sqrt / division enter (soft light, the
+    non-separable modes); the swatches are also held to the numpy model of the GLSL."""
+    got, st = render_direct(wrhip_lib(), getattr(scenes, scene)(**kw))
+    assert st["gl_error"] == 0 and (got != 255).any()
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, getattr(scenes, scene)(**kw))
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).sum() <= 1e-4 * d.size, (int(d.max()), int((d > 0).sum()))
+    if scene == "mix_blend_swatches":
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import np_model
+        fr = scenes.mix_blend_swatches()
+        H = got.shape[0]
+        for (x, y, ib, isrc, mode) in fr.swatches:
+            h, w = ib.shape[:2]
+            want = np_model.mix_blend_swatch(ib[..., [2, 1, 0, 3]], isrc[..., [2, 1, 0, 3]], mode)
+            d = np.abs(want.astype(int) - got[H - y - h:H - y][::-1, x:x + w].astype(int))
+            assert d.max() <= 1, (mode, int(d.max()))

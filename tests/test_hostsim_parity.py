@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -407,3 +407,13 @@ def test_hostsim_texture_cache_copies(hostsim, oracle_gcc, name, kw):
     assert st["gl_error"] == 0
     for k, v in want.items():
         assert v.any() and np.array_equal(got[k], v) and np.array_equal(ref[k], v), k
+
+
+@pytest.mark.parametrize("name,scene,kw", MIX_BLEND, ids=[c[0] for c in MIX_BLEND])
+def test_hostsim_mix_blend_matches_oracle(hostsim, oracle_gcc, name, scene, kw):
+    """brush_mix_blend: 0 differing bytes against swgl with the hand-written header (itself pinned by the numpy model of the
+    blend functions, tests/test_oracle.py)"""
+    want, _ = render_direct(oracle_gcc, getattr(scenes, scene)(**kw))
+    got, st = render_direct(hostsim, getattr(scenes, scene)(**kw))
+    assert st["gl_error"] == 0 and (want != 255).any()
+    assert np.array_equal(got, want)

@@ -293,3 +293,26 @@ def test_oracle_linear_gradients_match_numpy_model(oracle_gcc):
     assert dm.mean() < 0.35 and (got != 255).any()
     assert d.max() <= 2 and (d > 1).sum() <= 1e-4 * n and (d > 0).sum() <= 0.02 * n, \
         (int(d.max()), int((d > 1).sum()), int((d > 0).sum()), n)
+
+
+def check_mix_swatches(px, fr):
+    H = px.shape[0]
+    worst = 0
+    for (x, y, ib, isrc, mode) in fr.swatches:
+        h, w = ib.shape[:2]
+        want = np_model.mix_blend_swatch(ib[..., [2, 1, 0, 3]], isrc[..., [2, 1, 0, 3]], mode)      # atlas bytes are BGRA
+        got = px[H - y - h:H - y][::-1, x:x + w]                                                   # the window is bottom-up
+        d = np.abs(want.astype(int) - got.astype(int)).max()
+        assert d <= 0, f"mix-blend mode {mode}: max diff {d}"
+        worst = max(worst, d)
+    return worst
+
+
+def test_brush_mix_blend_oracle_matches_numpy_model(oracle_gcc):
+    """The hand-written brush_mix_blend shader header against an independent numpy float32 restatement of the GLSL's blend
+    functions (oracle/np_model.py mix_blend_swatch): 48 swatches, three per MixBlendMode 1..16 -- multiply, overlay, darken,
+    lighten, colour dodge / burn, hard / soft light, difference, hue, saturation, colour, luminosity, and the three modes the
+    shader leaves yellow -- with opaque, translucent and alpha == 0 backdrops and sources."""
+    fr = scenes.mix_blend_swatches()
+    px, _ = render_direct(oracle_gcc, fr)
+    check_mix_swatches(px, fr)

@@ -35,9 +35,11 @@ struct CopyPool {
   int n = 0;
   std::mutex m;
   std::condition_variable cv;
-  const std::function<void(int, int)>* job = nullptr;
-  uint64_t gen = 0;
-  std::atomic<int> left{0};
+  std::atomic<const std::function<void(int, int)>*> job{nullptr};
+  std::atomic<uint64_t> gen{0};
+  std::atomic<int> left{0}, parts{1}, sleepers{0};
+  int spin_iters = 0;          // how long a helper polls for the next job before it blocks: while frames stream (an upload every
+                               // few microseconds) the helpers stay awake and a hand-over costs a cache line, not a futex wake
   static std::atomic<bool>& forked() { static std::atomic<bool> f{false}; return f; }
   CopyPool() {
     // a fork()ed child inherits this object but not the helper threads: it copies on its own
@@ -47,34 +49,56 @@ struct CopyPool {
     const unsigned hc = std::thread::hardware_concurrency();
     if (hc && (int)hc - 1 < want) want = (int)hc - 1;
     n = want > 0 ? want : 0;
+    const char* sp = getenv("WRHIP_COPY_SPIN_US");
+    spin_iters = (sp ? atoi(sp) : 120) * 25;         // (a pause is ~40 ns)
     for (int i = 0; i < n; i++) std::thread([this, i] { worker(i + 1); }).detach();
   }
   void worker(int part) {
     uint64_t seen = 0;
     for (;;) {
-      const std::function<void(int, int)>* j;
-      {
+      int spins = 0;
+      auto posted = [&] { const uint64_t g = gen.load(std::memory_order_seq_cst); return g != seen && !(g & 1); };
+      while (!posted()) {
+        if (++spins < spin_iters) { __builtin_ia32_pause(); continue; }
         std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return gen != seen; });
-        seen = gen; j = job;
+        sleepers.fetch_add(1, std::memory_order_seq_cst);
+        cv.wait(lk, posted);
+        sleepers.fetch_sub(1, std::memory_order_relaxed);
       }
-      (*j)(part, n + 1);
-      left.fetch_sub(1, std::memory_order_release);
+      // (only the helpers that take a part are waited for: one that sleeps through a two-part copy costs the caller nothing;
+      // the job a helper reads must be the one of the generation it saw -- a bystander may look up while the next job is
+      // being posted)
+      uint64_t g; int np; const std::function<void(int, int)>* j;
+      do {
+        g = gen.load(std::memory_order_seq_cst);
+        np = parts.load(std::memory_order_seq_cst); j = job.load(std::memory_order_seq_cst);
+      } while ((g & 1) || gen.load(std::memory_order_seq_cst) != g);
+      if (g == seen) continue;
+      seen = g;
+      if (part < np) { (*j)(part, np); left.fetch_sub(1, std::memory_order_release); }
     }
   }
-  void run(const std::function<void(int, int)>& f) {
+  // f(part, parts) once per part, part 0 on the calling thread; `max_parts` bounds the fan-out of small copies
+  void run(const std::function<void(int, int)>& f, int max_parts = 1 << 20) {
     if (!n || forked().load(std::memory_order_relaxed)) { f(0, 1); return; }
-    {
-      std::lock_guard<std::mutex> lk(m);
-      job = &f; left.store(n, std::memory_order_relaxed); gen++;
-    }
-    cv.notify_all();
-    f(0, n + 1);
-    while (left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    const int np = std::min(n + 1, std::max(1, max_parts));
+    if (np == 1) { f(0, 1); return; }
+    // (a sequence lock: the generation is odd while the job is being written; helpers act on an even generation whose fields
+    // they read between two equal looks at it)
+    gen.fetch_add(1, std::memory_order_seq_cst);
+    job.store(&f, std::memory_order_seq_cst);
+    parts.store(np, std::memory_order_seq_cst);
+    left.store(np - 1, std::memory_order_seq_cst);
+    gen.fetch_add(1, std::memory_order_seq_cst);
+    if (sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
+    f(0, np);
+    while (left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
   }
 };
 CopyPool& copy_pool() { static CopyPool* p = new CopyPool(); return *p; }     // (never destroyed: the helpers outlive static destruction)
 constexpr size_t PARALLEL_COPY_MIN = 1u << 20;
+// (texture uploads: from this size on, two parts -- the caller and one helper --, all helpers from PARALLEL_COPY_MIN on)
+static size_t split_copy_min() { static const size_t v = getenv("WRHIP_COPY_SPLIT_MIN") ? (size_t)atoll(getenv("WRHIP_COPY_SPLIT_MIN")) : ((size_t)96 << 10); return v; }
 // Copy into the pinned staging ring with non-temporal stores: the ring is 96 MiB of memory the CPU never reads back (the
 // DMA engine does), so ordinary stores first fetch every destination line (read-for-ownership) and then evict useful
 // lines to keep it.  Streaming stores do neither; small copies keep memcpy.
@@ -260,6 +284,8 @@ const ShaderInfo SHADERS[] = {
     {"brush_opacity ALPHA_PASS,ANTIALIASING", WR_SH_BRUSH_OPACITY_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_blend", WR_SH_BRUSH_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_blend ALPHA_PASS", WR_SH_BRUSH_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_mix_blend", WR_SH_BRUSH_MIX_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1)},
+    {"brush_mix_blend ALPHA_PASS", WR_SH_BRUSH_MIX_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1)},
     {"composite TEXTURE_2D", WR_SH_COMPOSITE,
      {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
@@ -1567,6 +1593,7 @@ void flush_work(const std::vector<int>& sel_in) {
             f = ((draws[i].flags & WR_DF_MASK_ROWS) && mr_safe) ? WR_FEAT_BLUR : WR_FEAT_CLIP; break;
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: case WR_SH_CS_LINEAR_GRADIENT: case WR_SH_CS_RADIAL_GRADIENT: case WR_SH_CS_CONIC_GRADIENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_MIX_BLEND: case WR_SH_BRUSH_MIX_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: case WR_SH_PS_QUAD_RADIAL_GRADIENT: case WR_SH_PS_QUAD_CONIC_GRADIENT:
             f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: case WR_SH_CS_FAST_LINEAR_GRADIENT: case WR_SH_CS_LINE_DECORATION:
@@ -1924,6 +1951,7 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
     if (h || g) id_flags.fetch_or((h ? 1 : 0) | (g ? 2 : 0), std::memory_order_relaxed);
   };
   if (row * (size_t)height >= PARALLEL_COPY_MIN && height >= 8) copy_pool().run(copy_rows);
+  else if (row * (size_t)height >= split_copy_min() && height >= 4) copy_pool().run(copy_rows, 2);
   else copy_rows(0, 1);
   if (ids) {
     if (xoffset == 0 && yoffset == 0) t.complex_ids_headers = t.complex_ids_gpubuf = false;   // (uploads start at the origin: a fresh frame)

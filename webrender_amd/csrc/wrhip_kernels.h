@@ -526,7 +526,7 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 // image: 0 brush_solid, 1 / 2 brush_image (opaque / ALPHA_PASS), 3 linear gradient, 4 brush_blend,
 //        5 / 6 brush_image with REPETITION (opaque / ALPHA_PASS; Rp = its side record)
 WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr,
-                            WrFilterRec* F = nullptr, WrRepeatRec* Rp = nullptr) {
+                            WrFilterRec* F = nullptr, WrRepeatRec* Rp = nullptr, WrMixRec* Mx = nullptr) {
   const bool repetition = image == 5 || image == 6;
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
@@ -664,6 +664,41 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.has_color = 1; o.tail_clamp = 1; o.tail_modulate = 1;
     o.kind = tex.format == WR_FMT_RGBA8 ? WR_PK_TEX_RGBA8 : WR_PK_UNSUPPORTED;
     if (brush_flags & 1) o.kind = WR_PK_UNSUPPORTED;      // perspective interpolation: next
+    return;
+  }
+  if (image == 8) {
+    // brush_vs + get_uv (brush_mix_blend.glsl:26-84): the backdrop's uv (sColor0) in o.u / o.v, the source's (sColor1) in o.u2 / o.v2
+    const float persp = (brush_flags & 1) ? 1.0f : 0.0f;
+    for (int pass = 0; pass < 2; pass++) {
+      const int res_address = pass == 0 ? data1.y : data1.z;
+      const int sau = int(unsigned(res_address) % 1024u), sav = int(unsigned(res_address) / 1024u);
+      const wf4 res0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], sau, sav);
+      const int qa = res_address + 2;
+      const int qu = int(unsigned(qa) % 1024u), qv = int(unsigned(qa) / 1024u);
+      const wf4 st_tl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu, qv), st_tr = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 1, qv);
+      const wf4 st_bl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 2, qv), st_br = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 3, qv);
+      const WrTexDesc& tex = d.tex[pass == 0 ? WR_S_COLOR0 : WR_S_COLOR1];
+      const float itx = 1.0f / float(tex.ptr ? tex.width : 1), ity = 1.0f / float(tex.ptr ? tex.height : 1);
+      for (int n = 0; n < 4; n++) {
+        float fx = (vlx[n] - local_rect.x) / (local_rect.z - local_rect.x), fy = (vly[n] - local_rect.y) / (local_rect.w - local_rect.y);
+        const float xx = (st_tr.x - st_tl.x) * fx + st_tl.x, xy = (st_tr.y - st_tl.y) * fx + st_tl.y, xw = (st_tr.w - st_tl.w) * fx + st_tl.w;
+        const float yx = (st_br.x - st_bl.x) * fx + st_bl.x, yy = (st_br.y - st_bl.y) * fx + st_bl.y, yw = (st_br.w - st_bl.w) * fx + st_bl.w;
+        const float zx = (yx - xx) * fy + xx, zy = (yy - xy) * fy + xy, zw = (yw - xw) * fy + xw;
+        fx = zx / zw; fy = zy / zw;
+        const float uu = (res0.z - res0.x) * fx + res0.x, vv = (res0.w - res0.y) * fy + res0.y;
+        const float pm = pass == 0 ? 1.0f : (1.0f - vww[n]) * persp + vww[n];       // get_uv(.., 1.0, ..) for the backdrop
+        if (pass == 0) { o.u[n] = uu * itx * pm; o.v[n] = vv * ity * pm; }
+        else { o.u2[n] = uu * itx * pm; o.v2[n] = vv * ity * pm; }
+      }
+      const wf4 bounds = wf4{(res0.x + 0.5f) * itx, (res0.y + 0.5f) * ity, (res0.z - 0.5f) * itx, (res0.w - 0.5f) * ity};
+      if (pass == 0) o.uv_bounds = bounds;
+      else { Mx->s_bounds[0] = bounds.x; Mx->s_bounds[1] = bounds.y; Mx->s_bounds[2] = bounds.z; Mx->s_bounds[3] = bounds.w; }
+    }
+    Mx->op = data1.x;
+    o.tex_slot = WR_S_COLOR0;
+    o.tail_clamp = 1; o.tail_modulate = 0;
+    o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    o.kind = (brush_flags & 1) ? WR_PK_UNSUPPORTED : WR_PK_MIX_BLEND;      // perspective interpolation: next
     return;
   }
   if (image == 4) {
@@ -1851,7 +1886,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT || o.kind == WR_PK_FAST_GRADIENT || o.kind == WR_PK_LINE_DECORATION) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_MIX_BLEND || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT || o.kind == WR_PK_FAST_GRADIENT || o.kind == WR_PK_LINE_DECORATION) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -1879,6 +1914,14 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       const int rows = iy1 - iy0 - 1;
       P.rows_linear = (wr_accum_is_linear(P.uvL0[0], lsu, rows) && wr_accum_is_linear(P.uvL0[1], lsv, rows) &&
                        wr_accum_is_linear(P.uvR0[0], rsu, rows) && wr_accum_is_linear(P.uvR0[1], rsv, rows)) ? 1 : 0;
+    }
+    if (o.kind == WR_PK_MIX_BLEND) {
+      WrMixRec& M = auxp->mix;
+      const float l2u = (wr_pick4(o.u2, bl) - wr_pick4(o.u2, tl)) * yScale, l2v = (wr_pick4(o.v2, bl) - wr_pick4(o.v2, tl)) * yScale;
+      const float r2u = (wr_pick4(o.u2, br) - wr_pick4(o.u2, tr)) * yScale, r2v = (wr_pick4(o.v2, br) - wr_pick4(o.v2, tr)) * yScale;
+      M.sL0[0] = wr_pick4(o.u2, tl) + dy0 * l2u; M.sL0[1] = wr_pick4(o.v2, tl) + dy0 * l2v;
+      M.sR0[0] = wr_pick4(o.u2, tr) + dy0 * r2u; M.sR0[1] = wr_pick4(o.v2, tr) + dy0 * r2v;
+      M.sLs[0] = l2u; M.sLs[1] = l2v; M.sRs[0] = r2u; M.sRs[1] = r2v;
     }
     if (o.kind == WR_PK_BOX_SHADOW) {
       WrBoxRec& B = auxp->box;
@@ -2416,7 +2459,7 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
   const bool flat = runs && runs->n < 0;      // a flattened depth row: chunk by chunk through main(), from the span start
-  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span || flat;   // no draw_span for this program/target: all main()
+  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_MIX_BLEND || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span || flat;   // no draw_span for this program/target: all main()
   const int k = runs ? wr_find_run(runs, x) : -1;
   if (k >= 0) {
     r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
@@ -2892,6 +2935,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: wr_vs_brush(d, arena, inst, 3, o, &aux[gid].grad); break;
     case WR_SH_BRUSH_BLEND:
     case WR_SH_BRUSH_BLEND_ALPHA: wr_vs_brush(d, arena, inst, 4, o, nullptr, &aux[gid].filt); break;
+    case WR_SH_BRUSH_MIX_BLEND:
+    case WR_SH_BRUSH_MIX_BLEND_ALPHA: wr_vs_brush(d, arena, inst, 8, o, nullptr, nullptr, nullptr, &aux[gid].mix); break;
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
@@ -4219,6 +4264,122 @@ __device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterR
   return s;
 }
 
+// ---------------------------------------------------------------------------
+// brush_mix_blend fragment shader (brush_mix_blend.glsl:88-330), one pixel.  No span shader in swgl: main() on every chunk;
+// per pixel in strict fp32, same operation order.  The GLSL's scalar branches become selects there (every lane computes
+// both sides); the selected value is the branch's.
+WR_DEVICE void wr_texture_rgba_f(const WrTexDesc& t, float cu, float cv, float (&c)[4]) {      // texture(sampler, uv) -> (r, g, b, a)
+  const float W = float(t.width), H = float(t.height);
+  if (!t.ptr) { c[0] = c[1] = c[2] = c[3] = 0.0f; return; }
+  if (t.format == WR_FMT_R8) {
+    float m;
+    if (t.linear) m = float(wr_sample_linear_r8(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
+    else m = float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride]) * (1.0f / 255.0f);
+    c[0] = m; c[1] = 0.0f; c[2] = 0.0f; c[3] = 1.0f;
+  } else if (t.linear) {
+    const WrWide s = wr_sample_linear_rgba8(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)));
+    c[2] = float(s.bg & 0xFFFF) * (1.0f / 255.0f); c[1] = float(s.bg >> 16) * (1.0f / 255.0f);
+    c[0] = float(s.ra & 0xFFFF) * (1.0f / 255.0f); c[3] = float(s.ra >> 16) * (1.0f / 255.0f);
+  } else {
+    const uint32_t p = ((const uint32_t*)t.ptr)[(size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride];
+    c[2] = float(p & 0xFF) * (1.0f / 255.0f); c[1] = float((p >> 8) & 0xFF) * (1.0f / 255.0f);
+    c[0] = float((p >> 16) & 0xFF) * (1.0f / 255.0f); c[3] = float(p >> 24) * (1.0f / 255.0f);
+  }
+}
+WR_DEVICE float wr_mix_lum(const float (&c)[3]) { return (c[0] * 0.3f + c[1] * 0.59f) + c[2] * 0.11f; }
+WR_DEVICE void wr_mix_clip_color(float (&C)[3]) {
+  const float L = wr_mix_lum(C);
+  const float n = wr_min(C[0], wr_min(C[1], C[2])), x = wr_max(C[0], wr_max(C[1], C[2]));
+  if (n < 0.0f) for (int i = 0; i < 3; i++) C[i] = L + (((C[i] - L) * L) / (L - n));
+  if (x > 1.0f) for (int i = 0; i < 3; i++) C[i] = L + (((C[i] - L) * (1.0f - L)) / (x - L));
+}
+WR_DEVICE void wr_mix_set_lum(float (&C)[3], float l) {
+  const float d = l - wr_mix_lum(C);
+  for (int i = 0; i < 3; i++) C[i] = C[i] + d;
+  wr_mix_clip_color(C);
+}
+WR_DEVICE float wr_mix_sat(const float (&c)[3]) { return wr_max(c[0], wr_max(c[1], c[2])) - wr_min(c[0], wr_min(c[1], c[2])); }
+WR_DEVICE void wr_mix_set_sat_inner(float& Cmin, float& Cmid, float& Cmax, float s) {
+  if (Cmax > Cmin) { Cmid = ((Cmid - Cmin) * s) / (Cmax - Cmin); Cmax = s; } else { Cmid = 0.0f; Cmax = 0.0f; }
+  Cmin = 0.0f;
+}
+WR_DEVICE void wr_mix_set_sat(float (&C)[3], float s) {
+  float& r = C[0]; float& g = C[1]; float& b = C[2];
+  if (r <= g) {
+    if (g <= b) wr_mix_set_sat_inner(r, g, b, s);
+    else if (r <= b) wr_mix_set_sat_inner(r, b, g, s);
+    else wr_mix_set_sat_inner(b, r, g, s);
+  } else {
+    if (r <= b) wr_mix_set_sat_inner(g, r, b, s);
+    else if (g <= b) wr_mix_set_sat_inner(g, b, r, s);
+    else wr_mix_set_sat_inner(b, g, r, s);
+  }
+}
+WR_DEVICE float wr_mix_hard_light(float Cb, float Cs) {
+  const float m = Cb * (2.0f * Cs);
+  const float t = 2.0f * Cs - 1.0f;
+  const float sc = Cb + t - (Cb * t);
+  const float st = Cs < 0.5f ? 0.0f : 1.0f;         // step(edge, Cs)
+  return (sc - m) * st + m;                          // mix(m, s, step)
+}
+__device__ __noinline__ WrWide wr_mix_blend_pixel(const WrPrim* Pp, const WrMixRec* Mp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
+  const WrPrim& P = *Pp;
+  const WrMixRec& M = *Mp;
+  const WrTexDesc& tb = D->tex[WR_S_COLOR0];
+  const WrTexDesc& ts = D->tex[WR_S_COLOR1];
+  // v_backdrop_uv / v_src_uv of this pixel as the 4-wide fragment loop steps them, clamped to their sample bounds
+  float bu, bv, su, sv;
+  {
+    const WrTexRow r = wr_tex_row(P, tb, y, runs, x);
+    wr_tex_tail_uv(P, r, x - r.x0, bu, bv);
+  }
+  {
+    WrPrim P2 = P;            // the same walk on the second varying's edges
+    P2.uvL0[0] = M.sL0[0]; P2.uvL0[1] = M.sL0[1]; P2.uvLs[0] = M.sLs[0]; P2.uvLs[1] = M.sLs[1];
+    P2.uvR0[0] = M.sR0[0]; P2.uvR0[1] = M.sR0[1]; P2.uvRs[0] = M.sRs[0]; P2.uvRs[1] = M.sRs[1];
+    P2.uv_bounds[0] = M.s_bounds[0]; P2.uv_bounds[1] = M.s_bounds[1]; P2.uv_bounds[2] = M.s_bounds[2]; P2.uv_bounds[3] = M.s_bounds[3];
+    P2.rows_linear = 0;
+    const WrTexRow r = wr_tex_row(P2, ts, y, runs, x);
+    wr_tex_tail_uv(P2, r, x - r.x0, su, sv);
+  }
+  float Cb4[4], Cs4[4];
+  wr_texture_rgba_f(tb, bu, bv, Cb4);
+  wr_texture_rgba_f(ts, su, sv, Cs4);
+  float Cb[3], Cs[3];
+  for (int i = 0; i < 3; i++) { Cb[i] = Cb4[3] != 0.0f ? Cb4[i] / Cb4[3] : Cb4[i]; Cs[i] = Cs4[3] != 0.0f ? Cs4[i] / Cs4[3] : Cs4[i]; }
+  float res[3] = {1.0f, 1.0f, 0.0f};
+  switch (M.op & 0xFF) {
+    case 1: for (int i = 0; i < 3; i++) res[i] = Cb[i] * Cs[i]; break;
+    case 3: for (int i = 0; i < 3; i++) res[i] = wr_mix_hard_light(Cs[i], Cb[i]); break;
+    case 4: for (int i = 0; i < 3; i++) res[i] = wr_min(Cs[i], Cb[i]); break;
+    case 5: for (int i = 0; i < 3; i++) res[i] = wr_max(Cs[i], Cb[i]); break;
+    case 6: for (int i = 0; i < 3; i++) res[i] = Cb[i] == 0.0f ? 0.0f : (Cs[i] == 1.0f ? 1.0f : wr_min(1.0f, Cb[i] / (1.0f - Cs[i]))); break;
+    case 7: for (int i = 0; i < 3; i++) res[i] = Cb[i] == 1.0f ? 1.0f : (Cs[i] == 0.0f ? 0.0f : 1.0f - wr_min(1.0f, (1.0f - Cb[i]) / Cs[i])); break;
+    case 8: for (int i = 0; i < 3; i++) res[i] = wr_mix_hard_light(Cb[i], Cs[i]); break;
+    case 9:
+      for (int i = 0; i < 3; i++) {
+        if (Cs[i] <= 0.5f) res[i] = Cb[i] - (1.0f - 2.0f * Cs[i]) * Cb[i] * (1.0f - Cb[i]);
+        else {
+          const float Dd = Cb[i] <= 0.25f ? ((16.0f * Cb[i] - 12.0f) * Cb[i] + 4.0f) * Cb[i] : sqrtf(Cb[i]);
+          res[i] = Cb[i] + (2.0f * Cs[i] - 1.0f) * (Dd - Cb[i]);
+        }
+      }
+      break;
+    case 10: for (int i = 0; i < 3; i++) res[i] = fabsf(Cb[i] - Cs[i]); break;
+    case 12: { float c[3] = {Cs[0], Cs[1], Cs[2]}; wr_mix_set_sat(c, wr_mix_sat(Cb)); wr_mix_set_lum(c, wr_mix_lum(Cb)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; break; }
+    case 13: { float c[3] = {Cb[0], Cb[1], Cb[2]}; wr_mix_set_sat(c, wr_mix_sat(Cs)); wr_mix_set_lum(c, wr_mix_lum(Cb)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; break; }
+    case 14: { float c[3] = {Cs[0], Cs[1], Cs[2]}; wr_mix_set_lum(c, wr_mix_lum(Cb)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; break; }
+    case 15: { float c[3] = {Cb[0], Cb[1], Cb[2]}; wr_mix_set_lum(c, wr_mix_lum(Cs)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; break; }
+    default: break;
+  }
+  float rgb[3];
+  for (int i = 0; i < 3; i++) rgb[i] = ((1.0f - Cb4[3]) * Cs[i] + Cb4[3] * res[i]) * Cs4[3];
+  uint32_t pc[2];
+  wr_pack_color(wf4{rgb[0], rgb[1], rgb[2], Cs4[3]}, pc);
+  WrWide s; s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
 template <int FMT>
 __device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* Bp, int x, int y) {
   const WrPrim& P = *Pp;
@@ -5436,7 +5597,7 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 // The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
 // nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
 WR_DEVICE bool wr_kind_needs_runs(int kind) {
-  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION ||
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_MIX_BLEND || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION ||
          kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
 }
 // interval of prim `ci` (a depth writer) on row y
@@ -6013,7 +6174,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_FILTER || kind == WR_PK_TEX_REPEAT)) {
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_FILTER || kind == WR_PK_TEX_REPEAT || kind == WR_PK_MIX_BLEND)) {
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -6026,7 +6187,8 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       if (!in) continue;
       const WrRuns* rq = rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr;
       const WrWide raw = kind == WR_PK_FILTER ? wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2), rq)
-                                              : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2), rq);
+                         : kind == WR_PK_MIX_BLEND ? wr_mix_blend_pixel(Pp, &Ap->mix, D, px + (q & 3), py + 4 * (q >> 2), rq)
+                                                   : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2), rq);
       const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), raw);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;

@@ -71,6 +71,8 @@ enum WrShader {
   WR_SH_CS_CONIC_GRADIENT,
   WR_SH_PS_QUAD_RADIAL_GRADIENT,
   WR_SH_PS_QUAD_CONIC_GRADIENT,
+  WR_SH_BRUSH_MIX_BLEND,           // brush_mix_blend (batch.rs:1931-2003)
+  WR_SH_BRUSH_MIX_BLEND_ALPHA,
   WR_SH_PS_COPY,                   // texture-cache copies, batched uploads (renderer/mod.rs:1808-1846, upload.rs:540-620)
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
@@ -259,6 +261,8 @@ enum WrPrimKind {
   WR_PK_TEX_REPEAT,     // swgl_commitTextureRepeat[Color]RGBA8 (brush_image REPETITION): per-row replay of the repeat walk (WrRepeatRec)
   WR_PK_TEX_QUAD,       // a textured prim (WrQuadRec::base_kind) on a general convex quad and / or with swgl_antiAlias: per-row spans and
                         // edge interpolants from WrQuadRec, then the base kind's span / main() evaluation
+  WR_PK_MIX_BLEND,      // brush_mix_blend: fragment shader only, two textures; the backdrop uv travels in WrPrim's uv interpolants, the
+                        // source uv in WrMixRec
   WR_PK_QUAD_MASK,      // ps_quad_mask: fragment shader only (rounded-rect coverage, WrClipRec); vClipLocalPos.xy travels in the uv interpolants
   WR_PK_BORDER_SOLID,   // cs_border_solid: fragment shader only (corner clips, edge-colour mix; WrBorderRec); vPos travels in the uv interpolants
   WR_PK_BORDER_SEGMENT, // cs_border_segment: fragment shader only (styles double / groove / ridge, dot / dash clips; WrBorderSegRec)
@@ -417,6 +421,14 @@ struct WrFilterRec {
   float color_offset[4];    // v_color_offset
 };
 
+// brush_mix_blend (brush_mix_blend.glsl:9-23): v_op, and the second varying -- v_src_uv's edge interpolants, as WrPrim::uv* hold
+// the first one's (v_backdrop_uv) -- with its sample bounds
+struct WrMixRec {
+  int32_t op;
+  float sL0[2], sLs[2], sR0[2], sRs[2];
+  float s_bounds[4];
+};
+
 // cs_border_solid flat varyings (cs_border_solid.glsl:11-38)
 struct WrBorderRec {
   float color0[4], color1[4];       // vColor0, vColor1
@@ -500,6 +512,7 @@ union WrAux {
   WrAARec aa;
   WrGradRec grad;
   WrFilterRec filt;
+  WrMixRec mix;
   WrQuadRec quad;
   WrBorderRec border;
   WrBorderSegRec bseg;

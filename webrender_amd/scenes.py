@@ -1636,6 +1636,139 @@ def filter_swatches(seed=91):
 
 
 # ---------------------------------------------------------------------------
+# brush_mix_blend: CSS mix-blend-mode on isolated pictures (batch.rs:1931-2003).  sColor0 = the backdrop readback, sColor1 =
+# the picture; prim user data = [MixBlendMode, backdrop ImageSource address, source ImageSource address, 0]; blended onto the
+# target with the premultiplied-alpha key.  Modes Screen (2), Exclusion (11) and PlusLighter (16) are GL blend states in the
+# renderer and never reach the shader (brush_mix_blend.glsl:314-320): one of each is drawn anyway, the shader's answer to
+# them (opaque yellow under the backdrop's alpha) is part of what it does.
+def _mix_picture(rng, w, h, k):
+    img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if k % 4 == 0:
+        img[..., 3] = 255
+    elif k % 4 == 1:
+        img[..., 3] = np.where((xx // 6 + yy // 5) % 5 == 0, 0, img[..., 3])       # alpha == 0 lanes
+    elif k % 4 == 2:
+        img[..., 0] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+        img[..., 1] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+    img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)   # premultiplied
+    return img
+
+
+def mix_blend_swatches(seed=201):
+    """One tile of non-overlapping 64x48 brush_mix_blend swatches, backdrop and source both 1:1 and integer-aligned, three per
+    mode 1..16: frame.swatches lists (x, y, backdrop RGBA u8, source RGBA u8, mode) for an independent restatement."""
+    rng = np.random.default_rng(seed)
+    W, H = 1024, 512
+    frame = Frame(W, H, (1.0, 1.0, 1.0, 1.0))
+    atlas = 1024
+    pb, ps = np.zeros((atlas, atlas, 4), np.uint8), np.zeros((atlas, atlas, 4), np.uint8)
+    t_b = TextureRef("mix_backdrop_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pb, upload_format=G.GL_BGRA)
+    t_s = TextureRef("mix_source_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=ps, upload_format=G.GL_BGRA)
+    frame.static_textures += [t_b, t_s]
+    quad = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
+    sw, sh = 64, 48
+    frame.swatches = []
+    tex = TextureRef("tile_0_0", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+    target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+    task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (0.0, 0.0))
+    inst = []
+    for k in range(48):
+        mode = 1 + k // 3
+        ax, ay = (k % 12) * (sw + 6) + 3, (k // 12) * (sh + 6) + 3
+        bx, by = (k % 10) * (sw + 9) + 5, (k // 10) * (sh + 7) + 2
+        ib, isrc = _mix_picture(rng, sw, sh, k), _mix_picture(rng, sw, sh, k + 1)
+        if k % 3 == 1:
+            ib[::7, :, :] = 0                      # backdrop alpha == 0 rows
+        pb[by:by + sh, bx:bx + sw] = ib
+        ps[ay:ay + sh, ax:ax + sw] = isrc
+        a_b = frame.gpu_cache.push([[bx, by, bx + sw, by + sh], [0.0, 0.0, 0.0, 0.0]] + quad)
+        a_s = frame.gpu_cache.push([[ax, ay, ax + sw, ay + sh], [0.0, 0.0, 0.0, 0.0]] + quad)
+        px, py = 8 + (k % 12) * (sw + 12), 8 + (k // 12) * (sh + 12)
+        rect = (float(px), float(py), float(px + sw), float(py + sh))
+        ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), k + 1, 0, 0, task, (mode, a_b, a_s, 0))
+        inst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, edge_flags=15))
+        frame.swatches.append((px, py, ib, isrc, mode))
+    target.alpha.append(Step("brush_mix_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
+                             "PremultipliedAlpha", "alpha", textures={0: t_b, 1: t_s}))
+    frame.passes.append([target])
+    frame.composite_tiles.append(CompositeTile(tex, (0.0, 0.0, float(TILE_W), float(TILE_H)), (0.0, 0.0, float(W), float(H)), opaque=True))
+    return frame
+
+
+def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, only=None, fractional=True, masked=False):
+    """Overlapping, scaled, fractionally placed brush_mix_blend prims over the tile grid: backdrop and source pictures of
+    different sizes (linear filtering on both), sub-quads in homogeneous coordinates on some sources, every mode."""
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    atlas = 1024
+    pb, ps = np.zeros((atlas, atlas, 4), np.uint8), np.zeros((atlas, atlas, 4), np.uint8)
+
+    def pack(pix, count, seed_k):
+        out, x, y, shelf = [], 0, 0, 0
+        for i in range(count):
+            w, h = int(rng.integers(24, 170)), int(rng.integers(24, 140))
+            if x + w > atlas:
+                x, y, shelf = 0, y + shelf, 0
+            pix[y:y + h, x:x + w] = _mix_picture(rng, w, h, i + seed_k)
+            if i % 5 == 4:      # a sub-quad in homogeneous coordinates (w != 1)
+                quad = [[0.125, 0.0625, 0.0, 1.0], [1.75, 0.125, 0.0, 2.0], [0.0625, 0.9375, 0.0, 1.0], [0.96875, 1.0, 0.0, 1.0]]
+            else:
+                quad = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
+            out.append((w, h, frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]] + quad)))
+            x += w
+            shelf = max(shelf, h)
+        return out
+    backs, srcs = pack(pb, 24, 0), pack(ps, 24, 2)
+    t_b = TextureRef("mix_backdrop_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pb, upload_format=G.GL_BGRA)
+    t_s = TextureRef("mix_source_atlas", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR if seed % 2 else G.GL_NEAREST, pixels=ps, upload_format=G.GL_BGRA)
+    frame.static_textures += [t_b, t_s]
+    prims = []
+    for k in range(n):
+        bw, bh, a_b = backs[int(rng.integers(0, len(backs)))]
+        sw, sh, a_s = srcs[int(rng.integers(0, len(srcs)))]
+        sc = (1.0, 1.0, float(rng.uniform(1.1, 2.2)), 0.5, float(rng.uniform(0.5, 1.5)))[k % 5]
+        w, h = sw * sc, sh * sc
+        if k % 5 == 0 or not fractional:
+            px, py, w, h = float(rng.integers(-20, width - 20)), float(rng.integers(-10, height - 20)), float(round(w)), float(round(h))
+        else:
+            px, py = float(rng.uniform(0, width - w)), float(rng.uniform(0, height - 30))
+        prims.append(((px, py, px + w, py + h), 1 + k % 16, a_b, a_s))
+    t_mask, clip_tasks = None, [None] * len(prims)
+    if masked:
+        t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
+        frame.static_textures.append(t_mask)
+        clip_tasks = prim_clip_tasks(rng, [p[0] for p in prims], 1024, True)
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        al = []
+        for zi, (rect, mode, a_b, a_s) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (mode, a_b, a_s, 0))
+            ct = clip_tasks[zi]
+            clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
+            al.append(frame.brush_instance(ph, clip_addr, edge_flags=15))
+        if al:
+            target.alpha.append(Step("brush_mix_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={0: t_b, 1: t_s, 9: t_mask} if masked else {0: t_b, 1: t_s}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
+
+
+# ---------------------------------------------------------------------------
 # Rotated / skewed solid rectangles: the general convex-quad path of draw_quad_spans (rasterize.h:783-1055)
 # with swgl_antiAlias on all four edges (brush.glsl: non-axis-aligned transforms take the antialiased branch).
 def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile_filter=None, only=None, opaque_frac=0.0,
