@@ -51,6 +51,10 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_clip_box_shadow TEXTURE_2D", cs_clip_box_shadow)
   WRSH_ENTRY("brush_image TEXTURE_2D", brush_image_TEXTURE_2D)
   WRSH_ENTRY("brush_image ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
+  /* the ADVANCED_BLEND keys differ from the ALPHA_PASS ones by an output layout qualifier only (shared.glsl:86-88) */
+  WRSH_ENTRY("brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
+  WRSH_ENTRY("brush_image ADVANCED_BLEND,ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D",
+             brush_image_ALPHA_PASS_ANTIALIASING_REPETITION_TEXTURE_2D)
   WRSH_ENTRY("brush_image ANTIALIASING,REPETITION,TEXTURE_2D", brush_image_ANTIALIASING_REPETITION_TEXTURE_2D)
   WRSH_ENTRY("brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D",
              brush_image_ALPHA_PASS_ANTIALIASING_REPETITION_TEXTURE_2D)

@@ -38,8 +38,7 @@ struct CopyPool {
   std::atomic<const std::function<void(int, int)>*> job{nullptr};
   std::atomic<uint64_t> gen{0};
   std::atomic<int> left{0}, parts{1}, sleepers{0};
-  int spin_iters = 0;          // how long a helper polls for the next job before it blocks: while frames stream (an upload every
-                               // few microseconds) the helpers stay awake and a hand-over costs a cache line, not a futex wake
+  int spin_iters = 0;          // how long a helper polls for the next job before it blocks (WRHIP_COPY_SPIN_US; 0: it blocks at once)
   static std::atomic<bool>& forked() { static std::atomic<bool> f{false}; return f; }
   CopyPool() {
     // a fork()ed child inherits this object but not the helper threads: it copies on its own
@@ -50,7 +49,7 @@ struct CopyPool {
     if (hc && (int)hc - 1 < want) want = (int)hc - 1;
     n = want > 0 ? want : 0;
     const char* sp = getenv("WRHIP_COPY_SPIN_US");
-    spin_iters = (sp ? atoi(sp) : 120) * 25;         // (a pause is ~40 ns)
+    spin_iters = (sp ? atoi(sp) : 0) * 25;           // (a pause is ~40 ns; off by default: no gain measured, tools/r3_copy_ab.sh)
     for (int i = 0; i < n; i++) std::thread([this, i] { worker(i + 1); }).detach();
   }
   void worker(int part) {
@@ -97,8 +96,9 @@ struct CopyPool {
 };
 CopyPool& copy_pool() { static CopyPool* p = new CopyPool(); return *p; }     // (never destroyed: the helpers outlive static destruction)
 constexpr size_t PARALLEL_COPY_MIN = 1u << 20;
-// (texture uploads: from this size on, two parts -- the caller and one helper --, all helpers from PARALLEL_COPY_MIN on)
-static size_t split_copy_min() { static const size_t v = getenv("WRHIP_COPY_SPLIT_MIN") ? (size_t)atoll(getenv("WRHIP_COPY_SPLIT_MIN")) : ((size_t)96 << 10); return v; }
+// (texture uploads of WRHIP_COPY_SPLIT_MIN bytes and more could go in two parts -- the caller and one helper; off by default:
+// on a 0.75 MB cfg2 frame the hand-over costs what the second core saves)
+static size_t split_copy_min() { static const size_t v = getenv("WRHIP_COPY_SPLIT_MIN") ? (size_t)atoll(getenv("WRHIP_COPY_SPLIT_MIN")) : PARALLEL_COPY_MIN; return v; }
 // Copy into the pinned staging ring with non-temporal stores: the ring is 96 MiB of memory the CPU never reads back (the
 // DMA engine does), so ordinary stores first fetch every destination line (read-for-ownership) and then evict useful
 // lines to keep it.  Streaming stores do neither; small copies keep memcpy.
@@ -268,6 +268,10 @@ const ShaderInfo SHADERS[] = {
     {"brush_image ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    // (the ADVANCED_BLEND keys: the ALPHA_PASS programs with `layout(blend_support_all_equations) out`, shared.glsl:86-88 --
+    // what BlendMode::Advanced batches are drawn with, shade.rs:440-468)
+    {"brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_image ADVANCED_BLEND,ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_linear_gradient", WR_SH_BRUSH_LINEAR_GRADIENT, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
     {"brush_linear_gradient ALPHA_PASS", WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
     {"ps_quad_mask", WR_SH_PS_QUAD_MASK, {"aPosition", "aData", "aClipData"},

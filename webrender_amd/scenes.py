@@ -2163,8 +2163,9 @@ def blend_modes(width=1024, height=1024, per_state=14, seed=111, states=BLEND_ST
             if sol:
                 target.alpha.append(Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(sol, dtype=np.int32), st, "alpha", textures={}))
             if img:
-                target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(img, dtype=np.int32), st, "alpha",
-                                         textures={0: t_atlas}))
+                # BlendMode::Advanced batches take the ADVANCED_BLEND key of the program (shade.rs:440-468)
+                key = "brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_2D" if st.startswith("Advanced:") else "brush_image ALPHA_PASS,TEXTURE_2D"
+                target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(img, dtype=np.int32), st, "alpha", textures={0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
         frame.composite_tiles.append(CompositeTile(tex, rect, (float(x0), float(y0), float(min(x1, width)), float(min(y1, height))), opaque=True))
