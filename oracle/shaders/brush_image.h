@@ -9,7 +9,7 @@
 // swgl_antiAlias in brush_base.h).
 // RASTER_SCREEN quads (get_image_quad_uv) are not restated: scenes use local raster space.
 
-#define WRSH_BRUSH_IMAGE(NAME, KEYSTR, ALPHA_PASS, REPETITION)                 \
+#define WRSH_BRUSH_IMAGE(NAME, KEYSTR, ALPHA_PASS, REPETITION, DUAL)           \
   struct NAME##_vert : wrsh::brush_vert_base<NAME##_vert> {                    \
     typedef NAME##_vert Self;                                                  \
     static constexpr int VECS_PER_SPECIFIC_BRUSH = 3;                          \
@@ -253,12 +253,19 @@
       vec4 color;                                                              \
       if (ALPHA_PASS) {                                                        \
         float alpha = 1.0f;                                                    \
-        vec3 rgb = texel.sel(X, Y, Z) * v_mask_swizzle.x +                     \
-                   texel.sel(W, W, W) * v_mask_swizzle.y;                      \
-        texel = vec4(rgb, texel.w);                                            \
+        if (!DUAL) { /* brush_image.glsl:369-371 */                            \
+          vec3 rgb = texel.sel(X, Y, Z) * v_mask_swizzle.x +                   \
+                     texel.sel(W, W, W) * v_mask_swizzle.y;                    \
+          texel = vec4(rgb, texel.w);                                          \
+        }                                                                      \
         vec4 alpha_mask = texel * alpha;                                       \
         color = vec4(v_color) * alpha_mask;                                    \
         color *= 1.0f; /* do_clip() */                                         \
+        if (DUAL) { /* :376-378, brush.glsl:251-253: oFragBlend = frag.blend * clip_alpha */ \
+          vec4 blend = alpha_mask * v_mask_swizzle.x +                         \
+                       alpha_mask.sel(W, W, W, W) * v_mask_swizzle.y;          \
+          gl_SecondaryFragColor = blend * 1.0f;                                \
+        }                                                                      \
       } else {                                                                 \
         color = texel;                                                         \
       }                                                                        \
@@ -297,12 +304,19 @@
       vec4 color;                                                              \
       if (ALPHA_PASS) {                                                        \
         float alpha = 1.0f;                                                    \
-        vec3 rgb = texel.sel(X, Y, Z) * v_mask_swizzle.x +                     \
-                   texel.sel(W, W, W) * v_mask_swizzle.y;                      \
-        texel = vec4(rgb, texel.w);                                            \
+        if (!DUAL) { /* brush_image.glsl:369-371 */                            \
+          vec3 rgb = texel.sel(X, Y, Z) * v_mask_swizzle.x +                   \
+                     texel.sel(W, W, W) * v_mask_swizzle.y;                    \
+          texel = vec4(rgb, texel.w);                                          \
+        }                                                                      \
         vec4 alpha_mask = texel * alpha;                                       \
         color = vec4(v_color) * alpha_mask;                                    \
         color *= 1.0f; /* do_clip() */                                         \
+        if (DUAL) { /* :376-378, brush.glsl:251-253: oFragBlend = frag.blend * clip_alpha */ \
+          vec4 blend = alpha_mask * v_mask_swizzle.x +                         \
+                       alpha_mask.sel(W, W, W, W) * v_mask_swizzle.y;          \
+          gl_SecondaryFragColor = blend * 1.0f;                                \
+        }                                                                      \
       } else {                                                                 \
         color = texel;                                                         \
       }                                                                        \
@@ -356,14 +370,21 @@
       if (!REPETITION) {                                                       \
         WRSH_FRAG_WIRING_PERSPECTIVE()                                         \
       }                                                                        \
-      draw_span_RGBA8_func = &draw_span_RGBA8;                                 \
+      /* no span function under ALPHA_PASS + DUAL_SOURCE_BLENDING (:386) */    \
+      if (!(ALPHA_PASS && DUAL)) draw_span_RGBA8_func = &draw_span_RGBA8;      \
     }                                                                          \
   };                                                                           \
   WRSH_PROGRAM(NAME, KEYSTR)
 
-WRSH_BRUSH_IMAGE(brush_image_TEXTURE_2D, "brush_image TEXTURE_2D", false, false)
-WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_TEXTURE_2D, "brush_image ALPHA_PASS,TEXTURE_2D", true, false)
+WRSH_BRUSH_IMAGE(brush_image_TEXTURE_2D, "brush_image TEXTURE_2D", false, false, false)
+WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_TEXTURE_2D, "brush_image ALPHA_PASS,TEXTURE_2D", true, false, false)
 WRSH_BRUSH_IMAGE(brush_image_ANTIALIASING_REPETITION_TEXTURE_2D,
-                 "brush_image ANTIALIASING,REPETITION,TEXTURE_2D", false, true)
+                 "brush_image ANTIALIASING,REPETITION,TEXTURE_2D", false, true, false)
 WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_ANTIALIASING_REPETITION_TEXTURE_2D,
-                 "brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", true, true)
+                 "brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", true, true, false)
+// the DUAL_SOURCE_BLENDING keys (shader_features.rs:163-167): what BlendMode::SubpixelDualSource / MultiplyDualSource batches are
+// drawn with (shade.rs:462-467); the fragment stage writes a second colour, blended with GL_ONE, GL_ONE_MINUS_SRC1_COLOR
+WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D,
+                 "brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", true, false, true)
+WRSH_BRUSH_IMAGE(brush_image_ALPHA_PASS_ANTIALIASING_DUAL_SOURCE_BLENDING_REPETITION_TEXTURE_2D,
+                 "brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D", true, true, true)

@@ -51,6 +51,9 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("cs_clip_box_shadow TEXTURE_2D", cs_clip_box_shadow)
   WRSH_ENTRY("brush_image TEXTURE_2D", brush_image_TEXTURE_2D)
   WRSH_ENTRY("brush_image ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
+  WRSH_ENTRY("brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", brush_image_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D)
+  WRSH_ENTRY("brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D",
+             brush_image_ALPHA_PASS_ANTIALIASING_DUAL_SOURCE_BLENDING_REPETITION_TEXTURE_2D)
   /* the ADVANCED_BLEND keys differ from the ALPHA_PASS ones by an output layout qualifier only (shared.glsl:86-88) */
   WRSH_ENTRY("brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_2D", brush_image_ALPHA_PASS_TEXTURE_2D)
   WRSH_ENTRY("brush_image ADVANCED_BLEND,ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D",

@@ -21,6 +21,17 @@ def digest(px):
     return hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest()
 
 
+def round3_digests():
+    """brush_mix_blend, brush_image DUAL_SOURCE_BLENDING (window pixels)"""
+    from parity_cases import MIX_BLEND, DUAL_SOURCE
+    out = {}
+    for name, scene, kw in MIX_BLEND:
+        out[name] = digest(render_direct(LIB, getattr(scenes, scene)(**kw))[0])
+    for name, kw in DUAL_SOURCE:
+        out[name] = digest(render_direct(LIB, scenes.image_grid(**kw))[0])
+    return out
+
+
 def main():
     out = {}
     out["cfg1"] = digest(render_direct(LIB, scenes.cfg1_solid_colors())[0])
@@ -77,10 +88,18 @@ def main():
                      ("blur_r8_scaled", dict(fmt="r8", scale_steps=2, content=(166, 140), sigma=2.5)),
                      ("blur_rgba8_scaled", dict(fmt="rgba8", scale_steps=2, content=(150, 97), sigma=3.0))):
         out[name] = digest(render_direct(LIB, scenes.blur_chain(**kw))[0]["blur_h"])
+    out.update(round3_digests())
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "digests.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1))
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--round3":
+    # (only the entries added in round 3: the full set takes minutes of 4K / 8K oracle renders)
+    path = os.path.join(ROOT, "tests", "golden", "digests.json")
+    cur = json.load(open(path))
+    cur.update(round3_digests())
+    json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+    sys.exit(0)
 if __name__ == "__main__":
     main()
 
@@ -94,5 +113,12 @@ def abi_surface_golden():
     json.dump(d, open(os.path.join(ROOT, "tests", "golden", "abi_surface.json"), "w"), indent=1, sort_keys=True)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--round3":
+    # (only the entries added in round 3: the full set takes minutes of 4K / 8K oracle renders)
+    path = os.path.join(ROOT, "tests", "golden", "digests.json")
+    cur = json.load(open(path))
+    cur.update(round3_digests())
+    json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+    sys.exit(0)
 if __name__ == "__main__":
     abi_surface_golden()

@@ -204,3 +204,12 @@ MIX_BLEND = [
     ("mix_grid_masked", "mix_blend_grid", dict(seed=205, masked=True)),
     ("mix_grid_integer", "mix_blend_grid", dict(seed=207, fractional=False, n=50)),
 ]
+
+
+# brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING: images under GL_ONE, GL_ONE_MINUS_SRC1_COLOR with the second
+# colour main() writes -- COLOR_MODE_SUBPX_DUAL_SOURCE, MULTIPLY_DUAL_SOURCE and IMAGE, translucent image colours, clip masks
+DUAL_SOURCE = [
+    ("image_dual", dict(dual=True)),
+    ("image_dual_masked", dict(dual=True, masked=True, seed=52)),
+    ("image_dual_nearest", dict(dual=True, nearest=True, seed=53)),
+]

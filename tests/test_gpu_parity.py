@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -463,6 +463,9 @@ def test_hip_mix_blend_matches_oracle(name, scene, kw):
         want, _ = render_direct(ref, getattr(scenes, scene)(**kw))
         d = np.abs(got.astype(int) - want.astype(int))
         assert d.max() <= 1 and (d > 0).sum() <= 1e-4 * d.size, (int(d.max()), int((d > 0).sum()))
+    assert ref or name in GOLDEN
+    if not ref:
+        assert digest(got) == GOLDEN[name]
     if scene == "mix_blend_swatches":
         import sys
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -474,3 +477,18 @@ def test_hip_mix_blend_matches_oracle(name, scene, kw):
             want = np_model.mix_blend_swatch(ib[..., [2, 1, 0, 3]], isrc[..., [2, 1, 0, 3]], mode)
             d = np.abs(want.astype(int) - got[H - y - h:H - y][::-1, x:x + w].astype(int))
             assert d.max() <= 1, (mode, int(d.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", DUAL_SOURCE, ids=[c[0] for c in DUAL_SOURCE])
+def test_hip_dual_source_images_match_oracle(name, kw):
+    """brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under the dual-source blend state on the MI355X"""
+    got, st = render_direct(wrhip_lib(), scenes.image_grid(**kw))
+    assert st["gl_error"] == 0 and (got != 255).any()
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, scenes.image_grid(**kw))
+        assert np.array_equal(got, want)
+    if name in GOLDEN:
+        assert digest(got) == GOLDEN[name] or ref
+    assert ref or name in GOLDEN

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -416,4 +416,15 @@ def test_hostsim_mix_blend_matches_oracle(hostsim, oracle_gcc, name, scene, kw):
     want, _ = render_direct(oracle_gcc, getattr(scenes, scene)(**kw))
     got, st = render_direct(hostsim, getattr(scenes, scene)(**kw))
     assert st["gl_error"] == 0 and (want != 255).any()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,kw", DUAL_SOURCE, ids=[c[0] for c in DUAL_SOURCE])
+def test_hostsim_dual_source_images_match_oracle(hostsim, oracle_gcc, name, kw):
+    """brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under the dual-source blend state: 0 differing bytes, and not what the plain
+    ALPHA_PASS key draws"""
+    want, _ = render_direct(oracle_gcc, scenes.image_grid(**kw))
+    got, st = render_direct(hostsim, scenes.image_grid(**kw))
+    plain, _ = render_direct(oracle_gcc, scenes.image_grid(**{k: v for k, v in kw.items() if k != "dual"}))
+    assert st["gl_error"] == 0 and (want != plain).sum() > 100000
     assert np.array_equal(got, want)

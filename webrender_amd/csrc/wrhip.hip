@@ -268,6 +268,9 @@ const ShaderInfo SHADERS[] = {
     {"brush_image ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    // (ALPHA_PASS + DUAL_SOURCE_BLENDING: what BlendMode::SubpixelDualSource / MultiplyDualSource batches are drawn with,
+    // shade.rs:462-467 -- main() only, a second output colour; the REPETITION variant of the key is not implemented)
+    {"brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", WR_SH_BRUSH_IMAGE_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS},
     // (the ADVANCED_BLEND keys: the ALPHA_PASS programs with `layout(blend_support_all_equations) out`, shared.glsl:86-88 --
     // what BlendMode::Advanced batches are drawn with, shade.rs:440-468)
     {"brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
@@ -2483,7 +2486,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   d.blend = c->blend ? c->blend_key : WR_BLEND_NONE;
   // (GL_ONE, GL_ONE_MINUS_SRC1_COLOR under the dual-source text program is fine: every prim of that
   // program replaces the key with swgl_blendSubpixelText / swgl_blendDropShadow in its vertex stage)
-  const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && info->kind == WR_SH_PS_TEXT_RUN_DUAL;
+  const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && (info->kind == WR_SH_PS_TEXT_RUN_DUAL || info->kind == WR_SH_BRUSH_IMAGE_DUAL);      // (the image program writes the second colour itself)
   if (!dual_text && (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC)) {
     // not in swgl's key table either (gl.cc:614-645: the reference asserts) -- or GL_ONE, GL_ONE_MINUS_SRC1_COLOR outside the
     // dual-source text program, which needs gl_SecondaryFragColor from a shader that is not implemented

@@ -325,6 +325,7 @@ struct WrVsOut {
   int tail_modulate;   // fragment main(): multiplies texel by colour
   int blend_override;  // swgl_blendDropShadow / swgl_blendSubpixelText: WrBlend key replacing the draw's (0 = none)
   wf4 blend_color;     // ... and its constant colour (swgl_BlendColorRGBA8)
+  int dual; float dual_swz;   // brush_image DUAL_SOURCE_BLENDING (WrPrim::dual / dual_swz)
   float persp_div;     // brush_image: perspective_interpolate of `uv = v_uv * mix(gl_FragCoord.w, 1.0, .)` in main(); < 0: no such factor
 };
 
@@ -876,9 +877,19 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   wf4 vcol;
   if (color_mode == 4) vcol = color;                                          // COLOR_MODE_IMAGE
   else if (color_mode == 3) vcol = wf4{color.w, color.w, color.w, color.w};   // COLOR_MODE_COLOR_BITMAP
-  else { o.kind = WR_PK_UNSUPPORTED; return; }                                // blend overrides / dual source: next
+  else if (image == 9 && (color_mode == 1 || color_mode == 5)) vcol = color;  // COLOR_MODE_SUBPX_DUAL_SOURCE / MULTIPLY_DUAL_SOURCE
+  else { o.kind = WR_PK_UNSUPPORTED; return; }                                // blend overrides (drop shadows): next
   o.color = vcol;
   o.tail_modulate = 1;
+  if (image == 9) {
+    // ALPHA_PASS + DUAL_SOURCE_BLENDING (brush_image.glsl:296-311, 369-386): no span function, the texel is not swizzled,
+    // and main() writes oFragBlend = alpha_mask * v_mask_swizzle.x + alpha_mask.aaaa * v_mask_swizzle.y beside the colour
+    o.dual = color_mode == 5 ? 2 : 1;
+    o.dual_swz = color_mode == 1 ? color.w : (color_mode == 5 ? -color.w : 1.0f);
+    if (o.kind == WR_PK_TEX_RGBA8) o.kind = WR_PK_TEX_FS;
+    o.has_color = 1;
+    return;
+  }
   // swgl_commitTextureColorRGBA8 unless v_color == vec4(1.0) (:404-414)
   o.has_color = (vcol.x != 1.0f || vcol.y != 1.0f || vcol.z != 1.0f || vcol.w != 1.0f) ? 1 : 0;
 }
@@ -1708,6 +1719,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   P.draw = draw_index;
   P.color[0] = P.color[1] = 0; P.z = 0; P.tex_slot = 0;
   P.uv_add[0] = o.uv_add[0]; P.uv_add[1] = o.uv_add[1];
+  P.dual = o.dual; P.dual_swz = o.dual_swz;
   P.blend = (int16_t)d.blend;
   P.flags = d.flags & (WR_PF_DEPTH_TEST | WR_PF_DEPTH_WRITE | WR_PF_DEPTH_LESS);
   P.x0 = P.y0 = P.x1 = P.y1 = 0;
@@ -2892,8 +2904,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
                               int gid, WrPrim& P, WrAux* aux, const WrTargetDesc* targets, WrUnsupportedCounters* cnt,
                               const int* __restrict__ blk) {
   P.blend = 0; P.flags = 0; P.z = 0; P.color[0] = P.color[1] = 0; P.tex_slot = 0;
-  P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0;
-  P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0;
+  P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0; P.dual = 0; P.dual_swz = 0.0f;
+  P.uv_add[0] = P.uv_add[1] = 0.0f; P.rows_linear = 0; P.dual = 0; P.dual_swz = 0.0f;
   // the draw containing this instance: the host's per-block table gives the draw at the start of
   // the 64-prim block, the rest is a short forward scan (a binary search over the draws was
   // log2(n) dependent round trips before the first useful load)
@@ -2916,7 +2928,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
   WrVsOut o;
   o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
   o.uv_add[0] = o.uv_add[1] = 0.0f;
-  o.blend_override = 0; o.blend_color = wf4{0, 0, 0, 0}; o.persp_div = -1.0f;
+  o.blend_override = 0; o.blend_color = wf4{0, 0, 0, 0}; o.persp_div = -1.0f; o.dual = 0; o.dual_swz = 0.0f;
   switch (d.shader) {
     case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
     case WR_SH_PS_QUAD_MASK: wr_vs_ps_quad_textured(d, arena, inst, o, 1, &aux[gid].clip); break;
@@ -2927,6 +2939,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_SOLID_ALPHA: wr_vs_brush(d, arena, inst, 0, o); break;
     case WR_SH_BRUSH_IMAGE: wr_vs_brush(d, arena, inst, 1, o); break;
     case WR_SH_BRUSH_IMAGE_ALPHA: wr_vs_brush(d, arena, inst, 2, o); break;
+    case WR_SH_BRUSH_IMAGE_DUAL: wr_vs_brush(d, arena, inst, 9, o); break;
     case WR_SH_BRUSH_OPACITY:
     case WR_SH_BRUSH_OPACITY_ALPHA: wr_vs_brush(d, arena, inst, 7, o); break;
     case WR_SH_BRUSH_IMAGE_REPEAT: wr_vs_brush(d, arena, inst, 5, o, nullptr, nullptr, &aux[gid].rep); break;
@@ -3659,6 +3672,7 @@ WR_DEVICE WrWide wr_mask_src(const WrPrim& P, const WrDrawDesc* D, int x, int y,
 // Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
 // Kept out of line so the fast paths below stay small and the 16 pixels of a
 // lane stay in registers.
+WR_DEVICE void wr_texture_rgba_f(const WrTexDesc& t, float cu, float cv, float (&c)[4]);
 __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const WrDrawDesc* D, int x, int y, uint32_t dstp, const WrRuns* runs = nullptr) {
   const WrPrim& P = *Pp;
   WrWide src;
@@ -3670,6 +3684,34 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
     const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
     WrWide mm; mm.bg = mm.ra = m | (m << 16);
     src = wr_apply_color(mm, P.color);
+  } else if (P.dual && P.kind == WR_PK_TEX_FS && P.blend == WR_BLEND_DUAL_SRC) {
+    // brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under GL_ONE, GL_ONE_MINUS_SRC1_COLOR (blend.h:496-511): main() writes the
+    // colour v_color * texel and a second one, texel * swizzle.x + texel.aaaa * swizzle.y; dst' = src + dst - dst x second
+    // (under a clip mask both terms are scaled by it)
+    const WrTexDesc& t = D->tex[P.tex_slot];
+    const WrTexRow r = wr_tex_row(P, t, y, runs, x);
+    float cu, cv;
+    wr_tex_tail_uv(P, r, x - r.x0, cu, cv);
+    float tx[4];
+    wr_texture_rgba_f(t, cu, cv, tx);
+    const float sx = P.dual_swz, sy = P.dual == 2 ? -P.dual_swz : 0.0f;
+    uint32_t pc[2], ps[2];
+    wr_pack_color(wf4{P.fcolor[0] * tx[0], P.fcolor[1] * tx[1], P.fcolor[2] * tx[2], P.fcolor[3] * tx[3]}, pc);
+    wr_pack_color(wf4{tx[0] * sx + tx[3] * sy, tx[1] * sx + tx[3] * sy, tx[2] * sx + tx[3] * sy, tx[3] * sx + tx[3] * sy}, ps);
+    WrWide s2; s2.bg = pc[0]; s2.ra = pc[1];
+    const WrWide dst = wr_unpack(dstp);
+    WrWide second; second.bg = wr_muldiv255_2(ps[0], dst.bg); second.ra = wr_muldiv255_2(ps[1], dst.ra);    // applyColor(dst, secondary)
+    if (P.flags & WR_PF_MASKED) {
+      const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
+      const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
+      const uint32_t mm = m | (m << 16);
+      s2.bg = wr_muldiv255_2(s2.bg, mm); s2.ra = wr_muldiv255_2(s2.ra, mm);
+      second.bg = wr_muldiv255_2(second.bg, mm); second.ra = wr_muldiv255_2(second.ra, mm);
+    }
+    WrWide res;
+    res.bg = wr_sub2(wr_add2(s2.bg, dst.bg), second.bg);
+    res.ra = wr_sub2(wr_add2(s2.ra, dst.ra), second.ra);
+    return wr_pack(res);
   } else {
     src = wr_mask_src(P, D, x, y, wr_tex_pixel(P, D->tex[P.tex_slot], x, y, runs));
   }

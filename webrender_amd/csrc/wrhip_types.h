@@ -71,6 +71,7 @@ enum WrShader {
   WR_SH_CS_CONIC_GRADIENT,
   WR_SH_PS_QUAD_RADIAL_GRADIENT,
   WR_SH_PS_QUAD_CONIC_GRADIENT,
+  WR_SH_BRUSH_IMAGE_DUAL,          // brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D
   WR_SH_BRUSH_MIX_BLEND,           // brush_mix_blend (batch.rs:1931-2003)
   WR_SH_BRUSH_MIX_BLEND_ALPHA,
   WR_SH_PS_COPY,                   // texture-cache copies, batched uploads (renderer/mod.rs:1808-1846, upload.rs:540-620)
@@ -301,7 +302,8 @@ struct WrPrim {
   int32_t mask_off[2];      // WR_PK_SOLID_MASKED / WR_PF_MASKED: target pixel - mask texel (swgl_ClipMaskOffset)
   int32_t rows_linear;      // 1: edge interpolants at row k equal L0 + k*slope exactly (closed form of Edge::nextRow)
   float uv_add[2];          // added to the interpolated uv of every pixel before sampling (brush_image: + v_uv_bounds.xy)
-  int32_t pad2[2];
+  int32_t dual;             // brush_image DUAL_SOURCE_BLENDING: 1 -- main() also writes oFragBlend = mask * dual_swz[0] + mask.aaaa * dual_swz[1]
+  float dual_swz;           // ... v_mask_swizzle.x (y is -x for COLOR_MODE_MULTIPLY_DUAL_SOURCE, 0 otherwise: dual == 2)
 };
 
 // Compact per-prim record the raster stage streams (32 B, dense array): the

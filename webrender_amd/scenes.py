@@ -346,7 +346,10 @@ def scaled_composites(width=1024, height=768, seed=21, src=192):
 # alpha pass (batch.rs:2060-2150; ImageBrushData gpu_types.rs:707-724; GPU blocks
 # prim_store/image.rs: [color, background_color, stretch_size]).
 def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=None, modes=(0, 1, 2, 3, 4), translucent=True, only=None,
-               masked=False, nearest=False):
+               masked=False, nearest=False, dual=False):
+    """`dual`: the alpha-pass images go through "brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D" under the dual-source
+    blend state (BlendMode::SubpixelDualSource / MultiplyDualSource batches, batch.rs / shade.rs:462-467), colour modes
+    SUBPX_DUAL_SOURCE, MULTIPLY_DUAL_SOURCE and IMAGE in turn, with a translucent image colour."""
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -432,6 +435,11 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
                 continue
             spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
             ud = (4 | (1 << 16), 0, int(round(opacity * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
+            if dual and not opaque:
+                a = (0.35, 0.6, 0.85, 1.0)[zi % 4]
+                col = [((zi * 37) % 256) / 255.0 * a, ((zi * 91) % 256) / 255.0 * a, ((zi * 53) % 256) / 255.0 * a, a]
+                spec = frame.gpu_cache.push([col, [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
+                ud = ((1, 5, 4)[zi % 3] | (1 << 16), 0, int(round(opacity * 65535.0)), 0)
             ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, ud)
             ct = None if opaque else clip_tasks[zi]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
@@ -440,8 +448,10 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
             target.opaque.append(Step("brush_image TEXTURE_2D", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
                                       None, "opaque", textures={0: t_atlas}))
         if al:
-            target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
-                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
+            target.alpha.append(Step("brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D" if dual else "brush_image ALPHA_PASS,TEXTURE_2D",
+                                     "PRIM_INSTANCES", np.array(al, dtype=np.int32),
+                                     "SubpixelDualSource" if dual else "PremultipliedAlpha", "alpha",
+                                     textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
         clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
