@@ -29,6 +29,9 @@ def round3_digests():
         out[name] = digest(render_direct(LIB, getattr(scenes, scene)(**kw))[0])
     for name, kw in DUAL_SOURCE:
         out[name] = digest(render_direct(LIB, scenes.image_grid(**kw))[0])
+    for name, make in ROTATED:
+        if name.startswith("near_clipped") and name in ROTATED_GOLDEN:
+            out[name] = digest(render_direct(LIB, make())[0])
     return out
 
 

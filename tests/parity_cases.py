@@ -92,6 +92,21 @@ ROTATED += [
     ("perspective_masked_rects", lambda: scenes.masked_rects(perspective=True, force_aa=True, seed=15)),
     ("occluded_perspective_masked_rects", lambda: scenes.add_occluders(scenes.masked_rects(perspective=True, force_aa=True, fractional=True, seed=16), zmax=150, seed=42)),
 ]
+# clip_side (rasterize.h:1287-1430, 1490-1544): prims that reach the camera plane (a vertex with w <= 0) are clipped against the
+# view volume before they are projected -- near / far first, then x and y where a clipped vertex still has w <= 0 --, which
+# turns the quad into a polygon of up to ten vertices with interpolated varyings and a rewritten AA edge mask: solid rects in
+# both encodings, images with screen-linear and perspective-correct uv, behind occluders, writing depth, under clip masks.
+# 0 differing bytes.
+ROTATED += [
+    ("near_clipped_rects", lambda: scenes.rotated_rects(perspective="clip", seed=297)),
+    ("near_clipped_rects_quad", lambda: scenes.rotated_rects(perspective="clip", encoding="quad", seed=298)),
+    ("occluded_near_clipped_rects", lambda: scenes.add_occluders(scenes.rotated_rects(perspective="clip", seed=299), zmax=70, seed=38)),
+    ("near_clipped_depth_writers", lambda: scenes.rotated_rects(perspective="clip", opaque_frac=0.5, seed=396)),
+    ("near_clipped_images", lambda: scenes.rotated_images(perspective="clip", seed=304)),
+    ("near_clipped_images_quad", lambda: scenes.rotated_images(perspective="clip", encoding="quad", seed=302)),
+    ("near_clipped_images_masked", lambda: scenes.rotated_images(perspective="clip", masked=True, seed=306)),
+    ("occluded_near_clipped_images", lambda: scenes.add_occluders(scenes.rotated_images(perspective="clip", seed=305), zmax=60, seed=41)),
+]
 # Flattened depth rows.  A perspective span flattens the depth row it touches (rasterize.h:1222-1232), and swgl then draws every
 # LATER depth-tested prim on that row chunk by chunk through main(), from the span start, instead of handing the span shader one
 # depth run at a time (:1021-1031).  The setup stage records, per target row, the first depth-tested perspective prim whose span
@@ -137,7 +152,7 @@ ROTATED += [
     ("transforms_simple", lambda: scenes.transforms_simple()),
     ("transforms_simple_quad", lambda: scenes.transforms_simple(encoding="quad")),
 ]
-ROTATED_GOLDEN = ("transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
+ROTATED_GOLDEN = ("near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

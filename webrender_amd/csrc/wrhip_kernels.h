@@ -1690,12 +1690,216 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
   return Q.nseg > 0;
 }
 
+// ---------------------------------------------------------------------------
+// draw_perspective's clipped path (rasterize.h:1289-1430, 1490-1544): a quad with a vertex outside the near / far planes -- for
+// WebRender's z = z_id * w that means a vertex at or behind the camera plane, w <= 0 -- is clipped against the view volume
+// before it is projected: clip_side<Z>, and, if a clipped vertex still has w <= 0, clip_side<X> and clip_side<Y>; every pass
+// can add two vertices (up to ten), and rewrites the AA edge mask.  Interpolants: the prim's one vec2 varying.
+struct WrClipPt { float x, y, z, w, u, v; };
+WR_DEVICE float wr_clip_sel(const WrClipPt& p, int axis) { return axis == 0 ? p.x : (axis == 1 ? p.y : p.z); }
+WR_DEVICE WrClipPt wr_clip_lerp(const WrClipPt& a, const WrClipPt& b, float k) {       // prev + (cur - prev) * k, component by component
+  WrClipPt r;
+  r.x = a.x + (b.x - a.x) * k; r.y = a.y + (b.y - a.y) * k; r.z = a.z + (b.z - a.z) * k; r.w = a.w + (b.w - a.w) * k;
+  r.u = a.u + (b.u - a.u) * k; r.v = a.v + (b.v - a.v) * k;
+  return r;
+}
+__device__ __noinline__ int wr_clip_side(int axis, int nump, const WrClipPt* p, WrClipPt* out, int& edge_mask_io) {
+  const int POSITIVE = 1, NEGATIVE = 2;
+  int numClip = 0;
+  int edgeMask = edge_mask_io;
+  WrClipPt prev = p[nump - 1];
+  float prevCoord = wr_clip_sel(prev, axis);
+  int prevMask = (prevCoord < -prev.w ? NEGATIVE : 0) | (prevCoord > prev.w ? POSITIVE : 0);
+  int outMask = 0;
+  for (int i = 0; i < nump; i++, edgeMask >>= 1) {
+    const WrClipPt cur = p[i];
+    const float curCoord = wr_clip_sel(cur, axis);
+    const int curMask = (curCoord < -cur.w ? NEGATIVE : 0) | (curCoord > cur.w ? POSITIVE : 0);
+    if (!(curMask & prevMask)) {
+      if (prevMask) {            // an edge that was outside crosses inside
+        if (numClip >= nump + 2) return 0;
+        const float prevSide = ((prevMask & NEGATIVE) && (!(prevMask & POSITIVE) || prevCoord * (cur.w - prev.w) < prev.w * (curCoord - prevCoord))) ? -1.0f : 1.0f;
+        const float prevDist = prevCoord - prevSide * prev.w;
+        const float curDist = curCoord - prevSide * cur.w;
+        float k = prevDist / (prevDist - curDist);
+        WrClipPt clipped = wr_clip_lerp(prev, cur, k);
+        if (prevSide * wr_clip_sel(clipped, axis) > clipped.w) {      // (only the position is redone with the nudged weight)
+          k = nextafterf(k, 1.0f);
+          const WrClipPt c2 = wr_clip_lerp(prev, cur, k);
+          clipped.x = c2.x; clipped.y = c2.y; clipped.z = c2.z; clipped.w = c2.w;
+        }
+        const WrClipPt ci = wr_clip_lerp(prev, cur, k);
+        clipped.u = ci.u; clipped.v = ci.v;
+        out[numClip] = clipped;
+        numClip++;
+      }
+      if (curMask) {             // an edge that was inside crosses outside
+        if (numClip >= nump + 2) return 0;
+        const float curSide = ((curMask & POSITIVE) && (!(curMask & NEGATIVE) || prevCoord * (cur.w - prev.w) < prev.w * (curCoord - prevCoord))) ? 1.0f : -1.0f;
+        const float prevDist = prevCoord - curSide * prev.w;
+        const float curDist = curCoord - curSide * cur.w;
+        float k = prevDist / (prevDist - curDist);
+        WrClipPt clipped = wr_clip_lerp(prev, cur, k);
+        if (curSide * wr_clip_sel(clipped, axis) > clipped.w) {
+          k = nextafterf(k, 0.0f);
+          const WrClipPt c2 = wr_clip_lerp(prev, cur, k);
+          clipped.x = c2.x; clipped.y = c2.y; clipped.z = c2.z; clipped.w = c2.w;
+        }
+        const WrClipPt ci = wr_clip_lerp(prev, cur, k);
+        clipped.u = ci.u; clipped.v = ci.v;
+        out[numClip] = clipped;
+        outMask |= (edgeMask & 1) << numClip;
+        numClip++;
+      }
+    }
+    if (!curMask) {
+      if (numClip >= nump + 2) return 0;
+      out[numClip] = cur;
+      outMask |= (edgeMask & 1) << numClip;
+      numClip++;
+    }
+    prev = cur; prevCoord = curCoord; prevMask = curMask;
+  }
+  edge_mask_io = outMask;
+  return numClip;
+}
+
+// draw_perspective_spans (rasterize.h:1064-1280) for the clipped polygon, walked at setup time like wr_quad_walk: the start vertices
+// of the two descending chains (:1070-1105, flat tops included), STEP_EDGE, the clip span of every edge pair.  p*: screen x, y,
+// z and 1 / w per vertex; iu / iv: the varying times 1 / w.
+WR_DEVICE bool wr_poly_walk(const int nump, const float* px, const float* py, const float* iu, const float* iv, const float* iz,
+                                          const float* iw, float cx0, float cy0, float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0,
+                                          int& by0, int& bx1, int& by1) {
+  Q.nseg = 0; Q.aa = aa ? 1 : 0;
+  auto NEXT = [&](int i) { return i + 1 == nump ? 0 : i + 1; };
+  auto PREV = [&](int i) { return i == 0 ? nump - 1 : i - 1; };
+  int top = 0;
+  for (int i = 1; i < nump; i++) if (py[i] < py[top]) top = i;
+  int l0i = top;
+  for (int i = top + 1; i < nump && py[i] == py[top]; i++) l0i = i;
+  if (l0i == nump - 1) for (int i = 0; i <= top && py[i] == py[top]; i++) l0i = i;
+  int r0i = top;
+  for (int i = top - 1; i >= 0 && py[i] == py[top]; i--) r0i = i;
+  if (r0i == 0) for (int i = nump - 1; i >= top && py[i] == py[top]; i--) r0i = i;
+  int l1i = NEXT(l0i), r1i = PREV(r0i);
+  const float aaRound = aa ? 0.0f : 0.5f;
+  float y = floorf(wr_max(wr_min(py[l0i], cy1), cy0) + aaRound) + 0.5f;
+#define WR_PEDGE(a, b, m) wr_edge_init(y, px[a], py[a], px[b], py[b], (aa_mask >> (m)) & 1, iu[a], iv[a], iu[b], iv[b], iz[a], iw[a], iz[b], iw[b])
+  WrEdgeInst EL = WR_PEDGE(l0i, l1i, l1i);
+  WrEdgeInst ER = WR_PEDGE(r0i, r1i, r0i);
+  bool flipped;
+  {   // checkIfEdgesFlipped (:766-774)
+    const float l0x = px[l0i], r0x = px[r0i];
+    const float ax = px[l1i] - l0x, ay = py[l1i] - py[l0i], bx = px[r1i] - r0x, by = py[r1i] - py[r0i];
+    flipped = l0x > r0x || (l0x == r0x && (ax * by - ay * bx) > 0.0f);
+  }
+  float checkY = wr_min(wr_min(py[l1i], py[r1i]), cy1);
+  float b0, b1;
+#define WR_PCLIPSPAN()                                                                                 \
+  do {                                                                                                 \
+    const float lo = wr_min(wr_min(px[l0i], px[l1i]), wr_min(px[r0i], px[r1i]));                       \
+    const float hi = wr_max(wr_max(px[l0i], px[l1i]), wr_max(px[r0i], px[r1i]));                       \
+    b0 = wr_clamp(lo, cx0, cx1); b1 = wr_clamp(hi, cx0, cx1);                                          \
+  } while (0)
+  WR_PCLIPSPAN();
+  bx0 = 0x7FFFFFFF; bx1 = -0x7FFFFFFF; by0 = int(y); by1 = int(y);
+  for (int guard = 0; guard < 4 * WR_MAX_QSEG; guard++) {
+    if (y > checkY) {
+      if (y > cy1) break;
+      bool done = false;
+      if (y > py[l1i]) {          // STEP_EDGE(y, l0i, l0, l1i, l1, NEXT_POINT, r1i)
+        do { l0i = l1i; l1i = NEXT(l1i); if (l0i == r1i) { done = true; break; } } while (y > py[l1i]);
+        if (done) break;
+        EL = WR_PEDGE(l0i, l1i, l1i);
+      }
+      if (y > py[r1i]) {          // STEP_EDGE(y, r0i, r0, r1i, r1, PREV_POINT, l1i)
+        do { r0i = r1i; r1i = PREV(r1i); if (r0i == l1i) { done = true; break; } } while (y > py[r1i]);
+        if (done) break;
+        ER = WR_PEDGE(r0i, r1i, r0i);
+      }
+      WR_PCLIPSPAN();
+      checkY = wr_min(ceilf(wr_min(py[l1i], py[r1i]) - aaRound), cy1);
+    }
+    int n = 1;
+    if (checkY >= y) n = int(floor(double(checkY) - double(y))) + 1;
+    if (Q.nseg >= WR_MAX_QSEG) return false;
+    WrQuadSeg& S = Q.seg[Q.nseg++];
+    const WrEdgeInst& A = flipped ? ER : EL;
+    const WrEdgeInst& B = flipped ? EL : ER;
+    S.row_a = int(y); S.row_b = int(y) + n;
+    S.lx = A.x; S.ls = A.slope; S.lrow = A.row; S.lmask = A.mask;
+    S.rx = B.x; S.rs = B.slope; S.rrow = B.row; S.rmask = B.mask;
+    S.luv[0] = A.u; S.luv[1] = A.v; S.luvs[0] = A.us; S.luvs[1] = A.vs;
+    S.ruv[0] = B.u; S.ruv[1] = B.v; S.ruvs[0] = B.us; S.ruvs[1] = B.vs;
+    {
+      WrPerspRec& R = Q.persp;
+      const int k = Q.nseg - 1;
+      R.lz[k] = A.z; R.lzs[k] = A.zs; R.lw[k] = A.w; R.lws[k] = A.ws;
+      R.rz[k] = B.z; R.rzs[k] = B.zs; R.rw[k] = B.w; R.rws[k] = B.ws;
+    }
+    S.b0 = b0; S.b1 = b1;
+    bx0 = wr_imin(bx0, int(floorf(b0)) - 1); bx1 = wr_imax(bx1, int(ceilf(b1)) + 1);
+    by1 = S.row_b;
+    y = y + float(n);
+  }
+#undef WR_PCLIPSPAN
+#undef WR_PEDGE
+  return Q.nseg > 0;
+}
+
+// What the clipped walk needs of a prim, parked in the tail of its (still unused) quad record by the vertex-stage thread: the
+// walk runs after wr_finish_prim, when the vertex stage's outputs are dead -- called from inside it, the callee's registers
+// came on top of the ~60 live ones and the fused setup + tile-pass kernel lost a wave per SIMD.
+struct WrClipStash { float px[4], py[4], pz[4], pw[4], u[4], v[4]; float cx0, cy0, cx1, cy1; int32_t aa, aa_edges; float vp[4]; };
+static_assert(sizeof(WrClipStash) <= 5 * sizeof(WrQuadSeg), "the stash sits in seg[5..9]: the walk has copied it before it writes that far");
+WR_DEVICE WrClipStash* wr_clip_stash(WrQuadRec& Q) { return (WrClipStash*)&Q.seg[WR_MAX_QSEG - 5]; }
+// clip, project (rasterize.h:1518-1530), ClipRect::overlaps, and walk.  False: nothing to draw.
+WR_DEVICE bool wr_persp_clipped_walk(WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1, float& ocx0, float& ocy0, float& ocx1, float& ocy1) {
+  const WrClipStash o = *wr_clip_stash(Q);
+  const float cx0 = o.cx0, cy0 = o.cy0, cx1 = o.cx1, cy1 = o.cy1;
+  ocx0 = cx0; ocy0 = cy0; ocx1 = cx1; ocy1 = cy1;
+  const bool aa = o.aa != 0;
+  WrClipPt a[WR_MAX_QSEG], b[WR_MAX_QSEG];
+  for (int n = 0; n < 4; n++) { a[n].x = o.px[n]; a[n].y = o.py[n]; a[n].z = o.pz[n]; a[n].w = o.pw[n]; a[n].u = o.u[n]; a[n].v = o.v[n]; }
+  int mask = o.aa_edges;
+  int nump = wr_clip_side(2, 4, a, b, mask);
+#ifdef WRHIP_HOSTSIM
+  if (getenv("WRHIP_DEBUG_CLIP")) fprintf(stderr, "clip_side<Z>: %d points, w %g %g %g %g\n", nump, o.pw[0], o.pw[1], o.pw[2], o.pw[3]);
+#endif
+  if (nump < 3) return false;
+  bool behind = false;
+  for (int i = 0; i < nump; i++) if (b[i].w <= 0.0f) { behind = true; break; }
+  WrClipPt* cur = b;
+  if (behind) {
+    nump = wr_clip_side(0, nump, b, a, mask);
+    if (nump < 3) return false;
+    nump = wr_clip_side(1, nump, a, b, mask);
+#ifdef WRHIP_HOSTSIM
+    if (getenv("WRHIP_DEBUG_CLIP")) fprintf(stderr, "  after X / Y: %d points\n", nump);
+#endif
+    if (nump < 3) return false;
+  }
+  const float scx = o.vp[2] * 0.5f, scy = o.vp[3] * 0.5f;
+  const float ofx = o.vp[0] + scx, ofy = o.vp[1] + scy;
+  float px[WR_MAX_QSEG], py[WR_MAX_QSEG], pz[WR_MAX_QSEG], pw[WR_MAX_QSEG], qu[WR_MAX_QSEG], qv[WR_MAX_QSEG];
+  int sides = 0;
+  for (int i = 0; i < nump; i++) {
+    const float wn = 1.0f / cur[i].w;
+    if (wr_isfinite(wn)) { px[i] = cur[i].x * wn * scx + ofx; py[i] = cur[i].y * wn * scy + ofy; pz[i] = cur[i].z * wn * 0.5f + 0.5f; pw[i] = wn; }
+    else { px[i] = py[i] = pz[i] = pw[i] = 0.0f; }
+    qu[i] = cur[i].u * pw[i]; qv[i] = cur[i].v * pw[i];
+    sides |= px[i] < cx1 ? (px[i] > cx0 ? 3 : 1) : 2;
+    sides |= py[i] < cy1 ? (py[i] > cy0 ? 12 : 4) : 8;
+  }
+  if (sides != 0xF) return false;
+  return wr_poly_walk(nump, px, py, qu, qv, pz, pw, cx0, cy0, cx1, cy1, aa, mask, Q, bx0, by0, bx1, by1);
+}
+
 // The span of row y of a general quad (aa_span, rasterize.h:520-561): [s0, s1) -- with swgl_antiAlias the rounded-out one,
 // [la0, ra1).  False: the row is outside the walk.
 WR_DEVICE bool wr_quad_row_span(const WrQuadRec& Q, int y, int& s0, int& s1) {
   int si = -1;
-#pragma unroll
-  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  for (int i = 0; i < Q.nseg; i++) if (y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return false;
   const WrQuadSeg& S = Q.seg[si];
   const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
@@ -1730,17 +1934,25 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   float w = 1.0f / o.pw[0];
   if (!wr_isfinite(w)) w = 0.0f;
   float sx[4], sy[4], pz3[4], pw3[4];
+  bool clipped = false;
   if (persp) {
     bool inside = true;
     for (int n = 0; n < 4; n++) inside = inside && (o.pz[n] > -o.pw[n]) && (o.pz[n] < o.pw[n]);
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
     const bool ptex = (d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS);
-    if (!inside || !(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
+    if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
+    clipped = !inside;           // a vertex outside the near / far planes: clip_side first (wr_persp_clipped_walk)
+    if (clipped) {
+      // (the clip-space vertices are parked right away: kept in registers until the walk is set up below, they cost the fused
+      // setup + tile-pass kernel a wave per SIMD; the stash lies beyond any base kind's side record in the prim's WrAux)
+      WrClipStash& St = *wr_clip_stash(auxp->quad);
+      for (int n = 0; n < 4; n++) { St.px[n] = o.px[n]; St.py[n] = o.py[n]; St.pz[n] = o.pz[n]; St.pw[n] = o.pw[n]; St.u[n] = o.u[n]; St.v[n] = o.v[n]; }
+    }
     // screen = pos.xyz * (1 / pos.w) * scale + offset, scale = (viewport size, 1) / 2, offset = (viewport origin, 0) + scale
     const float scx = d.vp_size[0] * 0.5f, scy = d.vp_size[1] * 0.5f;
     const float ofx = d.vp_origin[0] + scx, ofy = d.vp_origin[1] + scy;
     for (int n = 0; n < 4; n++) {
-      const float wn = 1.0f / o.pw[n];
+      const float wn = clipped ? 0.0f : 1.0f / o.pw[n];
       sx[n] = o.px[n] * wn * scx + ofx;
       sy[n] = o.py[n] * wn * scy + ofy;
       pz3[n] = o.pz[n] * wn * 0.5f + 0.5f;
@@ -1781,7 +1993,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     sides |= sx[n] < cx1 ? (sx[n] > cx0 ? 3 : 1) : 2;
     sides |= sy[n] < cy1 ? (sy[n] > cy0 ? 12 : 4) : 8;
   }
-  if (sides != 0xF) return;
+  if (sides != 0xF && !clipped) return;
   if (!persp) {
     float screenZ = (o.pz[0] * w + 1.0f) * 0.5f;
     if (screenZ < 0.0f || screenZ > 1.0f) return;
@@ -1821,7 +2033,15 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // vertex and edges as draw_quad_spans for any quad without three vertices on one row)
     float qu[4], qv[4];
     for (int n = 0; n < 4; n++) { qu[n] = persp ? o.u[n] * pw3[n] : o.u[n]; qv[n] = persp ? o.v[n] * pw3[n] : o.v[n]; }
-    if (!wr_quad_walk(sx, sy, qu, qv, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1, pz3, pw3, persp)) return;
+    if (clipped) {
+      // (clipped against the view volume and walked after this function: wr_finish_clipped)
+      WrClipStash& St = *wr_clip_stash(auxp->quad);
+      St.cx0 = cx0; St.cy0 = cy0; St.cx1 = cx1; St.cy1 = cy1; St.aa = aa ? 1 : 0; St.aa_edges = o.aa_edges;
+      St.vp[0] = d.vp_origin[0]; St.vp[1] = d.vp_origin[1]; St.vp[2] = d.vp_size[0]; St.vp[3] = d.vp_size[1];
+      auxp->quad.nseg = -1;
+      bx0 = int(cx0); by0 = int(cy0); bx1 = int(cx0) + 1; by1 = int(cy0) + 1;      // (a placeholder box: replaced by the walk's)
+    }
+    else if (!wr_quad_walk(sx, sy, qu, qv, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1, pz3, pw3, persp)) return;
     // 1: a program without varyings (brush_solid): glsl-to-cxx wires its perspective entry points to the plain ones, which never
     // step gl_FragCoord.z -- every chunk of a span is depth-tested with the z of the span's first four pixels; 2: a program with
     // varyings (ps_quad_textured): run_perspective / skip_perspective advance z and w chunk by chunk (lib.rs:656-659, 3627-3636)
@@ -2978,6 +3198,17 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
   if (gid < 16384) wr_dbg_mid[gid] = wall_clock64();
 #endif
   wr_finish_prim(d, lo, o, P, &aux[gid], cnt);
+  if ((P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) && aux[gid].quad.nseg < 0) {
+    // a perspective prim that reaches the camera plane: clip_side, then the polygon's walk (wr_persp_clipped_walk)
+    int bx0, by0, bx1, by1;
+    float cx0, cy0, cx1, cy1;
+    bool ok = wr_persp_clipped_walk(aux[gid].quad, bx0, by0, bx1, by1, cx0, cy0, cx1, cy1);
+    if (ok) {
+      P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
+      ok = P.x1 > P.x0 && P.y1 > P.y0;
+    }
+    if (!ok) { P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; aux[gid].quad.nseg = 0; }
+  }
   if ((P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) && aux[gid].quad.pad != 0 && (P.flags & WR_PF_DEPTH_TEST)) {
     // a depth-tested perspective prim: the rows its spans touch are flattened from here on (WrTargetDesc::flat_rows)
     uint32_t* fr = targets[d.target].flat_rows;
@@ -3528,8 +3759,7 @@ __device__ __noinline__ WrQuadRowS wr_quad_row_setup(const WrQuadRec* Qp, int y,
   R.ok = 0; R.s0 = R.s1 = R.la1 = 0; R.lstart = R.rstart = 256.0f; R.lend = R.rend = 0.0f;
   R.xl = R.xr = 0.0f; R.si = -1; R.y = y;
   int si = -1;
-#pragma unroll
-  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  for (int i = 0; i < Q.nseg; i++) if (y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return R;
   const WrQuadSeg& S = Q.seg[si];
   float xl, xr;
@@ -3618,8 +3848,7 @@ WR_DEVICE void wr_quad_row_edges(const WrQuadRec& Q, int si, int y, WrQuadRowCac
 __device__ __noinline__ uint32_t wr_persp_depth(const WrQuadRec* Qp, int x, int y, WrQuadRowCache* cache = nullptr) {
   const WrQuadRec& Q = *Qp;
   int si = -1;
-#pragma unroll
-  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  for (int i = 0; i < Q.nseg; i++) if (y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return 0xFFFFFFFFu;
   const WrQuadSeg& S = Q.seg[si];
   WrQuadRowCache E;
@@ -3731,8 +3960,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
   const unsigned long long dstp = dstp_;
   const unsigned long long HIT = 1ull << 32;
   int si = -1;
-#pragma unroll
-  for (int i = 0; i < 4; i++) if (i < Q.nseg && y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
+  for (int i = 0; i < Q.nseg; i++) if (y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return dstp;
   const WrQuadSeg& S = Q.seg[si];
   WrQuadRowCache E;
@@ -5820,8 +6048,7 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
 // takes the flat-colour path: coverage 256 leaves the colour as it is (DO_AA, blend.h:433-446).
 WR_DEVICE bool wr_strip_inside_quad(const WrQuadRec& Q, int wx0, int wy0, int rows) {
   int si = -1;
-#pragma unroll
-  for (int i = 0; i < 4; i++) if (i < Q.nseg && wy0 >= Q.seg[i].row_a && wy0 + rows <= Q.seg[i].row_b) si = i;
+  for (int i = 0; i < Q.nseg; i++) if (wy0 >= Q.seg[i].row_a && wy0 + rows <= Q.seg[i].row_b) si = i;
   if (si < 0) return false;
   const WrQuadSeg& S = Q.seg[si];
   const float ya = float(wy0 - S.lrow), yb = float(wy0 + rows - 1 - S.lrow);

@@ -478,14 +478,17 @@ struct WrRepeatRec {
 
 // draw_perspective_spans (rasterize.h:1064-1280): the edges of a run also carry screen z and 1/w (Point3D edges; values at row
 // lrow / rrow of the run and per-row slopes), and the uv of WrQuadSeg are uv / w
-struct WrPerspRec { float lz[4], lzs[4], lw[4], lws[4], rz[4], rzs[4], rw[4], rws[4]; float div; };   // div: WrVsOut::persp_div
+// (a quad has at most four runs; one clipped against the view volume -- clip_side, rasterize.h:1287-1430: up to ten vertices --
+// at most nine)
+#define WR_MAX_QSEG 10
+struct WrPerspRec { float lz[WR_MAX_QSEG], lzs[WR_MAX_QSEG], lw[WR_MAX_QSEG], lws[WR_MAX_QSEG], rz[WR_MAX_QSEG], rzs[WR_MAX_QSEG], rw[WR_MAX_QSEG], rws[WR_MAX_QSEG]; float div; };   // div: WrVsOut::persp_div
 
 struct WrQuadRec {
   int32_t nseg;
   int32_t aa;                       // SWGL_CLIP_FLAG_AA set for this prim
   int32_t base_kind;                // WR_PK_TEX_QUAD: WR_PK_TEX_RGBA8 / TEX_FS / TEX_R8 / TEX_REPEAT / GRADIENT / FILTER / QUAD_MASK
   int32_t pad;                      // perspective: 0 no; 1 the program has no varyings (gl_FragCoord.zw never stepped); 2 it has
-  WrQuadSeg seg[4];
+  WrQuadSeg seg[WR_MAX_QSEG];
   union {                           // the base kind's own side record (the quad record took its place in WrAux)
     WrRepeatRec rep;                // WR_PK_TEX_REPEAT
     WrGradRec grad;                 // WR_PK_GRADIENT

@@ -1219,11 +1219,13 @@ def rotation_about(frame, rng, cx, cy, i):
     return frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
 
 
-def projective_about(a, cx, cy, rr, rng):
+def projective_about(a, cx, cy, rr, rng, strength=(0.15, 0.6)):
     """T(c) . P . A . T(-c): the 2x2 map `a` about (cx, cy) followed by a projective row w = 1 + k . (rotated offset from the
-    centre) with |k . offset| <= 0.6 inside radius rr, so that w stays positive over the prim."""
+    centre) with |k . offset| <= 0.6 inside radius rr, so that w stays positive over the prim.  A `strength` above 1 puts part
+    of the prim at or behind the camera plane (w <= 0): swgl clips it against the view volume first (clip_side,
+    rasterize.h:1287-1430, 1490-1544)."""
     k = rng.uniform(-1.0, 1.0, size=2)
-    k = k / max(float(np.hypot(*k)), 1e-3) * float(rng.uniform(0.15, 0.6)) / rr
+    k = k / max(float(np.hypot(*k)), 1e-3) * float(rng.uniform(*strength)) / rr
     tneg, tpos, rot, pm = np.eye(4), np.eye(4), np.eye(4), np.eye(4)
     tneg[:2, 3] = (-cx, -cy); tpos[:2, 3] = (cx, cy)
     rot[:2, :2] = a
@@ -1799,8 +1801,9 @@ def rotated_rects(width=1024, height=1024, n=70, seed=95, encoding="brush", tile
         m = np.eye(4)
         m[:2, :2] = a
         m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
-        if perspective:
-            m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng)
+        if perspective:      # ("clip": every other prim reaches behind the camera plane)
+            m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng,
+                                 strength=(1.1, 2.6) if (perspective == "clip" and i % 2 == 0) else (0.15, 0.6))
         inv = np.linalg.inv(m)
         tid = frame.add_transform(m.T.astype(np.float32), inv.T.astype(np.float32), axis_aligned=False)   # blocks = columns
         rgba = np.array([[rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, 256), rng.integers(90, 256)]], np.uint8)
@@ -1931,7 +1934,8 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
             m[:2, :2] = a
             m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
             if perspective:      # (see rotated_rects)
-                m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng)
+                m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng,
+                                     strength=(1.1, 2.6) if (perspective == "clip" and i % 3 == 0) else (0.15, 0.6))
                 if i % 2 == 0:
                     flags = 1         # BRUSH_FLAG_PERSPECTIVE_INTERPOLATION (brush encoding): perspective-correct uv
             tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
