@@ -104,6 +104,38 @@
     }                                                                          \
     /* brush_fs, brush_linear_gradient.glsl:66-83 + brush.glsl main() (SWGL:   \
        antialias_brush() == 1, do_clip() == 1) */                              \
+    /* the perspective entry points glsl-to-cxx emits for a program with a */  \
+    /* varying (lib.rs:660-690, 716-741, 3576-3590) */                         \
+    struct InterpPerspective {                                                 \
+      vec2 v_pos;                                                                \
+    };                                                                         \
+    InterpPerspective interp_perspective;                                      \
+    static void read_perspective_inputs(FragmentShaderImpl* impl,              \
+                                        const void* init_, const void* step_) { \
+      Self* self = (Self*)impl;                                                \
+      const InterpInputs* init = (const InterpInputs*)init_;                   \
+      const InterpInputs* step = (const InterpInputs*)step_;                   \
+      Float w = 1.0f / self->gl_FragCoord.w;                                   \
+      self->interp_perspective.v_pos = init_interp(init->v_pos, step->v_pos);        \
+      self->v_pos = self->interp_perspective.v_pos * w;                            \
+      self->interp_step.v_pos = step->v_pos * 4.0f;                                \
+    }                                                                          \
+    ALWAYS_INLINE void step_perspective_inputs(int steps = 4) {                \
+      step_perspective(steps);                                                 \
+      float chunks = steps * 0.25f;                                            \
+      Float w = 1.0f / gl_FragCoord.w;                                         \
+      interp_perspective.v_pos += interp_step.v_pos * chunks;                      \
+      v_pos = w * interp_perspective.v_pos;                                        \
+    }                                                                          \
+    static void run_perspective(FragmentShaderImpl* impl) {                    \
+      Self* self = (Self*)impl;                                                \
+      self->main();                                                              \
+      self->step_perspective_inputs();                                         \
+    }                                                                          \
+    static void skip_perspective(FragmentShaderImpl* impl, int steps) {        \
+      Self* self = (Self*)impl;                                                \
+      self->step_perspective_inputs(steps);                                    \
+    }                                                                          \
     void main() {                                                              \
       vec2 pos = fract(v_pos);                                                 \
       Float offset = dot(pos, vec2(v_scale_dir)) - v_start_offset.x;           \
@@ -131,6 +163,7 @@
     }                                                                          \
     NAME##_frag() {                                                            \
       WRSH_FRAG_WIRING()                                                       \
+      WRSH_FRAG_WIRING_PERSPECTIVE()                                           \
       draw_span_RGBA8_func = &draw_span_RGBA8;                                 \
     }                                                                          \
   };                                                                           \

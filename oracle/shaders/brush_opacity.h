@@ -76,9 +76,41 @@
       float chunks = steps * 0.25f;                                            \
       v_uv += interp_step.v_uv * chunks;                                       \
     }                                                                          \
+    /* the perspective entry points glsl-to-cxx emits for a program with a */  \
+    /* varying (lib.rs:660-690, 716-741, 3576-3590) */                         \
+    struct InterpPerspective {                                                 \
+      vec2 v_uv;                                                                \
+    };                                                                         \
+    InterpPerspective interp_perspective;                                      \
+    static void read_perspective_inputs(FragmentShaderImpl* impl,              \
+                                        const void* init_, const void* step_) { \
+      Self* self = (Self*)impl;                                                \
+      const InterpInputs* init = (const InterpInputs*)init_;                   \
+      const InterpInputs* step = (const InterpInputs*)step_;                   \
+      Float w = 1.0f / self->gl_FragCoord.w;                                   \
+      self->interp_perspective.v_uv = init_interp(init->v_uv, step->v_uv);        \
+      self->v_uv = self->interp_perspective.v_uv * w;                            \
+      self->interp_step.v_uv = step->v_uv * 4.0f;                                \
+    }                                                                          \
+    ALWAYS_INLINE void step_perspective_inputs(int steps = 4) {                \
+      step_perspective(steps);                                                 \
+      float chunks = steps * 0.25f;                                            \
+      Float w = 1.0f / gl_FragCoord.w;                                         \
+      interp_perspective.v_uv += interp_step.v_uv * chunks;                      \
+      v_uv = w * interp_perspective.v_uv;                                        \
+    }                                                                          \
+    static void run_perspective(FragmentShaderImpl* impl) {                    \
+      Self* self = (Self*)impl;                                                \
+      self->shade(mix(self->gl_FragCoord.w, Float(1.0f), Float(self->v_opacity_perspective_vec.y)));                                                              \
+      self->step_perspective_inputs();                                         \
+    }                                                                          \
+    static void skip_perspective(FragmentShaderImpl* impl, int steps) {        \
+      Self* self = (Self*)impl;                                                \
+      self->step_perspective_inputs(steps);                                    \
+    }                                                                          \
     /* brush_fs + main, brush_opacity.glsl:67-83 (2-D path: gl_FragCoord.w == 1) */ \
-    void main() {                                                              \
-      float perspective_divisor = mix(1.0f, 1.0f, v_opacity_perspective_vec.y); \
+    void main() { shade(Float(mix(1.0f, 1.0f, v_opacity_perspective_vec.y))); } \
+    void shade(Float perspective_divisor) {                                    \
       vec2 uv = v_uv * perspective_divisor;                                    \
       uv = clamp(uv, vec2_scalar(v_uv_sample_bounds.x, v_uv_sample_bounds.y),  \
                  vec2_scalar(v_uv_sample_bounds.z, v_uv_sample_bounds.w));     \
@@ -106,6 +138,7 @@
     }                                                                          \
     NAME##_frag() {                                                            \
       WRSH_FRAG_WIRING()                                                       \
+      WRSH_FRAG_WIRING_PERSPECTIVE()                                           \
       draw_span_RGBA8_func = &draw_span_RGBA8;                                 \
     }                                                                          \
   };                                                                           \

@@ -107,6 +107,18 @@ ROTATED += [
     ("near_clipped_images_masked", lambda: scenes.rotated_images(perspective="clip", masked=True, seed=306)),
     ("occluded_near_clipped_images", lambda: scenes.add_occluders(scenes.rotated_images(perspective="clip", seed=305), zmax=60, seed=41)),
 ]
+# The other programs' perspective inputs (glsl-to-cxx lib.rs:660-741): brush_blend, brush_opacity and brush_linear_gradient under
+# projective transforms -- main() on every chunk with the varying divided by the interpolated 1 / w per pixel, with and without
+# BRUSH_FLAG_PERSPECTIVE_INTERPOLATION, alone and behind occluders.  0 differing bytes.
+ROTATED += [
+    ("perspective_filters", lambda: scenes.filter_grid(rotate=True, perspective=True, seed=172)),
+    ("perspective_filters_exact", lambda: scenes.filter_grid(rotate=True, perspective=True, seed=173, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11])),
+    ("perspective_opacity", lambda: scenes.filter_grid(shader="opacity", rotate=True, perspective=True, seed=174)),
+    ("perspective_gradients", lambda: scenes.gradient_grid(rotate=True, perspective=True, seed=162)),
+    ("occluded_perspective_filters", lambda: scenes.add_occluders(scenes.filter_grid(rotate=True, perspective=True, seed=175, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]), zmax=60, seed=45)),
+    ("occluded_perspective_gradients", lambda: scenes.add_occluders(scenes.gradient_grid(rotate=True, perspective=True, seed=163), zmax=60, seed=46)),
+    ("perspective_filters_masked", lambda: scenes.filter_grid(rotate=True, perspective=True, masked=True, seed=176, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11])),
+]
 # Flattened depth rows.  A perspective span flattens the depth row it touches (rasterize.h:1222-1232), and swgl then draws every
 # LATER depth-tested prim on that row chunk by chunk through main(), from the span start, instead of handing the span shader one
 # depth run at a time (:1021-1031).  The setup stage records, per target row, the first depth-tested perspective prim whose span
@@ -152,7 +164,7 @@ ROTATED += [
     ("transforms_simple", lambda: scenes.transforms_simple()),
     ("transforms_simple_quad", lambda: scenes.transforms_simple(encoding="quad")),
 ]
-ROTATED_GOLDEN = ("near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
+ROTATED_GOLDEN = ("perspective_filters_exact", "perspective_opacity", "perspective_gradients", "near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

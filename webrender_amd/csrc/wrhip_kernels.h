@@ -632,8 +632,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
     o.tex_slot = WR_S_GPU_BUFFER_F;
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
-    o.kind = WR_PK_GRADIENT;
-    if (brush_flags & 1) o.kind = WR_PK_UNSUPPORTED;      // perspective interpolation: next
+    o.kind = WR_PK_GRADIENT;     // (v_pos carries no w factor: BRUSH_FLAG_PERSPECTIVE_INTERPOLATION does not enter, persp_div stays < 0)
     return;
   }
   if (image == 7) {
@@ -664,7 +663,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.color = wf4{opacity, opacity, opacity, opacity};
     o.has_color = 1; o.tail_clamp = 1; o.tail_modulate = 1;
     o.kind = tex.format == WR_FMT_RGBA8 ? WR_PK_TEX_RGBA8 : WR_PK_UNSUPPORTED;
-    if (brush_flags & 1) o.kind = WR_PK_UNSUPPORTED;      // perspective interpolation: next
+    o.persp_div = persp;           // brush_opacity.glsl:68-70, as brush_image
     return;
   }
   if (image == 8) {
@@ -730,7 +729,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.tail_clamp = 1; o.tail_modulate = 0;
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
     o.kind = WR_PK_FILTER;
-    if (brush_flags & 1) { o.kind = WR_PK_UNSUPPORTED; return; }   // perspective interpolation: next
+    o.persp_div = persp;           // main(): v_uv * mix(gl_FragCoord.w, 1.0, perspective_interpolate) (brush_blend.glsl:93-95)
     const float amount = float(data1.z) / 65536.0f;
     const int op = data1.y & 0xffff;
     F->op = op; F->amount = amount; F->table_address = 0;
@@ -1939,7 +1938,9 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     bool inside = true;
     for (int n = 0; n < 4; n++) inside = inside && (o.pz[n] > -o.pw[n]) && (o.pz[n] < o.pw[n]);
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
-    const bool ptex = (d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS);
+    // (and brush_opacity, brush_blend, brush_linear_gradient: main() on the perspective-correct varying)
+    const bool ptex = ((d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS)) ||
+                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA));
     if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     clipped = !inside;           // a vertex outside the near / far planes: clip_side first (wr_persp_clipped_walk)
     if (clipped) {
@@ -2015,7 +2016,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || (o.kind == WR_PK_SOLID && masked)))) {
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || (o.kind == WR_PK_SOLID && masked)))) {
       atomicAdd(&cnt->perspective_prims, 1u); return;
     }
     if (!solidq && !texq) {
@@ -3950,6 +3951,8 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
 struct WrGrad4 { WrWide v[4]; };
 __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradRec* Gp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 __device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+__device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, float cu, float cv);
+__device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDrawDesc* D, float lu, float lv);
 __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 // One pixel of a textured prim on a general quad and / or with swgl_antiAlias (WR_PK_TEX_QUAD): this row's span and the
 // pixel's coverage as in wr_quad_pixel_rgba8, the edge interpolants stepped row by row (Edge::nextRow), then the base
@@ -4048,7 +4051,10 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     }
     cu = cu + Pl.uv_add[0]; cv = cv + Pl.uv_add[1];
     if (Pl.flags & WR_PF_TAIL_CLAMP) { cu = wr_clamp(cu, Pl.uv_bounds[0], Pl.uv_bounds[2]); cv = wr_clamp(cv, Pl.uv_bounds[1], Pl.uv_bounds[3]); }
-    src = wr_tex_tail_texel(Pl, t, cu, cv);
+    // the program's main() with its varying at this pixel
+    if (Q.base_kind == WR_PK_FILTER) src = wr_filter_eval(&Pl, &Q.filt, D, cu, cv);
+    else if (Q.base_kind == WR_PK_GRADIENT) src = wr_gradient_main(&Q.grad, D, cu, cv);
+    else src = wr_tex_tail_texel(Pl, t, cu, cv);
   } else if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {
     // shader replays that take their interpolants from the prim: hand them this row as a one-row axis-aligned prim (the span
     // [s0, s1), the edges' x and interpolants on this row, no row stepping left to do)
@@ -4398,6 +4404,40 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
   }
   return out;
 }
+// main() of the gradient programs for one pixel whose v_pos is (lu, lv) (brush_linear_gradient.glsl:66-83, gradient.glsl:42-61; the
+// radial / conic quad patterns): what the loop above evaluates for the pixels the span shader leaves -- and what every pixel of
+// a prim under a perspective transform runs, with the perspective-correct v_pos
+__device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDrawDesc* D, float lu, float lv) {
+  const WrGradRec& G = *Gp;
+  const WrTexDesc& gb = D->tex[WR_S_GPU_BUFFER_F];
+  const float sdx = G.scale_dir[0], sdy = G.scale_dir[1];
+  float offset = (G.no_tile ? lu : wr_fract(lu)) * sdx + (G.no_tile ? lv : wr_fract(lv)) * sdy - G.start_offset;
+  if (G.radial == 1) offset = sqrtf(lu * lu + lv * lv) - G.start_offset;
+  if (G.radial == 3) {
+    const float ax_ = fabsf(lu), ay_ = fabsf(lv);
+    const float slope = wr_min(ax_, ay_) / wr_max(ax_, ay_);
+    const float s2 = slope * slope;
+    float r = ((-0.0464964749f * s2 + 0.15931422f) * s2 - 0.327622764f) * s2 * slope + slope;
+    r = ay_ > ax_ ? 1.57079637f - r : r;
+    r = lu < 0.0f ? 3.14159274f - r : r;
+    r = r * copysignf(1.0f, lv);
+    offset = wr_fract((r + G.conic_angle) / (2.0f * 3.141592653589793f)) * G.conic_scale - G.start_offset;
+  }
+  if (G.radial == 2) {
+    const float cur = atan2f(lv - G.scale_dir[1], lu - G.scale_dir[0]) + G.conic_angle;
+    offset = wr_fract(cur / (2.0f * 3.141592653589793f)) * G.conic_scale - G.start_offset;
+  }
+  offset -= floorf(offset) * G.repeat;
+  const float xe = wr_clamp(1.0f + offset * 128.0f, 0.0f, 1.0f + 128.0f);
+  const float ei = floorf(xe), ef = xe - ei;
+  const int addr = G.address + 2 * int(ei);
+  const wf4 t0 = wr_fetch_f(gb, int(unsigned(addr) % 1024u), int(unsigned(addr) / 1024u));
+  const wf4 t1 = wr_fetch_f(gb, int(unsigned(addr) % 1024u) + 1, int(unsigned(addr) / 1024u));
+  uint32_t pc[2];
+  wr_pack_color(wf4{t0.x + t1.x * ef, t0.y + t1.y * ef, t0.z + t1.z * ef, t0.w + t1.w * ef}, pc);
+  WrWide w; w.bg = pc[0]; w.ra = pc[1];
+  return w;
+}
 
 // ---------------------------------------------------------------------------
 // cs_blur, one destination pixel.  Returns the unpacked source value(s) that go
@@ -4434,14 +4474,21 @@ WR_DEVICE float wr_glsl_pow(float x, float y) {     // glsl.h:797-799
   return (x == 0.0f || x == 1.0f) ? x : wr_approx_pow2(wr_approx_log2(x) * y);
 }
 
+__device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, float cu, float cv);
 __device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
   const WrPrim& P = *Pp;
-  const WrFilterRec& F = *Fp;
   const WrTexDesc& t = D->tex[P.tex_slot];
   // v_uv of this pixel as the 4-wide fragment loop steps it, clamped to v_uv_sample_bounds
   const WrTexRow r = wr_tex_row(P, t, y, runs, x);
   float cu, cv;
   wr_tex_tail_uv(P, r, x - r.x0, cu, cv);
+  return wr_filter_eval(Pp, Fp, D, cu, cv);
+}
+// ... from the (clamped) uv on: texture(), CalculateFilter, the fragment colour
+__device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, float cu, float cv) {
+  const WrPrim& P = *Pp;
+  const WrFilterRec& F = *Fp;
+  const WrTexDesc& t = D->tex[P.tex_slot];
   // texture(sColor0, uv): texture.h:1028-1071 (linear RGBA8, 7-bit fractions) / nearest
   const float W = float(t.width), H = float(t.height);
   float cr, cg, cb, ca;

@@ -494,8 +494,9 @@ struct WrQuadRec {
     WrGradRec grad;                 // WR_PK_GRADIENT
     WrFilterRec filt;               // WR_PK_FILTER
     WrClipRec clip;                 // WR_PK_QUAD_MASK
-    WrPerspRec persp;               // pad != 0 (solid colours, plain textures)
   };
+  WrPerspRec persp;                 // pad != 0: screen z and 1 / w of the runs' edges (beside the base kind's record: filters and gradients
+                                    // under perspective need both)
 };
 
 // Depth runs of one target row of one prim (draw_depth_span, rasterize.h:612-664): with depth testing on, swgl hands the

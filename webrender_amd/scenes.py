@@ -1207,8 +1207,9 @@ def build_gradient_lut(stops, reverse=False):
     return entries.reshape(-1, 4)
 
 
-def rotation_about(frame, rng, cx, cy, i):
-    """A non-axis-aligned transform (rotation, every fourth one skewed as well) about (cx, cy) -> transform id."""
+def rotation_about(frame, rng, cx, cy, i, persp_radius=None):
+    """A non-axis-aligned transform (rotation, every fourth one skewed as well) about (cx, cy) -> transform id.
+    `persp_radius`: with a projective row on top (projective_about: w varies over the prim, > 0 inside that radius)."""
     th = float(rng.uniform(0, 2 * np.pi)) if i % 6 else float(rng.choice([np.pi / 4, np.pi / 2, 0.01]))
     sk = float(rng.uniform(-0.4, 0.4)) if i % 4 == 1 else 0.0
     c, sn = np.cos(th), np.sin(th)
@@ -1216,6 +1217,8 @@ def rotation_about(frame, rng, cx, cy, i):
     m = np.eye(4)
     m[:2, :2] = a
     m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+    if persp_radius is not None:
+        m = projective_about(a, cx, cy, persp_radius * (1.0 + abs(sk)), rng)
     return frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
 
 
@@ -1239,7 +1242,7 @@ def rotated_bounds(rect):
     return (cx - rad, cy - rad, cx + rad, cy + rad)
 
 
-def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only=None, fractional=True, rotate=False):
+def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only=None, fractional=True, rotate=False, perspective=False):
     """Opaque-pass gradients on a disjoint grid in the top band (see image_grid on why),
     translucent / overlapping ones below it in the alpha pass."""
     rng = np.random.default_rng(seed)
@@ -1282,7 +1285,11 @@ def gradient_grid(width=1024, height=1024, n=60, seed=61, tile_filter=None, only
         spec = frame.gpu_cache.push([[sp[0], sp[1], ep[0], ep[1]], [float(extend), stretch[0], stretch[1], 0.0]])
         tid, bb = 0, rect
         if rotate and not opaque_pass and k % 3 != 2:       # alpha-pass gradients under a rotation / skew: spans on general quads, AA edges
-            tid, bb = rotation_about(frame, rng, (x0 + x1) / 2, (y0 + y1) / 2, k), rotated_bounds(rect)
+            tid = rotation_about(frame, rng, (x0 + x1) / 2, (y0 + y1) / 2, k, float(np.hypot(w, h)) * 0.5 if perspective else None)
+            bb = rotated_bounds(rect)
+            if perspective:
+                rr = float(np.hypot(w, h)) * 1.4 + 4
+                bb = ((x0 + x1) / 2 - rr, (y0 + y1) / 2 - rr, (x0 + x1) / 2 + rr, (y0 + y1) / 2 + rr)
         prims.append((rect, spec, lut, opaque_pass, tid, bb))
 
     gx = 4.0
@@ -1343,7 +1350,7 @@ CT_IDENTITY, CT_TABLE, CT_DISCRETE, CT_LINEAR, CT_GAMMA = 0, 1, 2, 3, 4
 
 
 def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=None, ops=None, only=None,
-                fractional=True, masked=False, shader="blend", rotate=False):
+                fractional=True, masked=False, shader="blend", rotate=False, perspective=False):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -1446,7 +1453,8 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
     if rotate:       # alpha-pass filters under a rotation / skew
         for k, pr in enumerate(prims):
             if not pr[2] and k % 3 != 2:
-                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k)
+                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k,
+                                         float(np.hypot(pr[0][2] - pr[0][0], pr[0][3] - pr[0][1])) * 0.5 if perspective else None)
     t_mask, clip_tasks = None, [None] * len(prims)
     if masked:
         t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
@@ -1465,6 +1473,10 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
             if only is not None and zi not in only:
                 continue
             bb = rotated_bounds(rect) if tids[zi] else rect
+            if tids[zi] and perspective:
+                rr = float(np.hypot(rect[2] - rect[0], rect[3] - rect[1])) * 1.4 + 4
+                cxx, cyy = (rect[0] + rect[2]) / 2, (rect[1] + rect[3]) / 2
+                bb = (cxx - rr, cyy - rr, cxx + rr, cyy + rr)
             if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
             if shader == "opacity":     # brush_opacity: user data = (image source address, opacity * 65536)
@@ -1474,7 +1486,8 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
                 ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, tids[zi], task, (addr, mode, ud, 0))
             ct = None if opaque else clip_tasks[zi]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
-            (op if opaque else al).append(frame.brush_instance(ph, clip_addr, edge_flags=15))
+            # (BRUSH_FLAG_PERSPECTIVE_INTERPOLATION on every other perspective prim: perspective-correct uv; screen-linear otherwise)
+            (op if opaque else al).append(frame.brush_instance(ph, clip_addr, edge_flags=15, brush_flags=1 if (perspective and tids[zi] and zi % 2 == 0) else 0))
         keys = ("brush_opacity", "brush_opacity ALPHA_PASS,ANTIALIASING") if shader == "opacity" else ("brush_blend", "brush_blend ALPHA_PASS")
         if op:
             target.opaque.append(Step(keys[0], "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32),
