@@ -278,10 +278,33 @@ struct ps_quad_conic_gradient_frag : FragmentShaderImpl, ps_quad_conic_gradient_
     gl_FragColor = output_color;
   }
 
+  // the perspective entry points glsl-to-cxx emits for a program with a varying (lib.rs:660-690, 716-741, 3576-3590)
+  struct InterpPerspective {
+    vec2 v_pos;
+  };
+  InterpPerspective interp_perspective;
+  static void read_perspective_inputs(FragmentShaderImpl* impl, const void* init_, const void* step_) {
+    Self* self = (Self*)impl;
+    const InterpInputs* init = (const InterpInputs*)init_;
+    const InterpInputs* step = (const InterpInputs*)step_;
+    Float w = 1.0f / self->gl_FragCoord.w;
+    self->interp_perspective.v_pos = init_interp(init->v_pos, step->v_pos);
+    self->v_pos = self->interp_perspective.v_pos * w;
+    self->interp_step.v_pos = step->v_pos * 4.0f;
+  }
+  ALWAYS_INLINE void step_perspective_inputs(int steps = 4) {
+    step_perspective(steps);
+    float chunks = steps * 0.25f;
+    Float w = 1.0f / gl_FragCoord.w;
+    interp_perspective.v_pos += interp_step.v_pos * chunks;
+    v_pos = w * interp_perspective.v_pos;
+  }
+  WRSH_FRAG_ABI_PERSPECTIVE(Self)
+
   WRSH_FRAG_ABI(Self)
   ps_quad_conic_gradient_frag() {
     WRSH_FRAG_WIRING()
-    enable_perspective();
+    WRSH_FRAG_WIRING_PERSPECTIVE()
   }
 };
 

@@ -272,6 +272,29 @@ struct ps_quad_radial_gradient_frag : FragmentShaderImpl, ps_quad_radial_gradien
     swgl_commitRadialGradientRGBA8(sGpuBufferF, address, 128.0f, v_gradient_repeat.x != 0.0f, v_pos, v_start_radius.x);
   }
 
+  // the perspective entry points glsl-to-cxx emits for a program with a varying (lib.rs:660-690, 716-741, 3576-3590)
+  struct InterpPerspective {
+    vec2 v_pos;
+  };
+  InterpPerspective interp_perspective;
+  static void read_perspective_inputs(FragmentShaderImpl* impl, const void* init_, const void* step_) {
+    Self* self = (Self*)impl;
+    const InterpInputs* init = (const InterpInputs*)init_;
+    const InterpInputs* step = (const InterpInputs*)step_;
+    Float w = 1.0f / self->gl_FragCoord.w;
+    self->interp_perspective.v_pos = init_interp(init->v_pos, step->v_pos);
+    self->v_pos = self->interp_perspective.v_pos * w;
+    self->interp_step.v_pos = step->v_pos * 4.0f;
+  }
+  ALWAYS_INLINE void step_perspective_inputs(int steps = 4) {
+    step_perspective(steps);
+    float chunks = steps * 0.25f;
+    Float w = 1.0f / gl_FragCoord.w;
+    interp_perspective.v_pos += interp_step.v_pos * chunks;
+    v_pos = w * interp_perspective.v_pos;
+  }
+  WRSH_FRAG_ABI_PERSPECTIVE(Self)
+
   WRSH_FRAG_ABI(Self)
   static int draw_span_RGBA8(FragmentShaderImpl* impl) {
     Self* self = (Self*)impl;
@@ -281,7 +304,7 @@ struct ps_quad_radial_gradient_frag : FragmentShaderImpl, ps_quad_radial_gradien
   ps_quad_radial_gradient_frag() {
     WRSH_FRAG_WIRING()
     draw_span_RGBA8_func = &draw_span_RGBA8;
-    enable_perspective();
+    WRSH_FRAG_WIRING_PERSPECTIVE()
   }
 };
 

@@ -1940,7 +1940,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
     // (and brush_opacity, brush_blend, brush_linear_gradient: main() on the perspective-correct varying)
     const bool ptex = ((d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS)) ||
-                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA));
+                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
+                                                                              d.shader == WR_SH_PS_QUAD_RADIAL_GRADIENT || d.shader == WR_SH_PS_QUAD_CONIC_GRADIENT));
     if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     clipped = !inside;           // a vertex outside the near / far planes: clip_side first (wr_persp_clipped_walk)
     if (clipped) {

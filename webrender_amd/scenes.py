@@ -2638,7 +2638,7 @@ def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, n_cgrads=
 # ---------------------------------------------------------------------------
 # ps_quad_radial_gradient / ps_quad_conic_gradient: gradient patterns on the quad path (quad.rs pattern kinds; the
 # QuadHeader's pattern_input = (address of the two gradient blocks in sGpuBufferF, address of the 128-entry stop table)).
-def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, only=None, rotate=False):
+def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, only=None, rotate=False, perspective=False):
     rng, rects = random_rects(n, width, height, 24, 380, seed, True)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     prims = []
@@ -2667,8 +2667,12 @@ def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, on
             ratio = 1.0 if i % 4 else float(rng.uniform(0.4, 2.5))
             blocks = [[c[0], c[1], 1.0, 1.0], [r0, r1, ratio, repeat]]
         params = frame.gpu_buffer_f.push(blocks)
-        tid = rotation_about(frame, rng, (x0 + x1) / 2, (y0 + y1) / 2, i) if (rotate and i % 3 != 1) else 0
-        prims.append((rects[i], conic, params, table, tid, rotated_bounds(tuple(float(v) for v in rects[i])) if tid else tuple(rects[i])))
+        tid = rotation_about(frame, rng, (x0 + x1) / 2, (y0 + y1) / 2, i, float(np.hypot(x1 - x0, y1 - y0)) * 0.5 if perspective else None) if (rotate and i % 3 != 1) else 0
+        bb = rotated_bounds(tuple(float(v) for v in rects[i])) if tid else tuple(rects[i])
+        if tid and perspective:
+            rr = float(np.hypot(x1 - x0, y1 - y0)) * 1.4 + 4
+            bb = ((x0 + x1) / 2 - rr, (y0 + y1) / 2 - rr, (x0 + x1) / 2 + rr, (y0 + y1) / 2 + rr)
+        prims.append((rects[i], conic, params, table, tid, bb))
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
