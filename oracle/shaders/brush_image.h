@@ -240,12 +240,10 @@
     }                                                                          \
     /* main() as generated, with gl_FragCoord.w read per lane (:343-377); */   \
     /* the 2-D main() below is the same function with w == 1 folded in. */     \
-    /* REPETITION keys under perspective are not restated. */                  \
     void main_w() {                                                            \
       Float perspective_divisor =                                              \
           mix(gl_FragCoord.w, Float(1.0f), Float(v_perspective.x));            \
-      vec2 repeated_uv = v_uv * perspective_divisor +                          \
-                         vec2_scalar(v_uv_bounds.x, v_uv_bounds.y);            \
+      vec2 repeated_uv = repeated_uvs(perspective_divisor);                    \
       vec2 uv = clamp(repeated_uv,                                             \
                       vec2_scalar(v_uv_sample_bounds.x, v_uv_sample_bounds.y), \
                       vec2_scalar(v_uv_sample_bounds.z, v_uv_sample_bounds.w)); \
@@ -272,7 +270,8 @@
       gl_FragColor = color;                                                    \
     }                                                                          \
     /* compute_repeated_uvs: :318-341 */                                       \
-    vec2 repeated_uvs(float perspective_divisor) const {                       \
+    template <typename T>                                                      \
+    vec2 repeated_uvs(T perspective_divisor) const {                           \
       if (REPETITION) {                                                        \
         vec2_scalar uv_size = vec2_scalar(v_uv_bounds.z - v_uv_bounds.x,       \
                                           v_uv_bounds.w - v_uv_bounds.y);      \
@@ -367,9 +366,7 @@
     }                                                                          \
     NAME##_frag() {                                                            \
       WRSH_FRAG_WIRING()                                                       \
-      if (!REPETITION) {                                                       \
-        WRSH_FRAG_WIRING_PERSPECTIVE()                                         \
-      }                                                                        \
+      WRSH_FRAG_WIRING_PERSPECTIVE()                                           \
       /* no span function under ALPHA_PASS + DUAL_SOURCE_BLENDING (:386) */    \
       if (!(ALPHA_PASS && DUAL)) draw_span_RGBA8_func = &draw_span_RGBA8;      \
     }                                                                          \

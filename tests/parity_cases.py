@@ -118,6 +118,10 @@ ROTATED += [
     ("occluded_perspective_filters", lambda: scenes.add_occluders(scenes.filter_grid(rotate=True, perspective=True, seed=175, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]), zmax=60, seed=45)),
     ("occluded_perspective_gradients", lambda: scenes.add_occluders(scenes.gradient_grid(rotate=True, perspective=True, seed=163), zmax=60, seed=46)),
     ("perspective_filters_masked", lambda: scenes.filter_grid(rotate=True, perspective=True, masked=True, seed=176, ops=[0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11])),
+    # brush_image ANTIALIASING,REPETITION: compute_repeated_uvs on the perspective-correct uv (also clipped against the view volume)
+    ("perspective_images_repeat", lambda: scenes.rotated_images(perspective="all", repeat=True, seed=108)),
+    ("perspective_images_repeat_mixed", lambda: scenes.rotated_images(perspective=True, repeat=True, seed=107)),
+    ("near_clipped_images_repeat", lambda: scenes.rotated_images(perspective="clip", repeat=True, seed=109)),
     # ps_quad_radial_gradient / ps_quad_conic_gradient: the quad patterns' main() on the perspective-correct v_pos
     ("perspective_quad_gradients", lambda: scenes.quad_gradients(rotate=True, perspective=True, seed=185)),
     ("occluded_perspective_quad_gradients", lambda: scenes.add_occluders(scenes.quad_gradients(rotate=True, perspective=True, seed=186), zmax=60, seed=47)),
@@ -167,7 +171,7 @@ ROTATED += [
     ("transforms_simple", lambda: scenes.transforms_simple()),
     ("transforms_simple_quad", lambda: scenes.transforms_simple(encoding="quad")),
 ]
-ROTATED_GOLDEN = ("perspective_quad_gradients", "perspective_filters_exact", "perspective_opacity", "perspective_gradients", "near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
+ROTATED_GOLDEN = ("perspective_images_repeat", "perspective_quad_gradients", "perspective_filters_exact", "perspective_opacity", "perspective_gradients", "near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

@@ -306,14 +306,14 @@ def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
 
 
 def test_unimplemented_perspective_prims_are_reported(hostsim, capfd):
-    """Perspective prims outside the implemented set (here: repeating image brushes, whose read_perspective_inputs are not
-    restated) are counted by the setup stage, reported on stderr at Finish and raise GL_INVALID_OPERATION -- not drawn wrongly,
-    not dropped silently; the rest of the frame is drawn."""
+    """Perspective prims outside the implemented set (here: ps_quad_mask clips, whose perspective inputs -- a vec4 varying and
+    fwidth() of its quotient -- are not restated) are counted by the setup stage, reported on stderr at Finish and raise
+    GL_INVALID_OPERATION -- not drawn wrongly, not dropped silently; the rest of the frame is drawn."""
     from webrender_amd import glapi, glconst as G
     from webrender_amd.renderer import Renderer
     gl = glapi.GL(hostsim)
     r = Renderer(gl, 512, 512)
-    r.render(scenes.rotated_images(width=512, height=512, n=30, perspective=True, repeat=True, seed=5))
+    r.render(scenes.quad_masks(width=512, height=512, n=30, rotate=True, perspective=True, seed=5))
     r.finish()
     assert gl.GetError() == G.GL_INVALID_OPERATION
     assert gl.GetError() == 0

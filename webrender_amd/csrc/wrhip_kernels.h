@@ -1940,7 +1940,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
     // (and brush_opacity, brush_blend, brush_linear_gradient: main() on the perspective-correct varying)
     const bool ptex = ((d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS)) ||
-                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
+                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_TEX_REPEAT && o.persp_div >= 0.0f) || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
                                                                               d.shader == WR_SH_PS_QUAD_RADIAL_GRADIENT || d.shader == WR_SH_PS_QUAD_CONIC_GRADIENT));
     if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     clipped = !inside;           // a vertex outside the near / far planes: clip_side first (wr_persp_clipped_walk)
@@ -2017,7 +2017,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || (o.kind == WR_PK_SOLID && masked)))) {
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || (o.kind == WR_PK_SOLID && masked)))) {
       atomicAdd(&cnt->perspective_prims, 1u); return;
     }
     if (!solidq && !texq) {
@@ -2902,6 +2902,22 @@ WR_DEVICE void wr_tile_repeat_uv(float u, float v, const float (&tile_repeat)[2]
   }
   fu = u - floorf(u); fv = v - floorf(v);
 }
+// main() of the REPETITION keys for one pixel whose v_uv (times the perspective divisor) is (lu, lv): compute_repeated_uvs
+// (brush_image.glsl:318-341), the clamp to v_uv_sample_bounds, texture()
+WR_DEVICE WrWide wr_repeat_main(const WrPrim& P, const WrRepeatRec& R, const WrTexDesc& t, float lu, float lv) {
+  const float usx = R.uv_repeat[2] - R.uv_repeat[0], usy = R.uv_repeat[3] - R.uv_repeat[1];
+  float ru, rv;
+  if (R.alpha_pass) {
+    const float cu = wr_max(lu, 0.0f), cv = wr_max(lv, 0.0f);
+    ru = (cu - floorf(cu)) * usx + R.uv_repeat[0]; rv = (cv - floorf(cv)) * usy + R.uv_repeat[1];
+    if (cu >= R.tile_repeat[0]) ru = R.uv_repeat[2];
+    if (cv >= R.tile_repeat[1]) rv = R.uv_repeat[3];
+  } else {
+    ru = (lu - floorf(lu)) * usx + R.uv_repeat[0]; rv = (lv - floorf(lv)) * usy + R.uv_repeat[1];
+  }
+  ru = wr_clamp(ru, P.uv_bounds[0], P.uv_bounds[2]); rv = wr_clamp(rv, P.uv_bounds[1], P.uv_bounds[3]);
+  return wr_tex_tail_texel(P, t, ru, rv);
+}
 WR_DEVICE WrWide wr_repeat_pixel_row(const WrPrim& P, const WrRepeatRec& R, const WrTexDesc& t, const WrTexRow& r, int n) {
   const int span = R.no_span ? 0 : r.span;
   const float W = float(t.width), H = float(t.height);
@@ -2914,18 +2930,7 @@ WR_DEVICE WrWide wr_repeat_pixel_row(const WrPrim& P, const WrRepeatRec& R, cons
       lu = lu + (r.su * 4.0f) * chunks; lv = lv + (r.sv * 4.0f) * chunks;
     }
     lu = wr_accum(lu, (r.su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (r.sv * 4.0f) * 1.0f, m);
-    const float usx = R.uv_repeat[2] - R.uv_repeat[0], usy = R.uv_repeat[3] - R.uv_repeat[1];
-    float ru, rv;
-    if (R.alpha_pass) {
-      const float cu = wr_max(lu, 0.0f), cv = wr_max(lv, 0.0f);
-      ru = (cu - floorf(cu)) * usx + R.uv_repeat[0]; rv = (cv - floorf(cv)) * usy + R.uv_repeat[1];
-      if (cu >= R.tile_repeat[0]) ru = R.uv_repeat[2];
-      if (cv >= R.tile_repeat[1]) rv = R.uv_repeat[3];
-    } else {
-      ru = (lu - floorf(lu)) * usx + R.uv_repeat[0]; rv = (lv - floorf(lv)) * usy + R.uv_repeat[1];
-    }
-    ru = wr_clamp(ru, P.uv_bounds[0], P.uv_bounds[2]); rv = wr_clamp(rv, P.uv_bounds[1], P.uv_bounds[3]);
-    return wr_tex_tail_texel(P, t, ru, rv);
+    return wr_repeat_main(P, R, t, lu, lv);
   }
   const int k = n & 3, c = n >> 2, total = span >> 2;
   float ux[4], uy[4];
@@ -4053,7 +4058,8 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     cu = cu + Pl.uv_add[0]; cv = cv + Pl.uv_add[1];
     if (Pl.flags & WR_PF_TAIL_CLAMP) { cu = wr_clamp(cu, Pl.uv_bounds[0], Pl.uv_bounds[2]); cv = wr_clamp(cv, Pl.uv_bounds[1], Pl.uv_bounds[3]); }
     // the program's main() with its varying at this pixel
-    if (Q.base_kind == WR_PK_FILTER) src = wr_filter_eval(&Pl, &Q.filt, D, cu, cv);
+    if (Q.base_kind == WR_PK_TEX_REPEAT) src = wr_repeat_main(Pl, Q.rep, t, cu, cv);
+    else if (Q.base_kind == WR_PK_FILTER) src = wr_filter_eval(&Pl, &Q.filt, D, cu, cv);
     else if (Q.base_kind == WR_PK_GRADIENT) src = wr_gradient_main(&Q.grad, D, cu, cv);
     else src = wr_tex_tail_texel(Pl, t, cu, cv);
   } else if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {

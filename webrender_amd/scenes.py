@@ -1507,7 +1507,7 @@ def filter_grid(width=1024, height=1024, n=72, seed=71, atlas=1024, tile_filter=
 # ps_quad_mask: rounded-rectangle clips applied to quads.  The quad pattern is drawn first
 # (ps_quad_textured, solid colour), then one MaskInstance per clip multiplies the same pixels by the
 # clip's coverage (renderer: set_blend_mode_multiply; quad.rs / gpu_types.rs:618-624).
-def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractional=True, only=None, rotate=False):
+def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractional=True, only=None, rotate=False, perspective=False):
     from .frame import QF_APPLY_DEVICE_CLIP
     QF_IS_MASK = 16
     rng, rects = random_rects(n, width, height, 48, 360, seed, fractional)
@@ -1538,8 +1538,13 @@ def quad_masks(width=1024, height=1024, n=90, seed=81, tile_filter=None, fractio
     if rotate:       # quads (and the clips that live in their space) under a rotation / skew
         for i in range(n):
             if i % 3 != 2:
-                tids[i] = rotation_about(frame, rng, (rects[i][0] + rects[i][2]) / 2, (rects[i][1] + rects[i][3]) / 2, i)
+                tids[i] = rotation_about(frame, rng, (rects[i][0] + rects[i][2]) / 2, (rects[i][1] + rects[i][3]) / 2, i,
+                                         float(np.hypot(rects[i][2] - rects[i][0], rects[i][3] - rects[i][1])) * 0.5 if perspective else None)
                 bounds[i] = rotated_bounds(tuple(float(v) for v in rects[i]))
+                if perspective:
+                    rr = float(np.hypot(rects[i][2] - rects[i][0], rects[i][3] - rects[i][1])) * 1.4 + 4
+                    cxx, cyy = (rects[i][0] + rects[i][2]) / 2, (rects[i][1] + rects[i][3]) / 2
+                    bounds[i] = (cxx - rr, cyy - rr, cxx + rr, cyy + rr)
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
