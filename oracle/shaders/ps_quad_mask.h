@@ -355,11 +355,33 @@ struct NAME##_frag : FragmentShaderImpl, NAME##_vert { \
     gl_FragColor = output_color; \
   } \
  \
+  /* the perspective entry points glsl-to-cxx emits for a program with a varying (lib.rs:660-690, 716-741, 3576-3590) */ \
+  struct InterpPerspective { \
+    vec4 vClipLocalPos; \
+  }; \
+  InterpPerspective interp_perspective; \
+  static void read_perspective_inputs(FragmentShaderImpl* impl, const void* init_, const void* step_) { \
+    Self* self = (Self*)impl; \
+    const InterpInputs* init = (const InterpInputs*)init_; \
+    const InterpInputs* step = (const InterpInputs*)step_; \
+    Float w = 1.0f / self->gl_FragCoord.w; \
+    self->interp_perspective.vClipLocalPos = init_interp(init->vClipLocalPos, step->vClipLocalPos); \
+    self->vClipLocalPos = self->interp_perspective.vClipLocalPos * w; \
+    self->interp_step.vClipLocalPos = step->vClipLocalPos * 4.0f; \
+  } \
+  ALWAYS_INLINE void step_perspective_inputs(int steps = 4) { \
+    step_perspective(steps); \
+    float chunks = steps * 0.25f; \
+    Float w = 1.0f / gl_FragCoord.w; \
+    interp_perspective.vClipLocalPos += interp_step.vClipLocalPos * chunks; \
+    vClipLocalPos = w * interp_perspective.vClipLocalPos; \
+  } \
+  WRSH_FRAG_ABI_PERSPECTIVE(Self) \
   WRSH_FRAG_ABI(Self) \
  \
   NAME##_frag() { \
     WRSH_FRAG_WIRING() \
-    enable_perspective(); \
+    WRSH_FRAG_WIRING_PERSPECTIVE() \
   } \
 }; \
   WRSH_PROGRAM(NAME, KEYSTR)

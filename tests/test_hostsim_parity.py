@@ -306,14 +306,19 @@ def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
 
 
 def test_unimplemented_perspective_prims_are_reported(hostsim, capfd):
-    """Perspective prims outside the implemented set (here: ps_quad_mask clips, whose perspective inputs -- a vec4 varying and
-    fwidth() of its quotient -- are not restated) are counted by the setup stage, reported on stderr at Finish and raise
-    GL_INVALID_OPERATION -- not drawn wrongly, not dropped silently; the rest of the frame is drawn."""
+    """Perspective prims outside the implemented set (here: brush_mix_blend, which has no general-quad path) are counted by the
+    setup stage, reported on stderr at Finish and raise GL_INVALID_OPERATION -- not drawn wrongly, not dropped silently; the
+    rest of the frame is drawn."""
     from webrender_amd import glapi, glconst as G
     from webrender_amd.renderer import Renderer
     gl = glapi.GL(hostsim)
     r = Renderer(gl, 512, 512)
-    r.render(scenes.quad_masks(width=512, height=512, n=30, rotate=True, perspective=True, seed=5))
+    fr = scenes.mix_blend_grid(width=512, height=512, n=12, seed=5)
+    m = scenes.projective_about(np.eye(2), 256.0, 256.0, 400.0, np.random.default_rng(3))
+    tid = fr.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
+    hi = fr.prim_headers_i.data
+    hi[0:2 * 12:4, 2] = tid                  # every other prim under the projective transform ([z, specific, transform id, task])
+    r.render(fr)
     r.finish()
     assert gl.GetError() == G.GL_INVALID_OPERATION
     assert gl.GetError() == 0

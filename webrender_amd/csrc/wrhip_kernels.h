@@ -1940,7 +1940,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
     // (and brush_opacity, brush_blend, brush_linear_gradient: main() on the perspective-correct varying)
     const bool ptex = ((d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS)) ||
-                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_TEX_REPEAT && o.persp_div >= 0.0f) || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
+                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_QUAD_MASK && auxp->clip.w == 1.0f) || (o.kind == WR_PK_TEX_REPEAT && o.persp_div >= 0.0f) || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
                                                                               d.shader == WR_SH_PS_QUAD_RADIAL_GRADIENT || d.shader == WR_SH_PS_QUAD_CONIC_GRADIENT));
     if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     clipped = !inside;           // a vertex outside the near / far planes: clip_side first (wr_persp_clipped_walk)
@@ -2017,7 +2017,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || (o.kind == WR_PK_SOLID && masked)))) {
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked)))) {
       atomicAdd(&cnt->perspective_prims, 1u); return;
     }
     if (!solidq && !texq) {
@@ -3960,6 +3960,7 @@ __device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterR
 __device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, float cu, float cv);
 __device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDrawDesc* D, float lu, float lv);
 __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+WR_DEVICE WrWide wr_quad_mask_eval(const WrClipRec& C, float f0x, float f0y, float f1x, float f1y, float qx, float qy);
 // One pixel of a textured prim on a general quad and / or with swgl_antiAlias (WR_PK_TEX_QUAD): this row's span and the
 // pixel's coverage as in wr_quad_pixel_rgba8, the edge interpolants stepped row by row (Edge::nextRow), then the base
 // kind's span shader / main() evaluation of pixel x - span.start, DO_AA ahead of the clip mask (blend.h:452-460).
@@ -4044,11 +4045,31 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     if (!wr_isfinite(stepScale)) stepScale = 0.0f;
     const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale, sw = (wr - wl) * stepScale;
     const float start = (float(s0) + 0.5f) - xl;
-    float pu = Lu + su * start, pv = Lv + sv * start, fw = wl + sw * start;
     const int k = x - s0;
-    for (int i = 0; i < (k & 3); i++) { pu = pu + su; pv = pv + sv; fw = fw + sw; }
-    pu = wr_accum(pu, (su * 4.0f) * 1.0f, k >> 2); pv = wr_accum(pv, (sv * 4.0f) * 1.0f, k >> 2);
-    fw = wr_accum(fw, sw * 4.0f, k >> 2);
+    // the (uv / w, 1 / w) interpolants of lane kk of the span: init_interp lane, then a step of 4 per chunk
+    auto lane_at = [&](int kk, float& pu_, float& pv_, float& fw_) {
+      pu_ = Lu + su * start; pv_ = Lv + sv * start; fw_ = wl + sw * start;
+      for (int i = 0; i < (kk & 3); i++) { pu_ = pu_ + su; pv_ = pv_ + sv; fw_ = fw_ + sw; }
+      pu_ = wr_accum(pu_, (su * 4.0f) * 1.0f, kk >> 2); pv_ = wr_accum(pv_, (sv * 4.0f) * 1.0f, kk >> 2);
+      fw_ = wr_accum(fw_, sw * 4.0f, kk >> 2);
+    };
+    if (Q.base_kind == WR_PK_QUAD_MASK) {
+      // ps_quad_mask: vClipLocalPos = (xy, 0, 1) / w interpolated, times w per lane; clip_local_pos = .xy / .w of the pixel and of
+      // lanes 0 / 1 of its chunk (fwidth).  The varying's w is 1 at the vertices (checked by the setup stage), so its
+      // interpolant is the edges' 1 / w itself.
+      float px_[3], py_[3];
+      const int ks[3] = {k & ~3, (k & ~3) + 1, k};
+      for (int j = 0; j < 3; j++) {
+        float a_, b_, c_;
+        lane_at(ks[j], a_, b_, c_);
+        const float wq_ = 1.0f / c_;
+        const float vx = a_ * wq_, vy = b_ * wq_, vw = c_ * wq_;
+        px_[j] = vx / vw; py_[j] = vy / vw;
+      }
+      src = wr_quad_mask_eval(Q.clip, px_[0], py_[0], px_[1], py_[1], px_[2], py_[2]);
+    } else {
+    float pu, pv, fw;
+    lane_at(k, pu, pv, fw);
     const float wq = 1.0f / fw;
     float cu = pu * wq, cv = pv * wq;
     if (Q.persp.div >= 0.0f) {       // brush_image: v_uv * mix(gl_FragCoord.w, 1.0, perspective_interpolate)
@@ -4062,6 +4083,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     else if (Q.base_kind == WR_PK_FILTER) src = wr_filter_eval(&Pl, &Q.filt, D, cu, cv);
     else if (Q.base_kind == WR_PK_GRADIENT) src = wr_gradient_main(&Q.grad, D, cu, cv);
     else src = wr_tex_tail_texel(Pl, t, cu, cv);
+    }
   } else if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {
     // shader replays that take their interpolants from the prim: hand them this row as a one-row axis-aligned prim (the span
     // [s0, s1), the edges' x and interpolants on this row, no row stepping left to do)
@@ -4900,6 +4922,10 @@ __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClip
   wr_tex_tail_uv(P, r, n, qx, qy);
   const float wv = C.w;
   f0x = f0x / wv; f0y = f0y / wv; f1x = f1x / wv; f1y = f1y / wv; qx = qx / wv; qy = qy / wv;   // vClipLocalPos.xy / vClipLocalPos.w
+  return wr_quad_mask_eval(C, f0x, f0y, f1x, f1y, qx, qy);
+}
+// ... from clip_local_pos of the pixel (qx, qy) and of lanes 0 / 1 of its chunk (fwidth) on
+WR_DEVICE WrWide wr_quad_mask_eval(const WrClipRec& C, float f0x, float f0y, float f1x, float f1y, float qx, float qy) {
   const float aa_range = 1.0f / (fabsf(f1x - f0x) + fabsf(f1y - f0y));   // recip(fwidth(pos).x), shared.glsl:145-148
   const float dist = wr_clip_dist(C, qx, qy);
   const float alpha = wr_clamp(0.5f - dist * aa_range, 0.0f, 1.0f);
