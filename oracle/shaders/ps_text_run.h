@@ -138,6 +138,30 @@
       float chunks = steps * 0.25f;                                            \
       v_uv += interp_step.v_uv * chunks;                                       \
     }                                                                          \
+    /* the perspective entry points glsl-to-cxx emits for a program with a */  \
+    /* varying (lib.rs:660-690, 716-741, 3576-3590) */                         \
+    struct InterpPerspective {                                                 \
+      vec2 v_uv;                                                               \
+    };                                                                         \
+    InterpPerspective interp_perspective;                                      \
+    static void read_perspective_inputs(FragmentShaderImpl* impl,              \
+                                        const void* init_, const void* step_) { \
+      Self* self = (Self*)impl;                                                \
+      const InterpInputs* init = (const InterpInputs*)init_;                   \
+      const InterpInputs* step = (const InterpInputs*)step_;                   \
+      Float w = 1.0f / self->gl_FragCoord.w;                                   \
+      self->interp_perspective.v_uv = init_interp(init->v_uv, step->v_uv);     \
+      self->v_uv = self->interp_perspective.v_uv * w;                          \
+      self->interp_step.v_uv = step->v_uv * 4.0f;                              \
+    }                                                                          \
+    ALWAYS_INLINE void step_perspective_inputs(int steps = 4) {                \
+      step_perspective(steps);                                                 \
+      float chunks = steps * 0.25f;                                            \
+      Float w = 1.0f / gl_FragCoord.w;                                         \
+      interp_perspective.v_uv += interp_step.v_uv * chunks;                    \
+      v_uv = w * interp_perspective.v_uv;                                      \
+    }                                                                          \
+    WRSH_FRAG_ABI_PERSPECTIVE(Self)                                            \
     /* text_fs + main, ps_text_run.glsl:271-318 */                             \
     void main() {                                                              \
       vec2 tc = clamp(v_uv, vec2_scalar(v_uv_bounds.x, v_uv_bounds.y),         \
@@ -176,6 +200,7 @@
     }                                                                          \
     NAME##_frag() {                                                            \
       WRSH_FRAG_WIRING()                                                       \
+      WRSH_FRAG_WIRING_PERSPECTIVE()                                           \
       draw_span_RGBA8_func = &draw_span_RGBA8;                                 \
     }                                                                          \
   };                                                                           \

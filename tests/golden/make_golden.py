@@ -30,7 +30,7 @@ def round3_digests():
     for name, kw in DUAL_SOURCE:
         out[name] = digest(render_direct(LIB, scenes.image_grid(**kw))[0])
     for name, make in ROTATED:
-        if (name.startswith("near_clipped") or name in ("perspective_filters_exact", "perspective_opacity", "perspective_gradients", "perspective_quad_gradients", "perspective_images_repeat", "perspective_quad_masks")) and name in ROTATED_GOLDEN:
+        if (name.startswith("near_clipped") or name in ("perspective_filters_exact", "perspective_opacity", "perspective_gradients", "perspective_quad_gradients", "perspective_images_repeat", "perspective_quad_masks", "rotated_text", "perspective_text")) and name in ROTATED_GOLDEN:
             out[name] = digest(render_direct(LIB, make())[0])
     return out
 

@@ -122,6 +122,15 @@ ROTATED += [
     ("perspective_images_repeat", lambda: scenes.rotated_images(perspective="all", repeat=True, seed=108)),
     ("perspective_images_repeat_mixed", lambda: scenes.rotated_images(perspective=True, repeat=True, seed=107)),
     ("near_clipped_images_repeat", lambda: scenes.rotated_images(perspective="clip", repeat=True, seed=109)),
+    # ps_text_run (local raster space): glyph quads under rotations / skews and projective transforms, every colour mode, the
+    # dual-source program, behind occluders
+    ("rotated_text", lambda: scenes.cfg3_text(rotate=True, **_TEXT)),
+    ("rotated_text_modes", lambda: scenes.cfg3_text(rotate=True, color_modes=(0, 1, 2, 3), seed=4, **_TEXT)),
+    ("occluded_rotated_text", lambda: scenes.add_occluders(scenes.cfg3_text(rotate=True, seed=8, **_TEXT), zmax=100, seed=17)),
+    ("perspective_text", lambda: scenes.cfg3_text(perspective=True, **_TEXT)),
+    ("perspective_text_modes", lambda: scenes.cfg3_text(perspective=True, color_modes=(0, 1, 2, 3), seed=4, **_TEXT)),
+    ("perspective_text_dual", lambda: scenes.cfg3_text(perspective=True, color_modes=(1,), dual_source=True, seed=6, **_TEXT)),
+    ("occluded_perspective_text", lambda: scenes.add_occluders(scenes.cfg3_text(perspective=True, seed=7, **_TEXT), zmax=100, seed=15)),
     # ps_quad_mask: rounded-rect clips on quads under projective transforms (vClipLocalPos / its w per lane, fwidth of the quotient)
     ("perspective_quad_masks", lambda: scenes.quad_masks(rotate=True, perspective=True, seed=83)),
     ("occluded_perspective_quad_masks", lambda: scenes.add_occluders(scenes.quad_masks(rotate=True, perspective=True, seed=84), zmax=90, seed=48)),
@@ -174,7 +183,7 @@ ROTATED += [
     ("transforms_simple", lambda: scenes.transforms_simple()),
     ("transforms_simple_quad", lambda: scenes.transforms_simple(encoding="quad")),
 ]
-ROTATED_GOLDEN = ("perspective_quad_masks", "perspective_images_repeat", "perspective_quad_gradients", "perspective_filters_exact", "perspective_opacity", "perspective_gradients", "near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
+ROTATED_GOLDEN = ("rotated_text", "perspective_text", "perspective_quad_masks", "perspective_images_repeat", "perspective_quad_gradients", "perspective_filters_exact", "perspective_opacity", "perspective_gradients", "near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,

@@ -2547,7 +2547,8 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
                      info->kind == WR_SH_BRUSH_OPACITY || info->kind == WR_SH_BRUSH_OPACITY_ALPHA ||
                      info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA ||
                      info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
-                     info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA;
+                     info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA ||
+                     info->kind == WR_SH_PS_TEXT_RUN || info->kind == WR_SH_PS_TEXT_RUN_DUAL;      // (glyph quads under a rotation: local raster space)
     const bool texquad = (info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2) ||
                          info->kind == WR_SH_PS_QUAD_MASK || info->kind == WR_SH_PS_QUAD_MASK_FAST ||
                          info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT || info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT;

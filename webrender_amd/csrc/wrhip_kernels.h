@@ -1940,6 +1940,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
     // (and brush_opacity, brush_blend, brush_linear_gradient: main() on the perspective-correct varying)
     const bool ptex = ((d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS)) ||
+                      ((d.shader == WR_SH_PS_TEXT_RUN || d.shader == WR_SH_PS_TEXT_RUN_DUAL) && (o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_RGBA8)) ||
                       o.kind == WR_PK_FILTER || (o.kind == WR_PK_QUAD_MASK && auxp->clip.w == 1.0f) || (o.kind == WR_PK_TEX_REPEAT && o.persp_div >= 0.0f) || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
                                                                               d.shader == WR_SH_PS_QUAD_RADIAL_GRADIENT || d.shader == WR_SH_PS_QUAD_CONIC_GRADIENT));
     if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
@@ -2017,7 +2018,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked)))) {
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked)))) {
       atomicAdd(&cnt->perspective_prims, 1u); return;
     }
     if (!solidq && !texq) {

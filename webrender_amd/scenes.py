@@ -201,7 +201,8 @@ def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127)):
 
 
 def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=25, seed=3,
-              glyph_zoom=1.0, device_pixel_scale=1.0, tile_filter=None, color_modes=(0,), dual_source=False, **kw):
+              glyph_zoom=1.0, device_pixel_scale=1.0, tile_filter=None, color_modes=(0,), dual_source=False, rotate=False,
+              perspective=False, **kw):
     """`lines` x `glyphs_per_line` glyphs in runs of `run_len`, black-ish text
     on white, COLOR_MODE_ALPHA from an R8 atlas, PremultipliedAlpha blend
     (batch.rs:1109-1290).  glyph_zoom != 1 draws the cached bitmaps magnified
@@ -209,7 +210,10 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
     color_modes other than 0 (cycled per run: 1 = COLOR_MODE_SUBPX_DUAL_SOURCE, 2 = COLOR_MODE_BITMAP_SHADOW,
     3 = COLOR_MODE_COLOR_BITMAP) sample a BGRA8 atlas: per-channel coverage shifted by one texel per
     channel, as a subpixel rasteriser produces; dual_source selects the DUAL_SOURCE_BLENDING program
-    (batch.rs:1150-1180: BlendMode::SubpixelDualSource)."""
+    (batch.rs:1150-1180: BlendMode::SubpixelDualSource).
+    rotate / perspective: two runs in three sit under a rotation (skew) about their origin, with a projective row on top for
+    `perspective` -- local-raster-space text: the glyph quads are laid out in local space by the non-GLYPH_TRANSFORM program and
+    transformed as quads."""
     rng = np.random.default_rng(seed)
     atlas, table = build_glyph_atlas()
     sizes = sorted({k[0] for k in table})
@@ -258,7 +262,13 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
             asc = size * 1.3 * k_dev
             bx0, bx1 = origin[0] * dps - 2 * size, (origin[0] + x) * dps + 2 * size
             by0, by1 = origin[1] * dps - asc, origin[1] * dps + 0.5 * size * k_dev + 2
-            runs.append((origin, ref, color, size, run_chars, pts, (bx0, by0, bx1, by1), z))
+            tid = 0
+            if (rotate or perspective) and len(runs) % 3 != 2:
+                rad = float(np.hypot(x, 2.0 * size * k_dev / dps)) + 4.0
+                tid = rotation_about(frame, rng, origin[0], origin[1], len(runs), rad if perspective else None)
+                rr = rad * dps * (2.2 if perspective else 1.1)
+                bx0, bx1, by0, by1 = origin[0] * dps - rr, origin[0] * dps + rr, origin[1] * dps - rr, origin[1] * dps + rr
+            runs.append((origin, ref, color, size, run_chars, pts, (bx0, by0, bx1, by1), z, tid))
             z += 1
 
     run_addr = [frame.add_text_run(r[2], r[5]) for r in runs]
@@ -273,11 +283,11 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
         task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), dps,
                                      (float(ox), float(oy)))
         inst, inst_bgra = [], []
-        for ri, (origin, ref, color, size, run_chars, pts, bb, zid) in enumerate(runs):
+        for ri, (origin, ref, color, size, run_chars, pts, bb, zid, tid) in enumerate(runs):
             if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
             local_rect = (origin[0] - ref[0][0], origin[1] - ref[0][1], ref[1][0], ref[1][1])
-            ph = frame.add_prim_header(local_rect, (-BIG, -BIG, BIG, BIG), zid, run_addr[ri], 0, task,
+            ph = frame.add_prim_header(local_rect, (-BIG, -BIG, BIG, BIG), zid, run_addr[ri], tid, task,
                                        (int(round(raster_scale * 65535.0)), 0, 0, 0))
             mode = color_modes[ri % len(color_modes)]
             for gi, c in enumerate(run_chars):
