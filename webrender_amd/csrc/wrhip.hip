@@ -2547,15 +2547,17 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
                      info->kind == WR_SH_BRUSH_OPACITY || info->kind == WR_SH_BRUSH_OPACITY_ALPHA ||
                      info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA ||
                      info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
-                     info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA ||
-                     info->kind == WR_SH_PS_TEXT_RUN || info->kind == WR_SH_PS_TEXT_RUN_DUAL;      // (glyph quads under a rotation: local raster space)
+                     info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA;
+    // (glyph quads under a rotation -- local raster space -- ride on the same path; the program never asks for swgl_antiAlias,
+    // and a glyph instance's third word is not a brush's flags: the transform ids alone decide)
+    const bool text = info->kind == WR_SH_PS_TEXT_RUN || info->kind == WR_SH_PS_TEXT_RUN_DUAL;
     const bool texquad = (info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2) ||
                          info->kind == WR_SH_PS_QUAD_MASK || info->kind == WR_SH_PS_QUAD_MASK_FAST ||
                          info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT || info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT;
     const bool solid_masked = (info->kind == WR_SH_BRUSH_SOLID || info->kind == WR_SH_BRUSH_SOLID_ALPHA) && maskable;
-    if (colortex.internal_format == GL_RGBA8 && (img || texquad || solid_masked)) {
+    if (colortex.internal_format == GL_RGBA8 && (img || texquad || solid_masked || text)) {
       bool quads = !ids_clean(texquad ? WR_S_GPU_BUFFER_I : WR_S_PRIM_HEADERS_I, !texquad);
-      if (!quads && d.blend != WR_BLEND_NONE && d.attr_off[0] >= 0 && d.attr_bytes[0] >= 12 && inst_stride >= 12) {
+      if (!quads && !text && d.blend != WR_BLEND_NONE && d.attr_off[0] >= 0 && d.attr_bytes[0] >= 12 && inst_stride >= 12) {
         const uint8_t* ib = (const uint8_t*)instb->buf + d.attr_off[0];
         for (int i = 0; i < instancecount && !quads; i++) {
           int32_t zw; memcpy(&zw, ib + (size_t)i * inst_stride + 8, 4);
