@@ -61,6 +61,8 @@ def kernel_label(k):
         return "wr_setup_kernel"
     if k.kind == 3:
         return "wr_mask_rows_kernel"
+    if k.kind == 4:      # a run of thin R8 levels in one launch (k.depth = levels)
+        return f"wr_raster_chain_kernel<{k.feat}> x{k.depth} levels"
     return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
 
 

@@ -615,6 +615,62 @@ def text_tile(frame, target, atlas):
 
 
 # ---------------------------------------------------------------------------
+# ps_split_composite (webrender/res/ps_split_composite.glsl) for planes that face the screen at whole device pixels and 1:1 scale
+# (scenes.split_composites(pin=True)): the instance (header index, polygons address, z, render task: gpu_types.rs:531-551), the
+# bilerp of the polygon's four local points over aPosition (:41-45, 85-87), the destination task's origin, the image source's
+# uv rect through get_image_quad_uv's unit quad, texture(sColor0, uv) at texel centres and swgl's premultiplied-alpha key --
+# written from the GLSL and the Rust encoders only, as whole-rect array expressions.
+def split_tile(frame, target, atlas_rgba):
+    """One picture-cache tile of a scenes.split_composites(pin=True) frame -> uint8 [TILE_H, TILE_W, 4] RGBA"""
+    from webrender_amd.scenes import TILE_W, TILE_H
+    cache, hf, hi, tasks = frame.gpu_cache.data, frame.prim_headers_f.data, frame.prim_headers_i.data, frame.render_tasks.data
+    img = np.empty((TILE_H, TILE_W, 4), np.int64)
+    img[:] = np.floor(_f(target.clear_color) * _f(255.0) + _f(0.5)).astype(np.int64)
+    AH, AW = atlas_rgba.shape[:2]
+    for step in target.alpha:
+        assert step.shader == "ps_split_composite"
+        for inst in np.asarray(step.instances):
+            ph, poly, task_addr = int(inst[0]), int(inst[1]), int(inst[3])
+            lr = _f(hf[2 * ph]); h0 = hi[2 * ph]; h1 = hi[2 * ph + 1]
+            assert int(h0[2]) == 0                          # identity transform
+            trect, tdata = _f(tasks[2 * task_addr]), _f(tasks[2 * task_addr + 1])
+            dps, corigin = tdata[0], tdata[1:3]
+            b0, b1 = _f(cache[poly]), _f(cache[poly + 1])
+            local = [b0[0:2], b0[2:4], b1[0:2], b1[2:4]]
+            # the unit quad's corners through bilerp(local[0], local[1], local[3], local[2], aPosition.y, aPosition.x)
+            corners = []
+            for (ax, ay) in ((0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)):
+                xx = (local[1] - local[0]) * _f(ax) + local[0]
+                yy = (local[2] - local[3]) * _f(ax) + local[3]
+                corners.append((yy - xx) * _f(ay) + xx)
+            corners = np.array(corners)
+            lo, hi_ = corners.min(axis=0), corners.max(axis=0)
+            # world = local (identity); device = world * dps + (task origin - content origin)
+            d0 = lo * dps + (trect[0:2] - corigin); d1 = hi_ * dps + (trect[0:2] - corigin)
+            x0, x1 = int(np.floor(np.clip(d0[0], 0, TILE_W) + _f(0.5))), int(np.floor(np.clip(d1[0], 0, TILE_W) + _f(0.5)))
+            y0, y1 = int(np.floor(np.clip(d0[1], 0, TILE_H) + _f(0.5))), int(np.floor(np.clip(d1[1], 0, TILE_H) + _f(0.5)))
+            if x1 <= x0 or y1 <= y0:
+                continue
+            src_addr = int(h1[0])
+            uv_rect = _f(cache[src_addr])
+            gx = (np.arange(x0, x1, dtype=np.float32) + _f(0.5))[None, :]
+            gy = (np.arange(y0, y1, dtype=np.float32) + _f(0.5))[:, None]
+            lx = (gx - (trect[0] - corigin[0])) / dps
+            ly = (gy - (trect[1] - corigin[1])) / dps
+            fx, fy = (lx - lr[0]) / (lr[2] - lr[0]), (ly - lr[1]) / (lr[3] - lr[1])      # f = (local_pos - rect.p0) / rect size; unit image quad
+            u = (uv_rect[2] - uv_rect[0]) * fx + uv_rect[0]
+            v = (uv_rect[3] - uv_rect[1]) * fy + uv_rect[1]
+            u = np.clip(u, uv_rect[0] + _f(0.5), uv_rect[2] - _f(0.5)); v = np.clip(v, uv_rect[1] + _f(0.5), uv_rect[3] - _f(0.5))
+            ui, vi = np.floor(u).astype(np.int64), np.floor(v).astype(np.int64)          # texel centres: the linear filter returns the texel
+            uu, vv = np.broadcast_arrays(ui, vi)
+            src = atlas_rgba[vv, uu].astype(np.int64)
+            dst = img[y0:y1, x0:x1]
+            a = src[..., 3:4]
+            img[y0:y1, x0:x1] = src + dst - ((dst * a + dst) >> 8)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
 # ps_quad_mask (+FAST_PATH) on top of a solid ps_quad_textured quad (scenes.quad_masks, identity transforms): the quad's pixel
 # coverage from ps_quad.glsl:187-330 (local rect ∩ clip, device position clamped to the task's content rect, pixel centres),
 # pattern_fragment of ps_quad_mask.glsl:171-207 (sd_rounded_box / distance_to_rounded_rect of ellipse.glsl:48-92, distance_aa

@@ -29,6 +29,7 @@
 #include "ps_quad_conic_gradient.h"
 #include "ps_copy.h"
 #include "brush_mix_blend.h"
+#include "ps_split_composite.h"
 
 ProgramLoader load_shader(const char* name) {
 #define WRSH_ENTRY(KEY, SYM) \
@@ -40,9 +41,13 @@ ProgramLoader load_shader(const char* name) {
   WRSH_ENTRY("composite FAST_PATH,TEXTURE_2D", composite_FAST_PATH_TEXTURE_2D)
   WRSH_ENTRY("ps_clear", ps_clear)
   WRSH_ENTRY("ps_copy", ps_copy)
+  WRSH_ENTRY("ps_split_composite", ps_split_composite)
   WRSH_ENTRY("ps_text_run ALPHA_PASS,TEXTURE_2D", ps_text_run_ALPHA_PASS_TEXTURE_2D)
   WRSH_ENTRY("ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D",
              ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D)
+  WRSH_ENTRY("ps_text_run ALPHA_PASS,GLYPH_TRANSFORM,TEXTURE_2D", ps_text_run_ALPHA_PASS_GLYPH_TRANSFORM_TEXTURE_2D)
+  WRSH_ENTRY("ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,GLYPH_TRANSFORM,TEXTURE_2D",
+             ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_GLYPH_TRANSFORM_TEXTURE_2D)
   WRSH_ENTRY("cs_blur ALPHA_TARGET", cs_blur_ALPHA_TARGET)
   WRSH_ENTRY("cs_blur COLOR_TARGET", cs_blur_COLOR_TARGET)
   WRSH_ENTRY("cs_scale TEXTURE_2D", cs_scale_TEXTURE_2D)

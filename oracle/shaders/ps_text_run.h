@@ -6,16 +6,38 @@
 // the prim_shared helpers in brush_base.h, with SWGL defined (SWGL_BLEND,
 // SWGL_CLIP_DIST, SWGL_CLIP_MASK, SWGL_DRAW_SPAN: base.glsl:38-44).
 
-#define WRSH_PS_TEXT_RUN(NAME, KEYSTR, DUAL_SOURCE)                            \
+#define WRSH_PS_TEXT_RUN(NAME, KEYSTR, DUAL_SOURCE, GLYPH_TRANSFORM)                            \
   struct NAME##_vert : wrsh::prim_vert_base<NAME##_vert> {                     \
     typedef NAME##_vert Self;                                                  \
     vec4_scalar v_color;                                                       \
     vec3_scalar v_mask_swizzle;                                                \
     vec4_scalar v_uv_bounds;                                                   \
     vec2 v_uv;                                                                 \
-    struct InterpOutputs {                                                     \
+    /* (a program that writes gl_ClipDistance: the four distances of a vertex */ \
+    /* lead its interpolants, lib.rs:541-545, 570-577) */                      \
+    struct InterpOutputsPlain {                                                \
       vec2_scalar v_uv;                                                        \
     };                                                                         \
+    struct InterpOutputsClip {                                                 \
+      Float swgl_ClipDistance;                                                 \
+      vec2_scalar v_uv;                                                        \
+    };                                                                         \
+    typedef typename std::conditional<GLYPH_TRANSFORM, InterpOutputsClip,      \
+                                      InterpOutputsPlain>::type InterpOutputs; \
+    /* ps_text_run.glsl:24-35 */                                               \
+    static wrsh::RectWithEndpoint transform_rect(wrsh::RectWithEndpoint rect,  \
+                                                 mat2_scalar transform) {      \
+      vec2_scalar size = wrsh::rect_size(rect);                                \
+      vec2_scalar center = transform * (rect.p0 + size * 0.5f);                \
+      vec2_scalar radius = mat2_scalar(abs(transform[0]), abs(transform[1])) * \
+                           (size * 0.5f);                                      \
+      return wrsh::RectWithEndpoint{center - radius, center + radius};         \
+    }                                                                          \
+    static bool rect_inside_rect(wrsh::RectWithEndpoint little,                \
+                                 wrsh::RectWithEndpoint big) {                 \
+      return big.p0.x <= little.p0.x && big.p0.y <= little.p0.y &&             \
+             little.p1.x <= big.p1.x && little.p1.y <= big.p1.y;               \
+    }                                                                          \
     static vec2_scalar get_snap_bias(int subpx_dir) {                          \
       switch (subpx_dir) {                                                     \
         case 0:                                                                \
@@ -60,6 +82,46 @@
       vec2_scalar res_offset = vec2_scalar(res1.x, res1.y);                    \
       float res_scale = res1.z;                                                \
       vec2_scalar snap_bias = get_snap_bias(subpx_dir);                        \
+      BrushVertexInfo vi;                                                      \
+      vec2 f;                                                                  \
+      if (GLYPH_TRANSFORM) {                                                   \
+        /* ps_text_run.glsl:130-165, 206-216: glyphs rasterised in device */   \
+        /* space, clipped to their raster rect by gl_ClipDistance */           \
+        mat2_scalar glyph_transform =                                          \
+            mat2_scalar(vec2_scalar(transform.m[0].x, transform.m[0].y),       \
+                        vec2_scalar(transform.m[1].x, transform.m[1].y)) *     \
+            task.device_pixel_scale;                                           \
+        vec2_scalar glyph_translation =                                        \
+            vec2_scalar(transform.m[3].x, transform.m[3].y) *                  \
+            task.device_pixel_scale;                                           \
+        mat2_scalar glyph_transform_inv = inverse(glyph_transform);            \
+        vec2_scalar raster_glyph_offset =                                      \
+            floor(glyph_transform * glyph_offset + snap_bias);                 \
+        vec2_scalar raster_text_offset =                                       \
+            floor(glyph_transform * text_offset + glyph_translation + 0.5f) -  \
+            glyph_translation;                                                 \
+        vec2_scalar glyph_origin =                                             \
+            res_offset + raster_glyph_offset + raster_text_offset;             \
+        RectWithEndpoint glyph_rect{                                           \
+            glyph_origin,                                                      \
+            glyph_origin + vec2_scalar(res_uv_rect.z, res_uv_rect.w) -         \
+                vec2_scalar(res_uv_rect.x, res_uv_rect.y)};                    \
+        RectWithEndpoint local_rect =                                          \
+            transform_rect(glyph_rect, glyph_transform_inv);                   \
+        vec2 local_pos = mix(local_rect.p0, local_rect.p1, aPosition);         \
+        if (rect_inside_rect(local_rect, ph.local_clip_rect)) {                \
+          local_pos = glyph_transform_inv *                                    \
+                      mix(glyph_rect.p0, glyph_rect.p1, aPosition);            \
+        }                                                                      \
+        vi = write_vertex(local_pos, ph.local_clip_rect, ph.z, transform,      \
+                          task);                                               \
+        f = (glyph_transform * vi.local_pos - glyph_rect.p0) /                 \
+            rect_size(glyph_rect);                                             \
+        gl_ClipDistance[0] = f.x;                                              \
+        gl_ClipDistance[1] = f.y;                                              \
+        gl_ClipDistance[2] = 1.0f - f.x;                                       \
+        gl_ClipDistance[3] = 1.0f - f.y;                                       \
+      } else {                                                                 \
       /* ps_text_run.glsl:155-190 */                                           \
       float raster_scale = float(ph.user_data.x) / 65535.0f;                   \
       float glyph_raster_scale = raster_scale * task.device_pixel_scale;       \
@@ -75,9 +137,9 @@
                                             vec2_scalar(res_uv_rect.x,         \
                                                         res_uv_rect.y))};      \
       vec2 local_pos = mix(glyph_rect.p0, glyph_rect.p1, aPosition);           \
-      BrushVertexInfo vi =                                                     \
-          write_vertex(local_pos, ph.local_clip_rect, ph.z, transform, task);  \
-      vec2 f = (vi.local_pos - glyph_rect.p0) / rect_size(glyph_rect);         \
+      vi = write_vertex(local_pos, ph.local_clip_rect, ph.z, transform, task); \
+      f = (vi.local_pos - glyph_rect.p0) / rect_size(glyph_rect);              \
+      }                                                                        \
       write_clip(clip_area, task);                                             \
       /* ps_text_run.glsl:219-255 with SWGL_BLEND */                           \
       switch (color_mode) {                                                    \
@@ -112,19 +174,30 @@
                     vec4_scalar(texture_size.x, texture_size.y,                \
                                 texture_size.x, texture_size.y);               \
     }                                                                          \
+    void store_clip(InterpOutputsPlain*, int) {}                               \
+    void store_clip(InterpOutputsClip* dest, int n) {                          \
+      dest->swgl_ClipDistance.x = get_nth(gl_ClipDistance[0], n);              \
+      dest->swgl_ClipDistance.y = get_nth(gl_ClipDistance[1], n);              \
+      dest->swgl_ClipDistance.z = get_nth(gl_ClipDistance[2], n);              \
+      dest->swgl_ClipDistance.w = get_nth(gl_ClipDistance[3], n);              \
+    }                                                                          \
     ALWAYS_INLINE void store_interp_outputs(char* dest_ptr, size_t stride) {   \
       for (int n = 0; n < 4; n++) {                                            \
         auto* dest = reinterpret_cast<InterpOutputs*>(dest_ptr);               \
+        store_clip(dest, n);                                                   \
         dest->v_uv = get_nth(v_uv, n);                                         \
         dest_ptr += stride;                                                    \
       }                                                                        \
     }                                                                          \
     WRSH_VERT_ABI(Self)                                                        \
-    NAME##_vert() { WRSH_VERT_WIRING(Self) }                                   \
+    NAME##_vert() {                                                            \
+      WRSH_VERT_WIRING(Self)                                                   \
+      if (GLYPH_TRANSFORM) enable_clip_distance(); /* lib.rs:3645-3647 */      \
+    }                                                                          \
   };                                                                           \
   struct NAME##_frag : FragmentShaderImpl, NAME##_vert {                       \
     typedef NAME##_frag Self;                                                  \
-    typedef NAME##_vert::InterpOutputs InterpInputs;                           \
+    typedef typename NAME##_vert::InterpOutputs InterpInputs;                  \
     InterpInputs interp_step;                                                  \
     static void read_interp_inputs(FragmentShaderImpl* impl,                   \
                                    const void* init_, const void* step_) {     \
@@ -207,6 +280,11 @@
   WRSH_PROGRAM(NAME, KEYSTR)
 
 WRSH_PS_TEXT_RUN(ps_text_run_ALPHA_PASS_TEXTURE_2D,
-                 "ps_text_run ALPHA_PASS,TEXTURE_2D", false)
+                 "ps_text_run ALPHA_PASS,TEXTURE_2D", false, false)
 WRSH_PS_TEXT_RUN(ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_TEXTURE_2D,
-                 "ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", true)
+                 "ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", true, false)
+/* the GLYPH_TRANSFORM keys (shader_features.rs:222-226): text whose glyphs were rasterised under the run's 2-D transform */
+WRSH_PS_TEXT_RUN(ps_text_run_ALPHA_PASS_GLYPH_TRANSFORM_TEXTURE_2D,
+                 "ps_text_run ALPHA_PASS,GLYPH_TRANSFORM,TEXTURE_2D", false, true)
+WRSH_PS_TEXT_RUN(ps_text_run_ALPHA_PASS_DUAL_SOURCE_BLENDING_GLYPH_TRANSFORM_TEXTURE_2D,
+                 "ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,GLYPH_TRANSFORM,TEXTURE_2D", true, true)

@@ -29,6 +29,13 @@ def round3_digests():
         out[name] = digest(render_direct(LIB, getattr(scenes, scene)(**kw))[0])
     for name, kw in DUAL_SOURCE:
         out[name] = digest(render_direct(LIB, scenes.image_grid(**kw))[0])
+    from parity_cases import SPLIT, SPLIT_GOLDEN
+    for name, make in SPLIT:             # ps_split_composite
+        if name in SPLIT_GOLDEN:
+            out[name] = digest(render_direct(LIB, make())[0])
+    from parity_cases import GLYPH_TRANSFORM
+    for name, make in GLYPH_TRANSFORM[:3]:      # ps_text_run GLYPH_TRANSFORM (hold with the same PIL glyph bitmaps only: golden_applies)
+        out[name] = digest(render_direct(LIB, make())[0])
     for name, make in ROTATED:
         if (name.startswith("near_clipped") or name in ("perspective_filters_exact", "perspective_opacity", "perspective_gradients", "perspective_quad_gradients", "perspective_images_repeat", "perspective_quad_masks", "rotated_text", "perspective_text")) and name in ROTATED_GOLDEN:
             out[name] = digest(render_direct(LIB, make())[0])

@@ -185,6 +185,33 @@ ROTATED += [
 ]
 ROTATED_GOLDEN = ("rotated_text", "perspective_text", "perspective_quad_masks", "perspective_images_repeat", "perspective_quad_gradients", "perspective_filters_exact", "perspective_opacity", "perspective_gradients", "near_clipped_rects", "near_clipped_images", "near_clipped_images_quad", "transforms_simple", "perspective_rects", "occluded_perspective_rects", "perspective_images_quad", "perspective_images", "rotated_gradients", "rotated_filters", "rotated_quad_masks", "quad_gradients", "rotated_quad_gradients")
 
+# ps_split_composite: the polygons a preserve-3d context is split into, composited back to front -- convex
+# quads, triangles (two equal points) and both windings under rotations, skews, identity and projective transforms, with and
+# without perspective-correct uv, under clip masks, behind occluders, clipped against the view volume, with a nearest sampler.
+SPLIT = [
+    ("split_composites", lambda: scenes.split_composites()),
+    ("split_composites_wide", lambda: scenes.split_composites(width=2048, height=1024, n=140, seed=212)),
+    ("split_composites_masked", lambda: scenes.split_composites(masked=True, seed=213)),
+    ("split_composites_nearest", lambda: scenes.split_composites(nearest=True, seed=214)),
+    ("perspective_split_composites", lambda: scenes.split_composites(perspective="all", seed=215)),
+    ("perspective_split_composites_mixed", lambda: scenes.split_composites(perspective=True, seed=216)),
+    ("perspective_split_composites_masked", lambda: scenes.split_composites(perspective="all", masked=True, seed=217)),
+    ("near_clipped_split_composites", lambda: scenes.split_composites(perspective="clip", seed=218)),
+    ("occluded_split_composites", lambda: scenes.add_occluders(scenes.split_composites(seed=219), zmax=60, seed=47)),
+    ("occluded_perspective_split_composites", lambda: scenes.add_occluders(scenes.split_composites(perspective="all", seed=220), zmax=60, seed=48)),
+]
+# ps_text_run GLYPH_TRANSFORM: screen-raster-space text under rotations, skews and scales -- glyphs snapped
+# in device space, every span cut to the glyph's raster rect by gl_ClipDistance (clip_distance_range, rasterize.h:564-595), runs
+# under local clip rects that cut through their glyphs, every colour mode, the dual-source program, behind occluders.
+GLYPH_TRANSFORM = [
+    ("glyph_transform_text", lambda: scenes.cfg3_text(glyph_transform=True, **_TEXT)),
+    ("glyph_transform_text_modes", lambda: scenes.cfg3_text(glyph_transform=True, color_modes=(0, 1, 2, 3), seed=5, **_TEXT)),
+    ("glyph_transform_text_dual", lambda: scenes.cfg3_text(glyph_transform=True, color_modes=(1, 2), dual_source=True, seed=6, **_TEXT)),
+    ("glyph_transform_text_dps", lambda: scenes.cfg3_text(glyph_transform=True, device_pixel_scale=1.5, seed=7, **dict(_TEXT, width=1000, height=500))),
+    ("occluded_glyph_transform_text", lambda: scenes.add_occluders(scenes.cfg3_text(glyph_transform=True, seed=9, **_TEXT), zmax=100, seed=18)),
+]
+SPLIT_GOLDEN = ("split_composites", "perspective_split_composites", "near_clipped_split_composites")
+
 
 # cs_border_solid (first family): solid border segments -- corners with elliptical outer / inner radii,
 # adjacent-corner clips, two-colour corners mixed along the colour line, AA on / off, zero widths, edges -- rendered into a

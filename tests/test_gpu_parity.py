@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_lib
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -204,6 +204,36 @@ def test_hip_matches_oracle_small(name, make):
     if name in GOLDEN and golden_applies(name):
         assert digest(got) == GOLDEN[name]
     assert ref or (name in GOLDEN and golden_applies(name))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", SPLIT, ids=[c[0] for c in SPLIT])
+def test_hip_split_composites_match_oracle(name, make):
+    """(see tests/test_hostsim_parity.py::test_hostsim_split_composites_match_oracle)"""
+    got, stats = render_direct(wrhip_lib(), make())
+    assert stats["gl_error"] == 0
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, make())
+        assert np.array_equal(got, want)
+    if name in SPLIT_GOLDEN and name in GOLDEN:
+        assert digest(got) == GOLDEN[name]
+    assert ref or (name in SPLIT_GOLDEN and name in GOLDEN)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", GLYPH_TRANSFORM, ids=[c[0] for c in GLYPH_TRANSFORM])
+def test_hip_glyph_transform_text_matches_oracle(name, make):
+    """(see tests/test_hostsim_parity.py::test_hostsim_glyph_transform_text_matches_oracle)"""
+    got, stats = render_direct(wrhip_lib(), make())
+    assert stats["gl_error"] == 0
+    ref = oracle_lib("gcc")
+    if ref:
+        want, _ = render_direct(ref, make())
+        assert np.array_equal(got, want)
+    if name in GOLDEN and golden_applies("cfg3"):
+        assert digest(got) == GOLDEN[name]
+    assert ref or (name in GOLDEN and golden_applies("cfg3"))
 
 
 @pytest.mark.gpu

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE
+from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -180,6 +180,32 @@ def test_hostsim_matches_oracle(hostsim, oracle_gcc, name, make):
     assert np.array_equal(got, want)
     assert stats["raster_launches"] >= 1
     if name in GOLDEN and golden_applies(name):
+        assert digest(got) == GOLDEN[name]
+
+
+@pytest.mark.parametrize("name,make", SPLIT, ids=[c[0] for c in SPLIT])
+def test_hostsim_split_composites_match_oracle(hostsim, oracle_gcc, name, make):
+    """ps_split_composite (parity_cases.SPLIT): the split polygons of a preserve-3d context -- general quads by construction -- on
+    the general-quad / perspective paths.  0 differing bytes, nothing reported, and the polygons did leave pixels."""
+    want, _ = render_direct(oracle_gcc, make())
+    got, stats = render_direct(hostsim, make())
+    assert np.array_equal(got, want)
+    assert stats["gl_error"] == 0
+    assert (want != 255).any()
+    if name in SPLIT_GOLDEN and name in GOLDEN:
+        assert digest(got) == GOLDEN[name]
+
+
+@pytest.mark.parametrize("name,make", GLYPH_TRANSFORM, ids=[c[0] for c in GLYPH_TRANSFORM])
+def test_hostsim_glyph_transform_text_matches_oracle(hostsim, oracle_gcc, name, make):
+    """ps_text_run GLYPH_TRANSFORM (parity_cases.GLYPH_TRANSFORM): 0 differing bytes, nothing reported; the runs under a local
+    clip rect exist (their quads are not the glyph's raster rect: the gl_ClipDistance cut is what bounds them)."""
+    want, _ = render_direct(oracle_gcc, make())
+    got, stats = render_direct(hostsim, make())
+    assert np.array_equal(got, want)
+    assert stats["gl_error"] == 0
+    assert (want != 255).any()
+    if name in GOLDEN and golden_applies("cfg3"):
         assert digest(got) == GOLDEN[name]
 
 

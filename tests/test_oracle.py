@@ -250,6 +250,23 @@ def test_oracle_text_runs_match_numpy_model(oracle_gcc, kw):
     assert (got != 255).any() and over <= 0.01 * tot and off <= 0.15 * tot, (off, over, tot)
 
 
+def test_oracle_split_composites_match_numpy_model(oracle_gcc):
+    """ps_split_composite: the instance decoding, the bilerp of the polygon's local points (corner order, both windings), the
+    destination task's origin, the image source's uv mapping and the premultiplied-alpha blend, restated in numpy from the GLSL
+    and the Rust encoders (oracle/np_model.py: split_tile) for planes that face the screen at whole pixels and 1:1 scale --
+    where every sample is a texel centre -- against the oracle's hand-written header: 0 differing bytes."""
+    fr = scenes.split_composites(pin=True, n=120, seed=231)
+    got, _ = render_direct(oracle_gcc, fr)
+    atlas = np.asarray(fr.static_textures[0].pixels)[..., [2, 1, 0, 3]]      # uploaded as BGRA: ReadPixels order is RGBA
+    n = 0
+    for tgt, ct in zip(fr.passes[0], fr.composite_tiles):
+        tile = np_model.split_tile(fr, tgt, atlas)
+        x0, y0, x1, y1 = [int(v) for v in ct.clip_rect]
+        assert np.array_equal(got[::-1][y0:y1, x0:x1], tile[:y1 - y0, :x1 - x0])
+        n += int((tile != 255).any(axis=-1).sum())
+    assert n > 20000
+
+
 def _window_from_tiles(fr, tile_of):
     tiles = {}
     for tgt in fr.passes[0]:

@@ -20,7 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { TAG_INT, TAG_F32, TAG_F64, TAG_BLOB, TAG_NULL, TAG_SCRATCH, TAG_CTX };
+enum { TAG_INT, TAG_F32, TAG_F64, TAG_BLOB, TAG_NULL, TAG_SCRATCH, TAG_CTX, TAG_SCRATCH_INIT };
 typedef struct { uint32_t tag, aux; uint64_t value; } wr_arg;
 typedef struct { uint16_t id, nargs; wr_arg a[24]; } wr_rec;
 
@@ -77,6 +77,18 @@ static void wr_arg_scratch(wr_rec* r, int i, const void* p, size_t n) {
   G.scratch = off + n;
   r->a[i].tag = TAG_SCRATCH; r->a[i].aux = (uint32_t)n; r->a[i].value = off;
 }
+/* caller memory the backend both reads at the call and writes later (SetTextureBuffer's backing store): the bytes it holds now
+ * travel as a blob, the replayer copies them into scratch space of its own and hands that out.  value = blob offset << 32 |
+ * scratch offset: both have to fit 32 bits, as the header's totals do (wr_cap_write refuses larger traces). */
+static void wr_arg_scratch_init(wr_rec* r, int i, const void* p, size_t n) {
+  if (!p) { r->a[i].tag = TAG_NULL; return; }
+  wr_arg_blob(r, i, p, n);
+  const uint64_t blob_off = r->a[i].value;
+  size_t off = (G.scratch + 63) & ~(size_t)63;
+  G.scratch = off + n;
+  if (blob_off > 0xFFFFFFFFull || off > 0xFFFFFFFFull) { fprintf(stderr, "wr_capture: trace exceeds 4 GiB of payload: not representable in the WRTR format\n"); abort(); }
+  r->a[i].tag = TAG_SCRATCH_INIT; r->a[i].aux = (uint32_t)n; r->a[i].value = (blob_off << 32) | (uint64_t)off;
+}
 static void wr_commit(const wr_rec* r) {
   size_t n = 4 + (size_t)r->nargs * sizeof(wr_arg);
   grow(&G.calls, &G.calls_cap, G.calls_len + n);
@@ -129,13 +141,17 @@ static void wr_pre_DeleteBuffer(uint32_t n) {
   if (G.array_buffer == n) G.array_buffer = 0;
 }
 static void wr_pre_PixelStorei(uint32_t name, int32_t v) { if (name == GL_UNPACK_ROW_LENGTH) G.unpack_row_length = v; }
-static size_t buf_size[4096];
+static size_t* buf_size; static size_t buf_size_n;      /* by buffer id (grown on demand: ids are small integers, first-free) */
+static size_t* buf_slot(uint32_t id) {
+  if (id >= buf_size_n) { size_t n = buf_size_n ? buf_size_n : 4096; while (n <= id) n *= 2; buf_size = (size_t*)realloc(buf_size, n * sizeof(size_t)); memset(buf_size + buf_size_n, 0, (n - buf_size_n) * sizeof(size_t)); buf_size_n = n; }
+  return &buf_size[id];
+}
 static void wr_pre_BufferData(uint32_t target, size_t size, void* data, uint32_t usage) {
   (void)data; (void)usage;
   uint32_t* b = binding(target);
-  if (b) buf_size[*b & 4095] = size;
+  if (b) *buf_slot(*b) = size;
 }
-static size_t wr_bound_size(uint32_t target) { uint32_t* b = binding(target); return b ? buf_size[*b & 4095] : 0; }
+static size_t wr_bound_size(uint32_t target) { uint32_t* b = binding(target); return b ? *buf_slot(*b) : 0; }
 static void wr_note_mapping(uint32_t target, void* ptr, intptr_t offset, size_t len, int write) {
   if (!ptr) return;
   for (int k = 0; k < 4; k++)
@@ -193,6 +209,11 @@ static void wr_post(int id) {
 static void wr_cap_write(void) {
   const char* path = getenv("WR_CAPTURE_FILE");
   if (!path || !G.n_calls) return;
+  if (G.blobs_len > 0xFFFFFFFFull || G.scratch + 64 > 0xFFFFFFFFull) {
+    /* the WRTR header holds both totals in 32 bits: a larger session cannot be written faithfully -- say so instead of truncating */
+    fprintf(stderr, "wr_capture: %zu payload bytes / %zu scratch bytes exceed the format's 4 GiB: %s NOT written\n", G.blobs_len, G.scratch, path);
+    return;
+  }
   FILE* f = fopen(path, "wb");
   if (!f) { fprintf(stderr, "wr_capture: cannot write %s\n", path); return; }
   uint32_t hdr[4] = {0x52545257u /* 'WRTR' */, G.n_calls, (uint32_t)G.blobs_len, (uint32_t)(G.scratch + 64)};

@@ -23,7 +23,7 @@ typedef struct wr_replay {
   size_t scratch_size;
 } wr_replay;
 
-enum { TAG_INT, TAG_F32, TAG_F64, TAG_BLOB, TAG_NULL, TAG_SCRATCH, TAG_CTX };
+enum { TAG_INT, TAG_F32, TAG_F64, TAG_BLOB, TAG_NULL, TAG_SCRATCH, TAG_CTX, TAG_SCRATCH_INIT };
 
 static inline float wr_f32(const wr_arg* a) { float f; uint32_t u = (uint32_t)a->value; memcpy(&f, &u, 4); return f; }
 static inline double wr_f64(const wr_arg* a) { double d; memcpy(&d, &a->value, 8); return d; }
@@ -31,6 +31,11 @@ static inline void* wr_ptr(wr_replay* R, const wr_arg* a) {
   switch (a->tag) {
     case TAG_BLOB: return (void*)(R->blobs + a->value);
     case TAG_SCRATCH: return (void*)(R->scratch + a->value);
+    case TAG_SCRATCH_INIT: {     /* scratch the callee reads now and writes later: starts as the recorded bytes (value = blob << 32 | scratch) */
+      void* p = (void*)(R->scratch + (a->value & 0xFFFFFFFFull));
+      memcpy(p, R->blobs + (a->value >> 32), a->aux);
+      return p;
+    }
     case TAG_CTX: return R->ctx;
     case TAG_INT: return (void*)(uintptr_t)a->value;
     default: return NULL;

@@ -224,7 +224,9 @@ struct Texture {
   GLuint depth_owner = 0;            // colour target whose pending work last used this depth attachment
   // hazards against the pending list
   int own_y0 = 0, own_y1 = 0;   // multi-GPU: owned pixel rows (0,0 = all)
-  bool own_none = false;        // ... or none at all: draws and clears into this target are dropped when they are recorded
+  // ... or none at all (y1 < y0, or a range that misses the texture as it is NOW: the answer follows the storage, a call made
+  // before TexStorage or a later resize does not freeze it): draws and clears into such a target are dropped when recorded
+  bool own_none() const { return own_y1 < own_y0 || (own_y1 > own_y0 && height > 0 && (own_y0 >= height || own_y1 <= 0)); }
   bool pending_read = false, pending_write = false;
   int pending_target = -1;   // index into Context::work when pending_write
   bool tail_ref = false;     // read or written by the deferred last raster level (Context::Tail)
@@ -285,6 +287,8 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
     {"ps_quad_conic_gradient", WR_SH_PS_QUAD_CONIC_GRADIENT, {"aPosition", "aData"},
      S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
+    // (the split polygons of a preserve-3d context, shade.rs:1226; PRIM_INSTANCES layout)
+    {"ps_split_composite", WR_SH_PS_SPLIT_COMPOSITE, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_opacity", WR_SH_BRUSH_OPACITY, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_opacity ANTIALIASING", WR_SH_BRUSH_OPACITY, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_opacity ALPHA_PASS", WR_SH_BRUSH_OPACITY_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
@@ -302,6 +306,9 @@ const ShaderInfo SHADERS[] = {
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
     {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", WR_SH_PS_TEXT_RUN_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    // (glyphs rasterised under the run's transform -- rotated / scaled text in screen raster space, shader_features.rs:222-226)
+    {"ps_text_run ALPHA_PASS,GLYPH_TRANSFORM,TEXTURE_2D", WR_SH_PS_TEXT_RUN_GT, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,GLYPH_TRANSFORM,TEXTURE_2D", WR_SH_PS_TEXT_RUN_DUAL_GT, {"aPosition", "aData"}, PRIM_SAMPLERS},
 #define CLIP_RECT_ATTRIBS                                                                                             \
   {"aPosition", "aClipDeviceArea", "aClipOrigins", "aDevicePixelScale", "aTransformIds", "aClipLocalPos",           \
    "aClipLocalRect", "aClipMode", "aClipRect_TL", "aClipRadii_TL", "aClipRect_TR", "aClipRadii_TR", "aClipRect_BL", \
@@ -486,11 +493,14 @@ struct Context {
   std::vector<WrhipKernelStat> kstats;   // per kernel variant, while profiling
   int shard_rank = 0, shard_world = 1;
   int next_query_slot = 0;
+  GLuint query_slot_owner[WR_QUERY_SLOTS] = {};   // the GL_SAMPLES_PASSED query that last took each device slot
   bool forward_composites = true;      // WRHIP_NO_FORWARD=1 turns the write-through of opaque 1:1 composites off
   bool profiling_no_forward = false;
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
+  int chain_grid = 0;                  // workgroups of a chained R8 launch (0: off -- the default; WRHIP_CHAIN=1 turns it on, WRHIP_CHAIN_GRID overrides)
+  unsigned chain_base = 0;             // value of WrUnsupportedCounters::chain_arrive once every chained launch enqueued so far has run
 
   Context() {
     wrrt::stream_create(&stream);
@@ -499,6 +509,12 @@ struct Context {
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
+    // Chained thin R8 levels (wr_raster_chain_kernel) are OFF unless WRHIP_CHAIN=1: measured on cfg4 (profiles/r03_e_chain_ab.txt),
+    // the five chained levels take 144 us in one launch against ~100 us + four kernel boundaries apart -- a grid barrier that has
+    // to write back and invalidate the XCDs' L2s (the levels run on all eight) costs about what a kernel boundary costs.
+    // (grid: half the CUs -- two contexts' chained launches may meet on the chip and every workgroup of both has to be resident)
+    if (thin_r8 && getenv("WRHIP_CHAIN") && atoi(getenv("WRHIP_CHAIN")) > 0)
+      chain_grid = getenv("WRHIP_CHAIN_GRID") ? atoi(getenv("WRHIP_CHAIN_GRID")) : wrrt::cu_count() / 2;
     cell_raster = getenv("WRHIP_NO_CELLS") == nullptr;
     mask_rows = getenv("WRHIP_NO_MASK_ROWS") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
@@ -945,7 +961,7 @@ void record_clear(GLuint tex_id, bool color, uint32_t color_value, bool depth, G
                   const int rect[4]) {
   {
     Texture& t = ctx->textures[tex_id];
-    if (!t.has_storage() || t.own_none) return;
+    if (!t.has_storage() || t.own_none()) return;
   }
   if (depth) {
     const Texture& ct = ctx->textures[tex_id];
@@ -1047,8 +1063,13 @@ bool can_fuse(const Context::Held& H) {
 #ifndef WR_THIN_MAX_BINS
 #define WR_THIN_MAX_BINS 256
 #endif
+// `chain_n` >= 2: H is the first of chain_n consecutive thin R8 launches of one variant (chainable()); they go out as one
+// wr_raster_chain_kernel launch.
+bool chainable(const Context::Held& H) {
+  return ctx->chain_grid > 0 && H.fmt == WR_FMT_R8 && H.nb <= WR_THIN_MAX_BINS && (H.feat == 0 || H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR));
+}
 void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
-                   const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0) {
+                   const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0, int chain_n = 1) {
   Context* c = ctx;
 #define WR_K(FMT, DEPTH, FEAT)                                                                                          \
   do {                                                                                                                  \
@@ -1083,6 +1104,31 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
       S.mr_seen = seen;
     }
     c->stats.kernel_launches++;
+  }
+  if (chain_n >= 2) {
+    WrChain ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.n = chain_n;
+    int widest = 0; uint64_t bytes = 0;
+    for (int i = 0; i < chain_n; i++) { ch.first[i] = (&H)[i].off; ch.count[i] = (&H)[i].nb; widest = std::max(widest, (&H)[i].nb); bytes += (&H)[i].algo_bytes; }
+    const int grid = std::max(1, std::min(widest, c->chain_grid));
+    // arrivals at the barrier after level l: the workgroups that have a bin at level l or later (the others have left)
+    for (int l = 0; l + 1 < chain_n; l++) {
+      int part = 0;
+      for (int k = l; k < chain_n; k++) part = std::max(part, std::min(grid, ch.count[k]));
+      c->chain_base += (unsigned)part;
+      ch.want[l] = c->chain_base;
+    }
+    prof_begin();
+    if (H.feat == 0)
+      WR_LAUNCH((wr_raster_chain_kernel<0>), grid, 1024, c->stream, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs,
+                (const WrAux*)S.aux, (const float*)S.vtab, S.masks, ch, &c->dcounters->chain_arrive, c->dcounters);
+    else
+      WR_LAUNCH((wr_raster_chain_kernel<WR_FEAT_GENERIC | WR_FEAT_BLUR>), grid, 1024, c->stream, targets, n_targets, draws, (const WrPrim*)S.prims,
+                (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, ch, &c->dcounters->chain_arrive, c->dcounters);
+    prof_end(4, H.fmt, chain_n, H.feat, bytes, (uint64_t)grid);
+    c->stats.kernel_launches++; c->stats.raster_launches++;
+    return;
   }
   prof_begin();
   if (SA) {
@@ -1124,12 +1170,25 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   prof_end(2, H.fmt, H.depth, H.feat, H.algo_bytes, (uint64_t)H.nb);
   c->stats.kernel_launches++; c->stats.raster_launches++;
 }
+// A flush's raster launches in order; runs of chainable() launches of one variant (only the first may have mask rows: its rows
+// launch goes ahead of the chain) leave as one launch.  `fuse_at`: the launch that carries the next flush's setup stage.
+void launch_held(const std::vector<Context::Held>& held, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
+                 int fuse_at = -1, const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0) {
+  for (size_t i = 0; i < held.size();) {
+    size_t j = i + 1;
+    if (chainable(held[i]) && !(S.mr_ctl == nullptr && held[i].mr_rows > 0))
+      while (j < held.size() && j - i < WR_MAX_CHAIN && chainable(held[j]) && held[j].feat == held[i].feat && held[j].mr_rows == 0 && (int)j != fuse_at) j++;
+    const bool fuse = (int)i == fuse_at;
+    launch_raster(held[i], targets, n_targets, draws, S, fuse ? SA : nullptr, fuse ? n_setup_blocks : 0, (int)(j - i));
+    i = j;
+  }
+}
 // Launch the held-back raster launches on their own (nothing to fuse them with, or their results are needed now).
 void drain_tail() {
   Context* c = ctx;
   if (!c || !c->tail.pending) return;
   Context::Tail& T = c->tail;
-  for (const Context::Held& H : T.held) launch_raster(H, T.targets, T.n_targets, T.draws, c->scratch[T.set]);
+  launch_held(T.held, T.targets, T.n_targets, T.draws, c->scratch[T.set]);
   tail_launched();
 }
 void sync_stream() {
@@ -1163,8 +1222,11 @@ static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
     const WrTexDesc& st = d.tex[WR_S_COLOR0];
     if (!st.ptr || st.format != WR_FMT_RGBA8) return false;
     int src = -1;
-    for (int wi : sel) if (&c->work[wi] != &fb && c->textures[c->work[wi].tex].dptr == st.ptr && c->work[wi].level < fb.level) src = wi;
+    // (a source that was itself forwarded away has no raster pass to store from, and one that already forwards into another
+    // target has its one write-through taken: both take the ordinary composite path)
+    for (int wi : sel) if (&c->work[wi] != &fb && c->textures[c->work[wi].tex].dptr == st.ptr && c->work[wi].level < fb.level && !c->work[wi].forwarded_away) src = wi;
     if (src < 0) return false;
+    if (c->work[src].fwd_tex && c->work[src].fwd_tex != fb.tex) return false;
     const Texture& stex = c->textures[c->work[src].tex];
     if (stex.own_y1 > stex.own_y0) return false;
     for (int i = 0; i < d.count; i++) {
@@ -1537,10 +1599,7 @@ void flush_work(const std::vector<int>& sel_in) {
         // variant for (normally the tile pass, the longest) carries this flush's setup stage along
         Context::Tail& T = c->tail;
         WrSetupArgs SA{ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims, dtargets, S.masks, S.vtab, c->dcounters, dblk};
-        for (size_t hi = 0; hi < T.held.size(); hi++) {
-          if ((int)hi == fuse_at) launch_raster(T.held[hi], T.targets, T.n_targets, T.draws, c->scratch[T.set], &SA, n_setup_blocks);
-          else launch_raster(T.held[hi], T.targets, T.n_targets, T.draws, c->scratch[T.set]);
-        }
+        launch_held(T.held, T.targets, T.n_targets, T.draws, c->scratch[T.set], fuse_at, &SA, n_setup_blocks);
         tail_launched();
       } else {
         prof_begin();
@@ -1593,7 +1652,7 @@ void flush_work(const std::vector<int>& sel_in) {
       if (!(draws[i].flags & WR_DF_SIMPLE)) {
         switch (draws[i].shader) {
           case WR_SH_PS_CLEAR: case WR_SH_CLEAR_OP: break;
-          case WR_SH_PS_TEXT_RUN: case WR_SH_PS_TEXT_RUN_DUAL: f = WR_FEAT_R8TEX | WR_FEAT_TEX | WR_FEAT_GENERIC; break;
+          case WR_SH_PS_TEXT_RUN: case WR_SH_PS_TEXT_RUN_DUAL: case WR_SH_PS_TEXT_RUN_GT: case WR_SH_PS_TEXT_RUN_DUAL_GT: f = WR_FEAT_R8TEX | WR_FEAT_TEX | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_SOLID: case WR_SH_BRUSH_SOLID_ALPHA: f = WR_FEAT_R8TEX | WR_FEAT_GENERIC; break;   // masked / odd blend
           case WR_SH_CS_BLUR_ALPHA: case WR_SH_CS_BLUR_COLOR: f = WR_FEAT_BLUR; break;
           case WR_SH_CS_CLIP_RECT: case WR_SH_CS_CLIP_RECT_FAST: case WR_SH_CS_CLIP_BOX_SHADOW:
@@ -1642,7 +1701,7 @@ void flush_work(const std::vector<int>& sel_in) {
       }
       for (GLuint id : T.refs) if (Texture* t = c->textures.find(id)) t->tail_ref = true;
     } else {
-      for (const Context::Held& H : launches) launch_raster(H, dtargets, n_targets, ddraws, S);
+      launch_held(launches, dtargets, n_targets, ddraws, S);
     }
     c->flush_seq++;
     c->stats.flushes++;
@@ -1844,9 +1903,24 @@ void BeginQuery(GLenum target, GLuint id) {
   if (target == GL_SAMPLES_PASSED) {
     // shaded pixels of the draws issued inside the query (gl.cc:2784-2787), counted by the setup stage into a device slot
     q.value = 0;
-    q.slot = ctx->next_query_slot; ctx->next_query_slot = (ctx->next_query_slot + 1) % WR_QUERY_SLOTS;
+    const int slot = ctx->next_query_slot;
+    ctx->next_query_slot = (ctx->next_query_slot + 1) % WR_QUERY_SLOTS;
+    // the slot's previous owner (64 queries ago, its result not read yet): its draws go out and its count is kept with the query
+    // before the slot is zeroed for this one
+    if (GLuint prev = ctx->query_slot_owner[slot]) {
+      Query* pq = ctx->queries.find(prev);
+      if (pq && pq->slot == slot && prev != id) {
+        flush_all();
+        unsigned long long v = 0;
+        wrrt::d2h(&v, &ctx->dcounters->samples[slot], sizeof(v), ctx->stream);
+        sync_stream();
+        pq->value = v; pq->slot = -1;
+      }
+    }
+    q.slot = slot; ctx->query_slot_owner[slot] = id;
     wrrt::memset8(&ctx->dcounters->samples[q.slot], 0, sizeof(unsigned long long), ctx->stream);
   } else if (target == GL_TIME_ELAPSED) {
+    q.slot = -1;             // (an id that once counted samples: its result is the time from here on)
     // TIME_ELAPSED must cover the GPU work issued inside the query (renderer
     // GpuProfiler, device/query_gl.rs:141-163): drain what came before.
     flush_all(); sync_stream();
@@ -2375,7 +2449,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   GLuint color_id = fb.color_attachment;
   {
     Texture& colortex = c->textures[color_id];
-    if (!colortex.dptr || colortex.own_none) return;      // (own_none: another rank's target, WrhipSetTargetRows)
+    if (!colortex.dptr || colortex.own_none()) return;      // (own_none: another rank's target, WrhipSetTargetRows)
     if (colortex.internal_format != GL_RGBA8 && colortex.internal_format != GL_R8) { refuse("colour target is neither RGBA8 nor R8"); return; }
   }
   VertexArray& v = c->vertex_arrays[c->current_vertex_array];
@@ -2486,7 +2560,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   d.blend = c->blend ? c->blend_key : WR_BLEND_NONE;
   // (GL_ONE, GL_ONE_MINUS_SRC1_COLOR under the dual-source text program is fine: every prim of that
   // program replaces the key with swgl_blendSubpixelText / swgl_blendDropShadow in its vertex stage)
-  const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && (info->kind == WR_SH_PS_TEXT_RUN_DUAL || info->kind == WR_SH_BRUSH_IMAGE_DUAL);      // (the image program writes the second colour itself)
+  const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && (info->kind == WR_SH_PS_TEXT_RUN_DUAL || info->kind == WR_SH_PS_TEXT_RUN_DUAL_GT || info->kind == WR_SH_BRUSH_IMAGE_DUAL);      // (the image program writes the second colour itself)
   if (!dual_text && (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC)) {
     // not in swgl's key table either (gl.cc:614-645: the reference asserts) -- or GL_ONE, GL_ONE_MINUS_SRC1_COLOR outside the
     // dual-source text program, which needs gl_SecondaryFragColor from a shader that is not implemented
@@ -2540,6 +2614,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
       const bool quad_prog = info->kind == WR_SH_PS_QUAD_TEXTURED || info->kind == WR_SH_PS_QUAD_MASK || info->kind == WR_SH_PS_QUAD_MASK_FAST ||
                              info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT || info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT;
       if (!ids_clean(quad_prog ? WR_S_GPU_BUFFER_I : WR_S_PRIM_HEADERS_I, !quad_prog)) d.flags |= WR_DF_XFORM;
+      if (info->kind == WR_SH_PS_SPLIT_COMPOSITE) d.flags |= WR_DF_XFORM;      // (its vertices are any convex quad, whatever the transform)
     }
     // textured prims on rotated quads or with swgl_antiAlias need the WR_PK_TEX_QUAD path (WR_FEAT_SHADE launches): the
     // transform ids in the bound header texture and the AA requests in the instances say whether this draw can hold any
@@ -2550,7 +2625,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
                      info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA;
     // (glyph quads under a rotation -- local raster space -- ride on the same path; the program never asks for swgl_antiAlias,
     // and a glyph instance's third word is not a brush's flags: the transform ids alone decide)
-    const bool text = info->kind == WR_SH_PS_TEXT_RUN || info->kind == WR_SH_PS_TEXT_RUN_DUAL;
+    const bool text = info->kind == WR_SH_PS_TEXT_RUN || info->kind == WR_SH_PS_TEXT_RUN_DUAL || info->kind == WR_SH_PS_TEXT_RUN_GT || info->kind == WR_SH_PS_TEXT_RUN_DUAL_GT;
     const bool texquad = (info->kind == WR_SH_PS_QUAD_TEXTURED && d.tex[WR_S_COLOR0].width >= 2) ||
                          info->kind == WR_SH_PS_QUAD_MASK || info->kind == WR_SH_PS_QUAD_MASK_FAST ||
                          info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT || info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT;
@@ -2569,6 +2644,8 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
       }
       if (quads) d.flags |= WR_DF_QUADS;
     }
+    // (a split polygon is a general quad by construction: ps_split_composite.glsl:85-87)
+    if (info->kind == WR_SH_PS_SPLIT_COMPOSITE && colortex.internal_format == GL_RGBA8) d.flags |= WR_DF_QUADS;
   }
   apply_scissor(colortex, d.clip);
   d.vp_origin[0] = float(c->viewport[0] - colortex.offx); d.vp_origin[1] = float(c->viewport[1] - colortex.offy);
@@ -2597,6 +2674,10 @@ void Finish(void) {
     WrUnsupportedCounters h;
     wrrt::d2h(&h, ctx->dcounters, sizeof(h), ctx->stream);
     sync_stream();
+    if (h.chain_timeout != ctx->seen.chain_timeout) {
+      fprintf(stderr, "libwrhip: %u workgroup(s) of a chained mask launch gave up at a level barrier: the masks of this frame are not trustworthy\n", h.chain_timeout - ctx->seen.chain_timeout);
+      ctx->last_error = GL_INVALID_OPERATION;
+    }
     if (h.unsupported_prims != ctx->seen.unsupported_prims || h.perspective_prims != ctx->seen.perspective_prims) {
       fprintf(stderr, "libwrhip: %u prim(s) not reproduced exactly (no implementation: not drawn; more depth runs on a row than the tables hold: drawn from the span start), %u perspective ones (clipped by the near / far planes, or a program whose perspective inputs are not restated): not drawn\n",
               h.unsupported_prims - ctx->seen.unsupported_prims, h.perspective_prims - ctx->seen.perspective_prims);
@@ -2765,8 +2846,6 @@ void WrhipSetTargetRows(GLuint tex, int32_t y0, int32_t y1) {
   flush_all();
   Texture& t = ctx->textures[tex];
   t.own_y0 = y0; t.own_y1 = y1;
-  t.own_none = y1 < y0 || y0 >= t.height || (y1 > y0 && y1 <= 0);
-  if (t.own_none) { t.own_y0 = t.height; t.own_y1 = t.height + 1; }
 }
 void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height, int32_t* stride) {
   Texture* t = ctx ? ctx->textures.find(tex) : nullptr;

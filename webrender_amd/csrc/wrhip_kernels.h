@@ -326,6 +326,7 @@ struct WrVsOut {
   int blend_override;  // swgl_blendDropShadow / swgl_blendSubpixelText: WrBlend key replacing the draw's (0 = none)
   wf4 blend_color;     // ... and its constant colour (swgl_BlendColorRGBA8)
   int dual; float dual_swz;   // brush_image DUAL_SOURCE_BLENDING (WrPrim::dual / dual_swz)
+  int cd[4];           // gl_ClipDistance of ps_text_run GLYPH_TRANSFORM as a box in target pixels (x0, y0, x1, y1; x1 < x0: none)
   float persp_div;     // brush_image: perspective_interpolate of `uv = v_uv * mix(gl_FragCoord.w, 1.0, .)` in main(); < 0: no such factor
 };
 
@@ -893,10 +894,78 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   o.has_color = (vcol.x != 1.0f || vcol.y != 1.0f || vcol.z != 1.0f || vcol.w != 1.0f) ? 1 : 0;
 }
 
+// ps_split_composite.glsl:19-113 (vertex stage): one polygon of a preserve-3d context that was split against the other planes
+// (batch.rs:1985-2080; picture.rs:6571-6622 leaves its four local points in the GPU cache).  The vertices are a bilinear
+// blend of those points -- any convex quad, also under an identity transform -- so the prim always takes the general-quad
+// path (WR_DF_QUADS is set for every draw of this program); the fragment side is the plain image one: span =
+// swgl_commitTextureRGBA8(sColor0, vUv * mix(gl_FragCoord.w, 1, vPerspective.x), vUvSampleBounds), main() = the clamped texel.
+WR_DEVICE void wr_vs_ps_split_composite(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
+  const wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
+  const int prim_header_index = aData.x, polygons_address = aData.y, render_task_index = aData.w;
+  const float ci_z = float(aData.z);
+  const WrTexDesc& gc = d.tex[WR_S_GPU_CACHE];
+  const int gu = int(unsigned(polygons_address) % 1024u), gv = int(unsigned(polygons_address) / 1024u);
+  const wf4 g0 = wr_fetch_f(gc, gu, gv), g1 = wr_fetch_f(gc, gu + 1, gv);
+  int u, v;
+  wr_fetch_uv(prim_header_index, 2u, u, v);
+  const wf4 local_rect = wr_fetch_f(d.tex[WR_S_PRIM_HEADERS_F], u, v);
+  const wi4 data0 = wr_fetch_i(d.tex[WR_S_PRIM_HEADERS_I], u, v);
+  const wi4 data1 = wr_fetch_i(d.tex[WR_S_PRIM_HEADERS_I], u + 1, v);
+  const WrTransform transform = wr_fetch_transform(d, data0.z);
+  const WrTask task = wr_fetch_task(d, render_task_index);
+  wf2 ca_p0 = {0.f, 0.f}, ca_p1 = {0.f, 0.f}, ca_origin = {0.f, 0.f};
+  if (data1.w < 0x7FFFFFFF) {
+    const WrTask ct = wr_fetch_task(d, data1.w);
+    ca_p0 = ct.p0; ca_p1 = ct.p1; ca_origin = ct.origin;
+  }
+  o.aa_edges = 0;
+  o.has_mask = ((ca_p1.x - ca_p0.x) != 0.0f || (ca_p1.y - ca_p0.y) != 0.0f) ? 1 : 0;
+  o.mask_offset[0] = (task.p0.x - task.origin.x) - (ca_p0.x - ca_origin.x);
+  o.mask_offset[1] = (task.p0.y - task.origin.y) - (ca_p0.y - ca_origin.y);
+  o.mask_bb[0] = ca_p0.x; o.mask_bb[1] = ca_p0.y; o.mask_bb[2] = ca_p1.x - ca_p0.x; o.mask_bb[3] = ca_p1.y - ca_p0.y;
+  const float dox = task.p0.x - task.origin.x, doy = task.p0.y - task.origin.y;       // dest_origin
+  const int src = data1.x;
+  const wf4 res0 = wr_fetch_f(gc, int(unsigned(src) % 1024u), int(unsigned(src) / 1024u));     // fetch_image_source
+  const int qa = src + 2;
+  const int qu = int(unsigned(qa) % 1024u), qv = int(unsigned(qa) / 1024u);
+  const wf4 st_tl = wr_fetch_f(gc, qu, qv), st_tr = wr_fetch_f(gc, qu + 1, qv);
+  const wf4 st_bl = wr_fetch_f(gc, qu + 2, qv), st_br = wr_fetch_f(gc, qu + 3, qv);
+  const WrTexDesc& tex = d.tex[WR_S_COLOR0];
+  const float tsx = float(tex.ptr ? tex.width : 1), tsy = float(tex.ptr ? tex.height : 1);
+  const float persp = float(data1.y);
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    // bilerp(local[0], local[1], local[3], local[2], aPosition.y, aPosition.x): mix(a, b, t) = (b - a) * t + a
+    const float xx = (g0.z - g0.x) * ax + g0.x, xy = (g0.w - g0.y) * ax + g0.y;        // mix(local[0], local[1], t)
+    const float yx = (g1.x - g1.z) * ax + g1.z, yy = (g1.y - g1.w) * ax + g1.w;        // mix(local[3], local[2], t)
+    const float lx = (yx - xx) * ay + xx, ly = (yy - xy) * ay + xy;
+    const wf4 world = wr_mul(transform.m, wf4{lx, ly, 0.0f, 1.0f});
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform,
+                          wf4{dox * world.w + world.x * task.dps, doy * world.w + world.y * task.dps, world.w * ci_z, world.w});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+    float fx = (lx - local_rect.x) / (local_rect.z - local_rect.x), fy = (ly - local_rect.y) / (local_rect.w - local_rect.y);
+    // get_image_quad_uv (prim_shared.glsl:204-210)
+    const float hxx = (st_tr.x - st_tl.x) * fx + st_tl.x, hxy = (st_tr.y - st_tl.y) * fx + st_tl.y, hxw = (st_tr.w - st_tl.w) * fx + st_tl.w;
+    const float hyx = (st_br.x - st_bl.x) * fx + st_bl.x, hyy = (st_br.y - st_bl.y) * fx + st_bl.y, hyw = (st_br.w - st_bl.w) * fx + st_bl.w;
+    const float zx = (hyx - hxx) * fy + hxx, zy = (hyy - hxy) * fy + hxy, zw = (hyw - hxw) * fy + hxw;
+    fx = zx / zw; fy = zy / zw;
+    const float uu = (res0.z - res0.x) * fx + res0.x, vv = (res0.w - res0.y) * fy + res0.y;
+    const float pm = (1.0f - gp.w) * persp + gp.w;          // mix(gl_Position.w, 1.0, perspective_interpolate)
+    o.u[n] = uu / tsx * pm; o.v[n] = vv / tsy * pm;
+  }
+  const float mnx = wr_min(res0.x, res0.z), mny = wr_min(res0.y, res0.w), mxx = wr_max(res0.x, res0.z), mxy = wr_max(res0.y, res0.w);
+  o.uv_bounds = wf4{(mnx + 0.5f) / tsx, (mny + 0.5f) / tsy, (mxx - 0.5f) / tsx, (mxy - 0.5f) / tsy};
+  o.tex_slot = WR_S_COLOR0;
+  o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.has_color = 0; o.tail_clamp = 1; o.tail_modulate = 0;
+  o.kind = tex.format == WR_FMT_RGBA8 ? WR_PK_TEX_RGBA8 : WR_PK_UNSUPPORTED;      // (picture surfaces are RGBA8; no swgl_drawSpanR8 in the program)
+  o.persp_div = persp;
+}
+
 // ps_text_run.glsl:98-268, non-GLYPH_TRANSFORM branch (vertex stage), with the
 // prim_shared.glsl helpers.  Colour modes that need a blend override
 // (swgl_blendDropShadow / swgl_blendSubpixelText, :229-247) are "next".
-WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int inst, bool dual_source, WrVsOut& o) {
+WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int inst, bool dual_source, WrVsOut& o, bool glyph_transform = false) {
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int glyph_index = aData.z & 0xffff, flags = aData.z >> 16;
@@ -933,18 +1002,71 @@ WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int 
   float res_scale = res1.z;
   float sbx = (subpx_dir == 1 || subpx_dir == 3) ? 0.125f : 0.5f;   // get_snap_bias
   float sby = (subpx_dir == 2 || subpx_dir == 3) ? 0.125f : 0.5f;
-  float raster_scale = float(data1.x) / 65535.0f;
-  float grs = raster_scale * task.dps;
-  float gsi = res_scale / grs;
-  float rgx = floorf(gox * grs + sbx) / res_scale, rgy = floorf(goy * grs + sby) / res_scale;
-  float g0x = gsi * (res1.x + rgx) + tox, g0y = gsi * (res1.y + rgy) + toy;
-  float g1x = g0x + gsi * (uvr.z - uvr.x), g1y = g0y + gsi * (uvr.w - uvr.y);
   o.aa_edges = 0;
   o.has_mask = ((ca_p1.x - ca_p0.x) != 0.0f || (ca_p1.y - ca_p0.y) != 0.0f) ? 1 : 0;
   const WrTexDesc& atlas = d.tex[WR_S_COLOR0];
   float tsx = float(atlas.width), tsy = float(atlas.height);
   float st0x = uvr.x / tsx, st0y = uvr.y / tsy, st1x = uvr.z / tsx, st1y = uvr.w / tsy;
   float fox = -task.origin.x + task.p0.x, foy = -task.origin.y + task.p0.y;
+  bool gt_persp = false;
+  if (glyph_transform) {
+    // WR_FEATURE_GLYPH_TRANSFORM (ps_text_run.glsl:24-35, 130-165, 206-216): the glyphs were rasterised under the run's 2-D
+    // transform, so glyph space is device space less the translation.  mat2(transform.m) * dps, its inverse (glsl.h:2905-2908:
+    // the factor is float(1. / det) computed in double), the glyph rect snapped in glyph space, its bounding rect in local space.
+    const float a00 = transform.m.c[0].x * task.dps, a01 = transform.m.c[0].y * task.dps;     // column 0
+    const float a10 = transform.m.c[1].x * task.dps, a11 = transform.m.c[1].y * task.dps;     // column 1
+    const float gtx = transform.m.c[3].x * task.dps, gty = transform.m.c[3].y * task.dps;     // glyph_translation
+    const float det = a00 * a11 - a01 * a10;
+    const float idf = float(1.0 / double(det));
+    const float i00 = a11 * idf, i01 = -a01 * idf, i10 = -a10 * idf, i11 = a00 * idf;
+    const float rgx = floorf((a00 * gox + a10 * goy) + sbx), rgy = floorf((a01 * gox + a11 * goy) + sby);
+    const float rtx = floorf(((a00 * tox + a10 * toy) + gtx) + 0.5f) - gtx, rty = floorf(((a01 * tox + a11 * toy) + gty) + 0.5f) - gty;
+    const float q0x = (res1.x + rgx) + rtx, q0y = (res1.y + rgy) + rty;                       // glyph_origin
+    const float q1x = (q0x + uvr.z) - uvr.x, q1y = (q0y + uvr.w) - uvr.y;
+    // transform_rect(glyph_rect, glyph_transform_inv)
+    const float szx = q1x - q0x, szy = q1y - q0y;
+    const float hx = q0x + szx * 0.5f, hy = q0y + szy * 0.5f;
+    const float cxl = i00 * hx + i10 * hy, cyl = i01 * hx + i11 * hy;
+    const float rdx = fabsf(i00) * (szx * 0.5f) + fabsf(i10) * (szy * 0.5f), rdy = fabsf(i01) * (szx * 0.5f) + fabsf(i11) * (szy * 0.5f);
+    const float l0x = cxl - rdx, l0y = cyl - rdy, l1x = cxl + rdx, l1y = cyl + rdy;
+    const bool inside = local_clip.x <= l0x && local_clip.y <= l0y && l1x <= local_clip.z && l1y <= local_clip.w;       // rect_inside_rect
+    for (int n = 0; n < 4; n++) {
+      const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+      float lx = (l1x - l0x) * ax + l0x, ly = (l1y - l0y) * ay + l0y;
+      if (inside) {
+        const float mx = (q1x - q0x) * ax + q0x, my = (q1y - q0y) * ay + q0y;
+        lx = i00 * mx + i10 * my; ly = i01 * mx + i11 * my;
+      }
+      lx = wr_clamp(lx, local_clip.x, local_clip.z); ly = wr_clamp(ly, local_clip.y, local_clip.w);
+      const wf4 world = wr_mul(transform.m, wf4{lx, ly, 0.0f, 1.0f});
+      const float dx = world.x * task.dps, dy = world.y * task.dps;
+      const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{dx + fox * world.w, dy + foy * world.w, z * world.w, world.w});
+      o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+      if (world.w != 1.0f) gt_persp = true;
+      const float fx = ((a00 * lx + a10 * ly) - q0x) / (q1x - q0x), fy = ((a01 * lx + a11 * ly) - q0y) / (q1y - q0y);
+      o.u[n] = (st1x - st0x) * fx + st0x; o.v[n] = (st1y - st0y) * fy + st0y;
+    }
+    // gl_ClipDistance = (f, 1 - f) (SWGL_CLIP_DIST): every span is cut to where all four are >= 0 (clip_distance_range,
+    // rasterize.h:564-595).  f is affine in the device position -- glyph space is device space less the translation -- and
+    // zero / one on the glyph's raster rect, whose corners are whole device pixels by construction (raster_glyph_offset and
+    // raster_text_offset are floor()ed), half a pixel away from every pixel centre: the intercepts swgl computes from the edge
+    // interpolants land within float noise (1e-4) of those integers and round to them, so the cut IS that rect.  It travels
+    // as a box in target pixels that wr_finish_prim intersects the prim's box with; the span of a row starts at the box.
+    {
+      const wf4 g0 = wr_mul(*(const WrMat4*)d.transform, wf4{(q0x + gtx) + fox, (q0y + gty) + foy, 0.0f, 1.0f});
+      const wf4 g1 = wr_mul(*(const WrMat4*)d.transform, wf4{(q1x + gtx) + fox, (q1y + gty) + foy, 0.0f, 1.0f});
+      const float x0s = (g0.x / g0.w + 1.0f) * 0.5f * d.vp_size[0] + d.vp_origin[0], x1s = (g1.x / g1.w + 1.0f) * 0.5f * d.vp_size[0] + d.vp_origin[0];
+      const float y0s = (g0.y / g0.w + 1.0f) * 0.5f * d.vp_size[1] + d.vp_origin[1], y1s = (g1.y / g1.w + 1.0f) * 0.5f * d.vp_size[1] + d.vp_origin[1];
+      o.cd[0] = int(floorf(wr_min(x0s, x1s) + 0.5f)); o.cd[2] = int(floorf(wr_max(x0s, x1s) + 0.5f));
+      o.cd[1] = int(floorf(wr_min(y0s, y1s) + 0.5f)); o.cd[3] = int(floorf(wr_max(y0s, y1s) + 0.5f));
+    }
+  } else {
+  float raster_scale = float(data1.x) / 65535.0f;
+  float grs = raster_scale * task.dps;
+  float gsi = res_scale / grs;
+  float rgx = floorf(gox * grs + sbx) / res_scale, rgy = floorf(goy * grs + sby) / res_scale;
+  float g0x = gsi * (res1.x + rgx) + tox, g0y = gsi * (res1.y + rgy) + toy;
+  float g1x = g0x + gsi * (uvr.z - uvr.x), g1y = g0y + gsi * (uvr.w - uvr.y);
   for (int n = 0; n < 4; n++) {
     float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
     float lx = (g1x - g0x) * ax + g0x, ly = (g1y - g0y) * ay + g0y;
@@ -956,6 +1078,7 @@ WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int 
     o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
     float fx = (lx - g0x) / (g1x - g0x), fy = (ly - g0y) / (g1y - g0y);
     o.u[n] = (st1x - st0x) * fx + st0x; o.v[n] = (st1y - st0y) * fy + st0y;
+  }
   }
   o.uv_bounds = wf4{(uvr.x + 0.5f) / tsx, (uvr.y + 0.5f) / tsy, (uvr.z + -0.5f) / tsx, (uvr.w + -0.5f) / tsy};
   o.tex_slot = WR_S_COLOR0;
@@ -985,6 +1108,9 @@ WR_DEVICE void wr_vs_ps_text_run(const WrDrawDesc& d, const uint8_t* arena, int 
     if (color_mode == 3) { o.kind = WR_PK_UNSUPPORTED; return; }   // colour bitmaps are never batched with the dual-source program
     o.has_color = 0; o.tail_modulate = 1;       // main(): v_color (1) * mask, unswizzled
   }
+  // (the frame builder only selects GLYPH_TRANSFORM for transforms that reduce to 2-D, ps_text_run.glsl:139-142; under a
+  // projective one the clip distances are not a device rect: reported, not drawn)
+  if (gt_persp) o.kind = WR_PK_UNSUPPORTED;
 }
 
 // exp() of the vertex stage.  The reference calls libm expf (glsl.h:803), which
@@ -1940,7 +2066,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // (textures: ps_quad_textured and the plain brush_image keys, whose main() is restated with its perspective inputs)
     // (and brush_opacity, brush_blend, brush_linear_gradient: main() on the perspective-correct varying)
     const bool ptex = ((d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS)) ||
-                      ((d.shader == WR_SH_PS_TEXT_RUN || d.shader == WR_SH_PS_TEXT_RUN_DUAL) && (o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_RGBA8)) ||
+                      ((d.shader == WR_SH_PS_TEXT_RUN || d.shader == WR_SH_PS_TEXT_RUN_DUAL) && (o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_RGBA8)) ||      /* (the GLYPH_TRANSFORM keys never reach here with a projective transform: their vertex stage reports it) */
                       o.kind == WR_PK_FILTER || (o.kind == WR_PK_QUAD_MASK && auxp->clip.w == 1.0f) || (o.kind == WR_PK_TEX_REPEAT && o.persp_div >= 0.0f) || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
                                                                               d.shader == WR_SH_PS_QUAD_RADIAL_GRADIENT || d.shader == WR_SH_PS_QUAD_CONIC_GRADIENT));
     if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
@@ -2051,6 +2177,9 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     auxp->quad.pad = persp ? ((o.kind == WR_PK_SOLID && d.shader != WR_SH_PS_QUAD_TEXTURED) ? 1 : 2) : 0;
     if (persp) auxp->quad.persp.div = o.persp_div;
     P.x0 = wr_imax(bx0, int(cx0)); P.x1 = wr_imin(bx1, int(cx1)); P.y0 = wr_imax(by0, int(cy0)); P.y1 = wr_imin(by1, int(ceilf(cy1)));
+    // gl_ClipDistance (ps_text_run GLYPH_TRANSFORM: WrVsOut::cd): the rows' spans are cut to the box after they are rounded
+    // (rasterize.h:953-955) -- the raster stage intersects every span with the prim's box and starts the span there
+    if (o.cd[2] >= o.cd[0]) { P.x0 = wr_imax(P.x0, o.cd[0]); P.y0 = wr_imax(P.y0, o.cd[1]); P.x1 = wr_imin(P.x1, o.cd[2]); P.y1 = wr_imin(P.y1, o.cd[3]); }
     if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
     P.rows_linear = 0;
     if (solidq) {
@@ -2108,6 +2237,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   int iy1 = int(floorf(ylimit - 0.5f)) + 1;
   while ((float(iy1) + 0.5f) <= ylimit) iy1++;
   while (iy1 > iy0 && (float(iy1 - 1) + 0.5f) > ylimit) iy1--;
+  // (gl_ClipDistance as a box, see above.  An axis-aligned glyph quad is the glyph's raster rect, or what the local clip rect
+  // leaves of it: it lies inside the box, the cut is a no-op; x and the last row are cut all the same, the first row is not --
+  // the edge interpolants start from it)
+  if (o.cd[2] >= o.cd[0]) { ix0 = wr_imax(ix0, o.cd[0]); ix1 = wr_imin(ix1, o.cd[2]); iy1 = wr_imin(iy1, o.cd[3]); }
   if (ix1 <= ix0 || iy1 <= iy0) return;
   P.x0 = ix0; P.x1 = ix1; P.y0 = iy0; P.y1 = iy1;
   P.kind = (masked && o.kind == WR_PK_SOLID) ? (int16_t)WR_PK_SOLID_MASKED : (aa ? (int16_t)WR_PK_SOLID_AA : (int16_t)o.kind);
@@ -3157,6 +3290,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
   o.tex_slot = 0; o.uv_bounds = wf4{0, 0, 0, 0}; o.tail_clamp = 0; o.tail_modulate = 0;
   o.uv_add[0] = o.uv_add[1] = 0.0f;
   o.blend_override = 0; o.blend_color = wf4{0, 0, 0, 0}; o.persp_div = -1.0f; o.dual = 0; o.dual_swz = 0.0f;
+  o.cd[0] = o.cd[1] = 0; o.cd[2] = o.cd[3] = -1;
   switch (d.shader) {
     case WR_SH_PS_QUAD_TEXTURED: wr_vs_ps_quad_textured(d, arena, inst, o); break;
     case WR_SH_PS_QUAD_MASK: wr_vs_ps_quad_textured(d, arena, inst, o, 1, &aux[gid].clip); break;
@@ -3183,6 +3317,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
     case WR_SH_PS_TEXT_RUN: wr_vs_ps_text_run(d, arena, inst, false, o); break;
     case WR_SH_PS_TEXT_RUN_DUAL: wr_vs_ps_text_run(d, arena, inst, true, o); break;
+    case WR_SH_PS_TEXT_RUN_GT: wr_vs_ps_text_run(d, arena, inst, false, o, true); break;
+    case WR_SH_PS_TEXT_RUN_DUAL_GT: wr_vs_ps_text_run(d, arena, inst, true, o, true); break;
     case WR_SH_CS_BLUR_ALPHA: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     case WR_SH_CS_BLUR_COLOR: wr_vs_cs_blur(d, arena, inst, o, aux[gid].blur); break;
     case WR_SH_CS_CLIP_RECT: wr_vs_cs_clip_rect(d, arena, inst, false, o, aux[gid].clip); break;
@@ -3190,6 +3326,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_CLIP_BOX_SHADOW: wr_vs_cs_clip_box_shadow(d, arena, inst, o, aux[gid].box); break;
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
     case WR_SH_PS_COPY: wr_vs_ps_copy(d, arena, inst, o); break;
+    case WR_SH_PS_SPLIT_COMPOSITE: wr_vs_ps_split_composite(d, arena, inst, o); break;
     case WR_SH_CS_BORDER_SOLID: wr_vs_cs_border_solid(d, arena, inst, o, aux[gid].border); break;
     case WR_SH_CS_BORDER_SEGMENT: wr_vs_cs_border_segment(d, arena, inst, o, aux[gid].bseg); break;
     case WR_SH_CS_FAST_LINEAR_GRADIENT: wr_vs_cs_fast_linear_gradient(d, arena, inst, o, aux[gid].fgrad); break;
@@ -3233,7 +3370,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     // GL_SAMPLES_PASSED: ctx->shaded_pixels += span.len() for every row with a non-empty span, before any depth test
     unsigned long long n = 0;
     if (P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) {
-      for (int y = P.y0; y < P.y1; y++) { int s0, s1; if (wr_quad_row_span(aux[gid].quad, y, s0, s1) && s1 > s0) n += (unsigned long long)(s1 - s0); }
+      for (int y = P.y0; y < P.y1; y++) { int s0, s1; if (wr_quad_row_span(aux[gid].quad, y, s0, s1)) { s0 = wr_imax(s0, P.x0); s1 = wr_imin(s1, P.x1); if (s1 > s0) n += (unsigned long long)(s1 - s0); } }
     } else {
       n = (unsigned long long)(P.x1 - P.x0) * (unsigned long long)(P.y1 - P.y0);
     }
@@ -3982,6 +4119,9 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
   bool aa_skip = false;
   if (!Q.aa) {
     s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
+    // (the prim's box holds every span of the walk, so this changes nothing -- except under gl_ClipDistance, whose cut the
+    // setup stage folded into the box: span.intersect(clip_distance_range), rasterize.h:953-955)
+    s0 = wr_imax(s0, Pp->x0); s1 = wr_imin(s1, Pp->x1);
     if (x < s0 || x >= s1) return dstp;
   } else {
     const float radl = 0.5f * fabsf(S.ls), radr = 0.5f * fabsf(S.rs);
@@ -7603,6 +7743,58 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                  unsigned long long* __restrict__ masks, int bin_offset) {
   wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)blockIdx.x + bin_offset);
+}
+
+// A run of consecutive thin R8 levels in ONE launch (cfg4: corner-mask bins -> 2 x cs_scale -> cs_blur V / H are five
+// dependent launches of 144 / 36 / 9 / 9 / 9 workgroups): a persistent grid of at most one workgroup per CU walks level
+// after level, `bin = first + blockIdx.x, += gridDim.x`, with a grid-wide barrier in between -- an arrive counter in HBM
+// that is never reset (the host knows its value at launch, and how many workgroups still take part in each level:
+// launches of one stream are ordered), released / acquired at agent scope so a level's stores are written back from its
+// XCD's L2 and the next level's loads do not hit stale lines.  Every workgroup is resident (grid <= CUs, 1024 threads at
+// <= 128 VGPRs); a workgroup that nevertheless waits longer than a few seconds gives up, counts it
+// (WrUnsupportedCounters::chain_timeout -> GL_INVALID_OPERATION at Finish) and carries on rather than hang the queue.
+// MEASURED (cfg4, MI355X, profiles/r03_e_chain_ab.txt): bit-exact, but NOT faster -- 144 us for the five levels against
+// ~100 us + four kernel boundaries as separate launches (3.18 k vs 3.47 k frames/s): the L2 write-back + invalidate a
+// cross-XCD barrier needs costs what a kernel boundary costs (~13 us per level here; 217 us with all sixteen waves issuing
+// the invalidate, 280 us with acquire-polling).  Kept behind WRHIP_CHAIN=1, off by default.
+struct WrChain { int n; int first[WR_MAX_CHAIN]; int count[WR_MAX_CHAIN]; unsigned want[WR_MAX_CHAIN]; };   // want[l]: the arrive counter once level l is complete
+template <int FEAT>
+__global__ void __launch_bounds__(1024)
+wr_raster_chain_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
+                       const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                       const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
+                       unsigned long long* __restrict__ masks, WrChain ch, unsigned* __restrict__ arrive,
+                       WrUnsupportedCounters* __restrict__ cnt) {
+#ifndef WRHIP_HOSTSIM
+  for (int l = 0; l < ch.n; l++) {
+    for (int b = (int)blockIdx.x; b < ch.count[l]; b += (int)gridDim.x) {
+      wr_raster_body<WR_FMT_R8, false, 1, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, ch.first[l] + b);
+      __syncthreads();                      // (the body's LDS rows are reused by the next bin)
+    }
+    if (l + 1 == ch.n) break;
+    // (a workgroup past its last bin -- the levels of a mask chain shrink: 144, 36, 9, 9, 9 bins -- arrives and leaves: a crowd of
+    // idle workgroups polling one address slows the few that still work)
+    bool more = false;
+    for (int k = l + 1; k < ch.n; k++) more = more || (int)blockIdx.x < ch.count[k];
+    __syncthreads();                        // every wave's stores are issued and waited for ...
+    if (threadIdx.x == 0) {
+      const unsigned want = ch.want[l];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                     // ... and written back before the arrival shows
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      // (relaxed polls: an acquire per poll would invalidate the caches again and again -- 280 us per launch; ONE acquire follows
+      // the loop, from this wave only -- the invalidate it issues covers the CU's vector cache and the XCD's L2, which the
+      // other fifteen waves share: 217 -> 144 us)
+      while (more && (int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 21)) { atomicAdd(&cnt->chain_timeout, 1u); break; }
+      }
+      if (more) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (!more) return;                      // (the host counts only the workgroups that still take part in a level: ch.want)
+    __syncthreads();
+  }
+#endif
 }
 
 // The setup stage of flush k+1 and the last raster level of flush k in ONE launch: the first

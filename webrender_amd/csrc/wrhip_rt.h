@@ -49,6 +49,7 @@ typedef struct { double t; } wr_event_t;
       }                                                                 \
   } while (0)
 namespace wrrt {
+static inline int cu_count() { return 0; }
 static inline bool init(int*, char* name, size_t n) { snprintf(name, n, "hostsim (CPU, tests only)"); return true; }
 static inline void* dev_alloc(size_t n) { return calloc(1, n ? n : 1); }
 static inline void* try_dev_alloc(size_t n) { const char* lim = getenv("WRHIP_HOSTSIM_ALLOC_LIMIT"); if (lim && n > (size_t)atoll(lim)) return nullptr; return calloc(1, n ? n : 1); }
@@ -178,6 +179,8 @@ static inline void drain() { q().drain(); }
     });                                                                                                \
   } while (0)
 namespace wrrt {
+static inline int& cu_count_ref() { static int n = 0; return n; }
+static inline int cu_count() { return cu_count_ref(); }
 static inline bool init(int* device, char* name, size_t n) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return false;
@@ -188,6 +191,7 @@ static inline bool init(int* device, char* name, size_t n) {
   hipDeviceProp_t prop;
   WR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
   snprintf(name, n, "%s (%s)", prop.name, prop.gcnArchName);
+  cu_count_ref() = prop.multiProcessorCount;
   *device = dev;
   wrq::q().start(dev);
   return true;

@@ -75,6 +75,9 @@ enum WrShader {
   WR_SH_BRUSH_MIX_BLEND,           // brush_mix_blend (batch.rs:1931-2003)
   WR_SH_BRUSH_MIX_BLEND_ALPHA,
   WR_SH_PS_COPY,                   // texture-cache copies, batched uploads (renderer/mod.rs:1808-1846, upload.rs:540-620)
+  WR_SH_PS_TEXT_RUN_GT,            // ps_text_run ALPHA_PASS,GLYPH_TRANSFORM,TEXTURE_2D (glyphs rasterised under the run's 2-D transform)
+  WR_SH_PS_TEXT_RUN_DUAL_GT,       // ... with DUAL_SOURCE_BLENDING
+  WR_SH_PS_SPLIT_COMPOSITE,        // the split polygons of a preserve-3d context (batch.rs:1985-2080)
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -538,10 +541,13 @@ struct WrFlushParams {
 
 // statistics mirrored into WrhipStats (include/wrhip.h)
 #define WR_QUERY_SLOTS 64
+#define WR_MAX_CHAIN 8           // levels one chained R8 launch may hold
 struct WrUnsupportedCounters {
   uint32_t unsupported_prims;
   uint32_t perspective_prims;
   uint32_t dbg[6];          // diagnostics (WRHIP_DEBUG_COUNTERS)
+  uint32_t chain_timeout;   // workgroups of a chained launch (wr_raster_chain_kernel) that gave up waiting at a level barrier
+  uint32_t chain_arrive;    // that kernel's arrive counter (never reset: the host tracks its value)
   unsigned long long samples[WR_QUERY_SLOTS];   // GL_SAMPLES_PASSED: shaded pixels = sum of span lengths (rasterize.h:957-958, gl.cc:2784-2787)
 };
 

@@ -202,7 +202,7 @@ def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127)):
 
 def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=25, seed=3,
               glyph_zoom=1.0, device_pixel_scale=1.0, tile_filter=None, color_modes=(0,), dual_source=False, rotate=False,
-              perspective=False, **kw):
+              perspective=False, glyph_transform=False, **kw):
     """`lines` x `glyphs_per_line` glyphs in runs of `run_len`, black-ish text
     on white, COLOR_MODE_ALPHA from an R8 atlas, PremultipliedAlpha blend
     (batch.rs:1109-1290).  glyph_zoom != 1 draws the cached bitmaps magnified
@@ -213,7 +213,12 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
     (batch.rs:1150-1180: BlendMode::SubpixelDualSource).
     rotate / perspective: two runs in three sit under a rotation (skew) about their origin, with a projective row on top for
     `perspective` -- local-raster-space text: the glyph quads are laid out in local space by the non-GLYPH_TRANSFORM program and
-    transformed as quads."""
+    transformed as quads.
+    glyph_transform: screen-raster-space text under 2-D transforms (the GLYPH_TRANSFORM keys, batch.rs:1186-1200 /
+    shade.rs:1190-1210: the glyphs are rasterised under the run's transform, the program snaps them in device space and cuts
+    every span to the glyph's raster rect with gl_ClipDistance): four runs in five rotated / skewed, one scaled; every third
+    run under a local clip rect that cuts through its glyphs (the clamped quad is then a rotated rect reaching beyond the
+    glyph's raster rect)."""
     rng = np.random.default_rng(seed)
     atlas, table = build_glyph_atlas()
     sizes = sorted({k[0] for k in table})
@@ -263,12 +268,27 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
             bx0, bx1 = origin[0] * dps - 2 * size, (origin[0] + x) * dps + 2 * size
             by0, by1 = origin[1] * dps - asc, origin[1] * dps + 0.5 * size * k_dev + 2
             tid = 0
-            if (rotate or perspective) and len(runs) % 3 != 2:
+            lclip = (-BIG, -BIG, BIG, BIG)
+            if glyph_transform:
+                rad = float(np.hypot(x, 2.0 * size * k_dev / dps)) + 4.0
+                if len(runs) % 5 == 4:       # an axis-aligned scale (is_axis_aligned stays set)
+                    sx_, sy_ = float(rng.choice([1.25, 0.8, 1.0])), float(rng.choice([1.5, 0.75]))
+                    m = np.eye(4)
+                    m[0, 0], m[1, 1] = sx_, sy_
+                    m[:2, 3] = np.array(origin) - np.array([sx_ * origin[0], sy_ * origin[1]])
+                    tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=True)
+                else:
+                    tid = rotation_about(frame, rng, origin[0], origin[1], len(runs), None)
+                if len(runs) % 3 == 1:
+                    lclip = (origin[0] + 0.31 * x, origin[1] - 0.55 * size, origin[0] + 0.83 * x + 0.4, origin[1] + 0.12 * size)
+                rr = rad * dps * 1.6
+                bx0, bx1, by0, by1 = origin[0] * dps - rr, origin[0] * dps + rr, origin[1] * dps - rr, origin[1] * dps + rr
+            elif (rotate or perspective) and len(runs) % 3 != 2:
                 rad = float(np.hypot(x, 2.0 * size * k_dev / dps)) + 4.0
                 tid = rotation_about(frame, rng, origin[0], origin[1], len(runs), rad if perspective else None)
                 rr = rad * dps * (2.2 if perspective else 1.1)
                 bx0, bx1, by0, by1 = origin[0] * dps - rr, origin[0] * dps + rr, origin[1] * dps - rr, origin[1] * dps + rr
-            runs.append((origin, ref, color, size, run_chars, pts, (bx0, by0, bx1, by1), z, tid))
+            runs.append((origin, ref, color, size, run_chars, pts, (bx0, by0, bx1, by1), z, tid, lclip))
             z += 1
 
     run_addr = [frame.add_text_run(r[2], r[5]) for r in runs]
@@ -283,22 +303,23 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
         task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), dps,
                                      (float(ox), float(oy)))
         inst, inst_bgra = [], []
-        for ri, (origin, ref, color, size, run_chars, pts, bb, zid, tid) in enumerate(runs):
+        for ri, (origin, ref, color, size, run_chars, pts, bb, zid, tid, lclip) in enumerate(runs):
             if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
             local_rect = (origin[0] - ref[0][0], origin[1] - ref[0][1], ref[1][0], ref[1][1])
-            ph = frame.add_prim_header(local_rect, (-BIG, -BIG, BIG, BIG), zid, run_addr[ri], tid, task,
+            ph = frame.add_prim_header(local_rect, lclip, zid, run_addr[ri], tid, task,
                                        (int(round(raster_scale * 65535.0)), 0, 0, 0))
             mode = color_modes[ri % len(color_modes)]
             for gi, c in enumerate(run_chars):
                 (inst if mode == 0 else inst_bgra).append(
                     frame.glyph_instance(ph, gi, res_addr[(size, c)], color_mode=mode))
+        gt = "GLYPH_TRANSFORM," if glyph_transform else ""
         if inst:
-            target.alpha.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES",
+            target.alpha.append(Step(f"ps_text_run ALPHA_PASS,{gt}TEXTURE_2D", "PRIM_INSTANCES",
                                      np.array(inst, dtype=np.int32), "PremultipliedAlpha", "alpha",
                                      textures={0: atlas_ref}))
         if inst_bgra:
-            key = "ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D" if dual_source else "ps_text_run ALPHA_PASS,TEXTURE_2D"
+            key = f"ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,{gt}TEXTURE_2D" if dual_source else f"ps_text_run ALPHA_PASS,{gt}TEXTURE_2D"
             target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(inst_bgra, dtype=np.int32),
                                      "SubpixelDualSource" if dual_source else "PremultipliedAlpha", "alpha",
                                      textures={0: atlas_bgra_ref}))
@@ -2009,6 +2030,138 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
             al.append(frame.brush_instance(ph, clip_addr, brush_flags=flags, edge_flags=15, resource_address=addr))
         if al:
             target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha",
+                                     textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
+
+
+# ---------------------------------------------------------------------------
+# ps_split_composite: the planes of a preserve-3d context after plane splitting.  picture.rs:6571-6622 sorts the split polygons
+# back to front, maps each polygon's four world points back into its plane's local space and leaves them in the GPU cache
+# (two blocks: p0.xy p1.xy | p2.xy p3.xy); batch.rs:1985-2080 then draws each one with BatchKind::SplitComposite /
+# BlendMode::PremultipliedAlpha: prim header = (the child picture's rect, its clip rect, transform of its spatial node), user
+# data = (uv rect address of the child's surface, BrushFlags::PERSPECTIVE_INTERPOLATION, 0, clip task address), instance =
+# SplitCompositeInstance (gpu_types.rs:531-551: header index, polygons address, z, render task address).
+def split_composites(width=1024, height=1024, n=60, seed=211, atlas=512, masked=False, tile_filter=None, only=None, perspective=False,
+                     nearest=False, pin=False):
+    """pin: every plane faces the screen at whole device pixels and 1:1 scale, every polygon is an axis-aligned part of its
+    plane (whole, a left / top part, or the whole in the other winding) -- what oracle/np_model.split_tile restates."""
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    pix = np.zeros((atlas, atlas, 4), np.uint8)
+    srcs = []
+    x = y = shelf = 0
+    unit = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
+    for i in range(16):
+        w, h = int(rng.integers(24, 120)), int(rng.integers(24, 100))
+        if x + w > atlas:
+            x, y, shelf = 0, y + shelf, 0
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 0] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+        img[..., 1] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+        if i % 2 == 0:
+            img[..., 3] = 255
+        img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)
+        pix[y:y + h, x:x + w] = img
+        # the child surface's ImageSource: uv rect, user data, then the four homogeneous corners get_image_quad_uv blends
+        quad = unit if i % 5 != 4 else [[0.125, 0.0625, 0.0, 1.0], [1.75, 0.125, 0.0, 2.0], [0.0625, 0.9375, 0.0, 1.0], [0.96875, 1.0, 0.0, 1.0]]
+        srcs.append((w, h, frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]] + quad), quad is unit))
+        x += w + 2
+        shelf = max(shelf, h + 2)
+    t_atlas = TextureRef("split_surfaces", atlas, atlas, G.GL_RGBA8, G.GL_NEAREST if nearest else G.GL_LINEAR, pixels=pix,
+                         upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+    prims = []
+    for i in range(n):
+        sw, sh, addr, unitq = srcs[int(rng.integers(0, len(srcs)))]
+        sc = float(rng.uniform(0.8, 3.0))
+        w, h = sw * sc, sh * sc * float(rng.uniform(0.7, 1.4))
+        cx, cy = float(rng.uniform(0, width)), float(rng.uniform(0, height))
+        if pin:
+            while not unitq:       # (surfaces whose image quad is the unit square only)
+                sw, sh, addr, unitq = srcs[int(rng.integers(0, len(srcs)))]
+            w, h = float(sw), float(sh)
+            cx, cy = float(int(cx)) + (sw % 2) * 0.5, float(int(cy)) + (sh % 2) * 0.5
+            tid = 0
+        elif i % 7 == 6 and perspective != "all":
+            tid = 0            # a plane that faces the screen
+            if i % 2:
+                cx, cy = cx + float(rng.uniform(0, 1)), cy + float(rng.uniform(0, 1))
+        else:
+            th = float(rng.uniform(0, 2 * np.pi)) if i % 6 else float(rng.choice([np.pi / 4, np.pi / 2, 0.01]))
+            sk = float(rng.uniform(-0.4, 0.4)) if i % 4 == 1 else 0.0
+            c, sn = np.cos(th), np.sin(th)
+            a = np.array([[c, -sn + sk * c], [sn, c + sk * sn]], np.float64)
+            m = np.eye(4)
+            m[:2, :2] = a
+            m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
+            if perspective:
+                m = projective_about(a, cx, cy, float(np.hypot(w, h)) * 0.5 * (1.0 + abs(sk)), rng,
+                                     strength=(1.1, 2.6) if (perspective == "clip" and i % 3 == 0) else (0.15, 0.6))
+            tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
+        rect = (cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)
+        # the polygon: what the other planes left of this one -- a convex quad inside the rect, its points in order around it
+        x0, y0, x1, y1 = rect
+        kind = i % 5
+        if pin:
+            k = i % 4
+            ax_, ay_ = float(int(rng.integers(4, max(5, sw - 3)))), float(int(rng.integers(4, max(5, sh - 3))))
+            if k == 0:
+                pts = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+            elif k == 1:       # split by a vertical plane: the left part
+                pts = [(x0, y0), (x0 + ax_, y0), (x0 + ax_, y1), (x0, y1)]
+            elif k == 2:       # ... by a horizontal one: the top part
+                pts = [(x0, y0), (x1, y0), (x1, y0 + ay_), (x0, y0 + ay_)]
+            else:              # the whole rect in the other winding, starting from another corner
+                pts = [(x1, y1), (x1, y0), (x0, y0), (x0, y1)]
+        elif kind == 0:      # untouched: the whole rect
+            pts = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+        elif kind == 1:    # one cut: a trapezoid
+            a0, a1 = float(rng.uniform(0.2, 0.8)), float(rng.uniform(0.2, 0.8))
+            pts = [(x0, y0), (x0 + w * a0, y0), (x0 + w * a1, y1), (x0, y1)]
+        elif kind == 2:    # a corner cut off twice: a general quad
+            pts = [(x0 + w * float(rng.uniform(0.0, 0.4)), y0), (x1, y0 + h * float(rng.uniform(0.0, 0.4))),
+                   (x1 - w * float(rng.uniform(0.0, 0.4)), y1), (x0, y1 - h * float(rng.uniform(0.0, 0.4)))]
+        elif kind == 3:    # a triangle: plane_split hands four points, two of them equal
+            pts = [(x0, y0), (x1, y0 + h * float(rng.uniform(0.3, 1.0))), (x0 + w * float(rng.uniform(0.0, 0.7)), y1)]
+            pts.append(pts[2])
+        else:              # the other winding
+            a0 = float(rng.uniform(0.3, 0.9))
+            pts = [(x0, y0), (x0, y1), (x0 + w * a0, y1), (x1, y0)]
+        poly = frame.gpu_cache.push([[pts[0][0], pts[0][1], pts[1][0], pts[1][1]], [pts[2][0], pts[2][1], pts[3][0], pts[3][1]]])
+        rad = float(np.hypot(w, h)) * (1.4 if perspective else 0.75) + 4
+        persp_flag = 0 if i % 4 == 3 else 1          # (WebRender always passes PERSPECTIVE_INTERPOLATION; the program reads the flag)
+        prims.append((rect, tid, addr, (cx - rad, cy - rad, cx + rad, cy + rad), poly, persp_flag))
+    t_mask, clip_tasks = None, [None] * len(prims)
+    if masked:
+        t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
+        frame.static_textures.append(t_mask)
+        clip_tasks = prim_clip_tasks(rng, [p[3] for p in prims], 1024, True)
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        al = []
+        for zi, (rect, tid, addr, bb, poly, persp_flag) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
+                continue
+            ct = clip_tasks[zi]
+            clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, tid, task, (addr, persp_flag, 0, clip_addr))
+            al.append([ph, poly, zi + 1, task])
+        if al:
+            target.alpha.append(Step("ps_split_composite", "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha",
                                      textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))

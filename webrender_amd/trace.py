@@ -16,7 +16,9 @@ Binary layout (little endian):
   n_calls x { u16 fn_id, u16 nargs, nargs x { u32 tag, u32 aux, u64 value } }
   blob bytes
 tags: 0 int, 1 f32, 2 f64, 3 blob(value=offset, aux=len), 4 null,
-      5 scratch(value=offset into a replayer-owned buffer), 6 context handle
+      5 scratch(value=offset into a replayer-owned buffer), 6 context handle,
+      7 scratch initialised from a blob on every replay of the call (value = blob offset << 32 | scratch offset, aux=len:
+        caller memory the backend reads at the call and writes later -- SetTextureBuffer's backing store)
 """
 import ctypes as C
 import os
@@ -38,7 +40,7 @@ OUT_PTRS = {
 # pointer-typed args that are really byte offsets / small integers
 INT_PTRS = {("VertexAttribPointer", 5), ("VertexAttribIPointer", 4)}
 
-TAG_INT, TAG_F32, TAG_F64, TAG_BLOB, TAG_NULL, TAG_SCRATCH, TAG_CTX = range(7)
+TAG_INT, TAG_F32, TAG_F64, TAG_BLOB, TAG_NULL, TAG_SCRATCH, TAG_CTX, TAG_SCRATCH_INIT = range(8)
 
 
 def _nbytes(x):
