@@ -63,6 +63,8 @@ def kernel_label(k):
         return "wr_mask_rows_kernel"
     if k.kind == 4:      # a run of thin R8 levels in one launch (k.depth = levels)
         return f"wr_raster_chain_kernel<{k.feat}> x{k.depth} levels"
+    if k.kind == 5:      # glyph levels: the 128-VGPR instantiation of the textured variant
+        return f"wr_raster_dense_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
     return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
 
 
@@ -87,7 +89,7 @@ def pmc_traffic(workload, encoding, label):
     tag = label[label.index("<"):] if "<" in label else label
     tot = n = 0
     for name, k in d["kernels"].items():
-        if ("raster_kernel" + tag in name) if "<" in label else (label in name):
+        if ("raster_kernel" + tag in name or "raster_dense_kernel" + tag in name) if "<" in label else (label in name):
             tot += k["hbm_bytes_per_launch"] * k["launches"]
             n += k["launches"]
     if not n:
@@ -121,7 +123,7 @@ def cpu_baseline(rec, budget_s=12.0):
     ms = np.array(ms)
     out = {"value": round(1e3 / ms.mean(), 4), "unit": "frames/s", "cores": 1, "kind": kind,
            "ms_per_frame": round(float(ms.mean()), 3),
-           "oracle": "swgl's gl.cc compiled unmodified from /root/reference; the shader headers (38 program keys) it includes are this "
+           "oracle": "swgl's gl.cc compiled unmodified from /root/reference; the shader headers (48 program keys) it includes are this "
                      "repo's hand-written restatements of webrender/res/*.glsl (glsl-to-cxx needs cargo)",
            "sample": f"{len(ms)} frames of the same trace replayed by swgl ({os.path.basename(lib)}), "
                      f"{time.perf_counter() - t0:.1f} s"}
@@ -313,7 +315,7 @@ def main():
             if tr:
                 e["traffic"], e["traffic_source"] = tr
             per_kernel.append(e)
-        rasters = [e for e in per_kernel if e["name"].startswith("wr_raster_kernel")]
+        rasters = [e for e in per_kernel if e["name"].startswith("wr_raster_")]
         if rasters:
             dom = max(rasters, key=lambda e: e["us_per_frame"])
             roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],

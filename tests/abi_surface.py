@@ -71,6 +71,27 @@ def run(backend_path):
     gl.EndQuery(G.GL_TIME_ELAPSED)
     v = C.c_uint64(0); gl.GetQueryObjectui64v(qt, G.GL_QUERY_RESULT, v)
     out["time_elapsed_positive"] = int(v.value > 0)
+    # seventy sample queries whose results are only read at the end (more than the backend has device slots for: a slot is
+    # handed on only after its previous owner's count was collected), and an id that counted samples reused as a timer
+    qs = []
+    for k in range(70):
+        q = gl.gen("GenQueries")
+        gl.BeginQuery(G.GL_SAMPLES_PASSED, q)
+        r.render(scenes.cfg2_overlapping_rects(n=1 + k % 5, seed=300 + k, fractional=True, **small))
+        gl.EndQuery(G.GL_SAMPLES_PASSED)
+        qs.append(q)
+    late = []
+    for q in qs:
+        v = C.c_uint64(0); gl.GetQueryObjectui64v(q, G.GL_QUERY_RESULT, v)
+        late.append(int(v.value))
+    out["samples_late_reads"] = repr(late)
+    gl.BeginQuery(G.GL_TIME_ELAPSED, qs[3])
+    r.render(scenes.cfg2_overlapping_rects(n=3, seed=5, **small))
+    gl.EndQuery(G.GL_TIME_ELAPSED)
+    v = C.c_uint64(0); gl.GetQueryObjectui64v(qs[3], G.GL_QUERY_RESULT, v)
+    out["reused_query_is_a_timer"] = int(v.value > 0 and v.value != late[3])
+    for q in qs:
+        gl.DeleteQuery(q)
     r.finish()
     out["window_after_queries"] = r.read_pixels().copy()
 

@@ -282,6 +282,9 @@ MIX_BLEND = [
 # brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING: images under GL_ONE, GL_ONE_MINUS_SRC1_COLOR with the second
 # colour main() writes -- COLOR_MODE_SUBPX_DUAL_SOURCE, MULTIPLY_DUAL_SOURCE and IMAGE, translucent image colours, clip masks
 DUAL_SOURCE = [
+    # drop shadows of pictures: brush_image with COLOR_MODE_ALPHA / COLOR_MODE_BITMAP_SHADOW -> swgl_blendDropShadow per prim
+    ("image_shadows", dict(shadows=True, seed=54)),
+    ("image_shadows_masked", dict(shadows=True, masked=True, seed=55)),
     ("image_dual", dict(dual=True)),
     ("image_dual_masked", dict(dual=True, masked=True, seed=52)),
     ("image_dual_nearest", dict(dual=True, nearest=True, seed=53)),

@@ -452,10 +452,10 @@ def test_hostsim_mix_blend_matches_oracle(hostsim, oracle_gcc, name, scene, kw):
 
 @pytest.mark.parametrize("name,kw", DUAL_SOURCE, ids=[c[0] for c in DUAL_SOURCE])
 def test_hostsim_dual_source_images_match_oracle(hostsim, oracle_gcc, name, kw):
-    """brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under the dual-source blend state: 0 differing bytes, and not what the plain
-    ALPHA_PASS key draws"""
+    """brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under the dual-source blend state, and the drop-shadow colour modes of the plain
+    ALPHA_PASS key (swgl_blendDropShadow per prim): 0 differing bytes, and not what COLOR_MODE_IMAGE draws"""
     want, _ = render_direct(oracle_gcc, scenes.image_grid(**kw))
     got, st = render_direct(hostsim, scenes.image_grid(**kw))
-    plain, _ = render_direct(oracle_gcc, scenes.image_grid(**{k: v for k, v in kw.items() if k != "dual"}))
+    plain, _ = render_direct(oracle_gcc, scenes.image_grid(**{k: v for k, v in kw.items() if k not in ("dual", "shadows")}))
     assert st["gl_error"] == 0 and (want != plain).sum() > 100000
     assert np.array_equal(got, want)

@@ -460,7 +460,7 @@ struct Context {
   // plus a kernel boundary; the rest follow in order.  Anything that needs their results, or touches a
   // texture they read or write from outside the draw stream (host uploads, copies, readbacks,
   // deletes, Finish), drains them first (drain_tail).
-  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; int mr_rows = 0; };   // mr_rows > 0: wr_mask_rows_kernel goes first (bound on its rows)    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
+  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; int mr_rows = 0; int dense = 0; };   // dense: the level's R8-texture prims are glyph runs (wr_raster_dense_kernel)   // mr_rows > 0: wr_mask_rows_kernel goes first (bound on its rows)    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
   struct Tail {
     bool pending = false;
     std::vector<Held> held;          // the raster launches of the held-back flush, in order
@@ -473,7 +473,7 @@ struct Context {
   // Host -> HBM staging copies go through their own stream so the DMA of frame k+1's data overlaps the
   // raster work of frame k (in-stream it was a 30 us hole in every frame: 1.2 MB over PCIe); the draw
   // stream waits for the copy's event before the upload scatter.  Safe without further ordering: the copy
-  // writes fresh space of the staging mirror ring, which wraps only after a full sync.
+  // writes space of the staging mirror ring that ring_make_safe() has found dead (its last readers' fence completed).
   wr_stream_t copy_stream;
   wr_event_t ev_copy;
   bool copy_overlap = true;
@@ -486,6 +486,17 @@ struct Context {
   size_t pool_bytes = 0;
   // upload staging ring (pinned)
   uint8_t* staging = nullptr; size_t staging_size = 0, staging_pos = 0;
+  // The ring is reused lap after lap without draining the stream: `ring_base + staging_pos` is a position's VIRTUAL address
+  // (ring_base grows by the ring size at every wrap), a fence is recorded on the draw stream at the end of every flush with the
+  // lowest virtual address not shipped yet, and bytes below fence k-1's address are dead once fence k has completed (flush
+  // k-1's held-back raster launches, which still read its arena, go out with flush k).  An allocation that would overwrite
+  // virtual addresses above `ring_safe` waits for the one fence that frees them -- a frame or two back, normally long done --
+  // instead of the whole pipeline (cfg5 stages ~35 MB per frame: a 96 MB ring wrapped, and drained the GPU, every third frame).
+  uint64_t ring_base = 0, ring_safe = 0;
+  struct RingFence { uint64_t v = 0; wr_event_t ev; bool made = false; };
+  static const int RING_FENCES = 8;
+  RingFence ring_fence[RING_FENCES];
+  uint64_t ring_fences = 0;            // fences recorded so far (fence k lives in slot k % RING_FENCES)
   // profiling
   bool profiling = false;
   wr_event_t ev_a, ev_b;
@@ -499,6 +510,7 @@ struct Context {
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
+  bool dense_text = true;              // WRHIP_NO_DENSE_TEXT=1: text levels keep the 168-VGPR build of their variant
   int chain_grid = 0;                  // workgroups of a chained R8 launch (0: off -- the default; WRHIP_CHAIN=1 turns it on, WRHIP_CHAIN_GRID overrides)
   unsigned chain_base = 0;             // value of WrUnsupportedCounters::chain_arrive once every chained launch enqueued so far has run
 
@@ -509,6 +521,7 @@ struct Context {
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
+    dense_text = getenv("WRHIP_NO_DENSE_TEXT") == nullptr;
     // Chained thin R8 levels (wr_raster_chain_kernel) are OFF unless WRHIP_CHAIN=1: measured on cfg4 (profiles/r03_e_chain_ab.txt),
     // the five chained levels take 144 us in one launch against ~100 us + four kernel boundaries apart -- a grid barrier that has
     // to write back and invalidate the XCDs' L2s (the levels run on all eight) costs about what a kernel boundary costs.
@@ -629,6 +642,39 @@ void prof_begin();
 void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups);
 
 const size_t STAGING_BYTES = size_t(96) << 20;
+bool ring_make_safe(uint64_t need_v, bool may_drain);
+
+// Make the virtual addresses below `need_v` of the staging ring reusable.  `may_drain`: fall back to draining the stream when no
+// recorded fence frees them (false: report failure instead -- flush_uploads asks from inside a batch).
+bool ring_make_safe(uint64_t need_v, bool may_drain) {
+  Context* c = ctx;
+  if (need_v <= c->ring_safe) return true;
+  static const bool drain_only = getenv("WRHIP_RING_DRAIN") != nullptr;      // (A/B: the ring as it was -- a full drain whenever a lap ends)
+  const uint64_t first = drain_only ? c->ring_fences : c->ring_fences > (uint64_t)Context::RING_FENCES ? c->ring_fences - Context::RING_FENCES + 1 : 1;
+  for (uint64_t k = first; k < c->ring_fences; k++) {
+    Context::RingFence& prev = c->ring_fence[(k - 1) % Context::RING_FENCES];
+    if (prev.v < need_v) continue;
+    HostTimer ht(&c->stats.host_wait_ns);
+    wrrt::event_sync(&c->ring_fence[k % Context::RING_FENCES].ev);
+    c->ring_safe = prev.v;
+    return true;
+  }
+  if (!may_drain) return false;
+  flush_uploads();                  // (what is staged goes out, then everything enqueued completes)
+  sync_stream();
+  c->ring_safe = c->ring_base + c->staging_pos;
+  return true;
+}
+// End of a flush: the fence that (once the NEXT one has completed) frees what was shipped up to here.
+void ring_record_fence() {
+  Context* c = ctx;
+  if (!c->staging) return;
+  Context::RingFence& f = c->ring_fence[c->ring_fences % Context::RING_FENCES];
+  if (!f.made) { wrrt::event_create_sync(&f.ev); f.made = true; }
+  f.v = c->ring_base + (c->upload_open ? c->upload_begin : c->staging_pos);
+  wrrt::event_record(&f.ev, c->stream);
+  c->ring_fences++;
+}
 
 // Bump allocation from the pinned staging ring.  Returns the byte offset.
 size_t staging_alloc(size_t n) {
@@ -643,12 +689,16 @@ size_t staging_alloc(size_t n) {
     c->staging = (uint8_t*)wrrt::pinned_alloc(c->staging_size);
     c->dupload = (uint8_t*)wrrt::dev_alloc(c->staging_size);
     c->staging_pos = 0;
+    c->ring_base = c->ring_safe = 0; c->ring_fences = 0;      // (a new ring: nothing in flight refers to it)
   }
   if (c->staging_pos + n > c->staging_size) {
     flush_uploads();                // the pending batch must stay contiguous
-    sync_stream();   // everything staged so far has been consumed
+    c->ring_base += c->staging_size;   // the next lap
     c->staging_pos = 0;
   }
+  // what this allocation overwrites was staged one lap ago
+  const uint64_t end_v = c->ring_base + c->staging_pos + n;
+  if (end_v > c->staging_size) ring_make_safe(end_v - c->staging_size, true);
   if (!c->upload_open) { c->upload_open = true; c->upload_begin = c->staging_pos; }
   size_t off = c->staging_pos;
   c->staging_pos += n;
@@ -684,8 +734,9 @@ void flush_uploads(size_t) {
   if (nseg) {
     // descriptors ride along in the same batch (cannot wrap: checked by caller paths via staging_alloc)
     size_t need = (nseg * sizeof(WrUploadSeg) + 255) & ~size_t(255);
-    if (c->staging_pos + need > c->staging_size) {
-      // no room for descriptors at the tail: ship data first with per-segment copies
+    const uint64_t desc_end_v = c->ring_base + c->staging_pos + need;
+    if (c->staging_pos + need > c->staging_size || (desc_end_v > c->staging_size && !ring_make_safe(desc_end_v - c->staging_size, false))) {
+      // no room for descriptors at the tail (or their bytes of the previous lap are still in flight): ship data first with per-segment copies
       for (auto& sg : c->useg)
         wrrt::copy2d(sg.dst, sg.dst_stride, c->staging + sg.src_off, sg.row_bytes, sg.row_bytes, sg.rows, 0, c->stream);
       c->useg.clear(); nseg = 0;
@@ -1023,6 +1074,7 @@ Context::~Context() {
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::event_destroy(ev_copy);
+  for (RingFence& f : ring_fence) if (f.made) wrrt::event_destroy(f.ev);
   wrrt::stream_destroy(copy_stream);
   wrrt::stream_destroy(stream);
   ctx = saved == this ? nullptr : saved;
@@ -1043,7 +1095,7 @@ void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint6
   for (WrhipKernelStat& e : c->kstats) if (e.kind == kind && e.fmt == fmt && e.depth == depth && e.feat == feat) k = &e;
   if (!k) { c->kstats.push_back(WrhipKernelStat{kind, fmt, depth, feat, 0, 0, 0, 0}); k = &c->kstats.back(); }
   k->launches++; k->ns += ns; k->algo_bytes += algo_bytes; k->workgroups += workgroups;
-  if (kind == 2) c->stats.raster_ns += ns;
+  if (kind == 2 || kind == 4 || kind == 5) c->stats.raster_ns += ns;
 }
 
 void tail_launched() {
@@ -1131,7 +1183,21 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     return;
   }
   prof_begin();
-  if (SA) {
+  if (H.dense && H.fmt == WR_FMT_RGBA8 && H.feat == F7) {
+    // (glyph levels: the 128-VGPR instantiation of the same body, plain or with the next flush's setup stage in front)
+#define WR_KD(DEPTH)                                                                                                         \
+  do {                                                                                                                       \
+    if (SA) WR_LAUNCH((wr_setup_raster_dense_kernel<WR_FMT_RGBA8, DEPTH, 4, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX>), \
+                      n_setup_blocks + H.nb, 256, c->stream, *SA, n_setup_blocks, targets, n_targets, draws,                 \
+                      (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off); \
+    else WR_LAUNCH((wr_raster_dense_kernel<WR_FMT_RGBA8, DEPTH, 4, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX>), H.nb, 256, \
+                   c->stream, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux,  \
+                   (const float*)S.vtab, S.masks, H.off);                                                                    \
+  } while (0)
+    if (H.depth) WR_KD(true); else WR_KD(false);
+#undef WR_KD
+  }
+  else if (SA) {
     if (H.depth) {
       if (H.feat == 0) WR_KF(true, 0); else if (H.feat == F5) WR_KF(true, WR_FEAT_TEX | WR_FEAT_GENERIC);
       else WR_KF(true, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX);
@@ -1167,7 +1233,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   }
 #undef WR_K
 #undef WR_KF
-  prof_end(2, H.fmt, H.depth, H.feat, H.algo_bytes, (uint64_t)H.nb);
+  prof_end(H.dense ? 5 : 2, H.fmt, H.depth, H.feat, H.algo_bytes, (uint64_t)H.nb);      // (5: wr_raster_dense_kernel)
   c->stats.kernel_launches++; c->stats.raster_launches++;
 }
 // A flush's raster launches in order; runs of chainable() launches of one variant (only the first may have mask rows: its rows
@@ -1317,7 +1383,7 @@ void flush_work(const std::vector<int>& sel_in) {
     if (la != lb) return la < lb;
     return (c->textures[c->work[a].tex].internal_format == GL_R8) < (c->textures[c->work[b].tex].internal_format == GL_R8);
   });
-  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false; uint64_t bytes_rgba = 0, bytes_r8 = 0, mr_rows = 0; };
+  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false, text = false; uint64_t bytes_rgba = 0, bytes_r8 = 0, mr_rows = 0; };
   uint64_t mr_slots = 0, mr_rows = 0, mr_bytes = 0;      // bounds on what the cs_clip_* prims of this flush can reserve in the mask-row store
   std::vector<Level> levels;
   std::vector<int> target_level;
@@ -1670,6 +1736,7 @@ void flush_work(const std::vector<int>& sel_in) {
       }
       if (draws[i].flags & WR_DF_QUADS) f |= WR_FEAT_SHADE | WR_FEAT_GENERIC;
       (to_r8 ? L.feat_r8 : L.feat_rgba) |= f;
+      if (!to_r8 && !(draws[i].flags & WR_DF_SIMPLE) && (draws[i].shader == WR_SH_PS_TEXT_RUN || draws[i].shader == WR_SH_PS_TEXT_RUN_DUAL || draws[i].shader == WR_SH_PS_TEXT_RUN_GT || draws[i].shader == WR_SH_PS_TEXT_RUN_DUAL_GT)) L.text = true;
     }
     // one raster launch per dependency level and target format, in level order on the one stream: the
     // smallest instantiated superset of each level's feature set.  They are held back (Context::Tail)
@@ -1682,7 +1749,7 @@ void flush_work(const std::vector<int>& sel_in) {
         else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC))) f = WR_FEAT_TEX | WR_FEAT_GENERIC;
         else if (!(L.feat_rgba & ~(WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX))) f = WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX;
         else f = WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE;
-        launches.push_back(Context::Held{WR_FMT_RGBA8, L.any_depth ? 1 : 0, f, L.bins_rgba, L.bin0, L.bytes_rgba});
+        launches.push_back(Context::Held{WR_FMT_RGBA8, L.any_depth ? 1 : 0, f, L.bins_rgba, L.bin0, L.bytes_rgba, 0, (L.text && c->dense_text && f == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX)) ? 1 : 0});
       }
       if (L.bins_r8 > 0) {
         const int f = L.feat_r8 == 0 ? 0 : (!(L.feat_r8 & WR_FEAT_CLIP) ? (WR_FEAT_GENERIC | WR_FEAT_BLUR) : (WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP));
@@ -1703,6 +1770,7 @@ void flush_work(const std::vector<int>& sel_in) {
     } else {
       launch_held(launches, dtargets, n_targets, ddraws, S);
     }
+    ring_record_fence();
     c->flush_seq++;
     c->stats.flushes++;
     c->stats.prims += n_prims;

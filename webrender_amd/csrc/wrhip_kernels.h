@@ -878,7 +878,17 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   if (color_mode == 4) vcol = color;                                          // COLOR_MODE_IMAGE
   else if (color_mode == 3) vcol = wf4{color.w, color.w, color.w, color.w};   // COLOR_MODE_COLOR_BITMAP
   else if (image == 9 && (color_mode == 1 || color_mode == 5)) vcol = color;  // COLOR_MODE_SUBPX_DUAL_SOURCE / MULTIPLY_DUAL_SOURCE
-  else { o.kind = WR_PK_UNSUPPORTED; return; }                                // blend overrides (drop shadows): next
+  else if ((color_mode == 0 || color_mode == 2) && image != 9) {
+    // COLOR_MODE_ALPHA / COLOR_MODE_BITMAP_SHADOW with SWGL_BLEND (brush_image.glsl:281-291): what drop shadows of pictures are
+    // drawn with (ShaderColorMode::Alpha, prim_store/picture.rs) -- swgl_blendDropShadow(image_data.color): the texel is committed
+    // with v_color = 1 and the shadow colour travels in the blend stage, per primitive (blend.h:680-685), as for text
+    o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    o.has_color = 0; o.tail_modulate = 1;
+    o.blend_override = WR_BLEND_DROP_SHADOW;
+    o.blend_color = color;
+    return;
+  }
+  else { o.kind = WR_PK_UNSUPPORTED; return; }                                // (the dual-source key with a drop-shadow mode: not a combination the batcher makes)
   o.color = vcol;
   o.tail_modulate = 1;
   if (image == 9) {
@@ -7731,10 +7741,13 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 #ifndef WR_R8_CLIP_WAVES
 #define WR_R8_CLIP_WAVES 2
 #endif
+#ifndef WR_TEX_WAVES
+#define WR_TEX_WAVES 3          // waves per SIMD asked of the textured RGBA8 variants (168 VGPRs)
+#endif
 #ifdef WRHIP_HOSTSIM
 #define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R)
 #else
-#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? 3 : ((DEPTH) ? 4 : 8)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
+#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? WR_TEX_WAVES : ((DEPTH) ? 4 : 8)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
@@ -7811,7 +7824,7 @@ struct WrSetupArgs {
 #ifdef WRHIP_HOSTSIM
 #define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R)
 #else
-#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R, (FEAT) == 0 ? 4 : 3)   /* (depth-tested rect variant: 128 VGPRs as well) */
+#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R, (FEAT) == 0 ? 4 : WR_TEX_WAVES)   /* (depth-tested rect variant: 128 VGPRs as well) */
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_FUSED_BOUNDS(R, FEAT)
@@ -7820,6 +7833,33 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
                        const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                        const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                        unsigned long long* __restrict__ masks, int bin_offset) {
+  if ((int)blockIdx.x < n_setup_blocks) {
+    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
+    return;
+  }
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks,
+                                      (int)blockIdx.x - n_setup_blocks + bin_offset);
+}
+// Text launches: the glyph walk is latency-bound (cfg3: per-lane record + atlas fetches), a fourth wave per SIMD pays for the handful
+// of values a 128-VGPR build spills (tile pass 139 -> 128 us, 5.45 k -> 5.7-5.9 k frames/s; profiles/r03_e_ring_w4_ab.txt).  The
+// same 128-VGPR build costs the OTHER users of this variant -- masked solids (cfg4's tile pass 22.5 -> 29 us), perspective images
+// (+10..20 %) -- so it is a second instantiation of the same body that the host picks for levels whose R8-texture prims are
+// glyph runs (Context::Held::dense), not a change of the variant's bounds.
+template <int FMT, bool DEPTH, int R, int FEAT>
+__global__ void __launch_bounds__(1024 / R, 4)
+wr_raster_dense_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
+                       const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                       const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
+                       unsigned long long* __restrict__ masks, int bin_offset) {
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)blockIdx.x + bin_offset);
+}
+template <int FMT, bool DEPTH, int R, int FEAT>
+__global__ void __launch_bounds__(1024 / R, 4)
+wr_setup_raster_dense_kernel(WrSetupArgs S, int n_setup_blocks,
+                             const WrTargetDesc* __restrict__ targets, int n_targets,
+                             const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                             const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
+                             unsigned long long* __restrict__ masks, int bin_offset) {
   if ((int)blockIdx.x < n_setup_blocks) {
     wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
     return;

@@ -377,8 +377,9 @@ def scaled_composites(width=1024, height=768, seed=21, src=192):
 # alpha pass (batch.rs:2060-2150; ImageBrushData gpu_types.rs:707-724; GPU blocks
 # prim_store/image.rs: [color, background_color, stretch_size]).
 def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=None, modes=(0, 1, 2, 3, 4), translucent=True, only=None,
-               masked=False, nearest=False, dual=False):
-    """`dual`: the alpha-pass images go through "brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D" under the dual-source
+               masked=False, nearest=False, dual=False, shadows=False):
+    """`shadows`: every other alpha-pass image is a picture's drop shadow (COLOR_MODE_ALPHA / COLOR_MODE_BITMAP_SHADOW:
+    swgl_blendDropShadow).  `dual`: the alpha-pass images go through "brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D" under the dual-source
     blend state (BlendMode::SubpixelDualSource / MultiplyDualSource batches, batch.rs / shade.rs:462-467), colour modes
     SUBPX_DUAL_SOURCE, MULTIPLY_DUAL_SOURCE and IMAGE in turn, with a translucent image colour."""
     rng = np.random.default_rng(seed)
@@ -466,6 +467,13 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
                 continue
             spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
             ud = (4 | (1 << 16), 0, int(round(opacity * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
+            if shadows and not opaque and zi % 2 == 0:
+                # a picture's drop shadow: ShaderColorMode::Alpha (0) or BitmapShadow (2) with the shadow colour in the brush
+                # data, premultiplied or plain-alpha opacity (brush_image.glsl:268-291)
+                a = (0.35, 0.6, 0.85, 1.0)[zi % 4]
+                col = [((zi * 37) % 256) / 255.0 * a, ((zi * 91) % 256) / 255.0 * a, ((zi * 53) % 256) / 255.0 * a, a]
+                spec = frame.gpu_cache.push([col, [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
+                ud = ((0, 2)[(zi // 2) % 2] | ((zi // 4) % 2 << 16), 0, int(round(opacity * 65535.0)), 0)
             if dual and not opaque:
                 a = (0.35, 0.6, 0.85, 1.0)[zi % 4]
                 col = [((zi * 37) % 256) / 255.0 * a, ((zi * 91) % 256) / 255.0 * a, ((zi * 53) % 256) / 255.0 * a, a]
@@ -2049,7 +2057,7 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
 def split_composites(width=1024, height=1024, n=60, seed=211, atlas=512, masked=False, tile_filter=None, only=None, perspective=False,
                      nearest=False, pin=False):
     """pin: every plane faces the screen at whole device pixels and 1:1 scale, every polygon is an axis-aligned part of its
-    plane (whole, a left / top part, or the whole in the other winding) -- what oracle/np_model.split_tile restates."""
+    plane (whole, a left / top part, or the whole in the other winding) -- what the tests' numpy pin of the program restates."""
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
