@@ -1392,7 +1392,9 @@ void flush_work(const std::vector<int>& sel_in) {
   const int n_targets = (int)sel.size();
   std::vector<WrDrawDesc> draws;
   std::vector<WrTargetDesc> targets(n_targets);
-  std::vector<uint8_t> inst;
+  struct InstSeg { size_t base; const uint8_t* src; size_t size; };
+  std::vector<InstSeg> inst_segs;      // instance bytes of the selected targets, in arena order (copied at staging time)
+  size_t inst_bytes = 0;
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0;
   size_t vtab_cursor = 0;
   uint64_t algo_bytes = 0, pixels = 0;
@@ -1429,9 +1431,11 @@ void flush_work(const std::vector<int>& sel_in) {
       T.y_begin = (int)((int64_t)T.bins_y * c->shard_rank / c->shard_world) * WR_BIN_H;
       T.y_end = std::min(t.height, (int)((int64_t)T.bins_y * (c->shard_rank + 1) / c->shard_world) * WR_BIN_H);
     }
-    size_t inst_base = (inst.size() + 15) & ~size_t(15);
-    inst.resize(inst_base + w.inst.size());
-    if (!w.inst.empty()) big_memcpy(inst.data() + inst_base, w.inst.data(), w.inst.size());
+    // (the target's instance bytes go from its snapshot straight into the staging ring when the arena is laid out: gathering
+    // them in one vector first was a second pass over 2.4 MB per cfg5 frame)
+    size_t inst_base = (inst_bytes + 15) & ~size_t(15);
+    inst_bytes = inst_base + w.inst.size();
+    if (!w.inst.empty()) inst_segs.push_back(InstSeg{inst_base, w.inst.data(), w.inst.size()});
     bool any_kept = false;
     T.dw_first = 0; T.dw_end = 0;
     for (const WrDrawDesc& d0 : w.draws) {
@@ -1591,14 +1595,23 @@ void flush_work(const std::vector<int>& sel_in) {
     size_t off_inst = (off_targets + sizeof(WrTargetDesc) * n_targets + 255) & ~size_t(255);
     // first draw of every 64-prim block (wr_vertex_prim starts its draw lookup there)
     const int n_blocks = (n_prims + 63) / 64;
-    size_t off_blk = (off_inst + inst.size() + 255) & ~size_t(255);
+    size_t off_blk = (off_inst + inst_bytes + 255) & ~size_t(255);
     size_t total = off_blk + sizeof(int) * n_blocks + 256;
     size_t aoff = staging_alloc(total);
     uint8_t* h = c->staging + aoff;
     if (nd) stage_copy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     stage_copy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
-    if (inst.size() >= PARALLEL_COPY_MIN) big_memcpy(h + off_inst, inst.data(), inst.size());
-    else if (!inst.empty()) stage_copy(h + off_inst, inst.data(), inst.size());
+    if (inst_bytes >= PARALLEL_COPY_MIN && inst_segs.size() > 1) {
+      // many targets' worth of instances (cfg5: 72 snapshots of ~33 KB): the helpers take whole segments
+      copy_pool().run([&](int part, int parts) {
+        for (size_t i = (size_t)part; i < inst_segs.size(); i += (size_t)parts) stage_copy(h + off_inst + inst_segs[i].base, inst_segs[i].src, inst_segs[i].size);
+      });
+    } else {
+      for (const InstSeg& sg : inst_segs) {
+        if (sg.size >= PARALLEL_COPY_MIN) big_memcpy(h + off_inst + sg.base, sg.src, sg.size);
+        else stage_copy(h + off_inst + sg.base, sg.src, sg.size);
+      }
+    }
     {
       int* blk = (int*)(h + off_blk);
       int j = 0;
@@ -1610,7 +1623,7 @@ void flush_work(const std::vector<int>& sel_in) {
     flush_uploads();     // one DMA: queued texture uploads + this arena; then the scatter kernel
     uint8_t* darena = c->dupload + aoff;
     c->stats.h2d_bytes += total;
-    algo_bytes += inst.size() + sizeof(WrDrawDesc) * nd;
+    algo_bytes += inst_bytes + sizeof(WrDrawDesc) * nd;
     // ---- scratch (two sets: the deferred tail of the previous flush still reads the other one) ----
     Context::Scratch& S = c->scratch[c->flush_seq & 1];
     if (S.prims_cap < (size_t)n_prims + 1 || S.vtab_cap < vtab_cursor + 1 || S.masks_cap < (size_t)n_words + 1) {
@@ -1671,7 +1684,7 @@ void flush_work(const std::vector<int>& sel_in) {
         prof_begin();
         WR_LAUNCH(wr_setup_kernel, n_setup_blocks, 256, c->stream, ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims,
                   dtargets, S.masks, S.vtab, c->dcounters, dblk);
-        prof_end(1, 0, 0, 0, inst.size() + sizeof(WrDrawDesc) * nd + (uint64_t)n_prims * (sizeof(WrPrim) + sizeof(WrRec)), (uint64_t)n_setup_blocks);
+        prof_end(1, 0, 0, 0, inst_bytes + sizeof(WrDrawDesc) * nd + (uint64_t)n_prims * (sizeof(WrPrim) + sizeof(WrRec)), (uint64_t)n_setup_blocks);
         c->stats.kernel_launches += 1;
         drain_tail();        // (held-back launches the fused kernel has no variant for)
       }
@@ -1698,7 +1711,7 @@ void flush_work(const std::vector<int>& sel_in) {
                 draws[i].quad[5], draws[i].quad[6], draws[i].quad[7]);
       for (int i = 0; i < nd && i < 6; i++) {
         const float* f = (const float*)(dinst + draws[i].inst_offset);
-        fprintf(stderr, "     flush inst D%d: %g %g %g %g (inst.size %zu)\n", i, f[0], f[1], f[2], f[3], inst.size());
+        fprintf(stderr, "     flush inst D%d: %g %g %g %g (inst bytes %zu)\n", i, f[0], f[1], f[2], f[3], inst_bytes);
       }
       for (int i = 0; i < n_prims && i < 6; i++) {
         const WrPrim& P = S.prims[i];
@@ -2723,8 +2736,14 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   // snapshot the instance bytes (the caller may overwrite the VBO right after)
   TargetWork& w = c->work[wi];
   size_t pos = (w.inst.size() + 15) & ~size_t(15);
-  w.inst.resize(pos + need);
-  if (need) big_memcpy(w.inst.data() + pos, instb->buf, need);
+  if (need >= PARALLEL_COPY_MIN) {
+    w.inst.resize(pos + need);
+    big_memcpy(w.inst.data() + pos, instb->buf, need);
+  } else {
+    // (one pass: resize() would zero the bytes the copy is about to overwrite -- 72 snapshots of ~33 KB per cfg5 frame)
+    w.inst.resize(pos);
+    if (need) w.inst.insert(w.inst.end(), (const uint8_t*)instb->buf, (const uint8_t*)instb->buf + need);
+  }
   d.inst_offset = pos; d.inst_stride = inst_stride;
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG") && need >= 16) { const float* f = (const float*)(w.inst.data() + pos); fprintf(stderr, "record: sh %d buf %u need %zu first %g %g %g %g\n", d.shader, inst_buf, need, f[0], f[1], f[2], f[3]); }
