@@ -11,9 +11,10 @@ picture-cache tile rasterised, the composite pass, Finish), replayed natively
 configs[1]: 1000 overlapping translucent rects at 3840x2160 ("cfg2").  At N>1
 it is configs[4] -- 100 k rects at 7680x4320 ("cfg5"), the configuration the
 tile sharding is for: one frame split N ways ("strong" scaling), the window
-reassembled by an RCCL all-gather; the line also carries the same workload on
-one GPU measured in the same run (`single_gpu_same_workload`), the
-gather-to-rank-0 variant and every rank's prims / upload bytes per frame.
+reassembled on rank 0 -- the presenting GPU -- by an RCCL gather of the ranks'
+strips; the line also carries the same workload on one GPU measured in the same
+run (`single_gpu_same_workload`), the all-gather variant (every rank ends up
+with the window) and every rank's prims / upload bytes per frame.
 
 The timed region (K frames issued back to back + one Finish, between barrier +
 synchronize) is repeated REPEATS times and the median region is reported, so a
@@ -198,7 +199,10 @@ def main():
             single = {"value": round(args.steps / float(np.median(reg)), 2), "unit": "frames/s", "n_gpus": 1,
                       "note": "same workload, unsharded, rank 0's GPU, this run"}
             del p1
-        player = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world)
+        # (value: the window assembled on rank 0, the presenting GPU -- SURVEY section 8e's "gather to the presenting GPU"; the
+        # all-gather variant, every rank ending up with the whole window, is timed alongside: at 8K it moves 132 MB per frame
+        # into EVERY GPU, which bounds it near 0.4 k frames/s whatever the raster rate)
+        player = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="root")
         frame_w, frame_h = player.width, player.height
         rec = None
     else:
@@ -247,7 +251,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         del player
-        root = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="root")
+        root = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="all")
         root.frames(args.warmup, 0)
         rr = []
         for _ in range(3):
@@ -258,9 +262,9 @@ def main():
             rr.append(time.perf_counter() - t0)
         t = torch.tensor(rr, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        multi = {"rccl_ranks": world, "collective": "all_gather of window strips (value); gather to rank 0 alongside",
-                 "gather_to_rank0": {"value": round(args.steps / float(np.median(t.tolist())), 2), "unit": "frames/s"},
-                 "allgather_bytes_per_frame": int(root.strip * root.row_bytes * world), "per_rank": per_rank}
+        multi = {"rccl_ranks": world, "collective": "gather of window strips to rank 0, the presenting GPU (value); all_gather to every rank alongside",
+                 "all_gather": {"value": round(args.steps / float(np.median(t.tolist())), 2), "unit": "frames/s"},
+                 "window_bytes_per_frame": int(root.strip * root.row_bytes * world), "per_rank": per_rank}
         player = root
 
     # ---- where the host side of a frame goes: the library's own phase timers over one more streamed region -------
@@ -356,7 +360,7 @@ def main():
                 "cfg1": "16x16 opaque rect grid 1024x1024"}[args.workload],
                 "encoding": args.encoding, "target": f"{frame_w}x{frame_h}",
                 "parallelism": "single GPU" if not sharded else
-                f"tile rows sharded over {world} GPUs + RCCL all-gather of framebuffer strips"},
+                f"tile rows sharded over {world} GPUs + RCCL gather of framebuffer strips to rank 0"},
         }
         if multi:
             out["multi_gpu"] = multi

@@ -669,9 +669,14 @@ bool ring_make_safe(uint64_t need_v, bool may_drain) {
 void ring_record_fence() {
   Context* c = ctx;
   if (!c->staging) return;
+  // (one fence per eighth of the ring, not per flush: small frames -- cfg1 stages 0.3 MB -- need no event of their own, and the
+  // eight slots then always reach a full lap back.  Flush k-1's held-back launches still go out with flush k, which precedes
+  // whatever flush records the next fence.)
+  const uint64_t v_now = c->ring_base + (c->upload_open ? c->upload_begin : c->staging_pos);
+  if (c->ring_fences && v_now - c->ring_fence[(c->ring_fences - 1) % Context::RING_FENCES].v < c->staging_size / Context::RING_FENCES) return;
   Context::RingFence& f = c->ring_fence[c->ring_fences % Context::RING_FENCES];
   if (!f.made) { wrrt::event_create_sync(&f.ev); f.made = true; }
-  f.v = c->ring_base + (c->upload_open ? c->upload_begin : c->staging_pos);
+  f.v = v_now;
   wrrt::event_record(&f.ev, c->stream);
   c->ring_fences++;
 }
