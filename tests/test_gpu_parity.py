@@ -178,6 +178,22 @@ def test_hip_box_shadow_matches_oracle(name, kw, evaluation, monkeypatch):
     assert ref or name in GOLDEN
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(width=1024, height=1024), dict(dps=2.0)], ids=["small", "4k_dps2"])
+def test_hip_chained_mask_levels_are_bit_exact(kw, monkeypatch):
+    """WRHIP_CHAIN=1 (off by default: measured slower, profiles/r03_e_chain_ab.txt): the thin R8 levels of the box-shadow chain in
+    one persistent launch with grid barriers give the bytes the separate launches give, in fewer launches, and no workgroup
+    gives up at a barrier (that would raise GL_INVALID_OPERATION)."""
+    want, st0 = render_direct(wrhip_lib(), scenes.cfg4_box_shadow(**kw))
+    monkeypatch.setenv("WRHIP_CHAIN", "1")
+    got, st1 = render_direct(wrhip_lib(), scenes.cfg4_box_shadow(**kw))
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    assert st1["gl_error"] == 0
+    assert st1["kernel_launches"] < st0["kernel_launches"]
+
+
 @pytest.mark.parametrize("name,kw", [("cfg4_small", dict(width=1024, height=1024)), ("cfg4_4k_dps2", dict(dps=2.0))],
                          ids=["small", "4k_dps2"])
 def test_hip_cfg4_box_shadow_chain(name, kw):
