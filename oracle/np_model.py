@@ -615,6 +615,56 @@ def text_tile(frame, target, atlas):
 
 
 # ---------------------------------------------------------------------------
+# ps_text_run GLYPH_TRANSFORM (ps_text_run.glsl:130-165, 206-216) for runs whose glyphs lie inside their local clip rect: the glyphs
+# were rasterised under the run's 2-D transform, so each one is an upright 1:1 blit of its atlas rect at a device position the
+# vertex stage snaps in glyph space -- floor(glyph_transform * glyph offset + bias) + floor(glyph_transform * text offset +
+# translation + 0.5) - translation + the resource's offset, back into device space by adding the translation and the task
+# origin -- cut to that rect by gl_ClipDistance.  Written from the GLSL only: no quads, no spans, no clip distances.
+def glyph_transform_tile(frame, target, atlas):
+    """One picture-cache tile of a scenes.cfg3_text(glyph_transform=True, gt_clip=False) frame -> uint8 [TILE_H, TILE_W, 4] RGBA"""
+    from webrender_amd.scenes import TILE_W, TILE_H
+    cache, hf, hi, tasks = frame.gpu_cache.data, frame.prim_headers_f.data, frame.prim_headers_i.data, frame.render_tasks.data
+    xf = frame.transforms.data
+    img = np.empty((TILE_H, TILE_W, 4), np.int64)
+    img[:] = np.floor(_f(target.clear_color) * _f(255.0) + _f(0.5)).astype(np.int64)
+    for step in target.alpha:
+        assert step.shader == "ps_text_run ALPHA_PASS,GLYPH_TRANSFORM,TEXTURE_2D"
+        for inst in np.asarray(step.instances):
+            ph, flags, res_addr = int(inst[0]), int(inst[2]), int(inst[3])
+            glyph_index, color_mode, subpx = flags & 0xFFFF, (flags >> 16) & 0xFF, (flags >> 24) & 0xFF
+            assert color_mode == 0 and subpx == 0
+            lr = _f(hf[2 * ph]); h0 = hi[2 * ph]
+            spec, tid, task_addr = int(h0[1]), int(h0[2]) & 0x7FFFFF, int(h0[3])
+            trect, tdata = _f(tasks[2 * task_addr]), _f(tasks[2 * task_addr + 1])
+            dps, corigin = tdata[0], tdata[1:3]
+            m = _f(xf[8 * tid:8 * tid + 4])                    # columns of transform.m
+            gt = np.array([[m[0][0], m[1][0]], [m[0][1], m[1][1]]], np.float32) * dps      # mat2(transform.m) * dps, as a row-major 2 x 2
+            gtr = _f([m[3][0], m[3][1]]) * dps                 # glyph_translation
+            color = _f(cache[spec])
+            blk = _f(cache[spec + 1 + glyph_index // 2])
+            goff = (blk[0:2] if glyph_index % 2 == 0 else blk[2:4]) + lr[0:2]
+            text_offset = lr[2:4]
+            uv_rect, r1 = _f(cache[res_addr]), _f(cache[res_addr + 1])
+            roff = r1[0:2]
+            rgo = np.floor(gt @ goff + _f(0.5))
+            rto = np.floor(gt @ text_offset + gtr + _f(0.5)) - gtr
+            origin = roff + rgo + rto                          # glyph space
+            dev0 = origin + gtr + (trect[0:2] - corigin)       # device space, then the task's place in the target
+            x0, y0 = int(np.floor(dev0[0] + _f(0.5))), int(np.floor(dev0[1] + _f(0.5)))
+            gw, gh = int(uv_rect[2] - uv_rect[0]), int(uv_rect[3] - uv_rect[1])
+            ax, ay = int(uv_rect[0]), int(uv_rect[1])
+            cx0, cy0, cx1, cy1 = max(x0, 0), max(y0, 0), min(x0 + gw, TILE_W), min(y0 + gh, TILE_H)
+            if cx1 <= cx0 or cy1 <= cy0:
+                continue
+            mask = atlas[ay + (cy0 - y0):ay + (cy1 - y0), ax + (cx0 - x0):ax + (cx1 - x0)].astype(np.float32) * _f(1.0 / 255.0)
+            src = np.floor((color[None, None, :] * mask[..., None]) * _f(255.0) + _f(0.5)).astype(np.int64)
+            dst = img[cy0:cy1, cx0:cx1]
+            a = src[..., 3:4]
+            img[cy0:cy1, cx0:cx1] = src + dst - ((dst * a + dst) >> 8)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
 # ps_split_composite (webrender/res/ps_split_composite.glsl) for planes that face the screen at whole device pixels and 1:1 scale
 # (scenes.split_composites(pin=True)): the instance (header index, polygons address, z, render task: gpu_types.rs:531-551), the
 # bilerp of the polygon's four local points over aPosition (:41-45, 85-87), the destination task's origin, the image source's

@@ -250,6 +250,27 @@ def test_oracle_text_runs_match_numpy_model(oracle_gcc, kw):
     assert (got != 255).any() and over <= 0.01 * tot and off <= 0.15 * tot, (off, over, tot)
 
 
+def test_oracle_glyph_transform_text_matches_numpy_model(oracle_gcc):
+    """ps_text_run GLYPH_TRANSFORM: the device-space snapping of the vertex stage (glyph and text offsets floor()ed in glyph space,
+    the translation taken out and put back) and the gl_ClipDistance cut, pinned by a numpy restatement that knows neither quads
+    nor clip distances -- every glyph an upright 1:1 blit of its atlas rect at the snapped device position, under rotations,
+    skews and scales (oracle/np_model.py: glyph_transform_tile).  Allowance as for the plain text pin: the span shader
+    multiplies colour and mask as 8-bit integers where the model rounds a float product."""
+    fr = scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, glyph_transform=True, gt_clip=False)
+    got, _ = render_direct(oracle_gcc, fr)
+    atlas = np.asarray(fr.static_textures[0].pixels)
+    tot = off = over = 0
+    for tgt, ct in zip(fr.passes[0], fr.composite_tiles):
+        tile = np_model.glyph_transform_tile(fr, tgt, atlas)
+        x0, y0, x1, y1 = [int(v) for v in ct.clip_rect]
+        d = np.abs(got[::-1][y0:y1, x0:x1].astype(int) - tile[:y1 - y0, :x1 - x0].astype(int))
+        assert d.max() <= 4, int(d.max())
+        tot += d.size
+        off += int((d > 0).sum())
+        over += int((d > 1).sum())
+    assert (got != 255).any() and over <= 0.01 * tot and off <= 0.15 * tot, (off, over, tot)
+
+
 def test_oracle_split_composites_match_numpy_model(oracle_gcc):
     """ps_split_composite: the instance decoding, the bilerp of the polygon's local points (corner order, both windings), the
     destination task's origin, the image source's uv mapping and the premultiplied-alpha blend, restated in numpy from the GLSL

@@ -202,7 +202,7 @@ def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127)):
 
 def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=25, seed=3,
               glyph_zoom=1.0, device_pixel_scale=1.0, tile_filter=None, color_modes=(0,), dual_source=False, rotate=False,
-              perspective=False, glyph_transform=False, **kw):
+              perspective=False, glyph_transform=False, gt_clip=True, **kw):
     """`lines` x `glyphs_per_line` glyphs in runs of `run_len`, black-ish text
     on white, COLOR_MODE_ALPHA from an R8 atlas, PremultipliedAlpha blend
     (batch.rs:1109-1290).  glyph_zoom != 1 draws the cached bitmaps magnified
@@ -279,7 +279,7 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
                     tid = frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=True)
                 else:
                     tid = rotation_about(frame, rng, origin[0], origin[1], len(runs), None)
-                if len(runs) % 3 == 1:
+                if gt_clip and len(runs) % 3 == 1:
                     lclip = (origin[0] + 0.31 * x, origin[1] - 0.55 * size, origin[0] + 0.83 * x + 0.4, origin[1] + 0.12 * size)
                 rr = rad * dps * 1.6
                 bx0, bx1, by0, by1 = origin[0] * dps - rr, origin[0] * dps + rr, origin[1] * dps - rr, origin[1] * dps + rr
