@@ -82,22 +82,23 @@ def test_fused_setup_raster_kernel_vgpr_budget(tmp_path, feat, depth, max_vgpr):
     assert vgpr <= max_vgpr, f"fused FEAT={feat}: {vgpr} VGPRs > {max_vgpr}: the kernel lost a wave per SIMD"
 
 
-DENSE_SRC = SRC.split("template __global__")[0] + '''
-template __global__ void wr_raster_dense_kernel<WR_FMT_RGBA8, false, 4, 7>(const WrTargetDesc*, int, const WrDrawDesc*, const WrPrim*,
-    const WrRec*, const WrAux*, const float*, unsigned long long*, int);
-'''
-
-
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_dense_text_kernel_vgpr_budget(tmp_path):
     """Glyph levels run a second instantiation of the textured variant at 4 waves per SIMD (128 VGPRs): cfg3's tile pass is
-    latency-bound and gains 8 % from the fourth wave as long as the build spills no more than a few hundred bytes."""
-    src = tmp_path / "dense.hip"
-    src.write_text(DENSE_SRC)
-    out = tmp_path / "dense.s"
-    subprocess.check_call([HIPCC] + FLAGS + ["-I", CSRC, str(src), "-o", str(out)])
-    asm = out.read_text()
-    m = re.search(r"\.amdhsa_kernel _Z22wr_raster_dense_kernelILi3ELb0ELi4ELi7E.*?\.end_amdhsa_kernel", asm, re.S)
-    assert m, "kernel not found in the assembly"
-    assert int(re.search(r"next_free_vgpr (\d+)", m.group(0)).group(1)) <= 128
-    assert int(re.search(r"private_segment_fixed_size (\d+)", m.group(0)).group(1)) <= 512
+    latency-bound and gains 8 % from the fourth wave as long as the build spills no more than a few hundred bytes.  Read from
+    the built library's code object (the other budgets compile their variant on its own; this one would cost another minute)."""
+    lib = os.path.join(CSRC, "libwrhip.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        pytest.skip("libwrhip.so / llvm-readelf not present")
+    import glob
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.check_call([f"{llvm}/llvm-objdump", "--offloading", str(tmp_path / "lib.so")], stdout=subprocess.DEVNULL, cwd=tmp_path)
+    co = glob.glob(str(tmp_path / "lib.so.*gfx950*"))[0]
+    txt = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", co], text=True)
+    found = 0
+    for m in re.finditer(r"\.name:\s*(\S+).*?\.private_segment_fixed_size:\s*(\d+).*?\.vgpr_count:\s*(\d+)", txt, re.S):
+        name, scratch, vgpr = m.group(1), int(m.group(2)), int(m.group(3))
+        if name.startswith("_Z22wr_raster_dense_kernelILi3ELb0ELi4ELi7E"):
+            found += 1
+            assert vgpr <= 128 and scratch <= 512, (name, vgpr, scratch)
+    assert found == 1
