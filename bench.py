@@ -109,12 +109,14 @@ def cpu_baseline(rec, budget_s=12.0):
     """Reference swgl rasteriser on the host cores, bounded sample of the same frame trace: one core
     (swgl is single-threaded by design, swgl/README.md:6), then one replaying process per core."""
     from webrender_amd.harness import ScenePlayer
-    lib = os.path.join(ROOT, "oracle", "_ref", "libswgl_ref_clang.so")
     kind = "reference"
-    if not os.path.exists(lib):
-        lib = os.path.join(ROOT, "oracle", "_ref", "libswgl_ref_gcc.so")
-    if not os.path.exists(lib):
+    for name in ("libswgl_ref_gen_clang.so", "libswgl_ref_gen.so", "libswgl_ref_clang.so", "libswgl_ref_gcc.so"):
+        lib = os.path.join(ROOT, "oracle", "_ref", name)
+        if os.path.exists(lib):
+            break
+    else:
         return None
+    generated = "_gen" in os.path.basename(lib)
     p = ScenePlayer(lib, rec)          # setup + first frame (untimed)
     t0 = time.perf_counter()
     ms = list(p.frames(0, 1))
@@ -124,8 +126,11 @@ def cpu_baseline(rec, budget_s=12.0):
     ms = np.array(ms)
     out = {"value": round(1e3 / ms.mean(), 4), "unit": "frames/s", "cores": 1, "kind": kind,
            "ms_per_frame": round(float(ms.mean()), 3),
-           "oracle": "swgl's gl.cc compiled unmodified from /root/reference; the shader headers (48 program keys) it includes are this "
-                     "repo's hand-written restatements of webrender/res/*.glsl (glsl-to-cxx needs cargo)",
+           "oracle": ("swgl's gl.cc compiled unmodified from /root/reference with the shader headers (82 program keys) generated "
+                      "from webrender/res/*.glsl by oracle/gen (swgl/build.rs + glsl-to-cxx restated; clang, build.rs's flags)"
+                      if generated else
+                      "swgl's gl.cc compiled unmodified from /root/reference; the shader headers (48 program keys) it includes are "
+                      "this repo's hand-written restatements of webrender/res/*.glsl"),
            "sample": f"{len(ms)} frames of the same trace replayed by swgl ({os.path.basename(lib)}), "
                      f"{time.perf_counter() - t0:.1f} s"}
     # N processes, one per core, each replaying whole frames (how a tile-parallel swgl would use the box)

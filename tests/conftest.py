@@ -23,6 +23,13 @@ def oracle_lib(kind="gcc"):
     return p if os.path.exists(p) else None
 
 
+def oracle_ref(kind="gcc"):
+    """The oracle: the reference's gl.cc built with the shader headers generated from the reference's GLSL (oracle/gen) --
+    g++ strict IEEE ("gcc") or clang with swgl/build.rs's flags ("clang"); the build with the hand-written headers where
+    the generated one is absent."""
+    return oracle_lib("gen" if kind == "gcc" else "gen_clang") or oracle_lib(kind)
+
+
 def hostsim_lib():
     p = os.path.join(ROOT, "webrender_amd", "csrc", "libwrhip_hostsim.so")
     return p if os.path.exists(p) else None
@@ -44,6 +51,17 @@ def _built():
 
 @pytest.fixture(scope="session")
 def oracle_gcc():
+    """THE oracle of the parity tests: the reference's gl.cc built (g++, strict IEEE) with the shader headers generated
+    from the reference's GLSL (oracle/gen); the hand-written headers only where that build is absent."""
+    p = oracle_ref("gcc")
+    if p is None:
+        pytest.skip("oracle/_ref/libswgl_ref_gen.so not built (needs /root/reference)")
+    return p
+
+
+@pytest.fixture(scope="session")
+def oracle_hand():
+    """gl.cc with the hand-written headers of oracle/shaders/: the second derivation (tests/test_oracle_gen.py)"""
     p = oracle_lib("gcc")
     if p is None:
         pytest.skip("oracle/_ref/libswgl_ref_gcc.so not built (needs /root/reference)")
@@ -52,9 +70,17 @@ def oracle_gcc():
 
 @pytest.fixture(scope="session")
 def oracle_clang():
-    p = oracle_lib("clang")
+    p = oracle_ref("clang")
     if p is None:
-        pytest.skip("oracle/_ref/libswgl_ref_clang.so not built (needs /root/reference)")
+        pytest.skip("oracle/_ref/libswgl_ref_gen_clang.so not built (needs /root/reference)")
+    return p
+
+
+@pytest.fixture(scope="session")
+def oracle_gen():
+    p = oracle_lib("gen")
+    if p is None:
+        pytest.skip("oracle/_ref/libswgl_ref_gen.so not built (needs /root/reference)")
     return p
 
 

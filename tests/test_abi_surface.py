@@ -4,7 +4,7 @@ the same call sequence (tests/abi_surface.py) on the reference's swgl and on lib
 import json
 import os
 import pytest
-from conftest import ROOT, wrhip_lib, oracle_lib
+from conftest import ROOT, wrhip_lib, oracle_ref
 import abi_surface
 
 GOLDEN = os.path.join(ROOT, "tests", "golden", "abi_surface.json")
@@ -24,7 +24,7 @@ def test_hostsim_abi_surface_matches_oracle(hostsim, oracle_gcc):
 @pytest.mark.gpu
 def test_hip_abi_surface_matches_oracle():
     got = abi_surface.run(wrhip_lib())
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         assert not abi_surface.compare(got, abi_surface.run(ref))
     gold = json.load(open(GOLDEN))

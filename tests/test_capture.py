@@ -7,7 +7,7 @@ import subprocess
 import sys
 import numpy as np
 import pytest
-from conftest import ROOT, wrhip_lib, oracle_lib
+from conftest import ROOT, wrhip_lib, oracle_ref
 
 CAPTURE = os.path.join(ROOT, "webrender_amd", "csrc", "libwr_capture.so")
 
@@ -83,7 +83,7 @@ def test_capture_over_swgl_replays_on_hostsim(tmp_path, hostsim, oracle_gcc):
 
 @pytest.mark.gpu
 def test_capture_replays_on_hip(tmp_path):
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if not ref:
         pytest.skip("oracle not built")
     trace, want = capture(tmp_path, ref)

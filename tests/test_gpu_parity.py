@@ -7,7 +7,7 @@ import json
 import os
 import numpy as np
 import pytest
-from conftest import ROOT, wrhip_lib, oracle_lib
+from conftest import ROOT, wrhip_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
 from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
@@ -126,7 +126,7 @@ def test_hip_blur_matches_oracle(name, kw):
     bit-exact, the float fragment-shader edge columns are allowed +-1 LSB
     (exp() of the coefficient comes from a different libm)."""
     got, _ = render_direct(wrhip_lib(), scenes.blur_chain(**kw))
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.blur_chain(**kw))
         for k in want:
@@ -149,7 +149,7 @@ def test_hip_clip_rectangle_matches_oracle(name, kw, evaluation, monkeypatch):
     if evaluation == "in_raster":      # the prims evaluated inside the bin raster instead of by wr_mask_rows_kernel (the fallback
         monkeypatch.setenv("WRHIP_NO_MASK_ROWS", "1")     # of a flush whose masks exceed the mask-row store)
     got, _ = render_direct(wrhip_lib(), scenes.clip_masks(**kw))
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.clip_masks(**kw))
         d = np.abs(got["clip_masks"].astype(int) - want["clip_masks"].astype(int))
@@ -168,7 +168,7 @@ def test_hip_box_shadow_matches_oracle(name, kw, evaluation, monkeypatch):
     if evaluation == "in_raster":      # the prims evaluated inside the bin raster instead of by wr_mask_rows_kernel (the fallback
         monkeypatch.setenv("WRHIP_NO_MASK_ROWS", "1")     # of a flush whose masks exceed the mask-row store)
     got, _ = render_direct(wrhip_lib(), scenes.box_shadow_masks(**kw))
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.box_shadow_masks(**kw))
         d = np.abs(got["box_shadow_masks"].astype(int) - want["box_shadow_masks"].astype(int))
@@ -200,7 +200,7 @@ def test_hip_cfg4_box_shadow_chain(name, kw):
     """BASELINE config 4 (box-shadow-large.yaml): the whole mask / scale / blur /
     box-shadow / masked-brush chain on the GPU."""
     got, _ = render_direct(wrhip_lib(), scenes.cfg4_box_shadow(**kw))
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.cfg4_box_shadow(**kw))
         for k in want:
@@ -213,7 +213,7 @@ def test_hip_cfg4_box_shadow_chain(name, kw):
 def test_hip_matches_oracle_small(name, make):
     got, stats = render_direct(wrhip_lib(), make())
     assert stats["raster_launches"] >= 1
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, make())
         assert np.array_equal(got, want)
@@ -228,7 +228,7 @@ def test_hip_split_composites_match_oracle(name, make):
     """(see tests/test_hostsim_parity.py::test_hostsim_split_composites_match_oracle)"""
     got, stats = render_direct(wrhip_lib(), make())
     assert stats["gl_error"] == 0
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, make())
         assert np.array_equal(got, want)
@@ -243,7 +243,7 @@ def test_hip_glyph_transform_text_matches_oracle(name, make):
     """(see tests/test_hostsim_parity.py::test_hostsim_glyph_transform_text_matches_oracle)"""
     got, stats = render_direct(wrhip_lib(), make())
     assert stats["gl_error"] == 0
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, make())
         assert np.array_equal(got, want)
@@ -256,7 +256,7 @@ def test_hip_glyph_transform_text_matches_oracle(name, make):
 @pytest.mark.parametrize("name,make", FLAT, ids=[c[0] for c in FLAT])
 def test_hip_flattened_depth_rows_match_oracle(name, make):
     """(see tests/test_hostsim_parity.py::test_hostsim_flattened_depth_rows_match_oracle)"""
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if not ref:
         pytest.skip("oracle not built")
     want, _ = render_direct(ref, make())
@@ -269,7 +269,7 @@ def test_hip_flattened_depth_rows_match_oracle(name, make):
 @pytest.mark.parametrize("name,make", RUN_OVERFLOW, ids=[c[0] for c in RUN_OVERFLOW])
 def test_hip_depth_run_overflow_is_reported(name, make):
     """(see tests/test_hostsim_parity.py::test_hostsim_depth_run_overflow_is_reported)"""
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if not ref:
         pytest.skip("oracle not built")
     want, _ = render_direct(ref, make())
@@ -306,7 +306,7 @@ _SWEEP = _sweep_cases()
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,make", _SWEEP, ids=[c[0] for c in _SWEEP])
 def test_hip_randomised_sweep_matches_oracle(name, make):
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if not ref:
         pytest.skip("oracle not built")
     want, _ = render_direct(ref, make())
@@ -328,7 +328,7 @@ def test_hip_border_solid_matches_oracle(name, scene, kw):
     """cs_border_solid segments in the texture cache: float coverage (ellipse distances, colour-line mix) -> +-1 LSB allowed
     by north_star, the committed digest pins the exact result."""
     got, _ = render_direct(wrhip_lib(), getattr(scenes, scene)(**kw))
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, getattr(scenes, scene)(**kw))
         d = np.abs(got[_cache_key(scene)].astype(int) - want[_cache_key(scene)].astype(int))
@@ -344,7 +344,7 @@ def test_hip_cfg2_full_4k(encoding):
     oracle needs ~2 s per frame here, so it is also compared directly)."""
     got, _ = render_direct(wrhip_lib(), scenes.cfg2_overlapping_rects(encoding=encoding))
     assert digest(got) == GOLDEN[f"cfg2_4k_{encoding}"]
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.cfg2_overlapping_rects(encoding=encoding))
         assert np.array_equal(got, want)
@@ -353,7 +353,7 @@ def test_hip_cfg2_full_4k(encoding):
 def test_hip_cfg3_text_full_4k():
     """BASELINE config 3 at full size: ~67k glyph instances from the R8 atlas."""
     got, stats = render_direct(wrhip_lib(), scenes.cfg3_text())
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.cfg3_text())
         assert np.array_equal(got, want)
@@ -363,7 +363,7 @@ def test_hip_cfg3_text_full_4k():
 
 
 def test_hip_cfg2_4k_fractional_vs_oracle():
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if not ref:
         pytest.skip("oracle not built")
     got, _ = render_direct(wrhip_lib(), scenes.cfg2_overlapping_rects(fractional=True))
@@ -378,7 +378,7 @@ def test_hip_cfg5_full_8k():
     a, st = render_direct(wrhip_lib(), scenes.cfg5_many_rects(), frames=2)
     assert st["prims"] > 100_000
     assert digest(a) == GOLDEN["cfg5_8k"]
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.cfg5_many_rects())
         assert np.array_equal(a, want)
@@ -388,7 +388,7 @@ def test_hip_cfg5_full_8k():
 
 
 def test_hip_vs_clang_oracle_are_a_bounded_deviation():
-    ref = oracle_lib("clang")
+    ref = oracle_ref("clang")
     if not ref:
         pytest.skip("clang oracle not built")
     make = lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=300, seed=12, fractional=True)
@@ -447,7 +447,7 @@ def test_hip_pipelined_frames_match_isolated_frames():
     k+1 overlapping the GPU work of frame k; data textures re-uploaded, per-frame textures recycled
     through the HBM pool) must each produce exactly what they produce when rendered alone."""
     from webrender_amd.harness import render_pipelined
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     for rep in range(3):
         got = render_pipelined(wrhip_lib(), [m() for m in PIPELINED])
         for i, (g, m) in enumerate(zip(got, PIPELINED)):
@@ -459,7 +459,7 @@ def test_hip_filter_hue_rotate_are_a_bounded_deviation():
     """FILTER_HUE_ROTATE: the colour matrix comes from cos / sin of the angle (blend.glsl:49-58), libm
     on the reference's side and the device math library here -- the one brush_blend case that is
     held to the north-star tolerance (+-1 LSB) instead of 0."""
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if not ref:
         pytest.skip("oracle not built")
     make = lambda: scenes.filter_grid(ops=[2], n=48, seed=74)
@@ -488,7 +488,7 @@ def test_hip_texture_cache_copies(name, kw):
     want = copies_expected(fr)
     got, st = render_direct(wrhip_lib(), scenes.texture_cache_copies(**kw))
     assert st["gl_error"] == 0
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     for k, v in want.items():
         assert v.any() and np.array_equal(got[k], v), k
     if ref:
@@ -504,7 +504,7 @@ def test_hip_mix_blend_matches_oracle(name, scene, kw):
     non-separable modes); the swatches are also held to the numpy model of the GLSL."""
     got, st = render_direct(wrhip_lib(), getattr(scenes, scene)(**kw))
     assert st["gl_error"] == 0 and (got != 255).any()
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, getattr(scenes, scene)(**kw))
         d = np.abs(got.astype(int) - want.astype(int))
@@ -531,7 +531,7 @@ def test_hip_dual_source_images_match_oracle(name, kw):
     """brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under the dual-source blend state on the MI355X"""
     got, st = render_direct(wrhip_lib(), scenes.image_grid(**kw))
     assert st["gl_error"] == 0 and (got != 255).any()
-    ref = oracle_lib("gcc")
+    ref = oracle_ref()
     if ref:
         want, _ = render_direct(ref, scenes.image_grid(**kw))
         assert np.array_equal(got, want)

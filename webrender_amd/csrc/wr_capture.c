@@ -58,6 +58,8 @@ static void grow(uint8_t** p, size_t* cap, size_t need) {
 }
 static wr_rec* wr_begin(int id, int nargs) { G.cur.id = (uint16_t)id; G.cur.nargs = (uint16_t)nargs; memset(G.cur.a, 0, sizeof(G.cur.a)); return &G.cur; }
 static void wr_arg_int(wr_rec* r, int i, uint64_t v) { r->a[i].tag = TAG_INT; r->a[i].value = v; }
+/* one argument more than the call has (GetUniformLocation: the location the backend returned -- backend-specific, the replayer translates) */
+static void wr_arg_extra_int(wr_rec* r, int i, uint64_t v) { r->nargs = (uint16_t)(i + 1); wr_arg_int(r, i, v); }
 static void wr_arg_f32(wr_rec* r, int i, float f) { uint32_t u; memcpy(&u, &f, 4); r->a[i].tag = TAG_F32; r->a[i].value = u; }
 static void wr_arg_f64(wr_rec* r, int i, double d) { r->a[i].tag = TAG_F64; memcpy(&r->a[i].value, &d, 8); }
 static void wr_arg_null(wr_rec* r, int i) { r->a[i].tag = TAG_NULL; }

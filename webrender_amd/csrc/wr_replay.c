@@ -21,6 +21,14 @@ typedef struct wr_replay {
   const uint8_t* blobs;
   uint8_t* scratch;
   size_t scratch_size;
+  /* uniform locations are backend-specific (swgl numbers them per program in order of first use, the generated
+   * get_uniform(); libwrhip by sampler slot): GetUniformLocation records carry the location the RECORDING backend
+   * returned (trace.py), and Uniform1i / Uniform4fv / UniformMatrix4fv are issued with the location THIS backend gave
+   * for the same (program, name). */
+  uint32_t cur_program;
+  struct { uint32_t program; int32_t recorded, actual; } locs[1024];
+  int n_locs;
+  int id_get_uniform, id_use_program, id_uniform1i, id_uniform4fv, id_uniform_matrix4fv;
 } wr_replay;
 
 enum { TAG_INT, TAG_F32, TAG_F64, TAG_BLOB, TAG_NULL, TAG_SCRATCH, TAG_CTX, TAG_SCRATCH_INIT };
@@ -52,6 +60,11 @@ wr_replay* wr_replay_open(const char* path) {
   for (int i = 0; i < WR_FN_COUNT; i++) {
     R->fn[i] = dlsym(dl, WR_FN_NAMES[i]);
     if (!R->fn[i]) { fprintf(stderr, "wr_replay: %s lacks symbol %s\n", path, WR_FN_NAMES[i]); free(R); return NULL; }
+    if (!strcmp(WR_FN_NAMES[i], "GetUniformLocation")) R->id_get_uniform = i;
+    if (!strcmp(WR_FN_NAMES[i], "UseProgram")) R->id_use_program = i;
+    if (!strcmp(WR_FN_NAMES[i], "Uniform1i")) R->id_uniform1i = i;
+    if (!strcmp(WR_FN_NAMES[i], "Uniform4fv")) R->id_uniform4fv = i;
+    if (!strcmp(WR_FN_NAMES[i], "UniformMatrix4fv")) R->id_uniform_matrix4fv = i;
   }
   return R;
 }
@@ -76,6 +89,22 @@ static int run_once(wr_replay* R, const uint8_t* t, size_t len) {
     wr_arg args[24];
     memcpy(args, p, (size_t)nargs * sizeof(wr_arg));
     p += (size_t)nargs * sizeof(wr_arg);
+    if (id == R->id_get_uniform && nargs == 3) {
+      const uint32_t prog = (uint32_t)args[0].value;
+      const int32_t actual = ((int32_t(*)(uint32_t, const char*))R->fn[id])(prog, (const char*)wr_ptr(R, &args[1]));
+      const int32_t recorded = (int32_t)args[2].value;
+      int k = 0;
+      while (k < R->n_locs && !(R->locs[k].program == prog && R->locs[k].recorded == recorded)) k++;
+      if (k == R->n_locs && R->n_locs < 1024) R->n_locs++;
+      if (k < 1024) { R->locs[k].program = prog; R->locs[k].recorded = recorded; R->locs[k].actual = actual; }
+      continue;
+    }
+    if (id == R->id_use_program) R->cur_program = (uint32_t)args[0].value;
+    if (id == R->id_uniform1i || id == R->id_uniform4fv || id == R->id_uniform_matrix4fv) {
+      const int32_t recorded = (int32_t)args[0].value;
+      for (int k = 0; k < R->n_locs; k++)
+        if (R->locs[k].program == R->cur_program && R->locs[k].recorded == recorded) { args[0].value = (uint64_t)(int64_t)R->locs[k].actual; break; }
+    }
     if (wr_dispatch(R, id, args) != 0) return (int)i + 1;
   }
   return 0;

@@ -187,6 +187,12 @@ class GL:
         gl = self
 
         def call(*a):
+            if gl.trace is not None and name == "GetUniformLocation":
+                # uniform locations are backend-specific (swgl numbers them per program, gl.cc:1461-1470 via the generated
+                # get_uniform): the trace keeps the location this backend returned so that a replayer can translate
+                loc = fn(*a)
+                gl.trace.record(name, a, ret=loc)
+                return loc
             if gl.trace is not None:
                 gl.trace.record(name, a)
             if ptr_idx:

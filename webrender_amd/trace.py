@@ -15,6 +15,9 @@ Binary layout (little endian):
   u32 magic 'WRTR', u32 n_calls, u32 blob_bytes, u32 scratch_bytes
   n_calls x { u16 fn_id, u16 nargs, nargs x { u32 tag, u32 aux, u64 value } }
   blob bytes
+GetUniformLocation carries one argument more than the call has: the location the RECORDING backend returned.  Uniform
+locations are backend-specific (swgl: per program, in order of first use); a replayer maps recorded -> actual per program
+and rewrites the location of Uniform1i / Uniform4fv / UniformMatrix4fv (csrc/wr_replay.c).
 tags: 0 int, 1 f32, 2 f64, 3 blob(value=offset, aux=len), 4 null,
       5 scratch(value=offset into a replayer-owned buffer), 6 context handle,
       7 scratch initialised from a blob on every replay of the call (value = blob offset << 32 | scratch offset, aux=len:
@@ -72,7 +75,7 @@ class Trace:
         self.blobs.extend(data)
         return off
 
-    def record(self, name, args):
+    def record(self, name, args, ret=None):
         if not self.enabled:
             return
         argtypes = SIGNATURES[name][1]
@@ -102,6 +105,8 @@ class Trace:
                 out.append((TAG_F64, 0, struct.unpack("<Q", struct.pack("<d", float(a)))[0]))
             else:
                 out.append((TAG_INT, 0, int(a) & 0xFFFFFFFFFFFFFFFF))
+        if ret is not None:      # (GetUniformLocation: the location the recording backend returned, as one more int)
+            out.append((TAG_INT, 0, int(ret) & 0xFFFFFFFFFFFFFFFF))
         self.calls.append((FN_ID[name], out))
 
     def serialize(self):
