@@ -234,10 +234,14 @@ typedef struct WrhipStats {
 } WrhipStats;
 void WrhipGetStats(WrhipStats* out);
 void WrhipResetStats(void);
-/* Enable hipEvent timing of every kernel launch (one event pair and a sync per launch: for measurement runs only). */
+/* Enable hipEvent timing of every kernel launch (one event pair and a sync per launch: for measurement runs only).
+ * 1: every flush launches its own kernels at once (what a Finish per frame gives); 2: the launches stay where throughput
+ * mode issues them -- raster launches held back to the next flush, the first of them fused with that flush's setup stage. */
 void WrhipSetProfiling(int enabled);
 /* Per-kernel-variant totals collected while profiling is on: kind 0 = upload scatter, 1 = setup stage, 3 = mask rows (wr_mask_rows_kernel), 2 = raster
- * kernel wr_raster_kernel<fmt, depth, 4, feat>.  algo_bytes: the launch's algorithmic bytes:
+ * kernel wr_raster_kernel<fmt, depth, 4, feat>, 4 = a chained run of thin R8 levels, 5 = wr_raster_dense_kernel, 6 / 7 = kinds 2 / 5
+ * fused with the next flush's setup stage (wr_setup_raster[_dense]_kernel: setup bytes and workgroups added), 8 = wr_setup_rows_kernel
+ * (3 fused likewise).  algo_bytes: the launch's algorithmic bytes:
  * raster launches count every destination pixel they own once (twice when the target's old content is loaded) plus
  * the source texels their draws can sample; the setup stage counts instance + descriptor + record bytes.  Returns the
  * number of entries written (<= max). */

@@ -387,6 +387,22 @@ def test_hip_cfg5_full_8k():
     assert (a[..., 3] == 255).all()
 
 
+def test_hip_staging_ring_wraps_keep_every_frame():
+    """the staging ring's fence-based reuse under real asynchrony -- 40 different frames in flight through a 1 MB ring
+    (wraps every 3-4 frames, held-back tail launches still reading the previous arena) equal the 96 MB ring's frames, a
+    drain-per-lap run and the inline-submit run, byte for byte; the first five equal the oracle's."""
+    from test_hostsim_parity import ring_wrap_digests
+    base = ring_wrap_digests(wrhip_lib(), rounds=8)
+    assert len(set(base)) == len(base) == 40
+    assert ring_wrap_digests(wrhip_lib(), rounds=8, WRHIP_STAGING_BYTES=1 << 20) == base
+    assert ring_wrap_digests(wrhip_lib(), rounds=8, WRHIP_STAGING_BYTES=1 << 20, WRHIP_RING_DRAIN=1) == base
+    assert ring_wrap_digests(wrhip_lib(), rounds=8, WRHIP_STAGING_BYTES=3 << 19, WRHIP_NO_SUBMIT_THREAD=1) == base
+    assert ring_wrap_digests(wrhip_lib(), rounds=8, WRHIP_STAGING_BYTES=1 << 20, WRHIP_NO_COPY_STREAM=1) == base
+    ref = oracle_ref()
+    if ref:
+        assert ring_wrap_digests(ref, rounds=1) == base[:5]
+
+
 def test_hip_vs_clang_oracle_are_a_bounded_deviation():
     ref = oracle_ref("clang")
     if not ref:

@@ -331,6 +331,26 @@ def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
         assert np.array_equal(g[..., [2, 1, 0, 3]], want), f"frame {i}"
 
 
+def ring_wrap_digests(lib, rounds=4, **env):
+    import subprocess
+    import sys
+    e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tests", "ring_wrap_driver.py"), lib, str(rounds)], env=e)
+    return json.loads(out.decode().strip().splitlines()[-1])
+
+
+def test_staging_ring_wraps_keep_every_frame(hostsim, oracle_gcc):
+    """The fence-based reuse of the staging ring: 20 different frames issued without a Finish through a 1 MB ring
+    (each stages 0.1-0.4 MB: the ring wraps a dozen times, descriptors included) give the frames the 96 MB ring gives, the
+    frames a drain at every lap gives, the frames the inline submit path gives -- and the first ones are the reference's."""
+    base = ring_wrap_digests(hostsim)
+    assert len(set(base)) == len(base) == 20
+    assert ring_wrap_digests(hostsim, WRHIP_STAGING_BYTES=1 << 20) == base
+    assert ring_wrap_digests(hostsim, WRHIP_STAGING_BYTES=1 << 20, WRHIP_RING_DRAIN=1) == base
+    assert ring_wrap_digests(hostsim, WRHIP_STAGING_BYTES=3 << 19, WRHIP_NO_SUBMIT_THREAD=1) == base
+    assert ring_wrap_digests(oracle_gcc, rounds=1) == base[:5]
+
+
 def test_unimplemented_perspective_prims_are_reported(hostsim, capfd):
     """Perspective prims outside the implemented set (here: brush_mix_blend, which has no general-quad path) are counted by the
     setup stage, reported on stderr at Finish and raise GL_INVALID_OPERATION -- not drawn wrongly, not dropped silently; the

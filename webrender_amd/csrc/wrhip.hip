@@ -477,6 +477,16 @@ struct Context {
   wr_stream_t copy_stream;
   wr_event_t ev_copy;
   bool copy_overlap = true;
+  // The setup stage of flush k+1 next to the held-back raster launches of flush k WITHOUT sharing a kernel with them: on a
+  // stream of its own, after this flush's upload scatter (ev_up), the draw stream waiting for it (ev_setup) behind the
+  // held-back launches.  The fused kernel costs the tile pass its register budget (25.8 vs 19.9 us on cfg2: the setup
+  // stage's registers put the rect loop at 4 waves per SIMD); two launches on two queues keep both budgets -- and cost five
+  // more runtime calls per flush (2 records, 2 waits, 1 launch, ~5 us each on the submit thread), which is what bounds a cfg2
+  // frame: MEASURED SLOWER on every workload (profiles/r04_a_setup_stream_ab.txt: cfg2 14.7 k vs 20.2-21.6 k frames/s).
+  // Off; WRHIP_SETUP_STREAM=1 turns it on for A/B runs.
+  wr_stream_t setup_stream;
+  wr_event_t ev_up, ev_setup;
+  bool setup_on_stream = false;
   WrUnsupportedCounters* dcounters = nullptr;
   WrUnsupportedCounters seen = {};
   // HBM pool for texture storage: per-frame textures (GpuBufferF/I, render
@@ -499,6 +509,7 @@ struct Context {
   uint64_t ring_fences = 0;            // fences recorded so far (fence k lives in slot k % RING_FENCES)
   // profiling
   bool profiling = false;
+  bool profiling_deferred = false;     // WrhipSetProfiling(2): launches are timed where throughput mode issues them (held-back tail, fused kernels)
   wr_event_t ev_a, ev_b;
   WrhipStats stats;
   std::vector<WrhipKernelStat> kstats;   // per kernel variant, while profiling
@@ -518,6 +529,10 @@ struct Context {
     wrrt::stream_create(&stream);
     wrrt::stream_create(&copy_stream);
     wrrt::event_create_sync(&ev_copy);
+    wrrt::stream_create(&setup_stream);
+    wrrt::event_create_sync(&ev_up);
+    wrrt::event_create_sync(&ev_setup);
+    setup_on_stream = getenv("WRHIP_SETUP_STREAM") && atoi(getenv("WRHIP_SETUP_STREAM")) != 0;
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
@@ -638,10 +653,12 @@ void drain_tail();
 void sync_stream();
 
 void flush_uploads(size_t extra_end = 0);
-void prof_begin();
-void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups);
+void prof_begin(wr_stream_t* on = nullptr);
+void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups, wr_stream_t* on = nullptr);
 
-const size_t STAGING_BYTES = size_t(96) << 20;
+const size_t STAGING_BYTES_DEFAULT = size_t(96) << 20;
+// WRHIP_STAGING_BYTES: another ring size (tests/test_hostsim_parity.py wraps a few-MB ring many times per run)
+static size_t staging_bytes() { static const size_t v = getenv("WRHIP_STAGING_BYTES") ? std::max<size_t>(1 << 16, (size_t)atoll(getenv("WRHIP_STAGING_BYTES"))) : STAGING_BYTES_DEFAULT; return v; }
 bool ring_make_safe(uint64_t need_v, bool may_drain);
 
 // Make the virtual addresses below `need_v` of the staging ring reusable.  `may_drain`: fall back to draining the stream when no
@@ -690,7 +707,7 @@ size_t staging_alloc(size_t n) {
     sync_stream();
     wrrt::pinned_free(c->staging);
     wrrt::dev_free(c->dupload);
-    c->staging_size = std::max(n * 2, STAGING_BYTES);
+    c->staging_size = std::max(n * 2, staging_bytes());
     c->staging = (uint8_t*)wrrt::pinned_alloc(c->staging_size);
     c->dupload = (uint8_t*)wrrt::dev_alloc(c->staging_size);
     c->staging_pos = 0;
@@ -1089,18 +1106,18 @@ Context::~Context() {
 // Execute the selected pending targets: one H2D copy of the frame arena, then
 // vertex + bin + raster launches covering every selected target at once.
 // While profiling, every launch is bracketed by its own event pair and waited for (measurement runs only).
-void prof_begin() { if (ctx->profiling) wrrt::event_record(&ctx->ev_a, ctx->stream); }
-void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups) {
+void prof_begin(wr_stream_t* on) { if (ctx->profiling) wrrt::event_record(&ctx->ev_a, on ? *on : ctx->stream); }
+void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups, wr_stream_t* on) {
   Context* c = ctx;
   if (!c->profiling) return;
-  wrrt::event_record(&c->ev_b, c->stream);
+  wrrt::event_record(&c->ev_b, on ? *on : c->stream);
   wrrt::event_sync(&c->ev_b);
   const uint64_t ns = (uint64_t)(wrrt::event_elapsed_ms(&c->ev_a, &c->ev_b) * 1.0e6);
   WrhipKernelStat* k = nullptr;
   for (WrhipKernelStat& e : c->kstats) if (e.kind == kind && e.fmt == fmt && e.depth == depth && e.feat == feat) k = &e;
   if (!k) { c->kstats.push_back(WrhipKernelStat{kind, fmt, depth, feat, 0, 0, 0, 0}); k = &c->kstats.back(); }
   k->launches++; k->ns += ns; k->algo_bytes += algo_bytes; k->workgroups += workgroups;
-  if (kind == 2 || kind == 4 || kind == 5) c->stats.raster_ns += ns;
+  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7) c->stats.raster_ns += ns;
 }
 
 void tail_launched() {
@@ -1126,7 +1143,7 @@ bool chainable(const Context::Held& H) {
   return ctx->chain_grid > 0 && H.fmt == WR_FMT_R8 && H.nb <= WR_THIN_MAX_BINS && (H.feat == 0 || H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR));
 }
 void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
-                   const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0, int chain_n = 1) {
+                   const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0, int chain_n = 1, uint64_t setup_bytes = 0) {
   Context* c = ctx;
 #define WR_K(FMT, DEPTH, FEAT)                                                                                          \
   do {                                                                                                                  \
@@ -1144,6 +1161,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     // the cs_clip_* prims of this launch's targets, row by row (one wave per row), ahead of the bins that blend them
     const int wgs = std::max(1, std::min((H.mr_rows + 3) / 4, 4096));
     prof_begin();
+    const bool rows_fused = SA != nullptr;
     if (SA) {
       WR_LAUNCH(wr_setup_rows_kernel, n_setup_blocks + wgs, 256, c->stream, *SA, n_setup_blocks, targets, H.off, H.off + H.nb,
                 (const WrPrim*)S.prims, (const WrAux*)S.aux, S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
@@ -1151,13 +1169,13 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     } else
     WR_LAUNCH(wr_mask_rows_kernel, wgs, 256, c->stream, targets, H.off, H.off + H.nb, (const WrPrim*)S.prims, (const WrAux*)S.aux,
               S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
-    prof_end(3, H.fmt, 0, 0, 0, (uint64_t)wgs);
+    prof_end(rows_fused ? 8 : 3, H.fmt, 0, 0, rows_fused ? setup_bytes : 0, (uint64_t)wgs + (rows_fused ? n_setup_blocks : 0));      // (8: wr_setup_rows_kernel)
     if (c->profiling) {          // bytes this launch evaluated: the kernel's running count, read back (profiling syncs per launch anyway)
       unsigned long long parts[32], seen = 0;
       wrrt::d2h(parts, S.mr_ctl + 32, sizeof(parts), c->stream);
       wrrt::stream_sync(c->stream);
       for (unsigned long long v : parts) seen += v;
-      for (WrhipKernelStat& e : c->kstats) if (e.kind == 3 && e.fmt == H.fmt) e.algo_bytes += seen - S.mr_seen;
+      for (WrhipKernelStat& e : c->kstats) if (e.kind == (rows_fused ? 8 : 3) && e.fmt == H.fmt) e.algo_bytes += seen - S.mr_seen;
       S.mr_seen = seen;
     }
     c->stats.kernel_launches++;
@@ -1188,6 +1206,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     return;
   }
   prof_begin();
+  const bool fused = SA != nullptr;      // (SA still set: this raster launch carries the next flush's setup stage)
   if (H.dense && H.fmt == WR_FMT_RGBA8 && H.feat == F7) {
     // (glyph levels: the 128-VGPR instantiation of the same body, plain or with the next flush's setup stage in front)
 #define WR_KD(DEPTH)                                                                                                         \
@@ -1238,19 +1257,20 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   }
 #undef WR_K
 #undef WR_KF
-  prof_end(H.dense ? 5 : 2, H.fmt, H.depth, H.feat, H.algo_bytes, (uint64_t)H.nb);      // (5: wr_raster_dense_kernel)
+  // (5: wr_raster_dense_kernel; 6 / 7: the same two with the next flush's setup stage in front, wr_setup_raster[_dense]_kernel)
+  prof_end(fused ? (H.dense ? 7 : 6) : (H.dense ? 5 : 2), H.fmt, H.depth, H.feat, H.algo_bytes + (fused ? setup_bytes : 0), (uint64_t)H.nb + (fused ? n_setup_blocks : 0));
   c->stats.kernel_launches++; c->stats.raster_launches++;
 }
 // A flush's raster launches in order; runs of chainable() launches of one variant (only the first may have mask rows: its rows
 // launch goes ahead of the chain) leave as one launch.  `fuse_at`: the launch that carries the next flush's setup stage.
 void launch_held(const std::vector<Context::Held>& held, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
-                 int fuse_at = -1, const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0) {
+                 int fuse_at = -1, const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0, uint64_t setup_bytes = 0) {
   for (size_t i = 0; i < held.size();) {
     size_t j = i + 1;
     if (chainable(held[i]) && !(S.mr_ctl == nullptr && held[i].mr_rows > 0))
       while (j < held.size() && j - i < WR_MAX_CHAIN && chainable(held[j]) && held[j].feat == held[i].feat && held[j].mr_rows == 0 && (int)j != fuse_at) j++;
     const bool fuse = (int)i == fuse_at;
-    launch_raster(held[i], targets, n_targets, draws, S, fuse ? SA : nullptr, fuse ? n_setup_blocks : 0, (int)(j - i));
+    launch_raster(held[i], targets, n_targets, draws, S, fuse ? SA : nullptr, fuse ? n_setup_blocks : 0, (int)(j - i), fuse ? setup_bytes : 0);
     i = j;
   }
 }
@@ -1669,6 +1689,19 @@ void flush_work(const std::vector<int>& sel_in) {
 #endif
       const int n_setup_blocks = (n_prims + 255) / 256;
       int fuse_at = -1;
+      const uint64_t setup_bytes = inst_bytes + sizeof(WrDrawDesc) * nd + (uint64_t)n_prims * (sizeof(WrPrim) + sizeof(WrRec));
+      if (c->tail.pending && c->setup_on_stream) {
+        wrrt::event_record(&c->ev_up, c->stream);                 // (this flush's uploads and table resets are enqueued)
+        wrrt::stream_wait_event(c->setup_stream, &c->ev_up);
+        prof_begin(&c->setup_stream);
+        WR_LAUNCH(wr_setup_kernel, n_setup_blocks, 256, c->setup_stream, ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims,
+                  dtargets, S.masks, S.vtab, c->dcounters, dblk);
+        prof_end(1, 0, 0, 0, setup_bytes, (uint64_t)n_setup_blocks, &c->setup_stream);
+        wrrt::event_record(&c->ev_setup, c->setup_stream);
+        c->stats.kernel_launches += 1;
+        drain_tail();                                            // the previous flush's raster launches, concurrently
+        wrrt::stream_wait_event(c->stream, &c->ev_setup);
+      } else {
       if (c->tail.pending)
         {
           // the launch that hides the setup stage best: the largest mask-rows launch if there is one, else the first raster
@@ -1683,15 +1716,16 @@ void flush_work(const std::vector<int>& sel_in) {
         // variant for (normally the tile pass, the longest) carries this flush's setup stage along
         Context::Tail& T = c->tail;
         WrSetupArgs SA{ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims, dtargets, S.masks, S.vtab, c->dcounters, dblk};
-        launch_held(T.held, T.targets, T.n_targets, T.draws, c->scratch[T.set], fuse_at, &SA, n_setup_blocks);
+        launch_held(T.held, T.targets, T.n_targets, T.draws, c->scratch[T.set], fuse_at, &SA, n_setup_blocks, setup_bytes);
         tail_launched();
       } else {
         prof_begin();
         WR_LAUNCH(wr_setup_kernel, n_setup_blocks, 256, c->stream, ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims,
                   dtargets, S.masks, S.vtab, c->dcounters, dblk);
-        prof_end(1, 0, 0, 0, inst_bytes + sizeof(WrDrawDesc) * nd + (uint64_t)n_prims * (sizeof(WrPrim) + sizeof(WrRec)), (uint64_t)n_setup_blocks);
+        prof_end(1, 0, 0, 0, setup_bytes, (uint64_t)n_setup_blocks);
         c->stats.kernel_launches += 1;
         drain_tail();        // (held-back launches the fused kernel has no variant for)
+      }
       }
     } else {
       drain_tail();
@@ -1774,7 +1808,7 @@ void flush_work(const std::vector<int>& sel_in) {
         launches.push_back(Context::Held{WR_FMT_R8, 0, f, L.bins_r8, L.bin0 + L.bins_rgba, L.bytes_r8, (int)std::min<uint64_t>(L.mr_rows, WR_MR_MAX_ROWS)});
       }
     }
-    if (c->defer_tail && !c->profiling && !launches.empty()) {
+    if (c->defer_tail && (!c->profiling || c->profiling_deferred) && !launches.empty()) {
       Context::Tail& T = c->tail;      // (the previous tail went out with this flush's setup launch)
       T.pending = true; T.held = launches; T.n_targets = n_targets;
       T.targets = dtargets; T.draws = ddraws; T.set = (int)(c->flush_seq & 1);
@@ -2924,7 +2958,9 @@ void WrhipResetStats(void) { if (ctx) { memset(&ctx->stats, 0, sizeof(ctx->stats
 void WrhipSetProfiling(int enabled) {
   if (!ctx) return;
   if (enabled && !ctx->profiling) { flush_all(); flush_uploads(); sync_stream(); }   // nothing held back may go out unprofiled
+  if (!enabled && ctx->profiling) { flush_all(); flush_uploads(); sync_stream(); }
   ctx->profiling = enabled != 0;
+  ctx->profiling_deferred = enabled == 2;
 }
 int32_t WrhipGetKernelStats(WrhipKernelStat* out, int32_t max) {
   if (!ctx || !out) return 0;
