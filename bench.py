@@ -348,6 +348,7 @@ def main():
                 roof["traffic_source"] = dom["traffic_source"]
 
     if rank == 0:
+        from webrender_amd.wrench_scenes import DESCRIPTIONS as wrench_desc
         fps = args.steps / elapsed
         out = {
             "metric": "frames/sec + Mpixels/sec on wrench benchmarks, 4K target, 1/2/4/8 GPU",
@@ -362,7 +363,7 @@ def main():
             "mpixels_per_s": round(fps * frame_w * frame_h / 1e6, 1),
             "frame_latency_ms": round(float(np.mean(lat)), 4),
             "timed_regions_ms": [round(1e3 * r, 3) for r in regions],
-            "config": {"workload": f"{args.workload}: " + {
+            "config": {"workload": f"{args.workload}: " + wrench_desc.get(args.workload, "") + {
                 "cfg2": "1000 overlapping translucent rects (ps_quad_textured + premultiplied-alpha blend), "
                         "3840x2160, 20 picture-cache tiles + composite, seed 2",
                 "cfg5": "100k rects (50% opaque), 7680x4320, 72 tiles + composite, seed 5 (BASELINE configs[4])",
@@ -372,7 +373,8 @@ def main():
                 "cfg3": "text: 200 lines x 250 glyphs (ps_text_run, R8 glyph atlas 2048^2, premultiplied-alpha "
                         "blend), 3840x2160, 20 tiles + composite, seed 3",
                 "transforms": "wrench benchmarks/transforms-simple.yaml: 11 full-size translucent rects under rotate(45), 1024x1024",
-                "cfg1": "16x16 opaque rect grid 1024x1024"}[args.workload],
+                "simple-batching": "wrench benchmarks/simple-batching.yaml: 14 x rect [0,0,512,512] green, 3840x2160",
+                "cfg1": "16x16 opaque rect grid 1024x1024"}.get(args.workload, ""),
                 "encoding": args.encoding, "target": f"{frame_w}x{frame_h}",
                 "parallelism": "single GPU" if not sharded else
                 f"tile rows sharded over {world} GPUs + RCCL gather of framebuffer strips to rank 0"},

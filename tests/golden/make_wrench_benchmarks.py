@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Generates webrender_amd/wrench/benchmarks.json from the display lists of the reference's own benchmark set
+(/root/reference/wrench/benchmarks/*.yaml, benchmarks.list) -- the INPUT DATA of the workloads `bench.py --workload <name>`
+restates, not code: item types, bounds, colours, text strings.  The GPU box has no /root/reference, so the lists travel as
+this fixture; the scenes that consume it are webrender_amd/wrench_scenes.py.
+
+    python3 tests/golden/make_wrench_benchmarks.py        (in a container that has /root/reference)
+"""
+import json
+import os
+import re
+import yaml
+
+REF = "/root/reference/wrench/benchmarks"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "webrender_amd", "wrench", "benchmarks.json")
+
+
+def nums(v):
+    if isinstance(v, (list, tuple)):
+        return [float(x) for x in v]
+    return [float(x) for x in str(v).replace(",", " ").split()]
+
+
+def main():
+    out = {"source": "wrench/benchmarks/*.yaml of servo/webrender (display-list input data)"}
+    # text-rendering.yaml: runs of text (wrench/src/yaml_frame_reader.rs handle_text: origin = baseline start, size in px)
+    items = yaml.safe_load(open(os.path.join(REF, "text-rendering.yaml")))["root"]["items"]
+    out["text-rendering"] = [{"text": it["text"], "origin": nums(it["origin"]), "size": float(it["size"]),
+                              "color": it.get("color")} for it in items]
+    # many-images.yaml: a regular grid of 8x8 solid-colour images; verified here, stored as its rule
+    items = yaml.safe_load(open(os.path.join(REF, "many-images.yaml")))["root"]["items"]
+    cols = max(int(nums(it["bounds"])[0]) for it in items) // 8 + 1
+    for i, it in enumerate(items):
+        c, r = i % cols, i // cols
+        m = re.match(r"solid-color\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", it["image"])
+        assert [int(v) for v in m.groups()] == [c, r, 0, 255, 8, 8] and nums(it["bounds"]) == [8.0 * c, 8.0 * r, 8.0, 8.0], i
+    out["many-images"] = {"count": len(items), "cols": cols, "size": 8, "rule": "image i: solid-color(i % cols, i // cols, 0, 255), bounds 8x8 at (8 (i % cols), 8 (i // cols))"}
+    # aligned- / unaligned-gradient.yaml
+    for name in ("aligned-gradient", "unaligned-gradient"):
+        items = yaml.safe_load(open(os.path.join(REF, name + ".yaml")))["root"]["items"]
+        out[name] = [{"bounds": nums(it["bounds"]), "start": nums(it["start"]), "end": nums(it["end"]), "stops": it["stops"],
+                      "repeat": bool(it["repeat"])} for it in items]
+    # many-box-shadows.yaml
+    sc = yaml.safe_load(open(os.path.join(REF, "many-box-shadows.yaml")))["root"]["items"][0]
+    out["many-box-shadows"] = [{"box-bounds": nums(it["box-bounds"]), "clip-rect": nums(it["clip-rect"]), "offset": nums(it["offset"]),
+                                "color": nums(it["color"]), "blur-radius": float(it["blur-radius"]), "spread-radius": float(it["spread-radius"]),
+                                "clip-mode": it["clip-mode"]} for it in sc["items"] if it["type"] == "box-shadow"]
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", os.path.normpath(OUT), {k: (len(v) if isinstance(v, list) else v.get("count")) for k, v in out.items() if k != "source"})
+
+
+if __name__ == "__main__":
+    main()

@@ -289,3 +289,15 @@ DUAL_SOURCE = [
     ("image_dual_masked", dict(dual=True, masked=True, seed=52)),
     ("image_dual_nearest", dict(dual=True, nearest=True, seed=53)),
 ]
+
+
+# The reference's own benchmark set (wrench/benchmarks/benchmarks.list), restated by webrender_amd/wrench_scenes.py from the display
+# lists in webrender_amd/wrench/benchmarks.json: (name, workload, kwargs of the CPU-sized case, kwargs of the full GPU case)
+WRENCH = [
+    ("wrench_many_images", "many-images", dict(width=1024, height=512, count=2048), dict()),
+    ("wrench_aligned_gradient", "aligned-gradient", dict(width=2048, height=1024), dict()),
+    ("wrench_unaligned_gradient", "unaligned-gradient", dict(width=2048, height=1024), dict()),
+    ("wrench_text_rendering", "text-rendering", dict(width=2048, height=1024), dict()),
+    ("wrench_many_box_shadows", "many-box-shadows", dict(width=2048, height=1536), dict()),
+    ("wrench_simple_batching_4k", "simple-batching", None, dict()),
+]

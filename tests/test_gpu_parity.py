@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -385,6 +385,23 @@ def test_hip_cfg5_full_8k():
     b, _ = render_direct(wrhip_lib(), scenes.cfg5_many_rects(encoding="brush"))
     assert np.array_equal(a, b)
     assert (a[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("name,workload,_small,kw", WRENCH, ids=[c[0] for c in WRENCH])
+def test_hip_wrench_benchmarks_full_4k(name, workload, _small, kw):
+    """wrench/benchmarks/*.yaml (wrench_scenes.py) at the 4K target, the bench workloads themselves: 0 differing bytes in every
+    render target read back"""
+    ref = oracle_ref()
+    if not ref:
+        pytest.skip("oracle not built")
+    want, _ = render_direct(ref, scenes.make_workload(workload, **kw))
+    got, st = render_direct(wrhip_lib(), scenes.make_workload(workload, **kw))
+    assert st["gl_error"] == 0
+    if isinstance(want, dict):
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+    else:
+        assert np.array_equal(got, want)
 
 
 def test_hip_staging_ring_wraps_keep_every_frame():

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -329,6 +329,21 @@ def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
     for i, (g, m) in enumerate(zip(got, makes)):
         want, _ = render_direct(oracle_gcc, m())
         assert np.array_equal(g[..., [2, 1, 0, 3]], want), f"frame {i}"
+
+
+@pytest.mark.parametrize("name,workload,kw", [(n, w, k) for n, w, k, _ in WRENCH if k is not None], ids=[c[0] for c in WRENCH if c[2] is not None])
+def test_hostsim_wrench_benchmarks_match_oracle(hostsim, oracle_gcc, name, workload, kw):
+    """wrench/benchmarks/*.yaml as restated by wrench_scenes.py (reduced windows): every render target read back, 0 differing bytes"""
+    want, _ = render_direct(oracle_gcc, scenes.make_workload(workload, **kw))
+    got, st = render_direct(hostsim, scenes.make_workload(workload, **kw))
+    assert st["gl_error"] == 0
+    if isinstance(want, dict):
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+        want = want["window"]
+    else:
+        assert np.array_equal(got, want)
+    assert (want != 255).any()
 
 
 def ring_wrap_digests(lib, rounds=4, **env):

@@ -261,11 +261,15 @@ struct ShaderInfo {
 #define S(x) (1u << (x))
 const unsigned PRIM_SAMPLERS = S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) |
                                S(WR_S_PRIM_HEADERS_F) | S(WR_S_PRIM_HEADERS_I) | S(WR_S_CLIP_MASK);
+const unsigned PRIM_SAMPLERS_NO_COLOR = PRIM_SAMPLERS & ~S(WR_S_COLOR0);
+const unsigned CACHED_GRADIENT_SAMPLERS = S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I) | S(WR_S_GPU_CACHE) | S(WR_S_RENDER_TASKS);
+// (the sampler set of every key is the set of uniforms the reference's generated program answers GetUniformLocation for:
+// tests/test_abi.py::test_uniform_locations_exist_where_the_reference_has_them compares them key by key with the oracle)
 const ShaderInfo SHADERS[] = {
     {"ps_quad_textured", WR_SH_PS_QUAD_TEXTURED, {"aPosition", "aData"},
      S(WR_S_COLOR0) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
-    {"brush_solid", WR_SH_BRUSH_SOLID, {"aPosition", "aData"}, PRIM_SAMPLERS},
-    {"brush_solid ALPHA_PASS", WR_SH_BRUSH_SOLID_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_solid", WR_SH_BRUSH_SOLID, {"aPosition", "aData"}, PRIM_SAMPLERS_NO_COLOR},
+    {"brush_solid ALPHA_PASS", WR_SH_BRUSH_SOLID_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS_NO_COLOR},
     {"brush_image TEXTURE_2D", WR_SH_BRUSH_IMAGE, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT, {"aPosition", "aData"}, PRIM_SAMPLERS},
@@ -277,8 +281,8 @@ const ShaderInfo SHADERS[] = {
     // what BlendMode::Advanced batches are drawn with, shade.rs:440-468)
     {"brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ADVANCED_BLEND,ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
-    {"brush_linear_gradient", WR_SH_BRUSH_LINEAR_GRADIENT, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
-    {"brush_linear_gradient ALPHA_PASS", WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_GPU_BUFFER_F)},
+    {"brush_linear_gradient", WR_SH_BRUSH_LINEAR_GRADIENT, {"aPosition", "aData"}, PRIM_SAMPLERS_NO_COLOR | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
+    {"brush_linear_gradient ALPHA_PASS", WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS_NO_COLOR | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
     {"ps_quad_mask", WR_SH_PS_QUAD_MASK, {"aPosition", "aData", "aClipData"},
      S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) | S(WR_S_GPU_BUFFER_F) | S(WR_S_GPU_BUFFER_I)},
     {"ps_quad_mask FAST_PATH", WR_SH_PS_QUAD_MASK_FAST, {"aPosition", "aData", "aClipData"},
@@ -298,11 +302,9 @@ const ShaderInfo SHADERS[] = {
     {"brush_mix_blend", WR_SH_BRUSH_MIX_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1)},
     {"brush_mix_blend ALPHA_PASS", WR_SH_BRUSH_MIX_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1)},
     {"composite TEXTURE_2D", WR_SH_COMPOSITE,
-     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
-     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"}, S(WR_S_COLOR0)},
     {"composite FAST_PATH,TEXTURE_2D", WR_SH_COMPOSITE_FAST,
-     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"},
-     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"}, S(WR_S_COLOR0)},
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
     {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", WR_SH_PS_TEXT_RUN_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS},
@@ -313,10 +315,8 @@ const ShaderInfo SHADERS[] = {
   {"aPosition", "aClipDeviceArea", "aClipOrigins", "aDevicePixelScale", "aTransformIds", "aClipLocalPos",           \
    "aClipLocalRect", "aClipMode", "aClipRect_TL", "aClipRadii_TL", "aClipRect_TR", "aClipRadii_TR", "aClipRect_BL", \
    "aClipRadii_BL", "aClipRect_BR", "aClipRadii_BR"}
-    {"cs_clip_rectangle", WR_SH_CS_CLIP_RECT, CLIP_RECT_ATTRIBS,
-     S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
-    {"cs_clip_rectangle FAST_PATH", WR_SH_CS_CLIP_RECT_FAST, CLIP_RECT_ATTRIBS,
-     S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
+    {"cs_clip_rectangle", WR_SH_CS_CLIP_RECT, CLIP_RECT_ATTRIBS, S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
+    {"cs_clip_rectangle FAST_PATH", WR_SH_CS_CLIP_RECT_FAST, CLIP_RECT_ATTRIBS, S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
     {"cs_clip_box_shadow TEXTURE_2D", WR_SH_CS_CLIP_BOX_SHADOW,
      {"aPosition", "aClipDeviceArea", "aClipOrigins", "aDevicePixelScale", "aTransformIds", "aClipDataResourceAddress",
       "aClipSrcRectSize", "aClipMode", "aStretchMode", "aClipDestRect"},
@@ -332,13 +332,13 @@ const ShaderInfo SHADERS[] = {
     {"cs_line_decoration", WR_SH_CS_LINE_DECORATION,
      {"aPosition", "aTaskRect", "aLocalSize", "aWavyLineThickness", "aStyle", "aAxisSelect"}, 0},
     {"cs_linear_gradient", WR_SH_CS_LINEAR_GRADIENT,
-     {"aPosition", "aTaskRect", "aStartPoint", "aEndPoint", "aScale", "aExtendMode", "aGradientStopsAddress"}, 1u << WR_S_GPU_BUFFER_F},
+     {"aPosition", "aTaskRect", "aStartPoint", "aEndPoint", "aScale", "aExtendMode", "aGradientStopsAddress"}, CACHED_GRADIENT_SAMPLERS},
     {"cs_radial_gradient", WR_SH_CS_RADIAL_GRADIENT,
      {"aPosition", "aTaskRect", "aCenter", "aScale", "aStartRadius", "aEndRadius", "aXYRatio", "aExtendMode", "aGradientStopsAddress"},
-     1u << WR_S_GPU_BUFFER_F},
+     CACHED_GRADIENT_SAMPLERS},
     {"cs_conic_gradient", WR_SH_CS_CONIC_GRADIENT,
      {"aPosition", "aTaskRect", "aCenter", "aScale", "aStartOffset", "aEndOffset", "aAngle", "aExtendMode", "aGradientStopsAddress"},
-     1u << WR_S_GPU_BUFFER_F},
+     CACHED_GRADIENT_SAMPLERS},
     {"cs_blur ALPHA_TARGET", WR_SH_CS_BLUR_ALPHA,
      {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
     {"cs_blur COLOR_TARGET", WR_SH_CS_BLUR_COLOR,
@@ -2002,7 +2002,7 @@ GLint GetAttribLocation(GLuint program, const GLchar* name) {
 GLint GetUniformLocation(GLuint program, const GLchar* name) {
   Program& p = ctx->programs[program];
   if (!p.info) return -1;
-  if (!strcmp(name, "uTransform")) return UNIFORM_TRANSFORM;
+  if (!strcmp(name, "uTransform")) return p.info->kind == WR_SH_PS_COPY ? -1 : UNIFORM_TRANSFORM;     // (ps_copy's vertex stage has no uTransform)
   for (int s = 0; s < WR_MAX_TEX; s++)
     if (((p.info->samplers >> s) & 1) && !strcmp(SAMPLER_NAMES[s], name)) return s + 1;
   return -1;

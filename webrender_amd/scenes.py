@@ -998,11 +998,17 @@ def blur_chain(fmt="r8", content=(83, 83), sigma=2.5, atlas=256, n_tasks=1, seed
 # Geometry from the yaml: bounds [100,100,800,800], blur-radius 20, radii
 # TL 20 / TR 10 / BL 25 / BR 100, blue, outset.  `dps` scales the whole page
 # (device_pixel_scale); sizes follow compute_box_shadow_parameters (clip.rs:1765-1856).
-def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=None, **kw):
+def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=None, boxes=None, blur_radius=20.0,
+                    radii=((20.0, 20.0), (10.0, 10.0), (25.0, 25.0), (100.0, 100.0)), shadow_color=(0, 0, 255, 255), offset=(0.0, 0.0),
+                    clip_rects=None, **kw):
+    """`boxes`: the box-shadow items' box-bounds (x0, y0, x1, y1), default: n_shadows copies of [100, 100, 900, 900] stacked
+    down the page; `offset`: the shadow's offset from its box (the clip-out stays on the box); `radii`: TL, TR, BL, BR.  Every
+    shadow of one (blur radius, radii) shares ONE cached blurred minimal shadow (box_shadow.rs BoxShadowCacheKey)."""
     BLUR_SAMPLE_SCALE, MAX_BLUR_STD_DEV = 3.0, 4.0      # box_shadow.rs:48, render_task.rs:37
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
-    radii = ((20.0, 20.0), (10.0, 10.0), (25.0, 25.0), (100.0, 100.0))     # TL, TR, BL, BR
-    blur_radius = 20.0
+    if boxes is None:
+        boxes = [(100.0, 100.0 + i * 1000.0, 900.0, 900.0 + i * 1000.0) for i in range(n_shadows)]
+    n_shadows = len(boxes)
     blur_region = float(np.ceil(BLUR_SAMPLE_SCALE * blur_radius))          # 60
     corner = max(max(r[0] for r in radii), blur_region)
     min_size = 2.0 * corner + blur_region                                  # 260
@@ -1048,7 +1054,7 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
     frame.passes.append([tg_h])
     res = frame.gpu_cache.push([list(cur_rect), [0.0, 0.0, 0.0, 0.0]])     # ImageSource of the cached shadow
     # -- per-prim mask tasks + masked brushes (n_shadows copies stacked down the page)
-    masks_w = int(np.ceil(920.0 * dps)) + 8
+    masks_w = int(np.ceil((max(max(b[2] - b[0], b[3] - b[1]) for b in boxes) + 2.0 * blur_region) * dps)) + 8
     m_atlas_w = 1 << int(np.ceil(np.log2(masks_w)))
     m_atlas_h = 1 << int(np.ceil(np.log2(masks_w * n_shadows)))
     t_masks = TextureRef("bs_prim_masks", m_atlas_w, m_atlas_h, G.GL_R8, G.GL_LINEAR, render_target=True)
@@ -1057,9 +1063,8 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
     co_inst = []
     prims = []
     for i in range(n_shadows):
-        oy = i * 1000.0
-        box = (100.0, 100.0 + oy, 900.0, 900.0 + oy)
-        dest = (box[0] - blur_region, box[1] - blur_region, box[2] + blur_region, box[3] + blur_region)
+        box = tuple(float(v) for v in boxes[i])
+        dest = (box[0] + offset[0] - blur_region, box[1] + offset[1] - blur_region, box[2] + offset[0] + blur_region, box[3] + offset[1] + blur_region)
         dev = tuple(v * dps for v in dest)
         so = (float(np.floor(dev[0])), float(np.floor(dev[1])))
         tw, th = int(np.ceil(dev[2]) - so[0]), int(np.ceil(dev[3]) - so[1])
@@ -1080,8 +1085,10 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
     tg_m.steps.append(Step("cs_clip_rectangle", "CLIP_RECT", np.concatenate(co_inst), "Multiply", "none"))
     frame.passes.append([tg_m])
     # -- picture tiles
-    color = premultiply(np.array([[0, 0, 255, 255]], np.uint8))[0]
+    color = premultiply(np.array([list(shadow_color)], np.uint8))[0]
     addr_color = frame.gpu_cache.push([list(color)])
+    in_l, in_t = max(radii[0][0], radii[2][0]), max(radii[0][1], radii[1][1])     # largest left / top radii
+    in_r, in_b = max(radii[1][0], radii[3][0]), max(radii[2][1], radii[3][1])     # ... right / bottom radii
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
@@ -1096,15 +1103,16 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
             if not (dv[0] < x1 and dv[2] > x0 and dv[1] < y1 and dv[3] > y0):
                 continue
             # brush segments (prim_store BrushSegment): the ring around the box interior
-            ix0, iy0 = box[0] + 25.0, box[1] + 25.0          # inset by the largest left / top radii
-            ix1, iy1 = box[2] - 100.0, box[3] - 100.0        # ... right / bottom radii
+            ix0, iy0 = box[0] + in_l, box[1] + in_t          # inset by the largest left / top radii
+            ix1, iy1 = box[2] - in_r, box[3] - in_b          # ... right / bottom radii
             segs = [(dest[0], dest[1], dest[2], iy0), (dest[0], iy1, dest[2], dest[3]),
                     (dest[0], iy0, ix0, iy1), (ix1, iy0, dest[2], iy1)]
             blocks = [list(color)]
             for sg in segs:
                 blocks += [[sg[0] - dest[0], sg[1] - dest[1], sg[2] - dest[0], sg[3] - dest[1]], [0.0, 0.0, 0.0, 0.0]]
             addr = frame.gpu_cache.push(blocks)
-            ph = frame.add_prim_header(dest, (-BIG, -BIG, BIG, BIG), pi + 1, addr, 0, task, (65535, 0, 0, 0))
+            lclip = (-BIG, -BIG, BIG, BIG) if clip_rects is None else tuple(clip_rects[pi])      # the item's clip rect
+            ph = frame.add_prim_header(dest, lclip, pi + 1, addr, 0, task, (65535, 0, 0, 0))
             for si in range(4):
                 inst.append(frame.brush_instance(ph, clip_task, segment=si))
         if inst:
@@ -2392,6 +2400,12 @@ def make_workload(workload, **kw):
         return cfg3_text(**kw)
     if workload == "transforms":          # wrench/benchmarks/transforms-simple.yaml (not a BASELINE config)
         return transforms_simple(**kw)
+    if workload == "simple-batching":     # wrench/benchmarks/simple-batching.yaml at the 4K target
+        return simple_batching(width=3840, height=2160, **kw)
+    from . import wrench_scenes           # the rest of wrench/benchmarks/benchmarks.list
+    if workload in wrench_scenes.WORKLOADS:
+        kw.pop("encoding", None)
+        return wrench_scenes.WORKLOADS[workload](**kw)
     raise SystemExit(f"unknown workload {workload}")
 
 

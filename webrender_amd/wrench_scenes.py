@@ -1,0 +1,196 @@
+"""The reference's own benchmark set (wrench/benchmarks/benchmarks.list) as frames: what WebRender's frame builder hands the draw
+backend for each display list, restated like scenes.py restates the BASELINE configs (no Rust toolchain here: the frame
+builder cannot run).  The display lists themselves -- bounds, colours, text -- come from webrender_amd/wrench/benchmarks.json,
+generated from the YAML files by tests/golden/make_wrench_benchmarks.py.
+
+  many-images          8192 opaque 8x8 images, each its own texture-cache entry, one brush_image batch in the opaque pass
+                       (prepare.rs image prims -> batch.rs:2183-2300; shared texture cache: 16x16 slabs, texture_cache.rs)
+  aligned-gradient     10 x full-size two-stop linear gradient.  With swgl the gradient brush is used, not a cached task
+  unaligned-gradient   (scene_building.rs:3389-3396: `cached = (!is_software || is_tiled) && ...`); the axis-aligned
+                       decomposition (prim_store/gradient/linear.rs:115-335) leaves this gradient as ONE two-stop segment
+                       covering the prim.  Opaque stops => opaque pass, front to back: nine of the ten are depth-rejected
+  text-rendering       68 text runs, sizes 8-20 px, black / red / green / blue (ps_text_run, R8 glyph atlas; glyph bitmaps
+                       from PIL like cfg3's -- the reference rasterises with FreeType)
+  many-box-shadows     9 of the 10 outset box shadows (the cards': blur radius 45, offset (0, 22.5), no corner radii, colour rgba(0,0,0,0.102),
+                       each under its item clip rect: ONE cached blurred minimal shadow (BoxShadowCacheKey depends on blur
+                       radius and radii only), then a cs_clip_box_shadow x cs_clip_rectangle clip-out mask and masked
+                       brush_solid segments per shadow (scenes.cfg4_box_shadow generalised: box_shadow.rs, render_task.rs:1168-1194)
+
+Window: BASELINE's 4K target (3840x2160), device pixel scale 1, the display list in the top-left corner as wrench lays it out.
+"""
+import json
+import os
+import numpy as np
+from . import glconst as G
+from .frame import Frame, Step, Target, TextureRef, CompositeTile, CLIP_TASK_EMPTY
+from . import scenes
+from .scenes import TILE_W, TILE_H, BIG, tile_grid, premultiply
+
+CSS = {"red": (255, 0, 0, 255), "green": (0, 128, 0, 255), "blue": (0, 0, 255, 255), "black": (0, 0, 0, 255)}
+_DATA = None
+
+
+def display_lists():
+    global _DATA
+    if _DATA is None:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "wrench", "benchmarks.json")) as f:
+            _DATA = json.load(f)
+    return _DATA
+
+
+def _tiles(frame, width, height, tile_filter, dps=1.0):
+    """picture-cache tiles of the window: yields (target, picture task address, device rect) and registers the composite"""
+    out = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), dps, (float(ox), float(oy)))
+        out.append((target, task, (x0, y0, x1, y1)))
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    return out
+
+
+def many_images(width=3840, height=2160, tile_filter=None, count=None, **kw):
+    d = display_lists()["many-images"]
+    n, cols, sz = count or d["count"], d["cols"], d["size"]
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    # shared texture cache: every 8x8 image in a 16x16 slab of one 2048^2 RGBA8 texture (texture_cache.rs SlabSize::new)
+    atlas, slab = 2048, 16
+    per_row = atlas // slab
+    pix = np.zeros((atlas, atlas, 4), np.uint8)
+    i = np.arange(n)
+    ax, ay = (i % per_row) * slab, (i // per_row) * slab
+    for k in range(sz):
+        for j in range(sz):
+            pix[ay + k, ax + j] = np.stack([np.zeros(n, np.int64), i // cols, i % cols, np.full(n, 255)], axis=1).astype(np.uint8)   # B, G, R, A
+    t_atlas = TextureRef("shared_cache_rgba8", atlas, atlas, G.GL_RGBA8, G.GL_LINEAR, pixels=pix, upload_format=G.GL_BGRA)
+    frame.static_textures.append(t_atlas)
+    res = [frame.gpu_cache.push([[float(ax[k]), float(ay[k]), float(ax[k] + sz), float(ay[k] + sz)], [0.0, 0.0, 0.0, 0.0]]) for k in range(n)]
+    spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])      # ImageBrushData: white, no tiling
+    tiles = _tiles(frame, width, height, tile_filter)
+    for target, task, (x0, y0, x1, y1) in tiles:
+        op = []
+        if sz * cols <= x0 or sz * ((n + cols - 1) // cols) <= y0:
+            continue
+        for k in range(n):
+            c, r = k % cols, k // cols
+            rect = (float(sz * c), float(sz * r), float(sz * c + sz), float(sz * r + sz))
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), k + 1, spec, 0, task, (4 | (1 << 16), 0, 65535, 0))
+            op.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=res[k]))
+        if op:
+            target.opaque.append(Step("brush_image TEXTURE_2D", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32), None, "opaque",
+                                      textures={0: t_atlas}))
+    return _finish(frame, tiles)
+
+
+def _finish(frame, tiles):
+    frame.passes.append([t for t, _, _ in tiles])
+    return frame
+
+
+def linear_gradients(name, width=3840, height=2160, tile_filter=None, **kw):
+    items = display_lists()[name]
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    prims = []
+    for it in items:
+        x, y, w, h = it["bounds"]
+        stops = [(float(it["stops"][k]), tuple(v / 255.0 for v in CSS[it["stops"][k + 1]])) for k in range(0, len(it["stops"]), 2)]
+        sp, ep = it["start"], it["end"]
+        reverse = sp[0] > ep[0] or (sp[0] == ep[0] and sp[1] > ep[1])          # scene_building.rs:3369-3378
+        if reverse:
+            sp, ep = ep, sp
+        lut = frame.gpu_buffer_f.push(scenes.build_gradient_lut(stops, reverse=reverse))
+        spec = frame.gpu_cache.push([[sp[0], sp[1], ep[0], ep[1]], [1.0 if it["repeat"] else 0.0, w, h, 0.0]])
+        prims.append(((x, y, x + w, y + h), spec, lut))
+    tiles = _tiles(frame, width, height, tile_filter)
+    for target, task, (x0, y0, x1, y1) in tiles:
+        op = []
+        for zi, (rect, spec, lut) in enumerate(prims):
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, (lut, 0, 0, 0))
+            op.append(frame.brush_instance(ph, CLIP_TASK_EMPTY))
+        if op:
+            target.opaque.append(Step("brush_linear_gradient", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32), None, "opaque"))
+    return _finish(frame, tiles)
+
+
+def text_rendering(width=3840, height=2160, tile_filter=None, **kw):
+    items = display_lists()["text-rendering"]
+    sizes = sorted({int(t["size"]) for t in items})
+    atlas, table = scenes.build_glyph_atlas(sizes=tuple(sizes))
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    atlas_ref = TextureRef("glyph_atlas_r8", scenes.ATLAS_SIZE, scenes.ATLAS_SIZE, G.GL_R8, G.GL_LINEAR, pixels=atlas, upload_format=G.GL_RED)
+    frame.static_textures.append(atlas_ref)
+    res_addr = {k: frame.add_glyph_resource(v[0], v[1], 1.0) for k, v in table.items()}
+    runs = []
+    for zi, t in enumerate(items):
+        size = int(t["size"])
+        chars = [ord(c) for c in t["text"]]
+        pts, glyphs, x = [], [], 0.0
+        for c in chars:
+            if (size, c) in table:
+                pts.append((x, 0.0))
+                glyphs.append(c)
+                x += table[(size, c)][2]
+            else:                       # space (no bitmap): advance only
+                from PIL import ImageFont
+                x += float(ImageFont.truetype(scenes.FONT_PATH, size).getlength(chr(c)))
+        color = premultiply(np.array([list(CSS[t["color"] or "black"])], np.uint8))[0]
+        ox, oy = t["origin"]
+        bb = (ox - 2 * size, oy - 1.5 * size, ox + x + 2 * size, oy + size)
+        runs.append((frame.add_text_run(color, pts), (ox, oy), size, glyphs, bb, zi + 1))
+    tiles = _tiles(frame, width, height, tile_filter)
+    n_glyphs = 0
+    for target, task, (x0, y0, x1, y1) in tiles:
+        inst = []
+        for addr, origin, size, glyphs, bb, z in runs:
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
+                continue
+            ph = frame.add_prim_header((origin[0], origin[1], 0.0, 0.0), (-BIG, -BIG, BIG, BIG), z, addr, 0, task, (65535, 0, 0, 0))
+            inst += [frame.glyph_instance(ph, gi, res_addr[(size, c)]) for gi, c in enumerate(glyphs)]
+        if inst:
+            target.alpha.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={0: atlas_ref}))
+            n_glyphs += len(inst)
+    frame.n_glyphs = n_glyphs
+    return _finish(frame, tiles)
+
+
+def many_box_shadows(width=3840, height=2160, tile_filter=None, **kw):
+    items = display_lists()["many-box-shadows"]
+    # (the nine cards' shadows share every parameter but the box; the tenth item -- the 1.5 px shadow of the header bar, a
+    # second cache entry and chain of its own -- is left out)
+    items = [it for it in items if it["blur-radius"] == items[0]["blur-radius"]]
+    assert len(items) == 9 and len({(it["clip-mode"], tuple(it["offset"]), tuple(it["color"])) for it in items}) == 1
+    it0 = items[0]
+    boxes = [(b[0], b[1], b[0] + b[2], b[1] + b[3]) for b in (it["box-bounds"] for it in items)]
+    c = it0["color"]
+    color = (int(round(c[0] * 255)), int(round(c[1] * 255)), int(round(c[2] * 255)), int(round(c[3] * 255)))
+    zero = ((0.0, 0.0),) * 4
+    clips = [(c[0], c[1], c[0] + c[2], c[1] + c[3]) for c in (it["clip-rect"] for it in items)]
+    return scenes.cfg4_box_shadow(width=width, height=height, dps=1.0, tile_filter=tile_filter, boxes=boxes, clip_rects=clips,
+                                  blur_radius=it0["blur-radius"], radii=zero, shadow_color=color, offset=tuple(it0["offset"]))
+
+
+WORKLOADS = {
+    "many-images": many_images,
+    "aligned-gradient": lambda **kw: linear_gradients("aligned-gradient", **kw),
+    "unaligned-gradient": lambda **kw: linear_gradients("unaligned-gradient", **kw),
+    "text-rendering": text_rendering,
+    "many-box-shadows": many_box_shadows,
+}
+DESCRIPTIONS = {
+    "many-images": "wrench benchmarks/many-images.yaml: 8192 opaque 8x8 images (one texture-cache entry each), brush_image opaque pass",
+    "aligned-gradient": "wrench benchmarks/aligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient (brush_linear_gradient, opaque pass, depth-rejected overdraw)",
+    "unaligned-gradient": "wrench benchmarks/unaligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient off the axis (brush_linear_gradient, opaque pass)",
+    "text-rendering": "wrench benchmarks/text-rendering.yaml: 68 text runs, 8-20 px, four colours (ps_text_run, R8 glyph atlas from PIL)",
+    "many-box-shadows": "wrench benchmarks/many-box-shadows.yaml: its 9 card shadows, blur radius 45, rgba(0,0,0,0.1) (one cached blurred corner: mask -> 2 cs_scale -> cs_blur V/H, then cs_clip_box_shadow x clip-out masks and masked brush_solid segments)",
+}
