@@ -213,7 +213,7 @@ def main():
         # (value: the window assembled on rank 0, the presenting GPU -- SURVEY section 8e's "gather to the presenting GPU"; the
         # all-gather variant, every rank ending up with the whole window, is timed alongside: at 8K it moves 132 MB per frame
         # into EVERY GPU, which bounds it near 0.4 k frames/s whatever the raster rate)
-        player = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="root")
+        player = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="root", native="rccl")
         frame_w, frame_h = player.width, player.height
         rec = None
     else:
@@ -263,7 +263,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         del player
-        root = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="all")
+        root = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="all", native="rccl")
         root.frames(args.warmup, 0)
         rr = []
         for _ in range(3):
@@ -274,9 +274,10 @@ def main():
             rr.append(time.perf_counter() - t0)
         t = torch.tensor(rr, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        multi = {"rccl_ranks": world, "collective": "gather of window strips to rank 0, the presenting GPU (value); all_gather to every rank alongside",
+        multi = {"rccl_ranks": world, "collective": "window strips to rank 0, the presenting GPU (value): grouped ncclSend / ncclRecv on the backend's stream, "
+                                                    "in place between the ranks' windows, per-frame loop in native code (csrc/wr_replay.c wr_shard_stream); every rank to every rank alongside",
                  "all_gather": {"value": round(args.steps / float(np.median(t.tolist())), 2), "unit": "frames/s"},
-                 "window_bytes_per_frame": int(root.strip * root.row_bytes * world), "per_rank": per_rank}
+                 "window_bytes_per_frame": int(root.height * root.row_bytes), "per_rank": per_rank}
         player = root
 
     # ---- where the host side of a frame goes: the library's own phase timers over one more streamed region -------

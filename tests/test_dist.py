@@ -50,6 +50,18 @@ if rank == 0:
     ok = ok and np.array_equal(p2.assembled(), want)
 else:
     p2._drain()
+# the NATIVE per-frame loop (csrc/wr_replay.c wr_shard_stream: what bench.py runs with the RCCL transport), here with its CPU
+# stand-in transport: strips written straight into the receivers' windows, no Python per frame
+port = os.environ["MASTER_PORT"]
+for mode in ("all", "root"):
+    pn = ShardedFramePlayer(lib, "custom", "quad", rank, world, device="cpu", frame=make(), gather=mode, native="shm",
+                            shm_name=f"/wrshard_{port}_{mode}")
+    pn.frames(1, 1)
+    pn.stream(3)
+    if mode == "all" or rank == 0:
+        ok = ok and np.array_equal(pn.assembled(), want)
+    dist.barrier()
+    pn.close()
 # each rank only rasterised its own strip: pixels it does not own stay at the clear colour in its window
 y0, y1 = p.fb_rows
 flags = torch.tensor([1 if ok else 0])

@@ -458,6 +458,13 @@ def test_sharded_player_single_rank_rccl():
         got = p.assembled()                       # raw BGRA bytes as stored in HBM
         want, _ = render_direct(wrhip_lib(), make())   # ReadPixels(GL_RGBA)
         assert np.array_equal(got[..., [2, 1, 0, 3]], want)
+        # the native per-frame loop (what bench.py --gpus N runs): replay + WrhipFlush + in-place strip exchange in C
+        for mode in ("root", "all"):
+            pn = ShardedFramePlayer(wrhip_lib(), "custom", "quad", 0, 1, device="cuda", frame=make(), gather=mode, native="rccl")
+            pn.frames(1, 2)
+            pn.stream(4)
+            assert np.array_equal(pn.assembled(), want)
+            pn.close()
     finally:
         dist.destroy_process_group()
 

@@ -151,3 +151,162 @@ void wr_replay_close(wr_replay* R) {
   /* the backend library stays loaded: contexts may own device state */
   free(R);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Sharded stream: the per-frame loop of the multi-GPU harness in native code (webrender_amd/dist.py
+ * does the setup: which rows of which target this rank owns).  Every frame: replay the call stream, WrhipFlush() so that
+ * everything recorded is on the backend's stream, then move the window strips -- nothing else crosses ranks.
+ *
+ *   RCCL transport  grouped ncclSend / ncclRecv on the backend's own stream, in place: a rank sends the rows it owns
+ *                   straight out of its window, the receiver takes them straight into the same rows of ITS window (no
+ *                   staging copy, no host sync; RCCL moves peer-to-peer over xGMI).  mode 0: every rank -> rank 0 (the
+ *                   presenting GPU); mode 1: every rank -> every rank.  librccl is dlopen'ed; the communicator is made
+ *                   from a unique id the caller distributes (dist.py: torch.distributed, once, at setup).
+ *   shm transport   the CPU stand-in for the tests (world-2/3, host-simulation backend): the "window of the presenting
+ *                   GPU" is a POSIX shared-memory segment, a rank's strip is memcpy'd into its rows (the peer write), an
+ *                   arrival counter in the segment tells when a frame is complete.
+ */
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+typedef struct { char internal[128]; } wr_nccl_id;
+typedef struct wr_shard {
+  wr_replay* R;
+  int rank, world, mode;
+  int height, row_bytes;
+  int rows[2 * 64];                 /* framebuffer rows [y0, y1) of every rank's strip */
+  uint8_t* fb;                      /* this rank's window storage (device pointer; host pointer with the hostsim backend) */
+  void (*flush)(void);
+  void (*finish)(void);
+  void* (*get_stream)(void);
+  /* RCCL */
+  void* nccl_dl; void* comm;
+  int (*group_start)(void); int (*group_end)(void);
+  int (*send)(const void*, size_t, int, int, void*, void*);
+  int (*recv)(void*, size_t, int, int, void*, void*);
+  int (*comm_destroy)(void*);
+  /* shm */
+  uint8_t* shm; size_t shm_size; uint64_t frames_done;
+} wr_shard;
+
+int wr_shard_unique_id(const char* librccl, void* out128) {
+  void* dl = dlopen(librccl, RTLD_NOW | RTLD_GLOBAL);
+  if (!dl) { fprintf(stderr, "wr_shard: dlopen(%s): %s\n", librccl, dlerror()); return 1; }
+  int (*get_id)(wr_nccl_id*) = (int (*)(wr_nccl_id*))dlsym(dl, "ncclGetUniqueId");
+  if (!get_id) return 2;
+  return get_id((wr_nccl_id*)out128);
+}
+
+static wr_shard* shard_new(wr_replay* R, int rank, int world, int mode) {
+  if (world < 1 || world > 64) return NULL;
+  wr_shard* S = (wr_shard*)calloc(1, sizeof(wr_shard));
+  S->R = R; S->rank = rank; S->world = world; S->mode = mode;
+  S->flush = (void (*)(void))dlsym(R->dl, "WrhipFlush");
+  S->finish = (void (*)(void))dlsym(R->dl, "Finish");
+  S->get_stream = (void* (*)(void))dlsym(R->dl, "WrhipGetStream");
+  if (!S->flush || !S->finish || !S->get_stream) { fprintf(stderr, "wr_shard: backend lacks WrhipFlush / WrhipGetStream\n"); free(S); return NULL; }
+  return S;
+}
+
+wr_shard* wr_shard_open_rccl(wr_replay* R, const char* librccl, int rank, int world, int mode, const void* unique_id128) {
+  wr_shard* S = shard_new(R, rank, world, mode);
+  if (!S) return NULL;
+  if (world == 1) return S;         /* nothing to exchange: the strip is the window */
+  S->nccl_dl = dlopen(librccl, RTLD_NOW | RTLD_GLOBAL);
+  if (!S->nccl_dl) { fprintf(stderr, "wr_shard: dlopen(%s): %s\n", librccl, dlerror()); free(S); return NULL; }
+  int (*init)(void**, int, wr_nccl_id, int) = (int (*)(void**, int, wr_nccl_id, int))dlsym(S->nccl_dl, "ncclCommInitRank");
+  S->group_start = (int (*)(void))dlsym(S->nccl_dl, "ncclGroupStart");
+  S->group_end = (int (*)(void))dlsym(S->nccl_dl, "ncclGroupEnd");
+  S->send = (int (*)(const void*, size_t, int, int, void*, void*))dlsym(S->nccl_dl, "ncclSend");
+  S->recv = (int (*)(void*, size_t, int, int, void*, void*))dlsym(S->nccl_dl, "ncclRecv");
+  S->comm_destroy = (int (*)(void*))dlsym(S->nccl_dl, "ncclCommDestroy");
+  if (!init || !S->group_start || !S->group_end || !S->send || !S->recv) { fprintf(stderr, "wr_shard: librccl lacks the p2p API\n"); free(S); return NULL; }
+  wr_nccl_id id;
+  memcpy(&id, unique_id128, sizeof(id));
+  int rc = init(&S->comm, world, id, rank);
+  if (rc != 0) { fprintf(stderr, "wr_shard: ncclCommInitRank failed (%d)\n", rc); free(S); return NULL; }
+  return S;
+}
+
+wr_shard* wr_shard_open_shm(wr_replay* R, const char* name, int rank, int world, int mode, size_t window_bytes) {
+  wr_shard* S = shard_new(R, rank, world, mode);
+  if (!S) return NULL;
+  S->shm_size = window_bytes + 4096;
+  int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0 || ftruncate(fd, (off_t)S->shm_size) != 0) { fprintf(stderr, "wr_shard: shm_open(%s) failed\n", name); free(S); return NULL; }
+  S->shm = (uint8_t*)mmap(NULL, S->shm_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (S->shm == MAP_FAILED) { free(S); return NULL; }
+  return S;
+}
+
+void wr_shard_set_window(wr_shard* S, void* fb, int height, int row_bytes, const int* rows2w) {
+  S->fb = (uint8_t*)fb; S->height = height; S->row_bytes = row_bytes;
+  memcpy(S->rows, rows2w, sizeof(int) * 2 * (size_t)S->world);
+}
+
+static size_t strip_off(const wr_shard* S, int r) { return (size_t)S->rows[2 * r] * (size_t)S->row_bytes; }
+static size_t strip_len(const wr_shard* S, int r) { int n = S->rows[2 * r + 1] - S->rows[2 * r]; return n > 0 ? (size_t)n * (size_t)S->row_bytes : 0; }
+
+static int shard_exchange(wr_shard* S) {
+  if (S->shm) {
+    /* the peer write: this rank's rows into the shared window; then tell */
+    const size_t n = strip_len(S, S->rank);
+    if (n) memcpy(S->shm + 4096 + strip_off(S, S->rank), S->fb + strip_off(S, S->rank), n);
+    __atomic_add_fetch((uint64_t*)S->shm, 1, __ATOMIC_RELEASE);
+    S->frames_done++;
+    return 0;
+  }
+  if (S->world == 1) return 0;
+  void* stream = S->get_stream();
+  const int me = S->rank;
+  int rc = S->group_start();
+  for (int p = 0; p < S->world && rc == 0; p++) {
+    if (p == me) continue;
+    const int to_p = S->mode == 1 || p == 0, from_p = S->mode == 1 || me == 0;
+    if (to_p && strip_len(S, me)) rc = S->send(S->fb + strip_off(S, me), strip_len(S, me), 1 /* ncclUint8 */, p, S->comm, stream);
+    if (rc == 0 && from_p && strip_len(S, p)) rc = S->recv(S->fb + strip_off(S, p), strip_len(S, p), 1, p, S->comm, stream);
+  }
+  const int rc2 = S->group_end();
+  return rc ? rc : rc2;
+}
+
+/* `iters` frames back to back, the strips moved after every one, one Finish at the end.  Returns total wall ms in *total_ms. */
+int wr_shard_stream(wr_shard* S, const uint8_t* trace, size_t len, int iters, double* total_ms) {
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int i = 0; i < iters; i++) {
+    int rc = run_once(S->R, trace, len);
+    if (rc) return rc;
+    if (S->shm) S->finish(); else S->flush();      /* (the stand-in copies with the host: the strip has to be there) */
+    rc = shard_exchange(S);
+    if (rc) { fprintf(stderr, "wr_shard: exchange failed (%d)\n", rc); return -2; }
+  }
+  S->finish();                                      /* the backend's stream, collectives included */
+  if (S->shm) {                                     /* every rank's strip of the last frame has landed */
+    const uint64_t want = S->frames_done * (uint64_t)S->world;
+    for (long spins = 0; __atomic_load_n((uint64_t*)S->shm, __ATOMIC_ACQUIRE) < want; spins++) {
+      sched_yield();
+      if (spins > 200000000L) { fprintf(stderr, "wr_shard: peers did not arrive\n"); return -3; }
+    }
+    /* ... in the receivers' windows, as the RCCL transport leaves them: the peers' rows of this rank's own window */
+    if (S->mode == 1 || S->rank == 0)
+      for (int p = 0; p < S->world; p++)
+        if (p != S->rank && strip_len(S, p)) memcpy(S->fb + strip_off(S, p), S->shm + 4096 + strip_off(S, p), strip_len(S, p));
+  }
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  if (total_ms) *total_ms = (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6;
+  return 0;
+}
+
+/* shm transport: the assembled window (what rank 0's window holds on the GPU path) */
+const uint8_t* wr_shard_shm_window(wr_shard* S) { return S->shm ? S->shm + 4096 : NULL; }
+
+void wr_shard_close(wr_shard* S, const char* shm_name_to_unlink) {
+  if (!S) return;
+  if (S->comm && S->comm_destroy) S->comm_destroy(S->comm);
+  if (S->shm) { munmap(S->shm, S->shm_size); if (shm_name_to_unlink) shm_unlink(shm_name_to_unlink); }
+  free(S);
+}

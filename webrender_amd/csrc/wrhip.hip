@@ -2973,6 +2973,7 @@ void WrhipSetTargetRows(GLuint tex, int32_t y0, int32_t y1) {
   if (!ctx) return;
   flush_all();
   Texture& t = ctx->textures[tex];
+  if (y0 <= 0 && y1 >= t.height && t.height > 0) y0 = y1 = 0;     // every row: no restriction (keeps forwarded composites, one rank)
   t.own_y0 = y0; t.own_y1 = y1;
 }
 void* WrhipGetTextureDevicePtr(GLuint tex, int32_t* width, int32_t* height, int32_t* stride) {

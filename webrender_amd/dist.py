@@ -60,9 +60,13 @@ class ShardedFramePlayer:
     """Renders `workload` with rows sharded over `world` ranks and all-gathers
     the window.  Interface mirrors harness.ScenePlayer (frames / stream)."""
 
-    def __init__(self, lib, workload, encoding, rank, world, device="cuda", frame=None, gather="all"):
+    def __init__(self, lib, workload, encoding, rank, world, device="cuda", frame=None, gather="all", native=None, shm_name=None):
         """gather: "all" -- every rank receives the whole window (all-gather; north_star's reassembly step) -- or "root" --
-        only rank 0, the presenting GPU, does ("or gather to the presenting GPU if only one consumer")."""
+        only rank 0, the presenting GPU, does ("or gather to the presenting GPU if only one consumer").
+        native: "rccl" -- the per-frame loop runs in native code (csrc/wr_replay.c wr_shard_stream: replay, WrhipFlush, grouped
+        ncclSend / ncclRecv on the backend's stream straight between the ranks' windows, no Python and no staging copy per
+        frame) -- or "shm" -- the same loop with the CPU stand-in transport of the tests (shared-memory window).  None: the
+        torch.distributed loop below (what the native loop is tested against)."""
         import torch
         import torch.distributed as dist
         from .harness import record_scene, ScenePlayer
@@ -107,12 +111,62 @@ class ShardedFramePlayer:
         else:
             self.fb = None       # CPU/gloo test path reads the strip back through ReadPixels
             self.ext_stream = None
+        self.native = None
+        if native:
+            self._open_native(native, lib, get_ptr, fb_tex, shm_name)
+            return
         chunk = self.strip * self.row_bytes
         self.send = [torch.zeros(chunk, dtype=torch.uint8, device=device) for _ in range(2)]
         # (gather to rank 0: only the presenting rank holds the assembled window)
         self.gathered = [torch.zeros(chunk * world if (gather == "all" or rank == 0) else 0, dtype=torch.uint8, device=device) for _ in range(2)]
         self.pending = None
         self.k = 0
+
+    # -- the native loop ----------------------------------------------------------
+    def _open_native(self, kind, lib, get_ptr, fb_tex, shm_name):
+        import os
+        rl = self.player.rp.lib
+        rl.wr_shard_open_rccl.restype = C.c_void_p
+        rl.wr_shard_open_rccl.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+        rl.wr_shard_open_shm.restype = C.c_void_p
+        rl.wr_shard_open_shm.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_size_t]
+        rl.wr_shard_set_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        rl.wr_shard_stream.restype = C.c_int
+        rl.wr_shard_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        rl.wr_shard_unique_id.argtypes = [C.c_char_p, C.c_char_p]
+        rl.wr_shard_close.argtypes = [C.c_void_p, C.c_char_p]
+        mode = 1 if self.gather == "all" else 0
+        h = self.player.rp.h
+        if kind == "rccl":
+            librccl = os.path.join(os.path.dirname(self.torch.__file__), "lib", "librccl.so").encode()
+            ids = [None]
+            if self.world > 1:
+                if self.rank == 0:
+                    buf = C.create_string_buffer(128)
+                    assert rl.wr_shard_unique_id(librccl, buf) == 0
+                    ids = [buf.raw]
+                self.dist.broadcast_object_list(ids, src=0)       # (setup, once: the id of the communicator the native loop owns)
+            self.native = rl.wr_shard_open_rccl(h, librccl, self.rank, self.world, mode, ids[0] or b"\0" * 128)
+        else:
+            self.shm_name = shm_name.encode()
+            self.native = rl.wr_shard_open_shm(h, self.shm_name, self.rank, self.world, mode, self.height * self.row_bytes)
+        if not self.native:
+            raise RuntimeError("wr_shard_open failed")
+        rows = []
+        for r in range(self.world):
+            sy0, sy1, _ = strip_rows(self.height, r, self.world)
+            rows += [self.height - sy1, self.height - sy0]
+        ptr = get_ptr(fb_tex, None, None, None)
+        rl.wr_shard_set_window(self.native, ptr, self.height, self.row_bytes, (C.c_int * len(rows))(*rows))
+        self._rl = rl
+
+    def _native_stream(self, iters):
+        ms = C.c_double(0.0)
+        t = self.rec.stream
+        rc = self._rl.wr_shard_stream(self.native, t, len(t), iters, C.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"wr_shard_stream failed ({rc})")
+        return ms.value
 
     def _collect(self, i):
         """Start the collective that reassembles the window from every rank's strip (asynchronous)."""
@@ -152,6 +206,9 @@ class ShardedFramePlayer:
 
     def frames(self, warmup, iters):
         import time
+        if self.native:
+            self._native_stream(warmup) if warmup else None
+            return np.array([self._native_stream(1) for _ in range(iters)])
         out = []
         for it in range(warmup + iters):
             t0 = time.perf_counter()
@@ -162,11 +219,16 @@ class ShardedFramePlayer:
         return np.array(out)
 
     def stream(self, iters):
+        if self.native:
+            self._native_stream(iters)
+            return
         for _ in range(iters):
             self._frame()
         self._drain()
 
     def _drain(self):
+        if self.native:
+            return
         if self.pending is not None:
             if self.ext_stream is not None:
                 with self.torch.cuda.stream(self.ext_stream):
@@ -180,6 +242,8 @@ class ShardedFramePlayer:
     def assembled(self):
         """The reassembled window (uint8 [H, W, 4]) from the last gather, in
         framebuffer row order (bottom-up, as ReadPixels returns it)."""
+        if self.native:       # the strips landed in this rank's own window: an ordinary readback
+            return self.player.read_pixels()
         self._drain()
         g = self.gathered[(self.k - 1) & 1].cpu().numpy()
         chunk = self.strip * self.row_bytes
@@ -194,3 +258,8 @@ class ShardedFramePlayer:
 
     def symbol(self, name):
         return self.player.symbol(name)
+
+    def close(self):
+        if self.native:
+            self._rl.wr_shard_close(self.native, getattr(self, "shm_name", None) if self.rank == 0 else None)
+            self.native = None
