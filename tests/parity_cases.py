@@ -301,3 +301,12 @@ WRENCH = [
     ("wrench_many_box_shadows", "many-box-shadows", dict(width=2048, height=1536), dict()),
     ("wrench_simple_batching_4k", "simple-batching", None, dict()),
 ]
+
+# brush_yuv_image (video frames: YUV_FORMAT_PLANAR with three R8 planes, YUV_FORMAT_NV12 with R8 + RG8; the seven YuvRangedColorSpace
+# values; opaque and alpha pass; 1:1, fractional, scaled; linear and nearest plane samplers; behind occluders: depth runs)
+YUV = [
+    ("yuv_grid", lambda: scenes.yuv_grid()),
+    ("yuv_grid_nearest", lambda: scenes.yuv_grid(nearest=True, seed=302)),
+    ("yuv_grid_wide", lambda: scenes.yuv_grid(width=2048, height=1024, n=150, seed=303)),
+    ("occluded_yuv_grid", lambda: scenes.add_occluders(scenes.yuv_grid(seed=304, n=90), zmax=160, seed=41)),
+]

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, YUV, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -344,6 +344,16 @@ def test_hostsim_wrench_benchmarks_match_oracle(hostsim, oracle_gcc, name, workl
     else:
         assert np.array_equal(got, want)
     assert (want != 255).any()
+
+
+@pytest.mark.parametrize("name,make", YUV, ids=[c[0] for c in YUV])
+def test_hostsim_yuv_images_match_oracle(hostsim, oracle_gcc, name, make):
+    """brush_yuv_image (parity_cases.YUV): swgl_commitTextureLinearYUV spans (quantised plane sampling, the fixed-point colour
+    matrix with its saturating adds) and main() tails.  0 differing bytes against the reference's generated program."""
+    want, _ = render_direct(oracle_gcc, make())
+    got, st = render_direct(hostsim, make())
+    assert st["gl_error"] == 0 and (want != 255).any()
+    assert np.array_equal(got, want)
 
 
 def ring_wrap_digests(lib, rounds=4, **env):

@@ -299,6 +299,9 @@ const ShaderInfo SHADERS[] = {
     {"brush_opacity ALPHA_PASS,ANTIALIASING", WR_SH_BRUSH_OPACITY_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_blend", WR_SH_BRUSH_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_blend ALPHA_PASS", WR_SH_BRUSH_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    // (video: planar / semi-planar YUV frames, one R8 / RG8 texture per plane: batch.rs:2301-2390, shade.rs:1012-1040)
+    {"brush_yuv_image TEXTURE_2D,YUV", WR_SH_BRUSH_YUV, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
+    {"brush_yuv_image ALPHA_PASS,TEXTURE_2D,YUV", WR_SH_BRUSH_YUV_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
     {"brush_mix_blend", WR_SH_BRUSH_MIX_BLEND, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1)},
     {"brush_mix_blend ALPHA_PASS", WR_SH_BRUSH_MIX_BLEND_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1)},
     {"composite TEXTURE_2D", WR_SH_COMPOSITE,
@@ -1778,6 +1781,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: case WR_SH_CS_LINEAR_GRADIENT: case WR_SH_CS_RADIAL_GRADIENT: case WR_SH_CS_CONIC_GRADIENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_MIX_BLEND: case WR_SH_BRUSH_MIX_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_YUV: case WR_SH_BRUSH_YUV_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: case WR_SH_PS_QUAD_RADIAL_GRADIENT: case WR_SH_PS_QUAD_CONIC_GRADIENT:
             f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: case WR_SH_CS_FAST_LINEAR_GRADIENT: case WR_SH_CS_LINE_DECORATION:

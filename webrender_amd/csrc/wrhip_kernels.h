@@ -321,6 +321,7 @@ struct WrVsOut {
   float mask_offset[2], mask_bb[4];   // swgl_clipMask(offset, bb_origin, bb_size) arguments
   float uv_add[2];     // shader adds this to the interpolated uv before sampling (0 unless set)
   float u2[4], v2[4];  // a second interpolated vec2 varying (WR_PK_BOX_SHADOW: vLocalPos.xy)
+  float u3[4], v3[4];  // a third one (WR_PK_YUV: vUv_V)
   int tail_clamp;      // fragment main(): clamps uv to uv_bounds
   int tail_modulate;   // fragment main(): multiplies texel by colour
   int blend_override;  // swgl_blendDropShadow / swgl_blendSubpixelText: WrBlend key replacing the draw's (0 = none)
@@ -528,13 +529,13 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 // image: 0 brush_solid, 1 / 2 brush_image (opaque / ALPHA_PASS), 3 linear gradient, 4 brush_blend,
 //        5 / 6 brush_image with REPETITION (opaque / ALPHA_PASS; Rp = its side record)
 WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr,
-                            WrFilterRec* F = nullptr, WrRepeatRec* Rp = nullptr, WrMixRec* Mx = nullptr) {
+                            WrFilterRec* F = nullptr, WrRepeatRec* Rp = nullptr, WrMixRec* Mx = nullptr, WrYuvRec* Yv = nullptr) {
   const bool repetition = image == 5 || image == 6;
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
   const int resource_address = aData.w & 0xffffff;
-  const int vecs_per_brush = image == 3 ? 2 : (image ? 3 : 1);   // VECS_PER_SPECIFIC_BRUSH
+  const int vecs_per_brush = image == 3 ? 2 : ((image && image != 9) ? 3 : 1);   // VECS_PER_SPECIFIC_BRUSH
   // fetch_prim_header
   int u, v;
   wr_fetch_uv(prim_header_address, 2u, u, v);
@@ -665,6 +666,74 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.has_color = 1; o.tail_clamp = 1; o.tail_modulate = 1;
     o.kind = tex.format == WR_FMT_RGBA8 ? WR_PK_TEX_RGBA8 : WR_PK_UNSUPPORTED;
     o.persp_div = persp;           // brush_opacity.glsl:68-70, as brush_image
+    return;
+  }
+  if (image == 9) {
+    // brush_vs (brush_yuv_image.glsl:40-94) + get_rgb_from_ycbcr_info (yuv.glsl:96-165), strict fp32 in the shader's order
+    const int depth = int(color.x), color_space = int(color.y), format = int(color.z);      // fetch_yuv_primitive: the brush's one gpu-cache block
+    Yv->format = format;
+    Yv->rescale = (depth > 8 && format != 1) ? 16 - depth : 0;
+    float channel_max = 255.0f;
+    if (depth > 8) channel_max = format == 1 ? float((1 << depth) - 1) : 65535.0f;
+    // yuv_channel_zero_one_{narrow_range, full_range, identity}
+    const int sh = depth - 8;
+    const float n0 = float(16 << sh) / channel_max, n1 = float(128 << sh) / channel_max, n2 = float(235 << sh) / channel_max, n3 = float(240 << sh) / channel_max;
+    const float ones = float((1 << depth) - 1) / channel_max;
+    float z0, z1, o0, o1;
+    if (color_space == 0 || color_space == 2 || color_space == 4) { z0 = n0; z1 = n1; o0 = n2; o1 = n3; }
+    else if (color_space == 1 || color_space == 3 || color_space == 5) { z0 = 0.0f; z1 = n1; o0 = ones; o1 = ones; }
+    else { z0 = 0.0f; z1 = 0.0f; o0 = ones; o1 = ones; }
+    // RgbFromYuv_* (column-major)
+    float A[9];
+    if (color_space <= 1) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.17207f, 0.88600f, 0.70100f, -0.35707f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    else if (color_space <= 3) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.09366f, 0.92780f, 0.78740f, -0.23406f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    else if (color_space <= 5) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.08228f, 0.94070f, 0.73730f, -0.28568f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    else { const float m[9] = {0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    const float sx = 1.0f / (o0 - z0), sy = 1.0f / (o1 - z1);
+    Yv->bias[0] = z0; Yv->bias[1] = z1; Yv->bias[2] = z1;
+    // rgb_from_yuv * mat3(scale.x, 0, 0,  0, scale.y, 0,  0, 0, scale.y)   (glsl.h mat3 * mat3: r[c] = a[0] * b[c].x + a[1] * b[c].y + a[2] * b[c].z)
+    const float B[9] = {sx, 0.0f, 0.0f, 0.0f, sy, 0.0f, 0.0f, 0.0f, sy};
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) Yv->mat[3 * c + r] = A[r] * B[3 * c] + A[3 + r] * B[3 * c + 1] + A[6 + r] * B[3 * c + 2];
+    // YUVMatrix::From + ctor (composite.h:652-719): the matrix in 6 (7 for y) fractional bits
+    {
+      const double yc = double(Yv->mat[1]), rvd = double(Yv->mat[6]), gud = double(Yv->mat[4]), gvd = double(Yv->mat[7]), bud = double(Yv->mat[5]);
+      const int rs = Yv->rescale;
+      Yv->brmask = Yv->mat[0] == 0.0f ? 0 : -1;
+      Yv->bu = int(int16_t(bud * double(1 << (6 - rs)) + 0.5)); Yv->rv = int(int16_t(rvd * double(1 << (6 - rs)) + 0.5));
+      Yv->gu = -int(int16_t(-gud * double(1 << (6 - rs)) + 0.5)); Yv->gv = -int(int16_t(-gvd * double(1 << (6 - rs)) + 0.5));
+      Yv->ycoeff = int(uint16_t(yc * double(1 << (6 + 1 - rs)) + 0.5));
+      Yv->ybias = int(int16_t((double(Yv->bias[0] * 255.0f) * yc - 0.5) * double(1 << 6)));
+      Yv->uvbias = int(int16_t(double(Yv->bias[1] * float(255 << rs)) + 0.5));
+    }
+    // write_uv_rect per plane (yuv.glsl:167-183)
+    const int planes = format == 3 ? 3 : ((format == 0 || format == 1) ? 2 : (format == 4 ? 1 : 0));
+    for (int pl = 0; pl < 3; pl++) {
+      float* ou = pl == 0 ? o.u : (pl == 1 ? o.u2 : o.u3); float* ov = pl == 0 ? o.v : (pl == 1 ? o.v2 : o.v3);
+      float bnd[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pl < planes) {
+        const int ra = pl == 0 ? data1.x : (pl == 1 ? data1.y : data1.z);
+        const wf4 res = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(ra) % 1024u), int(unsigned(ra) / 1024u));      // fetch_image_source().uv_rect
+        const WrTexDesc& tex = d.tex[WR_S_COLOR0 + pl];
+        const float tsx = float(tex.ptr ? tex.width : 1), tsy = float(tex.ptr ? tex.height : 1);
+        for (int n = 0; n < 4; n++) {
+          const float fx = (vlx[n] - local_rect.x) / (local_rect.z - local_rect.x), fy = (vly[n] - local_rect.y) / (local_rect.w - local_rect.y);
+          ou[n] = ((res.z - res.x) * fx + res.x) / tsx; ov[n] = ((res.w - res.y) * fy + res.y) / tsy;
+        }
+        bnd[0] = (res.x + 0.5f) / tsx; bnd[1] = (res.y + 0.5f) / tsy; bnd[2] = (res.z - 0.5f) / tsx; bnd[3] = (res.w - 0.5f) / tsy;
+      } else {
+        for (int n = 0; n < 4; n++) { ou[n] = 0.0f; ov[n] = 0.0f; }
+      }
+      if (pl == 0) o.uv_bounds = wf4{bnd[0], bnd[1], bnd[2], bnd[3]};
+      else for (int k = 0; k < 4; k++) (pl == 1 ? Yv->u_bounds : Yv->v_bounds)[k] = bnd[k];
+    }
+    o.tex_slot = WR_S_COLOR0;
+    o.tail_clamp = 1;
+    o.tail_modulate = d.shader == WR_SH_BRUSH_YUV_ALPHA ? 1 : 0;      // (here: main() clamps the rgb to [0, 1] -- the ALPHA_PASS key, yuv.glsl:231-235)
+    o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
+    // (planar 8-bit and NV12 on axis-aligned prims; P010 / R16 planes, the interleaved format and rotated video: reported)
+    const bool fmt_ok = (format == 3 || format == 0) && depth == 8 && planes > 0;
+    o.kind = (fmt_ok && transform.axis_aligned && vww[0] == 1.0f && vww[1] == 1.0f && vww[2] == 1.0f && vww[3] == 1.0f) ? WR_PK_YUV : WR_PK_UNSUPPORTED;
     return;
   }
   if (image == 8) {
@@ -2264,7 +2333,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_MIX_BLEND || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT || o.kind == WR_PK_FAST_GRADIENT || o.kind == WR_PK_LINE_DECORATION) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_MIX_BLEND || o.kind == WR_PK_YUV || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT || o.kind == WR_PK_FAST_GRADIENT || o.kind == WR_PK_LINE_DECORATION) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -2300,6 +2369,19 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       M.sL0[0] = wr_pick4(o.u2, tl) + dy0 * l2u; M.sL0[1] = wr_pick4(o.v2, tl) + dy0 * l2v;
       M.sR0[0] = wr_pick4(o.u2, tr) + dy0 * r2u; M.sR0[1] = wr_pick4(o.v2, tr) + dy0 * r2v;
       M.sLs[0] = l2u; M.sLs[1] = l2v; M.sRs[0] = r2u; M.sRs[1] = r2v;
+    }
+    if (o.kind == WR_PK_YUV) {
+      WrYuvRec& Y = auxp->yuv;
+      for (int pl = 1; pl < 3; pl++) {
+        const float* pu = pl == 1 ? o.u2 : o.u3; const float* pv = pl == 1 ? o.v2 : o.v3;
+        const float u4[4] = {pu[0], pu[1], pu[2], pu[3]}, v4[4] = {pv[0], pv[1], pv[2], pv[3]};
+        const float l2u = (wr_pick4(u4, bl) - wr_pick4(u4, tl)) * yScale, l2v = (wr_pick4(v4, bl) - wr_pick4(v4, tl)) * yScale;
+        const float r2u = (wr_pick4(u4, br) - wr_pick4(u4, tr)) * yScale, r2v = (wr_pick4(v4, br) - wr_pick4(v4, tr)) * yScale;
+        float* L0 = pl == 1 ? Y.uL0 : Y.vL0; float* Ls = pl == 1 ? Y.uLs : Y.vLs; float* R0 = pl == 1 ? Y.uR0 : Y.vR0; float* Rs = pl == 1 ? Y.uRs : Y.vRs;
+        L0[0] = wr_pick4(u4, tl) + dy0 * l2u; L0[1] = wr_pick4(v4, tl) + dy0 * l2v;
+        R0[0] = wr_pick4(u4, tr) + dy0 * r2u; R0[1] = wr_pick4(v4, tr) + dy0 * r2v;
+        Ls[0] = l2u; Ls[1] = l2v; Rs[0] = r2u; Rs[1] = r2v;
+      }
     }
     if (o.kind == WR_PK_BOX_SHADOW) {
       WrBoxRec& B = auxp->box;
@@ -2658,6 +2740,9 @@ WR_DEVICE void wr_fetch_texel(const WrTexDesc& t, size_t idx, int (&c)[4]) {
   if (NCH == 4) {
     const uint32_t p = ((const uint32_t*)t.ptr)[idx];
     c[0] = p & 0xFF; c[1] = (p >> 8) & 0xFF; c[2] = (p >> 16) & 0xFF; c[3] = p >> 24;
+  } else if (NCH == 2) {      // RG8 (the chroma plane of NV12): stride and index in 2-byte texels
+    const uint32_t p = ((const uint16_t*)t.ptr)[idx];
+    c[0] = p & 0xFF; c[1] = p >> 8; c[2] = c[3] = 0;
   } else {
     c[0] = ((const uint8_t*)t.ptr)[idx]; c[1] = c[2] = c[3] = 0;
   }
@@ -3322,6 +3407,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_BLEND_ALPHA: wr_vs_brush(d, arena, inst, 4, o, nullptr, &aux[gid].filt); break;
     case WR_SH_BRUSH_MIX_BLEND:
     case WR_SH_BRUSH_MIX_BLEND_ALPHA: wr_vs_brush(d, arena, inst, 8, o, nullptr, nullptr, nullptr, &aux[gid].mix); break;
+    case WR_SH_BRUSH_YUV:
+    case WR_SH_BRUSH_YUV_ALPHA: wr_vs_brush(d, arena, inst, 9, o, nullptr, nullptr, nullptr, nullptr, &aux[gid].yuv); break;
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
@@ -4108,6 +4195,8 @@ __device__ __noinline__ WrWide wr_filter_pixel(const WrPrim* Pp, const WrFilterR
 __device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRec* Fp, const WrDrawDesc* D, float cu, float cv);
 __device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDrawDesc* D, float lu, float lv);
 __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+__device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+WR_DEVICE float wr_r8_texture(const WrTexDesc& t, float u, float v);
 WR_DEVICE WrWide wr_quad_mask_eval(const WrClipRec& C, float f0x, float f0y, float f1x, float f1y, float qx, float qy);
 // One pixel of a textured prim on a general quad and / or with swgl_antiAlias (WR_PK_TEX_QUAD): this row's span and the
 // pixel's coverage as in wr_quad_pixel_rgba8, the edge interpolants stepped row by row (Edge::nextRow), then the base
@@ -4873,6 +4962,90 @@ __device__ __noinline__ WrWide wr_mix_blend_pixel(const WrPrim* Pp, const WrMixR
   for (int i = 0; i < 3; i++) rgb[i] = ((1.0f - Cb4[3]) * Cs[i] + Cb4[3] * res[i]) * Cs4[3];
   uint32_t pc[2];
   wr_pack_color(wf4{rgb[0], rgb[1], rgb[2], Cs4[3]}, pc);
+  WrWide s; s.bg = pc[0]; s.ra = pc[1];
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// brush_yuv_image: one pixel.  Span part: swgl_commitTextureLinearYUV (swgl_ext.h:1028-1340) -- every plane sampled with
+// the quantised fallback stepping (LINEAR_QUANTIZE_UV, uv += uv_step per chunk, clamp, 7-bit bilinear), the samples put
+// through the fixed-point matrix (YUVMatrix::convert, composite.h:722-768: 16-bit lanes, saturating adds).  Tail: main() ->
+// sample_yuv (yuv.glsl:187-237) in float.
+WR_DEVICE int wr_sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+WR_DEVICE int wr_wrap16(int v) { return (int)(int16_t)v; }
+WR_DEVICE WrWide wr_yuv_convert(const WrYuvRec& Y, int y, int u, int v) {
+  // yy = (u16(y) * yCoeffs) >> 1 (16-bit wrap), - yBias; uv - uvBias; br = addsat(yy & mask, coeff * uv) >> 6;
+  // gg = addsat(yy, addsat(gu * u, gv * v)) >> 6; pack with unsigned saturation, alpha 255
+  int yy = wr_wrap16(int((uint32_t(uint16_t(y)) * uint32_t(uint16_t(Y.ycoeff))) & 0xFFFFu) >> 1);
+  yy = wr_wrap16(yy - Y.ybias);
+  const int uu = wr_wrap16(u - Y.uvbias), vv = wr_wrap16(v - Y.uvbias);
+  const int b = wr_sat16((yy & Y.brmask) + wr_wrap16(Y.bu * uu)) >> 6, r = wr_sat16((yy & Y.brmask) + wr_wrap16(Y.rv * vv)) >> 6;
+  const int g = wr_sat16(yy + wr_sat16(wr_wrap16(Y.gu * uu) + wr_wrap16(Y.gv * vv))) >> 6;
+  auto pk = [](int c) { return uint32_t(c < 0 ? 0 : (c > 255 ? 255 : c)); };
+  WrWide s;
+  s.bg = pk(b) | (pk(g) << 16); s.ra = pk(r) | (255u << 16);
+  return s;
+}
+__device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
+  const WrYuvRec& Y = *Yp;
+  const int planes = Y.format == 3 ? 3 : 2;
+  bool all_linear = true;
+  for (int pl = 0; pl < planes; pl++) all_linear = all_linear && D->tex[WR_S_COLOR0 + pl].linear != 0;
+  int sample[3] = {0, 0, 0};          // y, u, v as the span shader's u16 lanes
+  float fs[3] = {0.f, 0.f, 0.f};      // ... and as main()'s floats
+  bool tail = false;
+  for (int pl = 0; pl < planes; pl++) {
+    WrPrim P2 = *Pp;                  // the same walk on this plane's varying (wr_mix_blend_pixel)
+    P2.kind = WR_PK_TEX_R8;           // (the quantised fallback stepping of an R8 / RG8 plane: filter 1)
+    if (pl > 0) {
+      const float* L0 = pl == 1 ? Y.uL0 : Y.vL0; const float* Ls = pl == 1 ? Y.uLs : Y.vLs;
+      const float* R0 = pl == 1 ? Y.uR0 : Y.vR0; const float* Rs = pl == 1 ? Y.uRs : Y.vRs; const float* Bd = pl == 1 ? Y.u_bounds : Y.v_bounds;
+      P2.uvL0[0] = L0[0]; P2.uvL0[1] = L0[1]; P2.uvLs[0] = Ls[0]; P2.uvLs[1] = Ls[1];
+      P2.uvR0[0] = R0[0]; P2.uvR0[1] = R0[1]; P2.uvRs[0] = Rs[0]; P2.uvRs[1] = Rs[1];
+      P2.uv_bounds[0] = Bd[0]; P2.uv_bounds[1] = Bd[1]; P2.uv_bounds[2] = Bd[2]; P2.uv_bounds[3] = Bd[3];
+      P2.rows_linear = 0;
+    }
+    const WrTexDesc& t = D->tex[WR_S_COLOR0 + pl];
+    const WrTexRow r = wr_tex_row(P2, t, y, runs, x, !all_linear);
+    const int n = x - r.x0;
+    const float W = float(t.width), H = float(t.height);
+    if (n < r.span) {
+      const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+      float q[4], qy[4];
+      for (int i = 0; i < 4; i++) { q[i] = r.lu[i] * W * qs + qo; qy[i] = r.lv[i] * H * qs + qo; }
+      const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
+      const float minx = wr_max(P2.uv_bounds[0] * W * qs + qo, 0.0f), miny = wr_max(P2.uv_bounds[1] * H * qs + qo, 0.0f);
+      const float maxx = wr_max(P2.uv_bounds[2] * W * qs + qo, minx), maxy = wr_max(P2.uv_bounds[3] * H * qs + qo, miny);
+      int v4[4];
+      if (t.format == WR_FMT_RG8) {
+        wr_linear_span_pixel<2>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, 1, r.span, n, v4);
+        sample[1] = v4[0]; sample[2] = v4[1];
+      } else {
+        wr_linear_span_pixel<1>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, 1, r.span, n, v4);
+        sample[pl] = v4[0];
+      }
+    } else {
+      tail = true;
+      float cu, cv;
+      wr_tex_tail_uv(P2, r, n, cu, cv);
+      if (t.format == WR_FMT_RG8) {
+        int v4[4] = {0, 0, 0, 0};
+        if (t.linear) wr_bilinear<2>(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)), v4);
+        else wr_fetch_texel<2>(t, (size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride, v4);
+        fs[1] = float(v4[0]) * (1.0f / 255.0f); fs[2] = float(v4[1]) * (1.0f / 255.0f);
+      } else {
+        fs[pl] = wr_r8_texture(t, cu, cv);
+      }
+    }
+  }
+  if (!tail) return wr_yuv_convert(Y, sample[0], sample[1], sample[2]);
+  // rgb = vRgbFromDebiasedYcbcr * (ycbcr_sample - vYcbcrBias); ALPHA_PASS: clamp to [0, 1]; alpha 1
+  const float d0 = fs[0] - Y.bias[0], d1 = fs[1] - Y.bias[1], d2 = fs[2] - Y.bias[2];
+  float rgb[3];
+  for (int i = 0; i < 3; i++) rgb[i] = Y.mat[i] * d0 + Y.mat[3 + i] * d1 + Y.mat[6 + i] * d2;
+  if (Pp->flags & WR_PF_TAIL_MODULATE) for (int i = 0; i < 3; i++) rgb[i] = wr_clamp(rgb[i], 0.0f, 1.0f);
+  uint32_t pc[2];
+  wr_pack_color(wf4{rgb[0], rgb[1], rgb[2], 1.0f}, pc);
   WrWide s; s.bg = pc[0]; s.ra = pc[1];
   return s;
 }
@@ -6098,7 +6271,7 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 // The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
 // nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
 WR_DEVICE bool wr_kind_needs_runs(int kind) {
-  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_MIX_BLEND || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION ||
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_MIX_BLEND || kind == WR_PK_YUV || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION ||
          kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
 }
 // interval of prim `ci` (a depth writer) on row y
@@ -6692,7 +6865,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_FILTER || kind == WR_PK_TEX_REPEAT || kind == WR_PK_MIX_BLEND)) {
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_FILTER || kind == WR_PK_TEX_REPEAT || kind == WR_PK_MIX_BLEND || kind == WR_PK_YUV)) {
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -6706,6 +6879,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       const WrRuns* rq = rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr;
       const WrWide raw = kind == WR_PK_FILTER ? wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2), rq)
                          : kind == WR_PK_MIX_BLEND ? wr_mix_blend_pixel(Pp, &Ap->mix, D, px + (q & 3), py + 4 * (q >> 2), rq)
+                         : kind == WR_PK_YUV ? wr_yuv_pixel(Pp, &Ap->yuv, D, px + (q & 3), py + 4 * (q >> 2), rq)
                                                    : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2), rq);
       const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), raw);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);

@@ -78,6 +78,8 @@ enum WrShader {
   WR_SH_PS_TEXT_RUN_GT,            // ps_text_run ALPHA_PASS,GLYPH_TRANSFORM,TEXTURE_2D (glyphs rasterised under the run's 2-D transform)
   WR_SH_PS_TEXT_RUN_DUAL_GT,       // ... with DUAL_SOURCE_BLENDING
   WR_SH_PS_SPLIT_COMPOSITE,        // the split polygons of a preserve-3d context (batch.rs:1985-2080)
+  WR_SH_BRUSH_YUV,                 // brush_yuv_image TEXTURE_2D,YUV (video frames as planar / semi-planar YUV: batch.rs:2301-2390)
+  WR_SH_BRUSH_YUV_ALPHA,           // ... ALPHA_PASS
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -272,6 +274,8 @@ enum WrPrimKind {
   WR_PK_BORDER_SEGMENT, // cs_border_segment: fragment shader only (styles double / groove / ridge, dot / dash clips; WrBorderSegRec)
   WR_PK_FAST_GRADIENT,  // cs_fast_linear_gradient: main() only, mix(vColor0, vColor1, vPos) (WrFastGradRec); vPos travels in the u interpolant
   WR_PK_LINE_DECORATION,// cs_line_decoration: main() only (solid / dashed / dotted / wavy; WrLineRec); vLocalPos in the uv interpolants
+  WR_PK_YUV,            // brush_yuv_image: swgl_commitTextureLinearYUV (up to three planes, fixed-point colour matrix; WrYuvRec); the Y plane's
+                        // uv travels in WrPrim's uv interpolants, the chroma planes' in WrYuvRec
   WR_PK_MASK_ROWS,      // WrRec only: a WR_PK_BOX_SHADOW / WR_PK_CLIP_RECT prim whose rows wr_mask_rows_kernel has evaluated (WrMaskSlot)
 };
 
@@ -434,6 +438,16 @@ struct WrMixRec {
   float s_bounds[4];
 };
 
+// brush_yuv_image (brush_yuv_image.glsl:9-26): the flat varyings, the chroma planes' varyings as edge interpolants (as WrPrim::uv*
+// hold the luma plane's), and the coefficients of swgl's fixed-point matrix (YUVMatrix, composite.h:640-720)
+struct WrYuvRec {
+  int32_t format, rescale;          // vFormat.x (YUV_FORMAT_*), vRescaleFactor
+  float bias[3], mat[9];            // vYcbcrBias, vRgbFromDebiasedYcbcr (column-major)
+  int32_t bu, rv, gu, gv, ycoeff, ybias, uvbias, brmask;      // YUVMatrix: br_uvCoeffs, gg_uvCoeffs, yCoeffs, yBias, uvBias, br_yMask
+  float uL0[2], uLs[2], uR0[2], uRs[2], u_bounds[4];          // vUv_U, vUvBounds_U
+  float vL0[2], vLs[2], vR0[2], vRs[2], v_bounds[4];          // vUv_V, vUvBounds_V
+};
+
 // cs_border_solid flat varyings (cs_border_solid.glsl:11-38)
 struct WrBorderRec {
   float color0[4], color1[4];       // vColor0, vColor1
@@ -522,6 +536,7 @@ union WrAux {
   WrGradRec grad;
   WrFilterRec filt;
   WrMixRec mix;
+  WrYuvRec yuv;
   WrQuadRec quad;
   WrBorderRec border;
   WrBorderSegRec bseg;

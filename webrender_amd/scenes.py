@@ -2890,3 +2890,108 @@ def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, on
         frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
     frame.passes.append(targets)
     return frame
+
+
+# ---------------------------------------------------------------------------
+# brush_yuv_image: video frames as YUV planes (batch.rs:2301-2390 YuvImage prims; shade.rs brush_yuv_image).  One R8 texture per
+# plane for YUV_FORMAT_PLANAR (chroma at half resolution, 4:2:0), an R8 luma + an RG8 interleaved chroma texture for
+# YUV_FORMAT_NV12.  The brush's gpu-cache block is YuvImageData (prim_store/image.rs write_prim_gpu_blocks): [channel bit depth,
+# YuvRangedColorSpace, YuvFormat, 0]; prim_user_data = the planes' ImageSource addresses.
+YUV_FORMAT_NV12, YUV_FORMAT_PLANAR = 0, 3
+
+
+def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=None, nearest=False):
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    A = 1024
+    ypl, upl, vpl = np.zeros((A, A), np.uint8), np.zeros((A // 2, A // 2), np.uint8), np.zeros((A // 2, A // 2), np.uint8)
+    videos = []
+    x = y = shelf = 0
+    for i in range(12):
+        w, h = 2 * int(rng.integers(16, 120)), 2 * int(rng.integers(16, 90))
+        if x + w > A:
+            x, y, shelf = 0, y + shelf, 0
+        yy, xx = np.mgrid[0:h, 0:w]
+        ypl[y:y + h, x:x + w] = ((xx * 255 // max(w - 1, 1)) ^ rng.integers(0, 256, size=(h, w))).astype(np.uint8) if i % 3 else rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        upl[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = rng.integers(0, 256, size=(h // 2, w // 2), dtype=np.uint8)
+        vpl[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = rng.integers(0, 256, size=(h // 2, w // 2), dtype=np.uint8)
+        ry = frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]])
+        rc = frame.gpu_cache.push([[x // 2, y // 2, (x + w) // 2, (y + h) // 2], [0.0, 0.0, 0.0, 0.0]])
+        videos.append((w, h, ry, rc))
+        x += w
+        shelf = max(shelf, h)
+    filt = G.GL_NEAREST if nearest else G.GL_LINEAR
+    t_y = TextureRef("yuv_plane_y", A, A, G.GL_R8, filt, pixels=ypl, upload_format=G.GL_RED)
+    t_u = TextureRef("yuv_plane_u", A // 2, A // 2, G.GL_R8, filt, pixels=upl, upload_format=G.GL_RED)
+    t_v = TextureRef("yuv_plane_v", A // 2, A // 2, G.GL_R8, filt, pixels=vpl, upload_format=G.GL_RED)
+    t_uv = TextureRef("yuv_plane_uv", A // 2, A // 2, G.GL_RG8, filt, pixels=np.ascontiguousarray(np.stack([upl, vpl], axis=2)), upload_format=G.GL_RG)
+    frame.static_textures += [t_y, t_u, t_v, t_uv]
+    prims = []         # (rect, brush data address, user data, opaque pass, nv12)
+    band, gx, k = 200, 4.0, 0
+    while True:        # opaque-pass videos on a disjoint grid in the top band (see image_grid)
+        vw, vh, ry, rc = videos[k % len(videos)]
+        sc = (1.0, 1.0, 1.4, 0.5, 0.81)[k % 5]
+        w, h = vw * sc, min(vh * sc, band - 8.0)
+        if gx + w + 4 > width:
+            break
+        off = 0.37 if k % 5 == 1 else 0.0
+        spec = frame.gpu_cache.push([[8.0, float(k % 7), float(YUV_FORMAT_NV12 if k % 2 else YUV_FORMAT_PLANAR), 0.0]])
+        prims.append(((gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), spec, (ry, rc, rc, 0), True, k % 2 == 1))
+        gx += float(np.ceil(w)) + 6.0
+        k += 1
+    for k in range(n):
+        vw, vh, ry, rc = videos[int(rng.integers(0, len(videos)))]
+        mode = k % 5
+        if mode == 0:
+            w, h, px, py = float(vw), float(vh), float(rng.integers(-20, width - 20)), float(rng.integers(band, height - 20))
+        elif mode == 1:
+            w, h, px, py = float(vw), float(vh), float(rng.uniform(0, width - vw)), float(rng.uniform(band, height - vh))
+        elif mode == 2:
+            sc = float(rng.uniform(1.1, 3.0))
+            w, h = vw * sc, vh * sc
+            px, py = float(rng.integers(0, width)) - w / 2, max(float(rng.integers(band + 300, height + 100)) - h / 2, float(band))
+        elif mode == 3:
+            w, h, px, py = vw * 0.5, vh * 0.5, float(rng.integers(0, width - vw)), float(rng.integers(band, height - vh))
+        else:
+            w, h = vw * float(rng.uniform(0.3, 1.7)), vh * float(rng.uniform(0.3, 1.7))
+            px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - h))
+        spec = frame.gpu_cache.push([[8.0, float((k * 3 + 1) % 7), float(YUV_FORMAT_NV12 if (k // 2) % 2 else YUV_FORMAT_PLANAR), 0.0]])
+        prims.append(((px, py, px + w, py + h), spec, (ry, rc, rc, 0), False, (k // 2) % 2 == 1))
+    targets = []
+    for (tx, ty, ox, oy) in tile_grid(width, height):
+        if tile_filter is not None and not tile_filter(tx, ty):
+            continue
+        x0, y0, x1, y1 = ox, oy, ox + TILE_W, oy + TILE_H
+        tex = TextureRef(f"tile_{tx}_{ty}", TILE_W, TILE_H, G.GL_RGBA8, G.GL_LINEAR, render_target=True, with_depth=True)
+        target = Target(tex, "picture_tile", clear_color=(1.0, 1.0, 1.0, 1.0), clear_depth=True)
+        task = frame.add_render_task((0.0, 0.0, float(TILE_W), float(TILE_H)), 1.0, (float(ox), float(oy)))
+        batches = {}       # (opaque pass, nv12) -> instances; alpha-pass batches break wherever the plane textures change
+        order = []
+        for zi, (rect, spec, ud, opaque, nv12) in enumerate(prims):
+            if only is not None and zi not in only:
+                continue
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, ud)
+            inst = frame.brush_instance(ph, CLIP_TASK_EMPTY)
+            if opaque:
+                batches.setdefault((True, nv12), []).append(inst)
+            else:
+                if not order or order[-1][0] != nv12:
+                    order.append((nv12, []))
+                order[-1][1].append(inst)
+        tex_of = lambda nv12: {0: t_y, 1: t_uv} if nv12 else {0: t_y, 1: t_u, 2: t_v}
+        for nv12 in (False, True):
+            op = batches.get((True, nv12))
+            if op:
+                target.opaque.append(Step("brush_yuv_image TEXTURE_2D,YUV", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32), None, "opaque",
+                                          textures=tex_of(nv12)))
+        for nv12, al in order:
+            target.alpha.append(Step("brush_yuv_image ALPHA_PASS,TEXTURE_2D,YUV", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures=tex_of(nv12)))
+        targets.append(target)
+        rect = (float(x0), float(y0), float(x1), float(y1))
+        clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
+        frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
+    frame.passes.append(targets)
+    return frame
