@@ -309,4 +309,9 @@ YUV = [
     ("yuv_grid_nearest", lambda: scenes.yuv_grid(nearest=True, seed=302)),
     ("yuv_grid_wide", lambda: scenes.yuv_grid(width=2048, height=1024, n=150, seed=303)),
     ("occluded_yuv_grid", lambda: scenes.add_occluders(scenes.yuv_grid(seed=304, n=90), zmax=160, seed=41)),
+    # 10-bit video: three R16 planes (low bits, rescaled by the span shader) and P010 (R16 + RG16, high bits)
+    ("yuv_grid_10bit", lambda: scenes.yuv_grid(hdr=True, seed=305)),
+    # "composite TEXTURE_2D,YUV": video surfaces composited straight into the window (scaled, clipped, flipped, blended)
+    ("yuv_composites", lambda: scenes.yuv_composites()),
+    ("yuv_composites_nearest", lambda: scenes.yuv_composites(nearest=True, seed=312)),
 ]

@@ -308,6 +308,9 @@ const ShaderInfo SHADERS[] = {
      {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"}, S(WR_S_COLOR0)},
     {"composite FAST_PATH,TEXTURE_2D", WR_SH_COMPOSITE_FAST,
      {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"}, S(WR_S_COLOR0)},
+    {"composite TEXTURE_2D,YUV", WR_SH_COMPOSITE_YUV,
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aFlip", "aUvRect0", "aUvRect1", "aUvRect2"},
+     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
     {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"ps_text_run ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", WR_SH_PS_TEXT_RUN_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS},
@@ -1781,7 +1784,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: case WR_SH_CS_LINEAR_GRADIENT: case WR_SH_CS_RADIAL_GRADIENT: case WR_SH_CS_CONIC_GRADIENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_MIX_BLEND: case WR_SH_BRUSH_MIX_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
-          case WR_SH_BRUSH_YUV: case WR_SH_BRUSH_YUV_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_YUV: case WR_SH_BRUSH_YUV_ALPHA: case WR_SH_COMPOSITE_YUV: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: case WR_SH_PS_QUAD_RADIAL_GRADIENT: case WR_SH_PS_QUAD_CONIC_GRADIENT:
             f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: case WR_SH_CS_FAST_LINEAR_GRADIENT: case WR_SH_CS_LINE_DECORATION:

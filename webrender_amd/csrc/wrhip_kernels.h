@@ -331,6 +331,62 @@ struct WrVsOut {
   float persp_div;     // brush_image: perspective_interpolate of `uv = v_uv * mix(gl_FragCoord.w, 1.0, .)` in main(); < 0: no such factor
 };
 
+// get_rgb_from_ycbcr_info (yuv.glsl:96-165) in strict fp32 in the shader's order + vRescaleFactor, and the coefficients swgl's
+// YUVMatrix derives from them (composite.h:652-719): shared by brush_yuv_image and composite ... YUV
+WR_DEVICE void wr_yuv_setup(WrYuvRec& Y, int depth, int color_space, int format) {
+  WrYuvRec* Yv = &Y;
+    Yv->format = format;
+    Yv->rescale = (depth > 8 && format != 1) ? 16 - depth : 0;
+    float channel_max = 255.0f;
+    if (depth > 8) channel_max = format == 1 ? float((1 << depth) - 1) : 65535.0f;
+    // yuv_channel_zero_one_{narrow_range, full_range, identity}
+    const int sh = depth - 8;
+    const float n0 = float(16 << sh) / channel_max, n1 = float(128 << sh) / channel_max, n2 = float(235 << sh) / channel_max, n3 = float(240 << sh) / channel_max;
+    const float ones = float((1 << depth) - 1) / channel_max;
+    float z0, z1, o0, o1;
+    if (color_space == 0 || color_space == 2 || color_space == 4) { z0 = n0; z1 = n1; o0 = n2; o1 = n3; }
+    else if (color_space == 1 || color_space == 3 || color_space == 5) { z0 = 0.0f; z1 = n1; o0 = ones; o1 = ones; }
+    else { z0 = 0.0f; z1 = 0.0f; o0 = ones; o1 = ones; }
+    // RgbFromYuv_* (column-major)
+    float A[9];
+    if (color_space <= 1) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.17207f, 0.88600f, 0.70100f, -0.35707f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    else if (color_space <= 3) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.09366f, 0.92780f, 0.78740f, -0.23406f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    else if (color_space <= 5) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.08228f, 0.94070f, 0.73730f, -0.28568f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    else { const float m[9] = {0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
+    const float sx = 1.0f / (o0 - z0), sy = 1.0f / (o1 - z1);
+    Yv->bias[0] = z0; Yv->bias[1] = z1; Yv->bias[2] = z1;
+    // rgb_from_yuv * mat3(scale.x, 0, 0,  0, scale.y, 0,  0, 0, scale.y)   (glsl.h mat3 * mat3: r[c] = a[0] * b[c].x + a[1] * b[c].y + a[2] * b[c].z)
+    const float B[9] = {sx, 0.0f, 0.0f, 0.0f, sy, 0.0f, 0.0f, 0.0f, sy};
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) Yv->mat[3 * c + r] = A[r] * B[3 * c] + A[3 + r] * B[3 * c + 1] + A[6 + r] * B[3 * c + 2];
+    // YUVMatrix::From + ctor (composite.h:652-719): the matrix in 6 (7 for y) fractional bits
+    {
+      const double yc = double(Yv->mat[1]), rvd = double(Yv->mat[6]), gud = double(Yv->mat[4]), gvd = double(Yv->mat[7]), bud = double(Yv->mat[5]);
+      const int rs = Yv->rescale;
+      Yv->brmask = Yv->mat[0] == 0.0f ? 0 : -1;
+      Yv->bu = int(int16_t(bud * double(1 << (6 - rs)) + 0.5)); Yv->rv = int(int16_t(rvd * double(1 << (6 - rs)) + 0.5));
+      Yv->gu = -int(int16_t(-gud * double(1 << (6 - rs)) + 0.5)); Yv->gv = -int(int16_t(-gvd * double(1 << (6 - rs)) + 0.5));
+      Yv->ycoeff = int(uint16_t(yc * double(1 << (6 + 1 - rs)) + 0.5));
+      Yv->ybias = int(int16_t((double(Yv->bias[0] * 255.0f) * yc - 0.5) * double(1 << 6)));
+      Yv->uvbias = int(int16_t(double(Yv->bias[1] * float(255 << rs)) + 0.5));
+    }
+}
+
+// The plane layouts the YUV span shader has a sampler for (sampleYUV, swgl_ext.h:1050-1150): three R8 or three R16 planes
+// (YUV_FORMAT_PLANAR), R8 + RG8 (NV12) or R16 + RG16 (P010, 16-bit NV12); 16-bit planes linear-filtered.  The interleaved (YUY2)
+// format and anything else is reported.
+WR_DEVICE bool wr_yuv_planes_ok(const WrDrawDesc& d, int format, int depth) {
+  const WrTexDesc& t0 = d.tex[WR_S_COLOR0]; const WrTexDesc& t1 = d.tex[WR_S_COLOR1]; const WrTexDesc& t2 = d.tex[WR_S_COLOR2];
+  if (!t0.ptr || !t1.ptr) return false;
+  if (depth != 8 && depth != 10 && depth != 12 && depth != 16) return false;
+  const bool wide = t0.format == WR_FMT_R16;
+  if (wide != (depth > 8)) return false;
+  if (wide && !(t0.linear && t1.linear)) return false;
+  if (format == 3) return t2.ptr && t1.format == t0.format && t2.format == t0.format && (t0.format == WR_FMT_R8 || (wide && t2.linear));
+  if (format == 0 || format == 1) return wide ? t1.format == WR_FMT_RG16 : (t0.format == WR_FMT_R8 && t1.format == WR_FMT_RG8 && format == 0);
+  return false;
+}
+
 // ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
 // mask: 0 ps_quad_textured, 1 ps_quad_mask, 2 ps_quad_mask FAST_PATH (C = its side record)
 // mask: 0 ps_quad_textured, 1 / 2 ps_quad_mask (general / FAST_PATH; C = its side record), 3 / 4 ps_quad_radial_gradient /
@@ -671,41 +727,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   if (image == 9) {
     // brush_vs (brush_yuv_image.glsl:40-94) + get_rgb_from_ycbcr_info (yuv.glsl:96-165), strict fp32 in the shader's order
     const int depth = int(color.x), color_space = int(color.y), format = int(color.z);      // fetch_yuv_primitive: the brush's one gpu-cache block
-    Yv->format = format;
-    Yv->rescale = (depth > 8 && format != 1) ? 16 - depth : 0;
-    float channel_max = 255.0f;
-    if (depth > 8) channel_max = format == 1 ? float((1 << depth) - 1) : 65535.0f;
-    // yuv_channel_zero_one_{narrow_range, full_range, identity}
-    const int sh = depth - 8;
-    const float n0 = float(16 << sh) / channel_max, n1 = float(128 << sh) / channel_max, n2 = float(235 << sh) / channel_max, n3 = float(240 << sh) / channel_max;
-    const float ones = float((1 << depth) - 1) / channel_max;
-    float z0, z1, o0, o1;
-    if (color_space == 0 || color_space == 2 || color_space == 4) { z0 = n0; z1 = n1; o0 = n2; o1 = n3; }
-    else if (color_space == 1 || color_space == 3 || color_space == 5) { z0 = 0.0f; z1 = n1; o0 = ones; o1 = ones; }
-    else { z0 = 0.0f; z1 = 0.0f; o0 = ones; o1 = ones; }
-    // RgbFromYuv_* (column-major)
-    float A[9];
-    if (color_space <= 1) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.17207f, 0.88600f, 0.70100f, -0.35707f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
-    else if (color_space <= 3) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.09366f, 0.92780f, 0.78740f, -0.23406f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
-    else if (color_space <= 5) { const float m[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.08228f, 0.94070f, 0.73730f, -0.28568f, 0.00000f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
-    else { const float m[9] = {0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f}; for (int i = 0; i < 9; i++) A[i] = m[i]; }
-    const float sx = 1.0f / (o0 - z0), sy = 1.0f / (o1 - z1);
-    Yv->bias[0] = z0; Yv->bias[1] = z1; Yv->bias[2] = z1;
-    // rgb_from_yuv * mat3(scale.x, 0, 0,  0, scale.y, 0,  0, 0, scale.y)   (glsl.h mat3 * mat3: r[c] = a[0] * b[c].x + a[1] * b[c].y + a[2] * b[c].z)
-    const float B[9] = {sx, 0.0f, 0.0f, 0.0f, sy, 0.0f, 0.0f, 0.0f, sy};
-    for (int c = 0; c < 3; c++)
-      for (int r = 0; r < 3; r++) Yv->mat[3 * c + r] = A[r] * B[3 * c] + A[3 + r] * B[3 * c + 1] + A[6 + r] * B[3 * c + 2];
-    // YUVMatrix::From + ctor (composite.h:652-719): the matrix in 6 (7 for y) fractional bits
-    {
-      const double yc = double(Yv->mat[1]), rvd = double(Yv->mat[6]), gud = double(Yv->mat[4]), gvd = double(Yv->mat[7]), bud = double(Yv->mat[5]);
-      const int rs = Yv->rescale;
-      Yv->brmask = Yv->mat[0] == 0.0f ? 0 : -1;
-      Yv->bu = int(int16_t(bud * double(1 << (6 - rs)) + 0.5)); Yv->rv = int(int16_t(rvd * double(1 << (6 - rs)) + 0.5));
-      Yv->gu = -int(int16_t(-gud * double(1 << (6 - rs)) + 0.5)); Yv->gv = -int(int16_t(-gvd * double(1 << (6 - rs)) + 0.5));
-      Yv->ycoeff = int(uint16_t(yc * double(1 << (6 + 1 - rs)) + 0.5));
-      Yv->ybias = int(int16_t((double(Yv->bias[0] * 255.0f) * yc - 0.5) * double(1 << 6)));
-      Yv->uvbias = int(int16_t(double(Yv->bias[1] * float(255 << rs)) + 0.5));
-    }
+    wr_yuv_setup(*Yv, depth, color_space, format);
     // write_uv_rect per plane (yuv.glsl:167-183)
     const int planes = format == 3 ? 3 : ((format == 0 || format == 1) ? 2 : (format == 4 ? 1 : 0));
     for (int pl = 0; pl < 3; pl++) {
@@ -731,8 +753,8 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.tail_clamp = 1;
     o.tail_modulate = d.shader == WR_SH_BRUSH_YUV_ALPHA ? 1 : 0;      // (here: main() clamps the rgb to [0, 1] -- the ALPHA_PASS key, yuv.glsl:231-235)
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
-    // (planar 8-bit and NV12 on axis-aligned prims; P010 / R16 planes, the interleaved format and rotated video: reported)
-    const bool fmt_ok = (format == 3 || format == 0) && depth == 8 && planes > 0;
+    // (axis-aligned prims; the interleaved format and rotated video: reported)
+    const bool fmt_ok = planes > 0 && wr_yuv_planes_ok(d, format, depth);
     o.kind = (fmt_ok && transform.axis_aligned && vww[0] == 1.0f && vww[1] == 1.0f && vww[2] == 1.0f && vww[3] == 1.0f) ? WR_PK_YUV : WR_PK_UNSUPPORTED;
     return;
   }
@@ -1769,6 +1791,52 @@ WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int in
   }
 }
 
+// composite.glsl:75-128 with WR_FEATURE_YUV (vertex stage): the three uv rects are the planes' texel rects
+WR_DEVICE void wr_vs_composite_yuv(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o, WrYuvRec& Y) {
+  const wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
+  const wf4 aClip = wr_load_attr<wf4>(d, arena, inst, 1);
+  const wf4 aParams = wr_load_attr<wf4>(d, arena, inst, 3);
+  const wf2 aFlip = wr_load_attr<wf2>(d, arena, inst, 4);
+  const wf4 aUvR[3] = {wr_load_attr<wf4>(d, arena, inst, 5), wr_load_attr<wf4>(d, arena, inst, 6), wr_load_attr<wf4>(d, arena, inst, 7)};
+  wf4 dr;
+  dr.x = (aDeviceRect.z - aDeviceRect.x) * aFlip.x + aDeviceRect.x;
+  dr.y = (aDeviceRect.w - aDeviceRect.y) * aFlip.y + aDeviceRect.y;
+  dr.z = (aDeviceRect.x - aDeviceRect.z) * aFlip.x + aDeviceRect.z;
+  dr.w = (aDeviceRect.y - aDeviceRect.w) * aFlip.y + aDeviceRect.w;
+  const int color_space = int(aParams.y), format = int(aParams.z), depth = int(aParams.w);      // fetch_yuv_primitive (ExternalSurfaceDependency::Yuv)
+  wr_yuv_setup(Y, depth, color_space, format);
+  const int planes = format == 3 ? 3 : ((format == 0 || format == 1) ? 2 : (format == 4 ? 1 : 0));
+  float fxv[4], fyv[4];
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    const float wx = (dr.z - dr.x) * ax + dr.x, wy = (dr.w - dr.y) * ay + dr.y;
+    const float cx = wr_clamp(wx, aClip.x, aClip.z), cy = wr_clamp(wy, aClip.y, aClip.w);
+    fxv[n] = (cx - dr.x) / (dr.z - dr.x); fyv[n] = (cy - dr.y) / (dr.w - dr.y);
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{cx, cy, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  for (int pl = 0; pl < 3; pl++) {
+    float* ou = pl == 0 ? o.u : (pl == 1 ? o.u2 : o.u3); float* ov = pl == 0 ? o.v : (pl == 1 ? o.v2 : o.v3);
+    float bnd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pl < planes) {
+      const wf4 res = aUvR[pl];
+      const WrTexDesc& tex = d.tex[WR_S_COLOR0 + pl];
+      const float tsx = float(tex.ptr ? tex.width : 1), tsy = float(tex.ptr ? tex.height : 1);
+      for (int n = 0; n < 4; n++) { ou[n] = ((res.z - res.x) * fxv[n] + res.x) / tsx; ov[n] = ((res.w - res.y) * fyv[n] + res.y) / tsy; }
+      bnd[0] = (res.x + 0.5f) / tsx; bnd[1] = (res.y + 0.5f) / tsy; bnd[2] = (res.z - 0.5f) / tsx; bnd[3] = (res.w - 0.5f) / tsy;
+    } else {
+      for (int n = 0; n < 4; n++) { ou[n] = 0.0f; ov[n] = 0.0f; }
+    }
+    if (pl == 0) o.uv_bounds = wf4{bnd[0], bnd[1], bnd[2], bnd[3]};
+    else for (int k = 0; k < 4; k++) (pl == 1 ? Y.u_bounds : Y.v_bounds)[k] = bnd[k];
+  }
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0;
+  o.tail_clamp = 1; o.tail_modulate = 0;
+  o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.kind = (planes > 0 && wr_yuv_planes_ok(d, format, depth)) ? WR_PK_YUV : WR_PK_UNSUPPORTED;
+}
+
 // ps_clear.glsl:9-25
 WR_DEVICE void wr_vs_ps_clear(const WrDrawDesc& d, const uint8_t* arena, int inst, WrVsOut& o) {
   wf4 aRect = wr_load_attr<wf4>(d, arena, inst, 0);
@@ -2771,6 +2839,26 @@ WR_DEVICE void wr_bilinear(const WrTexDesc& t, int qx, int qy, int (&v)[4]) {   
   for (int c = 0; c < NCH; c++) v[c] = (int16_t)(l[c] + (int16_t)(((int16_t)((r[c] - l[c]) * fracx)) >> 7));
 }
 
+// textureLinearUnpackedR16 / RG16 (texture.h:654-822, the portable path): 15-bit samples, 7-bit fractions in the high byte,
+// a 32-bit multiply-high and a doubling per blend; int16 lanes
+template <int NCH>
+WR_DEVICE void wr_bilinear16(const WrTexDesc& t, int qx, int qy, int (&v)[4]) {
+  const int ix = qx >> 7, iy = qy >> 7;
+  const size_t row0 = (size_t)wr_clamp_coord(ix, t.width - 1) + (size_t)wr_clamp_coord(iy, t.height) * t.stride;
+  const size_t row1 = row0 + ((iy >= 0 && iy < t.height - 1) ? t.stride : 0);
+  const int fracx = ((((ix >= 0) ? qx : 0) | (ix > t.width - 2 ? -1 : 0)) & 0x7F) << 8, fracy = (qy & 0x7F) << 8;
+  auto texel = [&](size_t idx, int c) -> int {
+    if (NCH == 1) return int(((const uint16_t*)t.ptr)[idx]) >> 1;
+    const uint32_t p = ((const uint32_t*)t.ptr)[idx];
+    return int(c == 0 ? (p & 0xFFFFu) : (p >> 16)) >> 1;
+  };
+  auto lerp = [](int a, int b, int f) -> int { return (int)(int16_t)(a + (int)(int16_t)((int)(int16_t)(((int)(int16_t)(b - a) * f) >> 16) << 1)); };
+  for (int c = 0; c < NCH; c++) {
+    const int l = lerp(texel(row0, c), texel(row1, c), fracy), r = lerp(texel(row0 + 1, c), texel(row1 + 1, c), fracy);
+    v[c] = lerp(l, r, fracx);
+  }
+}
+
 template <int NCH>
 WR_DEVICE void wr_linear_span_pixel(const WrTexDesc& t, const float (&q)[4], const float (&qy)[4], float stepx, float stepy,
                                     float minx, float maxx, float miny, float maxy, int filter, int span, int n,
@@ -3409,6 +3497,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_MIX_BLEND_ALPHA: wr_vs_brush(d, arena, inst, 8, o, nullptr, nullptr, nullptr, &aux[gid].mix); break;
     case WR_SH_BRUSH_YUV:
     case WR_SH_BRUSH_YUV_ALPHA: wr_vs_brush(d, arena, inst, 9, o, nullptr, nullptr, nullptr, nullptr, &aux[gid].yuv); break;
+    case WR_SH_COMPOSITE_YUV: wr_vs_composite_yuv(d, arena, inst, o, aux[gid].yuv); break;
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
     case WR_SH_PS_CLEAR: wr_vs_ps_clear(d, arena, inst, o); break;
@@ -5017,7 +5106,14 @@ __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp
       const float minx = wr_max(P2.uv_bounds[0] * W * qs + qo, 0.0f), miny = wr_max(P2.uv_bounds[1] * H * qs + qo, 0.0f);
       const float maxx = wr_max(P2.uv_bounds[2] * W * qs + qo, minx), maxy = wr_max(P2.uv_bounds[3] * H * qs + qo, miny);
       int v4[4];
-      if (t.format == WR_FMT_RG8) {
+      if (t.format == WR_FMT_R16 || t.format == WR_FMT_RG16) {
+        // (blendYUV's stepping, as wr_linear_span_pixel's fallback does it; the samples shifted down to the matrix's 8 + rescale bits)
+        const int c = n >> 2, k = n & 3;
+        const int iqx = int(wr_clamp(wr_accum(q[k], stepx, c), minx, maxx)), iqy = int(wr_clamp(wr_accum(qy[k], stepy, c), miny, maxy));
+        const int bits = (16 - Y.rescale - 1) - 8;
+        if (t.format == WR_FMT_RG16) { wr_bilinear16<2>(t, iqx, iqy, v4); sample[1] = v4[0] >> bits; sample[2] = v4[1] >> bits; }
+        else { wr_bilinear16<1>(t, iqx, iqy, v4); sample[pl] = v4[0] >> bits; }
+      } else if (t.format == WR_FMT_RG8) {
         wr_linear_span_pixel<2>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, 1, r.span, n, v4);
         sample[1] = v4[0]; sample[2] = v4[1];
       } else {
@@ -5028,7 +5124,12 @@ __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp
       tail = true;
       float cu, cv;
       wr_tex_tail_uv(P2, r, n, cu, cv);
-      if (t.format == WR_FMT_RG8) {
+      if (t.format == WR_FMT_R16 || t.format == WR_FMT_RG16) {      // textureLinearR16 / RG16: sample * (1 / 32767)
+        int v4[4] = {0, 0, 0, 0};
+        const int iqx = int(cu * W * 128.0f + (0.5f - 64.0f)), iqy = int(cv * H * 128.0f + (0.5f - 64.0f));
+        if (t.format == WR_FMT_RG16) { wr_bilinear16<2>(t, iqx, iqy, v4); fs[1] = float(v4[0]) * (1.0f / 32767.0f); fs[2] = float(v4[1]) * (1.0f / 32767.0f); }
+        else { wr_bilinear16<1>(t, iqx, iqy, v4); fs[pl] = float(v4[0]) * (1.0f / 32767.0f); }
+      } else if (t.format == WR_FMT_RG8) {
         int v4[4] = {0, 0, 0, 0};
         if (t.linear) wr_bilinear<2>(t, int(cu * W * 128.0f + (0.5f - 64.0f)), int(cv * H * 128.0f + (0.5f - 64.0f)), v4);
         else wr_fetch_texel<2>(t, (size_t)wr_clamp_coord(int(cu * W), t.width) + (size_t)wr_clamp_coord(int(cv * H), t.height) * t.stride, v4);

@@ -80,6 +80,7 @@ enum WrShader {
   WR_SH_PS_SPLIT_COMPOSITE,        // the split polygons of a preserve-3d context (batch.rs:1985-2080)
   WR_SH_BRUSH_YUV,                 // brush_yuv_image TEXTURE_2D,YUV (video frames as planar / semi-planar YUV: batch.rs:2301-2390)
   WR_SH_BRUSH_YUV_ALPHA,           // ... ALPHA_PASS
+  WR_SH_COMPOSITE_YUV,             // composite TEXTURE_2D,YUV (video surfaces composited straight into the window: composite.rs ExternalSurfaceDependency::Yuv)
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };

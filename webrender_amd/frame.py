@@ -86,7 +86,8 @@ class TextureRef:
     target...).  Resolved to a device.Texture by the Renderer."""
 
     def __init__(self, name, w, h, fmt=G.GL_RGBA8, filter_=G.GL_LINEAR,
-                 render_target=False, with_depth=False, pixels=None, upload_format=None):
+                 render_target=False, with_depth=False, pixels=None, upload_format=None, upload_type=None):
+        self.upload_type = upload_type      # GL type of `pixels` (default GL_UNSIGNED_BYTE)
         self.name, self.w, self.h, self.fmt, self.filter = name, w, h, fmt, filter_
         self.render_target, self.with_depth = render_target, with_depth
         self.pixels = pixels  # optional numpy upload (atlases)
@@ -125,7 +126,10 @@ class CompositeTile:
     (composite.rs:1090-1160, renderer/mod.rs:3260-3334)."""
 
     def __init__(self, texture, rect, clip_rect=None, opaque=True, color=None, uv_rect=None,
-                 flip=(0.0, 0.0)):
+                 flip=(0.0, 0.0), yuv=None):
+        """yuv: an external YUV surface (composite.rs ExternalSurfaceDependency::Yuv -> "composite TEXTURE_2D,YUV"):
+        dict(planes=[TextureRef per plane], uv_rects=[texel rect per plane], color_space, format, depth); `texture` = planes[0]"""
+        self.yuv = yuv
         self.texture, self.rect = texture, rect
         self.clip_rect = clip_rect or rect
         self.opaque, self.color = opaque, color
@@ -133,7 +137,7 @@ class CompositeTile:
 
     @property
     def fast(self):
-        return self.color is None and self.uv_rect is None and self.flip == (0.0, 0.0)
+        return self.yuv is None and self.color is None and self.uv_rect is None and self.flip == (0.0, 0.0)
 
 
 class Frame:
@@ -232,11 +236,16 @@ class Frame:
 
     @staticmethod
     def composite_instance(rect, clip_rect, color=(1, 1, 1, 1), uv_rect=(0, 0, 1, 1),
-                           uv_type=0, flip=(0.0, 0.0)):
-        """gpu_types.rs:289-311 CompositeInstance (120 bytes)."""
+                           uv_type=0, flip=(0.0, 0.0), yuv=None):
+        """gpu_types.rs:289-311 CompositeInstance (120 bytes).  yuv: CompositeInstance::new_yuv (:338-365): params = [_, colour
+        space, format, channel bit depth], one texel uv rect per plane."""
         inst = np.zeros(30, dtype=np.float32)
         inst[0:4], inst[4:8], inst[8:12] = rect, clip_rect, color
         inst[12:16] = [0.0, float(uv_type), 0.0, 0.0]
         inst[16:20] = inst[20:24] = inst[24:28] = uv_rect
+        if yuv is not None:
+            inst[12:16] = [0.0, float(yuv["color_space"]), float(yuv["format"]), float(yuv["depth"])]
+            for k in range(3):
+                inst[16 + 4 * k:20 + 4 * k] = yuv["uv_rects"][min(k, len(yuv["uv_rects"]) - 1)]
         inst[28:30] = flip
         return inst

@@ -49,7 +49,7 @@ class Renderer:
             if ref.pixels is not None:
                 fmt = ref.upload_format or (G.GL_RED if ref.fmt == G.GL_R8 else G.GL_BGRA)
                 self.device.upload_texture(tex, 0, 0, ref.w, ref.h, fmt,
-                                           G.GL_UNSIGNED_BYTE, ref.pixels)
+                                           getattr(ref, "upload_type", None) or G.GL_UNSIGNED_BYTE, ref.pixels)
         return tex
 
     def _update_data_texture(self, sampler, store, fmt, upload_fmt, upload_ty, min_rows=1):
@@ -182,19 +182,24 @@ class Renderer:
             def flush():
                 if not batch:
                     return
-                key = "composite FAST_PATH,TEXTURE_2D" if cur[1] else "composite TEXTURE_2D"
+                key = "composite FAST_PATH,TEXTURE_2D" if cur[1] else ("composite TEXTURE_2D,YUV" if cur[2] else "composite TEXTURE_2D")
                 prog = d.create_program(key, "COMPOSITE")
                 vao = d.create_vao("COMPOSITE")
                 d.bind_program(prog, projection)
                 d.bind_texture(0, self.resolve(cur[0]).id)
+                if cur[2]:            # the chroma planes of a YUV surface (sColor1, sColor2)
+                    for slot, ref in enumerate(cur[2][1:], start=1):
+                        d.bind_texture(slot, self.resolve(ref).id)
                 d.draw_instanced_batch(vao, np.stack(batch))
             for t in tiles:
-                k = (t.texture, t.fast)
-                if cur is not None and (k[0] is not cur[0] or k[1] != cur[1]):
+                k = (t.texture, t.fast, tuple(t.yuv["planes"]) if t.yuv else None)
+                if cur is not None and (k[0] is not cur[0] or k[1] != cur[1] or k[2] != cur[2]):
                     flush()
                     batch.clear()
                 cur = k
-                if t.fast:
+                if t.yuv:
+                    batch.append(frame.composite_instance(t.rect, t.clip_rect, flip=t.flip, yuv=t.yuv))
+                elif t.fast:
                     batch.append(frame.composite_instance(t.rect, t.clip_rect))
                 else:
                     uv = t.uv_rect or (0.0, 0.0, float(t.texture.w), float(t.texture.h))

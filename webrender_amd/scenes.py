@@ -2900,7 +2900,9 @@ def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, on
 YUV_FORMAT_NV12, YUV_FORMAT_PLANAR = 0, 3
 
 
-def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=None, nearest=False):
+def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=None, nearest=False, hdr=False):
+    """hdr: 10-bit video -- three R16 planes holding the low 10 bits (YUV_FORMAT_PLANAR, channel bit depth 10: the span shader
+    rescales by 6 bits) and R16 + RG16 planes with the sample in the high bits (YUV_FORMAT_P010)."""
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     A = 1024
@@ -2921,11 +2923,26 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
         x += w
         shelf = max(shelf, h)
     filt = G.GL_NEAREST if nearest else G.GL_LINEAR
-    t_y = TextureRef("yuv_plane_y", A, A, G.GL_R8, filt, pixels=ypl, upload_format=G.GL_RED)
-    t_u = TextureRef("yuv_plane_u", A // 2, A // 2, G.GL_R8, filt, pixels=upl, upload_format=G.GL_RED)
-    t_v = TextureRef("yuv_plane_v", A // 2, A // 2, G.GL_R8, filt, pixels=vpl, upload_format=G.GL_RED)
-    t_uv = TextureRef("yuv_plane_uv", A // 2, A // 2, G.GL_RG8, filt, pixels=np.ascontiguousarray(np.stack([upl, vpl], axis=2)), upload_format=G.GL_RG)
-    frame.static_textures += [t_y, t_u, t_v, t_uv]
+    if hdr:
+        # 10-bit samples: the 8-bit pattern extended by two random low bits
+        ext = lambda p: (p.astype(np.uint16) << 2) | rng.integers(0, 4, size=p.shape).astype(np.uint16)
+        y10, u10, v10 = ext(ypl), ext(upl), ext(vpl)
+        US = G.GL_UNSIGNED_SHORT
+        t_y = TextureRef("yuv10_plane_y", A, A, G.GL_R16, filt, pixels=y10, upload_format=G.GL_RED, upload_type=US)
+        t_u = TextureRef("yuv10_plane_u", A // 2, A // 2, G.GL_R16, filt, pixels=u10, upload_format=G.GL_RED, upload_type=US)
+        t_v = TextureRef("yuv10_plane_v", A // 2, A // 2, G.GL_R16, filt, pixels=v10, upload_format=G.GL_RED, upload_type=US)
+        t_y_msb = TextureRef("p010_plane_y", A, A, G.GL_R16, filt, pixels=(y10 << 6).astype(np.uint16), upload_format=G.GL_RED, upload_type=US)
+        t_uv = TextureRef("p010_plane_uv", A // 2, A // 2, G.GL_RG16, filt, pixels=np.ascontiguousarray(np.stack([u10 << 6, v10 << 6], axis=2).astype(np.uint16)),
+                          upload_format=G.GL_RG, upload_type=US)
+        frame.static_textures += [t_y, t_u, t_v, t_y_msb, t_uv]
+    else:
+        t_y = TextureRef("yuv_plane_y", A, A, G.GL_R8, filt, pixels=ypl, upload_format=G.GL_RED)
+        t_u = TextureRef("yuv_plane_u", A // 2, A // 2, G.GL_R8, filt, pixels=upl, upload_format=G.GL_RED)
+        t_v = TextureRef("yuv_plane_v", A // 2, A // 2, G.GL_R8, filt, pixels=vpl, upload_format=G.GL_RED)
+        t_y_msb = t_y
+        t_uv = TextureRef("yuv_plane_uv", A // 2, A // 2, G.GL_RG8, filt, pixels=np.ascontiguousarray(np.stack([upl, vpl], axis=2)), upload_format=G.GL_RG)
+        frame.static_textures += [t_y, t_u, t_v, t_uv]
+    depth, fmt_semi = (10.0, 1.0) if hdr else (8.0, float(YUV_FORMAT_NV12))      # (YUV_FORMAT_P010 = 1)
     prims = []         # (rect, brush data address, user data, opaque pass, nv12)
     band, gx, k = 200, 4.0, 0
     while True:        # opaque-pass videos on a disjoint grid in the top band (see image_grid)
@@ -2935,7 +2952,7 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
         if gx + w + 4 > width:
             break
         off = 0.37 if k % 5 == 1 else 0.0
-        spec = frame.gpu_cache.push([[8.0, float(k % 7), float(YUV_FORMAT_NV12 if k % 2 else YUV_FORMAT_PLANAR), 0.0]])
+        spec = frame.gpu_cache.push([[depth, float(k % 7), fmt_semi if k % 2 else float(YUV_FORMAT_PLANAR), 0.0]])
         prims.append(((gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), spec, (ry, rc, rc, 0), True, k % 2 == 1))
         gx += float(np.ceil(w)) + 6.0
         k += 1
@@ -2955,7 +2972,7 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
         else:
             w, h = vw * float(rng.uniform(0.3, 1.7)), vh * float(rng.uniform(0.3, 1.7))
             px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - h))
-        spec = frame.gpu_cache.push([[8.0, float((k * 3 + 1) % 7), float(YUV_FORMAT_NV12 if (k // 2) % 2 else YUV_FORMAT_PLANAR), 0.0]])
+        spec = frame.gpu_cache.push([[depth, float((k * 3 + 1) % 7), fmt_semi if (k // 2) % 2 else float(YUV_FORMAT_PLANAR), 0.0]])
         prims.append(((px, py, px + w, py + h), spec, (ry, rc, rc, 0), False, (k // 2) % 2 == 1))
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
@@ -2980,7 +2997,7 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
                 if not order or order[-1][0] != nv12:
                     order.append((nv12, []))
                 order[-1][1].append(inst)
-        tex_of = lambda nv12: {0: t_y, 1: t_uv} if nv12 else {0: t_y, 1: t_u, 2: t_v}
+        tex_of = lambda nv12: {0: t_y_msb, 1: t_uv} if nv12 else {0: t_y, 1: t_u, 2: t_v}
         for nv12 in (False, True):
             op = batches.get((True, nv12))
             if op:
@@ -2994,4 +3011,46 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
         clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
         frame.composite_tiles.append(CompositeTile(tex, rect, clip, opaque=True))
     frame.passes.append(targets)
+    return frame
+
+
+def yuv_composites(width=1024, height=768, seed=311, nearest=False):
+    """Video surfaces composited straight into the window ("composite TEXTURE_2D,YUV": composite.rs ExternalSurfaceDependency::Yuv,
+    renderer/mod.rs:3335-3420): planar and NV12 frames, every colour space, 1:1 / scaled / clipped / flipped, opaque and
+    (premultiplied-alpha blended) on top of a picture-cache tile."""
+    rng = np.random.default_rng(seed)
+    frame = Frame(width, height, (0.2, 0.3, 0.4, 1.0))
+    filt = G.GL_NEAREST if nearest else G.GL_LINEAR
+    vids = []
+    for i in range(4):
+        w, h = 2 * int(rng.integers(60, 140)), 2 * int(rng.integers(40, 100))
+        yy, xx = np.mgrid[0:h, 0:w]
+        ypl = ((xx * 255 // (w - 1)) ^ rng.integers(0, 64, size=(h, w))).astype(np.uint8)
+        upl, vpl = rng.integers(0, 256, size=(h // 2, w // 2), dtype=np.uint8), rng.integers(0, 256, size=(h // 2, w // 2), dtype=np.uint8)
+        t_y = TextureRef(f"video{i}_y", w, h, G.GL_R8, filt, pixels=ypl, upload_format=G.GL_RED)
+        if i % 2 == 0:
+            planes = [t_y, TextureRef(f"video{i}_u", w // 2, h // 2, G.GL_R8, filt, pixels=upl, upload_format=G.GL_RED),
+                      TextureRef(f"video{i}_v", w // 2, h // 2, G.GL_R8, filt, pixels=vpl, upload_format=G.GL_RED)]
+            fmt = YUV_FORMAT_PLANAR
+        else:
+            planes = [t_y, TextureRef(f"video{i}_uv", w // 2, h // 2, G.GL_RG8, filt, pixels=np.ascontiguousarray(np.stack([upl, vpl], axis=2)),
+                                      upload_format=G.GL_RG)]
+            fmt = YUV_FORMAT_NV12
+        frame.static_textures += planes
+        vids.append((w, h, planes, fmt))
+    cases = [   # (video, x, y, scale x, scale y, flip, sub-rect of the frame in luma texels or None)
+        (0, 10.0, 10.0, 1.0, 1.0, (0.0, 0.0), None), (1, 300.25, 14.5, 1.0, 1.0, (0.0, 0.0), None), (2, 560.0, 8.0, 1.6, 1.6, (0.0, 0.0), None),
+        (3, 20.0, 250.0, 0.5, 0.5, (0.0, 0.0), None), (0, 200.0, 260.0, 0.73, 1.31, (0.0, 1.0), None), (1, 520.5, 300.0, 2.2, 0.9, (1.0, 0.0), None),
+        (2, -40.0, 520.0, 1.0, 1.0, (0.0, 0.0), None), (3, 330.0, 520.0, 1.5, 1.5, (0.0, 0.0), (16.0, 8.0, 96.0, 72.0)),
+    ]
+    for k, (vi, x, y, sx, sy, flip, sub) in enumerate(cases):
+        w, h, planes, fmt = vids[vi]
+        sr = sub or (0.0, 0.0, float(w), float(h))
+        dw, dh = (sr[2] - sr[0]) * sx, (sr[3] - sr[1]) * sy
+        rect = (x, y, x + dw, y + dh)
+        clip = (max(x, 0.0) + (7.0 if k % 3 == 2 else 0.0), max(y, 0.0), min(x + dw, float(width)), min(y + dh, float(height)) - (5.0 if k % 3 == 1 else 0.0))
+        uvs = [sr] + [(sr[0] / 2, sr[1] / 2, sr[2] / 2, sr[3] / 2)] * (len(planes) - 1)
+        yuv = dict(planes=planes, uv_rects=uvs, color_space=k % 7, format=fmt, depth=8)
+        frame.composite_tiles.append(CompositeTile(planes[0], rect, clip, opaque=(k % 2 == 0), flip=flip, yuv=yuv))
+    frame.passes.append([])
     return frame
