@@ -315,3 +315,13 @@ YUV = [
     ("yuv_composites", lambda: scenes.yuv_composites()),
     ("yuv_composites_nearest", lambda: scenes.yuv_composites(nearest=True, seed=312)),
 ]
+
+
+# cs_svg_filter / cs_svg_filter_node: every filter kind main() has a case for (and kinds it has none for), two chained colour
+# targets, 1:1 / scaled / fractionally offset inputs; linear and nearest input samplers
+SVG_FILTERS = [
+    ("svg_filters", lambda: scenes.svg_filters()),
+    ("svg_filters_nearest", lambda: scenes.svg_filters(nearest=True, seed=402)),
+    ("svg_filter_nodes", lambda: scenes.svg_filters(node=True, seed=403)),
+    ("svg_filter_nodes_nearest", lambda: scenes.svg_filters(node=True, nearest=True, seed=404)),
+]

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, YUV, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -354,6 +354,19 @@ def test_hostsim_yuv_images_match_oracle(hostsim, oracle_gcc, name, make):
     got, st = render_direct(hostsim, make())
     assert st["gl_error"] == 0 and (want != 255).any()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,make", SVG_FILTERS, ids=[c[0] for c in SVG_FILTERS])
+def test_hostsim_svg_filters_match_oracle(hostsim, oracle_gcc, name, make):
+    """cs_svg_filter / cs_svg_filter_node (parity_cases.SVG_FILTERS): main() of every filter kind restated per pixel in strict fp32
+    (glsl.h's pow approximation, its vector floor, libm powf in the node program's vertex stage).  0 differing bytes in both
+    colour targets against the reference's generated programs; every swatch holds something."""
+    want, _ = render_direct(oracle_gcc, make())
+    got, st = render_direct(hostsim, make())
+    assert st["gl_error"] == 0
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    assert (want["svg_pass_a"] != 0).any(axis=2).sum() > 100000 and (want["svg_pass_b"] != 0).any(axis=2).sum() > 100000
 
 
 def ring_wrap_digests(lib, rounds=4, **env):

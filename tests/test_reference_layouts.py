@@ -70,6 +70,8 @@ _STRUCT_DESC_DTYPE = [
     ("ClearInstance", "CLEAR", None),
     ("MaskInstance", "MASK", None),
     ("CopyInstance", "COPY", "COPY_DTYPE"),
+    ("SvgFilterInstance", "SVG_FILTER", "SVG_FILTER_DTYPE"),
+    ("SVGFEFilterInstance", "SVG_FILTER_NODE", "SVG_NODE_DTYPE"),
 ]
 
 

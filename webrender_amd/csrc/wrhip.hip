@@ -25,6 +25,14 @@
 #include "wrhip_types.h"
 #include "wrhip_rt.h"
 #include "wrhip_kernels.h"
+#ifndef WRHIP_HOSTSIM
+// (the raster kernel instantiations live in wrhip_inst.hip, one translation unit per group, so their device compiles run in
+// parallel: here they are only launched)
+#include "wrhip_inst.h"
+#define WR_INST_DECLARE(K, SIG, ...) extern template __global__ void K<__VA_ARGS__> SIG;
+WR_INST_ALL(WR_INST_DECLARE)
+#undef WR_INST_DECLARE
+#endif
 
 namespace {
 // Helper threads for the large host copies (a frame of 100 k prims stages ~24 MB of data-texture rows and instance arrays; one
@@ -309,7 +317,7 @@ const ShaderInfo SHADERS[] = {
     {"composite FAST_PATH,TEXTURE_2D", WR_SH_COMPOSITE_FAST,
      {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"}, S(WR_S_COLOR0)},
     {"composite TEXTURE_2D,YUV", WR_SH_COMPOSITE_YUV,
-     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aFlip", "aUvRect0", "aUvRect1", "aUvRect2"},
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aUvRect1", "aUvRect2", "aFlip"},
      S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2)},
     {"ps_clear", WR_SH_PS_CLEAR, {"aPosition", "aRect", "aColor"}, 0},
     {"ps_text_run ALPHA_PASS,TEXTURE_2D", WR_SH_PS_TEXT_RUN, {"aPosition", "aData"}, PRIM_SAMPLERS},
@@ -329,6 +337,15 @@ const ShaderInfo SHADERS[] = {
      S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS)},
     {"cs_scale TEXTURE_2D", WR_SH_CS_SCALE, {"aPosition", "aScaleTargetRect", "aScaleSourceRect", "aSourceRectType"},
      S(WR_S_COLOR0)},
+    // (one node of a CSS / SVG filter chain, and of an SVG filter graph: render_target.rs:901-1170; blend off, colour targets)
+    {"cs_svg_filter", WR_SH_CS_SVG_FILTER,
+     {"aPosition", "aFilterRenderTaskAddress", "aFilterInput1TaskAddress", "aFilterInput2TaskAddress", "aFilterKind", "aFilterInputCount",
+      "aFilterGenericInt", "aFilterExtraDataAddress"},
+     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_GPU_CACHE) | S(WR_S_RENDER_TASKS)},
+    {"cs_svg_filter_node", WR_SH_CS_SVG_FILTER_NODE,
+     {"aPosition", "aFilterTargetRect", "aFilterInput1ContentScaleAndOffset", "aFilterInput2ContentScaleAndOffset", "aFilterInput1TaskAddress",
+      "aFilterInput2TaskAddress", "aFilterKind", "aFilterInputCount", "aFilterExtraDataAddress"},
+     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_GPU_CACHE) | S(WR_S_RENDER_TASKS)},
     {"ps_copy", WR_SH_PS_COPY, {"aPosition", "a_src_rect", "a_dst_rect", "a_dst_texture_size"}, S(WR_S_COLOR0)},
     {"cs_border_solid", WR_SH_CS_BORDER_SOLID,
      {"aPosition", "aTaskOrigin", "aRect", "aColor0", "aColor1", "aFlags", "aWidths", "aRadii", "aClipParams1", "aClipParams2"}, 0},
@@ -1784,6 +1801,7 @@ void flush_work(const std::vector<int>& sel_in) {
           case WR_SH_BRUSH_LINEAR_GRADIENT: case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: case WR_SH_CS_LINEAR_GRADIENT: case WR_SH_CS_RADIAL_GRADIENT: case WR_SH_CS_CONIC_GRADIENT: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_BLEND: case WR_SH_BRUSH_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_MIX_BLEND: case WR_SH_BRUSH_MIX_BLEND_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_CS_SVG_FILTER: case WR_SH_CS_SVG_FILTER_NODE: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_BRUSH_YUV: case WR_SH_BRUSH_YUV_ALPHA: case WR_SH_COMPOSITE_YUV: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_PS_QUAD_MASK: case WR_SH_PS_QUAD_MASK_FAST: case WR_SH_PS_QUAD_RADIAL_GRADIENT: case WR_SH_PS_QUAD_CONIC_GRADIENT:
             f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
@@ -2676,7 +2694,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     std::vector<GLuint>& reads = c->work[wi].reads;
     if (std::find(reads.begin(), reads.end(), tid) == reads.end()) reads.push_back(tid);
     unsigned rmask = (1u << WR_S_COLOR0) | (1u << WR_S_COLOR1) | (1u << WR_S_COLOR2) | (1u << WR_S_CLIP_MASK);
-    if (info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA) rmask |= 1u << WR_S_GPU_CACHE;
+    if (info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA || info->kind == WR_SH_CS_SVG_FILTER || info->kind == WR_SH_CS_SVG_FILTER_NODE) rmask |= 1u << WR_S_GPU_CACHE;      // (component-transfer tables, read by main())
     if (info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA) rmask |= 1u << WR_S_GPU_BUFFER_F;
     if ((rmask >> s) & 1) {
       std::vector<GLuint>& rr = c->work[wi].rreads;

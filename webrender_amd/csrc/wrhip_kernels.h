@@ -30,6 +30,13 @@ static unsigned long long wr_dbg_paths[8];
 #else
 #define WR_DBG_PATH(i) ((void)0)
 #endif
+// (kernels that are not templates: defined once, by wrhip.hip; the translation units that only hold raster instantiations,
+// wrhip_inst.hip, see them as unused internal functions)
+#ifdef WR_INST_ONLY
+#define WR_GLOBAL_ONCE static __global__
+#else
+#define WR_GLOBAL_ONCE __global__
+#endif
 struct wf2 { float x, y; };
 struct wf4 { float x, y, z, w; };
 struct wi4 { int x, y, z, w; };
@@ -583,7 +590,8 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 // image: 0 brush_solid, 1 brush_image, 2 brush_image ALPHA_PASS, 3 brush_linear_gradient (G = its side record),
 //        4 brush_blend (F = its side record)
 // image: 0 brush_solid, 1 / 2 brush_image (opaque / ALPHA_PASS), 3 linear gradient, 4 brush_blend,
-//        5 / 6 brush_image with REPETITION (opaque / ALPHA_PASS; Rp = its side record)
+//        5 / 6 brush_image with REPETITION (opaque / ALPHA_PASS; Rp = its side record), 7 brush_opacity, 8 brush_mix_blend (Mx),
+//        9 brush_image DUAL_SOURCE_BLENDING, 10 brush_yuv_image (Yv)
 WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr,
                             WrFilterRec* F = nullptr, WrRepeatRec* Rp = nullptr, WrMixRec* Mx = nullptr, WrYuvRec* Yv = nullptr) {
   const bool repetition = image == 5 || image == 6;
@@ -591,7 +599,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   int prim_header_address = aData.x, clip_address = aData.y;
   int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
   const int resource_address = aData.w & 0xffffff;
-  const int vecs_per_brush = image == 3 ? 2 : ((image && image != 9) ? 3 : 1);   // VECS_PER_SPECIFIC_BRUSH
+  const int vecs_per_brush = image == 3 ? 2 : ((image && image != 10) ? 3 : 1);   // VECS_PER_SPECIFIC_BRUSH (brush_yuv_image: 1)
   // fetch_prim_header
   int u, v;
   wr_fetch_uv(prim_header_address, 2u, u, v);
@@ -724,7 +732,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.persp_div = persp;           // brush_opacity.glsl:68-70, as brush_image
     return;
   }
-  if (image == 9) {
+  if (image == 10) {
     // brush_vs (brush_yuv_image.glsl:40-94) + get_rgb_from_ycbcr_info (yuv.glsl:96-165), strict fp32 in the shader's order
     const int depth = int(color.x), color_space = int(color.y), format = int(color.z);      // fetch_yuv_primitive: the brush's one gpu-cache block
     wr_yuv_setup(*Yv, depth, color_space, format);
@@ -1323,6 +1331,127 @@ WR_DEVICE void wr_vs_cs_scale(const WrDrawDesc& d, const uint8_t* arena, int ins
   o.kind = (target_format == WR_FMT_RGBA8 && tex.format == WR_FMT_RGBA8) ? WR_PK_TEX_RGBA8 : WR_PK_TEX_FS;
 }
 
+// cs_svg_filter.glsl:48-167 and cs_svg_filter_node.glsl:167-395 (vertex stages), strict fp32 in the shaders' order.  No span
+// function: every pixel runs main() (wr_svg_filter_pixel).  vInput1Uv travels in the uv interpolants (unclamped: FILTER_OFFSET
+// adds to it before the clamp), vInput2Uv in o.u2 / o.v2.
+WR_DEVICE wf4 wr_gpu_cache_direct(const WrDrawDesc& d, int u, int v) { return wr_fetch_f(d.tex[WR_S_GPU_CACHE], u, v); }     // fetch_from_gpu_cache_1_direct
+WR_DEVICE float wr_vertex_srgb_to_linear(float c) {      // vertexSrgbToLinear (cs_svg_filter_node.glsl:181-189): libm powf, mix(c1, c2, step(0.04045, c))
+  const float c1 = c * (1.0f / 12.92f);
+  const float c2 = powf(c * (1.0f / 1.055f) + (0.055f / 1.055f), 2.4f);
+  return (c2 - c1) * (c < 0.04045f ? 0.0f : 1.0f) + c1;
+}
+WR_DEVICE void wr_vs_cs_svg_filter(const WrDrawDesc& d, const uint8_t* arena, int inst, bool node, WrVsOut& o, WrSvgRec& S) {
+  wf4 target;                       // the rect the quad covers
+  wf4 so1 = {0.f, 0.f, 0.f, 0.f}, so2 = {0.f, 0.f, 0.f, 0.f};
+  int in1, in2, kind, count, generic = 0;
+  wi4 extra;
+  wf2 user_xy = {0.f, 0.f}; float user_x = 0.0f;
+  if (node) {
+    target = wr_load_attr<wf4>(d, arena, inst, 0);
+    so1 = wr_load_attr<wf4>(d, arena, inst, 1); so2 = wr_load_attr<wf4>(d, arena, inst, 2);
+    in1 = wr_load_attr<int>(d, arena, inst, 3); in2 = wr_load_attr<int>(d, arena, inst, 4);
+    kind = wr_load_attr<int>(d, arena, inst, 5); count = wr_load_attr<int>(d, arena, inst, 6);
+    extra = wr_load_attr<wi4>(d, arena, inst, 7);
+  } else {
+    const int task_address = wr_load_attr<int>(d, arena, inst, 0);
+    in1 = wr_load_attr<int>(d, arena, inst, 1); in2 = wr_load_attr<int>(d, arena, inst, 2);
+    kind = wr_load_attr<int>(d, arena, inst, 3); count = wr_load_attr<int>(d, arena, inst, 4);
+    generic = wr_load_attr<int>(d, arena, inst, 5);
+    extra = wr_load_attr<wi4>(d, arena, inst, 6);
+    const WrTask ft = wr_fetch_task(d, task_address);       // fetch_filter_task: task_rect, user_data.xyz
+    target = wf4{ft.p0.x, ft.p0.y, ft.p1.x, ft.p1.y};
+    user_x = ft.dps; user_xy = ft.origin;                   // user_data.x / .yz (WrTask names them for picture tasks)
+  }
+  S.node = node ? 1 : 0; S.kind = kind; S.input_count = count;
+  const WrTexDesc& t0 = d.tex[WR_S_COLOR0];
+  const WrTexDesc& t1 = d.tex[WR_S_COLOR1];
+  const float ts0x = float(t0.ptr ? t0.width : 1), ts0y = float(t0.ptr ? t0.height : 1);
+  const float ts1x = float(t1.ptr ? t1.width : 1), ts1y = float(t1.ptr ? t1.height : 1);
+  wf2 i1p0 = {0.f, 0.f}, i1p1 = {0.f, 0.f};
+  for (int n = 0; n < 4; n++) { o.u[n] = 0.f; o.v[n] = 0.f; o.u2[n] = 0.f; o.v2[n] = 0.f; }
+  for (int k = 0; k < 4; k++) { S.rect1[k] = 0.f; S.rect2[k] = 0.f; S.fdata0[k] = 0.f; S.fdata1[k] = 0.f; S.funcs[k] = 0; }
+  for (int k = 0; k < 16; k++) S.color_mat[k] = 0.f;
+  S.data[0] = S.data[1] = 0; S.float0 = 0.f;
+  for (int pass = 0; pass < 2; pass++) {
+    if (count <= pass) break;
+    const float tsx = pass ? ts1x : ts0x, tsy = pass ? ts1y : ts0y;
+    int u, v;
+    wr_fetch_uv(pass ? in2 : in1, 2u, u, v);
+    const wf4 tr = wr_fetch_f(d.tex[WR_S_RENDER_TASKS], u, v);       // fetch_render_task_rect
+    if (!pass) { i1p0 = {tr.x, tr.y}; i1p1 = {tr.z, tr.w}; }
+    float* rect = pass ? S.rect2 : S.rect1;
+    rect[0] = (tr.x + 0.5f) / tsx; rect[1] = (tr.y + 0.5f) / tsy; rect[2] = (tr.z - 0.5f) / tsx; rect[3] = (tr.w - 0.5f) / tsy;     // compute_uv_rect
+    const wf4 so = pass ? so2 : so1;
+    for (int n = 0; n < 4; n++) {
+      const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+      float uu, vv;
+      if (node) {                   // compute_uv: (task_rect.p0 + scale_and_offset.zw + scale_and_offset.xy * aPosition.xy) / texture_size
+        uu = ((tr.x + so.z) + so.x * ax) / tsx; vv = ((tr.y + so.w) + so.y * ay) / tsy;
+      } else {                      // compute_uv: mix(p0 / size, floor(p1) / size, aPosition.xy)
+        const float u0 = tr.x / tsx, v0 = tr.y / tsy, u1 = floorf(tr.z) / tsx, v1 = floorf(tr.w) / tsy;
+        uu = (u1 - u0) * ax + u0; vv = (v1 - v0) * ay + v0;
+      }
+      if (pass) { o.u2[n] = uu; o.v2[n] = vv; } else { o.u[n] = uu; o.v[n] = vv; }
+    }
+  }
+  bool known = true;
+  if (!node) {
+    S.funcs[0] = (generic >> 12) & 0xf; S.funcs[1] = (generic >> 8) & 0xf; S.funcs[2] = (generic >> 4) & 0xf; S.funcs[3] = generic & 0xf;
+    switch (kind) {
+      case 0: S.data[0] = generic; break;                                                        // FILTER_BLEND
+      case 1: case 6: { const wf4 c = wr_gpu_cache_direct(d, extra.x, extra.y); S.fdata0[0] = c.x; S.fdata0[1] = c.y; S.fdata0[2] = c.z; S.fdata0[3] = c.w; break; }   // FLOOD, DROP_SHADOW
+      case 4: S.float0 = user_x; break;                                                          // OPACITY
+      case 5: {                                                                                  // COLOR_MATRIX
+        for (int k = 0; k < 4; k++) { const wf4 c = wr_gpu_cache_direct(d, extra.x + k, extra.y); S.color_mat[4 * k] = c.x; S.color_mat[4 * k + 1] = c.y; S.color_mat[4 * k + 2] = c.z; S.color_mat[4 * k + 3] = c.w; }
+        const wf4 c = wr_gpu_cache_direct(d, extra.x + 4, extra.y); S.fdata0[0] = c.x; S.fdata0[1] = c.y; S.fdata0[2] = c.z; S.fdata0[3] = c.w;
+        break;
+      }
+      case 7:                                                                                    // OFFSET
+        S.fdata0[0] = -user_x / ts0x; S.fdata0[1] = -user_xy.x / ts0y;
+        S.fdata1[0] = i1p0.x / ts0x; S.fdata1[1] = i1p0.y / ts0y; S.fdata1[2] = i1p1.x / ts0x; S.fdata1[3] = i1p1.y / ts0y;
+        break;
+      case 8: S.data[0] = extra.x; S.data[1] = extra.y; break;                                   // COMPONENT_TRANSFER
+      case 10:                                                                                   // COMPOSITE
+        S.data[0] = generic;
+        if (generic == 6) { const wf4 c = wr_gpu_cache_direct(d, extra.x, extra.y); S.fdata0[0] = c.x; S.fdata0[1] = c.y; S.fdata0[2] = c.z; S.fdata0[3] = c.w; }
+        break;
+      default: break;               // (no vertex-side data; an unknown kind leaves main() at its start colour)
+    }
+  } else {
+    switch (kind) {
+      case 2: case 3: S.float0 = so2.x; break;                                                   // OPACITY
+      case 38: case 39: {                                                                        // COLOR_MATRIX
+        for (int k = 0; k < 4; k++) { const wf4 c = wr_gpu_cache_direct(d, extra.x + k, extra.y); S.color_mat[4 * k] = c.x; S.color_mat[4 * k + 1] = c.y; S.color_mat[4 * k + 2] = c.z; S.color_mat[4 * k + 3] = c.w; }
+        const wf4 c = wr_gpu_cache_direct(d, extra.x + 4, extra.y); S.fdata0[0] = c.x; S.fdata0[1] = c.y; S.fdata0[2] = c.z; S.fdata0[3] = c.w;
+        break;
+      }
+      case 40: case 41: S.data[0] = extra.x; S.data[1] = extra.y; break;                         // COMPONENT_TRANSFER
+      case 42: case 43: { const wf4 c = wr_gpu_cache_direct(d, extra.x, extra.y); S.fdata0[0] = c.x; S.fdata0[1] = c.y; S.fdata0[2] = c.z; S.fdata0[3] = c.w; break; }   // COMPOSITE_ARITHMETIC
+      case 70: case 71: case 72: case 73: {                                                      // DROP_SHADOW / FLOOD: premultiplied colour, linearised under _CONVERTSRGB
+        wf4 c = kind < 72 ? wr_gpu_cache_direct(d, extra.x, extra.y) : so2;
+        if (kind & 1) { c.x = wr_vertex_srgb_to_linear(c.x); c.y = wr_vertex_srgb_to_linear(c.y); c.z = wr_vertex_srgb_to_linear(c.z); }
+        S.fdata0[0] = c.x * c.w; S.fdata0[1] = c.y * c.w; S.fdata0[2] = c.z * c.w; S.fdata0[3] = c.w;
+        break;
+      }
+      case 80: case 81: case 82: case 83: S.fdata0[0] = so2.x; S.fdata0[1] = so2.y; S.fdata0[2] = so2.z; S.fdata0[3] = so2.w; break;      // MORPHOLOGY (main() has no case for it yet)
+      default: break;               // (every other kind has no vertex-side data; main() falls back to its start colour where it has no case)
+    }
+  }
+  for (int n = 0; n < 4; n++) {
+    const float ax = d.quad[2 * n], ay = d.quad[2 * n + 1];
+    const float x = (target.z - target.x) * ax + target.x, y = (target.w - target.y) * ay + target.y;
+    const wf4 gp = wr_mul(*(const WrMat4*)d.transform, wf4{x, y, 0.0f, 1.0f});
+    o.px[n] = gp.x; o.py[n] = gp.y; o.pz[n] = gp.z; o.pw[n] = gp.w;
+  }
+  o.uv_bounds = wf4{S.rect1[0], S.rect1[1], S.rect1[2], S.rect1[3]};
+  o.tex_slot = WR_S_COLOR0;
+  o.aa_edges = 0; o.has_mask = 0; o.has_color = 0;
+  o.color = wf4{1.f, 1.f, 1.f, 1.f};
+  o.tail_clamp = 0; o.tail_modulate = 0;
+  const bool fmt_ok = (count < 1 || !t0.ptr || t0.format == WR_FMT_RGBA8) && (count < 2 || !t1.ptr || t1.format == WR_FMT_RGBA8);
+  o.kind = (known && fmt_ok) ? WR_PK_SVG_FILTER : WR_PK_UNSUPPORTED;
+}
+
 // ps_copy.glsl:18-26 (vertex stage).  No uTransform: the destination rect maps straight to the target's pixels
 // (pos / (size / 2) - 1 and back through the viewport); no span function: every pixel runs main(), a texelFetch at the
 // truncated texel-space uv.  Carried as WR_PK_TEX_FS on the nearest sampler with uv / texture size: for the 1:1 copies the
@@ -1796,8 +1925,8 @@ WR_DEVICE void wr_vs_composite_yuv(const WrDrawDesc& d, const uint8_t* arena, in
   const wf4 aDeviceRect = wr_load_attr<wf4>(d, arena, inst, 0);
   const wf4 aClip = wr_load_attr<wf4>(d, arena, inst, 1);
   const wf4 aParams = wr_load_attr<wf4>(d, arena, inst, 3);
-  const wf2 aFlip = wr_load_attr<wf2>(d, arena, inst, 4);
-  const wf4 aUvR[3] = {wr_load_attr<wf4>(d, arena, inst, 5), wr_load_attr<wf4>(d, arena, inst, 6), wr_load_attr<wf4>(d, arena, inst, 7)};
+  const wf2 aFlip = wr_load_attr<wf2>(d, arena, inst, 7);
+  const wf4 aUvR[3] = {wr_load_attr<wf4>(d, arena, inst, 4), wr_load_attr<wf4>(d, arena, inst, 5), wr_load_attr<wf4>(d, arena, inst, 6)};
   wf4 dr;
   dr.x = (aDeviceRect.z - aDeviceRect.x) * aFlip.x + aDeviceRect.x;
   dr.y = (aDeviceRect.w - aDeviceRect.y) * aFlip.y + aDeviceRect.y;
@@ -2401,7 +2530,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if (o.kind == WR_PK_SOLID) {
     wr_pack_color(o.color, P.color);
     if (masked) P.tex_slot = WR_S_CLIP_MASK;
-  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_MIX_BLEND || o.kind == WR_PK_YUV || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT || o.kind == WR_PK_FAST_GRADIENT || o.kind == WR_PK_LINE_DECORATION) {
+  } else if (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_BLUR || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_CLIP_RECT || o.kind == WR_PK_BOX_SHADOW || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_MIX_BLEND || o.kind == WR_PK_SVG_FILTER || o.kind == WR_PK_YUV || o.kind == WR_PK_QUAD_MASK || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_BORDER_SOLID || o.kind == WR_PK_BORDER_SEGMENT || o.kind == WR_PK_FAST_GRADIENT || o.kind == WR_PK_LINE_DECORATION) {
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
     if (o.tail_modulate) P.flags |= WR_PF_TAIL_MODULATE;
@@ -2432,6 +2561,14 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     }
     if (o.kind == WR_PK_MIX_BLEND) {
       WrMixRec& M = auxp->mix;
+      const float l2u = (wr_pick4(o.u2, bl) - wr_pick4(o.u2, tl)) * yScale, l2v = (wr_pick4(o.v2, bl) - wr_pick4(o.v2, tl)) * yScale;
+      const float r2u = (wr_pick4(o.u2, br) - wr_pick4(o.u2, tr)) * yScale, r2v = (wr_pick4(o.v2, br) - wr_pick4(o.v2, tr)) * yScale;
+      M.sL0[0] = wr_pick4(o.u2, tl) + dy0 * l2u; M.sL0[1] = wr_pick4(o.v2, tl) + dy0 * l2v;
+      M.sR0[0] = wr_pick4(o.u2, tr) + dy0 * r2u; M.sR0[1] = wr_pick4(o.v2, tr) + dy0 * r2v;
+      M.sLs[0] = l2u; M.sLs[1] = l2v; M.sRs[0] = r2u; M.sRs[1] = r2v;
+    }
+    if (o.kind == WR_PK_SVG_FILTER) {
+      WrSvgRec& M = auxp->svg;
       const float l2u = (wr_pick4(o.u2, bl) - wr_pick4(o.u2, tl)) * yScale, l2v = (wr_pick4(o.v2, bl) - wr_pick4(o.v2, tl)) * yScale;
       const float r2u = (wr_pick4(o.u2, br) - wr_pick4(o.u2, tr)) * yScale, r2v = (wr_pick4(o.v2, br) - wr_pick4(o.v2, tr)) * yScale;
       M.sL0[0] = wr_pick4(o.u2, tl) + dy0 * l2u; M.sL0[1] = wr_pick4(o.v2, tl) + dy0 * l2v;
@@ -3010,7 +3147,7 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   r.su = (Ru - Lu) * stepScale; r.sv = (Rv - Lv) * stepScale;
   const bool flat = runs && runs->n < 0;      // a flattened depth row: chunk by chunk through main(), from the span start
-  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_MIX_BLEND || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span || flat;   // no draw_span for this program/target: all main()
+  const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_MIX_BLEND || P.kind == WR_PK_SVG_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span || flat;   // no draw_span for this program/target: all main()
   const int k = runs ? wr_find_run(runs, x) : -1;
   if (k >= 0) {
     r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
@@ -3496,7 +3633,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_MIX_BLEND:
     case WR_SH_BRUSH_MIX_BLEND_ALPHA: wr_vs_brush(d, arena, inst, 8, o, nullptr, nullptr, nullptr, &aux[gid].mix); break;
     case WR_SH_BRUSH_YUV:
-    case WR_SH_BRUSH_YUV_ALPHA: wr_vs_brush(d, arena, inst, 9, o, nullptr, nullptr, nullptr, nullptr, &aux[gid].yuv); break;
+    case WR_SH_BRUSH_YUV_ALPHA: wr_vs_brush(d, arena, inst, 10, o, nullptr, nullptr, nullptr, nullptr, &aux[gid].yuv); break;
     case WR_SH_COMPOSITE_YUV: wr_vs_composite_yuv(d, arena, inst, o, aux[gid].yuv); break;
     case WR_SH_COMPOSITE: wr_vs_composite(d, arena, inst, false, o); break;
     case WR_SH_COMPOSITE_FAST: wr_vs_composite(d, arena, inst, true, o); break;
@@ -3512,6 +3649,8 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_CS_CLIP_BOX_SHADOW: wr_vs_cs_clip_box_shadow(d, arena, inst, o, aux[gid].box); break;
     case WR_SH_CS_SCALE: wr_vs_cs_scale(d, arena, inst, targets[d.target].format, o); break;
     case WR_SH_PS_COPY: wr_vs_ps_copy(d, arena, inst, o); break;
+    case WR_SH_CS_SVG_FILTER: wr_vs_cs_svg_filter(d, arena, inst, false, o, aux[gid].svg); break;
+    case WR_SH_CS_SVG_FILTER_NODE: wr_vs_cs_svg_filter(d, arena, inst, true, o, aux[gid].svg); break;
     case WR_SH_PS_SPLIT_COMPOSITE: wr_vs_ps_split_composite(d, arena, inst, o); break;
     case WR_SH_CS_BORDER_SOLID: wr_vs_cs_border_solid(d, arena, inst, o, aux[gid].border); break;
     case WR_SH_CS_BORDER_SEGMENT: wr_vs_cs_border_segment(d, arena, inst, o, aux[gid].bseg); break;
@@ -3981,7 +4120,7 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
 #endif
 }
 
-__global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+WR_GLOBAL_ONCE void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
                                 WrRec* __restrict__ recs, WrAux* __restrict__ aux, int n_prims,
                                 const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
@@ -3992,7 +4131,7 @@ __global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restr
 // Scatter queued texture uploads from the staging mirror to their textures.
 // 8 workgroups per segment; 16-byte lanes where the rows allow it.
 // `parts` workgroups per segment (the host sizes it for the largest segment of the batch: one per 64 KB, 8 .. 256)
-__global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs, int parts) {
+WR_GLOBAL_ONCE void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs, int parts) {
   const int si = (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
   if (si >= n_segs) return;
   const WrUploadSeg sg = segs[si];
@@ -4013,7 +4152,7 @@ __global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_seg
 }
 
 // BlitFramebuffer with scaling / flipping / format conversion (composite.h:62-283, 285-418); one thread per dest pixel.
-__global__ void wr_blit_kernel(WrBlitArgs a) {
+WR_GLOBAL_ONCE void wr_blit_kernel(WrBlitArgs a) {
   const int bw = a.bx1 - a.bx0, bh = a.by1 - a.by0;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)bw * bh) return;
@@ -4285,6 +4424,7 @@ __device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRe
 __device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDrawDesc* D, float lu, float lv);
 __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+__device__ __noinline__ WrWide wr_svg_filter_pixel(const WrPrim* Pp, const WrSvgRec* Sp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 WR_DEVICE float wr_r8_texture(const WrTexDesc& t, float u, float v);
 WR_DEVICE WrWide wr_quad_mask_eval(const WrClipRec& C, float f0x, float f0y, float f1x, float f1y, float qx, float qy);
 // One pixel of a textured prim on a general quad and / or with swgl_antiAlias (WR_PK_TEX_QUAD): this row's span and the
@@ -5053,6 +5193,236 @@ __device__ __noinline__ WrWide wr_mix_blend_pixel(const WrPrim* Pp, const WrMixR
   wr_pack_color(wf4{rgb[0], rgb[1], rgb[2], Cs4[3]}, pc);
   WrWide s; s.bg = pc[0]; s.ra = pc[1];
   return s;
+}
+
+// ---------------------------------------------------------------------------
+// cs_svg_filter (cs_svg_filter.glsl:170-592) and cs_svg_filter_node (cs_svg_filter_node.glsl:397-857) fragment shaders, one
+// pixel.  No span shader in swgl: main() on every chunk; per pixel in strict fp32, same operation order (the blend functions are
+// brush_mix_blend's, pow() is glsl.h's approximation, the vector floor its int round trip).
+WR_DEVICE float wr_svg_color_dodge(float Cb, float Cs) { return Cb == 0.0f ? 0.0f : (Cs == 1.0f ? 1.0f : wr_min(1.0f, Cb / (1.0f - Cs))); }
+WR_DEVICE float wr_svg_color_burn(float Cb, float Cs) { return Cb == 1.0f ? 1.0f : (Cs == 0.0f ? 0.0f : 1.0f - wr_min(1.0f, (1.0f - Cb) / Cs)); }
+WR_DEVICE float wr_svg_soft_light(float Cb, float Cs) {
+  if (Cs <= 0.5f) return Cb - (1.0f - 2.0f * Cs) * Cb * (1.0f - Cb);
+  const float Dd = Cb <= 0.25f ? ((16.0f * Cb - 12.0f) * Cb + 4.0f) * Cb : sqrtf(Cb);
+  return Cb + (2.0f * Cs - 1.0f) * (Dd - Cb);
+}
+WR_DEVICE float wr_srgb_to_linear1(float c) { const float c1 = c / 12.92f, c2 = wr_glsl_pow(c / 1.055f + (0.055f / 1.055f), 2.4f); return c <= 0.04045f ? c1 : c2; }
+WR_DEVICE float wr_linear_to_srgb1(float c) { const float c1 = c * 12.92f, c2 = 1.055f * wr_glsl_pow(c, 1.0f / 2.4f) - 0.055f; return c <= 0.0031308f ? c1 : c2; }
+// the sixteen MixBlendModes on un-premultiplied colours: B(Cb, Cs) of the compositing spec; false: no such mode
+WR_DEVICE bool wr_svg_blend_fn(int mode, const float (&Cb)[3], const float (&Cs)[3], float (&res)[3]) {
+  switch (mode) {
+    case 0: for (int i = 0; i < 3; i++) res[i] = Cs[i]; return true;
+    case 1: for (int i = 0; i < 3; i++) res[i] = Cb[i] * Cs[i]; return true;
+    case 2: for (int i = 0; i < 3; i++) res[i] = (Cb[i] + Cs[i]) - (Cb[i] * Cs[i]); return true;
+    case 3: for (int i = 0; i < 3; i++) res[i] = wr_mix_hard_light(Cs[i], Cb[i]); return true;
+    case 4: for (int i = 0; i < 3; i++) res[i] = wr_min(Cs[i], Cb[i]); return true;
+    case 5: for (int i = 0; i < 3; i++) res[i] = wr_max(Cs[i], Cb[i]); return true;
+    case 6: for (int i = 0; i < 3; i++) res[i] = wr_svg_color_dodge(Cb[i], Cs[i]); return true;
+    case 7: for (int i = 0; i < 3; i++) res[i] = wr_svg_color_burn(Cb[i], Cs[i]); return true;
+    case 8: for (int i = 0; i < 3; i++) res[i] = wr_mix_hard_light(Cb[i], Cs[i]); return true;
+    case 9: for (int i = 0; i < 3; i++) res[i] = wr_svg_soft_light(Cb[i], Cs[i]); return true;
+    case 10: for (int i = 0; i < 3; i++) res[i] = fabsf(Cb[i] - Cs[i]); return true;
+    case 11: for (int i = 0; i < 3; i++) res[i] = (Cb[i] + Cs[i]) - ((2.0f * Cb[i]) * Cs[i]); return true;
+    case 12: { float c[3] = {Cs[0], Cs[1], Cs[2]}; wr_mix_set_sat(c, wr_mix_sat(Cb)); wr_mix_set_lum(c, wr_mix_lum(Cb)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; return true; }
+    case 13: { float c[3] = {Cb[0], Cb[1], Cb[2]}; wr_mix_set_sat(c, wr_mix_sat(Cs)); wr_mix_set_lum(c, wr_mix_lum(Cb)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; return true; }
+    case 14: { float c[3] = {Cs[0], Cs[1], Cs[2]}; wr_mix_set_lum(c, wr_mix_lum(Cb)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; return true; }
+    case 15: { float c[3] = {Cb[0], Cb[1], Cb[2]}; wr_mix_set_lum(c, wr_mix_lum(Cs)); res[0] = c[0]; res[1] = c[1]; res[2] = c[2]; return true; }
+    default: return false;
+  }
+}
+// blend(Cs, Cb, mode) of cs_svg_filter.glsl:322-391
+WR_DEVICE void wr_svg_blend(const float (&Cs)[4], const float (&Cb)[4], int mode, float (&out)[4]) {
+  float res[3] = {1.0f, 0.0f, 0.0f};
+  const float cb3[3] = {Cb[0], Cb[1], Cb[2]}, cs3[3] = {Cs[0], Cs[1], Cs[2]};
+  wr_svg_blend_fn(mode, cb3, cs3, res);
+  for (int i = 0; i < 3; i++) {
+    const float rgb = ((1.0f - Cb[3]) * Cs[i]) + (Cb[3] * res[i]);
+    const float x = Cb[i] * Cb[3];
+    out[i] = (rgb - x) * Cs[3] + x;             // mix(vec4(Cb.rgb * Cb.a, Cb.a), vec4(rgb, 1.0), Cs.a)
+  }
+  out[3] = (1.0f - Cb[3]) * Cs[3] + Cb[3];
+}
+__device__ __noinline__ WrWide wr_svg_filter_pixel(const WrPrim* Pp, const WrSvgRec* Sp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
+  const WrPrim& P = *Pp;
+  const WrSvgRec& S = *Sp;
+  const WrTexDesc& t0 = D->tex[WR_S_COLOR0];
+  const WrTexDesc& t1 = D->tex[WR_S_COLOR1];
+  // vInput1Uv / vInput2Uv of this pixel as the 4-wide fragment loop steps them
+  float u1, v1, u2, v2;
+  {
+    const WrTexRow r = wr_tex_row(P, t0, y, runs, x);
+    wr_tex_tail_uv(P, r, x - r.x0, u1, v1);
+  }
+  {
+    WrPrim P2 = P;            // the same walk on the second varying's edges
+    P2.uvL0[0] = S.sL0[0]; P2.uvL0[1] = S.sL0[1]; P2.uvLs[0] = S.sLs[0]; P2.uvLs[1] = S.sLs[1];
+    P2.uvR0[0] = S.sR0[0]; P2.uvR0[1] = S.sR0[1]; P2.uvRs[0] = S.sRs[0]; P2.uvRs[1] = S.sRs[1];
+    P2.rows_linear = 0;
+    const WrTexRow r = wr_tex_row(P2, t1, y, runs, x);
+    wr_tex_tail_uv(P2, r, x - r.x0, u2, v2);
+  }
+  float A[4] = {0.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 0.f, 0.f, 0.f};       // sampleInUvRect of the two inputs
+  if (S.input_count > 0) wr_texture_rgba_f(t0, wr_clamp(u1, S.rect1[0], S.rect1[2]), wr_clamp(v1, S.rect1[1], S.rect1[3]), A);
+  if (S.input_count > 1) wr_texture_rgba_f(t1, wr_clamp(u2, S.rect2[0], S.rect2[2]), wr_clamp(v2, S.rect2[1], S.rect2[3]), B);
+  float res[4] = {1.0f, 0.0f, 0.0f, 1.0f};
+  const WrTexDesc& gc = D->tex[WR_S_GPU_CACHE];
+  if (!S.node) {
+    // cs_svg_filter: un-premultiplied inputs
+    if (S.input_count > 0 && A[3] != 0.0f) for (int i = 0; i < 3; i++) A[i] = A[i] / A[3];
+    if (S.input_count > 1 && B[3] != 0.0f) for (int i = 0; i < 3; i++) B[i] = B[i] / B[3];
+    bool premul = true;
+    switch (S.kind) {
+      case 0: wr_svg_blend(A, B, S.data[0], res); premul = false; break;
+      case 1: for (int i = 0; i < 4; i++) res[i] = S.fdata0[i]; premul = false; break;
+      case 2: for (int i = 0; i < 3; i++) res[i] = wr_linear_to_srgb1(A[i]); res[3] = A[3]; break;
+      case 3: for (int i = 0; i < 3; i++) res[i] = wr_srgb_to_linear1(A[i]); res[3] = A[3]; break;
+      case 4: for (int i = 0; i < 3; i++) res[i] = A[i]; res[3] = A[3] * S.float0; break;
+      case 5: {
+        const float* m = S.color_mat;
+        for (int i = 0; i < 4; i++) res[i] = wr_clamp((m[i] * A[0] + m[4 + i] * A[1] + m[8 + i] * A[2] + m[12 + i] * A[3]) + S.fdata0[i], 0.0f, 1.0f);
+        break;
+      }
+      case 6: {
+        const float shadow[4] = {S.fdata0[0], S.fdata0[1], S.fdata0[2], B[3] * S.fdata0[3]};
+        wr_svg_blend(A, shadow, 0, res); premul = false;
+        break;
+      }
+      case 7: {
+        const float ou = u1 + S.fdata0[0], ov = v1 + S.fdata0[1];
+        wr_texture_rgba_f(t0, wr_clamp(ou, S.rect1[0], S.rect1[2]), wr_clamp(ov, S.rect1[1], S.rect1[3]), res);
+        // point_inside_rect: (step(p0, p) - step(p1, p)).x * .y
+        const float sx = wr_step01(S.fdata1[0], ou) - wr_step01(S.fdata1[2], ou), sy = wr_step01(S.fdata1[1], ov) - wr_step01(S.fdata1[3], ov);
+        const float in = sx * sy;
+        for (int i = 0; i < 4; i++) res[i] = res[i] * in;
+        premul = false;
+        break;
+      }
+      case 8: {             // ComponentTransfer (cs_svg_filter.glsl:415-466)
+        float ch[4] = {A[0], A[1], A[2], A[3]};
+        int offset = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int fn = S.funcs[i];
+          if (fn == 1 || fn == 2) {
+            const int k = int(wr_glsl_floor(ch[i] * 255.0f + 0.5f));
+            const wf4 tx = wr_fetch_f(gc, S.data[0] + (offset + k / 4), S.data[1]);
+            const int sel = k % 4;
+            const float v = sel == 0 ? tx.x : (sel == 1 ? tx.y : (sel == 2 ? tx.z : (sel == 3 ? tx.w : 0.0f)));
+            ch[i] = wr_clamp(v, 0.0f, 1.0f);
+            offset += 64;
+          } else if (fn == 3) {
+            const wf4 tx = wr_fetch_f(gc, S.data[0] + offset, S.data[1]);
+            ch[i] = wr_clamp(tx.x * ch[i] + tx.y, 0.0f, 1.0f);
+            offset += 1;
+          } else if (fn == 4) {
+            const wf4 tx = wr_fetch_f(gc, S.data[0] + offset, S.data[1]);
+            ch[i] = wr_clamp(tx.x * wr_glsl_pow(ch[i], tx.y) + tx.z, 0.0f, 1.0f);
+            offset += 1;
+          }
+        }
+        for (int i = 0; i < 4; i++) res[i] = ch[i];
+        break;
+      }
+      case 9: for (int i = 0; i < 4; i++) res[i] = A[i]; break;
+      case 10: {            // composite(Cs = Ca, Cb, mode) (cs_svg_filter.glsl:470-507)
+        const float* Cs = A; const float* Cb = B;
+        float Cr[4] = {0.0f, 1.0f, 0.0f, 1.0f};
+        switch (S.data[0]) {
+          case 0: for (int i = 0; i < 3; i++) Cr[i] = (Cs[3] * Cs[i]) + ((Cb[3] * Cb[i]) * (1.0f - Cs[3])); Cr[3] = Cs[3] + (Cb[3] * (1.0f - Cs[3])); break;
+          case 1: for (int i = 0; i < 3; i++) Cr[i] = (Cs[3] * Cs[i]) * Cb[3]; Cr[3] = Cs[3] * Cb[3]; break;
+          case 2: for (int i = 0; i < 3; i++) Cr[i] = (Cs[3] * Cs[i]) * (1.0f - Cb[3]); Cr[3] = Cs[3] * (1.0f - Cb[3]); break;
+          case 3: for (int i = 0; i < 3; i++) Cr[i] = ((Cs[3] * Cs[i]) * Cb[3]) + ((Cb[3] * Cb[i]) * (1.0f - Cs[3])); Cr[3] = (Cs[3] * Cb[3]) + (Cb[3] * (1.0f - Cs[3])); break;
+          case 4: for (int i = 0; i < 3; i++) Cr[i] = ((Cs[3] * Cs[i]) * (1.0f - Cb[3])) + ((Cb[3] * Cb[i]) * (1.0f - Cs[3])); Cr[3] = (Cs[3] * (1.0f - Cb[3])) + (Cb[3] * (1.0f - Cs[3])); break;
+          case 5: for (int i = 0; i < 3; i++) Cr[i] = (Cs[3] * Cs[i]) + (Cb[3] * Cb[i]); Cr[3] = Cs[3] + Cb[3]; for (int i = 0; i < 4; i++) Cr[i] = wr_clamp(Cr[i], 0.0f, 1.0f); break;
+          case 6: for (int i = 0; i < 4; i++) Cr[i] = wr_clamp((((S.fdata0[0] * Cs[i]) * Cb[i]) + (S.fdata0[1] * Cs[i])) + (S.fdata0[2] * Cb[i]) + S.fdata0[3], 0.0f, 1.0f); break;
+          default: break;
+        }
+        for (int i = 0; i < 4; i++) res[i] = Cr[i];
+        premul = false;
+        break;
+      }
+      default: break;
+    }
+    if (premul) for (int i = 0; i < 3; i++) res[i] = res[i] * res[3];
+  } else {
+    // cs_svg_filter_node: raw premultiplied colours Rs / Rb (A / B), normalised Ns / Nb; odd kinds work in linear light
+    float* Rs = A; float* Rb = B;
+    float Ns[4] = {0.f, 0.f, 0.f, 0.f}, Nb[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool lin = (S.kind & 1) != 0;
+    if (S.input_count > 0) {
+      const float ia = 1.0f / wr_max(0.000001f, Rs[3]);
+      for (int i = 0; i < 3; i++) Ns[i] = Rs[i] * ia;
+      Ns[3] = Rs[3];
+      if (lin) for (int i = 0; i < 3; i++) { Ns[i] = wr_srgb_to_linear1(Ns[i]); Rs[i] = Ns[i] * Rs[3]; }
+    }
+    if (S.input_count > 1) {
+      const float ia = 1.0f / wr_max(0.000001f, Rb[3]);
+      for (int i = 0; i < 3; i++) Nb[i] = Rb[i] * ia;
+      Nb[3] = Rb[3];
+      if (lin) for (int i = 0; i < 3; i++) { Nb[i] = wr_srgb_to_linear1(Nb[i]); Rb[i] = Nb[i] * Rb[3]; }
+    }
+    const int k2 = S.kind >> 1;
+    bool done = false;
+    if (k2 == 0) { for (int i = 0; i < 4; i++) res[i] = Rs[i]; }                             // IDENTITY
+    else if (k2 == 1) { for (int i = 0; i < 4; i++) res[i] = Rs[i] * S.float0; }             // OPACITY
+    else if (k2 == 2) { res[0] = res[1] = res[2] = 0.0f; res[3] = Rs[3]; done = true; }      // TO_ALPHA: returns before the sRGB step
+    else if (k2 >= 3 && k2 <= 18) {                                                          // FILTER_BLEND_* in the shader's alphabetical order
+      // kind / 2 -> MixBlendMode of wr_svg_blend_fn; -1: the closed forms on premultiplied colours below
+      const int modes[16] = {14, 7, 6, -4, -10, -11, 8, 12, -5, 15, -1, -100, 3, 13, -2, 9};
+      const int mode = modes[k2 - 3];
+      const float ra = (Rb[3] * (1.0f - Rs[3])) + Rs[3];
+      if (mode >= 0) {
+        const float nb3[3] = {Nb[0], Nb[1], Nb[2]}, ns3[3] = {Ns[0], Ns[1], Ns[2]};
+        float r3[3] = {1.0f, 0.0f, 0.0f};
+        wr_svg_blend_fn(mode, nb3, ns3, r3);
+        for (int i = 0; i < 3; i++) res[i] = (((1.0f - Rb[3]) * Rs[i]) + ((1.0f - Rs[3]) * Rb[i])) + ((Rs[3] * Rb[3]) * r3[i]);
+        res[3] = ra;
+      } else if (mode == -4) { for (int i = 0; i < 3; i++) res[i] = (Rs[i] + Rb[i]) - wr_max(Rs[i] * Rb[3], Rb[i] * Rs[3]); res[3] = ra; }                 // DARKEN
+      else if (mode == -10) { for (int i = 0; i < 3; i++) res[i] = (Rs[i] + Rb[i]) - (2.0f * wr_min(Rs[i] * Rb[3], Rb[i] * Rs[3])); res[3] = ra; }         // DIFFERENCE
+      else if (mode == -11) { for (int i = 0; i < 3; i++) res[i] = (Rs[i] + Rb[i]) - (2.0f * (Rs[i] * Rb[i])); res[3] = ra; }                               // EXCLUSION
+      else if (mode == -5) { for (int i = 0; i < 3; i++) res[i] = (Rs[i] + Rb[i]) - wr_min(Rs[i] * Rb[3], Rb[i] * Rs[3]); res[3] = ra; }                  // LIGHTEN
+      else if (mode == -1) { for (int i = 0; i < 3; i++) res[i] = ((Rs[i] * (1.0f - Rb[3])) + (Rb[i] * (1.0f - Rs[3]))) + (Rs[i] * Rb[i]); res[3] = ra; }  // MULTIPLY
+      else if (mode == -100) { for (int i = 0; i < 4; i++) res[i] = (Rb[i] * (1.0f - Rs[3])) + Rs[i]; }                                                    // NORMAL
+      else { for (int i = 0; i < 3; i++) res[i] = (Rs[i] + Rb[i]) - (Rs[i] * Rb[i]); res[3] = ra; }                                                         // SCREEN
+    } else if (k2 == 19) {                                                                   // COLOR_MATRIX
+      const float* m = S.color_mat;
+      for (int i = 0; i < 4; i++) res[i] = wr_clamp((m[i] * Ns[0] + m[4 + i] * Ns[1] + m[8 + i] * Ns[2] + m[12 + i] * Ns[3]) + S.fdata0[i], 0.0f, 1.0f);
+      for (int i = 0; i < 3; i++) res[i] = res[i] * res[3];
+    } else if (k2 == 20) {                                                                   // COMPONENT_TRANSFER: a [256] table of RGBA blocks
+      int k[4];
+      for (int i = 0; i < 4; i++) k[i] = int(wr_glsl_floor(wr_clamp(Ns[i] * 255.0f, 0.0f, 255.0f)));
+      res[0] = wr_fetch_f(gc, S.data[0] + k[0], S.data[1]).x; res[1] = wr_fetch_f(gc, S.data[0] + k[1], S.data[1]).y;
+      res[2] = wr_fetch_f(gc, S.data[0] + k[2], S.data[1]).z; res[3] = wr_fetch_f(gc, S.data[0] + k[3], S.data[1]).w;
+      for (int i = 0; i < 3; i++) res[i] = res[i] * res[3];
+    } else if (k2 == 21) { for (int i = 0; i < 4; i++) res[i] = wr_clamp(((((Rs[i] * Rb[i]) * S.fdata0[0]) + (Rs[i] * S.fdata0[1])) + (Rb[i] * S.fdata0[2])) + S.fdata0[3], 0.0f, 1.0f); }    // ARITHMETIC
+    else if (k2 == 22) { for (int i = 0; i < 4; i++) res[i] = (Rs[i] * Rb[3]) + (Rb[i] * (1.0f - Rs[3])); }                       // ATOP
+    else if (k2 == 23) { for (int i = 0; i < 4; i++) res[i] = Rs[i] * Rb[3]; }                                                   // IN
+    else if (k2 == 24) { for (int i = 0; i < 4; i++) res[i] = wr_clamp(Rs[i] + Rb[i], 0.0f, 1.0f); }                             // LIGHTER
+    else if (k2 == 25) { for (int i = 0; i < 4; i++) res[i] = Rs[i] * (1.0f - Rb[3]); }                                          // OUT
+    else if (k2 == 26) { for (int i = 0; i < 4; i++) res[i] = Rs[i] + (Rb[i] * (1.0f - Rs[3])); }                                // OVER
+    else if (k2 == 27) { for (int i = 0; i < 4; i++) res[i] = (Rs[i] * (1.0f - Rb[3])) + (Rb[i] * (1.0f - Rs[3])); }             // XOR
+    else if (k2 == 35) { for (int i = 0; i < 4; i++) res[i] = Rs[i] + (S.fdata0[i] * (Rb[3] * (1.0f - Rs[3]))); }                // DROP_SHADOW
+    else if (k2 == 36) { for (int i = 0; i < 4; i++) res[i] = S.fdata0[i]; }                                                     // FLOOD
+    else if (k2 == 46) {                                                                     // TILE: rect_repeat(vInput1Uv, rect.xy, rect.zw), returns before the sRGB step
+      // rect_repeat (rect.glsl): p0 + s * fract(is * r), r = p - p0, s = p1 - p0, is = 1 / max(s, 0.000001)
+      const float sx = S.rect1[2] - S.rect1[0], sy = S.rect1[3] - S.rect1[1];
+      const float isx = 1.0f / wr_max(sx, 0.000001f), isy = 1.0f / wr_max(sy, 0.000001f);
+      const float rx = isx * (u1 - S.rect1[0]), ry = isy * (v1 - S.rect1[1]);
+      const float tu = S.rect1[0] + sx * (rx - wr_glsl_floor(rx)), tv = S.rect1[1] + sy * (ry - wr_glsl_floor(ry));
+      wr_texture_rgba_f(t0, wr_clamp(tu, S.rect1[0], S.rect1[2]), wr_clamp(tv, S.rect1[1], S.rect1[3]), res);
+      done = true;
+    }
+    // (every other kind -- convolve, lighting, displacement, gaussian blur, image, morphology, turbulence -- has no case in the
+    // reference's main(): the start colour (1, 0, 0, 1) goes through the sRGB step)
+    if (!done && lin) {
+      const float ia = 1.0f / wr_max(0.000001f, res[3]);
+      for (int i = 0; i < 3; i++) res[i] = wr_linear_to_srgb1(res[i] * ia) * res[3];
+    }
+  }
+  uint32_t pc[2];
+  wr_pack_color(wf4{res[0], res[1], res[2], res[3]}, pc);
+  WrWide w; w.bg = pc[0]; w.ra = pc[1];
+  return w;
 }
 
 // ---------------------------------------------------------------------------
@@ -6275,7 +6645,7 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
 #endif
   }
 }
-__global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
+WR_GLOBAL_ONCE void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                                                            const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
                                                            unsigned long long* __restrict__ ctl,
                                                            const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
@@ -6372,7 +6742,7 @@ WR_DEVICE void wr_select_masked(uint32_t& d, uint32_t v, wr_lanemask m) {
 // The pixel evaluators then look their run up (wr_find_run) and restart there.  Returns the strip's 16 WrRuns, or
 // nullptr when nothing can hide any part of P here (the common case: one scan, no LDS traffic).
 WR_DEVICE bool wr_kind_needs_runs(int kind) {
-  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_MIX_BLEND || kind == WR_PK_YUV || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION ||
+  return kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_R8 || kind == WR_PK_TEX_FS || kind == WR_PK_GRADIENT || kind == WR_PK_FILTER || kind == WR_PK_MIX_BLEND || kind == WR_PK_SVG_FILTER || kind == WR_PK_YUV || kind == WR_PK_QUAD_MASK || kind == WR_PK_BORDER_SOLID || kind == WR_PK_BORDER_SEGMENT || kind == WR_PK_FAST_GRADIENT || kind == WR_PK_LINE_DECORATION ||
          kind == WR_PK_TEX_REPEAT || kind == WR_PK_TEX_QUAD || kind == WR_PK_SOLID_QUAD || kind == WR_PK_SOLID_AA;
 }
 // interval of prim `ci` (a depth writer) on row y
@@ -6966,7 +7336,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
     }
     return;
   }
-  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_FILTER || kind == WR_PK_TEX_REPEAT || kind == WR_PK_MIX_BLEND || kind == WR_PK_YUV)) {
+  if ((FEAT & WR_FEAT_SHADE) && FMT == WR_FMT_RGBA8 && (kind == WR_PK_FILTER || kind == WR_PK_TEX_REPEAT || kind == WR_PK_MIX_BLEND || kind == WR_PK_YUV || kind == WR_PK_SVG_FILTER)) {
     const WrDrawDesc* D = &draws[Pp->draw];
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -6981,6 +7351,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       const WrWide raw = kind == WR_PK_FILTER ? wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2), rq)
                          : kind == WR_PK_MIX_BLEND ? wr_mix_blend_pixel(Pp, &Ap->mix, D, px + (q & 3), py + 4 * (q >> 2), rq)
                          : kind == WR_PK_YUV ? wr_yuv_pixel(Pp, &Ap->yuv, D, px + (q & 3), py + 4 * (q >> 2), rq)
+                         : kind == WR_PK_SVG_FILTER ? wr_svg_filter_pixel(Pp, &Ap->svg, D, px + (q & 3), py + 4 * (q >> 2), rq)
                                                    : wr_repeat_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2), rq);
       const WrWide src = wr_mask_src(*Pp, D, px + (q & 3), py + 4 * (q >> 2), raw);
       const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, D);
@@ -8162,7 +8533,7 @@ wr_setup_raster_dense_kernel(WrSetupArgs S, int n_setup_blocks,
 }
 // The same fusion for a flush whose longest held-back launch is a mask-rows launch (cfg4: the tile passes are 11-17 us, the
 // setup stage of the next frame 30-50 us of dependent latency, the rows launch 50-100 us).
-__global__ void __launch_bounds__(256, 4)
+WR_GLOBAL_ONCE void __launch_bounds__(256, 4)
 wr_setup_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                      const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, unsigned long long* __restrict__ ctl,
                      const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {

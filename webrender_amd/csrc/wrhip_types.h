@@ -81,6 +81,8 @@ enum WrShader {
   WR_SH_BRUSH_YUV,                 // brush_yuv_image TEXTURE_2D,YUV (video frames as planar / semi-planar YUV: batch.rs:2301-2390)
   WR_SH_BRUSH_YUV_ALPHA,           // ... ALPHA_PASS
   WR_SH_COMPOSITE_YUV,             // composite TEXTURE_2D,YUV (video surfaces composited straight into the window: composite.rs ExternalSurfaceDependency::Yuv)
+  WR_SH_CS_SVG_FILTER,             // cs_svg_filter: one node of a CSS / SVG filter chain (render_target.rs:901-990, renderer/mod.rs:2527-2554)
+  WR_SH_CS_SVG_FILTER_NODE,        // cs_svg_filter_node: one node of an SVG filter graph (render_target.rs:1000-1170, renderer/mod.rs:2556-2583)
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
 };
@@ -277,6 +279,8 @@ enum WrPrimKind {
   WR_PK_LINE_DECORATION,// cs_line_decoration: main() only (solid / dashed / dotted / wavy; WrLineRec); vLocalPos in the uv interpolants
   WR_PK_YUV,            // brush_yuv_image: swgl_commitTextureLinearYUV (up to three planes, fixed-point colour matrix; WrYuvRec); the Y plane's
                         // uv travels in WrPrim's uv interpolants, the chroma planes' in WrYuvRec
+  WR_PK_SVG_FILTER,     // cs_svg_filter / cs_svg_filter_node: main() only, up to two inputs; vInput1Uv travels in WrPrim's uv interpolants,
+                        // vInput2Uv and the flat varyings in WrSvgRec
   WR_PK_MASK_ROWS,      // WrRec only: a WR_PK_BOX_SHADOW / WR_PK_CLIP_RECT prim whose rows wr_mask_rows_kernel has evaluated (WrMaskSlot)
 };
 
@@ -439,6 +443,20 @@ struct WrMixRec {
   float s_bounds[4];
 };
 
+// cs_svg_filter (cs_svg_filter.glsl:9-27) and cs_svg_filter_node (cs_svg_filter_node.glsl:45-63): the flat varyings, and the second
+// input's varying as edge interpolants (as WrMixRec holds brush_mix_blend's)
+struct WrSvgRec {
+  int32_t node;                     // 0: cs_svg_filter, 1: cs_svg_filter_node
+  int32_t kind, input_count;        // vFilterKind, vFilterInputCount
+  float sL0[2], sLs[2], sR0[2], sRs[2];     // vInput2Uv
+  float rect1[4], rect2[4];         // vInput1UvRect, vInput2UvRect
+  int32_t data[2];                  // vData.xy
+  float fdata0[4], fdata1[4];       // vFilterData0, vFilterData1
+  float float0;                     // vFloat0.x
+  float color_mat[16];              // vColorMat, column-major
+  int32_t funcs[4];                 // vFuncs
+};
+
 // brush_yuv_image (brush_yuv_image.glsl:9-26): the flat varyings, the chroma planes' varyings as edge interpolants (as WrPrim::uv*
 // hold the luma plane's), and the coefficients of swgl's fixed-point matrix (YUVMatrix, composite.h:640-720)
 struct WrYuvRec {
@@ -538,6 +556,7 @@ union WrAux {
   WrFilterRec filt;
   WrMixRec mix;
   WrYuvRec yuv;
+  WrSvgRec svg;
   WrQuadRec quad;
   WrBorderRec border;
   WrBorderSegRec bseg;

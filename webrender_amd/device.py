@@ -100,6 +100,16 @@ DESC = {
     "CLEAR": VertexDescriptor(_POS, [("aRect", 4, F32), ("aColor", 4, F32)]),
     # vertex.rs:802-826 (CopyInstance, gpu_types.rs:169-175)
     "COPY": VertexDescriptor(_POS, [("a_src_rect", 4, F32), ("a_dst_rect", 4, F32), ("a_dst_texture_size", 2, F32)]),
+    # vertex.rs:532-581 (SvgFilterInstance, gpu_types.rs:148-158)
+    "SVG_FILTER": VertexDescriptor(_POS, [
+        ("aFilterRenderTaskAddress", 1, I32), ("aFilterInput1TaskAddress", 1, I32), ("aFilterInput2TaskAddress", 1, I32),
+        ("aFilterKind", 1, U16), ("aFilterInputCount", 1, U16), ("aFilterGenericInt", 1, U16), ("aUnused", 1, U16),
+        ("aFilterExtraDataAddress", 2, U16)]),
+    # vertex.rs:582-631 (SVGFEFilterInstance, gpu_types.rs:160-170)
+    "SVG_FILTER_NODE": VertexDescriptor(_POS, [
+        ("aFilterTargetRect", 4, F32), ("aFilterInput1ContentScaleAndOffset", 4, F32), ("aFilterInput2ContentScaleAndOffset", 4, F32),
+        ("aFilterInput1TaskAddress", 1, I32), ("aFilterInput2TaskAddress", 1, I32), ("aFilterKind", 1, U16),
+        ("aFilterInputCount", 1, U16), ("aFilterExtraDataAddress", 2, U16)]),
     # vertex.rs:633-650 (MaskInstance, gpu_types.rs:618-624)
     "MASK": VertexDescriptor(_POS, [("aData", 4, I32), ("aClipData", 4, I32)]),
 }

@@ -3054,3 +3054,184 @@ def yuv_composites(width=1024, height=768, seed=311, nearest=False):
         frame.composite_tiles.append(CompositeTile(planes[0], rect, clip, opaque=(k % 2 == 0), flip=flip, yuv=yuv))
     frame.passes.append([])
     return frame
+
+
+# ---------------------------------------------------------------------------
+# cs_svg_filter / cs_svg_filter_node: the nodes of CSS / SVG filter chains and graphs, drawn into colour targets with blending
+# off (renderer/mod.rs:3628-3640).  Instances as render_target.rs:901-1170 builds them; task data as render_task.rs:805-810
+# (user_data = [opacity] / [offset.x, offset.y]) and :843-905 (extra GPU-cache blocks: colour matrix 5, flood / drop-shadow
+# colour 1, arithmetic k 1, component-transfer tables).
+SVG_FILTER_DTYPE = np.dtype([("a", "<i4", (3,)), ("k", "<u2", (4,)), ("e", "<u2", (2,))])                     # SvgFilterInstance, gpu_types.rs:148-158
+SVG_NODE_DTYPE = np.dtype([("t", "<f4", (4,)), ("s1", "<f4", (4,)), ("s2", "<f4", (4,)), ("a", "<i4", (2,)),
+                           ("k", "<u2", (2,)), ("e", "<u2", (2,))])                                            # SVGFEFilterInstance, gpu_types.rs:160-170
+SVGF_BLEND, SVGF_FLOOD, SVGF_LINEAR_TO_SRGB, SVGF_SRGB_TO_LINEAR, SVGF_OPACITY, SVGF_COLOR_MATRIX = 0, 1, 2, 3, 4, 5
+SVGF_DROP_SHADOW, SVGF_OFFSET, SVGF_COMPONENT_TRANSFER, SVGF_IDENTITY, SVGF_COMPOSITE = 6, 7, 8, 9, 10
+SVG_INVALID_ADDRESS = 0xFFFF      # GpuCacheAddress::INVALID (u16::MAX, u16::MAX)
+
+
+def _svg_picture(rng, w, h, k):
+    """A premultiplied RGBA8 picture with the alpha patterns a filter input has: opaque, holes, soft ramps, zero rows"""
+    img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if k % 5 == 0:
+        img[..., 3] = 255
+    elif k % 5 == 1:
+        img[..., 3] = np.where((xx // 5 + yy // 4) % 4 == 0, 0, img[..., 3])
+    elif k % 5 == 2:
+        img[..., 3] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+    elif k % 5 == 3:
+        img[::6, :, 3] = 0
+        img[..., 0] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+    img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)
+    return img
+
+
+def svg_filters(node=False, seed=401, atlas=1024, window=(256, 256), nearest=False, only=None, chained=True):
+    """A colour target full of filter tasks (swatches of 56 x 40), every kind the program has: `node` False = cs_svg_filter (blend
+    x 16 modes + an unknown one, flood, both sRGB conversions, opacity, colour matrix, drop shadow, offset, component transfer
+    with every function type, identity, composite x 7 operators + an unknown one), True = cs_svg_filter_node (every FILTER_*
+    value with a case in main(), both colour spaces, plus kinds main() has no case for).  Inputs are two static premultiplied
+    atlases (as earlier passes' colour targets would be), sampled 1:1, scaled and at fractional offsets; with `chained` a second
+    target runs filters on the first target's output.  frame.readback lists the targets."""
+    rng = np.random.default_rng(seed)
+    frame = Frame(window[0], window[1], (1.0, 1.0, 1.0, 1.0))
+    filt = G.GL_NEAREST if nearest else G.GL_LINEAR
+    p1, p2 = np.zeros((atlas, atlas, 4), np.uint8), np.zeros((atlas, atlas, 4), np.uint8)
+    t_in1 = TextureRef("svg_input_1", atlas, atlas, G.GL_RGBA8, filt, pixels=p1, upload_format=G.GL_BGRA)
+    t_in2 = TextureRef("svg_input_2", atlas, atlas, G.GL_RGBA8, filt, pixels=p2, upload_format=G.GL_BGRA)
+    frame.static_textures += [t_in1, t_in2]
+    sw, sh = 56, 40
+    per_row = (atlas - 8) // (sw + 6)
+
+    def cache_address(addr):
+        return (addr % 1024, addr // 1024)       # GpuCacheAddress { u, v }: MAX_VERTEX_TEXTURE_WIDTH texels per row
+
+    def color_matrix_blocks():
+        m = rng.uniform(-0.5, 1.2, size=(4, 4)).astype(np.float32)
+        off = rng.uniform(-0.2, 0.3, size=4).astype(np.float32)
+        return cache_address(frame.gpu_cache.push([list(r) for r in m] + [list(off)]))
+
+    specs = []
+    if not node:
+        specs += [(SVGF_BLEND, m) for m in list(range(16)) + [23]]
+        specs += [(SVGF_FLOOD, 0)] * 2 + [(SVGF_LINEAR_TO_SRGB, 0)] * 3 + [(SVGF_SRGB_TO_LINEAR, 0)] * 3 + [(SVGF_OPACITY, 0)] * 3
+        specs += [(SVGF_COLOR_MATRIX, 0)] * 3 + [(SVGF_DROP_SHADOW, 0)] * 3 + [(SVGF_OFFSET, 0)] * 5 + [(SVGF_IDENTITY, 0)] * 3
+        specs += [(SVGF_COMPONENT_TRANSFER, j) for j in range(8)]
+        specs += [(SVGF_COMPOSITE, op) for op in list(range(7)) + [9]] + [(SVGF_COMPOSITE, 6)] + [(13, 0)]
+    else:
+        have = [0, 2, 4] + list(range(6, 38, 2)) + [38, 40, 42, 44, 46, 48, 50, 52, 54, 70, 72, 92]
+        for kd in have:
+            specs.append((kd, 0))
+            if kd not in (2, 4):
+                specs.append((kd + 1, 0))
+        specs += [(40, 1), (41, 1), (38, 1), (39, 1), (56, 0), (75, 0), (80, 0), (101, 0), (0, 1), (1, 1), (28, 1), (52, 1)]
+    if only is not None:
+        specs = [specs[i] for i in only]
+
+    def build_pass(name, in1, in2, in1_rects, in2_rects, seed_shift):
+        """one colour target: swatch k reads rect in1_rects[k] of in1 (and in2_rects[k] of in2)"""
+        tex = TextureRef(name, atlas, atlas, G.GL_RGBA8, filt, render_target=True)
+        tgt = Target(tex, "color", clear_color=(0.0, 0.0, 0.0, 0.0))
+        out_rects = []
+        inst = np.zeros(len(specs), SVG_NODE_DTYPE if node else SVG_FILTER_DTYPE)
+        for k, (kind, sub) in enumerate(specs):
+            gx, gy = k % per_row, k // per_row
+            x0, y0 = 5 + gx * (sw + 6), 7 + gy * (sh + 6)
+            trect = (float(x0), float(y0), float(x0 + sw), float(y0 + sh))
+            out_rects.append(trect)
+            r1, r2 = in1_rects[k % len(in1_rects)], in2_rects[k % len(in2_rects)]
+            a1, a2 = frame.add_render_task(r1), frame.add_render_task(r2)
+            extra = (SVG_INVALID_ADDRESS, SVG_INVALID_ADDRESS)
+            if not node:
+                ud = (0.0, 0.0, 0.0)
+                count = 0 if kind == SVGF_FLOOD else (2 if kind in (SVGF_BLEND, SVGF_DROP_SHADOW, SVGF_COMPOSITE) else 1)
+                generic = 0
+                if kind == SVGF_BLEND or kind == SVGF_COMPOSITE:
+                    generic = sub
+                    if kind == SVGF_COMPOSITE and sub == 6:
+                        kv = rng.uniform(-0.5, 1.0, size=4).astype(np.float32)
+                        extra = cache_address(frame.gpu_cache.push([list(kv)]))
+                elif kind in (SVGF_FLOOD, SVGF_DROP_SHADOW):
+                    c = [rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0.3, 1.0)]
+                    extra = cache_address(frame.gpu_cache.push([c]))
+                elif kind == SVGF_OPACITY:
+                    ud = (float(rng.uniform(0.1, 1.0)), 0.0, 0.0)
+                elif kind == SVGF_COLOR_MATRIX:
+                    extra = color_matrix_blocks()
+                elif kind == SVGF_OFFSET:
+                    ud = (float(rng.integers(-12, 13)) + (0.5 if k % 2 else 0.0), float(rng.integers(-9, 10)) + (0.25 if k % 3 == 0 else 0.0), 0.0)
+                elif kind == SVGF_COMPONENT_TRANSFER:
+                    funcs = [int(v) for v in rng.integers(0, 5, size=4)] if sub >= 2 else ([CT_TABLE, CT_DISCRETE, CT_LINEAR, CT_GAMMA] if sub else [CT_GAMMA, CT_IDENTITY, CT_TABLE, CT_LINEAR])
+                    blocks = []
+                    for f in funcs:
+                        if f in (CT_TABLE, CT_DISCRETE):
+                            lut = rng.uniform(-0.1, 1.1, size=256).astype(np.float32)
+                            blocks += [list(lut[4 * j:4 * j + 4]) for j in range(64)]
+                        elif f == CT_LINEAR:
+                            blocks.append([rng.uniform(-1.5, 2.0), rng.uniform(-0.3, 0.5), 0.0, 0.0])
+                        elif f == CT_GAMMA:
+                            blocks.append([rng.uniform(0.5, 1.5), float(rng.choice([0.4, 1.0, 2.2, 3.0])), rng.uniform(-0.1, 0.2), 0.0])
+                    if blocks:
+                        extra = cache_address(frame.gpu_cache.push(blocks))
+                    generic = funcs[0] << 12 | funcs[1] << 8 | funcs[2] << 4 | funcs[3]
+                a_t = frame.add_render_task(trect, ud[0], (ud[1], ud[2]))
+                inst["a"][k] = (a_t, a1 if count > 0 else 0, a2 if count > 1 else 0)
+                inst["k"][k] = (kind, count, generic, 0)
+                inst["e"][k] = extra
+            else:
+                count = 0 if kind in (72, 73) else (2 if (6 <= kind <= 37 or 42 <= kind <= 55 or kind in (70, 71)) else 1)
+                # (compute_uv: (task.p0 + offset + scale * aPosition) / texture size -- 1:1 is scale = the target size, offset = inflate)
+                def scale_offset(r, j):
+                    zoom = (1.0, 1.0, 0.5, 1.25, 1.0)[(k + j) % 5]
+                    off = ((0.0, 0.0), (1.0, 2.0), (0.5, 0.25), (-3.0, 4.0), (6.5, -2.0))[(k + 2 * j + sub) % 5]
+                    return [sw * zoom, sh * zoom, off[0], off[1]]
+                s1, s2 = scale_offset(r1, 0), scale_offset(r2, 1)
+                if kind in (2, 3):
+                    s2 = [float(rng.uniform(0.1, 1.0)), 0.0, 0.0, 0.0]
+                elif kind in (72, 73):
+                    s2 = [rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0.3, 1.0)]
+                elif kind in (80, 81, 82, 83):
+                    s2 = [2.0, 3.0, 0.0, 0.0]
+                elif kind in (38, 39):
+                    extra = color_matrix_blocks()
+                elif kind in (40, 41):
+                    lut = rng.uniform(-0.1, 1.1, size=(256, 4)).astype(np.float32)
+                    if sub:
+                        lut = np.clip(lut, 0.0, 1.0)
+                    # (a table never straddles a data-texture row: gpu_cache.rs allocates whole rows to 256-block requests)
+                    extra = cache_address(frame.gpu_cache.push([list(r) for r in lut]))
+                elif kind in (42, 43):
+                    extra = cache_address(frame.gpu_cache.push([list(rng.uniform(-0.5, 1.0, size=4).astype(np.float32))]))
+                elif kind in (70, 71):
+                    extra = cache_address(frame.gpu_cache.push([[rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0.3, 1.0)]]))
+                inst["t"][k] = trect
+                inst["s1"][k], inst["s2"][k] = s1, s2
+                inst["a"][k] = (a1 if count > 0 else 0x7FFFFFFF, a2 if count > 1 else 0x7FFFFFFF)
+                inst["k"][k] = (kind, count)
+                inst["e"][k] = extra
+        # one batch per (input 1, input 2) texture pair -- here one
+        tgt.steps.append(Step("cs_svg_filter_node" if node else "cs_svg_filter", "SVG_FILTER_NODE" if node else "SVG_FILTER", inst, None, "none",
+                              textures={0: in1, 1: in2}))
+        return tex, tgt, out_rects
+
+    # input pictures: one per swatch slot, some larger / smaller than the swatch (scaled sampling), some at fractional task rects
+    rects1, rects2 = [], []
+    for k in range(len(specs)):
+        gx, gy = k % per_row, k // per_row
+        for j, (pix, rects) in enumerate(((p1, rects1), (p2, rects2))):
+            w, h = ((sw, sh), (sw, sh), (sw + 17, sh + 9), (sw // 2, sh // 2), (sw, sh))[(k + j) % 5]
+            x0, y0 = 3 + gx * (sw + 24), 4 + gy * (sh + 14) + 5 * j
+            if x0 + w + 1 >= atlas or y0 + h + 1 >= atlas:
+                x0, y0 = 3, 4
+            pix[y0:y0 + h, x0:x0 + w] = _svg_picture(rng, w, h, k + 3 * j)
+            frac = 0.5 if (k + j) % 7 == 3 else 0.0
+            rects.append((float(x0), float(y0), float(x0 + w) + frac, float(y0 + h) + frac))
+    t_in1.pixels, t_in2.pixels = p1, p2
+    tex_a, tgt_a, out_a = build_pass("svg_pass_a", t_in1, t_in2, rects1, rects2, 0)
+    frame.passes.append([tgt_a])
+    frame.readback = [tex_a]
+    if chained:
+        tex_b, tgt_b, _ = build_pass("svg_pass_b", tex_a, t_in2, out_a[::-1], rects2[3:] + rects2[:3], 1)
+        frame.passes.append([tgt_b])
+        frame.readback.append(tex_b)
+    return frame
