@@ -413,7 +413,8 @@ def test_unimplemented_perspective_prims_are_reported(hostsim, capfd):
 
 
 def test_undrawable_draws_are_refused_when_recorded(hostsim, capfd):
-    """A draw the backend has no path for -- a shader key without an implementation (cs_svg_filter), an index pattern that is
+    """A draw the backend has no path for -- a shader key without an implementation (debug_color: the renderer's debug overlay,
+    out of scope), an index pattern that is
     not the unit quad's -- raises GL_INVALID_OPERATION in the DrawElementsInstanced call itself (visible to the very next
     GetError, before any Finish), and nothing is recorded for it."""
     from webrender_amd import glapi, glconst as G
@@ -427,7 +428,7 @@ def test_undrawable_draws_are_refused_when_recorded(hostsim, capfd):
     # (the link status already says so -- GetLinkStatus is what Device.create_program checks --; a caller that ignores it and
     # draws anyway is told at the draw)
     vs, fs = gl.CreateShader(G.GL_VERTEX_SHADER), gl.CreateShader(G.GL_FRAGMENT_SHADER)
-    gl.ShaderSourceByName(vs, b"cs_svg_filter"); gl.ShaderSourceByName(fs, b"cs_svg_filter")
+    gl.ShaderSourceByName(vs, b"debug_color"); gl.ShaderSourceByName(fs, b"debug_color")
     pid = gl.CreateProgram()
     gl.AttachShader(pid, vs); gl.AttachShader(pid, fs)
     gl.LinkProgram(pid)
@@ -437,7 +438,7 @@ def test_undrawable_draws_are_refused_when_recorded(hostsim, capfd):
     assert gl.GetError() == 0
     d.draw_instanced_batch(vao, np.zeros((3, 4), np.int32))
     assert gl.GetError() == G.GL_INVALID_OPERATION and gl.GetError() == 0
-    assert "cs_svg_filter" in capfd.readouterr().err
+    assert "debug_color" in capfd.readouterr().err
     # a known program, but not the unit quad
     prog2 = d.create_program("brush_solid", "PRIM_INSTANCES")
     d.bind_program(prog2, np.eye(4, dtype=np.float32))

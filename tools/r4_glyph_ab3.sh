@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out
+L=webrender_amd/csrc/libwrhip.so
+(bash tools/ab.sh text-rendering ab/libwrhip_base.so ab/libwrhip_g1.so $L; bash tools/ab.sh cfg3 ab/libwrhip_base.so ab/libwrhip_g1.so $L) 2>&1 | tee gpurun_out/r04_f_glyph_ab3.txt

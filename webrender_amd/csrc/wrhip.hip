@@ -341,11 +341,11 @@ const ShaderInfo SHADERS[] = {
     {"cs_svg_filter", WR_SH_CS_SVG_FILTER,
      {"aPosition", "aFilterRenderTaskAddress", "aFilterInput1TaskAddress", "aFilterInput2TaskAddress", "aFilterKind", "aFilterInputCount",
       "aFilterGenericInt", "aFilterExtraDataAddress"},
-     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_GPU_CACHE) | S(WR_S_RENDER_TASKS)},
+     PRIM_SAMPLERS | S(WR_S_COLOR1)},
     {"cs_svg_filter_node", WR_SH_CS_SVG_FILTER_NODE,
      {"aPosition", "aFilterTargetRect", "aFilterInput1ContentScaleAndOffset", "aFilterInput2ContentScaleAndOffset", "aFilterInput1TaskAddress",
       "aFilterInput2TaskAddress", "aFilterKind", "aFilterInputCount", "aFilterExtraDataAddress"},
-     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_GPU_CACHE) | S(WR_S_RENDER_TASKS)},
+     PRIM_SAMPLERS | S(WR_S_COLOR1)},
     {"ps_copy", WR_SH_PS_COPY, {"aPosition", "a_src_rect", "a_dst_rect", "a_dst_texture_size"}, S(WR_S_COLOR0)},
     {"cs_border_solid", WR_SH_CS_BORDER_SOLID,
      {"aPosition", "aTaskOrigin", "aRect", "aColor0", "aColor1", "aFlags", "aWidths", "aRadii", "aClipParams1", "aClipParams2"}, 0},
@@ -1592,6 +1592,19 @@ void flush_work(const std::vector<int>& sel_in) {
   }
   const int n_prims = prim_cursor, n_bins = bin_cursor, n_words = word_cursor;
   const int nd = (int)draws.size();
+  if (n_bins > 0) {
+    // the prim arrays of this flush's scratch set, sized here: the address of its glyph records goes into the target descriptors
+    Context::Scratch& S = c->scratch[c->flush_seq & 1];
+    if (S.prims_cap < (size_t)n_prims + 1) {
+      sync_stream();       // (drains the tail: nothing in flight references the buffers being replaced)
+      wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux);
+      S.prims_cap = (size_t)(n_prims + 1) * 2;
+      S.prims = (WrPrim*)wrrt::dev_alloc(S.prims_cap * sizeof(WrPrim));
+      S.recs = (WrRec*)wrrt::dev_alloc(S.prims_cap * (sizeof(WrRec) + sizeof(WrGlyphRec)));      // recs[], then the glyph records (WrTargetDesc::grecs)
+      S.aux = (WrAux*)wrrt::dev_alloc(S.prims_cap * sizeof(WrAux));
+    }
+    for (WrTargetDesc& T : targets) T.grecs = (const WrGlyphRec*)(S.recs + S.prims_cap);
+  }
   // Mask-row store.  When the bounds fit, no reservation of the setup stage can fail and the R8 launches take the light
   // variant (the rows kernel evaluates, the bins blend bytes); otherwise the store is capped, prims that do not fit keep their
   // in-raster evaluation and the launches the variant that has it.
@@ -1674,15 +1687,8 @@ void flush_work(const std::vector<int>& sel_in) {
     algo_bytes += inst_bytes + sizeof(WrDrawDesc) * nd;
     // ---- scratch (two sets: the deferred tail of the previous flush still reads the other one) ----
     Context::Scratch& S = c->scratch[c->flush_seq & 1];
-    if (S.prims_cap < (size_t)n_prims + 1 || S.vtab_cap < vtab_cursor + 1 || S.masks_cap < (size_t)n_words + 1) {
+    if (S.vtab_cap < vtab_cursor + 1 || S.masks_cap < (size_t)n_words + 1) {      // (prims / recs / aux: sized above)
       sync_stream();       // (drains the tail: nothing in flight references the buffers being replaced)
-      if (S.prims_cap < (size_t)n_prims + 1) {
-        wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux);
-        S.prims_cap = (size_t)(n_prims + 1) * 2;
-        S.prims = (WrPrim*)wrrt::dev_alloc(S.prims_cap * sizeof(WrPrim));
-        S.recs = (WrRec*)wrrt::dev_alloc(S.prims_cap * sizeof(WrRec));
-        S.aux = (WrAux*)wrrt::dev_alloc(S.prims_cap * sizeof(WrAux));
-      }
       if (S.vtab_cap < vtab_cursor + 1) {
         wrrt::dev_free(S.vtab);
         S.vtab_cap = (vtab_cursor + 1) * 2;

@@ -30,13 +30,6 @@ static unsigned long long wr_dbg_paths[8];
 #else
 #define WR_DBG_PATH(i) ((void)0)
 #endif
-// (kernels that are not templates: defined once, by wrhip.hip; the translation units that only hold raster instantiations,
-// wrhip_inst.hip, see them as unused internal functions)
-#ifdef WR_INST_ONLY
-#define WR_GLOBAL_ONCE static __global__
-#else
-#define WR_GLOBAL_ONCE __global__
-#endif
 struct wf2 { float x, y; };
 struct wf4 { float x, y, z, w; };
 struct wi4 { int x, y, z, w; };
@@ -3575,6 +3568,39 @@ WR_DEVICE WrTexRec wr_make_texrec(const WrPrim& P, const WrTexDesc& tex) {
   return t;
 }
 
+// The prim's WrGlyphRec (wrhip_types.h): valid when the raster stage's lane-by-lane glyph walk may apply it -- a unit-texel
+// blit with a byte colour under blend NONE / PREMULT, at least four columns wide (the walk loads four columns at once), whose
+// tail columns (the < 4 pixels of a row the span shader leaves to main()) are the columns next to the span's.
+WR_DEVICE void wr_write_glyph_rec(const WrTargetDesc& T, int gid, const WrPrim& P, const WrTexRec& t) {
+  if (!T.grecs) return;
+  WrGlyphRec g;
+  g.x0 = (int16_t)P.x0; g.y0 = (int16_t)P.y0; g.x1 = (int16_t)P.x1; g.y1 = (int16_t)P.y1;
+  g.c0 = P.color[0]; g.c1 = P.color[1];
+  g.stride = t.stride;
+  const int len = P.x1 - P.x0;
+  // (a prim narrower than four columns has no span: every column is a tail column, and the record's ix0 was never set)
+  const int ix0 = t.span > 0 ? t.ix0 : t.tix[0];
+  g.base = (uint64_t)(unsigned long long)t.ptr + (uint64_t)((long long)(t.iy0 - t.y0) * (long long)t.stride + (long long)(ix0 - P.x0));
+  const int tail_x = t.span >= len ? P.x1 : P.x0 + t.span;
+  // (a prim narrower than four columns is read from its first column on: up to three bytes past its last one, which must still lie
+  // inside the texture's memory)
+  const long long th = (long long)(t.wh >> 16), last = (long long)(t.iy0 + (P.y1 - P.y0) - 1) * (long long)t.stride + (long long)ix0 + 3;
+  bool ok = t.simple != 0 && t.unit != 0 && len >= 1 && (len >= 4 || last < th * (long long)t.stride) && (P.blend == WR_BLEND_NONE || P.blend == WR_BLEND_PREMULT) &&
+            P.x0 >= -32768 && P.y0 >= -32768 && P.x1 <= 32767 && P.y1 <= 32767;
+  for (int k = 0; k < 3; k++)
+    if (tail_x + k < P.x1) ok = ok && (k == 0 ? t.tix[0] : (k == 1 ? t.tix[1] : t.tix[2])) == ix0 + (tail_x - P.x0) + k;
+  g.fcolor[0] = t.fcolor[0]; g.fcolor[1] = t.fcolor[1]; g.fcolor[2] = t.fcolor[2]; g.fcolor[3] = t.fcolor[3];
+  g.info = ok ? (1u | ((P.flags & WR_PF_DEPTH_TEST) ? 2u : 0u) | (uint32_t(P.blend & 0xFF) << 8) | (uint32_t(uint16_t(int16_t(tail_x))) << 16)) : 0u;
+  ((WrGlyphRec*)T.grecs)[gid] = g;
+#ifdef WRHIP_HOSTSIM
+  if (getenv("WRHIP_DEBUG_GLYPHS")) {
+    static int n_ok = 0, n_bad = 0, n_nounit = 0, n_narrow = 0;
+    if (ok) n_ok++; else { n_bad++; if (!t.unit || !t.simple) n_nounit++; if (len < 4) n_narrow++; }
+    if (((n_ok + n_bad) & 1023) == 0 || getenv("WRHIP_DEBUG_GLYPHS")[0] == '2') fprintf(stderr, "glyph recs: %d eligible, %d not (%d not unit / simple, %d narrower than 4)\n", n_ok, n_bad, n_nounit, n_narrow);
+  }
+#endif
+}
+
 // Vertex stage of one instance: locate its draw, run the shader's vertex
 // function, then swgl's draw_quad setup.
 #ifdef WRHIP_TIMING
@@ -4064,7 +4090,10 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
         }
       }
     }
-    if (P.kind == WR_PK_TEX_R8) aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
+    if (P.kind == WR_PK_TEX_R8) {
+      aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
+      wr_write_glyph_rec(targets[draws[P.draw].target], gid, P, aux[gid].tex);
+    }
     if (P.kind == WR_PK_SOLID_MASKED) {
       // a masked solid is a unit-texel read of the mask: reuse the glyph path's record
       const WrTexDesc& mt = draws[P.draw].tex[WR_S_CLIP_MASK];
@@ -4075,6 +4104,7 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
       t.simple = ((P.color[0] | P.color[1]) & 0xFF00FF00u) == 0 ? 1 : 0;
       t.unit = 1; t.ix0 = P.x0 - P.mask_off[0]; t.iy0 = P.y0 - P.mask_off[1];
       aux[gid].tex = t;
+      wr_write_glyph_rec(targets[draws[P.draw].target], gid, P, t);
     }
     if (P.kind == WR_PK_TEX_RGBA8) {
       const WrDrawDesc& d = draws[P.draw];
@@ -4120,18 +4150,21 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
 #endif
 }
 
-WR_GLOBAL_ONCE void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone, not by the instantiation units wrhip_inst.hip) */
+__global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
                                 WrRec* __restrict__ recs, WrAux* __restrict__ aux, int n_prims,
                                 const WrTargetDesc* __restrict__ targets, unsigned long long* __restrict__ masks,
                                 float* __restrict__ vtab, WrUnsupportedCounters* cnt, const int* __restrict__ blk) {
   wr_setup_body(draws, n_draws, arena, prims, recs, aux, n_prims, targets, masks, vtab, cnt, blk, (int)blockIdx.x);
 }
+#endif
 
 // Scatter queued texture uploads from the staging mirror to their textures.
 // 8 workgroups per segment; 16-byte lanes where the rows allow it.
 // `parts` workgroups per segment (the host sizes it for the largest segment of the batch: one per 64 KB, 8 .. 256)
-WR_GLOBAL_ONCE void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs, int parts) {
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone, not by the instantiation units wrhip_inst.hip) */
+__global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs, int parts) {
   const int si = (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
   if (si >= n_segs) return;
   const WrUploadSeg sg = segs[si];
@@ -4150,9 +4183,11 @@ WR_GLOBAL_ONCE void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n
     }
   }
 }
+#endif
 
 // BlitFramebuffer with scaling / flipping / format conversion (composite.h:62-283, 285-418); one thread per dest pixel.
-WR_GLOBAL_ONCE void wr_blit_kernel(WrBlitArgs a) {
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone, not by the instantiation units wrhip_inst.hip) */
+__global__ void wr_blit_kernel(WrBlitArgs a) {
   const int bw = a.bx1 - a.bx0, bh = a.by1 - a.by0;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)bw * bh) return;
@@ -4216,6 +4251,7 @@ WR_GLOBAL_ONCE void wr_blit_kernel(WrBlitArgs a) {
     dp[0] = (uint8_t)wr_pack1(uint32_t(wr_sample_linear_r8(t, int(lu), int(lv))) & 0xFFFF);
   }
 }
+#endif
 
 // A solid colour on a general quad, one row at a time: the row's span from the edge instances of its run (aa_span / aa_edge /
 // aa_dist, rasterize.h:480-562) -- the two edge sums are what costs (Edge::nextRow, one add per row: wr_accum), so they are
@@ -6645,12 +6681,14 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
 #endif
   }
 }
-WR_GLOBAL_ONCE void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone, not by the instantiation units wrhip_inst.hip) */
+__global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                                                            const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux,
                                                            unsigned long long* __restrict__ ctl,
                                                            const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
   wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, (int)blockIdx.x, (int)gridDim.x);
 }
+#endif
 
 // min of two 16-bit fields packed in a u32 (v_pk_min_u16)
 WR_DEVICE uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
@@ -7619,60 +7657,82 @@ WR_DEVICE void wr_apply_tex_r8(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], u
 // walks its OWN list -- the prims of the run whose rect reaches its 4 x 4R footprint, in submission order -- and the wave is
 // done after max-over-lanes(list length) rounds instead of one round per prim.  Same arithmetic as wr_apply_tex_r8's unit path;
 // the prim's record and sampling setup are per-lane values here (vector loads from recs[] / aux[]).
-struct WrGlyphLoad { uint4 ra, rb, ta, tb; };      // WrRec (32 B) and the first 32 bytes of its WrTexRec
-WR_DEVICE WrGlyphLoad wr_unit_glyph_fetch(const WrRec* __restrict__ rec, const WrTexRec* __restrict__ Tp) {
-  WrGlyphLoad g;
-  g.ra = ((const uint4*)rec)[0]; g.rb = ((const uint4*)rec)[1];
-  g.ta = ((const uint4*)Tp)[0]; g.tb = ((const uint4*)Tp)[1];
-  return g;
+// (round 4) The lane reads ONE 32-byte WrGlyphRec per glyph (a dense array: neighbouring glyphs share cache lines) instead of the
+// prim's WrRec and the head of its WrTexRec, and the four columns of each of its rows with one unaligned dword load -- R loads
+// issued back to back at addresses that are valid whatever the lane's coverage (column clamped into [x0, max(x0, x1 - 4)], row into
+// [y0, y1)), then branch-free blends under selects -- where it used to issue up to 4R byte loads, each in its own divergent
+// region behind a full wait.  Tail columns (x >= WrGlyphRec::info >> 16: main()'s float path) are redone under one branch.
+WR_DEVICE void wr_glyph_tail_px(uint32_t& lo, uint32_t& hi, uint32_t um, float fr, float fg, float fb, float fa, bool premult) {
+  // main(): texel -> float, modulate, round_pixel (u16 lanes), then blend NONE / PREMULT (src + dst - muldiv255(dst, src.a)) and
+  // pack with swgl's saturation -- wr_pack_color + wr_blend_rgba8 on the (b, r) / (g, a) pairing the pixel registers use
+  const float mf = float(um) * (1.0f / 255.0f);
+  const uint32_t b = uint32_t(wr_round_pixel(fb * mf)) & 0xFFFF, g = uint32_t(wr_round_pixel(fg * mf)) & 0xFFFF;
+  const uint32_t r = uint32_t(wr_round_pixel(fr * mf)) & 0xFFFF, a = uint32_t(wr_round_pixel(fa * mf)) & 0xFFFF;
+  uint32_t slo = b | (r << 16), shi = g | (a << 16);
+  if (premult) {
+    const uint32_t aa = a | (a << 16);
+    slo = wr_sub2(wr_add2(slo, lo), wr_muldiv255_2(lo, aa));
+    shi = wr_sub2(wr_add2(shi, hi), wr_muldiv255_2(hi, aa));
+  }
+  lo = wr_pack1(slo & 0xFFFF) | (wr_pack1(slo >> 16) << 16);
+  hi = wr_pack1(shi & 0xFFFF) | (wr_pack1(shi >> 16) << 16);
 }
 template <int R>
-WR_DEVICE void wr_unit_glyph_lane(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], const WrGlyphLoad& g, const WrTexRec* __restrict__ Tp,
+WR_DEVICE void wr_unit_glyph_lane(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], const uint4 ga, const uint4 gb, const WrGlyphRec* __restrict__ Gp,
                                   const int px, const int py) {
-  const int x0 = (int)g.ra.x, y0 = (int)g.ra.y, x1 = (int)g.ra.z, y1 = (int)g.ra.w;
-  const uint32_t kbf = g.rb.y, c0 = g.rb.z, c1 = g.rb.w;
-  const int blend = (kbf >> 8) & 0xFF;
-  const uint8_t* sbuf = (const uint8_t*)(((unsigned long long)g.ta.y << 32) | g.ta.x);
-  const int stride = (int)g.ta.z, span = (int)g.ta.w, ix0 = (int)g.tb.y, iy0 = (int)g.tb.z, ty0 = (int)g.tb.w;
+  const int x0 = (int)(int16_t)(ga.x & 0xFFFF), y0 = (int)(int16_t)(ga.x >> 16), x1 = (int)(int16_t)(ga.y & 0xFFFF), y1 = (int)(int16_t)(ga.y >> 16);
+  const uint32_t c0 = ga.z, c1 = ga.w;
+  const uint8_t* base = (const uint8_t*)(((unsigned long long)gb.y << 32) | gb.x);
+  const long long stride = (long long)(int)gb.z;
+  const bool premult = ((gb.w >> 8) & 0xFF) == WR_BLEND_PREMULT;
+  const int tail_x = (int)(int16_t)(gb.w >> 16);
   const uint32_t clo = (c0 & 0xFFFF) | (c1 << 16), chi = (c0 >> 16) | (c1 & 0xFFFF0000u);
-  bool cx[4];
-  int colu[4]; bool tl[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
-    const int n = px + i - x0, k = n - span;
-    tl[i] = k >= 0;
-    colu[i] = ix0 + n;
-  }
-  if (px + 3 - x0 >= span) {             // (the <= 3 tail pixels of the row: their columns come from tix[])
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const int k = px + i - x0 - span; if (k >= 0) colu[i] = k == 0 ? Tp->tix[0] : (k == 1 ? Tp->tix[1] : Tp->tix[2]); }
-  }
+  const int cs = wr_iclamp(px, x0, wr_imax(x1 - 4, x0));
+  const int sh8 = 8 * (px - cs);              // pixel i of a covered column: byte (i + px - cs) of the row's dword
+  uint32_t rowv[R];
 #pragma unroll
   for (int j = 0; j < R; j++) {
-    if (!((unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0))) continue;
-    const uint8_t* srow = sbuf + (size_t)(iy0 + (py + 4 * j - ty0)) * stride;
+    const int y = wr_iclamp(py + 4 * j, y0, y1 - 1);
+#ifdef WR_GLYPH_ALIGNED_LOADS
+    const unsigned long long a = (unsigned long long)(base + (long long)y * stride + cs);
+    const uint2 v2 = *(const uint2*)(a & ~3ull);
+    rowv[j] = (uint32_t)(((((unsigned long long)v2.y) << 32) | v2.x) >> (8u * (unsigned)(a & 3ull)));
+#else
+    __builtin_memcpy(&rowv[j], base + (long long)y * stride + cs, 4);
+#endif
+  }
+  bool cx[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cx[i] = (unsigned)(px + i - x0) < (unsigned)(x1 - x0);
+  const uint32_t ksel = premult ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const bool rowin = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int q = 4 * j + i;
-      if (!cx[i]) continue;
-      const uint32_t um = srow[colu[i]];
-      if (!tl[i]) {
-        const uint32_t sl = wr_hi_bytes(wr_mul24(clo, um) + clo), sh = wr_hi_bytes(wr_mul24(chi, um) + chi);
-        uint32_t nl = sl, nh = sh;
-        if (blend == WR_BLEND_PREMULT) {
-          const uint32_t K = 255u - (sh >> 16);
-          nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
-          nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
-        }
-        plo[q] = nl; phi[q] = nh;
-      } else {
-        const float mf = float(um) * (1.0f / 255.0f);
-        uint32_t pc[2];
-        wr_pack_color(wf4{Tp->fcolor[0] * mf, Tp->fcolor[1] * mf, Tp->fcolor[2] * mf, Tp->fcolor[3] * mf}, pc);
-        WrWide src; src.bg = pc[0]; src.ra = pc[1];
-        const uint32_t r = wr_blend_rgba8(blend, plo[q] | (phi[q] << 8), src, nullptr);
-        plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
+      const uint32_t um = (rowv[j] >> ((sh8 + 8 * i) & 31)) & 0xFFu;
+      const uint32_t sl = wr_hi_bytes(wr_mul24(clo, um) + clo), sh = wr_hi_bytes(wr_mul24(chi, um) + chi);
+      const uint32_t K = (255u - (sh >> 16)) & ksel;
+      const uint32_t nl = wr_pk_min_u16(wr_hi_bytes(wr_mul24(plo[q], K) + WR_M8) + sl, WR_M8);
+      const uint32_t nh = wr_pk_min_u16(wr_hi_bytes(wr_mul24(phi[q], K) + WR_M8) + sh, WR_M8);
+      const bool on = rowin && cx[i] && px + i < tail_x;      // (branch-free: skipping a lane's uncovered rows was measured slower)
+      plo[q] = on ? nl : plo[q]; phi[q] = on ? nh : phi[q];
+    }
+  }
+  if (px + 3 >= tail_x && px < x1) {          // (some of this lane's columns are tail columns)
+    // (the colour sits in the record's third 16 bytes -- next to what the lane has just read, not in the prim's 1 KB-strided WrAux)
+    const uint4 gc = ((const uint4*)Gp)[2];
+    const float fr = wr_bits_f(gc.x), fg = wr_bits_f(gc.y), fb = wr_bits_f(gc.z), fa = wr_bits_f(gc.w);
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const bool rowin = (unsigned)(py + 4 * j - y0) < (unsigned)(y1 - y0);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * j + i;
+        if (!(rowin && cx[i] && px + i >= tail_x)) continue;
+        const uint32_t um = (rowv[j] >> ((sh8 + 8 * i) & 31)) & 0xFFu;
+        wr_glyph_tail_px(plo[q], phi[q], um, fr, fg, fb, fa, premult);
       }
     }
   }
@@ -8064,6 +8124,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // ---- apply every prim of this bin, in submission order -----------------
   // (first depth-tested perspective prim of the target: later depth-tested prims look their rows up in T.flat_rows)
   const uint32_t flat_first = (DEPTH && FEAT != 0 && T.flat_rows) ? T.flat_rows[T.height] : 0xFFFFFFFFu;
+  const WrGlyphRec* const grecs = T.grecs;      // (read once: left to the compiler, the glyph walk re-reads the descriptor word per glyph)
   uint32_t zcap = (DEPTH && !(T.load_depth && T.depth)) ? T.init_depth : 0xFFFFFFFFu;
 #ifdef WRHIP_HOSTSIM
   for (int w = 0; w < T.words_per_bin; w++) {
@@ -8119,7 +8180,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
       const uint32_t k8 = rb.y & 0xFF, b8 = (rb.y >> 8) & 0xFF;                                                                                                                                         \
       bool g = hit && (k8 == WR_PK_TEX_R8 || k8 == WR_PK_SOLID_MASKED) && (b8 == WR_BLEND_NONE || b8 == WR_BLEND_PREMULT) &&                                                                            \
                !(DEPTH && ((rb.y >> 16) & WR_PF_DEPTH_TEST));                                                                                                                                           \
-      if (g) { const WrTexRec* tp = &aux[pid].tex; g = tp->simple != 0 && tp->unit != 0; }                                                                                                              \
+      if (g) g = grecs != nullptr && (((const uint32_t*)&grecs[pid])[7] & 1u) != 0u;                                                                                                                      \
       glyphs = __ballot(g);                                                                                                                                                                             \
     }                                                                                                                                                                                                   \
     /* Rect-only launches (FEAT == 0): the survivors' records come back through the scalar cache, one s_load_dwordx8 per prim */                                                                        \
@@ -8157,10 +8218,12 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
     /* (the shuffle runs with every lane active: a lane that has no glyph left may hold the index another one asks for) */                                                                              \
               const int gp = sp ? __shfl(pid, b) : dbase + b;                                                                                                                                           \
               if (act) {                                                                                                                                                                                \
-    /* (requesting a lane's next records ahead of applying its current ones was tried: the 16 extra live VGPRs */                                                                                       \
-    /* spill in this loop, 170 -> 420 us) */                                                                                                                                                            \
-                const WrGlyphLoad g = wr_unit_glyph_fetch(&recs[gp], &aux[gp].tex);                                                                                                                     \
-                wr_unit_glyph_lane<R>(plo, phi, g, &aux[gp].tex, px, py);                                                                                                                               \
+    /* (requesting a lane's next record ahead of applying its current one was tried twice -- with the WrRec + WrTexRec pair the 16 */                                                                   \
+    /* extra live VGPRs spilled, 170 -> 420 us; with the 32-byte glyph record: 110 -> 112 us, cfg3 -- and is not done; nor is */                                                                        \
+    /* handing the records from lane to lane with ds_bpermutes instead of fetching them: 112 -> 118 us) */                                                                                              \
+                const uint4* gr_ = (const uint4*)&grecs[gp];                                                                                                                                            \
+                const uint4 ga_ = gr_[0], gb_ = gr_[1];                                                                                                                                                 \
+                wr_unit_glyph_lane<R>(plo, phi, ga_, gb_, &grecs[gp], px, py);                                                                                                                               \
               }                                                                                                                                                                                         \
             }                                                                                                                                                                                           \
             continue;                                                                                                                                                                                   \
@@ -8488,7 +8551,10 @@ struct WrSetupArgs {
 #ifdef WRHIP_HOSTSIM
 #define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R)
 #else
-#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R, (FEAT) == 0 ? 4 : WR_TEX_WAVES)   /* (depth-tested rect variant: 128 VGPRs as well) */
+#ifndef WR_FUSED_RECT_WAVES
+#define WR_FUSED_RECT_WAVES 4
+#endif
+#define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R, (FEAT) == 0 ? WR_FUSED_RECT_WAVES : WR_TEX_WAVES)   /* (depth-tested rect variant: 128 VGPRs as well) */
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_FUSED_BOUNDS(R, FEAT)
@@ -8509,8 +8575,11 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
 // same 128-VGPR build costs the OTHER users of this variant -- masked solids (cfg4's tile pass 22.5 -> 29 us), perspective images
 // (+10..20 %) -- so it is a second instantiation of the same body that the host picks for levels whose R8-texture prims are
 // glyph runs (Context::Held::dense), not a change of the variant's bounds.
+#ifndef WR_DENSE_WAVES
+#define WR_DENSE_WAVES 4
+#endif
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void __launch_bounds__(1024 / R, 4)
+__global__ void __launch_bounds__(1024 / R, WR_DENSE_WAVES)
 wr_raster_dense_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                        const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                        const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
@@ -8518,7 +8587,7 @@ wr_raster_dense_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
   wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)blockIdx.x + bin_offset);
 }
 template <int FMT, bool DEPTH, int R, int FEAT>
-__global__ void __launch_bounds__(1024 / R, 4)
+__global__ void __launch_bounds__(1024 / R, WR_DENSE_WAVES)
 wr_setup_raster_dense_kernel(WrSetupArgs S, int n_setup_blocks,
                              const WrTargetDesc* __restrict__ targets, int n_targets,
                              const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
@@ -8533,7 +8602,8 @@ wr_setup_raster_dense_kernel(WrSetupArgs S, int n_setup_blocks,
 }
 // The same fusion for a flush whose longest held-back launch is a mask-rows launch (cfg4: the tile passes are 11-17 us, the
 // setup stage of the next frame 30-50 us of dependent latency, the rows launch 50-100 us).
-WR_GLOBAL_ONCE void __launch_bounds__(256, 4)
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone, not by the instantiation units wrhip_inst.hip) */
+__global__ void __launch_bounds__(256, 4)
 wr_setup_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                      const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, unsigned long long* __restrict__ ctl,
                      const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
@@ -8543,3 +8613,4 @@ wr_setup_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __re
   }
   wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, (int)blockIdx.x - n_setup_blocks, (int)gridDim.x - n_setup_blocks);
 }
+#endif

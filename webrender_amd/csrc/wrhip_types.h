@@ -221,6 +221,7 @@ struct WrTargetDesc {
   // stage's early-out).  nullptr: the target cannot hold such a prim (the host saw no general-quad draw with the depth test on).
   uint32_t* flat_rows;
   struct WrUnsupportedCounters* counters;      // where the raster stage reports what it could not draw exactly
+  const struct WrGlyphRec* grecs;              // the flush's glyph records, one per prim (global prim index), see WrGlyphRec
 };
 
 // Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
@@ -325,6 +326,19 @@ struct WrRec {
   uint32_t z;
   uint32_t kbf;          // kind | blend << 8 | flags << 16
   uint32_t c0, c1;       // WrPrim::color
+};
+
+// A unit glyph blit (or a masked solid: one mask texel per pixel) as the lane-by-lane glyph walk of the raster stage reads it: ONE
+// 48-byte record (32 bytes for the pixels of the span, 16 more for a lane that holds tail columns) in a dense array beside recs[] (WrTargetDesc::grecs), instead of the prim's WrRec plus the head of its WrTexRec in
+// the 1 KB-strided aux[] -- two cache lines per (glyph, lane).  texel under target pixel (x, y) = base[y * stride + x]; the lane
+// fetches its four columns of a row with one unaligned dword load at a column clamped into [x0, max(x0, x1 - 4)].
+struct WrGlyphRec {
+  int16_t x0, y0, x1, y1;   // covered rect in target pixels
+  uint32_t c0, c1;          // WrPrim::color
+  uint64_t base;            // address of the atlas / mask texel under target pixel (0, 0)
+  int32_t stride;           // bytes per atlas row
+  uint32_t info;            // 0: the prim is not eligible; else 1 | depth-tested << 1 | blend << 8 | (first tail column, int16) << 16
+  float fcolor[4];          // WrTexRec::fcolor: the float colour main() modulates the tail columns' texels by (read by the lanes that hold any)
 };
 
 // Per-prim sampling setup of an axis-aligned textured prim, prepared by the
