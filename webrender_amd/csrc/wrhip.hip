@@ -407,6 +407,16 @@ struct TargetWork {
   // forwarded composite (set per flush by plan_forwarding): this target's finished pixels are also stored into `fwd_tex`
   GLuint fwd_tex = 0; int fwd_dx = 0, fwd_y0 = 0, fwd_ys = 1, fwd_clip[4] = {0, 0, 0, 0};
   bool forwarded_away = false;     // every draw of this target was turned into write-throughs of its sources: nothing left to rasterise
+  // back to the state of a new object, the vectors keeping their storage: a frame's 72 tiles x (three 1 KB draw packets + 33 KB of
+  // instance bytes) no longer cost an allocation, a growth copy and fresh pages each (cfg5: a third of the recording time)
+  void recycle() {
+    std::vector<WrDrawDesc> d; d.swap(draws); d.clear();
+    std::vector<uint8_t> i; i.swap(inst); i.clear();
+    std::vector<GLuint> r; r.swap(reads); r.clear();
+    std::vector<GLuint> rr; rr.swap(rreads); rr.clear();
+    *this = TargetWork();
+    draws.swap(d); inst.swap(i); reads.swap(r); rreads.swap(rr);
+  }
 };
 
 const size_t MAX_TEXTURE_UNITS = 16;
@@ -450,6 +460,7 @@ struct Context {
   wr_stream_t stream;
   // deferred work
   std::vector<TargetWork> work;       // render targets with pending draws
+  std::vector<TargetWork> spare;      // flushed ones, emptied, their vectors' storage kept for the next frame (TargetWork::recycle)
   std::vector<GLuint> referenced;     // textures with pending_read/pending_write set
   // Host->HBM traffic is batched: texture uploads (TexSubImage2D ...) and the
   // per-flush frame arena are bump-allocated from one pinned staging ring and
@@ -544,7 +555,9 @@ struct Context {
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
-  bool dense_text = true;              // WRHIP_NO_DENSE_TEXT=1: text levels keep the 168-VGPR build of their variant
+  bool dense_text = false;             // WRHIP_DENSE_TEXT=1: text levels run the 128-VGPR build of their variant (wr_raster_dense_kernel: four waves
+                                       // per SIMD; the default until the glyph walk read 32-byte glyph records -- since then the 168-VGPR
+                                       // build, which does not spill, is the faster one: cfg3 97.6 vs 102.3 us, profiles/r04_g_dense_waves_ab.txt)
   int chain_grid = 0;                  // workgroups of a chained R8 launch (0: off -- the default; WRHIP_CHAIN=1 turns it on, WRHIP_CHAIN_GRID overrides)
   unsigned chain_base = 0;             // value of WrUnsupportedCounters::chain_arrive once every chained launch enqueued so far has run
 
@@ -559,7 +572,7 @@ struct Context {
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
-    dense_text = getenv("WRHIP_NO_DENSE_TEXT") == nullptr;
+    dense_text = getenv("WRHIP_DENSE_TEXT") != nullptr;
     // Chained thin R8 levels (wr_raster_chain_kernel) are OFF unless WRHIP_CHAIN=1: measured on cfg4 (profiles/r03_e_chain_ab.txt),
     // the five chained levels take 144 us in one launch against ~100 us + four kernel boundaries apart -- a grid barrier that has
     // to write back and invalidate the XCDs' L2s (the levels run on all eight) costs about what a kernel boundary costs.
@@ -1027,9 +1040,13 @@ int find_or_add_work(GLuint tex_id) {
     if (t.pending_read) flush_all();
     if (t.pending_write && t.pending_target >= 0) return t.pending_target;
   }
-  TargetWork w;
-  w.tex = tex_id;
-  ctx->work.push_back(w);
+  if (!ctx->spare.empty()) {
+    ctx->work.push_back(std::move(ctx->spare.back()));
+    ctx->spare.pop_back();
+  } else {
+    ctx->work.emplace_back();
+  }
+  ctx->work.back().tex = tex_id;
   int idx = (int)ctx->work.size() - 1;
   mark_ref(tex_id, ctx->textures[tex_id], true, idx);
   return idx;
@@ -1865,7 +1882,10 @@ void flush_work(const std::vector<int>& sel_in) {
   for (int i : sel) gone[i] = 1;
   for (int i : forwarded_sel) gone[i] = 1;
   std::vector<TargetWork> rest;
-  for (size_t i = 0; i < c->work.size(); i++) if (!gone[i]) rest.push_back(std::move(c->work[i]));
+  for (size_t i = 0; i < c->work.size(); i++) {
+    if (!gone[i]) rest.push_back(std::move(c->work[i]));
+    else if (c->spare.size() < 256) { c->work[i].recycle(); c->spare.push_back(std::move(c->work[i])); }
+  }
   c->work.swap(rest);
   for (GLuint id : c->referenced)
     if (Texture* t = c->textures.find(id)) { t->pending_read = t->pending_write = false; t->pending_target = -1; }
@@ -2581,6 +2601,51 @@ void BlitFramebuffer(GLint srcX0, GLint srcY0, GLint srcX1, GLint srcY1, GLint d
   blit_textures(srcfb->color_attachment, s, dstfb->color_attachment, d, sr, dr, false, invertY, linear, false, nullptr, true);
 }
 
+// Does any instance of a batch ask for swgl_antiAlias?  The request travels in the third word of every instance (brush: flags =
+// z >> 16, BRUSH_FLAG_FORCE_AA = 1024, gpu_types.rs:690-703; quad: part = (z >> 8) & 0xff in PART_LEFT..PART_BOTTOM, or PART_ALL
+// with edge flags (z >> 16) & 0xff, gpu_types.rs:564-589).  A frame of cfg5 asks this of 65 k instances: eight at a time with
+// AVX2 gathers where the host has them (a quarter of the recording time as a scalar loop with an early exit).
+static inline uint32_t aa_request_bits(int32_t zw, bool quad) {
+  if (!quad) return (uint32_t)(zw >> 16) & 1024u;
+  const uint32_t part = ((uint32_t)zw >> 8) & 0xffu, edges = ((uint32_t)zw >> 16) & 0xffu;
+  return (uint32_t)((part - 1u) < 4u) | (uint32_t)((part == 5u) & (edges != 0u));
+}
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static bool any_aa_request_avx2(const uint8_t* ib, int n, int stride, bool quad) {
+  const __m256i idx = _mm256_mullo_epi32(_mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7), _mm256_set1_epi32(stride));
+  __m256i acc = _mm256_setzero_si256();
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const __m256i z = _mm256_i32gather_epi32((const int*)(ib + (size_t)i * stride + 8), idx, 1);
+    if (quad) {
+      const __m256i part = _mm256_and_si256(_mm256_srli_epi32(z, 8), _mm256_set1_epi32(0xff));
+      const __m256i edges = _mm256_and_si256(z, _mm256_set1_epi32(0xff0000));
+      // part in 1..4: (part - 1) < 4 as signed compare on small non-negative values; part - 1 == -1 for part 0
+      const __m256i pm1 = _mm256_sub_epi32(part, _mm256_set1_epi32(1));
+      const __m256i in14 = _mm256_andnot_si256(_mm256_cmpgt_epi32(_mm256_setzero_si256(), pm1), _mm256_cmpgt_epi32(_mm256_set1_epi32(4), pm1));
+      const __m256i all_e = _mm256_andnot_si256(_mm256_cmpeq_epi32(edges, _mm256_setzero_si256()), _mm256_cmpeq_epi32(part, _mm256_set1_epi32(5)));
+      acc = _mm256_or_si256(acc, _mm256_or_si256(in14, all_e));
+    } else {
+      acc = _mm256_or_si256(acc, _mm256_and_si256(z, _mm256_set1_epi32(1024 << 16)));
+    }
+    if ((i & 1016) == 1016 && !_mm256_testz_si256(acc, acc)) return true;      // (an early exit every 1024 instances)
+  }
+  if (!_mm256_testz_si256(acc, acc)) return true;
+  for (; i < n; i++) { int32_t zw; memcpy(&zw, ib + (size_t)i * stride + 8, 4); if (aa_request_bits(zw, quad)) return true; }
+  return false;
+}
+#endif
+static bool any_aa_request(const uint8_t* ib, int n, int stride, bool quad) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && n >= 16 && stride > 0 && (size_t)stride * 8 < (1u << 30)) return any_aa_request_avx2(ib, n, stride, quad);
+#endif
+  uint32_t bad = 0;
+  for (int i = 0; i < n; i++) { int32_t zw; memcpy(&zw, ib + (size_t)i * stride + 8, 4); bad |= aa_request_bits(zw, quad); if ((i & 255) == 255 && bad) return true; }
+  return bad != 0;
+}
+
 // ---- the hot path: record one instanced batch ------------------------------
 void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr offset, GLsizei instancecount) {
   Context* c = ctx;
@@ -2750,13 +2815,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
       // instance (brush: flags = z >> 16, BRUSH_FLAG_FORCE_AA = 1024, gpu_types.rs:690-703; quad:
       // part = (z >> 8) & 0xff, edge flags = (z >> 16) & 0xff, gpu_types.rs:564-589)
       const uint8_t* ib = (const uint8_t*)instb->buf + d.attr_off[0];
-      for (int i = 0; i < instancecount && simple; i++) {
-        int32_t zw; memcpy(&zw, ib + (size_t)i * inst_stride + 8, 4);
-        if (info->kind == WR_SH_PS_QUAD_TEXTURED) {
-          const int part = (zw >> 8) & 0xff, edges = (zw >> 16) & 0xff;
-          if ((part >= 1 && part <= 4) || (part == 5 && edges != 0)) simple = false;
-        } else if ((zw >> 16) & 1024) simple = false;
-      }
+      if (any_aa_request(ib, instancecount, inst_stride, info->kind == WR_SH_PS_QUAD_TEXTURED)) simple = false;
     }
     if (simple) d.flags |= WR_DF_SIMPLE;
     {
@@ -2785,13 +2844,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
       bool quads = !ids_clean(texquad ? WR_S_GPU_BUFFER_I : WR_S_PRIM_HEADERS_I, !texquad);
       if (!quads && !text && d.blend != WR_BLEND_NONE && d.attr_off[0] >= 0 && d.attr_bytes[0] >= 12 && inst_stride >= 12) {
         const uint8_t* ib = (const uint8_t*)instb->buf + d.attr_off[0];
-        for (int i = 0; i < instancecount && !quads; i++) {
-          int32_t zw; memcpy(&zw, ib + (size_t)i * inst_stride + 8, 4);
-          if (texquad) {
-            const int part = (zw >> 8) & 0xff, edges = (zw >> 16) & 0xff;
-            if ((part >= 1 && part <= 4) || (part == 5 && edges != 0)) quads = true;
-          } else if ((zw >> 16) & 1024) quads = true;
-        }
+        quads = any_aa_request(ib, instancecount, inst_stride, texquad);
       }
       if (quads) d.flags |= WR_DF_QUADS;
     }

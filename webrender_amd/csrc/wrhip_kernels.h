@@ -8575,6 +8575,9 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
 // same 128-VGPR build costs the OTHER users of this variant -- masked solids (cfg4's tile pass 22.5 -> 29 us), perspective images
 // (+10..20 %) -- so it is a second instantiation of the same body that the host picks for levels whose R8-texture prims are
 // glyph runs (Context::Held::dense), not a change of the variant's bounds.
+// Round 4: with the glyph records (WrGlyphRec) the walk issues a fraction of the loads it used to and the 168-VGPR build, free of
+// spills, is the faster one again (97.6 vs 102.3 us, profiles/r04_g_dense_waves_ab.txt): the dense instantiation is now opt-in
+// (WRHIP_DENSE_TEXT=1) and stays built for that A/B.
 #ifndef WR_DENSE_WAVES
 #define WR_DENSE_WAVES 4
 #endif

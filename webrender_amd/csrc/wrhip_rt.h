@@ -37,8 +37,12 @@ static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if 
 static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp, unsigned long long v) { unsigned long long o = *p; if (o == cmp) *p = v; return o; }
 typedef int wr_stream_t;
 typedef struct { double t; } wr_event_t;
+// (WRHIP_HOSTSIM_NOEXEC=1: launches are skipped -- the host side of a frame (recording, staging, flush) can then be timed in the
+// GPU-less container at the full sizes of the bench workloads: tools/host_profile.py)
+static inline bool wr_hostsim_noexec() { static const bool v = getenv("WRHIP_HOSTSIM_NOEXEC") != nullptr; return v; }
 #define WR_LAUNCH(kernel, grid, block, stream, ...)                     \
   do {                                                                  \
+    if (wr_hostsim_noexec()) break;                                     \
     gridDim = wr_dim3{(unsigned)(grid), 1, 1};                          \
     blockDim = wr_dim3{(unsigned)(block), 1, 1};                        \
     for (unsigned _b = 0; _b < (unsigned)(grid); _b++)                  \
