@@ -45,6 +45,20 @@ def main():
     out["many-box-shadows"] = [{"box-bounds": nums(it["box-bounds"]), "clip-rect": nums(it["clip-rect"]), "offset": nums(it["offset"]),
                                 "color": nums(it["color"]), "blur-radius": float(it["blur-radius"]), "spread-radius": float(it["spread-radius"]),
                                 "clip-mode": it["clip-mode"]} for it in sc["items"] if it["type"] == "box-shadow"]
+    # large-boxshadow-ellipse.yaml: one outset box shadow with elliptical corner radii (wrench yaml_frame_reader.rs handle_box_shadow:
+    # `bounds` is the box, border-radius {corner: [width, height]})
+    it = yaml.safe_load(open(os.path.join(REF, "large-boxshadow-ellipse.yaml")))["root"]["items"][0]
+    assert it["type"] == "box-shadow" and it["clip-mode"] == "outset"
+    out["large-boxshadow-ellipse"] = {"bounds": nums(it["bounds"]), "color": it["color"], "blur-radius": float(it["blur-radius"]),
+                                      "border-radius": {k: nums(v) for k, v in it["border-radius"].items()}}
+    # large-clip-rect.yaml: N identical opaque rects under one rounded-rectangle clip
+    clip = yaml.safe_load(open(os.path.join(REF, "large-clip-rect.yaml")))["root"]["items"][0]
+    assert clip["type"] == "clip" and len(clip["complex"]) == 1
+    rects = [nums(r["bounds"]) for r in clip["items"]]
+    assert all(r["type"] == "rect" and r["color"] == clip["items"][0]["color"] for r in clip["items"]) and all(r == rects[0] for r in rects)
+    out["large-clip-rect"] = {"clip-bounds": nums(clip["bounds"]), "complex-rect": nums(clip["complex"][0]["rect"]),
+                              "radius": float(clip["complex"][0]["radius"]), "rect-bounds": rects[0], "count": len(rects),
+                              "color": clip["items"][0]["color"]}
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.path.normpath(OUT), {k: (len(v) if isinstance(v, list) else v.get("count")) for k, v in out.items() if k != "source"})

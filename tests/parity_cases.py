@@ -300,6 +300,8 @@ WRENCH = [
     ("wrench_text_rendering", "text-rendering", dict(width=2048, height=1024), dict()),
     ("wrench_many_box_shadows", "many-box-shadows", dict(width=2048, height=1536), dict()),
     ("wrench_simple_batching_4k", "simple-batching", None, dict()),
+    ("wrench_large_boxshadow_ellipse", "large-boxshadow-ellipse", dict(width=1536, height=1536), dict()),
+    ("wrench_large_clip_rect", "large-clip-rect", dict(width=1536, height=1536), dict()),
 ]
 
 # brush_yuv_image (video frames: YUV_FORMAT_PLANAR with three R8 planes, YUV_FORMAT_NV12 with R8 + RG8; the seven YuvRangedColorSpace

@@ -8474,7 +8474,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 #ifdef WRHIP_HOSTSIM
 #define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R)
 #else
-#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? WR_TEX_WAVES : ((DEPTH) ? 4 : 8)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
+#ifndef WR_RECT_WAVES
+#define WR_RECT_WAVES 8
+#endif
+#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? WR_TEX_WAVES : ((DEPTH) ? 4 : WR_RECT_WAVES)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
@@ -8543,6 +8546,12 @@ wr_raster_chain_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
 // latency-bound workgroups, and a kernel boundary costs ~5 us on top: fused, the setup stage
 // disappears behind the composite pass of the previous frame instead of standing between two
 // frames.  Setup workgroups come first so they are dispatched first.
+// (the setup-stage workgroups of a fused launch are its long pole: a dozen latency-bound waves among thousands of raster waves)
+#if defined(WR_SETUP_PRIORITY) && !defined(WRHIP_HOSTSIM)
+#define WR_SETUP_PRIO() __builtin_amdgcn_s_setprio(WR_SETUP_PRIORITY)
+#else
+#define WR_SETUP_PRIO() ((void)0)
+#endif
 struct WrSetupArgs {
   const WrDrawDesc* draws; int n_draws; const uint8_t* arena; WrPrim* prims; WrRec* recs; WrAux* aux; int n_prims;
   const WrTargetDesc* targets; unsigned long long* masks; float* vtab; WrUnsupportedCounters* cnt; const int* blk;
@@ -8564,6 +8573,7 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
                        const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                        unsigned long long* __restrict__ masks, int bin_offset) {
   if ((int)blockIdx.x < n_setup_blocks) {
+    WR_SETUP_PRIO();
     wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
     return;
   }
@@ -8597,6 +8607,7 @@ wr_setup_raster_dense_kernel(WrSetupArgs S, int n_setup_blocks,
                              const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                              unsigned long long* __restrict__ masks, int bin_offset) {
   if ((int)blockIdx.x < n_setup_blocks) {
+    WR_SETUP_PRIO();
     wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
     return;
   }

@@ -1010,10 +1010,12 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
         boxes = [(100.0, 100.0 + i * 1000.0, 900.0, 900.0 + i * 1000.0) for i in range(n_shadows)]
     n_shadows = len(boxes)
     blur_region = float(np.ceil(BLUR_SAMPLE_SCALE * blur_radius))          # 60
-    corner = max(max(r[0] for r in radii), blur_region)
-    min_size = 2.0 * corner + blur_region                                  # 260
-    alloc = 2.0 * blur_region + np.ceil(min_size)                          # 380 (shadow_rect_alloc_size)
-    cache_px = int(np.ceil(alloc * dps))
+    # (per axis: the largest corner width / height, clip.rs:1786-1806 -- elliptical radii give a non-square minimal rect)
+    corner_w, corner_h = max(max(r[0] for r in radii), blur_region), max(max(r[1] for r in radii), blur_region)
+    min_w, min_h = 2.0 * corner_w + blur_region, 2.0 * corner_h + blur_region          # 260
+    alloc_w, alloc_h = 2.0 * blur_region + np.ceil(min_w), 2.0 * blur_region + np.ceil(min_h)      # 380 (shadow_rect_alloc_size)
+    cache_w, cache_h = int(np.ceil(alloc_w * dps)), int(np.ceil(alloc_h * dps))
+    cache_px = max(cache_w, cache_h)
     sigma = blur_radius * 0.5 * dps
     steps = 0
     while sigma > MAX_BLUR_STD_DEV:
@@ -1024,18 +1026,18 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
     # -- pass 0: the minimal rounded rect, at cache resolution
     t_m0 = TextureRef("bs_corner_mask", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
     tgt = Target(t_m0, "alpha", clear_color=zero)
-    task0 = (4.0, 4.0, 4.0 + cache_px, 4.0 + cache_px)
+    task0 = (4.0, 4.0, 4.0 + cache_w, 4.0 + cache_h)
     tgt.steps.append(Step("cs_clip_rectangle", "CLIP_RECT",
-                          clip_rect_instance(task0, (0.0, 0.0), dps, (blur_region, blur_region), (min_size, min_size),
+                          clip_rect_instance(task0, (0.0, 0.0), dps, (blur_region, blur_region), (min_w, min_h),
                                              radii, 0), None, "none"))
     frame.passes.append([tgt])
     # -- downscale passes
-    cur_tex, cur_rect, size = t_m0, task0, cache_px
+    cur_tex, cur_rect, size = t_m0, task0, (cache_w, cache_h)
     for st in range(steps):
-        size = (size + 1) // 2
+        size = ((size[0] + 1) // 2, (size[1] + 1) // 2)
         t_s = TextureRef(f"bs_scale_{st}", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
         tg = Target(t_s, "alpha", clear_color=zero)
-        nr = (4.0, 4.0, 4.0 + size, 4.0 + size)
+        nr = (4.0, 4.0, 4.0 + size[0], 4.0 + size[1])
         inst = np.zeros(1, SCALE_DTYPE)
         inst["t"][0], inst["s"][0], inst["k"][0] = nr, cur_rect, 1.0
         tg.steps.append(Step("cs_scale TEXTURE_2D", "SCALE", inst, None, "none", textures={0: cur_tex}))
@@ -1046,9 +1048,9 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
     t_cache = TextureRef("bs_texture_cache", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
     a_src, a_v, a_h = (frame.add_render_task(cur_rect) for _ in range(3))
     tg_v, tg_h = Target(t_v, "alpha", clear_color=zero), Target(t_cache, "alpha", clear_color=zero)
-    tg_v.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", blur_instance(a_v, a_src, 1, sigma, (size, size)), None,
+    tg_v.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", blur_instance(a_v, a_src, 1, sigma, size), None,
                            "none", textures={0: cur_tex}))
-    tg_h.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", blur_instance(a_h, a_v, 0, sigma, (size, size)), None,
+    tg_h.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", blur_instance(a_h, a_v, 0, sigma, size), None,
                            "none", textures={0: t_v}))
     frame.passes.append([tg_v])
     frame.passes.append([tg_h])
@@ -1073,7 +1075,7 @@ def cfg4_box_shadow(width=3840, height=2160, dps=1.0, n_shadows=1, tile_filter=N
         bs_inst["origins"][i] = (task[0], task[1], so[0], so[1])
         bs_inst["dps"][i] = dps
         bs_inst["res"][i] = (res % 1024, res // 1024)
-        bs_inst["src_size"][i] = (alloc, alloc)
+        bs_inst["src_size"][i] = (alloc_w, alloc_h)
         bs_inst["mode"][i] = 0
         bs_inst["stretch"][i] = (0, 0)
         bs_inst["dest"][i] = dest

@@ -180,7 +180,81 @@ def many_box_shadows(width=3840, height=2160, tile_filter=None, **kw):
                                   blur_radius=it0["blur-radius"], radii=zero, shadow_color=color, offset=tuple(it0["offset"]))
 
 
+def large_boxshadow_ellipse(width=3840, height=2160, tile_filter=None, **kw):
+    """large-boxshadow-ellipse.yaml: one outset box shadow of a 1024^2 box, blur radius 10, elliptical corner radii -- the box-shadow
+    chain of cfg4 (scenes.cfg4_box_shadow: compute_box_shadow_parameters per axis, clip.rs:1765-1856) on its parameters."""
+    it = display_lists()["large-boxshadow-ellipse"]
+    b, r = it["bounds"], it["border-radius"]
+    radii = tuple((r[k][0], r[k][1]) for k in ("top-left", "top-right", "bottom-left", "bottom-right"))
+    return scenes.cfg4_box_shadow(width=width, height=height, dps=1.0, tile_filter=tile_filter, boxes=[(b[0], b[1], b[0] + b[2], b[1] + b[3])],
+                                  blur_radius=it["blur-radius"], radii=radii, shadow_color=CSS[it["color"]], offset=(0.0, 0.0))
+
+
+def large_clip_rect(width=3840, height=2160, tile_filter=None, **kw):
+    """large-clip-rect.yaml: N identical opaque rects under one rounded-rectangle clip (radius 16).  What the frame builder makes of
+    each rect (prepare.rs build_segments_if_needed / update_clip_task_for_brush, segment.rs:397-470, 511-650): the clip's nine-patch
+    splits the brush into 3 x 3 segments, emitted row by row; the four corner segments carry a mask -- one 16 x 16 clip-mask task
+    each (cs_clip_rectangle FAST_PATH: uniform radius), per primitive, in an alpha target of the pass before -- and are drawn in
+    the alpha pass (brush_solid ALPHA_PASS under swgl_clipMask); the other five are opaque and go to the opaque pass, front to
+    back (batch.rs add_segmented_prim_to_batch: needs_blending = mask present)."""
+    it = display_lists()["large-clip-rect"]
+    n, rad = int(it["count"]), float(it["radius"])
+    rb, cb = it["rect-bounds"], it["complex-rect"]
+    rect = (rb[0], rb[1], rb[0] + rb[2], rb[1] + rb[3])
+    crect = (cb[0], cb[1], cb[0] + cb[2], cb[1] + cb[3])
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    # segments of the prim rect cut by the clip's inner rect (extract_inner_rect_safe: the rect less its radii)
+    xs = [rect[0], max(rect[0], crect[0] + rad), min(rect[2], crect[2] - rad), rect[2]]
+    ys = [rect[1], max(rect[1], crect[1] + rad), min(rect[3], crect[3] - rad), rect[3]]
+    segs = [(xs[i], ys[j], xs[i + 1], ys[j + 1], (i != 1 and j != 1)) for j in range(3) for i in range(3)]
+    color = premultiply(np.array([list(CSS[it["color"]])], np.uint8))[0]
+    # pass 0: the corner masks, 4 per prim, packed in one R8 alpha target
+    side = int(np.ceil(rad))
+    per_row = 32
+    atlas = 1 << int(np.ceil(np.log2(max(per_row * (side + 2) + 8, 256))))
+    t_masks = TextureRef("clip_corner_masks", atlas, atlas, G.GL_R8, G.GL_LINEAR, render_target=True)
+    tg_m = Target(t_masks, "alpha", clear_color=(1.0, 1.0, 1.0, 1.0))
+    minst, mask_task = [], {}
+    radii = ((rad, rad),) * 4
+    k = 0
+    for pi in range(n):
+        for si, sg in enumerate(segs):
+            if not sg[4]:
+                continue
+            x0, y0 = 4 + (k % per_row) * (side + 2), 4 + (k // per_row) * (side + 2)
+            task = (float(x0), float(y0), float(x0 + int(np.ceil(sg[2]) - np.floor(sg[0]))), float(y0 + int(np.ceil(sg[3]) - np.floor(sg[1]))))
+            so = (float(np.floor(sg[0])), float(np.floor(sg[1])))
+            minst.append(scenes.clip_rect_instance(task, so, 1.0, (crect[0], crect[1]), (crect[2] - crect[0], crect[3] - crect[1]), radii, 0))
+            mask_task[(pi, si)] = frame.add_render_task(task, 1.0, so)
+            k += 1
+    tg_m.steps.append(Step("cs_clip_rectangle FAST_PATH", "CLIP_RECT", np.concatenate(minst), None, "none"))
+    frame.passes.append([tg_m])
+    blocks = [list(color)]
+    for sg in segs:
+        blocks += [[sg[0] - rect[0], sg[1] - rect[1], sg[2] - rect[0], sg[3] - rect[1]], [0.0, 0.0, 0.0, 0.0]]
+    spec = frame.gpu_cache.push(blocks)
+    tiles = _tiles(frame, width, height, tile_filter)
+    for target, task, (x0, y0, x1, y1) in tiles:
+        if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+            continue
+        op, al = [], []
+        for pi in range(n):
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), pi + 1, spec, 0, task, (65535, 0, 0, 0))
+            for si, sg in enumerate(segs):
+                if sg[4]:
+                    al.append(frame.brush_instance(ph, mask_task[(pi, si)], segment=si))
+                else:
+                    op.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, segment=si))
+        target.opaque.append(Step("brush_solid", "PRIM_INSTANCES", np.array(op[::-1], dtype=np.int32), None, "opaque"))
+        target.alpha.append(Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha",
+                                 textures={9: t_masks}))
+    frame.readback = [t_masks]
+    return _finish(frame, tiles)
+
+
 WORKLOADS = {
+    "large-boxshadow-ellipse": large_boxshadow_ellipse,
+    "large-clip-rect": large_clip_rect,
     "many-images": many_images,
     "aligned-gradient": lambda **kw: linear_gradients("aligned-gradient", **kw),
     "unaligned-gradient": lambda **kw: linear_gradients("unaligned-gradient", **kw),
@@ -188,6 +262,8 @@ WORKLOADS = {
     "many-box-shadows": many_box_shadows,
 }
 DESCRIPTIONS = {
+    "large-boxshadow-ellipse": "wrench benchmarks/large-boxshadow-ellipse.yaml: one outset box shadow of a 1024x1024 box, blur radius 10, elliptical corner radii (cached blurred corner: mask -> cs_scale -> cs_blur V/H, then the cs_clip_box_shadow x clip-out mask and masked brush_solid segments)",
+    "large-clip-rect": "wrench benchmarks/large-clip-rect.yaml: 8 opaque 1024x1024 rects under one rounded-rectangle clip (radius 16): 3x3 brush segments per rect, 4 corner clip-mask tasks each (cs_clip_rectangle FAST_PATH), opaque + masked alpha pass",
     "many-images": "wrench benchmarks/many-images.yaml: 8192 opaque 8x8 images (one texture-cache entry each), brush_image opaque pass",
     "aligned-gradient": "wrench benchmarks/aligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient (brush_linear_gradient, opaque pass, depth-rejected overdraw)",
     "unaligned-gradient": "wrench benchmarks/unaligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient off the axis (brush_linear_gradient, opaque pass)",
