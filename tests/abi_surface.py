@@ -273,6 +273,51 @@ def run(backend_path):
     gl.UnlockResource(ls); gl.UnlockResource(ld)
     out["composite_texture_after"] = _read_tex(d, big)
 
+    # ---- CompositeYUV(): three locked planes -> locked RGBA8 through the fixed-point colour matrix (composite.h:1160-1386):
+    # 4:2:0 and 4:4:4 R8 planes and 10-bit R16 ones, every YUVRangedColorSpace, 1:1 / up / down scales (the half-resolution
+    # chroma fast path and the generic row walk), flips, clips, requests reaching outside the planes and the destination
+    rngv = np.random.default_rng(97)
+    vw, vh = 96, 64
+    def plane(w, h, bits=8):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = ((xx * 255 // max(w - 1, 1)) ^ rngv.integers(0, 256, size=(h, w))).astype(np.uint16) & 0xFF
+        return base.astype(np.uint8) if bits == 8 else ((base << (bits - 8)) | rngv.integers(0, 1 << (bits - 8), size=(h, w))).astype(np.uint16)
+    def video(cw, ch, bits=8):
+        fmt, ty = (G.GL_R8, G.GL_UNSIGNED_BYTE) if bits == 8 else (G.GL_R16, G.GL_UNSIGNED_SHORT)
+        texs = []
+        for (w, h) in ((vw, vh), (cw, ch), (cw, ch)):
+            t = d.create_texture(w, h, fmt)
+            d.upload_texture(t, 0, 0, w, h, G.GL_RED, ty, plane(w, h, bits))
+            texs.append(t)
+        return texs
+    yuv_dst = d.create_texture(200, 160, G.GL_RGBA8, render_target=True)
+    gl.ClearColorRect(yuv_dst.fbo, 0, 0, 200, 160, 0.25, 0.5, 0.75, 1.0)      # (fresh texture storage is not defined: start from a colour)
+    lyd = gl.LockTexture(yuv_dst.id)
+    def composite_yuv(planes, space, depth, src, dd, flip_x=0, flip_y=0, clip=None):
+        clip = clip or dd
+        locks = [gl.LockTexture(t.id) for t in planes]
+        gl.CompositeYUV(lyd, locks[0], locks[1], locks[2], space, depth, src[0], src[1], src[2], src[3], dd[0], dd[1], dd[2], dd[3],
+                        flip_x, flip_y, clip[0], clip[1], clip[2], clip[3])
+        for l in locks:
+            gl.UnlockResource(l)
+        pd = gl.GetResourceBuffer(lyd, w_, h_, s_)
+        return np.stack([_ptr_bytes(pd + y * s_.value, w_.value * 4) for y in range(h_.value)])
+    v420, v444, v420_10 = video(vw // 2, vh // 2), video(vw, vh), video(vw // 2, vh // 2, 10)
+    for space in range(7):
+        out[f"composite_yuv_420_1to1_space{space}"] = composite_yuv(v420, space, 8, (0, 0, vw, vh), (10 + space, 8, vw, vh))
+    out["composite_yuv_420_upscaled"] = composite_yuv(v420, 2, 8, (0, 0, vw, vh), (3, 5, 190, 150))
+    out["composite_yuv_420_upscaled_frac"] = composite_yuv(v420, 0, 8, (5, 3, 70, 50), (7, 9, 171, 131))
+    out["composite_yuv_420_downscaled"] = composite_yuv(v420, 3, 8, (0, 0, vw, vh), (20, 20, 41, 29))
+    out["composite_yuv_420_flip_xy"] = composite_yuv(v420, 1, 8, (0, 0, vw, vh), (30, 10, 120, 100), flip_x=1, flip_y=1)
+    out["composite_yuv_420_clipped"] = composite_yuv(v420, 4, 8, (0, 0, vw, vh), (-20, -12, 180, 140), clip=(10, 6, 100, 90))
+    out["composite_yuv_420_src_outside"] = composite_yuv(v420, 2, 8, (-9, -5, vw + 20, vh + 12), (15, 12, 150, 110))
+    out["composite_yuv_444_1to1"] = composite_yuv(v444, 5, 8, (0, 0, vw, vh), (40, 50, vw, vh))
+    out["composite_yuv_444_scaled"] = composite_yuv(v444, 2, 8, (2, 1, 80, 60), (0, 0, 133, 101))
+    out["composite_yuv_420_10bit"] = composite_yuv(v420_10, 2, 10, (0, 0, vw, vh), (12, 14, 150, 120))
+    out["composite_yuv_420_10bit_1to1"] = composite_yuv(v420_10, 4, 10, (0, 0, vw, vh), (50, 40, vw, vh), flip_y=1)
+    gl.UnlockResource(lyd)
+    out["composite_yuv_texture_after"] = _read_tex(d, yuv_dst)
+
     # ---- externally backed texture: the caller's memory holds the result after ResolveFramebuffer -------------
     ext = np.zeros((40, 64, 4), np.uint8)
     ext[..., 1] = 200

@@ -3030,10 +3030,116 @@ void Composite(LockedTexture* lockedDst, LockedTexture* lockedSrc, GLint srcX, G
   blit_textures(sid, s, did, d, sr, dr, flipX != 0, flipY != 0, useLinear, !opaque, clip, false);
   download_texture(d);
 }
-void CompositeYUV(LockedTexture*, LockedTexture*, LockedTexture*, LockedTexture*, YuvRangedColorSpace, GLuint, GLint, GLint,
-                  GLsizei, GLsizei, GLint, GLint, GLsizei, GLsizei, GLboolean, GLboolean, GLint, GLint, GLsizei, GLsizei) {
-  fprintf(stderr, "libwrhip: CompositeYUV() is not implemented (Gecko's software compositor entry point, out of scope)\n");
-  if (ctx) ctx->last_error = GL_INVALID_OPERATION;
+void CompositeYUV(LockedTexture* lockedDst, LockedTexture* lockedY, LockedTexture* lockedU, LockedTexture* lockedV, YuvRangedColorSpace colorSpace,
+                  GLuint colorDepth, GLint srcX, GLint srcY, GLsizei srcWidth, GLsizei srcHeight, GLint dstX, GLint dstY, GLsizei dstWidth,
+                  GLsizei dstHeight, GLboolean flipX, GLboolean flipY, GLint clipX, GLint clipY, GLsizei clipWidth, GLsizei clipHeight) {
+  // composite.h:1330-1386 -> linear_convert_yuv (:1160-1208): three locked R8 (or R16) planes scaled, flipped and clipped into a
+  // locked RGBA8 destination through the fixed-point colour matrix; always the linear-filter row walk (linear_row_yuv).
+  if (!lockedDst || !lockedY || !lockedU || !lockedV || !ctx) return;
+  if (colorSpace < 0 || colorSpace > 6) return;
+  Texture& yt = *(Texture*)lockedY; Texture& ut = *(Texture*)lockedU; Texture& vt = *(Texture*)lockedV; Texture& d = *(Texture*)lockedDst;
+  if (!yt.dptr || !ut.dptr || !vt.dptr || !d.dptr || d.bpp != 4) return;
+  if (yt.bpp != ut.bpp || yt.bpp != vt.bpp || !((yt.bpp == 1 && colorDepth == 8) || (yt.bpp == 2 && colorDepth > 8 && colorDepth <= 16)) ||
+      ut.width != vt.width || ut.height != vt.height) {
+    // (the reference asserts these: planes of one format -- R8 at 8 bits, R16 above --, chroma planes of one size)
+    ctx->last_error = GL_INVALID_OPERATION;
+    return;
+  }
+  const int sr[4] = {srcX - yt.offx, srcY - yt.offy, srcX + srcWidth - yt.offx, srcY + srcHeight - yt.offy};
+  const int dr[4] = {dstX - d.offx, dstY - d.offy, dstX + dstWidth - d.offx, dstY + dstHeight - d.offy};
+  if (sr[2] <= sr[0] || sr[3] <= sr[1] || dr[2] <= dr[0] || dr[3] <= dr[1]) return;
+  const int clip[4] = {clipX - dstX, clipY - dstY, clipX - dstX + clipWidth, clipY - dstY + clipHeight};
+  // dstBounds = dsttex.sample_bounds(dstReq) (relative to the request) & clipRect
+  int b[4] = {std::max(0, dr[0]) - dr[0], std::max(0, dr[1]) - dr[1], std::min(d.width, dr[2]) - dr[0], std::min(d.height, dr[3]) - dr[1]};
+  b[0] = std::max(b[0], clip[0]); b[1] = std::max(b[1], clip[1]); b[2] = std::min(b[2], clip[2]); b[3] = std::min(b[3], clip[3]);
+  if (b[2] <= b[0] || b[3] <= b[1]) return;
+  flush_all();
+  sync_texture_for_read(yt); sync_texture_for_read(ut); sync_texture_for_read(vt);
+  sync_texture_for_write(d);
+  flush_uploads();
+  WrYuvBlitArgs A;
+  memset(&A, 0, sizeof(A));
+  auto desc = [](const Texture& t) {
+    WrTexDesc td; td.ptr = t.dptr; td.width = t.width; td.height = t.height;
+    td.stride = t.bpp == 2 ? t.stride / 2 : t.stride; td.format = (int16_t)(t.bpp == 2 ? WR_FMT_R16 : WR_FMT_R8); td.linear = 1;
+    return td;
+  };
+  A.y = desc(yt); A.u = desc(ut); A.v = desc(vt);
+  A.dst = d.dptr; A.dst_stride = d.stride;
+  A.dx0 = dr[0] + b[0]; A.dy0 = dr[1] + b[1]; A.span = b[2] - b[0]; A.rows = b[3] - b[1];
+  A.color_depth = (int)colorDepth;
+  {
+    // get_ycbcr_info (composite.h:1292-1313, the colour depth forced to 8) -> YUVMatrix::From (:660-719)
+    float z0 = 0.0f, z1 = 0.0f, o0 = 1.0f, o1 = 1.0f;
+    const float n0 = float(16) / 255.0f, n1 = float(128) / 255.0f, n2 = float(235) / 255.0f, n3 = float(240) / 255.0f;
+    if (colorSpace == 0 || colorSpace == 2 || colorSpace == 4) { z0 = n0; z1 = n1; o0 = n2; o1 = n3; }
+    else if (colorSpace == 1 || colorSpace == 3 || colorSpace == 5) { z0 = 0.0f; z1 = n1; o0 = 1.0f; o1 = 1.0f; }
+    static const float M601[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.17207f, 0.88600f, 0.70100f, -0.35707f, 0.00000f};
+    static const float M709[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.09366f, 0.92780f, 0.78740f, -0.23406f, 0.00000f};
+    static const float M2020[9] = {1.00000f, 1.00000f, 1.00000f, 0.00000f, -0.08228f, 0.94070f, 0.73730f, -0.28568f, 0.00000f};
+    static const float MID[9] = {0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f};
+    const float* Am = colorSpace <= 1 ? M601 : (colorSpace <= 3 ? M709 : (colorSpace <= 5 ? M2020 : MID));
+    const float sx = 1.0f / (o0 - z0), sy = 1.0f / (o1 - z1);
+    const float Bm[9] = {sx, 0.0f, 0.0f, 0.0f, sy, 0.0f, 0.0f, 0.0f, sy};
+    float mat[9];       // rgb_from_yuv * yuv_from_debiased_ycbcr, column-major (glsl.h mat3 * mat3)
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) mat[3 * c + r] = Am[r] * Bm[3 * c] + Am[3 + r] * Bm[3 * c + 1] + Am[6 + r] * Bm[3 * c + 2];
+    const double yc = double(mat[1]), rvd = double(mat[6]), gud = double(mat[4]), gvd = double(mat[7]), bud = double(mat[5]);
+    A.brmask = mat[0] == 0.0f ? 0 : -1;
+    A.bu = int(int16_t(bud * double(1 << 6) + 0.5)); A.rv = int(int16_t(rvd * double(1 << 6) + 0.5));
+    A.gu = -int(int16_t(-gud * double(1 << 6) + 0.5)); A.gv = -int(int16_t(-gvd * double(1 << 6) + 0.5));
+    A.ycoeff = int(uint16_t(yc * double(1 << 7) + 0.5));
+    A.ybias = int(int16_t((double(z0 * 255.0f) * yc - 0.5) * double(1 << 6)));
+    A.uvbias = int(int16_t(double(z1 * float(255)) + 0.5));
+  }
+  // source coordinates (linear_convert_yuv): start, step, flips, the skip to the clamped destination start, the chroma planes' scale
+  float su = float(sr[0]), svv = float(sr[1]);
+  float du = float(sr[2] - sr[0]) / float(dr[2] - dr[0]), dv = float(sr[3] - sr[1]) / float(dr[3] - dr[1]);
+  if (flipX) { su += float(sr[2] - sr[0]); du = -du; }
+  if (flipY) { svv += float(sr[3] - sr[1]); dv = -dv; }
+  su += du * (float(b[0]) + 0.5f); svv += dv * (float(b[1]) + 0.5f);
+  const float csx = float(ut.width) / float(yt.width), csy = float(ut.height) / float(yt.height);
+  float cu = su * csx, cvv = svv * csy, cdu = du * csx, cdv = dv * csy;
+  A.src_u0 = su; A.chroma_u0 = cu;
+  A.nearest = (yt.width < 2 || ut.width < 2) ? 1 : 0;
+  if (!A.nearest) {
+    su = su * 128.0f + (0.5f - 0.5f * 128.0f); svv = svv * 128.0f + (0.5f - 0.5f * 128.0f); du *= 128.0f; dv *= 128.0f;
+    cu = cu * 128.0f + (0.5f - 0.5f * 128.0f); cvv = cvv * 128.0f + (0.5f - 0.5f * 128.0f); cdu *= 128.0f; cdv *= 128.0f;
+  }
+  A.src_v0 = svv; A.src_dv = dv; A.chroma_v0 = cvv; A.chroma_dv = cdv;
+  {
+    // linear_row_yuv's row-invariant integers (composite.h:999-1011)
+    const int STEP_BITS = 8;
+    auto lanes = [&](float x0, float dx, int (&out)[4]) {
+      const float l1 = x0 + dx, l2 = l1 + dx, l3 = l2 + dx;
+      const float v[4] = {x0, l1, l2, l3};
+      for (int i = 0; i < 4; i++) out[i] = (int)(v[i] * float(1 << STEP_BITS));
+    };
+    lanes(su, du, A.yU); lanes(cu, cdu, A.cU);
+    A.yDU = (int)(float(4 << STEP_BITS) * du); A.cDU = (int)(float(4 << STEP_BITS) * cdu);
+    A.fast0 = A.fast1 = 0;
+    if (!A.nearest && yt.bpp == 1 && A.yDU >= A.cDU && A.cDU > 0 && A.yDU <= (4 << (STEP_BITS + 7)) && A.cDU <= (2 << (STEP_BITS + 7))) {
+      // the half-resolution fast path (composite.h:1081-1122): chunks until both coordinates are positive, then as many whole chunks
+      // as stay four texels inside both planes
+      int span = A.span, chunk = 0;
+      int32_t yx = A.yU[0], cx = A.cU[0];
+      int32_t cl[4] = {A.cU[0], A.cU[1], A.cU[2], A.cU[3]};
+      for (; (yx < 0 || cx < 0) && span >= 4; span -= 4) {
+        yx = (int32_t)((uint32_t)yx + (uint32_t)A.yDU); cx = (int32_t)((uint32_t)cx + (uint32_t)A.cDU);
+        for (int i = 0; i < 4; i++) cl[i] = (int32_t)((uint32_t)cl[i] + (uint32_t)A.cDU);
+        chunk++;
+      }
+      const int inside = std::min(std::min((((yt.width - 4) << (STEP_BITS + 7)) - yx) / A.yDU, (((ut.width - 4) << (STEP_BITS + 7)) - cx) / A.cDU) * 4, span & ~3);
+      if (inside > 0) {
+        A.fast0 = chunk; A.fast1 = chunk + inside / 4;
+        A.cA = (cl[0] + cl[1]) >> 1; A.cB = (cl[2] + cl[3]) >> 1;      // cU = (cU.xzxz + cU.ywyw) >> 1
+      }
+    }
+  }
+  const long long n = (long long)((A.span + 3) / 4) * A.rows;
+  WR_LAUNCH(wr_composite_yuv_kernel, (int)((n + 255) / 256), 256, ctx->stream, A);
+  ctx->stats.kernel_launches++;
+  download_texture(d);
 }
 
 // ---- libwrhip additions ------------------------------------------------------

@@ -5557,6 +5557,113 @@ __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp
   return s;
 }
 
+// ---------------------------------------------------------------------------
+// CompositeYUV: linear_row_yuv (composite.h:993-1157) chunk by chunk.  One thread = one 4-pixel chunk of one destination row.
+WR_DEVICE int wr_i16(int v) { return (int)(int16_t)v; }
+// textureLinearRowR8 / textureLinearRowPairedR8 for one lane: x in 1/128 texels, the row pair and its 7-bit fraction given
+WR_DEVICE int wr_yuv_row_tap(const WrTexDesc& t, int qx, long long row_off, long long row_stride, int fracv) {
+  int ix = qx >> 7;
+  const int fracx = (((ix >= 0) ? qx : 0) | (ix > t.width - 2 ? -1 : 0)) & 0x7F;      // (127, not 128, past the last pair: composite.h:806)
+  ix = wr_clamp_coord(ix, t.width - 1);
+  const uint8_t* b = (const uint8_t*)t.ptr + row_off;
+  const int a0 = b[ix], a1 = b[ix + 1], b0 = b[row_stride + ix], b1 = b[row_stride + ix + 1];
+  const int l = wr_i16(a0 + wr_i16(wr_i16((b0 - a0) * fracv) >> 7)), r = wr_i16(a1 + wr_i16(wr_i16((b1 - a1) * fracv) >> 7));
+  return wr_i16(l + wr_i16(wr_i16((r - l) * fracx) >> 7));
+}
+WR_DEVICE int wr_yuv_vlerp(const uint8_t* row, long long stride, long long x, int fracv) {      // one column of a row pair
+  const int a = row[x], b = row[x + stride];
+  return wr_i16(a + wr_i16(wr_i16((b - a) * fracv) >> 7));
+}
+#ifndef WR_INST_ONLY
+__global__ void wr_composite_yuv_kernel(WrYuvBlitArgs A) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = (A.span + 3) >> 2;
+  if (tid >= (long long)chunks * A.rows) return;
+  const int row = (int)(tid / chunks), c = (int)(tid % chunks);
+  const int left = A.span - 4 * c, npx = left < 4 ? left : 4;
+  uint32_t* dst = (uint32_t*)((uint8_t*)A.dst + (size_t)(A.dy0 + row) * A.dst_stride) + A.dx0 + 4 * c;
+  WrYuvRec M;
+  M.bu = A.bu; M.rv = A.rv; M.gu = A.gu; M.gv = A.gv; M.ycoeff = A.ycoeff; M.ybias = A.ybias; M.uvbias = A.uvbias; M.brmask = A.brmask;
+  // the row's v coordinates: `srcUV.y += srcDUV.y` once per row
+  const float sv = wr_accum(A.src_v0, A.src_dv, row), cvf = wr_accum(A.chroma_v0, A.chroma_dv, row);
+  uint32_t out[4];
+  if (A.nearest) {
+    // a single texel of every plane, nearest, converted once (composite.h:1014-1031)
+    auto fetch = [](const WrTexDesc& t, float fu, float fv) -> float {
+      const int x = wr_clamp_coord(int(fu), t.width), y = wr_clamp_coord(int(fv), t.height);
+      if (t.format == WR_FMT_R16) return float(((const uint16_t*)t.ptr)[(size_t)y * t.stride + x]) * (1.0f / 65535.0f);
+      return float(((const uint8_t*)t.ptr)[(size_t)y * t.stride + x]) * (1.0f / 255.0f);
+    };
+    float yf = fetch(A.y, A.src_u0, sv), uf = fetch(A.u, A.chroma_u0, cvf), vf = fetch(A.v, A.chroma_u0, cvf);
+    if (A.color_depth > 8) { const float k = float(1 << (16 - A.color_depth)); yf *= k; uf *= k; vf *= k; }
+    const WrWide w = wr_yuv_convert(M, wr_i16(wr_round_pixel(yf)), wr_i16(wr_round_pixel(uf)), wr_i16(wr_round_pixel(vf)));
+    const uint32_t p = wr_pack(w);
+    for (int i = 0; i < 4; i++) out[i] = p;
+  } else {
+    int yV = int(sv), cV = int(cvf);                  // int32_t(srcUV.y): truncation
+    int yq[4], cq[4];
+    for (int i = 0; i < 4; i++) { yq[i] = (int)((uint32_t)A.yU[i] + (uint32_t)c * (uint32_t)A.yDU); cq[i] = (int)((uint32_t)A.cU[i] + (uint32_t)c * (uint32_t)A.cDU); }
+    int ys[4], us[4], vs[4];
+    if (A.y.format == WR_FMT_R16) {
+      const int bits = (A.color_depth - 1) - 8;
+      for (int i = 0; i < 4; i++) {
+        int t4[4];
+        wr_bilinear16<1>(A.y, yq[i] >> 8, yV, t4); ys[i] = t4[0] >> bits;
+        wr_bilinear16<1>(A.u, cq[i] >> 8, cV, t4); us[i] = t4[0] >> bits;
+        wr_bilinear16<1>(A.v, cq[i] >> 8, cV, t4); vs[i] = t4[0] >> bits;
+      }
+    } else {
+      const int yfv = yV & 0x7F, cfv = cV & 0x7F;
+      yV >>= 7; cV >>= 7;
+      const long long yoff = (long long)wr_clamp_coord(yV, A.y.height) * A.y.stride, ystr = (yV >= 0 && yV < A.y.height - 1) ? A.y.stride : 0;
+      const long long coff = (long long)wr_clamp_coord(cV, A.u.height) * A.u.stride, cstr = (cV >= 0 && cV < A.u.height - 1) ? A.u.stride : 0;
+      if (c >= A.fast0 && c < A.fast1) {
+        // upscaleYUV42R8 (composite.h:857-986): luma per lane out of a 4 + 4 texel window, chroma at the chunk's two averaged
+        // coordinates, the four pixels' chroma estimated from those two samples
+        const int k = c - A.fast0;
+        const uint8_t* yrow = (const uint8_t*)A.y.ptr + yoff;
+        const uint8_t* urow = (const uint8_t*)A.u.ptr + coff;
+        const uint8_t* vrow = (const uint8_t*)A.v.ptr + coff;
+        const int ca = (int)((uint32_t)A.cA + (uint32_t)k * (uint32_t)A.cDU), cb = (int)((uint32_t)A.cB + (uint32_t)k * (uint32_t)A.cDU);
+        int yI[4]; for (int i = 0; i < 4; i++) yI[i] = yq[i] >> 15;
+        const int cIx = ca >> 15, cIy = cb >> 15;
+        const int yInx = (int)((uint32_t)yq[0] + (uint32_t)A.yDU) >> 15, cInx = (int)((uint32_t)ca + (uint32_t)A.cDU) >> 15;
+        int s[4], n[4];
+        for (int i = 0; i < 4; i++) { s[i] = wr_yuv_vlerp(yrow, ystr, (long long)yI[0] + i, yfv); n[i] = wr_yuv_vlerp(yrow, ystr, (long long)yInx + i, yfv); }
+        int ysh[4] = {s[0], s[1], s[2], s[3]};
+        int ysn[4] = {s[1], s[2], s[3], yInx == yI[3] ? n[1] : n[0]};
+        if (yI[1] == yI[0]) { const int a[4] = {ysh[0], ysh[0], ysh[1], ysh[2]}, b[4] = {ysn[0], ysn[0], ysn[1], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
+        if (yI[2] == yI[1]) { const int a[4] = {ysh[0], ysh[1], ysh[1], ysh[2]}, b[4] = {ysn[0], ysn[1], ysn[1], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
+        if (yI[3] == yI[2]) { const int a[4] = {ysh[0], ysh[1], ysh[2], ysh[2]}, b[4] = {ysn[0], ysn[1], ysn[2], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
+        const int u0 = wr_yuv_vlerp(urow, cstr, cIx, cfv), u1 = wr_yuv_vlerp(urow, cstr, (long long)cIx + 1, cfv);
+        const int v0 = wr_yuv_vlerp(vrow, cstr, cIx, cfv), v1 = wr_yuv_vlerp(vrow, cstr, (long long)cIx + 1, cfv);
+        const int nu0 = wr_yuv_vlerp(urow, cstr, cInx, cfv), nu1 = wr_yuv_vlerp(urow, cstr, (long long)cInx + 1, cfv);
+        const int nv0 = wr_yuv_vlerp(vrow, cstr, cInx, cfv), nv1 = wr_yuv_vlerp(vrow, cstr, (long long)cInx + 1, cfv);
+        int csh[4] = {u0, u1, v0, v1};
+        int csn[4] = {u1, cInx == cIy ? nu1 : nu0, v1, cInx == cIy ? nv1 : nv0};
+        if (cIy == cIx) { csh[1] = csh[0]; csh[3] = csh[2]; csn[1] = csn[0]; csn[3] = csn[2]; }
+        const int fr[8] = {(yq[0] >> 8) & 0x7F, (yq[1] >> 8) & 0x7F, (yq[2] >> 8) & 0x7F, (yq[3] >> 8) & 0x7F, (ca >> 8) & 0x7F, (cb >> 8) & 0x7F, (ca >> 8) & 0x7F, (cb >> 8) & 0x7F};
+        int px[8];
+        for (int i = 0; i < 4; i++) px[i] = wr_i16(ysh[i] + wr_i16(wr_i16((ysn[i] - ysh[i]) * fr[i]) >> 7));
+        for (int i = 0; i < 4; i++) px[4 + i] = wr_i16(csh[i] + wr_i16(wr_i16((csn[i] - csh[i]) * fr[4 + i]) >> 7));
+        const int uA = px[4], uB = px[5], vA = px[6], vB = px[7];
+        for (int i = 0; i < 4; i++) ys[i] = px[i];
+        us[0] = wr_i16(uA + (wr_i16(uA - uB) >> 2)); us[1] = wr_i16(uA + (wr_i16(uB - uA) >> 2)); us[2] = wr_i16(uB + (wr_i16(uA - uB) >> 2)); us[3] = wr_i16(uB + (wr_i16(uB - uA) >> 2));
+        vs[0] = wr_i16(vA + (wr_i16(vA - vB) >> 2)); vs[1] = wr_i16(vA + (wr_i16(vB - vA) >> 2)); vs[2] = wr_i16(vB + (wr_i16(vA - vB) >> 2)); vs[3] = wr_i16(vB + (wr_i16(vB - vA) >> 2));
+      } else {
+        for (int i = 0; i < 4; i++) {
+          ys[i] = wr_yuv_row_tap(A.y, yq[i] >> 8, yoff, ystr, yfv);
+          us[i] = wr_yuv_row_tap(A.u, cq[i] >> 8, coff, cstr, cfv);
+          vs[i] = wr_yuv_row_tap(A.v, cq[i] >> 8, coff, cstr, cfv);
+        }
+      }
+    }
+    for (int i = 0; i < 4; i++) out[i] = wr_pack(wr_yuv_convert(M, ys[i], us[i], vs[i]));
+  }
+  for (int i = 0; i < npx; i++) dst[i] = out[i];
+}
+#endif
+
 template <int FMT>
 __device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* Bp, int x, int y) {
   const WrPrim& P = *Pp;

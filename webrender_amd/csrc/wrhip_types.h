@@ -614,3 +614,23 @@ struct WrBlitArgs {
   int32_t invert_y, linear;
   int32_t invert_x, composite;         // Composite(): X flips (linear only), premultiplied-over blend instead of a copy (RGBA8 <- RGBA8)
 };
+
+// CompositeYUV (composite.h:1160-1386): the destination rows of linear_convert_yuv, four pixels (one chunk of linear_row_yuv) per
+// thread.  Everything that is constant along a row -- the planes' x coordinates in 1/128 texel x 2^8 fixed point, their steps, where
+// the half-resolution fast path (upscaleYUV42R8) starts and ends -- is worked out once on the host, as the reference does per row.
+struct WrYuvBlitArgs {
+  WrTexDesc y, u, v;               // planes (R8, or R16 with colour depth > 8)
+  void* dst; int32_t dst_stride;   // RGBA8 destination, bytes per row
+  int32_t dx0, dy0, span, rows;    // destination bounds: first pixel, pixels per row, rows
+  float src_v0, src_dv;            // luma v (quantised to 1/128 texel unless a plane is narrower than 2) at the first row, step per row
+  float chroma_v0, chroma_dv;
+  float src_u0, chroma_u0;         // unquantised: the nearest fallback of a plane narrower than 2 texels reads ivec2(srcUV)
+  int32_t yU[4], cU[4];            // cast(init_interp(u, du) * 2^8) of the first chunk
+  int32_t yDU, cDU;                // per chunk
+  int32_t nearest;                 // a plane is narrower than two texels: one converted texel fills the row
+  int32_t color_depth;
+  int32_t fast0, fast1;            // chunks [fast0, fast1) of a row take upscaleYUV42R8; cA, cB: its averaged chroma coordinates at fast0
+  int32_t cA, cB;
+  int32_t bu, rv, gu, gv, ycoeff, ybias, uvbias, brmask;      // YUVMatrix (as WrYuvRec)
+};
+
