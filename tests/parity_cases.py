@@ -276,6 +276,10 @@ MIX_BLEND = [
     ("mix_grid_nearest_src", "mix_blend_grid", dict(seed=204, n=60)),
     ("mix_grid_masked", "mix_blend_grid", dict(seed=205, masked=True)),
     ("mix_grid_integer", "mix_blend_grid", dict(seed=207, fractional=False, n=50)),
+    # mix-blend-mode on rotated / skewed stacking contexts (the general-quad path, anti-aliased edges) and with BRUSH_FLAG_FORCE_AA
+    ("mix_grid_rotated", "mix_blend_grid", dict(seed=208, rotate=True)),
+    ("mix_grid_rotated_masked", "mix_blend_grid", dict(seed=209, rotate=True, masked=True, n=60)),
+    ("mix_grid_force_aa", "mix_blend_grid", dict(seed=210, force_aa=True, n=60)),
 ]
 
 
@@ -288,6 +292,12 @@ DUAL_SOURCE = [
     ("image_dual", dict(dual=True)),
     ("image_dual_masked", dict(dual=True, masked=True, seed=52)),
     ("image_dual_nearest", dict(dual=True, nearest=True, seed=53)),
+]
+# the REPETITION variant of the dual-source key (shader_features.rs:166-170): tiled / stretched / border-image-segment images under
+# the dual-source blend state
+REPEAT_DUAL = [
+    ("image_repeat_dual", dict(dual=True, seed=58)),
+    ("image_repeat_dual_nearest", dict(dual=True, nearest=True, seed=59)),
 ]
 
 

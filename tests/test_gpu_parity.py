@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -402,6 +402,18 @@ def test_hip_wrench_benchmarks_full_4k(name, workload, _small, kw):
             assert np.array_equal(got[k], want[k]), k
     else:
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,kw", REPEAT_DUAL, ids=[c[0] for c in REPEAT_DUAL])
+def test_hip_repeat_dual_source_images_match_oracle(name, kw):
+    """brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION on the MI355X: 0 differing bytes"""
+    ref = oracle_ref()
+    if not ref:
+        pytest.skip("oracle not built")
+    want, _ = render_direct(ref, scenes.image_repeat(**kw))
+    got, st = render_direct(wrhip_lib(), scenes.image_repeat(**kw))
+    assert st["gl_error"] == 0
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("name,make", YUV, ids=[c[0] for c in YUV])

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -506,6 +506,16 @@ def test_hostsim_mix_blend_matches_oracle(hostsim, oracle_gcc, name, scene, kw):
     want, _ = render_direct(oracle_gcc, getattr(scenes, scene)(**kw))
     got, st = render_direct(hostsim, getattr(scenes, scene)(**kw))
     assert st["gl_error"] == 0 and (want != 255).any()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,kw", REPEAT_DUAL, ids=[c[0] for c in REPEAT_DUAL])
+def test_hostsim_repeat_dual_source_images_match_oracle(hostsim, oracle_gcc, name, kw):
+    """brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION: 0 differing bytes, and not what the plain repetition key draws"""
+    want, _ = render_direct(oracle_gcc, scenes.image_repeat(**kw))
+    got, st = render_direct(hostsim, scenes.image_repeat(**kw))
+    plain, _ = render_direct(oracle_gcc, scenes.image_repeat(**{k: v for k, v in kw.items() if k != "dual"}))
+    assert st["gl_error"] == 0 and (want != plain).sum() > 100000
     assert np.array_equal(got, want)
 
 

@@ -283,8 +283,9 @@ const ShaderInfo SHADERS[] = {
     {"brush_image ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT, {"aPosition", "aData"}, PRIM_SAMPLERS},
     {"brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
     // (ALPHA_PASS + DUAL_SOURCE_BLENDING: what BlendMode::SubpixelDualSource / MultiplyDualSource batches are drawn with,
-    // shade.rs:462-467 -- main() only, a second output colour; the REPETITION variant of the key is not implemented)
+    // shade.rs:462-467 -- main() only, a second output colour; axis-aligned prims without swgl_antiAlias)
     {"brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D", WR_SH_BRUSH_IMAGE_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS},
+    {"brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D", WR_SH_BRUSH_IMAGE_REPEAT_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS},
     // (the ADVANCED_BLEND keys: the ALPHA_PASS programs with `layout(blend_support_all_equations) out`, shared.glsl:86-88 --
     // what BlendMode::Advanced batches are drawn with, shade.rs:440-468)
     {"brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_2D", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS},
@@ -1830,7 +1831,7 @@ void flush_work(const std::vector<int>& sel_in) {
             f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           case WR_SH_CS_BORDER_SOLID: case WR_SH_CS_BORDER_SEGMENT: case WR_SH_CS_FAST_LINEAR_GRADIENT: case WR_SH_CS_LINE_DECORATION:
             f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
-          case WR_SH_BRUSH_IMAGE_REPEAT: case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
+          case WR_SH_BRUSH_IMAGE_REPEAT: case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: case WR_SH_BRUSH_IMAGE_REPEAT_DUAL: f = WR_FEAT_SHADE | WR_FEAT_GENERIC; break;
           default: f = WR_FEAT_TEX | WR_FEAT_GENERIC; break;
         }
       }
@@ -2776,7 +2777,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   d.blend = c->blend ? c->blend_key : WR_BLEND_NONE;
   // (GL_ONE, GL_ONE_MINUS_SRC1_COLOR under the dual-source text program is fine: every prim of that
   // program replaces the key with swgl_blendSubpixelText / swgl_blendDropShadow in its vertex stage)
-  const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && (info->kind == WR_SH_PS_TEXT_RUN_DUAL || info->kind == WR_SH_PS_TEXT_RUN_DUAL_GT || info->kind == WR_SH_BRUSH_IMAGE_DUAL);      // (the image program writes the second colour itself)
+  const bool dual_text = d.blend == WR_BLEND_DUAL_SRC && (info->kind == WR_SH_PS_TEXT_RUN_DUAL || info->kind == WR_SH_PS_TEXT_RUN_DUAL_GT || info->kind == WR_SH_BRUSH_IMAGE_DUAL || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_DUAL);      // (the image program writes the second colour itself)
   if (!dual_text && (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC)) {
     // not in swgl's key table either (gl.cc:614-645: the reference asserts) -- or GL_ONE, GL_ONE_MINUS_SRC1_COLOR outside the
     // dual-source text program, which needs gl_SecondaryFragColor from a shader that is not implemented
@@ -2832,7 +2833,8 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
                      info->kind == WR_SH_BRUSH_OPACITY || info->kind == WR_SH_BRUSH_OPACITY_ALPHA ||
                      info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA ||
                      info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
-                     info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA;
+                     info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA ||
+                     info->kind == WR_SH_BRUSH_MIX_BLEND || info->kind == WR_SH_BRUSH_MIX_BLEND_ALPHA;
     // (glyph quads under a rotation -- local raster space -- ride on the same path; the program never asks for swgl_antiAlias,
     // and a glyph instance's third word is not a brush's flags: the transform ids alone decide)
     const bool text = info->kind == WR_SH_PS_TEXT_RUN || info->kind == WR_SH_PS_TEXT_RUN_DUAL || info->kind == WR_SH_PS_TEXT_RUN_GT || info->kind == WR_SH_PS_TEXT_RUN_DUAL_GT;

@@ -584,10 +584,10 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
 //        4 brush_blend (F = its side record)
 // image: 0 brush_solid, 1 / 2 brush_image (opaque / ALPHA_PASS), 3 linear gradient, 4 brush_blend,
 //        5 / 6 brush_image with REPETITION (opaque / ALPHA_PASS; Rp = its side record), 7 brush_opacity, 8 brush_mix_blend (Mx),
-//        9 brush_image DUAL_SOURCE_BLENDING, 10 brush_yuv_image (Yv)
+//        9 brush_image DUAL_SOURCE_BLENDING, 10 brush_yuv_image (Yv), 11 brush_image REPETITION + DUAL_SOURCE_BLENDING (Rp)
 WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, int image, WrVsOut& o, WrGradRec* G = nullptr,
                             WrFilterRec* F = nullptr, WrRepeatRec* Rp = nullptr, WrMixRec* Mx = nullptr, WrYuvRec* Yv = nullptr) {
-  const bool repetition = image == 5 || image == 6;
+  const bool repetition = image == 5 || image == 6 || image == 11;      // (11: the ALPHA_PASS repetition program with DUAL_SOURCE_BLENDING)
   wi4 aData = wr_load_attr<wi4>(d, arena, inst, 0);
   int prim_header_address = aData.x, clip_address = aData.y;
   int segment_index = aData.z & 0xffff, flags = aData.z >> 16;
@@ -950,8 +950,9 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.kind = WR_PK_TEX_REPEAT;
     o.uv_add[0] = o.uv_add[1] = 0.0f; o.tail_clamp = 0;
     Rp->uv_repeat[0] = ubx; Rp->uv_repeat[1] = uby; Rp->uv_repeat[2] = ubz; Rp->uv_repeat[3] = ubw;
-    Rp->tile_repeat[0] = image == 6 ? rpx + nox : 0.0f; Rp->tile_repeat[1] = image == 6 ? rpy + noy : 0.0f;
-    Rp->alpha_pass = image == 6; Rp->no_span = tex.format != WR_FMT_RGBA8;
+    const bool rep_alpha = image == 6 || image == 11;
+    Rp->tile_repeat[0] = rep_alpha ? rpx + nox : 0.0f; Rp->tile_repeat[1] = rep_alpha ? rpy + noy : 0.0f;
+    Rp->alpha_pass = rep_alpha; Rp->no_span = tex.format != WR_FMT_RGBA8 || image == 11;      // (no span shader under the dual-source key)
     if (tex.format != WR_FMT_RGBA8 && tex.format != WR_FMT_R8) { o.kind = WR_PK_UNSUPPORTED; return; }
   }
   if (data1.y != 0) { o.kind = WR_PK_UNSUPPORTED; return; }          // RASTER_SCREEN: next
@@ -969,8 +970,8 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   wf4 vcol;
   if (color_mode == 4) vcol = color;                                          // COLOR_MODE_IMAGE
   else if (color_mode == 3) vcol = wf4{color.w, color.w, color.w, color.w};   // COLOR_MODE_COLOR_BITMAP
-  else if (image == 9 && (color_mode == 1 || color_mode == 5)) vcol = color;  // COLOR_MODE_SUBPX_DUAL_SOURCE / MULTIPLY_DUAL_SOURCE
-  else if ((color_mode == 0 || color_mode == 2) && image != 9) {
+  else if ((image == 9 || image == 11) && (color_mode == 1 || color_mode == 5)) vcol = color;  // COLOR_MODE_SUBPX_DUAL_SOURCE / MULTIPLY_DUAL_SOURCE
+  else if ((color_mode == 0 || color_mode == 2) && image != 9 && image != 11) {
     // COLOR_MODE_ALPHA / COLOR_MODE_BITMAP_SHADOW with SWGL_BLEND (brush_image.glsl:281-291): what drop shadows of pictures are
     // drawn with (ShaderColorMode::Alpha, prim_store/picture.rs) -- swgl_blendDropShadow(image_data.color): the texel is committed
     // with v_color = 1 and the shadow colour travels in the blend stage, per primitive (blend.h:680-685), as for text
@@ -983,7 +984,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   else { o.kind = WR_PK_UNSUPPORTED; return; }                                // (the dual-source key with a drop-shadow mode: not a combination the batcher makes)
   o.color = vcol;
   o.tail_modulate = 1;
-  if (image == 9) {
+  if (image == 9 || image == 11) {
     // ALPHA_PASS + DUAL_SOURCE_BLENDING (brush_image.glsl:296-311, 369-386): no span function, the texel is not swizzled,
     // and main() writes oFragBlend = alpha_mask * v_mask_swizzle.x + alpha_mask.aaaa * v_mask_swizzle.y beside the colour
     o.dual = color_mode == 5 ? 2 : 1;
@@ -2401,9 +2402,12 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   // swgl_antiAlias only takes effect when blending is on (ClipRect ctor, rasterize.h:414-441)
   const bool aa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
   // textured kinds that can ride on WrQuadRec (general quads, swgl_antiAlias) when the host gave the launch the path for it
+  // (the dual-source programs have no general-quad / anti-aliased path: reported)
+  if (o.dual && ((o.aa_edges != 0 && d.blend != WR_BLEND_NONE) || persp)) { P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return; }
   const bool texq = (d.flags & WR_DF_QUADS) &&
                     (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT ||
-                     o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked));
+                     o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked) ||
+                     (o.kind == WR_PK_MIX_BLEND && !persp));
   if (aa && (o.kind != WR_PK_SOLID || masked) && !texq) {      // AA on masked solids / other shader families: "next"
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
@@ -2420,7 +2424,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
     }
     // the base kind's side record: the vertex stage left it in the (shared) WrAux slot the quad record is about to take
-    union { WrRepeatRec rep; WrGradRec grad; WrFilterRec filt; WrClipRec clip; } base;
+    union { WrRepeatRec rep; WrGradRec grad; WrFilterRec filt; WrClipRec clip; WrMixRec mix; } base;
+    if (o.kind == WR_PK_MIX_BLEND) base.mix = auxp->mix;
     if (o.kind == WR_PK_TEX_REPEAT) base.rep = auxp->rep;
     else if (o.kind == WR_PK_GRADIENT) base.grad = auxp->grad;
     else if (o.kind == WR_PK_FILTER) base.filt = auxp->filt;
@@ -2438,6 +2443,10 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       St.vp[0] = d.vp_origin[0]; St.vp[1] = d.vp_origin[1]; St.vp[2] = d.vp_size[0]; St.vp[3] = d.vp_size[1];
       auxp->quad.nseg = -1;
       bx0 = int(cx0); by0 = int(cy0); bx1 = int(cx0) + 1; by1 = int(cy0) + 1;      // (a placeholder box: replaced by the walk's)
+    }
+    else if (o.kind == WR_PK_MIX_BLEND) {
+      // brush_mix_blend's second varying (v_src_uv) rides in the walk's z / w slots
+      if (!wr_quad_walk(sx, sy, qu, qv, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1, o.u2, o.v2, true)) return;
     }
     else if (!wr_quad_walk(sx, sy, qu, qv, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1, pz3, pw3, persp)) return;
     // 1: a program without varyings (brush_solid): glsl-to-cxx wires its perspective entry points to the plain ones, which never
@@ -2463,6 +2472,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     else if (o.kind == WR_PK_GRADIENT) auxp->quad.grad = base.grad;
     else if (o.kind == WR_PK_FILTER) auxp->quad.filt = base.filt;
     else if (o.kind == WR_PK_QUAD_MASK) auxp->quad.clip = base.clip;
+    else if (o.kind == WR_PK_MIX_BLEND) auxp->quad.mix = base.mix;
     if (masked) P.flags |= WR_PF_MASKED;
     if (o.has_color) { P.flags |= WR_PF_HAS_COLOR; wr_pack_color(o.color, P.color); }
     if (o.tail_clamp) P.flags |= WR_PF_TAIL_CLAMP;
@@ -3473,6 +3483,29 @@ __device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatR
   const WrTexRow r = wr_tex_row(*Pp, t, y, runs, x, Rp->no_span != 0);
   return wr_repeat_pixel_row(*Pp, *Rp, t, r, x - r.x0);
 }
+// ... under the DUAL_SOURCE_BLENDING key (brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION): main() on every pixel --
+// compute_repeated_uvs, the clamp, texture() -- and both colours into the dual-source blend; returns the blended pixel
+WR_DEVICE uint32_t wr_dual_blend(const WrPrim& P, const WrDrawDesc* D, int x, int y, uint32_t dstp, const float (&tx)[4]);
+WR_DEVICE void wr_texture_rgba_f(const WrTexDesc& t, float cu, float cv, float (&c)[4]);
+__device__ __noinline__ uint32_t wr_repeat_dual_pixel(const WrPrim* Pp, const WrRepeatRec* Rp, const WrDrawDesc* D, int x, int y, uint32_t dstp,
+                                                      const WrRuns* runs = nullptr) {
+  const WrPrim& P = *Pp; const WrRepeatRec& R = *Rp;
+  const WrTexDesc& t = D->tex[P.tex_slot];
+  const WrTexRow r = wr_tex_row(P, t, y, runs, x, true);
+  const int n = x - r.x0, lane = n & 3, m = n >> 2;
+  float lu = wr_pick4(r.lu, lane), lv = wr_pick4(r.lv, lane);
+  lu = wr_accum(lu, (r.su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (r.sv * 4.0f) * 1.0f, m);
+  // compute_repeated_uvs (brush_image.glsl:318-341), ALPHA_PASS branch; then the clamp to v_uv_sample_bounds (wr_repeat_main)
+  const float usx = R.uv_repeat[2] - R.uv_repeat[0], usy = R.uv_repeat[3] - R.uv_repeat[1];
+  const float cu = wr_max(lu, 0.0f), cv = wr_max(lv, 0.0f);
+  float ru = (cu - floorf(cu)) * usx + R.uv_repeat[0], rv = (cv - floorf(cv)) * usy + R.uv_repeat[1];
+  if (cu >= R.tile_repeat[0]) ru = R.uv_repeat[2];
+  if (cv >= R.tile_repeat[1]) rv = R.uv_repeat[3];
+  ru = wr_clamp(ru, P.uv_bounds[0], P.uv_bounds[2]); rv = wr_clamp(rv, P.uv_bounds[1], P.uv_bounds[3]);
+  float tx[4];
+  wr_texture_rgba_f(t, ru, rv, tx);
+  return wr_dual_blend(P, D, x, y, dstp, tx);
+}
 
 // Compact raster record.  Solid prims on RGBA8 targets drawn without blending
 // or with premultiplied-alpha blending of a valid premultiplied colour are
@@ -3652,6 +3685,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     case WR_SH_BRUSH_OPACITY_ALPHA: wr_vs_brush(d, arena, inst, 7, o); break;
     case WR_SH_BRUSH_IMAGE_REPEAT: wr_vs_brush(d, arena, inst, 5, o, nullptr, nullptr, &aux[gid].rep); break;
     case WR_SH_BRUSH_IMAGE_REPEAT_ALPHA: wr_vs_brush(d, arena, inst, 6, o, nullptr, nullptr, &aux[gid].rep); break;
+    case WR_SH_BRUSH_IMAGE_REPEAT_DUAL: wr_vs_brush(d, arena, inst, 11, o, nullptr, nullptr, &aux[gid].rep); break;
     case WR_SH_BRUSH_LINEAR_GRADIENT:
     case WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA: wr_vs_brush(d, arena, inst, 3, o, &aux[gid].grad); break;
     case WR_SH_BRUSH_BLEND:
@@ -4327,7 +4361,7 @@ WR_DEVICE void wr_quad_row_edges(const WrQuadRec& Q, int si, int y, WrQuadRowCac
     for (int i = 0; i < dy; i++) {
       L.xl = L.xl + S.ls; L.xr = L.xr + S.rs;
       L.lu = L.lu + S.luvs[0]; L.lv = L.lv + S.luvs[1]; L.ru = L.ru + S.ruvs[0]; L.rv = L.rv + S.ruvs[1];
-      if (Q.pad) {
+      if (Q.pad || Q.base_kind == WR_PK_MIX_BLEND) {
         L.wl = L.wl + Q.persp.lws[si]; L.wr = L.wr + Q.persp.rws[si];
         L.zl = L.zl + Q.persp.lzs[si]; L.zr = L.zr + Q.persp.rzs[si];
       }
@@ -4337,7 +4371,7 @@ WR_DEVICE void wr_quad_row_edges(const WrQuadRec& Q, int si, int y, WrQuadRowCac
     L.lu = wr_accum(S.luv[0], S.luvs[0], y - S.lrow); L.lv = wr_accum(S.luv[1], S.luvs[1], y - S.lrow);
     L.ru = wr_accum(S.ruv[0], S.ruvs[0], y - S.rrow); L.rv = wr_accum(S.ruv[1], S.ruvs[1], y - S.rrow);
     L.wl = L.wr = L.zl = L.zr = 0.0f;
-    if (Q.pad) {
+    if (Q.pad || Q.base_kind == WR_PK_MIX_BLEND) {
       L.wl = wr_accum(Q.persp.lw[si], Q.persp.lws[si], y - S.lrow); L.wr = wr_accum(Q.persp.rw[si], Q.persp.rws[si], y - S.rrow);
       L.zl = wr_accum(Q.persp.lz[si], Q.persp.lzs[si], y - S.lrow); L.zr = wr_accum(Q.persp.rz[si], Q.persp.rzs[si], y - S.rrow);
     }
@@ -4404,6 +4438,29 @@ WR_DEVICE WrWide wr_mask_src(const WrPrim& P, const WrDrawDesc* D, int x, int y,
   return r;
 }
 
+// brush_image ... DUAL_SOURCE_BLENDING under GL_ONE, GL_ONE_MINUS_SRC1_COLOR (blend.h:496-511): main() writes the colour
+// v_color * texel and a second one, texel * swizzle.x + texel.aaaa * swizzle.y; dst' = src + dst - dst x second (under a clip
+// mask both terms are scaled by it).  `tx`: the texel main() sampled, (r, g, b, a) floats.
+WR_DEVICE uint32_t wr_dual_blend(const WrPrim& P, const WrDrawDesc* D, int x, int y, uint32_t dstp, const float (&tx)[4]) {
+  const float sx = P.dual_swz, sy = P.dual == 2 ? -P.dual_swz : 0.0f;
+  uint32_t pc[2], ps[2];
+  wr_pack_color(wf4{P.fcolor[0] * tx[0], P.fcolor[1] * tx[1], P.fcolor[2] * tx[2], P.fcolor[3] * tx[3]}, pc);
+  wr_pack_color(wf4{tx[0] * sx + tx[3] * sy, tx[1] * sx + tx[3] * sy, tx[2] * sx + tx[3] * sy, tx[3] * sx + tx[3] * sy}, ps);
+  WrWide s2; s2.bg = pc[0]; s2.ra = pc[1];
+  const WrWide dst = wr_unpack(dstp);
+  WrWide second; second.bg = wr_muldiv255_2(ps[0], dst.bg); second.ra = wr_muldiv255_2(ps[1], dst.ra);    // applyColor(dst, secondary)
+  if (P.flags & WR_PF_MASKED) {
+    const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
+    const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
+    const uint32_t mm = m | (m << 16);
+    s2.bg = wr_muldiv255_2(s2.bg, mm); s2.ra = wr_muldiv255_2(s2.ra, mm);
+    second.bg = wr_muldiv255_2(second.bg, mm); second.ra = wr_muldiv255_2(second.ra, mm);
+  }
+  WrWide res;
+  res.bg = wr_sub2(wr_add2(s2.bg, dst.bg), second.bg);
+  res.ra = wr_sub2(wr_add2(s2.ra, dst.ra), second.ra);
+  return wr_pack(res);
+}
 // Generic (slow-path) pixel: any prim kind / blend key, one pixel at a time.
 // Kept out of line so the fast paths below stay small and the 16 pixels of a
 // lane stay in registers.
@@ -4420,33 +4477,14 @@ __device__ __noinline__ uint32_t wr_generic_pixel_rgba8(const WrPrim* Pp, const 
     WrWide mm; mm.bg = mm.ra = m | (m << 16);
     src = wr_apply_color(mm, P.color);
   } else if (P.dual && P.kind == WR_PK_TEX_FS && P.blend == WR_BLEND_DUAL_SRC) {
-    // brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under GL_ONE, GL_ONE_MINUS_SRC1_COLOR (blend.h:496-511): main() writes the
-    // colour v_color * texel and a second one, texel * swizzle.x + texel.aaaa * swizzle.y; dst' = src + dst - dst x second
-    // (under a clip mask both terms are scaled by it)
+    // brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING under GL_ONE, GL_ONE_MINUS_SRC1_COLOR (wr_dual_blend)
     const WrTexDesc& t = D->tex[P.tex_slot];
     const WrTexRow r = wr_tex_row(P, t, y, runs, x);
     float cu, cv;
     wr_tex_tail_uv(P, r, x - r.x0, cu, cv);
     float tx[4];
     wr_texture_rgba_f(t, cu, cv, tx);
-    const float sx = P.dual_swz, sy = P.dual == 2 ? -P.dual_swz : 0.0f;
-    uint32_t pc[2], ps[2];
-    wr_pack_color(wf4{P.fcolor[0] * tx[0], P.fcolor[1] * tx[1], P.fcolor[2] * tx[2], P.fcolor[3] * tx[3]}, pc);
-    wr_pack_color(wf4{tx[0] * sx + tx[3] * sy, tx[1] * sx + tx[3] * sy, tx[2] * sx + tx[3] * sy, tx[3] * sx + tx[3] * sy}, ps);
-    WrWide s2; s2.bg = pc[0]; s2.ra = pc[1];
-    const WrWide dst = wr_unpack(dstp);
-    WrWide second; second.bg = wr_muldiv255_2(ps[0], dst.bg); second.ra = wr_muldiv255_2(ps[1], dst.ra);    // applyColor(dst, secondary)
-    if (P.flags & WR_PF_MASKED) {
-      const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
-      const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
-      const uint32_t mm = m | (m << 16);
-      s2.bg = wr_muldiv255_2(s2.bg, mm); s2.ra = wr_muldiv255_2(s2.ra, mm);
-      second.bg = wr_muldiv255_2(second.bg, mm); second.ra = wr_muldiv255_2(second.ra, mm);
-    }
-    WrWide res;
-    res.bg = wr_sub2(wr_add2(s2.bg, dst.bg), second.bg);
-    res.ra = wr_sub2(wr_add2(s2.ra, dst.ra), second.ra);
-    return wr_pack(res);
+    return wr_dual_blend(P, D, x, y, dstp, tx);
   } else {
     src = wr_mask_src(P, D, x, y, wr_tex_pixel(P, D->tex[P.tex_slot], x, y, runs));
   }
@@ -4460,6 +4498,7 @@ __device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRe
 __device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDrawDesc* D, float lu, float lv);
 __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+__device__ __noinline__ WrWide wr_mix_blend_pixel(const WrPrim* Pp, const WrMixRec* Mp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 __device__ __noinline__ WrWide wr_svg_filter_pixel(const WrPrim* Pp, const WrSvgRec* Sp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 WR_DEVICE float wr_r8_texture(const WrTexDesc& t, float u, float v);
 WR_DEVICE WrWide wr_quad_mask_eval(const WrClipRec& C, float f0x, float f0y, float f1x, float f1y, float qx, float qy);
@@ -4589,6 +4628,16 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     else if (Q.base_kind == WR_PK_GRADIENT) src = wr_gradient_main(&Q.grad, D, cu, cv);
     else src = wr_tex_tail_texel(Pl, t, cu, cv);
     }
+  } else if (Q.base_kind == WR_PK_MIX_BLEND) {
+    // brush_mix_blend on a rotated / skewed (or anti-aliased) quad: this row as a one-row axis-aligned prim, both varyings -- the
+    // backdrop's uv from the walk's uv edges, the source's from its z / w slots
+    Pl.uvL0[0] = Lu; Pl.uvL0[1] = Lv; Pl.uvR0[0] = Ru; Pl.uvR0[1] = Rv;
+    Pl.uvLs[0] = Pl.uvLs[1] = Pl.uvRs[0] = Pl.uvRs[1] = 0.0f;
+    Pl.xl = xl; Pl.xr = xr; Pl.x0 = s0; Pl.x1 = s1; Pl.y0 = y; Pl.y1 = y + 1; Pl.rows_linear = 1;
+    WrMixRec M2 = Q.mix;
+    M2.sL0[0] = E.zl; M2.sL0[1] = E.wl; M2.sR0[0] = E.zr; M2.sR0[1] = E.wr;
+    M2.sLs[0] = M2.sLs[1] = M2.sRs[0] = M2.sRs[1] = 0.0f;
+    src = wr_mix_blend_pixel(&Pl, &M2, D, x, y, runs);
   } else if (Q.base_kind == WR_PK_GRADIENT || Q.base_kind == WR_PK_FILTER || Q.base_kind == WR_PK_QUAD_MASK) {
     // shader replays that take their interpolants from the prim: hand them this row as a one-row axis-aligned prim (the span
     // [s0, s1), the edges' x and interpolants on this row, no row stepping left to do)
@@ -7493,6 +7542,11 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       }
       if (!in) continue;
       const WrRuns* rq = rr ? &rr[py + 4 * (q >> 2) - wy0] : nullptr;
+      if (kind == WR_PK_TEX_REPEAT && Pp->dual && blend == WR_BLEND_DUAL_SRC) {      // (the dual-source repetition key: the blend takes two colours)
+        const uint32_t r2 = wr_repeat_dual_pixel(Pp, &Ap->rep, D, px + (q & 3), py + 4 * (q >> 2), plo[q] | (phi[q] << 8), rq);
+        plo[q] = r2 & WR_M8; phi[q] = (r2 >> 8) & WR_M8;
+        continue;
+      }
       const WrWide raw = kind == WR_PK_FILTER ? wr_filter_pixel(Pp, &Ap->filt, D, px + (q & 3), py + 4 * (q >> 2), rq)
                          : kind == WR_PK_MIX_BLEND ? wr_mix_blend_pixel(Pp, &Ap->mix, D, px + (q & 3), py + 4 * (q >> 2), rq)
                          : kind == WR_PK_YUV ? wr_yuv_pixel(Pp, &Ap->yuv, D, px + (q & 3), py + 4 * (q >> 2), rq)

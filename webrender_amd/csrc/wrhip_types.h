@@ -82,6 +82,7 @@ enum WrShader {
   WR_SH_BRUSH_YUV_ALPHA,           // ... ALPHA_PASS
   WR_SH_COMPOSITE_YUV,             // composite TEXTURE_2D,YUV (video surfaces composited straight into the window: composite.rs ExternalSurfaceDependency::Yuv)
   WR_SH_CS_SVG_FILTER,             // cs_svg_filter: one node of a CSS / SVG filter chain (render_target.rs:901-990, renderer/mod.rs:2527-2554)
+  WR_SH_BRUSH_IMAGE_REPEAT_DUAL,   // brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D (shader_features.rs:166-170)
   WR_SH_CS_SVG_FILTER_NODE,        // cs_svg_filter_node: one node of an SVG filter graph (render_target.rs:1000-1170, renderer/mod.rs:2556-2583)
   WR_SH_CLEAR_OP,  // internal: glClear recorded as an ordered draw
   WR_SH_COUNT
@@ -544,6 +545,8 @@ struct WrQuadRec {
     WrGradRec grad;                 // WR_PK_GRADIENT
     WrFilterRec filt;               // WR_PK_FILTER
     WrClipRec clip;                 // WR_PK_QUAD_MASK
+    WrMixRec mix;                   // WR_PK_MIX_BLEND (rotations / skews only): op and the source's sample bounds; the second varying's edges
+                                    // travel in `persp`'s z / w slots (z = u, w = v of v_src_uv: Point3D edges step exactly like interpolants)
   };
   WrPerspRec persp;                 // pad != 0: screen z and 1 / w of the runs' edges (beside the base kind's record: filters and gradients
                                     // under perspective need both)

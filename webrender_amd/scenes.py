@@ -505,7 +505,10 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
 # than the primitive, and border-image style segments (BRUSH_FLAG_SEGMENT_RELATIVE with the REPEAT_X/Y,
 # *_ROUND and *_CENTERED flags, with and without a texel rect).  `nearest` switches the atlas sampler to
 # GL_NEAREST (blendTextureNearestRepeat instead of blendTextureLinearRepeat).
-def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=False, tile_filter=None, only=None, translucent=True):
+def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=False, tile_filter=None, only=None, translucent=True, dual=False):
+    """`dual`: the alpha-pass prims go through "brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D" under the
+    dual-source blend state (what a repeated image in a BlendMode::SubpixelDualSource / MultiplyDualSource batch is drawn with), colour
+    modes SUBPX_DUAL_SOURCE / MULTIPLY_DUAL_SOURCE / IMAGE in turn, a brush colour other than white"""
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -604,10 +607,14 @@ def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=Fals
             if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
                 continue
             blocks = [[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [pr["stretch"][0], pr["stretch"][1], 0.0, 0.0]]
+            ud = (4 | (1 << 16), 0, int(round(pr["opacity"] * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
+            if dual and not pr["opaque"]:
+                a = (0.35, 0.6, 0.85, 1.0)[zi % 4]
+                blocks[0] = [((zi * 37) % 256) / 255.0 * a, ((zi * 91) % 256) / 255.0 * a, ((zi * 53) % 256) / 255.0 * a, a]
+                ud = ((1, 5, 4)[zi % 3] | (1 << 16), 0, int(round(pr["opacity"] * 65535.0)), 0)
             for (srect, sdata, _) in (pr["segs"] or []):
                 blocks += [list(srect), list(sdata)]
             spec = frame.gpu_cache.push(blocks)
-            ud = (4 | (1 << 16), 0, int(round(pr["opacity"] * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
             ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, ud)
             dst = op if pr["opaque"] else al
             if pr["segs"] is None:
@@ -619,8 +626,9 @@ def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=Fals
             target.opaque.append(Step("brush_image ANTIALIASING,REPETITION,TEXTURE_2D", "PRIM_INSTANCES",
                                       np.array(op[::-1], dtype=np.int32), None, "opaque", textures={0: t_atlas}))
         if al:
-            target.alpha.append(Step("brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", "PRIM_INSTANCES",
-                                     np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+            target.alpha.append(Step("brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D" if dual else
+                                     "brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D", "PRIM_INSTANCES",
+                                     np.array(al, dtype=np.int32), "SubpixelDualSource" if dual else "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
         clip = (float(x0), float(y0), float(min(x1, width)), float(min(y1, height)))
@@ -1775,7 +1783,7 @@ def mix_blend_swatches(seed=201):
     return frame
 
 
-def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, only=None, fractional=True, masked=False):
+def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, only=None, fractional=True, masked=False, rotate=False, force_aa=False):
     """Overlapping, scaled, fractionally placed brush_mix_blend prims over the tile grid: backdrop and source pictures of
     different sizes (linear filtering on both), sub-quads in homogeneous coordinates on some sources, every mode."""
     rng = np.random.default_rng(seed)
@@ -1813,11 +1821,18 @@ def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, on
         else:
             px, py = float(rng.uniform(0, width - w)), float(rng.uniform(0, height - 30))
         prims.append(((px, py, px + w, py + h), 1 + k % 16, a_b, a_s))
+    # rotate: two prims out of three sit under a rotation / skew about their centre (mix-blend-mode on a rotated stacking context:
+    # the general-quad path with swgl_antiAlias on all four edges); force_aa: BRUSH_FLAG_FORCE_AA on axis-aligned ones
+    tids = [0] * len(prims)
+    if rotate:
+        for k, pr in enumerate(prims):
+            if k % 3 != 1:
+                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k)
     t_mask, clip_tasks = None, [None] * len(prims)
     if masked:
         t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
         frame.static_textures.append(t_mask)
-        clip_tasks = prim_clip_tasks(rng, [p[0] for p in prims], 1024, True)
+        clip_tasks = prim_clip_tasks(rng, [rotated_bounds(p[0]) if tids[k] else p[0] for k, p in enumerate(prims)], 1024, True)
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
@@ -1830,12 +1845,13 @@ def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, on
         for zi, (rect, mode, a_b, a_s) in enumerate(prims):
             if only is not None and zi not in only:
                 continue
-            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+            bb = rotated_bounds(rect) if tids[zi] else rect
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
-            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, 0, task, (mode, a_b, a_s, 0))
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, tids[zi], task, (mode, a_b, a_s, 0))
             ct = clip_tasks[zi]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
-            al.append(frame.brush_instance(ph, clip_addr, edge_flags=15))
+            al.append(frame.brush_instance(ph, clip_addr, edge_flags=15, brush_flags=1024 if (force_aa and zi % 2 == 0 and not tids[zi]) else 0))
         if al:
             target.alpha.append(Step("brush_mix_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
                                      "PremultipliedAlpha", "alpha", textures={0: t_b, 1: t_s, 9: t_mask} if masked else {0: t_b, 1: t_s}))
