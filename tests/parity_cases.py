@@ -329,6 +329,32 @@ YUV = [
 ]
 
 
+# The TEXTURE_RECT keys (brush_image x 8, brush_yuv_image x 2, composite x 3, cs_scale): the rectangle-texture twins of scenes of
+# those families (scenes.texture_rect: sampler2DRect samplers bound through GL_TEXTURE_RECTANGLE, unnormalised uv).  Each case also
+# has to differ from its TEXTURE_2D twin where the shaders differ (v_uv_bounds of brush_image, the composite fast path's bounds).
+TEXTURE_RECT = [
+    ("rect_image_grid", lambda: scenes.texture_rect(scenes.image_grid(seed=61))),
+    ("rect_image_grid_nearest", lambda: scenes.texture_rect(scenes.image_grid(seed=62, nearest=True))),
+    ("rect_image_grid_masked", lambda: scenes.texture_rect(scenes.image_grid(seed=63, masked=True))),
+    ("rect_image_repeat", lambda: scenes.texture_rect(scenes.image_repeat(seed=64))),
+    ("rect_image_repeat_nearest", lambda: scenes.texture_rect(scenes.image_repeat(seed=65, nearest=True))),
+    ("rect_image_dual", lambda: scenes.texture_rect(scenes.image_grid(dual=True, seed=66))),
+    ("rect_image_repeat_dual", lambda: scenes.texture_rect(scenes.image_repeat(dual=True, seed=67))),
+    ("rect_image_shadows", lambda: scenes.texture_rect(scenes.image_grid(shadows=True, seed=68))),
+    ("rect_rotated_images", lambda: scenes.texture_rect(scenes.rotated_images(seed=69))),
+    ("rect_rotated_images_repeat", lambda: scenes.texture_rect(scenes.rotated_images(seed=70, repeat=True))),
+    ("rect_occluded_image_grid", lambda: scenes.texture_rect(scenes.add_occluders(scenes.image_grid(seed=71), zmax=200, seed=43))),
+    ("rect_yuv_grid", lambda: scenes.texture_rect(scenes.yuv_grid(seed=306, planar=False))),      # NV12 (planar + linear: reported, see the test below)
+    ("rect_yuv_grid_nearest", lambda: scenes.texture_rect(scenes.yuv_grid(seed=307, nearest=True))),
+    ("rect_yuv_grid_10bit", lambda: scenes.texture_rect(scenes.yuv_grid(seed=308, hdr=True, planar=False))),      # P010
+    ("rect_yuv_composites", lambda: scenes.texture_rect(scenes.yuv_composites(seed=313, planar=False))),
+    ("rect_yuv_composites_nearest", lambda: scenes.texture_rect(scenes.yuv_composites(seed=314, nearest=True))),
+    ("rect_scaled_composites", lambda: scenes.texture_rect(scenes.scaled_composites(seed=22))),
+    ("rect_blur_chain_scaled", lambda: scenes.texture_rect(scenes.blur_chain(fmt="rgba8", scale_steps=2, content=(150, 97), sigma=3.0), composites=False)),
+    ("rect_blur_chain_r8", lambda: scenes.texture_rect(scenes.blur_chain(fmt="r8", scale_steps=2, content=(166, 140), sigma=2.5), composites=False)),
+]
+
+
 # cs_svg_filter / cs_svg_filter_node: every filter kind main() has a case for (and kinds it has none for), two chained colour
 # targets, 1:1 / scaled / fractionally offset inputs; linear and nearest input samplers
 SVG_FILTERS = [

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -426,6 +426,23 @@ def test_hip_yuv_images_match_oracle(name, make):
     got, st = render_direct(wrhip_lib(), make())
     assert st["gl_error"] == 0 and (want != 255).any()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,make", TEXTURE_RECT, ids=[c[0] for c in TEXTURE_RECT])
+def test_hip_texture_rect_keys_match_oracle(name, make):
+    """The TEXTURE_RECT keys (parity_cases.TEXTURE_RECT) on the MI355X: 0 differing bytes in every target read back"""
+    ref = oracle_ref()
+    if not ref:
+        pytest.skip("oracle not built")
+    want, _ = render_direct(ref, make())
+    got, st = render_direct(wrhip_lib(), make())
+    assert st["gl_error"] == 0
+    if isinstance(want, dict):
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+    else:
+        assert (want != 255).any()
+        assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("name,make", SVG_FILTERS, ids=[c[0] for c in SVG_FILTERS])

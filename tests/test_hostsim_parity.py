@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -354,6 +354,41 @@ def test_hostsim_yuv_images_match_oracle(hostsim, oracle_gcc, name, make):
     got, st = render_direct(hostsim, make())
     assert st["gl_error"] == 0 and (want != 255).any()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,make", TEXTURE_RECT, ids=[c[0] for c in TEXTURE_RECT])
+def test_hostsim_texture_rect_keys_match_oracle(hostsim, oracle_gcc, name, make):
+    """The TEXTURE_RECT keys of brush_image / brush_yuv_image / composite / cs_scale (parity_cases.TEXTURE_RECT): sampler2DRect samplers
+    bound through GL_TEXTURE_RECTANGLE, unnormalised uv.  0 differing bytes against the reference's generated programs, in every
+    target read back."""
+    want, _ = render_direct(oracle_gcc, make())
+    got, st = render_direct(hostsim, make())
+    assert st["gl_error"] == 0
+    if isinstance(want, dict):
+        assert set(got) == set(want)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+        assert any(w.any() for w in want.values())
+    else:
+        assert (want != 255).any()
+        assert np.array_equal(got, want)
+
+
+def test_hostsim_texture_rect_key_is_not_the_2d_key(hostsim):
+    """A rectangle-texture program reads the unit's GL_TEXTURE_RECTANGLE binding, not its GL_TEXTURE_2D one: the same frame under the
+    2D keys with nothing bound to GL_TEXTURE_2D... is not what this checks -- it checks that the REPETITION key's v_uv_bounds
+    (the whole texture under TEXTURE_RECT, brush_image.glsl:254-258) makes the two keys draw different pixels."""
+    a, _ = render_direct(hostsim, scenes.texture_rect(scenes.image_repeat(seed=64)))
+    b, _ = render_direct(hostsim, scenes.image_repeat(seed=64))
+    assert (a != b).sum() > 10000
+
+
+def test_hostsim_planar_yuv_under_a_rect_key_is_reported(hostsim, capfd):
+    """Three linear sampler2DRect planes take blendYUV's CompositeYUV-backed overload in the reference (swgl_ext.h:1195-1283), which the
+    raster stage does not restate: such prims are counted and surface as GL_INVALID_OPERATION at Finish, never drawn differently."""
+    _, st = render_direct(hostsim, scenes.texture_rect(scenes.yuv_grid(seed=306)))
+    assert st["gl_error"] == 0x0502          # GL_INVALID_OPERATION
+    assert "not reproduced exactly" in capfd.readouterr().err
 
 
 @pytest.mark.parametrize("name,make", SVG_FILTERS, ids=[c[0] for c in SVG_FILTERS])

@@ -265,6 +265,7 @@ struct ShaderInfo {
   const char* key; int kind;
   const char* attribs[WR_MAX_ATTRIBS + 2];   // [0] = per-vertex aPosition, then instance attributes in shader order
   unsigned samplers;         // bit s set: program declares the sampler of slot s
+  bool rect = false;         // a TEXTURE_RECT key: sColor0-2 are sampler2DRect (bound through GL_TEXTURE_RECTANGLE, unnormalised uv)
 };
 #define S(x) (1u << (x))
 const unsigned PRIM_SAMPLERS = S(WR_S_COLOR0) | S(WR_S_GPU_CACHE) | S(WR_S_TRANSFORMS) | S(WR_S_RENDER_TASKS) |
@@ -367,6 +368,28 @@ const ShaderInfo SHADERS[] = {
      {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
     {"cs_blur COLOR_TARGET", WR_SH_CS_BLUR_COLOR,
      {"aPosition", "aBlurRenderTaskAddress", "aBlurSourceTaskAddress", "aBlurDirection", "aBlurParams"}, PRIM_SAMPLERS},
+    // The TEXTURE_RECT keys (shader_features.rs:136-138, 181-198; swgl compiles them under ShaderFeatureFlags::GL): the same programs with
+    // sampler2DRect sColor0-2 -- unnormalised uv (samplerScale = 1, texture.h:440-443), texture_size = 1 in the vertex stages --
+    // bound through GL_TEXTURE_RECTANGLE: what external / IOSurface images and native compositor surfaces are drawn with.
+    {"brush_image TEXTURE_RECT", WR_SH_BRUSH_IMAGE, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_image ALPHA_PASS,TEXTURE_RECT", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_image ANTIALIASING,REPETITION,TEXTURE_RECT", WR_SH_BRUSH_IMAGE_REPEAT, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_RECT", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_RECT", WR_SH_BRUSH_IMAGE_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_RECT", WR_SH_BRUSH_IMAGE_REPEAT_DUAL, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_image ADVANCED_BLEND,ALPHA_PASS,TEXTURE_RECT", WR_SH_BRUSH_IMAGE_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_image ADVANCED_BLEND,ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_RECT", WR_SH_BRUSH_IMAGE_REPEAT_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS, true},
+    {"brush_yuv_image TEXTURE_RECT,YUV", WR_SH_BRUSH_YUV, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1) | S(WR_S_COLOR2), true},
+    {"brush_yuv_image ALPHA_PASS,TEXTURE_RECT,YUV", WR_SH_BRUSH_YUV_ALPHA, {"aPosition", "aData"}, PRIM_SAMPLERS | S(WR_S_COLOR1) | S(WR_S_COLOR2), true},
+    {"composite TEXTURE_RECT", WR_SH_COMPOSITE,
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"}, S(WR_S_COLOR0), true},
+    {"composite FAST_PATH,TEXTURE_RECT", WR_SH_COMPOSITE_FAST,
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aFlip"}, S(WR_S_COLOR0), true},
+    {"composite TEXTURE_RECT,YUV", WR_SH_COMPOSITE_YUV,
+     {"aPosition", "aDeviceRect", "aDeviceClipRect", "aColor", "aParams", "aUvRect0", "aUvRect1", "aUvRect2", "aFlip"},
+     S(WR_S_COLOR0) | S(WR_S_COLOR1) | S(WR_S_COLOR2), true},
+    {"cs_scale TEXTURE_RECT", WR_SH_CS_SCALE, {"aPosition", "aScaleTargetRect", "aScaleSourceRect", "aSourceRectType"},
+     S(WR_S_COLOR0), true},
 };
 #undef S
 const char* const SAMPLER_NAMES[WR_MAX_TEX] = {
@@ -1348,7 +1371,7 @@ static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
       continue;
     }
     seen_draw = true;
-    if (d.shader != WR_SH_COMPOSITE_FAST || d.blend != WR_BLEND_NONE || (d.flags & (WR_DF_DEPTH_TEST | WR_DF_DEPTH_WRITE)) || d.query_slot >= 0) return false;
+    if (d.shader != WR_SH_COMPOSITE_FAST || d.blend != WR_BLEND_NONE || (d.flags & (WR_DF_DEPTH_TEST | WR_DF_DEPTH_WRITE | WR_DF_TEX_RECT)) || d.query_slot >= 0) return false;
     if (d.attr_off[0] < 0 || d.attr_off[1] < 0 || d.attr_off[4] < 0 || d.attr_bytes[0] < 16 || d.attr_bytes[1] < 16 || d.attr_bytes[4] < 16) return false;
     if (d.quad[0] != 0.f || d.quad[1] != 0.f || d.quad[2] != 1.f || d.quad[3] != 0.f || d.quad[4] != 1.f || d.quad[5] != 1.f || d.quad[6] != 0.f || d.quad[7] != 1.f) return false;
     const WrTexDesc& st = d.tex[WR_S_COLOR0];
@@ -2026,7 +2049,7 @@ void AttachShader(GLuint program, GLuint shader) {
   Program& p = ctx->programs[program];
   Shader& s = ctx->shaders[shader];
   if (!p.info && s.kind != WR_SH_NONE)
-    for (const ShaderInfo& info : SHADERS) if (info.kind == s.kind) p.info = &info;
+    for (const ShaderInfo& info : SHADERS) if (!strcmp(info.key, s.name)) p.info = &info;      // (several keys share a kind: TEXTURE_RECT, ADVANCED_BLEND)
   if (!p.name[0]) memcpy(p.name, s.name, sizeof(p.name));
 }
 void DeleteShader(GLuint n) { if (n) ctx->shaders.erase(n); }
@@ -2742,9 +2765,14 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   // dependency level above it and the whole chain (masks -> blurs -> tiles -> composite) goes
   // through ONE flush -- one arena copy, one upload scatter, one setup launch, one raster launch
   // per level -- instead of a full launch sequence per pass.
+  // (sampler2DRect samplers read the unit's GL_TEXTURE_RECTANGLE binding, gl.cc:853-855)
+  auto bound_tex = [&](int s) {
+    const Context::TextureUnit& u = c->texture_units[prog->sampler_unit[s] & 15];
+    return (info->rect && (s == WR_S_COLOR0 || s == WR_S_COLOR1 || s == WR_S_COLOR2)) ? u.texture_rectangle_binding : u.texture_2d_binding;
+  };
   for (int s = 0; s < WR_MAX_TEX; s++) {
     if (!((info->samplers >> s) & 1)) continue;
-    GLuint tid = c->texture_units[prog->sampler_unit[s] & 15].texture_2d_binding;
+    GLuint tid = bound_tex(s);
     Texture* t = tid ? c->textures.find(tid) : nullptr;
     if (!t || !t->dptr || tid == color_id) continue;
     if (t->pending_write && t->pending_target >= 0)
@@ -2753,11 +2781,13 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
   Texture& colortex = c->textures[color_id];
   for (int s = 0; s < WR_MAX_TEX; s++) {
     if (!((info->samplers >> s) & 1)) continue;
-    GLuint tid = c->texture_units[prog->sampler_unit[s] & 15].texture_2d_binding;
+    GLuint tid = bound_tex(s);
     Texture* t = tid ? c->textures.find(tid) : nullptr;
     if (!t || !t->dptr || tid == color_id) continue;
     WrTexDesc& td = d.tex[s];
     td.ptr = t->dptr; td.width = t->width; td.height = t->height;
+    const bool rect_s = info->rect && (s == WR_S_COLOR0 || s == WR_S_COLOR1 || s == WR_S_COLOR2);
+    td.sw = rect_s ? 1.0f : float(t->width); td.sh = rect_s ? 1.0f : float(t->height);
     td.stride = t->bpp >= 4 ? t->stride / 4 : (t->bpp == 2 ? t->stride / 2 : t->stride);
     td.format = (int16_t)wr_format(t->internal_format);
     td.linear = (t->mag_filter == GL_LINEAR || t->mag_filter == GL_LINEAR_MIPMAP_LINEAR || t->mag_filter == GL_LINEAR_MIPMAP_NEAREST) && t->width >= 2;
@@ -2785,7 +2815,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
             c->blendfunc_sa, c->blendfunc_da, c->blend_equation);
     c->last_error = GL_INVALID_OPERATION;
   }
-  d.flags = 0;
+  d.flags = info->rect ? WR_DF_TEX_RECT : 0;
   Texture* depthtex = (c->depthtest && fb.depth_attachment) ? c->textures.find(fb.depth_attachment) : nullptr;
   if (depthtex && depthtex->internal_format == GL_DEPTH_COMPONENT24 && depthtex->depth_cleared) {
     d.flags |= WR_DF_DEPTH_TEST;
@@ -3064,6 +3094,7 @@ void CompositeYUV(LockedTexture* lockedDst, LockedTexture* lockedY, LockedTextur
   auto desc = [](const Texture& t) {
     WrTexDesc td; td.ptr = t.dptr; td.width = t.width; td.height = t.height;
     td.stride = t.bpp == 2 ? t.stride / 2 : t.stride; td.format = (int16_t)(t.bpp == 2 ? WR_FMT_R16 : WR_FMT_R8); td.linear = 1;
+    td.sw = float(t.width); td.sh = float(t.height);
     return td;
   };
   A.y = desc(yt); A.u = desc(ut); A.v = desc(vt);

@@ -386,6 +386,15 @@ WR_DEVICE bool wr_yuv_planes_ok(const WrDrawDesc& d, int format, int depth) {
   if (format == 0 || format == 1) return wide ? t1.format == WR_FMT_RG16 : (t0.format == WR_FMT_R8 && t1.format == WR_FMT_RG8 && format == 0);
   return false;
 }
+// Under the TEXTURE_RECT keys three linear sampler2DRect planes select blendYUV's second overload (swgl_ext.h:1195-1283): the
+// chunks of a span that lie inside all three clamp rects go through CompositeYUV's inner loop (linear_row_yuv: 8.8 fixed-point
+// stepping, the half-resolution chroma fast path) instead of the quantised float stepping -- different roundings.  That hybrid
+// is not restated in the raster stage yet: planar frames with linear samplers under a TEXTURE_RECT key are reported (the two-plane
+// formats -- NV12, P010, what IOSurface video is -- and nearest samplers take the shared path and are drawn).
+WR_DEVICE bool wr_yuv_rect_fast_path(const WrDrawDesc& d, int format) {
+  if (!(d.flags & WR_DF_TEX_RECT) || format != 3) return false;
+  return d.tex[WR_S_COLOR0].linear && d.tex[WR_S_COLOR1].linear && d.tex[WR_S_COLOR2].linear;
+}
 
 // ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
 // mask: 0 ps_quad_textured, 1 ps_quad_mask, 2 ps_quad_mask FAST_PATH (C = its side record)
@@ -738,7 +747,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
         const int ra = pl == 0 ? data1.x : (pl == 1 ? data1.y : data1.z);
         const wf4 res = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(ra) % 1024u), int(unsigned(ra) / 1024u));      // fetch_image_source().uv_rect
         const WrTexDesc& tex = d.tex[WR_S_COLOR0 + pl];
-        const float tsx = float(tex.ptr ? tex.width : 1), tsy = float(tex.ptr ? tex.height : 1);
+        const float tsx = tex.ptr ? tex.sw : 1.0f, tsy = tex.ptr ? tex.sh : 1.0f;      // TEX_SIZE_YUV: 1 under TEXTURE_RECT (yuv.glsl:18-22)
         for (int n = 0; n < 4; n++) {
           const float fx = (vlx[n] - local_rect.x) / (local_rect.z - local_rect.x), fy = (vly[n] - local_rect.y) / (local_rect.w - local_rect.y);
           ou[n] = ((res.z - res.x) * fx + res.x) / tsx; ov[n] = ((res.w - res.y) * fy + res.y) / tsy;
@@ -755,7 +764,8 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.tail_modulate = d.shader == WR_SH_BRUSH_YUV_ALPHA ? 1 : 0;      // (here: main() clamps the rgb to [0, 1] -- the ALPHA_PASS key, yuv.glsl:231-235)
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
     // (axis-aligned prims; the interleaved format and rotated video: reported)
-    const bool fmt_ok = planes > 0 && wr_yuv_planes_ok(d, format, depth);
+    bool fmt_ok = planes > 0 && wr_yuv_planes_ok(d, format, depth);
+    if (wr_yuv_rect_fast_path(d, format)) fmt_ok = false;
     o.kind = (fmt_ok && transform.axis_aligned && vww[0] == 1.0f && vww[1] == 1.0f && vww[2] == 1.0f && vww[3] == 1.0f) ? WR_PK_YUV : WR_PK_UNSUPPORTED;
     return;
   }
@@ -877,7 +887,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   const wf4 raw2 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(specific) % 1024u) + 2, int(unsigned(specific) / 1024u));
   float stx = raw2.x, sty = raw2.y;
   const WrTexDesc& tex = d.tex[WR_S_COLOR0];
-  const float tsx = float(tex.width), tsy = float(tex.height);
+  const float tsx = tex.sw, tsy = tex.sh;                // texture_size: vec2(1, 1) under TEXTURE_RECT (brush_image.glsl:68-74)
   const wf4 res0 = wr_fetch_f(d.tex[WR_S_GPU_CACHE], int(unsigned(resource_address) % 1024u), int(unsigned(resource_address) / 1024u));
   float uv0x = res0.x, uv0y = res0.y, uv1x = res0.z, uv1y = res0.w;
   wf4 lr = local_rect;
@@ -931,7 +941,8 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     if (brush_flags & 64) { const float t = rpx * 0.5f + 0.5f; nox = 1.0f - (t - floorf(t)); }     // SEGMENT_REPEAT_X_CENTERED
     if (brush_flags & 128) { const float t = rpy * 0.5f + 0.5f; noy = 1.0f - (t - floorf(t)); }
   }
-  const float ubx = mnx / tsx, uby = mny / tsy, ubz = mxx / tsx, ubw = mxy / tsy;                   // v_uv_bounds
+  float ubx = mnx / tsx, uby = mny / tsy, ubz = mxx / tsx, ubw = mxy / tsy;                         // v_uv_bounds
+  if (d.flags & WR_DF_TEX_RECT) { ubx = 0.0f; uby = 0.0f; ubz = float(tex.width); ubw = float(tex.height); }   // vec4(0, 0, textureSize(sColor0)), brush_image.glsl:254-255
   for (int n = 0; n < 4; n++) {
     const float fx = (vlx[n] - lr.x) / (lr.z - lr.x), fy = (vly[n] - lr.y) / (lr.w - lr.y);
     float uu = ((uv1x - uv0x) * fx + uv0x) - mnx, vv = ((uv1y - uv0y) * fy + uv0y) - mny;
@@ -1303,7 +1314,7 @@ WR_DEVICE void wr_vs_cs_scale(const WrDrawDesc& d, const uint8_t* arena, int ins
   const WrTexDesc& tex = d.tex[WR_S_COLOR0];
   wf4 uvr = {wr_min(sr.x, sr.z), wr_min(sr.y, sr.w), wr_max(sr.x, sr.z), wr_max(sr.y, sr.w)};
   const bool unnorm = int(type) == 1;
-  const float tsx = float(tex.width), tsy = float(tex.height);
+  const float tsx = tex.sw, tsy = tex.sh;                // (1, 1) under TEXTURE_RECT: the uv stay unnormalised (cs_scale.glsl:36-44)
   if (unnorm) {
     uvr = wf4{uvr.x + 0.5f, uvr.y + 0.5f, uvr.z - 0.5f, uvr.w - 0.5f};
     uvr = wf4{uvr.x / tsx, uvr.y / tsy, uvr.z / tsx, uvr.w / tsy};
@@ -1882,8 +1893,8 @@ WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int in
 #endif
   float tsx = 1.f, tsy = 1.f;
   if (unnorm) {
-    tsx = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].width : 1);
-    tsy = float(d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].height : 1);
+    tsx = d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].sw : 1.0f;        // (1 under TEXTURE_RECT, composite.glsl:136-147)
+    tsy = d.tex[WR_S_COLOR0].ptr ? d.tex[WR_S_COLOR0].sh : 1.0f;
     bounds = wf4{(bounds.x + 0.5f) / tsx, (bounds.y + 0.5f) / tsy, (bounds.z + -0.5f) / tsx, (bounds.w + -0.5f) / tsy};
   }
   for (int n = 0; n < 4; n++) {
@@ -1905,6 +1916,7 @@ WR_DEVICE void wr_vs_composite(const WrDrawDesc& d, const uint8_t* arena, int in
     o.has_color = 0;
     o.tail_clamp = 0; o.tail_modulate = 0;
     o.uv_bounds = wf4{0.f, 0.f, 1.f, 1.f};
+    if (d.flags & WR_DF_TEX_RECT) o.uv_bounds = wf4{0.f, 0.f, float(d.tex[WR_S_COLOR0].width), float(d.tex[WR_S_COLOR0].height)};   // vec4(vec2(0), textureSize(sColor0)), composite.glsl:219-223
   } else {
     o.color = aColor;
     o.tail_clamp = 1; o.tail_modulate = 1;
@@ -1944,7 +1956,7 @@ WR_DEVICE void wr_vs_composite_yuv(const WrDrawDesc& d, const uint8_t* arena, in
     if (pl < planes) {
       const wf4 res = aUvR[pl];
       const WrTexDesc& tex = d.tex[WR_S_COLOR0 + pl];
-      const float tsx = float(tex.ptr ? tex.width : 1), tsy = float(tex.ptr ? tex.height : 1);
+      const float tsx = tex.ptr ? tex.sw : 1.0f, tsy = tex.ptr ? tex.sh : 1.0f;      // TEX_SIZE_YUV: 1 under TEXTURE_RECT (yuv.glsl:18-22)
       for (int n = 0; n < 4; n++) { ou[n] = ((res.z - res.x) * fxv[n] + res.x) / tsx; ov[n] = ((res.w - res.y) * fyv[n] + res.y) / tsy; }
       bnd[0] = (res.x + 0.5f) / tsx; bnd[1] = (res.y + 0.5f) / tsy; bnd[2] = (res.z - 0.5f) / tsx; bnd[3] = (res.w - 0.5f) / tsy;
     } else {
@@ -1957,7 +1969,7 @@ WR_DEVICE void wr_vs_composite_yuv(const WrDrawDesc& d, const uint8_t* arena, in
   o.aa_edges = 0; o.has_mask = 0;
   o.tail_clamp = 1; o.tail_modulate = 0;
   o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
-  o.kind = (planes > 0 && wr_yuv_planes_ok(d, format, depth)) ? WR_PK_YUV : WR_PK_UNSUPPORTED;
+  o.kind = (planes > 0 && wr_yuv_planes_ok(d, format, depth) && !wr_yuv_rect_fast_path(d, format)) ? WR_PK_YUV : WR_PK_UNSUPPORTED;
 }
 
 // ps_clear.glsl:9-25
@@ -3167,7 +3179,7 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   r.filter = 0; r.ix = 0; r.minX = 0; r.maxX = 0; r.srow = 0;
   if (shaded) r.span = 0;
   if (r.span == 0 || P.kind == WR_PK_TEX_REPEAT) return r;
-  float W = float(t.width), H = float(t.height);
+  float W = t.sw, H = t.sh;            // samplerScale (texture.h:433-443)
   // lanes 0 and 1 of the uv vector handed to swgl_commitTexture* (shader-side offset included)
   const float p0u = r.lu[0] + P.uv_add[0], p0v = r.lv[0] + P.uv_add[1];
   const float ou1 = r.lu[1] + P.uv_add[0], ov1 = r.lv[1] + P.uv_add[1];
@@ -3240,7 +3252,7 @@ WR_DEVICE void wr_tex_tail_uv(const WrPrim& P, const WrTexRow& r, int n, float& 
 // A fragment-shader (main()) pixel of a textured prim: texture(sColor0, (cu, cv)) -> optional colour
 // modulation -> round_pixel.
 WR_DEVICE WrWide wr_tex_tail_texel(const WrPrim& P, const WrTexDesc& t, float cu, float cv) {
-  const float W = float(t.width), H = float(t.height);
+  const float W = t.sw, H = t.sh;
   const uint32_t* buf = (const uint32_t*)t.ptr;
   float tb, tg, tr, ta;
   if (P.kind == WR_PK_TEX_R8) {
@@ -3277,7 +3289,7 @@ WR_DEVICE WrWide wr_tex_tail_texel(const WrPrim& P, const WrTexDesc& t, float cu
 // One pixel of a WR_PK_TEX_RGBA8 prim on row y (returns the WideRGBA8 source,
 // colour modulation included).
 WR_DEVICE WrWide wr_tex_pixel_row(const WrPrim& P, const WrTexDesc& t, const WrTexRow& r, int n) {
-  const float W = float(t.width), H = float(t.height);
+  const float W = t.sw, H = t.sh;
   const uint32_t* buf = (const uint32_t*)t.ptr;
   if (n < r.span) {
     WrWide s;
@@ -3338,7 +3350,7 @@ WR_DEVICE WrWide wr_tex_pixel(const WrPrim& P, const WrTexDesc& t, int x, int y,
 WR_DEVICE int wr_needs_linear(const WrTexDesc& t, float p0u, float p0v, float p1u, float p1v, int span) {   // swgl_ext.h:553-587
   if (t.width < 2) return 0;
   if (p0v != p1v) return 1;
-  const float px0 = p0u * float(t.width), px1 = p1u * float(t.width), py0 = p0v * float(t.height);
+  const float px0 = p0u * t.sw, px1 = p1u * t.sw, py0 = p0v * t.sh;
   const int sp = (span & ~127) + 128;
   const int scaled = int(roundf((px1 - px0) * float(sp)));
   if (scaled != sp) return (px0 < px1 && px1 - px0 <= 1.0f) ? 2 : (scaled == sp * 2 ? 4 : 1);
@@ -3377,7 +3389,7 @@ WR_DEVICE WrWide wr_repeat_main(const WrPrim& P, const WrRepeatRec& R, const WrT
 }
 WR_DEVICE WrWide wr_repeat_pixel_row(const WrPrim& P, const WrRepeatRec& R, const WrTexDesc& t, const WrTexRow& r, int n) {
   const int span = R.no_span ? 0 : r.span;
-  const float W = float(t.width), H = float(t.height);
+  const float W = t.sw, H = t.sh;
   if (n >= span) {
     // main(): compute_repeated_uvs (brush_image.glsl:318-341), clamp to v_uv_sample_bounds, texture()
     const int lane = (n - span) & 3, m = (n - span) >> 2;
@@ -3858,6 +3870,7 @@ WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDes
 // the nearest-fast path out (scaled or subpixel-offset sampling).
 WR_DEVICE bool wr_texrow_x_setup(const WrPrim& P, const WrTexDesc& t, WrTexRec& T, WrUnsupportedCounters* cnt) {
   if (!t.ptr || P.uvLs[0] != 0.0f || P.uvRs[0] != 0.0f || P.uvL0[1] != P.uvR0[1] || P.uvLs[1] != P.uvRs[1]) return false;
+  if (t.sw != float(t.width) || t.sh != float(t.height)) return false;       // (sampler2DRect: the general row setup, WrTexRec keeps no sampler scale)
   const WrTexRow r = wr_tex_row(P, t, P.y0);       // u, su, span and the x clamps do not depend on the row here
   if (r.span == 0) return false;
   const float W = float(t.width);
@@ -4271,7 +4284,7 @@ __global__ void wr_blit_kernel(WrBlitArgs a) {
   const float lv = wr_accum(v0, dv, j);
   WrTexDesc t;
   t.ptr = a.src; t.width = a.sw; t.height = a.sh; t.stride = a.sbpp == 4 ? a.src_stride / 4 : (a.sbpp == 2 ? a.src_stride / 2 : a.src_stride);
-  t.format = a.sbpp == 4 ? WR_FMT_RGBA8 : WR_FMT_R8; t.linear = 1;
+  t.format = a.sbpp == 4 ? WR_FMT_RGBA8 : WR_FMT_R8; t.linear = 1; t.sw = float(a.sw); t.sh = float(a.sh);
   if (a.sbpp == 4) {
     const WrWide w = wr_sample_linear_rgba8(t, int(lu), int(lv));
     uint32_t o = wr_pack(w);
@@ -5073,7 +5086,7 @@ __device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRe
   const WrFilterRec& F = *Fp;
   const WrTexDesc& t = D->tex[P.tex_slot];
   // texture(sColor0, uv): texture.h:1028-1071 (linear RGBA8, 7-bit fractions) / nearest
-  const float W = float(t.width), H = float(t.height);
+  const float W = t.sw, H = t.sh;
   float cr, cg, cb, ca;
   if (!t.ptr) { cr = cg = cb = ca = 0.0f; }
   else if (t.format == WR_FMT_R8) {
@@ -5169,7 +5182,7 @@ __device__ __noinline__ WrWide wr_filter_eval(const WrPrim* Pp, const WrFilterRe
 // per pixel in strict fp32, same operation order.  The GLSL's scalar branches become selects there (every lane computes
 // both sides); the selected value is the branch's.
 WR_DEVICE void wr_texture_rgba_f(const WrTexDesc& t, float cu, float cv, float (&c)[4]) {      // texture(sampler, uv) -> (r, g, b, a)
-  const float W = float(t.width), H = float(t.height);
+  const float W = t.sw, H = t.sh;
   if (!t.ptr) { c[0] = c[1] = c[2] = c[3] = 0.0f; return; }
   if (t.format == WR_FMT_R8) {
     float m;
@@ -5552,7 +5565,7 @@ __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp
     const WrTexDesc& t = D->tex[WR_S_COLOR0 + pl];
     const WrTexRow r = wr_tex_row(P2, t, y, runs, x, !all_linear);
     const int n = x - r.x0;
-    const float W = float(t.width), H = float(t.height);
+    const float W = t.sw, H = t.sh;
     if (n < r.span) {
       const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
       float q[4], qy[4];
@@ -5817,7 +5830,7 @@ __device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* 
   for (int i = 0; i < lane; i++) { lu += su; lv += sv; }
   if (drawn > 0) { const float chunks = float(drawn) * 0.25f; lu = lu + (su * 4.0f) * chunks; lv = lv + (sv * 4.0f) * chunks; }
   lu = wr_accum(lu, (su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (sv * 4.0f) * 1.0f, m);
-  const WrTexDesc t{B.ptr, tw, th, B.stride, (int16_t)B.format, (int16_t)B.linear};
+  const WrTexDesc t{B.ptr, tw, th, B.stride, (int16_t)B.format, (int16_t)B.linear, W, H};
   auto sample = [&](float uu, float vv, float (&c)[4]) {
     // texture(sColor0, uv): linear (texture.h:1028-1071 / 576-583) or nearest
     if (B.format == WR_FMT_R8) {
@@ -6335,7 +6348,7 @@ __device__ __noinline__ WrRow4 wr_clip_rect_row4(const WrPrim* Pp, const WrClipR
 // swgl_commitPartialTextureLinear(Invert)R8 / solid centre fills -- or the
 // fragment shader (:123-138) for the tail.
 WR_DEVICE float wr_r8_texture(const WrTexDesc& t, float u, float v) {   // texture(sColor0, uv).r of an R8 sampler
-  const float W = float(t.width), H = float(t.height);
+  const float W = t.sw, H = t.sh;
   if (t.linear) return float(wr_sample_linear_r8(t, int(u * W * 128.0f + (0.5f - 64.0f)), int(v * H * 128.0f + (0.5f - 64.0f)))) * (1.0f / 255.0f);
   return float(((const uint8_t*)t.ptr)[(size_t)wr_clamp_coord(int(u * W), t.width) + (size_t)wr_clamp_coord(int(v * H), t.height) * t.stride]) * (1.0f / 255.0f);
 }
@@ -6365,7 +6378,7 @@ __device__ __noinline__ WrRow4 wr_box_shadow_row4(const WrPrim* Pp, const WrBoxR
   const WrBoxRec& B = *Bp;
   WrRow4 out;
   out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
-  const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear};
+  const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear, float(B.wh & 0xFFFF), float(B.wh >> 16)};
   float o4[4], s4[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) { o4[c] = rv.o[c]; s4[c] = rv.s[c]; }
@@ -6548,7 +6561,7 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const
                                        int part = 0, int parts = 1) {
   const int wl = lane + 64 * part, ws = 64 * parts;      // this wave's share of a run: pixels wl, wl + ws, ..
   int tchunk = 0;                                         // transitional chunks go round the parts
-  const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear};
+  const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear, float(B.wh & 0xFFFF), float(B.wh >> 16)};
   float o4[4], s4[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) { o4[c] = rv.o[c]; s4[c] = rv.s[c]; }

@@ -136,6 +136,8 @@ struct WrTexDesc {
   int32_t stride;    // in elements: bytes/4 for bpp>=4, bytes/2 for bpp 2, bytes for bpp 1 (gl.cc:883-899)
   int16_t format;    // WrTexFormat
   int16_t linear;    // TextureFilter::LINEAR (and width >= 2, gl.cc:874-880)
+  float sw, sh;      // samplerScale (texture.h:433-443): what a uv is multiplied by on its way to texels -- width / height for a
+                     // sampler2D, 1 / 1 for the sampler2DRect of a TEXTURE_RECT key (unnormalised uv); also TEX_SIZE in the vertex stages
 };
 
 enum WrDrawFlags {
@@ -149,6 +151,7 @@ enum WrDrawFlags {
   WR_DF_MASK_ROWS = 128,   // host: the cs_clip_* prims of this draw may be pre-evaluated row by row (wr_mask_rows_kernel) into the
                            // flush's mask-row store; the raster stage then only blends the stored bytes (WR_PK_MASK_ROWS)
   WR_DF_SIMPLE = 32,       // host promise: every prim of this draw is a solid with blend NONE/PREMULT (see WrFeat)
+  WR_DF_TEX_RECT = 512,    // the program is a TEXTURE_RECT key: sColor0-2 are sampler2DRect (WrTexDesc::sw / sh = 1)
   WR_DF_XFORM = 256,       // host: the transform ids this draw's prims can reference include non-axis-aligned ones (rotations, perspective)
 };
 

@@ -311,9 +311,10 @@ class Device:
             gl.DeleteFramebuffer(tex.fbo_with_depth)
         gl.DeleteTexture(tex.id)
 
-    def bind_texture(self, slot, tex_id):
+    def bind_texture(self, slot, tex_id, rect=False):
+        """rect: through GL_TEXTURE_RECTANGLE -- the binding a TEXTURE_RECT program's sampler2DRect reads (gl.cc:853-855)"""
         self.gl.ActiveTexture(G.GL_TEXTURE0 + slot)
-        self.gl.BindTexture(G.GL_TEXTURE_2D, tex_id)
+        self.gl.BindTexture(G.GL_TEXTURE_RECTANGLE if rect else G.GL_TEXTURE_2D, tex_id)
 
     def bind_draw_target(self, fbo, w, h):
         self.gl.BindFramebuffer(G.GL_DRAW_FRAMEBUFFER, fbo)

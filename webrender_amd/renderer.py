@@ -86,9 +86,10 @@ class Renderer:
     # ---- drawing -----------------------------------------------------------
     def _bind_step_textures(self, step):
         d = self.device
+        rect = "TEXTURE_RECT" in step.shader       # sColor0-2 are sampler2DRect (external / IOSurface images)
         for slot in (0, 1, 2, 9):  # Color0-2 + ClipMask, mod.rs:2066-2100
             ref = step.textures.get(slot)
-            d.bind_texture(slot, self.resolve(ref).id if ref is not None else self.dummy.id)
+            d.bind_texture(slot, self.resolve(ref).id if ref is not None else self.dummy.id, rect and slot != 9)
 
     def _draw_step(self, step, projection):
         d = self.device
@@ -176,6 +177,8 @@ class Renderer:
         opaque = [t for t in frame.composite_tiles if t.opaque]
         alpha = [t for t in frame.composite_tiles if not t.opaque]
 
+        rect = getattr(frame, "texture_rect", False)     # scenes.texture_rect: the surfaces are rectangle textures (texel uv)
+
         def draw_tile_list(tiles):
             # one batch per texture / program change (mod.rs:3260-3334)
             batch, cur = [], None
@@ -183,13 +186,15 @@ class Renderer:
                 if not batch:
                     return
                 key = "composite FAST_PATH,TEXTURE_2D" if cur[1] else ("composite TEXTURE_2D,YUV" if cur[2] else "composite TEXTURE_2D")
+                if rect:
+                    key = key.replace("TEXTURE_2D", "TEXTURE_RECT")
                 prog = d.create_program(key, "COMPOSITE")
                 vao = d.create_vao("COMPOSITE")
                 d.bind_program(prog, projection)
-                d.bind_texture(0, self.resolve(cur[0]).id)
+                d.bind_texture(0, self.resolve(cur[0]).id, rect)
                 if cur[2]:            # the chroma planes of a YUV surface (sColor1, sColor2)
                     for slot, ref in enumerate(cur[2][1:], start=1):
-                        d.bind_texture(slot, self.resolve(ref).id)
+                        d.bind_texture(slot, self.resolve(ref).id, rect)
                 d.draw_instanced_batch(vao, np.stack(batch))
             for t in tiles:
                 k = (t.texture, t.fast, tuple(t.yuv["planes"]) if t.yuv else None)
@@ -199,7 +204,7 @@ class Renderer:
                 cur = k
                 if t.yuv:
                     batch.append(frame.composite_instance(t.rect, t.clip_rect, flip=t.flip, yuv=t.yuv))
-                elif t.fast:
+                elif t.fast and not rect:
                     batch.append(frame.composite_instance(t.rect, t.clip_rect))
                 else:
                     uv = t.uv_rect or (0.0, 0.0, float(t.texture.w), float(t.texture.h))

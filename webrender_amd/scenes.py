@@ -2918,7 +2918,7 @@ def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, on
 YUV_FORMAT_NV12, YUV_FORMAT_PLANAR = 0, 3
 
 
-def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=None, nearest=False, hdr=False):
+def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=None, nearest=False, hdr=False, planar=True):
     """hdr: 10-bit video -- three R16 planes holding the low 10 bits (YUV_FORMAT_PLANAR, channel bit depth 10: the span shader
     rescales by 6 bits) and R16 + RG16 planes with the sample in the high bits (YUV_FORMAT_P010)."""
     rng = np.random.default_rng(seed)
@@ -2970,8 +2970,9 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
         if gx + w + 4 > width:
             break
         off = 0.37 if k % 5 == 1 else 0.0
-        spec = frame.gpu_cache.push([[depth, float(k % 7), fmt_semi if k % 2 else float(YUV_FORMAT_PLANAR), 0.0]])
-        prims.append(((gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), spec, (ry, rc, rc, 0), True, k % 2 == 1))
+        semi = k % 2 == 1 or not planar          # (planar=False: two-plane frames only -- NV12 / P010)
+        spec = frame.gpu_cache.push([[depth, float(k % 7), fmt_semi if semi else float(YUV_FORMAT_PLANAR), 0.0]])
+        prims.append(((gx + off, 4.0 + off, gx + off + w, 4.0 + off + h), spec, (ry, rc, rc, 0), True, semi))
         gx += float(np.ceil(w)) + 6.0
         k += 1
     for k in range(n):
@@ -2990,8 +2991,9 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
         else:
             w, h = vw * float(rng.uniform(0.3, 1.7)), vh * float(rng.uniform(0.3, 1.7))
             px, py = float(rng.uniform(0, width - w)), float(rng.uniform(band, height - h))
-        spec = frame.gpu_cache.push([[depth, float((k * 3 + 1) % 7), fmt_semi if (k // 2) % 2 else float(YUV_FORMAT_PLANAR), 0.0]])
-        prims.append(((px, py, px + w, py + h), spec, (ry, rc, rc, 0), False, (k // 2) % 2 == 1))
+        semi = (k // 2) % 2 == 1 or not planar
+        spec = frame.gpu_cache.push([[depth, float((k * 3 + 1) % 7), fmt_semi if semi else float(YUV_FORMAT_PLANAR), 0.0]])
+        prims.append(((px, py, px + w, py + h), spec, (ry, rc, rc, 0), False, semi))
     targets = []
     for (tx, ty, ox, oy) in tile_grid(width, height):
         if tile_filter is not None and not tile_filter(tx, ty):
@@ -3032,7 +3034,7 @@ def yuv_grid(width=1024, height=1024, n=60, seed=301, tile_filter=None, only=Non
     return frame
 
 
-def yuv_composites(width=1024, height=768, seed=311, nearest=False):
+def yuv_composites(width=1024, height=768, seed=311, nearest=False, planar=True):
     """Video surfaces composited straight into the window ("composite TEXTURE_2D,YUV": composite.rs ExternalSurfaceDependency::Yuv,
     renderer/mod.rs:3335-3420): planar and NV12 frames, every colour space, 1:1 / scaled / clipped / flipped, opaque and
     (premultiplied-alpha blended) on top of a picture-cache tile."""
@@ -3046,7 +3048,7 @@ def yuv_composites(width=1024, height=768, seed=311, nearest=False):
         ypl = ((xx * 255 // (w - 1)) ^ rng.integers(0, 64, size=(h, w))).astype(np.uint8)
         upl, vpl = rng.integers(0, 256, size=(h // 2, w // 2), dtype=np.uint8), rng.integers(0, 256, size=(h // 2, w // 2), dtype=np.uint8)
         t_y = TextureRef(f"video{i}_y", w, h, G.GL_R8, filt, pixels=ypl, upload_format=G.GL_RED)
-        if i % 2 == 0:
+        if i % 2 == 0 and planar:
             planes = [t_y, TextureRef(f"video{i}_u", w // 2, h // 2, G.GL_R8, filt, pixels=upl, upload_format=G.GL_RED),
                       TextureRef(f"video{i}_v", w // 2, h // 2, G.GL_R8, filt, pixels=vpl, upload_format=G.GL_RED)]
             fmt = YUV_FORMAT_PLANAR
@@ -3252,4 +3254,24 @@ def svg_filters(node=False, seed=401, atlas=1024, window=(256, 256), nearest=Fal
         tex_b, tgt_b, _ = build_pass("svg_pass_b", tex_a, t_in2, out_a[::-1], rects2[3:] + rects2[:3], 1)
         frame.passes.append([tgt_b])
         frame.readback.append(tex_b)
+    return frame
+
+
+# The TEXTURE_RECT keys (shader_features.rs:136-138, 181-198): what images, video planes and compositor surfaces backed by rectangle
+# textures (macOS IOSurfaces, external images) are drawn with -- the same batches, `sampler2DRect` samplers bound through
+# GL_TEXTURE_RECTANGLE, texel uv left unnormalised.  The frame data is the same (uv rects are texel rects either way), only the
+# program key and the texture target change, so any scene of those four families has a rectangle-texture twin.
+RECT_FAMILIES = ("brush_image", "brush_yuv_image", "composite", "cs_scale")
+
+
+def texture_rect(frame, composites=True):
+    n = 0
+    for targets in frame.passes:
+        for target in targets:
+            for step in list(target.opaque) + list(target.alpha) + list(target.steps):
+                if step.shader.split(" ")[0] in RECT_FAMILIES and "TEXTURE_2D" in step.shader:
+                    step.shader = step.shader.replace("TEXTURE_2D", "TEXTURE_RECT")
+                    n += 1
+    frame.texture_rect = bool(composites)
+    assert n > 0 or composites
     return frame
