@@ -505,6 +505,7 @@ struct Context {
     WrAux* aux = nullptr;
     float* vtab = nullptr; size_t vtab_cap = 0;   // per-row v tables of nearest-fast textured prims (WrDrawDesc::vtab_base)
     unsigned long long* masks = nullptr; size_t masks_cap = 0;
+    unsigned* bin_ctr = nullptr; size_t bin_ctr_cap = 0;   // per-bin arrival counters of thin launches that give a bin several workgroups (WrTargetDesc::bin_ctr), zero between launches
     // mask-row store (WrMaskSlot): allocation word, slot list, row bytes
     unsigned long long* mr_ctl = nullptr; WrMaskSlot* mr_slots = nullptr; size_t mr_slots_cap = 0;
     uint8_t* mr_store = nullptr; size_t mr_store_cap = 0;
@@ -579,6 +580,7 @@ struct Context {
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
+  int thin_parts = 4;                  // workgroups per bin of a thin launch (WRHIP_THIN_PARTS = 1, 2, 4, 8, 16): 16 / parts waves each, so that a wave shares its SIMD with fewer others
   bool dense_text = false;             // WRHIP_DENSE_TEXT=1: text levels run the 128-VGPR build of their variant (wr_raster_dense_kernel: four waves
                                        // per SIMD; the default until the glyph walk read 32-byte glyph records -- since then the 168-VGPR
                                        // build, which does not spill, is the faster one: cfg3 97.6 vs 102.3 us, profiles/r04_g_dense_waves_ab.txt)
@@ -596,6 +598,7 @@ struct Context {
     copy_overlap = getenv("WRHIP_NO_COPY_STREAM") == nullptr;
     forward_composites = getenv("WRHIP_NO_FORWARD") == nullptr;
     thin_r8 = getenv("WRHIP_NO_THIN") == nullptr;
+    if (const char* e = getenv("WRHIP_THIN_PARTS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) thin_parts = v; }
     dense_text = getenv("WRHIP_DENSE_TEXT") != nullptr;
     // Chained thin R8 levels (wr_raster_chain_kernel) are OFF unless WRHIP_CHAIN=1: measured on cfg4 (profiles/r03_e_chain_ab.txt),
     // the five chained levels take 144 us in one launch against ~100 us + four kernel boundaries apart -- a grid barrier that has
@@ -1156,7 +1159,7 @@ Context::~Context() {
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
   wrrt::dev_free(dupload); wrrt::dev_free(dcounters);
-  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); wrrt::dev_free(S.flat); }
+  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.bin_ctr); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); wrrt::dev_free(S.flat); }
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::event_destroy(ev_copy);
@@ -1311,7 +1314,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     const bool thin = c->thin_r8 && H.nb <= WR_THIN_MAX_BINS;
 #define WR_K1(FEAT)                                                                                                     \
   do {                                                                                                                  \
-    WR_LAUNCH((wr_raster_kernel<WR_FMT_R8, false, 1, FEAT>), H.nb, 1024, c->stream, targets, n_targets, draws,          \
+    WR_LAUNCH((wr_raster_kernel<WR_FMT_R8, false, 1, FEAT>), H.nb * c->thin_parts, 1024 / c->thin_parts, c->stream, targets, n_targets, draws,          \
               (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off); \
   } while (0)
     if (H.feat == 0) { if (thin) WR_K1(0); else WR_K(WR_FMT_R8, false, 0); }
@@ -1644,7 +1647,14 @@ void flush_work(const std::vector<int>& sel_in) {
       S.recs = (WrRec*)wrrt::dev_alloc(S.prims_cap * (sizeof(WrRec) + sizeof(WrGlyphRec)));      // recs[], then the glyph records (WrTargetDesc::grecs)
       S.aux = (WrAux*)wrrt::dev_alloc(S.prims_cap * sizeof(WrAux));
     }
-    for (WrTargetDesc& T : targets) T.grecs = (const WrGlyphRec*)(S.recs + S.prims_cap);
+    if (S.bin_ctr_cap < (size_t)n_bins) {
+      sync_stream();
+      wrrt::dev_free(S.bin_ctr);
+      S.bin_ctr_cap = (size_t)n_bins * 2;
+      S.bin_ctr = (unsigned*)wrrt::dev_alloc(S.bin_ctr_cap * sizeof(unsigned));
+      wrrt::memset8(S.bin_ctr, 0, S.bin_ctr_cap * sizeof(unsigned), c->stream);      // (the workgroups leave them at zero)
+    }
+    for (WrTargetDesc& T : targets) { T.grecs = (const WrGlyphRec*)(S.recs + S.prims_cap); T.bin_ctr = S.bin_ctr + T.first_bin; }
   }
   // Mask-row store.  When the bounds fit, no reservation of the setup stage can fail and the R8 launches take the light
   // variant (the rows kernel evaluates, the bins blend bytes); otherwise the store is capped, prims that do not fit keep their

@@ -8193,7 +8193,7 @@ template <int FMT, bool DEPTH, int R, int FEAT>
 WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
-                 unsigned long long* __restrict__ masks, const int bin) {
+                 unsigned long long* __restrict__ masks, const int bin, const int part = 0, const int parts = 1) {
   constexpr int NPX = 4 * R, STRIP = 4 * R;
   WR_CT(7);
   // the target this bin belongs to: the last one whose first bin is not beyond it
@@ -8226,11 +8226,15 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   if ((by + 1) * WR_BIN_H <= T.y_begin || by * WR_BIN_H >= T.y_end) return;      // rows of another rank (the setup stage bins nothing there)
   // the wave index is uniform across the wave: say so, or everything derived
   // from it (strip origin, coverage class of a prim) is treated as divergent
+  // (`parts` > 1, thin R8 launches only: the bin's sixteen strips are dealt out to `parts` workgroups of 16 / parts waves, so that
+  // each wave has a SIMD's issue slots to itself -- a thin launch is a few dozen waves each running one long instruction stream,
+  // and the four waves a 1024-thread workgroup puts on every SIMD take turns at its one vector issue port)
 #ifdef WRHIP_HOSTSIM
-  const int wave = threadIdx.x >> 6;
+  const int lwave = threadIdx.x >> 6;
 #else
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
+  const int wave = lwave + part * (int)(blockDim.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wx0 = bx * WR_BIN_W, wy0 = by * WR_BIN_H + wave * STRIP;
   const int px = wx0 + (lane & 15) * 4;
@@ -8534,10 +8538,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
         if (s0 < 64 && s0 + __popcll(mv) > 0) {
           int sl = s0;
           for (unsigned long long bts = mv; bts; bts &= bts - 1ull, sl++)
-            if ((unsigned)sl < 64u) pid_row[wave][sl] = T.first_prim + (wb + lane) * 64 + __builtin_ctzll(bts);
+            if ((unsigned)sl < 64u) pid_row[lwave][sl] = T.first_prim + (wb + lane) * 64 + __builtin_ctzll(bts);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        pid_ = lane < total - blk_round * 64 ? pid_row[wave][lane] : -1;
+        pid_ = lane < total - blk_round * 64 ? pid_row[lwave][lane] : -1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         dbase_ = 0;
       } else {
@@ -8577,6 +8581,19 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
   // Self-cleaning bin masks: once every wave of the workgroup has consumed the
   // bin's words, zero them so the next flush needs no memset launch.
   __syncthreads();
+  bool clean = true;
+  if (parts > 1) {
+    // several workgroups read this bin's words: the last one to have walked them cleans up (T.bin_ctr: zero between launches)
+    __shared__ int last_part;
+    if (threadIdx.x == 0) {
+      const unsigned seen = atomicAdd(&T.bin_ctr[lb], 1u);
+      last_part = seen == (unsigned)(parts - 1);
+      if (last_part) T.bin_ctr[lb] = 0u;
+    }
+    __syncthreads();
+    clean = last_part != 0;
+  }
+  if (clean)
   for (int w = threadIdx.x; w < nw; w += (int)blockDim.x) if (mw[w]) mw[w] = 0ull;      // (most words of a large target are empty already)
   }
 #endif
@@ -8659,6 +8676,11 @@ wr_raster_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
                  const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                  const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                  unsigned long long* __restrict__ masks, int bin_offset) {
+  if constexpr (R == 1) {
+    // thin launches: 1024 / blockDim.x workgroups per bin (see `parts` in wr_raster_body)
+    const int parts = 1024 / (int)blockDim.x;
+    wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)blockIdx.x / parts + bin_offset, (int)blockIdx.x % parts, parts);
+  } else
   wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, (int)blockIdx.x + bin_offset);
 }
 

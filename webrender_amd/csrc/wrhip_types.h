@@ -226,6 +226,8 @@ struct WrTargetDesc {
   uint32_t* flat_rows;
   struct WrUnsupportedCounters* counters;      // where the raster stage reports what it could not draw exactly
   const struct WrGlyphRec* grecs;              // the flush's glyph records, one per prim (global prim index), see WrGlyphRec
+  unsigned* bin_ctr;                           // one arrival counter per bin of this target (zero between launches): thin R8 launches that give
+                                               // a bin several workgroups count themselves in, the last one re-zeroes the bin's mask words
 };
 
 // Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
