@@ -59,6 +59,11 @@ def main():
     out["large-clip-rect"] = {"clip-bounds": nums(clip["bounds"]), "complex-rect": nums(clip["complex"][0]["rect"]),
                               "radius": float(clip["complex"][0]["radius"]), "rect-bounds": rects[0], "count": len(rects),
                               "color": clip["items"][0]["color"]}
+    # large-blur-radius.yaml: a stacking context with filter blur(100, 100) over one rect
+    sc = yaml.safe_load(open(os.path.join(REF, "large-blur-radius.yaml")))["root"]["items"][0]
+    assert sc["type"] == "stacking-context" and sc["filters"] == "blur(100, 100)" and len(sc["items"]) == 1 and sc["items"][0]["type"] == "rect"
+    out["large-blur-radius"] = {"bounds": nums(sc["bounds"]), "blur": [100.0, 100.0], "rect-bounds": nums(sc["items"][0]["bounds"]),
+                                "color": sc["items"][0]["color"]}
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.path.normpath(OUT), {k: (len(v) if isinstance(v, list) else v.get("count")) for k, v in out.items() if k != "source"})

@@ -289,6 +289,9 @@ DUAL_SOURCE = [
     # drop shadows of pictures: brush_image with COLOR_MODE_ALPHA / COLOR_MODE_BITMAP_SHADOW -> swgl_blendDropShadow per prim
     ("image_shadows", dict(shadows=True, seed=54)),
     ("image_shadows_masked", dict(shadows=True, masked=True, seed=55)),
+    # RasterizationSpace::Screen sources (what blurred and drop-shadow pictures are composited with): get_image_quad_uv in the vertex stage
+    ("image_screen", dict(screen=True, seed=56)),
+    ("image_screen_shadows_masked", dict(screen=True, shadows=True, masked=True, seed=57)),
     ("image_dual", dict(dual=True)),
     ("image_dual_masked", dict(dual=True, masked=True, seed=52)),
     ("image_dual_nearest", dict(dual=True, nearest=True, seed=53)),
@@ -312,6 +315,7 @@ WRENCH = [
     ("wrench_simple_batching_4k", "simple-batching", None, dict()),
     ("wrench_large_boxshadow_ellipse", "large-boxshadow-ellipse", dict(width=1536, height=1536), dict()),
     ("wrench_large_clip_rect", "large-clip-rect", dict(width=1536, height=1536), dict()),
+    ("wrench_large_blur_radius", "large-blur-radius", dict(width=1536, height=1536), dict()),
 ]
 
 # brush_yuv_image (video frames: YUV_FORMAT_PLANAR with three R8 planes, YUV_FORMAT_NV12 with R8 + RG8; the seven YuvRangedColorSpace

@@ -560,6 +560,6 @@ def test_hostsim_dual_source_images_match_oracle(hostsim, oracle_gcc, name, kw):
     ALPHA_PASS key (swgl_blendDropShadow per prim): 0 differing bytes, and not what COLOR_MODE_IMAGE draws"""
     want, _ = render_direct(oracle_gcc, scenes.image_grid(**kw))
     got, st = render_direct(hostsim, scenes.image_grid(**kw))
-    plain, _ = render_direct(oracle_gcc, scenes.image_grid(**{k: v for k, v in kw.items() if k not in ("dual", "shadows")}))
+    plain, _ = render_direct(oracle_gcc, scenes.image_grid(**{k: v for k, v in kw.items() if k not in ("dual", "shadows", "screen")}))
     assert st["gl_error"] == 0 and (want != plain).sum() > 100000
     assert np.array_equal(got, want)

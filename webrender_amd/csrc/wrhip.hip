@@ -1297,6 +1297,17 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
       else WR_KF(false, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX);
     }
   }
+  else if (H.fmt == WR_FMT_RGBA8 && !H.depth && c->thin_r8 && H.nb <= WR_THIN_MAX_BINS && H.feat != 0 && H.feat != F7) {
+    // Small colour launches without depth (a picture's blur chain: cs_scale halvings and cs_blur passes down to a single bin):
+    // as for the thin mask launches, a bin's sixteen strips go to four workgroups of four waves of 64 x 4 pixels instead of one
+    // workgroup of four waves of 64 x 16 (wrench large-blur-radius: 139 us for the one-bin blur passes)
+    if (H.feat == F5)
+      WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, false, 1, WR_FEAT_TEX | WR_FEAT_GENERIC>), H.nb * 4, 256, c->stream, targets, n_targets, draws,
+                (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);
+    else
+      WR_LAUNCH((wr_raster_kernel<WR_FMT_RGBA8, false, 1, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX | WR_FEAT_BLUR | WR_FEAT_SHADE>), H.nb * 4, 256, c->stream,
+                targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);
+  }
   else if (H.fmt == WR_FMT_RGBA8) {
     if (H.depth) {
       if (H.feat == 0) WR_K(WR_FMT_RGBA8, true, 0); else if (H.feat == F5) WR_K(WR_FMT_RGBA8, true, WR_FEAT_TEX | WR_FEAT_GENERIC);

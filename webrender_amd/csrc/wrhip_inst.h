@@ -22,5 +22,7 @@
 #define WR_INST_6(X)                                                                                                  \
   X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_R8, false, 4, 0) X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_R8, false, 4, 12) \
   X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_R8, false, 4, 28)
-#define WR_INST_ALL(X) WR_INST_1(X) WR_INST_2(X) WR_INST_3(X) WR_INST_4(X) WR_INST_5(X) WR_INST_6(X)
-#define WR_INST_GROUPS 6
+// (thin colour launches: picture blur / down-scale chains into RGBA8 targets of a few bins, 256-thread workgroups, four per bin)
+#define WR_INST_7(X) X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_RGBA8, false, 1, 5) X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_RGBA8, false, 1, 47)
+#define WR_INST_ALL(X) WR_INST_1(X) WR_INST_2(X) WR_INST_3(X) WR_INST_4(X) WR_INST_5(X) WR_INST_6(X) WR_INST_7(X)
+#define WR_INST_GROUPS 7

@@ -943,8 +943,24 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
   }
   float ubx = mnx / tsx, uby = mny / tsy, ubz = mxx / tsx, ubw = mxy / tsy;                         // v_uv_bounds
   if (d.flags & WR_DF_TEX_RECT) { ubx = 0.0f; uby = 0.0f; ubz = float(tex.width); ubw = float(tex.height); }   // vec4(0, 0, textureSize(sColor0)), brush_image.glsl:254-255
+  // RASTER_SCREEN (brush_image.glsl:200-205: what blurred / drop-shadow pictures are composited with, batch.rs:1537-1542): the
+  // image source's four homogeneous st corners (fetch_image_source_extra) turn the local position into the uv fraction
+  const bool raster_screen = data1.y != 0;
+  wf4 st_tl = {0.f, 0.f, 0.f, 1.f}, st_tr = st_tl, st_bl = st_tl, st_br = st_tl;
+  if (raster_screen) {
+    const int qa = resource_address + 2;
+    const int qu = int(unsigned(qa) % 1024u), qv = int(unsigned(qa) / 1024u);
+    st_tl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu, qv); st_tr = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 1, qv);
+    st_bl = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 2, qv); st_br = wr_fetch_f(d.tex[WR_S_GPU_CACHE], qu + 3, qv);
+  }
   for (int n = 0; n < 4; n++) {
-    const float fx = (vlx[n] - lr.x) / (lr.z - lr.x), fy = (vly[n] - lr.y) / (lr.w - lr.y);
+    float fx = (vlx[n] - lr.x) / (lr.z - lr.x), fy = (vly[n] - lr.y) / (lr.w - lr.y);
+    if (raster_screen) {      // get_image_quad_uv (prim_shared.glsl:204-210): mix(a, b, t) = (b - a) * t + a
+      const float xx = (st_tr.x - st_tl.x) * fx + st_tl.x, xy = (st_tr.y - st_tl.y) * fx + st_tl.y, xw = (st_tr.w - st_tl.w) * fx + st_tl.w;
+      const float yx = (st_br.x - st_bl.x) * fx + st_bl.x, yy = (st_br.y - st_bl.y) * fx + st_bl.y, yw = (st_br.w - st_bl.w) * fx + st_bl.w;
+      const float zx = (yx - xx) * fy + xx, zy = (yy - xy) * fy + xy, zw = (yw - xw) * fy + xw;
+      fx = zx / zw; fy = zy / zw;
+    }
     float uu = ((uv1x - uv0x) * fx + uv0x) - mnx, vv = ((uv1y - uv0y) * fy + uv0y) - mny;
     uu *= rpx; vv *= rpy;
     if (repetition) { uu += nox * (mxx - mnx); vv += noy * (mxy - mny); }
@@ -966,7 +982,6 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     Rp->alpha_pass = rep_alpha; Rp->no_span = tex.format != WR_FMT_RGBA8 || image == 11;      // (no span shader under the dual-source key)
     if (tex.format != WR_FMT_RGBA8 && tex.format != WR_FMT_R8) { o.kind = WR_PK_UNSUPPORTED; return; }
   }
-  if (data1.y != 0) { o.kind = WR_PK_UNSUPPORTED; return; }          // RASTER_SCREEN: next
   // BRUSH_FLAG_PERSPECTIVE_INTERPOLATION: v_uv was (not) multiplied by world_pos.w above; main() multiplies by
   // mix(gl_FragCoord.w, 1.0, perspective_interpolate) -- 1 on the 2-D path, evaluated per pixel on the perspective one
   o.persp_div = persp ? 1.0f : 0.0f;
@@ -8668,7 +8683,7 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 #ifndef WR_RECT_WAVES
 #define WR_RECT_WAVES 8
 #endif
-#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(1024 / R, ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? WR_TEX_WAVES : ((DEPTH) ? 4 : WR_RECT_WAVES)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
+#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(((R) == 1 && (FMT) == WR_FMT_RGBA8) ? 256 : 1024 / R, ((R) == 1 && (FMT) == WR_FMT_RGBA8) ? 0 : ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? WR_TEX_WAVES : ((DEPTH) ? 4 : WR_RECT_WAVES)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)

@@ -377,7 +377,7 @@ def scaled_composites(width=1024, height=768, seed=21, src=192):
 # alpha pass (batch.rs:2060-2150; ImageBrushData gpu_types.rs:707-724; GPU blocks
 # prim_store/image.rs: [color, background_color, stretch_size]).
 def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=None, modes=(0, 1, 2, 3, 4), translucent=True, only=None,
-               masked=False, nearest=False, dual=False, shadows=False):
+               masked=False, nearest=False, dual=False, shadows=False, screen=False):
     """`shadows`: every other alpha-pass image is a picture's drop shadow (COLOR_MODE_ALPHA / COLOR_MODE_BITMAP_SHADOW:
     swgl_blendDropShadow).  `dual`: the alpha-pass images go through "brush_image ALPHA_PASS,DUAL_SOURCE_BLENDING,TEXTURE_2D" under the dual-source
     blend state (BlendMode::SubpixelDualSource / MultiplyDualSource batches, batch.rs / shade.rs:462-467), colour modes
@@ -399,7 +399,16 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
             img[..., 3] = 255                        # opaque image
         img[..., :3] = (img[..., :3].astype(np.uint16) * img[..., 3:4] // 255).astype(np.uint8)
         pix[y:y + h, x:x + w] = img
-        addr = frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]])
+        # screen: RasterizationSpace::Screen sources (blurred / drop-shadow pictures, batch.rs:1537-1542) carry the four homogeneous st
+        # corners get_image_quad_uv blends: the whole task, a surface clipped by the screen (the unclipped rect's corners fall outside
+        # [0, 1], calculate_uv_rect_kind) or a sub-quad with w != 1
+        if i % 3 == 0:
+            quad = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
+        elif i % 3 == 1:
+            quad = [[-0.25, -0.125, 0.0, 1.0], [1.0, -0.125, 0.0, 1.0], [-0.25, 1.0625, 0.0, 1.0], [1.0, 1.0625, 0.0, 1.0]]
+        else:
+            quad = [[0.125, 0.0625, 0.0, 1.0], [1.75, 0.125, 0.0, 2.0], [0.0625, 0.9375, 0.0, 1.0], [0.96875, 1.0, 0.0, 1.0]]
+        addr = frame.gpu_cache.push([[x, y, x + w, y + h], [0.0, 0.0, 0.0, 0.0]] + (quad if screen else []))
         srcs.append((w, h, addr, i % 2 == 0))
         x += w
         shelf = max(shelf, h)
@@ -466,14 +475,14 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
             if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
                 continue
             spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
-            ud = (4 | (1 << 16), 0, int(round(opacity * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL
+            ud = (4 | (1 << 16), 1 if screen else 0, int(round(opacity * 65535.0)), 0)      # COLOR_MODE_IMAGE, premultiplied, RASTER_LOCAL / RASTER_SCREEN
             if shadows and not opaque and zi % 2 == 0:
                 # a picture's drop shadow: ShaderColorMode::Alpha (0) or BitmapShadow (2) with the shadow colour in the brush
                 # data, premultiplied or plain-alpha opacity (brush_image.glsl:268-291)
                 a = (0.35, 0.6, 0.85, 1.0)[zi % 4]
                 col = [((zi * 37) % 256) / 255.0 * a, ((zi * 91) % 256) / 255.0 * a, ((zi * 53) % 256) / 255.0 * a, a]
                 spec = frame.gpu_cache.push([col, [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
-                ud = ((0, 2)[(zi // 2) % 2] | ((zi // 4) % 2 << 16), 0, int(round(opacity * 65535.0)), 0)
+                ud = ((0, 2)[(zi // 2) % 2] | ((zi // 4) % 2 << 16), 1 if screen else 0, int(round(opacity * 65535.0)), 0)
             if dual and not opaque:
                 a = (0.35, 0.6, 0.85, 1.0)[zi % 4]
                 col = [((zi * 37) % 256) / 255.0 * a, ((zi * 91) % 256) / 255.0 * a, ((zi * 53) % 256) / 255.0 * a, a]

@@ -11,6 +11,8 @@ generated from the YAML files by tests/golden/make_wrench_benchmarks.py.
                        covering the prim.  Opaque stops => opaque pass, front to back: nine of the ten are depth-rejected
   text-rendering       68 text runs, sizes 8-20 px, black / red / green / blue (ps_text_run, R8 glyph atlas; glyph bitmaps
                        from PIL like cfg3's -- the reference rasterises with FreeType)
+  large-blur-radius    a stacking context under filter blur(100, 100): picture task -> 5 x cs_scale -> cs_blur V / H (RGBA8) -> brush_image
+                       with RasterizationSpace::Screen uv (picture.rs:5872-5930, render_task.rs:1168-1260, batch.rs:1509-1557)
   many-box-shadows     9 of the 10 outset box shadows (the cards': blur radius 45, offset (0, 22.5), no corner radii, colour rgba(0,0,0,0.102),
                        each under its item clip rect: ONE cached blurred minimal shadow (BoxShadowCacheKey depends on blur
                        radius and radii only), then a cs_clip_box_shadow x cs_clip_rectangle clip-out mask and masked
@@ -252,7 +254,105 @@ def large_clip_rect(width=3840, height=2160, tile_filter=None, **kw):
     return _finish(frame, tiles)
 
 
+def large_blur_radius(width=3840, height=2160, tile_filter=None, **kw):
+    """large-blur-radius.yaml: a stacking context with `filters: blur(100, 100)` over one 1024^2 red rect.  What the frame builder
+    makes of it:
+      * the picture's surface (picture.rs get_surface_rects, the generic arm :7799-7826, and PictureCompositeMode::get_rect
+        :4241-4253): the rect inflated by ceil(100) * BLUR_SAMPLE_SCALE = 300 on every side, clipped by the parent's clipping rect
+        inflated the same way, and by itself again -- here the whole inflated rect, 1624^2 device pixels, off-screen parts included;
+      * the picture task (:5872-5920): its size adjusted for the down-scaling passes (BlurTask::adjusted_blur_source_size,
+        render_task.rs:264-278: 1624 -> ceil(1624 / 32) * 32 = 1632), UvRectKind::Quad = where the unclipped rect's corners fall in
+        the adjusted task (calculate_uv_rect_kind, :7911-7941);
+      * RenderTask::new_blur (render_task.rs:1168-1260): std deviation 100 > MAX_BLUR_STD_DEVIATION = 4 -> five cs_scale halvings
+        (816, 408, 204, 102, 51: `blur_target_size / scale_factor` truncated), then cs_blur COLOR_TARGET vertical + horizontal at
+        51^2 with std deviation 3.125 and blur_region 1624 / 32 = 50;
+      * the composite (batch.rs:1509-1557): ONE brush_image ALPHA_PASS instance per tile the picture touches, premultiplied alpha,
+        ImageBrushData { color_mode: Image, raster_space: Screen, opacity: 1 }, the prim rect = the picture's unclipped rect, the
+        image source = the horizontal blur's task rect + the quad."""
+    it = display_lists()["large-blur-radius"]
+    BLUR_SAMPLE_SCALE, MAX_STD, MIN_RT = 3.0, 4.0, 8
+    ox, oy = it["bounds"][0], it["bounds"][1]
+    rb = it["rect-bounds"]
+    rect = (ox + rb[0], oy + rb[1], ox + rb[0] + rb[2], oy + rb[1] + rb[3])           # the rect in device space (dps 1, translation only)
+    std = it["blur"][0]
+    assert it["blur"][0] == it["blur"][1] and std <= 300.0                           # (clamp_blur_radius: MAX_BLUR_RADIUS = 300)
+    infl = float(np.ceil(std)) * BLUR_SAMPLE_SCALE
+    prim = (rect[0] - infl, rect[1] - infl, rect[2] + infl, rect[3] + infl)
+    # local clip = the window in the stacking context's space; get_rect(Some(prim & clip)) inflates again, & prim
+    clip = (0.0, 0.0, float(width), float(height))
+    nc = (max(prim[0], clip[0]) - infl, max(prim[1], clip[1]) - infl, min(prim[2], clip[2]) + infl, min(prim[3], clip[3]) + infl)
+    clipped = tuple(float(v) for v in (np.floor(max(nc[0], prim[0])), np.floor(max(nc[1], prim[1])), np.ceil(min(nc[2], prim[2])), np.ceil(min(nc[3], prim[3]))))
+    unclipped = prim
+    orig = (clipped[2] - clipped[0], clipped[3] - clipped[1])
+    # adjusted_blur_source_size
+    adj, sf, sd = orig, 1.0, std
+    while sd > MAX_STD:
+        if adj[0] < MIN_RT or adj[1] < MIN_RT:
+            break
+        sd *= 0.5
+        sf *= 2.0
+        adj = (float(np.ceil(orig[0] / sf)), float(np.ceil(orig[1] / sf)))
+    task_w, task_h = int(round(adj[0] * sf)), int(round(adj[1] * sf))
+    quad = [[(cx - clipped[0]) / task_w, (cy - clipped[1]) / task_h, 0.0, 1.0]
+            for cx, cy in ((unclipped[0], unclipped[1]), (unclipped[2], unclipped[1]), (unclipped[0], unclipped[3]), (unclipped[2], unclipped[3]))]
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    zero = (0.0, 0.0, 0.0, 0.0)
+    pot = lambda v: 1 << int(np.ceil(np.log2(max(v, 64))))
+    # -- the picture: the red rect into a transparent colour target, content origin = clipped.min
+    t_pic = TextureRef("blur_picture", pot(task_w), pot(task_h), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+    tg = Target(t_pic, "color", clear_color=zero)
+    pic_task = frame.add_render_task((0.0, 0.0, float(task_w), float(task_h)), 1.0, (clipped[0], clipped[1]))
+    col = premultiply(np.array([list(CSS[it["color"]])], np.uint8))[0]
+    spec = frame.gpu_cache.push([list(col)])
+    ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), 1, spec, 0, pic_task, (65535, 0, 0, 0))
+    tg.steps.append(Step("brush_solid", "PRIM_INSTANCES", np.array([frame.brush_instance(ph, CLIP_TASK_EMPTY)], dtype=np.int32), None, "none"))
+    frame.passes.append([tg])
+    frame.readback = [t_pic]
+    # -- new_blur: halvings, then vertical + horizontal
+    cur_tex, cur_rect, size, sd, sf = t_pic, (0.0, 0.0, float(task_w), float(task_h)), (task_w, task_h), std, 1.0
+    k = 0
+    while sd > MAX_STD:
+        if size[0] < MIN_RT or size[1] < MIN_RT:
+            break
+        sd *= 0.5
+        sf *= 2.0
+        size = (int(task_w / sf), int(task_h / sf))
+        t_s = TextureRef(f"blur_scale_{k}", pot(size[0]), pot(size[1]), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+        tgs = Target(t_s, "color", clear_color=zero)
+        nr = (0.0, 0.0, float(size[0]), float(size[1]))
+        inst = np.zeros(1, scenes.SCALE_DTYPE)
+        inst["t"][0], inst["s"][0], inst["k"][0] = nr, cur_rect, 1.0
+        tgs.steps.append(Step("cs_scale TEXTURE_2D", "SCALE", inst, None, "none", textures={0: cur_tex}))
+        frame.passes.append([tgs])
+        frame.readback.append(t_s)
+        cur_tex, cur_rect = t_s, nr
+        k += 1
+    region = (int(orig[0]) // int(sf), int(orig[1]) // int(sf))
+    t_v = TextureRef("blur_v", pot(size[0]), pot(size[1]), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+    t_h = TextureRef("blur_h", pot(size[0]), pot(size[1]), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+    a_src, a_v, a_h = frame.add_render_task(cur_rect), frame.add_render_task(cur_rect), frame.add_render_task(cur_rect)
+    tg_v, tg_h = Target(t_v, "color", clear_color=zero), Target(t_h, "color", clear_color=zero)
+    tg_v.steps.append(Step("cs_blur COLOR_TARGET", "BLUR", scenes.blur_instance(a_v, a_src, 1, sd, region), None, "none", textures={0: cur_tex}))
+    tg_h.steps.append(Step("cs_blur COLOR_TARGET", "BLUR", scenes.blur_instance(a_h, a_v, 0, sd, region), None, "none", textures={0: t_v}))
+    frame.passes.append([tg_v])
+    frame.passes.append([tg_h])
+    frame.readback += [t_v, t_h]
+    # -- the blurred picture over the tiles
+    src = frame.gpu_cache.push([[cur_rect[0], cur_rect[1], cur_rect[2], cur_rect[3]], [0.0, 0.0, 0.0, 0.0]] + quad)
+    bdata = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
+    tiles = _tiles(frame, width, height, tile_filter)
+    for target, task, (x0, y0, x1, y1) in tiles:
+        if not (unclipped[0] < x1 and unclipped[2] > x0 and unclipped[1] < y1 and unclipped[3] > y0):
+            continue
+        ph = frame.add_prim_header(unclipped, (-BIG, -BIG, BIG, BIG), 1, bdata, 0, task, (4 | (1 << 16), 1, 65535, 0))     # COLOR_MODE_IMAGE, premultiplied, RASTER_SCREEN
+        target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES",
+                                 np.array([frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=src)], dtype=np.int32),
+                                 "PremultipliedAlpha", "alpha", textures={0: t_h}))
+    return _finish(frame, tiles)
+
+
 WORKLOADS = {
+    "large-blur-radius": large_blur_radius,
     "large-boxshadow-ellipse": large_boxshadow_ellipse,
     "large-clip-rect": large_clip_rect,
     "many-images": many_images,
@@ -262,6 +362,7 @@ WORKLOADS = {
     "many-box-shadows": many_box_shadows,
 }
 DESCRIPTIONS = {
+    "large-blur-radius": "wrench benchmarks/large-blur-radius.yaml: filter blur(100, 100) over a 1024x1024 rect (the picture in a 1632^2 colour task, five cs_scale halvings, cs_blur COLOR_TARGET V/H at 51^2, the result composited by brush_image ALPHA_PASS with RasterizationSpace::Screen uv)",
     "large-boxshadow-ellipse": "wrench benchmarks/large-boxshadow-ellipse.yaml: one outset box shadow of a 1024x1024 box, blur radius 10, elliptical corner radii (cached blurred corner: mask -> cs_scale -> cs_blur V/H, then the cs_clip_box_shadow x clip-out mask and masked brush_solid segments)",
     "large-clip-rect": "wrench benchmarks/large-clip-rect.yaml: 8 opaque 1024x1024 rects under one rounded-rectangle clip (radius 16): 3x3 brush segments per rect, 4 corner clip-mask tasks each (cs_clip_rectangle FAST_PATH), opaque + masked alpha pass",
     "many-images": "wrench benchmarks/many-images.yaml: 8192 opaque 8x8 images (one texture-cache entry each), brush_image opaque pass",
