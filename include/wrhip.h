@@ -272,6 +272,8 @@ const char* WrhipDeviceName(void);
  * whose results a consumer enqueued behind it on the same stream will see.  The multi-GPU harness
  * orders its framebuffer-strip copy and the RCCL all-gather this way instead of a Finish per frame. */
 void WrhipFlush(void);
+/* ... the same, leaving this flush's own raster launches held back for the next flush (returns 1 if they are): see wrhip.hip */
+int WrhipFlushHeld(void);
 /* The context's hipStream_t (NULL in the host simulation), e.g. for torch.cuda.ExternalStream. */
 void* WrhipGetStream(void);
 

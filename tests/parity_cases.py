@@ -348,10 +348,13 @@ TEXTURE_RECT = [
     ("rect_rotated_images", lambda: scenes.texture_rect(scenes.rotated_images(seed=69))),
     ("rect_rotated_images_repeat", lambda: scenes.texture_rect(scenes.rotated_images(seed=70, repeat=True))),
     ("rect_occluded_image_grid", lambda: scenes.texture_rect(scenes.add_occluders(scenes.image_grid(seed=71), zmax=200, seed=43))),
-    ("rect_yuv_grid", lambda: scenes.texture_rect(scenes.yuv_grid(seed=306, planar=False))),      # NV12 (planar + linear: reported, see the test below)
+    ("rect_yuv_grid", lambda: scenes.texture_rect(scenes.yuv_grid(seed=306))),      # planar frames: blendYUV's CompositeYUV-backed overload (swgl_ext.h:1195-1283)
+    ("rect_yuv_grid_nv12", lambda: scenes.texture_rect(scenes.yuv_grid(seed=309, planar=False))),
     ("rect_yuv_grid_nearest", lambda: scenes.texture_rect(scenes.yuv_grid(seed=307, nearest=True))),
-    ("rect_yuv_grid_10bit", lambda: scenes.texture_rect(scenes.yuv_grid(seed=308, hdr=True, planar=False))),      # P010
-    ("rect_yuv_composites", lambda: scenes.texture_rect(scenes.yuv_composites(seed=313, planar=False))),
+    ("rect_yuv_grid_10bit", lambda: scenes.texture_rect(scenes.yuv_grid(seed=308, hdr=True))),      # three R16 planes / P010
+    ("rect_yuv_grid_wide", lambda: scenes.texture_rect(scenes.yuv_grid(width=2048, height=1024, n=150, seed=310))),
+    ("rect_occluded_yuv_grid", lambda: scenes.texture_rect(scenes.add_occluders(scenes.yuv_grid(seed=311, n=90), zmax=160, seed=41))),
+    ("rect_yuv_composites", lambda: scenes.texture_rect(scenes.yuv_composites(seed=313))),
     ("rect_yuv_composites_nearest", lambda: scenes.texture_rect(scenes.yuv_composites(seed=314, nearest=True))),
     ("rect_scaled_composites", lambda: scenes.texture_rect(scenes.scaled_composites(seed=22))),
     ("rect_blur_chain_scaled", lambda: scenes.texture_rect(scenes.blur_chain(fmt="rgba8", scale_steps=2, content=(150, 97), sigma=3.0), composites=False)),

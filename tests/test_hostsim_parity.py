@@ -383,14 +383,6 @@ def test_hostsim_texture_rect_key_is_not_the_2d_key(hostsim):
     assert (a != b).sum() > 10000
 
 
-def test_hostsim_planar_yuv_under_a_rect_key_is_reported(hostsim, capfd):
-    """Three linear sampler2DRect planes take blendYUV's CompositeYUV-backed overload in the reference (swgl_ext.h:1195-1283), which the
-    raster stage does not restate: such prims are counted and surface as GL_INVALID_OPERATION at Finish, never drawn differently."""
-    _, st = render_direct(hostsim, scenes.texture_rect(scenes.yuv_grid(seed=306)))
-    assert st["gl_error"] == 0x0502          # GL_INVALID_OPERATION
-    assert "not reproduced exactly" in capfd.readouterr().err
-
-
 @pytest.mark.parametrize("name,make", SVG_FILTERS, ids=[c[0] for c in SVG_FILTERS])
 def test_hostsim_svg_filters_match_oracle(hostsim, oracle_gcc, name, make):
     """cs_svg_filter / cs_svg_filter_node (parity_cases.SVG_FILTERS): main() of every filter kind restated per pixel in strict fp32

@@ -179,6 +179,7 @@ typedef struct wr_shard {
   int rows[2 * 64];                 /* framebuffer rows [y0, y1) of every rank's strip */
   uint8_t* fb;                      /* this rank's window storage (device pointer; host pointer with the hostsim backend) */
   void (*flush)(void);
+  int (*flush_held)(void);        /* optional: WrhipFlushHeld */
   void (*finish)(void);
   void* (*get_stream)(void);
   /* RCCL */
@@ -204,6 +205,7 @@ static wr_shard* shard_new(wr_replay* R, int rank, int world, int mode) {
   wr_shard* S = (wr_shard*)calloc(1, sizeof(wr_shard));
   S->R = R; S->rank = rank; S->world = world; S->mode = mode;
   S->flush = (void (*)(void))dlsym(R->dl, "WrhipFlush");
+  S->flush_held = getenv("WRHIP_SHARD_NO_PIPELINE") ? NULL : (int (*)(void))dlsym(R->dl, "WrhipFlushHeld");
   S->finish = (void (*)(void))dlsym(R->dl, "Finish");
   S->get_stream = (void* (*)(void))dlsym(R->dl, "WrhipGetStream");
   if (!S->flush || !S->finish || !S->get_stream) { fprintf(stderr, "wr_shard: backend lacks WrhipFlush / WrhipGetStream\n"); free(S); return NULL; }
@@ -277,12 +279,28 @@ static int shard_exchange(wr_shard* S) {
 int wr_shard_stream(wr_shard* S, const uint8_t* trace, size_t len, int iters, double* total_ms) {
   struct timespec a, b;
   clock_gettime(CLOCK_MONOTONIC, &a);
+  /* GPU path, software-pipelined by one frame: the backend holds a flush's raster launches back until the next flush (they leave
+     fused with its setup stage), so frame k's strips are moved right after frame k + 1's WrhipFlushHeld -- frame k is complete on
+     the stream by then and frame k + 1 has not written a pixel -- and the host records frame k + 1 while frame k rasterises,
+     exactly as the unsharded stream does. */
+  int pending = 0;                                  /* the previous frame's strips are still to be moved */
   for (int i = 0; i < iters; i++) {
     int rc = run_once(S->R, trace, len);
     if (rc) return rc;
-    if (S->shm) S->finish(); else S->flush();      /* (the stand-in copies with the host: the strip has to be there) */
-    rc = shard_exchange(S);
+    if (S->shm || !S->flush_held) {
+      if (S->shm) S->finish(); else S->flush();      /* (the stand-in copies with the host: the strip has to be there) */
+      rc = shard_exchange(S);
+    } else {
+      const int held = S->flush_held();
+      rc = pending ? shard_exchange(S) : 0;
+      pending = held;
+      if (!held && rc == 0) rc = shard_exchange(S);
+    }
     if (rc) { fprintf(stderr, "wr_shard: exchange failed (%d)\n", rc); return -2; }
+  }
+  if (pending) {
+    S->flush();
+    if (shard_exchange(S)) { fprintf(stderr, "wr_shard: exchange failed\n"); return -2; }
   }
   S->finish();                                      /* the backend's stream, collectives included */
   if (S->shm) {                                     /* every rank's strip of the last frame has landed */

@@ -3243,6 +3243,20 @@ void WrhipFlush(void) {
   wrq::drain();          // (the caller enqueues on the stream itself next: everything recorded so far must be on it)
 #endif
 }
+// WrhipFlush without draining the held-back raster launches: everything recorded so far is processed -- this flush's upload and
+// setup go out, and with them the raster launches the PREVIOUS flush left pending -- while this flush's own raster launches stay
+// held for the next one (Context::Tail).  Returns 1 if they are held, 0 if they were launched as well (deferral off / profiling).
+// The sharded frame loop moves frame k's strips right after frame k + 1's WrhipFlushHeld: frame k is complete on the stream,
+// frame k + 1 has not touched a pixel yet.
+int WrhipFlushHeld(void) {
+  if (!ctx) return 0;
+  flush_all();
+  flush_uploads();
+#ifndef WRHIP_HOSTSIM
+  wrq::drain();
+#endif
+  return ctx->tail.pending ? 1 : 0;
+}
 void* WrhipGetStream(void) {
 #ifdef WRHIP_HOSTSIM
   return nullptr;

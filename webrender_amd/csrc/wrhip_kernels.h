@@ -393,7 +393,8 @@ WR_DEVICE bool wr_yuv_planes_ok(const WrDrawDesc& d, int format, int depth) {
 // formats -- NV12, P010, what IOSurface video is -- and nearest samplers take the shared path and are drawn).
 WR_DEVICE bool wr_yuv_rect_fast_path(const WrDrawDesc& d, int format) {
   if (!(d.flags & WR_DF_TEX_RECT) || format != 3) return false;
-  return d.tex[WR_S_COLOR0].linear && d.tex[WR_S_COLOR1].linear && d.tex[WR_S_COLOR2].linear;
+  if (!(d.tex[WR_S_COLOR0].linear && d.tex[WR_S_COLOR1].linear && d.tex[WR_S_COLOR2].linear)) return false;
+  return d.tex[WR_S_COLOR0].width < 2 || d.tex[WR_S_COLOR1].width < 2;      // (linear_row_yuv's single-texel fill: not restated in the raster stage)
 }
 
 // ps_quad.glsl:164-418 + ps_quad_textured.glsl:13-37 (vertex stage)
@@ -2006,6 +2007,7 @@ WR_DEVICE void wr_vs_ps_clear(const WrDrawDesc& d, const uint8_t* arena, int ins
 // a[i] for a runtime i without making `a` addressable (a dynamically indexed local array, and
 // the struct around it, would live in scratch memory)
 WR_DEVICE float wr_pick4(const float (&a)[4], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+WR_DEVICE int wr_pick4i(const int (&a)[4], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
 WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
 
 // draw_quad_spans (rasterize.h:783-1055) for a general convex quad, walked at setup time: which vertex
@@ -5558,11 +5560,116 @@ WR_DEVICE WrWide wr_yuv_convert(const WrYuvRec& Y, int y, int u, int v) {
   s.bg = pk(b) | (pk(g) << 16); s.ra = pk(r) | (255u << 16);
   return s;
 }
+// linear_row_yuv's row-invariant integers (composite.h:999-1011, 1081-1122): the first chunk's 8.8 coordinates per lane, the steps per
+// chunk, the chunk range that takes upscaleYUV42R8 and its averaged chroma coordinates at that range's start
+struct WrYuvRowArgs { int yU[4], cU[4], yDU, cDU, fast0, fast1, cA, cB, color_depth; };
+WR_DEVICE void wr_yuv_row_chunk(const WrTexDesc& Ty, const WrTexDesc& Tu, const WrTexDesc& Tv, const WrYuvRowArgs& R, int yV, int cV, int c,
+                                int (&ys)[4], int (&us)[4], int (&vs)[4]);
+// linear_row_yuv's setup for a run of `span` pixels from (su, du) on the luma plane and (cu, cdu) on the chroma planes, 1/128 texels
+// (the device-side twin of what CompositeYUV's host code computes once per call)
+WR_DEVICE void wr_yuv_row_setup(WrYuvRowArgs& R, const WrTexDesc& Ty, const WrTexDesc& Tu, float su, float du, float cu, float cdu, int span) {
+  const int STEP_BITS = 8;
+  const float yl1 = su + du, yl2 = yl1 + du, yl3 = yl2 + du, cl1 = cu + cdu, cl2 = cl1 + cdu, cl3 = cl2 + cdu;      // init_interp
+  R.yU[0] = int(su * float(1 << STEP_BITS)); R.yU[1] = int(yl1 * float(1 << STEP_BITS)); R.yU[2] = int(yl2 * float(1 << STEP_BITS)); R.yU[3] = int(yl3 * float(1 << STEP_BITS));
+  R.cU[0] = int(cu * float(1 << STEP_BITS)); R.cU[1] = int(cl1 * float(1 << STEP_BITS)); R.cU[2] = int(cl2 * float(1 << STEP_BITS)); R.cU[3] = int(cl3 * float(1 << STEP_BITS));
+  R.yDU = int(float(4 << STEP_BITS) * du); R.cDU = int(float(4 << STEP_BITS) * cdu);
+  R.fast0 = R.fast1 = 0; R.cA = R.cB = 0;
+  if (Ty.format != WR_FMT_R16 && R.yDU >= R.cDU && R.cDU > 0 && R.yDU <= (4 << (STEP_BITS + 7)) && R.cDU <= (2 << (STEP_BITS + 7))) {
+    // the half-resolution fast path (composite.h:1081-1122): chunks until both coordinates are positive, then as many whole chunks
+    // as stay four texels inside both planes
+    int left = span, chunk = 0;
+    int yx = R.yU[0], cx = R.cU[0];
+    int cl[4] = {R.cU[0], R.cU[1], R.cU[2], R.cU[3]};
+    for (; (yx < 0 || cx < 0) && left >= 4; left -= 4) {
+      yx = int(uint32_t(yx) + uint32_t(R.yDU)); cx = int(uint32_t(cx) + uint32_t(R.cDU));
+      for (int i = 0; i < 4; i++) cl[i] = int(uint32_t(cl[i]) + uint32_t(R.cDU));
+      chunk++;
+    }
+    const int inside = wr_imin(wr_imin((((Ty.width - 4) << (STEP_BITS + 7)) - yx) / R.yDU, (((Tu.width - 4) << (STEP_BITS + 7)) - cx) / R.cDU) * 4, left & ~3);
+    if (inside > 0) {
+      R.fast0 = chunk; R.fast1 = chunk + inside / 4;
+      R.cA = (cl[0] + cl[1]) >> 1; R.cB = (cl[2] + cl[3]) >> 1;      // cU = (cU.xzxz + cU.ywyw) >> 1
+    }
+  }
+}
+
+// The span pixels of a PLANAR frame under a TEXTURE_RECT key: three linear sampler2DRect planes select blendYUV's second overload
+// (swgl_ext.h:1195-1283).  When the planes agree (one format, chroma planes of one size sampled at the same coordinates, no change of
+// row along the span, x increasing) the span is cut in three: chunks before both clamp rects are entered take the quantised float
+// stepping (blendYUVFallback), the chunks inside them CompositeYUV's inner loop (linear_row_yuv from the coordinates reached by
+// ONE multiply-add), the rest the float stepping again from where that run ended.  Returns false where the shared routine's value is
+// the reference's (conditions not met, or the pixel lies in the first part).
+WR_DEVICE bool wr_yuv_rect_span_pixel(const WrPrim* Pp, const WrYuvRec& Y, const WrDrawDesc* D, int x, int y, const WrRuns* runs, WrWide& out) {
+  const WrTexDesc& T0 = D->tex[WR_S_COLOR0]; const WrTexDesc& T1 = D->tex[WR_S_COLOR1]; const WrTexDesc& T2 = D->tex[WR_S_COLOR2];
+  if (!(T0.format == T1.format && T1.format == T2.format && T1.width == T2.width && T1.height == T2.height)) return false;
+  float q[3][4], qy[3][4], stepx[3], stepy[3], minx[3], maxx[3], miny[3], maxy[3];
+  int n = 0, span = 0;
+  for (int pl = 0; pl < 3; pl++) {
+    WrPrim P2 = *Pp;
+    P2.kind = WR_PK_TEX_R8;
+    if (pl > 0) {
+      const float* L0 = pl == 1 ? Y.uL0 : Y.vL0; const float* Ls = pl == 1 ? Y.uLs : Y.vLs;
+      const float* R0 = pl == 1 ? Y.uR0 : Y.vR0; const float* Rs = pl == 1 ? Y.uRs : Y.vRs; const float* Bd = pl == 1 ? Y.u_bounds : Y.v_bounds;
+      P2.uvL0[0] = L0[0]; P2.uvL0[1] = L0[1]; P2.uvLs[0] = Ls[0]; P2.uvLs[1] = Ls[1];
+      P2.uvR0[0] = R0[0]; P2.uvR0[1] = R0[1]; P2.uvRs[0] = Rs[0]; P2.uvRs[1] = Rs[1];
+      P2.uv_bounds[0] = Bd[0]; P2.uv_bounds[1] = Bd[1]; P2.uv_bounds[2] = Bd[2]; P2.uv_bounds[3] = Bd[3];
+      P2.rows_linear = 0;
+    }
+    const WrTexDesc& t = D->tex[WR_S_COLOR0 + pl];
+    const WrTexRow r = wr_tex_row(P2, t, y, runs, x, false);
+    if (pl == 0) { n = x - r.x0; span = r.span; if (n >= span) return false; }
+    const float W = t.sw, H = t.sh, qs = 128.0f, qo = 0.5f - 0.5f * qs;
+    for (int i = 0; i < 4; i++) { q[pl][i] = r.lu[i] * W * qs + qo; qy[pl][i] = r.lv[i] * H * qs + qo; }
+    stepx[pl] = 4.0f * (q[pl][1] - q[pl][0]); stepy[pl] = 4.0f * (qy[pl][1] - qy[pl][0]);
+    minx[pl] = wr_max(P2.uv_bounds[0] * W * qs + qo, 0.0f); miny[pl] = wr_max(P2.uv_bounds[1] * H * qs + qo, 0.0f);
+    maxx[pl] = wr_max(P2.uv_bounds[2] * W * qs + qo, minx[pl]); maxy[pl] = wr_max(P2.uv_bounds[3] * H * qs + qo, miny[pl]);
+  }
+  if (!(stepy[0] == 0.0f && stepx[0] > 0.0f && stepy[1] == 0.0f && stepx[1] > 0.0f && stepx[1] == stepx[2] && stepy[1] == stepy[2] &&
+        q[1][0] == q[2][0] && qy[1][0] == qy[2][0])) return false;
+  const int chunks = span >> 2, c = n >> 2, k = n & 3;
+  int outside = wr_imin(int(ceilf(wr_max((minx[0] - q[0][0]) / stepx[0], (minx[1] - q[1][0]) / stepx[1]))), chunks);
+  if (outside < 0) outside = 0;
+  if (c < outside) return false;
+  float u0[4], u1[4], u2[4];
+  for (int i = 0; i < 4; i++) { u0[i] = q[0][i]; u1[i] = q[1][i]; u2[i] = q[2][i]; }
+  if (outside > 0) for (int i = 0; i < 4; i++) { u0[i] += float(outside) * stepx[0]; u1[i] += float(outside) * stepx[1]; u2[i] += float(outside) * stepx[2]; }
+  int inside = wr_imin(int(wr_min((maxx[0] - u0[0]) / stepx[0], (maxx[1] - u1[0]) / stepx[1])), chunks - outside);
+  if (inside < 0) inside = 0;
+  int s3[3];
+  if (c < outside + inside) {
+    WrYuvRowArgs R;
+    R.color_depth = (T0.format == WR_FMT_R16 ? 16 : 8) - Y.rescale;
+    wr_yuv_row_setup(R, T0, T1, u0[0], stepx[0] / 4.0f, u1[0], stepx[1] / 4.0f, inside * 4);
+    int ys[4], us[4], vs[4];
+    wr_yuv_row_chunk(T0, T1, T2, R, int(qy[0][0]), int(qy[1][0]), c - outside, ys, us, vs);
+    s3[0] = wr_pick4i(ys, k); s3[1] = wr_pick4i(us, k); s3[2] = wr_pick4i(vs, k);
+  } else {
+    // what is left of the span: the float stepping again, from the coordinates the inside run ended on
+    if (inside > 0) for (int i = 0; i < 4; i++) { u0[i] += float(inside) * stepx[0]; u1[i] += float(inside) * stepx[1]; u2[i] += float(inside) * stepx[2]; }
+    const int cc = c - outside - inside;
+    const float us3[3] = {wr_pick4(u0, k), wr_pick4(u1, k), wr_pick4(u2, k)};
+    for (int pl = 0; pl < 3; pl++) {
+      const WrTexDesc& t = D->tex[WR_S_COLOR0 + pl];
+      const int iqx = int(wr_clamp(wr_accum(us3[pl], stepx[pl], cc), minx[pl], maxx[pl]));
+      const int iqy = int(wr_clamp(wr_accum(wr_pick4(qy[pl], k), stepy[pl], cc), miny[pl], maxy[pl]));
+      int v4[4];
+      if (t.format == WR_FMT_R16) { wr_bilinear16<1>(t, iqx, iqy, v4); s3[pl] = v4[0] >> ((16 - Y.rescale - 1) - 8); }
+      else { wr_bilinear<1>(t, iqx, iqy, v4); s3[pl] = v4[0]; }
+    }
+  }
+  out = wr_yuv_convert(Y, s3[0], s3[1], s3[2]);
+  return true;
+}
+
 __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp, const WrDrawDesc* D, int x, int y, const WrRuns* runs = nullptr) {
   const WrYuvRec& Y = *Yp;
   const int planes = Y.format == 3 ? 3 : 2;
   bool all_linear = true;
   for (int pl = 0; pl < planes; pl++) all_linear = all_linear && D->tex[WR_S_COLOR0 + pl].linear != 0;
+  if ((D->flags & WR_DF_TEX_RECT) && planes == 3 && all_linear) {
+    WrWide w;
+    if (wr_yuv_rect_span_pixel(Pp, Y, D, x, y, runs, w)) return w;
+  }
   int sample[3] = {0, 0, 0};          // y, u, v as the span shader's u16 lanes
   float fs[3] = {0.f, 0.f, 0.f};      // ... and as main()'s floats
   bool tail = false;
@@ -5651,6 +5758,66 @@ WR_DEVICE int wr_yuv_vlerp(const uint8_t* row, long long stride, long long x, in
   const int a = row[x], b = row[x + stride];
   return wr_i16(a + wr_i16(wr_i16((b - a) * fracv) >> 7));
 }
+// ... and one 4-pixel chunk `c` of the row: the planes' samples as the colour matrix takes them (yV, cV: int32_t(srcUV.y))
+WR_DEVICE void wr_yuv_row_chunk(const WrTexDesc& Ty, const WrTexDesc& Tu, const WrTexDesc& Tv, const WrYuvRowArgs& R, int yV, int cV, int c,
+                                int (&ys)[4], int (&us)[4], int (&vs)[4]) {
+    int yq[4], cq[4];
+    for (int i = 0; i < 4; i++) { yq[i] = (int)((uint32_t)R.yU[i] + (uint32_t)c * (uint32_t)R.yDU); cq[i] = (int)((uint32_t)R.cU[i] + (uint32_t)c * (uint32_t)R.cDU); }
+    if (Ty.format == WR_FMT_R16) {
+      const int bits = (R.color_depth - 1) - 8;
+      for (int i = 0; i < 4; i++) {
+        int t4[4];
+        wr_bilinear16<1>(Ty, yq[i] >> 8, yV, t4); ys[i] = t4[0] >> bits;
+        wr_bilinear16<1>(Tu, cq[i] >> 8, cV, t4); us[i] = t4[0] >> bits;
+        wr_bilinear16<1>(Tv, cq[i] >> 8, cV, t4); vs[i] = t4[0] >> bits;
+      }
+    } else {
+      const int yfv = yV & 0x7F, cfv = cV & 0x7F;
+      yV >>= 7; cV >>= 7;
+      const long long yoff = (long long)wr_clamp_coord(yV, Ty.height) * Ty.stride, ystr = (yV >= 0 && yV < Ty.height - 1) ? Ty.stride : 0;
+      const long long coff = (long long)wr_clamp_coord(cV, Tu.height) * Tu.stride, cstr = (cV >= 0 && cV < Tu.height - 1) ? Tu.stride : 0;
+      if (c >= R.fast0 && c < R.fast1) {
+        // upscaleYUV42R8 (composite.h:857-986): luma per lane out of a 4 + 4 texel window, chroma at the chunk's two averaged
+        // coordinates, the four pixels' chroma estimated from those two samples
+        const int k = c - R.fast0;
+        const uint8_t* yrow = (const uint8_t*)Ty.ptr + yoff;
+        const uint8_t* urow = (const uint8_t*)Tu.ptr + coff;
+        const uint8_t* vrow = (const uint8_t*)Tv.ptr + coff;
+        const int ca = (int)((uint32_t)R.cA + (uint32_t)k * (uint32_t)R.cDU), cb = (int)((uint32_t)R.cB + (uint32_t)k * (uint32_t)R.cDU);
+        int yI[4]; for (int i = 0; i < 4; i++) yI[i] = yq[i] >> 15;
+        const int cIx = ca >> 15, cIy = cb >> 15;
+        const int yInx = (int)((uint32_t)yq[0] + (uint32_t)R.yDU) >> 15, cInx = (int)((uint32_t)ca + (uint32_t)R.cDU) >> 15;
+        int s[4], n[4];
+        for (int i = 0; i < 4; i++) { s[i] = wr_yuv_vlerp(yrow, ystr, (long long)yI[0] + i, yfv); n[i] = wr_yuv_vlerp(yrow, ystr, (long long)yInx + i, yfv); }
+        int ysh[4] = {s[0], s[1], s[2], s[3]};
+        int ysn[4] = {s[1], s[2], s[3], yInx == yI[3] ? n[1] : n[0]};
+        if (yI[1] == yI[0]) { const int a[4] = {ysh[0], ysh[0], ysh[1], ysh[2]}, b[4] = {ysn[0], ysn[0], ysn[1], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
+        if (yI[2] == yI[1]) { const int a[4] = {ysh[0], ysh[1], ysh[1], ysh[2]}, b[4] = {ysn[0], ysn[1], ysn[1], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
+        if (yI[3] == yI[2]) { const int a[4] = {ysh[0], ysh[1], ysh[2], ysh[2]}, b[4] = {ysn[0], ysn[1], ysn[2], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
+        const int u0 = wr_yuv_vlerp(urow, cstr, cIx, cfv), u1 = wr_yuv_vlerp(urow, cstr, (long long)cIx + 1, cfv);
+        const int v0 = wr_yuv_vlerp(vrow, cstr, cIx, cfv), v1 = wr_yuv_vlerp(vrow, cstr, (long long)cIx + 1, cfv);
+        const int nu0 = wr_yuv_vlerp(urow, cstr, cInx, cfv), nu1 = wr_yuv_vlerp(urow, cstr, (long long)cInx + 1, cfv);
+        const int nv0 = wr_yuv_vlerp(vrow, cstr, cInx, cfv), nv1 = wr_yuv_vlerp(vrow, cstr, (long long)cInx + 1, cfv);
+        int csh[4] = {u0, u1, v0, v1};
+        int csn[4] = {u1, cInx == cIy ? nu1 : nu0, v1, cInx == cIy ? nv1 : nv0};
+        if (cIy == cIx) { csh[1] = csh[0]; csh[3] = csh[2]; csn[1] = csn[0]; csn[3] = csn[2]; }
+        const int fr[8] = {(yq[0] >> 8) & 0x7F, (yq[1] >> 8) & 0x7F, (yq[2] >> 8) & 0x7F, (yq[3] >> 8) & 0x7F, (ca >> 8) & 0x7F, (cb >> 8) & 0x7F, (ca >> 8) & 0x7F, (cb >> 8) & 0x7F};
+        int px[8];
+        for (int i = 0; i < 4; i++) px[i] = wr_i16(ysh[i] + wr_i16(wr_i16((ysn[i] - ysh[i]) * fr[i]) >> 7));
+        for (int i = 0; i < 4; i++) px[4 + i] = wr_i16(csh[i] + wr_i16(wr_i16((csn[i] - csh[i]) * fr[4 + i]) >> 7));
+        const int uA = px[4], uB = px[5], vA = px[6], vB = px[7];
+        for (int i = 0; i < 4; i++) ys[i] = px[i];
+        us[0] = wr_i16(uA + (wr_i16(uA - uB) >> 2)); us[1] = wr_i16(uA + (wr_i16(uB - uA) >> 2)); us[2] = wr_i16(uB + (wr_i16(uA - uB) >> 2)); us[3] = wr_i16(uB + (wr_i16(uB - uA) >> 2));
+        vs[0] = wr_i16(vA + (wr_i16(vA - vB) >> 2)); vs[1] = wr_i16(vA + (wr_i16(vB - vA) >> 2)); vs[2] = wr_i16(vB + (wr_i16(vA - vB) >> 2)); vs[3] = wr_i16(vB + (wr_i16(vB - vA) >> 2));
+      } else {
+        for (int i = 0; i < 4; i++) {
+          ys[i] = wr_yuv_row_tap(Ty, yq[i] >> 8, yoff, ystr, yfv);
+          us[i] = wr_yuv_row_tap(Tu, cq[i] >> 8, coff, cstr, cfv);
+          vs[i] = wr_yuv_row_tap(Tv, cq[i] >> 8, coff, cstr, cfv);
+        }
+      }
+    }
+}
 #ifndef WR_INST_ONLY
 __global__ void wr_composite_yuv_kernel(WrYuvBlitArgs A) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -5677,64 +5844,11 @@ __global__ void wr_composite_yuv_kernel(WrYuvBlitArgs A) {
     const uint32_t p = wr_pack(w);
     for (int i = 0; i < 4; i++) out[i] = p;
   } else {
-    int yV = int(sv), cV = int(cvf);                  // int32_t(srcUV.y): truncation
-    int yq[4], cq[4];
-    for (int i = 0; i < 4; i++) { yq[i] = (int)((uint32_t)A.yU[i] + (uint32_t)c * (uint32_t)A.yDU); cq[i] = (int)((uint32_t)A.cU[i] + (uint32_t)c * (uint32_t)A.cDU); }
     int ys[4], us[4], vs[4];
-    if (A.y.format == WR_FMT_R16) {
-      const int bits = (A.color_depth - 1) - 8;
-      for (int i = 0; i < 4; i++) {
-        int t4[4];
-        wr_bilinear16<1>(A.y, yq[i] >> 8, yV, t4); ys[i] = t4[0] >> bits;
-        wr_bilinear16<1>(A.u, cq[i] >> 8, cV, t4); us[i] = t4[0] >> bits;
-        wr_bilinear16<1>(A.v, cq[i] >> 8, cV, t4); vs[i] = t4[0] >> bits;
-      }
-    } else {
-      const int yfv = yV & 0x7F, cfv = cV & 0x7F;
-      yV >>= 7; cV >>= 7;
-      const long long yoff = (long long)wr_clamp_coord(yV, A.y.height) * A.y.stride, ystr = (yV >= 0 && yV < A.y.height - 1) ? A.y.stride : 0;
-      const long long coff = (long long)wr_clamp_coord(cV, A.u.height) * A.u.stride, cstr = (cV >= 0 && cV < A.u.height - 1) ? A.u.stride : 0;
-      if (c >= A.fast0 && c < A.fast1) {
-        // upscaleYUV42R8 (composite.h:857-986): luma per lane out of a 4 + 4 texel window, chroma at the chunk's two averaged
-        // coordinates, the four pixels' chroma estimated from those two samples
-        const int k = c - A.fast0;
-        const uint8_t* yrow = (const uint8_t*)A.y.ptr + yoff;
-        const uint8_t* urow = (const uint8_t*)A.u.ptr + coff;
-        const uint8_t* vrow = (const uint8_t*)A.v.ptr + coff;
-        const int ca = (int)((uint32_t)A.cA + (uint32_t)k * (uint32_t)A.cDU), cb = (int)((uint32_t)A.cB + (uint32_t)k * (uint32_t)A.cDU);
-        int yI[4]; for (int i = 0; i < 4; i++) yI[i] = yq[i] >> 15;
-        const int cIx = ca >> 15, cIy = cb >> 15;
-        const int yInx = (int)((uint32_t)yq[0] + (uint32_t)A.yDU) >> 15, cInx = (int)((uint32_t)ca + (uint32_t)A.cDU) >> 15;
-        int s[4], n[4];
-        for (int i = 0; i < 4; i++) { s[i] = wr_yuv_vlerp(yrow, ystr, (long long)yI[0] + i, yfv); n[i] = wr_yuv_vlerp(yrow, ystr, (long long)yInx + i, yfv); }
-        int ysh[4] = {s[0], s[1], s[2], s[3]};
-        int ysn[4] = {s[1], s[2], s[3], yInx == yI[3] ? n[1] : n[0]};
-        if (yI[1] == yI[0]) { const int a[4] = {ysh[0], ysh[0], ysh[1], ysh[2]}, b[4] = {ysn[0], ysn[0], ysn[1], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
-        if (yI[2] == yI[1]) { const int a[4] = {ysh[0], ysh[1], ysh[1], ysh[2]}, b[4] = {ysn[0], ysn[1], ysn[1], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
-        if (yI[3] == yI[2]) { const int a[4] = {ysh[0], ysh[1], ysh[2], ysh[2]}, b[4] = {ysn[0], ysn[1], ysn[2], ysn[2]}; for (int i = 0; i < 4; i++) { ysh[i] = a[i]; ysn[i] = b[i]; } }
-        const int u0 = wr_yuv_vlerp(urow, cstr, cIx, cfv), u1 = wr_yuv_vlerp(urow, cstr, (long long)cIx + 1, cfv);
-        const int v0 = wr_yuv_vlerp(vrow, cstr, cIx, cfv), v1 = wr_yuv_vlerp(vrow, cstr, (long long)cIx + 1, cfv);
-        const int nu0 = wr_yuv_vlerp(urow, cstr, cInx, cfv), nu1 = wr_yuv_vlerp(urow, cstr, (long long)cInx + 1, cfv);
-        const int nv0 = wr_yuv_vlerp(vrow, cstr, cInx, cfv), nv1 = wr_yuv_vlerp(vrow, cstr, (long long)cInx + 1, cfv);
-        int csh[4] = {u0, u1, v0, v1};
-        int csn[4] = {u1, cInx == cIy ? nu1 : nu0, v1, cInx == cIy ? nv1 : nv0};
-        if (cIy == cIx) { csh[1] = csh[0]; csh[3] = csh[2]; csn[1] = csn[0]; csn[3] = csn[2]; }
-        const int fr[8] = {(yq[0] >> 8) & 0x7F, (yq[1] >> 8) & 0x7F, (yq[2] >> 8) & 0x7F, (yq[3] >> 8) & 0x7F, (ca >> 8) & 0x7F, (cb >> 8) & 0x7F, (ca >> 8) & 0x7F, (cb >> 8) & 0x7F};
-        int px[8];
-        for (int i = 0; i < 4; i++) px[i] = wr_i16(ysh[i] + wr_i16(wr_i16((ysn[i] - ysh[i]) * fr[i]) >> 7));
-        for (int i = 0; i < 4; i++) px[4 + i] = wr_i16(csh[i] + wr_i16(wr_i16((csn[i] - csh[i]) * fr[4 + i]) >> 7));
-        const int uA = px[4], uB = px[5], vA = px[6], vB = px[7];
-        for (int i = 0; i < 4; i++) ys[i] = px[i];
-        us[0] = wr_i16(uA + (wr_i16(uA - uB) >> 2)); us[1] = wr_i16(uA + (wr_i16(uB - uA) >> 2)); us[2] = wr_i16(uB + (wr_i16(uA - uB) >> 2)); us[3] = wr_i16(uB + (wr_i16(uB - uA) >> 2));
-        vs[0] = wr_i16(vA + (wr_i16(vA - vB) >> 2)); vs[1] = wr_i16(vA + (wr_i16(vB - vA) >> 2)); vs[2] = wr_i16(vB + (wr_i16(vA - vB) >> 2)); vs[3] = wr_i16(vB + (wr_i16(vB - vA) >> 2));
-      } else {
-        for (int i = 0; i < 4; i++) {
-          ys[i] = wr_yuv_row_tap(A.y, yq[i] >> 8, yoff, ystr, yfv);
-          us[i] = wr_yuv_row_tap(A.u, cq[i] >> 8, coff, cstr, cfv);
-          vs[i] = wr_yuv_row_tap(A.v, cq[i] >> 8, coff, cstr, cfv);
-        }
-      }
-    }
+    WrYuvRowArgs R;
+    for (int i = 0; i < 4; i++) { R.yU[i] = A.yU[i]; R.cU[i] = A.cU[i]; }
+    R.yDU = A.yDU; R.cDU = A.cDU; R.fast0 = A.fast0; R.fast1 = A.fast1; R.cA = A.cA; R.cB = A.cB; R.color_depth = A.color_depth;
+    wr_yuv_row_chunk(A.y, A.u, A.v, R, int(sv), int(cvf), c, ys, us, vs);      // (int32_t(srcUV.y): truncation)
     for (int i = 0; i < 4; i++) out[i] = wr_pack(wr_yuv_convert(M, ys[i], us[i], vs[i]));
   }
   for (int i = 0; i < npx; i++) dst[i] = out[i];

@@ -134,6 +134,7 @@ EXTRA_SIGNATURES = {
     "WrhipGetFramebufferTexture": (u32, [u32]),
     "WrhipDeviceName": (c_char_p, []),
     "WrhipFlush": (None, []),
+    "WrhipFlushHeld": (i32, []),
     "WrhipGetStream": (P, []),
 }
 
