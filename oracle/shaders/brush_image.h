@@ -7,7 +7,7 @@
 // (FS), 380-428 (span) on brush_base.h. ANTIALIASING changes nothing under swgl
 // (antialias_brush() is 1.0 with SWGL_ANTIALIAS; the edge mask goes through
 // swgl_antiAlias in brush_base.h).
-// RASTER_SCREEN quads (get_image_quad_uv) are not restated: scenes use local raster space.
+// RASTER_SCREEN sources (get_image_quad_uv): restated below.
 
 #define WRSH_BRUSH_IMAGE(NAME, KEYSTR, ALPHA_PASS, REPETITION, DUAL)           \
   struct NAME##_vert : wrsh::brush_vert_base<NAME##_vert> {                    \
@@ -113,6 +113,17 @@
           vec4_scalar(texture_size.x, texture_size.y, texture_size.x,          \
                       texture_size.y);                                         \
       vec2 f = (vi.local_pos - local_rect.p0) / rect_size(local_rect);         \
+      /* RASTER_SCREEN: get_image_quad_uv, brush_image.glsl:200-205, prim_shared.glsl:204-210 */ \
+      if (prim_user_data.y != 0) {                                             \
+        vec4_scalar st_tl = fetch_from_gpu_cache(specific_resource_address + 2, 0); \
+        vec4_scalar st_tr = fetch_from_gpu_cache(specific_resource_address + 2, 1); \
+        vec4_scalar st_bl = fetch_from_gpu_cache(specific_resource_address + 2, 2); \
+        vec4_scalar st_br = fetch_from_gpu_cache(specific_resource_address + 2, 3); \
+        vec4 x = mix(vec4(st_tl), vec4(st_tr), f.x);                           \
+        vec4 y = mix(vec4(st_bl), vec4(st_br), f.x);                           \
+        vec4 z = mix(x, y, f.y);                                               \
+        f = z.sel(X, Y) / z.w;                                                 \
+      }                                                                        \
       int color_mode = prim_user_data.x & 0xffff;                              \
       int blend_mode = prim_user_data.x >> 16;                                 \
       vec2_scalar repeat = rect_size(local_rect) / stretch_size;               \

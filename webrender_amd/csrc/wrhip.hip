@@ -1374,7 +1374,13 @@ void sync_stream() {
 static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
   Context* c = ctx;
   Texture& ft = c->textures[fb.tex];
-  if (ft.internal_format != GL_RGBA8 || ft.own_y1 > ft.own_y0 || c->shard_world > 1 || c->profiling_no_forward) return false;
+  if (ft.internal_format != GL_RGBA8 || c->profiling_no_forward) return false;
+  // multi-GPU: this rank owns rows [oy0, oy1) of the window (WrhipSetTargetRows) and only those have to be covered -- by the tiles
+  // that were kept because they reach into the strip, rasterised over the bin rows that do (a bin row straddling the strip's edge
+  // also writes rows of the neighbour's strip: the exchange that follows on the stream overwrites them)
+  const bool strip = ft.own_y1 > ft.own_y0;
+  const int oy0 = strip ? std::max(0, ft.own_y0) : 0, oy1 = strip ? std::min(ft.height, ft.own_y1) : ft.height;
+  if (oy1 <= oy0) return false;
   struct Plan { int src; int dx, y0, ys, clip[4]; };
   std::vector<Plan> plans;
   bool seen_draw = false;
@@ -1394,10 +1400,8 @@ static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
     // (a source that was itself forwarded away has no raster pass to store from, and one that already forwards into another
     // target has its one write-through taken: both take the ordinary composite path)
     for (int wi : sel) if (&c->work[wi] != &fb && c->textures[c->work[wi].tex].dptr == st.ptr && c->work[wi].level < fb.level && !c->work[wi].forwarded_away) src = wi;
-    if (src < 0) return false;
-    if (c->work[src].fwd_tex && c->work[src].fwd_tex != fb.tex) return false;
-    const Texture& stex = c->textures[c->work[src].tex];
-    if (stex.own_y1 > stex.own_y0) return false;
+    if (src < 0 && !strip) return false;      // (a strip: the draw may lie wholly in other ranks' rows, its source dropped when it was recorded)
+    if (src >= 0 && c->work[src].fwd_tex && c->work[src].fwd_tex != fb.tex) return false;
     for (int i = 0; i < d.count; i++) {
       const uint8_t* ip = fb.inst.data() + d.inst_offset + (size_t)i * d.inst_stride;
       float rect[4], clip[4], prm[4] = {0, 0, 0, 0}, uv[4], flip[2] = {0, 0};
@@ -1420,6 +1424,10 @@ static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
       int ix0, iy0, ix1, iy1, icx0, icy0, icx1, icy1;
       if (!near_int(x0, ix0) || !near_int(y0, iy0) || !near_int(x1, ix1) || !near_int(y1, iy1) || !near_int(cx0, icx0) || !near_int(cy0, icy0) ||
           !near_int(cx1, icx1) || !near_int(cy1, icy1)) return false;
+      if (strip && std::min(std::max(icy0, icy1), oy1) <= std::max(std::min(icy0, icy1), oy0)) continue;      // (none of this rank's rows)
+      if (strip && std::min(std::max(iy0, iy1), oy1) <= std::max(std::min(iy0, iy1), oy0)) continue;
+      if (src < 0) return false;
+      const Texture& stex = c->textures[c->work[src].tex];
       if (ix1 - ix0 != stex.width || abs(iy1 - iy0) != stex.height) return false;          // texel for pixel
       for (const Plan& q : plans) if (q.src == src) return false;                            // one destination per source
       Plan P;
@@ -1438,13 +1446,13 @@ static bool plan_forwarding(TargetWork& fb, const std::vector<int>& sel) {
   long long area = 0;
   for (size_t a = 0; a < plans.size(); a++) {
     const int* A = plans[a].clip;
-    area += (long long)(A[2] - A[0]) * (A[3] - A[1]);
+    area += (long long)(A[2] - A[0]) * std::max(0, std::min(A[3], oy1) - std::max(A[1], oy0));
     for (size_t b = a + 1; b < plans.size(); b++) {
       const int* B = plans[b].clip;
       if (A[0] < B[2] && B[0] < A[2] && A[1] < B[3] && B[1] < A[3]) return false;
     }
   }
-  if (area != (long long)ft.width * ft.height) return false;
+  if (area != (long long)ft.width * (oy1 - oy0)) return false;
   for (const Plan& P : plans) {
     TargetWork& sw = c->work[P.src];
     sw.fwd_tex = fb.tex; sw.fwd_dx = P.dx; sw.fwd_y0 = P.y0; sw.fwd_ys = P.ys;
