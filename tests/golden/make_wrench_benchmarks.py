@@ -51,6 +51,11 @@ def main():
     assert it["type"] == "box-shadow" and it["clip-mode"] == "outset"
     out["large-boxshadow-ellipse"] = {"bounds": nums(it["bounds"]), "color": it["color"], "blur-radius": float(it["blur-radius"]),
                                       "border-radius": {k: nums(v) for k, v in it["border-radius"].items()}}
+    # large-boxshadow-ellipse-2.yaml (benchmarks.list:5): one INSET box shadow, blur radius 10000 (capped by the frame builder), radii of 400-700 px
+    it = yaml.safe_load(open(os.path.join(REF, "large-boxshadow-ellipse-2.yaml")))["root"]["items"][0]
+    assert it["type"] == "box-shadow" and it["clip-mode"] == "inset"
+    out["large-boxshadow-ellipse-2"] = {"bounds": nums(it["bounds"]), "color": it["color"], "blur-radius": float(it["blur-radius"]),
+                                        "clip-mode": it["clip-mode"], "border-radius": {k: nums(v) for k, v in it["border-radius"].items()}}
     # large-clip-rect.yaml: N identical opaque rects under one rounded-rectangle clip
     clip = yaml.safe_load(open(os.path.join(REF, "large-clip-rect.yaml")))["root"]["items"][0]
     assert clip["type"] == "clip" and len(clip["complex"]) == 1

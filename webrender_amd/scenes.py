@@ -2809,7 +2809,7 @@ def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, n_cgrads=
         elif mode == 1: c, r0, r1 = (0.0, 0.0), 0.0, float(np.hypot(W, H))
         elif mode == 2: c, r0, r1 = (W * 0.3, H * 0.7), min(W, H) * 0.1, min(W, H) * 0.4
         elif mode == 3: c, r0, r1 = (float(rng.uniform(-W, 2 * W)), float(rng.uniform(-H, 2 * H))), float(rng.uniform(0, 30)), float(rng.uniform(40, 200))
-        elif mode == 4: c, r0, r1 = (W * 0.5, H * 0.5), 10.0, 10.0                       # zero-length radius range: radius_scale = 0
+        elif mode == 4: c, r0, r1 = (W * 0.5, H * 0.5), 10.0, (10.0 if RADIAL_DEGENERATE else 14.5)   # zero-length radius range: radius_scale = 0
         else:           c, r0, r1 = (W * 0.5, -H), H * 0.9, H * 2.5                      # every row's span misses the centre row
         e = np.zeros(1, RGRAD_DTYPE)
         e["task"][0] = (o[0], o[1], o[0] + w, o[1] + h)
@@ -2855,6 +2855,12 @@ def cache_decorations(n_lines=60, n_grads=40, n_lgrads=30, n_rgrads=0, n_cgrads=
 # ---------------------------------------------------------------------------
 # ps_quad_radial_gradient / ps_quad_conic_gradient: gradient patterns on the quad path (quad.rs pattern kinds; the
 # QuadHeader's pattern_input = (address of the two gradient blocks in sGpuBufferF, address of the 128-entry stop table)).
+# Radial gradients with start radius == end radius (radius_scale = 0: every position maps to offset 0) are part of the parity
+# scenes.  The reference's SSE2 build evaluates them through fastSqrt<false>(0) = 0 * rsqrt(0) = NaN (swgl_ext.h:1607-1617, 1789):
+# tests/test_clang_budget.py turns them off for its family sweep and pins that behaviour in a case of its own.
+RADIAL_DEGENERATE = True
+
+
 def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, only=None, rotate=False, perspective=False):
     rng, rects = random_rects(n, width, height, 24, 380, seed, True)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
@@ -2880,7 +2886,7 @@ def quad_gradients(width=1024, height=1024, n=60, seed=181, tile_filter=None, on
             elif mode == 1: c, r0, r1 = (0.0, 0.0), 0.0, float(np.hypot(w, h))
             elif mode == 2: c, r0, r1 = (w * 0.3, h * 0.7), min(w, h) * 0.1, min(w, h) * 0.4
             elif mode == 3: c, r0, r1 = (float(rng.uniform(-w, 2 * w)), float(rng.uniform(-h, 2 * h))), float(rng.uniform(0, 30)), float(rng.uniform(40, 200))
-            else:           c, r0, r1 = (w * 0.5, h * 0.5), 10.0, 10.0
+            else:           c, r0, r1 = (w * 0.5, h * 0.5), 10.0, (10.0 if RADIAL_DEGENERATE else 14.5)
             ratio = 1.0 if i % 4 else float(rng.uniform(0.4, 2.5))
             blocks = [[c[0], c[1], 1.0, 1.0], [r0, r1, ratio, repeat]]
         params = frame.gpu_buffer_f.push(blocks)

@@ -351,9 +351,234 @@ def large_blur_radius(width=3840, height=2160, tile_filter=None, **kw):
     return _finish(frame, tiles)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Frame-builder pieces restated for the inset box shadow of large-boxshadow-ellipse-2.yaml
+def _au(v):
+    """app units: the interned keys hold lengths as Au (1/60 px), api/src/units.rs Au::from_f32_px"""
+    return float(np.float32(np.round(np.float32(v) * np.float32(60.0)) / np.float32(60.0)))
+
+
+def ensure_no_corner_overlap(radii, size):
+    """border.rs:168-215; radii = (TL, TR, BL, BR) as (w, h)"""
+    tl, tr, bl, br = radii
+    ratio = 1.0
+    if size[0] > 0.0:
+        for s in (tl[0] + tr[0], bl[0] + br[0]):
+            if size[0] < s:
+                ratio = min(ratio, size[0] / s)
+    if size[1] > 0.0:
+        for s in (tl[1] + bl[1], tr[1] + br[1]):
+            if size[1] < s:
+                ratio = min(ratio, size[1] / s)
+    if ratio < 1.0:
+        radii = tuple((float(np.float32(r[0]) * np.float32(ratio)), float(np.float32(r[1]) * np.float32(ratio))) for r in radii)
+    return radii
+
+
+def compute_box_shadow_parameters(fract_offset, size, radii, blur_radius):
+    """clip.rs:1765-1856 -> dict(minimal rect (x0, y0, w, h), alloc size, stretch modes (0 = stretch, 1 = simple), radii, blur region)"""
+    radii = ensure_no_corner_overlap(radii, size)
+    fract = (abs(size[0] - np.trunc(size[0])), abs(size[1] - np.trunc(size[1])))
+    cw, ch = max(r[0] for r in radii), max(r[1] for r in radii)
+    region = float(np.ceil(3.0 * blur_radius))
+    uw, uh = max(cw, region), max(ch, region)
+    mw, mh = 2.0 * uw + region + fract[0], 2.0 * uh + region + fract[1]
+    sx = sy = 0
+    if size[0] < mw:
+        mw, sx = size[0], 1
+    if size[1] < mh:
+        mh, sy = size[1], 1
+    alloc = (2.0 * region + float(np.ceil(mw)), 2.0 * region + float(np.ceil(mh)))
+    return dict(minimal=(region + fract_offset[0], region + fract_offset[1], mw, mh), alloc=alloc, stretch=(sx, sy), radii=radii, region=region)
+
+
+def new_box_shadow_clip(shadow_rect, radii, blur_radius):
+    """ClipItemKind::new_box_shadow (clip.rs:1860-1918): the minimal rect to blur; shadows whose allocation exceeds 2048 are rasterised
+    downscaled (original_alloc_size keeps the unscaled size: the shader stretches by it)."""
+    fo = (abs(shadow_rect[0] - np.trunc(shadow_rect[0])), abs(shadow_rect[1] - np.trunc(shadow_rect[1])))
+    size = (shadow_rect[2] - shadow_rect[0], shadow_rect[3] - shadow_rect[1])
+    src = compute_box_shadow_parameters(fo, size, radii, blur_radius)
+    src["original_alloc"], src["blur_radius"] = src["alloc"], blur_radius
+    m = max(src["alloc"])
+    if m > 2048.0:
+        k = float(np.float32(2048.0) / np.float32(m))
+        sc = tuple((float(np.float32(r[0]) * np.float32(k)), float(np.float32(r[1]) * np.float32(k))) for r in radii)
+        orig = src["alloc"]
+        src = compute_box_shadow_parameters((fo[0] * k, fo[1] * k), (float(np.float32(size[0]) * np.float32(k)), float(np.float32(size[1]) * np.float32(k))), sc,
+                                            float(np.float32(blur_radius) * np.float32(k)))
+        src["original_alloc"], src["blur_radius"] = orig, float(np.float32(blur_radius) * np.float32(k))
+    return src
+
+
+def extract_inner_rect_safe(rect, radii):
+    """util.rs:650-676 with k = 1"""
+    tl, tr, bl, br = radii
+    w, h = rect[2] - rect[0], rect[3] - rect[1]
+    xl, xr = np.ceil(max(tl[0], bl[0])), np.floor(w - max(tr[0], br[0]))
+    yt, yb = np.ceil(max(tl[1], tr[1])), np.floor(h - max(bl[1], br[1]))
+    if xl <= xr and yt <= yb:
+        return (rect[0] + float(xl), rect[1] + float(yt), rect[0] + float(xr), rect[1] + float(yb))
+    return None
+
+
+def build_segments(prim_rect, items):
+    """SegmentBuilder::build (segment.rs:511-650) for items = [(rect, mode, has_mask)], mode in (None, "clip", "clip_out"): the sweep
+    over the items' x / y events inside the prim rect -> [(x0, y0, x1, y1, has_mask)] row by row; a segment under a mask-less
+    clip-out item is dropped."""
+    items = [it for it in items if it[0][0] < prim_rect[2] and it[0][2] > prim_rect[0] and it[0][1] < prim_rect[3] and it[0][3] > prim_rect[1]]
+    q = lambda v: int(np.round(np.float32(v) * np.float32(60.0)))
+    cl = lambda v, lo, hi: min(max(v, lo), hi)
+    xs = sorted({cl(q(v), q(prim_rect[0]), q(prim_rect[2])) for it in items for v in (it[0][0], it[0][2])})
+    ys = sorted({cl(q(v), q(prim_rect[1]), q(prim_rect[3])) for it in items for v in (it[0][1], it[0][3])})
+    out = []
+    for y0, y1 in zip(ys, ys[1:]):
+        for x0, x1 in zip(xs, xs[1:]):
+            mask, drop = False, False
+            for (r, mode, has_mask) in items:
+                # active: begin <= segment start < end, in Au (EndClip sorts before BeginClip at one value)
+                if q(r[0]) <= x0 < q(r[2]) and q(r[1]) <= y0 < q(r[3]):
+                    mask |= has_mask
+                    drop |= (mode == "clip_out" and not has_mask)
+            if not drop:
+                out.append((x0 / 60.0, y0 / 60.0, x1 / 60.0, y1 / 60.0, mask))
+    return out
+
+
+def rounded_rect_items(rect, radii, mode):
+    """SegmentBuilder::push_clip_rect with a radius (segment.rs:397-470): the clip's nine-patch, corners carry the mask"""
+    inner = extract_inner_rect_safe(rect, radii)
+    if inner is None:
+        return [(rect, mode, True)]
+    p0, p1, p2, p3 = (rect[0], rect[1]), (inner[0], inner[1]), (inner[2], inner[3]), (rect[2], rect[3])
+    corners = [(p0[0], p0[1], p1[0], p1[1]), (p2[0], p0[1], p3[0], p1[1]), (p2[0], p2[1], p3[0], p3[1]), (p0[0], p2[1], p1[0], p3[1])]
+    others = [(p1[0], p0[1], p2[0], p1[1]), (p2[0], p1[1], p3[0], p2[1]), (p1[0], p2[1], p2[0], p3[1]), (p0[0], p1[1], p1[0], p2[1]), (p1[0], p1[1], p2[0], p2[1])]
+    return [(c, mode, True) for c in corners] + [(o, mode, False) for o in others]
+
+
+def large_boxshadow_ellipse_2(width=3840, height=2160, tile_filter=None, **kw):
+    """large-boxshadow-ellipse-2.yaml (benchmarks.list:5): an INSET box shadow of a 1024^2 box, blur radius 10000, elliptical radii of
+    400-700 px.  What the frame builder makes of it (box_shadow.rs:303-560 add_box_shadow, the "normal path"):
+      * blur radius capped at MAX_BLUR_RADIUS = 300; blur offset ceil(3 * 300) = 900, dest rect = the box inflated by it;
+      * the prim is a Rectangle on the BOX (inset shadows draw inside the original primitive) with two clips: the box's rounded
+        rect (ClipMode::Clip; its radii scaled by ensure_no_corner_overlap: the bottom widths 600 + 600 > 1024) and the box-shadow
+        clip source (BoxShadowClipMode::Inset);
+      * new_box_shadow (clip.rs:1860-1918): the minimal nine-patch (2 * 900 + 900 per axis) exceeds the 1024^2 shadow rect on both
+        axes -> BoxShadowStretchMode::Simple on both, the whole rect is blurred; its allocation 1800 + 1024 = 2824 > 2048 -> the
+        cached shadow is rasterised downscaled by 2048 / 2824 (radii, size and blur radius scaled; alloc 2 * 653 + 743 = 2049);
+      * the cached task (render_task.rs:613-700): rounded-rect mask of the minimal rect at 2049^2, new_blur with std deviation
+        round(217.56 / 2) = 109 -> five cs_scale halvings (1024 .. 64), cs_blur ALPHA_TARGET V / H at 64^2, std deviation 3.40625;
+      * segments (prepare.rs:1585-1660, segment.rs): the box-shadow mask region (dest rect; its inner rect -- the dest rect deflated
+        by half the ORIGINAL allocation -- is empty) marks every segment as masked, the rounded rect's nine-patch has a zero-width
+        centre column (xl = xr = 512) -> 2 x 3 segments, each with its own clip-mask task holding both clips
+        (cs_clip_box_shadow with clip mode 1 / simple stretch, cs_clip_rectangle multiplied on top), all drawn in the alpha pass."""
+    it = display_lists()["large-boxshadow-ellipse-2"]
+    b, r = it["bounds"], it["border-radius"]
+    box = (float(b[0]), float(b[1]), float(b[0] + b[2]), float(b[1] + b[3]))
+    raw = tuple((float(r[k][0]), float(r[k][1])) for k in ("top-left", "top-right", "bottom-left", "bottom-right"))
+    assert it["clip-mode"] == "inset"
+    blur_radius = min(float(it["blur-radius"]), 300.0)
+    size = (box[2] - box[0], box[3] - box[1])
+    clip_radii = tuple((_au(a), _au(c)) for a, c in ensure_no_corner_overlap(raw, size))       # ClipItemKeyKind::rounded_rect
+    blur_offset = float(np.ceil(3.0 * blur_radius))
+    dest = (box[0] - blur_offset, box[1] - blur_offset, box[2] + blur_offset, box[3] + blur_offset)
+    src = new_box_shadow_clip(box, raw, blur_radius)
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    zero = (0.0, 0.0, 0.0, 0.0)
+    pot = lambda v: 1 << int(np.ceil(np.log2(max(v, 64))))
+    # -- the cached blurred shadow: mask at cache resolution (device pixel scale 1), halvings, V / H blur
+    cache = (int(np.round(src["alloc"][0])), int(np.round(src["alloc"][1])))
+    sigma = float(np.floor(src["blur_radius"] * 0.5 + 0.5))                  # (blur_radius_dp * content_scale).round() as i32
+    t_m0 = TextureRef("bs2_corner_mask", pot(cache[0] + 8), pot(cache[1] + 8), G.GL_R8, G.GL_LINEAR, render_target=True)
+    tg0 = Target(t_m0, "alpha", clear_color=zero)
+    task0 = (4.0, 4.0, 4.0 + cache[0], 4.0 + cache[1])
+    mn = src["minimal"]
+    tg0.steps.append(Step("cs_clip_rectangle", "CLIP_RECT", scenes.clip_rect_instance(task0, (0.0, 0.0), 1.0, (mn[0], mn[1]), (mn[2], mn[3]), src["radii"], 0), None, "none"))
+    frame.passes.append([tg0])
+    frame.readback = [t_m0]
+    cur_tex, cur_rect, sz, sf = t_m0, task0, cache, 1.0
+    k = 0
+    while sigma > 4.0 and min(sz) >= 8:
+        sigma *= 0.5
+        sf *= 2.0
+        sz = (int(cache[0] / sf), int(cache[1] / sf))
+        t_s = TextureRef(f"bs2_scale_{k}", pot(sz[0] + 8), pot(sz[1] + 8), G.GL_R8, G.GL_LINEAR, render_target=True)
+        tgs = Target(t_s, "alpha", clear_color=zero)
+        nr = (4.0, 4.0, 4.0 + sz[0], 4.0 + sz[1])
+        inst = np.zeros(1, scenes.SCALE_DTYPE)
+        inst["t"][0], inst["s"][0], inst["k"][0] = nr, cur_rect, 1.0
+        tgs.steps.append(Step("cs_scale TEXTURE_2D", "SCALE", inst, None, "none", textures={0: cur_tex}))
+        frame.passes.append([tgs])
+        frame.readback.append(t_s)
+        cur_tex, cur_rect = t_s, nr
+        k += 1
+    region = (cache[0] // int(sf), cache[1] // int(sf))
+    t_v = TextureRef("bs2_blur_v", pot(sz[0] + 8), pot(sz[1] + 8), G.GL_R8, G.GL_LINEAR, render_target=True)
+    t_cache = TextureRef("bs2_texture_cache", pot(sz[0] + 8), pot(sz[1] + 8), G.GL_R8, G.GL_LINEAR, render_target=True)
+    a_src, a_v, a_h = (frame.add_render_task(cur_rect) for _ in range(3))
+    tg_v, tg_h = Target(t_v, "alpha", clear_color=zero), Target(t_cache, "alpha", clear_color=zero)
+    tg_v.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", scenes.blur_instance(a_v, a_src, 1, sigma, region), None, "none", textures={0: cur_tex}))
+    tg_h.steps.append(Step("cs_blur ALPHA_TARGET", "BLUR", scenes.blur_instance(a_h, a_v, 0, sigma, region), None, "none", textures={0: t_v}))
+    frame.passes += [[tg_v], [tg_h]]
+    frame.readback += [t_v, t_cache]
+    res = frame.gpu_cache.push([list(cur_rect), [0.0, 0.0, 0.0, 0.0]])
+    # -- segments and their clip-mask tasks
+    oa = src["original_alloc"]
+    inner = (dest[0] + 0.5 * oa[0], dest[1] + 0.5 * oa[1], dest[2] - 0.5 * oa[0], dest[3] - 0.5 * oa[1])
+    items = [(box, "clip", False), ((-BIG, -BIG, BIG, BIG), "clip", False)] + rounded_rect_items(box, clip_radii, "clip")
+    if inner[0] >= inner[2] or inner[1] >= inner[3]:           # push_mask_region with an empty inner rect: the whole region needs the mask
+        items.append((dest, None, True))
+    else:
+        raise NotImplementedError("inset shadow with a non-empty inner rect: eight mask regions + an inner clip-out")
+    segs = build_segments(box, items)
+    assert all(sg[4] for sg in segs)
+    mw = pot(int(max(sg[2] - sg[0] for sg in segs)) * 2 + 16)
+    t_masks = TextureRef("bs2_prim_masks", mw, pot(int(sum(sg[3] - sg[1] for sg in segs)) // 2 + 64), G.GL_R8, G.GL_LINEAR, render_target=True)
+    tg_m = Target(t_masks, "alpha", clear_color=(1.0, 1.0, 1.0, 1.0))
+    bs_inst = np.zeros(len(segs), scenes.BOX_SHADOW_DTYPE)
+    rr_inst, seg_task = [], []
+    col_y = [4, 4]
+    for si, sg in enumerate(segs):
+        so = (float(np.floor(sg[0])), float(np.floor(sg[1])))
+        tw, th = int(np.ceil(sg[2]) - so[0]), int(np.ceil(sg[3]) - so[1])
+        c = si % 2
+        x0, y0 = 4 + c * (mw // 2), col_y[c]
+        col_y[c] += th + 4
+        task = (float(x0), float(y0), float(x0 + tw), float(y0 + th))
+        bs_inst["area"][si] = (0.0, 0.0, tw, th)
+        bs_inst["origins"][si] = (task[0], task[1], so[0], so[1])
+        bs_inst["dps"][si] = 1.0
+        bs_inst["res"][si] = (res % 1024, res // 1024)
+        bs_inst["src_size"][si] = oa
+        bs_inst["mode"][si] = 1                                   # BoxShadowClipMode::Inset
+        bs_inst["stretch"][si] = src["stretch"]
+        bs_inst["dest"][si] = dest
+        rr_inst.append(scenes.clip_rect_instance(task, so, 1.0, (box[0], box[1]), size, clip_radii, 0))
+        seg_task.append(frame.add_render_task(task, 1.0, so))
+    tg_m.steps.append(Step("cs_clip_box_shadow TEXTURE_2D", "CLIP_BOX_SHADOW", bs_inst, None, "none", textures={0: t_cache}))
+    tg_m.steps.append(Step("cs_clip_rectangle", "CLIP_RECT", np.concatenate(rr_inst), "Multiply", "none"))
+    frame.passes.append([tg_m])
+    frame.readback.append(t_masks)
+    # -- the masked brush segments over the tiles
+    color = premultiply(np.array([list(CSS[it["color"]])], np.uint8))[0]
+    blocks = [list(color)]
+    for sg in segs:
+        blocks += [[sg[0] - box[0], sg[1] - box[1], sg[2] - box[0], sg[3] - box[1]], [0.0, 0.0, 0.0, 0.0]]
+    spec = frame.gpu_cache.push(blocks)
+    tiles = _tiles(frame, width, height, tile_filter)
+    for target, task, (x0, y0, x1, y1) in tiles:
+        if not (box[0] < x1 and box[2] > x0 and box[1] < y1 and box[3] > y0):
+            continue
+        ph = frame.add_prim_header(box, (-BIG, -BIG, BIG, BIG), 1, spec, 0, task, (65535, 0, 0, 0))
+        inst = [frame.brush_instance(ph, seg_task[si], segment=si) for si in range(len(segs))]
+        target.alpha.append(Step("brush_solid ALPHA_PASS", "PRIM_INSTANCES", np.array(inst, dtype=np.int32), "PremultipliedAlpha", "alpha",
+                                 textures={9: t_masks}))
+    return _finish(frame, tiles)
+
+
 WORKLOADS = {
     "large-blur-radius": large_blur_radius,
     "large-boxshadow-ellipse": large_boxshadow_ellipse,
+    "large-boxshadow-ellipse-2": large_boxshadow_ellipse_2,
     "large-clip-rect": large_clip_rect,
     "many-images": many_images,
     "aligned-gradient": lambda **kw: linear_gradients("aligned-gradient", **kw),
@@ -364,6 +589,7 @@ WORKLOADS = {
 DESCRIPTIONS = {
     "large-blur-radius": "wrench benchmarks/large-blur-radius.yaml: filter blur(100, 100) over a 1024x1024 rect (the picture in a 1632^2 colour task, five cs_scale halvings, cs_blur COLOR_TARGET V/H at 51^2, the result composited by brush_image ALPHA_PASS with RasterizationSpace::Screen uv)",
     "large-boxshadow-ellipse": "wrench benchmarks/large-boxshadow-ellipse.yaml: one outset box shadow of a 1024x1024 box, blur radius 10, elliptical corner radii (cached blurred corner: mask -> cs_scale -> cs_blur V/H, then the cs_clip_box_shadow x clip-out mask and masked brush_solid segments)",
+    "large-boxshadow-ellipse-2": "wrench benchmarks/large-boxshadow-ellipse-2.yaml: one INSET box shadow of a 1024x1024 box, blur radius capped at 300, elliptical radii of 400-700 px (the whole shadow rect blurred downscaled: 2049^2 mask -> five cs_scale halvings -> cs_blur V/H at 64^2; six masked brush_solid segments, each mask = cs_clip_box_shadow in inset / simple-stretch mode x the box's rounded rect)",
     "large-clip-rect": "wrench benchmarks/large-clip-rect.yaml: 8 opaque 1024x1024 rects under one rounded-rectangle clip (radius 16): 3x3 brush segments per rect, 4 corner clip-mask tasks each (cs_clip_rectangle FAST_PATH), opaque + masked alpha pass",
     "many-images": "wrench benchmarks/many-images.yaml: 8192 opaque 8x8 images (one texture-cache entry each), brush_image opaque pass",
     "aligned-gradient": "wrench benchmarks/aligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient (brush_linear_gradient, opaque pass, depth-rejected overdraw)",
