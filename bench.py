@@ -72,6 +72,8 @@ def kernel_label(k):
         return f"wr_setup_raster_dense_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
     if k.kind == 8:
         return "wr_setup_rows_kernel"
+    if k.kind == 9:      # the span-rows targets of a level (cs_blur / cs_scale passes): one wave per target row piece
+        return f"wr_span_rows_kernel<{k.fmt}>"
     return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
 
 
@@ -334,7 +336,7 @@ def main():
             if tr:
                 e["traffic"], e["traffic_source"] = tr
             per_kernel.append(e)
-        rasters = [e for e in per_kernel if e["name"].startswith("wr_raster_") or e["name"].startswith("wr_setup_raster")]
+        rasters = [e for e in per_kernel if e["name"].startswith("wr_raster_") or e["name"].startswith("wr_setup_raster") or e["name"].startswith("wr_span_rows")]
         if rasters:
             dom = max(rasters, key=lambda e: e["us_per_frame"])
             roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],

@@ -120,11 +120,15 @@ BLUR_CASES = [
 ]
 
 
+@pytest.mark.parametrize("evaluation", ["span_rows", "bins"])
 @pytest.mark.parametrize("name,kw", BLUR_CASES, ids=[c[0] for c in BLUR_CASES])
-def test_hip_blur_matches_oracle(name, kw):
+def test_hip_blur_matches_oracle(name, kw, evaluation, monkeypatch):
     """cs_blur vertical + horizontal passes on the GPU; integer 8.8 taps are
     bit-exact, the float fragment-shader edge columns are allowed +-1 LSB
-    (exp() of the coefficient comes from a different libm)."""
+    (exp() of the coefficient comes from a different libm).  Both evaluations: a wave per target row
+    (wr_span_rows_kernel, the default for cs_blur / cs_scale targets) and the bin raster (WRHIP_NO_SPAN_ROWS)."""
+    if evaluation == "bins":
+        monkeypatch.setenv("WRHIP_NO_SPAN_ROWS", "1")
     got, _ = render_direct(wrhip_lib(), scenes.blur_chain(**kw))
     ref = oracle_ref()
     if ref:
@@ -184,6 +188,7 @@ def test_hip_chained_mask_levels_are_bit_exact(kw, monkeypatch):
     """WRHIP_CHAIN=1 (off by default: measured slower, profiles/r03_e_chain_ab.txt): the thin R8 levels of the box-shadow chain in
     one persistent launch with grid barriers give the bytes the separate launches give, in fewer launches, and no workgroup
     gives up at a barrier (that would raise GL_INVALID_OPERATION)."""
+    monkeypatch.setenv("WRHIP_NO_SPAN_ROWS", "1")      # (the scale / blur levels as thin bin launches: what the chain is made of)
     want, st0 = render_direct(wrhip_lib(), scenes.cfg4_box_shadow(**kw))
     monkeypatch.setenv("WRHIP_CHAIN", "1")
     got, st1 = render_direct(wrhip_lib(), scenes.cfg4_box_shadow(**kw))

@@ -108,10 +108,14 @@ BLUR_CASES = [
 ]
 
 
+@pytest.mark.parametrize("evaluation", ["span_rows", "bins"])
 @pytest.mark.parametrize("name,kw", BLUR_CASES, ids=[c[0] for c in BLUR_CASES])
-def test_hostsim_blur_matches_oracle(hostsim, oracle_gcc, name, kw):
+def test_hostsim_blur_matches_oracle(hostsim, oracle_gcc, name, kw, evaluation, monkeypatch):
     """cs_blur vertical + horizontal passes (R8 and RGBA8 targets): every
-    render target of the chain is compared, not only the window."""
+    render target of the chain is compared, not only the window.  Both evaluations of the off-screen levels: a wave per
+    target row (wr_span_rows_kernel, the default) and the bin raster (WRHIP_NO_SPAN_ROWS=1)."""
+    if evaluation == "bins":
+        monkeypatch.setenv("WRHIP_NO_SPAN_ROWS", "1")
     want, _ = render_direct(oracle_gcc, scenes.blur_chain(**kw))
     got, _ = render_direct(hostsim, scenes.blur_chain(**kw))
     assert set(got) == set(want)

@@ -519,7 +519,7 @@ struct Context {
   // plus a kernel boundary; the rest follow in order.  Anything that needs their results, or touches a
   // texture they read or write from outside the draw stream (host uploads, copies, readbacks,
   // deletes, Finish), drains them first (drain_tail).
-  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; int mr_rows = 0; int dense = 0; };   // dense: the level's R8-texture prims are glyph runs (wr_raster_dense_kernel)   // mr_rows > 0: wr_mask_rows_kernel goes first (bound on its rows)    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
+  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; int mr_rows = 0; int dense = 0; int row_t0 = 0, row_n = 0, row_items = 0; };   // dense: the level's R8-texture prims are glyph runs (wr_raster_dense_kernel)   // mr_rows > 0: wr_mask_rows_kernel goes first (bound on its rows)    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
   struct Tail {
     bool pending = false;
     std::vector<Held> held;          // the raster launches of the held-back flush, in order
@@ -578,6 +578,7 @@ struct Context {
   bool forward_composites = true;      // WRHIP_NO_FORWARD=1 turns the write-through of opaque 1:1 composites off
   bool profiling_no_forward = false;
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
+  bool span_rows = true;               // WRHIP_NO_SPAN_ROWS=1: cs_blur / cs_scale targets go through the bin raster like everything else
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
   int thin_parts = 4;                  // workgroups per bin of a thin launch (WRHIP_THIN_PARTS = 1, 2, 4, 8, 16): 16 / parts waves each, so that a wave shares its SIMD with fewer others
@@ -608,6 +609,7 @@ struct Context {
       chain_grid = getenv("WRHIP_CHAIN_GRID") ? atoi(getenv("WRHIP_CHAIN_GRID")) : wrrt::cu_count() / 2;
     cell_raster = getenv("WRHIP_NO_CELLS") == nullptr;
     mask_rows = getenv("WRHIP_NO_MASK_ROWS") == nullptr;
+    span_rows = getenv("WRHIP_NO_SPAN_ROWS") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
@@ -1184,7 +1186,7 @@ void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint6
   for (WrhipKernelStat& e : c->kstats) if (e.kind == kind && e.fmt == fmt && e.depth == depth && e.feat == feat) k = &e;
   if (!k) { c->kstats.push_back(WrhipKernelStat{kind, fmt, depth, feat, 0, 0, 0, 0}); k = &c->kstats.back(); }
   k->launches++; k->ns += ns; k->algo_bytes += algo_bytes; k->workgroups += workgroups;
-  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7) c->stats.raster_ns += ns;
+  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9) c->stats.raster_ns += ns;
 }
 
 void tail_launched() {
@@ -1197,6 +1199,7 @@ void tail_launched() {
 // The instantiated raster kernels: RGBA8 (+depth) x {0, TEX|GENERIC, +R8TEX, everything}, R8 x {0, GENERIC|BLUR, +CLIP}.
 // `SA` non-null: launch the fused setup + raster variant (only for the variants can_fuse() names).
 bool can_fuse(const Context::Held& H) {
+  if (H.row_n > 0) return false;           // (a span-rows launch: short, nothing to hide a setup stage behind)
   if (H.mr_rows > 0) return true;          // (the mask-rows launch ahead of an R8 raster launch: wr_setup_rows_kernel)
   return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
                                    H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
@@ -1207,7 +1210,7 @@ bool can_fuse(const Context::Held& H) {
 // `chain_n` >= 2: H is the first of chain_n consecutive thin R8 launches of one variant (chainable()); they go out as one
 // wr_raster_chain_kernel launch.
 bool chainable(const Context::Held& H) {
-  return ctx->chain_grid > 0 && H.fmt == WR_FMT_R8 && H.nb <= WR_THIN_MAX_BINS && (H.feat == 0 || H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR));
+  return ctx->chain_grid > 0 && H.row_n == 0 && H.fmt == WR_FMT_R8 && H.nb <= WR_THIN_MAX_BINS && (H.feat == 0 || H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR));
 }
 void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_targets, const WrDrawDesc* draws, Context::Scratch& S,
                    const WrSetupArgs* SA = nullptr, int n_setup_blocks = 0, int chain_n = 1, uint64_t setup_bytes = 0) {
@@ -1223,6 +1226,17 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
               n_setup_blocks, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs,                  \
               (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);                                               \
   } while (0)
+  if (H.row_n > 0) {
+    // the span-rows targets of a level: one wave per (target row, 256-pixel piece), four waves per workgroup
+    const int wgs = std::max(1, std::min((H.row_items + 3) / 4, 16384));
+    static const bool dbg_rows = getenv("WRHIP_DEBUG_ROWS") != nullptr;
+    if (dbg_rows) fprintf(stderr, "span rows: targets [%d, %d) items %d workgroups %d\n", H.row_t0, H.row_t0 + H.row_n, H.row_items, wgs);
+    prof_begin();
+    WR_LAUNCH(wr_span_rows_kernel, wgs, 256, c->stream, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
+    prof_end(9, H.fmt, 0, 0, H.algo_bytes, (uint64_t)wgs);
+    c->stats.kernel_launches++; c->stats.raster_launches++;
+    return;
+  }
   const int F5 = WR_FEAT_TEX | WR_FEAT_GENERIC, F7 = F5 | WR_FEAT_R8TEX, FA = F7 | WR_FEAT_BLUR | WR_FEAT_SHADE;
   if (H.mr_rows > 0 && S.mr_ctl) {
     // the cs_clip_* prims of this launch's targets, row by row (one wave per row), ahead of the bins that blend them
@@ -1488,13 +1502,34 @@ void flush_work(const std::vector<int>& sel_in) {
   }
   std::vector<int> forwarded_sel;
   for (int wi : sel_in) if (c->work[wi].forwarded_away) forwarded_sel.push_back(wi);
-  // by dependency level, RGBA8 targets first inside a level, so each raster launch gets a contiguous bin range
+  // Span-rows targets (wr_span_rows_kernel): every draw is a cs_blur / cs_scale pass or a clear, unblended, without depth --
+  // the levels of a blur chain.  They get no bins; a wave per target row walks the target's few prims instead.
+  auto rows_eligible = [&](const TargetWork& w) {
+    if (!c->span_rows || w.fwd_tex || w.forwarded_away || w.depth_tex) return false;
+    const Texture& t = c->textures[w.tex];
+    if (t.internal_format != GL_R8 && t.internal_format != GL_RGBA8) return false;
+    int nprim = 0; bool any = false;
+    for (const WrDrawDesc& d : w.draws) {
+      if (d.shader == WR_SH_CLEAR_OP) { if (d.flags & WR_DF_CLEAR_DEPTH) return false; nprim += 1; continue; }
+      if (d.shader != WR_SH_CS_BLUR_ALPHA && d.shader != WR_SH_CS_BLUR_COLOR && d.shader != WR_SH_CS_SCALE) return false;
+      if (d.blend != WR_BLEND_NONE || (d.flags & (WR_DF_DEPTH_TEST | WR_DF_DEPTH_WRITE | WR_DF_QUADS | WR_DF_SIMPLE | WR_DF_XFORM))) return false;
+      any = true; nprim += d.count;
+    }
+    return any && nprim <= 48;
+  };
+  std::vector<char> rows_of(c->work.size(), 0);
+  for (int wi : sel) rows_of[wi] = rows_eligible(c->work[wi]) ? 1 : 0;
+  // by dependency level, RGBA8 targets first inside a level, span-rows targets last, so each launch gets a contiguous bin / target range
   std::stable_sort(sel.begin(), sel.end(), [&](int a, int b) {
     const int la = c->work[a].level, lb = c->work[b].level;
     if (la != lb) return la < lb;
-    return (c->textures[c->work[a].tex].internal_format == GL_R8) < (c->textures[c->work[b].tex].internal_format == GL_R8);
+    const int ka = rows_of[a] ? 2 : (c->textures[c->work[a].tex].internal_format == GL_R8 ? 1 : 0);
+    const int kb = rows_of[b] ? 2 : (c->textures[c->work[b].tex].internal_format == GL_R8 ? 1 : 0);
+    return ka < kb;
   });
-  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false, text = false; uint64_t bytes_rgba = 0, bytes_r8 = 0, mr_rows = 0; };
+  struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false, text = false; uint64_t bytes_rgba = 0, bytes_r8 = 0, mr_rows = 0;
+                 int row_t0 = -1, row_n = 0, row_items = 0, row_fmt = 0; uint64_t bytes_rows = 0; };
+  int n_row_targets = 0;
   uint64_t mr_slots = 0, mr_rows = 0, mr_bytes = 0;      // bounds on what the cs_clip_* prims of this flush can reserve in the mask-row store
   std::vector<Level> levels;
   std::vector<int> target_level;
@@ -1535,6 +1570,7 @@ void flush_work(const std::vector<int>& sel_in) {
       for (int k = 0; k < 4; k++) T.fwd_clip[k] = w.fwd_clip[k];
     }
     T.cells = c->cell_raster ? 1 : 0;
+    T.rows_mode = rows_of[sel[oi]] ? 1 : 0;
     T.y_begin = 0; T.y_end = t.height;
     if (t.own_y1 > t.own_y0) {   // WrhipSetTargetRows: rows of this target owned by this process
       T.y_begin = std::max(0, t.own_y0); T.y_end = std::min(t.height, t.own_y1);
@@ -1610,9 +1646,17 @@ void flush_work(const std::vector<int>& sel_in) {
     int nrel = T.end_prim - T.first_prim;
     T.words_per_bin = (nrel + 63) / 64;
     T.word_base = word_cursor;
-    word_cursor += T.words_per_bin * T.bins_x * T.bins_y;
-    bin_cursor += T.bins_x * T.bins_y;
-    (T.format == WR_FMT_RGBA8 ? L.bins_rgba : L.bins_r8) += T.bins_x * T.bins_y;
+    if (T.rows_mode) {
+      // no bins, no mask words: the level's span-rows launch takes targets [row_t0, row_t0 + row_n)
+      T.words_per_bin = 0;
+      if (L.row_n == 0) { L.row_t0 = oi; L.row_fmt = T.format; }
+      L.row_n++; n_row_targets++;
+      L.row_items += std::max(0, T.y_end - T.y_begin) * WR_SPAN_PIECES(t.width);
+    } else {
+      word_cursor += T.words_per_bin * T.bins_x * T.bins_y;
+      bin_cursor += T.bins_x * T.bins_y;
+      (T.format == WR_FMT_RGBA8 ? L.bins_rgba : L.bins_r8) += T.bins_x * T.bins_y;
+    }
     uint64_t owned = (uint64_t)t.width * std::max(0, T.y_end - T.y_begin);
     pixels += owned;
     {
@@ -1625,7 +1669,7 @@ void flush_work(const std::vector<int>& sel_in) {
       tb += std::min<uint64_t>(src, owned * t.bpp);
       if (w.fwd_tex) tb += (uint64_t)std::max(0, w.fwd_clip[2] - w.fwd_clip[0]) * std::max(0, w.fwd_clip[3] - w.fwd_clip[1]) * 4;   // the write-through
       algo_bytes += tb;
-      (T.format == WR_FMT_RGBA8 ? L.bytes_rgba : L.bytes_r8) += tb;
+      (T.rows_mode ? L.bytes_rows : (T.format == WR_FMT_RGBA8 ? L.bytes_rgba : L.bytes_r8)) += tb;
     }
     if (dt && nrel > 0 && w.depth_live && dt->depth_cleared && dt->depth_owner == w.tex) {
       // The caller has not invalidated (or fully cleared) the depth these draws leave behind: it outlives the flush -- a
@@ -1655,7 +1699,8 @@ void flush_work(const std::vector<int>& sel_in) {
   }
   const int n_prims = prim_cursor, n_bins = bin_cursor, n_words = word_cursor;
   const int nd = (int)draws.size();
-  if (n_bins > 0) {
+  const bool any_work = n_bins > 0 || n_row_targets > 0;
+  if (any_work) {
     // the prim arrays of this flush's scratch set, sized here: the address of its glyph records goes into the target descriptors
     Context::Scratch& S = c->scratch[c->flush_seq & 1];
     if (S.prims_cap < (size_t)n_prims + 1) {
@@ -1666,10 +1711,10 @@ void flush_work(const std::vector<int>& sel_in) {
       S.recs = (WrRec*)wrrt::dev_alloc(S.prims_cap * (sizeof(WrRec) + sizeof(WrGlyphRec)));      // recs[], then the glyph records (WrTargetDesc::grecs)
       S.aux = (WrAux*)wrrt::dev_alloc(S.prims_cap * sizeof(WrAux));
     }
-    if (S.bin_ctr_cap < (size_t)n_bins) {
+    if (S.bin_ctr_cap < (size_t)n_bins || !S.bin_ctr) {
       sync_stream();
       wrrt::dev_free(S.bin_ctr);
-      S.bin_ctr_cap = (size_t)n_bins * 2;
+      S.bin_ctr_cap = (size_t)std::max(n_bins, 64) * 2;
       S.bin_ctr = (unsigned*)wrrt::dev_alloc(S.bin_ctr_cap * sizeof(unsigned));
       wrrt::memset8(S.bin_ctr, 0, S.bin_ctr_cap * sizeof(unsigned), c->stream);      // (the workgroups leave them at zero)
     }
@@ -1708,7 +1753,7 @@ void flush_work(const std::vector<int>& sel_in) {
   }
   for (WrTargetDesc& T : targets) { T.flat_rows = nullptr; T.counters = c->dcounters; }
   static const bool no_flat = getenv("WRHIP_NO_FLAT") != nullptr;      // (debugging: leave flattened depth rows unmodelled)
-  if (flat_words && n_bins > 0 && !no_flat) {
+  if (flat_words && any_work && !no_flat) {
     Context::Scratch& S = c->scratch[c->flush_seq & 1];
     if (S.flat_cap < flat_words) {
       sync_stream();
@@ -1719,7 +1764,7 @@ void flush_work(const std::vector<int>& sel_in) {
     wrrt::memset8(S.flat, 0xFF, flat_words * 4, c->stream);          // (this set's previous user, two flushes back, has been launched)
     for (int oi = 0; oi < n_targets; oi++) if (flat_off[oi] != SIZE_MAX) targets[oi].flat_rows = S.flat + flat_off[oi];
   }
-  if (n_bins > 0) {
+  if (any_work) {
     // ---- frame arena: [draws | targets | instance bytes] -> one H2D copy ----
     size_t off_draws = 0;
     size_t off_targets = (off_draws + sizeof(WrDrawDesc) * nd + 255) & ~size_t(255);
@@ -1863,6 +1908,7 @@ void flush_work(const std::vector<int>& sel_in) {
     // specialised on the prim families present in the launch (FEAT) so that
     // rect-only passes do not pay the registers of the texture paths.
     for (int i = 0; i < nd; i++) {
+      if (targets[draws[i].target].rows_mode) continue;          // (span-rows targets are in no bin launch)
       const bool to_r8 = targets[draws[i].target].format == WR_FMT_R8;
       Level& L = levels[target_level[draws[i].target]];
       int f = 0;
@@ -1907,6 +1953,11 @@ void flush_work(const std::vector<int>& sel_in) {
       if (L.bins_r8 > 0) {
         const int f = L.feat_r8 == 0 ? 0 : (!(L.feat_r8 & WR_FEAT_CLIP) ? (WR_FEAT_GENERIC | WR_FEAT_BLUR) : (WR_FEAT_GENERIC | WR_FEAT_BLUR | WR_FEAT_CLIP));
         launches.push_back(Context::Held{WR_FMT_R8, 0, f, L.bins_r8, L.bin0 + L.bins_rgba, L.bytes_r8, (int)std::min<uint64_t>(L.mr_rows, WR_MR_MAX_ROWS)});
+      }
+      if (L.row_n > 0) {
+        Context::Held H{L.row_fmt, 0, 0, 0, 0, L.bytes_rows};
+        H.row_t0 = L.row_t0; H.row_n = L.row_n; H.row_items = L.row_items;
+        launches.push_back(H);
       }
     }
     if (c->defer_tail && (!c->profiling || c->profiling_deferred) && !launches.empty()) {

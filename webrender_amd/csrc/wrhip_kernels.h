@@ -3814,6 +3814,7 @@ WR_DEVICE void wr_bin_prim(const WrPrim& P, bool valid, int gid, const WrDrawDes
     by0 = wr_imax(P.y0, 0) / WR_BIN_H; by1 = (wr_imin(P.y1, T.height) - 1) / WR_BIN_H;
     by0 = wr_imax(by0, T.y_begin / WR_BIN_H); by1 = wr_imin(by1, (T.y_end - 1) / WR_BIN_H);
     rel = gid - T.first_prim;
+    if (T.rows_mode) bx1 = -1;        // a span-rows target has no bins (wr_span_rows_kernel walks its prim range per row)
   }
   const bool has = tgt >= 0 && bx1 >= bx0 && by1 >= by0;
 #ifdef WRHIP_HOSTSIM
@@ -5855,103 +5856,101 @@ __global__ void wr_composite_yuv_kernel(WrYuvBlitArgs A) {
 }
 #endif
 
+// The part of a cs_blur row that every pixel of the row shares: the interpolants at the span start, the integer texel position the span
+// shader starts from and how many pixels it draws (the rest of the row is main()'s).
+struct WrBlurRow { float ou, ov, su, sv; int startX, curY, drawn; };
 template <int FMT>
-__device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* Bp, int x, int y) {
-  const WrPrim& P = *Pp;
-  const WrBlurRec& B = *Bp;
-  const int tw = int(B.wh & 0xFFFF), th = int(B.wh >> 16);
-  const float W = float(tw), H = float(th);
+WR_DEVICE WrBlurRow wr_blur_row_setup(const WrPrim& P, const WrBlurRec& B, int y) {
+  WrBlurRow R;
+  const int tw = int(B.wh & 0xFFFF);
+  const float W = float(tw), H = float(int(B.wh >> 16));
   // interpolants at the span start (as wr_tex_row)
   const int k = y - P.y0;
   const float Lu = wr_accum(P.uvL0[0], P.uvLs[0], k), Lv = wr_accum(P.uvL0[1], P.uvLs[1], k);
   const float Ru = wr_accum(P.uvR0[0], P.uvRs[0], k), Rv = wr_accum(P.uvR0[1], P.uvRs[1], k);
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
-  const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
+  R.su = (Ru - Lu) * stepScale; R.sv = (Rv - Lv) * stepScale;
   const float start = float(P.x0) + 0.5f - P.xl;
-  const float ou = Lu + su * start, ov = Lv + sv * start;
+  R.ou = Lu + R.su * start; R.ov = Lv + R.sv * start;
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0;
-  const int n = x - P.x0;
-  constexpr int NCH = FMT == WR_FMT_RGBA8 ? 4 : 1;
   const bool fmt_ok = B.format == FMT && B.ptr != nullptr;
-  const int startX = int(ou * W), curY = int(ov * H);
-  int drawn = 0;
+  R.startX = int(R.ou * W); R.curY = int(R.ov * H);
+  R.drawn = 0;
   if (fmt_ok && span > 0) {
-    const int endX = wr_imin(wr_imin(B.bounds[2], startX + span), tw);
-    if (endX - startX >= 4) drawn = (endX - startX) & ~3;
+    const int endX = wr_imin(wr_imin(B.bounds[2], R.startX + span), tw);
+    if (endX - R.startX >= 4) R.drawn = (endX - R.startX) & ~3;
   }
+  return R;
+}
+// Span pixel n < drawn of the row (blendGaussianBlur -> gaussianBlurHorizontal / Vertical, texture.h:1165-1308): the chunk's texel
+// position is the integer position of the span start plus whole chunks; tap o reads the texels o to either side, each side clamped to
+// the blur bounds -- along the row in whole-chunk terms for the horizontal pass (taps inside the chunk's own four texels are never
+// clamped), along the column for the vertical one; 8.8 fixed-point weights, 16-bit wrap of every product, saturating adds.
+// One loop for both directions and both formats: this is the code a thin blur level runs from a cold instruction cache.
+template <int FMT>
+WR_DEVICE WrWide wr_blur_span_px(const WrBlurRec& B, const WrBlurRow& R, const int n) {
+  const int tw = int(B.wh & 0xFFFF), th = int(B.wh >> 16);
+  constexpr int NCH = FMT == WR_FMT_RGBA8 ? 4 : 1;
+  const int kk = n & 3, ix = R.startX + (n & ~3), curY = R.curY;
+  const int radius = B.radius;
+  const ptrdiff_t at = (ptrdiff_t)wr_clamp_coord(ix, tw - 1) + (ptrdiff_t)wr_clamp_coord(curY, th) * B.stride + kk;
+  const bool hori = B.hori != 0;
+  // horizontal: offsets in texels relative to the chunk start (rb / lb: how far the chunk start is from the bounds);
+  // vertical: offsets in rows (amax / bmax)
+  const int rlim = hori ? wr_imin(B.bounds[2], tw - 1) - ix : wr_imax(wr_imin(B.bounds[3], th - 1) - curY, 0);
+  const int llim = hori ? ix - wr_imax(B.bounds[0], 0) : wr_imax(curY - wr_imax(B.bounds[1], 0), 0);
+  const ptrdiff_t unit = hori ? 1 : (ptrdiff_t)B.stride;
+  auto texel = [&](ptrdiff_t i) -> uint32_t { return FMT == WR_FMT_RGBA8 ? ((const uint32_t*)B.ptr)[i] : (uint32_t)((const uint8_t*)B.ptr)[i]; };
+  uint32_t sum[NCH];
+  {
+    const uint32_t c = texel(at), w0 = B.weights[0];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) sum[ch] = (((c >> (8 * ch)) & 0xFF) * w0) & 0xFFFF;
+  }
+  // taps in batches of eight: the sixteen texel loads of a batch are issued together and waited for once (a tap per round trip
+  // made a thin level as long as radius x pixels-per-lane dependent L2 accesses); a tap beyond the radius re-reads the last one
+  // with weight 0, which leaves the saturating sum as it is
+  for (int o0 = 1; o0 <= radius; o0 += 8) {
+    uint32_t rr[8], ll[8], ww[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int o = wr_imin(o0 + j, radius);
+      // (hori: kk + o stays unclamped while it is inside the chunk, then min(kk + o, rb) from the chunk start; likewise to the left)
+      const int ro = hori ? ((kk + o <= 3) ? o : wr_imin(kk + o, rlim) - kk) : wr_imin(o, rlim);
+      const int lo = hori ? ((o <= kk) ? o : wr_imin(o - kk, llim) + kk) : wr_imin(o, llim);
+      rr[j] = texel(at + (ptrdiff_t)ro * unit); ll[j] = texel(at - (ptrdiff_t)lo * unit);
+      ww[j] = o0 + j <= radius ? (uint32_t)B.weights[o] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++) {
+        const uint32_t t = ((((rr[j] >> (8 * ch)) & 0xFF) + ((ll[j] >> (8 * ch)) & 0xFF)) * ww[j]) & 0xFFFF;
+        const uint32_t a = sum[ch] + t;
+        sum[ch] = a > 0xFFFF ? 0xFFFF : a;
+      }
+    }
+  }
+  WrWide out;
+  if (FMT == WR_FMT_RGBA8) {
+    out.bg = (sum[0] >> 8) | ((sum[1] >> 8) << 16);
+    out.ra = (sum[2] >> 8) | ((sum[3] >> 8) << 16);
+  } else {
+    out.bg = sum[0] >> 8; out.ra = 0;
+  }
+  return out;
+}
+// A pixel the span shader leaves to main() (cs_blur.glsl:137-181): the row's last (len & 3) pixels, or every pixel of a row it did not draw
+template <int FMT>
+__device__ __noinline__ WrWide wr_blur_tail_px(const WrPrim* Pp, const WrBlurRec* Bp, const WrBlurRow* Rp, const int n) {
+  const WrPrim& P = *Pp; const WrBlurRec& B = *Bp; const WrBlurRow& R = *Rp;
+  (void)P;
+  const int tw = int(B.wh & 0xFFFF), th = int(B.wh >> 16);
+  const float W = float(tw), H = float(th);
+  const float su = R.su, sv = R.sv, ou = R.ou, ov = R.ov;
+  const int drawn = R.drawn;
   WrWide out; out.bg = out.ra = 0;
-  if (n < drawn) {
-    const int kk = n & 3, ix = startX + (n & ~3);
-    const int radius = B.radius;
-    uint32_t sum[NCH];
-    const uint32_t w0 = B.weights[0];
-    if (B.hori) {
-      const size_t row = (size_t)wr_clamp_coord(ix, tw - 1) + (size_t)wr_clamp_coord(curY, th) * B.stride;
-      const int lb = ix - wr_imax(B.bounds[0], 0), rb = wr_imin(B.bounds[2], tw - 1) - ix;
-      if (FMT == WR_FMT_RGBA8) {
-        const uint32_t* buf = (const uint32_t*)B.ptr;
-        const uint32_t c = buf[row + kk];
-        for (int ch = 0; ch < NCH; ch++) sum[ch] = (((c >> (8 * ch)) & 0xFF) * w0) & 0xFFFF;
-        for (int o = 1; o <= radius; o++) {
-          const uint32_t r = buf[(ptrdiff_t)row + ((kk + o <= 3) ? kk + o : wr_imin(kk + o, rb))];
-          const uint32_t l = buf[(ptrdiff_t)row + ((o <= kk) ? kk - o : -wr_imin(o - kk, lb))];
-          const uint32_t w = B.weights[o];
-          for (int ch = 0; ch < NCH; ch++) {
-            const uint32_t t = ((((r >> (8 * ch)) & 0xFF) + ((l >> (8 * ch)) & 0xFF)) * w) & 0xFFFF;
-            const uint32_t a = sum[ch] + t;
-            sum[ch] = a > 0xFFFF ? 0xFFFF : a;
-          }
-        }
-      } else {
-        const uint8_t* buf = (const uint8_t*)B.ptr;
-        sum[0] = (uint32_t(buf[row + kk]) * w0) & 0xFFFF;
-        for (int o = 1; o <= radius; o++) {
-          const uint32_t r = buf[(ptrdiff_t)row + ((kk + o <= 3) ? kk + o : wr_imin(kk + o, rb))];
-          const uint32_t l = buf[(ptrdiff_t)row + ((o <= kk) ? kk - o : -wr_imin(o - kk, lb))];
-          const uint32_t t = ((r + l) * B.weights[o]) & 0xFFFF;
-          const uint32_t a = sum[0] + t;
-          sum[0] = a > 0xFFFF ? 0xFFFF : a;
-        }
-      }
-    } else {
-      const size_t row = (size_t)wr_clamp_coord(ix, tw - 1) + (size_t)wr_clamp_coord(curY, th) * B.stride;
-      const int below = curY - wr_imax(B.bounds[1], 0), above = wr_imin(B.bounds[3], th - 1) - curY;
-      const int amax = wr_imax(above, 0), bmax = wr_imax(below, 0);
-      if (FMT == WR_FMT_RGBA8) {
-        const uint32_t* buf = (const uint32_t*)B.ptr;
-        const uint32_t c = buf[row + kk];
-        for (int ch = 0; ch < NCH; ch++) sum[ch] = (((c >> (8 * ch)) & 0xFF) * w0) & 0xFFFF;
-        for (int o = 1; o <= radius; o++) {
-          const uint32_t r = buf[(ptrdiff_t)row + kk + (ptrdiff_t)wr_imin(o, amax) * B.stride];
-          const uint32_t l = buf[(ptrdiff_t)row + kk - (ptrdiff_t)wr_imin(o, bmax) * B.stride];
-          const uint32_t w = B.weights[o];
-          for (int ch = 0; ch < NCH; ch++) {
-            const uint32_t t = ((((r >> (8 * ch)) & 0xFF) + ((l >> (8 * ch)) & 0xFF)) * w) & 0xFFFF;
-            const uint32_t a = sum[ch] + t;
-            sum[ch] = a > 0xFFFF ? 0xFFFF : a;
-          }
-        }
-      } else {
-        const uint8_t* buf = (const uint8_t*)B.ptr;
-        sum[0] = (uint32_t(buf[row + kk]) * w0) & 0xFFFF;
-        for (int o = 1; o <= radius; o++) {
-          const uint32_t r = buf[(ptrdiff_t)row + kk + (ptrdiff_t)wr_imin(o, amax) * B.stride];
-          const uint32_t l = buf[(ptrdiff_t)row + kk - (ptrdiff_t)wr_imin(o, bmax) * B.stride];
-          const uint32_t t = ((r + l) * B.weights[o]) & 0xFFFF;
-          const uint32_t a = sum[0] + t;
-          sum[0] = a > 0xFFFF ? 0xFFFF : a;
-        }
-      }
-    }
-    if (FMT == WR_FMT_RGBA8) {
-      out.bg = (sum[0] >> 8) | ((sum[1] >> 8) << 16);
-      out.ra = (sum[2] >> 8) | ((sum[3] >> 8) << 16);
-    } else {
-      out.bg = sum[0] >> 8;
-    }
-    return out;
-  }
   // ---- fragment shader: uv of this pixel = its init_interp lane, stepped by
   // `drawn` at once (DISPATCH_DRAW_SPAN) and then chunk by chunk
   const int lane = (n - drawn) & 3, m = (n - drawn) >> 2;
@@ -6009,6 +6008,17 @@ __device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* 
     out.bg = uint32_t(wr_round_pixel(avg[0])) & 0xFFFF;
   }
   return out;
+}
+// pixel n of the row (n = x - P.x0)
+template <int FMT>
+WR_DEVICE WrWide wr_blur_row_pixel(const WrPrim& P, const WrBlurRec& B, const WrBlurRow& R, const int n) {
+  if (n < R.drawn) return wr_blur_span_px<FMT>(B, R, n);
+  return wr_blur_tail_px<FMT>(&P, &B, &R, n);
+}
+template <int FMT>
+__device__ __noinline__ WrWide wr_blur_pixel(const WrPrim* Pp, const WrBlurRec* Bp, int x, int y) {
+  const WrBlurRow R = wr_blur_row_setup<FMT>(*Pp, *Bp, y);
+  return wr_blur_row_pixel<FMT>(*Pp, *Bp, R, x - Pp->x0);
 }
 
 // ---------------------------------------------------------------------------
@@ -6985,6 +6995,145 @@ __global__ void __launch_bounds__(256, 4) wr_mask_rows_kernel(const WrTargetDesc
                                                            unsigned long long* __restrict__ ctl,
                                                            const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
   wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, (int)blockIdx.x, (int)gridDim.x);
+}
+#endif
+
+// ---------------------------------------------------------------------------
+// Span rows ("span rows").  The off-screen passes of a blur chain -- cs_scale halvings, cs_blur V / H, the
+// scissored clears in front of them -- are a handful of axis-aligned prims per target whose span shaders are state machines per
+// ROW (interpolants stepped along the row, the span / main() split, the filter decision); in the bin raster a lane replays that
+// row setup for every one of its pixels, a level of a few bins is one wave's dependent instruction stream (profiles/r04_j), and a
+// 51 x 51 task occupies 16 waves.  A span-rows target (WrTargetDesc::rows_mode, chosen by the host) has no bins: every 256-pixel
+// piece of every target row gets ONE wave; lane l holds pixels 4 l .. 4 l + 3 of the piece in registers, starts them from the
+// target's clear colour (or its content), applies the target's prims in submission order -- the row setup of a prim is wave-uniform
+// and evaluated once, then each lane evaluates its own pixels with the very routines the bin raster uses (wr_blur_row_pixel,
+// wr_tex_pixel_row: identical bytes by construction) and blends -- and stores once.  Rows of other ranks are skipped.
+// (out of line and called from rolled loops: a thin level runs its code from a cold instruction cache -- kernel boundaries invalidate it --
+// and what a wave pays for is the number of distinct instruction lines on its path: one copy of a pixel routine, fetched by the
+// lane's first pixel and hot for the other three, not four inlined copies; profiles/r05_c: 49 -> us for a 51 x 51 blur level)
+template <int FMT>
+__device__ __noinline__ void wr_span_blur_setup(const WrPrim* Pp, const WrBlurRec* Bp, int y, WrBlurRow* out) { *out = wr_blur_row_setup<FMT>(*Pp, *Bp, y); }
+template <int FMT>
+__device__ __noinline__ uint32_t wr_span_blur_px(const WrPrim* Pp, const WrBlurRec* Bp, const WrBlurRow* Rp, int n) {
+  const WrWide src = wr_blur_row_pixel<FMT>(*Pp, *Bp, *Rp, n);
+  return FMT == WR_FMT_RGBA8 ? wr_pack(src) : wr_pack1(src.bg & 0xFFFF);
+}
+__device__ __noinline__ void wr_span_tex_setup(const WrPrim* Pp, const WrTexDesc* tp, int y, WrTexRow* out) { *out = wr_tex_row(*Pp, *tp, y); }
+template <int FMT>
+__device__ __noinline__ uint32_t wr_span_tex_px(const WrPrim* Pp, const WrTexDesc* tp, const WrTexRow* rp, int n) {
+  const WrWide src = wr_tex_pixel_row(*Pp, *tp, *rp, n);
+  return FMT == WR_FMT_RGBA8 ? wr_pack(src) : wr_pack1(src.ra & 0xFFFF);
+}
+// PPL pixels per lane: 4 for wide targets (16-byte stores), 1 for the narrow ones -- the small levels of a chain are latency-bound,
+// and a lane that evaluates four pixels one after the other makes the level four pixel evaluations long
+template <int FMT, int PPL>
+WR_DEVICE void wr_span_row_piece(const WrTargetDesc& T, const int y, const int xbase, const WrDrawDesc* __restrict__ draws,
+                                 const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, const int piece_x0) {
+  constexpr int BPP = FMT == WR_FMT_RGBA8 ? 4 : 1;
+  uint32_t px[PPL];
+  uint8_t* rowp = (uint8_t*)T.color + (size_t)y * T.stride;
+  const int nvalid = wr_iclamp(T.width - xbase, 0, PPL);        // pixels of this lane inside the target
+  if (T.load_color) {
+#pragma unroll
+    for (int i = 0; i < PPL; i++) px[i] = i < nvalid ? (BPP == 4 ? ((const uint32_t*)rowp)[xbase + i] : (uint32_t)rowp[xbase + i]) : 0u;
+  } else {
+#pragma unroll
+    for (int i = 0; i < PPL; i++) px[i] = BPP == 4 ? T.init_color : (T.init_color & 0xFF);
+  }
+  for (int p = T.first_prim; p < T.end_prim; p++) {
+    const WrPrim& P = prims[p];
+    const int kind = P.kind;
+    if (kind == WR_PK_NONE || kind == WR_PK_UNSUPPORTED) continue;
+    if (y < P.y0 || y >= P.y1 || P.x1 <= piece_x0 || P.x0 >= piece_x0 + 64 * PPL) continue;       // (wave-uniform)
+    const WrDrawDesc* D = &draws[P.draw];
+    const int n0 = xbase - P.x0, len = P.x1 - P.x0;
+    if (kind == WR_PK_CLEAR) {
+      if (P.flags & WR_PF_CLEAR_COLOR) {
+#pragma unroll
+        for (int i = 0; i < PPL; i++) px[i] = (unsigned)(n0 + i) < (unsigned)len ? (BPP == 4 ? P.color[0] : (P.color[0] & 0xFF)) : px[i];
+      }
+    } else if (kind == WR_PK_BLUR && P.blend == WR_BLEND_NONE) {
+      const WrBlurRec* Bp = &aux[p].blur;
+      WrBlurRow R;
+      wr_span_blur_setup<FMT>(&P, Bp, y, &R);
+      // the lane's pixels through ONE copy of the routine: the values rotate through px[0]
+#pragma nounroll
+      for (int i = 0; i < PPL; i++) {
+        uint32_t v = px[0];
+        if ((unsigned)(n0 + i) < (unsigned)len) v = wr_span_blur_px<FMT>(&P, Bp, &R, n0 + i);
+#pragma unroll
+        for (int k = 0; k + 1 < PPL; k++) px[k] = px[k + 1];
+        px[PPL - 1] = v;
+      }
+    } else if ((kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_FS) && P.blend == WR_BLEND_NONE && !(P.flags & WR_PF_MASKED) && !P.dual) {
+      const WrTexDesc* tp = &D->tex[P.tex_slot];
+      WrTexRow r;
+      wr_span_tex_setup(&P, tp, y, &r);
+#pragma nounroll
+      for (int i = 0; i < PPL; i++) {
+        uint32_t v = px[0];
+        if ((unsigned)(n0 + i) < (unsigned)len) v = wr_span_tex_px<FMT>(&P, tp, &r, xbase + i - r.x0);
+#pragma unroll
+        for (int k = 0; k + 1 < PPL; k++) px[k] = px[k + 1];
+        px[PPL - 1] = v;
+      }
+    } else {
+      // the host's promise (only unblended row-evaluable prims in a span-rows target) does not hold for this prim: reported, not drawn
+      if (T.counters && xbase == piece_x0 && y == wr_imax(P.y0, T.y_begin) && piece_x0 <= P.x0) atomicAdd(&T.counters->unsupported_prims, 1u);
+    }
+  }
+  if (nvalid <= 0) return;
+  if (BPP == 4) {
+    uint32_t* dst = (uint32_t*)rowp + xbase;
+#ifndef WRHIP_HOSTSIM
+    if (PPL == 4 && nvalid == 4 && (((uintptr_t)dst) & 15) == 0) { *(uint4*)dst = make_uint4(px[0], px[1 % PPL], px[2 % PPL], px[3 % PPL]); return; }
+#endif
+#pragma unroll
+    for (int i = 0; i < PPL; i++) if (i < nvalid) dst[i] = px[i];
+  } else {
+    uint8_t* dst = rowp + xbase;
+    if (PPL == 4 && nvalid == 4) { *(uint32_t*)dst = (px[0] & 0xFF) | ((px[1 % PPL] & 0xFF) << 8) | ((px[2 % PPL] & 0xFF) << 16) | (px[3 % PPL] << 24); return; }
+#pragma unroll
+    for (int i = 0; i < PPL; i++) if (i < nvalid) dst[i] = (uint8_t)px[i];
+  }
+}
+// targets [t0, t0 + nt) are the span-rows targets of one dependency level; work item = (target, row, piece of 64 lanes x PPL pixels), one wave each
+WR_DEVICE void wr_span_rows_body(const WrTargetDesc* __restrict__ targets, const int t0, const int nt, const WrDrawDesc* __restrict__ draws,
+                                 const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, const int block, const int nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = int((nblocks * blockDim.x) >> 6);
+#ifdef WRHIP_HOSTSIM
+  const int gw = int((block * blockDim.x + threadIdx.x) >> 6);
+#else
+  const int gw = __builtin_amdgcn_readfirstlane(int((block * blockDim.x + threadIdx.x) >> 6));
+#endif
+  for (int item = gw;; item += nwaves) {
+    int rel = item, ti = 0, pieces = 1;
+    for (; ti < nt; ti++) {
+      const WrTargetDesc& Tq = targets[t0 + ti];
+      pieces = WR_SPAN_PIECES(Tq.width);
+      const int n = (Tq.y_end - Tq.y_begin) * pieces;
+      if (rel < n) break;
+      rel -= n;
+    }
+    if (ti >= nt) break;
+    const WrTargetDesc& T = targets[t0 + ti];
+    const int y = T.y_begin + rel / pieces;
+    if (WR_SPAN_PPL(T.width) == 4) {
+      const int piece_x0 = (rel % pieces) << 8;
+      if (T.format == WR_FMT_RGBA8) wr_span_row_piece<WR_FMT_RGBA8, 4>(T, y, piece_x0 + 4 * lane, draws, prims, aux, piece_x0);
+      else wr_span_row_piece<WR_FMT_R8, 4>(T, y, piece_x0 + 4 * lane, draws, prims, aux, piece_x0);
+    } else {
+      const int piece_x0 = (rel % pieces) << 6;
+      if (T.format == WR_FMT_RGBA8) wr_span_row_piece<WR_FMT_RGBA8, 1>(T, y, piece_x0 + lane, draws, prims, aux, piece_x0);
+      else wr_span_row_piece<WR_FMT_R8, 1>(T, y, piece_x0 + lane, draws, prims, aux, piece_x0);
+    }
+  }
+}
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone) */
+__global__ void __launch_bounds__(256, 2) wr_span_rows_kernel(const WrTargetDesc* __restrict__ targets, int t0, int nt, const WrDrawDesc* __restrict__ draws,
+                                                              const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux) {
+  wr_span_rows_body(targets, t0, nt, draws, prims, aux, (int)blockIdx.x, (int)gridDim.x);
 }
 #endif
 
@@ -8056,8 +8205,12 @@ WR_DEVICE bool wr_zcap_rejects(uint32_t kbf, uint32_t z, uint32_t zcap) {
 WR_DEVICE uint32_t wr_zcap_after(uint32_t kbf, uint32_t z, uint32_t zcap, bool full) {
   const uint32_t fl = (kbf >> 16) & 0xFF, k = kbf & 0xFF;
   if (k == WR_PK_CLEAR) return (fl & WR_PF_CLEAR_DEPTH) ? (full ? z : (z > zcap ? z : zcap)) : zcap;
-  // (rect kinds whose every pixel of [x0, x1) x [y0, y1) writes depth when it passes: solids, unmasked axis-aligned images)
-  if (full && (k == WR_PK_SOLID_FOLDED || k == WR_PK_SOLID || (k == WR_PK_TEX_RGBA8 && !(fl & WR_PF_MASKED))) && (fl & WR_PF_DEPTH_TEST) &&
+  // (rect kinds whose every pixel of [x0, x1) x [y0, y1) writes depth when it passes: solids and the unmasked axis-aligned shader
+  // replays -- images, gradients, filters, repeated images, video: the opaque pass of a page of stacked full-size gradients
+  // (wrench aligned- / unaligned-gradient: ten, front to back) is one gradient per strip and nine scalar rejections)
+  const bool rect_kind = k == WR_PK_SOLID_FOLDED || k == WR_PK_SOLID ||
+                         ((k == WR_PK_TEX_RGBA8 || k == WR_PK_TEX_FS || k == WR_PK_GRADIENT || k == WR_PK_FILTER || k == WR_PK_TEX_REPEAT || k == WR_PK_YUV) && !(fl & WR_PF_MASKED));
+  if (full && rect_kind && (fl & WR_PF_DEPTH_TEST) &&
       (fl & WR_PF_DEPTH_WRITE))
     return z < zcap ? z : zcap;
   return zcap;

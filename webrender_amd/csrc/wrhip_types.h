@@ -217,7 +217,9 @@ struct WrTargetDesc {
   uint32_t mr_cap16;             // capacity of mr_store in 16-byte units (< 2^28)
   uint32_t mr_max_slots;         // capacity of mr_slots (< 2^16)
   int32_t cells;                 // 1: rect-only bins that start from a clear may take the cell raster (wr_raster_cells)
-  int32_t pad_;
+  int32_t rows_mode;             // 1: a SPAN-ROWS target -- every draw is a row-evaluable off-screen pass (cs_blur, cs_scale, scissored clears)
+                                 // without blending hazards: its prims are not binned and it has no bins; wr_span_rows_kernel gives every
+                                 // 256-pixel piece of every target row one wave that applies the target's prims in order
   // Flattened depth rows.  A perspective span flattens the depth row it touches (rasterize.h:1222-1232), and swgl draws every
   // LATER depth-tested prim on that row chunk by chunk from the span start through main() (:1021-1031) instead of handing the
   // span shader one depth run at a time.  flat_rows[y] = index of the first depth-tested perspective prim with a non-empty
@@ -253,6 +255,9 @@ struct WrMaskSlot {
   uint32_t pad[3];               // pad[0]: waves sharing a row (1: see the setup stage)
   WrBoxKey key;                  // cs_clip_box_shadow: key of the prim's middle row (rows equal to it are not evaluated)
 };
+// span rows (WrTargetDesc::rows_mode): pixels per lane and wave-sized pieces per row of a target of the given width (host and kernel agree)
+#define WR_SPAN_PPL(width) ((width) > 512 ? 4 : 1)
+#define WR_SPAN_PIECES(width) (((width) + 64 * WR_SPAN_PPL(width) - 1) / (64 * WR_SPAN_PPL(width)))
 #define WR_MR_MAX_SLOTS 65535u
 #define WR_MR_MAX_ROWS 1048575u
 #define WR_MR_MAX_CAP16 268435455u
