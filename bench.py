@@ -74,6 +74,10 @@ def kernel_label(k):
         return "wr_setup_rows_kernel"
     if k.kind == 9:      # the span-rows targets of a level (cs_blur / cs_scale passes): one wave per target row piece
         return f"wr_span_rows_kernel<{k.fmt}>"
+    if k.kind == 10:     # picture targets of a few large gradient / image prims: one wave per tile row piece
+        return "wr_tile_rows_kernel"
+    if k.kind == 11:     # ... with the next flush's setup stage in front
+        return "wr_setup_tile_rows_kernel"
     return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
 
 
@@ -336,7 +340,7 @@ def main():
             if tr:
                 e["traffic"], e["traffic_source"] = tr
             per_kernel.append(e)
-        rasters = [e for e in per_kernel if e["name"].startswith("wr_raster_") or e["name"].startswith("wr_setup_raster") or e["name"].startswith("wr_span_rows")]
+        rasters = [e for e in per_kernel if e["name"].startswith("wr_raster_") or e["name"].startswith("wr_setup_raster") or e["name"].startswith("wr_span_rows") or e["name"].startswith("wr_tile_rows") or e["name"].startswith("wr_setup_tile_rows")]
         if rasters:
             dom = max(rasters, key=lambda e: e["us_per_frame"])
             roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],

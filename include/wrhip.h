@@ -231,6 +231,7 @@ typedef struct WrhipStats {
   uint64_t host_upload_ns;     /* TexSubImage2D / TexImage2D / BufferData / BufferSubData: staging of uploaded bytes */
   uint64_t host_flush_ns;      /* flush: descriptor arena, staging copy, kernel launches (no waiting) */
   uint64_t host_wait_ns;       /* Finish / ReadPixels / queries: blocked on the stream               */
+  uint64_t row_launches;       /* launches of the row kernels (wr_span_rows_kernel / wr_tile_rows_kernel); included in raster_launches */
 } WrhipStats;
 void WrhipGetStats(WrhipStats* out);
 void WrhipResetStats(void);
@@ -241,7 +242,8 @@ void WrhipSetProfiling(int enabled);
 /* Per-kernel-variant totals collected while profiling is on: kind 0 = upload scatter, 1 = setup stage, 3 = mask rows (wr_mask_rows_kernel), 2 = raster
  * kernel wr_raster_kernel<fmt, depth, 4, feat>, 4 = a chained run of thin R8 levels, 5 = wr_raster_dense_kernel, 6 / 7 = kinds 2 / 5
  * fused with the next flush's setup stage (wr_setup_raster[_dense]_kernel: setup bytes and workgroups added), 8 = wr_setup_rows_kernel
- * (3 fused likewise).  algo_bytes: the launch's algorithmic bytes:
+ * (3 fused likewise), 9 = wr_span_rows_kernel (the cs_blur / cs_scale targets of a level, a wave per target row piece), 10 = wr_tile_rows_kernel
+ * (picture targets of a few large gradient / image prims, likewise), 11 = wr_setup_tile_rows_kernel (10 fused with the next flush's setup stage).  algo_bytes: the launch's algorithmic bytes:
  * raster launches count every destination pixel they own once (twice when the target's old content is loaded) plus
  * the source texels their draws can sample; the setup stage counts instance + descriptor + record bytes.  Returns the
  * number of entries written (<= max). */

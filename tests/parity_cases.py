@@ -373,6 +373,26 @@ SVG_FILTERS = [
 ]
 
 
+# Tile rows (wr_tile_rows_kernel): picture targets of a FEW large gradient / image prims -- what the host hands to the row kernel
+# instead of the bin raster (<= 24 prims per tile, no general quads) -- alone, behind opaque occluders (depth runs: the span shader
+# restarts at every run), behind sliver fences (more runs than a record holds: reported), under clip masks, with a nearest sampler,
+# as drop shadows.  Every case has to take that kernel (WrhipStats::row_launches) and is rendered a second time through the bins
+# (WRHIP_NO_TILE_ROWS=1): both equal the oracle.
+TILE_ROWS = [
+    ("tile_rows_gradients", lambda: scenes.gradient_grid(n=14, seed=361)),
+    ("tile_rows_gradients_int", lambda: scenes.gradient_grid(n=12, seed=362, fractional=False)),
+    ("tile_rows_gradients_occluded", lambda: scenes.add_occluders(scenes.gradient_grid(n=12, seed=363), n=8, zmax=30, seed=51)),
+    ("tile_rows_gradients_wide", lambda: scenes.gradient_grid(width=2048, height=1024, n=30, seed=364)),
+    ("tile_rows_images", lambda: scenes.image_grid(n=16, seed=365)),
+    ("tile_rows_images_occluded", lambda: scenes.add_occluders(scenes.image_grid(n=12, seed=366), n=8, zmax=30, seed=52)),
+    ("tile_rows_images_masked", lambda: scenes.image_grid(n=14, seed=367, masked=True)),
+    ("tile_rows_images_nearest", lambda: scenes.image_grid(n=14, seed=368, nearest=True)),
+    ("tile_rows_image_shadows", lambda: scenes.image_grid(n=12, seed=369, shadows=True)),
+    ("tile_rows_images_screen", lambda: scenes.image_grid(n=12, seed=370, screen=True)),
+    ("tile_rows_images_slivers", lambda: scenes.add_slivers(scenes.image_grid(n=10, seed=371), pitch=40)),
+    ("tile_rows_images_sliver_overflow", lambda: scenes.add_slivers(scenes.image_grid(n=10, seed=372), pitch=9)),
+]
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Every parity family as (family, name, make) -- what tests/test_clang_budget.py (shipping-flags swgl build) and
 # tools/clang_spread.py walk.  SMALL / BLUR / CLIP / BOX live in the test modules that introduced them; they are handed in.

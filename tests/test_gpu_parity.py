@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import TILE_ROWS, WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -640,3 +640,20 @@ def test_hip_dual_source_images_match_oracle(name, kw):
     if name in GOLDEN:
         assert digest(got) == GOLDEN[name] or ref
     assert ref or name in GOLDEN
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", TILE_ROWS, ids=[c[0] for c in TILE_ROWS])
+def test_hip_tile_rows_match_oracle(name, make, monkeypatch):
+    """picture targets of a few large gradient / image prims: the row kernel (default) and the bin raster give the oracle's bytes"""
+    ref = oracle_ref()
+    got, st = render_direct(wrhip_lib(), make())
+    assert st["row_launches"] >= 1, "the case was meant for wr_tile_rows_kernel"
+    monkeypatch.setenv("WRHIP_NO_TILE_ROWS", "1")
+    got2, st2 = render_direct(wrhip_lib(), make())
+    assert st2["row_launches"] == 0
+    assert np.array_equal(got, got2)
+    assert st["gl_error"] == st2["gl_error"]
+    if ref:
+        want, _ = render_direct(ref, make())
+        assert np.array_equal(got, want)

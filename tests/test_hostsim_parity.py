@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import TILE_ROWS, WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -559,3 +559,17 @@ def test_hostsim_dual_source_images_match_oracle(hostsim, oracle_gcc, name, kw):
     plain, _ = render_direct(oracle_gcc, scenes.image_grid(**{k: v for k, v in kw.items() if k not in ("dual", "shadows", "screen")}))
     assert st["gl_error"] == 0 and (want != plain).sum() > 100000
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,make", TILE_ROWS, ids=[c[0] for c in TILE_ROWS])
+def test_hostsim_tile_rows_match_oracle(hostsim, oracle_gcc, name, make, monkeypatch):
+    """picture targets of a few large gradient / image prims: the row kernel (default) and the bin raster give the oracle's bytes"""
+    want, _ = render_direct(oracle_gcc, make())
+    got, st = render_direct(hostsim, make())
+    assert st["row_launches"] >= 1, "the case was meant for wr_tile_rows_kernel"
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("WRHIP_NO_TILE_ROWS", "1")
+    got2, st2 = render_direct(hostsim, make())
+    assert st2["row_launches"] == 0
+    assert np.array_equal(got2, want)
+    assert st["gl_error"] == st2["gl_error"]        # (the sliver-fence overflow is reported by both)

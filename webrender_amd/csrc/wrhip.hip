@@ -519,7 +519,7 @@ struct Context {
   // plus a kernel boundary; the rest follow in order.  Anything that needs their results, or touches a
   // texture they read or write from outside the draw stream (host uploads, copies, readbacks,
   // deletes, Finish), drains them first (drain_tail).
-  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; int mr_rows = 0; int dense = 0; int row_t0 = 0, row_n = 0, row_items = 0; };   // dense: the level's R8-texture prims are glyph runs (wr_raster_dense_kernel)   // mr_rows > 0: wr_mask_rows_kernel goes first (bound on its rows)    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
+  struct Held { int fmt, depth, feat, nb, off; uint64_t algo_bytes; int mr_rows = 0; int dense = 0; int row_t0 = 0, row_n = 0, row_items = 0, row_mode = 0; };   // dense: the level's R8-texture prims are glyph runs (wr_raster_dense_kernel)   // mr_rows > 0: wr_mask_rows_kernel goes first (bound on its rows)    // one raster launch: wr_raster_kernel<fmt, depth, 4, feat>, nb bins from `off`
   struct Tail {
     bool pending = false;
     std::vector<Held> held;          // the raster launches of the held-back flush, in order
@@ -579,6 +579,7 @@ struct Context {
   bool profiling_no_forward = false;
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool span_rows = true;               // WRHIP_NO_SPAN_ROWS=1: cs_blur / cs_scale targets go through the bin raster like everything else
+  bool tile_rows = true;               // WRHIP_NO_TILE_ROWS=1: picture targets of a few large gradient / image prims too
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
   int thin_parts = 4;                  // workgroups per bin of a thin launch (WRHIP_THIN_PARTS = 1, 2, 4, 8, 16): 16 / parts waves each, so that a wave shares its SIMD with fewer others
@@ -610,6 +611,7 @@ struct Context {
     cell_raster = getenv("WRHIP_NO_CELLS") == nullptr;
     mask_rows = getenv("WRHIP_NO_MASK_ROWS") == nullptr;
     span_rows = getenv("WRHIP_NO_SPAN_ROWS") == nullptr;
+    tile_rows = getenv("WRHIP_NO_TILE_ROWS") == nullptr;
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
@@ -1186,7 +1188,7 @@ void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint6
   for (WrhipKernelStat& e : c->kstats) if (e.kind == kind && e.fmt == fmt && e.depth == depth && e.feat == feat) k = &e;
   if (!k) { c->kstats.push_back(WrhipKernelStat{kind, fmt, depth, feat, 0, 0, 0, 0}); k = &c->kstats.back(); }
   k->launches++; k->ns += ns; k->algo_bytes += algo_bytes; k->workgroups += workgroups;
-  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9) c->stats.raster_ns += ns;
+  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9 || kind == 10 || kind == 11) c->stats.raster_ns += ns;
 }
 
 void tail_launched() {
@@ -1199,7 +1201,7 @@ void tail_launched() {
 // The instantiated raster kernels: RGBA8 (+depth) x {0, TEX|GENERIC, +R8TEX, everything}, R8 x {0, GENERIC|BLUR, +CLIP}.
 // `SA` non-null: launch the fused setup + raster variant (only for the variants can_fuse() names).
 bool can_fuse(const Context::Held& H) {
-  if (H.row_n > 0) return false;           // (a span-rows launch: short, nothing to hide a setup stage behind)
+  if (H.row_n > 0) return H.row_mode == 2;     // (tile rows carry it: wr_setup_tile_rows_kernel; a span-rows launch is too short to hide a setup stage behind)
   if (H.mr_rows > 0) return true;          // (the mask-rows launch ahead of an R8 raster launch: wr_setup_rows_kernel)
   return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
                                    H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
@@ -1230,11 +1232,14 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     // the span-rows targets of a level: one wave per (target row, 256-pixel piece), four waves per workgroup
     const int wgs = std::max(1, std::min((H.row_items + 3) / 4, 16384));
     static const bool dbg_rows = getenv("WRHIP_DEBUG_ROWS") != nullptr;
-    if (dbg_rows) fprintf(stderr, "span rows: targets [%d, %d) items %d workgroups %d\n", H.row_t0, H.row_t0 + H.row_n, H.row_items, wgs);
+    if (dbg_rows) fprintf(stderr, "span rows (mode %d): targets [%d, %d) items %d workgroups %d\n", H.row_mode, H.row_t0, H.row_t0 + H.row_n, H.row_items, wgs);
     prof_begin();
-    WR_LAUNCH(wr_span_rows_kernel, wgs, 256, c->stream, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
-    prof_end(9, H.fmt, 0, 0, H.algo_bytes, (uint64_t)wgs);
-    c->stats.kernel_launches++; c->stats.raster_launches++;
+    const bool rows_fused = SA != nullptr && H.row_mode == 2;
+    if (rows_fused) WR_LAUNCH(wr_setup_tile_rows_kernel, n_setup_blocks + wgs, 256, c->stream, *SA, n_setup_blocks, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
+    else if (H.row_mode == 2) WR_LAUNCH(wr_tile_rows_kernel, wgs, 256, c->stream, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
+    else WR_LAUNCH(wr_span_rows_kernel, wgs, 256, c->stream, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
+    prof_end(rows_fused ? 11 : (H.row_mode == 2 ? 10 : 9), H.fmt, 0, 0, H.algo_bytes + (rows_fused ? setup_bytes : 0), (uint64_t)wgs + (rows_fused ? n_setup_blocks : 0));
+    c->stats.kernel_launches++; c->stats.raster_launches++; c->stats.row_launches++;
     return;
   }
   const int F5 = WR_FEAT_TEX | WR_FEAT_GENERIC, F7 = F5 | WR_FEAT_R8TEX, FA = F7 | WR_FEAT_BLUR | WR_FEAT_SHADE;
@@ -1517,18 +1522,46 @@ void flush_work(const std::vector<int>& sel_in) {
     }
     return any && nprim <= 48;
   };
+  // Tile-rows targets (wr_tile_rows_kernel): a picture target of a few large axis-aligned prims, at least one of them a linear
+  // gradient or an image -- the kinds whose bin-raster variant runs at one wave per SIMD.  Solids only where the host has verified
+  // them plain (WR_DF_SIMPLE), nothing that may sit on a general quad or ask for anti-aliasing, no depth that outlives the flush.
+  auto tile_rows_eligible = [&](const TargetWork& w) {
+    if (!c->tile_rows || w.forwarded_away) return false;
+    const Texture& t = c->textures[w.tex];
+    if (t.internal_format != GL_RGBA8) return false;
+    if (Texture* dt = w.depth_tex ? c->textures.find(w.depth_tex) : nullptr) {
+      if (dt->depth_materialized) return false;
+      if (w.depth_live && dt->depth_cleared && dt->depth_owner == w.tex) return false;      // (would have to be stored per pixel)
+    }
+    int nprim = 0; bool heavy = false;
+    for (const WrDrawDesc& d : w.draws) {
+      if (d.shader == WR_SH_CLEAR_OP) { nprim += 1; continue; }
+      const bool solid = d.shader == WR_SH_BRUSH_SOLID || d.shader == WR_SH_BRUSH_SOLID_ALPHA || d.shader == WR_SH_PS_QUAD_TEXTURED;
+      const bool shade = d.shader == WR_SH_BRUSH_IMAGE || d.shader == WR_SH_BRUSH_IMAGE_ALPHA || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT ||
+                         d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA;
+      if (!solid && !shade) return false;
+      if (solid && !(d.flags & WR_DF_SIMPLE)) return false;
+      if (d.flags & (WR_DF_QUADS | WR_DF_XFORM | WR_DF_TEX_RECT)) return false;
+      if (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC) return false;
+      if (d.query_slot >= 0) return false;
+      heavy = heavy || shade;
+      nprim += d.count;
+    }
+    return heavy && nprim <= 24;
+  };
   std::vector<char> rows_of(c->work.size(), 0);
-  for (int wi : sel) rows_of[wi] = rows_eligible(c->work[wi]) ? 1 : 0;
+  for (int wi : sel) rows_of[wi] = rows_eligible(c->work[wi]) ? 1 : (tile_rows_eligible(c->work[wi]) ? 2 : 0);
   // by dependency level, RGBA8 targets first inside a level, span-rows targets last, so each launch gets a contiguous bin / target range
   std::stable_sort(sel.begin(), sel.end(), [&](int a, int b) {
     const int la = c->work[a].level, lb = c->work[b].level;
     if (la != lb) return la < lb;
-    const int ka = rows_of[a] ? 2 : (c->textures[c->work[a].tex].internal_format == GL_R8 ? 1 : 0);
-    const int kb = rows_of[b] ? 2 : (c->textures[c->work[b].tex].internal_format == GL_R8 ? 1 : 0);
+    const int ka = rows_of[a] ? 1 + rows_of[a] : (c->textures[c->work[a].tex].internal_format == GL_R8 ? 1 : 0);
+    const int kb = rows_of[b] ? 1 + rows_of[b] : (c->textures[c->work[b].tex].internal_format == GL_R8 ? 1 : 0);
     return ka < kb;
   });
   struct Level { int bin0 = 0, bins_rgba = 0, bins_r8 = 0, feat_rgba = 0, feat_r8 = 0; bool any_depth = false, text = false; uint64_t bytes_rgba = 0, bytes_r8 = 0, mr_rows = 0;
-                 int row_t0 = -1, row_n = 0, row_items = 0, row_fmt = 0; uint64_t bytes_rows = 0; };
+                 int row_t0 = -1, row_n = 0, row_items = 0, row_fmt = 0; uint64_t bytes_rows = 0;          // span-rows targets (rows_mode 1)
+                 int trow_t0 = -1, trow_n = 0, trow_items = 0; uint64_t bytes_trows = 0; };                // tile-rows targets (rows_mode 2)
   int n_row_targets = 0;
   uint64_t mr_slots = 0, mr_rows = 0, mr_bytes = 0;      // bounds on what the cs_clip_* prims of this flush can reserve in the mask-row store
   std::vector<Level> levels;
@@ -1570,7 +1603,7 @@ void flush_work(const std::vector<int>& sel_in) {
       for (int k = 0; k < 4; k++) T.fwd_clip[k] = w.fwd_clip[k];
     }
     T.cells = c->cell_raster ? 1 : 0;
-    T.rows_mode = rows_of[sel[oi]] ? 1 : 0;
+    T.rows_mode = rows_of[sel[oi]];
     T.y_begin = 0; T.y_end = t.height;
     if (t.own_y1 > t.own_y0) {   // WrhipSetTargetRows: rows of this target owned by this process
       T.y_begin = std::max(0, t.own_y0); T.y_end = std::min(t.height, t.own_y1);
@@ -1646,7 +1679,12 @@ void flush_work(const std::vector<int>& sel_in) {
     int nrel = T.end_prim - T.first_prim;
     T.words_per_bin = (nrel + 63) / 64;
     T.word_base = word_cursor;
-    if (T.rows_mode) {
+    if (T.rows_mode == 2) {
+      T.words_per_bin = 0;
+      if (L.trow_n == 0) L.trow_t0 = oi;
+      L.trow_n++; n_row_targets++;
+      L.trow_items += std::max(0, T.y_end - T.y_begin) * ((t.width + 255) >> 8);
+    } else if (T.rows_mode) {
       // no bins, no mask words: the level's span-rows launch takes targets [row_t0, row_t0 + row_n)
       T.words_per_bin = 0;
       if (L.row_n == 0) { L.row_t0 = oi; L.row_fmt = T.format; }
@@ -1669,7 +1707,7 @@ void flush_work(const std::vector<int>& sel_in) {
       tb += std::min<uint64_t>(src, owned * t.bpp);
       if (w.fwd_tex) tb += (uint64_t)std::max(0, w.fwd_clip[2] - w.fwd_clip[0]) * std::max(0, w.fwd_clip[3] - w.fwd_clip[1]) * 4;   // the write-through
       algo_bytes += tb;
-      (T.rows_mode ? L.bytes_rows : (T.format == WR_FMT_RGBA8 ? L.bytes_rgba : L.bytes_r8)) += tb;
+      (T.rows_mode == 2 ? L.bytes_trows : T.rows_mode ? L.bytes_rows : (T.format == WR_FMT_RGBA8 ? L.bytes_rgba : L.bytes_r8)) += tb;
     }
     if (dt && nrel > 0 && w.depth_live && dt->depth_cleared && dt->depth_owner == w.tex) {
       // The caller has not invalidated (or fully cleared) the depth these draws leave behind: it outlives the flush -- a
@@ -1956,7 +1994,12 @@ void flush_work(const std::vector<int>& sel_in) {
       }
       if (L.row_n > 0) {
         Context::Held H{L.row_fmt, 0, 0, 0, 0, L.bytes_rows};
-        H.row_t0 = L.row_t0; H.row_n = L.row_n; H.row_items = L.row_items;
+        H.row_t0 = L.row_t0; H.row_n = L.row_n; H.row_items = L.row_items; H.row_mode = 1;
+        launches.push_back(H);
+      }
+      if (L.trow_n > 0) {
+        Context::Held H{WR_FMT_RGBA8, 0, 0, 0, 0, L.bytes_trows};
+        H.row_t0 = L.trow_t0; H.row_n = L.trow_n; H.row_items = L.trow_items; H.row_mode = 2;
         launches.push_back(H);
       }
     }

@@ -308,6 +308,47 @@ WR_DEVICE void wr_pack_color(wf4 c, uint32_t out[2]) {
 
 // ---------------------------------------------------------------------------
 // Vertex stage outputs before draw_quad
+// GradientStops::can_merge (swgl_ext.h:1318-1326) of every pair of neighbouring entries of a validated 130-entry table, as a bitmap
+// (WrGradRec::merge).  Sixteen entries' steps are requested per round trip: the setup stage is one dependent chain per wave.
+WR_DEVICE void wr_grad_merge_bits(WrGradRec* G) {
+  const float* stops = G->stops;
+  uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;      // (in registers: the record lives in HBM)
+  if (stops) {
+    for (int base = 0; base < 129; base += 16) {
+      wr_u4 st[17];
+#pragma unroll
+      for (int j = 0; j < 17; j++) st[j] = wr_load16(stops + 8 * wr_imin(base + j, 129) + 4);
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const bool m = base + j < 129 && wr_bits_f(st[j].x) == wr_bits_f(st[j + 1].x) && wr_bits_f(st[j].y) == wr_bits_f(st[j + 1].y) &&
+                       wr_bits_f(st[j].z) == wr_bits_f(st[j + 1].z) && wr_bits_f(st[j].w) == wr_bits_f(st[j + 1].w);
+        bits |= m ? (1u << j) : 0u;
+      }
+      const uint32_t sh = bits << (base & 31);           // base is a multiple of 16: a batch never straddles a word
+      const int w = base >> 5;
+      m0 |= w == 0 ? sh : 0u; m1 |= w == 1 ? sh : 0u; m2 |= w == 2 ? sh : 0u; m3 |= w == 3 ? sh : 0u; m4 |= w == 4 ? sh : 0u;
+    }
+  }
+  G->merge[0] = m0; G->merge[1] = m1; G->merge[2] = m2; G->merge[3] = m3; G->merge[4] = m4;
+}
+// first i' >= i whose merge bit is clear / last i' < i whose merge bit is clear (-1: none); bits 129 .. 159 are clear
+WR_DEVICE int wr_merge_clear_from(const WrGradRec& G, int i) {
+  for (int w = i >> 5; w < 5; w++) {
+    const uint32_t v = ~G.merge[w] & (w == (i >> 5) ? (0xFFFFFFFFu << (i & 31)) : 0xFFFFFFFFu);
+    if (v) return 32 * w + __builtin_ctz(v);
+  }
+  return 160;
+}
+WR_DEVICE int wr_merge_clear_below(const WrGradRec& G, int i) {
+  if (i <= 0) return -1;
+  for (int w = (i - 1) >> 5; w >= 0; w--) {
+    const int top = w == ((i - 1) >> 5) ? ((i - 1) & 31) : 31;
+    const uint32_t v = ~G.merge[w] & (top == 31 ? 0xFFFFFFFFu : ((1u << (top + 1)) - 1u));
+    if (v) return 32 * w + 31 - __builtin_clz(v);
+  }
+  return -1;
+}
 struct WrVsOut {
   float px[4], py[4], pz[4], pw[4];  // gl_Position per SIMD lane (lane order 0,1,3,2)
   int kind;            // WrPrimKind
@@ -512,6 +553,7 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
       const int ax = int(unsigned(header.w) % 1024u), ay = int(unsigned(header.w) / 1024u);
       const bool ok = gbf.format == WR_FMT_RGBA32F && gbf.ptr && ay >= 0 && ay < gbf.height && ax >= 0 && ax < gbf.width && ax + 2 * 130 <= gbf.width;
       G->stops = ok ? (const float*)gbf.ptr + (size_t)ay * gbf.stride + (size_t)ax * 4 : nullptr;
+      wr_grad_merge_bits(G);
     } else {
       G->radial = 3;
       G->conic_scale = inv;
@@ -699,6 +741,7 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width &&
                     ax + 2 * 130 <= gb.width;
     G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
+    wr_grad_merge_bits(G);
     o.tex_slot = WR_S_GPU_BUFFER_F;
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
     o.kind = WR_PK_GRADIENT;     // (v_pos carries no w factor: BRUSH_FLAG_PERSPECTIVE_INTERPOLATION does not enter, persp_div stays < 0)
@@ -1634,6 +1677,7 @@ WR_DEVICE void wr_vs_cs_linear_gradient(const WrDrawDesc& d, const uint8_t* aren
   const int ax = int(unsigned(address) % 1024u), ay = int(unsigned(address) / 1024u);
   const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width && ax + 2 * 130 <= gb.width;
   G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
+  wr_grad_merge_bits(G);
   for (int n = 0; n < 4; n++) {
     const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
     o.u[n] = ax_ * scale.x; o.v[n] = ay_ * scale.y;
@@ -1664,6 +1708,7 @@ WR_DEVICE void wr_vs_cs_radial_gradient(const WrDrawDesc& d, const uint8_t* aren
   const int ax = int(unsigned(address) % 1024u), ay = int(unsigned(address) / 1024u);
   const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width && ax + 2 * 130 <= gb.width;
   G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
+  wr_grad_merge_bits(G);
   for (int n = 0; n < 4; n++) {
     const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
     o.u[n] = (((task.z - task.x) * ax_) * scale.x - center.x) * radius_scale;
@@ -4812,10 +4857,11 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
           const float searchOffset = (past ? endRadius : middleRadius) - startRadius;
           const int searchIndex = int(wr_clamp(1.0f + size * searchOffset, 1.0f, size));
           if (past) {
-            while (maxIndex + 1 <= searchIndex && wr_stops_merge(stops, maxIndex, maxIndex + 1)) maxIndex++;
+            // (while (maxIndex + 1 <= searchIndex && can_merge(maxIndex, maxIndex + 1)) maxIndex++, by the prim's merge bitmap)
+            if (maxIndex + 1 <= searchIndex) maxIndex = wr_imin(wr_merge_clear_from(G, maxIndex), searchIndex);
             intercept = float(maxIndex + 1);
           } else {
-            while (minIndex - 1 >= searchIndex && wr_stops_merge(stops, minIndex - 1, minIndex)) minIndex--;
+            if (minIndex - 1 >= searchIndex) minIndex = wr_imax(wr_merge_clear_below(G, minIndex) + 1, searchIndex);
             intercept = float(minIndex);
           }
           intercept = wr_clamp((intercept - 1.0f) / size, 0.0f, 1.0f) + startRadius;
@@ -4911,10 +4957,14 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
         const float endEntry = wr_clamp(1.0f + (off[0] + delta * float(int(chunks))) * size, 0.0f, 1.0f + size);
         minIndex = maxIndex = int(startEntry);
         if (delta > 0.0f) {
-          while (float(maxIndex + 1) < endEntry && wr_stops_merge(stops, maxIndex, maxIndex + 1)) maxIndex++;
+          // (while (float(maxIndex + 1) < endEntry && can_merge(maxIndex, maxIndex + 1)) maxIndex++, by the prim's merge bitmap: the walk
+          // ends at the first entry whose bit is clear or at the first j with j + 1 >= endEntry, i.e. j = ceil(endEntry) - 1)
+          if (float(maxIndex + 1) < endEntry) maxIndex = wr_imin(wr_merge_clear_from(G, maxIndex), wr_imax(maxIndex, int(ceilf(endEntry)) - 1));
           chunks = wr_min(chunks, (float(maxIndex + 1) - startEntry) / (delta * size));
         } else if (delta < 0.0f) {
-          while (float(minIndex - 1) > endEntry && wr_stops_merge(stops, minIndex - 1, minIndex)) minIndex--;
+          // (while (float(minIndex - 1) > endEntry && can_merge(minIndex - 1, minIndex)) minIndex--: down to the entry above the last
+          // clear bit below, or to the first j with j - 1 <= endEntry, i.e. j = floor(endEntry) + 1)
+          if (float(minIndex - 1) > endEntry) minIndex = wr_imax(wr_merge_clear_below(G, minIndex) + 1, wr_imin(minIndex, int(floorf(endEntry)) + 1));
           chunks = wr_min(chunks, (float(minIndex) - startEntry) / (delta * size));
         }
       } else {
@@ -7130,6 +7180,210 @@ WR_DEVICE void wr_span_rows_body(const WrTargetDesc* __restrict__ targets, const
     }
   }
 }
+// ---------------------------------------------------------------------------
+// Tile rows (WrTargetDesc::rows_mode == 2): the same wave-per-row-piece walk for a PICTURE target that holds a few large
+// axis-aligned prims with expensive span shaders -- full-size linear gradients (wrench aligned- / unaligned-gradient), a blurred
+// picture composited by brush_image (large-blur-radius) -- beside solids and clears.  In the bin raster those run in the one
+// variant that carries every shader replay (324 VGPRs, one wave per SIMD: every latency exposed, profiles/r05_g); here a lane
+// holds four pixels and their depth, the prims are applied in submission order with swgl's depth test (LEQUAL / LESS against
+// the lane's own samples), a prim nobody's pixel passes is skipped before any evaluation, and a depth-tested prim that consumes
+// interpolants gets its row's depth runs (draw_depth_span: the row span minus the spans of the earlier depth writers in front
+// of it -- every prim of such a target is a rect, so the sweep is a few scalar comparisons) exactly as wr_build_runs gives them
+// to the bins.  Finished rows are stored once, and a second time where a forwarded composite wants them.
+WR_DEVICE bool wr_kind_needs_runs(int kind);
+WR_DEVICE bool wr_row_runs(const WrTargetDesc& T, const WrPrim* __restrict__ prims, const int p, const int y, WrRuns& R) {
+  const WrPrim& P = prims[p];
+  const bool less = (P.flags & WR_PF_DEPTH_LESS) != 0;
+  const uint32_t z = P.z;
+  const int end = wr_imin(T.dw_end, p);
+  auto cand = [&](int i, int& lo, int& hi) -> bool {
+    const WrPrim& Q = prims[i];
+    lo = Q.x0; hi = Q.x1;
+    return (Q.flags & WR_PF_DEPTH_WRITE) && Q.kind != WR_PK_NONE && Q.kind != WR_PK_UNSUPPORTED && Q.kind != WR_PK_CLEAR &&
+           (less ? Q.z <= z : Q.z < z) && Q.x0 < P.x1 && Q.x1 > P.x0 && y >= Q.y0 && y < Q.y1;
+  };
+  int nc = 0;
+  for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi)) nc++; }
+  if (nc == 0) return false;
+  // wr_sweep_runs over the candidates
+  int n = 0, pos = P.x0;
+  const int b = P.x1;
+  bool overflow = false;
+  while (pos < b) {
+    int s0 = pos;
+    for (bool moved = true; moved;) {
+      moved = false;
+      for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi) && lo <= s0 && s0 < hi) { s0 = hi; moved = true; } }
+    }
+    if (s0 >= b) break;
+    int e = b;
+    for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi) && hi > lo && lo > s0 && lo < e) e = lo; }
+    if (n == WR_MAX_RUNS) { overflow = true; break; }
+    R.s[n] = s0; R.e[n] = e; n++;
+    pos = e;
+  }
+  R.n = overflow ? -2 : n;
+  return true;
+}
+__device__ __noinline__ uint32_t wr_tile_blend(int key, uint32_t dstp, uint32_t sbg, uint32_t sra, const WrDrawDesc* D, const uint32_t* bc) {
+  WrWide src; src.bg = sbg; src.ra = sra;
+  return wr_blend_rgba8(key, dstp, src, D, bc);
+}
+__device__ __noinline__ void wr_tile_tex_setup(const WrPrim* Pp, const WrTexDesc* tp, int y, WrTexRow* out) { *out = wr_tex_row(*Pp, *tp, y); }
+__device__ __noinline__ void wr_tile_tex_px(const WrPrim* Pp, const WrDrawDesc* D, const WrTexRow* rp, int x, int y, const WrRuns* runs, WrWide* out) {
+  const WrTexDesc& t = D->tex[Pp->tex_slot];
+  *out = wr_mask_src(*Pp, D, x, y, runs ? wr_tex_pixel(*Pp, t, x, y, runs) : wr_tex_pixel_row(*Pp, t, *rp, x - rp->x0));
+}
+WR_DEVICE void wr_tile_row_piece(const WrTargetDesc& T, const int y, const int xbase, const WrDrawDesc* __restrict__ draws,
+                                 const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, const int piece_x0) {
+  uint32_t px[4], dep[4];
+  uint8_t* rowp = (uint8_t*)T.color + (size_t)y * T.stride;
+  const int nvalid = wr_iclamp(T.width - xbase, 0, 4);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    px[i] = T.load_color ? (i < nvalid ? ((const uint32_t*)rowp)[xbase + i] : 0u) : T.init_color;
+    dep[i] = T.init_depth;
+  }
+  for (int p = T.first_prim; p < T.end_prim; p++) {
+    const WrPrim& P = prims[p];
+    const int kind = P.kind;
+    if (kind == WR_PK_NONE || kind == WR_PK_UNSUPPORTED) continue;
+    if (y < P.y0 || y >= P.y1 || P.x1 <= piece_x0 || P.x0 >= piece_x0 + 256) continue;       // (wave-uniform)
+    const WrDrawDesc* D = &draws[P.draw];
+    const int n0 = xbase - P.x0, len = P.x1 - P.x0;
+    const uint32_t z = P.z;
+    if (kind == WR_PK_CLEAR) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const bool in = (unsigned)(n0 + i) < (unsigned)len;
+        if (P.flags & WR_PF_CLEAR_COLOR) px[i] = in ? P.color[0] : px[i];
+        if (P.flags & WR_PF_CLEAR_DEPTH) dep[i] = in ? z : dep[i];
+      }
+      continue;
+    }
+    const bool dtest = (P.flags & WR_PF_DEPTH_TEST) != 0, dwrite = (P.flags & WR_PF_DEPTH_WRITE) != 0, dless = (P.flags & WR_PF_DEPTH_LESS) != 0;
+    bool in[4];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      in[i] = (unsigned)(n0 + i) < (unsigned)len;
+      if (dtest) {
+        in[i] = in[i] && (dless ? z < dep[i] : z <= dep[i]);
+        if (dwrite) dep[i] = in[i] ? z : dep[i];
+      }
+      any = any || in[i];
+    }
+#ifndef WRHIP_HOSTSIM
+    if (__ballot(any) == 0ull) continue;         // hidden (or beside this piece) for every lane: no row setup, no evaluation
+#else
+    if (!any) continue;
+#endif
+    if (kind == WR_PK_SOLID) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (in[i]) px[i] = wr_tile_blend(P.blend, px[i], P.color[0], P.color[1], D, P.color);
+      continue;
+    }
+    // depth runs of this row for the kinds whose span shader restarts at every run (wr_kind_needs_runs)
+    WrRuns R;
+    const WrRuns* runs = nullptr;
+    if (dtest && wr_kind_needs_runs(kind) && wr_row_runs(T, prims, p, y, R)) {
+      if (R.n == -2) { R.n = 0; if (T.counters && xbase == wr_imax(piece_x0, P.x0 & ~3)) atomicAdd(&T.counters->unsupported_prims, 1u); }
+      runs = &R;
+    }
+    if (kind == WR_PK_GRADIENT) {
+      const WrGradRec* Gp = &aux[p].grad;
+      WrGrad4 g4;
+      if (!runs) g4 = wr_gradient_row4(&P, Gp, D, xbase, y);
+#pragma nounroll
+      for (int i = 0; i < 4; i++) {
+        uint32_t v = px[0];
+        if (in[0]) {
+          WrWide g = g4.v[0];
+          if (runs) g = wr_gradient_row4(&P, Gp, D, xbase + i, y, runs).v[0];
+          const WrWide src = wr_mask_src(P, D, xbase + i, y, g);
+          v = wr_tile_blend(P.blend, v, src.bg, src.ra, D, nullptr);
+        }
+        px[0] = px[1]; px[1] = px[2]; px[2] = px[3]; px[3] = v;
+        in[0] = in[1]; in[1] = in[2]; in[2] = in[3];
+        g4.v[0] = g4.v[1]; g4.v[1] = g4.v[2]; g4.v[2] = g4.v[3];
+      }
+    } else if (kind == WR_PK_SOLID_MASKED || ((kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_FS) && P.dual && P.blend == WR_BLEND_DUAL_SRC)) {
+#pragma nounroll
+      for (int i = 0; i < 4; i++) {
+        uint32_t v = px[0];
+        if (in[0]) v = wr_generic_pixel_rgba8(&P, D, xbase + i, y, v, runs);
+        px[0] = px[1]; px[1] = px[2]; px[2] = px[3]; px[3] = v;
+        in[0] = in[1]; in[1] = in[2]; in[2] = in[3];
+      }
+    } else if (kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_FS) {
+      WrTexRow r;
+      if (!runs) wr_tile_tex_setup(&P, &D->tex[P.tex_slot], y, &r);
+#pragma nounroll
+      for (int i = 0; i < 4; i++) {
+        uint32_t v = px[0];
+        if (in[0]) {
+          WrWide src;
+          wr_tile_tex_px(&P, D, &r, xbase + i, y, runs, &src);
+          v = wr_tile_blend(P.blend, v, src.bg, src.ra, D, P.color);
+        }
+        px[0] = px[1]; px[1] = px[2]; px[2] = px[3]; px[3] = v;
+        in[0] = in[1]; in[1] = in[2]; in[2] = in[3];
+      }
+    } else {
+      // the host's promise (rect kinds of the solid / image / gradient programs only) does not hold for this prim: reported, not drawn
+      if (T.counters && xbase == wr_imax(piece_x0, P.x0 & ~3) && y == wr_imax(P.y0, T.y_begin)) atomicAdd(&T.counters->unsupported_prims, 1u);
+    }
+  }
+  if (nvalid <= 0) return;
+  uint32_t* dst = (uint32_t*)rowp + xbase;
+#ifndef WRHIP_HOSTSIM
+  if (nvalid == 4 && (((uintptr_t)dst) & 15) == 0) *(uint4*)dst = make_uint4(px[0], px[1], px[2], px[3]);
+  else
+#endif
+  {
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (i < nvalid) dst[i] = px[i];
+  }
+  if (T.fwd_color) {
+    // forwarded composite (WrTargetDesc::fwd_*): the same pixels a second time, at their place in the target that would have copied them
+    const int Y = T.fwd_y0 + T.fwd_ys * y, fX = xbase + T.fwd_dx;
+    if (Y >= T.fwd_clip[1] && Y < T.fwd_clip[3]) {
+      uint32_t* frow = (uint32_t*)((uint8_t*)T.fwd_color + (size_t)Y * T.fwd_stride);
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (i < nvalid && fX + i >= T.fwd_clip[0] && fX + i < T.fwd_clip[2]) frow[fX + i] = px[i];
+    }
+  }
+}
+WR_DEVICE void wr_tile_rows_body(const WrTargetDesc* __restrict__ targets, const int t0, const int nt, const WrDrawDesc* __restrict__ draws,
+                                 const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, const int block, const int nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = int((nblocks * blockDim.x) >> 6);
+#ifdef WRHIP_HOSTSIM
+  const int gw = int((block * blockDim.x + threadIdx.x) >> 6);
+#else
+  const int gw = __builtin_amdgcn_readfirstlane(int((block * blockDim.x + threadIdx.x) >> 6));
+#endif
+  for (int item = gw;; item += nwaves) {
+    int rel = item, ti = 0, pieces = 1;
+    for (; ti < nt; ti++) {
+      const WrTargetDesc& Tq = targets[t0 + ti];
+      pieces = (Tq.width + 255) >> 8;
+      const int n = (Tq.y_end - Tq.y_begin) * pieces;
+      if (rel < n) break;
+      rel -= n;
+    }
+    if (ti >= nt) break;
+    const WrTargetDesc& T = targets[t0 + ti];
+    const int y = T.y_begin + rel / pieces, piece_x0 = (rel % pieces) << 8;
+    wr_tile_row_piece(T, y, piece_x0 + 4 * lane, draws, prims, aux, piece_x0);
+  }
+}
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone) */
+__global__ void __launch_bounds__(256, 4) wr_tile_rows_kernel(const WrTargetDesc* __restrict__ targets, int t0, int nt, const WrDrawDesc* __restrict__ draws,
+                                                              const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux) {
+  wr_tile_rows_body(targets, t0, nt, draws, prims, aux, (int)blockIdx.x, (int)gridDim.x);
+}
+#endif
 #ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone) */
 __global__ void __launch_bounds__(256, 2) wr_span_rows_kernel(const WrTargetDesc* __restrict__ targets, int t0, int nt, const WrDrawDesc* __restrict__ draws,
                                                               const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux) {
@@ -8950,7 +9204,10 @@ WR_DEVICE void wr_raster_body(const WrTargetDesc* __restrict__ targets, int n_ta
 #ifndef WR_RECT_WAVES
 #define WR_RECT_WAVES 8
 #endif
-#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(((R) == 1 && (FMT) == WR_FMT_RGBA8) ? 256 : 1024 / R, ((R) == 1 && (FMT) == WR_FMT_RGBA8) ? 0 : ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? WR_TEX_WAVES : ((DEPTH) ? 4 : WR_RECT_WAVES)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : 0))
+#ifndef WR_SHADE_WAVES
+#define WR_SHADE_WAVES 0        // waves per SIMD asked of the RGBA8 variants that carry the shader replays (FEAT 47); 0: no request
+#endif
+#define WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT) __launch_bounds__(((R) == 1 && (FMT) == WR_FMT_RGBA8) ? 256 : 1024 / R, ((R) == 1 && (FMT) == WR_FMT_RGBA8) ? 0 : ((FMT) == WR_FMT_RGBA8 && (FEAT) < 16) ? ((FEAT) != 0 ? WR_TEX_WAVES : ((DEPTH) ? 4 : WR_RECT_WAVES)) : ((FMT) == WR_FMT_R8 && ((FEAT) & WR_FEAT_CLIP) ? WR_R8_CLIP_WAVES : ((FMT) == WR_FMT_RGBA8 ? WR_SHADE_WAVES : 0)))
 #endif
 template <int FMT, bool DEPTH, int R, int FEAT>
 __global__ void WR_RASTER_BOUNDS(R, FMT, DEPTH, FEAT)
@@ -9104,5 +9361,15 @@ wr_setup_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __re
     return;
   }
   wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, (int)blockIdx.x - n_setup_blocks, (int)gridDim.x - n_setup_blocks);
+}
+// ... and in front of a tile-rows launch (wr_tile_rows_kernel): a frame whose tiles all went to the row kernel has no bin launch to carry it
+__global__ void __launch_bounds__(256, 4)
+wr_setup_tile_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __restrict__ targets, int t0, int nt, const WrDrawDesc* __restrict__ draws,
+                          const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux) {
+  if ((int)blockIdx.x < n_setup_blocks) {
+    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
+    return;
+  }
+  wr_tile_rows_body(targets, t0, nt, draws, prims, aux, (int)blockIdx.x - n_setup_blocks, (int)gridDim.x - n_setup_blocks);
 }
 #endif

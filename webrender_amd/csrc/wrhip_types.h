@@ -448,6 +448,9 @@ struct WrGradRec {
                             // 3: ps_quad_conic_gradient (main() only, approx_atan2 of v_dir: scale_dir = 0)
                             // 2: cs_conic_gradient (main() only): scale_dir = v_center, start_offset = v_start_offset,
   float conic_scale, conic_angle;   //    v_offset_scale, v_angle
+  uint32_t merge[5];                // stops != nullptr: bit i = GradientStops::can_merge(entry i, entry i + 1) of the 130-entry table (i = 0 .. 128),
+                                    // worked out once per prim by the setup stage: the span shaders' "how far does this merged range reach"
+                                    // walks (up to 128 dependent table reads per call of the raster stage) become bit scans
 };
 
 // brush_blend flat varyings (brush_blend.glsl:17-41)

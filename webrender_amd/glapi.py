@@ -143,7 +143,7 @@ class WrhipStats(C.Structure):
     _fields_ = [(n, u64) for n in (
         "flushes", "kernel_launches", "raster_launches", "raster_ns",
         "raster_algo_bytes", "raster_pixels", "prims", "h2d_bytes", "d2h_bytes",
-        "host_record_ns", "host_upload_ns", "host_flush_ns", "host_wait_ns")]
+        "host_record_ns", "host_upload_ns", "host_flush_ns", "host_wait_ns", "row_launches")]
 
 
 class WrhipKernelStat(C.Structure):
