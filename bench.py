@@ -28,9 +28,10 @@ One JSON line on rank 0 with metric/value plus
                 stream around every launch, WrhipSetProfiling), against the
                 8 TB/s HBM peak; `per_kernel` lists every kernel of the frame
                 the same way (upload scatter, setup stage, each raster variant)
-  cpu_baseline  the reference's own swgl rasteriser (oracle/_ref: gl.cc compiled
-                from /root/reference with this repo's hand-written shader
-                headers, clang build = the shipping flags) replaying the same
+  cpu_baseline  the reference's own swgl rasteriser (oracle/_ref/libswgl_ref_gen_clang.so:
+                gl.cc compiled from /root/reference with the shader headers
+                oracle/gen generates from the reference's GLSL, clang build =
+                the shipping flags of swgl/build.rs) replaying the same
                 call stream on one host core, plus an N-process run (one
                 process per core, frames replayed independently) with the core
                 count stated
@@ -391,6 +392,11 @@ def main():
         if single:
             out["single_gpu_same_workload"] = single
             out["speedup_vs_single_gpu"] = round(fps / single["value"], 3)
+            # N > 1 runs another workload than the N = 1 headline (configs[4], the one the sharding is for): the metric names it, and
+            # the baseline of a strong-scaling point is the same frame on one GPU, measured in this very run
+            out["metric"] += f" [N > 1: {args.workload}, one frame split over the ranks]"
+            out["vs_baseline"] = out["speedup_vs_single_gpu"]
+            out["vs_baseline_note"] = "value / single_gpu_same_workload.value (same workload, unsharded, rank 0's GPU, this run); BASELINE.md has no published number"
         if host:
             out["host"] = host
         if roof:

@@ -25,8 +25,10 @@ typedef struct wr_replay {
    * get_uniform(); libwrhip by sampler slot): GetUniformLocation records carry the location the RECORDING backend
    * returned (trace.py), and Uniform1i / Uniform4fv / UniformMatrix4fv are issued with the location THIS backend gave
    * for the same (program, name). */
+#define WR_MAX_LOCS 4096
   uint32_t cur_program;
-  struct { uint32_t program; int32_t recorded, actual; } locs[1024];
+  int cur_first;
+  struct { uint32_t program; int32_t recorded, actual; } locs[WR_MAX_LOCS];
   int n_locs;
   int id_get_uniform, id_use_program, id_uniform1i, id_uniform4fv, id_uniform_matrix4fv;
 } wr_replay;
@@ -93,17 +95,28 @@ static int run_once(wr_replay* R, const uint8_t* t, size_t len) {
       const uint32_t prog = (uint32_t)args[0].value;
       const int32_t actual = ((int32_t(*)(uint32_t, const char*))R->fn[id])(prog, (const char*)wr_ptr(R, &args[1]));
       const int32_t recorded = (int32_t)args[2].value;
+      if (recorded < 0) continue;           /* a name the recording backend did not have: Uniform*(-1, ..) stays a no-op (GL), never translated */
       int k = 0;
       while (k < R->n_locs && !(R->locs[k].program == prog && R->locs[k].recorded == recorded)) k++;
-      if (k == R->n_locs && R->n_locs < 1024) R->n_locs++;
-      if (k < 1024) { R->locs[k].program = prog; R->locs[k].recorded = recorded; R->locs[k].actual = actual; }
+      if (k == R->n_locs) {
+        if (R->n_locs >= WR_MAX_LOCS) { fprintf(stderr, "wr_replay: more than %d uniform locations in one trace\n", WR_MAX_LOCS); return -4; }
+        R->n_locs++;
+      }
+      R->locs[k].program = prog; R->locs[k].recorded = recorded; R->locs[k].actual = actual;
       continue;
     }
-    if (id == R->id_use_program) R->cur_program = (uint32_t)args[0].value;
+    if (id == R->id_use_program) {
+      R->cur_program = (uint32_t)args[0].value;
+      R->cur_first = 0;                      /* the program's entries are contiguous (queried right after linking): remember where they start */
+      while (R->cur_first < R->n_locs && R->locs[R->cur_first].program != R->cur_program) R->cur_first++;
+    }
     if (id == R->id_uniform1i || id == R->id_uniform4fv || id == R->id_uniform_matrix4fv) {
       const int32_t recorded = (int32_t)args[0].value;
-      for (int k = 0; k < R->n_locs; k++)
-        if (R->locs[k].program == R->cur_program && R->locs[k].recorded == recorded) { args[0].value = (uint64_t)(int64_t)R->locs[k].actual; break; }
+      if (recorded >= 0) {
+        int k = R->cur_first;
+        while (k < R->n_locs && !(R->locs[k].program == R->cur_program && R->locs[k].recorded == recorded)) k++;
+        if (k < R->n_locs) args[0].value = (uint64_t)(int64_t)R->locs[k].actual;       /* (a location the trace never queried is passed as recorded) */
+      }
     }
     if (wr_dispatch(R, id, args) != 0) return (int)i + 1;
   }
@@ -180,6 +193,8 @@ typedef struct wr_shard {
   uint8_t* fb;                      /* this rank's window storage (device pointer; host pointer with the hostsim backend) */
   void (*flush)(void);
   int (*flush_held)(void);        /* optional: WrhipFlushHeld */
+  void (*get_stats)(void*);       /* WrhipGetStats: [0] = flushes */
+  int probed;
   void (*finish)(void);
   void* (*get_stream)(void);
   /* RCCL */
@@ -207,6 +222,7 @@ static wr_shard* shard_new(wr_replay* R, int rank, int world, int mode) {
   S->flush = (void (*)(void))dlsym(R->dl, "WrhipFlush");
   S->flush_held = getenv("WRHIP_SHARD_NO_PIPELINE") ? NULL : (int (*)(void))dlsym(R->dl, "WrhipFlushHeld");
   S->finish = (void (*)(void))dlsym(R->dl, "Finish");
+  S->get_stats = (void (*)(void*))dlsym(R->dl, "WrhipGetStats");
   S->get_stream = (void* (*)(void))dlsym(R->dl, "WrhipGetStream");
   if (!S->flush || !S->finish || !S->get_stream) { fprintf(stderr, "wr_shard: backend lacks WrhipFlush / WrhipGetStream\n"); free(S); return NULL; }
   return S;
@@ -231,6 +247,10 @@ wr_shard* wr_shard_open_rccl(wr_replay* R, const char* librccl, int rank, int wo
   if (rc != 0) { fprintf(stderr, "wr_shard: ncclCommInitRank failed (%d)\n", rc); free(S); return NULL; }
   return S;
 }
+
+/* shm transport: rank 0 removes a segment a crashed run may have left under this name (its arrival counter would be stale);
+   the caller puts a barrier between this and the ranks' wr_shard_open_shm */
+void wr_shard_shm_reset(const char* name) { shm_unlink(name); }
 
 wr_shard* wr_shard_open_shm(wr_replay* R, const char* name, int rank, int world, int mode, size_t window_bytes) {
   wr_shard* S = shard_new(R, rank, world, mode);
@@ -276,8 +296,15 @@ static int shard_exchange(wr_shard* S) {
 }
 
 /* `iters` frames back to back, the strips moved after every one, one Finish at the end.  Returns total wall ms in *total_ms. */
+int wr_shard_stream2(wr_shard* S, const uint8_t* trace, size_t len, const uint8_t* trace_b, size_t len_b, int iters, double* total_ms);
 int wr_shard_stream(wr_shard* S, const uint8_t* trace, size_t len, int iters, double* total_ms) {
+  return wr_shard_stream2(S, trace, len, trace, len, iters, total_ms);
+}
+/* ... frames alternating between two traces of one window (even frames: `trace`, odd ones: `trace_b`): what the tests use to see
+   that every exchange moves the strips of ITS frame (with one trace a late or early exchange moves identical bytes) */
+int wr_shard_stream2(wr_shard* S, const uint8_t* trace_a, size_t len_a, const uint8_t* trace_b, size_t len_b, int iters, double* total_ms) {
   struct timespec a, b;
+  const int shm_sync = S->shm && !getenv("WRHIP_SHARD_PIPELINE_SHM");     /* (the stand-in can take the pipelined order too: the tests do both) */
   clock_gettime(CLOCK_MONOTONIC, &a);
   /* GPU path, software-pipelined by one frame: the backend holds a flush's raster launches back until the next flush (they leave
      fused with its setup stage), so frame k's strips are moved right after frame k + 1's WrhipFlushHeld -- frame k is complete on
@@ -285,13 +312,35 @@ int wr_shard_stream(wr_shard* S, const uint8_t* trace, size_t len, int iters, do
      exactly as the unsharded stream does. */
   int pending = 0;                                  /* the previous frame's strips are still to be moved */
   for (int i = 0; i < iters; i++) {
+    const uint8_t* trace = (i & 1) ? trace_b : trace_a;
+    const size_t len = (i & 1) ? len_b : len_a;
+    if (!S->probed && !shm_sync && S->flush_held && S->get_stats) {
+      /* The pipelined order below is only right for a frame that flushes ONCE: a flush in the middle of frame k + 1 (a sampled
+         target overwritten, a query, ring pressure ...) puts its first segment on the stream ahead of frame k's exchange.  The
+         first frame of a stream is therefore replayed unpipelined and its flushes counted; a trace that flushes more than once
+         per frame keeps the unpipelined order (and WrhipFlushHeld reports a frame that does so later: code 2 below). */
+      uint64_t st0[16] = {0}, st1[16] = {0};
+      S->get_stats(st0);
+      int rc0 = run_once(S->R, trace, len);
+      if (rc0) return rc0;
+      S->flush();
+      S->get_stats(st1);
+      S->probed = 1;
+      if (st1[0] - st0[0] != 1) {
+        fprintf(stderr, "wr_shard: %llu flushes per frame: the strips are moved unpipelined\n", (unsigned long long)(st1[0] - st0[0]));
+        S->flush_held = NULL;
+      }
+      if (shard_exchange(S)) { fprintf(stderr, "wr_shard: exchange failed\n"); return -2; }
+      continue;
+    }
     int rc = run_once(S->R, trace, len);
     if (rc) return rc;
-    if (S->shm || !S->flush_held) {
+    if (shm_sync || !S->flush_held) {
       if (S->shm) S->finish(); else S->flush();      /* (the stand-in copies with the host: the strip has to be there) */
       rc = shard_exchange(S);
     } else {
       const int held = S->flush_held();
+      if (held == 2) { fprintf(stderr, "wr_shard: a frame wrote the window and flushed again before its end: not pipelinable\n"); return -6; }
       rc = pending ? shard_exchange(S) : 0;
       pending = held;
       if (!held && rc == 0) rc = shard_exchange(S);

@@ -513,6 +513,9 @@ struct Context {
     uint32_t* flat = nullptr; size_t flat_cap = 0;   // flattened-depth-row tables (WrTargetDesc::flat_rows), height + 1 words per target that needs one
   } scratch[2];
   int64_t flush_seq = 0;
+  int64_t held_seq = 0;            // flush_seq at the last WrhipFlushHeld
+  int fb_writes_since_held = 0;    // flushes since the last WrhipFlushHeld that wrote the default framebuffer's texture ...
+  bool last_flush_wrote_fb = false;   // ... and whether the most recent flush is one of them
   // The raster launches of a flush are not issued with it: they are held back, and the first of them
   // goes out fused with the setup stage of the NEXT flush (wr_setup_raster_kernel), which it does not
   // depend on and which would otherwise sit between two frames as a dozen latency-bound workgroups
@@ -2017,6 +2020,14 @@ void flush_work(const std::vector<int>& sel_in) {
     } else {
       launch_held(launches, dtargets, n_targets, ddraws, S);
     }
+    {
+      // (for WrhipFlushHeld: which flushes wrote the window -- as a target, or as the destination of forwarded tile stores)
+      const GLuint fbt = c->framebuffers.find(0) ? c->framebuffers[0].color_attachment : 0;
+      bool wrote = false;
+      for (int wi : sel_in) { const TargetWork& w = c->work[wi]; if (fbt && (w.tex == fbt || w.fwd_tex == fbt)) wrote = true; }
+      if (wrote) c->fb_writes_since_held++;
+      c->last_flush_wrote_fb = wrote;
+    }
     ring_record_fence();
     c->flush_seq++;
     c->stats.flushes++;
@@ -3034,6 +3045,7 @@ void Finish(void) {
   flush_all();
   flush_uploads();
   sync_stream();
+  ctx->held_seq = ctx->flush_seq; ctx->fb_writes_since_held = 0;
   {
     // prims the device could not draw faithfully are reported, never dropped silently
     WrUnsupportedCounters h;
@@ -3341,6 +3353,7 @@ void WrhipFlush(void) {
   flush_all();
   flush_uploads();
   drain_tail();
+  ctx->held_seq = ctx->flush_seq; ctx->fb_writes_since_held = 0;      // (everything is on the stream: WrhipFlushHeld counts from here)
 #ifndef WRHIP_HOSTSIM
   wrq::drain();          // (the caller enqueues on the stream itself next: everything recorded so far must be on it)
 #endif
@@ -3350,13 +3363,23 @@ void WrhipFlush(void) {
 // held for the next one (Context::Tail).  Returns 1 if they are held, 0 if they were launched as well (deferral off / profiling).
 // The sharded frame loop moves frame k's strips right after frame k + 1's WrhipFlushHeld: frame k is complete on the stream,
 // frame k + 1 has not touched a pixel yet.
+// Returns 2 when the invariant the pipelined exchange rests on is broken: more than one flush since the previous call (a
+// flush in the middle of the frame) and an earlier one of them already wrote the default framebuffer -- part of this frame's
+// window is on the stream ahead of the previous frame's exchange.
 int WrhipFlushHeld(void) {
   if (!ctx) return 0;
+  const int64_t seq0 = ctx->held_seq;
   flush_all();
   flush_uploads();
+  const int64_t n = ctx->flush_seq - seq0;
+  const bool early_fb = n > 1 && ctx->fb_writes_since_held - (ctx->last_flush_wrote_fb ? 1 : 0) > 0;
+  ctx->held_seq = ctx->flush_seq;
+  ctx->fb_writes_since_held = 0;
+  if (n == 0 && ctx->tail.pending) drain_tail();      // nothing was recorded since: what the previous flush held back goes out now
 #ifndef WRHIP_HOSTSIM
   wrq::drain();
 #endif
+  if (early_fb) return 2;
   return ctx->tail.pending ? 1 : 0;
 }
 void* WrhipGetStream(void) {

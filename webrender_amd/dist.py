@@ -133,6 +133,8 @@ class ShardedFramePlayer:
         rl.wr_shard_set_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         rl.wr_shard_stream.restype = C.c_int
         rl.wr_shard_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        rl.wr_shard_stream2.restype = C.c_int
+        rl.wr_shard_stream2.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         rl.wr_shard_unique_id.argtypes = [C.c_char_p, C.c_char_p]
         rl.wr_shard_close.argtypes = [C.c_void_p, C.c_char_p]
         mode = 1 if self.gather == "all" else 0
@@ -149,6 +151,11 @@ class ShardedFramePlayer:
             self.native = rl.wr_shard_open_rccl(h, librccl, self.rank, self.world, mode, ids[0] or b"\0" * 128)
         else:
             self.shm_name = shm_name.encode()
+            if self.rank == 0:                  # a stale segment of a crashed run (non-zero arrival counter) must not be picked up
+                rl.wr_shard_shm_reset.argtypes = [C.c_char_p]
+                rl.wr_shard_shm_reset(self.shm_name)
+            if self.world > 1:
+                self.dist.barrier()
             self.native = rl.wr_shard_open_shm(h, self.shm_name, self.rank, self.world, mode, self.height * self.row_bytes)
         if not self.native:
             raise RuntimeError("wr_shard_open failed")
@@ -166,6 +173,16 @@ class ShardedFramePlayer:
         rc = self._rl.wr_shard_stream(self.native, t, len(t), iters, C.byref(ms))
         if rc != 0:
             raise RuntimeError(f"wr_shard_stream failed ({rc})")
+        return ms.value
+
+    def stream_alternating(self, other_stream, iters):
+        """native loop only: `iters` frames alternating between this player's frame trace (even frames) and `other_stream` -- the
+        frame trace of another scene recorded with the same resources (same window, same texture ids) -- exchanged after every one"""
+        ms = C.c_double(0.0)
+        t = self.rec.stream
+        rc = self._rl.wr_shard_stream2(self.native, t, len(t), other_stream, len(other_stream), iters, C.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"wr_shard_stream2 failed ({rc})")
         return ms.value
 
     def _collect(self, i):
