@@ -79,6 +79,8 @@ def kernel_label(k):
         return "wr_tile_rows_kernel"
     if k.kind == 11:     # ... with the next flush's setup stage in front
         return "wr_setup_tile_rows_kernel"
+    if k.kind == 12:     # thin launches: the R = 1 instantiation (64 x 4 pixels per wave, several workgroups per bin)
+        return f"wr_raster_kernel<{k.fmt}, false, 1, {k.feat}>"
     return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
 
 

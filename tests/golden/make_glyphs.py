@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generates webrender_amd/wrench/glyphs.npz: glyph bitmaps of the reference's own reftest fonts (wrench/reftests/text/*.ttf),
+rasterised with FreeType exactly as WebRender's glyph rasteriser does on Linux -- a ctypes restatement of
+wr_glyph_rasterizer/src/platform/unix/font.rs (load_glyph :417-596, get_bounding_box :619-658, rasterize_glyph_outline :790-838,
+rasterize_glyph :884-1097) for FontRenderMode::Alpha with the platform's default options (FontHinting::LCD, which for an
+alpha-mode instance leaves FT_LOAD_DEFAULT; FT_LOAD_NO_BITMAP | FT_LOAD_IGNORE_GLOBAL_ADVANCE_WIDTH; identity font transform;
+FontInstanceFlags::SUBPIXEL_POSITION: four quarter-pixel x offsets; no texture padding in screen raster space).  There is no
+gamma preblend on this platform (the unix backend has none).  INPUT DATA of the text workloads and parity cases, not code: the GPU
+box has neither /root/reference nor these fonts, so the bitmaps travel as this fixture.
+
+    python3 tests/golden/make_glyphs.py        (in a container that has /root/reference and libfreetype.so.6)
+"""
+import ctypes as C
+import json
+import os
+import re
+import numpy as np
+import yaml
+
+REF = "/root/reference/wrench/reftests/text"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "webrender_amd", "wrench", "glyphs.npz")
+FT = C.CDLL("libfreetype.so.6")
+L = C.c_long
+
+
+class Vector(C.Structure): _fields_ = [("x", L), ("y", L)]
+class BBox(C.Structure): _fields_ = [("xMin", L), ("yMin", L), ("xMax", L), ("yMax", L)]
+class Generic(C.Structure): _fields_ = [("data", C.c_void_p), ("finalizer", C.c_void_p)]
+class Metrics(C.Structure): _fields_ = [(n, L) for n in ("width", "height", "horiBearingX", "horiBearingY", "horiAdvance", "vertBearingX", "vertBearingY", "vertAdvance")]
+class Bitmap(C.Structure):
+    _fields_ = [("rows", C.c_uint), ("width", C.c_uint), ("pitch", C.c_int), ("buffer", C.POINTER(C.c_ubyte)), ("num_grays", C.c_ushort),
+                ("pixel_mode", C.c_ubyte), ("palette_mode", C.c_ubyte), ("palette", C.c_void_p)]
+class Outline(C.Structure):
+    _fields_ = [("n_contours", C.c_short), ("n_points", C.c_short), ("points", C.c_void_p), ("tags", C.c_void_p), ("contours", C.c_void_p), ("flags", C.c_int)]
+class GlyphSlot(C.Structure):
+    _fields_ = [("library", C.c_void_p), ("face", C.c_void_p), ("next", C.c_void_p), ("glyph_index", C.c_uint), ("generic", Generic),
+                ("metrics", Metrics), ("linearHoriAdvance", L), ("linearVertAdvance", L), ("advance", Vector), ("format", C.c_int),
+                ("bitmap", Bitmap), ("bitmap_left", C.c_int), ("bitmap_top", C.c_int), ("outline", Outline)]
+class Face(C.Structure):
+    _fields_ = [("num_faces", L), ("face_index", L), ("face_flags", L), ("style_flags", L), ("num_glyphs", L), ("family_name", C.c_char_p),
+                ("style_name", C.c_char_p), ("num_fixed_sizes", C.c_int), ("available_sizes", C.c_void_p), ("num_charmaps", C.c_int),
+                ("charmaps", C.c_void_p), ("generic", Generic), ("bbox", BBox), ("units_per_EM", C.c_ushort), ("ascender", C.c_short),
+                ("descender", C.c_short), ("height", C.c_short), ("max_advance_width", C.c_short), ("max_advance_height", C.c_short),
+                ("underline_position", C.c_short), ("underline_thickness", C.c_short), ("glyph", C.POINTER(GlyphSlot))]
+
+
+FT_LOAD_DEFAULT, FT_LOAD_NO_BITMAP, FT_LOAD_IGNORE_GLOBAL_ADVANCE_WIDTH = 0, 1 << 3, 1 << 9
+FT_GLYPH_FORMAT_OUTLINE = (ord("o") << 24) | (ord("u") << 16) | (ord("t") << 8) | ord("l")
+lib = C.c_void_p()
+assert FT.FT_Init_FreeType(C.byref(lib)) == 0
+FT.FT_Outline_Get_CBox.argtypes = [C.POINTER(Outline), C.POINTER(BBox)]
+FT.FT_Outline_Translate.argtypes = [C.POINTER(Outline), L, L]
+FT.FT_Set_Char_Size.argtypes = [C.c_void_p, L, L, C.c_uint, C.c_uint]
+FT.FT_Load_Glyph.argtypes = [C.c_void_p, C.c_uint, C.c_int32]
+FT.FT_Render_Glyph.argtypes = [C.POINTER(GlyphSlot), C.c_int]
+FT.FT_Get_Char_Index.argtypes = [C.c_void_p, C.c_ulong]
+FT.FT_Get_Char_Index.restype = C.c_uint
+FT.FT_Set_Transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def open_face(name):
+    face = C.c_void_p()
+    assert FT.FT_New_Face(lib, os.path.join(REF, name).encode(), 0, C.byref(face)) == 0, name
+    return face
+
+
+def rasterize(face, size_px, glyph_index, subpx):
+    """-> (left, top, bitmap[h, w] u8, advance px) or None for a glyph without pixels (space).  left / top as RasterizedGlyph:
+    the bitmap's top-left corner is at (x + left, baseline - top)."""
+    fr = C.cast(face, C.POINTER(Face)).contents
+    FT.FT_Set_Transform(face, None, None)                        # (identity shape, zero delta)
+    req = int(size_px * 1.0 * 64.0 + 0.5)
+    assert FT.FT_Set_Char_Size(face, req, req, 0, 0) == 0
+    flags = FT_LOAD_DEFAULT | FT_LOAD_NO_BITMAP | FT_LOAD_IGNORE_GLOBAL_ADVANCE_WIDTH
+    assert FT.FT_Load_Glyph(face, glyph_index, flags) == 0
+    slot = fr.glyph.contents
+    assert slot.format == FT_GLYPH_FORMAT_OUTLINE
+    advance = slot.metrics.horiAdvance / 64.0
+    cbox = BBox()
+    FT.FT_Outline_Get_CBox(C.byref(slot.outline), C.byref(cbox))
+    if slot.outline.n_contours == 0:
+        return None, advance
+    dx = int(subpx * 0.25 / 1.0 * 64.0 + 0.5)                     # get_subpx_offset: quarter pixels along x; dy = 0
+    dy = -int(0.0 * 64.0 + 0.5)
+    bx0, by0, bx1, by1 = cbox.xMin + dx, cbox.yMin + dy, cbox.xMax + dx, cbox.yMax + dy
+    bx0 &= ~63; by0 &= ~63; bx1 = (bx1 + 63) & ~63; by1 = (by1 + 63) & ~63
+    left, top, width, height = bx0 >> 6, by1 >> 6, (bx1 - bx0) >> 6, (by1 - by0) >> 6
+    if width == 0 or height == 0:
+        return None, advance
+    FT.FT_Outline_Translate(C.byref(slot.outline), dx - ((cbox.xMin + dx) & ~63), dy - ((cbox.yMin + dy) & ~63))
+    assert FT.FT_Render_Glyph(fr.glyph, 0) == 0                 # FT_RENDER_MODE_NORMAL
+    bm = slot.bitmap
+    assert bm.pixel_mode == 2                                   # FT_PIXEL_MODE_GRAY
+    rows, w = bm.rows, bm.width
+    px = np.zeros((rows, w), np.uint8)
+    for r in range(rows):
+        px[r] = np.ctypeslib.as_array(bm.buffer, shape=(abs(bm.pitch) * rows,))[r * bm.pitch:r * bm.pitch + w]
+    left += slot.bitmap_left
+    top += slot.bitmap_top - height
+    return (left, top, px), advance
+
+
+def main():
+    bitmaps, index = [], {}            # index["font|size|glyph|subpx"] = [slot in the blob list or -1, left, top, w, h, advance]
+    def add(font, face, size, gid, subpxs):
+        for s in subpxs:
+            key = f"{font}|{size}|{gid}|{s}"
+            if key in index:
+                continue
+            g, adv = rasterize(face, size, gid, s)
+            if g is None:
+                index[key] = [-1, 0, 0, 0, 0, adv]
+            else:
+                index[key] = [len(bitmaps), g[0], g[1], g[2].shape[1], g[2].shape[0], adv]
+                bitmaps.append(g[2])
+    faces = {f: open_face(f) for f in ("VeraBd.ttf", "FreeSans.ttf")}
+    charmap = {}
+    # (1) the glyph runs of the text reftests with explicit glyph lists (wrench/reftests/text/reftest.list)
+    runs = {}
+    for name in ("text", "long-text", "negative-pos", "non-opaque", "snap-text-offset", "1658", "shadow-cover-1"):
+        doc = yaml.safe_load(open(os.path.join(REF, name + ".yaml")))
+        out = []
+        def walk(items, origin):
+            for it in items:
+                if it.get("type") == "stacking-context":
+                    b = it.get("bounds", [0, 0, 0, 0])
+                    walk(it.get("items", []), (origin[0] + b[0], origin[1] + b[1]))
+                elif "glyphs" in it:
+                    font = it.get("font", "VeraBd.ttf")
+                    e = dict(it); e["font"] = font; e["origin_offset"] = list(origin)
+                    out.append(e)
+                    for gid in set(it["glyphs"]):
+                        add(font, faces[font], float(it["size"]), int(gid), range(4))
+                else:
+                    out.append(dict(it, origin_offset=list(origin)))
+        walk(doc["root"]["items"], (0.0, 0.0))
+        runs[name] = out
+    # (2) the character sets of cfg3 / text-rendering: FreeSans, sizes 8 .. 24, printable ASCII, whole-pixel variant
+    for size in range(8, 25):
+        for ch in range(32, 127):
+            gid = FT.FT_Get_Char_Index(faces["FreeSans.ttf"], ch)
+            charmap[f"FreeSans.ttf|{ch}"] = int(gid)
+            add("FreeSans.ttf", faces["FreeSans.ttf"], float(size), int(gid), range(4) if size in (12, 16) else (0,))
+    blob = np.concatenate([b.reshape(-1) for b in bitmaps]) if bitmaps else np.zeros(0, np.uint8)
+    offs = np.cumsum([0] + [b.size for b in bitmaps]).astype(np.int64)
+    np.savez_compressed(OUT, blob=blob, offsets=offs, index=np.frombuffer(json.dumps(index).encode(), np.uint8),
+                        charmap=np.frombuffer(json.dumps(charmap).encode(), np.uint8),
+                        runs=np.frombuffer(json.dumps(runs).encode(), np.uint8))
+    print("wrote", OUT, len(bitmaps), "bitmaps,", blob.size, "bytes of coverage,", os.path.getsize(OUT), "bytes on disk")
+
+
+if __name__ == "__main__":
+    main()

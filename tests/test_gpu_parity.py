@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, wrhip_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import TILE_ROWS, WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import TEXT_REFTESTS, TILE_ROWS, WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
@@ -656,4 +656,21 @@ def test_hip_tile_rows_match_oracle(name, make, monkeypatch):
     assert st["gl_error"] == st2["gl_error"]
     if ref:
         want, _ = render_direct(ref, make())
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,_small,kw", TEXT_REFTESTS, ids=[c[0] for c in TEXT_REFTESTS])
+def test_hip_text_reftests_full_4k(name, _small, kw):
+    """BASELINE configs[2]: wrench/reftests/text/<name>.yaml at the 4K target over FreeType-rasterised glyphs of the reftest's own font"""
+    ref = oracle_ref()
+    if not ref:
+        pytest.skip("oracle not built")
+    want, _ = render_direct(ref, scenes.make_workload("reftest-text-" + name, **kw))
+    got, st = render_direct(wrhip_lib(), scenes.make_workload("reftest-text-" + name, **kw))
+    assert st["gl_error"] == 0
+    if isinstance(want, dict):
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+    else:
         assert np.array_equal(got, want)

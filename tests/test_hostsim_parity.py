@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct, record_scene, ScenePlayer
-from parity_cases import TILE_ROWS, WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
+from parity_cases import TEXT_REFTESTS, TILE_ROWS, WRENCH, TEXTURE_RECT, YUV, SVG_FILTERS, OCCLUDED, BLEND, ROTATED, BORDERS, BORDER_SEGMENTS, DECORATIONS, FLAT, RUN_OVERFLOW, COPIES, copies_expected, MIX_BLEND, DUAL_SOURCE, REPEAT_DUAL, SPLIT, SPLIT_GOLDEN, GLYPH_TRANSFORM
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
 
@@ -573,3 +573,18 @@ def test_hostsim_tile_rows_match_oracle(hostsim, oracle_gcc, name, make, monkeyp
     assert st2["row_launches"] == 0
     assert np.array_equal(got2, want)
     assert st["gl_error"] == st2["gl_error"]        # (the sliver-fence overflow is reported by both)
+
+
+@pytest.mark.parametrize("name,kw,_full", TEXT_REFTESTS, ids=[c[0] for c in TEXT_REFTESTS])
+def test_hostsim_text_reftests_match_oracle(hostsim, oracle_gcc, name, kw, _full):
+    """wrench/reftests/text/<name>.yaml over FreeType-rasterised glyphs of the reftest's own font: every target read back"""
+    want, _ = render_direct(oracle_gcc, scenes.make_workload("reftest-text-" + name, **kw))
+    got, st = render_direct(hostsim, scenes.make_workload("reftest-text-" + name, **kw))
+    assert st["gl_error"] == 0
+    if isinstance(want, dict):
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+        want = want["window"]
+    else:
+        assert np.array_equal(got, want)
+    assert (want != 255).any(), "no ink"

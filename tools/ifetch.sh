@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r3_ifetch.sh <tag> [workload] -- instruction-fetch counters per kernel: is a short dependent launch waiting for its own code?
+# usage: tools/ifetch.sh <tag> [workload] -- instruction-fetch counters per kernel: is a short dependent launch waiting for its own code?
 tag=$1; w=${2:-cfg4}
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 i=0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/round2_sq.sh <tag> -- SQ counters (waves, cycles, instruction mix, wait) of cfg2 / cfg3 / cfg4, one json per workload
+# usage: tools/sq.sh <tag> -- SQ counters (waves, cycles, instruction mix, wait) of cfg2 / cfg3 / cfg4, one json per workload
 tag=$1
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 for w in ${WORKLOADS:-cfg2 cfg3 cfg4}; do

@@ -1191,7 +1191,7 @@ void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint6
   for (WrhipKernelStat& e : c->kstats) if (e.kind == kind && e.fmt == fmt && e.depth == depth && e.feat == feat) k = &e;
   if (!k) { c->kstats.push_back(WrhipKernelStat{kind, fmt, depth, feat, 0, 0, 0, 0}); k = &c->kstats.back(); }
   k->launches++; k->ns += ns; k->algo_bytes += algo_bytes; k->workgroups += workgroups;
-  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9 || kind == 10 || kind == 11) c->stats.raster_ns += ns;
+  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9 || kind == 10 || kind == 11 || kind == 12) c->stats.raster_ns += ns;
 }
 
 void tail_launched() {
@@ -1295,6 +1295,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     return;
   }
   prof_begin();
+  uint64_t thin_wgs = 0;                 // a thin launch (R = 1 instantiation): its workgroups; reported as kind 12 (not mixed into the R = 4 rows)
   const bool fused = SA != nullptr;      // (SA still set: this raster launch carries the next flush's setup stage)
   if (H.dense && H.fmt == WR_FMT_RGBA8 && H.feat == F7) {
     // (glyph levels: the 128-VGPR instantiation of the same body, plain or with the next flush's setup stage in front)
@@ -1320,6 +1321,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     }
   }
   else if (H.fmt == WR_FMT_RGBA8 && !H.depth && c->thin_r8 && H.nb <= WR_THIN_MAX_BINS && H.feat != 0 && H.feat != F7) {
+    thin_wgs = (uint64_t)H.nb * 4;
     // Small colour launches without depth (a picture's blur chain: cs_scale halvings and cs_blur passes down to a single bin):
     // as for the thin mask launches, a bin's sixteen strips go to four workgroups of four waves of 64 x 4 pixels instead of one
     // workgroup of four waves of 64 x 16 (wrench large-blur-radius: 139 us for the one-bin blur passes)
@@ -1345,6 +1347,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     // Small mask launches (blur / down-scale passes of a few dozen bins) leave most of the chip idle and are bound by one
     // wave's critical path: there a bin is given 16 waves of 64 x 4 pixels (4 px per lane) instead of 4 waves of 64 x 16.
     const bool thin = c->thin_r8 && H.nb <= WR_THIN_MAX_BINS;
+    if (thin && (H.feat == 0 || H.feat == (WR_FEAT_GENERIC | WR_FEAT_BLUR))) thin_wgs = (uint64_t)H.nb * c->thin_parts;
 #define WR_K1(FEAT)                                                                                                     \
   do {                                                                                                                  \
     WR_LAUNCH((wr_raster_kernel<WR_FMT_R8, false, 1, FEAT>), H.nb * c->thin_parts, 1024 / c->thin_parts, c->stream, targets, n_targets, draws,          \
@@ -1358,7 +1361,8 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
 #undef WR_K
 #undef WR_KF
   // (5: wr_raster_dense_kernel; 6 / 7: the same two with the next flush's setup stage in front, wr_setup_raster[_dense]_kernel)
-  prof_end(fused ? (H.dense ? 7 : 6) : (H.dense ? 5 : 2), H.fmt, H.depth, H.feat, H.algo_bytes + (fused ? setup_bytes : 0), (uint64_t)H.nb + (fused ? n_setup_blocks : 0));
+  prof_end(thin_wgs ? 12 : fused ? (H.dense ? 7 : 6) : (H.dense ? 5 : 2), H.fmt, H.depth, H.feat, H.algo_bytes + (fused ? setup_bytes : 0),
+           thin_wgs ? thin_wgs : (uint64_t)H.nb + (fused ? n_setup_blocks : 0));
   c->stats.kernel_launches++; c->stats.raster_launches++;
 }
 // A flush's raster launches in order; runs of chainable() launches of one variant (only the first may have mask rows: its rows

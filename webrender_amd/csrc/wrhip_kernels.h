@@ -4171,6 +4171,15 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
         // [row map: rows x u32, padded to 16 B][rows x pitch bytes]
         const unsigned long long map16 = ((unsigned long long)rows * 4 + 15) >> 4;
         const unsigned long long n16 = map16 + (((unsigned long long)rows * pitch + 15) >> 4);
+        // (the middle row's key BEFORE the reservation loop: inside it the lanes of a wave succeed one at a time, and whatever the
+        // successful branch does runs once per prim, serially -- nine box shadows of one target took nine key evaluations in a row)
+        WrBoxKey key;
+        key.valid = 0;
+        if (P.kind == WR_PK_BOX_SHADOW) {
+          const int yc = P.y0 + (int(rows) >> 1);
+          const WrRowVals rvc = wr_box_row_vals(P, aux[gid].box, yc);
+          key = wr_box_row_key(P, aux[gid].box, rvc, wr_box_row_setup(P, aux[gid].box, rvc));
+        }
         unsigned long long old = *(volatile unsigned long long*)T.mr_ctl;
         for (;;) {
           const unsigned long long ns = old >> 48, nr = (old >> 28) & 0xFFFFFull, nb = old & 0xFFFFFFFull;
@@ -4184,12 +4193,7 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
             WrMaskSlot sl;
             sl.prim = gid; sl.target = draws[P.draw].target; sl.row0 = uint32_t(nr); sl.pitch = pitch; sl.off16 = uint32_t(nb);
             sl.pad[0] = parts; sl.pad[1] = sl.pad[2] = 0;
-            sl.key.valid = 0;
-            if (P.kind == WR_PK_BOX_SHADOW) {
-              const int yc = P.y0 + (int(rows) >> 1);
-              const WrRowVals rvc = wr_box_row_vals(P, aux[gid].box, yc);
-              sl.key = wr_box_row_key(P, aux[gid].box, rvc, wr_box_row_setup(P, aux[gid].box, rvc));
-            }
+            sl.key = key;
             T.mr_slots[ns] = sl;
             const unsigned long long addr = (unsigned long long)(T.mr_store + nb * 16);
             recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_MASK_ROWS;

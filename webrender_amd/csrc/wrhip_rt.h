@@ -11,6 +11,7 @@
 // separate library (libwrhip_hostsim.so) that no product entry point loads;
 // libwrhip.so itself has no CPU path and aborts when no HIP device is present.
 #pragma once
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -155,7 +156,8 @@ struct Queue {
     static_assert(std::is_trivially_destructible<Fn>::value, "closures in the ring are not destroyed");
     if (inline_mode()) { f(); return; }
     const uint64_t t = tail.load(std::memory_order_relaxed);
-    while (t - head.load(std::memory_order_acquire) >= N) __builtin_ia32_pause();
+    // (bounded spin, then yield: a helper that lost its core -- an oversubscribed box, a debugger -- must not pin this thread at 100 %)
+    for (int spins = 0; t - head.load(std::memory_order_acquire) >= N; spins++) { if (spins < 4096) __builtin_ia32_pause(); else sched_yield(); }
     Cmd& c = ring[t % N];
     new (c.buf) Fn(static_cast<F&&>(f));
     c.fn = +[](void* p) { (*(Fn*)p)(); };
@@ -165,7 +167,7 @@ struct Queue {
   void drain() {
     if (inline_mode()) return;
     const uint64_t t = tail.load(std::memory_order_relaxed);
-    while (head.load(std::memory_order_acquire) != t) __builtin_ia32_pause();
+    for (int spins = 0; head.load(std::memory_order_acquire) != t; spins++) { if (spins < 4096) __builtin_ia32_pause(); else sched_yield(); }
   }
 };
 static inline Queue& q() { static Queue* p = new Queue(); return *p; }      // (never destroyed: the helper outlives static destruction)

@@ -13,6 +13,7 @@ render target with its own picture task (task_rect at the texture origin,
 content_origin = tile origin), and only primitives intersecting a tile are
 batched into it (command_buffer.rs / batch.rs:813-).
 """
+import os
 import numpy as np
 from . import glconst as G
 from .frame import (Frame, Target, Step, TextureRef, CompositeTile,
@@ -156,48 +157,75 @@ def cfg5_many_rects(width=7680, height=4320, n=100_000, encoding="quad", seed=5,
 
 
 # ---------------------------------------------------------------------------
-# Text (BASELINE config 3).  The glyph *content* comes from PIL/FreeType
-# rasterising DejaVu Sans (the reference's wr_glyph_rasterizer cannot be built
-# here; SURVEY.md §8c: text content parity is unpinned, the blit is pinned).
-FONT_PATH = "/usr/share/fonts/truetype/dejavu/DejaVuSans.ttf"
+# Text (BASELINE config 3).  The glyph bitmaps are the reference's own reftest fonts (wrench/reftests/text/FreeSans.ttf,
+# VeraBd.ttf) rasterised by FreeType the way WebRender's Linux glyph rasteriser does (wr_glyph_rasterizer/src/platform/unix/
+# font.rs restated over ctypes by tests/golden/make_glyphs.py: alpha render mode, default hinting, quarter-pixel x offsets, no
+# gamma preblend on this platform) and committed as a fixture -- webrender_amd/wrench/glyphs.npz -- because neither the fonts
+# nor /root/reference exist on the GPU box.  (Rounds 1-4 took PIL's rendering of DejaVu Sans.)
 ATLAS_SIZE = 2048       # glyph atlas: R8 2048^2 (texture_cache.rs:533-540)
 _atlas_cache = {}
+_glyphs = None
 
 
-def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127)):
+class GlyphFixture:
+    def __init__(self):
+        import json
+        d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "wrench", "glyphs.npz"))
+        self.blob, self.offsets = d["blob"], d["offsets"]
+        self.index = json.loads(bytes(d["index"]).decode())
+        self.charmap = json.loads(bytes(d["charmap"]).decode())
+        self.runs = json.loads(bytes(d["runs"]).decode())
+
+    def glyph(self, font, size, gid, subpx=0):
+        """-> (left, top, bitmap or None, advance): RasterizedGlyph of wr_glyph_rasterizer (bitmap's top-left corner at
+        (x + left, baseline - top)); bitmap None: a glyph without pixels (space)"""
+        e = self.index[f"{font}|{float(size)}|{int(gid)}|{int(subpx)}"]
+        if e[0] < 0:
+            return 0, 0, None, e[5]
+        bm = self.blob[self.offsets[e[0]]:self.offsets[e[0] + 1]].reshape(e[4], e[3])
+        return e[1], e[2], bm, e[5]
+
+    def char(self, font, size, ch, subpx=0):
+        return self.glyph(font, size, self.charmap[f"{font}|{int(ch)}"], subpx)
+
+
+def glyph_fixture():
+    global _glyphs
+    if _glyphs is None:
+        _glyphs = GlyphFixture()
+    return _glyphs
+
+
+def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127), font="FreeSans.ttf"):
     """Shelf-pack one bitmap per (size, char) into an R8 atlas.  Returns
     (pixels[2048,2048] u8, {(size, ch): (uv_rect texels, (left, -top), advance)})."""
-    key = (tuple(sizes), tuple(chars))
+    key = (tuple(sizes), tuple(chars), font)
     if key in _atlas_cache:
         return _atlas_cache[key]
-    from PIL import ImageFont
+    fx = glyph_fixture()
     atlas = np.zeros((ATLAS_SIZE, ATLAS_SIZE), np.uint8)
     table = {}
     x = y = 1
     shelf = 0
     for size in sizes:
-        font = ImageFont.truetype(FONT_PATH, size)
-        ascent, _ = font.getmetrics()
         for ch in chars:
-            c = chr(ch)
-            l, t, r, b = font.getbbox(c)
-            w, h = r - l, b - t
-            if w <= 0 or h <= 0:
+            left, top, bmp, adv = fx.char(font, size, ch)
+            if bmp is None:
                 continue
-            bmp = np.frombuffer(bytes(font.getmask(c, mode="L")), np.uint8)
-            mw, mh = font.getmask(c, mode="L").size
-            bmp = bmp.reshape(mh, mw)
-            w, h = mw, mh
+            h, w = bmp.shape
             if x + w + 1 > ATLAS_SIZE:
                 x, y, shelf = 1, y + shelf + 1, 0
             assert y + h + 1 <= ATLAS_SIZE
             atlas[y:y + h, x:x + w] = bmp
-            table[(size, ch)] = ((float(x), float(y), float(x + w), float(y + h)),
-                                 (float(l), float(t - ascent)), float(font.getlength(c)))
+            table[(size, ch)] = ((float(x), float(y), float(x + w), float(y + h)), (float(left), float(-top)), float(adv))
             x += w + 1
             shelf = max(shelf, h)
     _atlas_cache[key] = (atlas, table)
     return atlas, table
+
+
+def char_advance(size, ch, font="FreeSans.ttf"):
+    return float(glyph_fixture().char(font, size, ch)[3])
 
 
 def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=25, seed=3,

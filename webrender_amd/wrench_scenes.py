@@ -9,8 +9,8 @@ generated from the YAML files by tests/golden/make_wrench_benchmarks.py.
   unaligned-gradient   (scene_building.rs:3389-3396: `cached = (!is_software || is_tiled) && ...`); the axis-aligned
                        decomposition (prim_store/gradient/linear.rs:115-335) leaves this gradient as ONE two-stop segment
                        covering the prim.  Opaque stops => opaque pass, front to back: nine of the ten are depth-rejected
-  text-rendering       68 text runs, sizes 8-20 px, black / red / green / blue (ps_text_run, R8 glyph atlas; glyph bitmaps
-                       from PIL like cfg3's -- the reference rasterises with FreeType)
+  text-rendering       68 text runs, sizes 8-20 px, black / red / green / blue (ps_text_run, R8 glyph atlas; glyph bitmaps:
+                       the FreeType fixture, like cfg3's)
   large-blur-radius    a stacking context under filter blur(100, 100): picture task -> 5 x cs_scale -> cs_blur V / H (RGBA8) -> brush_image
                        with RasterizationSpace::Screen uv (picture.rs:5872-5930, render_task.rs:1168-1260, batch.rs:1509-1557)
   many-box-shadows     9 of the 10 outset box shadows (the cards': blur radius 45, offset (0, 22.5), no corner radii, colour rgba(0,0,0,0.102),
@@ -143,8 +143,7 @@ def text_rendering(width=3840, height=2160, tile_filter=None, **kw):
                 glyphs.append(c)
                 x += table[(size, c)][2]
             else:                       # space (no bitmap): advance only
-                from PIL import ImageFont
-                x += float(ImageFont.truetype(scenes.FONT_PATH, size).getlength(chr(c)))
+                x += scenes.char_advance(size, c)
         color = premultiply(np.array([list(CSS[t["color"] or "black"])], np.uint8))[0]
         ox, oy = t["origin"]
         bb = (ox - 2 * size, oy - 1.5 * size, ox + x + 2 * size, oy + size)
@@ -575,7 +574,161 @@ def large_boxshadow_ellipse_2(width=3840, height=2160, tile_filter=None, **kw):
     return _finish(frame, tiles)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# wrench/reftests/text/*.yaml (BASELINE configs[2]: "wrench reftests/text/ suite"): the reftests whose display lists carry explicit
+# glyph indices and positions (no text layout needed), over FreeType-rasterised glyphs of the reftests' own fonts (the fixture of
+# tests/golden/make_glyphs.py), as the frame builder hands them to ps_text_run with `options(disable-subpixel)` (alpha glyphs):
+#   * a text run is one prim header at its (snapped) reference-frame-relative offset -- here the origin of the enclosing stacking
+#     contexts, snapped to device pixels (prim_store/text_run.rs:318-340) -- with the glyphs' layout positions in the run's
+#     gpu-cache blocks (text_run.rs:107-132) and one GlyphInstance per glyph that has pixels;
+#   * the glyph key of an instance carries the quarter-pixel x offset its device position quantises to (glyph_rasterizer
+#     SubpixelOffset::quantize: < 1/8 -> 0, < 3/8 -> 1/4, < 5/8 -> 1/2, < 7/8 -> 3/4, else 0 of the next pixel), the program's
+#     snap bias (ps_text_run.glsl:96-108, SubpixelDirection::Horizontal) places the bitmap accordingly;
+#   * text shadows with a blur radius (1658.yaml, shadow-cover-1.yaml: scene_building.rs push_shadow -> a picture under
+#     Filter::Blur(radius / 2)) are rendered as the shadow-coloured run in a colour task inflated by ceil(std) * 3, blurred V / H
+#     (std <= 4: no down-scaling) and composited by brush_image ALPHA_PASS with RasterizationSpace::Screen uv, under the text.
+TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-offset", "1658", "shadow-cover-1")
+
+
+def _css_color(c):
+    if isinstance(c, str):
+        parts = c.replace(",", " ").split()
+        if len(parts) == 1:
+            return CSS[c]
+        c = [float(v) for v in parts]
+    c = list(c)
+    if len(c) == 3:
+        c.append(1.0)
+    return (int(c[0]), int(c[1]), int(c[2]), int(round(float(c[3]) * 255.0)) if float(c[3]) <= 1.0 else int(c[3]))
+
+
+def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
+    fx = scenes.glyph_fixture()
+    items = fx.runs[name]
+    frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    # the glyph atlas of this test: every (font, size, glyph, quarter-pixel variant) the runs need
+    atlas = np.zeros((1024, 1024), np.uint8)
+    ax = ay = 1
+    shelf = 0
+    entries = {}
+
+    def resource(font, size, gid, sub):
+        nonlocal ax, ay, shelf
+        key = (font, size, gid, sub)
+        if key not in entries:
+            left, top, bmp, _adv = fx.glyph(font, size, gid, sub)
+            if bmp is None:
+                entries[key] = None
+            else:
+                h, w = bmp.shape
+                if ax + w + 1 > 1024:
+                    ax, ay, shelf = 1, ay + shelf + 1, 0
+                assert ay + h + 1 <= 1024
+                atlas[ay:ay + h, ax:ax + w] = bmp
+                entries[key] = frame.add_glyph_resource((float(ax), float(ay), float(ax + w), float(ay + h)), (float(left), float(-top)), 1.0)
+                ax += w + 1
+                shelf = max(shelf, h)
+        return entries[key]
+
+    runs, shadows, pending_shadow = [], [], None
+    z = 1
+    for it in items:
+        if it.get("type") == "shadow":
+            pending_shadow = it
+            continue
+        if it.get("type") == "pop-all-shadows":
+            pending_shadow = None
+            continue
+        if "glyphs" not in it:
+            continue
+        font, size = it["font"], float(it["size"])
+        off = it["offsets"]
+        so = it["origin_offset"]
+        ref = (float(np.floor(so[0] + 0.5)), float(np.floor(so[1] + 0.5)))         # snapped reference-frame-relative offset
+        pts = [(float(off[2 * i]), float(off[2 * i + 1])) for i in range(len(it["glyphs"]))]
+        col = _css_color(it.get("color", "black"))
+        insts = []
+        for gi, (gid, (gx, gy)) in enumerate(zip(it["glyphs"], pts)):
+            fr = (ref[0] + gx) - np.floor(ref[0] + gx)
+            sub = 0 if fr < 0.125 else 1 if fr < 0.375 else 2 if fr < 0.625 else 3 if fr < 0.875 else 0
+            res = resource(font, size, int(gid), sub)
+            if res is not None:
+                insts.append((gi, res))
+        xs, ys = [p[0] for p in pts], [p[1] for p in pts]
+        bb = (ref[0] + min(xs) - 2 * size, ref[1] + min(ys) - 1.5 * size, ref[0] + max(xs) + 2 * size, ref[1] + max(ys) + size)
+        run = dict(pts=pts, ref=ref, color=col, insts=insts, bb=bb, z=z)
+        z += 1
+        if pending_shadow is not None and float(pending_shadow.get("blur-radius", 0)) > 0:
+            shadows.append(dict(run=run, color=_css_color(pending_shadow.get("color", "black")), offset=[float(v) for v in pending_shadow.get("offset", [0, 0])],
+                                std=float(pending_shadow["blur-radius"]) * 0.5, z=z))
+            z += 1
+        if col[3] > 0:
+            runs.append(run)
+    t_atlas = TextureRef("glyph_atlas_r8", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=atlas, upload_format=G.GL_RED)
+    frame.static_textures.append(t_atlas)
+    pot = lambda v: 1 << int(np.ceil(np.log2(max(v, 64))))
+    zero = (0.0, 0.0, 0.0, 0.0)
+    frame.readback = []
+    composites = []              # (unclipped prim rect, image source address, blurred texture, z)
+    for si, sh in enumerate(shadows):
+        run, std = sh["run"], sh["std"]
+        infl = float(np.ceil(std)) * 3.0
+        bb = run["bb"]
+        rect = (float(np.floor(bb[0] + sh["offset"][0])), float(np.floor(bb[1] + sh["offset"][1])), float(np.ceil(bb[2] + sh["offset"][0])), float(np.ceil(bb[3] + sh["offset"][1])))
+        clipped = (rect[0] - infl, rect[1] - infl, rect[2] + infl, rect[3] + infl)
+        tw, th = int(clipped[2] - clipped[0]), int(clipped[3] - clipped[1])
+        t_pic = TextureRef(f"shadow_picture_{si}", pot(tw), pot(th), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+        tg = Target(t_pic, "color", clear_color=zero)
+        pic_task = frame.add_render_task((0.0, 0.0, float(tw), float(th)), 1.0, (clipped[0], clipped[1]))
+        scol = premultiply(np.array([list(sh["color"])], np.uint8))[0]
+        addr = frame.add_text_run(scol, run["pts"])
+        ref = (run["ref"][0] + sh["offset"][0], run["ref"][1] + sh["offset"][1])
+        ph = frame.add_prim_header((ref[0], ref[1], 0.0, 0.0), (-BIG, -BIG, BIG, BIG), 1, addr, 0, pic_task, (65535, 0, 0, 0))
+        inst = [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
+        tg.steps.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(inst, dtype=np.int32), "PremultipliedAlpha", "none", textures={0: t_atlas}))
+        frame.passes.append([tg])
+        cur_rect = (0.0, 0.0, float(tw), float(th))
+        t_v = TextureRef(f"shadow_blur_v_{si}", pot(tw), pot(th), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+        t_h = TextureRef(f"shadow_blur_h_{si}", pot(tw), pot(th), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
+        a_src, a_v, a_h = frame.add_render_task(cur_rect), frame.add_render_task(cur_rect), frame.add_render_task(cur_rect)
+        tg_v, tg_h = Target(t_v, "color", clear_color=zero), Target(t_h, "color", clear_color=zero)
+        tg_v.steps.append(Step("cs_blur COLOR_TARGET", "BLUR", scenes.blur_instance(a_v, a_src, 1, std, (tw, th)), None, "none", textures={0: t_pic}))
+        tg_h.steps.append(Step("cs_blur COLOR_TARGET", "BLUR", scenes.blur_instance(a_h, a_v, 0, std, (tw, th)), None, "none", textures={0: t_v}))
+        frame.passes += [[tg_v], [tg_h]]
+        frame.readback += [t_pic, t_h]
+        quad = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
+        src = frame.gpu_cache.push([[cur_rect[0], cur_rect[1], cur_rect[2], cur_rect[3]], [0.0, 0.0, 0.0, 0.0]] + quad)
+        composites.append((clipped, src, t_h, sh["z"]))
+    bdata = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
+    tiles = _tiles(frame, width, height, tile_filter)
+    n_glyphs = 0
+    for target, task, (x0, y0, x1, y1) in tiles:
+        for (rect, src, tex, zz) in composites:
+            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
+                continue
+            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zz, bdata, 0, task, (4 | (1 << 16), 1, 65535, 0))
+            target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES",
+                                     np.array([frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=src)], dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={0: tex}))
+        inst = []
+        for run in runs:
+            bb = run["bb"]
+            if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
+                continue
+            col = premultiply(np.array([list(run["color"])], np.uint8))[0]
+            addr = frame.add_text_run(col, run["pts"])
+            ph = frame.add_prim_header((run["ref"][0], run["ref"][1], 0.0, 0.0), (-BIG, -BIG, BIG, BIG), run["z"], addr, 0, task, (65535, 0, 0, 0))
+            inst += [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
+        if inst:
+            target.alpha.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
+                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
+            n_glyphs += len(inst)
+    frame.n_glyphs = n_glyphs
+    return _finish(frame, tiles)
+
+
 WORKLOADS = {
+    **{f"reftest-text-{n}": (lambda n=n, **kw: text_reftest(n, **kw)) for n in TEXT_REFTESTS},
     "large-blur-radius": large_blur_radius,
     "large-boxshadow-ellipse": large_boxshadow_ellipse,
     "large-boxshadow-ellipse-2": large_boxshadow_ellipse_2,
@@ -587,6 +740,7 @@ WORKLOADS = {
     "many-box-shadows": many_box_shadows,
 }
 DESCRIPTIONS = {
+    **{f"reftest-text-{n}": f"wrench reftests/text/{n}.yaml (explicit glyph runs over FreeType-rasterised glyphs of the reftest's own font, alpha glyphs, ps_text_run)" for n in TEXT_REFTESTS},
     "large-blur-radius": "wrench benchmarks/large-blur-radius.yaml: filter blur(100, 100) over a 1024x1024 rect (the picture in a 1632^2 colour task, five cs_scale halvings, cs_blur COLOR_TARGET V/H at 51^2, the result composited by brush_image ALPHA_PASS with RasterizationSpace::Screen uv)",
     "large-boxshadow-ellipse": "wrench benchmarks/large-boxshadow-ellipse.yaml: one outset box shadow of a 1024x1024 box, blur radius 10, elliptical corner radii (cached blurred corner: mask -> cs_scale -> cs_blur V/H, then the cs_clip_box_shadow x clip-out mask and masked brush_solid segments)",
     "large-boxshadow-ellipse-2": "wrench benchmarks/large-boxshadow-ellipse-2.yaml: one INSET box shadow of a 1024x1024 box, blur radius capped at 300, elliptical radii of 400-700 px (the whole shadow rect blurred downscaled: 2049^2 mask -> five cs_scale halvings -> cs_blur V/H at 64^2; six masked brush_solid segments, each mask = cs_clip_box_shadow in inset / simple-stretch mode x the box's rounded rect)",
@@ -594,6 +748,6 @@ DESCRIPTIONS = {
     "many-images": "wrench benchmarks/many-images.yaml: 8192 opaque 8x8 images (one texture-cache entry each), brush_image opaque pass",
     "aligned-gradient": "wrench benchmarks/aligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient (brush_linear_gradient, opaque pass, depth-rejected overdraw)",
     "unaligned-gradient": "wrench benchmarks/unaligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient off the axis (brush_linear_gradient, opaque pass)",
-    "text-rendering": "wrench benchmarks/text-rendering.yaml: 68 text runs, 8-20 px, four colours (ps_text_run, R8 glyph atlas from PIL)",
+    "text-rendering": "wrench benchmarks/text-rendering.yaml: 68 text runs, 8-20 px, four colours (ps_text_run, R8 glyph atlas of FreeType-rasterised FreeSans glyphs)",
     "many-box-shadows": "wrench benchmarks/many-box-shadows.yaml: its 9 card shadows, blur radius 45, rgba(0,0,0,0.1) (one cached blurred corner: mask -> 2 cs_scale -> cs_blur V/H, then cs_clip_box_shadow x clip-out masks and masked brush_solid segments)",
 }
