@@ -309,23 +309,26 @@ WR_DEVICE void wr_pack_color(wf4 c, uint32_t out[2]) {
 // ---------------------------------------------------------------------------
 // Vertex stage outputs before draw_quad
 // GradientStops::can_merge (swgl_ext.h:1318-1326) of every pair of neighbouring entries of a validated 130-entry table, as a bitmap
-// (WrGradRec::merge).  Sixteen entries' steps are requested per round trip: the setup stage is one dependent chain per wave.
+// (WrGradRec::merge).  Eight entries' steps are requested per round trip: the setup stage is one dependent chain per wave.
+// (eight entries per trip: with sixteen in flight every kernel that carries the setup stage spilled 1.8 KB more per lane; NOT out of
+// line -- a callee is compiled to its own register budget and the kernels that call it inherit its count: 128 -> 356 VGPRs)
 WR_DEVICE void wr_grad_merge_bits(WrGradRec* G) {
   const float* stops = G->stops;
   uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;      // (in registers: the record lives in HBM)
   if (stops) {
-    for (int base = 0; base < 129; base += 16) {
-      wr_u4 st[17];
+#pragma nounroll      /* (unrolled, its 17 x 9 sixteen-byte loads in flight took the setup kernel from 166 to 474 VGPRs) */
+    for (int base = 0; base < 129; base += 8) {
+      wr_u4 st[9];
 #pragma unroll
-      for (int j = 0; j < 17; j++) st[j] = wr_load16(stops + 8 * wr_imin(base + j, 129) + 4);
+      for (int j = 0; j < 9; j++) st[j] = wr_load16(stops + 8 * wr_imin(base + j, 129) + 4);
       uint32_t bits = 0u;
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < 8; j++) {
         const bool m = base + j < 129 && wr_bits_f(st[j].x) == wr_bits_f(st[j + 1].x) && wr_bits_f(st[j].y) == wr_bits_f(st[j + 1].y) &&
                        wr_bits_f(st[j].z) == wr_bits_f(st[j + 1].z) && wr_bits_f(st[j].w) == wr_bits_f(st[j + 1].w);
         bits |= m ? (1u << j) : 0u;
       }
-      const uint32_t sh = bits << (base & 31);           // base is a multiple of 16: a batch never straddles a word
+      const uint32_t sh = bits << (base & 31);           // base is a multiple of 8: a batch never straddles a word
       const int w = base >> 5;
       m0 |= w == 0 ? sh : 0u; m1 |= w == 1 ? sh : 0u; m2 |= w == 2 ? sh : 0u; m3 |= w == 3 ? sh : 0u; m4 |= w == 4 ? sh : 0u;
     }
@@ -553,7 +556,6 @@ WR_DEVICE void wr_vs_ps_quad_textured(const WrDrawDesc& d, const uint8_t* arena,
       const int ax = int(unsigned(header.w) % 1024u), ay = int(unsigned(header.w) / 1024u);
       const bool ok = gbf.format == WR_FMT_RGBA32F && gbf.ptr && ay >= 0 && ay < gbf.height && ax >= 0 && ax < gbf.width && ax + 2 * 130 <= gbf.width;
       G->stops = ok ? (const float*)gbf.ptr + (size_t)ay * gbf.stride + (size_t)ax * 4 : nullptr;
-      wr_grad_merge_bits(G);
     } else {
       G->radial = 3;
       G->conic_scale = inv;
@@ -741,7 +743,6 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width &&
                     ax + 2 * 130 <= gb.width;
     G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
-    wr_grad_merge_bits(G);
     o.tex_slot = WR_S_GPU_BUFFER_F;
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
     o.kind = WR_PK_GRADIENT;     // (v_pos carries no w factor: BRUSH_FLAG_PERSPECTIVE_INTERPOLATION does not enter, persp_div stays < 0)
@@ -1677,7 +1678,6 @@ WR_DEVICE void wr_vs_cs_linear_gradient(const WrDrawDesc& d, const uint8_t* aren
   const int ax = int(unsigned(address) % 1024u), ay = int(unsigned(address) / 1024u);
   const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width && ax + 2 * 130 <= gb.width;
   G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
-  wr_grad_merge_bits(G);
   for (int n = 0; n < 4; n++) {
     const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
     o.u[n] = ax_ * scale.x; o.v[n] = ay_ * scale.y;
@@ -1708,7 +1708,6 @@ WR_DEVICE void wr_vs_cs_radial_gradient(const WrDrawDesc& d, const uint8_t* aren
   const int ax = int(unsigned(address) % 1024u), ay = int(unsigned(address) / 1024u);
   const bool ok = gb.format == WR_FMT_RGBA32F && gb.ptr && ay >= 0 && ay < gb.height && ax >= 0 && ax < gb.width && ax + 2 * 130 <= gb.width;
   G->stops = ok ? (const float*)gb.ptr + (size_t)ay * gb.stride + (size_t)ax * 4 : nullptr;
-  wr_grad_merge_bits(G);
   for (int n = 0; n < 4; n++) {
     const float ax_ = d.quad[2 * n], ay_ = d.quad[2 * n + 1];
     o.u[n] = (((task.z - task.x) * ax_) * scale.x - center.x) * radius_scale;
@@ -4162,7 +4161,13 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
   if (dbg_mode == 2) { if (valid && P.x0 == 12345678) prims[gid] = P; return; }
 #endif
   if (valid) {
-    prims[gid] = P; recs[gid] = wr_make_rec(P, targets[draws[P.draw].target].format);
+    // The 32-byte record is all the bin raster reads of a prim that folded into `new = hi_bytes(dst * K + C)` (or was culled): its
+    // 128-byte WrPrim stays unwritten -- 80 % of what the setup stage stored for a frame of plain rects (cfg5: 41 -> 9 MB).  The row
+    // kernels walk prims[] of their targets directly, so those targets keep every WrPrim.
+    const WrTargetDesc& T_ = targets[draws[P.draw].target];
+    const WrRec rec_ = wr_make_rec(P, T_.format);
+    recs[gid] = rec_;
+    if (T_.rows_mode || ((rec_.kbf & 0xFF) != WR_PK_SOLID_FOLDED && (rec_.kbf & 0xFF) != WR_PK_NONE)) prims[gid] = P;
     if ((P.kind == WR_PK_BOX_SHADOW || P.kind == WR_PK_CLIP_RECT) && (draws[P.draw].flags & WR_DF_MASK_ROWS) && P.x1 > P.x0 && P.y1 > P.y0) {
       // reserve this prim's rows in the flush's mask-row store (WrMaskSlot); a prim that does not fit keeps its in-raster evaluation
       const WrTargetDesc& T = targets[draws[P.draw].target];
@@ -4204,6 +4209,10 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
         }
       }
     }
+    // gradient tables' can_merge bitmap (WrGradRec::merge): here, ONCE, after the vertex stage's registers are dead (at its four
+    // call sites inside the vertex stages it cost every kernel that carries the setup stage 2 KB of scratch per lane)
+    if (P.kind == WR_PK_GRADIENT) wr_grad_merge_bits(&aux[gid].grad);
+    else if (P.kind == WR_PK_TEX_QUAD && aux[gid].quad.base_kind == WR_PK_GRADIENT) wr_grad_merge_bits(&aux[gid].quad.grad);
     if (P.kind == WR_PK_TEX_R8) {
       aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
       wr_write_glyph_rec(targets[draws[P.draw].target], gid, P, aux[gid].tex);
