@@ -1205,15 +1205,19 @@ void tail_launched() {
 }
 // The instantiated raster kernels: RGBA8 (+depth) x {0, TEX|GENERIC, +R8TEX, everything}, R8 x {0, GENERIC|BLUR, +CLIP}.
 // `SA` non-null: launch the fused setup + raster variant (only for the variants can_fuse() names).
-bool can_fuse(const Context::Held& H) {
-  if (H.row_n > 0) return H.row_mode == 2;     // (tile rows carry it: wr_setup_tile_rows_kernel; a span-rows launch is too short to hide a setup stage behind)
-  if (H.mr_rows > 0) return true;          // (the mask-rows launch ahead of an R8 raster launch: wr_setup_rows_kernel)
-  return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
-                                   H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
-}
 #ifndef WR_THIN_MAX_BINS
 #define WR_THIN_MAX_BINS 256
 #endif
+bool can_fuse(const Context::Held& H) {
+  if (H.row_n > 0) return H.row_mode == 2;     // (tile rows carry it: wr_setup_tile_rows_kernel; a span-rows launch is too short to hide a setup stage behind)
+  if (H.mr_rows > 0) return true;          // (the mask-rows launch ahead of an R8 raster launch: wr_setup_rows_kernel)
+  // a small textured colour launch is worth more as a THIN launch (four workgroups per bin: a quarter of the rows per wave, four
+  // times the waves) than as the carrier of the setup stage: transforms-simple, 256 bins of eleven rotated rects, 241 us fused
+  static const bool thin_first = getenv("WRHIP_FUSE_SMALL") == nullptr;
+  if (thin_first && ctx->thin_r8 && H.fmt == WR_FMT_RGBA8 && !H.depth && H.nb <= WR_THIN_MAX_BINS && H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC)) return false;
+  return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
+                                   H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
+}
 // `chain_n` >= 2: H is the first of chain_n consecutive thin R8 launches of one variant (chainable()); they go out as one
 // wr_raster_chain_kernel launch.
 bool chainable(const Context::Held& H) {
