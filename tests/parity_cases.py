@@ -396,6 +396,11 @@ TILE_ROWS = [
     ("tile_rows_images_screen", lambda: scenes.image_grid(n=12, seed=370, screen=True)),
     ("tile_rows_images_slivers", lambda: scenes.add_slivers(scenes.image_grid(n=10, seed=371), pitch=40)),
     ("tile_rows_images_sliver_overflow", lambda: scenes.add_slivers(scenes.image_grid(n=10, seed=372), pitch=9)),
+    # solids under clip masks (the corner segments of rounded-rect clips): plain and masked solids, depth-tested against occluders
+    ("tile_rows_masked_rects", lambda: scenes.masked_rects(n=40, seed=373)),
+    ("tile_rows_masked_rects_frac", lambda: scenes.masked_rects(n=60, seed=374, fractional=True)),
+    ("tile_rows_masked_rects_occluded", lambda: scenes.add_occluders(scenes.masked_rects(n=40, seed=375), n=10, zmax=60, seed=53)),
+    ("tile_rows_large_clip_rect", lambda: scenes.make_workload("large-clip-rect", width=1536, height=1536)),
 ]
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -1553,14 +1553,19 @@ void flush_work(const std::vector<int>& sel_in) {
       const bool shade = d.shader == WR_SH_BRUSH_IMAGE || d.shader == WR_SH_BRUSH_IMAGE_ALPHA || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT ||
                          d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA;
       if (!solid && !shade) return false;
-      if (solid && !(d.flags & WR_DF_SIMPLE)) return false;
+      // (solids under a clip mask -- the corner segments of a rounded-rect clip, wrench large-clip-rect: 72 prims on two tiles are one
+      // serial walk per wave in the bin raster -- : the host has scanned such a draw for anti-aliasing requests (WR_DF_QUADS), so its
+      // prims are plain or masked solids)
+      const bool masked_solid = (d.shader == WR_SH_BRUSH_SOLID || d.shader == WR_SH_BRUSH_SOLID_ALPHA) && d.tex[WR_S_CLIP_MASK].ptr != nullptr &&
+                                d.tex[WR_S_CLIP_MASK].format == WR_FMT_R8;
+      if (solid && !(d.flags & WR_DF_SIMPLE) && !masked_solid) return false;
       if (d.flags & (WR_DF_QUADS | WR_DF_XFORM | WR_DF_TEX_RECT)) return false;
       if (d.blend == WR_BLEND_UNSUPPORTED || d.blend == WR_BLEND_DUAL_SRC) return false;
       if (d.query_slot >= 0) return false;
-      heavy = heavy || shade;
+      heavy = heavy || shade || (masked_solid && !(d.flags & WR_DF_SIMPLE));
       nprim += d.count;
     }
-    return heavy && nprim <= 24;
+    return heavy && nprim <= 96;
   };
   std::vector<char> rows_of(c->work.size(), 0);
   for (int wi : sel) rows_of[wi] = rows_eligible(c->work[wi]) ? 1 : (tile_rows_eligible(c->work[wi]) ? 2 : 0);
