@@ -141,6 +141,13 @@ def main():
             gid = FT.FT_Get_Char_Index(faces["FreeSans.ttf"], ch)
             charmap[f"FreeSans.ttf|{ch}"] = int(gid)
             add("FreeSans.ttf", faces["FreeSans.ttf"], float(size), int(gid), range(4) if size in (12, 16) else (0,))
+    # (3) wrench/benchmarks/overlapping-text-shadows.yaml: one 60 px string (whole-pixel variant, as text-rendering's)
+    ots = yaml.safe_load(open(os.path.join(REF, "..", "..", "benchmarks", "overlapping-text-shadows.yaml")))["root"]["items"]
+    for it in ots:
+        if "text" in it:
+            for ch in sorted(set(it["text"])):
+                gid = FT.FT_Get_Char_Index(faces["FreeSans.ttf"], ord(ch))
+                add("FreeSans.ttf", faces["FreeSans.ttf"], float(it["size"]), int(gid), (0,))
     blob = np.concatenate([b.reshape(-1) for b in bitmaps]) if bitmaps else np.zeros(0, np.uint8)
     offs = np.cumsum([0] + [b.size for b in bitmaps]).astype(np.int64)
     np.savez_compressed(OUT, blob=blob, offsets=offs, index=np.frombuffer(json.dumps(index).encode(), np.uint8),

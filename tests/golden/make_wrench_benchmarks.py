@@ -64,6 +64,29 @@ def main():
     out["large-clip-rect"] = {"clip-bounds": nums(clip["bounds"]), "complex-rect": nums(clip["complex"][0]["rect"]),
                               "radius": float(clip["complex"][0]["radius"]), "rect-bounds": rects[0], "count": len(rects),
                               "color": clip["items"][0]["color"]}
+    # clip-clear.yaml (in the directory, not in benchmarks.list): the same shape -- 11 rects of 300 x 300 under a rounded clip of
+    # radius 50, inside a stacking context at the origin
+    sc = yaml.safe_load(open(os.path.join(REF, "clip-clear.yaml")))["root"]["items"][0]
+    assert sc["type"] == "stacking-context" and nums(sc["bounds"])[:2] == [0.0, 0.0] and len(sc["items"]) == 1
+    clip = sc["items"][0]
+    assert clip["type"] == "clip" and len(clip["complex"]) == 1
+    rects = [nums(r["bounds"]) for r in clip["items"]]
+    assert all(r["type"] == "rect" and r["color"] == clip["items"][0]["color"] for r in clip["items"]) and all(r == rects[0] for r in rects)
+    out["clip-clear"] = {"clip-bounds": nums(clip["bounds"]), "complex-rect": nums(clip["complex"][0]["rect"]),
+                         "radius": float(clip["complex"][0]["radius"]), "rect-bounds": rects[0], "count": len(rects),
+                         "color": clip["items"][0]["color"]}
+    # overlapping-text-shadows.yaml (not in benchmarks.list): 200 unblurred shadows (offset (i, i), red) around one text item
+    items = yaml.safe_load(open(os.path.join(REF, "overlapping-text-shadows.yaml")))["root"]["items"]
+    shadows = [it for it in items if it.get("type") == "shadow"]
+    texts = [it for it in items if "text" in it]
+    assert len(texts) == 1 and items[-1]["type"] == "pop-all-shadows" and items.index(texts[0]) == len(shadows)
+    assert all("blur-radius" not in s for s in shadows)
+    assert all(nums(s["offset"]) == [float(i), float(i)] and s["color"] == shadows[0]["color"] for i, s in enumerate(shadows))
+    out["overlapping-text-shadows"] = {"shadow-count": len(shadows), "shadow-color": shadows[0]["color"], "rule": "shadow i: offset (i, i), no blur",
+                                       "text": texts[0]["text"], "origin": nums(texts[0]["origin"]), "size": float(texts[0]["size"]),
+                                       "color": texts[0].get("color")}
+    # radial-gradient.yaml (not in benchmarks.list) is NOT restated: it gives `start-radius` / `end-radius`, and the reference's wrench
+    # reads `radius` (wrench/src/yaml_helper.rs:1161-1163 `expect("radial gradient must have a radius")`): wrench itself panics on it
     # large-blur-radius.yaml: a stacking context with filter blur(100, 100) over one rect
     sc = yaml.safe_load(open(os.path.join(REF, "large-blur-radius.yaml")))["root"]["items"][0]
     assert sc["type"] == "stacking-context" and sc["filters"] == "blur(100, 100)" and len(sc["items"]) == 1 and sc["items"][0]["type"] == "rect"

@@ -317,6 +317,9 @@ WRENCH = [
     ("wrench_large_boxshadow_ellipse_2", "large-boxshadow-ellipse-2", dict(width=1536, height=1536), dict()),      # the inset one, benchmarks.list:5
     ("wrench_large_clip_rect", "large-clip-rect", dict(width=1536, height=1536), dict()),
     ("wrench_large_blur_radius", "large-blur-radius", dict(width=1536, height=1536), dict()),
+    # in wrench/benchmarks/ but not in benchmarks.list (radial-gradient.yaml, the third one, cannot be read by the reference's own wrench)
+    ("wrench_clip_clear", "clip-clear", dict(width=1024, height=512), dict()),
+    ("wrench_overlapping_text_shadows", "overlapping-text-shadows", dict(width=1024, height=512), dict()),
 ]
 
 # brush_yuv_image (video frames: YUV_FORMAT_PLANAR with three R8 planes, YUV_FORMAT_NV12 with R8 + RG8; the seven YuvRangedColorSpace

@@ -185,6 +185,10 @@ class GlyphFixture:
         bm = self.blob[self.offsets[e[0]]:self.offsets[e[0] + 1]].reshape(e[4], e[3])
         return e[1], e[2], bm, e[5]
 
+    def has_char(self, font, size, ch, subpx=0):
+        gid = self.charmap.get(f"{font}|{int(ch)}")
+        return gid is not None and f"{font}|{float(size)}|{int(gid)}|{int(subpx)}" in self.index
+
     def char(self, font, size, ch, subpx=0):
         return self.glyph(font, size, self.charmap[f"{font}|{int(ch)}"], subpx)
 
@@ -209,6 +213,8 @@ def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127), font="FreeSans.
     shelf = 0
     for size in sizes:
         for ch in chars:
+            if not fx.has_char(font, size, ch):      # (a size the fixture holds for the characters of one string only)
+                continue
             left, top, bmp, adv = fx.char(font, size, ch)
             if bmp is None:
                 continue

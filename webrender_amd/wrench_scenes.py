@@ -125,7 +125,22 @@ def linear_gradients(name, width=3840, height=2160, tile_filter=None, **kw):
 
 
 def text_rendering(width=3840, height=2160, tile_filter=None, **kw):
-    items = display_lists()["text-rendering"]
+    return _text_runs(display_lists()["text-rendering"], width, height, tile_filter)
+
+
+def overlapping_text_shadows(width=3840, height=2160, tile_filter=None, **kw):
+    """overlapping-text-shadows.yaml (in the benchmark directory, not in benchmarks.list): 200 shadows without blur, offset (i, i),
+    around one 60 px string.  A shadow whose blur is a no-op makes no picture: pop_all_shadows adds the text run once per shadow,
+    in the shadow's colour at the shadow's offset, straight to the draw list, in the shadows' order, and then the run itself
+    (scene_building.rs:2917-2994 `blur_is_noop` -> add_primitive_to_draw_list; create_shadow_prim) -- 201 runs of the same glyphs."""
+    it = display_lists()["overlapping-text-shadows"]
+    ox, oy = it["origin"]
+    items = [{"text": it["text"], "origin": [ox + i, oy + i], "size": it["size"], "color": it["shadow-color"]} for i in range(int(it["shadow-count"]))]
+    items.append({"text": it["text"], "origin": [ox, oy], "size": it["size"], "color": it["color"]})
+    return _text_runs(items, width, height, tile_filter)
+
+
+def _text_runs(items, width, height, tile_filter):
     sizes = sorted({int(t["size"]) for t in items})
     atlas, table = scenes.build_glyph_atlas(sizes=tuple(sizes))
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
@@ -191,14 +206,17 @@ def large_boxshadow_ellipse(width=3840, height=2160, tile_filter=None, **kw):
                                   blur_radius=it["blur-radius"], radii=radii, shadow_color=CSS[it["color"]], offset=(0.0, 0.0))
 
 
-def large_clip_rect(width=3840, height=2160, tile_filter=None, **kw):
-    """large-clip-rect.yaml: N identical opaque rects under one rounded-rectangle clip (radius 16).  What the frame builder makes of
+def large_clip_rect(width=3840, height=2160, tile_filter=None, name="large-clip-rect", **kw):
+    """clip-clear.yaml (name="clip-clear"; in the benchmark directory, not in benchmarks.list) has the same shape: 11 rects of 300 x 300
+    at (50, 50) under a rounded clip of radius 50 -- above MIN_BRUSH_SPLIT_AREA, so segmented the same way; 44 corner masks of 50 x 50
+    in a 2048^2 alpha target that is cleared whole ("large but has low usage": what that benchmark is about).
+    large-clip-rect.yaml: N identical opaque rects under one rounded-rectangle clip (radius 16).  What the frame builder makes of
     each rect (prepare.rs build_segments_if_needed / update_clip_task_for_brush, segment.rs:397-470, 511-650): the clip's nine-patch
     splits the brush into 3 x 3 segments, emitted row by row; the four corner segments carry a mask -- one 16 x 16 clip-mask task
     each (cs_clip_rectangle FAST_PATH: uniform radius), per primitive, in an alpha target of the pass before -- and are drawn in
     the alpha pass (brush_solid ALPHA_PASS under swgl_clipMask); the other five are opaque and go to the opaque pass, front to
     back (batch.rs add_segmented_prim_to_batch: needs_blending = mask present)."""
-    it = display_lists()["large-clip-rect"]
+    it = display_lists()[name]
     n, rad = int(it["count"]), float(it["radius"])
     rb, cb = it["rect-bounds"], it["complex-rect"]
     rect = (rb[0], rb[1], rb[0] + rb[2], rb[1] + rb[3])
@@ -733,6 +751,8 @@ WORKLOADS = {
     "large-boxshadow-ellipse": large_boxshadow_ellipse,
     "large-boxshadow-ellipse-2": large_boxshadow_ellipse_2,
     "large-clip-rect": large_clip_rect,
+    "clip-clear": lambda **kw: large_clip_rect(name="clip-clear", **kw),
+    "overlapping-text-shadows": overlapping_text_shadows,
     "many-images": many_images,
     "aligned-gradient": lambda **kw: linear_gradients("aligned-gradient", **kw),
     "unaligned-gradient": lambda **kw: linear_gradients("unaligned-gradient", **kw),
@@ -745,6 +765,8 @@ DESCRIPTIONS = {
     "large-boxshadow-ellipse": "wrench benchmarks/large-boxshadow-ellipse.yaml: one outset box shadow of a 1024x1024 box, blur radius 10, elliptical corner radii (cached blurred corner: mask -> cs_scale -> cs_blur V/H, then the cs_clip_box_shadow x clip-out mask and masked brush_solid segments)",
     "large-boxshadow-ellipse-2": "wrench benchmarks/large-boxshadow-ellipse-2.yaml: one INSET box shadow of a 1024x1024 box, blur radius capped at 300, elliptical radii of 400-700 px (the whole shadow rect blurred downscaled: 2049^2 mask -> five cs_scale halvings -> cs_blur V/H at 64^2; six masked brush_solid segments, each mask = cs_clip_box_shadow in inset / simple-stretch mode x the box's rounded rect)",
     "large-clip-rect": "wrench benchmarks/large-clip-rect.yaml: 8 opaque 1024x1024 rects under one rounded-rectangle clip (radius 16): 3x3 brush segments per rect, 4 corner clip-mask tasks each (cs_clip_rectangle FAST_PATH), opaque + masked alpha pass",
+    "clip-clear": "wrench benchmarks/clip-clear.yaml (not in benchmarks.list): 11 opaque 300x300 rects under one rounded-rectangle clip (radius 50): 3x3 brush segments per rect, 44 corner clip-mask tasks of 50x50 in a 2048^2 alpha target cleared whole",
+    "overlapping-text-shadows": "wrench benchmarks/overlapping-text-shadows.yaml (not in benchmarks.list): 200 unblurred red shadows at offsets (i, i) + the 60 px string itself = 201 ps_text_run runs of 21 glyphs over one another (FreeType-rasterised FreeSans glyphs)",
     "many-images": "wrench benchmarks/many-images.yaml: 8192 opaque 8x8 images (one texture-cache entry each), brush_image opaque pass",
     "aligned-gradient": "wrench benchmarks/aligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient (brush_linear_gradient, opaque pass, depth-rejected overdraw)",
     "unaligned-gradient": "wrench benchmarks/unaligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient off the axis (brush_linear_gradient, opaque pass)",
