@@ -504,6 +504,7 @@ struct Context {
     WrRec* recs = nullptr;
     WrAux* aux = nullptr;
     float* vtab = nullptr; size_t vtab_cap = 0;   // per-row v tables of nearest-fast textured prims (WrDrawDesc::vtab_base)
+    float* qtab = nullptr; size_t qtab_cap = 0;   // row tables of general quads (WrTargetDesc::qtab), handed out by the setup stage
     unsigned long long* masks = nullptr; size_t masks_cap = 0;
     unsigned* bin_ctr = nullptr; size_t bin_ctr_cap = 0;   // per-bin arrival counters of thin launches that give a bin several workgroups (WrTargetDesc::bin_ctr), zero between launches
     // mask-row store (WrMaskSlot): allocation word, slot list, row bytes
@@ -1168,7 +1169,7 @@ Context::~Context() {
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
   wrrt::dev_free(dupload); wrrt::dev_free(dcounters);
-  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.bin_ctr); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); wrrt::dev_free(S.flat); }
+  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.qtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.bin_ctr); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); wrrt::dev_free(S.flat); }
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::event_destroy(ev_copy);
@@ -1565,7 +1566,7 @@ void flush_work(const std::vector<int>& sel_in) {
       heavy = heavy || shade || (masked_solid && !(d.flags & WR_DF_SIMPLE));
       nprim += d.count;
     }
-    return heavy && nprim <= 96;
+    return heavy && nprim <= 128;
   };
   std::vector<char> rows_of(c->work.size(), 0);
   for (int wi : sel) rows_of[wi] = rows_eligible(c->work[wi]) ? 1 : (tile_rows_eligible(c->work[wi]) ? 2 : 0);
@@ -1594,6 +1595,8 @@ void flush_work(const std::vector<int>& sel_in) {
   size_t inst_bytes = 0;
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0;
   size_t vtab_cursor = 0;
+  size_t qtab_need = 0;        // floats: rows x instances x 10 of the draws that may hold rotated / projected prims (WR_DF_XFORM)
+  static const bool no_qtab = getenv("WRHIP_NO_QTAB") != nullptr;
   uint64_t algo_bytes = 0, pixels = 0;
   for (int oi = 0; oi < n_targets; oi++) {
     TargetWork& w = c->work[sel[oi]];
@@ -1682,6 +1685,10 @@ void flush_work(const std::vector<int>& sel_in) {
           d.vtab_base = (int)vtab_cursor; d.vtab_rows = rows;
           vtab_cursor += need;
         }
+      }
+      if (!no_qtab && T.format == WR_FMT_RGBA8 && (d.flags & WR_DF_XFORM) && !(d.flags & WR_DF_SIMPLE) && d.shader != WR_SH_CLEAR_OP) {
+        const int rows = std::max(0, std::min(d.clip[3], t.height) - std::max(d.clip[1], 0));
+        qtab_need += (size_t)rows * (size_t)d.count * 10;
       }
       draws.push_back(d);
     }
@@ -1774,7 +1781,18 @@ void flush_work(const std::vector<int>& sel_in) {
       S.bin_ctr = (unsigned*)wrrt::dev_alloc(S.bin_ctr_cap * sizeof(unsigned));
       wrrt::memset8(S.bin_ctr, 0, S.bin_ctr_cap * sizeof(unsigned), c->stream);      // (the workgroups leave them at zero)
     }
-    for (WrTargetDesc& T : targets) { T.grecs = (const WrGlyphRec*)(S.recs + S.prims_cap); T.bin_ctr = S.bin_ctr + T.first_bin; }
+    // the pool the setup stage cuts general quads' row tables from: what the flush's WR_DF_XFORM draws could ask for, up to 64 MB
+    const size_t qtab_want = std::min<size_t>(qtab_need, (size_t)16 << 20);
+    if (S.qtab_cap < qtab_want) {
+      sync_stream();
+      wrrt::dev_free(S.qtab);
+      S.qtab_cap = qtab_want * 2;
+      S.qtab = (float*)wrrt::dev_alloc(S.qtab_cap * sizeof(float));
+    }
+    for (WrTargetDesc& T : targets) {
+      T.grecs = (const WrGlyphRec*)(S.recs + S.prims_cap); T.bin_ctr = S.bin_ctr + T.first_bin;
+      T.qtab = qtab_want ? S.qtab : nullptr; T.qtab_cap = (uint32_t)std::min<size_t>(S.qtab_cap, (size_t)1 << 30); T.qtab_ctl = nullptr; T.qtab_pad = 0;
+    }
   }
   // Mask-row store.  When the bounds fit, no reservation of the setup stage can fail and the R8 launches take the light
   // variant (the rows kernel evaluates, the bins blend bytes); otherwise the store is capped, prims that do not fit keep their
@@ -1828,9 +1846,12 @@ void flush_work(const std::vector<int>& sel_in) {
     // first draw of every 64-prim block (wr_vertex_prim starts its draw lookup there)
     const int n_blocks = (n_prims + 63) / 64;
     size_t off_blk = (off_inst + inst_bytes + 255) & ~size_t(255);
-    size_t total = off_blk + sizeof(int) * n_blocks + 256;
+    const size_t off_qctl = (off_blk + sizeof(int) * n_blocks + 63) & ~size_t(63);      // the row-table pool's allocation word: zero on arrival
+    size_t total = off_qctl + 64 + 256;
     size_t aoff = staging_alloc(total);
     uint8_t* h = c->staging + aoff;
+    memset(h + off_qctl, 0, 64);
+    for (WrTargetDesc& T : targets) T.qtab_ctl = T.qtab ? (unsigned long long*)(c->dupload + aoff + off_qctl) : nullptr;
     if (nd) stage_copy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     stage_copy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
     if (inst_bytes >= PARALLEL_COPY_MIN && inst_segs.size() > 1) {

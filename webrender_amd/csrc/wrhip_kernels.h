@@ -2077,7 +2077,7 @@ WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, floa
 WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const float (&iu)[4], const float (&iv)[4], float cx0, float cy0,
                             float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1,
                             const float (&iz)[4], const float (&iw)[4], bool persp) {
-  Q.nseg = 0; Q.aa = aa ? 1 : 0;
+  Q.nseg = 0; Q.aa = aa ? 1 : 0; Q.rowtab = nullptr; Q.rowtab_rows = 0;
   // top-most point (:794-799)
   const int top = py[3] < py[2] ? (py[0] < py[1] ? (py[0] < py[3] ? 0 : 3) : (py[1] < py[3] ? 1 : 3))
                                 : (py[0] < py[1] ? (py[0] < py[2] ? 0 : 2) : (py[1] < py[2] ? 1 : 2));
@@ -2238,7 +2238,7 @@ __device__ __noinline__ int wr_clip_side(int axis, int nump, const WrClipPt* p, 
 WR_DEVICE bool wr_poly_walk(const int nump, const float* px, const float* py, const float* iu, const float* iv, const float* iz,
                                           const float* iw, float cx0, float cy0, float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0,
                                           int& by0, int& bx1, int& by1) {
-  Q.nseg = 0; Q.aa = aa ? 1 : 0;
+  Q.nseg = 0; Q.aa = aa ? 1 : 0; Q.rowtab = nullptr; Q.rowtab_rows = 0;
   auto NEXT = [&](int i) { return i + 1 == nump ? 0 : i + 1; };
   auto PREV = [&](int i) { return i == 0 ? nump - 1 : i - 1; };
   int top = 0;
@@ -2365,12 +2365,78 @@ WR_DEVICE bool wr_persp_clipped_walk(WrQuadRec& Q, int& bx0, int& by0, int& bx1,
 
 // The span of row y of a general quad (aa_span, rasterize.h:520-561): [s0, s1) -- with swgl_antiAlias the rounded-out one,
 // [la0, ra1).  False: the row is outside the walk.
+// x of both edges of run S (the LAST run of the walk that holds row y) on row y: Edge::nextRow's row-by-row sums -- read from the
+// prim's row table where the setup stage wrote one (WrQuadRec::rowtab)
+WR_DEVICE const float* wr_quad_rowtab_entry(const WrQuadRec& Q, int y) {
+  return (Q.rowtab && (unsigned)(y - Q.rowtab_y0) < (unsigned)Q.rowtab_rows) ? Q.rowtab + (size_t)(y - Q.rowtab_y0) * (size_t)Q.rowtab_stride : nullptr;
+}
+WR_DEVICE void wr_quad_row_x(const WrQuadRec& Q, const WrQuadSeg& S, int y, float& xl, float& xr) {
+  if (const float* e = wr_quad_rowtab_entry(Q, y)) { xl = e[0]; xr = e[1]; return; }
+  xl = wr_accum(S.lx, S.ls, y - S.lrow); xr = wr_accum(S.rx, S.rs, y - S.rrow);
+}
+// The setup stage's half: every edge value of every row of the prim's box, summed ONCE, row by row as Edge::nextRow does (the first
+// row of a run through wr_accum, then one add per row and value: by wr_accum's contract the same numbers the per-row calls return).
+// What this replaces: in the raster stage every lane evaluates its own rows, i.e. one wr_accum per value, lane-row and prim -- for a
+// full-size rotated rect 1448 rows x 16 lanes across x 2 values of a walk over binades each (wrench transforms-simple: 108 us of raster
+// for eleven such rects).  A prim whose table does not fit the flush's pool keeps the per-row sums.
+#define WR_QTAB_MIN_ROWS 16
+__device__ __noinline__ void wr_quad_build_rowtab(const WrTargetDesc* Tp, const WrPrim* Pp, WrQuadRec* Qp) {
+  const WrTargetDesc& T = *Tp; const WrPrim& P = *Pp; WrQuadRec& Q = *Qp;
+  Q.rowtab = nullptr; Q.rowtab_rows = 0; Q.rowtab_stride = 0; Q.rowtab_y0 = 0; Q.rowtab_pad = 0;
+  const int rows = P.y1 - P.y0;
+  if (!T.qtab || !T.qtab_ctl || rows < WR_QTAB_MIN_ROWS || Q.nseg <= 0) return;
+  const bool zw = Q.pad != 0 || (P.kind == WR_PK_TEX_QUAD && Q.base_kind == WR_PK_MIX_BLEND);
+  const int stride = zw ? 10 : (P.kind == WR_PK_TEX_QUAD ? 6 : 2);
+  const unsigned long long need = (unsigned long long)rows * (unsigned long long)stride;
+  const unsigned long long off = atomicAdd(T.qtab_ctl, need);
+  if (off + need > (unsigned long long)T.qtab_cap) return;
+  float* tab = T.qtab + off;
+  for (int i = 0; i < Q.nseg; i++) {          // (in order: where two runs hold a row, the later one is the one the raster stage picks)
+    const WrQuadSeg& S = Q.seg[i];
+    const int ya = wr_imax(S.row_a, P.y0), yb = wr_imin(S.row_b, P.y1);
+    if (yb <= ya) continue;
+    float xl = wr_accum(S.lx, S.ls, ya - S.lrow), xr = wr_accum(S.rx, S.rs, ya - S.rrow);
+    float lu = 0.0f, lv = 0.0f, ru = 0.0f, rv = 0.0f, wl = 0.0f, wr = 0.0f, zl = 0.0f, zr = 0.0f;
+    if (stride >= 6) {
+      lu = wr_accum(S.luv[0], S.luvs[0], ya - S.lrow); lv = wr_accum(S.luv[1], S.luvs[1], ya - S.lrow);
+      ru = wr_accum(S.ruv[0], S.ruvs[0], ya - S.rrow); rv = wr_accum(S.ruv[1], S.ruvs[1], ya - S.rrow);
+    }
+    if (stride >= 10) {
+      wl = wr_accum(Q.persp.lw[i], Q.persp.lws[i], ya - S.lrow); wr = wr_accum(Q.persp.rw[i], Q.persp.rws[i], ya - S.rrow);
+      zl = wr_accum(Q.persp.lz[i], Q.persp.lzs[i], ya - S.lrow); zr = wr_accum(Q.persp.rz[i], Q.persp.rzs[i], ya - S.rrow);
+    }
+    // (the slopes in registers: the table's stores may alias the record as far as the compiler knows, and a reload per row and value is a
+    // trip to memory on the one thread that walks the prim's rows -- 75 us for the 512 rows of a tile-high rect, measured)
+    const float ls = S.ls, rs = S.rs, lus = S.luvs[0], lvs = S.luvs[1], rus = S.ruvs[0], rvs = S.ruvs[1];
+    const float lws = stride >= 10 ? Q.persp.lws[i] : 0.0f, rws = stride >= 10 ? Q.persp.rws[i] : 0.0f;
+    const float lzs = stride >= 10 ? Q.persp.lzs[i] : 0.0f, rzs = stride >= 10 ? Q.persp.rzs[i] : 0.0f;
+    float* __restrict__ e = tab + (size_t)(ya - P.y0) * (size_t)stride;
+    if (stride == 2) {
+      for (int y = ya; y < yb; y++, e += 2) { e[0] = xl; e[1] = xr; xl = xl + ls; xr = xr + rs; }
+    } else {
+      for (int y = ya; y < yb; y++, e += stride) {
+        e[0] = xl; e[1] = xr; e[2] = lu; e[3] = lv; e[4] = ru; e[5] = rv;
+        xl = xl + ls; xr = xr + rs; lu = lu + lus; lv = lv + lvs; ru = ru + rus; rv = rv + rvs;
+        if (stride >= 10) {
+          e[6] = wl; e[7] = wr; e[8] = zl; e[9] = zr;
+          wl = wl + lws; wr = wr + rws; zl = zl + lzs; zr = zr + rzs;
+        }
+      }
+    }
+  }
+  Q.rowtab_y0 = P.y0; Q.rowtab_rows = rows; Q.rowtab_stride = stride;
+  Q.rowtab = tab;
+#ifdef WRHIP_HOSTSIM
+  { static const bool dbg = getenv("WRHIP_DEBUG_QTAB") != nullptr; if (dbg) fprintf(stderr, "row table: kind %d rows %d stride %d at %llu of %u\n", (int)P.kind, rows, stride, off, T.qtab_cap); }
+#endif
+}
 WR_DEVICE bool wr_quad_row_span(const WrQuadRec& Q, int y, int& s0, int& s1) {
   int si = -1;
   for (int i = 0; i < Q.nseg; i++) if (y >= Q.seg[i].row_a && y < Q.seg[i].row_b) si = i;
   if (si < 0) return false;
   const WrQuadSeg& S = Q.seg[si];
-  const float xl = wr_accum(S.lx, S.ls, y - S.lrow), xr = wr_accum(S.rx, S.rs, y - S.rrow);
+  float xl, xr;
+  wr_quad_row_x(Q, S, y, xl, xr);
   if (!Q.aa) {
     s0 = int(floorf(wr_clamp(xl, S.b0, S.b1) + 0.5f)); s1 = int(floorf(wr_clamp(xr, S.b0, S.b1) + 0.5f));
   } else {
@@ -2514,7 +2580,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       WrClipStash& St = *wr_clip_stash(auxp->quad);
       St.cx0 = cx0; St.cy0 = cy0; St.cx1 = cx1; St.cy1 = cy1; St.aa = aa ? 1 : 0; St.aa_edges = o.aa_edges;
       St.vp[0] = d.vp_origin[0]; St.vp[1] = d.vp_origin[1]; St.vp[2] = d.vp_size[0]; St.vp[3] = d.vp_size[1];
-      auxp->quad.nseg = -1;
+      auxp->quad.nseg = -1; auxp->quad.rowtab = nullptr; auxp->quad.rowtab_rows = 0;
       bx0 = int(cx0); by0 = int(cy0); bx1 = int(cx0) + 1; by1 = int(cy0) + 1;      // (a placeholder box: replaced by the walk's)
     }
     else if (o.kind == WR_PK_MIX_BLEND) {
@@ -3812,6 +3878,7 @@ WR_DEVICE void wr_vertex_prim(const WrDrawDesc* __restrict__ draws, int n_draws,
     }
     if (!ok) { P.kind = WR_PK_NONE; P.x0 = P.x1 = P.y0 = P.y1 = 0; aux[gid].quad.nseg = 0; }
   }
+  if (P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) wr_quad_build_rowtab(&targets[d.target], &P, &aux[gid].quad);
   if ((P.kind == WR_PK_SOLID_QUAD || P.kind == WR_PK_TEX_QUAD) && aux[gid].quad.pad != 0 && (P.flags & WR_PF_DEPTH_TEST)) {
     // a depth-tested perspective prim: the rows its spans touch are flattened from here on (WrTargetDesc::flat_rows)
     uint32_t* fr = targets[d.target].flat_rows;
@@ -4396,7 +4463,7 @@ __device__ __noinline__ WrQuadRowS wr_quad_row_setup(const WrQuadRec* Qp, int y,
     xl = pxl; xr = pxr;
     for (int i = py_; i < y; i++) { xl = xl + S.ls; xr = xr + S.rs; }
   } else {
-    xl = wr_accum(S.lx, S.ls, y - S.lrow); xr = wr_accum(S.rx, S.rs, y - S.rrow);   // Edge::nextRow, one add per row
+    wr_quad_row_x(Q, S, y, xl, xr);   // Edge::nextRow, one add per row
   }
   R.xl = xl; R.xr = xr; R.si = si;
   R.ok = 1;
@@ -4444,6 +4511,15 @@ struct WrQuadRowCache { int y, si; float xl, xr, lu, lv, ru, rv, wl, wr, zl, zr;
 WR_DEVICE void wr_quad_row_edges(const WrQuadRec& Q, int si, int y, WrQuadRowCache* C, WrQuadRowCache& L) {
   if (C && C->si == si && C->y == y) { L = *C; return; }
   const WrQuadSeg& S = Q.seg[si];
+  if (const float* e = Q.rowtab_stride >= 6 ? wr_quad_rowtab_entry(Q, y) : nullptr) {
+    // the row's edge values as the setup stage summed them (wr_quad_build_rowtab)
+    L.xl = e[0]; L.xr = e[1]; L.lu = e[2]; L.lv = e[3]; L.ru = e[4]; L.rv = e[5];
+    L.wl = L.wr = L.zl = L.zr = 0.0f;
+    if (Q.rowtab_stride >= 10) { L.wl = e[6]; L.wr = e[7]; L.zl = e[8]; L.zr = e[9]; }
+    L.y = y; L.si = si;
+    if (C) *C = L;
+    return;
+  }
   const int dy = C ? y - C->y : 0;
   if (C && C->si == si && dy > 0 && dy <= 8) {
     L = *C;

@@ -230,6 +230,13 @@ struct WrTargetDesc {
   const struct WrGlyphRec* grecs;              // the flush's glyph records, one per prim (global prim index), see WrGlyphRec
   unsigned* bin_ctr;                           // one arrival counter per bin of this target (zero between launches): thin R8 launches that give
                                                // a bin several workgroups count themselves in, the last one re-zeroes the bin's mask words
+  // Row tables of general quads (WrQuadRec::rowtab): a pool of floats the setup stage hands out with one atomicAdd per prim
+  // (`qtab_ctl`: a word of the flush's arena, zero when the arena arrives) -- the same pool for every target of a flush;
+  // nullptr: none (no draw of the flush can hold a rotated / projected prim), and a prim that does not fit keeps its per-row sums.
+  float* qtab;
+  unsigned long long* qtab_ctl;
+  uint32_t qtab_cap;                           // floats
+  uint32_t qtab_pad;
 };
 
 // Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
@@ -552,6 +559,13 @@ struct WrQuadRec {
   int32_t aa;                       // SWGL_CLIP_FLAG_AA set for this prim
   int32_t base_kind;                // WR_PK_TEX_QUAD: WR_PK_TEX_RGBA8 / TEX_FS / TEX_R8 / TEX_REPEAT / GRADIENT / FILTER / QUAD_MASK
   int32_t pad;                      // perspective: 0 no; 1 the program has no varyings (gl_FragCoord.zw never stepped); 2 it has
+  // Row table (wr_quad_build_rowtab): the edge values of every target row y in [rowtab_y0, rowtab_y0 + rowtab_rows) of this prim, written
+  // ONCE by the setup stage -- rowtab[(y - rowtab_y0) * rowtab_stride + ...] = x of the left and right edge (stride 2: WR_PK_SOLID_QUAD),
+  // then the two interpolants of both edges (stride 6), then 1/w and z of both edges (stride 10: perspective, or brush_mix_blend's
+  // second varying) -- instead of one row-by-row sum (wr_accum) per value, lane, row and prim in the raster stage.  nullptr: no table.
+  const float* rowtab;
+  int32_t rowtab_y0, rowtab_rows;
+  int32_t rowtab_stride, rowtab_pad;
   WrQuadSeg seg[WR_MAX_QSEG];
   union {                           // the base kind's own side record (the quad record took its place in WrAux)
     WrRepeatRec rep;                // WR_PK_TEX_REPEAT
