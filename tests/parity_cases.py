@@ -169,7 +169,8 @@ FLAT = [
     ("flat_rotated_rects", lambda: _U(scenes.rotated_rects(opaque_frac=0.3), seed=93)),
 ]
 # Many depth runs per row: thin opaque slivers at a fixed pitch in front of the image grid's opaque-pass images.
-# Up to WR_MAX_RUNS runs per row / WR_MAX_OCC occluders per strip are reproduced exactly; beyond that the prim is reported.
+# WR_MAX_RUNS runs per row / WR_MAX_OCC occluders per strip are what the LDS copies hold; rows and strips beyond that keep theirs in the
+# flush's pool (round 5: RUN_OVERFLOW below is exact too; only an exhausted pool is reported).
 OCCLUDED += [
     ("occluded_images_sliver_fence", lambda: scenes.add_slivers(scenes.image_grid(), pitch=40)),
     ("occluded_images_sliver_fence_dense", lambda: scenes.add_slivers(scenes.image_grid(seed=54), pitch=17)),
@@ -177,6 +178,11 @@ OCCLUDED += [
 RUN_OVERFLOW = [
     ("sliver_fence_overflow", lambda: scenes.add_slivers(scenes.image_grid(), pitch=9)),
     ("sliver_fence_overflow_4", lambda: scenes.add_slivers(scenes.image_grid(), pitch=4)),
+    # > WR_MAX_OCC occluders on a strip (every image wider than 195 px sits behind 65+ slivers), > WR_MAX_RUNS runs on every row
+    ("sliver_fence_overflow_3", lambda: scenes.add_slivers(scenes.image_grid(seed=55), pitch=3)),
+    ("sliver_fence_overflow_gradients", lambda: scenes.add_slivers(scenes.gradient_grid(), pitch=3)),
+    ("sliver_fence_overflow_text", lambda: scenes.add_slivers(scenes.cfg3_text(width=1024, height=512, lines=24, glyphs_per_line=60), pitch=5, width=1)),
+    ("sliver_fence_overflow_rotated_images", lambda: scenes.add_slivers(scenes.rotated_images(), pitch=3)),
 ]
 # wrench/benchmarks/transforms-simple.yaml (the reference's own transform benchmark): both encodings
 ROTATED += [

@@ -272,12 +272,18 @@ def test_hip_flattened_depth_rows_match_oracle(name, make):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,make", RUN_OVERFLOW, ids=[c[0] for c in RUN_OVERFLOW])
-def test_hip_depth_run_overflow_is_reported(name, make):
-    """(see tests/test_hostsim_parity.py::test_hostsim_depth_run_overflow_is_reported)"""
+def test_hip_depth_run_overflow_is_exact(name, make, monkeypatch):
+    """(see tests/test_hostsim_parity.py::test_hostsim_depth_run_overflow_is_exact)"""
     ref = oracle_ref()
     if not ref:
         pytest.skip("oracle not built")
     want, _ = render_direct(ref, make())
+    got, stats = render_direct(wrhip_lib(), make())
+    assert np.array_equal(got, want) and stats["gl_error"] == 0
+    monkeypatch.setenv("WRHIP_NO_TILE_ROWS", "1")
+    got, stats = render_direct(wrhip_lib(), make())
+    assert np.array_equal(got, want) and stats["gl_error"] == 0
+    monkeypatch.setenv("WRHIP_RUNS_POOL_WORDS", "0")
     got, stats = render_direct(wrhip_lib(), make())
     assert np.array_equal(got, want) or stats["gl_error"] == 0x0502
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 4

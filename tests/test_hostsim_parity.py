@@ -224,10 +224,17 @@ def test_hostsim_flattened_depth_rows_match_oracle(hostsim, oracle_gcc, name, ma
 
 
 @pytest.mark.parametrize("name,make", RUN_OVERFLOW, ids=[c[0] for c in RUN_OVERFLOW])
-def test_hostsim_depth_run_overflow_is_reported(hostsim, oracle_gcc, name, make):
-    """A row with more depth runs (or a strip with more occluders) than the backend's tables hold is not reproduced exactly:
-    the frame is either identical to swgl's or the caller is told (GL_INVALID_OPERATION at Finish) -- never silently off."""
+def test_hostsim_depth_run_overflow_is_exact(hostsim, oracle_gcc, name, make, monkeypatch):
+    """A row with more depth runs (or a strip with more occluders) than the LDS copies hold keeps them in the flush's pool: the frame
+    is swgl's, through the bins and through the row kernel.  With the pool taken away (WRHIP_RUNS_POOL_WORDS=0: what an exhausted pool
+    looks like) the frame is either identical to swgl's or the caller is told (GL_INVALID_OPERATION at Finish) -- never silently off."""
     want, _ = render_direct(oracle_gcc, make())
+    got, stats = render_direct(hostsim, make())
+    assert np.array_equal(got, want) and stats["gl_error"] == 0
+    monkeypatch.setenv("WRHIP_NO_TILE_ROWS", "1")
+    got, stats = render_direct(hostsim, make())
+    assert np.array_equal(got, want) and stats["gl_error"] == 0
+    monkeypatch.setenv("WRHIP_RUNS_POOL_WORDS", "0")
     got, stats = render_direct(hostsim, make())
     assert np.array_equal(got, want) or stats["gl_error"] == 0x0502
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 4

@@ -110,8 +110,8 @@ def test_shipped_kernel_budgets(tmp_path):
         "wr_setup_raster_kernel<3, true, 4, 5>": (168, 1280), "wr_setup_raster_kernel<3, true, 4, 7>": (168, 1280),
         "wr_raster_dense_kernel<3, false, 4, 7>": (128, 640), "wr_raster_dense_kernel<3, true, 4, 7>": (128, 640),
         "wr_setup_raster_dense_kernel<3, false, 4, 7>": (128, 1536), "wr_setup_raster_dense_kernel<3, true, 4, 7>": (128, 1536),
-        "wr_setup_kernel": (168, 768), "wr_setup_rows_kernel": (128, 1024), "wr_mask_rows_kernel": (128, 64),
-        "wr_span_rows_kernel": (72, 192), "wr_tile_rows_kernel": (128, 512), "wr_setup_tile_rows_kernel": (128, 1088),
+        "wr_setup_kernel": (168, 640), "wr_setup_rows_kernel": (128, 1024), "wr_mask_rows_kernel": (128, 64),
+        "wr_span_rows_kernel": (72, 192), "wr_tile_rows_kernel": (128, 512), "wr_setup_tile_rows_kernel": (128, 1024),
     }
     missing = [n for n in budget if n not in k]
     assert not missing, missing

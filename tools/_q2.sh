@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/r05_q2
+(time timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | tail -8) > gpurun_out/r05_q2/gpu_tests.log 2>&1
+cat gpurun_out/r05_q2/gpu_tests.log
+B=webrender_amd/csrc/ab/libwrhip_base.so
+bash tools/ab_mix.sh r05_q2 "transforms many-images cfg3 aligned-gradient" "base:lib=$B" "new"
+bash tools/ab_mix.sh r05_q2 "clip-clear" "new" "new_bins:WRHIP_NO_TILE_ROWS=1"

@@ -584,6 +584,9 @@ struct Context {
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool span_rows = true;               // WRHIP_NO_SPAN_ROWS=1: cs_blur / cs_scale targets go through the bin raster like everything else
   bool tile_rows = true;               // WRHIP_NO_TILE_ROWS=1: picture targets of a few large gradient / image prims too
+  bool quad_rowtabs = true;            // WRHIP_NO_QTAB=1: no row tables of general quads (the raster stage sums every row's edge values itself)
+  size_t runs_pool_words = (size_t)16 << 20;   // WRHIP_RUNS_POOL_WORDS: the share of a flush's pool (WrTargetDesc::qtab) kept for depth runs / occluder
+                                       // lists that outgrow their LDS copies, 4-byte words (64 MB; 0: none -- such rows are then reported)
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
   int thin_parts = 4;                  // workgroups per bin of a thin launch (WRHIP_THIN_PARTS = 1, 2, 4, 8, 16): 16 / parts waves each, so that a wave shares its SIMD with fewer others
@@ -616,6 +619,8 @@ struct Context {
     mask_rows = getenv("WRHIP_NO_MASK_ROWS") == nullptr;
     span_rows = getenv("WRHIP_NO_SPAN_ROWS") == nullptr;
     tile_rows = getenv("WRHIP_NO_TILE_ROWS") == nullptr;
+    quad_rowtabs = getenv("WRHIP_NO_QTAB") == nullptr;
+    if (const char* e = getenv("WRHIP_RUNS_POOL_WORDS")) runs_pool_words = (size_t)atoll(e);
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
     dcounters = (WrUnsupportedCounters*)wrrt::dev_alloc(sizeof(WrUnsupportedCounters));
@@ -1596,7 +1601,9 @@ void flush_work(const std::vector<int>& sel_in) {
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0;
   size_t vtab_cursor = 0;
   size_t qtab_need = 0;        // floats: rows x instances x 10 of the draws that may hold rotated / projected prims (WR_DF_XFORM)
-  static const bool no_qtab = getenv("WRHIP_NO_QTAB") != nullptr;
+  const bool no_qtab = !c->quad_rowtabs;
+  const size_t runs_pool_words = c->runs_pool_words;
+  bool runs_pool = false;
   uint64_t algo_bytes = 0, pixels = 0;
   for (int oi = 0; oi < n_targets; oi++) {
     TargetWork& w = c->work[sel[oi]];
@@ -1690,6 +1697,9 @@ void flush_work(const std::vector<int>& sel_in) {
         const int rows = std::max(0, std::min(d.clip[3], t.height) - std::max(d.clip[1], 0));
         qtab_need += (size_t)rows * (size_t)d.count * 10;
       }
+      // (the same pool takes the depth runs of a row and the occluder list of a strip that outgrow their LDS copies: a draw that is
+      // depth-tested and may consume interpolants can ask for them)
+      if (T.format == WR_FMT_RGBA8 && (d.flags & WR_DF_DEPTH_TEST) && !(d.flags & WR_DF_SIMPLE) && d.shader != WR_SH_CLEAR_OP) runs_pool = true;
       draws.push_back(d);
     }
     T.end_prim = prim_cursor;
@@ -1782,16 +1792,16 @@ void flush_work(const std::vector<int>& sel_in) {
       wrrt::memset8(S.bin_ctr, 0, S.bin_ctr_cap * sizeof(unsigned), c->stream);      // (the workgroups leave them at zero)
     }
     // the pool the setup stage cuts general quads' row tables from: what the flush's WR_DF_XFORM draws could ask for, up to 64 MB
-    const size_t qtab_want = std::min<size_t>(qtab_need, (size_t)16 << 20);
+    const size_t qtab_want = std::min<size_t>(qtab_need, (size_t)16 << 20) + (runs_pool ? runs_pool_words : 0);
     if (S.qtab_cap < qtab_want) {
       sync_stream();
       wrrt::dev_free(S.qtab);
-      S.qtab_cap = qtab_want * 2;
+      S.qtab_cap = qtab_want + qtab_want / 4;
       S.qtab = (float*)wrrt::dev_alloc(S.qtab_cap * sizeof(float));
     }
     for (WrTargetDesc& T : targets) {
       T.grecs = (const WrGlyphRec*)(S.recs + S.prims_cap); T.bin_ctr = S.bin_ctr + T.first_bin;
-      T.qtab = qtab_want ? S.qtab : nullptr; T.qtab_cap = (uint32_t)std::min<size_t>(S.qtab_cap, (size_t)1 << 30); T.qtab_ctl = nullptr; T.qtab_pad = 0;
+      T.qtab = qtab_want ? S.qtab : nullptr; T.qtab_cap = (uint32_t)std::min<size_t>(S.qtab_cap, (size_t)1 << 30); T.qtab_ctl = nullptr; T.qtab_pad = no_qtab ? 1u : 0u;
     }
   }
   // Mask-row store.  When the bounds fit, no reservation of the setup stage can fail and the R8 launches take the light
@@ -2967,7 +2977,10 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     if (std::find(reads.begin(), reads.end(), tid) == reads.end()) reads.push_back(tid);
     unsigned rmask = (1u << WR_S_COLOR0) | (1u << WR_S_COLOR1) | (1u << WR_S_COLOR2) | (1u << WR_S_CLIP_MASK);
     if (info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA || info->kind == WR_SH_CS_SVG_FILTER || info->kind == WR_SH_CS_SVG_FILTER_NODE) rmask |= 1u << WR_S_GPU_CACHE;      // (component-transfer tables, read by main())
-    if (info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA) rmask |= 1u << WR_S_GPU_BUFFER_F;
+    // (gradient tables: the span shaders and main() of every gradient program read the stops where the frame builder put them)
+    if (info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA || info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT ||
+        info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT || info->kind == WR_SH_CS_LINEAR_GRADIENT || info->kind == WR_SH_CS_RADIAL_GRADIENT ||
+        info->kind == WR_SH_CS_CONIC_GRADIENT) rmask |= 1u << WR_S_GPU_BUFFER_F;
     if ((rmask >> s) & 1) {
       std::vector<GLuint>& rr = c->work[wi].rreads;
       if (std::find(rr.begin(), rr.end(), tid) == rr.end()) rr.push_back(tid);

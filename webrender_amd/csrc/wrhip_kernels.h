@@ -66,6 +66,14 @@ WR_DEVICE wr_u4 wr_load16(const void* p) {
   return r;
 }
 WR_DEVICE float wr_bits_f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+WR_DEVICE void wr_store16(float* p, float a, float b, float c, float d) {      // p: 16-byte aligned
+#ifdef WRHIP_HOSTSIM
+  p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#else
+  typedef float wr_f4 __attribute__((ext_vector_type(4)));
+  *(wr_f4*)p = wr_f4{a, b, c, d};
+#endif
+}
 
 // texelFetch(sampler2D RGBA32F, ivec2_scalar, 0), texture.h:283-292
 WR_DEVICE wf4 wr_fetch_f(const WrTexDesc& t, int x, int y) {
@@ -2370,6 +2378,25 @@ WR_DEVICE bool wr_persp_clipped_walk(WrQuadRec& Q, int& bx0, int& by0, int& bx1,
 WR_DEVICE const float* wr_quad_rowtab_entry(const WrQuadRec& Q, int y) {
   return (Q.rowtab && (unsigned)(y - Q.rowtab_y0) < (unsigned)Q.rowtab_rows) ? Q.rowtab + (size_t)(y - Q.rowtab_y0) * (size_t)Q.rowtab_stride : nullptr;
 }
+// `nwords` 4-byte words of the flush's pool (WrTargetDesc::qtab: row tables of general quads, and the depth runs / occluder lists that
+// outgrow their LDS copies); nullptr: none left (the caller reports what it then cannot draw exactly)
+WR_DEVICE int32_t* wr_pool_words(const WrTargetDesc& T, unsigned long long nwords) {
+  if (!T.qtab || !T.qtab_ctl) return nullptr;
+  nwords = (nwords + 3ull) & ~3ull;          // (every piece of the pool starts on 16 bytes)
+  const unsigned long long off = atomicAdd(T.qtab_ctl, nwords);
+  return off + nwords <= (unsigned long long)T.qtab_cap ? (int32_t*)(T.qtab + off) : nullptr;
+}
+// ... one allocation for the whole wave (every lane asks for the same words: the tile rows' sweeps are wave-uniform)
+WR_DEVICE int32_t* wr_pool_words_wave(const WrTargetDesc& T, unsigned long long nwords) {
+#ifdef WRHIP_HOSTSIM
+  return wr_pool_words(T, nwords);
+#else
+  unsigned long long a = 0;
+  if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) a = (unsigned long long)(uintptr_t)wr_pool_words(T, nwords);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return (int32_t*)(uintptr_t)((unsigned long long)lo | ((unsigned long long)hi << 32));
+#endif
+}
 WR_DEVICE void wr_quad_row_x(const WrQuadRec& Q, const WrQuadSeg& S, int y, float& xl, float& xr) {
   if (const float* e = wr_quad_rowtab_entry(Q, y)) { xl = e[0]; xr = e[1]; return; }
   xl = wr_accum(S.lx, S.ls, y - S.lrow); xr = wr_accum(S.rx, S.rs, y - S.rrow);
@@ -2380,17 +2407,15 @@ WR_DEVICE void wr_quad_row_x(const WrQuadRec& Q, const WrQuadSeg& S, int y, floa
 // full-size rotated rect 1448 rows x 16 lanes across x 2 values of a walk over binades each (wrench transforms-simple: 108 us of raster
 // for eleven such rects).  A prim whose table does not fit the flush's pool keeps the per-row sums.
 #define WR_QTAB_MIN_ROWS 16
-__device__ __noinline__ void wr_quad_build_rowtab(const WrTargetDesc* Tp, const WrPrim* Pp, WrQuadRec* Qp) {
+WR_DEVICE void wr_quad_build_rowtab(const WrTargetDesc* Tp, const WrPrim* Pp, WrQuadRec* Qp) {
   const WrTargetDesc& T = *Tp; const WrPrim& P = *Pp; WrQuadRec& Q = *Qp;
   Q.rowtab = nullptr; Q.rowtab_rows = 0; Q.rowtab_stride = 0; Q.rowtab_y0 = 0; Q.rowtab_pad = 0;
   const int rows = P.y1 - P.y0;
-  if (!T.qtab || !T.qtab_ctl || rows < WR_QTAB_MIN_ROWS || Q.nseg <= 0) return;
+  if (!T.qtab || !T.qtab_ctl || (T.qtab_pad & 1u) || rows < WR_QTAB_MIN_ROWS || Q.nseg <= 0) return;
   const bool zw = Q.pad != 0 || (P.kind == WR_PK_TEX_QUAD && Q.base_kind == WR_PK_MIX_BLEND);
   const int stride = zw ? 10 : (P.kind == WR_PK_TEX_QUAD ? 6 : 2);
-  const unsigned long long need = (unsigned long long)rows * (unsigned long long)stride;
-  const unsigned long long off = atomicAdd(T.qtab_ctl, need);
-  if (off + need > (unsigned long long)T.qtab_cap) return;
-  float* tab = T.qtab + off;
+  float* tab = (float*)wr_pool_words(T, (unsigned long long)rows * (unsigned long long)stride);
+  if (!tab) return;
   for (int i = 0; i < Q.nseg; i++) {          // (in order: where two runs hold a row, the later one is the one the raster stage picks)
     const WrQuadSeg& S = Q.seg[i];
     const int ya = wr_imax(S.row_a, P.y0), yb = wr_imin(S.row_b, P.y1);
@@ -2412,7 +2437,15 @@ __device__ __noinline__ void wr_quad_build_rowtab(const WrTargetDesc* Tp, const 
     const float lzs = stride >= 10 ? Q.persp.lzs[i] : 0.0f, rzs = stride >= 10 ? Q.persp.rzs[i] : 0.0f;
     float* __restrict__ e = tab + (size_t)(ya - P.y0) * (size_t)stride;
     if (stride == 2) {
-      for (int y = ya; y < yb; y++, e += 2) { e[0] = xl; e[1] = xr; xl = xl + ls; xr = xr + rs; }
+      // (two rows per 16-byte store where the pair is aligned: the one thread that walks a prim's rows is bound by the stores it may have in flight)
+      int y = ya;
+      if (((y - P.y0) & 1) && y < yb) { e[0] = xl; e[1] = xr; xl = xl + ls; xr = xr + rs; y++; e += 2; }
+      for (; y + 2 <= yb; y += 2, e += 4) {
+        const float xl1 = xl + ls, xr1 = xr + rs;
+        wr_store16(e, xl, xr, xl1, xr1);
+        xl = xl1 + ls; xr = xr1 + rs;
+      }
+      if (y < yb) { e[0] = xl; e[1] = xr; }
     } else {
       for (int y = ya; y < yb; y++, e += stride) {
         e[0] = xl; e[1] = xr; e[2] = lu; e[3] = lv; e[4] = ru; e[5] = rv;
@@ -2427,7 +2460,7 @@ __device__ __noinline__ void wr_quad_build_rowtab(const WrTargetDesc* Tp, const 
   Q.rowtab_y0 = P.y0; Q.rowtab_rows = rows; Q.rowtab_stride = stride;
   Q.rowtab = tab;
 #ifdef WRHIP_HOSTSIM
-  { static const bool dbg = getenv("WRHIP_DEBUG_QTAB") != nullptr; if (dbg) fprintf(stderr, "row table: kind %d rows %d stride %d at %llu of %u\n", (int)P.kind, rows, stride, off, T.qtab_cap); }
+  { static const bool dbg = getenv("WRHIP_DEBUG_QTAB") != nullptr; if (dbg) fprintf(stderr, "row table: kind %d rows %d stride %d at word %lld of %u\n", (int)P.kind, rows, stride, (long long)(tab - T.qtab), T.qtab_cap); }
 #endif
 }
 WR_DEVICE bool wr_quad_row_span(const WrQuadRec& Q, int y, int& s0, int& s1) {
@@ -3242,7 +3275,19 @@ struct WrTexRow {
   int srow;              // nearest-fast: clamped source row
 };
 
+WR_DEVICE int wr_run_s(const WrRuns* R, int i) { return R->ext ? R->ext[2 * i] : R->s[i]; }
+WR_DEVICE int wr_run_e(const WrRuns* R, int i) { return R->ext ? R->ext[2 * i + 1] : R->e[i]; }
 WR_DEVICE int wr_find_run(const WrRuns* R, int x) {
+  if (R->ext) {           // (sorted, disjoint: a bisection over the pool's pairs)
+    int lo = 0, hi = R->n - 1;
+    while (lo <= hi) {
+      const int m = (lo + hi) >> 1;
+      if (x < R->ext[2 * m]) hi = m - 1;
+      else if (x >= R->ext[2 * m + 1]) lo = m + 1;
+      else return m;
+    }
+    return -1;
+  }
   for (int i = 0; i < R->n; i++) if (x >= R->s[i] && x < R->e[i]) return i;
   return -1;
 }
@@ -3252,13 +3297,13 @@ WR_DEVICE int wr_find_run(const WrRuns* R, int x) {
 // whole chunks (DISPATCH_DRAW_SPAN) or one step_interp_inputs() per chunk run by main(), one more for a partial chunk,
 // then skip(skip - (4 - partial)).  All of them are `lane += interp_step * (steps * 0.25f)` with interp_step = step * 4.
 WR_DEVICE void wr_run_lanes(const WrRuns* R, int k, float L, float step, float xl, bool span_shader, float (&lane)[4]) {
-  const float start = float(R->s[0]) + 0.5f - xl;
+  const float start = float(wr_run_s(R, 0)) + 0.5f - xl;
   lane[0] = L + step * start;
 #pragma unroll
   for (int i = 1; i < 4; i++) lane[i] = lane[i - 1] + step;
   const float step4 = step * 4.0f;
   for (int j = 0; j < k; j++) {
-    const int n = R->e[j] - R->s[j], rem = n & 3, full = n >> 2;
+    const int n = wr_run_e(R, j) - wr_run_s(R, j), rem = n & 3, full = n >> 2;
     if (full) {
       if (span_shader) {
         const float ch = float(n & ~3) * 0.25f;
@@ -3273,7 +3318,7 @@ WR_DEVICE void wr_run_lanes(const WrRuns* R, int k, float L, float step, float x
 #pragma unroll
       for (int i = 0; i < 4; i++) lane[i] = lane[i] + step4 * 1.0f;
     }
-    const int skip = R->s[j + 1] - R->e[j];
+    const int skip = wr_run_s(R, j + 1) - wr_run_e(R, j);
     const float ch = float(skip - (rem ? 4 - rem : 0)) * 0.25f;
 #pragma unroll
     for (int i = 0; i < 4; i++) lane[i] = lane[i] + step4 * ch;
@@ -3292,7 +3337,7 @@ WR_DEVICE WrTexRow wr_tex_row_span(const WrPrim& P, const WrTexDesc& t, float Lu
   const bool shaded = P.kind == WR_PK_TEX_FS || P.kind == WR_PK_FILTER || P.kind == WR_PK_MIX_BLEND || P.kind == WR_PK_SVG_FILTER || P.kind == WR_PK_QUAD_MASK || P.kind == WR_PK_BORDER_SOLID || P.kind == WR_PK_BORDER_SEGMENT || P.kind == WR_PK_FAST_GRADIENT || P.kind == WR_PK_LINE_DECORATION || no_span || flat;   // no draw_span for this program/target: all main()
   const int k = runs ? wr_find_run(runs, x) : -1;
   if (k >= 0) {
-    r.x0 = runs->s[k]; r.len = runs->e[k] - runs->s[k];
+    r.x0 = wr_run_s(runs, k); r.len = wr_run_e(runs, k) - wr_run_s(runs, k);
     wr_run_lanes(runs, k, Lu, r.su, xl, !shaded, r.lu);
     wr_run_lanes(runs, k, Lv, r.sv, xl, !shaded, r.lv);
   } else {
@@ -4492,7 +4537,7 @@ __device__ __noinline__ unsigned long long wr_quad_row_pixel_rgba8(WrQuadRowS R,
   if (!aa) return HIT | wr_blend_rgba8(blend, dstp_, src, D);
   // the 4-pixel chunks DO_AA sees start at the span start -- with depth runs, at the start of the run holding x
   int cs = R.s0;
-  if (runs) { const int k = wr_find_run(runs, x); if (k >= 0) cs = runs->s[k]; }
+  if (runs) { const int k = wr_find_run(runs, x); if (k >= 0) cs = wr_run_s(runs, k); }
   const int n = x - cs, lane = n & 3, base = cs + (n & ~3);
   const float off = float(4 * (base - R.la1));
   const float dl = (R.lstart + float(R.la1 + lane) * R.lend) + (R.lend / 4.0f) * off;
@@ -4701,7 +4746,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     if (S.lmask) { const float dx = (-1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.ls * S.ls)); lstart = 128.0f + dx * (xl - 0.5f); lend = -dx; }
     if (S.rmask) { const float dx = (1.0f * 256.0f) * (1.0f / sqrtf(1.0f + S.rs * S.rs)); rstart = 128.0f + dx * (xr - 0.5f); rend = -dx; }
     int cs = la0;
-    if (runs) { const int k = wr_find_run(runs, x); if (k >= 0) cs = runs->s[k]; }
+    if (runs) { const int k = wr_find_run(runs, x); if (k >= 0) cs = wr_run_s(runs, k); }
     const int n = x - cs, lane = n & 3, base = cs + (n & ~3);
     const float off = float(4 * (base - la1));
     const float dl = (lstart + float(la1 + lane) * lend) + (lend / 4.0f) * off;
@@ -4716,7 +4761,7 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
   const bool flat = runs && runs->n < 0;      // a flattened depth row (WrTargetDesc::flat_rows): the whole span, chunk by chunk through main()
   if (runs && !flat) {        // the span the shader sees is the depth run holding x
     const int k = wr_find_run(runs, x);
-    if (k >= 0) { s0 = runs->s[k]; s1 = runs->e[k]; } else runs = nullptr;
+    if (k >= 0) { s0 = wr_run_s(runs, k); s1 = wr_run_e(runs, k); } else runs = nullptr;
   }
   WrPrim Pl = *Pp;
   Pl.kind = (int16_t)Q.base_kind;
@@ -4874,9 +4919,9 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float su = (Ru - Lu) * stepScale, sv = (Rv - Lv) * stepScale;
   const int kr = runs ? wr_find_run(runs, x) : -1;
-  const int X0 = kr >= 0 ? runs->s[kr] : P.x0;                    // start of the sub-span the span shader sees
-  const int len = kr >= 0 ? runs->e[kr] - X0 : P.x1 - P.x0;
-  const float start = float(kr >= 0 ? runs->s[0] : P.x0) + 0.5f - P.xl;
+  const int X0 = kr >= 0 ? wr_run_s(runs, kr) : P.x0;                    // start of the sub-span the span shader sees
+  const int len = kr >= 0 ? wr_run_e(runs, kr) - X0 : P.x1 - P.x0;
+  const float start = float(kr >= 0 ? wr_run_s(runs, 0) : P.x0) + 0.5f - P.xl;
   const float sdx = G.scale_dir[0], sdy = G.scale_dir[1];
   int span = len >= 4 ? (len & ~3) : 0;
   // init_interp (glsl.h:3084-3089)
@@ -7294,24 +7339,34 @@ WR_DEVICE bool wr_row_runs(const WrTargetDesc& T, const WrPrim* __restrict__ pri
   int nc = 0;
   for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi)) nc++; }
   if (nc == 0) return false;
-  // wr_sweep_runs over the candidates
-  int n = 0, pos = P.x0;
+  // wr_sweep_runs over the candidates (a second time into the pool when the row has more runs than R holds)
   const int b = P.x1;
-  bool overflow = false;
-  while (pos < b) {
-    int s0 = pos;
-    for (bool moved = true; moved;) {
-      moved = false;
-      for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi) && lo <= s0 && s0 < hi) { s0 = hi; moved = true; } }
+  auto sweep = [&](int32_t* ext) -> int {
+    int n = 0, pos = P.x0;
+    while (pos < b) {
+      int s0 = pos;
+      for (bool moved = true; moved;) {
+        moved = false;
+        for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi) && lo <= s0 && s0 < hi) { s0 = hi; moved = true; } }
+      }
+      if (s0 >= b) break;
+      int e = b;
+      for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi) && hi > lo && lo > s0 && lo < e) e = lo; }
+      if (ext) { ext[2 * n] = s0; ext[2 * n + 1] = e; }
+      else if (n < WR_MAX_RUNS) { R.s[n] = s0; R.e[n] = e; }
+      n++;
+      pos = e;
     }
-    if (s0 >= b) break;
-    int e = b;
-    for (int i = T.dw_first; i < end; i++) { int lo, hi; if (cand(i, lo, hi) && hi > lo && lo > s0 && lo < e) e = lo; }
-    if (n == WR_MAX_RUNS) { overflow = true; break; }
-    R.s[n] = s0; R.e[n] = e; n++;
-    pos = e;
+    return n;
+  };
+  R.ext = nullptr; R.pad = 0;
+  int n = sweep(nullptr);
+  if (n > WR_MAX_RUNS) {
+    int32_t* ext = wr_pool_words_wave(T, 2ull * (unsigned long long)n);
+    if (ext) { sweep(ext); R.ext = ext; }
+    else n = -2;                       // (the pool is exhausted: reported by the caller, drawn from the span start)
   }
-  R.n = overflow ? -2 : n;
+  R.n = n;
   return true;
 }
 __device__ __noinline__ uint32_t wr_tile_blend(int key, uint32_t dstp, uint32_t sbg, uint32_t sra, const WrDrawDesc* D, const uint32_t* bc) {
@@ -7588,9 +7643,8 @@ WR_DEVICE void wr_occ_interval(const WrRec* __restrict__ recs, const WrAux* __re
 }
 // phase 3 for one row: [a, b) minus the candidate intervals iv[c] = (lo, hi), c < nc
 template <typename IV>
-WR_DEVICE void wr_sweep_runs(WrRuns& R, int a, int b, int nc, IV iv) {
+WR_DEVICE int wr_sweep_into(WrRuns& R, int32_t* ext, int a, int b, int nc, IV iv) {
   int n = 0, pos = a;
-  bool overflow = false;
   while (pos < b) {
     int s = pos;
     for (bool moved = true; moved;) {
@@ -7600,33 +7654,57 @@ WR_DEVICE void wr_sweep_runs(WrRuns& R, int a, int b, int nc, IV iv) {
     if (s >= b) break;
     int e = b;
     for (int c = 0; c < nc; c++) { int lo, hi; iv(c, lo, hi); if (hi > lo && lo > s && lo < e) e = lo; }
-    if (n == WR_MAX_RUNS) { overflow = true; break; }
-    R.s[n] = s; R.e[n] = e; n++;
+    if (ext) { ext[2 * n] = s; ext[2 * n + 1] = e; }
+    else if (n < WR_MAX_RUNS) { R.s[n] = s; R.e[n] = e; }
+    n++;
     pos = e;
   }
-  R.n = overflow ? -2 : n;          // (-2: more runs than WrRuns holds; the caller reports it and falls back to the span start)
+  return n;
+}
+// (a row with more runs than WrRuns holds inline is swept a second time, into the pool; n == -2: the pool is exhausted -- the caller
+// reports it and falls back to the span start)
+template <typename IV>
+WR_DEVICE void wr_sweep_runs(const WrTargetDesc& T, WrRuns& R, int a, int b, int nc, IV iv) {
+  R.ext = nullptr; R.pad = 0;
+  int n = wr_sweep_into(R, nullptr, a, b, nc, iv);
+  if (n > WR_MAX_RUNS) {
+    int32_t* ext = wr_pool_words(T, 2ull * (unsigned long long)n);
+    if (ext) { wr_sweep_into(R, ext, a, b, nc, iv); R.ext = ext; }
+    else n = -2;
+  }
+  R.n = n;
 }
 // The same for a target that continues from a materialised depth buffer (a flush in the middle of the target: the prims
 // that wrote it are gone): pixel by pixel, a pixel passes when it passes against the loaded depth AND no candidate of this
 // flush covers it.  A foreign call pattern (WebRender never flushes mid-target with depth live); kept simple, not fast.
 template <typename IV>
-WR_DEVICE void wr_scan_runs(WrRuns& R, int a, int b, int nc, IV iv, const uint32_t* __restrict__ drow, uint32_t z, bool less) {
-  int n = 0, x = a;
-  bool overflow = false;
+WR_DEVICE void wr_scan_runs(const WrTargetDesc& T, WrRuns& R, int a, int b, int nc, IV iv, const uint32_t* __restrict__ drow, uint32_t z, bool less) {
   auto pass = [&](int px) {
     if (!(less ? z < drow[px] : z <= drow[px])) return false;
     for (int c = 0; c < nc; c++) { int lo, hi; iv(c, lo, hi); if (lo <= px && px < hi) return false; }
     return true;
   };
-  while (x < b) {
-    while (x < b && !pass(x)) x++;
-    if (x >= b) break;
-    const int s0 = x;
-    while (x < b && pass(x)) x++;
-    if (n == WR_MAX_RUNS) { overflow = true; break; }
-    R.s[n] = s0; R.e[n] = x; n++;
+  auto scan = [&](int32_t* ext) -> int {
+    int n = 0, x = a;
+    while (x < b) {
+      while (x < b && !pass(x)) x++;
+      if (x >= b) break;
+      const int s0 = x;
+      while (x < b && pass(x)) x++;
+      if (ext) { ext[2 * n] = s0; ext[2 * n + 1] = x; }
+      else if (n < WR_MAX_RUNS) { R.s[n] = s0; R.e[n] = x; }
+      n++;
+    }
+    return n;
+  };
+  R.ext = nullptr; R.pad = 0;
+  int n = scan(nullptr);
+  if (n > WR_MAX_RUNS) {
+    int32_t* ext = wr_pool_words(T, 2ull * (unsigned long long)n);
+    if (ext) { scan(ext); R.ext = ext; }
+    else n = -2;                       // (the pool is exhausted: the caller reports it and falls back to the span start)
   }
-  R.n = overflow ? -2 : n;          // (-2: more runs than WrRuns holds; the caller reports it and falls back to the span start)
+  R.n = n;
 }
 template <int R4>
 WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, int pidx,
@@ -7640,37 +7718,46 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
   const bool loaded = T.load_depth && T.depth;       // continuation of a target whose depth was materialised
 #ifdef WRHIP_HOSTSIM
   // serial restatement: this thread does the whole wave's work for its own rows
-  static int cidx[WR_MAX_OCC];
+  static int cidx_lds[WR_MAX_OCC];
   static WrRuns runs[4 * R4];
+  const int* cidx = cidx_lds;
   int nc = 0;
-  for (int i = T.dw_first; i < end; i++) {
-    const WrRec Rc = recs[i];
-    const int ok = Rc.kbf & 0xFF, of = (Rc.kbf >> 16) & 0xFF;
-    if (!(of & WR_PF_DEPTH_WRITE) || ok == WR_PK_NONE || ok == WR_PK_UNSUPPORTED || ok == WR_PK_CLEAR) continue;
-    if (!(less ? Rc.z <= z : Rc.z < z)) continue;
-    if (Rc.x0 >= x1 || Rc.x1 <= x0 || Rc.y0 >= ry1 || Rc.y1 <= ry0) continue;
-    if (nc < WR_MAX_OCC) cidx[nc] = i;
-    nc++;
-  }
+  auto scan = [&](int* list, int cap) {
+    nc = 0;
+    for (int i = T.dw_first; i < end; i++) {
+      const WrRec Rc = recs[i];
+      const int ok = Rc.kbf & 0xFF, of = (Rc.kbf >> 16) & 0xFF;
+      if (!(of & WR_PF_DEPTH_WRITE) || ok == WR_PK_NONE || ok == WR_PK_UNSUPPORTED || ok == WR_PK_CLEAR) continue;
+      if (!(less ? Rc.z <= z : Rc.z < z)) continue;
+      if (Rc.x0 >= x1 || Rc.x1 <= x0 || Rc.y0 >= ry1 || Rc.y1 <= ry0) continue;
+      if (nc < cap) list[nc] = i;
+      nc++;
+    }
+  };
+  scan(cidx_lds, WR_MAX_OCC);
   bool anyflat = false;
   if (T.flat_rows) for (int y = ry0; y < ry1; y++) if (T.flat_rows[y] < (uint32_t)pidx) anyflat = true;
   if (nc == 0 && !loaded && !anyflat) return nullptr;
-  if (nc > WR_MAX_OCC) {          // more occluders than the list holds: evaluated from the span start, as if unoccluded -- and reported
-    if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u);
-    if (!anyflat) return nullptr;
-    nc = 0;
+  if (nc > WR_MAX_OCC) {          // more occluders than the LDS list holds: the list goes to the pool (a second scan fills it)
+    int* big = wr_pool_words(T, (unsigned long long)nc);
+    if (big) { scan(big, nc); cidx = big; }
+    else {                        // (the pool is exhausted: evaluated from the span start, as if unoccluded -- and reported)
+      if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u);
+      if (!anyflat) return nullptr;
+      nc = 0;
+    }
   }
   for (int j = 0; j < R4; j++) {
     const int r = (lane >> 4) + 4 * j, y = wy0 + r;
     WrRuns& RR = runs[r];
-    RR.n = 0;
+    RR.n = 0; RR.ext = nullptr; RR.pad = 0;
     if (y < ry0 || y >= ry1) continue;
     if (T.flat_rows && T.flat_rows[y] < (uint32_t)pidx) { RR.n = -1; continue; }
     int a = x0, b = x1;
     if (quad) { int s0, s1; if (!wr_quad_row_span(aux[pidx].quad, y, s0, s1)) continue; a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
     auto iv = [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, cidx[c], y, lo, hi); };
-    if (loaded) wr_scan_runs(RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
-    else wr_sweep_runs(RR, a, b, nc, iv);
+    if (loaded) wr_scan_runs(T, RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
+    else wr_sweep_runs(T, RR, a, b, nc, iv);
     if (RR.n == -2) { RR.n = 0; if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u); }
   }
   return runs;
@@ -7679,6 +7766,7 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
   __shared__ short ivs[4][WR_MAX_OCC][4 * R4][2];
   __shared__ WrRuns runs[4][4 * R4];
   int nc = 0;
+  int* ext = nullptr;               // a strip with more candidates than the wave's LDS list holds: its list in the pool (second scan)
   auto test = [&](int i, bool in) {
     bool hit = false;
     if (in) {
@@ -7691,10 +7779,13 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
     const unsigned long long m = __ballot(hit);
     if (hit) {
       const int slot = nc + __popcll(m & ((1ull << lane) - 1ull));
-      if (slot < WR_MAX_OCC) cidx[wave][slot] = i;
+      if (ext) ext[slot] = i;
+      else if (slot < WR_MAX_OCC) cidx[wave][slot] = i;
     }
     nc += __popcll(m);
   };
+  auto scan_all = [&]() {
+  nc = 0;
   if (bin_words && x0 >= bin_x0 && x1 <= bin_x0 + WR_BIN_W && end - T.dw_first > 256) {
     // A prim that lies inside this bin's columns: every depth writer that can cut its rows touches the bin too, so the
     // candidates are among the bin's own mask words (intact until the workgroup's last wave is done) -- a handful of words
@@ -7714,36 +7805,51 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
   } else {
     for (int b = T.dw_first; b < end; b += 64) test(b + lane, b + lane < end);
   }
+  };
+  scan_all();
   // rows of the strip that an earlier perspective prim has flattened (lane r looks at strip row r)
   bool myflat = false;
   if (T.flat_rows && lane < 4 * R4 && wy0 + lane >= ry0 && wy0 + lane < ry1) myflat = T.flat_rows[wy0 + lane] < (uint32_t)pidx;
   const bool anyflat = __ballot(myflat) != 0ull;
   if (nc == 0 && !loaded && !anyflat) return nullptr;
-  if (nc > WR_MAX_OCC) {          // more occluders than the list holds: evaluated from the span start, as if unoccluded -- and reported
-    if (lane == 0 && T.counters) atomicAdd(&T.counters->unsupported_prims, 1u);
-    if (!anyflat) return nullptr;
-    nc = 0;
+  bool big = false;                 // the candidates sit in the pool and their intervals are taken from the records as the sweeps ask for them
+  if (nc > WR_MAX_OCC) {          // more occluders than the LDS list holds: the list goes to the pool, a second scan fills it
+    ext = wr_pool_words_wave(T, (unsigned long long)nc);
+    if (ext) {
+      big = true;
+      scan_all();
+    } else {                        // (the pool is exhausted: evaluated from the span start, as if unoccluded -- and reported)
+      if (lane == 0 && T.counters) atomicAdd(&T.counters->unsupported_prims, 1u);
+      if (!anyflat) return nullptr;
+      nc = 0;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int idx = lane; idx < nc * 4 * R4; idx += 64) {
-    const int c = idx / (4 * R4), r = idx - c * (4 * R4);
-    int lo, hi;
-    wr_occ_interval(recs, aux, cidx[wave][c], wy0 + r, lo, hi);
-    ivs[wave][c][r][0] = (short)lo; ivs[wave][c][r][1] = (short)hi;
+  if (!big) {
+    for (int idx = lane; idx < nc * 4 * R4; idx += 64) {
+      const int c = idx / (4 * R4), r = idx - c * (4 * R4);
+      int lo, hi;
+      wr_occ_interval(recs, aux, cidx[wave][c], wy0 + r, lo, hi);
+      ivs[wave][c][r][0] = (short)lo; ivs[wave][c][r][1] = (short)hi;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane < 4 * R4) {
     const int r = lane, y = wy0 + r;
     WrRuns& RR = runs[wave][r];
-    RR.n = 0;
+    RR.n = 0; RR.ext = nullptr; RR.pad = 0;
     if (myflat) RR.n = -1;
     else if (y >= ry0 && y < ry1) {
       int a = x0, b = x1;
       bool ok = true;
       if (quad) { int s0, s1; ok = wr_quad_row_span(aux[pidx].quad, y, s0, s1); a = wr_imax(s0, x0); b = wr_imin(s1, x1); }
       auto iv = [&](int c, int& lo, int& hi) { lo = ivs[wave][c][r][0]; hi = ivs[wave][c][r][1]; };
-      if (ok && loaded) wr_scan_runs(RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
-      else if (ok) wr_sweep_runs(RR, a, b, nc, iv);
+      auto iv_big = [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, ext[c], y, lo, hi); };
+      if (!ok) {}
+      else if (big && loaded) wr_scan_runs(T, RR, a, b, nc, iv_big, T.depth + (size_t)y * T.width, z, less);
+      else if (big) wr_sweep_runs(T, RR, a, b, nc, iv_big);
+      else if (loaded) wr_scan_runs(T, RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
+      else wr_sweep_runs(T, RR, a, b, nc, iv);
       if (RR.n == -2) { RR.n = 0; if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u); }
     }
   }
@@ -8262,7 +8368,7 @@ WR_DEVICE void wr_apply_prim(uint32_t (&plo)[4 * R], uint32_t (&phi)[4 * R], uin
       }
       if (!in) continue;
       int cs = x0;             // start of the 4-pixel chunks: the span start, or the start of the depth run holding the pixel
-      if (rr) { const WrRuns* rq = &rr[py + 4 * (q >> 2) - wy0]; const int k = wr_find_run(rq, px + (q & 3)); if (k >= 0) cs = rq->s[k]; }
+      if (rr) { const WrRuns* rq = &rr[py + 4 * (q >> 2) - wy0]; const int k = wr_find_run(rq, px + (q & 3)); if (k >= 0) cs = wr_run_s(rq, k); }
       const uint32_t r = wr_aa_pixel_rgba8(&A, D, blend, c0, c1, px + (q & 3) - cs, cs, plo[q] | (phi[q] << 8));
       plo[q] = r & WR_M8; phi[q] = (r >> 8) & WR_M8;
     }

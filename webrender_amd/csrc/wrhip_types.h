@@ -236,7 +236,7 @@ struct WrTargetDesc {
   float* qtab;
   unsigned long long* qtab_ctl;
   uint32_t qtab_cap;                           // floats
-  uint32_t qtab_pad;
+  uint32_t qtab_pad;                           // bit 0: no row tables (WRHIP_NO_QTAB: the pool then only takes what the depth runs spill)
 };
 
 // Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
@@ -583,10 +583,13 @@ struct WrQuadRec {
 // span shader one sub-span per maximal run of pixels that pass the test -- the 4-pixel chunk phase, the span / main()
 // split and the filter decisions restart at every run start, and the interpolants reach run k through the chain of
 // step_interp_inputs() calls of runs 0 .. k-1.  Built per (wave, prim) by the raster stage from the rects of the earlier
-// depth-writing prims that can hide part of the row (wr_build_runs); n == 0: nothing to restart (or more runs than fit).
+// depth-writing prims that can hide part of the row (wr_build_runs); n == 0: nothing to restart.  Neither the runs of a row nor the
+// occluders of a strip are bounded by these constants: they size the LDS / register copies, what exceeds them lives in the pool.
 #define WR_MAX_RUNS 16
 #define WR_MAX_OCC 64
-struct WrRuns { int32_t n; int32_t s[WR_MAX_RUNS], e[WR_MAX_RUNS]; };
+// `ext`: a row with more runs than the inline arrays hold keeps them as (s, e) pairs in the flush's pool (WrTargetDesc::qtab, cut by
+// wr_pool_words) -- n counts them all then; readers go through wr_run_s / wr_run_e.  n == -1: a flattened depth row.
+struct WrRuns { int32_t n; int32_t pad; const int32_t* ext; int32_t s[WR_MAX_RUNS], e[WR_MAX_RUNS]; };
 
 // per-prim side record, written by the setup kernel for the kinds that need one
 union WrAux {
