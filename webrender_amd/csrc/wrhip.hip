@@ -584,6 +584,9 @@ struct Context {
   bool mask_rows = true;               // WRHIP_NO_MASK_ROWS=1: cs_clip_* prims are evaluated inside the bin raster
   bool span_rows = true;               // WRHIP_NO_SPAN_ROWS=1: cs_blur / cs_scale targets go through the bin raster like everything else
   bool tile_rows = true;               // WRHIP_NO_TILE_ROWS=1: picture targets of a few large gradient / image prims too
+  bool grad_tables = true;             // WRHIP_NO_GTAB=1: gradient tables are not copied into the pool (the raster stage reads sGpuBufferF, and an upload
+                                       // of that texture waits for the held-back launches that do)
+  size_t gtab_pending = 0;             // words promised to recorded, not yet flushed gradient draws (WR_DF_GTAB)
   bool quad_rowtabs = true;            // WRHIP_NO_QTAB=1: no row tables of general quads (the raster stage sums every row's edge values itself)
   size_t runs_pool_words = (size_t)16 << 20;   // WRHIP_RUNS_POOL_WORDS: the share of a flush's pool (WrTargetDesc::qtab) kept for depth runs / occluder
                                        // lists that outgrow their LDS copies, 4-byte words (64 MB; 0: none -- such rows are then reported)
@@ -620,6 +623,7 @@ struct Context {
     span_rows = getenv("WRHIP_NO_SPAN_ROWS") == nullptr;
     tile_rows = getenv("WRHIP_NO_TILE_ROWS") == nullptr;
     quad_rowtabs = getenv("WRHIP_NO_QTAB") == nullptr;
+    grad_tables = getenv("WRHIP_NO_GTAB") == nullptr;
     if (const char* e = getenv("WRHIP_RUNS_POOL_WORDS")) runs_pool_words = (size_t)atoll(e);
     wrrt::event_create(&ev_a); wrrt::event_create(&ev_b);
     memset(&stats, 0, sizeof(stats));
@@ -1504,6 +1508,7 @@ void flush_work(const std::vector<int>& sel_in) {
   Context* c = ctx;
   if (!c || c->work.empty() || sel_in.empty()) return;
   HostTimer ht(&c->stats.host_flush_ns);
+  c->gtab_pending = 0;
   std::vector<int> sel(sel_in);
   std::sort(sel.begin(), sel.end());
   sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
@@ -1600,6 +1605,8 @@ void flush_work(const std::vector<int>& sel_in) {
   size_t inst_bytes = 0;
   int prim_cursor = 0, bin_cursor = 0, word_cursor = 0;
   size_t vtab_cursor = 0;
+  size_t gtab_words = 0;       // the pool's fixed head: the gradient-table copies of the WR_DF_GTAB draws (WrDrawDesc::gtab_base); the setup stage's
+                               // allocations start behind it
   size_t qtab_need = 0;        // floats: rows x instances x 10 of the draws that may hold rotated / projected prims (WR_DF_XFORM)
   const bool no_qtab = !c->quad_rowtabs;
   const size_t runs_pool_words = c->runs_pool_words;
@@ -1682,6 +1689,8 @@ void flush_work(const std::vector<int>& sel_in) {
       }
       prim_cursor += d.count;
       // per-row v table budget for draws whose prims can take the nearest-fast texture path
+      d.gtab_base = -1;
+      if (d.flags & WR_DF_GTAB) { d.gtab_base = (int)gtab_words; gtab_words += (size_t)d.count * WR_GTAB_WORDS; }
       d.vtab_base = -1; d.vtab_rows = 0;
       if (T.format == WR_FMT_RGBA8 && !(d.flags & WR_DF_SIMPLE) &&
           (d.shader == WR_SH_COMPOSITE || d.shader == WR_SH_COMPOSITE_FAST || d.shader == WR_SH_CS_SCALE ||
@@ -1792,7 +1801,7 @@ void flush_work(const std::vector<int>& sel_in) {
       wrrt::memset8(S.bin_ctr, 0, S.bin_ctr_cap * sizeof(unsigned), c->stream);      // (the workgroups leave them at zero)
     }
     // the pool the setup stage cuts general quads' row tables from: what the flush's WR_DF_XFORM draws could ask for, up to 64 MB
-    const size_t qtab_want = std::min<size_t>(qtab_need, (size_t)16 << 20) + (runs_pool ? runs_pool_words : 0);
+    const size_t qtab_want = gtab_words + std::min<size_t>(qtab_need, (size_t)16 << 20) + (runs_pool ? runs_pool_words : 0);
     if (S.qtab_cap < qtab_want) {
       sync_stream();
       wrrt::dev_free(S.qtab);
@@ -1861,6 +1870,7 @@ void flush_work(const std::vector<int>& sel_in) {
     size_t aoff = staging_alloc(total);
     uint8_t* h = c->staging + aoff;
     memset(h + off_qctl, 0, 64);
+    *(unsigned long long*)(h + off_qctl) = (unsigned long long)gtab_words;      // (WR_GTAB_WORDS is a multiple of 4: the pieces behind stay on 16 bytes)
     for (WrTargetDesc& T : targets) T.qtab_ctl = T.qtab ? (unsigned long long*)(c->dupload + aoff + off_qctl) : nullptr;
     if (nd) stage_copy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     stage_copy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
@@ -1940,6 +1950,15 @@ void flush_work(const std::vector<int>& sel_in) {
           int best_rows = 0;
           for (size_t hi = 0; hi < c->tail.held.size(); hi++)
             if (c->tail.held[hi].mr_rows > best_rows) { best_rows = c->tail.held[hi].mr_rows; fuse_at = (int)hi; }
+          // (... else the largest tile-rows launch: a wave per row piece of a few heavy prims, the long launch of such a flush -- behind
+          // the short rect pass of the same flush a setup stage would stick out)
+          if (fuse_at < 0) {
+            int best_items = 0;
+            for (size_t hi = 0; hi < c->tail.held.size(); hi++) {
+              const Context::Held& Hh = c->tail.held[hi];
+              if (Hh.row_n > 0 && Hh.row_mode == 2 && Hh.row_items > best_items && can_fuse(Hh)) { best_items = Hh.row_items; fuse_at = (int)hi; }
+            }
+          }
           for (size_t hi = 0; hi < c->tail.held.size() && fuse_at < 0; hi++) if (can_fuse(c->tail.held[hi])) fuse_at = (int)hi;
         }
       if (fuse_at >= 0) {
@@ -2959,6 +2978,13 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
       c->work[wi].level = std::max(c->work[wi].level, c->work[t->pending_target].level + 1);
   }
   Texture& colortex = c->textures[color_id];
+  const bool grad_prog = info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA || info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT ||
+                         info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT || info->kind == WR_SH_CS_LINEAR_GRADIENT || info->kind == WR_SH_CS_RADIAL_GRADIENT ||
+                         info->kind == WR_SH_CS_CONIC_GRADIENT;
+  // a table copy per instance (WR_GTAB_WORDS words): promised here, where the raster stage's reads are booked, for draws of up to 256
+  // gradients while the promises of the pending flush stay under 256 MB
+  const bool gtab = grad_prog && c->grad_tables && instancecount <= 256 && c->gtab_pending + (size_t)instancecount * WR_GTAB_WORDS <= ((size_t)64 << 20);
+  if (gtab) c->gtab_pending += (size_t)instancecount * WR_GTAB_WORDS;
   for (int s = 0; s < WR_MAX_TEX; s++) {
     if (!((info->samplers >> s) & 1)) continue;
     GLuint tid = bound_tex(s);
@@ -2977,10 +3003,9 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     if (std::find(reads.begin(), reads.end(), tid) == reads.end()) reads.push_back(tid);
     unsigned rmask = (1u << WR_S_COLOR0) | (1u << WR_S_COLOR1) | (1u << WR_S_COLOR2) | (1u << WR_S_CLIP_MASK);
     if (info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA || info->kind == WR_SH_CS_SVG_FILTER || info->kind == WR_SH_CS_SVG_FILTER_NODE) rmask |= 1u << WR_S_GPU_CACHE;      // (component-transfer tables, read by main())
-    // (gradient tables: the span shaders and main() of every gradient program read the stops where the frame builder put them)
-    if (info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA || info->kind == WR_SH_PS_QUAD_RADIAL_GRADIENT ||
-        info->kind == WR_SH_PS_QUAD_CONIC_GRADIENT || info->kind == WR_SH_CS_LINEAR_GRADIENT || info->kind == WR_SH_CS_RADIAL_GRADIENT ||
-        info->kind == WR_SH_CS_CONIC_GRADIENT) rmask |= 1u << WR_S_GPU_BUFFER_F;
+    // (gradient tables: the span shaders and main() of every gradient program read the stops where the frame builder put them --
+    // unless the setup stage copies them into the flush's pool for this draw, WR_DF_GTAB)
+    if (grad_prog && !gtab) rmask |= 1u << WR_S_GPU_BUFFER_F;
     if ((rmask >> s) & 1) {
       std::vector<GLuint>& rr = c->work[wi].rreads;
       if (std::find(rr.begin(), rr.end(), tid) == rr.end()) rr.push_back(tid);
@@ -2998,7 +3023,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
             c->blendfunc_sa, c->blendfunc_da, c->blend_equation);
     c->last_error = GL_INVALID_OPERATION;
   }
-  d.flags = info->rect ? WR_DF_TEX_RECT : 0;
+  d.flags = (info->rect ? WR_DF_TEX_RECT : 0) | (gtab ? WR_DF_GTAB : 0);
   Texture* depthtex = (c->depthtest && fb.depth_attachment) ? c->textures.find(fb.depth_attachment) : nullptr;
   if (depthtex && depthtex->internal_format == GL_DEPTH_COMPONENT24 && depthtex->depth_cleared) {
     d.flags |= WR_DF_DEPTH_TEST;

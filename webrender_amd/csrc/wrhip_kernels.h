@@ -320,6 +320,71 @@ WR_DEVICE void wr_pack_color(wf4 c, uint32_t out[2]) {
 // (WrGradRec::merge).  Eight entries' steps are requested per round trip: the setup stage is one dependent chain per wave.
 // (eight entries per trip: with sixteen in flight every kernel that carries the setup stage spilled 1.8 KB more per lane; NOT out of
 // line -- a callee is compiled to its own register budget and the kernels that call it inherit its count: 128 -> 356 VGPRs)
+// The gradient table of one prim, copied into the flush's pool the way main() fetches it (gradient.glsl:42-61: entry i = texels
+// (u, v) and (u + 1, v) of address + 2 i) -- with the copy the raster stage does not read sGpuBufferF at all, so the next frame's
+// upload of that texture need not wait for this frame's tile pass (the held-back launches keep carrying the next setup stage:
+// wrench aligned- / unaligned-gradient).  One entry per trip: the setup stage's register budget (see wr_grad_merge_bits).
+WR_DEVICE void wr_grad_copy_table(const WrDrawDesc& d, const WrTargetDesc& T, int inst, WrGradRec* G) {
+  G->table = nullptr;
+  if (!(d.flags & WR_DF_GTAB) || d.gtab_base < 0 || !T.qtab) return;
+  float* dst = T.qtab + (size_t)d.gtab_base + (size_t)inst * WR_GTAB_WORDS;
+  const WrTexDesc& gb = d.tex[WR_S_GPU_BUFFER_F];
+  const int address = G->address;
+#pragma nounroll
+  for (int i = 0; i < 130; i++) {
+    const int addr = address + 2 * i;
+    const int u = int(unsigned(addr) % 1024u), v = int(unsigned(addr) / 1024u);
+    const wf4 t0 = wr_fetch_f(gb, u, v), t1 = wr_fetch_f(gb, u + 1, v);
+    wr_store16(dst + 8 * i, t0.x, t0.y, t0.z, t0.w);
+    wr_store16(dst + 8 * i + 4, t1.x, t1.y, t1.z, t1.w);
+  }
+  G->table = dst;
+  if (G->stops) G->stops = dst;
+}
+// ... for the gradient prims of one wave of the setup stage, `G` = this lane's record or nullptr.  On the device the wave shares out
+// the 130 entries of every table (one thread copying 130 entries fetches them one after the other: 45 us on top of a 35 us setup
+// stage, measured); the host simulation copies serially.
+WR_DEVICE void wr_grad_tables_wave(const WrDrawDesc* __restrict__ draws, const WrTargetDesc* __restrict__ targets, int draw, int gid, WrGradRec* G) {
+#ifdef WRHIP_HOSTSIM
+  if (G) { const WrDrawDesc& d = draws[draw]; wr_grad_copy_table(d, targets[d.target], gid - d.first_prim, G); }
+#else
+  const int lane = threadIdx.x & 63;
+  bool want = false;
+  unsigned long long dsta = 0ull;
+  int address = 0;
+  if (G) {
+    G->table = nullptr;
+    const WrDrawDesc& d = draws[draw];
+    const WrTargetDesc& T = targets[d.target];
+    if ((d.flags & WR_DF_GTAB) && d.gtab_base >= 0 && T.qtab) {
+      want = true;
+      dsta = (unsigned long long)(uintptr_t)(T.qtab + (size_t)d.gtab_base + (size_t)(gid - d.first_prim) * WR_GTAB_WORDS);
+      address = G->address;
+    }
+  }
+  for (unsigned long long m = __ballot(want); m; m &= m - 1ull) {
+    const int src = __builtin_ctzll(m);
+    const int sdraw = __builtin_amdgcn_readlane(draw, src), saddr = __builtin_amdgcn_readlane(address, src);
+    const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dsta, src), phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dsta >> 32), src);
+    float* dst = (float*)(uintptr_t)((unsigned long long)plo | ((unsigned long long)phi << 32));
+    const WrTexDesc& gb = draws[sdraw].tex[WR_S_GPU_BUFFER_F];
+    for (int i = lane; i < 130; i += 64) {
+      const int addr = saddr + 2 * i;
+      const int u = int(unsigned(addr) % 1024u), v = int(unsigned(addr) / 1024u);
+      const wf4 t0 = wr_fetch_f(gb, u, v), t1 = wr_fetch_f(gb, u + 1, v);
+      wr_store16(dst + 8 * i, t0.x, t0.y, t0.z, t0.w);
+      wr_store16(dst + 8 * i + 4, t1.x, t1.y, t1.z, t1.w);
+    }
+  }
+  // (the owners read their tables next -- wr_grad_merge_bits -- : other lanes' stores first)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (want) {
+    float* dst = (float*)(uintptr_t)dsta;
+    G->table = dst;
+    if (G->stops) G->stops = dst;
+  }
+#endif
+}
 WR_DEVICE void wr_grad_merge_bits(WrGradRec* G) {
   const float* stops = G->stops;
   uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;      // (in registers: the record lives in HBM)
@@ -4323,8 +4388,7 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
     }
     // gradient tables' can_merge bitmap (WrGradRec::merge): here, ONCE, after the vertex stage's registers are dead (at its four
     // call sites inside the vertex stages it cost every kernel that carries the setup stage 2 KB of scratch per lane)
-    if (P.kind == WR_PK_GRADIENT) wr_grad_merge_bits(&aux[gid].grad);
-    else if (P.kind == WR_PK_TEX_QUAD && aux[gid].quad.base_kind == WR_PK_GRADIENT) wr_grad_merge_bits(&aux[gid].quad.grad);
+    // (gradient prims: table copy and merge bitmap after this block, where the wave is whole again)
     if (P.kind == WR_PK_TEX_R8) {
       aux[gid].tex = wr_make_texrec(P, draws[P.draw].tex[P.tex_slot]);
       wr_write_glyph_rec(targets[draws[P.draw].target], gid, P, aux[gid].tex);
@@ -4365,6 +4429,16 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
         aux[gid].tex.simple = 0;
       }
     }
+  }
+  {
+    // gradient tables: copied into the flush's pool (wave-wide: wr_grad_tables_wave), then the can_merge bitmap (WrGradRec::merge) -- here, ONCE,
+    // after the vertex stage's registers are dead (at its four call sites inside the vertex stages it cost every kernel that carries
+    // the setup stage 2 KB of scratch per lane)
+    WrGradRec* Gq = nullptr;
+    if (valid && P.kind == WR_PK_GRADIENT) Gq = &aux[gid].grad;
+    else if (valid && P.kind == WR_PK_TEX_QUAD && aux[gid].quad.base_kind == WR_PK_GRADIENT) Gq = &aux[gid].quad.grad;
+    wr_grad_tables_wave(draws, targets, P.draw, gid, Gq);
+    if (Gq) wr_grad_merge_bits(Gq);
   }
 #ifdef WRHIP_TIMING
   const unsigned long long tm2 = wall_clock64();
@@ -5193,8 +5267,12 @@ __device__ __noinline__ WrGrad4 wr_gradient_row4(const WrPrim* Pp, const WrGradR
       const float xe = wr_clamp(1.0f + offset * 128.0f, 0.0f, 1.0f + 128.0f);
       const float ei = floorf(xe), ef = xe - ei;
       const int addr = G.address + 2 * int(ei);
-      const wf4 t0 = wr_fetch_f(gb, int(unsigned(addr) % 1024u), int(unsigned(addr) / 1024u));
-      const wf4 t1 = wr_fetch_f(gb, int(unsigned(addr) % 1024u) + 1, int(unsigned(addr) / 1024u));
+      wf4 t0, t1;
+      if (G.table) { const float* te = G.table + 8 * int(ei); t0 = wf4{te[0], te[1], te[2], te[3]}; t1 = wf4{te[4], te[5], te[6], te[7]}; }
+      else {
+        t0 = wr_fetch_f(gb, int(unsigned(addr) % 1024u), int(unsigned(addr) / 1024u));
+        t1 = wr_fetch_f(gb, int(unsigned(addr) % 1024u) + 1, int(unsigned(addr) / 1024u));
+      }
       uint32_t pc[2];
       wr_pack_color(wf4{t0.x + t1.x * ef, t0.y + t1.y * ef, t0.z + t1.z * ef, t0.w + t1.w * ef}, pc);
       out.v[X0 + n - x].bg = pc[0]; out.v[X0 + n - x].ra = pc[1];
@@ -5229,8 +5307,12 @@ __device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDra
   const float xe = wr_clamp(1.0f + offset * 128.0f, 0.0f, 1.0f + 128.0f);
   const float ei = floorf(xe), ef = xe - ei;
   const int addr = G.address + 2 * int(ei);
-  const wf4 t0 = wr_fetch_f(gb, int(unsigned(addr) % 1024u), int(unsigned(addr) / 1024u));
-  const wf4 t1 = wr_fetch_f(gb, int(unsigned(addr) % 1024u) + 1, int(unsigned(addr) / 1024u));
+  wf4 t0, t1;
+  if (G.table) { const float* te = G.table + 8 * int(ei); t0 = wf4{te[0], te[1], te[2], te[3]}; t1 = wf4{te[4], te[5], te[6], te[7]}; }
+  else {
+    t0 = wr_fetch_f(gb, int(unsigned(addr) % 1024u), int(unsigned(addr) / 1024u));
+    t1 = wr_fetch_f(gb, int(unsigned(addr) % 1024u) + 1, int(unsigned(addr) / 1024u));
+  }
   uint32_t pc[2];
   wr_pack_color(wf4{t0.x + t1.x * ef, t0.y + t1.y * ef, t0.z + t1.z * ef, t0.w + t1.w * ef}, pc);
   WrWide w; w.bg = pc[0]; w.ra = pc[1];

@@ -153,7 +153,10 @@ enum WrDrawFlags {
   WR_DF_SIMPLE = 32,       // host promise: every prim of this draw is a solid with blend NONE/PREMULT (see WrFeat)
   WR_DF_TEX_RECT = 512,    // the program is a TEXTURE_RECT key: sColor0-2 are sampler2DRect (WrTexDesc::sw / sh = 1)
   WR_DF_XFORM = 256,       // host: the transform ids this draw's prims can reference include non-axis-aligned ones (rotations, perspective)
+  WR_DF_GTAB = 1024,       // host: the gradient tables of this draw's prims are copied into the flush's pool by the setup stage
+                           // (WrDrawDesc::gtab_base) -- the raster stage then never reads sGpuBufferF for them
 };
+#define WR_GTAB_WORDS 1040        /* 130 entries x (start, step) x 4 floats */
 
 struct WrDrawDesc {
   int32_t shader;        // WrShader
@@ -177,7 +180,7 @@ struct WrDrawDesc {
   int32_t vtab_base;     // first entry of this draw's per-row v table (-1: none), vtab_rows entries per instance
   int32_t vtab_rows;
   int32_t query_slot;    // GL_SAMPLES_PASSED query active around this draw: slot of WrUnsupportedCounters::samples (-1: none)
-  int32_t pad_q;
+  int32_t gtab_base;     // WR_DF_GTAB: first word of this draw's gradient-table copies in the pool (WrTargetDesc::qtab), WR_GTAB_WORDS per instance; -1: none
   uint32_t attr_u16;     // bit k: attribute k is made of 16-bit unsigned integers (VertexAttributeKind::U16) // bytes provided by the VAO for that attribute (VertexAttrib::size)
   WrTexDesc tex[WR_MAX_TEX];
 };
@@ -446,6 +449,8 @@ struct WrAARec {
 struct WrGradRec {
   const float* stops;       // swgl_validateGradient: first float of the 130 x (start, step) table in sGpuBufferF,
                             // or nullptr (no span shader: every pixel runs main())
+  const float* table;       // the setup stage's copy of the table as main() fetches it (entry i: texels (u, v), (u + 1, v) of address + 2 i),
+                            // or nullptr (main() fetches from sGpuBufferF); where stops != nullptr it is the same memory
   int32_t address;          // v_gradient_address.x
   float repeat;             // v_gradient_repeat.x
   float scale_dir[2];       // v_scale_dir
