@@ -547,6 +547,16 @@ PIPELINED = [
     lambda: scenes.cfg3_text(width=1024, height=1024, lines=30, glyphs_per_line=60, run_len=12),
     lambda: scenes.masked_rects(fractional=True),
     lambda: scenes.cfg2_overlapping_rects(width=1024, height=1024, n=250, seed=43, encoding="brush"),
+    # round 5, the flush's pool across frames: gradient tables copied by the setup stage while the previous frame's held-back launches
+    # still read THEIR copies (two gradient frames in a row with different tables at the same GPU-buffer addresses), row tables of
+    # rotated prims, depth runs that outgrow the LDS tables
+    lambda: scenes.gradient_grid(seed=62),
+    lambda: scenes.gradient_grid(rotate=True, seed=66),
+    lambda: scenes.quad_gradients(),
+    lambda: scenes.rotated_rects(opaque_frac=0.3),
+    lambda: scenes.add_slivers(scenes.image_grid(seed=55), pitch=3),
+    lambda: scenes.rotated_images(),
+    lambda: scenes.gradient_grid(seed=63),
 ]
 
 

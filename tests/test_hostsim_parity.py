@@ -335,6 +335,11 @@ def test_pipelined_frames_match_isolated_frames(hostsim, oracle_gcc):
         lambda: scenes.image_grid(width=512, height=512, n=40),
         lambda: scenes.gradient_grid(width=512, height=512, n=20),
         lambda: scenes.cfg2_overlapping_rects(width=512, height=512, n=50, seed=42),
+        # (round 5: the flush's pool across frames -- gradient-table copies, row tables of rotated prims)
+        lambda: scenes.gradient_grid(width=512, height=512, n=20, seed=62),
+        lambda: scenes.gradient_grid(width=512, height=512, n=20, rotate=True, seed=66),
+        lambda: scenes.rotated_rects(width=512, height=512, n=30, opaque_frac=0.3),
+        lambda: scenes.gradient_grid(width=512, height=512, n=20, seed=63),
     ]
     got = render_pipelined(hostsim, [m() for m in makes])
     for i, (g, m) in enumerate(zip(got, makes)):
