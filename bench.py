@@ -81,6 +81,8 @@ def kernel_label(k):
         return "wr_setup_tile_rows_kernel"
     if k.kind == 12:     # thin launches: the R = 1 instantiation (64 x 4 pixels per wave, several workgroups per bin)
         return f"wr_raster_kernel<{k.fmt}, false, 1, {k.feat}>"
+    if k.kind == 13:     # ... with the next flush's setup stage in front
+        return f"wr_setup_raster_thin_kernel<{k.fmt}, false, 1, {k.feat}>"
     return f"wr_raster_kernel<{k.fmt}, {'true' if k.depth else 'false'}, 4, {k.feat}>"
 
 

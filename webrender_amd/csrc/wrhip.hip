@@ -1203,7 +1203,7 @@ void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint6
   for (WrhipKernelStat& e : c->kstats) if (e.kind == kind && e.fmt == fmt && e.depth == depth && e.feat == feat) k = &e;
   if (!k) { c->kstats.push_back(WrhipKernelStat{kind, fmt, depth, feat, 0, 0, 0, 0}); k = &c->kstats.back(); }
   k->launches++; k->ns += ns; k->algo_bytes += algo_bytes; k->workgroups += workgroups;
-  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9 || kind == 10 || kind == 11 || kind == 12) c->stats.raster_ns += ns;
+  if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9 || kind == 10 || kind == 11 || kind == 12 || kind == 13) c->stats.raster_ns += ns;
 }
 
 void tail_launched() {
@@ -1223,8 +1223,10 @@ bool can_fuse(const Context::Held& H) {
   if (H.mr_rows > 0) return true;          // (the mask-rows launch ahead of an R8 raster launch: wr_setup_rows_kernel)
   // a small textured colour launch is worth more as a THIN launch (four workgroups per bin: a quarter of the rows per wave, four
   // times the waves) than as the carrier of the setup stage: transforms-simple, 256 bins of eleven rotated rects, 241 us fused
+  // (round 5, later: the thin launch carries it itself -- wr_setup_raster_thin_kernel; WRHIP_NO_FUSE_THIN=1: it leaves without)
   static const bool thin_first = getenv("WRHIP_FUSE_SMALL") == nullptr;
-  if (thin_first && ctx->thin_r8 && H.fmt == WR_FMT_RGBA8 && !H.depth && H.nb <= WR_THIN_MAX_BINS && H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC)) return false;
+  static const bool fuse_thin = getenv("WRHIP_NO_FUSE_THIN") == nullptr;
+  if (thin_first && ctx->thin_r8 && H.fmt == WR_FMT_RGBA8 && !H.depth && H.nb <= WR_THIN_MAX_BINS && H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC)) return fuse_thin;
   return H.fmt == WR_FMT_RGBA8 && (H.feat == 0 || H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC) ||
                                    H.feat == (WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX));
 }
@@ -1327,6 +1329,12 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     if (H.depth) WR_KD(true); else WR_KD(false);
 #undef WR_KD
   }
+  else if (SA && H.fmt == WR_FMT_RGBA8 && !H.depth && c->thin_r8 && H.nb <= WR_THIN_MAX_BINS && H.feat == F5 && getenv("WRHIP_FUSE_SMALL") == nullptr) {
+    // the thin colour launch with the next flush's setup stage in front (can_fuse)
+    thin_wgs = (uint64_t)H.nb * 4 + (uint64_t)n_setup_blocks;
+    WR_LAUNCH((wr_setup_raster_thin_kernel<WR_FMT_RGBA8, false, 1, WR_FEAT_TEX | WR_FEAT_GENERIC>), n_setup_blocks + H.nb * 4, 256, c->stream, *SA,
+              n_setup_blocks, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);
+  }
   else if (SA) {
     if (H.depth) {
       if (H.feat == 0) WR_KF(true, 0); else if (H.feat == F5) WR_KF(true, WR_FEAT_TEX | WR_FEAT_GENERIC);
@@ -1377,7 +1385,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
 #undef WR_K
 #undef WR_KF
   // (5: wr_raster_dense_kernel; 6 / 7: the same two with the next flush's setup stage in front, wr_setup_raster[_dense]_kernel)
-  prof_end(thin_wgs ? 12 : fused ? (H.dense ? 7 : 6) : (H.dense ? 5 : 2), H.fmt, H.depth, H.feat, H.algo_bytes + (fused ? setup_bytes : 0),
+  prof_end(thin_wgs ? (fused ? 13 : 12) : fused ? (H.dense ? 7 : 6) : (H.dense ? 5 : 2), H.fmt, H.depth, H.feat, H.algo_bytes + (fused ? setup_bytes : 0),
            thin_wgs ? thin_wgs : (uint64_t)H.nb + (fused ? n_setup_blocks : 0));
   c->stats.kernel_launches++; c->stats.raster_launches++;
 }

@@ -24,5 +24,7 @@
   X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_R8, false, 4, 28)
 // (thin colour launches: picture blur / down-scale chains into RGBA8 targets of a few bins, 256-thread workgroups, four per bin)
 #define WR_INST_7(X) X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_RGBA8, false, 1, 5) X(wr_raster_kernel, WR_SIG_PLAIN, WR_FMT_RGBA8, false, 1, 47)
-#define WR_INST_ALL(X) WR_INST_1(X) WR_INST_2(X) WR_INST_3(X) WR_INST_4(X) WR_INST_5(X) WR_INST_6(X) WR_INST_7(X)
-#define WR_INST_GROUPS 7
+// (... and the thin colour launch that carries the next flush's setup stage)
+#define WR_INST_8(X) X(wr_setup_raster_thin_kernel, WR_SIG_FUSED, WR_FMT_RGBA8, false, 1, 5)
+#define WR_INST_ALL(X) WR_INST_1(X) WR_INST_2(X) WR_INST_3(X) WR_INST_4(X) WR_INST_5(X) WR_INST_6(X) WR_INST_7(X) WR_INST_8(X)
+#define WR_INST_GROUPS 8

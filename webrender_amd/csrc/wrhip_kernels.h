@@ -9592,6 +9592,25 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
   wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks,
                                       (int)blockIdx.x - n_setup_blocks + bin_offset);
 }
+// ... and for a THIN colour launch (<= 256 bins, four 256-thread workgroups of 64 x 4 pixel strips per bin: see wr_raster_kernel's R == 1
+// entry) -- wrench transforms-simple: 35 us of setup stage in line with 79 us of raster every frame, because the small launch was worth
+// more thin than as the carrier of the setup stage in its 64 x 16 shape (241 us).  Here it is both.
+template <int FMT, bool DEPTH, int R, int FEAT>
+__global__ void __launch_bounds__(256, WR_TEX_WAVES)
+wr_setup_raster_thin_kernel(WrSetupArgs S, int n_setup_blocks,
+                            const WrTargetDesc* __restrict__ targets, int n_targets,
+                            const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
+                            const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
+                            unsigned long long* __restrict__ masks, int bin_offset) {
+  static_assert(R == 1 && FMT == WR_FMT_RGBA8 && !DEPTH, "the thin colour shape");
+  if ((int)blockIdx.x < n_setup_blocks) {
+    WR_SETUP_PRIO();
+    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
+    return;
+  }
+  const int b = (int)blockIdx.x - n_setup_blocks;
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, b / 4 + bin_offset, b % 4, 4);
+}
 // Text launches: the glyph walk is latency-bound (cfg3: per-lane record + atlas fetches), a fourth wave per SIMD pays for the handful
 // of values a 128-VGPR build spills (tile pass 139 -> 128 us, 5.45 k -> 5.7-5.9 k frames/s; profiles/r03_e_ring_w4_ab.txt).  The
 // same 128-VGPR build costs the OTHER users of this variant -- masked solids (cfg4's tile pass 22.5 -> 29 us), perspective images
