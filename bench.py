@@ -224,7 +224,18 @@ def main():
         # (value: the window assembled on rank 0, the presenting GPU -- SURVEY section 8e's "gather to the presenting GPU"; the
         # all-gather variant, every rank ending up with the whole window, is timed alongside: at 8K it moves 132 MB per frame
         # into EVERY GPU, which bounds it near 0.4 k frames/s whatever the raster rate)
-        player = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="root", native="rccl")
+        # (the native loop owns its RCCL communicator; if it cannot be opened -- librccl not where torch keeps it, a symbol missing --
+        # every rank gets the same refusal and takes the torch.distributed loop the native one is tested against: slower per frame
+        # (Python per frame), same pixels; the line says which transport ran)
+        transport = os.environ.get("WRHIP_BENCH_TRANSPORT", "rccl")
+        def open_sharded(gather):
+            if transport == "rccl":
+                try:
+                    return ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather=gather, native="rccl"), "native loop, RCCL"
+                except RuntimeError as e:
+                    print(f"bench: native sharded loop unavailable on rank {rank} ({e}); torch.distributed loop instead", file=sys.stderr)
+            return ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather=gather, native=None), "torch.distributed loop (fallback)"
+        player, transport_used = open_sharded("root")
         frame_w, frame_h = player.width, player.height
         rec = None
     else:
@@ -274,7 +285,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         del player
-        root = ShardedFramePlayer(lib, args.workload, args.encoding, rank, world, gather="all", native="rccl")
+        root, _ = open_sharded("all")
         root.frames(args.warmup, 0)
         rr = []
         for _ in range(3):
@@ -285,7 +296,7 @@ def main():
             rr.append(time.perf_counter() - t0)
         t = torch.tensor(rr, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        multi = {"rccl_ranks": world, "collective": "window strips to rank 0, the presenting GPU (value): grouped ncclSend / ncclRecv on the backend's stream, "
+        multi = {"rccl_ranks": world, "transport": transport_used, "collective": "window strips to rank 0, the presenting GPU (value): grouped ncclSend / ncclRecv on the backend's stream, "
                                                     "in place between the ranks' windows, per-frame loop in native code (csrc/wr_replay.c wr_shard_stream); every rank to every rank alongside",
                  "all_gather": {"value": round(args.steps / float(np.median(t.tolist())), 2), "unit": "frames/s"},
                  "window_bytes_per_frame": int(root.height * root.row_bytes), "per_rank": per_rank}
