@@ -1315,6 +1315,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   prof_begin();
   uint64_t thin_wgs = 0;                 // a thin launch (R = 1 instantiation): its workgroups; reported as kind 12 (not mixed into the R = 4 rows)
   const bool fused = SA != nullptr;      // (SA still set: this raster launch carries the next flush's setup stage)
+  static const bool thin_carrier = getenv("WRHIP_FUSE_SMALL") == nullptr;      // (can_fuse's thin_first)
   if (H.dense && H.fmt == WR_FMT_RGBA8 && H.feat == F7) {
     // (glyph levels: the 128-VGPR instantiation of the same body, plain or with the next flush's setup stage in front)
 #define WR_KD(DEPTH)                                                                                                         \
@@ -1329,7 +1330,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     if (H.depth) WR_KD(true); else WR_KD(false);
 #undef WR_KD
   }
-  else if (SA && H.fmt == WR_FMT_RGBA8 && !H.depth && c->thin_r8 && H.nb <= WR_THIN_MAX_BINS && H.feat == F5 && getenv("WRHIP_FUSE_SMALL") == nullptr) {
+  else if (SA && H.fmt == WR_FMT_RGBA8 && !H.depth && c->thin_r8 && H.nb <= WR_THIN_MAX_BINS && H.feat == F5 && thin_carrier) {
     // the thin colour launch with the next flush's setup stage in front (can_fuse)
     thin_wgs = (uint64_t)H.nb * 4 + (uint64_t)n_setup_blocks;
     WR_LAUNCH((wr_setup_raster_thin_kernel<WR_FMT_RGBA8, false, 1, WR_FEAT_TEX | WR_FEAT_GENERIC>), n_setup_blocks + H.nb * 4, 256, c->stream, *SA,
