@@ -4316,6 +4316,72 @@ WR_DEVICE bool wr_box_keys_equal(const WrBoxKey& a, const WrBoxKey& b) {
          a.os23 == b.os23 && a.mv_mul == b.mv_mul && a.mv_div == b.mv_div && a.in_mul == b.in_mul && a.in_div == b.in_div;
 }
 
+// Rows of the flush's mask-row store for the mask prims of one wave of the setup stage (T == nullptr: this lane has none).  The store's
+// allocation word packs slots << 48 | rows << 28 | bytes / 16 and is advanced by compare-and-swap so that a request that does not fit
+// is refused whole.  Lane by lane that is one round trip to the word per PRIM, one after the other -- every lane of every wave of the
+// flush contends for the one address, and the lanes of a wave retry in lockstep: 44 corner masks of a rounded clip cost the setup
+// stage ~50 us (wrench clip-clear, large-clip-rect).  Here the wave adds its requests up (prefix sums over the requesting lanes, in
+// lane order: slots stay sorted by first row), the first requesting lane swaps ONCE for all of them, and every lane takes its share;
+// only when the wave's total does not fit do the lanes ask one by one for what still does.
+WR_DEVICE void wr_mask_rows_take(const WrTargetDesc& T, unsigned long long ns, unsigned long long nr, unsigned long long nb, uint32_t pitch,
+                                 const WrBoxKey& key, int gid, int target, WrRec* __restrict__ recs) {
+  WrMaskSlot sl;
+  sl.prim = gid; sl.target = target; sl.row0 = uint32_t(nr); sl.pitch = pitch; sl.off16 = uint32_t(nb);
+  sl.pad[0] = 1u; sl.pad[1] = sl.pad[2] = 0;          // (pad[0]: waves sharing a row -- measured on cfg4's 1840-pixel rows: 2 or 4 lose, 99 -> 138 us)
+  sl.key = key;
+  T.mr_slots[ns] = sl;
+  const unsigned long long addr = (unsigned long long)(T.mr_store + nb * 16);
+  recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_MASK_ROWS;
+  recs[gid].c0 = uint32_t(addr); recs[gid].c1 = uint32_t(addr >> 32); recs[gid].z = pitch;
+}
+// one request, swapped in on its own; false: it does not fit
+WR_DEVICE bool wr_mask_rows_cas(const WrTargetDesc& T, unsigned long long slots, unsigned long long rows, unsigned long long n16, unsigned long long& base) {
+  unsigned long long old = *(volatile unsigned long long*)T.mr_ctl;
+  for (;;) {
+    const unsigned long long ns = old >> 48, nr = (old >> 28) & 0xFFFFFull, nb = old & 0xFFFFFFFull;
+    if (ns + slots > T.mr_max_slots || nr + rows > WR_MR_MAX_ROWS || nb + n16 > T.mr_cap16) return false;
+    const unsigned long long want = ((ns + slots) << 48) | ((nr + rows) << 28) | (nb + n16);
+    const unsigned long long seen = atomicCAS(T.mr_ctl, old, want);
+    if (seen == old) { base = old; return true; }
+    old = seen;
+  }
+}
+WR_DEVICE void wr_mask_rows_reserve(const WrTargetDesc* T, uint32_t rows, uint32_t pitch, unsigned long long n16, const WrBoxKey& key,
+                                    int gid, int target, WrRec* __restrict__ recs) {
+#ifndef WRHIP_HOSTSIM
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = __ballot(T != nullptr);
+  if (!m) return;
+  // (the control block is the flush's, one for all its R8 targets: any requesting lane's descriptor names it)
+  uint32_t pre_slots = 0, pre_rows = 0, tot_slots = 0, tot_rows = 0;
+  unsigned long long pre_n16 = 0, tot_n16 = 0;
+  for (unsigned long long mm = m; mm; mm &= mm - 1ull) {
+    const int i = __builtin_ctzll(mm);
+    const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)rows, i);
+    const unsigned long long ni = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)n16, i) |
+                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(n16 >> 32), i) << 32);
+    if (lane == i) { pre_slots = tot_slots; pre_rows = tot_rows; pre_n16 = tot_n16; }
+    tot_slots += 1u; tot_rows += ri; tot_n16 += ni;
+  }
+  const int lead = __builtin_ctzll(m);
+  unsigned long long base = 0ull;
+  int ok = 0;
+  if (lane == lead) ok = wr_mask_rows_cas(*T, tot_slots, tot_rows, tot_n16, base) ? 1 : 0;
+  ok = __builtin_amdgcn_readlane(ok, lead);
+  if (ok) {
+    const unsigned long long b = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, lead) |
+                                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), lead) << 32);
+    if (T) wr_mask_rows_take(*T, (b >> 48) + pre_slots, ((b >> 28) & 0xFFFFFull) + pre_rows, (b & 0xFFFFFFFull) + pre_n16, pitch, key, gid, target, recs);
+    return;
+  }
+#endif
+  // (the host simulation's one thread at a time; a wave whose requests do not fit together)
+  if (T) {
+    unsigned long long base;
+    if (wr_mask_rows_cas(*T, 1, rows, n16, base)) wr_mask_rows_take(*T, base >> 48, (base >> 28) & 0xFFFFFull, base & 0xFFFFFFFull, pitch, key, gid, target, recs);
+  }
+}
+
 // Vertex stage + binning, one thread per instance.
 WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
                                 const uint8_t* __restrict__ arena, WrPrim* __restrict__ prims,
@@ -4337,6 +4403,11 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
   const unsigned long long tm1 = wall_clock64();
   if (dbg_mode == 2) { if (valid && P.x0 == 12345678) prims[gid] = P; return; }
 #endif
+  const WrTargetDesc* mr_T = nullptr;        // a mask prim's request for rows of the flush's mask-row store (below)
+  uint32_t mr_rows = 0, mr_pitch = 0;
+  unsigned long long mr_n16 = 0;
+  WrBoxKey mr_key;
+  mr_key.valid = 0;
   if (valid) {
     // The 32-byte record is all the bin raster reads of a prim that folded into `new = hi_bytes(dst * K + C)` (or was culled): its
     // 128-byte WrPrim stays unwritten -- 80 % of what the setup stage stored for a frame of plain rects (cfg5: 41 -> 9 MB).  The row
@@ -4346,43 +4417,20 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
     recs[gid] = rec_;
     if (T_.rows_mode || ((rec_.kbf & 0xFF) != WR_PK_SOLID_FOLDED && (rec_.kbf & 0xFF) != WR_PK_NONE)) prims[gid] = P;
     if ((P.kind == WR_PK_BOX_SHADOW || P.kind == WR_PK_CLIP_RECT) && (draws[P.draw].flags & WR_DF_MASK_ROWS) && P.x1 > P.x0 && P.y1 > P.y0) {
-      // reserve this prim's rows in the flush's mask-row store (WrMaskSlot); a prim that does not fit keeps its in-raster evaluation
+      // this prim wants its rows in the flush's mask-row store (WrMaskSlot): the request here, the reservation after this block, once per
+      // WAVE (wr_mask_rows_reserve); a prim that does not fit keeps its in-raster evaluation
       const WrTargetDesc& T = targets[draws[P.draw].target];
       if (T.mr_ctl) {
-        const uint32_t rows = uint32_t(P.y1 - P.y0), pitch = uint32_t(((P.x1 + 3) & ~3) - (P.x0 & ~3));
+        mr_T = &T;
+        mr_rows = uint32_t(P.y1 - P.y0); mr_pitch = uint32_t(((P.x1 + 3) & ~3) - (P.x0 & ~3));
         // [row map: rows x u32, padded to 16 B][rows x pitch bytes]
-        const unsigned long long map16 = ((unsigned long long)rows * 4 + 15) >> 4;
-        const unsigned long long n16 = map16 + (((unsigned long long)rows * pitch + 15) >> 4);
-        // (the middle row's key BEFORE the reservation loop: inside it the lanes of a wave succeed one at a time, and whatever the
-        // successful branch does runs once per prim, serially -- nine box shadows of one target took nine key evaluations in a row)
-        WrBoxKey key;
-        key.valid = 0;
+        const unsigned long long map16 = ((unsigned long long)mr_rows * 4 + 15) >> 4;
+        mr_n16 = map16 + (((unsigned long long)mr_rows * mr_pitch + 15) >> 4);
+        // (the middle row's key of a box shadow: what the rows kernel compares every row's key with)
         if (P.kind == WR_PK_BOX_SHADOW) {
-          const int yc = P.y0 + (int(rows) >> 1);
+          const int yc = P.y0 + (int(mr_rows) >> 1);
           const WrRowVals rvc = wr_box_row_vals(P, aux[gid].box, yc);
-          key = wr_box_row_key(P, aux[gid].box, rvc, wr_box_row_setup(P, aux[gid].box, rvc));
-        }
-        unsigned long long old = *(volatile unsigned long long*)T.mr_ctl;
-        for (;;) {
-          const unsigned long long ns = old >> 48, nr = (old >> 28) & 0xFFFFFull, nb = old & 0xFFFFFFFull;
-          // wide rows are shared by several waves (a row is one dependent chain of texel fetches otherwise): work items = rows x parts
-          // (measured on cfg4's 1840-pixel rows: 2 or 4 waves per row lose -- every item pays the row setup again, 99 -> 138 us)
-          const uint32_t parts = 1u;
-          if (ns + 1 > T.mr_max_slots || nr + rows * parts > WR_MR_MAX_ROWS || nb + n16 > T.mr_cap16) break;
-          const unsigned long long want = ((ns + 1) << 48) | ((nr + rows * parts) << 28) | (nb + n16);
-          const unsigned long long seen = atomicCAS(T.mr_ctl, old, want);
-          if (seen == old) {
-            WrMaskSlot sl;
-            sl.prim = gid; sl.target = draws[P.draw].target; sl.row0 = uint32_t(nr); sl.pitch = pitch; sl.off16 = uint32_t(nb);
-            sl.pad[0] = parts; sl.pad[1] = sl.pad[2] = 0;
-            sl.key = key;
-            T.mr_slots[ns] = sl;
-            const unsigned long long addr = (unsigned long long)(T.mr_store + nb * 16);
-            recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_MASK_ROWS;
-            recs[gid].c0 = uint32_t(addr); recs[gid].c1 = uint32_t(addr >> 32); recs[gid].z = pitch;
-            break;
-          }
-          old = seen;
+          mr_key = wr_box_row_key(P, aux[gid].box, rvc, wr_box_row_setup(P, aux[gid].box, rvc));
         }
       }
     }
@@ -4430,6 +4478,7 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
       }
     }
   }
+  wr_mask_rows_reserve(mr_T, mr_rows, mr_pitch, mr_n16, mr_key, gid, draws[P.draw].target, recs);
   {
     // gradient tables: copied into the flush's pool (wave-wide: wr_grad_tables_wave), then the can_merge bitmap (WrGradRec::merge) -- here, ONCE,
     // after the vertex stage's registers are dead (at its four call sites inside the vertex stages it cost every kernel that carries
