@@ -1618,6 +1618,7 @@ void flush_work(const std::vector<int>& sel_in) {
                                // allocations start behind it
   size_t qtab_need = 0;        // floats: rows x instances x 10 of the draws that may hold rotated / projected prims (WR_DF_XFORM)
   const bool no_qtab = !c->quad_rowtabs;
+  static const bool no_run_share = getenv("WRHIP_NO_RUN_SHARE") != nullptr;
   const size_t runs_pool_words = c->runs_pool_words;
   bool runs_pool = false;
   uint64_t algo_bytes = 0, pixels = 0;
@@ -1819,7 +1820,7 @@ void flush_work(const std::vector<int>& sel_in) {
     }
     for (WrTargetDesc& T : targets) {
       T.grecs = (const WrGlyphRec*)(S.recs + S.prims_cap); T.bin_ctr = S.bin_ctr + T.first_bin;
-      T.qtab = qtab_want ? S.qtab : nullptr; T.qtab_cap = (uint32_t)std::min<size_t>(S.qtab_cap, (size_t)1 << 30); T.qtab_ctl = nullptr; T.qtab_pad = no_qtab ? 1u : 0u;
+      T.qtab = qtab_want ? S.qtab : nullptr; T.qtab_cap = (uint32_t)std::min<size_t>(S.qtab_cap, (size_t)1 << 30); T.qtab_ctl = nullptr; T.qtab_pad = (no_qtab ? 1u : 0u) | (no_run_share ? 2u : 0u);
     }
   }
   // Mask-row store.  When the bounds fit, no reservation of the setup stage can fail and the R8 launches take the light

@@ -7794,16 +7794,19 @@ WR_DEVICE int wr_sweep_into(WrRuns& R, int32_t* ext, int a, int b, int nc, IV iv
 }
 // (a row with more runs than WrRuns holds inline is swept a second time, into the pool; n == -2: the pool is exhausted -- the caller
 // reports it and falls back to the span start)
+// (`fill` false: a longer row is left at its count, R.n > WR_MAX_RUNS with R.ext == nullptr, for wr_sweep_fill -- the bins' rows, which
+// first look whether a neighbouring row of the strip has the same runs)
 template <typename IV>
-WR_DEVICE void wr_sweep_runs(const WrTargetDesc& T, WrRuns& R, int a, int b, int nc, IV iv) {
+WR_DEVICE void wr_sweep_fill(const WrTargetDesc& T, WrRuns& R, int a, int b, int nc, IV iv) {
+  int32_t* ext = wr_pool_words(T, 2ull * (unsigned long long)R.n);
+  if (ext) { wr_sweep_into(R, ext, a, b, nc, iv); R.ext = ext; }
+  else R.n = -2;
+}
+template <typename IV>
+WR_DEVICE void wr_sweep_runs(const WrTargetDesc& T, WrRuns& R, int a, int b, int nc, IV iv, bool fill = true) {
   R.ext = nullptr; R.pad = 0;
-  int n = wr_sweep_into(R, nullptr, a, b, nc, iv);
-  if (n > WR_MAX_RUNS) {
-    int32_t* ext = wr_pool_words(T, 2ull * (unsigned long long)n);
-    if (ext) { wr_sweep_into(R, ext, a, b, nc, iv); R.ext = ext; }
-    else n = -2;
-  }
-  R.n = n;
+  R.n = wr_sweep_into(R, nullptr, a, b, nc, iv);
+  if (R.n > WR_MAX_RUNS && fill) wr_sweep_fill(T, R, a, b, nc, iv);
 }
 // The same for a target that continues from a materialised depth buffer (a flush in the middle of the target: the prims
 // that wrote it are gone): pixel by pixel, a pixel passes when it passes against the loaded depth AND no candidate of this
@@ -7978,11 +7981,42 @@ WR_DEVICE const WrRuns* wr_build_runs(const WrTargetDesc& T, const WrRec* __rest
       auto iv_big = [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, ext[c], y, lo, hi); };
       if (!ok) {}
       else if (big && loaded) wr_scan_runs(T, RR, a, b, nc, iv_big, T.depth + (size_t)y * T.width, z, less);
-      else if (big) wr_sweep_runs(T, RR, a, b, nc, iv_big);
+      else if (big) wr_sweep_runs(T, RR, a, b, nc, iv_big, quad);
       else if (loaded) wr_scan_runs(T, RR, a, b, nc, iv, T.depth + (size_t)y * T.width, z, less);
-      else wr_sweep_runs(T, RR, a, b, nc, iv);
-      if (RR.n == -2) { RR.n = 0; if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u); }
+      else wr_sweep_runs(T, RR, a, b, nc, iv, quad);
     }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // Rows with more runs than the LDS copy holds (left at their count, ext == nullptr): a row whose occluders cover it exactly as they
+  // cover the row above has the same runs -- behind a grid of axis-aligned rects that is fifteen of a strip's sixteen rows -- and
+  // points at that row's words of the pool instead of taking its own (the pool is what such a frame runs out of).
+  if (lane < 4 * R4) {
+    const int r = lane, y = wy0 + r;
+    WrRuns& RR = runs[wave][r];
+    const bool over = RR.n > WR_MAX_RUNS && RR.ext == nullptr;
+    bool same = false;
+    if (over && r > 0 && runs[wave][r - 1].n == RR.n && y - 1 >= ry0 && !(T.qtab_pad & 2u)) {
+      same = true;
+      for (int c = 0; c < nc && same; c++) {
+        int lo0, hi0, lo1, hi1;
+        if (big) { wr_occ_interval(recs, aux, ext[c], y, lo0, hi0); wr_occ_interval(recs, aux, ext[c], y - 1, lo1, hi1); }
+        else { lo0 = ivs[wave][c][r][0]; hi0 = ivs[wave][c][r][1]; lo1 = ivs[wave][c][r - 1][0]; hi1 = ivs[wave][c][r - 1][1]; }
+        same = lo0 == lo1 && hi0 == hi1;
+      }
+    }
+    const unsigned long long F = __ballot(same);
+    if (over && !same) {
+      auto iv = [&](int c, int& lo, int& hi) { lo = ivs[wave][c][r][0]; hi = ivs[wave][c][r][1]; };
+      auto iv_big = [&](int c, int& lo, int& hi) { wr_occ_interval(recs, aux, ext[c], y, lo, hi); };
+      if (big) wr_sweep_fill(T, RR, x0, x1, nc, iv_big); else wr_sweep_fill(T, RR, x0, x1, nc, iv);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (same) {
+      const unsigned long long leaders = ~F & ((1ull << r) - 1ull);        // (row 0 is never a follower: there is one)
+      const WrRuns& LR = runs[wave][63 - __builtin_clzll(leaders)];
+      RR.n = LR.n; RR.ext = LR.ext;
+    }
+    if (RR.n == -2) { RR.n = 0; RR.ext = nullptr; if (T.counters) atomicAdd(&T.counters->unsupported_prims, 1u); }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   return runs[wave];

@@ -239,7 +239,7 @@ struct WrTargetDesc {
   float* qtab;
   unsigned long long* qtab_ctl;
   uint32_t qtab_cap;                           // floats
-  uint32_t qtab_pad;                           // bit 0: no row tables (WRHIP_NO_QTAB: the pool then only takes what the depth runs spill)
+  uint32_t qtab_pad;                           // bit 0: no row tables (WRHIP_NO_QTAB: the pool then only takes what the depth runs spill); bit 1: rows of a strip do not share their runs (WRHIP_NO_RUN_SHARE: A/B)
 };
 
 // Pre-evaluated clip-mask prims.  A cs_clip_rectangle / cs_clip_box_shadow prim covers its rows with long solid runs and a few
