@@ -307,6 +307,9 @@ DUAL_SOURCE = [
 REPEAT_DUAL = [
     ("image_repeat_dual", dict(dual=True, seed=58)),
     ("image_repeat_dual_nearest", dict(dual=True, nearest=True, seed=59)),
+    # ... on anti-aliased prims (BRUSH_FLAG_FORCE_AA, all four edges: blend.h's AA_BLEND_KEY(GL_ONE, GL_ONE_MINUS_SRC1_COLOR) scales both colours)
+    ("image_repeat_dual_aa", dict(dual=True, aa=True, seed=58)),
+    ("image_repeat_dual_aa_nearest", dict(dual=True, aa=True, nearest=True, seed=59)),
 ]
 
 

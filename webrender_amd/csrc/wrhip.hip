@@ -3079,7 +3079,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     // transform ids in the bound header texture and the AA requests in the instances say whether this draw can hold any
     const bool img = info->kind == WR_SH_BRUSH_IMAGE || info->kind == WR_SH_BRUSH_IMAGE_ALPHA ||
                      info->kind == WR_SH_BRUSH_OPACITY || info->kind == WR_SH_BRUSH_OPACITY_ALPHA ||
-                     info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA ||
+                     info->kind == WR_SH_BRUSH_IMAGE_REPEAT || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_ALPHA || info->kind == WR_SH_BRUSH_IMAGE_REPEAT_DUAL ||
                      info->kind == WR_SH_BRUSH_LINEAR_GRADIENT || info->kind == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
                      info->kind == WR_SH_BRUSH_BLEND || info->kind == WR_SH_BRUSH_BLEND_ALPHA ||
                      info->kind == WR_SH_BRUSH_MIX_BLEND || info->kind == WR_SH_BRUSH_MIX_BLEND_ALPHA;

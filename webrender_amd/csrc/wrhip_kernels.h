@@ -2640,7 +2640,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   const bool aa = o.aa_edges != 0 && d.blend != WR_BLEND_NONE;
   // textured kinds that can ride on WrQuadRec (general quads, swgl_antiAlias) when the host gave the launch the path for it
   // (the dual-source programs have no general-quad / anti-aliased path: reported)
-  if (o.dual && ((o.aa_edges != 0 && d.blend != WR_BLEND_NONE) || persp)) { P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return; }
+  // (... except the REPETITION key on anti-aliased prims: its main() has one path, restated on the general-quad evaluator)
+  if (o.dual && (((o.aa_edges != 0 && d.blend != WR_BLEND_NONE) && o.kind != WR_PK_TEX_REPEAT) || persp)) { P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return; }
   const bool texq = (d.flags & WR_DF_QUADS) &&
                     (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT ||
                      o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked) ||
@@ -3734,7 +3735,7 @@ __device__ __noinline__ WrWide wr_repeat_pixel(const WrPrim* Pp, const WrRepeatR
 }
 // ... under the DUAL_SOURCE_BLENDING key (brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION): main() on every pixel --
 // compute_repeated_uvs, the clamp, texture() -- and both colours into the dual-source blend; returns the blended pixel
-WR_DEVICE uint32_t wr_dual_blend(const WrPrim& P, const WrDrawDesc* D, int x, int y, uint32_t dstp, const float (&tx)[4]);
+WR_DEVICE uint32_t wr_dual_blend(const WrPrim& P, const WrDrawDesc* D, int x, int y, uint32_t dstp, const float (&tx)[4], uint32_t cov = 256u, bool aa = false);
 WR_DEVICE void wr_texture_rgba_f(const WrTexDesc& t, float cu, float cv, float (&c)[4]);
 __device__ __noinline__ uint32_t wr_repeat_dual_pixel(const WrPrim* Pp, const WrRepeatRec* Rp, const WrDrawDesc* D, int x, int y, uint32_t dstp,
                                                       const WrRuns* runs = nullptr) {
@@ -4774,7 +4775,7 @@ WR_DEVICE WrWide wr_mask_src(const WrPrim& P, const WrDrawDesc* D, int x, int y,
 // brush_image ... DUAL_SOURCE_BLENDING under GL_ONE, GL_ONE_MINUS_SRC1_COLOR (blend.h:496-511): main() writes the colour
 // v_color * texel and a second one, texel * swizzle.x + texel.aaaa * swizzle.y; dst' = src + dst - dst x second (under a clip
 // mask both terms are scaled by it).  `tx`: the texel main() sampled, (r, g, b, a) floats.
-WR_DEVICE uint32_t wr_dual_blend(const WrPrim& P, const WrDrawDesc* D, int x, int y, uint32_t dstp, const float (&tx)[4]) {
+WR_DEVICE uint32_t wr_dual_blend(const WrPrim& P, const WrDrawDesc* D, int x, int y, uint32_t dstp, const float (&tx)[4], uint32_t cov, bool aa) {
   const float sx = P.dual_swz, sy = P.dual == 2 ? -P.dual_swz : 0.0f;
   uint32_t pc[2], ps[2];
   wr_pack_color(wf4{P.fcolor[0] * tx[0], P.fcolor[1] * tx[1], P.fcolor[2] * tx[2], P.fcolor[3] * tx[3]}, pc);
@@ -4782,12 +4783,18 @@ WR_DEVICE uint32_t wr_dual_blend(const WrPrim& P, const WrDrawDesc* D, int x, in
   WrWide s2; s2.bg = pc[0]; s2.ra = pc[1];
   const WrWide dst = wr_unpack(dstp);
   WrWide second; second.bg = wr_muldiv255_2(ps[0], dst.bg); second.ra = wr_muldiv255_2(ps[1], dst.ra);    // applyColor(dst, secondary)
+  // (anti-aliased prims of the REPETITION key, blend.h:513-530: AA_BLEND_KEY scales source AND secondary colour by the coverage,
+  // AA_MASK_BLEND_KEY scales the mask by it)
   if (P.flags & WR_PF_MASKED) {
     const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
-    const uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
+    uint32_t m = ((const uint8_t*)mt.ptr)[(size_t)(y - P.mask_off[1]) * mt.stride + (x - P.mask_off[0])];
+    if (aa) m = ((m * cov) & 0xFFFFu) >> 8;
     const uint32_t mm = m | (m << 16);
     s2.bg = wr_muldiv255_2(s2.bg, mm); s2.ra = wr_muldiv255_2(s2.ra, mm);
     second.bg = wr_muldiv255_2(second.bg, mm); second.ra = wr_muldiv255_2(second.ra, mm);
+  } else if (aa) {
+    auto sc = [&](uint32_t c) { return ((((c & 0xFFFFu) * cov) & 0xFFFFu) >> 8) | (((((c >> 16) * cov) & 0xFFFFu) >> 8) << 16); };
+    s2.bg = sc(s2.bg); s2.ra = sc(s2.ra); second.bg = sc(second.bg); second.ra = sc(second.ra);
   }
   WrWide res;
   res.bg = wr_sub2(wr_add2(s2.bg, dst.bg), second.bg);
@@ -4980,6 +4987,23 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     if (Q.base_kind == WR_PK_GRADIENT) src = wr_gradient_row4(&Pl, &Q.grad, D, x, y, runs).v[0];
     else if (Q.base_kind == WR_PK_FILTER) src = wr_filter_pixel(&Pl, &Q.filt, D, x, y, runs);
     else src = wr_quad_mask_pixel(&Pl, &Q.clip, D, x, y, runs);
+  } else if (Q.base_kind == WR_PK_TEX_REPEAT && Pl.dual && Pl.blend == WR_BLEND_DUAL_SRC) {
+    // the dual-source REPETITION key on an anti-aliased (or rotated) prim: no span shader under this key, every pixel runs main() --
+    // the repeated uv of wr_repeat_dual_pixel from this row's edge interpolants -- and the blend takes both colours and the coverage
+    const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0, runs, x, true);
+    const WrRepeatRec& R = Q.rep;
+    const int n = x - r.x0, lane = n & 3, m = n >> 2;
+    float lu = wr_pick4(r.lu, lane), lv = wr_pick4(r.lv, lane);
+    lu = wr_accum(lu, (r.su * 4.0f) * 1.0f, m); lv = wr_accum(lv, (r.sv * 4.0f) * 1.0f, m);
+    const float usx = R.uv_repeat[2] - R.uv_repeat[0], usy = R.uv_repeat[3] - R.uv_repeat[1];
+    const float cu = wr_max(lu, 0.0f), cv = wr_max(lv, 0.0f);
+    float ru = (cu - floorf(cu)) * usx + R.uv_repeat[0], rv = (cv - floorf(cv)) * usy + R.uv_repeat[1];
+    if (cu >= R.tile_repeat[0]) ru = R.uv_repeat[2];
+    if (cv >= R.tile_repeat[1]) rv = R.uv_repeat[3];
+    ru = wr_clamp(ru, Pl.uv_bounds[0], Pl.uv_bounds[2]); rv = wr_clamp(rv, Pl.uv_bounds[1], Pl.uv_bounds[3]);
+    float tx[4];
+    wr_texture_rgba_f(t, ru, rv, tx);
+    return HIT | wr_dual_blend(Pl, D, x, y, dstp_, tx, cov, Q.aa && !aa_skip);
   } else {
     const WrTexRow r = wr_tex_row_span(Pl, t, Lu, Lv, Ru, Rv, xl, xr, s0, s1 - s0, runs, x, Q.base_kind == WR_PK_TEX_REPEAT && Q.rep.no_span != 0);
     src = Q.base_kind == WR_PK_TEX_REPEAT ? wr_repeat_pixel_row(Pl, Q.rep, t, r, x - r.x0) : wr_tex_pixel_row(Pl, t, r, x - r.x0);

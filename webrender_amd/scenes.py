@@ -548,7 +548,7 @@ def image_grid(width=1024, height=1024, n=120, seed=51, atlas=1024, tile_filter=
 # than the primitive, and border-image style segments (BRUSH_FLAG_SEGMENT_RELATIVE with the REPEAT_X/Y,
 # *_ROUND and *_CENTERED flags, with and without a texel rect).  `nearest` switches the atlas sampler to
 # GL_NEAREST (blendTextureNearestRepeat instead of blendTextureLinearRepeat).
-def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=False, tile_filter=None, only=None, translucent=True, dual=False):
+def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=False, tile_filter=None, only=None, translucent=True, dual=False, aa=False):
     """`dual`: the alpha-pass prims go through "brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D" under the
     dual-source blend state (what a repeated image in a BlendMode::SubpixelDualSource / MultiplyDualSource batch is drawn with), colour
     modes SUBPX_DUAL_SOURCE / MULTIPLY_DUAL_SOURCE / IMAGE in turn, a brush colour other than white"""
@@ -661,7 +661,11 @@ def image_repeat(width=1024, height=1024, n=80, seed=57, atlas=512, nearest=Fals
             ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, 0, task, ud)
             dst = op if pr["opaque"] else al
             if pr["segs"] is None:
-                dst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=pr["addr"]))
+                # aa: BRUSH_FLAG_FORCE_AA + all four edges on the unsegmented alpha-pass prims (swgl_antiAlias)
+                if aa and not pr["opaque"]:
+                    dst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=pr["addr"], brush_flags=1024, edge_flags=15))
+                else:
+                    dst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=pr["addr"]))
             else:
                 for si, (_, _, flags) in enumerate(pr["segs"]):
                     dst.append(frame.brush_instance(ph, CLIP_TASK_EMPTY, segment=si, brush_flags=flags, resource_address=pr["addr"]))
