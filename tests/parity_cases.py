@@ -286,6 +286,10 @@ MIX_BLEND = [
     ("mix_grid_rotated", "mix_blend_grid", dict(seed=208, rotate=True)),
     ("mix_grid_rotated_masked", "mix_blend_grid", dict(seed=209, rotate=True, masked=True, n=60)),
     ("mix_grid_force_aa", "mix_blend_grid", dict(seed=210, force_aa=True, n=60)),
+    # ... inside a 3-D context (a projective row on top of the rotation; BRUSH_FLAG_PERSPECTIVE_INTERPOLATION on every other such prim):
+    # both varyings interpolated / w, the source's times mix(gl_FragCoord.w, 1, flag) -- round 5
+    ("mix_grid_perspective", "mix_blend_grid", dict(seed=211, perspective=True)),
+    ("mix_grid_perspective_masked", "mix_blend_grid", dict(seed=212, perspective=True, masked=True, n=60)),
 ]
 
 
@@ -489,4 +493,6 @@ CLANG_BUDGET = {
 
 
 def clang_budget(family, name):
+    if family == "mix_blend" and "perspective" in name:      # (two bilinear samplers per pixel under a projective transform: the rotated family's causes)
+        return CLANG_BUDGET["rotated"]
     return CLANG_BUDGET["near_clipped" if "near_clipped" in name else family]

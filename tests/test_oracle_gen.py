@@ -32,7 +32,9 @@ _SCENES += [(n, (lambda kw=kw: scenes.border_solid(**kw))) for n, kw in BORDERS]
 _SCENES += [(n, (lambda kw=kw: scenes.border_segments(**kw))) for n, kw in BORDER_SEGMENTS]
 _SCENES += [(n, (lambda kw=kw: scenes.cache_decorations(**kw))) for n, kw in DECORATIONS]
 _SCENES += [(n, (lambda kw=kw: scenes.texture_cache_copies(**kw))) for n, kw in COPIES]
-_SCENES += [(n, (lambda s=s, kw=kw: getattr(scenes, s)(**kw))) for n, s, kw in MIX_BLEND]
+# (the hand-written brush_mix_blend header has no perspective entry points -- it was written for 2-D transforms, gl_FragCoord.w fixed at 1 --,
+# so the projective cases are the generated oracle's alone: the header glsl-to-cxx's restatement emits from the reference's GLSL)
+_SCENES += [(n, (lambda s=s, kw=kw: getattr(scenes, s)(**kw))) for n, s, kw in MIX_BLEND if not kw.get("perspective")]
 _SCENES += [(n, (lambda kw=kw: scenes.image_grid(**kw))) for n, kw in DUAL_SOURCE]
 
 

@@ -919,7 +919,8 @@ WR_DEVICE void wr_vs_brush(const WrDrawDesc& d, const uint8_t* arena, int inst, 
     o.tex_slot = WR_S_COLOR0;
     o.tail_clamp = 1; o.tail_modulate = 0;
     o.has_color = 0; o.color = wf4{1.f, 1.f, 1.f, 1.f};
-    o.kind = (brush_flags & 1) ? WR_PK_UNSUPPORTED : WR_PK_MIX_BLEND;      // perspective interpolation: next
+    o.kind = WR_PK_MIX_BLEND;
+    o.persp_div = persp;              // main(): v_src_uv * mix(gl_FragCoord.w, 1.0, v_perspective.x) (brush_mix_blend.glsl; a projective transform only)
     return;
   }
   if (image == 4) {
@@ -2131,9 +2132,9 @@ WR_DEVICE bool wr_isfinite(float x) { return (x - x) == 0.0f; }
 // starts, which edges are the span's left and right ones, when each edge ends and is replaced
 // (STEP_EDGE), the clip span of every edge pair.  Returns false for degenerate walks (nothing to draw)
 // or more runs than WrQuadRec holds.  p[] in vertex-lane order (0,0) (1,0) (1,1) (0,1).
-struct WrEdgeInst { float x, slope; int row, mask; float u, v, us, vs; float z, w, zs, ws; };
+struct WrEdgeInst { float x, slope; int row, mask; float u, v, us, vs; float z, w, zs, ws; float u2, v2, u2s, v2s; };
 WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, float p1y, int mask, float u0, float v0, float u1,
-                                  float v1, float z0, float w0, float z1, float w1) {   // Edge ctor, :850-876 (:1127-1152 for z, w)
+                                  float v1, float z0, float w0, float z1, float w1, float a0 = 0.0f, float b0 = 0.0f, float a1 = 0.0f, float b1 = 0.0f) {   // Edge ctor, :850-876 (:1127-1152 for z, w)
   WrEdgeInst e;
   const float yScale = 1.0f / wr_max(p1y - p0y, 1.0f / 256.0f);
   e.slope = (p1x - p0x) * yScale;
@@ -2142,6 +2143,8 @@ WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, floa
   e.u = u0 + (y - p0y) * e.us; e.v = v0 + (y - p0y) * e.vs;
   e.zs = (z1 - z0) * yScale; e.ws = (w1 - w0) * yScale;
   e.z = z0 + (y - p0y) * e.zs; e.w = w0 + (y - p0y) * e.ws;
+  e.u2s = (a1 - a0) * yScale; e.v2s = (b1 - b0) * yScale;          // (a second interpolated vec2: brush_mix_blend under perspective)
+  e.u2 = a0 + (y - p0y) * e.u2s; e.v2 = b0 + (y - p0y) * e.v2s;
   e.row = int(y); e.mask = mask;
   return e;
 }
@@ -2149,7 +2152,7 @@ WR_DEVICE WrEdgeInst wr_edge_init(float y, float p0x, float p0y, float p1x, floa
 // iz / iw: screen z and 1/w per vertex of a perspective quad (stored in Q.persp when `persp`)
 WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const float (&iu)[4], const float (&iv)[4], float cx0, float cy0,
                             float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0, int& by0, int& bx1, int& by1,
-                            const float (&iz)[4], const float (&iw)[4], bool persp) {
+                            const float (&iz)[4], const float (&iw)[4], bool persp, const float* iu2 = nullptr, const float* iv2 = nullptr) {
   Q.nseg = 0; Q.aa = aa ? 1 : 0; Q.rowtab = nullptr; Q.rowtab_rows = 0;
   // top-most point (:794-799)
   const int top = py[3] < py[2] ? (py[0] < py[1] ? (py[0] < py[3] ? 0 : 3) : (py[1] < py[3] ? 1 : 3))
@@ -2164,8 +2167,10 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
   const float aaRound = aa ? 0.0f : 0.5f;
   float y = floorf(wr_max(wr_min(WR_PY(l0i), cy1), cy0) + aaRound) + 0.5f;
   // the l-chain walks forward through the points, the r-chain backward; `flipped` says which one is the span's left edge
+#define WR_P2(arr, i) ((arr) ? ((i) == 0 ? (arr)[0] : ((i) == 1 ? (arr)[1] : ((i) == 2 ? (arr)[2] : (arr)[3]))) : 0.0f)
 #define WR_EDGE(a, b, m) wr_edge_init(y, WR_PX(a), WR_PY(a), WR_PX(b), WR_PY(b), (aa_mask >> (m)) & 1, wr_pick4(iu, a), wr_pick4(iv, a), \
-                                     wr_pick4(iu, b), wr_pick4(iv, b), wr_pick4(iz, a), wr_pick4(iw, a), wr_pick4(iz, b), wr_pick4(iw, b))
+                                     wr_pick4(iu, b), wr_pick4(iv, b), wr_pick4(iz, a), wr_pick4(iw, a), wr_pick4(iz, b), wr_pick4(iw, b), \
+                                     WR_P2(iu2, a), WR_P2(iv2, a), WR_P2(iu2, b), WR_P2(iv2, b))
   WrEdgeInst EL = WR_EDGE(l0i, l1i, l1i);
   WrEdgeInst ER = WR_EDGE(r0i, r1i, r0i);
   bool flipped;
@@ -2218,6 +2223,10 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
       const int k = Q.nseg - 1;
       R.lz[k] = A.z; R.lzs[k] = A.zs; R.lw[k] = A.w; R.lws[k] = A.ws;
       R.rz[k] = B.z; R.rzs[k] = B.zs; R.rw[k] = B.w; R.rws[k] = B.ws;
+      if (iu2) {
+        R.l2u[k] = A.u2; R.l2us[k] = A.u2s; R.l2v[k] = A.v2; R.l2vs[k] = A.v2s;
+        R.r2u[k] = B.u2; R.r2us[k] = B.u2s; R.r2v[k] = B.v2; R.r2vs[k] = B.v2s;
+      }
     }
     S.b0 = b0; S.b1 = b1;
     bx0 = wr_imin(bx0, int(floorf(b0)) - 1); bx1 = wr_imax(bx1, int(ceilf(b1)) + 1);
@@ -2226,6 +2235,7 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
   }
 #undef WR_CLIPSPAN
 #undef WR_EDGE
+#undef WR_P2
 #undef WR_PX
 #undef WR_PY
   return Q.nseg > 0;
@@ -2574,7 +2584,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
     // (and brush_opacity, brush_blend, brush_linear_gradient: main() on the perspective-correct varying)
     const bool ptex = ((d.shader == WR_SH_PS_QUAD_TEXTURED || o.persp_div >= 0.0f) && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS)) ||
                       ((d.shader == WR_SH_PS_TEXT_RUN || d.shader == WR_SH_PS_TEXT_RUN_DUAL) && (o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_RGBA8)) ||      /* (the GLYPH_TRANSFORM keys never reach here with a projective transform: their vertex stage reports it) */
-                      o.kind == WR_PK_FILTER || (o.kind == WR_PK_QUAD_MASK && auxp->clip.w == 1.0f) || (o.kind == WR_PK_TEX_REPEAT && o.persp_div >= 0.0f) || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
+                      o.kind == WR_PK_FILTER || o.kind == WR_PK_MIX_BLEND || (o.kind == WR_PK_QUAD_MASK && auxp->clip.w == 1.0f) || (o.kind == WR_PK_TEX_REPEAT && o.persp_div >= 0.0f) || (o.kind == WR_PK_GRADIENT && (d.shader == WR_SH_BRUSH_LINEAR_GRADIENT || d.shader == WR_SH_BRUSH_LINEAR_GRADIENT_ALPHA ||
                                                                               d.shader == WR_SH_PS_QUAD_RADIAL_GRADIENT || d.shader == WR_SH_PS_QUAD_CONIC_GRADIENT));
     if (!(o.kind == WR_PK_SOLID || ptex)) { atomicAdd(&cnt->perspective_prims, 1u); return; }
     clipped = !inside;           // a vertex outside the near / far planes: clip_side first (wr_persp_clipped_walk)
@@ -2645,7 +2655,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   const bool texq = (d.flags & WR_DF_QUADS) &&
                     (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT ||
                      o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked) ||
-                     (o.kind == WR_PK_MIX_BLEND && !persp));
+                     o.kind == WR_PK_MIX_BLEND);
   if (aa && (o.kind != WR_PK_SOLID || masked) && !texq) {      // AA on masked solids / other shader families: "next"
     P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
   }
@@ -2655,8 +2665,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked)))) {
-      atomicAdd(&cnt->perspective_prims, 1u); return;
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked) || (o.kind == WR_PK_MIX_BLEND && !clipped)))) {
+      atomicAdd(&cnt->perspective_prims, 1u); return;        // (brush_mix_blend cut by the near plane: its second varying is not clipped along)
     }
     if (!solidq && !texq) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;
@@ -2681,6 +2691,12 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       St.vp[0] = d.vp_origin[0]; St.vp[1] = d.vp_origin[1]; St.vp[2] = d.vp_size[0]; St.vp[3] = d.vp_size[1];
       auxp->quad.nseg = -1; auxp->quad.rowtab = nullptr; auxp->quad.rowtab_rows = 0;
       bx0 = int(cx0); by0 = int(cy0); bx1 = int(cx0) + 1; by1 = int(cy0) + 1;      // (a placeholder box: replaced by the walk's)
+    }
+    else if (o.kind == WR_PK_MIX_BLEND && persp) {
+      // ... under a projective transform the z / w slots are taken: the second varying, divided by w like the first, on edges of its own
+      float qu2[4], qv2[4];
+      for (int n = 0; n < 4; n++) { qu2[n] = o.u2[n] * pw3[n]; qv2[n] = o.v2[n] * pw3[n]; }
+      if (!wr_quad_walk(sx, sy, qu, qv, cx0, cy0, cx1, cy1, aa, o.aa_edges, auxp->quad, bx0, by0, bx1, by1, pz3, pw3, true, qu2, qv2)) return;
     }
     else if (o.kind == WR_PK_MIX_BLEND) {
       // brush_mix_blend's second varying (v_src_uv) rides in the walk's z / w slots
@@ -4839,6 +4855,7 @@ __device__ __noinline__ WrWide wr_gradient_main(const WrGradRec* Gp, const WrDra
 __device__ __noinline__ WrWide wr_quad_mask_pixel(const WrPrim* Pp, const WrClipRec* Cp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 __device__ __noinline__ WrWide wr_yuv_pixel(const WrPrim* Pp, const WrYuvRec* Yp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 __device__ __noinline__ WrWide wr_mix_blend_pixel(const WrPrim* Pp, const WrMixRec* Mp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
+__device__ __noinline__ WrWide wr_mix_blend_main(const WrMixRec* Mp, const WrDrawDesc* D, float bu, float bv, float su, float sv);
 __device__ __noinline__ WrWide wr_svg_filter_pixel(const WrPrim* Pp, const WrSvgRec* Sp, const WrDrawDesc* D, int x, int y, const WrRuns* runs);
 WR_DEVICE float wr_r8_texture(const WrTexDesc& t, float u, float v);
 WR_DEVICE WrWide wr_quad_mask_eval(const WrClipRec& C, float f0x, float f0y, float f1x, float f1y, float qx, float qy);
@@ -4951,6 +4968,24 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
         px_[j] = vx / vw; py_[j] = vy / vw;
       }
       src = wr_quad_mask_eval(Q.clip, px_[0], py_[0], px_[1], py_[1], px_[2], py_[2]);
+    } else if (Q.base_kind == WR_PK_MIX_BLEND) {
+      // brush_mix_blend: v_backdrop_uv as it is, v_src_uv * mix(gl_FragCoord.w, 1.0, v_perspective.x) -- both varyings interpolated / w
+      // along the span (the second one's edge values on this row: sums of its own, WrPerspRec::l2u ..), each clamped to its bounds
+      float pu, pv, fw;
+      lane_at(k, pu, pv, fw);
+      const float wq = 1.0f / fw;
+      float bu = pu * wq, bv = pv * wq;
+      const float L2u = wr_accum(Q.persp.l2u[si], Q.persp.l2us[si], y - S.lrow), L2v = wr_accum(Q.persp.l2v[si], Q.persp.l2vs[si], y - S.lrow);
+      const float R2u = wr_accum(Q.persp.r2u[si], Q.persp.r2us[si], y - S.rrow), R2v = wr_accum(Q.persp.r2v[si], Q.persp.r2vs[si], y - S.rrow);
+      const float su2 = (R2u - L2u) * stepScale, sv2 = (R2v - L2v) * stepScale;
+      float qu = L2u + su2 * start, qv = L2v + sv2 * start;
+      for (int i = 0; i < (k & 3); i++) { qu = qu + su2; qv = qv + sv2; }
+      qu = wr_accum(qu, (su2 * 4.0f) * 1.0f, k >> 2); qv = wr_accum(qv, (sv2 * 4.0f) * 1.0f, k >> 2);
+      const float pd = (1.0f - fw) * Q.persp.div + fw;
+      float su_ = (qu * wq) * pd, sv_ = (qv * wq) * pd;
+      bu = wr_clamp(bu, Pl.uv_bounds[0], Pl.uv_bounds[2]); bv = wr_clamp(bv, Pl.uv_bounds[1], Pl.uv_bounds[3]);
+      su_ = wr_clamp(su_, Q.mix.s_bounds[0], Q.mix.s_bounds[2]); sv_ = wr_clamp(sv_, Q.mix.s_bounds[1], Q.mix.s_bounds[3]);
+      src = wr_mix_blend_main(&Q.mix, D, bu, bv, su_, sv_);
     } else {
     float pu, pv, fw;
     lane_at(k, pu, pv, fw);
@@ -5612,6 +5647,13 @@ __device__ __noinline__ WrWide wr_mix_blend_pixel(const WrPrim* Pp, const WrMixR
     const WrTexRow r = wr_tex_row(P2, ts, y, runs, x);
     wr_tex_tail_uv(P2, r, x - r.x0, su, sv);
   }
+  return wr_mix_blend_main(Mp, D, bu, bv, su, sv);
+}
+// ... main() of brush_mix_blend with both sample positions in hand (brush_mix_blend.glsl: Cb / Cs unpremultiplied, the sixteen modes)
+__device__ __noinline__ WrWide wr_mix_blend_main(const WrMixRec* Mp, const WrDrawDesc* D, float bu, float bv, float su, float sv) {
+  const WrMixRec& M = *Mp;
+  const WrTexDesc& tb = D->tex[WR_S_COLOR0];
+  const WrTexDesc& ts = D->tex[WR_S_COLOR1];
   float Cb4[4], Cs4[4];
   wr_texture_rgba_f(tb, bu, bv, Cb4);
   wr_texture_rgba_f(ts, su, sv, Cs4);

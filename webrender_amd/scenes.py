@@ -1830,7 +1830,8 @@ def mix_blend_swatches(seed=201):
     return frame
 
 
-def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, only=None, fractional=True, masked=False, rotate=False, force_aa=False):
+def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, only=None, fractional=True, masked=False, rotate=False, force_aa=False,
+                   perspective=False):
     """Overlapping, scaled, fractionally placed brush_mix_blend prims over the tile grid: backdrop and source pictures of
     different sizes (linear filtering on both), sub-quads in homogeneous coordinates on some sources, every mode."""
     rng = np.random.default_rng(seed)
@@ -1871,10 +1872,13 @@ def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, on
     # rotate: two prims out of three sit under a rotation / skew about their centre (mix-blend-mode on a rotated stacking context:
     # the general-quad path with swgl_antiAlias on all four edges); force_aa: BRUSH_FLAG_FORCE_AA on axis-aligned ones
     tids = [0] * len(prims)
-    if rotate:
+    # perspective: ... with a projective row on top (mix-blend-mode inside a 3-D context; every other such prim asks for
+    # perspective-correct interpolation of the source's uv: BRUSH_FLAG_PERSPECTIVE_INTERPOLATION)
+    if rotate or perspective:
         for k, pr in enumerate(prims):
             if k % 3 != 1:
-                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k)
+                rad = 0.5 * float(np.hypot(pr[0][2] - pr[0][0], pr[0][3] - pr[0][1]))
+                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k, rad if perspective else None)
     t_mask, clip_tasks = None, [None] * len(prims)
     if masked:
         t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
@@ -1893,12 +1897,19 @@ def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, on
             if only is not None and zi not in only:
                 continue
             bb = rotated_bounds(rect) if tids[zi] else rect
+            if tids[zi] and perspective:
+                rr = float(np.hypot(rect[2] - rect[0], rect[3] - rect[1])) * 1.4 + 4
+                cxx, cyy = (rect[0] + rect[2]) / 2, (rect[1] + rect[3]) / 2
+                bb = (cxx - rr, cyy - rr, cxx + rr, cyy + rr)
             if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
             ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, 0, tids[zi], task, (mode, a_b, a_s, 0))
             ct = clip_tasks[zi]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
-            al.append(frame.brush_instance(ph, clip_addr, edge_flags=15, brush_flags=1024 if (force_aa and zi % 2 == 0 and not tids[zi]) else 0))
+            bf = 1024 if (force_aa and zi % 2 == 0 and not tids[zi]) else 0
+            if perspective and tids[zi] and zi % 2 == 0:
+                bf |= 1                                    # BRUSH_FLAG_PERSPECTIVE_INTERPOLATION
+            al.append(frame.brush_instance(ph, clip_addr, edge_flags=15, brush_flags=bf))
         if al:
             target.alpha.append(Step("brush_mix_blend ALPHA_PASS", "PRIM_INSTANCES", np.array(al, dtype=np.int32),
                                      "PremultipliedAlpha", "alpha", textures={0: t_b, 1: t_s, 9: t_mask} if masked else {0: t_b, 1: t_s}))
