@@ -1178,7 +1178,7 @@ Context::~Context() {
   for (auto& kv : pool) wrrt::dev_free(kv.second);
   pool.clear();
   wrrt::dev_free(dupload); wrrt::dev_free(dcounters);
-  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.qtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.bin_ctr); wrrt::dev_free(S.mr_ctl); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); wrrt::dev_free(S.flat); }
+  for (Scratch& S : scratch) { wrrt::dev_free(S.prims); wrrt::dev_free(S.recs); wrrt::dev_free(S.aux); wrrt::dev_free(S.vtab); wrrt::dev_free(S.qtab); wrrt::dev_free(S.masks); wrrt::dev_free(S.bin_ctr); wrrt::dev_free(S.mr_slots); wrrt::dev_free(S.mr_store); wrrt::dev_free(S.flat); }
   wrrt::pinned_free(staging);
   wrrt::event_destroy(ev_a); wrrt::event_destroy(ev_b);
   wrrt::event_destroy(ev_copy);
@@ -1833,9 +1833,8 @@ void flush_work(const std::vector<int>& sel_in) {
     mr_safe = mr_slots <= WR_MR_MAX_SLOTS && mr_rows <= WR_MR_MAX_ROWS && mr_bytes <= kCap;
     const size_t want_slots = (size_t)std::min<uint64_t>(mr_slots, WR_MR_MAX_SLOTS);
     const size_t want_bytes = (size_t)std::min<uint64_t>(mr_bytes, mr_safe ? kCap : ((uint64_t)256 << 20));
-    if (!S.mr_ctl || S.mr_slots_cap < want_slots || S.mr_store_cap < want_bytes) {
+    if (S.mr_slots_cap < want_slots || S.mr_store_cap < want_bytes) {
       sync_stream();
-      if (!S.mr_ctl) S.mr_ctl = (unsigned long long*)wrrt::dev_alloc(512);       // [0] allocation word, [32..63] byte counters
       if (S.mr_slots_cap < want_slots) {
         wrrt::dev_free(S.mr_slots);
         S.mr_slots_cap = std::min<size_t>(want_slots * 2, WR_MR_MAX_SLOTS);
@@ -1849,7 +1848,7 @@ void flush_work(const std::vector<int>& sel_in) {
     }
     for (WrTargetDesc& T : targets) {
       if (T.format != WR_FMT_R8) continue;
-      T.mr_ctl = S.mr_ctl; T.mr_slots = S.mr_slots; T.mr_store = S.mr_store;
+      T.mr_ctl = nullptr; T.mr_slots = S.mr_slots; T.mr_store = S.mr_store;       // (mr_ctl: 512 bytes of this flush's arena, below)
       T.mr_cap16 = (uint32_t)std::min<uint64_t>(S.mr_store_cap >> 4, WR_MR_MAX_CAP16);
       T.mr_max_slots = (uint32_t)S.mr_slots_cap;
     }
@@ -1876,10 +1875,19 @@ void flush_work(const std::vector<int>& sel_in) {
     const int n_blocks = (n_prims + 63) / 64;
     size_t off_blk = (off_inst + inst_bytes + 255) & ~size_t(255);
     const size_t off_qctl = (off_blk + sizeof(int) * n_blocks + 63) & ~size_t(63);      // the row-table pool's allocation word: zero on arrival
-    size_t total = off_qctl + 64 + 256;
+    // ... and the mask-row store's control block ([0] allocation word, [32..63] byte counters): part of the arena as well, so that it
+    // arrives zeroed with the arena's DMA instead of by a fill launch of its own per flush (4.7 us of stream time and a runtime call
+    // per frame of every workload with clip masks)
+    const size_t off_mrctl = off_qctl + 64;
+    size_t total = off_mrctl + 512 + 256;
     size_t aoff = staging_alloc(total);
     uint8_t* h = c->staging + aoff;
-    memset(h + off_qctl, 0, 64);
+    memset(h + off_qctl, 0, 64 + 512);
+    if (mr_on) {
+      Context::Scratch& Sm = c->scratch[c->flush_seq & 1];
+      Sm.mr_ctl = (unsigned long long*)(c->dupload + aoff + off_mrctl); Sm.mr_seen = 0;
+      for (WrTargetDesc& T : targets) if (T.format == WR_FMT_R8 && T.mr_slots) T.mr_ctl = Sm.mr_ctl;
+    }
     *(unsigned long long*)(h + off_qctl) = (unsigned long long)gtab_words;      // (WR_GTAB_WORDS is a multiple of 4: the pieces behind stay on 16 bytes)
     for (WrTargetDesc& T : targets) T.qtab_ctl = T.qtab ? (unsigned long long*)(c->dupload + aoff + off_qctl) : nullptr;
     if (nd) stage_copy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
@@ -1930,7 +1938,6 @@ void flush_work(const std::vector<int>& sel_in) {
     const WrTargetDesc* dtargets = (const WrTargetDesc*)(darena + off_targets);
     const uint8_t* dinst = darena + off_inst;
     const int* dblk = (const int*)(darena + off_blk);
-    if (mr_on) { wrrt::memset8(S.mr_ctl, 0, 512, c->stream); S.mr_seen = 0; }     // (this set's previous user, two flushes back, has been launched)
     if (n_prims > 0) {
 #ifdef WRHIP_TIMING
       static const int setup_mode = getenv("WRHIP_SETUP_MODE") ? atoi(getenv("WRHIP_SETUP_MODE")) : 0;
