@@ -185,6 +185,15 @@ RUN_OVERFLOW = [
     ("sliver_fence_overflow_rotated_images", lambda: scenes.add_slivers(scenes.rotated_images(), pitch=3)),
 ]
 # wrench/benchmarks/transforms-simple.yaml (the reference's own transform benchmark): both encodings
+# the dual-source REPETITION key on rotated / skewed and on projected prims, anti-aliased, with and without clip masks (round 5: the
+# general-quad evaluator runs the key's main(), the blend takes both colours and the coverage -- AA_BLEND_KEY / AA_MASK_BLEND_KEY of
+# GL_ONE, GL_ONE_MINUS_SRC1_COLOR, blend.h:513-530)
+ROTATED += [
+    ("rotated_images_repeat_dual", lambda: scenes.rotated_images(repeat=True, dual=True, seed=105)),
+    ("rotated_images_repeat_dual_masked", lambda: scenes.rotated_images(repeat=True, dual=True, masked=True, seed=106)),
+    ("perspective_images_repeat_dual", lambda: scenes.rotated_images(repeat=True, dual=True, perspective=True, seed=107)),
+    ("perspective_images_repeat_dual_masked", lambda: scenes.rotated_images(repeat=True, dual=True, perspective="all", masked=True, seed=108)),
+]
 ROTATED += [
     ("transforms_simple", lambda: scenes.transforms_simple()),
     ("transforms_simple_quad", lambda: scenes.transforms_simple(encoding="quad")),

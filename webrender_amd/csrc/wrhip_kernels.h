@@ -2651,7 +2651,7 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   // textured kinds that can ride on WrQuadRec (general quads, swgl_antiAlias) when the host gave the launch the path for it
   // (the dual-source programs have no general-quad / anti-aliased path: reported)
   // (... except the REPETITION key on anti-aliased prims: its main() has one path, restated on the general-quad evaluator)
-  if (o.dual && (((o.aa_edges != 0 && d.blend != WR_BLEND_NONE) && o.kind != WR_PK_TEX_REPEAT) || persp)) { P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return; }
+  if (o.dual && ((o.aa_edges != 0 && d.blend != WR_BLEND_NONE) || persp) && o.kind != WR_PK_TEX_REPEAT) { P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return; }
   const bool texq = (d.flags & WR_DF_QUADS) &&
                     (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT ||
                      o.kind == WR_PK_GRADIENT || o.kind == WR_PK_FILTER || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked) ||
@@ -4998,6 +4998,20 @@ __device__ __noinline__ unsigned long long wr_quad_tex_pixel_rgba8(const WrPrim*
     cu = cu + Pl.uv_add[0]; cv = cv + Pl.uv_add[1];
     if (Pl.flags & WR_PF_TAIL_CLAMP) { cu = wr_clamp(cu, Pl.uv_bounds[0], Pl.uv_bounds[2]); cv = wr_clamp(cv, Pl.uv_bounds[1], Pl.uv_bounds[3]); }
     // the program's main() with its varying at this pixel
+    if (Q.base_kind == WR_PK_TEX_REPEAT && Pl.dual && Pl.blend == WR_BLEND_DUAL_SRC) {
+      // (the dual-source REPETITION key under a projective transform: the repeated uv of wr_repeat_dual_pixel from the
+      // perspective-correct v_uv, both colours and the coverage into the blend)
+      const WrRepeatRec& R = Q.rep;
+      const float usx = R.uv_repeat[2] - R.uv_repeat[0], usy = R.uv_repeat[3] - R.uv_repeat[1];
+      const float du = wr_max(cu, 0.0f), dv = wr_max(cv, 0.0f);
+      float ru = (du - floorf(du)) * usx + R.uv_repeat[0], rv = (dv - floorf(dv)) * usy + R.uv_repeat[1];
+      if (du >= R.tile_repeat[0]) ru = R.uv_repeat[2];
+      if (dv >= R.tile_repeat[1]) rv = R.uv_repeat[3];
+      ru = wr_clamp(ru, Pl.uv_bounds[0], Pl.uv_bounds[2]); rv = wr_clamp(rv, Pl.uv_bounds[1], Pl.uv_bounds[3]);
+      float tx[4];
+      wr_texture_rgba_f(t, ru, rv, tx);
+      return HIT | wr_dual_blend(Pl, D, x, y, dstp_, tx, cov, Q.aa && !aa_skip);
+    }
     if (Q.base_kind == WR_PK_TEX_REPEAT) src = wr_repeat_main(Pl, Q.rep, t, cu, cv);
     else if (Q.base_kind == WR_PK_FILTER) src = wr_filter_eval(&Pl, &Q.filt, D, cu, cv);
     else if (Q.base_kind == WR_PK_GRADIENT) src = wr_gradient_main(&Q.grad, D, cu, cv);

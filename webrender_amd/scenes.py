@@ -2031,7 +2031,7 @@ def transforms_simple(width=1024, height=1024, n=11, encoding="brush", tile_filt
 # `repeat`: through the ANTIALIASING,REPETITION image brush with tiling stretch sizes; `masked`: under
 # swgl_clipMask as well.  Alpha pass only (AA needs blending, rasterize.h:414-441).
 def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=False, nearest=False, masked=False, tile_filter=None,
-                   only=None, encoding="brush", perspective=False):
+                   only=None, encoding="brush", perspective=False, dual=False):
     rng = np.random.default_rng(seed)
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
     pix = np.zeros((atlas, atlas, 4), np.uint8)
@@ -2093,6 +2093,8 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
         frame.static_textures.append(t_mask)
         clip_tasks = prim_clip_tasks(rng, [p[3] for p in prims], 1024, True)
     key = "brush_image ALPHA_PASS,ANTIALIASING,REPETITION,TEXTURE_2D" if repeat else "brush_image ALPHA_PASS,TEXTURE_2D"
+    if dual:        # (with repeat: the dual-source REPETITION key on rotated / projected, anti-aliased prims -- see image_repeat)
+        key = "brush_image ALPHA_PASS,ANTIALIASING,DUAL_SOURCE_BLENDING,REPETITION,TEXTURE_2D"
     if encoding == "quad":
         key = "ps_quad_textured"
     targets = []
@@ -2114,14 +2116,19 @@ def rotated_images(width=1024, height=1024, n=60, seed=101, atlas=512, repeat=Fa
                                               transform_id=tid, quad_flags=0, edge_flags=15 if (tid or flags) else 0,
                                               uv_rect=tuple(float(v) for v in texels)))
                 continue
-            spec = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [st[0], st[1], 0.0, 0.0]])
+            col = [1.0, 1.0, 1.0, 1.0]
             ud = (4 | (1 << 16), 0, int(round(opacity * 65535.0)), 0)
+            if dual:
+                a = (0.35, 0.6, 0.85, 1.0)[zi % 4]
+                col = [((zi * 37) % 256) / 255.0 * a, ((zi * 91) % 256) / 255.0 * a, ((zi * 53) % 256) / 255.0 * a, a]
+                ud = ((1, 5, 4)[zi % 3] | (1 << 16), 0, int(round(opacity * 65535.0)), 0)
+            spec = frame.gpu_cache.push([col, [0.0, 0.0, 0.0, 0.0], [st[0], st[1], 0.0, 0.0]])
             ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zi + 1, spec, tid, task, ud)
             ct = clip_tasks[zi]
             clip_addr = CLIP_TASK_EMPTY if ct is None else frame.add_render_task(ct[0], 1.0, ct[1])
             al.append(frame.brush_instance(ph, clip_addr, brush_flags=flags, edge_flags=15, resource_address=addr))
         if al:
-            target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(al, dtype=np.int32), "PremultipliedAlpha", "alpha",
+            target.alpha.append(Step(key, "PRIM_INSTANCES", np.array(al, dtype=np.int32), "SubpixelDualSource" if dual else "PremultipliedAlpha", "alpha",
                                      textures={0: t_atlas, 9: t_mask} if masked else {0: t_atlas}))
         targets.append(target)
         rect = (float(x0), float(y0), float(x1), float(y1))
