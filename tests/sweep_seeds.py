@@ -45,6 +45,25 @@ FAMILIES = {
     "yuv_grid": lambda s: scenes.yuv_grid(seed=s),
     "image_repeat": lambda s: scenes.image_repeat(seed=s),
     "masked_rects_aa": lambda s: scenes.masked_rects(force_aa=True, fractional=True, seed=s),
+    # off-screen families (every read-back target is compared)
+    "border_solid": lambda s: scenes.border_solid(seed=s),
+    "border_segments": lambda s: scenes.border_segments(seed=s),
+    "cache_decorations": lambda s: scenes.cache_decorations(seed=s, n_rgrads=10, n_cgrads=10),
+    "svg_filters": lambda s: scenes.svg_filters(seed=s),
+    "svg_filter_nodes": lambda s: scenes.svg_filters(node=True, seed=s),
+    "texture_cache_copies": lambda s: scenes.texture_cache_copies(seed=s),
+    "yuv_composites": lambda s: scenes.yuv_composites(seed=s),
+    "yuv_composites_nv12": lambda s: scenes.yuv_composites(seed=s, planar=False),
+    "scaled_composites": lambda s: scenes.scaled_composites(seed=s),
+    "yuv_grid_hdr": lambda s: scenes.yuv_grid(seed=s, hdr=True),
+    "image_grid_masked": lambda s: scenes.image_grid(seed=s, masked=True),
+    "filter_grid_masked": lambda s: scenes.filter_grid(seed=s, masked=True),
+    "opacity": lambda s: scenes.filter_grid(seed=s, shader="opacity"),
+    "texture_rect_images": lambda s: scenes.texture_rect(scenes.image_grid(seed=s)),
+    "texture_rect_composites": lambda s: scenes.texture_rect(scenes.scaled_composites(seed=s)),
+    "cfg5": lambda s: scenes.cfg5_many_rects(width=1024, height=768, n=4000, seed=s),
+    "cfg3_modes": lambda s: scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, color_modes=(0, 1, 2, 3), seed=s),
+    "cfg3_dual": lambda s: scenes.cfg3_text(width=1024, height=512, lines=20, glyphs_per_line=60, run_len=12, color_modes=(1, 2), dual_source=True, seed=s),
 }
 
 
@@ -62,6 +81,8 @@ def main():
             except Exception as e:      # a scene builder that does not take the seed / raises
                 print(f"{name} seed {s}: {type(e).__name__}: {e}", flush=True)
                 continue
+            if isinstance(want, dict):
+                want, got = np.concatenate([want[k].ravel() for k in sorted(want)]), np.concatenate([got[k].ravel() for k in sorted(want)])
             d = int((got != want).sum())
             if d or st["gl_error"]:
                 bad += 1
