@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../webrender_amd/csrc"
 mkdir -p build/$name ../../ab
 HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -mllvm -structurizecfg-skip-uniform-regions"
 objs=""
-for g in host 1 2 3 4 5 6 7; do
+for g in host 1 2 3 4 5 6 7 8; do
   if [[ " $* " == *" $g "* ]]; then
     if [ $g = host ]; then /opt/rocm/bin/hipcc $HIPFLAGS $flags -c wrhip.hip -o build/$name/wrhip.o & objs="$objs build/$name/wrhip.o"
     else /opt/rocm/bin/hipcc $HIPFLAGS $flags -DWR_INST_GROUP=$g -c wrhip_inst.hip -o build/$name/wrhip_inst_$g.o & objs="$objs build/$name/wrhip_inst_$g.o"; fi

@@ -1682,7 +1682,7 @@ void flush_work(const std::vector<int>& sel_in) {
         if (cw > 0 && ch > 0 && d.count > 0) {
           d.flags |= WR_DF_MASK_ROWS;
           mr_slots += (uint64_t)d.count; mr_rows += (uint64_t)d.count * ch * 1;      // work items: rows x parts
-          mr_bytes += (uint64_t)d.count * ((uint64_t)((cw + 7) & ~3) * ch + (uint64_t)ch * 4 + 32);      // rows + row map
+          mr_bytes += (uint64_t)d.count * ((uint64_t)((cw + 7) & ~3) * ch + (uint64_t)ch * 4 + 48 + sizeof(WrAccTabs));      // rows + row map + row-sum tables
           L.mr_rows += (uint64_t)d.count * ch * 1;
         }
       }
@@ -3201,6 +3201,10 @@ WrhipContext* CreateContext(void) {
 #ifdef WR_CELL_TIMING
   static bool reg = false;
   if (!reg) { reg = true; atexit(wr_dump_cell_times); }
+#endif
+#ifdef WR_ROWS_TIMING
+  static bool reg3 = false;
+  if (!reg3) { reg3 = true; atexit(wr_dump_rows_times); }
 #endif
 #ifdef WRHIP_TIMING
   static bool reg2 = false;

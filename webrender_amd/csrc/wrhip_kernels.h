@@ -66,6 +66,7 @@ WR_DEVICE wr_u4 wr_load16(const void* p) {
   return r;
 }
 WR_DEVICE float wr_bits_f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+WR_DEVICE uint32_t wr_float_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 WR_DEVICE void wr_store16(float* p, float a, float b, float c, float d) {      // p: 16-byte aligned
 #ifdef WRHIP_HOSTSIM
   p[0] = a; p[1] = b; p[2] = c; p[3] = d;
@@ -297,6 +298,124 @@ WR_DEVICE float wr_accum_short(float s0, float step, int c) {
 WR_DEVICE float wr_row_interp(float s0, float step, int k, bool linear) {
   if (linear) return float(double(s0) + double(k) * double(step));
   return wr_accum(s0, step, k);
+}
+
+// ---- row-sum tables (WrAccTab, wrhip_types.h) ----
+// wr_accum's closed form, when it provably equals the sequential sum (see wr_accum): true and `out` set
+WR_DEVICE bool wr_accum_closed(float s0, float step, int c, float& out) {
+  if (c <= 0 || step == 0.0f) { out = s0; return true; }
+  if (c >= (1 << 24)) return false;
+  const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
+  const int g = g0 < g1 ? g0 : g1;
+  const float end = fmaf(float(c), step, s0);
+  const float a0 = fabsf(s0), a1 = fabsf(end);
+  const float bound = a0 > a1 ? a0 : a1;
+  uint32_t bb; __builtin_memcpy(&bb, &bound, 4);
+  const int be = int((bb >> 23) & 0xFF) - 127;
+  if (g > -900 && g < 100 && be + 1 <= g + 24 && be < 127) { out = end; return true; }
+  return false;
+}
+// The pieces of k -> s0 + step + .. + step (k adds) for k in [0, kmax]: the walk of wr_accum_binades, recorded.  A piece ends where
+// the plain add leaves the line its analysis predicted (a binade boundary, a rounding tie, zero / denormal sums: those rows are
+// pieces of their own), so the table is exact by construction wherever the bulk step is (tests/test_accum.py holds both to the
+// plain loop).  Returns the number of pieces, 0 when they do not fit.
+WR_DEVICE int wr_acctab_build(float s0, float step, int kmax, WrAccTab* T) {
+  float s = s0;
+  int k = 0, n = 0;
+  uint32_t db; __builtin_memcpy(&db, &step, 4);
+  const int ed = int((db >> 23) & 0xFF);
+  const uint32_t md = (db & 0x7FFFFFu) | 0x800000u;
+  while (k <= kmax) {
+    if (n == WR_ACCTAB_N) return 0;
+    uint32_t b; __builtin_memcpy(&b, &s, 4);
+    const int ex = int((b >> 23) & 0xFF);
+    const int sh = ex - ed;
+    bool single = ex == 0 || ex == 0xFF || ed == 0 || ed == 0xFF || sh < 0;
+    uint32_t q = 0;
+    if (!single) {
+      if (sh == 0) q = md;
+      else if (sh > 25) q = 0;
+      else {
+        const uint32_t half = 1u << (sh - 1), rem = md & ((1u << sh) - 1u);
+        q = md >> sh;
+        if (rem > half) q++;
+        else if (rem == half) single = true;
+      }
+    }
+    const bool up = ((b ^ db) >> 31) == 0;
+    const uint32_t S = (b & 0x7FFFFFu) | 0x800000u;
+    if (!single && q == 0) {
+      if (S == 0x800000u && !up) single = true;       // the binade floor, moving down: a finer grid below
+      else { T->k[n] = k; T->s[n] = b; T->q[n] = 0; return n + 1; }      // the sum no longer moves
+    }
+    T->k[n] = k; T->s[n] = b; T->q[n] = single ? 0 : (up ? int32_t(q) : -int32_t(q));
+    n++;
+    if (single) { s = s + step; k++; continue; }
+    const uint32_t dist = up ? (0x1000000u - S) : (S - 0x800000u);
+    const int nb = int(float(dist) / float(q)) - 3;
+    if (nb >= 1 && k < kmax) {
+      const int steps = nb > kmax - k ? kmax - k : nb;
+      const uint32_t S2 = up ? S + uint32_t(steps) * q : S - uint32_t(steps) * q;
+      const uint32_t nbits = (b & 0xFF800000u) | (S2 & 0x7FFFFFu);
+      __builtin_memcpy(&s, &nbits, 4);
+      k += steps;
+    }
+    // plain adds for as long as they stay on this piece's line
+    for (;;) {
+      if (k >= kmax) return n;
+      uint32_t bc; __builtin_memcpy(&bc, &s, 4);
+      const float s2 = s + step;
+      uint32_t b2; __builtin_memcpy(&b2, &s2, 4);
+      const uint32_t Sc = (bc & 0x7FFFFFu) | 0x800000u, Sn = (b2 & 0x7FFFFFu) | 0x800000u;
+      const bool on_line = (b2 >> 23) == (bc >> 23) && Sn == (up ? Sc + q : Sc - q);
+      s = s2; k++;
+      if (!on_line) break;
+    }
+  }
+  return n;
+}
+WR_DEVICE float wr_acctab_eval(const WrAccTab* T, int n, int k) {
+  int j = 0;
+#pragma unroll 8
+  for (int i = 1; i < WR_ACCTAB_N; i++) if (i < n && T->k[i] <= k) j = i;
+  const uint32_t b = T->s[j];
+  const int32_t q = T->q[j];
+  if (q == 0) return wr_bits_f(b);
+  const uint32_t S = ((b & 0x7FFFFFu) | 0x800000u) + uint32_t((k - T->k[j]) * q);
+  return wr_bits_f((b & 0xFF800000u) | (S & 0x7FFFFFu));
+}
+// sum i of a mask prim at row k: closed form, the prim's table, or the walk
+WR_DEVICE float wr_acc_row(const WrAccTabs* T, int i, float s0, float step, int k, bool linear) {
+  if (linear) return float(double(s0) + double(k) * double(step));
+  float r;
+  if (wr_accum_closed(s0, step, k, r)) return r;
+  if (T) {
+    const int t = T->ref[i], n = T->n[t];
+    if (n > 0) return wr_acctab_eval(&T->tab[t], n, k);
+  }
+  return wr_accum_binades(s0, step, k);
+}
+// the setup stage's side: the tables of a prim's `nsums` (4 or 8) interpolants over rows [0, kmax].  Sums come in left / right pairs
+// (i, i + 2) that are equal on axis-aligned prims: the right one then reads the left one's table.  (The arrays are only ever indexed
+// by constants -- a select chain picks sum i -- so they stay in registers: no scratch in the kernels that carry the setup stage.)
+WR_DEVICE float wr_pick8(const float (&a)[8], int i) {
+  return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : i == 4 ? a[4] : i == 5 ? a[5] : i == 6 ? a[6] : a[7];
+}
+WR_DEVICE void wr_acctabs_build(WrAccTabs* T, int nsums, const float (&s0)[8], const float (&st)[8], int kmax, bool uv_linear) {
+  for (int p = 0; p < 4; p++) {
+    const int iL = (p & 1) + 4 * (p >> 1), iR = iL + 2;
+    T->n[iL] = 0; T->ref[iL] = iL; T->n[iR] = 0; T->ref[iR] = iR;
+    if (iL >= nsums || (uv_linear && iL < 4)) continue;
+    const float aL = wr_pick8(s0, iL), dL = wr_pick8(st, iL), aR = wr_pick8(s0, iR), dR = wr_pick8(st, iR);
+    float r;
+    int nL = 0;
+    if (!wr_accum_closed(aL, dL, kmax, r)) {           // (closed at kmax: closed at every row before it)
+      nL = wr_acctab_build(aL, dL, kmax, &T->tab[iL]);
+      T->n[iL] = nL;
+    }
+    if (wr_float_bits(aL) == wr_float_bits(aR) && wr_float_bits(dL) == wr_float_bits(dR)) { T->ref[iR] = iL; continue; }
+    if (!wr_accum_closed(aR, dR, kmax, r)) T->n[iR] = wr_acctab_build(aR, dR, kmax, &T->tab[iR]);
+  }
 }
 
 // round_pixel (portable path): cast(v * 255 + 0.5), glsl.h:732-744
@@ -3337,6 +3456,149 @@ WR_DEVICE void wr_linear_span_pixel(const WrTexDesc& t, const float (&q)[4], con
   for (int c = 0; c < NCH; c++) out[c] = (int16_t)(a[c] + (int16_t)(((int16_t)((b[c] - a[c]) * fch[k])) >> 7));
 }
 
+// blendTextureLinear (above) for ALL pixels of an R8 run of `span` pixels, dealt out to the lanes by CHUNK (four pixels): lane
+// `wl` of `ws` takes chunks wl, wl + ws, ..  Where a chunk's coordinates come out of a chain of `uv += uv_step` adds -- the
+// fallback's lead-in / lead-out and the upscale filter -- every lane steps the chain itself (wave-uniform values: plain adds,
+// exactly the reference's loop) and keeps the values at its own chunk, instead of one wr_accum walk per pixel and interpolant:
+// the mask rows of a box shadow spent 70 k of a corner-band row's 90 k cycles in those walks (profiles/r06_a_rows_times.txt).
+// emit(n, v, count): the values of pixels n .. n + count - 1 of the run (count <= 4).  Same bytes as wr_linear_span_pixel<1>
+// pixel by pixel (tests: the mask-row cases run both, WRHIP_NO_MASK_ROWS=1 takes the per-pixel one in the bins).
+template <class Emit>
+WR_DEVICE void wr_linear_span_lanes_r8(const WrTexDesc& t, const float (&q)[4], const float (&qy)[4], float stepx, float stepy,
+                                       float minx, float maxx, float miny, float maxy, int filter, int span, int wl, int ws, Emit&& emit) {
+  int before = 0, inside = 0;
+  float U[4] = {q[0], q[1], q[2], q[3]};
+  if (filter != 1) {
+    const float beforeDist = wr_max(0.0f, minx) - U[0];
+    if (beforeDist > 0.0f) {
+      before = wr_iclamp(int(ceilf(beforeDist / stepx)) * 4, 0, span);
+      const float adv = float(before / 4) * stepx;
+      for (int i = 0; i < 4; i++) U[i] += adv;
+    }
+    const float insideDist = wr_min(maxx, float((t.width - 4) * 128)) - U[0];
+    if (stepx > 0.0f && insideDist >= stepx) {
+      inside = span - before;
+      if (filter == 4) inside = wr_imin(int(insideDist * (0.5f / 128.0f)) & ~3, inside);
+      else if (filter == 2) inside = wr_imin(int(insideDist / stepx) * 4, inside);
+      else inside = wr_imin(int(insideDist * (1.0f / 128.0f)) & ~3, inside);
+      if (inside < 0) inside = 0;
+    }
+  } else before = span;
+  // blendTextureLinearFallback over pixels [n0, n1) of the run, its chains starting from (bx, qy)
+  auto fallback = [&](const float (&bx)[4], int n0, int n1) {
+    const int nch = (n1 - n0 + 3) >> 2;
+    float u[4] = {bx[0], bx[1], bx[2], bx[3]}, v[4] = {qy[0], qy[1], qy[2], qy[3]};
+    for (int c0 = 0; c0 < nch; c0 += ws) {
+      const int mine = c0 + wl, end = wr_imin(c0 + ws, nch);
+      float mu[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int c = c0; c < end; c++) {
+        if (c == mine) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) { mu[i] = u[i]; mv[i] = v[i]; }
+        }
+        if (stepx != 0.0f) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) u[i] = u[i] + stepx;
+        }
+        if (stepy != 0.0f) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[i] = v[i] + stepy;
+        }
+      }
+      if (mine < end) {
+        int out[4] = {0, 0, 0, 0};
+        const int cnt = wr_imin(4, n1 - n0 - 4 * mine);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k >= cnt) break;
+          int o[4];
+          wr_bilinear<1>(t, int(wr_clamp(mu[k], minx, maxx)), int(wr_clamp(mv[k], miny, maxy)), o);
+          out[k] = o[0];
+        }
+        emit(n0 + 4 * mine, out, cnt);
+      }
+    }
+  };
+  if (before > 0) fallback(q, 0, before);
+  if (inside > 0) {
+    const int iq0y = int(wr_clamp(qy[0], miny, maxy));
+    const int iy = iq0y >> 7, fracy = iq0y & 0x7F;
+    const size_t rowy = (size_t)wr_clamp_coord(iy, t.height) * t.stride;
+    const size_t nexty = (iy >= 0 && iy < t.height - 1) ? t.stride : 0;
+    const int nch = inside >> 2;
+    if (filter == 3 || filter == 4) {
+      // blendTextureLinearFast / Downscale: constant fractions from lane 0 of the run start; no chain
+      const int iq0 = int(wr_clamp(U[0], minx, maxx));
+      const int ix = iq0 >> 7;
+      const int fracx = wr_frac_x(t, ix, iq0);
+      const size_t row0 = rowy + wr_clamp_coord(ix, t.width - 1), row1 = row0 + nexty;
+      for (int m = wl; m < nch; m += ws) {
+        int out[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int j = 4 * m + k;
+          const ptrdiff_t x = filter == 3 ? j : 2 * j;
+          int a[4], b[4];
+          wr_row_lerp<1>(t, row0, row1, x, fracy, a);
+          wr_row_lerp<1>(t, row0, row1, x + 1, fracy, b);
+          out[k] = (int16_t)(a[0] + (int16_t)(((int16_t)((b[0] - a[0]) * fracx)) >> 7));
+        }
+        emit(before + 4 * m, out, 4);
+      }
+    } else {
+      // blendTextureLinearUpscale: chunk m samples at U advanced m times (and the next chunk's first column)
+      float u[4] = {U[0], U[1], U[2], U[3]};
+      const size_t row0 = rowy, row1 = rowy + nexty;
+      for (int c0 = 0; c0 < nch; c0 += ws) {
+        const int mine = c0 + wl, end = wr_imin(c0 + ws, nch);
+        float mu[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nx0 = 0.0f;
+        for (int c = c0; c < end; c++) {
+          if (c == mine) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) mu[i] = u[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) u[i] = u[i] + stepx;
+          if (c == mine) nx0 = u[0];
+        }
+        if (mine < end) {
+          int ich[4], fch[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            if (mine == 0) {
+              const int iq = int(wr_clamp(mu[i], minx, maxx));
+              ich[i] = iq >> 7; fch[i] = wr_frac_x(t, ich[i], iq);
+            } else {
+              const int iq = int(mu[i]);
+              ich[i] = iq >> 7; fch[i] = iq & 0x7F;
+            }
+          }
+          const int ixn0 = int(nx0) >> 7;
+          int S[4] = {0, 1, 2, 3}, N[4] = {1, 2, 3, 4};
+          if (ich[1] == ich[0]) { S[3] = S[2]; S[2] = S[1]; S[1] = S[0]; N[3] = N[2]; N[2] = N[1]; N[1] = N[0]; }
+          if (ich[2] == ich[1]) { S[3] = S[2]; S[2] = S[1]; N[3] = N[2]; N[2] = N[1]; }
+          if (ich[3] == ich[2]) { S[3] = S[2]; N[3] = N[2]; }
+          int out[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            int a[4], b[4];
+            wr_row_lerp<1>(t, row0, row1, (ptrdiff_t)ich[0] + S[k], fracy, a);
+            if (N[k] < 4) wr_row_lerp<1>(t, row0, row1, (ptrdiff_t)ich[0] + N[k], fracy, b);
+            else wr_row_lerp<1>(t, row0, row1, (ptrdiff_t)ixn0 + (ixn0 == ich[3] ? 1 : 0), fracy, b);
+            out[k] = (int16_t)(a[0] + (int16_t)(((int16_t)((b[0] - a[0]) * fch[k])) >> 7));
+          }
+          emit(before + 4 * mine, out, 4);
+        }
+      }
+    }
+  }
+  if (before + inside < span) {
+    const float adv = float(inside / 4) * stepx;
+    const float bx[4] = {U[0] + adv, U[1] + adv, U[2] + adv, U[3] + adv};
+    fallback(bx, before + inside, span);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Raster stage.  Lane l of wave w in the workgroup of bin (bx,by) owns pixels
 //   x = 64*bx + 4*(l & 15) + i,   y = 64*by + 16*w + (l >> 4) + 4*j,  i,j in 0..3
@@ -4192,17 +4454,17 @@ WR_DEVICE float wr_step01(float edge, float x) { return x >= edge ? 1.0f : 0.0f;
 // by the in-raster evaluation) ----
 // row interpolants of a cs_clip_box_shadow prim: c = 0,1 vUv; 2,3 vLocalPos.xy
 struct WrRowVals { float o[4], s[4]; };
-WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
+WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y, const WrAccTabs* tabs = nullptr) {
   WrRowVals rv;
   const int k = y - P.y0;
   const bool lin = P.rows_linear != 0;     // (the vLocalPos interpolants share the uv ones' linearity in practice; wr_accum checks)
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float start = float(P.x0) + 0.5f - P.xl;
-  const float L0 = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
-  const float R0 = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
-  const float L2 = wr_accum(B.lpL0[0], B.lpLs[0], k), L3 = wr_accum(B.lpL0[1], B.lpLs[1], k);
-  const float R2 = wr_accum(B.lpR0[0], B.lpRs[0], k), R3 = wr_accum(B.lpR0[1], B.lpRs[1], k);
+  const float L0 = wr_acc_row(tabs, 0, P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_acc_row(tabs, 1, P.uvL0[1], P.uvLs[1], k, lin);
+  const float R0 = wr_acc_row(tabs, 2, P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_acc_row(tabs, 3, P.uvR0[1], P.uvRs[1], k, lin);
+  const float L2 = wr_acc_row(tabs, 4, B.lpL0[0], B.lpLs[0], k, false), L3 = wr_acc_row(tabs, 5, B.lpL0[1], B.lpLs[1], k, false);
+  const float R2 = wr_acc_row(tabs, 6, B.lpR0[0], B.lpRs[0], k, false), R3 = wr_acc_row(tabs, 7, B.lpR0[1], B.lpRs[1], k, false);
   rv.s[0] = (R0 - L0) * stepScale; rv.o[0] = L0 + rv.s[0] * start;
   rv.s[1] = (R1 - L1) * stepScale; rv.o[1] = L1 + rv.s[1] * start;
   rv.s[2] = (R2 - L2) * stepScale; rv.o[2] = L2 + rv.s[2] * start;
@@ -4214,7 +4476,7 @@ WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y) {
 // The same for a row the whole wave works on (wr_mask_rows_body: y is wave-uniform): the eight sums -- each a walk over the
 // binades its running sum passes through when the closed form does not apply, ~5 k cycles -- are taken by eight lanes at once
 // instead of one after the other on values every lane holds (measured: 38 k of a box-shadow row's 118 k cycles, cfg4).
-WR_DEVICE WrRowVals wr_box_row_vals_wave(const WrPrim& P, const WrBoxRec& B, int y, int lane) {
+WR_DEVICE WrRowVals wr_box_row_vals_wave(const WrPrim& P, const WrBoxRec& B, int y, int lane, const WrAccTabs* tabs = nullptr) {
   WrRowVals rv;
   const int k = y - P.y0;
   const bool lin = P.rows_linear != 0;
@@ -4224,7 +4486,7 @@ WR_DEVICE WrRowVals wr_box_row_vals_wave(const WrPrim& P, const WrBoxRec& B, int
   const int i = lane & 7;
   const float s0 = i == 0 ? P.uvL0[0] : i == 1 ? P.uvL0[1] : i == 2 ? P.uvR0[0] : i == 3 ? P.uvR0[1] : i == 4 ? B.lpL0[0] : i == 5 ? B.lpL0[1] : i == 6 ? B.lpR0[0] : B.lpR0[1];
   const float st = i == 0 ? P.uvLs[0] : i == 1 ? P.uvLs[1] : i == 2 ? P.uvRs[0] : i == 3 ? P.uvRs[1] : i == 4 ? B.lpLs[0] : i == 5 ? B.lpLs[1] : i == 6 ? B.lpRs[0] : B.lpRs[1];
-  const float r = wr_row_interp(s0, st, k, lin && i < 4);
+  const float r = wr_acc_row(tabs, i, s0, st, k, lin && i < 4);
   const float L0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)), L1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 1));
   const float R0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 2)), R1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 3));
   const float L2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 4)), L3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 5));
@@ -4341,12 +4603,13 @@ WR_DEVICE bool wr_box_keys_equal(const WrBoxKey& a, const WrBoxKey& b) {
 // lane order: slots stay sorted by first row), the first requesting lane swaps ONCE for all of them, and every lane takes its share;
 // only when the wave's total does not fit do the lanes ask one by one for what still does.
 WR_DEVICE void wr_mask_rows_take(const WrTargetDesc& T, unsigned long long ns, unsigned long long nr, unsigned long long nb, uint32_t pitch,
-                                 const WrBoxKey& key, int gid, int target, WrRec* __restrict__ recs) {
+                                 uint32_t tabs16, int gid, int target, WrRec* __restrict__ recs, int& slot_out) {
   WrMaskSlot sl;
   sl.prim = gid; sl.target = target; sl.row0 = uint32_t(nr); sl.pitch = pitch; sl.off16 = uint32_t(nb);
-  sl.pad[0] = 1u; sl.pad[1] = sl.pad[2] = 0;          // (pad[0]: waves sharing a row -- measured on cfg4's 1840-pixel rows: 2 or 4 lose, 99 -> 138 us)
-  sl.key = key;
+  sl.pad[0] = 1u; sl.pad[1] = tabs16; sl.pad[2] = 0;  // (pad[0]: waves sharing a row -- measured on cfg4's 1840-pixel rows: 2 or 4 lose, 99 -> 138 us)
+  sl.key.valid = 0;                                   // (the caller fills the key in once the prim's row-sum tables exist)
   T.mr_slots[ns] = sl;
+  slot_out = int(ns);
   const unsigned long long addr = (unsigned long long)(T.mr_store + nb * 16);
   recs[gid].kbf = (recs[gid].kbf & ~0xFFu) | WR_PK_MASK_ROWS;
   recs[gid].c0 = uint32_t(addr); recs[gid].c1 = uint32_t(addr >> 32); recs[gid].z = pitch;
@@ -4363,8 +4626,9 @@ WR_DEVICE bool wr_mask_rows_cas(const WrTargetDesc& T, unsigned long long slots,
     old = seen;
   }
 }
-WR_DEVICE void wr_mask_rows_reserve(const WrTargetDesc* T, uint32_t rows, uint32_t pitch, unsigned long long n16, const WrBoxKey& key,
-                                    int gid, int target, WrRec* __restrict__ recs) {
+WR_DEVICE void wr_mask_rows_reserve(const WrTargetDesc* T, uint32_t rows, uint32_t pitch, unsigned long long n16, uint32_t tabs16,
+                                    int gid, int target, WrRec* __restrict__ recs, int& slot_out) {
+  slot_out = -1;
 #ifndef WRHIP_HOSTSIM
   const int lane = threadIdx.x & 63;
   const unsigned long long m = __ballot(T != nullptr);
@@ -4388,14 +4652,14 @@ WR_DEVICE void wr_mask_rows_reserve(const WrTargetDesc* T, uint32_t rows, uint32
   if (ok) {
     const unsigned long long b = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, lead) |
                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), lead) << 32);
-    if (T) wr_mask_rows_take(*T, (b >> 48) + pre_slots, ((b >> 28) & 0xFFFFFull) + pre_rows, (b & 0xFFFFFFFull) + pre_n16, pitch, key, gid, target, recs);
+    if (T) wr_mask_rows_take(*T, (b >> 48) + pre_slots, ((b >> 28) & 0xFFFFFull) + pre_rows, (b & 0xFFFFFFFull) + pre_n16, pitch, tabs16, gid, target, recs, slot_out);
     return;
   }
 #endif
   // (the host simulation's one thread at a time; a wave whose requests do not fit together)
   if (T) {
     unsigned long long base;
-    if (wr_mask_rows_cas(*T, 1, rows, n16, base)) wr_mask_rows_take(*T, base >> 48, (base >> 28) & 0xFFFFFull, base & 0xFFFFFFFull, pitch, key, gid, target, recs);
+    if (wr_mask_rows_cas(*T, 1, rows, n16, base)) wr_mask_rows_take(*T, base >> 48, (base >> 28) & 0xFFFFFull, base & 0xFFFFFFFull, pitch, tabs16, gid, target, recs, slot_out);
   }
 }
 
@@ -4423,8 +4687,7 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
   const WrTargetDesc* mr_T = nullptr;        // a mask prim's request for rows of the flush's mask-row store (below)
   uint32_t mr_rows = 0, mr_pitch = 0;
   unsigned long long mr_n16 = 0;
-  WrBoxKey mr_key;
-  mr_key.valid = 0;
+  uint32_t mr_tabs16 = 0;
   if (valid) {
     // The 32-byte record is all the bin raster reads of a prim that folded into `new = hi_bytes(dst * K + C)` (or was culled): its
     // 128-byte WrPrim stays unwritten -- 80 % of what the setup stage stored for a frame of plain rects (cfg5: 41 -> 9 MB).  The row
@@ -4441,14 +4704,11 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
         mr_T = &T;
         mr_rows = uint32_t(P.y1 - P.y0); mr_pitch = uint32_t(((P.x1 + 3) & ~3) - (P.x0 & ~3));
         // [row map: rows x u32, padded to 16 B][rows x pitch bytes]
+        // [row map: rows x u32, padded to 16 B][rows x pitch bytes][row-sum tables: WrAccTabs]
         const unsigned long long map16 = ((unsigned long long)mr_rows * 4 + 15) >> 4;
         mr_n16 = map16 + (((unsigned long long)mr_rows * mr_pitch + 15) >> 4);
-        // (the middle row's key of a box shadow: what the rows kernel compares every row's key with)
-        if (P.kind == WR_PK_BOX_SHADOW) {
-          const int yc = P.y0 + (int(mr_rows) >> 1);
-          const WrRowVals rvc = wr_box_row_vals(P, aux[gid].box, yc);
-          mr_key = wr_box_row_key(P, aux[gid].box, rvc, wr_box_row_setup(P, aux[gid].box, rvc));
-        }
+        mr_tabs16 = uint32_t(mr_n16);
+        mr_n16 += WR_ACCTABS_N16;
       }
     }
     // gradient tables' can_merge bitmap (WrGradRec::merge): here, ONCE, after the vertex stage's registers are dead (at its four
@@ -4495,7 +4755,25 @@ WR_DEVICE void wr_setup_body(const WrDrawDesc* __restrict__ draws, int n_draws,
       }
     }
   }
-  wr_mask_rows_reserve(mr_T, mr_rows, mr_pitch, mr_n16, mr_key, gid, draws[P.draw].target, recs);
+  int mr_slot = -1;
+  wr_mask_rows_reserve(mr_T, mr_rows, mr_pitch, mr_n16, mr_tabs16, gid, draws[P.draw].target, recs, mr_slot);
+  if (mr_slot >= 0) {
+    // The prim has its rows: its row-sum tables (one walk over the prim's rows per interpolant that needs one, here, instead of one
+    // per ROW in the rows kernel), then -- for a box shadow -- the key of its middle row, which the rows kernel compares every row's
+    // key with.  (After the reservation: the wave's lanes get here together.)
+    WrMaskSlot& sl = mr_T->mr_slots[mr_slot];
+    WrAccTabs* tabs = (WrAccTabs*)(mr_T->mr_store + ((size_t)sl.off16 + mr_tabs16) * 16);
+    const bool box = P.kind == WR_PK_BOX_SHADOW;
+    const WrBoxRec& B = aux[gid].box;
+    const float s0[8] = {P.uvL0[0], P.uvL0[1], P.uvR0[0], P.uvR0[1], box ? B.lpL0[0] : 0.0f, box ? B.lpL0[1] : 0.0f, box ? B.lpR0[0] : 0.0f, box ? B.lpR0[1] : 0.0f};
+    const float st[8] = {P.uvLs[0], P.uvLs[1], P.uvRs[0], P.uvRs[1], box ? B.lpLs[0] : 0.0f, box ? B.lpLs[1] : 0.0f, box ? B.lpRs[0] : 0.0f, box ? B.lpRs[1] : 0.0f};
+    wr_acctabs_build(tabs, box ? 8 : 4, s0, st, int(mr_rows) - 1, P.rows_linear != 0);
+    if (box) {
+      const int yc = P.y0 + (int(mr_rows) >> 1);
+      const WrRowVals rvc = wr_box_row_vals(P, B, yc, tabs);
+      sl.key = wr_box_row_key(P, B, rvc, wr_box_row_setup(P, B, rvc));
+    }
+  }
   {
     // gradient tables: copied into the flush's pool (wave-wide: wr_grad_tables_wave), then the can_merge bitmap (WrGradRec::merge) -- here, ONCE,
     // after the vertex stage's registers are dead (at its four call sites inside the vertex stages it cost every kernel that carries
@@ -6685,12 +6963,12 @@ struct WrRow4 { uint32_t v[4]; };
 // Edge::nextRow has accumulated after (y - y0) rows.  They are the same for every pixel of the
 // row, and a wave's strip has 16 rows, so the raster stage evaluates them once per wave with 16
 // row-owning lanes and hands them round with ds_bpermute (wr_apply_prim) instead of once per lane-row.
-WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y) {
+WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y, const WrAccTabs* tabs = nullptr) {
   WrRowVals rv;
   const int k = y - P.y0;
   const bool lin = P.rows_linear != 0;
-  const float Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
-  const float Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+  const float Lu = wr_acc_row(tabs, 0, P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_acc_row(tabs, 1, P.uvL0[1], P.uvLs[1], k, lin);
+  const float Ru = wr_acc_row(tabs, 2, P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_acc_row(tabs, 3, P.uvR0[1], P.uvRs[1], k, lin);
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float start = float(P.x0) + 0.5f - P.xl;
@@ -6701,14 +6979,14 @@ WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y) {
 }
 #ifndef WRHIP_HOSTSIM
 // (a row the whole wave works on: the four sums on four lanes at once, see wr_box_row_vals_wave)
-WR_DEVICE WrRowVals wr_clip_row_vals_wave(const WrPrim& P, int y, int lane) {
+WR_DEVICE WrRowVals wr_clip_row_vals_wave(const WrPrim& P, int y, int lane, const WrAccTabs* tabs = nullptr) {
   WrRowVals rv;
   const int k = y - P.y0;
   const bool lin = P.rows_linear != 0;
   const int i = lane & 3;
   const float s0 = i == 0 ? P.uvL0[0] : i == 1 ? P.uvL0[1] : i == 2 ? P.uvR0[0] : P.uvR0[1];
   const float st = i == 0 ? P.uvLs[0] : i == 1 ? P.uvLs[1] : i == 2 ? P.uvRs[0] : P.uvRs[1];
-  const float r = wr_row_interp(s0, st, k, lin);
+  const float r = wr_acc_row(tabs, i, s0, st, k, lin);
   const float Lu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)), Lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 1));
   const float Ru = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 2)), Rv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 3));
   float stepScale = 1.0f / (P.xr - P.xl);
@@ -7094,7 +7372,6 @@ WR_DEVICE void wr_fill_lanes(uint8_t* dst, int a, int b, uint32_t v, int lane, i
 WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const WrRowVals& rv, const WrBoxRow& br, int lane, uint8_t* dst,
                                        int part = 0, int parts = 1) {
   const int wl = lane + 64 * part, ws = 64 * parts;      // this wave's share of a run: pixels wl, wl + ws, ..
-  int tchunk = 0;                                         // transitional chunks go round the parts
   const WrTexDesc t{B.ptr, int(B.wh & 0xFFFF), int(B.wh >> 16), B.stride, (int16_t)B.format, (int16_t)B.linear, float(B.wh & 0xFFFF), float(B.wh >> 16)};
   float o4[4], s4[4];
 #pragma unroll
@@ -7144,19 +7421,27 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const
     wr_fill_lanes(dst, 0, nb, v_clear, wl, ws);
     R -= nb; pos += nb;
   }
+  // The transitional chunks (per-fragment mapping, a texture fetch each) of the walk are collected -- chunk number k goes to the four
+  // lanes 4 (k mod 16) .., which keep their pixel's interpolants -- and shaded together, sixteen chunks at a time: one after the other
+  // on four lanes they were a dependent fetch per chunk.
+  int tchunk = 0, tn = -1;                          // transitional chunks met so far; tn: the pixel this lane holds (-1: none)
+  float tv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto shade_held = [&]() {
+    if (tn >= 0) dst[tn] = (uint8_t)(uint32_t(wr_round_pixel(wr_box_shade(B, t, tv[0], tv[1], tv[2], tv[3]))) & 0xFFFF);
+    tn = -1;
+  };
   while (R > 0) {
-    const bool my_chunk = (tchunk % parts) == part;
-    tchunk++;
-    if (lane < 4 && my_chunk) {                      // transitional chunk: per-fragment mapping
-      const int n = pos + lane;
+    if (tchunk > 0 && (tchunk & 15) == 0) shade_held();
+    if (part == (tchunk >> 4) % parts && (lane >> 2) == (tchunk & 15)) {
+      const int n = pos + (lane & 3);
       if (n < span) {
         const int l4 = n & 3;
-        dst[n] = (uint8_t)(uint32_t(wr_round_pixel(wr_box_shade(B, t, wr_sel4(cur[0][0], cur[0][1], cur[0][2], cur[0][3], l4),
-                                                                 wr_sel4(cur[1][0], cur[1][1], cur[1][2], cur[1][3], l4),
-                                                                 wr_sel4(cur[2][0], cur[2][1], cur[2][2], cur[2][3], l4),
-                                                                 wr_sel4(cur[3][0], cur[3][1], cur[3][2], cur[3][3], l4)))) & 0xFFFF);
+        tn = n;
+#pragma unroll
+        for (int c = 0; c < 4; c++) tv[c] = wr_sel4(cur[c][0], cur[c][1], cur[c][2], cur[c][3], l4);
       }
     }
+    tchunk++;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
 #pragma unroll
@@ -7205,7 +7490,15 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const
       // position: every pixel of it gets what its first pixel gets (WrBoxRow::xc)
       const bool one_value = !centre && xcl && num_inside >= 8 && rv.s[1] == 0.0f;
       const int end = wr_imin(pos + num_inside, span);
-      // pixel j of the run, sampled like swgl_commitTextureLinear(R8, sColor0, uv, uv_bounds, NoColor/InvertColor, num_inside)
+      // the run, sampled like swgl_commitTextureLinear(R8, sColor0, uv, uv_bounds, NoColor/InvertColor, num_inside)
+      const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
+      float q[4], qy[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) { q[a] = pu[a] * W * qs + qo; qy[a] = pv[a] * H * qs + qo; }
+      const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
+      const float minx = wr_max(ub0 * W * qs + qo, 0.0f), miny = wr_max(ub1 * H * qs + qo, 0.0f);
+      const float maxx = wr_max(ub2 * W * qs + qo, minx), maxy = wr_max(ub3 * H * qs + qo, miny);
+      // pixel j of the run (the one value of a u-clamped run; nearest runs)
       auto run_pixel = [&](int j) -> uint32_t {
         int v;
         if (filter == 0) {
@@ -7216,13 +7509,6 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const
           const int minX = wr_iclamp(minUx, 0, t.width - 1), maxX = wr_iclamp(maxUx, minX, t.width - 1);
           v = ((const uint8_t*)t.ptr)[(size_t)srow * t.stride + wr_iclamp(ix + j, minX, maxX)];
         } else {
-          const float qs = 128.0f, qo = 0.5f - 0.5f * qs;
-          float q[4], qy[4];
-#pragma unroll
-          for (int a = 0; a < 4; a++) { q[a] = pu[a] * W * qs + qo; qy[a] = pv[a] * H * qs + qo; }
-          const float stepx = 4.0f * (q[1] - q[0]), stepy = 4.0f * (qy[1] - qy[0]);
-          const float minx = wr_max(ub0 * W * qs + qo, 0.0f), miny = wr_max(ub1 * H * qs + qo, 0.0f);
-          const float maxx = wr_max(ub2 * W * qs + qo, minx), maxy = wr_max(ub3 * H * qs + qo, miny);
           int o[4];
           wr_linear_span_pixel<1>(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, filter, num_inside, j, o);
           v = o[0];
@@ -7238,8 +7524,19 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const
         wr_fill_lanes(dst, pos, end, uint32_t(wr_round_pixel(((1.0f - texel) - texel) * mode + texel)) & 0xFFFF, lane + 64 * part, ws);
       } else if (one_value) {
         wr_fill_lanes(dst, pos, end, run_pixel(0), wl, ws);
-      } else {
+      } else if (filter == 0) {
         for (int n = pos + wl; n < end; n += ws) dst[n] = (uint8_t)run_pixel(n - pos);
+      } else {
+        // a chunk per lane, the chains of `uv += uv_step` stepped by the wave (wr_linear_span_lanes_r8)
+        uint8_t* const rdst = dst + pos;
+        const int rlen = end - pos;
+        wr_linear_span_lanes_r8(t, q, qy, stepx, stepy, minx, maxx, miny, maxy, filter, num_inside, wl, ws, [&](int n, const int (&v)[4], int cnt) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (k >= cnt || n + k >= rlen) break;
+            rdst[n + k] = (uint8_t)(mode != 0.0f ? 255 - v[k] : v[k]);
+          }
+        });
       }
       const float f = float(num_inside / 4);
 #pragma unroll
@@ -7250,17 +7547,18 @@ WR_DEVICE void wr_box_shadow_row_lanes(const WrPrim& P, const WrBoxRec& B, const
       R -= num_inside; pos += num_inside;
     }
   }
+  shade_held();
   wr_fill_lanes(dst, pos, span, v_clear, wl, ws);    // solid lead-out
 }
 // cs_clip_rectangle (cs_clip_rectangle.glsl:223-420): the row's five phases are closed forms of the chunk index, so the lanes
 // take a chunk each; a chunk in a solid phase is a constant
-WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int y, int lane, uint8_t* dst, int part = 0, int parts = 1) {
+WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int y, int lane, uint8_t* dst, int part = 0, int parts = 1, const WrAccTabs* tabs = nullptr) {
   const int wl = lane + 64 * part, ws = 64 * parts;
   const WrPrim& P = *Pp;
 #ifdef WRHIP_HOSTSIM
-  const WrRowVals rv = wr_clip_row_vals(P, y);
+  const WrRowVals rv = wr_clip_row_vals(P, y, tabs);
 #else
-  const WrRowVals rv = wr_clip_row_vals_wave(P, y, lane);      // (y is wave-uniform here)
+  const WrRowVals rv = wr_clip_row_vals_wave(P, y, lane, tabs);      // (y is wave-uniform here)
 #endif
   const WrClipRow cr = wr_clip_row_setup(P, *Cp, rv);
   const int len = P.x1 - P.x0, span = len >= 4 ? (len & ~3) : 0, S = span >> 2;
@@ -7289,7 +7587,8 @@ WR_DEVICE void wr_clip_rect_row_lanes(const WrPrim* Pp, const WrClipRec* Cp, int
 }
 #if defined(WR_ROWS_TIMING) && !defined(WRHIP_HOSTSIM)
 __device__ unsigned long long wr_rows_times[4096 * 8];      // debug build: phase timestamps of the first item of the launch's first 4096 waves
-#define WR_RT(i) do { if (lane == 0 && gw < 4096 && item == gw) wr_rows_times[gw * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+// (-DWR_ROWS_TIMING=1: rows of box-shadow prims only, =2: of clip-rectangle prims only -- the launches of a frame overwrite one another's records)
+#define WR_RT(i) do { wr_rt[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WR_RT(i) ((void)0)
 #endif
@@ -7309,12 +7608,15 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
   // the first 64 slots, one per lane, requested together with the allocation word: a launch of a few hundred rows is one
   // dependent-load chain per wave, every level of it a cold miss
   WrMaskSlot mine;
-  mine.prim = mine.target = 0; mine.row0 = 0xFFFFFFFFu; mine.pitch = mine.off16 = 0; mine.pad[0] = 1;
+  mine.prim = mine.target = 0; mine.row0 = 0xFFFFFFFFu; mine.pitch = mine.off16 = 0; mine.pad[0] = 1; mine.pad[1] = 0;
   if (lane < ns) mine = slots[lane];
 #endif
   for (int item = gw; item < rows_total; item += nwaves) {
     WrMaskSlot sl;
     int si;
+#if defined(WR_ROWS_TIMING) && !defined(WRHIP_HOSTSIM)
+    unsigned long long wr_rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     WR_RT(0);
 #ifndef WRHIP_HOSTSIM
     const unsigned long long le = __ballot(lane < ns && (int)mine.row0 <= item);
@@ -7325,6 +7627,7 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
       sl.row0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.row0, idx); sl.pitch = (uint32_t)__builtin_amdgcn_readlane((int)mine.pitch, idx);
       sl.off16 = (uint32_t)__builtin_amdgcn_readlane((int)mine.off16, idx);
       sl.pad[0] = (uint32_t)__builtin_amdgcn_readlane((int)mine.pad[0], idx);
+      sl.pad[1] = (uint32_t)__builtin_amdgcn_readlane((int)mine.pad[1], idx);
     } else
 #endif
     {
@@ -7347,6 +7650,7 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
     const int nrows = Pp->y1 - Pp->y0;
     const uint32_t rows_at = uint32_t((nrows * 4 + 15) & ~15);                     // the pixel rows follow the row map
     uint8_t* pbase = store + (size_t)sl.off16 * 16;
+    const WrAccTabs* tabs = sl.pad[1] ? (const WrAccTabs*)(pbase + (size_t)sl.pad[1] * 16) : nullptr;      // the prim's row-sum tables (setup stage)
     uint32_t my_off = rows_at + uint32_t(y - Pp->y0) * sl.pitch;
     WrRowVals brv;
     WrBoxRow bbr;
@@ -7355,9 +7659,9 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
       // in the slot by the setup stage) points at that row's bytes instead of being evaluated (wr_box_row_key)
       const int yc = Pp->y0 + (nrows >> 1);
 #ifdef WRHIP_HOSTSIM
-      brv = wr_box_row_vals(*Pp, aux[sl.prim].box, y);
+      brv = wr_box_row_vals(*Pp, aux[sl.prim].box, y, tabs);
 #else
-      brv = wr_box_row_vals_wave(*Pp, aux[sl.prim].box, y, lane);
+      brv = wr_box_row_vals_wave(*Pp, aux[sl.prim].box, y, lane, tabs);
 #endif
       WR_RT(3);
       bbr = wr_box_row_setup(*Pp, aux[sl.prim].box, brv);
@@ -7376,11 +7680,14 @@ WR_DEVICE void wr_mask_rows_body(const WrTargetDesc* __restrict__ targets, int b
     uint8_t* dst = pbase + my_off + (Pp->x0 & 3);
     WR_RT(5);
     if (Pp->kind == WR_PK_BOX_SHADOW) wr_box_shadow_row_lanes(*Pp, aux[sl.prim].box, brv, bbr, lane, dst, part, parts);
-    else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst, part, parts);
+    else wr_clip_rect_row_lanes(Pp, &aux[sl.prim].clip, y, lane, dst, part, parts, tabs);
     WR_RT(6);
 #if defined(WR_ROWS_TIMING) && !defined(WRHIP_HOSTSIM)
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0 && gw < 4096 && item == gw) wr_rows_times[gw * 8 + 7] = ((unsigned long long)(Pp->kind == WR_PK_BOX_SHADOW ? 1 : 0) << 56) | ((unsigned long long)(uint32_t)y << 32) | (uint32_t)(__builtin_readcyclecounter() & 0xFFFFFFFFu);
+    if (lane == 0 && gw < 4096 && item == gw && (WR_ROWS_TIMING + 0 == 0 || WR_ROWS_TIMING + 0 == (Pp->kind == WR_PK_BOX_SHADOW ? 1 : 2))) {
+      for (int i = 0; i < 7; i++) wr_rows_times[gw * 8 + i] = wr_rt[i];
+      wr_rows_times[gw * 8 + 7] = ((unsigned long long)(Pp->kind == WR_PK_BOX_SHADOW ? 1 : 0) << 56) | ((unsigned long long)(uint32_t)y << 32) | (uint32_t)(__builtin_readcyclecounter() & 0xFFFFFFFFu);
+    }
 #endif
   }
 }

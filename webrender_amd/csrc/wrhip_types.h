@@ -256,13 +256,27 @@ struct WrBoxKey {                // what decides the bytes of a cs_clip_box_shad
   float mv_mul, mv_div, in_mul, in_div;
   int32_t valid;
 };
+// Row-sum tables of a mask prim ("row-sum tables").  swgl steps a prim's edge interpolants once per row
+// (Edge::nextRow: s += step), so row k holds the k-fold sequential fp32 sum.  While that sum stays inside one binade every add moves
+// it by the same whole number q of ulps, so s_k is piecewise linear in k with one piece per binade the sum passes through: the setup
+// stage walks a prim's rows ONCE per interpolant and leaves the pieces here -- rows [k[j], k[j + 1]) hold significand(s[j]) + (k - k[j]) * q[j]
+// at s[j]'s sign and exponent (q 0: the value s[j] itself) --, and the rows kernel reads a row's sums off them instead of walking
+// the binades again for every row (20-33 k cycles per row, profiles/r06_b_rows_times.txt).
+#define WR_ACCTAB_N 32
+struct WrAccTab { int32_t k[WR_ACCTAB_N]; uint32_t s[WR_ACCTAB_N]; int32_t q[WR_ACCTAB_N]; };
+struct WrAccTabs {
+  int32_t n[8];                  // entries of tab[i] (0: none -- the closed form always applies, or the walk did not fit: wr_accum)
+  int32_t ref[8];                // the table sum i reads (an earlier sum with the same start and step, or i)
+  WrAccTab tab[8];               // cs_clip_box_shadow: uv L0/L1/R0/R1, local pos L0/L1/R0/R1; cs_clip_rectangle: uv L0/L1/R0/R1
+};
+#define WR_ACCTABS_N16 ((sizeof(WrAccTabs) + 15) / 16)
 struct WrMaskSlot {
   int32_t prim;                  // global prim index
   int32_t target;                // its target (the rows kernel of a raster launch only evaluates that launch's targets)
   uint32_t row0;                 // first work row of this prim in the flush-wide row numbering
   uint32_t pitch;                // bytes per stored row (multiple of 4)
   uint32_t off16;                // first stored row, in 16-byte units into mr_store
-  uint32_t pad[3];               // pad[0]: waves sharing a row (1: see the setup stage)
+  uint32_t pad[3];               // pad[0]: waves sharing a row (1: see the setup stage); pad[1]: the prim's WrAccTabs, in 16-byte units from its first byte in the store (0: none)
   WrBoxKey key;                  // cs_clip_box_shadow: key of the prim's middle row (rows equal to it are not evaluated)
 };
 // span rows (WrTargetDesc::rows_mode): pixels per lane and wave-sized pieces per row of a target of the given width (host and kernel agree)
