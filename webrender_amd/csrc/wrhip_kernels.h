@@ -259,21 +259,29 @@ __device__ __noinline__ float wr_accum_binades(float s0, float step, int c) {
   }
   return s;
 }
+// wr_accum's closed form, when it provably equals the sequential sum (see wr_accum): true and `out` set
+WR_DEVICE bool wr_accum_closed(float s0, float step, int c, float& out) {
+  // (straight-line on purpose: with early returns -- a wave-uniform `c >= 2^24` test inside the divergent `step != 0` region -- the
+  // build's -structurizecfg-skip-uniform-regions lost the "step == 0: closed" lanes' flag and sent them through the walk, one plain
+  // add per row: 600 k cycles for row 1838 of cfg4's shadow, profiles/r06_e_acc_walk.txt)
+  const bool trivial = c <= 0 || step == 0.0f;
+  const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
+  const int g = g0 < g1 ? g0 : g1;
+  const float end = fmaf(float(c), step, s0);
+  const float a0 = fabsf(s0), a1 = fabsf(end);
+  const float bound = a0 > a1 ? a0 : a1;
+  uint32_t bb; __builtin_memcpy(&bb, &bound, 4);
+  const int be = int((bb >> 23) & 0xFF) - 127;
+  const bool ok = (c < (1 << 24)) & (g > -900) & (g < 100) & (be + 1 <= g + 24) & (be < 127);
+  out = trivial ? s0 : end;
+  return trivial | ok;
+}
 WR_DEVICE float wr_accum(float s0, float step, int c) {
-  if (c <= 0 || step == 0.0f) return s0;
   // closed form when provably identical: s0 and step are multiples of 2^g and every partial sum stays
   // below 2^(g+24), so every add is exact and the result is the real number s0 + c*step -- which one
   // fused multiply-add delivers (single rounding of an exactly representable value).  fp32 / integer only.
-  if (c < (1 << 24)) {
-    const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
-    const int g = g0 < g1 ? g0 : g1;
-    const float end = fmaf(float(c), step, s0);
-    const float a0 = fabsf(s0), a1 = fabsf(end);
-    const float bound = a0 > a1 ? a0 : a1;
-    uint32_t bb; __builtin_memcpy(&bb, &bound, 4);
-    const int be = int((bb >> 23) & 0xFF) - 127;          // bound < 2^(be+1)
-    if (g > -900 && g < 100 && be + 1 <= g + 24 && be < 127) return end;
-  }
+  float r;
+  if (wr_accum_closed(s0, step, c, r)) return r;
   WR_DBG_PATH(2);
   return wr_accum_binades(s0, step, c);
 }
@@ -301,20 +309,6 @@ WR_DEVICE float wr_row_interp(float s0, float step, int k, bool linear) {
 }
 
 // ---- row-sum tables (WrAccTab, wrhip_types.h) ----
-// wr_accum's closed form, when it provably equals the sequential sum (see wr_accum): true and `out` set
-WR_DEVICE bool wr_accum_closed(float s0, float step, int c, float& out) {
-  if (c <= 0 || step == 0.0f) { out = s0; return true; }
-  if (c >= (1 << 24)) return false;
-  const int g0 = wr_low_bit_exp(s0), g1 = wr_low_bit_exp(step);
-  const int g = g0 < g1 ? g0 : g1;
-  const float end = fmaf(float(c), step, s0);
-  const float a0 = fabsf(s0), a1 = fabsf(end);
-  const float bound = a0 > a1 ? a0 : a1;
-  uint32_t bb; __builtin_memcpy(&bb, &bound, 4);
-  const int be = int((bb >> 23) & 0xFF) - 127;
-  if (g > -900 && g < 100 && be + 1 <= g + 24 && be < 127) { out = end; return true; }
-  return false;
-}
 // The pieces of k -> s0 + step + .. + step (k adds) for k in [0, kmax]: the walk of wr_accum_binades, recorded.  A piece ends where
 // the plain add leaves the line its analysis predicted (a binade boundary, a rounding tie, zero / denormal sums: those rows are
 // pieces of their own), so the table is exact by construction wherever the bulk step is (tests/test_accum.py holds both to the
@@ -374,47 +368,81 @@ WR_DEVICE int wr_acctab_build(float s0, float step, int kmax, WrAccTab* T) {
   }
   return n;
 }
+// (every k[] is fetched, four to a 16-byte load, whatever n is -- one round trip for the scan instead of a dependent load per entry;
+// the pieces are in row order, so the piece of row k is the number of valid entries at or below k, less one)
 WR_DEVICE float wr_acctab_eval(const WrAccTab* T, int n, int k) {
-  int j = 0;
-#pragma unroll 8
-  for (int i = 1; i < WR_ACCTAB_N; i++) if (i < n && T->k[i] <= k) j = i;
+  int cnt = 0;
+#pragma unroll
+  for (int g = 0; g < WR_ACCTAB_N / 4; g++) {
+    const wr_u4 v = wr_load16(&T->k[4 * g]);
+    cnt += ((4 * g + 0 < n) & (int(v.x) <= k)) + ((4 * g + 1 < n) & (int(v.y) <= k)) + ((4 * g + 2 < n) & (int(v.z) <= k)) + ((4 * g + 3 < n) & (int(v.w) <= k));
+  }
+  const int j = cnt > 0 ? cnt - 1 : 0;
   const uint32_t b = T->s[j];
   const int32_t q = T->q[j];
+  const int32_t kj = T->k[j];
   if (q == 0) return wr_bits_f(b);
-  const uint32_t S = ((b & 0x7FFFFFu) | 0x800000u) + uint32_t((k - T->k[j]) * q);
+  const uint32_t S = ((b & 0x7FFFFFu) | 0x800000u) + uint32_t((k - kj) * q);
   return wr_bits_f((b & 0xFF800000u) | (S & 0x7FFFFFu));
 }
-// sum i of a mask prim at row k: closed form, the prim's table, or the walk
-WR_DEVICE float wr_acc_row(const WrAccTabs* T, int i, float s0, float step, int k, bool linear) {
-  if (linear) return float(double(s0) + double(k) * double(step));
-  float r;
-  if (wr_accum_closed(s0, step, k, r)) return r;
-  if (T) {
-    const int t = T->ref[i], n = T->n[t];
-    if (n > 0) return wr_acctab_eval(&T->tab[t], n, k);
+// sum i of a mask prim at row k, from the prim's tables (mode 4 -- the sum of the other edge -- is the caller's business)
+WR_DEVICE float wr_acctabs_row(const WrAccTabs* T, int i, int k) {
+  // (header and k[] in one round trip: nothing below depends on a load before all of them are out)
+  const float s0 = T->s0[i], st = T->st[i];
+  const int n = T->n[i], mode = T->mode[i];
+  const WrAccTab* tb = &T->tab[i];
+  int cnt = 0;
+#pragma unroll
+  for (int g = 0; g < WR_ACCTAB_N / 4; g++) {
+    const wr_u4 v = wr_load16(&tb->k[4 * g]);
+    cnt += ((4 * g + 0 < n) & (int(v.x) <= k)) + ((4 * g + 1 < n) & (int(v.y) <= k)) + ((4 * g + 2 < n) & (int(v.z) <= k)) + ((4 * g + 3 < n) & (int(v.w) <= k));
   }
-  return wr_accum_binades(s0, step, k);
+  if (mode == 0) return (k <= 0 || st == 0.0f) ? s0 : fmaf(float(k), st, s0);
+  if (mode == 1) return float(double(s0) + double(k) * double(st));
+  if (mode == 2) {
+    const int j = cnt > 0 ? cnt - 1 : 0;
+    const uint32_t b = tb->s[j];
+    const int32_t q = tb->q[j], kj = tb->k[j];
+    if (q == 0) return wr_bits_f(b);
+    const uint32_t S = ((b & 0x7FFFFFu) | 0x800000u) + uint32_t((k - kj) * q);
+    return wr_bits_f((b & 0xFF800000u) | (S & 0x7FFFFFu));
+  }
+  WR_DBG_PATH(2);
+  return wr_accum(s0, st, k);
+}
+// the same for one thread that wants sum i whatever its mode (the setup stage's middle-row key, the host simulation's rows)
+WR_DEVICE float wr_acctabs_row_any(const WrAccTabs* T, int i, int k) {
+  return wr_acctabs_row(T, T->mode[i] == 4 ? i - 2 : i, k);
 }
 // the setup stage's side: the tables of a prim's `nsums` (4 or 8) interpolants over rows [0, kmax].  Sums come in left / right pairs
-// (i, i + 2) that are equal on axis-aligned prims: the right one then reads the left one's table.  (The arrays are only ever indexed
-// by constants -- a select chain picks sum i -- so they stay in registers: no scratch in the kernels that carry the setup stage.)
+// (i, i + 2) that are equal on axis-aligned prims: the right one is then marked as such.  (The arrays are only ever indexed by
+// constants -- a select chain picks sum i -- so they stay in registers: no scratch in the kernels that carry the setup stage.)
 WR_DEVICE float wr_pick8(const float (&a)[8], int i) {
   return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : i == 4 ? a[4] : i == 5 ? a[5] : i == 6 ? a[6] : a[7];
 }
 WR_DEVICE void wr_acctabs_build(WrAccTabs* T, int nsums, const float (&s0)[8], const float (&st)[8], int kmax, bool uv_linear) {
   for (int p = 0; p < 4; p++) {
     const int iL = (p & 1) + 4 * (p >> 1), iR = iL + 2;
-    T->n[iL] = 0; T->ref[iL] = iL; T->n[iR] = 0; T->ref[iR] = iR;
-    if (iL >= nsums || (uv_linear && iL < 4)) continue;
     const float aL = wr_pick8(s0, iL), dL = wr_pick8(st, iL), aR = wr_pick8(s0, iR), dR = wr_pick8(st, iR);
-    float r;
-    int nL = 0;
-    if (!wr_accum_closed(aL, dL, kmax, r)) {           // (closed at kmax: closed at every row before it)
-      nL = wr_acctab_build(aL, dL, kmax, &T->tab[iL]);
-      T->n[iL] = nL;
+    T->s0[iL] = aL; T->st[iL] = dL; T->s0[iR] = aR; T->st[iR] = dR;
+    T->n[iL] = 0; T->n[iR] = 0;
+    int mL = 0, mR = 0;
+    if (iL < nsums) {
+      float r;
+      if (uv_linear && iL < 4) mL = mR = 1;
+      else {
+        if (!wr_accum_closed(aL, dL, kmax, r)) {          // (closed at the last row: closed at every row before it)
+          const int nL = wr_acctab_build(aL, dL, kmax, &T->tab[iL]);
+          T->n[iL] = nL; mL = nL > 0 ? 2 : 3;
+        }
+        if (wr_float_bits(aL) == wr_float_bits(aR) && wr_float_bits(dL) == wr_float_bits(dR)) mR = 4;
+        else if (!wr_accum_closed(aR, dR, kmax, r)) {
+          const int nR = wr_acctab_build(aR, dR, kmax, &T->tab[iR]);
+          T->n[iR] = nR; mR = nR > 0 ? 2 : 3;
+        }
+      }
     }
-    if (wr_float_bits(aL) == wr_float_bits(aR) && wr_float_bits(dL) == wr_float_bits(dR)) { T->ref[iR] = iL; continue; }
-    if (!wr_accum_closed(aR, dR, kmax, r)) T->n[iR] = wr_acctab_build(aR, dR, kmax, &T->tab[iR]);
+    T->mode[iL] = mL; T->mode[iR] = mR;
   }
 }
 
@@ -4461,10 +4489,16 @@ WR_DEVICE WrRowVals wr_box_row_vals(const WrPrim& P, const WrBoxRec& B, int y, c
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float start = float(P.x0) + 0.5f - P.xl;
-  const float L0 = wr_acc_row(tabs, 0, P.uvL0[0], P.uvLs[0], k, lin), L1 = wr_acc_row(tabs, 1, P.uvL0[1], P.uvLs[1], k, lin);
-  const float R0 = wr_acc_row(tabs, 2, P.uvR0[0], P.uvRs[0], k, lin), R1 = wr_acc_row(tabs, 3, P.uvR0[1], P.uvRs[1], k, lin);
-  const float L2 = wr_acc_row(tabs, 4, B.lpL0[0], B.lpLs[0], k, false), L3 = wr_acc_row(tabs, 5, B.lpL0[1], B.lpLs[1], k, false);
-  const float R2 = wr_acc_row(tabs, 6, B.lpR0[0], B.lpRs[0], k, false), R3 = wr_acc_row(tabs, 7, B.lpR0[1], B.lpRs[1], k, false);
+  float L0, L1, R0, R1, L2, L3, R2, R3;
+  if (tabs) {
+    L0 = wr_acctabs_row_any(tabs, 0, k); L1 = wr_acctabs_row_any(tabs, 1, k); R0 = wr_acctabs_row_any(tabs, 2, k); R1 = wr_acctabs_row_any(tabs, 3, k);
+    L2 = wr_acctabs_row_any(tabs, 4, k); L3 = wr_acctabs_row_any(tabs, 5, k); R2 = wr_acctabs_row_any(tabs, 6, k); R3 = wr_acctabs_row_any(tabs, 7, k);
+  } else {
+    L0 = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin); L1 = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+    R0 = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin); R1 = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+    L2 = wr_accum(B.lpL0[0], B.lpLs[0], k); L3 = wr_accum(B.lpL0[1], B.lpLs[1], k);
+    R2 = wr_accum(B.lpR0[0], B.lpRs[0], k); R3 = wr_accum(B.lpR0[1], B.lpRs[1], k);
+  }
   rv.s[0] = (R0 - L0) * stepScale; rv.o[0] = L0 + rv.s[0] * start;
   rv.s[1] = (R1 - L1) * stepScale; rv.o[1] = L1 + rv.s[1] * start;
   rv.s[2] = (R2 - L2) * stepScale; rv.o[2] = L2 + rv.s[2] * start;
@@ -4486,7 +4520,14 @@ WR_DEVICE WrRowVals wr_box_row_vals_wave(const WrPrim& P, const WrBoxRec& B, int
   const int i = lane & 7;
   const float s0 = i == 0 ? P.uvL0[0] : i == 1 ? P.uvL0[1] : i == 2 ? P.uvR0[0] : i == 3 ? P.uvR0[1] : i == 4 ? B.lpL0[0] : i == 5 ? B.lpL0[1] : i == 6 ? B.lpR0[0] : B.lpR0[1];
   const float st = i == 0 ? P.uvLs[0] : i == 1 ? P.uvLs[1] : i == 2 ? P.uvRs[0] : i == 3 ? P.uvRs[1] : i == 4 ? B.lpLs[0] : i == 5 ? B.lpLs[1] : i == 6 ? B.lpRs[0] : B.lpRs[1];
-  const float r = wr_acc_row(tabs, i, s0, st, k, lin && i < 4);
+  float r;
+  if (tabs) {
+    // (lane i reads sum i off the prim's tables; a right-edge sum marked equal to its left one takes that lane's value)
+    const int m = tabs->mode[i];
+    r = wr_acctabs_row(tabs, i, k);
+    const float other = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane & 63) - 2) << 2, __builtin_bit_cast(int, r)));
+    if (m == 4) r = other;
+  } else r = wr_row_interp(s0, st, k, lin && i < 4);
   const float L0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)), L1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 1));
   const float R0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 2)), R1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 3));
   const float L2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 4)), L3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 5));
@@ -6967,8 +7008,12 @@ WR_DEVICE WrRowVals wr_clip_row_vals(const WrPrim& P, int y, const WrAccTabs* ta
   WrRowVals rv;
   const int k = y - P.y0;
   const bool lin = P.rows_linear != 0;
-  const float Lu = wr_acc_row(tabs, 0, P.uvL0[0], P.uvLs[0], k, lin), Lv = wr_acc_row(tabs, 1, P.uvL0[1], P.uvLs[1], k, lin);
-  const float Ru = wr_acc_row(tabs, 2, P.uvR0[0], P.uvRs[0], k, lin), Rv = wr_acc_row(tabs, 3, P.uvR0[1], P.uvRs[1], k, lin);
+  float Lu, Lv, Ru, Rv;
+  if (tabs) { Lu = wr_acctabs_row_any(tabs, 0, k); Lv = wr_acctabs_row_any(tabs, 1, k); Ru = wr_acctabs_row_any(tabs, 2, k); Rv = wr_acctabs_row_any(tabs, 3, k); }
+  else {
+    Lu = wr_row_interp(P.uvL0[0], P.uvLs[0], k, lin); Lv = wr_row_interp(P.uvL0[1], P.uvLs[1], k, lin);
+    Ru = wr_row_interp(P.uvR0[0], P.uvRs[0], k, lin); Rv = wr_row_interp(P.uvR0[1], P.uvRs[1], k, lin);
+  }
   float stepScale = 1.0f / (P.xr - P.xl);
   if (!wr_isfinite(stepScale)) stepScale = 0.0f;
   const float start = float(P.x0) + 0.5f - P.xl;
@@ -6986,7 +7031,13 @@ WR_DEVICE WrRowVals wr_clip_row_vals_wave(const WrPrim& P, int y, int lane, cons
   const int i = lane & 3;
   const float s0 = i == 0 ? P.uvL0[0] : i == 1 ? P.uvL0[1] : i == 2 ? P.uvR0[0] : P.uvR0[1];
   const float st = i == 0 ? P.uvLs[0] : i == 1 ? P.uvLs[1] : i == 2 ? P.uvRs[0] : P.uvRs[1];
-  const float r = wr_acc_row(tabs, i, s0, st, k, lin);
+  float r;
+  if (tabs) {
+    const int m = tabs->mode[i];
+    r = wr_acctabs_row(tabs, i, k);
+    const float other = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane & 63) - 2) << 2, __builtin_bit_cast(int, r)));
+    if (m == 4) r = other;
+  } else r = wr_row_interp(s0, st, k, lin);
   const float Lu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)), Lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 1));
   const float Ru = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 2)), Rv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 3));
   float stepScale = 1.0f / (P.xr - P.xl);

@@ -265,9 +265,14 @@ struct WrBoxKey {                // what decides the bytes of a cs_clip_box_shad
 #define WR_ACCTAB_N 32
 struct WrAccTab { int32_t k[WR_ACCTAB_N]; uint32_t s[WR_ACCTAB_N]; int32_t q[WR_ACCTAB_N]; };
 struct WrAccTabs {
-  int32_t n[8];                  // entries of tab[i] (0: none -- the closed form always applies, or the walk did not fit: wr_accum)
-  int32_t ref[8];                // the table sum i reads (an earlier sum with the same start and step, or i)
-  WrAccTab tab[8];               // cs_clip_box_shadow: uv L0/L1/R0/R1, local pos L0/L1/R0/R1; cs_clip_rectangle: uv L0/L1/R0/R1
+  // (the header is what a row reads first -- start, step and kind of each sum, one lane per sum -- together with its table's k[]: one round
+  // trip, then the piece's s / q: a second one)
+  float s0[8], st[8];            // cs_clip_box_shadow: uv L0/L1/R0/R1, local pos L0/L1/R0/R1; cs_clip_rectangle: uv L0/L1/R0/R1
+  int32_t n[8];                  // pieces of tab[i] (mode 2)
+  int32_t mode[8];               // 0: s0 + k * st in one fused multiply-add is the sequential sum at every row (wr_accum's closed form holds at the
+                                 // last row, or the step is 0); 1: the prim's uv sums were verified linear (WrPrim::rows_linear: the fp64 form);
+                                 // 2: tab[i]; 3: the walk (the pieces did not fit); 4: the sum equals sum i - 2 (left / right edges of an axis-aligned prim)
+  WrAccTab tab[8];
 };
 #define WR_ACCTABS_N16 ((sizeof(WrAccTabs) + 15) / 16)
 struct WrMaskSlot {
