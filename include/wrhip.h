@@ -243,7 +243,7 @@ void WrhipSetProfiling(int enabled);
  * kernel wr_raster_kernel<fmt, depth, 4, feat>, 4 = a chained run of thin R8 levels, 5 = wr_raster_dense_kernel, 6 / 7 = kinds 2 / 5
  * fused with the next flush's setup stage (wr_setup_raster[_dense]_kernel: setup bytes and workgroups added), 8 = wr_setup_rows_kernel
  * (3 fused likewise), 9 = wr_span_rows_kernel (the cs_blur / cs_scale targets of a level, a wave per target row piece), 10 = wr_tile_rows_kernel
- * (picture targets of a few large gradient / image prims, likewise), 11 = wr_setup_tile_rows_kernel (10 fused with the next flush's setup stage), 12 = a thin launch of the raster kernel (wr_raster_kernel<fmt, false, 1, feat>:
+ * (picture targets of a few large gradient / image prims, likewise), 11 = wr_setup_tile_rows_kernel (10 fused with the next flush's setup stage), 12 = a thin launch of the raster kernel (13: the same with the next flush's setup stage in front, wr_setup_raster_thin_kernel) (wr_raster_kernel<fmt, false, 1, feat>:
  * small levels, several workgroups per bin).  algo_bytes: the launch's algorithmic bytes:
  * raster launches count every destination pixel they own once (twice when the target's old content is loaded) plus
  * the source texels their draws can sample; the setup stage counts instance + descriptor + record bytes.  Returns the

@@ -9,8 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from conftest import hostsim_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct
-hs, orc = hostsim_lib(), oracle_ref("gcc")
-rng = np.random.default_rng(int(sys.argv[1]))
+GENERATORS = None      # (blur, clip, box, chain), set below
 
 
 def blur(r):
@@ -40,26 +39,36 @@ def chain(r):
                                    offset=(float(r.integers(-10, 11)), float(r.integers(-10, 11))), dps=[1.0, 1.0, 1.5][int(r.integers(3))])
 
 
-bad = 0
-for it in range(int(sys.argv[2])):
-    for gen in (blur, clip, box, chain):
-        name, kw = gen(rng)
-        for env in ({}, {"WRHIP_NO_SPAN_ROWS": "1", "WRHIP_NO_MASK_ROWS": "1"}) if gen is not chain else ({},):
-            os.environ.update(env)
-            try:
-                want, _ = render_direct(orc, getattr(scenes, name)(**kw))
-                got, st = render_direct(hs, getattr(scenes, name)(**kw))
-            except Exception as e:
-                print(name, kw, type(e).__name__, str(e)[:120], flush=True)
-                break
-            finally:
-                for k in env:
-                    os.environ.pop(k, None)
-            if isinstance(want, dict):
-                diff = [k for k in want if not np.array_equal(got[k], want[k])]
-            else:
-                diff = [] if np.array_equal(got, want) else ["window"]
-            if diff or st["gl_error"]:
-                bad += 1
-                print(name, kw, env, "differs in", diff, "gl_error", hex(st["gl_error"]), flush=True)
-print("bad", bad)
+GENERATORS = (blur, clip, box, chain)
+
+
+def main():
+    hs, orc = hostsim_lib(), oracle_ref("gcc")
+    rng = np.random.default_rng(int(sys.argv[1]))
+    bad = 0
+    for it in range(int(sys.argv[2])):
+        for gen in GENERATORS:
+            name, kw = gen(rng)
+            for env in ({}, {"WRHIP_NO_SPAN_ROWS": "1", "WRHIP_NO_MASK_ROWS": "1"}) if gen is not chain else ({},):
+                os.environ.update(env)
+                try:
+                    want, _ = render_direct(orc, getattr(scenes, name)(**kw))
+                    got, st = render_direct(hs, getattr(scenes, name)(**kw))
+                except Exception as e:
+                    print(name, kw, type(e).__name__, str(e)[:120], flush=True)
+                    break
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+                if isinstance(want, dict):
+                    diff = [k for k in want if not np.array_equal(got[k], want[k])]
+                else:
+                    diff = [] if np.array_equal(got, want) else ["window"]
+                if diff or st["gl_error"]:
+                    bad += 1
+                    print(name, kw, env, "differs in", diff, "gl_error", hex(st["gl_error"]), flush=True)
+    print("bad", bad)
+
+
+if __name__ == "__main__":
+    main()

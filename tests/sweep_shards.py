@@ -30,9 +30,10 @@ F = {
 }
 
 
-def rank_strip(make, rank, world):
-    rec, _ = record_scene(hs, make())
-    p = ScenePlayer(hs, rec)
+def rank_strip(make, rank, world, lib=None):
+    lib = lib or hs
+    rec, _ = record_scene(lib, make())
+    p = ScenePlayer(lib, rec)
     sym = p.symbol
     set_rows = C.CFUNCTYPE(None, C.c_uint32, C.c_int32, C.c_int32)(sym("WrhipSetTargetRows"))
     fb_tex = C.CFUNCTYPE(C.c_uint32, C.c_uint32)(sym("WrhipGetFramebufferTexture"))(0)

@@ -123,9 +123,8 @@ BLUR_CASES = [
 @pytest.mark.parametrize("evaluation", ["span_rows", "bins"])
 @pytest.mark.parametrize("name,kw", BLUR_CASES, ids=[c[0] for c in BLUR_CASES])
 def test_hip_blur_matches_oracle(name, kw, evaluation, monkeypatch):
-    """cs_blur vertical + horizontal passes on the GPU; integer 8.8 taps are
-    bit-exact, the float fragment-shader edge columns are allowed +-1 LSB
-    (exp() of the coefficient comes from a different libm).  Both evaluations: a wave per target row
+    """cs_blur vertical + horizontal passes on the GPU: 0 differing bytes (integer 8.8 taps; the coefficient's exp() is
+    evaluated in fp64 and rounded once, like glibc's correctly rounded expf).  Both evaluations: a wave per target row
     (wr_span_rows_kernel, the default for cs_blur / cs_scale targets) and the bin raster (WRHIP_NO_SPAN_ROWS)."""
     if evaluation == "bins":
         monkeypatch.setenv("WRHIP_NO_SPAN_ROWS", "1")
@@ -135,10 +134,9 @@ def test_hip_blur_matches_oracle(name, kw, evaluation, monkeypatch):
         want, _ = render_direct(ref, scenes.blur_chain(**kw))
         for k in want:
             d = np.abs(got[k].astype(int) - want[k].astype(int))
-            assert d.max() <= 1, (k, int(d.max()))
+            assert d.max() == 0, (k, int(d.max()), int((d > 0).sum()))
     if name in GOLDEN:
-        d = digest(got["blur_h"]) == GOLDEN[name]
-        assert d or ref, "golden digest mismatch and no oracle to bound the difference"
+        assert digest(got["blur_h"]) == GOLDEN[name], "golden digest mismatch"
     assert ref or name in GOLDEN
 
 
@@ -148,8 +146,7 @@ CLIP_CASES = [("clip_masks", dict()), ("clip_masks_dps", dict(dps=1.5, seed=32))
 @pytest.mark.parametrize("evaluation", ["mask_rows", "in_raster"])
 @pytest.mark.parametrize("name,kw", CLIP_CASES, ids=[c[0] for c in CLIP_CASES])
 def test_hip_clip_rectangle_matches_oracle(name, kw, evaluation, monkeypatch):
-    """cs_clip_rectangle masks on the GPU: float coverage -> +-1 LSB allowed by
-    north_star, the committed digest pins the exact result."""
+    """cs_clip_rectangle masks on the GPU: 0 differing bytes against the oracle, and the committed digest."""
     if evaluation == "in_raster":      # the prims evaluated inside the bin raster instead of by wr_mask_rows_kernel (the fallback
         monkeypatch.setenv("WRHIP_NO_MASK_ROWS", "1")     # of a flush whose masks exceed the mask-row store)
     got, _ = render_direct(wrhip_lib(), scenes.clip_masks(**kw))
@@ -157,9 +154,9 @@ def test_hip_clip_rectangle_matches_oracle(name, kw, evaluation, monkeypatch):
     if ref:
         want, _ = render_direct(ref, scenes.clip_masks(**kw))
         d = np.abs(got["clip_masks"].astype(int) - want["clip_masks"].astype(int))
-        assert d.max() <= 1
+        assert d.max() == 0, (int(d.max()), int((d > 0).sum()))
     if name in GOLDEN:
-        assert digest(got["clip_masks"]) == GOLDEN[name] or ref
+        assert digest(got["clip_masks"]) == GOLDEN[name]
     assert ref or name in GOLDEN
 
 
@@ -176,9 +173,9 @@ def test_hip_box_shadow_matches_oracle(name, kw, evaluation, monkeypatch):
     if ref:
         want, _ = render_direct(ref, scenes.box_shadow_masks(**kw))
         d = np.abs(got["box_shadow_masks"].astype(int) - want["box_shadow_masks"].astype(int))
-        assert d.max() <= 1
+        assert d.max() == 0, (int(d.max()), int((d > 0).sum()))
     if name in GOLDEN:
-        assert digest(got["box_shadow_masks"]) == GOLDEN[name] or ref
+        assert digest(got["box_shadow_masks"]) == GOLDEN[name]
     assert ref or name in GOLDEN
 
 
@@ -210,8 +207,8 @@ def test_hip_cfg4_box_shadow_chain(name, kw):
         want, _ = render_direct(ref, scenes.cfg4_box_shadow(**kw))
         for k in want:
             d = np.abs(got[k].astype(int) - want[k].astype(int))
-            assert d.max() <= 1, (k, int(d.max()))
-    assert digest(got["window"]) == GOLDEN[name] or ref
+            assert d.max() == 0, (k, int(d.max()), int((d > 0).sum()))
+    assert digest(got["window"]) == GOLDEN[name]
 
 
 @pytest.mark.parametrize("name,make", SMALL + OCCLUDED + BLEND + ROTATED, ids=[c[0] for c in SMALL + OCCLUDED + BLEND + ROTATED])
@@ -336,16 +333,21 @@ _BORDER_CASES = ([(n, "border_solid", kw) for n, kw in BORDERS] + [(n, "border_s
 
 @pytest.mark.parametrize("name,scene,kw", _BORDER_CASES, ids=[c[0] for c in _BORDER_CASES])
 def test_hip_border_solid_matches_oracle(name, scene, kw):
-    """cs_border_solid segments in the texture cache: float coverage (ellipse distances, colour-line mix) -> +-1 LSB allowed
-    by north_star, the committed digest pins the exact result."""
+    """cs_border_solid / cs_border_segment tasks in the texture cache: 0 differing bytes and the committed digest.  The cached
+    gradient / line-decoration scenes hold conic gradients whose angle comes from libm atan2f (OCML's on the device): a handful of
+    pixels by 1 LSB there, nothing else."""
     got, _ = render_direct(wrhip_lib(), getattr(scenes, scene)(**kw))
     ref = oracle_ref()
+    exact = scene != "cache_decorations"
     if ref:
         want, _ = render_direct(ref, getattr(scenes, scene)(**kw))
         d = np.abs(got[_cache_key(scene)].astype(int) - want[_cache_key(scene)].astype(int))
-        assert d.max() <= 1
-    if name in GOLDEN:
-        assert digest(got[_cache_key(scene)]) == GOLDEN[name] or ref
+        if exact:
+            assert d.max() == 0, (int(d.max()), int((d > 0).sum()))
+        else:
+            assert d.max() <= 1 and (d > 0).sum() <= 2e-5 * d.size, (int(d.max()), int((d > 0).sum()))
+    if name in GOLDEN and exact:
+        assert digest(got[_cache_key(scene)]) == GOLDEN[name]
     assert ref or name in GOLDEN
 
 
@@ -666,7 +668,7 @@ def test_hip_dual_source_images_match_oracle(name, kw):
         want, _ = render_direct(ref, scenes.image_grid(**kw))
         assert np.array_equal(got, want)
     if name in GOLDEN:
-        assert digest(got) == GOLDEN[name] or ref
+        assert digest(got) == GOLDEN[name]
     assert ref or name in GOLDEN
 
 

@@ -1,0 +1,103 @@
+"""Randomised parity ON THE MI355X: the sweep scripts' scene families (tests/sweep_seeds.py, sweep_chains.py,
+sweep_shards.py -- until round 6 they only ever ran on the host simulation, which takes other code at every cross-lane site) drawn
+with seeds nobody pinned, libwrhip.so through the C ABI against the oracle.
+
+  WRHIP_SWEEP_SEED      the run's seed (default: derived from today's date, so every driver run draws new scenes; printed, and a failure
+                        message carries it: re-run with it to reproduce)
+  WRHIP_SWEEP_SECONDS   time budget (default 45): scenes are drawn in a shuffled order until it is spent; at least MIN_SCENES must fit
+
+0 differing bytes and no gl_error, except the families whose float functions come from the device's math library instead of glibc
+(conic gradients' atan2f, the SVG filter programs' sqrt / division / powf, mix-blend's sqrt / division): <= 1 LSB there."""
+import datetime
+import os
+import sys
+import time
+import numpy as np
+import pytest
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import wrhip_lib, oracle_ref
+from webrender_amd import scenes
+from webrender_amd.harness import render_direct
+
+ONE_LSB = {"cache_decorations", "svg_filters", "svg_filter_nodes", "mix_grid_perspective", "mix_grid_perspective_masked", "mix_grid_rotated"}
+MIN_SCENES = 40
+
+
+def _flat(x):
+    if isinstance(x, dict):
+        return np.concatenate([x[k].ravel() for k in sorted(x)])
+    return x.ravel()
+
+
+@pytest.mark.gpu
+def test_random_scenes_match_oracle_on_the_gpu():
+    import sweep_seeds, sweep_chains, sweep_shards
+    ref = oracle_ref()
+    if not ref:
+        pytest.skip("oracle not built")
+    lib = os.environ.get("WRHIP_SWEEP_LIB") or wrhip_lib()      # (the override: dry runs of this test's own logic on the host simulation)
+    seed = int(os.environ.get("WRHIP_SWEEP_SEED", datetime.date.today().strftime("%Y%m%d")))
+    budget = float(os.environ.get("WRHIP_SWEEP_SECONDS", "45"))
+    rng = np.random.default_rng(seed)
+    plan = [("family", n) for n in sweep_seeds.FAMILIES] + [("chain", g) for g in sweep_chains.GENERATORS] * 6 + \
+           [("shards", n) for n in ("rects", "rotated_images", "gradients", "text", "cfg5", "fence_images")]
+    order = rng.permutation(len(plan))
+    t0 = time.perf_counter()
+    done, failures = 0, []
+    for idx in order:
+        if time.perf_counter() - t0 > budget and done >= MIN_SCENES:
+            break
+        kind, what = plan[idx]
+        s = int(rng.integers(10000, 99999))
+        tag = f"{kind} {what if isinstance(what, str) else what.__name__} seed {s}"
+        try:
+            if kind == "family":
+                make = lambda: sweep_seeds.FAMILIES[what](s)
+                tol = 1 if what in ONE_LSB else 0
+                envs = ({},)
+            elif kind == "chain":
+                name, kw = what(rng)
+                make = lambda: getattr(scenes, name)(**kw)
+                tol = 0
+                tag = f"chain {name} {kw}"
+                # (both evaluations of the off-screen levels: the row kernels and the bins)
+                envs = ({}, {"WRHIP_NO_SPAN_ROWS": "1", "WRHIP_NO_MASK_ROWS": "1"}) if what is not sweep_chains.chain else ({},)
+            else:
+                # what the ranks of the multi-GPU path render (WrhipSetTargetRows per tile and for the window, as dist.py sets them),
+                # rank by rank in this process: the strips put together are the oracle's frame
+                world = int(rng.integers(2, 6))
+                mk = lambda: sweep_shards.F[what](s)
+                rec_full = sweep_shards.rank_strip(mk, 0, 1, lib)[1]
+                out = np.zeros_like(rec_full)
+                errs = 0
+                for rank in range(world):
+                    (f0, f1), px, err = sweep_shards.rank_strip(mk, rank, world, lib)
+                    errs |= err
+                    if f1 > f0:
+                        out[f0:f1] = px[f0:f1]
+                want, _ = render_direct(ref, mk())
+                done += 1
+                if errs or not np.array_equal(out, rec_full):
+                    failures.append(f"{tag} world {world}: {int((out != rec_full).sum())} bytes differ from the unsharded frame, gl_error {errs:#x}")
+                if not any(np.array_equal(f, want) for f in (rec_full, rec_full[::-1], rec_full[::-1][..., [2, 1, 0, 3]], rec_full[..., [2, 1, 0, 3]])):
+                    failures.append(f"{tag}: the unsharded frame is not the oracle's")
+                continue
+            want = _flat(render_direct(ref, make())[0])
+            for env in envs:
+                os.environ.update(env)
+                try:
+                    got, st = render_direct(lib, make())
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+                got = _flat(got)
+                d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+                done += 1
+                if d.max() > tol or (tol and (d > 0).sum() > 1e-3 * d.size) or st["gl_error"]:
+                    failures.append(f"{tag} {env}: max |diff| {int(d.max())}, {int((d > 0).sum())} bytes, gl_error {st['gl_error']:#x}")
+        except TypeError as e:       # a scene builder that does not take this combination of arguments
+            print(f"skipped {tag}: {e}")
+    print(f"\nWRHIP_SWEEP_SEED={seed}: {done} random scenes on {os.path.basename(lib)} against the oracle in {time.perf_counter() - t0:.1f} s, "
+          f"{len(failures)} failures")
+    assert not failures, f"WRHIP_SWEEP_SEED={seed}: " + "; ".join(failures[:8])
+    assert done >= MIN_SCENES

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include "../../include/wrhip.h"       /* WrhipStats (the sharded loop counts a frame's flushes) */
 
 typedef struct { uint32_t tag, aux; uint64_t value; } wr_arg;
 typedef struct wr_replay {
@@ -193,8 +194,10 @@ typedef struct wr_shard {
   uint8_t* fb;                      /* this rank's window storage (device pointer; host pointer with the hostsim backend) */
   void (*flush)(void);
   int (*flush_held)(void);        /* optional: WrhipFlushHeld */
-  void (*get_stats)(void*);       /* WrhipGetStats: [0] = flushes */
-  int probed;
+  void (*get_stats)(WrhipStats*);
+  int probed;                     /* the first frame of a stream has been replayed unpipelined and its flushes counted ... */
+  int probe_flushes;              /* ... this many */
+  int err_held;                   /* a frame that wrote the window and flushed again before its end was seen (reported at the end of the stream) */
   void (*finish)(void);
   void* (*get_stream)(void);
   /* RCCL */
@@ -222,7 +225,7 @@ static wr_shard* shard_new(wr_replay* R, int rank, int world, int mode) {
   S->flush = (void (*)(void))dlsym(R->dl, "WrhipFlush");
   S->flush_held = getenv("WRHIP_SHARD_NO_PIPELINE") ? NULL : (int (*)(void))dlsym(R->dl, "WrhipFlushHeld");
   S->finish = (void (*)(void))dlsym(R->dl, "Finish");
-  S->get_stats = (void (*)(void*))dlsym(R->dl, "WrhipGetStats");
+  S->get_stats = (void (*)(WrhipStats*))dlsym(R->dl, "WrhipGetStats");
   S->get_stream = (void* (*)(void))dlsym(R->dl, "WrhipGetStream");
   if (!S->flush || !S->finish || !S->get_stream) { fprintf(stderr, "wr_shard: backend lacks WrhipFlush / WrhipGetStream\n"); free(S); return NULL; }
   return S;
@@ -295,6 +298,35 @@ static int shard_exchange(wr_shard* S) {
   return rc ? rc : rc2;
 }
 
+/* The pipelined order of wr_shard_stream2 is only right for a frame that flushes ONCE: a flush in the middle of frame k + 1 (a
+   sampled target overwritten, a query, ring pressure ...) puts its first segment on the stream ahead of frame k's exchange.  The
+   first frame of a stream is therefore replayed unpipelined and its flushes counted.  Every rank has to take the SAME order (the
+   collectives match by call order: a rank that dropped to the unpipelined order alone would combine frame k's strips with its
+   peers' frame k - 1), and flush counts differ per rank (the targets kept per strip differ): the caller -- webrender_amd/dist.py --
+   probes on every rank, takes the maximum over the ranks and tells every rank the outcome (wr_shard_set_pipelined).  A stream that
+   is started without that (one process, the tests' single-rank paths) decides from its own count.  Returns the flushes of the
+   probe frame, < 0 on error. */
+int wr_shard_probe(wr_shard* S, const uint8_t* trace, size_t len) {
+  if (S->probed) return S->probe_flushes;
+  WrhipStats st0, st1;
+  memset(&st0, 0, sizeof(st0)); memset(&st1, 0, sizeof(st1));
+  if (S->get_stats) S->get_stats(&st0);
+  int rc0 = run_once(S->R, trace, len);
+  if (rc0) return rc0 > 0 ? -rc0 : rc0;
+  if (S->shm) S->finish(); else S->flush();
+  if (S->get_stats) S->get_stats(&st1);
+  S->probed = 1;
+  S->probe_flushes = S->get_stats ? (int)(st1.flushes - st0.flushes) : 2;      /* (no counter: unpipelined) */
+  if (shard_exchange(S)) { fprintf(stderr, "wr_shard: exchange failed\n"); return -2; }
+  return S->probe_flushes;
+}
+void wr_shard_set_pipelined(wr_shard* S, int on) {
+  if (!on && S->flush_held) {
+    fprintf(stderr, "wr_shard: a rank's frame flushes more than once: the strips are moved unpipelined on every rank\n");
+    S->flush_held = NULL;
+  }
+}
+
 /* `iters` frames back to back, the strips moved after every one, one Finish at the end.  Returns total wall ms in *total_ms. */
 int wr_shard_stream2(wr_shard* S, const uint8_t* trace, size_t len, const uint8_t* trace_b, size_t len_b, int iters, double* total_ms);
 int wr_shard_stream(wr_shard* S, const uint8_t* trace, size_t len, int iters, double* total_ms) {
@@ -314,23 +346,11 @@ int wr_shard_stream2(wr_shard* S, const uint8_t* trace_a, size_t len_a, const ui
   for (int i = 0; i < iters; i++) {
     const uint8_t* trace = (i & 1) ? trace_b : trace_a;
     const size_t len = (i & 1) ? len_b : len_a;
-    if (!S->probed && !shm_sync && S->flush_held && S->get_stats) {
-      /* The pipelined order below is only right for a frame that flushes ONCE: a flush in the middle of frame k + 1 (a sampled
-         target overwritten, a query, ring pressure ...) puts its first segment on the stream ahead of frame k's exchange.  The
-         first frame of a stream is therefore replayed unpipelined and its flushes counted; a trace that flushes more than once
-         per frame keeps the unpipelined order (and WrhipFlushHeld reports a frame that does so later: code 2 below). */
-      uint64_t st0[16] = {0}, st1[16] = {0};
-      S->get_stats(st0);
-      int rc0 = run_once(S->R, trace, len);
-      if (rc0) return rc0;
-      S->flush();
-      S->get_stats(st1);
-      S->probed = 1;
-      if (st1[0] - st0[0] != 1) {
-        fprintf(stderr, "wr_shard: %llu flushes per frame: the strips are moved unpipelined\n", (unsigned long long)(st1[0] - st0[0]));
-        S->flush_held = NULL;
-      }
-      if (shard_exchange(S)) { fprintf(stderr, "wr_shard: exchange failed\n"); return -2; }
+    if (!S->probed && !shm_sync && S->flush_held) {
+      /* (not probed by the caller: this process decides alone -- see wr_shard_probe) */
+      const int n = wr_shard_probe(S, trace, len);
+      if (n < 0) return n;
+      wr_shard_set_pipelined(S, n == 1);
       continue;
     }
     int rc = run_once(S->R, trace, len);
@@ -340,7 +360,9 @@ int wr_shard_stream2(wr_shard* S, const uint8_t* trace_a, size_t len_a, const ui
       rc = shard_exchange(S);
     } else {
       const int held = S->flush_held();
-      if (held == 2) { fprintf(stderr, "wr_shard: a frame wrote the window and flushed again before its end: not pipelinable\n"); return -6; }
+      /* (held == 2: the window holds a mix of two frames.  The stream goes on -- a rank that left here would leave its peers blocked
+         in their next collective -- and the error is returned at its end) */
+      if (held == 2 && !S->err_held) { fprintf(stderr, "wr_shard: a frame wrote the window and flushed again before its end: not pipelinable\n"); S->err_held = 1; }
       rc = pending ? shard_exchange(S) : 0;
       pending = held;
       if (!held && rc == 0) rc = shard_exchange(S);
@@ -365,6 +387,7 @@ int wr_shard_stream2(wr_shard* S, const uint8_t* trace_a, size_t len_a, const ui
   }
   clock_gettime(CLOCK_MONOTONIC, &b);
   if (total_ms) *total_ms = (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6;
+  if (S->err_held) { S->err_held = 0; return -6; }
   return 0;
 }
 

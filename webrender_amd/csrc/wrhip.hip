@@ -1517,7 +1517,6 @@ void flush_work(const std::vector<int>& sel_in) {
   Context* c = ctx;
   if (!c || c->work.empty() || sel_in.empty()) return;
   HostTimer ht(&c->stats.host_flush_ns);
-  c->gtab_pending = 0;
   std::vector<int> sel(sel_in);
   std::sort(sel.begin(), sel.end());
   sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
@@ -1700,7 +1699,11 @@ void flush_work(const std::vector<int>& sel_in) {
       prim_cursor += d.count;
       // per-row v table budget for draws whose prims can take the nearest-fast texture path
       d.gtab_base = -1;
-      if (d.flags & WR_DF_GTAB) { d.gtab_base = (int)gtab_words; gtab_words += (size_t)d.count * WR_GTAB_WORDS; }
+      if (d.flags & WR_DF_GTAB) {
+        d.gtab_base = (int)gtab_words; gtab_words += (size_t)d.count * WR_GTAB_WORDS;
+        // (the promise of THIS draw is redeemed; those of draws a partial flush leaves recorded stay counted: ADVICE r5)
+        c->gtab_pending -= std::min(c->gtab_pending, (size_t)d.count * WR_GTAB_WORDS);
+      }
       d.vtab_base = -1; d.vtab_rows = 0;
       if (T.format == WR_FMT_RGBA8 && !(d.flags & WR_DF_SIMPLE) &&
           (d.shader == WR_SH_COMPOSITE || d.shader == WR_SH_COMPOSITE_FAST || d.shader == WR_SH_CS_SCALE ||
@@ -1810,7 +1813,8 @@ void flush_work(const std::vector<int>& sel_in) {
       S.bin_ctr = (unsigned*)wrrt::dev_alloc(S.bin_ctr_cap * sizeof(unsigned));
       wrrt::memset8(S.bin_ctr, 0, S.bin_ctr_cap * sizeof(unsigned), c->stream);      // (the workgroups leave them at zero)
     }
-    // the pool the setup stage cuts general quads' row tables from: what the flush's WR_DF_XFORM draws could ask for, up to 64 MB
+    // the flush's pool: the gradient-table copies (fixed head, <= 256 MB of promises), what the flush's WR_DF_XFORM draws could ask for in
+    // row tables (<= 64 MB), and the depth runs' share (WRHIP_RUNS_POOL_WORDS, 64 MB by default)
     const size_t qtab_want = gtab_words + std::min<size_t>(qtab_need, (size_t)16 << 20) + (runs_pool ? runs_pool_words : 0);
     if (S.qtab_cap < qtab_want) {
       sync_stream();
@@ -2142,6 +2146,7 @@ void flush_all() {
   std::vector<int> sel(c->work.size());
   for (size_t i = 0; i < sel.size(); i++) sel[i] = (int)i;
   flush_work(sel);
+  c->gtab_pending = 0;          // (nothing is left recorded: promises of draws that were dropped without a flush go with it)
 }
 
 }  // namespace

@@ -7865,7 +7865,7 @@ WR_DEVICE void wr_span_rows_body(const WrTargetDesc* __restrict__ targets, const
     for (; ti < nt; ti++) {
       const WrTargetDesc& Tq = targets[t0 + ti];
       pieces = WR_SPAN_PIECES(Tq.width);
-      const int n = (Tq.y_end - Tq.y_begin) * pieces;
+      const int n = wr_imax(0, Tq.y_end - Tq.y_begin) * pieces;      // (as the host counts row_items: an empty or inverted row range holds no items)
       if (rel < n) break;
       rel -= n;
     }
@@ -8081,7 +8081,7 @@ WR_DEVICE void wr_tile_rows_body(const WrTargetDesc* __restrict__ targets, const
     for (; ti < nt; ti++) {
       const WrTargetDesc& Tq = targets[t0 + ti];
       pieces = (Tq.width + 255) >> 8;
-      const int n = (Tq.y_end - Tq.y_begin) * pieces;
+      const int n = wr_imax(0, Tq.y_end - Tq.y_begin) * pieces;      // (as the host counts row_items: an empty or inverted row range holds no items)
       if (rel < n) break;
       rel -= n;
     }

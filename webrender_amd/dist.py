@@ -141,13 +141,17 @@ class ShardedFramePlayer:
         h = self.player.rp.h
         if kind == "rccl":
             librccl = os.path.join(os.path.dirname(self.torch.__file__), "lib", "librccl.so").encode()
-            ids = [None]
+            ids = [None, 0]
             if self.world > 1:
                 if self.rank == 0:
                     buf = C.create_string_buffer(128)
-                    assert rl.wr_shard_unique_id(librccl, buf) == 0
-                    ids = [buf.raw]
-                self.dist.broadcast_object_list(ids, src=0)       # (setup, once: the id of the communicator the native loop owns)
+                    rc = rl.wr_shard_unique_id(librccl, buf)        # (1: librccl not found, 2: no ncclGetUniqueId)
+                    ids = [buf.raw if rc == 0 else None, rc]
+                # (setup, once: the id of the communicator the native loop owns -- and rank 0's status WITH it, so that a rank 0 that
+                # cannot get an id does not leave the others waiting in this broadcast: every rank raises the same RuntimeError)
+                self.dist.broadcast_object_list(ids, src=0)
+                if ids[1] != 0:
+                    raise RuntimeError(f"wr_shard_unique_id failed on rank 0 ({ids[1]})")
             self.native = rl.wr_shard_open_rccl(h, librccl, self.rank, self.world, mode, ids[0] or b"\0" * 128)
         else:
             self.shm_name = shm_name.encode()
@@ -157,8 +161,21 @@ class ShardedFramePlayer:
             if self.world > 1:
                 self.dist.barrier()
             self.native = rl.wr_shard_open_shm(h, self.shm_name, self.rank, self.world, mode, self.height * self.row_bytes)
+        if self.world > 1:
+            # every rank takes the same transport: one that could not open its side tells the others before anybody enters a collective
+            oks = [None] * self.world
+            self.dist.all_gather_object(oks, bool(self.native))
+            if not all(oks):
+                if self.native:
+                    rl.wr_shard_close(self.native, None)
+                    self.native = None
+                raise RuntimeError(f"wr_shard_open failed on rank(s) {[r for r, ok in enumerate(oks) if not ok]}")
         if not self.native:
             raise RuntimeError("wr_shard_open failed")
+        rl.wr_shard_probe.restype = C.c_int
+        rl.wr_shard_probe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        rl.wr_shard_set_pipelined.argtypes = [C.c_void_p, C.c_int]
+        self._probed = False
         rows = []
         for r in range(self.world):
             sy0, sy1, _ = strip_rows(self.height, r, self.world)
@@ -167,9 +184,25 @@ class ShardedFramePlayer:
         rl.wr_shard_set_window(self.native, ptr, self.height, self.row_bytes, (C.c_int * len(rows))(*rows))
         self._rl = rl
 
+    def _probe(self, t):
+        """Once per player, before its first streamed frame: the pipelined exchange order of the native loop is decided by ALL ranks
+        together (flush counts differ per rank; ranks in different orders would combine strips of different frames)."""
+        if self._probed:
+            return
+        self._probed = True
+        n = self._rl.wr_shard_probe(self.native, t, len(t))
+        ns = [n]
+        if self.world > 1:
+            ns = [None] * self.world
+            self.dist.all_gather_object(ns, int(n))
+        if min(ns) < 0:
+            raise RuntimeError(f"wr_shard_probe failed ({ns})")
+        self._rl.wr_shard_set_pipelined(self.native, 1 if max(ns) == 1 else 0)
+
     def _native_stream(self, iters):
         ms = C.c_double(0.0)
         t = self.rec.stream
+        self._probe(t)
         rc = self._rl.wr_shard_stream(self.native, t, len(t), iters, C.byref(ms))
         if rc != 0:
             raise RuntimeError(f"wr_shard_stream failed ({rc})")
@@ -180,6 +213,7 @@ class ShardedFramePlayer:
         frame trace of another scene recorded with the same resources (same window, same texture ids) -- exchanged after every one"""
         ms = C.c_double(0.0)
         t = self.rec.stream
+        self._probe(t)
         rc = self._rl.wr_shard_stream2(self.native, t, len(t), other_stream, len(other_stream), iters, C.byref(ms))
         if rc != 0:
             raise RuntimeError(f"wr_shard_stream2 failed ({rc})")

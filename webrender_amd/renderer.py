@@ -73,7 +73,35 @@ class Renderer:
         self._update_data_texture("sTransformPalette", frame.transforms, *F)
         self._update_data_texture("sRenderTasks", frame.render_tasks, *F)
         # GPU cache: persistent 1024 x >=20 RGBAF32 texture (gpu_cache.rs:46)
-        self._update_data_texture("sGpuCache", frame.gpu_cache, *F, min_rows=20)
+        self._update_gpu_cache(frame.gpu_cache, *F)
+
+    def _update_gpu_cache(self, store, fmt, upload_fmt, upload_ty):
+        """GpuCacheTexture::flush over the PixelBuffer bus (renderer/gpu_cache.rs:324-356; the bus a device without scatter shaders --
+        swgl -- gets, :104-150): the rows are kept on the CPU side, a row remembers the span of blocks that changed since it was last
+        uploaded (CacheRow::add_dirty, :51-54) and only that span of every dirty row goes to the texture; a frame that changed no block
+        uploads nothing.  A texture that had to grow is uploaded whole (:239-249)."""
+        d = self.device
+        data = store.texture_data(20)
+        rows = data.shape[0]
+        cur = self.data_tex.get("sGpuCache")
+        if cur is None or cur[1] < rows:
+            if cur is not None:
+                d.delete_texture(cur[0])
+            tex = d.create_texture(TEX_W, rows, fmt, G.GL_NEAREST)
+            self.data_tex["sGpuCache"] = (tex, rows)
+            self._gpu_cache_cpu = None
+        tex = self.data_tex["sGpuCache"][0]
+        old = getattr(self, "_gpu_cache_cpu", None)
+        if old is None or old.shape != data.shape:
+            d.upload_texture(tex, 0, 0, TEX_W, rows, upload_fmt, upload_ty, data)
+        else:
+            changed = (old.view(np.uint32) != data.view(np.uint32)).any(axis=2)       # [rows, TEX_W] blocks (bit patterns: NaN payloads too)
+            for r in np.nonzero(changed.any(axis=1))[0]:
+                cols = np.nonzero(changed[r])[0]
+                x0, x1 = int(cols[0]), int(cols[-1]) + 1
+                d.upload_texture(tex, x0, int(r), x1 - x0, 1, upload_fmt, upload_ty, np.ascontiguousarray(data[r, x0:x1]))
+        self._gpu_cache_cpu = data.copy()
+        d.bind_texture(SAMPLER_SLOTS["sGpuCache"], tex.id)
 
     def _create_gpu_buffer_texture(self, sampler, store, fmt, upload_fmt, upload_ty):
         d = self.device
