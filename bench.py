@@ -48,6 +48,20 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def measured_ceiling():
+    """What a streaming kernel achieves on this chip in ONE launch of the headline pass's size (tools/ubench/stream.hip, committed as
+    profiles/*_stream_ubench.json): the write-only figure is the practical denominator of a tile pass that starts from a clear."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_stream_ubench.json")))
+    if not files:
+        return None
+    r = {e["name"]: e for e in json.load(open(files[-1]))["results"]}
+    pick = lambda n: r[n]["median_GBps"] if n in r else None
+    return {"store_only_75MB_GBps": pick("store_wg2_75.8MB"), "copy_75MB_GBps": pick("copy_75.8MB"), "triad_75MB_GBps": pick("triad_75.8MB"),
+            "store_only_1GiB_GBps": pick("store_wg_1GiB"), "copy_1GiB_GBps": pick("copy_1GiB"), "empty_launch_us": r.get("empty_launch", {}).get("median_us"),
+            "source": "profiles/" + os.path.basename(files[-1])}
 REPEATS = 7            # timed regions per run; the median is reported
 
 
@@ -369,6 +383,11 @@ def main():
                     "per_kernel": per_kernel}
             if dom.get("traffic_source"):
                 roof["traffic_source"] = dom["traffic_source"]
+            mc = measured_ceiling()
+            if mc:
+                roof["peak_measured"] = mc
+                if mc.get("store_only_75MB_GBps"):
+                    roof["frac_of_measured_store_only"] = round(dom["GBps"] / mc["store_only_75MB_GBps"], 4)
 
     if rank == 0:
         from webrender_amd.wrench_scenes import DESCRIPTIONS as wrench_desc
@@ -414,6 +433,12 @@ def main():
             out["vs_baseline_note"] = "value / single_gpu_same_workload.value (same workload, unsharded, rank 0's GPU, this run); BASELINE.md has no published number"
         if host:
             out["host"] = host
+            if roof:
+                # is the GPU the bound?  kernel time per frame (event-timed pass) against the step, and the host's own work against it
+                out["gpu_busy_frac"] = round(roof["kernel_us_per_frame"] / (1e3 * out["ms_per_step"]), 3)
+                host_work = host["wall"] - host["blocked_on_stream"]
+                out["host_bound"] = bool(host_work > roof["kernel_us_per_frame"])
+                out["host_work_us_per_frame"] = round(host_work, 2)
         if roof:
             out["roofline"] = roof
         if not sharded and not args.no_cpu_baseline:

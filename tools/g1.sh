@@ -1,11 +1,17 @@
-cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/r06_f
-bash tools/rows_times.sh r06_f ab/libwrhip_rt.so many-box-shadows 2>&1 | grep -v 'slow row' | tail -12
-bash tools/rows_times.sh r06_f ab/libwrhip_rt.so cfg4 2>&1 | grep -v 'slow row' | tail -12
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "box or shadow or cfg4 or mask or clip" 2>&1 | tail -3
-for w in cfg4 many-box-shadows large-boxshadow-ellipse large-boxshadow-ellipse-2 large-clip-rect clip-clear; do
-  python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' > gpurun_out/r06_f/bench_$w.json
+cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/r06_g
+(time timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | tail -8) > gpurun_out/r06_g/gpu_tests.log 2>&1
+cat gpurun_out/r06_g/gpu_tests.log
+for i in 1 2; do
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' > gpurun_out/r06_g/bench_cfg2_$i.json
+python3 -c "
+import json
+d = json.load(open('gpurun_out/r06_g/bench_cfg2_$i.json')); r = d.get('roofline') or {}
+print('cfg2', 'fps', d['value'], 'host', d.get('host'), 'busy', d.get('gpu_busy_frac'), 'host_bound', d.get('host_bound'), 'kernel_us', r.get('kernel_us_per_frame'), '|', ' '.join('%s:%gx%.1f' % (k['name'].replace('wr_','').replace('_kernel','').replace(', false','F').replace(', true','T'), k['launches_per_frame'], k['us']) for k in r.get('per_kernel', [])))"
+done
+for w in cfg1 cfg3 cfg5; do
+  python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' > gpurun_out/r06_g/bench_$w.json
   python3 -c "
 import json
-d = json.load(open('gpurun_out/r06_f/bench_$w.json')); r = d.get('roofline') or {}
-print('$w', 'fps', d['value'], 'kernel_us', r.get('kernel_us_per_frame'), '|', ' '.join('%s:%gx%.1f' % (k['name'].replace('wr_','').replace('_kernel','').replace(', false','F').replace(', true','T'), k['launches_per_frame'], k['us']) for k in r.get('per_kernel', [])))"
+d = json.load(open('gpurun_out/r06_g/bench_$w.json')); r = d.get('roofline') or {}
+print('$w', 'fps', d['value'], 'host', d.get('host'), 'busy', d.get('gpu_busy_frac'), 'kernel_us', r.get('kernel_us_per_frame'), '|', ' '.join('%s:%gx%.1f' % (k['name'].replace('wr_','').replace('_kernel','').replace(', false','F').replace(', true','T'), k['launches_per_frame'], k['us']) for k in r.get('per_kernel', [])))"
 done

@@ -243,6 +243,11 @@ struct Texture {
   // sGpuBufferI (ps_quad header, id in .x); maintained on upload.  A draw is only declared
   // rectangle-only (WR_DF_SIMPLE) when the header texture it binds is clean.
   bool complex_ids_headers = false, complex_ids_gpubuf = false;
+  // Uploads of the open batch (Context::upload_batch).  up_batch: the batch that holds rows for this texture; view_batch / view_off: a
+  // WHOLE-texture upload of that batch sits at staging offset view_off in the texture's own layout (row bytes == stride), so a draw of the
+  // batch's flush can read it in the staging mirror and does not wait for the scatter (fused scatter)
+  uint64_t up_batch = 0, view_batch = 0;
+  size_t view_off = 0;
   bool has_storage() const { return dptr != nullptr; }
 };
 
@@ -496,6 +501,10 @@ struct Context {
   std::vector<UploadSeg> useg;
   size_t upload_begin = 0;        // staging offset where the pending batch starts
   bool upload_open = false;
+  uint64_t upload_batch = 1;      // id of the open (or next) batch: Texture::up_batch / view_batch compare with it
+  bool scatter_first = false;     // a recorded draw's setup stage reads a data texture the open batch writes PARTLY: the scatter has to precede it
+  struct PendingScatter { size_t seg_off = 0; int nseg = 0, parts = 0; uint64_t bytes = 0; bool valid = false; } ps;   // a batch's scatter handed to the flush's setup-carrying launch
+  bool fuse_scatter = true;       // WRHIP_NO_FUSE_SCATTER=1: the scatter keeps its own launch
   uint8_t* dupload = nullptr;     // HBM mirror of the staging ring
   // Per-flush scratch, two sets used alternately (flush_seq & 1): the deferred tail of flush k
   // still reads set k & 1 while the setup stage of flush k+1 fills the other one.
@@ -619,6 +628,7 @@ struct Context {
     if (thin_r8 && getenv("WRHIP_CHAIN") && atoi(getenv("WRHIP_CHAIN")) > 0)
       chain_grid = getenv("WRHIP_CHAIN_GRID") ? atoi(getenv("WRHIP_CHAIN_GRID")) : wrrt::cu_count() / 2;
     cell_raster = getenv("WRHIP_NO_CELLS") == nullptr;
+    fuse_scatter = getenv("WRHIP_NO_FUSE_SCATTER") == nullptr;
     mask_rows = getenv("WRHIP_NO_MASK_ROWS") == nullptr;
     span_rows = getenv("WRHIP_NO_SPAN_ROWS") == nullptr;
     tile_rows = getenv("WRHIP_NO_TILE_ROWS") == nullptr;
@@ -732,7 +742,7 @@ void drain_tail();
 // every host-side wait for the stream: the held-back raster level goes out first
 void sync_stream();
 
-void flush_uploads(size_t extra_end = 0);
+void flush_uploads(size_t extra_end = 0, bool may_defer = false);
 void prof_begin(wr_stream_t* on = nullptr);
 void prof_end(int kind, int fmt, int depth, int feat, uint64_t algo_bytes, uint64_t workgroups, wr_stream_t* on = nullptr);
 
@@ -828,7 +838,7 @@ void queue_upload(size_t src_off, void* dst, size_t dst_stride, size_t row_bytes
 }
 
 // One DMA for everything staged since the last flush, then the scatter kernel.
-void flush_uploads(size_t) {
+void flush_uploads(size_t, bool may_defer) {
   Context* c = ctx;
   if (!c->upload_open) return;
   size_t nseg = c->useg.size();
@@ -871,13 +881,30 @@ void flush_uploads(size_t) {
     // (... and at one workgroup per 64 KB a thread copied its sixteen 16-byte pieces one dependent round trip after the other:
     // 9.8 us for the 1.3 MB of a cfg2 frame; one workgroup per 8 KB of the largest segment = two pieces per thread)
     const int parts = (int)std::min<uint64_t>(256, std::max<uint64_t>(8, (largest + 8191) >> 13));
-    prof_begin();
-    WR_LAUNCH(wr_upload_kernel, (int)nseg * parts, 256, c->stream, (const WrUploadSeg*)(c->dupload + seg_off), (int)nseg, parts);
-    prof_end(0, 0, 0, 0, up_bytes, nseg * parts);
-    c->stats.kernel_launches++;
+    if (may_defer && c->fuse_scatter && !c->scatter_first && !c->ps.valid) {
+      // the caller's next launch carries the setup stage: its first workgroups run the scatter (no launch of its own)
+      c->ps.seg_off = seg_off; c->ps.nseg = (int)nseg; c->ps.parts = parts; c->ps.bytes = up_bytes; c->ps.valid = true;
+    } else {
+      prof_begin();
+      WR_LAUNCH(wr_upload_kernel, (int)nseg * parts, 256, c->stream, (const WrUploadSeg*)(c->dupload + seg_off), (int)nseg, parts);
+      prof_end(0, 0, 0, 0, up_bytes, nseg * parts);
+      c->stats.kernel_launches++;
+    }
     c->useg.clear();
   }
   c->upload_open = false;
+  c->upload_batch++;
+  c->scatter_first = false;
+}
+// a deferred scatter nobody took along (should not happen): on its own, now
+void launch_pending_scatter() {
+  Context* c = ctx;
+  if (!c->ps.valid) return;
+  prof_begin();
+  WR_LAUNCH(wr_upload_kernel, c->ps.nseg * c->ps.parts, 256, c->stream, (const WrUploadSeg*)(c->dupload + c->ps.seg_off), c->ps.nseg, c->ps.parts);
+  prof_end(0, 0, 0, 0, c->ps.bytes, (uint64_t)c->ps.nseg * c->ps.parts);
+  c->stats.kernel_launches++;
+  c->ps.valid = false;
 }
 
 void mark_ref(GLuint id, Texture& t, bool write, int target_index = -1) {
@@ -993,6 +1020,7 @@ void set_tex_storage(Texture& t, GLenum external_format, GLsizei width, GLsizei 
       } else memcpy(d, s, row);
     }
     queue_upload(st_off, t.dptr, t.stride, row, height);
+    t.up_batch = ctx->upload_batch; t.view_batch = 0;
   }
 }
 
@@ -1245,7 +1273,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   } while (0)
 #define WR_KF(DEPTH, FEAT)                                                                                              \
   do {                                                                                                                  \
-    WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, DEPTH, 4, FEAT>), n_setup_blocks + H.nb, 256, c->stream, *SA,        \
+    WR_LAUNCH((wr_setup_raster_kernel<WR_FMT_RGBA8, DEPTH, 4, FEAT>), n_setup_blocks + SA->up_blocks + H.nb, 256, c->stream, *SA,        \
               n_setup_blocks, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs,                  \
               (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);                                               \
   } while (0)
@@ -1256,7 +1284,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     if (dbg_rows) fprintf(stderr, "span rows (mode %d): targets [%d, %d) items %d workgroups %d\n", H.row_mode, H.row_t0, H.row_t0 + H.row_n, H.row_items, wgs);
     prof_begin();
     const bool rows_fused = SA != nullptr && H.row_mode == 2;
-    if (rows_fused) WR_LAUNCH(wr_setup_tile_rows_kernel, n_setup_blocks + wgs, 256, c->stream, *SA, n_setup_blocks, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
+    if (rows_fused) WR_LAUNCH(wr_setup_tile_rows_kernel, n_setup_blocks + SA->up_blocks + wgs, 256, c->stream, *SA, n_setup_blocks, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
     else if (H.row_mode == 2) WR_LAUNCH(wr_tile_rows_kernel, wgs, 256, c->stream, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
     else WR_LAUNCH(wr_span_rows_kernel, wgs, 256, c->stream, targets, H.row_t0, H.row_n, draws, (const WrPrim*)S.prims, (const WrAux*)S.aux);
     prof_end(rows_fused ? 11 : (H.row_mode == 2 ? 10 : 9), H.fmt, 0, 0, H.algo_bytes + (rows_fused ? setup_bytes : 0), (uint64_t)wgs + (rows_fused ? n_setup_blocks : 0));
@@ -1270,7 +1298,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
     prof_begin();
     const bool rows_fused = SA != nullptr;
     if (SA) {
-      WR_LAUNCH(wr_setup_rows_kernel, n_setup_blocks + wgs, 256, c->stream, *SA, n_setup_blocks, targets, H.off, H.off + H.nb,
+      WR_LAUNCH(wr_setup_rows_kernel, n_setup_blocks + SA->up_blocks + wgs, 256, c->stream, *SA, n_setup_blocks, targets, H.off, H.off + H.nb,
                 (const WrPrim*)S.prims, (const WrAux*)S.aux, S.mr_ctl, (const WrMaskSlot*)S.mr_slots, S.mr_store);
       SA = nullptr;                          // (the raster launch that follows is the plain one)
     } else
@@ -1321,7 +1349,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
 #define WR_KD(DEPTH)                                                                                                         \
   do {                                                                                                                       \
     if (SA) WR_LAUNCH((wr_setup_raster_dense_kernel<WR_FMT_RGBA8, DEPTH, 4, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX>), \
-                      n_setup_blocks + H.nb, 256, c->stream, *SA, n_setup_blocks, targets, n_targets, draws,                 \
+                      n_setup_blocks + SA->up_blocks + H.nb, 256, c->stream, *SA, n_setup_blocks, targets, n_targets, draws,                 \
                       (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off); \
     else WR_LAUNCH((wr_raster_dense_kernel<WR_FMT_RGBA8, DEPTH, 4, WR_FEAT_TEX | WR_FEAT_GENERIC | WR_FEAT_R8TEX>), H.nb, 256, \
                    c->stream, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux,  \
@@ -1333,7 +1361,7 @@ void launch_raster(const Context::Held& H, const WrTargetDesc* targets, int n_ta
   else if (SA && H.fmt == WR_FMT_RGBA8 && !H.depth && c->thin_r8 && H.nb <= WR_THIN_MAX_BINS && H.feat == F5 && thin_carrier) {
     // the thin colour launch with the next flush's setup stage in front (can_fuse)
     thin_wgs = (uint64_t)H.nb * 4 + (uint64_t)n_setup_blocks;
-    WR_LAUNCH((wr_setup_raster_thin_kernel<WR_FMT_RGBA8, false, 1, WR_FEAT_TEX | WR_FEAT_GENERIC>), n_setup_blocks + H.nb * 4, 256, c->stream, *SA,
+    WR_LAUNCH((wr_setup_raster_thin_kernel<WR_FMT_RGBA8, false, 1, WR_FEAT_TEX | WR_FEAT_GENERIC>), n_setup_blocks + SA->up_blocks + H.nb * 4, 256, c->stream, *SA,
               n_setup_blocks, targets, n_targets, draws, (const WrPrim*)S.prims, (const WrRec*)S.recs, (const WrAux*)S.aux, (const float*)S.vtab, S.masks, H.off);
   }
   else if (SA) {
@@ -1915,7 +1943,26 @@ void flush_work(const std::vector<int>& sel_in) {
         blk[b] = j;
       }
     }
-    flush_uploads();     // one DMA: queued texture uploads + this arena; then the scatter kernel
+    // the launch that will carry this flush's setup stage (if any): it also runs the batch's scatter, in its first workgroups
+    int fuse_at = -1;
+    if (n_prims > 0 && c->tail.pending && !c->setup_on_stream) {
+      // the launch that hides the setup stage best: the largest mask-rows launch if there is one, else the first raster
+      // launch the fused kernel has a variant for
+      int best_rows = 0;
+      for (size_t hi = 0; hi < c->tail.held.size(); hi++)
+        if (c->tail.held[hi].mr_rows > best_rows) { best_rows = c->tail.held[hi].mr_rows; fuse_at = (int)hi; }
+      // (... else the largest tile-rows launch: a wave per row piece of a few heavy prims, the long launch of such a flush -- behind
+      // the short rect pass of the same flush a setup stage would stick out)
+      if (fuse_at < 0) {
+        int best_items = 0;
+        for (size_t hi = 0; hi < c->tail.held.size(); hi++) {
+          const Context::Held& Hh = c->tail.held[hi];
+          if (Hh.row_n > 0 && Hh.row_mode == 2 && Hh.row_items > best_items && can_fuse(Hh)) { best_items = Hh.row_items; fuse_at = (int)hi; }
+        }
+      }
+      for (size_t hi = 0; hi < c->tail.held.size() && fuse_at < 0; hi++) if (can_fuse(c->tail.held[hi])) fuse_at = (int)hi;
+    }
+    flush_uploads(0, fuse_at >= 0);     // one DMA: queued texture uploads + this arena; then the scatter (its own launch, or the carrier's first workgroups)
     uint8_t* darena = c->dupload + aoff;
     c->stats.h2d_bytes += total;
     algo_bytes += inst_bytes + sizeof(WrDrawDesc) * nd;
@@ -1950,7 +1997,6 @@ void flush_work(const std::vector<int>& sel_in) {
       const int nd_arg = nd;
 #endif
       const int n_setup_blocks = (n_prims + 255) / 256;
-      int fuse_at = -1;
       const uint64_t setup_bytes = inst_bytes + sizeof(WrDrawDesc) * nd + (uint64_t)n_prims * (sizeof(WrPrim) + sizeof(WrRec));
       if (c->tail.pending && c->setup_on_stream) {
         wrrt::event_record(&c->ev_up, c->stream);                 // (this flush's uploads and table resets are enqueued)
@@ -1964,30 +2010,18 @@ void flush_work(const std::vector<int>& sel_in) {
         drain_tail();                                            // the previous flush's raster launches, concurrently
         wrrt::stream_wait_event(c->stream, &c->ev_setup);
       } else {
-      if (c->tail.pending)
-        {
-          // the launch that hides the setup stage best: the largest mask-rows launch if there is one, else the first raster
-          // launch the fused kernel has a variant for
-          int best_rows = 0;
-          for (size_t hi = 0; hi < c->tail.held.size(); hi++)
-            if (c->tail.held[hi].mr_rows > best_rows) { best_rows = c->tail.held[hi].mr_rows; fuse_at = (int)hi; }
-          // (... else the largest tile-rows launch: a wave per row piece of a few heavy prims, the long launch of such a flush -- behind
-          // the short rect pass of the same flush a setup stage would stick out)
-          if (fuse_at < 0) {
-            int best_items = 0;
-            for (size_t hi = 0; hi < c->tail.held.size(); hi++) {
-              const Context::Held& Hh = c->tail.held[hi];
-              if (Hh.row_n > 0 && Hh.row_mode == 2 && Hh.row_items > best_items && can_fuse(Hh)) { best_items = Hh.row_items; fuse_at = (int)hi; }
-            }
-          }
-          for (size_t hi = 0; hi < c->tail.held.size() && fuse_at < 0; hi++) if (can_fuse(c->tail.held[hi])) fuse_at = (int)hi;
-        }
       if (fuse_at >= 0) {
         // the previous flush's held-back raster launches, in order; the first one the fused kernel has a
         // variant for (normally the tile pass, the longest) carries this flush's setup stage along
         Context::Tail& T = c->tail;
-        WrSetupArgs SA{ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims, dtargets, S.masks, S.vtab, c->dcounters, dblk};
-        launch_held(T.held, T.targets, T.n_targets, T.draws, c->scratch[T.set], fuse_at, &SA, n_setup_blocks, setup_bytes);
+        WrSetupArgs SA{ddraws, nd_arg, dinst, S.prims, S.recs, S.aux, n_prims, dtargets, S.masks, S.vtab, c->dcounters, dblk, nullptr, 0, 0, 0};
+        uint64_t carried = setup_bytes;
+        if (c->ps.valid) {
+          SA.up_segs = (const WrUploadSeg*)(c->dupload + c->ps.seg_off); SA.up_nseg = c->ps.nseg; SA.up_parts = c->ps.parts; SA.up_blocks = c->ps.nseg * c->ps.parts;
+          carried += c->ps.bytes;
+          c->ps.valid = false;
+        }
+        launch_held(T.held, T.targets, T.n_targets, T.draws, c->scratch[T.set], fuse_at, &SA, n_setup_blocks, carried);
         tail_launched();
       } else {
         prof_begin();
@@ -2001,6 +2035,7 @@ void flush_work(const std::vector<int>& sel_in) {
     } else {
       drain_tail();
     }
+    launch_pending_scatter();      // (nothing is pending unless a carrier was planned and not used)
 #ifdef WRHIP_HOSTSIM
     if (getenv("WRHIP_DEBUG")) {
       fprintf(stderr, "flush: targets %d draws %d prims %d bins %d words %d\n", n_targets, nd, n_prims, n_bins, n_words);
@@ -2456,6 +2491,11 @@ void TexSubImage2D(GLenum target, GLint level, GLint xoffset, GLint yoffset, GLs
     t.complex_ids_headers |= (f & 1) != 0; t.complex_ids_gpubuf |= (f & 2) != 0;
   }
   queue_upload(st_off, (uint8_t*)t.dptr + (size_t)yoffset * t.stride + (size_t)xoffset * t.bpp, t.stride, row, height);
+  t.up_batch = ctx->upload_batch;
+  // (a data texture uploaded whole, its rows packed as the texture holds them: readable in the staging mirror)
+  if (xoffset == 0 && yoffset == 0 && width == t.width && height == t.height && row == (size_t)t.stride && (st_off & 15) == 0 &&
+      (t.internal_format == GL_RGBA32F || t.internal_format == GL_RGBA32I)) { t.view_batch = ctx->upload_batch; t.view_off = st_off; }
+  else t.view_batch = 0;
 }
 void TexImage2D(GLenum target, GLint level, GLint internal_format, GLsizei width, GLsizei height, GLint, GLenum format,
                 GLenum ty, const void* data) {
@@ -3028,6 +3068,13 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     // (gradient tables: the span shaders and main() of every gradient program read the stops where the frame builder put them --
     // unless the setup stage copies them into the flush's pool for this draw, WR_DF_GTAB)
     if (grad_prog && !gtab) rmask |= 1u << WR_S_GPU_BUFFER_F;
+    // Fused scatter: what the SETUP stage reads (the data textures: everything outside rmask) must not depend on the batch's scatter,
+    // which runs beside it in the same launch.  A texture the open batch uploads whole is read in the staging mirror (same layout,
+    // alive as long as the flush's arena); one it writes in part keeps the scatter in front of the setup stage.
+    if (!((rmask >> s) & 1) && c->upload_open && t->up_batch == c->upload_batch) {
+      if (t->view_batch == c->upload_batch && c->fuse_scatter) td.ptr = c->dupload + t->view_off;
+      else c->scatter_first = true;
+    }
     if ((rmask >> s) & 1) {
       std::vector<GLuint>& rr = c->work[wi].rreads;
       if (std::find(rr.begin(), rr.end(), tid) == rr.end()) rr.push_back(tid);

@@ -4857,9 +4857,10 @@ __global__ void __launch_bounds__(256) wr_setup_kernel(const WrDrawDesc* __restr
 // Scatter queued texture uploads from the staging mirror to their textures.
 // 8 workgroups per segment; 16-byte lanes where the rows allow it.
 // `parts` workgroups per segment (the host sizes it for the largest segment of the batch: one per 64 KB, 8 .. 256)
-#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone, not by the instantiation units wrhip_inst.hip) */
-__global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs, int parts) {
-  const int si = (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
+// (the body: also run by the first workgroups of a flush's setup-carrying launch -- WrSetupArgs::up_*, "fused scatter" --, which takes the
+// scatter off the frame's critical path: the setup stage reads whole-texture uploads of data textures straight from the staging mirror)
+WR_DEVICE void wr_upload_body(const WrUploadSeg* __restrict__ segs, int n_segs, int parts, int bid) {
+  const int si = bid / parts, part = bid % parts;
   if (si >= n_segs) return;
   const WrUploadSeg sg = segs[si];
   const size_t total = (size_t)sg.row_bytes * sg.rows;
@@ -4876,6 +4877,10 @@ __global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_seg
       ((uint8_t*)sg.dst)[r * sg.dst_stride + c] = sg.src[i];
     }
   }
+}
+#ifndef WR_INST_ONLY      /* (not a template: defined by wrhip.hip alone, not by the instantiation units wrhip_inst.hip) */
+__global__ void wr_upload_kernel(const WrUploadSeg* __restrict__ segs, int n_segs, int parts) {
+  wr_upload_body(segs, n_segs, parts, (int)blockIdx.x);
 }
 #endif
 
@@ -10088,7 +10093,20 @@ wr_raster_chain_kernel(const WrTargetDesc* __restrict__ targets, int n_targets,
 struct WrSetupArgs {
   const WrDrawDesc* draws; int n_draws; const uint8_t* arena; WrPrim* prims; WrRec* recs; WrAux* aux; int n_prims;
   const WrTargetDesc* targets; unsigned long long* masks; float* vtab; WrUnsupportedCounters* cnt; const int* blk;
+  // fused scatter: the batch's upload segments, run by the launch's first up_blocks workgroups (0: none)
+  const WrUploadSeg* up_segs; int up_nseg, up_parts, up_blocks;
 };
+// the workgroup's role in a setup-carrying launch: scatter first, then the setup stage, then the launch's own work (returns the index within it)
+#define WR_FUSED_PROLOGUE(S, n_setup_blocks)                                                                                      \
+  int wr_bid = (int)blockIdx.x;                                                                                                   \
+  if (wr_bid < (S).up_blocks) { wr_upload_body((S).up_segs, (S).up_nseg, (S).up_parts, wr_bid); return; }                         \
+  wr_bid -= (S).up_blocks;                                                                                                        \
+  if (wr_bid < (n_setup_blocks)) {                                                                                                \
+    WR_SETUP_PRIO();                                                                                                              \
+    wr_setup_body((S).draws, (S).n_draws, (S).arena, (S).prims, (S).recs, (S).aux, (S).n_prims, (S).targets, (S).masks, (S).vtab, (S).cnt, (S).blk, wr_bid); \
+    return;                                                                                                                       \
+  }                                                                                                                               \
+  wr_bid -= (n_setup_blocks);
 // (the setup stage needs ~114 VGPRs: the fused rect variant asks for 4 waves per SIMD, not the 8 of the plain one)
 #ifdef WRHIP_HOSTSIM
 #define WR_FUSED_BOUNDS(R, FEAT) __launch_bounds__(1024 / R)
@@ -10105,13 +10123,8 @@ wr_setup_raster_kernel(WrSetupArgs S, int n_setup_blocks,
                        const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                        const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                        unsigned long long* __restrict__ masks, int bin_offset) {
-  if ((int)blockIdx.x < n_setup_blocks) {
-    WR_SETUP_PRIO();
-    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
-    return;
-  }
-  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks,
-                                      (int)blockIdx.x - n_setup_blocks + bin_offset);
+  WR_FUSED_PROLOGUE(S, n_setup_blocks)
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, wr_bid + bin_offset);
 }
 // ... and for a THIN colour launch (<= 256 bins, four 256-thread workgroups of 64 x 4 pixel strips per bin: see wr_raster_kernel's R == 1
 // entry) -- wrench transforms-simple: 35 us of setup stage in line with 79 us of raster every frame, because the small launch was worth
@@ -10124,12 +10137,8 @@ wr_setup_raster_thin_kernel(WrSetupArgs S, int n_setup_blocks,
                             const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                             unsigned long long* __restrict__ masks, int bin_offset) {
   static_assert(R == 1 && FMT == WR_FMT_RGBA8 && !DEPTH, "the thin colour shape");
-  if ((int)blockIdx.x < n_setup_blocks) {
-    WR_SETUP_PRIO();
-    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
-    return;
-  }
-  const int b = (int)blockIdx.x - n_setup_blocks;
+  WR_FUSED_PROLOGUE(S, n_setup_blocks)
+  const int b = wr_bid;
   wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, b / 4 + bin_offset, b % 4, 4);
 }
 // Text launches: the glyph walk is latency-bound (cfg3: per-lane record + atlas fetches), a fourth wave per SIMD pays for the handful
@@ -10158,13 +10167,8 @@ wr_setup_raster_dense_kernel(WrSetupArgs S, int n_setup_blocks,
                              const WrDrawDesc* __restrict__ draws, const WrPrim* __restrict__ prims,
                              const WrRec* __restrict__ recs, const WrAux* __restrict__ aux, const float* __restrict__ vtab,
                              unsigned long long* __restrict__ masks, int bin_offset) {
-  if ((int)blockIdx.x < n_setup_blocks) {
-    WR_SETUP_PRIO();
-    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
-    return;
-  }
-  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks,
-                                      (int)blockIdx.x - n_setup_blocks + bin_offset);
+  WR_FUSED_PROLOGUE(S, n_setup_blocks)
+  wr_raster_body<FMT, DEPTH, R, FEAT>(targets, n_targets, draws, prims, recs, aux, vtab, masks, wr_bid + bin_offset);
 }
 // The same fusion for a flush whose longest held-back launch is a mask-rows launch (cfg4: the tile passes are 11-17 us, the
 // setup stage of the next frame 30-50 us of dependent latency, the rows launch 50-100 us).
@@ -10173,20 +10177,14 @@ __global__ void __launch_bounds__(256, 4)
 wr_setup_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __restrict__ targets, int bin_lo, int bin_hi,
                      const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux, unsigned long long* __restrict__ ctl,
                      const WrMaskSlot* __restrict__ slots, uint8_t* __restrict__ store) {
-  if ((int)blockIdx.x < n_setup_blocks) {
-    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
-    return;
-  }
-  wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, (int)blockIdx.x - n_setup_blocks, (int)gridDim.x - n_setup_blocks);
+  WR_FUSED_PROLOGUE(S, n_setup_blocks)
+  wr_mask_rows_body(targets, bin_lo, bin_hi, prims, aux, ctl, slots, store, wr_bid, (int)gridDim.x - n_setup_blocks - S.up_blocks);
 }
 // ... and in front of a tile-rows launch (wr_tile_rows_kernel): a frame whose tiles all went to the row kernel has no bin launch to carry it
 __global__ void __launch_bounds__(256, 4)
 wr_setup_tile_rows_kernel(WrSetupArgs S, int n_setup_blocks, const WrTargetDesc* __restrict__ targets, int t0, int nt, const WrDrawDesc* __restrict__ draws,
                           const WrPrim* __restrict__ prims, const WrAux* __restrict__ aux) {
-  if ((int)blockIdx.x < n_setup_blocks) {
-    wr_setup_body(S.draws, S.n_draws, S.arena, S.prims, S.recs, S.aux, S.n_prims, S.targets, S.masks, S.vtab, S.cnt, S.blk, (int)blockIdx.x);
-    return;
-  }
-  wr_tile_rows_body(targets, t0, nt, draws, prims, aux, (int)blockIdx.x - n_setup_blocks, (int)gridDim.x - n_setup_blocks);
+  WR_FUSED_PROLOGUE(S, n_setup_blocks)
+  wr_tile_rows_body(targets, t0, nt, draws, prims, aux, wr_bid, (int)gridDim.x - n_setup_blocks - S.up_blocks);
 }
 #endif
