@@ -65,6 +65,37 @@ def measured_ceiling():
 REPEATS = 7            # timed regions per run; the median is reported
 
 
+def pin_to_gpu_numa_node(local_rank):
+    """Run this process (and the threads the backend starts) on the CPU socket the GPU hangs off: the render thread writes the pinned
+    staging ring and rings doorbells for every frame, and a two-socket host places a new process on either socket (what `numactl
+    --cpunodebind` does for wrench on a multi-socket box).  Only when the launcher left the process free to run anywhere; WRHIP_BENCH_NO_PIN=1
+    turns it off.  Returns a description for the bench line."""
+    if os.environ.get("WRHIP_BENCH_NO_PIN"):
+        return "not pinned (WRHIP_BENCH_NO_PIN)"
+    try:
+        import ctypes as C
+        import torch
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(local_rank)) != 0:
+            return "not pinned (no PCI bus id)"
+        bus = buf.value.decode().lower()
+        node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read())
+        if node < 0:
+            return "not pinned (device reports no NUMA node)"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        if len(allowed) < os.cpu_count():
+            return f"not pinned (launcher restricted the process to {len(allowed)} CPUs)"
+        os.sched_setaffinity(0, cpus & allowed)
+        return f"NUMA node {node} of GPU {bus} ({len(cpus & allowed)} CPUs)"
+    except Exception as e:          # noqa: BLE001 -- placement is an optimisation, never a failure
+        return f"not pinned ({type(e).__name__}: {e})"
+
+
 def make_frame(workload, **kw):
     from webrender_amd import scenes
     return scenes.make_workload(workload, **kw)
@@ -205,6 +236,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libwrhip has no CPU path")
     torch.cuda.set_device(local_rank)
+    affinity = pin_to_gpu_numa_node(local_rank)
     if sharded:
         import torch.distributed as dist
         if world == 1:
@@ -431,6 +463,7 @@ def main():
             out["metric"] += f" [N > 1: {args.workload}, one frame split over the ranks]"
             out["vs_baseline"] = out["speedup_vs_single_gpu"]
             out["vs_baseline_note"] = "value / single_gpu_same_workload.value (same workload, unsharded, rank 0's GPU, this run); BASELINE.md has no published number"
+        out["host_affinity"] = affinity
         if host:
             out["host"] = host
             if roof:

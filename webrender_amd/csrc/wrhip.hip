@@ -501,6 +501,7 @@ struct Context {
   std::vector<UploadSeg> useg;
   size_t upload_begin = 0;        // staging offset where the pending batch starts
   bool upload_open = false;
+  uint64_t lap_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lap_n = 0;      // WRHIP_DEBUG_LAPS=1: where flush_work's time goes (printed at context destruction)
   uint64_t upload_batch = 1;      // id of the open (or next) batch: Texture::up_batch / view_batch compare with it
   bool scatter_first = false;     // a recorded draw's setup stage reads a data texture the open batch writes PARTLY: the scatter has to precede it
   struct PendingScatter { size_t seg_off = 0; int nseg = 0, parts = 0; uint64_t bytes = 0; bool valid = false; } ps;   // a batch's scatter handed to the flush's setup-carrying launch
@@ -767,7 +768,7 @@ bool ring_make_safe(uint64_t need_v, bool may_drain) {
     return true;
   }
   if (!may_drain) return false;
-  flush_uploads();                  // (what is staged goes out, then everything enqueued completes)
+  flush_uploads(771);                  // (what is staged goes out, then everything enqueued completes)
   sync_stream();
   c->ring_safe = c->ring_base + c->staging_pos;
   return true;
@@ -793,7 +794,7 @@ size_t staging_alloc(size_t n) {
   Context* c = ctx;
   n = (n + 255) & ~size_t(255);
   if (!c->staging || n > c->staging_size) {
-    flush_uploads();
+    flush_uploads(797);
     sync_stream();
     wrrt::pinned_free(c->staging);
     wrrt::dev_free(c->dupload);
@@ -804,7 +805,7 @@ size_t staging_alloc(size_t n) {
     c->ring_base = c->ring_safe = 0; c->ring_fences = 0;      // (a new ring: nothing in flight refers to it)
   }
   if (c->staging_pos + n > c->staging_size) {
-    flush_uploads();                // the pending batch must stay contiguous
+    flush_uploads(808);                // the pending batch must stay contiguous
     c->ring_base += c->staging_size;   // the next lap
     c->staging_pos = 0;
   }
@@ -824,7 +825,7 @@ void order_upload(const void* dst, size_t dst_stride, size_t row_bytes, size_t r
   const uint8_t* b0 = (const uint8_t*)dst; const uint8_t* b1 = b0 + (rows - 1) * dst_stride + row_bytes;
   for (const Context::UploadSeg& q : ctx->useg) {
     const uint8_t* a0 = (const uint8_t*)q.dst; const uint8_t* a1 = a0 + (size_t)(q.rows - 1) * q.dst_stride + q.row_bytes;
-    if (a0 < b1 && b0 < a1) { flush_uploads(); return; }
+    if (a0 < b1 && b0 < a1) { flush_uploads(828); return; }
   }
 }
 
@@ -838,7 +839,7 @@ void queue_upload(size_t src_off, void* dst, size_t dst_stride, size_t row_bytes
 }
 
 // One DMA for everything staged since the last flush, then the scatter kernel.
-void flush_uploads(size_t, bool may_defer) {
+void flush_uploads(size_t why, bool may_defer) {
   Context* c = ctx;
   if (!c->upload_open) return;
   size_t nseg = c->useg.size();
@@ -885,6 +886,8 @@ void flush_uploads(size_t, bool may_defer) {
       // the caller's next launch carries the setup stage: its first workgroups run the scatter (no launch of its own)
       c->ps.seg_off = seg_off; c->ps.nseg = (int)nseg; c->ps.parts = parts; c->ps.bytes = up_bytes; c->ps.valid = true;
     } else {
+      static const bool dbg = getenv("WRHIP_DEBUG_SCATTER") != nullptr;
+      if (dbg) fprintf(stderr, "scatter launch of its own (flush_uploads called from line %zu): %zu segments, may_defer %d scatter_first %d pending %d\n", why, nseg, (int)may_defer, (int)c->scatter_first, (int)c->ps.valid);
       prof_begin();
       WR_LAUNCH(wr_upload_kernel, (int)nseg * parts, 256, c->stream, (const WrUploadSeg*)(c->dupload + seg_off), (int)nseg, parts);
       prof_end(0, 0, 0, 0, up_bytes, nseg * parts);
@@ -918,7 +921,7 @@ void flush_work(const std::vector<int>& sel);
 // A host- or copy-side write to texture `t` (or its deletion / reallocation)
 // must not overtake pending draws that read or write it.
 void sync_texture_for_write(Texture& t) { if (t.pending_read || t.pending_write) flush_all(); if (t.tail_ref) drain_tail(); }
-void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); if (t.tail_ref) drain_tail(); flush_uploads(); }
+void sync_texture_for_read(Texture& t) { if (t.pending_write) flush_all(); if (t.tail_ref) drain_tail(); flush_uploads(924); }
 
 size_t pool_round(size_t n) {
   size_t g = n <= (1u << 20) ? 4096 : (size_t(1) << 16);
@@ -961,7 +964,7 @@ void pool_free(void* p, size_t n) {
 
 void free_texture_storage(Texture& t) {
   sync_texture_for_write(t);
-  flush_uploads();   // queued rows may target this storage
+  flush_uploads(967);   // queued rows may target this storage
   if (t.dptr) {
     pool_free(t.dptr, t.dsize);
     t.dptr = nullptr; t.dsize = 0;
@@ -982,7 +985,7 @@ bool allocate_texture(Texture& t) {
   }
   if (size == 0) return true;
   if (!t.dptr || size > t.dsize) {
-    if (t.dptr) { flush_uploads(); pool_free(t.dptr, t.dsize); }
+    if (t.dptr) { flush_uploads(988); pool_free(t.dptr, t.dsize); }
     size_t actual = 0;
     t.dptr = pool_alloc(size, &actual);
     t.dsize = actual;
@@ -1200,7 +1203,7 @@ Context::~Context() {
   Context* saved = ctx;
   ctx = this;
   flush_all();
-  flush_uploads();
+  flush_uploads(1206);
   sync_stream();
   for (Texture* t : textures.objects) if (t) { if (t->dptr) wrrt::dev_free(t->dptr); t->dptr = nullptr; free(t->hmirror); t->hmirror = nullptr; }
   for (auto& kv : pool) wrrt::dev_free(kv.second);
@@ -1545,6 +1548,10 @@ void flush_work(const std::vector<int>& sel_in) {
   Context* c = ctx;
   if (!c || c->work.empty() || sel_in.empty()) return;
   HostTimer ht(&c->stats.host_flush_ns);
+  static const bool laps = getenv("WRHIP_DEBUG_LAPS") != nullptr;
+  auto lap_t = std::chrono::steady_clock::now();
+  auto lap = [&](int i) { if (laps) { const auto n = std::chrono::steady_clock::now(); c->lap_ns[i] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(n - lap_t).count(); lap_t = n; } };
+  if (laps) c->lap_n++;
   std::vector<int> sel(sel_in);
   std::sort(sel.begin(), sel.end());
   sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
@@ -1899,6 +1906,7 @@ void flush_work(const std::vector<int>& sel_in) {
     for (int oi = 0; oi < n_targets; oi++) if (flat_off[oi] != SIZE_MAX) targets[oi].flat_rows = S.flat + flat_off[oi];
   }
   if (any_work) {
+    lap(0);      // planning: forwarding, levels, per-target descriptors
     // ---- frame arena: [draws | targets | instance bytes] -> one H2D copy ----
     size_t off_draws = 0;
     size_t off_targets = (off_draws + sizeof(WrDrawDesc) * nd + 255) & ~size_t(255);
@@ -1962,10 +1970,12 @@ void flush_work(const std::vector<int>& sel_in) {
       }
       for (size_t hi = 0; hi < c->tail.held.size() && fuse_at < 0; hi++) if (can_fuse(c->tail.held[hi])) fuse_at = (int)hi;
     }
+    lap(1);      // arena staged
     flush_uploads(0, fuse_at >= 0);     // one DMA: queued texture uploads + this arena; then the scatter (its own launch, or the carrier's first workgroups)
     uint8_t* darena = c->dupload + aoff;
     c->stats.h2d_bytes += total;
     algo_bytes += inst_bytes + sizeof(WrDrawDesc) * nd;
+    lap(2);      // DMA + scatter queued
     // ---- scratch (two sets: the deferred tail of the previous flush still reads the other one) ----
     Context::Scratch& S = c->scratch[c->flush_seq & 1];
     if (S.vtab_cap < vtab_cursor + 1 || S.masks_cap < (size_t)n_words + 1) {      // (prims / recs / aux: sized above)
@@ -2036,6 +2046,7 @@ void flush_work(const std::vector<int>& sel_in) {
       drain_tail();
     }
     launch_pending_scatter();      // (nothing is pending unless a carrier was planned and not used)
+    lap(3);      // setup + held launches queued
 #ifdef WRHIP_HOSTSIM
     if (getenv("WRHIP_DEBUG")) {
       fprintf(stderr, "flush: targets %d draws %d prims %d bins %d words %d\n", n_targets, nd, n_prims, n_bins, n_words);
@@ -2156,6 +2167,7 @@ void flush_work(const std::vector<int>& sel_in) {
     c->stats.raster_pixels += pixels;
     c->stats.raster_algo_bytes += algo_bytes;
   }
+  lap(4);        // this flush's own launches
   // ---- drop the flushed work, keep the rest, rebuild hazard flags ----------
   std::vector<char> gone(c->work.size(), 0);
   for (int i : sel) gone[i] = 1;
@@ -2172,6 +2184,13 @@ void flush_work(const std::vector<int>& sel_in) {
   for (size_t i = 0; i < c->work.size(); i++) {
     mark_ref(c->work[i].tex, c->textures[c->work[i].tex], true, (int)i);
     for (GLuint id : c->work[i].reads) if (Texture* t = c->textures.find(id)) mark_ref(id, *t, false);
+  }
+  lap(5);        // bookkeeping
+  if (laps && (c->lap_n % 1000) == 0) {
+    fprintf(stderr, "libwrhip flush laps (us per flush, %llu flushes): plan %.2f arena %.2f uploads %.2f setup+held %.2f own launches %.2f bookkeeping %.2f\n",
+            (unsigned long long)c->lap_n, c->lap_ns[0] / 1e3 / c->lap_n, c->lap_ns[1] / 1e3 / c->lap_n, c->lap_ns[2] / 1e3 / c->lap_n, c->lap_ns[3] / 1e3 / c->lap_n,
+            c->lap_ns[4] / 1e3 / c->lap_n, c->lap_ns[5] / 1e3 / c->lap_n);
+    memset(c->lap_ns, 0, sizeof(c->lap_ns)); c->lap_n = 0;
   }
 }
 
@@ -2808,7 +2827,7 @@ void CopyImageSubData(GLuint srcName, GLenum srcTarget, GLint, GLint srcX, GLint
       dstX + srcWidth > d.width || dstY + srcHeight > d.height) return;
   sync_texture_for_read(s);
   sync_texture_for_write(d);
-  flush_uploads();
+  flush_uploads(2830);
   wrrt::copy2d((uint8_t*)d.dptr + (size_t)dstY * d.stride + (size_t)dstX * d.bpp, d.stride,
                (const uint8_t*)s.dptr + (size_t)srcY * s.stride + (size_t)srcX * s.bpp, s.stride,
                (size_t)srcWidth * s.bpp, srcHeight, 2, ctx->stream);
@@ -2849,7 +2868,7 @@ static void blit_textures(GLuint src_id, Texture& s, GLuint dst_id, Texture& d, 
   }
   sync_texture_for_read(s);
   sync_texture_for_write(d);
-  flush_uploads();
+  flush_uploads(2871);
   WrBlitArgs a;
   a.src = s.dptr; a.dst = d.dptr; a.src_stride = s.stride; a.dst_stride = d.stride; a.sbpp = s.bpp; a.dbpp = d.bpp;
   a.sw = s.width; a.sh = s.height;
@@ -3073,7 +3092,11 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
     // alive as long as the flush's arena); one it writes in part keeps the scatter in front of the setup stage.
     if (!((rmask >> s) & 1) && c->upload_open && t->up_batch == c->upload_batch) {
       if (t->view_batch == c->upload_batch && c->fuse_scatter) td.ptr = c->dupload + t->view_off;
-      else c->scatter_first = true;
+      else {
+        static const bool dbg = getenv("WRHIP_DEBUG_SCATTER") != nullptr;
+        if (dbg && !c->scatter_first) fprintf(stderr, "scatter first: slot %d texture %u %dx%d fmt %x (the open batch writes it in part)\n", s, tid, t->width, t->height, t->internal_format);
+        c->scatter_first = true;
+      }
     }
     if ((rmask >> s) & 1) {
       std::vector<GLuint>& rr = c->work[wi].rreads;
@@ -3186,7 +3209,7 @@ void DrawElementsInstanced(GLenum mode, GLsizei count, GLenum type, GLintptr off
 
 void Finish(void) {
   flush_all();
-  flush_uploads();
+  flush_uploads(3212);
   sync_stream();
   ctx->held_seq = ctx->flush_seq; ctx->fb_writes_since_held = 0;
   {
@@ -3282,6 +3305,9 @@ void DestroyContext(WrhipContext* c_) {
 #ifdef WRHIP_HOSTSIM
   if (getenv("WRHIP_DEBUG")) fprintf(stderr, "paths: r8fast %llu (unit %llu) generic %llu accum_loop %llu linear: fallback %llu upscale %llu fast %llu downscale %llu\n", wr_dbg_paths[0], wr_dbg_paths[3], wr_dbg_paths[1], wr_dbg_paths[2], wr_dbg_paths[4], wr_dbg_paths[5], wr_dbg_paths[6], wr_dbg_paths[7]);
 #endif
+  if (c->lap_n) fprintf(stderr, "libwrhip flush laps (us per flush, %llu flushes): plan %.2f arena %.2f uploads %.2f setup+held %.2f own launches %.2f bookkeeping %.2f\n",
+                        (unsigned long long)c->lap_n, c->lap_ns[0] / 1e3 / c->lap_n, c->lap_ns[1] / 1e3 / c->lap_n, c->lap_ns[2] / 1e3 / c->lap_n, c->lap_ns[3] / 1e3 / c->lap_n,
+                        c->lap_ns[4] / 1e3 / c->lap_n, c->lap_ns[5] / 1e3 / c->lap_n);
   if (ctx == c) { delete c; ctx = nullptr; }
   else delete c;
 }
@@ -3370,7 +3396,7 @@ void CompositeYUV(LockedTexture* lockedDst, LockedTexture* lockedY, LockedTextur
   flush_all();
   sync_texture_for_read(yt); sync_texture_for_read(ut); sync_texture_for_read(vt);
   sync_texture_for_write(d);
-  flush_uploads();
+  flush_uploads(3399);
   WrYuvBlitArgs A;
   memset(&A, 0, sizeof(A));
   auto desc = [](const Texture& t) {
@@ -3462,8 +3488,8 @@ void WrhipGetStats(WrhipStats* out) { if (ctx && out) *out = ctx->stats; }
 void WrhipResetStats(void) { if (ctx) { memset(&ctx->stats, 0, sizeof(ctx->stats)); ctx->kstats.clear(); } }
 void WrhipSetProfiling(int enabled) {
   if (!ctx) return;
-  if (enabled && !ctx->profiling) { flush_all(); flush_uploads(); sync_stream(); }   // nothing held back may go out unprofiled
-  if (!enabled && ctx->profiling) { flush_all(); flush_uploads(); sync_stream(); }
+  if (enabled && !ctx->profiling) { flush_all(); flush_uploads(3491); sync_stream(); }   // nothing held back may go out unprofiled
+  if (!enabled && ctx->profiling) { flush_all(); flush_uploads(3492); sync_stream(); }
   ctx->profiling = enabled != 0;
   ctx->profiling_deferred = enabled == 2;
 }
@@ -3498,7 +3524,7 @@ const char* WrhipDeviceName(void) { return g_rt_ok ? g_device_name : nullptr; }
 void WrhipFlush(void) {
   if (!ctx) return;
   flush_all();
-  flush_uploads();
+  flush_uploads(3527);
   drain_tail();
   ctx->held_seq = ctx->flush_seq; ctx->fb_writes_since_held = 0;      // (everything is on the stream: WrhipFlushHeld counts from here)
 #ifndef WRHIP_HOSTSIM
@@ -3517,7 +3543,7 @@ int WrhipFlushHeld(void) {
   if (!ctx) return 0;
   const int64_t seq0 = ctx->held_seq;
   flush_all();
-  flush_uploads();
+  flush_uploads(3546);
   const int64_t n = ctx->flush_seq - seq0;
   const bool early_fb = n > 1 && ctx->fb_writes_since_held - (ctx->last_flush_wrote_fb ? 1 : 0) > 0;
   ctx->held_seq = ctx->flush_seq;
