@@ -1914,7 +1914,7 @@ void flush_work(const std::vector<int>& sel_in) {
     // first draw of every 64-prim block (wr_vertex_prim starts its draw lookup there)
     const int n_blocks = (n_prims + 63) / 64;
     size_t off_blk = (off_inst + inst_bytes + 255) & ~size_t(255);
-    const size_t off_qctl = (off_blk + sizeof(int) * n_blocks + 63) & ~size_t(63);      // the row-table pool's allocation word: zero on arrival
+    const size_t off_qctl = (off_blk + sizeof(WrBlock) * n_blocks + 63) & ~size_t(63);      // the row-table pool's allocation word: zero on arrival
     // ... and the mask-row store's control block ([0] allocation word, [32..63] byte counters): part of the arena as well, so that it
     // arrives zeroed with the arena's DMA instead of by a fill launch of its own per flush (4.7 us of stream time and a runtime call
     // per frame of every workload with clip masks)
@@ -1944,11 +1944,15 @@ void flush_work(const std::vector<int>& sel_in) {
       }
     }
     {
-      int* blk = (int*)(h + off_blk);
+      // (... and the draws and targets the block's wave stages in LDS: WrDescView)
+      WrBlock* blk = (WrBlock*)(h + off_blk);
       int j = 0;
       for (int b = 0; b < n_blocks; b++) {
         while (j + 1 < nd && draws[j + 1].first_prim <= 64 * b) j++;
-        blk[b] = j;
+        WrBlock B;
+        B.lo0 = j; B.nk = nd - j >= 2 ? 2 : nd - j;
+        B.t0 = B.nk > 0 ? draws[j].target : -1; B.t1 = B.nk > 1 ? draws[j + 1].target : -1;
+        blk[b] = B;
       }
     }
     // the launch that will carry this flush's setup stage (if any): it also runs the batch's scatter, in its first workgroups
@@ -3250,6 +3254,9 @@ static void wr_dump_prim_times() {
   wrq::drain();
   if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(wr_dbg_prim), h.size() * 4) != hipSuccess) return;
   if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+  std::vector<unsigned long long> tp(16384 * 8);
+  if (hipMemcpyFromSymbol(tp.data(), HIP_SYMBOL(wr_dbg_tp), tp.size() * 8) != hipSuccess) return;
+  if (FILE* f = fopen((std::string(path) + ".tp").c_str(), "wb")) { fwrite(tp.data(), 8, tp.size(), f); fclose(f); }
 }
 #endif
 #ifdef WR_ROWS_TIMING
