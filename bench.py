@@ -212,6 +212,78 @@ def cpu_baseline(rec, budget_s=12.0):
     return out
 
 
+XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
+XGMI_EFFICIENCY = 0.7        # ASSUMED payload efficiency of a large ncclSend / ncclRecv over one link (not measured: no multi-GPU node)
+
+
+def emulate_world(args):
+    """bench.py --emulate-world W [--workload cfg5]: what each rank of a W-rank run would do, one rank after the other on this one
+    GPU -- the rank's frame (built for its tiles: webrender_amd/dist.py build_rank_frame), its row restriction, its uploads -- each
+    streamed and timed like the N = 1 bench; then the projection: the frame rate of the slowest rank against the time the presenting
+    GPU needs to receive the other ranks' strips, each over its own xGMI link (the native loop moves frame k's strips while frame
+    k + 1 is flushed, so the two overlap: frame time = max of the two).  Everything under "projected" is a model, labelled so."""
+    import torch
+    import ctypes as C
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libwrhip has no CPU path")
+    torch.cuda.set_device(0)
+    from webrender_amd import glapi
+    from webrender_amd.harness import record_scene, ScenePlayer
+    from webrender_amd.dist import ShardedFramePlayer, strip_rows
+    W = args.emulate_world
+    wl = args.workload or "cfg5"
+    lib = glapi.wrhip_path()
+
+    def timed(player, stats_of):
+        player.frames(args.warmup, 0)
+        player.stream(max(2, args.warmup))
+        reg = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            player.stream(args.steps)
+            torch.cuda.synchronize()
+            reg.append(time.perf_counter() - t0)
+        st = glapi.WrhipStats()
+        C.CFUNCTYPE(None)(stats_of.symbol("WrhipResetStats"))()
+        player.stream(args.steps)
+        C.CFUNCTYPE(None, C.c_void_p)(stats_of.symbol("WrhipGetStats"))(C.byref(st))
+        return float(np.median(reg)) / args.steps, st
+
+    rec, _ = record_scene(lib, make_frame(wl, encoding=args.encoding))
+    full = ScenePlayer(lib, rec)
+    t1, s1 = timed(full, full)
+    width, height = rec.width, rec.height
+    del full
+    ranks = []
+    for r in range(W):
+        p = ShardedFramePlayer(lib, wl, args.encoding, r, W, device="cuda", native=None)
+        t, st = timed(p.player, p)          # (the rank's frames through the plain replayer: no exchange, that is the model's part)
+        sy0, sy1, _ = strip_rows(height, r, W)
+        ranks.append({"rank": r, "screen_rows": [int(sy0), int(sy1)], "us_per_frame": round(1e6 * t, 1), "prims_per_frame": int(st.prims // args.steps),
+                      "h2d_bytes_per_frame": int(st.h2d_bytes // args.steps)})
+        del p
+    slow = max(x["us_per_frame"] for x in ranks)
+    strip_bytes = max(x["screen_rows"][1] - x["screen_rows"][0] for x in ranks[1:]) * width * 4 if W > 1 else 0
+    gather_us = 1e6 * strip_bytes / (XGMI_LINK_GBS * 1e9 * XGMI_EFFICIENCY)
+    frame_us = max(slow, gather_us)
+    out = {"metric": f"PROJECTED frames/sec of {wl} split over {W} GPUs, from every rank's share measured on ONE GPU (bench.py --emulate-world)",
+           "value": round(1e6 / frame_us, 2), "unit": "frames/s", "projected": True, "n_gpus": 1, "emulated_world": W,
+           "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": wl, "encoding": args.encoding, "target": f"{width}x{height}"},
+           "single_gpu": {"us_per_frame": round(1e6 * t1, 1), "frames_per_s": round(1 / t1, 2), "h2d_bytes_per_frame": int(s1.h2d_bytes // args.steps),
+                          "prims_per_frame": int(s1.prims // args.steps)},
+           "per_rank": ranks,
+           "model": {"slowest_rank_us": slow, "gather_us": round(gather_us, 1), "strip_bytes": int(strip_bytes),
+                     "xgmi_link_GBps": XGMI_LINK_GBS, "assumed_efficiency": XGMI_EFFICIENCY,
+                     "statement": "rank 0 receives the W - 1 other strips concurrently, each over its own point-to-point xGMI link, while the next frame is "
+                                  "flushed (the native loop's pipelined order): frame time = max(slowest rank, one strip / (link x efficiency)); "
+                                  "RCCL launch latency, the host's share of a rank's frame under W processes and PCIe contention between ranks are NOT modelled"},
+           "projected_speedup_vs_single_gpu": round(t1 * 1e6 / frame_us, 3),
+           "max_rank_h2d_frac": round(max(x["h2d_bytes_per_frame"] for x in ranks) / max(1, int(s1.h2d_bytes // args.steps)), 3)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +295,12 @@ def main():
     ap.add_argument("--encoding", default="quad", choices=["quad", "brush"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="take the N > 1 code path (sharded player, collectives) even with one rank: a self-test")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="W",
+                    help="on ONE GPU: every rank's share of a W-rank run (its strip's rows, its frame's uploads) timed back to back, "
+                         "and a PROJECTED W-GPU rate under a stated xGMI gather model (no collective runs)")
     args = ap.parse_args()
+    if args.emulate_world:
+        return emulate_world(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -237,6 +314,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: libwrhip has no CPU path")
     torch.cuda.set_device(local_rank)
     affinity = pin_to_gpu_numa_node(local_rank)
+    if not sharded and os.environ.get("WRHIP_BENCH_INIT_DIST"):
+        # A/B: the UNSHARDED bench inside a process that initialised torch.distributed with the given backend
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        be = os.environ["WRHIP_BENCH_INIT_DIST"]
+        dist.init_process_group(be, **({"device_id": torch.device("cuda", local_rank)} if be == "nccl" else {}))
+        if os.environ.get("WRHIP_BENCH_DIST_WARM"):      # ... and made it create its communicator (one collective)
+            t = torch.zeros(1, device="cuda" if be == "nccl" else "cpu"); dist.all_reduce(t); torch.cuda.synchronize()
     if sharded:
         import torch.distributed as dist
         if world == 1:

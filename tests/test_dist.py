@@ -43,6 +43,25 @@ if world == 2:      # the strips are whole tile rows: each rank records, stages 
     assert mine[0] < 0.65 * sf.prims and mine[1] < sf.h2d_bytes, (mine, sf.prims, sf.h2d_bytes)
 want, _ = render_direct(lib, make())
 ok = np.array_equal(got, want)
+# PER-RANK FRAME BUILDING (SURVEY section 8e: per-rank H2D): the rank builds the frame for the tiles of its strip only, so its data
+# textures hold its share of the prims -- same window, and at world 2 at most 0.6 of the unsharded frame's host-to-device bytes
+# (a frame with enough prims for the data textures to outweigh the fixed uploads: 8000 rects, BASELINE configs[4]'s generator)
+big = lambda tf=None: scenes.cfg5_many_rects(width=1024, height=1000, n=8000, seed=5, **({"tile_filter": tf(1000)} if tf else {}))
+want_big, _ = render_direct(lib, big())          # (before the player: render_direct leaves no context current)
+pr = ShardedFramePlayer(lib, "custom", "quad", rank, world, device="cpu", frame=big)
+pr.frames(1, 1)
+ok = ok and np.array_equal(pr.assembled(), want_big)
+sr = WrhipStats()
+C.CFUNCTYPE(None)(pr.symbol("WrhipResetStats"))(); pr.frames(0, 2); C.CFUNCTYPE(None, C.c_void_p)(pr.symbol("WrhipGetStats"))(C.byref(sr))
+del pr
+rec_big, _ = record_scene(lib, big())
+full_big = ScenePlayer(lib, rec_big)
+full_big.frames(1, 0)
+C.CFUNCTYPE(None)(full_big.symbol("WrhipResetStats"))(); full_big.frames(0, 2)
+sfb = WrhipStats(); C.CFUNCTYPE(None, C.c_void_p)(full_big.symbol("WrhipGetStats"))(C.byref(sfb))
+print(f"RANK{rank} per-rank frame: prims {sr.prims} of {sfb.prims}, h2d {sr.h2d_bytes} of {sfb.h2d_bytes} unsharded")
+if world == 2:
+    assert sr.h2d_bytes <= 0.6 * sfb.h2d_bytes and sr.prims <= 0.6 * sfb.prims, (sr.h2d_bytes, sfb.h2d_bytes, sr.prims, sfb.prims)
 # the same frames with the window gathered on the presenting rank only (SURVEY section 8e: "or gather to the presenting GPU")
 p2 = ShardedFramePlayer(lib, "custom", "quad", rank, world, device="cpu", frame=make(), gather="root")
 p2.frames(1, 2)

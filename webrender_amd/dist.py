@@ -33,6 +33,31 @@ def strip_rows(height, rank, world, align=64):
     return y0, y1, per * align
 
 
+def strip_tile_filter(height, rank, world):
+    """tile_filter(tx, ty) of the scene builders for `rank`: the picture-cache tiles with a row in the rank's strip.  A rank BUILDS
+    its frame with it -- the frame builder of a strip-sharded WebRender only visits the tiles it draws (picture/tile.rs culls per
+    tile anyway) -- so the data textures it uploads (GPU buffers, prim headers: one entry per prim per visited tile) hold the
+    rank's share, not the frame's: SURVEY section 8e's per-rank H2D.  The kept prims keep their z ids and their order."""
+    from .scenes import TILE_H
+    sy0, sy1, _ = strip_rows(height, rank, world)
+
+    def keep(tx, ty):
+        return ty * TILE_H < sy1 and (ty + 1) * TILE_H > sy0
+    keep.rows = (sy0, sy1)          # ... and within a kept tile, the prims with a row in the strip (the builders cull against it)
+    return keep
+
+
+def build_rank_frame(workload, encoding, rank, world):
+    """The rank's frame of a named workload: built for its tiles only where the workload's builder takes a tile filter and the
+    frame's height is known up front (BASELINE configs 1 / 2 / 5: tile grids of rects), the whole frame otherwise (the row
+    restriction still drops the other tiles' draws when they are recorded; the data textures are then the whole frame's)."""
+    from .scenes import make_workload
+    heights = {"cfg1": 1024, "cfg2": 2160, "cfg5": 4320}
+    if world > 1 and workload in heights:
+        return make_workload(workload, encoding=encoding, tile_filter=strip_tile_filter(heights[workload], rank, world))
+    return make_workload(workload, encoding=encoding)
+
+
 def target_rows_for_rank(rec, rank, world):
     """{texture name: (y0, y1)} in texture rows for this rank, plus the window
     strip in framebuffer rows.  The window projection is y-flipped
@@ -74,8 +99,9 @@ class ShardedFramePlayer:
         self.rank, self.world = rank, world
         self.gather = gather
         if frame is None:
-            from .scenes import make_workload
-            frame = make_workload(workload, encoding=encoding)
+            frame = build_rank_frame(workload, encoding, rank, world)
+        elif callable(frame):                 # frame(tile_filter_for(height)): the caller's builder, for this rank's tiles
+            frame = frame(lambda height: strip_tile_filter(height, rank, world))
         self.width, self.height = frame.width, frame.height
         rec, _ = record_scene(lib, frame)
         self.rec = rec

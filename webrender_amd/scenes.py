@@ -58,8 +58,12 @@ def build_rect_frame(width, height, rects, colors, opaque, encoding="quad",
             continue
         tw, th = TILE_W, TILE_H
         x0, y0, x1, y1 = ox, oy, ox + tw, oy + th
+        # (a strip-sharded rank's builder also culls against the rows of the tile it draws -- tile_filter.rows, webrender_amd/dist.py
+        # strip_tile_filter --, as the frame builder culls against a tile's dirty rect: a prim outside them cannot touch a pixel the rank owns)
+        rows = getattr(tile_filter, "rows", None)
+        hy0, hy1 = (max(y0, rows[0]), min(y1, rows[1])) if rows else (y0, y1)
         hit = np.nonzero((rects[:, 0] < x1) & (rects[:, 2] > x0) &
-                         (rects[:, 1] < y1) & (rects[:, 3] > y0))[0]
+                         (rects[:, 1] < hy1) & (rects[:, 3] > hy0))[0]
         tex = TextureRef(f"tile_{tx}_{ty}", tw, th, G.GL_RGBA8, G.GL_LINEAR,
                          render_target=True, with_depth=True)
         target = Target(tex, "picture_tile", clear_color=clear_color, clear_depth=True)
