@@ -58,6 +58,14 @@ FT.FT_Get_Char_Index.restype = C.c_uint
 FT.FT_Set_Transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 
 
+TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-offset", "1658", "shadow-cover-1",
+                 # round 6
+                 "1658-ref", "non-opaque-notref", "shadow", "shadow-ref", "shadow-single", "shadow-cover-2", "shadow-many", "shadow-complex",
+                 "two-shadows", "subtle-shadow", "subtle-shadow-ref", "snap-clip", "snap-clip-ref", "subpixel-translate-ref",
+                 "shadow-partial-glyph", "shadow-partial-glyph-ref", "allow-subpixel-ref", "diacritics", "diacritics-ref", "transparent-no-aa",
+                 "transparent-no-aa-ref", "subpx-bg-mask-ref", "colors", "decorations-ref", "ahem-ref", "shadow-clip-ref", "blank")
+
+
 def open_face(name):
     face = C.c_void_p()
     assert FT.FT_New_Face(lib, os.path.join(REF, name).encode(), 0, C.byref(face)) == 0, name
@@ -115,25 +123,50 @@ def main():
                 bitmaps.append(g[2])
     faces = {f: open_face(f) for f in ("VeraBd.ttf", "FreeSans.ttf")}
     charmap = {}
-    # (1) the glyph runs of the text reftests with explicit glyph lists (wrench/reftests/text/reftest.list)
+    # (1) the display lists of the text reftests (wrench/reftests/text/reftest.list) that need no transform, clip chain or line decoration:
+    # text runs with explicit glyph lists, and `text:` strings laid out as wrench lays them out (wrench.rs:320-382 layout_simple_ascii:
+    # glyph indices of the characters the font has, the pen advanced by get_glyph_dimensions' advance -- font.rs:659-700, whole-pixel
+    # variant -- or by size / 3 for a glyph without pixels), rects, shadows.  Sizes are points: yaml_helper.rs:267-269 as_pt_to_f32,
+    # size * 16 / 12 pixels (rounds 5 and earlier rasterised at the yaml's number).
     runs = {}
-    for name in ("text", "long-text", "negative-pos", "non-opaque", "snap-text-offset", "1658", "shadow-cover-1"):
-        doc = yaml.safe_load(open(os.path.join(REF, name + ".yaml")))
+    for name in TEXT_REFTESTS:
+        doc = yaml.safe_load(open(os.path.join(REF, name + ".yaml"))) or {}
         out = []
         def walk(items, origin):
-            for it in items:
+            for it in items or []:
                 if it.get("type") == "stacking-context":
                     b = it.get("bounds", [0, 0, 0, 0])
                     walk(it.get("items", []), (origin[0] + b[0], origin[1] + b[1]))
-                elif "glyphs" in it:
+                elif "glyphs" in it or "text" in it:
                     font = it.get("font", "VeraBd.ttf")
-                    e = dict(it); e["font"] = font; e["origin_offset"] = list(origin)
+                    size_px = float(it.get("size", 12.0)) * 16.0 / 12.0                 # handle_text: default 16 px
+                    e = dict(it); e["font"] = font; e["origin_offset"] = list(origin); e["size_px"] = size_px
+                    o = it.get("origin", [0.0, 0.0])
+                    if isinstance(o, str):
+                        o = [float(v) for v in o.replace(",", " ").split()]
+                    if "glyphs" in it:
+                        gids = [int(g) for g in it["glyphs"]]
+                        offs = [float(v) for v in it["offsets"]]
+                        e["offsets"] = [offs[i] + float(o[i & 1]) for i in range(len(offs))]
+                    else:
+                        gids, offs = [], []
+                        cx, cy = float(o[0]), float(o[1])
+                        for ch in it["text"]:
+                            gid = FT.FT_Get_Char_Index(faces[font], ord(ch))
+                            if gid == 0:
+                                continue                                  # (get_glyph_indices: None for a character the font lacks)
+                            g, adv = rasterize(faces[font], size_px, int(gid), 0)
+                            gids.append(int(gid)); offs += [cx, cy]
+                            cx += np.float32(adv) if g is not None else np.float32(size_px / 3.0)
+                            cx = float(np.float32(cx))
+                        e["glyphs"], e["offsets"] = gids, offs
+                        del e["text"]
                     out.append(e)
-                    for gid in set(it["glyphs"]):
-                        add(font, faces[font], float(it["size"]), int(gid), range(4))
+                    for gid in set(gids):
+                        add(font, faces[font], size_px, int(gid), range(4))
                 else:
                     out.append(dict(it, origin_offset=list(origin)))
-        walk(doc["root"]["items"], (0.0, 0.0))
+        walk((doc.get("root") or {}).get("items"), (0.0, 0.0))
         runs[name] = out
     # (2) the character sets of cfg3 / text-rendering: FreeSans, sizes 8 .. 24, printable ASCII, whole-pixel variant
     for size in range(8, 25):
@@ -141,13 +174,17 @@ def main():
             gid = FT.FT_Get_Char_Index(faces["FreeSans.ttf"], ch)
             charmap[f"FreeSans.ttf|{ch}"] = int(gid)
             add("FreeSans.ttf", faces["FreeSans.ttf"], float(size), int(gid), range(4) if size in (12, 16) else (0,))
-    # (3) wrench/benchmarks/overlapping-text-shadows.yaml: one 60 px string (whole-pixel variant, as text-rendering's)
-    ots = yaml.safe_load(open(os.path.join(REF, "..", "..", "benchmarks", "overlapping-text-shadows.yaml")))["root"]["items"]
-    for it in ots:
-        if "text" in it:
-            for ch in sorted(set(it["text"])):
-                gid = FT.FT_Get_Char_Index(faces["FreeSans.ttf"], ord(ch))
-                add("FreeSans.ttf", faces["FreeSans.ttf"], float(it["size"]), int(gid), (0,))
+    # (3) wrench/benchmarks/text-rendering.yaml and overlapping-text-shadows.yaml: their sizes are points too (8 .. 20 pt = 10.67 .. 26.67 px,
+    # 60 pt = 80 px), whole-pixel variant
+    bench = os.path.join(REF, "..", "..", "benchmarks")
+    for yml in ("text-rendering.yaml", "overlapping-text-shadows.yaml"):
+        for it in yaml.safe_load(open(os.path.join(bench, yml)))["root"]["items"]:
+            if "text" in it:
+                px = float(it.get("size", 12.0)) * 16.0 / 12.0
+                for ch in sorted(set(it["text"])):
+                    gid = FT.FT_Get_Char_Index(faces["FreeSans.ttf"], ord(ch))
+                    charmap[f"FreeSans.ttf|{ord(ch)}"] = int(gid)
+                    add("FreeSans.ttf", faces["FreeSans.ttf"], px, int(gid), (0,))
     blob = np.concatenate([b.reshape(-1) for b in bitmaps]) if bitmaps else np.zeros(0, np.uint8)
     offs = np.cumsum([0] + [b.size for b in bitmaps]).astype(np.int64)
     np.savez_compressed(OUT, blob=blob, offsets=offs, index=np.frombuffer(json.dumps(index).encode(), np.uint8),

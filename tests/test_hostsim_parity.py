@@ -606,4 +606,4 @@ def test_hostsim_text_reftests_match_oracle(hostsim, oracle_gcc, name, kw, _full
         want = want["window"]
     else:
         assert np.array_equal(got, want)
-    assert (want != 255).any(), "no ink"
+    assert name == "blank" or (want != 255).any(), "no ink"

@@ -122,7 +122,7 @@ def cfg1_solid_colors(width=1024, height=1024, encoding="quad", **kw):
 def simple_batching(width=1024, height=1024, encoding="quad", **kw):
     """wrench/benchmarks/simple-batching.yaml: 14 x rect [0,0,512,512] green."""
     rects = np.tile(np.array([[0, 0, 512, 512]], np.float32), (14, 1))
-    rgba = np.tile(np.array([[0, 128, 0, 255]], np.uint8), (14, 1))
+    rgba = np.tile(np.array([[0, 255, 0, 255]], np.uint8), (14, 1))      # (wrench: "green" = (0, 1, 0), yaml_helper.rs:58)
     return build_rect_frame(width, height, rects, premultiply(rgba), np.ones(14, bool),
                             encoding, **kw)
 

@@ -9,7 +9,7 @@ generated from the YAML files by tests/golden/make_wrench_benchmarks.py.
   unaligned-gradient   (scene_building.rs:3389-3396: `cached = (!is_software || is_tiled) && ...`); the axis-aligned
                        decomposition (prim_store/gradient/linear.rs:115-335) leaves this gradient as ONE two-stop segment
                        covering the prim.  Opaque stops => opaque pass, front to back: nine of the ten are depth-rejected
-  text-rendering       68 text runs, sizes 8-20 px, black / red / green / blue (ps_text_run, R8 glyph atlas; glyph bitmaps:
+  text-rendering       68 text runs, sizes 8-20 pt (10.7-26.7 px), black / red / green / blue (ps_text_run, R8 glyph atlas; glyph bitmaps:
                        the FreeType fixture, like cfg3's)
   large-blur-radius    a stacking context under filter blur(100, 100): picture task -> 5 x cs_scale -> cs_blur V / H (RGBA8) -> brush_image
                        with RasterizationSpace::Screen uv (picture.rs:5872-5930, render_task.rs:1168-1260, batch.rs:1509-1557)
@@ -28,7 +28,9 @@ from .frame import Frame, Step, Target, TextureRef, CompositeTile, CLIP_TASK_EMP
 from . import scenes
 from .scenes import TILE_W, TILE_H, BIG, tile_grid, premultiply
 
-CSS = {"red": (255, 0, 0, 255), "green": (0, 128, 0, 255), "blue": (0, 0, 255, 255), "black": (0, 0, 0, 255)}
+# wrench's named colours (yaml_helper.rs:55-66 string_to_color: "green" is (0, 1, 0), not the CSS keyword's (0, 0.5, 0))
+CSS = {"red": (255, 0, 0, 255), "green": (0, 255, 0, 255), "blue": (0, 0, 255, 255), "white": (255, 255, 255, 255), "black": (0, 0, 0, 255),
+       "yellow": (255, 255, 0, 255), "cyan": (0, 255, 255, 255), "magenta": (255, 0, 255, 255), "transparent": (255, 255, 255, 0)}
 _DATA = None
 
 
@@ -141,24 +143,44 @@ def overlapping_text_shadows(width=3840, height=2160, tile_filter=None, **kw):
 
 
 def _text_runs(items, width, height, tile_filter):
-    sizes = sorted({int(t["size"]) for t in items})
-    atlas, table = scenes.build_glyph_atlas(sizes=tuple(sizes))
+    """`text:` items of a benchmark display list: sizes are points (yaml_helper.rs:267-269 as_pt_to_f32: size * 16 / 12 pixels), the
+    string is laid out as wrench does (wrench.rs:320-382 layout_simple_ascii: the pen advances by the glyph's advance, or by size / 3
+    for a glyph without pixels)."""
+    fx = scenes.glyph_fixture()
+    font = "FreeSans.ttf"
+    px_of = lambda t: float(t["size"]) * 16.0 / 12.0
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
+    atlas = np.zeros((scenes.ATLAS_SIZE, scenes.ATLAS_SIZE), np.uint8)
+    ax = ay = 1
+    shelf = 0
+    res_addr = {}
+    for size in sorted({px_of(t) for t in items}):
+        for c in sorted({ord(ch) for t in items if px_of(t) == size for ch in t["text"]}):
+            left, top, bmp, _adv = fx.char(font, size, c)
+            if bmp is None:
+                continue
+            h, w = bmp.shape
+            if ax + w + 1 > scenes.ATLAS_SIZE:
+                ax, ay, shelf = 1, ay + shelf + 1, 0
+            assert ay + h + 1 <= scenes.ATLAS_SIZE
+            atlas[ay:ay + h, ax:ax + w] = bmp
+            res_addr[(size, c)] = frame.add_glyph_resource((float(ax), float(ay), float(ax + w), float(ay + h)), (float(left), float(-top)), 1.0)
+            ax += w + 1
+            shelf = max(shelf, h)
     atlas_ref = TextureRef("glyph_atlas_r8", scenes.ATLAS_SIZE, scenes.ATLAS_SIZE, G.GL_R8, G.GL_LINEAR, pixels=atlas, upload_format=G.GL_RED)
     frame.static_textures.append(atlas_ref)
-    res_addr = {k: frame.add_glyph_resource(v[0], v[1], 1.0) for k, v in table.items()}
     runs = []
     for zi, t in enumerate(items):
-        size = int(t["size"])
-        chars = [ord(c) for c in t["text"]]
-        pts, glyphs, x = [], [], 0.0
-        for c in chars:
-            if (size, c) in table:
-                pts.append((x, 0.0))
+        size = px_of(t)
+        pts, glyphs, x = [], [], np.float32(0.0)
+        for c in (ord(ch) for ch in t["text"]):
+            if (size, c) in res_addr:
+                pts.append((float(x), 0.0))
                 glyphs.append(c)
-                x += table[(size, c)][2]
-            else:                       # space (no bitmap): advance only
-                x += scenes.char_advance(size, c)
+                x = np.float32(x + np.float32(fx.char(font, size, c)[3]))
+            else:                       # no pixels (space): a rough estimate, as wrench's
+                x = np.float32(x + np.float32(size / 3.0))
+        x = float(x)
         color = premultiply(np.array([list(CSS[t["color"] or "black"])], np.uint8))[0]
         ox, oy = t["origin"]
         bb = (ox - 2 * size, oy - 1.5 * size, ox + x + 2 * size, oy + size)
@@ -605,7 +627,13 @@ def large_boxshadow_ellipse_2(width=3840, height=2160, tile_filter=None, **kw):
 #   * text shadows with a blur radius (1658.yaml, shadow-cover-1.yaml: scene_building.rs push_shadow -> a picture under
 #     Filter::Blur(radius / 2)) are rendered as the shadow-coloured run in a colour task inflated by ceil(std) * 3, blurred V / H
 #     (std <= 4: no down-scaling) and composited by brush_image ALPHA_PASS with RasterizationSpace::Screen uv, under the text.
-TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-offset", "1658", "shadow-cover-1")
+TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-offset", "1658", "shadow-cover-1",
+                 # round 6: `text:` strings (laid out as wrench does, by the fixture's generator), rects, local clip rects, several
+                 # shadows per context with and without blur, several runs per shadow picture
+                 "1658-ref", "non-opaque-notref", "shadow", "shadow-ref", "shadow-single", "shadow-cover-2", "shadow-many", "shadow-complex",
+                 "two-shadows", "subtle-shadow", "subtle-shadow-ref", "snap-clip", "snap-clip-ref", "subpixel-translate-ref",
+                 "shadow-partial-glyph", "shadow-partial-glyph-ref", "allow-subpixel-ref", "diacritics", "diacritics-ref", "transparent-no-aa",
+                 "transparent-no-aa-ref", "subpx-bg-mask-ref", "colors", "decorations-ref", "ahem-ref", "shadow-clip-ref", "blank")
 
 
 def _css_color(c):
@@ -620,7 +648,19 @@ def _css_color(c):
     return (int(c[0]), int(c[1]), int(c[2]), int(round(float(c[3]) * 255.0)) if float(c[3]) <= 1.0 else int(c[3]))
 
 
+def _rect_of(v, off=(0.0, 0.0)):
+    if isinstance(v, str):
+        v = [float(t) for t in v.replace(",", " ").split()]
+    x, y, w, h = (float(t) for t in v)
+    return (x + off[0], y + off[1], x + w + off[0], y + h + off[1])
+
+
 def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
+    """One display list of wrench/reftests/text (the fixture holds its items: tests/golden/make_glyphs.py).  The draw list is put
+    together as scene_building.rs does: items outside a shadow context in order; a context's queue of shadows and prims by
+    pop_all_shadows (:2897-3047) -- a shadow takes EVERY prim that follows it in the queue: without blur each as a prim of its own in
+    the shadow's colour at the shadow's offset, straight into the draw list; with blur all of them in ONE picture under
+    Filter::Blur(radius / 2) --, a prim itself when its alpha is not zero."""
     fx = scenes.glyph_fixture()
     items = fx.runs[name]
     frame = Frame(width, height, (1.0, 1.0, 1.0, 1.0))
@@ -648,23 +688,13 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
                 shelf = max(shelf, h)
         return entries[key]
 
-    runs, shadows, pending_shadow = [], [], None
-    z = 1
-    for it in items:
-        if it.get("type") == "shadow":
-            pending_shadow = it
-            continue
-        if it.get("type") == "pop-all-shadows":
-            pending_shadow = None
-            continue
-        if "glyphs" not in it:
-            continue
-        font, size = it["font"], float(it["size"])
+    def make_run(it, offset=(0.0, 0.0), color=None):
+        """a text run prim: glyph variants chosen at its device position (`offset`: a shadow's)"""
+        font, size = it["font"], float(it.get("size_px", it["size"]))
         off = it["offsets"]
         so = it["origin_offset"]
-        ref = (float(np.floor(so[0] + 0.5)), float(np.floor(so[1] + 0.5)))         # snapped reference-frame-relative offset
+        ref = (float(np.floor(so[0] + 0.5)) + offset[0], float(np.floor(so[1] + 0.5)) + offset[1])   # snapped reference-frame-relative offset (+ the shadow's)
         pts = [(float(off[2 * i]), float(off[2 * i + 1])) for i in range(len(it["glyphs"]))]
-        col = _css_color(it.get("color", "black"))
         insts = []
         for gi, (gid, (gx, gy)) in enumerate(zip(it["glyphs"], pts)):
             fr = (ref[0] + gx) - np.floor(ref[0] + gx)
@@ -672,38 +702,83 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
             res = resource(font, size, int(gid), sub)
             if res is not None:
                 insts.append((gi, res))
-        xs, ys = [p[0] for p in pts], [p[1] for p in pts]
+        xs, ys = [p[0] for p in pts] or [0.0], [p[1] for p in pts] or [0.0]
         bb = (ref[0] + min(xs) - 2 * size, ref[1] + min(ys) - 1.5 * size, ref[0] + max(xs) + 2 * size, ref[1] + max(ys) + size)
-        run = dict(pts=pts, ref=ref, color=col, insts=insts, bb=bb, z=z)
-        z += 1
-        if pending_shadow is not None and float(pending_shadow.get("blur-radius", 0)) > 0:
-            shadows.append(dict(run=run, color=_css_color(pending_shadow.get("color", "black")), offset=[float(v) for v in pending_shadow.get("offset", [0, 0])],
-                                std=float(pending_shadow["blur-radius"]) * 0.5, z=z))
-            z += 1
-        if col[3] > 0:
-            runs.append(run)
+        clip = (-BIG, -BIG, BIG, BIG)
+        if "clip-rect" in it:
+            c = _rect_of(it["clip-rect"], (so[0] + offset[0], so[1] + offset[1]))
+            clip = c
+            bb = (max(bb[0], c[0]), max(bb[1], c[1]), min(bb[2], c[2]), min(bb[3], c[3]))
+        return dict(kind="run", pts=pts, ref=ref, color=color if color is not None else _css_color(it.get("color", "black")), insts=insts, bb=bb, clip=clip)
+
+    def make_rect(it):
+        so = it["origin_offset"]
+        r = _rect_of(it["rect"] if "rect" in it else it["bounds"], so)
+        return dict(kind="rect", rect=r, color=_css_color(it.get("color", "black")), bb=r, clip=(-BIG, -BIG, BIG, BIG))
+
+    draw, queue = [], None            # the draw list; the open shadow context's queue
+    def flush_queue(q):
+        while q:
+            kind, v = q.pop(0)
+            if kind == "S":
+                later = [p for k, p in q if k == "P"]
+                assert all("glyphs" in p for p in later), "shadows of text runs only"
+                off = tuple(float(t) for t in v.get("offset", [0, 0]))
+                col = _css_color(v.get("color", "black"))
+                std = float(v.get("blur-radius", 0)) * 0.5
+                if std == 0.0:
+                    draw.extend(make_run(p, off, col) for p in later)
+                elif later:
+                    assert std <= 4.0, "no down-scaling chain here"
+                    draw.append(dict(kind="pic", std=std, runs=[make_run(p, off, col) for p in later]))
+            elif "glyphs" in v:
+                r = make_run(v)
+                if r["color"][3] > 0:
+                    draw.append(r)
+            else:
+                r = make_rect(v)
+                if r["color"][3] > 0:
+                    draw.append(r)
+    for it in items:
+        t = it.get("type")
+        if t == "shadow":
+            queue = queue if queue is not None else []
+            queue.append(("S", it))
+        elif t == "pop-all-shadows":
+            flush_queue(queue or [])
+            queue = None
+        elif "glyphs" in it or t == "rect" or "rect" in it:
+            if queue is not None:
+                queue.append(("P", it))
+            else:
+                flush_queue([("P", it)])
+    assert queue is None, "unpopped shadows"
+
     t_atlas = TextureRef("glyph_atlas_r8", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=atlas, upload_format=G.GL_RED)
     frame.static_textures.append(t_atlas)
     pot = lambda v: 1 << int(np.ceil(np.log2(max(v, 64))))
     zero = (0.0, 0.0, 0.0, 0.0)
     frame.readback = []
-    composites = []              # (unclipped prim rect, image source address, blurred texture, z)
-    for si, sh in enumerate(shadows):
-        run, std = sh["run"], sh["std"]
+    # -- the blurred shadow pictures: the shadow-coloured runs in a colour task inflated by ceil(std) * 3, blurred V / H, composited by
+    # brush_image ALPHA_PASS with RasterizationSpace::Screen uv at the picture's place in the draw list
+    for si, d in enumerate(x for x in draw if x["kind"] == "pic"):
+        std = d["std"]
         infl = float(np.ceil(std)) * 3.0
-        bb = run["bb"]
-        rect = (float(np.floor(bb[0] + sh["offset"][0])), float(np.floor(bb[1] + sh["offset"][1])), float(np.ceil(bb[2] + sh["offset"][0])), float(np.ceil(bb[3] + sh["offset"][1])))
+        bbs = [r["bb"] for r in d["runs"]]
+        rect = (float(np.floor(min(b[0] for b in bbs))), float(np.floor(min(b[1] for b in bbs))), float(np.ceil(max(b[2] for b in bbs))), float(np.ceil(max(b[3] for b in bbs))))
         clipped = (rect[0] - infl, rect[1] - infl, rect[2] + infl, rect[3] + infl)
         tw, th = int(clipped[2] - clipped[0]), int(clipped[3] - clipped[1])
         t_pic = TextureRef(f"shadow_picture_{si}", pot(tw), pot(th), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
         tg = Target(t_pic, "color", clear_color=zero)
         pic_task = frame.add_render_task((0.0, 0.0, float(tw), float(th)), 1.0, (clipped[0], clipped[1]))
-        scol = premultiply(np.array([list(sh["color"])], np.uint8))[0]
-        addr = frame.add_text_run(scol, run["pts"])
-        ref = (run["ref"][0] + sh["offset"][0], run["ref"][1] + sh["offset"][1])
-        ph = frame.add_prim_header((ref[0], ref[1], 0.0, 0.0), (-BIG, -BIG, BIG, BIG), 1, addr, 0, pic_task, (65535, 0, 0, 0))
-        inst = [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
-        tg.steps.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(inst, dtype=np.int32), "PremultipliedAlpha", "none", textures={0: t_atlas}))
+        inst = []
+        for run in d["runs"]:
+            scol = premultiply(np.array([list(run["color"])], np.uint8))[0]
+            addr = frame.add_text_run(scol, run["pts"])
+            ph = frame.add_prim_header((run["ref"][0], run["ref"][1], 0.0, 0.0), run["clip"], 1, addr, 0, pic_task, (65535, 0, 0, 0))
+            inst += [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
+        if inst:
+            tg.steps.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(inst, dtype=np.int32), "PremultipliedAlpha", "none", textures={0: t_atlas}))
         frame.passes.append([tg])
         cur_rect = (0.0, 0.0, float(tw), float(th))
         t_v = TextureRef(f"shadow_blur_v_{si}", pot(tw), pot(th), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
@@ -715,32 +790,48 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
         frame.passes += [[tg_v], [tg_h]]
         frame.readback += [t_pic, t_h]
         quad = [[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 1.0, 0.0, 1.0]]
-        src = frame.gpu_cache.push([[cur_rect[0], cur_rect[1], cur_rect[2], cur_rect[3]], [0.0, 0.0, 0.0, 0.0]] + quad)
-        composites.append((clipped, src, t_h, sh["z"]))
+        d["src"] = frame.gpu_cache.push([[cur_rect[0], cur_rect[1], cur_rect[2], cur_rect[3]], [0.0, 0.0, 0.0, 0.0]] + quad)
+        d["tex"], d["bb"] = t_h, clipped
     bdata = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
+    rect_color = {}
     tiles = _tiles(frame, width, height, tile_filter)
     n_glyphs = 0
     for target, task, (x0, y0, x1, y1) in tiles:
-        for (rect, src, tex, zz) in composites:
-            if not (rect[0] < x1 and rect[2] > x0 and rect[1] < y1 and rect[3] > y0):
-                continue
-            ph = frame.add_prim_header(rect, (-BIG, -BIG, BIG, BIG), zz, bdata, 0, task, (4 | (1 << 16), 1, 65535, 0))
-            target.alpha.append(Step("brush_image ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES",
-                                     np.array([frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=src)], dtype=np.int32),
-                                     "PremultipliedAlpha", "alpha", textures={0: tex}))
-        inst = []
-        for run in runs:
-            bb = run["bb"]
+        # the tile's alpha pass: the draw list in order, consecutive prims of one program and texture in one batch (batch.rs AlphaBatchList)
+        cur_key, cur_inst, cur_tex = None, [], None
+        def close():
+            nonlocal cur_key, cur_inst, cur_tex
+            if cur_inst:
+                target.alpha.append(Step(cur_key, "PRIM_INSTANCES", np.array(cur_inst, dtype=np.int32), "PremultipliedAlpha", "alpha",
+                                         **({"textures": {0: cur_tex}} if cur_tex is not None else {})))
+            cur_key, cur_inst, cur_tex = None, [], None
+        for zi, d in enumerate(draw):
+            bb = d["bb"]
             if not (bb[0] < x1 and bb[2] > x0 and bb[1] < y1 and bb[3] > y0):
                 continue
-            col = premultiply(np.array([list(run["color"])], np.uint8))[0]
-            addr = frame.add_text_run(col, run["pts"])
-            ph = frame.add_prim_header((run["ref"][0], run["ref"][1], 0.0, 0.0), (-BIG, -BIG, BIG, BIG), run["z"], addr, 0, task, (65535, 0, 0, 0))
-            inst += [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
-        if inst:
-            target.alpha.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(inst, dtype=np.int32),
-                                     "PremultipliedAlpha", "alpha", textures={0: t_atlas}))
-            n_glyphs += len(inst)
+            z = zi + 1
+            if d["kind"] == "pic":
+                key, tex = "brush_image ALPHA_PASS,TEXTURE_2D", d["tex"]
+                ph = frame.add_prim_header(d["bb"], (-BIG, -BIG, BIG, BIG), z, bdata, 0, task, (4 | (1 << 16), 1, 65535, 0))
+                inst = [frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=d["src"])]
+            elif d["kind"] == "rect":
+                key, tex = "brush_solid ALPHA_PASS", None
+                if d["color"] not in rect_color:
+                    rect_color[d["color"]] = frame.gpu_cache.push([list(premultiply(np.array([list(d["color"])], np.uint8))[0])])
+                ph = frame.add_prim_header(d["rect"], d["clip"], z, rect_color[d["color"]], 0, task, (65535, 0, 0, 0))
+                inst = [frame.brush_instance(ph, CLIP_TASK_EMPTY)]
+            else:
+                key, tex = "ps_text_run ALPHA_PASS,TEXTURE_2D", t_atlas
+                col = premultiply(np.array([list(d["color"])], np.uint8))[0]
+                addr = frame.add_text_run(col, d["pts"])
+                ph = frame.add_prim_header((d["ref"][0], d["ref"][1], 0.0, 0.0), d["clip"], z, addr, 0, task, (65535, 0, 0, 0))
+                inst = [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in d["insts"]]
+                n_glyphs += len(inst)
+            if key != cur_key or tex is not cur_tex:
+                close()
+                cur_key, cur_tex = key, tex
+            cur_inst += inst
+        close()
     frame.n_glyphs = n_glyphs
     return _finish(frame, tiles)
 
@@ -760,16 +851,16 @@ WORKLOADS = {
     "many-box-shadows": many_box_shadows,
 }
 DESCRIPTIONS = {
-    **{f"reftest-text-{n}": f"wrench reftests/text/{n}.yaml (explicit glyph runs over FreeType-rasterised glyphs of the reftest's own font, alpha glyphs, ps_text_run)" for n in TEXT_REFTESTS},
+    **{f"reftest-text-{n}": f"wrench reftests/text/{n}.yaml (its text runs -- explicit glyph lists, or strings laid out as wrench does --, rects and shadows over FreeType-rasterised glyphs of the reftest's own font at size * 16 / 12 px, alpha glyphs: ps_text_run, brush_solid, cs_blur + brush_image for blurred shadows)" for n in TEXT_REFTESTS},
     "large-blur-radius": "wrench benchmarks/large-blur-radius.yaml: filter blur(100, 100) over a 1024x1024 rect (the picture in a 1632^2 colour task, five cs_scale halvings, cs_blur COLOR_TARGET V/H at 51^2, the result composited by brush_image ALPHA_PASS with RasterizationSpace::Screen uv)",
     "large-boxshadow-ellipse": "wrench benchmarks/large-boxshadow-ellipse.yaml: one outset box shadow of a 1024x1024 box, blur radius 10, elliptical corner radii (cached blurred corner: mask -> cs_scale -> cs_blur V/H, then the cs_clip_box_shadow x clip-out mask and masked brush_solid segments)",
     "large-boxshadow-ellipse-2": "wrench benchmarks/large-boxshadow-ellipse-2.yaml: one INSET box shadow of a 1024x1024 box, blur radius capped at 300, elliptical radii of 400-700 px (the whole shadow rect blurred downscaled: 2049^2 mask -> five cs_scale halvings -> cs_blur V/H at 64^2; six masked brush_solid segments, each mask = cs_clip_box_shadow in inset / simple-stretch mode x the box's rounded rect)",
     "large-clip-rect": "wrench benchmarks/large-clip-rect.yaml: 8 opaque 1024x1024 rects under one rounded-rectangle clip (radius 16): 3x3 brush segments per rect, 4 corner clip-mask tasks each (cs_clip_rectangle FAST_PATH), opaque + masked alpha pass",
     "clip-clear": "wrench benchmarks/clip-clear.yaml (not in benchmarks.list): 11 opaque 300x300 rects under one rounded-rectangle clip (radius 50): 3x3 brush segments per rect, 44 corner clip-mask tasks of 50x50 in a 2048^2 alpha target cleared whole",
-    "overlapping-text-shadows": "wrench benchmarks/overlapping-text-shadows.yaml (not in benchmarks.list): 200 unblurred red shadows at offsets (i, i) + the 60 px string itself = 201 ps_text_run runs of 21 glyphs over one another (FreeType-rasterised FreeSans glyphs)",
+    "overlapping-text-shadows": "wrench benchmarks/overlapping-text-shadows.yaml (not in benchmarks.list): 200 unblurred red shadows at offsets (i, i) + the 60 pt (80 px) string itself = 201 ps_text_run runs of 21 glyphs over one another (FreeType-rasterised FreeSans glyphs)",
     "many-images": "wrench benchmarks/many-images.yaml: 8192 opaque 8x8 images (one texture-cache entry each), brush_image opaque pass",
     "aligned-gradient": "wrench benchmarks/aligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient (brush_linear_gradient, opaque pass, depth-rejected overdraw)",
     "unaligned-gradient": "wrench benchmarks/unaligned-gradient.yaml: 10 x 1980x1080 two-stop linear gradient off the axis (brush_linear_gradient, opaque pass)",
-    "text-rendering": "wrench benchmarks/text-rendering.yaml: 68 text runs, 8-20 px, four colours (ps_text_run, R8 glyph atlas of FreeType-rasterised FreeSans glyphs)",
+    "text-rendering": "wrench benchmarks/text-rendering.yaml: 68 text runs, 8-20 pt (10.7-26.7 px: yaml_helper.rs as_pt_to_f32), four colours, strings laid out as wrench lays them out (ps_text_run, R8 glyph atlas of FreeType-rasterised FreeSans glyphs)",
     "many-box-shadows": "wrench benchmarks/many-box-shadows.yaml: its 9 card shadows, blur radius 45, rgba(0,0,0,0.1) (one cached blurred corner: mask -> 2 cs_scale -> cs_blur V/H, then cs_clip_box_shadow x clip-out masks and masked brush_solid segments)",
 }
