@@ -108,7 +108,59 @@ def rasterize(face, size_px, glyph_index, subpx):
     return (left, top, px), advance
 
 
+FT_LOAD_TARGET_LCD = (3 & 15) << 16
+FT_RENDER_MODE_LCD = 3
+FT_PIXEL_MODE_LCD = 5
+
+
+def rasterize_lcd(face, size_px, glyph_index, subpx):
+    """FontRenderMode::Subpixel (font.rs: load_glyph :448-458 FT_LOAD_TARGET_LCD under the default FontHinting::LCD; pad_bounding_box
+    :596-613 one pixel either side for the LCD filter; rasterize_glyph_outline :790-838 FT_RENDER_MODE_LCD; rasterize_glyph :957-971
+    [b, g, r, max(b, g, r)] per pixel, RGB subpixel order; the library's LCD filter set to FT_LCD_FILTER_DEFAULT :194).
+    -> (left, top, bgra[h, w, 4] u8) or None for a glyph without pixels."""
+    fr = C.cast(face, C.POINTER(Face)).contents
+    FT.FT_Set_Transform(face, None, None)
+    req = int(size_px * 1.0 * 64.0 + 0.5)
+    assert FT.FT_Set_Char_Size(face, req, req, 0, 0) == 0
+    flags = FT_LOAD_TARGET_LCD | FT_LOAD_NO_BITMAP | FT_LOAD_IGNORE_GLOBAL_ADVANCE_WIDTH
+    assert FT.FT_Load_Glyph(face, glyph_index, flags) == 0
+    slot = fr.glyph.contents
+    assert slot.format == FT_GLYPH_FORMAT_OUTLINE
+    if slot.outline.n_contours == 0:
+        return None
+    cbox = BBox()
+    FT.FT_Outline_Get_CBox(C.byref(slot.outline), C.byref(cbox))
+    cbox.xMin -= 64; cbox.xMax += 64                              # pad_bounding_box
+    dx = int(subpx * 0.25 / 1.0 * 64.0 + 0.5)
+    dy = -int(0.0 * 64.0 + 0.5)
+    bx0, by0, bx1, by1 = cbox.xMin + dx, cbox.yMin + dy, cbox.xMax + dx, cbox.yMax + dy
+    bx0 &= ~63; by0 &= ~63; bx1 = (bx1 + 63) & ~63; by1 = (by1 + 63) & ~63
+    left, top, width, height = bx0 >> 6, by1 >> 6, (bx1 - bx0) >> 6, (by1 - by0) >> 6
+    if width == 0 or height == 0:
+        return None
+    FT.FT_Outline_Translate(C.byref(slot.outline), dx - ((cbox.xMin + dx) & ~63), dy - ((cbox.yMin + dy) & ~63))
+    assert FT.FT_Render_Glyph(fr.glyph, FT_RENDER_MODE_LCD) == 0
+    bm = slot.bitmap
+    assert bm.pixel_mode == FT_PIXEL_MODE_LCD and bm.width % 3 == 0
+    rows, w = bm.rows, bm.width // 3
+    px = np.zeros((rows, w, 4), np.uint8)
+    if rows and w:
+        raw = np.ctypeslib.as_array(bm.buffer, shape=(abs(bm.pitch) * rows,))
+        for r in range(rows):
+            rgb = raw[r * bm.pitch:r * bm.pitch + 3 * w].reshape(w, 3)
+            px[r, :, 0], px[r, :, 1], px[r, :, 2] = rgb[:, 2], rgb[:, 1], rgb[:, 0]
+            px[r, :, 3] = rgb.max(axis=1)
+    left += slot.bitmap_left
+    top += slot.bitmap_top - height
+    return left, top, px
+
+
 def main():
+    try:
+        FT.FT_Library_SetLcdFilter.argtypes = [C.c_void_p, C.c_int]
+        print("FT_Library_SetLcdFilter(FT_LCD_FILTER_DEFAULT) ->", FT.FT_Library_SetLcdFilter(lib, 1), "(7: this FreeType build has no filter of its own and renders LCD by its default method)")
+    except AttributeError:
+        pass
     bitmaps, index = [], {}            # index["font|size|glyph|subpx"] = [slot in the blob list or -1, left, top, w, h, advance]
     def add(font, face, size, gid, subpxs):
         for s in subpxs:
@@ -185,11 +237,26 @@ def main():
                     gid = FT.FT_Get_Char_Index(faces["FreeSans.ttf"], ord(ch))
                     charmap[f"FreeSans.ttf|{ord(ch)}"] = int(gid)
                     add("FreeSans.ttf", faces["FreeSans.ttf"], px, int(gid), (0,))
+    # (4) the LCD (FontRenderMode::Subpixel) bitmaps of cfg3's character set: the BGRA atlas of its subpixel runs
+    lcd, lcd_index = [], {}
+    for size in range(8, 25):
+        for ch in range(33, 127):
+            gid = charmap[f"FreeSans.ttf|{ch}"]
+            g = rasterize_lcd(faces["FreeSans.ttf"], float(size), int(gid), 0)
+            key = f"FreeSans.ttf|{float(size)}|{gid}|0"
+            if g is None:
+                lcd_index[key] = [-1, 0, 0, 0, 0]
+            else:
+                lcd_index[key] = [len(lcd), g[0], g[1], g[2].shape[1], g[2].shape[0]]
+                lcd.append(g[2])
+    lcd_blob = np.concatenate([b.reshape(-1) for b in lcd])
+    lcd_offs = np.cumsum([0] + [b.size for b in lcd]).astype(np.int64)
     blob = np.concatenate([b.reshape(-1) for b in bitmaps]) if bitmaps else np.zeros(0, np.uint8)
     offs = np.cumsum([0] + [b.size for b in bitmaps]).astype(np.int64)
     np.savez_compressed(OUT, blob=blob, offsets=offs, index=np.frombuffer(json.dumps(index).encode(), np.uint8),
                         charmap=np.frombuffer(json.dumps(charmap).encode(), np.uint8),
-                        runs=np.frombuffer(json.dumps(runs).encode(), np.uint8))
+                        runs=np.frombuffer(json.dumps(runs).encode(), np.uint8),
+                        lcd_blob=lcd_blob, lcd_offsets=lcd_offs, lcd_index=np.frombuffer(json.dumps(lcd_index).encode(), np.uint8))
     print("wrote", OUT, len(bitmaps), "bitmaps,", blob.size, "bytes of coverage,", os.path.getsize(OUT), "bytes on disk")
 
 

@@ -179,6 +179,16 @@ class GlyphFixture:
         self.index = json.loads(bytes(d["index"]).decode())
         self.charmap = json.loads(bytes(d["charmap"]).decode())
         self.runs = json.loads(bytes(d["runs"]).decode())
+        # FontRenderMode::Subpixel bitmaps (FT_RENDER_MODE_LCD, BGRA as rasterize_glyph packs them) of cfg3's character set
+        self.lcd_blob, self.lcd_offsets = d["lcd_blob"], d["lcd_offsets"]
+        self.lcd_index = json.loads(bytes(d["lcd_index"]).decode())
+
+    def glyph_lcd(self, font, size, gid):
+        """-> (left, top, bgra[h, w, 4] or None): the subpixel-mode RasterizedGlyph (whole-pixel variant)"""
+        e = self.lcd_index[f"{font}|{float(size)}|{int(gid)}|0"]
+        if e[0] < 0:
+            return 0, 0, None
+        return e[1], e[2], self.lcd_blob[self.lcd_offsets[e[0]]:self.lcd_offsets[e[0] + 1]].reshape(e[4], e[3], 4)
 
     def glyph(self, font, size, gid, subpx=0):
         """-> (left, top, bitmap or None, advance): RasterizedGlyph of wr_glyph_rasterizer (bitmap's top-left corner at
@@ -234,6 +244,38 @@ def build_glyph_atlas(sizes=range(12, 25), chars=range(33, 127), font="FreeSans.
     return atlas, table
 
 
+def build_glyph_atlas_lcd(sizes=range(12, 25), chars=range(33, 127), font="FreeSans.ttf"):
+    """The BGRA8 atlas of subpixel-mode glyphs (FreeType LCD rendering with the reference's options: tests/golden/make_glyphs.py
+    rasterize_lcd), shelf-packed like build_glyph_atlas.  Returns (pixels[2048, 2048, 4] u8 in B, G, R, A order, {(size, ch): (uv rect,
+    (left, -top))}): an LCD bitmap is a pixel wider either side than the alpha one, so the layout is its own."""
+    key = ("lcd", tuple(sizes), tuple(chars), font)
+    if key in _atlas_cache:
+        return _atlas_cache[key]
+    fx = glyph_fixture()
+    atlas = np.zeros((ATLAS_SIZE, ATLAS_SIZE, 4), np.uint8)
+    table = {}
+    x = y = 1
+    shelf = 0
+    for size in sizes:
+        for ch in chars:
+            gid = fx.charmap.get(f"{font}|{int(ch)}")
+            if gid is None or f"{font}|{float(size)}|{int(gid)}|0" not in fx.lcd_index:
+                continue
+            left, top, bmp = fx.glyph_lcd(font, size, gid)
+            if bmp is None:
+                continue
+            h, w = bmp.shape[:2]
+            if x + w + 1 > ATLAS_SIZE:
+                x, y, shelf = 1, y + shelf + 1, 0
+            assert y + h + 1 <= ATLAS_SIZE
+            atlas[y:y + h, x:x + w] = bmp
+            table[(size, ch)] = ((float(x), float(y), float(x + w), float(y + h)), (float(left), float(-top)))
+            x += w + 1
+            shelf = max(shelf, h)
+    _atlas_cache[key] = (atlas, table)
+    return atlas, table
+
+
 def char_advance(size, ch, font="FreeSans.ttf"):
     return float(glyph_fixture().char(font, size, ch)[3])
 
@@ -246,9 +288,9 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
     (batch.rs:1109-1290).  glyph_zoom != 1 draws the cached bitmaps magnified
     (local raster space: raster_scale = 1/zoom) so that sampling is truly bilinear.
     color_modes other than 0 (cycled per run: 1 = COLOR_MODE_SUBPX_DUAL_SOURCE, 2 = COLOR_MODE_BITMAP_SHADOW,
-    3 = COLOR_MODE_COLOR_BITMAP) sample a BGRA8 atlas: per-channel coverage shifted by one texel per
-    channel, as a subpixel rasteriser produces; dual_source selects the DUAL_SOURCE_BLENDING program
-    (batch.rs:1150-1180: BlendMode::SubpixelDualSource).
+    3 = COLOR_MODE_COLOR_BITMAP) sample a BGRA8 atlas of the SUBPIXEL-mode glyphs: FreeType's LCD rendering of the same
+    characters with the reference's options (build_glyph_atlas_lcd; rounds 1-5 shifted the alpha coverage by a texel per
+    channel); dual_source selects the DUAL_SOURCE_BLENDING program (batch.rs:1150-1180: BlendMode::SubpixelDualSource).
     rotate / perspective: two runs in three sit under a rotation (skew) about their origin, with a projective row on top for
     `perspective` -- local-raster-space text: the glyph quads are laid out in local space by the non-GLYPH_TRANSFORM program and
     transformed as quads.
@@ -265,15 +307,13 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
                            pixels=atlas, upload_format=G.GL_RED)
     frame.static_textures.append(atlas_ref)
     atlas_bgra_ref = None
+    res_addr_lcd = {}
     if any(m != 0 for m in color_modes):
-        sub = np.zeros((ATLAS_SIZE, ATLAS_SIZE, 4), np.uint8)
-        sub[:, 1:, 0] = atlas[:, :-1]           # b: coverage one texel to the left
-        sub[..., 1] = atlas                      # g
-        sub[:, :-1, 2] = atlas[:, 1:]           # r: one texel to the right
-        sub[..., 3] = sub[..., :3].max(axis=2)   # a >= every channel (valid premultiplied colour bitmap)
+        sub, table_lcd = build_glyph_atlas_lcd()
         atlas_bgra_ref = TextureRef("glyph_atlas_bgra8", ATLAS_SIZE, ATLAS_SIZE, G.GL_RGBA8, G.GL_LINEAR,
                                     pixels=sub, upload_format=G.GL_BGRA)
         frame.static_textures.append(atlas_bgra_ref)
+        res_addr_lcd = {k: frame.add_glyph_resource(v[0], v[1], 1.0) for k, v in table_lcd.items()}
     res_addr = {k: frame.add_glyph_resource(v[0], v[1], 1.0) for k, v in table.items()}
     raster_scale = 1.0 / glyph_zoom
     dps = device_pixel_scale
@@ -350,7 +390,7 @@ def cfg3_text(width=3840, height=2160, lines=200, glyphs_per_line=250, run_len=2
             mode = color_modes[ri % len(color_modes)]
             for gi, c in enumerate(run_chars):
                 (inst if mode == 0 else inst_bgra).append(
-                    frame.glyph_instance(ph, gi, res_addr[(size, c)], color_mode=mode))
+                    frame.glyph_instance(ph, gi, (res_addr if mode == 0 else res_addr_lcd)[(size, c)], color_mode=mode))
         gt = "GLYPH_TRANSFORM," if glyph_transform else ""
         if inst:
             target.alpha.append(Step(f"ps_text_run ALPHA_PASS,{gt}TEXTURE_2D", "PRIM_INSTANCES",
