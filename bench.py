@@ -146,7 +146,7 @@ def pmc_traffic(workload, encoding, label):
     # the counters describe the kernels they were collected with: a profile of other kernel sources says nothing about these
     import hashlib
     cur = hashlib.sha256(b"".join(open(os.path.join(ROOT, "webrender_amd", "csrc", f), "rb").read()
-                                  for f in ("wrhip_kernels.h", "wrhip_types.h"))).hexdigest()[:16]
+                                  for f in ("wrhip_kernels.h", "wrhip_k_setup.h", "wrhip_k_pixels.h", "wrhip_k_rows.h", "wrhip_k_raster.h", "wrhip_types.h"))).hexdigest()[:16]
     if d.get("kernel_sources_sha256_16") != cur:
         return None
     tag = label[label.index("<"):] if "<" in label else label

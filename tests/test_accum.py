@@ -1,4 +1,4 @@
-"""wr_accum (csrc/wrhip_kernels.h): the n-fold sequential fp32 sum s0 + step + step + ... that swgl's
+"""wr_accum (csrc/wrhip_k_setup.h): the n-fold sequential fp32 sum s0 + step + step + ... that swgl's
 span loops and Edge::nextRow produce by repeated addition, evaluated binade by binade.  The kernel
 header is compiled for the host here and checked against the plain loop, bit for bit, on random,
 dyadic, tie-prone, binade-floor and raw-bit-pattern inputs."""
@@ -55,7 +55,7 @@ int main() {
 
 
 def test_accum_matches_sequential_adds(tmp_path):
-    hdr = open(os.path.join(ROOT, "webrender_amd", "csrc", "wrhip_kernels.h")).read()
+    hdr = open(os.path.join(ROOT, "webrender_amd", "csrc", "wrhip_k_setup.h")).read()
     a = hdr.index("WR_DEVICE int wr_low_bit_exp(float x)")
     b = hdr.index("// row-k edge interpolant")
     (tmp_path / "accum_only.h").write_text("#define WR_DBG_PATH(i) ((void)0)\n" + hdr[a:b])
@@ -127,7 +127,7 @@ int main() {
 
 def test_row_sum_tables_match_sequential_adds(tmp_path):
     """WrAccTab (the setup stage's per-prim row-sum tables): every row of every table against the plain loop."""
-    hdr = open(os.path.join(ROOT, "webrender_amd", "csrc", "wrhip_kernels.h")).read()
+    hdr = open(os.path.join(ROOT, "webrender_amd", "csrc", "wrhip_k_setup.h")).read()
     a = hdr.index("WR_DEVICE int wr_low_bit_exp(float x)")
     b = hdr.index("// round_pixel (portable path)")
     (tmp_path / "accum_only.h").write_text("#define WR_DBG_PATH(i) ((void)0)\n" + hdr[a:b])

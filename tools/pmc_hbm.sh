@@ -9,7 +9,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<PY
 import csv, collections, json, glob, hashlib
-src_hash = hashlib.sha256(b"".join(open("webrender_amd/csrc/" + f, "rb").read() for f in ("wrhip_kernels.h", "wrhip_types.h"))).hexdigest()[:16]
+src_hash = hashlib.sha256(b"".join(open("webrender_amd/csrc/" + f, "rb").read() for f in ("wrhip_kernels.h", "wrhip_k_setup.h", "wrhip_k_pixels.h", "wrhip_k_rows.h", "wrhip_k_raster.h", "wrhip_types.h"))).hexdigest()[:16]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/${tag}_%s/*counter_collection.csv" % ctr)
