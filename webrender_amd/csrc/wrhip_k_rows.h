@@ -547,7 +547,44 @@ WR_DEVICE void wr_tile_row_piece(const WrTargetDesc& T, const int y, const int x
     px[i] = T.load_color ? (i < nvalid ? ((const uint32_t*)rowp)[xbase + i] : 0u) : T.init_color;
     dep[i] = T.init_depth;
   }
+  // The target's prims in submission order.  On the device the wave looks at 64 of them at a time -- lane l fetches the head of prim
+  // base + l (box, z, kind, flags), one round trip for all of them -- and walks only the ones that reach this row piece (a ballot, lowest
+  // bit first: still submission order); prim by prim every test was a dependent fetch of its own, ~0.4 us each whether or not the prim
+  // touched the row (clip-clear: 99 segment prims a tile, a handful per row; profiles/r06_r_tile_rows_ab.txt).
+  // ... and a depth cap for the piece, kept in SGPRs over the walk: every pixel of the piece holds a depth <= zcap (the clear value, then the
+  // z of every depth-writing prim that spans the whole piece), so a depth-tested prim behind it is hidden on all 256 pixels and is not
+  // visited at all (ten full-size opaque gradients front to back: nine of them are, for most pieces).
+#ifndef WRHIP_HOSTSIM
+  uint32_t zcap = T.init_depth;
+  const int piece_x1 = wr_imin(piece_x0 + 256, T.width);
+  for (int pbase = T.first_prim; pbase < T.end_prim; pbase += 64) {
+    const int lane_ = (int)threadIdx.x & 63;
+    bool reach = false;
+    int qk = 0, qf = 0, qcov = 0;
+    uint32_t qz = 0;
+    if (pbase + lane_ < T.end_prim) {
+      const WrPrim& Q = prims[pbase + lane_];
+      qk = Q.kind; qf = Q.flags; qz = Q.z;
+      reach = qk != WR_PK_NONE && qk != WR_PK_UNSUPPORTED && y >= Q.y0 && y < Q.y1 && Q.x1 > piece_x0 && Q.x0 < piece_x0 + 256;
+      qcov = (Q.x0 <= piece_x0 && Q.x1 >= piece_x1) ? 1 : 0;
+    }
+  for (unsigned long long pm = __ballot(reach); pm; pm &= pm - 1ull) {
+    const int pb = (int)__builtin_ctzll(pm);
+    const int p = pbase + pb;
+    {
+      const int sk = __builtin_amdgcn_readlane(qk, pb), sf = __builtin_amdgcn_readlane(qf, pb), scov = __builtin_amdgcn_readlane(qcov, pb);
+      const uint32_t sz = (uint32_t)__builtin_amdgcn_readlane((int)qz, pb);
+      if (sk == WR_PK_CLEAR) {
+        if (sf & WR_PF_CLEAR_DEPTH) zcap = scov ? sz : (sz > zcap ? sz : zcap);
+      } else if (sf & WR_PF_DEPTH_TEST) {
+        if ((sf & WR_PF_DEPTH_LESS) ? sz >= zcap : sz > zcap) continue;          // fails against every pixel's depth
+        if ((sf & WR_PF_DEPTH_WRITE) && scov && sz < zcap) zcap = sz;
+      }
+    }
+#else
+  {
   for (int p = T.first_prim; p < T.end_prim; p++) {
+#endif
     const WrPrim& P = prims[p];
     const int kind = P.kind;
     if (kind == WR_PK_NONE || kind == WR_PK_UNSUPPORTED) continue;
@@ -610,7 +647,22 @@ WR_DEVICE void wr_tile_row_piece(const WrTargetDesc& T, const int y, const int x
         in[0] = in[1]; in[1] = in[2]; in[2] = in[3];
         g4.v[0] = g4.v[1]; g4.v[1] = g4.v[2]; g4.v[2] = g4.v[3];
       }
-    } else if (kind == WR_PK_SOLID_MASKED || ((kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_FS) && P.dual && P.blend == WR_BLEND_DUAL_SRC)) {
+    } else if (kind == WR_PK_SOLID_MASKED) {
+      // a solid under a clip mask: the lane's four mask texels fetched together (1:1 at (x, y) - offset), then applyColor(expand_mask(mask),
+      // colour) and the blend per pixel -- what wr_generic_pixel_rgba8 does, pixel after pixel behind a call, with a dependent fetch each
+      const WrTexDesc& mt = D->tex[WR_S_CLIP_MASK];
+      const uint8_t* mrow = (const uint8_t*)mt.ptr + (size_t)(y - P.mask_off[1]) * mt.stride + (xbase - P.mask_off[0]);
+      uint32_t m[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) m[i] = in[i] ? (uint32_t)mrow[i] : 0u;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (!in[i]) continue;
+        WrWide mm; mm.bg = mm.ra = m[i] | (m[i] << 16);
+        const WrWide src = wr_apply_color(mm, P.color);
+        px[i] = wr_tile_blend(P.blend, px[i], src.bg, src.ra, D, P.color);
+      }
+    } else if ((kind == WR_PK_TEX_RGBA8 || kind == WR_PK_TEX_FS) && P.dual && P.blend == WR_BLEND_DUAL_SRC) {
 #pragma nounroll
       for (int i = 0; i < 4; i++) {
         uint32_t v = px[0];
@@ -636,6 +688,7 @@ WR_DEVICE void wr_tile_row_piece(const WrTargetDesc& T, const int y, const int x
       // the host's promise (rect kinds of the solid / image / gradient programs only) does not hold for this prim: reported, not drawn
       if (T.counters && xbase == wr_imax(piece_x0, P.x0 & ~3) && y == wr_imax(P.y0, T.y_begin)) atomicAdd(&T.counters->unsupported_prims, 1u);
     }
+  }
   }
   if (nvalid <= 0) return;
   uint32_t* dst = (uint32_t*)rowp + xbase;
