@@ -7,7 +7,7 @@ with seeds nobody pinned, libwrhip.so through the C ABI against the oracle.
   WRHIP_SWEEP_SECONDS   time budget (default 45): scenes are drawn in a shuffled order until it is spent; at least MIN_SCENES must fit
 
 0 differing bytes and no gl_error, except the families whose float functions come from the device's math library instead of glibc
-(conic gradients' atan2f, the SVG filter programs' sqrt / division / powf, mix-blend's sqrt / division): <= 1 LSB there."""
+(conic gradients' atan2f, the SVG filter programs' sqrt / division / powf, mix-blend's sqrt / division, hue-rotate's cosf / sinf): <= 1 LSB there."""
 import datetime
 import os
 import sys
@@ -19,7 +19,9 @@ from conftest import wrhip_lib, oracle_ref
 from webrender_amd import scenes
 from webrender_amd.harness import render_direct
 
-ONE_LSB = {"cache_decorations", "svg_filters", "svg_filter_nodes", "mix_grid_perspective", "mix_grid_perspective_masked", "mix_grid_rotated"}
+# (filter_grid_masked draws all twelve filter ops: hue-rotate's matrix comes from cosf / sinf in the vertex stage -- 1 LSB on 1-2 bytes in 3 of
+# 46 seeds of round 6's long run, profiles/r06_s_gpu_sweep.txt; the parity case of the same name pins the eleven exact ops at 0)
+ONE_LSB = {"cache_decorations", "svg_filters", "svg_filter_nodes", "mix_grid_perspective", "mix_grid_perspective_masked", "mix_grid_rotated", "filter_grid_masked"}
 MIN_SCENES = 40
 
 

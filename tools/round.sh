@@ -13,6 +13,7 @@ for w in cfg1 cfg3 cfg4 cfg5; do
   python bench.py --workload $w --steps 50 --warmup 5 2>/dev/null | grep '"metric"' > gpurun_out/$tag/bench_$w.json
 done
 python bench.py --sharded --steps 20 --warmup 3 2>/dev/null | grep '"metric"' > gpurun_out/$tag/bench_sharded_world1_cfg5.json
+for W in 2 4 8; do python bench.py --emulate-world $W --steps 20 --warmup 3 2>/dev/null | grep '"metric"' > gpurun_out/$tag/bench_emulate_world${W}_cfg5.json; done
 for wl in aligned-gradient unaligned-gradient simple-batching large-boxshadow-ellipse large-boxshadow-ellipse-2 large-clip-rect transforms text-rendering many-images large-blur-radius many-box-shadows clip-clear overlapping-text-shadows; do
   python bench.py --workload $wl --steps 40 --warmup 5 $nocpu 2>/dev/null | grep '"metric"' > gpurun_out/$tag/bench_${wl}.json
 done
