@@ -286,6 +286,21 @@ def test_hip_depth_run_overflow_is_exact(name, make, monkeypatch):
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 4
 
 
+@pytest.mark.gpu
+def test_hip_pool_grows_on_demand(monkeypatch):
+    """(see tests/test_hostsim_parity.py::test_hostsim_pool_grows_on_demand)"""
+    from test_hostsim_parity import _two_frames
+    ref = oracle_ref()
+    if not ref:
+        pytest.skip("oracle not built")
+    make = RUN_OVERFLOW[2][1]
+    want, _ = render_direct(ref, make())
+    monkeypatch.setenv("WRHIP_RUNS_POOL_WORDS", "64")
+    (px1, e1), (px2, e2) = _two_frames(wrhip_lib(), make)
+    assert e1 == 0x0502
+    assert e2 == 0 and np.array_equal(px2, want)
+
+
 def _sweep_cases():
     """Randomised scenes that stress the prim-list walks (dense and thinly spread mask words, several 64-word blocks, the cell
     raster's and the LDS list walk's limits, the depth cap with opaque / translucent mixes) and the general-quad paths: the

@@ -240,6 +240,35 @@ def test_hostsim_depth_run_overflow_is_exact(hostsim, oracle_gcc, name, make, mo
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 4
 
 
+def _two_frames(lib, make):
+    """the same frame twice in ONE context: (pixels, gl_error) after each"""
+    from webrender_amd.glapi import GL
+    from webrender_amd.renderer import Renderer
+    gl = GL(lib)
+    frame = make()
+    r = Renderer(gl, frame.width, frame.height)
+    out = []
+    for _ in range(2):
+        r.render(frame)
+        r.finish()
+        err = int(gl.GetError())
+        out.append((r.read_pixels(), err))
+    r.destroy()
+    return out
+
+
+def test_hostsim_pool_grows_on_demand(hostsim, oracle_gcc, monkeypatch):
+    """The flush's pool is sized for what the frame before asked of it: with a pool too small for the sliver-fence frame (here forced
+    small: the default 64 MB holds this one) the first frame is REPORTED, Finish reads the pool's allocation word -- it counts every
+    request, granted or not -- and grows the share, and the same frame drawn again in the same context is swgl's, with no error."""
+    make = RUN_OVERFLOW[2][1]
+    want, _ = render_direct(oracle_gcc, make())
+    monkeypatch.setenv("WRHIP_RUNS_POOL_WORDS", "64")
+    (px1, e1), (px2, e2) = _two_frames(hostsim, make)
+    assert e1 == 0x0502, "the forced-small pool was expected to run out on the first frame"
+    assert e2 == 0 and np.array_equal(px2, want)
+
+
 def _cache_key(scene):
     return "decoration_cache" if scene == "cache_decorations" else "border_cache"
 

@@ -599,7 +599,12 @@ struct Context {
   size_t gtab_pending = 0;             // words promised to recorded, not yet flushed gradient draws (WR_DF_GTAB)
   bool quad_rowtabs = true;            // WRHIP_NO_QTAB=1: no row tables of general quads (the raster stage sums every row's edge values itself)
   size_t runs_pool_words = (size_t)16 << 20;   // WRHIP_RUNS_POOL_WORDS: the share of a flush's pool (WrTargetDesc::qtab) kept for depth runs / occluder
-                                       // lists that outgrow their LDS copies, 4-byte words (64 MB; 0: none -- such rows are then reported)
+                                       // lists that outgrow their LDS copies, 4-byte words (64 MB to start with; 0: none -- such rows are then reported).
+                                       // GROWN ON DEMAND: the pool's allocation word counts what was asked for, granted or not; Finish reads the last
+                                       // flush's and, if it ran out, sizes the share for what that frame asked (the frame itself stays reported:
+                                       // re-running a flush whose targets load their old content is not idempotent), up to 4 GB of the 288
+  unsigned long long* last_qctl = nullptr;     // the most recent flush's pool word (in the staging mirror) and the capacity it was given
+  size_t last_qtab_cap = 0;
   bool cell_raster = true;             // WRHIP_NO_CELLS=1: rect-only bins always take the pixel walk
   bool thin_r8 = true;                 // WRHIP_NO_THIN=1: small R8 launches keep the 4-wave workgroup shape
   int thin_parts = 4;                  // workgroups per bin of a thin launch (WRHIP_THIN_PARTS = 1, 2, 4, 8, 16): 16 / parts waves each, so that a wave shares its SIMD with fewer others
@@ -1930,6 +1935,8 @@ void flush_work(const std::vector<int>& sel_in) {
     }
     *(unsigned long long*)(h + off_qctl) = (unsigned long long)gtab_words;      // (WR_GTAB_WORDS is a multiple of 4: the pieces behind stay on 16 bytes)
     for (WrTargetDesc& T : targets) T.qtab_ctl = T.qtab ? (unsigned long long*)(c->dupload + aoff + off_qctl) : nullptr;
+    c->last_qctl = nullptr;
+    for (const WrTargetDesc& T : targets) if (T.qtab) { c->last_qctl = T.qtab_ctl; c->last_qtab_cap = T.qtab_cap; break; }
     if (nd) stage_copy(h + off_draws, draws.data(), sizeof(WrDrawDesc) * nd);
     stage_copy(h + off_targets, targets.data(), sizeof(WrTargetDesc) * n_targets);
     if (inst_bytes >= PARALLEL_COPY_MIN && inst_segs.size() > 1) {
@@ -3231,6 +3238,22 @@ void Finish(void) {
       // visible at the ABI, not only on stderr: the frame has holes, and the caller's GetError() says so (the reference
       // itself only ever raises GL_OUT_OF_MEMORY, gl.cc:1125-1134, so any other code is unambiguous)
       ctx->last_error = GL_INVALID_OPERATION;
+    }
+    if (ctx->last_qctl && ctx->runs_pool_words) {
+      // the flush's pool: what the last flush asked of it against what it held (Context::runs_pool_words)
+      unsigned long long asked = 0;
+      wrrt::d2h(&asked, ctx->last_qctl, sizeof(asked), ctx->stream);
+      sync_stream();
+      ctx->last_qctl = nullptr;
+      if (asked > (unsigned long long)ctx->last_qtab_cap) {
+        const unsigned long long extra = asked - ctx->last_qtab_cap;
+        const size_t want = std::min<size_t>(((size_t)1 << 30) - ((size_t)80 << 20), ctx->runs_pool_words + (size_t)(extra + extra / 4) + ((size_t)1 << 20));
+        if (want > ctx->runs_pool_words) {
+          fprintf(stderr, "libwrhip: the flush's pool ran out (%llu words asked, %zu held): its share for depth runs grows from %zu to %zu words for the following flushes\n",
+                  asked, ctx->last_qtab_cap, ctx->runs_pool_words, want);
+          ctx->runs_pool_words = want;
+        }
+      }
     }
     static const bool dbgc = getenv("WRHIP_DEBUG_COUNTERS") != nullptr;
     if (dbgc) fprintf(stderr, "libwrhip dbg counters (delta): %u %u %u %u %u (max %u)\n", h.dbg[0] - ctx->seen.dbg[0], h.dbg[1] - ctx->seen.dbg[1],
