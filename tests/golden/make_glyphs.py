@@ -63,7 +63,9 @@ TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-o
                  "1658-ref", "non-opaque-notref", "shadow", "shadow-ref", "shadow-single", "shadow-cover-2", "shadow-many", "shadow-complex",
                  "two-shadows", "subtle-shadow", "subtle-shadow-ref", "snap-clip", "snap-clip-ref", "subpixel-translate-ref",
                  "shadow-partial-glyph", "shadow-partial-glyph-ref", "allow-subpixel-ref", "diacritics", "diacritics-ref", "transparent-no-aa",
-                 "transparent-no-aa-ref", "subpx-bg-mask-ref", "colors", "decorations-ref", "ahem-ref", "shadow-clip-ref", "blank")
+                 "transparent-no-aa-ref", "subpx-bg-mask-ref", "colors", "decorations-ref", "ahem-ref", "shadow-clip-ref", "blank",
+                 "decorations", "shadow-atomic", "shadow-atomic-ref", "shadow-ordering", "shadow-ordering-ref", "shadow-clip-rect",
+                 "blurred-shadow-local-clip-rect")
 
 
 def open_face(name):

@@ -633,7 +633,11 @@ TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-o
                  "1658-ref", "non-opaque-notref", "shadow", "shadow-ref", "shadow-single", "shadow-cover-2", "shadow-many", "shadow-complex",
                  "two-shadows", "subtle-shadow", "subtle-shadow-ref", "snap-clip", "snap-clip-ref", "subpixel-translate-ref",
                  "shadow-partial-glyph", "shadow-partial-glyph-ref", "allow-subpixel-ref", "diacritics", "diacritics-ref", "transparent-no-aa",
-                 "transparent-no-aa-ref", "subpx-bg-mask-ref", "colors", "decorations-ref", "ahem-ref", "shadow-clip-ref", "blank")
+                 "transparent-no-aa-ref", "subpx-bg-mask-ref", "colors", "decorations-ref", "ahem-ref", "shadow-clip-ref", "blank",
+                 # solid line decorations (a LineDecoration without a cache key is drawn as a solid rect: scene_building.rs:3171-3210,
+                 # get_line_decoration_size is None for LineStyle::Solid), also as members of shadow contexts
+                 "decorations", "shadow-atomic", "shadow-atomic-ref", "shadow-ordering", "shadow-ordering-ref", "shadow-clip-rect",
+                 "blurred-shadow-local-clip-rect")
 
 
 def _css_color(c):
@@ -711,10 +715,25 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
             bb = (max(bb[0], c[0]), max(bb[1], c[1]), min(bb[2], c[2]), min(bb[3], c[3]))
         return dict(kind="run", pts=pts, ref=ref, color=color if color is not None else _css_color(it.get("color", "black")), insts=insts, bb=bb, clip=clip)
 
-    def make_rect(it):
-        so = it["origin_offset"]
-        r = _rect_of(it["rect"] if "rect" in it else it["bounds"], so)
-        return dict(kind="rect", rect=r, color=_css_color(it.get("color", "black")), bb=r, clip=(-BIG, -BIG, BIG, BIG))
+    def make_rect(it, offset=(0.0, 0.0), color=None):
+        """a rect item, or a SOLID line decoration (yaml_frame_reader.rs:845-900: horizontal = [start, baseline, end - start, width], vertical =
+        [baseline, start, width, end - start]); `offset` / `color`: a shadow's"""
+        so = (it["origin_offset"][0] + offset[0], it["origin_offset"][1] + offset[1])
+        if it.get("type") == "line" and "baseline" in it:
+            assert it.get("style", "solid") == "solid", "solid line decorations only"
+            b, a0, a1, w = float(it["baseline"]), float(it["start"]), float(it["end"]), float(it["width"])
+            geom = [a0, b, a1 - a0, w] if it["orientation"] == "horizontal" else [b, a0, w, a1 - a0]
+        else:
+            geom = it["rect"] if "rect" in it else it["bounds"]
+        r = _rect_of(geom, so)
+        clip, bb = (-BIG, -BIG, BIG, BIG), r
+        if "clip-rect" in it:
+            clip = _rect_of(it["clip-rect"], so)
+            bb = (max(r[0], clip[0]), max(r[1], clip[1]), min(r[2], clip[2]), min(r[3], clip[3]))
+        return dict(kind="rect", rect=r, color=color if color is not None else _css_color(it.get("color", "black")), bb=bb, clip=clip)
+
+    def make_prim(it, offset=(0.0, 0.0), color=None):
+        return make_run(it, offset, color) if "glyphs" in it else make_rect(it, offset, color)
 
     draw, queue = [], None            # the draw list; the open shadow context's queue
     def flush_queue(q):
@@ -722,15 +741,14 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
             kind, v = q.pop(0)
             if kind == "S":
                 later = [p for k, p in q if k == "P"]
-                assert all("glyphs" in p for p in later), "shadows of text runs only"
                 off = tuple(float(t) for t in v.get("offset", [0, 0]))
                 col = _css_color(v.get("color", "black"))
                 std = float(v.get("blur-radius", 0)) * 0.5
                 if std == 0.0:
-                    draw.extend(make_run(p, off, col) for p in later)
+                    draw.extend(make_prim(p, off, col) for p in later)
                 elif later:
                     assert std <= 4.0, "no down-scaling chain here"
-                    draw.append(dict(kind="pic", std=std, runs=[make_run(p, off, col) for p in later]))
+                    draw.append(dict(kind="pic", std=std, runs=[make_prim(p, off, col) for p in later]))
             elif "glyphs" in v:
                 r = make_run(v)
                 if r["color"][3] > 0:
@@ -747,7 +765,7 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
         elif t == "pop-all-shadows":
             flush_queue(queue or [])
             queue = None
-        elif "glyphs" in it or t == "rect" or "rect" in it:
+        elif "glyphs" in it or t in ("rect", "line") or "rect" in it:
             if queue is not None:
                 queue.append(("P", it))
             else:
@@ -771,14 +789,29 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
         t_pic = TextureRef(f"shadow_picture_{si}", pot(tw), pot(th), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
         tg = Target(t_pic, "color", clear_color=zero)
         pic_task = frame.add_render_task((0.0, 0.0, float(tw), float(th)), 1.0, (clipped[0], clipped[1]))
-        inst = []
+        cur_key, inst = None, []
+        def close_pic():
+            nonlocal cur_key, inst
+            if inst:
+                tg.steps.append(Step(cur_key, "PRIM_INSTANCES", np.array(inst, dtype=np.int32), "PremultipliedAlpha", "none",
+                                     **({"textures": {0: t_atlas}} if cur_key.startswith("ps_text_run") else {})))
+            cur_key, inst = None, []
         for run in d["runs"]:
             scol = premultiply(np.array([list(run["color"])], np.uint8))[0]
-            addr = frame.add_text_run(scol, run["pts"])
-            ph = frame.add_prim_header((run["ref"][0], run["ref"][1], 0.0, 0.0), run["clip"], 1, addr, 0, pic_task, (65535, 0, 0, 0))
-            inst += [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
-        if inst:
-            tg.steps.append(Step("ps_text_run ALPHA_PASS,TEXTURE_2D", "PRIM_INSTANCES", np.array(inst, dtype=np.int32), "PremultipliedAlpha", "none", textures={0: t_atlas}))
+            if run["kind"] == "rect":
+                key = "brush_solid ALPHA_PASS"
+                ph = frame.add_prim_header(run["rect"], run["clip"], 1, frame.gpu_cache.push([list(scol)]), 0, pic_task, (65535, 0, 0, 0))
+                new_inst = [frame.brush_instance(ph, CLIP_TASK_EMPTY)]
+            else:
+                key = "ps_text_run ALPHA_PASS,TEXTURE_2D"
+                addr = frame.add_text_run(scol, run["pts"])
+                ph = frame.add_prim_header((run["ref"][0], run["ref"][1], 0.0, 0.0), run["clip"], 1, addr, 0, pic_task, (65535, 0, 0, 0))
+                new_inst = [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
+            if key != cur_key:
+                close_pic()
+                cur_key = key
+            inst += new_inst
+        close_pic()
         frame.passes.append([tg])
         cur_rect = (0.0, 0.0, float(tw), float(th))
         t_v = TextureRef(f"shadow_blur_v_{si}", pot(tw), pot(th), G.GL_RGBA8, G.GL_LINEAR, render_target=True)
