@@ -65,7 +65,7 @@ TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-o
                  "shadow-partial-glyph", "shadow-partial-glyph-ref", "allow-subpixel-ref", "diacritics", "diacritics-ref", "transparent-no-aa",
                  "transparent-no-aa-ref", "subpx-bg-mask-ref", "colors", "decorations-ref", "ahem-ref", "shadow-clip-ref", "blank",
                  "decorations", "shadow-atomic", "shadow-atomic-ref", "shadow-ordering", "shadow-ordering-ref", "shadow-clip-rect",
-                 "blurred-shadow-local-clip-rect")
+                 "blurred-shadow-local-clip-rect", "subpixel-translate", "snap-text-offset-ref", "shadow-clip", "shadow-fast-clip", "shadow-fast-clip-ref")
 
 
 def open_face(name):
@@ -175,7 +175,7 @@ def main():
             else:
                 index[key] = [len(bitmaps), g[0], g[1], g[2].shape[1], g[2].shape[0], adv]
                 bitmaps.append(g[2])
-    faces = {f: open_face(f) for f in ("VeraBd.ttf", "FreeSans.ttf")}
+    faces = {f: open_face(f) for f in ("VeraBd.ttf", "FreeSans.ttf", "Ahem.ttf")}
     charmap = {}
     # (1) the display lists of the text reftests (wrench/reftests/text/reftest.list) that need no transform, clip chain or line decoration:
     # text runs with explicit glyph lists, and `text:` strings laid out as wrench lays them out (wrench.rs:320-382 layout_simple_ascii:
@@ -186,15 +186,20 @@ def main():
     for name in TEXT_REFTESTS:
         doc = yaml.safe_load(open(os.path.join(REF, name + ".yaml"))) or {}
         out = []
-        def walk(items, origin):
+        def walk(items, origin, xlate=(0.0, 0.0)):
             for it in items or []:
                 if it.get("type") == "stacking-context":
                     b = it.get("bounds", [0, 0, 0, 0])
-                    walk(it.get("items", []), (origin[0] + b[0], origin[1] + b[1]))
+                    t = xlate
+                    if "transform" in it:               # translate(x, y) only: a reference frame whose transform moves its content by a fraction
+                        m = re.fullmatch(r"\s*translate\(\s*([-0-9.]+)\s*,\s*([-0-9.]+)\s*\)\s*", str(it["transform"]))
+                        assert m, it["transform"]
+                        t = (xlate[0] + float(m.group(1)), xlate[1] + float(m.group(2)))
+                    walk(it.get("items", []), (origin[0] + b[0], origin[1] + b[1]), t)
                 elif "glyphs" in it or "text" in it:
                     font = it.get("font", "VeraBd.ttf")
                     size_px = float(it.get("size", 12.0)) * 16.0 / 12.0                 # handle_text: default 16 px
-                    e = dict(it); e["font"] = font; e["origin_offset"] = list(origin); e["size_px"] = size_px
+                    e = dict(it); e["font"] = font; e["origin_offset"] = list(origin); e["size_px"] = size_px; e["translate"] = list(xlate)
                     o = it.get("origin", [0.0, 0.0])
                     if isinstance(o, str):
                         o = [float(v) for v in o.replace(",", " ").split()]
@@ -219,7 +224,7 @@ def main():
                     for gid in set(gids):
                         add(font, faces[font], size_px, int(gid), range(4))
                 else:
-                    out.append(dict(it, origin_offset=list(origin)))
+                    out.append(dict(it, origin_offset=list(origin), translate=list(xlate)))
         walk((doc.get("root") or {}).get("items"), (0.0, 0.0))
         runs[name] = out
     # (2) the character sets of cfg3 / text-rendering: FreeSans, sizes 8 .. 24, printable ASCII, whole-pixel variant

@@ -400,7 +400,7 @@ SVG_FILTERS = [
 
 # BASELINE configs[2]: wrench/reftests/text -- the reftests with explicit glyph runs (webrender_amd/wrench_scenes.text_reftest) over the
 # FreeType fixture of the reftests' own fonts: (name, kwargs of the CPU-sized case, kwargs of the 4K case)
-from webrender_amd.wrench_scenes import TEXT_REFTESTS as _TEXT_REFTEST_NAMES      # 41 display lists of the suite (round 6: 7 -> 41)
+from webrender_amd.wrench_scenes import TEXT_REFTESTS as _TEXT_REFTEST_NAMES      # 46 display lists of the suite (round 6: 7 -> 46)
 TEXT_REFTESTS = [(n, dict(width=1024, height=1024), dict()) for n in _TEXT_REFTEST_NAMES]
 
 # Tile rows (wr_tile_rows_kernel): picture targets of a FEW large gradient / image prims -- what the host hands to the row kernel

@@ -637,7 +637,13 @@ TEXT_REFTESTS = ("text", "long-text", "negative-pos", "non-opaque", "snap-text-o
                  # solid line decorations (a LineDecoration without a cache key is drawn as a solid rect: scene_building.rs:3171-3210,
                  # get_line_decoration_size is None for LineStyle::Solid), also as members of shadow contexts
                  "decorations", "shadow-atomic", "shadow-atomic-ref", "shadow-ordering", "shadow-ordering-ref", "shadow-clip-rect",
-                 "blurred-shadow-local-clip-rect")
+                 "blurred-shadow-local-clip-rect",
+                 # text in a reference frame whose transform is a fractional translation
+                 "subpixel-translate", "snap-text-offset-ref",
+                 # rectangular clip nodes: on a prim (its clip chain does not move with a shadow's offset, its clip rect does), and on a
+                 # shadow -- push_shadow leaves the chain on the clip stack until pop-all-shadows (scene_building.rs:2879-2895): it clips the
+                 # context's prims and, for a blurred shadow, the PICTURE (after the blur), not the prims inside it
+                 "shadow-clip", "shadow-fast-clip", "shadow-fast-clip-ref")
 
 
 def _css_color(c):
@@ -657,6 +663,10 @@ def _rect_of(v, off=(0.0, 0.0)):
         v = [float(t) for t in v.replace(",", " ").split()]
     x, y, w, h = (float(t) for t in v)
     return (x + off[0], y + off[1], x + w + off[0], y + h + off[1])
+
+
+def _isect(a, b):
+    return (max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3]))
 
 
 def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
@@ -692,30 +702,55 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
                 shelf = max(shelf, h)
         return entries[key]
 
-    def make_run(it, offset=(0.0, 0.0), color=None):
-        """a text run prim: glyph variants chosen at its device position (`offset`: a shadow's)"""
+    clip_nodes = {}               # `type: clip` items with plain bounds: id -> rect
+
+    def chain_rect(it, extra=()):
+        """the rectangular clip nodes of the item's clip chain and of the enclosing shadows' (`extra`), intersected; None: none"""
+        rects = [clip_nodes[i] for i in it.get("clip-chain", [])] + list(extra)
+        out = None
+        for r in rects:
+            out = r if out is None else _isect(out, r)
+        return out
+
+    def make_run(it, offset=(0.0, 0.0), color=None, stack=()):
+        """a text run prim: glyph variants chosen at its device position (`offset`: a shadow's; `stack`: clip rects of enclosing shadows)"""
         font, size = it["font"], float(it.get("size_px", it["size"]))
         off = it["offsets"]
         so = it["origin_offset"]
-        ref = (float(np.floor(so[0] + 0.5)) + offset[0], float(np.floor(so[1] + 0.5)) + offset[1])   # snapped reference-frame-relative offset (+ the shadow's)
+        # The prim header of a text run (batch.rs / ps_text_run.glsl:108-120, 170-190): local_rect.p0 = prim origin - the UNSNAPPED
+        # reference-frame-relative offset -- with glyph points kept as the yaml gives them (relative to the context) that is the shadow's
+        # offset, nothing else --, added to every glyph offset BEFORE the shader floors it; local_rect.p1 = the offset SNAPPED to device
+        # pixels through the frame's transform (text_run.rs:318-340, SpaceSnapper::snap_point: to raster space, round, back -- for a
+        # translation t: round(so + t) - t), added AFTER the floor.  The glyph key's quarter-pixel variant comes from the point plus
+        # the prim offset (text_run.rs:470-477), i.e. without the context's offset and without the transform.
+        t = tuple(it.get("translate", (0.0, 0.0)))
+        p0 = (float(offset[0]), float(offset[1]))
+        p1 = (float(np.floor(so[0] + t[0] + 0.5)) - t[0], float(np.floor(so[1] + t[1] + 0.5)) - t[1])
+        ref = (p0[0] + p1[0], p0[1] + p1[1])
         pts = [(float(off[2 * i]), float(off[2 * i + 1])) for i in range(len(it["glyphs"]))]
         insts = []
         for gi, (gid, (gx, gy)) in enumerate(zip(it["glyphs"], pts)):
-            fr = (ref[0] + gx) - np.floor(ref[0] + gx)
+            fr = (p0[0] + gx) - np.floor(p0[0] + gx)
             sub = 0 if fr < 0.125 else 1 if fr < 0.375 else 2 if fr < 0.625 else 3 if fr < 0.875 else 0
             res = resource(font, size, int(gid), sub)
             if res is not None:
                 insts.append((gi, res))
         xs, ys = [p[0] for p in pts] or [0.0], [p[1] for p in pts] or [0.0]
-        bb = (ref[0] + min(xs) - 2 * size, ref[1] + min(ys) - 1.5 * size, ref[0] + max(xs) + 2 * size, ref[1] + max(ys) + size)
+        bb = (ref[0] + t[0] + min(xs) - 2 * size, ref[1] + t[1] + min(ys) - 1.5 * size, ref[0] + t[0] + max(xs) + 2 * size, ref[1] + t[1] + max(ys) + size)
         clip = (-BIG, -BIG, BIG, BIG)
+        assert t == (0.0, 0.0) or ("clip-rect" not in it and offset == (0.0, 0.0)), "no clips / shadows under a translated frame here"
         if "clip-rect" in it:
             c = _rect_of(it["clip-rect"], (so[0] + offset[0], so[1] + offset[1]))
             clip = c
             bb = (max(bb[0], c[0]), max(bb[1], c[1]), min(bb[2], c[2]), min(bb[3], c[3]))
-        return dict(kind="run", pts=pts, ref=ref, color=color if color is not None else _css_color(it.get("color", "black")), insts=insts, bb=bb, clip=clip)
+        cr = chain_rect(it, stack)
+        if cr is not None:
+            assert t == (0.0, 0.0)
+            clip = _isect(clip, cr)
+            bb = _isect(bb, cr)
+        return dict(kind="run", pts=pts, ref=ref, color=color if color is not None else _css_color(it.get("color", "black")), insts=insts, bb=bb, clip=clip, xlate=t, lrect=(p0[0], p0[1], p1[0], p1[1]))
 
-    def make_rect(it, offset=(0.0, 0.0), color=None):
+    def make_rect(it, offset=(0.0, 0.0), color=None, stack=()):
         """a rect item, or a SOLID line decoration (yaml_frame_reader.rs:845-900: horizontal = [start, baseline, end - start, width], vertical =
         [baseline, start, width, end - start]); `offset` / `color`: a shadow's"""
         so = (it["origin_offset"][0] + offset[0], it["origin_offset"][1] + offset[1])
@@ -730,36 +765,48 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
         if "clip-rect" in it:
             clip = _rect_of(it["clip-rect"], so)
             bb = (max(r[0], clip[0]), max(r[1], clip[1]), min(r[2], clip[2]), min(r[3], clip[3]))
+        cr = chain_rect(it, stack)
+        if cr is not None:
+            clip = _isect(clip, cr)
+            bb = _isect(bb, cr)
         return dict(kind="rect", rect=r, color=color if color is not None else _css_color(it.get("color", "black")), bb=bb, clip=clip)
 
-    def make_prim(it, offset=(0.0, 0.0), color=None):
-        return make_run(it, offset, color) if "glyphs" in it else make_rect(it, offset, color)
+    def make_prim(it, offset=(0.0, 0.0), color=None, stack=()):
+        return make_run(it, offset, color, stack) if "glyphs" in it else make_rect(it, offset, color, stack)
 
     draw, queue = [], None            # the draw list; the open shadow context's queue
     def flush_queue(q):
+        # the clip chains the context's shadows pushed (push_shadow): all of them are on the stack while pop_all_shadows makes the shadow prims
+        all_shadow_clips = tuple(r for r in (chain_rect(v) for k, v in q if k == "S") if r is not None)
+        seen_clips = []               # ... and the ones pushed so far when a prim of the context was added
         while q:
             kind, v = q.pop(0)
             if kind == "S":
+                r = chain_rect(v)
+                if r is not None:
+                    seen_clips.append(r)
                 later = [p for k, p in q if k == "P"]
                 off = tuple(float(t) for t in v.get("offset", [0, 0]))
                 col = _css_color(v.get("color", "black"))
                 std = float(v.get("blur-radius", 0)) * 0.5
                 if std == 0.0:
-                    draw.extend(make_prim(p, off, col) for p in later)
+                    draw.extend(make_prim(p, off, col, all_shadow_clips) for p in later)
                 elif later:
                     assert std <= 4.0, "no down-scaling chain here"
-                    draw.append(dict(kind="pic", std=std, runs=[make_prim(p, off, col) for p in later]))
-            elif "glyphs" in v:
-                r = make_run(v)
-                if r["color"][3] > 0:
-                    draw.append(r)
+                    pic_clip = None
+                    for r2 in all_shadow_clips:
+                        pic_clip = r2 if pic_clip is None else _isect(pic_clip, r2)
+                    draw.append(dict(kind="pic", std=std, runs=[make_prim(p, off, col) for p in later], clip=pic_clip))
             else:
-                r = make_rect(v)
+                r = make_prim(v, stack=tuple(v.get("_stack", ())))
                 if r["color"][3] > 0:
                     draw.append(r)
     for it in items:
         t = it.get("type")
-        if t == "shadow":
+        if t == "clip":
+            assert "complex" not in it and "bounds" in it, "rectangular clip nodes only"
+            clip_nodes[it["id"]] = _rect_of(it["bounds"], it["origin_offset"])
+        elif t == "shadow":
             queue = queue if queue is not None else []
             queue.append(("S", it))
         elif t == "pop-all-shadows":
@@ -767,7 +814,8 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
             queue = None
         elif "glyphs" in it or t in ("rect", "line") or "rect" in it:
             if queue is not None:
-                queue.append(("P", it))
+                stack = tuple(r for r in (chain_rect(v) for k, v in queue if k == "S") if r is not None)
+                queue.append(("P", dict(it, _stack=stack)))
             else:
                 flush_queue([("P", it)])
     assert queue is None, "unpopped shadows"
@@ -805,7 +853,7 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
             else:
                 key = "ps_text_run ALPHA_PASS,TEXTURE_2D"
                 addr = frame.add_text_run(scol, run["pts"])
-                ph = frame.add_prim_header((run["ref"][0], run["ref"][1], 0.0, 0.0), run["clip"], 1, addr, 0, pic_task, (65535, 0, 0, 0))
+                ph = frame.add_prim_header(run["lrect"], run["clip"], 1, addr, 0, pic_task, (65535, 0, 0, 0))
                 new_inst = [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in run["insts"]]
             if key != cur_key:
                 close_pic()
@@ -826,7 +874,7 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
         d["src"] = frame.gpu_cache.push([[cur_rect[0], cur_rect[1], cur_rect[2], cur_rect[3]], [0.0, 0.0, 0.0, 0.0]] + quad)
         d["tex"], d["bb"] = t_h, clipped
     bdata = frame.gpu_cache.push([[1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [-1.0, -1.0, 0.0, 0.0]])
-    rect_color = {}
+    rect_color, xform_ids = {}, {}
     tiles = _tiles(frame, width, height, tile_filter)
     n_glyphs = 0
     for target, task, (x0, y0, x1, y1) in tiles:
@@ -845,7 +893,7 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
             z = zi + 1
             if d["kind"] == "pic":
                 key, tex = "brush_image ALPHA_PASS,TEXTURE_2D", d["tex"]
-                ph = frame.add_prim_header(d["bb"], (-BIG, -BIG, BIG, BIG), z, bdata, 0, task, (4 | (1 << 16), 1, 65535, 0))
+                ph = frame.add_prim_header(d["bb"], d.get("clip") or (-BIG, -BIG, BIG, BIG), z, bdata, 0, task, (4 | (1 << 16), 1, 65535, 0))
                 inst = [frame.brush_instance(ph, CLIP_TASK_EMPTY, resource_address=d["src"])]
             elif d["kind"] == "rect":
                 key, tex = "brush_solid ALPHA_PASS", None
@@ -857,7 +905,13 @@ def text_reftest(name="text", width=3840, height=2160, tile_filter=None, **kw):
                 key, tex = "ps_text_run ALPHA_PASS,TEXTURE_2D", t_atlas
                 col = premultiply(np.array([list(d["color"])], np.uint8))[0]
                 addr = frame.add_text_run(col, d["pts"])
-                ph = frame.add_prim_header((d["ref"][0], d["ref"][1], 0.0, 0.0), d["clip"], z, addr, 0, task, (65535, 0, 0, 0))
+                tid = 0
+                if d.get("xlate", (0.0, 0.0)) != (0.0, 0.0):
+                    if d["xlate"] not in xform_ids:
+                        m = np.eye(4, dtype=np.float32); m[0, 3], m[1, 3] = d["xlate"]
+                        xform_ids[d["xlate"]] = frame.add_transform(m.T, np.linalg.inv(m).T.astype(np.float32), axis_aligned=True)
+                    tid = xform_ids[d["xlate"]]
+                ph = frame.add_prim_header(d["lrect"], d["clip"], z, addr, tid, task, (65535, 0, 0, 0))
                 inst = [frame.glyph_instance(ph, gi, res, subpx_dir=1) for gi, res in d["insts"]]
                 n_glyphs += len(inst)
             if key != cur_key or tex is not cur_tex:
