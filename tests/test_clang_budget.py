@@ -42,12 +42,46 @@ def _spread(a, b):
     return mx, n1 / max(tot, 1), n4 / max(tot, 1)
 
 
-def _check(family, name, got, want):
+import json
+import os
+# The MEASURED spread of every scene (tests/golden/make_clang_spread.py): [max, bytes > 1 LSB, bytes > 4 LSB, bytes].  Both builds of the
+# reference are deterministic, so on the CPU the numbers must come out UNCHANGED -- a family that improves shows as much as one that gets
+# worse ("a budget 2-3 x above the worst scene is not a bound anyone can act on") --; on the MI355X libwrhip equals the strict
+# build except where the device's math library enters (<= 1 LSB on a few bytes: DESIGN section 7), so it is held to the same numbers with
+# a margin of max(16 bytes, 2 %) and one LSB on the maximum.  The per-family budgets (parity_cases.CLANG_BUDGET) remain as the table of causes.
+# PER CPU VENDOR: the shipping build's rsqrtps / rcpps approximations differ between AMD and Intel, so the same oracle binary has another spread
+# on the GPU box's EPYC than in the Intel authoring container (radial gradients, KHR blend equations); a vendor without pins keeps the budgets only.
+_VENDOR = next((l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("vendor_id")), "unknown")
+_PINS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clang_spread.json"))).get(_VENDOR, {})
+
+
+def _counts(a, b):
+    if not isinstance(a, dict):
+        a, b = {"window": a}, {"window": b}
+    assert set(a) == set(b)
+    tot = n1 = n4 = mx = 0
+    for k in a:
+        d = np.abs(a[k].astype(np.int16) - b[k].astype(np.int16))
+        tot += d.size; n1 += int((d > 1).sum()); n4 += int((d > 4).sum()); mx = max(mx, int(d.max()) if d.size else 0)
+    return [mx, n1, n4, tot]
+
+
+def _check(family, name, got, want, exact=False, pinned=True):
     mx, f1, f4 = _spread(got, want)
     cap, b1, b4, cause = clang_budget(family, name)
     assert cap is None or mx <= cap, (name, mx, cause)
     assert f1 <= b1, (name, "bytes above 1 LSB", f1, b1, cause)
     assert f4 <= b4, (name, "bytes above 4 LSB", f4, b4, cause)
+    pin = _PINS.get(f"{family}-{name}") if pinned else None
+    if pin is None:
+        return
+    c = _counts(got, want)
+    if exact:
+        assert c == pin, (name, "measured spread changed: regenerate tests/golden/clang_spread.json if the scene or the oracle was meant to change", c, pin)
+    else:
+        assert c[3] == pin[3] and c[0] <= pin[0] + 1, (name, c, pin)
+        for i in (1, 2):
+            assert abs(c[i] - pin[i]) <= max(16, 0.02 * pin[i]), (name, "bytes above %d LSB" % (1 if i == 1 else 4), c, pin)
 
 
 @pytest.mark.parametrize("family,name,make", _FAM, ids=_IDS)
@@ -55,7 +89,7 @@ def test_reference_builds_spread_is_inside_the_budget(family, name, make, oracle
     """strict-IEEE g++ build vs shipping clang build of the reference itself"""
     a, _ = render_direct(oracle_gcc, make())
     b, _ = render_direct(oracle_clang, make())
-    _check(family, name, a, b)
+    _check(family, name, a, b, exact=True)
 
 
 @pytest.mark.gpu
@@ -80,7 +114,7 @@ def test_hip_wrench_4k_vs_shipping_build(name, workload, kw):
         pytest.skip("clang oracle not built")
     got, _ = render_direct(wrhip_lib(), scenes.make_workload(workload, **kw))
     want, _ = render_direct(ref, scenes.make_workload(workload, **kw))
-    _check("wrench", name, got, want)
+    _check("wrench", name, got, want, pinned=False)      # (the pins are the CPU-sized scenes')
 
 
 def _degenerate_only():
