@@ -299,6 +299,11 @@ MIX_BLEND = [
     # both varyings interpolated / w, the source's times mix(gl_FragCoord.w, 1, flag) -- round 5
     ("mix_grid_perspective", "mix_blend_grid", dict(seed=211, perspective=True)),
     ("mix_grid_perspective_masked", "mix_blend_grid", dict(seed=212, perspective=True, masked=True, n=60)),
+    # ... cut by the near plane (every other perspective prim's projective row is strong enough for w <= 0 on part of it): clip_side
+    # carries both varyings (rasterize.h:1402-1500 clips the whole Interpolants struct), the polygon's edges step the second one -- round 6
+    ("mix_grid_near_clipped", "mix_blend_grid", dict(seed=213, perspective="clip")),
+    ("mix_grid_near_clipped_masked", "mix_blend_grid", dict(seed=214, perspective="clip", masked=True, n=60)),
+    ("mix_grid_near_clipped_force_aa", "mix_blend_grid", dict(seed=215, perspective="clip", force_aa=True, n=60)),
 ]
 
 
@@ -498,10 +503,14 @@ CLANG_BUDGET = {
     # prims cut by the near plane: a clipped vertex has w -> 0+, its projection is the quotient of two nearly cancelling sums, and
     # the two builds put it pixels apart -- whole slivers of such a polygon are covered in one build and not in the other
     "near_clipped": (None, 0.35, 0.35, "near-plane clipped polygons: vertices at w -> 0 are ill-conditioned"),
+    # ... and a mix-blend prim's pixels all depend on where its backdrop's and its source's polygons ended up (measured worst 0.40 + 25 %)
+    "near_clipped_mix": (None, 0.5, 0.5, "near-plane clipped polygons under brush_mix_blend: two clipped pictures feed every pixel"),
 }
 
 
 def clang_budget(family, name):
     if family == "mix_blend" and "perspective" in name:      # (two bilinear samplers per pixel under a projective transform: the rotated family's causes)
         return CLANG_BUDGET["rotated"]
+    if family == "mix_blend" and "near_clipped" in name:
+        return CLANG_BUDGET["near_clipped_mix"]
     return CLANG_BUDGET["near_clipped" if "near_clipped" in name else family]

@@ -18,6 +18,8 @@ FAMILIES = {
     "mix_grid_perspective": lambda s: scenes.mix_blend_grid(seed=s, perspective=True),
     "mix_grid_perspective_masked": lambda s: scenes.mix_blend_grid(seed=s, perspective=True, masked=True, n=60),
     "mix_grid_rotated": lambda s: scenes.mix_blend_grid(seed=s, rotate=True),
+    "mix_grid_near_clipped": lambda s: scenes.mix_blend_grid(seed=s, perspective="clip"),
+    "mix_grid_near_clipped_masked": lambda s: scenes.mix_blend_grid(seed=s, perspective="clip", masked=True, n=60),
     "rotated_images": lambda s: scenes.rotated_images(seed=s),
     "perspective_images": lambda s: scenes.rotated_images(perspective=True, seed=s),
     "rotated_gradients": lambda s: scenes.gradient_grid(rotate=True, seed=s),

@@ -21,7 +21,7 @@ from webrender_amd.harness import render_direct
 
 # (filter_grid_masked draws all twelve filter ops: hue-rotate's matrix comes from cosf / sinf in the vertex stage -- 1 LSB on 1-2 bytes in 3 of
 # 46 seeds of round 6's long run, profiles/r06_s_gpu_sweep.txt; the parity case of the same name pins the eleven exact ops at 0)
-ONE_LSB = {"cache_decorations", "svg_filters", "svg_filter_nodes", "mix_grid_perspective", "mix_grid_perspective_masked", "mix_grid_rotated", "filter_grid_masked"}
+ONE_LSB = {"cache_decorations", "svg_filters", "svg_filter_nodes", "mix_grid_perspective", "mix_grid_perspective_masked", "mix_grid_rotated", "mix_grid_near_clipped", "mix_grid_near_clipped_masked", "filter_grid_masked"}
 MIN_SCENES = 40
 
 

@@ -462,19 +462,19 @@ def test_staging_ring_wraps_keep_every_frame(hostsim, oracle_gcc):
 
 
 def test_unimplemented_perspective_prims_are_reported(hostsim, capfd):
-    """Perspective prims outside the implemented set (here: brush_mix_blend CUT BY THE NEAR PLANE -- its second varying is not clipped
-    along with the first; under a projective transform that keeps w > 0 it is drawn since round 5) are counted by the setup stage,
-    reported on stderr at Finish and raise GL_INVALID_OPERATION -- not drawn wrongly, not dropped silently; the rest of the frame is
-    drawn."""
+    """Perspective prims outside the implemented set (here: ps_text_run GLYPH_TRANSFORM under a PROJECTIVE transform -- WebRender
+    rasterises such text in local space, so the key never meets one (batch.rs:1186-1200); brush_mix_blend cut by the near plane, the
+    case of rounds 4-5, is drawn since round 6) are counted by the setup stage, reported on stderr at Finish and raise
+    GL_INVALID_OPERATION -- not drawn wrongly, not dropped silently; the rest of the frame is drawn."""
     from webrender_amd import glapi, glconst as G
     from webrender_amd.renderer import Renderer
     gl = glapi.GL(hostsim)
     r = Renderer(gl, 512, 512)
-    fr = scenes.mix_blend_grid(width=512, height=512, n=12, seed=5)
-    m = scenes.projective_about(np.eye(2), 256.0, 256.0, 400.0, np.random.default_rng(3), strength=(1.6, 2.6))      # (w <= 0 on part of the frame)
+    fr = scenes.cfg3_text(width=512, height=512, lines=12, glyphs_per_line=30, run_len=10, glyph_transform=True, seed=5)
+    m = scenes.projective_about(np.eye(2), 256.0, 256.0, 400.0, np.random.default_rng(3), strength=(0.3, 0.6))
     tid = fr.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
     hi = fr.prim_headers_i.data
-    hi[0:2 * 12:4, 2] = tid                  # every other prim under the projective transform ([z, specific, transform id, task])
+    hi[0:hi.shape[0]:4, 2] = tid             # every other run under the projective transform ([z, specific, transform id, task])
     r.render(fr)
     r.finish()
     assert gl.GetError() == G.GL_INVALID_OPERATION

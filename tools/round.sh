@@ -7,6 +7,9 @@ tag=$1; cpu=$2
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out/$tag
 (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | tail -15) > gpurun_out/$tag/gpu_tests.log 2>&1
 cat gpurun_out/$tag/gpu_tests.log
+# (the HBM counter passes first, and their summaries into profiles/ ON THE BOX: bench.py takes `traffic` from the newest summary there that was
+# measured with these very kernel sources -- after a kernel edit the committed ones no longer match, and the lines below would carry null)
+for w in cfg2 cfg3 cfg4 cfg5; do bash tools/pmc_hbm.sh ${tag}_pmc_hbm_$w $w > gpurun_out/$tag/pmc_hbm_$w.log 2>&1; cp gpurun_out/${tag}_pmc_hbm_$w.json profiles/ 2>/dev/null; done
 nocpu="--no-cpu-baseline"; [ "$cpu" = cpu ] && nocpu=""
 python bench.py --steps 20 --warmup 5 > gpurun_out/$tag/bench_cfg2.json 2> gpurun_out/$tag/bench_cfg2.err
 for w in cfg1 cfg3 cfg4 cfg5; do
@@ -22,7 +25,6 @@ for w in cfg2 cfg3 cfg4 cfg5; do
   cp gpurun_out/$tag/prof_$w/r_kernel_stats.csv gpurun_out/$tag/${w}_kernel_stats.csv
   rm -rf gpurun_out/$tag/prof_$w
 done
-for w in cfg2 cfg3 cfg4 cfg5; do bash tools/pmc_hbm.sh ${tag}_pmc_hbm_$w $w > gpurun_out/$tag/pmc_hbm_$w.log 2>&1; done
 WORKLOADS="cfg2 cfg3 cfg4 cfg5" bash tools/sq.sh ${tag} > gpurun_out/$tag/sq.log 2>&1
 grep -h '"metric"' gpurun_out/$tag/bench_*.json | python3 -c "
 import sys, json

@@ -2431,12 +2431,13 @@ WR_DEVICE bool wr_quad_walk(const float (&px)[4], const float (&py)[4], const fl
 // WebRender's z = z_id * w that means a vertex at or behind the camera plane, w <= 0 -- is clipped against the view volume
 // before it is projected: clip_side<Z>, and, if a clipped vertex still has w <= 0, clip_side<X> and clip_side<Y>; every pass
 // can add two vertices (up to ten), and rewrites the AA edge mask.  Interpolants: the prim's one vec2 varying.
-struct WrClipPt { float x, y, z, w, u, v; };
+struct WrClipPt { float x, y, z, w, u, v, u2, v2; };      // (u2, v2: brush_mix_blend's second varying, clipped along with the first)
 WR_DEVICE float wr_clip_sel(const WrClipPt& p, int axis) { return axis == 0 ? p.x : (axis == 1 ? p.y : p.z); }
 WR_DEVICE WrClipPt wr_clip_lerp(const WrClipPt& a, const WrClipPt& b, float k) {       // prev + (cur - prev) * k, component by component
   WrClipPt r;
   r.x = a.x + (b.x - a.x) * k; r.y = a.y + (b.y - a.y) * k; r.z = a.z + (b.z - a.z) * k; r.w = a.w + (b.w - a.w) * k;
   r.u = a.u + (b.u - a.u) * k; r.v = a.v + (b.v - a.v) * k;
+  r.u2 = a.u2 + (b.u2 - a.u2) * k; r.v2 = a.v2 + (b.v2 - a.v2) * k;
   return r;
 }
 __device__ __noinline__ int wr_clip_side(int axis, int nump, const WrClipPt* p, WrClipPt* out, int& edge_mask_io) {
@@ -2465,7 +2466,7 @@ __device__ __noinline__ int wr_clip_side(int axis, int nump, const WrClipPt* p, 
           clipped.x = c2.x; clipped.y = c2.y; clipped.z = c2.z; clipped.w = c2.w;
         }
         const WrClipPt ci = wr_clip_lerp(prev, cur, k);
-        clipped.u = ci.u; clipped.v = ci.v;
+        clipped.u = ci.u; clipped.v = ci.v; clipped.u2 = ci.u2; clipped.v2 = ci.v2;
         out[numClip] = clipped;
         numClip++;
       }
@@ -2482,7 +2483,7 @@ __device__ __noinline__ int wr_clip_side(int axis, int nump, const WrClipPt* p, 
           clipped.x = c2.x; clipped.y = c2.y; clipped.z = c2.z; clipped.w = c2.w;
         }
         const WrClipPt ci = wr_clip_lerp(prev, cur, k);
-        clipped.u = ci.u; clipped.v = ci.v;
+        clipped.u = ci.u; clipped.v = ci.v; clipped.u2 = ci.u2; clipped.v2 = ci.v2;
         out[numClip] = clipped;
         outMask |= (edgeMask & 1) << numClip;
         numClip++;
@@ -2505,7 +2506,7 @@ __device__ __noinline__ int wr_clip_side(int axis, int nump, const WrClipPt* p, 
 // z and 1 / w per vertex; iu / iv: the varying times 1 / w.
 WR_DEVICE bool wr_poly_walk(const int nump, const float* px, const float* py, const float* iu, const float* iv, const float* iz,
                                           const float* iw, float cx0, float cy0, float cx1, float cy1, bool aa, int aa_mask, WrQuadRec& Q, int& bx0,
-                                          int& by0, int& bx1, int& by1) {
+                                          int& by0, int& bx1, int& by1, const float* iu2 = nullptr, const float* iv2 = nullptr) {
   Q.nseg = 0; Q.aa = aa ? 1 : 0; Q.rowtab = nullptr; Q.rowtab_rows = 0;
   auto NEXT = [&](int i) { return i + 1 == nump ? 0 : i + 1; };
   auto PREV = [&](int i) { return i == 0 ? nump - 1 : i - 1; };
@@ -2520,7 +2521,8 @@ WR_DEVICE bool wr_poly_walk(const int nump, const float* px, const float* py, co
   int l1i = NEXT(l0i), r1i = PREV(r0i);
   const float aaRound = aa ? 0.0f : 0.5f;
   float y = floorf(wr_max(wr_min(py[l0i], cy1), cy0) + aaRound) + 0.5f;
-#define WR_PEDGE(a, b, m) wr_edge_init(y, px[a], py[a], px[b], py[b], (aa_mask >> (m)) & 1, iu[a], iv[a], iu[b], iv[b], iz[a], iw[a], iz[b], iw[b])
+#define WR_PEDGE(a, b, m) wr_edge_init(y, px[a], py[a], px[b], py[b], (aa_mask >> (m)) & 1, iu[a], iv[a], iu[b], iv[b], iz[a], iw[a], iz[b], iw[b], \
+                                        iu2 ? iu2[a] : 0.0f, iv2 ? iv2[a] : 0.0f, iu2 ? iu2[b] : 0.0f, iv2 ? iv2[b] : 0.0f)
   WrEdgeInst EL = WR_PEDGE(l0i, l1i, l1i);
   WrEdgeInst ER = WR_PEDGE(r0i, r1i, r0i);
   bool flipped;
@@ -2572,6 +2574,10 @@ WR_DEVICE bool wr_poly_walk(const int nump, const float* px, const float* py, co
       const int k = Q.nseg - 1;
       R.lz[k] = A.z; R.lzs[k] = A.zs; R.lw[k] = A.w; R.lws[k] = A.ws;
       R.rz[k] = B.z; R.rzs[k] = B.zs; R.rw[k] = B.w; R.rws[k] = B.ws;
+      if (iu2) {
+        R.l2u[k] = A.u2; R.l2us[k] = A.u2s; R.l2v[k] = A.v2; R.l2vs[k] = A.v2s;
+        R.r2u[k] = B.u2; R.r2us[k] = B.u2s; R.r2v[k] = B.v2; R.r2vs[k] = B.v2s;
+      }
     }
     S.b0 = b0; S.b1 = b1;
     bx0 = wr_imin(bx0, int(floorf(b0)) - 1); bx1 = wr_imax(bx1, int(ceilf(b1)) + 1);
@@ -2586,7 +2592,7 @@ WR_DEVICE bool wr_poly_walk(const int nump, const float* px, const float* py, co
 // What the clipped walk needs of a prim, parked in the tail of its (still unused) quad record by the vertex-stage thread: the
 // walk runs after wr_finish_prim, when the vertex stage's outputs are dead -- called from inside it, the callee's registers
 // came on top of the ~60 live ones and the fused setup + tile-pass kernel lost a wave per SIMD.
-struct WrClipStash { float px[4], py[4], pz[4], pw[4], u[4], v[4]; float cx0, cy0, cx1, cy1; int32_t aa, aa_edges; float vp[4]; };
+struct WrClipStash { float px[4], py[4], pz[4], pw[4], u[4], v[4]; float cx0, cy0, cx1, cy1; int32_t aa, aa_edges; float vp[4]; float u2[4], v2[4]; int32_t two; };      // two: u2 / v2 hold a second varying (brush_mix_blend)
 static_assert(sizeof(WrClipStash) <= 5 * sizeof(WrQuadSeg), "the stash sits in seg[5..9]: the walk has copied it before it writes that far");
 WR_DEVICE WrClipStash* wr_clip_stash(WrQuadRec& Q) { return (WrClipStash*)&Q.seg[WR_MAX_QSEG - 5]; }
 // clip, project (rasterize.h:1518-1530), ClipRect::overlaps, and walk.  False: nothing to draw.
@@ -2596,7 +2602,7 @@ WR_DEVICE bool wr_persp_clipped_walk(WrQuadRec& Q, int& bx0, int& by0, int& bx1,
   ocx0 = cx0; ocy0 = cy0; ocx1 = cx1; ocy1 = cy1;
   const bool aa = o.aa != 0;
   WrClipPt a[WR_MAX_QSEG], b[WR_MAX_QSEG];
-  for (int n = 0; n < 4; n++) { a[n].x = o.px[n]; a[n].y = o.py[n]; a[n].z = o.pz[n]; a[n].w = o.pw[n]; a[n].u = o.u[n]; a[n].v = o.v[n]; }
+  for (int n = 0; n < 4; n++) { a[n].x = o.px[n]; a[n].y = o.py[n]; a[n].z = o.pz[n]; a[n].w = o.pw[n]; a[n].u = o.u[n]; a[n].v = o.v[n]; a[n].u2 = o.two ? o.u2[n] : 0.0f; a[n].v2 = o.two ? o.v2[n] : 0.0f; }
   int mask = o.aa_edges;
   int nump = wr_clip_side(2, 4, a, b, mask);
 #ifdef WRHIP_HOSTSIM
@@ -2617,18 +2623,19 @@ WR_DEVICE bool wr_persp_clipped_walk(WrQuadRec& Q, int& bx0, int& by0, int& bx1,
   }
   const float scx = o.vp[2] * 0.5f, scy = o.vp[3] * 0.5f;
   const float ofx = o.vp[0] + scx, ofy = o.vp[1] + scy;
-  float px[WR_MAX_QSEG], py[WR_MAX_QSEG], pz[WR_MAX_QSEG], pw[WR_MAX_QSEG], qu[WR_MAX_QSEG], qv[WR_MAX_QSEG];
+  float px[WR_MAX_QSEG], py[WR_MAX_QSEG], pz[WR_MAX_QSEG], pw[WR_MAX_QSEG], qu[WR_MAX_QSEG], qv[WR_MAX_QSEG], qu2[WR_MAX_QSEG], qv2[WR_MAX_QSEG];
   int sides = 0;
   for (int i = 0; i < nump; i++) {
     const float wn = 1.0f / cur[i].w;
     if (wr_isfinite(wn)) { px[i] = cur[i].x * wn * scx + ofx; py[i] = cur[i].y * wn * scy + ofy; pz[i] = cur[i].z * wn * 0.5f + 0.5f; pw[i] = wn; }
     else { px[i] = py[i] = pz[i] = pw[i] = 0.0f; }
     qu[i] = cur[i].u * pw[i]; qv[i] = cur[i].v * pw[i];
+    qu2[i] = cur[i].u2 * pw[i]; qv2[i] = cur[i].v2 * pw[i];
     sides |= px[i] < cx1 ? (px[i] > cx0 ? 3 : 1) : 2;
     sides |= py[i] < cy1 ? (py[i] > cy0 ? 12 : 4) : 8;
   }
   if (sides != 0xF) return false;
-  return wr_poly_walk(nump, px, py, qu, qv, pz, pw, cx0, cy0, cx1, cy1, aa, mask, Q, bx0, by0, bx1, by1);
+  return wr_poly_walk(nump, px, py, qu, qv, pz, pw, cx0, cy0, cx1, cy1, aa, mask, Q, bx0, by0, bx1, by1, o.two ? qu2 : nullptr, o.two ? qv2 : nullptr);
 }
 
 // The span of row y of a general quad (aa_span, rasterize.h:520-561): [s0, s1) -- with swgl_antiAlias the rounded-out one,
@@ -2778,6 +2785,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
       // setup + tile-pass kernel a wave per SIMD; the stash lies beyond any base kind's side record in the prim's WrAux)
       WrClipStash& St = *wr_clip_stash(auxp->quad);
       for (int n = 0; n < 4; n++) { St.px[n] = o.px[n]; St.py[n] = o.py[n]; St.pz[n] = o.pz[n]; St.pw[n] = o.pw[n]; St.u[n] = o.u[n]; St.v[n] = o.v[n]; }
+      St.two = o.kind == WR_PK_MIX_BLEND ? 1 : 0;
+      if (St.two) for (int n = 0; n < 4; n++) { St.u2[n] = o.u2[n]; St.v2[n] = o.v2[n]; }
     }
     // screen = pos.xyz * (1 / pos.w) * scale + offset, scale = (viewport size, 1) / 2, offset = (viewport origin, 0) + scale
     const float scx = d.vp_size[0] * 0.5f, scy = d.vp_size[1] * 0.5f;
@@ -2850,8 +2859,8 @@ WR_DEVICE void wr_finish_prim(const WrDrawDesc& d, int draw_index, const WrVsOut
   if ((!typeA && !typeB) || (aa && texq) || persp) {
     // general convex quad (rotation / skew), or an anti-aliased textured one: the scanline walk is done here, per prim
     const bool solidq = o.kind == WR_PK_SOLID && !masked && !(d.flags & WR_DF_SIMPLE);
-    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked) || (o.kind == WR_PK_MIX_BLEND && !clipped)))) {
-      atomicAdd(&cnt->perspective_prims, 1u); return;        // (brush_mix_blend cut by the near plane: its second varying is not clipped along)
+    if (persp && !solidq && !(texq && (o.kind == WR_PK_TEX_RGBA8 || o.kind == WR_PK_TEX_FS || o.kind == WR_PK_TEX_R8 || o.kind == WR_PK_TEX_REPEAT || o.kind == WR_PK_FILTER || o.kind == WR_PK_GRADIENT || o.kind == WR_PK_QUAD_MASK || (o.kind == WR_PK_SOLID && masked) || o.kind == WR_PK_MIX_BLEND))) {
+      atomicAdd(&cnt->perspective_prims, 1u); return;
     }
     if (!solidq && !texq) {
       P.kind = WR_PK_UNSUPPORTED; atomicAdd(&cnt->unsupported_prims, 1u); return;

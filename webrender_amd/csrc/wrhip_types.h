@@ -578,8 +578,8 @@ struct WrRepeatRec {
 #define WR_MAX_QSEG 10
 struct WrPerspRec { float lz[WR_MAX_QSEG], lzs[WR_MAX_QSEG], lw[WR_MAX_QSEG], lws[WR_MAX_QSEG], rz[WR_MAX_QSEG], rzs[WR_MAX_QSEG], rw[WR_MAX_QSEG], rws[WR_MAX_QSEG]; float div;   // div: WrVsOut::persp_div
   // brush_mix_blend under a projective transform: its SECOND varying (v_src_uv / w) on the runs' edges -- without perspective it rides in
-  // the z / w slots above, which a projective transform needs itself (the first four runs only: a prim clipped by the near plane is reported)
-  float l2u[4], l2us[4], l2v[4], l2vs[4], r2u[4], r2us[4], r2v[4], r2vs[4]; };
+  // the z / w slots above, which a projective transform needs itself (every run: a prim clipped by the near plane is a polygon of up to nine)
+  float l2u[WR_MAX_QSEG], l2us[WR_MAX_QSEG], l2v[WR_MAX_QSEG], l2vs[WR_MAX_QSEG], r2u[WR_MAX_QSEG], r2us[WR_MAX_QSEG], r2v[WR_MAX_QSEG], r2vs[WR_MAX_QSEG]; };
 
 struct WrQuadRec {
   int32_t nseg;

@@ -1355,7 +1355,7 @@ def build_gradient_lut(stops, reverse=False):
     return entries.reshape(-1, 4)
 
 
-def rotation_about(frame, rng, cx, cy, i, persp_radius=None):
+def rotation_about(frame, rng, cx, cy, i, persp_radius=None, strength=(0.15, 0.6)):
     """A non-axis-aligned transform (rotation, every fourth one skewed as well) about (cx, cy) -> transform id.
     `persp_radius`: with a projective row on top (projective_about: w varies over the prim, > 0 inside that radius)."""
     th = float(rng.uniform(0, 2 * np.pi)) if i % 6 else float(rng.choice([np.pi / 4, np.pi / 2, 0.01]))
@@ -1366,7 +1366,7 @@ def rotation_about(frame, rng, cx, cy, i, persp_radius=None):
     m[:2, :2] = a
     m[:2, 3] = np.array([cx, cy]) - a @ np.array([cx, cy])
     if persp_radius is not None:
-        m = projective_about(a, cx, cy, persp_radius * (1.0 + abs(sk)), rng)
+        m = projective_about(a, cx, cy, persp_radius * (1.0 + abs(sk)), rng, strength=strength)
     return frame.add_transform(m.T.astype(np.float32), np.linalg.inv(m).T.astype(np.float32), axis_aligned=False)
 
 
@@ -1922,7 +1922,9 @@ def mix_blend_grid(width=1024, height=1024, n=80, seed=203, tile_filter=None, on
         for k, pr in enumerate(prims):
             if k % 3 != 1:
                 rad = 0.5 * float(np.hypot(pr[0][2] - pr[0][0], pr[0][3] - pr[0][1]))
-                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k, rad if perspective else None)
+                # (perspective == "clip": every other such prim reaches behind the camera plane -- clip_side, then the polygon's walk)
+                tids[k] = rotation_about(frame, rng, (pr[0][0] + pr[0][2]) / 2, (pr[0][1] + pr[0][3]) / 2, k, rad if perspective else None,
+                                         strength=(1.1, 2.6) if (perspective == "clip" and k % 2 == 0) else (0.15, 0.6))
     t_mask, clip_tasks = None, [None] * len(prims)
     if masked:
         t_mask = TextureRef("clip_mask_atlas", 1024, 1024, G.GL_R8, G.GL_LINEAR, pixels=mask_atlas(1024), upload_format=G.GL_RED)
