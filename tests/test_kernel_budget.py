@@ -105,13 +105,16 @@ def test_shipped_kernel_budgets(tmp_path):
         "wr_raster_kernel<3, false, 4, 0>": (64, 16), "wr_raster_kernel<3, true, 4, 0>": (128, 16),
         "wr_raster_kernel<3, false, 4, 5>": (168, 256), "wr_raster_kernel<3, false, 4, 7>": (168, 256),
         "wr_raster_kernel<3, true, 4, 5>": (168, 512), "wr_raster_kernel<3, true, 4, 7>": (168, 512),
-        "wr_setup_raster_kernel<3, false, 4, 0>": (128, 1024), "wr_setup_raster_kernel<3, true, 4, 0>": (128, 1024),
-        "wr_setup_raster_kernel<3, false, 4, 5>": (168, 1024), "wr_setup_raster_kernel<3, false, 4, 7>": (168, 1024),
-        "wr_setup_raster_kernel<3, true, 4, 5>": (168, 1280), "wr_setup_raster_kernel<3, true, 4, 7>": (168, 1280),
+        # (every kernel that carries the setup stage: + 272 B since the near-plane clip carries brush_mix_blend's second varying -- two
+        # ten-point polygons of eight floats instead of six, two more ten-float arrays for the walk; touched by clipped prims only:
+        # cfg2's fused launch is unchanged, transforms' + 1 %, profiles/r06_zz_mixclip_ab.txt)
+        "wr_setup_raster_kernel<3, false, 4, 0>": (128, 1280), "wr_setup_raster_kernel<3, true, 4, 0>": (128, 1280),
+        "wr_setup_raster_kernel<3, false, 4, 5>": (168, 1280), "wr_setup_raster_kernel<3, false, 4, 7>": (168, 1280),
+        "wr_setup_raster_kernel<3, true, 4, 5>": (168, 1536), "wr_setup_raster_kernel<3, true, 4, 7>": (168, 1536),
         "wr_raster_dense_kernel<3, false, 4, 7>": (128, 640), "wr_raster_dense_kernel<3, true, 4, 7>": (128, 640),
-        "wr_setup_raster_dense_kernel<3, false, 4, 7>": (128, 1536), "wr_setup_raster_dense_kernel<3, true, 4, 7>": (128, 1536),
-        "wr_setup_kernel": (168, 640), "wr_setup_rows_kernel": (128, 1024), "wr_mask_rows_kernel": (128, 64),
-        "wr_span_rows_kernel": (72, 192), "wr_tile_rows_kernel": (128, 512), "wr_setup_tile_rows_kernel": (128, 1024),
+        "wr_setup_raster_dense_kernel<3, false, 4, 7>": (128, 1792), "wr_setup_raster_dense_kernel<3, true, 4, 7>": (128, 1792),
+        "wr_setup_kernel": (168, 1024), "wr_setup_rows_kernel": (128, 1280), "wr_mask_rows_kernel": (128, 64),
+        "wr_span_rows_kernel": (72, 192), "wr_tile_rows_kernel": (128, 512), "wr_setup_tile_rows_kernel": (128, 1280),
     }
     missing = [n for n in budget if n not in k]
     assert not missing, missing
