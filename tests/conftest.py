@@ -31,7 +31,8 @@ def oracle_ref(kind="gcc"):
 
 
 def hostsim_lib():
-    p = os.path.join(ROOT, "webrender_amd", "csrc", "libwrhip_hostsim.so")
+    # (WRHIP_HOSTSIM_LIB: another build of the host simulation, e.g. the AddressSanitizer / UBSan one of tools/asan.sh)
+    p = os.environ.get("WRHIP_HOSTSIM_LIB") or os.path.join(ROOT, "webrender_amd", "csrc", "libwrhip_hostsim.so")
     return p if os.path.exists(p) else None
 
 
