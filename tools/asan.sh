@@ -11,7 +11,7 @@ if [ ! -e $so ] || [ webrender_amd/csrc/wrhip.hip -nt $so ] || [ webrender_amd/c
      -fno-omit-frame-pointer -std=c++17 -fPIC -shared -ffp-contract=off -Wl,-Bsymbolic -Wno-unused-result wrhip.hip -o build/libwrhip_hostsim_asan.so) || exit 1
 fi
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
-export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=${UBSAN_OPTIONS:-print_stacktrace=1:halt_on_error=1}
 export WRHIP_HOSTSIM_LIB=$PWD/$so
 if [ $# -eq 0 ]; then set -- tests/test_hostsim_parity.py -q -x -p no:cacheprovider; fi
 exec python -m pytest "$@"

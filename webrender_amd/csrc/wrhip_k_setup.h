@@ -3440,7 +3440,7 @@ WR_DEVICE void wr_bilinear16(const WrTexDesc& t, int qx, int qy, int (&v)[4]) {
     const uint32_t p = ((const uint32_t*)t.ptr)[idx];
     return int(c == 0 ? (p & 0xFFFFu) : (p >> 16)) >> 1;
   };
-  auto lerp = [](int a, int b, int f) -> int { return (int)(int16_t)(a + (int)(int16_t)((int)(int16_t)(((int)(int16_t)(b - a) * f) >> 16) << 1)); };
+  auto lerp = [](int a, int b, int f) -> int { return (int)(int16_t)(a + (int)(int16_t)((int)(int16_t)(((int)(int16_t)(b - a) * f) >> 16) * 2)); };      // (* 2, not << 1: the operand can be negative)
   for (int c = 0; c < NCH; c++) {
     const int l = lerp(texel(row0, c), texel(row1, c), fracy), r = lerp(texel(row0 + 1, c), texel(row1 + 1, c), fracy);
     v[c] = lerp(l, r, fracx);
