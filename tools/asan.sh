@@ -13,5 +13,5 @@ fi
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=${UBSAN_OPTIONS:-print_stacktrace=1:halt_on_error=1}
 export WRHIP_HOSTSIM_LIB=$PWD/$so
-if [ $# -eq 0 ]; then set -- tests/test_hostsim_parity.py -q -x -p no:cacheprovider; fi
-exec python -m pytest "$@"
+if [ $# -eq 0 ]; then set -- tests/test_hostsim_parity.py tests/test_abi_surface.py tests/test_text_reftest_relations.py tests/test_dist.py -q -x -p no:cacheprovider; fi
+exec python -m pytest -m "not gpu" "$@"
